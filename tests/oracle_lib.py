@@ -1,0 +1,346 @@
+"""ctypes bindings for the CPU oracle (oracle/liblslam_oracle.so) and, when it was
+built, the reference's own nanoflann (oracle/_ref/libref_nanoflann.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class OracleOpts(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_int),
+        ("delta_t_abort", C.c_float),
+        ("delta_r_abort", C.c_float),
+        ("use_score", C.c_int),
+        ("fine_score", C.c_int),
+        ("score_threshold", C.c_double),
+        ("match_percentage_threshold", C.c_double),
+    ]
+
+
+class OracleStats(C.Structure):
+    _fields_ = [
+        ("status", C.c_int),
+        ("iterations", C.c_int),
+        ("n_line", C.c_int),
+        ("n_plane", C.c_int),
+        ("n_rows", C.c_int),
+        ("degenerate", C.c_int),
+        ("converged", C.c_int),
+        ("delta_r", C.c_float),
+        ("delta_t", C.c_float),
+        ("score", C.c_double),
+        ("percent", C.c_double),
+        ("t_build", C.c_double),
+        ("t_sweep", C.c_double),
+        ("t_solve", C.c_double),
+        ("point_residuals", C.c_longlong),
+    ]
+
+
+def build_oracle(native=False):
+    """Compile the oracle with its Makefile if the .so is missing or stale."""
+    target = "liblslam_oracle_native.so" if native else "liblslam_oracle.so"
+    so = os.path.join(ORACLE_DIR, target)
+    src = os.path.join(ORACLE_DIR, "lslam_oracle.c")
+    hdr = os.path.join(ORACLE_DIR, "lslam_oracle.h")
+    if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, target], stdout=subprocess.DEVNULL)
+    return so
+
+
+def _fp(a):
+    return a.ctypes.data_as(c_float_p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_int32_p)
+
+
+def as_cloud(a):
+    """(n,3|4|8) float array -> contiguous float32 (n,S) and stride in floats."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.ndim == 2 and a.shape[1] >= 3
+    return a, a.shape[1]
+
+
+class Oracle:
+    def __init__(self, native=False):
+        self.lib = C.CDLL(build_oracle(native))
+        L = self.lib
+        L.oracle_kdtree_build.restype = C.c_void_p
+        L.oracle_kdtree_build.argtypes = [c_float_p, C.c_size_t, C.c_size_t]
+        L.oracle_kdtree_free.argtypes = [C.c_void_p]
+        L.oracle_kdtree_knn.restype = C.c_int
+        L.oracle_kdtree_knn.argtypes = [C.c_void_p, c_float_p, C.c_int, c_int32_p, c_float_p]
+        L.oracle_kdtree_num_nodes.restype = C.c_size_t
+        L.oracle_kdtree_num_nodes.argtypes = [C.c_void_p]
+        L.oracle_kdtree_max_depth.restype = C.c_int
+        L.oracle_kdtree_max_depth.argtypes = [C.c_void_p]
+        L.oracle_kdtree_vind.argtypes = [C.c_void_p, c_int32_p]
+        L.oracle_kdtree_node.argtypes = [C.c_void_p, C.c_size_t, c_int32_p, c_int32_p, c_int32_p,
+                                         c_float_p, c_float_p, c_int32_p]
+        L.oracle_eig_sym3.argtypes = [c_float_p] * 3
+        L.oracle_eig_sym6.argtypes = [c_float_p] * 3
+        L.oracle_qr_solve_5x3.argtypes = [c_float_p] * 3
+        L.oracle_qr_solve_6x6.argtypes = [c_float_p] * 3
+        L.oracle_inverse6.argtypes = [c_float_p] * 2
+        L.oracle_pose_to_Rt.argtypes = [c_float_p] * 3
+        L.oracle_Rt_to_pose.argtypes = [c_float_p] * 3
+        L.oracle_transform_point.argtypes = [c_float_p] * 4
+        L.oracle_find_line.restype = C.c_int
+        L.oracle_find_line.argtypes = [c_float_p, C.c_size_t, c_int32_p, c_float_p, c_float_p]
+        L.oracle_corner_coeff.restype = C.c_int
+        L.oracle_corner_coeff.argtypes = [c_float_p] * 4
+        L.oracle_find_plane.restype = C.c_int
+        L.oracle_find_plane.argtypes = [c_float_p, C.c_size_t, c_int32_p, C.c_float, c_float_p]
+        L.oracle_surf_coeff.restype = C.c_int
+        L.oracle_surf_coeff.argtypes = [c_float_p] * 3
+        L.oracle_jacobian_row.argtypes = [c_float_p] * 5
+        L.oracle_default_opts.argtypes = [C.POINTER(OracleOpts)]
+        L.oracle_sweep.argtypes = [C.c_void_p, c_float_p, C.c_void_p, c_float_p, C.c_size_t,
+                                   c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_size_t,
+                                   c_float_p, c_int32_p, c_float_p, c_float_p, c_uint8_p, c_float_p]
+        L.oracle_scanmatch_scan.restype = C.c_int
+        L.oracle_scanmatch_scan.argtypes = [c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_size_t,
+                                            c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_size_t,
+                                            c_float_p, C.POINTER(OracleOpts), C.POINTER(OracleStats)]
+        L.oracle_gn_step.restype = C.c_int
+        L.oracle_gn_step.argtypes = [c_float_p, c_float_p, C.c_int, c_float_p, c_float_p,
+                                     C.POINTER(C.c_int), C.c_float, C.c_float, C.c_float,
+                                     c_float_p, c_float_p, c_float_p]
+
+    # ---- kd-tree -------------------------------------------------------
+    def kdtree(self, pts):
+        return OracleTree(self, pts)
+
+    # ---- dense algebra -------------------------------------------------
+    def eig_sym3(self, A):
+        A = np.ascontiguousarray(A, np.float32).reshape(9)
+        e = np.zeros(3, np.float32)
+        V = np.zeros(9, np.float32)
+        self.lib.oracle_eig_sym3(_fp(A), _fp(e), _fp(V))
+        return e, V.reshape(3, 3)
+
+    def eig_sym6(self, A):
+        A = np.ascontiguousarray(A, np.float32).reshape(36)
+        e = np.zeros(6, np.float32)
+        V = np.zeros(36, np.float32)
+        self.lib.oracle_eig_sym6(_fp(A), _fp(e), _fp(V))
+        return e, V.reshape(6, 6)
+
+    def qr_solve(self, A, b):
+        A = np.ascontiguousarray(A, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        x = np.zeros(A.shape[1], np.float32)
+        if A.shape == (5, 3):
+            self.lib.oracle_qr_solve_5x3(_fp(A), _fp(b), _fp(x))
+        elif A.shape == (6, 6):
+            self.lib.oracle_qr_solve_6x6(_fp(A), _fp(b), _fp(x))
+        else:
+            raise ValueError(A.shape)
+        return x
+
+    def inverse6(self, A):
+        A = np.ascontiguousarray(A, np.float32).reshape(36)
+        o = np.zeros(36, np.float32)
+        self.lib.oracle_inverse6(_fp(A), _fp(o))
+        return o.reshape(6, 6)
+
+    # ---- geometry --------------------------------------------------------
+    def pose_to_Rt(self, pose):
+        pose = np.ascontiguousarray(pose, np.float32)
+        R = np.zeros(9, np.float32)
+        t = np.zeros(3, np.float32)
+        self.lib.oracle_pose_to_Rt(_fp(pose), _fp(R), _fp(t))
+        return R.reshape(3, 3), t
+
+    def Rt_to_pose(self, R, t):
+        R = np.ascontiguousarray(R, np.float32).reshape(9)
+        t = np.ascontiguousarray(t, np.float32)
+        p = np.zeros(6, np.float32)
+        self.lib.oracle_Rt_to_pose(_fp(R), _fp(t), _fp(p))
+        return p
+
+    def find_line(self, cloud, idx):
+        cloud, s = as_cloud(cloud)
+        idx = np.ascontiguousarray(idx, np.int32)
+        A = np.zeros(3, np.float32)
+        B = np.zeros(3, np.float32)
+        ok = self.lib.oracle_find_line(_fp(cloud), s, _ip(idx), _fp(A), _fp(B))
+        return bool(ok), A, B
+
+    def corner_coeff(self, A, B, X):
+        A, B, X = (np.ascontiguousarray(v, np.float32) for v in (A, B, X))
+        c = np.zeros(4, np.float32)
+        ok = self.lib.oracle_corner_coeff(_fp(A), _fp(B), _fp(X), _fp(c))
+        return bool(ok), c
+
+    def find_plane(self, cloud, idx, max_distance=0.2):
+        cloud, s = as_cloud(cloud)
+        idx = np.ascontiguousarray(idx, np.int32)
+        pl = np.zeros(4, np.float32)
+        ok = self.lib.oracle_find_plane(_fp(cloud), s, _ip(idx), max_distance, _fp(pl))
+        return bool(ok), pl
+
+    def surf_coeff(self, plane, X):
+        plane, X = (np.ascontiguousarray(v, np.float32) for v in (plane, X))
+        c = np.zeros(4, np.float32)
+        ok = self.lib.oracle_surf_coeff(_fp(plane), _fp(X), _fp(c))
+        return bool(ok), c
+
+    def jacobian_row(self, sc, p, coeff):
+        sc, p, coeff = (np.ascontiguousarray(v, np.float32) for v in (sc, p, coeff))
+        row = np.zeros(6, np.float32)
+        b = np.zeros(1, np.float32)
+        self.lib.oracle_jacobian_row(_fp(sc), _fp(p), _fp(coeff), _fp(row), _fp(b))
+        return row, float(b[0])
+
+    # ---- sweep / full loop ------------------------------------------------
+    def default_opts(self):
+        o = OracleOpts()
+        self.lib.oracle_default_opts(C.byref(o))
+        return o
+
+    def sweep(self, tree_c, tree_s, qc, qs, pose):
+        qc, sq = as_cloud(qc)
+        qs, sq2 = as_cloud(qs)
+        assert sq == sq2 and tree_c.stride == tree_s.stride
+        n = len(qc) + len(qs)
+        pose = np.ascontiguousarray(pose, np.float32)
+        idx = np.zeros((n, 5), np.int32)
+        d2 = np.zeros((n, 5), np.float32)
+        coeff = np.zeros((n, 4), np.float32)
+        flags = np.zeros(n, np.uint8)
+        sums = np.zeros(29, np.float32)
+        self.lib.oracle_sweep(tree_c.h, _fp(tree_c.pts), tree_s.h, _fp(tree_s.pts), tree_c.stride,
+                              _fp(qc), len(qc), _fp(qs), len(qs), sq, _fp(pose), _ip(idx), _fp(d2),
+                              _fp(coeff), flags.ctypes.data_as(c_uint8_p), _fp(sums))
+        return dict(idx=idx, d2=d2, coeff=coeff, flags=flags, sums=sums)
+
+    def scanmatch_scan(self, map_c, map_s, qc, qs, pose, opts=None):
+        map_c, sm = as_cloud(map_c)
+        map_s, sm2 = as_cloud(map_s)
+        qc, sq = as_cloud(qc)
+        qs, sq2 = as_cloud(qs)
+        assert sm == sm2 and sq == sq2
+        pose = np.array(pose, np.float32)
+        if opts is None:
+            opts = self.default_opts()
+        st = OracleStats()
+        ok = self.lib.oracle_scanmatch_scan(_fp(map_c), len(map_c), _fp(map_s), len(map_s), sm,
+                                            _fp(qc), len(qc), _fp(qs), len(qs), sq, _fp(pose),
+                                            C.byref(opts), C.byref(st))
+        return bool(ok), pose, st
+
+    def gn_step(self, AtA, Atb, it, pose, matP, degenerate, eig_thresh=100.0, dr=0.05, dt=0.05):
+        AtA = np.ascontiguousarray(AtA, np.float32).reshape(36)
+        Atb = np.ascontiguousarray(Atb, np.float32)
+        pose = np.array(pose, np.float32)
+        matP = np.array(matP, np.float32).reshape(36)
+        deg = C.c_int(int(degenerate))
+        x = np.zeros(6, np.float32)
+        dR = np.zeros(1, np.float32)
+        dT = np.zeros(1, np.float32)
+        conv = self.lib.oracle_gn_step(_fp(AtA), _fp(Atb), it, _fp(pose), _fp(matP), C.byref(deg),
+                                       eig_thresh, dr, dt, _fp(x), _fp(dR), _fp(dT))
+        return dict(converged=bool(conv), pose=pose, matP=matP.reshape(6, 6), degenerate=bool(deg.value),
+                    x=x, delta_r=float(dR[0]), delta_t=float(dT[0]))
+
+
+class OracleTree:
+    def __init__(self, oracle, pts):
+        self.o = oracle
+        self.pts, self.stride = as_cloud(pts)
+        self.h = oracle.lib.oracle_kdtree_build(_fp(self.pts), len(self.pts), self.stride)
+
+    def __del__(self):
+        try:
+            self.o.lib.oracle_kdtree_free(self.h)
+        except Exception:
+            pass
+
+    def knn(self, q, k=5):
+        q = np.ascontiguousarray(q, np.float32)
+        nq = len(q)
+        idx = np.zeros((nq, k), np.int32)
+        d2 = np.zeros((nq, k), np.float32)
+        for i in range(nq):
+            qi = np.ascontiguousarray(q[i, :3])
+            self.o.lib.oracle_kdtree_knn(self.h, _fp(qi), k, _ip(idx[i]), _fp(d2[i]))
+        return idx, d2
+
+    def num_nodes(self):
+        return self.o.lib.oracle_kdtree_num_nodes(self.h)
+
+    def max_depth(self):
+        return self.o.lib.oracle_kdtree_max_depth(self.h)
+
+    def vind(self):
+        out = np.zeros(len(self.pts), np.int32)
+        self.o.lib.oracle_kdtree_vind(self.h, _ip(out))
+        return out
+
+    def nodes(self):
+        n = self.num_nodes()
+        kind = np.zeros(n, np.int32)
+        a = np.zeros(n, np.int32)
+        b = np.zeros(n, np.int32)
+        lo = np.zeros(n, np.float32)
+        hi = np.zeros(n, np.float32)
+        c2 = np.zeros(n, np.int32)
+        k_, a_, b_, c_ = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        l_, h_ = C.c_float(), C.c_float()
+        for i in range(n):
+            self.o.lib.oracle_kdtree_node(self.h, i, C.byref(k_), C.byref(a_), C.byref(b_),
+                                          C.byref(l_), C.byref(h_), C.byref(c_))
+            kind[i], a[i], b[i], lo[i], hi[i], c2[i] = k_.value, a_.value, b_.value, l_.value, h_.value, c_.value
+        return dict(kind=kind, a=a, b=b, divlow=lo, divhigh=hi, child2=c2)
+
+
+# ---------------------------------------------------------------------------
+# The reference's own nanoflann, when oracle/_ref was built (container only, or
+# shipped prebuilt to the GPU box).
+# ---------------------------------------------------------------------------
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libref_nanoflann.so")
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+class RefNanoflann:
+    def __init__(self, pts):
+        self.lib = C.CDLL(REF_SO)
+        self.lib.ref_kdtree_build.restype = C.c_void_p
+        self.lib.ref_kdtree_build.argtypes = [c_float_p, C.c_size_t, C.c_size_t]
+        self.lib.ref_kdtree_free.argtypes = [C.c_void_p]
+        self.lib.ref_kdtree_knn_batch.argtypes = [C.c_void_p, c_float_p, C.c_size_t, C.c_size_t,
+                                                  C.c_int, c_int32_p, c_float_p]
+        self.pts, self.stride = as_cloud(pts)
+        self.h = self.lib.ref_kdtree_build(_fp(self.pts), len(self.pts), self.stride)
+
+    def __del__(self):
+        try:
+            self.lib.ref_kdtree_free(self.h)
+        except Exception:
+            pass
+
+    def knn(self, q, k=5):
+        q = np.ascontiguousarray(q, np.float32)
+        idx = np.zeros((len(q), k), np.int32)
+        d2 = np.zeros((len(q), k), np.float32)
+        self.lib.ref_kdtree_knn_batch(self.h, _fp(q), len(q), q.shape[1], k, _ip(idx), _fp(d2))
+        return idx, d2

@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- point-residuals/s of the L_SLAM scan-to-map Gauss-Newton hot path on MI355X.
+
+A "step" is one scanMatchScan Gauss-Newton loop (ScanMatch.cpp:78-347: up to 10
+iterations of transform -> kd-tree 5-NN -> line/plane fit -> residual + Jacobian ->
+J^T J / J^T r -> 6x6 solve -> pose update) of one synthetic 64-ring x 1800 scan
+(115 200 points) against a resident ~1.3 M-point voxel map (BASELINE.json configs[2]).
+Map, kd-trees and scan are resident in HBM before the timed region starts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; the map
+is replicated, every rank matches its own scans (independent problems, no data-path
+collective: SURVEY.md 8e row 2) and `value` is the whole-job aggregate.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the sweep kernel's algorithmic
+bytes (1.7 KB per point-residual) against the 8 TB/s HBM peak, using
+the kernel's average duration measured with HIP events on the library's own stream
+inside the timed region.  `cpu_baseline` is the oracle (a port of the reference's
+single-threaded CPU path, including its per-call kd-tree rebuild) timed on this
+host on the same workload.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+ALG_BYTES_PER_POINT_RESIDUAL = 1700.0
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rings", type=int, default=64)
+    ap.add_argument("--jtj-mode", type=int, default=int(os.environ.get("LSLAM_JTJ_MODE", "0")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-repeats", type=int, default=3)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
+
+    pkg = importlib.import_module("the-cooper-mapper_amd")
+    synth = importlib.import_module("the-cooper-mapper_amd.synth")
+
+    # ---- workload: same map on every rank, a different scan pose per rank ----------
+    pr = synth.make_problem(rings=args.rings, azimuth_steps=1800, seed=rank)
+    n_pts = len(pr["corner"]) + len(pr["surf"])
+    ctx = pkg.Context(local_rank)
+    ctx.map_set(pr["map_corner"], pr["map_surf"])
+    info = ctx.map_info()
+    ctx.scan_set(pr["corner"], pr["surf"])
+    opts = ctx.default_opts()
+    opts.jtj_mode = args.jtj_mode
+    opts.profile = 1
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.run(pr["init_pose"], opts)
+
+    barrier()
+    t0 = time.perf_counter()
+    pt_res = 0
+    iters = 0
+    sweep_ms = 0.0
+    sweep_launches = 0
+    loop_ms = 0.0
+    last = None
+    for _ in range(args.steps):
+        status, pose, st = ctx.run(pr["init_pose"], opts)  # synchronises the library's stream
+        pt_res += st.point_residuals
+        iters += st.iterations
+        sweep_ms += st.gpu_ms_sweep
+        sweep_launches += st.sweep_launches
+        loop_ms += st.gpu_ms_total
+        last = (status, pose, st)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    tot = torch.tensor([float(pt_res), float(iters)], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    total_pt_res, total_iters = tot.tolist()
+    t = float(tmax.item())
+
+    status, pose, st = last
+    pose_err = np.abs(pose - pr["gt_pose"])
+
+    if rank == 0:
+        avg_sweep_ms = sweep_ms / max(1, sweep_launches)
+        alg_bytes = ALG_BYTES_PER_POINT_RESIDUAL * n_pts
+        achieved_gbs = alg_bytes / (avg_sweep_ms * 1e-3) / 1e9 if avg_sweep_ms > 0 else 0.0
+        out = {
+            "metric": "point-residuals/s",
+            "value": total_pt_res / t,
+            "unit": "point-residuals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * t / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "lm_iters_per_s": total_iters / t,
+            "config": {
+                "workload": "synthetic %d-ring x 1800 scan-to-map scanMatchScan GN loop (BASELINE configs[2])" % args.rings,
+                "scan_points": n_pts,
+                "scan_corner": int(len(pr["corner"])),
+                "scan_surf": int(len(pr["surf"])),
+                "map_corner": int(info.n_corner),
+                "map_surf": int(info.n_surf),
+                "kd_nodes": int(info.nodes_corner + info.nodes_surf),
+                "kd_depth": int(max(info.depth_corner, info.depth_surf)),
+                "gn_iters_per_step": iters / args.steps,
+                "sweeps_per_step": sweep_launches / args.steps,
+                "jtj_mode": "mfma_f32_16x16x4" if args.jtj_mode == 1 else "valu_shuffle",
+                "parallelism": "replicated map, scans sharded across %d GPU(s), no collective" % world,
+                "map_build_ms_outside_timed_region": float(info.build_ms + info.upload_ms),
+                "map_built_on_device": bool(info.built_on_device),
+                "gpu_loop_ms_per_step": loop_ms / args.steps,
+                "pose_err_vs_ground_truth_m": float(pose_err[3:].max()),
+                "pose_err_vs_ground_truth_rad": float(pose_err[:3].max()),
+                "converged": bool(st.converged),
+            },
+            "roofline": {
+                "kernel": "sweep_kernel",
+                "bound": "hbm",
+                "achieved": achieved_gbs,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved_gbs / HBM_PEAK_GBS,
+                "traffic": None,
+                "avg_kernel_ms": avg_sweep_ms,
+                "launches_timed": sweep_launches,
+                "alg_bytes_per_launch": alg_bytes,
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pr, args.cpu_repeats, pose, np)
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pr, repeats, gpu_pose, np):
+    """The oracle (port of the reference's single-threaded path, -O3 -march=native
+    -ffp-contract=off) on the SAME map and scan: full scanMatchScan calls including
+    the per-call kd-tree rebuild (quirk Q4)."""
+    from oracle_lib import Oracle
+    o = Oracle(native=True)
+    t0 = time.perf_counter()
+    pt = 0
+    t_build = t_sweep = 0.0
+    its = 0
+    for _ in range(repeats):
+        ok, pose, st = o.scanmatch_scan(pr["map_corner"], pr["map_surf"], pr["corner"], pr["surf"],
+                                        pr["init_pose"])
+        pt += st.point_residuals
+        t_build += st.t_build
+        t_sweep += st.t_sweep
+        its += st.iterations
+    dt = time.perf_counter() - t0
+    return {
+        "value": pt / dt,
+        "unit": "point-residuals/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "%d full scanMatchScan calls on the same map+scan (%d points, %d GN iterations each), "
+                  "kd-tree rebuilt per call as the reference does" % (repeats, len(pr["corner"]) + len(pr["surf"]), its // max(1, repeats)),
+        "seconds": dt,
+        "sweep_only_value": pt / t_sweep if t_sweep > 0 else None,
+        "tree_build_s_per_call": t_build / repeats,
+        "host_cpus": os.cpu_count(),
+        "pose_diff_gpu_vs_cpu_m": float(np.abs(pose[3:] - gpu_pose[3:]).max()),
+        "pose_diff_gpu_vs_cpu_rad": float(np.abs(pose[:3] - gpu_pose[:3]).max()),
+        "iterations": its // max(1, repeats),
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,192 @@
+/*
+ * lslam_c.h -- C ABI of the MI355X-native nonlinear-least-squares backend for L_SLAM.
+ *
+ * This is the drop-in boundary for the reference's scan-match hot path.  The
+ * reference has no FFI seam; its seam is the C++ class lidar_slam::ScanMatch
+ * (scan_to_scan_match/ScanMatch.h:21-61), called from
+ *   odometry/LaserMatcher.cpp:327-331      (LaserMatcher::optimizeTransform)
+ *   pose_graph/graph.cpp:185-190           (Graph::getFinalFeatureMap)
+ *   pose_graph/loop_detector.hpp:206-223   (LoopDetector::matching_nearest)
+ * Every entry point below names the reference interface it replaces.  All paths
+ * are relative to /root/reference/L_SLAM/src/.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++/torch types cross the ABI.
+ *   - Clouds are caller-owned host arrays of points `stride_bytes` apart, x,y,z
+ *     as three consecutive floats at offset 0 (pcl::PointXYZI: stride 32;
+ *     packed float4: 16; packed xyz: 12).  The library copies what it needs to
+ *     HBM; the caller's buffers are only read during the call.
+ *   - pose is {rot_x, rot_y, rot_z, pos_x, pos_y, pos_z} = the reference's
+ *     Twist (util/Twist.h:13-36); p_map = Rz(rz)*Ry(ry)*Rx(rx)*p + pos
+ *     (util/transform_utils.h:288-299).
+ *   - Functions return lslam_status and never throw.  One call in flight per
+ *     ctx (the reference's ScanMatch is not re-entrant either,
+ *     ScanMatch.h:63-85); different ctx may be used from different threads/GPUs.
+ *   - The library owns all device memory and its HIP stream.
+ *   - There is NO CPU fallback: without a usable HIP device every compute entry
+ *     point returns LSLAM_ERR_HIP.
+ */
+#ifndef LSLAM_C_H
+#define LSLAM_C_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lslam_ctx lslam_ctx;
+
+typedef enum {
+  /* outcomes of a scan match (ScanMatch::scanMatchScan returns bool; the
+   * reasons for `false` are distinguished here) */
+  LSLAM_OK = 0,               /* returned true (ScanMatch.cpp:340) */
+  LSLAM_TOO_FEW_REF = 1,      /* ScanMatch.cpp:57-61, pose untouched */
+  LSLAM_NOT_CONVERGED = 2,    /* ScanMatch.cpp:342-346 (also when use_score is off) */
+  LSLAM_LOW_SCORE = 3,        /* ScanMatch.cpp:323-328 */
+  LSLAM_LOW_PERCENT = 4,      /* ScanMatch.cpp:330-335 */
+  LSLAM_TOO_FEW_MATCHES = 5,  /* ScanMatch.cpp:141-145 break, then :342-346 */
+  /* errors */
+  LSLAM_ERR_INVALID = -1,     /* bad argument */
+  LSLAM_ERR_HIP = -2,         /* HIP runtime error / no device (see lslam_last_error) */
+  LSLAM_ERR_NO_MAP = -3,      /* scan match requested before lslam_map_set */
+  LSLAM_ERR_NO_SCAN = -4,     /* lslam_scanmatch_run before lslam_scan_set */
+  LSLAM_ERR_TREE_DEPTH = -5   /* kd-tree deeper than the device traversal stack */
+} lslam_status;
+
+/* Mirrors ScanMatch's constructor defaults and setters (ScanMatch.cpp:21-33,
+ * ScanMatch.h:21-34). */
+typedef struct {
+  int32_t max_iterations;            /* ScanMatch(maxIterations = 10) */
+  float delta_t_abort;               /* setConvergeThreshold, default 0.05 */
+  float delta_r_abort;               /* setConvergeThreshold, default 0.05 */
+  int32_t use_score;                 /* setUseCore, default 1 */
+  int32_t fine_score;                /* setFineScore, default 0 */
+  double score_threshold;            /* setScoreThreshold, default 800 */
+  double match_percentage_threshold; /* setPercentThreshold, default 0.4 */
+  /* backend knobs (no reference counterpart) */
+  int32_t jtj_mode;  /* 0: VALU + wave-shuffle reduction of J^T J; 1: MFMA f32 16x16x4 */
+  int32_t profile;   /* 1: bracket every sweep launch with HIP events (stats.gpu_ms_sweep) */
+} lslam_opts;
+
+/* Per-call statistics (the counters the reference prints, ScanMatch.cpp:35-40,
+ * 143,269, plus timing taps). */
+typedef struct {
+  int32_t status;          /* same value the call returned */
+  int32_t iterations;      /* GN iterations whose 6x6 solve ran */
+  int32_t n_line;          /* line_match_count of the last sweep */
+  int32_t n_plane;         /* plane_match_count of the last sweep */
+  int32_t n_rows;          /* laserCloudSelNum of the last sweep */
+  int32_t degenerate;      /* isDegenerate (ScanMatch.cpp:222-233) */
+  int32_t converged;       /* ScanMatch.cpp:257-260 */
+  float delta_r, delta_t;  /* of the last solve (deg, cm) */
+  double score, percent;   /* ScanMatch.cpp:265-268 (valid when converged && use_score) */
+  int64_t point_residuals; /* (Nc+Ns) x sweeps executed on the device */
+  int32_t sweeps;          /* sweep launches that did work (not early-exited) */
+  int32_t sweep_launches;  /* sweep launches timed (profile=1) */
+  float gpu_ms_total;      /* HIP events around the whole device-resident GN loop */
+  float gpu_ms_sweep;      /* sum of sweep-kernel durations (profile=1), else 0 */
+} lslam_stats;
+
+typedef struct {
+  uint64_t n_corner, n_surf;         /* map sizes */
+  uint32_t nodes_corner, nodes_surf; /* kd-tree node counts */
+  int32_t depth_corner, depth_surf;  /* kd-tree depths */
+  float build_ms;                    /* tree build wall time inside lslam_map_set */
+  float upload_ms;                   /* H2D copy time inside lslam_map_set */
+  int32_t built_on_device;           /* 1 if the trees were built by HIP kernels */
+} lslam_map_info;
+
+/* ---- lifecycle --------------------------------------------------------- */
+
+/* Creates a context on HIP device `device` with its own stream.
+ * Replaces: construction of a lidar_slam::ScanMatch member
+ * (odometry/LaserMatcher.h _scan_match; pose_graph/loop_detector.hpp:269). */
+int lslam_ctx_create(int device, lslam_ctx **out);
+void lslam_ctx_destroy(lslam_ctx *ctx);
+/* Last error text for this thread ("" if none). */
+const char *lslam_last_error(void);
+/* Fills opts with the reference defaults (ScanMatch.cpp:21-33). */
+void lslam_default_opts(lslam_opts *opts);
+
+/* ---- map (reference clouds) -------------------------------------------- */
+
+/* Uploads the reference corner/surf clouds and builds both kd-trees.
+ * Replaces: kdtreeCorner.setInputCloud / kdtreeSurf.setInputCloud,
+ * ScanMatch.cpp:68-76 (util/nanoflann_pcl.h:141-148 -> nanoflann.hpp:1270-1284).
+ * The map stays resident and may be reused by any number of scan matches
+ * (the reference rebuilds it on every call -- quirk Q4). */
+int lslam_map_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const void *surf,
+                  size_t n_surf, size_t stride_bytes);
+int lslam_map_info_get(const lslam_ctx *ctx, lslam_map_info *info);
+
+/* ---- scan (query clouds) ------------------------------------------------ */
+
+/* Uploads the scan's corner/surf feature clouds (CornerCloud / SurfCloud of
+ * ScanMatch.cpp:53-54) so that lslam_scanmatch_run works on HBM-resident data. */
+int lslam_scan_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const void *surf,
+                   size_t n_surf, size_t stride_bytes);
+
+/* ---- Gauss-Newton scan match ------------------------------------------- */
+
+/* The GN loop of ScanMatch::scanMatchScan(..., Twist&), ScanMatch.cpp:78-347,
+ * on the resident map and scan.  pose is in/out and is always written back
+ * except for LSLAM_TOO_FEW_REF and errors (ScanMatch.cpp:324,331,338,343). */
+int lslam_scanmatch_run(lslam_ctx *ctx, float pose[6], const lslam_opts *opts, lslam_stats *stats);
+
+/* = lslam_scan_set + lslam_scanmatch_run.  Replaces scanMatchScan against a map
+ * that is already resident (the FeatureMap::scanMatchScan usage, util/FeatureMap.h:490-691). */
+int lslam_scanmatch_scan(lslam_ctx *ctx, const void *corner, size_t n_corner, const void *surf,
+                         size_t n_surf, size_t stride_bytes, float pose[6],
+                         const lslam_opts *opts, lslam_stats *stats);
+
+/* = lslam_map_set + lslam_scan_set + lslam_scanmatch_run: the exact drop-in for
+ * bool ScanMatch::scanMatchScan(refCorner, refSurf, Corner, Surf, Twist&),
+ * ScanMatch.cpp:51-347, including the per-call tree rebuild. */
+int lslam_scanmatch_full(lslam_ctx *ctx, const void *ref_corner, size_t n_ref_corner,
+                         const void *ref_surf, size_t n_ref_surf, size_t ref_stride_bytes,
+                         const void *corner, size_t n_corner, const void *surf, size_t n_surf,
+                         size_t stride_bytes, float pose[6], const lslam_opts *opts,
+                         lslam_stats *stats);
+
+/* Isometry3f <-> Twist conversion used by the Isometry overloads
+ * (ScanMatch.cpp:349-360; util/transform_utils.h:308-323,54-60).  T is a
+ * row-major 4x4. Host-side helpers, no device work. */
+void lslam_isometry_to_pose(const float T[16], float pose[6]);
+void lslam_pose_to_isometry(const float pose[6], float T[16]);
+
+/* ---- parity / debug taps ------------------------------------------------ */
+
+/* Exact 5-NN of nq query points (already in the map frame) in the resident
+ * corner (which_map=0) or surf (1) tree.  Replaces
+ * KdTreeFLANN::nearestKSearch(p, 5, idx, d2), util/nanoflann_pcl.h:150-162.
+ * idx_out[nq*5] are indices into the cloud passed to lslam_map_set (int32,
+ * bit-exact with nanoflann), d2_out[nq*5] squared distances ascending. */
+int lslam_knn5(lslam_ctx *ctx, int which_map, const void *queries, size_t nq,
+               size_t stride_bytes, int32_t *idx_out, float *d2_out);
+
+/* One sweep (ScanMatch.cpp:97-204) over the resident scan at a fixed pose.
+ * Any output may be NULL.  Point order: corner queries then surf queries.
+ *   idx_out[N*5], d2_out[N*5]  kNN of the transformed point
+ *   coeff_out[N*4]             (w*dir|w*n, w*d) -- coeffSel
+ *   flags_out[N]               bit0 d2[4]<5, bit1 fit found, bit2 row kept
+ *   sums_out[30]               21 upper-tri A^T A (row-major) | 6 A^T b |
+ *                              n_rows | n_line+n_plane | score */
+int lslam_sweep(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_t *idx_out,
+                float *d2_out, float *coeff_out, uint8_t *flags_out, float *sums_out);
+
+/* One solve/update step (ScanMatch.cpp:206-260) run by the device solve kernel
+ * on caller-provided normal equations.  matP/degenerate are in/out state. */
+int lslam_gn_step(lslam_ctx *ctx, const float AtA[36], const float Atb[6], int32_t iter,
+                  float pose[6], float matP[36], int32_t *degenerate, float delta_r_abort,
+                  float delta_t_abort, float x_out[6], float *delta_r, float *delta_t,
+                  int32_t *converged);
+
+/* Device handle taps for harnesses that time on the library's stream. */
+void *lslam_stream(lslam_ctx *ctx); /* hipStream_t */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSLAM_C_H */

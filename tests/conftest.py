@@ -1,0 +1,64 @@
+import glob
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_pkg():
+    """The package directory has a hyphen in its name: import it via importlib and
+    register the alias cooper_mapper_amd."""
+    if "cooper_mapper_amd" not in sys.modules:
+        pkg = importlib.import_module("the-cooper-mapper_amd")
+        sys.modules["cooper_mapper_amd"] = pkg
+    return sys.modules["cooper_mapper_amd"]
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return load_pkg()
+
+
+@pytest.fixture(scope="session")
+def synth():
+    load_pkg()
+    return importlib.import_module("the-cooper-mapper_amd.synth")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle_lib import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def goldens():
+    out = {}
+    for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "knn_*.npz"))):
+        out[os.path.basename(f)[4:-4]] = dict(np.load(f))
+    assert out, "no golden kNN fixtures found"
+    return out
+
+
+@pytest.fixture(scope="session")
+def small_problem(synth):
+    """16-ring x 900 scan against a 120 m map: the oracle finishes in ~0.1 s."""
+    return synth.make_problem(rings=16, azimuth_steps=900, world_half=60.0)
+
+
+@pytest.fixture(scope="session")
+def ctx(pkg):
+    """GPU context; only requested by @pytest.mark.gpu tests."""
+    c = pkg.Context(0)
+    yield c
+    c.close()

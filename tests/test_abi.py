@@ -1,0 +1,73 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds/loads and
+exports every symbol include/lslam_c.h declares; without a GPU the compute entry
+points fail loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "lslam_c.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(lslam_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    from importlib import import_module
+    capi = import_module("the-cooper-mapper_amd.capi")
+    if not os.path.exists(capi.lib_path()):
+        capi.build_library()
+    lib = capi.load_library()
+    declared = header_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), "%s declared in include/lslam_c.h but not exported" % name
+    assert sorted(capi.SYMBOLS) == declared, "capi.SYMBOLS and include/lslam_c.h disagree"
+
+
+def test_struct_layouts_match_header(pkg):
+    # sizes the C compiler gives the ABI structs (natural alignment, LP64)
+    assert C.sizeof(pkg.LslamOpts) == 48
+    assert C.sizeof(pkg.LslamStats) == 80
+    assert C.sizeof(pkg.LslamMapInfo) == 48
+
+
+def test_default_opts_are_the_reference_defaults(pkg):
+    lib = pkg.load_library()
+    o = pkg.LslamOpts()
+    lib.lslam_default_opts(C.byref(o))
+    # ScanMatch.cpp:21-33
+    assert (o.max_iterations, o.use_score, o.fine_score) == (10, 1, 0)
+    assert abs(o.delta_t_abort - 0.05) < 1e-9 and abs(o.delta_r_abort - 0.05) < 1e-9
+    assert o.score_threshold == 800 and o.match_percentage_threshold == 0.4
+
+
+def test_isometry_twist_roundtrip(pkg, oracle):
+    lib = pkg.load_library()
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        pose = rng.uniform(-1, 1, 6).astype(np.float32)
+        T = np.zeros(16, np.float32)
+        back = np.zeros(6, np.float32)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        lib.lslam_pose_to_isometry(fp(pose), fp(T))
+        lib.lslam_isometry_to_pose(fp(T), fp(back))
+        R, t = oracle.pose_to_Rt(pose)
+        assert np.array_equal(T.reshape(4, 4)[:3, :3], R)  # same libm, same op order: bit-exact
+        assert np.array_equal(T.reshape(4, 4)[:3, 3], t)
+        assert np.array_equal(back, oracle.Rt_to_pose(R, t))
+
+
+def test_no_gpu_fails_loudly(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.LslamError) as e:
+        pkg.Context(0)
+    assert e.value.code == pkg.Status.ERR_HIP
+    assert "no CPU fallback" in str(e.value) or "HIP" in str(e.value)

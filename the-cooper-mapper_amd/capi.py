@@ -1,0 +1,143 @@
+"""ctypes binding of include/lslam_c.h (one declaration per exported symbol)."""
+import ctypes as C
+import enum
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_NAME = "liblslam_hip.so"
+
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class LslamError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("lslam status %d: %s" % (code, msg))
+        self.code = code
+
+
+class Status(enum.IntEnum):
+    OK = 0
+    TOO_FEW_REF = 1
+    NOT_CONVERGED = 2
+    LOW_SCORE = 3
+    LOW_PERCENT = 4
+    TOO_FEW_MATCHES = 5
+    ERR_INVALID = -1
+    ERR_HIP = -2
+    ERR_NO_MAP = -3
+    ERR_NO_SCAN = -4
+    ERR_TREE_DEPTH = -5
+
+
+class LslamOpts(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_int32),
+        ("delta_t_abort", C.c_float),
+        ("delta_r_abort", C.c_float),
+        ("use_score", C.c_int32),
+        ("fine_score", C.c_int32),
+        ("score_threshold", C.c_double),
+        ("match_percentage_threshold", C.c_double),
+        ("jtj_mode", C.c_int32),
+        ("profile", C.c_int32),
+    ]
+
+
+class LslamStats(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32),
+        ("iterations", C.c_int32),
+        ("n_line", C.c_int32),
+        ("n_plane", C.c_int32),
+        ("n_rows", C.c_int32),
+        ("degenerate", C.c_int32),
+        ("converged", C.c_int32),
+        ("delta_r", C.c_float),
+        ("delta_t", C.c_float),
+        ("score", C.c_double),
+        ("percent", C.c_double),
+        ("point_residuals", C.c_int64),
+        ("sweeps", C.c_int32),
+        ("sweep_launches", C.c_int32),
+        ("gpu_ms_total", C.c_float),
+        ("gpu_ms_sweep", C.c_float),
+    ]
+
+
+class LslamMapInfo(C.Structure):
+    _fields_ = [
+        ("n_corner", C.c_uint64),
+        ("n_surf", C.c_uint64),
+        ("nodes_corner", C.c_uint32),
+        ("nodes_surf", C.c_uint32),
+        ("depth_corner", C.c_int32),
+        ("depth_surf", C.c_int32),
+        ("build_ms", C.c_float),
+        ("upload_ms", C.c_float),
+        ("built_on_device", C.c_int32),
+    ]
+
+
+# every symbol include/lslam_c.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "lslam_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "lslam_ctx_destroy": (None, [C.c_void_p]),
+    "lslam_last_error": (C.c_char_p, []),
+    "lslam_default_opts": (None, [C.POINTER(LslamOpts)]),
+    "lslam_map_set": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t]),
+    "lslam_map_info_get": (C.c_int, [C.c_void_p, C.POINTER(LslamMapInfo)]),
+    "lslam_scan_set": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t]),
+    "lslam_scanmatch_run": (C.c_int, [C.c_void_p, c_float_p, C.POINTER(LslamOpts), C.POINTER(LslamStats)]),
+    "lslam_scanmatch_scan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                       C.c_size_t, c_float_p, C.POINTER(LslamOpts), C.POINTER(LslamStats)]),
+    "lslam_scanmatch_full": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
+                                       C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
+                                       c_float_p, C.POINTER(LslamOpts), C.POINTER(LslamStats)]),
+    "lslam_isometry_to_pose": (None, [c_float_p, c_float_p]),
+    "lslam_pose_to_isometry": (None, [c_float_p, c_float_p]),
+    "lslam_knn5": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, c_int32_p, c_float_p]),
+    "lslam_sweep": (C.c_int, [C.c_void_p, c_float_p, C.c_int32, c_int32_p, c_float_p, c_float_p,
+                              c_uint8_p, c_float_p]),
+    "lslam_gn_step": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_int32, c_float_p, c_float_p,
+                                c_int32_p, C.c_float, C.c_float, c_float_p, c_float_p, c_float_p,
+                                c_int32_p]),
+    "lslam_stream": (C.c_void_p, [C.c_void_p]),
+}
+
+
+def lib_path():
+    return os.path.join(HERE, LIB_NAME)
+
+
+def build_library(force=False):
+    """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", CSRC], stdout=subprocess.DEVNULL)
+    return lib_path()
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen liblslam_hip.so and bind every declared symbol.  Raises if missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s not found: build it with `make -C %s` (hipcc --offload-arch=gfx950). "
+            "This backend has no CPU fallback." % (path, CSRC))
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,587 @@
+// lslam_api.hip -- host side of the C ABI declared in include/lslam_c.h.
+//
+// Owns the HIP stream, the HBM-resident map (two kd-trees), the resident scan and
+// the device Gauss-Newton state; enqueues the sweep/solve kernels of one
+// scanMatchScan call back to back with no host round trip in between.
+#include "../../include/lslam_c.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+
+#include "lslam_internal.hpp"
+
+using namespace lslam;
+
+namespace {
+
+thread_local std::string g_err;
+
+void set_err(const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+#define HIP_TRY(expr)                                                              \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess) {                                                        \
+      set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return LSLAM_ERR_HIP;                                                        \
+    }                                                                              \
+  } while (0)
+
+double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 64;
+    hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct DevTree {
+  DevBuf<KdNode> nodes;
+  DevBuf<float4> pts;
+  TreeView view{};
+  int depth = 0;
+};
+
+struct HostSinCos {
+  void operator()(float a, float &s, float &c) const {
+    s = std::sin(a);  // util/Angle.h:17-18 std::sin/std::cos(float)
+    c = std::cos(a);
+  }
+};
+
+}  // namespace
+
+struct lslam_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevTree tc, ts;
+  bool have_map = false;
+  bool have_scan = false;
+  lslam_map_info info{};
+  DevBuf<float4> qc, qs;
+  int32_t nqc = 0, nqs = 0;
+  DevBuf<float> partials;
+  GNState *d_state = nullptr;
+  GNState *h_state = nullptr;  // pinned
+  // tap buffers
+  DevBuf<int32_t> t_idx;
+  DevBuf<float> t_d2;
+  DevBuf<float4> t_coeff;
+  DevBuf<uint8_t> t_flags;
+  DevBuf<float4> t_q;
+  DevBuf<float> t_small;  // AtA/Atb upload for the gn_step tap
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> sweep_ev;
+};
+
+namespace {
+
+// strided cloud -> packed float4 {x,y,z,w}
+void pack_cloud(const void *src, size_t n, size_t stride_bytes, std::vector<float4> &out) {
+  out.resize(n);
+  const char *p = static_cast<const char *>(src);
+  for (size_t i = 0; i < n; ++i) {
+    float xyz[3];
+    std::memcpy(xyz, p + i * stride_bytes, sizeof(xyz));
+    out[i] = make_float4(xyz[0], xyz[1], xyz[2], 0.0f);
+  }
+}
+
+int upload_tree(lslam_ctx *ctx, DevTree &dt, const HostTree &ht, const std::vector<float4> &cloud) {
+  const size_t n = cloud.size();
+  std::vector<float4> perm(n);
+  for (size_t i = 0; i < n; ++i) {
+    const int32_t oi = ht.vind[i];
+    float4 v = cloud[(size_t)oi];
+    v.w = __builtin_bit_cast(float, oi);
+    perm[i] = v;
+  }
+  HIP_TRY(dt.nodes.reserve(ht.nodes.size() ? ht.nodes.size() : 1));
+  HIP_TRY(dt.pts.reserve(n ? n : 1));
+  if (!ht.nodes.empty())
+    HIP_TRY(hipMemcpyAsync(dt.nodes.p, ht.nodes.data(), ht.nodes.size() * sizeof(KdNode),
+                           hipMemcpyHostToDevice, ctx->stream));
+  if (n)
+    HIP_TRY(hipMemcpyAsync(dt.pts.p, perm.data(), n * sizeof(float4), hipMemcpyHostToDevice,
+                           ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));  // perm is a local
+  dt.view.nodes = dt.nodes.p;
+  dt.view.pts = dt.pts.p;
+  for (int d = 0; d < 3; ++d) {
+    dt.view.bb_lo[d] = ht.bb_lo[d];
+    dt.view.bb_hi[d] = ht.bb_hi[d];
+  }
+  dt.view.n_pts = (int32_t)n;
+  dt.view.n_nodes = (int32_t)ht.nodes.size();
+  dt.depth = ht.depth;
+  return LSLAM_OK;
+}
+
+void init_state(GNState &s, const float pose[6]) {
+  std::memset(&s, 0, sizeof(s));
+  for (int i = 0; i < 6; ++i) s.pose[i] = pose[i];
+  pose_to_Rt_sc(pose, s.R, s.t, s.sc, HostSinCos());
+}
+
+void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
+  a.tc = ctx->tc.view;
+  a.ts = ctx->ts.view;
+  a.qc = ctx->qc.p;
+  a.qs = ctx->qs.p;
+  a.nqc = ctx->nqc;
+  a.nqs = ctx->nqs;
+  a.nb_corner = (ctx->nqc + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
+  a.nb_total = a.nb_corner + (ctx->nqs + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
+  a.state = ctx->d_state;
+  a.partials = ctx->partials.p;
+  a.idx_out = nullptr;
+  a.d2_out = nullptr;
+  a.coeff_out = nullptr;
+  a.flags_out = nullptr;
+}
+
+int check_ctx(lslam_ctx *ctx) {
+  if (!ctx) {
+    set_err("null ctx");
+    return LSLAM_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  return LSLAM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *lslam_last_error(void) { return g_err.c_str(); }
+
+void lslam_default_opts(lslam_opts *o) {
+  if (!o) return;
+  o->max_iterations = 10;  // ScanMatch.h:36
+  o->delta_t_abort = 0.05f;
+  o->delta_r_abort = 0.05f;  // ScanMatch.cpp:22
+  o->use_score = 1;          // :23
+  o->fine_score = 0;         // :32
+  o->score_threshold = 800;  // :24
+  o->match_percentage_threshold = 0.4;
+  o->jtj_mode = 0;
+  o->profile = 0;
+}
+
+int lslam_ctx_create(int device, lslam_ctx **out) {
+  if (!out) {
+    set_err("null out");
+    return LSLAM_ERR_INVALID;
+  }
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    set_err("no HIP device available (%s); this backend has no CPU fallback",
+            e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return LSLAM_ERR_HIP;
+  }
+  if (device < 0 || device >= count) {
+    set_err("device %d out of range [0,%d)", device, count);
+    return LSLAM_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(device));
+  lslam_ctx *ctx = new lslam_ctx();
+  ctx->device = device;
+  HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  HIP_TRY(hipMalloc((void **)&ctx->d_state, sizeof(GNState)));
+  HIP_TRY(hipHostMalloc((void **)&ctx->h_state, sizeof(GNState), hipHostMallocDefault));
+  HIP_TRY(hipEventCreate(&ctx->ev0));
+  HIP_TRY(hipEventCreate(&ctx->ev1));
+  *out = ctx;
+  return LSLAM_OK;
+}
+
+void lslam_ctx_destroy(lslam_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  ctx->tc.nodes.release(); ctx->tc.pts.release();
+  ctx->ts.nodes.release(); ctx->ts.pts.release();
+  ctx->qc.release(); ctx->qs.release(); ctx->partials.release();
+  ctx->t_idx.release(); ctx->t_d2.release(); ctx->t_coeff.release(); ctx->t_flags.release();
+  ctx->t_q.release(); ctx->t_small.release();
+  if (ctx->d_state) (void)hipFree(ctx->d_state);
+  if (ctx->h_state) (void)hipHostFree(ctx->h_state);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  for (hipEvent_t e : ctx->sweep_ev) (void)hipEventDestroy(e);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+void *lslam_stream(lslam_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int lslam_map_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const void *surf,
+                  size_t n_surf, size_t stride_bytes) {
+  int rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (stride_bytes < 12 || (stride_bytes & 3) || (n_corner && !corner) || (n_surf && !surf)) {
+    set_err("bad cloud arguments (stride %zu)", stride_bytes);
+    return LSLAM_ERR_INVALID;
+  }
+  if (n_corner > 0x0FFFFFFFu || n_surf > 0x0FFFFFFFu) {
+    set_err("map too large for 28-bit node indices");
+    return LSLAM_ERR_INVALID;
+  }
+  ctx->have_map = false;
+  const double t0 = now_ms();
+  std::vector<float4> cc, cs;
+  HostTree hc, hs;
+  std::thread th([&] {
+    pack_cloud(corner, n_corner, stride_bytes, cc);
+    build_kdtree_host(reinterpret_cast<const float *>(cc.data()), n_corner, 4, hc);
+  });
+  pack_cloud(surf, n_surf, stride_bytes, cs);
+  build_kdtree_host(reinterpret_cast<const float *>(cs.data()), n_surf, 4, hs);
+  th.join();
+  const double t1 = now_ms();
+  if (hc.depth > KD_STACK_MAX || hs.depth > KD_STACK_MAX) {
+    set_err("kd-tree depth %d/%d exceeds device stack %d", hc.depth, hs.depth, KD_STACK_MAX);
+    return LSLAM_ERR_TREE_DEPTH;
+  }
+  rc = upload_tree(ctx, ctx->tc, hc, cc);
+  if (rc) return rc;
+  rc = upload_tree(ctx, ctx->ts, hs, cs);
+  if (rc) return rc;
+  const double t2 = now_ms();
+  ctx->info.n_corner = n_corner;
+  ctx->info.n_surf = n_surf;
+  ctx->info.nodes_corner = (uint32_t)hc.nodes.size();
+  ctx->info.nodes_surf = (uint32_t)hs.nodes.size();
+  ctx->info.depth_corner = hc.depth;
+  ctx->info.depth_surf = hs.depth;
+  ctx->info.build_ms = (float)(t1 - t0);
+  ctx->info.upload_ms = (float)(t2 - t1);
+  ctx->info.built_on_device = 0;
+  ctx->have_map = true;
+  return LSLAM_OK;
+}
+
+int lslam_map_info_get(const lslam_ctx *ctx, lslam_map_info *info) {
+  if (!ctx || !info) return LSLAM_ERR_INVALID;
+  if (!ctx->have_map) return LSLAM_ERR_NO_MAP;
+  *info = ctx->info;
+  return LSLAM_OK;
+}
+
+int lslam_scan_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const void *surf,
+                   size_t n_surf, size_t stride_bytes) {
+  int rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (stride_bytes < 12 || (stride_bytes & 3) || (n_corner && !corner) || (n_surf && !surf) ||
+      n_corner > 0x3FFFFFFFu || n_surf > 0x3FFFFFFFu) {
+    set_err("bad scan arguments");
+    return LSLAM_ERR_INVALID;
+  }
+  ctx->have_scan = false;
+  std::vector<float4> c, s;
+  pack_cloud(corner, n_corner, stride_bytes, c);
+  pack_cloud(surf, n_surf, stride_bytes, s);
+  HIP_TRY(ctx->qc.reserve(n_corner ? n_corner : 1));
+  HIP_TRY(ctx->qs.reserve(n_surf ? n_surf : 1));
+  if (n_corner)
+    HIP_TRY(hipMemcpyAsync(ctx->qc.p, c.data(), n_corner * sizeof(float4), hipMemcpyHostToDevice,
+                           ctx->stream));
+  if (n_surf)
+    HIP_TRY(hipMemcpyAsync(ctx->qs.p, s.data(), n_surf * sizeof(float4), hipMemcpyHostToDevice,
+                           ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  ctx->nqc = (int32_t)n_corner;
+  ctx->nqs = (int32_t)n_surf;
+  const size_t nb = (n_corner + SWEEP_BLOCK - 1) / SWEEP_BLOCK + (n_surf + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
+  HIP_TRY(ctx->partials.reserve((nb ? nb : 1) * NCOL));
+  ctx->have_scan = true;
+  return LSLAM_OK;
+}
+
+int lslam_scanmatch_run(lslam_ctx *ctx, float pose[6], const lslam_opts *opts_in,
+                        lslam_stats *stats) {
+  int rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (!pose) {
+    set_err("null pose");
+    return LSLAM_ERR_INVALID;
+  }
+  lslam_opts o;
+  if (opts_in) o = *opts_in; else lslam_default_opts(&o);
+  lslam_stats st_local;
+  lslam_stats &st = stats ? *stats : st_local;
+  std::memset(&st, 0, sizeof(st));
+  if (!ctx->have_map) { st.status = LSLAM_ERR_NO_MAP; set_err("no map set"); return LSLAM_ERR_NO_MAP; }
+  if (!ctx->have_scan) { st.status = LSLAM_ERR_NO_SCAN; set_err("no scan set"); return LSLAM_ERR_NO_SCAN; }
+  // ScanMatch.cpp:57-61
+  if (ctx->info.n_corner < 50 || ctx->info.n_surf < 100) {
+    st.status = LSLAM_TOO_FEW_REF;
+    return LSLAM_TOO_FEW_REF;
+  }
+  const int max_it = o.max_iterations < 0 ? 0 : o.max_iterations;
+
+  init_state(*ctx->h_state, pose);
+  if (max_it == 0) ctx->h_state->done = 1;
+  HIP_TRY(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(GNState), hipMemcpyHostToDevice,
+                         ctx->stream));
+  SweepArgs sa;
+  fill_sweep_args(ctx, sa);
+  SolveArgs so{};
+  so.state = ctx->d_state;
+  so.partials = ctx->partials.p;
+  so.nb_total = sa.nb_total;
+  so.reduce_only = 0;
+  so.max_iterations = max_it;
+  so.delta_r_abort = o.delta_r_abort;
+  so.delta_t_abort = o.delta_t_abort;
+  so.eig_thresh = 100.0f;  // ScanMatch.cpp:223
+
+  if (o.profile) {
+    while ((int)ctx->sweep_ev.size() < 2 * max_it) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreate(&e));
+      ctx->sweep_ev.push_back(e);
+    }
+  }
+  HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+  for (int it = 0; it < max_it; ++it) {
+    if (o.profile) HIP_TRY(hipEventRecord(ctx->sweep_ev[2 * it], ctx->stream));
+    HIP_TRY(launch_sweep(sa, o.jtj_mode, ctx->stream));
+    if (o.profile) HIP_TRY(hipEventRecord(ctx->sweep_ev[2 * it + 1], ctx->stream));
+    HIP_TRY(launch_solve(so, ctx->stream));
+  }
+  HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState), hipMemcpyDeviceToHost,
+                         ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+
+  const GNState &g = *ctx->h_state;
+  for (int i = 0; i < 6; ++i) pose[i] = g.pose[i];  // always written back
+  st.iterations = g.iter;
+  st.n_line = g.n_line;
+  st.n_plane = g.n_plane;
+  st.n_rows = g.n_rows;
+  st.degenerate = g.degenerate;
+  st.converged = g.converged;
+  st.delta_r = g.delta_r;
+  st.delta_t = g.delta_t;
+  st.sweeps = g.sweeps;
+  st.point_residuals = (int64_t)g.sweeps * ((int64_t)ctx->nqc + (int64_t)ctx->nqs);
+  HIP_TRY(hipEventElapsedTime(&st.gpu_ms_total, ctx->ev0, ctx->ev1));
+  if (o.profile) {
+    float acc = 0.f;
+    int n = 0;
+    for (int it = 0; it < max_it && it < g.sweeps; ++it) {
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, ctx->sweep_ev[2 * it], ctx->sweep_ev[2 * it + 1]));
+      acc += ms;
+      ++n;
+    }
+    st.gpu_ms_sweep = acc;
+    st.sweep_launches = n;
+  }
+  int status;
+  if (g.converged && o.use_score) {  // ScanMatch.cpp:263-341
+    const double score = g.score;
+    const double match_count = (double)g.n_line + (double)g.n_plane;
+    const float percent = (float)(match_count / (double)((size_t)ctx->nqc + (size_t)ctx->nqs));
+    st.score = score;
+    st.percent = percent;
+    if (score < o.score_threshold) status = LSLAM_LOW_SCORE;
+    else if (percent < o.match_percentage_threshold) status = LSLAM_LOW_PERCENT;
+    else status = LSLAM_OK;
+  } else if (g.too_few) {
+    status = LSLAM_TOO_FEW_MATCHES;
+  } else {
+    status = LSLAM_NOT_CONVERGED;
+  }
+  st.status = status;
+  return status;
+}
+
+int lslam_scanmatch_scan(lslam_ctx *ctx, const void *corner, size_t n_corner, const void *surf,
+                         size_t n_surf, size_t stride_bytes, float pose[6],
+                         const lslam_opts *opts, lslam_stats *stats) {
+  int rc = lslam_scan_set(ctx, corner, n_corner, surf, n_surf, stride_bytes);
+  if (rc) return rc;
+  return lslam_scanmatch_run(ctx, pose, opts, stats);
+}
+
+int lslam_scanmatch_full(lslam_ctx *ctx, const void *ref_corner, size_t n_ref_corner,
+                         const void *ref_surf, size_t n_ref_surf, size_t ref_stride_bytes,
+                         const void *corner, size_t n_corner, const void *surf, size_t n_surf,
+                         size_t stride_bytes, float pose[6], const lslam_opts *opts,
+                         lslam_stats *stats) {
+  // ScanMatch.cpp:57-61 comes before the trees are built
+  if (n_ref_corner < 50 || n_ref_surf < 100) {
+    if (stats) {
+      std::memset(stats, 0, sizeof(*stats));
+      stats->status = LSLAM_TOO_FEW_REF;
+    }
+    return LSLAM_TOO_FEW_REF;
+  }
+  int rc = lslam_map_set(ctx, ref_corner, n_ref_corner, ref_surf, n_ref_surf, ref_stride_bytes);
+  if (rc) return rc;
+  return lslam_scanmatch_scan(ctx, corner, n_corner, surf, n_surf, stride_bytes, pose, opts, stats);
+}
+
+// util/transform_utils.h:313-323 + :54-60
+void lslam_isometry_to_pose(const float T[16], float pose[6]) {
+  pose[0] = std::atan2(T[2 * 4 + 1], T[2 * 4 + 2]);
+  pose[1] = std::asin(-T[2 * 4 + 0]);
+  pose[2] = std::atan2(T[1 * 4 + 0], T[0 * 4 + 0]);
+  pose[3] = T[0 * 4 + 3];
+  pose[4] = T[1 * 4 + 3];
+  pose[5] = T[2 * 4 + 3];
+}
+
+// util/transform_utils.h:308-311 + :288-299
+void lslam_pose_to_isometry(const float pose[6], float T[16]) {
+  float R[9], t[3], sc[6];
+  pose_to_Rt_sc(pose, R, t, sc, HostSinCos());
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) T[r * 4 + c] = R[r * 3 + c];
+    T[r * 4 + 3] = t[r];
+  }
+  T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
+}
+
+int lslam_knn5(lslam_ctx *ctx, int which_map, const void *queries, size_t nq, size_t stride_bytes,
+               int32_t *idx_out, float *d2_out) {
+  int rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (!ctx->have_map) { set_err("no map set"); return LSLAM_ERR_NO_MAP; }
+  if ((which_map != 0 && which_map != 1) || stride_bytes < 12 || (stride_bytes & 3) ||
+      (nq && (!queries || !idx_out || !d2_out)) || nq > 0x0FFFFFFFu) {
+    set_err("bad knn5 arguments");
+    return LSLAM_ERR_INVALID;
+  }
+  if (nq == 0) return LSLAM_OK;
+  std::vector<float4> q;
+  pack_cloud(queries, nq, stride_bytes, q);
+  HIP_TRY(ctx->t_q.reserve(nq));
+  HIP_TRY(ctx->t_idx.reserve(nq * 5));
+  HIP_TRY(ctx->t_d2.reserve(nq * 5));
+  HIP_TRY(hipMemcpyAsync(ctx->t_q.p, q.data(), nq * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  const TreeView &T = which_map ? ctx->ts.view : ctx->tc.view;
+  HIP_TRY(launch_knn5(T, ctx->t_q.p, (int)nq, ctx->t_idx.p, ctx->t_d2.p, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(idx_out, ctx->t_idx.p, nq * 5 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d2_out, ctx->t_d2.p, nq * 5 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return LSLAM_OK;
+}
+
+int lslam_sweep(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_t *idx_out,
+                float *d2_out, float *coeff_out, uint8_t *flags_out, float *sums_out) {
+  int rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (!ctx->have_map) { set_err("no map set"); return LSLAM_ERR_NO_MAP; }
+  if (!ctx->have_scan) { set_err("no scan set"); return LSLAM_ERR_NO_SCAN; }
+  if (!pose) { set_err("null pose"); return LSLAM_ERR_INVALID; }
+  const size_t N = (size_t)ctx->nqc + (size_t)ctx->nqs;
+  init_state(*ctx->h_state, pose);
+  HIP_TRY(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(GNState), hipMemcpyHostToDevice, ctx->stream));
+  SweepArgs sa;
+  fill_sweep_args(ctx, sa);
+  const bool taps = idx_out || d2_out || coeff_out || flags_out;
+  if (taps) {
+    HIP_TRY(ctx->t_idx.reserve(N * 5 + 1));
+    HIP_TRY(ctx->t_d2.reserve(N * 5 + 1));
+    HIP_TRY(ctx->t_coeff.reserve(N + 1));
+    HIP_TRY(ctx->t_flags.reserve(N + 1));
+    sa.idx_out = ctx->t_idx.p;
+    sa.d2_out = ctx->t_d2.p;
+    sa.coeff_out = ctx->t_coeff.p;
+    sa.flags_out = ctx->t_flags.p;
+  }
+  HIP_TRY(launch_sweep(sa, jtj_mode, ctx->stream));
+  SolveArgs so{};
+  so.state = ctx->d_state;
+  so.partials = ctx->partials.p;
+  so.nb_total = sa.nb_total;
+  so.reduce_only = 1;
+  HIP_TRY(launch_solve(so, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState), hipMemcpyDeviceToHost, ctx->stream));
+  if (N) {
+    if (idx_out) HIP_TRY(hipMemcpyAsync(idx_out, ctx->t_idx.p, N * 5 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (d2_out) HIP_TRY(hipMemcpyAsync(d2_out, ctx->t_d2.p, N * 5 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (coeff_out) HIP_TRY(hipMemcpyAsync(coeff_out, ctx->t_coeff.p, N * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    if (flags_out) HIP_TRY(hipMemcpyAsync(flags_out, ctx->t_flags.p, N, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (sums_out) {
+    const GNState &g = *ctx->h_state;
+    for (int i = 0; i < 27; ++i) sums_out[i] = (float)g.sums[i];
+    sums_out[27] = (float)g.sums[COL_ROWS];
+    sums_out[28] = (float)(g.sums[COL_LINE] + g.sums[COL_PLANE]);
+    sums_out[29] = (float)g.sums[COL_SCORE];
+  }
+  return LSLAM_OK;
+}
+
+int lslam_gn_step(lslam_ctx *ctx, const float AtA[36], const float Atb[6], int32_t iter,
+                  float pose[6], float matP[36], int32_t *degenerate, float delta_r_abort,
+                  float delta_t_abort, float x_out[6], float *delta_r, float *delta_t,
+                  int32_t *converged) {
+  int rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (!AtA || !Atb || !pose || !matP || !degenerate) { set_err("null argument"); return LSLAM_ERR_INVALID; }
+  init_state(*ctx->h_state, pose);
+  ctx->h_state->iter = iter;
+  ctx->h_state->degenerate = *degenerate;
+  std::memcpy(ctx->h_state->matP, matP, sizeof(float) * 36);
+  HIP_TRY(ctx->t_small.reserve(64));
+  float tmp[42];
+  std::memcpy(tmp, AtA, sizeof(float) * 36);
+  std::memcpy(tmp + 36, Atb, sizeof(float) * 6);
+  HIP_TRY(hipMemcpyAsync(ctx->t_small.p, tmp, sizeof(tmp), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(GNState), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));  // tmp is a local
+  HIP_TRY(launch_gn_step_tap(ctx->d_state, ctx->t_small.p, ctx->t_small.p + 36, delta_r_abort,
+                             delta_t_abort, 100.0f, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const GNState &g = *ctx->h_state;
+  for (int i = 0; i < 6; ++i) pose[i] = g.pose[i];
+  std::memcpy(matP, g.matP, sizeof(float) * 36);
+  *degenerate = g.degenerate;
+  if (x_out) for (int i = 0; i < 6; ++i) x_out[i] = g.x[i];
+  if (delta_r) *delta_r = g.delta_r;
+  if (delta_t) *delta_t = g.delta_t;
+  if (converged) *converged = g.converged;
+  return LSLAM_OK;
+}
+
+}  // extern "C"

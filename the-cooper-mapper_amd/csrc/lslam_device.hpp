@@ -1,0 +1,657 @@
+// lslam_device.hpp -- device-side arithmetic of the scan-match hot path (gfx950).
+//
+// Everything here is written so that, compiled with -ffp-contract=off, each
+// per-point result is the same IEEE fp32 operation sequence as the reference's
+// single-threaded CPU code (citations relative to /root/reference/L_SLAM/src/).
+// Small matrices live in registers: every loop is fully unrolled and every array
+// index is a compile-time constant after unrolling (pivoting is done with
+// predicated swaps), so nothing except the kd-tree traversal stack goes to scratch.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+namespace lslam {
+
+#define LSLAM_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------------------
+// kd-tree in HBM.  Topology and leaf order are exactly nanoflann v1.2.3's
+// (util/nanoflann.hpp:931-1078); nodes are stored in allocation (= preorder)
+// order so child1 is always self+1.
+//   inner: lo=divlow hi=divhigh a=child2 b=divfeat (0..2)
+//   leaf : a=left b=~right (b<0); points [left,right) of the permuted array
+// Points are stored permuted by vind as float4 {x,y,z,bitcast(original index)}:
+// a leaf is one contiguous <=160 B run.
+// ---------------------------------------------------------------------------
+struct alignas(16) KdNode {
+  float lo, hi;
+  int32_t a, b;
+};
+
+struct TreeView {
+  const KdNode *nodes;
+  const float4 *pts;
+  float bb_lo[3], bb_hi[3];  // root_bbox, nanoflann.hpp:1406-1427
+  int32_t n_pts, n_nodes;
+};
+
+constexpr int KD_STACK_MAX = 64;  // host refuses deeper trees (LSLAM_ERR_TREE_DEPTH)
+
+// nanoflann.hpp:364-372 L2_Simple_Adaptor::evalMetric, x->y->z, no contraction.
+LSLAM_DEV float dist2_xyz(float qx, float qy, float qz, const float4 &p) {
+  const float dx = __fsub_rn(qx, p.x);
+  float r = __fmul_rn(dx, dx);
+  const float dy = __fsub_rn(qy, p.y);
+  r = __fadd_rn(r, __fmul_rn(dy, dy));
+  const float dz = __fsub_rn(qz, p.z);
+  r = __fadd_rn(r, __fmul_rn(dz, dz));
+  return r;
+}
+
+// nanoflann.hpp:108-135 KNNResultSet::addPoint for capacity 5.  Empty slots hold
+// FLT_MAX (init(), :92-98), insertion goes after equal distances (strict '>').
+LSLAM_DEV void knn_insert(float (&d)[5], int (&p)[5], float dist, int pos) {
+  const bool g0 = d[0] > dist, g1 = d[1] > dist, g2 = d[2] > dist, g3 = d[3] > dist,
+             g4 = d[4] > dist;
+  d[4] = g4 ? (g3 ? d[3] : dist) : d[4];
+  p[4] = g4 ? (g3 ? p[3] : pos) : p[4];
+  d[3] = g3 ? (g2 ? d[2] : dist) : d[3];
+  p[3] = g3 ? (g2 ? p[2] : pos) : p[3];
+  d[2] = g2 ? (g1 ? d[1] : dist) : d[2];
+  p[2] = g2 ? (g1 ? p[1] : pos) : p[2];
+  d[1] = g1 ? (g0 ? d[0] : dist) : d[1];
+  p[1] = g1 ? (g0 ? p[0] : pos) : p[1];
+  d[0] = g0 ? dist : d[0];
+  p[0] = g0 ? pos : p[0];
+}
+
+// Exact 5-NN: nanoflann.hpp:1303-1323 findNeighbors + :1433-1497 searchLevel
+// (eps = 0), one query per lane, recursion turned into an explicit stack that
+// keeps nanoflann's mindistsq / dists[] values bit for bit:
+//   entry = {other child | feat<<28 | active<<30, mindistsq for that child, cut_dist}
+// An entry whose far child is being explored stays on the stack marked active and
+// holds the old dists[feat], restored when it is popped (searchLevel :1494).
+// p[] are positions in the permuted point array (pts[p].w carries the original index).
+LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, float (&d)[5],
+                           int (&p)[5]) {
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    d[i] = FLT_MAX;
+    p[i] = -1;
+  }
+  if (T.n_pts == 0) return;  // nanoflann.hpp:1306-1307
+
+  // nanoflann.hpp:1080-1097 computeInitialDistances
+  float ds0 = 0.0f, ds1 = 0.0f, ds2 = 0.0f, mind = 0.0f;
+  if (qx < T.bb_lo[0]) { ds0 = (qx - T.bb_lo[0]) * (qx - T.bb_lo[0]); mind += ds0; }
+  if (qx > T.bb_hi[0]) { ds0 = (qx - T.bb_hi[0]) * (qx - T.bb_hi[0]); mind += ds0; }
+  if (qy < T.bb_lo[1]) { ds1 = (qy - T.bb_lo[1]) * (qy - T.bb_lo[1]); mind += ds1; }
+  if (qy > T.bb_hi[1]) { ds1 = (qy - T.bb_hi[1]) * (qy - T.bb_hi[1]); mind += ds1; }
+  if (qz < T.bb_lo[2]) { ds2 = (qz - T.bb_lo[2]) * (qz - T.bb_lo[2]); mind += ds2; }
+  if (qz > T.bb_hi[2]) { ds2 = (qz - T.bb_hi[2]) * (qz - T.bb_hi[2]); mind += ds2; }
+
+  int stk_n[KD_STACK_MAX];
+  float stk_m[KD_STACK_MAX];
+  float stk_c[KD_STACK_MAX];
+  int sp = 0;
+  int node = 0;
+  for (;;) {
+    KdNode nd = T.nodes[node];
+    while (nd.b >= 0) {  // inner node: nanoflann.hpp:1459-1475
+      const int feat = nd.b;
+      const float val = feat == 0 ? qx : (feat == 1 ? qy : qz);
+      const float diff1 = val - nd.lo;
+      const float diff2 = val - nd.hi;
+      const bool left = (diff1 + diff2) < 0.0f;
+      const float cd = left ? diff2 * diff2 : diff1 * diff1;  // accum_dist :374-377
+      const float dst = feat == 0 ? ds0 : (feat == 1 ? ds1 : ds2);
+      const float nm = (mind + cd) - dst;  // :1486
+      stk_n[sp] = (left ? nd.a : node + 1) | (feat << 28);
+      stk_m[sp] = nm;
+      stk_c[sp] = cd;
+      ++sp;
+      node = left ? node + 1 : nd.a;
+      nd = T.nodes[node];
+    }
+    {  // leaf: nanoflann.hpp:1438-1457 (worst_dist cached once per leaf)
+      const int l = nd.a, r = ~nd.b;
+      const float worst = d[4];
+      for (int i = l; i < r; ++i) {
+        const float4 pt = T.pts[i];
+        const float dist = dist2_xyz(qx, qy, qz, pt);
+        if (dist < worst) knn_insert(d, p, dist, i);
+      }
+    }
+    bool descend = false;
+    while (sp > 0) {
+      const int e = stk_n[sp - 1];
+      const int feat = (e >> 28) & 3;
+      if (e & (1 << 30)) {  // far subtree finished: dists[idx] = dst  (:1494)
+        const float old = stk_c[sp - 1];
+        if (feat == 0) ds0 = old; else if (feat == 1) ds1 = old; else ds2 = old;
+        --sp;
+        continue;
+      }
+      const float nm = stk_m[sp - 1];
+      if (nm <= d[4]) {  // mindistsq*epsError <= worstDist  (:1487)
+        const float cd = stk_c[sp - 1];
+        float old;
+        if (feat == 0) { old = ds0; ds0 = cd; }
+        else if (feat == 1) { old = ds1; ds1 = cd; }
+        else { old = ds2; ds2 = cd; }
+        stk_c[sp - 1] = old;
+        stk_n[sp - 1] = e | (1 << 30);
+        mind = nm;
+        node = e & 0x0FFFFFFF;
+        descend = true;
+        break;
+      }
+      --sp;
+    }
+    if (!descend) break;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Small dense algebra -- Eigen 3.3 algorithms (Eigen is a dependency of the
+// reference that is not under /root/reference).  Row-major
+// register arrays, static indexing only.
+// ---------------------------------------------------------------------------
+
+template <typename T>
+LSLAM_DEV void cswap(bool c, T &a, T &b) {
+  const T ta = a, tb = b;
+  a = c ? tb : ta;
+  b = c ? ta : tb;
+}
+
+// Eigen Jacobi.h JacobiRotation::makeGivens, real case
+LSLAM_DEV void make_givens(float p, float q, float &c, float &s) {
+  if (q == 0.0f) {
+    c = p < 0.0f ? -1.0f : 1.0f;
+    s = 0.0f;
+  } else if (p == 0.0f) {
+    c = 0.0f;
+    s = q < 0.0f ? 1.0f : -1.0f;
+  } else if (fabsf(p) > fabsf(q)) {
+    const float t = q / p;
+    float u = sqrtf(1.0f + t * t);
+    if (p < 0.0f) u = -u;
+    c = 1.0f / u;
+    s = -t * c;
+  } else {
+    const float t = p / q;
+    float u = sqrtf(1.0f + t * t);
+    if (q < 0.0f) u = -u;
+    s = -1.0f / u;
+    c = -t * s;
+  }
+}
+
+// Eigen MathFunctionsImpl.h positive_real_hypot
+LSLAM_DEV float eigen_hypot(float x, float y) {
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float p = ax > ay ? ax : ay;
+  if (p == 0.0f) return 0.0f;
+  const float q = ax > ay ? ay : ax;
+  const float qp = q / p;
+  return p * sqrtf(1.0f + qp * qp);
+}
+
+// SelfAdjointEigenSolver.h tridiagonal_qr_step on the unreduced block [START,END]
+// of an N x N problem, eigenvectors accumulated in Q (row-major).
+template <int N, int START, int END>
+LSLAM_DEV void tridiag_qr_step(float (&diag)[N], float (&sub)[N - 1], float (&Q)[N * N]) {
+  const float td = (diag[END - 1] - diag[END]) * 0.5f;
+  const float e = sub[END - 1];
+  float mu = diag[END];
+  if (td == 0.0f) {
+    mu -= fabsf(e);
+  } else if (e != 0.0f) {
+    const float e2 = e * e;
+    const float h = eigen_hypot(td, e);
+    if (e2 == 0.0f)
+      mu -= e / ((td + (td > 0.0f ? h : -h)) / e);
+    else
+      mu -= e2 / (td + (td > 0.0f ? h : -h));
+  }
+  float x = diag[START] - mu;
+  float z = sub[START];
+#pragma unroll
+  for (int k = START; k < END; ++k) {
+    float c, s;
+    make_givens(x, z, c, s);
+    const float sdk = s * diag[k] + c * sub[k];
+    const float dkp1 = s * sub[k] + c * diag[k + 1];
+    diag[k] = c * (c * diag[k] - s * sub[k]) - s * (c * sub[k] - s * diag[k + 1]);
+    diag[k + 1] = s * sdk + c * dkp1;
+    sub[k] = c * sdk - s * dkp1;
+    if (k > START) sub[k - 1] = c * sub[k - 1] - s * z;
+    x = sub[k];
+    if (k < END - 1) {
+      z = -s * sub[k + 1];
+      sub[k + 1] = c * sub[k + 1];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const float xi = Q[i * N + k], yi = Q[i * N + k + 1];
+      Q[i * N + k] = c * xi - s * yi;
+      Q[i * N + k + 1] = s * xi + c * yi;
+    }
+  }
+}
+
+// SelfAdjointEigenSolver<Matrix3f>::compute: scale, 3x3 real tridiagonalisation
+// (Tridiagonalization.h, tridiagonalization_inplace_selector<M,3,false>),
+// computeFromTridiagonal_impl (maxIterations 30), ascending sort.
+// A: row-major, only the lower triangle is read.
+LSLAM_DEV void eig_sym3(const float (&A)[9], float (&evals)[3], float (&V)[9]) {
+  float m00 = A[0], m10 = A[3], m11 = A[4], m20 = A[6], m21 = A[7], m22 = A[8];
+  float scale = fabsf(m00);
+  scale = fmaxf(scale, fabsf(m10));
+  scale = fmaxf(scale, fabsf(m11));
+  scale = fmaxf(scale, fabsf(m20));
+  scale = fmaxf(scale, fabsf(m21));
+  scale = fmaxf(scale, fabsf(m22));
+  if (scale == 0.0f) scale = 1.0f;
+  m00 /= scale; m10 /= scale; m11 /= scale; m20 /= scale; m21 /= scale; m22 /= scale;
+
+  float diag[3], sub[2];
+  diag[0] = m00;
+  const float v1norm2 = m20 * m20;
+  if (v1norm2 <= FLT_MIN) {
+    diag[1] = m11;
+    diag[2] = m22;
+    sub[0] = m10;
+    sub[1] = m21;
+    V[0] = 1; V[1] = 0; V[2] = 0; V[3] = 0; V[4] = 1; V[5] = 0; V[6] = 0; V[7] = 0; V[8] = 1;
+  } else {
+    const float beta = sqrtf(m10 * m10 + v1norm2);
+    const float invBeta = 1.0f / beta;
+    const float m01 = m10 * invBeta;
+    const float m02 = m20 * invBeta;
+    const float q = 2.0f * m01 * m21 + m02 * (m22 - m11);
+    diag[1] = m11 + m02 * q;
+    diag[2] = m22 - m02 * q;
+    sub[0] = beta;
+    sub[1] = m21 - m01 * q;
+    V[0] = 1; V[1] = 0;   V[2] = 0;
+    V[3] = 0; V[4] = m01; V[5] = m02;
+    V[6] = 0; V[7] = m02; V[8] = -m01;
+  }
+  int end = 2, start = 0, iter = 0;
+  const float precision = 2.0f * FLT_EPSILON;
+  while (end > 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (i >= start && i < end)
+        if (fabsf(sub[i]) <= (fabsf(diag[i]) + fabsf(diag[i + 1])) * precision ||
+            fabsf(sub[i]) <= FLT_MIN)
+          sub[i] = 0.0f;
+    // while (end>0 && subdiag[end-1]==0) end--;
+    if (end == 2 && sub[1] == 0.0f) end = 1;
+    if (end == 1 && sub[0] == 0.0f) end = 0;
+    if (end <= 0) break;
+    iter++;
+    if (iter > 30 * 3) break;
+    start = end - 1;
+    if (start == 1 && sub[0] != 0.0f) start = 0;
+    if (end == 2) {
+      if (start == 0) tridiag_qr_step<3, 0, 2>(diag, sub, V);
+      else tridiag_qr_step<3, 1, 2>(diag, sub, V);
+    } else {
+      tridiag_qr_step<3, 0, 1>(diag, sub, V);
+    }
+  }
+  // selection sort ascending (minCoeff picks the first minimum)
+  {
+    const bool k2 = diag[2] < (diag[1] < diag[0] ? diag[1] : diag[0]);
+    const bool k1 = !k2 && diag[1] < diag[0];
+    cswap(k1, diag[0], diag[1]);
+    cswap(k1, V[0], V[1]); cswap(k1, V[3], V[4]); cswap(k1, V[6], V[7]);
+    cswap(k2, diag[0], diag[2]);
+    cswap(k2, V[0], V[2]); cswap(k2, V[3], V[5]); cswap(k2, V[6], V[8]);
+    const bool j1 = diag[2] < diag[1];
+    cswap(j1, diag[1], diag[2]);
+    cswap(j1, V[1], V[2]); cswap(j1, V[4], V[5]); cswap(j1, V[7], V[8]);
+  }
+  evals[0] = diag[0] * scale;
+  evals[1] = diag[1] * scale;
+  evals[2] = diag[2] * scale;
+}
+
+// ColPivHouseholderQR<Matrix<float,R,C>>::compute + solve (Eigen 3.3,
+// ColPivHouseholderQR.h computeInPlace/_solve_impl; Householder.h
+// makeHouseholder/applyHouseholderOnTheLeft).  A row-major (consumed).
+template <int R, int C>
+LSLAM_DEV void colpiv_qr_solve(float (&qr)[R * C], const float (&b)[R], float (&x)[C]) {
+  constexpr int SIZE = R < C ? R : C;
+  float hC[SIZE], nU[C], nD[C], c[R];
+  int trans[SIZE], perm[C];
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) s += qr[i * C + k] * qr[i * C + k];
+    nD[k] = sqrtf(s);
+    nU[k] = nD[k];
+  }
+  float maxn = nU[0];
+#pragma unroll
+  for (int k = 1; k < C; ++k) maxn = nU[k] > maxn ? nU[k] : maxn;
+  const float th = maxn * FLT_EPSILON;
+  const float threshold_helper = (th * th) / (float)R;
+  const float norm_downdate_threshold = sqrtf(FLT_EPSILON);
+  int nonzero_pivots = SIZE;
+#pragma unroll
+  for (int k = 0; k < SIZE; ++k) {
+    int big = k;
+    float bigv = nU[k];
+#pragma unroll
+    for (int j = k + 1; j < C; ++j) {
+      const bool g = nU[j] > bigv;
+      bigv = g ? nU[j] : bigv;
+      big = g ? j : big;
+    }
+    const float biggest_col_sq_norm = bigv * bigv;
+    if (nonzero_pivots == SIZE && biggest_col_sq_norm < threshold_helper * (float)(R - k))
+      nonzero_pivots = k;
+    trans[k] = big;
+#pragma unroll
+    for (int j = k + 1; j < C; ++j) {
+      const bool sw = (big == j);
+#pragma unroll
+      for (int i = 0; i < R; ++i) cswap(sw, qr[i * C + k], qr[i * C + j]);
+      cswap(sw, nU[k], nU[j]);
+      cswap(sw, nD[k], nD[j]);
+    }
+    // makeHouseholderInPlace on column k, rows k..R-1
+    float tau, beta;
+    {
+      float tailSqNorm = 0.0f;
+#pragma unroll
+      for (int i = k + 1; i < R; ++i) tailSqNorm += qr[i * C + k] * qr[i * C + k];
+      const float c0 = qr[k * C + k];
+      if (tailSqNorm <= FLT_MIN) {
+        tau = 0.0f;
+        beta = c0;
+#pragma unroll
+        for (int i = k + 1; i < R; ++i) qr[i * C + k] = 0.0f;
+      } else {
+        beta = sqrtf(c0 * c0 + tailSqNorm);
+        if (c0 >= 0.0f) beta = -beta;
+        const float denom = c0 - beta;
+#pragma unroll
+        for (int i = k + 1; i < R; ++i) qr[i * C + k] = qr[i * C + k] / denom;
+        tau = (beta - c0) / beta;
+      }
+    }
+    hC[k] = tau;
+    qr[k * C + k] = beta;
+    // applyHouseholderOnTheLeft to the block rows k..R-1, cols k+1..C-1
+    if (R - k == 1) {
+#pragma unroll
+      for (int j = k + 1; j < C; ++j) qr[k * C + j] *= (1.0f - tau);
+    } else if (tau != 0.0f) {
+#pragma unroll
+      for (int j = k + 1; j < C; ++j) {
+        float tmp = 0.0f;
+#pragma unroll
+        for (int i = k + 1; i < R; ++i) tmp += qr[i * C + k] * qr[i * C + j];
+        tmp += qr[k * C + j];
+        qr[k * C + j] -= tau * tmp;
+#pragma unroll
+        for (int i = k + 1; i < R; ++i) qr[i * C + j] -= tau * qr[i * C + k] * tmp;
+      }
+    }
+    // column norm downdate
+#pragma unroll
+    for (int j = k + 1; j < C; ++j) {
+      if (nU[j] != 0.0f) {
+        float temp = fabsf(qr[k * C + j]) / nU[j];
+        temp = (1.0f + temp) * (1.0f - temp);
+        temp = temp < 0.0f ? 0.0f : temp;
+        const float r = nU[j] / nD[j];
+        const float temp2 = temp * (r * r);
+        if (temp2 <= norm_downdate_threshold) {
+          float s = 0.0f;
+#pragma unroll
+          for (int i = k + 1; i < R; ++i) s += qr[i * C + j] * qr[i * C + j];
+          nD[j] = sqrtf(s);
+          nU[j] = nD[j];
+        } else {
+          nU[j] *= sqrtf(temp);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < C; ++k) perm[k] = k;
+#pragma unroll
+  for (int k = 0; k < SIZE; ++k) {
+#pragma unroll
+    for (int j = k + 1; j < C; ++j) cswap(trans[k] == j, perm[k], perm[j]);
+  }
+  if (nonzero_pivots == 0) {
+#pragma unroll
+    for (int i = 0; i < C; ++i) x[i] = 0.0f;
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < R; ++i) c[i] = b[i];
+  // c = Q^T c : H_0 first
+#pragma unroll
+  for (int k = 0; k < SIZE; ++k) {
+    if (k < nonzero_pivots) {
+      const float tau = hC[k];
+      if (R - k == 1) {
+        c[k] *= (1.0f - tau);
+      } else if (tau != 0.0f) {
+        float tmp = 0.0f;
+#pragma unroll
+        for (int i = k + 1; i < R; ++i) tmp += qr[i * C + k] * c[i];
+        tmp += c[k];
+        c[k] -= tau * tmp;
+#pragma unroll
+        for (int i = k + 1; i < R; ++i) c[i] -= tau * qr[i * C + k] * tmp;
+      }
+    }
+  }
+  // upper-triangular solve on the leading nonzero_pivots block (column oriented)
+#pragma unroll
+  for (int i = SIZE - 1; i >= 0; --i) {
+    if (i < nonzero_pivots) {
+      c[i] /= qr[i * C + i];
+#pragma unroll
+      for (int r = 0; r < i; ++r) c[r] -= c[i] * qr[r * C + i];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < C; ++j) x[j] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < SIZE; ++i) {
+    if (i < nonzero_pivots) {
+#pragma unroll
+      for (int j = 0; j < C; ++j)
+        if (perm[i] == j) x[j] = c[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Geometry: util/feature_utils.h
+// ---------------------------------------------------------------------------
+
+LSLAM_DEV void cross3(const float (&a)[3], const float (&b)[3], float (&o)[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+LSLAM_DEV float norm3(const float (&a)[3]) {
+  return sqrtf((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
+}
+
+// feature_utils.h:108-154 findLine on the 5 gathered neighbours
+LSLAM_DEV bool find_line(const float4 (&nb)[5], float (&A)[3], float (&B)[3]) {
+  float c[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    c[0] += nb[j].x;
+    c[1] += nb[j].y;
+    c[2] += nb[j].z;
+  }
+  c[0] /= 5.0f; c[1] /= 5.0f; c[2] /= 5.0f;
+  float M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const float a0 = nb[j].x - c[0], a1 = nb[j].y - c[1], a2 = nb[j].z - c[2];
+    M[0] += a0 * a0;
+    M[3] += a0 * a1;
+    M[6] += a0 * a2;
+    M[4] += a1 * a1;
+    M[7] += a1 * a2;
+    M[8] += a2 * a2;
+  }
+  M[0] /= 5.0f; M[3] /= 5.0f; M[6] /= 5.0f; M[4] /= 5.0f; M[7] /= 5.0f; M[8] /= 5.0f;
+  float D[3], V[9];
+  eig_sym3(M, D, V);
+  if (D[2] > 5 * D[1]) {
+    const float v[3] = {V[2], V[5], V[8]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      A[i] = c[i] - v[i] * 0.1f;
+      B[i] = c[i] + v[i] * 0.1f;
+    }
+    return true;
+  }
+  return false;
+}
+
+// feature_utils.h:17-26 getLinePointDistance + :63-75 getCornerFeatureCoefficients
+LSLAM_DEV bool corner_coeff(const float (&A)[3], const float (&B)[3], const float (&X)[3],
+                            float (&coeff)[4]) {
+  const float XB[3] = {X[0] - B[0], X[1] - B[1], X[2] - B[2]};
+  const float XA[3] = {X[0] - A[0], X[1] - A[1], X[2] - A[2]};
+  float n[3];
+  cross3(XB, XA, n);
+  const float nn = norm3(n);
+  const float AB[3] = {A[0] - B[0], A[1] - B[1], A[2] - B[2]};
+  const float lengthAB = norm3(AB);
+  const float BA[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
+  const float mn[3] = {-n[0], -n[1], -n[2]};
+  float cr[3];
+  cross3(mn, BA, cr);
+  const float den = nn * lengthAB;
+  const float distance = nn / lengthAB;
+  const float weight = 1 - 0.9f * fabsf(distance);
+  coeff[0] = (cr[0] / den) * weight;
+  coeff[1] = (cr[1] / den) * weight;
+  coeff[2] = (cr[2] / den) * weight;
+  coeff[3] = distance * weight;
+  return (double)weight > 0.1;  // float vs double literal, as in the reference
+}
+
+// feature_utils.h:157-204 findPlane
+LSLAM_DEV bool find_plane(const float4 (&nb)[5], float max_distance, float (&plane)[4]) {
+  float Am[15];
+  const float bm[5] = {-1.0f, -1.0f, -1.0f, -1.0f, -1.0f};
+  float x[3];
+  float c[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    c[0] += nb[j].x;
+    c[1] += nb[j].y;
+    c[2] += nb[j].z;
+    Am[j * 3 + 0] = nb[j].x;
+    Am[j * 3 + 1] = nb[j].y;
+    Am[j * 3 + 2] = nb[j].z;
+  }
+  c[0] /= 5.0f; c[1] /= 5.0f; c[2] /= 5.0f;
+  colpiv_qr_solve<5, 3>(Am, bm, x);
+  const float norm = sqrtf(((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]) + 0.0f * 0.0f);
+  plane[0] = x[0] / norm;
+  plane[1] = x[1] / norm;
+  plane[2] = x[2] / norm;
+  plane[3] = -((plane[0] * c[0] + plane[1] * c[1]) + plane[2] * c[2]);
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const float distance = ((plane[0] * nb[j].x + plane[1] * nb[j].y) + plane[2] * nb[j].z) + plane[3];
+    ok = ok && !(fabsf(distance) > max_distance);
+  }
+  return ok;
+}
+
+// feature_utils.h:97-106 getSurfaceFeatureCoefficients (double literal 0.9)
+LSLAM_DEV bool surf_coeff(const float (&plane)[4], const float (&X)[3], float (&coeff)[4]) {
+  const float distance = ((plane[0] * X[0] + plane[1] * X[1]) + plane[2] * X[2]) + plane[3];
+  const float xn = norm3(X);
+  const float weight = (float)(1 - 0.9 * (double)fabsf(distance) / sqrt((double)xn));
+  coeff[0] = plane[0] * weight;
+  coeff[1] = plane[1] * weight;
+  coeff[2] = plane[2] * weight;
+  coeff[3] = distance * weight;
+  return (double)weight > 0.1;  // float vs double literal, as in the reference
+}
+
+// scan_to_scan_match/ScanMatch.cpp:185-203 with the original operator precedence
+// (quirk Q1 in arz).  sc = {srx,crx,sry,cry,srz,crz}
+LSLAM_DEV void jacobian_row(const float (&sc)[6], float px, float py, float pz,
+                            const float (&coeff)[4], float (&row)[6], float &b) {
+  const float srx = sc[0], crx = sc[1], sry = sc[2], cry = sc[3], srz = sc[4], crz = sc[5];
+  const float cx = coeff[0], cy = coeff[1], cz = coeff[2];
+  const float arx =
+      ((crz * sry * crx + srz * srx) * py + (srz * crx - crz * sry * srx) * pz) * cx +
+      ((srz * sry * crx - crz * srx) * py - (srz * sry * srx + crz * crx) * pz) * cy +
+      (cry * crx * py - cry * srx * pz) * cz;
+  const float ary = (-crz * sry * px + crz * cry * srx * py + crz * cry * crx * pz) * cx +
+                    (-srz * sry * px + srz * cry * srx * py + srz * cry * crx * pz) * cy +
+                    (-cry * px - sry * srx * py - sry * crx * pz) * cz;
+  const float arz =
+      (-srz * cry * px - (srz * sry * srx + crz * crx) * py + (crz * srx - srz * sry * crx) * pz) * cx +
+      (crz * cry * px + (crz * sry * srx - srz * crx) * py + crz * sry * crx + srz * srx * pz) * cy +
+      0 * cz;
+  row[0] = arx; row[1] = ary; row[2] = arz;
+  row[3] = cx; row[4] = cy; row[5] = cz;
+  b = -coeff[3];
+}
+
+// util/transform_utils.h:288-299 getTransformationTZYX (+ :308-311):
+// q = AngleAxis(rz,Z)*AngleAxis(ry,Y)*AngleAxis(rx,X); R = q.toRotationMatrix().
+// Shared by host (std::sin/std::cos(float), exactly the reference's libm calls) and
+// device (solve kernel) through the SinCos functor.
+struct Quat { float w, x, y, z; };
+template <typename F>
+__host__ __device__ inline void pose_to_Rt_sc(const float pose[6], float R[9], float t[3],
+                                              float sc[6], F sincos_f) {
+  Quat qx, qy, qz;
+  float s, c;
+  sincos_f(0.5f * pose[0], s, c); qx = {c, s, 0.0f, 0.0f};
+  sincos_f(0.5f * pose[1], s, c); qy = {c, 0.0f, s, 0.0f};
+  sincos_f(0.5f * pose[2], s, c); qz = {c, 0.0f, 0.0f, s};
+  auto mul = [](const Quat &a, const Quat &b) {
+    Quat r;
+    r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+    r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+    return r;
+  };
+  const Quat q = mul(mul(qz, qy), qx);
+  const float tx = 2.0f * q.x, ty = 2.0f * q.y, tz = 2.0f * q.z;
+  const float twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  const float txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  const float tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  R[0] = 1.0f - (tyy + tzz); R[1] = txy - twz;          R[2] = txz + twy;
+  R[3] = txy + twz;          R[4] = 1.0f - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;          R[7] = tyz + twx;          R[8] = 1.0f - (txx + tyy);
+  t[0] = pose[3]; t[1] = pose[4]; t[2] = pose[5];
+  // util/Angle.h:17-18 cached sin/cos of the full angles
+  sincos_f(pose[0], sc[0], sc[1]);
+  sincos_f(pose[1], sc[2], sc[3]);
+  sincos_f(pose[2], sc[4], sc[5]);
+}
+
+}  // namespace lslam

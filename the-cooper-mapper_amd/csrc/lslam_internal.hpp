@@ -1,0 +1,89 @@
+// lslam_internal.hpp -- structures shared by the host API and the HIP kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "lslam_device.hpp"
+
+namespace lslam {
+
+// Columns of one block's partial-sum record (and of the reduced sums).
+enum : int {
+  COL_ATA = 0,      // 21 upper-triangular entries of A^T A, row-major
+  COL_ATB = 21,     // 6 entries of A^T b
+  COL_ROWS = 27,    // rows kept (laserCloudSelNum)
+  COL_LINE = 28,    // line_match_count   (corner blocks only)
+  COL_PLANE = 29,   // plane_match_count  (surf blocks only)
+  COL_SCORE = 30,   // sum exp(-|res|) over kept rows (ScanMatch.cpp:42-49)
+  NCOL = 32
+};
+
+// Device-resident Gauss-Newton state: the loop of ScanMatch.cpp:91-261 never
+// returns to the host between iterations.
+struct GNState {
+  float pose[6];   // Twist: rot_x rot_y rot_z pos_x pos_y pos_z
+  float R[9];      // rotation of the current pose (row-major)
+  float t[3];
+  float sc[6];     // srx crx sry cry srz crz (util/Angle.h cached values)
+  float matP[36];  // degeneracy projector (ScanMatch.cpp:234)
+  float x[6];      // last update
+  float delta_r, delta_t;
+  int32_t iter;        // solves performed
+  int32_t done;        // loop has ended; later launches exit at once
+  int32_t converged;   // ScanMatch.cpp:257-260
+  int32_t degenerate;  // ScanMatch.cpp:222-233
+  int32_t too_few;     // ScanMatch.cpp:141-145
+  int32_t n_line, n_plane, n_rows;
+  int32_t sweeps;      // sweeps that did work
+  int32_t pad;
+  double score;        // of the last sweep
+  double sums[NCOL];   // last reduced sums (parity tap)
+};
+
+struct SweepArgs {
+  TreeView tc, ts;
+  const float4 *qc, *qs;  // scan points, sensor frame, {x,y,z,-}
+  int32_t nqc, nqs;
+  int32_t nb_corner, nb_total;  // blocks are type-homogeneous: [0,nb_corner) corner
+  const GNState *state;
+  float *partials;  // [nb_total][NCOL]
+  // optional per-point taps (all NULL in the production loop)
+  int32_t *idx_out;    // [N][5] original map indices
+  float *d2_out;       // [N][5]
+  float4 *coeff_out;   // [N]
+  uint8_t *flags_out;  // [N]
+};
+
+struct SolveArgs {
+  GNState *state;
+  const float *partials;
+  int32_t nb_total;
+  int32_t reduce_only;  // 1: only reduce partials into state->sums (tap)
+  int32_t max_iterations;
+  float delta_r_abort, delta_t_abort;
+  float eig_thresh;  // 100 (ScanMatch.cpp:223)
+};
+
+constexpr int SWEEP_BLOCK = 128;
+
+// launchers (lslam_kernels.hip)
+hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s);
+hipError_t launch_solve(const SolveArgs &a, hipStream_t s);
+hipError_t launch_knn5(const TreeView &T, const float4 *q, int nq, int32_t *idx, float *d2,
+                       hipStream_t s);
+hipError_t launch_gn_step_tap(GNState *st, const float *AtA, const float *Atb, float dr, float dt,
+                              float eig_thresh, hipStream_t s);
+
+// host kd-tree builder (kdtree_host.cpp): nanoflann v1.2.3 topology, device node format
+struct HostTree {
+  std::vector<KdNode> nodes;
+  std::vector<int32_t> vind;
+  float bb_lo[3], bb_hi[3];
+  int depth = 0;
+};
+void build_kdtree_host(const float *pts, size_t n, size_t stride_floats, HostTree &out);
+
+}  // namespace lslam

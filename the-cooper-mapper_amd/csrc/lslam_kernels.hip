@@ -1,0 +1,569 @@
+// lslam_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, wave64).
+//
+//   sweep_kernel   one lane per scan point: transform -> exact kd-tree 5-NN ->
+//                  line/plane fit -> residual coefficient -> Jacobian row ->
+//                  27 normal-equation terms, reduced per block
+//                  (ScanMatch.cpp:97-204 + the products of :206-208)
+//   solve_kernel   deterministic cross-block reduction, 6x6 solve, degeneracy
+//                  projection, pose update, convergence test (ScanMatch.cpp:141-145,
+//                  206-260); writes the next pose for the following sweep, so the
+//                  whole Gauss-Newton loop stays on the device
+//   knn5_kernel    parity tap: nearestKSearch(p, 5, ...) (nanoflann_pcl.h:150-162)
+//
+// Compile with -ffp-contract=off (see lslam_device.hpp).
+#include "lslam_internal.hpp"
+
+namespace lslam {
+
+// Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b%8).  Remap
+// so that every XCD works on one contiguous range of scan points: neighbouring
+// scan points walk the same kd-tree nodes and leaves, which then stay in that
+// XCD's private 4 MiB L2.  Bijective for any grid size.
+LSLAM_DEV int xcd_remap(int b, int nb) {
+  const int xcd = b & 7;
+  const int q = nb >> 3, r = nb & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+LSLAM_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// J^T J by MFMA (jtj_mode 1): the wave's 64 rows [J | b] (7 of 16 columns used)
+// are staged through LDS and contracted with v_mfma_f32_16x16x4_f32, 4 scan
+// points per instruction, 16 instructions per wave.  For J^T J the A operand
+// (16 x 4: A[i][k] = J[k][i]) and the B operand (4 x 16: B[k][j] = J[k][j]) hold
+// the SAME value in lane l = 16*k + i, so one ds_read feeds both.  The MFMA is an
+// exact fp32 fma chain in k order (no reduced precision).
+// ---------------------------------------------------------------------------
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void sweep_kernel(SweepArgs a, int jtj_mode) {
+  const GNState *st = a.state;
+  if (st->done) return;  // loop already ended (ScanMatch.cpp:144,259)
+
+  constexpr int NWAVE = BLOCK / 64;
+  __shared__ float red[NWAVE][NCOL];
+  __shared__ float jrows[NWAVE][64][8];  // MFMA staging: [point][J0..J5,b,0]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lb = xcd_remap(blockIdx.x, a.nb_total);
+  const bool is_surf = lb >= a.nb_corner;
+  const int qi = (is_surf ? lb - a.nb_corner : lb) * BLOCK + tid;
+  const int nq = is_surf ? a.nqs : a.nqc;
+  const bool active = qi < nq;
+
+  // pose of this iteration: wave-uniform scalar loads
+  float R[9], t[3], sc[6];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = st->R[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) t[i] = st->t[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) sc[i] = st->sc[i];
+
+  float row[6] = {0, 0, 0, 0, 0, 0};
+  float rb = 0.0f;
+  float kept = 0.0f, matched = 0.0f, score = 0.0f;
+
+  if (active) {
+    const float4 q = (is_surf ? a.qs : a.qc)[qi];
+    // util/transform_utils.h:476-482 pointAssociateToMap: it * p
+    float sel[3];
+    sel[0] = ((R[0] * q.x + R[1] * q.y) + R[2] * q.z) + t[0];
+    sel[1] = ((R[3] * q.x + R[4] * q.y) + R[5] * q.z) + t[1];
+    sel[2] = ((R[6] * q.x + R[7] * q.y) + R[8] * q.z) + t[2];
+
+    float d[5];
+    int p[5];
+    TreeView T;  // block-uniform choice of tree
+    T.nodes = is_surf ? a.ts.nodes : a.tc.nodes;
+    T.pts = is_surf ? a.ts.pts : a.tc.pts;
+    T.n_pts = is_surf ? a.ts.n_pts : a.tc.n_pts;
+    T.n_nodes = is_surf ? a.ts.n_nodes : a.tc.n_nodes;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      T.bb_lo[i] = is_surf ? a.ts.bb_lo[i] : a.tc.bb_lo[i];
+      T.bb_hi[i] = is_surf ? a.ts.bb_hi[i] : a.tc.bb_hi[i];
+    }
+    knn5_search(T, sel[0], sel[1], sel[2], d, p);
+
+    float coeff[4] = {0, 0, 0, 0};
+    unsigned flag = 0;
+    float4 nb[5];
+    const bool gate = d[4] < 5.0f;  // ScanMatch.cpp:102,120
+    if (gate) {
+      flag |= 1u;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) nb[j] = T.pts[p[j]];
+      if (!is_surf) {
+        float A[3], B[3];
+        if (find_line(nb, A, B)) {  // ScanMatch.cpp:105-112
+          flag |= 2u;
+          if (corner_coeff(A, B, sel, coeff)) flag |= 4u;
+        }
+      } else {
+        float plane[4];
+        if (find_plane(nb, 0.2f, plane)) {  // ScanMatch.cpp:122-130
+          flag |= 2u;
+          if (surf_coeff(plane, sel, coeff)) flag |= 4u;
+        }
+      }
+    }
+    if (flag & 2u) matched = 1.0f;
+    if (flag & 4u) {
+      jacobian_row(sc, q.x, q.y, q.z, coeff, row, rb);
+      kept = 1.0f;
+      score = expf(-fabsf(coeff[3]));
+    }
+    if (a.flags_out) {  // parity taps
+      const int gi = is_surf ? a.nqc + qi : qi;
+      a.flags_out[gi] = (uint8_t)flag;
+      if (a.coeff_out) a.coeff_out[gi] = make_float4(coeff[0], coeff[1], coeff[2], coeff[3]);
+      if (a.idx_out) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          a.idx_out[gi * 5 + j] = p[j] >= 0 ? __float_as_int(T.pts[p[j]].w) : -1;
+          a.d2_out[gi * 5 + j] = d[j];
+        }
+      }
+    }
+  }
+
+  // ---- normal equations: per-wave reduction --------------------------------
+  float v[NCOL];
+#pragma unroll
+  for (int i = 0; i < NCOL; ++i) v[i] = 0.0f;
+
+  if (jtj_mode == 1) {
+    // stage [J | b] rows; rows of rejected points are zero
+    float *jr = &jrows[wave][lane][0];
+    *reinterpret_cast<float4 *>(jr) = make_float4(row[0], row[1], row[2], row[3]);
+    *reinterpret_cast<float4 *>(jr + 4) = make_float4(row[4], row[5], rb, 0.0f);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int i16 = lane & 15, k4 = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float op = (i16 < 8) ? jrows[wave][4 * s + k4][i16] : 0.0f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(op, op, acc, 0, 0, 0);
+    }
+    // C/D layout: col = lane&15, row = (lane>>4)*4 + reg.  Entry (r,c), r<=c<7.
+    // Scatter the 27 needed entries back to column slots through LDS.
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int rr = k4 * 4 + r4, cc = i16;
+      if (rr < 6 && cc < 7 && cc >= rr) {
+        int col;
+        if (cc == 6) col = COL_ATB + rr;
+        else col = COL_ATA + (rr * 6 - (rr * (rr - 1)) / 2) + (cc - rr);
+        red[wave][col] = acc[r4];
+      }
+    }
+    // counters still go through the shuffle reduction
+    const float s_rows = wave_sum(kept), s_match = wave_sum(matched), s_score = wave_sum(score);
+    if (lane == 0) {
+      red[wave][COL_ROWS] = s_rows;
+      red[wave][COL_LINE] = is_surf ? 0.0f : s_match;
+      red[wave][COL_PLANE] = is_surf ? s_match : 0.0f;
+      red[wave][COL_SCORE] = s_score;
+      red[wave][31] = 0.0f;
+    }
+  } else {
+    // ScanMatch.cpp:206-208 products, then gfx950 wave-shuffle reduction
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = i; j < 6; ++j) v[k++] = row[i] * row[j];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[COL_ATB + i] = row[i] * rb;
+    v[COL_ROWS] = kept;
+    v[COL_LINE] = is_surf ? 0.0f : matched;
+    v[COL_PLANE] = is_surf ? matched : 0.0f;
+    v[COL_SCORE] = score;
+#pragma unroll
+    for (int i = 0; i < 31; ++i) v[i] = wave_sum(v[i]);
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < NCOL; ++i) red[wave][i] = v[i];
+    }
+  }
+  __syncthreads();
+  // LDS-staged per-block accumulation: fixed order over the block's waves
+  if (tid < NCOL) {
+    float s = red[0][tid];
+#pragma unroll
+    for (int w = 1; w < NWAVE; ++w) s += red[w][tid];
+    a.partials[(size_t)lb * NCOL + tid] = s;
+  }
+}
+
+hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s) {
+  if (a.nb_total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(sweep_kernel<SWEEP_BLOCK>, dim3(a.nb_total), dim3(SWEEP_BLOCK), 0, s, a,
+                     jtj_mode);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// 6x6 symmetric eigen-decomposition and inverse for the degeneracy test (first
+// iteration only; single thread, plain arrays).  Eigen 3.3
+// SelfAdjointEigenSolver<Matrix<float,6,6>> generic path and
+// Matrix::inverse() (PartialPivLU).
+// ---------------------------------------------------------------------------
+__device__ static void make_householder_dyn(float *c0, float *tail, int tail_len, int stride,
+                                            float *tau, float *beta) {
+  float tailSqNorm = 0.0f;
+  for (int i = 0; i < tail_len; ++i) tailSqNorm += tail[i * stride] * tail[i * stride];
+  if (tailSqNorm <= FLT_MIN) {
+    *tau = 0.0f;
+    *beta = *c0;
+    for (int i = 0; i < tail_len; ++i) tail[i * stride] = 0.0f;
+  } else {
+    float b = sqrtf((*c0) * (*c0) + tailSqNorm);
+    if (*c0 >= 0.0f) b = -b;
+    const float denom = *c0 - b;
+    for (int i = 0; i < tail_len; ++i) tail[i * stride] = tail[i * stride] / denom;
+    *tau = (b - *c0) / b;
+    *beta = b;
+  }
+}
+
+__device__ static void eig_sym6_dyn(const float *A, float *evals, float *V) {
+  constexpr int N = 6;
+  float m[N * N];
+  float scale = 0.0f;
+  for (int r = 0; r < N; ++r)
+    for (int c = 0; c < N; ++c) {
+      m[r * N + c] = (c <= r) ? A[r * N + c] : 0.0f;
+      scale = fmaxf(scale, fabsf(m[r * N + c]));
+    }
+  if (scale == 0.0f) scale = 1.0f;
+  for (int r = 0; r < N; ++r)
+    for (int c = 0; c <= r; ++c) m[r * N + c] /= scale;
+  float hCoeffs[N - 1];
+  for (int i = 0; i < N - 1; ++i) {
+    const int rem = N - i - 1;
+    float h, beta;
+    make_householder_dyn(&m[(i + 1) * N + i], &m[(i + 2) * N + i], rem - 1, N, &h, &beta);
+    m[(i + 1) * N + i] = 1.0f;
+    float v[N], p[N];
+    for (int aa = 0; aa < rem; ++aa) v[aa] = m[(i + 1 + aa) * N + i];
+    for (int aa = 0; aa < rem; ++aa) {
+      float acc = 0.0f;
+      for (int bb = 0; bb < rem; ++bb) {
+        const int r = i + 1 + (aa > bb ? aa : bb), c = i + 1 + (aa > bb ? bb : aa);
+        acc += m[r * N + c] * (h * v[bb]);
+      }
+      p[aa] = acc;
+    }
+    float dot = 0.0f;
+    for (int aa = 0; aa < rem; ++aa) dot += p[aa] * v[aa];
+    const float alpha = h * -0.5f * dot;
+    for (int aa = 0; aa < rem; ++aa) p[aa] += alpha * v[aa];
+    for (int aa = 0; aa < rem; ++aa)
+      for (int bb = 0; bb <= aa; ++bb)
+        m[(i + 1 + aa) * N + (i + 1 + bb)] -= (v[aa] * p[bb] + p[aa] * v[bb]);
+    m[(i + 1) * N + i] = beta;
+    hCoeffs[i] = h;
+  }
+  float diag[N], sub[N - 1];
+  for (int i = 0; i < N; ++i) diag[i] = m[i * N + i];
+  for (int i = 0; i < N - 1; ++i) sub[i] = m[(i + 1) * N + i];
+  for (int r = 0; r < N; ++r)
+    for (int c = 0; c < N; ++c) V[r * N + c] = (r == c) ? 1.0f : 0.0f;
+  for (int k = N - 2; k >= 0; --k) {
+    // applyHouseholderOnTheLeft on V[k+1.., k+1..] with essential = m[k+2.., k]
+    const int rows = N - k - 1;
+    const float tau = hCoeffs[k];
+    float *M = &V[(k + 1) * N + (k + 1)];
+    const float *ess = &m[(k + 2) * N + k];
+    if (rows == 1) {
+      M[0] *= (1.0f - tau);
+    } else if (tau != 0.0f) {
+      for (int j = 0; j < rows; ++j) {
+        float tmp = 0.0f;
+        for (int i = 1; i < rows; ++i) tmp += ess[(i - 1) * N] * M[i * N + j];
+        tmp += M[j];
+        M[j] -= tau * tmp;
+        for (int i = 1; i < rows; ++i) M[i * N + j] -= tau * ess[(i - 1) * N] * tmp;
+      }
+    }
+  }
+  // computeFromTridiagonal_impl
+  int end = N - 1, start = 0, iter = 0;
+  const float precision = 2.0f * FLT_EPSILON;
+  while (end > 0) {
+    for (int i = start; i < end; ++i)
+      if (fabsf(sub[i]) <= (fabsf(diag[i]) + fabsf(diag[i + 1])) * precision ||
+          fabsf(sub[i]) <= FLT_MIN)
+        sub[i] = 0.0f;
+    while (end > 0 && sub[end - 1] == 0.0f) end--;
+    if (end <= 0) break;
+    iter++;
+    if (iter > 30 * N) break;
+    start = end - 1;
+    while (start > 0 && sub[start - 1] != 0.0f) start--;
+    {
+      const float td = (diag[end - 1] - diag[end]) * 0.5f;
+      const float e = sub[end - 1];
+      float mu = diag[end];
+      if (td == 0.0f) {
+        mu -= fabsf(e);
+      } else if (e != 0.0f) {
+        const float e2 = e * e;
+        const float h = eigen_hypot(td, e);
+        if (e2 == 0.0f) mu -= e / ((td + (td > 0.0f ? h : -h)) / e);
+        else mu -= e2 / (td + (td > 0.0f ? h : -h));
+      }
+      float x = diag[start] - mu;
+      float z = sub[start];
+      for (int k = start; k < end; ++k) {
+        float c, s;
+        make_givens(x, z, c, s);
+        const float sdk = s * diag[k] + c * sub[k];
+        const float dkp1 = s * sub[k] + c * diag[k + 1];
+        diag[k] = c * (c * diag[k] - s * sub[k]) - s * (c * sub[k] - s * diag[k + 1]);
+        diag[k + 1] = s * sdk + c * dkp1;
+        sub[k] = c * sdk - s * dkp1;
+        if (k > start) sub[k - 1] = c * sub[k - 1] - s * z;
+        x = sub[k];
+        if (k < end - 1) {
+          z = -s * sub[k + 1];
+          sub[k + 1] = c * sub[k + 1];
+        }
+        for (int i = 0; i < N; ++i) {
+          const float xi = V[i * N + k], yi = V[i * N + k + 1];
+          V[i * N + k] = c * xi - s * yi;
+          V[i * N + k + 1] = s * xi + c * yi;
+        }
+      }
+    }
+  }
+  for (int i = 0; i < N - 1; ++i) {
+    int k = 0;
+    float mn = diag[i];
+    for (int j = 1; j < N - i; ++j)
+      if (diag[i + j] < mn) { mn = diag[i + j]; k = j; }
+    if (k > 0) {
+      float tmp = diag[i]; diag[i] = diag[k + i]; diag[k + i] = tmp;
+      for (int r = 0; r < N; ++r) {
+        tmp = V[r * N + i]; V[r * N + i] = V[r * N + k + i]; V[r * N + k + i] = tmp;
+      }
+    }
+  }
+  for (int i = 0; i < N; ++i) evals[i] = diag[i] * scale;
+}
+
+__device__ static void inverse6_dyn(const float *A, float *Ainv) {
+  constexpr int N = 6;
+  float lu[N * N];
+  int piv[N];
+  for (int i = 0; i < N * N; ++i) lu[i] = A[i];
+  for (int k = 0; k < N; ++k) {
+    int p = k;
+    float best = fabsf(lu[k * N + k]);
+    for (int r = k + 1; r < N; ++r)
+      if (fabsf(lu[r * N + k]) > best) { best = fabsf(lu[r * N + k]); p = r; }
+    piv[k] = p;
+    if (p != k)
+      for (int c = 0; c < N; ++c) { const float t = lu[k * N + c]; lu[k * N + c] = lu[p * N + c]; lu[p * N + c] = t; }
+    if (lu[k * N + k] != 0.0f)
+      for (int r = k + 1; r < N; ++r) lu[r * N + k] /= lu[k * N + k];
+    for (int r = k + 1; r < N; ++r)
+      for (int c = k + 1; c < N; ++c) lu[r * N + c] -= lu[r * N + k] * lu[k * N + c];
+  }
+  for (int col = 0; col < N; ++col) {
+    float y[N];
+    for (int r = 0; r < N; ++r) y[r] = (r == col) ? 1.0f : 0.0f;
+    for (int k = 0; k < N; ++k) { const float t = y[k]; y[k] = y[piv[k]]; y[piv[k]] = t; }
+    for (int r = 0; r < N; ++r)
+      for (int c = 0; c < r; ++c) y[r] -= lu[r * N + c] * y[c];
+    for (int r = N - 1; r >= 0; --r) {
+      for (int c = r + 1; c < N; ++c) y[r] -= lu[r * N + c] * y[c];
+      y[r] /= lu[r * N + r];
+    }
+    for (int r = 0; r < N; ++r) Ainv[r * N + col] = y[r];
+  }
+}
+
+struct DevSinCos {
+  // the host uses std::sin/std::cos(float); the double-precision ocml functions
+  // rounded to float agree with glibc's (correctly rounded in practice)
+  __device__ void operator()(float a, float &s, float &c) const {
+    s = (float)sin((double)a);
+    c = (float)cos((double)a);
+  }
+};
+
+// ScanMatch.cpp:206-260 for one iteration, single thread.
+__device__ static void gn_step_device(GNState *st, const float (&AtA_in)[36],
+                                      const float (&Atb)[6], float eig_thresh, float dr_abort,
+                                      float dt_abort) {
+  float x[6];
+  {
+    float qr[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) qr[i] = AtA_in[i];
+    colpiv_qr_solve<6, 6>(qr, Atb, x);  // :209
+  }
+  if (st->iter == 0) {  // :211-235
+    float E[6], V[36], V2[36], Vinv[36];
+    eig_sym6_dyn(AtA_in, E, V);
+    for (int i = 0; i < 36; ++i) V2[i] = V[i];
+    int deg = 0;
+    for (int i = 0; i < 6; ++i) {
+      if (E[i] < eig_thresh) {
+        for (int j = 0; j < 6; ++j) V2[i * 6 + j] = 0.0f;  // row i: quirk Q2
+        deg = 1;
+      } else
+        break;
+    }
+    st->degenerate = deg;
+    if (deg) {
+      inverse6_dyn(V, Vinv);
+      for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) {
+          float s = 0.0f;
+          for (int k = 0; k < 6; ++k) s += Vinv[r * 6 + k] * V2[k * 6 + c];
+          st->matP[r * 6 + c] = s;
+        }
+    }
+  }
+  if (st->degenerate) {  // :237-240
+    float x2[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x2[i] = x[i];
+    for (int r = 0; r < 6; ++r) {
+      float s = 0.0f;
+      for (int k = 0; k < 6; ++k) s += st->matP[r * 6 + k] * x2[k];
+      x[r] = s;
+    }
+  }
+  float pose[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    pose[i] = st->pose[i] + x[i];  // :242-247
+    st->pose[i] = pose[i];
+    st->x[i] = x[i];
+  }
+  // :249-253 (rad2deg(float) -> float, pow(float,int) -> double)
+  const double kPi = 3.14159265358979323846;
+  const double r0 = (double)(float)((double)x[0] * 180.0 / kPi);
+  const double r1 = (double)(float)((double)x[1] * 180.0 / kPi);
+  const double r2 = (double)(float)((double)x[2] * 180.0 / kPi);
+  const float dR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+  const double t0 = (double)(x[3] * 100), t1 = (double)(x[4] * 100), t2 = (double)(x[5] * 100);
+  const float dT = (float)sqrt(t0 * t0 + t1 * t1 + t2 * t2);
+  st->delta_r = dR;
+  st->delta_t = dT;
+  st->iter += 1;
+  pose_to_Rt_sc(pose, st->R, st->t, st->sc, DevSinCos());
+  if (dR < dr_abort && dT < dt_abort) {  // :257-260
+    st->converged = 1;
+    st->done = 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void solve_kernel(SolveArgs a) {
+  GNState *st = a.state;
+  if (st->done) return;
+  __shared__ double red[8][NCOL];
+  __shared__ double tot[NCOL];
+  const int tid = threadIdx.x, col = tid & 31, grp = tid >> 5;
+  double s = 0.0;
+  for (int b = grp; b < a.nb_total; b += 8) s += (double)a.partials[(size_t)b * NCOL + col];
+  red[grp][col] = s;
+  __syncthreads();
+  if (tid < NCOL) {
+    double v = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) v += red[g][tid];
+    tot[tid] = v;
+    st->sums[tid] = v;
+  }
+  __syncthreads();
+  if (tid != 0 || a.reduce_only) return;
+
+  st->sweeps += 1;
+  st->n_rows = (int)tot[COL_ROWS];
+  st->n_line = (int)tot[COL_LINE];
+  st->n_plane = (int)tot[COL_PLANE];
+  st->score = tot[COL_SCORE];
+  if (st->n_rows < 50) {  // ScanMatch.cpp:141-145
+    st->too_few = 1;
+    st->done = 1;
+    return;
+  }
+  float AtA[36], Atb[6];
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = i; j < 6; ++j) {
+      const float vv = (float)tot[k++];
+      AtA[i * 6 + j] = vv;
+      AtA[j * 6 + i] = vv;
+    }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) Atb[i] = (float)tot[COL_ATB + i];
+  gn_step_device(st, AtA, Atb, a.eig_thresh, a.delta_r_abort, a.delta_t_abort);
+  if (st->iter >= a.max_iterations) st->done = 1;
+}
+
+hipError_t launch_solve(const SolveArgs &a, hipStream_t s) {
+  hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+__global__ void gn_step_tap_kernel(GNState *st, const float *AtA, const float *Atb, float dr,
+                                   float dt, float eig_thresh) {
+  if (threadIdx.x != 0) return;
+  float A[36], b[6];
+  for (int i = 0; i < 36; ++i) A[i] = AtA[i];
+  for (int i = 0; i < 6; ++i) b[i] = Atb[i];
+  gn_step_device(st, A, b, eig_thresh, dr, dt);
+}
+
+hipError_t launch_gn_step_tap(GNState *st, const float *AtA, const float *Atb, float dr, float dt,
+                              float eig_thresh, hipStream_t s) {
+  hipLaunchKernelGGL(gn_step_tap_kernel, dim3(1), dim3(64), 0, s, st, AtA, Atb, dr, dt,
+                     eig_thresh);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// parity tap: nearestKSearch(p, 5, idx, d2) for nq points already in map frame
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void knn5_kernel(TreeView T, const float4 *q, int nq,
+                                                   int32_t *idx, float *d2) {
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int i = lb * 128 + threadIdx.x;
+  if (i >= nq) return;
+  const float4 qq = q[i];
+  float d[5];
+  int p[5];
+  knn5_search(T, qq.x, qq.y, qq.z, d, p);
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    idx[i * 5 + j] = p[j] >= 0 ? __float_as_int(T.pts[p[j]].w) : -1;
+    d2[i * 5 + j] = d[j];
+  }
+}
+
+hipError_t launch_knn5(const TreeView &T, const float4 *q, int nq, int32_t *idx, float *d2,
+                       hipStream_t s) {
+  if (nq <= 0) return hipSuccess;
+  hipLaunchKernelGGL(knn5_kernel, dim3((nq + 127) / 128), dim3(128), 0, s, T, q, nq, idx, d2);
+  return hipGetLastError();
+}
+
+}  // namespace lslam

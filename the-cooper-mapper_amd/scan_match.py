@@ -1,0 +1,243 @@
+"""Host-side mirror of the reference's scan-match interface over the C ABI.
+
+``ScanMatch`` keeps the method names, argument meaning and return behaviour of
+``lidar_slam::ScanMatch`` (/root/reference/L_SLAM/src/scan_to_scan_match/
+ScanMatch.h:21-61, ScanMatch.cpp:21-398); ``Context`` is the thin handle over
+``include/lslam_c.h`` that tests and bench.py drive directly.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .capi import (LslamError, LslamMapInfo, LslamOpts, LslamStats, Status, c_float_p, c_int32_p,
+                   c_uint8_p, load_library)
+
+
+def _cloud(a):
+    """(n, >=3) array -> C-contiguous float32 and its stride in bytes."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] < 3:
+        raise ValueError("cloud must be (n, >=3) float32, got %r" % (a.shape,))
+    return a, a.shape[1] * 4
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _fp(a):
+    return a.ctypes.data_as(c_float_p)
+
+
+class Context:
+    """One lslam_ctx: a HIP stream, an HBM-resident map and scan, the device GN state."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.lslam_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise LslamError(rc, self.lib.lslam_last_error().decode())
+        self.h = h
+        self.device = device
+        self.n_scan = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lslam_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            raise LslamError(rc, self.lib.lslam_last_error().decode())
+        return rc
+
+    def default_opts(self):
+        o = LslamOpts()
+        self.lib.lslam_default_opts(C.byref(o))
+        return o
+
+    # -- map / scan ----------------------------------------------------------
+    def map_set(self, corner, surf):
+        c, sc = _cloud(corner)
+        s, ss = _cloud(surf)
+        if sc != ss:
+            raise ValueError("corner/surf strides differ")
+        self._check(self.lib.lslam_map_set(self.h, _vp(c), len(c), _vp(s), len(s), sc))
+
+    def map_info(self):
+        info = LslamMapInfo()
+        self._check(self.lib.lslam_map_info_get(self.h, C.byref(info)))
+        return info
+
+    def scan_set(self, corner, surf):
+        c, sc = _cloud(corner)
+        s, ss = _cloud(surf)
+        if sc != ss:
+            raise ValueError("corner/surf strides differ")
+        self._check(self.lib.lslam_scan_set(self.h, _vp(c), len(c), _vp(s), len(s), sc))
+        self.n_scan = len(c) + len(s)
+
+    # -- GN loop ---------------------------------------------------------------
+    def run(self, pose, opts=None):
+        """lslam_scanmatch_run on the resident map+scan -> (status, pose, stats)."""
+        p = np.array(pose, dtype=np.float32).reshape(6)
+        st = LslamStats()
+        rc = self.lib.lslam_scanmatch_run(self.h, _fp(p), C.byref(opts) if opts is not None else None,
+                                          C.byref(st))
+        self._check(rc)
+        return Status(rc), p, st
+
+    def scanmatch_scan(self, corner, surf, pose, opts=None):
+        c, sc = _cloud(corner)
+        s, _ = _cloud(surf)
+        p = np.array(pose, dtype=np.float32).reshape(6)
+        st = LslamStats()
+        rc = self.lib.lslam_scanmatch_scan(self.h, _vp(c), len(c), _vp(s), len(s), sc, _fp(p),
+                                           C.byref(opts) if opts is not None else None, C.byref(st))
+        self._check(rc)
+        self.n_scan = len(c) + len(s)
+        return Status(rc), p, st
+
+    def scanmatch_full(self, ref_corner, ref_surf, corner, surf, pose, opts=None):
+        rc_, rs = _cloud(ref_corner)
+        rs_, _ = _cloud(ref_surf)
+        c, sc = _cloud(corner)
+        s, _ = _cloud(surf)
+        p = np.array(pose, dtype=np.float32).reshape(6)
+        st = LslamStats()
+        rc = self.lib.lslam_scanmatch_full(self.h, _vp(rc_), len(rc_), _vp(rs_), len(rs_), rs,
+                                           _vp(c), len(c), _vp(s), len(s), sc, _fp(p),
+                                           C.byref(opts) if opts is not None else None, C.byref(st))
+        self._check(rc)
+        return Status(rc), p, st
+
+    # -- parity taps -------------------------------------------------------------
+    def knn5(self, which_map, queries):
+        q, sq = _cloud(queries)
+        idx = np.zeros((len(q), 5), np.int32)
+        d2 = np.zeros((len(q), 5), np.float32)
+        self._check(self.lib.lslam_knn5(self.h, int(which_map), _vp(q), len(q), sq,
+                                        idx.ctypes.data_as(c_int32_p), _fp(d2)))
+        return idx, d2
+
+    def sweep(self, pose, jtj_mode=0, taps=True):
+        p = np.array(pose, dtype=np.float32).reshape(6)
+        n = self.n_scan
+        sums = np.zeros(30, np.float32)
+        if taps:
+            idx = np.zeros((n, 5), np.int32)
+            d2 = np.zeros((n, 5), np.float32)
+            coeff = np.zeros((n, 4), np.float32)
+            flags = np.zeros(n, np.uint8)
+            self._check(self.lib.lslam_sweep(self.h, _fp(p), jtj_mode, idx.ctypes.data_as(c_int32_p),
+                                             _fp(d2), _fp(coeff), flags.ctypes.data_as(c_uint8_p),
+                                             _fp(sums)))
+            return dict(idx=idx, d2=d2, coeff=coeff, flags=flags, sums=sums)
+        self._check(self.lib.lslam_sweep(self.h, _fp(p), jtj_mode, None, None, None, None, _fp(sums)))
+        return dict(sums=sums)
+
+    def gn_step(self, AtA, Atb, it, pose, matP, degenerate, dr=0.05, dt=0.05):
+        AtA = np.ascontiguousarray(AtA, np.float32).reshape(36)
+        Atb = np.ascontiguousarray(Atb, np.float32).reshape(6)
+        p = np.array(pose, dtype=np.float32).reshape(6)
+        mp = np.array(matP, dtype=np.float32).reshape(36)
+        deg = C.c_int32(int(degenerate))
+        x = np.zeros(6, np.float32)
+        dR, dT, conv = C.c_float(), C.c_float(), C.c_int32()
+        self._check(self.lib.lslam_gn_step(self.h, _fp(AtA), _fp(Atb), int(it), _fp(p), _fp(mp),
+                                           C.byref(deg), dr, dt, _fp(x), C.byref(dR), C.byref(dT),
+                                           C.byref(conv)))
+        return dict(converged=bool(conv.value), pose=p, matP=mp.reshape(6, 6),
+                    degenerate=bool(deg.value), x=x, delta_r=dR.value, delta_t=dT.value)
+
+    # -- Isometry <-> Twist (ScanMatch.cpp:349-360) --------------------------------
+    def isometry_to_pose(self, T):
+        T = np.ascontiguousarray(T, np.float32).reshape(16)
+        p = np.zeros(6, np.float32)
+        self.lib.lslam_isometry_to_pose(_fp(T), _fp(p))
+        return p
+
+    def pose_to_isometry(self, pose):
+        p = np.ascontiguousarray(pose, np.float32).reshape(6)
+        T = np.zeros(16, np.float32)
+        self.lib.lslam_pose_to_isometry(_fp(p), _fp(T))
+        return T.reshape(4, 4)
+
+
+class ScanMatch:
+    """Mirror of lidar_slam::ScanMatch (ScanMatch.h:12-86).
+
+    Clouds are (n, >=3) float arrays (x, y, z first).  ``pose`` is either the
+    6-vector Twist {rot_x, rot_y, rot_z, x, y, z} or a 4x4 Isometry3f; the method
+    returns ``(success, pose)`` with pose in the form it was given, updated exactly
+    when the reference writes it back (always, except "reference cloud points too few").
+    """
+
+    def __init__(self, maxIterations=10, device=0, ctx=None):
+        self.ctx = ctx if ctx is not None else Context(device)
+        self.opts = self.ctx.default_opts()
+        self.opts.max_iterations = int(maxIterations)
+        self._match_count = 0       # ScanMatch.h:84
+        self._fail_match_count = 0  # ScanMatch.h:85
+        self._total_score = 0.0     # ScanMatch.h:83
+        self.last_stats = None
+
+    # setters, ScanMatch.h:21-34
+    def setPercentThreshold(self, percent):
+        self.opts.match_percentage_threshold = float(percent)
+
+    def setScoreThreshold(self, score):
+        self.opts.score_threshold = float(score)
+
+    def setFineScore(self, enable):
+        self.opts.fine_score = int(bool(enable))
+
+    def setConvergeThreshold(self, deltaTAbort, deltaRAbort):
+        self.opts.delta_t_abort = float(deltaTAbort)
+        self.opts.delta_r_abort = float(deltaRAbort)
+
+    def setUseCore(self, useScore):
+        self.opts.use_score = int(bool(useScore))
+
+    def getAverageScore(self):  # ScanMatch.h:59-61
+        return self._total_score / self._match_count if self._match_count > 0 else 0.0
+
+    def _finish(self, status, stats):
+        self.last_stats = stats
+        if status == Status.OK:  # ScanMatch.cpp:336-340
+            self._total_score += stats.score
+            self._match_count += 1
+            return True
+        if status != Status.TOO_FEW_REF:  # ScanMatch.cpp:325,332,344
+            self._fail_match_count += 1
+        return False
+
+    def scanMatchScan(self, referenceCornerCloud, referenceSurfCloud, CornerCloud, SurfCloud, pose):
+        """ScanMatch.cpp:51-360 (both overloads); rebuilds the map trees per call (quirk Q4)."""
+        pose = np.asarray(pose, dtype=np.float32)
+        iso = pose.shape == (4, 4)
+        tw = self.ctx.isometry_to_pose(pose) if iso else pose.reshape(6)
+        status, tw, st = self.ctx.scanmatch_full(referenceCornerCloud, referenceSurfCloud,
+                                                 CornerCloud, SurfCloud, tw, self.opts)
+        ok = self._finish(status, st)
+        return ok, (self.ctx.pose_to_isometry(tw) if iso else tw)
+
+    def setMap(self, referenceCornerCloud, referenceSurfCloud):
+        """Keep a map resident across calls (the FeatureMap::scanMatchScan usage,
+        util/FeatureMap.h:490-691, where trees are built once per map update)."""
+        self.ctx.map_set(referenceCornerCloud, referenceSurfCloud)
+
+    def scanMatchResident(self, CornerCloud, SurfCloud, pose):
+        pose = np.asarray(pose, dtype=np.float32)
+        iso = pose.shape == (4, 4)
+        tw = self.ctx.isometry_to_pose(pose) if iso else pose.reshape(6)
+        status, tw, st = self.ctx.scanmatch_scan(CornerCloud, SurfCloud, tw, self.opts)
+        ok = self._finish(status, st)
+        return ok, (self.ctx.pose_to_isometry(tw) if iso else tw)

@@ -62,6 +62,24 @@ def test_knn5_pointxyzi_stride(ctx, oracle):
     assert np.array_equal(gi, oi) and np.array_equal(bits(gd), bits(od))
 
 
+def test_knn5_deep_tree_uses_overflow_stack(ctx, oracle):
+    """Geometrically spaced clusters make nanoflann's mid-split tree ~45 levels deep:
+    deeper than the LDS part of the traversal stack (32 entries)."""
+    rng = np.random.default_rng(2)
+    centers = 1.6 ** np.arange(56)
+    pts = np.concatenate([np.stack([c + rng.uniform(0, 0.01 * c, 12), rng.uniform(0, 0.01, 12),
+                                    rng.uniform(0, 0.01, 12)], 1) for c in centers]).astype(np.float32)
+    tree = oracle.kdtree(pts)
+    assert 34 < tree.max_depth() <= 64
+    q = np.concatenate([pts[rng.integers(0, len(pts), 300)] * np.float32(1.001),
+                        rng.uniform(0, 100, (200, 3)).astype(np.float32)])
+    ctx.map_set(pts, pts)
+    assert ctx.map_info().depth_surf == tree.max_depth()
+    gi, gd = ctx.knn5(1, q)
+    oi, od = tree.knn(q, 5)
+    assert np.array_equal(gi, oi) and np.array_equal(bits(gd), bits(od))
+
+
 @pytest.mark.parametrize("jtj_mode", [0, 1])
 def test_sweep_matches_oracle(ctx, oracle, small_problem, jtj_mode):
     pr = small_problem

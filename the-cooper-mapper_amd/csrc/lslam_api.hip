@@ -91,6 +91,7 @@ struct lslam_ctx {
   DevBuf<float4> qc, qs;
   int32_t nqc = 0, nqs = 0;
   DevBuf<float> partials;
+  DevBuf<uint32_t> stack_ovf;  // only allocated for trees deeper than KD_STACK_LDS+1
   GNState *d_state = nullptr;
   GNState *h_state = nullptr;  // pinned
   // tap buffers
@@ -164,10 +165,20 @@ void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
   a.nb_total = a.nb_corner + (ctx->nqs + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
   a.state = ctx->d_state;
   a.partials = ctx->partials.p;
+  a.stack_ovf = nullptr;
   a.idx_out = nullptr;
   a.d2_out = nullptr;
   a.coeff_out = nullptr;
   a.flags_out = nullptr;
+}
+
+// Trees deeper than the LDS part of the traversal stack need the global overflow area.
+int ensure_stack_ovf(lslam_ctx *ctx, size_t n_threads, uint32_t **out) {
+  *out = nullptr;
+  if (ctx->tc.depth <= KD_STACK_LDS + 1 && ctx->ts.depth <= KD_STACK_LDS + 1) return LSLAM_OK;
+  HIP_TRY(ctx->stack_ovf.reserve(stack_ovf_words(n_threads)));
+  *out = ctx->stack_ovf.p;
+  return LSLAM_OK;
 }
 
 int check_ctx(lslam_ctx *ctx) {
@@ -233,7 +244,7 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   ctx->tc.nodes.release(); ctx->tc.pts.release();
   ctx->ts.nodes.release(); ctx->ts.pts.release();
-  ctx->qc.release(); ctx->qs.release(); ctx->partials.release();
+  ctx->qc.release(); ctx->qs.release(); ctx->partials.release(); ctx->stack_ovf.release();
   ctx->t_idx.release(); ctx->t_d2.release(); ctx->t_coeff.release(); ctx->t_flags.release();
   ctx->t_q.release(); ctx->t_small.release();
   if (ctx->d_state) (void)hipFree(ctx->d_state);
@@ -358,6 +369,8 @@ int lslam_scanmatch_run(lslam_ctx *ctx, float pose[6], const lslam_opts *opts_in
                          ctx->stream));
   SweepArgs sa;
   fill_sweep_args(ctx, sa);
+  rc = ensure_stack_ovf(ctx, (size_t)sa.nb_total * SWEEP_BLOCK, &sa.stack_ovf);
+  if (rc) return rc;
   SolveArgs so{};
   so.state = ctx->d_state;
   so.partials = ctx->partials.p;
@@ -496,7 +509,10 @@ int lslam_knn5(lslam_ctx *ctx, int which_map, const void *queries, size_t nq, si
   HIP_TRY(ctx->t_d2.reserve(nq * 5));
   HIP_TRY(hipMemcpyAsync(ctx->t_q.p, q.data(), nq * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
   const TreeView &T = which_map ? ctx->ts.view : ctx->tc.view;
-  HIP_TRY(launch_knn5(T, ctx->t_q.p, (int)nq, ctx->t_idx.p, ctx->t_d2.p, ctx->stream));
+  uint32_t *ovf = nullptr;
+  rc = ensure_stack_ovf(ctx, ((nq + 127) / 128) * 128, &ovf);
+  if (rc) return rc;
+  HIP_TRY(launch_knn5(T, ctx->t_q.p, (int)nq, ctx->t_idx.p, ctx->t_d2.p, ovf, ctx->stream));
   HIP_TRY(hipMemcpyAsync(idx_out, ctx->t_idx.p, nq * 5 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(d2_out, ctx->t_d2.p, nq * 5 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -515,6 +531,8 @@ int lslam_sweep(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_t *
   HIP_TRY(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(GNState), hipMemcpyHostToDevice, ctx->stream));
   SweepArgs sa;
   fill_sweep_args(ctx, sa);
+  rc = ensure_stack_ovf(ctx, (size_t)sa.nb_total * SWEEP_BLOCK, &sa.stack_ovf);
+  if (rc) return rc;
   const bool taps = idx_out || d2_out || coeff_out || flags_out;
   if (taps) {
     HIP_TRY(ctx->t_idx.reserve(N * 5 + 1));

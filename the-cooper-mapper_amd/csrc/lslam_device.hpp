@@ -51,31 +51,77 @@ LSLAM_DEV float dist2_xyz(float qx, float qy, float qz, const float4 &p) {
 }
 
 // nanoflann.hpp:108-135 KNNResultSet::addPoint for capacity 5.  Empty slots hold
-// FLT_MAX (init(), :92-98), insertion goes after equal distances (strict '>').
+// FLT_MAX (init(), :92-98); the new element goes after every element that is not
+// strictly greater (strict '>' in :117), the last one drops out.  Written as
+// "insertion index k, then per-slot selects on k" so that it stays straight-line
+// v_cmp/v_cndmask code.
 LSLAM_DEV void knn_insert(float (&d)[5], int (&p)[5], float dist, int pos) {
-  const bool g0 = d[0] > dist, g1 = d[1] > dist, g2 = d[2] > dist, g3 = d[3] > dist,
-             g4 = d[4] > dist;
-  d[4] = g4 ? (g3 ? d[3] : dist) : d[4];
-  p[4] = g4 ? (g3 ? p[3] : pos) : p[4];
-  d[3] = g3 ? (g2 ? d[2] : dist) : d[3];
-  p[3] = g3 ? (g2 ? p[2] : pos) : p[3];
-  d[2] = g2 ? (g1 ? d[1] : dist) : d[2];
-  p[2] = g2 ? (g1 ? p[1] : pos) : p[2];
-  d[1] = g1 ? (g0 ? d[0] : dist) : d[1];
-  p[1] = g1 ? (g0 ? p[0] : pos) : p[1];
-  d[0] = g0 ? dist : d[0];
-  p[0] = g0 ? pos : p[0];
+  const int k = (int)!(d[0] > dist) + (int)!(d[1] > dist) + (int)!(d[2] > dist) +
+                (int)!(d[3] > dist) + (int)!(d[4] > dist);
+  float nd[5];
+  int np[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const float dl = j > 0 ? d[j - 1] : 0.0f;
+    const int pl = j > 0 ? p[j - 1] : 0;
+    nd[j] = (j < k) ? d[j] : ((j == k) ? dist : dl);
+    np[j] = (j < k) ? p[j] : ((j == k) ? pos : pl);
+  }
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    d[j] = nd[j];
+    p[j] = np[j];
+  }
 }
 
+// Per-lane traversal stack.  Entries are two 32-bit words.  The first KD_STACK_LDS
+// levels live in LDS (layout [level][thread]: lanes at the same depth hit distinct
+// banks); deeper levels -- only reached by trees deeper than KD_STACK_LDS+1 -- go
+// to a global overflow buffer [2][KD_STACK_MAX-KD_STACK_LDS][n_threads] that the
+// host allocates only for such trees.
+constexpr int KD_STACK_LDS = 32;
+
+template <int BLOCK>
+struct KdStack {
+  uint32_t *lds;  // [2][KD_STACK_LDS][BLOCK], already offset by the thread index
+  uint32_t *ovf;  // global overflow, already offset by the global thread index (or null)
+  size_t ovf_stride;  // n_threads
+  LSLAM_DEV void put(int e, uint32_t w0, uint32_t w1) {
+    if (e < KD_STACK_LDS) {
+      lds[e * BLOCK] = w0;
+      lds[(KD_STACK_LDS + e) * BLOCK] = w1;
+    } else {
+      ovf[(size_t)(e - KD_STACK_LDS) * ovf_stride] = w0;
+      ovf[(size_t)(KD_STACK_MAX - KD_STACK_LDS + e - KD_STACK_LDS) * ovf_stride] = w1;
+    }
+  }
+  LSLAM_DEV uint32_t get0(int e) const {
+    return e < KD_STACK_LDS ? lds[e * BLOCK] : ovf[(size_t)(e - KD_STACK_LDS) * ovf_stride];
+  }
+  LSLAM_DEV uint32_t get1(int e) const {
+    return e < KD_STACK_LDS
+               ? lds[(KD_STACK_LDS + e) * BLOCK]
+               : ovf[(size_t)(KD_STACK_MAX - KD_STACK_LDS + e - KD_STACK_LDS) * ovf_stride];
+  }
+};
+
 // Exact 5-NN: nanoflann.hpp:1303-1323 findNeighbors + :1433-1497 searchLevel
-// (eps = 0), one query per lane, recursion turned into an explicit stack that
-// keeps nanoflann's mindistsq / dists[] values bit for bit:
-//   entry = {other child | feat<<28 | active<<30, mindistsq for that child, cut_dist}
-// An entry whose far child is being explored stays on the stack marked active and
-// holds the old dists[feat], restored when it is popped (searchLevel :1494).
+// (eps = 0), one query per lane.  The recursion becomes an explicit stack that
+// reproduces nanoflann's mindistsq / dists[] values bit for bit:
+//   entry = { parent node | feat<<28 | active<<30 ,  mindistsq of the far child }
+// * A far child is only pushed if its mindistsq is <= the current worst distance:
+//   the worst distance never grows, so an entry failing the test now would also
+//   fail nanoflann's test (:1487) when the recursion returns -- same visits.
+// * When an entry is taken, the parent node is re-read and the split arithmetic
+//   (:1459-1475) replayed, which yields the same cut_dist / child without storing
+//   them; the entry stays on the stack marked active, its second word now holding
+//   the old dists[feat], restored when it is popped (:1494).
+// * A leaf (<= 10 points, one contiguous run) is fetched with 10 independent
+//   16-byte loads before any distance is evaluated (the point array is padded).
 // p[] are positions in the permuted point array (pts[p].w carries the original index).
+template <int BLOCK>
 LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, float (&d)[5],
-                           int (&p)[5]) {
+                           int (&p)[5], KdStack<BLOCK> &stk) {
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     d[i] = FLT_MAX;
@@ -92,9 +138,6 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
   if (qz < T.bb_lo[2]) { ds2 = (qz - T.bb_lo[2]) * (qz - T.bb_lo[2]); mind += ds2; }
   if (qz > T.bb_hi[2]) { ds2 = (qz - T.bb_hi[2]) * (qz - T.bb_hi[2]); mind += ds2; }
 
-  int stk_n[KD_STACK_MAX];
-  float stk_m[KD_STACK_MAX];
-  float stk_c[KD_STACK_MAX];
   int sp = 0;
   int node = 0;
   for (;;) {
@@ -108,43 +151,53 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
       const float cd = left ? diff2 * diff2 : diff1 * diff1;  // accum_dist :374-377
       const float dst = feat == 0 ? ds0 : (feat == 1 ? ds1 : ds2);
       const float nm = (mind + cd) - dst;  // :1486
-      stk_n[sp] = (left ? nd.a : node + 1) | (feat << 28);
-      stk_m[sp] = nm;
-      stk_c[sp] = cd;
-      ++sp;
+      if (nm <= d[4]) {
+        stk.put(sp, (uint32_t)node | ((uint32_t)feat << 28), __float_as_uint(nm));
+        ++sp;
+      }
       node = left ? node + 1 : nd.a;
       nd = T.nodes[node];
     }
     {  // leaf: nanoflann.hpp:1438-1457 (worst_dist cached once per leaf)
       const int l = nd.a, r = ~nd.b;
       const float worst = d[4];
-      for (int i = l; i < r; ++i) {
-        const float4 pt = T.pts[i];
-        const float dist = dist2_xyz(qx, qy, qz, pt);
-        if (dist < worst) knn_insert(d, p, dist, i);
+      float4 pt[10];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) pt[j] = T.pts[l + j];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        if (l + j < r) {
+          const float dist = dist2_xyz(qx, qy, qz, pt[j]);
+          if (dist < worst) knn_insert(d, p, dist, l + j);
+        }
       }
     }
     bool descend = false;
     while (sp > 0) {
-      const int e = stk_n[sp - 1];
+      const uint32_t e = stk.get0(sp - 1);
       const int feat = (e >> 28) & 3;
-      if (e & (1 << 30)) {  // far subtree finished: dists[idx] = dst  (:1494)
-        const float old = stk_c[sp - 1];
+      if (e & (1u << 30)) {  // far subtree finished: dists[idx] = dst  (:1494)
+        const float old = __uint_as_float(stk.get1(sp - 1));
         if (feat == 0) ds0 = old; else if (feat == 1) ds1 = old; else ds2 = old;
         --sp;
         continue;
       }
-      const float nm = stk_m[sp - 1];
+      const float nm = __uint_as_float(stk.get1(sp - 1));
       if (nm <= d[4]) {  // mindistsq*epsError <= worstDist  (:1487)
-        const float cd = stk_c[sp - 1];
+        const int parent = (int)(e & 0x0FFFFFFFu);
+        const KdNode pn = T.nodes[parent];
+        const float val = feat == 0 ? qx : (feat == 1 ? qy : qz);
+        const float diff1 = val - pn.lo;
+        const float diff2 = val - pn.hi;
+        const bool left = (diff1 + diff2) < 0.0f;
+        const float cd = left ? diff2 * diff2 : diff1 * diff1;
         float old;
         if (feat == 0) { old = ds0; ds0 = cd; }
         else if (feat == 1) { old = ds1; ds1 = cd; }
         else { old = ds2; ds2 = cd; }
-        stk_c[sp - 1] = old;
-        stk_n[sp - 1] = e | (1 << 30);
+        stk.put(sp - 1, e | (1u << 30), __float_as_uint(old));
         mind = nm;
-        node = e & 0x0FFFFFFF;
+        node = left ? pn.a : parent + 1;  // the child NOT taken on the way down
         descend = true;
         break;
       }

@@ -50,6 +50,7 @@ struct SweepArgs {
   int32_t nb_corner, nb_total;  // blocks are type-homogeneous: [0,nb_corner) corner
   const GNState *state;
   float *partials;  // [nb_total][NCOL]
+  uint32_t *stack_ovf;  // traversal-stack overflow (null unless a tree is deeper than 33)
   // optional per-point taps (all NULL in the production loop)
   int32_t *idx_out;    // [N][5] original map indices
   float *d2_out;       // [N][5]
@@ -73,7 +74,11 @@ constexpr int SWEEP_BLOCK = 128;
 hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s);
 hipError_t launch_solve(const SolveArgs &a, hipStream_t s);
 hipError_t launch_knn5(const TreeView &T, const float4 *q, int nq, int32_t *idx, float *d2,
-                       hipStream_t s);
+                       uint32_t *stack_ovf, hipStream_t s);
+// words of overflow stack needed for n_threads lanes
+inline size_t stack_ovf_words(size_t n_threads) {
+  return 2 * (size_t)(KD_STACK_MAX - KD_STACK_LDS) * n_threads;
+}
 hipError_t launch_gn_step_tap(GNState *st, const float *AtA, const float *Atb, float dr, float dt,
                               float eig_thresh, hipStream_t s);
 

@@ -42,13 +42,14 @@ LSLAM_DEV float wave_sum(float v) {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void sweep_kernel(SweepArgs a, int jtj_mode) {
+__global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mode) {
   const GNState *st = a.state;
   if (st->done) return;  // loop already ended (ScanMatch.cpp:144,259)
 
   constexpr int NWAVE = BLOCK / 64;
   __shared__ float red[NWAVE][NCOL];
   __shared__ float jrows[NWAVE][64][8];  // MFMA staging: [point][J0..J5,b,0]
+  __shared__ uint32_t stack_lds[2 * KD_STACK_LDS * BLOCK];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -91,7 +92,11 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(SweepArgs a, int jtj_mode)
       T.bb_lo[i] = is_surf ? a.ts.bb_lo[i] : a.tc.bb_lo[i];
       T.bb_hi[i] = is_surf ? a.ts.bb_hi[i] : a.tc.bb_hi[i];
     }
-    knn5_search(T, sel[0], sel[1], sel[2], d, p);
+    KdStack<BLOCK> stk;
+    stk.lds = stack_lds + tid;
+    stk.ovf = a.stack_ovf ? a.stack_ovf + ((size_t)blockIdx.x * BLOCK + tid) : nullptr;
+    stk.ovf_stride = (size_t)a.nb_total * BLOCK;
+    knn5_search<BLOCK>(T, sel[0], sel[1], sel[2], d, p, stk);
 
     float coeff[4] = {0, 0, 0, 0};
     unsigned flag = 0;
@@ -543,15 +548,21 @@ hipError_t launch_gn_step_tap(GNState *st, const float *AtA, const float *Atb, f
 // ---------------------------------------------------------------------------
 // parity tap: nearestKSearch(p, 5, idx, d2) for nq points already in map frame
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void knn5_kernel(TreeView T, const float4 *q, int nq,
-                                                   int32_t *idx, float *d2) {
+__global__ __launch_bounds__(128, 2) void knn5_kernel(TreeView T, const float4 *q, int nq,
+                                                      int32_t *idx, float *d2,
+                                                      uint32_t *stack_ovf) {
+  __shared__ uint32_t stack_lds[2 * KD_STACK_LDS * 128];
   const int lb = xcd_remap(blockIdx.x, gridDim.x);
   const int i = lb * 128 + threadIdx.x;
   if (i >= nq) return;
   const float4 qq = q[i];
   float d[5];
   int p[5];
-  knn5_search(T, qq.x, qq.y, qq.z, d, p);
+  KdStack<128> stk;
+  stk.lds = stack_lds + threadIdx.x;
+  stk.ovf = stack_ovf ? stack_ovf + ((size_t)blockIdx.x * 128 + threadIdx.x) : nullptr;
+  stk.ovf_stride = (size_t)gridDim.x * 128;
+  knn5_search<128>(T, qq.x, qq.y, qq.z, d, p, stk);
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
     idx[i * 5 + j] = p[j] >= 0 ? __float_as_int(T.pts[p[j]].w) : -1;
@@ -560,9 +571,10 @@ __global__ __launch_bounds__(128) void knn5_kernel(TreeView T, const float4 *q, 
 }
 
 hipError_t launch_knn5(const TreeView &T, const float4 *q, int nq, int32_t *idx, float *d2,
-                       hipStream_t s) {
+                       uint32_t *stack_ovf, hipStream_t s) {
   if (nq <= 0) return hipSuccess;
-  hipLaunchKernelGGL(knn5_kernel, dim3((nq + 127) / 128), dim3(128), 0, s, T, q, nq, idx, d2);
+  hipLaunchKernelGGL(knn5_kernel, dim3((nq + 127) / 128), dim3(128), 0, s, T, q, nq, idx, d2,
+                     stack_ovf);
   return hipGetLastError();
 }
 

@@ -110,7 +110,8 @@ SYMBOLS = {
 
 
 def lib_path():
-    return os.path.join(HERE, LIB_NAME)
+    # LSLAM_LIB lets profiling scripts load an experimental build of the same ABI
+    return os.environ.get("LSLAM_LIB") or os.path.join(HERE, LIB_NAME)
 
 
 def build_library(force=False):

@@ -144,6 +144,7 @@ int upload_tree(lslam_ctx *ctx, DevTree &dt, const HostTree &ht, const std::vect
   }
   dt.view.n_pts = (int32_t)n;
   dt.view.n_nodes = (int32_t)ht.nodes.size();
+  dt.view.root_ref = ht.root_ref;
   dt.depth = ht.depth;
   return LSLAM_OK;
 }
@@ -170,6 +171,7 @@ void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
   a.d2_out = nullptr;
   a.coeff_out = nullptr;
   a.flags_out = nullptr;
+  a.dbg = nullptr;
 }
 
 // Trees deeper than the LDS part of the traversal stack need the global overflow area.
@@ -258,6 +260,37 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
 
 void *lslam_stream(lslam_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+// Profiling tap (not part of the drop-in surface): one sweep at `pose` with per-wave
+// shader-clock stamps {start, after kNN, after fit, end}; out[n_waves*4], returns n_waves.
+int lslam_debug_sweep_clocks(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode,
+                             uint64_t *out, size_t out_cap_waves) {
+  int rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (!ctx->have_map || !ctx->have_scan) return LSLAM_ERR_NO_MAP;
+  init_state(*ctx->h_state, pose);
+  HIP_TRY(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(GNState), hipMemcpyHostToDevice, ctx->stream));
+  SweepArgs sa;
+  fill_sweep_args(ctx, sa);
+  rc = ensure_stack_ovf(ctx, (size_t)sa.nb_total * SWEEP_BLOCK, &sa.stack_ovf);
+  if (rc) return rc;
+  const size_t nw = (size_t)sa.nb_total * (SWEEP_BLOCK / 64);
+  if (nw > out_cap_waves) return LSLAM_ERR_INVALID;
+  uint64_t *d = nullptr;
+  size_t words = nw * 4;
+#ifdef LSLAM_TRAVERSAL_STATS
+  words += (size_t)sa.nb_total * SWEEP_BLOCK * 8;  // per-lane traversal statistics follow
+  if (nw * 4 + (size_t)sa.nb_total * SWEEP_BLOCK * 8 > out_cap_waves * 4) return LSLAM_ERR_INVALID;
+#endif
+  HIP_TRY(hipMalloc((void **)&d, words * sizeof(uint64_t)));
+  HIP_TRY(hipMemsetAsync(d, 0, words * sizeof(uint64_t), ctx->stream));
+  sa.dbg = d;
+  HIP_TRY(launch_sweep(sa, jtj_mode, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(out, d, words * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  (void)hipFree(d);
+  return (int)nw;
+}
+
 int lslam_map_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const void *surf,
                   size_t n_surf, size_t stride_bytes) {
   int rc = check_ctx(ctx);
@@ -266,8 +299,8 @@ int lslam_map_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const voi
     set_err("bad cloud arguments (stride %zu)", stride_bytes);
     return LSLAM_ERR_INVALID;
   }
-  if (n_corner > 0x0FFFFFFFu || n_surf > 0x0FFFFFFFu) {
-    set_err("map too large for 28-bit node indices");
+  if (n_corner >= KD_MAX_POINTS || n_surf >= KD_MAX_POINTS) {
+    set_err("map too large for 27-bit leaf references");
     return LSLAM_ERR_INVALID;
   }
   ctx->have_map = false;
@@ -293,8 +326,8 @@ int lslam_map_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const voi
   const double t2 = now_ms();
   ctx->info.n_corner = n_corner;
   ctx->info.n_surf = n_surf;
-  ctx->info.nodes_corner = (uint32_t)hc.nodes.size();
-  ctx->info.nodes_surf = (uint32_t)hs.nodes.size();
+  ctx->info.nodes_corner = (uint32_t)(hc.nodes.size() + hc.n_leaves);  // nanoflann's node count
+  ctx->info.nodes_surf = (uint32_t)(hs.nodes.size() + hs.n_leaves);
   ctx->info.depth_corner = hc.depth;
   ctx->info.depth_surf = hs.depth;
   ctx->info.build_ms = (float)(t1 - t0);

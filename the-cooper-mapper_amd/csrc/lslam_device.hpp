@@ -18,23 +18,33 @@ namespace lslam {
 
 // ---------------------------------------------------------------------------
 // kd-tree in HBM.  Topology and leaf order are exactly nanoflann v1.2.3's
-// (util/nanoflann.hpp:931-1078); nodes are stored in allocation (= preorder)
-// order so child1 is always self+1.
-//   inner: lo=divlow hi=divhigh a=child2 b=divfeat (0..2)
-//   leaf : a=left b=~right (b<0); points [left,right) of the permuted array
-// Points are stored permuted by vind as float4 {x,y,z,bitcast(original index)}:
-// a leaf is one contiguous <=160 B run.
+// (util/nanoflann.hpp:931-1078); only the encoding is ours:
+//  * only inner nodes are stored; a child is a 32-bit reference
+//      inner: (node index << 2) | divfeat of THAT node        (bit 31 clear)
+//      leaf : 0x80000000 | (left << 4) | count                (count <= 10)
+//    so reaching a leaf costs no extra dependent load;
+//  * node = {divlow, divhigh, ref(child1), ref(child2)}, 16 bytes;
+//  * nodes are placed in breadth-first groups of 8 (one 128-byte cache line holds a
+//    node and about three levels below it), so most steps of a descent hit a line
+//    the lane has just touched;
+//  * points are stored permuted by vind as float4 {x,y,z,bitcast(original index)}:
+//    a leaf is one contiguous <=160 B run.
 // ---------------------------------------------------------------------------
 struct alignas(16) KdNode {
-  float lo, hi;
-  int32_t a, b;
+  float lo, hi;     // divlow, divhigh (nanoflann.hpp:838)
+  uint32_t c1, c2;  // child references
 };
+
+constexpr uint32_t KD_LEAF = 0x80000000u;
+constexpr uint32_t KD_MAX_POINTS = 1u << 27;  // leaf reference: 27-bit left
+constexpr uint32_t KD_MAX_INNER = 1u << 29;   // stack entry: 29-bit node index
 
 struct TreeView {
   const KdNode *nodes;
   const float4 *pts;
   float bb_lo[3], bb_hi[3];  // root_bbox, nanoflann.hpp:1406-1427
   int32_t n_pts, n_nodes;
+  uint32_t root_ref;
 };
 
 constexpr int KD_STACK_MAX = 64;  // host refuses deeper trees (LSLAM_ERR_TREE_DEPTH)
@@ -81,13 +91,16 @@ LSLAM_DEV void knn_insert(float (&d)[5], int (&p)[5], float dist, int pos) {
 // host allocates only for such trees.
 constexpr int KD_STACK_LDS = 32;
 
-template <int BLOCK>
+template <int BLOCK, bool OVF>
 struct KdStack {
   uint32_t *lds;  // [2][KD_STACK_LDS][BLOCK], already offset by the thread index
-  uint32_t *ovf;  // global overflow, already offset by the global thread index (or null)
+  uint32_t *ovf;  // global overflow, already offset by the global thread index (OVF only)
   size_t ovf_stride;  // n_threads
+  // OVF=false kernels (every tree at most KD_STACK_LDS+1 levels deep) touch LDS only, so
+  // the accesses stay ds_read/ds_write; the OVF=true variant branches explicitly (a
+  // select between the two address spaces would turn every access into a flat one).
   LSLAM_DEV void put(int e, uint32_t w0, uint32_t w1) {
-    if (e < KD_STACK_LDS) {
+    if (!OVF || e < KD_STACK_LDS) {
       lds[e * BLOCK] = w0;
       lds[(KD_STACK_LDS + e) * BLOCK] = w1;
     } else {
@@ -95,20 +108,32 @@ struct KdStack {
       ovf[(size_t)(KD_STACK_MAX - KD_STACK_LDS + e - KD_STACK_LDS) * ovf_stride] = w1;
     }
   }
-  LSLAM_DEV uint32_t get0(int e) const {
-    return e < KD_STACK_LDS ? lds[e * BLOCK] : ovf[(size_t)(e - KD_STACK_LDS) * ovf_stride];
-  }
-  LSLAM_DEV uint32_t get1(int e) const {
-    return e < KD_STACK_LDS
-               ? lds[(KD_STACK_LDS + e) * BLOCK]
-               : ovf[(size_t)(KD_STACK_MAX - KD_STACK_LDS + e - KD_STACK_LDS) * ovf_stride];
+  LSLAM_DEV void get(int e, uint32_t &w0, uint32_t &w1) const {
+    if (!OVF || e < KD_STACK_LDS) {
+      w0 = lds[e * BLOCK];
+      w1 = lds[(KD_STACK_LDS + e) * BLOCK];
+    } else {
+      w0 = ovf[(size_t)(e - KD_STACK_LDS) * ovf_stride];
+      w1 = ovf[(size_t)(KD_STACK_MAX - KD_STACK_LDS + e - KD_STACK_LDS) * ovf_stride];
+    }
   }
 };
+
+#ifdef LSLAM_TRAVERSAL_STATS  // profiling build only (tools/traversal_stats.py)
+struct TravStats { unsigned long long t_desc, t_leaf, t_pop; unsigned n_node, n_leaf, n_pop, n_take; };
+#define TS_BEGIN unsigned long long _ts = __builtin_readcyclecounter();
+#define TS_ADD(f) { unsigned long long _n = __builtin_readcyclecounter(); ts.f += _n - _ts; _ts = _n; }
+#define TS_INC(f) ts.f++;
+#else
+#define TS_BEGIN
+#define TS_ADD(f)
+#define TS_INC(f)
+#endif
 
 // Exact 5-NN: nanoflann.hpp:1303-1323 findNeighbors + :1433-1497 searchLevel
 // (eps = 0), one query per lane.  The recursion becomes an explicit stack that
 // reproduces nanoflann's mindistsq / dists[] values bit for bit:
-//   entry = { parent node | feat<<28 | active<<30 ,  mindistsq of the far child }
+//   entry = { parent node | feat<<29 | active<<31 ,  mindistsq of the far child }
 // * A far child is only pushed if its mindistsq is <= the current worst distance:
 //   the worst distance never grows, so an entry failing the test now would also
 //   fail nanoflann's test (:1487) when the recursion returns -- same visits.
@@ -116,12 +141,17 @@ struct KdStack {
 //   (:1459-1475) replayed, which yields the same cut_dist / child without storing
 //   them; the entry stays on the stack marked active, its second word now holding
 //   the old dists[feat], restored when it is popped (:1494).
+// * Entries are popped four at a time (8 LDS reads in flight, one wait).
 // * A leaf (<= 10 points, one contiguous run) is fetched with 10 independent
 //   16-byte loads before any distance is evaluated (the point array is padded).
 // p[] are positions in the permuted point array (pts[p].w carries the original index).
-template <int BLOCK>
+template <int BLOCK, bool OVF>
 LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, float (&d)[5],
-                           int (&p)[5], KdStack<BLOCK> &stk) {
+                           int (&p)[5], KdStack<BLOCK, OVF> &stk
+#ifdef LSLAM_TRAVERSAL_STATS
+                           , TravStats &ts
+#endif
+                           ) {
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     d[i] = FLT_MAX;
@@ -139,11 +169,14 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
   if (qz > T.bb_hi[2]) { ds2 = (qz - T.bb_hi[2]) * (qz - T.bb_hi[2]); mind += ds2; }
 
   int sp = 0;
-  int node = 0;
+  uint32_t ref = T.root_ref;
+  TS_BEGIN
   for (;;) {
-    KdNode nd = T.nodes[node];
-    while (nd.b >= 0) {  // inner node: nanoflann.hpp:1459-1475
-      const int feat = nd.b;
+    while (!(ref & KD_LEAF)) {  // inner node: nanoflann.hpp:1459-1475
+      TS_INC(n_node)
+      const uint32_t node = ref >> 2;
+      const uint32_t feat = ref & 3u;
+      const KdNode nd = T.nodes[node];
       const float val = feat == 0 ? qx : (feat == 1 ? qy : qz);
       const float diff1 = val - nd.lo;
       const float diff2 = val - nd.hi;
@@ -152,58 +185,79 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
       const float dst = feat == 0 ? ds0 : (feat == 1 ? ds1 : ds2);
       const float nm = (mind + cd) - dst;  // :1486
       if (nm <= d[4]) {
-        stk.put(sp, (uint32_t)node | ((uint32_t)feat << 28), __float_as_uint(nm));
+        stk.put(sp, node | (feat << 29), __float_as_uint(nm));
         ++sp;
       }
-      node = left ? node + 1 : nd.a;
-      nd = T.nodes[node];
+      ref = left ? nd.c1 : nd.c2;
     }
-    {  // leaf: nanoflann.hpp:1438-1457 (worst_dist cached once per leaf)
-      const int l = nd.a, r = ~nd.b;
-      const float worst = d[4];
+    TS_ADD(t_desc)
+    {  // leaf: nanoflann.hpp:1438-1457
+      TS_INC(n_leaf)
+      const int l = (int)((ref & ~KD_LEAF) >> 4), cnt = (int)(ref & 15u);
+      const float worst = d[4];  // worst_dist cached once per leaf
       float4 pt[10];
 #pragma unroll
       for (int j = 0; j < 10; ++j) pt[j] = T.pts[l + j];
 #pragma unroll
       for (int j = 0; j < 10; ++j) {
-        if (l + j < r) {
+        if (j < cnt) {
           const float dist = dist2_xyz(qx, qy, qz, pt[j]);
           if (dist < worst) knn_insert(d, p, dist, l + j);
         }
       }
     }
-    bool descend = false;
-    while (sp > 0) {
-      const uint32_t e = stk.get0(sp - 1);
-      const int feat = (e >> 28) & 3;
-      if (e & (1u << 30)) {  // far subtree finished: dists[idx] = dst  (:1494)
-        const float old = __uint_as_float(stk.get1(sp - 1));
-        if (feat == 0) ds0 = old; else if (feat == 1) ds1 = old; else ds2 = old;
-        --sp;
-        continue;
+    TS_ADD(t_leaf)
+    bool take = false;
+    uint32_t te = 0;
+    float tm = 0.0f;
+    while (sp > 0 && !take) {
+      uint32_t e[4];
+      float m[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = sp - 1 - j < 0 ? 0 : sp - 1 - j;
+        uint32_t w1;
+        stk.get(idx, e[j], w1);
+        m[j] = __uint_as_float(w1);
       }
-      const float nm = __uint_as_float(stk.get1(sp - 1));
-      if (nm <= d[4]) {  // mindistsq*epsError <= worstDist  (:1487)
-        const int parent = (int)(e & 0x0FFFFFFFu);
-        const KdNode pn = T.nodes[parent];
-        const float val = feat == 0 ? qx : (feat == 1 ? qy : qz);
-        const float diff1 = val - pn.lo;
-        const float diff2 = val - pn.hi;
-        const bool left = (diff1 + diff2) < 0.0f;
-        const float cd = left ? diff2 * diff2 : diff1 * diff1;
-        float old;
-        if (feat == 0) { old = ds0; ds0 = cd; }
-        else if (feat == 1) { old = ds1; ds1 = cd; }
-        else { old = ds2; ds2 = cd; }
-        stk.put(sp - 1, e | (1u << 30), __float_as_uint(old));
-        mind = nm;
-        node = left ? pn.a : parent + 1;  // the child NOT taken on the way down
-        descend = true;
-        break;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (!take && sp > 0) {
+          TS_INC(n_pop)
+          const uint32_t feat = (e[j] >> 29) & 3u;
+          if (e[j] & 0x80000000u) {  // far subtree finished: dists[idx] = dst  (:1494)
+            if (feat == 0) ds0 = m[j]; else if (feat == 1) ds1 = m[j]; else ds2 = m[j];
+            --sp;
+          } else if (m[j] <= d[4]) {  // mindistsq*epsError <= worstDist  (:1487)
+            take = true;
+            te = e[j];
+            tm = m[j];
+          } else {
+            --sp;
+          }
+        }
       }
-      --sp;
     }
-    if (!descend) break;
+    if (!take) { TS_ADD(t_pop) break; }
+    {
+      TS_INC(n_take)
+      const uint32_t parent = te & 0x1FFFFFFFu;
+      const uint32_t feat = (te >> 29) & 3u;
+      const KdNode pn = T.nodes[parent];
+      const float val = feat == 0 ? qx : (feat == 1 ? qy : qz);
+      const float diff1 = val - pn.lo;
+      const float diff2 = val - pn.hi;
+      const bool left = (diff1 + diff2) < 0.0f;
+      const float cd = left ? diff2 * diff2 : diff1 * diff1;
+      float old;
+      if (feat == 0) { old = ds0; ds0 = cd; }
+      else if (feat == 1) { old = ds1; ds1 = cd; }
+      else { old = ds2; ds2 = cd; }
+      stk.put(sp - 1, te | 0x80000000u, __float_as_uint(old));
+      mind = tm;
+      ref = left ? pn.c2 : pn.c1;  // the child NOT taken on the way down
+    }
+    TS_ADD(t_pop)
   }
 }
 

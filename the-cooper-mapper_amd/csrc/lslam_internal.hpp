@@ -56,6 +56,7 @@ struct SweepArgs {
   float *d2_out;       // [N][5]
   float4 *coeff_out;   // [N]
   uint8_t *flags_out;  // [N]
+  uint64_t *dbg;       // optional [nb_total][waves][4] shader-clock stamps (profiling tap)
 };
 
 struct SolveArgs {
@@ -84,10 +85,12 @@ hipError_t launch_gn_step_tap(GNState *st, const float *AtA, const float *Atb, f
 
 // host kd-tree builder (kdtree_host.cpp): nanoflann v1.2.3 topology, device node format
 struct HostTree {
-  std::vector<KdNode> nodes;
+  std::vector<KdNode> nodes;  // inner nodes only, cache-line grouped (lslam_device.hpp)
   std::vector<int32_t> vind;
   float bb_lo[3], bb_hi[3];
-  int depth = 0;
+  uint32_t root_ref = 0;
+  int depth = 0;       // levels including the leaf level
+  size_t n_leaves = 0;
 };
 void build_kdtree_host(const float *pts, size_t n, size_t stride_floats, HostTree &out);
 

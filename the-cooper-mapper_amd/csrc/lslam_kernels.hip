@@ -41,7 +41,7 @@ LSLAM_DEV float wave_sum(float v) {
 // ---------------------------------------------------------------------------
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-template <int BLOCK>
+template <int BLOCK, bool OVF>
 __global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mode) {
   const GNState *st = a.state;
   if (st->done) return;  // loop already ended (ScanMatch.cpp:144,259)
@@ -54,6 +54,8 @@ __global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mo
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int lb = xcd_remap(blockIdx.x, a.nb_total);
+  const uint64_t dbg_t0 = a.dbg ? __builtin_readcyclecounter() : 0;
+  uint64_t dbg_t1 = 0, dbg_t2 = 0;
   const bool is_surf = lb >= a.nb_corner;
   const int qi = (is_surf ? lb - a.nb_corner : lb) * BLOCK + tid;
   const int nq = is_surf ? a.nqs : a.nqc;
@@ -87,16 +89,28 @@ __global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mo
     T.pts = is_surf ? a.ts.pts : a.tc.pts;
     T.n_pts = is_surf ? a.ts.n_pts : a.tc.n_pts;
     T.n_nodes = is_surf ? a.ts.n_nodes : a.tc.n_nodes;
+    T.root_ref = is_surf ? a.ts.root_ref : a.tc.root_ref;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       T.bb_lo[i] = is_surf ? a.ts.bb_lo[i] : a.tc.bb_lo[i];
       T.bb_hi[i] = is_surf ? a.ts.bb_hi[i] : a.tc.bb_hi[i];
     }
-    KdStack<BLOCK> stk;
+    KdStack<BLOCK, OVF> stk;
     stk.lds = stack_lds + tid;
-    stk.ovf = a.stack_ovf ? a.stack_ovf + ((size_t)blockIdx.x * BLOCK + tid) : nullptr;
+    stk.ovf = OVF ? a.stack_ovf + ((size_t)blockIdx.x * BLOCK + tid) : nullptr;
     stk.ovf_stride = (size_t)a.nb_total * BLOCK;
-    knn5_search<BLOCK>(T, sel[0], sel[1], sel[2], d, p, stk);
+#ifdef LSLAM_TRAVERSAL_STATS
+    TravStats ts = {0, 0, 0, 0, 0, 0, 0};
+    knn5_search<BLOCK, OVF>(T, sel[0], sel[1], sel[2], d, p, stk, ts);
+    if (a.dbg) {  // per-lane stats: [N][8] after the per-wave stamps
+      uint64_t *o = a.dbg + (size_t)a.nb_total * NWAVE * 4 + ((size_t)lb * BLOCK + tid) * 8;
+      o[0] = ts.t_desc; o[1] = ts.t_leaf; o[2] = ts.t_pop; o[3] = ts.n_node;
+      o[4] = ts.n_leaf; o[5] = ts.n_pop; o[6] = ts.n_take; o[7] = 1;
+    }
+#else
+    knn5_search<BLOCK, OVF>(T, sel[0], sel[1], sel[2], d, p, stk);
+#endif
+    if (a.dbg) dbg_t1 = __builtin_readcyclecounter();
 
     float coeff[4] = {0, 0, 0, 0};
     unsigned flag = 0;
@@ -140,6 +154,7 @@ __global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mo
     }
   }
 
+  if (a.dbg) dbg_t2 = __builtin_readcyclecounter();
   // ---- normal equations: per-wave reduction --------------------------------
   float v[NCOL];
 #pragma unroll
@@ -209,12 +224,23 @@ __global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mo
     for (int w = 1; w < NWAVE; ++w) s += red[w][tid];
     a.partials[(size_t)lb * NCOL + tid] = s;
   }
+  if (a.dbg && lane == 0) {  // per-wave phase stamps (shader clock)
+    uint64_t *o = a.dbg + ((size_t)lb * NWAVE + wave) * 4;
+    o[0] = dbg_t0;
+    o[1] = dbg_t1;
+    o[2] = dbg_t2;
+    o[3] = __builtin_readcyclecounter();
+  }
 }
 
 hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s) {
   if (a.nb_total <= 0) return hipSuccess;
-  hipLaunchKernelGGL(sweep_kernel<SWEEP_BLOCK>, dim3(a.nb_total), dim3(SWEEP_BLOCK), 0, s, a,
-                     jtj_mode);
+  if (a.stack_ovf)
+    hipLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true>), dim3(a.nb_total), dim3(SWEEP_BLOCK), 0, s,
+                       a, jtj_mode);
+  else
+    hipLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false>), dim3(a.nb_total), dim3(SWEEP_BLOCK), 0,
+                       s, a, jtj_mode);
   return hipGetLastError();
 }
 
@@ -548,6 +574,7 @@ hipError_t launch_gn_step_tap(GNState *st, const float *AtA, const float *Atb, f
 // ---------------------------------------------------------------------------
 // parity tap: nearestKSearch(p, 5, idx, d2) for nq points already in map frame
 // ---------------------------------------------------------------------------
+template <bool OVF>
 __global__ __launch_bounds__(128, 2) void knn5_kernel(TreeView T, const float4 *q, int nq,
                                                       int32_t *idx, float *d2,
                                                       uint32_t *stack_ovf) {
@@ -558,11 +585,16 @@ __global__ __launch_bounds__(128, 2) void knn5_kernel(TreeView T, const float4 *
   const float4 qq = q[i];
   float d[5];
   int p[5];
-  KdStack<128> stk;
+  KdStack<128, OVF> stk;
   stk.lds = stack_lds + threadIdx.x;
-  stk.ovf = stack_ovf ? stack_ovf + ((size_t)blockIdx.x * 128 + threadIdx.x) : nullptr;
+  stk.ovf = OVF ? stack_ovf + ((size_t)blockIdx.x * 128 + threadIdx.x) : nullptr;
   stk.ovf_stride = (size_t)gridDim.x * 128;
-  knn5_search<128>(T, qq.x, qq.y, qq.z, d, p, stk);
+#ifdef LSLAM_TRAVERSAL_STATS
+  TravStats ts = {0, 0, 0, 0, 0, 0, 0};
+  knn5_search<128, OVF>(T, qq.x, qq.y, qq.z, d, p, stk, ts);
+#else
+  knn5_search<128, OVF>(T, qq.x, qq.y, qq.z, d, p, stk);
+#endif
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
     idx[i * 5 + j] = p[j] >= 0 ? __float_as_int(T.pts[p[j]].w) : -1;
@@ -573,8 +605,12 @@ __global__ __launch_bounds__(128, 2) void knn5_kernel(TreeView T, const float4 *
 hipError_t launch_knn5(const TreeView &T, const float4 *q, int nq, int32_t *idx, float *d2,
                        uint32_t *stack_ovf, hipStream_t s) {
   if (nq <= 0) return hipSuccess;
-  hipLaunchKernelGGL(knn5_kernel, dim3((nq + 127) / 128), dim3(128), 0, s, T, q, nq, idx, d2,
-                     stack_ovf);
+  if (stack_ovf)
+    hipLaunchKernelGGL(knn5_kernel<true>, dim3((nq + 127) / 128), dim3(128), 0, s, T, q, nq, idx,
+                       d2, stack_ovf);
+  else
+    hipLaunchKernelGGL(knn5_kernel<false>, dim3((nq + 127) / 128), dim3(128), 0, s, T, q, nq, idx,
+                       d2, stack_ovf);
   return hipGetLastError();
 }
 

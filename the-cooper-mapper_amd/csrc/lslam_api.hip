@@ -103,6 +103,7 @@ struct lslam_ctx {
   DevBuf<float> t_small;  // AtA/Atb upload for the gn_step tap
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> sweep_ev;
+  int iter_hint = 4;  // size of the first batch of enqueued GN iterations
 };
 
 namespace {
@@ -421,17 +422,32 @@ int lslam_scanmatch_run(lslam_ctx *ctx, float pose[6], const lslam_opts *opts_in
       ctx->sweep_ev.push_back(e);
     }
   }
+  // The loop is device-resident: sweep/solve pairs are enqueued back to back and a
+  // finished loop turns the remaining launches into immediate exits.  To avoid paying
+  // for many such exits the first batch is sized from the previous call's iteration
+  // count (+1 spare); only if the loop is still running after it does the host look at
+  // the state (one round trip) and enqueue two more iterations at a time.
   HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-  for (int it = 0; it < max_it; ++it) {
-    if (o.profile) HIP_TRY(hipEventRecord(ctx->sweep_ev[2 * it], ctx->stream));
-    HIP_TRY(launch_sweep(sa, o.jtj_mode, ctx->stream));
-    if (o.profile) HIP_TRY(hipEventRecord(ctx->sweep_ev[2 * it + 1], ctx->stream));
-    HIP_TRY(launch_solve(so, ctx->stream));
+  int launched = 0;
+  int batch = ctx->iter_hint < 1 ? 1 : ctx->iter_hint;
+  for (;;) {
+    if (batch > max_it - launched) batch = max_it - launched;
+    for (int b = 0; b < batch; ++b) {
+      const int it = launched + b;
+      if (o.profile) HIP_TRY(hipEventRecord(ctx->sweep_ev[2 * it], ctx->stream));
+      HIP_TRY(launch_sweep(sa, o.jtj_mode, ctx->stream));
+      if (o.profile) HIP_TRY(hipEventRecord(ctx->sweep_ev[2 * it + 1], ctx->stream));
+      HIP_TRY(launch_solve(so, ctx->stream));
+    }
+    launched += batch;
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_state->done || launched >= max_it) break;
+    batch = 2;
   }
-  HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState), hipMemcpyDeviceToHost,
-                         ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  ctx->iter_hint = ctx->h_state->iter + 1;
 
   const GNState &g = *ctx->h_state;
   for (int i = 0; i < 6; ++i) pose[i] = g.pose[i];  // always written back

@@ -120,7 +120,7 @@ struct KdStack {
 };
 
 #ifdef LSLAM_TRAVERSAL_STATS  // profiling build only (tools/traversal_stats.py)
-struct TravStats { unsigned long long t_desc, t_leaf, t_pop; unsigned n_node, n_leaf, n_pop, n_take; };
+struct TravStats { unsigned long long t_desc, t_leaf, t_pop, t_take; unsigned n_node, n_leaf, n_pop, n_take, n_popit; };
 #define TS_BEGIN unsigned long long _ts = __builtin_readcyclecounter();
 #define TS_ADD(f) { unsigned long long _n = __builtin_readcyclecounter(); ts.f += _n - _ts; _ts = _n; }
 #define TS_INC(f) ts.f++;
@@ -211,6 +211,7 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
     uint32_t te = 0;
     float tm = 0.0f;
     while (sp > 0 && !take) {
+      TS_INC(n_popit)
       uint32_t e[4];
       float m[4];
 #pragma unroll
@@ -238,7 +239,8 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
         }
       }
     }
-    if (!take) { TS_ADD(t_pop) break; }
+    TS_ADD(t_pop)
+    if (!take) break;
     {
       TS_INC(n_take)
       const uint32_t parent = te & 0x1FFFFFFFu;
@@ -257,7 +259,7 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
       mind = tm;
       ref = left ? pn.c2 : pn.c1;  // the child NOT taken on the way down
     }
-    TS_ADD(t_pop)
+    TS_ADD(t_take)
   }
 }
 
@@ -309,7 +311,7 @@ LSLAM_DEV float eigen_hypot(float x, float y) {
 
 // SelfAdjointEigenSolver.h tridiagonal_qr_step on the unreduced block [START,END]
 // of an N x N problem, eigenvectors accumulated in Q (row-major).
-template <int N, int START, int END>
+template <int N, int START, int END, bool VEC = true>
 LSLAM_DEV void tridiag_qr_step(float (&diag)[N], float (&sub)[N - 1], float (&Q)[N * N]) {
   const float td = (diag[END - 1] - diag[END]) * 0.5f;
   const float e = sub[END - 1];
@@ -341,11 +343,13 @@ LSLAM_DEV void tridiag_qr_step(float (&diag)[N], float (&sub)[N - 1], float (&Q)
       z = -s * sub[k + 1];
       sub[k + 1] = c * sub[k + 1];
     }
+    if (VEC) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const float xi = Q[i * N + k], yi = Q[i * N + k + 1];
-      Q[i * N + k] = c * xi - s * yi;
-      Q[i * N + k + 1] = s * xi + c * yi;
+      for (int i = 0; i < N; ++i) {
+        const float xi = Q[i * N + k], yi = Q[i * N + k + 1];
+        Q[i * N + k] = c * xi - s * yi;
+        Q[i * N + k + 1] = s * xi + c * yi;
+      }
     }
   }
 }
@@ -427,6 +431,134 @@ LSLAM_DEV void eig_sym3(const float (&A)[9], float (&evals)[3], float (&V)[9]) {
   evals[0] = diag[0] * scale;
   evals[1] = diag[1] * scale;
   evals[2] = diag[2] * scale;
+}
+
+// SelfAdjointEigenSolver<Matrix<float,6,6>>: EIGENVALUES ONLY, registers only.
+// Generic Householder tridiagonalisation (Tridiagonalization.h
+// tridiagonalization_inplace) + computeFromTridiagonal_impl.  The eigenvalues do not
+// depend on whether eigenvectors are accumulated, so this equals the eigenvalue part of
+// the full decomposition bit for bit; the degeneracy test (ScanMatch.cpp:223-233) only
+// needs the vectors when an eigenvalue is below the threshold (then the slow full
+// version runs).
+template <int S, int E>
+LSLAM_DEV void eig6_step(float (&diag)[6], float (&sub)[5]) {
+  float dummy[36];
+  tridiag_qr_step<6, S, E, false>(diag, sub, dummy);
+}
+
+LSLAM_DEV void eig_sym6_values(const float (&A)[36], float (&evals)[6]) {
+  constexpr int N = 6;
+  float m[N * N];
+  float scale = 0.0f;
+#pragma unroll
+  for (int r = 0; r < N; ++r)
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+      m[r * N + c] = (c <= r) ? A[r * N + c] : 0.0f;
+      scale = fmaxf(scale, fabsf(m[r * N + c]));
+    }
+  if (scale == 0.0f) scale = 1.0f;
+#pragma unroll
+  for (int r = 0; r < N; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) m[r * N + c] /= scale;
+#pragma unroll
+  for (int i = 0; i < N - 1; ++i) {
+    const int rem = N - i - 1;
+    float h, beta;
+    {  // makeHouseholderInPlace on column i, rows i+1..5
+      float tailSqNorm = 0.0f;
+#pragma unroll
+      for (int r = i + 2; r < N; ++r) tailSqNorm += m[r * N + i] * m[r * N + i];
+      const float c0 = m[(i + 1) * N + i];
+      if (tailSqNorm <= FLT_MIN) {
+        h = 0.0f;
+        beta = c0;
+#pragma unroll
+        for (int r = i + 2; r < N; ++r) m[r * N + i] = 0.0f;
+      } else {
+        beta = sqrtf(c0 * c0 + tailSqNorm);
+        if (c0 >= 0.0f) beta = -beta;
+        const float denom = c0 - beta;
+#pragma unroll
+        for (int r = i + 2; r < N; ++r) m[r * N + i] = m[r * N + i] / denom;
+        h = (beta - c0) / beta;
+      }
+    }
+    m[(i + 1) * N + i] = 1.0f;
+    float v[N], p[N];
+#pragma unroll
+    for (int a = 0; a < rem; ++a) v[a] = m[(i + 1 + a) * N + i];
+#pragma unroll
+    for (int a = 0; a < rem; ++a) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int b = 0; b < rem; ++b) {
+        const int r = i + 1 + (a > b ? a : b), c = i + 1 + (a > b ? b : a);
+        acc += m[r * N + c] * (h * v[b]);
+      }
+      p[a] = acc;
+    }
+    float dot = 0.0f;
+#pragma unroll
+    for (int a = 0; a < rem; ++a) dot += p[a] * v[a];
+    const float alpha = h * -0.5f * dot;
+#pragma unroll
+    for (int a = 0; a < rem; ++a) p[a] += alpha * v[a];
+#pragma unroll
+    for (int a = 0; a < rem; ++a)
+#pragma unroll
+      for (int b = 0; b <= a; ++b)
+        m[(i + 1 + a) * N + (i + 1 + b)] -= (v[a] * p[b] + p[a] * v[b]);
+    m[(i + 1) * N + i] = beta;
+  }
+  float diag[N], sub[N - 1];
+#pragma unroll
+  for (int i = 0; i < N; ++i) diag[i] = m[i * N + i];
+#pragma unroll
+  for (int i = 0; i < N - 1; ++i) sub[i] = m[(i + 1) * N + i];
+  int end = N - 1, start = 0, iter = 0;
+  const float precision = 2.0f * FLT_EPSILON;
+  while (end > 0) {
+#pragma unroll
+    for (int i = 0; i < N - 1; ++i)
+      if (i >= start && i < end)
+        if (fabsf(sub[i]) <= (fabsf(diag[i]) + fabsf(diag[i + 1])) * precision ||
+            fabsf(sub[i]) <= FLT_MIN)
+          sub[i] = 0.0f;
+#pragma unroll
+    for (int e = N - 1; e >= 1; --e)
+      if (end == e && sub[e - 1] == 0.0f) end = e - 1;
+    if (end <= 0) break;
+    iter++;
+    if (iter > 30 * N) break;
+    start = end - 1;
+#pragma unroll
+    for (int st = N - 2; st >= 1; --st)
+      if (start == st && sub[st - 1] != 0.0f) start = st - 1;
+#define LSLAM_E6(S, E) else if (start == S && end == E) eig6_step<S, E>(diag, sub);
+    if (false) {}
+    LSLAM_E6(0, 1) LSLAM_E6(0, 2) LSLAM_E6(1, 2) LSLAM_E6(0, 3) LSLAM_E6(1, 3) LSLAM_E6(2, 3)
+    LSLAM_E6(0, 4) LSLAM_E6(1, 4) LSLAM_E6(2, 4) LSLAM_E6(3, 4)
+    LSLAM_E6(0, 5) LSLAM_E6(1, 5) LSLAM_E6(2, 5) LSLAM_E6(3, 5) LSLAM_E6(4, 5)
+#undef LSLAM_E6
+  }
+  // ascending selection sort (values only)
+#pragma unroll
+  for (int i = 0; i < N - 1; ++i) {
+    float mn = diag[i];
+    int k = i;
+#pragma unroll
+    for (int j = i + 1; j < N; ++j) {
+      const bool g = diag[j] < mn;
+      mn = g ? diag[j] : mn;
+      k = g ? j : k;
+    }
+#pragma unroll
+    for (int j = i + 1; j < N; ++j) cswap(k == j, diag[i], diag[j]);
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) evals[i] = diag[i] * scale;
 }
 
 // ColPivHouseholderQR<Matrix<float,R,C>>::compute + solve (Eigen 3.3,
@@ -727,17 +859,18 @@ LSLAM_DEV void jacobian_row(const float (&sc)[6], float px, float py, float pz,
 
 // util/transform_utils.h:288-299 getTransformationTZYX (+ :308-311):
 // q = AngleAxis(rz,Z)*AngleAxis(ry,Y)*AngleAxis(rx,X); R = q.toRotationMatrix().
-// Shared by host (std::sin/std::cos(float), exactly the reference's libm calls) and
-// device (solve kernel) through the SinCos functor.
+// hs/hc: sin/cos of the half angles (Eigen AngleAxis -> Quaternion), fs/fc: sin/cos of
+// the full angles (util/Angle.h:17-18 cached values).  The host evaluates them with
+// std::sin/std::cos(float) -- exactly the reference's libm calls -- the device solve
+// kernel evaluates the six angles in six lanes.
 struct Quat { float w, x, y, z; };
-template <typename F>
-__host__ __device__ inline void pose_to_Rt_sc(const float pose[6], float R[9], float t[3],
-                                              float sc[6], F sincos_f) {
-  Quat qx, qy, qz;
-  float s, c;
-  sincos_f(0.5f * pose[0], s, c); qx = {c, s, 0.0f, 0.0f};
-  sincos_f(0.5f * pose[1], s, c); qy = {c, 0.0f, s, 0.0f};
-  sincos_f(0.5f * pose[2], s, c); qz = {c, 0.0f, 0.0f, s};
+__host__ __device__ inline void sincos_to_Rt_sc(const float pose[6], const float hs[3],
+                                                const float hc[3], const float fs[3],
+                                                const float fc[3], float R[9], float t[3],
+                                                float sc[6]) {
+  const Quat qx = {hc[0], hs[0], 0.0f, 0.0f};
+  const Quat qy = {hc[1], 0.0f, hs[1], 0.0f};
+  const Quat qz = {hc[2], 0.0f, 0.0f, hs[2]};
   auto mul = [](const Quat &a, const Quat &b) {
     Quat r;
     r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
@@ -755,10 +888,161 @@ __host__ __device__ inline void pose_to_Rt_sc(const float pose[6], float R[9], f
   R[3] = txy + twz;          R[4] = 1.0f - (txx + tzz); R[5] = tyz - twx;
   R[6] = txz - twy;          R[7] = tyz + twx;          R[8] = 1.0f - (txx + tyy);
   t[0] = pose[3]; t[1] = pose[4]; t[2] = pose[5];
-  // util/Angle.h:17-18 cached sin/cos of the full angles
-  sincos_f(pose[0], sc[0], sc[1]);
-  sincos_f(pose[1], sc[2], sc[3]);
-  sincos_f(pose[2], sc[4], sc[5]);
+  sc[0] = fs[0]; sc[1] = fc[0];
+  sc[2] = fs[1]; sc[3] = fc[1];
+  sc[4] = fs[2]; sc[5] = fc[2];
+}
+
+template <typename F>
+__host__ __device__ inline void pose_to_Rt_sc(const float pose[6], float R[9], float t[3],
+                                              float sc[6], F sincos_f) {
+  float hs[3], hc[3], fs[3], fc[3];
+  for (int i = 0; i < 3; ++i) {
+    sincos_f(0.5f * pose[i], hs[i], hc[i]);
+    sincos_f(pose[i], fs[i], fc[i]);
+  }
+  sincos_to_Rt_sc(pose, hs, hc, fs, fc, R, t, sc);
+}
+
+// ---------------------------------------------------------------------------
+// Wave-parallel ColPivHouseholderQR<Matrix<float,6,6>>::solve: lane j (0..5) owns
+// column j of A^T A, lane 6 owns the right-hand side.  Every element goes through the
+// same fp32 operations in the same order as the sequential algorithm above (column
+// norms, Householder reflectors and their application are column-local), so the
+// result is bit-identical to colpiv_qr_solve<6,6>; only the critical path shrinks.
+// col[] is this lane's column (consumed).  Returns x[6] in every lane.
+// ---------------------------------------------------------------------------
+LSLAM_DEV void colpiv_qr_solve6_wave(float (&col)[6], int lane, float (&x)[6]) {
+  const bool is_mat = lane < 6;
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) s += col[i] * col[i];
+  float nD = sqrtf(s), nU = nD;
+  float u[6];
+#pragma unroll
+  for (int l = 0; l < 6; ++l) u[l] = __shfl(nU, l, 64);
+  float maxn = u[0];
+#pragma unroll
+  for (int l = 1; l < 6; ++l) maxn = u[l] > maxn ? u[l] : maxn;
+  const float th = maxn * FLT_EPSILON;
+  const float threshold_helper = (th * th) / 6.0f;
+  const float norm_downdate_threshold = sqrtf(FLT_EPSILON);
+  int nonzero_pivots = 6;
+  int perm[6];
+#pragma unroll
+  for (int l = 0; l < 6; ++l) perm[l] = l;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+#pragma unroll
+    for (int l = 0; l < 6; ++l) u[l] = __shfl(nU, l, 64);
+    int big = k;
+    float bigv = u[k];
+#pragma unroll
+    for (int j = k + 1; j < 6; ++j) {
+      const bool g = u[j] > bigv;
+      bigv = g ? u[j] : bigv;
+      big = g ? j : big;
+    }
+    if (nonzero_pivots == 6 && bigv * bigv < threshold_helper * (float)(6 - k)) nonzero_pivots = k;
+    // column transposition k <-> big (and the permutation bookkeeping)
+    const int src = lane == k ? big : (lane == big ? k : lane);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) col[i] = __shfl(col[i], src, 64);
+    nU = __shfl(nU, src, 64);
+    nD = __shfl(nD, src, 64);
+#pragma unroll
+    for (int j = k + 1; j < 6; ++j) cswap(big == j, perm[k], perm[j]);
+    // Householder vector of column k (every lane computes its own, lane k's is used)
+    float tau, beta, ess[6];
+    {
+      float tailSqNorm = 0.0f;
+#pragma unroll
+      for (int i = k + 1; i < 6; ++i) tailSqNorm += col[i] * col[i];
+      const float c0 = col[k];
+      if (tailSqNorm <= FLT_MIN) {
+        tau = 0.0f;
+        beta = c0;
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) ess[i] = 0.0f;
+      } else {
+        beta = sqrtf(c0 * c0 + tailSqNorm);
+        if (c0 >= 0.0f) beta = -beta;
+        const float denom = c0 - beta;
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) ess[i] = col[i] / denom;
+        tau = (beta - c0) / beta;
+      }
+    }
+    tau = __shfl(tau, k, 64);
+    beta = __shfl(beta, k, 64);
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) ess[i] = __shfl(ess[i], k, 64);
+    if (lane == k) {
+      col[k] = beta;
+#pragma unroll
+      for (int i = k + 1; i < 6; ++i) col[i] = ess[i];
+    }
+    // apply H_k to the remaining columns and (while pivots are non-zero) to the rhs
+    const bool apply = (is_mat && lane > k) || (lane == 6 && k < nonzero_pivots);
+    if (apply) {
+      if (k == 5) {
+        col[5] *= (1.0f - tau);
+      } else if (tau != 0.0f) {
+        float tmp = 0.0f;
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) tmp += ess[i] * col[i];
+        tmp += col[k];
+        col[k] -= tau * tmp;
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) col[i] -= tau * ess[i] * tmp;
+      }
+    }
+    // column-norm downdate for the remaining matrix columns
+    if (is_mat && lane > k) {
+      if (nU != 0.0f) {
+        float temp = fabsf(col[k]) / nU;
+        temp = (1.0f + temp) * (1.0f - temp);
+        temp = temp < 0.0f ? 0.0f : temp;
+        const float r = nU / nD;
+        const float temp2 = temp * (r * r);
+        if (temp2 <= norm_downdate_threshold) {
+          float ss = 0.0f;
+#pragma unroll
+          for (int i = k + 1; i < 6; ++i) ss += col[i] * col[i];
+          nD = sqrtf(ss);
+          nU = nD;
+        } else {
+          nU *= sqrtf(temp);
+        }
+      }
+    }
+  }
+  // gather R (upper triangle) and c = Q^T b into every lane, back-substitute
+  float Rm[6][6], c[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    c[i] = __shfl(col[i], 6, 64);
+#pragma unroll
+    for (int r = 0; r <= i; ++r) Rm[r][i] = __shfl(col[r], i, 64);
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    if (i < nonzero_pivots) {
+      c[i] /= Rm[i][i];
+#pragma unroll
+      for (int r = 0; r < i; ++r) c[r] -= c[i] * Rm[r][i];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) x[j] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    if (i < nonzero_pivots) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        if (perm[i] == j) x[j] = c[i];
+    }
+  }
 }
 
 }  // namespace lslam

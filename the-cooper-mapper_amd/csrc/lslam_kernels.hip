@@ -100,12 +100,12 @@ __global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mo
     stk.ovf = OVF ? a.stack_ovf + ((size_t)blockIdx.x * BLOCK + tid) : nullptr;
     stk.ovf_stride = (size_t)a.nb_total * BLOCK;
 #ifdef LSLAM_TRAVERSAL_STATS
-    TravStats ts = {0, 0, 0, 0, 0, 0, 0};
+    TravStats ts = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     knn5_search<BLOCK, OVF>(T, sel[0], sel[1], sel[2], d, p, stk, ts);
     if (a.dbg) {  // per-lane stats: [N][8] after the per-wave stamps
       uint64_t *o = a.dbg + (size_t)a.nb_total * NWAVE * 4 + ((size_t)lb * BLOCK + tid) * 8;
       o[0] = ts.t_desc; o[1] = ts.t_leaf; o[2] = ts.t_pop; o[3] = ts.n_node;
-      o[4] = ts.n_leaf; o[5] = ts.n_pop; o[6] = ts.n_take; o[7] = 1;
+      o[4] = ts.n_leaf; o[5] = ts.n_pop; o[6] = ((uint64_t)ts.n_popit << 32) | ts.n_take; o[7] = ts.t_take | (1ull << 63);
     }
 #else
     knn5_search<BLOCK, OVF>(T, sel[0], sel[1], sel[2], d, p, stk);
@@ -426,66 +426,89 @@ __device__ static void inverse6_dyn(const float *A, float *Ainv) {
   }
 }
 
-struct DevSinCos {
-  // the host uses std::sin/std::cos(float); the double-precision ocml functions
-  // rounded to float agree with glibc's (correctly rounded in practice)
-  __device__ void operator()(float a, float &s, float &c) const {
-    s = (float)sin((double)a);
-    c = (float)cos((double)a);
-  }
+// ScanMatch.cpp:206-260 for one iteration, executed by the whole solve block:
+//   wave 0           6x6 column-pivoted Householder QR solve, one column per lane
+//   wave 1, lane 0   (first iteration) eigenvalues of A^T A for the degeneracy test,
+//                    concurrently with the solve
+//   wave 0           pose update, convergence test, six sin/cos pairs in six lanes,
+//                    next rotation
+// sA/sb: A^T A (row-major) and A^T b in LDS.  Contains block barriers: call from all
+// threads of a block of >= 128 threads.
+struct GnShared {
+  float A[36];
+  float b[6];
+  float matP[36];
+  int degenerate;
 };
 
-// ScanMatch.cpp:206-260 for one iteration, single thread.
-__device__ static void gn_step_device(GNState *st, const float (&AtA_in)[36],
-                                      const float (&Atb)[6], float eig_thresh, float dr_abort,
-                                      float dt_abort) {
-  float x[6];
-  {
-    float qr[36];
+__device__ static void gn_step_block(GNState *st, GnShared &sh, float eig_thresh, float dr_abort,
+                                     float dt_abort) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int iter = st->iter;  // uniform
+  float x[6] = {0, 0, 0, 0, 0, 0};
+  if (wave == 0) {
+    float col[6];
 #pragma unroll
-    for (int i = 0; i < 36; ++i) qr[i] = AtA_in[i];
-    colpiv_qr_solve<6, 6>(qr, Atb, x);  // :209
+    for (int i = 0; i < 6; ++i) col[i] = lane < 6 ? sh.A[i * 6 + lane] : (lane == 6 ? sh.b[i] : 0.0f);
+    colpiv_qr_solve6_wave(col, lane, x);  // :209
+  } else if (wave == 1 && lane == 0 && iter == 0) {  // :211-233
+    float A[36], E[6];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) A[i] = sh.A[i];
+    eig_sym6_values(A, E);
+    sh.degenerate = E[0] < eig_thresh ? 1 : 0;  // ascending: any below <=> the smallest
   }
-  if (st->iter == 0) {  // :211-235
-    float E[6], V[36], V2[36], Vinv[36];
-    eig_sym6_dyn(AtA_in, E, V);
-    for (int i = 0; i < 36; ++i) V2[i] = V[i];
-    int deg = 0;
-    for (int i = 0; i < 6; ++i) {
-      if (E[i] < eig_thresh) {
-        for (int j = 0; j < 6; ++j) V2[i * 6 + j] = 0.0f;  // row i: quirk Q2
-        deg = 1;
-      } else
-        break;
-    }
-    st->degenerate = deg;
-    if (deg) {
-      inverse6_dyn(V, Vinv);
-      for (int r = 0; r < 6; ++r)
-        for (int c = 0; c < 6; ++c) {
-          float s = 0.0f;
-          for (int k = 0; k < 6; ++k) s += Vinv[r * 6 + k] * V2[k * 6 + c];
-          st->matP[r * 6 + c] = s;
+  __syncthreads();
+  if (wave != 0) return;
+  int degenerate;
+  if (iter == 0) {
+    degenerate = sh.degenerate;
+    if (degenerate) {  // rare: needs the eigenvectors (quirk Q2), single lane
+      if (lane == 0) {
+        float A[36], E[6], V[36], V2[36], Vinv[36];
+        for (int i = 0; i < 36; ++i) A[i] = sh.A[i];
+        eig_sym6_dyn(A, E, V);
+        for (int i = 0; i < 36; ++i) V2[i] = V[i];
+        for (int i = 0; i < 6; ++i) {
+          if (E[i] < eig_thresh) {
+            for (int j = 0; j < 6; ++j) V2[i * 6 + j] = 0.0f;  // row i
+          } else
+            break;
         }
+        inverse6_dyn(V, Vinv);  // :234
+        for (int r = 0; r < 6; ++r)
+          for (int c = 0; c < 6; ++c) {
+            float s = 0.0f;
+            for (int kk = 0; kk < 6; ++kk) s += Vinv[r * 6 + kk] * V2[kk * 6 + c];
+            sh.matP[r * 6 + c] = s;
+            st->matP[r * 6 + c] = s;
+          }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
     }
+    if (lane == 0) st->degenerate = degenerate;
+  } else {
+    degenerate = st->degenerate;
+    if (degenerate && lane < 36) sh.matP[lane] = st->matP[lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
   }
-  if (st->degenerate) {  // :237-240
+  if (degenerate) {  // :237-240
     float x2[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) x2[i] = x[i];
+#pragma unroll
     for (int r = 0; r < 6; ++r) {
       float s = 0.0f;
-      for (int k = 0; k < 6; ++k) s += st->matP[r * 6 + k] * x2[k];
+#pragma unroll
+      for (int kk = 0; kk < 6; ++kk) s += sh.matP[r * 6 + kk] * x2[kk];
       x[r] = s;
     }
   }
   float pose[6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    pose[i] = st->pose[i] + x[i];  // :242-247
-    st->pose[i] = pose[i];
-    st->x[i] = x[i];
-  }
+  for (int i = 0; i < 6; ++i) pose[i] = st->pose[i] + x[i];  // :242-247
   // :249-253 (rad2deg(float) -> float, pow(float,int) -> double)
   const double kPi = 3.14159265358979323846;
   const double r0 = (double)(float)((double)x[0] * 180.0 / kPi);
@@ -494,13 +517,41 @@ __device__ static void gn_step_device(GNState *st, const float (&AtA_in)[36],
   const float dR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);
   const double t0 = (double)(x[3] * 100), t1 = (double)(x[4] * 100), t2 = (double)(x[5] * 100);
   const float dT = (float)sqrt(t0 * t0 + t1 * t1 + t2 * t2);
-  st->delta_r = dR;
-  st->delta_t = dT;
-  st->iter += 1;
-  pose_to_Rt_sc(pose, st->R, st->t, st->sc, DevSinCos());
-  if (dR < dr_abort && dT < dt_abort) {  // :257-260
-    st->converged = 1;
-    st->done = 1;
+  // next rotation: lanes 0..2 half angles, 3..5 full angles (the host uses
+  // std::sin/std::cos(float); the double-precision functions rounded to float agree)
+  const int ai = lane < 3 ? lane : (lane < 6 ? lane - 3 : 0);
+  float ang = ai == 0 ? pose[0] : (ai == 1 ? pose[1] : pose[2]);
+  if (lane < 3) ang = 0.5f * ang;
+  const float sv = (float)sin((double)ang);
+  const float cv = (float)cos((double)ang);
+  float hs[3], hc[3], fs[3], fc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    hs[i] = __shfl(sv, i, 64);
+    hc[i] = __shfl(cv, i, 64);
+    fs[i] = __shfl(sv, 3 + i, 64);
+    fc[i] = __shfl(cv, 3 + i, 64);
+  }
+  if (lane == 0) {
+    float R[9], t[3], sc[6];
+    sincos_to_Rt_sc(pose, hs, hc, fs, fc, R, t, sc);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      st->pose[i] = pose[i];
+      st->x[i] = x[i];
+      st->sc[i] = sc[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) st->R[i] = R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) st->t[i] = t[i];
+    st->delta_r = dR;
+    st->delta_t = dT;
+    st->iter = iter + 1;
+    if (dR < dr_abort && dT < dt_abort) {  // :257-260
+      st->converged = 1;
+      st->done = 1;
+    }
   }
 }
 
@@ -509,6 +560,8 @@ __global__ __launch_bounds__(256) void solve_kernel(SolveArgs a) {
   if (st->done) return;
   __shared__ double red[8][NCOL];
   __shared__ double tot[NCOL];
+  __shared__ GnShared sh;
+  __shared__ int go;
   const int tid = threadIdx.x, col = tid & 31, grp = tid >> 5;
   double s = 0.0;
   for (int b = grp; b < a.nb_total; b += 8) s += (double)a.partials[(size_t)b * NCOL + col];
@@ -522,32 +575,31 @@ __global__ __launch_bounds__(256) void solve_kernel(SolveArgs a) {
     st->sums[tid] = v;
   }
   __syncthreads();
-  if (tid != 0 || a.reduce_only) return;
-
-  st->sweeps += 1;
-  st->n_rows = (int)tot[COL_ROWS];
-  st->n_line = (int)tot[COL_LINE];
-  st->n_plane = (int)tot[COL_PLANE];
-  st->score = tot[COL_SCORE];
-  if (st->n_rows < 50) {  // ScanMatch.cpp:141-145
-    st->too_few = 1;
-    st->done = 1;
-    return;
-  }
-  float AtA[36], Atb[6];
-  int k = 0;
-#pragma unroll
-  for (int i = 0; i < 6; ++i)
-#pragma unroll
-    for (int j = i; j < 6; ++j) {
-      const float vv = (float)tot[k++];
-      AtA[i * 6 + j] = vv;
-      AtA[j * 6 + i] = vv;
+  if (a.reduce_only) return;
+  if (tid == 0) {
+    st->sweeps += 1;
+    const int n_rows = (int)tot[COL_ROWS];
+    st->n_rows = n_rows;
+    st->n_line = (int)tot[COL_LINE];
+    st->n_plane = (int)tot[COL_PLANE];
+    st->score = tot[COL_SCORE];
+    go = 1;
+    if (n_rows < 50) {  // ScanMatch.cpp:141-145
+      st->too_few = 1;
+      st->done = 1;
+      go = 0;
     }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) Atb[i] = (float)tot[COL_ATB + i];
-  gn_step_device(st, AtA, Atb, a.eig_thresh, a.delta_r_abort, a.delta_t_abort);
-  if (st->iter >= a.max_iterations) st->done = 1;
+  }
+  if (tid < 36) {  // symmetric A^T A from the 21 reduced upper-triangular sums
+    const int r = tid / 6, c = tid % 6;
+    const int i = r < c ? r : c, j = r < c ? c : r;
+    sh.A[tid] = (float)tot[COL_ATA + (i * 6 - (i * (i - 1)) / 2) + (j - i)];
+  }
+  if (tid < 6) sh.b[tid] = (float)tot[COL_ATB + tid];
+  __syncthreads();
+  if (!go) return;
+  gn_step_block(st, sh, a.eig_thresh, a.delta_r_abort, a.delta_t_abort);
+  if (tid == 0 && st->iter >= a.max_iterations) st->done = 1;
 }
 
 hipError_t launch_solve(const SolveArgs &a, hipStream_t s) {
@@ -555,18 +607,21 @@ hipError_t launch_solve(const SolveArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
-__global__ void gn_step_tap_kernel(GNState *st, const float *AtA, const float *Atb, float dr,
-                                   float dt, float eig_thresh) {
-  if (threadIdx.x != 0) return;
-  float A[36], b[6];
-  for (int i = 0; i < 36; ++i) A[i] = AtA[i];
-  for (int i = 0; i < 6; ++i) b[i] = Atb[i];
-  gn_step_device(st, A, b, eig_thresh, dr, dt);
+__global__ __launch_bounds__(128) void gn_step_tap_kernel(GNState *st, const float *AtA,
+                                                          const float *Atb, float dr, float dt,
+                                                          float eig_thresh) {
+  __shared__ GnShared sh;
+  const int tid = threadIdx.x;
+  if (tid < 36) sh.A[tid] = AtA[tid];
+  if (tid < 6) sh.b[tid] = Atb[tid];
+  if (tid < 36) sh.matP[tid] = st->matP[tid];
+  __syncthreads();
+  gn_step_block(st, sh, eig_thresh, dr, dt);
 }
 
 hipError_t launch_gn_step_tap(GNState *st, const float *AtA, const float *Atb, float dr, float dt,
                               float eig_thresh, hipStream_t s) {
-  hipLaunchKernelGGL(gn_step_tap_kernel, dim3(1), dim3(64), 0, s, st, AtA, Atb, dr, dt,
+  hipLaunchKernelGGL(gn_step_tap_kernel, dim3(1), dim3(128), 0, s, st, AtA, Atb, dr, dt,
                      eig_thresh);
   return hipGetLastError();
 }
@@ -590,7 +645,7 @@ __global__ __launch_bounds__(128, 2) void knn5_kernel(TreeView T, const float4 *
   stk.ovf = OVF ? stack_ovf + ((size_t)blockIdx.x * 128 + threadIdx.x) : nullptr;
   stk.ovf_stride = (size_t)gridDim.x * 128;
 #ifdef LSLAM_TRAVERSAL_STATS
-  TravStats ts = {0, 0, 0, 0, 0, 0, 0};
+  TravStats ts = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   knn5_search<128, OVF>(T, qq.x, qq.y, qq.z, d, p, stk, ts);
 #else
   knn5_search<128, OVF>(T, qq.x, qq.y, qq.z, d, p, stk);

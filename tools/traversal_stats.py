@@ -22,21 +22,26 @@ for rep in range(2):
     n = lib.lslam_debug_sweep_clocks(ctx.h, pose.ctypes.data_as(C.POINTER(C.c_float)), 0,
                                      buf.ctypes.data_as(C.POINTER(C.c_uint64)), cap)
 assert n == nw, n
-st = buf[nw * 4: nw * 4 + nb * 128 * 8].reshape(nb * 128, 8).astype(np.int64)
-valid = st[:, 7] == 1
+raw = buf[nw * 4: nw * 4 + nb * 128 * 8].reshape(nb * 128, 8)
+valid = (raw[:, 7] >> np.uint64(63)) == 1
+st = np.zeros((nb * 128, 9), np.int64)
+st[:, :6] = raw[:, :6].astype(np.int64)
+st[:, 6] = (raw[:, 6] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+st[:, 7] = (raw[:, 6] >> np.uint64(32)).astype(np.int64)
+st[:, 8] = (raw[:, 7] & np.uint64((1 << 63) - 1)).astype(np.int64)
 print("lanes", valid.sum())
-names = ["t_desc", "t_leaf", "t_pop", "n_node", "n_leaf", "n_pop", "n_take"]
+names = ["t_desc", "t_leaf", "t_pop", "n_node", "n_leaf", "n_pop", "n_take", "n_popit", "t_take"]
 for i, nme in enumerate(names):
     v = st[valid, i]
     print("%-7s per-lane mean %9.1f p50 %8.0f p90 %8.0f max %8.0f" % (nme, v.mean(), np.percentile(v, 50), np.percentile(v, 90), v.max()))
 # per-wave: lanes in a wave run in lockstep, so the wave pays roughly the max over lanes
-w = st.reshape(nb * 2, 64, 8)
+w = st.reshape(nb * 2, 64, 9)
 wm = w.max(axis=1)
 print("per-wave max over lanes:")
 for i, nme in enumerate(names):
     v = wm[:, i]
     print("%-7s wave mean %9.1f p50 %8.0f p90 %8.0f max %8.0f" % (nme, v.mean(), np.percentile(v, 50), np.percentile(v, 90), v.max()))
-tot = wm[:, 0] + wm[:, 1] + wm[:, 2]
+tot = wm[:, 0] + wm[:, 1] + wm[:, 2] + wm[:, 8]
 print("cycles per node step (wave): %.0f ; per leaf: %.0f ; per pop: %.0f" % (
     wm[:, 0].sum() / max(1, wm[:, 3].sum()), wm[:, 1].sum() / max(1, wm[:, 4].sum()), wm[:, 2].sum() / max(1, wm[:, 5].sum())))
 for g in np.array_split(np.arange(nb * 2), 12):

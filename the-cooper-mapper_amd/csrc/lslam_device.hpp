@@ -222,21 +222,23 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
         m[j] = __uint_as_float(w1);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (!take && sp > 0) {
-          TS_INC(n_pop)
-          const uint32_t feat = (e[j] >> 29) & 3u;
-          if (e[j] & 0x80000000u) {  // far subtree finished: dists[idx] = dst  (:1494)
-            if (feat == 0) ds0 = m[j]; else if (feat == 1) ds1 = m[j]; else ds2 = m[j];
-            --sp;
-          } else if (m[j] <= d[4]) {  // mindistsq*epsError <= worstDist  (:1487)
-            take = true;
-            te = e[j];
-            tm = m[j];
-          } else {
-            --sp;
-          }
-        }
+      for (int j = 0; j < 4; ++j) {  // predicated: no divergent branches in the pop loop
+        const bool valid = !take && sp > 0;
+        const uint32_t feat = (e[j] >> 29) & 3u;
+        const bool act = (e[j] & 0x80000000u) != 0;  // far subtree finished (:1494)
+        const bool pass = !act && (m[j] <= d[4]);    // mindistsq*epsError <= worstDist (:1487)
+        const bool rst = valid && act;
+        ds0 = (rst && feat == 0) ? m[j] : ds0;        // dists[idx] = dst
+        ds1 = (rst && feat == 1) ? m[j] : ds1;
+        ds2 = (rst && feat == 2) ? m[j] : ds2;
+        const bool tk = valid && pass;
+        te = tk ? e[j] : te;
+        tm = tk ? m[j] : tm;
+        take = take || tk;
+        sp -= (valid && !pass) ? 1 : 0;
+#ifdef LSLAM_TRAVERSAL_STATS
+        ts.n_pop += valid ? 1 : 0;
+#endif
       }
     }
     TS_ADD(t_pop)

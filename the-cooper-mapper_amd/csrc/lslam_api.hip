@@ -5,10 +5,12 @@
 // scanMatchScan call back to back with no host round trip in between.
 #include "../../include/lslam_c.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -117,6 +119,42 @@ void pack_cloud(const void *src, size_t n, size_t stride_bytes, std::vector<floa
     std::memcpy(xyz, p + i * stride_bytes, sizeof(xyz));
     out[i] = make_float4(xyz[0], xyz[1], xyz[2], 0.0f);
   }
+}
+
+// Scan points are processed one per lane; lanes of a wave run in lockstep, so a wave is
+// as slow as its most expensive traversal.  Ordering the scan along a Morton curve
+// (0.25 m cells) makes the 64 points of a wave spatial neighbours that walk the same
+// part of the kd-tree.  The original index travels in .w: per-point outputs are
+// written back in the caller's order, only the order of summation changes.
+inline uint32_t spread10(uint32_t v) {
+  v &= 0x3FFu;
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+void morton_order(std::vector<float4> &pts) {
+  const size_t n = pts.size();
+  std::vector<std::pair<uint32_t, uint32_t>> key(n);
+  for (size_t i = 0; i < n; ++i) {
+    auto q = [](float v) {
+      float c = v * 4.0f + 512.0f;  // 0.25 m cells, +-128 m
+      c = c < 0.0f ? 0.0f : (c > 1023.0f ? 1023.0f : c);
+      return (uint32_t)c;
+    };
+    key[i] = {spread10(q(pts[i].x)) | (spread10(q(pts[i].y)) << 1) | (spread10(q(pts[i].z)) << 2),
+              (uint32_t)i};
+  }
+  std::sort(key.begin(), key.end());
+  std::vector<float4> out(n);
+  for (size_t i = 0; i < n; ++i) {
+    float4 v = pts[key[i].second];
+    v.w = __builtin_bit_cast(float, key[i].second);
+    out[i] = v;
+  }
+  pts.swap(out);
 }
 
 int upload_tree(lslam_ctx *ctx, DevTree &dt, const HostTree &ht, const std::vector<float4> &cloud) {
@@ -261,6 +299,11 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
 
 void *lslam_stream(lslam_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+// Profiling tap: phase stamps of the last solve kernel (100 MHz ticks).
+void lslam_debug_solve_clocks(lslam_ctx *ctx, uint64_t out[8]) {
+  for (int i = 0; i < 8; ++i) out[i] = ctx->h_state->clk[i];
+}
+
 // Profiling tap (not part of the drop-in surface): one sweep at `pose` with per-wave
 // shader-clock stamps {start, after kNN, after fit, end}; out[n_waves*4], returns n_waves.
 int lslam_debug_sweep_clocks(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode,
@@ -358,6 +401,14 @@ int lslam_scan_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const vo
   std::vector<float4> c, s;
   pack_cloud(corner, n_corner, stride_bytes, c);
   pack_cloud(surf, n_surf, stride_bytes, s);
+  static const bool no_morton = std::getenv("LSLAM_NO_MORTON") != nullptr;  // profiling A/B
+  if (!no_morton) {
+    morton_order(c);
+    morton_order(s);
+  } else {
+    for (size_t i = 0; i < c.size(); ++i) c[i].w = __builtin_bit_cast(float, (uint32_t)i);
+    for (size_t i = 0; i < s.size(); ++i) s[i].w = __builtin_bit_cast(float, (uint32_t)i);
+  }
   HIP_TRY(ctx->qc.reserve(n_corner ? n_corner : 1));
   HIP_TRY(ctx->qs.reserve(n_surf ? n_surf : 1));
   if (n_corner)
@@ -434,9 +485,11 @@ int lslam_scanmatch_run(lslam_ctx *ctx, float pose[6], const lslam_opts *opts_in
     if (batch > max_it - launched) batch = max_it - launched;
     for (int b = 0; b < batch; ++b) {
       const int it = launched + b;
-      if (o.profile) HIP_TRY(hipEventRecord(ctx->sweep_ev[2 * it], ctx->stream));
-      HIP_TRY(launch_sweep(sa, o.jtj_mode, ctx->stream));
-      if (o.profile) HIP_TRY(hipEventRecord(ctx->sweep_ev[2 * it + 1], ctx->stream));
+      if (o.profile)
+        HIP_TRY(launch_sweep(sa, o.jtj_mode, ctx->stream, ctx->sweep_ev[2 * it],
+                             ctx->sweep_ev[2 * it + 1]));
+      else
+        HIP_TRY(launch_sweep(sa, o.jtj_mode, ctx->stream));
       HIP_TRY(launch_solve(so, ctx->stream));
     }
     launched += batch;

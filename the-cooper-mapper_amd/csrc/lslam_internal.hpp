@@ -41,11 +41,12 @@ struct GNState {
   int32_t pad;
   double score;        // of the last sweep
   double sums[NCOL];   // last reduced sums (parity tap)
+  uint64_t clk[8];     // solve-kernel phase stamps, 100 MHz wall clock (profiling tap)
 };
 
 struct SweepArgs {
   TreeView tc, ts;
-  const float4 *qc, *qs;  // scan points, sensor frame, {x,y,z,-}
+  const float4 *qc, *qs;  // scan points, sensor frame, Morton order, {x,y,z,bitcast(original index)}
   int32_t nqc, nqs;
   int32_t nb_corner, nb_total;  // blocks are type-homogeneous: [0,nb_corner) corner
   const GNState *state;
@@ -69,10 +70,14 @@ struct SolveArgs {
   float eig_thresh;  // 100 (ScanMatch.cpp:223)
 };
 
-constexpr int SWEEP_BLOCK = 128;
+#ifndef LSLAM_SWEEP_BLOCK
+#define LSLAM_SWEEP_BLOCK 256
+#endif
+constexpr int SWEEP_BLOCK = LSLAM_SWEEP_BLOCK;
 
 // launchers (lslam_kernels.hip)
-hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s);
+hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s,
+                        hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 hipError_t launch_solve(const SolveArgs &a, hipStream_t s);
 hipError_t launch_knn5(const TreeView &T, const float4 *q, int nq, int32_t *idx, float *d2,
                        uint32_t *stack_ovf, hipStream_t s);

@@ -11,6 +11,8 @@
 //   knn5_kernel    parity tap: nearestKSearch(p, 5, ...) (nanoflann_pcl.h:150-162)
 //
 // Compile with -ffp-contract=off (see lslam_device.hpp).
+#include <hip/hip_ext.h>
+
 #include "lslam_internal.hpp"
 
 namespace lslam {
@@ -141,7 +143,8 @@ __global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mo
       score = expf(-fabsf(coeff[3]));
     }
     if (a.flags_out) {  // parity taps
-      const int gi = is_surf ? a.nqc + qi : qi;
+      const int oi = __float_as_int(q.w);  // caller's index of this scan point
+      const int gi = is_surf ? a.nqc + oi : oi;
       a.flags_out[gi] = (uint8_t)flag;
       if (a.coeff_out) a.coeff_out[gi] = make_float4(coeff[0], coeff[1], coeff[2], coeff[3]);
       if (a.idx_out) {
@@ -233,14 +236,17 @@ __global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mo
   }
 }
 
-hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s) {
+// start/stop (optional) time exactly this dispatch on its own stream: the events are
+// attached to the kernel's AQL packet, no extra barrier packets are enqueued.
+hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t start,
+                        hipEvent_t stop) {
   if (a.nb_total <= 0) return hipSuccess;
   if (a.stack_ovf)
-    hipLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true>), dim3(a.nb_total), dim3(SWEEP_BLOCK), 0, s,
-                       a, jtj_mode);
+    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true>), dim3(a.nb_total), dim3(SWEEP_BLOCK), 0,
+                          s, start, stop, 0, a, jtj_mode);
   else
-    hipLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false>), dim3(a.nb_total), dim3(SWEEP_BLOCK), 0,
-                       s, a, jtj_mode);
+    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false>), dim3(a.nb_total), dim3(SWEEP_BLOCK),
+                          0, s, start, stop, 0, a, jtj_mode);
   return hipGetLastError();
 }
 
@@ -451,6 +457,7 @@ __device__ static void gn_step_block(GNState *st, GnShared &sh, float eig_thresh
 #pragma unroll
     for (int i = 0; i < 6; ++i) col[i] = lane < 6 ? sh.A[i * 6 + lane] : (lane == 6 ? sh.b[i] : 0.0f);
     colpiv_qr_solve6_wave(col, lane, x);  // :209
+    if (lane == 0) st->clk[2] = wall_clock64();
   } else if (wave == 1 && lane == 0 && iter == 0) {  // :211-233
     float A[36], E[6];
 #pragma unroll
@@ -555,28 +562,45 @@ __device__ static void gn_step_block(GNState *st, GnShared &sh, float eig_thresh
   }
 }
 
-__global__ __launch_bounds__(256) void solve_kernel(SolveArgs a) {
+constexpr int SOLVE_THREADS = 1024;
+constexpr int SOLVE_GROUPS = SOLVE_THREADS / NCOL;  // 32 row groups x 32 columns
+
+__global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(SolveArgs a) {
   GNState *st = a.state;
   if (st->done) return;
-  __shared__ double red[8][NCOL];
+  __shared__ double red[SOLVE_GROUPS][NCOL];
   __shared__ double tot[NCOL];
   __shared__ GnShared sh;
   __shared__ int go;
   const int tid = threadIdx.x, col = tid & 31, grp = tid >> 5;
+  if (tid == 0) st->clk[0] = wall_clock64();
+  // Deterministic cross-block reduction in fp64: thread (grp, col) adds rows
+  // grp, grp+32, ... in order; 32 independent loads are in flight per pass, so up to
+  // 1024 sweep blocks cost a single memory round trip.
   double s = 0.0;
-  for (int b = grp; b < a.nb_total; b += 8) s += (double)a.partials[(size_t)b * NCOL + col];
+  for (int b0 = grp; b0 < a.nb_total; b0 += SOLVE_GROUPS * 32) {
+    float v[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      const int b = b0 + u * SOLVE_GROUPS;
+      v[u] = b < a.nb_total ? a.partials[(size_t)b * NCOL + col] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 32; ++u) s += (double)v[u];
+  }
   red[grp][col] = s;
   __syncthreads();
   if (tid < NCOL) {
     double v = 0.0;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) v += red[g][tid];
+    for (int g = 0; g < SOLVE_GROUPS; ++g) v += red[g][tid];
     tot[tid] = v;
     st->sums[tid] = v;
   }
   __syncthreads();
   if (a.reduce_only) return;
   if (tid == 0) {
+    st->clk[1] = wall_clock64();
     st->sweeps += 1;
     const int n_rows = (int)tot[COL_ROWS];
     st->n_rows = n_rows;
@@ -600,10 +624,11 @@ __global__ __launch_bounds__(256) void solve_kernel(SolveArgs a) {
   if (!go) return;
   gn_step_block(st, sh, a.eig_thresh, a.delta_r_abort, a.delta_t_abort);
   if (tid == 0 && st->iter >= a.max_iterations) st->done = 1;
+  if (tid == 0) st->clk[3] = wall_clock64();
 }
 
 hipError_t launch_solve(const SolveArgs &a, hipStream_t s) {
-  hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(SOLVE_THREADS), 0, s, a);
   return hipGetLastError();
 }
 

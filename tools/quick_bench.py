@@ -18,6 +18,12 @@ sw = []; lp = []
 for _ in range(int(os.environ.get("REPS", "20"))):
     status, pose, st = ctx.run(pr["init_pose"], opts)
     sw.append(st.gpu_ms_sweep / max(1, st.sweep_launches)); lp.append(st.gpu_ms_total)
+import ctypes as C
+clk = (C.c_uint64 * 8)()
+ctx.lib.lslam_debug_solve_clocks.argtypes = [C.c_void_p, C.c_uint64 * 8]
+ctx.lib.lslam_debug_solve_clocks(ctx.h, clk)
+c = [int(x) for x in clk]
+print("last solve kernel (us): reduce %.2f  qr %.2f  rest %.2f  total %.2f" % ((c[1]-c[0])/100, (c[2]-c[1])/100, (c[3]-c[2])/100, (c[3]-c[0])/100))
 print("%-40s sweep_us median %.1f min %.1f | loop_us median %.1f | iters %d pose %s" % (
     os.path.basename(os.environ.get("LSLAM_LIB", "default")), 1e3 * np.median(sw), 1e3 * min(sw), 1e3 * np.median(lp),
     st.iterations, np.array2string(pose, precision=5)))

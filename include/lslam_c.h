@@ -128,12 +128,29 @@ int lslam_map_info_get(const lslam_ctx *ctx, lslam_map_info *info);
 int lslam_scan_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const void *surf,
                    size_t n_surf, size_t stride_bytes);
 
+/* Batch form: n_scans independent scans (e.g. keyframes) made resident together; they
+ * are matched against the same resident map by ONE sequence of kernel launches, which
+ * is what fills a 256-CU GPU (one 64-ring scan is only ~1800 wavefronts).
+ * Replaces the per-keyframe loop of Graph::getFinalFeatureMap (pose_graph/graph.cpp:171-197)
+ * and the per-candidate loop of LoopDetector::matching_nearest
+ * (pose_graph/loop_detector.hpp:166-226). */
+int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *corner,
+                         const size_t *n_corner, const void *const *surf, const size_t *n_surf,
+                         size_t stride_bytes);
+
 /* ---- Gauss-Newton scan match ------------------------------------------- */
 
 /* The GN loop of ScanMatch::scanMatchScan(..., Twist&), ScanMatch.cpp:78-347,
  * on the resident map and scan.  pose is in/out and is always written back
  * except for LSLAM_TOO_FEW_REF and errors (ScanMatch.cpp:324,331,338,343). */
 int lslam_scanmatch_run(lslam_ctx *ctx, float pose[6], const lslam_opts *opts, lslam_stats *stats);
+
+/* The same loop for every resident scan of a batch, each with its own pose, iteration
+ * count and convergence: poses[n_scans*6] in/out, stats[n_scans] (may be NULL).
+ * gpu_ms_* in every stats entry are those of the whole batch.  Returns LSLAM_OK if
+ * every scan returned true, else the first non-OK outcome (errors are negative). */
+int lslam_scanmatch_run_batch(lslam_ctx *ctx, int32_t n_scans, float *poses,
+                              const lslam_opts *opts, lslam_stats *stats);
 
 /* = lslam_scan_set + lslam_scanmatch_run.  Replaces scanMatchScan against a map
  * that is already resident (the FeatureMap::scanMatchScan usage, util/FeatureMap.h:490-691). */

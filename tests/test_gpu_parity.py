@@ -225,6 +225,37 @@ def test_guards_and_edge_cases(ctx, pkg, oracle, small_problem):
     c2.close()
 
 
+def test_batch_equals_individual_runs(ctx, synth, small_problem):
+    """Independent scans matched together (one launch sequence) give, bit for bit, what
+    each gives alone: every scan keeps its own block decomposition and summation order."""
+    pr = small_problem
+    world = pr["world"]
+    scans, inits = [], []
+    for k, (rings, steps) in enumerate(((16, 900), (16, 450), (8, 300), (16, 1200))):
+        gt = (0.01 * k, -0.01, 0.3 + 0.2 * k, 3.0 - 2 * k, -2.0 + k, synth.SENSOR_HEIGHT)
+        qc, qs, gt = synth.make_scan(world, rings, steps, gt_pose=gt, seed=100 + k)
+        scans.append((qc, qs))
+        inits.append(synth.perturb_pose(gt, seed=200 + k))
+    inits[2][3] += 400.0  # this one is far from the map: too few matches, pose untouched
+    ctx.map_set(pr["map_corner"], pr["map_surf"])
+    single = []
+    for (qc, qs), p0 in zip(scans, inits):
+        single.append(ctx.scanmatch_scan(qc, qs, p0))
+    ctx.scan_set_batch(scans)
+    worst, poses, stats = ctx.run_batch(np.stack(inits))
+    for k, (status, pose, st) in enumerate(single):
+        assert stats[k].status == st.status and stats[k].iterations == st.iterations, k
+        assert (stats[k].n_rows, stats[k].n_line, stats[k].n_plane) == (st.n_rows, st.n_line, st.n_plane)
+        assert np.array_equal(bits(poses[k]), bits(pose)), k
+        assert stats[k].point_residuals == st.point_residuals
+    assert stats[2].status == 5 and np.array_equal(poses[2], inits[2])
+    assert len({s.iterations for s in stats}) > 1  # scans really stop at different iterations
+    assert worst == 5
+    # a second batch call on the same resident scans is deterministic
+    _, poses2, _ = ctx.run_batch(np.stack(inits))
+    assert np.array_equal(bits(poses2), bits(poses))
+
+
 def test_scanmatch_class_mirrors_reference_api(pkg, oracle, small_problem):
     pr = small_problem
     sm = pkg.ScanMatch(10)

@@ -91,6 +91,10 @@ SYMBOLS = {
     "lslam_map_set": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t]),
     "lslam_map_info_get": (C.c_int, [C.c_void_p, C.POINTER(LslamMapInfo)]),
     "lslam_scan_set": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t]),
+    "lslam_scan_set_batch": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                       C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t]),
+    "lslam_scanmatch_run_batch": (C.c_int, [C.c_void_p, C.c_int32, c_float_p, C.POINTER(LslamOpts),
+                                            C.POINTER(LslamStats)]),
     "lslam_scanmatch_run": (C.c_int, [C.c_void_p, c_float_p, C.POINTER(LslamOpts), C.POINTER(LslamStats)]),
     "lslam_scanmatch_scan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                        C.c_size_t, c_float_p, C.POINTER(LslamOpts), C.POINTER(LslamStats)]),

@@ -90,12 +90,21 @@ struct lslam_ctx {
   bool have_map = false;
   bool have_scan = false;
   lslam_map_info info{};
-  DevBuf<float4> qc, qs;
-  int32_t nqc = 0, nqs = 0;
+  // resident scans (a batch of independent scan-match problems against the same map)
+  DevBuf<float4> q;             // all points, per scan: corner block-run then surf
+  DevBuf<BlockDesc> blocks;
+  DevBuf<ProbBlocks> probs;
+  std::vector<BlockDesc> h_blocks;
+  std::vector<ProbBlocks> h_probs;
+  std::vector<int32_t> nqc, nqs;  // per scan
+  int32_t n_prob = 0;
+  int32_t nb_total = 0;
+  size_t n_points = 0;
   DevBuf<float> partials;
   DevBuf<uint32_t> stack_ovf;  // only allocated for trees deeper than KD_STACK_LDS+1
-  GNState *d_state = nullptr;
-  GNState *h_state = nullptr;  // pinned
+  GNState *d_state = nullptr;   // [state_cap]
+  GNState *h_state = nullptr;   // pinned, [state_cap]
+  int32_t state_cap = 0;
   // tap buffers
   DevBuf<int32_t> t_idx;
   DevBuf<float> t_d2;
@@ -197,13 +206,10 @@ void init_state(GNState &s, const float pose[6]) {
 void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
   a.tc = ctx->tc.view;
   a.ts = ctx->ts.view;
-  a.qc = ctx->qc.p;
-  a.qs = ctx->qs.p;
-  a.nqc = ctx->nqc;
-  a.nqs = ctx->nqs;
-  a.nb_corner = (ctx->nqc + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
-  a.nb_total = a.nb_corner + (ctx->nqs + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
-  a.state = ctx->d_state;
+  a.q = ctx->q.p;
+  a.blocks = ctx->blocks.p;
+  a.nb_total = ctx->nb_total;
+  a.states = ctx->d_state;
   a.partials = ctx->partials.p;
   a.stack_ovf = nullptr;
   a.idx_out = nullptr;
@@ -211,6 +217,19 @@ void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
   a.coeff_out = nullptr;
   a.flags_out = nullptr;
   a.dbg = nullptr;
+}
+
+int ensure_states(lslam_ctx *ctx, int32_t n) {
+  if (n <= ctx->state_cap) return LSLAM_OK;
+  if (ctx->d_state) (void)hipFree(ctx->d_state);
+  if (ctx->h_state) (void)hipHostFree(ctx->h_state);
+  ctx->d_state = nullptr;
+  ctx->h_state = nullptr;
+  ctx->state_cap = 0;
+  HIP_TRY(hipMalloc((void **)&ctx->d_state, sizeof(GNState) * (size_t)n));
+  HIP_TRY(hipHostMalloc((void **)&ctx->h_state, sizeof(GNState) * (size_t)n, hipHostMallocDefault));
+  ctx->state_cap = n;
+  return LSLAM_OK;
 }
 
 // Trees deeper than the LDS part of the traversal stack need the global overflow area.
@@ -271,8 +290,10 @@ int lslam_ctx_create(int device, lslam_ctx **out) {
   lslam_ctx *ctx = new lslam_ctx();
   ctx->device = device;
   HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  HIP_TRY(hipMalloc((void **)&ctx->d_state, sizeof(GNState)));
-  HIP_TRY(hipHostMalloc((void **)&ctx->h_state, sizeof(GNState), hipHostMallocDefault));
+  {
+    int rc = ensure_states(ctx, 1);
+    if (rc) return rc;
+  }
   HIP_TRY(hipEventCreate(&ctx->ev0));
   HIP_TRY(hipEventCreate(&ctx->ev1));
   *out = ctx;
@@ -285,7 +306,7 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   ctx->tc.nodes.release(); ctx->tc.pts.release();
   ctx->ts.nodes.release(); ctx->ts.pts.release();
-  ctx->qc.release(); ctx->qs.release(); ctx->partials.release(); ctx->stack_ovf.release();
+  ctx->q.release(); ctx->blocks.release(); ctx->probs.release(); ctx->partials.release(); ctx->stack_ovf.release();
   ctx->t_idx.release(); ctx->t_d2.release(); ctx->t_coeff.release(); ctx->t_flags.release();
   ctx->t_q.release(); ctx->t_small.release();
   if (ctx->d_state) (void)hipFree(ctx->d_state);
@@ -310,7 +331,7 @@ int lslam_debug_sweep_clocks(lslam_ctx *ctx, const float pose[6], int32_t jtj_mo
                              uint64_t *out, size_t out_cap_waves) {
   int rc = check_ctx(ctx);
   if (rc) return rc;
-  if (!ctx->have_map || !ctx->have_scan) return LSLAM_ERR_NO_MAP;
+  if (!ctx->have_map || !ctx->have_scan || ctx->n_prob != 1) return LSLAM_ERR_NO_MAP;
   init_state(*ctx->h_state, pose);
   HIP_TRY(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(GNState), hipMemcpyHostToDevice, ctx->stream));
   SweepArgs sa;
@@ -388,78 +409,140 @@ int lslam_map_info_get(const lslam_ctx *ctx, lslam_map_info *info) {
   return LSLAM_OK;
 }
 
-int lslam_scan_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const void *surf,
-                   size_t n_surf, size_t stride_bytes) {
+int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *corner,
+                         const size_t *n_corner, const void *const *surf, const size_t *n_surf,
+                         size_t stride_bytes) {
   int rc = check_ctx(ctx);
   if (rc) return rc;
-  if (stride_bytes < 12 || (stride_bytes & 3) || (n_corner && !corner) || (n_surf && !surf) ||
-      n_corner > 0x3FFFFFFFu || n_surf > 0x3FFFFFFFu) {
+  if (n_scans <= 0 || !corner || !n_corner || !surf || !n_surf || stride_bytes < 12 ||
+      (stride_bytes & 3)) {
     set_err("bad scan arguments");
     return LSLAM_ERR_INVALID;
   }
-  ctx->have_scan = false;
-  std::vector<float4> c, s;
-  pack_cloud(corner, n_corner, stride_bytes, c);
-  pack_cloud(surf, n_surf, stride_bytes, s);
-  static const bool no_morton = std::getenv("LSLAM_NO_MORTON") != nullptr;  // profiling A/B
-  if (!no_morton) {
-    morton_order(c);
-    morton_order(s);
-  } else {
-    for (size_t i = 0; i < c.size(); ++i) c[i].w = __builtin_bit_cast(float, (uint32_t)i);
-    for (size_t i = 0; i < s.size(); ++i) s[i].w = __builtin_bit_cast(float, (uint32_t)i);
+  size_t total = 0;
+  for (int32_t p = 0; p < n_scans; ++p) {
+    if ((n_corner[p] && !corner[p]) || (n_surf[p] && !surf[p])) {
+      set_err("null cloud in scan %d", p);
+      return LSLAM_ERR_INVALID;
+    }
+    total += n_corner[p] + n_surf[p];
   }
-  HIP_TRY(ctx->qc.reserve(n_corner ? n_corner : 1));
-  HIP_TRY(ctx->qs.reserve(n_surf ? n_surf : 1));
-  if (n_corner)
-    HIP_TRY(hipMemcpyAsync(ctx->qc.p, c.data(), n_corner * sizeof(float4), hipMemcpyHostToDevice,
-                           ctx->stream));
-  if (n_surf)
-    HIP_TRY(hipMemcpyAsync(ctx->qs.p, s.data(), n_surf * sizeof(float4), hipMemcpyHostToDevice,
-                           ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  ctx->nqc = (int32_t)n_corner;
-  ctx->nqs = (int32_t)n_surf;
-  const size_t nb = (n_corner + SWEEP_BLOCK - 1) / SWEEP_BLOCK + (n_surf + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
+  if (total > 0x3FFFFFFFu) {
+    set_err("batch too large");
+    return LSLAM_ERR_INVALID;
+  }
+  ctx->have_scan = false;
+  std::vector<float4> all;
+  all.reserve(total);
+  ctx->h_blocks.clear();
+  ctx->h_probs.assign((size_t)n_scans, ProbBlocks{0, 0});
+  ctx->nqc.assign((size_t)n_scans, 0);
+  ctx->nqs.assign((size_t)n_scans, 0);
+  std::vector<float4> c, s;
+  static const bool no_morton = std::getenv("LSLAM_NO_MORTON") != nullptr;  // profiling A/B
+  int32_t out_base = 0;
+  for (int32_t p = 0; p < n_scans; ++p) {
+    pack_cloud(corner[p], n_corner[p], stride_bytes, c);
+    pack_cloud(surf[p], n_surf[p], stride_bytes, s);
+    if (!no_morton) {
+      morton_order(c);
+      morton_order(s);
+    } else {
+      for (size_t i = 0; i < c.size(); ++i) c[i].w = __builtin_bit_cast(float, (uint32_t)i);
+      for (size_t i = 0; i < s.size(); ++i) s[i].w = __builtin_bit_cast(float, (uint32_t)i);
+    }
+    ctx->h_probs[(size_t)p].first_block = (int32_t)ctx->h_blocks.size();
+    for (int type = 0; type < 2; ++type) {
+      const std::vector<float4> &v = type ? s : c;
+      const int32_t base = (int32_t)all.size();
+      for (size_t off = 0; off < v.size(); off += SWEEP_BLOCK) {
+        BlockDesc bd{};
+        bd.prob = p;
+        bd.first = base + (int32_t)off;
+        bd.count = (int32_t)std::min<size_t>(SWEEP_BLOCK, v.size() - off);
+        bd.is_surf = type;
+        bd.out_base = out_base + (type ? (int32_t)c.size() : 0);
+        ctx->h_blocks.push_back(bd);
+      }
+      all.insert(all.end(), v.begin(), v.end());
+    }
+    ctx->h_probs[(size_t)p].n_blocks = (int32_t)ctx->h_blocks.size() - ctx->h_probs[(size_t)p].first_block;
+    ctx->nqc[(size_t)p] = (int32_t)c.size();
+    ctx->nqs[(size_t)p] = (int32_t)s.size();
+    out_base += (int32_t)(c.size() + s.size());
+  }
+  const size_t nb = ctx->h_blocks.size();
+  HIP_TRY(ctx->q.reserve(total ? total : 1));
+  HIP_TRY(ctx->blocks.reserve(nb ? nb : 1));
+  HIP_TRY(ctx->probs.reserve((size_t)n_scans));
   HIP_TRY(ctx->partials.reserve((nb ? nb : 1) * NCOL));
+  rc = ensure_states(ctx, n_scans);
+  if (rc) return rc;
+  if (total)
+    HIP_TRY(hipMemcpyAsync(ctx->q.p, all.data(), total * sizeof(float4), hipMemcpyHostToDevice,
+                           ctx->stream));
+  if (nb)
+    HIP_TRY(hipMemcpyAsync(ctx->blocks.p, ctx->h_blocks.data(), nb * sizeof(BlockDesc),
+                           hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->probs.p, ctx->h_probs.data(), (size_t)n_scans * sizeof(ProbBlocks),
+                         hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  ctx->n_prob = n_scans;
+  ctx->nb_total = (int32_t)nb;
+  ctx->n_points = total;
   ctx->have_scan = true;
   return LSLAM_OK;
 }
 
-int lslam_scanmatch_run(lslam_ctx *ctx, float pose[6], const lslam_opts *opts_in,
-                        lslam_stats *stats) {
+int lslam_scan_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const void *surf,
+                   size_t n_surf, size_t stride_bytes) {
+  if ((n_corner && !corner) || (n_surf && !surf)) {
+    set_err("bad scan arguments");
+    return LSLAM_ERR_INVALID;
+  }
+  return lslam_scan_set_batch(ctx, 1, &corner, &n_corner, &surf, &n_surf, stride_bytes);
+}
+
+int lslam_scanmatch_run_batch(lslam_ctx *ctx, int32_t n_scans, float *poses,
+                              const lslam_opts *opts_in, lslam_stats *stats) {
   int rc = check_ctx(ctx);
   if (rc) return rc;
-  if (!pose) {
-    set_err("null pose");
+  if (!poses || n_scans <= 0) {
+    set_err("null poses");
     return LSLAM_ERR_INVALID;
   }
   lslam_opts o;
   if (opts_in) o = *opts_in; else lslam_default_opts(&o);
-  lslam_stats st_local;
-  lslam_stats &st = stats ? *stats : st_local;
-  std::memset(&st, 0, sizeof(st));
-  if (!ctx->have_map) { st.status = LSLAM_ERR_NO_MAP; set_err("no map set"); return LSLAM_ERR_NO_MAP; }
-  if (!ctx->have_scan) { st.status = LSLAM_ERR_NO_SCAN; set_err("no scan set"); return LSLAM_ERR_NO_SCAN; }
-  // ScanMatch.cpp:57-61
-  if (ctx->info.n_corner < 50 || ctx->info.n_surf < 100) {
-    st.status = LSLAM_TOO_FEW_REF;
-    return LSLAM_TOO_FEW_REF;
+  if (stats) std::memset(stats, 0, sizeof(lslam_stats) * (size_t)n_scans);
+  auto fail_all = [&](int code) {
+    if (stats) for (int32_t p = 0; p < n_scans; ++p) stats[p].status = code;
+    return code;
+  };
+  if (!ctx->have_map) { set_err("no map set"); return fail_all(LSLAM_ERR_NO_MAP); }
+  if (!ctx->have_scan) { set_err("no scan set"); return fail_all(LSLAM_ERR_NO_SCAN); }
+  if (n_scans != ctx->n_prob) {
+    set_err("batch size %d does not match the %d resident scans", n_scans, ctx->n_prob);
+    return fail_all(LSLAM_ERR_INVALID);
   }
+  // ScanMatch.cpp:57-61
+  if (ctx->info.n_corner < 50 || ctx->info.n_surf < 100) return fail_all(LSLAM_TOO_FEW_REF);
   const int max_it = o.max_iterations < 0 ? 0 : o.max_iterations;
 
-  init_state(*ctx->h_state, pose);
-  if (max_it == 0) ctx->h_state->done = 1;
-  HIP_TRY(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(GNState), hipMemcpyHostToDevice,
-                         ctx->stream));
+  for (int32_t p = 0; p < n_scans; ++p) {
+    init_state(ctx->h_state[p], poses + 6 * p);
+    if (max_it == 0) ctx->h_state[p].done = 1;
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(GNState) * (size_t)n_scans,
+                         hipMemcpyHostToDevice, ctx->stream));
   SweepArgs sa;
   fill_sweep_args(ctx, sa);
   rc = ensure_stack_ovf(ctx, (size_t)sa.nb_total * SWEEP_BLOCK, &sa.stack_ovf);
   if (rc) return rc;
   SolveArgs so{};
-  so.state = ctx->d_state;
+  so.states = ctx->d_state;
   so.partials = ctx->partials.p;
-  so.nb_total = sa.nb_total;
+  so.probs = ctx->probs.p;
+  so.n_prob = n_scans;
   so.reduce_only = 0;
   so.max_iterations = max_it;
   so.delta_r_abort = o.delta_r_abort;
@@ -476,8 +559,8 @@ int lslam_scanmatch_run(lslam_ctx *ctx, float pose[6], const lslam_opts *opts_in
   // The loop is device-resident: sweep/solve pairs are enqueued back to back and a
   // finished loop turns the remaining launches into immediate exits.  To avoid paying
   // for many such exits the first batch is sized from the previous call's iteration
-  // count (+1 spare); only if the loop is still running after it does the host look at
-  // the state (one round trip) and enqueue two more iterations at a time.
+  // count (+1 spare); only if a loop is still running after it does the host look at
+  // the states (one round trip) and enqueue two more iterations at a time.
   HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
   int launched = 0;
   int batch = ctx->iter_hint < 1 ? 1 : ctx->iter_hint;
@@ -494,56 +577,84 @@ int lslam_scanmatch_run(lslam_ctx *ctx, float pose[6], const lslam_opts *opts_in
     }
     launched += batch;
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState), hipMemcpyDeviceToHost,
-                           ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState) * (size_t)n_scans,
+                           hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (ctx->h_state->done || launched >= max_it) break;
+    bool all_done = true;
+    for (int32_t p = 0; p < n_scans; ++p) all_done = all_done && ctx->h_state[p].done;
+    if (all_done || launched >= max_it) break;
     batch = 2;
   }
-  ctx->iter_hint = ctx->h_state->iter + 1;
+  int max_sweeps = 0, max_iter = 0;
+  for (int32_t p = 0; p < n_scans; ++p) {
+    max_sweeps = std::max(max_sweeps, ctx->h_state[p].sweeps);
+    max_iter = std::max(max_iter, ctx->h_state[p].iter);
+  }
+  ctx->iter_hint = max_iter + 1;
 
-  const GNState &g = *ctx->h_state;
-  for (int i = 0; i < 6; ++i) pose[i] = g.pose[i];  // always written back
-  st.iterations = g.iter;
-  st.n_line = g.n_line;
-  st.n_plane = g.n_plane;
-  st.n_rows = g.n_rows;
-  st.degenerate = g.degenerate;
-  st.converged = g.converged;
-  st.delta_r = g.delta_r;
-  st.delta_t = g.delta_t;
-  st.sweeps = g.sweeps;
-  st.point_residuals = (int64_t)g.sweeps * ((int64_t)ctx->nqc + (int64_t)ctx->nqs);
-  HIP_TRY(hipEventElapsedTime(&st.gpu_ms_total, ctx->ev0, ctx->ev1));
+  float gpu_ms_total = 0.f, gpu_ms_sweep = 0.f;
+  int sweep_launches = 0;
+  HIP_TRY(hipEventElapsedTime(&gpu_ms_total, ctx->ev0, ctx->ev1));
   if (o.profile) {
-    float acc = 0.f;
-    int n = 0;
-    for (int it = 0; it < max_it && it < g.sweeps; ++it) {
+    for (int it = 0; it < launched && it < max_sweeps; ++it) {
       float ms = 0.f;
       HIP_TRY(hipEventElapsedTime(&ms, ctx->sweep_ev[2 * it], ctx->sweep_ev[2 * it + 1]));
-      acc += ms;
-      ++n;
+      gpu_ms_sweep += ms;
+      ++sweep_launches;
     }
-    st.gpu_ms_sweep = acc;
-    st.sweep_launches = n;
   }
-  int status;
-  if (g.converged && o.use_score) {  // ScanMatch.cpp:263-341
-    const double score = g.score;
-    const double match_count = (double)g.n_line + (double)g.n_plane;
-    const float percent = (float)(match_count / (double)((size_t)ctx->nqc + (size_t)ctx->nqs));
-    st.score = score;
-    st.percent = percent;
-    if (score < o.score_threshold) status = LSLAM_LOW_SCORE;
-    else if (percent < o.match_percentage_threshold) status = LSLAM_LOW_PERCENT;
-    else status = LSLAM_OK;
-  } else if (g.too_few) {
-    status = LSLAM_TOO_FEW_MATCHES;
-  } else {
-    status = LSLAM_NOT_CONVERGED;
+  int worst = LSLAM_OK;
+  for (int32_t p = 0; p < n_scans; ++p) {
+    const GNState &g = ctx->h_state[p];
+    for (int i = 0; i < 6; ++i) poses[6 * p + i] = g.pose[i];  // always written back
+    const size_t npts = (size_t)ctx->nqc[(size_t)p] + (size_t)ctx->nqs[(size_t)p];
+    int status;
+    double score = 0.0, percent = 0.0;
+    if (g.converged && o.use_score) {  // ScanMatch.cpp:263-341
+      score = g.score;
+      const double match_count = (double)g.n_line + (double)g.n_plane;
+      percent = (float)(match_count / (double)npts);
+      if (score < o.score_threshold) status = LSLAM_LOW_SCORE;
+      else if (percent < o.match_percentage_threshold) status = LSLAM_LOW_PERCENT;
+      else status = LSLAM_OK;
+    } else if (g.too_few) {
+      status = LSLAM_TOO_FEW_MATCHES;
+    } else {
+      status = LSLAM_NOT_CONVERGED;
+    }
+    if (status != LSLAM_OK && worst == LSLAM_OK) worst = status;
+    if (stats) {
+      lslam_stats &st = stats[p];
+      st.status = status;
+      st.iterations = g.iter;
+      st.n_line = g.n_line;
+      st.n_plane = g.n_plane;
+      st.n_rows = g.n_rows;
+      st.degenerate = g.degenerate;
+      st.converged = g.converged;
+      st.delta_r = g.delta_r;
+      st.delta_t = g.delta_t;
+      st.score = score;
+      st.percent = percent;
+      st.sweeps = g.sweeps;
+      st.point_residuals = (int64_t)g.sweeps * (int64_t)npts;
+      st.gpu_ms_total = gpu_ms_total;    // whole batch
+      st.gpu_ms_sweep = gpu_ms_sweep;    // whole batch
+      st.sweep_launches = sweep_launches;
+    }
   }
-  st.status = status;
-  return status;
+  return n_scans == 1 ? (stats ? stats[0].status : worst) : worst;
+}
+
+int lslam_scanmatch_run(lslam_ctx *ctx, float pose[6], const lslam_opts *opts, lslam_stats *stats) {
+  if (!pose) {
+    set_err("null pose");
+    return LSLAM_ERR_INVALID;
+  }
+  lslam_stats local;
+  lslam_stats *st = stats ? stats : &local;
+  const int rc = lslam_scanmatch_run_batch(ctx, 1, pose, opts, st);
+  return rc < 0 ? rc : st->status;
 }
 
 int lslam_scanmatch_scan(lslam_ctx *ctx, const void *corner, size_t n_corner, const void *surf,
@@ -628,7 +739,8 @@ int lslam_sweep(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_t *
   if (!ctx->have_map) { set_err("no map set"); return LSLAM_ERR_NO_MAP; }
   if (!ctx->have_scan) { set_err("no scan set"); return LSLAM_ERR_NO_SCAN; }
   if (!pose) { set_err("null pose"); return LSLAM_ERR_INVALID; }
-  const size_t N = (size_t)ctx->nqc + (size_t)ctx->nqs;
+  if (ctx->n_prob != 1) { set_err("lslam_sweep is a single-scan tap"); return LSLAM_ERR_INVALID; }
+  const size_t N = ctx->n_points;
   init_state(*ctx->h_state, pose);
   HIP_TRY(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(GNState), hipMemcpyHostToDevice, ctx->stream));
   SweepArgs sa;
@@ -648,9 +760,10 @@ int lslam_sweep(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_t *
   }
   HIP_TRY(launch_sweep(sa, jtj_mode, ctx->stream));
   SolveArgs so{};
-  so.state = ctx->d_state;
+  so.states = ctx->d_state;
   so.partials = ctx->partials.p;
-  so.nb_total = sa.nb_total;
+  so.probs = ctx->probs.p;
+  so.n_prob = 1;
   so.reduce_only = 1;
   HIP_TRY(launch_solve(so, ctx->stream));
   HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState), hipMemcpyDeviceToHost, ctx->stream));

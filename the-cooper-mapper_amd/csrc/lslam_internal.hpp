@@ -44,14 +44,31 @@ struct GNState {
   uint64_t clk[8];     // solve-kernel phase stamps, 100 MHz wall clock (profiling tap)
 };
 
+// One sweep launch covers every scan of the batch.  A block works on one scan and one
+// feature type (corner blocks run findLine, surf blocks findPlane: no divergence
+// between the two fits inside a block).
+struct BlockDesc {
+  int32_t prob;      // scan (problem) index
+  int32_t first;     // first point of this block in SweepArgs::q
+  int32_t count;     // points in this block (<= SWEEP_BLOCK)
+  int32_t is_surf;
+  int32_t out_base;  // tap outputs: index of this scan's corner (or surf) point 0
+  int32_t pad[3];
+};
+
+struct ProbBlocks {
+  int32_t first_block, n_blocks;
+};
+
 struct SweepArgs {
   TreeView tc, ts;
-  const float4 *qc, *qs;  // scan points, sensor frame, Morton order, {x,y,z,bitcast(original index)}
-  int32_t nqc, nqs;
-  int32_t nb_corner, nb_total;  // blocks are type-homogeneous: [0,nb_corner) corner
-  const GNState *state;
-  float *partials;  // [nb_total][NCOL]
-  uint32_t *stack_ovf;  // traversal-stack overflow (null unless a tree is deeper than 33)
+  const float4 *q;  // scan points of all scans, sensor frame, Morton order within a scan
+                    // and type, {x,y,z,bitcast(original index)}
+  const BlockDesc *blocks;  // [nb_total]
+  int32_t nb_total;
+  const GNState *states;  // [n_prob]
+  float *partials;        // [nb_total][NCOL]
+  uint32_t *stack_ovf;    // traversal-stack overflow (null unless a tree is deeper than 33)
   // optional per-point taps (all NULL in the production loop)
   int32_t *idx_out;    // [N][5] original map indices
   float *d2_out;       // [N][5]
@@ -61,9 +78,10 @@ struct SweepArgs {
 };
 
 struct SolveArgs {
-  GNState *state;
+  GNState *states;            // [n_prob]; block p of the solve grid handles scan p
   const float *partials;
-  int32_t nb_total;
+  const ProbBlocks *probs;    // [n_prob] block range of each scan
+  int32_t n_prob;
   int32_t reduce_only;  // 1: only reduce partials into state->sums (tap)
   int32_t max_iterations;
   float delta_r_abort, delta_t_abort;

@@ -45,8 +45,10 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 template <int BLOCK, bool OVF>
 __global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mode) {
-  const GNState *st = a.state;
-  if (st->done) return;  // loop already ended (ScanMatch.cpp:144,259)
+  const int lb = xcd_remap(blockIdx.x, a.nb_total);
+  const BlockDesc bd = a.blocks[lb];
+  const GNState *st = a.states + bd.prob;
+  if (st->done) return;  // this scan's loop already ended (ScanMatch.cpp:144,259)
 
   constexpr int NWAVE = BLOCK / 64;
   __shared__ float red[NWAVE][NCOL];
@@ -55,13 +57,11 @@ __global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mo
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int lb = xcd_remap(blockIdx.x, a.nb_total);
   const uint64_t dbg_t0 = a.dbg ? __builtin_readcyclecounter() : 0;
   uint64_t dbg_t1 = 0, dbg_t2 = 0;
-  const bool is_surf = lb >= a.nb_corner;
-  const int qi = (is_surf ? lb - a.nb_corner : lb) * BLOCK + tid;
-  const int nq = is_surf ? a.nqs : a.nqc;
-  const bool active = qi < nq;
+  const bool is_surf = bd.is_surf != 0;
+  const int qi = bd.first + tid;
+  const bool active = tid < bd.count;
 
   // pose of this iteration: wave-uniform scalar loads
   float R[9], t[3], sc[6];
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mo
   float kept = 0.0f, matched = 0.0f, score = 0.0f;
 
   if (active) {
-    const float4 q = (is_surf ? a.qs : a.qc)[qi];
+    const float4 q = a.q[qi];
     // util/transform_utils.h:476-482 pointAssociateToMap: it * p
     float sel[3];
     sel[0] = ((R[0] * q.x + R[1] * q.y) + R[2] * q.z) + t[0];
@@ -143,8 +143,7 @@ __global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mo
       score = expf(-fabsf(coeff[3]));
     }
     if (a.flags_out) {  // parity taps
-      const int oi = __float_as_int(q.w);  // caller's index of this scan point
-      const int gi = is_surf ? a.nqc + oi : oi;
+      const int gi = bd.out_base + __float_as_int(q.w);  // caller's index of this point
       a.flags_out[gi] = (uint8_t)flag;
       if (a.coeff_out) a.coeff_out[gi] = make_float4(coeff[0], coeff[1], coeff[2], coeff[3]);
       if (a.idx_out) {
@@ -566,8 +565,11 @@ constexpr int SOLVE_THREADS = 1024;
 constexpr int SOLVE_GROUPS = SOLVE_THREADS / NCOL;  // 32 row groups x 32 columns
 
 __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(SolveArgs a) {
-  GNState *st = a.state;
+  GNState *st = a.states + blockIdx.x;  // one block per scan of the batch
   if (st->done) return;
+  const ProbBlocks pb = a.probs[blockIdx.x];
+  const float *partials = a.partials + (size_t)pb.first_block * NCOL;
+  const int nb = pb.n_blocks;
   __shared__ double red[SOLVE_GROUPS][NCOL];
   __shared__ double tot[NCOL];
   __shared__ GnShared sh;
@@ -578,12 +580,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(SolveArgs a) {
   // grp, grp+32, ... in order; 32 independent loads are in flight per pass, so up to
   // 1024 sweep blocks cost a single memory round trip.
   double s = 0.0;
-  for (int b0 = grp; b0 < a.nb_total; b0 += SOLVE_GROUPS * 32) {
+  for (int b0 = grp; b0 < nb; b0 += SOLVE_GROUPS * 32) {
     float v[32];
 #pragma unroll
     for (int u = 0; u < 32; ++u) {
       const int b = b0 + u * SOLVE_GROUPS;
-      v[u] = b < a.nb_total ? a.partials[(size_t)b * NCOL + col] : 0.0f;
+      v[u] = b < nb ? partials[(size_t)b * NCOL + col] : 0.0f;
     }
 #pragma unroll
     for (int u = 0; u < 32; ++u) s += (double)v[u];
@@ -628,7 +630,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(SolveArgs a) {
 }
 
 hipError_t launch_solve(const SolveArgs &a, hipStream_t s) {
-  hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(SOLVE_THREADS), 0, s, a);
+  if (a.n_prob <= 0) return hipSuccess;
+  hipLaunchKernelGGL(solve_kernel, dim3(a.n_prob), dim3(SOLVE_THREADS), 0, s, a);
   return hipGetLastError();
 }
 

@@ -84,6 +84,36 @@ class Context:
         self._check(self.lib.lslam_scan_set(self.h, _vp(c), len(c), _vp(s), len(s), sc))
         self.n_scan = len(c) + len(s)
 
+    def scan_set_batch(self, scans):
+        """scans: list of (corner, surf) clouds made resident together (lslam_scan_set_batch)."""
+        n = len(scans)
+        keep = []
+        cp = (C.c_void_p * n)()
+        sp = (C.c_void_p * n)()
+        nc = (C.c_size_t * n)()
+        ns = (C.c_size_t * n)()
+        stride = None
+        for i, (corner, surf) in enumerate(scans):
+            c, sc = _cloud(corner)
+            s, ss = _cloud(surf)
+            if sc != ss or (stride is not None and sc != stride):
+                raise ValueError("all clouds of a batch must share one stride")
+            stride = sc
+            keep.append((c, s))
+            cp[i], sp[i], nc[i], ns[i] = c.ctypes.data, s.ctypes.data, len(c), len(s)
+        self._check(self.lib.lslam_scan_set_batch(self.h, n, cp, nc, sp, ns, stride))
+        self.n_scan = sum(len(c) + len(s) for c, s in keep)
+        self.n_batch = n
+
+    def run_batch(self, poses, opts=None):
+        """lslam_scanmatch_run_batch -> (worst status, poses (n,6), [stats])."""
+        p = np.array(poses, dtype=np.float32).reshape(-1, 6)
+        n = len(p)
+        st = (LslamStats * n)()
+        rc = self.lib.lslam_scanmatch_run_batch(self.h, n, _fp(p), C.byref(opts) if opts is not None else None, st)
+        self._check(rc)
+        return Status(rc), p, list(st)
+
     # -- GN loop ---------------------------------------------------------------
     def run(self, pose, opts=None):
         """lslam_scanmatch_run on the resident map+scan -> (status, pose, stats)."""

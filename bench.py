@@ -4,8 +4,11 @@
 A "step" is one scanMatchScan Gauss-Newton loop (ScanMatch.cpp:78-347: up to 10
 iterations of transform -> kd-tree 5-NN -> line/plane fit -> residual + Jacobian ->
 J^T J / J^T r -> 6x6 solve -> pose update) of one synthetic 64-ring x 1800 scan
-(115 200 points) against a resident ~1.3 M-point voxel map (BASELINE.json configs[2]).
-Map, kd-trees and scan are resident in HBM before the timed region starts.
+(115 200 points) against a resident ~1.3 M-point voxel map (BASELINE.json configs[2]);
+`--batch` (default 8) different scans are matched together per step, the way keyframes
+are re-matched against a map (pose_graph/graph.cpp:171-197).  The single-scan (latency)
+figure is reported in the same line under "single_scan".
+Map, kd-trees and scans are resident in HBM before the timed region starts.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
@@ -41,9 +44,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rings", type=int, default=64)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("LSLAM_BATCH", "1")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("LSLAM_BATCH", "8")),
                     help="independent scans matched together per step on each GPU")
-    ap.add_argument("--jtj-mode", type=int, default=int(os.environ.get("LSLAM_JTJ_MODE", "0")))
+    ap.add_argument("--jtj-mode", type=int, default=int(os.environ.get("LSLAM_JTJ_MODE", "1")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     args = ap.parse_args()
@@ -51,17 +54,11 @@ def main():
     import numpy as np
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
-        dist = dist_
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    distmod = importlib.import_module("the-cooper-mapper_amd.dist")
+    rank, local_rank, world = distmod.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
+    dist = distmod.init("nccl")
 
     pkg = importlib.import_module("the-cooper-mapper_amd")
     synth = importlib.import_module("the-cooper-mapper_amd.synth")
@@ -87,10 +84,7 @@ def main():
     opts.profile = 1
 
     def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        distmod.barrier(dist)
 
     for _ in range(args.warmup):
         ctx.run_batch(inits, opts)
@@ -114,13 +108,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    tot = torch.tensor([float(pt_res), float(iters)], dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    total_pt_res, total_iters = tot.tolist()
-    t = float(tmax.item())
+    (total_pt_res, total_iters), t = distmod.aggregate(dist, [pt_res, iters], elapsed)
 
     status, poses, sts = last
     pose, st = poses[0], sts[0]
@@ -180,14 +168,39 @@ def main():
                 "alg_bytes_per_launch": alg_bytes,
             },
         }
+        out["single_scan"] = single_scan_leg(ctx, pr, opts, max(10, args.steps // 2))
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pr, args.cpu_repeats, pose, np)
         print(json.dumps(out), flush=True)
 
-    ctx.close()
     if dist is not None:
         dist.barrier()
+    ctx.close()
+    if dist is not None:
         dist.destroy_process_group()
+
+
+def single_scan_leg(ctx, pr, opts, steps):
+    """Latency view of the same path: ONE 115 200-point scan in flight (rank 0, after the
+    timed region): wall time per scanMatchScan loop and the sweep kernel on its own."""
+    ctx.scan_set(pr["corner"], pr["surf"])
+    for _ in range(3):
+        ctx.run(pr["init_pose"], opts)
+    t0 = time.perf_counter()
+    pt = 0
+    sw_ms = 0.0
+    sw_n = 0
+    for _ in range(steps):
+        status, pose, st = ctx.run(pr["init_pose"], opts)
+        pt += st.point_residuals
+        sw_ms += st.gpu_ms_sweep
+        sw_n += st.sweep_launches
+    dt = time.perf_counter() - t0
+    avg = sw_ms / max(1, sw_n)
+    n = len(pr["corner"]) + len(pr["surf"])
+    return {"value": pt / dt, "unit": "point-residuals/s", "ms_per_scanmatch": 1e3 * dt / steps,
+            "gn_iterations": st.iterations, "sweep_kernel_ms": avg,
+            "roofline_frac": ALG_BYTES_PER_POINT_RESIDUAL * n / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS if avg > 0 else None}
 
 
 def cpu_baseline(pr, repeats, gpu_pose, np):

@@ -1,0 +1,132 @@
+// lslam_scan_match.hpp -- header-only C++ shim with the reference's class surface.
+//
+// `lidar_slam::ScanMatch` below has the method names, argument order, defaults and
+// return behaviour of the reference class declared in
+// /root/reference/L_SLAM/src/scan_to_scan_match/ScanMatch.h:12-86, implemented on top
+// of the C ABI in lslam_c.h, so that the reference's call sites
+//   odometry/LaserMatcher.cpp:327-331, pose_graph/graph.cpp:185-190,
+//   pose_graph/loop_detector.hpp:206-223
+// compile against it unchanged.  It is templated on the cloud / pose types so that it
+// needs neither PCL nor Eigen at build time:
+//   CloudPtr  : anything with ->points.data() and ->points.size() whose elements start
+//               with float x,y,z (pcl::PointCloud<pcl::PointXYZI>::ConstPtr works;
+//               sizeof(point) is taken as the stride -- 32 for PointXYZI, quirk Q9)
+//   Isometry  : anything with .matrix()(r,c) read/write access (Eigen::Isometry3f works)
+//   Twist     : rot_x/rot_y/rot_z with .rad() and assignment from float, pos(i)
+//               (util/Twist.h:13-36 works)
+#pragma once
+
+#include <cstddef>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+
+#include "lslam_c.h"
+
+namespace lidar_slam {
+
+class ScanMatch {
+public:
+  // ScanMatch.h:21-34
+  inline void setPercentThreshold(double percent) { _opts.match_percentage_threshold = percent; }
+  inline void setScoreThreshold(double score) { _opts.score_threshold = score; }
+  inline void setFineScore(bool enable) { _opts.fine_score = enable ? 1 : 0; }
+  inline void setConvergeThreshold(float deltaTAbort, float deltaRAbort) {
+    _opts.delta_t_abort = deltaTAbort;
+    _opts.delta_r_abort = deltaRAbort;
+  }
+  inline void setUseCore(bool useScore) { _opts.use_score = useScore ? 1 : 0; }
+
+  // ScanMatch.h:36, ScanMatch.cpp:21-33.  `device` selects the GPU (no reference counterpart).
+  explicit ScanMatch(const size_t maxIterations = 10, int device = 0)
+      : _ctx(nullptr), _total_score(0), _match_count(0), _fail_match_count(0) {
+    lslam_default_opts(&_opts);
+    _opts.max_iterations = (int32_t)maxIterations;
+    if (lslam_ctx_create(device, &_ctx) != LSLAM_OK)
+      throw std::runtime_error(std::string("lslam_ctx_create: ") + lslam_last_error());
+  }
+  // ScanMatch.cpp:35-40
+  ~ScanMatch() {
+    std::cout << "[ScanMatch]\n"
+              << " ,match_count:" << _match_count << " ,fail_match_count:" << _fail_match_count
+              << " ,averageScore:" << getAverageScore() << std::endl;
+    lslam_ctx_destroy(_ctx);
+  }
+  ScanMatch(const ScanMatch &) = delete;
+  ScanMatch &operator=(const ScanMatch &) = delete;
+
+  // ScanMatch.cpp:51-347 (Twist overload; selected when the pose type has rot_x/pos)
+  template <typename CloudPtr, typename TwistT>
+  auto scanMatchScan(const CloudPtr &referenceCornerCloud, const CloudPtr &referenceSurfCloud,
+                     const CloudPtr &CornerCloud, const CloudPtr &SurfCloud, TwistT &transform)
+      -> decltype(transform.rot_x.rad(), bool()) {
+    float pose[6] = {transform.rot_x.rad(), transform.rot_y.rad(), transform.rot_z.rad(),
+                     transform.pos(0), transform.pos(1), transform.pos(2)};
+    const bool ok = run(referenceCornerCloud, referenceSurfCloud, CornerCloud, SurfCloud, pose);
+    if (_last.status != LSLAM_TOO_FEW_REF) {  // pose written back on every other path
+      transform.rot_x = pose[0];
+      transform.rot_y = pose[1];
+      transform.rot_z = pose[2];
+      transform.pos(0) = pose[3];
+      transform.pos(1) = pose[4];
+      transform.pos(2) = pose[5];
+    }
+    return ok;
+  }
+
+  // ScanMatch.cpp:349-360 (Isometry3f overload): Isometry -> Twist -> match -> Isometry
+  // (selected when the pose type has matrix())
+  template <typename CloudPtr, typename Isometry>
+  auto scanMatchScan(const CloudPtr &referenceCornerCloud, const CloudPtr &referenceSurfCloud,
+                     const CloudPtr &CornerCloud, const CloudPtr &SurfCloud, Isometry &relative_pose)
+      -> decltype(relative_pose.matrix(), bool()) {
+    float T[16], pose[6];
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) T[r * 4 + c] = relative_pose.matrix()(r, c);
+    lslam_isometry_to_pose(T, pose);
+    const bool ok = run(referenceCornerCloud, referenceSurfCloud, CornerCloud, SurfCloud, pose);
+    lslam_pose_to_isometry(pose, T);  // the reference converts back unconditionally (:358)
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) relative_pose.matrix()(r, c) = T[r * 4 + c];
+    return ok;
+  }
+
+  inline double getAverageScore() { return (_match_count > 0) ? _total_score / _match_count : 0; }
+  const lslam_stats &lastStats() const { return _last; }
+  lslam_ctx *context() { return _ctx; }
+
+private:
+  template <typename CloudPtr>
+  bool run(const CloudPtr &rc, const CloudPtr &rs, const CloudPtr &c, const CloudPtr &s, float pose[6]) {
+    typedef decltype(rc->points.data()) P;
+    const size_t stride = sizeof(*P());
+    const int st = lslam_scanmatch_full(_ctx, rc->points.data(), rc->points.size(), rs->points.data(),
+                                        rs->points.size(), stride, c->points.data(), c->points.size(),
+                                        s->points.data(), s->points.size(), stride, pose, &_opts, &_last);
+    if (st < 0) {
+      std::cout << "[ScanMatch] backend error: " << lslam_last_error() << std::endl;
+      _last.status = st;
+      return false;
+    }
+    if (st == LSLAM_TOO_FEW_REF) {  // ScanMatch.cpp:57-61
+      std::cout << "reference cloud points too few." << std::endl;
+      return false;
+    }
+    if (st == LSLAM_OK) {  // :336-340
+      _total_score += _last.score;
+      _match_count++;
+      return true;
+    }
+    _fail_match_count++;  // :325,332,344
+    return false;
+  }
+
+  lslam_ctx *_ctx;
+  lslam_opts _opts;
+  lslam_stats _last{};
+  double _total_score;
+  long _match_count;
+  long _fail_match_count;
+};
+
+}  // namespace lidar_slam

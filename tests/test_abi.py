@@ -71,3 +71,19 @@ def test_no_gpu_fails_loudly(pkg):
         pkg.Context(0)
     assert e.value.code == pkg.Status.ERR_HIP
     assert "no CPU fallback" in str(e.value) or "HIP" in str(e.value)
+
+
+def test_cpp_shim_compiles_and_fails_loudly_without_gpu(pkg, tmp_path):
+    """include/lslam_scan_match.hpp (the reference's class surface over the C ABI) builds with
+    g++ -std=c++11 against stand-in cloud/pose types and links the product library."""
+    import subprocess
+    import torch
+    exe = tmp_path / "shim_test"
+    libdir = os.path.dirname(pkg.lib_path())
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "shim_compile_test.cpp"), "-o", str(exe),
+                           "-L", libdir, "-llslam_hip", "-Wl,-rpath," + libdir])
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the no-device branch is not reachable")
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "no CPU fallback" in out.stdout

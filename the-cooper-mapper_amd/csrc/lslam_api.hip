@@ -265,7 +265,7 @@ void lslam_default_opts(lslam_opts *o) {
   o->fine_score = 0;         // :32
   o->score_threshold = 800;  // :24
   o->match_percentage_threshold = 0.4;
-  o->jtj_mode = 0;
+  o->jtj_mode = 1;  // MFMA J^T J: measured >= the VALU path (profiles/), same sums to 1e-5
   o->profile = 0;
 }
 

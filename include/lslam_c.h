@@ -200,6 +200,57 @@ int lslam_gn_step(lslam_ctx *ctx, const float AtA[36], const float Atb[6], int32
                   float delta_t_abort, float x_out[6], float *delta_r, float *delta_t,
                   int32_t *converged);
 
+/* ---- SE(3) pose-graph Levenberg-Marquardt ------------------------------------
+ * Replaces pose_graph::SolverG2O (pose_graph/solver_g2o.cpp:51-95): add_se3_node /
+ * add_se3_edge build the arrays passed to lslam_pg_create, optimize() becomes
+ * lslam_pg_optimize.  g2o conventions (VertexSE3 / EdgeSE3 / "lm_var"): a pose is
+ * {tx,ty,tz, qx,qy,qz,qw}; an edge e has vertices ij[2e], ij[2e+1], measurement
+ * meas7[7e..] and a row-major 6x6 information matrix over [translation, rotation]
+ * (pose_graph/graph.cpp:279-288: diag(0.8,0.4,0.8,1,2,1) for odometry, :333-339: 2*I
+ * for loop closures); vertex `fixed_vertex` is held fixed (solver_g2o.cpp:55-59).  fp64.
+ *
+ * Multi-GPU (one process per GPU): every rank creates the same graph, calls
+ * lslam_pg_set_shard with its edge range and an all-reduce callback; the block system
+ * [diagonal blocks | off-diagonal blocks | b | chi2] is summed across ranks through the
+ * callback (RCCL over xGMI when the callback wraps torch.distributed.all_reduce on the
+ * buffer passed as system_buf), the damped solve is replicated. */
+typedef struct lslam_pg lslam_pg;
+
+typedef struct {
+  int32_t iterations;     /* LM iterations (SparseOptimizer::optimize return value) */
+  int32_t lm_trials;      /* damped solves, accepted + rejected */
+  int32_t cg_iterations;  /* total preconditioned-CG iterations */
+  int32_t status;
+  double chi2_initial, chi2_final, lambda;
+  float gpu_ms_total;
+  float pad;
+} lslam_pg_stats;
+
+/* In-place SUM over all ranks of `count` doubles at DEVICE address `buf`; must have
+ * completed when it returns. */
+typedef void (*lslam_allreduce_fn)(void *user, double *buf, size_t count);
+
+int lslam_pg_create(int device, int32_t n_vertices, const double *poses7, int32_t n_edges,
+                    const int32_t *ij, const double *meas7, const double *info36,
+                    int32_t fixed_vertex, lslam_pg **out);
+void lslam_pg_destroy(lslam_pg *pg);
+const char *lslam_pg_last_error(void);
+/* Edge shard [e_begin, e_end) of this rank; fn == NULL: single GPU.  system_buf: optional
+ * caller-owned DEVICE buffer of lslam_pg_system_doubles() doubles to assemble into. */
+int lslam_pg_set_shard(lslam_pg *pg, int32_t e_begin, int32_t e_end, lslam_allreduce_fn fn,
+                       void *user, double *system_buf);
+size_t lslam_pg_system_doubles(const lslam_pg *pg);
+int32_t lslam_pg_num_offdiag(const lslam_pg *pg);
+/* SolverG2O::optimize (solver_g2o.cpp:79-95): up to max_iters LM iterations. */
+int lslam_pg_optimize(lslam_pg *pg, int32_t max_iters, lslam_pg_stats *stats);
+int lslam_pg_get_poses(lslam_pg *pg, double *poses7);
+/* Parity taps: the assembled system at the current estimate (diag[n_v*36],
+ * off[n_off*36] with its (i<j) pairs off_ij[n_off*2], b[n_v*6], chi2), and one damped
+ * solve (H + lambda I) dx = b. Any output may be NULL. */
+int lslam_pg_linearize(lslam_pg *pg, double *diag_out, double *off_out, int32_t *off_ij_out,
+                       double *b_out, double *chi2_out);
+int lslam_pg_solve(lslam_pg *pg, double lambda, double *dx_out, int32_t *cg_iters);
+
 /* Device handle taps for harnesses that time on the library's stream. */
 void *lslam_stream(lslam_ctx *ctx); /* hipStream_t */
 

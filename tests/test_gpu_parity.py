@@ -302,3 +302,115 @@ def test_full_size_64ring_properties(ctx, synth):
     opts.jtj_mode = 1
     status4, pose4, st4 = ctx.run(pr["init_pose"], opts)
     assert st4.iterations == st.iterations and np.abs(pose4 - pose).max() <= POSE_TOL_M
+
+
+# ---------------------------------------------------------------------------------------
+# pose-graph LM (config 4): HIP kernels vs the numpy oracle (parity unpinned: no g2o here)
+# ---------------------------------------------------------------------------------------
+def _pg_oracle():
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import posegraph_oracle as po
+    return po
+
+
+def test_posegraph_linearize_matches_oracle(pkg):
+    po = _pg_oracle()
+    g = po.make_graph(n_kf=150, n_loop=500, laps=3, radius=18.0)
+    pg = pkg.PoseGraph(0)
+    pg.set_graph(g["init"], g["ij"], g["meas"], g["info"])
+    s = pg.linearize()
+    H, b, c2 = po.linearize(g["init"], g["ij"], g["meas"], g["info"])  # numeric Jacobians
+    Hd = H.toarray()
+    n = len(g["init"])
+    scale = np.abs(Hd).max()
+    assert abs(s["chi2"] - c2) <= 1e-10 * c2
+    for v in range(1, n):  # vertex 0 is fixed: identity block, zero rhs
+        assert np.abs(s["diag"][v] - Hd[6 * v:6 * v + 6, 6 * v:6 * v + 6]).max() <= 2e-6 * scale
+    assert np.array_equal(s["diag"][0], np.eye(6)) and not s["b"][:6].any()
+    assert np.abs(s["b"][6:] - b[6:]).max() <= 2e-6 * np.abs(b).max()
+    for (i, j), blk in zip(s["off_ij"], s["off"]):
+        ref = Hd[6 * i:6 * i + 6, 6 * j:6 * j + 6] if i != 0 else np.zeros((6, 6))
+        assert i < j and np.abs(blk - ref).max() <= 2e-6 * scale
+    # one damped solve against scipy's sparse LU on the oracle system
+    lam = 1e-5 * Hd.diagonal()[6:].max()
+    dx, cg = pg.solve(lam)
+    ref = po.solve_damped(H, b, lam, 0)
+    assert cg > 0 and np.abs(dx - ref).max() <= 1e-5 * np.abs(ref).max()
+    pg.close()
+
+
+def test_posegraph_optimize_matches_oracle(pkg):
+    po = _pg_oracle()
+    g = po.make_graph(n_kf=300, n_loop=1200, laps=3, radius=40.0)
+    pg = pkg.PoseGraph(0)
+    pg.set_graph(g["init"], g["ij"], g["meas"], g["info"])
+    iters = pg.optimize(8)
+    st = pg.last_stats
+    P, hist = po.optimize(g["init"], g["ij"], g["meas"], g["info"], max_iters=8)
+    assert iters == len(hist) == 8
+    assert abs(st.chi2_initial - po.chi2(g["init"], g["ij"], g["meas"], g["info"])) <= 1e-9 * st.chi2_initial
+    assert abs(st.chi2_final - hist[-1]["chi2"]) <= 1e-4 * hist[-1]["chi2"]
+    got = pg.poses()
+    assert np.abs(got[:, :3] - P[:, :3]).max() < 1e-4 and np.abs(got[:, 3:] - P[:, 3:]).max() < 1e-5
+    assert np.allclose(got[0], g["init"][0])
+    pg.close()
+
+
+def test_posegraph_solver_g2o_style_api(pkg):
+    """add_se3_node / add_se3_edge / optimize as pose_graph/solver_g2o.cpp:51-95, with the
+    information matrices of pose_graph/graph.cpp:279-288,333-339."""
+    po = _pg_oracle()
+    g = po.make_graph(n_kf=80, n_loop=200, laps=2, radius=14.0)
+    from importlib import import_module
+    pgm = import_module("the-cooper-mapper_amd.pose_graph")
+    pg = pkg.PoseGraph(0)
+    ids = [pg.add_se3_node(pgm.pose7_to_mat(p)) for p in g["init"]]
+    assert ids == list(range(80))
+    for (i, j), z, w in zip(g["ij"], g["meas"], g["info"]):
+        pg.add_se3_edge(i, j, pgm.pose7_to_mat(z), w)
+    c0 = po.chi2(g["init"], g["ij"], g["meas"], g["info"])
+    assert pg.optimize(10) >= 1
+    assert pg.last_stats.chi2_final < 1e-2 * c0
+    T0 = pg.estimate(0)
+    assert np.allclose(T0, pgm.pose7_to_mat(g["init"][0]))  # first node fixed
+    pg.close()
+
+
+def test_posegraph_sharded_equals_full(pkg):
+    """Two edge shards summed through the all-reduce hook (here: a local sum standing in
+    for RCCL) give the single-shard system."""
+    import torch
+    po = _pg_oracle()
+    g = po.make_graph(n_kf=100, n_loop=300, laps=2, radius=16.0)
+    full = pkg.PoseGraph(0)
+    full.set_graph(g["init"], g["ij"], g["meas"], g["info"])
+    ref = full.linearize()
+    ne = len(g["ij"])
+    parts = []
+    for a, e in ((0, ne // 2), (ne // 2, ne)):
+        p = pkg.PoseGraph(0)
+        p.set_graph(g["init"], g["ij"], g["meas"], g["info"])
+        p.set_shard(a, e)  # no all-reduce: raw shard contribution
+        parts.append(p.linearize())
+        p.close()
+    n = len(g["init"])
+    assert abs(parts[0]["chi2"] + parts[1]["chi2"] - ref["chi2"]) <= 1e-12 * ref["chi2"]
+    assert np.abs(parts[0]["b"] + parts[1]["b"] - ref["b"]).max() <= 1e-12 * np.abs(ref["b"]).max()
+    d = parts[0]["diag"] + parts[1]["diag"]
+    d[0] = np.eye(6)  # each raw shard carries the fixed vertex's identity block
+    assert np.abs(d - ref["diag"]).max() <= 1e-12 * np.abs(ref["diag"]).max()
+    assert np.abs(parts[0]["off"] + parts[1]["off"] - ref["off"]).max() <= 1e-12 * np.abs(ref["off"]).max()
+    # the hook itself: a "world" of one rank whose all-reduce doubles nothing
+    calls = []
+    hooked = pkg.PoseGraph(0)
+    hooked.set_graph(g["init"], g["ij"], g["meas"], g["info"])
+    sysbuf = torch.zeros(hooked.system_doubles(), dtype=torch.float64, device="cuda")
+    hooked.set_shard(0, ne, allreduce=lambda ptr, count: calls.append((ptr, count)), system_tensor=sysbuf)
+    got = hooked.linearize()
+    assert calls and calls[0][0] == sysbuf.data_ptr() and calls[0][1] == hooked.system_doubles()
+    assert np.abs(got["b"] - ref["b"]).max() <= 1e-12 * np.abs(ref["b"]).max()
+    assert abs(float(sysbuf[-1]) - ref["chi2"]) <= 1e-12 * ref["chi2"]
+    hooked.close()
+    full.close()

@@ -14,6 +14,7 @@ The directory name contains a hyphen, so import it with
 from .capi import (LslamError, LslamOpts, LslamStats, LslamMapInfo, Status, lib_path, load_library,
                    build_library)
 from .scan_match import Context, ScanMatch
+from .pose_graph import PoseGraph
 
-__all__ = ["Context", "ScanMatch", "LslamError", "LslamOpts", "LslamStats", "LslamMapInfo",
+__all__ = ["Context", "ScanMatch", "PoseGraph", "LslamError", "LslamOpts", "LslamStats", "LslamMapInfo",
            "Status", "lib_path", "load_library", "build_library"]

@@ -82,6 +82,23 @@ class LslamMapInfo(C.Structure):
     ]
 
 
+class LslamPgStats(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int32),
+        ("lm_trials", C.c_int32),
+        ("cg_iterations", C.c_int32),
+        ("status", C.c_int32),
+        ("chi2_initial", C.c_double),
+        ("chi2_final", C.c_double),
+        ("lambda_", C.c_double),
+        ("gpu_ms_total", C.c_float),
+        ("pad", C.c_float),
+    ]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
+c_double_p = C.POINTER(C.c_double)
+
 # every symbol include/lslam_c.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "lslam_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
@@ -110,6 +127,17 @@ SYMBOLS = {
                                 c_int32_p, C.c_float, C.c_float, c_float_p, c_float_p, c_float_p,
                                 c_int32_p]),
     "lslam_stream": (C.c_void_p, [C.c_void_p]),
+    "lslam_pg_create": (C.c_int, [C.c_int, C.c_int32, c_double_p, C.c_int32, c_int32_p, c_double_p, c_double_p,
+                                  C.c_int32, C.POINTER(C.c_void_p)]),
+    "lslam_pg_destroy": (None, [C.c_void_p]),
+    "lslam_pg_last_error": (C.c_char_p, []),
+    "lslam_pg_set_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, ALLREDUCE_FN, C.c_void_p, C.c_void_p]),
+    "lslam_pg_system_doubles": (C.c_size_t, [C.c_void_p]),
+    "lslam_pg_num_offdiag": (C.c_int32, [C.c_void_p]),
+    "lslam_pg_optimize": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(LslamPgStats)]),
+    "lslam_pg_get_poses": (C.c_int, [C.c_void_p, c_double_p]),
+    "lslam_pg_linearize": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_int32_p, c_double_p, c_double_p]),
+    "lslam_pg_solve": (C.c_int, [C.c_void_p, C.c_double, c_double_p, c_int32_p]),
 }
 
 

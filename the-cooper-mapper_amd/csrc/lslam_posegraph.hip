@@ -1,0 +1,919 @@
+// lslam_posegraph.hip -- SE(3) pose-graph Levenberg-Marquardt on gfx950 (fp64).
+//
+// Replaces pose_graph::SolverG2O (pose_graph/solver_g2o.cpp:51-95: add_se3_node,
+// add_se3_edge, optimize), i.e. g2o's VertexSE3 / EdgeSE3 / "lm_var".  g2o itself is not
+// under /root/reference (and not pinned by it): the conventions restated here are g2o's
+// published ones -- update X <- X * fromVectorMQT(d), error toVectorMQT(Z^-1 Xi^-1 Xj),
+// LM schedule of OptimizationAlgorithmLevenberg -- see oracle/posegraph_oracle.py.
+//
+// Data parallel structure
+//   pg_edge_kernel      one lane per edge of this rank's shard: error, analytic Jacobians,
+//                       J^T Omega J blocks, J^T Omega e, chi2 -> per-edge records
+//   pg_assemble_kernel  deterministic gather of the records into the block system
+//                       [diag blocks | off-diagonal blocks | b | chi2]  (fixed order, no atomics)
+//   (all-reduce of that buffer across ranks: callback, RCCL via torch.distributed)
+//   pg_expand / pg_precond / pg_spmv / pg_cg_*   replicated block-Jacobi PCG on (H + lambda I)
+//   pg_update_kernel    X <- X * fromVectorMQT(dx)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/lslam_c.h"
+
+namespace {
+
+#define PG_DEV __device__ __forceinline__
+
+struct Q4 { double x, y, z, w; };
+struct V3 { double x, y, z; };
+
+PG_DEV Q4 qmul(const Q4 &a, const Q4 &b) {
+  return {a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
+          a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+PG_DEV Q4 qconj(const Q4 &q) { return {-q.x, -q.y, -q.z, q.w}; }
+PG_DEV void qrotmat(const Q4 &q, double R[9]) {
+  const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+  const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+  R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+PG_DEV V3 mulR(const double R[9], const V3 &v) {
+  return {R[0] * v.x + R[1] * v.y + R[2] * v.z, R[3] * v.x + R[4] * v.y + R[5] * v.z,
+          R[6] * v.x + R[7] * v.y + R[8] * v.z};
+}
+PG_DEV V3 mulRt(const double R[9], const V3 &v) {
+  return {R[0] * v.x + R[3] * v.y + R[6] * v.z, R[1] * v.x + R[4] * v.y + R[7] * v.z,
+          R[2] * v.x + R[5] * v.y + R[8] * v.z};
+}
+PG_DEV void skew(const V3 &v, double S[9]) {
+  S[0] = 0; S[1] = -v.z; S[2] = v.y;
+  S[3] = v.z; S[4] = 0; S[5] = -v.x;
+  S[6] = -v.y; S[7] = v.x; S[8] = 0;
+}
+
+struct Pose { V3 t; Q4 q; };
+PG_DEV Pose load_pose(const double *p) { return {{p[0], p[1], p[2]}, {p[3], p[4], p[5], p[6]}}; }
+
+// e = toVectorMQT(Z^-1 * Xi^-1 * Xj); optionally the Jacobians w.r.t. the local updates.
+// Ji/Jj row-major 6x6.
+template <bool JAC>
+PG_DEV void edge_error(const Pose &xi, const Pose &xj, const Pose &z, double e[6], double *Ji,
+                       double *Jj) {
+  double Ri[9], Rz[9];
+  qrotmat(xi.q, Ri);
+  qrotmat(z.q, Rz);
+  const V3 d = {xj.t.x - xi.t.x, xj.t.y - xi.t.y, xj.t.z - xi.t.z};
+  const V3 tb = mulRt(Ri, d);                                  // Xi^-1 Xj translation
+  const Q4 qb = qmul(qconj(xi.q), xj.q);                       // Xi^-1 Xj rotation
+  const V3 te = mulRt(Rz, {tb.x - z.t.x, tb.y - z.t.y, tb.z - z.t.z});
+  Q4 qe = qmul(qconj(z.q), qb);
+  const double nrm = sqrt(qe.x * qe.x + qe.y * qe.y + qe.z * qe.z + qe.w * qe.w);
+  qe = {qe.x / nrm, qe.y / nrm, qe.z / nrm, qe.w / nrm};
+  const double sgn = qe.w < 0 ? -1.0 : 1.0;
+  qe = {sgn * qe.x, sgn * qe.y, sgn * qe.z, sgn * qe.w};
+  e[0] = te.x; e[1] = te.y; e[2] = te.z;
+  e[3] = qe.x; e[4] = qe.y; e[5] = qe.z;
+  if (!JAC) return;
+  // ---- vertex j: E' = E * Delta_j ------------------------------------------------
+  double Re[9];
+  qrotmat(qe, Re);
+  double Sv[9];
+  skew({qe.x, qe.y, qe.z}, Sv);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      Jj[r * 6 + c] = Re[r * 3 + c];                                  // d te / d dt_j = R_e
+      Jj[r * 6 + 3 + c] = 0.0;
+      Jj[(3 + r) * 6 + c] = 0.0;
+      Jj[(3 + r) * 6 + 3 + c] = (r == c ? qe.w : 0.0) + Sv[r * 3 + c];  // w_e I + [v_e]x
+    }
+  // ---- vertex i: E' = Z^-1 Delta_i^-1 Xi^-1 Xj ----------------------------------
+  // translation: -Rz^T ; Rz^T * 2 [t_b]x
+  double Stb[9];
+  skew(tb, Stb);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      Ji[r * 6 + c] = -Rz[c * 3 + r];
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) s += Rz[k * 3 + r] * 2.0 * Stb[k * 3 + c];
+      Ji[r * 6 + 3 + c] = s;
+      Ji[(3 + r) * 6 + c] = 0.0;
+    }
+  // rotation: q' = qz* (x) (1,-d) (x) qb ;  d q'_v / d d =
+  //   wz (-wb I + [vb]x) - vz vb^T - [vz]x (-wb I + [vb]x), times the sign of q_e
+  const V3 vb = {qb.x, qb.y, qb.z}, vz = {z.q.x, z.q.y, z.q.z};
+  double Sb[9], Sz[9], M[9];
+  skew(vb, Sb);
+  skew(vz, Sz);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) M[r * 3 + c] = (r == c ? -qb.w : 0.0) + Sb[r * 3 + c];
+  const double vzv[3] = {vz.x, vz.y, vz.z}, vbv[3] = {vb.x, vb.y, vb.z};
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double s = z.q.w * M[r * 3 + c] - vzv[r] * vbv[c];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) s -= Sz[r * 3 + k] * M[k * 3 + c];
+      Ji[(3 + r) * 6 + 3 + c] = sgn * s / nrm;
+    }
+}
+
+// Per-edge record: [Hii(36) bi(6) | Hjj(36) bj(6) | Hoff(36) | chi2] = 121 doubles
+constexpr int REC = 121;
+
+__global__ void pg_edge_kernel(const double *poses, const int32_t *ij, const double *meas,
+                               const double *info, int e_begin, int e_end, int fixed, double *rec) {
+  const int e = e_begin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= e_end) return;
+  const int i = ij[2 * e], j = ij[2 * e + 1];
+  const Pose xi = load_pose(poses + 7 * i), xj = load_pose(poses + 7 * j), z = load_pose(meas + 7 * e);
+  double er[6], Ji[36], Jj[36], Om[36];
+  edge_error<true>(xi, xj, z, er, Ji, Jj);
+#pragma unroll
+  for (int k = 0; k < 36; ++k) Om[k] = info[(size_t)e * 36 + k];
+  double *o = rec + (size_t)(e - e_begin) * REC;
+  // A = J^T Omega
+  double Ai[36], Aj[36];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double si = 0.0, sj = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        si += Ji[k * 6 + r] * Om[k * 6 + c];
+        sj += Jj[k * 6 + r] * Om[k * 6 + c];
+      }
+      Ai[r * 6 + c] = si;
+      Aj[r * 6 + c] = sj;
+    }
+  const bool fi = (i == fixed), fj = (j == fixed);
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double hii = 0.0, hjj = 0.0, hij = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        hii += Ai[r * 6 + k] * Ji[k * 6 + c];
+        hjj += Aj[r * 6 + k] * Jj[k * 6 + c];
+        hij += Ai[r * 6 + k] * Jj[k * 6 + c];
+      }
+      o[r * 6 + c] = fi ? 0.0 : hii;
+      o[42 + r * 6 + c] = fj ? 0.0 : hjj;
+      // off-diagonal block is stored for the pair (min,max): transposed when i > j
+      const double v = (fi || fj) ? 0.0 : hij;
+      if (i < j) o[84 + r * 6 + c] = v; else o[84 + c * 6 + r] = v;
+    }
+    double bi = 0.0, bj = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      bi += Ai[r * 6 + k] * er[k];
+      bj += Aj[r * 6 + k] * er[k];
+    }
+    o[36 + r] = fi ? 0.0 : -bi;
+    o[42 + 36 + r] = fj ? 0.0 : -bj;
+  }
+  double c2 = 0.0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) s += Om[r * 6 + c] * er[c];
+    c2 += er[r] * s;
+  }
+  o[120] = c2;
+}
+
+// chi2 only (trial evaluation): per-edge value
+__global__ void pg_chi2_kernel(const double *poses, const int32_t *ij, const double *meas,
+                               const double *info, int e_begin, int e_end, double *out) {
+  const int e = e_begin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= e_end) return;
+  const int i = ij[2 * e], j = ij[2 * e + 1];
+  const Pose xi = load_pose(poses + 7 * i), xj = load_pose(poses + 7 * j), z = load_pose(meas + 7 * e);
+  double er[6];
+  edge_error<false>(xi, xj, z, er, nullptr, nullptr);
+  double c2 = 0.0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) s += info[(size_t)e * 36 + r * 6 + c] * er[c];
+    c2 += er[r] * s;
+  }
+  out[e - e_begin] = c2;
+}
+
+// fixed-order sum of n doubles into *dst (+ optional add), single block
+__global__ void pg_sum_kernel(const double *src, int n, int stride, double *dst) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int k = threadIdx.x; k < n; k += 256) s += src[(size_t)k * stride];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *dst = sh[0];
+}
+
+// Gather the per-edge records into the block system, fixed order (edge index order).
+// vertex part: thread per (vertex, k<42): sum over incident shard edges.
+__global__ void pg_assemble_vertex_kernel(const double *rec, const int32_t *v_ptr, const int32_t *v_adj,
+                                          int n_v, int fixed, double *diag, double *b) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int v = t / 42, k = t % 42;
+  if (v >= n_v) return;
+  double s = 0.0;
+  for (int a = v_ptr[v]; a < v_ptr[v + 1]; ++a) {
+    const int code = v_adj[a];  // (local edge << 1) | role
+    s += rec[(size_t)(code >> 1) * REC + (code & 1) * 42 + k];
+  }
+  if (v == fixed) s = (k < 36 && (k / 6 == k % 6)) ? 1.0 : 0.0;  // identity row: dx_fixed = 0
+  if (k < 36) diag[(size_t)v * 36 + k] = s; else b[(size_t)v * 6 + (k - 36)] = s;
+}
+__global__ void pg_assemble_off_kernel(const double *rec, const int32_t *o_ptr, const int32_t *o_adj,
+                                       int n_off, double *off) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int blk = t / 36, k = t % 36;
+  if (blk >= n_off) return;
+  double s = 0.0;
+  for (int a = o_ptr[blk]; a < o_ptr[blk + 1]; ++a) s += rec[(size_t)o_adj[a] * REC + 84 + k];
+  off[(size_t)blk * 36 + k] = s;
+}
+
+// Full block-CSR copy of the symmetric system for the solver: entry a of row v refers to
+// block `src` (diag: v; off: n_v + id), transposed or not.
+__global__ void pg_expand_kernel(const double *sys, const int32_t *row_src, int n_entries, double lambda,
+                                 double *vals) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int a = t / 36, k = t % 36;
+  if (a >= n_entries) return;
+  const int code = row_src[a];  // (block index in [diag|off] << 2) | transposed<<1 | is_diag
+  const int blk = code >> 2;
+  const bool tr = (code & 2) != 0, dg = (code & 1) != 0;
+  const int r = k / 6, c = k % 6;
+  double v = sys[(size_t)blk * 36 + (tr ? c * 6 + r : k)];
+  if (dg && r == c) v += lambda;
+  vals[(size_t)a * 36 + k] = v;
+}
+
+// block-Jacobi preconditioner: inverse of the (damped) 6x6 diagonal blocks via Cholesky
+__global__ void pg_precond_kernel(const double *vals, const int32_t *row_ptr, int n_v, double *minv) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n_v) return;
+  const double *A = vals + (size_t)row_ptr[v] * 36;  // the diagonal entry is first in its row
+  double L[36];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) L[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      double s = A[i * 6 + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * L[j * 6 + k];
+      L[i * 6 + j] = (i == j) ? sqrt(s > 1e-300 ? s : 1e-300) : s / L[j * 6 + j];
+    }
+  // inverse: solve L L^T X = I column by column
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      double s = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k];
+      y[i] = s / L[i * 6 + i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+      double s = y[i];
+#pragma unroll
+      for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * y[k];
+      y[i] = s / L[i * 6 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) minv[(size_t)v * 36 + i * 6 + c] = y[i];
+  }
+}
+
+// ---- PCG on the expanded block-CSR, one thread per scalar row ---------------------
+// scal: [0] rz_old  [1] alpha-den (p.q)  [2] rz_new  [3] rr  [4] bb  [5] done flag (as double)
+constexpr int CG_BLOCK = 256;
+constexpr int CG_ROWS = 252;  // rows per block: a multiple of 6, so a vertex never straddles blocks
+
+PG_DEV double block_sum(double v, double *sh) {
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int w = CG_BLOCK / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  const double r = sh[0];
+  __syncthreads();
+  return r;
+}
+PG_DEV double sum_partials(const double *part, int n) {  // every thread, fixed order
+  double s = 0.0;
+  for (int k = 0; k < n; ++k) s += part[k];
+  return s;
+}
+
+struct CgArgs {
+  const double *vals;
+  const int32_t *row_ptr, *row_col;
+  const double *minv;
+  const double *b;
+  double *x, *r, *z, *p, *q;
+  double *part_pq, *part_rz, *part_rr;  // [n_blocks]
+  double *scal;
+  int n6, n_blocks;
+  double tol2;
+};
+
+__global__ __launch_bounds__(CG_BLOCK) void pg_cg_init_kernel(CgArgs a) {
+  __shared__ double sh[CG_BLOCK];
+  const int row = blockIdx.x * CG_ROWS + threadIdx.x;
+  double rz = 0.0, bb = 0.0;
+  if (threadIdx.x < CG_ROWS && row < a.n6) {
+    const int v = row / 6, rr = row % 6;
+    a.x[row] = 0.0;
+    const double bi = a.b[row];
+    a.r[row] = bi;
+    double z = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) z += a.minv[(size_t)v * 36 + rr * 6 + c] * a.b[v * 6 + c];
+    a.z[row] = z;
+    a.p[row] = z;
+    rz = bi * z;
+    bb = bi * bi;
+  }
+  const double s1 = block_sum(rz, sh), s2 = block_sum(bb, sh);
+  if (threadIdx.x == 0) {
+    a.part_rz[blockIdx.x] = s1;
+    a.part_rr[blockIdx.x] = s2;
+  }
+}
+__global__ void pg_cg_init2_kernel(CgArgs a) {  // single thread: scalars of iteration 0
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double rz = sum_partials(a.part_rz, a.n_blocks), bb = sum_partials(a.part_rr, a.n_blocks);
+  a.scal[0] = rz;
+  a.scal[4] = bb;
+  a.scal[5] = (bb == 0.0) ? 1.0 : 0.0;
+  a.scal[6] = 0.0;  // iterations done
+}
+
+// q = A p ; partial p.q
+__global__ __launch_bounds__(CG_BLOCK) void pg_cg_spmv_kernel(CgArgs a) {
+  __shared__ double sh[CG_BLOCK];
+  if (a.scal[5] != 0.0) return;
+  const int row = blockIdx.x * CG_ROWS + threadIdx.x;
+  double pq = 0.0;
+  if (threadIdx.x < CG_ROWS && row < a.n6) {
+    const int v = row / 6, rr = row % 6;
+    double s = 0.0;
+    for (int e = a.row_ptr[v]; e < a.row_ptr[v + 1]; ++e) {
+      const double *A = a.vals + (size_t)e * 36 + rr * 6;
+      const double *pc = a.p + (size_t)a.row_col[e] * 6;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) s += A[c] * pc[c];
+    }
+    a.q[row] = s;
+    pq = a.p[row] * s;
+  }
+  const double s1 = block_sum(pq, sh);
+  if (threadIdx.x == 0) a.part_pq[blockIdx.x] = s1;
+}
+// x += alpha p ; r -= alpha q ; z = M r ; partial r.z, r.r
+__global__ __launch_bounds__(CG_BLOCK) void pg_cg_update_kernel(CgArgs a) {
+  __shared__ double sh[CG_BLOCK];
+  __shared__ double rloc[CG_BLOCK];
+  if (a.scal[5] != 0.0) return;
+  const double alpha = a.scal[0] / sum_partials(a.part_pq, a.n_blocks);
+  const int row = blockIdx.x * CG_ROWS + threadIdx.x;
+  const bool on = threadIdx.x < CG_ROWS && row < a.n6;
+  double rnew = 0.0;
+  if (on) {
+    a.x[row] += alpha * a.p[row];
+    rnew = a.r[row] - alpha * a.q[row];
+    a.r[row] = rnew;
+  }
+  rloc[threadIdx.x] = rnew;
+  __syncthreads();
+  double rz = 0.0, rr = 0.0;
+  if (on) {
+    const int v = row / 6, rrow = row % 6;
+    const int base = (int)threadIdx.x - rrow;  // this vertex's 6 residuals sit in this block
+    double z = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) z += a.minv[(size_t)v * 36 + rrow * 6 + c] * rloc[base + c];
+    a.z[row] = z;
+    rz = rnew * z;
+    rr = rnew * rnew;
+  }
+  const double s1 = block_sum(rz, sh), s2 = block_sum(rr, sh);
+  if (threadIdx.x == 0) {
+    a.part_rz[blockIdx.x] = s1;
+    a.part_rr[blockIdx.x] = s2;
+  }
+}
+// p = z + beta p ; rotate scalars ; convergence
+__global__ __launch_bounds__(CG_BLOCK) void pg_cg_dir_kernel(CgArgs a) {
+  if (a.scal[5] != 0.0) return;
+  const double rz_new = sum_partials(a.part_rz, a.n_blocks);
+  const double beta = rz_new / a.scal[0];
+  const int row = blockIdx.x * CG_ROWS + threadIdx.x;
+  if (threadIdx.x < CG_ROWS && row < a.n6) a.p[row] = a.z[row] + beta * a.p[row];
+  // the scalars are rewritten by the last block to finish reading them: use a separate
+  // tiny kernel instead (pg_cg_rotate_kernel) to stay race free
+}
+__global__ void pg_cg_rotate_kernel(CgArgs a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (a.scal[5] != 0.0) return;
+  const double rz_new = sum_partials(a.part_rz, a.n_blocks);
+  const double rr = sum_partials(a.part_rr, a.n_blocks);
+  a.scal[0] = rz_new;
+  a.scal[3] = rr;
+  a.scal[6] += 1.0;
+  if (rr <= a.tol2 * a.scal[4] || !(rz_new > 0.0)) a.scal[5] = 1.0;
+}
+
+// X <- X * fromVectorMQT(dx)
+__global__ void pg_update_kernel(const double *src, const double *dx, int n_v, int fixed, double *dst) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n_v) return;
+  const Pose x = load_pose(src + 7 * v);
+  double d[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) d[k] = (v == fixed) ? 0.0 : dx[v * 6 + k];
+  const double w2 = 1.0 - (d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+  Q4 dq = {d[3], d[4], d[5], sqrt(w2 > 0 ? w2 : 0.0)};
+  if (w2 < 0) dq = {0, 0, 0, 1};
+  double R[9];
+  qrotmat(x.q, R);
+  const V3 t = mulR(R, {d[0], d[1], d[2]});
+  Q4 q = qmul(x.q, dq);
+  const double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  double *o = dst + 7 * v;
+  o[0] = x.t.x + t.x; o[1] = x.t.y + t.y; o[2] = x.t.z + t.z;
+  o[3] = q.x / n; o[4] = q.y / n; o[5] = q.z / n; o[6] = q.w / n;
+}
+
+__global__ void pg_dot_scale_kernel(const double *dx, const double *b, int n6, double lambda, double *part) {
+  __shared__ double sh[CG_BLOCK];
+  const int row = blockIdx.x * CG_ROWS + threadIdx.x;
+  const double v = (threadIdx.x < CG_ROWS && row < n6) ? dx[row] * (lambda * dx[row] + b[row]) : 0.0;
+  const double s = block_sum(v, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void pg_maxdiag_kernel(const double *diag, int n_v, int fixed, double *out) {
+  __shared__ double sh[256];
+  double m = 0.0;
+  for (int k = threadIdx.x; k < n_v * 6; k += 256) {
+    const int v = k / 6, r = k % 6;
+    if (v != fixed) m = fmax(m, diag[(size_t)v * 36 + r * 6 + r]);
+  }
+  sh[threadIdx.x] = m;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + w]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = sh[0];
+}
+
+thread_local std::string g_pg_err;
+#define PG_TRY(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      char _b[512];                                                                      \
+      snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      g_pg_err = _b;                                                                     \
+      return LSLAM_ERR_HIP;                                                              \
+    }                                                                                    \
+  } while (0)
+
+template <typename T>
+hipError_t dev_upload(T **d, const std::vector<T> &h) {
+  hipError_t e = hipMalloc((void **)d, std::max<size_t>(1, h.size()) * sizeof(T));
+  if (e != hipSuccess) return e;
+  if (!h.empty()) e = hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+  return e;
+}
+
+}  // namespace
+
+struct lslam_pg {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int n_v = 0, n_e = 0, fixed = 0, n_off = 0, n_entries = 0;
+  int e_begin = 0, e_end = 0;
+  lslam_allreduce_fn allreduce = nullptr;
+  void *allreduce_user = nullptr;
+  // graph
+  double *d_poses = nullptr, *d_trial = nullptr, *d_meas = nullptr, *d_info = nullptr;
+  int32_t *d_ij = nullptr;
+  std::vector<int32_t> h_ij;
+  std::vector<int32_t> edge_block;  // per edge: off-diagonal block id
+  std::vector<int32_t> off_pairs;   // [n_off][2]
+  // shard structures
+  double *d_rec = nullptr, *d_chi = nullptr;
+  int32_t *d_vptr = nullptr, *d_vadj = nullptr, *d_optr = nullptr, *d_oadj = nullptr;
+  // system buffer [diag | off | b | chi2]; owned unless supplied by the caller
+  double *d_sys = nullptr;
+  bool own_sys = true;
+  // solver
+  int32_t *d_row_ptr = nullptr, *d_row_col = nullptr, *d_row_src = nullptr;
+  double *d_vals = nullptr, *d_minv = nullptr;
+  double *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_p = nullptr, *d_q = nullptr;
+  double *d_part = nullptr, *d_scal = nullptr, *d_tmp = nullptr;
+  int n_cg_blocks = 0;
+  size_t sys_doubles() const { return (size_t)n_v * 36 + (size_t)n_off * 36 + (size_t)n_v * 6 + 1; }
+  double *diag() const { return d_sys; }
+  double *off() const { return d_sys + (size_t)n_v * 36; }
+  double *b() const { return d_sys + (size_t)n_v * 36 + (size_t)n_off * 36; }
+  double *chi() const { return b() + (size_t)n_v * 6; }
+};
+
+namespace {
+
+int build_shard(lslam_pg *pg, int e_begin, int e_end) {
+  for (void *p : {(void *)pg->d_rec, (void *)pg->d_chi, (void *)pg->d_vptr, (void *)pg->d_vadj,
+                  (void *)pg->d_optr, (void *)pg->d_oadj})
+    if (p) (void)hipFree(p);
+  pg->d_rec = pg->d_chi = nullptr;
+  pg->d_vptr = pg->d_vadj = pg->d_optr = pg->d_oadj = nullptr;
+  pg->e_begin = e_begin;
+  pg->e_end = e_end;
+  const int ne = e_end - e_begin;
+  std::vector<int32_t> vptr(pg->n_v + 1, 0), optr(pg->n_off + 1, 0);
+  for (int e = e_begin; e < e_end; ++e) {
+    vptr[pg->h_ij[2 * e] + 1]++;
+    vptr[pg->h_ij[2 * e + 1] + 1]++;
+    optr[pg->edge_block[e] + 1]++;
+  }
+  for (int v = 0; v < pg->n_v; ++v) vptr[v + 1] += vptr[v];
+  for (int k = 0; k < pg->n_off; ++k) optr[k + 1] += optr[k];
+  std::vector<int32_t> vadj(2 * (size_t)ne), oadj((size_t)ne), vc(vptr.begin(), vptr.end() - 1),
+      oc(optr.begin(), optr.end() - 1);
+  for (int e = e_begin; e < e_end; ++e) {  // edge order = summation order
+    const int le = e - e_begin;
+    vadj[vc[pg->h_ij[2 * e]]++] = (le << 1) | 0;
+    vadj[vc[pg->h_ij[2 * e + 1]]++] = (le << 1) | 1;
+    oadj[oc[pg->edge_block[e]]++] = le;
+  }
+  PG_TRY(hipMalloc((void **)&pg->d_rec, std::max<size_t>(1, (size_t)ne) * REC * sizeof(double)));
+  PG_TRY(hipMalloc((void **)&pg->d_chi, std::max<size_t>(1, (size_t)ne) * sizeof(double)));
+  PG_TRY(dev_upload(&pg->d_vptr, vptr));
+  PG_TRY(dev_upload(&pg->d_vadj, vadj));
+  PG_TRY(dev_upload(&pg->d_optr, optr));
+  PG_TRY(dev_upload(&pg->d_oadj, oadj));
+  return LSLAM_OK;
+}
+
+// system of this shard's edges into pg->d_sys, then the all-reduce over ranks
+int linearize(lslam_pg *pg, const double *poses) {
+  const int ne = pg->e_end - pg->e_begin;
+  if (ne > 0)
+    hipLaunchKernelGGL(pg_edge_kernel, dim3((ne + 127) / 128), dim3(128), 0, pg->stream, poses, pg->d_ij,
+                       pg->d_meas, pg->d_info, pg->e_begin, pg->e_end, pg->fixed, pg->d_rec);
+  hipLaunchKernelGGL(pg_assemble_vertex_kernel, dim3((pg->n_v * 42 + 255) / 256), dim3(256), 0, pg->stream,
+                     pg->d_rec, pg->d_vptr, pg->d_vadj, pg->n_v, pg->allreduce ? -1 : pg->fixed,
+                     pg->diag(), pg->b());
+  if (pg->n_off > 0)
+    hipLaunchKernelGGL(pg_assemble_off_kernel, dim3((pg->n_off * 36 + 255) / 256), dim3(256), 0, pg->stream,
+                       pg->d_rec, pg->d_optr, pg->d_oadj, pg->n_off, pg->off());
+  hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(256), 0, pg->stream, pg->d_rec + 120, ne, REC, pg->chi());
+  PG_TRY(hipGetLastError());
+  if (pg->allreduce) {
+    PG_TRY(hipStreamSynchronize(pg->stream));
+    pg->allreduce(pg->allreduce_user, pg->d_sys, pg->sys_doubles());
+    // identity block of the fixed vertex after the sum over ranks
+    std::vector<double> I(36, 0.0);
+    for (int k = 0; k < 6; ++k) I[k * 7] = 1.0;
+    if (pg->fixed >= 0)
+      PG_TRY(hipMemcpyAsync(pg->diag() + (size_t)pg->fixed * 36, I.data(), 36 * sizeof(double),
+                            hipMemcpyHostToDevice, pg->stream));
+    PG_TRY(hipStreamSynchronize(pg->stream));
+  }
+  return LSLAM_OK;
+}
+
+int eval_chi2(lslam_pg *pg, const double *poses, double *out) {
+  const int ne = pg->e_end - pg->e_begin;
+  if (ne > 0)
+    hipLaunchKernelGGL(pg_chi2_kernel, dim3((ne + 127) / 128), dim3(128), 0, pg->stream, poses, pg->d_ij,
+                       pg->d_meas, pg->d_info, pg->e_begin, pg->e_end, pg->d_chi);
+  hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(256), 0, pg->stream, pg->d_chi, ne, 1, pg->d_tmp);
+  PG_TRY(hipGetLastError());
+  if (pg->allreduce) {
+    PG_TRY(hipStreamSynchronize(pg->stream));
+    pg->allreduce(pg->allreduce_user, pg->d_tmp, 1);
+  }
+  PG_TRY(hipMemcpyAsync(out, pg->d_tmp, sizeof(double), hipMemcpyDeviceToHost, pg->stream));
+  PG_TRY(hipStreamSynchronize(pg->stream));
+  return LSLAM_OK;
+}
+
+// (H + lambda I) dx = b by block-Jacobi PCG; returns iterations
+int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
+  const int n6 = pg->n_v * 6;
+  hipLaunchKernelGGL(pg_expand_kernel, dim3((pg->n_entries * 36 + 255) / 256), dim3(256), 0, pg->stream,
+                     pg->d_sys, pg->d_row_src, pg->n_entries, lambda, pg->d_vals);
+  hipLaunchKernelGGL(pg_precond_kernel, dim3((pg->n_v + 63) / 64), dim3(64), 0, pg->stream, pg->d_vals,
+                     pg->d_row_ptr, pg->n_v, pg->d_minv);
+  CgArgs a;
+  a.vals = pg->d_vals;
+  a.row_ptr = pg->d_row_ptr;
+  a.row_col = pg->d_row_col;
+  a.minv = pg->d_minv;
+  a.b = pg->b();
+  a.x = pg->d_x; a.r = pg->d_r; a.z = pg->d_z; a.p = pg->d_p; a.q = pg->d_q;
+  a.part_pq = pg->d_part;
+  a.part_rz = pg->d_part + pg->n_cg_blocks;
+  a.part_rr = pg->d_part + 2 * pg->n_cg_blocks;
+  a.scal = pg->d_scal;
+  a.n6 = n6;
+  a.n_blocks = pg->n_cg_blocks;
+  a.tol2 = tol * tol;
+  const dim3 g(pg->n_cg_blocks), blk(CG_BLOCK);
+  hipLaunchKernelGGL(pg_cg_init_kernel, g, blk, 0, pg->stream, a);
+  hipLaunchKernelGGL(pg_cg_init2_kernel, dim3(1), dim3(1), 0, pg->stream, a);
+  double scal[8] = {0};
+  int done_iters = 0;
+  for (int it = 0; it < max_cg;) {
+    const int chunk = std::min(50, max_cg - it);
+    for (int k = 0; k < chunk; ++k) {
+      hipLaunchKernelGGL(pg_cg_spmv_kernel, g, blk, 0, pg->stream, a);
+      hipLaunchKernelGGL(pg_cg_update_kernel, g, blk, 0, pg->stream, a);
+      hipLaunchKernelGGL(pg_cg_dir_kernel, g, blk, 0, pg->stream, a);
+      hipLaunchKernelGGL(pg_cg_rotate_kernel, dim3(1), dim3(1), 0, pg->stream, a);
+    }
+    it += chunk;
+    PG_TRY(hipMemcpyAsync(scal, pg->d_scal, sizeof(scal), hipMemcpyDeviceToHost, pg->stream));
+    PG_TRY(hipStreamSynchronize(pg->stream));
+    done_iters = (int)scal[6];
+    if (scal[5] != 0.0) break;
+  }
+  PG_TRY(hipGetLastError());
+  *iters_out = done_iters;
+  return LSLAM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *lslam_pg_last_error(void) { return g_pg_err.c_str(); }
+
+int lslam_pg_create(int device, int32_t n_v, const double *poses7, int32_t n_e, const int32_t *ij,
+                    const double *meas7, const double *info36, int32_t fixed_vertex, lslam_pg **out) {
+  if (!out || n_v <= 0 || n_e < 0 || !poses7 || (n_e && (!ij || !meas7 || !info36)) || fixed_vertex >= n_v) {
+    g_pg_err = "bad pose-graph arguments";
+    return LSLAM_ERR_INVALID;
+  }
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    g_pg_err = "no HIP device available; this backend has no CPU fallback";
+    return LSLAM_ERR_HIP;
+  }
+  PG_TRY(hipSetDevice(device));
+  for (int e = 0; e < n_e; ++e)
+    if (ij[2 * e] < 0 || ij[2 * e] >= n_v || ij[2 * e + 1] < 0 || ij[2 * e + 1] >= n_v || ij[2 * e] == ij[2 * e + 1]) {
+      g_pg_err = "edge endpoint out of range";
+      return LSLAM_ERR_INVALID;
+    }
+  lslam_pg *pg = new lslam_pg();
+  pg->device = device;
+  pg->n_v = n_v;
+  pg->n_e = n_e;
+  pg->fixed = fixed_vertex;
+  PG_TRY(hipStreamCreateWithFlags(&pg->stream, hipStreamNonBlocking));
+  pg->h_ij.assign(ij, ij + 2 * (size_t)n_e);
+  // off-diagonal block ids: distinct (min,max) pairs in first-appearance order of a sorted map
+  std::map<std::pair<int, int>, int> ids;
+  for (int e = 0; e < n_e; ++e) ids.emplace(std::minmax(ij[2 * e], ij[2 * e + 1]), 0);
+  int nid = 0;
+  for (auto &kv : ids) kv.second = nid++;
+  pg->n_off = nid;
+  pg->off_pairs.resize(2 * (size_t)nid);
+  for (auto &kv : ids) {
+    pg->off_pairs[2 * kv.second] = kv.first.first;
+    pg->off_pairs[2 * kv.second + 1] = kv.first.second;
+  }
+  pg->edge_block.resize(n_e);
+  for (int e = 0; e < n_e; ++e) pg->edge_block[e] = ids[std::minmax(ij[2 * e], ij[2 * e + 1])];
+  // solver block-CSR: row v = [diag, then neighbours in block-id order]
+  std::vector<std::vector<std::pair<int, int>>> rows(n_v);  // (col, code)
+  for (int v = 0; v < n_v; ++v) rows[v].push_back({v, (v << 2) | 1});
+  for (int k = 0; k < nid; ++k) {
+    const int a = pg->off_pairs[2 * k], b = pg->off_pairs[2 * k + 1];
+    rows[a].push_back({b, ((n_v + k) << 2) | 0});
+    rows[b].push_back({a, ((n_v + k) << 2) | 2});
+  }
+  std::vector<int32_t> rptr(n_v + 1, 0), rcol, rsrc;
+  for (int v = 0; v < n_v; ++v) {
+    rptr[v + 1] = rptr[v] + (int)rows[v].size();
+    for (auto &pr : rows[v]) {
+      rcol.push_back(pr.first);
+      rsrc.push_back(pr.second);
+    }
+  }
+  pg->n_entries = (int)rcol.size();
+  std::vector<double> hp(poses7, poses7 + 7 * (size_t)n_v), hm(meas7, meas7 + 7 * (size_t)n_e),
+      hi(info36, info36 + 36 * (size_t)n_e);
+  PG_TRY(dev_upload(&pg->d_poses, hp));
+  PG_TRY(dev_upload(&pg->d_trial, hp));
+  PG_TRY(dev_upload(&pg->d_meas, hm));
+  PG_TRY(dev_upload(&pg->d_info, hi));
+  PG_TRY(dev_upload(&pg->d_ij, pg->h_ij));
+  PG_TRY(dev_upload(&pg->d_row_ptr, rptr));
+  PG_TRY(dev_upload(&pg->d_row_col, rcol));
+  PG_TRY(dev_upload(&pg->d_row_src, rsrc));
+  const size_t n6 = (size_t)n_v * 6;
+  pg->n_cg_blocks = (int)((n6 + CG_ROWS - 1) / CG_ROWS);
+  PG_TRY(hipMalloc((void **)&pg->d_sys, pg->sys_doubles() * sizeof(double)));
+  PG_TRY(hipMalloc((void **)&pg->d_vals, (size_t)pg->n_entries * 36 * sizeof(double)));
+  PG_TRY(hipMalloc((void **)&pg->d_minv, (size_t)n_v * 36 * sizeof(double)));
+  for (double **p : {&pg->d_x, &pg->d_r, &pg->d_z, &pg->d_p, &pg->d_q})
+    PG_TRY(hipMalloc((void **)p, n6 * sizeof(double)));
+  PG_TRY(hipMalloc((void **)&pg->d_part, 3 * (size_t)pg->n_cg_blocks * sizeof(double)));
+  PG_TRY(hipMalloc((void **)&pg->d_scal, 8 * sizeof(double)));
+  PG_TRY(hipMalloc((void **)&pg->d_tmp, 8 * sizeof(double)));
+  int rc = build_shard(pg, 0, n_e);
+  if (rc) return rc;
+  *out = pg;
+  return LSLAM_OK;
+}
+
+void lslam_pg_destroy(lslam_pg *pg) {
+  if (!pg) return;
+  (void)hipSetDevice(pg->device);
+  if (pg->stream) (void)hipStreamSynchronize(pg->stream);
+  for (void *p : {(void *)pg->d_poses, (void *)pg->d_trial, (void *)pg->d_meas, (void *)pg->d_info,
+                  (void *)pg->d_ij, (void *)pg->d_rec, (void *)pg->d_chi, (void *)pg->d_vptr,
+                  (void *)pg->d_vadj, (void *)pg->d_optr, (void *)pg->d_oadj, (void *)pg->d_row_ptr,
+                  (void *)pg->d_row_col, (void *)pg->d_row_src, (void *)pg->d_vals, (void *)pg->d_minv,
+                  (void *)pg->d_x, (void *)pg->d_r, (void *)pg->d_z, (void *)pg->d_p, (void *)pg->d_q,
+                  (void *)pg->d_part, (void *)pg->d_scal, (void *)pg->d_tmp})
+    if (p) (void)hipFree(p);
+  if (pg->own_sys && pg->d_sys) (void)hipFree(pg->d_sys);
+  if (pg->stream) (void)hipStreamDestroy(pg->stream);
+  delete pg;
+}
+
+size_t lslam_pg_system_doubles(const lslam_pg *pg) { return pg ? pg->sys_doubles() : 0; }
+int32_t lslam_pg_num_offdiag(const lslam_pg *pg) { return pg ? pg->n_off : 0; }
+
+int lslam_pg_set_shard(lslam_pg *pg, int32_t e_begin, int32_t e_end, lslam_allreduce_fn fn, void *user,
+                       double *system_buf) {
+  if (!pg || e_begin < 0 || e_end < e_begin || e_end > pg->n_e) {
+    g_pg_err = "bad shard";
+    return LSLAM_ERR_INVALID;
+  }
+  PG_TRY(hipSetDevice(pg->device));
+  pg->allreduce = fn;
+  pg->allreduce_user = user;
+  if (system_buf) {
+    if (pg->own_sys && pg->d_sys) (void)hipFree(pg->d_sys);
+    pg->d_sys = system_buf;
+    pg->own_sys = false;
+  }
+  return build_shard(pg, e_begin, e_end);
+}
+
+int lslam_pg_linearize(lslam_pg *pg, double *diag_out, double *off_out, int32_t *off_ij_out, double *b_out,
+                       double *chi2_out) {
+  if (!pg) return LSLAM_ERR_INVALID;
+  PG_TRY(hipSetDevice(pg->device));
+  int rc = linearize(pg, pg->d_poses);
+  if (rc) return rc;
+  if (diag_out) PG_TRY(hipMemcpyAsync(diag_out, pg->diag(), (size_t)pg->n_v * 36 * 8, hipMemcpyDeviceToHost, pg->stream));
+  if (off_out) PG_TRY(hipMemcpyAsync(off_out, pg->off(), (size_t)pg->n_off * 36 * 8, hipMemcpyDeviceToHost, pg->stream));
+  if (b_out) PG_TRY(hipMemcpyAsync(b_out, pg->b(), (size_t)pg->n_v * 6 * 8, hipMemcpyDeviceToHost, pg->stream));
+  if (chi2_out) PG_TRY(hipMemcpyAsync(chi2_out, pg->chi(), 8, hipMemcpyDeviceToHost, pg->stream));
+  PG_TRY(hipStreamSynchronize(pg->stream));
+  if (off_ij_out) std::memcpy(off_ij_out, pg->off_pairs.data(), pg->off_pairs.size() * sizeof(int32_t));
+  return LSLAM_OK;
+}
+
+int lslam_pg_solve(lslam_pg *pg, double lambda, double *dx_out, int32_t *cg_iters) {
+  if (!pg) return LSLAM_ERR_INVALID;
+  PG_TRY(hipSetDevice(pg->device));
+  int it = 0;
+  int rc = solve(pg, lambda, 4000, 1e-10, &it);
+  if (rc) return rc;
+  if (dx_out) {
+    PG_TRY(hipMemcpyAsync(dx_out, pg->d_x, (size_t)pg->n_v * 6 * 8, hipMemcpyDeviceToHost, pg->stream));
+    PG_TRY(hipStreamSynchronize(pg->stream));
+  }
+  if (cg_iters) *cg_iters = it;
+  return LSLAM_OK;
+}
+
+int lslam_pg_get_poses(lslam_pg *pg, double *poses7) {
+  if (!pg || !poses7) return LSLAM_ERR_INVALID;
+  PG_TRY(hipSetDevice(pg->device));
+  PG_TRY(hipMemcpyAsync(poses7, pg->d_poses, (size_t)pg->n_v * 7 * 8, hipMemcpyDeviceToHost, pg->stream));
+  PG_TRY(hipStreamSynchronize(pg->stream));
+  return LSLAM_OK;
+}
+
+// g2o OptimizationAlgorithmLevenberg schedule (see oracle/posegraph_oracle.py)
+int lslam_pg_optimize(lslam_pg *pg, int32_t max_iters, lslam_pg_stats *st_out) {
+  if (!pg) return LSLAM_ERR_INVALID;
+  PG_TRY(hipSetDevice(pg->device));
+  lslam_pg_stats st;
+  std::memset(&st, 0, sizeof(st));
+  hipEvent_t ev0, ev1;
+  PG_TRY(hipEventCreate(&ev0));
+  PG_TRY(hipEventCreate(&ev1));
+  PG_TRY(hipEventRecord(ev0, pg->stream));
+  const int n6 = pg->n_v * 6;
+  double lambda = -1.0, ni = 2.0;
+  for (int it = 0; it < max_iters; ++it) {
+    int rc = linearize(pg, pg->d_poses);
+    if (rc) return rc;
+    double cur;
+    PG_TRY(hipMemcpyAsync(&cur, pg->chi(), 8, hipMemcpyDeviceToHost, pg->stream));
+    if (lambda < 0) {
+      hipLaunchKernelGGL(pg_maxdiag_kernel, dim3(1), dim3(256), 0, pg->stream, pg->diag(), pg->n_v, pg->fixed, pg->d_tmp + 1);
+      double md;
+      PG_TRY(hipMemcpyAsync(&md, pg->d_tmp + 1, 8, hipMemcpyDeviceToHost, pg->stream));
+      PG_TRY(hipStreamSynchronize(pg->stream));
+      lambda = 1e-5 * md;
+    }
+    PG_TRY(hipStreamSynchronize(pg->stream));
+    if (it == 0) st.chi2_initial = cur;
+    double rho = 0.0;
+    int qmax = 0;
+    for (;;) {
+      int cg = 0;
+      rc = solve(pg, lambda, 4000, 1e-10, &cg);
+      if (rc) return rc;
+      st.cg_iterations += cg;
+      hipLaunchKernelGGL(pg_update_kernel, dim3((pg->n_v + 127) / 128), dim3(128), 0, pg->stream, pg->d_poses,
+                         pg->d_x, pg->n_v, pg->fixed, pg->d_trial);
+      double tmp;
+      rc = eval_chi2(pg, pg->d_trial, &tmp);
+      if (rc) return rc;
+      hipLaunchKernelGGL(pg_dot_scale_kernel, dim3(pg->n_cg_blocks), dim3(CG_BLOCK), 0, pg->stream, pg->d_x,
+                         pg->b(), n6, lambda, pg->d_part);
+      hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(256), 0, pg->stream, pg->d_part, pg->n_cg_blocks, 1, pg->d_tmp + 2);
+      double scale;
+      PG_TRY(hipMemcpyAsync(&scale, pg->d_tmp + 2, 8, hipMemcpyDeviceToHost, pg->stream));
+      PG_TRY(hipStreamSynchronize(pg->stream));
+      scale += 1e-3;
+      rho = (cur - tmp) / scale;
+      st.lm_trials++;
+      if (rho > 0 && std::isfinite(tmp)) {
+        double alpha = 1.0 - std::pow(2 * rho - 1, 3);
+        alpha = std::min(alpha, 2.0 / 3.0);
+        lambda *= std::max(1.0 / 3.0, alpha);
+        ni = 2.0;
+        std::swap(pg->d_poses, pg->d_trial);  // accept
+        cur = tmp;
+      } else {
+        lambda *= ni;
+        ni *= 2.0;
+      }
+      qmax++;
+      if (!(rho < 0 && qmax < 10)) break;
+    }
+    st.iterations = it + 1;
+    st.chi2_final = cur;
+    st.lambda = lambda;
+    if (qmax == 10 || rho == 0) break;
+  }
+  PG_TRY(hipEventRecord(ev1, pg->stream));
+  PG_TRY(hipStreamSynchronize(pg->stream));
+  PG_TRY(hipEventElapsedTime(&st.gpu_ms_total, ev0, ev1));
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
+  if (st_out) *st_out = st;
+  return LSLAM_OK;
+}
+
+}  // extern "C"

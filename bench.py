@@ -48,6 +48,8 @@ def main():
                     help="independent scans matched together per step on each GPU")
     ap.add_argument("--jtj-mode", type=int, default=int(os.environ.get("LSLAM_JTJ_MODE", "1")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pose-graph", action="store_true")
+    ap.add_argument("--pg-iters", type=int, default=10, help="LM iterations of the pose-graph leg")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     args = ap.parse_args()
 
@@ -169,6 +171,12 @@ def main():
             },
         }
         out["single_scan"] = single_scan_leg(ctx, pr, opts, max(10, args.steps // 2))
+    if not args.no_pose_graph:
+        pgres = pose_graph_leg(pkg, synth, distmod, dist, rank, world, local_rank, torch, np,
+                               args.pg_iters, not args.no_cpu_baseline)
+        if rank == 0:
+            out["pose_graph"] = pgres
+    if rank == 0:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pr, args.cpu_repeats, pose, np)
         print(json.dumps(out), flush=True)
@@ -178,6 +186,55 @@ def main():
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pose_graph_leg(pkg, synth, distmod, dist, rank, world, local_rank, torch, np, lm_iters, with_cpu):
+    """BASELINE config 4: SE(3) pose-graph LM, 5 000 keyframes / 4 999 odometry + 20 000 loop
+    edges, fp64.  Edges are sharded across the ranks; every LM iteration all-reduces the block
+    system [H blocks | b | chi2] over RCCL, the damped PCG solve is replicated."""
+    g = synth.make_pose_graph()
+    pg = pkg.PoseGraph(local_rank)
+    pg.set_graph(g["init"], g["ij"], g["meas"], g["info"])
+    ne = len(g["ij"])
+    nbytes = 0
+    if dist is not None:
+        sysbuf = torch.zeros(pg.system_doubles(), dtype=torch.float64, device="cuda")
+        base = sysbuf.data_ptr()
+
+        def allreduce(ptr, count):
+            off = (ptr - base) // 8
+            dist.all_reduce(sysbuf[off:off + count], op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+        b, e = distmod.shard_range(ne, rank, world)
+        pg.set_shard(b, e, allreduce=allreduce, system_tensor=sysbuf)
+        nbytes = sysbuf.numel() * 8
+    pg.optimize(1)  # warm-up (also builds the structures); restart from the initial estimate
+    pg.set_graph(g["init"], g["ij"], g["meas"], g["info"])
+    if dist is not None:
+        pg.set_shard(b, e, allreduce=allreduce, system_tensor=sysbuf)
+    distmod.barrier(dist)
+    t0 = time.perf_counter()
+    iters = pg.optimize(lm_iters)
+    distmod.barrier(dist)
+    dt = time.perf_counter() - t0
+    (_,), tmax = distmod.aggregate(dist, [0.0], dt)
+    st = pg.last_stats
+    res = {"lm_iters_per_s": iters / tmax, "lm_iterations": iters, "lm_trials": st.lm_trials,
+           "cg_iterations": st.cg_iterations, "chi2_initial": st.chi2_initial, "chi2_final": st.chi2_final,
+           "keyframes": len(g["init"]), "edges": ne, "dtype": "f64", "n_gpus": world,
+           "allreduce_bytes_per_lm_iteration": nbytes,
+           "parallelism": "edges sharded over %d GPU(s), RCCL all-reduce of the block system, replicated PCG" % world}
+    pg.close()
+    if with_cpu and rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import posegraph_oracle as po
+        t0 = time.perf_counter()
+        _, hist = po.optimize(g["init"], g["ij"], g["meas"], g["info"], max_iters=2)
+        cdt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": len(hist) / cdt, "unit": "LM-iters/s", "cores": 1, "kind": "port",
+                               "sample": "2 LM iterations of the numpy/SuperLU oracle on the same graph "
+                                         "(g2o, the reference's solver, is not available here)"}
+    return res
 
 
 def single_scan_leg(ctx, pr, opts, steps):

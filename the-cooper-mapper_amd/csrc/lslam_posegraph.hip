@@ -621,17 +621,19 @@ int linearize(lslam_pg *pg, const double *poses) {
 }
 
 int eval_chi2(lslam_pg *pg, const double *poses, double *out) {
+  // the chi2 slot of the system buffer is free again once the current chi2 has been read
+  // back, and it lives in the buffer the all-reduce hook knows how to address
   const int ne = pg->e_end - pg->e_begin;
   if (ne > 0)
     hipLaunchKernelGGL(pg_chi2_kernel, dim3((ne + 127) / 128), dim3(128), 0, pg->stream, poses, pg->d_ij,
                        pg->d_meas, pg->d_info, pg->e_begin, pg->e_end, pg->d_chi);
-  hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(256), 0, pg->stream, pg->d_chi, ne, 1, pg->d_tmp);
+  hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(256), 0, pg->stream, pg->d_chi, ne, 1, pg->chi());
   PG_TRY(hipGetLastError());
   if (pg->allreduce) {
     PG_TRY(hipStreamSynchronize(pg->stream));
-    pg->allreduce(pg->allreduce_user, pg->d_tmp, 1);
+    pg->allreduce(pg->allreduce_user, pg->chi(), 1);
   }
-  PG_TRY(hipMemcpyAsync(out, pg->d_tmp, sizeof(double), hipMemcpyDeviceToHost, pg->stream));
+  PG_TRY(hipMemcpyAsync(out, pg->chi(), sizeof(double), hipMemcpyDeviceToHost, pg->stream));
   PG_TRY(hipStreamSynchronize(pg->stream));
   return LSLAM_OK;
 }

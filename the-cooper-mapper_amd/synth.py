@@ -216,3 +216,75 @@ def make_problem(rings=64, azimuth_steps=1800, map_radius=None, world_half=175.0
     init = perturb_pose(gt, seed=99 + seed)
     return dict(world=world, map_corner=map_c, map_surf=map_s, corner=qc, surf=qs,
                 gt_pose=gt.astype(np.float32), init_pose=init)
+
+
+# ---------------------------------------------------------------------------
+# synthetic pose graph (BASELINE config 4)
+# ---------------------------------------------------------------------------
+def _qmul(a, b):
+    ax, ay, az, aw = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    bx, by, bz, bw = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    return np.stack([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz], axis=-1)
+
+
+def _qrot(q, v):
+    qv = np.concatenate([v, np.zeros(v.shape[:-1] + (1,))], axis=-1)
+    qc = q * np.array([-1.0, -1.0, -1.0, 1.0])
+    return _qmul(_qmul(q, qv), qc)[..., :3]
+
+
+def _pmul(a, b):
+    return np.concatenate([a[..., :3] + _qrot(a[..., 3:], b[..., :3]), _qmul(a[..., 3:], b[..., 3:])], axis=-1)
+
+
+def _pinv(a):
+    qi = a[..., 3:] * np.array([-1.0, -1.0, -1.0, 1.0])
+    return np.concatenate([-_qrot(qi, a[..., :3]), qi], axis=-1)
+
+
+def make_pose_graph(n_kf=5000, n_loop=20000, laps=8, radius=100.0, seed=7,
+                    odo_sigma=(0.02, 0.002), loop_sigma=(0.01, 0.001)):
+    """Keyframes {t, q_xyzw} on `laps` laps of a closed loop, n_kf-1 odometry edges with drift,
+    n_loop loop-closure edges between keyframes < 5 m apart and > 30 m of path apart
+    (pose_graph/loop_detector.hpp:57-60), information matrices as pose_graph/graph.cpp:279-288
+    (odometry diag(0.8,0.4,0.8,1,2,1)) and :333-339 (loops 2*I).  Initial estimate: dead-reckoned."""
+    rng = np.random.default_rng(seed)
+    s = np.linspace(0, 2 * np.pi * laps, n_kf, endpoint=False)
+    r = radius * (1 + 0.02 * np.sin(5 * s))
+    pos = np.stack([r * np.cos(s), r * np.sin(s), 0.5 * np.sin(3 * s)], 1)
+    yaw = s + np.pi / 2
+    gt = np.concatenate([pos, np.stack([np.zeros(n_kf), np.zeros(n_kf), np.sin(yaw / 2), np.cos(yaw / 2)], 1)], 1)
+
+    def noisy_rel(a, b, sig):
+        rel = _pmul(_pinv(gt[a]), gt[b])
+        v = rng.normal(0, sig[1], (len(a), 3))
+        dq = np.concatenate([v, np.sqrt(1 - (v * v).sum(1, keepdims=True))], 1)
+        d = np.concatenate([rng.normal(0, sig[0], (len(a), 3)), dq], 1)
+        return _pmul(rel, d)
+
+    a = np.arange(n_kf - 1)
+    odo = noisy_rel(a, a + 1, odo_sigma)
+    step = np.linalg.norm(pos[1] - pos[0])
+    per_lap = n_kf // laps
+    cand = np.zeros((0, 2), np.int64)
+    while len(cand) < n_loop:  # same place, a whole number of laps later (+- a few keyframes)
+        i = rng.integers(0, n_kf, 4 * n_loop)
+        j = i + per_lap * rng.integers(1, laps, 4 * n_loop) + rng.integers(-3, 4, 4 * n_loop)
+        ok = (j < n_kf) & (j > i)
+        i, j = i[ok], j[ok]
+        ok = ((j - i) * step > 30.0) & (np.linalg.norm(pos[i] - pos[j], axis=1) < 5.0)
+        cand = np.concatenate([cand, np.stack([i[ok], j[ok]], 1)])
+    cand = cand[:n_loop]
+    loops = noisy_rel(cand[:, 0], cand[:, 1], loop_sigma)
+    ij = np.concatenate([np.stack([a, a + 1], 1), cand]).astype(np.int32)
+    meas = np.concatenate([odo, loops])
+    info = np.zeros((len(ij), 6, 6))
+    info[: n_kf - 1] = np.diag([0.8, 0.4, 0.8, 1.0, 2.0, 1.0])
+    info[n_kf - 1:] = 2.0 * np.eye(6)
+    init = np.zeros_like(gt)
+    init[0] = gt[0]
+    for k in range(n_kf - 1):
+        init[k + 1] = _pmul(init[k][None], odo[k][None])[0]
+    init[:, 3:] /= np.linalg.norm(init[:, 3:], axis=1, keepdims=True)
+    return dict(gt=gt, init=init, ij=ij, meas=meas, info=info, n_odo=n_kf - 1)

@@ -48,6 +48,83 @@ def test_knn5_matches_oracle_large(ctx, oracle, synth):
         assert np.array_equal(bits(gd), bits(od))
 
 
+def _tree_dump(ctx, which, n_pts):
+    import ctypes as C
+    lib = ctx.lib
+    lib.lslam_debug_tree_dump.restype = C.c_int
+    lib.lslam_debug_tree_dump.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_size_t,
+                                          C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_uint32),
+                                          C.POINTER(C.c_int32)]
+    cap = 2 * n_pts // 3 + 128
+    nodes = np.zeros((cap, 4), np.uint32)
+    pts = np.zeros((max(1, n_pts), 4), np.float32)
+    root, nn = C.c_uint32(), C.c_int32()
+    rc = lib.lslam_debug_tree_dump(ctx.h, which, nodes.ctypes.data_as(C.POINTER(C.c_uint32)), cap,
+                                   pts.ctypes.data_as(C.POINTER(C.c_float)), len(pts), C.byref(root), C.byref(nn))
+    assert rc == 0
+    return nodes[:nn.value], pts[:n_pts], root.value
+
+
+def _walk(nodes, root):
+    """(divfeat, divlow, divhigh) of inner nodes and (left, count) of leaves in nanoflann's
+    preorder, independent of where the device placed the nodes."""
+    inner, leaves = [], []
+    stack = [root]
+    f32 = nodes.view(np.float32)
+    while stack:
+        ref = stack.pop()
+        if ref & 0x80000000:
+            leaves.append(((ref & 0x7FFFFFFF) >> 4, ref & 15))
+            continue
+        n = ref >> 2
+        inner.append((ref & 3, f32[n, 0], f32[n, 1]))
+        stack.append(int(nodes[n, 3]))
+        stack.append(int(nodes[n, 2]))
+    return inner, leaves
+
+
+@pytest.mark.parametrize("kind", ["planar", "uniform", "lattice", "duplicates", "big"])
+def test_device_tree_build_is_nanoflann_exact(ctx, oracle, synth, kind):
+    """The GPU-built tree has nanoflann's split at every node and nanoflann's point order
+    (vind): compared with the oracle's restatement, which is pinned to the reference."""
+    rng = np.random.default_rng(11)
+    if kind == "planar":
+        n = 60000
+        pts = np.stack([rng.uniform(-60, 60, n), rng.uniform(-60, 60, n), rng.normal(0, 0.02, n)], 1)
+    elif kind == "uniform":
+        pts = rng.uniform(-30, 30, (40000, 3))
+    elif kind == "lattice":  # equal coordinates everywhere: the '== cutval' runs matter
+        g = np.arange(-12, 12, 0.4)
+        X, Y = np.meshgrid(g, g)
+        pts = np.concatenate([np.stack([X.ravel(), Y.ravel(), np.zeros(X.size)], 1),
+                              np.stack([np.full(X.size, 5.0), X.ravel(), Y.ravel() + 12], 1)])
+    elif kind == "duplicates":
+        base = rng.uniform(-5, 5, (3000, 3))
+        pts = np.repeat(base, 4, axis=0)[rng.permutation(12000)]
+    else:
+        pr = synth.make_problem(rings=16, azimuth_steps=900, world_half=100.0)
+        pts = pr["map_surf"][:, :3]
+    pts = np.ascontiguousarray(pts, np.float32)
+    ctx.map_set(pts, pts)
+    info = ctx.map_info()
+    if not info.built_on_device:
+        pytest.skip("host tree build forced (LSLAM_HOST_TREE)")
+    tree = oracle.kdtree(pts)
+    nodes, dpts, root = _tree_dump(ctx, 1, len(pts))
+    assert np.array_equal(dpts[:, 3].view(np.int32), tree.vind())      # same permutation
+    assert np.array_equal(dpts[:, :3], pts[tree.vind()])
+    inner, leaves = _walk(nodes, root)
+    on = tree.nodes()
+    o_inner = [(int(a), lo, hi) for k, a, lo, hi in zip(on["kind"], on["a"], on["divlow"], on["divhigh"]) if k == 1]
+    o_leaves = [(int(a), int(b - a)) for k, a, b in zip(on["kind"], on["a"], on["b"]) if k == 0]
+    assert len(inner) == len(o_inner) and len(leaves) == len(o_leaves)
+    assert leaves == o_leaves
+    assert [i[0] for i in inner] == [i[0] for i in o_inner]
+    assert np.array_equal(np.array([i[1:] for i in inner], np.float32).view(np.int32),
+                          np.array([i[1:] for i in o_inner], np.float32).view(np.int32))
+    assert info.depth_surf == tree.max_depth()
+
+
 def test_knn5_pointxyzi_stride(ctx, oracle):
     """32-byte pcl::PointXYZI layout (quirk Q9) gives the same answers as packed xyz."""
     rng = np.random.default_rng(1)

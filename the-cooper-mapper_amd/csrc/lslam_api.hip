@@ -320,6 +320,26 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
 
 void *lslam_stream(lslam_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+// Parity tap: download a resident tree (inner nodes as 4 words each, permuted points).
+int lslam_debug_tree_dump(lslam_ctx *ctx, int which, uint32_t *nodes_out, size_t node_cap,
+                          float *pts_out, size_t pts_cap, uint32_t *root_ref, int32_t *n_nodes) {
+  int rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (!ctx->have_map) return LSLAM_ERR_NO_MAP;
+  const DevTree &dt = which ? ctx->ts : ctx->tc;
+  if ((size_t)dt.view.n_nodes > node_cap || (size_t)dt.view.n_pts > pts_cap) return LSLAM_ERR_INVALID;
+  if (dt.view.n_nodes)
+    HIP_TRY(hipMemcpyAsync(nodes_out, dt.nodes.p, (size_t)dt.view.n_nodes * sizeof(KdNode),
+                           hipMemcpyDeviceToHost, ctx->stream));
+  if (dt.view.n_pts)
+    HIP_TRY(hipMemcpyAsync(pts_out, dt.pts.p, (size_t)dt.view.n_pts * sizeof(float4), hipMemcpyDeviceToHost,
+                           ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *root_ref = dt.view.root_ref;
+  *n_nodes = dt.view.n_nodes;
+  return LSLAM_OK;
+}
+
 // Profiling tap: phase stamps of the last solve kernel (100 MHz ticks).
 void lslam_debug_solve_clocks(lslam_ctx *ctx, uint64_t out[8]) {
   for (int i = 0; i < 8; ++i) out[i] = ctx->h_state->clk[i];
@@ -371,33 +391,73 @@ int lslam_map_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const voi
   ctx->have_map = false;
   const double t0 = now_ms();
   std::vector<float4> cc, cs;
-  HostTree hc, hs;
-  std::thread th([&] {
+  static const bool host_tree = std::getenv("LSLAM_HOST_TREE") != nullptr;  // A/B and fallback
+  double t1 = t0, t2 = t0;
+  size_t nodes_c = 0, nodes_s = 0;
+  int built_on_device = 0;
+  bool need_host = host_tree;
+  if (!host_tree) {
+    // ---- device build: upload {x,y,z,index}, build both trees in HBM --------------------
     pack_cloud(corner, n_corner, stride_bytes, cc);
-    build_kdtree_host(reinterpret_cast<const float *>(cc.data()), n_corner, 4, hc);
-  });
-  pack_cloud(surf, n_surf, stride_bytes, cs);
-  build_kdtree_host(reinterpret_cast<const float *>(cs.data()), n_surf, 4, hs);
-  th.join();
-  const double t1 = now_ms();
-  if (hc.depth > KD_STACK_MAX || hs.depth > KD_STACK_MAX) {
-    set_err("kd-tree depth %d/%d exceeds device stack %d", hc.depth, hs.depth, KD_STACK_MAX);
+    pack_cloud(surf, n_surf, stride_bytes, cs);
+    for (size_t i = 0; i < cc.size(); ++i) cc[i].w = __builtin_bit_cast(float, (uint32_t)i);
+    for (size_t i = 0; i < cs.size(); ++i) cs[i].w = __builtin_bit_cast(float, (uint32_t)i);
+    t1 = now_ms();
+    DevTree *trees[2] = {&ctx->tc, &ctx->ts};
+    const std::vector<float4> *clouds[2] = {&cc, &cs};
+    size_t *ncount[2] = {&nodes_c, &nodes_s};
+    for (int k = 0; k < 2 && !need_host; ++k) {
+      DevTree &dt = *trees[k];
+      const size_t n = clouds[k]->size();
+      const size_t cap = ((2 * n / 3 + 64) + 7) & ~(size_t)7;
+      HIP_TRY(dt.pts.reserve(n ? n : 1));
+      HIP_TRY(dt.nodes.reserve(cap));
+      if (n)
+        HIP_TRY(hipMemcpyAsync(dt.pts.p, clouds[k]->data(), n * sizeof(float4), hipMemcpyHostToDevice,
+                               ctx->stream));
+      int fallback = 0;
+      size_t n_leaves = 0;
+      HIP_TRY(build_kdtree_device(dt.pts.p, (int32_t)n, dt.nodes.p, (int32_t)cap, ctx->stream, &dt.view,
+                                  &dt.depth, &n_leaves, &fallback));
+      if (fallback) need_host = true;
+      *ncount[k] = (size_t)dt.view.n_nodes / 8 * 7 + n_leaves;  // approximate node count
+    }
+    t2 = now_ms();
+    if (!need_host) built_on_device = 1;
+  }
+  if (need_host) {
+    HostTree hc, hs;
+    std::thread th([&] {
+      pack_cloud(corner, n_corner, stride_bytes, cc);
+      build_kdtree_host(reinterpret_cast<const float *>(cc.data()), n_corner, 4, hc);
+    });
+    pack_cloud(surf, n_surf, stride_bytes, cs);
+    build_kdtree_host(reinterpret_cast<const float *>(cs.data()), n_surf, 4, hs);
+    th.join();
+    t1 = now_ms();
+    rc = upload_tree(ctx, ctx->tc, hc, cc);
+    if (rc) return rc;
+    rc = upload_tree(ctx, ctx->ts, hs, cs);
+    if (rc) return rc;
+    t2 = now_ms();
+    nodes_c = hc.nodes.size() + hc.n_leaves;  // nanoflann's node count
+    nodes_s = hs.nodes.size() + hs.n_leaves;
+    built_on_device = 0;
+  }
+  if (ctx->tc.depth > KD_STACK_MAX || ctx->ts.depth > KD_STACK_MAX) {
+    set_err("kd-tree depth %d/%d exceeds device stack %d", ctx->tc.depth, ctx->ts.depth, KD_STACK_MAX);
     return LSLAM_ERR_TREE_DEPTH;
   }
-  rc = upload_tree(ctx, ctx->tc, hc, cc);
-  if (rc) return rc;
-  rc = upload_tree(ctx, ctx->ts, hs, cs);
-  if (rc) return rc;
-  const double t2 = now_ms();
   ctx->info.n_corner = n_corner;
   ctx->info.n_surf = n_surf;
-  ctx->info.nodes_corner = (uint32_t)(hc.nodes.size() + hc.n_leaves);  // nanoflann's node count
-  ctx->info.nodes_surf = (uint32_t)(hs.nodes.size() + hs.n_leaves);
-  ctx->info.depth_corner = hc.depth;
-  ctx->info.depth_surf = hs.depth;
-  ctx->info.build_ms = (float)(t1 - t0);
-  ctx->info.upload_ms = (float)(t2 - t1);
-  ctx->info.built_on_device = 0;
+  ctx->info.nodes_corner = (uint32_t)nodes_c;
+  ctx->info.nodes_surf = (uint32_t)nodes_s;
+  ctx->info.depth_corner = ctx->tc.depth;
+  ctx->info.depth_surf = ctx->ts.depth;
+  // host build: [build | upload]; device build: [pack | upload + build]
+  ctx->info.build_ms = (float)(built_on_device ? (t2 - t1) : (t1 - t0));
+  ctx->info.upload_ms = (float)(built_on_device ? (t1 - t0) : (t2 - t1));
+  ctx->info.built_on_device = built_on_device;
   ctx->have_map = true;
   return LSLAM_OK;
 }

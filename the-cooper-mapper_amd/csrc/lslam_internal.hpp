@@ -117,4 +117,9 @@ struct HostTree {
 };
 void build_kdtree_host(const float *pts, size_t n, size_t stride_floats, HostTree &out);
 
+// device kd-tree builder (lslam_treebuild.hip): same tree, built in HBM
+hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_t node_cap,
+                               hipStream_t stream, TreeView *view, int *depth, size_t *n_leaves,
+                               int *fallback);
+
 }  // namespace lslam

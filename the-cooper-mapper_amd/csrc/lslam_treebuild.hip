@@ -1,0 +1,503 @@
+// lslam_treebuild.hip -- kd-tree construction on the GPU (gfx950).
+//
+// Builds, for a cloud already in HBM, the tree nanoflann v1.2.3 builds
+// (util/nanoflann.hpp:931-1078 divideTree / middleSplit_ / planeSplit, leaf_max_size 10)
+// -- same split dimension, split value and balance rule at every node AND the same
+// in-place permutation of the points, so leaves hold the same points in the same order
+// as the reference's `vind` -- directly in the device encoding of lslam_device.hpp.
+//
+// How the sequential algorithm is reproduced in parallel
+//   * A node is processed by one workgroup: min/max of the three coordinates, the split
+//     decision (middleSplit_, :982-1031), the counts lim1/lim2, the partition, the tight
+//     bounds divlow/divhigh of the two halves (:966-971).
+//   * planeSplit (:1043-1078) is two Hoare passes.  A Hoare pass with pivot predicate P
+//     leaves the elements that already are on their side in place and swaps the k-th
+//     misplaced element counted from the left with the k-th misplaced element counted
+//     from the right.  That pairing is computed with two block-wide prefix scans and
+//     applied as independent swaps, which yields exactly nanoflann's arrangement.
+//   * Workgroups are persistent: big nodes (> LOCAL_MAX points) travel through a global
+//     queue (agent-scope release/acquire around every hand-off, per the CDNA4 guide);
+//     a node with <= LOCAL_MAX points is finished, with its whole subtree, by the
+//     workgroup that produced it (explicit stack in LDS).
+//   * Nodes are placed in groups of 8 slots (one 128-byte line) holding a node, its
+//     children and grandchildren (heap order); great-grandchildren open new groups.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "lslam_internal.hpp"
+
+namespace lslam {
+
+namespace {
+
+constexpr int TB = 256;            // threads per workgroup
+constexpr int LOCAL_MAX = 8192;    // subtrees up to this many points are finished locally
+constexpr int LOCAL_STACK = 64;
+
+struct BuildItem {   // one pending inner node
+  int32_t l, r;      // point range
+  float lo[3], hi[3];  // propagated bounding box (nanoflann.hpp:955-961)
+  int32_t slot;      // node slot of this node
+  int32_t heap;      // position inside its 8-slot group (0; 1,2; 3..6)
+  int32_t parent_word;  // index (in 32-bit words of the node array) of the reference to this
+                        // node in its parent, -1 for the root: the node ORs its divfeat there
+  int32_t depth;
+};
+
+struct BuildCtl {
+  int32_t q_head, q_tail_reserved, q_pending;  // queue indices / nodes not yet finished
+  int32_t next_group;   // next free 8-slot group
+  int32_t max_depth;
+  int32_t overflow;     // node array or queue too small
+  int32_t root_feat;
+  int32_t n_leaves;
+};
+
+struct BuildArgs {
+  float4 *pts;        // permuted in place; .w = original index
+  KdNode *nodes;
+  int32_t node_cap;   // in nodes (multiple of 8)
+  BuildItem *queue;
+  int32_t *q_ready;   // per queue entry
+  int32_t queue_cap;
+  int32_t *tmpA, *tmpB;  // scratch, one int per point
+  BuildCtl *ctl;
+  int32_t n;
+};
+
+__device__ __forceinline__ float coord(const float4 &p, int d) { return d == 0 ? p.x : (d == 1 ? p.y : p.z); }
+
+struct Sh {
+  float fmin[3][TB / 64], fmax[3][TB / 64];
+  int isum[2][TB / 64];
+  int scan[TB / 64];
+  float bc_f[8];
+  int bc_i[8];
+  BuildItem item;
+  BuildItem stack[LOCAL_STACK];
+  int sp;
+  int have;
+};
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// exclusive prefix sum of `flag` over the block's TB threads; returns prefix, *total
+__device__ __forceinline__ int block_excl_scan(int flag, Sh &sh, int *total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int v = flag;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  if (lane == 63) sh.scan[wave] = v;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < TB / 64; ++w) {
+    if (w < wave) base += sh.scan[w];
+    tot += sh.scan[w];
+  }
+  __syncthreads();
+  *total = tot;
+  return base + v - flag;
+}
+
+// One Hoare pass over pts[l+a .. l+b) (nanoflann.hpp:1043-1060 or :1062-1076).
+// `lt` selects the predicate: true: "x < cut" belongs left; false: "x <= cut" belongs left.
+// L = number of elements that belong left.  Elements [a, a+L) that do not belong left are
+// swapped, k-th from the left, with the k-th element from the right of [a+L, b) that does.
+__device__ void hoare_pass(const BuildArgs &A, Sh &sh, int l, int a, int b, int L, int feat, float cut,
+                           bool lt) {
+  const int tid = threadIdx.x;
+  const int nl = L, nr = (b - a) - L;
+  if (nl == 0 || nr == 0) return;
+  int run = 0;
+  for (int c = 0; c < nl; c += TB) {  // misplaced on the left, increasing index
+    const int i = c + tid;
+    int flag = 0;
+    if (i < nl) {
+      const float x = coord(A.pts[l + a + i], feat);
+      flag = lt ? !(x < cut) : !(x <= cut);
+    }
+    int tot;
+    const int pre = block_excl_scan(flag, sh, &tot);
+    if (flag) A.tmpA[l + run + pre] = a + i;
+    run += tot;
+  }
+  const int m = run;
+  if (m == 0) return;
+  run = 0;
+  for (int c = 0; c < nr; c += TB) {  // misplaced on the right, decreasing index
+    const int i = c + tid;
+    int flag = 0;
+    if (i < nr) {
+      const float x = coord(A.pts[l + b - 1 - i], feat);
+      flag = lt ? (x < cut) : (x <= cut);
+    }
+    int tot;
+    const int pre = block_excl_scan(flag, sh, &tot);
+    if (flag) A.tmpB[l + run + pre] = b - 1 - i;
+    run += tot;
+  }
+  __syncthreads();
+  for (int k = tid; k < m; k += TB) {
+    const int i = l + A.tmpA[l + k], j = l + A.tmpB[l + k];
+    const float4 t = A.pts[i];
+    A.pts[i] = A.pts[j];
+    A.pts[j] = t;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ int alloc_group(const BuildArgs &A) {
+  const int g = atomicAdd(&A.ctl->next_group, 1);
+  if ((g + 1) * 8 > A.node_cap) {
+    A.ctl->overflow = 1;
+    return 0;
+  }
+  return g * 8;
+}
+
+// Process one inner node (block-cooperative).  Children that are inner nodes are returned
+// in out[0..1] (count in *n_out) for the caller to schedule.
+__device__ void process_node(const BuildArgs &A, Sh &sh, const BuildItem &it, BuildItem out[2], int *n_out) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l = it.l, n = it.r - it.l;
+  // ---- min / max of the three coordinates (computeMinMax, :908-920) ---------------
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = tid; i < n; i += TB) {
+    const float4 p = A.pts[l + i];
+    mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+    mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+    mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float a = wave_min(mn[d]), b = wave_max(mx[d]);
+    if (lane == 0) { sh.fmin[d][wave] = a; sh.fmax[d][wave] = b; }
+  }
+  __syncthreads();
+  if (tid == 0) {  // middleSplit_, :982-1031
+    float emin[3], emax[3];
+    for (int d = 0; d < 3; ++d) {
+      emin[d] = sh.fmin[d][0]; emax[d] = sh.fmax[d][0];
+      for (int w = 1; w < TB / 64; ++w) { emin[d] = fminf(emin[d], sh.fmin[d][w]); emax[d] = fmaxf(emax[d], sh.fmax[d][w]); }
+    }
+    const float EPS = 0.00001f;
+    float max_span = it.hi[0] - it.lo[0];
+    for (int d = 1; d < 3; ++d) { const float span = it.hi[d] - it.lo[d]; if (span > max_span) max_span = span; }
+    float max_spread = -1;
+    int cutfeat = 0;
+    for (int d = 0; d < 3; ++d) {
+      const float span = it.hi[d] - it.lo[d];
+      if (span > (1 - EPS) * max_span) {
+        const float spread = emax[d] - emin[d];
+        if (spread > max_spread) { cutfeat = d; max_spread = spread; }
+      }
+    }
+    const float split_val = (it.lo[cutfeat] + it.hi[cutfeat]) / 2;
+    const float cutval = split_val < emin[cutfeat] ? emin[cutfeat] : (split_val > emax[cutfeat] ? emax[cutfeat] : split_val);
+    sh.bc_i[0] = cutfeat;
+    sh.bc_f[0] = cutval;
+  }
+  __syncthreads();
+  const int feat = sh.bc_i[0];
+  const float cut = sh.bc_f[0];
+  // ---- lim1 = #(x < cut), lim2 = #(x <= cut) ---------------------------------------
+  int c1 = 0, c2 = 0;
+  for (int i = tid; i < n; i += TB) {
+    const float x = coord(A.pts[l + i], feat);
+    c1 += x < cut;
+    c2 += x <= cut;
+  }
+  c1 = wave_sum_i(c1);
+  c2 = wave_sum_i(c2);
+  if (lane == 0) { sh.isum[0][wave] = c1; sh.isum[1][wave] = c2; }
+  __syncthreads();
+  int lim1 = 0, lim2 = 0;
+#pragma unroll
+  for (int w = 0; w < TB / 64; ++w) { lim1 += sh.isum[0][w]; lim2 += sh.isum[1][w]; }
+  __syncthreads();
+  // ---- planeSplit: two Hoare passes -----------------------------------------------
+  hoare_pass(A, sh, l, 0, n, lim1, feat, cut, true);
+  if (lim2 > lim1) hoare_pass(A, sh, l, lim1, n, lim2 - lim1, feat, cut, false);
+  const int half = n / 2;
+  const int index = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);  // :1024-1029
+  // ---- tight bounds of the two halves along the split dimension (:966-971) ----------
+  float lmax = -FLT_MAX, rmin = FLT_MAX;
+  for (int i = tid; i < n; i += TB) {
+    const float x = coord(A.pts[l + i], feat);
+    if (i < index) lmax = fmaxf(lmax, x); else rmin = fminf(rmin, x);
+  }
+  lmax = wave_max(lmax);
+  rmin = wave_min(rmin);
+  if (lane == 0) { sh.fmax[0][wave] = lmax; sh.fmin[0][wave] = rmin; }
+  __syncthreads();
+  if (tid == 0) {
+    float divlow = sh.fmax[0][0], divhigh = sh.fmin[0][0];
+    for (int w = 1; w < TB / 64; ++w) { divlow = fmaxf(divlow, sh.fmax[0][w]); divhigh = fminf(divhigh, sh.fmin[0][w]); }
+    int cnt = 0;
+    uint32_t ref[2];
+    for (int c = 0; c < 2; ++c) {
+      const int cl = c == 0 ? it.l : it.l + index, cr = c == 0 ? it.l + index : it.r;
+      if (cr - cl <= 10) {  // leaf (:936-951)
+        ref[c] = KD_LEAF | ((uint32_t)cl << 4) | (uint32_t)(cr - cl);
+        atomicAdd(&A.ctl->n_leaves, 1);
+        atomicMax(&A.ctl->max_depth, it.depth + 1);
+      } else {
+        BuildItem ch;
+        ch.l = cl;
+        ch.r = cr;
+        for (int d = 0; d < 3; ++d) { ch.lo[d] = it.lo[d]; ch.hi[d] = it.hi[d]; }
+        if (c == 0) ch.hi[feat] = cut; else ch.lo[feat] = cut;  // :955-961
+        if (it.heap < 3) {  // child stays in this 8-slot group
+          ch.heap = 2 * it.heap + 1 + c;
+          ch.slot = it.slot - it.heap + ch.heap;
+        } else {
+          ch.heap = 0;
+          ch.slot = alloc_group(A);
+        }
+        ch.parent_word = it.slot * 4 + 2 + c;
+        ch.depth = it.depth + 1;
+        ref[c] = (uint32_t)ch.slot << 2;  // the child ORs its divfeat in when it is processed
+        out[cnt++] = ch;
+      }
+    }
+    KdNode nd;
+    nd.lo = divlow;
+    nd.hi = divhigh;
+    nd.c1 = ref[0];
+    nd.c2 = ref[1];
+    A.nodes[it.slot] = nd;
+    if (it.parent_word >= 0)
+      atomicOr(reinterpret_cast<unsigned int *>(A.nodes) + it.parent_word, (unsigned int)feat);
+    else
+      A.ctl->root_feat = feat;
+    *n_out = cnt;
+    sh.bc_i[1] = cnt;
+  }
+  // every wave drains its stores (point swaps, node record) before the barrier, so that
+  // one lane's agent-scope release afterwards covers the whole workgroup
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(TB) void kd_build_kernel(BuildArgs A) {
+  __shared__ Sh sh;
+  const int tid = threadIdx.x;
+  if (tid == 0) sh.sp = 0;
+  __syncthreads();
+  for (;;) {
+    // ---- take a node: local stack first, then the global queue --------------------
+    if (tid == 0) {
+      sh.have = 0;
+      if (sh.sp > 0) {
+        sh.item = sh.stack[--sh.sp];
+        sh.have = 1;
+      } else {
+        for (unsigned spins = 0;; ++spins) {
+          const int head = __hip_atomic_load(&A.ctl->q_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int tail = __hip_atomic_load(&A.ctl->q_tail_reserved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (head < tail) {
+            int expect = head;
+            if (__hip_atomic_compare_exchange_strong(&A.ctl->q_head, &expect, head + 1, __ATOMIC_RELAXED,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+              // wait until the producer has published entry `head`
+              while (__hip_atomic_load(&A.q_ready[head], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                __builtin_amdgcn_s_sleep(2);
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+              const int *src = reinterpret_cast<const int *>(&A.queue[head]);
+              int *dst = reinterpret_cast<int *>(&sh.item);
+              for (int k = 0; k < (int)(sizeof(BuildItem) / 4); ++k)
+                dst[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              sh.have = 2;
+              break;
+            }
+          } else if (__hip_atomic_load(&A.ctl->q_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 ||
+                     __hip_atomic_load(&A.ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            break;  // everything is built
+          } else {
+            __builtin_amdgcn_s_sleep(8);
+            if (spins > (1u << 26)) { A.ctl->overflow = 2; break; }  // bounded spin
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (!sh.have) return;
+    if (sh.have == 2) {  // points written by another workgroup: drop stale L1 lines
+      if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __syncthreads();
+    }
+    const BuildItem it = sh.item;
+    BuildItem kids[2];
+    int nk = 0;
+    process_node(A, sh, it, kids, &nk);
+    // ---- schedule the children ------------------------------------------------------
+    if (tid == 0) {
+      int published = 0;
+      for (int c = 0; c < nk; ++c) {
+        const int cn = kids[c].r - kids[c].l;
+        if (cn <= LOCAL_MAX && sh.sp < LOCAL_STACK) {
+          sh.stack[sh.sp++] = kids[c];
+        } else {
+          const int e = atomicAdd(&A.ctl->q_tail_reserved, 1);
+          if (e >= A.queue_cap) { A.ctl->overflow = 3; continue; }
+          if (!published) {  // make this workgroup's point swaps / node writes visible
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            published = 1;
+          }
+          atomicAdd(&A.ctl->q_pending, 1);
+          const int *src = reinterpret_cast<const int *>(&kids[c]);
+          int *dst = reinterpret_cast<int *>(&A.queue[e]);
+          for (int k = 0; k < (int)(sizeof(BuildItem) / 4); ++k)
+            __hip_atomic_store(dst + k, src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&A.q_ready[e], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (sh.have == 2) atomicSub(&A.ctl->q_pending, 1);  // this queued node is done
+    }
+    __syncthreads();
+  }
+}
+
+// bounding box of the whole cloud (computeBoundingBox, :1406-1427) + identity .w
+__global__ __launch_bounds__(256) void kd_bbox_kernel(const float4 *pts, int n, float *part) {
+  __shared__ float smin[3][4], smax[3][4];
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float4 p = pts[i];
+    mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+    mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+    mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int d = 0; d < 3; ++d) {
+    const float a = wave_min(mn[d]), b = wave_max(mx[d]);
+    if (lane == 0) { smin[d][wave] = a; smax[d][wave] = b; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int d = threadIdx.x;
+    float a = smin[d][0], b = smax[d][0];
+    for (int w = 1; w < 4; ++w) { a = fminf(a, smin[d][w]); b = fmaxf(b, smax[d][w]); }
+    part[blockIdx.x * 6 + d] = a;
+    part[blockIdx.x * 6 + 3 + d] = b;
+  }
+}
+
+}  // namespace
+
+// Build the tree of `n` points at d_pts (float4 {x,y,z,bitcast(original index)}, permuted in
+// place).  d_nodes must hold node_cap nodes.  Returns hipSuccess and fills `view`/depth, or
+// sets *fallback when the structure limits were hit (caller then uses the host builder).
+hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_t node_cap,
+                               hipStream_t stream, TreeView *view, int *depth, size_t *n_leaves,
+                               int *fallback) {
+  *fallback = 0;
+  view->nodes = d_nodes;
+  view->pts = d_pts;
+  view->n_pts = n;
+  view->n_nodes = 0;
+  view->root_ref = KD_LEAF;
+  for (int d = 0; d < 3; ++d) view->bb_lo[d] = view->bb_hi[d] = 0.f;
+  *depth = 0;
+  *n_leaves = 0;
+  if (n == 0) return hipSuccess;
+  hipError_t e;
+  // bounding box
+  constexpr int NB = 256;
+  float *d_part = nullptr;
+  if ((e = hipMalloc((void **)&d_part, NB * 6 * sizeof(float))) != hipSuccess) return e;
+  hipLaunchKernelGGL(kd_bbox_kernel, dim3(NB), dim3(256), 0, stream, d_pts, n, d_part);
+  float h_part[NB * 6];
+  if ((e = hipMemcpyAsync(h_part, d_part, sizeof(h_part), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+  (void)hipFree(d_part);
+  const int used = std::min(NB, (n + 255) / 256);
+  for (int d = 0; d < 3; ++d) {
+    float a = h_part[d], b = h_part[3 + d];
+    for (int k = 1; k < used; ++k) { a = std::min(a, h_part[k * 6 + d]); b = std::max(b, h_part[k * 6 + 3 + d]); }
+    view->bb_lo[d] = a;
+    view->bb_hi[d] = b;
+  }
+  if (n <= 10) {  // the root is a leaf
+    view->root_ref = KD_LEAF | (uint32_t)n;
+    *depth = 1;
+    *n_leaves = 1;
+    return hipSuccess;
+  }
+  const int32_t queue_cap = std::max(64, 4 * (n / LOCAL_MAX + 16));
+  BuildArgs A{};
+  A.pts = d_pts;
+  A.nodes = d_nodes;
+  A.node_cap = node_cap & ~7;
+  A.queue_cap = queue_cap;
+  A.n = n;
+  void *blob = nullptr;
+  const size_t sz_queue = (size_t)queue_cap * sizeof(BuildItem), sz_ready = (size_t)queue_cap * sizeof(int32_t),
+               sz_tmp = (size_t)n * sizeof(int32_t), sz_ctl = 256;
+  if ((e = hipMalloc(&blob, sz_queue + sz_ready + 2 * sz_tmp + sz_ctl)) != hipSuccess) return e;
+  char *p = static_cast<char *>(blob);
+  A.queue = reinterpret_cast<BuildItem *>(p); p += sz_queue;
+  A.q_ready = reinterpret_cast<int32_t *>(p); p += sz_ready;
+  A.tmpA = reinterpret_cast<int32_t *>(p); p += sz_tmp;
+  A.tmpB = reinterpret_cast<int32_t *>(p); p += sz_tmp;
+  A.ctl = reinterpret_cast<BuildCtl *>(p);
+  if ((e = hipMemsetAsync(A.q_ready, 0, sz_ready, stream)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(d_nodes, 0, (size_t)A.node_cap * sizeof(KdNode), stream)) != hipSuccess) return e;
+  BuildCtl ctl{};
+  ctl.q_head = 0;
+  ctl.q_tail_reserved = 1;
+  ctl.q_pending = 1;
+  ctl.next_group = 1;  // group 0 holds the root
+  BuildItem root{};
+  root.l = 0;
+  root.r = n;
+  for (int d = 0; d < 3; ++d) { root.lo[d] = view->bb_lo[d]; root.hi[d] = view->bb_hi[d]; }
+  root.slot = 0;
+  root.heap = 0;
+  root.parent_word = -1;
+  root.depth = 1;
+  const int32_t one = 1;
+  if ((e = hipMemcpyAsync(A.ctl, &ctl, sizeof(ctl), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(A.queue, &root, sizeof(root), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(A.q_ready, &one, sizeof(one), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+  // persistent grid: every workgroup must be resident (they wait on each other's output)
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  hipLaunchKernelGGL(kd_build_kernel, dim3(cus * 2), dim3(TB), 0, stream, A);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(&ctl, A.ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+  (void)hipFree(blob);
+  if (ctl.overflow) {
+    *fallback = ctl.overflow;
+    return hipSuccess;
+  }
+  view->n_nodes = ctl.next_group * 8;
+  view->root_ref = (0u << 2) | (uint32_t)ctl.root_feat;
+  *depth = ctl.max_depth;
+  *n_leaves = (size_t)ctl.n_leaves;
+  return hipSuccess;
+}
+
+}  // namespace lslam

@@ -409,17 +409,29 @@ int lslam_map_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const voi
     for (int k = 0; k < 2 && !need_host; ++k) {
       DevTree &dt = *trees[k];
       const size_t n = clouds[k]->size();
-      const size_t cap = ((2 * n / 3 + 64) + 7) & ~(size_t)7;
       HIP_TRY(dt.pts.reserve(n ? n : 1));
-      HIP_TRY(dt.nodes.reserve(cap));
-      if (n)
-        HIP_TRY(hipMemcpyAsync(dt.pts.p, clouds[k]->data(), n * sizeof(float4), hipMemcpyHostToDevice,
-                               ctx->stream));
+      // Node slots come in groups of 8 (one cache line per 3-level treelet); how full the
+      // groups get depends on the shape of the tree (a cloud of vertical lines leaves most
+      // of them nearly empty), so grow the slot array until the build fits: 2n/3, 8n/3, 8n.
       int fallback = 0;
       size_t n_leaves = 0;
-      HIP_TRY(build_kdtree_device(dt.pts.p, (int32_t)n, dt.nodes.p, (int32_t)cap, ctx->stream, &dt.view,
-                                  &dt.depth, &n_leaves, &fallback));
-      if (fallback) need_host = true;
+      for (int attempt = 0; attempt < 3; ++attempt) {
+        const size_t mult[3] = {2, 8, 24};
+        const size_t cap = ((mult[attempt] * n / 3 + 64) + 7) & ~(size_t)7;
+        HIP_TRY(dt.nodes.reserve(cap));
+        if (n)
+          HIP_TRY(hipMemcpyAsync(dt.pts.p, clouds[k]->data(), n * sizeof(float4), hipMemcpyHostToDevice,
+                                 ctx->stream));
+        HIP_TRY(build_kdtree_device(dt.pts.p, (int32_t)n, dt.nodes.p, (int32_t)cap, ctx->stream, &dt.view,
+                                    &dt.depth, &n_leaves, &fallback));
+        if (fallback != 1) break;
+      }
+      if (fallback) {
+        need_host = true;
+        if (std::getenv("LSLAM_DEBUG"))
+          fprintf(stderr, "[lslam] device kd-tree build of %zu points hit limit %d (1 nodes, 2 spin, 3 queue): "
+                          "host build instead\n", n, fallback);
+      }
       *ncount[k] = (size_t)dt.view.n_nodes / 8 * 7 + n_leaves;  // approximate node count
     }
     t2 = now_ms();

@@ -24,6 +24,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include "lslam_internal.hpp"
 
@@ -31,9 +34,15 @@ namespace lslam {
 
 namespace {
 
-constexpr int TB = 256;            // threads per workgroup
-constexpr int LOCAL_MAX = 8192;    // subtrees up to this many points are finished locally
-constexpr int LOCAL_STACK = 64;
+// Two phases.  Phase A: workgroups of TB_BIG threads take nodes with more than LOCAL_MAX
+// points from a global queue (hand-off with agent-scope release/acquire); a child with at
+// most LOCAL_MAX points goes to the subtree list instead.  Phase B: one wavefront per
+// subtree of that list builds it completely (explicit stack in LDS, no barriers needed).
+constexpr int TB_BIG = 1024;
+constexpr int TB_SMALL = 64;
+constexpr int TE = 8;              // consecutive elements per thread in the partition scans
+constexpr int LOCAL_MAX = 2048;    // subtrees up to this many points are built by one wavefront
+constexpr int LOCAL_STACK = 48;
 
 struct BuildItem {   // one pending inner node
   int32_t l, r;      // point range
@@ -52,6 +61,8 @@ struct BuildCtl {
   int32_t overflow;     // node array or queue too small
   int32_t root_feat;
   int32_t n_leaves;
+  int32_t n_sub;       // entries of the subtree list
+  int32_t sub_next;    // next entry to take in phase B
 };
 
 struct BuildArgs {
@@ -61,6 +72,8 @@ struct BuildArgs {
   BuildItem *queue;
   int32_t *q_ready;   // per queue entry
   int32_t queue_cap;
+  BuildItem *sublist;  // phase B work list (subtree roots with <= LOCAL_MAX points)
+  int32_t sub_cap;
   int32_t *tmpA, *tmpB;  // scratch, one int per point
   BuildCtl *ctl;
   int32_t n;
@@ -68,6 +81,7 @@ struct BuildArgs {
 
 __device__ __forceinline__ float coord(const float4 &p, int d) { return d == 0 ? p.x : (d == 1 ? p.y : p.z); }
 
+template <int TB>
 struct Sh {
   float fmin[3][TB / 64], fmax[3][TB / 64];
   int isum[2][TB / 64];
@@ -97,7 +111,8 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 }
 
 // exclusive prefix sum of `flag` over the block's TB threads; returns prefix, *total
-__device__ __forceinline__ int block_excl_scan(int flag, Sh &sh, int *total) {
+template <int TB>
+__device__ __forceinline__ int block_excl_scan(int flag, Sh<TB> &sh, int *total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int v = flag;
 #pragma unroll
@@ -122,37 +137,50 @@ __device__ __forceinline__ int block_excl_scan(int flag, Sh &sh, int *total) {
 // `lt` selects the predicate: true: "x < cut" belongs left; false: "x <= cut" belongs left.
 // L = number of elements that belong left.  Elements [a, a+L) that do not belong left are
 // swapped, k-th from the left, with the k-th element from the right of [a+L, b) that does.
-__device__ void hoare_pass(const BuildArgs &A, Sh &sh, int l, int a, int b, int L, int feat, float cut,
+template <int TB>
+__device__ void hoare_pass(const BuildArgs &A, Sh<TB> &sh, int l, int a, int b, int L, int feat, float cut,
                            bool lt) {
   const int tid = threadIdx.x;
   const int nl = L, nr = (b - a) - L;
   if (nl == 0 || nr == 0) return;
   int run = 0;
-  for (int c = 0; c < nl; c += TB) {  // misplaced on the left, increasing index
-    const int i = c + tid;
-    int flag = 0;
-    if (i < nl) {
-      const float x = coord(A.pts[l + a + i], feat);
-      flag = lt ? !(x < cut) : !(x <= cut);
+  for (int c = 0; c < nl; c += TB * TE) {  // misplaced on the left, increasing index
+    const int i0 = c + tid * TE;           // each thread owns TE consecutive elements
+    unsigned mask = 0;
+#pragma unroll
+    for (int u = 0; u < TE; ++u) {
+      const int i = i0 + u;
+      if (i < nl) {
+        const float x = coord(A.pts[l + a + i], feat);
+        if (lt ? !(x < cut) : !(x <= cut)) mask |= 1u << u;
+      }
     }
     int tot;
-    const int pre = block_excl_scan(flag, sh, &tot);
-    if (flag) A.tmpA[l + run + pre] = a + i;
+    int pre = block_excl_scan(__popc(mask), sh, &tot);
+#pragma unroll
+    for (int u = 0; u < TE; ++u)
+      if (mask & (1u << u)) A.tmpA[l + run + pre++] = a + i0 + u;
     run += tot;
   }
   const int m = run;
   if (m == 0) return;
   run = 0;
-  for (int c = 0; c < nr; c += TB) {  // misplaced on the right, decreasing index
-    const int i = c + tid;
-    int flag = 0;
-    if (i < nr) {
-      const float x = coord(A.pts[l + b - 1 - i], feat);
-      flag = lt ? (x < cut) : (x <= cut);
+  for (int c = 0; c < nr; c += TB * TE) {  // misplaced on the right, decreasing index
+    const int i0 = c + tid * TE;
+    unsigned mask = 0;
+#pragma unroll
+    for (int u = 0; u < TE; ++u) {
+      const int i = i0 + u;
+      if (i < nr) {
+        const float x = coord(A.pts[l + b - 1 - i], feat);
+        if (lt ? (x < cut) : (x <= cut)) mask |= 1u << u;
+      }
     }
     int tot;
-    const int pre = block_excl_scan(flag, sh, &tot);
-    if (flag) A.tmpB[l + run + pre] = b - 1 - i;
+    int pre = block_excl_scan(__popc(mask), sh, &tot);
+#pragma unroll
+    for (int u = 0; u < TE; ++u)
+      if (mask & (1u << u)) A.tmpB[l + run + pre++] = b - 1 - (i0 + u);
     run += tot;
   }
   __syncthreads();
@@ -176,7 +204,8 @@ __device__ __forceinline__ int alloc_group(const BuildArgs &A) {
 
 // Process one inner node (block-cooperative).  Children that are inner nodes are returned
 // in out[0..1] (count in *n_out) for the caller to schedule.
-__device__ void process_node(const BuildArgs &A, Sh &sh, const BuildItem &it, BuildItem out[2], int *n_out) {
+template <int TB>
+__device__ void process_node(const BuildArgs &A, Sh<TB> &sh, const BuildItem &it, BuildItem out[2], int *n_out) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l = it.l, n = it.r - it.l;
   // ---- min / max of the three coordinates (computeMinMax, :908-920) ---------------
@@ -298,71 +327,65 @@ __device__ void process_node(const BuildArgs &A, Sh &sh, const BuildItem &it, Bu
   __syncthreads();
 }
 
-__global__ __launch_bounds__(TB) void kd_build_kernel(BuildArgs A) {
-  __shared__ Sh sh;
+// Phase A: nodes with more than LOCAL_MAX points, one workgroup per node, global queue.
+__global__ __launch_bounds__(TB_BIG) void kd_build_big_kernel(BuildArgs A) {
+  constexpr int TB = TB_BIG;
+  __shared__ Sh<TB> sh;
   const int tid = threadIdx.x;
-  if (tid == 0) sh.sp = 0;
-  __syncthreads();
   for (;;) {
-    // ---- take a node: local stack first, then the global queue --------------------
     if (tid == 0) {
       sh.have = 0;
-      if (sh.sp > 0) {
-        sh.item = sh.stack[--sh.sp];
-        sh.have = 1;
-      } else {
-        for (unsigned spins = 0;; ++spins) {
-          const int head = __hip_atomic_load(&A.ctl->q_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const int tail = __hip_atomic_load(&A.ctl->q_tail_reserved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (head < tail) {
-            int expect = head;
-            if (__hip_atomic_compare_exchange_strong(&A.ctl->q_head, &expect, head + 1, __ATOMIC_RELAXED,
-                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-              // wait until the producer has published entry `head`
-              while (__hip_atomic_load(&A.q_ready[head], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-                __builtin_amdgcn_s_sleep(2);
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-              const int *src = reinterpret_cast<const int *>(&A.queue[head]);
-              int *dst = reinterpret_cast<int *>(&sh.item);
-              for (int k = 0; k < (int)(sizeof(BuildItem) / 4); ++k)
-                dst[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              sh.have = 2;
-              break;
-            }
-          } else if (__hip_atomic_load(&A.ctl->q_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 ||
-                     __hip_atomic_load(&A.ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-            break;  // everything is built
-          } else {
-            __builtin_amdgcn_s_sleep(8);
-            if (spins > (1u << 26)) { A.ctl->overflow = 2; break; }  // bounded spin
+      for (unsigned spins = 0;; ++spins) {
+        const int head = __hip_atomic_load(&A.ctl->q_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int tail = __hip_atomic_load(&A.ctl->q_tail_reserved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (head < tail) {
+          int expect = head;
+          if (__hip_atomic_compare_exchange_strong(&A.ctl->q_head, &expect, head + 1, __ATOMIC_RELAXED,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            // wait until the producer has published entry `head`
+            while (__hip_atomic_load(&A.q_ready[head], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+              __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const int *src = reinterpret_cast<const int *>(&A.queue[head]);
+            int *dst = reinterpret_cast<int *>(&sh.item);
+            for (int k = 0; k < (int)(sizeof(BuildItem) / 4); ++k)
+              dst[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh.have = 1;
+            break;
           }
+        } else if (__hip_atomic_load(&A.ctl->q_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 ||
+                   __hip_atomic_load(&A.ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          break;  // every big node is done
+        } else {
+          __builtin_amdgcn_s_sleep(8);
+          if (spins > (1u << 26)) { A.ctl->overflow = 2; break; }  // bounded spin
         }
       }
     }
     __syncthreads();
     if (!sh.have) return;
-    if (sh.have == 2) {  // points written by another workgroup: drop stale L1 lines
-      if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __syncthreads();
-    }
+    // the points of this range were last written by another workgroup: drop stale L1 lines
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
     const BuildItem it = sh.item;
     BuildItem kids[2];
     int nk = 0;
-    process_node(A, sh, it, kids, &nk);
-    // ---- schedule the children ------------------------------------------------------
+    process_node<TB>(A, sh, it, kids, &nk);
     if (tid == 0) {
-      int published = 0;
+      bool released = false;
       for (int c = 0; c < nk; ++c) {
         const int cn = kids[c].r - kids[c].l;
-        if (cn <= LOCAL_MAX && sh.sp < LOCAL_STACK) {
-          sh.stack[sh.sp++] = kids[c];
+        if (cn <= LOCAL_MAX) {  // phase B (next launch: ordinary kernel-boundary visibility)
+          const int e = atomicAdd(&A.ctl->n_sub, 1);
+          if (e >= A.sub_cap) { A.ctl->overflow = 3; continue; }
+          A.sublist[e] = kids[c];
         } else {
           const int e = atomicAdd(&A.ctl->q_tail_reserved, 1);
           if (e >= A.queue_cap) { A.ctl->overflow = 3; continue; }
-          if (!published) {  // make this workgroup's point swaps / node writes visible
+          if (!released) {  // make this workgroup's point swaps / node writes visible
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            published = 1;
+            released = true;
           }
           atomicAdd(&A.ctl->q_pending, 1);
           const int *src = reinterpret_cast<const int *>(&kids[c]);
@@ -372,9 +395,44 @@ __global__ __launch_bounds__(TB) void kd_build_kernel(BuildArgs A) {
           __hip_atomic_store(&A.q_ready[e], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-      if (sh.have == 2) atomicSub(&A.ctl->q_pending, 1);  // this queued node is done
+      atomicSub(&A.ctl->q_pending, 1);  // this node is done
     }
     __syncthreads();
+  }
+}
+
+// Phase B: one wavefront per listed subtree; depth-first with a stack in LDS.
+__global__ __launch_bounds__(TB_SMALL) void kd_build_small_kernel(BuildArgs A) {
+  constexpr int TB = TB_SMALL;
+  __shared__ Sh<TB> sh;
+  const int tid = threadIdx.x;
+  for (;;) {
+    if (tid == 0) {
+      const int e = atomicAdd(&A.ctl->sub_next, 1);
+      sh.have = e < A.ctl->n_sub;
+      if (sh.have) {
+        sh.stack[0] = A.sublist[e];
+        sh.sp = 1;
+      }
+    }
+    __syncthreads();
+    if (!sh.have) return;
+    while (sh.sp > 0) {
+      __syncthreads();
+      const BuildItem it = sh.stack[sh.sp - 1];
+      __syncthreads();
+      BuildItem kids[2];
+      int nk = 0;
+      process_node<TB>(A, sh, it, kids, &nk);
+      if (tid == 0) {
+        --sh.sp;
+        for (int c = nk - 1; c >= 0; --c) {  // left child on top: nanoflann's recursion order
+          if (sh.sp < LOCAL_STACK) sh.stack[sh.sp++] = kids[c];
+          else A.ctl->overflow = 4;
+        }
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -411,6 +469,9 @@ __global__ __launch_bounds__(256) void kd_bbox_kernel(const float4 *pts, int n, 
 hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_t node_cap,
                                hipStream_t stream, TreeView *view, int *depth, size_t *n_leaves,
                                int *fallback) {
+  const bool dbg = std::getenv("LSLAM_DEBUG") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double T0 = now();
   *fallback = 0;
   view->nodes = d_nodes;
   view->pts = d_pts;
@@ -438,6 +499,7 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
     view->bb_lo[d] = a;
     view->bb_hi[d] = b;
   }
+  const double T1 = now();
   if (n <= 10) {  // the root is a leaf
     view->root_ref = KD_LEAF | (uint32_t)n;
     *depth = 1;
@@ -445,6 +507,7 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
     return hipSuccess;
   }
   const int32_t queue_cap = std::max(64, 4 * (n / LOCAL_MAX + 16));
+  const int32_t sub_cap = std::max(64, 4 * (n / LOCAL_MAX + 16) + n / 8);
   BuildArgs A{};
   A.pts = d_pts;
   A.nodes = d_nodes;
@@ -452,11 +515,13 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
   A.queue_cap = queue_cap;
   A.n = n;
   void *blob = nullptr;
+  A.sub_cap = sub_cap;
   const size_t sz_queue = (size_t)queue_cap * sizeof(BuildItem), sz_ready = (size_t)queue_cap * sizeof(int32_t),
-               sz_tmp = (size_t)n * sizeof(int32_t), sz_ctl = 256;
-  if ((e = hipMalloc(&blob, sz_queue + sz_ready + 2 * sz_tmp + sz_ctl)) != hipSuccess) return e;
+               sz_tmp = (size_t)n * sizeof(int32_t), sz_ctl = 256, sz_sub = (size_t)sub_cap * sizeof(BuildItem);
+  if ((e = hipMalloc(&blob, sz_queue + sz_sub + sz_ready + 2 * sz_tmp + sz_ctl)) != hipSuccess) return e;
   char *p = static_cast<char *>(blob);
   A.queue = reinterpret_cast<BuildItem *>(p); p += sz_queue;
+  A.sublist = reinterpret_cast<BuildItem *>(p); p += sz_sub;
   A.q_ready = reinterpret_cast<int32_t *>(p); p += sz_ready;
   A.tmpA = reinterpret_cast<int32_t *>(p); p += sz_tmp;
   A.tmpB = reinterpret_cast<int32_t *>(p); p += sz_tmp;
@@ -477,18 +542,31 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
   root.parent_word = -1;
   root.depth = 1;
   const int32_t one = 1;
+  const bool root_small = n <= LOCAL_MAX;
+  if (root_small) {  // the whole tree is one phase-B subtree
+    ctl.q_tail_reserved = 0;
+    ctl.q_pending = 0;
+    ctl.n_sub = 1;
+  }
   if ((e = hipMemcpyAsync(A.ctl, &ctl, sizeof(ctl), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-  if ((e = hipMemcpyAsync(A.queue, &root, sizeof(root), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(root_small ? A.sublist : A.queue, &root, sizeof(root), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(A.q_ready, &one, sizeof(one), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
   // persistent grid: every workgroup must be resident (they wait on each other's output)
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  hipLaunchKernelGGL(kd_build_kernel, dim3(cus * 2), dim3(TB), 0, stream, A);
+  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+  const double T2 = now();
+  if (!root_small) hipLaunchKernelGGL(kd_build_big_kernel, dim3(cus), dim3(TB_BIG), 0, stream, A);
+  hipLaunchKernelGGL(kd_build_small_kernel, dim3(cus * 16), dim3(TB_SMALL), 0, stream, A);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(&ctl, A.ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
   if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+  const double T3 = now();
   (void)hipFree(blob);
+  if (dbg)
+    fprintf(stderr, "[lslam] tree build n=%d: bbox %.2f ms, setup %.2f ms, build kernel %.2f ms, free %.2f ms (overflow %d, groups %d)\n",
+            n, T1 - T0, T2 - T1, T3 - T2, now() - T3, ctl.overflow, ctl.next_group);
   if (ctl.overflow) {
     *fallback = ctl.overflow;
     return hipSuccess;

@@ -121,6 +121,19 @@ int lslam_map_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const voi
                   size_t n_surf, size_t stride_bytes);
 int lslam_map_info_get(const lslam_ctx *ctx, lslam_map_info *info);
 
+/* Variant C -- the map as FeatureMap keeps it (util/FeatureMap.h): a grid of dims[0] x dims[1]
+ * x dims[2] cubes of cube_size metres (50), cube of a point = round(p/cube_size) + origin
+ * (worldToCube, :475-487); every cube gets its own kd-tree (as _kdtreeCorner/_kdtreeSurf,
+ * :71-72,438,453).  After this call the scan-match entry points behave like
+ * FeatureMap::scanMatchScan (:490-691): a scan point is searched only in the tree of the cube
+ * it falls into, cubes with fewer than 5 points are skipped, and there is no
+ * "reference cloud too few" guard.  The caller passes the reference's settings through
+ * lslam_opts (max_iterations 10, thresholds 0.05/0.05, use_score 0).  lslam_map_set
+ * switches back to the whole-map trees of ScanMatch::scanMatchScan. */
+int lslam_cubemap_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const void *surf,
+                      size_t n_surf, size_t stride_bytes, float cube_size, const int32_t origin[3],
+                      const int32_t dims[3]);
+
 /* ---- scan (query clouds) ------------------------------------------------ */
 
 /* Uploads the scan's corner/surf feature clouds (CornerCloud / SurfCloud of

@@ -1135,3 +1135,108 @@ int oracle_scanmatch_scan(const float *map_c, size_t nc, const float *map_s, siz
   oracle_kdtree_free(ts);
   return ok;
 }
+
+
+/* ======================================================================== */
+/* Variant C: per-cube kd-trees (util/FeatureMap.h:465-691)                 */
+/* ======================================================================== */
+
+typedef struct {
+  float *pts;          /* packed 4 floats per point, cube by cube */
+  oracle_kdtree **tree; /* per cube (NULL when empty) */
+  size_t *count, *first;
+  int n_cubes;
+} cube_set;
+
+/* worldToCube + isIndexValid + toIndex (FeatureMap.h:475-487,102-108,146-148) */
+static int cube_index(const oracle_cube_grid *g, float x, float y, float z) {
+  int gi = (int)(roundf(x / g->cube_size) + (float)g->origin[0]);
+  int gj = (int)(roundf(y / g->cube_size) + (float)g->origin[1]);
+  int gk = (int)(roundf(z / g->cube_size) + (float)g->origin[2]);
+  if (0 <= gi && gi < g->dims[0] && 0 <= gj && gj < g->dims[1] && 0 <= gk && gk < g->dims[2])
+    return gi + gj * g->dims[0] + gk * g->dims[0] * g->dims[1];
+  return -1;
+}
+
+static void cube_set_build(cube_set *cs, const oracle_cube_grid *g, const float *map, size_t n, size_t stride) {
+  cs->n_cubes = g->dims[0] * g->dims[1] * g->dims[2];
+  cs->count = (size_t *)calloc((size_t)cs->n_cubes, sizeof(size_t));
+  cs->first = (size_t *)calloc((size_t)cs->n_cubes + 1, sizeof(size_t));
+  cs->tree = (oracle_kdtree **)calloc((size_t)cs->n_cubes, sizeof(oracle_kdtree *));
+  cs->pts = (float *)malloc((n ? n : 1) * 4 * sizeof(float));
+  int *idx = (int *)malloc((n ? n : 1) * sizeof(int));
+  for (size_t i = 0; i < n; ++i) {  /* pushCornerPoint / pushSurfPoint, :188-204 */
+    idx[i] = cube_index(g, map[i * stride], map[i * stride + 1], map[i * stride + 2]);
+    if (idx[i] >= 0) cs->count[idx[i]]++;
+  }
+  for (int c = 0; c < cs->n_cubes; ++c) cs->first[c + 1] = cs->first[c] + cs->count[c];
+  size_t *fill = (size_t *)calloc((size_t)cs->n_cubes, sizeof(size_t));
+  for (size_t i = 0; i < n; ++i) {
+    if (idx[i] < 0) continue;
+    float *d = cs->pts + 4 * (cs->first[idx[i]] + fill[idx[i]]++);
+    d[0] = map[i * stride]; d[1] = map[i * stride + 1]; d[2] = map[i * stride + 2]; d[3] = 0;
+  }
+  for (int c = 0; c < cs->n_cubes; ++c)
+    if (cs->count[c]) cs->tree[c] = oracle_kdtree_build(cs->pts + 4 * cs->first[c], cs->count[c], 4);
+  free(fill);
+  free(idx);
+}
+
+static void cube_set_free(cube_set *cs) {
+  for (int c = 0; c < cs->n_cubes; ++c) oracle_kdtree_free(cs->tree[c]);
+  free(cs->tree); free(cs->count); free(cs->first); free(cs->pts);
+}
+
+int oracle_scanmatch_cubes(const float *map_c, size_t nc, const float *map_s, size_t ns,
+                           size_t map_stride, const oracle_cube_grid *grid, const float *qc,
+                           size_t nqc, const float *qs, size_t nqs, size_t q_stride,
+                           float pose_io[6], oracle_stats *st) {
+  oracle_stats local;
+  if (!st) st = &local;
+  memset(st, 0, sizeof(*st));
+  cube_set cc, cs;
+  cube_set_build(&cc, grid, map_c, nc, map_stride);
+  cube_set_build(&cs, grid, map_s, ns, map_stride);
+  float pose[6];
+  memcpy(pose, pose_io, sizeof(pose));
+  int converge = 0, degenerate = 0;
+  float matP[36];
+  memset(matP, 0, sizeof(matP));
+  sweep_acc acc;
+  for (int iter = 0; iter < 10; ++iter) { /* FeatureMap.h:515 */
+    float R[9], t[3], sc[6];
+    memset(&acc, 0, sizeof(acc));
+    oracle_pose_to_Rt(pose, R, t);
+    pose_sincos(pose, sc);
+    for (int type = 0; type < 2; ++type) {
+      const cube_set *set = type ? &cs : &cc;
+      const float *q = type ? qs : qc;
+      const size_t nq = type ? nqs : nqc;
+      for (size_t i = 0; i < nq; ++i) {
+        float sel[3];
+        oracle_transform_point(R, t, q + i * q_stride, sel);
+        int idx = cube_index(grid, sel[0], sel[1], sel[2]); /* :523,545 */
+        if (idx < 0) continue;
+        if (set->count[idx] < 5) continue;                  /* :524,546 */
+        sweep_point(set->tree[idx], set->pts + 4 * set->first[idx], 4, type, q + i * q_stride, R, t, sc,
+                    -1.0f, &acc, NULL, NULL, NULL, NULL);
+      }
+    }
+    st->point_residuals += (long long)(nqc + nqs);
+    st->n_line = acc.n_line;
+    st->n_plane = acc.n_plane;
+    st->n_rows = acc.n_rows;
+    if (acc.n_rows < 50) break; /* :571-574 */
+    converge = oracle_gn_step(acc.AtA, acc.Atb, iter, pose, matP, &degenerate, 100.0f, 0.05f, 0.05f, NULL,
+                              &st->delta_r, &st->delta_t);
+    st->iterations = iter + 1;
+    if (converge) break; /* :685-688 */
+  }
+  st->degenerate = degenerate;
+  st->converged = converge;
+  st->status = converge ? 0 : 2;
+  memcpy(pose_io, pose, sizeof(pose)); /* :690 */
+  cube_set_free(&cc);
+  cube_set_free(&cs);
+  return converge;
+}

@@ -146,6 +146,23 @@ int oracle_scanmatch_scan(const float *map_c, size_t nc, const float *map_s, siz
                           size_t nqs, size_t q_stride, float pose[6],
                           const oracle_opts *opts, oracle_stats *stats);
 
+/* Variant C: FeatureMap::scanMatchScan(Corner, Surf, Twist&) (util/FeatureMap.h:490-691):
+ * the map is a grid of cubes (worldToCube, :475-487: round(p/size)+origin), each with its
+ * own kd-tree; a scan point is searched only in the tree of the cube it falls into, cubes
+ * with fewer than 5 points are skipped (:524,546); at most 10 iterations, thresholds
+ * 0.05/0.05 (:515,685), no score gate, no return value (quirk Q6).
+ * map clouds are partitioned into cubes in input order (pushCornerPoint, :188-196). */
+typedef struct {
+  float cube_size;    /* _worldCubeSize (50) */
+  int32_t origin[3];  /* _cubeOriginWidth/Height/Depth */
+  int32_t dims[3];    /* _cubeWidth/Height/Depth */
+} oracle_cube_grid;
+
+int oracle_scanmatch_cubes(const float *map_c, size_t nc, const float *map_s, size_t ns,
+                           size_t map_stride, const oracle_cube_grid *grid, const float *qc,
+                           size_t nqc, const float *qs, size_t nqs, size_t q_stride,
+                           float pose[6], oracle_stats *stats);
+
 /* One GN solve step given sums (ScanMatch.cpp:206-260).  iter==0 computes the
  * degeneracy projector into matP/degenerate (in/out state). Returns converged. */
 int oracle_gn_step(const float AtA[36], const float Atb[6], int iter, float pose[6],

@@ -30,6 +30,10 @@ class OracleOpts(C.Structure):
     ]
 
 
+class OracleCubeGrid(C.Structure):
+    _fields_ = [("cube_size", C.c_float), ("origin", C.c_int32 * 3), ("dims", C.c_int32 * 3)]
+
+
 class OracleStats(C.Structure):
     _fields_ = [
         ("status", C.c_int),
@@ -117,6 +121,10 @@ class Oracle:
         L.oracle_scanmatch_scan.argtypes = [c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_size_t,
                                             c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_size_t,
                                             c_float_p, C.POINTER(OracleOpts), C.POINTER(OracleStats)]
+        L.oracle_scanmatch_cubes.restype = C.c_int
+        L.oracle_scanmatch_cubes.argtypes = [c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_size_t,
+                                             C.POINTER(OracleCubeGrid), c_float_p, C.c_size_t, c_float_p,
+                                             C.c_size_t, C.c_size_t, c_float_p, C.POINTER(OracleStats)]
         L.oracle_gn_step.restype = C.c_int
         L.oracle_gn_step.argtypes = [c_float_p, c_float_p, C.c_int, c_float_p, c_float_p,
                                      C.POINTER(C.c_int), C.c_float, C.c_float, C.c_float,
@@ -243,6 +251,18 @@ class Oracle:
         ok = self.lib.oracle_scanmatch_scan(_fp(map_c), len(map_c), _fp(map_s), len(map_s), sm,
                                             _fp(qc), len(qc), _fp(qs), len(qs), sq, _fp(pose),
                                             C.byref(opts), C.byref(st))
+        return bool(ok), pose, st
+
+    def scanmatch_cubes(self, map_c, map_s, qc, qs, pose, cube_size, origin, dims):
+        map_c, sm = as_cloud(map_c)
+        map_s, _ = as_cloud(map_s)
+        qc, sq = as_cloud(qc)
+        qs, _ = as_cloud(qs)
+        pose = np.array(pose, np.float32)
+        g = OracleCubeGrid(cube_size, (C.c_int32 * 3)(*origin), (C.c_int32 * 3)(*dims))
+        st = OracleStats()
+        ok = self.lib.oracle_scanmatch_cubes(_fp(map_c), len(map_c), _fp(map_s), len(map_s), sm, C.byref(g),
+                                             _fp(qc), len(qc), _fp(qs), len(qs), sq, _fp(pose), C.byref(st))
         return bool(ok), pose, st
 
     def gn_step(self, AtA, Atb, it, pose, matP, degenerate, eig_thresh=100.0, dr=0.05, dt=0.05):

@@ -333,6 +333,34 @@ def test_batch_equals_individual_runs(ctx, synth, small_problem):
     assert np.array_equal(bits(poses2), bits(poses))
 
 
+def test_cube_map_variant_matches_oracle(ctx, oracle, small_problem):
+    """Variant C, FeatureMap::scanMatchScan (util/FeatureMap.h:490-691): per-cube kd-trees.
+    20 m cubes so that the 120 m test map spans many cubes and points near cube borders
+    really see a different neighbourhood than with the whole-map tree."""
+    pr = small_problem
+    grid = dict(cube_size=20.0, origin=(5, 5, 1), dims=(11, 11, 3))
+    ctx.cubemap_set(pr["map_corner"], pr["map_surf"], **grid)
+    opts = ctx.default_opts()
+    opts.use_score = 0  # no score gate in this variant
+    status, pose, st = ctx.scanmatch_scan(pr["corner"], pr["surf"], pr["init_pose"], opts)
+    ok, opose, ost = oracle.scanmatch_cubes(pr["map_corner"], pr["map_surf"], pr["corner"], pr["surf"],
+                                            pr["init_pose"], grid["cube_size"], grid["origin"], grid["dims"])
+    assert st.converged == ost.converged == 1 and st.iterations == ost.iterations
+    assert (st.n_line, st.n_plane, st.n_rows) == (ost.n_line, ost.n_plane, ost.n_rows)
+    assert np.abs(pose[3:] - opose[3:]).max() <= POSE_TOL_M and np.abs(pose[:3] - opose[:3]).max() <= POSE_TOL_RAD
+    # it is a different computation from the whole-map search
+    ok2, wpose, wst = oracle.scanmatch_scan(pr["map_corner"], pr["map_surf"], pr["corner"], pr["surf"],
+                                            pr["init_pose"])
+    assert wst.n_rows != ost.n_rows
+    # a grid that does not cover the scene: every point falls outside -> too few matches
+    ctx.cubemap_set(pr["map_corner"], pr["map_surf"], cube_size=20.0, origin=(-50, -50, 0), dims=(2, 2, 1))
+    status, pose, st = ctx.scanmatch_scan(pr["corner"], pr["surf"], pr["init_pose"], opts)
+    assert status == 5 and st.n_rows == 0
+    ctx.map_set(pr["map_corner"], pr["map_surf"])  # back to whole-map trees
+    status, pose, st = ctx.scanmatch_scan(pr["corner"], pr["surf"], pr["init_pose"])
+    assert st.n_rows == wst.n_rows
+
+
 def test_scanmatch_class_mirrors_reference_api(pkg, oracle, small_problem):
     pr = small_problem
     sm = pkg.ScanMatch(10)

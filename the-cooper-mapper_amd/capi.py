@@ -107,6 +107,8 @@ SYMBOLS = {
     "lslam_default_opts": (None, [C.POINTER(LslamOpts)]),
     "lslam_map_set": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t]),
     "lslam_map_info_get": (C.c_int, [C.c_void_p, C.POINTER(LslamMapInfo)]),
+    "lslam_cubemap_set": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
+                                    C.c_float, c_int32_p, c_int32_p]),
     "lslam_scan_set": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t]),
     "lslam_scan_set_batch": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                        C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t]),

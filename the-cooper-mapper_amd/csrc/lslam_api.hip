@@ -87,6 +87,11 @@ struct lslam_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   DevTree tc, ts;
+  // variant C: per-cube trees (shared node/point arrays in tc/ts, one TreeView per cube)
+  bool cube_mode = false;
+  CubeGridDev gc{}, gs{};
+  DevBuf<int32_t> cell_c, cell_s;
+  DevBuf<TreeView> views_c, views_s;
   bool have_map = false;
   bool have_scan = false;
   lslam_map_info info{};
@@ -206,6 +211,12 @@ void init_state(GNState &s, const float pose[6]) {
 void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
   a.tc = ctx->tc.view;
   a.ts = ctx->ts.view;
+  a.gc = CubeGridDev{};
+  a.gs = CubeGridDev{};
+  if (ctx->cube_mode) {
+    a.gc = ctx->gc;
+    a.gs = ctx->gs;
+  }
   a.q = ctx->q.p;
   a.blocks = ctx->blocks.p;
   a.nb_total = ctx->nb_total;
@@ -306,6 +317,7 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   ctx->tc.nodes.release(); ctx->tc.pts.release();
   ctx->ts.nodes.release(); ctx->ts.pts.release();
+  ctx->cell_c.release(); ctx->cell_s.release(); ctx->views_c.release(); ctx->views_s.release();
   ctx->q.release(); ctx->blocks.release(); ctx->probs.release(); ctx->partials.release(); ctx->stack_ovf.release();
   ctx->t_idx.release(); ctx->t_d2.release(); ctx->t_coeff.release(); ctx->t_flags.release();
   ctx->t_q.release(); ctx->t_small.release();
@@ -389,6 +401,7 @@ int lslam_map_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const voi
     return LSLAM_ERR_INVALID;
   }
   ctx->have_map = false;
+  ctx->cube_mode = false;
   const double t0 = now_ms();
   std::vector<float4> cc, cs;
   static const bool host_tree = std::getenv("LSLAM_HOST_TREE") != nullptr;  // A/B and fallback
@@ -470,6 +483,125 @@ int lslam_map_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const voi
   ctx->info.build_ms = (float)(built_on_device ? (t2 - t1) : (t1 - t0));
   ctx->info.upload_ms = (float)(built_on_device ? (t1 - t0) : (t2 - t1));
   ctx->info.built_on_device = built_on_device;
+  ctx->have_map = true;
+  return LSLAM_OK;
+}
+
+namespace {
+
+// Partition one cloud into cubes (pushCornerPoint / pushSurfPoint, util/FeatureMap.h:188-204:
+// input order is kept inside a cube), build one tree per cube with >= 5 points and upload
+// everything into shared node / point arrays.
+int build_cube_trees(lslam_ctx *ctx, const void *cloud, size_t n, size_t stride_bytes, float cube_size,
+                     const int32_t origin[3], const int32_t dims[3], DevTree &dt, DevBuf<int32_t> &cells_d,
+                     DevBuf<TreeView> &views_d, CubeGridDev &grid, int *max_depth, size_t *n_nodes) {
+  std::vector<float4> pts;
+  pack_cloud(cloud, n, stride_bytes, pts);
+  const size_t n_cells = (size_t)dims[0] * dims[1] * dims[2];
+  std::vector<int32_t> cell_of(n), count(n_cells, 0);
+  for (size_t i = 0; i < n; ++i) {
+    const int gi = (int)(std::round(pts[i].x / cube_size) + (float)origin[0]);
+    const int gj = (int)(std::round(pts[i].y / cube_size) + (float)origin[1]);
+    const int gk = (int)(std::round(pts[i].z / cube_size) + (float)origin[2]);
+    const bool ok = 0 <= gi && gi < dims[0] && 0 <= gj && gj < dims[1] && 0 <= gk && gk < dims[2];
+    cell_of[i] = ok ? gi + gj * dims[0] + gk * dims[0] * dims[1] : -1;
+    if (ok) count[cell_of[i]]++;
+  }
+  std::vector<size_t> first(n_cells + 1, 0);
+  for (size_t c = 0; c < n_cells; ++c) first[c + 1] = first[c] + (size_t)count[c];
+  std::vector<float4> sorted(first[n_cells]);
+  std::vector<size_t> fill(first.begin(), first.end() - 1);
+  for (size_t i = 0; i < n; ++i)
+    if (cell_of[i] >= 0) sorted[fill[cell_of[i]]++] = pts[i];
+  std::vector<int32_t> cell_tree(n_cells, -1);
+  std::vector<TreeView> views;
+  std::vector<KdNode> all_nodes;
+  std::vector<float4> all_pts;
+  std::vector<size_t> node_off, pts_off;
+  *max_depth = 0;
+  for (size_t c = 0; c < n_cells; ++c) {
+    if (count[c] < 5) continue;  // FeatureMap.h:524,546
+    HostTree ht;
+    build_kdtree_host(reinterpret_cast<const float *>(sorted.data() + first[c]), (size_t)count[c], 4, ht);
+    TreeView v{};
+    v.n_pts = count[c];
+    v.n_nodes = (int32_t)ht.nodes.size();
+    v.root_ref = ht.root_ref;
+    for (int d = 0; d < 3; ++d) { v.bb_lo[d] = ht.bb_lo[d]; v.bb_hi[d] = ht.bb_hi[d]; }
+    cell_tree[c] = (int32_t)views.size();
+    node_off.push_back(all_nodes.size());
+    pts_off.push_back(all_pts.size());
+    all_nodes.insert(all_nodes.end(), ht.nodes.begin(), ht.nodes.end());
+    while (all_nodes.size() & 7) all_nodes.push_back(KdNode{0.f, 0.f, KD_LEAF, KD_LEAF});  // keep lines aligned
+    for (int32_t k = 0; k < count[c]; ++k) {
+      float4 p = sorted[first[c] + (size_t)ht.vind[(size_t)k]];
+      p.w = __builtin_bit_cast(float, ht.vind[(size_t)k]);  // index inside the cube's cloud
+      all_pts.push_back(p);
+    }
+    views.push_back(v);
+    *max_depth = std::max(*max_depth, ht.depth);
+  }
+  HIP_TRY(dt.nodes.reserve(all_nodes.size() + 8));
+  HIP_TRY(dt.pts.reserve(all_pts.size() + 16));
+  HIP_TRY(cells_d.reserve(n_cells));
+  HIP_TRY(views_d.reserve(views.size() + 1));
+  for (size_t t = 0; t < views.size(); ++t) {
+    views[t].nodes = dt.nodes.p + node_off[t];
+    views[t].pts = dt.pts.p + pts_off[t];
+  }
+  if (!all_nodes.empty())
+    HIP_TRY(hipMemcpyAsync(dt.nodes.p, all_nodes.data(), all_nodes.size() * sizeof(KdNode), hipMemcpyHostToDevice, ctx->stream));
+  if (!all_pts.empty())
+    HIP_TRY(hipMemcpyAsync(dt.pts.p, all_pts.data(), all_pts.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(cells_d.p, cell_tree.data(), n_cells * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  if (!views.empty())
+    HIP_TRY(hipMemcpyAsync(views_d.p, views.data(), views.size() * sizeof(TreeView), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  grid.cube_size = cube_size;
+  for (int d = 0; d < 3; ++d) { grid.origin[d] = origin[d]; grid.dims[d] = dims[d]; }
+  grid.cell_tree = cells_d.p;
+  grid.trees = views_d.p;
+  dt.depth = *max_depth;
+  dt.view = TreeView{};
+  *n_nodes = all_nodes.size();
+  return LSLAM_OK;
+}
+
+}  // namespace
+
+int lslam_cubemap_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const void *surf, size_t n_surf,
+                      size_t stride_bytes, float cube_size, const int32_t origin[3], const int32_t dims[3]) {
+  int rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (stride_bytes < 12 || (stride_bytes & 3) || (n_corner && !corner) || (n_surf && !surf) || !origin || !dims ||
+      !(cube_size > 0) || dims[0] <= 0 || dims[1] <= 0 || dims[2] <= 0 ||
+      (size_t)dims[0] * dims[1] * dims[2] > (1u << 26) || n_corner >= KD_MAX_POINTS || n_surf >= KD_MAX_POINTS) {
+    set_err("bad cube map arguments");
+    return LSLAM_ERR_INVALID;
+  }
+  ctx->have_map = false;
+  const double t0 = now_ms();
+  int dc = 0, ds = 0;
+  size_t nc_nodes = 0, ns_nodes = 0;
+  rc = build_cube_trees(ctx, corner, n_corner, stride_bytes, cube_size, origin, dims, ctx->tc, ctx->cell_c,
+                        ctx->views_c, ctx->gc, &dc, &nc_nodes);
+  if (rc) return rc;
+  rc = build_cube_trees(ctx, surf, n_surf, stride_bytes, cube_size, origin, dims, ctx->ts, ctx->cell_s,
+                        ctx->views_s, ctx->gs, &ds, &ns_nodes);
+  if (rc) return rc;
+  if (dc > KD_STACK_MAX || ds > KD_STACK_MAX) {
+    set_err("kd-tree depth %d/%d exceeds device stack %d", dc, ds, KD_STACK_MAX);
+    return LSLAM_ERR_TREE_DEPTH;
+  }
+  ctx->info = lslam_map_info{};
+  ctx->info.n_corner = n_corner;
+  ctx->info.n_surf = n_surf;
+  ctx->info.nodes_corner = (uint32_t)nc_nodes;
+  ctx->info.nodes_surf = (uint32_t)ns_nodes;
+  ctx->info.depth_corner = dc;
+  ctx->info.depth_surf = ds;
+  ctx->info.build_ms = (float)(now_ms() - t0);
+  ctx->cube_mode = true;
   ctx->have_map = true;
   return LSLAM_OK;
 }
@@ -596,8 +728,8 @@ int lslam_scanmatch_run_batch(lslam_ctx *ctx, int32_t n_scans, float *poses,
     set_err("batch size %d does not match the %d resident scans", n_scans, ctx->n_prob);
     return fail_all(LSLAM_ERR_INVALID);
   }
-  // ScanMatch.cpp:57-61
-  if (ctx->info.n_corner < 50 || ctx->info.n_surf < 100) return fail_all(LSLAM_TOO_FEW_REF);
+  // ScanMatch.cpp:57-61 (variant C, FeatureMap::scanMatchScan, has no such guard)
+  if (!ctx->cube_mode && (ctx->info.n_corner < 50 || ctx->info.n_surf < 100)) return fail_all(LSLAM_TOO_FEW_REF);
   const int max_it = o.max_iterations < 0 ? 0 : o.max_iterations;
 
   for (int32_t p = 0; p < n_scans; ++p) {
@@ -780,7 +912,7 @@ int lslam_knn5(lslam_ctx *ctx, int which_map, const void *queries, size_t nq, si
                int32_t *idx_out, float *d2_out) {
   int rc = check_ctx(ctx);
   if (rc) return rc;
-  if (!ctx->have_map) { set_err("no map set"); return LSLAM_ERR_NO_MAP; }
+  if (!ctx->have_map || ctx->cube_mode) { set_err("no whole-map tree set"); return LSLAM_ERR_NO_MAP; }
   if ((which_map != 0 && which_map != 1) || stride_bytes < 12 || (stride_bytes & 3) ||
       (nq && (!queries || !idx_out || !d2_out)) || nq > 0x0FFFFFFFu) {
     set_err("bad knn5 arguments");

@@ -60,8 +60,19 @@ struct ProbBlocks {
   int32_t first_block, n_blocks;
 };
 
+// Variant C (util/FeatureMap.h:465-691): the map as a grid of cubes, one kd-tree per cube.
+// cell_tree[toIndex(i,j,k)] = index into `trees`, or -1 for a cube with fewer than 5 points.
+struct CubeGridDev {
+  float cube_size;
+  int32_t origin[3];
+  int32_t dims[3];
+  const int32_t *cell_tree;
+  const TreeView *trees;
+};
+
 struct SweepArgs {
   TreeView tc, ts;
+  CubeGridDev gc, gs;  // used instead of tc/ts by the per-cube kernels
   const float4 *q;  // scan points of all scans, sensor frame, Morton order within a scan
                     // and type, {x,y,z,bitcast(original index)}
   const BlockDesc *blocks;  // [nb_total]

@@ -43,7 +43,17 @@ LSLAM_DEV float wave_sum(float v) {
 // ---------------------------------------------------------------------------
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-template <int BLOCK, bool OVF>
+// worldToCube + isIndexValid + toIndex (util/FeatureMap.h:475-487,102-108,146-148)
+LSLAM_DEV int cube_tree_of(const CubeGridDev &g, float x, float y, float z) {
+  const int gi = (int)(roundf(x / g.cube_size) + (float)g.origin[0]);
+  const int gj = (int)(roundf(y / g.cube_size) + (float)g.origin[1]);
+  const int gk = (int)(roundf(z / g.cube_size) + (float)g.origin[2]);
+  if (0 <= gi && gi < g.dims[0] && 0 <= gj && gj < g.dims[1] && 0 <= gk && gk < g.dims[2])
+    return g.cell_tree[gi + gj * g.dims[0] + gk * g.dims[0] * g.dims[1]];
+  return -1;
+}
+
+template <int BLOCK, bool OVF, bool CUBES>
 __global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mode) {
   const int lb = xcd_remap(blockIdx.x, a.nb_total);
   const BlockDesc bd = a.blocks[lb];
@@ -86,17 +96,25 @@ __global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mo
 
     float d[5];
     int p[5];
-    TreeView T;  // block-uniform choice of tree
-    T.nodes = is_surf ? a.ts.nodes : a.tc.nodes;
-    T.pts = is_surf ? a.ts.pts : a.tc.pts;
-    T.n_pts = is_surf ? a.ts.n_pts : a.tc.n_pts;
-    T.n_nodes = is_surf ? a.ts.n_nodes : a.tc.n_nodes;
-    T.root_ref = is_surf ? a.ts.root_ref : a.tc.root_ref;
+    TreeView T;
+    bool searched = true;
+    if (CUBES) {  // per-lane tree: the cube the transformed point falls into (FeatureMap.h:523-526)
+      const int tree = cube_tree_of(is_surf ? a.gs : a.gc, sel[0], sel[1], sel[2]);
+      searched = tree >= 0;
+      T = (is_surf ? a.gs.trees : a.gc.trees)[searched ? tree : 0];
+    } else {  // block-uniform choice of tree
+      T.nodes = is_surf ? a.ts.nodes : a.tc.nodes;
+      T.pts = is_surf ? a.ts.pts : a.tc.pts;
+      T.n_pts = is_surf ? a.ts.n_pts : a.tc.n_pts;
+      T.n_nodes = is_surf ? a.ts.n_nodes : a.tc.n_nodes;
+      T.root_ref = is_surf ? a.ts.root_ref : a.tc.root_ref;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      T.bb_lo[i] = is_surf ? a.ts.bb_lo[i] : a.tc.bb_lo[i];
-      T.bb_hi[i] = is_surf ? a.ts.bb_hi[i] : a.tc.bb_hi[i];
+      for (int i = 0; i < 3; ++i) {
+        T.bb_lo[i] = is_surf ? a.ts.bb_lo[i] : a.tc.bb_lo[i];
+        T.bb_hi[i] = is_surf ? a.ts.bb_hi[i] : a.tc.bb_hi[i];
+      }
     }
+    if (CUBES && !searched) T.n_pts = 0;  // knn5_search returns at once, d[4] stays FLT_MAX
     KdStack<BLOCK, OVF> stk;
     stk.lds = stack_lds + tid;
     stk.ovf = OVF ? a.stack_ovf + ((size_t)blockIdx.x * BLOCK + tid) : nullptr;
@@ -240,12 +258,16 @@ __global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mo
 hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t start,
                         hipEvent_t stop) {
   if (a.nb_total <= 0) return hipSuccess;
-  if (a.stack_ovf)
-    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true>), dim3(a.nb_total), dim3(SWEEP_BLOCK), 0,
-                          s, start, stop, 0, a, jtj_mode);
+  const dim3 g(a.nb_total), b(SWEEP_BLOCK);
+  const bool cubes = a.gc.trees != nullptr;
+  if (cubes && a.stack_ovf)
+    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, true>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+  else if (cubes)
+    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false, true>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+  else if (a.stack_ovf)
+    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false>), g, b, 0, s, start, stop, 0, a, jtj_mode);
   else
-    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false>), dim3(a.nb_total), dim3(SWEEP_BLOCK),
-                          0, s, start, stop, 0, a, jtj_mode);
+    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false, false>), g, b, 0, s, start, stop, 0, a, jtj_mode);
   return hipGetLastError();
 }
 

@@ -71,6 +71,17 @@ class Context:
             raise ValueError("corner/surf strides differ")
         self._check(self.lib.lslam_map_set(self.h, _vp(c), len(c), _vp(s), len(s), sc))
 
+    def cubemap_set(self, corner, surf, cube_size=50.0, origin=(60, 60, 5), dims=(121, 121, 11)):
+        """Per-cube trees as FeatureMap keeps them (util/FeatureMap.h; defaults: LaserMatcher.cpp:107-113)."""
+        c, sc = _cloud(corner)
+        s, ss = _cloud(surf)
+        if sc != ss:
+            raise ValueError("corner/surf strides differ")
+        o = np.asarray(origin, np.int32)
+        d = np.asarray(dims, np.int32)
+        self._check(self.lib.lslam_cubemap_set(self.h, _vp(c), len(c), _vp(s), len(s), sc, float(cube_size),
+                                               o.ctypes.data_as(c_int32_p), d.ctypes.data_as(c_int32_p)))
+
     def map_info(self):
         info = LslamMapInfo()
         self._check(self.lib.lslam_map_info_get(self.h, C.byref(info)))

@@ -164,7 +164,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic_bytes(args.batch),
                 "avg_kernel_ms": avg_sweep_ms,
                 "launches_timed": sweep_launches,
                 "alg_bytes_per_launch": alg_bytes,
@@ -186,6 +186,24 @@ def main():
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pmc_traffic_bytes(batch):
+    """HBM bytes per sweep launch from the committed rocprofv3 --pmc passes of this same
+    command (PMC counters cannot be collected inside the timed run; FETCH_SIZE and
+    WRITE_SIZE need separate passes).  MI355X_MICROARCH.md: counters are in KiB and
+    FETCH_SIZE under-reports wide reads by 2x on gfx950, so traffic = (2*FETCH + WRITE)*1024."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_sweep_batch%d.csv" % batch)
+    if not os.path.exists(path):
+        return None
+    vals = {}
+    for line in open(path):
+        f = line.strip().split(",")
+        if len(f) == 4 and f[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+            vals[f[1]] = float(f[3])
+    if len(vals) != 2:
+        return None
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
 
 
 def pose_graph_leg(pkg, synth, distmod, dist, rank, world, local_rank, torch, np, lm_iters, with_cpu):

@@ -121,9 +121,9 @@ def make_scan(world, rings=64, azimuth_steps=1800, gt_pose=(0, 0, 0.3, 3.0, -2.0
     tt, sid, axis = _raycast(world, t, d_w)
     valid = np.isfinite(tt) & (tt < MAX_RANGE)
     rng_noise = rng.normal(0, noise_sigma, len(tt))
-    r = tt + rng_noise
+    r = np.where(valid, tt + rng_noise, 0.0)
     p_s = d_s * r[:, None]
-    hit_w = t[None, :] + d_w * tt[:, None]
+    hit_w = t[None, :] + d_w * np.where(valid, tt, 0.0)[:, None]
     # corner label: hit on a pole, or on a box/wall face within corner_band of a vertical edge
     solids = world.solids()
     nb = len(world.boxes)

@@ -180,10 +180,32 @@ int lslam_scanmatch_full(lslam_ctx *ctx, const void *ref_corner, size_t n_ref_co
                          size_t stride_bytes, float pose[6], const lslam_opts *opts,
                          lslam_stats *stats);
 
+/* Variant B -- scan-to-scan odometry: void LaserOdometry::scanMatch()
+ * (odometry/LaserOdometry.cpp:328-647): nearest neighbour + ring-window correspondences
+ * refreshed every 5th iteration, motion-interpolated de-skew (transformToStart, :135-142),
+ * weights from iteration 5 on, b = -0.05 d, eigenvalue threshold 10, NaN reset.
+ * Clouds are {x,y,z,intensity} (intensity = ring id + relative time; at byte 16 for
+ * stride >= 32 as in pcl::PointXYZI, else at byte 12); last_corner / last_surf
+ * (_lastCornerCloud / _lastSurfaceCloud) must be in scan order.  pose is the persistent
+ * `_transform` (in/out).  Defaults of the reference: 25 iterations, 0.1 / 0.1 (:24-25).
+ * Returns LSLAM_OK when the loop converged (:642-644), LSLAM_NOT_CONVERGED otherwise,
+ * LSLAM_TOO_FEW_REF when the guard of :337 fails. */
+int lslam_odometry_match(lslam_ctx *ctx, const void *last_corner, size_t n_last_corner,
+                         const void *last_surf, size_t n_last_surf, const void *sharp, size_t n_sharp,
+                         const void *flat, size_t n_flat, size_t stride_bytes, float pose[6],
+                         int32_t max_iterations, float delta_t_abort, float delta_r_abort,
+                         lslam_stats *stats);
+
 /* Isometry3f <-> Twist conversion used by the Isometry overloads
  * (ScanMatch.cpp:349-360; util/transform_utils.h:308-323,54-60).  T is a
  * row-major 4x4. Host-side helpers, no device work. */
 void lslam_isometry_to_pose(const float T[16], float pose[6]);
+/* The odometry-prior merge that precedes the scan match in the mapping node,
+ * transformAssociate(Lold, Lnew, Wold, Wnew): Wnew = Wold * Lold^-1 * Lnew
+ * (util/transform_utils.h:502-507, called from LaserMatcher::transformMerge,
+ * odometry/LaserMatcher.cpp:333-340).  Row-major 4x4 matrices, host helper. */
+void lslam_transform_associate(const float Lold[16], const float Lnew[16], const float Wold[16],
+                               float Wnew[16]);
 void lslam_pose_to_isometry(const float pose[6], float T[16]);
 
 /* ---- parity / debug taps ------------------------------------------------ */

@@ -1240,3 +1240,214 @@ int oracle_scanmatch_cubes(const float *map_c, size_t nc, const float *map_s, si
   cube_set_free(&cs);
   return converge;
 }
+
+
+/* ======================================================================== */
+/* Variant B: LaserOdometry::scanMatch (odometry/LaserOdometry.cpp:328-647) */
+/* ======================================================================== */
+
+/* LaserOdometry.cpp:135-142 transformToStart: s = 10*frac(intensity); Twist t = _transform*s
+ * (Twist.h:28-35, Angle.h:45-49); it = getTransformationTZYX(t); po = it * pi */
+static void odom_transform_to_start(const float pose[6], const float *pi, float po[3]) {
+  float s = 10 * (pi[3] - (int)pi[3]);
+  float ps[6];
+  for (int k = 0; k < 3; ++k) ps[k] = pose[k] * s;        /* rot * scale */
+  for (int k = 3; k < 6; ++k) ps[k] = pose[k] * s;        /* pos * scale */
+  float R[9], t[3];
+  oracle_pose_to_Rt(ps, R, t);
+  oracle_transform_point(R, t, pi, po);
+}
+
+/* math_utils.h:47-54 calcSquaredDiff(a, b) */
+static inline float sq_diff(const float *a, const float *b) {
+  float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+  return dx * dx + dy * dy + dz * dz;
+}
+
+/* feature_utils.h:42-61 getCornerFeatureCoefficients(A,B,X,iteration,coeff) */
+static int odom_corner_coeff(const float *A, const float *B, const float *X, int iter, float coeff[4]) {
+  float XB[3] = {X[0] - B[0], X[1] - B[1], X[2] - B[2]};
+  float XA[3] = {X[0] - A[0], X[1] - A[1], X[2] - A[2]};
+  float n[3];
+  cross3(XB, XA, n);
+  float nn = norm3(n);
+  float AB[3] = {A[0] - B[0], A[1] - B[1], A[2] - B[2]};
+  float lengthAB = norm3(AB);
+  float BA[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
+  float mn[3] = {-n[0], -n[1], -n[2]};
+  float cr[3];
+  cross3(mn, BA, cr);
+  float den = nn * lengthAB;
+  float dir[3] = {cr[0] / den, cr[1] / den, cr[2] / den};
+  float distance = nn / lengthAB;
+  float weight = 1.0;
+  if (iter >= 5) weight = (float)(1 - 1.8 * (double)fabsf(distance));
+  coeff[0] = dir[0] * weight;
+  coeff[1] = dir[1] * weight;
+  coeff[2] = dir[2] * weight;
+  coeff[3] = distance * weight;
+  return ((double)weight > 0.1 && distance != 0);
+}
+
+/* feature_utils.h:28-40 getSurfacePointDistance + :77-95 getSurfaceFeatureCoefficients(A,B,C,X,it) */
+static int odom_surf_coeff(const float *A, const float *B, const float *C, const float *X, int iter,
+                           float coeff[4]) {
+  float BA[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
+  float CA[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
+  float nrm[3];
+  cross3(BA, CA, nrm);
+  float z = (nrm[0] * nrm[0] + nrm[1] * nrm[1]) + nrm[2] * nrm[2];
+  if (z > 0.0f) { /* Eigen normalize() */
+    float l = sqrtf(z);
+    nrm[0] /= l; nrm[1] /= l; nrm[2] /= l;
+  }
+  float XA[3] = {X[0] - A[0], X[1] - A[1], X[2] - A[2]};
+  float distance = (XA[0] * nrm[0] + XA[1] * nrm[1]) + XA[2] * nrm[2];
+  float AX[3] = {A[0] - X[0], A[1] - X[1], A[2] - X[2]};
+  float cosv = distance / norm3(nrm) / norm3(AX);
+  if (cosv < 0) { nrm[0] *= -1.0f; nrm[1] *= -1.0f; nrm[2] *= -1.0f; }
+  distance = fabsf(distance);
+  float weight = 1;
+  if (iter >= 5) weight = (float)(1 - 1.8 * (double)fabsf(distance) / sqrt((double)norm3(X)));
+  coeff[0] = weight * nrm[0];
+  coeff[1] = weight * nrm[1];
+  coeff[2] = weight * nrm[2];
+  coeff[3] = weight * distance;
+  return ((double)weight > 0.1 && distance != 0);
+}
+
+int oracle_odometry_match(const float *lc, size_t n_lc, const float *ls, size_t n_ls, const float *sharp,
+                          size_t n_sharp, const float *flat, size_t n_flat, size_t stride, float pose[6],
+                          const oracle_odom_opts *opts, oracle_stats *st) {
+  oracle_stats local;
+  if (!st) st = &local;
+  memset(st, 0, sizeof(*st));
+  if (!(n_lc > 10 && n_ls > 100)) return 0; /* :337 */
+  oracle_kdtree *tc = oracle_kdtree_build(lc, n_lc, stride);
+  oracle_kdtree *ts = oracle_kdtree_build(ls, n_ls, stride);
+  int *c1 = (int *)calloc(n_sharp + 1, sizeof(int)), *c2 = (int *)calloc(n_sharp + 1, sizeof(int));
+  int *s1 = (int *)calloc(n_flat + 1, sizeof(int)), *s2 = (int *)calloc(n_flat + 1, sizeof(int)),
+      *s3 = (int *)calloc(n_flat + 1, sizeof(int));
+  int degenerate = 0;
+  float matP[36];
+  memset(matP, 0, sizeof(matP));
+  int iters = 0;
+  for (int iter = 0; iter < opts->max_iterations; ++iter) {
+    sweep_acc acc;
+    memset(&acc, 0, sizeof(acc));
+    float sc[6];
+    /* rows are accumulated in push order: sharp points then flat points */
+    for (size_t i = 0; i < n_sharp; ++i) {
+      const float *pi = sharp + i * stride;
+      float sel[3];
+      odom_transform_to_start(pose, pi, sel);
+      if (iter % 5 == 0) { /* :358-408 */
+        int32_t idx;
+        float d2;
+        oracle_kdtree_knn(tc, sel, 1, &idx, &d2);
+        int closest = -1, min2 = -1;
+        if (d2 < 25) {
+          closest = idx;
+          int scan = (int)lc[(size_t)closest * stride + 3];
+          float minD2 = 25;
+          /* quirk Q5: the loop bound is the QUERY count (:370); never read past the cloud */
+          for (int j = closest + 1; j < (int)n_sharp && j < (int)n_lc; j++) {
+            if ((int)lc[(size_t)j * stride + 3] > scan + 2.5) break;
+            float d = sq_diff(lc + (size_t)j * stride, sel);
+            if ((int)lc[(size_t)j * stride + 3] > scan) {
+              if (d < minD2) { minD2 = d; min2 = j; }
+            }
+          }
+          for (int j = closest - 1; j >= 0; j--) {
+            if ((int)lc[(size_t)j * stride + 3] < scan - 2.5) break;
+            float d = sq_diff(lc + (size_t)j * stride, sel);
+            if ((int)lc[(size_t)j * stride + 3] < scan) {
+              if (d < minD2) { minD2 = d; min2 = j; }
+            }
+          }
+        }
+        c1[i] = closest;
+        c2[i] = min2;
+      }
+      if (c2[i] >= 0) { /* :409-418 */
+        float coeff[4];
+        if (odom_corner_coeff(lc + (size_t)c1[i] * stride, lc + (size_t)c2[i] * stride, sel, iter, coeff)) {
+          float row[6], b;
+          pose_sincos(pose, sc);
+          oracle_jacobian_row(sc, pi, coeff, row, &b);
+          b = (float)(-0.05 * (double)coeff[3]); /* :575 */
+          acc_row(&acc, row, b);
+          acc.n_rows++;
+          acc.n_line++;
+        }
+      }
+    }
+    for (size_t i = 0; i < n_flat; ++i) {
+      const float *pi = flat + i * stride;
+      float sel[3];
+      odom_transform_to_start(pose, pi, sel);
+      if (iter % 5 == 0) { /* :424-483 */
+        int32_t idx;
+        float d2;
+        oracle_kdtree_knn(ts, sel, 1, &idx, &d2);
+        int closest = -1, min2 = -1, min3 = -1;
+        if (d2 < 25) {
+          closest = idx;
+          int scan = (int)ls[(size_t)closest * stride + 3];
+          float minD2 = 25, minD3 = 25;
+          for (int j = closest + 1; j < (int)n_flat && j < (int)n_ls; j++) { /* Q5: :434 */
+            if ((int)ls[(size_t)j * stride + 3] > scan + 2.5) break;
+            float d = sq_diff(ls + (size_t)j * stride, sel);
+            if ((int)ls[(size_t)j * stride + 3] <= scan) {
+              if (d < minD2) { minD2 = d; min2 = j; }
+            } else {
+              if (d < minD3) { minD3 = d; min3 = j; }
+            }
+          }
+          for (int j = closest - 1; j >= 0; j--) {
+            if ((int)ls[(size_t)j * stride + 3] < scan - 2.5) break;
+            float d = sq_diff(ls + (size_t)j * stride, sel);
+            if ((int)ls[(size_t)j * stride + 3] >= scan) {
+              if (d < minD2) { minD2 = d; min2 = j; }
+            } else {
+              if (d < minD3) { minD3 = d; min3 = j; }
+            }
+          }
+        }
+        s1[i] = closest;
+        s2[i] = min2;
+        s3[i] = min3;
+      }
+      if (s2[i] >= 0 && s3[i] >= 0) { /* :485-496 */
+        float coeff[4];
+        if (odom_surf_coeff(ls + (size_t)s1[i] * stride, ls + (size_t)s2[i] * stride,
+                            ls + (size_t)s3[i] * stride, sel, iter, coeff)) {
+          float row[6], b;
+          pose_sincos(pose, sc);
+          oracle_jacobian_row(sc, pi, coeff, row, &b);
+          b = (float)(-0.05 * (double)coeff[3]);
+          acc_row(&acc, row, b);
+          acc.n_rows++;
+          acc.n_plane++;
+        }
+      }
+    }
+    st->point_residuals += (long long)(n_sharp + n_flat);
+    st->n_rows = acc.n_rows;
+    st->n_line = acc.n_line;
+    st->n_plane = acc.n_plane;
+    iters = iter + 1;
+    if (acc.n_rows < 10) continue; /* :501-503 */
+    int conv = oracle_gn_step(acc.AtA, acc.Atb, iter, pose, matP, &degenerate, 10.0f, opts->delta_r_abort,
+                              opts->delta_t_abort, NULL, &st->delta_r, &st->delta_t); /* :581-640, lambda<10 :596 */
+    st->iterations++;
+    for (int k = 0; k < 6; ++k)
+      if (!isfinite(pose[k])) pose[k] = 0.0f; /* :622-634 */
+    if (conv) { st->converged = 1; break; }   /* :642-644 */
+  }
+  st->degenerate = degenerate;
+  free(c1); free(c2); free(s1); free(s2); free(s3);
+  oracle_kdtree_free(tc);
+  oracle_kdtree_free(ts);
+  return iters;
+}

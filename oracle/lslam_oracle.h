@@ -163,6 +163,21 @@ int oracle_scanmatch_cubes(const float *map_c, size_t nc, const float *map_s, si
                            size_t nqc, const float *qs, size_t nqs, size_t q_stride,
                            float pose[6], oracle_stats *stats);
 
+/* Variant B: LaserOdometry::scanMatch (odometry/LaserOdometry.cpp:328-647) -- scan-to-scan.
+ * Clouds are {x,y,z,intensity} with intensity = ring id + relative time (util/pcl_util.h:30-37);
+ * last_corner/last_surf must be in scan order (the ring-window searches walk neighbouring
+ * indices).  pose is the persistent `_transform` (in/out).  Returns iterations executed. */
+typedef struct {
+  int max_iterations;  /* LaserOdometry.cpp:24 (25) */
+  float delta_t_abort; /* :25 (0.1) */
+  float delta_r_abort; /* :25 (0.1) */
+} oracle_odom_opts;
+
+int oracle_odometry_match(const float *last_corner, size_t n_lc, const float *last_surf, size_t n_ls,
+                          const float *sharp, size_t n_sharp, const float *flat, size_t n_flat,
+                          size_t stride, float pose[6], const oracle_odom_opts *opts,
+                          oracle_stats *stats);
+
 /* One GN solve step given sums (ScanMatch.cpp:206-260).  iter==0 computes the
  * degeneracy projector into matP/degenerate (in/out state). Returns converged. */
 int oracle_gn_step(const float AtA[36], const float Atb[6], int iter, float pose[6],

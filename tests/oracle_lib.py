@@ -34,6 +34,10 @@ class OracleCubeGrid(C.Structure):
     _fields_ = [("cube_size", C.c_float), ("origin", C.c_int32 * 3), ("dims", C.c_int32 * 3)]
 
 
+class OracleOdomOpts(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("delta_t_abort", C.c_float), ("delta_r_abort", C.c_float)]
+
+
 class OracleStats(C.Structure):
     _fields_ = [
         ("status", C.c_int),
@@ -125,6 +129,10 @@ class Oracle:
         L.oracle_scanmatch_cubes.argtypes = [c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_size_t,
                                              C.POINTER(OracleCubeGrid), c_float_p, C.c_size_t, c_float_p,
                                              C.c_size_t, C.c_size_t, c_float_p, C.POINTER(OracleStats)]
+        L.oracle_odometry_match.restype = C.c_int
+        L.oracle_odometry_match.argtypes = [c_float_p, C.c_size_t, c_float_p, C.c_size_t, c_float_p, C.c_size_t,
+                                            c_float_p, C.c_size_t, C.c_size_t, c_float_p,
+                                            C.POINTER(OracleOdomOpts), C.POINTER(OracleStats)]
         L.oracle_gn_step.restype = C.c_int
         L.oracle_gn_step.argtypes = [c_float_p, c_float_p, C.c_int, c_float_p, c_float_p,
                                      C.POINTER(C.c_int), C.c_float, C.c_float, C.c_float,
@@ -264,6 +272,19 @@ class Oracle:
         ok = self.lib.oracle_scanmatch_cubes(_fp(map_c), len(map_c), _fp(map_s), len(map_s), sm, C.byref(g),
                                              _fp(qc), len(qc), _fp(qs), len(qs), sq, _fp(pose), C.byref(st))
         return bool(ok), pose, st
+
+    def odometry_match(self, last_corner, last_surf, sharp, flat, pose, max_iterations=25, dt=0.1, dr=0.1):
+        lc, s = as_cloud(last_corner)
+        ls, _ = as_cloud(last_surf)
+        sh, _ = as_cloud(sharp)
+        fl, _ = as_cloud(flat)
+        assert s >= 4
+        pose = np.array(pose, np.float32)
+        op = OracleOdomOpts(max_iterations, dt, dr)
+        st = OracleStats()
+        n = self.lib.oracle_odometry_match(_fp(lc), len(lc), _fp(ls), len(ls), _fp(sh), len(sh), _fp(fl), len(fl),
+                                           s, _fp(pose), C.byref(op), C.byref(st))
+        return n, pose, st
 
     def gn_step(self, AtA, Atb, it, pose, matP, degenerate, eig_thresh=100.0, dr=0.05, dt=0.05):
         AtA = np.ascontiguousarray(AtA, np.float32).reshape(36)

@@ -87,3 +87,23 @@ def test_cpp_shim_compiles_and_fails_loudly_without_gpu(pkg, tmp_path):
         pytest.skip("GPU present: the no-device branch is not reachable")
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0 and "no CPU fallback" in out.stdout
+
+
+def test_transform_associate(pkg, oracle):
+    """transformAssociate (util/transform_utils.h:502-507): Wnew = Wold * Lold^-1 * Lnew."""
+    lib = pkg.load_library()
+    rng = np.random.default_rng(4)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+
+    def iso():
+        R, t = oracle.pose_to_Rt(rng.uniform(-1, 1, 6).astype(np.float32))
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :3], T[:3, 3] = R, t * 10
+        return T
+    for _ in range(20):
+        Lo, Ln, Wo = iso(), iso(), iso()
+        Wn = np.zeros((4, 4), np.float32)
+        lib.lslam_transform_associate(fp(Lo), fp(Ln), fp(Wo), fp(Wn))
+        ref = Wo.astype(np.float64) @ np.linalg.inv(Lo.astype(np.float64)) @ Ln.astype(np.float64)
+        assert np.abs(Wn - ref).max() < 2e-5
+        assert np.array_equal(Wn[3], [0, 0, 0, 1])

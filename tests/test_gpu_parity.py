@@ -361,6 +361,47 @@ def test_cube_map_variant_matches_oracle(ctx, oracle, small_problem):
     assert st.n_rows == wst.n_rows
 
 
+def _odometry_pair(synth, world, k=0):
+    """Two consecutive 16-ring scans: targets = features of the previous scan (scan order),
+    queries = a subset of the current scan's corner / surf points (sharp / flat)."""
+    gt0 = (0.0, 0.0, 0.30 + 0.05 * k, 3.0, -2.0, synth.SENSOR_HEIGHT)
+    gt1 = (0.002, -0.003, 0.33 + 0.05 * k, 3.35, -1.9, synth.SENSOR_HEIGHT)
+    lc, ls, _ = synth.make_scan(world, 16, 900, gt_pose=gt0, seed=40 + k)
+    c1, s1, _ = synth.make_scan(world, 16, 900, gt_pose=gt1, seed=41 + k)
+    return lc, ls[::2], c1[::3], s1[::20]
+
+
+def test_odometry_variant_matches_oracle(ctx, oracle, synth, small_problem):
+    """Variant B, LaserOdometry::scanMatch (odometry/LaserOdometry.cpp:328-647).  The per-point
+    de-skew uses device sin/cos (not glibc's), so parity is by tolerance here."""
+    lc, ls, sharp, flat = _odometry_pair(synth, small_problem["world"])
+    assert 100 < len(sharp) < len(lc) and 300 < len(flat) < len(ls)
+    p0 = np.zeros(6, np.float32)
+    status, pose, st = ctx.odometry_match(lc, ls, sharp, flat, p0)
+    n, opose, ost = oracle.odometry_match(lc, ls, sharp, flat, p0)
+    assert st.converged == ost.converged and st.iterations == ost.iterations and st.sweeps == n
+    assert (st.n_rows, st.n_line, st.n_plane) == (ost.n_rows, ost.n_line, ost.n_plane)
+    assert np.abs(pose[3:] - opose[3:]).max() <= POSE_TOL_M and np.abs(pose[:3] - opose[:3]).max() <= POSE_TOL_RAD
+    assert np.abs(pose).max() > 1e-3  # it moved
+    # persistent _transform as the next initial guess; few iterations allowed
+    status2, pose2, st2 = ctx.odometry_match(lc, ls, sharp, flat, pose, max_iterations=3)
+    n2, opose2, ost2 = oracle.odometry_match(lc, ls, sharp, flat, opose, max_iterations=3)
+    assert st2.iterations == ost2.iterations and np.abs(pose2 - opose2).max() <= POSE_TOL_M
+    # guard of LaserOdometry.cpp:337
+    status3, pose3, st3 = ctx.odometry_match(lc[:10], ls, sharp, flat, p0)
+    assert status3 == 1 and np.array_equal(pose3, p0)
+    # PointXYZI layout (32-byte stride, intensity at byte 16)
+    def xyzi(a):
+        o = np.zeros((len(a), 8), np.float32)
+        o[:, :3] = a[:, :3]
+        o[:, 4] = a[:, 3]
+        return o
+    status4, pose4, st4 = ctx.odometry_match(xyzi(lc), xyzi(ls), xyzi(sharp), xyzi(flat), p0)
+    assert np.array_equal(bits(pose4), bits(pose))
+    # the map slot was used for the odometry trees: a scan match now needs a new map
+    ctx.map_set(small_problem["map_corner"], small_problem["map_surf"])
+
+
 def test_scanmatch_class_mirrors_reference_api(pkg, oracle, small_problem):
     pr = small_problem
     sm = pkg.ScanMatch(10)

@@ -120,8 +120,12 @@ SYMBOLS = {
     "lslam_scanmatch_full": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
                                        C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
                                        c_float_p, C.POINTER(LslamOpts), C.POINTER(LslamStats)]),
+    "lslam_odometry_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                       C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, c_float_p, C.c_int32,
+                                       C.c_float, C.c_float, C.POINTER(LslamStats)]),
     "lslam_isometry_to_pose": (None, [c_float_p, c_float_p]),
     "lslam_pose_to_isometry": (None, [c_float_p, c_float_p]),
+    "lslam_transform_associate": (None, [c_float_p, c_float_p, c_float_p, c_float_p]),
     "lslam_knn5": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, c_int32_p, c_float_p]),
     "lslam_sweep": (C.c_int, [C.c_void_p, c_float_p, C.c_int32, c_int32_p, c_float_p, c_float_p,
                               c_uint8_p, c_float_p]),

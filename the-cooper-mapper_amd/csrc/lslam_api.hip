@@ -752,6 +752,9 @@ int lslam_scanmatch_run_batch(lslam_ctx *ctx, int32_t n_scans, float *poses,
   so.delta_r_abort = o.delta_r_abort;
   so.delta_t_abort = o.delta_t_abort;
   so.eig_thresh = 100.0f;  // ScanMatch.cpp:223
+  so.min_rows = 50;        // ScanMatch.cpp:142
+  so.too_few_continue = 0;
+  so.nan_reset = 0;
 
   if (o.profile) {
     while ((int)ctx->sweep_ev.size() < 2 * max_it) {
@@ -887,6 +890,151 @@ int lslam_scanmatch_full(lslam_ctx *ctx, const void *ref_corner, size_t n_ref_co
   return lslam_scanmatch_scan(ctx, corner, n_corner, surf, n_surf, stride_bytes, pose, opts, stats);
 }
 
+// Variant B: LaserOdometry::scanMatch (odometry/LaserOdometry.cpp:328-647)
+int lslam_odometry_match(lslam_ctx *ctx, const void *last_corner, size_t n_lc, const void *last_surf,
+                         size_t n_ls, const void *sharp, size_t n_sharp, const void *flat, size_t n_flat,
+                         size_t stride_bytes, float pose[6], int32_t max_iterations, float delta_t_abort,
+                         float delta_r_abort, lslam_stats *stats) {
+  int rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (stride_bytes < 16 || (stride_bytes & 3) || !pose || (n_lc && !last_corner) || (n_ls && !last_surf) ||
+      (n_sharp && !sharp) || (n_flat && !flat) || n_lc >= KD_MAX_POINTS || n_ls >= KD_MAX_POINTS) {
+    set_err("bad odometry arguments (clouds need x,y,z,intensity: stride >= 16)");
+    return LSLAM_ERR_INVALID;
+  }
+  lslam_stats local;
+  lslam_stats &st = stats ? *stats : local;
+  std::memset(&st, 0, sizeof(st));
+  if (!(n_lc > 10 && n_ls > 100)) {  // :337
+    st.status = LSLAM_TOO_FEW_REF;
+    return LSLAM_TOO_FEW_REF;
+  }
+  auto pack4 = [&](const void *src, size_t n, std::vector<float4> &out) {
+    out.resize(n);
+    const char *p = static_cast<const char *>(src);
+    const size_t ioff = stride_bytes >= 32 ? 16 : 12;  // pcl::PointXYZI keeps intensity at byte 16
+    for (size_t i = 0; i < n; ++i) {
+      float xyz[3], w;
+      std::memcpy(xyz, p + i * stride_bytes, 12);
+      std::memcpy(&w, p + i * stride_bytes + ioff, 4);
+      out[i] = make_float4(xyz[0], xyz[1], xyz[2], w);
+    }
+  };
+  std::vector<float4> lc, ls, q, qf;
+  pack4(last_corner, n_lc, lc);
+  pack4(last_surf, n_ls, ls);
+  pack4(sharp, n_sharp, q);
+  pack4(flat, n_flat, qf);
+  q.insert(q.end(), qf.begin(), qf.end());
+  // the map slot of the context holds the two kd-trees (host builder: the clouds are small)
+  ctx->have_map = false;
+  ctx->cube_mode = false;
+  HostTree hc, hs;
+  build_kdtree_host(reinterpret_cast<const float *>(lc.data()), n_lc, 4, hc);
+  build_kdtree_host(reinterpret_cast<const float *>(ls.data()), n_ls, 4, hs);
+  if (hc.depth > KD_STACK_LDS + 1 || hs.depth > KD_STACK_LDS + 1) {
+    set_err("kd-tree deeper than %d", KD_STACK_LDS + 1);
+    return LSLAM_ERR_TREE_DEPTH;
+  }
+  rc = upload_tree(ctx, ctx->tc, hc, lc);
+  if (rc) return rc;
+  rc = upload_tree(ctx, ctx->ts, hs, ls);
+  if (rc) return rc;
+  const size_t nq = q.size();
+  DevBuf<float4> d_oc, d_os, d_q;
+  DevBuf<int32_t> d_ind;
+  HIP_TRY(d_oc.reserve(n_lc + 1));
+  HIP_TRY(d_os.reserve(n_ls + 1));
+  HIP_TRY(d_q.reserve(nq + 1));
+  HIP_TRY(d_ind.reserve(3 * nq + 1));
+  HIP_TRY(hipMemcpyAsync(d_oc.p, lc.data(), n_lc * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_os.p, ls.data(), n_ls * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  if (nq) HIP_TRY(hipMemcpyAsync(d_q.p, q.data(), nq * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemsetAsync(d_ind.p, 0xFF, (3 * nq + 1) * sizeof(int32_t), ctx->stream));
+  OdomArgs oa{};
+  oa.tc = ctx->tc.view;
+  oa.ts = ctx->ts.view;
+  oa.oc = d_oc.p;
+  oa.os = d_os.p;
+  oa.n_oc = (int32_t)n_lc;
+  oa.n_os = (int32_t)n_ls;
+  oa.q = d_q.p;
+  oa.n_sharp = (int32_t)n_sharp;
+  oa.n_flat = (int32_t)n_flat;
+  oa.nb_sharp = (int32_t)((n_sharp + 255) / 256);
+  oa.nb_total = oa.nb_sharp + (int32_t)((n_flat + 255) / 256);
+  oa.ind = d_ind.p;
+  oa.state = ctx->d_state;
+  HIP_TRY(ctx->partials.reserve((size_t)(oa.nb_total ? oa.nb_total : 1) * NCOL));
+  oa.partials = ctx->partials.p;
+  ProbBlocks pb{0, oa.nb_total};
+  HIP_TRY(ctx->probs.reserve(1));
+  HIP_TRY(hipMemcpyAsync(ctx->probs.p, &pb, sizeof(pb), hipMemcpyHostToDevice, ctx->stream));
+  init_state(*ctx->h_state, pose);
+  const int max_it = max_iterations < 0 ? 0 : max_iterations;
+  if (max_it == 0 || oa.nb_total == 0) ctx->h_state->done = 1;
+  HIP_TRY(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(GNState), hipMemcpyHostToDevice, ctx->stream));
+  SolveArgs so{};
+  so.states = ctx->d_state;
+  so.partials = ctx->partials.p;
+  so.probs = ctx->probs.p;
+  so.n_prob = 1;
+  so.max_iterations = max_it;
+  so.delta_r_abort = delta_r_abort;
+  so.delta_t_abort = delta_t_abort;
+  so.eig_thresh = 10.0f;  // :596
+  so.min_rows = 10;       // :501
+  so.too_few_continue = 1;
+  so.nan_reset = 1;
+  HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+  for (int it = 0; it < max_it; ++it) {
+    HIP_TRY(launch_odom_sweep(oa, ctx->stream));
+    HIP_TRY(launch_solve(so, ctx->stream));
+  }
+  HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  d_oc.release(); d_os.release(); d_q.release(); d_ind.release();
+  const GNState &g = *ctx->h_state;
+  for (int i = 0; i < 6; ++i) pose[i] = g.pose[i];
+  st.iterations = g.iter;
+  st.sweeps = g.sweeps;
+  st.n_rows = g.n_rows;
+  st.n_line = g.n_line;
+  st.n_plane = g.n_plane;
+  st.degenerate = g.degenerate;
+  st.converged = g.converged;
+  st.delta_r = g.delta_r;
+  st.delta_t = g.delta_t;
+  st.point_residuals = (int64_t)g.sweeps * (int64_t)nq;
+  HIP_TRY(hipEventElapsedTime(&st.gpu_ms_total, ctx->ev0, ctx->ev1));
+  st.status = g.converged ? LSLAM_OK : LSLAM_NOT_CONVERGED;
+  ctx->have_scan = false;
+  return st.status;
+}
+
+// util/transform_utils.h:502-507 transformAssociate: Wnew = (Wold * Lold^-1) * Lnew
+// (Eigen::Isometry3f::inverse() = [R^T | -R^T t]; fp32 products in row.column order)
+void lslam_transform_associate(const float Lold[16], const float Lnew[16], const float Wold[16],
+                               float Wnew[16]) {
+  auto mul = [](const float A[16], const float B[16], float C[16]) {
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c)
+        C[r * 4 + c] = (A[r * 4 + 0] * B[0 * 4 + c] + A[r * 4 + 1] * B[1 * 4 + c]) + A[r * 4 + 2] * B[2 * 4 + c];
+      C[r * 4 + 3] = ((A[r * 4 + 0] * B[3] + A[r * 4 + 1] * B[7]) + A[r * 4 + 2] * B[11]) + A[r * 4 + 3];
+    }
+    C[12] = 0.f; C[13] = 0.f; C[14] = 0.f; C[15] = 1.f;
+  };
+  float Linv[16], L2W[16];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) Linv[r * 4 + c] = Lold[c * 4 + r];
+    Linv[r * 4 + 3] = -((Lold[0 * 4 + r] * Lold[3] + Lold[1 * 4 + r] * Lold[7]) + Lold[2 * 4 + r] * Lold[11]);
+  }
+  Linv[12] = 0.f; Linv[13] = 0.f; Linv[14] = 0.f; Linv[15] = 1.f;
+  mul(Wold, Linv, L2W);
+  mul(L2W, Lnew, Wnew);
+}
+
 // util/transform_utils.h:313-323 + :54-60
 void lslam_isometry_to_pose(const float T[16], float pose[6]) {
   pose[0] = std::atan2(T[2 * 4 + 1], T[2 * 4 + 2]);
@@ -997,6 +1145,7 @@ int lslam_gn_step(lslam_ctx *ctx, const float AtA[36], const float Atb[6], int32
   if (!AtA || !Atb || !pose || !matP || !degenerate) { set_err("null argument"); return LSLAM_ERR_INVALID; }
   init_state(*ctx->h_state, pose);
   ctx->h_state->iter = iter;
+  ctx->h_state->loop_iter = iter;
   ctx->h_state->degenerate = *degenerate;
   std::memcpy(ctx->h_state->matP, matP, sizeof(float) * 36);
   HIP_TRY(ctx->t_small.reserve(64));

@@ -32,6 +32,8 @@ struct GNState {
   float x[6];      // last update
   float delta_r, delta_t;
   int32_t iter;        // solves performed
+  int32_t loop_iter;   // loop counter of the reference's for(iterCount...) (== iter except in
+                       // variant B, where an iteration with too few rows is skipped, not ended)
   int32_t done;        // loop has ended; later launches exit at once
   int32_t converged;   // ScanMatch.cpp:257-260
   int32_t degenerate;  // ScanMatch.cpp:222-233
@@ -96,8 +98,25 @@ struct SolveArgs {
   int32_t reduce_only;  // 1: only reduce partials into state->sums (tap)
   int32_t max_iterations;
   float delta_r_abort, delta_t_abort;
-  float eig_thresh;  // 100 (ScanMatch.cpp:223)
+  float eig_thresh;  // 100 (ScanMatch.cpp:223); 10 in LaserOdometry.cpp:596
+  int32_t min_rows;          // 50 (ScanMatch.cpp:142); 10 in LaserOdometry.cpp:501
+  int32_t too_few_continue;  // variant B: `continue` instead of `break` (LaserOdometry.cpp:501-503)
+  int32_t nan_reset;         // variant B: LaserOdometry.cpp:622-634
 };
+
+// Variant B (LaserOdometry::scanMatch): one launch = one iteration over sharp + flat points.
+struct OdomArgs {
+  TreeView tc, ts;              // kd-trees of the last corner / surface clouds
+  const float4 *oc, *os;        // the same clouds in scan order {x,y,z,intensity}
+  int32_t n_oc, n_os;
+  const float4 *q;              // sharp points then flat points {x,y,z,intensity}
+  int32_t n_sharp, n_flat;
+  int32_t nb_sharp, nb_total;   // blocks: [0,nb_sharp) sharp
+  int32_t *ind;                 // [3][n_sharp+n_flat] cached correspondences (:357-408,:423-483)
+  const GNState *state;
+  float *partials;
+};
+hipError_t launch_odom_sweep(const OdomArgs &a, hipStream_t s);
 
 #ifndef LSLAM_SWEEP_BLOCK
 #define LSLAM_SWEEP_BLOCK 256

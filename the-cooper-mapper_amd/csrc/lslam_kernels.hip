@@ -469,9 +469,9 @@ struct GnShared {
 };
 
 __device__ static void gn_step_block(GNState *st, GnShared &sh, float eig_thresh, float dr_abort,
-                                     float dt_abort) {
+                                     float dt_abort, bool nan_reset = false) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int iter = st->iter;  // uniform
+  const int iter = st->loop_iter;  // uniform; the reference's iterCount
   float x[6] = {0, 0, 0, 0, 0, 0};
   if (wave == 0) {
     float col[6];
@@ -537,6 +537,11 @@ __device__ static void gn_step_block(GNState *st, GnShared &sh, float eig_thresh
   float pose[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) pose[i] = st->pose[i] + x[i];  // :242-247
+  if (nan_reset) {  // LaserOdometry.cpp:622-634
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      if (!isfinite(pose[i])) pose[i] = 0.0f;
+  }
   // :249-253 (rad2deg(float) -> float, pow(float,int) -> double)
   const double kPi = 3.14159265358979323846;
   const double r0 = (double)(float)((double)x[0] * 180.0 / kPi);
@@ -575,7 +580,7 @@ __device__ static void gn_step_block(GNState *st, GnShared &sh, float eig_thresh
     for (int i = 0; i < 3; ++i) st->t[i] = t[i];
     st->delta_r = dR;
     st->delta_t = dT;
-    st->iter = iter + 1;
+    st->iter += 1;
     if (dR < dr_abort && dT < dt_abort) {  // :257-260
       st->converged = 1;
       st->done = 1;
@@ -632,10 +637,15 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(SolveArgs a) {
     st->n_plane = (int)tot[COL_PLANE];
     st->score = tot[COL_SCORE];
     go = 1;
-    if (n_rows < 50) {  // ScanMatch.cpp:141-145
-      st->too_few = 1;
-      st->done = 1;
+    if (n_rows < a.min_rows) {  // ScanMatch.cpp:141-145 (break) / LaserOdometry.cpp:501-503 (continue)
       go = 0;
+      if (a.too_few_continue) {
+        st->loop_iter += 1;
+        if (st->loop_iter >= a.max_iterations) st->done = 1;
+      } else {
+        st->too_few = 1;
+        st->done = 1;
+      }
     }
   }
   if (tid < 36) {  // symmetric A^T A from the 21 reduced upper-triangular sums
@@ -646,9 +656,206 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(SolveArgs a) {
   if (tid < 6) sh.b[tid] = (float)tot[COL_ATB + tid];
   __syncthreads();
   if (!go) return;
-  gn_step_block(st, sh, a.eig_thresh, a.delta_r_abort, a.delta_t_abort);
-  if (tid == 0 && st->iter >= a.max_iterations) st->done = 1;
+  gn_step_block(st, sh, a.eig_thresh, a.delta_r_abort, a.delta_t_abort, a.nan_reset != 0);
+  if (tid == 0) {
+    st->loop_iter += 1;
+    if (st->loop_iter >= a.max_iterations) st->done = 1;
+  }
   if (tid == 0) st->clk[3] = wall_clock64();
+}
+
+// ---------------------------------------------------------------------------
+// Variant B: LaserOdometry::scanMatch (odometry/LaserOdometry.cpp:328-647), one
+// iteration per launch, one lane per sharp / flat point.
+// ---------------------------------------------------------------------------
+LSLAM_DEV float sq_diff3(const float4 &a, const float (&b)[3]) {  // math_utils.h:47-54
+  const float dx = a.x - b[0], dy = a.y - b[1], dz = a.z - b[2];
+  return dx * dx + dy * dy + dz * dz;
+}
+
+// feature_utils.h:42-61
+LSLAM_DEV bool odom_corner_coeff(const float4 &A4, const float4 &B4, const float (&X)[3], int iter,
+                                 float (&coeff)[4]) {
+  const float A[3] = {A4.x, A4.y, A4.z}, B[3] = {B4.x, B4.y, B4.z};
+  const float XB[3] = {X[0] - B[0], X[1] - B[1], X[2] - B[2]};
+  const float XA[3] = {X[0] - A[0], X[1] - A[1], X[2] - A[2]};
+  float n[3];
+  cross3(XB, XA, n);
+  const float nn = norm3(n);
+  const float AB[3] = {A[0] - B[0], A[1] - B[1], A[2] - B[2]};
+  const float lengthAB = norm3(AB);
+  const float BA[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
+  const float mn[3] = {-n[0], -n[1], -n[2]};
+  float cr[3];
+  cross3(mn, BA, cr);
+  const float den = nn * lengthAB;
+  const float distance = nn / lengthAB;
+  float weight = 1.0f;
+  if (iter >= 5) weight = (float)(1 - 1.8 * (double)fabsf(distance));
+  coeff[0] = (cr[0] / den) * weight;
+  coeff[1] = (cr[1] / den) * weight;
+  coeff[2] = (cr[2] / den) * weight;
+  coeff[3] = distance * weight;
+  return (double)weight > 0.1 && distance != 0.0f;
+}
+
+// feature_utils.h:28-40 + :77-95
+LSLAM_DEV bool odom_surf_coeff(const float4 &A4, const float4 &B4, const float4 &C4, const float (&X)[3],
+                               int iter, float (&coeff)[4]) {
+  const float BA[3] = {B4.x - A4.x, B4.y - A4.y, B4.z - A4.z};
+  const float CA[3] = {C4.x - A4.x, C4.y - A4.y, C4.z - A4.z};
+  float nrm[3];
+  cross3(BA, CA, nrm);
+  const float z = (nrm[0] * nrm[0] + nrm[1] * nrm[1]) + nrm[2] * nrm[2];
+  if (z > 0.0f) {
+    const float l = sqrtf(z);
+    nrm[0] /= l; nrm[1] /= l; nrm[2] /= l;
+  }
+  const float XA[3] = {X[0] - A4.x, X[1] - A4.y, X[2] - A4.z};
+  float distance = (XA[0] * nrm[0] + XA[1] * nrm[1]) + XA[2] * nrm[2];
+  const float AX[3] = {A4.x - X[0], A4.y - X[1], A4.z - X[2]};
+  const float cosv = distance / norm3(nrm) / norm3(AX);
+  if (cosv < 0) { nrm[0] *= -1.0f; nrm[1] *= -1.0f; nrm[2] *= -1.0f; }
+  distance = fabsf(distance);
+  float weight = 1.0f;
+  if (iter >= 5) weight = (float)(1 - 1.8 * (double)fabsf(distance) / sqrt((double)norm3(X)));
+  coeff[0] = weight * nrm[0];
+  coeff[1] = weight * nrm[1];
+  coeff[2] = weight * nrm[2];
+  coeff[3] = weight * distance;
+  return (double)weight > 0.1 && distance != 0.0f;
+}
+
+struct DevSinCosF {
+  __device__ void operator()(float a, float &s, float &c) const {
+    s = (float)sin((double)a);
+    c = (float)cos((double)a);
+  }
+};
+
+__global__ __launch_bounds__(256, 2) void odom_sweep_kernel(OdomArgs a) {
+  const GNState *st = a.state;
+  if (st->done) return;
+  constexpr int BLOCK = 256, NWAVE = 4;
+  __shared__ float red[NWAVE][NCOL];
+  __shared__ uint32_t stack_lds[2 * KD_STACK_LDS * BLOCK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lb = blockIdx.x;
+  const bool is_flat = lb >= a.nb_sharp;
+  const int li = (is_flat ? lb - a.nb_sharp : lb) * BLOCK + tid;
+  const int nq = is_flat ? a.n_flat : a.n_sharp;
+  const bool active = li < nq;
+  const int qi = is_flat ? a.n_sharp + li : li;
+  const int iter = st->loop_iter;
+  const int nall = a.n_sharp + a.n_flat;
+  float row[6] = {0, 0, 0, 0, 0, 0};
+  float rb = 0.0f, kept = 0.0f;
+  if (active) {
+    const float4 q = a.q[qi];
+    // transformToStart (:135-142): s = 10*frac(intensity); t = _transform * s
+    const float s = 10 * (q.w - (int)q.w);
+    float ps[6], R[9], t[3], scd[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ps[k] = st->pose[k] * s;
+    pose_to_Rt_sc(ps, R, t, scd, DevSinCosF());
+    float sel[3];
+    sel[0] = ((R[0] * q.x + R[1] * q.y) + R[2] * q.z) + t[0];
+    sel[1] = ((R[3] * q.x + R[4] * q.y) + R[5] * q.z) + t[1];
+    sel[2] = ((R[6] * q.x + R[7] * q.y) + R[8] * q.z) + t[2];
+    const float4 *org = is_flat ? a.os : a.oc;
+    const int n_org = is_flat ? a.n_os : a.n_oc;
+    int i1 = a.ind[qi], i2 = a.ind[nall + qi], i3 = a.ind[2 * nall + qi];
+    if (iter % 5 == 0) {  // :357 / :423
+      TreeView T = is_flat ? a.ts : a.tc;
+      float d[5];
+      int p[5];
+      KdStack<BLOCK, false> stk;
+      stk.lds = stack_lds + tid;
+      stk.ovf = nullptr;
+      stk.ovf_stride = 0;
+      knn5_search<BLOCK, false>(T, sel[0], sel[1], sel[2], d, p, stk);  // top-1 of the 5 == nearestKSearch(.,1)
+      i1 = -1; i2 = -1; i3 = -1;
+      if (d[0] < 25.0f) {
+        i1 = __float_as_int(T.pts[p[0]].w);
+        const int scan = (int)org[i1].w;
+        float m2 = 25.0f, m3 = 25.0f;
+        for (int j = i1 + 1; j < nq && j < n_org; ++j) {  // quirk Q5: bound is the query count
+          const float4 o = org[j];
+          if ((double)(int)o.w > scan + 2.5) break;
+          const float dd = sq_diff3(o, sel);
+          if (!is_flat) {
+            if ((int)o.w > scan && dd < m2) { m2 = dd; i2 = j; }
+          } else if ((int)o.w <= scan) {
+            if (dd < m2) { m2 = dd; i2 = j; }
+          } else {
+            if (dd < m3) { m3 = dd; i3 = j; }
+          }
+        }
+        for (int j = i1 - 1; j >= 0; --j) {
+          const float4 o = org[j];
+          if ((double)(int)o.w < scan - 2.5) break;
+          const float dd = sq_diff3(o, sel);
+          if (!is_flat) {
+            if ((int)o.w < scan && dd < m2) { m2 = dd; i2 = j; }
+          } else if ((int)o.w >= scan) {
+            if (dd < m2) { m2 = dd; i2 = j; }
+          } else {
+            if (dd < m3) { m3 = dd; i3 = j; }
+          }
+        }
+      }
+      a.ind[qi] = i1;
+      a.ind[nall + qi] = i2;
+      a.ind[2 * nall + qi] = i3;
+    }
+    float coeff[4];
+    bool ok = false;
+    if (!is_flat) {
+      if (i2 >= 0) ok = odom_corner_coeff(org[i1], org[i2], sel, iter, coeff);
+    } else {
+      if (i2 >= 0 && i3 >= 0) ok = odom_surf_coeff(org[i1], org[i2], org[i3], sel, iter, coeff);
+    }
+    if (ok) {
+      float sc[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) sc[k] = st->sc[k];
+      jacobian_row(sc, q.x, q.y, q.z, coeff, row, rb);
+      rb = (float)(-0.05 * (double)coeff[3]);  // :575
+      kept = 1.0f;
+    }
+  }
+  float v[NCOL];
+#pragma unroll
+  for (int i = 0; i < NCOL; ++i) v[i] = 0.0f;
+  int kk = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = i; j < 6; ++j) v[kk++] = row[i] * row[j];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) v[COL_ATB + i] = row[i] * rb;
+  v[COL_ROWS] = kept;
+  v[COL_LINE] = is_flat ? 0.0f : kept;
+  v[COL_PLANE] = is_flat ? kept : 0.0f;
+#pragma unroll
+  for (int i = 0; i < 31; ++i) v[i] = wave_sum(v[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NCOL; ++i) red[wave][i] = v[i];
+  }
+  __syncthreads();
+  if (tid < NCOL) {
+    float sacc = red[0][tid];
+#pragma unroll
+    for (int w = 1; w < NWAVE; ++w) sacc += red[w][tid];
+    a.partials[(size_t)lb * NCOL + tid] = sacc;
+  }
+}
+
+hipError_t launch_odom_sweep(const OdomArgs &a, hipStream_t s) {
+  if (a.nb_total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(odom_sweep_kernel, dim3(a.nb_total), dim3(256), 0, s, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_solve(const SolveArgs &a, hipStream_t s) {

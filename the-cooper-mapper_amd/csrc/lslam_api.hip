@@ -107,6 +107,8 @@ struct lslam_ctx {
   size_t n_points = 0;
   DevBuf<float> partials;
   DevBuf<uint32_t> stack_ovf;  // only allocated for trees deeper than KD_STACK_LDS+1
+  DevBuf<int32_t> prev_nb;     // neighbours of the previous sweep, per resident scan point
+  bool prev_valid = false;
   GNState *d_state = nullptr;   // [state_cap]
   GNState *h_state = nullptr;   // pinned, [state_cap]
   int32_t state_cap = 0;
@@ -223,6 +225,9 @@ void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
   a.states = ctx->d_state;
   a.partials = ctx->partials.p;
   a.stack_ovf = nullptr;
+  a.prev_nb = ctx->prev_nb.p;
+  a.prev_valid = 0;
+  a.bounded = 0;
   a.idx_out = nullptr;
   a.d2_out = nullptr;
   a.coeff_out = nullptr;
@@ -318,6 +323,7 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   ctx->tc.nodes.release(); ctx->tc.pts.release();
   ctx->ts.nodes.release(); ctx->ts.pts.release();
   ctx->cell_c.release(); ctx->cell_s.release(); ctx->views_c.release(); ctx->views_s.release();
+  ctx->prev_nb.release();
   ctx->q.release(); ctx->blocks.release(); ctx->probs.release(); ctx->partials.release(); ctx->stack_ovf.release();
   ctx->t_idx.release(); ctx->t_d2.release(); ctx->t_coeff.release(); ctx->t_flags.release();
   ctx->t_q.release(); ctx->t_small.release();
@@ -402,6 +408,7 @@ int lslam_map_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const voi
   }
   ctx->have_map = false;
   ctx->cube_mode = false;
+  ctx->prev_valid = false;
   const double t0 = now_ms();
   std::vector<float4> cc, cs;
   static const bool host_tree = std::getenv("LSLAM_HOST_TREE") != nullptr;  // A/B and fallback
@@ -580,6 +587,7 @@ int lslam_cubemap_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const
     return LSLAM_ERR_INVALID;
   }
   ctx->have_map = false;
+  ctx->prev_valid = false;
   const double t0 = now_ms();
   int dc = 0, ds = 0;
   size_t nc_nodes = 0, ns_nodes = 0;
@@ -680,6 +688,8 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
   HIP_TRY(ctx->blocks.reserve(nb ? nb : 1));
   HIP_TRY(ctx->probs.reserve((size_t)n_scans));
   HIP_TRY(ctx->partials.reserve((nb ? nb : 1) * NCOL));
+  HIP_TRY(ctx->prev_nb.reserve((total ? total : 1) * 5));
+  ctx->prev_valid = false;
   rc = ensure_states(ctx, n_scans);
   if (rc) return rc;
   if (total)
@@ -775,6 +785,10 @@ int lslam_scanmatch_run_batch(lslam_ctx *ctx, int32_t n_scans, float *poses,
     if (batch > max_it - launched) batch = max_it - launched;
     for (int b = 0; b < batch; ++b) {
       const int it = launched + b;
+      static const bool unbounded = std::getenv("LSLAM_UNBOUNDED_KNN") != nullptr;  // A/B switch
+      sa.bounded = (ctx->cube_mode || unbounded) ? 0 : 1;  // per-cube positions are tree-relative
+      sa.prev_valid = ctx->prev_valid ? 1 : 0;
+      if (sa.bounded) ctx->prev_valid = true;  // after this launch the buffer is filled
       if (o.profile)
         HIP_TRY(launch_sweep(sa, o.jtj_mode, ctx->stream, ctx->sweep_ev[2 * it],
                              ctx->sweep_ev[2 * it + 1]));
@@ -929,6 +943,7 @@ int lslam_odometry_match(lslam_ctx *ctx, const void *last_corner, size_t n_lc, c
   // the map slot of the context holds the two kd-trees (host builder: the clouds are small)
   ctx->have_map = false;
   ctx->cube_mode = false;
+  ctx->prev_valid = false;
   HostTree hc, hs;
   build_kdtree_host(reinterpret_cast<const float *>(lc.data()), n_lc, 4, hc);
   build_kdtree_host(reinterpret_cast<const float *>(ls.data()), n_ls, 4, hs);

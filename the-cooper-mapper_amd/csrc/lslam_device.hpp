@@ -145,9 +145,14 @@ struct TravStats { unsigned long long t_desc, t_leaf, t_pop, t_take; unsigned n_
 // * A leaf (<= 10 points, one contiguous run) is fetched with 10 independent
 //   16-byte loads before any distance is evaluated (the point array is padded).
 // p[] are positions in the permuted point array (pts[p].w carries the original index).
+//
+// `bound` (FLT_MAX for nanoflann's plain search) is an upper bound of the 5th neighbour's
+// squared distance known in advance: subtrees and points beyond it cannot be among the five
+// nearest, so they are skipped; what is visited is visited in the same order, hence the same
+// result (callers pad the bound by a few ulps' worth to cover the rounding of mindistsq).
 template <int BLOCK, bool OVF>
 LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, float (&d)[5],
-                           int (&p)[5], KdStack<BLOCK, OVF> &stk
+                           int (&p)[5], KdStack<BLOCK, OVF> &stk, const float bound = FLT_MAX
 #ifdef LSLAM_TRAVERSAL_STATS
                            , TravStats &ts
 #endif
@@ -184,7 +189,7 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
       const float cd = left ? diff2 * diff2 : diff1 * diff1;  // accum_dist :374-377
       const float dst = feat == 0 ? ds0 : (feat == 1 ? ds1 : ds2);
       const float nm = (mind + cd) - dst;  // :1486
-      if (nm <= d[4]) {
+      if (nm <= fminf(d[4], bound)) {
         stk.put(sp, node | (feat << 29), __float_as_uint(nm));
         ++sp;
       }
@@ -194,7 +199,7 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
     {  // leaf: nanoflann.hpp:1438-1457
       TS_INC(n_leaf)
       const int l = (int)((ref & ~KD_LEAF) >> 4), cnt = (int)(ref & 15u);
-      const float worst = d[4];  // worst_dist cached once per leaf
+      const float worst = fminf(d[4], bound);  // worst_dist cached once per leaf
       float4 pt[10];
 #pragma unroll
       for (int j = 0; j < 10; ++j) pt[j] = T.pts[l + j];
@@ -226,7 +231,7 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
         const bool valid = !take && sp > 0;
         const uint32_t feat = (e[j] >> 29) & 3u;
         const bool act = (e[j] & 0x80000000u) != 0;  // far subtree finished (:1494)
-        const bool pass = !act && (m[j] <= d[4]);    // mindistsq*epsError <= worstDist (:1487)
+        const bool pass = !act && (m[j] <= fminf(d[4], bound));  // mindistsq*epsError <= worstDist (:1487)
         const bool rst = valid && act;
         ds0 = (rst && feat == 0) ? m[j] : ds0;        // dists[idx] = dst
         ds1 = (rst && feat == 1) ? m[j] : ds1;

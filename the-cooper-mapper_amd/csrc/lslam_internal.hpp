@@ -82,6 +82,9 @@ struct SweepArgs {
   const GNState *states;  // [n_prob]
   float *partials;        // [nb_total][NCOL]
   uint32_t *stack_ovf;    // traversal-stack overflow (null unless a tree is deeper than 33)
+  int32_t *prev_nb;       // [points][5] neighbour positions found by the previous sweep
+  int32_t prev_valid;     // prev_nb holds positions of the current trees
+  int32_t bounded;        // 1: production loop (bounded search), 0: taps (nanoflann's plain search)
   // optional per-point taps (all NULL in the production loop)
   int32_t *idx_out;    // [N][5] original map indices
   float *d2_out;       // [N][5]

@@ -119,6 +119,26 @@ __global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mo
     stk.lds = stack_lds + tid;
     stk.ovf = OVF ? a.stack_ovf + ((size_t)blockIdx.x * BLOCK + tid) : nullptr;
     stk.ovf_stride = (size_t)a.nb_total * BLOCK;
+    // Bound on the 5th neighbour's distance (production loop only; the taps run nanoflann's
+    // unbounded search).  Points whose 5th neighbour is not closer than sqrt(5) m are rejected
+    // by the gate below anyway (ScanMatch.cpp:102,120), and the five neighbours found in the
+    // previous sweep -- any five map points -- bound the new distance from above.  Both are
+    // padded by 1e-5 relative, far above the rounding of the traversal's mindistsq.
+    float bound = FLT_MAX;
+    if (a.bounded) {
+      bound = 5.0f * (1.0f + 1e-5f);
+      if (a.prev_valid) {
+        float u = 0.0f;
+        bool all = true;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const int pp = a.prev_nb[(size_t)qi * 5 + j];
+          all = all && pp >= 0 && pp < T.n_pts;
+          if (pp >= 0 && pp < T.n_pts) u = fmaxf(u, dist2_xyz(sel[0], sel[1], sel[2], T.pts[pp]));
+        }
+        if (all) bound = fminf(bound, u * (1.0f + 1e-5f) + 1e-12f);
+      }
+    }
 #ifdef LSLAM_TRAVERSAL_STATS
     TravStats ts = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     knn5_search<BLOCK, OVF>(T, sel[0], sel[1], sel[2], d, p, stk, ts);
@@ -128,7 +148,11 @@ __global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mo
       o[4] = ts.n_leaf; o[5] = ts.n_pop; o[6] = ((uint64_t)ts.n_popit << 32) | ts.n_take; o[7] = ts.t_take | (1ull << 63);
     }
 #else
-    knn5_search<BLOCK, OVF>(T, sel[0], sel[1], sel[2], d, p, stk);
+    knn5_search<BLOCK, OVF>(T, sel[0], sel[1], sel[2], d, p, stk, bound);
+    if (a.bounded) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) a.prev_nb[(size_t)qi * 5 + j] = p[j];
+    }
 #endif
     if (a.dbg) dbg_t1 = __builtin_readcyclecounter();
 

@@ -228,6 +228,7 @@ void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
   a.prev_nb = ctx->prev_nb.p;
   a.prev_valid = 0;
   a.bounded = 0;
+  a.deep_tree = (ctx->tc.depth > KD_STACK_LDS + 1 || ctx->ts.depth > KD_STACK_LDS + 1) ? 1 : 0;
   a.idx_out = nullptr;
   a.d2_out = nullptr;
   a.coeff_out = nullptr;
@@ -387,6 +388,9 @@ int lslam_debug_sweep_clocks(lslam_ctx *ctx, const float pose[6], int32_t jtj_mo
   HIP_TRY(hipMalloc((void **)&d, words * sizeof(uint64_t)));
   HIP_TRY(hipMemsetAsync(d, 0, words * sizeof(uint64_t), ctx->stream));
   sa.dbg = d;
+  sa.bounded = std::getenv("LSLAM_UNBOUNDED_KNN") ? 0 : 1;
+  sa.prev_valid = ctx->prev_valid ? 1 : 0;
+  if (sa.bounded) ctx->prev_valid = true;
   HIP_TRY(launch_sweep(sa, jtj_mode, ctx->stream));
   HIP_TRY(hipMemcpyAsync(out, d, words * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -750,8 +754,9 @@ int lslam_scanmatch_run_batch(lslam_ctx *ctx, int32_t n_scans, float *poses,
                          hipMemcpyHostToDevice, ctx->stream));
   SweepArgs sa;
   fill_sweep_args(ctx, sa);
-  rc = ensure_stack_ovf(ctx, (size_t)sa.nb_total * SWEEP_BLOCK, &sa.stack_ovf);
-  if (rc) return rc;
+  // the production sweep keeps a shallow stack in LDS: it always gets the overflow area
+  HIP_TRY(ctx->stack_ovf.reserve(stack_ovf_words((size_t)sa.nb_total * SWEEP_BLOCK)));
+  sa.stack_ovf = ctx->stack_ovf.p;
   SolveArgs so{};
   so.states = ctx->d_state;
   so.partials = ctx->partials.p;

@@ -91,30 +91,32 @@ LSLAM_DEV void knn_insert(float (&d)[5], int (&p)[5], float dist, int pos) {
 // host allocates only for such trees.
 constexpr int KD_STACK_LDS = 32;
 
-template <int BLOCK, bool OVF>
+template <int BLOCK, bool OVF, int LDS_DEPTH = KD_STACK_LDS>
 struct KdStack {
-  uint32_t *lds;  // [2][KD_STACK_LDS][BLOCK], already offset by the thread index
+  uint32_t *lds;  // [2][LDS_DEPTH][BLOCK], already offset by the thread index
   uint32_t *ovf;  // global overflow, already offset by the global thread index (OVF only)
   size_t ovf_stride;  // n_threads
-  // OVF=false kernels (every tree at most KD_STACK_LDS+1 levels deep) touch LDS only, so
-  // the accesses stay ds_read/ds_write; the OVF=true variant branches explicitly (a
-  // select between the two address spaces would turn every access into a flat one).
+  // OVF=false kernels (every tree at most LDS_DEPTH+1 levels deep) touch LDS only, so the
+  // accesses stay ds_read/ds_write; the OVF=true variant branches explicitly (a select
+  // between the two address spaces would turn every access into a flat one).  The
+  // production sweep keeps only LDS_DEPTH = 12 levels in LDS (the bounded search rarely
+  // stacks more) so that four workgroups fit a CU instead of two.
   LSLAM_DEV void put(int e, uint32_t w0, uint32_t w1) {
-    if (!OVF || e < KD_STACK_LDS) {
+    if (!OVF || e < LDS_DEPTH) {
       lds[e * BLOCK] = w0;
-      lds[(KD_STACK_LDS + e) * BLOCK] = w1;
+      lds[(LDS_DEPTH + e) * BLOCK] = w1;
     } else {
-      ovf[(size_t)(e - KD_STACK_LDS) * ovf_stride] = w0;
-      ovf[(size_t)(KD_STACK_MAX - KD_STACK_LDS + e - KD_STACK_LDS) * ovf_stride] = w1;
+      ovf[(size_t)(e - LDS_DEPTH) * ovf_stride] = w0;
+      ovf[(size_t)(KD_STACK_MAX - LDS_DEPTH + e - LDS_DEPTH) * ovf_stride] = w1;
     }
   }
   LSLAM_DEV void get(int e, uint32_t &w0, uint32_t &w1) const {
-    if (!OVF || e < KD_STACK_LDS) {
+    if (!OVF || e < LDS_DEPTH) {
       w0 = lds[e * BLOCK];
-      w1 = lds[(KD_STACK_LDS + e) * BLOCK];
+      w1 = lds[(LDS_DEPTH + e) * BLOCK];
     } else {
-      w0 = ovf[(size_t)(e - KD_STACK_LDS) * ovf_stride];
-      w1 = ovf[(size_t)(KD_STACK_MAX - KD_STACK_LDS + e - KD_STACK_LDS) * ovf_stride];
+      w0 = ovf[(size_t)(e - LDS_DEPTH) * ovf_stride];
+      w1 = ovf[(size_t)(KD_STACK_MAX - LDS_DEPTH + e - LDS_DEPTH) * ovf_stride];
     }
   }
 };
@@ -150,13 +152,13 @@ struct TravStats { unsigned long long t_desc, t_leaf, t_pop, t_take; unsigned n_
 // squared distance known in advance: subtrees and points beyond it cannot be among the five
 // nearest, so they are skipped; what is visited is visited in the same order, hence the same
 // result (callers pad the bound by a few ulps' worth to cover the rounding of mindistsq).
-template <int BLOCK, bool OVF>
+template <int BLOCK, bool OVF, int LDS_DEPTH>
 LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, float (&d)[5],
-                           int (&p)[5], KdStack<BLOCK, OVF> &stk, const float bound = FLT_MAX
+                           int (&p)[5], KdStack<BLOCK, OVF, LDS_DEPTH> &stk,
 #ifdef LSLAM_TRAVERSAL_STATS
-                           , TravStats &ts
+                           TravStats &ts,
 #endif
-                           ) {
+                           const float bound = FLT_MAX) {
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     d[i] = FLT_MAX;

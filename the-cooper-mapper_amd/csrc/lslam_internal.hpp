@@ -85,6 +85,7 @@ struct SweepArgs {
   int32_t *prev_nb;       // [points][5] neighbour positions found by the previous sweep
   int32_t prev_valid;     // prev_nb holds positions of the current trees
   int32_t bounded;        // 1: production loop (bounded search), 0: taps (nanoflann's plain search)
+  int32_t deep_tree;      // a tree is deeper than KD_STACK_LDS+1: the LDS-only kernels cannot be used
   // optional per-point taps (all NULL in the production loop)
   int32_t *idx_out;    // [N][5] original map indices
   float *d2_out;       // [N][5]
@@ -134,7 +135,7 @@ hipError_t launch_knn5(const TreeView &T, const float4 *q, int nq, int32_t *idx,
                        uint32_t *stack_ovf, hipStream_t s);
 // words of overflow stack needed for n_threads lanes
 inline size_t stack_ovf_words(size_t n_threads) {
-  return 2 * (size_t)(KD_STACK_MAX - KD_STACK_LDS) * n_threads;
+  return 2 * (size_t)KD_STACK_MAX * n_threads;  // enough for any LDS depth
 }
 hipError_t launch_gn_step_tap(GNState *st, const float *AtA, const float *Atb, float dr, float dt,
                               float eig_thresh, hipStream_t s);

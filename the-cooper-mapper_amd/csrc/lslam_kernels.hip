@@ -53,8 +53,8 @@ LSLAM_DEV int cube_tree_of(const CubeGridDev &g, float x, float y, float z) {
   return -1;
 }
 
-template <int BLOCK, bool OVF, bool CUBES>
-__global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mode) {
+template <int BLOCK, bool OVF, bool CUBES, int LDS_DEPTH>
+__global__ __launch_bounds__(BLOCK, LDS_DEPTH <= 16 ? 4 : 2) void sweep_kernel(SweepArgs a, int jtj_mode) {
   const int lb = xcd_remap(blockIdx.x, a.nb_total);
   const BlockDesc bd = a.blocks[lb];
   const GNState *st = a.states + bd.prob;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mo
   constexpr int NWAVE = BLOCK / 64;
   __shared__ float red[NWAVE][NCOL];
   __shared__ float jrows[NWAVE][64][8];  // MFMA staging: [point][J0..J5,b,0]
-  __shared__ uint32_t stack_lds[2 * KD_STACK_LDS * BLOCK];
+  __shared__ uint32_t stack_lds[2 * LDS_DEPTH * BLOCK];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mo
       }
     }
     if (CUBES && !searched) T.n_pts = 0;  // knn5_search returns at once, d[4] stays FLT_MAX
-    KdStack<BLOCK, OVF> stk;
+    KdStack<BLOCK, OVF, LDS_DEPTH> stk;
     stk.lds = stack_lds + tid;
     stk.ovf = OVF ? a.stack_ovf + ((size_t)blockIdx.x * BLOCK + tid) : nullptr;
     stk.ovf_stride = (size_t)a.nb_total * BLOCK;
@@ -141,14 +141,18 @@ __global__ __launch_bounds__(BLOCK, 2) void sweep_kernel(SweepArgs a, int jtj_mo
     }
 #ifdef LSLAM_TRAVERSAL_STATS
     TravStats ts = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    knn5_search<BLOCK, OVF>(T, sel[0], sel[1], sel[2], d, p, stk, ts);
+    knn5_search<BLOCK, OVF, LDS_DEPTH>(T, sel[0], sel[1], sel[2], d, p, stk, ts, bound);
+    if (a.bounded) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) a.prev_nb[(size_t)qi * 5 + j] = p[j];
+    }
     if (a.dbg) {  // per-lane stats: [N][8] after the per-wave stamps
       uint64_t *o = a.dbg + (size_t)a.nb_total * NWAVE * 4 + ((size_t)lb * BLOCK + tid) * 8;
       o[0] = ts.t_desc; o[1] = ts.t_leaf; o[2] = ts.t_pop; o[3] = ts.n_node;
       o[4] = ts.n_leaf; o[5] = ts.n_pop; o[6] = ((uint64_t)ts.n_popit << 32) | ts.n_take; o[7] = ts.t_take | (1ull << 63);
     }
 #else
-    knn5_search<BLOCK, OVF>(T, sel[0], sel[1], sel[2], d, p, stk, bound);
+    knn5_search<BLOCK, OVF, LDS_DEPTH>(T, sel[0], sel[1], sel[2], d, p, stk, bound);
     if (a.bounded) {
 #pragma unroll
       for (int j = 0; j < 5; ++j) a.prev_nb[(size_t)qi * 5 + j] = p[j];
@@ -284,14 +288,22 @@ hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEven
   if (a.nb_total <= 0) return hipSuccess;
   const dim3 g(a.nb_total), b(SWEEP_BLOCK);
   const bool cubes = a.gc.trees != nullptr;
-  if (cubes && a.stack_ovf)
-    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, true>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+  constexpr int SHALLOW = 12;  // LDS levels of the production (bounded) sweep
+  // A launch with more wavefronts than two per SIMD (256 CUs x 4 SIMDs) is throughput bound:
+  // take the shallow-stack kernel (4 workgroups per CU).  A smaller launch is latency bound
+  // and every wavefront is resident anyway: keep the whole stack in LDS.
+  const bool many_waves = (long)a.nb_total * (SWEEP_BLOCK / 64) > 2 * 1024;
+  const bool deep_tree = a.deep_tree != 0;
+  if (a.bounded && a.stack_ovf && !cubes && (many_waves || deep_tree))
+    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, SHALLOW>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+  else if (cubes && a.stack_ovf && deep_tree)
+    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, true, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
   else if (cubes)
-    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false, true>), g, b, 0, s, start, stop, 0, a, jtj_mode);
-  else if (a.stack_ovf)
-    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false, true, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+  else if (a.stack_ovf && deep_tree)
+    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
   else
-    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false, false>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false, false, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
   return hipGetLastError();
 }
 
@@ -793,11 +805,16 @@ __global__ __launch_bounds__(256, 2) void odom_sweep_kernel(OdomArgs a) {
       TreeView T = is_flat ? a.ts : a.tc;
       float d[5];
       int p[5];
-      KdStack<BLOCK, false> stk;
+      KdStack<BLOCK, false, KD_STACK_LDS> stk;
       stk.lds = stack_lds + tid;
       stk.ovf = nullptr;
       stk.ovf_stride = 0;
-      knn5_search<BLOCK, false>(T, sel[0], sel[1], sel[2], d, p, stk);  // top-1 of the 5 == nearestKSearch(.,1)
+#ifdef LSLAM_TRAVERSAL_STATS
+      TravStats ts_unused = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      knn5_search<BLOCK, false, KD_STACK_LDS>(T, sel[0], sel[1], sel[2], d, p, stk, ts_unused);
+#else
+      knn5_search<BLOCK, false, KD_STACK_LDS>(T, sel[0], sel[1], sel[2], d, p, stk);  // top-1 of the 5 == nearestKSearch(.,1)
+#endif
       i1 = -1; i2 = -1; i3 = -1;
       if (d[0] < 25.0f) {
         i1 = __float_as_int(T.pts[p[0]].w);
@@ -921,15 +938,15 @@ __global__ __launch_bounds__(128, 2) void knn5_kernel(TreeView T, const float4 *
   const float4 qq = q[i];
   float d[5];
   int p[5];
-  KdStack<128, OVF> stk;
+  KdStack<128, OVF, KD_STACK_LDS> stk;
   stk.lds = stack_lds + threadIdx.x;
   stk.ovf = OVF ? stack_ovf + ((size_t)blockIdx.x * 128 + threadIdx.x) : nullptr;
   stk.ovf_stride = (size_t)gridDim.x * 128;
 #ifdef LSLAM_TRAVERSAL_STATS
   TravStats ts = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  knn5_search<128, OVF>(T, qq.x, qq.y, qq.z, d, p, stk, ts);
+  knn5_search<128, OVF, KD_STACK_LDS>(T, qq.x, qq.y, qq.z, d, p, stk, ts);
 #else
-  knn5_search<128, OVF>(T, qq.x, qq.y, qq.z, d, p, stk);
+  knn5_search<128, OVF, KD_STACK_LDS>(T, qq.x, qq.y, qq.z, d, p, stk);
 #endif
 #pragma unroll
   for (int j = 0; j < 5; ++j) {

@@ -265,23 +265,33 @@ __global__ void pg_assemble_off_kernel(const double *rec, const int32_t *o_ptr, 
 // block `src` (diag: v; off: n_v + id), transposed or not.
 __global__ void pg_expand_kernel(const double *sys, const int32_t *row_src, int n_entries, double lambda,
                                  double *vals) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int a = t / 36, k = t % 36;
-  if (a >= n_entries) return;
+  // solver layout: six column planes, vals[c * n_items + entry * 6 + r] (n_items = 6 n_entries), so
+  // that the product kernel's lanes (one per (entry, r)) read consecutive doubles
+  const size_t n_items = (size_t)n_entries * 6;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_items * 6) return;
+  const int c = (int)(t / n_items);
+  const size_t item = t - (size_t)c * n_items;
+  const int a = (int)(item / 6), r = (int)(item % 6);
   const int code = row_src[a];  // (block index in [diag|off] << 2) | transposed<<1 | is_diag
   const int blk = code >> 2;
   const bool tr = (code & 2) != 0, dg = (code & 1) != 0;
-  const int r = k / 6, c = k % 6;
-  double v = sys[(size_t)blk * 36 + (tr ? c * 6 + r : k)];
+  double v = sys[(size_t)blk * 36 + (tr ? c * 6 + r : r * 6 + c)];
   if (dg && r == c) v += lambda;
-  vals[(size_t)a * 36 + k] = v;
+  vals[t] = v;
 }
 
 // block-Jacobi preconditioner: inverse of the (damped) 6x6 diagonal blocks via Cholesky
-__global__ void pg_precond_kernel(const double *vals, const int32_t *row_ptr, int n_v, double *minv) {
+__global__ void pg_precond_kernel(const double *vals, const int32_t *row_ptr, int n_v, size_t n_items,
+                                  double *minv) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= n_v) return;
-  const double *A = vals + (size_t)row_ptr[v] * 36;  // the diagonal entry is first in its row
+  const double *Ad = vals + (size_t)row_ptr[v] * 6;  // the diagonal entry is first in its row
+  double A[36];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) A[i * 6 + j] = Ad[(size_t)j * n_items + i];
   double L[36];
 #pragma unroll
   for (int i = 0; i < 36; ++i) L[i] = 0.0;
@@ -319,8 +329,8 @@ __global__ void pg_precond_kernel(const double *vals, const int32_t *row_ptr, in
 
 // ---- PCG on the expanded block-CSR, one thread per scalar row ---------------------
 // scal: [0] rz_old  [1] alpha-den (p.q)  [2] rz_new  [3] rr  [4] bb  [5] done flag (as double)
-constexpr int CG_BLOCK = 256;
-constexpr int CG_ROWS = 252;  // rows per block: a multiple of 6, so a vertex never straddles blocks
+constexpr int CG_BLOCK = 128;
+constexpr int CG_ROWS = 126;  // rows per block: a multiple of 6, so a vertex never straddles blocks
 
 PG_DEV double block_sum(double v, double *sh) {
   sh[threadIdx.x] = v;
@@ -333,28 +343,60 @@ PG_DEV double block_sum(double v, double *sh) {
   __syncthreads();
   return r;
 }
-PG_DEV double sum_partials(const double *part, int n) {  // every thread, fixed order
-  double s = 0.0;
-  for (int k = 0; k < n; ++k) s += part[k];
-  return s;
+// Fixed-order sums: xor butterfly inside each wavefront (every lane ends with the same
+// total), then the four wavefront totals in order.  M values at once.
+template <int M, int BLOCK = CG_BLOCK>
+PG_DEV void block_sum_m(double (&v)[M], double *sh /* [M * BLOCK / 64] */) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int m = 0; m < M; ++m) v[m] += __shfl_xor(v[m], off);
+  constexpr int W = BLOCK / 64;
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int m = 0; m < M; ++m) sh[m * W + (threadIdx.x >> 6)] = v[m];
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    double s = sh[m * W];
+#pragma unroll
+    for (int w = 1; w < W; ++w) s += sh[m * W + w];
+    v[m] = s;
+  }
+  __syncthreads();
+}
+// sums of M per-block partial arrays, identical in every thread of every block
+template <int M, int BLOCK = CG_BLOCK>
+PG_DEV void sum_partials_m(const double *const (&part)[M], int n, double (&out)[M], double *sh) {
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    double s = 0.0;
+    for (int k = threadIdx.x; k < n; k += BLOCK) s += part[m][k];
+    out[m] = s;
+  }
+  block_sum_m<M, BLOCK>(out, sh);
 }
 
 struct CgArgs {
-  const double *vals;
-  const int32_t *row_ptr, *row_col;
+  const double *vals;  // six planes of n_items
+  const int32_t *row_ptr, *row_col, *row_of;  // block-CSR; row_of[e] = the vertex entry e belongs to
   const double *minv;
   const double *b;
-  double *x, *r, *z, *p, *q;
-  double *part_pq, *part_rz, *part_rr;  // [n_blocks]
-  double *scal;
-  int n6, n_blocks;
+  double *x, *r, *z;
+  double *d;             // [n_items] per-(entry,row) products A_e[r,:] . p[col_e]
+  double *p[2];          // search direction of iteration k lives in p[k & 1]
+  double *part_pq;       // [n_pblocks]
+  double *part_rz[2];    // r.z entering iteration k lives in part_rz[k & 1]
+  double *part_rr;       // [n_blocks]
+  double *scal;          // [3] rr  [4] bb  [5] done flag  [6] iterations done
+  int n6, n_blocks, n_items, n_pblocks;
   double tol2;
 };
 
 __global__ __launch_bounds__(CG_BLOCK) void pg_cg_init_kernel(CgArgs a) {
-  __shared__ double sh[CG_BLOCK];
+  __shared__ double sh[2 * CG_BLOCK / 64];
   const int row = blockIdx.x * CG_ROWS + threadIdx.x;
-  double rz = 0.0, bb = 0.0;
+  double s[2] = {0.0, 0.0};
   if (threadIdx.x < CG_ROWS && row < a.n6) {
     const int v = row / 6, rr = row % 6;
     a.x[row] = 0.0;
@@ -364,98 +406,153 @@ __global__ __launch_bounds__(CG_BLOCK) void pg_cg_init_kernel(CgArgs a) {
 #pragma unroll
     for (int c = 0; c < 6; ++c) z += a.minv[(size_t)v * 36 + rr * 6 + c] * a.b[v * 6 + c];
     a.z[row] = z;
-    a.p[row] = z;
-    rz = bi * z;
-    bb = bi * bi;
+    s[0] = bi * z;
+    s[1] = bi * bi;
   }
-  const double s1 = block_sum(rz, sh), s2 = block_sum(bb, sh);
+  block_sum_m<2>(s, sh);
   if (threadIdx.x == 0) {
-    a.part_rz[blockIdx.x] = s1;
-    a.part_rr[blockIdx.x] = s2;
+    a.part_rz[0][blockIdx.x] = s[0];
+    a.part_rr[blockIdx.x] = s[1];
   }
 }
-__global__ void pg_cg_init2_kernel(CgArgs a) {  // single thread: scalars of iteration 0
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const double rz = sum_partials(a.part_rz, a.n_blocks), bb = sum_partials(a.part_rr, a.n_blocks);
-  a.scal[0] = rz;
-  a.scal[4] = bb;
-  a.scal[5] = (bb == 0.0) ? 1.0 : 0.0;
-  a.scal[6] = 0.0;  // iterations done
+__global__ __launch_bounds__(CG_BLOCK) void pg_cg_init2_kernel(CgArgs a) {  // one block: |b|^2
+  __shared__ double sh[CG_BLOCK / 64];
+  const double *const parts[1] = {a.part_rr};
+  double s[1];
+  sum_partials_m<1>(parts, a.n_blocks, s, sh);
+  if (threadIdx.x == 0) {
+    a.scal[3] = s[0];
+    a.scal[4] = s[0];
+    a.scal[5] = (s[0] == 0.0) ? 1.0 : 0.0;
+    a.scal[6] = 0.0;
+  }
 }
 
-// q = A p ; partial p.q
-__global__ __launch_bounds__(CG_BLOCK) void pg_cg_spmv_kernel(CgArgs a) {
-  __shared__ double sh[CG_BLOCK];
+// Iteration k, first half: convergence test on the previous update, then the products
+// d[e,r] = A_e[r,:] . p_k[col_e] with one lane per (entry, row) -- p_k = z + beta p_{k-1} is
+// recomputed where it is needed, so no grid-wide barrier separates the direction update from
+// the product -- and the partials of p_k . (A p_k) summed in item order.
+constexpr int PROD_BLOCK = 256;
+__global__ __launch_bounds__(PROD_BLOCK) void pg_cg_prod_kernel(CgArgs a, int k) {
+  __shared__ double sh[3 * PROD_BLOCK / 64];
   if (a.scal[5] != 0.0) return;
-  const int row = blockIdx.x * CG_ROWS + threadIdx.x;
-  double pq = 0.0;
-  if (threadIdx.x < CG_ROWS && row < a.n6) {
-    const int v = row / 6, rr = row % 6;
-    double s = 0.0;
-    for (int e = a.row_ptr[v]; e < a.row_ptr[v + 1]; ++e) {
-      const double *A = a.vals + (size_t)e * 36 + rr * 6;
-      const double *pc = a.p + (size_t)a.row_col[e] * 6;
+  // operand loads first: they do not depend on beta, and the launch is latency bound
+  const double *po = (k > 0) ? a.p[(k + 1) & 1] : a.z;  // k == 0: beta = 0, p_0 = z
+  double *pn = a.p[k & 1];
+  const int t = blockIdx.x * PROD_BLOCK + threadIdx.x;
+  const bool on = t < a.n_items;
+  const int tt = on ? t : a.n_items - 1;
+  const int e = tt / 6, r = tt - e * 6;
+  const int v = a.row_of[e];
+  const size_t c0 = (size_t)a.row_col[e] * 6;
+  const int row = v * 6 + r;
+  const bool diag = e == a.row_ptr[v];
+  double A[6], zc[6], pc[6];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) s += A[c] * pc[c];
-    }
-    a.q[row] = s;
-    pq = a.p[row] * s;
+  for (int c = 0; c < 6; ++c) {
+    A[c] = a.vals[(size_t)c * a.n_items + tt];
+    zc[c] = a.z[c0 + c];
+    pc[c] = po[c0 + c];
   }
-  const double s1 = block_sum(pq, sh);
-  if (threadIdx.x == 0) a.part_pq[blockIdx.x] = s1;
+  const double zr = a.z[row], pr0 = po[row];
+  double beta = 0.0;
+  if (k > 0) {
+    const double *const parts[3] = {a.part_rz[k & 1], a.part_rz[(k + 1) & 1], a.part_rr};
+    double s[3];
+    sum_partials_m<3, PROD_BLOCK>(parts, a.n_blocks, s, sh);
+    if (s[2] <= a.tol2 * a.scal[4] || !(s[0] > 0.0)) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.scal[3] = s[2];
+        a.scal[5] = 1.0;
+      }
+      return;
+    }
+    beta = s[0] / s[1];
+  }
+  double pq[1] = {0.0};
+  if (on) {
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) s += A[c] * (zc[c] + beta * pc[c]);
+    a.d[t] = s;
+    const double pr = zr + beta * pr0;
+    if (diag) pn[row] = pr;  // the diagonal entry publishes p_k
+    pq[0] = pr * s;
+  }
+  block_sum_m<1, PROD_BLOCK>(pq, sh);
+  if (threadIdx.x == 0) a.part_pq[blockIdx.x] = pq[0];
 }
-// x += alpha p ; r -= alpha q ; z = M r ; partial r.z, r.r
-__global__ __launch_bounds__(CG_BLOCK) void pg_cg_update_kernel(CgArgs a) {
-  __shared__ double sh[CG_BLOCK];
+// Iteration k, second half: q = row sums of d ; x += alpha p ; r -= alpha q ; z = M r ; partial r.z, r.r
+__global__ __launch_bounds__(CG_BLOCK) void pg_cg_update_kernel(CgArgs a, int k) {
+  __shared__ double sh[2 * CG_BLOCK / 64];
   __shared__ double rloc[CG_BLOCK];
   if (a.scal[5] != 0.0) return;
-  const double alpha = a.scal[0] / sum_partials(a.part_pq, a.n_blocks);
   const int row = blockIdx.x * CG_ROWS + threadIdx.x;
   const bool on = threadIdx.x < CG_ROWS && row < a.n6;
+  const int rowc = on ? row : 0;
+  const int v = rowc / 6, rrow = rowc % 6;
+  // everything that does not need alpha first (latency bound launch)
+  double q = 0.0;  // (A p)[row]: this row's products, in entry order
+  {
+    const int e0 = a.row_ptr[v], e1 = a.row_ptr[v + 1];
+    for (int e = e0; e < e1; e += 4) {
+      double dv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dv[j] = a.d[(size_t)((e + j < e1) ? e + j : e1 - 1) * 6 + rrow];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (e + j < e1) q += dv[j];
+    }
+  }
+  const double xr = a.x[rowc], pr = a.p[k & 1][rowc], rr0 = a.r[rowc];
+  double mi[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) mi[c] = a.minv[(size_t)v * 36 + rrow * 6 + c];
+  double s0[1], s1[1];
+  {
+    const double *const p0[1] = {a.part_rz[k & 1]};
+    const double *const p1[1] = {a.part_pq};
+    sum_partials_m<1>(p0, a.n_blocks, s0, sh);
+    sum_partials_m<1>(p1, a.n_pblocks, s1, sh);
+  }
+  const double alpha = s0[0] / s1[0];
   double rnew = 0.0;
   if (on) {
-    a.x[row] += alpha * a.p[row];
-    rnew = a.r[row] - alpha * a.q[row];
+    a.x[row] = xr + alpha * pr;
+    rnew = rr0 - alpha * q;
     a.r[row] = rnew;
   }
   rloc[threadIdx.x] = rnew;
   __syncthreads();
-  double rz = 0.0, rr = 0.0;
+  double o[2] = {0.0, 0.0};
   if (on) {
-    const int v = row / 6, rrow = row % 6;
     const int base = (int)threadIdx.x - rrow;  // this vertex's 6 residuals sit in this block
     double z = 0.0;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) z += a.minv[(size_t)v * 36 + rrow * 6 + c] * rloc[base + c];
+    for (int c = 0; c < 6; ++c) z += mi[c] * rloc[base + c];
     a.z[row] = z;
-    rz = rnew * z;
-    rr = rnew * rnew;
+    o[0] = rnew * z;
+    o[1] = rnew * rnew;
   }
-  const double s1 = block_sum(rz, sh), s2 = block_sum(rr, sh);
+  block_sum_m<2>(o, sh);
   if (threadIdx.x == 0) {
-    a.part_rz[blockIdx.x] = s1;
-    a.part_rr[blockIdx.x] = s2;
+    a.part_rz[(k + 1) & 1][blockIdx.x] = o[0];
+    a.part_rr[blockIdx.x] = o[1];
+    if (blockIdx.x == 0) a.scal[6] = (double)(k + 1);
   }
 }
-// p = z + beta p ; rotate scalars ; convergence
-__global__ __launch_bounds__(CG_BLOCK) void pg_cg_dir_kernel(CgArgs a) {
+// one block: convergence test after iteration k-1 (what pg_cg_spmv_kernel(k) would decide),
+// run before the host reads the flag
+__global__ __launch_bounds__(CG_BLOCK) void pg_cg_check_kernel(CgArgs a, int k) {
+  __shared__ double sh[2 * CG_BLOCK / 64];
   if (a.scal[5] != 0.0) return;
-  const double rz_new = sum_partials(a.part_rz, a.n_blocks);
-  const double beta = rz_new / a.scal[0];
-  const int row = blockIdx.x * CG_ROWS + threadIdx.x;
-  if (threadIdx.x < CG_ROWS && row < a.n6) a.p[row] = a.z[row] + beta * a.p[row];
-  // the scalars are rewritten by the last block to finish reading them: use a separate
-  // tiny kernel instead (pg_cg_rotate_kernel) to stay race free
-}
-__global__ void pg_cg_rotate_kernel(CgArgs a) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (a.scal[5] != 0.0) return;
-  const double rz_new = sum_partials(a.part_rz, a.n_blocks);
-  const double rr = sum_partials(a.part_rr, a.n_blocks);
-  a.scal[0] = rz_new;
-  a.scal[3] = rr;
-  a.scal[6] += 1.0;
-  if (rr <= a.tol2 * a.scal[4] || !(rz_new > 0.0)) a.scal[5] = 1.0;
+  const double *const parts[2] = {a.part_rz[k & 1], a.part_rr};
+  double s[2];
+  sum_partials_m<2>(parts, a.n_blocks, s, sh);
+  if (threadIdx.x == 0) {
+    a.scal[3] = s[1];
+    if (s[1] <= a.tol2 * a.scal[4] || !(s[0] > 0.0)) a.scal[5] = 1.0;
+  }
 }
 
 // X <- X * fromVectorMQT(dx)
@@ -544,7 +641,7 @@ struct lslam_pg {
   double *d_sys = nullptr;
   bool own_sys = true;
   // solver
-  int32_t *d_row_ptr = nullptr, *d_row_col = nullptr, *d_row_src = nullptr;
+  int32_t *d_row_ptr = nullptr, *d_row_col = nullptr, *d_row_src = nullptr, *d_row_of = nullptr;
   double *d_vals = nullptr, *d_minv = nullptr;
   double *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_p = nullptr, *d_q = nullptr;
   double *d_part = nullptr, *d_scal = nullptr, *d_tmp = nullptr;
@@ -641,38 +738,44 @@ int eval_chi2(lslam_pg *pg, const double *poses, double *out) {
 // (H + lambda I) dx = b by block-Jacobi PCG; returns iterations
 int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
   const int n6 = pg->n_v * 6;
-  hipLaunchKernelGGL(pg_expand_kernel, dim3((pg->n_entries * 36 + 255) / 256), dim3(256), 0, pg->stream,
+  const size_t n_items = (size_t)pg->n_entries * 6;
+  hipLaunchKernelGGL(pg_expand_kernel, dim3((unsigned)((n_items * 6 + 255) / 256)), dim3(256), 0, pg->stream,
                      pg->d_sys, pg->d_row_src, pg->n_entries, lambda, pg->d_vals);
   hipLaunchKernelGGL(pg_precond_kernel, dim3((pg->n_v + 63) / 64), dim3(64), 0, pg->stream, pg->d_vals,
-                     pg->d_row_ptr, pg->n_v, pg->d_minv);
+                     pg->d_row_ptr, pg->n_v, n_items, pg->d_minv);
   CgArgs a;
   a.vals = pg->d_vals;
   a.row_ptr = pg->d_row_ptr;
   a.row_col = pg->d_row_col;
+  a.row_of = pg->d_row_of;
   a.minv = pg->d_minv;
   a.b = pg->b();
-  a.x = pg->d_x; a.r = pg->d_r; a.z = pg->d_z; a.p = pg->d_p; a.q = pg->d_q;
-  a.part_pq = pg->d_part;
-  a.part_rz = pg->d_part + pg->n_cg_blocks;
+  a.x = pg->d_x; a.r = pg->d_r; a.z = pg->d_z; a.d = pg->d_q;
+  a.p[0] = pg->d_p;
+  a.p[1] = pg->d_p + n6;
+  a.part_rz[0] = pg->d_part;
+  a.part_rz[1] = pg->d_part + pg->n_cg_blocks;
   a.part_rr = pg->d_part + 2 * pg->n_cg_blocks;
+  a.part_pq = pg->d_part + 3 * pg->n_cg_blocks;
+  a.n_items = (int)n_items;
+  a.n_pblocks = (int)((n_items + PROD_BLOCK - 1) / PROD_BLOCK);
   a.scal = pg->d_scal;
   a.n6 = n6;
   a.n_blocks = pg->n_cg_blocks;
   a.tol2 = tol * tol;
   const dim3 g(pg->n_cg_blocks), blk(CG_BLOCK);
   hipLaunchKernelGGL(pg_cg_init_kernel, g, blk, 0, pg->stream, a);
-  hipLaunchKernelGGL(pg_cg_init2_kernel, dim3(1), dim3(1), 0, pg->stream, a);
+  hipLaunchKernelGGL(pg_cg_init2_kernel, dim3(1), blk, 0, pg->stream, a);
   double scal[8] = {0};
   int done_iters = 0;
   for (int it = 0; it < max_cg;) {
     const int chunk = std::min(50, max_cg - it);
-    for (int k = 0; k < chunk; ++k) {
-      hipLaunchKernelGGL(pg_cg_spmv_kernel, g, blk, 0, pg->stream, a);
-      hipLaunchKernelGGL(pg_cg_update_kernel, g, blk, 0, pg->stream, a);
-      hipLaunchKernelGGL(pg_cg_dir_kernel, g, blk, 0, pg->stream, a);
-      hipLaunchKernelGGL(pg_cg_rotate_kernel, dim3(1), dim3(1), 0, pg->stream, a);
+    for (int k = it; k < it + chunk; ++k) {
+      hipLaunchKernelGGL(pg_cg_prod_kernel, dim3(a.n_pblocks), dim3(PROD_BLOCK), 0, pg->stream, a, k);
+      hipLaunchKernelGGL(pg_cg_update_kernel, g, blk, 0, pg->stream, a, k);
     }
     it += chunk;
+    hipLaunchKernelGGL(pg_cg_check_kernel, dim3(1), blk, 0, pg->stream, a, it);
     PG_TRY(hipMemcpyAsync(scal, pg->d_scal, sizeof(scal), hipMemcpyDeviceToHost, pg->stream));
     PG_TRY(hipStreamSynchronize(pg->stream));
     done_iters = (int)scal[6];
@@ -735,12 +838,13 @@ int lslam_pg_create(int device, int32_t n_v, const double *poses7, int32_t n_e, 
     rows[a].push_back({b, ((n_v + k) << 2) | 0});
     rows[b].push_back({a, ((n_v + k) << 2) | 2});
   }
-  std::vector<int32_t> rptr(n_v + 1, 0), rcol, rsrc;
+  std::vector<int32_t> rptr(n_v + 1, 0), rcol, rsrc, rof;
   for (int v = 0; v < n_v; ++v) {
     rptr[v + 1] = rptr[v] + (int)rows[v].size();
     for (auto &pr : rows[v]) {
       rcol.push_back(pr.first);
       rsrc.push_back(pr.second);
+      rof.push_back(v);
     }
   }
   pg->n_entries = (int)rcol.size();
@@ -754,14 +858,17 @@ int lslam_pg_create(int device, int32_t n_v, const double *poses7, int32_t n_e, 
   PG_TRY(dev_upload(&pg->d_row_ptr, rptr));
   PG_TRY(dev_upload(&pg->d_row_col, rcol));
   PG_TRY(dev_upload(&pg->d_row_src, rsrc));
+  PG_TRY(dev_upload(&pg->d_row_of, rof));
   const size_t n6 = (size_t)n_v * 6;
   pg->n_cg_blocks = (int)((n6 + CG_ROWS - 1) / CG_ROWS);
   PG_TRY(hipMalloc((void **)&pg->d_sys, pg->sys_doubles() * sizeof(double)));
   PG_TRY(hipMalloc((void **)&pg->d_vals, (size_t)pg->n_entries * 36 * sizeof(double)));
   PG_TRY(hipMalloc((void **)&pg->d_minv, (size_t)n_v * 36 * sizeof(double)));
-  for (double **p : {&pg->d_x, &pg->d_r, &pg->d_z, &pg->d_p, &pg->d_q})
+  for (double **p : {&pg->d_x, &pg->d_r, &pg->d_z})
     PG_TRY(hipMalloc((void **)p, n6 * sizeof(double)));
-  PG_TRY(hipMalloc((void **)&pg->d_part, 3 * (size_t)pg->n_cg_blocks * sizeof(double)));
+  PG_TRY(hipMalloc((void **)&pg->d_q, (size_t)pg->n_entries * 6 * sizeof(double)));
+  PG_TRY(hipMalloc((void **)&pg->d_p, 2 * n6 * sizeof(double)));
+  PG_TRY(hipMalloc((void **)&pg->d_part, (3 * (size_t)pg->n_cg_blocks + ((size_t)pg->n_entries * 6 + PROD_BLOCK - 1) / PROD_BLOCK) * sizeof(double)));
   PG_TRY(hipMalloc((void **)&pg->d_scal, 8 * sizeof(double)));
   PG_TRY(hipMalloc((void **)&pg->d_tmp, 8 * sizeof(double)));
   int rc = build_shard(pg, 0, n_e);
@@ -777,7 +884,7 @@ void lslam_pg_destroy(lslam_pg *pg) {
   for (void *p : {(void *)pg->d_poses, (void *)pg->d_trial, (void *)pg->d_meas, (void *)pg->d_info,
                   (void *)pg->d_ij, (void *)pg->d_rec, (void *)pg->d_chi, (void *)pg->d_vptr,
                   (void *)pg->d_vadj, (void *)pg->d_optr, (void *)pg->d_oadj, (void *)pg->d_row_ptr,
-                  (void *)pg->d_row_col, (void *)pg->d_row_src, (void *)pg->d_vals, (void *)pg->d_minv,
+                  (void *)pg->d_row_col, (void *)pg->d_row_src, (void *)pg->d_row_of, (void *)pg->d_vals, (void *)pg->d_minv,
                   (void *)pg->d_x, (void *)pg->d_r, (void *)pg->d_z, (void *)pg->d_p, (void *)pg->d_q,
                   (void *)pg->d_part, (void *)pg->d_scal, (void *)pg->d_tmp})
     if (p) (void)hipFree(p);

@@ -155,6 +155,11 @@ class PoseGraph:
             raise LslamError(rc, self.lib.lslam_pg_last_error().decode())
         return rc
 
+    def build(self):
+        """Upload the graph and build the device-side structures now (otherwise the first
+        optimize()/linearize() does it); the counterpart of g2o's initializeOptimization()."""
+        self._build()
+
     def _drop(self):
         if self.h:
             self.lib.lslam_pg_destroy(self.h)

@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--jtj-mode", type=int, default=int(os.environ.get("LSLAM_JTJ_MODE", "1")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pose-graph", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the single-scan latency leg")
     ap.add_argument("--pg-iters", type=int, default=10, help="LM iterations of the pose-graph leg")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     args = ap.parse_args()
@@ -170,7 +171,8 @@ def main():
                 "alg_bytes_per_launch": alg_bytes,
             },
         }
-        out["single_scan"] = single_scan_leg(ctx, pr, opts, max(10, args.steps // 2))
+        if not args.no_single:
+            out["single_scan"] = single_scan_leg(ctx, pr, opts, max(10, args.steps // 2))
     if not args.no_pose_graph:
         pgres = pose_graph_leg(pkg, synth, distmod, dist, rank, world, local_rank, torch, np,
                                args.pg_iters, not args.no_cpu_baseline)
@@ -199,7 +201,7 @@ def pmc_traffic_bytes(batch):
     vals = {}
     for line in open(path):
         f = line.strip().split(",")
-        if len(f) == 4 and f[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+        if len(f) >= 4 and f[1] in ("FETCH_SIZE", "WRITE_SIZE"):
             vals[f[1]] = float(f[3])
     if len(vals) != 2:
         return None

@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pose-graph", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the single-scan latency leg")
+    ap.add_argument("--shard-points", action="store_true",
+                    help="run the sharded-points leg even on one GPU (all-reduce over a world of 1)")
     ap.add_argument("--pg-iters", type=int, default=10, help="LM iterations of the pose-graph leg")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     args = ap.parse_args()
@@ -173,6 +175,13 @@ def main():
         }
         if not args.no_single:
             out["single_scan"] = single_scan_leg(ctx, pr, opts, max(10, args.steps // 2))
+    if world > 1 or args.shard_points:
+        try:
+            shres = sharded_points_leg(pkg, synth, distmod, dist, rank, world, ctx, opts, torch, np, args)
+        except Exception as e:  # never let the secondary leg take the headline line down
+            shres = {"error": repr(e)}
+        if rank == 0:
+            out["sharded_points"] = shres
     if not args.no_pose_graph:
         pgres = pose_graph_leg(pkg, synth, distmod, dist, rank, world, local_rank, torch, np,
                                args.pg_iters, not args.no_cpu_baseline)
@@ -206,6 +215,39 @@ def pmc_traffic_bytes(batch):
     if len(vals) != 2:
         return None
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
+def sharded_points_leg(pkg, synth, distmod, dist, rank, world, ctx, opts, torch, np, args):
+    """ONE 115 200-point scan, its points sharded contiguously over the ranks,
+    the 32 fp64 normal-equation sums all-reduced over RCCL every Gauss-Newton iteration, the
+    6x6 solve replicated.  Latency-bound by construction (two host round trips per iteration);
+    reported as measured, next to the recommended no-collective batch mode."""
+    pr = synth.make_problem(rings=args.rings, azimuth_steps=1800, seed=0)  # the same scan on every rank
+    cb, ce = distmod.shard_range(len(pr["corner"]), rank, world)
+    sb, se = distmod.shard_range(len(pr["surf"]), rank, world)
+    ctx.scan_set(pr["corner"][cb:ce], pr["surf"][sb:se])
+    xchg = torch.zeros(32, dtype=torch.float64, device="cuda")
+
+    def allreduce(ptr, count):
+        if dist is not None:
+            dist.all_reduce(xchg, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+    for _ in range(3):
+        ctx.run_sharded(pr["init_pose"], allreduce, xchg, opts)
+    steps = max(10, args.steps // 2)
+    distmod.barrier(dist)
+    t0 = time.perf_counter()
+    pt = 0
+    for _ in range(steps):
+        status, pose, st = ctx.run_sharded(pr["init_pose"], allreduce, xchg, opts)
+        pt += st.point_residuals
+    distmod.barrier(dist)
+    dt = time.perf_counter() - t0
+    (tot,), tmax = distmod.aggregate(dist, [pt], dt)
+    return {"value": tot / tmax, "unit": "point-residuals/s", "ms_per_scanmatch": 1e3 * tmax / steps,
+            "gn_iterations": int(st.iterations), "n_gpus": world, "scaling": "strong",
+            "allreduce_bytes_per_iteration": 256,
+            "pose_err_vs_ground_truth_m": float(np.abs(pose - pr["gt_pose"])[3:].max())}
 
 
 def pose_graph_leg(pkg, synth, distmod, dist, rank, world, local_rank, torch, np, lm_iters, with_cpu):

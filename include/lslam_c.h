@@ -265,6 +265,19 @@ typedef struct {
  * completed when it returns. */
 typedef void (*lslam_allreduce_fn)(void *user, double *buf, size_t count);
 
+/* ONE scan's points sharded over the ranks (the reference has no such seam: it is the
+ * data-parallel form of ScanMatch.cpp:97-209 -- every point's row is independent given the
+ * pose, the only coupling is the sum A^T A, A^T b and the counters).  Each rank holds its
+ * contiguous shard of the corner and surf points (lslam_scan_set) and the whole map; per
+ * Gauss-Newton iteration the rank's 32 fp64 sums (21 upper-triangular A^T A, 6 A^T b, rows,
+ * line matches, plane matches, score, spare) are copied to xchg32 (DEVICE, 32 doubles, caller
+ * owned -- e.g. a torch tensor the hook can all-reduce over RCCL), fn sums them over the
+ * ranks in place, and every rank runs the same 6x6 solve on the same numbers.  The summation
+ * order differs from the single-GPU loop: poses agree to ~1e-6, not bit for bit. */
+int lslam_scanmatch_run_sharded(lslam_ctx *ctx, float pose[6], const lslam_opts *opts,
+                                lslam_allreduce_fn fn, void *user, double *xchg32,
+                                lslam_stats *stats);
+
 int lslam_pg_create(int device, int32_t n_vertices, const double *poses7, int32_t n_edges,
                     const int32_t *ij, const double *meas7, const double *info36,
                     int32_t fixed_vertex, lslam_pg **out);

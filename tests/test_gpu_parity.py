@@ -560,3 +560,68 @@ def test_posegraph_sharded_equals_full(pkg):
     assert abs(float(sysbuf[-1]) - ref["chi2"]) <= 1e-12 * ref["chi2"]
     hooked.close()
     full.close()
+
+
+def test_sharded_points_gn_loop(pkg, ctx, oracle, small_problem):
+    """one scan's points sharded over ranks, 32 fp64 sums all-reduced per GN
+    iteration.  (a) a world of one rank reproduces lslam_scanmatch_run bit for bit; (b) two
+    shards on two contexts (two host threads, a local sum standing in for RCCL) give the
+    single-GPU pose to 1e-5 m with identical iteration and match counts."""
+    import threading
+    import torch
+    pr = small_problem
+    ctx.map_set(pr["map_corner"], pr["map_surf"])
+    ctx.scan_set(pr["corner"], pr["surf"])
+    status, pose, st = ctx.run(pr["init_pose"])
+    calls = []
+    x = torch.zeros(32, dtype=torch.float64, device="cuda")
+    s1, p1, st1 = ctx.run_sharded(pr["init_pose"], lambda ptr, n: calls.append((ptr, n)), x)
+    assert calls[0] == (x.data_ptr(), 32) and len(calls) == 1 + st.iterations
+    assert s1 == status and st1.iterations == st.iterations and np.array_equal(bits(p1), bits(pose))
+    assert (st1.n_rows, st1.n_line, st1.n_plane) == (st.n_rows, st.n_line, st.n_plane)
+    assert abs(st1.score - st.score) <= 1e-9 * max(1.0, abs(st.score)) and st1.percent == st.percent
+
+    from importlib import import_module
+    dist = import_module("the-cooper-mapper_amd.dist")
+    world = 2
+    xs = [torch.zeros(32, dtype=torch.float64, device="cuda") for _ in range(world)]
+    bar = threading.Barrier(world)
+    out = [None] * world
+    err = []
+
+    def rank_main(r):
+        try:
+            c = pkg.Context(0)
+            c.map_set(pr["map_corner"], pr["map_surf"])
+            cb, ce = dist.shard_range(len(pr["corner"]), r, world)
+            sb, se = dist.shard_range(len(pr["surf"]), r, world)
+            c.scan_set(pr["corner"][cb:ce], pr["surf"][sb:se])
+
+            def allreduce(ptr, n):
+                assert ptr == xs[r].data_ptr() and n == 32
+                bar.wait()
+                if r == 0:
+                    tot = xs[0] + xs[1]
+                    xs[0].copy_(tot)
+                    xs[1].copy_(tot)
+                    torch.cuda.synchronize()
+                bar.wait()
+            out[r] = c.run_sharded(pr["init_pose"], allreduce, xs[r])
+            c.close()
+        except Exception as e:  # pragma: no cover
+            err.append(e)
+            bar.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not err, err
+    for r in range(world):
+        s2, p2, st2 = out[r]
+        assert s2 == status and st2.iterations == st.iterations
+        assert (st2.n_rows, st2.n_line, st2.n_plane) == (st.n_rows, st.n_line, st.n_plane)
+        assert np.abs(p2[3:] - pose[3:]).max() <= 1e-5 and np.abs(p2[:3] - pose[:3]).max() <= 1e-6
+        assert st2.percent == st.percent
+    assert np.array_equal(bits(out[0][1]), bits(out[1][1]))  # every rank ends on the same pose

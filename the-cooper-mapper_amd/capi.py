@@ -115,6 +115,8 @@ SYMBOLS = {
     "lslam_scanmatch_run_batch": (C.c_int, [C.c_void_p, C.c_int32, c_float_p, C.POINTER(LslamOpts),
                                             C.POINTER(LslamStats)]),
     "lslam_scanmatch_run": (C.c_int, [C.c_void_p, c_float_p, C.POINTER(LslamOpts), C.POINTER(LslamStats)]),
+    "lslam_scanmatch_run_sharded": (C.c_int, [C.c_void_p, c_float_p, C.POINTER(LslamOpts), ALLREDUCE_FN,
+                                              C.c_void_p, C.c_void_p, C.POINTER(LslamStats)]),
     "lslam_scanmatch_scan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                        C.c_size_t, c_float_p, C.POINTER(LslamOpts), C.POINTER(LslamStats)]),
     "lslam_scanmatch_full": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,

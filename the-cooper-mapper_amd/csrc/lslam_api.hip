@@ -721,8 +721,13 @@ int lslam_scan_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const vo
   return lslam_scan_set_batch(ctx, 1, &corner, &n_corner, &surf, &n_surf, stride_bytes);
 }
 
-int lslam_scanmatch_run_batch(lslam_ctx *ctx, int32_t n_scans, float *poses,
-                              const lslam_opts *opts_in, lslam_stats *stats) {
+namespace {
+// Shared body of lslam_scanmatch_run_batch and lslam_scanmatch_run_sharded.  With `fn` set the
+// resident scan is this rank's shard of ONE scan's points: every iteration reduces the local
+// partials, hands the 32 fp64 sums to `fn` (sum over ranks, in place, on `xchg`) and then
+// every rank runs the same solve on the same numbers.
+int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_opts *opts_in,
+                   lslam_stats *stats, lslam_allreduce_fn fn, void *user, double *xchg) {
   int rc = check_ctx(ctx);
   if (rc) return rc;
   if (!poses || n_scans <= 0) {
@@ -763,6 +768,7 @@ int lslam_scanmatch_run_batch(lslam_ctx *ctx, int32_t n_scans, float *poses,
   so.probs = ctx->probs.p;
   so.n_prob = n_scans;
   so.reduce_only = 0;
+  so.ext_sums = nullptr;
   so.max_iterations = max_it;
   so.delta_r_abort = o.delta_r_abort;
   so.delta_t_abort = o.delta_t_abort;
@@ -786,7 +792,45 @@ int lslam_scanmatch_run_batch(lslam_ctx *ctx, int32_t n_scans, float *poses,
   HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
   int launched = 0;
   int batch = ctx->iter_hint < 1 ? 1 : ctx->iter_hint;
-  for (;;) {
+  double total_points = -1.0;  // sharded: points of the whole scan (sum over ranks)
+  if (fn) {
+    // xchg[32]: the local point count first (one exchange per call), then the sums per iteration
+    double cnt[NCOL] = {0};
+    cnt[0] = (double)ctx->nqc[0] + (double)ctx->nqs[0];
+    HIP_TRY(hipMemcpyAsync(xchg, cnt, sizeof(cnt), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    fn(user, xchg, NCOL);
+    HIP_TRY(hipMemcpyAsync(cnt, xchg, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    total_points = cnt[0];
+    while (launched < max_it) {
+      const int it = launched;
+      static const bool unbounded = std::getenv("LSLAM_UNBOUNDED_KNN") != nullptr;
+      sa.bounded = (ctx->cube_mode || unbounded) ? 0 : 1;
+      sa.prev_valid = ctx->prev_valid ? 1 : 0;
+      if (sa.bounded) ctx->prev_valid = true;
+      if (o.profile)
+        HIP_TRY(launch_sweep(sa, o.jtj_mode, ctx->stream, ctx->sweep_ev[2 * it], ctx->sweep_ev[2 * it + 1]));
+      else
+        HIP_TRY(launch_sweep(sa, o.jtj_mode, ctx->stream));
+      so.reduce_only = 1;
+      so.ext_sums = nullptr;
+      HIP_TRY(launch_solve(so, ctx->stream));
+      HIP_TRY(hipMemcpyAsync(xchg, (const char *)ctx->d_state + offsetof(GNState, sums), sizeof(double) * NCOL,
+                             hipMemcpyDeviceToDevice, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      fn(user, xchg, NCOL);  // returns with the sum visible to this stream
+      so.reduce_only = 0;
+      so.ext_sums = xchg;
+      HIP_TRY(launch_solve(so, ctx->stream));
+      ++launched;
+      HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+      HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState), hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      if (ctx->h_state[0].done) break;  // identical on every rank: same sums, same solve
+    }
+  }
+  for (; !fn;) {
     if (batch > max_it - launched) batch = max_it - launched;
     for (int b = 0; b < batch; ++b) {
       const int it = launched + b;
@@ -839,7 +883,7 @@ int lslam_scanmatch_run_batch(lslam_ctx *ctx, int32_t n_scans, float *poses,
     if (g.converged && o.use_score) {  // ScanMatch.cpp:263-341
       score = g.score;
       const double match_count = (double)g.n_line + (double)g.n_plane;
-      percent = (float)(match_count / (double)npts);
+      percent = (float)(match_count / (total_points >= 0.0 ? total_points : (double)npts));
       if (score < o.score_threshold) status = LSLAM_LOW_SCORE;
       else if (percent < o.match_percentage_threshold) status = LSLAM_LOW_PERCENT;
       else status = LSLAM_OK;
@@ -870,6 +914,28 @@ int lslam_scanmatch_run_batch(lslam_ctx *ctx, int32_t n_scans, float *poses,
     }
   }
   return n_scans == 1 ? (stats ? stats[0].status : worst) : worst;
+}
+}  // namespace
+
+int lslam_scanmatch_run_batch(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_opts *opts,
+                              lslam_stats *stats) {
+  return run_batch_impl(ctx, n_scans, poses, opts, stats, nullptr, nullptr, nullptr);
+}
+
+int lslam_scanmatch_run_sharded(lslam_ctx *ctx, float pose[6], const lslam_opts *opts, lslam_allreduce_fn fn,
+                                void *user, double *xchg32, lslam_stats *stats) {
+  if (!pose || !fn || !xchg32) {
+    set_err("run_sharded needs a pose, an all-reduce hook and a 32-double device buffer");
+    return LSLAM_ERR_INVALID;
+  }
+  if (ctx && ctx->n_prob != 1) {
+    set_err("run_sharded works on one resident scan shard (lslam_scan_set)");
+    return LSLAM_ERR_INVALID;
+  }
+  lslam_stats local;
+  lslam_stats *st = stats ? stats : &local;
+  const int rc = run_batch_impl(ctx, 1, pose, opts, st, fn, user, xchg32);
+  return rc < 0 ? rc : st->status;
 }
 
 int lslam_scanmatch_run(lslam_ctx *ctx, float pose[6], const lslam_opts *opts, lslam_stats *stats) {

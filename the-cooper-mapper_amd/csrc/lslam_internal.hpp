@@ -99,7 +99,8 @@ struct SolveArgs {
   const float *partials;
   const ProbBlocks *probs;    // [n_prob] block range of each scan
   int32_t n_prob;
-  int32_t reduce_only;  // 1: only reduce partials into state->sums (tap)
+  int32_t reduce_only;  // 1: only reduce partials into state->sums (tap; first half of a sharded iteration)
+  const double *ext_sums;  // non-null: [n_prob][32] sums already reduced (and summed over ranks); skip the reduction
   int32_t max_iterations;
   float delta_r_abort, delta_t_abort;
   float eig_thresh;  // 100 (ScanMatch.cpp:223); 10 in LaserOdometry.cpp:596

@@ -642,27 +642,36 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(SolveArgs a) {
   // Deterministic cross-block reduction in fp64: thread (grp, col) adds rows
   // grp, grp+32, ... in order; 32 independent loads are in flight per pass, so up to
   // 1024 sweep blocks cost a single memory round trip.
-  double s = 0.0;
-  for (int b0 = grp; b0 < nb; b0 += SOLVE_GROUPS * 32) {
-    float v[32];
-#pragma unroll
-    for (int u = 0; u < 32; ++u) {
-      const int b = b0 + u * SOLVE_GROUPS;
-      v[u] = b < nb ? partials[(size_t)b * NCOL + col] : 0.0f;
+  if (a.ext_sums) {  // sharded points: the sums were reduced per rank and all-reduced by the caller
+    if (tid < NCOL) {
+      const double v = a.ext_sums[(size_t)blockIdx.x * NCOL + tid];
+      tot[tid] = v;
+      st->sums[tid] = v;
     }
-#pragma unroll
-    for (int u = 0; u < 32; ++u) s += (double)v[u];
+    __syncthreads();
+  } else {
+    double s = 0.0;
+    for (int b0 = grp; b0 < nb; b0 += SOLVE_GROUPS * 32) {
+      float v[32];
+  #pragma unroll
+      for (int u = 0; u < 32; ++u) {
+        const int b = b0 + u * SOLVE_GROUPS;
+        v[u] = b < nb ? partials[(size_t)b * NCOL + col] : 0.0f;
+      }
+  #pragma unroll
+      for (int u = 0; u < 32; ++u) s += (double)v[u];
+    }
+    red[grp][col] = s;
+    __syncthreads();
+    if (tid < NCOL) {
+      double v = 0.0;
+  #pragma unroll
+      for (int g = 0; g < SOLVE_GROUPS; ++g) v += red[g][tid];
+      tot[tid] = v;
+      st->sums[tid] = v;
+    }
+    __syncthreads();
   }
-  red[grp][col] = s;
-  __syncthreads();
-  if (tid < NCOL) {
-    double v = 0.0;
-#pragma unroll
-    for (int g = 0; g < SOLVE_GROUPS; ++g) v += red[g][tid];
-    tot[tid] = v;
-    st->sums[tid] = v;
-  }
-  __syncthreads();
   if (a.reduce_only) return;
   if (tid == 0) {
     st->clk[1] = wall_clock64();

@@ -135,6 +135,24 @@ class Context:
         self._check(rc)
         return Status(rc), p, st
 
+    def run_sharded(self, pose, allreduce, xchg, opts=None):
+        """lslam_scanmatch_run_sharded: the resident scan is this rank's shard of one scan's
+        points; `allreduce(ptr, count)` sums `count` doubles at device address `ptr` over the
+        ranks in place (e.g. torch.distributed.all_reduce on `xchg`, a 32-double CUDA tensor
+        whose data_ptr() is what the library writes the sums to) -> (status, pose, stats)."""
+        from .capi import ALLREDUCE_FN
+
+        def _tramp(_user, ptr, count):
+            allreduce(ptr, count)
+        cb = ALLREDUCE_FN(_tramp)
+        p = np.array(pose, dtype=np.float32).reshape(6)
+        st = LslamStats()
+        ptr = xchg.data_ptr() if hasattr(xchg, "data_ptr") else int(xchg)
+        rc = self.lib.lslam_scanmatch_run_sharded(self.h, _fp(p), C.byref(opts) if opts is not None else None,
+                                                  cb, None, C.c_void_p(ptr), C.byref(st))
+        self._check(rc)
+        return Status(rc), p, st
+
     def scanmatch_scan(self, corner, surf, pose, opts=None):
         c, sc = _cloud(corner)
         s, _ = _cloud(surf)

@@ -235,6 +235,53 @@ int lslam_gn_step(lslam_ctx *ctx, const float AtA[36], const float Atb[6], int32
                   float delta_t_abort, float x_out[6], float *delta_r, float *delta_t,
                   int32_t *converged);
 
+/* ---- map maintenance ----------------------------------------
+ * Replaces lidar_slam::FeatureMap<PointXYZI> (util/FeatureMap.h) for the steps either side of
+ * the scan match: the cube grid, addFeatureCloud + per-cube pcl::VoxelGrid, the active area and
+ * the surround concatenation -- all resident in HBM, so that the map never returns to the host
+ * between frames.  Clouds handed in are {x,y,z} at offset 0 with the intensity at byte 12 of
+ * 16-byte points or byte 16 of pcl::PointXYZI (32 bytes); clouds handed out are packed
+ * {x,y,z,intensity}.  One in-flight call per ctx, like everything else on a ctx. */
+typedef struct lslam_fmap lslam_fmap;
+
+/* FeatureMap(cubeWidth, cubeHeight, cubeDepth), FeatureMap.h:55-68 (origin = round((size-1)/2),
+ * cube 50 m, valid distance 150 m, leaves 0.2/0.2/0.6). */
+int lslam_fmap_create(lslam_ctx *ctx, int32_t cube_width, int32_t cube_height, int32_t cube_depth,
+                      lslam_fmap **out);
+void lslam_fmap_destroy(lslam_fmap *fm);
+int lslam_fmap_setup_filter_size(lslam_fmap *fm, float corner, float surf, float map);     /* :72-76 */
+int lslam_fmap_setup_world_origin(lslam_fmap *fm, int32_t ox, int32_t oy, int32_t oz);     /* :78-83 */
+int lslam_fmap_setup_world_cube_size(lslam_fmap *fm, float size);                          /* :85-87 */
+int lslam_fmap_setup_lidar_valid_distance(lslam_fmap *fm, float dist);                     /* :89-91 */
+/* update(sensorPose), FeatureMap.h:232-254: clamp the sensor's cube 3 cubes inside the grid,
+ * shift() the cube contents (with the reference's swap-chain behaviour, :353-377), move the
+ * origin, recompute the active area (:307-352). */
+int lslam_fmap_update(lslam_fmap *fm, const float sensor_xyz[3]);
+/* addFeatureCloud(corner, surf, tf), FeatureMap.h:218-230: transform by the row-major 4x4 T, push
+ * every point into its cube (worldToCube, :475-487; points outside the grid are dropped), then
+ * downsizeValidCloud (:288-306): VoxelGrid every cube of the active area. */
+int lslam_fmap_add_feature_cloud(lslam_fmap *fm, const void *corner, size_t n_corner, const void *surf,
+                                 size_t n_surf, size_t stride_bytes, const float T[16]);
+/* getSurroundFeature, FeatureMap.h:256-265: the active cubes' clouds, concatenated in
+ * _cubeValidInd order.  counts first, then the copy to the host ... */
+int lslam_fmap_surround_counts(lslam_fmap *fm, size_t *n_corner, size_t *n_surf);
+int lslam_fmap_get_surround(lslam_fmap *fm, float *corner_xyzi, size_t cap_corner, float *surf_xyzi,
+                            size_t cap_surf);
+/* ... or, without leaving HBM: the surround becomes the ctx's map (what
+ * LaserMatcher::prepareFeatureSurround + ScanMatch.cpp:68-76 do through the host), kd-trees
+ * built on the device. */
+int lslam_fmap_surround_to_map(lslam_fmap *fm);
+/* getFullMap, FeatureMap.h:267-286: per cube, VoxelGrid(map leaf) of corner then surf. */
+int lslam_fmap_get_full_map(lslam_fmap *fm, float *out_xyzi, size_t cap, size_t *n_out);
+/* introspection: grid origin, _cubeValidInd, points held per type; any output may be NULL */
+int lslam_fmap_info(lslam_fmap *fm, int32_t origin[3], int32_t *n_valid, int32_t *valid_out, size_t cap,
+                    size_t *n_corner_total, size_t *n_surf_total);
+/* pcl::VoxelGrid<PointXYZI>::filter with a cubic leaf on one cloud (LaserMatcher.cpp:289-301,
+ * ScanMatch.cpp:362-398 scanMatchLocal): one centroid {x,y,z,intensity} per occupied voxel, in
+ * ascending voxel index.  Points of a voxel are summed in input order (PCL: unspecified). */
+int lslam_voxel_grid(lslam_ctx *ctx, const void *cloud, size_t n, size_t stride_bytes, float leaf,
+                     float *out_xyzi, size_t cap, size_t *n_out);
+
 /* ---- SE(3) pose-graph Levenberg-Marquardt ------------------------------------
  * Replaces pose_graph::SolverG2O (pose_graph/solver_g2o.cpp:51-95): add_se3_node /
  * add_se3_edge build the arrays passed to lslam_pg_create, optimize() becomes

@@ -20,6 +20,7 @@
 #include <iostream>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "lslam_c.h"
 
@@ -91,6 +92,41 @@ public:
     return ok;
   }
 
+  // ScanMatch.cpp:375-398 (Twist overload): pcl::VoxelGrid all four clouds (corner leaf 0.2,
+  // surf leaf 0.4, ScanMatch.cpp:29-30), then scanMatchScan on the downsampled clouds
+  template <typename CloudPtr, typename TwistT>
+  auto scanMatchLocal(const CloudPtr &referenceCornerCloud, const CloudPtr &referenceSurfCloud,
+                      const CloudPtr &CornerCloud, const CloudPtr &SurfCloud, TwistT &transform)
+      -> decltype(transform.rot_x.rad(), bool()) {
+    float pose[6] = {transform.rot_x.rad(), transform.rot_y.rad(), transform.rot_z.rad(),
+                     transform.pos(0), transform.pos(1), transform.pos(2)};
+    const bool ok = run_local(referenceCornerCloud, referenceSurfCloud, CornerCloud, SurfCloud, pose);
+    if (_last.status != LSLAM_TOO_FEW_REF && _last.status >= 0) {
+      transform.rot_x = pose[0];
+      transform.rot_y = pose[1];
+      transform.rot_z = pose[2];
+      transform.pos(0) = pose[3];
+      transform.pos(1) = pose[4];
+      transform.pos(2) = pose[5];
+    }
+    return ok;
+  }
+  // ScanMatch.cpp:362-373 (Isometry3f overload)
+  template <typename CloudPtr, typename Isometry>
+  auto scanMatchLocal(const CloudPtr &referenceCornerCloud, const CloudPtr &referenceSurfCloud,
+                      const CloudPtr &CornerCloud, const CloudPtr &SurfCloud, Isometry &relative_pose)
+      -> decltype(relative_pose.matrix(), bool()) {
+    float T[16], pose[6];
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) T[r * 4 + c] = relative_pose.matrix()(r, c);
+    lslam_isometry_to_pose(T, pose);
+    const bool ok = run_local(referenceCornerCloud, referenceSurfCloud, CornerCloud, SurfCloud, pose);
+    lslam_pose_to_isometry(pose, T);
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) relative_pose.matrix()(r, c) = T[r * 4 + c];
+    return ok;
+  }
+
   inline double getAverageScore() { return (_match_count > 0) ? _total_score / _match_count : 0; }
   const lslam_stats &lastStats() const { return _last; }
   lslam_ctx *context() { return _ctx; }
@@ -100,9 +136,37 @@ private:
   bool run(const CloudPtr &rc, const CloudPtr &rs, const CloudPtr &c, const CloudPtr &s, float pose[6]) {
     typedef decltype(rc->points.data()) P;
     const size_t stride = sizeof(*P());
-    const int st = lslam_scanmatch_full(_ctx, rc->points.data(), rc->points.size(), rs->points.data(),
-                                        rs->points.size(), stride, c->points.data(), c->points.size(),
-                                        s->points.data(), s->points.size(), stride, pose, &_opts, &_last);
+    return run_raw(rc->points.data(), rc->points.size(), rs->points.data(), rs->points.size(), stride,
+                   c->points.data(), c->points.size(), s->points.data(), s->points.size(), stride, pose);
+  }
+
+  template <typename CloudPtr>
+  bool downsize(const CloudPtr &in, float leaf, std::vector<float> &out) {
+    typedef decltype(in->points.data()) P;
+    out.resize(4 * in->points.size() + 4);
+    size_t n = 0;
+    const int st = lslam_voxel_grid(_ctx, in->points.data(), in->points.size(), sizeof(*P()), leaf, out.data(),
+                                    in->points.size(), &n);
+    out.resize(4 * n);
+    return st == LSLAM_OK;
+  }
+
+  template <typename CloudPtr>
+  bool run_local(const CloudPtr &rc, const CloudPtr &rs, const CloudPtr &c, const CloudPtr &s, float pose[6]) {
+    if (!downsize(rc, 0.2f, _ds[0]) || !downsize(rs, 0.4f, _ds[1]) || !downsize(c, 0.2f, _ds[2]) ||
+        !downsize(s, 0.4f, _ds[3])) {
+      std::cout << "[ScanMatch] backend error: " << lslam_last_error() << std::endl;
+      _last.status = LSLAM_ERR_HIP;
+      return false;
+    }
+    return run_raw(_ds[0].data(), _ds[0].size() / 4, _ds[1].data(), _ds[1].size() / 4, 16, _ds[2].data(),
+                   _ds[2].size() / 4, _ds[3].data(), _ds[3].size() / 4, 16, pose);
+  }
+
+  bool run_raw(const void *rc, size_t nrc, const void *rs, size_t nrs, size_t ref_stride, const void *c, size_t nc,
+               const void *s, size_t ns, size_t stride, float pose[6]) {
+    const int st = lslam_scanmatch_full(_ctx, rc, nrc, rs, nrs, ref_stride, c, nc, s, ns, stride, pose, &_opts,
+                                        &_last);
     if (st < 0) {
       std::cout << "[ScanMatch] backend error: " << lslam_last_error() << std::endl;
       _last.status = st;
@@ -124,6 +188,7 @@ private:
   lslam_ctx *_ctx;
   lslam_opts _opts;
   lslam_stats _last{};
+  std::vector<float> _ds[4];  // _referenceCornerCloudDS, _referenceSurfCloudDS, _CornerCloudDS, _SurfCloudDS
   double _total_score;
   long _match_count;
   long _fail_match_count;

@@ -62,9 +62,8 @@ def build_oracle(native=False):
     """Compile the oracle with its Makefile if the .so is missing or stale."""
     target = "liblslam_oracle_native.so" if native else "liblslam_oracle.so"
     so = os.path.join(ORACLE_DIR, target)
-    src = os.path.join(ORACLE_DIR, "lslam_oracle.c")
-    hdr = os.path.join(ORACLE_DIR, "lslam_oracle.h")
-    if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("lslam_oracle.c", "lslam_oracle.h", "fmap_oracle.c", "fmap_oracle.h")]
+    if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, target], stdout=subprocess.DEVNULL)
     return so
 
@@ -137,6 +136,37 @@ class Oracle:
         L.oracle_gn_step.argtypes = [c_float_p, c_float_p, C.c_int, c_float_p, c_float_p,
                                      C.POINTER(C.c_int), C.c_float, C.c_float, C.c_float,
                                      c_float_p, c_float_p, c_float_p]
+
+        L.oracle_voxel_grid.restype = C.c_size_t
+        L.oracle_voxel_grid.argtypes = [c_float_p, C.c_size_t, C.c_size_t, C.c_float, c_float_p]
+        L.oracle_fmap_create.restype = C.c_void_p
+        L.oracle_fmap_create.argtypes = [C.c_int] * 3
+        L.oracle_fmap_free.argtypes = [C.c_void_p]
+        L.oracle_fmap_setup_filter_size.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+        L.oracle_fmap_setup_cube_size.argtypes = [C.c_void_p, C.c_float]
+        L.oracle_fmap_setup_valid_distance.argtypes = [C.c_void_p, C.c_float]
+        L.oracle_fmap_origin.argtypes = [C.c_void_p, c_int32_p]
+        L.oracle_fmap_update.argtypes = [C.c_void_p, c_float_p]
+        L.oracle_fmap_valid_cubes.restype = C.c_size_t
+        L.oracle_fmap_valid_cubes.argtypes = [C.c_void_p, c_int32_p, C.c_size_t]
+        L.oracle_fmap_add_feature_cloud.argtypes = [C.c_void_p, c_float_p, C.c_size_t, c_float_p, C.c_size_t,
+                                                    C.c_size_t, c_float_p]
+        L.oracle_fmap_get_surround.restype = C.c_size_t
+        L.oracle_fmap_get_surround.argtypes = [C.c_void_p, C.c_int, c_float_p, C.c_size_t]
+        L.oracle_fmap_cube_count.restype = C.c_size_t
+        L.oracle_fmap_cube_count.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.oracle_fmap_get_full_map.restype = C.c_size_t
+        L.oracle_fmap_get_full_map.argtypes = [C.c_void_p, c_float_p, C.c_size_t]
+
+    # ---- map maintenance -----------------------------------------------
+    def voxel_grid(self, cloud, leaf):
+        a = np.ascontiguousarray(cloud, dtype=np.float32)
+        out = np.zeros((len(a), 4), np.float32)
+        n = self.lib.oracle_voxel_grid(_fp(a), len(a), a.shape[1], leaf, _fp(out))
+        return out[:n].copy()
+
+    def feature_map(self, w=21, h=11, d=21):
+        return OracleFeatureMap(self, w, h, d)
 
     # ---- kd-tree -------------------------------------------------------
     def kdtree(self, pts):
@@ -299,6 +329,61 @@ class Oracle:
                                        eig_thresh, dr, dt, _fp(x), _fp(dR), _fp(dT))
         return dict(converged=bool(conv), pose=pose, matP=matP.reshape(6, 6), degenerate=bool(deg.value),
                     x=x, delta_r=float(dR[0]), delta_t=float(dT[0]))
+
+
+class OracleFeatureMap:
+    """oracle_fmap_* (oracle/fmap_oracle.c): FeatureMap<PointXYZI> restated on the CPU."""
+
+    def __init__(self, oracle, w, h, d):
+        self.L = oracle.lib
+        self.h = C.c_void_p(self.L.oracle_fmap_create(w, h, d))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.oracle_fmap_free(self.h)
+            self.h = None
+
+    def setup_filter_size(self, corner, surf, map_leaf):
+        self.L.oracle_fmap_setup_filter_size(self.h, corner, surf, map_leaf)
+
+    def setup_world_cube_size(self, s):
+        self.L.oracle_fmap_setup_cube_size(self.h, s)
+
+    def setup_lidar_valid_distance(self, d):
+        self.L.oracle_fmap_setup_valid_distance(self.h, d)
+
+    def update(self, pos):
+        p = np.ascontiguousarray(pos, dtype=np.float32).reshape(3)
+        self.L.oracle_fmap_update(self.h, _fp(p))
+
+    def add_feature_cloud(self, corner, surf, tf):
+        c = np.ascontiguousarray(corner, dtype=np.float32)
+        s = np.ascontiguousarray(surf, dtype=np.float32)
+        T = np.ascontiguousarray(tf, dtype=np.float32).reshape(16)
+        self.L.oracle_fmap_add_feature_cloud(self.h, _fp(c), len(c), _fp(s), len(s), c.shape[1], _fp(T))
+
+    def get_surround_feature(self):
+        out = []
+        for which in (0, 1):
+            n = self.L.oracle_fmap_get_surround(self.h, which, None, 0)
+            a = np.zeros((n, 4), np.float32)
+            self.L.oracle_fmap_get_surround(self.h, which, _fp(a), n)
+            out.append(a)
+        return tuple(out)
+
+    def get_full_map(self):
+        n = self.L.oracle_fmap_get_full_map(self.h, None, 0)
+        a = np.zeros((n, 4), np.float32)
+        self.L.oracle_fmap_get_full_map(self.h, _fp(a), n)
+        return a
+
+    def info(self):
+        origin = np.zeros(3, np.int32)
+        self.L.oracle_fmap_origin(self.h, _ip(origin))
+        n = self.L.oracle_fmap_valid_cubes(self.h, None, 0)
+        valid = np.zeros(n, np.int32)
+        self.L.oracle_fmap_valid_cubes(self.h, _ip(valid), n)
+        return dict(origin=origin, valid=valid)
 
 
 class OracleTree:

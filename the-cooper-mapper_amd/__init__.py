@@ -15,6 +15,7 @@ from .capi import (LslamError, LslamOpts, LslamStats, LslamMapInfo, Status, lib_
                    build_library)
 from .scan_match import Context, ScanMatch
 from .pose_graph import PoseGraph
+from .feature_map import FeatureMap, voxel_grid
 
-__all__ = ["Context", "ScanMatch", "PoseGraph", "LslamError", "LslamOpts", "LslamStats", "LslamMapInfo",
+__all__ = ["Context", "ScanMatch", "PoseGraph", "FeatureMap", "voxel_grid", "LslamError", "LslamOpts", "LslamStats", "LslamMapInfo",
            "Status", "lib_path", "load_library", "build_library"]

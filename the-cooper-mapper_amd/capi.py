@@ -139,6 +139,23 @@ SYMBOLS = {
                                   C.c_int32, C.POINTER(C.c_void_p)]),
     "lslam_pg_destroy": (None, [C.c_void_p]),
     "lslam_pg_last_error": (C.c_char_p, []),
+    "lslam_fmap_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "lslam_fmap_destroy": (None, [C.c_void_p]),
+    "lslam_fmap_setup_filter_size": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float]),
+    "lslam_fmap_setup_world_origin": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "lslam_fmap_setup_world_cube_size": (C.c_int, [C.c_void_p, C.c_float]),
+    "lslam_fmap_setup_lidar_valid_distance": (C.c_int, [C.c_void_p, C.c_float]),
+    "lslam_fmap_update": (C.c_int, [C.c_void_p, c_float_p]),
+    "lslam_fmap_add_feature_cloud": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                               C.c_size_t, c_float_p]),
+    "lslam_fmap_surround_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "lslam_fmap_get_surround": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t, c_float_p, C.c_size_t]),
+    "lslam_fmap_surround_to_map": (C.c_int, [C.c_void_p]),
+    "lslam_fmap_get_full_map": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "lslam_fmap_info": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p, c_int32_p, C.c_size_t,
+                                  C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "lslam_voxel_grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float, c_float_p,
+                                   C.c_size_t, C.POINTER(C.c_size_t)]),
     "lslam_pg_set_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, ALLREDUCE_FN, C.c_void_p, C.c_void_p]),
     "lslam_pg_system_doubles": (C.c_size_t, [C.c_void_p]),
     "lslam_pg_num_offdiag": (C.c_int32, [C.c_void_p]),

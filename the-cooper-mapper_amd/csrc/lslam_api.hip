@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <string>
 #include <thread>
 
@@ -22,6 +24,8 @@ using namespace lslam;
 namespace {
 
 thread_local std::string g_err;
+std::mutex g_live_mu;
+std::set<const lslam_ctx *> g_live;  // contexts that exist (dependants check before touching a stream)
 
 void set_err(const char *fmt, ...) {
   char buf[512];
@@ -313,12 +317,20 @@ int lslam_ctx_create(int device, lslam_ctx **out) {
   }
   HIP_TRY(hipEventCreate(&ctx->ev0));
   HIP_TRY(hipEventCreate(&ctx->ev1));
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live.insert(ctx);
+  }
   *out = ctx;
   return LSLAM_OK;
 }
 
 void lslam_ctx_destroy(lslam_ctx *ctx) {
   if (!ctx) return;
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live.erase(ctx);
+  }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   ctx->tc.nodes.release(); ctx->tc.pts.release();
@@ -398,11 +410,19 @@ int lslam_debug_sweep_clocks(lslam_ctx *ctx, const float pose[6], int32_t jtj_mo
   return (int)nw;
 }
 
-int lslam_map_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const void *surf,
-                  size_t n_surf, size_t stride_bytes) {
+}  // extern "C"
+
+namespace {
+// Body of lslam_map_set.  dev_corner/dev_surf non-null: the clouds are already in HBM as
+// float4 {x, y, z, bitcast(index)} (map maintenance hands the surround over without a host hop);
+// corner/surf are then ignored unless the device build has to fall back to the host builder.
+int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void *surf, size_t n_surf,
+                 size_t stride_bytes, const float4 *dev_corner, const float4 *dev_surf) {
   int rc = check_ctx(ctx);
   if (rc) return rc;
-  if (stride_bytes < 12 || (stride_bytes & 3) || (n_corner && !corner) || (n_surf && !surf)) {
+  const bool from_dev = dev_corner != nullptr || dev_surf != nullptr;
+  std::vector<float4> dl_c, dl_s;  // host copies of device clouds, only for the host-builder path
+  if (!from_dev && (stride_bytes < 12 || (stride_bytes & 3) || (n_corner && !corner) || (n_surf && !surf))) {
     set_err("bad cloud arguments (stride %zu)", stride_bytes);
     return LSLAM_ERR_INVALID;
   }
@@ -422,17 +442,21 @@ int lslam_map_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const voi
   bool need_host = host_tree;
   if (!host_tree) {
     // ---- device build: upload {x,y,z,index}, build both trees in HBM --------------------
-    pack_cloud(corner, n_corner, stride_bytes, cc);
-    pack_cloud(surf, n_surf, stride_bytes, cs);
-    for (size_t i = 0; i < cc.size(); ++i) cc[i].w = __builtin_bit_cast(float, (uint32_t)i);
-    for (size_t i = 0; i < cs.size(); ++i) cs[i].w = __builtin_bit_cast(float, (uint32_t)i);
+    if (!from_dev) {
+      pack_cloud(corner, n_corner, stride_bytes, cc);
+      pack_cloud(surf, n_surf, stride_bytes, cs);
+      for (size_t i = 0; i < cc.size(); ++i) cc[i].w = __builtin_bit_cast(float, (uint32_t)i);
+      for (size_t i = 0; i < cs.size(); ++i) cs[i].w = __builtin_bit_cast(float, (uint32_t)i);
+    }
     t1 = now_ms();
     DevTree *trees[2] = {&ctx->tc, &ctx->ts};
     const std::vector<float4> *clouds[2] = {&cc, &cs};
+    const float4 *dev_src[2] = {dev_corner, dev_surf};
+    const size_t counts[2] = {n_corner, n_surf};
     size_t *ncount[2] = {&nodes_c, &nodes_s};
     for (int k = 0; k < 2 && !need_host; ++k) {
       DevTree &dt = *trees[k];
-      const size_t n = clouds[k]->size();
+      const size_t n = counts[k];
       HIP_TRY(dt.pts.reserve(n ? n : 1));
       // Node slots come in groups of 8 (one cache line per 3-level treelet); how full the
       // groups get depends on the shape of the tree (a cloud of vertical lines leaves most
@@ -443,7 +467,9 @@ int lslam_map_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const voi
         const size_t mult[3] = {2, 8, 24};
         const size_t cap = ((mult[attempt] * n / 3 + 64) + 7) & ~(size_t)7;
         HIP_TRY(dt.nodes.reserve(cap));
-        if (n)
+        if (n && from_dev)
+          HIP_TRY(hipMemcpyAsync(dt.pts.p, dev_src[k], n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+        else if (n)
           HIP_TRY(hipMemcpyAsync(dt.pts.p, clouds[k]->data(), n * sizeof(float4), hipMemcpyHostToDevice,
                                  ctx->stream));
         HIP_TRY(build_kdtree_device(dt.pts.p, (int32_t)n, dt.nodes.p, (int32_t)cap, ctx->stream, &dt.view,
@@ -460,6 +486,16 @@ int lslam_map_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const voi
     }
     t2 = now_ms();
     if (!need_host) built_on_device = 1;
+  }
+  if (need_host && from_dev) {  // bring the clouds to the host for the host builder
+    dl_c.resize(n_corner);
+    dl_s.resize(n_surf);
+    if (n_corner) HIP_TRY(hipMemcpyAsync(dl_c.data(), dev_corner, n_corner * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    if (n_surf) HIP_TRY(hipMemcpyAsync(dl_s.data(), dev_surf, n_surf * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    corner = dl_c.data();
+    surf = dl_s.data();
+    stride_bytes = sizeof(float4);
   }
   if (need_host) {
     HostTree hc, hs;
@@ -496,6 +532,27 @@ int lslam_map_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const voi
   ctx->info.built_on_device = built_on_device;
   ctx->have_map = true;
   return LSLAM_OK;
+}
+}  // namespace
+
+namespace lslam {
+int map_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t n_corner, const float4 *d_surf, size_t n_surf) {
+  return map_set_impl(ctx, nullptr, n_corner, nullptr, n_surf, sizeof(float4), d_corner ? d_corner : d_surf,
+                      d_surf ? d_surf : d_corner);
+}
+void set_error(const char *msg) { set_err("%s", msg); }
+int ctx_device(const lslam_ctx *ctx) { return ctx ? ctx->device : -1; }
+bool ctx_alive(const lslam_ctx *ctx) {
+  std::lock_guard<std::mutex> lk(g_live_mu);
+  return g_live.count(ctx) != 0;
+}
+}  // namespace lslam
+
+extern "C" {
+
+int lslam_map_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const void *surf, size_t n_surf,
+                  size_t stride_bytes) {
+  return map_set_impl(ctx, corner, n_corner, surf, n_surf, stride_bytes, nullptr, nullptr);
 }
 
 namespace {

@@ -1,0 +1,888 @@
+// lslam_fmap.hip -- map maintenance in HBM: the cube grid of
+// util/FeatureMap.h, addFeatureCloud with the per-cube pcl::VoxelGrid downsample, the active
+// area, the surround concatenation handed straight to the kd-tree builder, and a stand-alone
+// VoxelGrid (LaserMatcher.cpp:289-301, ScanMatch.cpp:362-398).
+//
+// Layout: per feature type ONE array of float4 {x, y, z, intensity} holding every cube's cloud
+// back to back (cube-major, inside a cube in the reference's order), a parallel int32 array with
+// the cube of each point, and a [cube] -> (begin, end) table.  addFeatureCloud appends the
+// transformed scan and rebuilds the array with ONE stable radix sort on the key
+//     (cube | voxel z | voxel y | voxel x)     voxel bits only for cubes that get filtered,
+// which at once (i) appends each new point to its cube in push order, (ii) groups the points of a
+// filtered cube by voxel in pcl::VoxelGrid's output order (ascending x + y*dx + z*dx*dy, which is
+// the lexicographic (z, y, x) order whatever min_b/div_b are) with the members of a voxel in
+// input order, and (iii) drops points outside the grid.  One thread per voxel then writes the
+// centroid (sum in member order / count, all four fields).
+//
+// Which cubes are filtered: every cube of the active area, on every addFeatureCloud, exactly as
+// FeatureMap.h:288-306 does (re-filtering an already filtered cube is almost always the identity,
+// but a centroid that rounds onto a voxel boundary can move -- so nothing is skipped).  The sort
+// covers all points anyway; the voxel bits of the key cost nothing extra.
+//
+// rocPRIM supplies the radix sort and the scan (plain library primitives); the rest is HIP.
+#include "../../include/lslam_c.h"
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lslam_internal.hpp"
+
+namespace {
+
+#define FM_TRY(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      char _b[400];                                                                      \
+      snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      lslam::set_error(_b);                                                              \
+      return LSLAM_ERR_HIP;                                                              \
+    }                                                                                    \
+  } while (0)
+
+template <typename T>
+struct Buf {
+  T *p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = n + n / 4 + 256;
+    hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  // grow, keeping the first `keep` elements
+  hipError_t grow(size_t n, size_t keep, hipStream_t s) {
+    if (n <= cap) return hipSuccess;
+    const size_t want = n + n / 4 + 256;
+    T *q = nullptr;
+    hipError_t e = hipMalloc((void **)&q, want * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (keep && p) {
+      e = hipMemcpyAsync(q, p, keep * sizeof(T), hipMemcpyDeviceToDevice, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    if (p) (void)hipFree(p);
+    p = q;
+    cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+constexpr uint64_t KEY_DROP = ~0ull;
+
+// How a point becomes a sort key.
+struct KeyParams {
+  int32_t W, H, D;         // cube grid (1,1,1 for the stand-alone filter)
+  int32_t origin[3];
+  float cube_size;
+  float inv_leaf;          // 1 / leaf (float, as pcl::VoxelGrid computes it)
+  int32_t axis_bits;       // bits per voxel axis
+  int32_t single;          // 1: stand-alone filter, every point is in cube 0, base = base0
+  int32_t base0[3];
+};
+
+__device__ __forceinline__ int32_t cube_of_point(const KeyParams &k, float x, float y, float z, int32_t g[3]) {
+  // FeatureMap.h:475-487: round(p / size) + origin, float arithmetic, truncated to int
+  g[0] = (int32_t)(roundf(x / k.cube_size) + (float)k.origin[0]);
+  g[1] = (int32_t)(roundf(y / k.cube_size) + (float)k.origin[1]);
+  g[2] = (int32_t)(roundf(z / k.cube_size) + (float)k.origin[2]);
+  if (g[0] < 0 || g[0] >= k.W || g[1] < 0 || g[1] >= k.H || g[2] < 0 || g[2] >= k.D) return -1;
+  return g[0] + g[1] * k.W + g[2] * k.W * k.H;
+}
+
+// new points: p' = R p + t (pcl::transformPointCloud), cube of p'
+__global__ void fm_transform_kernel(const float4 *in, int n, const float *T, KeyParams k, float4 *out,
+                                    int32_t *cube_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = in[i];
+  float4 q;
+  q.x = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[0], p.x), __fmul_rn(T[1], p.y)), __fmul_rn(T[2], p.z)), T[3]);
+  q.y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[4], p.x), __fmul_rn(T[5], p.y)), __fmul_rn(T[6], p.z)), T[7]);
+  q.z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[8], p.x), __fmul_rn(T[9], p.y)), __fmul_rn(T[10], p.z)), T[11]);
+  q.w = p.w;
+  int32_t g[3];
+  const int32_t c = cube_of_point(k, q.x, q.y, q.z, g);
+  out[i] = q;
+  cube_out[i] = c;
+}
+
+// flags[c] != 0: cube c is filtered by this rebuild (active area; every cube for getFullMap);
+// flags == nullptr: no cube is
+__device__ __forceinline__ bool cube_filtered(const uint8_t *flags, int32_t c) {
+  return flags != nullptr && flags[c] != 0;
+}
+
+__device__ __forceinline__ int32_t ordered_int(float f) {  // monotone float -> int map for atomicMin/Max
+  const int32_t i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float ordered_float(int32_t i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
+// getMinMax3D per filtered cube (pcl::VoxelGrid::applyFilter works on each cube's own cloud)
+__global__ void fm_minmax_kernel(const float4 *pts, const int32_t *cube, int n, const uint8_t *flags, int32_t *cmin,
+                                 int32_t *cmax) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t c = cube[i];
+  if (c < 0 || !flags[c]) return;
+  const float4 p = pts[i];
+  const float v[3] = {p.x, p.y, p.z};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int32_t o = ordered_int(v[d]);
+    if (o < cmin[3 * c + d]) atomicMin(&cmin[3 * c + d], o);
+    if (o > cmax[3 * c + d]) atomicMax(&cmax[3 * c + d], o);
+  }
+}
+
+// per cube: min_b, the "leaf too small" guard of applyFilter, the widest voxel extent
+__global__ void fm_extent_kernel(const uint8_t *flags, const int32_t *cmin, const int32_t *cmax, int ncube,
+                                 float inv_leaf, uint8_t *eff, int32_t *base, int32_t *max_div) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncube) return;
+  uint8_t e = 0;
+  if (flags[c] && cmin[3 * c] <= cmax[3 * c]) {  // filtered and not empty
+    long long vol = 1;
+    int32_t div = 1;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float mn = ordered_float(cmin[3 * c + d]), mx = ordered_float(cmax[3 * c + d]);
+      vol *= (long long)(__fmul_rn(__fsub_rn(mx, mn), inv_leaf)) + 1;
+      const int32_t b0 = (int32_t)floorf(__fmul_rn(mn, inv_leaf)), b1 = (int32_t)floorf(__fmul_rn(mx, inv_leaf));
+      base[3 * c + d] = b0;
+      div = max(div, b1 - b0 + 1);
+    }
+    if (vol <= 2147483647ll) {  // else: PCL warns and hands the cloud back unfiltered
+      e = 1;
+      atomicMax(max_div, div);
+    }
+  }
+  eff[c] = e;
+}
+
+__global__ void fm_key_kernel(const float4 *pts, const int32_t *cube, int n, KeyParams k, const uint8_t *flags,
+                              const int32_t *cube_base, uint64_t *keys, uint32_t *idx, int32_t *err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  idx[i] = (uint32_t)i;
+  const int32_t c = k.single ? 0 : cube[i];
+  if (c < 0) {
+    keys[i] = KEY_DROP;
+    return;
+  }
+  uint64_t key = (uint64_t)c;
+  const int ab = k.axis_bits;
+  uint64_t vox = 0;
+  if (k.single || cube_filtered(flags, c)) {
+    const float4 p = pts[i];
+    int32_t base[3];
+    if (k.single) {
+      base[0] = k.base0[0]; base[1] = k.base0[1]; base[2] = k.base0[2];
+    } else {
+      base[0] = cube_base[3 * c]; base[1] = cube_base[3 * c + 1]; base[2] = cube_base[3 * c + 2];
+    }
+    const float v[3] = {p.x, p.y, p.z};
+    int32_t r[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      r[d] = (int32_t)floorf(__fmul_rn(v[d], k.inv_leaf)) - base[d];
+      if (r[d] < 0 || r[d] >= (1 << ab)) {
+        atomicExch(err, 1);
+        r[d] = r[d] < 0 ? 0 : (1 << ab) - 1;
+      }
+    }
+    vox = ((uint64_t)r[2] << (2 * ab)) | ((uint64_t)r[1] << ab) | (uint64_t)r[0];
+  }
+  keys[i] = (key << (3 * ab)) | vox;
+}
+
+__global__ void fm_head_kernel(const uint64_t *keys, int n, int axis_bits, int single, const uint8_t *flags,
+                               uint32_t *head) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = keys[i];
+  uint32_t h = 0;
+  if (k != KEY_DROP) {
+    const int32_t c = (int32_t)(k >> (3 * axis_bits));
+    const bool filt = single || cube_filtered(flags, c);
+    h = (i == 0 || !filt || keys[i - 1] != k) ? 1u : 0u;
+  }
+  head[i] = h;
+}
+
+// one thread per voxel (head): centroid over its members in sorted (= input) order
+__global__ void fm_centroid_kernel(const float4 *pts, const uint64_t *keys, const uint32_t *idx, const uint32_t *head,
+                                   const uint32_t *pos, int n, int axis_bits, float4 *out, int32_t *cube_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !head[i]) return;
+  const uint64_t k = keys[i];
+  float4 p = pts[idx[i]];
+  float sx = p.x, sy = p.y, sz = p.z, sw = p.w;
+  int j = i + 1;
+  while (j < n && !head[j] && keys[j] == k) {
+    p = pts[idx[j]];
+    sx = __fadd_rn(sx, p.x);
+    sy = __fadd_rn(sy, p.y);
+    sz = __fadd_rn(sz, p.z);
+    sw = __fadd_rn(sw, p.w);
+    ++j;
+  }
+  const float cnt = (float)(j - i);
+  // PCL starts from a zero vector: 0 + x = x, so the sums above equal its sums
+  out[pos[i]] = make_float4(__fdiv_rn(sx, cnt), __fdiv_rn(sy, cnt), __fdiv_rn(sz, cnt), __fdiv_rn(sw, cnt));
+  cube_out[pos[i]] = (int32_t)(k >> (3 * axis_bits));
+}
+
+__global__ void fm_segment_kernel(const int32_t *cube, int n, int32_t *begin, int32_t *end) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t c = cube[i];
+  if (i == 0 || cube[i - 1] != c) begin[c] = i;
+  if (i == n - 1 || cube[i + 1] != c) end[c] = i + 1;
+}
+
+__global__ void fm_relabel_kernel(int32_t *cube, int n, const int32_t *new_of_old) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && cube[i] >= 0) cube[i] = new_of_old[cube[i]];
+}
+
+// surround: concatenation of the active cubes' segments; seg = {src begin, dst begin} per cube
+__global__ void fm_gather_kernel(const float4 *pts, const int32_t *src_begin, const int32_t *dst_begin, int n_seg,
+                                 int n_out, int index_in_w, float4 *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  int lo = 0, hi = n_seg - 1;  // last segment with dst_begin <= i
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (dst_begin[mid] <= i) lo = mid; else hi = mid - 1;
+  }
+  float4 p = pts[src_begin[lo] + (i - dst_begin[lo])];
+  if (index_in_w) p.w = __builtin_bit_cast(float, (uint32_t)i);
+  out[i] = p;
+}
+
+int bits_for(double cells) {
+  int b = 1;
+  while ((double)(1 << b) < cells) ++b;
+  return b;
+}
+
+struct Scratch {
+  Buf<uint64_t> k0, k1;
+  Buf<uint32_t> i0, i1, head, pos;
+  Buf<char> tmp;
+  Buf<int32_t> err;               // [0] key-range error, [1] widest voxel extent of a filtered cube
+  Buf<int32_t> cmin, cmax, base;  // [ncube][3]
+  Buf<uint8_t> eff;               // [ncube] cubes this rebuild really filters
+  void release() {
+    k0.release(); k1.release(); i0.release(); i1.release(); head.release(); pos.release(); tmp.release();
+    err.release(); cmin.release(); cmax.release(); base.release(); eff.release();
+  }
+};
+
+}  // namespace
+
+struct lslam_fmap {
+  lslam_ctx *ctx = nullptr;
+  hipStream_t stream = nullptr;
+  int W = 0, H = 0, D = 0, ncube = 0;
+  int origin[3] = {0, 0, 0};
+  int cur[3] = {0, 0, 0};
+  float cube_size = 50.0f, valid_dist = 150.0f;
+  float leaf[3] = {0.2f, 0.2f, 0.6f};  // corner, surf, map (FeatureMap.h:64-66)
+  std::vector<int32_t> valid;          // _cubeValidInd
+  // per type
+  Buf<float4> pts[2], pts_alt[2];
+  Buf<int32_t> cube[2], cube_alt[2];
+  size_t n[2] = {0, 0};
+  Buf<uint8_t> active;                 // per cube: 1 = in the active area (_cubeValidInd)
+  Buf<int32_t> seg_begin[2], seg_end[2];
+  std::vector<int32_t> h_begin[2], h_end[2];
+  bool seg_current[2] = {false, false};
+  Buf<float4> in_raw, in_tf;
+  Buf<int32_t> in_cube;
+  Buf<float> d_T;
+  Buf<int32_t> d_remap;
+  Buf<int32_t> g_src, g_dst;
+  Buf<float4> sur[2];
+  Scratch sc;
+};
+
+namespace {
+
+KeyParams key_params(const lslam_fmap *fm, float leaf) {
+  KeyParams k{};
+  k.W = fm->W; k.H = fm->H; k.D = fm->D;
+  for (int d = 0; d < 3; ++d) k.origin[d] = fm->origin[d];
+  k.cube_size = fm->cube_size;
+  k.inv_leaf = 1.0f / leaf;
+  k.axis_bits = 1;  // set by run_pipeline from the cubes' real extents
+  k.single = 0;
+  return k;
+}
+
+int cube_bits(int ncube) {
+  int b = 1;
+  while ((1ll << b) < (long long)ncube) ++b;
+  return b;
+}
+
+// The rebuild: [old points | extra points] -> sorted, filtered, compacted arrays.
+// in_pts/in_cube hold n_total points (already concatenated).  Writes out_pts/out_cube, returns
+// the number of output points.  flags selects the cubes to filter (nullptr: none); kp.single: the
+// stand-alone filter (one pseudo cube, base and bits prepared by the caller).
+int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t *in_cube, size_t n_total,
+                 KeyParams kp, int ncube, const uint8_t *flags, float4 *out_pts, int32_t *out_cube, size_t *n_out) {
+  *n_out = 0;
+  if (n_total == 0) return LSLAM_OK;
+  const int n = (int)n_total;
+  const int n_cube_bits = kp.single ? 1 : cube_bits(ncube + 1);
+  const dim3 blk(256), grd((n + 255) / 256);
+  FM_TRY(sc.err.reserve(2));
+  FM_TRY(hipMemsetAsync(sc.err.p, 0, 2 * sizeof(int32_t), s));
+  const uint8_t *eff = nullptr;
+  if (!kp.single && flags) {
+    FM_TRY(sc.cmin.reserve(3 * (size_t)ncube));
+    FM_TRY(sc.cmax.reserve(3 * (size_t)ncube));
+    FM_TRY(sc.base.reserve(3 * (size_t)ncube));
+    FM_TRY(sc.eff.reserve(ncube));
+    FM_TRY(hipMemsetAsync(sc.cmin.p, 0x7f, 3 * sizeof(int32_t) * (size_t)ncube, s));  // +large
+    FM_TRY(hipMemsetAsync(sc.cmax.p, 0x80, 3 * sizeof(int32_t) * (size_t)ncube, s));  // -large
+    hipLaunchKernelGGL(fm_minmax_kernel, grd, blk, 0, s, in_pts, in_cube, n, flags, sc.cmin.p, sc.cmax.p);
+    hipLaunchKernelGGL(fm_extent_kernel, dim3((ncube + 255) / 256), blk, 0, s, flags, sc.cmin.p, sc.cmax.p, ncube,
+                       kp.inv_leaf, sc.eff.p, sc.base.p, sc.err.p + 1);
+    int32_t max_div = 0;
+    FM_TRY(hipMemcpyAsync(&max_div, sc.err.p + 1, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    FM_TRY(hipStreamSynchronize(s));
+    kp.axis_bits = bits_for((double)max_div + 1.0);
+    eff = sc.eff.p;
+  } else if (!kp.single) {
+    kp.axis_bits = 1;
+  }
+  if (3 * kp.axis_bits + n_cube_bits > 63) {
+    lslam::set_error("voxel grid too fine for the 63-bit sort key (leaf too small for this extent)");
+    return LSLAM_ERR_INVALID;
+  }
+  FM_TRY(sc.k0.reserve(n_total));
+  FM_TRY(sc.k1.reserve(n_total));
+  FM_TRY(sc.i0.reserve(n_total));
+  FM_TRY(sc.i1.reserve(n_total));
+  FM_TRY(sc.head.reserve(n_total + 1));
+  FM_TRY(sc.pos.reserve(n_total + 1));
+  hipLaunchKernelGGL(fm_key_kernel, grd, blk, 0, s, in_pts, in_cube, n, kp, eff, sc.base.p, sc.k0.p, sc.i0.p, sc.err.p);
+  const unsigned end_bit = (unsigned)(3 * kp.axis_bits + n_cube_bits);
+  size_t tmp_bytes = 0;
+  // KEY_DROP has every bit set: within [0, end_bit) it is the largest key, so dropped points sort last
+  FM_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, sc.k0.p, sc.k1.p, sc.i0.p, sc.i1.p, n_total, 0u, end_bit, s));
+  size_t tmp2 = 0;
+  FM_TRY(rocprim::exclusive_scan(nullptr, tmp2, sc.head.p, sc.pos.p, 0u, n_total + 1, rocprim::plus<uint32_t>(), s));
+  FM_TRY(sc.tmp.reserve(std::max(tmp_bytes, tmp2)));
+  FM_TRY(rocprim::radix_sort_pairs((void *)sc.tmp.p, tmp_bytes, sc.k0.p, sc.k1.p, sc.i0.p, sc.i1.p, n_total, 0u,
+                                   end_bit, s));
+  hipLaunchKernelGGL(fm_head_kernel, grd, blk, 0, s, sc.k1.p, n, kp.axis_bits, kp.single, eff, sc.head.p);
+  FM_TRY(hipMemsetAsync(sc.head.p + n_total, 0, sizeof(uint32_t), s));
+  FM_TRY(rocprim::exclusive_scan((void *)sc.tmp.p, tmp2, sc.head.p, sc.pos.p, 0u, n_total + 1,
+                                 rocprim::plus<uint32_t>(), s));
+  hipLaunchKernelGGL(fm_centroid_kernel, grd, blk, 0, s, in_pts, sc.k1.p, sc.i1.p, sc.head.p, sc.pos.p, n,
+                     kp.axis_bits, out_pts, out_cube);
+  uint32_t total = 0;
+  int32_t err = 0;
+  FM_TRY(hipMemcpyAsync(&total, sc.pos.p + n_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  FM_TRY(hipMemcpyAsync(&err, sc.err.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  FM_TRY(hipStreamSynchronize(s));
+  if (err) {
+    lslam::set_error("voxel index outside its key range (non-finite point?)");
+    return LSLAM_ERR_INVALID;
+  }
+  *n_out = total;
+  return LSLAM_OK;
+}
+
+// KEY_DROP & the cube field: a dropped point's key must compare above every real key inside the
+// sorted bit range; real cube ids are < ncube <= 2^bits - 1 only if ncube is not a power of two...
+// so one more bit is reserved (cube_bits(ncube + 1)).
+
+int refresh_segments(lslam_fmap *fm, int t) {
+  if (fm->seg_current[t]) return LSLAM_OK;
+  hipStream_t s = fm->stream;
+  FM_TRY(fm->seg_begin[t].reserve(fm->ncube));
+  FM_TRY(fm->seg_end[t].reserve(fm->ncube));
+  FM_TRY(hipMemsetAsync(fm->seg_begin[t].p, 0, sizeof(int32_t) * fm->ncube, s));
+  FM_TRY(hipMemsetAsync(fm->seg_end[t].p, 0, sizeof(int32_t) * fm->ncube, s));
+  if (fm->n[t])
+    hipLaunchKernelGGL(fm_segment_kernel, dim3(((int)fm->n[t] + 255) / 256), dim3(256), 0, s, fm->cube[t].p,
+                       (int)fm->n[t], fm->seg_begin[t].p, fm->seg_end[t].p);
+  fm->h_begin[t].resize(fm->ncube);
+  fm->h_end[t].resize(fm->ncube);
+  FM_TRY(hipMemcpyAsync(fm->h_begin[t].data(), fm->seg_begin[t].p, sizeof(int32_t) * fm->ncube, hipMemcpyDeviceToHost, s));
+  FM_TRY(hipMemcpyAsync(fm->h_end[t].data(), fm->seg_end[t].p, sizeof(int32_t) * fm->ncube, hipMemcpyDeviceToHost, s));
+  FM_TRY(hipStreamSynchronize(s));
+  fm->seg_current[t] = true;
+  return LSLAM_OK;
+}
+
+// rebuild type t from its current points plus n_new transformed points (fm->in_tf / in_cube)
+int rebuild(lslam_fmap *fm, int t, size_t n_new, bool allow_filter) {
+  hipStream_t s = fm->stream;
+  const size_t n_old = fm->n[t], n_total = n_old + n_new;
+  if (n_total == 0) return LSLAM_OK;
+  FM_TRY(fm->pts[t].grow(n_total, n_old, s));
+  FM_TRY(fm->cube[t].grow(n_total, n_old, s));
+  if (n_new) {
+    FM_TRY(hipMemcpyAsync(fm->pts[t].p + n_old, fm->in_tf.p, n_new * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    FM_TRY(hipMemcpyAsync(fm->cube[t].p + n_old, fm->in_cube.p, n_new * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  }
+  FM_TRY(fm->pts_alt[t].reserve(n_total));
+  FM_TRY(fm->cube_alt[t].reserve(n_total));
+  KeyParams kp = key_params(fm, fm->leaf[t]);
+  size_t n_out = 0;
+  int rc = run_pipeline(s, fm->sc, fm->pts[t].p, fm->cube[t].p, n_total, kp, fm->ncube,
+                        allow_filter ? fm->active.p : nullptr, fm->pts_alt[t].p, fm->cube_alt[t].p, &n_out);
+  if (rc) return rc;
+  std::swap(fm->pts[t], fm->pts_alt[t]);
+  std::swap(fm->cube[t], fm->cube_alt[t]);
+  fm->n[t] = n_out;
+  fm->seg_current[t] = false;
+  return LSLAM_OK;
+}
+
+bool idx_valid(const lslam_fmap *fm, int i, int j, int k) {
+  return 0 <= i && i < fm->W && 0 <= j && j < fm->H && 0 <= k && k < fm->D;
+}
+int to_index(const lslam_fmap *fm, int i, int j, int k) { return i + j * fm->W + k * fm->W * fm->H; }
+
+// FeatureMap.h:307-352
+void compute_active_area(lslam_fmap *fm, const float pos[3]) {
+  fm->valid.clear();
+  const int win = (int)std::ceil(fm->valid_dist / fm->cube_size);
+  for (int i = fm->cur[0] - win; i <= fm->cur[0] + win; ++i)
+    for (int j = fm->cur[1] - win; j <= fm->cur[1] + win; ++j)
+      for (int k = fm->cur[2] - win; k <= fm->cur[2] + win; ++k) {
+        if (!idx_valid(fm, i, j, k)) continue;
+        const float cx = fm->cube_size * (float)(i - fm->origin[0]);
+        const float cy = fm->cube_size * (float)(j - fm->origin[1]);
+        const float cz = fm->cube_size * (float)(k - fm->origin[2]);
+        bool in_fov = false;
+        for (int ii = -1; ii <= 1 && !in_fov; ii += 2)
+          for (int jj = -1; jj <= 1 && !in_fov; jj += 2)
+            for (int kk = -1; kk <= 1 && !in_fov; kk += 2) {
+              const float x = (float)((double)cx + (double)fm->cube_size / 2.0 * ii);
+              const float y = (float)((double)cy + (double)fm->cube_size / 2.0 * jj);
+              const float z = (float)((double)cz + (double)fm->cube_size / 2.0 * kk);
+              const float dx = pos[0] - x, dy = pos[1] - y, dz = pos[2] - z;
+              const float sq = dx * dx + dy * dy + dz * dz;
+              if (std::sqrt((double)sq) < (double)fm->valid_dist) in_fov = true;
+            }
+        if (in_fov) fm->valid.push_back(to_index(fm, i, j, k));
+      }
+}
+
+int upload_active(lslam_fmap *fm) {
+  std::vector<uint8_t> h(fm->ncube, 0);
+  for (int32_t c : fm->valid) h[c] = 1;
+  FM_TRY(hipMemcpyAsync(fm->active.p, h.data(), fm->ncube, hipMemcpyHostToDevice, fm->stream));
+  FM_TRY(hipStreamSynchronize(fm->stream));  // h is a local
+  return LSLAM_OK;
+}
+
+int pack_input(lslam_fmap *fm, const void *src, size_t n, size_t stride_bytes) {
+  // {x,y,z} at offset 0; intensity at offset 12 for 16-byte points, 16 for pcl::PointXYZI (32 bytes)
+  std::vector<float4> h(n);
+  const char *p = static_cast<const char *>(src);
+  const size_t ioff = stride_bytes == 16 ? 12 : 16;
+  for (size_t i = 0; i < n; ++i) {
+    float v[3], w = 0.0f;
+    std::memcpy(v, p + i * stride_bytes, 12);
+    if (stride_bytes >= ioff + 4) std::memcpy(&w, p + i * stride_bytes + ioff, 4);
+    h[i] = make_float4(v[0], v[1], v[2], w);
+  }
+  FM_TRY(fm->in_raw.reserve(n));
+  FM_TRY(hipMemcpyAsync(fm->in_raw.p, h.data(), n * sizeof(float4), hipMemcpyHostToDevice, fm->stream));
+  FM_TRY(hipStreamSynchronize(fm->stream));  // h is a local
+  return LSLAM_OK;
+}
+
+int check_fm(lslam_fmap *fm) {
+  if (!fm || !lslam::ctx_alive(fm->ctx)) {
+    lslam::set_error("null feature map, or its ctx was destroyed");
+    return LSLAM_ERR_INVALID;
+  }
+  FM_TRY(hipSetDevice(lslam::ctx_device(fm->ctx)));
+  return LSLAM_OK;
+}
+
+// surround arrays of type t into fm->sur[t]; returns count
+int gather_surround(lslam_fmap *fm, int t, int index_in_w, size_t *n_out) {
+  int rc = refresh_segments(fm, t);
+  if (rc) return rc;
+  std::vector<int32_t> src, dst;
+  size_t total = 0;
+  for (int32_t c : fm->valid) {
+    const int32_t b = fm->h_begin[t][c], e = fm->h_end[t][c];
+    if (e > b) {
+      src.push_back(b);
+      dst.push_back((int32_t)total);
+      total += (size_t)(e - b);
+    }
+  }
+  *n_out = total;
+  if (!total) return LSLAM_OK;
+  hipStream_t s = fm->stream;
+  FM_TRY(fm->g_src.reserve(src.size()));
+  FM_TRY(fm->g_dst.reserve(dst.size()));
+  FM_TRY(fm->sur[t].reserve(total));
+  FM_TRY(hipMemcpyAsync(fm->g_src.p, src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  FM_TRY(hipMemcpyAsync(fm->g_dst.p, dst.data(), dst.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(fm_gather_kernel, dim3(((int)total + 255) / 256), dim3(256), 0, s, fm->pts[t].p, fm->g_src.p,
+                     fm->g_dst.p, (int)src.size(), (int)total, index_in_w, fm->sur[t].p);
+  FM_TRY(hipStreamSynchronize(s));  // src/dst are locals
+  return LSLAM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lslam_fmap_create(lslam_ctx *ctx, int32_t w, int32_t h, int32_t d, lslam_fmap **out) {
+  if (!ctx || !out || w <= 0 || h <= 0 || d <= 0 || (long long)w * h * d > (1ll << 24)) {
+    lslam::set_error("bad feature-map arguments");
+    return LSLAM_ERR_INVALID;
+  }
+  *out = nullptr;
+  FM_TRY(hipSetDevice(lslam::ctx_device(ctx)));
+  lslam_fmap *fm = new lslam_fmap();
+  fm->ctx = ctx;
+  fm->stream = (hipStream_t)lslam_stream(ctx);
+  fm->W = w; fm->H = h; fm->D = d;
+  fm->ncube = w * h * d;
+  // FeatureMap.h:60-62: origin = round(--size / 2.0)
+  fm->origin[0] = (int)std::round((w - 1) / 2.0);
+  fm->origin[1] = (int)std::round((h - 1) / 2.0);
+  fm->origin[2] = (int)std::round((d - 1) / 2.0);
+  FM_TRY(fm->active.reserve(fm->ncube));
+  FM_TRY(hipMemsetAsync(fm->active.p, 0, fm->ncube, fm->stream));
+  FM_TRY(fm->d_T.reserve(16));
+  FM_TRY(hipStreamSynchronize(fm->stream));
+  *out = fm;
+  return LSLAM_OK;
+}
+
+void lslam_fmap_destroy(lslam_fmap *fm) {
+  if (!fm) return;
+  if (lslam::ctx_alive(fm->ctx)) {  // a feature map may outlive its ctx; its stream is then gone
+    (void)hipSetDevice(lslam::ctx_device(fm->ctx));
+    (void)hipStreamSynchronize(fm->stream);
+  }
+  for (int t = 0; t < 2; ++t) {
+    fm->pts[t].release(); fm->pts_alt[t].release(); fm->cube[t].release(); fm->cube_alt[t].release();
+    fm->seg_begin[t].release(); fm->seg_end[t].release(); fm->sur[t].release();
+  }
+  fm->active.release(); fm->in_raw.release(); fm->in_tf.release(); fm->in_cube.release(); fm->d_T.release();
+  fm->d_remap.release(); fm->g_src.release(); fm->g_dst.release();
+  fm->sc.release();
+  delete fm;
+}
+
+int lslam_fmap_setup_filter_size(lslam_fmap *fm, float corner, float surf, float map) {
+  if (!fm || !(corner > 0.f) || !(surf > 0.f) || !(map > 0.f)) return LSLAM_ERR_INVALID;
+  fm->leaf[0] = corner; fm->leaf[1] = surf; fm->leaf[2] = map;
+  return LSLAM_OK;
+}
+int lslam_fmap_setup_world_cube_size(lslam_fmap *fm, float size) {
+  if (!fm || !(size > 0.f)) return LSLAM_ERR_INVALID;
+  fm->cube_size = size;
+  return LSLAM_OK;
+}
+int lslam_fmap_setup_lidar_valid_distance(lslam_fmap *fm, float dist) {
+  if (!fm) return LSLAM_ERR_INVALID;
+  fm->valid_dist = dist;
+  return LSLAM_OK;
+}
+int lslam_fmap_setup_world_origin(lslam_fmap *fm, int32_t ox, int32_t oy, int32_t oz) {
+  if (!fm) return LSLAM_ERR_INVALID;
+  fm->origin[0] = ox; fm->origin[1] = oy; fm->origin[2] = oz;
+  return LSLAM_OK;
+}
+
+int lslam_fmap_update(lslam_fmap *fm, const float pos[3]) {
+  int rc = check_fm(fm);
+  if (rc) return rc;
+  if (!pos) return LSLAM_ERR_INVALID;
+  hipStream_t s = fm->stream;
+  int g[3];
+  const int lim[3] = {fm->W, fm->H, fm->D};
+  for (int d = 0; d < 3; ++d) g[d] = (int)(std::round(pos[d] / fm->cube_size) + (float)fm->origin[d]);
+  const int PAD = 3;  // FeatureMap.h:236
+  int ng[3], dl[3];
+  for (int d = 0; d < 3; ++d) {
+    ng[d] = std::min(std::max(g[d], PAD), lim[d] - PAD - 1);
+    dl[d] = ng[d] - g[d];
+  }
+  if (dl[0] || dl[1] || dl[2]) {
+    // FeatureMap.h:353-377 verbatim on cube handles: the loop swaps cube POINTERS while it walks
+    // the grid, so what ends up where is whatever this sequential swap chain produces
+    std::vector<int32_t> content(fm->ncube);  // content[slot] = original slot whose cloud sits here, -1 = cleared
+    for (int c = 0; c < fm->ncube; ++c) content[c] = c;
+    for (int i = 0; i < fm->W; ++i)
+      for (int j = 0; j < fm->H; ++j)
+        for (int k = 0; k < fm->D; ++k) {
+          const int oi = i - dl[0], oj = j - dl[1], ok = k - dl[2];
+          const int a = to_index(fm, i, j, k);
+          if (idx_valid(fm, oi, oj, ok)) std::swap(content[a], content[to_index(fm, oi, oj, ok)]);
+          else content[a] = -1;
+        }
+    std::vector<int32_t> new_of_old(fm->ncube, -1);
+    for (int c = 0; c < fm->ncube; ++c)
+      if (content[c] >= 0) new_of_old[content[c]] = c;
+    FM_TRY(fm->d_remap.reserve(fm->ncube));
+    FM_TRY(hipMemcpyAsync(fm->d_remap.p, new_of_old.data(), sizeof(int32_t) * fm->ncube, hipMemcpyHostToDevice, s));
+    for (int t = 0; t < 2; ++t) {
+      if (fm->n[t])
+        hipLaunchKernelGGL(fm_relabel_kernel, dim3(((int)fm->n[t] + 255) / 256), dim3(256), 0, s, fm->cube[t].p,
+                           (int)fm->n[t], fm->d_remap.p);
+      rc = rebuild(fm, t, 0, false);  // re-sort by the new cube ids, drop cleared cubes, no filtering
+      if (rc) return rc;
+    }
+  }
+  for (int d = 0; d < 3; ++d) {
+    fm->origin[d] += dl[d];
+    fm->cur[d] = ng[d];
+  }
+  compute_active_area(fm, pos);
+  return upload_active(fm);
+}
+
+int lslam_fmap_add_feature_cloud(lslam_fmap *fm, const void *corner, size_t n_corner, const void *surf,
+                                 size_t n_surf, size_t stride_bytes, const float T[16]) {
+  int rc = check_fm(fm);
+  if (rc) return rc;
+  if (!T || stride_bytes < 12 || (stride_bytes & 3) || (n_corner && !corner) || (n_surf && !surf)) {
+    lslam::set_error("bad cloud arguments");
+    return LSLAM_ERR_INVALID;
+  }
+  hipStream_t s = fm->stream;
+  FM_TRY(hipMemcpyAsync(fm->d_T.p, T, 16 * sizeof(float), hipMemcpyHostToDevice, s));
+  const void *src[2] = {corner, surf};
+  const size_t cnt[2] = {n_corner, n_surf};
+  for (int t = 0; t < 2; ++t) {
+    const size_t n = cnt[t];
+    if (n) {
+      rc = pack_input(fm, src[t], n, stride_bytes);
+      if (rc) return rc;
+      FM_TRY(fm->in_tf.reserve(n));
+      FM_TRY(fm->in_cube.reserve(n));
+      KeyParams kp = key_params(fm, fm->leaf[t]);
+      hipLaunchKernelGGL(fm_transform_kernel, dim3(((int)n + 255) / 256), dim3(256), 0, s, fm->in_raw.p, (int)n,
+                         fm->d_T.p, kp, fm->in_tf.p, fm->in_cube.p);
+    }
+    rc = rebuild(fm, t, n, true);
+    if (rc) return rc;
+  }
+  FM_TRY(hipStreamSynchronize(s));
+  return LSLAM_OK;
+}
+
+int lslam_fmap_surround_counts(lslam_fmap *fm, size_t *n_corner, size_t *n_surf) {
+  int rc = check_fm(fm);
+  if (rc) return rc;
+  size_t *out[2] = {n_corner, n_surf};
+  for (int t = 0; t < 2; ++t) {
+    rc = refresh_segments(fm, t);
+    if (rc) return rc;
+    size_t total = 0;
+    for (int32_t c : fm->valid) total += (size_t)(fm->h_end[t][c] - fm->h_begin[t][c]);
+    if (out[t]) *out[t] = total;
+  }
+  return LSLAM_OK;
+}
+
+int lslam_fmap_get_surround(lslam_fmap *fm, float *corner_xyzi, size_t cap_corner, float *surf_xyzi,
+                            size_t cap_surf) {
+  int rc = check_fm(fm);
+  if (rc) return rc;
+  float *out[2] = {corner_xyzi, surf_xyzi};
+  const size_t cap[2] = {cap_corner, cap_surf};
+  for (int t = 0; t < 2; ++t) {
+    if (!out[t]) continue;
+    size_t n = 0;
+    rc = gather_surround(fm, t, 0, &n);
+    if (rc) return rc;
+    if (n > cap[t]) {
+      lslam::set_error("surround buffer too small");
+      return LSLAM_ERR_INVALID;
+    }
+    if (n) FM_TRY(hipMemcpyAsync(out[t], fm->sur[t].p, n * sizeof(float4), hipMemcpyDeviceToHost, fm->stream));
+  }
+  FM_TRY(hipStreamSynchronize(fm->stream));
+  return LSLAM_OK;
+}
+
+int lslam_fmap_surround_to_map(lslam_fmap *fm) {
+  int rc = check_fm(fm);
+  if (rc) return rc;
+  size_t n[2] = {0, 0};
+  for (int t = 0; t < 2; ++t) {
+    rc = gather_surround(fm, t, 1, &n[t]);
+    if (rc) return rc;
+  }
+  if (n[0] == 0 && n[1] == 0) return lslam_map_set(fm->ctx, nullptr, 0, nullptr, 0, 16);
+  FM_TRY(fm->sur[0].reserve(1));
+  FM_TRY(fm->sur[1].reserve(1));
+  return lslam::map_set_device(fm->ctx, fm->sur[0].p, n[0], fm->sur[1].p, n[1]);
+}
+
+int lslam_fmap_info(lslam_fmap *fm, int32_t origin[3], int32_t *n_valid, int32_t *valid_out, size_t cap,
+                    size_t *n_corner_total, size_t *n_surf_total) {
+  if (!fm) return LSLAM_ERR_INVALID;
+  if (origin) for (int d = 0; d < 3; ++d) origin[d] = fm->origin[d];
+  if (n_valid) *n_valid = (int32_t)fm->valid.size();
+  if (valid_out) for (size_t i = 0; i < fm->valid.size() && i < cap; ++i) valid_out[i] = fm->valid[i];
+  if (n_corner_total) *n_corner_total = fm->n[0];
+  if (n_surf_total) *n_surf_total = fm->n[1];
+  return LSLAM_OK;
+}
+
+// FeatureMap.h:267-286: per cube, VoxelGrid(map leaf) of the corner cloud then of the surf cloud
+int lslam_fmap_get_full_map(lslam_fmap *fm, float *out_xyzi, size_t cap, size_t *n_out) {
+  int rc = check_fm(fm);
+  if (rc) return rc;
+  hipStream_t s = fm->stream;
+  std::vector<float4> h[2];
+  std::vector<int32_t> hc[2];
+  Buf<uint8_t> force;
+  FM_TRY(force.reserve(fm->ncube));
+  FM_TRY(hipMemsetAsync(force.p, 1, fm->ncube, s));  // filter every cube
+  for (int t = 0; t < 2; ++t) {
+    const size_t n = fm->n[t];
+    if (!n) continue;
+    FM_TRY(fm->pts_alt[t].reserve(n));
+    FM_TRY(fm->cube_alt[t].reserve(n));
+    KeyParams kp = key_params(fm, fm->leaf[2]);
+    size_t m = 0;
+    rc = run_pipeline(s, fm->sc, fm->pts[t].p, fm->cube[t].p, n, kp, fm->ncube, force.p, fm->pts_alt[t].p,
+                      fm->cube_alt[t].p, &m);
+    if (rc) { force.release(); return rc; }
+    h[t].resize(m);
+    hc[t].resize(m);
+    if (m) {
+      FM_TRY(hipMemcpyAsync(h[t].data(), fm->pts_alt[t].p, m * sizeof(float4), hipMemcpyDeviceToHost, s));
+      FM_TRY(hipMemcpyAsync(hc[t].data(), fm->cube_alt[t].p, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    }
+    FM_TRY(hipStreamSynchronize(s));
+  }
+  force.release();
+  const size_t total = h[0].size() + h[1].size();
+  if (n_out) *n_out = total;
+  if (!out_xyzi) return LSLAM_OK;
+  if (total > cap) {
+    lslam::set_error("full-map buffer too small");
+    return LSLAM_ERR_INVALID;
+  }
+  size_t a = 0, b = 0, o = 0;  // merge by cube: corner of cube c, then surf of cube c
+  while (a < h[0].size() || b < h[1].size()) {
+    const int32_t ca = a < h[0].size() ? hc[0][a] : INT32_MAX, cb = b < h[1].size() ? hc[1][b] : INT32_MAX;
+    const int32_t c = ca < cb ? ca : cb;
+    while (a < h[0].size() && hc[0][a] == c) std::memcpy(out_xyzi + 4 * o++, &h[0][a++], 16);
+    while (b < h[1].size() && hc[1][b] == c) std::memcpy(out_xyzi + 4 * o++, &h[1][b++], 16);
+  }
+  return LSLAM_OK;
+}
+
+// pcl::VoxelGrid<PointXYZI> with a cubic leaf on one host cloud (LaserMatcher.cpp:289-301)
+int lslam_voxel_grid(lslam_ctx *ctx, const void *cloud, size_t n, size_t stride_bytes, float leaf,
+                     float *out_xyzi, size_t cap, size_t *n_out) {
+  if (!ctx || !n_out || !(leaf > 0.f) || stride_bytes < 12 || (stride_bytes & 3) || (n && !cloud)) {
+    lslam::set_error("bad voxel-grid arguments");
+    return LSLAM_ERR_INVALID;
+  }
+  *n_out = 0;
+  if (n == 0) return LSLAM_OK;
+  FM_TRY(hipSetDevice(lslam::ctx_device(ctx)));
+  hipStream_t s = (hipStream_t)lslam_stream(ctx);
+  lslam_fmap tmp;  // borrows the staging helpers; no grid
+  tmp.ctx = ctx;
+  tmp.stream = s;
+  int rc = pack_input(&tmp, cloud, n, stride_bytes);
+  Buf<float4> out;
+  Buf<int32_t> oc;
+  Scratch sc;
+  auto cleanup = [&] {
+    tmp.in_raw.release(); out.release(); oc.release();
+    sc.release();
+  };
+  if (rc) { cleanup(); return rc; }
+  // min/max on the host while the cloud is at hand (VoxelGrid::applyFilter: getMinMax3D)
+  const float inv = 1.0f / leaf;
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  const char *p = static_cast<const char *>(cloud);
+  for (size_t i = 0; i < n; ++i) {
+    float v[3];
+    std::memcpy(v, p + i * stride_bytes, 12);
+    for (int d = 0; d < 3; ++d) {
+      mn[d] = v[d] < mn[d] ? v[d] : mn[d];
+      mx[d] = v[d] > mx[d] ? v[d] : mx[d];
+    }
+  }
+  KeyParams kp{};
+  kp.W = kp.H = kp.D = 1;
+  kp.cube_size = 1.0f;
+  kp.inv_leaf = inv;
+  kp.single = 1;
+  double cells = 1.0;
+  long long vol = 1;
+  for (int d = 0; d < 3; ++d) {
+    kp.base0[d] = (int32_t)std::floor(mn[d] * inv);
+    const double c = (double)((int32_t)std::floor(mx[d] * inv) - kp.base0[d] + 1);
+    cells = c > cells ? c : cells;
+    vol *= (long long)((mx[d] - mn[d]) * inv) + 1;
+  }
+  kp.axis_bits = bits_for(cells + 1.0);
+  if (!(vol <= (long long)INT32_MAX)) {
+    // applyFilter: "Leaf size is too small for the input dataset" -> the input is returned unfiltered
+    if (n > cap) { cleanup(); lslam::set_error("voxel-grid output buffer too small"); return LSLAM_ERR_INVALID; }
+    FM_TRY(hipMemcpyAsync(out_xyzi, tmp.in_raw.p, n * sizeof(float4), hipMemcpyDeviceToHost, s));
+    FM_TRY(hipStreamSynchronize(s));
+    *n_out = n;
+    cleanup();
+    return LSLAM_OK;
+  }
+  hipError_t e = out.reserve(n);
+  if (e == hipSuccess) e = oc.reserve(n);
+  if (e != hipSuccess) { cleanup(); FM_TRY(e); }
+  size_t m = 0;
+  rc = run_pipeline(s, sc, tmp.in_raw.p, nullptr, n, kp, 1, nullptr, out.p, oc.p, &m);
+  if (!rc) {
+    if (m > cap) {
+      lslam::set_error("voxel-grid output buffer too small");
+      rc = LSLAM_ERR_INVALID;
+    } else if (out_xyzi && m) {
+      if (hipMemcpyAsync(out_xyzi, out.p, m * sizeof(float4), hipMemcpyDeviceToHost, s) != hipSuccess ||
+          hipStreamSynchronize(s) != hipSuccess) {
+        lslam::set_error("voxel-grid download failed");
+        rc = LSLAM_ERR_HIP;
+      }
+    }
+    *n_out = m;
+  }
+  cleanup();
+  return rc;
+}
+
+}  // extern "C"

@@ -157,4 +157,12 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
                                hipStream_t stream, TreeView *view, int *depth, size_t *n_leaves,
                                int *fallback);
 
+// lslam_api.hip internals used by lslam_fmap.hip (map maintenance)
+}  // namespace lslam
+struct lslam_ctx;
+namespace lslam {
+int map_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t n_corner, const float4 *d_surf, size_t n_surf);
+void set_error(const char *msg);
+int ctx_device(const lslam_ctx *ctx);
+bool ctx_alive(const lslam_ctx *ctx);  // false once lslam_ctx_destroy ran
 }  // namespace lslam

@@ -302,6 +302,15 @@ class ScanMatch:
         ok = self._finish(status, st)
         return ok, (self.ctx.pose_to_isometry(tw) if iso else tw)
 
+    def scanMatchLocal(self, referenceCornerCloud, referenceSurfCloud, CornerCloud, SurfCloud, pose):
+        """ScanMatch.cpp:362-398: pcl::VoxelGrid all four clouds (corner leaf 0.2, surf leaf 0.4,
+        ScanMatch.cpp:29-30), then scanMatchScan on the downsampled clouds.  Clouds are (n, 4)
+        {x, y, z, intensity} (or (n, 8) pcl::PointXYZI)."""
+        from .feature_map import voxel_grid
+        ds = [voxel_grid(self.ctx, c, leaf) for c, leaf in ((referenceCornerCloud, 0.2), (referenceSurfCloud, 0.4),
+                                                            (CornerCloud, 0.2), (SurfCloud, 0.4))]
+        return self.scanMatchScan(ds[0], ds[1], ds[2], ds[3], pose)
+
     def setMap(self, referenceCornerCloud, referenceSurfCloud):
         """Keep a map resident across calls (the FeatureMap::scanMatchScan usage,
         util/FeatureMap.h:490-691, where trees are built once per map update)."""

@@ -76,6 +76,7 @@ struct DevTree {
   DevBuf<float4> pts;
   TreeView view{};
   int depth = 0;
+  int cap_attempt = 0;  // node-slot multiplier that last fitted this tree (device build)
 };
 
 struct HostSinCos {
@@ -90,6 +91,7 @@ struct HostSinCos {
 struct lslam_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;  // the corner tree is built beside the surf tree
   DevTree tc, ts;
   // variant C: per-cube trees (shared node/point arrays in tc/ts, one TreeView per cube)
   bool cube_mode = false;
@@ -311,6 +313,7 @@ int lslam_ctx_create(int device, lslam_ctx **out) {
   lslam_ctx *ctx = new lslam_ctx();
   ctx->device = device;
   HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
   {
     int rc = ensure_states(ctx, 1);
     if (rc) return rc;
@@ -345,6 +348,7 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   for (hipEvent_t e : ctx->sweep_ev) (void)hipEventDestroy(e);
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -454,35 +458,55 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
     const float4 *dev_src[2] = {dev_corner, dev_surf};
     const size_t counts[2] = {n_corner, n_surf};
     size_t *ncount[2] = {&nodes_c, &nodes_s};
-    for (int k = 0; k < 2 && !need_host; ++k) {
+    // the two trees are independent: build the corner tree on a second stream from a second
+    // host thread (the builder synchronises its stream a few times) while this one builds surf
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    int fb[2] = {0, 0};
+    hipError_t errs[2] = {hipSuccess, hipSuccess};
+    auto build_one = [&](int k, hipStream_t st) {
       DevTree &dt = *trees[k];
       const size_t n = counts[k];
-      HIP_TRY(dt.pts.reserve(n ? n : 1));
+      (void)hipSetDevice(ctx->device);
+      if ((errs[k] = dt.pts.reserve(n ? n : 1)) != hipSuccess) return;
       // Node slots come in groups of 8 (one cache line per 3-level treelet); how full the
       // groups get depends on the shape of the tree (a cloud of vertical lines leaves most
-      // of them nearly empty), so grow the slot array until the build fits: 2n/3, 8n/3, 8n.
+      // of them nearly empty), so grow the slot array until the build fits: 2n/3, 8n/3, 8n --
+      // starting from what fitted this tree last time.
       int fallback = 0;
       size_t n_leaves = 0;
-      for (int attempt = 0; attempt < 3; ++attempt) {
+      for (int attempt = dt.cap_attempt; attempt < 3; ++attempt) {
         const size_t mult[3] = {2, 8, 24};
         const size_t cap = ((mult[attempt] * n / 3 + 64) + 7) & ~(size_t)7;
-        HIP_TRY(dt.nodes.reserve(cap));
+        if ((errs[k] = dt.nodes.reserve(cap)) != hipSuccess) return;
         if (n && from_dev)
-          HIP_TRY(hipMemcpyAsync(dt.pts.p, dev_src[k], n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+          errs[k] = hipMemcpyAsync(dt.pts.p, dev_src[k], n * sizeof(float4), hipMemcpyDeviceToDevice, st);
         else if (n)
-          HIP_TRY(hipMemcpyAsync(dt.pts.p, clouds[k]->data(), n * sizeof(float4), hipMemcpyHostToDevice,
-                                 ctx->stream));
-        HIP_TRY(build_kdtree_device(dt.pts.p, (int32_t)n, dt.nodes.p, (int32_t)cap, ctx->stream, &dt.view,
-                                    &dt.depth, &n_leaves, &fallback));
-        if (fallback != 1) break;
+          errs[k] = hipMemcpyAsync(dt.pts.p, clouds[k]->data(), n * sizeof(float4), hipMemcpyHostToDevice, st);
+        if (errs[k] != hipSuccess) return;
+        errs[k] = build_kdtree_device(dt.pts.p, (int32_t)n, dt.nodes.p, (int32_t)cap, st, &dt.view, &dt.depth,
+                                      &n_leaves, &fallback);
+        if (errs[k] != hipSuccess) return;
+        if (fallback != 1) {
+          if (!fallback) dt.cap_attempt = attempt;
+          break;
+        }
       }
-      if (fallback) {
+      fb[k] = fallback;
+      *ncount[k] = (size_t)dt.view.n_nodes / 8 * 7 + n_leaves;  // approximate node count
+    };
+    {
+      std::thread th(build_one, 0, ctx->stream2);
+      build_one(1, ctx->stream);
+      th.join();
+    }
+    for (int k = 0; k < 2; ++k) {
+      HIP_TRY(errs[k]);
+      if (fb[k]) {
         need_host = true;
         if (std::getenv("LSLAM_DEBUG"))
           fprintf(stderr, "[lslam] device kd-tree build of %zu points hit limit %d (1 nodes, 2 spin, 3 queue): "
-                          "host build instead\n", n, fallback);
+                          "host build instead\n", counts[k], fb[k]);
       }
-      *ncount[k] = (size_t)dt.view.n_nodes / 8 * 7 + n_leaves;  // approximate node count
     }
     t2 = now_ms();
     if (!need_host) built_on_device = 1;

@@ -92,6 +92,7 @@ struct lslam_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // the corner tree is built beside the surf tree
+  ScanPrep *scanprep = nullptr;
   DevTree tc, ts;
   // variant C: per-cube trees (shared node/point arrays in tc/ts, one TreeView per cube)
   bool cube_mode = false;
@@ -348,6 +349,7 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   for (hipEvent_t e : ctx->sweep_ev) (void)hipEventDestroy(e);
+  scanprep_destroy(ctx->scanprep);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -736,12 +738,17 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
   ctx->nqc.assign((size_t)n_scans, 0);
   ctx->nqs.assign((size_t)n_scans, 0);
   std::vector<float4> c, s;
-  static const bool no_morton = std::getenv("LSLAM_NO_MORTON") != nullptr;  // profiling A/B
+  // LSLAM_NO_MORTON: caller order (profiling A/B); LSLAM_HOST_MORTON: order on the host (A/B, and the
+  // definition the device ordering is tested against)
+  static const bool no_morton = std::getenv("LSLAM_NO_MORTON") != nullptr;
+  static const bool host_morton = std::getenv("LSLAM_HOST_MORTON") != nullptr;
+  const bool dev_morton = !no_morton && !host_morton;
+  std::vector<int32_t> seg_off;
   int32_t out_base = 0;
   for (int32_t p = 0; p < n_scans; ++p) {
     pack_cloud(corner[p], n_corner[p], stride_bytes, c);
     pack_cloud(surf[p], n_surf[p], stride_bytes, s);
-    if (!no_morton) {
+    if (host_morton && !no_morton) {
       morton_order(c);
       morton_order(s);
     } else {
@@ -752,6 +759,7 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
     for (int type = 0; type < 2; ++type) {
       const std::vector<float4> &v = type ? s : c;
       const int32_t base = (int32_t)all.size();
+      seg_off.push_back(base);
       for (size_t off = 0; off < v.size(); off += SWEEP_BLOCK) {
         BlockDesc bd{};
         bd.prob = p;
@@ -768,6 +776,7 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
     ctx->nqs[(size_t)p] = (int32_t)s.size();
     out_base += (int32_t)(c.size() + s.size());
   }
+  seg_off.push_back((int32_t)all.size());
   const size_t nb = ctx->h_blocks.size();
   HIP_TRY(ctx->q.reserve(total ? total : 1));
   HIP_TRY(ctx->blocks.reserve(nb ? nb : 1));
@@ -777,9 +786,14 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
   ctx->prev_valid = false;
   rc = ensure_states(ctx, n_scans);
   if (rc) return rc;
-  if (total)
+  if (total && dev_morton) {
+    if (!ctx->scanprep) ctx->scanprep = scanprep_create();
+    HIP_TRY(scanprep_order(ctx->scanprep, ctx->stream, all.data(), total, seg_off.data(), (int)seg_off.size() - 1,
+                           ctx->q.p));
+  } else if (total) {
     HIP_TRY(hipMemcpyAsync(ctx->q.p, all.data(), total * sizeof(float4), hipMemcpyHostToDevice,
                            ctx->stream));
+  }
   if (nb)
     HIP_TRY(hipMemcpyAsync(ctx->blocks.p, ctx->h_blocks.data(), nb * sizeof(BlockDesc),
                            hipMemcpyHostToDevice, ctx->stream));

@@ -164,5 +164,12 @@ namespace lslam {
 int map_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t n_corner, const float4 *d_surf, size_t n_surf);
 void set_error(const char *msg);
 int ctx_device(const lslam_ctx *ctx);
-bool ctx_alive(const lslam_ctx *ctx);  // false once lslam_ctx_destroy ran
+bool ctx_alive(const lslam_ctx *ctx);
+
+// lslam_scanprep.hip: Morton ordering of the resident scans on the device
+struct ScanPrep;
+ScanPrep *scanprep_create();
+void scanprep_destroy(ScanPrep *sp);
+hipError_t scanprep_order(ScanPrep *sp, hipStream_t s, const float4 *h_pts, size_t n, const int32_t *h_seg_off,
+                          int nseg, float4 *d_out);  // false once lslam_ctx_destroy ran
 }  // namespace lslam

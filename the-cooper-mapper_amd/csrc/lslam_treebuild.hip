@@ -94,20 +94,36 @@ struct Sh {
   int have;
 };
 
+// Wavefront-wide reductions on the DPP path (no LDS crossbar): xor-1 and xor-2 inside each quad,
+// row_half_mirror and row_mirror complete the 16-lane rows, four readlanes combine the rows.  Every
+// lane receives the result.  (__shfl_xor lowers to ds_bpermute, ~10x the latency; a small kd-tree
+// node needs about a dozen of these reductions.)
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+template <typename Op>
+__device__ __forceinline__ int wave_reduce_bits(int v, Op op) {
+  v = op(v, dpp_i<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = op(v, dpp_i<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = op(v, dpp_i<0x141>(v));  // row_half_mirror
+  v = op(v, dpp_i<0x140>(v));  // row_mirror
+  const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16),
+            r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+  return op(op(r0, r1), op(r2, r3));
+}
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
+  return __int_as_float(wave_reduce_bits(__float_as_int(v), [](int a, int b) {
+    return __float_as_int(fminf(__int_as_float(a), __int_as_float(b)));
+  }));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  return __int_as_float(wave_reduce_bits(__float_as_int(v), [](int a, int b) {
+    return __float_as_int(fmaxf(__int_as_float(a), __int_as_float(b)));
+  }));
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  return wave_reduce_bits(v, [](int a, int b) { return a + b; });
 }
 
 // exclusive prefix sum of `flag` over the block's TB threads; returns prefix, *total
@@ -184,11 +200,26 @@ __device__ void hoare_pass(const BuildArgs &A, Sh<TB> &sh, int l, int a, int b, 
     run += tot;
   }
   __syncthreads();
-  for (int k = tid; k < m; k += TB) {
-    const int i = l + A.tmpA[l + k], j = l + A.tmpB[l + k];
-    const float4 t = A.pts[i];
-    A.pts[i] = A.pts[j];
-    A.pts[j] = t;
+  for (int k0 = tid; k0 < m; k0 += TB * 4) {  // independent swaps, four per thread in flight
+    int ii[4], jj[4];
+    float4 pi[4], pj[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + u * TB < m ? k0 + u * TB : k0;
+      ii[u] = l + A.tmpA[l + k];
+      jj[u] = l + A.tmpB[l + k];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      pi[u] = A.pts[ii[u]];
+      pj[u] = A.pts[jj[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (k0 + u * TB < m) {
+        A.pts[ii[u]] = pj[u];
+        A.pts[jj[u]] = pi[u];
+      }
   }
   __syncthreads();
 }
@@ -209,12 +240,23 @@ __device__ void process_node(const BuildArgs &A, Sh<TB> &sh, const BuildItem &it
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l = it.l, n = it.r - it.l;
   // ---- min / max of the three coordinates (computeMinMax, :908-920) ---------------
+  // UN loads in flight per thread in the streaming passes: a workgroup streams its node alone, so
+  // without them every pass is bound by one load latency per point
+  constexpr int UN = TB >= 256 ? 8 : 4;
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (int i = tid; i < n; i += TB) {
-    const float4 p = A.pts[l + i];
-    mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
-    mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
-    mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+  for (int i0 = tid; i0 < n; i0 += TB * UN) {
+    float4 p[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int i = i0 + u * TB;
+      p[u] = A.pts[l + (i < n ? i : n - 1)];  // a clamped duplicate of the last point changes no min/max
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      mn[0] = fminf(mn[0], p[u].x); mx[0] = fmaxf(mx[0], p[u].x);
+      mn[1] = fminf(mn[1], p[u].y); mx[1] = fmaxf(mx[1], p[u].y);
+      mn[2] = fminf(mn[2], p[u].z); mx[2] = fmaxf(mx[2], p[u].z);
+    }
   }
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
@@ -250,10 +292,19 @@ __device__ void process_node(const BuildArgs &A, Sh<TB> &sh, const BuildItem &it
   const float cut = sh.bc_f[0];
   // ---- lim1 = #(x < cut), lim2 = #(x <= cut) ---------------------------------------
   int c1 = 0, c2 = 0;
-  for (int i = tid; i < n; i += TB) {
-    const float x = coord(A.pts[l + i], feat);
-    c1 += x < cut;
-    c2 += x <= cut;
+  for (int i0 = tid; i0 < n; i0 += TB * UN) {
+    float x[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int i = i0 + u * TB;
+      x[u] = coord(A.pts[l + (i < n ? i : n - 1)], feat);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+      if (i0 + u * TB < n) {
+        c1 += x[u] < cut;
+        c2 += x[u] <= cut;
+      }
   }
   c1 = wave_sum_i(c1);
   c2 = wave_sum_i(c2);
@@ -270,9 +321,20 @@ __device__ void process_node(const BuildArgs &A, Sh<TB> &sh, const BuildItem &it
   const int index = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);  // :1024-1029
   // ---- tight bounds of the two halves along the split dimension (:966-971) ----------
   float lmax = -FLT_MAX, rmin = FLT_MAX;
-  for (int i = tid; i < n; i += TB) {
-    const float x = coord(A.pts[l + i], feat);
-    if (i < index) lmax = fmaxf(lmax, x); else rmin = fminf(rmin, x);
+  for (int i0 = tid; i0 < n; i0 += TB * UN) {
+    float x[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int i = i0 + u * TB;
+      x[u] = coord(A.pts[l + (i < n ? i : n - 1)], feat);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int i = i0 + u * TB;
+      if (i < n) {
+        if (i < index) lmax = fmaxf(lmax, x[u]); else rmin = fminf(rmin, x[u]);
+      }
+    }
   }
   lmax = wave_max(lmax);
   rmin = wave_min(rmin);
@@ -401,38 +463,215 @@ __global__ __launch_bounds__(TB_BIG) void kd_build_big_kernel(BuildArgs A) {
   }
 }
 
-// Phase B: one wavefront per listed subtree; depth-first with a stack in LDS.
-__global__ __launch_bounds__(TB_SMALL) void kd_build_small_kernel(BuildArgs A) {
-  constexpr int TB = TB_SMALL;
-  __shared__ Sh<TB> sh;
-  const int tid = threadIdx.x;
+// Phase B: one wavefront per listed subtree (<= LOCAL_MAX points).  The subtree's points live in
+// LDS for the whole build (structure of arrays: x, y, z, bitcast index = 32 KB) together with the two
+// index lists of the Hoare pairing (2 x 4 KB of uint16) and the depth-first stack, so every split
+// below the hand-over size costs LDS round trips only; the permuted points are written back once.
+// A single wavefront needs no barriers: reductions are wave shuffles, the "k-th misplaced" ranks of
+// the Hoare pairing come from ballots.  Node-group slots are taken from the global counter eight
+// groups at a time; leaf / depth statistics are accumulated per wavefront and added once.
+struct SmallItem {
+  int32_t a, b;        // point range relative to the subtree's first point
+  float lo[3], hi[3];  // propagated bounding box
+  int32_t slot, heap, parent_word, depth;
+};
+
+__global__ __launch_bounds__(64) void kd_build_small_kernel(BuildArgs A) {
+  __shared__ float sx[LOCAL_MAX], sy[LOCAL_MAX], sz[LOCAL_MAX];
+  __shared__ uint32_t sw[LOCAL_MAX];
+  __shared__ uint16_t ta[LOCAL_MAX], tb[LOCAL_MAX];
+  __shared__ SmallItem stack[LOCAL_STACK];
+  __shared__ int sh_e;
+  const int lane = threadIdx.x;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int grp_next = 0, grp_end = 0;   // wave-uniform: pre-allocated node groups [grp_next, grp_end)
+  int n_leaves = 0, max_depth = 0;
   for (;;) {
-    if (tid == 0) {
-      const int e = atomicAdd(&A.ctl->sub_next, 1);
-      sh.have = e < A.ctl->n_sub;
-      if (sh.have) {
-        sh.stack[0] = A.sublist[e];
-        sh.sp = 1;
-      }
-    }
+    if (lane == 0) sh_e = atomicAdd(&A.ctl->sub_next, 1);
     __syncthreads();
-    if (!sh.have) return;
-    while (sh.sp > 0) {
+    const int e = sh_e;
+    __syncthreads();
+    if (e >= A.ctl->n_sub) break;
+    const BuildItem root = A.sublist[e];
+    const int L0 = root.l, N = root.r - root.l;
+    for (int i = lane; i < N; i += 64) {
+      const float4 p = A.pts[L0 + i];
+      sx[i] = p.x; sy[i] = p.y; sz[i] = p.z; sw[i] = __float_as_uint(p.w);
+    }
+    if (lane == 0) {
+      SmallItem r;
+      r.a = 0; r.b = N;
+      for (int d = 0; d < 3; ++d) { r.lo[d] = root.lo[d]; r.hi[d] = root.hi[d]; }
+      r.slot = root.slot; r.heap = root.heap; r.parent_word = root.parent_word; r.depth = root.depth;
+      stack[0] = r;
+    }
+    int sp = 1;  // wave-uniform
+    __syncthreads();
+    while (sp > 0) {
+      const SmallItem it = stack[sp - 1];
+      --sp;
       __syncthreads();
-      const BuildItem it = sh.stack[sh.sp - 1];
-      __syncthreads();
-      BuildItem kids[2];
-      int nk = 0;
-      process_node<TB>(A, sh, it, kids, &nk);
-      if (tid == 0) {
-        --sh.sp;
-        for (int c = nk - 1; c >= 0; --c) {  // left child on top: nanoflann's recursion order
-          if (sh.sp < LOCAL_STACK) sh.stack[sh.sp++] = kids[c];
-          else A.ctl->overflow = 4;
+      const int a = it.a, n = it.b - it.a;
+      // ---- computeMinMax (:908-920) ------------------------------------------------------
+      float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+      for (int i = lane; i < n; i += 64) {
+        const float x = sx[a + i], y = sy[a + i], z = sz[a + i];
+        mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
+        mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
+        mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+      }
+      float emin[3], emax[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { emin[d] = wave_min(mn[d]); emax[d] = wave_max(mx[d]); }
+      // ---- middleSplit_ (:982-1031), computed by every lane ------------------------------
+      const float EPS = 0.00001f;
+      float max_span = it.hi[0] - it.lo[0];
+#pragma unroll
+      for (int d = 1; d < 3; ++d) { const float span = it.hi[d] - it.lo[d]; if (span > max_span) max_span = span; }
+      float max_spread = -1;
+      int feat = 0;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const float span = it.hi[d] - it.lo[d];
+        if (span > (1 - EPS) * max_span) {
+          const float spread = emax[d] - emin[d];
+          if (spread > max_spread) { feat = d; max_spread = spread; }
         }
       }
+      const float flo = feat == 0 ? it.lo[0] : (feat == 1 ? it.lo[1] : it.lo[2]);
+      const float fhi = feat == 0 ? it.hi[0] : (feat == 1 ? it.hi[1] : it.hi[2]);
+      const float fmn = feat == 0 ? emin[0] : (feat == 1 ? emin[1] : emin[2]);
+      const float fmx = feat == 0 ? emax[0] : (feat == 1 ? emax[1] : emax[2]);
+      const float split_val = (flo + fhi) / 2;
+      const float cut = split_val < fmn ? fmn : (split_val > fmx ? fmx : split_val);
+      const float *sc = feat == 0 ? sx : (feat == 1 ? sy : sz);
+      // ---- lim1 = #(x < cut), lim2 = #(x <= cut) ----------------------------------------
+      int c1 = 0, c2 = 0;
+      for (int i = lane; i < n; i += 64) {
+        const float x = sc[a + i];
+        c1 += x < cut;
+        c2 += x <= cut;
+      }
+      const int lim1 = wave_sum_i(c1), lim2 = wave_sum_i(c2);
+      // ---- planeSplit (:1043-1078): two Hoare passes -------------------------------------
+#pragma unroll 1
+      for (int pass = 0; pass < 2; ++pass) {
+        const int pa = pass == 0 ? 0 : lim1, Lc = pass == 0 ? lim1 : lim2 - lim1;
+        const int nl = Lc, nr = (n - pa) - Lc;
+        if (nl <= 0 || nr <= 0) continue;
+        int m = 0;
+        for (int c = 0; c < nl; c += 64) {  // misplaced on the left, increasing index
+          const int i = c + lane;
+          bool f = false;
+          if (i < nl) {
+            const float x = sc[a + pa + i];
+            f = pass == 0 ? !(x < cut) : !(x <= cut);
+          }
+          const unsigned long long mask = __ballot(f);
+          if (f) ta[m + __popcll(mask & lt_mask)] = (uint16_t)(pa + i);
+          m += __popcll(mask);
+        }
+        if (m == 0) continue;
+        int m2 = 0;
+        for (int c = 0; c < nr; c += 64) {  // misplaced on the right, decreasing index
+          const int i = c + lane;
+          bool f = false;
+          if (i < nr) {
+            const float x = sc[a + n - 1 - i];
+            f = pass == 0 ? (x < cut) : (x <= cut);
+          }
+          const unsigned long long mask = __ballot(f);
+          if (f) tb[m2 + __popcll(mask & lt_mask)] = (uint16_t)(n - 1 - i);
+          m2 += __popcll(mask);
+        }
+        __syncthreads();
+        for (int k = lane; k < m; k += 64) {
+          const int i = a + ta[k], j = a + tb[k];
+          const float x = sx[i], y = sy[i], z = sz[i];
+          const uint32_t w = sw[i];
+          sx[i] = sx[j]; sy[i] = sy[j]; sz[i] = sz[j]; sw[i] = sw[j];
+          sx[j] = x; sy[j] = y; sz[j] = z; sw[j] = w;
+        }
+        __syncthreads();
+      }
+      const int half = n / 2;
+      const int index = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);  // :1024-1029
+      // ---- tight bounds of the halves along the split dimension (:966-971) -----------------
+      float lmax = -FLT_MAX, rmin = FLT_MAX;
+      for (int i = lane; i < n; i += 64) {
+        const float x = sc[a + i];
+        if (i < index) lmax = fmaxf(lmax, x); else rmin = fminf(rmin, x);
+      }
+      const float divlow = wave_max(lmax), divhigh = wave_min(rmin);
+      // ---- children (every lane computes them; lane 0 writes) --------------------------------
+      uint32_t ref[2];
+#pragma unroll
+      for (int c = 1; c >= 0; --c) {  // right child pushed first: the left one is built next
+        const int ca = c == 0 ? it.a : it.a + index, cb = c == 0 ? it.a + index : it.b;
+        if (cb - ca <= 10) {  // leaf (:936-951)
+          ref[c] = KD_LEAF | ((uint32_t)(L0 + ca) << 4) | (uint32_t)(cb - ca);
+          ++n_leaves;
+          max_depth = max(max_depth, it.depth + 1);
+        } else {
+          SmallItem ch;
+          ch.a = ca; ch.b = cb;
+#pragma unroll
+          for (int d = 0; d < 3; ++d) { ch.lo[d] = it.lo[d]; ch.hi[d] = it.hi[d]; }
+          if (c == 0) { if (feat == 0) ch.hi[0] = cut; else if (feat == 1) ch.hi[1] = cut; else ch.hi[2] = cut; }
+          else        { if (feat == 0) ch.lo[0] = cut; else if (feat == 1) ch.lo[1] = cut; else ch.lo[2] = cut; }
+          if (it.heap < 3) {  // child stays in this 8-slot group
+            ch.heap = 2 * it.heap + 1 + c;
+            ch.slot = it.slot - it.heap + ch.heap;
+          } else {
+            if (grp_next == grp_end) {  // take eight groups at once
+              int g = 0;
+              if (lane == 0) g = atomicAdd(&A.ctl->next_group, 8);
+              g = __shfl(g, 0, 64);
+              grp_next = g;
+              grp_end = g + 8;
+            }
+            ch.heap = 0;
+            ch.slot = grp_next * 8;
+            if ((grp_next + 1) * 8 > A.node_cap) {
+              if (lane == 0) A.ctl->overflow = 1;
+              ch.slot = 0;
+            }
+            ++grp_next;
+          }
+          ch.parent_word = it.slot * 4 + 2 + c;
+          ch.depth = it.depth + 1;
+          ref[c] = (uint32_t)ch.slot << 2;  // the child ORs its divfeat in when it is processed
+          if (sp < LOCAL_STACK) {
+            if (lane == 0) stack[sp] = ch;
+            ++sp;
+          } else if (lane == 0) {
+            A.ctl->overflow = 4;
+          }
+        }
+      }
+      if (lane == 0) {
+        KdNode nd;
+        nd.lo = divlow;
+        nd.hi = divhigh;
+        nd.c1 = ref[0];
+        nd.c2 = ref[1];
+        // the children's divfeat bits may already be... no: children run after this store (same wave,
+        // program order), and they OR into these words atomically
+        A.nodes[it.slot] = nd;
+        if (it.parent_word >= 0)
+          atomicOr(reinterpret_cast<unsigned int *>(A.nodes) + it.parent_word, (unsigned int)feat);
+        else
+          A.ctl->root_feat = feat;
+      }
       __syncthreads();
     }
+    for (int i = lane; i < N; i += 64) A.pts[L0 + i] = make_float4(sx[i], sy[i], sz[i], __uint_as_float(sw[i]));
+    __syncthreads();
+  }
+  // n_leaves / max_depth were counted by every lane identically
+  if (lane == 0) {
+    if (n_leaves) atomicAdd(&A.ctl->n_leaves, n_leaves);
+    atomicMax(&A.ctl->max_depth, max_depth);
   }
 }
 
@@ -571,7 +810,7 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
     *fallback = ctl.overflow;
     return hipSuccess;
   }
-  view->n_nodes = ctl.next_group * 8;
+  view->n_nodes = std::min(ctl.next_group * 8, A.node_cap);  // groups are taken eight at a time: the last few may be unused
   view->root_ref = (0u << 2) | (uint32_t)ctl.root_feat;
   *depth = ctl.max_depth;
   *n_leaves = (size_t)ctl.n_leaves;

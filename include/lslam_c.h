@@ -282,6 +282,36 @@ int lslam_fmap_info(lslam_fmap *fm, int32_t origin[3], int32_t *n_valid, int32_t
 int lslam_voxel_grid(lslam_ctx *ctx, const void *cloud, size_t n, size_t stride_bytes, float leaf,
                      float *out_xyzi, size_t cap, size_t *n_out);
 
+/* ---- feature extraction front end ------------------------------
+ * Replaces ScanRegistration::extractFeatures (odometry/ScanRegistration.cpp:190-425, with
+ * setScanBuffersFor :471-531, setRegionBuffersFor :427-469, markAsPicked :533-555 and
+ * pointClassify :557-687) on the ring-sorted full-resolution cloud MultiScanRegistration::process
+ * builds (MultiScanRegistration.cpp:178-190).  Building that cloud from raw driver packets is the
+ * caller's (ring from the vertical angle, IMU de-skew). */
+typedef struct lslam_reg_params {     /* RegistrationParams, ScanRegistration.h:45-112 */
+  int32_t n_feature_regions;          /* 6 */
+  int32_t curvature_region;           /* 5 */
+  int32_t max_corner_sharp;           /* 2 */
+  int32_t max_surface_flat;           /* 4 */
+  float less_flat_filter_size;        /* 0.2 */
+  float surface_curvature_threshold;  /* 0.02 */
+  float blind_threshold;              /* cos(deg2rad(blindDegreeThreshold = 0.5)) */
+  int32_t reserved;
+} lslam_reg_params;
+void lslam_reg_default_params(lslam_reg_params *p);
+/* cloud: n_points points, {x,y,z} at offset 0 and, at intensity_offset_bytes, the float copied to
+ * the outputs' intensity (toXYZI, util/pcl_util.h:30-37: the `curvature` field = ring id +
+ * relative time).  scan_ranges: n_scans x {first, last} inclusive index ranges (a ring of more
+ * than 2560 points is refused).  sharp / less_sharp / flat / less_flat: room for n_points
+ * {x,y,z,intensity} each (any may be NULL); counts = their sizes.  Optional taps, n_points each:
+ * curvature (0 outside the feature regions), _scanNeighborPicked right after setScanBuffersFor,
+ * final region label (PointLabel values, 6 = UNKNOW). */
+int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, size_t stride_bytes,
+                           size_t intensity_offset_bytes, const int32_t *scan_ranges, size_t n_scans,
+                           const lslam_reg_params *params, float *sharp, float *less_sharp, float *flat,
+                           float *less_flat, size_t counts[4], float *curvature_out, int8_t *picked_out,
+                           int8_t *label_out);
+
 /* ---- SE(3) pose-graph Levenberg-Marquardt ------------------------------------
  * Replaces pose_graph::SolverG2O (pose_graph/solver_g2o.cpp:51-95): add_se3_node /
  * add_se3_edge build the arrays passed to lslam_pg_create, optimize() becomes

@@ -38,6 +38,12 @@ class OracleOdomOpts(C.Structure):
     _fields_ = [("max_iterations", C.c_int), ("delta_t_abort", C.c_float), ("delta_r_abort", C.c_float)]
 
 
+class OracleRegParams(C.Structure):
+    _fields_ = [("n_feature_regions", C.c_int), ("curvature_region", C.c_int), ("max_corner_sharp", C.c_int),
+                ("max_surface_flat", C.c_int), ("less_flat_filter_size", C.c_float),
+                ("surface_curvature_threshold", C.c_float), ("blind_threshold", C.c_float)]
+
+
 class OracleStats(C.Structure):
     _fields_ = [
         ("status", C.c_int),
@@ -62,7 +68,8 @@ def build_oracle(native=False):
     """Compile the oracle with its Makefile if the .so is missing or stale."""
     target = "liblslam_oracle_native.so" if native else "liblslam_oracle.so"
     so = os.path.join(ORACLE_DIR, target)
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("lslam_oracle.c", "lslam_oracle.h", "fmap_oracle.c", "fmap_oracle.h")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("lslam_oracle.c", "lslam_oracle.h", "fmap_oracle.c", "fmap_oracle.h", "features_oracle.c",
+                                                 "features_oracle.h")]
     if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, target], stdout=subprocess.DEVNULL)
     return so
@@ -157,6 +164,44 @@ class Oracle:
         L.oracle_fmap_cube_count.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.oracle_fmap_get_full_map.restype = C.c_size_t
         L.oracle_fmap_get_full_map.argtypes = [C.c_void_p, c_float_p, C.c_size_t]
+
+        L.oracle_reg_default_params.argtypes = [C.POINTER(OracleRegParams)]
+        L.oracle_point_classify.restype = C.c_int
+        L.oracle_point_classify.argtypes = [c_float_p, C.c_size_t, C.c_size_t, C.c_int]
+        L.oracle_extract_features.argtypes = [c_float_p, C.c_size_t, C.c_size_t, C.c_size_t, c_int32_p, C.c_size_t,
+                                              C.POINTER(OracleRegParams), c_float_p, c_float_p, c_float_p, c_float_p,
+                                              C.POINTER(C.c_size_t), c_float_p, C.POINTER(C.c_int8),
+                                              C.POINTER(C.c_int8)]
+
+    # ---- feature extraction --------------------------------------------
+    def reg_params(self):
+        p = OracleRegParams()
+        self.lib.oracle_reg_default_params(C.byref(p))
+        return p
+
+    def point_classify(self, cloud, idx, curvature_region=5):
+        a = np.ascontiguousarray(cloud, dtype=np.float32)
+        return self.lib.oracle_point_classify(_fp(a), a.shape[1], int(idx), curvature_region)
+
+    def extract_features(self, cloud, scan_ranges, params=None, curvature_field=3):
+        """-> dict(sharp, less_sharp, flat, less_flat (n,4 each), curvature, picked, label)."""
+        a = np.ascontiguousarray(cloud, dtype=np.float32)
+        r = np.ascontiguousarray(scan_ranges, dtype=np.int32).reshape(-1, 2)
+        if params is None:
+            params = self.reg_params()
+        n = len(a)
+        outs = [np.zeros((n, 4), np.float32) for _ in range(4)]
+        counts = (C.c_size_t * 4)()
+        curv = np.zeros(n, np.float32)
+        picked = np.zeros(n, np.int8)
+        label = np.zeros(n, np.int8)
+        self.lib.oracle_extract_features(_fp(a), n, a.shape[1], curvature_field, _ip(r), len(r), C.byref(params),
+                                         _fp(outs[0]), _fp(outs[1]), _fp(outs[2]), _fp(outs[3]), counts, _fp(curv),
+                                         picked.ctypes.data_as(C.POINTER(C.c_int8)),
+                                         label.ctypes.data_as(C.POINTER(C.c_int8)))
+        return dict(sharp=outs[0][:counts[0]].copy(), less_sharp=outs[1][:counts[1]].copy(),
+                    flat=outs[2][:counts[2]].copy(), less_flat=outs[3][:counts[3]].copy(), curvature=curv,
+                    picked=picked, label=label)
 
     # ---- map maintenance -----------------------------------------------
     def voxel_grid(self, cloud, leaf):

@@ -1,0 +1,86 @@
+"""GPU parity for the feature-extraction front end: lslam_extract_features against
+oracle/features_oracle.c on the same ring-sorted scans -- bit for bit, including the taps."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _compare(got, ref, tag):
+    for k in ("curvature",):
+        assert np.array_equal(bits(got[k]), bits(ref[k])), (tag, k)
+    assert np.array_equal(got["picked"], ref["picked"]), tag
+    bad = np.nonzero(got["label"] != ref["label"])[0]
+    assert len(bad) == 0, (tag, bad[:10], got["label"][bad[:10]], ref["label"][bad[:10]])
+    for k in ("sharp", "less_sharp", "flat", "less_flat"):
+        assert got[k].shape == ref[k].shape, (tag, k, got[k].shape, ref[k].shape)
+        assert np.array_equal(bits(got[k]), bits(ref[k])), (tag, k)
+
+
+@pytest.mark.parametrize("rings,steps,seed", [(16, 900, 1), (16, 1800, 2), (64, 1800, 3), (32, 2400, 4)])
+def test_extract_features_matches_oracle(pkg, ctx, oracle, synth, rings, steps, seed):
+    world = synth.World(half_extent=120.0, wall_half=90.0)
+    gt = (0.01, -0.02, 0.3 * seed, 3.0 - seed, -2.0 + 2 * seed, synth.SENSOR_HEIGHT)
+    c, s, gt, cloud, ranges = synth.make_scan(world, rings, steps, gt_pose=gt, seed=100 + seed, full=True)
+    got = pkg.scan_registration.extract_features(ctx, cloud, ranges, taps=True)
+    ref = oracle.extract_features(cloud, ranges)
+    assert len(ref["sharp"]) > 10 and len(ref["flat"]) > 50 and len(ref["less_flat"]) > 1000
+    _compare(got, ref, (rings, steps))
+
+
+def test_extract_features_parameters_and_edges(pkg, ctx, oracle, synth):
+    world = synth.World(half_extent=60.0, wall_half=55.0)
+    c, s, gt, cloud, ranges = synth.make_scan(world, 16, 900, full=True)
+    # other parameters (the launch files set some of these)
+    p, q = pkg.scan_registration.default_params(ctx), oracle.reg_params()
+    for obj in (p, q):
+        obj.n_feature_regions = 4
+        obj.curvature_region = 3
+        obj.max_corner_sharp = 4
+        obj.max_surface_flat = 2
+        obj.surface_curvature_threshold = 0.1
+        obj.less_flat_filter_size = 0.4
+    _compare(pkg.scan_registration.extract_features(ctx, cloud, ranges, p, taps=True),
+             oracle.extract_features(cloud, ranges, q), "params")
+    # rings that are empty or too short are skipped (ScanRegistration.cpp:205-207)
+    n0 = int(ranges[3, 1]) + 1
+    short = np.concatenate([ranges[:4], [[n0, n0 - 1], [n0, n0 + 9], [n0 + 10, int(ranges[4, 1])]], ranges[5:]]).astype(np.int32)
+    _compare(pkg.scan_registration.extract_features(ctx, cloud, short, taps=True),
+             oracle.extract_features(cloud, short), "short")
+    # PointXYZINormal-like stride: the copied field is at another offset
+    wide = np.zeros((len(cloud), 12), np.float32)
+    wide[:, :3] = cloud[:, :3]
+    wide[:, 8] = cloud[:, 3]
+    _compare(pkg.scan_registration.extract_features(ctx, wide, ranges, intensity_field=8, taps=True),
+             oracle.extract_features(cloud, ranges), "wide")
+    with pytest.raises(pkg.LslamError):
+        pkg.scan_registration.extract_features(ctx, cloud, np.array([[0, len(cloud)]], np.int32))
+    with pytest.raises(pkg.LslamError):
+        pkg.scan_registration.extract_features(ctx, cloud, np.array([[0, 4000]], np.int32))  # > 2560 points
+
+
+def test_features_feed_odometry(pkg, ctx, oracle, synth, small_problem):
+    """Config 1 end to end on the device: extractFeatures on two consecutive sweeps, then
+    LaserOdometry::scanMatch (variant B) of sweep 2's sharp/flat points against sweep 1's
+    less-sharp/less-flat clouds -- the same clouds and the same result as the oracle chain."""
+    world = small_problem["world"]
+    clouds = []
+    for k in range(2):
+        gt = np.array([0.0, 0.0, 0.3 + 0.01 * k, 3.0 + 0.25 * k, -2.0 + 0.1 * k, synth.SENSOR_HEIGHT])
+        c, s, gt, cloud, ranges = synth.make_scan(world, 16, 900, gt_pose=gt, seed=700 + k, full=True)
+        g = pkg.scan_registration.extract_features(ctx, cloud, ranges)
+        r = oracle.extract_features(cloud, ranges)
+        for key in ("sharp", "less_sharp", "flat", "less_flat"):
+            assert np.array_equal(bits(g[key]), bits(r[key]))
+        clouds.append(g)
+    pose0 = np.zeros(6, np.float32)
+    _, pose_g, st_g = ctx.odometry_match(clouds[0]["less_sharp"], clouds[0]["less_flat"], clouds[1]["sharp"],
+                                            clouds[1]["flat"], pose0)
+    it_o, pose_o, st_o = oracle.odometry_match(clouds[0]["less_sharp"], clouds[0]["less_flat"], clouds[1]["sharp"],
+                                               clouds[1]["flat"], pose0)
+    assert st_g.iterations == it_o and it_o > 0
+    assert np.abs(pose_g[3:] - pose_o[3:]).max() <= 1e-4 and np.abs(pose_g[:3] - pose_o[:3]).max() <= 1e-5

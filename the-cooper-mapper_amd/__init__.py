@@ -16,6 +16,7 @@ from .capi import (LslamError, LslamOpts, LslamStats, LslamMapInfo, Status, lib_
 from .scan_match import Context, ScanMatch
 from .pose_graph import PoseGraph
 from .feature_map import FeatureMap, voxel_grid
+from . import scan_registration
 
-__all__ = ["Context", "ScanMatch", "PoseGraph", "FeatureMap", "voxel_grid", "LslamError", "LslamOpts", "LslamStats", "LslamMapInfo",
+__all__ = ["Context", "ScanMatch", "PoseGraph", "FeatureMap", "voxel_grid", "scan_registration", "LslamError", "LslamOpts", "LslamStats", "LslamMapInfo",
            "Status", "lib_path", "load_library", "build_library"]

@@ -47,6 +47,13 @@ class LslamOpts(C.Structure):
     ]
 
 
+class LslamRegParams(C.Structure):
+    """lslam_reg_params (include/lslam_c.h)."""
+    _fields_ = [("n_feature_regions", C.c_int32), ("curvature_region", C.c_int32), ("max_corner_sharp", C.c_int32),
+                ("max_surface_flat", C.c_int32), ("less_flat_filter_size", C.c_float),
+                ("surface_curvature_threshold", C.c_float), ("blind_threshold", C.c_float), ("reserved", C.c_int32)]
+
+
 class LslamStats(C.Structure):
     _fields_ = [
         ("status", C.c_int32),
@@ -156,6 +163,11 @@ SYMBOLS = {
                                   C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "lslam_voxel_grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float, c_float_p,
                                    C.c_size_t, C.POINTER(C.c_size_t)]),
+    "lslam_reg_default_params": (None, [C.POINTER(LslamRegParams)]),
+    "lslam_extract_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, c_int32_p,
+                                         C.c_size_t, C.POINTER(LslamRegParams), c_float_p, c_float_p, c_float_p,
+                                         c_float_p, C.POINTER(C.c_size_t), c_float_p, C.POINTER(C.c_int8),
+                                         C.POINTER(C.c_int8)]),
     "lslam_pg_set_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, ALLREDUCE_FN, C.c_void_p, C.c_void_p]),
     "lslam_pg_system_doubles": (C.c_size_t, [C.c_void_p]),
     "lslam_pg_num_offdiag": (C.c_int32, [C.c_void_p]),

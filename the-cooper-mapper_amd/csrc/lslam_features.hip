@@ -1,0 +1,458 @@
+// lslam_features.hip -- feature-extraction front end on the device:
+// ScanRegistration::extractFeatures (odometry/ScanRegistration.cpp:190-425) on the ring-sorted
+// full-resolution cloud, one workgroup per scan ring.
+//
+// What is parallel and what is not.  Everything that does not depend on the order of picking runs
+// across the workgroup: the neighbour tests behind setScanBuffersFor (:471-531), the curvature of
+// every region point (:427-455), the stable ascending order by curvature (a rank sort: rank =
+// #smaller + #equal-with-lower-index, which is what the reference's `<=` merge sort produces,
+// :151-186), and pointClassify (:557-687, two 6-point line fits with the 3x3 symmetric
+// eigen-solver) for every point whose curvature reaches the threshold -- exactly the set the
+// reference's third loop visits.  The picking itself (marks applied in scan order, at most
+// maxSurfaceFlat / maxCornerSharp picks per region with markAsPicked exclusion, regions of a ring
+// sharing one mark array) is sequential by definition and is done by lane 0 on LDS-resident state:
+// a few thousand integer steps per ring, all rings in parallel.  The per-ring VoxelGrid of the
+// less-flat points (:398-407) is the segment filter of lslam_fmap.hip.
+#include "../../include/lslam_c.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "lslam_device.hpp"
+#include "lslam_internal.hpp"
+
+namespace {
+
+#define FX_TRY(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      char _b[400];                                                                      \
+      snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      lslam::set_error(_b);                                                              \
+      return LSLAM_ERR_HIP;                                                              \
+    }                                                                                    \
+  } while (0)
+
+constexpr int FX_BLOCK = 256;
+constexpr int MAXR = 2560;  // points per ring held in LDS
+
+// PointLabel, ScanRegistration.h:22-42
+enum : int {
+  L_UNKNOW = 6, L_SURF_PICKED_NEAR = 3, L_CORNER_SHARP = 1, L_SURFACE_LESS_FLAT = 0, L_SURFACE_FLAT = -1,
+  L_ONESIDE_FLAT = 5, L_EDGE_BROKEN = -2, L_NEAR_BLOCK = -3, L_BLIND_BLOCK = -4, L_MESSY = 9
+};
+
+struct FxArgs {
+  const float4 *pts;        // n_points {x, y, z, intensity-to-copy}
+  const int32_t *ranges;    // n_scans x {first, last}
+  int32_t n_scans;
+  int32_t nf, cr, max_sharp, max_flat;
+  float surf_thr, blind_thr;
+  double c175, c5, c135, c45;  // cos of the pointClassify angle gates, evaluated on the host
+  // staging: every ring writes at its own first index
+  float4 *st_sharp, *st_less_sharp, *st_flat, *st_less_flat;
+  int32_t *counts;          // [n_scans][4]
+  float *curv_out;          // optional taps, [n_points]
+  int8_t *picked_out, *label_out;
+};
+
+__device__ __forceinline__ float fx_pdist(float x, float y, float z) {
+  return sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+}
+
+// one half of pointClassify; sign < 0: points idx-0 .. idx-cr, sign > 0: idx+cr .. idx+0
+__device__ bool fx_one_sided_line(const float *sx, const float *sy, const float *sz, int idx, int cr, int sign,
+                                  float (&v)[3]) {
+  float c[3] = {0.f, 0.f, 0.f};
+  for (int q = 0; q <= cr; ++q) {
+    const int k = sign < 0 ? idx - q : idx + (cr - q);
+    c[0] = __fadd_rn(c[0], sx[k]);
+    c[1] = __fadd_rn(c[1], sy[k]);
+    c[2] = __fadd_rn(c[2], sz[k]);
+  }
+  const float inv = (float)(cr + 1);
+  c[0] = __fdiv_rn(c[0], inv); c[1] = __fdiv_rn(c[1], inv); c[2] = __fdiv_rn(c[2], inv);
+  float A[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q <= cr; ++q) {
+    const int k = sign < 0 ? idx - q : idx + (cr - q);
+    const float a0 = __fsub_rn(sx[k], c[0]), a1 = __fsub_rn(sy[k], c[1]), a2 = __fsub_rn(sz[k], c[2]);
+    A[0] = __fadd_rn(A[0], __fmul_rn(a0, a0));
+    A[3] = __fadd_rn(A[3], __fmul_rn(a0, a1));
+    A[6] = __fadd_rn(A[6], __fmul_rn(a0, a2));
+    A[4] = __fadd_rn(A[4], __fmul_rn(a1, a1));
+    A[7] = __fadd_rn(A[7], __fmul_rn(a1, a2));
+    A[8] = __fadd_rn(A[8], __fmul_rn(a2, a2));
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) A[k] = __fdiv_rn(A[k], inv);
+  float D[3], V[9];
+  lslam::eig_sym3(A, D, V);
+  if (!(D[2] > __fmul_rn(100.0f, D[1]) && D[2] > __fmul_rn(10000.0f, D[0]))) return false;
+  v[0] = V[2]; v[1] = V[5]; v[2] = V[8];
+  const float vn = fx_pdist(v[0], v[1], v[2]);
+  for (int q = 0; q <= cr; ++q) {
+    const int k = sign < 0 ? idx - q : idx + (cr - q);
+    const float a0 = __fsub_rn(sx[k], c[0]), a1 = __fsub_rn(sy[k], c[1]), a2 = __fsub_rn(sz[k], c[2]);
+    const float cx = __fsub_rn(__fmul_rn(a1, v[2]), __fmul_rn(a2, v[1]));
+    const float cy = __fsub_rn(__fmul_rn(a2, v[0]), __fmul_rn(a0, v[2]));
+    const float cz = __fsub_rn(__fmul_rn(a0, v[1]), __fmul_rn(a1, v[0]));
+    const float distance = __fdiv_rn(fx_pdist(cx, cy, cz), vn);
+    if ((double)fabsf(distance) > 0.08) return false;
+  }
+  return true;
+}
+
+__device__ int fx_point_classify(const float *sx, const float *sy, const float *sz, int idx, const FxArgs &a) {
+  float v1[3], v2[3];
+  const bool line1 = fx_one_sided_line(sx, sy, sz, idx, a.cr, -1, v1);
+  const bool line2 = fx_one_sided_line(sx, sy, sz, idx, a.cr, +1, v2);
+  if (line1 && line2) {
+    const float ab = __fadd_rn(__fadd_rn(__fmul_rn(v1[0], v2[0]), __fmul_rn(v1[1], v2[1])), __fmul_rn(v1[2], v2[2]));
+    const float dis = __fmul_rn(fx_pdist(v1[0], v1[1], v1[2]), fx_pdist(v2[0], v2[1], v2[2]));
+    const double diff = (double)__fdiv_rn(ab, dis);
+    if (diff < a.c175 || diff > a.c5) return L_SURFACE_FLAT;
+    if (diff > a.c135 && diff < a.c45) return L_CORNER_SHARP;
+  }
+  return (line1 || line2) ? L_ONESIDE_FLAT : L_MESSY;
+}
+
+__global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
+  __shared__ float sx[MAXR], sy[MAXR], sz[MAXR];
+  __shared__ float curv[MAXR];
+  __shared__ uint16_t sorted[MAXR];
+  __shared__ int8_t picked[MAXR], cls[MAXR], rlabel[MAXR];
+  __shared__ uint8_t pfl[MAXR];
+  const int ring = blockIdx.x, tid = threadIdx.x;
+  const int start = a.ranges[2 * ring], end = a.ranges[2 * ring + 1];
+  const int cr = a.cr, nf = a.nf;
+  int n_sharp = 0, n_less_sharp = 0, n_flat = 0, n_less = 0;  // lane 0 only
+  if (!(end <= start + 2 * cr)) {  // :205-207
+    const int n = end - start + 1;
+    for (int i = tid; i < n; i += FX_BLOCK) {
+      const float4 p = a.pts[start + i];
+      sx[i] = p.x; sy[i] = p.y; sz[i] = p.z;
+      picked[i] = 0;
+    }
+    __syncthreads();
+    // ---- neighbour tests of setScanBuffersFor, one per point pair (i, i+1) ------------------------
+    // bit0: cos(angle(p_i, p_i+1)) < blindThreshold   bit1: |p_i+1 - p_i|^2 > 1.0
+    // bit2: depth_i > depth_i+1                          bit3: |p_i-1 - p_i|^2 / |p_i+1 - p_i|^2 < 0.2
+    for (int i = tid; i < n - 1; i += FX_BLOCK) {
+      const float x = sx[i], y = sy[i], z = sz[i], xn = sx[i + 1], yn = sy[i + 1], zn = sz[i + 1];
+      const float ab = __fadd_rn(__fadd_rn(__fmul_rn(x, xn), __fmul_rn(y, yn)), __fmul_rn(z, zn));
+      const float d1 = fx_pdist(x, y, z), d2 = fx_pdist(xn, yn, zn);
+      const float cosang = __fdiv_rn(ab, __fmul_rn(d1, d2));
+      const float dx = __fsub_rn(xn, x), dy = __fsub_rn(yn, y), dz = __fsub_rn(zn, z);
+      const float diff_next = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      uint8_t f = 0;
+      if (cosang < a.blind_thr) f |= 1;
+      if ((double)diff_next > 1.0) f |= 2;
+      if (d1 > d2) f |= 4;
+      if (i > 0) {
+        const float px = __fsub_rn(sx[i - 1], x), py = __fsub_rn(sy[i - 1], y), pz = __fsub_rn(sz[i - 1], z);
+        const float diff_prev = __fadd_rn(__fadd_rn(__fmul_rn(px, px), __fmul_rn(py, py)), __fmul_rn(pz, pz));
+        if ((double)__fdiv_rn(diff_prev, diff_next) < 0.2) f |= 8;
+      }
+      pfl[i] = f;
+    }
+    __syncthreads();
+    if (tid == 0) {  // the marks, in the reference's order (:477-530)
+      for (int i = 0; i < cr; ++i)
+        if (pfl[i] & 1) for (int q = 0; q <= cr; ++q) picked[i + q] = L_BLIND_BLOCK;
+      for (int i = 0; i < cr; ++i)
+        if (pfl[n - 1 - i - 1] & 1) for (int q = 0; q <= cr; ++q) picked[n - 1 - i - cr + q] = L_BLIND_BLOCK;
+      for (int i = cr; i < n - 1 - cr; ++i) {
+        const uint8_t f = pfl[i];
+        if (f & 1) {
+          for (int q = 0; q < 2 * cr; ++q) picked[i - cr + 1 + q] = L_BLIND_BLOCK;
+          continue;
+        }
+        if (f & 2) {
+          if (f & 4) {
+            if (picked[i + 1] > L_NEAR_BLOCK && (f & 8)) picked[i + 1] = L_EDGE_BROKEN;
+            for (int q = 0; q < cr; ++q) picked[i - cr + 1 + q] = L_NEAR_BLOCK;
+          } else {
+            if (picked[i] > L_NEAR_BLOCK && (f & 8)) picked[i] = L_EDGE_BROKEN;
+            for (int q = 0; q < cr; ++q) picked[i + 1 + q] = L_NEAR_BLOCK;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (a.picked_out)
+      for (int i = tid; i < n; i += FX_BLOCK) a.picked_out[start + i] = picked[i];
+    // ---- regions --------------------------------------------------------------------------------
+    for (int j = 0; j < nf; ++j) {
+      const size_t S = (size_t)start + cr, E = (size_t)end - cr;
+      const int sp = (int)((S * (size_t)(nf - j) + E * (size_t)j) / (size_t)nf);
+      const int ep = (int)((S * (size_t)(nf - 1 - j) + E * (size_t)(j + 1)) / (size_t)nf) - 1;
+      if (ep <= sp) continue;  // block-uniform
+      const int rs = ep - sp + 1, r0 = sp - start;  // r0: ring-relative index of the region's first point
+      const float w = (float)(-2 * cr);
+      for (int r = tid; r < rs; r += FX_BLOCK) {  // setRegionBuffersFor, :437-454
+        const int i = r0 + r;
+        float dx = __fmul_rn(w, sx[i]), dy = __fmul_rn(w, sy[i]), dz = __fmul_rn(w, sz[i]);
+        for (int q = 1; q <= cr; ++q) {
+          dx = __fadd_rn(dx, __fadd_rn(sx[i + q], sx[i - q]));
+          dy = __fadd_rn(dy, __fadd_rn(sy[i + q], sy[i - q]));
+          dz = __fadd_rn(dz, __fadd_rn(sz[i + q], sz[i - q]));
+        }
+        curv[r] = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        rlabel[r] = L_UNKNOW;
+      }
+      __syncthreads();
+      for (int r = tid; r < rs; r += FX_BLOCK) {
+        const float c = curv[r];
+        int rank = 0;  // stable ascending order: the reference's `<=` merge sort
+        for (int k = 0; k < rs; ++k) {
+          const float ck = curv[k];
+          rank += (ck < c) || (ck == c && k < r);
+        }
+        sorted[rank] = (uint16_t)r;
+        // pointClassify for every point the third loop will visit
+        cls[r] = (c < a.surf_thr) ? (int8_t)L_UNKNOW : (int8_t)fx_point_classify(sx, sy, sz, r0 + r, a);
+        if (a.curv_out) a.curv_out[sp + r] = c;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        // flat surface features, :268-284
+        int surf_picked = 0;
+        for (int k = 0; k < rs && surf_picked < a.max_flat; ++k) {
+          const int r = sorted[k], si = r0 + r;
+          if (picked[si] != L_SURF_PICKED_NEAR && curv[r] < a.surf_thr) {
+            ++surf_picked;
+            rlabel[r] = L_SURFACE_FLAT;
+            a.st_flat[start + n_flat++] = a.pts[sp + r];
+            picked[si] = L_SURF_PICKED_NEAR;  // markAsPicked, :533-555
+            for (int q = 1; q <= cr; ++q) picked[si + q] = L_SURF_PICKED_NEAR;
+            for (int q = 1; q <= cr; ++q) picked[si - q] = L_SURF_PICKED_NEAR;
+          }
+        }
+        // less flat + broken edges, :286-302
+        for (int k = 0; k < rs; ++k) {
+          const int si = r0 + k;
+          if (curv[k] < a.surf_thr) {
+            a.st_less_flat[start + n_less++] = a.pts[sp + k];
+            if (rlabel[k] != L_SURFACE_FLAT) rlabel[k] = L_SURFACE_LESS_FLAT;
+          }
+          if (picked[si] == L_EDGE_BROKEN) {
+            const float4 p = a.pts[sp + k];
+            a.st_sharp[start + n_sharp++] = p;
+            a.st_less_sharp[start + n_less_sharp++] = p;
+            rlabel[k] = L_CORNER_SHARP;
+          }
+        }
+        // classified features in descending curvature, :304-354
+        int corner_picked = 0;
+        surf_picked = 0;
+        for (int k = rs; k > 0;) {
+          const int r = sorted[--k], si = r0 + r;
+          if (curv[r] < a.surf_thr) break;
+          const int lab = cls[r];
+          if (lab == L_SURFACE_FLAT) {
+            rlabel[r] = L_SURFACE_FLAT;
+            if (surf_picked < a.max_flat) ++surf_picked;
+            a.st_less_flat[start + n_less++] = a.pts[sp + r];
+          } else if (lab == L_CORNER_SHARP) {
+            if (picked[si] > L_EDGE_BROKEN) {
+              rlabel[r] = L_CORNER_SHARP;
+              const float4 p = a.pts[sp + r];
+              if (corner_picked < a.max_sharp) {
+                ++corner_picked;
+                a.st_sharp[start + n_sharp++] = p;
+              }
+              a.st_less_sharp[start + n_less_sharp++] = p;
+            }
+          } else if (lab == L_ONESIDE_FLAT) {
+            rlabel[r] = L_ONESIDE_FLAT;
+            const float4 p = a.pts[sp + r];
+            if (surf_picked < a.max_flat) {
+              ++surf_picked;
+              a.st_flat[start + n_flat++] = p;
+            }
+            a.st_less_flat[start + n_less++] = p;
+          }
+        }
+      }
+      __syncthreads();
+      if (a.label_out)
+        for (int r = tid; r < rs; r += FX_BLOCK) a.label_out[sp + r] = rlabel[r];
+      __syncthreads();
+    }
+  }
+  if (tid == 0) {
+    a.counts[4 * ring + 0] = n_sharp;
+    a.counts[4 * ring + 1] = n_less_sharp;
+    a.counts[4 * ring + 2] = n_flat;
+    a.counts[4 * ring + 3] = n_less;
+  }
+}
+
+// ring r's list (written from its first index) -> out[off[r] ...]; seg_out optional
+__global__ void fx_compact_kernel(const float4 *stage, const int32_t *ranges, const int32_t *off, int n_scans,
+                                  int total, float4 *out, int32_t *seg_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int lo = 0, hi = n_scans - 1;  // last ring with off <= i
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (off[mid] <= i) lo = mid; else hi = mid - 1;
+  }
+  out[i] = stage[ranges[2 * lo] + (i - off[lo])];
+  if (seg_out) seg_out[i] = lo;
+}
+
+}  // namespace
+
+extern "C" {
+
+void lslam_reg_default_params(lslam_reg_params *p) {
+  if (!p) return;
+  // RegistrationParams ctor defaults, ScanRegistration.h:49-57 / ScanRegistration.cpp:14-30
+  p->n_feature_regions = 6;
+  p->curvature_region = 5;
+  p->max_corner_sharp = 2;
+  p->max_surface_flat = 4;
+  p->less_flat_filter_size = 0.2f;
+  p->surface_curvature_threshold = 0.02f;
+  const float deg = 0.5f;                              // blindDegreeThreshold
+  const float rad = (float)(deg * M_PI / 180.0);       // deg2rad(float), util/math_utils.h:37
+  p->blind_threshold = (float)std::cos((double)rad);
+  p->reserved = 0;
+}
+
+int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, size_t stride_bytes,
+                           size_t intensity_offset_bytes, const int32_t *scan_ranges, size_t n_scans,
+                           const lslam_reg_params *params, float *sharp, float *less_sharp, float *flat,
+                           float *less_flat, size_t counts[4], float *curvature_out, int8_t *picked_out,
+                           int8_t *label_out) {
+  if (!ctx || !lslam::ctx_alive(ctx) || !scan_ranges || !counts || (n_points && !cloud) || stride_bytes < 12 ||
+      (stride_bytes & 3) || intensity_offset_bytes + 4 > stride_bytes || n_scans == 0 || n_scans > 4096) {
+    lslam::set_error("bad feature-extraction arguments");
+    return LSLAM_ERR_INVALID;
+  }
+  lslam_reg_params prm;
+  if (params) prm = *params; else lslam_reg_default_params(&prm);
+  if (prm.curvature_region < 1 || prm.curvature_region > 16 || prm.n_feature_regions < 1) {
+    lslam::set_error("bad registration parameters");
+    return LSLAM_ERR_INVALID;
+  }
+  for (int k = 0; k < 4; ++k) counts[k] = 0;
+  for (size_t s = 0; s < n_scans; ++s) {
+    const int32_t a = scan_ranges[2 * s], b = scan_ranges[2 * s + 1];
+    if (b < a) continue;  // empty ring (MultiScanRegistration.cpp:184-189 gives {size, size - 1})
+    if (a < 0 || (size_t)b >= n_points) {
+      lslam::set_error("scan range outside the cloud");
+      return LSLAM_ERR_INVALID;
+    }
+    if (b - a + 1 > MAXR) {
+      lslam::set_error("a scan ring has more points than the kernel holds in LDS (2560)");
+      return LSLAM_ERR_INVALID;
+    }
+  }
+  if (n_points == 0) return LSLAM_OK;
+  FX_TRY(hipSetDevice(lslam::ctx_device(ctx)));
+  hipStream_t s = (hipStream_t)lslam_stream(ctx);
+  // pack {x, y, z, intensity-to-copy} (toXYZI, util/pcl_util.h:30-37: the `curvature` field)
+  std::vector<float4> h(n_points);
+  const char *src = static_cast<const char *>(cloud);
+  for (size_t i = 0; i < n_points; ++i) {
+    float v[3], w;
+    std::memcpy(v, src + i * stride_bytes, 12);
+    std::memcpy(&w, src + i * stride_bytes + intensity_offset_bytes, 4);
+    h[i] = make_float4(v[0], v[1], v[2], w);
+  }
+  char *blob = nullptr;
+  const size_t np4 = n_points * sizeof(float4);
+  const size_t bytes = 5 * np4 + 2 * n_scans * 4 + 4 * n_scans * 4 + n_points * 4 + 2 * n_points + 4 * (n_scans + 1) * 4 +
+                       2 * np4 + 2 * n_points * 4 + 256;
+  FX_TRY(hipMalloc((void **)&blob, bytes));
+  char *q = blob;
+  auto take = [&](size_t b) { char *r = q; q += (b + 15) & ~(size_t)15; return r; };
+  float4 *d_pts = (float4 *)take(np4), *st0 = (float4 *)take(np4), *st1 = (float4 *)take(np4), *st2 = (float4 *)take(np4),
+         *st3 = (float4 *)take(np4);
+  int32_t *d_ranges = (int32_t *)take(2 * n_scans * 4), *d_counts = (int32_t *)take(4 * n_scans * 4);
+  float *d_curv = (float *)take(n_points * 4);
+  int8_t *d_picked = (int8_t *)take(n_points), *d_label = (int8_t *)take(n_points);
+  int32_t *d_off = (int32_t *)take(4 * (n_scans + 1) * 4);
+  float4 *d_out = (float4 *)take(np4), *d_out2 = (float4 *)take(np4);
+  int32_t *d_seg = (int32_t *)take(n_points * 4), *d_seg2 = (int32_t *)take(n_points * 4);
+  int rc = LSLAM_OK;
+  auto fail = [&](int code) { (void)hipFree(blob); return code; };
+#define FX_TRY2(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { lslam::set_error(hipGetErrorString(_e)); return fail(LSLAM_ERR_HIP); } } while (0)
+  FX_TRY2(hipMemcpyAsync(d_pts, h.data(), np4, hipMemcpyHostToDevice, s));
+  FX_TRY2(hipMemcpyAsync(d_ranges, scan_ranges, 2 * n_scans * 4, hipMemcpyHostToDevice, s));
+  if (curvature_out) FX_TRY2(hipMemsetAsync(d_curv, 0, n_points * 4, s));
+  if (picked_out) FX_TRY2(hipMemsetAsync(d_picked, 0, n_points, s));
+  if (label_out) FX_TRY2(hipMemsetAsync(d_label, L_UNKNOW, n_points, s));
+  FxArgs a{};
+  a.pts = d_pts;
+  a.ranges = d_ranges;
+  a.n_scans = (int32_t)n_scans;
+  a.nf = prm.n_feature_regions;
+  a.cr = prm.curvature_region;
+  a.max_sharp = prm.max_corner_sharp;
+  a.max_flat = prm.max_surface_flat;
+  a.surf_thr = prm.surface_curvature_threshold;
+  a.blind_thr = prm.blind_threshold;
+  a.c175 = std::cos(175.0 * M_PI / 180.0);  // deg2rad(double), util/math_utils.h:29
+  a.c5 = std::cos(5.0 * M_PI / 180.0);
+  a.c135 = std::cos(135.0 * M_PI / 180.0);
+  a.c45 = std::cos(45.0 * M_PI / 180.0);
+  a.st_sharp = st0; a.st_less_sharp = st1; a.st_flat = st2; a.st_less_flat = st3;
+  a.counts = d_counts;
+  a.curv_out = curvature_out ? d_curv : nullptr;
+  a.picked_out = picked_out ? d_picked : nullptr;
+  a.label_out = label_out ? d_label : nullptr;
+  hipLaunchKernelGGL(fx_ring_kernel, dim3((unsigned)n_scans), dim3(FX_BLOCK), 0, s, a);
+  std::vector<int32_t> hc(4 * n_scans);
+  FX_TRY2(hipMemcpyAsync(hc.data(), d_counts, 4 * n_scans * 4, hipMemcpyDeviceToHost, s));
+  FX_TRY2(hipStreamSynchronize(s));
+  // per-list offsets of the rings, then compaction in ring order
+  std::vector<int32_t> off(4 * (n_scans + 1));
+  for (int k = 0; k < 4; ++k) {
+    int32_t run = 0;
+    for (size_t r = 0; r < n_scans; ++r) {
+      off[k * (n_scans + 1) + r] = run;
+      run += hc[4 * r + k];
+    }
+    off[k * (n_scans + 1) + n_scans] = run;
+  }
+  FX_TRY2(hipMemcpyAsync(d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, s));
+  const float4 *stage[4] = {st0, st1, st2, st3};
+  float *outs[3] = {sharp, less_sharp, flat};
+  for (int k = 0; k < 4 && rc == LSLAM_OK; ++k) {
+    const int32_t total = off[k * (n_scans + 1) + n_scans];
+    if (k < 3) counts[k] = (size_t)total;
+    if (total == 0) continue;
+    hipLaunchKernelGGL(fx_compact_kernel, dim3((total + 255) / 256), dim3(256), 0, s, stage[k], d_ranges,
+                       d_off + k * (n_scans + 1), (int)n_scans, total, d_out, k == 3 ? d_seg : nullptr);
+    if (k < 3) {
+      if (outs[k]) FX_TRY2(hipMemcpyAsync(outs[k], d_out, (size_t)total * sizeof(float4), hipMemcpyDeviceToHost, s));
+      FX_TRY2(hipStreamSynchronize(s));
+    } else {
+      size_t m = 0;  // :398-407: VoxelGrid(lessFlatFilterSize) per ring
+      rc = lslam::voxel_filter_segments(s, d_out, d_seg, (size_t)total, (int)n_scans, prm.less_flat_filter_size, d_out2,
+                                        d_seg2, &m);
+      if (rc == LSLAM_OK) {
+        counts[3] = m;
+        if (less_flat && m) FX_TRY2(hipMemcpyAsync(less_flat, d_out2, m * sizeof(float4), hipMemcpyDeviceToHost, s));
+      }
+    }
+  }
+  if (rc == LSLAM_OK) {
+    if (curvature_out) FX_TRY2(hipMemcpyAsync(curvature_out, d_curv, n_points * 4, hipMemcpyDeviceToHost, s));
+    if (picked_out) FX_TRY2(hipMemcpyAsync(picked_out, d_picked, n_points, hipMemcpyDeviceToHost, s));
+    if (label_out) FX_TRY2(hipMemcpyAsync(label_out, d_label, n_points, hipMemcpyDeviceToHost, s));
+    FX_TRY2(hipStreamSynchronize(s));
+  }
+  (void)hipFree(blob);
+  return rc;
+}
+
+}  // extern "C"

@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -557,6 +558,28 @@ int gather_surround(lslam_fmap *fm, int t, int index_in_w, size_t *n_out) {
 }
 
 }  // namespace
+
+namespace lslam {
+// VoxelGrid per segment for other translation units (feature extraction: one segment per scan ring):
+// in_seg[i] is the segment of point i (ascending or not), every segment is filtered with `leaf`;
+// output ordered by segment, inside a segment in VoxelGrid order.  Scratch is cached per process.
+int voxel_filter_segments(hipStream_t s, const float4 *in_pts, const int32_t *in_seg, size_t n, int nseg, float leaf,
+                          float4 *out_pts, int32_t *out_seg, size_t *n_out) {
+  static Scratch sc;
+  static Buf<uint8_t> all;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  FM_TRY(all.reserve((size_t)nseg));
+  FM_TRY(hipMemsetAsync(all.p, 1, (size_t)nseg, s));
+  KeyParams kp{};
+  kp.W = nseg; kp.H = 1; kp.D = 1;
+  kp.cube_size = 1.0f;
+  kp.inv_leaf = 1.0f / leaf;
+  kp.axis_bits = 1;
+  kp.single = 0;
+  return run_pipeline(s, sc, in_pts, in_seg, n, kp, nseg, all.p, out_pts, out_seg, n_out);
+}
+}  // namespace lslam
 
 extern "C" {
 

@@ -1,0 +1,44 @@
+"""Host-side mirror of the feature-extraction front end: ``ScanRegistration::extractFeatures``
+(/root/reference/L_SLAM/src/odometry/ScanRegistration.cpp:190-425) over the C ABI
+(``lslam_extract_features``, kernels in ``csrc/lslam_features.hip``)."""
+import ctypes as C
+
+import numpy as np
+
+from .capi import LslamError, LslamRegParams, c_float_p, c_int32_p
+
+
+def default_params(ctx):
+    p = LslamRegParams()
+    ctx.lib.lslam_reg_default_params(C.byref(p))
+    return p
+
+
+def extract_features(ctx, cloud, scan_ranges, params=None, intensity_field=3, taps=False):
+    """cloud: (n, >=4) float32, xyz first, ``intensity_field`` = column copied to the outputs'
+    intensity; scan_ranges: (rings, 2) inclusive [first, last].  Returns a dict with the four feature
+    clouds ``sharp``, ``less_sharp``, ``flat``, ``less_flat`` ((m, 4) each) and, with ``taps``, the
+    per-point ``curvature``, ``picked`` (marks after setScanBuffersFor) and ``label``."""
+    a = np.ascontiguousarray(cloud, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] < 4:
+        raise ValueError("cloud must be (n, >=4) float32")
+    r = np.ascontiguousarray(scan_ranges, dtype=np.int32).reshape(-1, 2)
+    n = len(a)
+    outs = [np.zeros((n, 4), np.float32) for _ in range(4)]
+    counts = (C.c_size_t * 4)()
+    curv = np.zeros(n, np.float32) if taps else None
+    picked = np.zeros(n, np.int8) if taps else None
+    label = np.zeros(n, np.int8) if taps else None
+    fp = lambda x: x.ctypes.data_as(c_float_p) if x is not None else None
+    bp = lambda x: x.ctypes.data_as(C.POINTER(C.c_int8)) if x is not None else None
+    rc = ctx.lib.lslam_extract_features(ctx.h, a.ctypes.data_as(C.c_void_p), n, a.shape[1] * 4,
+                                        int(intensity_field) * 4, r.ctypes.data_as(c_int32_p), len(r),
+                                        C.byref(params) if params is not None else None, fp(outs[0]), fp(outs[1]),
+                                        fp(outs[2]), fp(outs[3]), counts, fp(curv), bp(picked), bp(label))
+    if rc < 0:
+        raise LslamError(rc, ctx.lib.lslam_last_error().decode())
+    res = dict(sharp=outs[0][:counts[0]].copy(), less_sharp=outs[1][:counts[1]].copy(),
+               flat=outs[2][:counts[2]].copy(), less_flat=outs[3][:counts[3]].copy())
+    if taps:
+        res.update(curvature=curv, picked=picked, label=label)
+    return res

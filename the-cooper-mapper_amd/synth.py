@@ -106,7 +106,7 @@ def pose_to_Rt(pose):
 
 
 def make_scan(world, rings=64, azimuth_steps=1800, gt_pose=(0, 0, 0.3, 3.0, -2.0, SENSOR_HEIGHT),
-              noise_sigma=0.02, seed=1234, corner_band=0.12):
+              noise_sigma=0.02, seed=1234, corner_band=0.12, full=False):
     """Ray-cast one scan.  Returns (corner, surf) as (n,4) float32 {x,y,z,intensity} in the
     SENSOR frame (ring-major, azimuth-minor order) and the float64 ground-truth pose.
     intensity = ring id + relative time (util/pcl_util.h:30-37 semantics)."""
@@ -141,6 +141,16 @@ def make_scan(world, rings=64, azimuth_steps=1800, gt_pose=(0, 0, 0.3, 3.0, -2.0
     pts = np.concatenate([p_s, (ring + reltime)[:, None]], axis=1).astype(np.float32)
     corner = pts[valid & is_corner]
     surf = pts[valid & ~is_corner]
+    if full:
+        # the ring-sorted full-resolution cloud MultiScanRegistration::process hands to
+        # extractFeatures, with its per-ring [first, last] index ranges
+        # (MultiScanRegistration.cpp:178-190); invalid returns are dropped like NaN points are
+        cloud = pts[valid]
+        cnt = np.bincount(ring[valid], minlength=rings)
+        first = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+        last = np.where(np.cumsum(cnt) > 0, np.cumsum(cnt) - 1, 0)
+        ranges = np.stack([first, last], axis=1).astype(np.int32)
+        return corner, surf, gt_pose, cloud, ranges
     return corner, surf, gt_pose
 
 

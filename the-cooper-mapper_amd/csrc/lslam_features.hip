@@ -54,8 +54,9 @@ struct FxArgs {
   int32_t nf, cr, max_sharp, max_flat;
   float surf_thr, blind_thr;
   double c175, c5, c135, c45;  // cos of the pointClassify angle gates, evaluated on the host
-  // staging: every ring writes at its own first index
-  float4 *st_sharp, *st_less_sharp, *st_flat, *st_less_flat;
+  // staging: every ring writes, from its own first index on, the cloud indices of its picks (index
+  // stores only: the sequential picking never waits for a global load)
+  int32_t *st_sharp, *st_less_sharp, *st_flat, *st_less_flat;
   int32_t *counts;          // [n_scans][4]
   float *curv_out;          // optional taps, [n_points]
   int8_t *picked_out, *label_out;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
   const int ring = blockIdx.x, tid = threadIdx.x;
   const int start = a.ranges[2 * ring], end = a.ranges[2 * ring + 1];
   const int cr = a.cr, nf = a.nf;
-  int n_sharp = 0, n_less_sharp = 0, n_flat = 0, n_less = 0;  // lane 0 only
+  int n_sharp = 0, n_less_sharp = 0, n_flat = 0, n_less = 0;  // uniform across wavefront 0
   if (!(end <= start + 2 * cr)) {  // :205-207
     const int n = end - start + 1;
     for (int i = tid; i < n; i += FX_BLOCK) {
@@ -166,19 +167,28 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
         if (pfl[i] & 1) for (int q = 0; q <= cr; ++q) picked[i + q] = L_BLIND_BLOCK;
       for (int i = 0; i < cr; ++i)
         if (pfl[n - 1 - i - 1] & 1) for (int q = 0; q <= cr; ++q) picked[n - 1 - i - cr + q] = L_BLIND_BLOCK;
-      for (int i = cr; i < n - 1 - cr; ++i) {
-        const uint8_t f = pfl[i];
-        if (f & 1) {
-          for (int q = 0; q < 2 * cr; ++q) picked[i - cr + 1 + q] = L_BLIND_BLOCK;
-          continue;
-        }
-        if (f & 2) {
-          if (f & 4) {
-            if (picked[i + 1] > L_NEAR_BLOCK && (f & 8)) picked[i + 1] = L_EDGE_BROKEN;
-            for (int q = 0; q < cr; ++q) picked[i - cr + 1 + q] = L_NEAR_BLOCK;
-          } else {
-            if (picked[i] > L_NEAR_BLOCK && (f & 8)) picked[i] = L_EDGE_BROKEN;
-            for (int q = 0; q < cr; ++q) picked[i + 1 + q] = L_NEAR_BLOCK;
+    }
+    if (tid < 64) {
+      // the main marking loop (:497-530) is a chain of dependent LDS round trips if written naively;
+      // the flags are fetched 64 at a time (one per lane) and handed to lane 0 by readlane
+      for (int base = cr; base < n - 1 - cr; base += 64) {
+        const int mine = base + tid;
+        const int fl = (mine < n - 1 - cr) ? (int)pfl[mine] : 0;
+        const int cnt = min(64, n - 1 - cr - base);
+        for (int jx = 0; jx < cnt; ++jx) {
+          const int f = __builtin_amdgcn_readlane(fl, jx);
+          if ((f & 3) == 0) continue;  // wave-uniform
+          if (tid == 0) {
+            const int i = base + jx;
+            if (f & 1) {
+              for (int q = 0; q < 2 * cr; ++q) picked[i - cr + 1 + q] = L_BLIND_BLOCK;
+            } else if (f & 4) {
+              if (picked[i + 1] > L_NEAR_BLOCK && (f & 8)) picked[i + 1] = L_EDGE_BROKEN;
+              for (int q = 0; q < cr; ++q) picked[i - cr + 1 + q] = L_NEAR_BLOCK;
+            } else {
+              if (picked[i] > L_NEAR_BLOCK && (f & 8)) picked[i] = L_EDGE_BROKEN;
+              for (int q = 0; q < cr; ++q) picked[i + 1 + q] = L_NEAR_BLOCK;
+            }
           }
         }
       }
@@ -219,64 +229,80 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
         if (a.curv_out) a.curv_out[sp + r] = c;
       }
       __syncthreads();
-      if (tid == 0) {
-        // flat surface features, :268-284
+      if (tid < 64) {  // wavefront 0; the counters are wave-uniform
+        const unsigned long long lt_mask = tid == 0 ? 0ull : (~0ull >> (64 - tid));
+        // flat surface features, :268-284 -- sequential: every pick excludes its neighbourhood
         int surf_picked = 0;
-        for (int k = 0; k < rs && surf_picked < a.max_flat; ++k) {
-          const int r = sorted[k], si = r0 + r;
-          if (picked[si] != L_SURF_PICKED_NEAR && curv[r] < a.surf_thr) {
-            ++surf_picked;
-            rlabel[r] = L_SURFACE_FLAT;
-            a.st_flat[start + n_flat++] = a.pts[sp + r];
-            picked[si] = L_SURF_PICKED_NEAR;  // markAsPicked, :533-555
-            for (int q = 1; q <= cr; ++q) picked[si + q] = L_SURF_PICKED_NEAR;
-            for (int q = 1; q <= cr; ++q) picked[si - q] = L_SURF_PICKED_NEAR;
+        if (tid == 0) {
+          for (int k = 0; k < rs && surf_picked < a.max_flat; ++k) {
+            const int r = sorted[k], si = r0 + r;
+            if (picked[si] != L_SURF_PICKED_NEAR && curv[r] < a.surf_thr) {
+              ++surf_picked;
+              rlabel[r] = L_SURFACE_FLAT;
+              a.st_flat[start + n_flat + surf_picked - 1] = sp + r;
+              picked[si] = L_SURF_PICKED_NEAR;  // markAsPicked, :533-555
+              for (int q = 1; q <= cr; ++q) picked[si + q] = L_SURF_PICKED_NEAR;
+              for (int q = 1; q <= cr; ++q) picked[si - q] = L_SURF_PICKED_NEAR;
+            }
           }
         }
-        // less flat + broken edges, :286-302
-        for (int k = 0; k < rs; ++k) {
-          const int si = r0 + k;
-          if (curv[k] < a.surf_thr) {
-            a.st_less_flat[start + n_less++] = a.pts[sp + k];
+        n_flat += __builtin_amdgcn_readfirstlane(surf_picked);  // lane 0's count, to every lane
+        // less flat + broken edges, :286-302 -- an ordered compaction, 64 region points at a time
+        int n_low = 0;
+        for (int base = 0; base < rs; base += 64) {
+          const int k = base + tid;
+          const bool valid = k < rs;
+          const bool low = valid && curv[valid ? k : 0] < a.surf_thr;
+          const bool eb = valid && picked[r0 + (valid ? k : 0)] == L_EDGE_BROKEN;
+          const unsigned long long m1 = __ballot(low), m2 = __ballot(eb);
+          if (low) {
+            a.st_less_flat[start + n_less + __popcll(m1 & lt_mask)] = sp + k;
             if (rlabel[k] != L_SURFACE_FLAT) rlabel[k] = L_SURFACE_LESS_FLAT;
           }
-          if (picked[si] == L_EDGE_BROKEN) {
-            const float4 p = a.pts[sp + k];
-            a.st_sharp[start + n_sharp++] = p;
-            a.st_less_sharp[start + n_less_sharp++] = p;
+          if (eb) {
+            const int pos = __popcll(m2 & lt_mask);
+            a.st_sharp[start + n_sharp + pos] = sp + k;
+            a.st_less_sharp[start + n_less_sharp + pos] = sp + k;
             rlabel[k] = L_CORNER_SHARP;
           }
+          n_less += __popcll(m1);
+          n_low += __popcll(m1);
+          n_sharp += __popcll(m2);
+          n_less_sharp += __popcll(m2);
         }
-        // classified features in descending curvature, :304-354
-        int corner_picked = 0;
-        surf_picked = 0;
-        for (int k = rs; k > 0;) {
-          const int r = sorted[--k], si = r0 + r;
-          if (curv[r] < a.surf_thr) break;
-          const int lab = cls[r];
-          if (lab == L_SURFACE_FLAT) {
-            rlabel[r] = L_SURFACE_FLAT;
-            if (surf_picked < a.max_flat) ++surf_picked;
-            a.st_less_flat[start + n_less++] = a.pts[sp + r];
-          } else if (lab == L_CORNER_SHARP) {
-            if (picked[si] > L_EDGE_BROKEN) {
-              rlabel[r] = L_CORNER_SHARP;
-              const float4 p = a.pts[sp + r];
-              if (corner_picked < a.max_sharp) {
-                ++corner_picked;
-                a.st_sharp[start + n_sharp++] = p;
-              }
-              a.st_less_sharp[start + n_less_sharp++] = p;
-            }
-          } else if (lab == L_ONESIDE_FLAT) {
-            rlabel[r] = L_ONESIDE_FLAT;
-            const float4 p = a.pts[sp + r];
-            if (surf_picked < a.max_flat) {
-              ++surf_picked;
-              a.st_flat[start + n_flat++] = p;
-            }
-            a.st_less_flat[start + n_less++] = p;
-          }
+        // classified features in descending curvature, :304-354: the loop only reads the marks and
+        // counts its own picks, so it is an ordered compaction too (the saturating counters of the
+        // reference equal min(max, number of earlier candidates of that kind))
+        int run_surf = 0, run_corner = 0;
+        const int T = rs - n_low;  // points with curvature >= threshold: sorted[n_low .. rs)
+        for (int base = 0; base < T; base += 64) {
+          const int t = base + tid;
+          const bool valid = t < T;
+          const int r = sorted[valid ? rs - 1 - t : 0], si = r0 + r;
+          const int lab = valid ? (int)cls[r] : L_MESSY;
+          const bool is_f = lab == L_SURFACE_FLAT, is_o = lab == L_ONESIDE_FLAT;
+          const bool is_c = lab == L_CORNER_SHARP && picked[si] > L_EDGE_BROKEN;
+          const unsigned long long ms = __ballot(is_f || is_o), mc = __ballot(is_c), mo = __ballot(is_o);
+          const int surf_before = run_surf + __popcll(ms & lt_mask);
+          const int corner_before = run_corner + __popcll(mc & lt_mask);
+          // flat picks among the one-side-flat candidates: those with fewer than max earlier surf-like ones
+          const bool flat_pick = is_o && surf_before < a.max_flat;
+          const bool sharp_pick = is_c && corner_before < a.max_sharp;
+          const unsigned long long mfp = __ballot(flat_pick), msp = __ballot(sharp_pick);
+          if (is_f || is_o) a.st_less_flat[start + n_less + __popcll(ms & lt_mask)] = sp + r;
+          if (flat_pick) a.st_flat[start + n_flat + __popcll(mfp & lt_mask)] = sp + r;
+          if (is_c) a.st_less_sharp[start + n_less_sharp + __popcll(mc & lt_mask)] = sp + r;
+          if (sharp_pick) a.st_sharp[start + n_sharp + __popcll(msp & lt_mask)] = sp + r;
+          if (is_f) rlabel[r] = L_SURFACE_FLAT;
+          else if (is_o) rlabel[r] = L_ONESIDE_FLAT;
+          else if (is_c) rlabel[r] = L_CORNER_SHARP;
+          (void)mo;
+          n_less += __popcll(ms);
+          n_flat += __popcll(mfp);
+          n_less_sharp += __popcll(mc);
+          n_sharp += __popcll(msp);
+          run_surf += __popcll(ms);
+          run_corner += __popcll(mc);
         }
       }
       __syncthreads();
@@ -294,8 +320,8 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
 }
 
 // ring r's list (written from its first index) -> out[off[r] ...]; seg_out optional
-__global__ void fx_compact_kernel(const float4 *stage, const int32_t *ranges, const int32_t *off, int n_scans,
-                                  int total, float4 *out, int32_t *seg_out) {
+__global__ void fx_compact_kernel(const float4 *pts, const int32_t *stage, const int32_t *ranges, const int32_t *off,
+                                  int n_scans, int total, float4 *out, int32_t *seg_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   int lo = 0, hi = n_scans - 1;  // last ring with off <= i
@@ -303,7 +329,7 @@ __global__ void fx_compact_kernel(const float4 *stage, const int32_t *ranges, co
     const int mid = (lo + hi + 1) >> 1;
     if (off[mid] <= i) lo = mid; else hi = mid - 1;
   }
-  out[i] = stage[ranges[2 * lo] + (i - off[lo])];
+  out[i] = pts[stage[ranges[2 * lo] + (i - off[lo])]];
   if (seg_out) seg_out[i] = lo;
 }
 
@@ -374,8 +400,8 @@ int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, s
   FX_TRY(hipMalloc((void **)&blob, bytes));
   char *q = blob;
   auto take = [&](size_t b) { char *r = q; q += (b + 15) & ~(size_t)15; return r; };
-  float4 *d_pts = (float4 *)take(np4), *st0 = (float4 *)take(np4), *st1 = (float4 *)take(np4), *st2 = (float4 *)take(np4),
-         *st3 = (float4 *)take(np4);
+  float4 *d_pts = (float4 *)take(np4);
+  int32_t *st0 = (int32_t *)take(np4), *st1 = (int32_t *)take(np4), *st2 = (int32_t *)take(np4), *st3 = (int32_t *)take(np4);
   int32_t *d_ranges = (int32_t *)take(2 * n_scans * 4), *d_counts = (int32_t *)take(4 * n_scans * 4);
   float *d_curv = (float *)take(n_points * 4);
   int8_t *d_picked = (int8_t *)take(n_points), *d_label = (int8_t *)take(n_points);
@@ -424,13 +450,13 @@ int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, s
     off[k * (n_scans + 1) + n_scans] = run;
   }
   FX_TRY2(hipMemcpyAsync(d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, s));
-  const float4 *stage[4] = {st0, st1, st2, st3};
+  const int32_t *stage[4] = {st0, st1, st2, st3};
   float *outs[3] = {sharp, less_sharp, flat};
   for (int k = 0; k < 4 && rc == LSLAM_OK; ++k) {
     const int32_t total = off[k * (n_scans + 1) + n_scans];
     if (k < 3) counts[k] = (size_t)total;
     if (total == 0) continue;
-    hipLaunchKernelGGL(fx_compact_kernel, dim3((total + 255) / 256), dim3(256), 0, s, stage[k], d_ranges,
+    hipLaunchKernelGGL(fx_compact_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d_pts, stage[k], d_ranges,
                        d_off + k * (n_scans + 1), (int)n_scans, total, d_out, k == 3 ? d_seg : nullptr);
     if (k < 3) {
       if (outs[k]) FX_TRY2(hipMemcpyAsync(outs[k], d_out, (size_t)total * sizeof(float4), hipMemcpyDeviceToHost, s));

@@ -140,16 +140,38 @@ __device__ __forceinline__ float ordered_float(int32_t i) { return __int_as_floa
 __global__ void fm_minmax_kernel(const float4 *pts, const int32_t *cube, int n, const uint8_t *flags, int32_t *cmin,
                                  int32_t *cmax) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int32_t c = cube[i];
-  if (c < 0 || !flags[c]) return;
-  const float4 p = pts[i];
-  const float v[3] = {p.x, p.y, p.z};
+  const int32_t c = (i < n) ? cube[i] : -1;
+  const bool on = c >= 0 && flags[c];
+  int32_t o[3] = {0, 0, 0};
+  if (on) {
+    const float4 p = pts[i];
+    o[0] = ordered_int(p.x); o[1] = ordered_int(p.y); o[2] = ordered_int(p.z);
+  }
+  // points arrive cube after cube, so a wavefront usually sits inside one cube: reduce there first
+  // (64 lanes hammering the same six words is what made this kernel slow)
+  const int32_t c0 = __builtin_amdgcn_readfirstlane(c);
+  if (__all(on && c == c0)) {
+    int32_t lo[3] = {o[0], o[1], o[2]}, hi[3] = {o[0], o[1], o[2]};
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        lo[d] = min(lo[d], __shfl_xor(lo[d], s, 64));
+        hi[d] = max(hi[d], __shfl_xor(hi[d], s, 64));
+      }
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        if (lo[d] < cmin[3 * c0 + d]) atomicMin(&cmin[3 * c0 + d], lo[d]);
+        if (hi[d] > cmax[3 * c0 + d]) atomicMax(&cmax[3 * c0 + d], hi[d]);
+      }
+    return;
+  }
+  if (!on) return;
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    const int32_t o = ordered_int(v[d]);
-    if (o < cmin[3 * c + d]) atomicMin(&cmin[3 * c + d], o);
-    if (o > cmax[3 * c + d]) atomicMax(&cmax[3 * c + d], o);
+    if (o[d] < cmin[3 * c + d]) atomicMin(&cmin[3 * c + d], o[d]);
+    if (o[d] > cmax[3 * c + d]) atomicMax(&cmax[3 * c + d], o[d]);
   }
 }
 

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Feature-extraction timing (row n2): lslam_extract_features on a 64x1800 sweep vs the CPU oracle."""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+pkg = importlib.import_module("the-cooper-mapper_amd")
+synth = importlib.import_module("the-cooper-mapper_amd.synth")
+w = synth.World(half_extent=175.0)
+ctx = pkg.Context(0)
+for rings in (16, 64):
+    c, s, gt, cloud, ranges = synth.make_scan(w, rings, 1800, full=True)
+    for _ in range(3):
+        out = pkg.scan_registration.extract_features(ctx, cloud, ranges)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        out = pkg.scan_registration.extract_features(ctx, cloud, ranges)
+    dt = (time.perf_counter() - t0) / 10
+    line = "%d rings, %d points: GPU %.2f ms per sweep (host buffers in and out)" % (rings, len(cloud), 1e3 * dt)
+    if "--cpu" in sys.argv:
+        from oracle_lib import Oracle
+        o = Oracle(native=True)
+        t0 = time.perf_counter(); ref = o.extract_features(cloud, ranges); cdt = time.perf_counter() - t0
+        line += "; CPU oracle %.1f ms" % (1e3 * cdt)
+    print(line, {k: len(v) for k, v in out.items()})

@@ -369,6 +369,15 @@ int32_t lslam_pg_num_offdiag(const lslam_pg *pg);
 /* SolverG2O::optimize (solver_g2o.cpp:79-95): up to max_iters LM iterations. */
 int lslam_pg_optimize(lslam_pg *pg, int32_t max_iters, lslam_pg_stats *stats);
 int lslam_pg_get_poses(lslam_pg *pg, double *poses7);
+/* SolverG2O::save (solver_g2o.cpp:97-100): the graph with its current estimates in g2o's text
+ * format (VERTEX_SE3:QUAT / FIX / EDGE_SE3:QUAT with the 21 upper-triangular information
+ * entries) -- the route to cross-check this solver against an external g2o. */
+int lslam_pg_save_g2o(lslam_pg *pg, const char *path);
+/* Reader for that format (host only).  *n_vertices / *n_edges: in = capacity of the arrays, out =
+ * what the file holds (call with NULL arrays to size them); vertex ids are renumbered 0..n-1 in
+ * order of appearance; *fixed_vertex = first FIX id or -1. */
+int lslam_g2o_read(const char *path, int32_t *n_vertices, double *poses7, int32_t *n_edges, int32_t *ij,
+                   double *meas7, double *info36, int32_t *fixed_vertex);
 /* Parity taps: the assembled system at the current estimate (diag[n_v*36],
  * off[n_off*36] with its (i<j) pairs off_ij[n_off*2], b[n_v*6], chi2), and one damped
  * solve (H + lambda I) dx = b. Any output may be NULL. */

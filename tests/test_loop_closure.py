@@ -1,0 +1,70 @@
+"""Loop-closure front end (pose_graph/loop_detector.hpp): the candidate gating on the CPU, a full
+detect -> scanMatchLocal -> Loop on the GPU."""
+import numpy as np
+import pytest
+
+
+def _kf(pkg, x, z, accum, y=0.0):
+    T = np.eye(4)
+    T[:3, 3] = (x, y, z)
+    return pkg.KeyFrame(T, accum, np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32))
+
+
+def test_candidate_gating_follows_the_reference(pkg):
+    det = pkg.LoopDetector()
+    # a straight 40 m run, then back over the start: keyframe spacing 1 m of travel
+    kfs = [_kf(pkg, float(i), 0.0, float(i)) for i in range(41)]
+    kfs += [_kf(pkg, 40.0 - 0.5 * i, 1.0, 40.0 + 2.0 * i, y=7.0 * i) for i in range(1, 40)]
+    det.update_trajectory(kfs)
+    new = _kf(pkg, 2.0, 1.0, 200.0, y=3.0)
+    idx, d2 = det.radius_search(np.array([2.0, 0.0, 1.0], np.float32), 5.0)
+    # "radius" 5.0 is compared with squared distances: only points within sqrt(5) m, y ignored
+    assert len(idx) > 0 and (d2 < 5.0).all() and np.all(np.diff(d2) >= 0)
+    assert all(abs(kfs[i].estimate[0, 3] - 2.0) <= np.sqrt(5.0) + 1e-6 for i in idx)
+    cand = det.find_nearest_candidates(kfs, new)
+    # at most 6, all travelled >= 30 m before `new`, within 5 m of travel of the first candidate
+    assert 0 < len(cand) <= 6
+    assert all(new.accum_distance - c.accum_distance >= 30.0 for c in cand)
+    assert all(abs(c.accum_distance - cand[0].accum_distance) <= 5.0 for c in cand)
+    # too little travel since the last loop: no candidates at all
+    det.last_loop_accum_distance = 198.5
+    assert det.find_nearest_candidates(kfs, new) == []
+    det.last_loop_accum_distance = 0.0
+    # keyframes travelled less than 30 m ago are skipped
+    recent = _kf(pkg, 2.0, 1.0, 20.0)
+    assert det.find_nearest_candidates(kfs, recent) == []
+    # nothing within sqrt(5) m
+    far = _kf(pkg, 500.0, 0.0, 500.0)
+    assert det.find_nearest_candidates(kfs, far) == []
+
+
+@pytest.mark.gpu
+def test_detect_nearest_closes_a_loop(pkg, ctx, synth, small_problem):
+    """Two candidate keyframes around a place, a new keyframe revisiting it with a drifted estimate:
+    the detector gates them in, merges the candidates' clouds, aligns with scanMatchLocal and returns
+    the relative pose of the revisit -- close to the ground truth, far closer than the drifted guess."""
+    world = small_problem["world"]
+    def frame(pose6, seed, accum, drift=None):
+        c, s, gt = synth.make_scan(world, 16, 900, gt_pose=pose6, seed=seed)
+        R, t = synth.pose_to_Rt(gt)
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = R, t
+        est = T.copy()
+        if drift is not None:
+            est[:3, 3] += drift
+        return pkg.KeyFrame(est, accum, c, s), T
+    k0, T0 = frame((0, 0, 0.30, 3.0, -2.0, synth.SENSOR_HEIGHT), 11, 0.0)
+    k1, T1 = frame((0, 0, 0.32, 3.8, -2.2, synth.SENSOR_HEIGHT), 12, 1.0)
+    filler = [_kf(pkg, 50.0 + i, 0.0, 2.0 + i) for i in range(3)]
+    new, Tn = frame((0, 0, 0.35, 3.4, -1.8, synth.SENSOR_HEIGHT), 13, 60.0, drift=np.array([0.25, -0.2, 0.0]))
+    det = pkg.LoopDetector(ctx=ctx)
+    loops = det.detect_nearest([k0, k1] + filler, [new])
+    assert len(loops) == 1 and det.get_loop_count() == 1
+    lp = loops[0]
+    assert lp.key1 in (k0, k1) and lp.key2 is new
+    T_ref = {id(k0): T0, id(k1): T1}[id(lp.key1)]
+    truth = np.linalg.inv(T_ref) @ Tn
+    guess = np.linalg.inv(lp.key1.estimate) @ new.estimate
+    err = np.abs(lp.relative_pose[:3, 3] - truth[:3, 3]).max()
+    assert err < 0.05 and err < 0.3 * np.abs(guess[:3, 3] - truth[:3, 3]).max()
+    assert det.last_loop_accum_distance == 60.0

@@ -20,7 +20,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <fstream>
+#include <iomanip>
 #include <map>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -947,6 +950,102 @@ int lslam_pg_get_poses(lslam_pg *pg, double *poses7) {
   PG_TRY(hipSetDevice(pg->device));
   PG_TRY(hipMemcpyAsync(poses7, pg->d_poses, (size_t)pg->n_v * 7 * 8, hipMemcpyDeviceToHost, pg->stream));
   PG_TRY(hipStreamSynchronize(pg->stream));
+  return LSLAM_OK;
+}
+
+// SolverG2O::save (solver_g2o.cpp:97-100 -> g2o::OptimizableGraph::save): the graph in g2o's text
+// format -- VERTEX_SE3:QUAT id x y z qx qy qz qw, FIX id, EDGE_SE3:QUAT i j x y z qx qy qz qw and
+// the 21 upper-triangular information entries, row by row -- with the current estimates.  Numbers are
+// written with 17 significant digits (g2o uses the stream default of 6; readers accept both).
+int lslam_pg_save_g2o(lslam_pg *pg, const char *path) {
+  if (!pg || !path) return LSLAM_ERR_INVALID;
+  PG_TRY(hipSetDevice(pg->device));
+  std::vector<double> poses((size_t)pg->n_v * 7), meas((size_t)pg->n_e * 7), info((size_t)pg->n_e * 36);
+  PG_TRY(hipMemcpyAsync(poses.data(), pg->d_poses, poses.size() * 8, hipMemcpyDeviceToHost, pg->stream));
+  if (pg->n_e) {
+    PG_TRY(hipMemcpyAsync(meas.data(), pg->d_meas, meas.size() * 8, hipMemcpyDeviceToHost, pg->stream));
+    PG_TRY(hipMemcpyAsync(info.data(), pg->d_info, info.size() * 8, hipMemcpyDeviceToHost, pg->stream));
+  }
+  PG_TRY(hipStreamSynchronize(pg->stream));
+  std::ofstream ofs(path);
+  if (!ofs) {
+    g_pg_err = std::string("cannot open ") + path;
+    return LSLAM_ERR_INVALID;
+  }
+  ofs << std::setprecision(17);
+  for (int v = 0; v < pg->n_v; ++v) {
+    ofs << "VERTEX_SE3:QUAT " << v;
+    for (int k = 0; k < 7; ++k) ofs << ' ' << poses[(size_t)v * 7 + k];
+    ofs << '\n';
+    if (v == pg->fixed) ofs << "FIX " << v << '\n';
+  }
+  for (int e = 0; e < pg->n_e; ++e) {
+    ofs << "EDGE_SE3:QUAT " << pg->h_ij[2 * e] << ' ' << pg->h_ij[2 * e + 1];
+    for (int k = 0; k < 7; ++k) ofs << ' ' << meas[(size_t)e * 7 + k];
+    for (int r = 0; r < 6; ++r)
+      for (int c = r; c < 6; ++c) ofs << ' ' << info[(size_t)e * 36 + r * 6 + c];
+    ofs << '\n';
+  }
+  return ofs.good() ? LSLAM_OK : LSLAM_ERR_INVALID;
+}
+
+// Reader for the same format (host only, no device needed).  Two-call pattern: with NULL arrays it
+// returns the counts; vertex ids are mapped to 0..n-1 in order of appearance.
+int lslam_g2o_read(const char *path, int32_t *n_vertices, double *poses7, int32_t *n_edges, int32_t *ij,
+                   double *meas7, double *info36, int32_t *fixed_vertex) {
+  if (!path || !n_vertices || !n_edges) return LSLAM_ERR_INVALID;
+  std::ifstream ifs(path);
+  if (!ifs) {
+    g_pg_err = std::string("cannot open ") + path;
+    return LSLAM_ERR_INVALID;
+  }
+  std::map<long, int> ids;
+  int nv = 0, ne = 0, fixed = -1;
+  const int cap_v = *n_vertices, cap_e = *n_edges;
+  std::string line, tag;
+  while (std::getline(ifs, line)) {
+    std::istringstream ls(line);
+    if (!(ls >> tag)) continue;
+    if (tag == "VERTEX_SE3:QUAT") {
+      long id;
+      double v[7];
+      if (!(ls >> id)) continue;
+      for (int k = 0; k < 7; ++k) ls >> v[k];
+      if (!ls) { g_pg_err = "malformed VERTEX_SE3:QUAT line"; return LSLAM_ERR_INVALID; }
+      ids[id] = nv;
+      if (poses7 && nv < cap_v) for (int k = 0; k < 7; ++k) poses7[(size_t)nv * 7 + k] = v[k];
+      ++nv;
+    } else if (tag == "FIX") {
+      long id;
+      if (ls >> id) { auto it = ids.find(id); if (it != ids.end() && fixed < 0) fixed = it->second; }
+    } else if (tag == "EDGE_SE3:QUAT") {
+      long a, b;
+      double m[7], u[21];
+      ls >> a >> b;
+      for (int k = 0; k < 7; ++k) ls >> m[k];
+      for (int k = 0; k < 21; ++k) ls >> u[k];
+      if (!ls) { g_pg_err = "malformed EDGE_SE3:QUAT line"; return LSLAM_ERR_INVALID; }
+      auto ia = ids.find(a), ib = ids.find(b);
+      if (ia == ids.end() || ib == ids.end()) { g_pg_err = "edge refers to an unknown vertex"; return LSLAM_ERR_INVALID; }
+      if (ne < cap_e) {
+        if (ij) { ij[2 * ne] = ia->second; ij[2 * ne + 1] = ib->second; }
+        if (meas7) for (int k = 0; k < 7; ++k) meas7[(size_t)ne * 7 + k] = m[k];
+        if (info36) {
+          int q = 0;
+          for (int r = 0; r < 6; ++r)
+            for (int c = r; c < 6; ++c) {
+              info36[(size_t)ne * 36 + r * 6 + c] = u[q];
+              info36[(size_t)ne * 36 + c * 6 + r] = u[q];
+              ++q;
+            }
+        }
+      }
+      ++ne;
+    }
+  }
+  *n_vertices = nv;
+  *n_edges = ne;
+  if (fixed_vertex) *fixed_vertex = fixed;
   return LSLAM_OK;
 }
 

@@ -99,6 +99,37 @@ class PoseGraph:
         self._info = [w for w in np.asarray(info, np.float64).reshape(-1, 6, 6)]
         self._drop()
 
+    # ---- g2o text format (solver_g2o.cpp:97-100) -----------------------------------------
+    def save(self, path):
+        """SolverG2O::save: the graph with its current estimates as a .g2o file."""
+        self._build()
+        self._check(self.lib.lslam_pg_save_g2o(self.h, str(path).encode()))
+
+    @staticmethod
+    def read_g2o(path, lib=None):
+        """-> dict(poses (n,7), ij (m,2), meas (m,7), info (m,6,6), fixed) from a .g2o file (host only)."""
+        from .capi import load_library
+        lib = lib or load_library()
+        nv, ne, fx = C.c_int32(0), C.c_int32(0), C.c_int32(-1)
+        rc = lib.lslam_g2o_read(str(path).encode(), C.byref(nv), None, C.byref(ne), None, None, None, C.byref(fx))
+        if rc < 0:
+            raise LslamError(rc, lib.lslam_pg_last_error().decode())
+        poses = np.zeros((nv.value, 7))
+        ij = np.zeros((ne.value, 2), np.int32)
+        meas = np.zeros((ne.value, 7))
+        info = np.zeros((ne.value, 6, 6))
+        rc = lib.lslam_g2o_read(str(path).encode(), C.byref(nv), _dp(poses), C.byref(ne),
+                                ij.ctypes.data_as(c_int32_p), _dp(meas), _dp(info), C.byref(fx))
+        if rc < 0:
+            raise LslamError(rc, lib.lslam_pg_last_error().decode())
+        return dict(poses=poses, ij=ij, meas=meas, info=info, fixed=fx.value)
+
+    def load(self, path):
+        """Replace the graph by the one in a .g2o file."""
+        g = PoseGraph.read_g2o(path, self.lib)
+        self.set_graph(g["poses"], g["ij"], g["meas"], g["info"])
+        return g
+
     def poses(self):
         self._build()
         out = np.zeros((len(self._nodes), 7))

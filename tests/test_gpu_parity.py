@@ -86,7 +86,7 @@ def _walk(nodes, root):
     return inner, leaves
 
 
-@pytest.mark.parametrize("kind", ["planar", "uniform", "lattice", "duplicates", "big"])
+@pytest.mark.parametrize("kind", ["planar", "uniform", "lattice", "lattice_big", "duplicates", "big"])
 def test_device_tree_build_is_nanoflann_exact(ctx, oracle, synth, kind):
     """The GPU-built tree has nanoflann's split at every node and nanoflann's point order
     (vind): compared with the oracle's restatement, which is pinned to the reference."""
@@ -98,6 +98,11 @@ def test_device_tree_build_is_nanoflann_exact(ctx, oracle, synth, kind):
         pts = rng.uniform(-30, 30, (40000, 3))
     elif kind == "lattice":  # equal coordinates everywhere: the '== cutval' runs matter
         g = np.arange(-12, 12, 0.4)
+        X, Y = np.meshgrid(g, g)
+        pts = np.concatenate([np.stack([X.ravel(), Y.ravel(), np.zeros(X.size)], 1),
+                              np.stack([np.full(X.size, 5.0), X.ravel(), Y.ravel() + 12], 1)])
+    elif kind == "lattice_big":  # > 32768 points per node: the level-synchronous phase with '== cutval' runs
+        g = np.arange(-12, 12, 0.1)
         X, Y = np.meshgrid(g, g)
         pts = np.concatenate([np.stack([X.ravel(), Y.ravel(), np.zeros(X.size)], 1),
                               np.stack([np.full(X.size, 5.0), X.ravel(), Y.ravel() + 12], 1)])

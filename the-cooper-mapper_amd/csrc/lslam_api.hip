@@ -350,6 +350,8 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   for (hipEvent_t e : ctx->sweep_ev) (void)hipEventDestroy(e);
   scanprep_destroy(ctx->scanprep);
+  treebuild_release_scratch(ctx->stream);
+  treebuild_release_scratch(ctx->stream2);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

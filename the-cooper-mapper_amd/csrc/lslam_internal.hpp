@@ -157,6 +157,8 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
                                hipStream_t stream, TreeView *view, int *depth, size_t *n_leaves,
                                int *fallback);
 
+void treebuild_release_scratch(hipStream_t s);  // frees the per-stream build scratch
+
 // lslam_api.hip internals used by lslam_fmap.hip (map maintenance)
 }  // namespace lslam
 struct lslam_ctx;

@@ -24,6 +24,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -419,8 +424,11 @@ __global__ __launch_bounds__(TB_BIG) void kd_build_big_kernel(BuildArgs A) {
                    __hip_atomic_load(&A.ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
           break;  // every big node is done
         } else {
-          __builtin_amdgcn_s_sleep(8);
-          if (spins > (1u << 26)) { A.ctl->overflow = 2; break; }  // bounded spin
+          // idle workgroups poll one cache line that the working ones need for their own atomics
+          // (queue tail, pending count, group allocator): back off hard
+          __builtin_amdgcn_s_sleep(127);
+          __builtin_amdgcn_s_sleep(127);
+          if (spins > (1u << 22)) { A.ctl->overflow = 2; break; }  // bounded spin
         }
       }
     }
@@ -675,6 +683,339 @@ __global__ __launch_bounds__(64) void kd_build_small_kernel(BuildArgs A) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Phase 0: nodes with more than HUGE_MIN points, level by level, every node of a level spread
+// over the whole chip in chunks of LV_CH points.  One workgroup streaming a 1.26 M-point root alone
+// was 2.5 ms of a 10 ms build; here each pass of a level is one launch over all its chunks, with
+// per-node results combined by integer atomics (min/max on order-preserving ints, counts), so the
+// outcome is independent of scheduling.  The Hoare pairing needs the rank of every misplaced
+// element inside its node: per-chunk counts, a per-node scan of the chunk counts, then ranks
+// inside the chunk.
+constexpr int HUGE_MIN = LOCAL_MAX;  // everything above the wavefront-local size goes level by level
+constexpr int LV_CH = 4096;
+constexpr int LV_TB = 256;
+constexpr int LV_PER = LV_CH / LV_TB;  // consecutive elements per thread
+
+struct LvStat {
+  int32_t mn[3], mx[3];      // order-preserving ints of the coordinate extrema
+  int32_t feat;
+  float cut;
+  int32_t lim1, lim2;
+  int32_t m[2];              // misplaced pairs of the two Hoare passes
+  int32_t lmax, rmin;        // order-preserving ints
+};
+
+struct LvArgs {
+  BuildArgs A;
+  const BuildItem *items;    // nodes of this level
+  LvStat *stat;              // [n_nodes]
+  const int32_t *chunk_node; // [n_chunks] node of a chunk
+  const int32_t *chunk_first;// [n_nodes] first chunk of a node
+  int32_t *cntL, *cntR, *baseL, *baseR;  // [n_chunks]
+  BuildItem *next_items;     // children that are huge again
+  int32_t *next_count;
+  int32_t n_nodes, n_chunks, next_cap;
+};
+
+__device__ __forceinline__ int32_t ord_i(float f) {
+  const int32_t i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float ord_f(int32_t i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
+// block-wide exclusive scan of one int per thread (LV_TB threads); *total = block sum
+__device__ __forceinline__ int lv_scan(int v, int *sh /*[LV_TB/64]*/, int *total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(x, o, 64);
+    if (lane >= o) x += t;
+  }
+  if (lane == 63) sh[wave] = x;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < LV_TB / 64; ++w) {
+    if (w < wave) base += sh[w];
+    tot += sh[w];
+  }
+  __syncthreads();
+  *total = tot;
+  return base + x - v;
+}
+
+#define LV_PROLOGUE                                                     \
+  const int node = L.chunk_node[blockIdx.x];                            \
+  const BuildItem it = L.items[node];                                   \
+  const int n = it.r - it.l, l = it.l;                                  \
+  const int c0 = (blockIdx.x - L.chunk_first[node]) * LV_CH;            \
+  const int c1 = min(n, c0 + LV_CH);                                    \
+  (void)c1; (void)l;
+
+__global__ void lv_init_kernel(LvArgs L) {  // one thread per node: neutral statistics; thread 0: empty next level
+  const int node = blockIdx.x * blockDim.x + threadIdx.x;
+  if (node == 0) *L.next_count = 0;
+  if (node >= L.n_nodes) return;
+  LvStat st{};
+  for (int d = 0; d < 3; ++d) { st.mn[d] = INT32_MAX; st.mx[d] = INT32_MIN; }
+  st.lmax = INT32_MIN;
+  st.rmin = INT32_MAX;
+  L.stat[node] = st;
+}
+
+__global__ __launch_bounds__(LV_TB) void lv_minmax_kernel(LvArgs L) {
+  LV_PROLOGUE
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = c0 + threadIdx.x; i < c1; i += LV_TB) {
+    const float4 p = L.A.pts[l + i];
+    mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+    mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+    mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float a = wave_min(mn[d]), b = wave_max(mx[d]);
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(&L.stat[node].mn[d], ord_i(a));
+      atomicMax(&L.stat[node].mx[d], ord_i(b));
+    }
+  }
+}
+
+__global__ void lv_split_kernel(LvArgs L) {  // middleSplit_, :982-1031, one thread per node
+  const int node = blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= L.n_nodes) return;
+  const BuildItem it = L.items[node];
+  LvStat &st = L.stat[node];
+  float emin[3], emax[3];
+  for (int d = 0; d < 3; ++d) { emin[d] = ord_f(st.mn[d]); emax[d] = ord_f(st.mx[d]); }
+  const float EPS = 0.00001f;
+  float max_span = it.hi[0] - it.lo[0];
+  for (int d = 1; d < 3; ++d) { const float span = it.hi[d] - it.lo[d]; if (span > max_span) max_span = span; }
+  float max_spread = -1;
+  int cutfeat = 0;
+  for (int d = 0; d < 3; ++d) {
+    const float span = it.hi[d] - it.lo[d];
+    if (span > (1 - EPS) * max_span) {
+      const float spread = emax[d] - emin[d];
+      if (spread > max_spread) { cutfeat = d; max_spread = spread; }
+    }
+  }
+  const float split_val = (it.lo[cutfeat] + it.hi[cutfeat]) / 2;
+  st.feat = cutfeat;
+  st.cut = split_val < emin[cutfeat] ? emin[cutfeat] : (split_val > emax[cutfeat] ? emax[cutfeat] : split_val);
+}
+
+__global__ __launch_bounds__(LV_TB) void lv_count_kernel(LvArgs L) {
+  LV_PROLOGUE
+  const int feat = L.stat[node].feat;
+  const float cut = L.stat[node].cut;
+  int a = 0, b = 0;
+  for (int i = c0 + threadIdx.x; i < c1; i += LV_TB) {
+    const float x = coord(L.A.pts[l + i], feat);
+    a += x < cut;
+    b += x <= cut;
+  }
+  a = wave_sum_i(a);
+  b = wave_sum_i(b);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&L.stat[node].lim1, a);
+    atomicAdd(&L.stat[node].lim2, b);
+  }
+}
+
+// region of Hoare pass p inside the node: [pa, n), its first Lc elements belong left
+__device__ __forceinline__ void lv_region(const LvStat &st, int p, int *pa, int *Lc) {
+  *pa = p == 0 ? 0 : st.lim1;
+  *Lc = p == 0 ? st.lim1 : st.lim2 - st.lim1;
+}
+// bit u of the masks: element c0 + tid*LV_PER + u is a misplaced one of the left / right part
+__device__ __forceinline__ void lv_flags(const LvArgs &L, int l, int n, int c0, int feat, float cut, int p, int pa,
+                                         int Lc, unsigned *mL, unsigned *mR) {
+  unsigned a = 0, b = 0;
+  const int i0 = c0 + threadIdx.x * LV_PER;
+  float x[LV_PER];
+#pragma unroll
+  for (int u = 0; u < LV_PER; ++u) x[u] = (i0 + u < n) ? coord(L.A.pts[l + i0 + u], feat) : 0.0f;
+#pragma unroll
+  for (int u = 0; u < LV_PER; ++u) {
+    const int i = i0 + u;
+    if (i >= n || i < pa) continue;
+    const bool left_ok = p == 0 ? (x[u] < cut) : (x[u] <= cut);
+    if (i < pa + Lc) { if (!left_ok) a |= 1u << u; }
+    else if (left_ok) b |= 1u << u;
+  }
+  *mL = a;
+  *mR = b;
+}
+
+__global__ __launch_bounds__(LV_TB) void lv_hflags_kernel(LvArgs L, int p) {
+  LV_PROLOGUE
+  __shared__ int sh[LV_TB / 64];
+  const LvStat st = L.stat[node];
+  int pa, Lc;
+  lv_region(st, p, &pa, &Lc);
+  unsigned mL, mR;
+  lv_flags(L, l, n, c0, st.feat, st.cut, p, pa, Lc, &mL, &mR);
+  int tL, tR;
+  lv_scan(__popc(mL), sh, &tL);
+  lv_scan(__popc(mR), sh, &tR);
+  if (threadIdx.x == 0) {
+    L.cntL[blockIdx.x] = tL;
+    L.cntR[blockIdx.x] = tR;
+  }
+}
+
+// per node: ranks of the chunks.  left: ascending chunks; right: the k-th misplaced from the RIGHT
+__global__ __launch_bounds__(LV_TB) void lv_hscan_kernel(LvArgs L, int p) {
+  __shared__ int sh[LV_TB / 64];
+  const int node = blockIdx.x;
+  const BuildItem it = L.items[node];
+  const int nch = (it.r - it.l + LV_CH - 1) / LV_CH, first = L.chunk_first[node];
+  int runL = 0, runR = 0;
+  for (int base = 0; base < nch; base += LV_TB) {
+    const int c = base + threadIdx.x;
+    const int vL = c < nch ? L.cntL[first + c] : 0;
+    const int cr = nch - 1 - c;  // right side walks the chunks downwards
+    const int vR = c < nch ? L.cntR[first + cr] : 0;
+    int tL, tR;
+    const int eL = lv_scan(vL, sh, &tL), eR = lv_scan(vR, sh, &tR);
+    if (c < nch) {
+      L.baseL[first + c] = runL + eL;
+      L.baseR[first + cr] = runR + eR;
+    }
+    runL += tL;
+    runR += tR;
+  }
+  if (threadIdx.x == 0) L.stat[node].m[p] = runL;  // == runR
+}
+
+__global__ __launch_bounds__(LV_TB) void lv_hwrite_kernel(LvArgs L, int p) {
+  LV_PROLOGUE
+  __shared__ int sh[LV_TB / 64];
+  const LvStat st = L.stat[node];
+  if (st.m[p] == 0) return;
+  int pa, Lc;
+  lv_region(st, p, &pa, &Lc);
+  unsigned mL, mR;
+  lv_flags(L, l, n, c0, st.feat, st.cut, p, pa, Lc, &mL, &mR);
+  int tL, tR;
+  int eL = lv_scan(__popc(mL), sh, &tL);
+  const int eR = lv_scan(__popc(mR), sh, &tR);
+  const int i0 = c0 + threadIdx.x * LV_PER;
+  int posL = L.baseL[blockIdx.x] + eL;
+  // rank from the right inside the chunk: elements after this one in the chunk
+  int after = tR - eR;  // flagged right elements at or after this thread's first element
+#pragma unroll
+  for (int u = 0; u < LV_PER; ++u) {
+    if (mL & (1u << u)) L.A.tmpA[l + posL++] = i0 + u;
+    if (mR & (1u << u)) {
+      --after;  // now: flagged elements strictly after this one
+      L.A.tmpB[l + L.baseR[blockIdx.x] + after] = i0 + u;
+    }
+  }
+}
+
+__global__ __launch_bounds__(LV_TB) void lv_hswap_kernel(LvArgs L, int p) {
+  LV_PROLOGUE
+  const int m = L.stat[node].m[p];
+  for (int k = c0 + threadIdx.x; k < min(m, c0 + LV_CH); k += LV_TB) {
+    const int i = l + L.A.tmpA[l + k], j = l + L.A.tmpB[l + k];
+    const float4 t = L.A.pts[i];
+    L.A.pts[i] = L.A.pts[j];
+    L.A.pts[j] = t;
+  }
+}
+
+__device__ __forceinline__ int lv_index(const LvStat &st, int n) {  // :1024-1029
+  const int half = n / 2;
+  return st.lim1 > half ? st.lim1 : (st.lim2 < half ? st.lim2 : half);
+}
+
+__global__ __launch_bounds__(LV_TB) void lv_bounds_kernel(LvArgs L) {
+  LV_PROLOGUE
+  const LvStat st = L.stat[node];
+  const int index = lv_index(st, n);
+  float lmax = -FLT_MAX, rmin = FLT_MAX;
+  for (int i = c0 + threadIdx.x; i < c1; i += LV_TB) {
+    const float x = coord(L.A.pts[l + i], st.feat);
+    if (i < index) lmax = fmaxf(lmax, x); else rmin = fminf(rmin, x);
+  }
+  lmax = wave_max(lmax);
+  rmin = wave_min(rmin);
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&L.stat[node].lmax, ord_i(lmax));
+    atomicMin(&L.stat[node].rmin, ord_i(rmin));
+  }
+}
+
+// one thread per node: the node record and its two children (what lane 0 of process_node does)
+__global__ void lv_final_kernel(LvArgs L) {
+  const int node = blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= L.n_nodes) return;
+  const BuildArgs &A = L.A;
+  const BuildItem it = L.items[node];
+  const LvStat st = L.stat[node];
+  const int n = it.r - it.l, index = lv_index(st, n), feat = st.feat;
+  uint32_t ref[2];
+  for (int c = 0; c < 2; ++c) {
+    const int cl = c == 0 ? it.l : it.l + index, cr = c == 0 ? it.l + index : it.r;
+    if (cr - cl <= 10) {
+      ref[c] = KD_LEAF | ((uint32_t)cl << 4) | (uint32_t)(cr - cl);
+      atomicAdd(&A.ctl->n_leaves, 1);
+      atomicMax(&A.ctl->max_depth, it.depth + 1);
+      continue;
+    }
+    BuildItem ch;
+    ch.l = cl;
+    ch.r = cr;
+    for (int d = 0; d < 3; ++d) { ch.lo[d] = it.lo[d]; ch.hi[d] = it.hi[d]; }
+    if (c == 0) ch.hi[feat] = st.cut; else ch.lo[feat] = st.cut;
+    if (it.heap < 3) {
+      ch.heap = 2 * it.heap + 1 + c;
+      ch.slot = it.slot - it.heap + ch.heap;
+    } else {
+      ch.heap = 0;
+      ch.slot = alloc_group(A);
+    }
+    ch.parent_word = it.slot * 4 + 2 + c;
+    ch.depth = it.depth + 1;
+    ref[c] = (uint32_t)ch.slot << 2;
+    const int cn = cr - cl;
+    if (cn > HUGE_MIN) {
+      const int e = atomicAdd(L.next_count, 1);
+      if (e < L.next_cap) L.next_items[e] = ch; else A.ctl->overflow = 3;
+    } else if (cn > LOCAL_MAX) {
+      const int e = atomicAdd(&A.ctl->q_tail_reserved, 1);
+      if (e >= A.queue_cap) { A.ctl->overflow = 3; continue; }
+      atomicAdd(&A.ctl->q_pending, 1);
+      A.queue[e] = ch;
+      A.q_ready[e] = 1;
+    } else {
+      const int e = atomicAdd(&A.ctl->n_sub, 1);
+      if (e >= A.sub_cap) { A.ctl->overflow = 3; continue; }
+      A.sublist[e] = ch;
+    }
+  }
+  KdNode nd;
+  nd.lo = ord_f(st.lmax);
+  nd.hi = ord_f(st.rmin);
+  nd.c1 = ref[0];
+  nd.c2 = ref[1];
+  // the children OR their split dimension into c1/c2 later (next level or phases A/B), never before
+  // this store: they are processed by later launches
+  KdNode *dst = &A.nodes[it.slot];
+  dst->lo = nd.lo;
+  dst->hi = nd.hi;
+  atomicOr(&dst->c1, nd.c1);  // the slot was zeroed; OR-ing keeps the word consistent with the children's later ORs
+  atomicOr(&dst->c2, nd.c2);
+  if (it.parent_word >= 0)
+    atomicOr(reinterpret_cast<unsigned int *>(A.nodes) + it.parent_word, (unsigned int)feat);
+  else
+    A.ctl->root_feat = feat;
+}
+
 // bounding box of the whole cloud (computeBoundingBox, :1406-1427) + identity .w
 __global__ __launch_bounds__(256) void kd_bbox_kernel(const float4 *pts, int n, float *part) {
   __shared__ float smin[3][4], smax[3][4];
@@ -705,6 +1046,45 @@ __global__ __launch_bounds__(256) void kd_bbox_kernel(const float4 *pts, int n, 
 // Build the tree of `n` points at d_pts (float4 {x,y,z,bitcast(original index)}, permuted in
 // place).  d_nodes must hold node_cap nodes.  Returns hipSuccess and fills `view`/depth, or
 // sets *fallback when the structure limits were hit (caller then uses the host builder).
+namespace {
+// Scratch of a build, kept per stream between builds (hipMalloc/hipFree of tens of MB per call cost
+// more than a millisecond); released by treebuild_release_scratch.
+struct BuildPool {
+  void *blob = nullptr, *lv = nullptr, *part = nullptr;
+  size_t cap = 0, lv_cap = 0;
+};
+std::mutex g_pool_mu;
+std::map<hipStream_t, BuildPool> g_pool;
+
+hipError_t pool_get(hipStream_t s, bool lv, size_t bytes, void **out) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  BuildPool &p = g_pool[s];
+  void *&ptr = lv ? p.lv : p.blob;
+  size_t &cap = lv ? p.lv_cap : p.cap;
+  if (bytes > cap) {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 4;
+    hipError_t e = hipMalloc(&ptr, want);
+    if (e != hipSuccess) return e;
+    cap = want;
+  }
+  *out = ptr;
+  return hipSuccess;
+}
+}  // namespace
+
+void treebuild_release_scratch(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  auto it = g_pool.find(s);
+  if (it == g_pool.end()) return;
+  if (it->second.blob) (void)hipFree(it->second.blob);
+  if (it->second.lv) (void)hipFree(it->second.lv);
+  if (it->second.part) (void)hipFree(it->second.part);
+  g_pool.erase(it);
+}
+
 hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_t node_cap,
                                hipStream_t stream, TreeView *view, int *depth, size_t *n_leaves,
                                int *fallback) {
@@ -725,12 +1105,16 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
   // bounding box
   constexpr int NB = 256;
   float *d_part = nullptr;
-  if ((e = hipMalloc((void **)&d_part, NB * 6 * sizeof(float))) != hipSuccess) return e;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    BuildPool &bp = g_pool[stream];
+    if (!bp.part && (e = hipMalloc(&bp.part, NB * 6 * sizeof(float))) != hipSuccess) return e;
+    d_part = static_cast<float *>(bp.part);
+  }
   hipLaunchKernelGGL(kd_bbox_kernel, dim3(NB), dim3(256), 0, stream, d_pts, n, d_part);
   float h_part[NB * 6];
   if ((e = hipMemcpyAsync(h_part, d_part, sizeof(h_part), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
   if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-  (void)hipFree(d_part);
   const int used = std::min(NB, (n + 255) / 256);
   for (int d = 0; d < 3; ++d) {
     float a = h_part[d], b = h_part[3 + d];
@@ -757,7 +1141,7 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
   A.sub_cap = sub_cap;
   const size_t sz_queue = (size_t)queue_cap * sizeof(BuildItem), sz_ready = (size_t)queue_cap * sizeof(int32_t),
                sz_tmp = (size_t)n * sizeof(int32_t), sz_ctl = 256, sz_sub = (size_t)sub_cap * sizeof(BuildItem);
-  if ((e = hipMalloc(&blob, sz_queue + sz_sub + sz_ready + 2 * sz_tmp + sz_ctl)) != hipSuccess) return e;
+  if ((e = pool_get(stream, false, sz_queue + sz_sub + sz_ready + 2 * sz_tmp + sz_ctl, &blob)) != hipSuccess) return e;
   char *p = static_cast<char *>(blob);
   A.queue = reinterpret_cast<BuildItem *>(p); p += sz_queue;
   A.sublist = reinterpret_cast<BuildItem *>(p); p += sz_sub;
@@ -782,14 +1166,98 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
   root.depth = 1;
   const int32_t one = 1;
   const bool root_small = n <= LOCAL_MAX;
+  static const bool no_levels = std::getenv("LSLAM_NO_LEVEL_BUILD") != nullptr;  // A/B switch
+  const bool root_huge = n > HUGE_MIN && !no_levels;
   if (root_small) {  // the whole tree is one phase-B subtree
     ctl.q_tail_reserved = 0;
     ctl.q_pending = 0;
     ctl.n_sub = 1;
   }
+  if (root_huge) {  // the root goes through phase 0; its descendants fill the queue
+    ctl.q_tail_reserved = 0;
+    ctl.q_pending = 0;
+  }
   if ((e = hipMemcpyAsync(A.ctl, &ctl, sizeof(ctl), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-  if ((e = hipMemcpyAsync(root_small ? A.sublist : A.queue, &root, sizeof(root), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-  if ((e = hipMemcpyAsync(A.q_ready, &one, sizeof(one), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+  if (!root_huge) {
+    if ((e = hipMemcpyAsync(root_small ? A.sublist : A.queue, &root, sizeof(root), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(A.q_ready, &one, sizeof(one), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+  }
+  void *lv_blob = nullptr;
+  if (root_huge) {
+    // ---- phase 0: level-synchronous processing of the nodes with more than HUGE_MIN points ----
+    const int cap_nodes = n / HUGE_MIN * 2 + 8, cap_chunks = n / LV_CH + cap_nodes + 8;
+    const size_t sz_items = (size_t)cap_nodes * sizeof(BuildItem), sz_stat = (size_t)cap_nodes * sizeof(LvStat),
+                 sz_ci = (size_t)cap_chunks * sizeof(int32_t), sz_ni = (size_t)cap_nodes * sizeof(int32_t);
+    if ((e = pool_get(stream, true, 2 * sz_items + sz_stat + 5 * sz_ci + sz_ni + 64, &lv_blob)) != hipSuccess) return e;
+    char *q = static_cast<char *>(lv_blob);
+    BuildItem *d_items = reinterpret_cast<BuildItem *>(q); q += sz_items;
+    BuildItem *d_next = reinterpret_cast<BuildItem *>(q); q += sz_items;
+    LvStat *d_stat = reinterpret_cast<LvStat *>(q); q += sz_stat;
+    int32_t *d_chunk_node = reinterpret_cast<int32_t *>(q); q += sz_ci;
+    int32_t *d_cntL = reinterpret_cast<int32_t *>(q); q += sz_ci;
+    int32_t *d_cntR = reinterpret_cast<int32_t *>(q); q += sz_ci;
+    int32_t *d_baseL = reinterpret_cast<int32_t *>(q); q += sz_ci;
+    int32_t *d_baseR = reinterpret_cast<int32_t *>(q); q += sz_ci;
+    int32_t *d_chunk_first = reinterpret_cast<int32_t *>(q); q += sz_ni;
+    int32_t *d_next_count = reinterpret_cast<int32_t *>(q);
+    // items ping-pong between two device buffers; the header word in front of each holds the count
+    // the previous level's final kernel produced (one download + one synchronisation per level)
+    std::vector<BuildItem> level(1, root);
+    std::vector<int32_t> chunk_node, chunk_first;
+    std::vector<char> dl(sizeof(BuildItem) * (size_t)cap_nodes + 16);
+    BuildItem *d_cur = d_items, *d_nxt = d_next;
+    if ((e = hipMemcpyAsync(d_cur, &root, sizeof(root), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    while (!level.empty()) {
+      const int H = (int)level.size();
+      chunk_node.clear();
+      chunk_first.assign(H, 0);
+      for (int j = 0; j < H; ++j) {
+        chunk_first[j] = (int32_t)chunk_node.size();
+        const int nch = (level[j].r - level[j].l + LV_CH - 1) / LV_CH;
+        chunk_node.insert(chunk_node.end(), nch, j);
+      }
+      const int C = (int)chunk_node.size();
+      if (H > cap_nodes || C > cap_chunks) { *fallback = 3; return hipSuccess; }
+      if ((e = hipMemcpyAsync(d_chunk_node, chunk_node.data(), (size_t)C * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+      if ((e = hipMemcpyAsync(d_chunk_first, chunk_first.data(), (size_t)H * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+      LvArgs L{};
+      L.A = A;
+      L.items = d_cur;
+      L.stat = d_stat;
+      L.chunk_node = d_chunk_node;
+      L.chunk_first = d_chunk_first;
+      L.cntL = d_cntL; L.cntR = d_cntR; L.baseL = d_baseL; L.baseR = d_baseR;
+      L.next_items = d_nxt;
+      L.next_count = d_next_count;
+      L.n_nodes = H;
+      L.n_chunks = C;
+      L.next_cap = cap_nodes;
+      const dim3 gc(C), gn((H + 63) / 64), bt(LV_TB);
+      hipLaunchKernelGGL(lv_init_kernel, gn, dim3(64), 0, stream, L);
+      hipLaunchKernelGGL(lv_minmax_kernel, gc, bt, 0, stream, L);
+      hipLaunchKernelGGL(lv_split_kernel, gn, dim3(64), 0, stream, L);
+      hipLaunchKernelGGL(lv_count_kernel, gc, bt, 0, stream, L);
+      for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(lv_hflags_kernel, gc, bt, 0, stream, L, pass);
+        hipLaunchKernelGGL(lv_hscan_kernel, dim3(H), bt, 0, stream, L, pass);
+        hipLaunchKernelGGL(lv_hwrite_kernel, gc, bt, 0, stream, L, pass);
+        hipLaunchKernelGGL(lv_hswap_kernel, gc, bt, 0, stream, L, pass);
+      }
+      hipLaunchKernelGGL(lv_bounds_kernel, gc, bt, 0, stream, L);
+      hipLaunchKernelGGL(lv_final_kernel, gn, dim3(64), 0, stream, L);
+      // the children that are huge again: count first (4 bytes), then as many items as a level of this
+      // size can produce (2 H) in the same round trip
+      int32_t n_next = 0;
+      const size_t want = (size_t)std::min(2 * H, cap_nodes) * sizeof(BuildItem);
+      if ((e = hipMemcpyAsync(&n_next, d_next_count, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+      if ((e = hipMemcpyAsync(dl.data(), d_nxt, want, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+      if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+      n_next = std::min(n_next, std::min(2 * H, cap_nodes));
+      level.resize((size_t)n_next);
+      if (n_next) std::memcpy(level.data(), dl.data(), (size_t)n_next * sizeof(BuildItem));
+      std::swap(d_cur, d_nxt);
+    }
+  }
   // persistent grid: every workgroup must be resident (they wait on each other's output)
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
@@ -802,7 +1270,7 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
   if ((e = hipMemcpyAsync(&ctl, A.ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
   if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
   const double T3 = now();
-  (void)hipFree(blob);
+  (void)lv_blob;  // pooled
   if (dbg)
     fprintf(stderr, "[lslam] tree build n=%d: bbox %.2f ms, setup %.2f ms, build kernel %.2f ms, free %.2f ms (overflow %d, groups %d)\n",
             n, T1 - T0, T2 - T1, T3 - T2, now() - T3, ctl.overflow, ctl.next_group);

@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pose-graph", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the single-scan latency leg")
+    ap.add_argument("--no-mapping-frame", action="store_true", help="skip the per-frame mapping pipeline leg")
     ap.add_argument("--shard-points", action="store_true",
                     help="run the sharded-points leg even on one GPU (all-reduce over a world of 1)")
     ap.add_argument("--pg-iters", type=int, default=10, help="LM iterations of the pose-graph leg")
@@ -175,6 +176,11 @@ def main():
         }
         if not args.no_single:
             out["single_scan"] = single_scan_leg(ctx, pr, opts, max(10, args.steps // 2))
+    if rank == 0 and not args.no_mapping_frame:
+        try:
+            out["mapping_frame"] = mapping_frame_leg(pkg, synth, ctx, pr, opts, np, not args.no_cpu_baseline)
+        except Exception as e:  # a secondary leg never takes the headline line down
+            out["mapping_frame"] = {"error": repr(e)}
     if world > 1 or args.shard_points:
         try:
             shres = sharded_points_leg(pkg, synth, distmod, dist, rank, world, ctx, opts, torch, np, args)
@@ -333,6 +339,82 @@ def single_scan_leg(ctx, pr, opts, steps):
             "host_buffers_value": pt_h / dth, "host_buffers_ms_per_scanmatch": 1e3 * dth / steps,
             "gn_iterations": st.iterations, "sweep_kernel_ms": avg,
             "roofline_frac": ALG_BYTES_PER_POINT_RESIDUAL * n / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS if avg > 0 else None}
+
+
+def mapping_frame_leg(pkg, synth, ctx, pr, opts, np, with_cpu):
+    """One LaserMapping frame end to end on the device (SURVEY 8f n1/n2 around the hot path), per step:
+    extractFeatures on the 64x1800 sweep, VoxelGrid of the features (LaserMatcher.cpp:289-301, leaf
+    1.0 = the reference default), FeatureMap::update, surround -> kd-trees, scanMatchScan,
+    addFeatureCloud -- next to the oracle doing the same steps on one host core (one frame)."""
+    def xyzi(a):
+        o = np.zeros((len(a), 4), np.float32)
+        o[:, :3] = a[:, :3]
+        return o
+    _, _, gt, cloud, ranges = synth.make_scan(pr["world"], 64, 1800, gt_pose=pr["gt_pose"], seed=4321, full=True)
+    fm = pkg.FeatureMap(ctx, 21, 11, 21)
+    fm.setup_filter_size(0.2, 0.4, 0.6)
+    fm.update(gt[3:])
+    fm.add_feature_cloud(xyzi(pr["map_corner"]), xyzi(pr["map_surf"]), np.eye(4, dtype=np.float32))
+    R, t = synth.pose_to_Rt(gt)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3], T[:3, 3] = R, t
+    init = synth.perturb_pose(gt, seed=77, dt=0.1, dr_deg=0.5)
+    steps = ("extract_features", "voxel_grid", "update", "surround_to_map", "scan_match", "add_feature_cloud")
+    acc = {k: 0.0 for k in steps}
+    frames = 6
+    for f in range(frames + 1):  # first frame = warm-up
+        t0 = time.perf_counter()
+        feat = pkg.scan_registration.extract_features(ctx, cloud, ranges)
+        t1 = time.perf_counter()
+        dc, ds = pkg.voxel_grid(ctx, feat["less_sharp"], 1.0), pkg.voxel_grid(ctx, feat["less_flat"], 1.0)
+        t2 = time.perf_counter()
+        fm.update(gt[3:])
+        t3 = time.perf_counter()
+        fm.surround_to_map()
+        t4 = time.perf_counter()
+        status, pose, st = ctx.scanmatch_scan(dc, ds, init, opts)
+        t5 = time.perf_counter()
+        fm.add_feature_cloud(dc, ds, T)
+        t6 = time.perf_counter()
+        if f == 0:
+            pose_first = pose.copy()  # same map state as the oracle's single frame below
+        if f > 0:
+            for k, d in zip(steps, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5)):
+                acc[k] += d
+    gpu = {k: 1e3 * v / frames for k, v in acc.items()}
+    res = {"gpu_ms": gpu, "gpu_ms_per_frame": sum(gpu.values()), "frames": frames,
+           "sweep_points": int(len(cloud)), "features": {k: int(len(v)) for k, v in feat.items()},
+           "scan_points_after_voxel_grid": int(len(dc) + len(ds)), "map_points": fm.info()["n_corner"] + fm.info()["n_surf"],
+           "scan_match_iterations": int(st.iterations),
+           "pose_err_vs_ground_truth_m": float(np.abs(pose[3:] - gt[3:]).max())}
+    if with_cpu:
+        from oracle_lib import Oracle
+        o = Oracle(native=True)
+        ofm = o.feature_map(21, 11, 21)
+        ofm.setup_filter_size(0.2, 0.4, 0.6)
+        ofm.update(gt[3:])
+        ofm.add_feature_cloud(xyzi(pr["map_corner"]), xyzi(pr["map_surf"]), np.eye(4, dtype=np.float32))
+        t0 = time.perf_counter()
+        ofeat = o.extract_features(cloud, ranges)
+        t1 = time.perf_counter()
+        odc, ods = o.voxel_grid(ofeat["less_sharp"], 1.0), o.voxel_grid(ofeat["less_flat"], 1.0)
+        t2 = time.perf_counter()
+        ofm.update(gt[3:])
+        t3 = time.perf_counter()
+        oc, os_ = ofm.get_surround_feature()
+        t4 = time.perf_counter()
+        ok, opose, ost = o.scanmatch_scan(oc, os_, odc, ods, init)  # kd-trees rebuilt inside (quirk Q4)
+        t5 = time.perf_counter()
+        ofm.add_feature_cloud(odc, ods, T)
+        t6 = time.perf_counter()
+        cpu = {k: 1e3 * d for k, d in zip(("extract_features", "voxel_grid", "update", "surround", "scan_match_incl_tree_build",
+                                            "add_feature_cloud"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5))}
+        res["cpu_ms"] = cpu
+        res["cpu_ms_per_frame"] = sum(cpu.values())
+        res["cpu"] = {"cores": 1, "kind": "port", "sample": "one frame of the same steps in the oracle"}
+        res["pose_diff_gpu_vs_cpu_m"] = float(np.abs(opose[3:] - pose_first[3:]).max())
+    fm.close()
+    return res
 
 
 def cpu_baseline(pr, repeats, gpu_pose, np):

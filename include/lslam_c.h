@@ -273,6 +273,12 @@ int lslam_fmap_get_surround(lslam_fmap *fm, float *corner_xyzi, size_t cap_corne
 int lslam_fmap_surround_to_map(lslam_fmap *fm);
 /* getFullMap, FeatureMap.h:267-286: per cube, VoxelGrid(map leaf) of corner then surf. */
 int lslam_fmap_get_full_map(lslam_fmap *fm, float *out_xyzi, size_t cap, size_t *n_out);
+/* saveCloudToFiles / loadCloudFromFiles, FeatureMap.h:378-462: one binary PCD (fields x y z
+ * intensity) per non-empty (cube, type) named <count>.pcd and index.txt with lines
+ * "count type i j k size"; loading runs every loaded cube through its type's VoxelGrid and
+ * replaces that cube's content.  ascii and binary PCDs are read, binary_compressed is not. */
+int lslam_fmap_save(lslam_fmap *fm, const char *directory);
+int lslam_fmap_load(lslam_fmap *fm, const char *directory);
 /* introspection: grid origin, _cubeValidInd, points held per type; any output may be NULL */
 int lslam_fmap_info(lslam_fmap *fm, int32_t origin[3], int32_t *n_valid, int32_t *valid_out, size_t cap,
                     size_t *n_corner_total, size_t *n_surf_total);

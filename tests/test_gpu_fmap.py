@@ -157,3 +157,57 @@ def test_scan_match_local_matches_oracle(pkg, ctx, oracle, small_problem):
     assert sm.last_stats.iterations == ost.iterations
     assert (sm.last_stats.n_rows, sm.last_stats.n_line, sm.last_stats.n_plane) == (ost.n_rows, ost.n_line, ost.n_plane)
     assert np.abs(pose[3:] - opose[3:]).max() <= 1e-4 and np.abs(pose[:3] - opose[:3]).max() <= 1e-5
+
+
+def test_feature_map_files_round_trip(pkg, ctx, oracle, tmp_path):
+    """saveCloudToFiles / loadCloudFromFiles (FeatureMap.h:378-462): PCD cube files + index.txt."""
+    rng = np.random.default_rng(9)
+    fm = pkg.FeatureMap(ctx, 9, 8, 7)
+    fm.setup_world_cube_size(10.0)
+    fm.setup_lidar_valid_distance(25.0)
+    fm.setup_filter_size(0.4, 0.8, 1.5)
+    fm.update(np.zeros(3, np.float32))
+    pts = rng.normal(0, 9.0, (6000, 4)).astype(np.float32)
+    pts[:, 3] = rng.uniform(0, 16, len(pts))
+    fm.add_feature_cloud(pts[:1000], pts[1000:], np.eye(4, dtype=np.float32))
+    c0, s0 = fm.get_surround_feature()
+    assert fm.save_cloud_to_files(tmp_path)
+    # the files are what pcl::io::savePCDFileBinary writes for PointXYZI
+    idx = [l.split() for l in (tmp_path / "index.txt").read_text().splitlines()]
+    assert len(idx) > 4 and all(len(l) == 6 for l in idx)
+    total = {0: 0, 1: 0}
+    for cnt, typ, i, j, k, size in idx:
+        raw = (tmp_path / (cnt + ".pcd")).read_bytes()
+        head, _, body = raw.partition(b"DATA binary\n")
+        assert b"FIELDS x y z intensity" in head and ("POINTS %s" % size).encode() in head
+        assert len(body) == 16 * int(size)
+        total[int(typ)] += int(size)
+    info = fm.info()
+    assert total[0] == info["n_corner"] and total[1] == info["n_surf"]
+    # a fresh map loads them; every cube of the active area held one point per voxel already, so the
+    # VoxelGrid on load leaves them as they are (cubes outside the area held raw points: now filtered)
+    fm2 = pkg.FeatureMap(ctx, 9, 8, 7)
+    assert fm2.load_cloud_from_files(tmp_path / "nothing_here") is False
+    fm2.setup_world_cube_size(10.0)
+    fm2.setup_lidar_valid_distance(25.0)
+    fm2.setup_filter_size(0.4, 0.8, 1.5)
+    assert fm2.load_cloud_from_files(tmp_path)
+    fm2.update(np.zeros(3, np.float32))
+    c1, s1 = fm2.get_surround_feature()
+    assert c1.shape == c0.shape and s1.shape == s0.shape
+    assert np.array_equal(bits(c1), bits(c0)) and np.array_equal(bits(s1), bits(s0))
+    # an ascii PCD with another field order is read as well
+    (tmp_path / "a").mkdir()
+    (tmp_path / "a" / "index.txt").write_text("0 1 4 4 3 2\n")
+    (tmp_path / "a" / "0.pcd").write_text("# .PCD v0.7\nVERSION 0.7\nFIELDS intensity x y z\nSIZE 4 4 4 4\nTYPE F F F F\n"
+                                          "COUNT 1 1 1 1\nWIDTH 2\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS 2\nDATA ascii\n"
+                                          "7 1.0 2.0 3.0\n8 1.1 2.0 3.0\n")
+    fm3 = pkg.FeatureMap(ctx, 9, 8, 7)
+    fm3.setup_world_cube_size(10.0)
+    fm3.setup_filter_size(0.4, 5.0, 1.5)
+    assert fm3.load_cloud_from_files(tmp_path / "a")
+    fm3.update(np.zeros(3, np.float32))
+    c3, s3 = fm3.get_surround_feature()
+    assert len(c3) == 0 and len(s3) == 1 and np.allclose(s3[0], [1.05, 2.0, 3.0, 7.5])
+    for m in (fm, fm2, fm3):
+        m.close()

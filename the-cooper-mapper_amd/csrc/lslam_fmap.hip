@@ -29,7 +29,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <fstream>
 #include <mutex>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -281,6 +283,12 @@ __global__ void fm_segment_kernel(const int32_t *cube, int n, int32_t *begin, in
   if (i == n - 1 || cube[i + 1] != c) end[c] = i + 1;
 }
 
+// points of flagged cubes are dropped (a cube loaded from a file replaces what was there)
+__global__ void fm_dropflag_kernel(int32_t *cube, int n, const uint8_t *flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && cube[i] >= 0 && flags[cube[i]]) cube[i] = -1;
+}
+
 __global__ void fm_relabel_kernel(int32_t *cube, int n, const int32_t *new_of_old) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && cube[i] >= 0) cube[i] = new_of_old[cube[i]];
@@ -462,7 +470,7 @@ int refresh_segments(lslam_fmap *fm, int t) {
 }
 
 // rebuild type t from its current points plus n_new transformed points (fm->in_tf / in_cube)
-int rebuild(lslam_fmap *fm, int t, size_t n_new, bool allow_filter) {
+int rebuild(lslam_fmap *fm, int t, size_t n_new, bool allow_filter, const uint8_t *flags_override = nullptr) {
   hipStream_t s = fm->stream;
   const size_t n_old = fm->n[t], n_total = n_old + n_new;
   if (n_total == 0) return LSLAM_OK;
@@ -477,7 +485,8 @@ int rebuild(lslam_fmap *fm, int t, size_t n_new, bool allow_filter) {
   KeyParams kp = key_params(fm, fm->leaf[t]);
   size_t n_out = 0;
   int rc = run_pipeline(s, fm->sc, fm->pts[t].p, fm->cube[t].p, n_total, kp, fm->ncube,
-                        allow_filter ? fm->active.p : nullptr, fm->pts_alt[t].p, fm->cube_alt[t].p, &n_out);
+                        flags_override ? flags_override : (allow_filter ? fm->active.p : nullptr), fm->pts_alt[t].p,
+                        fm->cube_alt[t].p, &n_out);
   if (rc) return rc;
   std::swap(fm->pts[t], fm->pts_alt[t]);
   std::swap(fm->cube[t], fm->cube_alt[t]);
@@ -848,6 +857,176 @@ int lslam_fmap_get_full_map(lslam_fmap *fm, float *out_xyzi, size_t cap, size_t 
     while (b < h[1].size() && hc[1][b] == c) std::memcpy(out_xyzi + 4 * o++, &h[1][b++], 16);
   }
   return LSLAM_OK;
+}
+
+// ---- on-disk format: FeatureMap::saveCloudToFiles / loadCloudFromFiles,
+// util/FeatureMap.h:378-462 -- one binary PCD per non-empty (cube, type) named <count>.pcd plus
+// index.txt with lines "count type i j k size".
+namespace {
+bool write_pcd_binary(const std::string &path, const float4 *p, size_t n) {
+  FILE *f = std::fopen(path.c_str(), "wb");
+  if (!f) return false;
+  // pcl::io::savePCDFileBinary of a PointXYZI cloud: the four named fields, 16 bytes per point
+  std::fprintf(f, "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\n"
+                  "TYPE F F F F\nCOUNT 1 1 1 1\nWIDTH %zu\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %zu\nDATA binary\n", n, n);
+  const bool ok = std::fwrite(p, sizeof(float4), n, f) == n;
+  return std::fclose(f) == 0 && ok;
+}
+
+// reads x y z intensity from an ascii or binary PCD (any field order / extra fields of 4-byte types)
+bool read_pcd(const std::string &path, std::vector<float4> &out, std::string &err) {
+  FILE *f = std::fopen(path.c_str(), "rb");
+  if (!f) { err = path + " not exist!"; return false; }
+  std::vector<std::string> fields;
+  std::vector<int> sizes, counts;
+  size_t points = 0;
+  std::string data;
+  char line[1024];
+  while (std::fgets(line, sizeof(line), f)) {
+    std::istringstream ls(line);
+    std::string tag;
+    ls >> tag;
+    if (tag == "FIELDS") { std::string v; while (ls >> v) fields.push_back(v); }
+    else if (tag == "SIZE") { int v; while (ls >> v) sizes.push_back(v); }
+    else if (tag == "COUNT") { int v; while (ls >> v) counts.push_back(v); }
+    else if (tag == "POINTS") ls >> points;
+    else if (tag == "DATA") { ls >> data; break; }
+  }
+  if (counts.empty()) counts.assign(fields.size(), 1);
+  if (fields.empty() || sizes.size() != fields.size() || counts.size() != fields.size()) {
+    std::fclose(f); err = "malformed PCD header in " + path; return false;
+  }
+  int off[4] = {-1, -1, -1, -1}, step = 0, col[4] = {-1, -1, -1, -1}, ncol = 0;
+  const char *want[4] = {"x", "y", "z", "intensity"};
+  for (size_t k = 0; k < fields.size(); ++k) {
+    for (int w = 0; w < 4; ++w)
+      if (fields[k] == want[w] && sizes[k] == 4) { off[w] = step; col[w] = ncol; }
+    step += sizes[k] * counts[k];
+    ncol += counts[k];
+  }
+  if (off[0] < 0 || off[1] < 0 || off[2] < 0) { std::fclose(f); err = "PCD without float x y z: " + path; return false; }
+  out.assign(points, make_float4(0.f, 0.f, 0.f, 0.f));
+  bool ok = true;
+  if (data == "binary") {
+    std::vector<char> rec((size_t)step);
+    for (size_t i = 0; i < points && ok; ++i) {
+      ok = std::fread(rec.data(), 1, (size_t)step, f) == (size_t)step;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int w = 0; w < 4; ++w) if (off[w] >= 0) std::memcpy(&v[w], rec.data() + off[w], 4);
+      out[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  } else if (data == "ascii") {
+    std::vector<double> row((size_t)ncol);
+    for (size_t i = 0; i < points && ok; ++i) {
+      for (int c = 0; c < ncol && ok; ++c) ok = std::fscanf(f, "%lf", &row[(size_t)c]) == 1;
+      out[i] = make_float4((float)row[(size_t)col[0]], (float)row[(size_t)col[1]], (float)row[(size_t)col[2]],
+                           col[3] >= 0 ? (float)row[(size_t)col[3]] : 0.f);
+    }
+  } else {
+    ok = false;
+    err = "unsupported PCD DATA '" + data + "' in " + path;
+  }
+  std::fclose(f);
+  if (!ok && err.empty()) err = "truncated PCD " + path;
+  return ok;
+}
+}  // namespace
+
+int lslam_fmap_save(lslam_fmap *fm, const char *directory) {
+  int rc = check_fm(fm);
+  if (rc) return rc;
+  if (!directory) return LSLAM_ERR_INVALID;
+  hipStream_t s = fm->stream;
+  std::vector<float4> h[2];
+  for (int t = 0; t < 2; ++t) {
+    rc = refresh_segments(fm, t);
+    if (rc) return rc;
+    h[t].resize(fm->n[t]);
+    if (fm->n[t]) FM_TRY(hipMemcpyAsync(h[t].data(), fm->pts[t].p, fm->n[t] * sizeof(float4), hipMemcpyDeviceToHost, s));
+  }
+  FM_TRY(hipStreamSynchronize(s));
+  const std::string dir(directory);
+  std::ofstream fout(dir + "/index.txt");
+  if (!fout) {
+    lslam::set_error("save files error!");
+    return LSLAM_ERR_INVALID;
+  }
+  int count = 0;
+  for (int i = 0; i < fm->W; ++i)
+    for (int j = 0; j < fm->H; ++j)
+      for (int k = 0; k < fm->D; ++k) {
+        const int c = to_index(fm, i, j, k);
+        for (int t = 0; t < 2; ++t) {
+          const int32_t b = fm->h_begin[t][c], e = fm->h_end[t][c];
+          if (e <= b) continue;
+          if (!write_pcd_binary(dir + "/" + std::to_string(count) + ".pcd", h[t].data() + b, (size_t)(e - b))) {
+            lslam::set_error("cannot write a cube file");
+            return LSLAM_ERR_INVALID;
+          }
+          fout << count << " " << t << " " << i << " " << j << " " << k << " " << (e - b) << std::endl;
+          ++count;
+        }
+      }
+  return LSLAM_OK;
+}
+
+int lslam_fmap_load(lslam_fmap *fm, const char *directory) {
+  int rc = check_fm(fm);
+  if (rc) return rc;
+  if (!directory) return LSLAM_ERR_INVALID;
+  const std::string dir(directory);
+  std::ifstream fin(dir + "/index.txt");
+  if (!fin) {
+    lslam::set_error("no index.txt in the directory");
+    return LSLAM_ERR_INVALID;  // the reference returns false and starts with an empty map
+  }
+  std::vector<float4> pts[2];
+  std::vector<int32_t> cube[2];
+  std::vector<uint8_t> loaded[2];
+  loaded[0].assign(fm->ncube, 0);
+  loaded[1].assign(fm->ncube, 0);
+  int count, type, i, j, k, size;
+  std::string err;
+  while (fin >> count >> type >> i >> j >> k >> size) {  // (the reference's eof() loop re-reads the last
+    if ((type != 0 && type != 1) || !idx_valid(fm, i, j, k)) continue;  // line: same result)
+    std::vector<float4> cl;
+    if (!read_pcd(dir + "/" + std::to_string(count) + ".pcd", cl, err)) continue;  // reference: prints, goes on
+    const int c = to_index(fm, i, j, k);
+    if (loaded[type][c]) {  // a later entry for the same cube replaces the earlier one
+      size_t w = 0;
+      for (size_t q = 0; q < pts[type].size(); ++q)
+        if (cube[type][q] != c) { pts[type][w] = pts[type][q]; cube[type][w] = cube[type][q]; ++w; }
+      pts[type].resize(w);
+      cube[type].resize(w);
+    }
+    loaded[type][c] = 1;
+    pts[type].insert(pts[type].end(), cl.begin(), cl.end());
+    cube[type].insert(cube[type].end(), cl.size(), c);
+  }
+  hipStream_t s = fm->stream;
+  Buf<uint8_t> d_flags;
+  FM_TRY(d_flags.reserve(fm->ncube));
+  for (int t = 0; t < 2 && rc == LSLAM_OK; ++t) {
+    const size_t n = pts[t].size();
+    if (hipMemcpyAsync(d_flags.p, loaded[t].data(), fm->ncube, hipMemcpyHostToDevice, s) != hipSuccess) { rc = LSLAM_ERR_HIP; break; }
+    if (fm->n[t])
+      hipLaunchKernelGGL(fm_dropflag_kernel, dim3(((int)fm->n[t] + 255) / 256), dim3(256), 0, s, fm->cube[t].p, (int)fm->n[t],
+                         d_flags.p);
+    if (n) {
+      if (fm->in_tf.reserve(n) != hipSuccess || fm->in_cube.reserve(n) != hipSuccess ||
+          hipMemcpyAsync(fm->in_tf.p, pts[t].data(), n * sizeof(float4), hipMemcpyHostToDevice, s) != hipSuccess ||
+          hipMemcpyAsync(fm->in_cube.p, cube[t].data(), n * sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess) {
+        rc = LSLAM_ERR_HIP;
+        break;
+      }
+    }
+    // each loaded cube goes through its type's VoxelGrid (FeatureMap.h:432-436,448-452)
+    rc = rebuild(fm, t, n, true, d_flags.p);
+    if (rc == LSLAM_OK && hipStreamSynchronize(s) != hipSuccess) rc = LSLAM_ERR_HIP;
+  }
+  d_flags.release();
+  if (rc == LSLAM_ERR_HIP) lslam::set_error("HIP error while loading cube files");
+  return rc;
 }
 
 // pcl::VoxelGrid<PointXYZI> with a cubic leaf on one host cloud (LaserMatcher.cpp:289-301)

@@ -100,6 +100,20 @@ class FeatureMap:
         self._check(self.lib.lslam_fmap_get_full_map(self.h, _fp(out), n.value, C.byref(n)))
         return out
 
+    # ---- FeatureMap.h:378-462 -------------------------------------------------------------
+    def save_cloud_to_files(self, directory):
+        """saveCloudToFiles: <count>.pcd (binary, x y z intensity) per non-empty cube and type + index.txt."""
+        self._check(self.lib.lslam_fmap_save(self.h, str(directory).encode()))
+        return True
+
+    def load_cloud_from_files(self, directory):
+        """loadCloudFromFiles: False (like the reference) when the directory has no index.txt."""
+        import os
+        if not os.path.exists(os.path.join(str(directory), "index.txt")):
+            return False
+        self._check(self.lib.lslam_fmap_load(self.h, str(directory).encode()))
+        return True
+
     def info(self):
         origin = np.zeros(3, np.int32)
         nv = C.c_int32()

@@ -271,6 +271,10 @@ int lslam_fmap_get_surround(lslam_fmap *fm, float *corner_xyzi, size_t cap_corne
  * LaserMatcher::prepareFeatureSurround + ScanMatch.cpp:68-76 do through the host), kd-trees
  * built on the device. */
 int lslam_fmap_surround_to_map(lslam_fmap *fm);
+/* ... or as a variant-C map: one kd-tree per cube of the active area (cubes with fewer than 5
+ * points skipped, FeatureMap.h:524,546), all built in one go on the device; scan points are then
+ * matched against the tree of the cube they fall into (FeatureMap::scanMatchScan, :490-691). */
+int lslam_fmap_to_cubemap(lslam_fmap *fm);
 /* getFullMap, FeatureMap.h:267-286: per cube, VoxelGrid(map leaf) of corner then surf. */
 int lslam_fmap_get_full_map(lslam_fmap *fm, float *out_xyzi, size_t cap, size_t *n_out);
 /* saveCloudToFiles / loadCloudFromFiles, FeatureMap.h:378-462: one binary PCD (fields x y z

@@ -211,3 +211,39 @@ def test_feature_map_files_round_trip(pkg, ctx, oracle, tmp_path):
     assert len(c3) == 0 and len(s3) == 1 and np.allclose(s3[0], [1.05, 2.0, 3.0, 7.5])
     for m in (fm, fm2, fm3):
         m.close()
+
+
+def test_feature_map_to_cubemap_matches_oracle(pkg, ctx, oracle, synth, small_problem):
+    """Variant C on the maintained map: the active cubes become per-cube kd-trees on the device
+    (lslam_fmap_to_cubemap) and a scan is matched against them -- against the oracle's
+    FeatureMap::scanMatchScan restatement on the oracle map's content (same cubes, same points)."""
+    pr = small_problem
+    W, H, D, size = 13, 13, 5, 20.0
+    fm = pkg.FeatureMap(ctx, W, H, D)
+    ofm = oracle.feature_map(W, H, D)
+    for m in (fm, ofm):
+        m.setup_world_cube_size(size)
+        m.setup_lidar_valid_distance(90.0)
+        m.setup_filter_size(0.2, 0.4, 0.6)
+    def xyzi(a):
+        o = np.zeros((len(a), 4), np.float32)
+        o[:, :3] = a[:, :3]
+        return o
+    gt = pr["gt_pose"]
+    for m in (fm, ofm):
+        m.update(gt[3:])
+        m.add_feature_cloud(xyzi(pr["map_corner"]), xyzi(pr["map_surf"]), np.eye(4, dtype=np.float32))
+    oc, os_ = ofm.get_surround_feature()
+    gc, gs = fm.get_surround_feature()
+    assert np.array_equal(bits(gc), bits(oc)) and np.array_equal(bits(gs), bits(os_))
+    fm.to_cubemap()
+    assert ctx.map_info().built_on_device == 1
+    opts = ctx.default_opts()
+    opts.use_score = 0
+    status, pose, st = ctx.scanmatch_scan(pr["corner"], pr["surf"], pr["init_pose"], opts)
+    origin = [int(v) for v in fm.info()["origin"]]
+    ok, opose, ost = oracle.scanmatch_cubes(oc, os_, pr["corner"], pr["surf"], pr["init_pose"], size, origin, (W, H, D))
+    assert st.converged == ost.converged == 1 and st.iterations == ost.iterations
+    assert (st.n_line, st.n_plane, st.n_rows) == (ost.n_line, ost.n_plane, ost.n_rows)
+    assert np.abs(pose[3:] - opose[3:]).max() <= 1e-4 and np.abs(pose[:3] - opose[:3]).max() <= 1e-5
+    fm.close()

@@ -93,6 +93,7 @@ struct lslam_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // the corner tree is built beside the surf tree
   ScanPrep *scanprep = nullptr;
+  int cube_sides_on_device = 0;  // cube-map sides built by the device forest builder (of the last set)
   DevTree tc, ts;
   // variant C: per-cube trees (shared node/point arrays in tc/ts, one TreeView per cube)
   bool cube_mode = false;
@@ -563,10 +564,58 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
 }
 }  // namespace
 
+namespace {
+int build_cube_side_device(lslam_ctx *ctx, DevTree &dt, const float4 *src, bool src_on_device, size_t n_pts,
+                           const std::vector<int32_t> &roots_lr, const std::vector<int32_t> &cell_tree, float cube_size,
+                           const int32_t origin[3], const int32_t dims[3], DevBuf<int32_t> &cells_d,
+                           DevBuf<TreeView> &views_d, CubeGridDev &grid, int *max_depth, size_t *n_nodes, int *fallback);
+}  // namespace
+
 namespace lslam {
 int map_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t n_corner, const float4 *d_surf, size_t n_surf) {
   return map_set_impl(ctx, nullptr, n_corner, nullptr, n_surf, sizeof(float4), d_corner ? d_corner : d_surf,
                       d_surf ? d_surf : d_corner);
+}
+// variant C map straight from device arrays (map maintenance): per side the cubes' clouds back to
+// back with .w = index inside the cube, their ranges, and the cell -> tree table
+int cubemap_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t nc, const std::vector<int32_t> &roots_c,
+                       const std::vector<int32_t> &cells_c, const float4 *d_surf, size_t ns,
+                       const std::vector<int32_t> &roots_s, const std::vector<int32_t> &cells_s, float cube_size,
+                       const int32_t origin[3], const int32_t dims[3]) {
+  int rc = check_ctx(ctx);
+  if (rc) return rc;
+  ctx->have_map = false;
+  ctx->prev_valid = false;
+  const double t0 = now_ms();
+  int dc = 0, ds = 0, fb = 0;
+  size_t nn_c = 0, nn_s = 0;
+  rc = build_cube_side_device(ctx, ctx->tc, d_corner, true, nc, roots_c, cells_c, cube_size, origin, dims, ctx->cell_c,
+                              ctx->views_c, ctx->gc, &dc, &nn_c, &fb);
+  if (rc) return rc;
+  if (!fb)
+    rc = build_cube_side_device(ctx, ctx->ts, d_surf, true, ns, roots_s, cells_s, cube_size, origin, dims, ctx->cell_s,
+                                ctx->views_s, ctx->gs, &ds, &nn_s, &fb);
+  if (rc) return rc;
+  if (fb) {
+    set_err("device cube-tree build hit a structure limit (%d)", fb);
+    return LSLAM_ERR_INVALID;
+  }
+  if (dc > KD_STACK_MAX || ds > KD_STACK_MAX) {
+    set_err("kd-tree depth %d/%d exceeds device stack %d", dc, ds, KD_STACK_MAX);
+    return LSLAM_ERR_TREE_DEPTH;
+  }
+  ctx->info = lslam_map_info{};
+  ctx->info.n_corner = nc;
+  ctx->info.n_surf = ns;
+  ctx->info.nodes_corner = (uint32_t)nn_c;
+  ctx->info.nodes_surf = (uint32_t)nn_s;
+  ctx->info.depth_corner = dc;
+  ctx->info.depth_surf = ds;
+  ctx->info.build_ms = (float)(now_ms() - t0);
+  ctx->info.built_on_device = 1;
+  ctx->cube_mode = true;
+  ctx->have_map = true;
+  return LSLAM_OK;
 }
 void set_error(const char *msg) { set_err("%s", msg); }
 int ctx_device(const lslam_ctx *ctx) { return ctx ? ctx->device : -1; }
@@ -584,6 +633,48 @@ int lslam_map_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const voi
 }
 
 namespace {
+
+// One side (corner or surf) of a cube map built on the device: `src` holds the cubes' clouds back to
+// back (cube after cube, .w = index inside the cube's cloud), roots_lr the range of every cube that
+// gets a tree, cell_tree[cell] = index into roots_lr or -1.  All trees share dt.nodes / dt.pts.
+// *fallback != 0: the device build gave up (caller uses the host builder).
+int build_cube_side_device(lslam_ctx *ctx, DevTree &dt, const float4 *src, bool src_on_device, size_t n_pts,
+                           const std::vector<int32_t> &roots_lr, const std::vector<int32_t> &cell_tree, float cube_size,
+                           const int32_t origin[3], const int32_t dims[3], DevBuf<int32_t> &cells_d,
+                           DevBuf<TreeView> &views_d, CubeGridDev &grid, int *max_depth, size_t *n_nodes, int *fallback) {
+  const int T = (int)(roots_lr.size() / 2);
+  *fallback = 0;
+  *max_depth = 0;
+  *n_nodes = 0;
+  HIP_TRY(dt.pts.reserve(n_pts + 16));
+  HIP_TRY(cells_d.reserve(cell_tree.size()));
+  HIP_TRY(views_d.reserve((size_t)T + 1));
+  std::vector<TreeView> views((size_t)T);
+  size_t n_leaves = 0;
+  for (int attempt = 0; attempt < 3 && T > 0; ++attempt) {
+    const size_t mult[3] = {2, 8, 24};
+    const size_t cap = ((mult[attempt] * n_pts / 3 + 64 + 8 * (size_t)T) + 7) & ~(size_t)7;
+    HIP_TRY(dt.nodes.reserve(cap));
+    if (n_pts)
+      HIP_TRY(hipMemcpyAsync(dt.pts.p, src, n_pts * sizeof(float4), src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                             ctx->stream));
+    HIP_TRY(build_kdforest_device(dt.pts.p, (int32_t)n_pts, roots_lr.data(), T, dt.nodes.p, (int32_t)cap, ctx->stream,
+                                  views.data(), max_depth, &n_leaves, fallback));
+    if (*fallback != 1) break;
+  }
+  if (*fallback) return LSLAM_OK;
+  HIP_TRY(hipMemcpyAsync(cells_d.p, cell_tree.data(), cell_tree.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  if (T) HIP_TRY(hipMemcpyAsync(views_d.p, views.data(), (size_t)T * sizeof(TreeView), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  grid.cube_size = cube_size;
+  for (int d = 0; d < 3; ++d) { grid.origin[d] = origin[d]; grid.dims[d] = dims[d]; }
+  grid.cell_tree = cells_d.p;
+  grid.trees = views_d.p;
+  dt.depth = *max_depth;
+  dt.view = TreeView{};
+  *n_nodes = T ? (size_t)views[0].n_nodes / 8 * 7 + n_leaves : 0;
+  return LSLAM_OK;
+}
 
 // Partition one cloud into cubes (pushCornerPoint / pushSurfPoint, util/FeatureMap.h:188-204:
 // input order is kept inside a cube), build one tree per cube with >= 5 points and upload
@@ -609,6 +700,26 @@ int build_cube_trees(lslam_ctx *ctx, const void *cloud, size_t n, size_t stride_
   std::vector<size_t> fill(first.begin(), first.end() - 1);
   for (size_t i = 0; i < n; ++i)
     if (cell_of[i] >= 0) sorted[fill[cell_of[i]]++] = pts[i];
+  static const bool host_tree = std::getenv("LSLAM_HOST_TREE") != nullptr;
+  if (!host_tree) {  // all cube trees at once on the device
+    std::vector<int32_t> roots_lr, cell_tree_dev(n_cells, -1);
+    for (size_t c = 0; c < n_cells; ++c) {
+      if (count[c] < 5) continue;  // FeatureMap.h:524,546
+      cell_tree_dev[c] = (int32_t)(roots_lr.size() / 2);
+      roots_lr.push_back((int32_t)first[c]);
+      roots_lr.push_back((int32_t)first[c + 1]);
+      for (int32_t k = 0; k < count[c]; ++k) sorted[first[c] + (size_t)k].w = __builtin_bit_cast(float, k);
+    }
+    int fallback = 0;
+    int rc = build_cube_side_device(ctx, dt, sorted.data(), false, sorted.size(), roots_lr, cell_tree_dev, cube_size, origin,
+                                    dims, cells_d, views_d, grid, max_depth, n_nodes, &fallback);
+    if (rc) return rc;
+    if (!fallback) {
+      ctx->cube_sides_on_device++;
+      return LSLAM_OK;
+    }
+    if (std::getenv("LSLAM_DEBUG")) fprintf(stderr, "[lslam] device cube-tree build hit limit %d: host build instead\n", fallback);
+  }
   std::vector<int32_t> cell_tree(n_cells, -1);
   std::vector<TreeView> views;
   std::vector<KdNode> all_nodes;
@@ -680,6 +791,7 @@ int lslam_cubemap_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const
   const double t0 = now_ms();
   int dc = 0, ds = 0;
   size_t nc_nodes = 0, ns_nodes = 0;
+  ctx->cube_sides_on_device = 0;
   rc = build_cube_trees(ctx, corner, n_corner, stride_bytes, cube_size, origin, dims, ctx->tc, ctx->cell_c,
                         ctx->views_c, ctx->gc, &dc, &nc_nodes);
   if (rc) return rc;
@@ -698,6 +810,7 @@ int lslam_cubemap_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const
   ctx->info.depth_corner = dc;
   ctx->info.depth_surf = ds;
   ctx->info.build_ms = (float)(now_ms() - t0);
+  ctx->info.built_on_device = ctx->cube_sides_on_device == 2 ? 1 : 0;
   ctx->cube_mode = true;
   ctx->have_map = true;
   return LSLAM_OK;

@@ -305,7 +305,8 @@ __global__ void fm_gather_kernel(const float4 *pts, const int32_t *src_begin, co
     if (dst_begin[mid] <= i) lo = mid; else hi = mid - 1;
   }
   float4 p = pts[src_begin[lo] + (i - dst_begin[lo])];
-  if (index_in_w) p.w = __builtin_bit_cast(float, (uint32_t)i);
+  if (index_in_w == 1) p.w = __builtin_bit_cast(float, (uint32_t)i);
+  else if (index_in_w == 2) p.w = __builtin_bit_cast(float, (uint32_t)(i - dst_begin[lo]));  // index inside the cube
   out[i] = p;
 }
 
@@ -561,14 +562,21 @@ int check_fm(lslam_fmap *fm) {
 }
 
 // surround arrays of type t into fm->sur[t]; returns count
-int gather_surround(lslam_fmap *fm, int t, int index_in_w, size_t *n_out) {
+int gather_surround(lslam_fmap *fm, int t, int index_in_w, size_t *n_out, int min_points = 1,
+                    std::vector<int32_t> *roots_lr = nullptr, std::vector<int32_t> *cell_tree = nullptr) {
   int rc = refresh_segments(fm, t);
   if (rc) return rc;
   std::vector<int32_t> src, dst;
   size_t total = 0;
+  if (cell_tree) cell_tree->assign((size_t)fm->ncube, -1);
   for (int32_t c : fm->valid) {
     const int32_t b = fm->h_begin[t][c], e = fm->h_end[t][c];
-    if (e > b) {
+    if (e - b >= min_points && e > b) {
+      if (roots_lr) {
+        if (cell_tree) (*cell_tree)[(size_t)c] = (int32_t)(roots_lr->size() / 2);
+        roots_lr->push_back((int32_t)total);
+        roots_lr->push_back((int32_t)(total + (size_t)(e - b)));
+      }
       src.push_back(b);
       dst.push_back((int32_t)total);
       total += (size_t)(e - b);
@@ -800,6 +808,23 @@ int lslam_fmap_surround_to_map(lslam_fmap *fm) {
   FM_TRY(fm->sur[0].reserve(1));
   FM_TRY(fm->sur[1].reserve(1));
   return lslam::map_set_device(fm->ctx, fm->sur[0].p, n[0], fm->sur[1].p, n[1]);
+}
+
+// The active area as a variant-C map (FeatureMap::scanMatchScan, FeatureMap.h:490-691: one kd-tree
+// per cube, cubes with fewer than 5 points skipped :524,546), built for all cubes at once on the device.
+int lslam_fmap_to_cubemap(lslam_fmap *fm) {
+  int rc = check_fm(fm);
+  if (rc) return rc;
+  std::vector<int32_t> roots[2], cells[2];
+  size_t n[2] = {0, 0};
+  for (int t = 0; t < 2; ++t) {
+    rc = gather_surround(fm, t, 2, &n[t], 5, &roots[t], &cells[t]);
+    if (rc) return rc;
+    FM_TRY(fm->sur[t].reserve(1));
+  }
+  const int32_t dims[3] = {fm->W, fm->H, fm->D};
+  return lslam::cubemap_set_device(fm->ctx, fm->sur[0].p, n[0], roots[0], cells[0], fm->sur[1].p, n[1], roots[1], cells[1],
+                                   fm->cube_size, fm->origin, dims);
 }
 
 int lslam_fmap_info(lslam_fmap *fm, int32_t origin[3], int32_t *n_valid, int32_t *valid_out, size_t cap,

@@ -157,6 +157,9 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
                                hipStream_t stream, TreeView *view, int *depth, size_t *n_leaves,
                                int *fallback);
 
+hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *roots_lr, int T, KdNode *d_nodes,
+                                 int32_t node_cap, hipStream_t stream, TreeView *views, int *max_depth,
+                                 size_t *n_leaves, int *fallback);
 void treebuild_release_scratch(hipStream_t s);  // frees the per-stream build scratch
 
 // lslam_api.hip internals used by lslam_fmap.hip (map maintenance)
@@ -164,6 +167,10 @@ void treebuild_release_scratch(hipStream_t s);  // frees the per-stream build sc
 struct lslam_ctx;
 namespace lslam {
 int map_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t n_corner, const float4 *d_surf, size_t n_surf);
+int cubemap_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t nc, const std::vector<int32_t> &roots_c,
+                       const std::vector<int32_t> &cells_c, const float4 *d_surf, size_t ns,
+                       const std::vector<int32_t> &roots_s, const std::vector<int32_t> &cells_s, float cube_size,
+                       const int32_t origin[3], const int32_t dims[3]);
 void set_error(const char *msg);
 int ctx_device(const lslam_ctx *ctx);
 bool ctx_alive(const lslam_ctx *ctx);

@@ -81,6 +81,7 @@ struct BuildArgs {
   int32_t sub_cap;
   int32_t *tmpA, *tmpB;  // scratch, one int per point
   BuildCtl *ctl;
+  int32_t *root_feat;  // split dimension of root t (a root's parent_word is -1 - t)
   int32_t n;
 };
 
@@ -384,7 +385,7 @@ __device__ void process_node(const BuildArgs &A, Sh<TB> &sh, const BuildItem &it
     if (it.parent_word >= 0)
       atomicOr(reinterpret_cast<unsigned int *>(A.nodes) + it.parent_word, (unsigned int)feat);
     else
-      A.ctl->root_feat = feat;
+      A.root_feat[-1 - it.parent_word] = feat;
     *n_out = cnt;
     sh.bc_i[1] = cnt;
   }
@@ -669,7 +670,7 @@ __global__ __launch_bounds__(64) void kd_build_small_kernel(BuildArgs A) {
         if (it.parent_word >= 0)
           atomicOr(reinterpret_cast<unsigned int *>(A.nodes) + it.parent_word, (unsigned int)feat);
         else
-          A.ctl->root_feat = feat;
+          A.root_feat[-1 - it.parent_word] = feat;
       }
       __syncthreads();
     }
@@ -1013,7 +1014,7 @@ __global__ void lv_final_kernel(LvArgs L) {
   if (it.parent_word >= 0)
     atomicOr(reinterpret_cast<unsigned int *>(A.nodes) + it.parent_word, (unsigned int)feat);
   else
-    A.ctl->root_feat = feat;
+    A.root_feat[-1 - it.parent_word] = feat;
 }
 
 // bounding box of the whole cloud (computeBoundingBox, :1406-1427) + identity .w
@@ -1038,6 +1039,32 @@ __global__ __launch_bounds__(256) void kd_bbox_kernel(const float4 *pts, int n, 
     for (int w = 1; w < 4; ++w) { a = fminf(a, smin[d][w]); b = fmaxf(b, smax[d][w]); }
     part[blockIdx.x * 6 + d] = a;
     part[blockIdx.x * 6 + 3 + d] = b;
+  }
+}
+
+// one workgroup per root: bounding box of its own point range (computeBoundingBox, :1406-1427)
+__global__ __launch_bounds__(256) void kd_bbox_seg_kernel(const float4 *pts, const int32_t *roots_lr, float *out) {
+  __shared__ float smin[3][4], smax[3][4];
+  const int l = roots_lr[2 * blockIdx.x], r = roots_lr[2 * blockIdx.x + 1];
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = l + threadIdx.x; i < r; i += 256) {
+    const float4 p = pts[i];
+    mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+    mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+    mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int d = 0; d < 3; ++d) {
+    const float a = wave_min(mn[d]), b = wave_max(mx[d]);
+    if (lane == 0) { smin[d][wave] = a; smax[d][wave] = b; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int d = threadIdx.x;
+    float a = smin[d][0], b = smax[d][0];
+    for (int w = 1; w < 4; ++w) { a = fminf(a, smin[d][w]); b = fmaxf(b, smax[d][w]); }
+    out[blockIdx.x * 6 + d] = a;
+    out[blockIdx.x * 6 + 3 + d] = b;
   }
 }
 
@@ -1084,6 +1111,91 @@ void treebuild_release_scratch(hipStream_t s) {
   if (it->second.part) (void)hipFree(it->second.part);
   g_pool.erase(it);
 }
+
+namespace {
+// Phase 0 driver: processes `level` (every entry more than HUGE_MIN points) and the levels it
+// spawns; smaller children land in A.queue / A.sublist.  n = points the trees span in total.
+hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t n, hipStream_t stream, int *fallback) {
+  hipError_t e;
+  void *lv_blob = nullptr;
+  {
+    const int n_first = (int)level.size();
+    const int cap_nodes = n / HUGE_MIN * 2 + n_first + 8, cap_chunks = n / LV_CH + cap_nodes + 8;
+    const size_t sz_items = (size_t)cap_nodes * sizeof(BuildItem), sz_stat = (size_t)cap_nodes * sizeof(LvStat),
+                 sz_ci = (size_t)cap_chunks * sizeof(int32_t), sz_ni = (size_t)cap_nodes * sizeof(int32_t);
+    if ((e = pool_get(stream, true, 2 * sz_items + sz_stat + 5 * sz_ci + sz_ni + 64, &lv_blob)) != hipSuccess) return e;
+    char *q = static_cast<char *>(lv_blob);
+    BuildItem *d_items = reinterpret_cast<BuildItem *>(q); q += sz_items;
+    BuildItem *d_next = reinterpret_cast<BuildItem *>(q); q += sz_items;
+    LvStat *d_stat = reinterpret_cast<LvStat *>(q); q += sz_stat;
+    int32_t *d_chunk_node = reinterpret_cast<int32_t *>(q); q += sz_ci;
+    int32_t *d_cntL = reinterpret_cast<int32_t *>(q); q += sz_ci;
+    int32_t *d_cntR = reinterpret_cast<int32_t *>(q); q += sz_ci;
+    int32_t *d_baseL = reinterpret_cast<int32_t *>(q); q += sz_ci;
+    int32_t *d_baseR = reinterpret_cast<int32_t *>(q); q += sz_ci;
+    int32_t *d_chunk_first = reinterpret_cast<int32_t *>(q); q += sz_ni;
+    int32_t *d_next_count = reinterpret_cast<int32_t *>(q);
+    // items ping-pong between two device buffers; the header word in front of each holds the count
+    // the previous level's final kernel produced (one download + one synchronisation per level)
+    std::vector<int32_t> chunk_node, chunk_first;
+    std::vector<char> dl(sizeof(BuildItem) * (size_t)cap_nodes + 16);
+    BuildItem *d_cur = d_items, *d_nxt = d_next;
+    if ((e = hipMemcpyAsync(d_cur, level.data(), (size_t)n_first * sizeof(BuildItem), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;  // `level` is rewritten below
+    while (!level.empty()) {
+      const int H = (int)level.size();
+      chunk_node.clear();
+      chunk_first.assign(H, 0);
+      for (int j = 0; j < H; ++j) {
+        chunk_first[j] = (int32_t)chunk_node.size();
+        const int nch = (level[j].r - level[j].l + LV_CH - 1) / LV_CH;
+        chunk_node.insert(chunk_node.end(), nch, j);
+      }
+      const int C = (int)chunk_node.size();
+      if (H > cap_nodes || C > cap_chunks) { *fallback = 3; return hipSuccess; }
+      if ((e = hipMemcpyAsync(d_chunk_node, chunk_node.data(), (size_t)C * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+      if ((e = hipMemcpyAsync(d_chunk_first, chunk_first.data(), (size_t)H * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+      LvArgs L{};
+      L.A = A;
+      L.items = d_cur;
+      L.stat = d_stat;
+      L.chunk_node = d_chunk_node;
+      L.chunk_first = d_chunk_first;
+      L.cntL = d_cntL; L.cntR = d_cntR; L.baseL = d_baseL; L.baseR = d_baseR;
+      L.next_items = d_nxt;
+      L.next_count = d_next_count;
+      L.n_nodes = H;
+      L.n_chunks = C;
+      L.next_cap = cap_nodes;
+      const dim3 gc(C), gn((H + 63) / 64), bt(LV_TB);
+      hipLaunchKernelGGL(lv_init_kernel, gn, dim3(64), 0, stream, L);
+      hipLaunchKernelGGL(lv_minmax_kernel, gc, bt, 0, stream, L);
+      hipLaunchKernelGGL(lv_split_kernel, gn, dim3(64), 0, stream, L);
+      hipLaunchKernelGGL(lv_count_kernel, gc, bt, 0, stream, L);
+      for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(lv_hflags_kernel, gc, bt, 0, stream, L, pass);
+        hipLaunchKernelGGL(lv_hscan_kernel, dim3(H), bt, 0, stream, L, pass);
+        hipLaunchKernelGGL(lv_hwrite_kernel, gc, bt, 0, stream, L, pass);
+        hipLaunchKernelGGL(lv_hswap_kernel, gc, bt, 0, stream, L, pass);
+      }
+      hipLaunchKernelGGL(lv_bounds_kernel, gc, bt, 0, stream, L);
+      hipLaunchKernelGGL(lv_final_kernel, gn, dim3(64), 0, stream, L);
+      // the children that are huge again: count first (4 bytes), then as many items as a level of this
+      // size can produce (2 H) in the same round trip
+      int32_t n_next = 0;
+      const size_t want = (size_t)std::min(2 * H, cap_nodes) * sizeof(BuildItem);
+      if ((e = hipMemcpyAsync(&n_next, d_next_count, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+      if ((e = hipMemcpyAsync(dl.data(), d_nxt, want, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+      if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+      n_next = std::min(n_next, std::min(2 * H, cap_nodes));
+      level.resize((size_t)n_next);
+      if (n_next) std::memcpy(level.data(), dl.data(), (size_t)n_next * sizeof(BuildItem));
+      std::swap(d_cur, d_nxt);
+    }
+  }
+  return hipSuccess;
+}
+}  // namespace
 
 hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_t node_cap,
                                hipStream_t stream, TreeView *view, int *depth, size_t *n_leaves,
@@ -1149,6 +1261,7 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
   A.tmpA = reinterpret_cast<int32_t *>(p); p += sz_tmp;
   A.tmpB = reinterpret_cast<int32_t *>(p); p += sz_tmp;
   A.ctl = reinterpret_cast<BuildCtl *>(p);
+  A.root_feat = &A.ctl->root_feat;
   if ((e = hipMemsetAsync(A.q_ready, 0, sz_ready, stream)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(d_nodes, 0, (size_t)A.node_cap * sizeof(KdNode), stream)) != hipSuccess) return e;
   BuildCtl ctl{};
@@ -1182,81 +1295,10 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
     if ((e = hipMemcpyAsync(root_small ? A.sublist : A.queue, &root, sizeof(root), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(A.q_ready, &one, sizeof(one), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
   }
-  void *lv_blob = nullptr;
   if (root_huge) {
     // ---- phase 0: level-synchronous processing of the nodes with more than HUGE_MIN points ----
-    const int cap_nodes = n / HUGE_MIN * 2 + 8, cap_chunks = n / LV_CH + cap_nodes + 8;
-    const size_t sz_items = (size_t)cap_nodes * sizeof(BuildItem), sz_stat = (size_t)cap_nodes * sizeof(LvStat),
-                 sz_ci = (size_t)cap_chunks * sizeof(int32_t), sz_ni = (size_t)cap_nodes * sizeof(int32_t);
-    if ((e = pool_get(stream, true, 2 * sz_items + sz_stat + 5 * sz_ci + sz_ni + 64, &lv_blob)) != hipSuccess) return e;
-    char *q = static_cast<char *>(lv_blob);
-    BuildItem *d_items = reinterpret_cast<BuildItem *>(q); q += sz_items;
-    BuildItem *d_next = reinterpret_cast<BuildItem *>(q); q += sz_items;
-    LvStat *d_stat = reinterpret_cast<LvStat *>(q); q += sz_stat;
-    int32_t *d_chunk_node = reinterpret_cast<int32_t *>(q); q += sz_ci;
-    int32_t *d_cntL = reinterpret_cast<int32_t *>(q); q += sz_ci;
-    int32_t *d_cntR = reinterpret_cast<int32_t *>(q); q += sz_ci;
-    int32_t *d_baseL = reinterpret_cast<int32_t *>(q); q += sz_ci;
-    int32_t *d_baseR = reinterpret_cast<int32_t *>(q); q += sz_ci;
-    int32_t *d_chunk_first = reinterpret_cast<int32_t *>(q); q += sz_ni;
-    int32_t *d_next_count = reinterpret_cast<int32_t *>(q);
-    // items ping-pong between two device buffers; the header word in front of each holds the count
-    // the previous level's final kernel produced (one download + one synchronisation per level)
-    std::vector<BuildItem> level(1, root);
-    std::vector<int32_t> chunk_node, chunk_first;
-    std::vector<char> dl(sizeof(BuildItem) * (size_t)cap_nodes + 16);
-    BuildItem *d_cur = d_items, *d_nxt = d_next;
-    if ((e = hipMemcpyAsync(d_cur, &root, sizeof(root), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-    while (!level.empty()) {
-      const int H = (int)level.size();
-      chunk_node.clear();
-      chunk_first.assign(H, 0);
-      for (int j = 0; j < H; ++j) {
-        chunk_first[j] = (int32_t)chunk_node.size();
-        const int nch = (level[j].r - level[j].l + LV_CH - 1) / LV_CH;
-        chunk_node.insert(chunk_node.end(), nch, j);
-      }
-      const int C = (int)chunk_node.size();
-      if (H > cap_nodes || C > cap_chunks) { *fallback = 3; return hipSuccess; }
-      if ((e = hipMemcpyAsync(d_chunk_node, chunk_node.data(), (size_t)C * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-      if ((e = hipMemcpyAsync(d_chunk_first, chunk_first.data(), (size_t)H * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-      LvArgs L{};
-      L.A = A;
-      L.items = d_cur;
-      L.stat = d_stat;
-      L.chunk_node = d_chunk_node;
-      L.chunk_first = d_chunk_first;
-      L.cntL = d_cntL; L.cntR = d_cntR; L.baseL = d_baseL; L.baseR = d_baseR;
-      L.next_items = d_nxt;
-      L.next_count = d_next_count;
-      L.n_nodes = H;
-      L.n_chunks = C;
-      L.next_cap = cap_nodes;
-      const dim3 gc(C), gn((H + 63) / 64), bt(LV_TB);
-      hipLaunchKernelGGL(lv_init_kernel, gn, dim3(64), 0, stream, L);
-      hipLaunchKernelGGL(lv_minmax_kernel, gc, bt, 0, stream, L);
-      hipLaunchKernelGGL(lv_split_kernel, gn, dim3(64), 0, stream, L);
-      hipLaunchKernelGGL(lv_count_kernel, gc, bt, 0, stream, L);
-      for (int pass = 0; pass < 2; ++pass) {
-        hipLaunchKernelGGL(lv_hflags_kernel, gc, bt, 0, stream, L, pass);
-        hipLaunchKernelGGL(lv_hscan_kernel, dim3(H), bt, 0, stream, L, pass);
-        hipLaunchKernelGGL(lv_hwrite_kernel, gc, bt, 0, stream, L, pass);
-        hipLaunchKernelGGL(lv_hswap_kernel, gc, bt, 0, stream, L, pass);
-      }
-      hipLaunchKernelGGL(lv_bounds_kernel, gc, bt, 0, stream, L);
-      hipLaunchKernelGGL(lv_final_kernel, gn, dim3(64), 0, stream, L);
-      // the children that are huge again: count first (4 bytes), then as many items as a level of this
-      // size can produce (2 H) in the same round trip
-      int32_t n_next = 0;
-      const size_t want = (size_t)std::min(2 * H, cap_nodes) * sizeof(BuildItem);
-      if ((e = hipMemcpyAsync(&n_next, d_next_count, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-      if ((e = hipMemcpyAsync(dl.data(), d_nxt, want, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-      if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-      n_next = std::min(n_next, std::min(2 * H, cap_nodes));
-      level.resize((size_t)n_next);
-      if (n_next) std::memcpy(level.data(), dl.data(), (size_t)n_next * sizeof(BuildItem));
-      std::swap(d_cur, d_nxt);
-    }
+    if ((e = run_levels(A, std::vector<BuildItem>(1, root), n, stream, fallback)) != hipSuccess) return e;
+    if (*fallback) return hipSuccess;
   }
   // persistent grid: every workgroup must be resident (they wait on each other's output)
   int dev = 0, cus = 256;
@@ -1270,7 +1312,6 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
   if ((e = hipMemcpyAsync(&ctl, A.ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
   if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
   const double T3 = now();
-  (void)lv_blob;  // pooled
   if (dbg)
     fprintf(stderr, "[lslam] tree build n=%d: bbox %.2f ms, setup %.2f ms, build kernel %.2f ms, free %.2f ms (overflow %d, groups %d)\n",
             n, T1 - T0, T2 - T1, T3 - T2, now() - T3, ctl.overflow, ctl.next_group);
@@ -1281,6 +1322,117 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
   view->n_nodes = std::min(ctl.next_group * 8, A.node_cap);  // groups are taken eight at a time: the last few may be unused
   view->root_ref = (0u << 2) | (uint32_t)ctl.root_feat;
   *depth = ctl.max_depth;
+  *n_leaves = (size_t)ctl.n_leaves;
+  return hipSuccess;
+}
+
+// Many trees at once (variant C: one tree per map cube): `roots_lr` holds T point ranges of d_pts
+// (host array), all trees share d_nodes; tree t's root sits in node group t.  Phase 0 takes every
+// root above HUGE_MIN points, phase B the rest; roots of at most 10 points are leaves.  views[t] is
+// filled for every root (nodes = d_nodes, pts = d_pts: references are absolute).
+hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *roots_lr, int T, KdNode *d_nodes,
+                                 int32_t node_cap, hipStream_t stream, TreeView *views, int *max_depth,
+                                 size_t *n_leaves, int *fallback) {
+  *fallback = 0;
+  *max_depth = 0;
+  *n_leaves = 0;
+  if (T <= 0) return hipSuccess;
+  hipError_t e;
+  const int32_t sub_cap = std::max(64, 4 * (n_total / LOCAL_MAX + 16) + n_total / 8 + T);
+  const int32_t queue_cap = 64;  // unused: nothing sits between LOCAL_MAX and HUGE_MIN
+  BuildArgs A{};
+  A.pts = d_pts;
+  A.nodes = d_nodes;
+  A.node_cap = node_cap & ~7;
+  A.queue_cap = queue_cap;
+  A.sub_cap = sub_cap;
+  A.n = n_total;
+  const size_t sz_queue = (size_t)queue_cap * sizeof(BuildItem), sz_ready = (size_t)queue_cap * sizeof(int32_t),
+               sz_tmp = (size_t)std::max(n_total, 1) * sizeof(int32_t), sz_ctl = 256, sz_sub = (size_t)sub_cap * sizeof(BuildItem),
+               sz_rf = ((size_t)T * 4 + 15) & ~(size_t)15, sz_lr = ((size_t)T * 8 + 15) & ~(size_t)15, sz_bb = (size_t)T * 24;
+  void *blob = nullptr;
+  if ((e = pool_get(stream, false, sz_queue + sz_sub + sz_ready + 2 * sz_tmp + sz_ctl + sz_rf + sz_lr + sz_bb, &blob)) != hipSuccess) return e;
+  char *p = static_cast<char *>(blob);
+  A.queue = reinterpret_cast<BuildItem *>(p); p += sz_queue;
+  A.sublist = reinterpret_cast<BuildItem *>(p); p += sz_sub;
+  A.q_ready = reinterpret_cast<int32_t *>(p); p += sz_ready;
+  A.tmpA = reinterpret_cast<int32_t *>(p); p += sz_tmp;
+  A.tmpB = reinterpret_cast<int32_t *>(p); p += sz_tmp;
+  A.ctl = reinterpret_cast<BuildCtl *>(p); p += sz_ctl;
+  A.root_feat = reinterpret_cast<int32_t *>(p); p += sz_rf;
+  int32_t *d_lr = reinterpret_cast<int32_t *>(p); p += sz_lr;
+  float *d_bb = reinterpret_cast<float *>(p);
+  if ((e = hipMemcpyAsync(d_lr, roots_lr, (size_t)T * 8, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+  hipLaunchKernelGGL(kd_bbox_seg_kernel, dim3(T), dim3(256), 0, stream, d_pts, d_lr, d_bb);
+  std::vector<float> bb((size_t)T * 6);
+  if ((e = hipMemcpyAsync(bb.data(), d_bb, bb.size() * 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(d_nodes, 0, (size_t)A.node_cap * sizeof(KdNode), stream)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(A.root_feat, 0, sz_rf, stream)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+  std::vector<BuildItem> level, small;
+  std::vector<int32_t> slot_of(T, -1);
+  int groups = 0, leaves = 0;
+  for (int t = 0; t < T; ++t) {
+    const int l = roots_lr[2 * t], r = roots_lr[2 * t + 1], n = r - l;
+    TreeView &v = views[t];
+    v.nodes = d_nodes;
+    v.pts = d_pts;
+    v.n_pts = n;
+    v.n_nodes = 0;
+    for (int d = 0; d < 3; ++d) { v.bb_lo[d] = n > 0 ? bb[(size_t)t * 6 + d] : 0.f; v.bb_hi[d] = n > 0 ? bb[(size_t)t * 6 + 3 + d] : 0.f; }
+    if (n <= 10) {  // the root is a leaf (nanoflann.hpp:936-951)
+      v.root_ref = KD_LEAF | ((uint32_t)l << 4) | (uint32_t)std::max(n, 0);
+      if (n > 0) { ++leaves; *max_depth = std::max(*max_depth, 1); }
+      continue;
+    }
+    BuildItem it{};
+    it.l = l;
+    it.r = r;
+    for (int d = 0; d < 3; ++d) { it.lo[d] = v.bb_lo[d]; it.hi[d] = v.bb_hi[d]; }
+    it.slot = groups * 8;
+    it.heap = 0;
+    it.parent_word = -1 - t;
+    it.depth = 1;
+    slot_of[t] = it.slot;
+    ++groups;
+    (n > HUGE_MIN ? level : small).push_back(it);
+  }
+  if ((groups + 1) * 8 > A.node_cap || (int32_t)small.size() > sub_cap) {
+    *fallback = 1;
+    return hipSuccess;
+  }
+  BuildCtl ctl{};
+  ctl.next_group = groups;
+  ctl.n_sub = (int32_t)small.size();
+  ctl.n_leaves = leaves;
+  if ((e = hipMemcpyAsync(A.ctl, &ctl, sizeof(ctl), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+  if (!small.empty() &&
+      (e = hipMemcpyAsync(A.sublist, small.data(), small.size() * sizeof(BuildItem), hipMemcpyHostToDevice, stream)) != hipSuccess)
+    return e;
+  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;  // locals
+  if (!level.empty()) {
+    if ((e = run_levels(A, level, n_total, stream, fallback)) != hipSuccess) return e;
+    if (*fallback) return hipSuccess;
+  }
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  hipLaunchKernelGGL(kd_build_small_kernel, dim3(cus * 16), dim3(TB_SMALL), 0, stream, A);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  std::vector<int32_t> rf(T);
+  if ((e = hipMemcpyAsync(&ctl, A.ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(rf.data(), A.root_feat, (size_t)T * 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+  if (ctl.overflow) {
+    *fallback = ctl.overflow;
+    return hipSuccess;
+  }
+  const int32_t n_nodes = std::min(ctl.next_group * 8, A.node_cap);
+  for (int t = 0; t < T; ++t) {
+    views[t].n_nodes = n_nodes;
+    if (slot_of[t] >= 0) views[t].root_ref = ((uint32_t)slot_of[t] << 2) | (uint32_t)rf[t];
+  }
+  *max_depth = std::max(*max_depth, ctl.max_depth);
   *n_leaves = (size_t)ctl.n_leaves;
   return hipSuccess;
 }

@@ -93,6 +93,10 @@ class FeatureMap:
         """The surround becomes ``ctx``'s map without leaving HBM (device kd-tree build)."""
         self._check(self.lib.lslam_fmap_surround_to_map(self.h))
 
+    def to_cubemap(self):
+        """The active area becomes ``ctx``'s variant-C map: one kd-tree per cube (FeatureMap.h:490-691)."""
+        self._check(self.lib.lslam_fmap_to_cubemap(self.h))
+
     def get_full_map(self):
         n = C.c_size_t()
         self._check(self.lib.lslam_fmap_get_full_map(self.h, None, 0, C.byref(n)))

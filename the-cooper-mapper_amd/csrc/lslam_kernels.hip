@@ -53,8 +53,11 @@ LSLAM_DEV int cube_tree_of(const CubeGridDev &g, float x, float y, float z) {
   return -1;
 }
 
+#ifndef LSLAM_SHALLOW_OCC
+#define LSLAM_SHALLOW_OCC 5  // wavefronts per SIMD the shallow-stack variant is compiled for (96 VGPRs, 25 KB LDS per workgroup)
+#endif
 template <int BLOCK, bool OVF, bool CUBES, int LDS_DEPTH>
-__global__ __launch_bounds__(BLOCK, LDS_DEPTH <= 16 ? 4 : 2) void sweep_kernel(SweepArgs a, int jtj_mode) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH <= 16 ? LSLAM_SHALLOW_OCC : 2))) void sweep_kernel(SweepArgs a, int jtj_mode) {
   const int lb = xcd_remap(blockIdx.x, a.nb_total);
   const BlockDesc bd = a.blocks[lb];
   const GNState *st = a.states + bd.prob;
@@ -62,8 +65,11 @@ __global__ __launch_bounds__(BLOCK, LDS_DEPTH <= 16 ? 4 : 2) void sweep_kernel(S
 
   constexpr int NWAVE = BLOCK / 64;
   __shared__ float red[NWAVE][NCOL];
-  __shared__ float jrows[NWAVE][64][8];  // MFMA staging: [point][J0..J5,b,0]
+  // The MFMA staging of [J | b] (8 floats per point) lives in the wavefront's OWN traversal-stack
+  // slots -- word row c, lane slot p -- which are dead once its 5-NN searches are over: no extra LDS,
+  // no cross-wavefront hazard (the shallow variant then fits six workgroups per CU instead of four).
   __shared__ uint32_t stack_lds[2 * LDS_DEPTH * BLOCK];
+  static_assert(2 * LDS_DEPTH >= 8, "staging needs eight word rows of the stack");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -210,16 +216,18 @@ __global__ __launch_bounds__(BLOCK, LDS_DEPTH <= 16 ? 4 : 2) void sweep_kernel(S
 
   if (jtj_mode == 1) {
     // stage [J | b] rows; rows of rejected points are zero
-    float *jr = &jrows[wave][lane][0];
-    *reinterpret_cast<float4 *>(jr) = make_float4(row[0], row[1], row[2], row[3]);
-    *reinterpret_cast<float4 *>(jr + 4) = make_float4(row[4], row[5], rb, 0.0f);
+    float *jr = reinterpret_cast<float *>(stack_lds) + wave * 64;  // [c * BLOCK + p]
+#pragma unroll
+    for (int c = 0; c < 6; ++c) jr[c * BLOCK + lane] = row[c];
+    jr[6 * BLOCK + lane] = rb;
+    jr[7 * BLOCK + lane] = 0.0f;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     const int i16 = lane & 15, k4 = lane >> 4;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      const float op = (i16 < 8) ? jrows[wave][4 * s + k4][i16] : 0.0f;
+      const float op = (i16 < 8) ? jr[i16 * BLOCK + 4 * s + k4] : 0.0f;
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(op, op, acc, 0, 0, 0);
     }
     // C/D layout: col = lane&15, row = (lane>>4)*4 + reg.  Entry (r,c), r<=c<7.

@@ -338,7 +338,9 @@ def single_scan_leg(ctx, pr, opts, steps):
     return {"value": pt / dt, "unit": "point-residuals/s", "ms_per_scanmatch": 1e3 * dt / steps,
             "host_buffers_value": pt_h / dth, "host_buffers_ms_per_scanmatch": 1e3 * dth / steps,
             "gn_iterations": st.iterations, "sweep_kernel_ms": avg,
-            "roofline_frac": ALG_BYTES_PER_POINT_RESIDUAL * n / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS if avg > 0 else None}
+            # algorithmic bytes of the points actually processed / time of ALL sweep launches (the one
+            # trailing launch per call that finds the loop finished costs a few microseconds)
+            "roofline_frac": ALG_BYTES_PER_POINT_RESIDUAL * pt / (sw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sw_ms > 0 else None}
 
 
 def mapping_frame_leg(pkg, synth, ctx, pr, opts, np, with_cpu):

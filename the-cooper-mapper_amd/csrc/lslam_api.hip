@@ -1076,7 +1076,9 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
   int sweep_launches = 0;
   HIP_TRY(hipEventElapsedTime(&gpu_ms_total, ctx->ev0, ctx->ev1));
   if (o.profile) {
-    for (int it = 0; it < launched && it < max_sweeps; ++it) {
+    // every sweep launch of this call, the trailing ones that found all scans converged included
+    // (a few microseconds each): the same population rocprofv3's per-kernel average is taken over
+    for (int it = 0; it < launched; ++it) {
       float ms = 0.f;
       HIP_TRY(hipEventElapsedTime(&ms, ctx->sweep_ev[2 * it], ctx->sweep_ev[2 * it + 1]));
       gpu_ms_sweep += ms;

@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -43,10 +44,13 @@ namespace {
 // points from a global queue (hand-off with agent-scope release/acquire); a child with at
 // most LOCAL_MAX points goes to the subtree list instead.  Phase B: one wavefront per
 // subtree of that list builds it completely (explicit stack in LDS, no barriers needed).
+#ifndef LSLAM_LOCAL_MAX
+#define LSLAM_LOCAL_MAX 2048
+#endif
 constexpr int TB_BIG = 1024;
 constexpr int TB_SMALL = 64;
 constexpr int TE = 8;              // consecutive elements per thread in the partition scans
-constexpr int LOCAL_MAX = 2048;    // subtrees up to this many points are built by one wavefront
+constexpr int LOCAL_MAX = LSLAM_LOCAL_MAX;    // subtrees up to this many points are built by one wavefront
 constexpr int LOCAL_STACK = 48;
 
 struct BuildItem {   // one pending inner node
@@ -714,8 +718,11 @@ struct LvArgs {
   const int32_t *chunk_first;// [n_nodes] first chunk of a node
   int32_t *cntL, *cntR, *baseL, *baseR;  // [n_chunks]
   BuildItem *next_items;     // children that are huge again
+  const int32_t *cur_count;  // number of items of this level (written by the previous level / the host)
   int32_t *next_count;
-  int32_t n_nodes, n_chunks, next_cap;
+  int32_t *hdr;              // [0] nodes, [1] chunks of this level (lv_setup_kernel)
+  int32_t *chunk_node_w, *chunk_first_w;  // writable views for lv_setup_kernel
+  int32_t cap_nodes, cap_chunks, next_cap;
 };
 
 __device__ __forceinline__ int32_t ord_i(float f) {
@@ -747,6 +754,7 @@ __device__ __forceinline__ int lv_scan(int v, int *sh /*[LV_TB/64]*/, int *total
 }
 
 #define LV_PROLOGUE                                                     \
+  if ((int)blockIdx.x >= L.hdr[1]) return;                              \
   const int node = L.chunk_node[blockIdx.x];                            \
   const BuildItem it = L.items[node];                                   \
   const int n = it.r - it.l, l = it.l;                                  \
@@ -754,15 +762,68 @@ __device__ __forceinline__ int lv_scan(int v, int *sh /*[LV_TB/64]*/, int *total
   const int c1 = min(n, c0 + LV_CH);                                    \
   (void)c1; (void)l;
 
-__global__ void lv_init_kernel(LvArgs L) {  // one thread per node: neutral statistics; thread 0: empty next level
-  const int node = blockIdx.x * blockDim.x + threadIdx.x;
-  if (node == 0) *L.next_count = 0;
-  if (node >= L.n_nodes) return;
-  LvStat st{};
-  for (int d = 0; d < 3; ++d) { st.mn[d] = INT32_MAX; st.mx[d] = INT32_MIN; }
-  st.lmax = INT32_MIN;
-  st.rmin = INT32_MAX;
-  L.stat[node] = st;
+// One workgroup: the bookkeeping of a level, on the device so that the host never has to look
+// between levels -- node count, chunks per node, chunk -> node table, neutral statistics, and an
+// empty next level.  Grids are launched at capacity; blocks beyond hdr[] exit at once.
+__global__ __launch_bounds__(1024) void lv_setup_kernel(LvArgs L) {
+  __shared__ int wsum[16];
+  __shared__ int run_sh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int n_nodes = *L.cur_count;
+  if (n_nodes > L.cap_nodes) {
+    if (tid == 0) L.A.ctl->overflow = 3;
+    n_nodes = 0;
+  }
+  if (tid == 0) run_sh = 0;
+  __syncthreads();
+  for (int base = 0; base < n_nodes; base += 1024) {
+    const int j = base + tid;
+    int nch = 0;
+    if (j < n_nodes) {
+      const BuildItem it = L.items[j];
+      nch = (it.r - it.l + LV_CH - 1) / LV_CH;
+      LvStat st{};
+      for (int d = 0; d < 3; ++d) { st.mn[d] = INT32_MAX; st.mx[d] = INT32_MIN; }
+      st.lmax = INT32_MIN;
+      st.rmin = INT32_MAX;
+      L.stat[j] = st;
+    }
+    int x = nch;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(x, o, 64);
+      if (lane >= o) x += t;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int before = run_sh;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (j < n_nodes) L.chunk_first_w[j] = before + x - nch;
+    __syncthreads();
+    if (tid == 1023) run_sh = before + x;
+    __syncthreads();
+  }
+  int n_chunks = run_sh;
+  if (n_chunks > L.cap_chunks) {
+    if (tid == 0) L.A.ctl->overflow = 3;
+    n_chunks = 0;
+    n_nodes = 0;
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int c = tid; c < n_chunks; c += 1024) {  // last node whose first chunk is <= c
+    int lo = 0, hi = n_nodes - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (L.chunk_first_w[mid] <= c) lo = mid; else hi = mid - 1;
+    }
+    L.chunk_node_w[c] = lo;
+  }
+  if (tid == 0) {
+    L.hdr[0] = n_nodes;
+    L.hdr[1] = n_chunks;
+    *L.next_count = 0;
+  }
 }
 
 __global__ __launch_bounds__(LV_TB) void lv_minmax_kernel(LvArgs L) {
@@ -786,7 +847,7 @@ __global__ __launch_bounds__(LV_TB) void lv_minmax_kernel(LvArgs L) {
 
 __global__ void lv_split_kernel(LvArgs L) {  // middleSplit_, :982-1031, one thread per node
   const int node = blockIdx.x * blockDim.x + threadIdx.x;
-  if (node >= L.n_nodes) return;
+  if (node >= L.hdr[0]) return;
   const BuildItem it = L.items[node];
   LvStat &st = L.stat[node];
   float emin[3], emax[3];
@@ -872,6 +933,7 @@ __global__ __launch_bounds__(LV_TB) void lv_hflags_kernel(LvArgs L, int p) {
 __global__ __launch_bounds__(LV_TB) void lv_hscan_kernel(LvArgs L, int p) {
   __shared__ int sh[LV_TB / 64];
   const int node = blockIdx.x;
+  if (node >= L.hdr[0]) return;
   const BuildItem it = L.items[node];
   const int nch = (it.r - it.l + LV_CH - 1) / LV_CH, first = L.chunk_first[node];
   int runL = 0, runR = 0;
@@ -954,7 +1016,7 @@ __global__ __launch_bounds__(LV_TB) void lv_bounds_kernel(LvArgs L) {
 // one thread per node: the node record and its two children (what lane 0 of process_node does)
 __global__ void lv_final_kernel(LvArgs L) {
   const int node = blockIdx.x * blockDim.x + threadIdx.x;
-  if (node >= L.n_nodes) return;
+  if (node >= L.hdr[0]) return;
   const BuildArgs &A = L.A;
   const BuildItem it = L.items[node];
   const LvStat st = L.stat[node];
@@ -1118,81 +1180,70 @@ namespace {
 hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t n, hipStream_t stream, int *fallback) {
   hipError_t e;
   void *lv_blob = nullptr;
-  {
-    const int n_first = (int)level.size();
-    const int cap_nodes = n / HUGE_MIN * 2 + n_first + 8, cap_chunks = n / LV_CH + cap_nodes + 8;
-    const size_t sz_items = (size_t)cap_nodes * sizeof(BuildItem), sz_stat = (size_t)cap_nodes * sizeof(LvStat),
-                 sz_ci = (size_t)cap_chunks * sizeof(int32_t), sz_ni = (size_t)cap_nodes * sizeof(int32_t);
-    if ((e = pool_get(stream, true, 2 * sz_items + sz_stat + 5 * sz_ci + sz_ni + 64, &lv_blob)) != hipSuccess) return e;
-    char *q = static_cast<char *>(lv_blob);
-    BuildItem *d_items = reinterpret_cast<BuildItem *>(q); q += sz_items;
-    BuildItem *d_next = reinterpret_cast<BuildItem *>(q); q += sz_items;
-    LvStat *d_stat = reinterpret_cast<LvStat *>(q); q += sz_stat;
-    int32_t *d_chunk_node = reinterpret_cast<int32_t *>(q); q += sz_ci;
-    int32_t *d_cntL = reinterpret_cast<int32_t *>(q); q += sz_ci;
-    int32_t *d_cntR = reinterpret_cast<int32_t *>(q); q += sz_ci;
-    int32_t *d_baseL = reinterpret_cast<int32_t *>(q); q += sz_ci;
-    int32_t *d_baseR = reinterpret_cast<int32_t *>(q); q += sz_ci;
-    int32_t *d_chunk_first = reinterpret_cast<int32_t *>(q); q += sz_ni;
-    int32_t *d_next_count = reinterpret_cast<int32_t *>(q);
-    // items ping-pong between two device buffers; the header word in front of each holds the count
-    // the previous level's final kernel produced (one download + one synchronisation per level)
-    std::vector<int32_t> chunk_node, chunk_first;
-    std::vector<char> dl(sizeof(BuildItem) * (size_t)cap_nodes + 16);
-    BuildItem *d_cur = d_items, *d_nxt = d_next;
-    if ((e = hipMemcpyAsync(d_cur, level.data(), (size_t)n_first * sizeof(BuildItem), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;  // `level` is rewritten below
-    while (!level.empty()) {
-      const int H = (int)level.size();
-      chunk_node.clear();
-      chunk_first.assign(H, 0);
-      for (int j = 0; j < H; ++j) {
-        chunk_first[j] = (int32_t)chunk_node.size();
-        const int nch = (level[j].r - level[j].l + LV_CH - 1) / LV_CH;
-        chunk_node.insert(chunk_node.end(), nch, j);
-      }
-      const int C = (int)chunk_node.size();
-      if (H > cap_nodes || C > cap_chunks) { *fallback = 3; return hipSuccess; }
-      if ((e = hipMemcpyAsync(d_chunk_node, chunk_node.data(), (size_t)C * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-      if ((e = hipMemcpyAsync(d_chunk_first, chunk_first.data(), (size_t)H * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+  const int n_first = (int)level.size();
+  const int cap_nodes = n / HUGE_MIN * 2 + n_first + 8, cap_chunks = n / LV_CH + cap_nodes + 8;
+  const size_t sz_items = (size_t)cap_nodes * sizeof(BuildItem), sz_stat = (size_t)cap_nodes * sizeof(LvStat),
+               sz_ci = (size_t)cap_chunks * sizeof(int32_t), sz_ni = (size_t)cap_nodes * sizeof(int32_t);
+  if ((e = pool_get(stream, true, 2 * sz_items + sz_stat + 5 * sz_ci + sz_ni + 64, &lv_blob)) != hipSuccess) return e;
+  char *q = static_cast<char *>(lv_blob);
+  BuildItem *d_items[2];
+  d_items[0] = reinterpret_cast<BuildItem *>(q); q += sz_items;
+  d_items[1] = reinterpret_cast<BuildItem *>(q); q += sz_items;
+  LvStat *d_stat = reinterpret_cast<LvStat *>(q); q += sz_stat;
+  int32_t *d_chunk_node = reinterpret_cast<int32_t *>(q); q += sz_ci;
+  int32_t *d_cntL = reinterpret_cast<int32_t *>(q); q += sz_ci;
+  int32_t *d_cntR = reinterpret_cast<int32_t *>(q); q += sz_ci;
+  int32_t *d_baseL = reinterpret_cast<int32_t *>(q); q += sz_ci;
+  int32_t *d_baseR = reinterpret_cast<int32_t *>(q); q += sz_ci;
+  int32_t *d_chunk_first = reinterpret_cast<int32_t *>(q); q += sz_ni;
+  int32_t *d_small = reinterpret_cast<int32_t *>(q);  // [0],[1] item counts (ping-pong), [2],[3] level header
+  if (n_first > cap_nodes) { *fallback = 3; return hipSuccess; }
+  const int32_t init[4] = {n_first, 0, 0, 0};
+  if ((e = hipMemcpyAsync(d_items[0], level.data(), (size_t)n_first * sizeof(BuildItem), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(d_small, init, sizeof(init), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;  // host buffers are the caller's
+  // Levels are enqueued in batches without looking at their outcome (grids at capacity, exhausted
+  // levels cost a handful of empty launches); the host checks the item count once per batch.
+  const dim3 gc(cap_chunks), gn((cap_nodes + 63) / 64), gh(cap_nodes), bt(LV_TB);
+  int lvl = 0;
+  for (int batch = 0; batch < 16; ++batch) {
+    const int per_batch = batch == 0 ? std::max(2, (int)std::ceil(std::log2(std::max(2.0, (double)n / HUGE_MIN))) + 1) : 3;
+    for (int k = 0; k < per_batch; ++k, ++lvl) {
       LvArgs L{};
       L.A = A;
-      L.items = d_cur;
+      L.items = d_items[lvl & 1];
+      L.next_items = d_items[(lvl + 1) & 1];
       L.stat = d_stat;
       L.chunk_node = d_chunk_node;
       L.chunk_first = d_chunk_first;
+      L.chunk_node_w = d_chunk_node;
+      L.chunk_first_w = d_chunk_first;
       L.cntL = d_cntL; L.cntR = d_cntR; L.baseL = d_baseL; L.baseR = d_baseR;
-      L.next_items = d_nxt;
-      L.next_count = d_next_count;
-      L.n_nodes = H;
-      L.n_chunks = C;
+      L.cur_count = d_small + (lvl & 1);
+      L.next_count = d_small + ((lvl + 1) & 1);
+      L.hdr = d_small + 2;
+      L.cap_nodes = cap_nodes;
+      L.cap_chunks = cap_chunks;
       L.next_cap = cap_nodes;
-      const dim3 gc(C), gn((H + 63) / 64), bt(LV_TB);
-      hipLaunchKernelGGL(lv_init_kernel, gn, dim3(64), 0, stream, L);
+      hipLaunchKernelGGL(lv_setup_kernel, dim3(1), dim3(1024), 0, stream, L);
       hipLaunchKernelGGL(lv_minmax_kernel, gc, bt, 0, stream, L);
       hipLaunchKernelGGL(lv_split_kernel, gn, dim3(64), 0, stream, L);
       hipLaunchKernelGGL(lv_count_kernel, gc, bt, 0, stream, L);
       for (int pass = 0; pass < 2; ++pass) {
         hipLaunchKernelGGL(lv_hflags_kernel, gc, bt, 0, stream, L, pass);
-        hipLaunchKernelGGL(lv_hscan_kernel, dim3(H), bt, 0, stream, L, pass);
+        hipLaunchKernelGGL(lv_hscan_kernel, gh, bt, 0, stream, L, pass);
         hipLaunchKernelGGL(lv_hwrite_kernel, gc, bt, 0, stream, L, pass);
         hipLaunchKernelGGL(lv_hswap_kernel, gc, bt, 0, stream, L, pass);
       }
       hipLaunchKernelGGL(lv_bounds_kernel, gc, bt, 0, stream, L);
       hipLaunchKernelGGL(lv_final_kernel, gn, dim3(64), 0, stream, L);
-      // the children that are huge again: count first (4 bytes), then as many items as a level of this
-      // size can produce (2 H) in the same round trip
-      int32_t n_next = 0;
-      const size_t want = (size_t)std::min(2 * H, cap_nodes) * sizeof(BuildItem);
-      if ((e = hipMemcpyAsync(&n_next, d_next_count, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-      if ((e = hipMemcpyAsync(dl.data(), d_nxt, want, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-      if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-      n_next = std::min(n_next, std::min(2 * H, cap_nodes));
-      level.resize((size_t)n_next);
-      if (n_next) std::memcpy(level.data(), dl.data(), (size_t)n_next * sizeof(BuildItem));
-      std::swap(d_cur, d_nxt);
     }
+    int32_t remaining = 0;
+    if ((e = hipMemcpyAsync(&remaining, d_small + (lvl & 1), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    if (remaining == 0) return hipSuccess;
   }
+  *fallback = 3;  // 50+ levels above the wavefront-local size: give the cloud to the host builder
   return hipSuccess;
 }
 }  // namespace

@@ -247,3 +247,34 @@ def test_feature_map_to_cubemap_matches_oracle(pkg, ctx, oracle, synth, small_pr
     assert (st.n_line, st.n_plane, st.n_rows) == (ost.n_line, ost.n_plane, ost.n_rows)
     assert np.abs(pose[3:] - opose[3:]).max() <= 1e-4 and np.abs(pose[:3] - opose[:3]).max() <= 1e-5
     fm.close()
+
+
+def test_feature_map_full_size_properties(pkg, ctx, synth):
+    """The bench-size map (1.3 M points) through properties: one point per occupied voxel and cube,
+    every point inside its cube, an empty addFeatureCloud changes nothing (VoxelGrid of a VoxelGrid
+    output is the identity here)."""
+    pr = synth.make_problem(rings=16, azimuth_steps=900)  # the map does not depend on the scan
+    def xyzi(a):
+        o = np.zeros((len(a), 4), np.float32)
+        o[:, :3] = a[:, :3]
+        return o
+    fm = pkg.FeatureMap(ctx, 21, 11, 21)
+    fm.setup_filter_size(0.2, 0.4, 0.6)
+    fm.update(pr["gt_pose"][3:])
+    fm.add_feature_cloud(xyzi(pr["map_corner"]), xyzi(pr["map_surf"]), np.eye(4, dtype=np.float32))
+    c, s = fm.get_surround_feature()
+    info = fm.info()
+    # cubes beyond the 150 m valid distance are not part of the surround (and keep their raw points)
+    assert 0.8 * info["n_corner"] < len(c) <= info["n_corner"] and 800000 < len(s) <= info["n_surf"]
+    origin = info["origin"].astype(np.int64)
+    for cloud, leaf in ((c, 0.2), (s, 0.4)):
+        cube = np.round(cloud[:, :3] / np.float32(50.0)).astype(np.int64) + origin
+        assert (cube >= 0).all() and (cube < np.array([21, 11, 21])).all()
+        vox = np.floor(cloud[:, :3] * (np.float32(1.0) / np.float32(leaf))).astype(np.int64)
+        key = np.concatenate([cube, vox], 1)
+        assert len(np.unique(key, axis=0)) >= len(cloud) - 8  # a centroid may round onto a voxel face
+    empty = np.zeros((0, 4), np.float32)
+    fm.add_feature_cloud(empty, empty, np.eye(4, dtype=np.float32))
+    c2, s2 = fm.get_surround_feature()
+    assert abs(len(c2) - len(c)) <= 4 and abs(len(s2) - len(s)) <= 8
+    fm.close()

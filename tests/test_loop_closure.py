@@ -68,3 +68,59 @@ def test_detect_nearest_closes_a_loop(pkg, ctx, synth, small_problem):
     err = np.abs(lp.relative_pose[:3, 3] - truth[:3, 3]).max()
     assert err < 0.05 and err < 0.3 * np.abs(guess[:3, 3] - truth[:3, 3]).max()
     assert det.last_loop_accum_distance == 60.0
+
+
+def test_keyframe_updater_thresholds(pkg):
+    """keyframe_updater.hpp:21-44: a new keyframe needs 0.25 m or 0.05 rad; travel accumulates."""
+    ku = pkg.KeyframeUpdater()
+    T = np.eye(4)
+    assert ku.update(T) and ku.get_accum_distance() == 0.0
+    T1 = T.copy(); T1[0, 3] = 0.2
+    assert not ku.update(T1)
+    T2 = T.copy(); T2[0, 3] = 0.3
+    assert ku.update(T2) and abs(ku.get_accum_distance() - 0.3) < 1e-12
+    c, s = np.cos(0.06), np.sin(0.06)
+    T3 = T2.copy(); T3[:3, :3] = [[c, -s, 0], [s, c, 0], [0, 0, 1]]
+    assert ku.update(T3) and abs(ku.get_accum_distance() - 0.3) < 1e-12  # rotation only: no travel added
+    assert ku.get_unique_id() == 1 and ku.get_unique_id() == 2
+
+
+@pytest.mark.gpu
+def test_graph_closes_the_loop_end_to_end(pkg, ctx, synth, small_problem):
+    """Config 4 end to end at toy size: drive a 40 m loop twice with drifting odometry, let the graph
+    pick keyframes, add odometry edges, find the loop on the second lap (radius search -> gating ->
+    scanMatchLocal on the device), add the loop edge and optimise: the trajectory error drops."""
+    world = small_problem["world"]
+    rng = np.random.default_rng(5)
+    g = pkg.Graph(ctx=ctx)
+    g.loop_detector.accum_distance_thresh = 25.0
+    # square path of side 10 m around (5, 5), 1 m steps, two laps, sensor yaw fixed
+    way = []
+    for lap in range(2):
+        for side, (dx, dy) in enumerate(((1, 0), (0, 1), (-1, 0), (0, -1))):
+            for k in range(10):
+                way.append((dx, dy))
+    x, y = 0.0, 0.0
+    drift = np.zeros(2)
+    gts, odoms = [], []
+    n_loops = 0
+    for step, (dx, dy) in enumerate([(0, 0)] + way):
+        x += dx; y += dy
+        drift += rng.normal(0, 0.01, 2) + np.array([0.004, -0.003])
+        gt = (0.0, 0.0, 0.3, x, y, synth.SENSOR_HEIGHT)
+        c, s, gtp = synth.make_scan(world, 16, 450, gt_pose=gt, seed=1000 + step)
+        R, t = synth.pose_to_Rt(gtp)
+        T = np.eye(4); T[:3, :3], T[:3, 3] = R, t
+        O = T.copy(); O[:2, 3] += drift
+        kf = g.add_frame(O, c, s)
+        assert kf is not None
+        gts.append(T); odoms.append(O)
+        loops, its = g.optimize(20)
+        n_loops += len(loops)
+    assert len(g.keyframes) == len(gts) and n_loops >= 1
+    est = np.array([k.estimate[:3, 3] for k in g.keyframes])
+    gt_xyz = np.array([T[:3, 3] for T in gts])
+    od_xyz = np.array([O[:3, 3] for O in odoms])
+    err_est = np.linalg.norm(est - gt_xyz, axis=1)
+    err_odo = np.linalg.norm(od_xyz - gt_xyz, axis=1)
+    assert err_est[-1] < 0.85 * err_odo[-1] and err_est.mean() < err_odo.mean()

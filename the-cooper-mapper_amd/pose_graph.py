@@ -93,6 +93,7 @@ class PoseGraph:
 
     # ---- bulk construction / access ---------------------------------------------------
     def set_graph(self, poses7, ij, meas7, info):
+        self._drop(keep_estimates=False)
         self._nodes = [p for p in np.asarray(poses7, np.float64).reshape(-1, 7)]
         self._ij = [tuple(int(v) for v in e) for e in np.asarray(ij).reshape(-1, 2)]
         self._meas = [m for m in np.asarray(meas7, np.float64).reshape(-1, 7)]
@@ -191,8 +192,14 @@ class PoseGraph:
         optimize()/linearize() does it); the counterpart of g2o's initializeOptimization()."""
         self._build()
 
-    def _drop(self):
+    def _drop(self, keep_estimates=True):
+        """Release the device graph.  The optimised estimates are pulled back first (g2o keeps its
+        vertices' estimates when vertices or edges are added after an optimize())."""
         if self.h:
+            if keep_estimates and len(self._nodes):
+                out = np.zeros((len(self._nodes), 7))
+                if self.lib.lslam_pg_get_poses(self.h, _dp(out)) == 0:
+                    self._nodes = [p for p in out]
             self.lib.lslam_pg_destroy(self.h)
             self.h = None
 
@@ -212,7 +219,7 @@ class PoseGraph:
         self.h = h
 
     def close(self):
-        self._drop()
+        self._drop(keep_estimates=False)
 
     def __del__(self):
         try:

@@ -92,6 +92,14 @@ def test_graph_closes_the_loop_end_to_end(pkg, ctx, synth, small_problem):
     scanMatchLocal on the device), add the loop edge and optimise: the trajectory error drops."""
     world = small_problem["world"]
     rng = np.random.default_rng(5)
+    # The detector flattens the trajectory with y = 0 (loop_detector.hpp:98,120): the reference lives
+    # in LOAM's camera-style frame (y up).  The synthetic world is z-up, so poses and clouds are
+    # expressed in that frame through the fixed permutation (x, y, z)_loam = (y, z, x)_world.
+    P = np.array([[0, 1, 0, 0], [0, 0, 1, 0], [1, 0, 0, 0], [0, 0, 0, 1]], np.float64)
+    def to_loam_cloud(c):
+        o = c.copy()
+        o[:, :3] = c[:, [1, 2, 0]]
+        return o
     g = pkg.Graph(ctx=ctx)
     g.loop_detector.accum_distance_thresh = 25.0
     # square path of side 10 m around (5, 5), 1 m steps, two laps, sensor yaw fixed
@@ -112,7 +120,8 @@ def test_graph_closes_the_loop_end_to_end(pkg, ctx, synth, small_problem):
         R, t = synth.pose_to_Rt(gtp)
         T = np.eye(4); T[:3, :3], T[:3, 3] = R, t
         O = T.copy(); O[:2, 3] += drift
-        kf = g.add_frame(O, c, s)
+        T, O = P @ T @ P.T, P @ O @ P.T
+        kf = g.add_frame(O, to_loam_cloud(c), to_loam_cloud(s))
         assert kf is not None
         gts.append(T); odoms.append(O)
         loops, its = g.optimize(20)
@@ -123,4 +132,4 @@ def test_graph_closes_the_loop_end_to_end(pkg, ctx, synth, small_problem):
     od_xyz = np.array([O[:3, 3] for O in odoms])
     err_est = np.linalg.norm(est - gt_xyz, axis=1)
     err_odo = np.linalg.norm(od_xyz - gt_xyz, axis=1)
-    assert err_est[-1] < 0.85 * err_odo[-1] and err_est.mean() < err_odo.mean()
+    assert err_est[-1] < 0.6 * err_odo[-1] and err_est.mean() < err_odo.mean() and err_est.max() < 0.5

@@ -70,17 +70,17 @@ class PoseGraph:
     def add_se3_node(self, pose):
         """solver_g2o.cpp:51-63: returns the vertex id; the first vertex is fixed."""
         p = np.asarray(pose, np.float64)
+        self._drop()  # first: it pulls the optimised estimates of the existing vertices back
         self._nodes.append(mat_to_pose7(p) if p.shape == (4, 4) else p.reshape(7).copy())
-        self._drop()
         return len(self._nodes) - 1
 
     def add_se3_edge(self, v1, v2, relative_pose, information_matrix):
         """solver_g2o.cpp:65-77."""
         z = np.asarray(relative_pose, np.float64)
+        self._drop()
         self._ij.append((int(v1), int(v2)))
         self._meas.append(mat_to_pose7(z) if z.shape == (4, 4) else z.reshape(7).copy())
         self._info.append(np.asarray(information_matrix, np.float64).reshape(6, 6).copy())
-        self._drop()
         return len(self._ij) - 1
 
     def optimize(self, max_iterations=1000):

@@ -229,6 +229,9 @@ def sharded_points_leg(pkg, synth, distmod, dist, rank, world, ctx, opts, torch,
     6x6 solve replicated.  Latency-bound by construction (two host round trips per iteration);
     reported as measured, next to the recommended no-collective batch mode."""
     pr = synth.make_problem(rings=args.rings, azimuth_steps=1800, seed=0)  # the same scan on every rank
+    # ... and the same map: every rank must take the same decisions from the same all-reduced sums
+    # (rank 0's map was replaced by the mapping-frame leg)
+    ctx.map_set(pr["map_corner"], pr["map_surf"])
     cb, ce = distmod.shard_range(len(pr["corner"]), rank, world)
     sb, se = distmod.shard_range(len(pr["surf"]), rank, world)
     ctx.scan_set(pr["corner"][cb:ce], pr["surf"][sb:se])

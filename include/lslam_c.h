@@ -322,6 +322,17 @@ int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, s
                            float *less_flat, size_t counts[4], float *curvature_out, int8_t *picked_out,
                            int8_t *label_out);
 
+/* MultiScanRegistration::process (odometry/MultiScanRegistration.cpp:94-190) without the IMU
+ * branch: raw driver cloud {x,y,z} -> ring-sorted cloud {x', y', z', ring + relTime} in the
+ * registration's swapped axes (x' = y, y' = z, z' = x) with its per-ring {first, last} ranges --
+ * the input of lslam_extract_features (intensity offset 12).  Linear ring mapper
+ * (MultiScanRegistration.h:57-87: VLP-16 = -15..15 deg / 16, HDL-32 = -30.67..10.67 / 32).  atan /
+ * atan2 are evaluated on the device: ring ids equal the reference's except for points within an
+ * ulp of a ring boundary, relTime agrees to ~1e-7. */
+int lslam_multiscan_register(lslam_ctx *ctx, const void *cloud, size_t n_points, size_t stride_bytes,
+                             float lower_deg, float upper_deg, int32_t n_rings, float scan_period,
+                             float *out_xyzc, size_t cap, size_t *n_out, int32_t *ranges_out);
+
 /* ---- SE(3) pose-graph Levenberg-Marquardt ------------------------------------
  * Replaces pose_graph::SolverG2O (pose_graph/solver_g2o.cpp:51-95): add_se3_node /
  * add_se3_edge build the arrays passed to lslam_pg_create, optimize() becomes

@@ -23,6 +23,7 @@
  */
 #include "features_oracle.h"
 
+#define _GNU_SOURCE
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -284,4 +285,59 @@ void oracle_extract_features(const float *cloud, size_t n_points, size_t stride_
   counts[2] = o_flat.n;
   counts[3] = o_less_flat.n;
   free(picked); free(curv); free(rlabel); free(sorted); free(tmp); free(scan_less); free(scan_ds);
+}
+
+/* MultiScanRegistration::process (MultiScanRegistration.cpp:94-190) without the IMU branch
+ * (hasIMUData() == false): axis swap, validity, ring from the vertical angle (linear mapper,
+ * MultiScanRegistration.h:57-87), sweep-relative time from the horizontal angle with the
+ * half-passed logic, per-ring clouds in arrival order.  out: {x, y, z, curvature = ring + relTime}. */
+size_t oracle_multiscan_register(const float *in, size_t n, size_t stride_floats, float lower_deg, float upper_deg,
+                                 int n_rings, float scan_period, float *out, int32_t *ranges) {
+  const float factor = (n_rings - 1) / (upper_deg - lower_deg); /* :63 */
+  int32_t *ring = (int32_t *)malloc(sizeof(int32_t) * (n + 1));
+  float *tmp = (float *)malloc(sizeof(float) * 4 * (n + 1));
+  size_t *count = (size_t *)calloc((size_t)n_rings + 1, sizeof(size_t));
+  const float *first = in, *last = in + (n - 1) * stride_floats;
+  float start_ori = -atan2f(first[1], first[0]);
+  float end_ori = -atan2f(last[1], last[0]) + 2 * (float)OR_PI;
+  if (end_ori - start_ori > 3 * OR_PI) end_ori -= 2 * OR_PI;
+  else if (end_ori - start_ori < OR_PI) end_ori += 2 * OR_PI;
+  int half_passed = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const float *p = in + i * stride_floats;
+    const float x = p[1], y = p[2], z = p[0]; /* :127-129 */
+    ring[i] = -1;
+    if (!isfinite(x) || !isfinite(y) || !isfinite(z)) continue;
+    if (x * x + y * y + z * z < 0.0001) continue;
+    const float angle = atanf(y / sqrtf(x * x + z * z));
+    const int scan_id = (int)(((angle * 180 / OR_PI) - lower_deg) * factor + 0.5);
+    if (scan_id >= n_rings || scan_id < 0) continue;
+    float ori = -atan2f(x, z);
+    if (!half_passed) {
+      if (ori < start_ori - OR_PI / 2) ori += 2 * OR_PI;
+      else if (ori > start_ori + OR_PI * 3 / 2) ori -= 2 * OR_PI;
+      if (ori - start_ori > OR_PI) half_passed = 1;
+    } else {
+      ori += 2 * OR_PI;
+      if (ori < end_ori - OR_PI * 3 / 2) ori += 2 * OR_PI;
+      else if (ori > end_ori + OR_PI / 2) ori -= 2 * OR_PI;
+    }
+    const float rel_time = scan_period * (ori - start_ori) / (end_ori - start_ori);
+    ring[i] = scan_id;
+    tmp[4 * i] = x; tmp[4 * i + 1] = y; tmp[4 * i + 2] = z;
+    tmp[4 * i + 3] = scan_id + rel_time;
+    count[scan_id]++;
+  }
+  size_t total = 0;
+  size_t *fill = (size_t *)malloc(sizeof(size_t) * ((size_t)n_rings + 1));
+  for (int r = 0; r < n_rings; ++r) { /* :180-190 */
+    fill[r] = total;
+    ranges[2 * r] = (int32_t)total;
+    total += count[r];
+    ranges[2 * r + 1] = total > 0 ? (int32_t)total - 1 : 0;
+  }
+  for (size_t i = 0; i < n; ++i)
+    if (ring[i] >= 0) memcpy(out + 4 * fill[ring[i]]++, tmp + 4 * i, 4 * sizeof(float));
+  free(ring); free(tmp); free(count); free(fill);
+  return total;
 }

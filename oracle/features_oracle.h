@@ -36,6 +36,12 @@ void oracle_extract_features(const float *cloud, size_t n_points, size_t stride_
                              float *sharp, float *less_sharp, float *flat, float *less_flat, size_t counts[4],
                              float *curvature_out, int8_t *picked_out, int8_t *label_out);
 
+/* MultiScanRegistration::process (MultiScanRegistration.cpp:94-190), no IMU: in = raw driver cloud
+ * {x, y, z, ...}; out = ring-sorted {x, y, z, curvature = ring + relTime} in the registration's
+ * swapped axes; ranges = n_rings x {first, last}; returns the number of points kept. */
+size_t oracle_multiscan_register(const float *in, size_t n, size_t stride_floats, float lower_deg, float upper_deg,
+                                 int n_rings, float scan_period, float *out, int32_t *ranges);
+
 #ifdef __cplusplus
 }
 #endif

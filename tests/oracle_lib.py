@@ -173,6 +173,18 @@ class Oracle:
                                               C.POINTER(C.c_size_t), c_float_p, C.POINTER(C.c_int8),
                                               C.POINTER(C.c_int8)]
 
+        L.oracle_multiscan_register.restype = C.c_size_t
+        L.oracle_multiscan_register.argtypes = [c_float_p, C.c_size_t, C.c_size_t, C.c_float, C.c_float, C.c_int,
+                                                C.c_float, c_float_p, c_int32_p]
+
+    def multiscan_register(self, cloud, lower_deg, upper_deg, n_rings, scan_period=0.1):
+        a = np.ascontiguousarray(cloud, dtype=np.float32)
+        out = np.zeros((len(a), 4), np.float32)
+        ranges = np.zeros((n_rings, 2), np.int32)
+        n = self.lib.oracle_multiscan_register(_fp(a), len(a), a.shape[1], lower_deg, upper_deg, n_rings, scan_period,
+                                               _fp(out), _ip(ranges))
+        return out[:n].copy(), ranges
+
     # ---- feature extraction --------------------------------------------
     def reg_params(self):
         p = OracleRegParams()

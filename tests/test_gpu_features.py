@@ -84,3 +84,21 @@ def test_features_feed_odometry(pkg, ctx, oracle, synth, small_problem):
                                                clouds[1]["flat"], pose0)
     assert st_g.iterations == it_o and it_o > 0
     assert np.abs(pose_g[3:] - pose_o[3:]).max() <= 1e-4 and np.abs(pose_g[:3] - pose_o[:3]).max() <= 1e-5
+
+
+@pytest.mark.parametrize("rings,lo,hi", [(16, -15.0, 15.0), (64, -24.9, 2.0)])
+def test_multiscan_register_matches_oracle(pkg, ctx, oracle, synth, rings, lo, hi):
+    """MultiScanRegistration::process on the device: same points in the same rings in the same order;
+    ring + relTime within 2e-6 (atan / atan2 are the device's), and the chain into extractFeatures."""
+    from test_oracle_features import _raw_sweep
+    raw, ring = _raw_sweep(synth, rings=rings, steps=900, seed=8)
+    got, granges = pkg.scan_registration.multiscan_register(ctx, raw, lo, hi, rings)
+    ref, oranges = oracle.multiscan_register(raw, lo, hi, rings)
+    assert got.shape == ref.shape and np.array_equal(granges, oranges)
+    assert np.array_equal(bits(got[:, :3]), bits(ref[:, :3]))
+    assert np.array_equal(np.floor(got[:, 3]), np.floor(ref[:, 3]))
+    assert np.abs(got[:, 3] - ref[:, 3]).max() <= 2e-6 * rings
+    feat = pkg.scan_registration.extract_features(ctx, got, granges)
+    ofeat = oracle.extract_features(ref, oranges)
+    for k in ("sharp", "less_sharp", "flat"):
+        assert feat[k].shape == ofeat[k].shape and np.array_equal(bits(feat[k][:, :3]), bits(ofeat[k][:, :3])), k

@@ -73,3 +73,37 @@ def test_point_classify_on_constructed_geometry(oracle):
     mess = line.copy()
     mess[:, :3] += rng.normal(0, 0.5, (11, 3)).astype(np.float32)
     assert oracle.point_classify(mess, 5) == 9
+
+
+def _raw_sweep(synth, rings=16, steps=900, seed=3):
+    """A raw driver cloud: z-up sensor frame, points in arrival order (azimuth sweeping, all rings per
+    azimuth step) -- what MultiScanRegistration::process receives."""
+    world = synth.World(half_extent=60.0, wall_half=55.0)
+    c, s, gt, cloud, ranges = synth.make_scan(world, rings, steps, seed=seed, full=True)
+    ring = np.floor(cloud[:, 3]).astype(np.int64)
+    rel = cloud[:, 3] - ring
+    order = np.lexsort((ring, -rel))  # a Velodyne turns clockwise: azimuth falls along the sweep; then by ring
+    return cloud[order], ring[order]
+
+
+def test_multiscan_register_rings_and_time(oracle, synth):
+    raw, ring = _raw_sweep(synth)
+    out, ranges = oracle.multiscan_register(raw, -15.0, 15.0, 16)
+    assert len(out) == len(raw)  # nothing dropped: all returns are finite, inside the ring table
+    for r in range(16):
+        a, b = ranges[r]
+        seg = out[a:b + 1]
+        assert len(seg) == (ring == r).sum()
+        assert np.all(np.floor(seg[:, 3]) == r)
+        # axes swapped (x', y', z') = (y, z, x); arrival order kept; relTime grows along the sweep
+        src = raw[ring == r]
+        assert np.array_equal(seg[:, 0], src[:, 1]) and np.array_equal(seg[:, 1], src[:, 2]) and np.array_equal(seg[:, 2], src[:, 0])
+        rel = seg[:, 3] - r
+        assert rel.min() >= -1e-4 and rel.max() <= 0.1 + 1e-4 and np.all(np.diff(rel) > -1e-4)
+    # invalid points are dropped: NaN, near-zero, outside the ring table
+    bad = raw[:5].copy()
+    bad[0, 0] = np.nan
+    bad[1, :3] = 1e-4
+    bad[2, :3] = (1.0, 0.0, 5.0)   # 78 degrees up
+    out2, ranges2 = oracle.multiscan_register(np.concatenate([raw[:1], bad, raw[1:]]), -15.0, 15.0, 16)
+    assert len(out2) == len(raw) + 2

@@ -171,6 +171,9 @@ SYMBOLS = {
                                          C.c_size_t, C.POINTER(LslamRegParams), c_float_p, c_float_p, c_float_p,
                                          c_float_p, C.POINTER(C.c_size_t), c_float_p, C.POINTER(C.c_int8),
                                          C.POINTER(C.c_int8)]),
+    "lslam_multiscan_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float, C.c_float,
+                                           C.c_int32, C.c_float, c_float_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                           c_int32_p]),
     "lslam_pg_save_g2o": (C.c_int, [C.c_void_p, C.c_char_p]),
     "lslam_g2o_read": (C.c_int, [C.c_char_p, c_int32_p, c_double_p, c_int32_p, c_int32_p, c_double_p, c_double_p,
                                  c_int32_p]),

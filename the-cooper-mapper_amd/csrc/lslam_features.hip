@@ -17,6 +17,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -333,6 +334,64 @@ __global__ void fx_compact_kernel(const float4 *pts, const int32_t *stage, const
   if (seg_out) seg_out[i] = lo;
 }
 
+
+// ---- MultiScanRegistration::process (MultiScanRegistration.cpp:94-190, no IMU) -------------------
+struct MsArgs {
+  const float4 *in;   // raw driver cloud {x, y, z, *}
+  int n, n_rings;
+  float lower, factor, scan_period, start_ori, end_ori;
+  float4 *out;        // {x', y', z', ring + relTime} in the registration's swapped axes, arrival order
+  int32_t *ring;      // -1 = dropped
+  float *ori_raw;
+  int32_t *first_half;  // index of the first kept point at which halfPassed flips
+};
+
+__device__ __forceinline__ float ms_mode_a(float ori, float start_ori) {  // :150-156
+  if ((double)ori < (double)start_ori - M_PI / 2) ori = (float)((double)ori + 2 * M_PI);
+  else if ((double)ori > (double)start_ori + M_PI * 3 / 2) ori = (float)((double)ori - 2 * M_PI);
+  return ori;
+}
+
+__global__ void ms_prep_kernel(MsArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const float4 p = a.in[i];
+  const float x = p.y, y = p.z, z = p.x;  // :127-129
+  int ring = -1;
+  float ori = 0.0f;
+  if (isfinite(x) && isfinite(y) && isfinite(z) &&
+      !((double)__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)) < 0.0001)) {
+    const float angle = atanf(__fdiv_rn(y, sqrtf(__fadd_rn(__fmul_rn(x, x), __fmul_rn(z, z)))));
+    const int id = (int)((((double)__fmul_rn(angle, 180.0f) / M_PI) - (double)a.lower) * (double)a.factor + 0.5);
+    if (id < a.n_rings && id >= 0) {
+      ring = id;
+      ori = -atan2f(x, z);
+      const float oa = ms_mode_a(ori, a.start_ori);
+      if ((double)__fsub_rn(oa, a.start_ori) > M_PI) atomicMin(a.first_half, i);
+    }
+  }
+  a.ring[i] = ring;
+  a.ori_raw[i] = ori;
+}
+
+__global__ void ms_final_kernel(MsArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const int ring = a.ring[i];
+  if (ring < 0) return;
+  const float4 p = a.in[i];
+  float ori = a.ori_raw[i];
+  if (i <= *a.first_half) {  // the point that flips halfPassed is itself still handled as "not passed"
+    ori = ms_mode_a(ori, a.start_ori);
+  } else {                   // :157-165
+    ori = (float)((double)ori + 2 * M_PI);
+    if ((double)ori < (double)a.end_ori - M_PI * 3 / 2) ori = (float)((double)ori + 2 * M_PI);
+    else if ((double)ori > (double)a.end_ori + M_PI / 2) ori = (float)((double)ori - 2 * M_PI);
+  }
+  const float rel = __fdiv_rn(__fmul_rn(a.scan_period, __fsub_rn(ori, a.start_ori)), __fsub_rn(a.end_ori, a.start_ori));
+  a.out[i] = make_float4(p.y, p.z, p.x, __fadd_rn((float)ring, rel));
+}
+
 }  // namespace
 
 extern "C" {
@@ -479,6 +538,85 @@ int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, s
   }
   (void)hipFree(blob);
   return rc;
+}
+
+
+int lslam_multiscan_register(lslam_ctx *ctx, const void *cloud, size_t n_points, size_t stride_bytes, float lower_deg,
+                             float upper_deg, int32_t n_rings, float scan_period, float *out_xyzc, size_t cap,
+                             size_t *n_out, int32_t *ranges_out) {
+  if (!ctx || !lslam::ctx_alive(ctx) || !n_out || !ranges_out || (n_points && !cloud) || stride_bytes < 12 ||
+      (stride_bytes & 3) || n_rings <= 0 || n_rings > 4096 || !(upper_deg > lower_deg) || n_points > 0x3FFFFFFFu) {
+    lslam::set_error("bad multi-scan registration arguments");
+    return LSLAM_ERR_INVALID;
+  }
+  *n_out = 0;
+  for (int r = 0; r < n_rings; ++r) { ranges_out[2 * r] = 0; ranges_out[2 * r + 1] = 0; }
+  if (n_points == 0) return LSLAM_OK;
+  FX_TRY(hipSetDevice(lslam::ctx_device(ctx)));
+  hipStream_t s = (hipStream_t)lslam_stream(ctx);
+  std::vector<float4> h(n_points);
+  const char *src = static_cast<const char *>(cloud);
+  for (size_t i = 0; i < n_points; ++i) {
+    float v[3];
+    std::memcpy(v, src + i * stride_bytes, 12);
+    h[i] = make_float4(v[0], v[1], v[2], 0.0f);
+  }
+  // sweep start / end orientation (:101-109), on the host with the C library the reference uses
+  float start_ori = -std::atan2(h[0].y, h[0].x);
+  float end_ori = -std::atan2(h[n_points - 1].y, h[n_points - 1].x) + 2 * float(M_PI);
+  if (end_ori - start_ori > 3 * M_PI) end_ori -= 2 * M_PI;
+  else if (end_ori - start_ori < M_PI) end_ori += 2 * M_PI;
+  char *blob = nullptr;
+  const size_t np4 = n_points * sizeof(float4);
+  FX_TRY(hipMalloc((void **)&blob, 3 * np4 + 4 * n_points * 4 + 64));
+  float4 *d_in = (float4 *)blob, *d_tmp = d_in + n_points, *d_out = d_tmp + n_points;
+  int32_t *d_ring = (int32_t *)(d_out + n_points), *d_seg = d_ring + n_points;
+  float *d_ori = (float *)(d_seg + n_points);
+  int32_t *d_first = (int32_t *)(d_ori + n_points);
+  auto fail = [&](int code) { (void)hipFree(blob); return code; };
+  const int32_t big = INT32_MAX;
+  FX_TRY2(hipMemcpyAsync(d_in, h.data(), np4, hipMemcpyHostToDevice, s));
+  FX_TRY2(hipMemcpyAsync(d_first, &big, 4, hipMemcpyHostToDevice, s));
+  MsArgs a{};
+  a.in = d_in;
+  a.n = (int)n_points;
+  a.n_rings = n_rings;
+  a.lower = lower_deg;
+  a.factor = (n_rings - 1) / (upper_deg - lower_deg);  // MultiScanRegistration.h:63
+  a.scan_period = scan_period;
+  a.start_ori = start_ori;
+  a.end_ori = end_ori;
+  a.out = d_tmp;
+  a.ring = d_ring;
+  a.ori_raw = d_ori;
+  a.first_half = d_first;
+  const dim3 grd((unsigned)((n_points + 255) / 256)), blk(256);
+  hipLaunchKernelGGL(ms_prep_kernel, grd, blk, 0, s, a);
+  hipLaunchKernelGGL(ms_final_kernel, grd, blk, 0, s, a);
+  size_t m = 0;  // per-ring clouds in arrival order (:178-190): a stable grouping by ring
+  int rc = lslam::voxel_filter_segments(s, d_tmp, d_ring, n_points, n_rings, 1.0f, d_out, d_seg, &m, false);
+  if (rc) return fail(rc);
+  if (m > cap && out_xyzc) {
+    lslam::set_error("registration output buffer too small");
+    return fail(LSLAM_ERR_INVALID);
+  }
+  std::vector<int32_t> seg(m);
+  if (m) {
+    if (out_xyzc) FX_TRY2(hipMemcpyAsync(out_xyzc, d_out, m * sizeof(float4), hipMemcpyDeviceToHost, s));
+    FX_TRY2(hipMemcpyAsync(seg.data(), d_seg, m * 4, hipMemcpyDeviceToHost, s));
+    FX_TRY2(hipStreamSynchronize(s));
+  }
+  (void)hipFree(blob);
+  std::vector<size_t> count((size_t)n_rings, 0);
+  for (size_t i = 0; i < m; ++i) count[(size_t)seg[i]]++;
+  size_t total = 0;
+  for (int r = 0; r < n_rings; ++r) {  // IndexRange(first, last), :184-189
+    ranges_out[2 * r] = (int32_t)total;
+    total += count[(size_t)r];
+    ranges_out[2 * r + 1] = total > 0 ? (int32_t)total - 1 : 0;
+  }
+  *n_out = m;
+  return LSLAM_OK;
 }
 
 }  // extern "C"

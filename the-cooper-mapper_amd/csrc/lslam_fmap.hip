@@ -603,7 +603,7 @@ namespace lslam {
 // in_seg[i] is the segment of point i (ascending or not), every segment is filtered with `leaf`;
 // output ordered by segment, inside a segment in VoxelGrid order.  Scratch is cached per process.
 int voxel_filter_segments(hipStream_t s, const float4 *in_pts, const int32_t *in_seg, size_t n, int nseg, float leaf,
-                          float4 *out_pts, int32_t *out_seg, size_t *n_out) {
+                          float4 *out_pts, int32_t *out_seg, size_t *n_out, bool filter) {
   static Scratch sc;
   static Buf<uint8_t> all;
   static std::mutex mu;
@@ -616,7 +616,8 @@ int voxel_filter_segments(hipStream_t s, const float4 *in_pts, const int32_t *in
   kp.inv_leaf = 1.0f / leaf;
   kp.axis_bits = 1;
   kp.single = 0;
-  return run_pipeline(s, sc, in_pts, in_seg, n, kp, nseg, all.p, out_pts, out_seg, n_out);
+  // filter == false: only the stable grouping by segment (points with segment -1 are dropped)
+  return run_pipeline(s, sc, in_pts, in_seg, n, kp, nseg, filter ? all.p : nullptr, out_pts, out_seg, n_out);
 }
 }  // namespace lslam
 

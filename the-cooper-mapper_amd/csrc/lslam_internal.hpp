@@ -177,7 +177,7 @@ bool ctx_alive(const lslam_ctx *ctx);
 
 // lslam_fmap.hip: pcl::VoxelGrid per segment (see there)
 int voxel_filter_segments(hipStream_t s, const float4 *in_pts, const int32_t *in_seg, size_t n, int nseg, float leaf,
-                          float4 *out_pts, int32_t *out_seg, size_t *n_out);
+                          float4 *out_pts, int32_t *out_seg, size_t *n_out, bool filter = true);
 
 // lslam_scanprep.hip: Morton ordering of the resident scans on the device
 struct ScanPrep;

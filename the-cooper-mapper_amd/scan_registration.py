@@ -42,3 +42,19 @@ def extract_features(ctx, cloud, scan_ranges, params=None, intensity_field=3, ta
     if taps:
         res.update(curvature=curv, picked=picked, label=label)
     return res
+
+
+def multiscan_register(ctx, cloud, lower_deg, upper_deg, n_rings, scan_period=0.1):
+    """MultiScanRegistration::process (no IMU): raw driver cloud (n, >=3) -> (ring-sorted (m, 4)
+    {x', y', z', ring + relTime}, ranges (n_rings, 2)) -- the inputs of :func:`extract_features`."""
+    a = np.ascontiguousarray(cloud, dtype=np.float32)
+    out = np.zeros((len(a), 4), np.float32)
+    ranges = np.zeros((int(n_rings), 2), np.int32)
+    n = C.c_size_t()
+    rc = ctx.lib.lslam_multiscan_register(ctx.h, a.ctypes.data_as(C.c_void_p), len(a), a.shape[1] * 4,
+                                          float(lower_deg), float(upper_deg), int(n_rings), float(scan_period),
+                                          out.ctypes.data_as(c_float_p), len(out), C.byref(n),
+                                          ranges.ctypes.data_as(c_int32_p))
+    if rc < 0:
+        raise LslamError(rc, ctx.lib.lslam_last_error().decode())
+    return out[:n.value].copy(), ranges

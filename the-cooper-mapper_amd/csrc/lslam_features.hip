@@ -21,6 +21,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "lslam_device.hpp"
@@ -452,11 +454,23 @@ int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, s
     std::memcpy(&w, src + i * stride_bytes + intensity_offset_bytes, 4);
     h[i] = make_float4(v[0], v[1], v[2], w);
   }
-  char *blob = nullptr;
+  // device scratch is kept per device between calls (a sweep arrives every 100 ms)
+  struct Cache { char *p = nullptr; size_t cap = 0; };
+  static std::map<int, Cache> caches;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  Cache &cache = caches[lslam::ctx_device(ctx)];
   const size_t np4 = n_points * sizeof(float4);
   const size_t bytes = 5 * np4 + 2 * n_scans * 4 + 4 * n_scans * 4 + n_points * 4 + 2 * n_points + 4 * (n_scans + 1) * 4 +
-                       2 * np4 + 2 * n_points * 4 + 256;
-  FX_TRY(hipMalloc((void **)&blob, bytes));
+                       2 * np4 + 2 * n_points * 4 + 256 + 16 * 16;
+  if (bytes > cache.cap) {
+    if (cache.p) (void)hipFree(cache.p);
+    cache.p = nullptr;
+    cache.cap = 0;
+    FX_TRY(hipMalloc((void **)&cache.p, bytes + bytes / 4));
+    cache.cap = bytes + bytes / 4;
+  }
+  char *blob = cache.p;
   char *q = blob;
   auto take = [&](size_t b) { char *r = q; q += (b + 15) & ~(size_t)15; return r; };
   float4 *d_pts = (float4 *)take(np4);
@@ -468,7 +482,7 @@ int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, s
   float4 *d_out = (float4 *)take(np4), *d_out2 = (float4 *)take(np4);
   int32_t *d_seg = (int32_t *)take(n_points * 4), *d_seg2 = (int32_t *)take(n_points * 4);
   int rc = LSLAM_OK;
-  auto fail = [&](int code) { (void)hipFree(blob); return code; };
+  auto fail = [&](int code) { return code; };
 #define FX_TRY2(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { lslam::set_error(hipGetErrorString(_e)); return fail(LSLAM_ERR_HIP); } } while (0)
   FX_TRY2(hipMemcpyAsync(d_pts, h.data(), np4, hipMemcpyHostToDevice, s));
   FX_TRY2(hipMemcpyAsync(d_ranges, scan_ranges, 2 * n_scans * 4, hipMemcpyHostToDevice, s));
@@ -536,7 +550,6 @@ int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, s
     if (label_out) FX_TRY2(hipMemcpyAsync(label_out, d_label, n_points, hipMemcpyDeviceToHost, s));
     FX_TRY2(hipStreamSynchronize(s));
   }
-  (void)hipFree(blob);
   return rc;
 }
 

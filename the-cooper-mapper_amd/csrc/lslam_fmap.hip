@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -604,10 +605,17 @@ namespace lslam {
 // output ordered by segment, inside a segment in VoxelGrid order.  Scratch is cached per process.
 int voxel_filter_segments(hipStream_t s, const float4 *in_pts, const int32_t *in_seg, size_t n, int nseg, float leaf,
                           float4 *out_pts, int32_t *out_seg, size_t *n_out, bool filter) {
-  static Scratch sc;
-  static Buf<uint8_t> all;
+  struct Cache {
+    Scratch sc;
+    Buf<uint8_t> all;
+  };
+  static std::map<int, Cache> caches;  // per device
   static std::mutex mu;
   std::lock_guard<std::mutex> lk(mu);
+  int dev = 0;
+  FM_TRY(hipGetDevice(&dev));
+  Scratch &sc = caches[dev].sc;
+  Buf<uint8_t> &all = caches[dev].all;
   FM_TRY(all.reserve((size_t)nseg));
   FM_TRY(hipMemsetAsync(all.p, 1, (size_t)nseg, s));
   KeyParams kp{};
@@ -1066,18 +1074,26 @@ int lslam_voxel_grid(lslam_ctx *ctx, const void *cloud, size_t n, size_t stride_
   if (n == 0) return LSLAM_OK;
   FM_TRY(hipSetDevice(lslam::ctx_device(ctx)));
   hipStream_t s = (hipStream_t)lslam_stream(ctx);
-  lslam_fmap tmp;  // borrows the staging helpers; no grid
+  // staging and scratch are kept between calls (allocation costs more than the filter itself)
+  struct Cache {
+    lslam_fmap tmp;  // borrows the staging helpers; no grid
+    Buf<float4> out;
+    Buf<int32_t> oc;
+    Scratch sc;
+  };
+  static std::map<int, Cache> caches;  // per device
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  Cache &cache = caches[lslam::ctx_device(ctx)];
+  lslam_fmap &tmp = cache.tmp;
+  Buf<float4> &out = cache.out;
+  Buf<int32_t> &oc = cache.oc;
+  Scratch &sc = cache.sc;
   tmp.ctx = ctx;
   tmp.stream = s;
   int rc = pack_input(&tmp, cloud, n, stride_bytes);
-  Buf<float4> out;
-  Buf<int32_t> oc;
-  Scratch sc;
-  auto cleanup = [&] {
-    tmp.in_raw.release(); out.release(); oc.release();
-    sc.release();
-  };
-  if (rc) { cleanup(); return rc; }
+  auto cleanup = [] {};
+  if (rc) return rc;
   // min/max on the host while the cloud is at hand (VoxelGrid::applyFilter: getMinMax3D)
   const float inv = 1.0f / leaf;
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};

@@ -178,7 +178,9 @@ def main():
             out["single_scan"] = single_scan_leg(ctx, pr, opts, max(10, args.steps // 2))
     if rank == 0 and not args.no_mapping_frame:
         try:
-            out["mapping_frame"] = mapping_frame_leg(pkg, synth, ctx, pr, opts, np, not args.no_cpu_baseline)
+            out["mapping_frame"] = mapping_frame_leg(pkg, synth, ctx, pr, opts, np, not args.no_cpu_baseline, 64)
+            # BASELINE configs[1]: the same frame with a VLP-16 (16 x 1800) sweep
+            out["mapping_frame_vlp16"] = mapping_frame_leg(pkg, synth, ctx, pr, opts, np, not args.no_cpu_baseline, 16)
         except Exception as e:  # a secondary leg never takes the headline line down
             out["mapping_frame"] = {"error": repr(e)}
     if world > 1 or args.shard_points:
@@ -346,7 +348,7 @@ def single_scan_leg(ctx, pr, opts, steps):
             "roofline_frac": ALG_BYTES_PER_POINT_RESIDUAL * pt / (sw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sw_ms > 0 else None}
 
 
-def mapping_frame_leg(pkg, synth, ctx, pr, opts, np, with_cpu):
+def mapping_frame_leg(pkg, synth, ctx, pr, opts, np, with_cpu, rings=64):
     """One LaserMapping frame end to end on the device (SURVEY 8f n1/n2 around the hot path), per step:
     extractFeatures on the 64x1800 sweep, VoxelGrid of the features (LaserMatcher.cpp:289-301, leaf
     1.0 = the reference default), FeatureMap::update, surround -> kd-trees, scanMatchScan,
@@ -355,7 +357,7 @@ def mapping_frame_leg(pkg, synth, ctx, pr, opts, np, with_cpu):
         o = np.zeros((len(a), 4), np.float32)
         o[:, :3] = a[:, :3]
         return o
-    _, _, gt, cloud, ranges = synth.make_scan(pr["world"], 64, 1800, gt_pose=pr["gt_pose"], seed=4321, full=True)
+    _, _, gt, cloud, ranges = synth.make_scan(pr["world"], rings, 1800, gt_pose=pr["gt_pose"], seed=4321, full=True)
     fm = pkg.FeatureMap(ctx, 21, 11, 21)
     fm.setup_filter_size(0.2, 0.4, 0.6)
     fm.update(gt[3:])
@@ -387,7 +389,7 @@ def mapping_frame_leg(pkg, synth, ctx, pr, opts, np, with_cpu):
             for k, d in zip(steps, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5)):
                 acc[k] += d
     gpu = {k: 1e3 * v / frames for k, v in acc.items()}
-    res = {"gpu_ms": gpu, "gpu_ms_per_frame": sum(gpu.values()), "frames": frames,
+    res = {"rings": rings, "gpu_ms": gpu, "gpu_ms_per_frame": sum(gpu.values()), "frames": frames,
            "sweep_points": int(len(cloud)), "features": {k: int(len(v)) for k, v in feat.items()},
            "scan_points_after_voxel_grid": int(len(dc) + len(ds)), "map_points": fm.info()["n_corner"] + fm.info()["n_surf"],
            "scan_match_iterations": int(st.iterations),

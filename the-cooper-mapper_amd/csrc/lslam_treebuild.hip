@@ -845,11 +845,8 @@ __global__ __launch_bounds__(LV_TB) void lv_minmax_kernel(LvArgs L) {
   }
 }
 
-__global__ void lv_split_kernel(LvArgs L) {  // middleSplit_, :982-1031, one thread per node
-  const int node = blockIdx.x * blockDim.x + threadIdx.x;
-  if (node >= L.hdr[0]) return;
-  const BuildItem it = L.items[node];
-  LvStat &st = L.stat[node];
+// middleSplit_ (:982-1031) from the node's extrema: evaluated identically by every block of the node
+__device__ __forceinline__ void lv_split(const BuildItem &it, const LvStat &st, int *feat, float *cut) {
   float emin[3], emax[3];
   for (int d = 0; d < 3; ++d) { emin[d] = ord_f(st.mn[d]); emax[d] = ord_f(st.mx[d]); }
   const float EPS = 0.00001f;
@@ -865,14 +862,19 @@ __global__ void lv_split_kernel(LvArgs L) {  // middleSplit_, :982-1031, one thr
     }
   }
   const float split_val = (it.lo[cutfeat] + it.hi[cutfeat]) / 2;
-  st.feat = cutfeat;
-  st.cut = split_val < emin[cutfeat] ? emin[cutfeat] : (split_val > emax[cutfeat] ? emax[cutfeat] : split_val);
+  *feat = cutfeat;
+  *cut = split_val < emin[cutfeat] ? emin[cutfeat] : (split_val > emax[cutfeat] ? emax[cutfeat] : split_val);
 }
 
 __global__ __launch_bounds__(LV_TB) void lv_count_kernel(LvArgs L) {
   LV_PROLOGUE
-  const int feat = L.stat[node].feat;
-  const float cut = L.stat[node].cut;
+  int feat;
+  float cut;
+  lv_split(it, L.stat[node], &feat, &cut);
+  if (c0 == 0 && threadIdx.x == 0) {  // the node's first chunk publishes the split for the later passes
+    L.stat[node].feat = feat;
+    L.stat[node].cut = cut;
+  }
   int a = 0, b = 0;
   for (int i = c0 + threadIdx.x; i < c1; i += LV_TB) {
     const float x = coord(L.A.pts[l + i], feat);
@@ -929,36 +931,26 @@ __global__ __launch_bounds__(LV_TB) void lv_hflags_kernel(LvArgs L, int p) {
   }
 }
 
-// per node: ranks of the chunks.  left: ascending chunks; right: the k-th misplaced from the RIGHT
-__global__ __launch_bounds__(LV_TB) void lv_hscan_kernel(LvArgs L, int p) {
-  __shared__ int sh[LV_TB / 64];
-  const int node = blockIdx.x;
-  if (node >= L.hdr[0]) return;
-  const BuildItem it = L.items[node];
-  const int nch = (it.r - it.l + LV_CH - 1) / LV_CH, first = L.chunk_first[node];
-  int runL = 0, runR = 0;
-  for (int base = 0; base < nch; base += LV_TB) {
-    const int c = base + threadIdx.x;
-    const int vL = c < nch ? L.cntL[first + c] : 0;
-    const int cr = nch - 1 - c;  // right side walks the chunks downwards
-    const int vR = c < nch ? L.cntR[first + cr] : 0;
-    int tL, tR;
-    const int eL = lv_scan(vL, sh, &tL), eR = lv_scan(vR, sh, &tR);
-    if (c < nch) {
-      L.baseL[first + c] = runL + eL;
-      L.baseR[first + cr] = runR + eR;
-    }
-    runL += tL;
-    runR += tR;
-  }
-  if (threadIdx.x == 0) L.stat[node].m[p] = runL;  // == runR
-}
-
 __global__ __launch_bounds__(LV_TB) void lv_hwrite_kernel(LvArgs L, int p) {
   LV_PROLOGUE
   __shared__ int sh[LV_TB / 64];
+  // ranks of this chunk inside its node: misplaced-left elements of the chunks before it, wanted-left
+  // elements of the chunks after it (the k-th from the RIGHT), and the node's total
+  const int first = L.chunk_first[node], nch = (n + LV_CH - 1) / LV_CH, mine = (int)blockIdx.x - first;
+  int bl = 0, br = 0, tot = 0;
+  for (int c = threadIdx.x; c < nch; c += LV_TB) {
+    const int vl = L.cntL[first + c], vr = L.cntR[first + c];
+    tot += vl;
+    if (c < mine) bl += vl;
+    if (c > mine) br += vr;
+  }
+  int baseL, baseR, m;
+  lv_scan(bl, sh, &baseL);
+  lv_scan(br, sh, &baseR);
+  lv_scan(tot, sh, &m);
+  if (mine == 0 && threadIdx.x == 0) L.stat[node].m[p] = m;
+  if (m == 0) return;
   const LvStat st = L.stat[node];
-  if (st.m[p] == 0) return;
   int pa, Lc;
   lv_region(st, p, &pa, &Lc);
   unsigned mL, mR;
@@ -967,15 +959,14 @@ __global__ __launch_bounds__(LV_TB) void lv_hwrite_kernel(LvArgs L, int p) {
   int eL = lv_scan(__popc(mL), sh, &tL);
   const int eR = lv_scan(__popc(mR), sh, &tR);
   const int i0 = c0 + threadIdx.x * LV_PER;
-  int posL = L.baseL[blockIdx.x] + eL;
-  // rank from the right inside the chunk: elements after this one in the chunk
-  int after = tR - eR;  // flagged right elements at or after this thread's first element
+  int posL = baseL + eL;
+  int after = tR - eR;  // wanted-left elements of this chunk at or after this thread's first element
 #pragma unroll
   for (int u = 0; u < LV_PER; ++u) {
     if (mL & (1u << u)) L.A.tmpA[l + posL++] = i0 + u;
     if (mR & (1u << u)) {
-      --after;  // now: flagged elements strictly after this one
-      L.A.tmpB[l + L.baseR[blockIdx.x] + after] = i0 + u;
+      --after;  // now: those strictly after this one
+      L.A.tmpB[l + baseR + after] = i0 + u;
     }
   }
 }
@@ -1204,7 +1195,7 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
   if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;  // host buffers are the caller's
   // Levels are enqueued in batches without looking at their outcome (grids at capacity, exhausted
   // levels cost a handful of empty launches); the host checks the item count once per batch.
-  const dim3 gc(cap_chunks), gn((cap_nodes + 63) / 64), gh(cap_nodes), bt(LV_TB);
+  const dim3 gc(cap_chunks), gn((cap_nodes + 63) / 64), bt(LV_TB);
   int lvl = 0;
   for (int batch = 0; batch < 16; ++batch) {
     const int per_batch = batch == 0 ? std::max(2, (int)std::ceil(std::log2(std::max(2.0, (double)n / HUGE_MIN))) + 1) : 3;
@@ -1227,11 +1218,9 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
       L.next_cap = cap_nodes;
       hipLaunchKernelGGL(lv_setup_kernel, dim3(1), dim3(1024), 0, stream, L);
       hipLaunchKernelGGL(lv_minmax_kernel, gc, bt, 0, stream, L);
-      hipLaunchKernelGGL(lv_split_kernel, gn, dim3(64), 0, stream, L);
       hipLaunchKernelGGL(lv_count_kernel, gc, bt, 0, stream, L);
       for (int pass = 0; pass < 2; ++pass) {
         hipLaunchKernelGGL(lv_hflags_kernel, gc, bt, 0, stream, L, pass);
-        hipLaunchKernelGGL(lv_hscan_kernel, gh, bt, 0, stream, L, pass);
         hipLaunchKernelGGL(lv_hwrite_kernel, gc, bt, 0, stream, L, pass);
         hipLaunchKernelGGL(lv_hswap_kernel, gc, bt, 0, stream, L, pass);
       }

@@ -920,6 +920,13 @@ __global__ __launch_bounds__(LV_TB) void lv_hflags_kernel(LvArgs L, int p) {
   const LvStat st = L.stat[node];
   int pa, Lc;
   lv_region(st, p, &pa, &Lc);
+  if (Lc == 0 || Lc == n - pa) {  // nothing belongs left, or everything does: no pairs (the usual case of pass 2)
+    if (threadIdx.x == 0) {
+      L.cntL[blockIdx.x] = 0;
+      L.cntR[blockIdx.x] = 0;
+    }
+    return;
+  }
   unsigned mL, mR;
   lv_flags(L, l, n, c0, st.feat, st.cut, p, pa, Lc, &mL, &mR);
   int tL, tR;

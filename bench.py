@@ -442,7 +442,22 @@ def cpu_baseline(pr, repeats, gpu_pose, np):
         t_sweep += st.t_sweep
         its += st.iterations
     dt = time.perf_counter() - t0
+    # the same loop with the sweep spread over all host cores (OpenMP) -- a generous
+    # upper bound for a CPU, NOT what the reference does (its hot path is one thread)
+    all_cores = None
+    try:
+        oo = Oracle(native="omp")
+        oo.scanmatch_scan(pr["map_corner"], pr["map_surf"], pr["corner"], pr["surf"], pr["init_pose"])  # threads up
+        t1 = time.perf_counter()
+        ok2, pose2, st2 = oo.scanmatch_scan(pr["map_corner"], pr["map_surf"], pr["corner"], pr["surf"], pr["init_pose"])
+        dt2 = time.perf_counter() - t1
+        all_cores = {"value": st2.point_residuals / dt2, "sweep_only_value": st2.point_residuals / st2.t_sweep if st2.t_sweep > 0 else None,
+                     "cores": os.cpu_count(), "kind": "port, OpenMP over the scan points -- not reference behaviour",
+                     "pose_diff_vs_single_thread_m": float(np.abs(pose2[3:] - pose[3:]).max())}
+    except Exception as e:
+        all_cores = {"error": repr(e)}
     return {
+        "all_cores": all_cores,
         "value": pt / dt,
         "unit": "point-residuals/s",
         "cores": 1,

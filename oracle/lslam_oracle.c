@@ -13,6 +13,9 @@
 #define _POSIX_C_SOURCE 199309L
 #define ORACLE_PI 3.14159265358979323846 /* M_PI */
 #include "lslam_oracle.h"
+#ifdef ORACLE_OMP
+#include <omp.h>
+#endif
 
 #include <float.h>
 #include <math.h>
@@ -990,6 +993,45 @@ static void sweep_all(const oracle_kdtree *tc, const float *map_c, const oracle_
   memset(acc, 0, sizeof(*acc));
   oracle_pose_to_Rt(pose, R, t);
   pose_sincos(pose, sc);
+#ifdef ORACLE_OMP
+  /* NOT reference behaviour (its hot path is single-threaded): the "all host cores" upper bound of
+   * SURVEY 8d.  Points are split into contiguous chunks, one accumulator per thread, combined in
+   * thread order (the sums differ from the sequential ones in the last bits). */
+  {
+    const int nth = omp_get_max_threads();
+    sweep_acc *part = (sweep_acc *)calloc((size_t)nth, sizeof(sweep_acc));
+    const long long total = (long long)(nqc + nqs);
+#pragma omp parallel
+    {
+      sweep_acc local; /* on the thread's own stack: no false sharing */
+      sweep_acc *a = &local;
+      memset(a, 0, sizeof(*a));
+#pragma omp for schedule(static) nowait
+      for (long long k = 0; k < total; ++k) {
+        const size_t o = (size_t)k;
+        if (o < nqc)
+          sweep_point(tc, map_c, map_stride, 0, qc + o * q_stride, R, t, sc, gate_c, a,
+                      knn_idx ? knn_idx + 5 * o : NULL, knn_d2 ? knn_d2 + 5 * o : NULL,
+                      coeff ? coeff + 4 * o : NULL, flags ? flags + o : NULL);
+        else
+          sweep_point(ts, map_s, map_stride, 1, qs + (o - nqc) * q_stride, R, t, sc, gate_s, a,
+                      knn_idx ? knn_idx + 5 * o : NULL, knn_d2 ? knn_d2 + 5 * o : NULL,
+                      coeff ? coeff + 4 * o : NULL, flags ? flags + o : NULL);
+      }
+      part[omp_get_thread_num()] = local;
+    }
+    for (int th = 0; th < nth; ++th) {
+      for (int i = 0; i < 36; ++i) acc->AtA[i] += part[th].AtA[i];
+      for (int i = 0; i < 6; ++i) acc->Atb[i] += part[th].Atb[i];
+      acc->n_rows += part[th].n_rows;
+      acc->n_line += part[th].n_line;
+      acc->n_plane += part[th].n_plane;
+      acc->score += part[th].score;
+    }
+    free(part);
+    return;
+  }
+#endif
   for (size_t i = 0; i < nqc; ++i)
     sweep_point(tc, map_c, map_stride, 0, qc + i * q_stride, R, t, sc, gate_c, acc,
                 knn_idx ? knn_idx + 5 * i : NULL, knn_d2 ? knn_d2 + 5 * i : NULL,

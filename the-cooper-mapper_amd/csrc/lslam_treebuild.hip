@@ -45,7 +45,7 @@ namespace {
 // most LOCAL_MAX points goes to the subtree list instead.  Phase B: one wavefront per
 // subtree of that list builds it completely (explicit stack in LDS, no barriers needed).
 #ifndef LSLAM_LOCAL_MAX
-#define LSLAM_LOCAL_MAX 2048
+#define LSLAM_LOCAL_MAX 1536
 #endif
 constexpr int TB_BIG = 1024;
 constexpr int TB_SMALL = 64;

@@ -196,6 +196,11 @@ int lslam_odometry_match(lslam_ctx *ctx, const void *last_corner, size_t n_last_
                          int32_t max_iterations, float delta_t_abort, float delta_r_abort,
                          lslam_stats *stats);
 
+/* LaserOdometry::transformToEnd (odometry/LaserOdometry.cpp:156-168): every point of a host
+ * cloud ({x,y,z} + intensity = ring + relTime at byte 12 of 16-byte points, byte 16 of PointXYZI)
+ * is de-skewed to the sweep start and moved to the sweep end, in place. */
+int lslam_transform_to_end(lslam_ctx *ctx, void *cloud, size_t n, size_t stride_bytes, const float pose[6]);
+
 /* Isometry3f <-> Twist conversion used by the Isometry overloads
  * (ScanMatch.cpp:349-360; util/transform_utils.h:308-323,54-60).  T is a
  * row-major 4x4. Host-side helpers, no device work. */

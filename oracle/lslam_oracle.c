@@ -1300,6 +1300,23 @@ static void odom_transform_to_start(const float pose[6], const float *pi, float 
   oracle_transform_point(R, t, pi, po);
 }
 
+/* LaserOdometry.cpp:156-168 transformToEnd(CloudI): every point is de-skewed to the sweep start
+ * (transformToStart) and then moved to the sweep end by the inverse of the full transform
+ * (Eigen Isometry inverse: R^T, -R^T t). */
+void oracle_transform_to_end(float *cloud, size_t n, size_t stride_floats, const float pose[6]) {
+  float R[9], t[3], Ri[9], ti[3];
+  oracle_pose_to_Rt(pose, R, t);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) Ri[r * 3 + c] = R[c * 3 + r];
+  for (int r = 0; r < 3; ++r) ti[r] = (-Ri[r * 3] * t[0] + -Ri[r * 3 + 1] * t[1]) + -Ri[r * 3 + 2] * t[2];
+  for (size_t i = 0; i < n; ++i) {
+    float *p = cloud + i * stride_floats, a[3], b[3];
+    odom_transform_to_start(pose, p, a);
+    oracle_transform_point(Ri, ti, a, b);
+    p[0] = b[0]; p[1] = b[1]; p[2] = b[2];
+  }
+}
+
 /* math_utils.h:47-54 calcSquaredDiff(a, b) */
 static inline float sq_diff(const float *a, const float *b) {
   float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];

@@ -178,6 +178,10 @@ int oracle_odometry_match(const float *last_corner, size_t n_lc, const float *la
                           size_t stride, float pose[6], const oracle_odom_opts *opts,
                           oracle_stats *stats);
 
+/* LaserOdometry::transformToEnd (odometry/LaserOdometry.cpp:156-168): cloud {x,y,z,intensity}
+ * in place. */
+void oracle_transform_to_end(float *cloud, size_t n, size_t stride_floats, const float pose[6]);
+
 /* One GN solve step given sums (ScanMatch.cpp:206-260).  iter==0 computes the
  * degeneracy projector into matP/degenerate (in/out state). Returns converged. */
 int oracle_gn_step(const float AtA[36], const float Atb[6], int iter, float pose[6],

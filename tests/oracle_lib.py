@@ -140,6 +140,7 @@ class Oracle:
         L.oracle_odometry_match.argtypes = [c_float_p, C.c_size_t, c_float_p, C.c_size_t, c_float_p, C.c_size_t,
                                             c_float_p, C.c_size_t, C.c_size_t, c_float_p,
                                             C.POINTER(OracleOdomOpts), C.POINTER(OracleStats)]
+        L.oracle_transform_to_end.argtypes = [c_float_p, C.c_size_t, C.c_size_t, c_float_p]
         L.oracle_gn_step.restype = C.c_int
         L.oracle_gn_step.argtypes = [c_float_p, c_float_p, C.c_int, c_float_p, c_float_p,
                                      C.POINTER(C.c_int), C.c_float, C.c_float, C.c_float,
@@ -373,6 +374,12 @@ class Oracle:
         n = self.lib.oracle_odometry_match(_fp(lc), len(lc), _fp(ls), len(ls), _fp(sh), len(sh), _fp(fl), len(fl),
                                            s, _fp(pose), C.byref(op), C.byref(st))
         return n, pose, st
+
+    def transform_to_end(self, cloud, pose):
+        a = np.array(cloud, dtype=np.float32, order="C")
+        p = np.ascontiguousarray(pose, np.float32).reshape(6)
+        self.lib.oracle_transform_to_end(_fp(a), len(a), a.shape[1], _fp(p))
+        return a
 
     def gn_step(self, AtA, Atb, it, pose, matP, degenerate, eig_thresh=100.0, dr=0.05, dt=0.05):
         AtA = np.ascontiguousarray(AtA, np.float32).reshape(36)

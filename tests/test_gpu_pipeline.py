@@ -1,0 +1,107 @@
+"""The whole per-sweep chain on the device against the same chain made of oracle calls:
+MultiScanRegistration::process -> extractFeatures -> LaserOdometry::process -> LaserMapping::process
+(SURVEY 8f n1/n2 around the hot path)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_transform_to_end_matches_oracle(ctx, oracle):
+    rng = np.random.default_rng(2)
+    c = rng.uniform(-40, 40, (5000, 4)).astype(np.float32)
+    c[:, 3] = rng.integers(0, 16, len(c)) + rng.uniform(0, 0.0999, len(c)).astype(np.float32)
+    pose = np.array([0.01, -0.02, 0.03, 0.4, -0.1, 0.05], np.float32)
+    got, ref = ctx.transform_to_end(c, pose), oracle.transform_to_end(c, pose)
+    assert np.array_equal(got[:, 3], c[:, 3])
+    assert np.abs(got[:, :3] - ref[:, :3]).max() <= 2e-5  # per-point sin/cos are the device's
+    # the sweep-end point of a zero transform is the point itself
+    assert np.array_equal(bits(ctx.transform_to_end(c, np.zeros(6, np.float32))[:, :3]), bits(c[:, :3]))
+
+
+class OracleChain:
+    """LaserOdometry::process + LaserMapping::process written with oracle calls only."""
+
+    def __init__(self, oracle, ctx_for_conversions, cube_dims):
+        self.o, self.cv = oracle, ctx_for_conversions  # Twist<->Isometry conversions are host helpers of the ABI
+        self.transform = np.zeros(6, np.float32)
+        self.Tsum = np.eye(4, dtype=np.float32)
+        self.inited = False
+        self.fm = oracle.feature_map(*cube_dims)
+        self.fm.setup_filter_size(1.0, 1.0, 2.0)
+        self.odom_last = np.eye(4, dtype=np.float32)
+        self.mapped_last = np.eye(4, dtype=np.float32)
+
+    def odometry(self, f):
+        if not self.inited:
+            self.tree_c, self.tree_s = f["less_sharp"], f["less_flat"]
+            self.inited = True
+            return None
+        it, pose, st = self.o.odometry_match(self.tree_c, self.tree_s, f["sharp"], f["flat"], self.transform)
+        self.transform = pose
+        self.Tsum = (self.Tsum @ self.cv.pose_to_isometry(pose)).astype(np.float32)
+        ls, lf = self.o.transform_to_end(f["less_sharp"], pose), self.o.transform_to_end(f["less_flat"], pose)
+        self.last_c, self.last_s = ls, lf
+        if len(ls) > 10 and len(lf) > 100:
+            self.tree_c, self.tree_s = ls, lf
+        return self.Tsum.copy()
+
+    def mapping(self, corner_last, surf_last, odom_new):
+        new = (self.mapped_last @ np.linalg.inv(self.odom_last) @ odom_new).astype(np.float32)
+        cds, sds = self.o.voxel_grid(corner_last, 1.0), self.o.voxel_grid(surf_last, 1.0)
+        self.fm.update(new[:3, 3])
+        mc, ms = self.fm.get_surround_feature()
+        if len(mc) or len(ms):
+            opts = self.o.default_opts()
+            opts.delta_t_abort = opts.delta_r_abort = 0.1
+            opts.use_score = 0
+            ok, pose, st = self.o.scanmatch_scan(mc, ms, cds, sds, self.cv.isometry_to_pose(new), opts)
+            if st.status != 1:
+                new = self.cv.pose_to_isometry(pose)
+        self.mapped_last, self.odom_last = new.copy(), odom_new.copy()
+        self.fm.add_feature_cloud(cds, sds, new)
+        return new
+
+
+def test_registration_to_mapping_chain(pkg, ctx, oracle, synth, small_problem):
+    """Five consecutive VLP-16 sweeps of a drive through the synthetic world, raw driver clouds in:
+    the device chain and the oracle chain agree on every intermediate product (feature clouds bit for
+    bit) and on the odometry and map poses to 1e-3 m (the chain passes through per-point sin/cos and
+    two Gauss-Newton loops per sweep; each stage's own parity bar is tighter)."""
+    from test_oracle_features import _raw_sweep  # noqa: F401  (same raw-sweep construction)
+    world = small_problem["world"]
+    dims = (21, 21, 11)
+    odo = pkg.LaserOdometry(ctx)
+    mapper = pkg.LaserMapping(ctx, cube_dims=dims)
+    chain = OracleChain(oracle, ctx, dims)
+    sr = pkg.scan_registration
+    for k in range(5):
+        gt = (0.0, 0.0, 0.3 + 0.01 * k, 3.0 + 0.4 * k, -2.0 + 0.15 * k, synth.SENSOR_HEIGHT)
+        c, s, gtp, cloud, ranges = synth.make_scan(world, 16, 900, gt_pose=gt, seed=300 + k, full=True)
+        ring = np.floor(cloud[:, 3]).astype(np.int64)
+        raw = cloud[np.lexsort((ring, -(cloud[:, 3] - ring)))]
+        reg, rr = sr.multiscan_register(ctx, raw, -15.0, 15.0, 16)
+        oreg, orr = oracle.multiscan_register(raw, -15.0, 15.0, 16)
+        assert np.array_equal(rr, orr) and np.array_equal(bits(reg[:, :3]), bits(oreg[:, :3]))
+        # from here on both chains consume the DEVICE registration (its ring + relTime differs from the
+        # oracle's in the last bits), so that every later stage is compared on identical input
+        f = sr.extract_features(ctx, reg, rr)
+        of = oracle.extract_features(reg, rr)
+        for key in ("sharp", "less_sharp", "flat", "less_flat"):
+            assert np.array_equal(bits(f[key]), bits(of[key])), (k, key)
+        T_g, T_o = odo.process(f["sharp"], f["less_sharp"], f["flat"], f["less_flat"]), chain.odometry(of)
+        if k == 0:
+            assert T_g is None and T_o is None
+            continue
+        assert np.abs(T_g - T_o).max() <= 1e-3, (k, np.abs(T_g - T_o).max())
+        M_g = mapper.process(odo.last_corner, odo.last_surf, T_g)
+        M_o = chain.mapping(chain.last_c, chain.last_s, T_o)
+        assert np.abs(M_g - M_o).max() <= 1e-3, (k, np.abs(M_g - M_o).max())
+    # the sensor moved 1.6 m / 0.6 m between the first and the last sweep: the map pose (relative to the
+    # first sweep) has travelled that far
+    assert abs(np.linalg.norm(M_g[:3, 3]) - np.hypot(1.6, 0.6)) < 0.1
+    mapper.feature_map.close()

@@ -19,6 +19,7 @@ from .feature_map import FeatureMap, voxel_grid
 from . import scan_registration
 from .loop_closure import KeyFrame, Loop, LoopDetector
 from .graph import Graph, KeyframeUpdater
+from .pipeline import LaserOdometry, LaserMapping
 
-__all__ = ["Context", "ScanMatch", "PoseGraph", "FeatureMap", "voxel_grid", "scan_registration", "KeyFrame", "Loop", "LoopDetector", "Graph", "KeyframeUpdater", "LslamError", "LslamOpts", "LslamStats", "LslamMapInfo",
+__all__ = ["Context", "ScanMatch", "PoseGraph", "FeatureMap", "voxel_grid", "scan_registration", "KeyFrame", "Loop", "LoopDetector", "Graph", "KeyframeUpdater", "LaserOdometry", "LaserMapping", "LslamError", "LslamOpts", "LslamStats", "LslamMapInfo",
            "Status", "lib_path", "load_library", "build_library"]

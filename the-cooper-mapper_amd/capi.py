@@ -132,6 +132,7 @@ SYMBOLS = {
     "lslam_odometry_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                        C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, c_float_p, C.c_int32,
                                        C.c_float, C.c_float, C.POINTER(LslamStats)]),
+    "lslam_transform_to_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, c_float_p]),
     "lslam_isometry_to_pose": (None, [c_float_p, c_float_p]),
     "lslam_pose_to_isometry": (None, [c_float_p, c_float_p]),
     "lslam_transform_associate": (None, [c_float_p, c_float_p, c_float_p, c_float_p]),

@@ -1311,6 +1311,35 @@ int lslam_odometry_match(lslam_ctx *ctx, const void *last_corner, size_t n_lc, c
   return st.status;
 }
 
+// LaserOdometry::transformToEnd (odometry/LaserOdometry.cpp:156-168) on a host cloud, in place.
+int lslam_transform_to_end(lslam_ctx *ctx, void *cloud, size_t n, size_t stride_bytes, const float pose[6]) {
+  int rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (!pose || (n && !cloud) || stride_bytes < 16 || (stride_bytes & 3) || n > 0x3FFFFFFFu) {
+    set_err("bad transform_to_end arguments (points need {x,y,z} and the intensity)");
+    return LSLAM_ERR_INVALID;
+  }
+  if (n == 0) return LSLAM_OK;
+  const size_t ioff = stride_bytes == 16 ? 12 : 16;  // PointXYZI: intensity at byte 16
+  std::vector<float4> h(n);
+  char *p = static_cast<char *>(cloud);
+  for (size_t i = 0; i < n; ++i) {
+    float v[3], w;
+    std::memcpy(v, p + i * stride_bytes, 12);
+    std::memcpy(&w, p + i * stride_bytes + ioff, 4);
+    h[i] = make_float4(v[0], v[1], v[2], w);
+  }
+  HIP_TRY(ctx->t_q.reserve(n));
+  HIP_TRY(ctx->t_small.reserve(64));
+  HIP_TRY(hipMemcpyAsync(ctx->t_q.p, h.data(), n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->t_small.p, pose, 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(launch_odom_to_end(ctx->t_q.p, (int)n, ctx->t_small.p, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(h.data(), ctx->t_q.p, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < n; ++i) std::memcpy(p + i * stride_bytes, &h[i], 12);
+  return LSLAM_OK;
+}
+
 // util/transform_utils.h:502-507 transformAssociate: Wnew = (Wold * Lold^-1) * Lnew
 // (Eigen::Isometry3f::inverse() = [R^T | -R^T t]; fp32 products in row.column order)
 void lslam_transform_associate(const float Lold[16], const float Lnew[16], const float Wold[16],

@@ -122,6 +122,7 @@ struct OdomArgs {
   float *partials;
 };
 hipError_t launch_odom_sweep(const OdomArgs &a, hipStream_t s);
+hipError_t launch_odom_to_end(float4 *pts, int n, const float *d_pose6, hipStream_t s);
 
 #ifndef LSLAM_SWEEP_BLOCK
 #define LSLAM_SWEEP_BLOCK 256

@@ -786,6 +786,41 @@ struct DevSinCosF {
   }
 };
 
+// LaserOdometry::transformToEnd (LaserOdometry.cpp:156-168): de-skew every point to the sweep start
+// (transformToStart, :135-142), then move it to the sweep end with the inverse of the full transform.
+__global__ void odom_to_end_kernel(float4 *pts, int n, const float *pose6) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float pose[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) pose[k] = pose6[k];
+  float R[9], t[3], scd[6];
+  pose_to_Rt_sc(pose, R, t, scd, DevSinCosF());
+  float ti[3];  // Eigen Isometry inverse: R^T, (-R^T) t
+#pragma unroll
+  for (int r = 0; r < 3; ++r) ti[r] = ((-R[r] * t[0]) + (-R[3 + r] * t[1])) + (-R[6 + r] * t[2]);
+  const float4 q = pts[i];
+  const float s = 10 * (q.w - (int)q.w);
+  float ps[6], Rs[9], ts[3];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) ps[k] = pose[k] * s;
+  pose_to_Rt_sc(ps, Rs, ts, scd, DevSinCosF());
+  const float a0 = ((Rs[0] * q.x + Rs[1] * q.y) + Rs[2] * q.z) + ts[0];
+  const float a1 = ((Rs[3] * q.x + Rs[4] * q.y) + Rs[5] * q.z) + ts[1];
+  const float a2 = ((Rs[6] * q.x + Rs[7] * q.y) + Rs[8] * q.z) + ts[2];
+  float4 o;
+  o.x = ((R[0] * a0 + R[3] * a1) + R[6] * a2) + ti[0];
+  o.y = ((R[1] * a0 + R[4] * a1) + R[7] * a2) + ti[1];
+  o.z = ((R[2] * a0 + R[5] * a1) + R[8] * a2) + ti[2];
+  o.w = q.w;
+  pts[i] = o;
+}
+
+hipError_t launch_odom_to_end(float4 *pts, int n, const float *d_pose6, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(odom_to_end_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, d_pose6);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256, 2) void odom_sweep_kernel(OdomArgs a) {
   const GNState *st = a.state;
   if (st->done) return;

@@ -1,0 +1,106 @@
+"""Node-level mirrors of the two per-sweep state machines around the hot path, on the device through
+the C ABI (clouds are (n, 4) float32 {x, y, z, intensity = ring + relTime}):
+
+* :class:`LaserOdometry` -- ``LaserOdometry::process`` (/root/reference/L_SLAM/src/odometry/
+  LaserOdometry.cpp:288-326, 649-653): first sweep initialises the "last" clouds; afterwards
+  scanMatch (variant B) against them with the persistent ``_transform`` as initial guess,
+  ``_Tsum = _Tsum * transform``, transformToEnd of the less-sharp / less-flat clouds, which become the
+  next "last" clouds (their kd-trees are refreshed only when they hold > 10 / > 100 points).
+* :class:`LaserMapping` -- ``LaserMapping::process`` (LaserMapping.cpp:39-59) over ``LaserMatcher``
+  (LaserMatcher.cpp:289-354): transformMerge (odometry prior), VoxelGrid of the frame's features,
+  FeatureMap::update + surround, scanMatchScan (thresholds 0.1 / 0.1, score gate off, return value
+  ignored), transformUpdate, addFeatureCloud.
+
+ROS plumbing (topics, time-stamp checks, tf, frame skipping) is not mirrored.
+"""
+import numpy as np
+
+from .feature_map import FeatureMap, voxel_grid
+
+
+class LaserOdometry:
+    def __init__(self, ctx, max_iterations=25, delta_t_abort=0.1, delta_r_abort=0.1):
+        self.ctx = ctx
+        self.max_iterations, self.dt, self.dr = max_iterations, delta_t_abort, delta_r_abort
+        self.transform = np.zeros(6, np.float32)  # _transform: sweep-to-sweep motion, kept as next guess
+        self.Tsum = np.eye(4, dtype=np.float32)   # _Tsum
+        self.system_inited = False
+        self.last_corner = self.last_surf = None   # _lastCornerCloud / _lastSurfaceCloud
+        self.tree_corner = self.tree_surf = None   # what the kd-trees were last built from
+        self.last_stats = None
+
+    def process(self, sharp, less_sharp, flat, less_flat):
+        """One sweep's four feature clouds -> _Tsum (4x4) after the sweep (None for the first one)."""
+        less_sharp = np.ascontiguousarray(less_sharp, np.float32)
+        less_flat = np.ascontiguousarray(less_flat, np.float32)
+        if not self.system_inited:  # :295-303
+            self.last_corner, self.last_surf = less_sharp, less_flat
+            self.tree_corner, self.tree_surf = less_sharp, less_flat
+            self.system_inited = True
+            return None
+        status, pose, st = self.ctx.odometry_match(self.tree_corner, self.tree_surf, sharp, flat, self.transform,
+                                                   self.max_iterations, self.dt, self.dr)
+        self.last_stats = st
+        self.transform = pose
+        self.Tsum = (self.Tsum @ self.ctx.pose_to_isometry(pose)).astype(np.float32)  # transformUpdate, :649-653
+        ls = self.ctx.transform_to_end(less_sharp, pose)   # :312-313
+        lf = self.ctx.transform_to_end(less_flat, pose)
+        self.last_corner, self.last_surf = ls, lf            # :315-316
+        if len(ls) > 10 and len(lf) > 100:                   # :321-324
+            self.tree_corner, self.tree_surf = ls, lf
+        return self.Tsum.copy()
+
+
+class LaserMapping:
+    def __init__(self, ctx, cube_dims=(121, 121, 11), filter_corner=1.0, filter_surf=1.0, map_filter_corner=1.0,
+                 map_filter_surf=1.0, map_filter=2.0):
+        # LaserMatcher.cpp:80-116 defaults
+        self.ctx = ctx
+        self.filter_corner, self.filter_surf = filter_corner, filter_surf
+        self.feature_map = FeatureMap(ctx, *cube_dims)
+        self.feature_map.setup_filter_size(map_filter_corner, map_filter_surf, map_filter)
+        self.opts = ctx.default_opts()
+        self.opts.delta_t_abort = 0.1   # _scan_match.setConvergeThreshold(0.1, 0.1), :94
+        self.opts.delta_r_abort = 0.1
+        self.opts.use_score = 0         # setUseCore(false), :95
+        self.lidar_odom_last = np.eye(4, dtype=np.float32)    # _lidarOdomLast
+        self.lidar_mapped_last = np.eye(4, dtype=np.float32)  # _lidarMappedLast
+        self.lidar_mapped_new = np.eye(4, dtype=np.float32)   # _lidarMappedNew
+        self.last_stats = None
+
+    def _associate(self, l_old, l_new, w_old):
+        import ctypes as C
+        from .capi import c_float_p
+        out = np.zeros(16, np.float32)
+        a, b, c = (np.ascontiguousarray(m, np.float32).reshape(16) for m in (l_old, l_new, w_old))
+        fp = lambda x: x.ctypes.data_as(c_float_p)
+        self.ctx.lib.lslam_transform_associate(fp(a), fp(b), fp(c), fp(out))
+        return out.reshape(4, 4)
+
+    def process(self, corner_last, surf_last, lidar_odom_new):
+        """The odometry node's last corner / surf clouds (sweep-end frame) and its _Tsum -> the sweep's
+        pose in the map (4x4)."""
+        lidar_odom_new = np.ascontiguousarray(lidar_odom_new, np.float32).reshape(4, 4)
+        # transformMerge, :333-340
+        self.lidar_mapped_new = self._associate(self.lidar_odom_last, lidar_odom_new, self.lidar_mapped_last)
+        odom_merged = lidar_odom_new
+        # prepareFeatureFrame, :289-301
+        corner_ds = voxel_grid(self.ctx, corner_last, self.filter_corner)
+        surf_ds = voxel_grid(self.ctx, surf_last, self.filter_surf)
+        # prepareFeatureSurround, :303-325
+        self.feature_map.update(self.lidar_mapped_new[:3, 3])
+        nc, ns = self.feature_map.surround_counts()
+        # optimizeTransform, :327-331 (return value ignored; pose written back unless "too few ref")
+        if nc or ns:
+            self.feature_map.surround_to_map()
+            pose = self.ctx.isometry_to_pose(self.lidar_mapped_new)
+            status, pose, st = self.ctx.scanmatch_scan(corner_ds, surf_ds, pose, self.opts)
+            self.last_stats = st
+            if int(status) != 1:  # LSLAM_TOO_FEW_REF leaves the pose untouched (ScanMatch.cpp:57-61)
+                self.lidar_mapped_new = self.ctx.pose_to_isometry(pose)
+        # transformUpdate, :342-347
+        self.lidar_mapped_last = self.lidar_mapped_new.copy()
+        self.lidar_odom_last = odom_merged.copy()
+        # featureMapUpdate, :349-354
+        self.feature_map.add_feature_cloud(corner_ds, surf_ds, self.lidar_mapped_new)
+        return self.lidar_mapped_new.copy()

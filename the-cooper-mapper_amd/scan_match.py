@@ -191,6 +191,15 @@ class Context:
         self._check(rc)
         return Status(rc), p, st
 
+    def transform_to_end(self, cloud, pose):
+        """LaserOdometry::transformToEnd (LaserOdometry.cpp:156-168) -> new (n, 4) cloud."""
+        a = np.array(cloud, dtype=np.float32, order="C")
+        if a.ndim != 2 or a.shape[1] not in (4, 8):
+            raise ValueError("cloud must be (n, 4) {x,y,z,intensity} or (n, 8) PointXYZI")
+        p = np.ascontiguousarray(pose, np.float32).reshape(6)
+        self._check(self.lib.lslam_transform_to_end(self.h, _vp(a), len(a), a.shape[1] * 4, _fp(p)))
+        return a
+
     # -- parity taps -------------------------------------------------------------
     def knn5(self, which_map, queries):
         q, sq = _cloud(queries)

@@ -1223,24 +1223,20 @@ int lslam_odometry_match(lslam_ctx *ctx, const void *last_corner, size_t n_lc, c
   pack4(sharp, n_sharp, q);
   pack4(flat, n_flat, qf);
   q.insert(q.end(), qf.begin(), qf.end());
-  // the map slot of the context holds the two kd-trees (host builder: the clouds are small)
-  ctx->have_map = false;
-  ctx->cube_mode = false;
-  ctx->prev_valid = false;
-  HostTree hc, hs;
-  build_kdtree_host(reinterpret_cast<const float *>(lc.data()), n_lc, 4, hc);
-  build_kdtree_host(reinterpret_cast<const float *>(ls.data()), n_ls, 4, hs);
-  if (hc.depth > KD_STACK_LDS + 1 || hs.depth > KD_STACK_LDS + 1) {
+  // the map slot of the context holds the two kd-trees of the last clouds (device build, host
+  // builder as its fallback -- the same path as lslam_map_set)
+  rc = map_set_impl(ctx, lc.data(), n_lc, ls.data(), n_ls, sizeof(float4), nullptr, nullptr);
+  if (rc) return rc;
+  ctx->have_map = false;  // these trees belong to this call, not to a resident map
+  if (ctx->tc.depth > KD_STACK_LDS + 1 || ctx->ts.depth > KD_STACK_LDS + 1) {
     set_err("kd-tree deeper than %d", KD_STACK_LDS + 1);
     return LSLAM_ERR_TREE_DEPTH;
   }
-  rc = upload_tree(ctx, ctx->tc, hc, lc);
-  if (rc) return rc;
-  rc = upload_tree(ctx, ctx->ts, hs, ls);
-  if (rc) return rc;
   const size_t nq = q.size();
   DevBuf<float4> d_oc, d_os, d_q;
   DevBuf<int32_t> d_ind;
+  DevBuf<float4> d_sel;
+  HIP_TRY(d_sel.reserve(nq + 1));
   HIP_TRY(d_oc.reserve(n_lc + 1));
   HIP_TRY(d_os.reserve(n_ls + 1));
   HIP_TRY(d_q.reserve(nq + 1));
@@ -1262,6 +1258,8 @@ int lslam_odometry_match(lslam_ctx *ctx, const void *last_corner, size_t n_lc, c
   oa.nb_sharp = (int32_t)((n_sharp + 255) / 256);
   oa.nb_total = oa.nb_sharp + (int32_t)((n_flat + 255) / 256);
   oa.ind = d_ind.p;
+  oa.sel = d_sel.p;
+  oa.mode = 0;
   oa.state = ctx->d_state;
   HIP_TRY(ctx->partials.reserve((size_t)(oa.nb_total ? oa.nb_total : 1) * NCOL));
   oa.partials = ctx->partials.p;
@@ -1285,14 +1283,28 @@ int lslam_odometry_match(lslam_ctx *ctx, const void *last_corner, size_t n_lc, c
   so.too_few_continue = 1;
   so.nan_reset = 1;
   HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+  static const bool inline_search = std::getenv("LSLAM_ODOM_INLINE_SEARCH") != nullptr;  // A/B switch
   for (int it = 0; it < max_it; ++it) {
+    // loop_iter advances by one per solve launch until the loop is done, so the host knows which
+    // launches refresh the correspondences (every fifth, :357,:423): nearest neighbour per lane, then
+    // the ring-window searches one wavefront per query, then the residual pass on the cached indices
+    if (inline_search) {
+      oa.mode = 0;
+    } else {
+      if (it % 5 == 0) {
+        oa.mode = 1;
+        HIP_TRY(launch_odom_sweep(oa, ctx->stream));
+        HIP_TRY(launch_odom_window(oa, ctx->stream));
+      }
+      oa.mode = 2;
+    }
     HIP_TRY(launch_odom_sweep(oa, ctx->stream));
     HIP_TRY(launch_solve(so, ctx->stream));
   }
   HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  d_oc.release(); d_os.release(); d_q.release(); d_ind.release();
+  d_oc.release(); d_os.release(); d_q.release(); d_ind.release(); d_sel.release();
   const GNState &g = *ctx->h_state;
   for (int i = 0; i < 6; ++i) pose[i] = g.pose[i];
   st.iterations = g.iter;

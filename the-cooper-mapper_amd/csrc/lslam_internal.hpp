@@ -118,10 +118,14 @@ struct OdomArgs {
   int32_t n_sharp, n_flat;
   int32_t nb_sharp, nb_total;   // blocks: [0,nb_sharp) sharp
   int32_t *ind;                 // [3][n_sharp+n_flat] cached correspondences (:357-408,:423-483)
+  float4 *sel;                  // [n_sharp+n_flat] de-skewed query of the last correspondence refresh
+  int32_t mode;                 // 0: search inline (one lane per query); 1: nearest neighbour only, store
+                                // it and the de-skewed query; 2: cached correspondences only
   const GNState *state;
   float *partials;
 };
 hipError_t launch_odom_sweep(const OdomArgs &a, hipStream_t s);
+hipError_t launch_odom_window(const OdomArgs &a, hipStream_t s);
 hipError_t launch_odom_to_end(float4 *pts, int n, const float *d_pose6, hipStream_t s);
 
 #ifndef LSLAM_SWEEP_BLOCK

@@ -853,7 +853,7 @@ __global__ __launch_bounds__(256, 2) void odom_sweep_kernel(OdomArgs a) {
     const float4 *org = is_flat ? a.os : a.oc;
     const int n_org = is_flat ? a.n_os : a.n_oc;
     int i1 = a.ind[qi], i2 = a.ind[nall + qi], i3 = a.ind[2 * nall + qi];
-    if (iter % 5 == 0) {  // :357 / :423
+    if (iter % 5 == 0 && a.mode != 2) {  // :357 / :423
       TreeView T = is_flat ? a.ts : a.tc;
       float d[5];
       int p[5];
@@ -868,7 +868,11 @@ __global__ __launch_bounds__(256, 2) void odom_sweep_kernel(OdomArgs a) {
       knn5_search<BLOCK, false, KD_STACK_LDS>(T, sel[0], sel[1], sel[2], d, p, stk);  // top-1 of the 5 == nearestKSearch(.,1)
 #endif
       i1 = -1; i2 = -1; i3 = -1;
-      if (d[0] < 25.0f) {
+      if (a.mode == 1) {  // the ring-window searches run in odom_window_kernel, one wavefront per query
+        if (d[0] < 25.0f) i1 = __float_as_int(T.pts[p[0]].w);
+        a.ind[qi] = i1;
+        a.sel[qi] = make_float4(sel[0], sel[1], sel[2], 0.0f);
+      } else if (d[0] < 25.0f) {
         i1 = __float_as_int(T.pts[p[0]].w);
         const int scan = (int)org[i1].w;
         float m2 = 25.0f, m3 = 25.0f;
@@ -897,9 +901,11 @@ __global__ __launch_bounds__(256, 2) void odom_sweep_kernel(OdomArgs a) {
           }
         }
       }
-      a.ind[qi] = i1;
-      a.ind[nall + qi] = i2;
-      a.ind[2 * nall + qi] = i3;
+      if (a.mode != 1) {
+        a.ind[qi] = i1;
+        a.ind[nall + qi] = i2;
+        a.ind[2 * nall + qi] = i3;
+      }
     }
     float coeff[4];
     bool ok = false;
@@ -917,6 +923,7 @@ __global__ __launch_bounds__(256, 2) void odom_sweep_kernel(OdomArgs a) {
       kept = 1.0f;
     }
   }
+  if (a.mode == 1) return;  // correspondence refresh only; the residual pass follows as its own launch
   float v[NCOL];
 #pragma unroll
   for (int i = 0; i < NCOL; ++i) v[i] = 0.0f;
@@ -943,6 +950,87 @@ __global__ __launch_bounds__(256, 2) void odom_sweep_kernel(OdomArgs a) {
     for (int w = 1; w < NWAVE; ++w) sacc += red[w][tid];
     a.partials[(size_t)lb * NCOL + tid] = sacc;
   }
+}
+
+// The ring-window searches of LaserOdometry::scanMatch (:366-403 sharp, :430-477 flat), one
+// WAVEFRONT per query instead of one lane: the reference walks forwards (to the query count, quirk
+// Q5) and backwards from the nearest neighbour until the ring id leaves scan +- 2.5, keeping the
+// first strictly smaller squared distance per category.  The wavefront takes the window 64 candidates
+// at a time; "first minimum in scan order" = minimum distance, lowest position on ties, compared
+// strictly with the running minimum -- the same choice.
+__global__ __launch_bounds__(64) void odom_window_kernel(OdomArgs a) {
+  if (a.state->done) return;
+  const int qi = blockIdx.x, lane = threadIdx.x;
+  const int nall = a.n_sharp + a.n_flat;
+  const bool is_flat = qi >= a.n_sharp;
+  const int nq = is_flat ? a.n_flat : a.n_sharp;
+  const float4 *org = is_flat ? a.os : a.oc;
+  const int n_org = is_flat ? a.n_os : a.n_oc;
+  const int i1 = a.ind[qi];
+  int i2 = -1, i3 = -1;
+  if (i1 >= 0) {
+    const float4 sq = a.sel[qi];
+    const float sel[3] = {sq.x, sq.y, sq.z};
+    const int scan = (int)org[i1].w;
+    float m2 = 25.0f, m3 = 25.0f;
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int dir = 0; dir < 2; ++dir) {
+      const int limit = dir == 0 ? min(nq, n_org) : 0;  // forward: j < limit; backward: j >= 0
+      for (int base = 0;; base += 64) {
+        const int j = dir == 0 ? i1 + 1 + base + lane : i1 - 1 - base - lane;
+        const bool valid = dir == 0 ? j < limit : j >= 0;
+        if (!__any(valid)) break;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) o = org[j];
+        const int ring = (int)o.w;
+        const bool brk = valid && (dir == 0 ? (double)ring > scan + 2.5 : (double)ring < scan - 2.5);
+        const unsigned long long mb = __ballot(brk);
+        const bool use = valid && (mb == 0 || (below & mb) == 0) && !brk;  // candidates before the first break
+        const float dd = use ? sq_diff3(o, sel) : 3.0e38f;
+        bool c2, c3;
+        if (!is_flat) {
+          c2 = use && (dir == 0 ? ring > scan : ring < scan);
+          c3 = false;
+        } else {
+          c2 = use && (dir == 0 ? ring <= scan : ring >= scan);
+          c3 = use && !c2;
+        }
+        // category 2
+        float dmin = c2 ? dd : 3.0e38f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, off, 64));
+        if (dmin < m2) {
+          const unsigned long long hit = __ballot(c2 && dd == dmin);
+          const int l0 = __ffsll((long long)hit) - 1;
+          m2 = dmin;
+          i2 = dir == 0 ? i1 + 1 + base + l0 : i1 - 1 - base - l0;
+        }
+        if (is_flat) {
+          float dmin3 = c3 ? dd : 3.0e38f;
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) dmin3 = fminf(dmin3, __shfl_xor(dmin3, off, 64));
+          if (dmin3 < m3) {
+            const unsigned long long hit = __ballot(c3 && dd == dmin3);
+            const int l0 = __ffsll((long long)hit) - 1;
+            m3 = dmin3;
+            i3 = dir == 0 ? i1 + 1 + base + l0 : i1 - 1 - base - l0;
+          }
+        }
+        if (mb != 0) break;
+      }
+    }
+  }
+  if (lane == 0) {
+    a.ind[nall + qi] = i2;
+    a.ind[2 * nall + qi] = i3;
+  }
+}
+
+hipError_t launch_odom_window(const OdomArgs &a, hipStream_t s) {
+  const int n = a.n_sharp + a.n_flat;
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(odom_window_kernel, dim3(n), dim3(64), 0, s, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_odom_sweep(const OdomArgs &a, hipStream_t s) {

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Whole per-sweep chain timing: raw sweep -> registration -> extraction -> odometry -> mapping."""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("the-cooper-mapper_amd")
+synth = importlib.import_module("the-cooper-mapper_amd.synth")
+rings = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+lo, hi = (-15.0, 15.0) if rings == 16 else (-24.9, 2.0)
+world = synth.World(half_extent=175.0)
+ctx = pkg.Context(0)
+odo = pkg.LaserOdometry(ctx)
+mapper = pkg.LaserMapping(ctx, cube_dims=(21, 21, 11))
+sr = pkg.scan_registration
+raws = []
+for k in range(8):
+    gt = (0.0, 0.0, 0.3 + 0.01 * k, 3.0 + 0.4 * k, -2.0 + 0.15 * k, synth.SENSOR_HEIGHT)
+    c, s, gtp, cloud, ranges = synth.make_scan(world, rings, 1800, gt_pose=gt, seed=300 + k, full=True)
+    ring = np.floor(cloud[:, 3]).astype(np.int64)
+    raws.append(cloud[np.lexsort((ring, -(cloud[:, 3] - ring)))])
+acc = {"register": 0.0, "extract": 0.0, "odometry": 0.0, "mapping": 0.0}
+n = 0
+for k, raw in enumerate(raws):
+    t0 = time.perf_counter(); reg, rr = sr.multiscan_register(ctx, raw, lo, hi, rings)
+    t1 = time.perf_counter(); f = sr.extract_features(ctx, reg, rr)
+    t2 = time.perf_counter(); T = odo.process(f["sharp"], f["less_sharp"], f["flat"], f["less_flat"])
+    t3 = time.perf_counter()
+    if T is not None:
+        M = mapper.process(odo.last_corner, odo.last_surf, T)
+    t4 = time.perf_counter()
+    if k >= 2:
+        for key, d in zip(acc, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+            acc[key] += d
+        n += 1
+print("%d rings, %d points/sweep: " % (rings, len(raws[0])) + ", ".join("%s %.2f ms" % (k, 1e3 * v / n) for k, v in acc.items()) +
+      " -> %.2f ms per sweep (odometry iterations %d)" % (1e3 * sum(acc.values()) / n, odo.last_stats.iterations))
+print("map pose", M[:3, 3])

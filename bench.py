@@ -183,6 +183,12 @@ def main():
             out["mapping_frame_vlp16"] = mapping_frame_leg(pkg, synth, ctx, pr, opts, np, not args.no_cpu_baseline, 16)
         except Exception as e:  # a secondary leg never takes the headline line down
             out["mapping_frame"] = {"error": repr(e)}
+    if rank == 0 and not args.no_mapping_frame:
+        try:
+            out["sweep_pipeline"] = {"vlp16": sweep_pipeline_leg(pkg, synth, ctx, 16, np),
+                                     "rings64": sweep_pipeline_leg(pkg, synth, ctx, 64, np)}
+        except Exception as e:
+            out["sweep_pipeline"] = {"error": repr(e)}
     if world > 1 or args.shard_points:
         try:
             shres = sharded_points_leg(pkg, synth, distmod, dist, rank, world, ctx, opts, torch, np, args)
@@ -422,6 +428,43 @@ def mapping_frame_leg(pkg, synth, ctx, pr, opts, np, with_cpu, rings=64):
         res["pose_diff_gpu_vs_cpu_m"] = float(np.abs(opose[3:] - pose_first[3:]).max())
     fm.close()
     return res
+
+
+def sweep_pipeline_leg(pkg, synth, ctx, rings, np):
+    """The whole per-sweep chain on the device, raw driver cloud in, map pose out:
+    MultiScanRegistration::process -> extractFeatures -> LaserOdometry::process ->
+    LaserMapping::process (the-cooper-mapper_amd/pipeline.py), milliseconds per stage."""
+    lo, hi = (-15.0, 15.0) if rings == 16 else (-24.9, 2.0)
+    world = synth.World(half_extent=175.0)
+    odo = pkg.LaserOdometry(ctx)
+    mapper = pkg.LaserMapping(ctx, cube_dims=(21, 21, 11))
+    sr = pkg.scan_registration
+    acc = {"register": 0.0, "extract": 0.0, "odometry": 0.0, "mapping": 0.0}
+    n = 0
+    for k in range(7):
+        gt = (0.0, 0.0, 0.3 + 0.01 * k, 3.0 + 0.4 * k, -2.0 + 0.15 * k, synth.SENSOR_HEIGHT)
+        _, _, _, cloud, _ = synth.make_scan(world, rings, 1800, gt_pose=gt, seed=300 + k, full=True)
+        ring = np.floor(cloud[:, 3]).astype(np.int64)
+        raw = cloud[np.lexsort((ring, -(cloud[:, 3] - ring)))]  # arrival order of a clockwise sweep
+        t0 = time.perf_counter()
+        reg, rr = sr.multiscan_register(ctx, raw, lo, hi, rings)
+        t1 = time.perf_counter()
+        f = sr.extract_features(ctx, reg, rr)
+        t2 = time.perf_counter()
+        T = odo.process(f["sharp"], f["less_sharp"], f["flat"], f["less_flat"])
+        t3 = time.perf_counter()
+        if T is not None:
+            M = mapper.process(odo.last_corner, odo.last_surf, T)
+        t4 = time.perf_counter()
+        if k >= 2:
+            for key, d in zip(acc, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                acc[key] += d
+            n += 1
+    mapper.feature_map.close()
+    ms = {k: 1e3 * v / n for k, v in acc.items()}
+    return {"rings": rings, "points_per_sweep": int(len(raw)), "ms": ms, "ms_per_sweep": sum(ms.values()),
+            "sweeps_per_s": 1e3 / sum(ms.values()), "sweeps_timed": n,
+            "travelled_m": float(np.linalg.norm(M[:3, 3]))}
 
 
 def cpu_baseline(pr, repeats, gpu_pose, np):

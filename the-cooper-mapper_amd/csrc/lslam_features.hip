@@ -579,14 +579,26 @@ int lslam_multiscan_register(lslam_ctx *ctx, const void *cloud, size_t n_points,
   float end_ori = -std::atan2(h[n_points - 1].y, h[n_points - 1].x) + 2 * float(M_PI);
   if (end_ori - start_ori > 3 * M_PI) end_ori -= 2 * M_PI;
   else if (end_ori - start_ori < M_PI) end_ori += 2 * M_PI;
-  char *blob = nullptr;
+  struct Cache { char *p = nullptr; size_t cap = 0; };
+  static std::map<int, Cache> caches;  // device scratch kept per device between sweeps
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  Cache &cache = caches[lslam::ctx_device(ctx)];
   const size_t np4 = n_points * sizeof(float4);
-  FX_TRY(hipMalloc((void **)&blob, 3 * np4 + 4 * n_points * 4 + 64));
+  const size_t bytes = 3 * np4 + 4 * n_points * 4 + 64;
+  if (bytes > cache.cap) {
+    if (cache.p) (void)hipFree(cache.p);
+    cache.p = nullptr;
+    cache.cap = 0;
+    FX_TRY(hipMalloc((void **)&cache.p, bytes + bytes / 4));
+    cache.cap = bytes + bytes / 4;
+  }
+  char *blob = cache.p;
   float4 *d_in = (float4 *)blob, *d_tmp = d_in + n_points, *d_out = d_tmp + n_points;
   int32_t *d_ring = (int32_t *)(d_out + n_points), *d_seg = d_ring + n_points;
   float *d_ori = (float *)(d_seg + n_points);
   int32_t *d_first = (int32_t *)(d_ori + n_points);
-  auto fail = [&](int code) { (void)hipFree(blob); return code; };
+  auto fail = [&](int code) { return code; };
   const int32_t big = INT32_MAX;
   FX_TRY2(hipMemcpyAsync(d_in, h.data(), np4, hipMemcpyHostToDevice, s));
   FX_TRY2(hipMemcpyAsync(d_first, &big, 4, hipMemcpyHostToDevice, s));
@@ -619,7 +631,6 @@ int lslam_multiscan_register(lslam_ctx *ctx, const void *cloud, size_t n_points,
     FX_TRY2(hipMemcpyAsync(seg.data(), d_seg, m * 4, hipMemcpyDeviceToHost, s));
     FX_TRY2(hipStreamSynchronize(s));
   }
-  (void)hipFree(blob);
   std::vector<size_t> count((size_t)n_rings, 0);
   for (size_t i = 0; i < m; ++i) count[(size_t)seg[i]]++;
   size_t total = 0;

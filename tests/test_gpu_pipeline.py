@@ -105,3 +105,24 @@ def test_registration_to_mapping_chain(pkg, ctx, oracle, synth, small_problem):
     # first sweep) has travelled that far
     assert abs(np.linalg.norm(M_g[:3, 3]) - np.hypot(1.6, 0.6)) < 0.1
     mapper.feature_map.close()
+
+
+def test_laser_mapping_default_grid(pkg, ctx, oracle, synth, small_problem):
+    """The mapping node's default cube grid (121 x 121 x 11 cubes of 50 m, LaserMatcher.cpp:107-109):
+    161 051 cubes on the device, same surround as the oracle after two frames."""
+    world = small_problem["world"]
+    mapper = pkg.LaserMapping(ctx)
+    ofm = oracle.feature_map(121, 121, 11)
+    ofm.setup_filter_size(1.0, 1.0, 2.0)
+    T = np.eye(4, dtype=np.float32)
+    for k in range(2):
+        c, s, gt = synth.make_scan(world, 16, 450, gt_pose=(0, 0, 0.3, 3.0 + k, -2.0, synth.SENSOR_HEIGHT), seed=40 + k)
+        M = mapper.process(c, s, T)  # identity odometry: the match has to find the metre of motion itself
+        cds, sds = oracle.voxel_grid(c, 1.0), oracle.voxel_grid(s, 1.0)
+        ofm.update(M[:3, 3])
+        ofm.add_feature_cloud(cds, sds, M)
+    gc, gs = mapper.feature_map.get_surround_feature()
+    oc, os_ = ofm.get_surround_feature()
+    assert mapper.feature_map.dims == (121, 121, 11) and len(gs) > 1000
+    assert np.array_equal(bits(gc), bits(oc)) and np.array_equal(bits(gs), bits(os_))
+    mapper.feature_map.close()

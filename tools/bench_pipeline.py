@@ -11,7 +11,8 @@ lo, hi = (-15.0, 15.0) if rings == 16 else (-24.9, 2.0)
 world = synth.World(half_extent=175.0)
 ctx = pkg.Context(0)
 odo = pkg.LaserOdometry(ctx)
-mapper = pkg.LaserMapping(ctx, cube_dims=(21, 21, 11))
+dims = tuple(int(v) for v in os.environ.get("DIMS", "21,21,11").split(","))
+mapper = pkg.LaserMapping(ctx, cube_dims=dims)
 sr = pkg.scan_registration
 raws = []
 for k in range(8):

@@ -8,7 +8,10 @@ import os
 
 
 def env_rank():
-    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+    """(rank, device index, world).  LSLAM_FORCE_DEVICE pins the device index (pre-flight runs of the
+    multi-rank code paths on a box with fewer GPUs than ranks, together with LSLAM_DIST_BACKEND=gloo)."""
+    dev = os.environ.get("LSLAM_FORCE_DEVICE")
+    return (int(os.environ.get("RANK", "0")), int(dev) if dev is not None else int(os.environ.get("LOCAL_RANK", "0")),
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
@@ -27,8 +30,11 @@ def init(backend=None, device=None):
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = os.environ.get("LSLAM_DIST_BACKEND", backend)
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
     kw = {}
     if backend == "nccl":
         torch.cuda.set_device(local_rank)

@@ -381,6 +381,45 @@ int lslam_scanmatch_run_sharded(lslam_ctx *ctx, float pose[6], const lslam_opts 
                                 lslam_allreduce_fn fn, void *user, double *xchg32,
                                 lslam_stats *stats);
 
+/* ---- joint LiDAR + stereo term (BASELINE configs[4]) ------------------
+ *
+ * The reference only announces this (README.md:51-71: ORB-SLAM2 on a ZED stereo camera, "planning
+ * to extend the LOAM module to integrate Lidar and Visual SLAM methods"): it holds no code for a
+ * visual term, so there is nothing to cite line by line and PARITY IS UNPINNED.  The
+ * arithmetic restated here (and in oracle/lslam_oracle.c) is the published one of ORB-SLAM2's
+ * pose-only stereo edge (g2o EdgeStereoSE3ProjectXYZOnlyPose as used by
+ * Optimizer::PoseOptimization): a landmark X_w (map frame) seen at (uL, v, uR) projects as
+ *   X_c = R_cl * (R^T (X_w - t)) + t_cl          (R, t: the Twist being optimised, sensor -> map)
+ *   uL' = fx x/z + cx,  v' = fy y/z + cy,  uR' = uL' - bf/z
+ * error e = (uL'-uL, v'-v, uR'-uR), chi2 = |e|^2 * inv_sigma2, Huber weight with
+ * delta = sqrt(7.815) (sqrt(5.991) for a monocular observation, uR < 0: two rows), optional
+ * outlier gate chi2 > delta^2.  Its rows, scaled by sqrt(weight * inv_sigma2 * w_huber), are added
+ * to the LOAM rows of ScanMatch.cpp:134-204 in the SAME 6x6 A^T A / A^T b of every Gauss-Newton
+ * iteration (Jacobian taken with respect to the same six Twist parameters), followed by the same
+ * solve / degeneracy / convergence steps (ScanMatch.cpp:206-260). */
+typedef struct {
+  float fx, fy, cx, cy;   /* rectified pinhole intrinsics */
+  float bf;               /* stereo baseline times fx (ORB-SLAM2's mbf) */
+  float T_cl[12];         /* camera-from-lidar rigid transform, row-major 3x4 [R_cl | t_cl] */
+  float weight;           /* lambda: scale of the stereo block against the LiDAR block */
+  float huber_stereo;     /* sqrt(7.815) */
+  float huber_mono;       /* sqrt(5.991) */
+  int32_t gate_outliers;  /* 1: skip observations whose chi2 exceeds delta^2 at the current pose */
+  float min_depth;        /* observations with camera z <= min_depth are skipped */
+} lslam_stereo_cam;
+void lslam_stereo_default_cam(lslam_stereo_cam *cam);
+/* Makes n observations resident on the context: landmarks_xyz[n][3] (map frame),
+ * obs[n][3] = (uL, v, uR; uR < 0: monocular), inv_sigma2[n] (NULL: all 1).  From then on
+ * lslam_scanmatch_run / _scan / _run_sharded of a SINGLE resident scan assemble the joint
+ * system (under _run_sharded each rank holds its own shard of the observations; the stereo sums
+ * travel in the same 32-double all-reduce).  n = 0 removes the term. */
+int lslam_stereo_set(lslam_ctx *ctx, const float *landmarks_xyz, const float *obs, const float *inv_sigma2,
+                     size_t n, const lslam_stereo_cam *cam);
+int lslam_stereo_clear(lslam_ctx *ctx);
+/* Parity tap: the stereo term alone at `pose`: sums32 = {21 upper-triangular A^T A, 6 A^T b,
+ * rows, 0, 0, 0, observations used} (fp64 reduction of the per-block fp32 partials). */
+int lslam_stereo_sums(lslam_ctx *ctx, const float pose[6], double sums32[32]);
+
 int lslam_pg_create(int device, int32_t n_vertices, const double *poses7, int32_t n_edges,
                     const int32_t *ij, const double *meas7, const double *info36,
                     int32_t fixed_vertex, lslam_pg **out);

@@ -1110,10 +1110,130 @@ int oracle_gn_step(const float AtA[36], const float Atb[6], int iter, float pose
   return (dR < delta_r_abort && dT < delta_t_abort);
 }
 
+/* ---- stereo reprojection rows (no reference code: PARITY UNPINNED; include/lslam_c.h states the
+ * arithmetic, ORB-SLAM2's pose-only stereo edge) ------------------------------------------- */
+static void stereo_dR(const float sc[6], float dRx[9], float dRy[9], float dRz[9]) {
+  /* derivatives of R = Rz(rz) Ry(ry) Rx(rx) (transform_utils.h:288-299) by rx, ry, rz */
+  const float srx = sc[0], crx = sc[1], sry = sc[2], cry = sc[3], srz = sc[4], crz = sc[5];
+  dRx[0] = 0.0f; dRx[1] = crz * sry * crx + srz * srx;  dRx[2] = srz * crx - crz * sry * srx;
+  dRx[3] = 0.0f; dRx[4] = srz * sry * crx - crz * srx;  dRx[5] = -(srz * sry * srx) - crz * crx;
+  dRx[6] = 0.0f; dRx[7] = cry * crx;                    dRx[8] = -(cry * srx);
+  dRy[0] = -(crz * sry); dRy[1] = crz * cry * srx; dRy[2] = crz * cry * crx;
+  dRy[3] = -(srz * sry); dRy[4] = srz * cry * srx; dRy[5] = srz * cry * crx;
+  dRy[6] = -cry;         dRy[7] = -(sry * srx);    dRy[8] = -(sry * crx);
+  dRz[0] = -(srz * cry); dRz[1] = -(srz * sry * srx) - crz * crx; dRz[2] = crz * srx - srz * sry * crx;
+  dRz[3] = crz * cry;    dRz[4] = crz * sry * srx - srz * crx;    dRz[5] = crz * sry * crx + srz * srx;
+  dRz[6] = 0.0f; dRz[7] = 0.0f; dRz[8] = 0.0f;
+}
+
+static void mat3T_vec(const float M[9], const float d[3], float out[3]) { /* M^T d */
+  out[0] = M[0] * d[0] + M[3] * d[1] + M[6] * d[2];
+  out[1] = M[1] * d[0] + M[4] * d[1] + M[7] * d[2];
+  out[2] = M[2] * d[0] + M[5] * d[1] + M[8] * d[2];
+}
+
+/* One observation: rows[3][7] = scaled [J | b]; returns the number of rows (0, 2 or 3). */
+static int stereo_rows(const oracle_stereo_cam *c, const float R[9], const float t[3], const float dRx[9],
+                       const float dRy[9], const float dRz[9], const float Xw[3], const float ob[3],
+                       float inv_sigma2, float rows[3][7]) {
+  memset(rows, 0, sizeof(float) * 21);
+  const float d[3] = {Xw[0] - t[0], Xw[1] - t[1], Xw[2] - t[2]};
+  float p[3], G[6][3]; /* G[k] = d p / d theta_k (lidar frame) */
+  mat3T_vec(R, d, p);
+  mat3T_vec(dRx, d, G[0]);
+  mat3T_vec(dRy, d, G[1]);
+  mat3T_vec(dRz, d, G[2]);
+  for (int k = 0; k < 3; ++k) { /* d p / d t_k = -R^T e_k = -(row k of R) */
+    G[3 + k][0] = -R[3 * k + 0];
+    G[3 + k][1] = -R[3 * k + 1];
+    G[3 + k][2] = -R[3 * k + 2];
+  }
+  const float *T = c->T_cl;
+  const float x = T[0] * p[0] + T[1] * p[1] + T[2] * p[2] + T[3];
+  const float y = T[4] * p[0] + T[5] * p[1] + T[6] * p[2] + T[7];
+  const float z = T[8] * p[0] + T[9] * p[1] + T[10] * p[2] + T[11];
+  if (!(z > c->min_depth)) return 0;
+  const int mono = ob[2] < 0.0f;
+  const float iz = 1.0f / z;
+  const float uL = c->fx * x * iz + c->cx, v = c->fy * y * iz + c->cy, uR = uL - c->bf * iz;
+  const float e0 = uL - ob[0], e1 = v - ob[1], e2 = mono ? 0.0f : uR - ob[2];
+  const float chi2 = (e0 * e0 + e1 * e1 + e2 * e2) * inv_sigma2;
+  const float delta = mono ? c->huber_mono : c->huber_stereo;
+  if (c->gate_outliers && chi2 > delta * delta) return 0;
+  const float rchi = sqrtf(chi2);
+  const float wh = rchi <= delta ? 1.0f : delta / rchi;
+  const float s = sqrtf(c->weight * inv_sigma2 * wh);
+  for (int k = 0; k < 6; ++k) {
+    const float gx = T[0] * G[k][0] + T[1] * G[k][1] + T[2] * G[k][2];
+    const float gy = T[4] * G[k][0] + T[5] * G[k][1] + T[6] * G[k][2];
+    const float gz = T[8] * G[k][0] + T[9] * G[k][1] + T[10] * G[k][2];
+    const float ju = c->fx * iz * (gx - x * iz * gz);
+    const float jv = c->fy * iz * (gy - y * iz * gz);
+    rows[0][k] = s * ju;
+    rows[1][k] = s * jv;
+    rows[2][k] = mono ? 0.0f : s * (ju + c->bf * iz * iz * gz);
+  }
+  rows[0][6] = -(s * e0);
+  rows[1][6] = -(s * e1);
+  rows[2][6] = mono ? 0.0f : -(s * e2);
+  return mono ? 2 : 3;
+}
+
+static int stereo_accumulate(const oracle_stereo *s, const float pose[6], sweep_acc *acc, float *rows_out) {
+  float R[9], t[3], sc[6], dRx[9], dRy[9], dRz[9];
+  oracle_pose_to_Rt(pose, R, t);
+  pose_sincos(pose, sc);
+  stereo_dR(sc, dRx, dRy, dRz);
+  int used = 0;
+  for (size_t i = 0; i < s->n; ++i) {
+    float rows[3][7];
+    const int nr = stereo_rows(&s->cam, R, t, dRx, dRy, dRz, s->landmarks + 3 * i, s->obs + 3 * i,
+                               s->inv_sigma2 ? s->inv_sigma2[i] : 1.0f, rows);
+    if (rows_out) memcpy(rows_out + 21 * i, rows, sizeof(float) * 21);
+    for (int r = 0; r < nr; ++r) acc_row(acc, rows[r], rows[r][6]);
+    acc->n_rows += nr;
+    used += nr > 0;
+  }
+  return used;
+}
+
+void oracle_stereo_sums(const oracle_stereo *s, const float pose[6], float sums[29], float *rows_out) {
+  sweep_acc acc;
+  memset(&acc, 0, sizeof(acc));
+  const int used = stereo_accumulate(s, pose, &acc, rows_out);
+  int k = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 6; ++j) sums[k++] = acc.AtA[i * 6 + j];
+  for (int i = 0; i < 6; ++i) sums[k++] = acc.Atb[i];
+  sums[27] = (float)acc.n_rows;
+  sums[28] = (float)used;
+}
+
+static int scanmatch_impl(const float *map_c, size_t nc, const float *map_s, size_t ns,
+                          size_t map_stride, const float *qc, size_t nqc, const float *qs,
+                          size_t nqs, size_t q_stride, float pose_io[6], const oracle_opts *opts,
+                          oracle_stats *st, const oracle_stereo *stereo, int *n_stereo_used);
+
 int oracle_scanmatch_scan(const float *map_c, size_t nc, const float *map_s, size_t ns,
                           size_t map_stride, const float *qc, size_t nqc, const float *qs,
                           size_t nqs, size_t q_stride, float pose_io[6], const oracle_opts *opts,
                           oracle_stats *st) {
+  return scanmatch_impl(map_c, nc, map_s, ns, map_stride, qc, nqc, qs, nqs, q_stride, pose_io, opts, st, NULL,
+                        NULL);
+}
+
+int oracle_scanmatch_joint(const float *map_c, size_t nc, const float *map_s, size_t ns,
+                           size_t map_stride, const float *qc, size_t nqc, const float *qs,
+                           size_t nqs, size_t q_stride, const oracle_stereo *stereo, float pose_io[6],
+                           const oracle_opts *opts, oracle_stats *st, int *n_stereo_used) {
+  return scanmatch_impl(map_c, nc, map_s, ns, map_stride, qc, nqc, qs, nqs, q_stride, pose_io, opts, st,
+                        stereo, n_stereo_used);
+}
+
+static int scanmatch_impl(const float *map_c, size_t nc, const float *map_s, size_t ns,
+                          size_t map_stride, const float *qc, size_t nqc, const float *qs,
+                          size_t nqs, size_t q_stride, float pose_io[6], const oracle_opts *opts,
+                          oracle_stats *st, const oracle_stereo *stereo, int *n_stereo_used) {
   oracle_stats local;
   if (!st) st = &local;
   memset(st, 0, sizeof(*st));
@@ -1139,6 +1259,10 @@ int oracle_scanmatch_scan(const float *map_c, size_t nc, const float *map_s, siz
               &acc, NULL, NULL, NULL, NULL);
     st->t_sweep += now_s() - ts0;
     st->point_residuals += (long long)(nqc + nqs);
+    if (stereo && stereo->n) { /* the stereo rows join the same A^T A / A^T b */
+      const int used = stereo_accumulate(stereo, pose, &acc, NULL);
+      if (n_stereo_used) *n_stereo_used = used;
+    }
     st->n_line = acc.n_line;
     st->n_plane = acc.n_plane;
     st->n_rows = acc.n_rows;

@@ -189,6 +189,37 @@ int oracle_gn_step(const float AtA[36], const float Atb[6], int iter, float pose
                    float delta_r_abort, float delta_t_abort, float x_out[6],
                    float *delta_r, float *delta_t);
 
+/* ---------------- joint LiDAR + stereo term (BASELINE configs[4]) -------------------------
+ * PARITY UNPINNED: the reference holds no code for a visual term (README.md:51-71 announces it).
+ * Restated from the published arithmetic of ORB-SLAM2's pose-only stereo edge
+ * (EdgeStereoSE3ProjectXYZOnlyPose / Optimizer::PoseOptimization); see include/lslam_c.h. */
+typedef struct {
+  float fx, fy, cx, cy, bf;
+  float T_cl[12];
+  float weight, huber_stereo, huber_mono;
+  int32_t gate_outliers;
+  float min_depth;
+} oracle_stereo_cam;
+
+typedef struct {
+  const float *landmarks; /* [n][3] map frame */
+  const float *obs;       /* [n][3] uL, v, uR (uR < 0: monocular) */
+  const float *inv_sigma2; /* [n] or NULL */
+  size_t n;
+  oracle_stereo_cam cam;
+} oracle_stereo;
+
+/* The stereo rows at `pose`, accumulated sequentially in fp32 in observation order:
+ * sums[29] = {21 upper-tri AtA, 6 Atb, rows, observations used}.  rows_out (optional,
+ * [n][3][7]): the scaled rows [J | b] of every observation (zero when skipped). */
+void oracle_stereo_sums(const oracle_stereo *s, const float pose[6], float sums[29], float *rows_out);
+
+/* oracle_scanmatch_scan with the stereo rows added to every iteration's normal equations. */
+int oracle_scanmatch_joint(const float *map_c, size_t nc, const float *map_s, size_t ns,
+                           size_t map_stride, const float *qc, size_t nqc, const float *qs,
+                           size_t nqs, size_t q_stride, const oracle_stereo *stereo, float pose[6],
+                           const oracle_opts *opts, oracle_stats *stats, int *n_stereo_used);
+
 #ifdef __cplusplus
 }
 #endif

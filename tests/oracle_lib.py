@@ -44,6 +44,17 @@ class OracleRegParams(C.Structure):
                 ("surface_curvature_threshold", C.c_float), ("blind_threshold", C.c_float)]
 
 
+class OracleStereoCam(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float),
+                ("T_cl", C.c_float * 12), ("weight", C.c_float), ("huber_stereo", C.c_float),
+                ("huber_mono", C.c_float), ("gate_outliers", C.c_int32), ("min_depth", C.c_float)]
+
+
+class OracleStereo(C.Structure):
+    _fields_ = [("landmarks", C.POINTER(C.c_float)), ("obs", C.POINTER(C.c_float)),
+                ("inv_sigma2", C.POINTER(C.c_float)), ("n", C.c_size_t), ("cam", OracleStereoCam)]
+
+
 class OracleStats(C.Structure):
     _fields_ = [
         ("status", C.c_int),
@@ -132,6 +143,13 @@ class Oracle:
         L.oracle_scanmatch_scan.argtypes = [c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_size_t,
                                             c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_size_t,
                                             c_float_p, C.POINTER(OracleOpts), C.POINTER(OracleStats)]
+        L.oracle_stereo_sums.restype = None
+        L.oracle_stereo_sums.argtypes = [C.POINTER(OracleStereo), c_float_p, c_float_p, c_float_p]
+        L.oracle_scanmatch_joint.restype = C.c_int
+        L.oracle_scanmatch_joint.argtypes = [c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_size_t,
+                                             c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_size_t,
+                                             C.POINTER(OracleStereo), c_float_p, C.POINTER(OracleOpts),
+                                             C.POINTER(OracleStats), C.POINTER(C.c_int)]
         L.oracle_scanmatch_cubes.restype = C.c_int
         L.oracle_scanmatch_cubes.argtypes = [c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_size_t,
                                              C.POINTER(OracleCubeGrid), c_float_p, C.c_size_t, c_float_p,
@@ -349,6 +367,42 @@ class Oracle:
                                             _fp(qc), len(qc), _fp(qs), len(qs), sq, _fp(pose),
                                             C.byref(opts), C.byref(st))
         return bool(ok), pose, st
+
+    # ---- stereo term of the joint system (parity unpinned: no reference code) --------------------
+    def _stereo(self, landmarks, obs, inv_sigma2, cam):
+        lm = np.ascontiguousarray(landmarks, np.float32).reshape(-1, 3)
+        ob = np.ascontiguousarray(obs, np.float32).reshape(-1, 3)
+        w = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32).reshape(len(lm))
+        oc = OracleStereoCam()
+        for f, _ in OracleStereoCam._fields_:  # same field names as lslam_stereo_cam
+            setattr(oc, f, getattr(cam, f))
+        s = OracleStereo(_fp(lm), _fp(ob), _fp(w) if w is not None else None, len(lm), oc)
+        s._keep = (lm, ob, w)
+        return s
+
+    def stereo_sums(self, landmarks, obs, inv_sigma2, cam, pose, want_rows=False):
+        s = self._stereo(landmarks, obs, inv_sigma2, cam)
+        pose = np.array(pose, np.float32)
+        sums = np.zeros(29, np.float32)
+        rows = np.zeros((s.n, 3, 7), np.float32) if want_rows else None
+        self.lib.oracle_stereo_sums(C.byref(s), _fp(pose), _fp(sums), _fp(rows) if want_rows else None)
+        return (sums, rows) if want_rows else sums
+
+    def scanmatch_joint(self, map_c, map_s, qc, qs, landmarks, obs, inv_sigma2, cam, pose, opts=None):
+        map_c, sm = as_cloud(map_c)
+        map_s, _ = as_cloud(map_s)
+        qc, sq = as_cloud(qc)
+        qs, _ = as_cloud(qs)
+        s = self._stereo(landmarks, obs, inv_sigma2, cam)
+        pose = np.array(pose, np.float32)
+        if opts is None:
+            opts = self.default_opts()
+        st = OracleStats()
+        used = C.c_int(0)
+        ok = self.lib.oracle_scanmatch_joint(_fp(map_c), len(map_c), _fp(map_s), len(map_s), sm,
+                                             _fp(qc), len(qc), _fp(qs), len(qs), sq, C.byref(s), _fp(pose),
+                                             C.byref(opts), C.byref(st), C.byref(used))
+        return bool(ok), pose, st, used.value
 
     def scanmatch_cubes(self, map_c, map_s, qc, qs, pose, cube_size, origin, dims):
         map_c, sm = as_cloud(map_c)

@@ -11,7 +11,7 @@ The directory name contains a hyphen, so import it with
 ``importlib.import_module("the-cooper-mapper_amd")`` (tests/conftest.py and
 ``__graft_entry__`` register it as ``cooper_mapper_amd`` in ``sys.modules``).
 """
-from .capi import (LslamError, LslamOpts, LslamStats, LslamMapInfo, Status, lib_path, load_library,
+from .capi import (LslamError, LslamOpts, LslamStats, LslamMapInfo, LslamStereoCam, Status, lib_path, load_library,
                    build_library)
 from .scan_match import Context, ScanMatch
 from .pose_graph import PoseGraph
@@ -21,5 +21,5 @@ from .loop_closure import KeyFrame, Loop, LoopDetector
 from .graph import Graph, KeyframeUpdater
 from .pipeline import LaserOdometry, LaserMapping
 
-__all__ = ["Context", "ScanMatch", "PoseGraph", "FeatureMap", "voxel_grid", "scan_registration", "KeyFrame", "Loop", "LoopDetector", "Graph", "KeyframeUpdater", "LaserOdometry", "LaserMapping", "LslamError", "LslamOpts", "LslamStats", "LslamMapInfo",
+__all__ = ["Context", "ScanMatch", "PoseGraph", "FeatureMap", "voxel_grid", "scan_registration", "KeyFrame", "Loop", "LoopDetector", "Graph", "KeyframeUpdater", "LaserOdometry", "LaserMapping", "LslamError", "LslamOpts", "LslamStats", "LslamMapInfo", "LslamStereoCam",
            "Status", "lib_path", "load_library", "build_library"]

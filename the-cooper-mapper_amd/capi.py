@@ -54,6 +54,13 @@ class LslamRegParams(C.Structure):
                 ("surface_curvature_threshold", C.c_float), ("blind_threshold", C.c_float), ("reserved", C.c_int32)]
 
 
+class LslamStereoCam(C.Structure):
+    """lslam_stereo_cam (include/lslam_c.h)."""
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float),
+                ("T_cl", C.c_float * 12), ("weight", C.c_float), ("huber_stereo", C.c_float),
+                ("huber_mono", C.c_float), ("gate_outliers", C.c_int32), ("min_depth", C.c_float)]
+
+
 class LslamStats(C.Structure):
     _fields_ = [
         ("status", C.c_int32),
@@ -124,6 +131,10 @@ SYMBOLS = {
     "lslam_scanmatch_run": (C.c_int, [C.c_void_p, c_float_p, C.POINTER(LslamOpts), C.POINTER(LslamStats)]),
     "lslam_scanmatch_run_sharded": (C.c_int, [C.c_void_p, c_float_p, C.POINTER(LslamOpts), ALLREDUCE_FN,
                                               C.c_void_p, C.c_void_p, C.POINTER(LslamStats)]),
+    "lslam_stereo_default_cam": (None, [C.POINTER(LslamStereoCam)]),
+    "lslam_stereo_set": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p, C.c_size_t, C.POINTER(LslamStereoCam)]),
+    "lslam_stereo_clear": (C.c_int, [C.c_void_p]),
+    "lslam_stereo_sums": (C.c_int, [C.c_void_p, c_float_p, c_double_p]),
     "lslam_scanmatch_scan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                        C.c_size_t, c_float_p, C.POINTER(LslamOpts), C.POINTER(LslamStats)]),
     "lslam_scanmatch_full": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
@@ -204,6 +215,23 @@ def build_library(force=False):
 _lib = None
 
 
+def _preload_torch_runtime():
+    """The PyTorch-ROCm wheel ships its own libamdhip64 / libhsa-runtime64 (same SONAMEs as /opt/rocm's).
+    A process gets whichever copy is loaded first: this library runs on either, torch only on its own
+    ("No HIP GPUs are available" otherwise).  So when torch is installed and not loaded yet, load it
+    before liblslam_hip.so -- harnesses (tests, bench.py) use both in one process.  A C/C++ host that
+    links liblslam_hip.so never sees this.  LSLAM_NO_TORCH_PRELOAD=1 skips it."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("LSLAM_NO_TORCH_PRELOAD"):
+        return
+    try:
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
+    except Exception:  # a broken torch install must not take the backend down
+        pass
+
+
 def load_library():
     """dlopen liblslam_hip.so and bind every declared symbol.  Raises if missing."""
     global _lib
@@ -214,6 +242,7 @@ def load_library():
         raise ImportError(
             "%s not found: build it with `make -C %s` (hipcc --offload-arch=gfx950). "
             "This backend has no CPU fallback." % (path, CSRC))
+    _preload_torch_runtime()
     lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -130,6 +130,12 @@ struct lslam_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> sweep_ev;
   int iter_hint = 4;  // size of the first batch of enqueued GN iterations
+  // stereo term of the joint system (lslam_stereo_set)
+  DevBuf<float4> st_lm, st_obs;
+  DevBuf<float> st_partials;
+  DevBuf<ProbBlocks> st_noblocks;  // {0, 0}: a problem with no LiDAR blocks (lslam_stereo_sums)
+  int32_t n_stereo = 0;
+  StereoCam st_cam{};
 };
 
 namespace {
@@ -986,6 +992,22 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
   so.min_rows = 50;        // ScanMatch.cpp:142
   so.too_few_continue = 0;
   so.nan_reset = 0;
+  // joint LiDAR + stereo system: the stereo blocks' records join the reduction of every iteration
+  StereoArgs sta{};
+  if (ctx->n_stereo > 0) {
+    if (n_scans != 1) {
+      set_err("the stereo term needs a single resident scan (%d resident)", n_scans);
+      return fail_all(LSLAM_ERR_INVALID);
+    }
+    sta.landmarks = ctx->st_lm.p;
+    sta.obs = ctx->st_obs.p;
+    sta.n = ctx->n_stereo;
+    sta.cam = ctx->st_cam;
+    sta.state = ctx->d_state;
+    sta.partials = ctx->st_partials.p;
+    so.partials2 = ctx->st_partials.p;
+    so.n_blocks2 = stereo_blocks(ctx->n_stereo);
+  }
 
   if (o.profile) {
     while ((int)ctx->sweep_ev.size() < 2 * max_it) {
@@ -1023,6 +1045,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
         HIP_TRY(launch_sweep(sa, o.jtj_mode, ctx->stream, ctx->sweep_ev[2 * it], ctx->sweep_ev[2 * it + 1]));
       else
         HIP_TRY(launch_sweep(sa, o.jtj_mode, ctx->stream));
+      HIP_TRY(launch_stereo(sta, ctx->stream));
       so.reduce_only = 1;
       so.ext_sums = nullptr;
       HIP_TRY(launch_solve(so, ctx->stream));
@@ -1053,6 +1076,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
                              ctx->sweep_ev[2 * it + 1]));
       else
         HIP_TRY(launch_sweep(sa, o.jtj_mode, ctx->stream));
+      HIP_TRY(launch_stereo(sta, ctx->stream));
       HIP_TRY(launch_solve(so, ctx->stream));
     }
     launched += batch;
@@ -1128,6 +1152,102 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
   return n_scans == 1 ? (stats ? stats[0].status : worst) : worst;
 }
 }  // namespace
+
+// ---- stereo term of the joint system (include/lslam_c.h; no reference code: parity unpinned) -----
+void lslam_stereo_default_cam(lslam_stereo_cam *c) {
+  if (!c) return;
+  std::memset(c, 0, sizeof(*c));
+  c->fx = c->fy = 700.0f;  // a ZED-class rectified pair at 1280x720 (README.md:53)
+  c->cx = 640.0f;
+  c->cy = 360.0f;
+  c->bf = 0.12f * 700.0f;
+  c->T_cl[0] = c->T_cl[5] = c->T_cl[10] = 1.0f;
+  c->weight = 1e-4f;
+  c->huber_stereo = 2.7955322f;  // sqrt(7.815)
+  c->huber_mono = 2.4476519f;    // sqrt(5.991)
+  c->gate_outliers = 0;
+  c->min_depth = 0.1f;
+}
+
+int lslam_stereo_clear(lslam_ctx *ctx) {
+  int rc = check_ctx(ctx);
+  if (rc) return rc;
+  ctx->n_stereo = 0;
+  return LSLAM_OK;
+}
+
+int lslam_stereo_set(lslam_ctx *ctx, const float *landmarks_xyz, const float *obs, const float *inv_sigma2,
+                     size_t n, const lslam_stereo_cam *cam) {
+  int rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (n == 0) return lslam_stereo_clear(ctx);
+  if (!landmarks_xyz || !obs || !cam || n >= (size_t)1 << 30) {
+    set_err("bad stereo arguments");
+    return LSLAM_ERR_INVALID;
+  }
+  if (!(cam->fx > 0.0f) || !(cam->fy > 0.0f) || !(cam->weight >= 0.0f) || !(cam->huber_stereo > 0.0f) ||
+      !(cam->huber_mono > 0.0f)) {
+    set_err("bad stereo camera (fx, fy, huber deltas must be positive, weight non-negative)");
+    return LSLAM_ERR_INVALID;
+  }
+  std::vector<float4> lm(n), ob(n);
+  for (size_t i = 0; i < n; ++i) {
+    lm[i] = make_float4(landmarks_xyz[3 * i], landmarks_xyz[3 * i + 1], landmarks_xyz[3 * i + 2],
+                        inv_sigma2 ? inv_sigma2[i] : 1.0f);
+    ob[i] = make_float4(obs[3 * i], obs[3 * i + 1], obs[3 * i + 2], 0.0f);
+  }
+  HIP_TRY(ctx->st_lm.reserve(n));
+  HIP_TRY(ctx->st_obs.reserve(n));
+  HIP_TRY(ctx->st_partials.reserve((size_t)stereo_blocks((int)n) * NCOL));
+  HIP_TRY(hipMemcpyAsync(ctx->st_lm.p, lm.data(), n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->st_obs.p, ob.data(), n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));  // lm, ob are locals
+  StereoCam &c = ctx->st_cam;
+  c.fx = cam->fx; c.fy = cam->fy; c.cx = cam->cx; c.cy = cam->cy; c.bf = cam->bf;
+  std::memcpy(c.T_cl, cam->T_cl, sizeof(c.T_cl));
+  c.weight = cam->weight;
+  c.huber_stereo = cam->huber_stereo;
+  c.huber_mono = cam->huber_mono;
+  c.gate_outliers = cam->gate_outliers;
+  c.min_depth = cam->min_depth;
+  ctx->n_stereo = (int32_t)n;
+  return LSLAM_OK;
+}
+
+int lslam_stereo_sums(lslam_ctx *ctx, const float pose[6], double sums32[32]) {
+  int rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (!pose || !sums32) { set_err("null argument"); return LSLAM_ERR_INVALID; }
+  if (ctx->n_stereo <= 0) { set_err("no stereo observations set"); return LSLAM_ERR_INVALID; }
+  rc = ensure_states(ctx, 1);
+  if (rc) return rc;
+  init_state(*ctx->h_state, pose);
+  HIP_TRY(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(GNState), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx->st_noblocks.reserve(1));
+  const ProbBlocks none{0, 0};
+  HIP_TRY(hipMemcpyAsync(ctx->st_noblocks.p, &none, sizeof(none), hipMemcpyHostToDevice, ctx->stream));
+  StereoArgs sta{};
+  sta.landmarks = ctx->st_lm.p;
+  sta.obs = ctx->st_obs.p;
+  sta.n = ctx->n_stereo;
+  sta.cam = ctx->st_cam;
+  sta.state = ctx->d_state;
+  sta.partials = ctx->st_partials.p;
+  HIP_TRY(launch_stereo(sta, ctx->stream));
+  SolveArgs so{};
+  so.states = ctx->d_state;
+  so.partials = ctx->st_partials.p;  // unused: the problem has no LiDAR blocks
+  so.probs = ctx->st_noblocks.p;
+  so.n_prob = 1;
+  so.reduce_only = 1;
+  so.partials2 = ctx->st_partials.p;
+  so.n_blocks2 = stereo_blocks(ctx->n_stereo);
+  HIP_TRY(launch_solve(so, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));  // `none` is a local too
+  for (int i = 0; i < NCOL; ++i) sums32[i] = ctx->h_state->sums[i];
+  return LSLAM_OK;
+}
 
 int lslam_scanmatch_run_batch(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_opts *opts,
                               lslam_stats *stats) {

@@ -18,6 +18,7 @@ enum : int {
   COL_LINE = 28,    // line_match_count   (corner blocks only)
   COL_PLANE = 29,   // plane_match_count  (surf blocks only)
   COL_SCORE = 30,   // sum exp(-|res|) over kept rows (ScanMatch.cpp:42-49)
+  COL_STEREO = 31,  // stereo observations used (joint LiDAR + stereo system; zero in LiDAR blocks)
   NCOL = 32
 };
 
@@ -101,6 +102,8 @@ struct SolveArgs {
   int32_t n_prob;
   int32_t reduce_only;  // 1: only reduce partials into state->sums (tap; first half of a sharded iteration)
   const double *ext_sums;  // non-null: [n_prob][32] sums already reduced (and summed over ranks); skip the reduction
+  const float *partials2;  // non-null (single scan only): block records of the stereo term, added after the LiDAR ones
+  int32_t n_blocks2;
   int32_t max_iterations;
   float delta_r_abort, delta_t_abort;
   float eig_thresh;  // 100 (ScanMatch.cpp:223); 10 in LaserOdometry.cpp:596
@@ -108,6 +111,25 @@ struct SolveArgs {
   int32_t too_few_continue;  // variant B: `continue` instead of `break` (LaserOdometry.cpp:501-503)
   int32_t nan_reset;         // variant B: LaserOdometry.cpp:622-634
 };
+
+// Stereo reprojection rows of the joint system (lslam_stereo.hip; include/lslam_c.h lslam_stereo_cam).
+struct StereoCam {
+  float fx, fy, cx, cy, bf;
+  float T_cl[12];
+  float weight, huber_stereo, huber_mono;
+  int32_t gate_outliers;
+  float min_depth;
+};
+struct StereoArgs {
+  const float4 *landmarks;  // {X, Y, Z, inv_sigma2}, map frame
+  const float4 *obs;        // {uL, v, uR (< 0: monocular), -}
+  int32_t n;
+  StereoCam cam;
+  const GNState *state;
+  float *partials;          // [stereo_blocks(n)][NCOL]
+};
+int stereo_blocks(int n);
+hipError_t launch_stereo(const StereoArgs &a, hipStream_t s);
 
 // Variant B (LaserOdometry::scanMatch): one launch = one iteration over sharp + flat points.
 struct OdomArgs {

@@ -669,6 +669,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(SolveArgs a) {
   #pragma unroll
       for (int u = 0; u < 32; ++u) s += (double)v[u];
     }
+    if (a.partials2)  // stereo blocks of the joint system: same pattern, after the LiDAR blocks
+      for (int b = grp; b < a.n_blocks2; b += SOLVE_GROUPS) s += (double)a.partials2[(size_t)b * NCOL + col];
     red[grp][col] = s;
     __syncthreads();
     if (tid < NCOL) {

@@ -153,6 +153,37 @@ class Context:
         self._check(rc)
         return Status(rc), p, st
 
+    # ---- joint LiDAR + stereo system (BASELINE configs[4]; include/lslam_c.h) ----------------
+    def default_stereo_cam(self):
+        from .capi import LslamStereoCam
+        cam = LslamStereoCam()
+        self.lib.lslam_stereo_default_cam(C.byref(cam))
+        return cam
+
+    def stereo_set(self, landmarks, obs, inv_sigma2=None, cam=None):
+        """lslam_stereo_set: landmarks (n,3) in the map frame, obs (n,3) = (uL, v, uR; uR < 0:
+        monocular), inv_sigma2 (n,) or None.  The scan matches of a single resident scan then solve
+        the joint system.  n = 0 removes the term."""
+        lm = np.ascontiguousarray(landmarks, np.float32).reshape(-1, 3)
+        ob = np.ascontiguousarray(obs, np.float32).reshape(-1, 3)
+        if len(lm) != len(ob):
+            raise ValueError("landmarks and observations differ in length")
+        w = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32).reshape(len(lm))
+        cam = cam if cam is not None else self.default_stereo_cam()
+        self._check(self.lib.lslam_stereo_set(self.h, _fp(lm), _fp(ob), _fp(w) if w is not None else None,
+                                              len(lm), C.byref(cam)))
+
+    def stereo_clear(self):
+        self._check(self.lib.lslam_stereo_clear(self.h))
+
+    def stereo_sums(self, pose):
+        """Parity tap: the 32 reduced sums of the stereo term alone at `pose`."""
+        from .capi import c_double_p
+        p = np.array(pose, dtype=np.float32).reshape(6)
+        out = np.zeros(32)
+        self._check(self.lib.lslam_stereo_sums(self.h, _fp(p), out.ctypes.data_as(c_double_p)))
+        return out
+
     def scanmatch_scan(self, corner, surf, pose, opts=None):
         c, sc = _cloud(corner)
         s, _ = _cloud(surf)

@@ -229,6 +229,50 @@ def make_problem(rings=64, azimuth_steps=1800, map_radius=None, world_half=175.0
 
 
 # ---------------------------------------------------------------------------
+# synthetic stereo observations (BASELINE config 5: joint LiDAR + stereo system)
+# ---------------------------------------------------------------------------
+# camera looks along the LiDAR's +x: x_c = -y_l, y_c = -z_l, z_c = x_l, mounted 10 cm above / 5 cm ahead
+T_CAM_LIDAR = np.array([[0.0, -1.0, 0.0, 0.0],
+                        [0.0, 0.0, -1.0, 0.10],
+                        [1.0, 0.0, 0.0, -0.05]])
+
+
+def stereo_project(points_map, pose, fx=700.0, fy=700.0, cx=640.0, cy=360.0, bf=84.0, T_cl=T_CAM_LIDAR):
+    """Map-frame points -> (uL, v, uR), camera depth; float64 (include/lslam_c.h conventions)."""
+    R, t = pose_to_Rt(np.asarray(pose, np.float64))
+    p = (np.asarray(points_map, np.float64)[:, :3] - t) @ R          # R^T (X - t)
+    Xc = p @ T_cl[:, :3].T + T_cl[:, 3]
+    z = Xc[:, 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        uL = fx * Xc[:, 0] / z + cx
+        v = fy * Xc[:, 1] / z + cy
+        uR = uL - bf / z
+    return np.stack([uL, v, uR], 1), z
+
+
+def make_stereo(points_map, gt_pose, n=2000, seed=5, sigma_px=0.5, mono_frac=0.1, outlier_frac=0.05,
+                width=1280, height=720, max_depth=60.0, **cam):
+    """Landmarks = map points in view of the camera at `gt_pose`; observations = their projections
+    + Gaussian pixel noise scaled by an ORB pyramid level (1.2^level), some without a right match
+    (uR = -1), some gross outliers.  -> landmarks (n,3) f32, obs (n,3) f32, inv_sigma2 (n,) f32."""
+    rng = np.random.default_rng(seed)
+    pts = np.asarray(points_map, np.float64)[:, :3]
+    uvr, z = stereo_project(pts, gt_pose, **cam)
+    ok = (z > 0.5) & (z < max_depth) & (uvr[:, 0] >= 0) & (uvr[:, 0] < width) & (uvr[:, 1] >= 0) & (uvr[:, 1] < height)
+    cand = np.flatnonzero(ok)
+    pick = cand[rng.permutation(len(cand))[:n]]
+    lm, ob = pts[pick], uvr[pick]
+    level = rng.integers(0, 8, len(pick))
+    scale = 1.2 ** level
+    ob = ob + rng.normal(0.0, sigma_px, ob.shape) * scale[:, None]
+    out = rng.random(len(pick)) < outlier_frac
+    ob[out, :2] += rng.uniform(-80.0, 80.0, (int(out.sum()), 2))
+    mono = rng.random(len(pick)) < mono_frac
+    ob[mono, 2] = -1.0
+    return lm.astype(np.float32), ob.astype(np.float32), (1.0 / scale ** 2).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------
 # synthetic pose graph (SURVEY.md section 8d, BASELINE config 4)
 # ---------------------------------------------------------------------------
 def _qmul(a, b):

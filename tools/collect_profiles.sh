@@ -6,7 +6,7 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="$root/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-pose-graph --no-single --no-mapping-frame"
+B="$root/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-pose-graph --no-single --no-mapping-frame --no-joint-stereo"
 timeout 900 python3 $root/bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o s -- python3 $root/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $out/${tag}_stats.log 2>&1
 cp $out/${tag}_stats/s_kernel_stats.csv $out/${tag}_kernel_stats.csv

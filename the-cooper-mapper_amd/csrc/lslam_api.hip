@@ -130,6 +130,10 @@ struct lslam_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> sweep_ev;
   int iter_hint = 4;  // size of the first batch of enqueued GN iterations
+  // variant B (lslam_odometry_match): clouds, correspondences (grow-only, reused across sweeps)
+  DevBuf<float4> od_oc, od_os, od_q, od_sel;
+  DevBuf<int32_t> od_ind;
+  int od_iter_hint = 6;
   // stereo term of the joint system (lslam_stereo_set)
   DevBuf<float4> st_lm, st_obs;
   DevBuf<float> st_partials;
@@ -1353,9 +1357,8 @@ int lslam_odometry_match(lslam_ctx *ctx, const void *last_corner, size_t n_lc, c
     return LSLAM_ERR_TREE_DEPTH;
   }
   const size_t nq = q.size();
-  DevBuf<float4> d_oc, d_os, d_q;
-  DevBuf<int32_t> d_ind;
-  DevBuf<float4> d_sel;
+  DevBuf<float4> &d_oc = ctx->od_oc, &d_os = ctx->od_os, &d_q = ctx->od_q, &d_sel = ctx->od_sel;
+  DevBuf<int32_t> &d_ind = ctx->od_ind;
   HIP_TRY(d_sel.reserve(nq + 1));
   HIP_TRY(d_oc.reserve(n_lc + 1));
   HIP_TRY(d_os.reserve(n_ls + 1));
@@ -1404,27 +1407,39 @@ int lslam_odometry_match(lslam_ctx *ctx, const void *last_corner, size_t n_lc, c
   so.nan_reset = 1;
   HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
   static const bool inline_search = std::getenv("LSLAM_ODOM_INLINE_SEARCH") != nullptr;  // A/B switch
-  for (int it = 0; it < max_it; ++it) {
-    // loop_iter advances by one per solve launch until the loop is done, so the host knows which
-    // launches refresh the correspondences (every fifth, :357,:423): nearest neighbour per lane, then
-    // the ring-window searches one wavefront per query, then the residual pass on the cached indices
-    if (inline_search) {
-      oa.mode = 0;
-    } else {
-      if (it % 5 == 0) {
-        oa.mode = 1;
-        HIP_TRY(launch_odom_sweep(oa, ctx->stream));
-        HIP_TRY(launch_odom_window(oa, ctx->stream));
+  // Like the scan-to-map loop: the first batch of iterations is sized from the previous sweep's count
+  // (+1 spare), then the host looks at the state and enqueues five more at a time -- launches after the
+  // loop has ended exit at once but still cost a few microseconds each (25 x 2 of them per sweep).
+  // loop_iter advances by one per solve launch until the loop is done, so the host knows which
+  // launches refresh the correspondences (every fifth, :357,:423): nearest neighbour per lane, then
+  // the ring-window searches one wavefront per query, then the residual pass on the cached indices
+  int launched = 0;
+  int batch = ctx->od_iter_hint < 1 ? 1 : ctx->od_iter_hint;
+  for (;;) {
+    if (batch > max_it - launched) batch = max_it - launched;
+    for (int b = 0; b < batch; ++b) {
+      const int it = launched + b;
+      if (inline_search) {
+        oa.mode = 0;
+      } else {
+        if (it % 5 == 0) {
+          oa.mode = 1;
+          HIP_TRY(launch_odom_sweep(oa, ctx->stream));
+          HIP_TRY(launch_odom_window(oa, ctx->stream));
+        }
+        oa.mode = 2;
       }
-      oa.mode = 2;
+      HIP_TRY(launch_odom_sweep(oa, ctx->stream));
+      HIP_TRY(launch_solve(so, ctx->stream));
     }
-    HIP_TRY(launch_odom_sweep(oa, ctx->stream));
-    HIP_TRY(launch_solve(so, ctx->stream));
+    launched += batch;
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_state->done || launched >= max_it) break;
+    batch = 5;
   }
-  HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  d_oc.release(); d_os.release(); d_q.release(); d_ind.release(); d_sel.release();
+  ctx->od_iter_hint = ctx->h_state->loop_iter + 1;
   const GNState &g = *ctx->h_state;
   for (int i = 0; i < 6; ++i) pose[i] = g.pose[i];
   st.iterations = g.iter;

@@ -87,6 +87,7 @@ struct BuildArgs {
   BuildCtl *ctl;
   int32_t *root_feat;  // split dimension of root t (a root's parent_word is -1 - t)
   int32_t n;
+  int32_t reg_nodes;   // 1: nodes of at most 64 points are finished in registers (phase B)
 };
 
 __device__ __forceinline__ float coord(const float4 &p, int d) { return d == 0 ? p.x : (d == 1 ? p.y : p.z); }
@@ -499,6 +500,11 @@ __global__ __launch_bounds__(64) void kd_build_small_kernel(BuildArgs A) {
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   int grp_next = 0, grp_end = 0;   // wave-uniform: pre-allocated node groups [grp_next, grp_end)
   int n_leaves = 0, max_depth = 0;
+  int reg_depth = 0;  // per lane: deepest leaf written by the register path
+  // The grid is sized for the largest list; the list is complete before this launch.  Wavefronts
+  // beyond its length leave without touching the shared counter: 4 096 atomics on one address are
+  // 100 us, the whole cost of this kernel for a small tree.
+  if ((int)blockIdx.x >= A.ctl->n_sub) return;
   for (;;) {
     if (lane == 0) sh_e = atomicAdd(&A.ctl->sub_next, 1);
     __syncthreads();
@@ -525,6 +531,171 @@ __global__ __launch_bounds__(64) void kd_build_small_kernel(BuildArgs A) {
       --sp;
       __syncthreads();
       const int a = it.a, n = it.b - it.a;
+      if (n <= 64 && A.reg_nodes) {
+        // ---- a node of at most 64 points and its whole subtree, in registers -----------------
+        // One point per lane.  The subtree is built a LEVEL at a time: the nodes of a level are
+        // disjoint lane ranges ("segments"), and every step of divideTree/middleSplit_/planeSplit
+        // is done for all of them at once -- segmented shuffle scans for the extents, ballots
+        // masked to the segment for the counts and for the ranks of the Hoare pairing, lane
+        // permutes for the swaps.  Same splits, same final order of the points as the
+        // node-at-a-time loop below (which costs ~3.5 us per node in dependent LDS round trips;
+        // three quarters of a subtree's nodes have fewer than 64 points).
+        int sa = 0, sb = n;  // my segment [sa, sb), in lanes
+        bool act = lane < n;
+        if (!act) { sa = lane; sb = lane + 1; }
+        const int li = a + (act ? lane : 0);
+        float px = sx[li], py = sy[li], pz = sz[li];
+        uint32_t pw = sw[li];
+        float lo0 = it.lo[0], lo1 = it.lo[1], lo2 = it.lo[2], hi0 = it.hi[0], hi1 = it.hi[1], hi2 = it.hi[2];
+        int slot = it.slot, heap = it.heap, pword = it.parent_word, depth = it.depth;
+        bool top = true;  // the segment is the popped node: its parent stored a reference already
+        const unsigned long long gt_mask = lane == 63 ? 0ull : (~0ull << (lane + 1));
+        while (__any(act)) {
+          const int ns = sb - sa;
+          // computeMinMax (:908-920): inclusive segmented scans, the segment's last lane has the result
+          float mnx = px, mny = py, mnz = pz, mxx = px, mxy = py, mxz = pz;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const float t0 = __shfl_up(mnx, off, 64), t1 = __shfl_up(mny, off, 64), t2 = __shfl_up(mnz, off, 64);
+            const float t3 = __shfl_up(mxx, off, 64), t4 = __shfl_up(mxy, off, 64), t5 = __shfl_up(mxz, off, 64);
+            if (lane - off >= sa) {
+              mnx = fminf(mnx, t0); mny = fminf(mny, t1); mnz = fminf(mnz, t2);
+              mxx = fmaxf(mxx, t3); mxy = fmaxf(mxy, t4); mxz = fmaxf(mxz, t5);
+            }
+          }
+          const int last = sb - 1;
+          const float en0 = __shfl(mnx, last, 64), en1 = __shfl(mny, last, 64), en2 = __shfl(mnz, last, 64);
+          const float ex0 = __shfl(mxx, last, 64), ex1 = __shfl(mxy, last, 64), ex2 = __shfl(mxz, last, 64);
+          // middleSplit_ (:982-1031)
+          const float EPS = 0.00001f;
+          const float sp0 = hi0 - lo0, sp1 = hi1 - lo1, sp2 = hi2 - lo2;
+          float max_span = sp0;
+          if (sp1 > max_span) max_span = sp1;
+          if (sp2 > max_span) max_span = sp2;
+          float max_spread = -1;
+          int feat = 0;
+          if (sp0 > (1 - EPS) * max_span) { const float spread = ex0 - en0; if (spread > max_spread) { feat = 0; max_spread = spread; } }
+          if (sp1 > (1 - EPS) * max_span) { const float spread = ex1 - en1; if (spread > max_spread) { feat = 1; max_spread = spread; } }
+          if (sp2 > (1 - EPS) * max_span) { const float spread = ex2 - en2; if (spread > max_spread) { feat = 2; max_spread = spread; } }
+          const float flo = feat == 0 ? lo0 : (feat == 1 ? lo1 : lo2);
+          const float fhi = feat == 0 ? hi0 : (feat == 1 ? hi1 : hi2);
+          const float fmn = feat == 0 ? en0 : (feat == 1 ? en1 : en2);
+          const float fmx = feat == 0 ? ex0 : (feat == 1 ? ex1 : ex2);
+          const float split_val = (flo + fhi) / 2;
+          const float cut = split_val < fmn ? fmn : (split_val > fmx ? fmx : split_val);
+          float x = feat == 0 ? px : (feat == 1 ? py : pz);
+          const unsigned long long segmask = (sb >= 64 ? ~0ull : ((1ull << sb) - 1)) & ~((1ull << sa) - 1);
+          const int lim1 = __popcll(__ballot(act && x < cut) & segmask);
+          const int lim2 = __popcll(__ballot(act && x <= cut) & segmask);
+          // planeSplit (:1043-1078): two Hoare passes; the k-th misplaced element of the left part
+          // (increasing index) changes places with the k-th misplaced of the right part (decreasing)
+#pragma unroll
+          for (int pass = 0; pass < 2; ++pass) {
+            const int pa = pass == 0 ? sa : sa + lim1, Lc = pass == 0 ? lim1 : lim2 - lim1;
+            const bool go = act && Lc > 0 && sb - pa - Lc > 0;
+            const bool below = pass == 0 ? (x < cut) : (x <= cut);
+            const bool misl = go && lane >= pa && lane < pa + Lc && !below;
+            const bool misr = go && lane >= pa + Lc && below;
+            const unsigned long long bl = __ballot(misl), br = __ballot(misr);
+            if ((bl | br) == 0) continue;  // wave-uniform
+            const int kl = __popcll(bl & segmask & lt_mask), kr = __popcll(br & segmask & gt_mask);
+            if (misl) ta[sa + kl] = (uint16_t)lane;
+            if (misr) tb[sa + kr] = (uint16_t)lane;
+            __syncthreads();
+            int partner = lane;
+            if (misl) partner = tb[sa + kl];
+            if (misr) partner = ta[sa + kr];
+            __syncthreads();
+            px = __shfl(px, partner, 64);
+            py = __shfl(py, partner, 64);
+            pz = __shfl(pz, partner, 64);
+            pw = (uint32_t)__shfl((int)pw, partner, 64);
+            x = feat == 0 ? px : (feat == 1 ? py : pz);
+          }
+          const int half = ns / 2;
+          const int index = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);  // :1024-1029
+          const int mid = sa + index;
+          // tight bounds of the halves along the split dimension (:966-971): max of the left
+          // child's lanes, min (= -max of the negated values) of the right child's
+          const bool left = lane < mid;
+          const int csa = left ? sa : mid;
+          float v = left ? x : -x;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const float t = __shfl_up(v, off, 64);
+            if (lane - off >= csa) v = fmaxf(v, t);
+          }
+          const float divlow = __shfl(v, mid - 1, 64), divhigh = -__shfl(v, last, 64);
+          // children: leaves (:936-951) or the segments of the next level
+          const int cntL = index, cntR = ns - index;
+          const bool leafL = cntL <= 10, leafR = cntR <= 10;
+          const bool leader = act && lane == sa;
+          const bool needL = leader && heap >= 3 && !leafL, needR = leader && heap >= 3 && !leafR;
+          const unsigned long long mL = __ballot(needL), mR = __ballot(needR);
+          const int total = __popcll(mL) + __popcll(mR);
+          if (total > grp_end - grp_next) {  // wave-uniform
+            const int take = total > 8 ? total : 8;
+            int g = 0;
+            if (lane == 0) g = atomicAdd(&A.ctl->next_group, take);
+            g = __shfl(g, 0, 64);
+            grp_next = g;
+            grp_end = g + take;
+          }
+          int gL = grp_next + __popcll(mL & lt_mask) + __popcll(mR & lt_mask);
+          int gR = gL + (needL ? 1 : 0);
+          gL = __shfl(gL, sa, 64);  // every lane of the segment takes its leader's numbers
+          gR = __shfl(gR, sa, 64);
+          grp_next += total;
+          int slotL, heapL, slotR, heapR;
+          if (heap < 3) {  // the children stay in this 8-slot group
+            heapL = 2 * heap + 1; slotL = slot - heap + heapL;
+            heapR = 2 * heap + 2; slotR = slot - heap + heapR;
+          } else {
+            heapL = 0; slotL = gL * 8;
+            heapR = 0; slotR = gR * 8;
+            if (!leafL && (gL + 1) * 8 > A.node_cap) { if (leader) A.ctl->overflow = 1; slotL = 0; }
+            if (!leafR && (gR + 1) * 8 > A.node_cap) { if (leader) A.ctl->overflow = 1; slotR = 0; }
+          }
+          if (leader) {
+            uint32_t *words = reinterpret_cast<uint32_t *>(A.nodes);
+            // my reference in the parent: the popped node's parent holds (slot << 2) already and gets
+            // the split dimension ORed in (as below); deeper levels write the whole word -- the parent
+            // (this wave, a level ago) left the words of its non-leaf children untouched
+            if (top) {
+              if (pword >= 0) atomicOr(reinterpret_cast<unsigned int *>(words) + pword, (unsigned int)feat);
+              else A.root_feat[-1 - pword] = feat;
+            } else {
+              words[pword] = ((uint32_t)slot << 2) | (uint32_t)feat;
+            }
+            float *fw = reinterpret_cast<float *>(words + (size_t)slot * 4);
+            fw[0] = divlow;
+            fw[1] = divhigh;
+            if (leafL) words[(size_t)slot * 4 + 2] = KD_LEAF | ((uint32_t)(L0 + a + sa) << 4) | (uint32_t)cntL;
+            if (leafR) words[(size_t)slot * 4 + 3] = KD_LEAF | ((uint32_t)(L0 + a + mid) << 4) | (uint32_t)cntR;
+            if (leafL || leafR) reg_depth = max(reg_depth, depth + 1);
+          }
+          n_leaves += __popcll(__ballot(leader && leafL)) + __popcll(__ballot(leader && leafR));
+          if (act) {
+            pword = slot * 4 + (left ? 2 : 3);
+            if (left) {
+              sb = mid;
+              if (feat == 0) hi0 = cut; else if (feat == 1) hi1 = cut; else hi2 = cut;
+              slot = slotL; heap = heapL;
+              if (leafL) act = false;
+            } else {
+              sa = mid;
+              if (feat == 0) lo0 = cut; else if (feat == 1) lo1 = cut; else lo2 = cut;
+              slot = slotR; heap = heapR;
+              if (leafR) act = false;
+            }
+            depth += 1;
+          }
+          top = false;
+        }
+        if (lane < n) { sx[a + lane] = px; sy[a + lane] = py; sz[a + lane] = pz; sw[a + lane] = pw; }
+        __syncthreads();
+        continue;
+      }
       // ---- computeMinMax (:908-920) ------------------------------------------------------
       float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
       for (int i = lane; i < n; i += 64) {
@@ -681,10 +852,13 @@ __global__ __launch_bounds__(64) void kd_build_small_kernel(BuildArgs A) {
     for (int i = lane; i < N; i += 64) A.pts[L0 + i] = make_float4(sx[i], sy[i], sz[i], __uint_as_float(sw[i]));
     __syncthreads();
   }
-  // n_leaves / max_depth were counted by every lane identically
+  // n_leaves / max_depth were counted by every lane identically, reg_depth per lane
+  int md = max(max_depth, reg_depth);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) md = max(md, __shfl_xor(md, o, 64));
   if (lane == 0) {
     if (n_leaves) atomicAdd(&A.ctl->n_leaves, n_leaves);
-    atomicMax(&A.ctl->max_depth, max_depth);
+    atomicMax(&A.ctl->max_depth, md);
   }
 }
 
@@ -1244,6 +1418,11 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
 }
 }  // namespace
 
+static int32_t reg_nodes_enabled() {
+  static const bool off = std::getenv("LSLAM_NO_REG_NODES") != nullptr;  // A/B switch
+  return off ? 0 : 1;
+}
+
 hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_t node_cap,
                                hipStream_t stream, TreeView *view, int *depth, size_t *n_leaves,
                                int *fallback) {
@@ -1296,6 +1475,7 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
   A.node_cap = node_cap & ~7;
   A.queue_cap = queue_cap;
   A.n = n;
+  A.reg_nodes = reg_nodes_enabled();
   void *blob = nullptr;
   A.sub_cap = sub_cap;
   const size_t sz_queue = (size_t)queue_cap * sizeof(BuildItem), sz_ready = (size_t)queue_cap * sizeof(int32_t),
@@ -1327,7 +1507,11 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
   const int32_t one = 1;
   const bool root_small = n <= LOCAL_MAX;
   static const bool no_levels = std::getenv("LSLAM_NO_LEVEL_BUILD") != nullptr;  // A/B switch
-  const bool root_huge = n > HUGE_MIN && !no_levels;
+  // Below ~50 k points the ~11 launches per level cost more host time than the persistent phase-A
+  // kernel (one workgroup per node, one launch) costs device time: 0.49 against 0.62 ms at 16 k
+  // points, equal at 64 k, 4.3 against 1.6 ms at 512 k (tools/tree_size_sweep.py).
+  constexpr int LEVELS_MIN_POINTS = 49152;
+  const bool root_huge = n > HUGE_MIN && n > LEVELS_MIN_POINTS && !no_levels;
   if (root_small) {  // the whole tree is one phase-B subtree
     ctl.q_tail_reserved = 0;
     ctl.q_pending = 0;
@@ -1351,9 +1535,11 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+  if (dbg && (e = hipStreamSynchronize(stream)) != hipSuccess) return e;  // only to split the timing below
   const double T2 = now();
-  if (!root_small) hipLaunchKernelGGL(kd_build_big_kernel, dim3(cus), dim3(TB_BIG), 0, stream, A);
+  // phase A has work only if something sits between LOCAL_MAX and HUGE_MIN, or the levels are off
+  if (!root_small && !(root_huge && HUGE_MIN == LOCAL_MAX))
+    hipLaunchKernelGGL(kd_build_big_kernel, dim3(cus), dim3(TB_BIG), 0, stream, A);
   hipLaunchKernelGGL(kd_build_small_kernel, dim3(cus * 16), dim3(TB_SMALL), 0, stream, A);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(&ctl, A.ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
@@ -1394,6 +1580,7 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   A.queue_cap = queue_cap;
   A.sub_cap = sub_cap;
   A.n = n_total;
+  A.reg_nodes = reg_nodes_enabled();
   const size_t sz_queue = (size_t)queue_cap * sizeof(BuildItem), sz_ready = (size_t)queue_cap * sizeof(int32_t),
                sz_tmp = (size_t)std::max(n_total, 1) * sizeof(int32_t), sz_ctl = 256, sz_sub = (size_t)sub_cap * sizeof(BuildItem),
                sz_rf = ((size_t)T * 4 + 15) & ~(size_t)15, sz_lr = ((size_t)T * 8 + 15) & ~(size_t)15, sz_bb = (size_t)T * 24;

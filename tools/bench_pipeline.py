@@ -37,3 +37,27 @@ for k, raw in enumerate(raws):
 print("%d rings, %d points/sweep: " % (rings, len(raws[0])) + ", ".join("%s %.2f ms" % (k, 1e3 * v / n) for k, v in acc.items()) +
       " -> %.2f ms per sweep (odometry iterations %d)" % (1e3 * sum(acc.values()) / n, odo.last_stats.iterations))
 print("map pose", M[:3, 3])
+if os.environ.get("DETAIL"):
+    # where the odometry stage's wall time goes: the match call (packing, kd-trees of the last clouds,
+    # the device loop) and the two transformToEnd calls
+    import types
+    tm = {"odometry_match": 0.0, "transform_to_end": 0.0, "loop_gpu_ms": 0.0}
+    om, te = ctx.odometry_match, ctx.transform_to_end
+
+    def om2(*a, **k):
+        t = time.perf_counter(); r = om(*a, **k); tm["odometry_match"] += time.perf_counter() - t
+        tm["loop_gpu_ms"] += r[2].gpu_ms_total * 1e-3
+        return r
+
+    def te2(*a, **k):
+        t = time.perf_counter(); r = te(*a, **k); tm["transform_to_end"] += time.perf_counter() - t
+        return r
+    ctx.odometry_match, ctx.transform_to_end = om2, te2
+    reps = 0
+    for k, raw in enumerate(raws[2:]):
+        reg, rr = sr.multiscan_register(ctx, raw, lo, hi, rings)
+        f = sr.extract_features(ctx, reg, rr)
+        odo.process(f["sharp"], f["less_sharp"], f["flat"], f["less_flat"])
+        reps += 1
+    print("odometry detail per sweep:", {k: round(1e3 * v / reps, 3) for k, v in tm.items()},
+          "targets", len(odo.tree_corner), len(odo.tree_surf), "queries", len(f["sharp"]), len(f["flat"]))

@@ -86,6 +86,28 @@ def _walk(nodes, root):
     return inner, leaves
 
 
+def _assert_tree_is_nanoflann_exact(ctx, oracle, pts):
+    pts = np.ascontiguousarray(pts, np.float32)
+    ctx.map_set(pts, pts)
+    info = ctx.map_info()
+    if not info.built_on_device:
+        pytest.skip("host tree build forced (LSLAM_HOST_TREE)")
+    tree = oracle.kdtree(pts)
+    nodes, dpts, root = _tree_dump(ctx, 1, len(pts))
+    assert np.array_equal(dpts[:, 3].view(np.int32), tree.vind())      # same permutation
+    assert np.array_equal(dpts[:, :3], pts[tree.vind()])
+    inner, leaves = _walk(nodes, root)
+    on = tree.nodes()
+    o_inner = [(int(a), lo, hi) for k, a, lo, hi in zip(on["kind"], on["a"], on["divlow"], on["divhigh"]) if k == 1]
+    o_leaves = [(int(a), int(b - a)) for k, a, b in zip(on["kind"], on["a"], on["b"]) if k == 0]
+    assert len(inner) == len(o_inner) and len(leaves) == len(o_leaves)
+    assert leaves == o_leaves
+    assert [i[0] for i in inner] == [i[0] for i in o_inner]
+    assert np.array_equal(np.array([i[1:] for i in inner], np.float32).view(np.int32),
+                          np.array([i[1:] for i in o_inner], np.float32).view(np.int32))
+    assert info.depth_surf == tree.max_depth()
+
+
 @pytest.mark.parametrize("kind", ["planar", "uniform", "lattice", "lattice_big", "duplicates", "big"])
 def test_device_tree_build_is_nanoflann_exact(ctx, oracle, synth, kind):
     """The GPU-built tree has nanoflann's split at every node and nanoflann's point order
@@ -112,25 +134,30 @@ def test_device_tree_build_is_nanoflann_exact(ctx, oracle, synth, kind):
     else:
         pr = synth.make_problem(rings=16, azimuth_steps=900, world_half=100.0)
         pts = pr["map_surf"][:, :3]
-    pts = np.ascontiguousarray(pts, np.float32)
-    ctx.map_set(pts, pts)
-    info = ctx.map_info()
-    if not info.built_on_device:
-        pytest.skip("host tree build forced (LSLAM_HOST_TREE)")
-    tree = oracle.kdtree(pts)
-    nodes, dpts, root = _tree_dump(ctx, 1, len(pts))
-    assert np.array_equal(dpts[:, 3].view(np.int32), tree.vind())      # same permutation
-    assert np.array_equal(dpts[:, :3], pts[tree.vind()])
-    inner, leaves = _walk(nodes, root)
-    on = tree.nodes()
-    o_inner = [(int(a), lo, hi) for k, a, lo, hi in zip(on["kind"], on["a"], on["divlow"], on["divhigh"]) if k == 1]
-    o_leaves = [(int(a), int(b - a)) for k, a, b in zip(on["kind"], on["a"], on["b"]) if k == 0]
-    assert len(inner) == len(o_inner) and len(leaves) == len(o_leaves)
-    assert leaves == o_leaves
-    assert [i[0] for i in inner] == [i[0] for i in o_inner]
-    assert np.array_equal(np.array([i[1:] for i in inner], np.float32).view(np.int32),
-                          np.array([i[1:] for i in o_inner], np.float32).view(np.int32))
-    assert info.depth_surf == tree.max_depth()
+    _assert_tree_is_nanoflann_exact(ctx, oracle, pts)
+
+
+def test_device_tree_build_small_and_degenerate_clouds(ctx, oracle):
+    """Sizes around the 10-point leaf, the 64-point register path and its hand-over from the LDS path,
+    with exact duplicates, all-equal clouds and points on a line (every '== cutval' branch of
+    planeSplit, roots that are themselves register nodes)."""
+    rng = np.random.default_rng(5)
+    for n in (11, 12, 20, 21, 22, 63, 64, 65, 127, 128, 129, 640, 1536, 1537, 3000):
+        for kind in ("random", "dups", "equal", "line"):
+            if kind == "random":
+                pts = rng.uniform(-3, 3, (n, 3))
+            elif kind == "dups":
+                pts = rng.uniform(-3, 3, (max(2, n // 5), 3))[rng.integers(0, max(2, n // 5), n)]
+            elif kind == "equal":
+                pts = np.tile(rng.uniform(-3, 3, (1, 3)), (n, 1))
+            else:
+                pts = np.zeros((n, 3))
+                # many ties along the only spread axis.  "+ 0.0" turns the -0.0 that np.round produces
+                # into +0.0: a node holding both zeros gets divlow/divhigh = -0.0 from the hardware's
+                # min/max (-0 < +0) where nanoflann's "if (v < min)" keeps whichever came first -- the
+                # two differ in the sign bit of a zero only, which no distance or comparison can see.
+                pts[:, 1] = np.round(rng.uniform(-3, 3, n), 1) + 0.0
+            _assert_tree_is_nanoflann_exact(ctx, oracle, pts)
 
 
 def test_knn5_pointxyzi_stride(ctx, oracle):

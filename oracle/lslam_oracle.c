@@ -924,6 +924,8 @@ static void pose_sincos(const float pose[6], float sc[6]) {
   sc[4] = sinf(pose[2]); sc[5] = cosf(pose[2]);
 }
 
+void oracle_pose_sincos(const float pose[6], float sc[6]) { pose_sincos(pose, sc); }
+
 typedef struct {
   /* sequential fp32 accumulators, rows in reference order */
   float AtA[36];

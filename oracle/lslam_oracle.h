@@ -97,6 +97,8 @@ int oracle_surf_coeff(const float plane[4], const float X[3], float coeff[4]);
 
 /* ScanMatch.cpp:185-203: Jacobian row (6) and rhs b for one matched point.
  * sc = {srx,crx,sry,cry,srz,crz}. */
+/* {srx, crx, sry, cry, srz, crz}: the values Angle caches (util/Angle.h:17-18) */
+void oracle_pose_sincos(const float pose[6], float sc[6]);
 void oracle_jacobian_row(const float sc[6], const float p[3], const float coeff[4],
                          float row[6], float *b);
 

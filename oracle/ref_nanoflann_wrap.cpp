@@ -13,8 +13,11 @@
 // tests/golden/knn_*.npz.
 #include "nanoflann.hpp"
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
+#include <utility>
+#include <vector>
 
 namespace {
 struct CloudAdaptor {  // mirrors nanoflann_pcl.h:86-93,189-210 PointCloud_Adaptor
@@ -54,6 +57,32 @@ int ref_kdtree_knn(void *h, const float *q, int k, int32_t *idx_out, float *d2_o
   rs.init(idx_out, d2_out);
   r->tree.findNeighbors(rs, q, nanoflann::SearchParams());
   return (int)rs.size();
+}
+// KdTreeFLANN::radiusSearch (nanoflann_pcl.h:164-186): RadiusResultSet(radius) -- `radius` is compared
+// with SQUARED distances --, SearchParams() (sorted = true), then std::sort by distance.
+int ref_kdtree_radius(void *h, const float *q, float radius, int32_t *idx_out, float *d2_out, int cap) {
+  RefIndex *r = static_cast<RefIndex *>(h);
+  std::vector<std::pair<int, float>> found;
+  found.reserve(128);
+  nanoflann::RadiusResultSet<float, int> rs(radius, found);
+  const nanoflann::SearchParams params;
+  r->tree.findNeighbors(rs, q, params);
+  const size_t n = found.size();  // everything the result set collected (see ref_kdtree_radius_nfound)
+  if (params.sorted) std::sort(found.begin(), found.end(), nanoflann::IndexDist_Sorter());
+  for (size_t i = 0; i < n && (int)i < cap; ++i) {
+    idx_out[i] = found[i].first;
+    d2_out[i] = found[i].second;
+  }
+  return (int)n;
+}
+// The count KdTreeFLANN::radiusSearch itself returns (nanoflann_pcl.h:173: `const size_t nFound =
+// _kdtree.findNeighbors(resultSet, ...)`), i.e. the value of findNeighbors converted to size_t.
+int ref_kdtree_radius_nfound(void *h, const float *q, float radius) {
+  RefIndex *r = static_cast<RefIndex *>(h);
+  std::vector<std::pair<int, float>> found;
+  nanoflann::RadiusResultSet<float, int> rs(radius, found);
+  const size_t nFound = r->tree.findNeighbors(rs, q, nanoflann::SearchParams());
+  return (int)nFound;
 }
 // batch helper so Python does not pay one ctypes call per query
 void ref_kdtree_knn_batch(void *h, const float *q, size_t nq, size_t q_stride, int k,

@@ -583,6 +583,24 @@ class RefNanoflann:
         except Exception:
             pass
 
+    def radius(self, q, radius, cap=4096):
+        """KdTreeFLANN::radiusSearch of the reference (radius against squared distances, sorted)."""
+        self.lib.ref_kdtree_radius.restype = C.c_int
+        self.lib.ref_kdtree_radius.argtypes = [C.c_void_p, c_float_p, C.c_float, c_int32_p, c_float_p, C.c_int]
+        q = np.ascontiguousarray(q, np.float32).reshape(-1)
+        idx = np.zeros(cap, np.int32)
+        d2 = np.zeros(cap, np.float32)
+        n = self.lib.ref_kdtree_radius(self.h, _fp(q), float(radius), _ip(idx), _fp(d2), cap)
+        assert n <= cap
+        return idx[:n], d2[:n]
+
+    def radius_as_wrapped(self, q, radius):
+        """nFound of nanoflann_pcl.h:173 (the bool findNeighbors returns, as a count)."""
+        self.lib.ref_kdtree_radius_nfound.restype = C.c_int
+        self.lib.ref_kdtree_radius_nfound.argtypes = [C.c_void_p, c_float_p, C.c_float]
+        q = np.ascontiguousarray(q, np.float32).reshape(-1)
+        return self.lib.ref_kdtree_radius_nfound(self.h, _fp(q), float(radius))
+
     def knn(self, q, k=5):
         q = np.ascontiguousarray(q, np.float32)
         idx = np.zeros((len(q), k), np.int32)

@@ -17,9 +17,13 @@ def test_candidate_gating_follows_the_reference(pkg):
     kfs += [_kf(pkg, 40.0 - 0.5 * i, 1.0, 40.0 + 2.0 * i, y=7.0 * i) for i in range(1, 40)]
     det.update_trajectory(kfs)
     new = _kf(pkg, 2.0, 1.0, 200.0, y=3.0)
+    det.single_result_quirk = False
     idx, d2 = det.radius_search(np.array([2.0, 0.0, 1.0], np.float32), 5.0)
     # "radius" 5.0 is compared with squared distances: only points within sqrt(5) m, y ignored
-    assert len(idx) > 0 and (d2 < 5.0).all() and np.all(np.diff(d2) >= 0)
+    assert len(idx) > 1 and (d2 < 5.0).all() and np.all(np.diff(d2) >= 0)
+    det.single_result_quirk = True  # the reference's wrapper hands back the nearest one only
+    idx1, d21 = det.radius_search(np.array([2.0, 0.0, 1.0], np.float32), 5.0)
+    assert len(idx1) == 1 and idx1[0] == idx[0]
     assert all(abs(kfs[i].estimate[0, 3] - 2.0) <= np.sqrt(5.0) + 1e-6 for i in idx)
     cand = det.find_nearest_candidates(kfs, new)
     # at most 6, all travelled >= 30 m before `new`, within 5 m of travel of the first candidate
@@ -133,3 +137,39 @@ def test_graph_closes_the_loop_end_to_end(pkg, ctx, synth, small_problem):
     err_est = np.linalg.norm(est - gt_xyz, axis=1)
     err_odo = np.linalg.norm(od_xyz - gt_xyz, axis=1)
     assert err_est[-1] < 0.6 * err_odo[-1] and err_est.mean() < err_odo.mean() and err_est.max() < 0.5
+
+
+def test_trajectory_radius_search_matches_reference_nanoflann(pkg):
+    """LoopDetector.radius_search against the reference's own KdTreeFLANN::radiusSearch
+    (oracle/_ref/libref_nanoflann.so, nanoflann_pcl.h:164-186): same indices in the same order, same
+    squared distances, on a looping trajectory flattened to y = 0 as loop_detector.hpp:86-96 does."""
+    from oracle_lib import RefNanoflann, have_ref
+    if not have_ref():
+        pytest.skip("oracle/_ref not built (reference absent)")
+    rng = np.random.default_rng(3)
+    s = np.linspace(0, 6 * np.pi, 900)
+    xz = np.stack([40 * np.cos(s) + rng.normal(0, 0.3, len(s)), 40 * np.sin(s) + rng.normal(0, 0.3, len(s))], 1)
+    kfs = [_kf(pkg, float(x), float(z), float(i), y=float(rng.normal(0, 2))) for i, (x, z) in enumerate(xz)]
+    det = pkg.LoopDetector()
+    det.update_trajectory(kfs)
+    ref = RefNanoflann(det._trajectory)  # x, 0, z, index: the cloud the reference builds its tree on
+    hits = 0
+    for k in range(0, len(kfs), 7):
+        q = det._trajectory[k, :3] + rng.normal(0, 0.5, 3).astype(np.float32)
+        q[1] = 0.0
+        for radius in (5.0, 1.0, 30.0):
+            # the search itself: every point within the radius (compared with squared distances), ascending
+            det.single_result_quirk = False
+            idx, d2 = det.radius_search(q, radius)
+            ridx, rd2 = ref.radius(q, radius)
+            assert np.array_equal(idx, ridx) and np.array_equal(d2.view(np.uint32), rd2.view(np.uint32))
+            hits += len(idx)
+            # what KdTreeFLANN::radiusSearch hands to its caller: one result (nFound is a bool)
+            det.single_result_quirk = True
+            idx1, d21 = det.radius_search(q, radius)
+            n_ref = ref.radius_as_wrapped(q, radius)
+            if len(ridx):
+                assert n_ref == 1 and np.array_equal(idx1, ridx[:1]) and np.array_equal(d21, rd2[:1])
+            else:
+                assert len(idx1) == 0  # the reference reports 1 and reads an empty vector here (UB)
+    assert hits > 1000

@@ -5,10 +5,19 @@ n3).  The arithmetic that matters -- the fine alignment -- runs on the device th
 :class:`ScanMatch`; the gating is a few comparisons per keyframe and stays on the host, as in the
 reference.
 
-Two things of the reference are restated as they are, not as they were probably meant:
+Three things of the reference are restated as they are, not as they were probably meant:
   * ``radiusSearch(pos, 5.0, ...)`` (loop_detector.hpp:124-126) hands 5.0 to nanoflann's
     RadiusResultSet, which compares SQUARED distances with it (util/nanoflann_pcl.h:166-186), so
     the search radius is sqrt(5) m and the ``>= estimated_distance_thresh`` break (:133) never fires;
+  * the same ``KdTreeFLANN::radiusSearch`` takes its result count from
+    ``_kdtree.findNeighbors(...)`` (nanoflann_pcl.h:173), which in the vendored nanoflann returns
+    ``result.full()`` -- a bool, always true for a RadiusResultSet (nanoflann.hpp:171,1304-1322) --
+    so it hands back exactly ONE result, the nearest trajectory point (after the sort, :175-176).
+    Checked against the reference's own nanoflann (tests/test_loop_closure.py).  When nothing lies
+    within the radius the reference still reports one result and reads element 0 of an empty
+    vector (undefined behaviour: in practice a stale entry of an earlier search); that is not
+    reproduced -- ``radius_search`` returns nothing then.  ``single_result_quirk = False`` gives
+    the search its documented meaning (all points within the radius, ascending);
   * the trajectory is flattened with ``pos.y = 0`` (:98,120).
 The coarse alignment (``corseMatching``, :232-255) is PCL's ``IterativeClosestPoint`` -- external,
 not under /root/reference, not restated: ``coarse_matcher`` is a hook
@@ -54,6 +63,7 @@ def transform_cloud(cloud, tf):
 class LoopDetector:
     def __init__(self, scan_match=None, coarse_matcher=None, device=0, ctx=None):
         # loop_detector.hpp:55-63
+        self.single_result_quirk = True  # nanoflann_pcl.h:173 (see the module docstring)
         self.estimated_distance_thresh = 25.0
         self.accum_distance_thresh = 30.0
         self.last_loop_interval_thresh = 3.0
@@ -108,6 +118,8 @@ class LoopDetector:
         d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
         idx = np.nonzero(d2 < np.float32(radius))[0]
         order = np.argsort(d2[idx], kind="stable")
+        if self.single_result_quirk:
+            order = order[:1]
         return idx[order], d2[idx][order]
 
     # ---- :108-164 ---------------------------------------------------------------------------------

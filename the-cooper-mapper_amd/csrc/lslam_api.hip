@@ -130,6 +130,9 @@ struct lslam_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> sweep_ev;
   int iter_hint = 4;  // size of the first batch of enqueued GN iterations
+  // pinned staging area for the scan clouds a caller hands over (packed here, copied from here)
+  float4 *h_stage = nullptr;
+  size_t h_stage_cap = 0;
   // variant B (lslam_odometry_match): clouds, correspondences (grow-only, reused across sweeps)
   DevBuf<float4> od_oc, od_os, od_q, od_sel;
   DevBuf<int32_t> od_ind;
@@ -356,6 +359,7 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   ctx->t_idx.release(); ctx->t_d2.release(); ctx->t_coeff.release(); ctx->t_flags.release();
   ctx->t_q.release(); ctx->t_small.release();
   if (ctx->d_state) (void)hipFree(ctx->d_state);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_state) (void)hipHostFree(ctx->h_state);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -856,13 +860,23 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
     return LSLAM_ERR_INVALID;
   }
   ctx->have_scan = false;
-  std::vector<float4> all;
-  all.reserve(total);
+  // the clouds are packed straight into pinned memory: one pass over the caller's points, and the
+  // H2D copy is a real asynchronous DMA instead of a staged pageable copy
+  if (total > ctx->h_stage_cap) {
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    ctx->h_stage = nullptr;
+    ctx->h_stage_cap = 0;
+    const size_t cap = total + total / 4 + 1024;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_stage), cap * sizeof(float4), hipHostMallocDefault));
+    ctx->h_stage_cap = cap;
+  }
+  float4 *all = ctx->h_stage;
+  size_t n_all = 0;
   ctx->h_blocks.clear();
   ctx->h_probs.assign((size_t)n_scans, ProbBlocks{0, 0});
   ctx->nqc.assign((size_t)n_scans, 0);
   ctx->nqs.assign((size_t)n_scans, 0);
-  std::vector<float4> c, s;
+  std::vector<float4> tmp;
   // LSLAM_NO_MORTON: caller order (profiling A/B); LSLAM_HOST_MORTON: order on the host (A/B, and the
   // definition the device ordering is tested against)
   static const bool no_morton = std::getenv("LSLAM_NO_MORTON") != nullptr;
@@ -871,37 +885,42 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
   std::vector<int32_t> seg_off;
   int32_t out_base = 0;
   for (int32_t p = 0; p < n_scans; ++p) {
-    pack_cloud(corner[p], n_corner[p], stride_bytes, c);
-    pack_cloud(surf[p], n_surf[p], stride_bytes, s);
-    if (host_morton && !no_morton) {
-      morton_order(c);
-      morton_order(s);
-    } else {
-      for (size_t i = 0; i < c.size(); ++i) c[i].w = __builtin_bit_cast(float, (uint32_t)i);
-      for (size_t i = 0; i < s.size(); ++i) s[i].w = __builtin_bit_cast(float, (uint32_t)i);
-    }
     ctx->h_probs[(size_t)p].first_block = (int32_t)ctx->h_blocks.size();
     for (int type = 0; type < 2; ++type) {
-      const std::vector<float4> &v = type ? s : c;
-      const int32_t base = (int32_t)all.size();
+      const void *src = type ? surf[p] : corner[p];
+      const size_t cnt = type ? n_surf[p] : n_corner[p];
+      const int32_t base = (int32_t)n_all;
+      float4 *dst = all + n_all;
+      if (host_morton && !no_morton) {
+        pack_cloud(src, cnt, stride_bytes, tmp);
+        morton_order(tmp);
+        std::copy(tmp.begin(), tmp.end(), dst);
+      } else {
+        const char *sp = static_cast<const char *>(src);
+        for (size_t i = 0; i < cnt; ++i) {  // {x, y, z, bitcast(original index)}
+          float xyz[3];
+          std::memcpy(xyz, sp + i * stride_bytes, sizeof(xyz));
+          dst[i] = make_float4(xyz[0], xyz[1], xyz[2], __builtin_bit_cast(float, (uint32_t)i));
+        }
+      }
       seg_off.push_back(base);
-      for (size_t off = 0; off < v.size(); off += SWEEP_BLOCK) {
+      for (size_t off = 0; off < cnt; off += SWEEP_BLOCK) {
         BlockDesc bd{};
         bd.prob = p;
         bd.first = base + (int32_t)off;
-        bd.count = (int32_t)std::min<size_t>(SWEEP_BLOCK, v.size() - off);
+        bd.count = (int32_t)std::min<size_t>(SWEEP_BLOCK, cnt - off);
         bd.is_surf = type;
-        bd.out_base = out_base + (type ? (int32_t)c.size() : 0);
+        bd.out_base = out_base + (type ? (int32_t)n_corner[p] : 0);
         ctx->h_blocks.push_back(bd);
       }
-      all.insert(all.end(), v.begin(), v.end());
+      n_all += cnt;
     }
     ctx->h_probs[(size_t)p].n_blocks = (int32_t)ctx->h_blocks.size() - ctx->h_probs[(size_t)p].first_block;
-    ctx->nqc[(size_t)p] = (int32_t)c.size();
-    ctx->nqs[(size_t)p] = (int32_t)s.size();
-    out_base += (int32_t)(c.size() + s.size());
+    ctx->nqc[(size_t)p] = (int32_t)n_corner[p];
+    ctx->nqs[(size_t)p] = (int32_t)n_surf[p];
+    out_base += (int32_t)(n_corner[p] + n_surf[p]);
   }
-  seg_off.push_back((int32_t)all.size());
+  seg_off.push_back((int32_t)n_all);
   const size_t nb = ctx->h_blocks.size();
   HIP_TRY(ctx->q.reserve(total ? total : 1));
   HIP_TRY(ctx->blocks.reserve(nb ? nb : 1));
@@ -913,11 +932,10 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
   if (rc) return rc;
   if (total && dev_morton) {
     if (!ctx->scanprep) ctx->scanprep = scanprep_create();
-    HIP_TRY(scanprep_order(ctx->scanprep, ctx->stream, all.data(), total, seg_off.data(), (int)seg_off.size() - 1,
+    HIP_TRY(scanprep_order(ctx->scanprep, ctx->stream, all, total, seg_off.data(), (int)seg_off.size() - 1,
                            ctx->q.p));
   } else if (total) {
-    HIP_TRY(hipMemcpyAsync(ctx->q.p, all.data(), total * sizeof(float4), hipMemcpyHostToDevice,
-                           ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->q.p, all, total * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
   }
   if (nb)
     HIP_TRY(hipMemcpyAsync(ctx->blocks.p, ctx->h_blocks.data(), nb * sizeof(BlockDesc),

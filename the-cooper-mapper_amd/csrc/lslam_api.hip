@@ -133,6 +133,9 @@ struct lslam_ctx {
   // pinned staging area for the scan clouds a caller hands over (packed here, copied from here)
   float4 *h_stage = nullptr;
   size_t h_stage_cap = 0;
+  // ... and for the two map clouds of lslam_map_set (one per tree: they are packed on two threads)
+  float4 *h_map_stage[2] = {nullptr, nullptr};
+  size_t h_map_cap[2] = {0, 0};
   // variant B (lslam_odometry_match): clouds, correspondences (grow-only, reused across sweeps)
   DevBuf<float4> od_oc, od_os, od_q, od_sel;
   DevBuf<int32_t> od_ind;
@@ -360,6 +363,8 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   ctx->t_q.release(); ctx->t_small.release();
   if (ctx->d_state) (void)hipFree(ctx->d_state);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  for (int k = 0; k < 2; ++k)
+    if (ctx->h_map_stage[k]) (void)hipHostFree(ctx->h_map_stage[k]);
   if (ctx->h_state) (void)hipHostFree(ctx->h_state);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -465,15 +470,9 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
   bool need_host = host_tree;
   if (!host_tree) {
     // ---- device build: upload {x,y,z,index}, build both trees in HBM --------------------
-    if (!from_dev) {
-      pack_cloud(corner, n_corner, stride_bytes, cc);
-      pack_cloud(surf, n_surf, stride_bytes, cs);
-      for (size_t i = 0; i < cc.size(); ++i) cc[i].w = __builtin_bit_cast(float, (uint32_t)i);
-      for (size_t i = 0; i < cs.size(); ++i) cs[i].w = __builtin_bit_cast(float, (uint32_t)i);
-    }
     t1 = now_ms();
     DevTree *trees[2] = {&ctx->tc, &ctx->ts};
-    const std::vector<float4> *clouds[2] = {&cc, &cs};
+    const void *host_src[2] = {corner, surf};
     const float4 *dev_src[2] = {dev_corner, dev_surf};
     const size_t counts[2] = {n_corner, n_surf};
     size_t *ncount[2] = {&nodes_c, &nodes_s};
@@ -497,10 +496,36 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
         const size_t mult[3] = {2, 8, 24};
         const size_t cap = ((mult[attempt] * n / 3 + 64) + 7) & ~(size_t)7;
         if ((errs[k] = dt.nodes.reserve(cap)) != hipSuccess) return;
-        if (n && from_dev)
+        if (n && from_dev) {
           errs[k] = hipMemcpyAsync(dt.pts.p, dev_src[k], n * sizeof(float4), hipMemcpyDeviceToDevice, st);
-        else if (n)
-          errs[k] = hipMemcpyAsync(dt.pts.p, clouds[k]->data(), n * sizeof(float4), hipMemcpyHostToDevice, st);
+        } else if (n && attempt > dt.cap_attempt) {
+          errs[k] = hipMemcpyAsync(dt.pts.p, ctx->h_map_stage[k], n * sizeof(float4), hipMemcpyHostToDevice, st);
+        } else if (n) {
+          // {x, y, z, bitcast(index)} packed straight into pinned memory, a chunk at a time, each
+          // chunk's DMA running while the next one is packed
+          if (n > ctx->h_map_cap[k]) {
+            if (ctx->h_map_stage[k]) (void)hipHostFree(ctx->h_map_stage[k]);
+            ctx->h_map_stage[k] = nullptr;
+            ctx->h_map_cap[k] = 0;
+            const size_t want = n + n / 4 + 1024;
+            if ((errs[k] = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_map_stage[k]), want * sizeof(float4),
+                                         hipHostMallocDefault)) != hipSuccess)
+              return;
+            ctx->h_map_cap[k] = want;
+          }
+          float4 *stage = ctx->h_map_stage[k];
+          const char *sp = static_cast<const char *>(host_src[k]);
+          constexpr size_t CHUNK = 1u << 17;
+          for (size_t off = 0; off < n && errs[k] == hipSuccess; off += CHUNK) {
+            const size_t end = std::min(n, off + CHUNK);
+            for (size_t i = off; i < end; ++i) {
+              float xyz[3];
+              std::memcpy(xyz, sp + i * stride_bytes, sizeof(xyz));
+              stage[i] = make_float4(xyz[0], xyz[1], xyz[2], __builtin_bit_cast(float, (uint32_t)i));
+            }
+            errs[k] = hipMemcpyAsync(dt.pts.p + off, stage + off, (end - off) * sizeof(float4), hipMemcpyHostToDevice, st);
+          }
+        }
         if (errs[k] != hipSuccess) return;
         errs[k] = build_kdtree_device(dt.pts.p, (int32_t)n, dt.nodes.p, (int32_t)cap, st, &dt.view, &dt.depth,
                                       &n_leaves, &fallback);

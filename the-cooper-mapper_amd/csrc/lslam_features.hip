@@ -445,8 +445,23 @@ int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, s
   if (n_points == 0) return LSLAM_OK;
   FX_TRY(hipSetDevice(lslam::ctx_device(ctx)));
   hipStream_t s = (hipStream_t)lslam_stream(ctx);
+  // device scratch and the pinned staging area of the input are kept per device between calls (a
+  // sweep arrives every 100 ms)
+  struct Cache { char *p = nullptr; size_t cap = 0; float4 *pin = nullptr; size_t pin_cap = 0; };
+  static std::map<int, Cache> caches;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  Cache &cache = caches[lslam::ctx_device(ctx)];
+  const size_t np4 = n_points * sizeof(float4);
+  if (n_points > cache.pin_cap) {
+    if (cache.pin) (void)hipHostFree(cache.pin);
+    cache.pin = nullptr;
+    cache.pin_cap = 0;
+    FX_TRY(hipHostMalloc((void **)&cache.pin, (n_points + n_points / 4) * sizeof(float4), hipHostMallocDefault));
+    cache.pin_cap = n_points + n_points / 4;
+  }
   // pack {x, y, z, intensity-to-copy} (toXYZI, util/pcl_util.h:30-37: the `curvature` field)
-  std::vector<float4> h(n_points);
+  float4 *h = cache.pin;
   const char *src = static_cast<const char *>(cloud);
   for (size_t i = 0; i < n_points; ++i) {
     float v[3], w;
@@ -454,13 +469,6 @@ int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, s
     std::memcpy(&w, src + i * stride_bytes + intensity_offset_bytes, 4);
     h[i] = make_float4(v[0], v[1], v[2], w);
   }
-  // device scratch is kept per device between calls (a sweep arrives every 100 ms)
-  struct Cache { char *p = nullptr; size_t cap = 0; };
-  static std::map<int, Cache> caches;
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lk(mu);
-  Cache &cache = caches[lslam::ctx_device(ctx)];
-  const size_t np4 = n_points * sizeof(float4);
   const size_t bytes = 5 * np4 + 2 * n_scans * 4 + 4 * n_scans * 4 + n_points * 4 + 2 * n_points + 4 * (n_scans + 1) * 4 +
                        2 * np4 + 2 * n_points * 4 + 256 + 16 * 16;
   if (bytes > cache.cap) {
@@ -484,7 +492,7 @@ int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, s
   int rc = LSLAM_OK;
   auto fail = [&](int code) { return code; };
 #define FX_TRY2(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { lslam::set_error(hipGetErrorString(_e)); return fail(LSLAM_ERR_HIP); } } while (0)
-  FX_TRY2(hipMemcpyAsync(d_pts, h.data(), np4, hipMemcpyHostToDevice, s));
+  FX_TRY2(hipMemcpyAsync(d_pts, h, np4, hipMemcpyHostToDevice, s));
   FX_TRY2(hipMemcpyAsync(d_ranges, scan_ranges, 2 * n_scans * 4, hipMemcpyHostToDevice, s));
   if (curvature_out) FX_TRY2(hipMemsetAsync(d_curv, 0, n_points * 4, s));
   if (picked_out) FX_TRY2(hipMemsetAsync(d_picked, 0, n_points, s));
@@ -567,7 +575,20 @@ int lslam_multiscan_register(lslam_ctx *ctx, const void *cloud, size_t n_points,
   if (n_points == 0) return LSLAM_OK;
   FX_TRY(hipSetDevice(lslam::ctx_device(ctx)));
   hipStream_t s = (hipStream_t)lslam_stream(ctx);
-  std::vector<float4> h(n_points);
+  struct Cache { char *p = nullptr; size_t cap = 0; float4 *pin = nullptr; size_t pin_cap = 0; };
+  static std::map<int, Cache> caches;  // device scratch + pinned input staging kept per device between sweeps
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  Cache &cache = caches[lslam::ctx_device(ctx)];
+  const size_t np4 = n_points * sizeof(float4);
+  if (n_points > cache.pin_cap) {
+    if (cache.pin) (void)hipHostFree(cache.pin);
+    cache.pin = nullptr;
+    cache.pin_cap = 0;
+    FX_TRY(hipHostMalloc((void **)&cache.pin, (n_points + n_points / 4) * sizeof(float4), hipHostMallocDefault));
+    cache.pin_cap = n_points + n_points / 4;
+  }
+  float4 *h = cache.pin;
   const char *src = static_cast<const char *>(cloud);
   for (size_t i = 0; i < n_points; ++i) {
     float v[3];
@@ -579,12 +600,6 @@ int lslam_multiscan_register(lslam_ctx *ctx, const void *cloud, size_t n_points,
   float end_ori = -std::atan2(h[n_points - 1].y, h[n_points - 1].x) + 2 * float(M_PI);
   if (end_ori - start_ori > 3 * M_PI) end_ori -= 2 * M_PI;
   else if (end_ori - start_ori < M_PI) end_ori += 2 * M_PI;
-  struct Cache { char *p = nullptr; size_t cap = 0; };
-  static std::map<int, Cache> caches;  // device scratch kept per device between sweeps
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lk(mu);
-  Cache &cache = caches[lslam::ctx_device(ctx)];
-  const size_t np4 = n_points * sizeof(float4);
   const size_t bytes = 3 * np4 + 4 * n_points * 4 + 64;
   if (bytes > cache.cap) {
     if (cache.p) (void)hipFree(cache.p);
@@ -600,7 +615,7 @@ int lslam_multiscan_register(lslam_ctx *ctx, const void *cloud, size_t n_points,
   int32_t *d_first = (int32_t *)(d_ori + n_points);
   auto fail = [&](int code) { return code; };
   const int32_t big = INT32_MAX;
-  FX_TRY2(hipMemcpyAsync(d_in, h.data(), np4, hipMemcpyHostToDevice, s));
+  FX_TRY2(hipMemcpyAsync(d_in, h, np4, hipMemcpyHostToDevice, s));
   FX_TRY2(hipMemcpyAsync(d_first, &big, 4, hipMemcpyHostToDevice, s));
   MsArgs a{};
   a.in = d_in;

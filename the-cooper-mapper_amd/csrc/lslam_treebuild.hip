@@ -137,6 +137,28 @@ __device__ __forceinline__ int wave_sum_i(int v) {
   return wave_reduce_bits(v, [](int a, int b) { return a + b; });
 }
 
+// Inclusive segmented scan (min or max) over lanes [sa, lane] of the lane's segment -- segments are
+// disjoint lane ranges, sa <= lane -- on the DPP path: row_shr 1/2/4/8 inside the 16-lane rows (a lane
+// shifted in from outside the row keeps its own value), then rows 1 and 3 take the total of the row
+// below them (row_bcast15) and rows 2 and 3 that of the lower half (row_bcast31), each step only where
+// the source lane belongs to the same segment.  Six ds_bpermute round trips (__shfl_up) become six
+// register moves.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <bool MAX>
+__device__ __forceinline__ float seg_scan(float v, int lane, int sa) {
+  float t;
+  t = dpp_f<0x111, 0xf>(v); if (lane - 1 >= sa) v = MAX ? fmaxf(v, t) : fminf(v, t);
+  t = dpp_f<0x112, 0xf>(v); if (lane - 2 >= sa) v = MAX ? fmaxf(v, t) : fminf(v, t);
+  t = dpp_f<0x114, 0xf>(v); if (lane - 4 >= sa) v = MAX ? fmaxf(v, t) : fminf(v, t);
+  t = dpp_f<0x118, 0xf>(v); if (lane - 8 >= sa) v = MAX ? fmaxf(v, t) : fminf(v, t);
+  t = dpp_f<0x142, 0xa>(v); if ((lane & 16) && sa < (lane & ~15)) v = MAX ? fmaxf(v, t) : fminf(v, t);
+  t = dpp_f<0x143, 0xc>(v); if (lane >= 32 && sa < 32) v = MAX ? fmaxf(v, t) : fminf(v, t);
+  return v;
+}
+
 // exclusive prefix sum of `flag` over the block's TB threads; returns prefix, *total
 template <int TB>
 __device__ __forceinline__ int block_excl_scan(int flag, Sh<TB> &sh, int *total) {
@@ -553,16 +575,10 @@ __global__ __launch_bounds__(64) void kd_build_small_kernel(BuildArgs A) {
         while (__any(act)) {
           const int ns = sb - sa;
           // computeMinMax (:908-920): inclusive segmented scans, the segment's last lane has the result
-          float mnx = px, mny = py, mnz = pz, mxx = px, mxy = py, mxz = pz;
-#pragma unroll
-          for (int off = 1; off < 64; off <<= 1) {
-            const float t0 = __shfl_up(mnx, off, 64), t1 = __shfl_up(mny, off, 64), t2 = __shfl_up(mnz, off, 64);
-            const float t3 = __shfl_up(mxx, off, 64), t4 = __shfl_up(mxy, off, 64), t5 = __shfl_up(mxz, off, 64);
-            if (lane - off >= sa) {
-              mnx = fminf(mnx, t0); mny = fminf(mny, t1); mnz = fminf(mnz, t2);
-              mxx = fmaxf(mxx, t3); mxy = fmaxf(mxy, t4); mxz = fmaxf(mxz, t5);
-            }
-          }
+          const float mnx = seg_scan<false>(px, lane, sa), mny = seg_scan<false>(py, lane, sa),
+                      mnz = seg_scan<false>(pz, lane, sa);
+          const float mxx = seg_scan<true>(px, lane, sa), mxy = seg_scan<true>(py, lane, sa),
+                      mxz = seg_scan<true>(pz, lane, sa);
           const int last = sb - 1;
           const float en0 = __shfl(mnx, last, 64), en1 = __shfl(mny, last, 64), en2 = __shfl(mnz, last, 64);
           const float ex0 = __shfl(mxx, last, 64), ex1 = __shfl(mxy, last, 64), ex2 = __shfl(mxz, last, 64);
@@ -619,12 +635,7 @@ __global__ __launch_bounds__(64) void kd_build_small_kernel(BuildArgs A) {
           // child's lanes, min (= -max of the negated values) of the right child's
           const bool left = lane < mid;
           const int csa = left ? sa : mid;
-          float v = left ? x : -x;
-#pragma unroll
-          for (int off = 1; off < 64; off <<= 1) {
-            const float t = __shfl_up(v, off, 64);
-            if (lane - off >= csa) v = fmaxf(v, t);
-          }
+          const float v = seg_scan<true>(left ? x : -x, lane, csa);
           const float divlow = __shfl(v, mid - 1, 64), divhigh = -__shfl(v, last, 64);
           // children: leaves (:936-951) or the segments of the next level
           const int cntL = index, cntR = ns - index;

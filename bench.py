@@ -573,9 +573,89 @@ def sweep_pipeline_leg(pkg, synth, ctx, rings, np):
             n += 1
     mapper.feature_map.close()
     ms = {k: 1e3 * v / n for k, v in acc.items()}
-    return {"rings": rings, "points_per_sweep": int(len(raw)), "ms": ms, "ms_per_sweep": sum(ms.values()),
-            "sweeps_per_s": 1e3 / sum(ms.values()), "sweeps_timed": n,
-            "travelled_m": float(np.linalg.norm(M[:3, 3]))}
+    res = {"rings": rings, "points_per_sweep": int(len(raw)), "ms": ms, "ms_per_sweep": sum(ms.values()),
+           "sweeps_per_s": 1e3 / sum(ms.values()), "sweeps_timed": n,
+           "travelled_m": float(np.linalg.norm(M[:3, 3]))}
+    try:
+        res["node_threads"] = sweep_pipeline_threads(pkg, synth, rings, np, lo, hi, world)
+    except Exception as e:
+        res["node_threads"] = {"error": repr(e)}
+    return res
+
+
+def sweep_pipeline_threads(pkg, synth, rings, np, lo, hi, world):
+    """The same chain the way the reference runs it: scan registration, odometry and mapping are three
+    nodelets with their own threads (nodelets.xml; LaserOdometry.cpp spin(), LaserMapping.cpp:27-37),
+    joined by the /laser_cloud_* and /laser_odom_to_init topics.  Three host threads with a context each
+    (one call in flight per context), queues between them; ctypes releases the GIL during the calls, the
+    three streams share the GPU.  Throughput of the chain, not the latency of a sweep."""
+    import queue
+    import threading
+    sweeps = 14
+    raws = []
+    for k in range(sweeps):
+        gt = (0.0, 0.0, 0.3 + 0.01 * k, 3.0 + 0.4 * k, -2.0 + 0.15 * k, synth.SENSOR_HEIGHT)
+        _, _, _, cloud, _ = synth.make_scan(world, rings, 1800, gt_pose=gt, seed=300 + k, full=True)
+        ring = np.floor(cloud[:, 3]).astype(np.int64)
+        raws.append(cloud[np.lexsort((ring, -(cloud[:, 3] - ring)))])
+    ctx_r, ctx_o, ctx_m = pkg.Context(0), pkg.Context(0), pkg.Context(0)
+    odo = pkg.LaserOdometry(ctx_o)
+    mapper = pkg.LaserMapping(ctx_m, cube_dims=(21, 21, 11))
+    sr = pkg.scan_registration
+    q1, q2 = queue.Queue(maxsize=2), queue.Queue(maxsize=2)
+    out, err = [], []
+    warm = 3
+    stamps = {}
+
+    def registration():  # MultiScanRegistration nodelet: raw sweep -> feature clouds
+        try:
+            for k, raw in enumerate(raws):
+                if k == warm:
+                    stamps["t0"] = time.perf_counter()
+                reg, rr = sr.multiscan_register(ctx_r, raw, lo, hi, rings)
+                q1.put(sr.extract_features(ctx_r, reg, rr))
+        except Exception as e:
+            err.append(e)
+        q1.put(None)
+
+    def odometry():  # LaserOdometry nodelet
+        try:
+            while True:
+                f = q1.get()
+                if f is None:
+                    break
+                T = odo.process(f["sharp"], f["less_sharp"], f["flat"], f["less_flat"])
+                if T is not None:
+                    q2.put((odo.last_corner, odo.last_surf, T))
+        except Exception as e:
+            err.append(e)
+        q2.put(None)
+
+    def mapping():  # LaserMapping nodelet
+        try:
+            while True:
+                item = q2.get()
+                if item is None:
+                    break
+                out.append(mapper.process(*item))
+        except Exception as e:
+            err.append(e)
+        stamps["t1"] = time.perf_counter()
+    quiet_gc()
+    th = [threading.Thread(target=f) for f in (registration, odometry, mapping)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    mapper.feature_map.close()
+    for c in (ctx_r, ctx_o, ctx_m):
+        c.close()
+    if err:
+        raise err[0]
+    n = sweeps - warm
+    dt = stamps["t1"] - stamps["t0"]
+    return {"threads": 3, "ms_per_sweep": 1e3 * dt / n, "sweeps_per_s": n / dt, "sweeps_timed": n,
+            "travelled_m": float(np.linalg.norm(out[-1][:3, 3]))}
 
 
 def cpu_baseline(pr, repeats, gpu_pose, np):

@@ -126,3 +126,54 @@ def test_laser_mapping_default_grid(pkg, ctx, oracle, synth, small_problem):
     assert mapper.feature_map.dims == (121, 121, 11) and len(gs) > 1000
     assert np.array_equal(bits(gc), bits(oc)) and np.array_equal(bits(gs), bits(os_))
     mapper.feature_map.close()
+
+
+def test_contexts_on_concurrent_threads_equal_serial_runs(pkg, synth, small_problem):
+    """The reference runs registration, odometry and mapping as nodelets in their own threads; here: three
+    host threads, a context each, hammering feature extraction, VoxelGrid, a kd-tree build + scan match and
+    a feature-map insert at the same time.  Every result must equal, bit for bit, what the same call gives
+    on its own (the helpers that cache device scratch per device serialise on their locks; the contexts
+    share nothing else)."""
+    import threading
+    pr = small_problem
+    _, _, gt, cloud, ranges = synth.make_scan(pr["world"], 16, 900, gt_pose=pr["gt_pose"], seed=11, full=True)
+
+    def work(ctx, kind):
+        if kind == 0:
+            f = pkg.scan_registration.extract_features(ctx, cloud, ranges)
+            return [f[k] for k in ("sharp", "less_sharp", "flat", "less_flat")]
+        if kind == 1:
+            return [pkg.voxel_grid(ctx, pr["map_surf"], 1.0), pkg.voxel_grid(ctx, pr["map_corner"], 0.7)]
+        ctx.map_set(pr["map_corner"], pr["map_surf"])
+        s, pose, st = ctx.scanmatch_scan(pr["corner"], pr["surf"], pr["init_pose"])
+        fm = pkg.FeatureMap(ctx, 21, 11, 21)
+        fm.update(pr["gt_pose"][3:])
+        fm.add_feature_cloud(pr["corner"], pr["surf"], np.eye(4, dtype=np.float32))
+        c, sf = fm.get_surround_feature()
+        fm.close()
+        return [pose, c, sf]
+
+    serial_ctx = pkg.Context(0)
+    ref = [work(serial_ctx, k) for k in range(3)]
+    serial_ctx.close()
+    out, err = {}, []
+
+    def run(kind):
+        try:
+            c = pkg.Context(0)
+            for rep in range(6):
+                out[(kind, rep)] = work(c, kind)
+            c.close()
+        except Exception as e:  # pragma: no cover
+            err.append(e)
+
+    th = [threading.Thread(target=run, args=(k,)) for k in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not err, err
+    for (kind, rep), got in out.items():
+        assert len(got) == len(ref[kind])
+        for a, b in zip(got, ref[kind]):
+            assert a.shape == b.shape and np.array_equal(bits(a), bits(b)), (kind, rep)

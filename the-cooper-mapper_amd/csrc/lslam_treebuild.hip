@@ -1014,19 +1014,45 @@ __global__ __launch_bounds__(1024) void lv_setup_kernel(LvArgs L) {
 __global__ __launch_bounds__(LV_TB) void lv_minmax_kernel(LvArgs L) {
   LV_PROLOGUE
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (int i = c0 + threadIdx.x; i < c1; i += LV_TB) {
-    const float4 p = L.A.pts[l + i];
+  // a chunk is LV_CH / LV_TB = 16 points per thread: all loads issued before the first use (a rolled
+  // loop pays one memory round trip per point)
+  float4 pv[LV_CH / LV_TB];
+#pragma unroll
+  for (int u = 0; u < LV_CH / LV_TB; ++u) {
+    const int i = c0 + threadIdx.x + u * LV_TB;
+    pv[u] = L.A.pts[l + (i < c1 ? i : c0)];
+  }
+#pragma unroll
+  for (int u = 0; u < LV_CH / LV_TB; ++u) {
+    if (c0 + (int)threadIdx.x + u * LV_TB >= c1) continue;
+    const float4 p = pv[u];
     mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
     mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
     mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
   }
+  // one set of atomics per chunk, and only where the chunk improves on what the node already has: at
+  // the top levels every chunk of the launch belongs to one or two nodes, and a thousand atomics on one
+  // cache line are tens of microseconds
+  __shared__ float sh[6][LV_TB / 64];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     const float a = wave_min(mn[d]), b = wave_max(mx[d]);
     if ((threadIdx.x & 63) == 0) {
-      atomicMin(&L.stat[node].mn[d], ord_i(a));
-      atomicMax(&L.stat[node].mx[d], ord_i(b));
+      sh[d][threadIdx.x >> 6] = a;
+      sh[3 + d][threadIdx.x >> 6] = b;
     }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int d = threadIdx.x;
+    float v = sh[d][0];
+#pragma unroll
+    for (int w = 1; w < LV_TB / 64; ++w) v = d < 3 ? fminf(v, sh[d][w]) : fmaxf(v, sh[d][w]);
+    const int32_t o = ord_i(v);
+    int32_t *dst = d < 3 ? &L.stat[node].mn[d] : &L.stat[node].mx[d - 3];
+    const int32_t cur = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d < 3) { if (o < cur) atomicMin(dst, o); }
+    else       { if (o > cur) atomicMax(dst, o); }
   }
 }
 
@@ -1068,9 +1094,17 @@ __global__ __launch_bounds__(LV_TB) void lv_count_kernel(LvArgs L) {
   }
   a = wave_sum_i(a);
   b = wave_sum_i(b);
+  __shared__ int shc[2][LV_TB / 64];
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&L.stat[node].lim1, a);
-    atomicAdd(&L.stat[node].lim2, b);
+    shc[0][threadIdx.x >> 6] = a;
+    shc[1][threadIdx.x >> 6] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {  // one pair of atomics per chunk
+    int v = 0;
+#pragma unroll
+    for (int w = 0; w < LV_TB / 64; ++w) v += shc[threadIdx.x][w];
+    if (v) atomicAdd(threadIdx.x == 0 ? &L.stat[node].lim1 : &L.stat[node].lim2, v);
   }
 }
 
@@ -1184,15 +1218,35 @@ __global__ __launch_bounds__(LV_TB) void lv_bounds_kernel(LvArgs L) {
   const LvStat st = L.stat[node];
   const int index = lv_index(st, n);
   float lmax = -FLT_MAX, rmin = FLT_MAX;
-  for (int i = c0 + threadIdx.x; i < c1; i += LV_TB) {
-    const float x = coord(L.A.pts[l + i], st.feat);
-    if (i < index) lmax = fmaxf(lmax, x); else rmin = fminf(rmin, x);
+  float xv[LV_CH / LV_TB];
+#pragma unroll
+  for (int u = 0; u < LV_CH / LV_TB; ++u) {
+    const int i = c0 + threadIdx.x + u * LV_TB;
+    xv[u] = coord(L.A.pts[l + (i < c1 ? i : c0)], st.feat);
+  }
+#pragma unroll
+  for (int u = 0; u < LV_CH / LV_TB; ++u) {
+    const int i = c0 + threadIdx.x + u * LV_TB;
+    if (i >= c1) continue;
+    if (i < index) lmax = fmaxf(lmax, xv[u]); else rmin = fminf(rmin, xv[u]);
   }
   lmax = wave_max(lmax);
   rmin = wave_min(rmin);
+  __shared__ float shb[2][LV_TB / 64];
   if ((threadIdx.x & 63) == 0) {
-    atomicMax(&L.stat[node].lmax, ord_i(lmax));
-    atomicMin(&L.stat[node].rmin, ord_i(rmin));
+    shb[0][threadIdx.x >> 6] = lmax;
+    shb[1][threadIdx.x >> 6] = rmin;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {  // one pair of atomics per chunk, skipped where the chunk does not improve the bound
+    float v = shb[threadIdx.x][0];
+#pragma unroll
+    for (int w = 1; w < LV_TB / 64; ++w) v = threadIdx.x == 0 ? fmaxf(v, shb[0][w]) : fminf(v, shb[1][w]);
+    const int32_t o = ord_i(v);
+    int32_t *dst = threadIdx.x == 0 ? &L.stat[node].lmax : &L.stat[node].rmin;
+    const int32_t cur = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) { if (o > cur) atomicMax(dst, o); }
+    else                  { if (o < cur) atomicMin(dst, o); }
   }
 }
 

@@ -375,7 +375,8 @@ def test_cube_map_variant_matches_oracle(ctx, oracle, small_problem):
     pr = small_problem
     grid = dict(cube_size=20.0, origin=(5, 5, 1), dims=(11, 11, 3))
     ctx.cubemap_set(pr["map_corner"], pr["map_surf"], **grid)
-    assert ctx.map_info().built_on_device == 1  # all cube trees in one device build
+    if not os.environ.get("LSLAM_HOST_TREE"):
+        assert ctx.map_info().built_on_device == 1  # all cube trees in one device build
     opts = ctx.default_opts()
     opts.use_score = 0  # no score gate in this variant
     status, pose, st = ctx.scanmatch_scan(pr["corner"], pr["surf"], pr["init_pose"], opts)

@@ -551,11 +551,14 @@ def sweep_pipeline_leg(pkg, synth, ctx, rings, np):
     sr = pkg.scan_registration
     acc = {"register": 0.0, "extract": 0.0, "odometry": 0.0, "mapping": 0.0}
     n = 0
-    for k in range(7):
+    raws = []
+    for k in range(10):  # ten consecutive sweeps of a moving sensor: 7 for the stage timings, all for the threads
         gt = (0.0, 0.0, 0.3 + 0.01 * k, 3.0 + 0.4 * k, -2.0 + 0.15 * k, synth.SENSOR_HEIGHT)
         _, _, _, cloud, _ = synth.make_scan(world, rings, 1800, gt_pose=gt, seed=300 + k, full=True)
         ring = np.floor(cloud[:, 3]).astype(np.int64)
-        raw = cloud[np.lexsort((ring, -(cloud[:, 3] - ring)))]  # arrival order of a clockwise sweep
+        raws.append(cloud[np.lexsort((ring, -(cloud[:, 3] - ring)))])  # arrival order of a clockwise sweep
+    for k in range(7):
+        raw = raws[k]
         quiet_gc()
         t0 = time.perf_counter()
         reg, rr = sr.multiscan_register(ctx, raw, lo, hi, rings)
@@ -577,13 +580,13 @@ def sweep_pipeline_leg(pkg, synth, ctx, rings, np):
            "sweeps_per_s": 1e3 / sum(ms.values()), "sweeps_timed": n,
            "travelled_m": float(np.linalg.norm(M[:3, 3]))}
     try:
-        res["node_threads"] = sweep_pipeline_threads(pkg, synth, rings, np, lo, hi, world)
+        res["node_threads"] = sweep_pipeline_threads(pkg, synth, rings, np, lo, hi, raws)
     except Exception as e:
         res["node_threads"] = {"error": repr(e)}
     return res
 
 
-def sweep_pipeline_threads(pkg, synth, rings, np, lo, hi, world):
+def sweep_pipeline_threads(pkg, synth, rings, np, lo, hi, raws):
     """The same chain the way the reference runs it: scan registration, odometry and mapping are three
     nodelets with their own threads (nodelets.xml; LaserOdometry.cpp spin(), LaserMapping.cpp:27-37),
     joined by the /laser_cloud_* and /laser_odom_to_init topics.  Three host threads with a context each
@@ -591,13 +594,8 @@ def sweep_pipeline_threads(pkg, synth, rings, np, lo, hi, world):
     three streams share the GPU.  Throughput of the chain, not the latency of a sweep."""
     import queue
     import threading
-    sweeps = 14
-    raws = []
-    for k in range(sweeps):
-        gt = (0.0, 0.0, 0.3 + 0.01 * k, 3.0 + 0.4 * k, -2.0 + 0.15 * k, synth.SENSOR_HEIGHT)
-        _, _, _, cloud, _ = synth.make_scan(world, rings, 1800, gt_pose=gt, seed=300 + k, full=True)
-        ring = np.floor(cloud[:, 3]).astype(np.int64)
-        raws.append(cloud[np.lexsort((ring, -(cloud[:, 3] - ring)))])
+    raws = list(raws) + list(raws[-2:0:-1])  # out and back again: 18 sweeps of bounded motion
+    sweeps = len(raws)
     ctx_r, ctx_o, ctx_m = pkg.Context(0), pkg.Context(0), pkg.Context(0)
     odo = pkg.LaserOdometry(ctx_o)
     mapper = pkg.LaserMapping(ctx_m, cube_dims=(21, 21, 11))

@@ -67,6 +67,38 @@ class OracleChain:
         return new
 
 
+def test_chain_through_a_velocity_reversal(pkg, ctx, oracle, synth, small_problem):
+    """The same chain over sweeps that go out and come back (0 1 2 3 2 1 0): at the turn the odometry's
+    initial guess (the previous sweep's motion, LaserOdometry.cpp:288-326) points the wrong way by 0.8 m,
+    so its Gauss-Newton loop starts far from the answer and runs long.  Device and oracle chains must stay
+    together through that as well (the paths a smooth drive never takes)."""
+    world = small_problem["world"]
+    dims = (21, 21, 11)
+    odo = pkg.LaserOdometry(ctx)
+    mapper = pkg.LaserMapping(ctx, cube_dims=dims)
+    chain = OracleChain(oracle, ctx, dims)
+    sr = pkg.scan_registration
+    iters = []
+    for step, k in enumerate((0, 1, 2, 3, 2, 1, 0)):
+        gt = (0.0, 0.0, 0.3 + 0.01 * k, 3.0 + 0.4 * k, -2.0 + 0.15 * k, synth.SENSOR_HEIGHT)
+        c, s, gtp, cloud, ranges = synth.make_scan(world, 16, 900, gt_pose=gt, seed=300 + k, full=True)
+        ring = np.floor(cloud[:, 3]).astype(np.int64)
+        raw = cloud[np.lexsort((ring, -(cloud[:, 3] - ring)))]
+        reg, rr = sr.multiscan_register(ctx, raw, -15.0, 15.0, 16)
+        f = sr.extract_features(ctx, reg, rr)
+        of = oracle.extract_features(reg, rr)
+        T_g, T_o = odo.process(f["sharp"], f["less_sharp"], f["flat"], f["less_flat"]), chain.odometry(of)
+        if step == 0:
+            continue
+        iters.append(odo.last_stats.iterations)
+        assert np.abs(T_g - T_o).max() <= 2e-3, (step, np.abs(T_g - T_o).max())
+        M_g = mapper.process(odo.last_corner, odo.last_surf, T_g)
+        M_o = chain.mapping(chain.last_c, chain.last_s, T_o)
+        assert np.abs(M_g - M_o).max() <= 2e-3, (step, np.abs(M_g - M_o).max())
+    assert max(iters) == 25  # some loops run to the iteration limit (LaserOdometry.cpp: 25) without converging
+    mapper.feature_map.close()
+
+
 def test_registration_to_mapping_chain(pkg, ctx, oracle, synth, small_problem):
     """Five consecutive VLP-16 sweeps of a drive through the synthetic world, raw driver clouds in:
     the device chain and the oracle chain agree on every intermediate product (feature clouds bit for

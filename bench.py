@@ -132,6 +132,7 @@ def main():
         # converged are skipped by later launches, so count the points actually processed
         alg_bytes = ALG_BYTES_PER_POINT_RESIDUAL * pt_res / max(1, sweep_launches)
         achieved_gbs = alg_bytes / (avg_sweep_ms * 1e-3) / 1e9 if avg_sweep_ms > 0 else 0.0
+        compulsory = float(info.n_corner + info.n_surf) * 16.0 + (pt_res / max(1, sweep_launches)) * (16.0 + 36.0)
         out = {
             "metric": "point-residuals/s",
             "value": total_pt_res / t,
@@ -178,6 +179,10 @@ def main():
                 "avg_kernel_ms": avg_sweep_ms,
                 "launches_timed": sweep_launches,
                 "alg_bytes_per_launch": alg_bytes,
+                # SURVEY 8d asks for both accountings: the compulsory-unique lower bound of a sweep -- every map
+                # point and every query read once, every output written once: (Mc+Ms) 16 B + N (16 + 36) B
+                "compulsory_bytes_per_launch": compulsory,
+                "compulsory_achieved_gbs": compulsory / (avg_sweep_ms * 1e-3) / 1e9 if avg_sweep_ms > 0 else 0.0,
             },
         }
         if not args.no_single:

@@ -1,94 +1,165 @@
 #!/usr/bin/env python3
 """bench.py -- point-residuals/s of the L_SLAM scan-to-map Gauss-Newton hot path on MI355X.
 
-A "step" is one scanMatchScan Gauss-Newton loop (ScanMatch.cpp:78-347: up to 10
-iterations of transform -> kd-tree 5-NN -> line/plane fit -> residual + Jacobian ->
-J^T J / J^T r -> 6x6 solve -> pose update) of one synthetic 64-ring x 1800 scan
-(115 200 points) against a resident ~1.3 M-point voxel map (BASELINE.json configs[2]);
-`--batch` (default 8) different scans are matched together per step, the way keyframes
-are re-matched against a map (pose_graph/graph.cpp:171-197).  The single-scan (latency)
-figure is reported in the same line under "single_scan".
+Workload (BASELINE.json configs[2] on the map of configs[1])
+  * world: 600 x 600 m Manhattan grid (ground, box buildings, street poles, perimeter wall);
+  * map: the "10k-frame voxel map" -- `--map-frames` (10 000) VLP-16 frames ray cast along a closed loop
+    through the streets, each filtered and pushed at its ground-truth pose through
+    FeatureMap::addFeatureCloud (util/FeatureMap.h:219-230,289-306; corner leaf 0.2 m, surf 0.4 m) on the
+    device map; what is matched against is the active surround at the end of the loop
+    (getSurroundFeature, :256-265), kd-trees built on the device;
+  * queries: `--scans` (512) different synthetic 64-ring x 1800 scans (115 200 points each, every
+    return a query) taken around the end of the loop, initial pose error +-0.3 m / +-2 deg.
+A "step" is one pass of the hot path over that batch: the scanMatchScan Gauss-Newton loop
+(ScanMatch.cpp:78-347: <= 10 iterations of transform -> kd-tree 5-NN -> line/plane fit -> residual +
+Jacobian -> J^T J / J^T r -> 6x6 solve -> pose update) of every resident scan, `--batch` scans in
+flight per launch sequence -- the way every keyframe is re-matched against the map in
+pose_graph/graph.cpp:171-197.  Every call starts cold (no neighbour lists carried over).
 Map, kd-trees and scans are resident in HBM before the timed region starts.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-For N > 1 the driver launches one rank per GPU with torch.distributed.run; the map
-is replicated, every rank matches its own scans (independent problems, no data-path
-collective: SURVEY.md 8e row 2) and `value` is the whole-job aggregate.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment makes THIS process start N ranks
+(python -m torch.distributed.run, one per GPU) before it touches the GPU, and relay rank 0's line; under
+a launcher (WORLD_SIZE set) the rank count must equal --gpus.  The map is replicated, every rank matches
+its own scans (independent problems, no data-path collective: SURVEY.md 8e row 2), `value` is the
+whole-job aggregate.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the sweep kernel's algorithmic
-bytes (1.7 KB per point-residual) against the 8 TB/s HBM peak, using
-the kernel's average duration measured with HIP events on the library's own stream
-inside the timed region.  `cpu_baseline` is the oracle (a port of the reference's
-single-threaded CPU path, including its per-call kd-tree rebuild) timed on this
-host on the same workload.
+Prints ONE JSON line (rank 0).  `roofline` carries the sweep kernel's algorithmic bytes (1.7 KB per
+point-residual) over its average duration, measured with HIP events on the library's own
+stream inside the timed region, next to what the committed rocprofv3 counter passes of this same command
+say bounds it.  `cpu_baseline` is the oracle (a port of the reference's single-threaded CPU path,
+including its per-call kd-tree rebuild) timed on this host on a sample of the same workload.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 ALG_BYTES_PER_POINT_RESIDUAL = 1700.0
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8 TB/s spec
+L2_PEAK_GBS = 34500.0                  # MI355X_MICROARCH.md: ~34.5 TB/s aggregate
+PMC_PROFILE = os.path.join("profiles", "r02_pmc_sweep.csv")
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rings", type=int, default=64)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("LSLAM_BATCH", "8")),
-                    help="independent scans matched together per step on each GPU")
+    ap.add_argument("--scans", type=int, default=int(os.environ.get("LSLAM_SCANS", "512")),
+                    help="resident query scans per GPU; one step matches all of them")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("LSLAM_BATCH", "32")),
+                    help="scans in flight per launch sequence (lslam_opts.scans_in_flight)")
+    ap.add_argument("--map-frames", type=int, default=10000, help="frames accumulated into the voxel map")
+    ap.add_argument("--map-rings", type=int, default=16, help="rings of the frames the map is built from (VLP-16)")
     ap.add_argument("--jtj-mode", type=int, default=int(os.environ.get("LSLAM_JTJ_MODE", "1")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-joint-stereo", action="store_true")
     ap.add_argument("--no-pose-graph", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the single-scan latency leg")
     ap.add_argument("--no-mapping-frame", action="store_true", help="skip the per-frame mapping pipeline leg")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the whole-chain (registration..mapping) leg")
+    ap.add_argument("--headline-only", action="store_true", help="only the timed region (profiling passes)")
     ap.add_argument("--shard-points", action="store_true",
-                    help="run the sharded-points leg even on one GPU (all-reduce over a world of 1)")
-    ap.add_argument("--pg-iters", type=int, default=10, help="LM iterations of the pose-graph leg")
-    ap.add_argument("--cpu-repeats", type=int, default=3)
-    args = ap.parse_args()
+                    help="run the sharded-points leg even on one GPU (RCCL all-reduce over a world of 1)")
+    ap.add_argument("--pg-iters", type=int, default=100, help="LM iteration limit of the pose-graph leg")
+    ap.add_argument("--cpu-scans", type=int, default=8, help="scans the single-core CPU baseline matches")
+    return ap.parse_args()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves.  This parent has not
+    imported torch or touched HIP; it only relays the children's output and exit code."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if args.headline_only:
+        args.no_cpu_baseline = args.no_joint_stereo = args.no_pose_graph = args.no_single = True
+        args.no_mapping_frame = args.no_pipeline = True
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        print("bench.py: --gpus %d but the launcher started %s rank(s)" % (args.gpus, os.environ.get("WORLD_SIZE")),
+              file=sys.stderr)
+        sys.exit(2)
 
     import numpy as np
     import torch
 
     distmod = importlib.import_module("the-cooper-mapper_amd.dist")
     rank, local_rank, world = distmod.env_rank()
+    if os.environ.get("LSLAM_BENCH_DRY_RUN"):  # launcher test (tests/test_dist_cpu.py): rendezvous only, no GPU
+        dist = distmod.init("gloo")
+        (n,), _ = distmod.aggregate(dist, [1.0], 0.0)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_counted": int(n)}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
     dist = distmod.init("nccl")
 
     pkg = importlib.import_module("the-cooper-mapper_amd")
     synth = importlib.import_module("the-cooper-mapper_amd.synth")
+    import synth_gpu
 
-    # ---- workload: same map on every rank, a different scan pose per rank ----------
-    pr = synth.make_problem(rings=args.rings, azimuth_steps=1800, seed=rank)
+    # ---- the world, the 10k-frame voxel map and the query scans -------------------------------------
+    t_setup = time.perf_counter()
+    world_model = synth.World(half_extent=300.0, wall_half=295.0)
+    lidar = synth_gpu.GpuLidar(world_model, local_rank)
+    traj = synth_gpu.loop_trajectory(args.map_frames)
     ctx = pkg.Context(local_rank)
-    ctx.map_set(pr["map_corner"], pr["map_surf"])
+    fm, mapstats = synth_gpu.build_voxel_map(pkg, ctx, lidar, traj, rings=args.map_rings,
+                                             progress=2000 if rank == 0 else None)
+    end_pose = traj[-1]
+    fm.update(end_pose[3:].astype(np.float32))
+    fm.surround_to_map()
     info = ctx.map_info()
-    # the batch: `--batch` different scans of the same world (different sensor poses)
-    scans, inits, gts = [(pr["corner"], pr["surf"])], [pr["init_pose"]], [pr["gt_pose"]]
-    for k in range(1, args.batch):
-        gt = (0.01, -0.015, 0.3 + 0.37 * k + 0.1 * rank, 3.0 - 1.7 * k, -2.0 + 2.3 * k, synth.SENSOR_HEIGHT)
-        qc, qs, gt = synth.make_scan(pr["world"], args.rings, 1800, gt_pose=gt, seed=1234 + 17 * k + rank)
+    # query poses: on the loop within +-25 m of path around its end (the loop is closed), a little off the line
+    rng = np.random.default_rng(4242 + rank)
+    dense = synth_gpu.loop_trajectory(100000)
+    per = 0.0
+    seg = np.linalg.norm(np.diff(dense[:, 3:5], axis=0), axis=1).mean()
+    span = int(25.0 / seg)
+    scans, inits, gts = [], [], []
+    for k in range(args.scans):
+        g = dense[int(rng.integers(-span, span)) % len(dense)].copy()
+        g[3:5] += rng.uniform(-1.0, 1.0, 2)
+        g[2] += rng.uniform(-0.2, 0.2)
+        qc, qs = lidar.scan(g, args.rings, 1800, seed=900000 + 1000 * rank + k)
         scans.append((qc, qs))
-        inits.append(synth.perturb_pose(gt, seed=99 + k))
-        gts.append(gt.astype(np.float32))
+        gts.append(g.astype(np.float32))
+        inits.append(synth.perturb_pose(g, seed=99 + 1000 * rank + k))
     n_pts = sum(len(c) + len(s) for c, s in scans)
+    n_corner = sum(len(c) for c, _ in scans)
     ctx.scan_set_batch(scans)
     inits = np.stack(inits)
+    gts = np.stack(gts)
     opts = ctx.default_opts()
     opts.jtj_mode = args.jtj_mode
     opts.profile = 1
+    opts.scans_in_flight = args.batch
+    setup_s = time.perf_counter() - t_setup
     # The interpreter holds ~170 k objects by now (torch, numpy): a generation-2 collection of the Python
     # garbage collector takes 25-35 ms and would land in whichever timed region happens to allocate the
     # triggering object.  Park everything allocated so far in the permanent generation (the same reason
@@ -123,16 +194,37 @@ def main():
     (total_pt_res, total_iters), t = distmod.aggregate(dist, [pt_res, iters], elapsed)
 
     status, poses, sts = last
-    pose, st = poses[0], sts[0]
-    pose_err = np.abs(poses - np.stack(gts)).max(axis=0)
+    pose_err = np.abs(poses - gts)
+    n_conv = int(sum(1 for s in sts if s.converged))
 
+    out = None
     if rank == 0:
         avg_sweep_ms = sweep_ms / max(1, sweep_launches)
-        # algorithmic bytes of an average timed launch: scans of a batch that have already
+        # algorithmic bytes of an average timed launch: scans of a chunk that have already
         # converged are skipped by later launches, so count the points actually processed
-        alg_bytes = ALG_BYTES_PER_POINT_RESIDUAL * pt_res / max(1, sweep_launches)
+        pts_per_launch = pt_res / max(1, sweep_launches)
+        alg_bytes = ALG_BYTES_PER_POINT_RESIDUAL * pts_per_launch
         achieved_gbs = alg_bytes / (avg_sweep_ms * 1e-3) / 1e9 if avg_sweep_ms > 0 else 0.0
-        compulsory = float(info.n_corner + info.n_surf) * 16.0 + (pt_res / max(1, sweep_launches)) * (16.0 + 36.0)
+        compulsory = float(info.n_corner + info.n_surf) * 16.0 + pts_per_launch * (16.0 + 36.0)
+        roof = {
+            "kernel": "sweep_kernel",
+            "achieved": achieved_gbs,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved_gbs / HBM_PEAK_GBS,
+            "accounting": "achieved = 1.7 KB algorithmic bytes per point-residual (SURVEY 8d: the working set of "
+                          "nanoflann's unbounded search) x points an average timed launch processed / its HIP-event "
+                          "duration; almost all of those bytes are L1/L2/Infinity-Cache hits, see `counters`",
+            "avg_kernel_ms": avg_sweep_ms,
+            "launches_timed": sweep_launches,
+            "points_per_launch": pts_per_launch,
+            "alg_bytes_per_launch": alg_bytes,
+            # SURVEY 8d asks for both accountings: the compulsory-unique lower bound of a sweep -- every map
+            # point and every query read once, every output written once: (Mc+Ms) 16 B + N (16 + 36) B
+            "compulsory_bytes_per_launch": compulsory,
+            "compulsory_achieved_gbs": compulsory / (avg_sweep_ms * 1e-3) / 1e9 if avg_sweep_ms > 0 else 0.0,
+        }
+        roof.update(pmc_counters(avg_sweep_ms))
         out = {
             "metric": "point-residuals/s",
             "value": total_pt_res / t,
@@ -147,89 +239,98 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "lm_iters_per_s": total_iters / t,
+            "timed_region_s": t,
             "config": {
-                "workload": "synthetic %d-ring x 1800 scan-to-map scanMatchScan GN loop (BASELINE configs[2])" % args.rings,
+                "workload": "synthetic %d-ring x 1800 scan-to-map scanMatchScan GN loops (BASELINE configs[2]) against "
+                            "the %d-frame voxel map of a 600 x 600 m world (configs[1]): %d scans per step and GPU"
+                            % (args.rings, args.map_frames, args.scans),
+                "scans_per_step_per_gpu": args.scans,
                 "scans_in_flight_per_gpu": args.batch,
-                "scan_points": n_pts,
-                "scan_corner": int(len(pr["corner"])),
-                "scan_surf": int(len(pr["surf"])),
-                "map_corner": int(info.n_corner),
-                "map_surf": int(info.n_surf),
-                "kd_nodes": int(info.nodes_corner + info.nodes_surf),
-                "kd_depth": int(max(info.depth_corner, info.depth_surf)),
-                "gn_iters_per_step_per_scan": iters / args.steps / args.batch,
+                "scan_points_per_step": n_pts,
+                "scan_corner_share": n_corner / max(1, n_pts),
+                "map": dict(mapstats, surround_corner=int(info.n_corner), surround_surf=int(info.n_surf),
+                            kd_nodes=int(info.nodes_corner + info.nodes_surf),
+                            kd_depth=int(max(info.depth_corner, info.depth_surf)),
+                            tree_build_ms=float(info.build_ms + info.upload_ms), build_attempts=int(info.build_attempts)),
+                "gn_iters_per_scan": iters / args.steps / args.scans,
                 "sweep_launches_per_step": sweep_launches / args.steps,
                 "jtj_mode": "mfma_f32_16x16x4" if args.jtj_mode == 1 else "valu_shuffle",
                 "parallelism": "replicated map, scans sharded across %d GPU(s), no collective" % world,
-                "map_build_ms_outside_timed_region": float(info.build_ms + info.upload_ms),
-                "map_built_on_device": bool(info.built_on_device),
+                "setup_s_outside_timed_region": setup_s,
                 "gpu_loop_ms_per_step": loop_ms / args.steps,
-                "pose_err_vs_ground_truth_m": float(pose_err[3:].max()),
-                "pose_err_vs_ground_truth_rad": float(pose_err[:3].max()),
-                "converged": bool(all(s.converged for s in sts)),
+                "pose_err_vs_ground_truth_m": {"max": float(pose_err[:, 3:].max()), "median": float(np.median(pose_err[:, 3:].max(axis=1)))},
+                "pose_err_vs_ground_truth_rad": float(pose_err[:, :3].max()),
+                "converged_scans": n_conv,
             },
-            "roofline": {
-                "kernel": "sweep_kernel",
-                "bound": "hbm",
-                "achieved": achieved_gbs,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_bytes(args.batch),
-                "avg_kernel_ms": avg_sweep_ms,
-                "launches_timed": sweep_launches,
-                "alg_bytes_per_launch": alg_bytes,
-                # SURVEY 8d asks for both accountings: the compulsory-unique lower bound of a sweep -- every map
-                # point and every query read once, every output written once: (Mc+Ms) 16 B + N (16 + 36) B
-                "compulsory_bytes_per_launch": compulsory,
-                "compulsory_achieved_gbs": compulsory / (avg_sweep_ms * 1e-3) / 1e9 if avg_sweep_ms > 0 else 0.0,
-            },
+            "roofline": roof,
         }
         if not args.no_single:
-            out["single_scan"] = single_scan_leg(ctx, pr, opts, max(10, args.steps // 2))
+            out["single_scan"] = single_scan_leg(ctx, scans[0], inits[0], opts, 200)
+    surround = None
+    if rank == 0 and not (args.no_cpu_baseline and args.no_mapping_frame):
+        surround = fm.get_surround_feature()  # the map the timed region matched against, on the host
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(surround, scans, inits, poses, min(args.cpu_scans, args.scans), np)
     if rank == 0 and not args.no_mapping_frame:
         try:
-            out["mapping_frame"] = mapping_frame_leg(pkg, synth, ctx, pr, opts, np, not args.no_cpu_baseline, 64)
+            out["mapping_frame"] = mapping_frame_leg(pkg, synth, ctx, surround, lidar, end_pose, opts, np, not args.no_cpu_baseline, 64)
             # BASELINE configs[1]: the same frame with a VLP-16 (16 x 1800) sweep
-            out["mapping_frame_vlp16"] = mapping_frame_leg(pkg, synth, ctx, pr, opts, np, not args.no_cpu_baseline, 16)
+            out["mapping_frame_vlp16"] = mapping_frame_leg(pkg, synth, ctx, surround, lidar, end_pose, opts, np, not args.no_cpu_baseline, 16)
         except Exception as e:  # a secondary leg never takes the headline line down
             out["mapping_frame"] = {"error": repr(e)}
-    if rank == 0 and not args.no_mapping_frame:
+    fm.close()
+    if rank == 0 and not args.no_pipeline:
         try:
             out["sweep_pipeline"] = {"vlp16": sweep_pipeline_leg(pkg, synth, ctx, 16, np),
                                      "rings64": sweep_pipeline_leg(pkg, synth, ctx, 64, np)}
         except Exception as e:
             out["sweep_pipeline"] = {"error": repr(e)}
-    if world > 1 or args.shard_points:
+    comm = None
+    if (world > 1 or args.shard_points) and not args.headline_only:
+        comm = make_comm(pkg, dist, torch, rank, local_rank, world)
         try:
-            shres = sharded_points_leg(pkg, synth, distmod, dist, rank, world, ctx, opts, torch, np, args)
+            shres = sharded_points_leg(pkg, synth, distmod, dist, rank, world, ctx, comm, opts, np, args)
         except Exception as e:  # never let the secondary leg take the headline line down
             shres = {"error": repr(e)}
         if rank == 0:
             out["sharded_points"] = shres
     if not args.no_joint_stereo:
         try:
-            jres = joint_stereo_leg(pkg, synth, distmod, dist, rank, world, ctx, opts, torch, np, args,
+            jres = joint_stereo_leg(pkg, synth, distmod, dist, rank, world, ctx, comm, opts, np, args,
                                     not args.no_cpu_baseline)
         except Exception as e:
             jres = {"error": repr(e)}
         if rank == 0:
             out["joint_lidar_stereo"] = jres
     if not args.no_pose_graph:
-        pgres = pose_graph_leg(pkg, synth, distmod, dist, rank, world, local_rank, torch, np,
-                               args.pg_iters, not args.no_cpu_baseline)
+        try:
+            pgres = pose_graph_leg(pkg, synth, distmod, dist, rank, world, local_rank, comm, np,
+                                   args.pg_iters, not args.no_cpu_baseline)
+        except Exception as e:
+            pgres = {"error": repr(e)}
         if rank == 0:
             out["pose_graph"] = pgres
     if rank == 0:
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pr, args.cpu_repeats, pose, np)
         print(json.dumps(out), flush=True)
 
     if dist is not None:
         dist.barrier()
     ctx.close()
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def make_comm(pkg, dist, torch, rank, local_rank, world):
+    """The library's own RCCL communicator: rank 0 makes the id, torch.distributed carries the 128 bytes."""
+    import numpy as np
+    uid = pkg.Comm.unique_id() if rank == 0 else np.zeros(128, np.uint8)
+    if dist is not None:
+        t = torch.from_numpy(uid.astype(np.int32)).cuda()
+        dist.broadcast(t, src=0)
+        uid = t.cpu().numpy().astype(np.uint8)
+    return pkg.Comm(local_rank, uid, rank, world)
 
 
 def quiet_gc():
@@ -238,29 +339,71 @@ def quiet_gc():
     gc.freeze()
 
 
-def pmc_traffic_bytes(batch):
-    """HBM bytes per sweep launch from the committed rocprofv3 --pmc passes of this same
-    command (PMC counters cannot be collected inside the timed run; FETCH_SIZE and
-    WRITE_SIZE need separate passes).  MI355X_MICROARCH.md: counters are in KiB and
-    FETCH_SIZE under-reports wide reads by 2x on gfx950, so traffic = (2*FETCH + WRITE)*1024."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_sweep_batch%d.csv" % batch)
+def pmc_counters(avg_sweep_ms):
+    """What the hardware counters say about the sweep kernel.  PMC counters cannot be collected inside the
+    timed run (rocprofv3 needs its own passes, FETCH_SIZE / WRITE_SIZE separate ones), so these figures are
+    read from the COMMITTED summary of the passes of this same command (tools/collect_profiles.sh ->
+    profiles/r02_pmc_sweep.csv; per launch, largest launches only) and labelled as such.
+    MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB and FETCH_SIZE under-reports wide reads by 2x
+    on gfx950, so HBM-side traffic = (2 * FETCH + WRITE) * 1024; an L2 request is 128 B."""
+    path = os.path.join(ROOT, PMC_PROFILE)
     if not os.path.exists(path):
-        return None
-    vals = {}
+        return {"bound": "unknown (no committed counter profile)", "traffic": None}
+    v = {}
+    src = ""
     for line in open(path):
+        if line.startswith("#"):
+            src += line[1:].strip() + " "
+            continue
         f = line.strip().split(",")
-        if len(f) >= 4 and f[1] in ("FETCH_SIZE", "WRITE_SIZE"):
-            vals[f[1]] = float(f[3])
-    if len(vals) != 2:
-        return None
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+        if len(f) >= 4 and f[0] != "pass":
+            v[f[1]] = float(f[3])
+    g = v.get
+    traffic = (2.0 * g("FETCH_SIZE", 0.0) + g("WRITE_SIZE", 0.0)) * 1024.0 if "FETCH_SIZE" in v else None
+    # the profile's own kernel duration (SQ_BUSY_CYCLES is per-SE; use wave-cycle ratios, which need none)
+    c = {"source": "%s (rocprofv3 --pmc passes; %s)" % (PMC_PROFILE, src.strip()[:200])}
+    t_s = avg_sweep_ms * 1e-3
+    if traffic is not None and t_s > 0:
+        c["hbm_gbs"] = traffic / t_s / 1e9
+        c["hbm_frac"] = c["hbm_gbs"] / HBM_PEAK_GBS
+    if "TCC_REQ_sum" in v and t_s > 0:
+        c["l2_gbs"] = v["TCC_REQ_sum"] * 128.0 / t_s / 1e9
+        c["l2_frac"] = c["l2_gbs"] / L2_PEAK_GBS
+        if v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0) > 0:
+            c["l2_hit_rate"] = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
+    if "SQ_THREAD_CYCLES_VALU" in v and v.get("SQ_ACTIVE_INST_VALU", 0) > 0:
+        # thread-cycles per VALU instruction-cycle: lanes doing work out of 64
+        c["lanes_active"] = v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 4.0) if v["SQ_ACTIVE_INST_VALU"] else None
+    if "SQ_INSTS_VALU" in v and "SQ_THREAD_CYCLES_VALU" in v and v["SQ_INSTS_VALU"] > 0:
+        c["lanes_active"] = v["SQ_THREAD_CYCLES_VALU"] / v["SQ_INSTS_VALU"]
+    if "SQ_WAIT_ANY" in v and v.get("SQ_WAVE_CYCLES", 0) > 0:
+        c["wait_frac"] = v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"]
+    if "SQ_ACTIVE_INST_VALU" in v and v.get("SQ_BUSY_CYCLES", 0) > 0:
+        # SQ_ACTIVE_INST_VALU counts cycles (x4 per quad-issue) summed over SIMDs; SQ_BUSY_CYCLES per shader engine
+        c["valu_busy"] = v["SQ_ACTIVE_INST_VALU"] * 4.0 / (v["SQ_BUSY_CYCLES"] / 32.0 * 1024.0) if v["SQ_BUSY_CYCLES"] else None
+    for k in ("TA_BUSY_avr", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_PENDING_STALL_CYCLES_sum", "TA_FLAT_READ_WAVEFRONTS_sum",
+              "TCP_TCC_READ_REQ_sum", "GRBM_GUI_ACTIVE", "TA_BUSY_max", "TCP_GATE_EN1_sum", "TCP_GATE_EN2_sum", "TA_TA_BUSY_sum"):
+        if k in v:
+            c[k] = v[k]
+    # which resource is closest to its limit: that is the bound the line reports
+    cand = {"hbm": c.get("hbm_frac", 0.0) or 0.0, "l2": c.get("l2_frac", 0.0) or 0.0, "valu-issue": c.get("valu_busy", 0.0) or 0.0}
+    if "vmem_lane_rate_frac" in v:
+        cand["vector-memory lane rate (TA / L1)"] = v["vmem_lane_rate_frac"]
+        c["vmem_lane_rate_frac"] = v["vmem_lane_rate_frac"]
+    top = max(cand, key=cand.get)
+    bound = top
+    if cand[top] < 0.6 and c.get("wait_frac", 0.0) > 0.4:
+        bound = "latency of dependent gathers + %s (no bandwidth above 60 %% of its peak; waves wait %.0f %% of their life)" % (
+            top, 100.0 * c.get("wait_frac", 0.0))
+    return {"bound": bound, "traffic": traffic, "counters": c}
 
 
-def sharded_points_leg(pkg, synth, distmod, dist, rank, world, ctx, opts, torch, np, args):
+def sharded_points_leg(pkg, synth, distmod, dist, rank, world, ctx, comm, opts, np, args):
     """ONE 115 200-point scan, its points sharded contiguously over the ranks,
-    the 32 fp64 normal-equation sums all-reduced over RCCL every Gauss-Newton iteration, the
-    6x6 solve replicated.  Latency-bound by construction (two host round trips per iteration);
-    reported as measured, next to the recommended no-collective batch mode."""
+    the 32 fp64 normal-equation sums all-reduced every Gauss-Newton iteration by the library's own RCCL
+    communicator on the library's stream (ncclAllReduce between the reducing and the solving kernel, the
+    loop stays device-resident), the 6x6 solve replicated.  Strong scaling of a ~60 us sweep: reported as
+    measured, next to the recommended no-collective batch mode."""
     pr = synth.make_problem(rings=args.rings, azimuth_steps=1800, seed=0)  # the same scan on every rank
     # ... and the same map: every rank must take the same decisions from the same all-reduced sums
     # (rank 0's map was replaced by the mapping-frame leg)
@@ -268,32 +411,28 @@ def sharded_points_leg(pkg, synth, distmod, dist, rank, world, ctx, opts, torch,
     cb, ce = distmod.shard_range(len(pr["corner"]), rank, world)
     sb, se = distmod.shard_range(len(pr["surf"]), rank, world)
     ctx.scan_set(pr["corner"][cb:ce], pr["surf"][sb:se])
-    xchg = torch.zeros(32, dtype=torch.float64, device="cuda")
-
-    def allreduce(ptr, count):
-        if dist is not None:
-            dist.all_reduce(xchg, op=dist.ReduceOp.SUM)
-        torch.cuda.synchronize()
+    ctx.set_comm(comm)
     for _ in range(3):
-        ctx.run_sharded(pr["init_pose"], allreduce, xchg, opts)
-    steps = max(10, args.steps // 2)
+        ctx.run_sharded(pr["init_pose"], opts=opts)
+    steps = 50
     quiet_gc()
     distmod.barrier(dist)
     t0 = time.perf_counter()
     pt = 0
     for _ in range(steps):
-        status, pose, st = ctx.run_sharded(pr["init_pose"], allreduce, xchg, opts)
+        status, pose, st = ctx.run_sharded(pr["init_pose"], opts=opts)
         pt += st.point_residuals
     distmod.barrier(dist)
     dt = time.perf_counter() - t0
+    ctx.set_comm(None)
     (tot,), tmax = distmod.aggregate(dist, [pt], dt)
     return {"value": tot / tmax, "unit": "point-residuals/s", "ms_per_scanmatch": 1e3 * tmax / steps,
             "gn_iterations": int(st.iterations), "n_gpus": world, "scaling": "strong",
-            "allreduce_bytes_per_iteration": 256,
+            "allreduce_bytes_per_iteration": 256, "transport": "ncclAllReduce (RCCL) on the library's stream",
             "pose_err_vs_ground_truth_m": float(np.abs(pose - pr["gt_pose"])[3:].max())}
 
 
-def joint_stereo_leg(pkg, synth, distmod, dist, rank, world, ctx, opts, torch, np, args, with_cpu):
+def joint_stereo_leg(pkg, synth, distmod, dist, rank, world, ctx, comm, opts, np, args, with_cpu):
     """BASELINE configs[4]: LOAM edge/plane rows + stereo reprojection rows in ONE joint 6x6 system per
     Gauss-Newton iteration (include/lslam_c.h lslam_stereo_set; the reference has no code for the visual
     term -- parity unpinned, the oracle restates ORB-SLAM2's pose-only stereo edge).  One 64-ring scan
@@ -311,17 +450,13 @@ def joint_stereo_leg(pkg, synth, distmod, dist, rank, world, ctx, opts, torch, n
     sb, se = distmod.shard_range(len(pr["surf"]), rank, world)
     o0, o1 = distmod.shard_range(len(lm), rank, world)
     ctx.scan_set(pr["corner"][cb:ce], pr["surf"][sb:se])
-    xchg = torch.zeros(32, dtype=torch.float64, device="cuda")
-
-    def allreduce(ptr, count):
-        if dist is not None:
-            dist.all_reduce(xchg, op=dist.ReduceOp.SUM)
-        torch.cuda.synchronize()
+    if world > 1:
+        ctx.set_comm(comm)
 
     def run():
         if world == 1:
             return ctx.run(pr["init_pose"], opts)
-        return ctx.run_sharded(pr["init_pose"], allreduce, xchg, opts)
+        return ctx.run_sharded(pr["init_pose"], opts=opts)
 
     def timed(steps):
         for _ in range(3):
@@ -339,11 +474,13 @@ def joint_stereo_leg(pkg, synth, distmod, dist, rank, world, ctx, opts, torch, n
         _, med = distmod.aggregate(dist, [0.0], float(np.median(each)))
         _, worst = distmod.aggregate(dist, [0.0], float(max(each)))
         return 1e3 * med, 1e3 * worst, pose, st
-    steps = max(10, args.steps // 2)
+    steps = 25
     ms_lidar, worst_lidar, pose_l, st_l = timed(steps)
     ctx.stereo_set(lm[o0:o1], ob[o0:o1], w[o0:o1], cam)
     ms_joint, worst_joint, pose_j, st_j = timed(steps)
     ctx.stereo_clear()
+    if world > 1:
+        ctx.set_comm(None)
     n_pts = len(pr["corner"]) + len(pr["surf"])
     res = {"ms_per_joint_scanmatch": ms_joint, "ms_per_lidar_only_scanmatch": ms_lidar,
            "statistic": "median of %d calls (max over ranks)" % steps, "ms_worst_call": [worst_lidar, worst_joint],
@@ -375,30 +512,24 @@ def joint_stereo_leg(pkg, synth, distmod, dist, rank, world, ctx, opts, torch, n
     return res
 
 
-def pose_graph_leg(pkg, synth, distmod, dist, rank, world, local_rank, torch, np, lm_iters, with_cpu):
+def pose_graph_leg(pkg, synth, distmod, dist, rank, world, local_rank, comm, np, lm_iters, with_cpu):
     """BASELINE config 4: SE(3) pose-graph LM, 5 000 keyframes / 4 999 odometry + 20 000 loop
-    edges, fp64.  Edges are sharded across the ranks; every LM iteration all-reduces the block
-    system [H blocks | b | chi2] over RCCL, the damped PCG solve is replicated."""
+    edges, fp64, run until the solver's own stopping rule ends it (limit `lm_iters`).  Edges are sharded
+    across the ranks; every linearisation all-reduces the block system [H blocks | b | chi2] with the
+    library's RCCL communicator on the solver's stream, the damped solve is replicated."""
     g = synth.make_pose_graph()
     pg = pkg.PoseGraph(local_rank)
     pg.set_graph(g["init"], g["ij"], g["meas"], g["info"])
     ne = len(g["ij"])
     nbytes = 0
-    if dist is not None:
-        sysbuf = torch.zeros(pg.system_doubles(), dtype=torch.float64, device="cuda")
-        base = sysbuf.data_ptr()
-
-        def allreduce(ptr, count):
-            off = (ptr - base) // 8
-            dist.all_reduce(sysbuf[off:off + count], op=dist.ReduceOp.SUM)
-            torch.cuda.synchronize()
-        b, e = distmod.shard_range(ne, rank, world)
-        pg.set_shard(b, e, allreduce=allreduce, system_tensor=sysbuf)
-        nbytes = sysbuf.numel() * 8
+    b, e = distmod.shard_range(ne, rank, world)
+    if world > 1:
+        pg.set_comm(comm, b, e)
+        nbytes = pg.system_doubles() * 8
     pg.optimize(1)  # warm-up (also builds the structures); restart from the initial estimate
     pg.set_graph(g["init"], g["ij"], g["meas"], g["info"])
-    if dist is not None:
-        pg.set_shard(b, e, allreduce=allreduce, system_tensor=sysbuf)
+    if world > 1:
+        pg.set_comm(comm, b, e)
     t0 = time.perf_counter()
     pg.build()  # graph upload + block structure (g2o: initializeOptimization), outside the timed LM
     build_ms = 1e3 * (time.perf_counter() - t0)
@@ -410,12 +541,16 @@ def pose_graph_leg(pkg, synth, distmod, dist, rank, world, local_rank, torch, np
     dt = time.perf_counter() - t0
     (_,), tmax = distmod.aggregate(dist, [0.0], dt)
     st = pg.last_stats
+    est = pg.poses()
+    err = np.linalg.norm(est[:, :3] - g["gt"][:, :3], axis=1)
     res = {"lm_iters_per_s": iters / tmax, "lm_iterations": iters, "lm_trials": st.lm_trials,
-           "cg_iterations": st.cg_iterations, "chi2_initial": st.chi2_initial, "chi2_final": st.chi2_final,
-           "keyframes": len(g["init"]), "edges": ne, "dtype": "f64", "n_gpus": world,
-           "graph_build_ms": build_ms,
-           "allreduce_bytes_per_lm_iteration": nbytes,
-           "parallelism": "edges sharded over %d GPU(s), RCCL all-reduce of the block system, replicated PCG" % world}
+           "solver_iterations": st.cg_iterations, "chi2_initial": st.chi2_initial, "chi2_final": st.chi2_final,
+           "seconds": tmax, "keyframes": len(g["init"]), "edges": ne, "dtype": "f64", "n_gpus": world,
+           "graph_build_ms": build_ms, "gpu_ms_total": st.gpu_ms_total,
+           "position_err_vs_ground_truth_m": {"mean": float(err.mean()), "max": float(err.max())},
+           "allreduce_bytes_per_linearisation": nbytes,
+           "parallelism": "edges sharded over %d GPU(s), ncclAllReduce of the block system on the solver's stream, "
+                          "replicated damped solve" % world}
     pg.close()
     if with_cpu and rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -429,58 +564,59 @@ def pose_graph_leg(pkg, synth, distmod, dist, rank, world, local_rank, torch, np
     return res
 
 
-def single_scan_leg(ctx, pr, opts, steps):
-    """Latency view of the same path: ONE 115 200-point scan in flight (rank 0, after the
-    timed region): wall time per scanMatchScan loop and the sweep kernel on its own."""
-    ctx.scan_set(pr["corner"], pr["surf"])
-    for _ in range(3):
-        ctx.run(pr["init_pose"], opts)
+def single_scan_leg(ctx, scan, init, opts, steps):
+    """Latency view of the same path: ONE 115 200-point scan in flight (rank 0, after the timed region;
+    the map is the same surround): wall time per scanMatchScan loop and the sweep kernel on its own."""
+    qc, qs = scan
+    ctx.scan_set(qc, qs)
+    for _ in range(5):
+        ctx.run(init, opts)
     t0 = time.perf_counter()
     pt = 0
     sw_ms = 0.0
     sw_n = 0
     for _ in range(steps):
-        status, pose, st = ctx.run(pr["init_pose"], opts)
+        status, pose, st = ctx.run(init, opts)
         pt += st.point_residuals
         sw_ms += st.gpu_ms_sweep
         sw_n += st.sweep_launches
     dt = time.perf_counter() - t0
     avg = sw_ms / max(1, sw_n)
-    n = len(pr["corner"]) + len(pr["surf"])
     # PCIe-inclusive: the caller hands over HOST clouds on every call (lslam_scanmatch_scan:
     # pack + Morton order + H2D, then the loop); never the headline value
     t1 = time.perf_counter()
     pt_h = 0
     for _ in range(steps):
-        status, pose, st2 = ctx.scanmatch_scan(pr["corner"], pr["surf"], pr["init_pose"], opts)
+        status, pose, st2 = ctx.scanmatch_scan(qc, qs, init, opts)
         pt_h += st2.point_residuals
     dth = time.perf_counter() - t1
     return {"value": pt / dt, "unit": "point-residuals/s", "ms_per_scanmatch": 1e3 * dt / steps,
             "host_buffers_value": pt_h / dth, "host_buffers_ms_per_scanmatch": 1e3 * dth / steps,
-            "gn_iterations": st.iterations, "sweep_kernel_ms": avg,
+            "gn_iterations": st.iterations, "sweep_kernel_ms": avg, "scan_points": int(len(qc) + len(qs)),
+            "sweep_us_per_full_scan": 1e3 * sw_ms * (len(qc) + len(qs)) / max(1, pt),
             # algorithmic bytes of the points actually processed / time of ALL sweep launches (the one
             # trailing launch per call that finds the loop finished costs a few microseconds)
             "roofline_frac": ALG_BYTES_PER_POINT_RESIDUAL * pt / (sw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sw_ms > 0 else None}
 
 
-def mapping_frame_leg(pkg, synth, ctx, pr, opts, np, with_cpu, rings=64):
+def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, rings=64):
     """One LaserMapping frame end to end on the device (SURVEY 8f n1/n2 around the hot path), per step:
-    extractFeatures on the 64x1800 sweep, VoxelGrid of the features (LaserMatcher.cpp:289-301, leaf
+    extractFeatures on the full-resolution sweep, VoxelGrid of the features (LaserMatcher.cpp:289-301, leaf
     1.0 = the reference default), FeatureMap::update, surround -> kd-trees, scanMatchScan,
-    addFeatureCloud -- next to the oracle doing the same steps on one host core (one frame)."""
-    def xyzi(a):
-        o = np.zeros((len(a), 4), np.float32)
-        o[:, :3] = a[:, :3]
-        return o
-    _, _, gt, cloud, ranges = synth.make_scan(pr["world"], rings, 1800, gt_pose=pr["gt_pose"], seed=4321, full=True)
-    fm = pkg.FeatureMap(ctx, 21, 11, 21)
+    addFeatureCloud -- next to the oracle doing the same steps on one host core (one frame).  The map is
+    the active area of the 10k-frame voxel map (both sides load the same downloaded surround)."""
+    sur_c, sur_s = surround
+    gt = np.asarray(gt, np.float64)
+    _, _, cloud, ranges = lidar.scan(gt, rings, 1800, seed=4321, full=True)
+    fm = pkg.FeatureMap(ctx, 21, 21, 11)
     fm.setup_filter_size(0.2, 0.4, 0.6)
-    fm.update(gt[3:])
-    fm.add_feature_cloud(xyzi(pr["map_corner"]), xyzi(pr["map_surf"]), np.eye(4, dtype=np.float32))
+    fm.update(gt[3:].astype(np.float32))
+    fm.add_feature_cloud(sur_c, sur_s, np.eye(4, dtype=np.float32))
     R, t = synth.pose_to_Rt(gt)
     T = np.eye(4, dtype=np.float32)
     T[:3, :3], T[:3, 3] = R, t
     init = synth.perturb_pose(gt, seed=77, dt=0.1, dr_deg=0.5)
+    gt32 = gt.astype(np.float32)
     steps = ("extract_features", "voxel_grid", "update", "surround_to_map", "scan_match", "add_feature_cloud")
     acc = {k: [] for k in steps}
     frames = 6
@@ -491,7 +627,7 @@ def mapping_frame_leg(pkg, synth, ctx, pr, opts, np, with_cpu, rings=64):
         t1 = time.perf_counter()
         dc, ds = pkg.voxel_grid(ctx, feat["less_sharp"], 1.0), pkg.voxel_grid(ctx, feat["less_flat"], 1.0)
         t2 = time.perf_counter()
-        fm.update(gt[3:])
+        fm.update(gt[3:].astype(np.float32))
         t3 = time.perf_counter()
         fm.surround_to_map()
         t4 = time.perf_counter()
@@ -514,20 +650,20 @@ def mapping_frame_leg(pkg, synth, ctx, pr, opts, np, with_cpu, rings=64):
            "sweep_points": int(len(cloud)), "features": {k: int(len(v)) for k, v in feat.items()},
            "scan_points_after_voxel_grid": int(len(dc) + len(ds)), "map_points": fm.info()["n_corner"] + fm.info()["n_surf"],
            "scan_match_iterations": int(st.iterations),
-           "pose_err_vs_ground_truth_m": float(np.abs(pose[3:] - gt[3:]).max())}
+           "pose_err_vs_ground_truth_m": float(np.abs(pose[3:] - gt[3:].astype(np.float32)).max())}
     if with_cpu:
         from oracle_lib import Oracle
         o = Oracle(native=True)
-        ofm = o.feature_map(21, 11, 21)
+        ofm = o.feature_map(21, 21, 11)
         ofm.setup_filter_size(0.2, 0.4, 0.6)
-        ofm.update(gt[3:])
-        ofm.add_feature_cloud(xyzi(pr["map_corner"]), xyzi(pr["map_surf"]), np.eye(4, dtype=np.float32))
+        ofm.update(gt[3:].astype(np.float32))
+        ofm.add_feature_cloud(sur_c, sur_s, np.eye(4, dtype=np.float32))
         t0 = time.perf_counter()
         ofeat = o.extract_features(cloud, ranges)
         t1 = time.perf_counter()
         odc, ods = o.voxel_grid(ofeat["less_sharp"], 1.0), o.voxel_grid(ofeat["less_flat"], 1.0)
         t2 = time.perf_counter()
-        ofm.update(gt[3:])
+        ofm.update(gt[3:].astype(np.float32))
         t3 = time.perf_counter()
         oc, os_ = ofm.get_surround_feature()
         t4 = time.perf_counter()
@@ -660,36 +796,39 @@ def sweep_pipeline_threads(pkg, synth, rings, np, lo, hi, raws):
             "travelled_m": float(np.linalg.norm(out[-1][:3, 3]))}
 
 
-def cpu_baseline(pr, repeats, gpu_pose, np):
+def cpu_baseline(surround, scans, inits, gpu_poses, n_scans, np):
     """The oracle (port of the reference's single-threaded path, -O3 -march=native
-    -ffp-contract=off) on the SAME map and scan: full scanMatchScan calls including
-    the per-call kd-tree rebuild (quirk Q4)."""
+    -ffp-contract=off) on a bounded sample of the SAME workload: the first `n_scans` scans of the step
+    against the same map (the surround the timed region used), full scanMatchScan calls including the
+    per-call kd-tree rebuild (quirk Q4), one core -- the reference's hot path is single-threaded."""
     from oracle_lib import Oracle
     o = Oracle(native=True)
+    map_c, map_s = surround
     t0 = time.perf_counter()
     pt = 0
     t_build = t_sweep = 0.0
     its = 0
-    for _ in range(repeats):
-        ok, pose, st = o.scanmatch_scan(pr["map_corner"], pr["map_surf"], pr["corner"], pr["surf"],
-                                        pr["init_pose"])
+    dpos, drot = 0.0, 0.0
+    for k in range(n_scans):
+        ok, pose, st = o.scanmatch_scan(map_c, map_s, scans[k][0], scans[k][1], inits[k])
         pt += st.point_residuals
         t_build += st.t_build
         t_sweep += st.t_sweep
         its += st.iterations
+        dpos = max(dpos, float(np.abs(pose[3:] - gpu_poses[k][3:]).max()))
+        drot = max(drot, float(np.abs(pose[:3] - gpu_poses[k][:3]).max()))
     dt = time.perf_counter() - t0
     # SURVEY 8d (2): the same loop with the sweep spread over all host cores (OpenMP) -- a generous
     # upper bound for a CPU, NOT what the reference does (its hot path is one thread)
     all_cores = None
     try:
         oo = Oracle(native="omp")
-        oo.scanmatch_scan(pr["map_corner"], pr["map_surf"], pr["corner"], pr["surf"], pr["init_pose"])  # threads up
+        oo.scanmatch_scan(map_c, map_s, scans[0][0], scans[0][1], inits[0])  # threads up
         t1 = time.perf_counter()
-        ok2, pose2, st2 = oo.scanmatch_scan(pr["map_corner"], pr["map_surf"], pr["corner"], pr["surf"], pr["init_pose"])
+        ok2, pose2, st2 = oo.scanmatch_scan(map_c, map_s, scans[0][0], scans[0][1], inits[0])
         dt2 = time.perf_counter() - t1
         all_cores = {"value": st2.point_residuals / dt2, "sweep_only_value": st2.point_residuals / st2.t_sweep if st2.t_sweep > 0 else None,
-                     "cores": os.cpu_count(), "kind": "port, OpenMP over the scan points -- not reference behaviour",
-                     "pose_diff_vs_single_thread_m": float(np.abs(pose2[3:] - pose[3:]).max())}
+                     "cores": os.cpu_count(), "kind": "port, OpenMP over the scan points -- not reference behaviour"}
     except Exception as e:
         all_cores = {"error": repr(e)}
     return {
@@ -698,15 +837,15 @@ def cpu_baseline(pr, repeats, gpu_pose, np):
         "unit": "point-residuals/s",
         "cores": 1,
         "kind": "port",
-        "sample": "%d full scanMatchScan calls on the same map+scan (%d points, %d GN iterations each), "
-                  "kd-tree rebuilt per call as the reference does" % (repeats, len(pr["corner"]) + len(pr["surf"]), its // max(1, repeats)),
+        "sample": "%d of the step's scans: full scanMatchScan calls against the same %d-point map (%d GN iterations "
+                  "each on average), kd-tree rebuilt per call as the reference does" % (n_scans, len(map_c) + len(map_s), its // max(1, n_scans)),
         "seconds": dt,
         "sweep_only_value": pt / t_sweep if t_sweep > 0 else None,
-        "tree_build_s_per_call": t_build / repeats,
+        "tree_build_s_per_call": t_build / n_scans,
         "host_cpus": os.cpu_count(),
-        "pose_diff_gpu_vs_cpu_m": float(np.abs(pose[3:] - gpu_pose[3:]).max()),
-        "pose_diff_gpu_vs_cpu_rad": float(np.abs(pose[:3] - gpu_pose[:3]).max()),
-        "iterations": its // max(1, repeats),
+        "pose_diff_gpu_vs_cpu_m": dpos,
+        "pose_diff_gpu_vs_cpu_rad": drot,
+        "iterations": its // max(1, n_scans),
     }
 
 

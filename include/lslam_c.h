@@ -52,7 +52,10 @@ typedef enum {
   LSLAM_ERR_HIP = -2,         /* HIP runtime error / no device (see lslam_last_error) */
   LSLAM_ERR_NO_MAP = -3,      /* scan match requested before lslam_map_set */
   LSLAM_ERR_NO_SCAN = -4,     /* lslam_scanmatch_run before lslam_scan_set */
-  LSLAM_ERR_TREE_DEPTH = -5   /* kd-tree deeper than the device traversal stack */
+  LSLAM_ERR_TREE_DEPTH = -5,  /* kd-tree deeper than the device traversal stack */
+  LSLAM_ERR_TREE_BUILD = -6,  /* the device kd-tree builder hit a structure limit (lslam_last_error says which);
+                                 nothing is rebuilt on the host -- the call fails */
+  LSLAM_ERR_COMM = -7         /* RCCL communicator error (lslam_comm_*) */
 } lslam_status;
 
 /* Mirrors ScanMatch's constructor defaults and setters (ScanMatch.cpp:21-33,
@@ -68,6 +71,9 @@ typedef struct {
   /* backend knobs (no reference counterpart) */
   int32_t jtj_mode;  /* 0: VALU + wave-shuffle reduction of J^T J; 1: MFMA f32 16x16x4 */
   int32_t profile;   /* 1: bracket every sweep launch with HIP events (stats.gpu_ms_sweep) */
+  int32_t scans_in_flight; /* lslam_scanmatch_run_batch: resident scans matched together by one sequence of
+                              launches; more scans are taken in chunks of this size (0: up to 32) */
+  int32_t reserved;
 } lslam_opts;
 
 /* Per-call statistics (the counters the reference prints, ScanMatch.cpp:35-40,
@@ -95,7 +101,8 @@ typedef struct {
   int32_t depth_corner, depth_surf;  /* kd-tree depths */
   float build_ms;                    /* tree build wall time inside lslam_map_set */
   float upload_ms;                   /* H2D copy time inside lslam_map_set */
-  int32_t built_on_device;           /* 1 if the trees were built by HIP kernels */
+  int32_t built_on_device;           /* always 1: the HIP builder is the only one */
+  int32_t build_attempts;            /* node-slot array sizes tried (1: the first, 2n/3 slots, fitted) */
 } lslam_map_info;
 
 /* ---- lifecycle --------------------------------------------------------- */
@@ -368,6 +375,28 @@ typedef struct {
  * completed when it returns. */
 typedef void (*lslam_allreduce_fn)(void *user, double *buf, size_t count);
 
+/* ---- collectives: RCCL inside the library (north star: "RCCL all-reduce over xGMI of
+ * the block Hessian") ------------------------------------------------------------------------
+ * One process per GPU.  Rank 0 makes an id (lslam_comm_unique_id), the host program carries its 128
+ * bytes to the other ranks (MPI, a file, torch.distributed ...), every rank creates a communicator
+ * on its device and attaches it to a context (lslam_ctx_set_comm) and / or a pose graph
+ * (lslam_pg_set_comm).  The sharded paths then enqueue ncclAllReduce on the library's own stream
+ * between the producing and the consuming kernel: no host round trip per iteration.  librccl is
+ * dlopen'ed on first use.  The lslam_allreduce_fn callbacks below remain for hosts that bring their
+ * own transport (and for tests on one GPU, where RCCL refuses two ranks on one device). */
+#define LSLAM_COMM_ID_BYTES 128
+typedef struct lslam_comm lslam_comm;
+int lslam_comm_unique_id(uint8_t id[LSLAM_COMM_ID_BYTES]);
+int lslam_comm_create(int device, const uint8_t id[LSLAM_COMM_ID_BYTES], int32_t rank, int32_t world,
+                      lslam_comm **out);
+void lslam_comm_destroy(lslam_comm *comm);
+int lslam_comm_info(const lslam_comm *comm, int32_t *rank, int32_t *world);
+/* In-place SUM of `count` doubles at DEVICE address buf over all ranks, enqueued on hip_stream. */
+int lslam_comm_allreduce_f64(lslam_comm *comm, double *device_buf, size_t count, void *hip_stream);
+/* Attach (or, with NULL, detach) a communicator: lslam_scanmatch_run_sharded then needs no callback.
+ * The communicator must outlive its use by the context. */
+int lslam_ctx_set_comm(lslam_ctx *ctx, lslam_comm *comm);
+
 /* ONE scan's points sharded over the ranks (the reference has no such seam: it is the
  * data-parallel form of ScanMatch.cpp:97-209 -- every point's row is independent given the
  * pose, the only coupling is the sum A^T A, A^T b and the counters).  Each rank holds its
@@ -376,7 +405,9 @@ typedef void (*lslam_allreduce_fn)(void *user, double *buf, size_t count);
  * line matches, plane matches, score, spare) are copied to xchg32 (DEVICE, 32 doubles, caller
  * owned -- e.g. a torch tensor the hook can all-reduce over RCCL), fn sums them over the
  * ranks in place, and every rank runs the same 6x6 solve on the same numbers.  The summation
- * order differs from the single-GPU loop: poses agree to ~1e-6, not bit for bit. */
+ * order differs from the single-GPU loop: poses agree to ~1e-6, not bit for bit.
+ * With a communicator attached (lslam_ctx_set_comm) fn and xchg32 may be NULL: the sums are then
+ * all-reduced by RCCL on the library's stream and the whole loop stays device-resident. */
 int lslam_scanmatch_run_sharded(lslam_ctx *ctx, float pose[6], const lslam_opts *opts,
                                 lslam_allreduce_fn fn, void *user, double *xchg32,
                                 lslam_stats *stats);
@@ -429,6 +460,8 @@ const char *lslam_pg_last_error(void);
  * caller-owned DEVICE buffer of lslam_pg_system_doubles() doubles to assemble into. */
 int lslam_pg_set_shard(lslam_pg *pg, int32_t e_begin, int32_t e_end, lslam_allreduce_fn fn,
                        void *user, double *system_buf);
+/* The same with the library's own RCCL communicator instead of a callback (NULL detaches). */
+int lslam_pg_set_comm(lslam_pg *pg, lslam_comm *comm);
 size_t lslam_pg_system_doubles(const lslam_pg *pg);
 int32_t lslam_pg_num_offdiag(const lslam_pg *pg);
 /* SolverG2O::optimize (solver_g2o.cpp:79-95): up to max_iters LM iterations. */

@@ -59,3 +59,22 @@ def test_shard_range_partitions(n, world):
     assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
     sizes = [e - b for b, e in parts]
     assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` outside a launcher starts 2 ranks itself (before anything touches the GPU)
+    and rank 0 reports n_gpus == 2; under a launcher whose world size differs from --gpus it refuses."""
+    import json
+    import subprocess
+    env = dict(os.environ, LSLAM_BENCH_DRY_RUN="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["ranks_counted"] == 2
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"],
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "--gpus 4" in bad.stderr

@@ -714,3 +714,82 @@ def test_posegraph_full_size_properties(pkg, synth):
     assert err1 < err0  # ten iterations do not finish the job on 48 m of drift; they must not make it worse
     assert np.array_equal(runs[0][3].view(np.int64), runs[1][3].view(np.int64)) and runs[0][2] == runs[1][2]
     assert np.allclose(np.linalg.norm(poses[:, 3:], axis=1), 1.0, atol=1e-12)  # unit quaternions
+
+
+# ---- the device builder is the only builder: its structure limits fail loudly -----------------
+def _fresh_ctx(pkg):
+    return pkg.Context(0)
+
+
+def test_tree_build_retries_with_more_node_slots(pkg, oracle, monkeypatch):
+    """Limit 1 (node-slot array too small) is resolved by the retry with a larger array, and the
+    tree that results is still nanoflann's."""
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-30, 30, (30000, 3)).astype(np.float32)
+    monkeypatch.setenv("LSLAM_DEBUG_NODE_CAP_DIV", "4")  # first attempt gets a quarter of its slots
+    c = _fresh_ctx(pkg)
+    try:
+        c.map_set(pts, pts)
+        info = c.map_info()
+        assert info.build_attempts >= 2 and info.built_on_device == 1
+        monkeypatch.delenv("LSLAM_DEBUG_NODE_CAP_DIV")
+        tree = oracle.kdtree(pts)
+        q = pts[:2000, :3] + rng.normal(0, 0.3, (2000, 3)).astype(np.float32)
+        gi, gd = c.knn5(1, q)
+        oi, od = tree.knn(q, 5)
+        assert np.array_equal(gi, oi) and np.array_equal(bits(gd), bits(od))
+    finally:
+        c.close()
+
+
+def test_tree_build_node_limit_fails_loudly(pkg, monkeypatch):
+    rng = np.random.default_rng(4)
+    pts = rng.uniform(-30, 30, (30000, 3)).astype(np.float32)
+    monkeypatch.setenv("LSLAM_DEBUG_NODE_CAP_DIV", "100000")  # no attempt can fit
+    c = _fresh_ctx(pkg)
+    try:
+        with pytest.raises(pkg.LslamError) as ei:
+            c.map_set(pts, pts)
+        assert ei.value.code == pkg.Status.ERR_TREE_BUILD and "limit 1" in str(ei.value)
+        monkeypatch.delenv("LSLAM_DEBUG_NODE_CAP_DIV")
+        c.map_set(pts, pts)  # the context is still usable
+        assert c.map_info().n_surf == len(pts)
+    finally:
+        c.close()
+
+
+def test_tree_build_queue_watchdog_reports(pkg, monkeypatch):
+    """Limit 2: the watchdog of the persistent phase-A kernel, forced by a zero spin budget."""
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-30, 30, (40000, 3)).astype(np.float32)  # <= 49152 points: the phase-A path
+    monkeypatch.setenv("LSLAM_DEBUG_SPIN_LIMIT", "0")
+    c = _fresh_ctx(pkg)
+    try:
+        with pytest.raises(pkg.LslamError) as ei:
+            c.map_set(pts, pts)
+        assert ei.value.code == pkg.Status.ERR_TREE_BUILD and "limit 2" in str(ei.value)
+        monkeypatch.delenv("LSLAM_DEBUG_SPIN_LIMIT")
+        c.map_set(pts, pts)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("n_chain", [100, 8000])
+def test_tree_deeper_than_traversal_stack_is_refused(pkg, n_chain):
+    """Limits 3 / 4: a cloud whose nanoflann tree is deeper than the 64-level device stack (every
+    middleSplit_ peels two points off a geometric progression) is refused with TREE_DEPTH -- by the
+    wavefront-local builder for the small cloud, by the level driver / node queue for the big one."""
+    k = np.arange(200)
+    chain = np.stack([1000.0 * 1.5 ** -k, np.zeros(200), np.zeros(200)], 1)
+    rng = np.random.default_rng(6)
+    # the big variant hangs a few thousand points on every chain node so that the deep nodes stay big
+    pts = chain if n_chain == 100 else np.concatenate([chain[i] + rng.uniform(0, 1e-3 * chain[i, 0], (n_chain // 20, 3))
+                                                          for i in range(200)])
+    pts = np.ascontiguousarray(pts, np.float32)
+    c = _fresh_ctx(pkg)
+    try:
+        with pytest.raises(pkg.LslamError) as ei:
+            c.map_set(pts, pts)
+        assert ei.value.code == pkg.Status.ERR_TREE_DEPTH
+    finally:
+        c.close()

@@ -13,7 +13,7 @@ The directory name contains a hyphen, so import it with
 """
 from .capi import (LslamError, LslamOpts, LslamStats, LslamMapInfo, LslamStereoCam, Status, lib_path, load_library,
                    build_library)
-from .scan_match import Context, ScanMatch
+from .scan_match import Comm, Context, ScanMatch
 from .pose_graph import PoseGraph
 from .feature_map import FeatureMap, voxel_grid
 from . import scan_registration
@@ -21,5 +21,5 @@ from .loop_closure import KeyFrame, Loop, LoopDetector
 from .graph import Graph, KeyframeUpdater
 from .pipeline import LaserOdometry, LaserMapping
 
-__all__ = ["Context", "ScanMatch", "PoseGraph", "FeatureMap", "voxel_grid", "scan_registration", "KeyFrame", "Loop", "LoopDetector", "Graph", "KeyframeUpdater", "LaserOdometry", "LaserMapping", "LslamError", "LslamOpts", "LslamStats", "LslamMapInfo", "LslamStereoCam",
+__all__ = ["Comm", "Context", "ScanMatch", "PoseGraph", "FeatureMap", "voxel_grid", "scan_registration", "KeyFrame", "Loop", "LoopDetector", "Graph", "KeyframeUpdater", "LaserOdometry", "LaserMapping", "LslamError", "LslamOpts", "LslamStats", "LslamMapInfo", "LslamStereoCam",
            "Status", "lib_path", "load_library", "build_library"]

@@ -31,6 +31,8 @@ class Status(enum.IntEnum):
     ERR_NO_MAP = -3
     ERR_NO_SCAN = -4
     ERR_TREE_DEPTH = -5
+    ERR_TREE_BUILD = -6
+    ERR_COMM = -7
 
 
 class LslamOpts(C.Structure):
@@ -44,6 +46,8 @@ class LslamOpts(C.Structure):
         ("match_percentage_threshold", C.c_double),
         ("jtj_mode", C.c_int32),
         ("profile", C.c_int32),
+        ("scans_in_flight", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -93,6 +97,7 @@ class LslamMapInfo(C.Structure):
         ("build_ms", C.c_float),
         ("upload_ms", C.c_float),
         ("built_on_device", C.c_int32),
+        ("build_attempts", C.c_int32),
     ]
 
 
@@ -196,7 +201,16 @@ SYMBOLS = {
     "lslam_pg_get_poses": (C.c_int, [C.c_void_p, c_double_p]),
     "lslam_pg_linearize": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_int32_p, c_double_p, c_double_p]),
     "lslam_pg_solve": (C.c_int, [C.c_void_p, C.c_double, c_double_p, c_int32_p]),
+    "lslam_comm_unique_id": (C.c_int, [c_uint8_p]),
+    "lslam_comm_create": (C.c_int, [C.c_int, c_uint8_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "lslam_comm_destroy": (None, [C.c_void_p]),
+    "lslam_comm_info": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p]),
+    "lslam_comm_allreduce_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "lslam_ctx_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lslam_pg_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
+
+COMM_ID_BYTES = 128
 
 
 def lib_path():

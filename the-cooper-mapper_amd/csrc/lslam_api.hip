@@ -117,6 +117,8 @@ struct lslam_ctx {
   DevBuf<uint32_t> stack_ovf;  // only allocated for trees deeper than KD_STACK_LDS+1
   DevBuf<int32_t> prev_nb;     // neighbours of the previous sweep, per resident scan point
   bool prev_valid = false;
+  lslam_comm *comm = nullptr;  // RCCL communicator of the sharded-points path (not owned)
+  DevBuf<double> xchg;         // its exchange buffer
   GNState *d_state = nullptr;   // [state_cap]
   GNState *h_state = nullptr;   // pinned, [state_cap]
   int32_t state_cap = 0;
@@ -195,37 +197,6 @@ void morton_order(std::vector<float4> &pts) {
     out[i] = v;
   }
   pts.swap(out);
-}
-
-int upload_tree(lslam_ctx *ctx, DevTree &dt, const HostTree &ht, const std::vector<float4> &cloud) {
-  const size_t n = cloud.size();
-  std::vector<float4> perm(n);
-  for (size_t i = 0; i < n; ++i) {
-    const int32_t oi = ht.vind[i];
-    float4 v = cloud[(size_t)oi];
-    v.w = __builtin_bit_cast(float, oi);
-    perm[i] = v;
-  }
-  HIP_TRY(dt.nodes.reserve(ht.nodes.size() ? ht.nodes.size() : 1));
-  HIP_TRY(dt.pts.reserve(n ? n : 1));
-  if (!ht.nodes.empty())
-    HIP_TRY(hipMemcpyAsync(dt.nodes.p, ht.nodes.data(), ht.nodes.size() * sizeof(KdNode),
-                           hipMemcpyHostToDevice, ctx->stream));
-  if (n)
-    HIP_TRY(hipMemcpyAsync(dt.pts.p, perm.data(), n * sizeof(float4), hipMemcpyHostToDevice,
-                           ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));  // perm is a local
-  dt.view.nodes = dt.nodes.p;
-  dt.view.pts = dt.pts.p;
-  for (int d = 0; d < 3; ++d) {
-    dt.view.bb_lo[d] = ht.bb_lo[d];
-    dt.view.bb_hi[d] = ht.bb_hi[d];
-  }
-  dt.view.n_pts = (int32_t)n;
-  dt.view.n_nodes = (int32_t)ht.nodes.size();
-  dt.view.root_ref = ht.root_ref;
-  dt.depth = ht.depth;
-  return LSLAM_OK;
 }
 
 void init_state(GNState &s, const float pose[6]) {
@@ -308,6 +279,8 @@ void lslam_default_opts(lslam_opts *o) {
   o->match_percentage_threshold = 0.4;
   o->jtj_mode = 1;  // MFMA J^T J: measured >= the VALU path (profiles/), same sums to 1e-5
   o->profile = 0;
+  o->scans_in_flight = 0;
+  o->reserved = 0;
 }
 
 int lslam_ctx_create(int device, lslam_ctx **out) {
@@ -358,6 +331,7 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   ctx->ts.nodes.release(); ctx->ts.pts.release();
   ctx->cell_c.release(); ctx->cell_s.release(); ctx->views_c.release(); ctx->views_s.release();
   ctx->prev_nb.release();
+  ctx->xchg.release();
   ctx->q.release(); ctx->blocks.release(); ctx->probs.release(); ctx->partials.release(); ctx->stack_ovf.release();
   ctx->t_idx.release(); ctx->t_d2.release(); ctx->t_coeff.release(); ctx->t_flags.release();
   ctx->t_q.release(); ctx->t_small.release();
@@ -378,6 +352,12 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
 }
 
 void *lslam_stream(lslam_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int lslam_ctx_set_comm(lslam_ctx *ctx, lslam_comm *comm) {
+  if (!ctx) return LSLAM_ERR_INVALID;
+  ctx->comm = comm;
+  return LSLAM_OK;
+}
 
 // Parity tap: download a resident tree (inner nodes as 4 words each, permuted points).
 int lslam_debug_tree_dump(lslam_ctx *ctx, int which, uint32_t *nodes_out, size_t node_cap,
@@ -443,13 +423,30 @@ int lslam_debug_sweep_clocks(lslam_ctx *ctx, const float pose[6], int32_t jtj_mo
 namespace {
 // Body of lslam_map_set.  dev_corner/dev_surf non-null: the clouds are already in HBM as
 // float4 {x, y, z, bitcast(index)} (map maintenance hands the surround over without a host hop);
-// corner/surf are then ignored unless the device build has to fall back to the host builder.
+// corner/surf are then ignored.  There is one builder, the device one (lslam_treebuild.hip): when it
+// reports a structure limit the call FAILS with the reason -- nothing is rebuilt elsewhere.
+//   1  node-slot array too small: retried here with 8n/3 and 8n slots (8n always fits: a group of
+//      eight slots holds at least one inner node and a tree of n points has fewer than n of them)
+//   2  watchdog of the persistent phase-A kernel (an idle workgroup saw unfinished nodes for ~1 s):
+//      cannot happen by construction -- a workgroup that holds a node never waits for another one --
+//      it only bounds a hang if that reasoning were ever broken; reported as LSLAM_ERR_TREE_BUILD
+//   3  more levels of >1536-point nodes than the level driver / node queue is sized for: the tree is
+//      deeper than the 64 levels the device traversal stack holds, i.e. LSLAM_ERR_TREE_DEPTH anyway
+//   4  more than 64 pending siblings on one path of a wavefront-local subtree: likewise too deep
+int tree_build_failed(int limit, size_t n_points) {
+  if (limit == 3 || limit == 4) {
+    set_err("kd-tree of %zu points is deeper than the device traversal stack (%d levels)", n_points, KD_STACK_MAX);
+    return LSLAM_ERR_TREE_DEPTH;
+  }
+  set_err("device kd-tree build of %zu points hit structure limit %d (1 node slots, 2 queue watchdog)", n_points, limit);
+  return LSLAM_ERR_TREE_BUILD;
+}
+
 int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void *surf, size_t n_surf,
                  size_t stride_bytes, const float4 *dev_corner, const float4 *dev_surf) {
   int rc = check_ctx(ctx);
   if (rc) return rc;
   const bool from_dev = dev_corner != nullptr || dev_surf != nullptr;
-  std::vector<float4> dl_c, dl_s;  // host copies of device clouds, only for the host-builder path
   if (!from_dev && (stride_bytes < 12 || (stride_bytes & 3) || (n_corner && !corner) || (n_surf && !surf))) {
     set_err("bad cloud arguments (stride %zu)", stride_bytes);
     return LSLAM_ERR_INVALID;
@@ -462,13 +459,10 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
   ctx->cube_mode = false;
   ctx->prev_valid = false;
   const double t0 = now_ms();
-  std::vector<float4> cc, cs;
-  static const bool host_tree = std::getenv("LSLAM_HOST_TREE") != nullptr;  // A/B and fallback
   double t1 = t0, t2 = t0;
   size_t nodes_c = 0, nodes_s = 0;
-  int built_on_device = 0;
-  bool need_host = host_tree;
-  if (!host_tree) {
+  int attempts_used = 1;
+  {
     // ---- device build: upload {x,y,z,index}, build both trees in HBM --------------------
     t1 = now_ms();
     DevTree *trees[2] = {&ctx->tc, &ctx->ts};
@@ -494,7 +488,9 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
       size_t n_leaves = 0;
       for (int attempt = dt.cap_attempt; attempt < 3; ++attempt) {
         const size_t mult[3] = {2, 8, 24};
-        const size_t cap = ((mult[attempt] * n / 3 + 64) + 7) & ~(size_t)7;
+        size_t cap = ((mult[attempt] * n / 3 + 64) + 7) & ~(size_t)7;
+        if (const char *dv = std::getenv("LSLAM_DEBUG_NODE_CAP_DIV"))  // tests: force the retry / failure paths
+          cap = std::max<size_t>(16, (cap / (size_t)std::max(1, atoi(dv))) & ~(size_t)7);
         if ((errs[k] = dt.nodes.reserve(cap)) != hipSuccess) return;
         if (n && from_dev) {
           errs[k] = hipMemcpyAsync(dt.pts.p, dev_src[k], n * sizeof(float4), hipMemcpyDeviceToDevice, st);
@@ -545,44 +541,10 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
     }
     for (int k = 0; k < 2; ++k) {
       HIP_TRY(errs[k]);
-      if (fb[k]) {
-        need_host = true;
-        if (std::getenv("LSLAM_DEBUG"))
-          fprintf(stderr, "[lslam] device kd-tree build of %zu points hit limit %d (1 nodes, 2 spin, 3 queue): "
-                          "host build instead\n", counts[k], fb[k]);
-      }
+      attempts_used = std::max(attempts_used, trees[k]->cap_attempt + 1);
+      if (fb[k]) return tree_build_failed(fb[k], counts[k]);
     }
     t2 = now_ms();
-    if (!need_host) built_on_device = 1;
-  }
-  if (need_host && from_dev) {  // bring the clouds to the host for the host builder
-    dl_c.resize(n_corner);
-    dl_s.resize(n_surf);
-    if (n_corner) HIP_TRY(hipMemcpyAsync(dl_c.data(), dev_corner, n_corner * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-    if (n_surf) HIP_TRY(hipMemcpyAsync(dl_s.data(), dev_surf, n_surf * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    corner = dl_c.data();
-    surf = dl_s.data();
-    stride_bytes = sizeof(float4);
-  }
-  if (need_host) {
-    HostTree hc, hs;
-    std::thread th([&] {
-      pack_cloud(corner, n_corner, stride_bytes, cc);
-      build_kdtree_host(reinterpret_cast<const float *>(cc.data()), n_corner, 4, hc);
-    });
-    pack_cloud(surf, n_surf, stride_bytes, cs);
-    build_kdtree_host(reinterpret_cast<const float *>(cs.data()), n_surf, 4, hs);
-    th.join();
-    t1 = now_ms();
-    rc = upload_tree(ctx, ctx->tc, hc, cc);
-    if (rc) return rc;
-    rc = upload_tree(ctx, ctx->ts, hs, cs);
-    if (rc) return rc;
-    t2 = now_ms();
-    nodes_c = hc.nodes.size() + hc.n_leaves;  // nanoflann's node count
-    nodes_s = hs.nodes.size() + hs.n_leaves;
-    built_on_device = 0;
   }
   if (ctx->tc.depth > KD_STACK_MAX || ctx->ts.depth > KD_STACK_MAX) {
     set_err("kd-tree depth %d/%d exceeds device stack %d", ctx->tc.depth, ctx->ts.depth, KD_STACK_MAX);
@@ -594,10 +556,10 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
   ctx->info.nodes_surf = (uint32_t)nodes_s;
   ctx->info.depth_corner = ctx->tc.depth;
   ctx->info.depth_surf = ctx->ts.depth;
-  // host build: [build | upload]; device build: [pack | upload + build]
-  ctx->info.build_ms = (float)(built_on_device ? (t2 - t1) : (t1 - t0));
-  ctx->info.upload_ms = (float)(built_on_device ? (t1 - t0) : (t2 - t1));
-  ctx->info.built_on_device = built_on_device;
+  ctx->info.build_ms = (float)(t2 - t1);   // [pack | upload + build]
+  ctx->info.upload_ms = (float)(t1 - t0);
+  ctx->info.built_on_device = 1;  // there is no other builder
+  ctx->info.build_attempts = attempts_used;
   ctx->have_map = true;
   return LSLAM_OK;
 }
@@ -635,10 +597,7 @@ int cubemap_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t nc, const 
     rc = build_cube_side_device(ctx, ctx->ts, d_surf, true, ns, roots_s, cells_s, cube_size, origin, dims, ctx->cell_s,
                                 ctx->views_s, ctx->gs, &ds, &nn_s, &fb);
   if (rc) return rc;
-  if (fb) {
-    set_err("device cube-tree build hit a structure limit (%d)", fb);
-    return LSLAM_ERR_INVALID;
-  }
+  if (fb) return tree_build_failed(fb, nc + ns);
   if (dc > KD_STACK_MAX || ds > KD_STACK_MAX) {
     set_err("kd-tree depth %d/%d exceeds device stack %d", dc, ds, KD_STACK_MAX);
     return LSLAM_ERR_TREE_DEPTH;
@@ -739,77 +698,21 @@ int build_cube_trees(lslam_ctx *ctx, const void *cloud, size_t n, size_t stride_
   std::vector<size_t> fill(first.begin(), first.end() - 1);
   for (size_t i = 0; i < n; ++i)
     if (cell_of[i] >= 0) sorted[fill[cell_of[i]]++] = pts[i];
-  static const bool host_tree = std::getenv("LSLAM_HOST_TREE") != nullptr;
-  if (!host_tree) {  // all cube trees at once on the device
-    std::vector<int32_t> roots_lr, cell_tree_dev(n_cells, -1);
-    for (size_t c = 0; c < n_cells; ++c) {
-      if (count[c] < 5) continue;  // FeatureMap.h:524,546
-      cell_tree_dev[c] = (int32_t)(roots_lr.size() / 2);
-      roots_lr.push_back((int32_t)first[c]);
-      roots_lr.push_back((int32_t)first[c + 1]);
-      for (int32_t k = 0; k < count[c]; ++k) sorted[first[c] + (size_t)k].w = __builtin_bit_cast(float, k);
-    }
-    int fallback = 0;
-    int rc = build_cube_side_device(ctx, dt, sorted.data(), false, sorted.size(), roots_lr, cell_tree_dev, cube_size, origin,
-                                    dims, cells_d, views_d, grid, max_depth, n_nodes, &fallback);
-    if (rc) return rc;
-    if (!fallback) {
-      ctx->cube_sides_on_device++;
-      return LSLAM_OK;
-    }
-    if (std::getenv("LSLAM_DEBUG")) fprintf(stderr, "[lslam] device cube-tree build hit limit %d: host build instead\n", fallback);
-  }
-  std::vector<int32_t> cell_tree(n_cells, -1);
-  std::vector<TreeView> views;
-  std::vector<KdNode> all_nodes;
-  std::vector<float4> all_pts;
-  std::vector<size_t> node_off, pts_off;
-  *max_depth = 0;
+  // all cube trees at once on the device
+  std::vector<int32_t> roots_lr, cell_tree_dev(n_cells, -1);
   for (size_t c = 0; c < n_cells; ++c) {
     if (count[c] < 5) continue;  // FeatureMap.h:524,546
-    HostTree ht;
-    build_kdtree_host(reinterpret_cast<const float *>(sorted.data() + first[c]), (size_t)count[c], 4, ht);
-    TreeView v{};
-    v.n_pts = count[c];
-    v.n_nodes = (int32_t)ht.nodes.size();
-    v.root_ref = ht.root_ref;
-    for (int d = 0; d < 3; ++d) { v.bb_lo[d] = ht.bb_lo[d]; v.bb_hi[d] = ht.bb_hi[d]; }
-    cell_tree[c] = (int32_t)views.size();
-    node_off.push_back(all_nodes.size());
-    pts_off.push_back(all_pts.size());
-    all_nodes.insert(all_nodes.end(), ht.nodes.begin(), ht.nodes.end());
-    while (all_nodes.size() & 7) all_nodes.push_back(KdNode{0.f, 0.f, KD_LEAF, KD_LEAF});  // keep lines aligned
-    for (int32_t k = 0; k < count[c]; ++k) {
-      float4 p = sorted[first[c] + (size_t)ht.vind[(size_t)k]];
-      p.w = __builtin_bit_cast(float, ht.vind[(size_t)k]);  // index inside the cube's cloud
-      all_pts.push_back(p);
-    }
-    views.push_back(v);
-    *max_depth = std::max(*max_depth, ht.depth);
+    cell_tree_dev[c] = (int32_t)(roots_lr.size() / 2);
+    roots_lr.push_back((int32_t)first[c]);
+    roots_lr.push_back((int32_t)first[c + 1]);
+    for (int32_t k = 0; k < count[c]; ++k) sorted[first[c] + (size_t)k].w = __builtin_bit_cast(float, k);
   }
-  HIP_TRY(dt.nodes.reserve(all_nodes.size() + 8));
-  HIP_TRY(dt.pts.reserve(all_pts.size() + 16));
-  HIP_TRY(cells_d.reserve(n_cells));
-  HIP_TRY(views_d.reserve(views.size() + 1));
-  for (size_t t = 0; t < views.size(); ++t) {
-    views[t].nodes = dt.nodes.p + node_off[t];
-    views[t].pts = dt.pts.p + pts_off[t];
-  }
-  if (!all_nodes.empty())
-    HIP_TRY(hipMemcpyAsync(dt.nodes.p, all_nodes.data(), all_nodes.size() * sizeof(KdNode), hipMemcpyHostToDevice, ctx->stream));
-  if (!all_pts.empty())
-    HIP_TRY(hipMemcpyAsync(dt.pts.p, all_pts.data(), all_pts.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(cells_d.p, cell_tree.data(), n_cells * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-  if (!views.empty())
-    HIP_TRY(hipMemcpyAsync(views_d.p, views.data(), views.size() * sizeof(TreeView), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  grid.cube_size = cube_size;
-  for (int d = 0; d < 3; ++d) { grid.origin[d] = origin[d]; grid.dims[d] = dims[d]; }
-  grid.cell_tree = cells_d.p;
-  grid.trees = views_d.p;
-  dt.depth = *max_depth;
-  dt.view = TreeView{};
-  *n_nodes = all_nodes.size();
+  int fallback = 0;
+  int rc = build_cube_side_device(ctx, dt, sorted.data(), false, sorted.size(), roots_lr, cell_tree_dev, cube_size, origin,
+                                  dims, cells_d, views_d, grid, max_depth, n_nodes, &fallback);
+  if (rc) return rc;
+  if (fallback) return tree_build_failed(fallback, sorted.size());
+  ctx->cube_sides_on_device++;
   return LSLAM_OK;
 }
 
@@ -990,7 +893,7 @@ namespace {
 // partials, hands the 32 fp64 sums to `fn` (sum over ranks, in place, on `xchg`) and then
 // every rank runs the same solve on the same numbers.
 int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_opts *opts_in,
-                   lslam_stats *stats, lslam_allreduce_fn fn, void *user, double *xchg) {
+                   lslam_stats *stats, lslam_allreduce_fn fn, void *user, double *xchg, bool use_comm = false) {
   int rc = check_ctx(ctx);
   if (rc) return rc;
   if (!poses || n_scans <= 0) {
@@ -1013,6 +916,10 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
   // ScanMatch.cpp:57-61 (variant C, FeatureMap::scanMatchScan, has no such guard)
   if (!ctx->cube_mode && (ctx->info.n_corner < 50 || ctx->info.n_surf < 100)) return fail_all(LSLAM_TOO_FEW_REF);
   const int max_it = o.max_iterations < 0 ? 0 : o.max_iterations;
+  // Every call starts cold: the neighbour lists a previous call left behind belong to another pose (or
+  // another scan) and must not bound this call's first sweep -- a real call on a new scan has none.
+  // From the second sweep on the bound comes from the first sweep of THIS loop.
+  ctx->prev_valid = false;
 
   for (int32_t p = 0; p < n_scans; ++p) {
     init_state(ctx->h_state[p], poses + 6 * p);
@@ -1022,9 +929,17 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
                          hipMemcpyHostToDevice, ctx->stream));
   SweepArgs sa;
   fill_sweep_args(ctx, sa);
-  // the production sweep keeps a shallow stack in LDS: it always gets the overflow area
-  HIP_TRY(ctx->stack_ovf.reserve(stack_ovf_words((size_t)sa.nb_total * SWEEP_BLOCK)));
-  sa.stack_ovf = ctx->stack_ovf.p;
+  // the production sweep keeps a shallow stack in LDS: it always gets the overflow area (sized per
+  // chunk below; the sharded path has one resident scan)
+  const bool sharded = fn != nullptr || use_comm;
+  if (sharded) {
+    HIP_TRY(ctx->stack_ovf.reserve(stack_ovf_words((size_t)sa.nb_total * SWEEP_BLOCK)));
+    sa.stack_ovf = ctx->stack_ovf.p;
+    if (!xchg) {  // the library's own exchange buffer
+      HIP_TRY(ctx->xchg.reserve(NCOL));
+      xchg = ctx->xchg.p;
+    }
+  }
   SolveArgs so{};
   so.states = ctx->d_state;
   so.partials = ctx->partials.p;
@@ -1056,13 +971,19 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
     so.n_blocks2 = stereo_blocks(ctx->n_stereo);
   }
 
-  if (o.profile) {
-    while ((int)ctx->sweep_ev.size() < 2 * max_it) {
+  auto sweep_events = [&](int launch, hipEvent_t *e0, hipEvent_t *e1) -> hipError_t {
+    *e0 = *e1 = nullptr;
+    if (!o.profile) return hipSuccess;
+    while ((int)ctx->sweep_ev.size() < 2 * (launch + 1)) {
       hipEvent_t e;
-      HIP_TRY(hipEventCreate(&e));
+      hipError_t rc_e = hipEventCreate(&e);
+      if (rc_e != hipSuccess) return rc_e;
       ctx->sweep_ev.push_back(e);
     }
-  }
+    *e0 = ctx->sweep_ev[2 * launch];
+    *e1 = ctx->sweep_ev[2 * launch + 1];
+    return hipSuccess;
+  };
   // The loop is device-resident: sweep/solve pairs are enqueued back to back and a
   // finished loop turns the remaining launches into immediate exits.  To avoid paying
   // for many such exits the first batch is sized from the previous call's iteration
@@ -1072,69 +993,135 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
   int launched = 0;
   int batch = ctx->iter_hint < 1 ? 1 : ctx->iter_hint;
   double total_points = -1.0;  // sharded: points of the whole scan (sum over ranks)
-  if (fn) {
+  if (sharded) {
     // xchg[32]: the local point count first (one exchange per call), then the sums per iteration
+    static const bool unbounded = std::getenv("LSLAM_UNBOUNDED_KNN") != nullptr;
+    sa.bounded = (ctx->cube_mode || unbounded) ? 0 : 1;
+    auto exchange = [&]() -> int {  // sum xchg[0..32) over the ranks; ordered on the library's stream
+      if (fn) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        fn(user, xchg, NCOL);  // returns with the sum visible to this stream
+      } else {
+        if (comm_allreduce_f64(ctx->comm, xchg, NCOL, ctx->stream) != hipSuccess) return LSLAM_ERR_COMM;
+      }
+      return LSLAM_OK;
+    };
     double cnt[NCOL] = {0};
     cnt[0] = (double)ctx->nqc[0] + (double)ctx->nqs[0];
     HIP_TRY(hipMemcpyAsync(xchg, cnt, sizeof(cnt), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    fn(user, xchg, NCOL);
+    rc = exchange();
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(cnt, xchg, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     total_points = cnt[0];
+    // With the library's communicator the loop is device-resident like the single-GPU one: sweep ->
+    // per-rank reduction straight into the exchange buffer -> ncclAllReduce -> replicated solve, `batch`
+    // iterations enqueued before the host looks.  Every rank sees the same sums, hence the same `done`
+    // flag, hence enqueues the same number of collectives.  A callback transport (fn) needs the host
+    // between the two halves of every iteration.
     while (launched < max_it) {
-      const int it = launched;
-      static const bool unbounded = std::getenv("LSLAM_UNBOUNDED_KNN") != nullptr;
-      sa.bounded = (ctx->cube_mode || unbounded) ? 0 : 1;
-      sa.prev_valid = ctx->prev_valid ? 1 : 0;
-      if (sa.bounded) ctx->prev_valid = true;
-      if (o.profile)
-        HIP_TRY(launch_sweep(sa, o.jtj_mode, ctx->stream, ctx->sweep_ev[2 * it], ctx->sweep_ev[2 * it + 1]));
-      else
-        HIP_TRY(launch_sweep(sa, o.jtj_mode, ctx->stream));
-      HIP_TRY(launch_stereo(sta, ctx->stream));
-      so.reduce_only = 1;
-      so.ext_sums = nullptr;
-      HIP_TRY(launch_solve(so, ctx->stream));
-      HIP_TRY(hipMemcpyAsync(xchg, (const char *)ctx->d_state + offsetof(GNState, sums), sizeof(double) * NCOL,
-                             hipMemcpyDeviceToDevice, ctx->stream));
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
-      fn(user, xchg, NCOL);  // returns with the sum visible to this stream
-      so.reduce_only = 0;
-      so.ext_sums = xchg;
-      HIP_TRY(launch_solve(so, ctx->stream));
-      ++launched;
+      const int todo = fn ? 1 : std::min(batch, max_it - launched);
+      for (int b = 0; b < todo; ++b) {
+        sa.prev_valid = (sa.bounded && launched > 0) ? 1 : 0;
+        hipEvent_t e0, e1;
+        HIP_TRY(sweep_events(launched, &e0, &e1));
+        HIP_TRY(launch_sweep(sa, o.jtj_mode, ctx->stream, e0, e1));
+        HIP_TRY(launch_stereo(sta, ctx->stream));
+        so.reduce_only = 1;
+        so.ext_sums = nullptr;
+        so.sums_out = xchg;
+        HIP_TRY(launch_solve(so, ctx->stream));
+        rc = exchange();
+        if (rc) return rc;
+        so.reduce_only = 0;
+        so.ext_sums = xchg;
+        so.sums_out = nullptr;
+        HIP_TRY(launch_solve(so, ctx->stream));
+        ++launched;
+      }
       HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
       HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState), hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(hipStreamSynchronize(ctx->stream));
       if (ctx->h_state[0].done) break;  // identical on every rank: same sums, same solve
+      batch = 2;
     }
   }
-  for (; !fn;) {
-    if (batch > max_it - launched) batch = max_it - launched;
-    for (int b = 0; b < batch; ++b) {
-      const int it = launched + b;
-      static const bool unbounded = std::getenv("LSLAM_UNBOUNDED_KNN") != nullptr;  // A/B switch
-      sa.bounded = (ctx->cube_mode || unbounded) ? 0 : 1;  // per-cube positions are tree-relative
-      sa.prev_valid = ctx->prev_valid ? 1 : 0;
-      if (sa.bounded) ctx->prev_valid = true;  // after this launch the buffer is filled
-      if (o.profile)
-        HIP_TRY(launch_sweep(sa, o.jtj_mode, ctx->stream, ctx->sweep_ev[2 * it],
-                             ctx->sweep_ev[2 * it + 1]));
-      else
-        HIP_TRY(launch_sweep(sa, o.jtj_mode, ctx->stream));
-      HIP_TRY(launch_stereo(sta, ctx->stream));
-      HIP_TRY(launch_solve(so, ctx->stream));
+  // ---- device-resident loops -----------------------------------------------------------------------
+  // The resident scans are matched `in_flight` at a time (a keyframe re-matching pass holds hundreds
+  // of scans, pose_graph/graph.cpp:171-197): every chunk is its own sequence of sweep/solve launches
+  // over its block range, so the traversal-stack overflow area and the wavefront count of a launch stay
+  // bounded.  All chunks' first `batch` iterations are enqueued back to back before the host looks once.
+  int n_launches = 0;
+  if (!sharded) {
+    const int in_flight = o.scans_in_flight > 0 ? std::min<int>(o.scans_in_flight, n_scans) : std::min<int>(n_scans, 32);
+    const int n_chunks = (n_scans + in_flight - 1) / in_flight;
+    static const bool unbounded = std::getenv("LSLAM_UNBOUNDED_KNN") != nullptr;  // A/B switch
+    sa.bounded = (ctx->cube_mode || unbounded) ? 0 : 1;  // per-cube positions are tree-relative
+    std::vector<int> done_iters((size_t)n_chunks, 0);    // iterations enqueued per chunk
+    std::vector<char> finished((size_t)n_chunks, 0);
+    auto enqueue = [&](int c, int iters) -> int {
+      const int p0 = c * in_flight, p1 = std::min(n_scans, p0 + in_flight);
+      const int32_t fb = ctx->h_probs[(size_t)p0].first_block;
+      const int32_t lb = ctx->h_probs[(size_t)p1 - 1].first_block + ctx->h_probs[(size_t)p1 - 1].n_blocks;
+      SweepArgs sc = sa;
+      sc.blocks = ctx->blocks.p + fb;
+      sc.nb_total = lb - fb;
+      sc.partials = ctx->partials.p + (size_t)fb * NCOL;
+      SolveArgs soc = so;
+      soc.states = ctx->d_state + p0;
+      soc.probs = ctx->probs.p + p0;
+      soc.n_prob = p1 - p0;
+      for (int b = 0; b < iters; ++b) {
+        // the first sweep of a loop is bounded by the acceptance gate only, later ones also by the
+        // neighbours the previous sweep of THIS loop found
+        sc.prev_valid = (sc.bounded && done_iters[(size_t)c] > 0) ? 1 : 0;
+        hipEvent_t e0, e1;
+        HIP_TRY(sweep_events(n_launches, &e0, &e1));
+        HIP_TRY(launch_sweep(sc, o.jtj_mode, ctx->stream, e0, e1));
+        ++n_launches;
+        HIP_TRY(launch_stereo(sta, ctx->stream));
+        HIP_TRY(launch_solve(soc, ctx->stream));
+        ++done_iters[(size_t)c];
+      }
+      return LSLAM_OK;
+    };
+    // overflow area of the shallow LDS stack: sized for the largest chunk
+    {
+      int32_t max_nb = 0;
+      for (int c = 0; c < n_chunks; ++c) {
+        const int p0 = c * in_flight, p1 = std::min(n_scans, p0 + in_flight);
+        max_nb = std::max(max_nb, ctx->h_probs[(size_t)p1 - 1].first_block + ctx->h_probs[(size_t)p1 - 1].n_blocks -
+                                      ctx->h_probs[(size_t)p0].first_block);
+      }
+      HIP_TRY(ctx->stack_ovf.reserve(stack_ovf_words((size_t)std::max(max_nb, 1) * SWEEP_BLOCK)));
+      sa.stack_ovf = ctx->stack_ovf.p;
     }
-    launched += batch;
-    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState) * (size_t)n_scans,
-                           hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    bool all_done = true;
-    for (int32_t p = 0; p < n_scans; ++p) all_done = all_done && ctx->h_state[p].done;
-    if (all_done || launched >= max_it) break;
-    batch = 2;
+    for (;;) {
+      bool any = false;
+      for (int c = 0; c < n_chunks; ++c) {
+        if (finished[(size_t)c]) continue;
+        const int iters = std::min(batch, max_it - done_iters[(size_t)c]);
+        if (iters <= 0) { finished[(size_t)c] = 1; continue; }
+        rc = enqueue(c, iters);
+        if (rc) return rc;
+        any = true;
+      }
+      launched = *std::max_element(done_iters.begin(), done_iters.end());
+      HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+      HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState) * (size_t)n_scans,
+                             hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      bool all_done = true;
+      for (int c = 0; c < n_chunks; ++c) {
+        const int p0 = c * in_flight, p1 = std::min(n_scans, p0 + in_flight);
+        bool cd = true;
+        for (int p = p0; p < p1; ++p) cd = cd && ctx->h_state[p].done;
+        if (cd || done_iters[(size_t)c] >= max_it) finished[(size_t)c] = 1;
+        all_done = all_done && finished[(size_t)c];
+      }
+      if (all_done || !any) break;
+      batch = 2;
+    }
   }
   int max_sweeps = 0, max_iter = 0;
   for (int32_t p = 0; p < n_scans; ++p) {
@@ -1149,7 +1136,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
   if (o.profile) {
     // every sweep launch of this call, the trailing ones that found all scans converged included
     // (a few microseconds each): the same population rocprofv3's per-kernel average is taken over
-    for (int it = 0; it < launched; ++it) {
+    for (int it = 0; it < (sharded ? launched : n_launches); ++it) {
       float ms = 0.f;
       HIP_TRY(hipEventElapsedTime(&ms, ctx->sweep_ev[2 * it], ctx->sweep_ev[2 * it + 1]));
       gpu_ms_sweep += ms;
@@ -1303,8 +1290,9 @@ int lslam_scanmatch_run_batch(lslam_ctx *ctx, int32_t n_scans, float *poses, con
 
 int lslam_scanmatch_run_sharded(lslam_ctx *ctx, float pose[6], const lslam_opts *opts, lslam_allreduce_fn fn,
                                 void *user, double *xchg32, lslam_stats *stats) {
-  if (!pose || !fn || !xchg32) {
-    set_err("run_sharded needs a pose, an all-reduce hook and a 32-double device buffer");
+  if (!pose || (fn && !xchg32) || (!fn && !(ctx && ctx->comm))) {
+    set_err("run_sharded needs a pose and either an attached communicator (lslam_ctx_set_comm) or an all-reduce hook "
+            "with a 32-double device buffer");
     return LSLAM_ERR_INVALID;
   }
   if (ctx && ctx->n_prob != 1) {
@@ -1313,7 +1301,7 @@ int lslam_scanmatch_run_sharded(lslam_ctx *ctx, float pose[6], const lslam_opts 
   }
   lslam_stats local;
   lslam_stats *st = stats ? stats : &local;
-  const int rc = run_batch_impl(ctx, 1, pose, opts, st, fn, user, xchg32);
+  const int rc = run_batch_impl(ctx, 1, pose, opts, st, fn, user, xchg32, fn == nullptr);
   return rc < 0 ? rc : st->status;
 }
 

@@ -110,6 +110,7 @@ struct SolveArgs {
   int32_t min_rows;          // 50 (ScanMatch.cpp:142); 10 in LaserOdometry.cpp:501
   int32_t too_few_continue;  // variant B: `continue` instead of `break` (LaserOdometry.cpp:501-503)
   int32_t nan_reset;         // variant B: LaserOdometry.cpp:622-634
+  double *sums_out;          // reduce_only: also write the [n_prob][32] sums here (the all-reduce buffer)
 };
 
 // Stereo reprojection rows of the joint system (lslam_stereo.hip; include/lslam_c.h lslam_stereo_cam).
@@ -168,17 +169,6 @@ inline size_t stack_ovf_words(size_t n_threads) {
 hipError_t launch_gn_step_tap(GNState *st, const float *AtA, const float *Atb, float dr, float dt,
                               float eig_thresh, hipStream_t s);
 
-// host kd-tree builder (kdtree_host.cpp): nanoflann v1.2.3 topology, device node format
-struct HostTree {
-  std::vector<KdNode> nodes;  // inner nodes only, cache-line grouped (lslam_device.hpp)
-  std::vector<int32_t> vind;
-  float bb_lo[3], bb_hi[3];
-  uint32_t root_ref = 0;
-  int depth = 0;       // levels including the leaf level
-  size_t n_leaves = 0;
-};
-void build_kdtree_host(const float *pts, size_t n, size_t stride_floats, HostTree &out);
-
 // device kd-tree builder (lslam_treebuild.hip): same tree, built in HBM
 hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_t node_cap,
                                hipStream_t stream, TreeView *view, int *depth, size_t *n_leaves,
@@ -192,7 +182,12 @@ void treebuild_release_scratch(hipStream_t s);  // frees the per-stream build sc
 // lslam_api.hip internals used by lslam_fmap.hip (map maintenance)
 }  // namespace lslam
 struct lslam_ctx;
+struct lslam_comm;
 namespace lslam {
+// lslam_comm.hip: in-place fp64 SUM over the ranks of `comm`, enqueued on `s`
+hipError_t comm_allreduce_f64(lslam_comm *comm, double *buf, size_t count, hipStream_t s);
+int comm_world(const lslam_comm *comm);
+int comm_rank(const lslam_comm *comm);
 int map_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t n_corner, const float4 *d_surf, size_t n_surf);
 int cubemap_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t nc, const std::vector<int32_t> &roots_c,
                        const std::vector<int32_t> &cells_c, const float4 *d_surf, size_t ns,

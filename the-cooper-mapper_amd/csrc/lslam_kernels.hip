@@ -679,6 +679,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(SolveArgs a) {
       for (int g = 0; g < SOLVE_GROUPS; ++g) v += red[g][tid];
       tot[tid] = v;
       st->sums[tid] = v;
+      if (a.sums_out) a.sums_out[(size_t)blockIdx.x * NCOL + tid] = v;
     }
     __syncthreads();
   }

@@ -29,6 +29,10 @@
 
 #include "../../include/lslam_c.h"
 
+namespace lslam {  // lslam_comm.hip
+hipError_t comm_allreduce_f64(lslam_comm *comm, double *buf, size_t count, hipStream_t s);
+}
+
 namespace {
 
 #define PG_DEV __device__ __forceinline__
@@ -631,6 +635,17 @@ struct lslam_pg {
   int e_begin = 0, e_end = 0;
   lslam_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
+  lslam_comm *comm = nullptr;  // the library's RCCL communicator (not owned); used when no callback is set
+  bool sharded() const { return allreduce != nullptr || comm != nullptr; }
+  // in-place sum over the ranks, ordered on the stream
+  int reduce(double *buf, size_t count) {
+    if (allreduce) {
+      if (hipStreamSynchronize(stream) != hipSuccess) return LSLAM_ERR_HIP;
+      allreduce(allreduce_user, buf, count);  // contract: complete when it returns
+      return LSLAM_OK;
+    }
+    return lslam::comm_allreduce_f64(comm, buf, count, stream) == hipSuccess ? LSLAM_OK : LSLAM_ERR_COMM;
+  }
   // graph
   double *d_poses = nullptr, *d_trial = nullptr, *d_meas = nullptr, *d_info = nullptr;
   int32_t *d_ij = nullptr;
@@ -699,23 +714,21 @@ int linearize(lslam_pg *pg, const double *poses) {
     hipLaunchKernelGGL(pg_edge_kernel, dim3((ne + 127) / 128), dim3(128), 0, pg->stream, poses, pg->d_ij,
                        pg->d_meas, pg->d_info, pg->e_begin, pg->e_end, pg->fixed, pg->d_rec);
   hipLaunchKernelGGL(pg_assemble_vertex_kernel, dim3((pg->n_v * 42 + 255) / 256), dim3(256), 0, pg->stream,
-                     pg->d_rec, pg->d_vptr, pg->d_vadj, pg->n_v, pg->allreduce ? -1 : pg->fixed,
+                     pg->d_rec, pg->d_vptr, pg->d_vadj, pg->n_v, pg->sharded() ? -1 : pg->fixed,
                      pg->diag(), pg->b());
   if (pg->n_off > 0)
     hipLaunchKernelGGL(pg_assemble_off_kernel, dim3((pg->n_off * 36 + 255) / 256), dim3(256), 0, pg->stream,
                        pg->d_rec, pg->d_optr, pg->d_oadj, pg->n_off, pg->off());
   hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(256), 0, pg->stream, pg->d_rec + 120, ne, REC, pg->chi());
   PG_TRY(hipGetLastError());
-  if (pg->allreduce) {
-    PG_TRY(hipStreamSynchronize(pg->stream));
-    pg->allreduce(pg->allreduce_user, pg->d_sys, pg->sys_doubles());
+  if (pg->sharded()) {
+    const int rc = pg->reduce(pg->d_sys, pg->sys_doubles());
+    if (rc) return rc;
     // identity block of the fixed vertex after the sum over ranks
-    std::vector<double> I(36, 0.0);
-    for (int k = 0; k < 6; ++k) I[k * 7] = 1.0;
+    static const double I[36] = {1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0,
+                                 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1};
     if (pg->fixed >= 0)
-      PG_TRY(hipMemcpyAsync(pg->diag() + (size_t)pg->fixed * 36, I.data(), 36 * sizeof(double),
-                            hipMemcpyHostToDevice, pg->stream));
-    PG_TRY(hipStreamSynchronize(pg->stream));
+      PG_TRY(hipMemcpyAsync(pg->diag() + (size_t)pg->fixed * 36, I, 36 * sizeof(double), hipMemcpyHostToDevice, pg->stream));
   }
   return LSLAM_OK;
 }
@@ -729,9 +742,9 @@ int eval_chi2(lslam_pg *pg, const double *poses, double *out) {
                        pg->d_meas, pg->d_info, pg->e_begin, pg->e_end, pg->d_chi);
   hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(256), 0, pg->stream, pg->d_chi, ne, 1, pg->chi());
   PG_TRY(hipGetLastError());
-  if (pg->allreduce) {
-    PG_TRY(hipStreamSynchronize(pg->stream));
-    pg->allreduce(pg->allreduce_user, pg->chi(), 1);
+  if (pg->sharded()) {
+    const int rc = pg->reduce(pg->chi(), 1);
+    if (rc) return rc;
   }
   PG_TRY(hipMemcpyAsync(out, pg->chi(), sizeof(double), hipMemcpyDeviceToHost, pg->stream));
   PG_TRY(hipStreamSynchronize(pg->stream));
@@ -897,6 +910,12 @@ void lslam_pg_destroy(lslam_pg *pg) {
 }
 
 size_t lslam_pg_system_doubles(const lslam_pg *pg) { return pg ? pg->sys_doubles() : 0; }
+
+int lslam_pg_set_comm(lslam_pg *pg, lslam_comm *comm) {
+  if (!pg) return LSLAM_ERR_INVALID;
+  pg->comm = comm;
+  return LSLAM_OK;
+}
 int32_t lslam_pg_num_offdiag(const lslam_pg *pg) { return pg ? pg->n_off : 0; }
 
 int lslam_pg_set_shard(lslam_pg *pg, int32_t e_begin, int32_t e_end, lslam_allreduce_fn fn, void *user,

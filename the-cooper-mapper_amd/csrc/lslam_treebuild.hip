@@ -51,7 +51,7 @@ constexpr int TB_BIG = 1024;
 constexpr int TB_SMALL = 64;
 constexpr int TE = 8;              // consecutive elements per thread in the partition scans
 constexpr int LOCAL_MAX = LSLAM_LOCAL_MAX;    // subtrees up to this many points are built by one wavefront
-constexpr int LOCAL_STACK = 48;
+constexpr int LOCAL_STACK = KD_STACK_MAX;  // pending siblings along one root-to-leaf path: a deeper tree is refused anyway
 
 struct BuildItem {   // one pending inner node
   int32_t l, r;      // point range
@@ -88,6 +88,7 @@ struct BuildArgs {
   int32_t *root_feat;  // split dimension of root t (a root's parent_word is -1 - t)
   int32_t n;
   int32_t reg_nodes;   // 1: nodes of at most 64 points are finished in registers (phase B)
+  uint32_t spin_limit; // watchdog of idle phase-A workgroups (polls of ~2 x 127 sleep units)
 };
 
 __device__ __forceinline__ float coord(const float4 &p, int d) { return d == 0 ? p.x : (d == 1 ? p.y : p.z); }
@@ -456,7 +457,10 @@ __global__ __launch_bounds__(TB_BIG) void kd_build_big_kernel(BuildArgs A) {
           // (queue tail, pending count, group allocator): back off hard
           __builtin_amdgcn_s_sleep(127);
           __builtin_amdgcn_s_sleep(127);
-          if (spins > (1u << 22)) { A.ctl->overflow = 2; break; }  // bounded spin
+          // Watchdog only.  No workgroup ever waits for another one while it holds a node (it finishes
+          // the node and publishes the children), so q_pending reaches 0 as long as ONE workgroup is
+          // resident; this bound (~1 s) merely turns a broken invariant into an error instead of a hang.
+          if (spins > A.spin_limit) { A.ctl->overflow = 2; break; }
         }
       }
     }
@@ -1371,7 +1375,7 @@ __global__ __launch_bounds__(256) void kd_bbox_seg_kernel(const float4 *pts, con
 
 // Build the tree of `n` points at d_pts (float4 {x,y,z,bitcast(original index)}, permuted in
 // place).  d_nodes must hold node_cap nodes.  Returns hipSuccess and fills `view`/depth, or
-// sets *fallback when the structure limits were hit (caller then uses the host builder).
+// sets *fallback when a structure limit was hit (the caller retries with more node slots or fails).
 namespace {
 // Scratch of a build, kept per stream between builds (hipMalloc/hipFree of tens of MB per call cost
 // more than a millisecond); released by treebuild_release_scratch.
@@ -1478,7 +1482,7 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
     if (remaining == 0) return hipSuccess;
   }
-  *fallback = 3;  // 50+ levels above the wavefront-local size: give the cloud to the host builder
+  *fallback = 3;  // 50+ levels above the wavefront-local size: deeper than the traversal stack allows anyway
   return hipSuccess;
 }
 }  // namespace
@@ -1532,7 +1536,10 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
     *n_leaves = 1;
     return hipSuccess;
   }
-  const int32_t queue_cap = std::max(64, 4 * (n / LOCAL_MAX + 16));
+  // queue entries are nodes above LOCAL_MAX points: at most n / LOCAL_MAX of them on one level and the
+  // device traversal stack refuses trees deeper than KD_STACK_MAX levels, so this never overflows for a
+  // tree the search could use; subtree roots hold more than 10 points each (n / 8 is generous)
+  const int32_t queue_cap = KD_STACK_MAX * (n / LOCAL_MAX + 1) + 64;
   const int32_t sub_cap = std::max(64, 4 * (n / LOCAL_MAX + 16) + n / 8);
   BuildArgs A{};
   A.pts = d_pts;
@@ -1541,6 +1548,8 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
   A.queue_cap = queue_cap;
   A.n = n;
   A.reg_nodes = reg_nodes_enabled();
+  A.spin_limit = 1u << 22;
+  if (const char *sl = std::getenv("LSLAM_DEBUG_SPIN_LIMIT")) A.spin_limit = (uint32_t)strtoul(sl, nullptr, 10);  // tests
   void *blob = nullptr;
   A.sub_cap = sub_cap;
   const size_t sz_queue = (size_t)queue_cap * sizeof(BuildItem), sz_ready = (size_t)queue_cap * sizeof(int32_t),

@@ -157,6 +157,15 @@ class PoseGraph:
         self._check(self.lib.lslam_pg_set_shard(self.h, int(e_begin), int(e_end), self._cb, None, buf))
         self._sys_tensor = system_tensor
 
+    def set_comm(self, comm, e_begin, e_end):
+        """Edge shard [e_begin, e_end) of this rank, the block system all-reduced by the library's own
+        RCCL communicator (lslam_pg_set_comm) on the solver's stream."""
+        self._build()
+        self._cb = ALLREDUCE_FN(0)
+        self._check(self.lib.lslam_pg_set_shard(self.h, int(e_begin), int(e_end), self._cb, None, None))
+        self._check(self.lib.lslam_pg_set_comm(self.h, comm.h if comm is not None else None))
+        self._comm = comm
+
     def system_doubles(self):
         self._build()
         return self.lib.lslam_pg_system_doubles(self.h)

@@ -29,6 +29,45 @@ def _fp(a):
     return a.ctypes.data_as(c_float_p)
 
 
+class Comm:
+    """lslam_comm: the library's own RCCL communicator (include/lslam_c.h "collectives").  Rank 0 calls
+    ``Comm.unique_id()`` and the host program hands the 128 bytes to every rank."""
+
+    @staticmethod
+    def unique_id():
+        lib = load_library()
+        buf = np.zeros(128, np.uint8)
+        rc = lib.lslam_comm_unique_id(buf.ctypes.data_as(c_uint8_p))
+        if rc != 0:
+            raise LslamError(rc, lib.lslam_last_error().decode())
+        return buf
+
+    def __init__(self, device, unique_id, rank, world):
+        self.lib = load_library()
+        uid = np.ascontiguousarray(unique_id, np.uint8).reshape(128)
+        h = C.c_void_p()
+        rc = self.lib.lslam_comm_create(int(device), uid.ctypes.data_as(c_uint8_p), int(rank), int(world), C.byref(h))
+        if rc != 0:
+            raise LslamError(rc, self.lib.lslam_last_error().decode())
+        self.h, self.rank, self.world = h, int(rank), int(world)
+
+    def allreduce_f64(self, device_ptr, count, stream=None):
+        rc = self.lib.lslam_comm_allreduce_f64(self.h, C.c_void_p(int(device_ptr)), int(count), C.c_void_p(stream or 0))
+        if rc != 0:
+            raise LslamError(rc, self.lib.lslam_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lslam_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     """One lslam_ctx: a HIP stream, an HBM-resident map and scan, the device GN state."""
 
@@ -135,21 +174,31 @@ class Context:
         self._check(rc)
         return Status(rc), p, st
 
-    def run_sharded(self, pose, allreduce, xchg, opts=None):
-        """lslam_scanmatch_run_sharded: the resident scan is this rank's shard of one scan's
-        points; `allreduce(ptr, count)` sums `count` doubles at device address `ptr` over the
-        ranks in place (e.g. torch.distributed.all_reduce on `xchg`, a 32-double CUDA tensor
-        whose data_ptr() is what the library writes the sums to) -> (status, pose, stats)."""
-        from .capi import ALLREDUCE_FN
+    def set_comm(self, comm):
+        """lslam_ctx_set_comm: attach the library's RCCL communicator (None detaches)."""
+        self._check(self.lib.lslam_ctx_set_comm(self.h, comm.h if comm is not None else None))
+        self._comm = comm
 
-        def _tramp(_user, ptr, count):
-            allreduce(ptr, count)
-        cb = ALLREDUCE_FN(_tramp)
+    def run_sharded(self, pose, allreduce=None, xchg=None, opts=None):
+        """lslam_scanmatch_run_sharded: the resident scan is this rank's shard of one scan's
+        points.  With a communicator attached (set_comm) nothing else is needed: the sums are
+        all-reduced by RCCL on the library's stream.  Otherwise `allreduce(ptr, count)` sums `count`
+        doubles at device address `ptr` over the ranks in place (e.g. torch.distributed.all_reduce on
+        `xchg`, a 32-double CUDA tensor whose data_ptr() is what the library writes the sums to)
+        -> (status, pose, stats)."""
+        from .capi import ALLREDUCE_FN
+        if allreduce is not None:
+            def _tramp(_user, ptr, count):
+                allreduce(ptr, count)
+            cb = ALLREDUCE_FN(_tramp)
+            ptr = C.c_void_p(xchg.data_ptr() if hasattr(xchg, "data_ptr") else int(xchg))
+        else:
+            cb = ALLREDUCE_FN(0)
+            ptr = None
         p = np.array(pose, dtype=np.float32).reshape(6)
         st = LslamStats()
-        ptr = xchg.data_ptr() if hasattr(xchg, "data_ptr") else int(xchg)
         rc = self.lib.lslam_scanmatch_run_sharded(self.h, _fp(p), C.byref(opts) if opts is not None else None,
-                                                  cb, None, C.c_void_p(ptr), C.byref(st))
+                                                  cb, None, ptr, C.byref(st))
         self._check(rc)
         return Status(rc), p, st
 

@@ -1,0 +1,147 @@
+"""GPU side of the synthetic workload (bench / test infrastructure, not product code).
+
+* GpuLidar: the ray caster of the-cooper-mapper_amd/synth.py (make_scan) as a HIP kernel
+  (tools/synth_raycast.hip -> tools/libsynth_hip.so): same world, ring tables and corner labelling.
+* loop_trajectory: the closed loop the sensor drives through the 600 x 600 m world.
+* build_voxel_map: the "10k-frame voxel map" of BASELINE configs[1]/[2] -- every frame is ray cast at
+  its ground-truth pose, its corner / surface points are voxel-filtered like the mapping node filters
+  a frame (LaserMatcher.cpp:289-301) and pushed through FeatureMap::addFeatureCloud
+  (util/FeatureMap.h:219-230,289-306) on the device map of the-cooper-mapper_amd (lslam_fmap_*).
+"""
+import ctypes as C
+import importlib
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+_lib = None
+
+
+def load_lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(HERE, "libsynth_hip.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", HERE], stdout=subprocess.DEVNULL)
+        importlib.import_module("the-cooper-mapper_amd").load_library()  # same HIP runtime for both libraries
+        lib = C.CDLL(path)
+        lib.synth_raycast.restype = C.c_int
+        lib.synth_raycast.argtypes = [C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_double,
+                                      C.c_double, C.c_float, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def ring_table(rings):
+    """(lower, upper) elevation in degrees: MultiScanRegistration.h:90-92 (VLP-16), :100-102 (64 rings)."""
+    return (-24.9, 2.0) if rings == 64 else (-15.0, 15.0)
+
+
+class GpuLidar:
+    def __init__(self, world, device=0, max_range=140.0):
+        self.lib = load_lib()
+        self.device = device
+        self.max_range = max_range
+        b, p, w = world.boxes, world.poles, world.walls
+        kind = np.concatenate([np.zeros(len(b)), np.ones(len(p)), np.full(len(w), 2.0)])
+        s = np.concatenate([b, p, w], axis=0)
+        self.solids = np.concatenate([s, kind[:, None]], axis=1).astype(np.float32)  # x0 x1 y0 y1 h kind
+        self.cx = 0.5 * (s[:, 0] + s[:, 1])
+        self.cy = 0.5 * (s[:, 2] + s[:, 3])
+        self.rad = 0.5 * np.hypot(s[:, 1] - s[:, 0], s[:, 3] - s[:, 2])
+
+    def cast(self, pose, rings=64, az_steps=1800, seed=1234, noise_sigma=0.02, corner_band=0.12):
+        """-> pts (rings*az_steps, 4) float32 sensor frame {x,y,z,ring+relTime}, label uint8 (0 none, 1 surf, 2 corner)"""
+        pose = np.ascontiguousarray(pose, np.float64)
+        near = np.hypot(self.cx - pose[3], self.cy - pose[4]) < self.max_range + self.rad + 1.0
+        sol = np.ascontiguousarray(self.solids[near])
+        n = rings * az_steps
+        pts = np.empty((n, 4), np.float32)
+        lab = np.empty(n, np.uint8)
+        lo, hi = ring_table(rings)
+        rc = self.lib.synth_raycast(self.device, sol.ctypes.data, len(sol), pose.ctypes.data_as(C.POINTER(C.c_double)), rings,
+                                    az_steps, lo, hi, noise_sigma, seed & 0xFFFFFFFF, corner_band, self.max_range,
+                                    pts.ctypes.data, lab.ctypes.data)
+        if rc:
+            raise RuntimeError("synth_raycast failed: %d" % rc)
+        return pts, lab
+
+    def scan(self, pose, rings=64, az_steps=1800, seed=1234, noise_sigma=0.02, corner_band=0.12, full=False):
+        """make_scan's return values: corner, surf (n,4) float32 in the sensor frame (ring-major order)
+        [, the full ring-sorted cloud and its per-ring [first, last] ranges]."""
+        pts, lab = self.cast(pose, rings, az_steps, seed, noise_sigma, corner_band)
+        corner, surf = pts[lab == 2], pts[lab == 1]
+        if not full:
+            return corner, surf
+        valid = lab != 0
+        cloud = pts[valid]
+        cnt = np.bincount(np.repeat(np.arange(rings), az_steps)[valid], minlength=rings)
+        cum = np.cumsum(cnt)
+        first = np.concatenate([[0], cum[:-1]])
+        last = np.where(cum > 0, cum - 1, 0)
+        return corner, surf, cloud, np.stack([first, last], axis=1).astype(np.int32)
+
+
+def loop_trajectory(n_frames=10000, half=157.0, radius=12.0, height=1.8):
+    """Closed rounded-rectangle loop along the streets x, y = +-half of the Manhattan world
+    (buildings sit on a 40 m pitch, so +-157 runs 3 m off the centre line of a street), driven
+    counter-clockwise at constant speed.  -> (n, 6) float64 poses {rx, ry, rz, x, y, z}."""
+    straight = 2.0 * (half - radius)
+    arc = 0.5 * np.pi * radius
+    per = 4.0 * (straight + arc)
+    s = (np.arange(n_frames) + 0.5) * per / n_frames
+    seg = straight + arc
+    k = np.floor(s / seg).astype(int) % 4  # side index
+    u = s - np.floor(s / seg) * seg
+    on_arc = u > straight
+    # side 0: x = +half, y from -(half-radius) upwards, heading +y; corners turn left
+    x0 = np.where(on_arc, half - radius + radius * np.cos((u - straight) / radius), half)
+    y0 = np.where(on_arc, half - radius + radius * np.sin((u - straight) / radius), -(half - radius) + u)
+    yaw0 = np.where(on_arc, np.pi / 2 + (u - straight) / radius, np.pi / 2)
+    c, sn = np.cos(k * np.pi / 2), np.sin(k * np.pi / 2)
+    x, y = c * x0 - sn * y0, sn * x0 + c * y0
+    yaw = yaw0 + k * np.pi / 2
+    yaw = (yaw + np.pi) % (2 * np.pi) - np.pi
+    wob = 2.0 * np.pi * s / 37.0
+    return np.stack([0.01 * np.sin(wob), 0.012 * np.cos(1.3 * wob), yaw, x, y, np.full(n_frames, height)], axis=1)
+
+
+def pose_matrix(pose):
+    synth = importlib.import_module("the-cooper-mapper_amd.synth")
+    R, t = synth.pose_to_Rt(pose)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3], T[:3, 3] = R, t
+    return T
+
+
+def build_voxel_map(pkg, ctx, lidar, poses, rings=16, az_steps=1800, leaf_corner=0.2, leaf_surf=0.4,
+                    cube_dims=(21, 21, 11), seed0=5000, corner_band=0.12, progress=None):
+    """Push every frame through the device FeatureMap.  Returns (feature map, stats)."""
+    fm = pkg.FeatureMap(ctx, *cube_dims)
+    fm.setup_filter_size(leaf_corner, leaf_surf, 0.6)
+    t0 = time.perf_counter()
+    n_in = 0
+    for i, pose in enumerate(poses):
+        corner, surf = lidar.scan(pose, rings, az_steps, seed=seed0 + i, corner_band=corner_band)
+        n_in += len(corner) + len(surf)
+        # the mapping node filters a frame's feature clouds before it matches / inserts them
+        dc = pkg.voxel_grid(ctx, corner, leaf_corner) if len(corner) else corner
+        ds = pkg.voxel_grid(ctx, surf, leaf_surf) if len(surf) else surf
+        fm.update(pose[3:].astype(np.float32))
+        fm.add_feature_cloud(dc, ds, pose_matrix(pose))
+        if progress and (i + 1) % progress == 0:
+            info = fm.info()
+            print("[map] %d frames, %d corner + %d surf points held, %.1f s" %
+                  (i + 1, info["n_corner"], info["n_surf"], time.perf_counter() - t0), file=sys.stderr, flush=True)
+    info = fm.info()
+    return fm, {"frames": int(len(poses)), "frame_rings": rings, "points_cast": int(n_in), "build_s": time.perf_counter() - t0,
+                "map_corner_total": int(info["n_corner"]), "map_surf_total": int(info["n_surf"]),
+                "leaf_corner": leaf_corner, "leaf_surf": leaf_surf, "cube_dims": list(cube_dims)}

@@ -73,8 +73,16 @@ typedef struct {
   int32_t profile;   /* 1: bracket every sweep launch with HIP events (stats.gpu_ms_sweep) */
   int32_t scans_in_flight; /* lslam_scanmatch_run_batch: resident scans matched together by one sequence of
                               launches; more scans are taken in chunks of this size (0: up to 32) */
-  int32_t reserved;
+  int32_t search_mode;     /* how the 5-NN search maps to the GPU: LSLAM_SEARCH_AUTO / _LANE / _PACKET */
 } lslam_opts;
+
+/* 5-NN search implementations (same answer, bit for bit):
+ *   LANE    one query per lane, nanoflann's traversal with an explicit per-lane stack
+ *   PACKET  one wavefront walks the tree once for its 64 (Morton-neighbouring) queries: nodes and leaves
+ *           arrive by scalar loads, lanes test them against their own query (csrc/lslam_packet.hpp)
+ *   AUTO    the faster one on MI355X: LANE (the packet search trades the divergent gathers for about twice
+ *           the vector ALU work and measured slower; DESIGN.md has the numbers) */
+enum { LSLAM_SEARCH_AUTO = 0, LSLAM_SEARCH_LANE = 1, LSLAM_SEARCH_PACKET = 2 };
 
 /* Per-call statistics (the counters the reference prints, ScanMatch.cpp:35-40,
  * 143,269, plus timing taps). */
@@ -239,6 +247,13 @@ int lslam_knn5(lslam_ctx *ctx, int which_map, const void *queries, size_t nq,
  *                              n_rows | n_line+n_plane | score */
 int lslam_sweep(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_t *idx_out,
                 float *d2_out, float *coeff_out, uint8_t *flags_out, float *sums_out);
+
+/* The two taps above with the search implementation chosen explicitly (LSLAM_SEARCH_*); n_ties (may be
+ * NULL) receives the number of queries whose answer needed nanoflann's visit order (exact distance ties). */
+int lslam_knn5_ex(lslam_ctx *ctx, int which_map, const void *queries, size_t nq, size_t stride_bytes,
+                  int32_t search_mode, int32_t *idx_out, float *d2_out, int32_t *n_ties);
+int lslam_sweep_ex(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_t search_mode, int32_t *idx_out,
+                   float *d2_out, float *coeff_out, uint8_t *flags_out, float *sums_out);
 
 /* One solve/update step (ScanMatch.cpp:206-260) run by the device solve kernel
  * on caller-provided normal equations.  matP/degenerate are in/out state. */

@@ -22,7 +22,15 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.int32)
 
 
-def test_knn5_matches_reference_goldens(ctx, goldens):
+SEARCH = {"lane": 1, "packet": 2}  # LSLAM_SEARCH_LANE / _PACKET (include/lslam_c.h)
+
+
+@pytest.mark.parametrize("search", ["lane", "packet"])
+def test_knn5_matches_reference_goldens(ctx, goldens, search):
+    """Both search implementations against the outputs of the reference's own nanoflann -- including the
+    lattice / duplicate fixtures, where exact distance ties make the answer depend on nanoflann's visit order
+    (the packet search detects such queries and redoes them with nanoflann's traversal)."""
+    ties_seen = 0
     for name, g in goldens.items():
         pts = g["pts"]
         if len(pts) < 5:
@@ -30,12 +38,16 @@ def test_knn5_matches_reference_goldens(ctx, goldens):
         # the map API wants a corner and a surf cloud; use the same cloud for both
         ctx.map_set(pts, pts)
         for which in (0, 1):
-            idx, d2 = ctx.knn5(which, g["queries"])
+            idx, d2, ties = ctx.knn5(which, g["queries"], search_mode=SEARCH[search], want_ties=True)
             assert np.array_equal(idx, g["idx"]), (name, which)
             assert np.array_equal(bits(d2), bits(g["d2"])), (name, which)
+            ties_seen += ties
+    if search == "packet":
+        assert ties_seen > 0  # the tie fixtures did go through the redo path
 
 
-def test_knn5_matches_oracle_large(ctx, oracle, synth):
+@pytest.mark.parametrize("search", ["lane", "packet"])
+def test_knn5_matches_oracle_large(ctx, oracle, synth, search):
     pr = synth.make_problem(rings=16, azimuth_steps=1800, world_half=100.0)
     ctx.map_set(pr["map_corner"], pr["map_surf"])
     info = ctx.map_info()
@@ -45,7 +57,7 @@ def test_knn5_matches_oracle_large(ctx, oracle, synth):
         tree = oracle.kdtree(cloud)
         q = cloud[rng.integers(0, len(cloud), 4000), :3] + rng.normal(0, 0.5, (4000, 3)).astype(np.float32)
         q = np.concatenate([q, rng.uniform(-150, 150, (500, 3)).astype(np.float32)])  # far outside
-        gi, gd = ctx.knn5(which, q)
+        gi, gd = ctx.knn5(which, q, search_mode=SEARCH[search])
         oi, od = tree.knn(q, 5)
         assert np.array_equal(gi, oi)
         assert np.array_equal(bits(gd), bits(od))
@@ -192,14 +204,15 @@ def test_knn5_deep_tree_uses_overflow_stack(ctx, oracle):
     assert np.array_equal(gi, oi) and np.array_equal(bits(gd), bits(od))
 
 
+@pytest.mark.parametrize("search", ["lane", "packet"])
 @pytest.mark.parametrize("jtj_mode", [0, 1])
-def test_sweep_matches_oracle(ctx, oracle, small_problem, jtj_mode):
+def test_sweep_matches_oracle(ctx, oracle, small_problem, jtj_mode, search):
     pr = small_problem
     ctx.map_set(pr["map_corner"], pr["map_surf"])
     ctx.scan_set(pr["corner"], pr["surf"])
     tc, ts = oracle.kdtree(pr["map_corner"]), oracle.kdtree(pr["map_surf"])
     for pose in (pr["init_pose"], pr["gt_pose"]):
-        g = ctx.sweep(pose, jtj_mode=jtj_mode)
+        g = ctx.sweep(pose, jtj_mode=jtj_mode, search_mode=SEARCH[search])
         o = oracle.sweep(tc, ts, pr["corner"], pr["surf"], pose)
         assert np.array_equal(g["idx"], o["idx"])
         assert np.array_equal(bits(g["d2"]), bits(o["d2"]))
@@ -258,11 +271,13 @@ def test_gn_step_degenerate_projection(ctx, oracle):
     assert np.abs(g["x"] - o["x"]).max() < 1e-5 + 1e-4 * np.abs(o["x"]).max()
 
 
+@pytest.mark.parametrize("search", ["lane", "packet"])
 @pytest.mark.parametrize("jtj_mode", [0, 1])
-def test_full_loop_pose_matches_oracle(ctx, oracle, small_problem, jtj_mode):
+def test_full_loop_pose_matches_oracle(ctx, oracle, small_problem, jtj_mode, search):
     pr = small_problem
     opts = ctx.default_opts()
     opts.jtj_mode = jtj_mode
+    opts.search_mode = SEARCH[search]
     status, pose, st = ctx.scanmatch_full(pr["map_corner"], pr["map_surf"], pr["corner"], pr["surf"],
                                           pr["init_pose"], opts)
     ok, opose, ost = oracle.scanmatch_scan(pr["map_corner"], pr["map_surf"], pr["corner"], pr["surf"],
@@ -485,6 +500,18 @@ def test_full_size_64ring_properties(ctx, synth):
     opts.jtj_mode = 1
     status4, pose4, st4 = ctx.run(pr["init_pose"], opts)
     assert st4.iterations == st.iterations and np.abs(pose4 - pose).max() <= POSE_TOL_M
+    # the two search implementations find the same neighbours: same rows, same sums order -> same bits
+    res = {}
+    for name, mode in SEARCH.items():
+        o2 = ctx.default_opts()
+        o2.search_mode = mode
+        res[name] = ctx.run(pr["init_pose"], o2)
+        sw = ctx.sweep(pr["init_pose"], jtj_mode=1, search_mode=mode)
+        res[name + "_sweep"] = sw
+    assert np.array_equal(bits(res["lane"][1]), bits(res["packet"][1]))
+    assert res["lane"][2].iterations == res["packet"][2].iterations and res["lane"][2].n_rows == res["packet"][2].n_rows
+    for k in ("idx", "d2", "flags", "coeff"):
+        assert np.array_equal(res["lane_sweep"][k].view(np.uint8), res["packet_sweep"][k].view(np.uint8)), k
 
 
 # ---------------------------------------------------------------------------------------

@@ -47,7 +47,7 @@ class LslamOpts(C.Structure):
         ("jtj_mode", C.c_int32),
         ("profile", C.c_int32),
         ("scans_in_flight", C.c_int32),
-        ("reserved", C.c_int32),
+        ("search_mode", C.c_int32),
     ]
 
 
@@ -155,6 +155,10 @@ SYMBOLS = {
     "lslam_knn5": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, c_int32_p, c_float_p]),
     "lslam_sweep": (C.c_int, [C.c_void_p, c_float_p, C.c_int32, c_int32_p, c_float_p, c_float_p,
                               c_uint8_p, c_float_p]),
+    "lslam_knn5_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int32, c_int32_p, c_float_p,
+                                c_int32_p]),
+    "lslam_sweep_ex": (C.c_int, [C.c_void_p, c_float_p, C.c_int32, C.c_int32, c_int32_p, c_float_p, c_float_p,
+                                 c_uint8_p, c_float_p]),
     "lslam_gn_step": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_int32, c_float_p, c_float_p,
                                 c_int32_p, C.c_float, C.c_float, c_float_p, c_float_p, c_float_p,
                                 c_int32_p]),
@@ -211,6 +215,7 @@ SYMBOLS = {
 }
 
 COMM_ID_BYTES = 128
+SEARCH_AUTO, SEARCH_LANE, SEARCH_PACKET = 0, 1, 2
 
 
 def lib_path():

@@ -73,6 +73,7 @@ struct DevBuf {
 
 struct DevTree {
   DevBuf<KdNode> nodes;
+  DevBuf<PNode> pn;  // packet-search nodes, same slots
   DevBuf<float4> pts;
   TreeView view{};
   int depth = 0;
@@ -224,11 +225,26 @@ void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
   a.prev_valid = 0;
   a.bounded = 0;
   a.deep_tree = (ctx->tc.depth > KD_STACK_LDS + 1 || ctx->ts.depth > KD_STACK_LDS + 1) ? 1 : 0;
+  a.packet = 0;
   a.idx_out = nullptr;
   a.d2_out = nullptr;
   a.coeff_out = nullptr;
   a.flags_out = nullptr;
   a.dbg = nullptr;
+}
+
+// LSLAM_SEARCH_AUTO = the per-lane search.  The packet search (lslam_packet.hpp) removes the divergent gathers
+// that bound the per-lane kernel, but pays ~2x the VALU work (every lane tests the union of the packet's nodes
+// and leaves, every insert runs when ANY lane needs it): measured on MI355X it is SLOWER -- 0.81 against 0.45 ms
+// per 2.6 M-point launch, 277 against 59 us for a single 115 200-point scan (incoherent far-range packets make
+// a long tail) -- so it stays an explicit choice (LSLAM_SEARCH_PACKET, or LSLAM_SEARCH=packet for A/B runs).
+int resolve_search_mode(const lslam_ctx *ctx, int32_t requested) {
+  static const char *env = std::getenv("LSLAM_SEARCH");
+  if (env && !std::strcmp(env, "lane")) requested = LSLAM_SEARCH_LANE;
+  if (env && !std::strcmp(env, "packet")) requested = LSLAM_SEARCH_PACKET;
+  if (ctx->cube_mode || !ctx->tc.view.pn || !ctx->ts.view.pn) return LSLAM_SEARCH_LANE;
+  if (requested == LSLAM_SEARCH_LANE || requested == LSLAM_SEARCH_PACKET) return requested;
+  return LSLAM_SEARCH_LANE;
 }
 
 int ensure_states(lslam_ctx *ctx, int32_t n) {
@@ -280,7 +296,7 @@ void lslam_default_opts(lslam_opts *o) {
   o->jtj_mode = 1;  // MFMA J^T J: measured >= the VALU path (profiles/), same sums to 1e-5
   o->profile = 0;
   o->scans_in_flight = 0;
-  o->reserved = 0;
+  o->search_mode = LSLAM_SEARCH_AUTO;
 }
 
 int lslam_ctx_create(int device, lslam_ctx **out) {
@@ -327,8 +343,8 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  ctx->tc.nodes.release(); ctx->tc.pts.release();
-  ctx->ts.nodes.release(); ctx->ts.pts.release();
+  ctx->tc.nodes.release(); ctx->tc.pts.release(); ctx->tc.pn.release();
+  ctx->ts.nodes.release(); ctx->ts.pts.release(); ctx->ts.pn.release();
   ctx->cell_c.release(); ctx->cell_s.release(); ctx->views_c.release(); ctx->views_s.release();
   ctx->prev_nb.release();
   ctx->xchg.release();
@@ -492,6 +508,7 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
         if (const char *dv = std::getenv("LSLAM_DEBUG_NODE_CAP_DIV"))  // tests: force the retry / failure paths
           cap = std::max<size_t>(16, (cap / (size_t)std::max(1, atoi(dv))) & ~(size_t)7);
         if ((errs[k] = dt.nodes.reserve(cap)) != hipSuccess) return;
+        if ((errs[k] = dt.pn.reserve(cap)) != hipSuccess) return;
         if (n && from_dev) {
           errs[k] = hipMemcpyAsync(dt.pts.p, dev_src[k], n * sizeof(float4), hipMemcpyDeviceToDevice, st);
         } else if (n && attempt > dt.cap_attempt) {
@@ -523,7 +540,7 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
           }
         }
         if (errs[k] != hipSuccess) return;
-        errs[k] = build_kdtree_device(dt.pts.p, (int32_t)n, dt.nodes.p, (int32_t)cap, st, &dt.view, &dt.depth,
+        errs[k] = build_kdtree_device(dt.pts.p, (int32_t)n, dt.nodes.p, dt.pn.p, (int32_t)cap, st, &dt.view, &dt.depth,
                                       &n_leaves, &fallback);
         if (errs[k] != hipSuccess) return;
         if (fallback != 1) {
@@ -653,10 +670,11 @@ int build_cube_side_device(lslam_ctx *ctx, DevTree &dt, const float4 *src, bool 
     const size_t mult[3] = {2, 8, 24};
     const size_t cap = ((mult[attempt] * n_pts / 3 + 64 + 8 * (size_t)T) + 7) & ~(size_t)7;
     HIP_TRY(dt.nodes.reserve(cap));
+    HIP_TRY(dt.pn.reserve(cap));
     if (n_pts)
       HIP_TRY(hipMemcpyAsync(dt.pts.p, src, n_pts * sizeof(float4), src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                              ctx->stream));
-    HIP_TRY(build_kdforest_device(dt.pts.p, (int32_t)n_pts, roots_lr.data(), T, dt.nodes.p, (int32_t)cap, ctx->stream,
+    HIP_TRY(build_kdforest_device(dt.pts.p, (int32_t)n_pts, roots_lr.data(), T, dt.nodes.p, dt.pn.p, (int32_t)cap, ctx->stream,
                                   views.data(), max_depth, &n_leaves, fallback));
     if (*fallback != 1) break;
   }
@@ -929,6 +947,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
                          hipMemcpyHostToDevice, ctx->stream));
   SweepArgs sa;
   fill_sweep_args(ctx, sa);
+  sa.packet = resolve_search_mode(ctx, o.search_mode) == LSLAM_SEARCH_PACKET ? 1 : 0;
   // the production sweep keeps a shallow stack in LDS: it always gets the overflow area (sized per
   // chunk below; the sharded path has one resident scan)
   const bool sharded = fn != nullptr || use_comm;
@@ -1563,6 +1582,11 @@ void lslam_pose_to_isometry(const float pose[6], float T[16]) {
 
 int lslam_knn5(lslam_ctx *ctx, int which_map, const void *queries, size_t nq, size_t stride_bytes,
                int32_t *idx_out, float *d2_out) {
+  return lslam_knn5_ex(ctx, which_map, queries, nq, stride_bytes, LSLAM_SEARCH_LANE, idx_out, d2_out, nullptr);
+}
+
+int lslam_knn5_ex(lslam_ctx *ctx, int which_map, const void *queries, size_t nq, size_t stride_bytes,
+                  int32_t search_mode, int32_t *idx_out, float *d2_out, int32_t *n_ties) {
   int rc = check_ctx(ctx);
   if (rc) return rc;
   if (!ctx->have_map || ctx->cube_mode) { set_err("no whole-map tree set"); return LSLAM_ERR_NO_MAP; }
@@ -1580,17 +1604,50 @@ int lslam_knn5(lslam_ctx *ctx, int which_map, const void *queries, size_t nq, si
   HIP_TRY(hipMemcpyAsync(ctx->t_q.p, q.data(), nq * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
   const TreeView &T = which_map ? ctx->ts.view : ctx->tc.view;
   uint32_t *ovf = nullptr;
-  rc = ensure_stack_ovf(ctx, ((nq + 127) / 128) * 128, &ovf);
-  if (rc) return rc;
-  HIP_TRY(launch_knn5(T, ctx->t_q.p, (int)nq, ctx->t_idx.p, ctx->t_d2.p, ovf, ctx->stream));
+  if (n_ties) *n_ties = 0;
+  if (search_mode == LSLAM_SEARCH_PACKET) {
+    if (!T.pn) { set_err("this map has no packet-search nodes"); return LSLAM_ERR_INVALID; }
+    const size_t nthr = ((nq + 255) / 256) * 256;
+    HIP_TRY(ctx->stack_ovf.reserve(stack_ovf_words(nthr)));
+    HIP_TRY(ctx->t_small.reserve(64));
+    int32_t *d_tie = reinterpret_cast<int32_t *>(ctx->t_small.p);
+    HIP_TRY(hipMemsetAsync(d_tie, 0, sizeof(int32_t), ctx->stream));
+    HIP_TRY(launch_knn5_packet(T, ctx->t_q.p, (int)nq, ctx->t_idx.p, ctx->t_d2.p, ctx->stack_ovf.p, d_tie, ctx->stream));
+    if (n_ties) HIP_TRY(hipMemcpyAsync(n_ties, d_tie, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  } else {
+    rc = ensure_stack_ovf(ctx, ((nq + 127) / 128) * 128, &ovf);
+    if (rc) return rc;
+    HIP_TRY(launch_knn5(T, ctx->t_q.p, (int)nq, ctx->t_idx.p, ctx->t_d2.p, ovf, ctx->stream));
+  }
   HIP_TRY(hipMemcpyAsync(idx_out, ctx->t_idx.p, nq * 5 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(d2_out, ctx->t_d2.p, nq * 5 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return LSLAM_OK;
 }
 
+#ifdef LSLAM_PACKET_STATS
+// profiling build only: queries (map frame, caller's order = packet order) -> per-wave counters [nwaves][8]
+int lslam_debug_packet_stats(lslam_ctx *ctx, int which_map, const float *q_xyzw, size_t nq, uint32_t *out) {
+  int rc = check_ctx(ctx);
+  if (rc) return rc;
+  const TreeView &T = which_map ? ctx->ts.view : ctx->tc.view;
+  HIP_TRY(ctx->t_q.reserve(nq));
+  HIP_TRY(ctx->t_idx.reserve(((nq + 63) / 64) * 8 + 64));
+  HIP_TRY(hipMemcpyAsync(ctx->t_q.p, q_xyzw, nq * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(launch_packet_stats(T, ctx->t_q.p, (int)nq, reinterpret_cast<unsigned *>(ctx->t_idx.p), ctx->stream));
+  HIP_TRY(hipMemcpyAsync(out, ctx->t_idx.p, ((nq + 63) / 64) * 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return LSLAM_OK;
+}
+#endif
+
 int lslam_sweep(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_t *idx_out,
                 float *d2_out, float *coeff_out, uint8_t *flags_out, float *sums_out) {
+  return lslam_sweep_ex(ctx, pose, jtj_mode, LSLAM_SEARCH_LANE, idx_out, d2_out, coeff_out, flags_out, sums_out);
+}
+
+int lslam_sweep_ex(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_t search_mode, int32_t *idx_out,
+                   float *d2_out, float *coeff_out, uint8_t *flags_out, float *sums_out) {
   int rc = check_ctx(ctx);
   if (rc) return rc;
   if (!ctx->have_map) { set_err("no map set"); return LSLAM_ERR_NO_MAP; }
@@ -1604,6 +1661,12 @@ int lslam_sweep(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_t *
   fill_sweep_args(ctx, sa);
   rc = ensure_stack_ovf(ctx, (size_t)sa.nb_total * SWEEP_BLOCK, &sa.stack_ovf);
   if (rc) return rc;
+  if (search_mode == LSLAM_SEARCH_PACKET) {
+    if (ctx->cube_mode || !ctx->tc.view.pn || !ctx->ts.view.pn) { set_err("this map has no packet-search nodes"); return LSLAM_ERR_INVALID; }
+    HIP_TRY(ctx->stack_ovf.reserve(stack_ovf_words((size_t)std::max(sa.nb_total, 1) * SWEEP_BLOCK)));
+    sa.stack_ovf = ctx->stack_ovf.p;
+    sa.packet = 1;
+  }
   const bool taps = idx_out || d2_out || coeff_out || flags_out;
   if (taps) {
     HIP_TRY(ctx->t_idx.reserve(N * 5 + 1));

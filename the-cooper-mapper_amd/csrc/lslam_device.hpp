@@ -15,6 +15,9 @@
 namespace lslam {
 
 #define LSLAM_DEV __device__ __forceinline__
+#ifndef LSLAM_LEAF_LOAD_ALL
+#define LSLAM_LEAF_LOAD_ALL 1  // 0: a lane only loads the points its leaf holds -- measured SLOWER (0.475 vs 0.448 ms per 2.6 M-point launch): the vector memory pipe is paid per wave-instruction, not per active lane
+#endif
 
 // ---------------------------------------------------------------------------
 // kd-tree in HBM.  Topology and leaf order are exactly nanoflann v1.2.3's
@@ -35,12 +38,22 @@ struct alignas(16) KdNode {
   uint32_t c1, c2;  // child references
 };
 
+// Node of the packet search (lslam_packet.hpp): the two child references of the KdNode in the same
+// slot and the TIGHT bounding boxes {min x,y,z, max x,y,z} of the points below each child.  64 bytes,
+// fetched with one scalar load by a wavefront that walks the tree for 64 neighbouring queries at once.
+struct alignas(64) PNode {
+  uint32_t c1, c2;
+  float box[2][6];
+  uint32_t pad[2];
+};
+
 constexpr uint32_t KD_LEAF = 0x80000000u;
 constexpr uint32_t KD_MAX_POINTS = 1u << 27;  // leaf reference: 27-bit left
 constexpr uint32_t KD_MAX_INNER = 1u << 29;   // stack entry: 29-bit node index
 
 struct TreeView {
   const KdNode *nodes;
+  const PNode *pn;  // same slots as `nodes` (null: tree built without boxes)
   const float4 *pts;
   float bb_lo[3], bb_hi[3];  // root_bbox, nanoflann.hpp:1406-1427
   int32_t n_pts, n_nodes;
@@ -202,9 +215,11 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
       TS_INC(n_leaf)
       const int l = (int)((ref & ~KD_LEAF) >> 4), cnt = (int)(ref & 15u);
       const float worst = fminf(d[4], bound);  // worst_dist cached once per leaf
+      // all of the leaf's loads are issued before any distance is evaluated
       float4 pt[10];
 #pragma unroll
-      for (int j = 0; j < 10; ++j) pt[j] = T.pts[l + j];
+      for (int j = 0; j < 10; ++j)
+        if (LSLAM_LEAF_LOAD_ALL || j < cnt) pt[j] = T.pts[l + j];
 #pragma unroll
       for (int j = 0; j < 10; ++j) {
         if (j < cnt) {

@@ -87,6 +87,7 @@ struct SweepArgs {
   int32_t prev_valid;     // prev_nb holds positions of the current trees
   int32_t bounded;        // 1: production loop (bounded search), 0: taps (nanoflann's plain search)
   int32_t deep_tree;      // a tree is deeper than KD_STACK_LDS+1: the LDS-only kernels cannot be used
+  int32_t packet;         // 1: wave-cooperative packet search (lslam_packet.hpp); needs stack_ovf and the trees' PNodes
   // optional per-point taps (all NULL in the production loop)
   int32_t *idx_out;    // [N][5] original map indices
   float *d2_out;       // [N][5]
@@ -162,6 +163,11 @@ hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s,
 hipError_t launch_solve(const SolveArgs &a, hipStream_t s);
 hipError_t launch_knn5(const TreeView &T, const float4 *q, int nq, int32_t *idx, float *d2,
                        uint32_t *stack_ovf, hipStream_t s);
+hipError_t launch_knn5_packet(const TreeView &T, const float4 *q, int nq, int32_t *idx, float *d2, uint32_t *stack_ovf,
+                              int32_t *n_tie, hipStream_t s);
+#ifdef LSLAM_PACKET_STATS
+hipError_t launch_packet_stats(const TreeView &T, const float4 *q, int nq, unsigned *out, hipStream_t s);
+#endif
 // words of overflow stack needed for n_threads lanes
 inline size_t stack_ovf_words(size_t n_threads) {
   return 2 * (size_t)KD_STACK_MAX * n_threads;  // enough for any LDS depth
@@ -170,12 +176,13 @@ hipError_t launch_gn_step_tap(GNState *st, const float *AtA, const float *Atb, f
                               float eig_thresh, hipStream_t s);
 
 // device kd-tree builder (lslam_treebuild.hip): same tree, built in HBM
-hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_t node_cap,
+// d_pn (node_cap PNodes, or null): also the packet-search nodes (child boxes) of every used slot
+hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, PNode *d_pn, int32_t node_cap,
                                hipStream_t stream, TreeView *view, int *depth, size_t *n_leaves,
                                int *fallback);
 
 hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *roots_lr, int T, KdNode *d_nodes,
-                                 int32_t node_cap, hipStream_t stream, TreeView *views, int *max_depth,
+                                 PNode *d_pn, int32_t node_cap, hipStream_t stream, TreeView *views, int *max_depth,
                                  size_t *n_leaves, int *fallback);
 void treebuild_release_scratch(hipStream_t s);  // frees the per-stream build scratch
 

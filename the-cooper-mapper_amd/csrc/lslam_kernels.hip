@@ -14,6 +14,7 @@
 #include <hip/hip_ext.h>
 
 #include "lslam_internal.hpp"
+#include "lslam_packet.hpp"
 
 namespace lslam {
 
@@ -56,7 +57,10 @@ LSLAM_DEV int cube_tree_of(const CubeGridDev &g, float x, float y, float z) {
 #ifndef LSLAM_SHALLOW_OCC
 #define LSLAM_SHALLOW_OCC 5  // wavefronts per SIMD the shallow-stack variant is compiled for (96 VGPRs, 25 KB LDS per workgroup)
 #endif
-template <int BLOCK, bool OVF, bool CUBES, int LDS_DEPTH>
+// PACKET: the 5-NN search is the wave-cooperative one of lslam_packet.hpp (scalar loads, no per-lane
+// traversal stack: LDS_DEPTH = 4 only provides the eight staging rows of the MFMA contraction); lanes
+// that see an exact distance tie redo their search with nanoflann's traversal (stack in HBM).
+template <int BLOCK, bool OVF, bool CUBES, int LDS_DEPTH, bool PACKET = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH <= 16 ? LSLAM_SHALLOW_OCC : 2))) void sweep_kernel(SweepArgs a, int jtj_mode) {
   const int lb = xcd_remap(blockIdx.x, a.nb_total);
   const BlockDesc bd = a.blocks[lb];
@@ -92,18 +96,68 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
   float rb = 0.0f;
   float kept = 0.0f, matched = 0.0f, score = 0.0f;
 
-  if (active) {
-    const float4 q = a.q[qi];
-    // util/transform_utils.h:476-482 pointAssociateToMap: it * p
-    float sel[3];
+  // PACKET: the search is a wave-level operation -- every lane of the wavefront takes part (lanes without
+  // a point carry a dummy query and are masked out of every decision)
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  float sel[3] = {0.f, 0.f, 0.f};
+  float d[5];
+  int p[5];
+  TreeView T;
+  if (PACKET) {
+    if (active) q = a.q[qi];
     sel[0] = ((R[0] * q.x + R[1] * q.y) + R[2] * q.z) + t[0];
     sel[1] = ((R[3] * q.x + R[4] * q.y) + R[5] * q.z) + t[1];
     sel[2] = ((R[6] * q.x + R[7] * q.y) + R[8] * q.z) + t[2];
+    T = is_surf ? a.ts : a.tc;  // block-uniform
+    float cap = FLT_MAX;
+    if (a.bounded) {
+      cap = 5.0f * (1.0f + 1e-5f);
+      if (a.prev_valid && active) {
+        float u = 0.0f;
+        bool all = true;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const int pp = a.prev_nb[(size_t)qi * 5 + j];
+          all = all && pp >= 0 && pp < T.n_pts;
+          if (pp >= 0 && pp < T.n_pts) u = fmaxf(u, dist2_xyz(sel[0], sel[1], sel[2], T.pts[pp]));
+        }
+        if (all) cap = fminf(cap, u * (1.0f + 1e-5f) + 1e-12f);
+      }
+    }
+    bool tie;
+#ifdef LSLAM_PACKET_STATS
+    PacketStats ps_unused = {0, 0, 0, 0};
+    knn5_packet(T, sel[0], sel[1], sel[2], active, cap, d, p, tie, ps_unused);
+#else
+    knn5_packet(T, sel[0], sel[1], sel[2], active, cap, d, p, tie);
+#endif
+    if (a.bounded) tie = tie && d[4] < 5.0f;  // beyond the gate the five are not used (ScanMatch.cpp:102,120)
+    if (__any(tie)) {  // exact distance ties: nanoflann's visit order decides -- its own traversal, stack in HBM
+      if (tie) {
+        KdStack<BLOCK, true, 0> stk;
+        stk.lds = nullptr;
+        stk.ovf = a.stack_ovf + ((size_t)blockIdx.x * BLOCK + tid);
+        stk.ovf_stride = (size_t)a.nb_total * BLOCK;
+        knn5_search<BLOCK, true, 0>(T, sel[0], sel[1], sel[2], d, p, stk);
+      }
+    }
+    if (a.bounded && active) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) a.prev_nb[(size_t)qi * 5 + j] = p[j];
+    }
+  }
 
-    float d[5];
-    int p[5];
-    TreeView T;
+  if (active) {
+    if (!PACKET) {
+    q = a.q[qi];
+    // util/transform_utils.h:476-482 pointAssociateToMap: it * p
+    sel[0] = ((R[0] * q.x + R[1] * q.y) + R[2] * q.z) + t[0];
+    sel[1] = ((R[3] * q.x + R[4] * q.y) + R[5] * q.z) + t[1];
+    sel[2] = ((R[6] * q.x + R[7] * q.y) + R[8] * q.z) + t[2];
+    }
+
     bool searched = true;
+    if (!PACKET) {
     if (CUBES) {  // per-lane tree: the cube the transformed point falls into (FeatureMap.h:523-526)
       const int tree = cube_tree_of(is_surf ? a.gs : a.gc, sel[0], sel[1], sel[2]);
       searched = tree >= 0;
@@ -164,6 +218,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
       for (int j = 0; j < 5; ++j) a.prev_nb[(size_t)qi * 5 + j] = p[j];
     }
 #endif
+    }  // !PACKET
+    (void)searched;
     if (a.dbg) dbg_t1 = __builtin_readcyclecounter();
 
     float coeff[4] = {0, 0, 0, 0};
@@ -302,7 +358,9 @@ hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEven
   // and every wavefront is resident anyway: keep the whole stack in LDS.
   const bool many_waves = (long)a.nb_total * (SWEEP_BLOCK / 64) > 2 * 1024;
   const bool deep_tree = a.deep_tree != 0;
-  if (a.bounded && a.stack_ovf && !cubes && (many_waves || deep_tree))
+  if (a.packet && !cubes && a.stack_ovf && a.tc.pn && a.ts.pn)
+    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, 4, true>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+  else if (a.bounded && a.stack_ovf && !cubes && (many_waves || deep_tree))
     hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, SHALLOW>), g, b, 0, s, start, stop, 0, a, jtj_mode);
   else if (cubes && a.stack_ovf && deep_tree)
     hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, true, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
@@ -1096,6 +1154,74 @@ __global__ __launch_bounds__(128, 2) void knn5_kernel(TreeView T, const float4 *
     idx[i * 5 + j] = p[j] >= 0 ? __float_as_int(T.pts[p[j]].w) : -1;
     d2[i * 5 + j] = d[j];
   }
+}
+
+// the same tap through the packet search: 64 consecutive queries per wavefront (their order is the
+// caller's: scattered queries make slow packets, the answer does not depend on it); tie lanes are redone
+// with knn5_search on the HBM stack
+__global__ __launch_bounds__(256) void knn5_packet_kernel(TreeView T, const float4 *q, int nq, int32_t *idx, float *d2,
+                                                          uint32_t *stack_ovf, int32_t *n_tie) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool on = i < nq;
+  const float4 qq = on ? q[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float d[5];
+  int p[5];
+  bool tie;
+#ifdef LSLAM_PACKET_STATS
+  PacketStats ps_unused = {0, 0, 0, 0};
+  knn5_packet(T, qq.x, qq.y, qq.z, on, FLT_MAX, d, p, tie, ps_unused);
+#else
+  knn5_packet(T, qq.x, qq.y, qq.z, on, FLT_MAX, d, p, tie);
+#endif
+  if (__any(tie)) {
+    if (tie) {
+      if (n_tie) atomicAdd(n_tie, 1);
+      KdStack<256, true, 0> stk;
+      stk.lds = nullptr;
+      stk.ovf = stack_ovf + i;
+      stk.ovf_stride = (size_t)gridDim.x * 256;
+      knn5_search<256, true, 0>(T, qq.x, qq.y, qq.z, d, p, stk);
+    }
+  }
+  if (!on) return;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    idx[i * 5 + j] = p[j] >= 0 ? __float_as_int(T.pts[p[j]].w) : -1;
+    d2[i * 5 + j] = d[j];
+  }
+}
+
+#ifdef LSLAM_PACKET_STATS
+// profiling build only (tools/packet_stats.py): per wavefront {nodes, leaves, inserts, pops, ties, cycles}
+__global__ __launch_bounds__(256) void packet_stats_kernel(TreeView T, const float4 *q, int nq, unsigned *out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool on = i < nq;
+  const float4 qq = on ? q[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float d[5];
+  int p[5];
+  bool tie;
+  PacketStats ps = {0, 0, 0, 0};
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  knn5_packet(T, qq.x, qq.y, qq.z, on, 5.0f, d, p, tie, ps);
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  const int nt = __popcll(__ballot(tie && d[4] < 5.0f));
+  if ((threadIdx.x & 63) == 0) {
+    unsigned *o = out + (size_t)(i >> 6) * 8;
+    o[0] = ps.nodes; o[1] = ps.leaves; o[2] = ps.inserts; o[3] = ps.pops; o[4] = nt; o[5] = (unsigned)(t1 - t0);
+    o[6] = (unsigned)__float_as_uint(d[4]); o[7] = 0;
+  }
+}
+hipError_t launch_packet_stats(const TreeView &T, const float4 *q, int nq, unsigned *out, hipStream_t s) {
+  hipLaunchKernelGGL(packet_stats_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, T, q, nq, out);
+  return hipGetLastError();
+}
+#endif
+
+hipError_t launch_knn5_packet(const TreeView &T, const float4 *q, int nq, int32_t *idx, float *d2, uint32_t *stack_ovf,
+                              int32_t *n_tie, hipStream_t s) {
+  if (nq <= 0) return hipSuccess;
+  hipLaunchKernelGGL(knn5_packet_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, T, q, nq, idx, d2, stack_ovf, n_tie);
+  return hipGetLastError();
 }
 
 hipError_t launch_knn5(const TreeView &T, const float4 *q, int nq, int32_t *idx, float *d2,

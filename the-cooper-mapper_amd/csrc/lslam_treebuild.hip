@@ -89,7 +89,17 @@ struct BuildArgs {
   int32_t n;
   int32_t reg_nodes;   // 1: nodes of at most 64 points are finished in registers (phase B)
   uint32_t spin_limit; // watchdog of idle phase-A workgroups (polls of ~2 x 127 sleep units)
+  float *own_box;      // [node_cap][6] (or null): tight bounding box {min xyz, max xyz} of every inner node's points --
+                       // the extrema middleSplit_ needs anyway; the packet search's node boxes are made from them
 };
+
+__device__ __forceinline__ void store_own_box(const BuildArgs &A, int slot, float n0, float n1, float n2, float x0, float x1,
+                                              float x2) {
+  if (A.own_box) {
+    float *o = A.own_box + (size_t)slot * 6;
+    o[0] = n0; o[1] = n1; o[2] = n2; o[3] = x0; o[4] = x1; o[5] = x2;
+  }
+}
 
 __device__ __forceinline__ float coord(const float4 &p, int d) { return d == 0 ? p.x : (d == 1 ? p.y : p.z); }
 
@@ -304,6 +314,7 @@ __device__ void process_node(const BuildArgs &A, Sh<TB> &sh, const BuildItem &it
       emin[d] = sh.fmin[d][0]; emax[d] = sh.fmax[d][0];
       for (int w = 1; w < TB / 64; ++w) { emin[d] = fminf(emin[d], sh.fmin[d][w]); emax[d] = fmaxf(emax[d], sh.fmax[d][w]); }
     }
+    store_own_box(A, it.slot, emin[0], emin[1], emin[2], emax[0], emax[1], emax[2]);
     const float EPS = 0.00001f;
     float max_span = it.hi[0] - it.lo[0];
     for (int d = 1; d < 3; ++d) { const float span = it.hi[d] - it.lo[d]; if (span > max_span) max_span = span; }
@@ -685,6 +696,7 @@ __global__ __launch_bounds__(64) void kd_build_small_kernel(BuildArgs A) {
             float *fw = reinterpret_cast<float *>(words + (size_t)slot * 4);
             fw[0] = divlow;
             fw[1] = divhigh;
+            store_own_box(A, slot, en0, en1, en2, ex0, ex1, ex2);
             if (leafL) words[(size_t)slot * 4 + 2] = KD_LEAF | ((uint32_t)(L0 + a + sa) << 4) | (uint32_t)cntL;
             if (leafR) words[(size_t)slot * 4 + 3] = KD_LEAF | ((uint32_t)(L0 + a + mid) << 4) | (uint32_t)cntR;
             if (leafL || leafR) reg_depth = max(reg_depth, depth + 1);
@@ -722,6 +734,7 @@ __global__ __launch_bounds__(64) void kd_build_small_kernel(BuildArgs A) {
       float emin[3], emax[3];
 #pragma unroll
       for (int d = 0; d < 3; ++d) { emin[d] = wave_min(mn[d]); emax[d] = wave_max(mx[d]); }
+      if (lane == 0) store_own_box(A, it.slot, emin[0], emin[1], emin[2], emax[0], emax[1], emax[2]);
       // ---- middleSplit_ (:982-1031), computed by every lane ------------------------------
       const float EPS = 0.00001f;
       float max_span = it.hi[0] - it.lo[0];
@@ -1087,6 +1100,10 @@ __global__ __launch_bounds__(LV_TB) void lv_count_kernel(LvArgs L) {
   float cut;
   lv_split(it, L.stat[node], &feat, &cut);
   if (c0 == 0 && threadIdx.x == 0) {  // the node's first chunk publishes the split for the later passes
+    {
+      const LvStat &sb = L.stat[node];
+      store_own_box(L.A, it.slot, ord_f(sb.mn[0]), ord_f(sb.mn[1]), ord_f(sb.mn[2]), ord_f(sb.mx[0]), ord_f(sb.mx[1]), ord_f(sb.mx[2]));
+    }
     L.stat[node].feat = feat;
     L.stat[node].cut = cut;
   }
@@ -1371,6 +1388,40 @@ __global__ __launch_bounds__(256) void kd_bbox_seg_kernel(const float4 *pts, con
   }
 }
 
+// Packet-search nodes: per used slot the child references and the children's tight boxes -- an inner
+// child's box is the extrema its own split computed (own_box), a leaf child's box comes from its <= 10 points.
+__global__ __launch_bounds__(256) void kd_pnode_kernel(const KdNode *nodes, int n_slots, const float4 *pts,
+                                                       const float *own_box, PNode *pn) {
+  const int slot = blockIdx.x * 256 + threadIdx.x;
+  if (slot >= n_slots) return;
+  const KdNode nd = nodes[slot];
+  PNode o;
+  o.c1 = nd.c1;
+  o.c2 = nd.c2;
+  o.pad[0] = o.pad[1] = 0;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const uint32_t ref = c ? nd.c2 : nd.c1;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    if ((nd.c1 | nd.c2) == 0) {  // unused slot
+    } else if (ref & KD_LEAF) {
+      const int l = (int)((ref & ~KD_LEAF) >> 4), cnt = (int)(ref & 15u);
+      for (int k = 0; k < cnt; ++k) {
+        const float4 p = pts[l + k];
+        mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+        mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+        mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+      }
+    } else {
+      const float *b = own_box + (size_t)(ref >> 2) * 6;
+      mn[0] = b[0]; mn[1] = b[1]; mn[2] = b[2]; mx[0] = b[3]; mx[1] = b[4]; mx[2] = b[5];
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { o.box[c][d] = mn[d]; o.box[c][3 + d] = mx[d]; }
+  }
+  pn[slot] = o;
+}
+
 }  // namespace
 
 // Build the tree of `n` points at d_pts (float4 {x,y,z,bitcast(original index)}, permuted in
@@ -1492,7 +1543,7 @@ static int32_t reg_nodes_enabled() {
   return off ? 0 : 1;
 }
 
-hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_t node_cap,
+hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, PNode *d_pn, int32_t node_cap,
                                hipStream_t stream, TreeView *view, int *depth, size_t *n_leaves,
                                int *fallback) {
   const bool dbg = std::getenv("LSLAM_DEBUG") != nullptr;
@@ -1500,6 +1551,7 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
   const double T0 = now();
   *fallback = 0;
   view->nodes = d_nodes;
+  view->pn = d_pn;
   view->pts = d_pts;
   view->n_pts = n;
   view->n_nodes = 0;
@@ -1553,15 +1605,17 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
   void *blob = nullptr;
   A.sub_cap = sub_cap;
   const size_t sz_queue = (size_t)queue_cap * sizeof(BuildItem), sz_ready = (size_t)queue_cap * sizeof(int32_t),
-               sz_tmp = (size_t)n * sizeof(int32_t), sz_ctl = 256, sz_sub = (size_t)sub_cap * sizeof(BuildItem);
-  if ((e = pool_get(stream, false, sz_queue + sz_sub + sz_ready + 2 * sz_tmp + sz_ctl, &blob)) != hipSuccess) return e;
+               sz_tmp = (size_t)n * sizeof(int32_t), sz_ctl = 256, sz_sub = (size_t)sub_cap * sizeof(BuildItem),
+               sz_own = d_pn ? (size_t)A.node_cap * 6 * sizeof(float) : 0;
+  if ((e = pool_get(stream, false, sz_queue + sz_sub + sz_ready + 2 * sz_tmp + sz_ctl + sz_own, &blob)) != hipSuccess) return e;
   char *p = static_cast<char *>(blob);
   A.queue = reinterpret_cast<BuildItem *>(p); p += sz_queue;
   A.sublist = reinterpret_cast<BuildItem *>(p); p += sz_sub;
   A.q_ready = reinterpret_cast<int32_t *>(p); p += sz_ready;
   A.tmpA = reinterpret_cast<int32_t *>(p); p += sz_tmp;
   A.tmpB = reinterpret_cast<int32_t *>(p); p += sz_tmp;
-  A.ctl = reinterpret_cast<BuildCtl *>(p);
+  A.ctl = reinterpret_cast<BuildCtl *>(p); p += sz_ctl;
+  A.own_box = d_pn ? reinterpret_cast<float *>(p) : nullptr;
   A.root_feat = &A.ctl->root_feat;
   if ((e = hipMemsetAsync(A.q_ready, 0, sz_ready, stream)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(d_nodes, 0, (size_t)A.node_cap * sizeof(KdNode), stream)) != hipSuccess) return e;
@@ -1618,6 +1672,11 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(&ctl, A.ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
   if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+  if (d_pn && !ctl.overflow) {  // packet-search nodes of the slots in use (stays enqueued behind the build)
+    const int n_slots = std::min(ctl.next_group * 8, A.node_cap);
+    hipLaunchKernelGGL(kd_pnode_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, stream, d_nodes, n_slots, d_pts, A.own_box, d_pn);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
   const double T3 = now();
   if (dbg)
     fprintf(stderr, "[lslam] tree build n=%d: bbox %.2f ms, setup %.2f ms, build kernel %.2f ms, free %.2f ms (overflow %d, groups %d)\n",
@@ -1638,7 +1697,7 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, int32_
 // root above HUGE_MIN points, phase B the rest; roots of at most 10 points are leaves.  views[t] is
 // filled for every root (nodes = d_nodes, pts = d_pts: references are absolute).
 hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *roots_lr, int T, KdNode *d_nodes,
-                                 int32_t node_cap, hipStream_t stream, TreeView *views, int *max_depth,
+                                 PNode *d_pn, int32_t node_cap, hipStream_t stream, TreeView *views, int *max_depth,
                                  size_t *n_leaves, int *fallback) {
   *fallback = 0;
   *max_depth = 0;
@@ -1657,9 +1716,10 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   A.reg_nodes = reg_nodes_enabled();
   const size_t sz_queue = (size_t)queue_cap * sizeof(BuildItem), sz_ready = (size_t)queue_cap * sizeof(int32_t),
                sz_tmp = (size_t)std::max(n_total, 1) * sizeof(int32_t), sz_ctl = 256, sz_sub = (size_t)sub_cap * sizeof(BuildItem),
-               sz_rf = ((size_t)T * 4 + 15) & ~(size_t)15, sz_lr = ((size_t)T * 8 + 15) & ~(size_t)15, sz_bb = (size_t)T * 24;
+               sz_rf = ((size_t)T * 4 + 15) & ~(size_t)15, sz_lr = ((size_t)T * 8 + 15) & ~(size_t)15,
+               sz_bb = ((size_t)T * 24 + 15) & ~(size_t)15, sz_own = d_pn ? (size_t)A.node_cap * 6 * sizeof(float) : 0;
   void *blob = nullptr;
-  if ((e = pool_get(stream, false, sz_queue + sz_sub + sz_ready + 2 * sz_tmp + sz_ctl + sz_rf + sz_lr + sz_bb, &blob)) != hipSuccess) return e;
+  if ((e = pool_get(stream, false, sz_queue + sz_sub + sz_ready + 2 * sz_tmp + sz_ctl + sz_rf + sz_lr + sz_bb + sz_own, &blob)) != hipSuccess) return e;
   char *p = static_cast<char *>(blob);
   A.queue = reinterpret_cast<BuildItem *>(p); p += sz_queue;
   A.sublist = reinterpret_cast<BuildItem *>(p); p += sz_sub;
@@ -1669,7 +1729,9 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   A.ctl = reinterpret_cast<BuildCtl *>(p); p += sz_ctl;
   A.root_feat = reinterpret_cast<int32_t *>(p); p += sz_rf;
   int32_t *d_lr = reinterpret_cast<int32_t *>(p); p += sz_lr;
-  float *d_bb = reinterpret_cast<float *>(p);
+  float *d_bb = reinterpret_cast<float *>(p); p += sz_bb;
+  A.own_box = d_pn ? reinterpret_cast<float *>(p) : nullptr;
+  A.spin_limit = 1u << 22;
   if ((e = hipMemcpyAsync(d_lr, roots_lr, (size_t)T * 8, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
   hipLaunchKernelGGL(kd_bbox_seg_kernel, dim3(T), dim3(256), 0, stream, d_pts, d_lr, d_bb);
   std::vector<float> bb((size_t)T * 6);
@@ -1684,6 +1746,7 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
     const int l = roots_lr[2 * t], r = roots_lr[2 * t + 1], n = r - l;
     TreeView &v = views[t];
     v.nodes = d_nodes;
+    v.pn = d_pn;
     v.pts = d_pts;
     v.n_pts = n;
     v.n_nodes = 0;
@@ -1736,6 +1799,11 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
     return hipSuccess;
   }
   const int32_t n_nodes = std::min(ctl.next_group * 8, A.node_cap);
+  if (d_pn) {
+    hipLaunchKernelGGL(kd_pnode_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, d_nodes, n_nodes, d_pts, A.own_box, d_pn);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;  // the scratch holding own_box is reused by the next build
+  }
   for (int t = 0; t < T; ++t) {
     views[t].n_nodes = n_nodes;
     if (slot_of[t] >= 0) views[t].root_ref = ((uint32_t)slot_of[t] << 2) | (uint32_t)rf[t];

@@ -281,15 +281,17 @@ class Context:
         return a
 
     # -- parity taps -------------------------------------------------------------
-    def knn5(self, which_map, queries):
+    def knn5(self, which_map, queries, search_mode=1, want_ties=False):
+        """lslam_knn5_ex; search_mode 1 = one query per lane (nanoflann's traversal), 2 = packet search."""
         q, sq = _cloud(queries)
         idx = np.zeros((len(q), 5), np.int32)
         d2 = np.zeros((len(q), 5), np.float32)
-        self._check(self.lib.lslam_knn5(self.h, int(which_map), _vp(q), len(q), sq,
-                                        idx.ctypes.data_as(c_int32_p), _fp(d2)))
-        return idx, d2
+        ties = C.c_int32(0)
+        self._check(self.lib.lslam_knn5_ex(self.h, int(which_map), _vp(q), len(q), sq, int(search_mode),
+                                           idx.ctypes.data_as(c_int32_p), _fp(d2), C.byref(ties)))
+        return (idx, d2, ties.value) if want_ties else (idx, d2)
 
-    def sweep(self, pose, jtj_mode=0, taps=True):
+    def sweep(self, pose, jtj_mode=0, taps=True, search_mode=1):
         p = np.array(pose, dtype=np.float32).reshape(6)
         n = self.n_scan
         sums = np.zeros(30, np.float32)
@@ -298,11 +300,11 @@ class Context:
             d2 = np.zeros((n, 5), np.float32)
             coeff = np.zeros((n, 4), np.float32)
             flags = np.zeros(n, np.uint8)
-            self._check(self.lib.lslam_sweep(self.h, _fp(p), jtj_mode, idx.ctypes.data_as(c_int32_p),
-                                             _fp(d2), _fp(coeff), flags.ctypes.data_as(c_uint8_p),
-                                             _fp(sums)))
+            self._check(self.lib.lslam_sweep_ex(self.h, _fp(p), jtj_mode, int(search_mode), idx.ctypes.data_as(c_int32_p),
+                                                _fp(d2), _fp(coeff), flags.ctypes.data_as(c_uint8_p),
+                                                _fp(sums)))
             return dict(idx=idx, d2=d2, coeff=coeff, flags=flags, sums=sums)
-        self._check(self.lib.lslam_sweep(self.h, _fp(p), jtj_mode, None, None, None, None, _fp(sums)))
+        self._check(self.lib.lslam_sweep_ex(self.h, _fp(p), jtj_mode, int(search_mode), None, None, None, None, _fp(sums)))
         return dict(sums=sums)
 
     def gn_step(self, AtA, Atb, it, pose, matP, degenerate, dr=0.05, dt=0.05):

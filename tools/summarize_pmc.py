@@ -25,8 +25,8 @@ def main():
             for c in sorted(acc):
                 lines.append((os.path.basename(os.path.normpath(d)), c, len(acc[c]), sum(acc[c]) / len(acc[c]), gmax))
     with open(out, "w") as fo:
-        fo.write("# rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python3 bench.py --steps 6 --warmup 2 "
-                 "--no-cpu-baseline --no-pose-graph --no-single --no-mapping-frame   (one pass per counter set)\n")
+        fo.write("# rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python3 bench.py --headline-only --steps 2 --warmup 1 "
+                 "(one pass per counter set)\n")
         fo.write("# kernel: %s ; full-batch launches only (Grid_Size = max); FETCH_SIZE/WRITE_SIZE in KiB as reported\n" % kname)
         fo.write("pass,counter,launches,mean_per_launch,grid_size\n")
         for l in lines:

@@ -360,6 +360,19 @@ int lslam_multiscan_register(lslam_ctx *ctx, const void *cloud, size_t n_points,
                              float lower_deg, float upper_deg, int32_t n_rings, float scan_period,
                              float *out_xyzc, size_t cap, size_t *n_out, int32_t *ranges_out);
 
+/* ---- coarse alignment of a loop-closure candidate ------------------------------
+ * Replaces LoopDetector::corseMatching (pose_graph/loop_detector.hpp:232-255), i.e.
+ * pcl::IterativeClosestPoint<PointXYZI, PointXYZI> with default settings: point-to-point ICP of `source`
+ * onto `target` from the initial guess T (row-major 4x4, in/out = getFinalTransformation()).  PCL is not
+ * part of the reference tree: PARITY UNPINNED (csrc/lslam_icp.hip states the restated defaults;
+ * oracle/icp_oracle.py is the independent CPU statement).  max_iterations <= 0: 10; transformation_epsilon
+ * 0 and max_correspondence_distance <= 0 (unlimited) are PCL's defaults.  *converged = hasConverged(),
+ * *fitness = getFitnessScore().  An empty target returns converged = 0 (:233-235).  The context's resident
+ * map is replaced by the target's kd-tree (like lslam_odometry_match). */
+int lslam_icp_align(lslam_ctx *ctx, const void *target, size_t n_target, const void *source, size_t n_source,
+                    size_t stride_bytes, float T[16], int32_t max_iterations, double transformation_epsilon,
+                    double max_correspondence_distance, double *fitness, int32_t *converged, int32_t *iterations);
+
 /* ---- SE(3) pose-graph Levenberg-Marquardt ------------------------------------
  * Replaces pose_graph::SolverG2O (pose_graph/solver_g2o.cpp:51-95): add_se3_node /
  * add_se3_edge build the arrays passed to lslam_pg_create, optimize() becomes

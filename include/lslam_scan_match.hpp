@@ -16,9 +16,9 @@
 //               (util/Twist.h:13-36 works)
 #pragma once
 
+#include <cmath>
 #include <cstddef>
 #include <iostream>
-#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -39,13 +39,20 @@ public:
   inline void setUseCore(bool useScore) { _opts.use_score = useScore ? 1 : 0; }
 
   // ScanMatch.h:36, ScanMatch.cpp:21-33.  `device` selects the GPU (no reference counterpart).
-  explicit ScanMatch(const size_t maxIterations = 10, int device = 0)
+  // Never throws (the reference's constructor cannot fail and LaserMatcher holds a ScanMatch by value,
+  // odometry/LaserMatcher.h): if no context can be created the failure is kept, every match returns false
+  // with the backend's message on the console -- the way the reference reports a failed match.
+  explicit ScanMatch(const size_t maxIterations = 10, int device = 0) noexcept
       : _ctx(nullptr), _total_score(0), _match_count(0), _fail_match_count(0) {
     lslam_default_opts(&_opts);
     _opts.max_iterations = (int32_t)maxIterations;
-    if (lslam_ctx_create(device, &_ctx) != LSLAM_OK)
-      throw std::runtime_error(std::string("lslam_ctx_create: ") + lslam_last_error());
+    if (lslam_ctx_create(device, &_ctx) != LSLAM_OK) {
+      _ctx = nullptr;
+      _init_error = lslam_last_error();
+    }
   }
+  bool ok() const { return _ctx != nullptr; }
+  const std::string &initError() const { return _init_error; }
   // ScanMatch.cpp:35-40
   ~ScanMatch() {
     std::cout << "[ScanMatch]\n"
@@ -127,6 +134,14 @@ public:
     return ok;
   }
 
+  // ScanMatch.cpp:42-49: sum of exp(-|intensity|) over a coefficient cloud (intensity = weighted residual)
+  template <typename Cloud>
+  double getScore(const Cloud &coeffCloud) {
+    double score = 0;
+    for (size_t i = 0; i < coeffCloud.points.size(); ++i) score += std::exp(-std::fabs((double)coeffCloud.points[i].intensity));  // fabs/exp in double, as in the reference
+    return score;
+  }
+
   inline double getAverageScore() { return (_match_count > 0) ? _total_score / _match_count : 0; }
   const lslam_stats &lastStats() const { return _last; }
   lslam_ctx *context() { return _ctx; }
@@ -142,6 +157,7 @@ private:
 
   template <typename CloudPtr>
   bool downsize(const CloudPtr &in, float leaf, std::vector<float> &out) {
+    if (!_ctx) return false;
     typedef decltype(in->points.data()) P;
     out.resize(4 * in->points.size() + 4);
     size_t n = 0;
@@ -165,6 +181,12 @@ private:
 
   bool run_raw(const void *rc, size_t nrc, const void *rs, size_t nrs, size_t ref_stride, const void *c, size_t nc,
                const void *s, size_t ns, size_t stride, float pose[6]) {
+    if (!_ctx) {
+      std::cout << "[ScanMatch] backend unavailable: " << _init_error << std::endl;
+      _last.status = LSLAM_ERR_HIP;
+      _fail_match_count++;
+      return false;
+    }
     const int st = lslam_scanmatch_full(_ctx, rc, nrc, rs, nrs, ref_stride, c, nc, s, ns, stride, pose, &_opts,
                                         &_last);
     if (st < 0) {
@@ -186,6 +208,7 @@ private:
   }
 
   lslam_ctx *_ctx;
+  std::string _init_error;
   lslam_opts _opts;
   lslam_stats _last{};
   std::vector<float> _ds[4];  // _referenceCornerCloudDS, _referenceSurfCloudDS, _CornerCloudDS, _SurfCloudDS

@@ -42,7 +42,11 @@ int main() {
   for (size_t i = 0; i < ms->points.size(); i += 7) to_scan(ms->points[i], *qs);
   for (size_t i = 0; i < mc->points.size(); i += 3) to_scan(mc->points[i], *qc);
 
-  lidar_slam::ScanMatch sm(10);
+  lidar_slam::ScanMatch sm(10);  // never throws: a missing backend shows in ok() and in every match returning false
+  if (!sm.ok()) {
+    std::fprintf(stderr, "backend unavailable: %s\n", sm.initError().c_str());
+    return 1;
+  }
   sm.setConvergeThreshold(0.1f, 0.1f);
   // --- FeatureMap shim: push the map, get the surround back, hand it to the matcher on the device
   lidar_slam::FeatureMap<Pt, Cloud> fmap(sm.context());

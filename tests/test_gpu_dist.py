@@ -1,0 +1,160 @@
+"""The sharded (multi-GPU) paths under a REAL process group and through the library's own RCCL communicator.
+
+* two processes (torch.distributed, gloo), both on device 0 -- RCCL refuses two ranks on one GPU, so the data-path
+  sums travel through the lslam_allreduce_fn callback here (device -> host -> gloo all_reduce -> device): the
+  sharded-points Gauss-Newton loop and the edge-sharded pose graph (row 3) must reproduce the
+  single-process results;
+* one process, world of one rank, the library's RCCL communicator (lslam_comm_*): ncclAllReduce on the library's
+  stream -- the device-resident sharded loop equals lslam_scanmatch_run bit for bit, the pose graph likewise.
+"""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(port), LSLAM_FORCE_DEVICE="0", LSLAM_DIST_BACKEND="gloo")
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import torch
+        pkg = importlib.import_module("the-cooper-mapper_amd")
+        synth = importlib.import_module("the-cooper-mapper_amd.synth")
+        d = importlib.import_module("the-cooper-mapper_amd.dist")
+        dist = d.init("gloo")
+        torch.cuda.set_device(0)
+
+        def make_allreduce(tensor):
+            base = tensor.data_ptr()
+
+            def allreduce(ptr, count):
+                off = (ptr - base) // 8
+                view = tensor[off:off + count]
+                h = view.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                view.copy_(h)
+                torch.cuda.synchronize()
+            return allreduce
+
+        # ---- sharded points: one scan's points split over the ranks ------------------------------------
+        pr = synth.make_problem(rings=16, azimuth_steps=900, world_half=60.0)
+        ctx = pkg.Context(0)
+        ctx.map_set(pr["map_corner"], pr["map_surf"])
+        cb, ce = d.shard_range(len(pr["corner"]), rank, world)
+        sb, se = d.shard_range(len(pr["surf"]), rank, world)
+        ctx.scan_set(pr["corner"][cb:ce], pr["surf"][sb:se])
+        xchg = torch.zeros(32, dtype=torch.float64, device="cuda")
+        status, pose, st = ctx.run_sharded(pr["init_pose"], make_allreduce(xchg), xchg)
+        res = {"pose": pose.copy(), "iters": st.iterations, "rows": st.n_rows, "status": int(status), "percent": st.percent}
+        if rank == 0:  # the same scan, unsharded, in this process
+            ctx.scan_set(pr["corner"], pr["surf"])
+            s1, p1, st1 = ctx.run(pr["init_pose"])
+            res.update(full_pose=p1.copy(), full_iters=st1.iterations, full_rows=st1.n_rows, full_status=int(s1),
+                       full_percent=st1.percent)
+        ctx.close()
+        # ---- sharded pose graph: edges split over the ranks ---------------------------------------------
+        import posegraph_oracle as po
+        g = po.make_graph(n_kf=200, n_loop=600, laps=3)
+        pg = pkg.PoseGraph(0)
+        pg.set_graph(g["init"], g["ij"], g["meas"], g["info"])
+        sysbuf = torch.zeros(pg.system_doubles(), dtype=torch.float64, device="cuda")
+        b, e = d.shard_range(len(g["ij"]), rank, world)
+        pg.set_shard(b, e, allreduce=make_allreduce(sysbuf), system_tensor=sysbuf)
+        pg.optimize(8)
+        res["pg_poses"] = pg.poses()
+        res["pg_chi2"] = pg.last_stats.chi2_final
+        pg.close()
+        if rank == 0:
+            pg1 = pkg.PoseGraph(0)
+            pg1.set_graph(g["init"], g["ij"], g["meas"], g["info"])
+            pg1.optimize(8)
+            res["pg_full"] = pg1.poses()
+            res["pg_full_chi2"] = pg1.last_stats.chi2_final
+            pg1.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, res))
+    except Exception as ex:  # pragma: no cover
+        import traceback
+        q.put((rank, {"error": traceback.format_exc() + repr(ex)}))
+
+
+def test_sharded_paths_under_a_real_process_group():
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+    for r in (0, 1):
+        assert "error" not in out[r], out[r].get("error")
+    r0, r1 = out[0], out[1]
+    # every rank ends with the same pose and the same decisions (same all-reduced sums, replicated solve)
+    assert np.array_equal(r0["pose"].view(np.uint32), r1["pose"].view(np.uint32))
+    assert (r0["iters"], r0["rows"], r0["status"]) == (r1["iters"], r1["rows"], r1["status"])
+    # ... and they are the unsharded loop's, up to the order of summation
+    assert r0["iters"] == r0["full_iters"] and r0["rows"] == r0["full_rows"] and r0["status"] == r0["full_status"]
+    assert np.abs(r0["pose"][3:] - r0["full_pose"][3:]).max() <= 1e-5 and np.abs(r0["pose"][:3] - r0["full_pose"][:3]).max() <= 1e-6
+    assert abs(r0["percent"] - r0["full_percent"]) < 1e-6   # the match percentage counts the WHOLE scan's points
+    # pose graph: identical on both ranks, equal to the single-process solve
+    assert np.array_equal(r0["pg_poses"], r1["pg_poses"])
+    assert np.abs(r0["pg_poses"] - r0["pg_full"]).max() < 1e-8 and abs(r0["pg_chi2"] - r0["pg_full_chi2"]) <= 1e-9 * r0["pg_full_chi2"]
+
+
+def test_rccl_communicator_world_of_one(pkg, ctx, small_problem):
+    """lslam_comm_*: librccl is dlopen'ed, a one-rank communicator is created from a fresh unique id, and both
+    sharded paths run their all-reduce as ncclAllReduce on the library's stream."""
+    pr = small_problem
+    comm = pkg.Comm(0, pkg.Comm.unique_id(), 0, 1)
+    try:
+        ctx.map_set(pr["map_corner"], pr["map_surf"])
+        ctx.scan_set(pr["corner"], pr["surf"])
+        s0, p0, st0 = ctx.run(pr["init_pose"])
+        ctx.set_comm(comm)
+        s1, p1, st1 = ctx.run_sharded(pr["init_pose"])
+        ctx.set_comm(None)
+        assert int(s0) == int(s1) and st0.iterations == st1.iterations and st0.n_rows == st1.n_rows
+        assert np.array_equal(p0.view(np.uint32), p1.view(np.uint32))  # one rank: the same sums in the same order
+        with pytest.raises(pkg.LslamError):
+            ctx.run_sharded(pr["init_pose"])  # neither a communicator nor a callback
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import posegraph_oracle as po
+        g = po.make_graph(n_kf=200, n_loop=600, laps=3)
+        res = []
+        for use_comm in (False, True):
+            pg = pkg.PoseGraph(0)
+            pg.set_graph(g["init"], g["ij"], g["meas"], g["info"])
+            if use_comm:
+                pg.set_comm(comm, 0, len(g["ij"]))
+            pg.optimize(6)
+            res.append((pg.poses(), pg.last_stats.chi2_final))
+            pg.close()
+        assert np.abs(res[0][0] - res[1][0]).max() < 1e-10 and abs(res[0][1] - res[1][1]) <= 1e-10 * res[0][1]
+        # the raw collective on a device buffer
+        import torch
+        t = torch.arange(8, dtype=torch.float64, device="cuda")
+        comm.allreduce_f64(t.data_ptr(), 8)
+        torch.cuda.synchronize()
+        assert torch.equal(t.cpu(), torch.arange(8, dtype=torch.float64))
+    finally:
+        comm.close()

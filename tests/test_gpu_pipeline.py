@@ -11,6 +11,11 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
+# the north-star bar (pose within 1e-4 m of the CPU reference) also for the five-sweep chain: two
+# Gauss-Newton loops per sweep, the odometry's per-point de-skew with the device's sin/cos
+CHAIN_TOL = 1e-4
+
+
 def test_transform_to_end_matches_oracle(ctx, oracle):
     rng = np.random.default_rng(2)
     c = rng.uniform(-40, 40, (5000, 4)).astype(np.float32)
@@ -102,7 +107,7 @@ def test_chain_through_a_velocity_reversal(pkg, ctx, oracle, synth, small_proble
 def test_registration_to_mapping_chain(pkg, ctx, oracle, synth, small_problem):
     """Five consecutive VLP-16 sweeps of a drive through the synthetic world, raw driver clouds in:
     the device chain and the oracle chain agree on every intermediate product (feature clouds bit for
-    bit) and on the odometry and map poses to 1e-3 m (the chain passes through per-point sin/cos and
+    bit) and on the odometry and map poses to 1e-4 m (the chain passes through per-point sin/cos and
     two Gauss-Newton loops per sweep; each stage's own parity bar is tighter)."""
     from test_oracle_features import _raw_sweep  # noqa: F401  (same raw-sweep construction)
     world = small_problem["world"]
@@ -111,6 +116,7 @@ def test_registration_to_mapping_chain(pkg, ctx, oracle, synth, small_problem):
     mapper = pkg.LaserMapping(ctx, cube_dims=dims)
     chain = OracleChain(oracle, ctx, dims)
     sr = pkg.scan_registration
+    worst = 0.0
     for k in range(5):
         gt = (0.0, 0.0, 0.3 + 0.01 * k, 3.0 + 0.4 * k, -2.0 + 0.15 * k, synth.SENSOR_HEIGHT)
         c, s, gtp, cloud, ranges = synth.make_scan(world, 16, 900, gt_pose=gt, seed=300 + k, full=True)
@@ -129,13 +135,15 @@ def test_registration_to_mapping_chain(pkg, ctx, oracle, synth, small_problem):
         if k == 0:
             assert T_g is None and T_o is None
             continue
-        assert np.abs(T_g - T_o).max() <= 1e-3, (k, np.abs(T_g - T_o).max())
+        assert np.abs(T_g - T_o).max() <= CHAIN_TOL, (k, np.abs(T_g - T_o).max())
         M_g = mapper.process(odo.last_corner, odo.last_surf, T_g)
         M_o = chain.mapping(chain.last_c, chain.last_s, T_o)
-        assert np.abs(M_g - M_o).max() <= 1e-3, (k, np.abs(M_g - M_o).max())
+        assert np.abs(M_g - M_o).max() <= CHAIN_TOL, (k, np.abs(M_g - M_o).max())
+        worst = max(worst, float(np.abs(T_g - T_o).max()), float(np.abs(M_g - M_o).max()))
     # the sensor moved 1.6 m / 0.6 m between the first and the last sweep: the map pose (relative to the
     # first sweep) has travelled that far
     assert abs(np.linalg.norm(M_g[:3, 3]) - np.hypot(1.6, 0.6)) < 0.1
+    print("chain worst |device - oracle| = %.3g (bar %.0e)" % (worst, CHAIN_TOL))
     mapper.feature_map.close()
 
 

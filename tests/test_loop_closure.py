@@ -139,6 +139,64 @@ def test_graph_closes_the_loop_end_to_end(pkg, ctx, synth, small_problem):
     assert err_est[-1] < 0.6 * err_odo[-1] and err_est.mean() < err_odo.mean() and err_est.max() < 0.5
 
 
+def test_cpp_loop_closure_mirrors_compile(pkg, tmp_path):
+    """include/lslam_loop_closure.hpp (LoopDetector / KeyframeUpdater / Graph over the C ABI) builds with g++ -std=c++11
+    -Wall -Werror; without a GPU the program reports the missing backend."""
+    import subprocess
+    import torch
+    from test_abi import _build_cpp
+    exe = _build_cpp(pkg, tmp_path, "loop_closure_end_to_end")
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu-marked run of the same program")
+    (tmp_path / "none.bin").write_bytes(b"")
+    out = subprocess.run([str(exe), str(tmp_path / "none.bin"), "25"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1 and "no CPU fallback" in out.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_graph_equals_python_graph(pkg, ctx, synth, small_problem, tmp_path):
+    """The two-lap drive of test_graph_closes_the_loop_end_to_end through the C++ Graph / LoopDetector mirrors and the
+    Python ones: same loops, same keyframe estimates (both issue the same C-ABI calls)."""
+    import subprocess
+    from test_abi import _build_cpp
+    exe = _build_cpp(pkg, tmp_path, "loop_closure_end_to_end")
+    world = small_problem["world"]
+    rng = np.random.default_rng(5)
+    P = np.array([[0, 1, 0, 0], [0, 0, 1, 0], [1, 0, 0, 0], [0, 0, 0, 1]], np.float64)
+    g = pkg.Graph(ctx=ctx)
+    g.loop_detector.accum_distance_thresh = 25.0
+    way = [(dx, dy) for lap in range(2) for (dx, dy) in ((1, 0), (0, 1), (-1, 0), (0, -1)) for k in range(10)]
+    x = y = 0.0
+    drift = np.zeros(2)
+    n_loops = 0
+    path = tmp_path / "frames.bin"
+    with open(path, "wb") as fo:
+        for step, (dx, dy) in enumerate([(0, 0)] + way):
+            x += dx; y += dy
+            drift += rng.normal(0, 0.01, 2) + np.array([0.004, -0.003])
+            c, s, gtp = synth.make_scan(world, 16, 450, gt_pose=(0.0, 0.0, 0.3, x, y, synth.SENSOR_HEIGHT), seed=1000 + step)
+            R, t = synth.pose_to_Rt(gtp)
+            O = np.eye(4); O[:3, :3], O[:3, 3] = R, t
+            O[:2, 3] += drift
+            O = P @ O @ P.T
+            cl, sl = c.copy(), s.copy()
+            cl[:, :3], sl[:, :3] = c[:, [1, 2, 0]], s[:, [1, 2, 0]]
+            fo.write(np.ascontiguousarray(O, np.float64).tobytes())
+            for a in (cl, sl):
+                fo.write(np.uint32(len(a)).tobytes())
+                fo.write(np.ascontiguousarray(a, np.float32).tobytes())
+            assert g.add_frame(O, cl, sl) is not None
+            loops, its = g.optimize(20)
+            n_loops += len(loops)
+    out = subprocess.run([str(exe), str(path), "25"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    head = [l for l in out.stdout.splitlines() if l.startswith("LOOPS")][0].split()
+    assert int(head[1]) == n_loops >= 1 and int(head[5]) == len(g.keyframes)
+    kf = np.array([[float(v) for v in l.split()[2:5]] for l in out.stdout.splitlines() if l.startswith("KF ")])
+    est = np.array([k.estimate[:3, 3] for k in g.keyframes])
+    assert np.abs(kf - est).max() < 1e-6
+
+
 def test_trajectory_radius_search_matches_reference_nanoflann(pkg):
     """LoopDetector.radius_search against the reference's own KdTreeFLANN::radiusSearch
     (oracle/_ref/libref_nanoflann.so, nanoflann_pcl.h:164-186): same indices in the same order, same

@@ -205,6 +205,8 @@ SYMBOLS = {
     "lslam_pg_get_poses": (C.c_int, [C.c_void_p, c_double_p]),
     "lslam_pg_linearize": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_int32_p, c_double_p, c_double_p]),
     "lslam_pg_solve": (C.c_int, [C.c_void_p, C.c_double, c_double_p, c_int32_p]),
+    "lslam_icp_align": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, c_float_p, C.c_int32,
+                                  C.c_double, C.c_double, c_double_p, c_int32_p, c_int32_p]),
     "lslam_comm_unique_id": (C.c_int, [c_uint8_p]),
     "lslam_comm_create": (C.c_int, [C.c_int, c_uint8_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "lslam_comm_destroy": (None, [C.c_void_p]),

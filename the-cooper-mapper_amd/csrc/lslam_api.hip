@@ -633,6 +633,17 @@ int cubemap_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t nc, const 
   return LSLAM_OK;
 }
 void set_error(const char *msg) { set_err("%s", msg); }
+hipStream_t ctx_stream(lslam_ctx *ctx) { return ctx->stream; }
+TreeView ctx_tree_view(lslam_ctx *ctx, int which) { return which ? ctx->ts.view : ctx->tc.view; }
+void ctx_invalidate_map(lslam_ctx *ctx) { ctx->have_map = false; ctx->have_scan = false; }
+int ctx_scratch(lslam_ctx *ctx, size_t n_float4, size_t n_double, float4 **pts, double **dbl) {
+  HIP_TRY(ctx->t_q.reserve(n_float4 ? n_float4 : 1));
+  HIP_TRY(ctx->xchg.reserve(n_double ? n_double : 1));
+  *pts = ctx->t_q.p;
+  *dbl = ctx->xchg.p;
+  return LSLAM_OK;
+}
+int ctx_stack_ovf_if_deep(lslam_ctx *ctx, size_t n_threads, uint32_t **out) { return ensure_stack_ovf(ctx, n_threads, out); }
 int ctx_device(const lslam_ctx *ctx) { return ctx ? ctx->device : -1; }
 bool ctx_alive(const lslam_ctx *ctx) {
   std::lock_guard<std::mutex> lk(g_live_mu);

@@ -201,6 +201,12 @@ int cubemap_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t nc, const 
                        const std::vector<int32_t> &roots_s, const std::vector<int32_t> &cells_s, float cube_size,
                        const int32_t origin[3], const int32_t dims[3]);
 void set_error(const char *msg);
+// small accessors for translation units that work on a context (lslam_icp.hip)
+hipStream_t ctx_stream(lslam_ctx *ctx);
+TreeView ctx_tree_view(lslam_ctx *ctx, int which);   // 0 corner, 1 surf tree of the resident map
+void ctx_invalidate_map(lslam_ctx *ctx);              // the resident trees belong to the caller's own call from here on
+int ctx_scratch(lslam_ctx *ctx, size_t n_float4, size_t n_double, float4 **pts, double **dbl);  // grow-only scratch
+int ctx_stack_ovf_if_deep(lslam_ctx *ctx, size_t n_threads, uint32_t **out);  // null unless a tree is deeper than the LDS stack
 int ctx_device(const lslam_ctx *ctx);
 bool ctx_alive(const lslam_ctx *ctx);
 

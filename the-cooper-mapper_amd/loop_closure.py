@@ -19,10 +19,11 @@ Three things of the reference are restated as they are, not as they were probabl
     reproduced -- ``radius_search`` returns nothing then.  ``single_result_quirk = False`` gives
     the search its documented meaning (all points within the radius, ascending);
   * the trajectory is flattened with ``pos.y = 0`` (:98,120).
-The coarse alignment (``corseMatching``, :232-255) is PCL's ``IterativeClosestPoint`` -- external,
-not under /root/reference, not restated: ``coarse_matcher`` is a hook
-``(reference_surf, surf, guess4x4) -> (converged, guess4x4)`` whose default accepts the odometry
-guess unchanged.
+The coarse alignment (``corseMatching``, :232-255) is PCL's ``IterativeClosestPoint`` with default
+settings -- external, parity unpinned: the default ``coarse_matcher`` is the device ICP
+(``lslam_icp_align``, csrc/lslam_icp.hip, PCL's defaults restated), including the reference's two
+guards -- an empty reference cloud and a non-converged ICP both reject the candidate.  Any
+``(reference_surf, surf, guess4x4) -> (converged, guess4x4)`` callable can be passed instead.
 """
 import numpy as np
 
@@ -73,13 +74,20 @@ class LoopDetector:
         self._trajectory = np.zeros((0, 4), np.float32)
         self._scan_match = scan_match
         self._device, self._ctx = device, ctx
-        self.coarse_matcher = coarse_matcher or (lambda refer_surf, surf, guess: (True, guess))
+        self.coarse_matcher = coarse_matcher or self._icp_coarse_matcher
 
     @property
     def scan_match(self):
         if self._scan_match is None:  # created on first use: the gating needs no device
             self._scan_match = ScanMatch(10, device=self._device, ctx=self._ctx)
         return self._scan_match
+
+    def _icp_coarse_matcher(self, refer_surf, surf, guess):
+        """corseMatching, loop_detector.hpp:232-255: registration->align(aligned, guess) with PCL's defaults."""
+        if len(refer_surf) == 0:  # :233-235
+            return False, guess
+        T, converged, _its, _fit = self.scan_match.ctx.icp_align(refer_surf, surf, guess)
+        return converged, T
 
     def get_distance_thresh(self):
         return self.estimated_distance_thresh

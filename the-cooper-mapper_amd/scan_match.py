@@ -280,6 +280,23 @@ class Context:
         self._check(self.lib.lslam_transform_to_end(self.h, _vp(a), len(a), a.shape[1] * 4, _fp(p)))
         return a
 
+    def icp_align(self, target, source, guess, max_iterations=10, transformation_epsilon=0.0,
+                  max_correspondence_distance=0.0):
+        """lslam_icp_align: point-to-point ICP with PCL's defaults (LoopDetector::corseMatching,
+        pose_graph/loop_detector.hpp:232-255) -> (T 4x4 float32, converged, iterations, fitness)."""
+        from .capi import c_double_p
+        t, st = _cloud(target)
+        s, ss = _cloud(source)
+        if st != ss:
+            raise ValueError("target/source strides differ")
+        T = np.array(guess, dtype=np.float32).reshape(16)
+        fit = C.c_double(0.0)
+        conv, its = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.lslam_icp_align(self.h, _vp(t), len(t), _vp(s), len(s), st, _fp(T), int(max_iterations),
+                                             float(transformation_epsilon), float(max_correspondence_distance),
+                                             C.byref(fit), C.byref(conv), C.byref(its)))
+        return T.reshape(4, 4), bool(conv.value), its.value, fit.value
+
     # -- parity taps -------------------------------------------------------------
     def knn5(self, which_map, queries, search_mode=1, want_ties=False):
         """lslam_knn5_ex; search_mode 1 = one query per lane (nanoflann's traversal), 2 = packet search."""

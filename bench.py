@@ -8,7 +8,7 @@ Workload (BASELINE.json configs[2] on the map of configs[1])
     FeatureMap::addFeatureCloud (util/FeatureMap.h:219-230,289-306; corner leaf 0.2 m, surf 0.4 m) on the
     device map; what is matched against is the active surround at the end of the loop
     (getSurroundFeature, :256-265), kd-trees built on the device;
-  * queries: `--scans` (512) different synthetic 64-ring x 1800 scans (115 200 points each, every
+  * queries: `--scans` (640) different synthetic 64-ring x 1800 scans (115 200 points each, every
     return a query) taken around the end of the loop, initial pose error +-0.3 m / +-2 deg.
 A "step" is one pass of the hot path over that batch: the scanMatchScan Gauss-Newton loop
 (ScanMatch.cpp:78-347: <= 10 iterations of transform -> kd-tree 5-NN -> line/plane fit -> residual +
@@ -57,12 +57,15 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rings", type=int, default=64)
-    ap.add_argument("--scans", type=int, default=int(os.environ.get("LSLAM_SCANS", "512")),
+    ap.add_argument("--scans", type=int, default=int(os.environ.get("LSLAM_SCANS", "640")),
                     help="resident query scans per GPU; one step matches all of them")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("LSLAM_BATCH", "32")),
                     help="scans in flight per launch sequence (lslam_opts.scans_in_flight)")
     ap.add_argument("--map-frames", type=int, default=10000, help="frames accumulated into the voxel map")
     ap.add_argument("--map-rings", type=int, default=16, help="rings of the frames the map is built from (VLP-16)")
+    ap.add_argument("--map-cache", default=None,
+                    help="profiling passes: file to keep the built surround map in (built and saved on the first run, loaded "
+                         "afterwards: rocprofv3 --pmc serialises the ~200 k dispatches of the 10k-frame build otherwise)")
     ap.add_argument("--jtj-mode", type=int, default=int(os.environ.get("LSLAM_JTJ_MODE", "1")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-joint-stereo", action="store_true")
@@ -125,14 +128,26 @@ def main():
 
     # ---- the world, the 10k-frame voxel map and the query scans -------------------------------------
     t_setup = time.perf_counter()
-    world_model = synth.World(half_extent=300.0, wall_half=295.0)
+    world_model = synth.World(half_extent=300.0, wall_half=295.0, pole_pitch=2.5)  # poles / trunks every 2.5 m along the streets: ~10 % corner returns
     lidar = synth_gpu.GpuLidar(world_model, local_rank)
     traj = synth_gpu.loop_trajectory(args.map_frames)
     ctx = pkg.Context(local_rank)
-    fm, mapstats = synth_gpu.build_voxel_map(pkg, ctx, lidar, traj, rings=args.map_rings,
-                                             progress=2000 if rank == 0 else None)
     end_pose = traj[-1]
-    fm.update(end_pose[3:].astype(np.float32))
+    cache = args.map_cache + (".rank%d.npz" % rank) if args.map_cache else None
+    if cache and os.path.exists(cache):
+        z = np.load(cache, allow_pickle=True)
+        mapstats = dict(z["stats"].item(), loaded_from_cache=True)
+        fm = pkg.FeatureMap(ctx, 21, 21, 11)
+        fm.setup_filter_size(0.2, 0.4, 0.6)
+        fm.update(end_pose[3:].astype(np.float32))
+        fm.add_feature_cloud(z["corner"], z["surf"], np.eye(4, dtype=np.float32))  # already filtered: stays as it is
+    else:
+        fm, mapstats = synth_gpu.build_voxel_map(pkg, ctx, lidar, traj, rings=args.map_rings,
+                                                 progress=2000 if rank == 0 else None)
+        fm.update(end_pose[3:].astype(np.float32))
+        if cache:
+            sc, ss = fm.get_surround_feature()
+            np.savez(cache, corner=sc, surf=ss, stats=np.array(mapstats, dtype=object))
     fm.surround_to_map()
     info = ctx.map_info()
     # query poses: on the loop within +-25 m of path around its end (the loop is closed), a little off the line

@@ -302,6 +302,12 @@ int lslam_fmap_surround_to_map(lslam_fmap *fm);
  * points skipped, FeatureMap.h:524,546), all built in one go on the device; scan points are then
  * matched against the tree of the cube they fall into (FeatureMap::scanMatchScan, :490-691). */
 int lslam_fmap_to_cubemap(lslam_fmap *fm);
+/* The per-cube trees persist between calls: lslam_fmap_to_cubemap rebuilds only the trees of cubes whose cloud changed
+ * since their tree was built (addFeatureCloud marks the cubes that received points; shifts and loads mark all).
+ * Counts of the last call: trees built in it / trees kept from earlier calls. */
+int lslam_fmap_cubemap_stats(lslam_fmap *fm, int64_t *trees_built, int64_t *trees_reused);
+/* Forget the cached trees (the next lslam_fmap_to_cubemap rebuilds the whole active area). */
+int lslam_fmap_cubemap_invalidate(lslam_fmap *fm);
 /* getFullMap, FeatureMap.h:267-286: per cube, VoxelGrid(map leaf) of corner then surf. */
 int lslam_fmap_get_full_map(lslam_fmap *fm, float *out_xyzi, size_t cap, size_t *n_out);
 /* saveCloudToFiles / loadCloudFromFiles, FeatureMap.h:378-462: one binary PCD (fields x y z

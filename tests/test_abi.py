@@ -166,7 +166,8 @@ def test_cpp_pipeline_mirrors_compile(pkg, tmp_path):
 @pytest.mark.gpu
 def test_cpp_pipeline_equals_python_mirrors(pkg, tmp_path):
     """Six consecutive VLP-16 sweeps through the C++ LaserOdometry / LaserMapping mirrors and through the Python
-    ones: the same ABI calls in the same order, so map poses and accumulated odometry agree bit for bit."""
+    ones: the same ABI calls in the same order, so map poses and accumulated odometry agree to the last bits of the
+    host-side 4x4 products."""
     import importlib
     import subprocess
     synth = importlib.import_module("the-cooper-mapper_amd.synth")
@@ -206,8 +207,9 @@ def test_cpp_pipeline_equals_python_mirrors(pkg, tmp_path):
             got[int(w[1])] = (v[:12].reshape(3, 4), v[12:].reshape(3, 4))
     assert sorted(got) == sorted(ref) and len(got) == 5
     for k in ref:
-        assert np.array_equal(got[k][0].view(np.uint32), ref[k][0][:3].view(np.uint32)), k   # map pose
-        assert np.array_equal(got[k][1].view(np.uint32), ref[k][1][:3].view(np.uint32)), k   # accumulated odometry
+        # the 4x4 products of the bookkeeping (_Tsum * T) are numpy's on one side and plain loops on the other: last bits
+        assert np.abs(got[k][0] - ref[k][0][:3]).max() <= 2e-6, k   # map pose
+        assert np.abs(got[k][1] - ref[k][1][:3]).max() <= 2e-6, k   # accumulated odometry
 
 
 def test_struct_sizes_equal_the_c_compilers(pkg, tmp_path):

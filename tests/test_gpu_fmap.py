@@ -278,3 +278,69 @@ def test_feature_map_full_size_properties(pkg, ctx, synth):
     c2, s2 = fm.get_surround_feature()
     assert abs(len(c2) - len(c)) <= 4 and abs(len(s2) - len(s)) <= 8
     fm.close()
+
+
+def test_incremental_cube_forest_over_20_frames(pkg, ctx, oracle, synth, small_problem):
+    """per-cube search structures kept between frames.  Twenty frames of a drive across a cube border,
+    every frame matched against the per-cube trees (FeatureMap::scanMatchScan, util/FeatureMap.h:490-691) and then
+    inserted (addFeatureCloud + VoxelGrid).  lslam_fmap_to_cubemap rebuilds only the cubes that received points:
+      * the pose of every frame is the oracle's variant-C pose on the oracle's map (bar 1e-4 m / 1e-5 rad);
+      * a sweep over the incrementally kept forest equals, bit for bit (neighbours, distances, flags, coefficients),
+        the same sweep after ALL trees were rebuilt from the current clouds;
+      * trees really are reused (and rebuilt where the scan landed)."""
+    world = small_problem["world"]
+    dims = (21, 21, 11)
+    cube = 20.0  # small cubes: the 120 m test world spans many of them, the drive crosses borders
+    fm = pkg.FeatureMap(ctx, *dims)
+    fm.setup_world_cube_size(cube)
+    fm.setup_lidar_valid_distance(60.0)
+    fm.setup_filter_size(0.2, 0.4, 0.6)
+    ofm = oracle.feature_map(*dims)
+    ofm.setup_world_cube_size(cube)
+    ofm.setup_lidar_valid_distance(60.0)
+    ofm.setup_filter_size(0.2, 0.4, 0.6)
+    opts = ctx.default_opts()
+    opts.max_iterations = 10
+    opts.delta_t_abort = opts.delta_r_abort = 0.05
+    opts.use_score = 0
+    built_total = reused_total = 0
+    partial_frames = 0
+    for k in range(20):
+        gt = np.array([0.0, 0.0, 0.3 + 0.01 * k, 1.0 + 1.2 * k, -2.0 + 0.2 * k, synth.SENSOR_HEIGHT])
+        c, s, gtp = synth.make_scan(world, 16, 450, gt_pose=gt, seed=700 + k)
+        cds, sds = pkg.voxel_grid(ctx, c, 0.4), pkg.voxel_grid(ctx, s, 0.8)
+        pos = gtp[3:].astype(np.float32)
+        fm.update(pos)
+        ofm.update(pos)
+        if k > 0:
+            init = synth.perturb_pose(gtp, seed=50 + k, dt=0.15, dr_deg=1.0)
+            status, pose, st = fm.scan_match_scan(cds, sds, init, opts)
+            built, reused = fm.cubemap_stats()
+            built_total += built
+            reused_total += reused
+            partial_frames += int(built > 0 and reused > 0)
+            info = fm.info()
+            oc, os_ = ofm.get_surround_feature()
+            ok, opose, ost = oracle.scanmatch_cubes(oc, os_, cds, sds, init, cube, tuple(int(v) for v in info["origin"]), dims)
+            assert st.iterations == ost.iterations and st.n_rows == ost.n_rows, k
+            assert np.abs(pose[3:] - opose[3:]).max() <= 1e-4 and np.abs(pose[:3] - opose[:3]).max() <= 1e-5, k
+            # incremental forest == forest rebuilt from scratch
+            ctx.scan_set(cds, sds)
+            a = ctx.sweep(pose, jtj_mode=0)
+            fm.cubemap_invalidate()
+            fm.to_cubemap()
+            b_all, r_all = fm.cubemap_stats()
+            assert r_all == 0 and b_all == built + reused
+            b = ctx.sweep(pose, jtj_mode=0)
+            for key in ("idx", "d2", "flags", "coeff"):
+                assert np.array_equal(a[key].view(np.uint8), b[key].view(np.uint8)), (k, key)
+        R, t = synth.pose_to_Rt(gtp)
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :3], T[:3, 3] = R, t
+        fm.add_feature_cloud(cds, sds, T)
+        ofm.add_feature_cloud(cds, sds, T)
+    assert reused_total > 0 and built_total > 0 and partial_frames >= 5
+    fm.close()
+    # the context no longer points at the freed trees
+    with pytest.raises(pkg.LslamError):
+        ctx.scanmatch_scan(cds, sds, init, opts)

@@ -112,54 +112,77 @@ def test_point_on_the_line_gives_nan_direction(oracle):
     assert ok and np.isnan(cf[:3]).all() and cf[3] == 0.0
 
 
-def _cases(oracle):
-    """(kind, 5 map points, query) for every adjacent pair around every rule; clusters 40 m apart."""
-    cases = []
-    k = [0]
+CENTRES = [np.array([8.0 * i, 8.0 * j, 1.0]) for i in (-2, -1, 1, 2) for j in (-2, -1, 0, 1, 2)]  # 8 m apart, within 23 m
 
-    def centre():
-        k[0] += 1
-        return np.array([40.0 * k[0], 7.0, 1.0])
-    c = centre()
-    lo, hi, _ = _adjacent_flip(lambda s: oracle.find_line(cloud4(line_points(s, c)), np.arange(5))[0], 0.05, 0.6)
-    for s in (lo, hi):
-        c2 = centre()
-        cases.append(("corner", line_points(s, c2) - c2.astype(np.float32) + c2.astype(np.float32), (c2 + [0.1, 0.3, 0.2]).astype(np.float32)))
-    c = centre()
-    lo, hi, _ = _adjacent_flip(lambda dl: oracle.find_plane(cloud4(plane_points(dl, c)), np.arange(5))[0], 0.05, 1.5)
-    for dl in (lo, hi):
-        c2 = centre()
-        cases.append(("surf", plane_points(dl, c2), (c2 + [0.1, 0.1, 0.3]).astype(np.float32)))
-    # weight gates: a fixed thin cluster / flat patch, the query moved across the gate
-    for side in (0.9999, 1.0, 1.0001, 1.001):
-        c2 = centre()
-        cases.append(("corner", line_points(0.0, c2), (c2 + [0.0, side, 0.0]).astype(np.float32)))
-    for z in (np.sqrt(np.linalg.norm([40.0 * (k[0] + 1), 7.0, 1.0])) * f for f in (0.95, 1.0, 1.05)):
-        c2 = centre()
-        cases.append(("surf", plane_points(0.0, c2), (c2 + [0.0, 0.0, z]).astype(np.float32)))
-    c2 = centre()  # the d = 0 row: a query exactly on the fitted line
-    cases.append(("corner", line_points(0.0, c2), c2.astype(np.float32)))
+
+def _decide(oracle, kind, pts5, q):
+    """the oracle's flags for one query against one five-point cluster, through its sweep (neighbours arrive in kNN order,
+    which the fits' rounding depends on -- the decision is bisected on exactly the path the comparison takes)"""
+    far = cloud4(np.array([[900.0 + i, 900.0, 0.0] for i in range(5)], np.float32))
+    mc, ms = (cloud4(pts5), far) if kind == "corner" else (far, cloud4(pts5))
+    qc, qs = (cloud4(q[None]), far[:0]) if kind == "corner" else (far[:0], cloud4(q[None]))
+    r = oracle.sweep(oracle.kdtree(mc), oracle.kdtree(ms), qc, qs, np.zeros(6, np.float32))
+    return int(r["flags"][0])
+
+
+def _cases(oracle, side):
+    """(kind, 5 map points, query) per rule; `side` 0 / 1 picks the member of every adjacent pair (the last value that is
+    accepted / the first that is rejected).  Every cluster keeps its place in both variants: the fits depend on where
+    the points lie (the plane fit [x y z] n = -1 is not translation invariant), so a pair is bisected where it is used."""
+    cases = []
+    it = iter(CENTRES)
+    c = next(it)
+    q1 = (c + [0.1, 0.3, 0.2]).astype(np.float32)
+    pair = _adjacent_flip(lambda s: bool(_decide(oracle, "corner", line_points(s, c), q1) & 2), 0.05, 0.6)
+    cases.append(("corner", line_points(pair[side], c), q1))
+    c2 = next(it)
+    q2 = (c2 + [0.1, 0.1, 0.3]).astype(np.float32)
+    pair = _adjacent_flip(lambda dl: bool(_decide(oracle, "surf", plane_points(dl, c2), q2) & 2), 0.02, 1.5)
+    cases.append(("surf", plane_points(pair[side], c2), q2))
+    # weight gates: a fixed thin cluster / flat patch, the query moved across the gate in one-ulp steps
+    c3 = next(it)
+    pair = _adjacent_flip(lambda d: bool(_decide(oracle, "corner", line_points(0.0, c3), (c3 + [0.0, float(d), 0.0]).astype(np.float32)) & 4),
+                          0.5, 1.5)
+    cases.append(("corner", line_points(0.0, c3), (c3 + [0.0, float(pair[side]), 0.0]).astype(np.float32)))
+    c4 = np.array([1.0, 0.5, 0.2])  # near the origin: the surface weight 1 - 0.9 |d| / sqrt(|X|) only trips within the 5 m^2 gate there
+    pair = _adjacent_flip(lambda z: bool(_decide(oracle, "surf", plane_points(0.0, c4), (c4 + [0.0, 0.0, float(z)]).astype(np.float32)) & 4),
+                          0.5, 2.0)
+    cases.append(("surf", plane_points(0.0, c4), (c4 + [0.0, 0.0, float(pair[side])]).astype(np.float32)))
+    c5 = next(it)  # the d = 0 row: a query exactly on the fitted line
+    cases.append(("corner", line_points(0.0, c5), c5.astype(np.float32)))
+    # plain accepted rows so that every tree holds a few clusters
+    for k in range(3):
+        c6 = next(it)
+        cases.append(("corner", line_points(0.02, c6), (c6 + [0.2, 0.2, 0.1]).astype(np.float32)))
+        c7 = next(it)
+        cases.append(("surf", plane_points(0.01, c7), (c7 + [0.1, -0.2, 0.25]).astype(np.float32)))
     return cases
 
 
 @pytest.mark.gpu
 def test_device_takes_the_oracles_decisions_at_every_threshold(ctx, oracle):
-    cases = _cases(oracle)
-    mc = np.concatenate([m for kind, m, q in cases if kind == "corner"])
-    ms = np.concatenate([m for kind, m, q in cases if kind == "surf"])
-    qc = np.stack([q for kind, m, q in cases if kind == "corner"])
-    qs = np.stack([q for kind, m, q in cases if kind == "surf"])
-    ctx.map_set(cloud4(mc), cloud4(ms))
-    ctx.scan_set(cloud4(qc), cloud4(qs))
-    pose = np.zeros(6, np.float32)
-    tc, ts = oracle.kdtree(cloud4(mc)), oracle.kdtree(cloud4(ms))
-    o = oracle.sweep(tc, ts, cloud4(qc), cloud4(qs), pose)
-    for search in (1, 2):
-        g = ctx.sweep(pose, jtj_mode=0, search_mode=search)
-        assert np.array_equal(g["idx"], o["idx"]) and np.array_equal(g["flags"], o["flags"])
-        nan_o, nan_g = np.isnan(o["coeff"]), np.isnan(g["coeff"])
-        assert np.array_equal(nan_o, nan_g) and nan_o.any()            # the d = 0 row is there, NaN in both
-        assert np.array_equal(g["coeff"][~nan_g].view(np.uint32), o["coeff"][~nan_o].view(np.uint32))
-    # both outcomes of every rule really occur among the cases
-    fl = o["flags"]
-    assert (fl & 2).any() and not (fl & 2).all() and (fl & 4).any() and ((fl & 2) != 0).sum() > ((fl & 4) != 0).sum()
+    seen = []
+    for side in (0, 1):
+        cases = _cases(oracle, side)
+        mc = np.concatenate([m for kind, m, q in cases if kind == "corner"])
+        ms = np.concatenate([m for kind, m, q in cases if kind == "surf"])
+        qc = np.stack([q for kind, m, q in cases if kind == "corner"])
+        qs = np.stack([q for kind, m, q in cases if kind == "surf"])
+        ctx.map_set(cloud4(mc), cloud4(ms))
+        ctx.scan_set(cloud4(qc), cloud4(qs))
+        pose = np.zeros(6, np.float32)
+        tc, ts = oracle.kdtree(cloud4(mc)), oracle.kdtree(cloud4(ms))
+        o = oracle.sweep(tc, ts, cloud4(qc), cloud4(qs), pose)
+        for search in (1, 2):
+            g = ctx.sweep(pose, jtj_mode=0, search_mode=search)
+            assert np.array_equal(g["idx"], o["idx"]) and np.array_equal(g["flags"], o["flags"])
+            nan_o, nan_g = np.isnan(o["coeff"]), np.isnan(g["coeff"])
+            assert np.array_equal(nan_o, nan_g) and nan_o.any()            # the d = 0 row is there, NaN in both
+            assert np.array_equal(g["coeff"][~nan_g].view(np.uint32), o["coeff"][~nan_o].view(np.uint32))
+        seen.append(o["flags"].copy())
+    # the four rule cases (line fit, plane fit, corner weight, surf weight) flip between the two variants, nothing else does
+    nc = sum(1 for kind, m, q in _cases(oracle, 0) if kind == "corner")
+    flips = np.nonzero(seen[0] != seen[1])[0].tolist()
+    assert flips == [0, 1, nc, nc + 1], flips
+    assert (seen[0][[0, nc]] & 2).all() and not (seen[1][[0, nc]] & 2).any()          # fit accepted -> rejected
+    assert (seen[0][[1, nc + 1]] & 4).all() and not (seen[1][[1, nc + 1]] & 4).any()  # row kept -> dropped

@@ -632,6 +632,57 @@ int cubemap_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t nc, const 
   ctx->have_map = true;
   return LSLAM_OK;
 }
+int cubemap_set_views(lslam_ctx *ctx, const std::vector<TreeView> &views_c, const std::vector<int32_t> &cells_c, size_t nc,
+                      int depth_c, const std::vector<TreeView> &views_s, const std::vector<int32_t> &cells_s, size_t ns, int depth_s,
+                      float cube_size, const int32_t origin[3], const int32_t dims[3]) {
+  int rc = check_ctx(ctx);
+  if (rc) return rc;
+  ctx->have_map = false;
+  ctx->prev_valid = false;
+  if (depth_c > KD_STACK_MAX || depth_s > KD_STACK_MAX) {
+    set_err("kd-tree depth %d/%d exceeds device stack %d", depth_c, depth_s, KD_STACK_MAX);
+    return LSLAM_ERR_TREE_DEPTH;
+  }
+  const std::vector<TreeView> *views[2] = {&views_c, &views_s};
+  const std::vector<int32_t> *cells[2] = {&cells_c, &cells_s};
+  DevBuf<TreeView> *vd[2] = {&ctx->views_c, &ctx->views_s};
+  DevBuf<int32_t> *cd[2] = {&ctx->cell_c, &ctx->cell_s};
+  CubeGridDev *grid[2] = {&ctx->gc, &ctx->gs};
+  for (int t = 0; t < 2; ++t) {
+    HIP_TRY(vd[t]->reserve(views[t]->size() + 1));
+    HIP_TRY(cd[t]->reserve(cells[t]->size() + 1));
+    if (!views[t]->empty())
+      HIP_TRY(hipMemcpyAsync(vd[t]->p, views[t]->data(), views[t]->size() * sizeof(TreeView), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(cd[t]->p, cells[t]->data(), cells[t]->size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    grid[t]->cube_size = cube_size;
+    for (int d = 0; d < 3; ++d) { grid[t]->origin[d] = origin[d]; grid[t]->dims[d] = dims[d]; }
+    grid[t]->cell_tree = cd[t]->p;
+    grid[t]->trees = vd[t]->p;
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->stream));  // the tables are the caller's locals
+  ctx->tc.view = TreeView{};
+  ctx->ts.view = TreeView{};
+  ctx->tc.depth = depth_c;
+  ctx->ts.depth = depth_s;
+  ctx->info = lslam_map_info{};
+  ctx->info.n_corner = nc;
+  ctx->info.n_surf = ns;
+  ctx->info.nodes_corner = (uint32_t)views_c.size();
+  ctx->info.nodes_surf = (uint32_t)views_s.size();
+  ctx->info.depth_corner = depth_c;
+  ctx->info.depth_surf = depth_s;
+  ctx->info.built_on_device = 1;
+  ctx->info.build_attempts = 1;
+  ctx->cube_mode = true;
+  ctx->have_map = true;
+  return LSLAM_OK;
+}
+void cubemap_drop_views(lslam_ctx *ctx) {
+  if (ctx->cube_mode) {
+    ctx->have_map = false;
+    ctx->cube_mode = false;
+  }
+}
 void set_error(const char *msg) { set_err("%s", msg); }
 hipStream_t ctx_stream(lslam_ctx *ctx) { return ctx->stream; }
 TreeView ctx_tree_view(lslam_ctx *ctx, int which) { return which ? ctx->ts.view : ctx->tc.view; }

@@ -15,9 +15,11 @@
 namespace lslam {
 
 #define LSLAM_DEV __device__ __forceinline__
-#ifndef LSLAM_LEAF_LOAD_ALL
-#define LSLAM_LEAF_LOAD_ALL 1  // 0: a lane only loads the points its leaf holds -- measured SLOWER (0.475 vs 0.448 ms per 2.6 M-point launch): the vector memory pipe is paid per wave-instruction, not per active lane
+#ifndef LSLAM_BRANCHY_LEAF
+#define LSLAM_BRANCHY_LEAF 0  // 1: the per-candidate `if (dist < worst) insert` form (A/B switch)
 #endif
+// (a lane loading only the points its leaf holds -- exec-masked loads -- measured SLOWER, 0.475 against 0.448 ms per
+// 2.6 M-point launch: the vector memory pipe is paid per wave-instruction, not per active lane)
 
 // ---------------------------------------------------------------------------
 // kd-tree in HBM.  Topology and leaf order are exactly nanoflann v1.2.3's
@@ -95,6 +97,26 @@ LSLAM_DEV void knn_insert(float (&d)[5], int (&p)[5], float dist, int pos) {
     d[j] = nd[j];
     p[j] = np[j];
   }
+}
+
+// The same insertion as straight-line min / med3 / select code (19 operations, no k): for ascending d and the
+// new value x, slot i of the result is clamp(x, d[i-1], d[i]) = med3(d[i-1], d[i], x); the index follows with the
+// comparisons c_i = (x < d[i]) -- strict, so x goes after every element that is not strictly greater, as
+// KNNResultSet::addPoint does (:117).  x = FLT_MAX (an empty slot's value) leaves the set as it is.
+LSLAM_DEV void knn_insert_sorted(float (&d)[5], int (&p)[5], float x, int pos) {
+  const bool c0 = x < d[0], c1 = x < d[1], c2 = x < d[2], c3 = x < d[3], c4 = x < d[4];
+  const float n0 = fminf(d[0], x);
+  const float n1 = __builtin_amdgcn_fmed3f(d[0], d[1], x);
+  const float n2 = __builtin_amdgcn_fmed3f(d[1], d[2], x);
+  const float n3 = __builtin_amdgcn_fmed3f(d[2], d[3], x);
+  const float n4 = __builtin_amdgcn_fmed3f(d[3], d[4], x);
+  const int q4 = c3 ? p[3] : (c4 ? pos : p[4]);
+  const int q3 = c2 ? p[2] : (c3 ? pos : p[3]);
+  const int q2 = c1 ? p[1] : (c2 ? pos : p[2]);
+  const int q1 = c0 ? p[0] : (c1 ? pos : p[1]);
+  const int q0 = c0 ? pos : p[0];
+  d[0] = n0; d[1] = n1; d[2] = n2; d[3] = n3; d[4] = n4;
+  p[0] = q0; p[1] = q1; p[2] = q2; p[3] = q3; p[4] = q4;
 }
 
 // Per-lane traversal stack.  Entries are two 32-bit words.  The first KD_STACK_LDS
@@ -218,8 +240,8 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
       // all of the leaf's loads are issued before any distance is evaluated
       float4 pt[10];
 #pragma unroll
-      for (int j = 0; j < 10; ++j)
-        if (LSLAM_LEAF_LOAD_ALL || j < cnt) pt[j] = T.pts[l + j];
+      for (int j = 0; j < 10; ++j) pt[j] = T.pts[l + j];
+#if LSLAM_BRANCHY_LEAF
 #pragma unroll
       for (int j = 0; j < 10; ++j) {
         if (j < cnt) {
@@ -227,6 +249,18 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
           if (dist < worst) knn_insert(d, p, dist, l + j);
         }
       }
+#else
+      // Straight-line: every lane offers all ten slots to the sorted insert; a slot beyond the leaf's count, or a
+      // candidate nanoflann's test `dist < worst_dist` (:1448) turns away, is offered as FLT_MAX and changes nothing.
+      // No divergent branch per candidate: the 64 lanes of a wavefront sit in 64 different leaves, so "any lane
+      // inserts" was true for almost every candidate and ran the insert with a handful of lanes active.
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        const float dist = dist2_xyz(qx, qy, qz, pt[j]);
+        const float x = (j < cnt && dist < worst) ? dist : FLT_MAX;
+        knn_insert_sorted(d, p, x, l + j);
+      }
+#endif
     }
     TS_ADD(t_leaf)
     bool take = false;

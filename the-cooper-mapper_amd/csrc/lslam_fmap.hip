@@ -112,7 +112,7 @@ __device__ __forceinline__ int32_t cube_of_point(const KeyParams &k, float x, fl
 
 // new points: p' = R p + t (pcl::transformPointCloud), cube of p'
 __global__ void fm_transform_kernel(const float4 *in, int n, const float *T, KeyParams k, float4 *out,
-                                    int32_t *cube_out) {
+                                    int32_t *cube_out, uint8_t *touched) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float4 p = in[i];
@@ -125,6 +125,7 @@ __global__ void fm_transform_kernel(const float4 *in, int n, const float *T, Key
   const int32_t c = cube_of_point(k, q.x, q.y, q.z, g);
   out[i] = q;
   cube_out[i] = c;
+  if (touched && c >= 0) touched[c] = 1;  // this cube's cloud changes: its kd-tree (per-cube forest) is stale
 }
 
 // flags[c] != 0: cube c is filtered by this rebuild (active area; every cube for getFullMap);
@@ -367,6 +368,28 @@ struct lslam_fmap {
   Buf<int32_t> g_src, g_dst;
   Buf<float4> sur[2];
   Scratch sc;
+  // ---- per-cube kd-trees kept between frames (lslam_fmap_to_cubemap; FeatureMap.h:438,453 _kdtreeCorner/_kdtreeSurf) ----
+  // A cube's tree is rebuilt only when its cloud changed: addFeatureCloud marks the cubes that received points
+  // (the VoxelGrid re-filter of an untouched cube reproduces its cloud bit for bit), shifts and loads mark all.
+  // Trees built together share one node / point array ("generation"); a generation is freed when none of its trees
+  // is current any more.
+  struct Generation {
+    Buf<lslam::KdNode> nodes;
+    Buf<lslam::PNode> pn;
+    Buf<float4> pts;
+    int live = 0, depth = 0;
+  };
+  struct CubeTree {
+    int gen = -1;           // index into gens (-1: no tree)
+    lslam::TreeView view{};
+  };
+  std::vector<Generation *> gens[2];
+  std::vector<CubeTree> cube_tree[2];   // [ncube]
+  std::vector<uint8_t> dirty[2];        // [ncube]
+  Buf<uint8_t> d_touched;               // [ncube] set by the insert kernel
+  Buf<int32_t> d_cells[2];
+  Buf<lslam::TreeView> d_views[2];
+  int64_t trees_built = 0, trees_reused = 0;  // statistics of the last lslam_fmap_to_cubemap
 };
 
 namespace {
@@ -509,6 +532,7 @@ int rebuild(lslam_fmap *fm, int t, size_t n_new, bool allow_filter, const uint8_
   std::swap(fm->cube[t], fm->cube_alt[t]);
   fm->n[t] = n_out;
   fm->seg_current[t] = false;
+  if (n_new == 0 || flags_override) fm->dirty[t].assign((size_t)fm->ncube, 1);  // shift / load: every cube's cloud may have moved
   return LSLAM_OK;
 }
 
@@ -680,6 +704,13 @@ void lslam_fmap_destroy(lslam_fmap *fm) {
     fm->pts[t].release(); fm->pts_alt[t].release(); fm->cube[t].release(); fm->cube_alt[t].release();
     fm->seg_begin[t].release(); fm->seg_end[t].release(); fm->sur[t].release();
   }
+  for (int t = 0; t < 2; ++t) {
+    for (lslam_fmap::Generation *g : fm->gens[t])
+      if (g) { g->nodes.release(); g->pn.release(); g->pts.release(); delete g; }
+    fm->gens[t].clear();
+  }
+  fm->d_touched.release();
+  if (lslam::ctx_alive(fm->ctx)) lslam::cubemap_drop_views(fm->ctx);  // the context may still point at this map's trees
   fm->active.release(); fm->in_raw.release(); fm->in_tf.release(); fm->in_cube.release(); fm->d_T.release();
   fm->d_remap.release(); fm->g_src.release(); fm->g_dst.release();
   fm->sc.release();
@@ -767,6 +798,8 @@ int lslam_fmap_add_feature_cloud(lslam_fmap *fm, const void *corner, size_t n_co
   FM_TRY(hipMemcpyAsync(fm->d_T.p, T, 16 * sizeof(float), hipMemcpyHostToDevice, s));
   const void *src[2] = {corner, surf};
   const size_t cnt[2] = {n_corner, n_surf};
+  FM_TRY(fm->d_touched.reserve(fm->ncube));
+  std::vector<uint8_t> h_touched((size_t)fm->ncube);
   for (int t = 0; t < 2; ++t) {
     const size_t n = cnt[t];
     if (n) {
@@ -775,11 +808,17 @@ int lslam_fmap_add_feature_cloud(lslam_fmap *fm, const void *corner, size_t n_co
       FM_TRY(fm->in_tf.reserve(n));
       FM_TRY(fm->in_cube.reserve(n));
       KeyParams kp = key_params(fm, fm->leaf[t]);
+      FM_TRY(hipMemsetAsync(fm->d_touched.p, 0, fm->ncube, s));
       hipLaunchKernelGGL(fm_transform_kernel, dim3(((int)n + 255) / 256), dim3(256), 0, s, fm->in_raw.p, (int)n,
-                         fm->d_T.p, kp, fm->in_tf.p, fm->in_cube.p);
+                         fm->d_T.p, kp, fm->in_tf.p, fm->in_cube.p, fm->d_touched.p);
+      FM_TRY(hipMemcpyAsync(h_touched.data(), fm->d_touched.p, fm->ncube, hipMemcpyDeviceToHost, s));
     }
-    rc = rebuild(fm, t, n, true);
+    rc = rebuild(fm, t, n, true);  // synchronises the stream
     if (rc) return rc;
+    if (n) {
+      fm->dirty[t].resize((size_t)fm->ncube, 1);
+      for (int c = 0; c < fm->ncube; ++c) fm->dirty[t][(size_t)c] |= h_touched[(size_t)c];
+    }
   }
   FM_TRY(hipStreamSynchronize(s));
   return LSLAM_OK;
@@ -834,21 +873,143 @@ int lslam_fmap_surround_to_map(lslam_fmap *fm) {
   return lslam::map_set_device(fm->ctx, fm->sur[0].p, n[0], fm->sur[1].p, n[1]);
 }
 
-// The active area as a variant-C map (FeatureMap::scanMatchScan, FeatureMap.h:490-691: one kd-tree
-// per cube, cubes with fewer than 5 points skipped :524,546), built for all cubes at once on the device.
+static void drop_cube_trees(lslam_fmap *fm, int t) {
+  for (lslam_fmap::CubeTree &ct : fm->cube_tree[t]) {
+    if (ct.gen >= 0) fm->gens[t][(size_t)ct.gen]->live--;
+    ct.gen = -1;
+  }
+}
+
+// Forget the cached per-cube trees: the next lslam_fmap_to_cubemap builds every tree of the active area anew.
+int lslam_fmap_cubemap_invalidate(lslam_fmap *fm) {
+  if (!fm) return LSLAM_ERR_INVALID;
+  for (int t = 0; t < 2; ++t) drop_cube_trees(fm, t);
+  return LSLAM_OK;
+}
+
+// The active area as a variant-C map (FeatureMap::scanMatchScan, FeatureMap.h:490-691: one kd-tree per cube,
+// cubes with fewer than 5 points skipped :524,546).  The reference builds a cube's tree when its cloud is loaded
+// and keeps it (:438,453); here a cube's tree is kept as long as its cloud is unchanged: only the cubes that
+// received points since their tree was built (or that never had one) are gathered and built -- all of them in one
+// go by the device forest builder -- the others keep theirs.
 int lslam_fmap_to_cubemap(lslam_fmap *fm) {
   int rc = check_fm(fm);
   if (rc) return rc;
-  std::vector<int32_t> roots[2], cells[2];
-  size_t n[2] = {0, 0};
+  hipStream_t s = fm->stream;
+  std::vector<lslam::TreeView> views[2];
+  std::vector<int32_t> cells[2];
+  size_t n_pts[2] = {0, 0};
+  int depth[2] = {0, 0};
+  fm->trees_built = fm->trees_reused = 0;
   for (int t = 0; t < 2; ++t) {
-    rc = gather_surround(fm, t, 2, &n[t], 5, &roots[t], &cells[t]);
+    rc = refresh_segments(fm, t);
     if (rc) return rc;
-    FM_TRY(fm->sur[t].reserve(1));
+    fm->cube_tree[t].resize((size_t)fm->ncube);
+    fm->dirty[t].resize((size_t)fm->ncube, 1);
+    // compaction: too many generations alive means many half-empty arrays -- drop every tree, the active area is
+    // rebuilt into one generation below
+    if (fm->gens[t].size() > 12) drop_cube_trees(fm, t);
+    std::vector<int32_t> build, src, dst, roots_lr;
+    size_t total = 0;
+    for (int32_t c : fm->valid) {
+      const int32_t b = fm->h_begin[t][c], e = fm->h_end[t][c];
+      lslam_fmap::CubeTree &ct = fm->cube_tree[t][(size_t)c];
+      const bool wants_tree = e - b >= 5;
+      if (!wants_tree || fm->dirty[t][(size_t)c]) {
+        if (ct.gen >= 0) {  // its tree is stale
+          fm->gens[t][(size_t)ct.gen]->live--;
+          ct.gen = -1;
+        }
+      }
+      if (wants_tree && ct.gen < 0) {
+        build.push_back(c);
+        src.push_back(b);
+        dst.push_back((int32_t)total);
+        roots_lr.push_back((int32_t)total);
+        roots_lr.push_back((int32_t)(total + (size_t)(e - b)));
+        total += (size_t)(e - b);
+      }
+      fm->dirty[t][(size_t)c] = 0;
+    }
+    if (!build.empty()) {
+      lslam_fmap::Generation *g = new lslam_fmap::Generation();
+      const int T = (int)build.size();
+      int gi = -1;
+      for (size_t k = 0; k < fm->gens[t].size(); ++k)
+        if (!fm->gens[t][k]) { gi = (int)k; break; }
+      if (gi < 0) { gi = (int)fm->gens[t].size(); fm->gens[t].push_back(nullptr); }
+      fm->gens[t][(size_t)gi] = g;
+      FM_TRY(g->pts.reserve(total + 16));
+      FM_TRY(fm->g_src.reserve(src.size()));
+      FM_TRY(fm->g_dst.reserve(dst.size()));
+      FM_TRY(hipMemcpyAsync(fm->g_src.p, src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+      FM_TRY(hipMemcpyAsync(fm->g_dst.p, dst.data(), dst.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(fm_gather_kernel, dim3(((int)total + 255) / 256), dim3(256), 0, s, fm->pts[t].p, fm->g_src.p,
+                         fm->g_dst.p, (int)src.size(), (int)total, 2, g->pts.p);
+      FM_TRY(hipStreamSynchronize(s));  // src/dst are locals
+      std::vector<lslam::TreeView> built((size_t)T);
+      int fallback = 0, max_depth = 0;
+      size_t n_leaves = 0;
+      for (int attempt = 0; attempt < 3; ++attempt) {
+        const size_t mult[3] = {2, 8, 24};
+        const size_t cap = ((mult[attempt] * total / 3 + 64 + 8 * (size_t)T) + 7) & ~(size_t)7;
+        FM_TRY(g->nodes.reserve(cap));
+        FM_TRY(g->pn.reserve(cap));
+        if (attempt > 0) {  // the failed attempt permuted the points: gather them again
+          hipLaunchKernelGGL(fm_gather_kernel, dim3(((int)total + 255) / 256), dim3(256), 0, s, fm->pts[t].p, fm->g_src.p,
+                             fm->g_dst.p, (int)src.size(), (int)total, 2, g->pts.p);
+        }
+        FM_TRY(lslam::build_kdforest_device(g->pts.p, (int32_t)total, roots_lr.data(), T, g->nodes.p, g->pn.p, (int32_t)cap, s,
+                                            built.data(), &max_depth, &n_leaves, &fallback));
+        if (fallback != 1) break;
+      }
+      if (fallback) {
+        lslam::set_error("device cube-tree build hit a structure limit");
+        return fallback == 1 || fallback == 2 ? LSLAM_ERR_TREE_BUILD : LSLAM_ERR_TREE_DEPTH;
+      }
+      g->depth = max_depth;
+      g->live = T;
+      for (int k = 0; k < T; ++k) {
+        lslam_fmap::CubeTree &ct = fm->cube_tree[t][(size_t)build[(size_t)k]];
+        ct.gen = gi;
+        ct.view = built[(size_t)k];
+      }
+      fm->trees_built += T;
+    }
+    // generations none of whose trees is current any more
+    for (size_t k = 0; k < fm->gens[t].size(); ++k) {
+      lslam_fmap::Generation *g = fm->gens[t][k];
+      if (g && g->live <= 0) {
+        g->nodes.release(); g->pn.release(); g->pts.release();
+        delete g;
+        fm->gens[t][k] = nullptr;
+      }
+    }
+    while (!fm->gens[t].empty() && !fm->gens[t].back()) fm->gens[t].pop_back();
+    // the table the sweep reads: cell -> tree view, active cubes only
+    cells[t].assign((size_t)fm->ncube, -1);
+    for (int32_t c : fm->valid) {
+      const lslam_fmap::CubeTree &ct = fm->cube_tree[t][(size_t)c];
+      if (ct.gen < 0) continue;
+      cells[t][(size_t)c] = (int32_t)views[t].size();
+      views[t].push_back(ct.view);
+      n_pts[t] += (size_t)ct.view.n_pts;
+      depth[t] = std::max(depth[t], fm->gens[t][(size_t)ct.gen]->depth);
+    }
+    fm->trees_reused += (int64_t)views[t].size();
   }
+  fm->trees_reused -= fm->trees_built;
   const int32_t dims[3] = {fm->W, fm->H, fm->D};
-  return lslam::cubemap_set_device(fm->ctx, fm->sur[0].p, n[0], roots[0], cells[0], fm->sur[1].p, n[1], roots[1], cells[1],
-                                   fm->cube_size, fm->origin, dims);
+  return lslam::cubemap_set_views(fm->ctx, views[0], cells[0], n_pts[0], depth[0], views[1], cells[1], n_pts[1], depth[1],
+                                  fm->cube_size, fm->origin, dims);
+}
+
+// statistics of the last lslam_fmap_to_cubemap: trees built in that call / kept from earlier calls
+int lslam_fmap_cubemap_stats(lslam_fmap *fm, int64_t *trees_built, int64_t *trees_reused) {
+  if (!fm) return LSLAM_ERR_INVALID;
+  if (trees_built) *trees_built = fm->trees_built;
+  if (trees_reused) *trees_reused = fm->trees_reused;
+  return LSLAM_OK;
 }
 
 int lslam_fmap_info(lslam_fmap *fm, int32_t origin[3], int32_t *n_valid, int32_t *valid_out, size_t cap,

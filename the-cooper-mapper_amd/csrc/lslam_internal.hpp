@@ -200,6 +200,12 @@ int cubemap_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t nc, const 
                        const std::vector<int32_t> &cells_c, const float4 *d_surf, size_t ns,
                        const std::vector<int32_t> &roots_s, const std::vector<int32_t> &cells_s, float cube_size,
                        const int32_t origin[3], const int32_t dims[3]);
+// variant-C map whose trees are owned by the caller (lslam_fmap's per-cube forest): views / cell tables are uploaded,
+// the trees themselves are referenced, not copied
+int cubemap_set_views(lslam_ctx *ctx, const std::vector<TreeView> &views_c, const std::vector<int32_t> &cells_c, size_t nc,
+                      int depth_c, const std::vector<TreeView> &views_s, const std::vector<int32_t> &cells_s, size_t ns, int depth_s,
+                      float cube_size, const int32_t origin[3], const int32_t dims[3]);
+void cubemap_drop_views(lslam_ctx *ctx);  // the owner of such trees goes away
 void set_error(const char *msg);
 // small accessors for translation units that work on a context (lslam_icp.hip)
 hipStream_t ctx_stream(lslam_ctx *ctx);

@@ -352,7 +352,10 @@ hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEven
   if (a.nb_total <= 0) return hipSuccess;
   const dim3 g(a.nb_total), b(SWEEP_BLOCK);
   const bool cubes = a.gc.trees != nullptr;
-  constexpr int SHALLOW = 12;  // LDS levels of the production (bounded) sweep
+#ifndef LSLAM_SHALLOW_DEPTH
+#define LSLAM_SHALLOW_DEPTH 12
+#endif
+  constexpr int SHALLOW = LSLAM_SHALLOW_DEPTH;  // LDS levels of the production (bounded) sweep
   // A launch with more wavefronts than two per SIMD (256 CUs x 4 SIMDs) is throughput bound:
   // take the shallow-stack kernel (4 workgroups per CU).  A smaller launch is latency bound
   // and every wavefront is resident anyway: keep the whole stack in LDS.

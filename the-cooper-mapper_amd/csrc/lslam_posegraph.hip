@@ -1069,15 +1069,25 @@ int lslam_g2o_read(const char *path, int32_t *n_vertices, double *poses7, int32_
 }
 
 // g2o OptimizationAlgorithmLevenberg schedule (see oracle/posegraph_oracle.py)
+namespace {
+struct EventPair {  // destroyed on every exit path
+  hipEvent_t a = nullptr, b = nullptr;
+  ~EventPair() {
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+  }
+};
+}  // namespace
+
 int lslam_pg_optimize(lslam_pg *pg, int32_t max_iters, lslam_pg_stats *st_out) {
   if (!pg) return LSLAM_ERR_INVALID;
   PG_TRY(hipSetDevice(pg->device));
   lslam_pg_stats st;
   std::memset(&st, 0, sizeof(st));
-  hipEvent_t ev0, ev1;
-  PG_TRY(hipEventCreate(&ev0));
-  PG_TRY(hipEventCreate(&ev1));
-  PG_TRY(hipEventRecord(ev0, pg->stream));
+  EventPair ev;
+  PG_TRY(hipEventCreate(&ev.a));
+  PG_TRY(hipEventCreate(&ev.b));
+  PG_TRY(hipEventRecord(ev.a, pg->stream));
   const int n6 = pg->n_v * 6;
   double lambda = -1.0, ni = 2.0;
   for (int it = 0; it < max_iters; ++it) {
@@ -1087,6 +1097,7 @@ int lslam_pg_optimize(lslam_pg *pg, int32_t max_iters, lslam_pg_stats *st_out) {
     PG_TRY(hipMemcpyAsync(&cur, pg->chi(), 8, hipMemcpyDeviceToHost, pg->stream));
     if (lambda < 0) {
       hipLaunchKernelGGL(pg_maxdiag_kernel, dim3(1), dim3(256), 0, pg->stream, pg->diag(), pg->n_v, pg->fixed, pg->d_tmp + 1);
+      PG_TRY(hipGetLastError());
       double md;
       PG_TRY(hipMemcpyAsync(&md, pg->d_tmp + 1, 8, hipMemcpyDeviceToHost, pg->stream));
       PG_TRY(hipStreamSynchronize(pg->stream));
@@ -1103,12 +1114,14 @@ int lslam_pg_optimize(lslam_pg *pg, int32_t max_iters, lslam_pg_stats *st_out) {
       st.cg_iterations += cg;
       hipLaunchKernelGGL(pg_update_kernel, dim3((pg->n_v + 127) / 128), dim3(128), 0, pg->stream, pg->d_poses,
                          pg->d_x, pg->n_v, pg->fixed, pg->d_trial);
+      PG_TRY(hipGetLastError());
       double tmp;
       rc = eval_chi2(pg, pg->d_trial, &tmp);
       if (rc) return rc;
       hipLaunchKernelGGL(pg_dot_scale_kernel, dim3(pg->n_cg_blocks), dim3(CG_BLOCK), 0, pg->stream, pg->d_x,
                          pg->b(), n6, lambda, pg->d_part);
       hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(256), 0, pg->stream, pg->d_part, pg->n_cg_blocks, 1, pg->d_tmp + 2);
+      PG_TRY(hipGetLastError());  // a failed launch must not turn into a stale read below
       double scale;
       PG_TRY(hipMemcpyAsync(&scale, pg->d_tmp + 2, 8, hipMemcpyDeviceToHost, pg->stream));
       PG_TRY(hipStreamSynchronize(pg->stream));
@@ -1134,11 +1147,9 @@ int lslam_pg_optimize(lslam_pg *pg, int32_t max_iters, lslam_pg_stats *st_out) {
     st.lambda = lambda;
     if (qmax == 10 || rho == 0) break;
   }
-  PG_TRY(hipEventRecord(ev1, pg->stream));
+  PG_TRY(hipEventRecord(ev.b, pg->stream));
   PG_TRY(hipStreamSynchronize(pg->stream));
-  PG_TRY(hipEventElapsedTime(&st.gpu_ms_total, ev0, ev1));
-  (void)hipEventDestroy(ev0);
-  (void)hipEventDestroy(ev1);
+  PG_TRY(hipEventElapsedTime(&st.gpu_ms_total, ev.a, ev.b));
   if (st_out) *st_out = st;
   return LSLAM_OK;
 }

@@ -97,6 +97,27 @@ class FeatureMap:
         """The active area becomes ``ctx``'s variant-C map: one kd-tree per cube (FeatureMap.h:490-691)."""
         self._check(self.lib.lslam_fmap_to_cubemap(self.h))
 
+    def cubemap_stats(self):
+        """(trees built by the last to_cubemap(), trees it kept from earlier calls)."""
+        b, r = C.c_int64(), C.c_int64()
+        self._check(self.lib.lslam_fmap_cubemap_stats(self.h, C.byref(b), C.byref(r)))
+        return b.value, r.value
+
+    def cubemap_invalidate(self):
+        self._check(self.lib.lslam_fmap_cubemap_invalidate(self.h))
+
+    def scan_match_scan(self, corner, surf, pose, opts=None):
+        """FeatureMap::scanMatchScan (util/FeatureMap.h:490-691): the scan against the per-cube trees of the active
+        area (kept between calls, rebuilt only where the map changed) with the reference's settings -- at most 10
+        iterations, thresholds 0.05 / 0.05, no score gate.  -> (status, pose, stats); the reference returns nothing."""
+        self.to_cubemap()
+        if opts is None:
+            opts = self.ctx.default_opts()
+            opts.max_iterations = 10
+            opts.delta_t_abort = opts.delta_r_abort = 0.05
+            opts.use_score = 0
+        return self.ctx.scanmatch_scan(corner, surf, pose, opts)
+
     def get_full_map(self):
         n = C.c_size_t()
         self._check(self.lib.lslam_fmap_get_full_map(self.h, None, 0, C.byref(n)))

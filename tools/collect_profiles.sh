@@ -6,9 +6,10 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-H="$root/bench.py --headline-only --steps 2 --warmup 1"
+H="$root/bench.py --headline-only --steps 2 --warmup 1 --map-cache /tmp/lslam_${tag}_map"
+timeout 600 python3 $H > $out/${tag}_headline.json 2> $out/${tag}_headline.err   # builds and saves the map once
 timeout 1500 python3 $root/bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o s -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --pg-iters 20 > $out/${tag}_stats.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o s -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --pg-iters 20 --map-cache /tmp/lslam_${tag}_map > $out/${tag}_stats.log 2>&1
 cp $out/${tag}_stats/s_kernel_stats.csv $out/${tag}_kernel_stats.csv
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" \
@@ -21,5 +22,5 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
   timeout 900 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/${tag}_pmc/p$i -o p -- python3 $H > $out/${tag}_pmc_p$i.log 2>&1
 done
 python3 $root/tools/summarize_pmc.py sweep_kernel $out/${tag}_pmc_sweep.csv $out/${tag}_pmc/p1 $out/${tag}_pmc/p2 $out/${tag}_pmc/p3 $out/${tag}_pmc/p4 $out/${tag}_pmc/p5 $out/${tag}_pmc/p6 $out/${tag}_pmc/p7 > /dev/null
-rm -rf $out/${tag}_pmc/*/*/*_agent_info.csv
+rm -rf $out/${tag}_pmc $out/${tag}_stats   # raw traces are gigabytes; the summaries above are what is kept
 du -sh $out | tail -1

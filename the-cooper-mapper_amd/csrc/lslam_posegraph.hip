@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iomanip>
@@ -1109,7 +1110,13 @@ int lslam_pg_optimize(lslam_pg *pg, int32_t max_iters, lslam_pg_stats *st_out) {
     int qmax = 0;
     for (;;) {
       int cg = 0;
-      rc = solve(pg, lambda, 4000, 1e-10, &cg);
+      // Every damped system is solved to 1e-10 (relative residual), however many PCG iterations that takes: near the
+      // optimum lambda shrinks, the system of a 5 000-keyframe chain reaches a condition number of ~1e7 and block-Jacobi
+      // PCG needs thousands of iterations -- but a TRUNCATED solve leaves exactly the slow (global bending) modes
+      // unresolved, and LM then crawls (measured: capped at 800 iterations the 5 k / 25 k graph is still 5 m from its
+      // optimum after 2 000 LM iterations; uncapped it arrives in 342).  LSLAM_PG_MAX_CG overrides the cap for A/B runs.
+      static const int max_cg = std::getenv("LSLAM_PG_MAX_CG") ? std::atoi(std::getenv("LSLAM_PG_MAX_CG")) : 20000;
+      rc = solve(pg, lambda, max_cg, 1e-10, &cg);
       if (rc) return rc;
       st.cg_iterations += cg;
       hipLaunchKernelGGL(pg_update_kernel, dim3((pg->n_v + 127) / 128), dim3(128), 0, pg->stream, pg->d_poses,

@@ -398,7 +398,19 @@ struct CgArgs {
   double *part_rr;       // [n_blocks]
   double *scal;          // [3] rr  [4] bb  [5] done flag  [6] iterations done
   int n6, n_blocks, n_items, n_pblocks;
+  int n_parts;           // entries of part_rz[] / part_rr: n_blocks + the coarse level's blocks (zero when it is off)
   double tol2;
+};
+
+// ---- second level of the preconditioner (see solve()) -----------------------------------------------------------
+struct CoarseArgs {
+  const double *poses;    // current estimate (7 per vertex)
+  double *P;              // [n_v][36] prolongation blocks: delta_i = P_i xi_a
+  double *Ac;             // [n_c][n_c] coarse matrix, inverted in place
+  double *rc, *yc;        // [n_c]
+  double *Rbuf, *Cbuf, *Bbuf;  // block Gauss-Jordan scratch: [6][n_c], [n_c][6], [36]
+  const int32_t *cb_ptr, *cb_ent, *cb_ab;  // coarse blocks: fine entries of each, its (row, column) aggregate
+  int n_v, G, na, n_c, n_cb, n_cblk;
 };
 
 __global__ __launch_bounds__(CG_BLOCK) void pg_cg_init_kernel(CgArgs a) {
@@ -467,7 +479,7 @@ __global__ __launch_bounds__(PROD_BLOCK) void pg_cg_prod_kernel(CgArgs a, int k)
   if (k > 0) {
     const double *const parts[3] = {a.part_rz[k & 1], a.part_rz[(k + 1) & 1], a.part_rr};
     double s[3];
-    sum_partials_m<3, PROD_BLOCK>(parts, a.n_blocks, s, sh);
+    sum_partials_m<3, PROD_BLOCK>(parts, a.n_parts, s, sh);
     if (s[2] <= a.tol2 * a.scal[4] || !(s[0] > 0.0)) {
       if (blockIdx.x == 0 && threadIdx.x == 0) {
         a.scal[3] = s[2];
@@ -520,7 +532,7 @@ __global__ __launch_bounds__(CG_BLOCK) void pg_cg_update_kernel(CgArgs a, int k)
   {
     const double *const p0[1] = {a.part_rz[k & 1]};
     const double *const p1[1] = {a.part_pq};
-    sum_partials_m<1>(p0, a.n_blocks, s0, sh);
+    sum_partials_m<1>(p0, a.n_parts, s0, sh);
     sum_partials_m<1>(p1, a.n_pblocks, s1, sh);
   }
   const double alpha = s0[0] / s1[0];
@@ -556,11 +568,185 @@ __global__ __launch_bounds__(CG_BLOCK) void pg_cg_check_kernel(CgArgs a, int k) 
   if (a.scal[5] != 0.0) return;
   const double *const parts[2] = {a.part_rz[k & 1], a.part_rr};
   double s[2];
-  sum_partials_m<2>(parts, a.n_blocks, s, sh);
+  sum_partials_m<2>(parts, a.n_parts, s, sh);
   if (threadIdx.x == 0) {
     a.scal[3] = s[1];
     if (s[1] <= a.tol2 * a.scal[4] || !(s[0] > 0.0)) a.scal[5] = 1.0;
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Second level of the preconditioner: rigid motions of runs of G consecutive keyframes.
+// A long trajectory bends almost for free -- moving a whole sub-chain rigidly only strains the edges at its two ends --
+// and those global modes are what block-Jacobi PCG needs thousands of iterations for once lambda is small.  The coarse
+// unknown of aggregate a is a world-frame twist xi_a = (rho, phi) about the aggregate's first keyframe c_a; applied on
+// the left it is, to first order, the local increment (g2o's right-multiplied [dt, dq]) delta_i = P_i xi_a of every
+// keyframe i = (R_i, t_i) of the aggregate,  P_i = [ R_i^T   -R_i^T [t_i - c_a]x ;  0   R_i^T / 2 ].
+// M^-1 = blockdiag(A)^-1 + P (P^T A P)^-1 P^T  (additive two-level Schwarz, symmetric positive definite).  The coarse
+// matrix is dense (6 ceil(n/G) unknowns), inverted once per damped system by block Gauss-Jordan; per PCG iteration the
+// level costs a restriction, a dense matrix-vector product and a prolongation.  No atomics: every sum has a fixed order,
+// so the solve stays bit-reproducible and identical on every rank of a sharded run.
+__global__ void pgc_P_kernel(CoarseArgs c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c.n_v) return;
+  const Pose x = load_pose(c.poses + 7 * i);
+  const Pose x0 = load_pose(c.poses + 7 * ((i / c.G) * c.G));
+  double R[9];
+  qrotmat(x.q, R);
+  const double d[3] = {x.t.x - x0.t.x, x.t.y - x0.t.y, x.t.z - x0.t.z};
+  // S = [d]x
+  const double S[9] = {0, -d[2], d[1], d[2], 0, -d[0], -d[1], d[0], 0};
+  double *P = c.P + (size_t)i * 36;
+  for (int r = 0; r < 3; ++r)
+    for (int col = 0; col < 3; ++col) {
+      const double rt = R[col * 3 + r];  // R^T[r][col]
+      double m = 0.0;                    // (R^T S)[r][col]
+      for (int k = 0; k < 3; ++k) m += R[k * 3 + r] * S[k * 3 + col];
+      P[r * 6 + col] = rt;
+      P[r * 6 + 3 + col] = -m;
+      P[(3 + r) * 6 + col] = 0.0;
+      P[(3 + r) * 6 + 3 + col] = 0.5 * rt;
+    }
+}
+
+// A_c[a][b] = sum over the fine entries (i, j) with i in a, j in b of P_i^T A_ij P_j; one 64-thread block per coarse block
+__global__ __launch_bounds__(64) void pgc_assemble_kernel(CoarseArgs c, const double *vals, const int32_t *row_of,
+                                                          const int32_t *row_col, size_t n_items) {
+  __shared__ double T[36];
+  const int cb = blockIdx.x, t = threadIdx.x;
+  const int r = t / 6, col = t % 6;  // t < 36
+  double acc = 0.0;
+  for (int q = c.cb_ptr[cb]; q < c.cb_ptr[cb + 1]; ++q) {
+    const int e = c.cb_ent[q];
+    const int i = row_of[e], j = row_col[e];
+    if (t < 36) {  // T = A_e P_j
+      double s = 0.0;
+      for (int l = 0; l < 6; ++l) s += vals[(size_t)l * n_items + (size_t)e * 6 + r] * c.P[(size_t)j * 36 + l * 6 + col];
+      T[t] = s;
+    }
+    __syncthreads();
+    if (t < 36) {
+      for (int k = 0; k < 6; ++k) acc += c.P[(size_t)i * 36 + k * 6 + r] * T[k * 6 + col];
+    }
+    __syncthreads();
+  }
+  if (t < 36) c.Ac[(size_t)(c.cb_ab[2 * cb] * 6 + r) * c.n_c + c.cb_ab[2 * cb + 1] * 6 + col] = acc;
+}
+
+// block Gauss-Jordan, pivot block k: B = A_kk^-1, R = B A_k*, C = A_*k  (one workgroup)
+__global__ __launch_bounds__(256) void pgc_gj_pivot_kernel(CoarseArgs c, int k) {
+  __shared__ double B[36];
+  const int n = c.n_c, t = threadIdx.x;
+  if (t == 0) {  // 6x6 inverse by Gauss-Jordan with partial pivoting
+    double M[6][12];
+    for (int r = 0; r < 6; ++r)
+      for (int q = 0; q < 6; ++q) {
+        M[r][q] = c.Ac[(size_t)(k * 6 + r) * n + k * 6 + q];
+        M[r][6 + q] = r == q ? 1.0 : 0.0;
+      }
+    for (int p = 0; p < 6; ++p) {
+      int best = p;
+      for (int r = p + 1; r < 6; ++r)
+        if (fabs(M[r][p]) > fabs(M[best][p])) best = r;
+      if (best != p)
+        for (int q = 0; q < 12; ++q) { const double tmp = M[p][q]; M[p][q] = M[best][q]; M[best][q] = tmp; }
+      const double inv = 1.0 / M[p][p];
+      for (int q = 0; q < 12; ++q) M[p][q] *= inv;
+      for (int r = 0; r < 6; ++r)
+        if (r != p) {
+          const double f = M[r][p];
+          for (int q = 0; q < 12; ++q) M[r][q] -= f * M[p][q];
+        }
+    }
+    for (int r = 0; r < 6; ++r)
+      for (int q = 0; q < 6; ++q) { B[r * 6 + q] = M[r][6 + q]; c.Bbuf[r * 6 + q] = M[r][6 + q]; }
+  }
+  __syncthreads();
+  for (int j = t; j < n; j += 256) {
+    double a[6];
+    for (int r = 0; r < 6; ++r) {
+      a[r] = c.Ac[(size_t)(k * 6 + r) * n + j];
+      c.Cbuf[(size_t)j * 6 + r] = c.Ac[(size_t)j * n + k * 6 + r];
+    }
+    for (int r = 0; r < 6; ++r) {
+      double s = 0.0;
+      for (int q = 0; q < 6; ++q) s += B[r * 6 + q] * a[q];
+      c.Rbuf[(size_t)r * n + j] = s;
+    }
+  }
+}
+// ... and the update of every entry with it
+__global__ __launch_bounds__(256) void pgc_gj_update_kernel(CoarseArgs c, int k) {
+  const int n = c.n_c;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)n * n) return;
+  const int i = (int)(idx / n), j = (int)(idx % n);
+  const bool ik = i / 6 == k, jk = j / 6 == k;
+  double v;
+  if (ik && jk) {
+    v = c.Bbuf[(i - k * 6) * 6 + (j - k * 6)];
+  } else if (ik) {
+    v = c.Rbuf[(size_t)(i - k * 6) * n + j];
+  } else if (jk) {
+    double s = 0.0;
+    for (int m = 0; m < 6; ++m) s += c.Cbuf[(size_t)i * 6 + m] * c.Bbuf[m * 6 + (j - k * 6)];
+    v = -s;
+  } else {
+    double s = 0.0;
+    for (int m = 0; m < 6; ++m) s += c.Cbuf[(size_t)i * 6 + m] * c.Rbuf[(size_t)m * n + j];
+    v = c.Ac[idx] - s;
+  }
+  c.Ac[idx] = v;
+}
+
+// r_c = P^T r: one wavefront per aggregate
+__global__ __launch_bounds__(64) void pgc_restrict_kernel(CoarseArgs c, const double *r) {
+  const int a = blockIdx.x, j = threadIdx.x;
+  const int i = a * c.G + j;
+  double w[6] = {0, 0, 0, 0, 0, 0};
+  if (j < c.G && i < c.n_v) {
+    const double *P = c.P + (size_t)i * 36;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double rk = r[(size_t)i * 6 + k];
+#pragma unroll
+      for (int m = 0; m < 6; ++m) w[m] += P[k * 6 + m] * rk;
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 6; ++m) {
+    double s = w[m];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (j == 0) c.rc[a * 6 + m] = s;
+  }
+}
+// y_c = A_c^-1 r_c and this block's share of r . (P y_c) = r_c . y_c; four rows per workgroup
+__global__ __launch_bounds__(256) void pgc_mv_kernel(CoarseArgs c, double *part_rz_extra) {
+  __shared__ double dots[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w;
+  double s = 0.0;
+  if (row < c.n_c)
+    for (int col = lane; col < c.n_c; col += 64) s += c.Ac[(size_t)row * c.n_c + col] * c.rc[col];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) {
+    if (row < c.n_c) c.yc[row] = s;
+    dots[w] = row < c.n_c ? s * c.rc[row] : 0.0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) part_rz_extra[blockIdx.x] = ((dots[0] + dots[1]) + dots[2]) + dots[3];
+}
+// z += P y_c
+__global__ void pgc_prolong_kernel(CoarseArgs c, double *z) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= c.n_v * 6) return;
+  const int i = row / 6, r = row % 6;
+  const double *P = c.P + (size_t)i * 36 + r * 6;
+  const double *y = c.yc + (size_t)(i / c.G) * 6;
+  double s = 0.0;
+#pragma unroll
+  for (int m = 0; m < 6; ++m) s += P[m] * y[m];
+  z[row] += s;
 }
 
 // X <- X * fromVectorMQT(dx)
@@ -665,6 +851,14 @@ struct lslam_pg {
   double *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_p = nullptr, *d_q = nullptr;
   double *d_part = nullptr, *d_scal = nullptr, *d_tmp = nullptr;
   int n_cg_blocks = 0;
+  // second level of the preconditioner (rigid motions of runs of `agg` consecutive keyframes)
+  std::vector<int32_t> h_row_of, h_row_col;
+  int agg = 32, n_agg = 0, n_c = 0, n_cb = 0, n_cblk = 0, n_parts = 0;
+  double *d_P = nullptr, *d_Ac = nullptr, *d_rc = nullptr, *d_yc = nullptr, *d_gj = nullptr;
+  int32_t *d_cb_ptr = nullptr, *d_cb_ent = nullptr, *d_cb_ab = nullptr;
+  int coarse_mode = -1;     // -1 automatic (switched on by a solve that needed many iterations), 0 off, 1 on
+  bool coarse_on = false;
+  int coarse_solves = 0;    // damped systems solved with the second level (statistics)
   size_t sys_doubles() const { return (size_t)n_v * 36 + (size_t)n_off * 36 + (size_t)n_v * 6 + 1; }
   double *diag() const { return d_sys; }
   double *off() const { return d_sys + (size_t)n_v * 36; }
@@ -771,9 +965,11 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
   a.p[0] = pg->d_p;
   a.p[1] = pg->d_p + n6;
   a.part_rz[0] = pg->d_part;
-  a.part_rz[1] = pg->d_part + pg->n_cg_blocks;
-  a.part_rr = pg->d_part + 2 * pg->n_cg_blocks;
-  a.part_pq = pg->d_part + 3 * pg->n_cg_blocks;
+  a.part_rz[1] = pg->d_part + pg->n_parts;
+  a.part_rr = pg->d_part + 2 * pg->n_parts;
+  a.part_pq = pg->d_part + 3 * pg->n_parts;
+  a.n_parts = pg->n_parts;
+  PG_TRY(hipMemsetAsync(pg->d_part, 0, 3 * (size_t)pg->n_parts * sizeof(double), pg->stream));  // the coarse level's slots
   a.n_items = (int)n_items;
   a.n_pblocks = (int)((n_items + PROD_BLOCK - 1) / PROD_BLOCK);
   a.scal = pg->d_scal;
@@ -781,8 +977,35 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
   a.n_blocks = pg->n_cg_blocks;
   a.tol2 = tol * tol;
   const dim3 g(pg->n_cg_blocks), blk(CG_BLOCK);
+  // second level (see pgc_P_kernel): on when forced, or -- automatic -- once a solve of this graph needed many iterations
+  const bool coarse = pg->coarse_mode == 1 || (pg->coarse_mode < 0 && pg->coarse_on);
+  CoarseArgs c{};
+  if (coarse) {
+    c.poses = pg->d_poses;
+    c.P = pg->d_P; c.Ac = pg->d_Ac; c.rc = pg->d_rc; c.yc = pg->d_yc;
+    c.Rbuf = pg->d_gj; c.Cbuf = pg->d_gj + (size_t)6 * pg->n_c; c.Bbuf = pg->d_gj + (size_t)12 * pg->n_c;
+    c.cb_ptr = pg->d_cb_ptr; c.cb_ent = pg->d_cb_ent; c.cb_ab = pg->d_cb_ab;
+    c.n_v = pg->n_v; c.G = pg->agg; c.na = pg->n_agg; c.n_c = pg->n_c; c.n_cb = pg->n_cb; c.n_cblk = pg->n_cblk;
+    const size_t nn = (size_t)c.n_c * c.n_c;
+    hipLaunchKernelGGL(pgc_P_kernel, dim3((pg->n_v + 127) / 128), dim3(128), 0, pg->stream, c);
+    PG_TRY(hipMemsetAsync(c.Ac, 0, nn * sizeof(double), pg->stream));
+    hipLaunchKernelGGL(pgc_assemble_kernel, dim3(c.n_cb), dim3(64), 0, pg->stream, c, pg->d_vals, pg->d_row_of, pg->d_row_col, n_items);
+    for (int k = 0; k < c.na; ++k) {
+      hipLaunchKernelGGL(pgc_gj_pivot_kernel, dim3(1), dim3(256), 0, pg->stream, c, k);
+      hipLaunchKernelGGL(pgc_gj_update_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, pg->stream, c, k);
+    }
+    PG_TRY(hipGetLastError());
+    pg->coarse_solves++;
+  }
+  auto coarse_correct = [&](int k) {  // z += P A_c^-1 P^T r and the matching share of r.z, entering iteration k + 1
+    if (!coarse) return;
+    hipLaunchKernelGGL(pgc_restrict_kernel, dim3(c.na), dim3(64), 0, pg->stream, c, (const double *)a.r);
+    hipLaunchKernelGGL(pgc_mv_kernel, dim3(c.n_cblk), dim3(256), 0, pg->stream, c, a.part_rz[(k + 1) & 1] + pg->n_cg_blocks);
+    hipLaunchKernelGGL(pgc_prolong_kernel, dim3((n6 + 255) / 256), dim3(256), 0, pg->stream, c, a.z);
+  };
   hipLaunchKernelGGL(pg_cg_init_kernel, g, blk, 0, pg->stream, a);
   hipLaunchKernelGGL(pg_cg_init2_kernel, dim3(1), blk, 0, pg->stream, a);
+  coarse_correct(-1);
   double scal[8] = {0};
   int done_iters = 0;
   for (int it = 0; it < max_cg;) {
@@ -790,6 +1013,7 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
     for (int k = it; k < it + chunk; ++k) {
       hipLaunchKernelGGL(pg_cg_prod_kernel, dim3(a.n_pblocks), dim3(PROD_BLOCK), 0, pg->stream, a, k);
       hipLaunchKernelGGL(pg_cg_update_kernel, g, blk, 0, pg->stream, a, k);
+      coarse_correct(k);
     }
     it += chunk;
     hipLaunchKernelGGL(pg_cg_check_kernel, dim3(1), blk, 0, pg->stream, a, it);
@@ -800,6 +1024,7 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
   }
   PG_TRY(hipGetLastError());
   *iters_out = done_iters;
+  if (done_iters > 300) pg->coarse_on = true;  // ill-conditioned from here on: later solves of this graph take the second level
   return LSLAM_OK;
 }
 
@@ -865,6 +1090,34 @@ int lslam_pg_create(int device, int32_t n_v, const double *poses7, int32_t n_e, 
     }
   }
   pg->n_entries = (int)rcol.size();
+  pg->h_row_of = rof;
+  pg->h_row_col = rcol;
+  {  // coarse blocks: fine entries grouped by (aggregate of the row, aggregate of the column), in entry order
+    if (const char *g = std::getenv("LSLAM_PG_AGG")) pg->agg = std::max(2, std::min(64, std::atoi(g)));
+    if (const char *m = std::getenv("LSLAM_PG_COARSE")) pg->coarse_mode = std::atoi(m);
+    const int G = pg->agg;
+    pg->n_agg = (n_v + G - 1) / G;
+    pg->n_c = 6 * pg->n_agg;
+    pg->n_cblk = (pg->n_c + 3) / 4;
+    std::map<std::pair<int, int>, std::vector<int32_t>> cb;
+    for (int e = 0; e < pg->n_entries; ++e) cb[{rof[(size_t)e] / G, rcol[(size_t)e] / G}].push_back(e);
+    std::vector<int32_t> cptr(1, 0), cent, cab;
+    for (auto &kv : cb) {
+      cab.push_back(kv.first.first);
+      cab.push_back(kv.first.second);
+      cent.insert(cent.end(), kv.second.begin(), kv.second.end());
+      cptr.push_back((int32_t)cent.size());
+    }
+    pg->n_cb = (int)cb.size();
+    PG_TRY(dev_upload(&pg->d_cb_ptr, cptr));
+    PG_TRY(dev_upload(&pg->d_cb_ent, cent));
+    PG_TRY(dev_upload(&pg->d_cb_ab, cab));
+    PG_TRY(hipMalloc((void **)&pg->d_P, (size_t)n_v * 36 * sizeof(double)));
+    PG_TRY(hipMalloc((void **)&pg->d_Ac, (size_t)pg->n_c * pg->n_c * sizeof(double)));
+    PG_TRY(hipMalloc((void **)&pg->d_rc, (size_t)pg->n_c * sizeof(double)));
+    PG_TRY(hipMalloc((void **)&pg->d_yc, (size_t)pg->n_c * sizeof(double)));
+    PG_TRY(hipMalloc((void **)&pg->d_gj, ((size_t)12 * pg->n_c + 36) * sizeof(double)));
+  }
   std::vector<double> hp(poses7, poses7 + 7 * (size_t)n_v), hm(meas7, meas7 + 7 * (size_t)n_e),
       hi(info36, info36 + 36 * (size_t)n_e);
   PG_TRY(dev_upload(&pg->d_poses, hp));
@@ -878,6 +1131,7 @@ int lslam_pg_create(int device, int32_t n_v, const double *poses7, int32_t n_e, 
   PG_TRY(dev_upload(&pg->d_row_of, rof));
   const size_t n6 = (size_t)n_v * 6;
   pg->n_cg_blocks = (int)((n6 + CG_ROWS - 1) / CG_ROWS);
+  pg->n_parts = pg->n_cg_blocks + pg->n_cblk;
   PG_TRY(hipMalloc((void **)&pg->d_sys, pg->sys_doubles() * sizeof(double)));
   PG_TRY(hipMalloc((void **)&pg->d_vals, (size_t)pg->n_entries * 36 * sizeof(double)));
   PG_TRY(hipMalloc((void **)&pg->d_minv, (size_t)n_v * 36 * sizeof(double)));
@@ -885,7 +1139,7 @@ int lslam_pg_create(int device, int32_t n_v, const double *poses7, int32_t n_e, 
     PG_TRY(hipMalloc((void **)p, n6 * sizeof(double)));
   PG_TRY(hipMalloc((void **)&pg->d_q, (size_t)pg->n_entries * 6 * sizeof(double)));
   PG_TRY(hipMalloc((void **)&pg->d_p, 2 * n6 * sizeof(double)));
-  PG_TRY(hipMalloc((void **)&pg->d_part, (3 * (size_t)pg->n_cg_blocks + ((size_t)pg->n_entries * 6 + PROD_BLOCK - 1) / PROD_BLOCK) * sizeof(double)));
+  PG_TRY(hipMalloc((void **)&pg->d_part, (3 * (size_t)pg->n_parts + ((size_t)pg->n_entries * 6 + PROD_BLOCK - 1) / PROD_BLOCK) * sizeof(double)));
   PG_TRY(hipMalloc((void **)&pg->d_scal, 8 * sizeof(double)));
   PG_TRY(hipMalloc((void **)&pg->d_tmp, 8 * sizeof(double)));
   int rc = build_shard(pg, 0, n_e);
@@ -902,6 +1156,8 @@ void lslam_pg_destroy(lslam_pg *pg) {
                   (void *)pg->d_ij, (void *)pg->d_rec, (void *)pg->d_chi, (void *)pg->d_vptr,
                   (void *)pg->d_vadj, (void *)pg->d_optr, (void *)pg->d_oadj, (void *)pg->d_row_ptr,
                   (void *)pg->d_row_col, (void *)pg->d_row_src, (void *)pg->d_row_of, (void *)pg->d_vals, (void *)pg->d_minv,
+                  (void *)pg->d_P, (void *)pg->d_Ac, (void *)pg->d_rc, (void *)pg->d_yc, (void *)pg->d_gj, (void *)pg->d_cb_ptr,
+                  (void *)pg->d_cb_ent, (void *)pg->d_cb_ab,
                   (void *)pg->d_x, (void *)pg->d_r, (void *)pg->d_z, (void *)pg->d_p, (void *)pg->d_q,
                   (void *)pg->d_part, (void *)pg->d_scal, (void *)pg->d_tmp})
     if (p) (void)hipFree(p);

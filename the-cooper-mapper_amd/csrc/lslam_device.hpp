@@ -321,6 +321,15 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
   }
 }
 
+#ifdef LSLAM_TRAVERSAL_STATS  // call sites that keep no statistics
+template <int BLOCK, bool OVF, int LDS_DEPTH>
+LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, float (&d)[5], int (&p)[5],
+                           KdStack<BLOCK, OVF, LDS_DEPTH> &stk, const float bound = FLT_MAX) {
+  TravStats ts = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  knn5_search<BLOCK, OVF, LDS_DEPTH>(T, qx, qy, qz, d, p, stk, ts, bound);
+}
+#endif
+
 // ---------------------------------------------------------------------------
 // Small dense algebra -- Eigen 3.3 algorithms (Eigen is a dependency of the
 // reference that is not under /root/reference).  Row-major

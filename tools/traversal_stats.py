@@ -1,50 +1,76 @@
 #!/usr/bin/env python3
-"""Per-lane traversal statistics (needs a -DLSLAM_TRAVERSAL_STATS build: LSLAM_LIB=build/liblslam_hip_stats.so)."""
+"""Per-lane traversal statistics of the sweep kernel on the bench workload (one 64-ring scan against the
+10k-frame voxel map).  Needs a -DLSLAM_TRAVERSAL_STATS build:
+
+    make -C the-cooper-mapper_amd/csrc EXTRA=-DLSLAM_TRAVERSAL_STATS OBJDIR=../../build/obj_trav OUT=../../build/liblslam_trav.so
+    LSLAM_LIB=build/liblslam_trav.so python tools/traversal_stats.py
+
+Prints, for the first (unbounded) sweep of a call and for a later (bounded) one: node / leaf / pop counts per
+lane, the same as the maximum over the 64 lanes of a wavefront (what the wavefront pays, lanes run in
+lock step), and the lane utilisation  sum(lane work) / (64 x max lane work)  a scheme that refills finished
+lanes with new queries could recover."""
 import ctypes as C, importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 pkg = importlib.import_module("the-cooper-mapper_amd")
 synth = importlib.import_module("the-cooper-mapper_amd.synth")
-pr = synth.make_problem(rings=64, azimuth_steps=1800)
+import synth_gpu
+
+frames = int(os.environ.get("MAP_FRAMES", "10000"))
+world_model = synth.World(half_extent=300.0, wall_half=295.0, pole_pitch=2.5)
+lidar = synth_gpu.GpuLidar(world_model, 0)
+traj = synth_gpu.loop_trajectory(frames)
 ctx = pkg.Context(0)
-ctx.map_set(pr["map_corner"], pr["map_surf"])
-ctx.scan_set(pr["corner"], pr["surf"])
+fm, mapstats = synth_gpu.build_voxel_map(pkg, ctx, lidar, traj, rings=16, progress=None)
+fm.update(traj[-1][3:].astype(np.float32))
+fm.surround_to_map()
+info = ctx.map_info()
+print("map: %d corner + %d surf, depth %d" % (info.n_corner, info.n_surf, max(info.depth_corner, info.depth_surf)))
+g = traj[-1].copy()
+qc, qs = lidar.scan(g, 64, 1800, seed=900000)
+ctx.scan_set(qc, qs)
 lib = ctx.lib
 lib.lslam_debug_sweep_clocks.restype = C.c_int
 lib.lslam_debug_sweep_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_uint64), C.c_size_t]
-pose = np.array(pr["init_pose"], np.float32)
-nb = (len(pr["corner"]) + 255) // 256 + (len(pr["surf"]) + 255) // 256
+init = synth.perturb_pose(g, seed=99).astype(np.float32)
+nb = (len(qc) + 255) // 256 + (len(qs) + 255) // 256
 nw = nb * 4
 cap = nw + nb * 256 * 2 + 16
-buf = np.zeros(cap * 4, np.uint64)
-for rep in range(2):
+names = ["t_desc", "t_leaf", "t_pop", "n_node", "n_leaf", "n_pop", "n_take", "n_popit", "t_take"]
+
+
+def run(pose, label):
+    buf = np.zeros(cap * 4, np.uint64)
     n = lib.lslam_debug_sweep_clocks(ctx.h, pose.ctypes.data_as(C.POINTER(C.c_float)), 0,
                                      buf.ctypes.data_as(C.POINTER(C.c_uint64)), cap)
-assert n == nw, n
-raw = buf[nw * 4: nw * 4 + nb * 256 * 8].reshape(nb * 256, 8)
-valid = (raw[:, 7] >> np.uint64(63)) == 1
-st = np.zeros((nb * 256, 9), np.int64)
-st[:, :6] = raw[:, :6].astype(np.int64)
-st[:, 6] = (raw[:, 6] & np.uint64(0xFFFFFFFF)).astype(np.int64)
-st[:, 7] = (raw[:, 6] >> np.uint64(32)).astype(np.int64)
-st[:, 8] = (raw[:, 7] & np.uint64((1 << 63) - 1)).astype(np.int64)
-print("lanes", valid.sum())
-names = ["t_desc", "t_leaf", "t_pop", "n_node", "n_leaf", "n_pop", "n_take", "n_popit", "t_take"]
-for i, nme in enumerate(names):
-    v = st[valid, i]
-    print("%-7s per-lane mean %9.1f p50 %8.0f p90 %8.0f max %8.0f" % (nme, v.mean(), np.percentile(v, 50), np.percentile(v, 90), v.max()))
-# per-wave: lanes in a wave run in lockstep, so the wave pays roughly the max over lanes
-w = st.reshape(nb * 4, 64, 9)
-wm = w.max(axis=1)
-print("per-wave max over lanes:")
-for i, nme in enumerate(names):
-    v = wm[:, i]
-    print("%-7s wave mean %9.1f p50 %8.0f p90 %8.0f max %8.0f" % (nme, v.mean(), np.percentile(v, 50), np.percentile(v, 90), v.max()))
-tot = wm[:, 0] + wm[:, 1] + wm[:, 2] + wm[:, 8]
-print("cycles per node step (wave): %.0f ; per leaf: %.0f ; per pop: %.0f" % (
-    wm[:, 0].sum() / max(1, wm[:, 3].sum()), wm[:, 1].sum() / max(1, wm[:, 4].sum()), wm[:, 2].sum() / max(1, wm[:, 5].sum())))
-for g in np.array_split(np.arange(nb * 4), 12):
-    print("waves %5d-%5d  n_node %6.1f n_leaf %5.1f n_pop %6.1f | lane-mean n_node %6.1f n_leaf %5.1f | t %8.0f" % (
-        g[0], g[-1], wm[g, 3].mean(), wm[g, 4].mean(), wm[g, 5].mean(),
-        w[g][:, :, 3].mean(), w[g][:, :, 4].mean(), tot[g].mean()))
+    assert n == nw, n
+    raw = buf[nw * 4: nw * 4 + nb * 256 * 8].reshape(nb * 256, 8)
+    valid = (raw[:, 7] >> np.uint64(63)) == 1
+    st = np.zeros((nb * 256, 9), np.int64)
+    st[:, :6] = raw[:, :6].astype(np.int64)
+    st[:, 6] = (raw[:, 6] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    st[:, 7] = (raw[:, 6] >> np.uint64(32)).astype(np.int64)
+    st[:, 8] = (raw[:, 7] & np.uint64((1 << 63) - 1)).astype(np.int64)
+    print("== %s: %d lanes" % (label, valid.sum()))
+    w = st.reshape(nb * 4, 64, 9)
+    wm = w.max(axis=1)
+    for i in (3, 4, 5, 6, 7):
+        v = st[valid, i]
+        util = w[:, :, i].sum() / max(1, 64 * wm[:, i].sum())
+        print("%-7s lane mean %7.1f p50 %5.0f p90 %5.0f p99 %5.0f max %5.0f | wave-max mean %7.1f | lane utilisation %.2f" % (
+            names[i], v.mean(), np.percentile(v, 50), np.percentile(v, 90), np.percentile(v, 99), v.max(), wm[:, i].mean(), util))
+    cyc = st[:, 0] + st[:, 1] + st[:, 2] + st[:, 8]
+    cw = cyc.reshape(nb * 4, 64)
+    print("search cycles: lane mean %.0f, wave-max mean %.0f; per node step %.0f, per leaf %.0f, per pop round %.0f" % (
+        cyc[valid].mean(), cw.max(axis=1).mean(), wm[:, 0].sum() / max(1, wm[:, 3].sum()),
+        wm[:, 1].sum() / max(1, wm[:, 4].sum()), wm[:, 2].sum() / max(1, wm[:, 7].sum())))
+    # what a wavefront pays today is ~ sum over its outer rounds of the longest descent + a leaf + the longest pop;
+    # with refilled lanes the bound is the lane-sum / 64
+    for i, cost in ((3, "node"), (4, "leaf")):
+        print("  %s steps: paid by the wavefronts %d, lane-sum/64 %d" % (cost, wm[:, i].sum(), w[:, :, i].sum() // 64))
+
+
+run(init, "first sweep of a call (unbounded)")
+run(init, "second sweep, same pose (bounded by the previous neighbours)")
+run(g.astype(np.float32), "sweep at the converged pose (bounded by neighbours found 1 step away)")

@@ -255,6 +255,14 @@ int lslam_knn5_ex(lslam_ctx *ctx, int which_map, const void *queries, size_t nq,
 int lslam_sweep_ex(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_t search_mode, int32_t *idx_out,
                    float *d2_out, float *coeff_out, uint8_t *flags_out, float *sums_out);
 
+/* The names SURVEY.md 8(b) gave these entry points before they were built, kept as exported aliases:
+ *   lslam_residuals        = lslam_sweep with the MFMA contraction: coeff_out[N*4], valid_out[N] (the flag bits of
+ *                            lslam_sweep), JtJ27_out[27] = the 21 upper-triangular A^T A sums then the 6 A^T b sums
+ *   lslam_scanmatch_batch  = lslam_scanmatch_run_batch
+ *   lslam_posegraph_optimize (further down) = lslam_pg_create + lslam_pg_optimize + lslam_pg_get_poses + destroy */
+int lslam_residuals(lslam_ctx *ctx, const float pose[6], float *coeff_out, uint8_t *valid_out, float *JtJ27_out);
+int lslam_scanmatch_batch(lslam_ctx *ctx, int32_t n_problems, float *poses, const lslam_opts *opts, lslam_stats *stats);
+
 /* One solve/update step (ScanMatch.cpp:206-260) run by the device solve kernel
  * on caller-provided normal equations.  matP/degenerate are in/out state. */
 int lslam_gn_step(lslam_ctx *ctx, const float AtA[36], const float Atb[6], int32_t iter,
@@ -501,6 +509,10 @@ int32_t lslam_pg_num_offdiag(const lslam_pg *pg);
 /* SolverG2O::optimize (solver_g2o.cpp:79-95): up to max_iters LM iterations. */
 int lslam_pg_optimize(lslam_pg *pg, int32_t max_iters, lslam_pg_stats *stats);
 int lslam_pg_get_poses(lslam_pg *pg, double *poses7);
+/* One-call form: poses7 is in/out; single GPU. */
+int lslam_posegraph_optimize(int device, int32_t n_vertices, double *poses7, int32_t n_edges, const int32_t *ij,
+                             const double *meas7, const double *info36, int32_t fixed_vertex, int32_t max_iters,
+                             lslam_pg_stats *stats);
 /* SolverG2O::save (solver_g2o.cpp:97-100): the graph with its current estimates in g2o's text
  * format (VERTEX_SE3:QUAT / FIX / EDGE_SE3:QUAT with the 21 upper-triangular information
  * entries) -- the route to cross-check this solver against an external g2o. */

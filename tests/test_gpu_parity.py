@@ -820,3 +820,45 @@ def test_tree_deeper_than_traversal_stack_is_refused(pkg, n_chain):
         assert ei.value.code == pkg.Status.ERR_TREE_DEPTH
     finally:
         c.close()
+
+
+def test_survey_8b_alias_exports(ctx, pkg, synth, small_problem):
+    """SURVEY 8(b)'s names for three entry points are exported aliases of the ones the tests above drive."""
+    import ctypes as C
+    from importlib import import_module
+    capi = import_module("the-cooper-mapper_amd.capi")
+    pr = small_problem
+    ctx.map_set(pr["map_corner"], pr["map_surf"])
+    ctx.scan_set(pr["corner"], pr["surf"])
+    ref = ctx.sweep(pr["init_pose"], jtj_mode=1)
+    n = ctx.n_scan
+    coeff, valid, jtj = np.zeros((n, 4), np.float32), np.zeros(n, np.uint8), np.zeros(27, np.float32)
+    p = np.array(pr["init_pose"], np.float32)
+    rc = ctx.lib.lslam_residuals(ctx.h, p.ctypes.data_as(capi.c_float_p), coeff.ctypes.data_as(capi.c_float_p),
+                                 valid.ctypes.data_as(capi.c_uint8_p), jtj.ctypes.data_as(capi.c_float_p))
+    assert rc == 0
+    assert np.array_equal(bits(coeff), bits(ref["coeff"])) and np.array_equal(valid, ref["flags"])
+    assert np.array_equal(bits(jtj), bits(ref["sums"][:27]))
+    # batch alias
+    ctx.scan_set_batch([(pr["corner"], pr["surf"])] * 2)
+    _, want, _ = ctx.run_batch(np.stack([p, p]))
+    got = np.stack([p, p]).copy()
+    st = (capi.LslamStats * 2)()
+    assert ctx.lib.lslam_scanmatch_batch(ctx.h, 2, got.ctypes.data_as(capi.c_float_p), None, st) >= 0
+    assert np.array_equal(bits(got), bits(want))
+    # one-call pose graph
+    g = synth.make_pose_graph(n_kf=120, n_loop=240, laps=2, radius=15.0)
+    pg = pkg.PoseGraph(0)
+    pg.set_graph(g["init"], g["ij"], g["meas"], g["info"])
+    pg.optimize(5)
+    want = pg.poses()
+    poses = np.ascontiguousarray(g["init"], np.float64).copy()
+    ij = np.ascontiguousarray(g["ij"], np.int32)
+    meas = np.ascontiguousarray(g["meas"], np.float64)
+    info = np.ascontiguousarray(g["info"], np.float64)
+    pst = capi.LslamPgStats()
+    dp = lambda a: a.ctypes.data_as(capi.c_double_p)
+    rc = ctx.lib.lslam_posegraph_optimize(0, len(poses), dp(poses), len(ij), ij.ctypes.data_as(capi.c_int32_p), dp(meas),
+                                          dp(info), 0, 5, C.byref(pst))
+    assert rc >= 0 and pst.iterations == pg.last_stats.iterations
+    assert np.array_equal(poses, want)

@@ -159,6 +159,10 @@ SYMBOLS = {
                                 c_int32_p]),
     "lslam_sweep_ex": (C.c_int, [C.c_void_p, c_float_p, C.c_int32, C.c_int32, c_int32_p, c_float_p, c_float_p,
                                  c_uint8_p, c_float_p]),
+    "lslam_residuals": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_uint8_p, c_float_p]),
+    "lslam_scanmatch_batch": (C.c_int, [C.c_void_p, C.c_int32, c_float_p, C.POINTER(LslamOpts), C.POINTER(LslamStats)]),
+    "lslam_posegraph_optimize": (C.c_int, [C.c_int, C.c_int32, c_double_p, C.c_int32, c_int32_p, c_double_p, c_double_p,
+                                           C.c_int32, C.c_int32, C.POINTER(LslamPgStats)]),
     "lslam_gn_step": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_int32, c_float_p, c_float_p,
                                 c_int32_p, C.c_float, C.c_float, c_float_p, c_float_p, c_float_p,
                                 c_int32_p]),

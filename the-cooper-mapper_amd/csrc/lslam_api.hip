@@ -1708,6 +1708,17 @@ int lslam_sweep(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_t *
   return lslam_sweep_ex(ctx, pose, jtj_mode, LSLAM_SEARCH_LANE, idx_out, d2_out, coeff_out, flags_out, sums_out);
 }
 
+int lslam_residuals(lslam_ctx *ctx, const float pose[6], float *coeff_out, uint8_t *valid_out, float *JtJ27_out) {
+  float sums[32];
+  const int rc = lslam_sweep_ex(ctx, pose, 1, LSLAM_SEARCH_LANE, nullptr, nullptr, coeff_out, valid_out, JtJ27_out ? sums : nullptr);
+  if (rc == LSLAM_OK && JtJ27_out) std::memcpy(JtJ27_out, sums, 27 * sizeof(float));
+  return rc;
+}
+
+int lslam_scanmatch_batch(lslam_ctx *ctx, int32_t n_problems, float *poses, const lslam_opts *opts, lslam_stats *stats) {
+  return lslam_scanmatch_run_batch(ctx, n_problems, poses, opts, stats);
+}
+
 int lslam_sweep_ex(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_t search_mode, int32_t *idx_out,
                    float *d2_out, float *coeff_out, uint8_t *flags_out, float *sums_out) {
   int rc = check_ctx(ctx);

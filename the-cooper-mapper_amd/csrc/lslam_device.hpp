@@ -157,7 +157,7 @@ struct KdStack {
 };
 
 #ifdef LSLAM_TRAVERSAL_STATS  // profiling build only (tools/traversal_stats.py)
-struct TravStats { unsigned long long t_desc, t_leaf, t_pop, t_take; unsigned n_node, n_leaf, n_pop, n_take, n_popit; };
+struct TravStats { unsigned long long t_desc, t_leaf, t_pop, t_take; unsigned n_node, n_leaf, n_pop, n_take, n_popit, n_hit, n_cand; };
 #define TS_BEGIN unsigned long long _ts = __builtin_readcyclecounter();
 #define TS_ADD(f) { unsigned long long _n = __builtin_readcyclecounter(); ts.f += _n - _ts; _ts = _n; }
 #define TS_INC(f) ts.f++;
@@ -254,12 +254,22 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
       // candidate nanoflann's test `dist < worst_dist` (:1448) turns away, is offered as FLT_MAX and changes nothing.
       // No divergent branch per candidate: the 64 lanes of a wavefront sit in 64 different leaves, so "any lane
       // inserts" was true for almost every candidate and ran the insert with a handful of lanes active.
+#ifdef LSLAM_TRAVERSAL_STATS
+      bool hit = false;
+#endif
 #pragma unroll
       for (int j = 0; j < 10; ++j) {
         const float dist = dist2_xyz(qx, qy, qz, pt[j]);
         const float x = (j < cnt && dist < worst) ? dist : FLT_MAX;
+#ifdef LSLAM_TRAVERSAL_STATS
+        hit = hit || x < d[4];
+        ts.n_cand += x < d[4] ? 1 : 0;
+#endif
         knn_insert_sorted(d, p, x, l + j);
       }
+#ifdef LSLAM_TRAVERSAL_STATS
+      ts.n_hit += hit ? 1 : 0;
+#endif
 #endif
     }
     TS_ADD(t_leaf)
@@ -325,7 +335,7 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
 template <int BLOCK, bool OVF, int LDS_DEPTH>
 LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, float (&d)[5], int (&p)[5],
                            KdStack<BLOCK, OVF, LDS_DEPTH> &stk, const float bound = FLT_MAX) {
-  TravStats ts = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  TravStats ts = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   knn5_search<BLOCK, OVF, LDS_DEPTH>(T, qx, qy, qz, d, p, stk, ts, bound);
 }
 #endif

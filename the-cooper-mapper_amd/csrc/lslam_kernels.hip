@@ -200,7 +200,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
       }
     }
 #ifdef LSLAM_TRAVERSAL_STATS
-    TravStats ts = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    TravStats ts = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     knn5_search<BLOCK, OVF, LDS_DEPTH>(T, sel[0], sel[1], sel[2], d, p, stk, ts, bound);
     if (a.bounded) {
 #pragma unroll
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
     if (a.dbg) {  // per-lane stats: [N][8] after the per-wave stamps
       uint64_t *o = a.dbg + (size_t)a.nb_total * NWAVE * 4 + ((size_t)lb * BLOCK + tid) * 8;
       o[0] = ts.t_desc; o[1] = ts.t_leaf; o[2] = ts.t_pop; o[3] = ts.n_node;
-      o[4] = ts.n_leaf; o[5] = ts.n_pop; o[6] = ((uint64_t)ts.n_popit << 32) | ts.n_take; o[7] = ts.t_take | (1ull << 63);
+      o[4] = ts.n_leaf | ((uint64_t)ts.n_hit << 32); o[5] = ts.n_pop | ((uint64_t)ts.n_cand << 32); o[6] = ((uint64_t)ts.n_popit << 32) | ts.n_take; o[7] = ts.t_take | (1ull << 63);
     }
 #else
     knn5_search<BLOCK, OVF, LDS_DEPTH>(T, sel[0], sel[1], sel[2], d, p, stk, bound);
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(256, 2) void odom_sweep_kernel(OdomArgs a) {
       stk.ovf = nullptr;
       stk.ovf_stride = 0;
 #ifdef LSLAM_TRAVERSAL_STATS
-      TravStats ts_unused = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      TravStats ts_unused = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
       knn5_search<BLOCK, false, KD_STACK_LDS>(T, sel[0], sel[1], sel[2], d, p, stk, ts_unused);
 #else
       knn5_search<BLOCK, false, KD_STACK_LDS>(T, sel[0], sel[1], sel[2], d, p, stk);  // top-1 of the 5 == nearestKSearch(.,1)
@@ -1147,7 +1147,7 @@ __global__ __launch_bounds__(128, 2) void knn5_kernel(TreeView T, const float4 *
   stk.ovf = OVF ? stack_ovf + ((size_t)blockIdx.x * 128 + threadIdx.x) : nullptr;
   stk.ovf_stride = (size_t)gridDim.x * 128;
 #ifdef LSLAM_TRAVERSAL_STATS
-  TravStats ts = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  TravStats ts = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   knn5_search<128, OVF, KD_STACK_LDS>(T, qq.x, qq.y, qq.z, d, p, stk, ts);
 #else
   knn5_search<128, OVF, KD_STACK_LDS>(T, qq.x, qq.y, qq.z, d, p, stk);

@@ -1417,4 +1417,19 @@ int lslam_pg_optimize(lslam_pg *pg, int32_t max_iters, lslam_pg_stats *st_out) {
   return LSLAM_OK;
 }
 
+int lslam_posegraph_optimize(int device, int32_t n_vertices, double *poses7, int32_t n_edges, const int32_t *ij,
+                             const double *meas7, const double *info36, int32_t fixed_vertex, int32_t max_iters,
+                             lslam_pg_stats *stats) {
+  lslam_pg *pg = nullptr;
+  int rc = lslam_pg_create(device, n_vertices, poses7, n_edges, ij, meas7, info36, fixed_vertex, &pg);
+  if (rc < 0) return rc;
+  rc = lslam_pg_optimize(pg, max_iters, stats);
+  if (rc >= 0) {
+    const int rc2 = lslam_pg_get_poses(pg, poses7);
+    if (rc2 < 0) rc = rc2;
+  }
+  lslam_pg_destroy(pg);
+  return rc;
+}
+
 }  // extern "C"

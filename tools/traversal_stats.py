@@ -37,7 +37,7 @@ init = synth.perturb_pose(g, seed=99).astype(np.float32)
 nb = (len(qc) + 255) // 256 + (len(qs) + 255) // 256
 nw = nb * 4
 cap = nw + nb * 256 * 2 + 16
-names = ["t_desc", "t_leaf", "t_pop", "n_node", "n_leaf", "n_pop", "n_take", "n_popit", "t_take"]
+names = ["t_desc", "t_leaf", "t_pop", "n_node", "n_leaf", "n_pop", "n_take", "n_popit", "t_take", "n_hit", "n_cand"]
 
 
 def run(pose, label):
@@ -47,20 +47,27 @@ def run(pose, label):
     assert n == nw, n
     raw = buf[nw * 4: nw * 4 + nb * 256 * 8].reshape(nb * 256, 8)
     valid = (raw[:, 7] >> np.uint64(63)) == 1
-    st = np.zeros((nb * 256, 9), np.int64)
+    st = np.zeros((nb * 256, 11), np.int64)
     st[:, :6] = raw[:, :6].astype(np.int64)
+    st[:, 4] = (raw[:, 4] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    st[:, 5] = (raw[:, 5] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    st[:, 9] = (raw[:, 4] >> np.uint64(32)).astype(np.int64)   # leaves with at least one accepted candidate
+    st[:, 10] = (raw[:, 5] >> np.uint64(32)).astype(np.int64)  # accepted candidates
     st[:, 6] = (raw[:, 6] & np.uint64(0xFFFFFFFF)).astype(np.int64)
     st[:, 7] = (raw[:, 6] >> np.uint64(32)).astype(np.int64)
     st[:, 8] = (raw[:, 7] & np.uint64((1 << 63) - 1)).astype(np.int64)
     print("== %s: %d lanes" % (label, valid.sum()))
-    w = st.reshape(nb * 4, 64, 9)
+    w = st.reshape(nb * 4, 64, 11)
     wm = w.max(axis=1)
-    for i in (3, 4, 5, 6, 7):
+    for i in (3, 4, 9, 10, 5, 6, 7):
         v = st[valid, i]
         util = w[:, :, i].sum() / max(1, 64 * wm[:, i].sum())
         print("%-7s lane mean %7.1f p50 %5.0f p90 %5.0f p99 %5.0f max %5.0f | wave-max mean %7.1f | lane utilisation %.2f" % (
             names[i], v.mean(), np.percentile(v, 50), np.percentile(v, 90), np.percentile(v, 99), v.max(), wm[:, i].mean(), util))
     cyc = st[:, 0] + st[:, 1] + st[:, 2] + st[:, 8]
+    tot = float(cyc[valid].sum())
+    print("share of the search's cycles: descent %.2f, leaves %.2f, pops %.2f, takes %.2f" % tuple(
+        st[valid, i].sum() / tot for i in (0, 1, 2, 8)))
     cw = cyc.reshape(nb * 4, 64)
     print("search cycles: lane mean %.0f, wave-max mean %.0f; per node step %.0f, per leaf %.0f, per pop round %.0f" % (
         cyc[valid].mean(), cw.max(axis=1).mean(), wm[:, 0].sum() / max(1, wm[:, 3].sum()),

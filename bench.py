@@ -302,6 +302,7 @@ def main():
             out["mapping_frame"] = mapping_frame_leg(pkg, synth, ctx, surround, lidar, end_pose, opts, np, not args.no_cpu_baseline, 64)
             # BASELINE configs[1]: the same frame with a VLP-16 (16 x 1800) sweep
             out["mapping_frame_vlp16"] = mapping_frame_leg(pkg, synth, ctx, surround, lidar, end_pose, opts, np, not args.no_cpu_baseline, 16)
+            out["mapping_frame_cubes"] = mapping_frame_leg(pkg, synth, ctx, surround, lidar, end_pose, opts, np, False, 64, cubes=True)
         except Exception as e:  # a secondary leg never takes the headline line down
             out["mapping_frame"] = {"error": repr(e)}
     fm.close()
@@ -649,7 +650,7 @@ def single_scan_leg(ctx, scan, init, opts, steps):
             "roofline_frac": ALG_BYTES_PER_POINT_RESIDUAL * pt / (sw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sw_ms > 0 else None}
 
 
-def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, rings=64):
+def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, rings=64, cubes=False):
     """One LaserMapping frame end to end on the device (SURVEY 8f n1/n2 around the hot path), per step:
     extractFeatures on the full-resolution sweep, VoxelGrid of the features (LaserMatcher.cpp:289-301, leaf
     1.0 = the reference default), FeatureMap::update, surround -> kd-trees, scanMatchScan,
@@ -667,8 +668,12 @@ def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, 
     T[:3, :3], T[:3, 3] = R, t
     init = synth.perturb_pose(gt, seed=77, dt=0.1, dr_deg=0.5)
     gt32 = gt.astype(np.float32)
-    steps = ("extract_features", "voxel_grid", "update", "surround_to_map", "scan_match", "add_feature_cloud")
+    # cubes: variant C (FeatureMap::scanMatchScan, util/FeatureMap.h:490-691) -- one kd-tree per cube of the active
+    # area, kept between frames; only the cubes the previous frame's addFeatureCloud touched are rebuilt
+    steps = ("extract_features", "voxel_grid", "update", "to_cubemap_incremental" if cubes else "surround_to_map",
+             "scan_match", "add_feature_cloud")
     acc = {k: [] for k in steps}
+    trees = []
     frames = 6
     quiet_gc()
     for f in range(frames + 1):  # first frame = warm-up
@@ -679,7 +684,12 @@ def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, 
         t2 = time.perf_counter()
         fm.update(gt[3:].astype(np.float32))
         t3 = time.perf_counter()
-        fm.surround_to_map()
+        if cubes:
+            fm.to_cubemap()
+            if f > 0:
+                trees.append(fm.cubemap_stats())
+        else:
+            fm.surround_to_map()
         t4 = time.perf_counter()
         status, pose, st = ctx.scanmatch_scan(dc, ds, init, opts)
         t5 = time.perf_counter()
@@ -701,6 +711,11 @@ def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, 
            "scan_points_after_voxel_grid": int(len(dc) + len(ds)), "map_points": fm.info()["n_corner"] + fm.info()["n_surf"],
            "scan_match_iterations": int(st.iterations),
            "pose_err_vs_ground_truth_m": float(np.abs(pose[3:] - gt[3:].astype(np.float32)).max())}
+    if cubes:
+        res["cube_trees_built_reused_per_frame"] = [[int(b), int(r)] for b, r in trees]
+        res["variant"] = "C: per-cube trees kept between frames (FeatureMap::scanMatchScan)"
+        fm.close()
+        return res
     if with_cpu:
         from oracle_lib import Oracle
         o = Oracle(native=True)

@@ -187,6 +187,9 @@ struct TravStats { unsigned long long t_desc, t_leaf, t_pop, t_take; unsigned n_
 // squared distance known in advance: subtrees and points beyond it cannot be among the five
 // nearest, so they are skipped; what is visited is visited in the same order, hence the same
 // result (callers pad the bound by a few ulps' worth to cover the rounding of mindistsq).
+#ifndef LSLAM_POPW_SHALLOW
+#define LSLAM_POPW_SHALLOW 2
+#endif
 template <int BLOCK, bool OVF, int LDS_DEPTH>
 LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, float (&d)[5],
                            int (&p)[5], KdStack<BLOCK, OVF, LDS_DEPTH> &stk,
@@ -194,6 +197,9 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
                            TravStats &ts,
 #endif
                            const float bound = FLT_MAX) {
+  // stack entries examined per pop round: four in flight where a wavefront's latency is what counts (single scans,
+  // whole stack in LDS), fewer where instruction issue is (the shallow-stack batch variant)
+  constexpr int POPW = (LDS_DEPTH <= 16 && LDS_DEPTH > 0) ? LSLAM_POPW_SHALLOW : 4;
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     d[i] = FLT_MAX;
@@ -231,6 +237,19 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
         ++sp;
       }
       ref = left ? nd.c1 : nd.c2;
+#ifdef LSLAM_NODE_TWICE  // profiling only: the node-step arithmetic once more with no effect
+      {
+        float off = 0.0f;
+        asm volatile("" : "+v"(off));
+        const float v2 = (feat == 0 ? qx : (feat == 1 ? qy : qz)) + off;
+        const float e1 = v2 - nd.lo, e2 = v2 - nd.hi;
+        const bool l2 = (e1 + e2) < 0.0f;
+        const float c2 = l2 ? e2 * e2 : e1 * e1;
+        const float n2 = (mind + c2) - (feat == 0 ? ds0 : (feat == 1 ? ds1 : ds2));
+        const uint32_t r2 = l2 ? nd.c1 : nd.c2;
+        if (n2 < off - 1.0f) ref = r2 ^ (node | (feat << 29));  // never
+      }
+#endif
     }
     TS_ADD(t_desc)
     {  // leaf: nanoflann.hpp:1438-1457
@@ -270,6 +289,18 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
 #ifdef LSLAM_TRAVERSAL_STATS
       ts.n_hit += hit ? 1 : 0;
 #endif
+#ifdef LSLAM_LEAF_TWICE  // profiling only: the leaf arithmetic once more with no effect -> its share of the kernel time
+      {
+        float thr = -1.0f, qz2 = qz;
+        asm volatile("" : "+v"(thr), "+v"(qz2));
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+          const float dist = dist2_xyz(qx, qy, qz2, pt[j]);
+          const float x = (j < cnt && dist < thr) ? dist : FLT_MAX;
+          knn_insert_sorted(d, p, x, l + j);
+        }
+      }
+#endif
 #endif
     }
     TS_ADD(t_leaf)
@@ -278,17 +309,17 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
     float tm = 0.0f;
     while (sp > 0 && !take) {
       TS_INC(n_popit)
-      uint32_t e[4];
-      float m[4];
+      uint32_t e[POPW];
+      float m[POPW];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < POPW; ++j) {
         const int idx = sp - 1 - j < 0 ? 0 : sp - 1 - j;
         uint32_t w1;
         stk.get(idx, e[j], w1);
         m[j] = __uint_as_float(w1);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {  // predicated: no divergent branches in the pop loop
+      for (int j = 0; j < POPW; ++j) {  // predicated: no divergent branches in the pop loop
         const bool valid = !take && sp > 0;
         const uint32_t feat = (e[j] >> 29) & 3u;
         const bool act = (e[j] & 0x80000000u) != 0;  // far subtree finished (:1494)

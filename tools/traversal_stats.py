@@ -45,6 +45,12 @@ def run(pose, label):
     n = lib.lslam_debug_sweep_clocks(ctx.h, pose.ctypes.data_as(C.POINTER(C.c_float)), 0,
                                      buf.ctypes.data_as(C.POINTER(C.c_uint64)), cap)
     assert n == nw, n
+    print("== %s" % label)
+    stamps = buf[:nw * 4].reshape(nw, 4).astype(np.int64)
+    ok = (stamps[:, 3] > stamps[:, 0]) & (stamps[:, 1] > 0) & (stamps[:, 2] > 0)
+    ph = np.stack([stamps[ok, 1] - stamps[ok, 0], stamps[ok, 2] - stamps[ok, 1], stamps[ok, 3] - stamps[ok, 2]], 1)
+    print("per-wavefront shader-clock stamps: search %.0f, fit + Jacobian %.0f, contraction + block sums %.0f cycles "
+          "(shares %.2f / %.2f / %.2f)" % (*ph.mean(0), *(ph.sum(0) / ph.sum())))
     raw = buf[nw * 4: nw * 4 + nb * 256 * 8].reshape(nb * 256, 8)
     valid = (raw[:, 7] >> np.uint64(63)) == 1
     st = np.zeros((nb * 256, 11), np.int64)
@@ -56,7 +62,6 @@ def run(pose, label):
     st[:, 6] = (raw[:, 6] & np.uint64(0xFFFFFFFF)).astype(np.int64)
     st[:, 7] = (raw[:, 6] >> np.uint64(32)).astype(np.int64)
     st[:, 8] = (raw[:, 7] & np.uint64((1 << 63) - 1)).astype(np.int64)
-    print("== %s: %d lanes" % (label, valid.sum()))
     w = st.reshape(nb * 4, 64, 11)
     wm = w.max(axis=1)
     for i in (3, 4, 9, 10, 5, 6, 7):

@@ -81,6 +81,7 @@ def parse_args():
     ap.add_argument("--headline-only", action="store_true", help="only the timed region (profiling passes)")
     ap.add_argument("--shard-points", action="store_true",
                     help="run the sharded-points leg even on one GPU (RCCL all-reduce over a world of 1)")
+    ap.add_argument("--leg-timeout", type=int, default=1500, help="seconds the legs after the headline may take in all")
     ap.add_argument("--pg-iters", type=int, default=1000, help="LM iteration limit of the pose-graph leg")
     ap.add_argument("--cpu-scans", type=int, default=8, help="scans the single-core CPU baseline matches")
     return ap.parse_args()
@@ -292,6 +293,20 @@ def main():
         }
         if not args.no_single:
             out["single_scan"] = single_scan_leg(ctx, scans[0], inits[0], opts, 200)
+    # From here on the legs are secondary (and, with N > 1, use the library's own RCCL communicator, which no
+    # builder-side run could exercise on more than one GPU): a leg that hangs must not cost the headline line.
+    # Every rank arms a watchdog; if it fires, rank 0 prints the line it has and all ranks leave.
+    import threading
+
+    def give_up():
+        if rank == 0 and out is not None:
+            out["aborted_secondary_legs"] = "watchdog: a leg after the headline did not finish within %d s" % args.leg_timeout
+            print(json.dumps(out), flush=True)
+        os._exit(0 if rank != 0 or out is not None else 3)
+
+    watchdog = threading.Timer(args.leg_timeout, give_up)
+    watchdog.daemon = True
+    watchdog.start()
     surround = None
     if rank == 0 and not (args.no_cpu_baseline and args.no_mapping_frame):
         surround = fm.get_surround_feature()  # the map the timed region matched against, on the host
@@ -314,7 +329,18 @@ def main():
             out["sweep_pipeline"] = {"error": repr(e)}
     comm = None
     if (world > 1 or args.shard_points) and not args.headline_only:
-        comm = make_comm(pkg, dist, torch, rank, local_rank, world)
+        try:
+            comm = make_comm(pkg, dist, torch, rank, local_rank, world)
+            ok = 1.0
+        except Exception as e:
+            comm, ok = None, 0.0
+            print("bench.py: rank %d could not create the RCCL communicator: %r" % (rank, e), file=sys.stderr)
+        (n_ok,), _ = distmod.aggregate(dist, [ok], 0.0)  # all ranks or none
+        if int(round(n_ok)) != world:
+            comm = None
+            if rank == 0:
+                out["sharded_points"] = {"error": "RCCL communicator not available on every rank (%d of %d)" % (int(round(n_ok)), world)}
+    if comm is not None:
         try:
             shres = sharded_points_leg(pkg, synth, distmod, dist, rank, world, ctx, comm, opts, np, args)
         except Exception as e:  # never let the secondary leg take the headline line down
@@ -337,6 +363,7 @@ def main():
             pgres = {"error": repr(e)}
         if rank == 0:
             out["pose_graph"] = pgres
+    watchdog.cancel()
     if rank == 0:
         print(json.dumps(out), flush=True)
 

@@ -34,6 +34,7 @@
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "lslam_internal.hpp"
@@ -384,6 +385,7 @@ struct lslam_fmap {
     lslam::TreeView view{};
   };
   std::vector<Generation *> gens[2];
+  std::vector<Generation *> spare;      // dead generations kept with their allocations: no hipMalloc / hipFree per frame
   std::vector<CubeTree> cube_tree[2];   // [ncube]
   std::vector<uint8_t> dirty[2];        // [ncube]
   Buf<uint8_t> d_touched;               // [ncube] set by the insert kernel
@@ -709,6 +711,8 @@ void lslam_fmap_destroy(lslam_fmap *fm) {
       if (g) { g->nodes.release(); g->pn.release(); g->pts.release(); delete g; }
     fm->gens[t].clear();
   }
+  for (lslam_fmap::Generation *g : fm->spare) { g->nodes.release(); g->pn.release(); g->pts.release(); delete g; }
+  fm->spare.clear();
   fm->d_touched.release();
   if (lslam::ctx_alive(fm->ctx)) lslam::cubemap_drop_views(fm->ctx);  // the context may still point at this map's trees
   fm->active.release(); fm->in_raw.release(); fm->in_tf.release(); fm->in_cube.release(); fm->d_T.release();
@@ -875,7 +879,7 @@ int lslam_fmap_surround_to_map(lslam_fmap *fm) {
 
 static void drop_cube_trees(lslam_fmap *fm, int t) {
   for (lslam_fmap::CubeTree &ct : fm->cube_tree[t]) {
-    if (ct.gen >= 0) fm->gens[t][(size_t)ct.gen]->live--;
+    if (ct.gen >= 0) fm->gens[0][(size_t)ct.gen]->live--;  // one generation list for both feature types
     ct.gen = -1;
   }
 }
@@ -901,92 +905,150 @@ int lslam_fmap_to_cubemap(lslam_fmap *fm) {
   size_t n_pts[2] = {0, 0};
   int depth[2] = {0, 0};
   fm->trees_built = fm->trees_reused = 0;
+  const bool timing = std::getenv("LSLAM_FMAP_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count();
+  };
+  const auto t0 = now();
+  // Corner and surf cubes that need a tree are built TOGETHER: one generation, one forest build (a forest build costs
+  // ~0.9 ms of dependent launches whatever its size, so two of them per frame were most of this call).  Generations
+  // live in gens[0]; CubeTree::gen indexes that list for both feature types.
+  std::vector<lslam_fmap::Generation *> &gens = fm->gens[0];
   for (int t = 0; t < 2; ++t) {
     rc = refresh_segments(fm, t);
     if (rc) return rc;
     fm->cube_tree[t].resize((size_t)fm->ncube);
     fm->dirty[t].resize((size_t)fm->ncube, 1);
-    // compaction: too many generations alive means many half-empty arrays -- drop every tree, the active area is
-    // rebuilt into one generation below
-    if (fm->gens[t].size() > 12) drop_cube_trees(fm, t);
-    std::vector<int32_t> build, src, dst, roots_lr;
-    size_t total = 0;
+  }
+  // compaction: too many generations alive means many half-empty arrays -- drop every tree, the active area is
+  // rebuilt into one generation below
+  if (gens.size() > 12) {
+    drop_cube_trees(fm, 0);
+    drop_cube_trees(fm, 1);
+  }
+  std::vector<int32_t> build[2], src[2], dst[2], roots_lr;
+  size_t total_t[2] = {0, 0};
+  for (int t = 0; t < 2; ++t) {
+    const size_t base = t == 0 ? 0 : total_t[0];
     for (int32_t c : fm->valid) {
       const int32_t b = fm->h_begin[t][c], e = fm->h_end[t][c];
       lslam_fmap::CubeTree &ct = fm->cube_tree[t][(size_t)c];
       const bool wants_tree = e - b >= 5;
       if (!wants_tree || fm->dirty[t][(size_t)c]) {
         if (ct.gen >= 0) {  // its tree is stale
-          fm->gens[t][(size_t)ct.gen]->live--;
+          gens[(size_t)ct.gen]->live--;
           ct.gen = -1;
         }
       }
       if (wants_tree && ct.gen < 0) {
-        build.push_back(c);
-        src.push_back(b);
-        dst.push_back((int32_t)total);
-        roots_lr.push_back((int32_t)total);
-        roots_lr.push_back((int32_t)(total + (size_t)(e - b)));
-        total += (size_t)(e - b);
+        build[t].push_back(c);
+        src[t].push_back(b);
+        dst[t].push_back((int32_t)total_t[t]);  // relative to this type's part of the generation
+        roots_lr.push_back((int32_t)(base + total_t[t]));
+        roots_lr.push_back((int32_t)(base + total_t[t] + (size_t)(e - b)));
+        total_t[t] += (size_t)(e - b);
       }
       fm->dirty[t][(size_t)c] = 0;
     }
-    if (!build.empty()) {
-      lslam_fmap::Generation *g = new lslam_fmap::Generation();
-      const int T = (int)build.size();
-      int gi = -1;
-      for (size_t k = 0; k < fm->gens[t].size(); ++k)
-        if (!fm->gens[t][k]) { gi = (int)k; break; }
-      if (gi < 0) { gi = (int)fm->gens[t].size(); fm->gens[t].push_back(nullptr); }
-      fm->gens[t][(size_t)gi] = g;
-      FM_TRY(g->pts.reserve(total + 16));
-      FM_TRY(fm->g_src.reserve(src.size()));
-      FM_TRY(fm->g_dst.reserve(dst.size()));
-      FM_TRY(hipMemcpyAsync(fm->g_src.p, src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-      FM_TRY(hipMemcpyAsync(fm->g_dst.p, dst.data(), dst.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-      hipLaunchKernelGGL(fm_gather_kernel, dim3(((int)total + 255) / 256), dim3(256), 0, s, fm->pts[t].p, fm->g_src.p,
-                         fm->g_dst.p, (int)src.size(), (int)total, 2, g->pts.p);
-      FM_TRY(hipStreamSynchronize(s));  // src/dst are locals
-      std::vector<lslam::TreeView> built((size_t)T);
-      int fallback = 0, max_depth = 0;
-      size_t n_leaves = 0;
-      for (int attempt = 0; attempt < 3; ++attempt) {
-        const size_t mult[3] = {2, 8, 24};
-        const size_t cap = ((mult[attempt] * total / 3 + 64 + 8 * (size_t)T) + 7) & ~(size_t)7;
-        FM_TRY(g->nodes.reserve(cap));
-        FM_TRY(g->pn.reserve(cap));
-        if (attempt > 0) {  // the failed attempt permuted the points: gather them again
-          hipLaunchKernelGGL(fm_gather_kernel, dim3(((int)total + 255) / 256), dim3(256), 0, s, fm->pts[t].p, fm->g_src.p,
-                             fm->g_dst.p, (int)src.size(), (int)total, 2, g->pts.p);
-        }
-        FM_TRY(lslam::build_kdforest_device(g->pts.p, (int32_t)total, roots_lr.data(), T, g->nodes.p, g->pn.p, (int32_t)cap, s,
-                                            built.data(), &max_depth, &n_leaves, &fallback));
-        if (fallback != 1) break;
+  }
+  const size_t total = total_t[0] + total_t[1];
+  const int T = (int)(build[0].size() + build[1].size());
+  const auto t1 = now();
+  if (T > 0) {
+    lslam_fmap::Generation *g = nullptr;
+    {  // a spare generation (the one with the largest point array: reserve() only ever grows it) or a new one
+      size_t best = 0;
+      for (size_t k = 0; k < fm->spare.size(); ++k)
+        if (fm->spare[k]->pts.cap >= fm->spare[best]->pts.cap) best = k;
+      if (!fm->spare.empty()) {
+        g = fm->spare[best];
+        fm->spare.erase(fm->spare.begin() + (long)best);
+      } else {
+        g = new lslam_fmap::Generation();
       }
-      if (fallback) {
-        lslam::set_error("device cube-tree build hit a structure limit");
-        return fallback == 1 || fallback == 2 ? LSLAM_ERR_TREE_BUILD : LSLAM_ERR_TREE_DEPTH;
-      }
-      g->depth = max_depth;
-      g->live = T;
-      for (int k = 0; k < T; ++k) {
-        lslam_fmap::CubeTree &ct = fm->cube_tree[t][(size_t)build[(size_t)k]];
-        ct.gen = gi;
-        ct.view = built[(size_t)k];
-      }
-      fm->trees_built += T;
     }
-    // generations none of whose trees is current any more
-    for (size_t k = 0; k < fm->gens[t].size(); ++k) {
-      lslam_fmap::Generation *g = fm->gens[t][k];
-      if (g && g->live <= 0) {
+    int gi = -1;
+    for (size_t k = 0; k < gens.size(); ++k)
+      if (!gens[k]) { gi = (int)k; break; }
+    if (gi < 0) { gi = (int)gens.size(); gens.push_back(nullptr); }
+    gens[(size_t)gi] = g;
+    FM_TRY(g->pts.reserve(total + 16));
+    const size_t n_seg = src[0].size() + src[1].size();
+    FM_TRY(fm->g_src.reserve(n_seg));
+    FM_TRY(fm->g_dst.reserve(n_seg));
+    auto gather = [&]() -> hipError_t {
+      size_t seg0 = 0, base = 0;
+      for (int t = 0; t < 2; ++t) {
+        if (!src[t].empty()) {
+          hipLaunchKernelGGL(fm_gather_kernel, dim3(((int)total_t[t] + 255) / 256), dim3(256), 0, s, fm->pts[t].p,
+                             fm->g_src.p + seg0, fm->g_dst.p + seg0, (int)src[t].size(), (int)total_t[t], 2, g->pts.p + base);
+        }
+        seg0 += src[t].size();
+        base += total_t[t];
+      }
+      return hipGetLastError();
+    };
+    {
+      size_t seg0 = 0;
+      for (int t = 0; t < 2; ++t) {
+        if (src[t].empty()) continue;
+        FM_TRY(hipMemcpyAsync(fm->g_src.p + seg0, src[t].data(), src[t].size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        FM_TRY(hipMemcpyAsync(fm->g_dst.p + seg0, dst[t].data(), dst[t].size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        seg0 += src[t].size();
+      }
+    }
+    FM_TRY(gather());
+    FM_TRY(hipStreamSynchronize(s));  // src/dst are locals
+    const auto t2 = now();
+    std::vector<lslam::TreeView> built((size_t)T);
+    int fallback = 0, max_depth = 0;
+    size_t n_leaves = 0;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+      const size_t mult[3] = {2, 8, 24};
+      const size_t cap = ((mult[attempt] * total / 3 + 64 + 8 * (size_t)T) + 7) & ~(size_t)7;
+      FM_TRY(g->nodes.reserve(cap));
+      FM_TRY(g->pn.reserve(cap));
+      if (attempt > 0) FM_TRY(gather());  // the failed attempt permuted the points: gather them again
+      FM_TRY(lslam::build_kdforest_device(g->pts.p, (int32_t)total, roots_lr.data(), T, g->nodes.p, g->pn.p, (int32_t)cap, s,
+                                          built.data(), &max_depth, &n_leaves, &fallback));
+      if (fallback != 1) break;
+    }
+    if (fallback) {
+      lslam::set_error("device cube-tree build hit a structure limit");
+      return fallback == 1 || fallback == 2 ? LSLAM_ERR_TREE_BUILD : LSLAM_ERR_TREE_DEPTH;
+    }
+    if (timing)
+      std::fprintf(stderr, "[to_cubemap] segments %.3f ms, gather of %zu + %zu points in %zu + %zu cubes %.3f ms, forest %.3f ms\n",
+                   ms(t0, t1), total_t[0], total_t[1], build[0].size(), build[1].size(), ms(t1, t2), ms(t2, now()));
+    g->depth = max_depth;
+    g->live = T;
+    int k = 0;
+    for (int t = 0; t < 2; ++t)
+      for (int32_t c : build[t]) {
+        lslam_fmap::CubeTree &ct = fm->cube_tree[t][(size_t)c];
+        ct.gen = gi;
+        ct.view = built[(size_t)k++];
+      }
+    fm->trees_built += T;
+  }
+  // generations none of whose trees is current any more: kept as spares with their allocations
+  for (size_t k = 0; k < gens.size(); ++k) {
+    lslam_fmap::Generation *g = gens[k];
+    if (g && g->live <= 0) {
+      g->live = g->depth = 0;
+      if (fm->spare.size() < 8) {
+        fm->spare.push_back(g);
+      } else {
         g->nodes.release(); g->pn.release(); g->pts.release();
         delete g;
-        fm->gens[t][k] = nullptr;
       }
+      gens[k] = nullptr;
     }
-    while (!fm->gens[t].empty() && !fm->gens[t].back()) fm->gens[t].pop_back();
-    // the table the sweep reads: cell -> tree view, active cubes only
+  }
+  while (!gens.empty() && !gens.back()) gens.pop_back();
+  // the tables the sweep reads: cell -> tree view, active cubes only
+  for (int t = 0; t < 2; ++t) {
     cells[t].assign((size_t)fm->ncube, -1);
     for (int32_t c : fm->valid) {
       const lslam_fmap::CubeTree &ct = fm->cube_tree[t][(size_t)c];
@@ -994,7 +1056,7 @@ int lslam_fmap_to_cubemap(lslam_fmap *fm) {
       cells[t][(size_t)c] = (int32_t)views[t].size();
       views[t].push_back(ct.view);
       n_pts[t] += (size_t)ct.view.n_pts;
-      depth[t] = std::max(depth[t], fm->gens[t][(size_t)ct.gen]->depth);
+      depth[t] = std::max(depth[t], gens[(size_t)ct.gen]->depth);
     }
     fm->trees_reused += (int64_t)views[t].size();
   }

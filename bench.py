@@ -459,7 +459,11 @@ def pmc_counters(avg_sweep_ms):
     if cand[top] < 0.6 and c.get("wait_frac", 0.0) > 0.4:
         bound = "latency of dependent gathers + %s (no bandwidth above 60 %% of its peak; waves wait %.0f %% of their life)" % (
             top, 100.0 * c.get("wait_frac", 0.0))
-    return {"bound": bound, "bound_frac": cand[top], "traffic": traffic, "counters": c}
+    return {"bound": bound, "bound_frac": cand[top], "traffic": traffic,
+            "traffic_source": "committed rocprofv3 --pmc passes of `bench.py --headline-only` (tools/collect_profiles.sh -> %s), "
+                              "per launch over the largest launches; not measured in this run" % PMC_PROFILE,
+            # the fraction of HBM peak the MEASURED traffic amounts to (the algorithmic-bytes fraction above is nominal)
+            "measured_hbm_gbs": c.get("hbm_gbs"), "measured_hbm_frac": c.get("hbm_frac"), "counters": c}
 
 
 def sharded_points_leg(pkg, synth, distmod, dist, rank, world, ctx, comm, opts, np, args):

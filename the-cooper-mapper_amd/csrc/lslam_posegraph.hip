@@ -410,6 +410,7 @@ struct CoarseArgs {
   double *rc, *yc;        // [n_c]
   double *Rbuf, *Cbuf, *Bbuf;  // block Gauss-Jordan scratch: [6][n_c], [n_c][6], [36]
   const int32_t *cb_ptr, *cb_ent, *cb_ab;  // coarse blocks: fine entries of each, its (row, column) aggregate
+  const int32_t *agg_of, *agg_ptr, *agg_mem;  // vertex -> aggregate; aggregate -> its members (at most 64), first = its origin
   int n_v, G, na, n_c, n_cb, n_cblk;
 };
 
@@ -576,9 +577,13 @@ __global__ __launch_bounds__(CG_BLOCK) void pg_cg_check_kernel(CgArgs a, int k) 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Second level of the preconditioner: rigid motions of runs of G consecutive keyframes.
-// A long trajectory bends almost for free -- moving a whole sub-chain rigidly only strains the edges at its two ends --
-// and those global modes are what block-Jacobi PCG needs thousands of iterations for once lambda is small.  The coarse
+// Second level of the preconditioner: rigid motions of AGGREGATES of up to G keyframes that are close in the graph.
+// A long trajectory bends almost for free -- moving a bundle of keyframes rigidly only strains the edges that leave
+// it -- and those global modes are what block-Jacobi PCG needs thousands of iterations for once lambda is small.
+// The aggregates are grown breadth-first over the graph's edges (odometry AND loop closures, lslam_pg_create), so a place
+// that was visited on several laps -- keyframes tied together by loop edges -- falls into one aggregate; runs of
+// consecutive keyframes instead (what this level used first) miss exactly those couplings and need six times the
+// iterations on the bench graph (1 079 against 175 at lambda -> 0, numpy prototype and device agree).  The coarse
 // unknown of aggregate a is a world-frame twist xi_a = (rho, phi) about the aggregate's first keyframe c_a; applied on
 // the left it is, to first order, the local increment (g2o's right-multiplied [dt, dq]) delta_i = P_i xi_a of every
 // keyframe i = (R_i, t_i) of the aggregate,  P_i = [ R_i^T   -R_i^T [t_i - c_a]x ;  0   R_i^T / 2 ].
@@ -590,7 +595,7 @@ __global__ void pgc_P_kernel(CoarseArgs c) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= c.n_v) return;
   const Pose x = load_pose(c.poses + 7 * i);
-  const Pose x0 = load_pose(c.poses + 7 * ((i / c.G) * c.G));
+  const Pose x0 = load_pose(c.poses + 7 * c.agg_mem[c.agg_ptr[c.agg_of[i]]]);
   double R[9];
   qrotmat(x.q, R);
   const double d[3] = {x.t.x - x0.t.x, x.t.y - x0.t.y, x.t.z - x0.t.z};
@@ -702,9 +707,10 @@ __global__ __launch_bounds__(256) void pgc_gj_update_kernel(CoarseArgs c, int k)
 // r_c = P^T r: one wavefront per aggregate
 __global__ __launch_bounds__(64) void pgc_restrict_kernel(CoarseArgs c, const double *r) {
   const int a = blockIdx.x, j = threadIdx.x;
-  const int i = a * c.G + j;
+  const int m0 = c.agg_ptr[a], m1 = c.agg_ptr[a + 1];
   double w[6] = {0, 0, 0, 0, 0, 0};
-  if (j < c.G && i < c.n_v) {
+  if (m0 + j < m1) {
+    const int i = c.agg_mem[m0 + j];
     const double *P = c.P + (size_t)i * 36;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -736,13 +742,46 @@ __global__ __launch_bounds__(256) void pgc_mv_kernel(CoarseArgs c, double *part_
   __syncthreads();
   if (threadIdx.x == 0) part_rz_extra[blockIdx.x] = ((dots[0] + dots[1]) + dots[2]) + dots[3];
 }
+// The two steps above in one launch (a PCG iteration is a chain of dependent launches, each worth ~7 us): one workgroup
+// per aggregate computes ITS six rows of y_c = A_c^-1 r_c, its share r_c[a] . y_c[a] of r . z, and prolongs to its members.
+__global__ __launch_bounds__(256) void pgc_mvp_kernel(CoarseArgs c, double *z, double *part_rz_extra) {
+  __shared__ double sh[6 * 256 / 64];
+  __shared__ double y6[6];
+  const int a = blockIdx.x, t = threadIdx.x;
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  for (int col = t; col < c.n_c; col += 256) {
+    const double rc = c.rc[col];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) s[m] += c.Ac[(size_t)(a * 6 + m) * c.n_c + col] * rc;
+  }
+  block_sum_m<6, 256>(s, sh);  // every thread holds the six sums
+  if (t == 0) {
+    double dot = 0.0;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+      y6[m] = s[m];
+      dot += s[m] * c.rc[a * 6 + m];
+    }
+    part_rz_extra[a] = dot;
+  }
+  __syncthreads();
+  const int m0 = c.agg_ptr[a], cnt = (c.agg_ptr[a + 1] - m0) * 6;
+  for (int idx = t; idx < cnt; idx += 256) {
+    const int i = c.agg_mem[m0 + idx / 6], r = idx % 6;
+    const double *P = c.P + (size_t)i * 36 + r * 6;
+    double acc = 0.0;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) acc += P[m] * y6[m];
+    z[(size_t)i * 6 + r] += acc;
+  }
+}
 // z += P y_c
 __global__ void pgc_prolong_kernel(CoarseArgs c, double *z) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= c.n_v * 6) return;
   const int i = row / 6, r = row % 6;
   const double *P = c.P + (size_t)i * 36 + r * 6;
-  const double *y = c.yc + (size_t)(i / c.G) * 6;
+  const double *y = c.yc + (size_t)c.agg_of[i] * 6;
   double s = 0.0;
 #pragma unroll
   for (int m = 0; m < 6; ++m) s += P[m] * y[m];
@@ -851,9 +890,10 @@ struct lslam_pg {
   double *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_p = nullptr, *d_q = nullptr;
   double *d_part = nullptr, *d_scal = nullptr, *d_tmp = nullptr;
   int n_cg_blocks = 0;
-  // second level of the preconditioner (rigid motions of runs of `agg` consecutive keyframes)
+  // second level of the preconditioner (rigid motions of graph aggregates of at most `agg` keyframes)
   std::vector<int32_t> h_row_of, h_row_col;
-  int agg = 32, n_agg = 0, n_c = 0, n_cb = 0, n_cblk = 0, n_parts = 0;
+  int agg = 64, n_agg = 0, n_c = 0, n_cb = 0, n_cblk = 0, n_parts = 0;
+  int32_t *d_agg_of = nullptr, *d_agg_ptr = nullptr, *d_agg_mem = nullptr;
   double *d_P = nullptr, *d_Ac = nullptr, *d_rc = nullptr, *d_yc = nullptr, *d_gj = nullptr;
   int32_t *d_cb_ptr = nullptr, *d_cb_ent = nullptr, *d_cb_ab = nullptr;
   int coarse_mode = -1;     // -1 automatic (switched on by a solve that needed many iterations), 0 off, 1 on
@@ -985,6 +1025,7 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
     c.P = pg->d_P; c.Ac = pg->d_Ac; c.rc = pg->d_rc; c.yc = pg->d_yc;
     c.Rbuf = pg->d_gj; c.Cbuf = pg->d_gj + (size_t)6 * pg->n_c; c.Bbuf = pg->d_gj + (size_t)12 * pg->n_c;
     c.cb_ptr = pg->d_cb_ptr; c.cb_ent = pg->d_cb_ent; c.cb_ab = pg->d_cb_ab;
+    c.agg_of = pg->d_agg_of; c.agg_ptr = pg->d_agg_ptr; c.agg_mem = pg->d_agg_mem;
     c.n_v = pg->n_v; c.G = pg->agg; c.na = pg->n_agg; c.n_c = pg->n_c; c.n_cb = pg->n_cb; c.n_cblk = pg->n_cblk;
     const size_t nn = (size_t)c.n_c * c.n_c;
     hipLaunchKernelGGL(pgc_P_kernel, dim3((pg->n_v + 127) / 128), dim3(128), 0, pg->stream, c);
@@ -1000,8 +1041,7 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
   auto coarse_correct = [&](int k) {  // z += P A_c^-1 P^T r and the matching share of r.z, entering iteration k + 1
     if (!coarse) return;
     hipLaunchKernelGGL(pgc_restrict_kernel, dim3(c.na), dim3(64), 0, pg->stream, c, (const double *)a.r);
-    hipLaunchKernelGGL(pgc_mv_kernel, dim3(c.n_cblk), dim3(256), 0, pg->stream, c, a.part_rz[(k + 1) & 1] + pg->n_cg_blocks);
-    hipLaunchKernelGGL(pgc_prolong_kernel, dim3((n6 + 255) / 256), dim3(256), 0, pg->stream, c, a.z);
+    hipLaunchKernelGGL(pgc_mvp_kernel, dim3(c.na), dim3(256), 0, pg->stream, c, a.z, a.part_rz[(k + 1) & 1] + pg->n_cg_blocks);
   };
   hipLaunchKernelGGL(pg_cg_init_kernel, g, blk, 0, pg->stream, a);
   hipLaunchKernelGGL(pg_cg_init2_kernel, dim3(1), blk, 0, pg->stream, a);
@@ -1096,11 +1136,35 @@ int lslam_pg_create(int device, int32_t n_v, const double *poses7, int32_t n_e, 
     if (const char *g = std::getenv("LSLAM_PG_AGG")) pg->agg = std::max(2, std::min(64, std::atoi(g)));
     if (const char *m = std::getenv("LSLAM_PG_COARSE")) pg->coarse_mode = std::atoi(m);
     const int G = pg->agg;
-    pg->n_agg = (n_v + G - 1) / G;
+    // aggregates: breadth-first from the lowest unassigned vertex over the solver rows (neighbours in block-id order,
+    // i.e. deterministic), at most G members each
+    std::vector<int32_t> agg_of((size_t)n_v, -1), agg_ptr(1, 0), agg_mem;
+    for (int seed = 0; seed < n_v; ++seed) {
+      if (agg_of[(size_t)seed] >= 0) continue;
+      const int a = (int)agg_ptr.size() - 1;
+      const size_t first = agg_mem.size();
+      agg_of[(size_t)seed] = a;
+      agg_mem.push_back(seed);
+      for (size_t head = first; head < agg_mem.size() && (int)(agg_mem.size() - first) < G; ++head) {
+        const int u = agg_mem[head];
+        for (int e = rptr[(size_t)u]; e < rptr[(size_t)u + 1] && (int)(agg_mem.size() - first) < G; ++e) {
+          const int v = rcol[(size_t)e];
+          if (agg_of[(size_t)v] < 0) {
+            agg_of[(size_t)v] = a;
+            agg_mem.push_back(v);
+          }
+        }
+      }
+      agg_ptr.push_back((int32_t)agg_mem.size());
+    }
+    pg->n_agg = (int)agg_ptr.size() - 1;
     pg->n_c = 6 * pg->n_agg;
-    pg->n_cblk = (pg->n_c + 3) / 4;
+    pg->n_cblk = pg->n_agg;  // partial-sum slots of the coarse level: one per aggregate (pgc_mvp_kernel)
+    PG_TRY(dev_upload(&pg->d_agg_of, agg_of));
+    PG_TRY(dev_upload(&pg->d_agg_ptr, agg_ptr));
+    PG_TRY(dev_upload(&pg->d_agg_mem, agg_mem));
     std::map<std::pair<int, int>, std::vector<int32_t>> cb;
-    for (int e = 0; e < pg->n_entries; ++e) cb[{rof[(size_t)e] / G, rcol[(size_t)e] / G}].push_back(e);
+    for (int e = 0; e < pg->n_entries; ++e) cb[{agg_of[(size_t)rof[(size_t)e]], agg_of[(size_t)rcol[(size_t)e]]}].push_back(e);
     std::vector<int32_t> cptr(1, 0), cent, cab;
     for (auto &kv : cb) {
       cab.push_back(kv.first.first);
@@ -1157,7 +1221,7 @@ void lslam_pg_destroy(lslam_pg *pg) {
                   (void *)pg->d_vadj, (void *)pg->d_optr, (void *)pg->d_oadj, (void *)pg->d_row_ptr,
                   (void *)pg->d_row_col, (void *)pg->d_row_src, (void *)pg->d_row_of, (void *)pg->d_vals, (void *)pg->d_minv,
                   (void *)pg->d_P, (void *)pg->d_Ac, (void *)pg->d_rc, (void *)pg->d_yc, (void *)pg->d_gj, (void *)pg->d_cb_ptr,
-                  (void *)pg->d_cb_ent, (void *)pg->d_cb_ab,
+                  (void *)pg->d_cb_ent, (void *)pg->d_cb_ab, (void *)pg->d_agg_of, (void *)pg->d_agg_ptr, (void *)pg->d_agg_mem,
                   (void *)pg->d_x, (void *)pg->d_r, (void *)pg->d_z, (void *)pg->d_p, (void *)pg->d_q,
                   (void *)pg->d_part, (void *)pg->d_scal, (void *)pg->d_tmp})
     if (p) (void)hipFree(p);

@@ -64,7 +64,7 @@ def parse_args():
     ap.add_argument("--rings", type=int, default=64)
     ap.add_argument("--scans", type=int, default=int(os.environ.get("LSLAM_SCANS", "640")),
                     help="resident query scans per GPU; one step matches all of them")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("LSLAM_BATCH", "32")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("LSLAM_BATCH", "320")),
                     help="scans in flight per launch sequence (lslam_opts.scans_in_flight)")
     ap.add_argument("--map-frames", type=int, default=10000, help="frames accumulated into the voxel map")
     ap.add_argument("--map-rings", type=int, default=16, help="rings of the frames the map is built from (VLP-16)")

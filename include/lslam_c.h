@@ -72,7 +72,8 @@ typedef struct {
   int32_t jtj_mode;  /* 0: VALU + wave-shuffle reduction of J^T J; 1: MFMA f32 16x16x4 */
   int32_t profile;   /* 1: bracket every sweep launch with HIP events (stats.gpu_ms_sweep) */
   int32_t scans_in_flight; /* lslam_scanmatch_run_batch: resident scans matched together by one sequence of
-                              launches; more scans are taken in chunks of this size (0: up to 32) */
+                              launches; more scans are taken in chunks of this size (0: up to 128; a scan
+                              in flight costs ~1.3 MB of scratch in HBM for a 115 200-point scan) */
   int32_t search_mode;     /* how the 5-NN search maps to the GPU: LSLAM_SEARCH_AUTO / _LANE / _PACKET */
 } lslam_opts;
 

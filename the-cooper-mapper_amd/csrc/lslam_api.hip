@@ -1134,7 +1134,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
   // bounded.  All chunks' first `batch` iterations are enqueued back to back before the host looks once.
   int n_launches = 0;
   if (!sharded) {
-    const int in_flight = o.scans_in_flight > 0 ? std::min<int>(o.scans_in_flight, n_scans) : std::min<int>(n_scans, 32);
+    const int in_flight = o.scans_in_flight > 0 ? std::min<int>(o.scans_in_flight, n_scans) : std::min<int>(n_scans, 128);
     const int n_chunks = (n_scans + in_flight - 1) / in_flight;
     static const bool unbounded = std::getenv("LSLAM_UNBOUNDED_KNN") != nullptr;  // A/B switch
     sa.bounded = (ctx->cube_mode || unbounded) ? 0 : 1;  // per-cube positions are tree-relative
@@ -1174,7 +1174,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
         max_nb = std::max(max_nb, ctx->h_probs[(size_t)p1 - 1].first_block + ctx->h_probs[(size_t)p1 - 1].n_blocks -
                                       ctx->h_probs[(size_t)p0].first_block);
       }
-      HIP_TRY(ctx->stack_ovf.reserve(stack_ovf_words((size_t)std::max(max_nb, 1) * SWEEP_BLOCK)));
+      HIP_TRY(ctx->stack_ovf.reserve(stack_ovf_words((size_t)std::max(max_nb, 1) * SWEEP_BLOCK, std::max(ctx->tc.depth, ctx->ts.depth))));
       sa.stack_ovf = ctx->stack_ovf.p;
     }
     for (;;) {

@@ -122,7 +122,7 @@ LSLAM_DEV void knn_insert_sorted(float (&d)[5], int (&p)[5], float x, int pos) {
 // Per-lane traversal stack.  Entries are two 32-bit words.  The first KD_STACK_LDS
 // levels live in LDS (layout [level][thread]: lanes at the same depth hit distinct
 // banks); deeper levels -- only reached by trees deeper than KD_STACK_LDS+1 -- go
-// to a global overflow buffer [2][KD_STACK_MAX-KD_STACK_LDS][n_threads] that the
+// to a global overflow buffer [levels beyond the LDS ones][2][n_threads] (as many levels as the trees are deep) that the
 // host allocates only for such trees.
 constexpr int KD_STACK_LDS = 32;
 
@@ -141,8 +141,8 @@ struct KdStack {
       lds[e * BLOCK] = w0;
       lds[(LDS_DEPTH + e) * BLOCK] = w1;
     } else {
-      ovf[(size_t)(e - LDS_DEPTH) * ovf_stride] = w0;
-      ovf[(size_t)(KD_STACK_MAX - LDS_DEPTH + e - LDS_DEPTH) * ovf_stride] = w1;
+      ovf[(size_t)(2 * (e - LDS_DEPTH)) * ovf_stride] = w0;
+      ovf[(size_t)(2 * (e - LDS_DEPTH) + 1) * ovf_stride] = w1;
     }
   }
   LSLAM_DEV void get(int e, uint32_t &w0, uint32_t &w1) const {
@@ -150,8 +150,8 @@ struct KdStack {
       w0 = lds[e * BLOCK];
       w1 = lds[(LDS_DEPTH + e) * BLOCK];
     } else {
-      w0 = ovf[(size_t)(e - LDS_DEPTH) * ovf_stride];
-      w1 = ovf[(size_t)(KD_STACK_MAX - LDS_DEPTH + e - LDS_DEPTH) * ovf_stride];
+      w0 = ovf[(size_t)(2 * (e - LDS_DEPTH)) * ovf_stride];
+      w1 = ovf[(size_t)(2 * (e - LDS_DEPTH) + 1) * ovf_stride];
     }
   }
 };

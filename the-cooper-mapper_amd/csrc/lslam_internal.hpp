@@ -169,8 +169,11 @@ hipError_t launch_knn5_packet(const TreeView &T, const float4 *q, int nq, int32_
 hipError_t launch_packet_stats(const TreeView &T, const float4 *q, int nq, unsigned *out, hipStream_t s);
 #endif
 // words of overflow stack needed for n_threads lanes
-inline size_t stack_ovf_words(size_t n_threads) {
-  return 2 * (size_t)KD_STACK_MAX * n_threads;  // enough for any LDS depth
+// (level e of the stack lives in rows 2(e - LDS_DEPTH), 2(e - LDS_DEPTH) + 1; a traversal of a tree of depth d stacks at
+// most d entries; without a depth the size covers the deepest tree the library accepts and any LDS depth)
+inline size_t stack_ovf_words(size_t n_threads, int tree_depth = KD_STACK_MAX) {
+  const int levels = tree_depth + 2 < KD_STACK_MAX ? tree_depth + 2 : KD_STACK_MAX;
+  return 2 * (size_t)levels * n_threads;
 }
 hipError_t launch_gn_step_tap(GNState *st, const float *AtA, const float *Atb, float dr, float dt,
                               float eig_thresh, hipStream_t s);

@@ -8,7 +8,7 @@ Workload (BASELINE.json configs[2] on the map of configs[1])
     FeatureMap::addFeatureCloud (util/FeatureMap.h:219-230,289-306; corner leaf 0.2 m, surf 0.4 m) on the
     device map; what is matched against is the active surround at the end of the loop
     (getSurroundFeature, :256-265), kd-trees built on the device;
-  * queries: `--scans` (640) different synthetic 64-ring x 1800 scans (115 200 points each, every
+  * queries: `--scans` (960) different synthetic 64-ring x 1800 scans (115 200 points each, every
     return a query) taken around the end of the loop, initial pose error +-0.3 m / +-2 deg.
 A "step" is one pass of the hot path over that batch: the scanMatchScan Gauss-Newton loop
 (ScanMatch.cpp:78-347: <= 10 iterations of transform -> kd-tree 5-NN -> line/plane fit -> residual +
@@ -62,7 +62,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rings", type=int, default=64)
-    ap.add_argument("--scans", type=int, default=int(os.environ.get("LSLAM_SCANS", "640")),
+    ap.add_argument("--scans", type=int, default=int(os.environ.get("LSLAM_SCANS", "960")),
                     help="resident query scans per GPU; one step matches all of them")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("LSLAM_BATCH", "320")),
                     help="scans in flight per launch sequence (lslam_opts.scans_in_flight)")

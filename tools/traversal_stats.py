@@ -81,8 +81,31 @@ def run(pose, label):
     # with refilled lanes the bound is the lane-sum / 64
     for i, cost in ((3, "node"), (4, "leaf")):
         print("  %s steps: paid by the wavefronts %d, lane-sum/64 %d" % (cost, wm[:, i].sum(), w[:, :, i].sum() // 64))
+    return st
 
 
-run(init, "first sweep of a call (unbounded)")
-run(init, "second sweep, same pose (bounded by the previous neighbours)")
-run(g.astype(np.float32), "sweep at the converged pose (bounded by neighbours found 1 step away)")
+def regroup(st, key, label):
+    """What the wavefronts would pay if the 256 queries of every workgroup were dealt to its four wavefronts in the order
+    of `key` (lightest 64 first): sum over wavefronts of the lane maximum, for node steps, leaf visits and pop rounds."""
+    nblk = len(st) // 256
+    k = key.reshape(nblk, 256)
+    order = np.argsort(k, axis=1, kind="stable")
+    out = []
+    for i in (3, 4, 7):
+        v = np.take_along_axis(st[:, i].reshape(nblk, 256), order, axis=1).reshape(nblk * 4, 64)
+        out.append(v.max(axis=1).sum())
+    base = [st[:, i].reshape(-1, 64).max(axis=1).sum() for i in (3, 4, 7)]
+    print("regrouped by %-32s node steps %.3f  leaf visits %.3f  pop rounds %.3f  of what the wavefronts pay now" % (
+        label, out[0] / base[0], out[1] / base[1], out[2] / base[2]))
+
+
+s1 = run(init, "first sweep of a call (unbounded)")
+s2 = run(init, "second sweep, same pose (bounded by the previous neighbours)")
+s3 = run(g.astype(np.float32), "sweep at the converged pose (bounded by neighbours found 1 step away)")
+mid = (0.7 * g + 0.3 * init).astype(np.float32)
+s4 = run(mid, "sweep 30 % of the way back to the initial pose")
+work = lambda st: st[:, 4] * 16 + st[:, 3]  # leaf visits, then node steps
+regroup(s3, work(s3), "its own work (upper bound)")
+regroup(s3, work(s2), "the work of the sweep 0.3 m earlier")
+regroup(s4, work(s3), "the work of the previous sweep")
+regroup(s4, s3[:, 4], "the previous sweep's leaf visits")

@@ -417,11 +417,14 @@ def pmc_counters(avg_sweep_ms):
     # the profile's own kernel duration (SQ_BUSY_CYCLES is per-SE; use wave-cycle ratios, which need none)
     c = {"source": "%s (rocprofv3 --pmc passes; %s)" % (PMC_PROFILE, src.strip()[:200])}
     t_s = avg_sweep_ms * 1e-3
-    if v.get("SQ_BUSY_CYCLES", 0) > 0:
-        # the profiled launches are the largest of the run, not the average timed one: rate them over their own
-        # duration, SQ_BUSY_CYCLES (summed over the 32 shader engines) at the 2.4 GHz engine clock
-        t_s = v["SQ_BUSY_CYCLES"] / 32.0 / 2.4e9
+    # the profiled launches are the largest of the run, not the average timed one: rate them over their own
+    # duration in engine cycles -- GRBM_GUI_ACTIVE (summed over the 8 XCDs; at 2.4 GHz it reproduces the HIP-event
+    # duration of these launches), else SQ_BUSY_CYCLES (summed over the 32 shader engines)
+    cyc = v["GRBM_GUI_ACTIVE"] / 8.0 if v.get("GRBM_GUI_ACTIVE", 0) > 0 else v.get("SQ_BUSY_CYCLES", 0.0) / 32.0
+    if cyc > 0:
+        t_s = cyc / 2.4e9
         c["profiled_launch_ms"] = 1e3 * t_s
+        c["profiled_launch_cycles"] = cyc
     if traffic is not None and t_s > 0:
         c["hbm_gbs"] = traffic / t_s / 1e9
         c["hbm_frac"] = c["hbm_gbs"] / HBM_PEAK_GBS
@@ -437,9 +440,9 @@ def pmc_counters(avg_sweep_ms):
         c["lanes_active"] = v["SQ_THREAD_CYCLES_VALU"] / v["SQ_INSTS_VALU"]
     if "SQ_WAIT_ANY" in v and v.get("SQ_WAVE_CYCLES", 0) > 0:
         c["wait_frac"] = v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"]
-    if "SQ_ACTIVE_INST_VALU" in v and v.get("SQ_BUSY_CYCLES", 0) > 0:
-        # SQ_ACTIVE_INST_VALU counts cycles (x4 per quad-issue) summed over SIMDs; SQ_BUSY_CYCLES per shader engine
-        c["valu_busy"] = v["SQ_ACTIVE_INST_VALU"] * 4.0 / (v["SQ_BUSY_CYCLES"] / 32.0 * 1024.0) if v["SQ_BUSY_CYCLES"] else None
+    if "SQ_ACTIVE_INST_VALU" in v and cyc > 0:
+        # SQ_ACTIVE_INST_VALU counts quad-cycles of VALU issue summed over the 1 024 SIMDs
+        c["valu_busy"] = v["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 1024.0)
     for k in ("TA_BUSY_avr", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_PENDING_STALL_CYCLES_sum", "TA_FLAT_READ_WAVEFRONTS_sum",
               "TCP_TCC_READ_REQ_sum", "GRBM_GUI_ACTIVE", "TA_BUSY_max", "TCP_GATE_EN1_sum", "TCP_GATE_EN2_sum", "TA_TA_BUSY_sum"):
         if k in v:
@@ -448,8 +451,8 @@ def pmc_counters(avg_sweep_ms):
     cand = {"hbm": c.get("hbm_frac", 0.0) or 0.0, "l2": c.get("l2_frac", 0.0) or 0.0,
             "valu-issue (one fp32 VALU instruction per SIMD every 4 cycles; %.0f of 64 lanes active)" % c.get("lanes_active", 0.0):
                 c.get("valu_busy", 0.0) or 0.0}
-    if "TA_BUSY_avr" in v and v.get("SQ_BUSY_CYCLES", 0) > 0:
-        c["ta_busy"] = v["TA_BUSY_avr"] / (v["SQ_BUSY_CYCLES"] / 32.0)  # texture-address units: vector-memory instruction issue
+    if "TA_BUSY_avr" in v and cyc > 0:
+        c["ta_busy"] = v["TA_BUSY_avr"] / cyc  # texture-address units: vector-memory instruction issue
         cand["vector-memory issue (TA)"] = c["ta_busy"]
     if "vmem_lane_rate_frac" in v:
         cand["vector-memory lane rate (TA / L1)"] = v["vmem_lane_rate_frac"]

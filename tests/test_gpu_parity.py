@@ -822,6 +822,30 @@ def test_tree_deeper_than_traversal_stack_is_refused(pkg, n_chain):
         c.close()
 
 
+def test_batch_chunking_does_not_change_a_bit(ctx, synth, small_problem):
+    """lslam_opts.scans_in_flight only decides how many scans share a launch sequence: 7 scans matched 1, 2, 3 or
+    all at a time (and with the default, 0) end with the same pose bits, iteration counts and row counts."""
+    pr = small_problem
+    world = pr["world"]
+    scans, inits = [], []
+    for k in range(7):
+        gt = (0.005 * k, -0.01, 0.2 + 0.15 * k, 2.5 - 0.8 * k, -2.0 + 0.6 * k, synth.SENSOR_HEIGHT)
+        qc, qs, gt = synth.make_scan(world, 16, 300 + 150 * (k % 3), gt_pose=gt, seed=300 + k)
+        scans.append((qc, qs))
+        inits.append(synth.perturb_pose(gt, seed=400 + k))
+    ctx.map_set(pr["map_corner"], pr["map_surf"])
+    ctx.scan_set_batch(scans)
+    ref = None
+    for in_flight in (0, 1, 2, 3, 7, 64):
+        opts = ctx.default_opts()
+        opts.scans_in_flight = in_flight
+        _, poses, stats = ctx.run_batch(np.stack(inits), opts)
+        sig = (bits(poses).tobytes(), [(s.status, s.iterations, s.n_rows, s.point_residuals) for s in stats])
+        if ref is None:
+            ref = sig
+        assert sig == ref, in_flight
+
+
 def test_survey_8b_alias_exports(ctx, pkg, synth, small_problem):
     """SURVEY 8(b)'s names for three entry points are exported aliases of the ones the tests above drive."""
     import ctypes as C

@@ -289,6 +289,14 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
 #ifdef LSLAM_TRAVERSAL_STATS
       ts.n_hit += hit ? 1 : 0;
 #endif
+#ifdef LSLAM_INSERT_TWICE  // profiling only: the ten sorted inserts once more with no effect -> their share of the kernel time
+      {
+        float big = FLT_MAX;
+        asm volatile("" : "+v"(big));
+#pragma unroll
+        for (int j = 0; j < 10; ++j) knn_insert_sorted(d, p, big, l + j);
+      }
+#endif
 #ifdef LSLAM_LEAF_TWICE  // profiling only: the leaf arithmetic once more with no effect -> its share of the kernel time
       {
         float thr = -1.0f, qz2 = qz;

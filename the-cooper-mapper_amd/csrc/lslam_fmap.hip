@@ -384,7 +384,7 @@ struct lslam_fmap {
     int gen = -1;           // index into gens (-1: no tree)
     lslam::TreeView view{};
   };
-  std::vector<Generation *> gens[2];
+  std::vector<Generation *> gens;       // one list for both feature types: a generation holds corner AND surf trees
   std::vector<Generation *> spare;      // dead generations kept with their allocations: no hipMalloc / hipFree per frame
   std::vector<CubeTree> cube_tree[2];   // [ncube]
   std::vector<uint8_t> dirty[2];        // [ncube]
@@ -706,11 +706,9 @@ void lslam_fmap_destroy(lslam_fmap *fm) {
     fm->pts[t].release(); fm->pts_alt[t].release(); fm->cube[t].release(); fm->cube_alt[t].release();
     fm->seg_begin[t].release(); fm->seg_end[t].release(); fm->sur[t].release();
   }
-  for (int t = 0; t < 2; ++t) {
-    for (lslam_fmap::Generation *g : fm->gens[t])
-      if (g) { g->nodes.release(); g->pn.release(); g->pts.release(); delete g; }
-    fm->gens[t].clear();
-  }
+  for (lslam_fmap::Generation *g : fm->gens)
+    if (g) { g->nodes.release(); g->pn.release(); g->pts.release(); delete g; }
+  fm->gens.clear();
   for (lslam_fmap::Generation *g : fm->spare) { g->nodes.release(); g->pn.release(); g->pts.release(); delete g; }
   fm->spare.clear();
   fm->d_touched.release();
@@ -879,7 +877,7 @@ int lslam_fmap_surround_to_map(lslam_fmap *fm) {
 
 static void drop_cube_trees(lslam_fmap *fm, int t) {
   for (lslam_fmap::CubeTree &ct : fm->cube_tree[t]) {
-    if (ct.gen >= 0) fm->gens[0][(size_t)ct.gen]->live--;  // one generation list for both feature types
+    if (ct.gen >= 0) fm->gens[(size_t)ct.gen]->live--;
     ct.gen = -1;
   }
 }
@@ -913,8 +911,8 @@ int lslam_fmap_to_cubemap(lslam_fmap *fm) {
   const auto t0 = now();
   // Corner and surf cubes that need a tree are built TOGETHER: one generation, one forest build (a forest build costs
   // ~0.9 ms of dependent launches whatever its size, so two of them per frame were most of this call).  Generations
-  // live in gens[0]; CubeTree::gen indexes that list for both feature types.
-  std::vector<lslam_fmap::Generation *> &gens = fm->gens[0];
+  // live in one list; CubeTree::gen indexes it for both feature types.
+  std::vector<lslam_fmap::Generation *> &gens = fm->gens;
   for (int t = 0; t < 2; ++t) {
     rc = refresh_segments(fm, t);
     if (rc) return rc;

@@ -1,5 +1,9 @@
-import importlib, sys, time, json
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tools'); sys.path.insert(0,'/root/repo/tests')
+#!/usr/bin/env python3
+"""One mapping frame with the incrementally kept per-cube trees (variant C) next to the whole-surround rebuild
+(variant A) on a 3 000-frame map; LSLAM_FMAP_TIMING=1 prints where lslam_fmap_to_cubemap spends its time."""
+import importlib, os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import bench
 pkg = importlib.import_module("the-cooper-mapper_amd"); synth = importlib.import_module("the-cooper-mapper_amd.synth")

@@ -898,7 +898,10 @@ __global__ __launch_bounds__(64) void kd_build_small_kernel(BuildArgs A) {
 // outcome is independent of scheduling.  The Hoare pairing needs the rank of every misplaced
 // element inside its node: per-chunk counts, a per-node scan of the chunk counts, then ranks
 // inside the chunk.
-constexpr int HUGE_MIN = LOCAL_MAX;  // everything above the wavefront-local size goes level by level
+#ifndef LSLAM_HUGE_MIN
+#define LSLAM_HUGE_MIN LSLAM_LOCAL_MAX
+#endif
+constexpr int HUGE_MIN = LSLAM_HUGE_MIN;  // nodes above this size go level by level; between LOCAL_MAX and this, through the phase-A queue
 constexpr int LV_CH = 4096;
 constexpr int LV_TB = 256;
 constexpr int LV_PER = LV_CH / LV_TB;  // consecutive elements per thread

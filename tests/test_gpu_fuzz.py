@@ -1,0 +1,19 @@
+"""Seeded parity fuzz (tools/fuzz_parity.py): random worlds / ring counts / poses, voxel-filtered and 1-cm-rounded maps
+(exact distance ties), both search implementations -- sweep taps bit for bit against the oracle, whole loops within
+the north-star bar.  Nine problems here; run the tool itself with N_SEEDS=... for more."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_parity_fuzz_nine_problems():
+    env = dict(os.environ, N_SEEDS="9")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py")], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "9 problems, no mismatch" in r.stdout

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Seeded parity fuzz on the GPU box: many random problems (worlds, ring counts, poses, map densities, voxel-filtered maps
+with lattice-like coordinates) through the sweep taps and the whole scanMatchScan loop, device against oracle.
+Bit-exact: neighbour indices, distances, flags, coefficients; the loop: status / iterations / rows equal, pose within
+1e-4 m / 1e-5 rad.  N_SEEDS (default 24) problems; exits non-zero on the first mismatch.
+
+    python tools/fuzz_parity.py
+"""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+pkg = importlib.import_module("the-cooper-mapper_amd")
+synth = importlib.import_module("the-cooper-mapper_amd.synth")
+from oracle_lib import Oracle
+
+bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
+o = Oracle()
+ctx = pkg.Context(0)
+n_seeds = int(os.environ.get("N_SEEDS", "24"))
+bad = 0
+for seed in range(n_seeds):
+    rng = np.random.default_rng(1000 + seed)
+    rings = int(rng.choice([8, 16, 32]))
+    steps = int(rng.choice([300, 600, 900]))
+    half = float(rng.choice([40.0, 60.0, 90.0]))
+    pr = synth.make_problem(rings=rings, azimuth_steps=steps, world_half=half, seed=seed % 7)
+    mc, ms = pr["map_corner"], pr["map_surf"]
+    if seed % 3 == 1:  # voxel-filtered map: centroids on a near-lattice, many equal coordinates
+        mc, ms = pkg.voxel_grid(ctx, np.c_[mc[:, :3], np.zeros(len(mc), np.float32)], 0.2)[:, :3], \
+                 pkg.voxel_grid(ctx, np.c_[ms[:, :3], np.zeros(len(ms), np.float32)], 0.4)[:, :3]
+    if seed % 3 == 2:  # coordinates rounded to 1 cm: exact distance ties
+        mc, ms = np.round(mc, 2).astype(np.float32), np.round(ms, 2).astype(np.float32)
+    mc = np.ascontiguousarray(mc, np.float32); ms = np.ascontiguousarray(ms, np.float32)
+    init = synth.perturb_pose(pr["gt_pose"], seed=seed, dt=float(rng.uniform(0.05, 0.5)), dr_deg=float(rng.uniform(0.2, 3.0)))
+    ctx.map_set(mc, ms)
+    ctx.scan_set(pr["corner"], pr["surf"])
+    tc, ts = o.kdtree(mc), o.kdtree(ms)
+    for pose in (init, pr["gt_pose"]):
+        for mode in (1, 2):
+            g = ctx.sweep(pose, jtj_mode=1, search_mode=mode)
+            r = o.sweep(tc, ts, pr["corner"], pr["surf"], pose)
+            for key in ("idx", "flags"):
+                if not np.array_equal(g[key], r[key]):
+                    bad += 1; print("seed", seed, "mode", mode, key, "differs at", np.argwhere(g[key] != r[key])[:3].tolist())
+            for key in ("d2", "coeff"):
+                if not np.array_equal(bits(g[key]), bits(r[key])):
+                    bad += 1; print("seed", seed, "mode", mode, key, "differs at", np.argwhere(bits(g[key]) != bits(r[key]))[:3].tolist())
+    ok, opose, ost = o.scanmatch_scan(mc, ms, pr["corner"], pr["surf"], init)
+    status, pose, st = ctx.run(init)
+    if (st.iterations, st.n_rows) != (ost.iterations, ost.n_rows) or np.abs(pose[3:] - opose[3:]).max() > 1e-4 or np.abs(pose[:3] - opose[:3]).max() > 1e-5:
+        bad += 1; print("seed", seed, "loop differs", st.iterations, ost.iterations, st.n_rows, ost.n_rows, np.abs(pose - opose).max())
+    print("seed %2d rings %2d steps %3d half %3.0f map %6d+%6d scan %5d: %s" % (seed, rings, steps, half, len(mc), len(ms), len(pr["corner"]) + len(pr["surf"]), "ok" if not bad else "MISMATCH"), flush=True)
+    if bad:
+        sys.exit(1)
+print("fuzz: %d problems, no mismatch" % n_seeds)

@@ -29,8 +29,12 @@ def load_lib():
     global _lib
     if _lib is None:
         path = os.path.join(HERE, "libsynth_hip.so")
-        if not os.path.exists(path):
-            subprocess.check_call(["make", "-C", HERE], stdout=subprocess.DEVNULL)
+        if not os.path.exists(path):  # normally built by __graft_entry__.build(); several ranks may get here at once
+            import fcntl
+            with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                if not os.path.exists(path):
+                    subprocess.check_call(["make", "-C", HERE], stdout=subprocess.DEVNULL)
         importlib.import_module("the-cooper-mapper_amd").load_library()  # same HIP runtime for both libraries
         lib = C.CDLL(path)
         lib.synth_raycast.restype = C.c_int

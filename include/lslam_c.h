@@ -397,11 +397,14 @@ int lslam_icp_align(lslam_ctx *ctx, const void *target, size_t n_target, const v
  * (pose_graph/graph.cpp:279-288: diag(0.8,0.4,0.8,1,2,1) for odometry, :333-339: 2*I
  * for loop closures); vertex `fixed_vertex` is held fixed (solver_g2o.cpp:55-59).  fp64.
  *
- * Multi-GPU (one process per GPU): every rank creates the same graph, calls
- * lslam_pg_set_shard with its edge range and an all-reduce callback; the block system
- * [diagonal blocks | off-diagonal blocks | b | chi2] is summed across ranks through the
- * callback (RCCL over xGMI when the callback wraps torch.distributed.all_reduce on the
- * buffer passed as system_buf), the damped solve is replicated. */
+ * The damped system is solved by preconditioned CG (block Jacobi + a coarse level of rigid-body motions of graph
+ * aggregates, csrc/lslam_posegraph.hip) instead of g2o's sparse Cholesky: same optimum (tests/test_posegraph_bench_fixture.py).
+ *
+ * Multi-GPU (one process per GPU): every rank creates the same graph and takes an edge range
+ * (lslam_pg_set_shard); the block system [diagonal blocks | off-diagonal blocks | b | chi2] is summed
+ * across ranks once per linearisation -- by the library's RCCL communicator on the solver's stream
+ * (lslam_pg_set_comm, further up) or through the callback of lslam_pg_set_shard for hosts with their own
+ * transport; the damped solve is replicated and bit-identical on every rank. */
 typedef struct lslam_pg lslam_pg;
 
 typedef struct {

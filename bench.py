@@ -629,8 +629,8 @@ def pose_graph_leg(pkg, synth, distmod, dist, rank, world, local_rank, comm, np,
     spmv_bytes = blocks * 36 * 8 + blocks * 4 + 3 * len(g["init"]) * 6 * 8
     if st.cg_iterations > 0 and st.gpu_ms_total > 0:
         per_it_s = st.gpu_ms_total * 1e-3 / st.cg_iterations
-        res["roofline"] = {"kernel": "pg_cg_prod_kernel", "bound": "launch latency: four dependent launches per PCG "
-                           "iteration on a 15.9 MB system that lives in L2 / Infinity Cache (not a bandwidth limit)",
+        res["roofline"] = {"kernel": "pg_cg_prod_kernel", "bound": "chain of four small dependent launches per PCG iteration (6-8 us kernels + ~3 us "
+                           "launch-to-launch) on a 15.9 MB system that lives in L2 / Infinity Cache (not a bandwidth limit)",
                            "achieved": spmv_bytes / per_it_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": spmv_bytes / per_it_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
                            "alg_bytes_per_cg_iteration": spmv_bytes, "us_per_cg_iteration": 1e6 * per_it_s,

@@ -792,7 +792,7 @@ def sweep_pipeline_leg(pkg, synth, ctx, rings, np):
     acc = {"register": 0.0, "extract": 0.0, "odometry": 0.0, "mapping": 0.0}
     n = 0
     raws = []
-    for k in range(14):  # consecutive sweeps of a moving sensor: 7 for the stage timings, all for the threads
+    for k in range(28):  # consecutive sweeps of a moving sensor: 7 for the stage timings, all for the threads
         gt = (0.0, 0.0, 0.3 + 0.01 * k, 3.0 + 0.4 * k, -2.0 + 0.15 * k, synth.SENSOR_HEIGHT)
         _, _, _, cloud, _ = synth.make_scan(world, rings, 1800, gt_pose=gt, seed=300 + k, full=True)
         ring = np.floor(cloud[:, 3]).astype(np.int64)

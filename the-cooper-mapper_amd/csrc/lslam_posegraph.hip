@@ -899,6 +899,14 @@ struct lslam_pg {
   int coarse_mode = -1;     // -1 automatic (switched on by a solve that needed many iterations), 0 off, 1 on
   bool coarse_on = false;
   int coarse_solves = 0;    // damped systems solved with the second level (statistics)
+  // The coarse inverse (with the P it was built from) is a preconditioner, not part of the answer: it is kept across
+  // damped solves while it still works -- rebuilt when lambda has moved by more than 10x since it was built, or when the
+  // previous solve that used it needed over 1.3x the iterations of the first solve after it was built.  The rule only
+  // looks at lambda and iteration counts, which are identical on every rank of a sharded run.
+  bool coarse_valid = false;
+  double coarse_lambda = 0.0;
+  int coarse_fresh_iters = 0, coarse_last_iters = 0;
+  int coarse_setups = 0;
   size_t sys_doubles() const { return (size_t)n_v * 36 + (size_t)n_off * 36 + (size_t)n_v * 6 + 1; }
   double *diag() const { return d_sys; }
   double *off() const { return d_sys + (size_t)n_v * 36; }
@@ -1019,6 +1027,7 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
   const dim3 g(pg->n_cg_blocks), blk(CG_BLOCK);
   // second level (see pgc_P_kernel): on when forced, or -- automatic -- once a solve of this graph needed many iterations
   const bool coarse = pg->coarse_mode == 1 || (pg->coarse_mode < 0 && pg->coarse_on);
+  bool fresh_inverse = false;
   CoarseArgs c{};
   if (coarse) {
     c.poses = pg->d_poses;
@@ -1028,6 +1037,14 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
     c.agg_of = pg->d_agg_of; c.agg_ptr = pg->d_agg_ptr; c.agg_mem = pg->d_agg_mem;
     c.n_v = pg->n_v; c.G = pg->agg; c.na = pg->n_agg; c.n_c = pg->n_c; c.n_cb = pg->n_cb; c.n_cblk = pg->n_cblk;
     const size_t nn = (size_t)c.n_c * c.n_c;
+    static const bool no_reuse = std::getenv("LSLAM_PG_NO_REUSE") != nullptr;  // A/B switch
+    bool rebuild = !pg->coarse_valid || no_reuse;
+    if (!rebuild) {
+      const double ratio = lambda > pg->coarse_lambda ? lambda / pg->coarse_lambda : pg->coarse_lambda / lambda;
+      rebuild = !(ratio <= 10.0) || (pg->coarse_fresh_iters > 0 && 10 * pg->coarse_last_iters > 13 * pg->coarse_fresh_iters);
+    }
+    fresh_inverse = rebuild;
+    if (rebuild) {
     hipLaunchKernelGGL(pgc_P_kernel, dim3((pg->n_v + 127) / 128), dim3(128), 0, pg->stream, c);
     PG_TRY(hipMemsetAsync(c.Ac, 0, nn * sizeof(double), pg->stream));
     hipLaunchKernelGGL(pgc_assemble_kernel, dim3(c.n_cb), dim3(64), 0, pg->stream, c, pg->d_vals, pg->d_row_of, pg->d_row_col, n_items);
@@ -1036,6 +1053,11 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
       hipLaunchKernelGGL(pgc_gj_update_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, pg->stream, c, k);
     }
     PG_TRY(hipGetLastError());
+    pg->coarse_valid = true;
+    pg->coarse_lambda = lambda;
+    pg->coarse_fresh_iters = 0;
+    pg->coarse_setups++;
+    }
     pg->coarse_solves++;
   }
   auto coarse_correct = [&](int k) {  // z += P A_c^-1 P^T r and the matching share of r.z, entering iteration k + 1
@@ -1065,6 +1087,10 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
   PG_TRY(hipGetLastError());
   *iters_out = done_iters;
   if (done_iters > 300) pg->coarse_on = true;  // ill-conditioned from here on: later solves of this graph take the second level
+  if (coarse) {
+    if (fresh_inverse) pg->coarse_fresh_iters = done_iters;
+    pg->coarse_last_iters = done_iters;
+  }
   return LSLAM_OK;
 }
 

@@ -83,14 +83,29 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
   const int qi = bd.first + tid;
   const bool active = tid < bd.count;
 
-  // pose of this iteration: wave-uniform scalar loads
+  // pose of this iteration: R, t, sc are 18 consecutive floats of the scan's GNState.  The compiler cannot prove the
+  // state invariant (the solve kernel writes it between launches) and would fetch it with vector loads into 18 VGPRs
+  // that then sit in the register file through the whole search: fetched with scalar loads they live in SGPRs.
   float R[9], t[3], sc[6];
+  {
+    static_assert(offsetof(GNState, R) == 24 && offsetof(GNState, t) == 60 && offsetof(GNState, sc) == 72, "GNState layout");
+    typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    u32x16_t w;
+    u32x2_t w2;
+    asm volatile("s_load_dwordx16 %0, %2, 0x18\n\ts_load_dwordx2 %1, %2, 0x58\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(w), "=&s"(w2)
+                 : "s"(st)
+                 : "memory");
 #pragma unroll
-  for (int i = 0; i < 9; ++i) R[i] = st->R[i];
+    for (int i = 0; i < 9; ++i) R[i] = __uint_as_float(w[i]);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) t[i] = st->t[i];
+    for (int i = 0; i < 3; ++i) t[i] = __uint_as_float(w[9 + i]);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) sc[i] = st->sc[i];
+    for (int i = 0; i < 4; ++i) sc[i] = __uint_as_float(w[12 + i]);
+    sc[4] = __uint_as_float(w2[0]);
+    sc[5] = __uint_as_float(w2[1]);
+  }
 
   float row[6] = {0, 0, 0, 0, 0, 0};
   float rb = 0.0f;
@@ -187,15 +202,23 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
     float bound = FLT_MAX;
     if (a.bounded) {
       bound = 5.0f * (1.0f + 1e-5f);
-      if (a.prev_valid) {
-        float u = 0.0f;
+      if (a.prev_valid && T.n_pts > 0) {
+        // the five indices, then the five points, all in flight together (a guarded load per neighbour would be a chain
+        // of ten dependent round trips at the head of every wavefront): an invalid index reads point 0 and is ignored
+        int pp[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) pp[j] = a.prev_nb[(size_t)qi * 5 + j];
+        float4 pv[5];
         bool all = true;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-          const int pp = a.prev_nb[(size_t)qi * 5 + j];
-          all = all && pp >= 0 && pp < T.n_pts;
-          if (pp >= 0 && pp < T.n_pts) u = fmaxf(u, dist2_xyz(sel[0], sel[1], sel[2], T.pts[pp]));
+          const bool ok = pp[j] >= 0 && pp[j] < T.n_pts;
+          all = all && ok;
+          pv[j] = T.pts[ok ? pp[j] : 0];
         }
+        float u = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) u = fmaxf(u, dist2_xyz(sel[0], sel[1], sel[2], pv[j]));
         if (all) bound = fminf(bound, u * (1.0f + 1e-5f) + 1e-12f);
       }
     }

@@ -126,9 +126,13 @@ LSLAM_DEV void knn_insert_sorted(float (&d)[5], int (&p)[5], float x, int pos) {
 // host allocates only for such trees.
 constexpr int KD_STACK_LDS = 32;
 
+// The LDS part is addressed through an LDS-address-space pointer: with a generic pointer the compiler merges the
+// two arms of get() into ONE flat_load behind an address select (seen in the ISA of the batch kernel: two flat loads per
+// popped entry instead of one ds_read2st64_b32).
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 template <int BLOCK, bool OVF, int LDS_DEPTH = KD_STACK_LDS>
 struct KdStack {
-  uint32_t *lds;  // [2][LDS_DEPTH][BLOCK], already offset by the thread index
+  lds_u32 *lds;   // [2][LDS_DEPTH][BLOCK], already offset by the thread index
   uint32_t *ovf;  // global overflow, already offset by the global thread index (OVF only)
   size_t ovf_stride;  // n_threads
   // OVF=false kernels (every tree at most LDS_DEPTH+1 levels deep) touch LDS only, so the

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(ICP_BLOCK) void icp_corr_kernel(IcpArgs a) {
     float d[5];
     int p[5];
     KdStack<ICP_BLOCK, OVF, KD_STACK_LDS> stk;
-    stk.lds = stack_lds + threadIdx.x;
+    stk.lds = (lds_u32 *)(stack_lds + threadIdx.x);
     stk.ovf = OVF ? a.stack_ovf + ((size_t)blockIdx.x * ICP_BLOCK + threadIdx.x) : nullptr;
     stk.ovf_stride = (size_t)gridDim.x * ICP_BLOCK;
 #ifdef LSLAM_TRAVERSAL_STATS

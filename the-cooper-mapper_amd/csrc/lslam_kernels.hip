@@ -191,7 +191,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
     }
     if (CUBES && !searched) T.n_pts = 0;  // knn5_search returns at once, d[4] stays FLT_MAX
     KdStack<BLOCK, OVF, LDS_DEPTH> stk;
-    stk.lds = stack_lds + tid;
+    stk.lds = (lds_u32 *)(stack_lds + tid);
     stk.ovf = OVF ? a.stack_ovf + ((size_t)blockIdx.x * BLOCK + tid) : nullptr;
     stk.ovf_stride = (size_t)a.nb_total * BLOCK;
     // Bound on the 5th neighbour's distance (production loop only; the taps run nanoflann's
@@ -945,7 +945,7 @@ __global__ __launch_bounds__(256, 2) void odom_sweep_kernel(OdomArgs a) {
       float d[5];
       int p[5];
       KdStack<BLOCK, false, KD_STACK_LDS> stk;
-      stk.lds = stack_lds + tid;
+      stk.lds = (lds_u32 *)(stack_lds + tid);
       stk.ovf = nullptr;
       stk.ovf_stride = 0;
 #ifdef LSLAM_TRAVERSAL_STATS
@@ -1166,7 +1166,7 @@ __global__ __launch_bounds__(128, 2) void knn5_kernel(TreeView T, const float4 *
   float d[5];
   int p[5];
   KdStack<128, OVF, KD_STACK_LDS> stk;
-  stk.lds = stack_lds + threadIdx.x;
+  stk.lds = (lds_u32 *)(stack_lds + threadIdx.x);
   stk.ovf = OVF ? stack_ovf + ((size_t)blockIdx.x * 128 + threadIdx.x) : nullptr;
   stk.ovf_stride = (size_t)gridDim.x * 128;
 #ifdef LSLAM_TRAVERSAL_STATS

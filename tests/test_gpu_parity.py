@@ -102,8 +102,7 @@ def _assert_tree_is_nanoflann_exact(ctx, oracle, pts):
     pts = np.ascontiguousarray(pts, np.float32)
     ctx.map_set(pts, pts)
     info = ctx.map_info()
-    if not info.built_on_device:
-        pytest.skip("host tree build forced (LSLAM_HOST_TREE)")
+    assert info.built_on_device == 1  # there is no other builder
     tree = oracle.kdtree(pts)
     nodes, dpts, root = _tree_dump(ctx, 1, len(pts))
     assert np.array_equal(dpts[:, 3].view(np.int32), tree.vind())      # same permutation
@@ -390,8 +389,7 @@ def test_cube_map_variant_matches_oracle(ctx, oracle, small_problem):
     pr = small_problem
     grid = dict(cube_size=20.0, origin=(5, 5, 1), dims=(11, 11, 3))
     ctx.cubemap_set(pr["map_corner"], pr["map_surf"], **grid)
-    if not os.environ.get("LSLAM_HOST_TREE"):
-        assert ctx.map_info().built_on_device == 1  # all cube trees in one device build
+    assert ctx.map_info().built_on_device == 1  # all cube trees in one device build
     opts = ctx.default_opts()
     opts.use_score = 0  # no score gate in this variant
     status, pose, st = ctx.scanmatch_scan(pr["corner"], pr["surf"], pr["init_pose"], opts)

@@ -267,6 +267,25 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
         }
       }
     }
+#ifdef LSLAM_FIT_TWICE  // profiling only: the fit and the coefficient once more with no effect -> their share of the kernel time
+    if (gate) {
+      float4 nb2[5];
+      float off = 0.0f;
+      asm volatile("" : "+v"(off));
+#pragma unroll
+      for (int j = 0; j < 5; ++j) nb2[j] = make_float4(nb[j].x + off, nb[j].y, nb[j].z, nb[j].w);
+      float c2[4] = {0, 0, 0, 0};
+      bool any2 = false;
+      if (!is_surf) {
+        float A[3], B[3];
+        if (find_line(nb2, A, B)) any2 = corner_coeff(A, B, sel, c2);
+      } else {
+        float plane[4];
+        if (find_plane(nb2, 0.2f, plane)) any2 = surf_coeff(plane, sel, c2);
+      }
+      if (any2 && c2[3] == off + 1e30f) coeff[3] = c2[0];  // never
+    }
+#endif
     if (flag & 2u) matched = 1.0f;
     if (flag & 4u) {
       jacobian_row(sc, q.x, q.y, q.z, coeff, row, rb);

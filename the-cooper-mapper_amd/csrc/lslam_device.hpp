@@ -51,7 +51,7 @@ struct alignas(64) PNode {
 
 constexpr uint32_t KD_LEAF = 0x80000000u;
 constexpr uint32_t KD_MAX_POINTS = 1u << 27;  // leaf reference: 27-bit left
-constexpr uint32_t KD_MAX_INNER = 1u << 29;   // stack entry: 29-bit node index
+constexpr uint32_t KD_MAX_INNER = 1u << 28;   // stack entry: 28-bit node index
 
 struct TreeView {
   const KdNode *nodes;
@@ -161,7 +161,7 @@ struct KdStack {
 };
 
 #ifdef LSLAM_TRAVERSAL_STATS  // profiling build only (tools/traversal_stats.py)
-struct TravStats { unsigned long long t_desc, t_leaf, t_pop, t_take; unsigned n_node, n_leaf, n_pop, n_take, n_popit, n_hit, n_cand; };
+struct TravStats { unsigned long long t_desc, t_leaf, t_pop, t_take; unsigned n_node, n_leaf, n_pop, n_take, n_popit, n_hit, n_cand, n_cull; };
 #define TS_BEGIN unsigned long long _ts = __builtin_readcyclecounter();
 #define TS_ADD(f) { unsigned long long _n = __builtin_readcyclecounter(); ts.f += _n - _ts; _ts = _n; }
 #define TS_INC(f) ts.f++;
@@ -174,7 +174,7 @@ struct TravStats { unsigned long long t_desc, t_leaf, t_pop, t_take; unsigned n_
 // Exact 5-NN: nanoflann.hpp:1303-1323 findNeighbors + :1433-1497 searchLevel
 // (eps = 0), one query per lane.  The recursion becomes an explicit stack that
 // reproduces nanoflann's mindistsq / dists[] values bit for bit:
-//   entry = { parent node | feat<<29 | active<<31 ,  mindistsq of the far child }
+//   entry = { parent node | far side<<28 | feat<<29 | active<<31 ,  mindistsq of the far child }
 // * A far child is only pushed if its mindistsq is <= the current worst distance:
 //   the worst distance never grows, so an entry failing the test now would also
 //   fail nanoflann's test (:1487) when the recursion returns -- same visits.
@@ -193,6 +193,9 @@ struct TravStats { unsigned long long t_desc, t_leaf, t_pop, t_take; unsigned n_
 // result (callers pad the bound by a few ulps' worth to cover the rounding of mindistsq).
 #ifndef LSLAM_POPW_SHALLOW
 #define LSLAM_POPW_SHALLOW 2
+#endif
+#ifndef LSLAM_CULL_TAKE
+#define LSLAM_CULL_TAKE 0  // 1: far subtrees are tested against their tight box before they are entered (A/B switch)
 #endif
 template <int BLOCK, bool OVF, int LDS_DEPTH>
 LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, float (&d)[5],
@@ -237,7 +240,7 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
       const float dst = feat == 0 ? ds0 : (feat == 1 ? ds1 : ds2);
       const float nm = (mind + cd) - dst;  // :1486
       if (nm <= fminf(d[4], bound)) {
-        stk.put(sp, node | (feat << 29), __float_as_uint(nm));
+        stk.put(sp, node | (left ? (1u << 28) : 0u) | (feat << 29), __float_as_uint(nm));
         ++sp;
       }
       ref = left ? nd.c1 : nd.c2;
@@ -351,10 +354,51 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
       }
     }
     TS_ADD(t_pop)
+#if LSLAM_CULL_TAKE
+    // A/B switch, measured SLOWER (6.70e9 against 7.02e9 point-residuals/s on the bench workload) and off by default:
+    // the far subtree's TIGHT box (recorded by the builder next to the node) against the current worst distance before
+    // the subtree is entered.  Every point p of the subtree has fl-dist(q,p) >= fl-dist(q,box) -- per axis
+    // |fl(q-p)| >= fl(gap) by monotonic rounding, the squares and the x->y->z sums are the same operations on termwise
+    // larger values -- so when the box is not closer than worst_dist no point below would pass nanoflann's
+    // `dist < worst_dist` (:1448), now or later: the visit would change nothing.  Only 0.5-1.2 of a query's 3 far
+    // subtrees are culled, and the box load + 14 operations in every pop round cost more than those visits.
+    while (take && T.pn) {
+      const uint32_t parent = te & 0x0FFFFFFFu;
+      const float2 *bx = reinterpret_cast<const float2 *>(&T.pn[parent].box[(te >> 28) & 1u][0]);
+      const float2 b01 = bx[0], b23 = bx[1], b45 = bx[2];  // {min x, min y} {min z, max x} {max y, max z}
+      const float gx = fmaxf(fmaxf(b01.x - qx, qx - b23.y), 0.0f);
+      const float gy = fmaxf(fmaxf(b01.y - qy, qy - b45.x), 0.0f);
+      const float gz = fmaxf(fmaxf(b23.x - qz, qz - b45.y), 0.0f);
+      float bd = gx * gx;
+      bd = bd + gy * gy;
+      bd = bd + gz * gz;
+      if (!(bd >= fminf(d[4], bound))) break;
+      TS_INC(n_cull)
+      take = false;
+      --sp;
+      while (sp > 0 && !take) {  // the pop round above, one entry at a time
+        uint32_t e, w1;
+        stk.get(sp - 1, e, w1);
+        const float m = __uint_as_float(w1);
+        const uint32_t feat = (e >> 29) & 3u;
+        const bool act = (e & 0x80000000u) != 0;
+        if (act) {
+          ds0 = feat == 0 ? m : ds0;
+          ds1 = feat == 1 ? m : ds1;
+          ds2 = feat == 2 ? m : ds2;
+          --sp;
+        } else if (m <= fminf(d[4], bound)) {
+          te = e; tm = m; take = true;
+        } else {
+          --sp;
+        }
+      }
+    }
+#endif
     if (!take) break;
     {
       TS_INC(n_take)
-      const uint32_t parent = te & 0x1FFFFFFFu;
+      const uint32_t parent = te & 0x0FFFFFFFu;
       const uint32_t feat = (te >> 29) & 3u;
       const KdNode pn = T.nodes[parent];
       const float val = feat == 0 ? qx : (feat == 1 ? qy : qz);

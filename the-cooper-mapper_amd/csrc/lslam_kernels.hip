@@ -179,6 +179,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
       T = (is_surf ? a.gs.trees : a.gc.trees)[searched ? tree : 0];
     } else {  // block-uniform choice of tree
       T.nodes = is_surf ? a.ts.nodes : a.tc.nodes;
+      T.pn = is_surf ? a.ts.pn : a.tc.pn;
       T.pts = is_surf ? a.ts.pts : a.tc.pts;
       T.n_pts = is_surf ? a.ts.n_pts : a.tc.n_pts;
       T.n_nodes = is_surf ? a.ts.n_nodes : a.tc.n_nodes;
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
     }
     if (a.dbg) {  // per-lane stats: [N][8] after the per-wave stamps
       uint64_t *o = a.dbg + (size_t)a.nb_total * NWAVE * 4 + ((size_t)lb * BLOCK + tid) * 8;
-      o[0] = ts.t_desc; o[1] = ts.t_leaf; o[2] = ts.t_pop; o[3] = ts.n_node;
+      o[0] = ts.t_desc; o[1] = ts.t_leaf; o[2] = ts.t_pop; o[3] = ts.n_node | ((uint64_t)ts.n_cull << 32);
       o[4] = ts.n_leaf | ((uint64_t)ts.n_hit << 32); o[5] = ts.n_pop | ((uint64_t)ts.n_cand << 32); o[6] = ((uint64_t)ts.n_popit << 32) | ts.n_take; o[7] = ts.t_take | (1ull << 63);
     }
 #else

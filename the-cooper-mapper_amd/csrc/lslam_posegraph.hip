@@ -788,6 +788,628 @@ __global__ void pgc_prolong_kernel(CoarseArgs c, double *z) {
   z[row] += s;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The whole PCG solve in ONE persistent launch.  The multi-launch loop above spends a PCG iteration on four small
+// dependent launches (~25-30 us: each kernel ramps up, reads its operands from L2 / Infinity Cache and drains; section 6
+// of DESIGN.md); here one workgroup per AGGREGATE stays resident for the whole solve and keeps everything that does not
+// change between iterations on chip -- its rows' matrix items in registers (6 doubles per (entry, row) item, PK_KREG
+// items per thread), its rows of the block-Jacobi inverses and of P, in LDS its six rows of the coarse inverse -- and its
+// rows' x, r, p, q in registers as well, so an iteration only moves the vectors other workgroups need and synchronises
+// the grid TWICE:
+//
+//   phase 1   (exchange A: r.z / r.r partials and the columns' z of the previous phase 2)  beta -- every workgroup sums
+//             the same partials in the same order: identical decisions everywhere, convergence included;  columns
+//             p = z + beta p_old into LDS;  products of the workgroup's items, row sums q = (A p)[rows] in entry order;
+//             publishes its partial p.q and the RESTRICTED q, P^T q
+//   phase 2   (exchange B: p.q partials and P^T q of every aggregate)  alpha;  x += alpha p, r -= alpha q;  z = M^-1 r
+//             with the block-Jacobi part local and the coarse part from  r_c(new) = r_c(old) - alpha P^T q  for ALL
+//             aggregates (the same vector in every workgroup, so M^-1 is one symmetric operator; r_c(old) is the exact
+//             restriction its owner published one iteration ago, so the recurrence never runs longer than one step), its own
+//             six rows of A_c^-1 r_c, prolonged to its rows;  publishes z, the exact restriction of its new residual and
+//             the partials r.z, r.r
+//
+// An exchange is barrier and data in one: what other workgroups read travels through relaxed agent-scope atomic stores /
+// loads (written through to, and read from, the device's coherence point -- no cache write-back / invalidate: an acquire
+// at agent scope empties the XCD's L2, after which every operand of the next phase, register spills included, came from
+// the fabric: tools/ubench_gridbar.hip, 6.2 us per counter barrier with a published value against 2.7 us without the
+// cache maintenance), and the values a phase waits for live in slots that hold a SENTINEL (a NaN payload no computation
+// produces) until their owner publishes them: a reader polls the slots themselves, one round trip when everybody is
+// on time, instead of a counter barrier (136 serialised atomics) followed by the loads.  Slots are double-buffered by
+// iteration parity and reset by their owner one exchange after everybody has read them (a workgroup that has published
+// exchange j+1 has finished reading exchange j); values that are not polled (p, the exact r_c) are complete before the
+// polled ones are stored (s_waitcnt + workgroup barrier), so whoever sees the latter can read the former.
+//
+// Every sum has a fixed order: the solve is bit-reproducible and identical on every rank of a sharded run.  A spin limit
+// raises an abort flag instead of hanging.  Used when the graph fits (one workgroup per aggregate co-resident, LDS for
+// its columns and items); otherwise the multi-launch loop runs.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int PK_BLOCK = 512;
+constexpr int PK_W = PK_BLOCK / 64;
+constexpr int PK_KREG = 9;   // matrix items per thread kept in registers (more are streamed from memory)
+constexpr int PK_CM = 3;     // column values per thread whose p_old is fetched ahead of the poll
+constexpr unsigned PK_SPIN_LIMIT = 1u << 20;
+constexpr unsigned PK_SENT32 = 0xFFF8DEADu;  // both halves of the sentinel double (hipMemsetD32)
+constexpr long long PK_SENT = (long long)(((unsigned long long)PK_SENT32 << 32) | PK_SENT32);
+
+struct PkArgs {
+  const double *vals, *minv, *b;
+  double *x, *p0, *p1;
+  const int32_t *agg_ptr, *agg_mem;     // aggregate -> member vertices
+  const int32_t *bent_ptr, *bent, *blc; // aggregate -> its rows' entries (global entry id, local column), member by member
+  const int32_t *bmptr;                 // per aggregate nm + 1 offsets: member -> its first local entry
+  const int32_t *bcol_ptr, *bcol;       // aggregate -> the vertices its entries' columns refer to
+  const double *P, *Ainv;
+  double *rc0, *rc1;                    // exact restricted residual, by iteration parity
+  double *zA, *rzA, *rrA;               // exchange A slots: [2][n6], [2][n_agg], [2][n_agg]
+  double *pqB, *qcB;                    // exchange B slots: [2][n_agg], [2][n_c]
+  double *scal;
+  unsigned *bar;                        // [0] arrivals of the set-up barrier  [1] abort flag
+  size_t n_items;
+  int n6, n_agg, n_c, coarse, max_iter, lds_cols, lds_items;
+  double tol2;
+};
+
+#ifdef LSLAM_PK_CLOCKS  // profiling build: where an iteration of the persistent kernel spends its time (workgroup 0)
+#define PK_T(i) { const unsigned long long _n = wall_clock64(); pk_t[i] += _n - pk_last; pk_last = _n; }
+#else
+#define PK_T(i)
+#endif
+PG_DEV double pk_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+PG_DEV void pk_st(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+PG_DEV bool pk_is_sent(double v) { return __double_as_longlong(v) == PK_SENT; }
+PG_DEV double pk_sent() { return __longlong_as_double(PK_SENT); }
+PG_DEV bool pk_aborted(unsigned *bar) { return __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u; }
+PG_DEV void pk_abort(unsigned *bar) { __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// counter barrier of the set-up (once per solve)
+PG_DEV bool pk_grid_barrier(unsigned *bar, unsigned target, int *ok_lds) {
+  __builtin_amdgcn_s_waitcnt(0);  // this wavefront's published values are at the coherence point
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    int good = 1;
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      ++spins;
+      if ((spins & 1023u) == 0 && (spins > PK_SPIN_LIMIT || pk_aborted(bar))) {
+        pk_abort(bar);
+        good = 0;
+        break;
+      }
+    }
+    *ok_lds = good;
+  }
+  __syncthreads();
+  return *ok_lds != 0;
+}
+
+// Sums of up to eight per-thread values over the workgroup, fixed order, every thread ends with the totals.  Inside a
+// wavefront a butterfly that HALVES the values it carries at each of its first three steps: partners lane ^ 1 split the
+// eight values (the even lane adds both lanes' first four, the odd lane the last four), lane ^ 2 split the four, lane ^ 4
+// the two -- 4 + 2 + 1 additions instead of 3 x 8 -- then lane ^ 8, ^ 16, ^ 32 on the one value left: lane l ends with the
+// wavefront's sum of value 4 (l & 1) + 2 (l >> 1 & 1) + (l >> 2 & 1).  The moves are DPP quad permutes, ds_swizzle and one
+// ds_bpermute; the eight wavefronts' sums meet in LDS and are added by a second, three-step butterfly.
+// (__shfl_xor on doubles is two ds_bpermute round trips per step and value: 3 us for seven values.)
+template <int CTRL>
+PG_DEV double pk_dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int PATTERN>
+PG_DEV double pk_swz(double v) {  // ds_swizzle, bit mode: lane ^ (PATTERN >> 10) inside each half of the wavefront
+  return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), PATTERN), __builtin_amdgcn_ds_swizzle(__double2loint(v), PATTERN));
+}
+template <int M>
+PG_DEV void pk_reduce(double (&v)[M], double *sh) {
+  static_assert(M <= 8, "at most eight values");
+  const int lane = threadIdx.x & 63;
+  double t8[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) t8[m] = m < M ? v[m] : 0.0;
+  double t4[4], t2[2], t;
+  {
+    const bool hi = (lane & 1) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t4[i] = (hi ? t8[4 + i] : t8[i]) + pk_dpp<0xB1>(hi ? t8[i] : t8[4 + i]);  // quad_perm [1,0,3,2]
+  }
+  {
+    const bool hi = (lane & 2) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) t2[i] = (hi ? t4[2 + i] : t4[i]) + pk_dpp<0x4E>(hi ? t4[i] : t4[2 + i]);  // quad_perm [2,3,0,1]
+  }
+  {
+    const bool hi = (lane & 4) != 0;
+    t = (hi ? t2[1] : t2[0]) + pk_swz<0x101F>(hi ? t2[0] : t2[1]);  // lane ^ 4
+  }
+  t += pk_swz<0x201F>(t);  // lane ^ 8
+  t += pk_swz<0x401F>(t);  // lane ^ 16
+  t += __shfl_xor(t, 32);  // lane ^ 32
+  if (lane < 8) sh[(4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1)) * PK_W + (threadIdx.x >> 6)] = t;
+  __syncthreads();
+  // lane l takes the sum of wavefront l & 7 for value l >> 3; three butterfly steps over the wavefront index leave every
+  // lane of the group with the value's total, broadcast from lane 8 m
+  static_assert(PK_W == 8, "eight wavefronts");
+  double u = sh[lane];
+  u += pk_dpp<0xB1>(u);
+  u += pk_dpp<0x4E>(u);
+  u += pk_swz<0x101F>(u);
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+    v[m] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(u), 8 * m), __builtin_amdgcn_readlane(__double2loint(u), 8 * m));
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(PK_BLOCK) void pg_pcg_persistent_kernel(PkArgs a) {
+  extern __shared__ double pk_lds[];
+  double *pf = pk_lds;                           // [lds_cols * 6] the columns' p
+  double *dl = pf + (size_t)a.lds_cols * 6;      // [lds_items] products
+  double *rloc = dl + a.lds_items;               // [384] residuals of the rows
+  double *rcs = rloc + 384;                      // [n_c] restricted residual
+  double *ainv = rcs + a.n_c;                    // [6 * n_c] this aggregate's rows of the coarse inverse
+  double *sh = ainv + 6 * (size_t)a.n_c;         // [8 * PK_W] wavefront sums
+  __shared__ int bar_ok;
+  const int ag = blockIdx.x, tid = threadIdx.x;
+  const int m0 = a.agg_ptr[ag], nm = a.agg_ptr[ag + 1] - m0, nrow = nm * 6;
+  const int e0 = a.bent_ptr[ag], nit = (a.bent_ptr[ag + 1] - e0) * 6;
+  const int c0 = a.bcol_ptr[ag], ncol6 = (a.bcol_ptr[ag + 1] - c0) * 6;
+  const bool coarse = a.coarse != 0;
+
+  // ---- what stays on chip for the whole solve ----
+  double A[PK_KREG][6];
+  int lcol[PK_KREG];
+#pragma unroll
+  for (int j = 0; j < PK_KREG; ++j) {
+    const int i = tid + PK_BLOCK * j;
+    const bool on = i < nit;
+    const int le = on ? i / 6 : 0, r = on ? i - le * 6 : 0;
+    const int e = on ? a.bent[e0 + le] : 0;
+    lcol[j] = on ? a.blc[e0 + le] * 6 : 0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) A[j][c] = on ? a.vals[(size_t)c * a.n_items + (size_t)e * 6 + r] : 0.0;
+  }
+  const bool isrow = tid < nrow;
+  const int jm = tid / 6, rr = tid - jm * 6;
+  const int v = isrow ? a.agg_mem[m0 + jm] : 0;
+  const int row = v * 6 + rr;
+  double mi[6], Pr[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    mi[c] = isrow ? a.minv[(size_t)v * 36 + rr * 6 + c] : 0.0;
+    Pr[c] = (isrow && coarse) ? a.P[(size_t)v * 36 + rr * 6 + c] : 0.0;
+  }
+  const int le_b = isrow ? a.bmptr[m0 + ag + jm] : 0, le_e = isrow ? a.bmptr[m0 + ag + jm + 1] : 0;
+  size_t gcol[PK_CM];  // the global (vertex, component) of the column values this thread fetches
+#pragma unroll
+  for (int j = 0; j < PK_CM; ++j) {
+    const int i = tid + PK_BLOCK * j;
+    const int ci = i < ncol6 ? i / 6 : 0;
+    gcol[j] = i < ncol6 ? (size_t)a.bcol[c0 + ci] * 6 + (i - ci * 6) : 0;
+  }
+  if (coarse)
+    for (int i = tid; i < 6 * a.n_c; i += PK_BLOCK) ainv[i] = a.Ainv[(size_t)ag * 6 * a.n_c + i];
+  // y = this aggregate's six rows of A_c^-1 times rcs (both in LDS); every thread ends with the six sums
+  auto coarse_rows = [&](double (&s)[6]) {
+#pragma unroll
+    for (int m = 0; m < 6; ++m) s[m] = 0.0;
+    for (int col = tid; col < a.n_c; col += PK_BLOCK) {
+      const double rcv = rcs[col];
+#pragma unroll
+      for (int m = 0; m < 6; ++m) s[m] += ainv[m * a.n_c + col] * rcv;
+    }
+    pk_reduce<6>(s, sh);
+  };
+
+  // ---- x = 0, r = b, z = M^-1 r ----
+  double x = 0.0, r = isrow ? a.b[row] : 0.0, q = 0.0, p_own = 0.0, z_own = 0.0;
+  if (tid < 384) rloc[tid] = r;
+  __syncthreads();
+  {
+    double zj = 0.0;
+    if (isrow) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) zj += mi[c] * rloc[jm * 6 + c];
+    }
+    z_own = zj;
+  }
+  if (coarse) {
+    double w[6];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) w[m] = Pr[m] * r;
+    pk_reduce<6>(w, sh);
+    if (tid == 0) {
+#pragma unroll
+      for (int m = 0; m < 6; ++m) pk_st(a.rc0 + ag * 6 + m, w[m]);
+    }
+    if (!pk_grid_barrier(a.bar, gridDim.x, &bar_ok)) return;
+    for (int col = tid; col < a.n_c; col += PK_BLOCK) rcs[col] = pk_ld(a.rc0 + col);
+    __syncthreads();
+    double y[6];
+    coarse_rows(y);
+#pragma unroll
+    for (int m = 0; m < 6; ++m) z_own += Pr[m] * y[m];
+  }
+  {  // exchange A of iteration 0
+    if (isrow) pk_st(a.zA + row, z_own);
+    double o[2] = {r * z_own, r * r};
+    pk_reduce<2>(o, sh);
+    if (tid == 0) {
+      pk_st(a.rzA + ag, o[0]);
+      pk_st(a.rrA + ag, o[1]);
+    }
+  }
+
+  double rz_old = 0.0, bb = 0.0, rr_last = 0.0;
+  int k = 0, done = 0;
+#ifdef LSLAM_PK_CLOCKS
+  unsigned long long pk_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pk_last = wall_clock64();
+#endif
+  for (;;) {
+    const int g = k & 1;
+    // ---- phase 1: exchange A ----
+    const double *po = g ? a.p0 : a.p1;  // p of iteration k - 1 (complete: published before exchange B of k - 1)
+    double *pn = g ? a.p1 : a.p0;
+    double ppv[PK_CM];
+#pragma unroll
+    for (int j = 0; j < PK_CM; ++j) ppv[j] = (k > 0 && tid + PK_BLOCK * j < ncol6) ? pk_ld(po + gcol[j]) : 0.0;
+    double S[2];
+    {
+      const double *zg = a.zA + (size_t)g * a.n6, *rzg = a.rzA + g * a.n_agg, *rrg = a.rrA + g * a.n_agg;
+      for (unsigned spins = 0;; ++spins) {
+        int bad = 0;
+        S[0] = S[1] = 0.0;
+        if (tid < a.n_agg) {
+          S[0] = pk_ld(rzg + tid);
+          S[1] = pk_ld(rrg + tid);
+          bad |= (pk_is_sent(S[0]) || pk_is_sent(S[1])) ? 1 : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < PK_CM; ++j) {
+          const int i = tid + PK_BLOCK * j;
+          if (i < ncol6) {
+            const double zz = pk_ld(zg + gcol[j]);
+            pf[i] = zz;
+            bad |= pk_is_sent(zz) ? 1 : 0;
+          }
+        }
+        for (int i = tid + PK_BLOCK * PK_CM; i < ncol6; i += PK_BLOCK) {
+          const int ci = i / 6;
+          const double zz = pk_ld(zg + (size_t)a.bcol[c0 + ci] * 6 + (i - ci * 6));
+          pf[i] = zz;
+          bad |= pk_is_sent(zz) ? 1 : 0;
+        }
+        if (!__syncthreads_or(bad)) break;
+        if ((spins & 255u) == 255u && (spins > PK_SPIN_LIMIT || pk_aborted(a.bar))) {
+          pk_abort(a.bar);
+          return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    if (k > 0 && tid == 0) {  // everybody has read exchange B of iteration k - 1: its slots are free again
+      double *pq = a.pqB + (g ^ 1) * a.n_agg, *qc = a.qcB + (size_t)(g ^ 1) * a.n_c;
+      pk_st(pq + ag, pk_sent());
+#pragma unroll
+      for (int m = 0; m < 6; ++m) pk_st(qc + ag * 6 + m, pk_sent());
+    }
+    pk_reduce<2>(S, sh);
+    PK_T(0)
+    if (k == 0) bb = S[1];
+    rr_last = S[1];
+    if (S[1] <= a.tol2 * bb || !(S[0] > 0.0)) {
+      done = 1;
+      break;
+    }
+    if (k >= a.max_iter) break;
+    const double beta = k > 0 ? S[0] / rz_old : 0.0;
+#pragma unroll
+    for (int j = 0; j < PK_CM; ++j) {
+      const int i = tid + PK_BLOCK * j;
+      if (i < ncol6) pf[i] += beta * ppv[j];
+    }
+    if (k > 0)
+      for (int i = tid + PK_BLOCK * PK_CM; i < ncol6; i += PK_BLOCK) {
+        const int ci = i / 6;
+        pf[i] += beta * pk_ld(po + (size_t)a.bcol[c0 + ci] * 6 + (i - ci * 6));
+      }
+    if (isrow) {
+      p_own = z_own + beta * p_own;
+      pk_st(pn + row, p_own);
+    }
+    __syncthreads();
+    PK_T(1)
+#pragma unroll
+    for (int j = 0; j < PK_KREG; ++j) {
+      const int i = tid + PK_BLOCK * j;
+      if (i < nit) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s += A[j][c] * pf[lcol[j] + c];
+        dl[i] = s;
+      }
+      if (j & 1) __builtin_amdgcn_sched_barrier(0);  // two items' operands in flight, not all of them (register pressure)
+    }
+    for (int i = tid + PK_BLOCK * PK_KREG; i < nit; i += PK_BLOCK) {  // an aggregate with more items than the registers hold
+      const int le = i / 6, rw = i - le * 6;
+      const int e = a.bent[e0 + le], lc = a.blc[e0 + le] * 6;
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) s += a.vals[(size_t)c * a.n_items + (size_t)e * 6 + rw] * pf[lc + c];
+      dl[i] = s;
+    }
+    __syncthreads();
+    PK_T(2)
+    q = 0.0;
+    for (int le = le_b; le < le_e; ++le) q += dl[le * 6 + rr];
+    {
+      double w[7];
+#pragma unroll
+      for (int m = 0; m < 6; ++m) w[m] = Pr[m] * q;
+      w[6] = p_own * q;
+      pk_reduce<7>(w, sh);  // (its workgroup barrier: every wavefront's p is at the coherence point before the slots are filled)
+      if (tid == 0) {
+        double *qc = a.qcB + (size_t)g * a.n_c;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) pk_st(qc + ag * 6 + m, w[m]);
+        pk_st(a.pqB + g * a.n_agg + ag, w[6]);
+      }
+    }
+    PK_T(3)
+    // ---- phase 2: exchange B ----
+    const double *rco = g ? a.rc1 : a.rc0;  // exact r_c entering this iteration (complete: published before exchange A)
+    double rcv[2] = {0.0, 0.0}, qcv[2] = {0.0, 0.0};
+    if (coarse) {
+#pragma unroll
+      for (int jc = 0; jc < 2; ++jc) {
+        const int col = tid + PK_BLOCK * jc;
+        if (col < a.n_c) rcv[jc] = pk_ld(rco + col);
+      }
+    }
+    double Spq[1];
+    {
+      const double *pq = a.pqB + g * a.n_agg, *qc = a.qcB + (size_t)g * a.n_c;
+      for (unsigned spins = 0;; ++spins) {
+        int bad = 0;
+        Spq[0] = 0.0;
+        if (tid < a.n_agg) {
+          Spq[0] = pk_ld(pq + tid);
+          bad |= pk_is_sent(Spq[0]) ? 1 : 0;
+        }
+        if (coarse) {
+#pragma unroll
+          for (int jc = 0; jc < 2; ++jc) {
+            const int col = tid + PK_BLOCK * jc;
+            if (col < a.n_c) {
+              qcv[jc] = pk_ld(qc + col);
+              bad |= pk_is_sent(qcv[jc]) ? 1 : 0;
+            }
+          }
+          for (int col = tid + 2 * PK_BLOCK; col < a.n_c; col += PK_BLOCK) {
+            const double t = pk_ld(qc + col);
+            rcs[col] = t;
+            bad |= pk_is_sent(t) ? 1 : 0;
+          }
+        }
+        if (!__syncthreads_or(bad)) break;
+        if ((spins & 255u) == 255u && (spins > PK_SPIN_LIMIT || pk_aborted(a.bar))) {
+          pk_abort(a.bar);
+          return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    PK_T(4)
+    {  // everybody has read exchange A of this iteration: its slots are free again
+      double *zg = a.zA + (size_t)g * a.n6;
+      if (isrow) pk_st(zg + row, pk_sent());
+      if (tid == 0) {
+        pk_st(a.rzA + g * a.n_agg + ag, pk_sent());
+        pk_st(a.rrA + g * a.n_agg + ag, pk_sent());
+      }
+    }
+    pk_reduce<1>(Spq, sh);
+    PK_T(5)
+    const double alpha = S[0] / Spq[0];
+    x += alpha * p_own;
+    r -= alpha * q;
+    if (tid < 384) rloc[tid] = r;
+    if (coarse) {
+#pragma unroll
+      for (int jc = 0; jc < 2; ++jc) {
+        const int col = tid + PK_BLOCK * jc;
+        if (col < a.n_c) rcs[col] = rcv[jc] - alpha * qcv[jc];
+      }
+      for (int col = tid + 2 * PK_BLOCK; col < a.n_c; col += PK_BLOCK) rcs[col] = pk_ld(rco + col) - alpha * rcs[col];
+    }
+    __syncthreads();
+    PK_T(6)
+    {
+      double zj = 0.0;
+      if (isrow) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) zj += mi[c] * rloc[jm * 6 + c];
+      }
+      z_own = zj;
+    }
+    if (coarse) {
+      double y[6];
+      coarse_rows(y);
+#pragma unroll
+      for (int m = 0; m < 6; ++m) z_own += Pr[m] * y[m];
+    }
+    PK_T(7)
+    if (isrow) pk_st(a.zA + (size_t)(g ^ 1) * a.n6 + row, z_own);  // exchange A of iteration k + 1
+    {
+      double o[8];
+#pragma unroll
+      for (int m = 0; m < 6; ++m) o[m] = Pr[m] * r;
+      o[6] = r * z_own;
+      o[7] = r * r;
+      pk_reduce<8>(o, sh);
+      if (tid == 0) {
+        double *rcn = g ? a.rc0 : a.rc1;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) pk_st(rcn + ag * 6 + m, o[m]);
+        // (the exact r_c is read after exchange B of the next iteration, which this workgroup publishes several workgroup
+        // barriers from here: complete by then)
+        pk_st(a.rzA + (g ^ 1) * a.n_agg + ag, o[6]);
+        pk_st(a.rrA + (g ^ 1) * a.n_agg + ag, o[7]);
+      }
+    }
+    rz_old = S[0];
+    PK_T(8)
+    ++k;
+  }
+  if (isrow) a.x[row] = x;
+  if (ag == 0 && tid == 0) {
+    a.scal[3] = rr_last;
+    a.scal[4] = bb;
+    a.scal[5] = done ? 1.0 : 0.0;
+    a.scal[6] = (double)k;
+#ifdef LSLAM_PK_CLOCKS
+    for (int i = 0; i < 12; ++i) a.scal[8 + i] += (double)pk_t[i];  // 100 MHz ticks, accumulated over the solves
+#endif
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// The coarse inverse in ONE persistent launch.  The two-launch-per-pivot loop above (pgc_gj_pivot_kernel: one workgroup,
+// a serial 6 x 6 inverse, 29 us; pgc_gj_update_kernel: 7 us) costs 136 x 36 us = 4.9 ms per inverse on the bench graph,
+// a quarter of the whole LM run once the PCG iterations are fused.  Here workgroup i owns block row i of the matrix
+// (6 x n_c doubles, in registers, GJ_CREG columns per thread) for the whole elimination.  At step k the pivot's owner
+// inverts A_kk (36 lanes, in-place Gauss-Jordan in LDS; the pivot blocks of an SPD matrix need no pivoting), scales its
+// row, R = A_kk^-1 A_k*, and publishes it -- with A_kk^-1 itself in the pivot's own columns -- into slot k of a buffer
+// that holds a sentinel until then; every other workgroup polls that slot for its own columns (barrier and data in one
+// round trip, as in pg_pcg_persistent_kernel) and updates its row:  A_i* <- A_i* - A_ik R  (its pivot columns: -A_ik A_kk^-1).
+// Same arithmetic as the launch-per-pivot form up to the 6 x 6 inverse's pivoting.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int GJ_BLOCK = 512;
+constexpr int GJ_CREG = 4;
+struct GjArgs {
+  double *Ac;      // [n_c][n_c], inverted in place
+  double *slots;   // [na][6][n_c], sentinel-filled
+  unsigned *bar;   // [1] abort flag
+  int n_c, na;
+};
+__global__ __launch_bounds__(GJ_BLOCK) void pgc_gj_persistent_kernel(GjArgs g) {
+  __shared__ double Cb[36];
+  __shared__ double Mb[36];
+  const int i = blockIdx.x, tid = threadIdx.x, n = g.n_c;
+  double A[GJ_CREG][6];
+#pragma unroll
+  for (int jc = 0; jc < GJ_CREG; ++jc) {
+    const int col = tid + GJ_BLOCK * jc;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) A[jc][r] = col < n ? g.Ac[(size_t)(i * 6 + r) * n + col] : 0.0;
+  }
+  for (int k = 0; k < g.na; ++k) {
+    const int k6 = k * 6;
+    double *slot = g.slots + (size_t)k * 6 * n;
+    if (i == k) {
+#pragma unroll
+      for (int jc = 0; jc < GJ_CREG; ++jc) {
+        const int col = tid + GJ_BLOCK * jc;
+        if (col >= k6 && col < k6 + 6) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) Mb[r * 6 + (col - k6)] = A[jc][r];
+        }
+      }
+      __syncthreads();
+      if (tid < 64) {  // in-place Gauss-Jordan on the 6 x 6 block, one lane per element (LDS serves a wavefront's accesses in order)
+        volatile double *M = Mb;
+        const int r = tid / 6, c = tid - r * 6;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+          double nv = 0.0;
+          if (tid < 36) {
+            const double inv = 1.0 / M[p * 6 + p];
+            const double mpc = M[p * 6 + c], mrp = M[r * 6 + p], mrc = M[r * 6 + c];
+            if (r == p) nv = (c == p) ? inv : mpc * inv;
+            else nv = (c == p) ? -(mrp * inv) : mrc - mrp * (mpc * inv);
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (tid < 36) M[tid] = nv;
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int jc = 0; jc < GJ_CREG; ++jc) {
+        const int col = tid + GJ_BLOCK * jc;
+        if (col < n) {
+          const bool ink = col >= k6 && col < k6 + 6;
+          double Rv[6];
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) t += Mb[r * 6 + q] * A[jc][q];
+            Rv[r] = ink ? Mb[r * 6 + (col - k6)] : t;
+          }
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            A[jc][r] = Rv[r];
+            pk_st(slot + (size_t)r * n + col, Rv[r]);
+          }
+        }
+      }
+      __syncthreads();
+    } else {
+#pragma unroll
+      for (int jc = 0; jc < GJ_CREG; ++jc) {
+        const int col = tid + GJ_BLOCK * jc;
+        if (col >= k6 && col < k6 + 6) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) Cb[r * 6 + (col - k6)] = A[jc][r];
+        }
+      }
+      double Rv[GJ_CREG][6];
+      for (unsigned spins = 0;; ++spins) {
+        int bad = 0;
+#pragma unroll
+        for (int jc = 0; jc < GJ_CREG; ++jc) {
+          const int col = tid + GJ_BLOCK * jc;
+#pragma unroll
+          for (int m = 0; m < 6; ++m) {
+            Rv[jc][m] = col < n ? pk_ld(slot + (size_t)m * n + col) : 0.0;
+            bad |= pk_is_sent(Rv[jc][m]) ? 1 : 0;
+          }
+        }
+        if (!__syncthreads_or(bad)) break;  // (its barrier also makes Cb visible)
+        if ((spins & 255u) == 255u && (spins > PK_SPIN_LIMIT || pk_aborted(g.bar))) {
+          pk_abort(g.bar);
+          return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int jc = 0; jc < GJ_CREG; ++jc) {
+        const int col = tid + GJ_BLOCK * jc;
+        const bool ink = col >= k6 && col < k6 + 6;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          double t = 0.0;
+#pragma unroll
+          for (int m = 0; m < 6; ++m) t += Cb[r * 6 + m] * Rv[jc][m];
+          A[jc][r] = (ink ? 0.0 : A[jc][r]) - t;
+        }
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int jc = 0; jc < GJ_CREG; ++jc) {
+    const int col = tid + GJ_BLOCK * jc;
+    if (col < n) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) g.Ac[(size_t)(i * 6 + r) * n + col] = A[jc][r];
+    }
+  }
+}
+
 // X <- X * fromVectorMQT(dx)
 __global__ void pg_update_kernel(const double *src, const double *dx, int n_v, int fixed, double *dst) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -907,6 +1529,16 @@ struct lslam_pg {
   double coarse_lambda = 0.0;
   int coarse_fresh_iters = 0, coarse_last_iters = 0;
   int coarse_setups = 0;
+  // persistent PCG kernel (pg_pcg_persistent_kernel): per-aggregate entry / column lists, its buffers, whether the graph fits
+  int32_t *d_bent_ptr = nullptr, *d_bent = nullptr, *d_blc = nullptr, *d_bmptr = nullptr, *d_bcol_ptr = nullptr, *d_bcol = nullptr;
+  double *d_pk = nullptr;      // [rc0 | rc1] then the exchange slots of pg_pcg_persistent_kernel
+  unsigned *d_bar = nullptr;
+  int pk_lds_cols = 0, pk_lds_items = 0;
+  size_t pk_lds_bytes = 0;
+  double *d_gjslots = nullptr; // pgc_gj_persistent_kernel's pivot-row slots [n_agg][6][n_c]
+  int gj_fit = -1;             // as pk_fit, for the coarse inverse
+  int pk_fit = -1;             // -1 not decided yet, 0 the multi-launch loop, 1 the persistent kernel
+  int fused_solves = 0, total_solves = 0;
   size_t sys_doubles() const { return (size_t)n_v * 36 + (size_t)n_off * 36 + (size_t)n_v * 6 + 1; }
   double *diag() const { return d_sys; }
   double *off() const { return d_sys + (size_t)n_v * 36; }
@@ -1048,9 +1680,30 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
     hipLaunchKernelGGL(pgc_P_kernel, dim3((pg->n_v + 127) / 128), dim3(128), 0, pg->stream, c);
     PG_TRY(hipMemsetAsync(c.Ac, 0, nn * sizeof(double), pg->stream));
     hipLaunchKernelGGL(pgc_assemble_kernel, dim3(c.n_cb), dim3(64), 0, pg->stream, c, pg->d_vals, pg->d_row_of, pg->d_row_col, n_items);
+    if (pg->gj_fit < 0) {  // the persistent inverse when a workgroup per aggregate is co-resident and the row fits its registers
+      pg->gj_fit = 0;
+      static const bool off = std::getenv("LSLAM_PG_PERSISTENT") && std::atoi(std::getenv("LSLAM_PG_PERSISTENT")) == 0;
+      hipDeviceProp_t prop;
+      int per_cu = 0;
+      if (!off && c.n_c <= GJ_CREG * GJ_BLOCK && hipGetDeviceProperties(&prop, pg->device) == hipSuccess &&
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pgc_gj_persistent_kernel, GJ_BLOCK, 0) == hipSuccess &&
+          (long)per_cu * prop.multiProcessorCount >= c.na &&
+          hipMalloc((void **)&pg->d_gjslots, (size_t)c.na * 6 * c.n_c * sizeof(double)) == hipSuccess)
+        pg->gj_fit = 1;
+      (void)hipGetLastError();
+    }
+    if (pg->gj_fit == 1) {
+      GjArgs gj;
+      gj.Ac = c.Ac; gj.slots = pg->d_gjslots; gj.bar = pg->d_bar; gj.n_c = c.n_c; gj.na = c.na;
+      PG_TRY(hipMemsetAsync(pg->d_bar, 0, 2 * sizeof(unsigned), pg->stream));
+      PG_TRY(hipMemsetD32Async((hipDeviceptr_t)pg->d_gjslots, (int)PK_SENT32, (size_t)c.na * 6 * c.n_c * 2, pg->stream));
+      void *gargs[] = {(void *)&gj};
+      PG_TRY(hipLaunchCooperativeKernel((const void *)pgc_gj_persistent_kernel, dim3((unsigned)c.na), dim3(GJ_BLOCK), gargs, 0, pg->stream));
+    } else {
     for (int k = 0; k < c.na; ++k) {
       hipLaunchKernelGGL(pgc_gj_pivot_kernel, dim3(1), dim3(256), 0, pg->stream, c, k);
       hipLaunchKernelGGL(pgc_gj_update_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, pg->stream, c, k);
+    }
     }
     PG_TRY(hipGetLastError());
     pg->coarse_valid = true;
@@ -1059,6 +1712,63 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
     pg->coarse_setups++;
     }
     pg->coarse_solves++;
+  }
+  // The persistent kernel when the graph fits: one workgroup per aggregate, all co-resident, LDS for its columns / items.
+  if (pg->pk_fit < 0) {
+    pg->pk_fit = 0;
+    static const bool off = std::getenv("LSLAM_PG_PERSISTENT") && std::atoi(std::getenv("LSLAM_PG_PERSISTENT")) == 0;
+    hipDeviceProp_t prop;
+    int per_cu = 0;
+    if (!off && pg->pk_lds_bytes <= 150 * 1024 && hipGetDeviceProperties(&prop, pg->device) == hipSuccess &&
+        hipFuncSetAttribute((const void *)pg_pcg_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)pg->pk_lds_bytes) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pg_pcg_persistent_kernel, PK_BLOCK, pg->pk_lds_bytes) == hipSuccess &&
+        (long)per_cu * prop.multiProcessorCount >= pg->n_agg)
+      pg->pk_fit = 1;
+    (void)hipGetLastError();
+  }
+  pg->total_solves++;
+  if (pg->pk_fit == 1) {
+    PkArgs k;
+    k.vals = pg->d_vals; k.minv = pg->d_minv; k.b = pg->b();
+    k.x = pg->d_x; k.p0 = pg->d_p; k.p1 = pg->d_p + n6;
+    k.agg_ptr = pg->d_agg_ptr; k.agg_mem = pg->d_agg_mem;
+    k.bent_ptr = pg->d_bent_ptr; k.bent = pg->d_bent; k.blc = pg->d_blc; k.bmptr = pg->d_bmptr;
+    k.bcol_ptr = pg->d_bcol_ptr; k.bcol = pg->d_bcol;
+    k.P = pg->d_P; k.Ainv = pg->d_Ac;
+    k.rc0 = pg->d_pk; k.rc1 = pg->d_pk + pg->n_c;
+    double *slots = pg->d_pk + 2 * (size_t)pg->n_c;
+    const size_t n_slots = 2 * (size_t)n6 + 6 * (size_t)pg->n_agg + 2 * (size_t)pg->n_c;
+    k.zA = slots; k.rzA = k.zA + 2 * (size_t)n6; k.rrA = k.rzA + 2 * pg->n_agg; k.pqB = k.rrA + 2 * pg->n_agg;
+    k.qcB = k.pqB + 2 * pg->n_agg;
+    k.scal = pg->d_scal; k.bar = pg->d_bar;
+    k.n_items = n_items;
+    k.n6 = n6; k.n_agg = pg->n_agg; k.n_c = pg->n_c; k.coarse = coarse ? 1 : 0; k.max_iter = max_cg;
+    k.lds_cols = pg->pk_lds_cols; k.lds_items = pg->pk_lds_items;
+    k.tol2 = tol * tol;
+    PG_TRY(hipMemsetAsync(pg->d_bar, 0, 2 * sizeof(unsigned), pg->stream));
+    PG_TRY(hipMemsetD32Async((hipDeviceptr_t)slots, (int)PK_SENT32, 2 * n_slots, pg->stream));
+    void *kargs[] = {(void *)&k};
+    PG_TRY(hipLaunchCooperativeKernel((const void *)pg_pcg_persistent_kernel, dim3((unsigned)pg->n_agg), dim3(PK_BLOCK), kargs,
+                                      (unsigned)pg->pk_lds_bytes, pg->stream));
+    double scal[8] = {0};
+    unsigned bar[2] = {0, 0};
+    PG_TRY(hipMemcpyAsync(scal, pg->d_scal, sizeof(scal), hipMemcpyDeviceToHost, pg->stream));
+    PG_TRY(hipMemcpyAsync(bar, pg->d_bar, sizeof(bar), hipMemcpyDeviceToHost, pg->stream));
+    PG_TRY(hipStreamSynchronize(pg->stream));
+    if (bar[1] != 0) {
+      g_pg_err = "persistent PCG kernel: grid barrier timed out";
+      return LSLAM_ERR_HIP;
+    }
+    const int done_iters = (int)scal[6];
+    *iters_out = done_iters;
+    pg->fused_solves++;
+    if (done_iters > 300) pg->coarse_on = true;
+    if (coarse) {
+      if (fresh_inverse) pg->coarse_fresh_iters = done_iters;
+      pg->coarse_last_iters = done_iters;
+    }
+    return LSLAM_OK;
   }
   auto coarse_correct = [&](int k) {  // z += P A_c^-1 P^T r and the matching share of r.z, entering iteration k + 1
     if (!coarse) return;
@@ -1207,6 +1917,50 @@ int lslam_pg_create(int device, int32_t n_v, const double *poses7, int32_t n_e, 
     PG_TRY(hipMalloc((void **)&pg->d_rc, (size_t)pg->n_c * sizeof(double)));
     PG_TRY(hipMalloc((void **)&pg->d_yc, (size_t)pg->n_c * sizeof(double)));
     PG_TRY(hipMalloc((void **)&pg->d_gj, ((size_t)12 * pg->n_c + 36) * sizeof(double)));
+    {  // the persistent PCG kernel's view: per aggregate its rows' entries member by member, and a local numbering of
+       // the column vertices those entries refer to (first appearance order)
+      std::vector<int32_t> bent_ptr(1, 0), bent, blc, bmptr, bcol_ptr(1, 0), bcol;
+      std::vector<int32_t> local((size_t)n_v, -1);
+      int max_cols = 0, max_items = 0;
+      for (int a = 0; a < pg->n_agg; ++a) {
+        const size_t cfirst = bcol.size();
+        const size_t efirst = bent.size();
+        for (int m = agg_ptr[(size_t)a]; m < agg_ptr[(size_t)a + 1]; ++m) {
+          const int u = agg_mem[(size_t)m];
+          bmptr.push_back((int32_t)(bent.size() - efirst));
+          for (int e = rptr[(size_t)u]; e < rptr[(size_t)u + 1]; ++e) {
+            const int cv = rcol[(size_t)e];
+            if (local[(size_t)cv] < 0) {
+              local[(size_t)cv] = (int32_t)(bcol.size() - cfirst);
+              bcol.push_back(cv);
+            }
+            bent.push_back(e);
+            blc.push_back(local[(size_t)cv]);
+          }
+        }
+        bmptr.push_back((int32_t)(bent.size() - efirst));
+        for (size_t c = cfirst; c < bcol.size(); ++c) local[(size_t)bcol[c]] = -1;
+        bent_ptr.push_back((int32_t)bent.size());
+        bcol_ptr.push_back((int32_t)bcol.size());
+        max_cols = std::max(max_cols, (int)(bcol.size() - cfirst));
+        max_items = std::max(max_items, 6 * (int)(bent.size() - efirst));
+      }
+      pg->pk_lds_cols = max_cols;
+      pg->pk_lds_items = max_items;
+      pg->pk_lds_bytes = ((size_t)max_cols * 6 + (size_t)max_items + 384 + 7 * (size_t)pg->n_c + 8 * PK_W) * sizeof(double);
+      if (std::getenv("LSLAM_DEBUG"))
+        fprintf(stderr, "[lslam pg] %d aggregates, widest: %d columns, %d items; persistent-kernel LDS %zu bytes\n", pg->n_agg,
+                max_cols, max_items, pg->pk_lds_bytes);
+      PG_TRY(dev_upload(&pg->d_bent_ptr, bent_ptr));
+      PG_TRY(dev_upload(&pg->d_bent, bent));
+      PG_TRY(dev_upload(&pg->d_blc, blc));
+      PG_TRY(dev_upload(&pg->d_bmptr, bmptr));
+      PG_TRY(dev_upload(&pg->d_bcol_ptr, bcol_ptr));
+      PG_TRY(dev_upload(&pg->d_bcol, bcol));
+      // [rc0 | rc1] then the sentinel-initialised slots [zA 2 n6 | rzA 2 n_agg | rrA 2 n_agg | pqB 2 n_agg | qcB 2 n_c]
+      PG_TRY(hipMalloc((void **)&pg->d_pk, (4 * (size_t)pg->n_c + 6 * (size_t)pg->n_agg + 12 * (size_t)n_v) * sizeof(double)));
+      PG_TRY(hipMalloc((void **)&pg->d_bar, 2 * sizeof(unsigned)));
+    }
   }
   std::vector<double> hp(poses7, poses7 + 7 * (size_t)n_v), hm(meas7, meas7 + 7 * (size_t)n_e),
       hi(info36, info36 + 36 * (size_t)n_e);
@@ -1230,7 +1984,8 @@ int lslam_pg_create(int device, int32_t n_v, const double *poses7, int32_t n_e, 
   PG_TRY(hipMalloc((void **)&pg->d_q, (size_t)pg->n_entries * 6 * sizeof(double)));
   PG_TRY(hipMalloc((void **)&pg->d_p, 2 * n6 * sizeof(double)));
   PG_TRY(hipMalloc((void **)&pg->d_part, (3 * (size_t)pg->n_parts + ((size_t)pg->n_entries * 6 + PROD_BLOCK - 1) / PROD_BLOCK) * sizeof(double)));
-  PG_TRY(hipMalloc((void **)&pg->d_scal, 8 * sizeof(double)));
+  PG_TRY(hipMalloc((void **)&pg->d_scal, 32 * sizeof(double)));
+  PG_TRY(hipMemset(pg->d_scal, 0, 32 * sizeof(double)));
   PG_TRY(hipMalloc((void **)&pg->d_tmp, 8 * sizeof(double)));
   int rc = build_shard(pg, 0, n_e);
   if (rc) return rc;
@@ -1249,7 +2004,9 @@ void lslam_pg_destroy(lslam_pg *pg) {
                   (void *)pg->d_P, (void *)pg->d_Ac, (void *)pg->d_rc, (void *)pg->d_yc, (void *)pg->d_gj, (void *)pg->d_cb_ptr,
                   (void *)pg->d_cb_ent, (void *)pg->d_cb_ab, (void *)pg->d_agg_of, (void *)pg->d_agg_ptr, (void *)pg->d_agg_mem,
                   (void *)pg->d_x, (void *)pg->d_r, (void *)pg->d_z, (void *)pg->d_p, (void *)pg->d_q,
-                  (void *)pg->d_part, (void *)pg->d_scal, (void *)pg->d_tmp})
+                  (void *)pg->d_part, (void *)pg->d_scal, (void *)pg->d_tmp, (void *)pg->d_bent_ptr, (void *)pg->d_bent,
+                  (void *)pg->d_blc, (void *)pg->d_bmptr, (void *)pg->d_bcol_ptr, (void *)pg->d_bcol, (void *)pg->d_pk,
+                  (void *)pg->d_bar, (void *)pg->d_gjslots})
     if (p) (void)hipFree(p);
   if (pg->own_sys && pg->d_sys) (void)hipFree(pg->d_sys);
   if (pg->stream) (void)hipStreamDestroy(pg->stream);
@@ -1308,6 +2065,14 @@ int lslam_pg_solve(lslam_pg *pg, double lambda, double *dx_out, int32_t *cg_iter
     PG_TRY(hipStreamSynchronize(pg->stream));
   }
   if (cg_iters) *cg_iters = it;
+  return LSLAM_OK;
+}
+
+// Profiling tap (-DLSLAM_PK_CLOCKS builds): accumulated per-phase time of the persistent PCG kernel, 100 MHz ticks.
+int lslam_pg_debug_clocks(lslam_pg *pg, double out[12]) {
+  if (!pg || !out) return LSLAM_ERR_INVALID;
+  PG_TRY(hipSetDevice(pg->device));
+  PG_TRY(hipMemcpy(out, pg->d_scal + 8, 12 * sizeof(double), hipMemcpyDeviceToHost));
   return LSLAM_OK;
 }
 

@@ -55,6 +55,8 @@ def run(pose, label):
     valid = (raw[:, 7] >> np.uint64(63)) == 1
     st = np.zeros((nb * 256, 11), np.int64)
     st[:, :6] = raw[:, :6].astype(np.int64)
+    st[:, 3] = (raw[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    n_cull = (raw[:, 3] >> np.uint64(32)).astype(np.int64)  # far subtrees skipped by their tight box
     st[:, 4] = (raw[:, 4] & np.uint64(0xFFFFFFFF)).astype(np.int64)
     st[:, 5] = (raw[:, 5] & np.uint64(0xFFFFFFFF)).astype(np.int64)
     st[:, 9] = (raw[:, 4] >> np.uint64(32)).astype(np.int64)   # leaves with at least one accepted candidate
@@ -69,6 +71,8 @@ def run(pose, label):
         util = w[:, :, i].sum() / max(1, 64 * wm[:, i].sum())
         print("%-7s lane mean %7.1f p50 %5.0f p90 %5.0f p99 %5.0f max %5.0f | wave-max mean %7.1f | lane utilisation %.2f" % (
             names[i], v.mean(), np.percentile(v, 50), np.percentile(v, 90), np.percentile(v, 99), v.max(), wm[:, i].mean(), util))
+    print("far subtrees culled by their tight box: lane mean %.2f, wave-max mean %.2f" % (
+        n_cull[valid].mean(), n_cull.reshape(nb * 4, 64).max(axis=1).mean()))
     cyc = st[:, 0] + st[:, 1] + st[:, 2] + st[:, 8]
     tot = float(cyc[valid].sum())
     print("share of the search's cycles: descent %.2f, leaves %.2f, pops %.2f, takes %.2f" % tuple(

@@ -629,8 +629,15 @@ def pose_graph_leg(pkg, synth, distmod, dist, rank, world, local_rank, comm, np,
     spmv_bytes = blocks * 36 * 8 + blocks * 4 + 3 * len(g["init"]) * 6 * 8
     if st.cg_iterations > 0 and st.gpu_ms_total > 0:
         per_it_s = st.gpu_ms_total * 1e-3 / st.cg_iterations
-        res["roofline"] = {"kernel": "pg_cg_prod_kernel", "bound": "chain of four small dependent launches per PCG iteration (6-8 us kernels + ~3 us "
-                           "launch-to-launch) on a 15.9 MB system that lives in L2 / Infinity Cache (not a bandwidth limit)",
+        fused = st.fused_solves == st.lm_trials
+        res["fused_solves"] = st.fused_solves
+        res["roofline"] = {"kernel": "pg_pcg_persistent_kernel" if fused else "pg_cg_prod_kernel",
+                           "bound": ("latency: two grid-wide exchanges per PCG iteration through the device's coherence point (~2.5 us each, "
+                                     "publish -> visible) plus ~6 us of per-aggregate work; the matrix stays in registers for the whole solve, so the "
+                                     "algorithmic bytes below are not read from memory at all after the first iteration (not a bandwidth limit)")
+                           if fused else
+                           ("chain of four small dependent launches per PCG iteration (6-8 us kernels + ~3 us launch-to-launch) on a 15.9 MB "
+                            "system that lives in L2 / Infinity Cache (not a bandwidth limit)"),
                            "achieved": spmv_bytes / per_it_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": spmv_bytes / per_it_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
                            "alg_bytes_per_cg_iteration": spmv_bytes, "us_per_cg_iteration": 1e6 * per_it_s,

@@ -414,7 +414,8 @@ typedef struct {
   int32_t status;
   double chi2_initial, chi2_final, lambda;
   float gpu_ms_total;
-  float pad;
+  int32_t fused_solves;   /* damped solves whose whole PCG loop ran in the persistent kernel (the rest took the
+                             launch-per-step loop: graph too large for one workgroup per aggregate to be co-resident) */
 } lslam_pg_stats;
 
 /* In-place SUM over all ranks of `count` doubles at DEVICE address `buf`; must have

@@ -47,4 +47,6 @@ def test_save_read_round_trip(pkg, synth, tmp_path):
     pg2.load(f)
     pg.optimize(2)
     pg2.optimize(2)
-    assert np.abs(pg2.poses() - pg.poses()).max() < 1e-9
+    # (to the damped solves' tolerance -- PCG to a relative residual of 1e-8: the first graph may already have switched its
+    # second preconditioner level on, the loaded one starts without it)
+    assert np.abs(pg2.poses() - pg.poses()).max() < 1e-7

@@ -741,6 +741,36 @@ def test_posegraph_full_size_properties(pkg, synth):
     assert np.allclose(np.linalg.norm(poses[:, 3:], axis=1), 1.0, atol=1e-12)  # unit quaternions
 
 
+def test_posegraph_persistent_solve_equals_launch_loop(pkg, synth, monkeypatch):
+    """The damped solve has two forms -- the whole PCG loop in one persistent launch (one workgroup per aggregate,
+    grid-wide exchanges through sentinel slots) and the launch-per-step loop kept for graphs that do not fit.  Same
+    operator, same stopping rule: the steps agree to the solves' tolerance with the second preconditioner level off and
+    on (persistent Gauss-Jordan inverse against the launch-per-pivot one), the LM runs land on the same chi2, and the
+    statistics say which form ran."""
+    g = synth.make_pose_graph(n_kf=1500, n_loop=4000, laps=2, radius=30.0)
+    out = {}
+    for coarse in ("0", "1"):
+        monkeypatch.setenv("LSLAM_PG_COARSE", coarse)
+        for persistent in ("1", "0"):
+            monkeypatch.setenv("LSLAM_PG_PERSISTENT", persistent)
+            pg = pkg.PoseGraph(0)
+            pg.set_graph(g["init"], g["ij"], g["meas"], g["info"])
+            pg.linearize()
+            dx, it = pg.solve(1e-3)
+            its = pg.optimize(6)
+            st = pg.last_stats
+            out[(coarse, persistent)] = (dx, it, st.chi2_final, st.fused_solves, st.lm_trials, its)
+            pg.close()
+    for coarse in ("0", "1"):
+        a, b = out[(coarse, "1")], out[(coarse, "0")]
+        assert a[3] == a[4] > 0 and b[3] == 0          # every solve fused / none
+        assert a[1] > 0 and abs(a[1] - b[1]) <= 2 + 0.05 * b[1]   # the same PCG, up to rounding, stops at the same place
+        assert np.abs(a[0] - b[0]).max() <= 1e-6 * np.abs(b[0]).max()
+        assert a[5] == b[5] and abs(a[2] - b[2]) <= 1e-6 * b[2]
+    # the second level does its job in both forms: fewer iterations for the same system
+    assert out[("1", "1")][1] < out[("0", "1")][1] and out[("1", "0")][1] < out[("0", "0")][1]
+
+
 # ---- the device builder is the only builder: its structure limits fail loudly -----------------
 def _fresh_ctx(pkg):
     return pkg.Context(0)

@@ -111,7 +111,7 @@ class LslamPgStats(C.Structure):
         ("chi2_final", C.c_double),
         ("lambda_", C.c_double),
         ("gpu_ms_total", C.c_float),
-        ("pad", C.c_float),
+        ("fused_solves", C.c_int32),
     ]
 
 

@@ -111,7 +111,7 @@ typedef struct {
   float build_ms;                    /* tree build wall time inside lslam_map_set */
   float upload_ms;                   /* H2D copy time inside lslam_map_set */
   int32_t built_on_device;           /* always 1: the HIP builder is the only one */
-  int32_t build_attempts;            /* node-slot array sizes tried (1: the first, 2n/3 slots, fitted) */
+  int32_t build_attempts;            /* node-slot array sizes tried (1: the first, 8n/3 slots, fitted) */
 } lslam_map_info;
 
 /* ---- lifecycle --------------------------------------------------------- */

@@ -781,7 +781,7 @@ def test_tree_build_retries_with_more_node_slots(pkg, oracle, monkeypatch):
     tree that results is still nanoflann's."""
     rng = np.random.default_rng(3)
     pts = rng.uniform(-30, 30, (30000, 3)).astype(np.float32)
-    monkeypatch.setenv("LSLAM_DEBUG_NODE_CAP_DIV", "4")  # first attempt gets a quarter of its slots
+    monkeypatch.setenv("LSLAM_DEBUG_NODE_CAP_DIV", "16")  # every attempt gets a sixteenth of its slots: the first cannot fit
     c = _fresh_ctx(pkg)
     try:
         c.map_set(pts, pts)

@@ -498,12 +498,13 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
       if ((errs[k] = dt.pts.reserve(n ? n : 1)) != hipSuccess) return;
       // Node slots come in groups of 8 (one cache line per 3-level treelet); how full the
       // groups get depends on the shape of the tree (a cloud of vertical lines leaves most
-      // of them nearly empty), so grow the slot array until the build fits: 2n/3, 8n/3, 8n --
-      // starting from what fitted this tree last time.
+      // of them nearly empty), so grow the slot array until the build fits: 8n/3, 16n/3, 8n --
+      // starting from what fitted this tree last time.  (Slots are taken in order, so a generous array costs a memset and
+      // address space, not traffic: the first guess is the one a voxel map's surface-shaped trees need, 43 B per point.)
       int fallback = 0;
       size_t n_leaves = 0;
       for (int attempt = dt.cap_attempt; attempt < 3; ++attempt) {
-        const size_t mult[3] = {2, 8, 24};
+        const size_t mult[3] = {8, 16, 24};
         size_t cap = ((mult[attempt] * n / 3 + 64) + 7) & ~(size_t)7;
         if (const char *dv = std::getenv("LSLAM_DEBUG_NODE_CAP_DIV"))  // tests: force the retry / failure paths
           cap = std::max<size_t>(16, (cap / (size_t)std::max(1, atoi(dv))) & ~(size_t)7);

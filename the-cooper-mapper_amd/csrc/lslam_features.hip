@@ -41,7 +41,7 @@ namespace {
     }                                                                                    \
   } while (0)
 
-constexpr int FX_BLOCK = 256;
+constexpr int FX_BLOCK = 1024;  // a ring of 1 800 points: every point of every region has a thread in the parallel phases
 constexpr int MAXR = 2560;  // points per ring held in LDS
 
 // PointLabel, ScanRegistration.h:22-42
@@ -125,13 +125,25 @@ __device__ int fx_point_classify(const float *sx, const float *sy, const float *
   return (line1 || line2) ? L_ONESIDE_FLAT : L_MESSY;
 }
 
+#ifdef LSLAM_FX_CLOCKS  // profiling build: where a ring's workgroup spends its time (100 MHz ticks, summed over rings and calls)
+__device__ unsigned long long fx_clk[8];
+#define FX_T(i) if (threadIdx.x == 0) { const unsigned long long _n = wall_clock64(); atomicAdd(&fx_clk[i], _n - fx_last); fx_last = _n; }
+#else
+#define FX_T(i)
+#endif
 __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
+#ifdef LSLAM_FX_CLOCKS
+  unsigned long long fx_last = wall_clock64();
+#endif
   __shared__ float sx[MAXR], sy[MAXR], sz[MAXR];
-  __shared__ float curv[MAXR];
-  __shared__ uint16_t sorted[MAXR];
-  __shared__ int8_t picked[MAXR], cls[MAXR], rlabel[MAXR];
+  __shared__ float curv_ring[MAXR];
+  __shared__ uint16_t sorted_ring[MAXR];
+  __shared__ int8_t picked[MAXR], cls_ring[MAXR], rlabel_ring[MAXR];
   __shared__ uint8_t pfl[MAXR];
+  __shared__ uint16_t need[MAXR];
+  __shared__ int n_need;
   const int ring = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) n_need = 0;
   const int start = a.ranges[2 * ring], end = a.ranges[2 * ring + 1];
   const int cr = a.cr, nf = a.nf;
   int n_sharp = 0, n_less_sharp = 0, n_flat = 0, n_less = 0;  // uniform across wavefront 0
@@ -177,10 +189,11 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
       for (int base = cr; base < n - 1 - cr; base += 64) {
         const int mine = base + tid;
         const int fl = (mine < n - 1 - cr) ? (int)pfl[mine] : 0;
-        const int cnt = min(64, n - 1 - cr - base);
-        for (int jx = 0; jx < cnt; ++jx) {
+        unsigned long long todo = __ballot((fl & 3) != 0);  // only the flagged pairs take a step, in scan order
+        while (todo) {
+          const int jx = __builtin_ctzll(todo);
+          todo &= todo - 1;
           const int f = __builtin_amdgcn_readlane(fl, jx);
-          if ((f & 3) == 0) continue;  // wave-uniform
           if (tid == 0) {
             const int i = base + jx;
             if (f & 1) {
@@ -197,41 +210,72 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
       }
     }
     __syncthreads();
+    FX_T(0)
     if (a.picked_out)
       for (int i = tid; i < n; i += FX_BLOCK) a.picked_out[start + i] = picked[i];
-    // ---- regions --------------------------------------------------------------------------------
-    for (int j = 0; j < nf; ++j) {
-      const size_t S = (size_t)start + cr, E = (size_t)end - cr;
-      const int sp = (int)((S * (size_t)(nf - j) + E * (size_t)j) / (size_t)nf);
-      const int ep = (int)((S * (size_t)(nf - 1 - j) + E * (size_t)(j + 1)) / (size_t)nf) - 1;
-      if (ep <= sp) continue;  // block-uniform
-      const int rs = ep - sp + 1, r0 = sp - start;  // r0: ring-relative index of the region's first point
+    // ---- everything about the regions that does not depend on the picking, for ALL regions at once -------------
+    // (curvature, the stable rank inside the region, pointClassify: a region is ~300 points, the ring ~1800 -- region
+    // after region a 256-thread workgroup ran these in twelve rounds, most of the time of the kernel)
+    const size_t S = (size_t)start + cr, E = (size_t)end - cr;
+    auto region_of = [&](int j, int &sp, int &ep) {
+      sp = (int)((S * (size_t)(nf - j) + E * (size_t)j) / (size_t)nf);
+      ep = (int)((S * (size_t)(nf - 1 - j) + E * (size_t)(j + 1)) / (size_t)nf) - 1;
+    };
+    {
       const float w = (float)(-2 * cr);
-      for (int r = tid; r < rs; r += FX_BLOCK) {  // setRegionBuffersFor, :437-454
-        const int i = r0 + r;
+      for (int i = cr + tid; i <= n - 1 - cr; i += FX_BLOCK) {  // setRegionBuffersFor, :437-454
         float dx = __fmul_rn(w, sx[i]), dy = __fmul_rn(w, sy[i]), dz = __fmul_rn(w, sz[i]);
         for (int q = 1; q <= cr; ++q) {
           dx = __fadd_rn(dx, __fadd_rn(sx[i + q], sx[i - q]));
           dy = __fadd_rn(dy, __fadd_rn(sy[i + q], sy[i - q]));
           dz = __fadd_rn(dz, __fadd_rn(sz[i + q], sz[i - q]));
         }
-        curv[r] = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-        rlabel[r] = L_UNKNOW;
+        curv_ring[i] = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        rlabel_ring[i] = L_UNKNOW;
       }
       __syncthreads();
-      for (int r = tid; r < rs; r += FX_BLOCK) {
-        const float c = curv[r];
+      FX_T(1)
+      for (int i = cr + tid; i <= n - 1 - cr; i += FX_BLOCK) {
+        // the region this point belongs to (regions tile [start + cr, end - cr); the last point belongs to none)
+        int sp = 0, ep = -1, j = 0;
+        for (; j < nf; ++j) {
+          region_of(j, sp, ep);
+          if (start + i <= ep) break;
+        }
+        if (j == nf || start + i < sp || ep <= sp) continue;  // :210 skips a region of one point
+        const int r0 = sp - start, rs = ep - sp + 1, r = i - r0;
+        const float c = curv_ring[i];
         int rank = 0;  // stable ascending order: the reference's `<=` merge sort
         for (int k = 0; k < rs; ++k) {
-          const float ck = curv[k];
+          const float ck = curv_ring[r0 + k];
           rank += (ck < c) || (ck == c && k < r);
         }
-        sorted[rank] = (uint16_t)r;
-        // pointClassify for every point the third loop will visit
-        cls[r] = (c < a.surf_thr) ? (int8_t)L_UNKNOW : (int8_t)fx_point_classify(sx, sy, sz, r0 + r, a);
-        if (a.curv_out) a.curv_out[sp + r] = c;
+        sorted_ring[r0 + rank] = (uint16_t)r;
+        // pointClassify for every point the third loop will visit: those are collected first (any order: a point's class
+        // depends on nothing else), so that the eigen-solver runs on full wavefronts instead of on the lanes that happen
+        // to hold such a point
+        cls_ring[i] = (int8_t)L_UNKNOW;
+        if (!(c < a.surf_thr)) need[atomicAdd(&n_need, 1)] = (uint16_t)i;
+        if (a.curv_out) a.curv_out[start + i] = c;
       }
       __syncthreads();
+      for (int t = tid; t < n_need; t += FX_BLOCK) {
+        const int i = need[t];
+        cls_ring[i] = (int8_t)fx_point_classify(sx, sy, sz, i, a);
+      }
+      __syncthreads();
+      FX_T(2)
+    }
+    // ---- regions: the picking, in order (regions of a ring share one mark array) -----------------------------
+    for (int j = 0; j < nf; ++j) {
+      int sp, ep;
+      region_of(j, sp, ep);
+      if (ep <= sp) continue;  // block-uniform
+      const int rs = ep - sp + 1, r0 = sp - start;  // r0: ring-relative index of the region's first point
+      const float *curv = curv_ring + r0;            // region-relative views
+      const uint16_t *sorted = sorted_ring + r0;
+      const int8_t *cls = cls_ring + r0;
+      int8_t *rlabel = rlabel_ring + r0;
       if (tid < 64) {  // wavefront 0; the counters are wave-uniform
         const unsigned long long lt_mask = tid == 0 ? 0ull : (~0ull >> (64 - tid));
         // flat surface features, :268-284 -- sequential: every pick excludes its neighbourhood
@@ -250,6 +294,7 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
           }
         }
         n_flat += __builtin_amdgcn_readfirstlane(surf_picked);  // lane 0's count, to every lane
+        FX_T(3)
         // less flat + broken edges, :286-302 -- an ordered compaction, 64 region points at a time
         int n_low = 0;
         for (int base = 0; base < rs; base += 64) {
@@ -307,6 +352,7 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
           run_surf += __popcll(ms);
           run_corner += __popcll(mc);
         }
+        FX_T(4)
       }
       __syncthreads();
       if (a.label_out)
@@ -397,6 +443,15 @@ __global__ void ms_final_kernel(MsArgs a) {
 }  // namespace
 
 extern "C" {
+#ifdef LSLAM_FX_CLOCKS
+int lslam_debug_fx_clocks(double out[8]) {
+  unsigned long long h[8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(fx_clk), sizeof(h)) != hipSuccess) return -1;
+  for (int i = 0; i < 8; ++i) out[i] = (double)h[i];
+  return 0;
+}
+#endif
+
 
 void lslam_reg_default_params(lslam_reg_params *p) {
   if (!p) return;

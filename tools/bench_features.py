@@ -23,3 +23,10 @@ for rings in (16, 64):
         t0 = time.perf_counter(); ref = o.extract_features(cloud, ranges); cdt = time.perf_counter() - t0
         line += "; CPU oracle %.1f ms" % (1e3 * cdt)
     print(line, {k: len(v) for k, v in out.items()})
+if os.environ.get("FX_CLOCKS"):  # -DLSLAM_FX_CLOCKS build
+    import ctypes as C
+    clk = (C.c_double * 8)()
+    ctx.lib.lslam_debug_fx_clocks.argtypes = [C.c_double * 8]
+    ctx.lib.lslam_debug_fx_clocks(clk)
+    tot = sum(clk[:5])
+    print("fx_ring_kernel, share of thread 0's time: marks %.2f, curvature %.2f, rank sort + classify %.2f, flat picks %.2f, compactions %.2f" % tuple(c / tot for c in clk[:5]))

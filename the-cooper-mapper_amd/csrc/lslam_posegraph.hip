@@ -1729,7 +1729,8 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
     const bool off = std::getenv("LSLAM_PG_PERSISTENT") && std::atoi(std::getenv("LSLAM_PG_PERSISTENT")) == 0;
     hipDeviceProp_t prop;
     int per_cu = 0;
-    if (!off && pg->pk_lds_bytes <= 150 * 1024 && hipGetDeviceProperties(&prop, pg->device) == hipSuccess &&
+    if (!off && pg->n_agg <= PK_BLOCK /* one thread per aggregate sums the partials */ && pg->pk_lds_bytes <= 150 * 1024 &&
+        hipGetDeviceProperties(&prop, pg->device) == hipSuccess &&
         hipFuncSetAttribute((const void *)pg_pcg_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)pg->pk_lds_bytes) == hipSuccess &&
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pg_pcg_persistent_kernel, PK_BLOCK, pg->pk_lds_bytes) == hipSuccess &&

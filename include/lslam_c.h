@@ -402,9 +402,9 @@ int lslam_icp_align(lslam_ctx *ctx, const void *target, size_t n_target, const v
  * When a workgroup per aggregate fits the device at once (the 5 000-keyframe bench graph does: 136 aggregates) the whole PCG
  * loop of a damped solve, and the inverse of the coarse matrix, each run as ONE persistent cooperative launch
  * (lslam_pg_stats.fused_solves counts them); larger graphs take a launch-per-step loop with the same arithmetic.  A
- * cooperative launch wants its workgroups resident together: two pose graphs solving at the same moment on one device are
- * serialised by the runtime, and a grid exchange that does not complete within its spin limit returns LSLAM_ERR_HIP
- * ("grid barrier timed out") instead of hanging.
+ * cooperative launch wants its workgroups resident together; if they are not (another process's persistent kernel on the
+ * same device) a grid exchange runs into its spin limit, the kernel raises an abort flag instead of hanging, the solve is
+ * redone by the launch-per-step loop and the graph stays on that loop (tested through a debug hook).
  *
  * Multi-GPU (one process per GPU): every rank creates the same graph and takes an edge range
  * (lslam_pg_set_shard); the block system [diagonal blocks | off-diagonal blocks | b | chi2] is summed

@@ -771,6 +771,25 @@ def test_posegraph_persistent_solve_equals_launch_loop(pkg, synth, monkeypatch):
     assert out[("1", "1")][1] < out[("0", "1")][1] and out[("1", "0")][1] < out[("0", "0")][1]
 
 
+def test_posegraph_persistent_timeout_falls_back_to_launch_loop(pkg, synth, monkeypatch):
+    """A grid exchange that runs into its spin limit (workgroups not all resident: e.g. another process's persistent
+    kernel on the same device) raises the kernel's abort flag; the solve is then redone by the launch-per-step loop and
+    the graph stays on it.  Forced here through the debug hook that raises the flag at iteration 3."""
+    g = synth.make_pose_graph(n_kf=600, n_loop=1500, laps=2, radius=20.0)
+    ref = pkg.PoseGraph(0)
+    ref.set_graph(g["init"], g["ij"], g["meas"], g["info"])
+    ref.optimize(5)
+    monkeypatch.setenv("LSLAM_DEBUG_PG_ABORT", "3")
+    pg = pkg.PoseGraph(0)
+    pg.set_graph(g["init"], g["ij"], g["meas"], g["info"])
+    its = pg.optimize(5)
+    st = pg.last_stats
+    assert its == ref.last_stats.iterations and st.fused_solves == 0 and st.lm_trials > 0
+    assert abs(st.chi2_final - ref.last_stats.chi2_final) <= 1e-6 * ref.last_stats.chi2_final
+    assert np.abs(pg.poses() - ref.poses()).max() < 1e-6
+    pg.close(); ref.close()
+
+
 # ---- the device builder is the only builder: its structure limits fail loudly -----------------
 def _fresh_ctx(pkg):
     return pkg.Context(0)

@@ -741,6 +741,31 @@ def test_posegraph_full_size_properties(pkg, synth):
     assert np.allclose(np.linalg.norm(poses[:, 3:], axis=1), 1.0, atol=1e-12)  # unit quaternions
 
 
+def test_persistent_gn_loop_equals_launch_loop(pkg, synth, monkeypatch):
+    """LSLAM_PERSISTENT_GN=1: the whole Gauss-Newton loop of a resident scan in one persistent launch (every workgroup
+    keeps its own copy of the state, grid-wide exchanges of the blocks' sums, the solve replicated) -- bit for bit the
+    launch loop's pose, counters and sums, for the scan-to-map settings and the mapping settings."""
+    pr = synth.make_problem(rings=64, azimuth_steps=1800)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("LSLAM_PERSISTENT_GN", mode)
+        c = pkg.Context(0)
+        try:
+            c.map_set(pr["map_corner"], pr["map_surf"])
+            c.scan_set(pr["corner"], pr["surf"])
+            res = []
+            for max_it, dr, dt in ((10, 0.05, 0.05), (30, 0.01, 0.01), (2, 0.05, 0.05)):
+                opts = c.default_opts()
+                opts.max_iterations, opts.delta_r_abort, opts.delta_t_abort = max_it, dr, dt
+                status, pose, st = c.run(pr["init_pose"], opts)
+                res.append((status, bits(pose).tolist(), st.iterations, st.n_rows, st.n_line, st.n_plane, st.converged, st.sweeps))
+            out[mode] = res
+        finally:
+            c.close()
+    assert out["0"] == out["1"]
+    assert out["1"][0][6] == 1 and out["1"][2][2] == 2  # the first converges, the last stops at its iteration limit
+
+
 def test_posegraph_persistent_solve_equals_launch_loop(pkg, synth, monkeypatch):
     """The damped solve has two forms -- the whole PCG loop in one persistent launch (one workgroup per aggregate,
     grid-wide exchanges through sentinel slots) and the launch-per-step loop kept for graphs that do not fit.  Same

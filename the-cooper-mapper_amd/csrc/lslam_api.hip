@@ -137,6 +137,12 @@ struct lslam_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> sweep_ev;
   int iter_hint = 4;  // size of the first batch of enqueued GN iterations
+  // gn_persistent_kernel (one resident scan: the whole loop in one cooperative launch)
+  DevBuf<float> gnp_slots;
+  DevBuf<unsigned> gnp_bar;
+  int gnp_cap = -1;       // workgroups the device holds at once (-1: not asked yet)
+  bool gnp_ok = true;     // false once an exchange timed out: the launch loop from then on
+  int gnp_runs = 0;
   // pinned staging area for the scan clouds a caller hands over (packed here, copied from here)
   float4 *h_stage = nullptr;
   size_t h_stage_cap = 0;
@@ -352,6 +358,7 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   ctx->cell_c.release(); ctx->cell_s.release(); ctx->views_c.release(); ctx->views_s.release();
   ctx->prev_nb.release();
   ctx->xchg.release();
+  ctx->gnp_slots.release(); ctx->gnp_bar.release();
   ctx->q.release(); ctx->blocks.release(); ctx->probs.release(); ctx->partials.release(); ctx->stack_ovf.release();
   ctx->t_idx.release(); ctx->t_d2.release(); ctx->t_coeff.release(); ctx->t_flags.release();
   ctx->t_q.release(); ctx->t_small.release();
@@ -1231,7 +1238,60 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
   // over its block range, so the traversal-stack overflow area and the wavefront count of a launch stay
   // bounded.  All chunks' first `batch` iterations are enqueued back to back before the host looks once.
   int n_launches = 0;
-  if (!sharded) {
+  // One resident scan: the whole loop in ONE persistent launch (gn_persistent_kernel) when every block of the sweep can
+  // be resident at once and nothing needs the launches in between (per-launch profiling, the stereo term, the exchange of
+  // a sharded run, per-cube trees, the packet search, trees deeper than the LDS stack).  OFF by default
+  // (LSLAM_PERSISTENT_GN=1 turns it on): bit-identical results, but measured no faster than the launch loop -- 327 us
+  // against 315 us of device time per four-iteration scanMatchScan of 115 200 points; the two grid exchanges and the
+  // replicated solve of an iteration cost what the solve launch and its two gaps do.
+  bool gnp_done = false;
+  {
+    const bool gnp_off = !(std::getenv("LSLAM_PERSISTENT_GN") && std::atoi(std::getenv("LSLAM_PERSISTENT_GN")) == 1);
+    static const bool unbounded = std::getenv("LSLAM_UNBOUNDED_KNN") != nullptr;
+    if (!sharded && n_scans == 1 && !gnp_off && ctx->gnp_ok && !o.profile && ctx->n_stereo == 0 && !ctx->cube_mode &&
+        !sa.packet && max_it > 0 && ctx->tc.depth <= KD_STACK_LDS + 1 && ctx->ts.depth <= KD_STACK_LDS + 1 &&
+        sa.nb_total > 0 && sa.nb_total <= 512) {
+      if (ctx->gnp_cap < 0) ctx->gnp_cap = gn_persistent_capacity(ctx->device);
+      if (sa.nb_total <= ctx->gnp_cap) {
+        // [2][nb][32] floats, then [3][32][32] doubles (8-byte aligned: the float part is a multiple of 64 words)
+        const size_t n_slot = 2 * (size_t)sa.nb_total * NCOL + 2 * 3 * 32 * NCOL;
+        HIP_TRY(ctx->gnp_slots.reserve(n_slot));
+        HIP_TRY(ctx->gnp_bar.reserve(2));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ctx->gnp_slots.p, (int)0xFFF8DEADu, n_slot, ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->gnp_bar.p, 0, 2 * sizeof(unsigned), ctx->stream));
+        SweepArgs sp = sa;
+        sp.bounded = unbounded ? 0 : 1;
+        sp.stack_ovf = nullptr;
+        GnLoopArgs gl{};
+        gl.slots = ctx->gnp_slots.p;
+        gl.gslots = reinterpret_cast<double *>(ctx->gnp_slots.p + 2 * (size_t)sa.nb_total * NCOL);
+        gl.bar = ctx->gnp_bar.p;
+        gl.state_out = ctx->d_state;
+        gl.max_iterations = max_it;
+        gl.min_rows = so.min_rows;
+        gl.delta_r_abort = so.delta_r_abort;
+        gl.delta_t_abort = so.delta_t_abort;
+        gl.eig_thresh = so.eig_thresh;
+        HIP_TRY(launch_gn_persistent(sp, o.jtj_mode, gl, ctx->stream));
+        HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+        unsigned gbar[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(gbar, ctx->gnp_bar.p, sizeof(gbar), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (gbar[1] == 0) {
+          gnp_done = true;
+          ctx->gnp_runs++;
+          launched = ctx->h_state[0].sweeps;
+        } else {  // an exchange ran into its spin limit (the workgroups were not all resident): the launch loop, from the start
+          if (std::getenv("LSLAM_DEBUG")) fprintf(stderr, "[lslam] persistent GN kernel timed out in its grid exchange: launch loop from here on\n");
+          ctx->gnp_ok = false;
+          init_state(ctx->h_state[0], poses);
+          HIP_TRY(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(GNState), hipMemcpyHostToDevice, ctx->stream));
+        }
+      }
+    }
+  }
+  if (!sharded && !gnp_done) {
     const int in_flight = o.scans_in_flight > 0 ? std::min<int>(o.scans_in_flight, n_scans) : std::min<int>(n_scans, 128);
     const int n_chunks = (n_scans + in_flight - 1) / in_flight;
     static const bool unbounded = std::getenv("LSLAM_UNBOUNDED_KNN") != nullptr;  // A/B switch

@@ -114,6 +114,18 @@ struct SolveArgs {
   double *sums_out;          // reduce_only: also write the [n_prob][32] sums here (the all-reduce buffer)
 };
 
+// gn_persistent_kernel: the whole Gauss-Newton loop of one resident scan in one cooperative launch (lslam_kernels.hip)
+struct GnLoopArgs {
+  float *slots;       // [2][nb_total][NCOL] the blocks' sums; exchange slots, filled with the sentinel 0xFFF8DEAD before the launch
+  double *gslots;     // [3][32][NCOL] the 32 row groups' sums (same sentinel in both halves)
+  unsigned *bar;      // [1] abort flag
+  GNState *state_out; // where workgroup 0 leaves the final state (SweepArgs::states holds the initial one)
+  int32_t max_iterations, min_rows;
+  float delta_r_abort, delta_t_abort, eig_thresh;
+};
+int gn_persistent_capacity(int device);
+hipError_t launch_gn_persistent(const SweepArgs &a, int jtj_mode, const GnLoopArgs &g, hipStream_t s);
+
 // Stereo reprojection rows of the joint system (lslam_stereo.hip; include/lslam_c.h lslam_stereo_cam).
 struct StereoCam {
   float fx, fy, cx, cy, bf;

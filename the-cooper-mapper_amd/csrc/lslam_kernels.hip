@@ -60,19 +60,13 @@ LSLAM_DEV int cube_tree_of(const CubeGridDev &g, float x, float y, float z) {
 // PACKET: the 5-NN search is the wave-cooperative one of lslam_packet.hpp (scalar loads, no per-lane
 // traversal stack: LDS_DEPTH = 4 only provides the eight staging rows of the MFMA contraction); lanes
 // that see an exact distance tie redo their search with nanoflann's traversal (stack in HBM).
-template <int BLOCK, bool OVF, bool CUBES, int LDS_DEPTH, bool PACKET = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH <= 16 ? LSLAM_SHALLOW_OCC : 2))) void sweep_kernel(SweepArgs a, int jtj_mode) {
-  const int lb = xcd_remap(blockIdx.x, a.nb_total);
-  const BlockDesc bd = a.blocks[lb];
-  const GNState *st = a.states + bd.prob;
-  if (st->done) return;  // this scan's loop already ended (ScanMatch.cpp:144,259)
-
+// One block of one sweep: the body of sweep_kernel, and of an iteration of gn_persistent_kernel.  `st` is the scan's
+// state -- in HBM (STATE_LDS = false: R, t, sc arrive by scalar loads) or a workgroup's LDS copy (true); `red` and
+// `stack_lds` are the caller's LDS; the block's 32 sums go to partial_out[0..32).
+template <int BLOCK, bool OVF, bool CUBES, int LDS_DEPTH, bool PACKET, bool STATE_LDS>
+LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, const BlockDesc &bd, const GNState *st,
+                          uint32_t *stack_lds, float (*red)[NCOL], float *partial_out, const int prev_valid) {
   constexpr int NWAVE = BLOCK / 64;
-  __shared__ float red[NWAVE][NCOL];
-  // The MFMA staging of [J | b] (8 floats per point) lives in the wavefront's OWN traversal-stack
-  // slots -- word row c, lane slot p -- which are dead once its 5-NN searches are over: no extra LDS,
-  // no cross-wavefront hazard (the shallow variant then fits six workgroups per CU instead of four).
-  __shared__ uint32_t stack_lds[2 * LDS_DEPTH * BLOCK];
   static_assert(2 * LDS_DEPTH >= 8, "staging needs eight word rows of the stack");
 
   const int tid = threadIdx.x;
@@ -87,7 +81,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
   // state invariant (the solve kernel writes it between launches) and would fetch it with vector loads into 18 VGPRs
   // that then sit in the register file through the whole search: fetched with scalar loads they live in SGPRs.
   float R[9], t[3], sc[6];
-  {
+  if (STATE_LDS) {  // the workgroup's own copy: wave-uniform values, moved to SGPRs
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(st->R[i])));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(st->t[i])));
+#pragma unroll
+    for (int i = 0; i < 6; ++i) sc[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(st->sc[i])));
+  } else {
     static_assert(offsetof(GNState, R) == 24 && offsetof(GNState, t) == 60 && offsetof(GNState, sc) == 72, "GNState layout");
     typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
     float cap = FLT_MAX;
     if (a.bounded) {
       cap = 5.0f * (1.0f + 1e-5f);
-      if (a.prev_valid && active) {
+      if (prev_valid && active) {
         float u = 0.0f;
         bool all = true;
 #pragma unroll
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
     float bound = FLT_MAX;
     if (a.bounded) {
       bound = 5.0f * (1.0f + 1e-5f);
-      if (a.prev_valid && T.n_pts > 0) {
+      if (prev_valid && T.n_pts > 0) {
         // the five indices, then the five points, all in flight together (a guarded load per neighbour would be a chain
         // of ten dependent round trips at the head of every wavefront): an invalid index reads point 0 and is ignored
         int pp[5];
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
     float s = red[0][tid];
 #pragma unroll
     for (int w = 1; w < NWAVE; ++w) s += red[w][tid];
-    a.partials[(size_t)lb * NCOL + tid] = s;
+    partial_out[tid] = s;
   }
   if (a.dbg && lane == 0) {  // per-wave phase stamps (shader clock)
     uint64_t *o = a.dbg + ((size_t)lb * NWAVE + wave) * 4;
@@ -387,6 +388,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
     o[2] = dbg_t2;
     o[3] = __builtin_readcyclecounter();
   }
+}
+
+// PACKET: the 5-NN search is the wave-cooperative one of lslam_packet.hpp (see sweep_body).
+template <int BLOCK, bool OVF, bool CUBES, int LDS_DEPTH, bool PACKET = false>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH <= 16 ? LSLAM_SHALLOW_OCC : 2))) void sweep_kernel(SweepArgs a, int jtj_mode) {
+  const int lb = xcd_remap(blockIdx.x, a.nb_total);
+  const BlockDesc bd = a.blocks[lb];
+  const GNState *st = a.states + bd.prob;
+  if (st->done) return;  // this scan's loop already ended (ScanMatch.cpp:144,259)
+  __shared__ float red[BLOCK / 64][NCOL];
+  // The MFMA staging of [J | b] (8 floats per point) lives in the wavefront's OWN traversal-stack
+  // slots -- word row c, lane slot p -- which are dead once its 5-NN searches are over: no extra LDS,
+  // no cross-wavefront hazard (the shallow variant then fits six workgroups per CU instead of four).
+  __shared__ uint32_t stack_lds[2 * LDS_DEPTH * BLOCK];
+  sweep_body<BLOCK, OVF, CUBES, LDS_DEPTH, PACKET, false>(a, jtj_mode, lb, bd, st, stack_lds, red, a.partials + (size_t)lb * NCOL, a.prev_valid);
 }
 
 // start/stop (optional) time exactly this dispatch on its own stream: the events are
@@ -823,6 +839,179 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(SolveArgs a) {
     if (st->loop_iter >= a.max_iterations) st->done = 1;
   }
   if (tid == 0) st->clk[3] = wall_clock64();
+}
+
+// ---------------------------------------------------------------------------
+// The whole Gauss-Newton loop of ONE scan in one persistent launch.  As launches an iteration is a sweep
+// (44-55 us for 115 200 points), a solve launch (13 us: 1024 threads ramp up to reduce 450 x 32 partials
+// and run a 6 x 6 QR), two launch-to-launch gaps and, after the last iteration, a spare pair that finds
+// the loop ended: ~79 us per iteration, 0.32 ms of device time per scanMatchScan of four.  Here every workgroup of the
+// sweep stays resident (450 of them at two per CU), keeps ITS OWN copy of the scan's state in LDS and,
+// after its block of the sweep, takes part in one grid-wide exchange of the blocks' 32 sums -- slots that
+// hold a sentinel until their owner stores them, polled by the readers themselves (the mechanism of
+// pg_pcg_persistent_kernel, lslam_posegraph.hip; three generations, a slot is reset one exchange after
+// everybody has read it) -- reduces them in the solve kernel's order and runs the solve REPLICATED: every
+// workgroup computes the same next pose from the same numbers, nothing travels back.  Bit for bit the
+// launch loop's result (same sums in the same order, same solve; tests/test_gpu_parity.py holds the two
+// against each other).  For a single resident scan against shallow trees without the stereo term,
+// the sharded exchange or per-launch profiling; a spin limit raises an abort flag instead of hanging
+// and the caller falls back to the launch loop.  MEASURED NO FASTER than the launch loop (327 us against
+// 315 us per four-iteration loop: the exchanges and the replicated solve cost what the solve launch and
+// its gaps do) and therefore off unless LSLAM_PERSISTENT_GN=1; kept as the A/B switch of that result.
+// ---------------------------------------------------------------------------
+constexpr uint32_t GNP_SENT = 0xFFF8DEADu;  // a NaN payload no sum produces
+constexpr long long GNP_SENT64 = (long long)(((unsigned long long)GNP_SENT << 32) | GNP_SENT);
+constexpr unsigned GNP_SPIN_LIMIT = 1u << 20;
+LSLAM_DEV float gnp_ld(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+LSLAM_DEV void gnp_st(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void gn_persistent_kernel(SweepArgs a, int jtj_mode, GnLoopArgs g) {
+  constexpr int BLOCK = SWEEP_BLOCK, LDS_DEPTH = KD_STACK_LDS;
+  static_assert(BLOCK == 256, "the reduction below is written for 256 threads");
+  __shared__ float red[BLOCK / 64][NCOL];
+  __shared__ uint32_t stack_lds[2 * LDS_DEPTH * BLOCK];
+  __shared__ GNState lst;       // this workgroup's copy of the scan's state
+  __shared__ float part[NCOL];
+  __shared__ double tot[NCOL];
+  __shared__ GnShared sh;
+  __shared__ int go;
+  __shared__ double redd[32][NCOL];
+  const int tid = threadIdx.x;
+  const int lb = xcd_remap(blockIdx.x, a.nb_total);
+  const BlockDesc bd = a.blocks[lb];
+  const int nb = a.nb_total;
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(a.states);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&lst);
+    for (int i = tid; i < (int)(sizeof(GNState) / 4); i += BLOCK) dst[i] = src[i];
+  }
+  __syncthreads();
+  for (int it = 0; it < g.max_iterations && !lst.done; ++it) {
+    sweep_body<BLOCK, false, false, LDS_DEPTH, false, true>(a, jtj_mode, lb, bd, &lst, stack_lds, red, part, (a.bounded && it > 0) ? 1 : 0);
+    __syncthreads();
+    // Exchange in two stages, the solve kernel's summation order kept: the blocks' 32 sums go to slots (two generations);
+    // workgroup `grp` < 32 adds rows grp, grp + 32, ... of them in fp64 and publishes the group's sums (three generations);
+    // every workgroup adds the 32 groups in order.  (One stage -- every workgroup reading all 450 x 32 sums through the
+    // coherence point, 26 MB per iteration -- cost more than the launches it replaced.)
+    float *slot = g.slots + (size_t)(it & 1) * nb * NCOL;
+    double *gsl = g.gslots + (size_t)(it % 3) * 32 * NCOL;
+    if (tid < NCOL) gnp_st(slot + (size_t)lb * NCOL + tid, part[tid]);
+    if (lb < 32) {
+      float *pv = reinterpret_cast<float *>(stack_lds);  // [<= 16][NCOL] this group's rows (the traversal stack is dead by now)
+      const int nrow = lb < nb ? (nb - lb + 31) / 32 : 0;
+      for (unsigned spins = 0;; ++spins) {
+        int bad = 0;
+        for (int i = tid; i < nrow * NCOL; i += BLOCK) {
+          const float v = gnp_ld(slot + (size_t)(lb + 32 * (i / NCOL)) * NCOL + (i % NCOL));
+          pv[i] = v;
+          bad |= (__float_as_uint(v) == GNP_SENT) ? 1 : 0;
+        }
+        if (!__syncthreads_or(bad)) break;
+        if ((spins & 255u) == 255u &&
+            (spins > GNP_SPIN_LIMIT || __hip_atomic_load(g.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+          __hip_atomic_store(g.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (tid < NCOL) {
+        double sgrp = 0.0;
+        for (int r = 0; r < nrow; ++r) sgrp += (double)pv[r * NCOL + tid];
+        __hip_atomic_store(gsl + lb * NCOL + tid, sgrp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    for (unsigned spins = 0;; ++spins) {
+      int bad = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double v = __hip_atomic_load(gsl + tid + BLOCK * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (&redd[0][0])[tid + BLOCK * j] = v;
+        bad |= (__double_as_longlong(v) == GNP_SENT64) ? 1 : 0;
+      }
+      if (!__syncthreads_or(bad)) break;
+      if ((spins & 255u) == 255u &&
+          (spins > GNP_SPIN_LIMIT || __hip_atomic_load(g.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+        __hip_atomic_store(g.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    // all 32 group sums are there: every reducer has read every block's sums of this iteration, and every workgroup
+    // has finished reading the group sums of the iteration before the last
+    if (tid < NCOL) gnp_st(slot + (size_t)lb * NCOL + tid, __uint_as_float(GNP_SENT));
+    if (it > 0 && lb < 32 && tid < NCOL)
+      __hip_atomic_store(g.gslots + (size_t)((it - 1) % 3) * 32 * NCOL + lb * NCOL + tid, __longlong_as_double(GNP_SENT64),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < NCOL) {
+      double v = 0.0;
+#pragma unroll 8
+      for (int gi = 0; gi < 32; ++gi) v += redd[gi][tid];
+      tot[tid] = v;
+      lst.sums[tid] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {  // solve_kernel's bookkeeping (ScanMatch.cpp:141-145)
+      lst.sweeps += 1;
+      const int n_rows = (int)tot[COL_ROWS];
+      lst.n_rows = n_rows;
+      lst.n_line = (int)tot[COL_LINE];
+      lst.n_plane = (int)tot[COL_PLANE];
+      lst.score = tot[COL_SCORE];
+      go = 1;
+      if (n_rows < g.min_rows) {
+        go = 0;
+        lst.too_few = 1;
+        lst.done = 1;
+      }
+    }
+    if (tid < 36) {
+      const int r = tid / 6, c = tid % 6;
+      const int i = r < c ? r : c, j = r < c ? c : r;
+      sh.A[tid] = (float)tot[COL_ATA + (i * 6 - (i * (i - 1)) / 2) + (j - i)];
+    }
+    if (tid < 6) sh.b[tid] = (float)tot[COL_ATB + tid];
+    __syncthreads();
+    if (go) {
+      gn_step_block(&lst, sh, g.eig_thresh, g.delta_r_abort, g.delta_t_abort, false);
+      if (tid == 0) {
+        lst.loop_iter += 1;
+        if (lst.loop_iter >= g.max_iterations) lst.done = 1;
+      }
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0) {
+    uint32_t *dst = reinterpret_cast<uint32_t *>(g.state_out);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&lst);
+    for (int i = tid; i < (int)(sizeof(GNState) / 4); i += BLOCK) dst[i] = src[i];
+  }
+}
+
+int gn_persistent_capacity(int device) {  // workgroups of gn_persistent_kernel the device holds at once
+  hipDeviceProp_t prop;
+  int per_cu = 0;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gn_persistent_kernel, SWEEP_BLOCK, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return per_cu * prop.multiProcessorCount;
+}
+
+hipError_t launch_gn_persistent(const SweepArgs &a, int jtj_mode, const GnLoopArgs &g, hipStream_t s) {
+  // An ordinary launch: the caller has checked that the grid fits the device at once, and the kernel's spin limit turns
+  // the case it does not (another process on the device) into a fallback instead of a hang.  hipLaunchCooperativeKernel
+  // adds tens of microseconds per launch on this runtime -- more than the launches this kernel saves.
+  static const bool coop = std::getenv("LSLAM_GNP_COOPERATIVE") != nullptr;  // A/B switch
+  if (coop) {
+    SweepArgs aa = a;
+    int jm = jtj_mode;
+    GnLoopArgs gg = g;
+    void *args[] = {(void *)&aa, (void *)&jm, (void *)&gg};
+    return hipLaunchCooperativeKernel((const void *)gn_persistent_kernel, dim3((unsigned)a.nb_total), dim3(SWEEP_BLOCK), args, 0, s);
+  }
+  hipLaunchKernelGGL(gn_persistent_kernel, dim3((unsigned)a.nb_total), dim3(SWEEP_BLOCK), 0, s, a, jtj_mode, g);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------

@@ -27,3 +27,16 @@ print("last solve kernel (us): reduce %.2f  qr %.2f  rest %.2f  total %.2f" % ((
 print("%-40s sweep_us median %.1f min %.1f | loop_us median %.1f | iters %d pose %s" % (
     os.path.basename(os.environ.get("LSLAM_LIB", "default")), 1e3 * np.median(sw), 1e3 * min(sw), 1e3 * np.median(lp),
     st.iterations, np.array2string(pose, precision=5)))
+# the same loop without per-launch events (a single resident scan then runs as ONE persistent launch unless
+# LSLAM_PERSISTENT_GN=0): device time of the whole loop and wall time of the call
+import time
+opts.profile = 0
+for _ in range(3):
+    ctx.run(pr["init_pose"], opts)
+lp = []; wall = []
+for _ in range(int(os.environ.get("REPS", "20"))):
+    t0 = time.perf_counter()
+    status, pose, st = ctx.run(pr["init_pose"], opts)
+    wall.append(time.perf_counter() - t0); lp.append(st.gpu_ms_total)
+print("no per-launch events: loop_us median %.1f | wall_us median %.1f | iters %d pose %s" % (
+    1e3 * np.median(lp), 1e6 * np.median(wall), st.iterations, np.array2string(pose, precision=5)))

@@ -1095,6 +1095,9 @@ __host__ __device__ inline void pose_to_Rt_sc(const float pose[6], float R[9], f
 // result is bit-identical to colpiv_qr_solve<6,6>; only the critical path shrinks.
 // col[] is this lane's column (consumed).  Returns x[6] in every lane.
 // ---------------------------------------------------------------------------
+// (Values cross lanes by v_readlane -- the source lane is uniform everywhere, a constant or the pivot index -- not by
+// ds_bpermute shuffles: ~130 dependent LDS round trips were most of the 5 us this solve took.)
+LSLAM_DEV float qr_rl(float v, int l) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l)); }
 LSLAM_DEV void colpiv_qr_solve6_wave(float (&col)[6], int lane, float (&x)[6]) {
   const bool is_mat = lane < 6;
   float s = 0.0f;
@@ -1103,7 +1106,7 @@ LSLAM_DEV void colpiv_qr_solve6_wave(float (&col)[6], int lane, float (&x)[6]) {
   float nD = sqrtf(s), nU = nD;
   float u[6];
 #pragma unroll
-  for (int l = 0; l < 6; ++l) u[l] = __shfl(nU, l, 64);
+  for (int l = 0; l < 6; ++l) u[l] = qr_rl(nU, l);
   float maxn = u[0];
 #pragma unroll
   for (int l = 1; l < 6; ++l) maxn = u[l] > maxn ? u[l] : maxn;
@@ -1117,7 +1120,7 @@ LSLAM_DEV void colpiv_qr_solve6_wave(float (&col)[6], int lane, float (&x)[6]) {
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
 #pragma unroll
-    for (int l = 0; l < 6; ++l) u[l] = __shfl(nU, l, 64);
+    for (int l = 0; l < 6; ++l) u[l] = qr_rl(nU, l);
     int big = k;
     float bigv = u[k];
 #pragma unroll
@@ -1128,11 +1131,18 @@ LSLAM_DEV void colpiv_qr_solve6_wave(float (&col)[6], int lane, float (&x)[6]) {
     }
     if (nonzero_pivots == 6 && bigv * bigv < threshold_helper * (float)(6 - k)) nonzero_pivots = k;
     // column transposition k <-> big (and the permutation bookkeeping)
-    const int src = lane == k ? big : (lane == big ? k : lane);
+    const int bigu = __builtin_amdgcn_readfirstlane(big);  // the same in every lane: it comes from the broadcast norms
+    {
+      const bool at_k = lane == k, at_big = lane == bigu;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) col[i] = __shfl(col[i], src, 64);
-    nU = __shfl(nU, src, 64);
-    nD = __shfl(nD, src, 64);
+      for (int i = 0; i < 6; ++i) {
+        const float vk = qr_rl(col[i], k), vb = qr_rl(col[i], bigu);
+        col[i] = at_k ? vb : (at_big ? vk : col[i]);
+      }
+      const float uk = qr_rl(nU, k), ub = qr_rl(nU, bigu), dk = qr_rl(nD, k), db = qr_rl(nD, bigu);
+      nU = at_k ? ub : (at_big ? uk : nU);
+      nD = at_k ? db : (at_big ? dk : nD);
+    }
 #pragma unroll
     for (int j = k + 1; j < 6; ++j) cswap(big == j, perm[k], perm[j]);
     // Householder vector of column k (every lane computes its own, lane k's is used)
@@ -1156,10 +1166,10 @@ LSLAM_DEV void colpiv_qr_solve6_wave(float (&col)[6], int lane, float (&x)[6]) {
         tau = (beta - c0) / beta;
       }
     }
-    tau = __shfl(tau, k, 64);
-    beta = __shfl(beta, k, 64);
+    tau = qr_rl(tau, k);
+    beta = qr_rl(beta, k);
 #pragma unroll
-    for (int i = k + 1; i < 6; ++i) ess[i] = __shfl(ess[i], k, 64);
+    for (int i = k + 1; i < 6; ++i) ess[i] = qr_rl(ess[i], k);
     if (lane == k) {
       col[k] = beta;
 #pragma unroll
@@ -1204,9 +1214,9 @@ LSLAM_DEV void colpiv_qr_solve6_wave(float (&col)[6], int lane, float (&x)[6]) {
   float Rm[6][6], c[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    c[i] = __shfl(col[i], 6, 64);
+    c[i] = qr_rl(col[i], 6);
 #pragma unroll
-    for (int r = 0; r <= i; ++r) Rm[r][i] = __shfl(col[r], i, 64);
+    for (int r = 0; r <= i; ++r) Rm[r][i] = qr_rl(col[r], i);
   }
 #pragma unroll
   for (int i = 5; i >= 0; --i) {

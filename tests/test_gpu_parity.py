@@ -70,7 +70,7 @@ def _tree_dump(ctx, which, n_pts):
     lib.lslam_debug_tree_dump.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_size_t,
                                           C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_uint32),
                                           C.POINTER(C.c_int32)]
-    cap = 16 * n_pts // 3 + 256  # a large map's two trees are one forest: the node array holds both
+    cap = 2 * n_pts // 3 + 128
     nodes = np.zeros((cap, 4), np.uint32)
     pts = np.zeros((max(1, n_pts), 4), np.float32)
     root, nn = C.c_uint32(), C.c_int32()

@@ -78,10 +78,6 @@ struct DevTree {
   TreeView view{};
   int depth = 0;
   int cap_attempt = 0;  // node-slot multiplier that last fitted this tree (device build)
-  // Large maps build both trees as ONE forest (map_set_impl): the arrays then live in the corner tree's buffers and this
-  // tree's points start at `base` of them (leaf references are absolute)
-  bool in_pair = false;
-  int32_t base = 0;
 };
 
 struct HostSinCos {
@@ -393,29 +389,16 @@ int lslam_debug_tree_dump(lslam_ctx *ctx, int which, uint32_t *nodes_out, size_t
   if (rc) return rc;
   if (!ctx->have_map) return LSLAM_ERR_NO_MAP;
   const DevTree &dt = which ? ctx->ts : ctx->tc;
-  const DevTree &store = dt.in_pair ? ctx->tc : dt;  // a pair built as one forest lives in the corner tree's buffers
   if ((size_t)dt.view.n_nodes > node_cap || (size_t)dt.view.n_pts > pts_cap) return LSLAM_ERR_INVALID;
   if (dt.view.n_nodes)
-    HIP_TRY(hipMemcpyAsync(nodes_out, store.nodes.p, (size_t)dt.view.n_nodes * sizeof(KdNode),
+    HIP_TRY(hipMemcpyAsync(nodes_out, dt.nodes.p, (size_t)dt.view.n_nodes * sizeof(KdNode),
                            hipMemcpyDeviceToHost, ctx->stream));
   if (dt.view.n_pts)
-    HIP_TRY(hipMemcpyAsync(pts_out, store.pts.p + dt.base, (size_t)dt.view.n_pts * sizeof(float4), hipMemcpyDeviceToHost,
+    HIP_TRY(hipMemcpyAsync(pts_out, dt.pts.p, (size_t)dt.view.n_pts * sizeof(float4), hipMemcpyDeviceToHost,
                            ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   *root_ref = dt.view.root_ref;
   *n_nodes = dt.view.n_nodes;
-  if (dt.base) {  // leaf references relative to this tree's own points, as a tree built alone has them
-    auto rel = [&](uint32_t ref) -> uint32_t {
-      if (!(ref & KD_LEAF)) return ref;
-      const uint32_t l = (ref & ~KD_LEAF) >> 4, cnt = ref & 15u;
-      return l >= (uint32_t)dt.base ? (KD_LEAF | ((l - (uint32_t)dt.base) << 4) | cnt) : ref;  // (the other tree's leaves stay)
-    };
-    for (int32_t k = 0; k < dt.view.n_nodes; ++k) {
-      nodes_out[4 * k + 2] = rel(nodes_out[4 * k + 2]);
-      nodes_out[4 * k + 3] = rel(nodes_out[4 * k + 3]);
-    }
-    *root_ref = rel(*root_ref);
-  }
   return LSLAM_OK;
 }
 
@@ -502,87 +485,7 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
   double t1 = t0, t2 = t0;
   size_t nodes_c = 0, nodes_s = 0;
   int attempts_used = 1;
-  // Large maps: both trees in ONE forest build.  The level-synchronous phase of the builder is a chain of ~11 small
-  // launches per level; two trees on two streams ran those chains side by side without overlapping (264 launches, 1.85 of
-  // the 2.65 ms of a 157 k + 587 k-point surround), one forest runs one chain for both (the builder that makes the cube
-  // trees of variant C).  Small maps keep the two-stream path (their trees go through the persistent phase A).
-  const bool pair = std::max(n_corner, n_surf) > 49152 && !std::getenv("LSLAM_NO_PAIR_BUILD");
-  ctx->tc.in_pair = ctx->ts.in_pair = false;
-  ctx->tc.base = ctx->ts.base = 0;
-  if (pair) {
-    t1 = now_ms();
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    DevTree &dt = ctx->tc;
-    const size_t n_tot = n_corner + n_surf;
-    const void *host_src[2] = {corner, surf};
-    const float4 *dev_src[2] = {dev_corner, dev_surf};
-    const size_t counts[2] = {n_corner, n_surf}, offs[2] = {0, n_corner};
-    HIP_TRY(dt.pts.reserve(n_tot + 16));
-    if (!from_dev) {  // {x, y, z, bitcast(index)} packed into pinned memory once; retries upload it again
-      for (int k = 0; k < 2; ++k) {
-        const size_t n = counts[k];
-        if (n > ctx->h_map_cap[k]) {
-          if (ctx->h_map_stage[k]) (void)hipHostFree(ctx->h_map_stage[k]);
-          ctx->h_map_stage[k] = nullptr;
-          ctx->h_map_cap[k] = 0;
-          const size_t want = n + n / 4 + 1024;
-          HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_map_stage[k]), want * sizeof(float4), hipHostMallocDefault));
-          ctx->h_map_cap[k] = want;
-        }
-      }
-    }
-    const int32_t roots_lr[4] = {0, (int32_t)n_corner, (int32_t)n_corner, (int32_t)n_tot};
-    TreeView views[2];
-    int fallback = 0, max_depth = 0;
-    size_t n_leaves = 0;
-    for (int attempt = dt.cap_attempt; attempt < 3; ++attempt) {
-      const size_t mult[3] = {8, 16, 24};
-      size_t cap = ((mult[attempt] * n_tot / 3 + 64 + 16) + 7) & ~(size_t)7;
-      if (const char *dv = std::getenv("LSLAM_DEBUG_NODE_CAP_DIV"))  // tests: force the retry / failure paths
-        cap = std::max<size_t>(32, (cap / (size_t)std::max(1, atoi(dv))) & ~(size_t)7);
-      HIP_TRY(dt.nodes.reserve(cap));
-      HIP_TRY(dt.pn.reserve(cap));
-      for (int k = 0; k < 2; ++k) {
-        const size_t n = counts[k];
-        if (!n) continue;
-        if (from_dev) {
-          HIP_TRY(hipMemcpyAsync(dt.pts.p + offs[k], dev_src[k], n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
-        } else if (attempt > dt.cap_attempt) {
-          HIP_TRY(hipMemcpyAsync(dt.pts.p + offs[k], ctx->h_map_stage[k], n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-        } else {  // a chunk's DMA runs while the next one is packed
-          float4 *stage = ctx->h_map_stage[k];
-          const char *sp = static_cast<const char *>(host_src[k]);
-          constexpr size_t CHUNK = 1u << 17;
-          for (size_t off = 0; off < n; off += CHUNK) {
-            const size_t end = std::min(n, off + CHUNK);
-            for (size_t i = off; i < end; ++i) {
-              float xyz[3];
-              std::memcpy(xyz, sp + i * stride_bytes, sizeof(xyz));
-              stage[i] = make_float4(xyz[0], xyz[1], xyz[2], __builtin_bit_cast(float, (uint32_t)i));
-            }
-            HIP_TRY(hipMemcpyAsync(dt.pts.p + offs[k] + off, stage + off, (end - off) * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-          }
-        }
-      }
-      HIP_TRY(build_kdforest_device(dt.pts.p, (int32_t)n_tot, roots_lr, 2, dt.nodes.p, dt.pn.p, (int32_t)cap, ctx->stream, views,
-                                    &max_depth, &n_leaves, &fallback));
-      if (fallback != 1) {
-        if (!fallback) dt.cap_attempt = attempt;
-        break;
-      }
-    }
-    attempts_used = dt.cap_attempt + 1;
-    if (fallback) return tree_build_failed(fallback, n_tot);
-    ctx->tc.view = views[0];
-    ctx->ts.view = views[1];
-    ctx->tc.depth = ctx->ts.depth = max_depth;  // the deeper of the two (the forest keeps one maximum)
-    ctx->tc.in_pair = ctx->ts.in_pair = true;
-    ctx->ts.base = (int32_t)n_corner;
-    const size_t nodes_all = (size_t)views[0].n_nodes / 8 * 7 + n_leaves;  // approximate, split by point count
-    nodes_c = n_tot ? nodes_all * n_corner / n_tot : 0;
-    nodes_s = nodes_all - nodes_c;
-    t2 = now_ms();
-  } else {
+  {
     // ---- device build: upload {x,y,z,index}, build both trees in HBM --------------------
     t1 = now_ms();
     DevTree *trees[2] = {&ctx->tc, &ctx->ts};

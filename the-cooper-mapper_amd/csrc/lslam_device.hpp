@@ -60,7 +60,6 @@ struct TreeView {
   float bb_lo[3], bb_hi[3];  // root_bbox, nanoflann.hpp:1406-1427
   int32_t n_pts, n_nodes;
   uint32_t root_ref;
-  int32_t pos_end;  // one past the last position of this tree's points in `pts` (n_pts for a tree built alone; trees of a forest share `pts`)
 };
 
 constexpr int KD_STACK_MAX = 64;  // host refuses deeper trees (LSLAM_ERR_TREE_DEPTH)

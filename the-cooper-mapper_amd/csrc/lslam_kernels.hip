@@ -134,8 +134,8 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
           const int pp = a.prev_nb[(size_t)qi * 5 + j];
-          all = all && pp >= 0 && pp < T.pos_end;
-          if (pp >= 0 && pp < T.pos_end) u = fmaxf(u, dist2_xyz(sel[0], sel[1], sel[2], T.pts[pp]));
+          all = all && pp >= 0 && pp < T.n_pts;
+          if (pp >= 0 && pp < T.n_pts) u = fmaxf(u, dist2_xyz(sel[0], sel[1], sel[2], T.pts[pp]));
         }
         if (all) cap = fminf(cap, u * (1.0f + 1e-5f) + 1e-12f);
       }
@@ -183,7 +183,6 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
       T.pn = is_surf ? a.ts.pn : a.tc.pn;
       T.pts = is_surf ? a.ts.pts : a.tc.pts;
       T.n_pts = is_surf ? a.ts.n_pts : a.tc.n_pts;
-      T.pos_end = is_surf ? a.ts.pos_end : a.tc.pos_end;
       T.n_nodes = is_surf ? a.ts.n_nodes : a.tc.n_nodes;
       T.root_ref = is_surf ? a.ts.root_ref : a.tc.root_ref;
 #pragma unroll
@@ -215,7 +214,7 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
         bool all = true;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-          const bool ok = pp[j] >= 0 && pp[j] < T.pos_end;
+          const bool ok = pp[j] >= 0 && pp[j] < T.n_pts;
           all = all && ok;
           pv[j] = T.pts[ok ? pp[j] : 0];
         }

@@ -1365,14 +1365,12 @@ __global__ __launch_bounds__(256) void kd_bbox_kernel(const float4 *pts, int n, 
   }
 }
 
-// bounding box of every root's own point range (computeBoundingBox, :1406-1427): gridDim.y workgroups per root, each its
-// slice of the range (one workgroup per root is right for the hundreds of cube trees of a forest and took 0.62 ms for the
-// two trees of a 745 k-point surround); the host folds a root's slices (min / max: any order)
+// one workgroup per root: bounding box of its own point range (computeBoundingBox, :1406-1427)
 __global__ __launch_bounds__(256) void kd_bbox_seg_kernel(const float4 *pts, const int32_t *roots_lr, float *out) {
   __shared__ float smin[3][4], smax[3][4];
   const int l = roots_lr[2 * blockIdx.x], r = roots_lr[2 * blockIdx.x + 1];
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (int i = l + blockIdx.y * 256 + threadIdx.x; i < r; i += 256 * gridDim.y) {
+  for (int i = l + threadIdx.x; i < r; i += 256) {
     const float4 p = pts[i];
     mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
     mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
@@ -1388,8 +1386,8 @@ __global__ __launch_bounds__(256) void kd_bbox_seg_kernel(const float4 *pts, con
     const int d = threadIdx.x;
     float a = smin[d][0], b = smax[d][0];
     for (int w = 1; w < 4; ++w) { a = fminf(a, smin[d][w]); b = fmaxf(b, smax[d][w]); }
-    out[(blockIdx.x * gridDim.y + blockIdx.y) * 6 + d] = a;
-    out[(blockIdx.x * gridDim.y + blockIdx.y) * 6 + 3 + d] = b;
+    out[blockIdx.x * 6 + d] = a;
+    out[blockIdx.x * 6 + 3 + d] = b;
   }
 }
 
@@ -1559,7 +1557,6 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, PNode 
   view->pn = d_pn;
   view->pts = d_pts;
   view->n_pts = n;
-  view->pos_end = n;
   view->n_nodes = 0;
   view->root_ref = KD_LEAF;
   for (int d = 0; d < 3; ++d) view->bb_lo[d] = view->bb_hi[d] = 0.f;
@@ -1723,7 +1720,7 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   const size_t sz_queue = (size_t)queue_cap * sizeof(BuildItem), sz_ready = (size_t)queue_cap * sizeof(int32_t),
                sz_tmp = (size_t)std::max(n_total, 1) * sizeof(int32_t), sz_ctl = 256, sz_sub = (size_t)sub_cap * sizeof(BuildItem),
                sz_rf = ((size_t)T * 4 + 15) & ~(size_t)15, sz_lr = ((size_t)T * 8 + 15) & ~(size_t)15,
-               sz_bb = ((size_t)T * 24 * 64 + 15) & ~(size_t)15, sz_own = d_pn ? (size_t)A.node_cap * 6 * sizeof(float) : 0;
+               sz_bb = ((size_t)T * 24 + 15) & ~(size_t)15, sz_own = d_pn ? (size_t)A.node_cap * 6 * sizeof(float) : 0;
   void *blob = nullptr;
   if ((e = pool_get(stream, false, sz_queue + sz_sub + sz_ready + 2 * sz_tmp + sz_ctl + sz_rf + sz_lr + sz_bb + sz_own, &blob)) != hipSuccess) return e;
   char *p = static_cast<char *>(blob);
@@ -1739,25 +1736,12 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   A.own_box = d_pn ? reinterpret_cast<float *>(p) : nullptr;
   A.spin_limit = 1u << 22;
   if ((e = hipMemcpyAsync(d_lr, roots_lr, (size_t)T * 8, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-  int biggest = 0;
-  for (int t = 0; t < T; ++t) biggest = std::max(biggest, roots_lr[2 * t + 1] - roots_lr[2 * t]);
-  const int slices = biggest > 32768 ? 64 : 1;
-  hipLaunchKernelGGL(kd_bbox_seg_kernel, dim3(T, slices), dim3(256), 0, stream, d_pts, d_lr, d_bb);
-  std::vector<float> bbs((size_t)T * slices * 6), bb((size_t)T * 6);
-  if ((e = hipMemcpyAsync(bbs.data(), d_bb, bbs.size() * 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+  hipLaunchKernelGGL(kd_bbox_seg_kernel, dim3(T), dim3(256), 0, stream, d_pts, d_lr, d_bb);
+  std::vector<float> bb((size_t)T * 6);
+  if ((e = hipMemcpyAsync(bb.data(), d_bb, bb.size() * 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(d_nodes, 0, (size_t)A.node_cap * sizeof(KdNode), stream)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(A.root_feat, 0, sz_rf, stream)) != hipSuccess) return e;
   if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-  for (int t = 0; t < T; ++t)
-    for (int d = 0; d < 3; ++d) {
-      float a = bbs[((size_t)t * slices) * 6 + d], b = bbs[((size_t)t * slices) * 6 + 3 + d];
-      for (int sl = 1; sl < slices; ++sl) {
-        a = std::min(a, bbs[((size_t)t * slices + sl) * 6 + d]);
-        b = std::max(b, bbs[((size_t)t * slices + sl) * 6 + 3 + d]);
-      }
-      bb[(size_t)t * 6 + d] = a;
-      bb[(size_t)t * 6 + 3 + d] = b;
-    }
   std::vector<BuildItem> level, small;
   std::vector<int32_t> slot_of(T, -1);
   int groups = 0, leaves = 0;
@@ -1768,7 +1752,6 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
     v.pn = d_pn;
     v.pts = d_pts;
     v.n_pts = n;
-    v.pos_end = r;
     v.n_nodes = 0;
     for (int d = 0; d < 3; ++d) { v.bb_lo[d] = n > 0 ? bb[(size_t)t * 6 + d] : 0.f; v.bb_hi[d] = n > 0 ? bb[(size_t)t * 6 + 3 + d] : 0.f; }
     if (n <= 10) {  // the root is a leaf (nanoflann.hpp:936-951)

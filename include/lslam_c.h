@@ -399,7 +399,7 @@ int lslam_icp_align(lslam_ctx *ctx, const void *target, size_t n_target, const v
  *
  * The damped system is solved by preconditioned CG (block Jacobi + a coarse level of rigid-body motions of graph
  * aggregates, csrc/lslam_posegraph.hip) instead of g2o's sparse Cholesky: same optimum (tests/test_posegraph_bench_fixture.py).
- * When a workgroup per aggregate fits the device at once (the 5 000-keyframe bench graph does: 136 aggregates) the whole PCG
+ * When a workgroup per aggregate fits the device at once (the 5 000-keyframe bench graph does: 88 aggregates) the whole PCG
  * loop of a damped solve, and the inverse of the coarse matrix, each run as ONE persistent cooperative launch
  * (lslam_pg_stats.fused_solves counts them); larger graphs take a launch-per-step loop with the same arithmetic.  A
  * cooperative launch wants its workgroups resident together; if they are not (another process's persistent kernel on the

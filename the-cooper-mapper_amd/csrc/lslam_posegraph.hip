@@ -418,7 +418,7 @@ struct CoarseArgs {
   double *rc, *yc;        // [n_c]
   double *Rbuf, *Cbuf, *Bbuf;  // block Gauss-Jordan scratch: [6][n_c], [n_c][6], [36]
   const int32_t *cb_ptr, *cb_ent, *cb_ab;  // coarse blocks: fine entries of each, its (row, column) aggregate
-  const int32_t *agg_of, *agg_ptr, *agg_mem;  // vertex -> aggregate; aggregate -> its members (at most 64), first = its origin
+  const int32_t *agg_of, *agg_ptr, *agg_mem;  // vertex -> aggregate; aggregate -> its members (at most PG_AGG_MAX), first = its origin
   int n_v, G, na, n_c, n_cb, n_cblk;
 };
 
@@ -717,8 +717,8 @@ __global__ __launch_bounds__(64) void pgc_restrict_kernel(CoarseArgs c, const do
   const int a = blockIdx.x, j = threadIdx.x;
   const int m0 = c.agg_ptr[a], m1 = c.agg_ptr[a + 1];
   double w[6] = {0, 0, 0, 0, 0, 0};
-  if (m0 + j < m1) {
-    const int i = c.agg_mem[m0 + j];
+  for (int jj = j; m0 + jj < m1; jj += 64) {
+    const int i = c.agg_mem[m0 + jj];
     const double *P = c.P + (size_t)i * 36;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -833,6 +833,8 @@ __global__ void pgc_prolong_kernel(CoarseArgs c, double *z) {
 // its columns and items); otherwise the multi-launch loop runs.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int PK_BLOCK = 512;
+constexpr int PG_AGG_MAX = 85;             // members of an aggregate: its 6 x 85 rows have a thread each in the persistent kernel
+constexpr int PK_ROWS = 6 * PG_AGG_MAX;
 constexpr int PK_W = PK_BLOCK / 64;
 constexpr int PK_KREG = 9;   // matrix items per thread kept in registers (more are streamed from memory)
 constexpr int PK_CM = 3;     // column values per thread whose p_old is fetched ahead of the poll
@@ -956,8 +958,8 @@ __global__ __launch_bounds__(PK_BLOCK) void pg_pcg_persistent_kernel(PkArgs a) {
   extern __shared__ double pk_lds[];
   double *pf = pk_lds;                           // [lds_cols * 6] the columns' p
   double *dl = pf + (size_t)a.lds_cols * 6;      // [lds_items] products
-  double *rloc = dl + a.lds_items;               // [384] residuals of the rows
-  double *rcs = rloc + 384;                      // [n_c] restricted residual
+  double *rloc = dl + a.lds_items;               // [PK_ROWS] residuals of the rows
+  double *rcs = rloc + PK_ROWS;                  // [n_c] restricted residual
   double *ainv = rcs + a.n_c;                    // [6 * n_c] this aggregate's rows of the coarse inverse
   double *sh = ainv + 6 * (size_t)a.n_c;         // [8 * PK_W] wavefront sums
   __shared__ int bar_ok;
@@ -1014,7 +1016,7 @@ __global__ __launch_bounds__(PK_BLOCK) void pg_pcg_persistent_kernel(PkArgs a) {
 
   // ---- x = 0, r = b, z = M^-1 r ----
   double x = 0.0, r = isrow ? a.b[row] : 0.0, q = 0.0, p_own = 0.0, z_own = 0.0;
-  if (tid < 384) rloc[tid] = r;
+  if (tid < PK_ROWS) rloc[tid] = r;
   __syncthreads();
   {
     double zj = 0.0;
@@ -1225,7 +1227,7 @@ __global__ __launch_bounds__(PK_BLOCK) void pg_pcg_persistent_kernel(PkArgs a) {
     const double alpha = S[0] / Spq[0];
     x += alpha * p_own;
     r -= alpha * q;
-    if (tid < 384) rloc[tid] = r;
+    if (tid < PK_ROWS) rloc[tid] = r;
     if (coarse) {
 #pragma unroll
       for (int jc = 0; jc < 2; ++jc) {
@@ -1896,21 +1898,22 @@ int lslam_pg_create(int device, int32_t n_v, const double *poses7, int32_t n_e, 
   pg->h_row_of = rof;
   pg->h_row_col = rcol;
   {  // coarse blocks: fine entries grouped by (aggregate of the row, aggregate of the column), in entry order
-    if (const char *g = std::getenv("LSLAM_PG_AGG")) pg->agg = std::max(2, std::min(64, std::atoi(g)));
+    if (const char *g = std::getenv("LSLAM_PG_AGG")) pg->agg = std::max(2, std::min(PG_AGG_MAX, std::atoi(g)));
     if (const char *m = std::getenv("LSLAM_PG_COARSE")) pg->coarse_mode = std::atoi(m);
     const int G = pg->agg;
     // aggregates: breadth-first from the lowest unassigned vertex over the solver rows (neighbours in block-id order,
     // i.e. deterministic), at most G members each
     std::vector<int32_t> agg_of((size_t)n_v, -1), agg_ptr(1, 0), agg_mem;
+    const int Gg = std::getenv("LSLAM_PG_NO_MERGE") ? G : std::max(2, G - G / 8);  // growth limit (the merge below fills up to G)
     for (int seed = 0; seed < n_v; ++seed) {
       if (agg_of[(size_t)seed] >= 0) continue;
       const int a = (int)agg_ptr.size() - 1;
       const size_t first = agg_mem.size();
       agg_of[(size_t)seed] = a;
       agg_mem.push_back(seed);
-      for (size_t head = first; head < agg_mem.size() && (int)(agg_mem.size() - first) < G; ++head) {
+      for (size_t head = first; head < agg_mem.size() && (int)(agg_mem.size() - first) < Gg; ++head) {
         const int u = agg_mem[head];
-        for (int e = rptr[(size_t)u]; e < rptr[(size_t)u + 1] && (int)(agg_mem.size() - first) < G; ++e) {
+        for (int e = rptr[(size_t)u]; e < rptr[(size_t)u + 1] && (int)(agg_mem.size() - first) < Gg; ++e) {
           const int v = rcol[(size_t)e];
           if (agg_of[(size_t)v] < 0) {
             agg_of[(size_t)v] = a;
@@ -1919,6 +1922,50 @@ int lslam_pg_create(int device, int32_t n_v, const double *poses7, int32_t n_e, 
         }
       }
       agg_ptr.push_back((int32_t)agg_mem.size());
+    }
+    // Breadth-first growth leaves pockets: a handful of keyframes cut off between two full aggregates (59 of the bench
+    // graph's 136 aggregates had fewer than eight members).  Each would be a workgroup of the persistent solver, a
+    // participant of every grid exchange and six coarse unknowns of little use: a pocket joins the smallest adjacent
+    // aggregate that has room for it (the growth above stops at 7/8 of the limit to leave that room).
+    if (!std::getenv("LSLAM_PG_NO_MERGE")) {
+      const int n0 = (int)agg_ptr.size() - 1;
+      std::vector<int> size(n0), into(n0);
+      for (int a = 0; a < n0; ++a) { size[a] = agg_ptr[(size_t)a + 1] - agg_ptr[(size_t)a]; into[a] = a; }
+      for (int a = 0; a < n0; ++a) {
+        if (size[a] > std::max(1, G / 8)) continue;
+        int best = -1;
+        for (int m = agg_ptr[(size_t)a]; m < agg_ptr[(size_t)a + 1]; ++m) {
+          const int u = agg_mem[(size_t)m];
+          for (int e = rptr[(size_t)u]; e < rptr[(size_t)u + 1]; ++e) {
+            int b = agg_of[(size_t)rcol[(size_t)e]];
+            while (into[b] != b) b = into[b];
+            if (b != a && size[b] + size[a] <= G && (best < 0 || size[b] < size[best] || (size[b] == size[best] && b < best))) best = b;
+          }
+        }
+        if (best >= 0) { into[a] = best; size[best] += size[a]; size[a] = 0; }
+      }
+      std::vector<int> newid(n0, -1);
+      int nn = 0;
+      for (int a = 0; a < n0; ++a) if (into[a] == a) newid[a] = nn++;
+      std::vector<std::vector<int32_t>> mem((size_t)nn);
+      for (int a = 0; a < n0; ++a) {  // the receiving aggregate's members first (its first member stays its origin), pockets after them in order
+        int b = a;
+        while (into[b] != b) b = into[b];
+        if (b == a)
+          for (int m = agg_ptr[(size_t)a]; m < agg_ptr[(size_t)a + 1]; ++m) mem[(size_t)newid[a]].push_back(agg_mem[(size_t)m]);
+      }
+      for (int a = 0; a < n0; ++a) {
+        int b = a;
+        while (into[b] != b) b = into[b];
+        if (b != a)
+          for (int m = agg_ptr[(size_t)a]; m < agg_ptr[(size_t)a + 1]; ++m) mem[(size_t)newid[b]].push_back(agg_mem[(size_t)m]);
+      }
+      agg_ptr.assign(1, 0);
+      agg_mem.clear();
+      for (int a = 0; a < nn; ++a) {
+        for (int32_t u : mem[(size_t)a]) { agg_of[(size_t)u] = a; agg_mem.push_back(u); }
+        agg_ptr.push_back((int32_t)agg_mem.size());
+      }
     }
     pg->n_agg = (int)agg_ptr.size() - 1;
     pg->n_c = 6 * pg->n_agg;
@@ -1974,7 +2021,13 @@ int lslam_pg_create(int device, int32_t n_v, const double *poses7, int32_t n_e, 
       }
       pg->pk_lds_cols = max_cols;
       pg->pk_lds_items = max_items;
-      pg->pk_lds_bytes = ((size_t)max_cols * 6 + (size_t)max_items + 384 + 7 * (size_t)pg->n_c + 8 * PK_W) * sizeof(double);
+      pg->pk_lds_bytes = ((size_t)max_cols * 6 + (size_t)max_items + PK_ROWS + 7 * (size_t)pg->n_c + 8 * PK_W) * sizeof(double);
+      if (std::getenv("LSLAM_DEBUG")) {
+        int hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int a = 0; a < pg->n_agg; ++a) hist[std::min(8, (agg_ptr[(size_t)a + 1] - agg_ptr[(size_t)a]) / 8)]++;
+        fprintf(stderr, "[lslam pg] aggregate sizes (members / 8): %d %d %d %d %d %d %d %d %d\n", hist[0], hist[1], hist[2], hist[3],
+                hist[4], hist[5], hist[6], hist[7], hist[8]);
+      }
       if (std::getenv("LSLAM_DEBUG"))
         fprintf(stderr, "[lslam pg] %d aggregates, widest: %d columns, %d items; persistent-kernel LDS %zu bytes\n", pg->n_agg,
                 max_cols, max_items, pg->pk_lds_bytes);

@@ -147,7 +147,7 @@ PG_DEV void edge_error(const Pose &xi, const Pose &xj, const Pose &z, double e[6
 constexpr int REC = 121;
 
 __global__ void pg_edge_kernel(const double *poses, const int32_t *ij, const double *meas,
-                               const double *info, int e_begin, int e_end, int fixed, double *rec) {
+                               const double *info, int e_begin, int e_end, int fixed, double *rec, double *chi) {
   const int e = e_begin + blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= e_end) return;
   const int i = ij[2 * e], j = ij[2 * e + 1];
@@ -208,6 +208,7 @@ __global__ void pg_edge_kernel(const double *poses, const int32_t *ij, const dou
     c2 += er[r] * s;
   }
   o[120] = c2;
+  chi[e - e_begin] = c2;  // also compact: the sum over the edges then reads consecutive doubles instead of one per record
 }
 
 // chi2 only (trial evaluation): per-edge value
@@ -1601,14 +1602,14 @@ int linearize(lslam_pg *pg, const double *poses) {
   const int ne = pg->e_end - pg->e_begin;
   if (ne > 0)
     hipLaunchKernelGGL(pg_edge_kernel, dim3((ne + 127) / 128), dim3(128), 0, pg->stream, poses, pg->d_ij,
-                       pg->d_meas, pg->d_info, pg->e_begin, pg->e_end, pg->fixed, pg->d_rec);
+                       pg->d_meas, pg->d_info, pg->e_begin, pg->e_end, pg->fixed, pg->d_rec, pg->d_chi);
   hipLaunchKernelGGL(pg_assemble_vertex_kernel, dim3((pg->n_v * 42 + 255) / 256), dim3(256), 0, pg->stream,
                      pg->d_rec, pg->d_vptr, pg->d_vadj, pg->n_v, pg->sharded() ? -1 : pg->fixed,
                      pg->diag(), pg->b());
   if (pg->n_off > 0)
     hipLaunchKernelGGL(pg_assemble_off_kernel, dim3((pg->n_off * 36 + 255) / 256), dim3(256), 0, pg->stream,
                        pg->d_rec, pg->d_optr, pg->d_oadj, pg->n_off, pg->off());
-  hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(SUM_BLOCK), 0, pg->stream, pg->d_rec + 120, ne, REC, pg->chi());
+  hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(SUM_BLOCK), 0, pg->stream, pg->d_chi, ne, 1, pg->chi());
   PG_TRY(hipGetLastError());
   if (pg->sharded()) {
     const int rc = pg->reduce(pg->d_sys, pg->sys_doubles());

@@ -971,11 +971,14 @@ __global__ __launch_bounds__(PK_BLOCK) void pg_pcg_persistent_kernel(PkArgs a) {
   const bool coarse = a.coarse != 0;
 
   // ---- what stays on chip for the whole solve ----
+  // a thread's items come in units of three consecutive rows of one entry (unit u = tid + PK_BLOCK ju holds items
+  // 3 u .. 3 u + 2): the three share the entry's column, fetched from LDS once
+  static_assert(PK_KREG % 3 == 0, "items in units of three rows");
   double A[PK_KREG][6];
   int lcol[PK_KREG];
 #pragma unroll
   for (int j = 0; j < PK_KREG; ++j) {
-    const int i = tid + PK_BLOCK * j;
+    const int i = 3 * (tid + PK_BLOCK * (j / 3)) + j % 3;
     const bool on = i < nit;
     const int le = on ? i / 6 : 0, r = on ? i - le * 6 : 0;
     const int e = on ? a.bent[e0 + le] : 0;
@@ -1135,17 +1138,23 @@ __global__ __launch_bounds__(PK_BLOCK) void pg_pcg_persistent_kernel(PkArgs a) {
     __syncthreads();
     PK_T(1)
 #pragma unroll
-    for (int j = 0; j < PK_KREG; ++j) {
-      const int i = tid + PK_BLOCK * j;
-      if (i < nit) {
-        double s = 0.0;
+    for (int ju = 0; ju < PK_KREG / 3; ++ju) {
+      const int i0 = 3 * (tid + PK_BLOCK * ju);
+      if (i0 < nit) {  // (the items of an entry come in sixes: a unit is whole or absent)
+        double pc[6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) s += A[j][c] * pf[lcol[j] + c];
-        dl[i] = s;
+        for (int c = 0; c < 6; ++c) pc[c] = pf[lcol[3 * ju] + c];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          double s = 0.0;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) s += A[3 * ju + k][c] * pc[c];
+          dl[i0 + k] = s;
+        }
       }
-      if (j & 1) __builtin_amdgcn_sched_barrier(0);  // two items' operands in flight, not all of them (register pressure)
+      __builtin_amdgcn_sched_barrier(0);  // one unit's operands in flight, not all of them (register pressure)
     }
-    for (int i = tid + PK_BLOCK * PK_KREG; i < nit; i += PK_BLOCK) {  // an aggregate with more items than the registers hold
+    for (int i = 3 * PK_BLOCK * (PK_KREG / 3) + tid; i < nit; i += PK_BLOCK) {  // an aggregate with more items than the registers hold
       const int le = i / 6, rw = i - le * 6;
       const int e = a.bent[e0 + le], lc = a.blc[e0 + le] * 6;
       double s = 0.0;

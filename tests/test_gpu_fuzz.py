@@ -17,3 +17,13 @@ def test_parity_fuzz_nine_problems():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "9 problems, no mismatch" in r.stdout
+
+
+@pytest.mark.gpu
+def test_posegraph_solver_forms_fuzz_twenty_graphs():
+    """tools/fuzz_posegraph.py: random graphs from 2 keyframes up (hubs, aggregates of one member, one workgroup only) --
+    the persistent kernels against the launch loop, and a persistent run against itself bit for bit."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_posegraph.py"), "20"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "pose-graph fuzz: 20 graphs" in r.stdout

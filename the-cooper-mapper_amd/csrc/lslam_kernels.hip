@@ -866,7 +866,6 @@ LSLAM_DEV void gnp_st(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_REL
 
 __global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void gn_persistent_kernel(SweepArgs a, int jtj_mode, GnLoopArgs g) {
   constexpr int BLOCK = SWEEP_BLOCK, LDS_DEPTH = KD_STACK_LDS;
-  static_assert(BLOCK == 256, "the reduction below is written for 256 threads");
   __shared__ float red[BLOCK / 64][NCOL];
   __shared__ uint32_t stack_lds[2 * LDS_DEPTH * BLOCK];
   __shared__ GNState lst;       // this workgroup's copy of the scan's state
@@ -921,10 +920,10 @@ __global__ __launch_bounds__(SWEEP_BLOCK) __attribute__((amdgpu_waves_per_eu(2))
     }
     for (unsigned spins = 0;; ++spins) {
       int bad = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const double v = __hip_atomic_load(gsl + tid + BLOCK * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        (&redd[0][0])[tid + BLOCK * j] = v;
+#pragma unroll 4
+      for (int i = tid; i < 32 * NCOL; i += BLOCK) {
+        const double v = __hip_atomic_load(gsl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (&redd[0][0])[i] = v;
         bad |= (__double_as_longlong(v) == GNP_SENT64) ? 1 : 0;
       }
       if (!__syncthreads_or(bad)) break;

@@ -64,7 +64,7 @@ def parse_args():
     ap.add_argument("--rings", type=int, default=64)
     ap.add_argument("--scans", type=int, default=int(os.environ.get("LSLAM_SCANS", "960")),
                     help="resident query scans per GPU; one step matches all of them")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("LSLAM_BATCH", "320")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("LSLAM_BATCH", "960")),
                     help="scans in flight per launch sequence (lslam_opts.scans_in_flight)")
     ap.add_argument("--map-frames", type=int, default=10000, help="frames accumulated into the voxel map")
     ap.add_argument("--map-rings", type=int, default=16, help="rings of the frames the map is built from (VLP-16)")
@@ -442,7 +442,10 @@ def pmc_counters(avg_sweep_ms):
         c["wait_frac"] = v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"]
     if "SQ_ACTIVE_INST_VALU" in v and cyc > 0:
         # SQ_ACTIVE_INST_VALU counts quad-cycles of VALU issue summed over the 1 024 SIMDs
-        c["valu_busy"] = v["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 1024.0)
+        # (normalised by GRBM_GUI_ACTIVE / 8 engine cycles: the eight XCDs do not start and end a launch on the same cycle,
+        # so the ratio can come out a per cent above one -- reported raw next to the capped value)
+        c["valu_busy_raw"] = v["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 1024.0)
+        c["valu_busy"] = min(1.0, c["valu_busy_raw"])
     for k in ("TA_BUSY_avr", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_PENDING_STALL_CYCLES_sum", "TA_FLAT_READ_WAVEFRONTS_sum",
               "TCP_TCC_READ_REQ_sum", "GRBM_GUI_ACTIVE", "TA_BUSY_max", "TCP_GATE_EN1_sum", "TCP_GATE_EN2_sum", "TA_TA_BUSY_sum"):
         if k in v:

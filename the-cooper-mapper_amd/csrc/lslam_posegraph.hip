@@ -1645,6 +1645,7 @@ int eval_chi2(lslam_pg *pg, const double *poses, double *out) {
     const int rc = pg->reduce(pg->chi(), 1);
     if (rc) return rc;
   }
+  if (!out) return LSLAM_OK;  // the caller reads pg->chi() itself, behind more work on the stream
   PG_TRY(hipMemcpyAsync(out, pg->chi(), sizeof(double), hipMemcpyDeviceToHost, pg->stream));
   PG_TRY(hipStreamSynchronize(pg->stream));
   return LSLAM_OK;
@@ -2327,14 +2328,15 @@ int lslam_pg_optimize(lslam_pg *pg, int32_t max_iters, lslam_pg_stats *st_out) {
       hipLaunchKernelGGL(pg_update_kernel, dim3((pg->n_v + 127) / 128), dim3(128), 0, pg->stream, pg->d_poses,
                          pg->d_x, pg->n_v, pg->fixed, pg->d_trial);
       PG_TRY(hipGetLastError());
-      double tmp;
-      rc = eval_chi2(pg, pg->d_trial, &tmp);
+      // the trial's chi2 and the gain denominator are enqueued together and read back after ONE wait
+      double tmp, scale;
+      rc = eval_chi2(pg, pg->d_trial, nullptr);  // enqueue only
       if (rc) return rc;
       hipLaunchKernelGGL(pg_dot_scale_kernel, dim3(pg->n_cg_blocks), dim3(CG_BLOCK), 0, pg->stream, pg->d_x,
                          pg->b(), n6, lambda, pg->d_part);
       hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(SUM_BLOCK), 0, pg->stream, pg->d_part, pg->n_cg_blocks, 1, pg->d_tmp + 2);
       PG_TRY(hipGetLastError());  // a failed launch must not turn into a stale read below
-      double scale;
+      PG_TRY(hipMemcpyAsync(&tmp, pg->chi(), 8, hipMemcpyDeviceToHost, pg->stream));
       PG_TRY(hipMemcpyAsync(&scale, pg->d_tmp + 2, 8, hipMemcpyDeviceToHost, pg->stream));
       PG_TRY(hipStreamSynchronize(pg->stream));
       scale += 1e-3;

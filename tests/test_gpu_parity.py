@@ -813,6 +813,20 @@ def test_posegraph_persistent_timeout_falls_back_to_launch_loop(pkg, synth, monk
     assert abs(st.chi2_final - ref.last_stats.chi2_final) <= 1e-6 * ref.last_stats.chi2_final
     assert np.abs(pg.poses() - ref.poses()).max() < 1e-6
     pg.close(); ref.close()
+    # the persistent coarse inverse likewise (second level forced on): its abort flag sends the inverse, assembled once
+    # more, through the launch-per-pivot loop
+    monkeypatch.delenv("LSLAM_DEBUG_PG_ABORT")
+    monkeypatch.setenv("LSLAM_PG_COARSE", "1")
+    ref = pkg.PoseGraph(0)
+    ref.set_graph(g["init"], g["ij"], g["meas"], g["info"])
+    ref.optimize(5)
+    monkeypatch.setenv("LSLAM_DEBUG_GJ_ABORT", "2")
+    pg = pkg.PoseGraph(0)
+    pg.set_graph(g["init"], g["ij"], g["meas"], g["info"])
+    assert pg.optimize(5) == ref.last_stats.iterations
+    assert abs(pg.last_stats.chi2_final - ref.last_stats.chi2_final) <= 1e-6 * ref.last_stats.chi2_final
+    assert np.abs(pg.poses() - ref.poses()).max() < 1e-6
+    pg.close(); ref.close()
 
 
 # ---- the device builder is the only builder: its structure limits fail loudly -----------------

@@ -1312,6 +1312,7 @@ __global__ __launch_bounds__(PK_BLOCK) void pg_pcg_persistent_kernel(PkArgs a) {
 constexpr int GJ_BLOCK = 512;
 constexpr int GJ_CREG = 4;
 struct GjArgs {
+  int debug_abort; // tests: workgroup 0 raises the abort flag at this pivot step (-1: never)
   double *Ac;      // [n_c][n_c], inverted in place
   double *slots;   // [na][6][n_c], sentinel-filled
   unsigned *bar;   // [1] abort flag
@@ -1332,6 +1333,7 @@ __global__ __launch_bounds__(GJ_BLOCK) void pgc_gj_persistent_kernel(GjArgs g) {
   for (int k = 0; k < g.na; ++k) {
     const int k6 = k * 6;
     double *slot = g.slots + (size_t)k * 6 * n;
+    if (k == g.debug_abort && i == 0 && tid == 0) pk_abort(g.bar);
     if (i == k) {
 #pragma unroll
       for (int jc = 0; jc < GJ_CREG; ++jc) {
@@ -1720,6 +1722,7 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
     if (pg->gj_fit == 1) {
       GjArgs gj;
       gj.Ac = c.Ac; gj.slots = pg->d_gjslots; gj.bar = pg->d_bar; gj.n_c = c.n_c; gj.na = c.na;
+      gj.debug_abort = std::getenv("LSLAM_DEBUG_GJ_ABORT") ? std::atoi(std::getenv("LSLAM_DEBUG_GJ_ABORT")) : -1;
       PG_TRY(hipMemsetAsync(pg->d_bar, 0, 2 * sizeof(unsigned), pg->stream));
       PG_TRY(hipMemsetD32Async((hipDeviceptr_t)pg->d_gjslots, (int)PK_SENT32, (size_t)c.na * 6 * c.n_c * 2, pg->stream));
       void *gargs[] = {(void *)&gj};
@@ -1727,10 +1730,13 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
       unsigned gbar[2] = {0, 0};
       PG_TRY(hipMemcpyAsync(gbar, pg->d_bar, sizeof(gbar), hipMemcpyDeviceToHost, pg->stream));
       PG_TRY(hipStreamSynchronize(pg->stream));
-      if (gbar[1] != 0) {  // not all workgroups resident at once (see the PCG kernel's fallback): A_c is untouched, the launch loop inverts it
+      if (gbar[1] != 0) {  // not all workgroups resident at once (see the PCG kernel's fallback): the launch loop inverts A_c,
+                           // assembled once more (a kernel that timed out wrote nothing back, but nothing here relies on that)
         if (std::getenv("LSLAM_DEBUG")) fprintf(stderr, "[lslam pg] persistent Gauss-Jordan kernel timed out: launch loop from here on\n");
         pg->gj_fit = 0;
         pg->pk_timeouts++;
+        PG_TRY(hipMemsetAsync(c.Ac, 0, nn * sizeof(double), pg->stream));
+        hipLaunchKernelGGL(pgc_assemble_kernel, dim3(c.n_cb), dim3(64), 0, pg->stream, c, pg->d_vals, pg->d_row_of, pg->d_row_col, n_items);
       }
     }
     if (pg->gj_fit != 1) {

@@ -646,6 +646,24 @@ def pose_graph_leg(pkg, synth, distmod, dist, rank, world, local_rank, comm, np,
                            "alg_bytes_per_cg_iteration": spmv_bytes, "us_per_cg_iteration": 1e6 * per_it_s,
                            "accounting": "block-CSR bytes of one product / (solver GPU time / PCG iterations): the time "
                                          "includes the preconditioner, the vector updates and the linearisations"}
+        # measured memory traffic of the persistent kernel from the committed counter passes (profiles/r02_pg_pmc.csv:
+        # rocprofv3 --pmc of tools/bench_posegraph.py, mean per launch = per damped solve), not measured in this run
+        pmc = os.path.join(ROOT, "profiles", "r02_pg_pmc.csv")
+        if fused and os.path.exists(pmc):
+            v = {}
+            for line in open(pmc):
+                f = line.strip().split(",")
+                if len(f) >= 4 and not line.startswith("#") and f[0] != "pass":
+                    v[f[1]] = float(f[3])
+            if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                per_launch = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
+                its = st.cg_iterations / max(1, st.lm_trials)
+                res["roofline"]["traffic"] = per_launch / its
+                res["roofline"]["traffic_source"] = ("profiles/r02_pg_pmc.csv: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch of "
+                                                     "pg_pcg_persistent_kernel (one damped solve) / this run's %.0f PCG iterations per solve; "
+                                                     "not measured in this run" % its)
+                if v.get("SQ_WAVE_CYCLES", 0) > 0:
+                    res["roofline"]["wait_frac"] = v.get("SQ_WAIT_ANY", 0.0) / v["SQ_WAVE_CYCLES"]
     pg.close()
     if with_cpu and rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -84,6 +84,15 @@ typedef struct {
  *   AUTO    the faster one on MI355X: LANE (the packet search trades the divergent gathers for about twice
  *           the vector ALU work and measured slower; DESIGN.md has the numbers) */
 enum { LSLAM_SEARCH_AUTO = 0, LSLAM_SEARCH_LANE = 1, LSLAM_SEARCH_PACKET = 2 };
+/* Traversal-stack shape of the LANE search, ORed into a search mode (same answer, bit for bit -- the shapes hold the
+ * same entries; only where they live differs):
+ *   DEEP     all 32 levels of a lane's stack in LDS (two workgroups per CU): what a latency-bound single-scan launch takes
+ *   SHALLOW  12 levels in LDS, deeper ones in an HBM overflow area (five wavefronts per SIMD): what a launch of more than
+ *            2 048 wavefronts -- a batch, the bench -- takes
+ *   AUTO     by the size of the launch
+ * LSLAM_FORCE_STACK=deep|shallow|auto in the environment overrides the bits.  The parity tests run every oracle
+ * comparison through both shapes; lslam_debug_sweep_launches says which kernel really ran. */
+enum { LSLAM_STACK_AUTO = 0, LSLAM_STACK_DEEP = 0x100, LSLAM_STACK_SHALLOW = 0x200 };
 
 /* Per-call statistics (the counters the reference prints, ScanMatch.cpp:35-40,
  * 143,269, plus timing taps). */
@@ -542,6 +551,10 @@ int lslam_pg_solve(lslam_pg *pg, double lambda, double *dx_out, int32_t *cg_iter
 
 /* Device handle taps for harnesses that time on the library's stream. */
 void *lslam_stream(lslam_ctx *ctx); /* hipStream_t */
+/* Sweep launches of this context so far, per kernel instantiation: [0] whole stack in LDS, [1] the same with the HBM
+ * overflow (trees deeper than 33 levels), [2] the shallow-stack batch kernel sweep_kernel<256,true,false,12>, [3] per-cube
+ * trees, [4] per-cube trees with overflow, [5] packet search, [6] persistent Gauss-Newton kernel, [7] unused. */
+void lslam_debug_sweep_launches(lslam_ctx *ctx, uint64_t counts[8]);
 
 #ifdef __cplusplus
 }

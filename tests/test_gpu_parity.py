@@ -23,6 +23,10 @@ def bits(a):
 
 
 SEARCH = {"lane": 1, "packet": 2}  # LSLAM_SEARCH_LANE / _PACKET (include/lslam_c.h)
+# the lane search through each traversal-stack shape (LSLAM_STACK_DEEP / _SHALLOW): "lane_shallow" is the instantiation a
+# batch launch -- the bench -- takes, sweep_kernel<256, true, false, 12> (12 levels in LDS, the rest in HBM)
+SEARCH_SHAPES = {"lane": 1 | 0x100, "lane_shallow": 1 | 0x200, "packet": 2}
+SHAPE_VARIANT = {"lane": "deep", "lane_shallow": "shallow", "packet": "packet"}
 
 
 @pytest.mark.parametrize("search", ["lane", "packet"])
@@ -203,15 +207,16 @@ def test_knn5_deep_tree_uses_overflow_stack(ctx, oracle):
     assert np.array_equal(gi, oi) and np.array_equal(bits(gd), bits(od))
 
 
-@pytest.mark.parametrize("search", ["lane", "packet"])
+@pytest.mark.parametrize("search", ["lane", "lane_shallow", "packet"])
 @pytest.mark.parametrize("jtj_mode", [0, 1])
 def test_sweep_matches_oracle(ctx, oracle, small_problem, jtj_mode, search):
     pr = small_problem
     ctx.map_set(pr["map_corner"], pr["map_surf"])
     ctx.scan_set(pr["corner"], pr["surf"])
     tc, ts = oracle.kdtree(pr["map_corner"]), oracle.kdtree(pr["map_surf"])
+    before = ctx.sweep_launches()
     for pose in (pr["init_pose"], pr["gt_pose"]):
-        g = ctx.sweep(pose, jtj_mode=jtj_mode, search_mode=SEARCH[search])
+        g = ctx.sweep(pose, jtj_mode=jtj_mode, search_mode=SEARCH_SHAPES[search])
         o = oracle.sweep(tc, ts, pr["corner"], pr["surf"], pose)
         assert np.array_equal(g["idx"], o["idx"])
         assert np.array_equal(bits(g["d2"]), bits(o["d2"]))
@@ -222,6 +227,9 @@ def test_sweep_matches_oracle(ctx, oracle, small_problem, jtj_mode, search):
         assert np.abs(g["sums"][:27] - o["sums"][:27]).max() <= 2e-5 * scale
         assert g["sums"][27] == o["sums"][27] and g["sums"][28] == o["sums"][28]
         assert (o["flags"] & 4).sum() > 1000
+    after = ctx.sweep_launches()  # the instantiation asked for is the one that ran
+    assert after[SHAPE_VARIANT[search]] - before[SHAPE_VARIANT[search]] == 2
+    assert sum(after.values()) - sum(before.values()) == 2
 
 
 def test_sweep_mfma_equals_valu_path(ctx, small_problem):
@@ -270,13 +278,14 @@ def test_gn_step_degenerate_projection(ctx, oracle):
     assert np.abs(g["x"] - o["x"]).max() < 1e-5 + 1e-4 * np.abs(o["x"]).max()
 
 
-@pytest.mark.parametrize("search", ["lane", "packet"])
+@pytest.mark.parametrize("search", ["lane", "lane_shallow", "packet"])
 @pytest.mark.parametrize("jtj_mode", [0, 1])
 def test_full_loop_pose_matches_oracle(ctx, oracle, small_problem, jtj_mode, search):
     pr = small_problem
     opts = ctx.default_opts()
     opts.jtj_mode = jtj_mode
-    opts.search_mode = SEARCH[search]
+    opts.search_mode = SEARCH_SHAPES[search]
+    before = ctx.sweep_launches()
     status, pose, st = ctx.scanmatch_full(pr["map_corner"], pr["map_surf"], pr["corner"], pr["surf"],
                                           pr["init_pose"], opts)
     ok, opose, ost = oracle.scanmatch_scan(pr["map_corner"], pr["map_surf"], pr["corner"], pr["surf"],
@@ -289,6 +298,9 @@ def test_full_loop_pose_matches_oracle(ctx, oracle, small_problem, jtj_mode, sea
     assert abs(st.score - ost.score) <= 1e-5 * ost.score
     assert abs(st.percent - ost.percent) <= 1e-6
     assert st.point_residuals == ost.point_residuals
+    after = ctx.sweep_launches()
+    ran = {k for k in after if after[k] != before[k]}
+    assert ran == {SHAPE_VARIANT[search]}, ran
 
 
 def test_full_loop_mapping_settings(ctx, oracle, small_problem):

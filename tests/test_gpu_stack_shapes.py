@@ -1,0 +1,232 @@
+"""The kernel the bench times under the oracle (-m gpu, through the C ABI).
+
+`launch_sweep` (csrc/lslam_kernels.hip) has two traversal-stack shapes for the lane search of
+ScanMatch.cpp:97-132: the whole 32-level stack in LDS (`sweep_kernel<256,false,false,32>`, what a single
+scan's latency-bound launch takes) and 12 levels in LDS with an HBM overflow area
+(`sweep_kernel<256,true,false,12>`: five wavefronts per SIMD, two-entry pop rounds), which every launch of
+more than 2 048 wavefronts takes -- i.e. every batch, and the whole timed region of bench.py.  These tests put
+THAT instantiation against the oracle: forced through the LSLAM_STACK_* bits on small problems (here and in
+tests/test_gpu_parity.py), and picked by the library itself on batches large enough -- with
+`lslam_debug_sweep_launches` saying which kernel really ran.
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_M = 1e-4    # BASELINE.json north_star: pose within 1e-4 m of the CPU reference
+POSE_TOL_RAD = 1e-5
+LANE, DEEP, SHALLOW = 1, 0x100, 0x200  # LSLAM_SEARCH_LANE, LSLAM_STACK_DEEP, LSLAM_STACK_SHALLOW
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _counts_close(a, b):
+    """Match counts of the LAST sweep of a loop.  GPU and oracle sum A^T A in different orders, so from the second iteration
+    on their poses differ in the last bits (<= 1e-6 m); a point that sits exactly on a gate (d2[4] < 5, the 0.2 m plane
+    bound, w > 0.1) can then fall on either side.  At a FIXED pose flags are compared bit for bit (the sweep taps); here a
+    handful of threshold-adjacent points out of >= 10^4 may differ."""
+    return all(abs(int(x) - int(y)) <= max(2, int(1e-4 * max(x, y))) for x, y in zip(a, b))
+
+
+def _ran(before, after):
+    return {k: after[k] - before[k] for k in after if after[k] != before[k]}
+
+
+def _deepen(pts, n_clusters, seed):
+    """Geometrically spaced far clusters appended to a cloud: nanoflann's mid-split peels them off one or two at a time,
+    so the tree over the real points hangs ~n_clusters levels down (deeper than the 33 levels the LDS stack covers)."""
+    rng = np.random.default_rng(seed)
+    c = 500.0 * 1.6 ** np.arange(n_clusters)
+    extra = np.concatenate([np.stack([cc + rng.uniform(0, 0.01 * cc, 12), rng.uniform(-1, 1, 12), rng.uniform(0, 1, 12)], 1)
+                            for cc in c]).astype(np.float32)
+    out = np.zeros((len(extra), pts.shape[1]), np.float32)
+    out[:, :3] = extra
+    return np.concatenate([pts, out])
+
+
+@pytest.mark.parametrize("shape", ["deep", "shallow"])
+def test_full_loop_on_a_deep_tree_matches_oracle(ctx, oracle, small_problem, shape):
+    """The whole Gauss-Newton loop against trees 40 / 46 levels deep: the overflow area of BOTH shapes is really used
+    (levels >= 32 of the deep shape, levels >= 12 of the shallow one), sweeps and final pose against the oracle."""
+    pr = small_problem
+    mc, ms = _deepen(pr["map_corner"], 34, 1), _deepen(pr["map_surf"], 34, 2)
+    tc, ts = oracle.kdtree(mc), oracle.kdtree(ms)
+    assert 34 < tc.max_depth() <= 64 and 34 < ts.max_depth() <= 64
+    mode = LANE | (DEEP if shape == "deep" else SHALLOW)
+    variant = "deep_ovf" if shape == "deep" else "shallow"
+    ctx.map_set(mc, ms)
+    info = ctx.map_info()
+    assert info.depth_corner == tc.max_depth() and info.depth_surf == ts.max_depth()
+    ctx.scan_set(pr["corner"], pr["surf"])
+    before = ctx.sweep_launches()
+    for pose in (pr["init_pose"], pr["gt_pose"]):  # unbounded sweeps: every neighbour list against nanoflann's
+        g = ctx.sweep(pose, jtj_mode=1, search_mode=mode)
+        o = oracle.sweep(tc, ts, pr["corner"], pr["surf"], pose)
+        assert np.array_equal(g["idx"], o["idx"]) and np.array_equal(bits(g["d2"]), bits(o["d2"]))
+        assert np.array_equal(g["flags"], o["flags"]) and np.array_equal(bits(g["coeff"]), bits(o["coeff"]))
+    opts = ctx.default_opts()
+    opts.search_mode = mode
+    status, pose, st = ctx.run(pr["init_pose"], opts)  # bounded sweeps, neighbours of the previous sweep as the bound
+    ok, opose, ost = oracle.scanmatch_scan(mc, ms, pr["corner"], pr["surf"], pr["init_pose"])
+    assert (status == 0) == ok and st.iterations == ost.iterations and st.converged == ost.converged
+    assert (st.n_line, st.n_plane, st.n_rows) == (ost.n_line, ost.n_plane, ost.n_rows)
+    assert np.abs(pose[3:] - opose[3:]).max() <= POSE_TOL_M and np.abs(pose[:3] - opose[:3]).max() <= POSE_TOL_RAD
+    assert set(_ran(before, ctx.sweep_launches())) == {variant}
+    # AUTO on a deep tree takes the shallow kernel (bounded loop), whatever the launch size
+    before = ctx.sweep_launches()
+    status2, pose2, st2 = ctx.run(pr["init_pose"])
+    assert set(_ran(before, ctx.sweep_launches())) == {"shallow"}
+    assert np.array_equal(bits(pose2), bits(pose)) and st2.iterations == st.iterations
+
+
+def test_batch_above_512_blocks_runs_the_shallow_kernel_and_matches_oracle(ctx, oracle, synth, small_problem):
+    """Twelve 16 x 900 scans resident together: ~640 blocks = ~2 560 wavefronts, so `launch_sweep` itself picks
+    sweep_kernel<256,true,false,12> -- the instantiation bench.py times.  Every scan against `oracle.scanmatch_scan`, and
+    bit for bit against its own run alone through the deep stack; one scan far from the map, one empty."""
+    pr = small_problem
+    world = pr["world"]
+    scans, inits = [], []
+    for k in range(12):
+        gt = (0.004 * k, -0.006 + 0.001 * k, 0.15 + 0.09 * k, 4.0 - 0.9 * k, -3.0 + 0.55 * k, synth.SENSOR_HEIGHT)
+        qc, qs, gt = synth.make_scan(world, 16, 900, gt_pose=gt, seed=300 + k)
+        scans.append((qc, qs))
+        inits.append(synth.perturb_pose(gt, seed=400 + k))
+    inits[5][3] += 400.0                                   # far from the map: ScanMatch.cpp:141-145, pose untouched
+    empty = np.zeros((0, 4), np.float32)
+    scans[9] = (empty, empty)                              # no points at all
+    ctx.map_set(pr["map_corner"], pr["map_surf"])
+    deep = ctx.default_opts()
+    deep.search_mode = LANE | DEEP
+    single = []
+    before = ctx.sweep_launches()
+    for (qc, qs), p0 in zip(scans, inits):
+        single.append(ctx.scanmatch_scan(qc, qs, p0, deep))
+    assert set(_ran(before, ctx.sweep_launches())) == {"deep"}
+    ctx.scan_set_batch(scans)
+    opts = ctx.default_opts()
+    opts.scans_in_flight = 12
+    before = ctx.sweep_launches()
+    worst, poses, stats = ctx.run_batch(np.stack(inits), opts)
+    ran = _ran(before, ctx.sweep_launches())
+    assert set(ran) == {"shallow"} and ran["shallow"] >= 3, ran  # picked by launch size, not forced
+    n_blocks = sum((len(c) + 255) // 256 + (len(s) + 255) // 256 for c, s in scans)
+    assert n_blocks > 512
+    for k, (status, pose, st) in enumerate(single):
+        assert stats[k].status == st.status and stats[k].iterations == st.iterations, k
+        assert (stats[k].n_rows, stats[k].n_line, stats[k].n_plane) == (st.n_rows, st.n_line, st.n_plane), k
+        assert np.array_equal(bits(poses[k]), bits(pose)), k  # shallow batch == deep single run, bit for bit
+        assert stats[k].point_residuals == st.point_residuals
+    for k, ((qc, qs), p0) in enumerate(zip(scans, inits)):
+        ok, opose, ost = oracle.scanmatch_scan(pr["map_corner"], pr["map_surf"], qc, qs, p0)
+        # the reference has one `return false` for "too few matches" and "not converged" (ScanMatch.cpp:342-346, oracle: 2);
+        # the C ABI tells them apart (LSLAM_TOO_FEW_MATCHES = 5)
+        assert (2 if stats[k].status == 5 else stats[k].status) == ost.status, k
+        assert stats[k].iterations == ost.iterations and stats[k].converged == ost.converged, k
+        assert _counts_close((stats[k].n_line, stats[k].n_plane, stats[k].n_rows), (ost.n_line, ost.n_plane, ost.n_rows)), k
+        assert np.abs(poses[k][3:] - opose[3:]).max() <= POSE_TOL_M, k
+        assert np.abs(poses[k][:3] - opose[:3]).max() <= POSE_TOL_RAD, k
+    assert stats[5].status == 5 and np.array_equal(poses[5], inits[5])
+    assert stats[9].status == 5 and stats[9].n_rows == 0
+    assert len({s.iterations for s in stats}) > 2  # the scans really leave the launches at different iterations
+    # the same batch forced through the deep stack: same bits
+    opts.search_mode = LANE | DEEP
+    before = ctx.sweep_launches()
+    _, poses_d, stats_d = ctx.run_batch(np.stack(inits), opts)
+    assert set(_ran(before, ctx.sweep_launches())) == {"deep"}
+    assert np.array_equal(bits(poses_d), bits(poses))
+
+
+@pytest.fixture(scope="module")
+def voxel_map_problem(pkg, synth):
+    """A reduced BASELINE configs[1] map built the way bench.py builds its 10 000-frame one: VLP-16 frames ray cast along
+    the loop through the 600 x 600 m world, voxel-filtered and pushed at their ground-truth poses through the product's
+    FeatureMap::addFeatureCloud (util/FeatureMap.h:219-230,289-306; corner leaf 0.2 m, surf leaf 0.4 m) -- 400 frames of the
+    last 500 m of the loop -- and full 64 x 1800 scans (configs[2]) taken on that stretch."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    synth_gpu = importlib.import_module("synth_gpu")
+    world = synth.World(half_extent=300.0, wall_half=295.0, pole_pitch=2.5)
+    lidar = synth_gpu.GpuLidar(world, 0)
+    traj = synth_gpu.loop_trajectory(10000)[-4000::10]
+    ctx = pkg.Context(0)
+    fm, stats = synth_gpu.build_voxel_map(pkg, ctx, lidar, traj, rings=16)
+    assert stats["frames"] == 400
+    end = traj[-120]  # 150 m before the end of the mapped stretch: the surround is mapped on both sides
+    fm.update(end[3:].astype(np.float32))
+    surround = fm.get_surround_feature()
+    fm.surround_to_map()
+    rng = np.random.default_rng(31)
+    scans, inits, gts = [], [], []
+    for k in range(3):
+        g = traj[-120 + int(rng.integers(-12, 12))].copy()
+        g[3:5] += rng.uniform(-1.0, 1.0, 2)
+        g[2] += rng.uniform(-0.2, 0.2)
+        qc, qs = lidar.scan(g, 64, 1800, seed=7000 + k)
+        scans.append((qc, qs))
+        gts.append(g.astype(np.float32))
+        inits.append(synth.perturb_pose(g, seed=60 + k))
+    yield dict(ctx=ctx, fm=fm, surround=surround, scans=scans, inits=np.stack(inits), gts=np.stack(gts))
+    fm.close()
+    ctx.close()
+
+
+def test_voxel_map_batch_of_full_scans_matches_oracle(voxel_map_problem, oracle):
+    """configs[1] map (reduced) x configs[2] scans: three full 64 x 1800 scans (~1 350 blocks) in one batch against the
+    surround of the addFeatureCloud-built voxel map -- the bench's workload shape, kernel instantiation and code path --
+    with every scan's pose, row counts and iteration count against the oracle on the same clouds."""
+    vp = voxel_map_problem
+    ctx = vp["ctx"]
+    mc, ms = vp["surround"]
+    assert len(mc) > 20000 and len(ms) > 100000
+    n_blocks = sum((len(c) + 255) // 256 + (len(s) + 255) // 256 for c, s in vp["scans"])
+    assert n_blocks >= 600 and all(len(c) + len(s) > 100000 for c, s in vp["scans"])
+    ctx.scan_set_batch(vp["scans"])
+    opts = ctx.default_opts()
+    opts.scans_in_flight = 3
+    before = ctx.sweep_launches()
+    worst, poses, stats = ctx.run_batch(vp["inits"], opts)
+    ran = _ran(before, ctx.sweep_launches())
+    assert set(ran) == {"shallow"}, ran
+    for k, (qc, qs) in enumerate(vp["scans"]):
+        ok, opose, ost = oracle.scanmatch_scan(mc, ms, qc, qs, vp["inits"][k])
+        assert stats[k].status == ost.status and stats[k].converged == ost.converged == 1, k
+        assert stats[k].iterations == ost.iterations, k
+        assert _counts_close((stats[k].n_line, stats[k].n_plane, stats[k].n_rows), (ost.n_line, ost.n_plane, ost.n_rows)), k
+        assert np.abs(poses[k][3:] - opose[3:]).max() <= POSE_TOL_M, k
+        assert np.abs(poses[k][:3] - opose[:3]).max() <= POSE_TOL_RAD, k
+        assert abs(stats[k].score - ost.score) <= 1e-4 * ost.score and abs(stats[k].percent - ost.percent) <= 1e-4
+        # and it is a real match: within centimetres of where the scan was taken
+        assert np.abs(poses[k][3:] - vp["gts"][k][3:]).max() < 0.05, k
+    # a single full scan (deep stack, latency-bound launch) gives the batch's bits
+    ctx.scan_set(*vp["scans"][1])
+    before = ctx.sweep_launches()
+    status, pose1, st1 = ctx.run(vp["inits"][1])
+    assert set(_ran(before, ctx.sweep_launches())) == {"deep"}
+    assert np.array_equal(bits(pose1), bits(poses[1])) and st1.iterations == stats[1].iterations
+
+
+def test_voxel_map_sweep_taps_match_oracle_through_the_shallow_kernel(voxel_map_problem, oracle):
+    """One unbounded sweep of a full 64 x 1800 scan over the voxel map through the shallow-stack kernel: neighbour
+    indices, distances, flags and coefficients of all ~115 000 points bit for bit against the oracle."""
+    vp = voxel_map_problem
+    ctx = vp["ctx"]
+    mc, ms = vp["surround"]
+    qc, qs = vp["scans"][0]
+    tc, ts = oracle.kdtree(mc), oracle.kdtree(ms)
+    ctx.scan_set(qc, qs)
+    before = ctx.sweep_launches()
+    g = ctx.sweep(vp["inits"][0], jtj_mode=1, search_mode=LANE | SHALLOW)
+    assert set(_ran(before, ctx.sweep_launches())) == {"shallow"}
+    o = oracle.sweep(tc, ts, qc, qs, vp["inits"][0])
+    assert np.array_equal(g["idx"], o["idx"]) and np.array_equal(bits(g["d2"]), bits(o["d2"]))
+    assert np.array_equal(g["flags"], o["flags"]) and np.array_equal(bits(g["coeff"]), bits(o["coeff"]))
+    scale = np.abs(o["sums"][:27]).max()
+    assert np.abs(g["sums"][:27] - o["sums"][:27]).max() <= 2e-5 * scale
+    assert g["sums"][27] == o["sums"][27] and g["sums"][28] == o["sums"][28]
+    assert (o["flags"] & 4).sum() > 50000

@@ -167,6 +167,7 @@ SYMBOLS = {
                                 c_int32_p, C.c_float, C.c_float, c_float_p, c_float_p, c_float_p,
                                 c_int32_p]),
     "lslam_stream": (C.c_void_p, [C.c_void_p]),
+    "lslam_debug_sweep_launches": (None, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "lslam_pg_create": (C.c_int, [C.c_int, C.c_int32, c_double_p, C.c_int32, c_int32_p, c_double_p, c_double_p,
                                   C.c_int32, C.POINTER(C.c_void_p)]),
     "lslam_pg_destroy": (None, [C.c_void_p]),
@@ -224,6 +225,9 @@ SYMBOLS = {
 
 COMM_ID_BYTES = 128
 SEARCH_AUTO, SEARCH_LANE, SEARCH_PACKET = 0, 1, 2
+STACK_AUTO, STACK_DEEP, STACK_SHALLOW = 0, 0x100, 0x200  # ORed into a search mode (LSLAM_STACK_*)
+# lslam_debug_sweep_launches: index of each sweep-kernel instantiation
+SWEEP_VARIANTS = ("deep", "deep_ovf", "shallow", "cubes", "cubes_ovf", "packet", "persistent", "unused")
 
 
 def lib_path():

@@ -155,6 +155,7 @@ struct lslam_ctx {
   DevBuf<ProbBlocks> st_noblocks;  // {0, 0}: a problem with no LiDAR blocks (lslam_stereo_sums)
   int32_t n_stereo = 0;
   StereoCam st_cam{};
+  uint64_t sweep_variants[SWEEP_N_VARIANTS] = {0};  // sweep launches per kernel instantiation (lslam_debug_sweep_launches)
 };
 
 namespace {
@@ -232,6 +233,7 @@ void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
   a.bounded = 0;
   a.deep_tree = (ctx->tc.depth > KD_STACK_LDS + 1 || ctx->ts.depth > KD_STACK_LDS + 1) ? 1 : 0;
   a.packet = 0;
+  a.stack_mode = SWEEP_STACK_AUTO;
   a.idx_out = nullptr;
   a.d2_out = nullptr;
   a.coeff_out = nullptr;
@@ -249,8 +251,29 @@ int resolve_search_mode(const lslam_ctx *ctx, int32_t requested) {
   if (env && !std::strcmp(env, "lane")) requested = LSLAM_SEARCH_LANE;
   if (env && !std::strcmp(env, "packet")) requested = LSLAM_SEARCH_PACKET;
   if (ctx->cube_mode || !ctx->tc.view.pn || !ctx->ts.view.pn) return LSLAM_SEARCH_LANE;
+  requested &= 0xFF;  // the LSLAM_STACK_* bits are resolve_stack_mode's
   if (requested == LSLAM_SEARCH_LANE || requested == LSLAM_SEARCH_PACKET) return requested;
   return LSLAM_SEARCH_LANE;
+}
+
+// Traversal-stack shape asked for: LSLAM_STACK_* bits of a search mode, overridden by LSLAM_FORCE_STACK=deep|shallow|auto
+// in the environment (read per call: tests switch it between calls).
+int resolve_stack_mode(int32_t search_mode) {
+  int m = (search_mode & LSLAM_STACK_SHALLOW) ? SWEEP_STACK_SHALLOW : ((search_mode & LSLAM_STACK_DEEP) ? SWEEP_STACK_DEEP : SWEEP_STACK_AUTO);
+  if (const char *env = std::getenv("LSLAM_FORCE_STACK")) {
+    if (!std::strcmp(env, "deep")) m = SWEEP_STACK_DEEP;
+    else if (!std::strcmp(env, "shallow")) m = SWEEP_STACK_SHALLOW;
+    else if (!std::strcmp(env, "auto")) m = SWEEP_STACK_AUTO;
+  }
+  return m;
+}
+
+// launch_sweep + the per-context count of the instantiation it took
+hipError_t sweep_launch(lslam_ctx *ctx, const SweepArgs &a, int jtj_mode, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+  int v = -1;
+  const hipError_t e = launch_sweep(a, jtj_mode, ctx->stream, e0, e1, &v);
+  if (v >= 0 && v < SWEEP_N_VARIANTS) ctx->sweep_variants[v]++;
+  return e;
 }
 
 int ensure_states(lslam_ctx *ctx, int32_t n) {
@@ -376,6 +399,10 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
 
 void *lslam_stream(lslam_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+void lslam_debug_sweep_launches(lslam_ctx *ctx, uint64_t counts[8]) {
+  for (int i = 0; i < 8; ++i) counts[i] = ctx ? ctx->sweep_variants[i] : 0;
+}
+
 int lslam_ctx_set_comm(lslam_ctx *ctx, lslam_comm *comm) {
   if (!ctx) return LSLAM_ERR_INVALID;
   ctx->comm = comm;
@@ -434,7 +461,7 @@ int lslam_debug_sweep_clocks(lslam_ctx *ctx, const float pose[6], int32_t jtj_mo
   sa.bounded = std::getenv("LSLAM_UNBOUNDED_KNN") ? 0 : 1;
   sa.prev_valid = ctx->prev_valid ? 1 : 0;
   if (sa.bounded) ctx->prev_valid = true;
-  HIP_TRY(launch_sweep(sa, jtj_mode, ctx->stream));
+  HIP_TRY(sweep_launch(ctx, sa, jtj_mode));
   HIP_TRY(hipMemcpyAsync(out, d, words * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   (void)hipFree(d);
@@ -1018,6 +1045,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
   SweepArgs sa;
   fill_sweep_args(ctx, sa);
   sa.packet = resolve_search_mode(ctx, o.search_mode) == LSLAM_SEARCH_PACKET ? 1 : 0;
+  sa.stack_mode = resolve_stack_mode(o.search_mode);
   // the production sweep keeps a shallow stack in LDS: it always gets the overflow area (sized per
   // chunk below; the sharded path has one resident scan)
   const bool sharded = fn != nullptr || use_comm;
@@ -1114,7 +1142,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
         sa.prev_valid = (sa.bounded && launched > 0) ? 1 : 0;
         hipEvent_t e0, e1;
         HIP_TRY(sweep_events(launched, &e0, &e1));
-        HIP_TRY(launch_sweep(sa, o.jtj_mode, ctx->stream, e0, e1));
+        HIP_TRY(sweep_launch(ctx, sa, o.jtj_mode, e0, e1));
         HIP_TRY(launch_stereo(sta, ctx->stream));
         so.reduce_only = 1;
         so.ext_sums = nullptr;
@@ -1152,7 +1180,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
     const bool gnp_off = !(std::getenv("LSLAM_PERSISTENT_GN") && std::atoi(std::getenv("LSLAM_PERSISTENT_GN")) == 1);
     static const bool unbounded = std::getenv("LSLAM_UNBOUNDED_KNN") != nullptr;
     if (!sharded && n_scans == 1 && !gnp_off && ctx->gnp_ok && !o.profile && ctx->n_stereo == 0 && !ctx->cube_mode &&
-        !sa.packet && max_it > 0 && ctx->tc.depth <= KD_STACK_LDS + 1 && ctx->ts.depth <= KD_STACK_LDS + 1 &&
+        !sa.packet && sa.stack_mode != SWEEP_STACK_SHALLOW && max_it > 0 && ctx->tc.depth <= KD_STACK_LDS + 1 && ctx->ts.depth <= KD_STACK_LDS + 1 &&
         sa.nb_total > 0 && sa.nb_total <= 512) {
       if (ctx->gnp_cap < 0) ctx->gnp_cap = gn_persistent_capacity(ctx->device);
       if (sa.nb_total <= ctx->gnp_cap) {
@@ -1176,6 +1204,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
         gl.delta_t_abort = so.delta_t_abort;
         gl.eig_thresh = so.eig_thresh;
         HIP_TRY(launch_gn_persistent(sp, o.jtj_mode, gl, ctx->stream));
+        ctx->sweep_variants[SWEEP_VARIANT_PERSISTENT]++;
         HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
         unsigned gbar[2] = {0, 0};
         HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState), hipMemcpyDeviceToHost, ctx->stream));
@@ -1219,7 +1248,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
         sc.prev_valid = (sc.bounded && done_iters[(size_t)c] > 0) ? 1 : 0;
         hipEvent_t e0, e1;
         HIP_TRY(sweep_events(n_launches, &e0, &e1));
-        HIP_TRY(launch_sweep(sc, o.jtj_mode, ctx->stream, e0, e1));
+        HIP_TRY(sweep_launch(ctx, sc, o.jtj_mode, e0, e1));
         ++n_launches;
         HIP_TRY(launch_stereo(sta, ctx->stream));
         HIP_TRY(launch_solve(soc, ctx->stream));
@@ -1795,6 +1824,12 @@ int lslam_sweep_ex(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_
   fill_sweep_args(ctx, sa);
   rc = ensure_stack_ovf(ctx, (size_t)sa.nb_total * SWEEP_BLOCK, &sa.stack_ovf);
   if (rc) return rc;
+  sa.stack_mode = resolve_stack_mode(search_mode);
+  search_mode &= 0xFF;
+  if (sa.stack_mode == SWEEP_STACK_SHALLOW && !ctx->cube_mode) {  // the batch kernel's stack shape on this (unbounded) tap
+    HIP_TRY(ctx->stack_ovf.reserve(stack_ovf_words((size_t)std::max(sa.nb_total, 1) * SWEEP_BLOCK, std::max(ctx->tc.depth, ctx->ts.depth))));
+    sa.stack_ovf = ctx->stack_ovf.p;
+  }
   if (search_mode == LSLAM_SEARCH_PACKET) {
     if (ctx->cube_mode || !ctx->tc.view.pn || !ctx->ts.view.pn) { set_err("this map has no packet-search nodes"); return LSLAM_ERR_INVALID; }
     HIP_TRY(ctx->stack_ovf.reserve(stack_ovf_words((size_t)std::max(sa.nb_total, 1) * SWEEP_BLOCK)));
@@ -1812,7 +1847,7 @@ int lslam_sweep_ex(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_
     sa.coeff_out = ctx->t_coeff.p;
     sa.flags_out = ctx->t_flags.p;
   }
-  HIP_TRY(launch_sweep(sa, jtj_mode, ctx->stream));
+  HIP_TRY(sweep_launch(ctx, sa, jtj_mode));
   SolveArgs so{};
   so.states = ctx->d_state;
   so.partials = ctx->partials.p;

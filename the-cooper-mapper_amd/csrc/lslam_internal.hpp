@@ -88,6 +88,7 @@ struct SweepArgs {
   int32_t bounded;        // 1: production loop (bounded search), 0: taps (nanoflann's plain search)
   int32_t deep_tree;      // a tree is deeper than KD_STACK_LDS+1: the LDS-only kernels cannot be used
   int32_t packet;         // 1: wave-cooperative packet search (lslam_packet.hpp); needs stack_ovf and the trees' PNodes
+  int32_t stack_mode;     // SWEEP_STACK_*: which traversal-stack shape launch_sweep takes (AUTO: by launch size)
   // optional per-point taps (all NULL in the production loop)
   int32_t *idx_out;    // [N][5] original map indices
   float *d2_out;       // [N][5]
@@ -170,8 +171,21 @@ hipError_t launch_odom_to_end(float4 *pts, int n, const float *d_pose6, hipStrea
 constexpr int SWEEP_BLOCK = LSLAM_SWEEP_BLOCK;
 
 // launchers (lslam_kernels.hip)
+// Traversal-stack shape of a sweep launch (include/lslam_c.h LSLAM_STACK_*) and the instantiation launch_sweep took
+// (reported through `variant`, counted per context: lslam_debug_sweep_launches).
+enum : int { SWEEP_STACK_AUTO = 0, SWEEP_STACK_DEEP = 1, SWEEP_STACK_SHALLOW = 2 };
+enum : int {
+  SWEEP_VARIANT_DEEP = 0,       // sweep_kernel<256, false, false, 32>: whole stack in LDS
+  SWEEP_VARIANT_DEEP_OVF = 1,   // sweep_kernel<256, true, false, 32>: trees deeper than 33 levels
+  SWEEP_VARIANT_SHALLOW = 2,    // sweep_kernel<256, true, false, 12>: the batch (bench) kernel
+  SWEEP_VARIANT_CUBES = 3,      // sweep_kernel<256, false, true, 32>
+  SWEEP_VARIANT_CUBES_OVF = 4,  // sweep_kernel<256, true, true, 32>
+  SWEEP_VARIANT_PACKET = 5,     // sweep_kernel<256, true, false, 4, true>
+  SWEEP_VARIANT_PERSISTENT = 6, // gn_persistent_kernel
+  SWEEP_N_VARIANTS = 8
+};
 hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s,
-                        hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+                        hipEvent_t start = nullptr, hipEvent_t stop = nullptr, int *variant = nullptr);
 hipError_t launch_solve(const SolveArgs &a, hipStream_t s);
 hipError_t launch_knn5(const TreeView &T, const float4 *q, int nq, int32_t *idx, float *d2,
                        uint32_t *stack_ovf, hipStream_t s);

@@ -407,7 +407,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
 // start/stop (optional) time exactly this dispatch on its own stream: the events are
 // attached to the kernel's AQL packet, no extra barrier packets are enqueued.
 hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t start,
-                        hipEvent_t stop) {
+                        hipEvent_t stop, int *variant) {
+  if (variant) *variant = -1;
   if (a.nb_total <= 0) return hipSuccess;
   const dim3 g(a.nb_total), b(SWEEP_BLOCK);
   const bool cubes = a.gc.trees != nullptr;
@@ -420,18 +421,34 @@ hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEven
   // and every wavefront is resident anyway: keep the whole stack in LDS.
   const bool many_waves = (long)a.nb_total * (SWEEP_BLOCK / 64) > 2 * 1024;
   const bool deep_tree = a.deep_tree != 0;
-  if (a.packet && !cubes && a.stack_ovf && a.tc.pn && a.ts.pn)
+  // The stack shape is a matter of speed only -- both kernels hold the same entries, the shallow one
+  // keeps levels >= 12 in HBM -- so a caller may force either (LSLAM_STACK_DEEP / _SHALLOW in the search
+  // mode, LSLAM_FORCE_STACK in the environment): the parity tests run every comparison against the
+  // oracle through both, whatever the size of their launch.
+  const bool shallow_ok = a.stack_ovf != nullptr && !cubes;
+  const bool shallow = shallow_ok && (a.stack_mode == SWEEP_STACK_SHALLOW ||
+                                      (a.stack_mode == SWEEP_STACK_AUTO && a.bounded && (many_waves || deep_tree)));
+  int v;
+  if (a.packet && !cubes && a.stack_ovf && a.tc.pn && a.ts.pn) {
+    v = SWEEP_VARIANT_PACKET;
     hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, 4, true>), g, b, 0, s, start, stop, 0, a, jtj_mode);
-  else if (a.bounded && a.stack_ovf && !cubes && (many_waves || deep_tree))
+  } else if (shallow) {
+    v = SWEEP_VARIANT_SHALLOW;
     hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, SHALLOW>), g, b, 0, s, start, stop, 0, a, jtj_mode);
-  else if (cubes && a.stack_ovf && deep_tree)
+  } else if (cubes && a.stack_ovf && deep_tree) {
+    v = SWEEP_VARIANT_CUBES_OVF;
     hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, true, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
-  else if (cubes)
+  } else if (cubes) {
+    v = SWEEP_VARIANT_CUBES;
     hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false, true, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
-  else if (a.stack_ovf && deep_tree)
+  } else if (a.stack_ovf && deep_tree) {
+    v = SWEEP_VARIANT_DEEP_OVF;
     hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
-  else
+  } else {
+    v = SWEEP_VARIANT_DEEP;
     hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false, false, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+  }
+  if (variant) *variant = v;
   return hipGetLastError();
 }
 

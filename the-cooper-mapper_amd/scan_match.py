@@ -102,6 +102,14 @@ class Context:
         self.lib.lslam_default_opts(C.byref(o))
         return o
 
+    def sweep_launches(self):
+        """lslam_debug_sweep_launches: sweep launches of this context so far per kernel instantiation
+        (capi.SWEEP_VARIANTS: 'deep', 'deep_ovf', 'shallow' = sweep_kernel<256,true,false,12>, ...)."""
+        from .capi import SWEEP_VARIANTS
+        out = (C.c_uint64 * 8)()
+        self.lib.lslam_debug_sweep_launches(self.h, out)
+        return dict(zip(SWEEP_VARIANTS, (int(v) for v in out)))
+
     # -- map / scan ----------------------------------------------------------
     def map_set(self, corner, surf):
         c, sc = _cloud(corner)

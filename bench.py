@@ -52,9 +52,10 @@ ALG_BYTES_PER_POINT_RESIDUAL = 1700.0  # working set of nanoflann'
 # per-block partial sums amortised to < 1 B) = 1.30 KB
 ALG_BYTES_PER_POINT_BOUNDED = 24.6 * 16 + 3.4 * 16 + 4.4 * 160 + 100 + 16 + 20
 POSE_TOL_M, POSE_TOL_RAD = 1e-4, 1e-5  # BASELINE.json north_star: pose within 1e-4 m of the CPU reference (tests: 1e-5 rad)
+FLOPS_PER_POINT_RESIDUAL = 1200.0      # ~1.2 kflop per point-residual (distances 0.35 k, fit 0.4 k, transform + Jacobian 0.15 k, ...)
+FP32_PEAK_TFLOPS = 157.3               # MI355X_MICROARCH.md: vector fp32
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8 TB/s spec
 L2_PEAK_GBS = 34500.0                  # MI355X_MICROARCH.md: ~34.5 TB/s aggregate
-PMC_PROFILE = os.path.join("profiles", "r02_pmc_sweep.csv")
 
 
 def parse_args():
@@ -77,6 +78,7 @@ def parse_args():
     ap.add_argument("--no-joint-stereo", action="store_true")
     ap.add_argument("--no-pose-graph", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the single-scan latency leg")
+    ap.add_argument("--no-vlp16", action="store_true", help="skip the 16-ring x 1800 throughput leg")
     ap.add_argument("--no-mapping-frame", action="store_true", help="skip the per-frame mapping pipeline leg")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the whole-chain (registration..mapping) leg")
     ap.add_argument("--headline-only", action="store_true", help="only the timed region (profiling passes)")
@@ -103,7 +105,7 @@ def spawn_ranks(n):
 def main():
     args = parse_args()
     if args.headline_only:
-        args.no_cpu_baseline = args.no_joint_stereo = args.no_pose_graph = args.no_single = True
+        args.no_cpu_baseline = args.no_joint_stereo = args.no_pose_graph = args.no_single = args.no_vlp16 = True
         args.no_mapping_frame = args.no_pipeline = True
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))
@@ -221,38 +223,7 @@ def main():
 
     out = None
     if rank == 0:
-        avg_sweep_ms = sweep_ms / max(1, sweep_launches)
-        # algorithmic bytes of an average timed launch: scans of a chunk that have already
-        # converged are skipped by later launches, so count the points actually processed
-        pts_per_launch = pt_res / max(1, sweep_launches)
-        alg_bytes = ALG_BYTES_PER_POINT_BOUNDED * pts_per_launch
-        achieved_gbs = alg_bytes / (avg_sweep_ms * 1e-3) / 1e9 if avg_sweep_ms > 0 else 0.0
-        survey_gbs = ALG_BYTES_PER_POINT_RESIDUAL * pts_per_launch / (avg_sweep_ms * 1e-3) / 1e9 if avg_sweep_ms > 0 else 0.0
-        compulsory = float(info.n_corner + info.n_surf) * 16.0 + pts_per_launch * (16.0 + 36.0)
-        roof = {
-            "kernel": "sweep_kernel",
-            "achieved": achieved_gbs,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved_gbs / HBM_PEAK_GBS,
-            "accounting": "achieved = %.0f B the bounded search touches per point-residual on this map (node, leaf and "
-                          "neighbour records counted from tools/traversal_stats.py, DESIGN 4) x points an average timed "
-                          "launch processed / its HIP-event duration.  NOMINAL against HBM: 97 %% of those bytes are "
-                          "L1 hits and the rest L2 / Infinity-Cache hits (see `counters`, `traffic`); what bounds the "
-                          "kernel is `bound`, and the fraction of THAT limit is `bound_frac`" % ALG_BYTES_PER_POINT_BOUNDED,
-            "alg_bytes_per_point": ALG_BYTES_PER_POINT_BOUNDED,
-            "survey_8d_accounting": {"alg_bytes_per_point": ALG_BYTES_PER_POINT_RESIDUAL, "achieved": survey_gbs,
-                                     "frac": survey_gbs / HBM_PEAK_GBS},
-            "avg_kernel_ms": avg_sweep_ms,
-            "launches_timed": sweep_launches,
-            "points_per_launch": pts_per_launch,
-            "alg_bytes_per_launch": alg_bytes,
-            # SURVEY 8d asks for both accountings: the compulsory-unique lower bound of a sweep -- every map
-            # point and every query read once, every output written once: (Mc+Ms) 16 B + N (16 + 36) B
-            "compulsory_bytes_per_launch": compulsory,
-            "compulsory_achieved_gbs": compulsory / (avg_sweep_ms * 1e-3) / 1e9 if avg_sweep_ms > 0 else 0.0,
-        }
-        roof.update(pmc_counters(avg_sweep_ms))
+        roof = sweep_roofline(pt_res, sweep_ms, sweep_launches, float(info.n_corner + info.n_surf))
         out = {
             "metric": "point-residuals/s",
             "value": total_pt_res / t,
@@ -294,6 +265,15 @@ def main():
         }
         if not args.no_single:
             out["single_scan"] = single_scan_leg(ctx, scans[0], inits[0], opts, 200)
+    # ---- the same timed region on 16-ring x 1800 scans (VLP-16, MultiScanRegistration.h:90-92; BASELINE north star:
+    # "throughput on synthetic 16- and 64-ring scans") -- every rank, same protocol, its own roofline object
+    if not args.no_vlp16:
+        try:
+            v16 = vlp16_throughput_leg(ctx, lidar, synth, dense, span, rank, world, args, opts, distmod, dist, info, np)
+        except Exception as e:  # never takes the headline line down
+            v16 = {"error": repr(e)}
+        if rank == 0:
+            out["vlp16_throughput"] = v16
     # From here on the legs are secondary (and, with N > 1, use the library's own RCCL communicator, which no
     # builder-side run could exercise on more than one GPU): a leg that hangs must not cost the headline line.
     # Every rank arms a watchdog; if it fires, rank 0 prints the line it has and all ranks leave.
@@ -391,6 +371,109 @@ def main():
         sys.exit(4)
 
 
+def vlp16_throughput_leg(ctx, lidar, synth, dense, span, rank, world, args, opts, distmod, dist, info, np):
+    """point-residuals/s on 16-ring x 1800 scans (BASELINE configs[1]'s sensor, every return a query -- SURVEY 8d) against the
+    same map: `--scans` different VLP-16 scans per step and GPU, all in flight, cold calls, barrier + max over ranks like the
+    headline; a quarter of the headline's steps (a step is a quarter of its size)."""
+    rng = np.random.default_rng(9191 + rank)
+    scans, inits = [], []
+    for k in range(args.scans):
+        g = dense[int(rng.integers(-span, span)) % len(dense)].copy()
+        g[3:5] += rng.uniform(-1.0, 1.0, 2)
+        g[2] += rng.uniform(-0.2, 0.2)
+        qc, qs = lidar.scan(g, 16, 1800, seed=1900000 + 1000 * rank + k)
+        scans.append((qc, qs))
+        inits.append(synth.perturb_pose(g, seed=5099 + 1000 * rank + k))
+    n_pts = sum(len(c) + len(s) for c, s in scans)
+    n_corner = sum(len(c) for c, _ in scans)
+    ctx.scan_set_batch(scans)
+    inits = np.stack(inits)
+    steps = max(2, args.steps // 2)
+    quiet_gc()
+    for _ in range(min(2, args.warmup)):
+        ctx.run_batch(inits, opts)
+    distmod.barrier(dist)
+    t0 = time.perf_counter()
+    pt_res = iters = sweep_launches = 0
+    sweep_ms = 0.0
+    n_conv = 0
+    for _ in range(steps):
+        status, poses, sts = ctx.run_batch(inits, opts)
+        pt_res += sum(s.point_residuals for s in sts)
+        iters += sum(s.iterations for s in sts)
+        sweep_ms += sts[0].gpu_ms_sweep
+        sweep_launches += sts[0].sweep_launches
+        n_conv = int(sum(1 for s in sts if s.converged))
+    distmod.barrier(dist)
+    elapsed = time.perf_counter() - t0
+    (total_pt_res, total_iters), t = distmod.aggregate(dist, [pt_res, iters], elapsed)
+    if rank != 0:
+        return None
+    roof = sweep_roofline(pt_res, sweep_ms, sweep_launches, float(info.n_corner + info.n_surf))
+    # the committed counter passes are of the 64-ring command: the 16-ring launches run the same kernel on a quarter of the points
+    roof["counters_of"] = "the 64-ring headline command (same kernel instantiation)"
+    return {"metric": "point-residuals/s", "value": total_pt_res / t, "unit": "point-residuals/s", "n_gpus": world, "steps": steps,
+            "ms_per_step": 1e3 * t / steps, "timed_region_s": t, "lm_iters_per_s": total_iters / t, "dtype": "f32",
+            "config": {"workload": "synthetic 16-ring x 1800 (VLP-16) scan-to-map scanMatchScan GN loops against the same %d-frame "
+                                   "voxel map: %d scans per step and GPU, all in flight" % (args.map_frames, args.scans),
+                       "scan_points_per_step": n_pts, "scan_corner_share": n_corner / max(1, n_pts),
+                       "gn_iters_per_scan": iters / steps / args.scans, "converged_scans": n_conv},
+            "roofline": roof}
+
+
+def sweep_roofline(pt_res, sweep_ms, sweep_launches, map_points):
+    """The roofline object of one timed region of sweep launches (the 64-ring headline, the 16-ring leg).
+
+    achieved / peak / frac are PHYSICAL: the sweep kernel is bound by vector-ALU instruction issue (the counter passes: 99 % of the
+    fp32 issue slots of the 1 024 SIMDs are taken), so the line prices it on the fp32 roof -- SURVEY 8d's 1.2 kflop per
+    point-residual x the points an average timed launch processed / that launch's HIP-event duration, against the 157.3 TFLOP/s
+    vector fp32 peak of MI355X_MICROARCH.md.  The fraction is small because the search is divergent (43 of 64 lanes active) and
+    most of its instructions are compares, selects and address arithmetic, not the counted flops; `valu_issue` says how full the
+    issue port is.  SURVEY 8d's byte pricing is kept beside it as `nominal_hbm` (it exceeds 1: those bytes are bytes TOUCHED, 97 %
+    of them L1 hits -- not a fraction of anything) and the counter-measured HBM-side traffic as `measured_hbm`."""
+    avg_sweep_ms = sweep_ms / max(1, sweep_launches)
+    t_s = avg_sweep_ms * 1e-3
+    # algorithmic work of an average timed launch: scans of a chunk that have already converged are skipped by later
+    # launches, so count the points actually processed
+    pts_per_launch = pt_res / max(1, sweep_launches)
+    flops = FLOPS_PER_POINT_RESIDUAL * pts_per_launch
+    tflops = flops / t_s / 1e12 if t_s > 0 else 0.0
+    survey_gbs = ALG_BYTES_PER_POINT_RESIDUAL * pts_per_launch / t_s / 1e9 if t_s > 0 else 0.0
+    bounded_gbs = ALG_BYTES_PER_POINT_BOUNDED * pts_per_launch / t_s / 1e9 if t_s > 0 else 0.0
+    compulsory = map_points * 16.0 + pts_per_launch * (16.0 + 36.0)
+    roof = {
+        "kernel": "sweep_kernel<256,true,false,12> (the shallow-stack batch instantiation; tests/test_gpu_stack_shapes.py holds it "
+                  "against the oracle)",
+        "bound": "valu",
+        "achieved": tflops,
+        "peak": FP32_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": tflops / FP32_PEAK_TFLOPS,
+        "accounting": "achieved = %.0f flop per point-residual (SURVEY 8d) x %.4g points an average timed launch processed / its "
+                      "HIP-event duration of %.4g ms; peak = vector fp32 (MI355X_MICROARCH.md).  Neither `hbm` nor `mfma` bounds "
+                      "this kernel: the counters put VALU issue at `valu_issue.frac` of its slots and HBM at `measured_hbm.frac`"
+                      % (FLOPS_PER_POINT_RESIDUAL, pts_per_launch, avg_sweep_ms),
+        "alg_flops_per_point": FLOPS_PER_POINT_RESIDUAL,
+        "alg_flops_per_launch": flops,
+        "avg_kernel_ms": avg_sweep_ms,
+        "launches_timed": sweep_launches,
+        "points_per_launch": pts_per_launch,
+        # SURVEY 8d's byte pricing (1.7 KB per point-residual, nanoflann's unbounded search on the surveyed map) and the same
+        # with the bytes the bounded search really touches on this map: NOMINAL -- above the HBM peak because they are L1 hits
+        "nominal_hbm": {"alg_bytes_per_point": ALG_BYTES_PER_POINT_RESIDUAL, "alg_bytes_per_launch": ALG_BYTES_PER_POINT_RESIDUAL * pts_per_launch,
+                        "achieved": survey_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": survey_gbs / HBM_PEAK_GBS,
+                        "bounded_search": {"alg_bytes_per_point": ALG_BYTES_PER_POINT_BOUNDED, "achieved": bounded_gbs,
+                                           "frac": bounded_gbs / HBM_PEAK_GBS},
+                        "note": "bytes touched, not bytes moved from HBM: a fraction above 1 means exactly that"},
+        # SURVEY 8d asks for both accountings: the compulsory-unique lower bound of a sweep -- every map point and every
+        # query read once, every output written once: (Mc+Ms) 16 B + N (16 + 36) B
+        "compulsory_hbm": {"bytes_per_launch": compulsory, "achieved": compulsory / t_s / 1e9 if t_s > 0 else 0.0, "unit": "GB/s",
+                           "frac": (compulsory / t_s / 1e9 if t_s > 0 else 0.0) / HBM_PEAK_GBS},
+    }
+    roof.update(pmc_counters(avg_sweep_ms))
+    return roof
+
+
 def make_comm(pkg, dist, torch, rank, local_rank, world):
     """The library's own RCCL communicator: rank 0 makes the id, torch.distributed carries the 128 bytes."""
     import numpy as np
@@ -408,19 +491,27 @@ def quiet_gc():
     gc.freeze()
 
 
+def newest_profile(suffix):
+    """profiles/rNN_<suffix> of the highest round that has one (the counter passes are committed per round)."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return os.path.relpath(c[-1], ROOT) if c else None
+
+
 def pmc_counters(avg_sweep_ms):
     """What the hardware counters say about the sweep kernel.  PMC counters cannot be collected inside the
     timed run (rocprofv3 needs its own passes, FETCH_SIZE / WRITE_SIZE separate ones), so these figures are
     read from the COMMITTED summary of the passes of this same command (tools/collect_profiles.sh ->
-    profiles/r02_pmc_sweep.csv; per launch, largest launches only) and labelled as such.
+    profiles/rNN_pmc_sweep.csv; mean per launch over the launches with the full grid -- which is every sweep launch of the
+    profiled run: converged scans' blocks exit early, the grid does not shrink) and labelled as such.
     MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB and FETCH_SIZE under-reports wide reads by 2x
     on gfx950, so HBM-side traffic = (2 * FETCH + WRITE) * 1024; an L2 request is 128 B."""
-    path = os.path.join(ROOT, PMC_PROFILE)
-    if not os.path.exists(path):
-        return {"bound": "unknown (no committed counter profile)", "traffic": None}
+    prof = newest_profile("pmc_sweep.csv")
+    if not prof:
+        return {"traffic": None, "valu_issue": None, "measured_hbm": None, "counters": "no committed counter profile"}
     v = {}
     src = ""
-    for line in open(path):
+    for line in open(os.path.join(ROOT, prof)):
         if line.startswith("#"):
             src += line[1:].strip() + " "
             continue
@@ -429,62 +520,48 @@ def pmc_counters(avg_sweep_ms):
             v[f[1]] = float(f[3])
     g = v.get
     traffic = (2.0 * g("FETCH_SIZE", 0.0) + g("WRITE_SIZE", 0.0)) * 1024.0 if "FETCH_SIZE" in v else None
-    # the profile's own kernel duration (SQ_BUSY_CYCLES is per-SE; use wave-cycle ratios, which need none)
-    c = {"source": "%s (rocprofv3 --pmc passes; %s)" % (PMC_PROFILE, src.strip()[:200])}
-    t_s = avg_sweep_ms * 1e-3
-    # the profiled launches are the largest of the run, not the average timed one: rate them over their own
-    # duration in engine cycles -- GRBM_GUI_ACTIVE (summed over the 8 XCDs; at 2.4 GHz it reproduces the HIP-event
-    # duration of these launches), else SQ_BUSY_CYCLES (summed over the 32 shader engines)
+    c = {"source": "%s (rocprofv3 --pmc passes; %s)" % (prof, src.strip()[:200])}
+    # the profiled launches' own duration in engine cycles: GRBM_GUI_ACTIVE (summed over the 8 XCDs; at 2.4 GHz it reproduces
+    # the HIP-event duration of these launches), else SQ_BUSY_CYCLES (summed over the 32 shader engines)
     cyc = v["GRBM_GUI_ACTIVE"] / 8.0 if v.get("GRBM_GUI_ACTIVE", 0) > 0 else v.get("SQ_BUSY_CYCLES", 0.0) / 32.0
+    t_s = cyc / 2.4e9 if cyc > 0 else avg_sweep_ms * 1e-3
     if cyc > 0:
-        t_s = cyc / 2.4e9
         c["profiled_launch_ms"] = 1e3 * t_s
         c["profiled_launch_cycles"] = cyc
+    measured_hbm = None
     if traffic is not None and t_s > 0:
-        c["hbm_gbs"] = traffic / t_s / 1e9
-        c["hbm_frac"] = c["hbm_gbs"] / HBM_PEAK_GBS
+        gbs = traffic / t_s / 1e9
+        measured_hbm = {"bytes_per_launch": traffic, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "source": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch (%s) / that launch's duration" % prof}
     if "TCC_REQ_sum" in v and t_s > 0:
         c["l2_gbs"] = v["TCC_REQ_sum"] * 128.0 / t_s / 1e9
         c["l2_frac"] = c["l2_gbs"] / L2_PEAK_GBS
         if v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0) > 0:
             c["l2_hit_rate"] = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
-    if "SQ_THREAD_CYCLES_VALU" in v and v.get("SQ_ACTIVE_INST_VALU", 0) > 0:
-        # thread-cycles per VALU instruction-cycle: lanes doing work out of 64
-        c["lanes_active"] = v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 4.0) if v["SQ_ACTIVE_INST_VALU"] else None
     if "SQ_INSTS_VALU" in v and "SQ_THREAD_CYCLES_VALU" in v and v["SQ_INSTS_VALU"] > 0:
         c["lanes_active"] = v["SQ_THREAD_CYCLES_VALU"] / v["SQ_INSTS_VALU"]
     if "SQ_WAIT_ANY" in v and v.get("SQ_WAVE_CYCLES", 0) > 0:
         c["wait_frac"] = v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"]
+    valu_issue = None
     if "SQ_ACTIVE_INST_VALU" in v and cyc > 0:
-        # SQ_ACTIVE_INST_VALU counts quad-cycles of VALU issue summed over the 1 024 SIMDs
-        # (normalised by GRBM_GUI_ACTIVE / 8 engine cycles: the eight XCDs do not start and end a launch on the same cycle,
-        # so the ratio can come out a per cent above one -- reported raw next to the capped value)
-        c["valu_busy_raw"] = v["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 1024.0)
-        c["valu_busy"] = min(1.0, c["valu_busy_raw"])
-    for k in ("TA_BUSY_avr", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_PENDING_STALL_CYCLES_sum", "TA_FLAT_READ_WAVEFRONTS_sum",
-              "TCP_TCC_READ_REQ_sum", "GRBM_GUI_ACTIVE", "TA_BUSY_max", "TCP_GATE_EN1_sum", "TCP_GATE_EN2_sum", "TA_TA_BUSY_sum"):
+        # SQ_ACTIVE_INST_VALU counts quad-cycles of VALU issue summed over the 1 024 SIMDs (normalised by GRBM_GUI_ACTIVE / 8
+        # engine cycles: the eight XCDs do not start and end a launch on the same cycle, so the ratio can come out a per
+        # cent above one -- reported raw next to the capped value)
+        raw = v["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 1024.0)
+        valu_issue = {"achieved": v["SQ_ACTIVE_INST_VALU"] * 4.0 / t_s, "peak": 1024.0 * 2.4e9, "unit": "SIMD issue cycles/s",
+                      "frac": min(1.0, raw), "frac_raw": raw, "lanes_active_of_64": c.get("lanes_active"),
+                      "valu_wave_instructions_per_launch": v.get("SQ_INSTS_VALU"),
+                      "source": "SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), %s" % prof}
+    for k in ("TA_BUSY_avr", "TCP_TOTAL_CACHE_ACCESSES_sum", "TA_FLAT_READ_WAVEFRONTS_sum", "TCP_TCC_READ_REQ_sum", "GRBM_GUI_ACTIVE",
+              "TA_TA_BUSY_sum", "SQ_INSTS_VALU_MFMA_F32", "SQ_VALU_MFMA_BUSY_CYCLES"):
         if k in v:
             c[k] = v[k]
-    # which resource is closest to its limit: that is the bound the line reports
-    cand = {"hbm": c.get("hbm_frac", 0.0) or 0.0, "l2": c.get("l2_frac", 0.0) or 0.0,
-            "valu-issue (one fp32 VALU instruction per SIMD every 4 cycles; %.0f of 64 lanes active)" % c.get("lanes_active", 0.0):
-                c.get("valu_busy", 0.0) or 0.0}
     if "TA_BUSY_avr" in v and cyc > 0:
         c["ta_busy"] = v["TA_BUSY_avr"] / cyc  # texture-address units: vector-memory instruction issue
-        cand["vector-memory issue (TA)"] = c["ta_busy"]
-    if "vmem_lane_rate_frac" in v:
-        cand["vector-memory lane rate (TA / L1)"] = v["vmem_lane_rate_frac"]
-        c["vmem_lane_rate_frac"] = v["vmem_lane_rate_frac"]
-    top = max(cand, key=cand.get)
-    bound = top
-    if cand[top] < 0.6 and c.get("wait_frac", 0.0) > 0.4:
-        bound = "latency of dependent gathers + %s (no bandwidth above 60 %% of its peak; waves wait %.0f %% of their life)" % (
-            top, 100.0 * c.get("wait_frac", 0.0))
-    return {"bound": bound, "bound_frac": cand[top], "traffic": traffic,
-            "traffic_source": "committed rocprofv3 --pmc passes of `bench.py --headline-only` (tools/collect_profiles.sh -> %s), "
-                              "per launch over the largest launches; not measured in this run" % PMC_PROFILE,
-            # the fraction of HBM peak the MEASURED traffic amounts to (the algorithmic-bytes fraction above is nominal)
-            "measured_hbm_gbs": c.get("hbm_gbs"), "measured_hbm_frac": c.get("hbm_frac"), "counters": c}
+    return {"traffic": traffic,
+            "traffic_source": "committed rocprofv3 --pmc passes of `bench.py --headline-only` (tools/collect_profiles.sh -> %s), mean per "
+                              "launch over all launches of the kernel (every launch has the full grid); not measured in this run" % prof,
+            "valu_issue": valu_issue, "measured_hbm": measured_hbm, "counters": c}
 
 
 def sharded_points_leg(pkg, synth, distmod, dist, rank, world, ctx, comm, opts, np, args):

@@ -2,8 +2,9 @@
 """Summarise rocprofv3 --pmc passes: mean counter value per launch of one kernel.
 
 usage: summarize_pmc.py <kernel-substring> <out.csv> <pass_dir> [<pass_dir> ...]
-Only the largest launches of the kernel (max Grid_Size: the full batch) are averaged, so the
-figures are per launch like roofline.achieved.  FETCH_SIZE/WRITE_SIZE stay in KiB as reported;
+Launches of the kernel with the largest grid are averaged.  For bench.py's sweep that is EVERY launch of the
+profiled run (a converged scan's blocks exit early, the grid does not shrink), so the figures are the mean over all
+launches -- the same population as roofline.avg_kernel_ms and rocprofv3's per-kernel average.  FETCH_SIZE/WRITE_SIZE stay in KiB as reported;
 bench.py applies the gfx950 correction (2 x FETCH_SIZE) from MI355X_MICROARCH.md."""
 import csv, glob, os, sys, collections
 
@@ -27,7 +28,7 @@ def main():
     with open(out, "w") as fo:
         fo.write("# rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python3 bench.py --headline-only --steps 2 --warmup 1 "
                  "(one pass per counter set)\n")
-        fo.write("# kernel: %s ; full-batch launches only (Grid_Size = max); FETCH_SIZE/WRITE_SIZE in KiB as reported\n" % kname)
+        fo.write("# kernel: %s ; mean over the launches with the largest grid (for the bench's sweep: all of them); FETCH_SIZE/WRITE_SIZE in KiB as reported\n" % kname)
         fo.write("pass,counter,launches,mean_per_launch,grid_size\n")
         for l in lines:
             fo.write("%s,%s,%d,%g,%d\n" % l)

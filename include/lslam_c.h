@@ -65,7 +65,9 @@ typedef struct {
   float delta_t_abort;               /* setConvergeThreshold, default 0.05 */
   float delta_r_abort;               /* setConvergeThreshold, default 0.05 */
   int32_t use_score;                 /* setUseCore, default 1 */
-  int32_t fine_score;                /* setFineScore, default 0 */
+  int32_t fine_score;                /* setFineScore, default 0: after a converged loop, one more sweep at the final pose gated
+                                        on d2[0] < 0.02 (corner) / 0.05 (surf) -> stats.score2 / percent2 (ScanMatch.cpp:272-321;
+                                        printed by the reference, never part of the return value) */
   double score_threshold;            /* setScoreThreshold, default 800 */
   double match_percentage_threshold; /* setPercentThreshold, default 0.4 */
   /* backend knobs (no reference counterpart) */
@@ -111,6 +113,7 @@ typedef struct {
   int32_t sweep_launches;  /* sweep launches timed (profile=1) */
   float gpu_ms_total;      /* HIP events around the whole device-resident GN loop */
   float gpu_ms_sweep;      /* sum of sweep-kernel durations (profile=1), else 0 */
+  double score2, percent2; /* ScanMatch.cpp:317-319 (opts.fine_score && converged && use_score, else 0) */
 } lslam_stats;
 
 typedef struct {

@@ -198,6 +198,13 @@ private:
       std::cout << "reference cloud points too few." << std::endl;
       return false;
     }
+    if (_last.converged && _opts.use_score) {  // the reference's console lines, ScanMatch.cpp:268-269,319-320,326,333
+      std::cout << "scan match score:" << _last.score << ",per:" << (float)_last.percent << std::endl;
+      if (_opts.fine_score)
+        std::cout << "scan match score2:" << _last.score2 << " ,per2:" << (float)_last.percent2 << std::endl;
+      if (st == LSLAM_LOW_SCORE) std::cout << "low score!!" << _last.score << ",per:" << (float)_last.percent << std::endl;
+      if (st == LSLAM_LOW_PERCENT) std::cout << "low percent!!" << _last.score << ",per:" << (float)_last.percent << std::endl;
+    }
     if (st == LSLAM_OK) {  // :336-340
       _total_score += _last.score;
       _match_count++;

@@ -1290,6 +1290,8 @@ static int scanmatch_impl(const float *map_c, size_t nc, const float *map_s, siz
       sweep_acc acc2;
       sweep_all(tc, map_c, ts, map_s, map_stride, qc, nqc, qs, nqs, q_stride, pose, 0.02f, 0.05f,
                 &acc2, NULL, NULL, NULL, NULL);
+      st->score2 = acc2.score;                                                           /* :317 */
+      st->percent2 = (float)((double)(acc2.n_line + acc2.n_plane) / (double)(nqc + nqs)); /* :318-319 */
     }
     st->score = score;
     st->percent = percent;

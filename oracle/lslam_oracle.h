@@ -127,6 +127,8 @@ typedef struct {
   /* timing taps for the CPU baseline (seconds) */
   double t_build, t_sweep, t_solve;
   long long point_residuals; /* sum over sweeps of (Nc+Ns) */
+  double score2, percent2;   /* _fineScore (ScanMatch.cpp:272-321): the re-sweep at the final pose gated on d2[0] < 0.02 / 0.05;
+                                the reference only prints them; 0 unless fine_score && converged && use_score */
 } oracle_stats;
 
 void oracle_default_opts(oracle_opts *o);

@@ -72,6 +72,8 @@ class OracleStats(C.Structure):
         ("t_sweep", C.c_double),
         ("t_solve", C.c_double),
         ("point_residuals", C.c_longlong),
+        ("score2", C.c_double),
+        ("percent2", C.c_double),
     ]
 
 

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(pkg):
 def test_struct_layouts_match_header(pkg):
     # sizes the C compiler gives the ABI structs (natural alignment, LP64)
     assert C.sizeof(pkg.LslamOpts) == 56
-    assert C.sizeof(pkg.LslamStats) == 80
+    assert C.sizeof(pkg.LslamStats) == 96  # + score2, percent2
     assert C.sizeof(pkg.LslamMapInfo) == 48
 
 

@@ -303,6 +303,46 @@ def test_full_loop_pose_matches_oracle(ctx, oracle, small_problem, jtj_mode, sea
     assert ran == {SHAPE_VARIANT[search]}, ran
 
 
+@pytest.mark.parametrize("search", ["lane", "lane_shallow"])
+def test_fine_score_matches_oracle(ctx, oracle, synth, small_problem, search):
+    """setFineScore(true), ScanMatch.cpp:272-321: after a converged loop one more sweep at the final pose, gated on the NEAREST
+    neighbour (d2[0] < 0.02 corner / 0.05 surf), gives score2 / percent2 -- printed by the reference, never part of the
+    return value.  Device against oracle; single scan and a batch in which one scan does not converge."""
+    pr = small_problem
+    opts = ctx.default_opts()
+    opts.fine_score = 1
+    opts.search_mode = SEARCH_SHAPES[search]
+    oopts = oracle.default_opts()
+    oopts.fine_score = 1
+    ctx.map_set(pr["map_corner"], pr["map_surf"])
+    status, pose, st = ctx.scanmatch_scan(pr["corner"], pr["surf"], pr["init_pose"], opts)
+    ok, opose, ost = oracle.scanmatch_scan(pr["map_corner"], pr["map_surf"], pr["corner"], pr["surf"], pr["init_pose"], oopts)
+    assert st.converged and ost.converged and (status == 0) == ok
+    assert ost.score2 > 100 and 0.05 < ost.percent2 < ost.percent  # the tighter gate keeps fewer points
+    assert abs(st.score2 - ost.score2) <= 2e-3 * ost.score2   # a handful of points sit within the poses' last-bit difference of the gate
+    assert abs(st.percent2 - ost.percent2) <= 2e-3
+    assert abs(st.score - ost.score) <= 1e-5 * ost.score and abs(st.percent - ost.percent) <= 1e-6  # the gate's inputs: untouched
+    assert np.abs(pose - opose).max() <= POSE_TOL_M
+    # off: zeros; score gate off: the reference never gets there (:263)
+    st0 = ctx.scanmatch_scan(pr["corner"], pr["surf"], pr["init_pose"])[2]
+    assert st0.score2 == 0.0 and st0.percent2 == 0.0 and st0.score == st.score
+    opts.use_score = 0
+    st1 = ctx.scanmatch_scan(pr["corner"], pr["surf"], pr["init_pose"], opts)[2]
+    assert st1.score2 == 0.0 and st1.status == 2
+    opts.use_score = 1
+    # batch: scan 1 is far from the map (no convergence -> no fine sweep for it), scans 0 and 2 get their own numbers
+    qc2, qs2, gt2 = synth.make_scan(pr["world"], 16, 450, gt_pose=(0.0, 0.01, 0.5, 1.0, -1.0, synth.SENSOR_HEIGHT), seed=77)
+    scans = [(pr["corner"], pr["surf"]), (pr["corner"][:200], pr["surf"][:3000]), (qc2, qs2)]
+    inits = np.stack([pr["init_pose"], pr["init_pose"] + np.array([0, 0, 0, 400, 0, 0], np.float32), synth.perturb_pose(gt2, seed=5)])
+    ctx.scan_set_batch(scans)
+    worst, poses, stats = ctx.run_batch(inits, opts)
+    assert abs(stats[0].score2 - st.score2) <= 1e-9 * st.score2 and stats[0].percent2 == st.percent2  # same bits as alone
+    assert stats[1].status == 5 and stats[1].score2 == 0.0
+    ok2, opose2, ost2 = oracle.scanmatch_scan(pr["map_corner"], pr["map_surf"], qc2, qs2, inits[2], oopts)
+    assert stats[2].converged and ost2.converged
+    assert abs(stats[2].score2 - ost2.score2) <= 2e-3 * ost2.score2 and abs(stats[2].percent2 - ost2.percent2) <= 2e-3
+
+
 def test_full_loop_mapping_settings(ctx, oracle, small_problem):
     """LaserMatcher.cpp:94-95: thresholds 0.1/0.1 and score gate off -> always 'false', pose used (Q7)."""
     pr = small_problem

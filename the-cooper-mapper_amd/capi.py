@@ -83,6 +83,8 @@ class LslamStats(C.Structure):
         ("sweep_launches", C.c_int32),
         ("gpu_ms_total", C.c_float),
         ("gpu_ms_sweep", C.c_float),
+        ("score2", C.c_double),
+        ("percent2", C.c_double),
     ]
 
 

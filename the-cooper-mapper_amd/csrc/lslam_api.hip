@@ -234,6 +234,7 @@ void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
   a.deep_tree = (ctx->tc.depth > KD_STACK_LDS + 1 || ctx->ts.depth > KD_STACK_LDS + 1) ? 1 : 0;
   a.packet = 0;
   a.stack_mode = SWEEP_STACK_AUTO;
+  a.fine_gate_c = a.fine_gate_s = -1.0f;
   a.idx_out = nullptr;
   a.d2_out = nullptr;
   a.coeff_out = nullptr;
@@ -1110,19 +1111,19 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
   int launched = 0;
   int batch = ctx->iter_hint < 1 ? 1 : ctx->iter_hint;
   double total_points = -1.0;  // sharded: points of the whole scan (sum over ranks)
+  auto exchange = [&]() -> int {  // sharded: sum xchg[0..32) over the ranks; ordered on the library's stream
+    if (fn) {
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      fn(user, xchg, NCOL);  // returns with the sum visible to this stream
+    } else {
+      if (comm_allreduce_f64(ctx->comm, xchg, NCOL, ctx->stream) != hipSuccess) return LSLAM_ERR_COMM;
+    }
+    return LSLAM_OK;
+  };
   if (sharded) {
     // xchg[32]: the local point count first (one exchange per call), then the sums per iteration
     static const bool unbounded = std::getenv("LSLAM_UNBOUNDED_KNN") != nullptr;
     sa.bounded = (ctx->cube_mode || unbounded) ? 0 : 1;
-    auto exchange = [&]() -> int {  // sum xchg[0..32) over the ranks; ordered on the library's stream
-      if (fn) {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        fn(user, xchg, NCOL);  // returns with the sum visible to this stream
-      } else {
-        if (comm_allreduce_f64(ctx->comm, xchg, NCOL, ctx->stream) != hipSuccess) return LSLAM_ERR_COMM;
-      }
-      return LSLAM_OK;
-    };
     double cnt[NCOL] = {0};
     cnt[0] = (double)ctx->nqc[0] + (double)ctx->nqs[0];
     HIP_TRY(hipMemcpyAsync(xchg, cnt, sizeof(cnt), hipMemcpyHostToDevice, ctx->stream));
@@ -1294,6 +1295,67 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
       batch = 2;
     }
   }
+  // ---- _fineScore (ScanMatch.cpp:272-321) ---------------------------------------------------------------------------
+  // After a converged loop with the score gate on, the reference sweeps once more at the FINAL pose, accepting a point when
+  // its nearest neighbour is within sqrt(0.02) m (corner) / sqrt(0.05) m (surf) instead of the fifth within sqrt(5) m, and
+  // prints score2 / percent2; neither enters the return value.  One more launch over the converged scans (unbounded search:
+  // the bound of the loop's sweeps assumes the d2[4] < 5 gate), their sums reduced by the solve kernel's first half.
+  std::vector<double> score2((size_t)n_scans, 0.0), match2((size_t)n_scans, 0.0);
+  if (o.fine_score && o.use_score && max_it > 0) {
+    bool any_conv = false;
+    for (int32_t p = 0; p < n_scans; ++p) any_conv = any_conv || ctx->h_state[p].converged;
+    if (any_conv) {
+      SweepArgs sf = sa;
+      sf.bounded = 0;
+      sf.prev_valid = 0;
+      sf.fine_gate_c = 0.02f;  // :282
+      sf.fine_gate_s = 0.05f;  // :302
+      const int in_flight = sharded ? n_scans : (o.scans_in_flight > 0 ? std::min<int>(o.scans_in_flight, n_scans) : std::min<int>(n_scans, 128));
+      const int n_chunks = (n_scans + in_flight - 1) / in_flight;
+      int32_t max_nb = 1;
+      for (int c = 0; c < n_chunks; ++c) {
+        const int p0 = c * in_flight, p1 = std::min(n_scans, p0 + in_flight);
+        max_nb = std::max(max_nb, ctx->h_probs[(size_t)p1 - 1].first_block + ctx->h_probs[(size_t)p1 - 1].n_blocks - ctx->h_probs[(size_t)p0].first_block);
+      }
+      HIP_TRY(ctx->stack_ovf.reserve(stack_ovf_words((size_t)max_nb * SWEEP_BLOCK, std::max(ctx->tc.depth, ctx->ts.depth))));
+      sf.stack_ovf = ctx->stack_ovf.p;
+      for (int c = 0; c < n_chunks; ++c) {
+        const int p0 = c * in_flight, p1 = std::min(n_scans, p0 + in_flight);
+        const int32_t fb = ctx->h_probs[(size_t)p0].first_block;
+        const int32_t lb = ctx->h_probs[(size_t)p1 - 1].first_block + ctx->h_probs[(size_t)p1 - 1].n_blocks;
+        SweepArgs sc = sf;
+        sc.blocks = ctx->blocks.p + fb;
+        sc.nb_total = lb - fb;
+        sc.partials = ctx->partials.p + (size_t)fb * NCOL;
+        SolveArgs soc = so;
+        soc.states = ctx->d_state + p0;
+        soc.probs = ctx->probs.p + p0;
+        soc.n_prob = p1 - p0;
+        soc.reduce_only = 2;
+        soc.ext_sums = nullptr;
+        soc.partials2 = nullptr;  // LiDAR rows only
+        soc.n_blocks2 = 0;
+        soc.sums_out = sharded ? xchg : nullptr;
+        HIP_TRY(sweep_launch(ctx, sc, o.jtj_mode));
+        HIP_TRY(launch_solve(soc, ctx->stream));
+      }
+      double xs[NCOL] = {0};
+      if (sharded) {  // every rank converged together (same sums, same solve): every rank is here
+        rc = exchange();
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(xs, xchg, sizeof(xs), hipMemcpyDeviceToHost, ctx->stream));
+      }
+      HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+      HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState) * (size_t)n_scans, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      for (int32_t p = 0; p < n_scans; ++p) {
+        if (!ctx->h_state[p].converged) continue;
+        const double *sm = sharded ? xs : ctx->h_state[p].sums;
+        score2[(size_t)p] = sm[COL_SCORE];
+        match2[(size_t)p] = sm[COL_LINE] + sm[COL_PLANE];
+      }
+    }
+  }
   int max_sweeps = 0, max_iter = 0;
   for (int32_t p = 0; p < n_scans; ++p) {
     max_sweeps = std::max(max_sweeps, ctx->h_state[p].sweeps);
@@ -1320,11 +1382,15 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
     for (int i = 0; i < 6; ++i) poses[6 * p + i] = g.pose[i];  // always written back
     const size_t npts = (size_t)ctx->nqc[(size_t)p] + (size_t)ctx->nqs[(size_t)p];
     int status;
-    double score = 0.0, percent = 0.0;
+    double score = 0.0, percent = 0.0, s2 = 0.0, pc2 = 0.0;
     if (g.converged && o.use_score) {  // ScanMatch.cpp:263-341
       score = g.score;
       const double match_count = (double)g.n_line + (double)g.n_plane;
       percent = (float)(match_count / (total_points >= 0.0 ? total_points : (double)npts));
+      if (o.fine_score) {  // :317-319
+        s2 = score2[(size_t)p];
+        pc2 = (float)(match2[(size_t)p] / (total_points >= 0.0 ? total_points : (double)npts));
+      }
       if (score < o.score_threshold) status = LSLAM_LOW_SCORE;
       else if (percent < o.match_percentage_threshold) status = LSLAM_LOW_PERCENT;
       else status = LSLAM_OK;
@@ -1347,6 +1413,8 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
       st.delta_t = g.delta_t;
       st.score = score;
       st.percent = percent;
+      st.score2 = s2;
+      st.percent2 = pc2;
       st.sweeps = g.sweeps;
       st.point_residuals = (int64_t)g.sweeps * (int64_t)npts;
       st.gpu_ms_total = gpu_ms_total;    // whole batch

@@ -89,6 +89,10 @@ struct SweepArgs {
   int32_t deep_tree;      // a tree is deeper than KD_STACK_LDS+1: the LDS-only kernels cannot be used
   int32_t packet;         // 1: wave-cooperative packet search (lslam_packet.hpp); needs stack_ovf and the trees' PNodes
   int32_t stack_mode;     // SWEEP_STACK_*: which traversal-stack shape launch_sweep takes (AUTO: by launch size)
+  // _fineScore re-sweep (ScanMatch.cpp:272-321): >= 0 -> the acceptance gate is d2[0] < fine_gate_c (corner blocks) /
+  // fine_gate_s (surf blocks) instead of d2[4] < 5, and the launch works on the scans whose loop CONVERGED (their `done`
+  // flag is set) instead of the ones still running
+  float fine_gate_c, fine_gate_s;
   // optional per-point taps (all NULL in the production loop)
   int32_t *idx_out;    // [N][5] original map indices
   float *d2_out;       // [N][5]
@@ -103,6 +107,7 @@ struct SolveArgs {
   const ProbBlocks *probs;    // [n_prob] block range of each scan
   int32_t n_prob;
   int32_t reduce_only;  // 1: only reduce partials into state->sums (tap; first half of a sharded iteration)
+                        // 2: the same for the scans whose loop converged (the _fineScore re-sweep)
   const double *ext_sums;  // non-null: [n_prob][32] sums already reduced (and summed over ranks); skip the reduction
   const float *partials2;  // non-null (single scan only): block records of the stereo term, added after the LiDAR ones
   int32_t n_blocks2;

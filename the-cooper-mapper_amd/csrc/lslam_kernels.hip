@@ -250,7 +250,8 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
     float coeff[4] = {0, 0, 0, 0};
     unsigned flag = 0;
     float4 nb[5];
-    const bool gate = d[4] < 5.0f;  // ScanMatch.cpp:102,120
+    // ScanMatch.cpp:102,120; the _fineScore re-sweep gates on the nearest neighbour instead (:282,302)
+    const bool gate = a.fine_gate_c >= 0.0f ? d[0] < (is_surf ? a.fine_gate_s : a.fine_gate_c) : d[4] < 5.0f;
     if (gate) {
       flag |= 1u;
 #pragma unroll
@@ -395,7 +396,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
   const int lb = xcd_remap(blockIdx.x, a.nb_total);
   const BlockDesc bd = a.blocks[lb];
   const GNState *st = a.states + bd.prob;
-  if (st->done) return;  // this scan's loop already ended (ScanMatch.cpp:144,259)
+  // this scan's loop already ended (ScanMatch.cpp:144,259); the _fineScore re-sweep visits the converged scans only
+  if (a.fine_gate_c >= 0.0f ? !st->converged : st->done) return;
   __shared__ float red[BLOCK / 64][NCOL];
   // The MFMA staging of [J | b] (8 floats per point) lives in the wavefront's OWN traversal-stack
   // slots -- word row c, lane slot p -- which are dead once its 5-NN searches are over: no extra LDS,
@@ -774,7 +776,7 @@ constexpr int SOLVE_GROUPS = SOLVE_THREADS / NCOL;  // 32 row groups x 32 column
 
 __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(SolveArgs a) {
   GNState *st = a.states + blockIdx.x;  // one block per scan of the batch
-  if (st->done) return;
+  if (a.reduce_only == 2 ? !st->converged : st->done) return;
   const ProbBlocks pb = a.probs[blockIdx.x];
   const float *partials = a.partials + (size_t)pb.first_block * NCOL;
   const int nb = pb.n_blocks;

@@ -419,7 +419,7 @@ int lslam_icp_align(lslam_ctx *ctx, const void *target, size_t n_target, const v
  * redone by the launch-per-step loop and the graph stays on that loop (tested through a debug hook).
  *
  * Multi-GPU (one process per GPU): every rank creates the same graph and takes an edge range
- * (lslam_pg_set_shard); the block system [diagonal blocks | off-diagonal blocks | b | chi2] is summed
+ * (lslam_pg_set_shard); the block system [diagonal blocks | off-diagonal blocks | b | chi2 | flag] is summed
  * across ranks once per linearisation -- by the library's RCCL communicator on the solver's stream
  * (lslam_pg_set_comm, further up) or through the callback of lslam_pg_set_shard for hosts with their own
  * transport; the damped solve is replicated and bit-identical on every rank. */

@@ -87,6 +87,21 @@ def _worker(rank, world, port, q):
             res["pg_full"] = pg1.poses()
             res["pg_full_chi2"] = pg1.last_stats.chi2_final
             pg1.close()
+        # ---- one rank's persistent PCG kernel gives up (debug hook: what another process's persistent kernel on the same
+        # device can cause): it takes the launch loop, whose sums differ in the last bits -- every rank must follow it, or the
+        # replicated solves drift apart and the LM decisions (hence the number of collectives) with them
+        if rank == 1:
+            os.environ["LSLAM_DEBUG_PG_ABORT"] = "3"
+        pg = pkg.PoseGraph(0)
+        pg.set_graph(g["init"], g["ij"], g["meas"], g["info"])
+        sysbuf2 = torch.zeros(pg.system_doubles(), dtype=torch.float64, device="cuda")
+        pg.set_shard(b, e, allreduce=make_allreduce(sysbuf2), system_tensor=sysbuf2)
+        pg.optimize(8)
+        os.environ.pop("LSLAM_DEBUG_PG_ABORT", None)
+        res["fb_poses"] = pg.poses()
+        res["fb_fused"] = pg.last_stats.fused_solves
+        res["fb_trials"] = pg.last_stats.lm_trials
+        pg.close()
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, res))
@@ -119,6 +134,11 @@ def test_sharded_paths_under_a_real_process_group():
     # pose graph: identical on both ranks, equal to the single-process solve
     assert np.array_equal(r0["pg_poses"], r1["pg_poses"])
     assert np.abs(r0["pg_poses"] - r0["pg_full"]).max() < 1e-8 and abs(r0["pg_chi2"] - r0["pg_full_chi2"]) <= 1e-9 * r0["pg_full_chi2"]
+    # rank 1's persistent kernel gave up in its first solve: rank 0 (whose first solve was fused) followed it to the launch
+    # loops after that trial, both finished, with the same bits and the same number of trials
+    assert np.array_equal(r0["fb_poses"], r1["fb_poses"]) and r0["fb_trials"] == r1["fb_trials"]
+    assert r1["fb_fused"] == 0 and r0["fb_fused"] == 1
+    assert np.abs(r0["fb_poses"] - r0["pg_full"]).max() < 1e-6  # launch loop against persistent kernel: two PCG solves to 1e-8
 
 
 def test_rccl_communicator_world_of_one(pkg, ctx, small_problem):

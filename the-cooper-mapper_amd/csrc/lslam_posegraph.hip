@@ -827,12 +827,14 @@ __global__ void pgc_prolong_kernel(CoarseArgs c, double *z) {
 // on time, instead of a counter barrier (136 serialised atomics) followed by the loads.  Slots are double-buffered by
 // iteration parity and reset by their owner one exchange after everybody has read them (a workgroup that has published
 // exchange j+1 has finished reading exchange j); values that are not polled (p, the exact r_c) are complete before the
-// polled ones are stored (s_waitcnt + workgroup barrier), so whoever sees the latter can read the former.
+// polled ones are stored (an explicit s_waitcnt vmcnt(0) in every wavefront, then a workgroup barrier), so whoever sees the
+// latter can read the former.
 //
 // Every sum has a fixed order: the solve is bit-reproducible and identical on every rank of a sharded run.  A spin limit
 // raises an abort flag instead of hanging.  Used when the graph fits (one workgroup per aggregate co-resident, LDS for
 // its columns and items); otherwise the multi-launch loop runs.
 // ------------------------------------------------------------------------------------------------------------------
+constexpr int PG_COARSE_MAX = 6144;        // coarse unknowns (1 024 aggregates): the dense inverse is 302 MB and O(n_c^3) beyond that is no preconditioner
 constexpr int PK_BLOCK = 512;
 constexpr int PG_AGG_MAX = 85;             // members of an aggregate: its 6 x 85 rows have a thread each in the persistent kernel
 constexpr int PK_ROWS = 6 * PG_AGG_MAX;
@@ -1171,7 +1173,12 @@ __global__ __launch_bounds__(PK_BLOCK) void pg_pcg_persistent_kernel(PkArgs a) {
 #pragma unroll
       for (int m = 0; m < 6; ++m) w[m] = Pr[m] * q;
       w[6] = p_own * q;
-      pk_reduce<7>(w, sh);  // (its workgroup barrier: every wavefront's p is at the coherence point before the slots are filled)
+      // Everything this workgroup stored without a sentinel -- every wavefront's p, the exact r_c and the sentinel resets of the
+      // previous phase -- must be at the coherence point before the polled slots below are filled: whoever sees those may read
+      // the former.  The compiler's own wait ahead of a workgroup barrier covers LDS only (s_waitcnt lgkmcnt(0)), so every
+      // wavefront waits for its outstanding vector-memory operations explicitly (they were issued a phase ago: no stall).
+      __builtin_amdgcn_s_waitcnt(0);
+      pk_reduce<7>(w, sh);  // (its workgroup barrier: nobody fills a slot before every wavefront has waited)
       if (tid == 0) {
         double *qc = a.qcB + (size_t)g * a.n_c;
 #pragma unroll
@@ -1263,6 +1270,9 @@ __global__ __launch_bounds__(PK_BLOCK) void pg_pcg_persistent_kernel(PkArgs a) {
       for (int m = 0; m < 6; ++m) z_own += Pr[m] * y[m];
     }
     PK_T(7)
+    // the sentinel resets of exchange A's slots (start of this phase) are complete before this workgroup publishes anything
+    // of exchange A of the next iteration; the z stores below are polled themselves and stay in flight behind it
+    __builtin_amdgcn_s_waitcnt(0);
     if (isrow) pk_st(a.zA + (size_t)(g ^ 1) * a.n6 + row, z_own);  // exchange A of iteration k + 1
     {
       double o[8];
@@ -1565,7 +1575,9 @@ struct lslam_pg {
   int gj_fit = -1;             // as pk_fit, for the coarse inverse
   int pk_fit = -1;             // -1 not decided yet, 0 the multi-launch loop, 1 the persistent kernel
   int fused_solves = 0, total_solves = 0, pk_timeouts = 0;
-  size_t sys_doubles() const { return (size_t)n_v * 36 + (size_t)n_off * 36 + (size_t)n_v * 6 + 1; }
+  bool fell_back = false;      // a persistent kernel gave way to its launch loop during the last solve() (sharded runs: every rank must follow)
+  // [diag | off | b | chi2 | fallback flag]: the last double travels with the trial chi2's all-reduce of a sharded run
+  size_t sys_doubles() const { return (size_t)n_v * 36 + (size_t)n_off * 36 + (size_t)n_v * 6 + 2; }
   double *diag() const { return d_sys; }
   double *off() const { return d_sys + (size_t)n_v * 36; }
   double *b() const { return d_sys + (size_t)n_v * 36 + (size_t)n_off * 36; }
@@ -1644,7 +1656,12 @@ int eval_chi2(lslam_pg *pg, const double *poses, double *out) {
   hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(SUM_BLOCK), 0, pg->stream, pg->d_chi, ne, 1, pg->chi());
   PG_TRY(hipGetLastError());
   if (pg->sharded()) {
-    const int rc = pg->reduce(pg->chi(), 1);
+    // chi2 and, next to it, whether this rank's persistent kernels gave way to their launch loops in the solve before:
+    // one all-reduce carries both (lslam_pg_optimize makes every rank follow a rank that fell back)
+    const double flag = pg->fell_back ? 1.0 : 0.0;
+    PG_TRY(hipMemcpyAsync(pg->chi() + 1, &flag, sizeof(double), hipMemcpyHostToDevice, pg->stream));
+    PG_TRY(hipStreamSynchronize(pg->stream));  // `flag` is a local
+    const int rc = pg->reduce(pg->chi(), 2);
     if (rc) return rc;
   }
   if (!out) return LSLAM_OK;  // the caller reads pg->chi() itself, behind more work on the stream
@@ -1703,6 +1720,12 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
       rebuild = !(ratio <= 10.0) || (pg->coarse_fresh_iters > 0 && 10 * pg->coarse_last_iters > 13 * pg->coarse_fresh_iters);
     }
     fresh_inverse = rebuild;
+    if (!pg->d_Ac) {  // first solve with the second level: its dense matrix and scratch
+      PG_TRY(hipMalloc((void **)&pg->d_Ac, nn * sizeof(double)));
+      PG_TRY(hipMalloc((void **)&pg->d_gj, ((size_t)12 * pg->n_c + 36) * sizeof(double)));
+      c.Ac = pg->d_Ac;
+      c.Rbuf = pg->d_gj; c.Cbuf = pg->d_gj + (size_t)6 * pg->n_c; c.Bbuf = pg->d_gj + (size_t)12 * pg->n_c;
+    }
     if (rebuild) {
     hipLaunchKernelGGL(pgc_P_kernel, dim3((pg->n_v + 127) / 128), dim3(128), 0, pg->stream, c);
     PG_TRY(hipMemsetAsync(c.Ac, 0, nn * sizeof(double), pg->stream));
@@ -1726,15 +1749,22 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
       PG_TRY(hipMemsetAsync(pg->d_bar, 0, 2 * sizeof(unsigned), pg->stream));
       PG_TRY(hipMemsetD32Async((hipDeviceptr_t)pg->d_gjslots, (int)PK_SENT32, (size_t)c.na * 6 * c.n_c * 2, pg->stream));
       void *gargs[] = {(void *)&gj};
-      PG_TRY(hipLaunchCooperativeKernel((const void *)pgc_gj_persistent_kernel, dim3((unsigned)c.na), dim3(GJ_BLOCK), gargs, 0, pg->stream));
       unsigned gbar[2] = {0, 0};
-      PG_TRY(hipMemcpyAsync(gbar, pg->d_bar, sizeof(gbar), hipMemcpyDeviceToHost, pg->stream));
-      PG_TRY(hipStreamSynchronize(pg->stream));
+      if (hipLaunchCooperativeKernel((const void *)pgc_gj_persistent_kernel, dim3((unsigned)c.na), dim3(GJ_BLOCK), gargs, 0, pg->stream) != hipSuccess) {
+        // no cooperative launch on this device / partition mode, or the runtime's residency count differs from the occupancy
+        // query: not an error of the solve -- the launch loop inverts A_c (which is untouched)
+        (void)hipGetLastError();
+        gbar[1] = 1;
+      } else {
+        PG_TRY(hipMemcpyAsync(gbar, pg->d_bar, sizeof(gbar), hipMemcpyDeviceToHost, pg->stream));
+        PG_TRY(hipStreamSynchronize(pg->stream));
+      }
       if (gbar[1] != 0) {  // not all workgroups resident at once (see the PCG kernel's fallback): the launch loop inverts A_c,
                            // assembled once more (a kernel that timed out wrote nothing back, but nothing here relies on that)
         if (std::getenv("LSLAM_DEBUG")) fprintf(stderr, "[lslam pg] persistent Gauss-Jordan kernel timed out: launch loop from here on\n");
         pg->gj_fit = 0;
         pg->pk_timeouts++;
+        pg->fell_back = true;
         PG_TRY(hipMemsetAsync(c.Ac, 0, nn * sizeof(double), pg->stream));
         hipLaunchKernelGGL(pgc_assemble_kernel, dim3(c.n_cb), dim3(64), 0, pg->stream, c, pg->d_vals, pg->d_row_of, pg->d_row_col, n_items);
       }
@@ -1791,13 +1821,17 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
     PG_TRY(hipMemsetAsync(pg->d_bar, 0, 2 * sizeof(unsigned), pg->stream));
     PG_TRY(hipMemsetD32Async((hipDeviceptr_t)slots, (int)PK_SENT32, 2 * n_slots, pg->stream));
     void *kargs[] = {(void *)&k};
-    PG_TRY(hipLaunchCooperativeKernel((const void *)pg_pcg_persistent_kernel, dim3((unsigned)pg->n_agg), dim3(PK_BLOCK), kargs,
-                                      (unsigned)pg->pk_lds_bytes, pg->stream));
     double scal[8] = {0};
     unsigned bar[2] = {0, 0};
-    PG_TRY(hipMemcpyAsync(scal, pg->d_scal, sizeof(scal), hipMemcpyDeviceToHost, pg->stream));
-    PG_TRY(hipMemcpyAsync(bar, pg->d_bar, sizeof(bar), hipMemcpyDeviceToHost, pg->stream));
-    PG_TRY(hipStreamSynchronize(pg->stream));
+    if (hipLaunchCooperativeKernel((const void *)pg_pcg_persistent_kernel, dim3((unsigned)pg->n_agg), dim3(PK_BLOCK), kargs,
+                                   (unsigned)pg->pk_lds_bytes, pg->stream) != hipSuccess) {
+      (void)hipGetLastError();  // as for the coarse inverse: a refused cooperative launch means the launch loop, not a failed solve
+      bar[1] = 1;
+    } else {
+      PG_TRY(hipMemcpyAsync(scal, pg->d_scal, sizeof(scal), hipMemcpyDeviceToHost, pg->stream));
+      PG_TRY(hipMemcpyAsync(bar, pg->d_bar, sizeof(bar), hipMemcpyDeviceToHost, pg->stream));
+      PG_TRY(hipStreamSynchronize(pg->stream));
+    }
     if (bar[1] == 0) {
       const int done_iters = (int)scal[6];
       *iters_out = done_iters;
@@ -1815,6 +1849,7 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
     if (std::getenv("LSLAM_DEBUG")) fprintf(stderr, "[lslam pg] persistent PCG kernel timed out in a grid exchange: launch loop from here on\n");
     pg->pk_fit = 0;
     pg->pk_timeouts++;
+    pg->fell_back = true;
   }
   auto coarse_correct = [&](int k) {  // z += P A_c^-1 P^T r and the matching share of r.z, entering iteration k + 1
     if (!coarse) return;
@@ -1875,6 +1910,10 @@ int lslam_pg_create(int device, int32_t n_v, const double *poses7, int32_t n_e, 
       return LSLAM_ERR_INVALID;
     }
   lslam_pg *pg = new lslam_pg();
+  struct Guard {  // a failure below frees what was built so far
+    lslam_pg *p;
+    ~Guard() { if (p) lslam_pg_destroy(p); }
+  } guard{pg};
   pg->device = device;
   pg->n_v = n_v;
   pg->n_e = n_e;
@@ -2004,10 +2043,15 @@ int lslam_pg_create(int device, int32_t n_v, const double *poses7, int32_t n_e, 
     PG_TRY(dev_upload(&pg->d_cb_ent, cent));
     PG_TRY(dev_upload(&pg->d_cb_ab, cab));
     PG_TRY(hipMalloc((void **)&pg->d_P, (size_t)n_v * 36 * sizeof(double)));
-    PG_TRY(hipMalloc((void **)&pg->d_Ac, (size_t)pg->n_c * pg->n_c * sizeof(double)));
     PG_TRY(hipMalloc((void **)&pg->d_rc, (size_t)pg->n_c * sizeof(double)));
     PG_TRY(hipMalloc((void **)&pg->d_yc, (size_t)pg->n_c * sizeof(double)));
-    PG_TRY(hipMalloc((void **)&pg->d_gj, ((size_t)12 * pg->n_c + 36) * sizeof(double)));
+    // the dense coarse matrix (n_c^2 doubles) and the Gauss-Jordan scratch are allocated by the first solve that takes the
+    // second level (solve()); graphs whose coarse matrix would exceed PG_COARSE_MAX unknowns never take it
+    if (pg->n_c > PG_COARSE_MAX) {
+      if (std::getenv("LSLAM_DEBUG"))
+        fprintf(stderr, "[lslam pg] %d coarse unknowns > %d: the dense second level is not used for this graph (block-Jacobi PCG)\n", pg->n_c, PG_COARSE_MAX);
+      pg->coarse_mode = 0;
+    }
     {  // the persistent PCG kernel's view: per aggregate its rows' entries member by member, and a local numbering of
        // the column vertices those entries refer to (first appearance order)
       std::vector<int32_t> bent_ptr(1, 0), bent, blc, bmptr, bcol_ptr(1, 0), bcol;
@@ -2086,6 +2130,7 @@ int lslam_pg_create(int device, int32_t n_v, const double *poses7, int32_t n_e, 
   PG_TRY(hipMalloc((void **)&pg->d_tmp, 8 * sizeof(double)));
   int rc = build_shard(pg, 0, n_e);
   if (rc) return rc;
+  guard.p = nullptr;
   *out = pg;
   return LSLAM_OK;
 }
@@ -2328,6 +2373,7 @@ int lslam_pg_optimize(lslam_pg *pg, int32_t max_iters, lslam_pg_stats *st_out) {
       // optimum after 2 000 LM iterations; uncapped it arrives in 342).  LSLAM_PG_MAX_CG overrides the cap for A/B runs.
       static const int max_cg = std::getenv("LSLAM_PG_MAX_CG") ? std::atoi(std::getenv("LSLAM_PG_MAX_CG")) : 20000;
       static const double cg_tol = std::getenv("LSLAM_PG_TOL") ? std::atof(std::getenv("LSLAM_PG_TOL")) : 1e-8;
+      pg->fell_back = false;
       rc = solve(pg, lambda, max_cg, cg_tol, &cg);
       if (rc) return rc;
       st.cg_iterations += cg;
@@ -2342,9 +2388,21 @@ int lslam_pg_optimize(lslam_pg *pg, int32_t max_iters, lslam_pg_stats *st_out) {
                          pg->b(), n6, lambda, pg->d_part);
       hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(SUM_BLOCK), 0, pg->stream, pg->d_part, pg->n_cg_blocks, 1, pg->d_tmp + 2);
       PG_TRY(hipGetLastError());  // a failed launch must not turn into a stale read below
-      PG_TRY(hipMemcpyAsync(&tmp, pg->chi(), 8, hipMemcpyDeviceToHost, pg->stream));
+      double chi_flag[2] = {0.0, 0.0};
+      PG_TRY(hipMemcpyAsync(chi_flag, pg->chi(), pg->sharded() ? 16 : 8, hipMemcpyDeviceToHost, pg->stream));
       PG_TRY(hipMemcpyAsync(&scale, pg->d_tmp + 2, 8, hipMemcpyDeviceToHost, pg->stream));
       PG_TRY(hipStreamSynchronize(pg->stream));
+      tmp = chi_flag[0];
+      if (pg->sharded() && chi_flag[1] > 0.0) {
+        // Some rank's persistent kernel timed out (or was refused) in this trial and that rank solved with the launch loop: a
+        // different summation order, dx equal to ~1e-8 instead of bit for bit -- and the replicated solve is only useful while
+        // every rank takes the same LM decisions.  Every rank switches to the launch loops for good and repeats the trial
+        // (one more chi2 all-reduce on every rank: the collectives stay matched).
+        pg->pk_fit = 0;
+        if (pg->gj_fit == 1) pg->gj_fit = 0;
+        pg->coarse_valid = false;
+        continue;
+      }
       scale += 1e-3;
       rho = (cur - tmp) / scale;
       st.lm_trials++;

@@ -556,7 +556,8 @@ int lslam_pg_solve(lslam_pg *pg, double lambda, double *dx_out, int32_t *cg_iter
 void *lslam_stream(lslam_ctx *ctx); /* hipStream_t */
 /* Sweep launches of this context so far, per kernel instantiation: [0] whole stack in LDS, [1] the same with the HBM
  * overflow (trees deeper than 33 levels), [2] the shallow-stack batch kernel sweep_kernel<256,true,false,12>, [3] per-cube
- * trees, [4] per-cube trees with overflow, [5] packet search, [6] persistent Gauss-Newton kernel, [7] unused. */
+ * trees, [4] per-cube trees with overflow, [5] packet search, [6] persistent Gauss-Newton kernel, [7] the whole-stack kernel with
+ * the 6x6 solve fused into its tail (the Gauss-Newton loop of single scans: one launch per iteration). */
 void lslam_debug_sweep_launches(lslam_ctx *ctx, uint64_t counts[8]);
 
 #ifdef __cplusplus

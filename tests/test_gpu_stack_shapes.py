@@ -60,7 +60,8 @@ def test_full_loop_on_a_deep_tree_matches_oracle(ctx, oracle, small_problem, sha
     tc, ts = oracle.kdtree(mc), oracle.kdtree(ms)
     assert 34 < tc.max_depth() <= 64 and 34 < ts.max_depth() <= 64
     mode = LANE | (DEEP if shape == "deep" else SHALLOW)
-    variant = "deep_ovf" if shape == "deep" else "shallow"
+    variant = "deep_ovf" if shape == "deep" else "shallow"      # the taps' launches
+    loop_variant = variant
     ctx.map_set(mc, ms)
     info = ctx.map_info()
     assert info.depth_corner == tc.max_depth() and info.depth_surf == ts.max_depth()
@@ -78,7 +79,7 @@ def test_full_loop_on_a_deep_tree_matches_oracle(ctx, oracle, small_problem, sha
     assert (status == 0) == ok and st.iterations == ost.iterations and st.converged == ost.converged
     assert (st.n_line, st.n_plane, st.n_rows) == (ost.n_line, ost.n_plane, ost.n_rows)
     assert np.abs(pose[3:] - opose[3:]).max() <= POSE_TOL_M and np.abs(pose[:3] - opose[:3]).max() <= POSE_TOL_RAD
-    assert set(_ran(before, ctx.sweep_launches())) == {variant}
+    assert set(_ran(before, ctx.sweep_launches())) == {variant, loop_variant}
     # AUTO on a deep tree takes the shallow kernel (bounded loop), whatever the launch size
     before = ctx.sweep_launches()
     status2, pose2, st2 = ctx.run(pr["init_pose"])
@@ -230,3 +231,44 @@ def test_voxel_map_sweep_taps_match_oracle_through_the_shallow_kernel(voxel_map_
     assert np.abs(g["sums"][:27] - o["sums"][:27]).max() <= 2e-5 * scale
     assert g["sums"][27] == o["sums"][27] and g["sums"][28] == o["sums"][28]
     assert (o["flags"] & 4).sum() > 50000
+
+
+def test_fused_solve_equals_the_solve_launch(ctx, synth, small_problem, monkeypatch):
+    """The 6 x 6 solve in the tail of the sweep launch (the block that retires the scan's last record reduces and solves) against
+    the solve kernel as its own launch: same reduction order, same solve -- same bits; single scan, a small batch with a scan
+    that ends early, and the mapping node's settings.  (Measured no faster: LSLAM_FUSED_SOLVE=1 is an A/B switch, off by default.)"""
+    pr = small_problem
+    ctx.map_set(pr["map_corner"], pr["map_surf"])
+    world = pr["world"]
+    scans, inits = [(pr["corner"], pr["surf"])], [pr["init_pose"]]
+    for k in range(3):
+        gt = (0.0, 0.01 * k, 0.2 + 0.3 * k, 2.0 - 1.5 * k, -1.0 + k, synth.SENSOR_HEIGHT)
+        qc, qs, gt = synth.make_scan(world, 16, 450, gt_pose=gt, seed=500 + k)
+        scans.append((qc, qs))
+        inits.append(synth.perturb_pose(gt, seed=600 + k))
+    inits[2][3] += 400.0
+    opts = ctx.default_opts()
+    mopts = ctx.default_opts()
+    mopts.delta_t_abort = mopts.delta_r_abort = 0.1
+    mopts.use_score = 0
+    res = {}
+    for fused in (True, False):
+        if fused:
+            monkeypatch.setenv("LSLAM_FUSED_SOLVE", "1")
+        else:
+            monkeypatch.delenv("LSLAM_FUSED_SOLVE", raising=False)
+        before = ctx.sweep_launches()
+        ctx.scan_set(*scans[0])
+        a = ctx.run(inits[0], opts)
+        b = ctx.run(inits[0], mopts)
+        ctx.scan_set_batch(scans)
+        c = ctx.run_batch(np.stack(inits), opts)
+        assert set(_ran(before, ctx.sweep_launches())) == {"deep_fused" if fused else "deep"}
+        res[fused] = (a, b, c)
+    for x, y in ((res[True][0], res[False][0]), (res[True][1], res[False][1])):
+        assert np.array_equal(bits(x[1]), bits(y[1])) and x[2].iterations == y[2].iterations and x[2].n_rows == y[2].n_rows
+        assert x[2].score == y[2].score and int(x[0]) == int(y[0]) and x[2].sweeps == y[2].sweeps
+    (_, pf, sf), (_, pu, su) = res[True][2], res[False][2]
+    assert np.array_equal(bits(pf), bits(pu))
+    assert [(s.status, s.iterations, s.n_rows, s.sweeps) for s in sf] == [(s.status, s.iterations, s.n_rows, s.sweeps) for s in su]
+    assert sf[2].status == 5 and len({s.iterations for s in sf}) > 1

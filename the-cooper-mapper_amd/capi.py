@@ -229,7 +229,7 @@ COMM_ID_BYTES = 128
 SEARCH_AUTO, SEARCH_LANE, SEARCH_PACKET = 0, 1, 2
 STACK_AUTO, STACK_DEEP, STACK_SHALLOW = 0, 0x100, 0x200  # ORed into a search mode (LSLAM_STACK_*)
 # lslam_debug_sweep_launches: index of each sweep-kernel instantiation
-SWEEP_VARIANTS = ("deep", "deep_ovf", "shallow", "cubes", "cubes_ovf", "packet", "persistent", "unused")
+SWEEP_VARIANTS = ("deep", "deep_ovf", "shallow", "cubes", "cubes_ovf", "packet", "persistent", "deep_fused")
 
 
 def lib_path():

@@ -115,6 +115,7 @@ struct lslam_ctx {
   int32_t nb_total = 0;
   size_t n_points = 0;
   DevBuf<float> partials;
+  DevBuf<int32_t> tail_count;  // per resident scan: the fused solve's ticket counter (zero between launches)
   DevBuf<uint32_t> stack_ovf;  // only allocated for trees deeper than KD_STACK_LDS+1
   DevBuf<int32_t> prev_nb;     // neighbours of the previous sweep, per resident scan point
   bool prev_valid = false;
@@ -142,6 +143,7 @@ struct lslam_ctx {
   // pinned staging area for the scan clouds a caller hands over (packed here, copied from here)
   float4 *h_stage = nullptr;
   size_t h_stage_cap = 0;
+  bool stage_busy = false;  // a copy out of h_stage was enqueued and no wait on the stream has happened since
   // ... and for the two map clouds of lslam_map_set (one per tree: they are packed on two threads)
   float4 *h_map_stage[2] = {nullptr, nullptr};
   size_t h_map_cap[2] = {0, 0};
@@ -235,6 +237,7 @@ void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
   a.packet = 0;
   a.stack_mode = SWEEP_STACK_AUTO;
   a.fine_gate_c = a.fine_gate_s = -1.0f;
+  a.tail = SweepTail{};
   a.idx_out = nullptr;
   a.d2_out = nullptr;
   a.coeff_out = nullptr;
@@ -270,10 +273,12 @@ int resolve_stack_mode(int32_t search_mode) {
 }
 
 // launch_sweep + the per-context count of the instantiation it took
-hipError_t sweep_launch(lslam_ctx *ctx, const SweepArgs &a, int jtj_mode, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+hipError_t sweep_launch(lslam_ctx *ctx, const SweepArgs &a, int jtj_mode, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
+                        int *variant = nullptr) {
   int v = -1;
   const hipError_t e = launch_sweep(a, jtj_mode, ctx->stream, e0, e1, &v);
   if (v >= 0 && v < SWEEP_N_VARIANTS) ctx->sweep_variants[v]++;
+  if (variant) *variant = v;
   return e;
 }
 
@@ -904,6 +909,10 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
     return LSLAM_ERR_INVALID;
   }
   ctx->have_scan = false;
+  if (ctx->stage_busy) {  // the previous call's copy out of the pinned staging area may still be in flight
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stage_busy = false;
+  }
   // the clouds are packed straight into pinned memory: one pass over the caller's points, and the
   // H2D copy is a real asynchronous DMA instead of a staged pageable copy
   if (total > ctx->h_stage_cap) {
@@ -971,6 +980,8 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
   HIP_TRY(ctx->probs.reserve((size_t)n_scans));
   HIP_TRY(ctx->partials.reserve((nb ? nb : 1) * NCOL));
   HIP_TRY(ctx->prev_nb.reserve((total ? total : 1) * 5));
+  HIP_TRY(ctx->tail_count.reserve((size_t)n_scans));
+  HIP_TRY(hipMemsetAsync(ctx->tail_count.p, 0, sizeof(int32_t) * (size_t)n_scans, ctx->stream));
   ctx->prev_valid = false;
   rc = ensure_states(ctx, n_scans);
   if (rc) return rc;
@@ -986,7 +997,10 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
                            hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemcpyAsync(ctx->probs.p, ctx->h_probs.data(), (size_t)n_scans * sizeof(ProbBlocks),
                          hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  // No wait here: everything that uses the scan is ordered behind these copies on the same stream, the block / range tables
+  // are pageable (consumed when hipMemcpyAsync returns) and the pinned staging area is guarded by `stage_busy` -- so that
+  // lslam_scanmatch_scan reaches the host once per call, when the loop's result comes back.
+  ctx->stage_busy = true;
   ctx->n_prob = n_scans;
   ctx->nb_total = (int32_t)nb;
   ctx->n_points = total;
@@ -1231,6 +1245,28 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
     sa.bounded = (ctx->cube_mode || unbounded) ? 0 : 1;  // per-cube positions are tree-relative
     std::vector<int> done_iters((size_t)n_chunks, 0);    // iterations enqueued per chunk
     std::vector<char> finished((size_t)n_chunks, 0);
+    // LSLAM_FUSED_SOLVE=1 (read per call: the tests switch it): the solve rides in the tail of the sweep launch whenever that
+    // launch is a latency-bound one (launch_sweep takes the whole-stack kernel: single scans, small batches) -- the block that
+    // retires a scan's last record reduces and solves, one launch per Gauss-Newton iteration.  Bit-identical to the solve
+    // kernel as its own launch (tests/test_gpu_stack_shapes.py) and MEASURED NO FASTER, so off by default: per working
+    // iteration of a 115 200-point scan 83 us against 47 + 13 us of kernels plus a ~3 us gap (rocprofv3 --kernel-trace);
+    // 0.270 against 0.237 ms of device time per three-iteration loop, 0.244 against 0.229 ms for a 4 835-point scan.  The
+    // tail is the solve's own dependent chain (reduction round trip, 6 x 6 QR, pose update: ~13 us) run by ONE workgroup
+    // that first had to finish its share of the sweep, reading the records through the coherence point; the launch it saves
+    // costs less than that.  Not with the stereo term (its records come from a launch of their own).
+    const bool no_fuse = !(std::getenv("LSLAM_FUSED_SOLVE") && std::atoi(std::getenv("LSLAM_FUSED_SOLVE")) == 1);
+    if (!no_fuse && ctx->n_stereo == 0) {
+      sa.tail.count = ctx->tail_count.p;
+      sa.tail.probs = ctx->probs.p;
+      sa.tail.partials_abs = ctx->partials.p;
+      sa.tail.sp.max_iterations = so.max_iterations;
+      sa.tail.sp.min_rows = so.min_rows;
+      sa.tail.sp.too_few_continue = so.too_few_continue;
+      sa.tail.sp.nan_reset = so.nan_reset;
+      sa.tail.sp.delta_r_abort = so.delta_r_abort;
+      sa.tail.sp.delta_t_abort = so.delta_t_abort;
+      sa.tail.sp.eig_thresh = so.eig_thresh;
+    }
     auto enqueue = [&](int c, int iters) -> int {
       const int p0 = c * in_flight, p1 = std::min(n_scans, p0 + in_flight);
       const int32_t fb = ctx->h_probs[(size_t)p0].first_block;
@@ -1249,10 +1285,11 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
         sc.prev_valid = (sc.bounded && done_iters[(size_t)c] > 0) ? 1 : 0;
         hipEvent_t e0, e1;
         HIP_TRY(sweep_events(n_launches, &e0, &e1));
-        HIP_TRY(sweep_launch(ctx, sc, o.jtj_mode, e0, e1));
+        int variant = -1;
+        HIP_TRY(sweep_launch(ctx, sc, o.jtj_mode, e0, e1, &variant));
         ++n_launches;
         HIP_TRY(launch_stereo(sta, ctx->stream));
-        HIP_TRY(launch_solve(soc, ctx->stream));
+        if (variant != SWEEP_VARIANT_DEEP_FUSED) HIP_TRY(launch_solve(soc, ctx->stream));
         ++done_iters[(size_t)c];
       }
       return LSLAM_OK;
@@ -1306,6 +1343,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
     for (int32_t p = 0; p < n_scans; ++p) any_conv = any_conv || ctx->h_state[p].converged;
     if (any_conv) {
       SweepArgs sf = sa;
+      sf.tail = SweepTail{};  // this pass only reduces
       sf.bounded = 0;
       sf.prev_valid = 0;
       sf.fine_gate_c = 0.02f;  // :282
@@ -1356,6 +1394,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
       }
     }
   }
+  ctx->stage_busy = false;  // the stream has been waited for since the scan was set
   int max_sweeps = 0, max_iter = 0;
   for (int32_t p = 0; p < n_scans; ++p) {
     max_sweeps = std::max(max_sweeps, ctx->h_state[p].sweeps);

@@ -73,6 +73,25 @@ struct CubeGridDev {
   const TreeView *trees;
 };
 
+// The solve fused into the tail of a sweep launch (ScanMatch.cpp:206-260 right behind :97-204): the block that retires a
+// scan's LAST partial record runs the cross-block reduction, the 6x6 solve and the pose update for that scan, so a
+// Gauss-Newton iteration of a latency-bound (single-scan) launch is ONE launch instead of a sweep, a 13 us solve launch and
+// the gap between them.  count == nullptr: no fusion (the solve kernel follows as its own launch).
+struct SolveParams {
+  int32_t max_iterations;
+  int32_t min_rows;          // 50 (ScanMatch.cpp:142); 10 in LaserOdometry.cpp:501
+  int32_t too_few_continue;  // variant B: `continue` instead of `break` (LaserOdometry.cpp:501-503)
+  int32_t nan_reset;         // variant B: LaserOdometry.cpp:622-634
+  float delta_r_abort, delta_t_abort;
+  float eig_thresh;          // 100 (ScanMatch.cpp:223); 10 in LaserOdometry.cpp:596
+};
+struct SweepTail {
+  int32_t *count;            // [n_prob] blocks of the scan that have stored their record in this launch (zero between launches)
+  const ProbBlocks *probs;   // [n_prob] absolute block range of each scan
+  float *partials_abs;       // the records of block 0 (SweepArgs::partials is the chunk's base)
+  SolveParams sp;
+};
+
 struct SweepArgs {
   TreeView tc, ts;
   CubeGridDev gc, gs;  // used instead of tc/ts by the per-cube kernels
@@ -93,6 +112,7 @@ struct SweepArgs {
   // fine_gate_s (surf blocks) instead of d2[4] < 5, and the launch works on the scans whose loop CONVERGED (their `done`
   // flag is set) instead of the ones still running
   float fine_gate_c, fine_gate_s;
+  SweepTail tail;
   // optional per-point taps (all NULL in the production loop)
   int32_t *idx_out;    // [N][5] original map indices
   float *d2_out;       // [N][5]
@@ -187,6 +207,7 @@ enum : int {
   SWEEP_VARIANT_CUBES_OVF = 4,  // sweep_kernel<256, true, true, 32>
   SWEEP_VARIANT_PACKET = 5,     // sweep_kernel<256, true, false, 4, true>
   SWEEP_VARIANT_PERSISTENT = 6, // gn_persistent_kernel
+  SWEEP_VARIANT_DEEP_FUSED = 7, // sweep_kernel<256, *, false, 32> with the solve in its tail (single scans)
   SWEEP_N_VARIANTS = 8
 };
 hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s,

@@ -63,7 +63,7 @@ LSLAM_DEV int cube_tree_of(const CubeGridDev &g, float x, float y, float z) {
 // One block of one sweep: the body of sweep_kernel, and of an iteration of gn_persistent_kernel.  `st` is the scan's
 // state -- in HBM (STATE_LDS = false: R, t, sc arrive by scalar loads) or a workgroup's LDS copy (true); `red` and
 // `stack_lds` are the caller's LDS; the block's 32 sums go to partial_out[0..32).
-template <int BLOCK, bool OVF, bool CUBES, int LDS_DEPTH, bool PACKET, bool STATE_LDS>
+template <int BLOCK, bool OVF, bool CUBES, int LDS_DEPTH, bool PACKET, bool STATE_LDS, bool FUSE = false>
 LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, const BlockDesc &bd, const GNState *st,
                           uint32_t *stack_lds, float (*red)[NCOL], float *partial_out, const int prev_valid) {
   constexpr int NWAVE = BLOCK / 64;
@@ -379,7 +379,10 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
     float s = red[0][tid];
 #pragma unroll
     for (int w = 1; w < NWAVE; ++w) s += red[w][tid];
-    partial_out[tid] = s;
+    // fused solve: the record is read by another workgroup of THIS launch (possibly on another XCD) -- written through to
+    // the device's coherence point; otherwise by the next launch
+    if (FUSE) __hip_atomic_store(partial_out + tid, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else partial_out[tid] = s;
   }
   if (a.dbg && lane == 0) {  // per-wave phase stamps (shader clock)
     uint64_t *o = a.dbg + ((size_t)lb * NWAVE + wave) * 4;
@@ -388,70 +391,6 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
     o[2] = dbg_t2;
     o[3] = __builtin_readcyclecounter();
   }
-}
-
-// PACKET: the 5-NN search is the wave-cooperative one of lslam_packet.hpp (see sweep_body).
-template <int BLOCK, bool OVF, bool CUBES, int LDS_DEPTH, bool PACKET = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH <= 16 ? LSLAM_SHALLOW_OCC : 2))) void sweep_kernel(SweepArgs a, int jtj_mode) {
-  const int lb = xcd_remap(blockIdx.x, a.nb_total);
-  const BlockDesc bd = a.blocks[lb];
-  const GNState *st = a.states + bd.prob;
-  // this scan's loop already ended (ScanMatch.cpp:144,259); the _fineScore re-sweep visits the converged scans only
-  if (a.fine_gate_c >= 0.0f ? !st->converged : st->done) return;
-  __shared__ float red[BLOCK / 64][NCOL];
-  // The MFMA staging of [J | b] (8 floats per point) lives in the wavefront's OWN traversal-stack
-  // slots -- word row c, lane slot p -- which are dead once its 5-NN searches are over: no extra LDS,
-  // no cross-wavefront hazard (the shallow variant then fits six workgroups per CU instead of four).
-  __shared__ uint32_t stack_lds[2 * LDS_DEPTH * BLOCK];
-  sweep_body<BLOCK, OVF, CUBES, LDS_DEPTH, PACKET, false>(a, jtj_mode, lb, bd, st, stack_lds, red, a.partials + (size_t)lb * NCOL, a.prev_valid);
-}
-
-// start/stop (optional) time exactly this dispatch on its own stream: the events are
-// attached to the kernel's AQL packet, no extra barrier packets are enqueued.
-hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t start,
-                        hipEvent_t stop, int *variant) {
-  if (variant) *variant = -1;
-  if (a.nb_total <= 0) return hipSuccess;
-  const dim3 g(a.nb_total), b(SWEEP_BLOCK);
-  const bool cubes = a.gc.trees != nullptr;
-#ifndef LSLAM_SHALLOW_DEPTH
-#define LSLAM_SHALLOW_DEPTH 12
-#endif
-  constexpr int SHALLOW = LSLAM_SHALLOW_DEPTH;  // LDS levels of the production (bounded) sweep
-  // A launch with more wavefronts than two per SIMD (256 CUs x 4 SIMDs) is throughput bound:
-  // take the shallow-stack kernel (4 workgroups per CU).  A smaller launch is latency bound
-  // and every wavefront is resident anyway: keep the whole stack in LDS.
-  const bool many_waves = (long)a.nb_total * (SWEEP_BLOCK / 64) > 2 * 1024;
-  const bool deep_tree = a.deep_tree != 0;
-  // The stack shape is a matter of speed only -- both kernels hold the same entries, the shallow one
-  // keeps levels >= 12 in HBM -- so a caller may force either (LSLAM_STACK_DEEP / _SHALLOW in the search
-  // mode, LSLAM_FORCE_STACK in the environment): the parity tests run every comparison against the
-  // oracle through both, whatever the size of their launch.
-  const bool shallow_ok = a.stack_ovf != nullptr && !cubes;
-  const bool shallow = shallow_ok && (a.stack_mode == SWEEP_STACK_SHALLOW ||
-                                      (a.stack_mode == SWEEP_STACK_AUTO && a.bounded && (many_waves || deep_tree)));
-  int v;
-  if (a.packet && !cubes && a.stack_ovf && a.tc.pn && a.ts.pn) {
-    v = SWEEP_VARIANT_PACKET;
-    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, 4, true>), g, b, 0, s, start, stop, 0, a, jtj_mode);
-  } else if (shallow) {
-    v = SWEEP_VARIANT_SHALLOW;
-    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, SHALLOW>), g, b, 0, s, start, stop, 0, a, jtj_mode);
-  } else if (cubes && a.stack_ovf && deep_tree) {
-    v = SWEEP_VARIANT_CUBES_OVF;
-    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, true, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
-  } else if (cubes) {
-    v = SWEEP_VARIANT_CUBES;
-    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false, true, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
-  } else if (a.stack_ovf && deep_tree) {
-    v = SWEEP_VARIANT_DEEP_OVF;
-    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
-  } else {
-    v = SWEEP_VARIANT_DEEP;
-    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false, false, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
-  }
-  if (variant) *variant = v;
-  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
@@ -772,57 +711,46 @@ __device__ static void gn_step_block(GNState *st, GnShared &sh, float eig_thresh
 }
 
 constexpr int SOLVE_THREADS = 1024;
-constexpr int SOLVE_GROUPS = SOLVE_THREADS / NCOL;  // 32 row groups x 32 columns
+constexpr int SOLVE_GROUPS = 32;  // 32 row groups x 32 columns: the summation order of the cross-block reduction
 
-__global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(SolveArgs a) {
-  GNState *st = a.states + blockIdx.x;  // one block per scan of the batch
-  if (a.reduce_only == 2 ? !st->converged : st->done) return;
-  const ProbBlocks pb = a.probs[blockIdx.x];
-  const float *partials = a.partials + (size_t)pb.first_block * NCOL;
-  const int nb = pb.n_blocks;
-  __shared__ double red[SOLVE_GROUPS][NCOL];
-  __shared__ double tot[NCOL];
-  __shared__ GnShared sh;
-  __shared__ int go;
-  const int tid = threadIdx.x, col = tid & 31, grp = tid >> 5;
-  if (tid == 0) st->clk[0] = wall_clock64();
-  // Deterministic cross-block reduction in fp64: thread (grp, col) adds rows
-  // grp, grp+32, ... in order; 32 independent loads are in flight per pass, so up to
-  // 1024 sweep blocks cost a single memory round trip.
-  if (a.ext_sums) {  // sharded points: the sums were reduced per rank and all-reduced by the caller
-    if (tid < NCOL) {
-      const double v = a.ext_sums[(size_t)blockIdx.x * NCOL + tid];
-      tot[tid] = v;
-      st->sums[tid] = v;
-    }
-    __syncthreads();
-  } else {
-    double s = 0.0;
-    for (int b0 = grp; b0 < nb; b0 += SOLVE_GROUPS * 32) {
-      float v[32];
-  #pragma unroll
-      for (int u = 0; u < 32; ++u) {
-        const int b = b0 + u * SOLVE_GROUPS;
-        v[u] = b < nb ? partials[(size_t)b * NCOL + col] : 0.0f;
+// Deterministic cross-block reduction in fp64 of one scan's block records: the thread that owns (group grp, column col)
+// adds rows grp, grp + 32, ... in order (32 independent loads in flight per pass, so up to 1024 sweep blocks cost a single
+// memory round trip); red[grp][col] receives the group's sum.  Called by THREADS = 32 * G threads, each owning 32 / G groups:
+// the order inside a group -- the only order that matters -- does not depend on G (the solve kernel: 1024 threads, the fused
+// tail of a sweep block: 256).  COHERENT: the records were written by other workgroups of the same launch (relaxed
+// agent-scope atomic loads, served by the coherence point).
+template <int THREADS, bool COHERENT>
+LSLAM_DEV void reduce_partials(const float *partials, int nb, double (*red)[NCOL]) {
+  constexpr int G = THREADS / NCOL;       // groups worked on at a time
+  constexpr int NG = SOLVE_GROUPS / G;    // groups per thread (1 for the solve kernel, 4 for a sweep block)
+  constexpr int CH = NG == 1 ? 32 : 16;   // rows of a group fetched together: NG * CH loads in flight per thread
+  const int tid = threadIdx.x, col = tid & 31, g0 = tid >> 5;
+  double s[NG];
+#pragma unroll
+  for (int gg = 0; gg < NG; ++gg) s[gg] = 0.0;
+  for (int b0 = 0; b0 < nb; b0 += SOLVE_GROUPS * CH) {  // one pass for up to 32 * CH blocks
+    float v[NG][CH];
+#pragma unroll
+    for (int gg = 0; gg < NG; ++gg)
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int b = b0 + (g0 + G * gg) + u * SOLVE_GROUPS;
+        if (COHERENT) v[gg][u] = b < nb ? __hip_atomic_load(partials + (size_t)b * NCOL + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+        else v[gg][u] = b < nb ? partials[(size_t)b * NCOL + col] : 0.0f;
       }
-  #pragma unroll
-      for (int u = 0; u < 32; ++u) s += (double)v[u];
-    }
-    if (a.partials2)  // stereo blocks of the joint system: same pattern, after the LiDAR blocks
-      for (int b = grp; b < a.n_blocks2; b += SOLVE_GROUPS) s += (double)a.partials2[(size_t)b * NCOL + col];
-    red[grp][col] = s;
-    __syncthreads();
-    if (tid < NCOL) {
-      double v = 0.0;
-  #pragma unroll
-      for (int g = 0; g < SOLVE_GROUPS; ++g) v += red[g][tid];
-      tot[tid] = v;
-      st->sums[tid] = v;
-      if (a.sums_out) a.sums_out[(size_t)blockIdx.x * NCOL + tid] = v;
-    }
-    __syncthreads();
+#pragma unroll
+    for (int gg = 0; gg < NG; ++gg)
+#pragma unroll
+      for (int u = 0; u < CH; ++u) s[gg] += (double)v[gg][u];  // rows grp, grp + 32, ... in order
   }
-  if (a.reduce_only) return;
+#pragma unroll
+  for (int gg = 0; gg < NG; ++gg) red[g0 + G * gg][col] = s[gg];
+}
+
+// ScanMatch.cpp:141-145 + :206-260 on the reduced sums tot[32] (LDS): bookkeeping, the too-few-rows guard, A^T A / A^T b,
+// gn_step_block, loop counter.  Block barriers inside: all threads of a block of >= 128 threads.
+__device__ static void solve_finish(GNState *st, const double *tot, GnShared &sh, int &go, const SolveParams &p) {
+  const int tid = threadIdx.x;
   if (tid == 0) {
     st->clk[1] = wall_clock64();
     st->sweeps += 1;
@@ -832,11 +760,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(SolveArgs a) {
     st->n_plane = (int)tot[COL_PLANE];
     st->score = tot[COL_SCORE];
     go = 1;
-    if (n_rows < a.min_rows) {  // ScanMatch.cpp:141-145 (break) / LaserOdometry.cpp:501-503 (continue)
+    if (n_rows < p.min_rows) {  // ScanMatch.cpp:141-145 (break) / LaserOdometry.cpp:501-503 (continue)
       go = 0;
-      if (a.too_few_continue) {
+      if (p.too_few_continue) {
         st->loop_iter += 1;
-        if (st->loop_iter >= a.max_iterations) st->done = 1;
+        if (st->loop_iter >= p.max_iterations) st->done = 1;
       } else {
         st->too_few = 1;
         st->done = 1;
@@ -851,12 +779,167 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(SolveArgs a) {
   if (tid < 6) sh.b[tid] = (float)tot[COL_ATB + tid];
   __syncthreads();
   if (!go) return;
-  gn_step_block(st, sh, a.eig_thresh, a.delta_r_abort, a.delta_t_abort, a.nan_reset != 0);
+  gn_step_block(st, sh, p.eig_thresh, p.delta_r_abort, p.delta_t_abort, p.nan_reset != 0);
   if (tid == 0) {
     st->loop_iter += 1;
-    if (st->loop_iter >= a.max_iterations) st->done = 1;
+    if (st->loop_iter >= p.max_iterations) st->done = 1;
   }
   if (tid == 0) st->clk[3] = wall_clock64();
+}
+
+__global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(SolveArgs a) {
+  GNState *st = a.states + blockIdx.x;  // one block per scan of the batch
+  if (a.reduce_only == 2 ? !st->converged : st->done) return;
+  const ProbBlocks pb = a.probs[blockIdx.x];
+  const float *partials = a.partials + (size_t)pb.first_block * NCOL;
+  const int nb = pb.n_blocks;
+  __shared__ double red[SOLVE_GROUPS][NCOL];
+  __shared__ double tot[NCOL];
+  __shared__ GnShared sh;
+  __shared__ int go;
+  const int tid = threadIdx.x, col = tid & 31, grp = tid >> 5;
+  if (tid == 0) st->clk[0] = wall_clock64();
+  if (a.ext_sums) {  // sharded points: the sums were reduced per rank and all-reduced by the caller
+    if (tid < NCOL) {
+      const double v = a.ext_sums[(size_t)blockIdx.x * NCOL + tid];
+      tot[tid] = v;
+      st->sums[tid] = v;
+    }
+    __syncthreads();
+  } else {
+    reduce_partials<SOLVE_THREADS, false>(partials, nb, red);
+    if (a.partials2) {  // stereo blocks of the joint system: same pattern, after the LiDAR blocks
+      double s = red[grp][col];  // (this thread's own group)
+      for (int b = grp; b < a.n_blocks2; b += SOLVE_GROUPS) s += (double)a.partials2[(size_t)b * NCOL + col];
+      red[grp][col] = s;
+    }
+    __syncthreads();
+    if (tid < NCOL) {
+      double v = 0.0;
+  #pragma unroll
+      for (int g = 0; g < SOLVE_GROUPS; ++g) v += red[g][tid];
+      tot[tid] = v;
+      st->sums[tid] = v;
+      if (a.sums_out) a.sums_out[(size_t)blockIdx.x * NCOL + tid] = v;
+    }
+    __syncthreads();
+  }
+  if (a.reduce_only) return;
+  SolveParams p;
+  p.max_iterations = a.max_iterations;
+  p.min_rows = a.min_rows;
+  p.too_few_continue = a.too_few_continue;
+  p.nan_reset = a.nan_reset;
+  p.delta_r_abort = a.delta_r_abort;
+  p.delta_t_abort = a.delta_t_abort;
+  p.eig_thresh = a.eig_thresh;
+  solve_finish(st, tot, sh, go, p);
+}
+
+// PACKET: the 5-NN search is the wave-cooperative one of lslam_packet.hpp (see sweep_body).
+// FUSE: the block that retires a scan's last record of the launch runs that scan's reduction + solve (SweepTail).
+template <int BLOCK, bool OVF, bool CUBES, int LDS_DEPTH, bool PACKET = false, bool FUSE = false>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH <= 16 ? LSLAM_SHALLOW_OCC : 2))) void sweep_kernel(SweepArgs a, int jtj_mode) {
+  const int lb = xcd_remap(blockIdx.x, a.nb_total);
+  const BlockDesc bd = a.blocks[lb];
+  GNState *st = const_cast<GNState *>(a.states) + bd.prob;
+  // this scan's loop already ended (ScanMatch.cpp:144,259); the _fineScore re-sweep visits the converged scans only
+  if (a.fine_gate_c >= 0.0f ? !st->converged : st->done) return;
+  __shared__ float red[BLOCK / 64][NCOL];
+  // The MFMA staging of [J | b] (8 floats per point) lives in the wavefront's OWN traversal-stack
+  // slots -- word row c, lane slot p -- which are dead once its 5-NN searches are over: no extra LDS,
+  // no cross-wavefront hazard (the shallow variant then fits six workgroups per CU instead of four).
+  __shared__ uint32_t stack_lds[2 * LDS_DEPTH * BLOCK];
+  sweep_body<BLOCK, OVF, CUBES, LDS_DEPTH, PACKET, false, FUSE>(a, jtj_mode, lb, bd, st, stack_lds, red, a.partials + (size_t)lb * NCOL, a.prev_valid);
+  if (FUSE) {
+    static_assert(!FUSE || (2 * LDS_DEPTH * BLOCK * 4 >= (int)((SOLVE_GROUPS + 1) * NCOL * sizeof(double) + sizeof(GnShared) + 16)), "the tail's LDS lives in the stack");
+    __shared__ int last;
+    // every wavefront's record stores are at the coherence point before the ticket is taken
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    const ProbBlocks pb = a.tail.probs[bd.prob];
+    if (threadIdx.x == 0) {
+      const int ticket = __hip_atomic_fetch_add(a.tail.count + bd.prob, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = ticket == pb.n_blocks - 1;
+      if (last) __hip_atomic_store(a.tail.count + bd.prob, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+    }
+    __syncthreads();
+    if (!last) return;
+    // the traversal stack is dead: the reduction's 32 x 32 doubles, the totals and the solve's 6 x 6 system live in it
+    double (*redd)[NCOL] = reinterpret_cast<double (*)[NCOL]>(stack_lds);
+    double *tot = &redd[SOLVE_GROUPS][0];
+    GnShared &sh = *reinterpret_cast<GnShared *>(tot + NCOL);
+    int &go = *reinterpret_cast<int *>(reinterpret_cast<char *>(&sh) + sizeof(GnShared));
+    const int tid = threadIdx.x;
+    if (tid == 0) st->clk[0] = wall_clock64();
+    reduce_partials<BLOCK, true>(a.tail.partials_abs + (size_t)pb.first_block * NCOL, pb.n_blocks, redd);
+    __syncthreads();
+    if (tid < NCOL) {
+      double v = 0.0;
+#pragma unroll
+      for (int g = 0; g < SOLVE_GROUPS; ++g) v += redd[g][tid];
+      tot[tid] = v;
+      st->sums[tid] = v;
+    }
+    __syncthreads();
+    solve_finish(st, tot, sh, go, a.tail.sp);
+  }
+}
+
+// start/stop (optional) time exactly this dispatch on its own stream: the events are
+// attached to the kernel's AQL packet, no extra barrier packets are enqueued.
+hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t start,
+                        hipEvent_t stop, int *variant) {
+  if (variant) *variant = -1;
+  if (a.nb_total <= 0) return hipSuccess;
+  const dim3 g(a.nb_total), b(SWEEP_BLOCK);
+  const bool cubes = a.gc.trees != nullptr;
+#ifndef LSLAM_SHALLOW_DEPTH
+#define LSLAM_SHALLOW_DEPTH 12
+#endif
+  constexpr int SHALLOW = LSLAM_SHALLOW_DEPTH;  // LDS levels of the production (bounded) sweep
+  // A launch with more wavefronts than two per SIMD (256 CUs x 4 SIMDs) is throughput bound:
+  // take the shallow-stack kernel (4 workgroups per CU).  A smaller launch is latency bound
+  // and every wavefront is resident anyway: keep the whole stack in LDS.
+  const bool many_waves = (long)a.nb_total * (SWEEP_BLOCK / 64) > 2 * 1024;
+  const bool deep_tree = a.deep_tree != 0;
+  // The stack shape is a matter of speed only -- both kernels hold the same entries, the shallow one
+  // keeps levels >= 12 in HBM -- so a caller may force either (LSLAM_STACK_DEEP / _SHALLOW in the search
+  // mode, LSLAM_FORCE_STACK in the environment): the parity tests run every comparison against the
+  // oracle through both, whatever the size of their launch.
+  const bool shallow_ok = a.stack_ovf != nullptr && !cubes;
+  const bool shallow = shallow_ok && (a.stack_mode == SWEEP_STACK_SHALLOW ||
+                                      (a.stack_mode == SWEEP_STACK_AUTO && a.bounded && (many_waves || deep_tree)));
+  int v;
+  if (a.packet && !cubes && a.stack_ovf && a.tc.pn && a.ts.pn) {
+    v = SWEEP_VARIANT_PACKET;
+    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, 4, true>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+  } else if (shallow) {
+    v = SWEEP_VARIANT_SHALLOW;
+    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, SHALLOW>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+  } else if (cubes && a.stack_ovf && deep_tree) {
+    v = SWEEP_VARIANT_CUBES_OVF;
+    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, true, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+  } else if (cubes) {
+    v = SWEEP_VARIANT_CUBES;
+    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false, true, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+  } else if (a.stack_ovf && deep_tree) {
+    if (a.tail.count) {
+      v = SWEEP_VARIANT_DEEP_FUSED;
+      hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, KD_STACK_LDS, false, true>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+    } else {
+      v = SWEEP_VARIANT_DEEP_OVF;
+      hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+    }
+  } else if (a.tail.count) {  // latency-bound launch: the solve rides in its tail
+    v = SWEEP_VARIANT_DEEP_FUSED;
+    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false, false, KD_STACK_LDS, false, true>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+  } else {
+    v = SWEEP_VARIANT_DEEP;
+    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false, false, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+  }
+  if (variant) *variant = v;
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------

@@ -70,7 +70,7 @@ void scanprep_destroy(ScanPrep *sp) {
 }
 
 // h_pts: n packed points in caller order (cloud after cloud); h_seg_off: nseg + 1 offsets.
-// Writes the ordered points to d_out (n float4) on `s`; host buffers may be released on return.
+// Writes the ordered points to d_out (n float4) on `s`, asynchronously: h_pts must stay untouched until `s` has been waited for.
 hipError_t scanprep_order(ScanPrep *sp, hipStream_t s, const float4 *h_pts, size_t n, const int32_t *h_seg_off,
                           int nseg, float4 *d_out) {
   if (n == 0) return hipSuccess;
@@ -117,8 +117,9 @@ hipError_t scanprep_order(ScanPrep *sp, hipStream_t s, const float4 *h_pts, size
   if ((e = rocprim::radix_sort_pairs(sp->tmp, tmp_bytes, k0, k1, i0, i1, n, 0u, end_bit, s)) != hipSuccess) return e;
   hipLaunchKernelGGL(sp_gather_kernel, grd, blk, 0, s, (const float4 *)sp->raw, i1, k1, (const int32_t *)sp->seg, (int)n,
                      d_out);
-  if ((e = hipGetLastError()) != hipSuccess) return e;
-  return hipStreamSynchronize(s);  // the host staging buffers are the caller's locals
+  // No wait: h_seg_off is pageable (consumed when hipMemcpyAsync returned), h_pts is the context's pinned staging area,
+  // which the caller does not touch again before it has waited on `s` (lslam_ctx::stage_busy).
+  return hipGetLastError();
 }
 
 }  // namespace lslam

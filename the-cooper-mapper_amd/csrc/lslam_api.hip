@@ -73,7 +73,8 @@ struct DevBuf {
 
 struct DevTree {
   DevBuf<KdNode> nodes;
-  DevBuf<PNode> pn;  // packet-search nodes, same slots
+  DevBuf<PNode> pn;  // packet-search nodes, same slots: made on demand (ensure_packet_nodes)
+  DevBuf<float> own_box;  // [slots][6] tight boxes recorded by the build (whole-map trees only)
   DevBuf<float4> pts;
   TreeView view{};
   int depth = 0;
@@ -250,13 +251,28 @@ void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
 // and leaves, every insert runs when ANY lane needs it): measured on MI355X it is SLOWER -- 0.81 against 0.45 ms
 // per 2.6 M-point launch, 277 against 59 us for a single 115 200-point scan (incoherent far-range packets make
 // a long tail) -- so it stays an explicit choice (LSLAM_SEARCH_PACKET, or LSLAM_SEARCH=packet for A/B runs).
+// The packet search's nodes of the resident whole-map trees, made the first time that search is asked for on this map.
+int ensure_packet_nodes(lslam_ctx *ctx) {
+  if (!ctx->have_map || ctx->cube_mode) return LSLAM_OK;
+  for (DevTree *dt : {&ctx->tc, &ctx->ts}) {
+    if (dt->view.pn || !dt->own_box.p) continue;
+    HIP_TRY(dt->pn.reserve((size_t)std::max(dt->view.n_nodes, 1)));  // (a tree whose root is a leaf has no inner node)
+    HIP_TRY(build_packet_nodes(dt->view, dt->own_box.p, dt->pn.p, ctx->stream));
+    dt->view.pn = dt->pn.p;
+  }
+  return LSLAM_OK;
+}
+
 int resolve_search_mode(const lslam_ctx *ctx, int32_t requested) {
   static const char *env = std::getenv("LSLAM_SEARCH");
   if (env && !std::strcmp(env, "lane")) requested = LSLAM_SEARCH_LANE;
   if (env && !std::strcmp(env, "packet")) requested = LSLAM_SEARCH_PACKET;
-  if (ctx->cube_mode || !ctx->tc.view.pn || !ctx->ts.view.pn) return LSLAM_SEARCH_LANE;
   requested &= 0xFF;  // the LSLAM_STACK_* bits are resolve_stack_mode's
-  if (requested == LSLAM_SEARCH_LANE || requested == LSLAM_SEARCH_PACKET) return requested;
+  if (ctx->cube_mode) return LSLAM_SEARCH_LANE;
+  if (requested == LSLAM_SEARCH_PACKET) {  // its nodes exist only once somebody has asked for it
+    if (ensure_packet_nodes(const_cast<lslam_ctx *>(ctx)) != LSLAM_OK || !ctx->tc.view.pn || !ctx->ts.view.pn) return LSLAM_SEARCH_LANE;
+    return requested;
+  }
   return LSLAM_SEARCH_LANE;
 }
 
@@ -378,8 +394,8 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  ctx->tc.nodes.release(); ctx->tc.pts.release(); ctx->tc.pn.release();
-  ctx->ts.nodes.release(); ctx->ts.pts.release(); ctx->ts.pn.release();
+  ctx->tc.nodes.release(); ctx->tc.pts.release(); ctx->tc.pn.release(); ctx->tc.own_box.release();
+  ctx->ts.nodes.release(); ctx->ts.pts.release(); ctx->ts.pn.release(); ctx->ts.own_box.release();
   ctx->cell_c.release(); ctx->cell_s.release(); ctx->views_c.release(); ctx->views_s.release();
   ctx->prev_nb.release();
   ctx->xchg.release();
@@ -549,7 +565,7 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
         if (const char *dv = std::getenv("LSLAM_DEBUG_NODE_CAP_DIV"))  // tests: force the retry / failure paths
           cap = std::max<size_t>(16, (cap / (size_t)std::max(1, atoi(dv))) & ~(size_t)7);
         if ((errs[k] = dt.nodes.reserve(cap)) != hipSuccess) return;
-        if ((errs[k] = dt.pn.reserve(cap)) != hipSuccess) return;
+        if ((errs[k] = dt.own_box.reserve(cap * 6)) != hipSuccess) return;
         if (n && from_dev) {
           errs[k] = hipMemcpyAsync(dt.pts.p, dev_src[k], n * sizeof(float4), hipMemcpyDeviceToDevice, st);
         } else if (n && attempt > dt.cap_attempt) {
@@ -581,7 +597,7 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
           }
         }
         if (errs[k] != hipSuccess) return;
-        errs[k] = build_kdtree_device(dt.pts.p, (int32_t)n, dt.nodes.p, dt.pn.p, (int32_t)cap, st, &dt.view, &dt.depth,
+        errs[k] = build_kdtree_device(dt.pts.p, (int32_t)n, dt.nodes.p, dt.own_box.p, (int32_t)cap, st, &dt.view, &dt.depth,
                                       &n_leaves, &fallback);
         if (errs[k] != hipSuccess) return;
         if (fallback != 1) {
@@ -773,11 +789,10 @@ int build_cube_side_device(lslam_ctx *ctx, DevTree &dt, const float4 *src, bool 
     const size_t mult[3] = {2, 8, 24};
     const size_t cap = ((mult[attempt] * n_pts / 3 + 64 + 8 * (size_t)T) + 7) & ~(size_t)7;
     HIP_TRY(dt.nodes.reserve(cap));
-    HIP_TRY(dt.pn.reserve(cap));
     if (n_pts)
       HIP_TRY(hipMemcpyAsync(dt.pts.p, src, n_pts * sizeof(float4), src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                              ctx->stream));
-    HIP_TRY(build_kdforest_device(dt.pts.p, (int32_t)n_pts, roots_lr.data(), T, dt.nodes.p, dt.pn.p, (int32_t)cap, ctx->stream,
+    HIP_TRY(build_kdforest_device(dt.pts.p, (int32_t)n_pts, roots_lr.data(), T, dt.nodes.p, nullptr, (int32_t)cap, ctx->stream,
                                   views.data(), max_depth, &n_leaves, fallback));
     if (*fallback != 1) break;
   }
@@ -1057,9 +1072,10 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
   }
   HIP_TRY(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(GNState) * (size_t)n_scans,
                          hipMemcpyHostToDevice, ctx->stream));
+  const int search = resolve_search_mode(ctx, o.search_mode);  // (may make the packet search's nodes: before the views are copied)
   SweepArgs sa;
   fill_sweep_args(ctx, sa);
-  sa.packet = resolve_search_mode(ctx, o.search_mode) == LSLAM_SEARCH_PACKET ? 1 : 0;
+  sa.packet = search == LSLAM_SEARCH_PACKET ? 1 : 0;
   sa.stack_mode = resolve_stack_mode(o.search_mode);
   // the production sweep keeps a shallow stack in LDS: it always gets the overflow area (sized per
   // chunk below; the sharded path has one resident scan)
@@ -1865,6 +1881,8 @@ int lslam_knn5_ex(lslam_ctx *ctx, int which_map, const void *queries, size_t nq,
   uint32_t *ovf = nullptr;
   if (n_ties) *n_ties = 0;
   if (search_mode == LSLAM_SEARCH_PACKET) {
+    rc = ensure_packet_nodes(ctx);
+    if (rc) return rc;
     if (!T.pn) { set_err("this map has no packet-search nodes"); return LSLAM_ERR_INVALID; }
     const size_t nthr = ((nq + 255) / 256) * 256;
     HIP_TRY(ctx->stack_ovf.reserve(stack_ovf_words(nthr)));
@@ -1938,7 +1956,11 @@ int lslam_sweep_ex(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_
     sa.stack_ovf = ctx->stack_ovf.p;
   }
   if (search_mode == LSLAM_SEARCH_PACKET) {
+    rc = ensure_packet_nodes(ctx);
+    if (rc) return rc;
     if (ctx->cube_mode || !ctx->tc.view.pn || !ctx->ts.view.pn) { set_err("this map has no packet-search nodes"); return LSLAM_ERR_INVALID; }
+    sa.tc = ctx->tc.view;
+    sa.ts = ctx->ts.view;
     HIP_TRY(ctx->stack_ovf.reserve(stack_ovf_words((size_t)std::max(sa.nb_total, 1) * SWEEP_BLOCK)));
     sa.stack_ovf = ctx->stack_ovf.p;
     sa.packet = 1;

@@ -1006,9 +1006,8 @@ int lslam_fmap_to_cubemap(lslam_fmap *fm) {
       const size_t mult[3] = {2, 8, 24};
       const size_t cap = ((mult[attempt] * total / 3 + 64 + 8 * (size_t)T) + 7) & ~(size_t)7;
       FM_TRY(g->nodes.reserve(cap));
-      FM_TRY(g->pn.reserve(cap));
       if (attempt > 0) FM_TRY(gather());  // the failed attempt permuted the points: gather them again
-      FM_TRY(lslam::build_kdforest_device(g->pts.p, (int32_t)total, roots_lr.data(), T, g->nodes.p, g->pn.p, (int32_t)cap, s,
+      FM_TRY(lslam::build_kdforest_device(g->pts.p, (int32_t)total, roots_lr.data(), T, g->nodes.p, nullptr, (int32_t)cap, s,
                                           built.data(), &max_depth, &n_leaves, &fallback));
       if (fallback != 1) break;
     }

@@ -231,11 +231,13 @@ hipError_t launch_gn_step_tap(GNState *st, const float *AtA, const float *Atb, f
                               float eig_thresh, hipStream_t s);
 
 // device kd-tree builder (lslam_treebuild.hip): same tree, built in HBM
-// d_pn (node_cap PNodes, or null): also the packet-search nodes (child boxes) of every used slot
-hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, PNode *d_pn, int32_t node_cap,
+// d_own_box (node_cap x 6 floats, or null): the tight box of every inner node's points, from which build_packet_nodes makes
+// the packet search's nodes when that search is asked for
+hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, float *d_own_box, int32_t node_cap,
                                hipStream_t stream, TreeView *view, int *depth, size_t *n_leaves,
                                int *fallback);
 
+hipError_t build_packet_nodes(const TreeView &view, const float *d_own_box, PNode *d_pn, hipStream_t stream);
 hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *roots_lr, int T, KdNode *d_nodes,
                                  PNode *d_pn, int32_t node_cap, hipStream_t stream, TreeView *views, int *max_depth,
                                  size_t *n_leaves, int *fallback);

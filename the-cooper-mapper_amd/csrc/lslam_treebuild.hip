@@ -907,18 +907,32 @@ constexpr int LV_TB = 256;
 constexpr int LV_PER = LV_CH / LV_TB;  // consecutive elements per thread
 
 struct LvStat {
-  int32_t mn[3], mx[3];      // order-preserving ints of the coordinate extrema
+  int32_t mn[3], mx[3];      // order-preserving ints of the coordinate extrema (written by whoever made the node: the host
+                             // for a root -- its bounding box IS its extrema --, the parent's lv_bounds pass for the others)
   int32_t feat;
   float cut;
   int32_t lim1, lim2;
   int32_t m[2];              // misplaced pairs of the two Hoare passes
   int32_t lmax, rmin;        // order-preserving ints
+  int32_t cmn[2][3], cmx[2][3];  // extrema of the two children's points (lv_bounds_kernel): next level's mn / mx
 };
+__device__ __host__ inline void lv_stat_reset(LvStat &st) {  // everything but mn / mx
+  st.feat = 0;
+  st.cut = 0.f;
+  st.lim1 = st.lim2 = 0;
+  st.m[0] = st.m[1] = 0;
+  st.lmax = INT32_MIN;
+  st.rmin = INT32_MAX;
+  for (int c = 0; c < 2; ++c)
+    for (int d = 0; d < 3; ++d) { st.cmn[c][d] = INT32_MAX; st.cmx[c][d] = INT32_MIN; }
+}
 
 struct LvArgs {
   BuildArgs A;
   const BuildItem *items;    // nodes of this level
   LvStat *stat;              // [n_nodes]
+  LvStat *stat_next;         // the next level's (filled by lv_final_kernel for the children that stay in phase 0)
+  int32_t *final_done;       // lv_final_kernel's ticket counter: its last block sets up the next level
   const int32_t *chunk_node; // [n_chunks] node of a chunk
   const int32_t *chunk_first;// [n_nodes] first chunk of a node
   int32_t *cntL, *cntR, *baseL, *baseR;  // [n_chunks]
@@ -968,30 +982,27 @@ __device__ __forceinline__ int lv_scan(int v, int *sh /*[LV_TB/64]*/, int *total
   (void)c1; (void)l;
 
 // One workgroup: the bookkeeping of a level, on the device so that the host never has to look
-// between levels -- node count, chunks per node, chunk -> node table, neutral statistics, and an
-// empty next level.  Grids are launched at capacity; blocks beyond hdr[] exit at once.
-__global__ __launch_bounds__(1024) void lv_setup_kernel(LvArgs L) {
-  __shared__ int wsum[16];
-  __shared__ int run_sh;
+// between levels -- node count, chunks per node, chunk -> node table and an empty level after it.
+// Grids are launched at capacity; blocks beyond hdr[] exit at once.  Run by lv_setup_kernel for the first level and by
+// the LAST block of lv_final_kernel for every later one (no launch of its own).  TBS threads (a multiple of 64).
+template <int TBS>
+__device__ __forceinline__ void lv_setup_body(const LvArgs &L, const BuildItem *items, const int32_t *count, int32_t *empty_count,
+                                              int *wsum /* [TBS / 64] */, int *run_sh) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int n_nodes = *L.cur_count;
+  int n_nodes = __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (n_nodes > L.cap_nodes) {
     if (tid == 0) L.A.ctl->overflow = 3;
     n_nodes = 0;
   }
-  if (tid == 0) run_sh = 0;
+  if (tid == 0) *run_sh = 0;
   __syncthreads();
-  for (int base = 0; base < n_nodes; base += 1024) {
+  for (int base = 0; base < n_nodes; base += TBS) {
     const int j = base + tid;
     int nch = 0;
     if (j < n_nodes) {
-      const BuildItem it = L.items[j];
-      nch = (it.r - it.l + LV_CH - 1) / LV_CH;
-      LvStat st{};
-      for (int d = 0; d < 3; ++d) { st.mn[d] = INT32_MAX; st.mx[d] = INT32_MIN; }
-      st.lmax = INT32_MIN;
-      st.rmin = INT32_MAX;
-      L.stat[j] = st;
+      const int32_t l = __hip_atomic_load(&items[j].l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int32_t r = __hip_atomic_load(&items[j].r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      nch = (r - l + LV_CH - 1) / LV_CH;
     }
     int x = nch;
 #pragma unroll
@@ -1001,14 +1012,14 @@ __global__ __launch_bounds__(1024) void lv_setup_kernel(LvArgs L) {
     }
     if (lane == 63) wsum[wave] = x;
     __syncthreads();
-    int before = run_sh;
+    int before = *run_sh;
     for (int w = 0; w < wave; ++w) before += wsum[w];
     if (j < n_nodes) L.chunk_first_w[j] = before + x - nch;
     __syncthreads();
-    if (tid == 1023) run_sh = before + x;
+    if (tid == TBS - 1) *run_sh = before + x;
     __syncthreads();
   }
-  int n_chunks = run_sh;
+  int n_chunks = *run_sh;
   if (n_chunks > L.cap_chunks) {
     if (tid == 0) L.A.ctl->overflow = 3;
     n_chunks = 0;
@@ -1016,7 +1027,7 @@ __global__ __launch_bounds__(1024) void lv_setup_kernel(LvArgs L) {
   }
   __threadfence_block();
   __syncthreads();
-  for (int c = tid; c < n_chunks; c += 1024) {  // last node whose first chunk is <= c
+  for (int c = tid; c < n_chunks; c += TBS) {  // last node whose first chunk is <= c
     int lo = 0, hi = n_nodes - 1;
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
@@ -1027,53 +1038,15 @@ __global__ __launch_bounds__(1024) void lv_setup_kernel(LvArgs L) {
   if (tid == 0) {
     L.hdr[0] = n_nodes;
     L.hdr[1] = n_chunks;
-    *L.next_count = 0;
+    *empty_count = 0;
+    *L.final_done = 0;
   }
 }
 
-__global__ __launch_bounds__(LV_TB) void lv_minmax_kernel(LvArgs L) {
-  LV_PROLOGUE
-  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  // a chunk is LV_CH / LV_TB = 16 points per thread: all loads issued before the first use (a rolled
-  // loop pays one memory round trip per point)
-  float4 pv[LV_CH / LV_TB];
-#pragma unroll
-  for (int u = 0; u < LV_CH / LV_TB; ++u) {
-    const int i = c0 + threadIdx.x + u * LV_TB;
-    pv[u] = L.A.pts[l + (i < c1 ? i : c0)];
-  }
-#pragma unroll
-  for (int u = 0; u < LV_CH / LV_TB; ++u) {
-    if (c0 + (int)threadIdx.x + u * LV_TB >= c1) continue;
-    const float4 p = pv[u];
-    mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
-    mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
-    mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
-  }
-  // one set of atomics per chunk, and only where the chunk improves on what the node already has: at
-  // the top levels every chunk of the launch belongs to one or two nodes, and a thousand atomics on one
-  // cache line are tens of microseconds
-  __shared__ float sh[6][LV_TB / 64];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const float a = wave_min(mn[d]), b = wave_max(mx[d]);
-    if ((threadIdx.x & 63) == 0) {
-      sh[d][threadIdx.x >> 6] = a;
-      sh[3 + d][threadIdx.x >> 6] = b;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    const int d = threadIdx.x;
-    float v = sh[d][0];
-#pragma unroll
-    for (int w = 1; w < LV_TB / 64; ++w) v = d < 3 ? fminf(v, sh[d][w]) : fmaxf(v, sh[d][w]);
-    const int32_t o = ord_i(v);
-    int32_t *dst = d < 3 ? &L.stat[node].mn[d] : &L.stat[node].mx[d - 3];
-    const int32_t cur = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (d < 3) { if (o < cur) atomicMin(dst, o); }
-    else       { if (o > cur) atomicMax(dst, o); }
-  }
+__global__ __launch_bounds__(1024) void lv_setup_kernel(LvArgs L) {
+  __shared__ int wsum[16];
+  __shared__ int run_sh;
+  lv_setup_body<1024>(L, L.items, L.cur_count, L.next_count, wsum, &run_sh);
 }
 
 // middleSplit_ (:982-1031) from the node's extrema: evaluated identically by every block of the node
@@ -1111,10 +1084,20 @@ __global__ __launch_bounds__(LV_TB) void lv_count_kernel(LvArgs L) {
     L.stat[node].cut = cut;
   }
   int a = 0, b = 0;
-  for (int i = c0 + threadIdx.x; i < c1; i += LV_TB) {
-    const float x = coord(L.A.pts[l + i], feat);
-    a += x < cut;
-    b += x <= cut;
+  {  // a chunk is LV_CH / LV_TB = 16 points per thread: all loads issued before the first use (a rolled loop pays one
+     // memory round trip per point: this kernel was 22 us at the top levels)
+    float xv[LV_CH / LV_TB];
+#pragma unroll
+    for (int u = 0; u < LV_CH / LV_TB; ++u) {
+      const int i = c0 + threadIdx.x + u * LV_TB;
+      xv[u] = coord(L.A.pts[l + (i < c1 ? i : c0)], feat);
+    }
+#pragma unroll
+    for (int u = 0; u < LV_CH / LV_TB; ++u) {
+      if (c0 + (int)threadIdx.x + u * LV_TB >= c1) continue;
+      a += xv[u] < cut;
+      b += xv[u] <= cut;
+    }
   }
   a = wave_sum_i(a);
   b = wave_sum_i(b);
@@ -1232,52 +1215,169 @@ __global__ __launch_bounds__(LV_TB) void lv_hswap_kernel(LvArgs L, int p) {
   }
 }
 
+// The SECOND Hoare pass of planeSplit (:1062-1076: the elements equal to the cut value move to the front of the right part) as
+// ONE launch: a workgroup per node.  Almost always there is nothing to do -- no element equals the cut, or all of the right
+// part does -- and the three launches the first pass needs (flags, ranks, swaps) were three empty launches per level; a node
+// that does have such elements is processed here chunk after chunk by its one workgroup (same flags, same ranks, same pairing:
+// the k-th misplaced element from the left with the k-th from the right), which is slow only for degenerate clouds.
+__global__ __launch_bounds__(LV_TB) void lv_pass2_kernel(LvArgs L) {
+  const int node = blockIdx.x;
+  if (node >= L.hdr[0]) return;
+  const BuildItem it = L.items[node];
+  const int n = it.r - it.l, l = it.l;
+  const LvStat st = L.stat[node];
+  int pa, Lc;
+  lv_region(st, 1, &pa, &Lc);
+  if (Lc == 0 || Lc == n - pa) return;  // nothing belongs left, or everything does: no pairs
+  __shared__ int sh[LV_TB / 64];
+  __shared__ int run[3];
+  const int first = L.chunk_first[node], nch = (n + LV_CH - 1) / LV_CH;
+  const int ch0 = pa / LV_CH;  // chunks before the region hold nothing of it
+  for (int c = ch0; c < nch; ++c) {  // per-chunk counts
+    unsigned mL, mR;
+    lv_flags(L, l, n, c * LV_CH, st.feat, st.cut, 1, pa, Lc, &mL, &mR);
+    int tL, tR;
+    lv_scan(__popc(mL), sh, &tL);
+    lv_scan(__popc(mR), sh, &tR);
+    if (threadIdx.x == 0) {
+      L.cntL[first + c] = tL;
+      L.cntR[first + c] = tR;
+    }
+  }
+  __syncthreads();
+  int tot = 0, totR = 0;
+  for (int c = ch0 + (int)threadIdx.x; c < nch; c += LV_TB) { tot += L.cntL[first + c]; totR += L.cntR[first + c]; }
+  int m, mr;
+  lv_scan(tot, sh, &m);
+  lv_scan(totR, sh, &mr);
+  if (threadIdx.x == 0) L.stat[node].m[1] = m;
+  if (m == 0) return;
+  if (threadIdx.x == 0) { run[0] = 0; run[1] = mr; }
+  __syncthreads();
+  for (int c = ch0; c < nch; ++c) {  // ranks: misplaced-left elements of the chunks before, wanted-left elements of the chunks after
+    const int cl = L.cntL[first + c], cr = L.cntR[first + c];
+    const int baseL = run[0], baseR = run[1] - cr;
+    unsigned mL, mR;
+    lv_flags(L, l, n, c * LV_CH, st.feat, st.cut, 1, pa, Lc, &mL, &mR);
+    int tL, tR;
+    const int eL = lv_scan(__popc(mL), sh, &tL);
+    const int eR = lv_scan(__popc(mR), sh, &tR);
+    const int i0 = c * LV_CH + threadIdx.x * LV_PER;
+    int posL = baseL + eL;
+    int after = tR - eR;
+#pragma unroll
+    for (int u = 0; u < LV_PER; ++u) {
+      if (mL & (1u << u)) L.A.tmpA[l + posL++] = i0 + u;
+      if (mR & (1u << u)) {
+        --after;
+        L.A.tmpB[l + baseR + after] = i0 + u;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { run[0] = baseL + cl; run[1] = baseR; }
+    __syncthreads();
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int k = threadIdx.x; k < m; k += LV_TB) {
+    const int i = l + L.A.tmpA[l + k], j = l + L.A.tmpB[l + k];
+    const float4 t = L.A.pts[i];
+    L.A.pts[i] = L.A.pts[j];
+    L.A.pts[j] = t;
+  }
+}
+
 __device__ __forceinline__ int lv_index(const LvStat &st, int n) {  // :1024-1029
   const int half = n / 2;
   return st.lim1 > half ? st.lim1 : (st.lim2 < half ? st.lim2 : half);
 }
 
+// divlow / divhigh (:966-971) and, in the same pass over the node's points, the coordinate extrema of its two children:
+// what the next level's middleSplit_ needs (the min / max pass every level used to start with).
 __global__ __launch_bounds__(LV_TB) void lv_bounds_kernel(LvArgs L) {
   LV_PROLOGUE
   const LvStat st = L.stat[node];
   const int index = lv_index(st, n);
-  float lmax = -FLT_MAX, rmin = FLT_MAX;
-  float xv[LV_CH / LV_TB];
+  float4 pv[LV_CH / LV_TB];
 #pragma unroll
   for (int u = 0; u < LV_CH / LV_TB; ++u) {
     const int i = c0 + threadIdx.x + u * LV_TB;
-    xv[u] = coord(L.A.pts[l + (i < c1 ? i : c0)], st.feat);
+    pv[u] = L.A.pts[l + (i < c1 ? i : c0)];
   }
+  // a chunk straddles the children's border at most once: side 0 = left child
+  float mn[2][3], mx[2][3];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { mn[c][d] = FLT_MAX; mx[c][d] = -FLT_MAX; }
 #pragma unroll
   for (int u = 0; u < LV_CH / LV_TB; ++u) {
     const int i = c0 + threadIdx.x + u * LV_TB;
     if (i >= c1) continue;
-    if (i < index) lmax = fmaxf(lmax, xv[u]); else rmin = fminf(rmin, xv[u]);
+    const float4 p = pv[u];
+    const bool right = i >= index;
+    mn[0][0] = right ? mn[0][0] : fminf(mn[0][0], p.x); mx[0][0] = right ? mx[0][0] : fmaxf(mx[0][0], p.x);
+    mn[0][1] = right ? mn[0][1] : fminf(mn[0][1], p.y); mx[0][1] = right ? mx[0][1] : fmaxf(mx[0][1], p.y);
+    mn[0][2] = right ? mn[0][2] : fminf(mn[0][2], p.z); mx[0][2] = right ? mx[0][2] : fmaxf(mx[0][2], p.z);
+    mn[1][0] = right ? fminf(mn[1][0], p.x) : mn[1][0]; mx[1][0] = right ? fmaxf(mx[1][0], p.x) : mx[1][0];
+    mn[1][1] = right ? fminf(mn[1][1], p.y) : mn[1][1]; mx[1][1] = right ? fmaxf(mx[1][1], p.y) : mx[1][1];
+    mn[1][2] = right ? fminf(mn[1][2], p.z) : mn[1][2]; mx[1][2] = right ? fmaxf(mx[1][2], p.z) : mx[1][2];
   }
-  lmax = wave_max(lmax);
-  rmin = wave_min(rmin);
-  __shared__ float shb[2][LV_TB / 64];
-  if ((threadIdx.x & 63) == 0) {
-    shb[0][threadIdx.x >> 6] = lmax;
-    shb[1][threadIdx.x >> 6] = rmin;
-  }
-  __syncthreads();
-  if (threadIdx.x < 2) {  // one pair of atomics per chunk, skipped where the chunk does not improve the bound
-    float v = shb[threadIdx.x][0];
+  __shared__ float shb[12][LV_TB / 64];
 #pragma unroll
-    for (int w = 1; w < LV_TB / 64; ++w) v = threadIdx.x == 0 ? fmaxf(v, shb[0][w]) : fminf(v, shb[1][w]);
-    const int32_t o = ord_i(v);
-    int32_t *dst = threadIdx.x == 0 ? &L.stat[node].lmax : &L.stat[node].rmin;
-    const int32_t cur = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x == 0) { if (o > cur) atomicMax(dst, o); }
-    else                  { if (o < cur) atomicMin(dst, o); }
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float a = wave_min(mn[c][d]), b = wave_max(mx[c][d]);
+      if ((threadIdx.x & 63) == 0) {
+        shb[c * 3 + d][threadIdx.x >> 6] = a;
+        shb[6 + c * 3 + d][threadIdx.x >> 6] = b;
+      }
+    }
+  __syncthreads();
+  if (threadIdx.x < 12) {  // one set of atomics per chunk, and only where the chunk improves on what the node already has
+    const int k = threadIdx.x;
+    const bool is_max = k >= 6;
+    float v = shb[k][0];
+#pragma unroll
+    for (int w = 1; w < LV_TB / 64; ++w) v = is_max ? fmaxf(v, shb[k][w]) : fminf(v, shb[k][w]);
+    const int c = (k % 6) / 3, d = k % 3;
+    if (is_max ? v > -FLT_MAX : v < FLT_MAX) {  // the chunk holds points of that child
+      const int32_t o = ord_i(v);
+      int32_t *dst = is_max ? &L.stat[node].cmx[c][d] : &L.stat[node].cmn[c][d];
+      const int32_t cur = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (is_max) { if (o > cur) atomicMax(dst, o); }
+      else        { if (o < cur) atomicMin(dst, o); }
+      // the tight bounds of the split (:966-971) are the children's extrema along the split dimension: the left child's
+      // maximum and the right child's minimum
+      if (d == st.feat && ((is_max && c == 0) || (!is_max && c == 1))) {
+        int32_t *bd = is_max ? &L.stat[node].lmax : &L.stat[node].rmin;
+        const int32_t cb = __hip_atomic_load(bd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (is_max) { if (o > cb) atomicMax(bd, o); }
+        else        { if (o < cb) atomicMin(bd, o); }
+      }
+    }
   }
 }
 
 // one thread per node: the node record and its two children (what lane 0 of process_node does)
-__global__ void lv_final_kernel(LvArgs L) {
+__device__ __forceinline__ void lv_final_node(const LvArgs &L, int node);
+__global__ __launch_bounds__(64) void lv_final_kernel(LvArgs L) {
   const int node = blockIdx.x * blockDim.x + threadIdx.x;
-  if (node >= L.hdr[0]) return;
+  if (node < L.hdr[0]) lv_final_node(L, node);
+  // The last block to get here sets up the next level (what lv_setup_kernel did in a launch of its own): the children that
+  // stay in phase 0 were appended with device-scope atomics and their ranges written through to the coherence point.
+  __shared__ int last, wsum[1], run_sh;
+  __builtin_amdgcn_s_waitcnt(0);
+  if (threadIdx.x == 0) {
+    const int ticket = __hip_atomic_fetch_add(L.final_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = ticket == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  lv_setup_body<64>(L, L.next_items, L.next_count, const_cast<int32_t *>(L.cur_count), wsum, &run_sh);
+}
+__device__ __forceinline__ void lv_final_node(const LvArgs &L, int node) {
   const BuildArgs &A = L.A;
   const BuildItem it = L.items[node];
   const LvStat st = L.stat[node];
@@ -1309,7 +1409,18 @@ __global__ void lv_final_kernel(LvArgs L) {
     const int cn = cr - cl;
     if (cn > HUGE_MIN) {
       const int e = atomicAdd(L.next_count, 1);
-      if (e < L.next_cap) L.next_items[e] = ch; else A.ctl->overflow = 3;
+      if (e < L.next_cap) {
+        L.next_items[e] = ch;
+        // (the range once more, written through: the block that sets up the next level may sit on another XCD)
+        __hip_atomic_store(&L.next_items[e].l, ch.l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&L.next_items[e].r, ch.r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        LvStat cs;
+        for (int d = 0; d < 3; ++d) { cs.mn[d] = st.cmn[c][d]; cs.mx[d] = st.cmx[c][d]; }
+        lv_stat_reset(cs);
+        L.stat_next[e] = cs;
+      } else {
+        A.ctl->overflow = 3;
+      }
     } else if (cn > LOCAL_MAX) {
       const int e = atomicAdd(&A.ctl->q_tail_reserved, 1);
       if (e >= A.queue_cap) { A.ctl->overflow = 3; continue; }
@@ -1479,24 +1590,37 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
   const int cap_nodes = n / HUGE_MIN * 2 + n_first + 8, cap_chunks = n / LV_CH + cap_nodes + 8;
   const size_t sz_items = (size_t)cap_nodes * sizeof(BuildItem), sz_stat = (size_t)cap_nodes * sizeof(LvStat),
                sz_ci = (size_t)cap_chunks * sizeof(int32_t), sz_ni = (size_t)cap_nodes * sizeof(int32_t);
-  if ((e = pool_get(stream, true, 2 * sz_items + sz_stat + 5 * sz_ci + sz_ni + 64, &lv_blob)) != hipSuccess) return e;
+  if ((e = pool_get(stream, true, 2 * sz_items + 2 * sz_stat + 5 * sz_ci + sz_ni + 64, &lv_blob)) != hipSuccess) return e;
   char *q = static_cast<char *>(lv_blob);
   BuildItem *d_items[2];
   d_items[0] = reinterpret_cast<BuildItem *>(q); q += sz_items;
   d_items[1] = reinterpret_cast<BuildItem *>(q); q += sz_items;
-  LvStat *d_stat = reinterpret_cast<LvStat *>(q); q += sz_stat;
+  LvStat *d_stat[2];
+  d_stat[0] = reinterpret_cast<LvStat *>(q); q += sz_stat;
+  d_stat[1] = reinterpret_cast<LvStat *>(q); q += sz_stat;
   int32_t *d_chunk_node = reinterpret_cast<int32_t *>(q); q += sz_ci;
   int32_t *d_cntL = reinterpret_cast<int32_t *>(q); q += sz_ci;
   int32_t *d_cntR = reinterpret_cast<int32_t *>(q); q += sz_ci;
   int32_t *d_baseL = reinterpret_cast<int32_t *>(q); q += sz_ci;
   int32_t *d_baseR = reinterpret_cast<int32_t *>(q); q += sz_ci;
   int32_t *d_chunk_first = reinterpret_cast<int32_t *>(q); q += sz_ni;
-  int32_t *d_small = reinterpret_cast<int32_t *>(q);  // [0],[1] item counts (ping-pong), [2],[3] level header
+  int32_t *d_small = reinterpret_cast<int32_t *>(q);  // [0],[1] item counts (ping-pong), [2],[3] level header, [4] lv_final's tickets
   if (n_first > cap_nodes) { *fallback = 3; return hipSuccess; }
-  const int32_t init[4] = {n_first, 0, 0, 0};
+  const int32_t init[8] = {n_first, 0, 0, 0, 0, 0, 0, 0};
+  // a root's extrema are its bounding box (kd_bbox_kernel / kd_bbox_seg_kernel computed exactly that)
+  std::vector<LvStat> stat0((size_t)n_first);
+  for (int j = 0; j < n_first; ++j) {
+    for (int d = 0; d < 3; ++d) {
+      const int32_t a = __builtin_bit_cast(int32_t, level[(size_t)j].lo[d]), b = __builtin_bit_cast(int32_t, level[(size_t)j].hi[d]);
+      stat0[(size_t)j].mn[d] = a >= 0 ? a : a ^ 0x7FFFFFFF;
+      stat0[(size_t)j].mx[d] = b >= 0 ? b : b ^ 0x7FFFFFFF;
+    }
+    lv_stat_reset(stat0[(size_t)j]);
+  }
+  // (pageable sources: consumed when hipMemcpyAsync returns, no wait needed)
   if ((e = hipMemcpyAsync(d_items[0], level.data(), (size_t)n_first * sizeof(BuildItem), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(d_stat[0], stat0.data(), (size_t)n_first * sizeof(LvStat), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(d_small, init, sizeof(init), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;  // host buffers are the caller's
   // Levels are enqueued in batches without looking at their outcome (grids at capacity, exhausted
   // levels cost a handful of empty launches); the host checks the item count once per batch.
   const dim3 gc(cap_chunks), gn((cap_nodes + 63) / 64), bt(LV_TB);
@@ -1508,7 +1632,9 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
       L.A = A;
       L.items = d_items[lvl & 1];
       L.next_items = d_items[(lvl + 1) & 1];
-      L.stat = d_stat;
+      L.stat = d_stat[lvl & 1];
+      L.stat_next = d_stat[(lvl + 1) & 1];
+      L.final_done = d_small + 4;
       L.chunk_node = d_chunk_node;
       L.chunk_first = d_chunk_first;
       L.chunk_node_w = d_chunk_node;
@@ -1520,14 +1646,14 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
       L.cap_nodes = cap_nodes;
       L.cap_chunks = cap_chunks;
       L.next_cap = cap_nodes;
-      hipLaunchKernelGGL(lv_setup_kernel, dim3(1), dim3(1024), 0, stream, L);
-      hipLaunchKernelGGL(lv_minmax_kernel, gc, bt, 0, stream, L);
+      // seven launches per level (eleven until round 3): the extrema come from the parent's bounds pass, the second Hoare
+      // pass is one launch, the next level is set up by lv_final_kernel's last block
+      if (lvl == 0) hipLaunchKernelGGL(lv_setup_kernel, dim3(1), dim3(1024), 0, stream, L);
       hipLaunchKernelGGL(lv_count_kernel, gc, bt, 0, stream, L);
-      for (int pass = 0; pass < 2; ++pass) {
-        hipLaunchKernelGGL(lv_hflags_kernel, gc, bt, 0, stream, L, pass);
-        hipLaunchKernelGGL(lv_hwrite_kernel, gc, bt, 0, stream, L, pass);
-        hipLaunchKernelGGL(lv_hswap_kernel, gc, bt, 0, stream, L, pass);
-      }
+      hipLaunchKernelGGL(lv_hflags_kernel, gc, bt, 0, stream, L, 0);
+      hipLaunchKernelGGL(lv_hwrite_kernel, gc, bt, 0, stream, L, 0);
+      hipLaunchKernelGGL(lv_hswap_kernel, gc, bt, 0, stream, L, 0);
+      hipLaunchKernelGGL(lv_pass2_kernel, dim3(cap_nodes), bt, 0, stream, L);
       hipLaunchKernelGGL(lv_bounds_kernel, gc, bt, 0, stream, L);
       hipLaunchKernelGGL(lv_final_kernel, gn, dim3(64), 0, stream, L);
     }
@@ -1546,7 +1672,7 @@ static int32_t reg_nodes_enabled() {
   return off ? 0 : 1;
 }
 
-hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, PNode *d_pn, int32_t node_cap,
+hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, float *d_own_box, int32_t node_cap,
                                hipStream_t stream, TreeView *view, int *depth, size_t *n_leaves,
                                int *fallback) {
   const bool dbg = std::getenv("LSLAM_DEBUG") != nullptr;
@@ -1554,7 +1680,7 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, PNode 
   const double T0 = now();
   *fallback = 0;
   view->nodes = d_nodes;
-  view->pn = d_pn;
+  view->pn = nullptr;  // the packet search's nodes are made from d_own_box when somebody asks for that search (build_packet_nodes)
   view->pts = d_pts;
   view->n_pts = n;
   view->n_nodes = 0;
@@ -1608,9 +1734,8 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, PNode 
   void *blob = nullptr;
   A.sub_cap = sub_cap;
   const size_t sz_queue = (size_t)queue_cap * sizeof(BuildItem), sz_ready = (size_t)queue_cap * sizeof(int32_t),
-               sz_tmp = (size_t)n * sizeof(int32_t), sz_ctl = 256, sz_sub = (size_t)sub_cap * sizeof(BuildItem),
-               sz_own = d_pn ? (size_t)A.node_cap * 6 * sizeof(float) : 0;
-  if ((e = pool_get(stream, false, sz_queue + sz_sub + sz_ready + 2 * sz_tmp + sz_ctl + sz_own, &blob)) != hipSuccess) return e;
+               sz_tmp = (size_t)n * sizeof(int32_t), sz_ctl = 256, sz_sub = (size_t)sub_cap * sizeof(BuildItem);
+  if ((e = pool_get(stream, false, sz_queue + sz_sub + sz_ready + 2 * sz_tmp + sz_ctl, &blob)) != hipSuccess) return e;
   char *p = static_cast<char *>(blob);
   A.queue = reinterpret_cast<BuildItem *>(p); p += sz_queue;
   A.sublist = reinterpret_cast<BuildItem *>(p); p += sz_sub;
@@ -1618,7 +1743,7 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, PNode 
   A.tmpA = reinterpret_cast<int32_t *>(p); p += sz_tmp;
   A.tmpB = reinterpret_cast<int32_t *>(p); p += sz_tmp;
   A.ctl = reinterpret_cast<BuildCtl *>(p); p += sz_ctl;
-  A.own_box = d_pn ? reinterpret_cast<float *>(p) : nullptr;
+  A.own_box = d_own_box;
   A.root_feat = &A.ctl->root_feat;
   if ((e = hipMemsetAsync(A.q_ready, 0, sz_ready, stream)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(d_nodes, 0, (size_t)A.node_cap * sizeof(KdNode), stream)) != hipSuccess) return e;
@@ -1675,11 +1800,6 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, PNode 
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(&ctl, A.ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
   if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-  if (d_pn && !ctl.overflow) {  // packet-search nodes of the slots in use (stays enqueued behind the build)
-    const int n_slots = std::min(ctl.next_group * 8, A.node_cap);
-    hipLaunchKernelGGL(kd_pnode_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, stream, d_nodes, n_slots, d_pts, A.own_box, d_pn);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-  }
   const double T3 = now();
   if (dbg)
     fprintf(stderr, "[lslam] tree build n=%d: bbox %.2f ms, setup %.2f ms, build kernel %.2f ms, free %.2f ms (overflow %d, groups %d)\n",
@@ -1693,6 +1813,16 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, PNode 
   *depth = ctl.max_depth;
   *n_leaves = (size_t)ctl.n_leaves;
   return hipSuccess;
+}
+
+// The packet search's nodes (lslam_packet.hpp) of a built tree, from the own boxes its build recorded: made on demand -- the
+// packet search is an explicit choice (it measured slower than the lane search) and a map rebuilt every frame
+// should not pay 64 B per node and a launch for it.
+hipError_t build_packet_nodes(const TreeView &view, const float *d_own_box, PNode *d_pn, hipStream_t stream) {
+  if (view.n_nodes <= 0) return hipSuccess;
+  hipLaunchKernelGGL(kd_pnode_kernel, dim3((view.n_nodes + 255) / 256), dim3(256), 0, stream, view.nodes, view.n_nodes, view.pts,
+                     d_own_box, d_pn);
+  return hipGetLastError();
 }
 
 // Many trees at once (variant C: one tree per map cube): `roots_lr` holds T point ranges of d_pts

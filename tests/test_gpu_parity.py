@@ -74,7 +74,7 @@ def _tree_dump(ctx, which, n_pts):
     lib.lslam_debug_tree_dump.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_size_t,
                                           C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_uint32),
                                           C.POINTER(C.c_int32)]
-    cap = 2 * n_pts // 3 + 128
+    cap = 3 * n_pts + 128  # node slots are taken in groups of eight, the subtrees of at most 64 points get five groups each up front
     nodes = np.zeros((cap, 4), np.uint32)
     pts = np.zeros((max(1, n_pts), 4), np.float32)
     root, nn = C.c_uint32(), C.c_int32()
@@ -891,7 +891,7 @@ def test_tree_build_retries_with_more_node_slots(pkg, oracle, monkeypatch):
     tree that results is still nanoflann's."""
     rng = np.random.default_rng(3)
     pts = rng.uniform(-30, 30, (30000, 3)).astype(np.float32)
-    monkeypatch.setenv("LSLAM_DEBUG_NODE_CAP_DIV", "16")  # every attempt gets a sixteenth of its slots: the first cannot fit
+    monkeypatch.setenv("LSLAM_DEBUG_NODE_CAP_DIV", "8")  # every attempt gets an eighth of its slots (n/3, 2n/3, n): the first cannot fit
     c = _fresh_ctx(pkg)
     try:
         c.map_set(pts, pts)

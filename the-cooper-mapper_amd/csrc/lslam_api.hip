@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <set>
 #include <string>
@@ -81,6 +83,56 @@ struct DevTree {
   int cap_attempt = 0;  // node-slot multiplier that last fitted this tree (device build)
 };
 
+// A helper thread that lives as long as its context: the corner tree of a map is built from it while the calling thread
+// builds the surf tree.  (A std::thread per lslam_map_set cost ~100 us before its first launch -- creation plus the HIP
+// runtime's per-thread set-up -- and with the level phase at seven launches per level the corner tree, started that late, had
+// become the end of the build.)
+struct Worker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool has_job = false, busy = false, quit = false;
+  void start() {
+    if (th.joinable()) return;
+    th = std::thread([this] {
+      std::unique_lock<std::mutex> lk(mu);
+      for (;;) {
+        cv.wait(lk, [this] { return has_job || quit; });
+        if (quit) return;
+        std::function<void()> f = std::move(job);
+        has_job = false;
+        lk.unlock();
+        f();
+        lk.lock();
+        busy = false;
+        cv.notify_all();
+      }
+    });
+  }
+  void submit(std::function<void()> f) {
+    start();
+    std::lock_guard<std::mutex> lk(mu);
+    job = std::move(f);
+    has_job = true;
+    busy = true;
+    cv.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [this] { return !busy; });
+  }
+  void stop() {
+    if (!th.joinable()) return;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+      cv.notify_all();
+    }
+    th.join();
+  }
+};
+
 struct HostSinCos {
   void operator()(float a, float &s, float &c) const {
     s = std::sin(a);  // util/Angle.h:17-18 std::sin/std::cos(float)
@@ -95,6 +147,7 @@ struct lslam_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // the corner tree is built beside the surf tree
   ScanPrep *scanprep = nullptr;
+  Worker worker;  // builds the corner tree beside the surf tree
   int cube_sides_on_device = 0;  // cube-map sides built by the device forest builder (of the last set)
   DevTree tc, ts;
   // variant C: per-cube trees (shared node/point arrays in tc/ts, one TreeView per cube)
@@ -392,6 +445,7 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
     std::lock_guard<std::mutex> lk(g_live_mu);
     g_live.erase(ctx);
   }
+  ctx->worker.stop();
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   ctx->tc.nodes.release(); ctx->tc.pts.release(); ctx->tc.pn.release(); ctx->tc.own_box.release();
@@ -609,9 +663,9 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
       *ncount[k] = (size_t)dt.view.n_nodes / 8 * 7 + n_leaves;  // approximate node count
     };
     {
-      std::thread th(build_one, 0, ctx->stream2);
+      ctx->worker.submit([&] { build_one(0, ctx->stream2); });
       build_one(1, ctx->stream);
-      th.join();
+      ctx->worker.wait();
     }
     for (int k = 0; k < 2; ++k) {
       HIP_TRY(errs[k]);

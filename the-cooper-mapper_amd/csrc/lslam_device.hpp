@@ -18,6 +18,9 @@ namespace lslam {
 #ifndef LSLAM_BRANCHY_LEAF
 #define LSLAM_BRANCHY_LEAF 0  // 1: the per-candidate `if (dist < worst) insert` form (A/B switch)
 #endif
+#ifndef LSLAM_LEAF_COMPACT
+#define LSLAM_LEAF_COMPACT 0  // 1: accept test on all ten slots, sorted insert for the accepted ones only (A/B switch, see knn5_search)
+#endif
 // (a lane loading only the points its leaf holds -- exec-masked loads -- measured SLOWER, 0.475 against 0.448 ms per
 // 2.6 M-point launch: the vector memory pipe is paid per wave-instruction, not per active lane)
 
@@ -285,7 +288,40 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
       float4 pt[10];
 #pragma unroll
       for (int j = 0; j < 10; ++j) pt[j] = T.pts[l + j];
-#if LSLAM_BRANCHY_LEAF
+#if LSLAM_LEAF_COMPACT
+      // A/B switch (round 3): the cheap accept test on all ten slots first, then the sorted insert only for the ACCEPTED
+      // candidates -- a lane accepts 5-8 of the ~44 candidates it is offered in a sweep, the straight-line form below pays
+      // the 19-operation insert for all 44.  The accepted slots are taken in slot order (lowest set bit first: the order
+      // nanoflann's loop offers them in, so ties resolve the same way); a round of the loop costs the insert plus the
+      // extraction of the slot's distance from ten registers by a select tree (a lane cannot index registers), and the
+      // wavefront runs as many rounds as its busiest lane has accepted candidates in this leaf.
+      {
+        float dist[10];
+        unsigned acc = 0;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+          dist[j] = dist2_xyz(qx, qy, qz, pt[j]);
+          acc |= (j < cnt && dist[j] < worst) ? (1u << j) : 0u;
+        }
+#ifdef LSLAM_TRAVERSAL_STATS
+        ts.n_cand += __popc(acc);
+        ts.n_hit += acc ? 1 : 0;
+#endif
+        while (__builtin_amdgcn_ballot_w64(acc != 0u) != 0ull) {
+          const int j = acc ? __builtin_ctz(acc) : 0;
+          // select tree over the bits of j
+          const bool b0 = (j & 1) != 0, b1 = (j & 2) != 0, b2 = (j & 4) != 0, b3 = (j & 8) != 0;
+          const float s01 = b0 ? dist[1] : dist[0], s23 = b0 ? dist[3] : dist[2], s45 = b0 ? dist[5] : dist[4],
+                      s67 = b0 ? dist[7] : dist[6], s89 = b0 ? dist[9] : dist[8];
+          const float s03 = b1 ? s23 : s01, s47 = b1 ? s67 : s45;
+          const float s07 = b2 ? s47 : s03;
+          const float sx = b3 ? s89 : s07;
+          const float x = acc ? sx : FLT_MAX;  // a lane with nothing left offers FLT_MAX: changes nothing
+          knn_insert_sorted(d, p, x, l + j);
+          acc &= acc - 1u;
+        }
+      }
+#elif LSLAM_BRANCHY_LEAF
 #pragma unroll
       for (int j = 0; j < 10; ++j) {
         if (j < cnt) {

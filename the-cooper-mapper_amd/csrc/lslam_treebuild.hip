@@ -61,6 +61,7 @@ struct BuildItem {   // one pending inner node
   int32_t parent_word;  // index (in 32-bit words of the node array) of the reference to this
                         // node in its parent, -1 for the root: the node ORs its divfeat there
   int32_t depth;
+  int32_t g0, g1;       // phase C entries: node groups [g0, g1) reserved for the subtree by the wavefront that handed it on
 };
 
 struct BuildCtl {
@@ -89,6 +90,9 @@ struct BuildArgs {
   int32_t n;
   int32_t reg_nodes;   // 1: nodes of at most 64 points are finished in registers (phase B)
   uint32_t spin_limit; // watchdog of idle phase-A workgroups (polls of ~2 x 127 sleep units)
+  int32_t *tiny_acc;    // [TINY_ACC][32]: {leaves, max depth} of phase C, spread over cache lines
+  BuildItem *tiny_list; // (or null) phase C work list: nodes of at most 64 points that phase B hands on instead of finishing
+  int32_t tiny_cap;
   float *own_box;      // [node_cap][6] (or null): tight bounding box {min xyz, max xyz} of every inner node's points --
                        // the extrema middleSplit_ needs anyway; the packet search's node boxes are made from them
 };
@@ -527,6 +531,158 @@ struct SmallItem {
   int32_t slot, heap, parent_word, depth;
 };
 
+constexpr int TINY_ACC = 64;     // cache lines the phase-C wavefronts' leaf counts / depths are spread over
+// A node of at most 64 points and its whole subtree, in registers: one point per lane (px, py, pz, pw; lanes >= n idle).
+// The subtree is built a LEVEL at a time: the nodes of a level are disjoint lane ranges ("segments"), and every step of
+// divideTree / middleSplit_ / planeSplit is done for all of them at once -- segmented DPP scans for the extents, ballots
+// masked to the segment for the counts and for the ranks of the Hoare pairing, lane permutes for the swaps.  Same splits,
+// same final order of the points as a node-at-a-time loop.  `base` = index of lane 0's point in the point array (leaf
+// references); ta / tb: 64 LDS slots each of the calling wavefront (a workgroup is one wavefront).  Used by phase B
+// in place (LSLAM_TINY_PHASE=0) and by kd_build_tiny_kernel, which spreads these subtrees over the whole chip.
+__device__ __forceinline__ void build_reg_subtree(const BuildArgs &A, const int lane, const int n, const int base, float &px,
+                                                  float &py, float &pz, uint32_t &pw, float lo0, float lo1, float lo2, float hi0,
+                                                  float hi1, float hi2, int slot, int heap, int pword, int depth, int &grp_next,
+                                                  int &grp_end, int &n_leaves, int &reg_depth, uint16_t *ta, uint16_t *tb) {
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int sa = 0, sb = n;  // my segment [sa, sb), in lanes
+  bool act = lane < n;
+  if (!act) { sa = lane; sb = lane + 1; }
+    bool top = true;  // the segment is the popped node: its parent stored a reference already
+    const unsigned long long gt_mask = lane == 63 ? 0ull : (~0ull << (lane + 1));
+    while (__any(act)) {
+      const int ns = sb - sa;
+      // computeMinMax (:908-920): inclusive segmented scans, the segment's last lane has the result
+      const float mnx = seg_scan<false>(px, lane, sa), mny = seg_scan<false>(py, lane, sa),
+                  mnz = seg_scan<false>(pz, lane, sa);
+      const float mxx = seg_scan<true>(px, lane, sa), mxy = seg_scan<true>(py, lane, sa),
+                  mxz = seg_scan<true>(pz, lane, sa);
+      const int last = sb - 1;
+      const float en0 = __shfl(mnx, last, 64), en1 = __shfl(mny, last, 64), en2 = __shfl(mnz, last, 64);
+      const float ex0 = __shfl(mxx, last, 64), ex1 = __shfl(mxy, last, 64), ex2 = __shfl(mxz, last, 64);
+      // middleSplit_ (:982-1031)
+      const float EPS = 0.00001f;
+      const float sp0 = hi0 - lo0, sp1 = hi1 - lo1, sp2 = hi2 - lo2;
+      float max_span = sp0;
+      if (sp1 > max_span) max_span = sp1;
+      if (sp2 > max_span) max_span = sp2;
+      float max_spread = -1;
+      int feat = 0;
+      if (sp0 > (1 - EPS) * max_span) { const float spread = ex0 - en0; if (spread > max_spread) { feat = 0; max_spread = spread; } }
+      if (sp1 > (1 - EPS) * max_span) { const float spread = ex1 - en1; if (spread > max_spread) { feat = 1; max_spread = spread; } }
+      if (sp2 > (1 - EPS) * max_span) { const float spread = ex2 - en2; if (spread > max_spread) { feat = 2; max_spread = spread; } }
+      const float flo = feat == 0 ? lo0 : (feat == 1 ? lo1 : lo2);
+      const float fhi = feat == 0 ? hi0 : (feat == 1 ? hi1 : hi2);
+      const float fmn = feat == 0 ? en0 : (feat == 1 ? en1 : en2);
+      const float fmx = feat == 0 ? ex0 : (feat == 1 ? ex1 : ex2);
+      const float split_val = (flo + fhi) / 2;
+      const float cut = split_val < fmn ? fmn : (split_val > fmx ? fmx : split_val);
+      float x = feat == 0 ? px : (feat == 1 ? py : pz);
+      const unsigned long long segmask = (sb >= 64 ? ~0ull : ((1ull << sb) - 1)) & ~((1ull << sa) - 1);
+      const int lim1 = __popcll(__ballot(act && x < cut) & segmask);
+      const int lim2 = __popcll(__ballot(act && x <= cut) & segmask);
+      // planeSplit (:1043-1078): two Hoare passes; the k-th misplaced element of the left part
+      // (increasing index) changes places with the k-th misplaced of the right part (decreasing)
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int pa = pass == 0 ? sa : sa + lim1, Lc = pass == 0 ? lim1 : lim2 - lim1;
+        const bool go = act && Lc > 0 && sb - pa - Lc > 0;
+        const bool below = pass == 0 ? (x < cut) : (x <= cut);
+        const bool misl = go && lane >= pa && lane < pa + Lc && !below;
+        const bool misr = go && lane >= pa + Lc && below;
+        const unsigned long long bl = __ballot(misl), br = __ballot(misr);
+        if ((bl | br) == 0) continue;  // wave-uniform
+        const int kl = __popcll(bl & segmask & lt_mask), kr = __popcll(br & segmask & gt_mask);
+        if (misl) ta[sa + kl] = (uint16_t)lane;
+        if (misr) tb[sa + kr] = (uint16_t)lane;
+        __syncthreads();
+        int partner = lane;
+        if (misl) partner = tb[sa + kl];
+        if (misr) partner = ta[sa + kr];
+        __syncthreads();
+        px = __shfl(px, partner, 64);
+        py = __shfl(py, partner, 64);
+        pz = __shfl(pz, partner, 64);
+        pw = (uint32_t)__shfl((int)pw, partner, 64);
+        x = feat == 0 ? px : (feat == 1 ? py : pz);
+      }
+      const int half = ns / 2;
+      const int index = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);  // :1024-1029
+      const int mid = sa + index;
+      // tight bounds of the halves along the split dimension (:966-971): max of the left
+      // child's lanes, min (= -max of the negated values) of the right child's
+      const bool left = lane < mid;
+      const int csa = left ? sa : mid;
+      const float v = seg_scan<true>(left ? x : -x, lane, csa);
+      const float divlow = __shfl(v, mid - 1, 64), divhigh = -__shfl(v, last, 64);
+      // children: leaves (:936-951) or the segments of the next level
+      const int cntL = index, cntR = ns - index;
+      const bool leafL = cntL <= 10, leafR = cntR <= 10;
+      const bool leader = act && lane == sa;
+      const bool needL = leader && heap >= 3 && !leafL, needR = leader && heap >= 3 && !leafR;
+      const unsigned long long mL = __ballot(needL), mR = __ballot(needR);
+      const int total = __popcll(mL) + __popcll(mR);
+      if (total > grp_end - grp_next) {  // wave-uniform
+        const int take = total > 8 ? total : 8;
+        int g = 0;
+        if (lane == 0) g = atomicAdd(&A.ctl->next_group, take);
+        g = __shfl(g, 0, 64);
+        grp_next = g;
+        grp_end = g + take;
+      }
+      int gL = grp_next + __popcll(mL & lt_mask) + __popcll(mR & lt_mask);
+      int gR = gL + (needL ? 1 : 0);
+      gL = __shfl(gL, sa, 64);  // every lane of the segment takes its leader's numbers
+      gR = __shfl(gR, sa, 64);
+      grp_next += total;
+      int slotL, heapL, slotR, heapR;
+      if (heap < 3) {  // the children stay in this 8-slot group
+        heapL = 2 * heap + 1; slotL = slot - heap + heapL;
+        heapR = 2 * heap + 2; slotR = slot - heap + heapR;
+      } else {
+        heapL = 0; slotL = gL * 8;
+        heapR = 0; slotR = gR * 8;
+        if (!leafL && (gL + 1) * 8 > A.node_cap) { if (leader) A.ctl->overflow = 1; slotL = 0; }
+        if (!leafR && (gR + 1) * 8 > A.node_cap) { if (leader) A.ctl->overflow = 1; slotR = 0; }
+      }
+      if (leader) {
+        uint32_t *words = reinterpret_cast<uint32_t *>(A.nodes);
+        // my reference in the parent: the popped node's parent holds (slot << 2) already and gets
+        // the split dimension ORed in (as below); deeper levels write the whole word -- the parent
+        // (this wave, a level ago) left the words of its non-leaf children untouched
+        if (top) {
+          if (pword >= 0) atomicOr(reinterpret_cast<unsigned int *>(words) + pword, (unsigned int)feat);
+          else A.root_feat[-1 - pword] = feat;
+        } else {
+          words[pword] = ((uint32_t)slot << 2) | (uint32_t)feat;
+        }
+        float *fw = reinterpret_cast<float *>(words + (size_t)slot * 4);
+        fw[0] = divlow;
+        fw[1] = divhigh;
+        store_own_box(A, slot, en0, en1, en2, ex0, ex1, ex2);
+        if (leafL) words[(size_t)slot * 4 + 2] = KD_LEAF | ((uint32_t)(base + sa) << 4) | (uint32_t)cntL;
+        if (leafR) words[(size_t)slot * 4 + 3] = KD_LEAF | ((uint32_t)(base + mid) << 4) | (uint32_t)cntR;
+        if (leafL || leafR) reg_depth = max(reg_depth, depth + 1);
+      }
+      n_leaves += __popcll(__ballot(leader && leafL)) + __popcll(__ballot(leader && leafR));
+      if (act) {
+        pword = slot * 4 + (left ? 2 : 3);
+        if (left) {
+          sb = mid;
+          if (feat == 0) hi0 = cut; else if (feat == 1) hi1 = cut; else hi2 = cut;
+          slot = slotL; heap = heapL;
+          if (leafL) act = false;
+        } else {
+          sa = mid;
+          if (feat == 0) lo0 = cut; else if (feat == 1) lo1 = cut; else lo2 = cut;
+          slot = slotR; heap = heapR;
+          if (leafR) act = false;
+        }
+        depth += 1;
+      }
+      top = false;
+    }
+}
+
 __global__ __launch_bounds__(64) void kd_build_small_kernel(BuildArgs A) {
   __shared__ float sx[LOCAL_MAX], sy[LOCAL_MAX], sz[LOCAL_MAX];
   __shared__ uint32_t sw[LOCAL_MAX];
@@ -577,148 +733,44 @@ __global__ __launch_bounds__(64) void kd_build_small_kernel(BuildArgs A) {
         // permutes for the swaps.  Same splits, same final order of the points as the
         // node-at-a-time loop below (which costs ~3.5 us per node in dependent LDS round trips;
         // three quarters of a subtree's nodes have fewer than 64 points).
-        int sa = 0, sb = n;  // my segment [sa, sb), in lanes
-        bool act = lane < n;
-        if (!act) { sa = lane; sb = lane + 1; }
-        const int li = a + (act ? lane : 0);
-        float px = sx[li], py = sy[li], pz = sz[li];
-        uint32_t pw = sw[li];
-        float lo0 = it.lo[0], lo1 = it.lo[1], lo2 = it.lo[2], hi0 = it.hi[0], hi1 = it.hi[1], hi2 = it.hi[2];
-        int slot = it.slot, heap = it.heap, pword = it.parent_word, depth = it.depth;
-        bool top = true;  // the segment is the popped node: its parent stored a reference already
-        const unsigned long long gt_mask = lane == 63 ? 0ull : (~0ull << (lane + 1));
-        while (__any(act)) {
-          const int ns = sb - sa;
-          // computeMinMax (:908-920): inclusive segmented scans, the segment's last lane has the result
-          const float mnx = seg_scan<false>(px, lane, sa), mny = seg_scan<false>(py, lane, sa),
-                      mnz = seg_scan<false>(pz, lane, sa);
-          const float mxx = seg_scan<true>(px, lane, sa), mxy = seg_scan<true>(py, lane, sa),
-                      mxz = seg_scan<true>(pz, lane, sa);
-          const int last = sb - 1;
-          const float en0 = __shfl(mnx, last, 64), en1 = __shfl(mny, last, 64), en2 = __shfl(mnz, last, 64);
-          const float ex0 = __shfl(mxx, last, 64), ex1 = __shfl(mxy, last, 64), ex2 = __shfl(mxz, last, 64);
-          // middleSplit_ (:982-1031)
-          const float EPS = 0.00001f;
-          const float sp0 = hi0 - lo0, sp1 = hi1 - lo1, sp2 = hi2 - lo2;
-          float max_span = sp0;
-          if (sp1 > max_span) max_span = sp1;
-          if (sp2 > max_span) max_span = sp2;
-          float max_spread = -1;
-          int feat = 0;
-          if (sp0 > (1 - EPS) * max_span) { const float spread = ex0 - en0; if (spread > max_spread) { feat = 0; max_spread = spread; } }
-          if (sp1 > (1 - EPS) * max_span) { const float spread = ex1 - en1; if (spread > max_spread) { feat = 1; max_spread = spread; } }
-          if (sp2 > (1 - EPS) * max_span) { const float spread = ex2 - en2; if (spread > max_spread) { feat = 2; max_spread = spread; } }
-          const float flo = feat == 0 ? lo0 : (feat == 1 ? lo1 : lo2);
-          const float fhi = feat == 0 ? hi0 : (feat == 1 ? hi1 : hi2);
-          const float fmn = feat == 0 ? en0 : (feat == 1 ? en1 : en2);
-          const float fmx = feat == 0 ? ex0 : (feat == 1 ? ex1 : ex2);
-          const float split_val = (flo + fhi) / 2;
-          const float cut = split_val < fmn ? fmn : (split_val > fmx ? fmx : split_val);
-          float x = feat == 0 ? px : (feat == 1 ? py : pz);
-          const unsigned long long segmask = (sb >= 64 ? ~0ull : ((1ull << sb) - 1)) & ~((1ull << sa) - 1);
-          const int lim1 = __popcll(__ballot(act && x < cut) & segmask);
-          const int lim2 = __popcll(__ballot(act && x <= cut) & segmask);
-          // planeSplit (:1043-1078): two Hoare passes; the k-th misplaced element of the left part
-          // (increasing index) changes places with the k-th misplaced of the right part (decreasing)
-#pragma unroll
-          for (int pass = 0; pass < 2; ++pass) {
-            const int pa = pass == 0 ? sa : sa + lim1, Lc = pass == 0 ? lim1 : lim2 - lim1;
-            const bool go = act && Lc > 0 && sb - pa - Lc > 0;
-            const bool below = pass == 0 ? (x < cut) : (x <= cut);
-            const bool misl = go && lane >= pa && lane < pa + Lc && !below;
-            const bool misr = go && lane >= pa + Lc && below;
-            const unsigned long long bl = __ballot(misl), br = __ballot(misr);
-            if ((bl | br) == 0) continue;  // wave-uniform
-            const int kl = __popcll(bl & segmask & lt_mask), kr = __popcll(br & segmask & gt_mask);
-            if (misl) ta[sa + kl] = (uint16_t)lane;
-            if (misr) tb[sa + kr] = (uint16_t)lane;
-            __syncthreads();
-            int partner = lane;
-            if (misl) partner = tb[sa + kl];
-            if (misr) partner = ta[sa + kr];
-            __syncthreads();
-            px = __shfl(px, partner, 64);
-            py = __shfl(py, partner, 64);
-            pz = __shfl(pz, partner, 64);
-            pw = (uint32_t)__shfl((int)pw, partner, 64);
-            x = feat == 0 ? px : (feat == 1 ? py : pz);
-          }
-          const int half = ns / 2;
-          const int index = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);  // :1024-1029
-          const int mid = sa + index;
-          // tight bounds of the halves along the split dimension (:966-971): max of the left
-          // child's lanes, min (= -max of the negated values) of the right child's
-          const bool left = lane < mid;
-          const int csa = left ? sa : mid;
-          const float v = seg_scan<true>(left ? x : -x, lane, csa);
-          const float divlow = __shfl(v, mid - 1, 64), divhigh = -__shfl(v, last, 64);
-          // children: leaves (:936-951) or the segments of the next level
-          const int cntL = index, cntR = ns - index;
-          const bool leafL = cntL <= 10, leafR = cntR <= 10;
-          const bool leader = act && lane == sa;
-          const bool needL = leader && heap >= 3 && !leafL, needR = leader && heap >= 3 && !leafR;
-          const unsigned long long mL = __ballot(needL), mR = __ballot(needR);
-          const int total = __popcll(mL) + __popcll(mR);
-          if (total > grp_end - grp_next) {  // wave-uniform
-            const int take = total > 8 ? total : 8;
+        if (A.tiny_list) {  // handed to kd_build_tiny_kernel: one wavefront of the whole chip per such subtree instead of this one for all of its own
+          // its slot in the (zero-filled) list is its first point's index / 11: such subtrees are disjoint ranges of more
+          // than 10 points, so no two share a slot -- no counter, no atomics (9 000 of them on one address are 200 us)
+          // ... and it takes a few node groups with it out of this wavefront's batch (the batch is refilled 16 groups
+          // at a time: one atomic per ~5 subtrees; thousands of phase-C wavefronts allocating on their own were 200 us of
+          // atomics on one address); a subtree that needs more -- a degenerate one -- allocates the rest itself
+          const int want = 1 + n / 16;  // (wave-uniform) 64 points: 5 groups, 32: 3, 11: 1 -- the rest of what such a subtree needs sits in its parent's group
+          if (grp_end - grp_next < want) {
             int g = 0;
-            if (lane == 0) g = atomicAdd(&A.ctl->next_group, take);
+            if (lane == 0) g = atomicAdd(&A.ctl->next_group, 16);
             g = __shfl(g, 0, 64);
             grp_next = g;
-            grp_end = g + take;
+            grp_end = g + 16;
           }
-          int gL = grp_next + __popcll(mL & lt_mask) + __popcll(mR & lt_mask);
-          int gR = gL + (needL ? 1 : 0);
-          gL = __shfl(gL, sa, 64);  // every lane of the segment takes its leader's numbers
-          gR = __shfl(gR, sa, 64);
-          grp_next += total;
-          int slotL, heapL, slotR, heapR;
-          if (heap < 3) {  // the children stay in this 8-slot group
-            heapL = 2 * heap + 1; slotL = slot - heap + heapL;
-            heapR = 2 * heap + 2; slotR = slot - heap + heapR;
-          } else {
-            heapL = 0; slotL = gL * 8;
-            heapR = 0; slotR = gR * 8;
-            if (!leafL && (gL + 1) * 8 > A.node_cap) { if (leader) A.ctl->overflow = 1; slotL = 0; }
-            if (!leafR && (gR + 1) * 8 > A.node_cap) { if (leader) A.ctl->overflow = 1; slotR = 0; }
-          }
-          if (leader) {
-            uint32_t *words = reinterpret_cast<uint32_t *>(A.nodes);
-            // my reference in the parent: the popped node's parent holds (slot << 2) already and gets
-            // the split dimension ORed in (as below); deeper levels write the whole word -- the parent
-            // (this wave, a level ago) left the words of its non-leaf children untouched
-            if (top) {
-              if (pword >= 0) atomicOr(reinterpret_cast<unsigned int *>(words) + pword, (unsigned int)feat);
-              else A.root_feat[-1 - pword] = feat;
+          const int tg0 = grp_next;
+          grp_next += want;
+          if (lane == 0) {
+            const int e = (L0 + a) / 11;
+            if (e < A.tiny_cap && (tg0 + want) * 8 <= A.node_cap) {
+              BuildItem t;
+              t.g0 = tg0; t.g1 = tg0 + want;
+              t.l = L0 + a; t.r = L0 + a + n;
+              for (int d = 0; d < 3; ++d) { t.lo[d] = it.lo[d]; t.hi[d] = it.hi[d]; }
+              t.slot = it.slot; t.heap = it.heap; t.parent_word = it.parent_word; t.depth = it.depth;
+              A.tiny_list[e] = t;
             } else {
-              words[pword] = ((uint32_t)slot << 2) | (uint32_t)feat;
+              A.ctl->overflow = e < A.tiny_cap ? 1 : 3;  // 1: the node array is too small (retried with more slots)
             }
-            float *fw = reinterpret_cast<float *>(words + (size_t)slot * 4);
-            fw[0] = divlow;
-            fw[1] = divhigh;
-            store_own_box(A, slot, en0, en1, en2, ex0, ex1, ex2);
-            if (leafL) words[(size_t)slot * 4 + 2] = KD_LEAF | ((uint32_t)(L0 + a + sa) << 4) | (uint32_t)cntL;
-            if (leafR) words[(size_t)slot * 4 + 3] = KD_LEAF | ((uint32_t)(L0 + a + mid) << 4) | (uint32_t)cntR;
-            if (leafL || leafR) reg_depth = max(reg_depth, depth + 1);
           }
-          n_leaves += __popcll(__ballot(leader && leafL)) + __popcll(__ballot(leader && leafR));
-          if (act) {
-            pword = slot * 4 + (left ? 2 : 3);
-            if (left) {
-              sb = mid;
-              if (feat == 0) hi0 = cut; else if (feat == 1) hi1 = cut; else hi2 = cut;
-              slot = slotL; heap = heapL;
-              if (leafL) act = false;
-            } else {
-              sa = mid;
-              if (feat == 0) lo0 = cut; else if (feat == 1) lo1 = cut; else lo2 = cut;
-              slot = slotR; heap = heapR;
-              if (leafR) act = false;
-            }
-            depth += 1;
-          }
-          top = false;
+          __syncthreads();
+          continue;
         }
+        const bool act0 = lane < n;
+        const int li = a + (act0 ? lane : 0);
+        float px = sx[li], py = sy[li], pz = sz[li];
+        uint32_t pw = sw[li];
+        build_reg_subtree(A, lane, n, L0 + a, px, py, pz, pw, it.lo[0], it.lo[1], it.lo[2], it.hi[0], it.hi[1], it.hi[2], it.slot, it.heap,
+                          it.parent_word, it.depth, grp_next, grp_end, n_leaves, reg_depth, ta, tb);
         if (lane < n) { sx[a + lane] = px; sy[a + lane] = py; sz[a + lane] = pz; sw[a + lane] = pw; }
         __syncthreads();
         continue;
@@ -887,6 +939,49 @@ __global__ __launch_bounds__(64) void kd_build_small_kernel(BuildArgs A) {
   if (lane == 0) {
     if (n_leaves) atomicAdd(&A.ctl->n_leaves, n_leaves);
     atomicMax(&A.ctl->max_depth, md);
+  }
+}
+
+// Phase C: the subtrees of at most 64 points -- three quarters of all nodes, and until round 3 two thirds of phase B's time,
+// where each wavefront finished the ~30 such subtrees of its own 1 536-point subtree one after the other (~9 us each): here every
+// one of them gets a wavefront of its own, the whole list spread over the chip (wavefront w takes entries w, w + G, ...: no
+// shared counter).  The points come from and go back to HBM (64 x 16 B per subtree).
+constexpr int TINY_SLOTS = 8;
+__global__ __launch_bounds__(64) void kd_build_tiny_kernel(BuildArgs A) {
+  __shared__ uint16_t ta[64], tb[64];
+  const int lane = threadIdx.x;
+  int grp_next = 0, grp_end = 0, n_leaves = 0, reg_depth = 0;
+  // the list is sparse (slot = first point / 11, an unused slot is all zero; about one slot in six is used): a wavefront
+  // looks at TINY_SLOTS slots at a time -- one or two subtrees each, so that the list spreads over ~6 000 wavefronts
+  for (int s0 = blockIdx.x * TINY_SLOTS; s0 < A.tiny_cap; s0 += gridDim.x * TINY_SLOTS) {
+    const int sidx = s0 + lane;
+    const bool have = lane < TINY_SLOTS && sidx < A.tiny_cap && A.tiny_list[sidx].r > A.tiny_list[sidx].l;
+    unsigned long long todo = __ballot(have);
+    while (todo) {
+      const int k = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const BuildItem it = A.tiny_list[s0 + k];
+      const int n = it.r - it.l;
+      grp_next = it.g0;
+      grp_end = it.g1;
+      const float4 p = A.pts[it.l + (lane < n ? lane : 0)];
+      float px = p.x, py = p.y, pz = p.z;
+      uint32_t pw = __float_as_uint(p.w);
+      build_reg_subtree(A, lane, n, it.l, px, py, pz, pw, it.lo[0], it.lo[1], it.lo[2], it.hi[0], it.hi[1], it.hi[2], it.slot, it.heap,
+                        it.parent_word, it.depth, grp_next, grp_end, n_leaves, reg_depth, ta, tb);
+      if (lane < n) A.pts[it.l + lane] = make_float4(px, py, pz, __uint_as_float(pw));
+      __syncthreads();
+    }
+  }
+  int md = reg_depth;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) md = max(md, __shfl_xor(md, o, 64));
+  if (lane == 0) {
+    // thousands of wavefronts end here: their two counters are spread over TINY_ACC cache lines (13 000 atomics on ONE
+    // address were most of this kernel's time), summed by the host
+    int32_t *acc = A.tiny_acc + (blockIdx.x % TINY_ACC) * 32;
+    if (n_leaves) atomicAdd(acc, n_leaves);
+    if (md) atomicMax(acc + 1, md);
   }
 }
 
@@ -1476,6 +1571,58 @@ __global__ __launch_bounds__(256) void kd_bbox_kernel(const float4 *pts, int n, 
   }
 }
 
+// The root of a single tree, made on the device from kd_bbox_kernel's partial boxes: control block, root item -- into the
+// first level's tables (mode 0), the phase-A queue (1) or the phase-B list (2) -- and the box itself for the host, which
+// reads it back with the control block when the build is over.  (Until round 3 the host fetched the box, built the root
+// and uploaded four small buffers: a stream wait and five copies at the head of every build.)
+struct RootInit {
+  const float *part;   // [used][6] partial boxes
+  int32_t used;
+  int32_t mode;        // 0: first level of phase 0, 1: phase-A queue, 2: phase-B list
+  float *bbox_out;     // [6]
+  BuildItem *lv_item;  // mode 0: items[0], stat[0], the levels' small counters
+  LvStat *lv_stat;
+  int32_t *lv_small;
+};
+__global__ __launch_bounds__(64) void kd_root_kernel(BuildArgs A, RootInit R) {
+  const int lane = threadIdx.x;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int k = lane; k < R.used; k += 64)
+    for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], R.part[k * 6 + d]); mx[d] = fmaxf(mx[d], R.part[k * 6 + 3 + d]); }
+  float lo[3], hi[3];
+  for (int d = 0; d < 3; ++d) { lo[d] = wave_min(mn[d]); hi[d] = wave_max(mx[d]); }
+  if (lane != 0) return;
+  BuildCtl c{};
+  c.q_head = 0;
+  c.q_tail_reserved = R.mode == 1 ? 1 : 0;
+  c.q_pending = R.mode == 1 ? 1 : 0;
+  c.next_group = 1;  // group 0 holds the root
+  c.n_sub = R.mode == 2 ? 1 : 0;
+  *A.ctl = c;
+  BuildItem root{};
+  root.l = 0;
+  root.r = A.n;
+  for (int d = 0; d < 3; ++d) { root.lo[d] = lo[d]; root.hi[d] = hi[d]; R.bbox_out[d] = lo[d]; R.bbox_out[3 + d] = hi[d]; }
+  root.slot = 0;
+  root.heap = 0;
+  root.parent_word = -1;
+  root.depth = 1;
+  if (R.mode == 0) {
+    *R.lv_item = root;
+    LvStat st;
+    for (int d = 0; d < 3; ++d) { st.mn[d] = ord_i(lo[d]); st.mx[d] = ord_i(hi[d]); }  // a root's extrema are its box
+    lv_stat_reset(st);
+    *R.lv_stat = st;
+    R.lv_small[0] = 1;
+    for (int k = 1; k < 8; ++k) R.lv_small[k] = 0;
+  } else if (R.mode == 1) {
+    A.queue[0] = root;
+    A.q_ready[0] = 1;
+  } else {
+    A.sublist[0] = root;
+  }
+}
+
 // one workgroup per root: bounding box of its own point range (computeBoundingBox, :1406-1427)
 __global__ __launch_bounds__(256) void kd_bbox_seg_kernel(const float4 *pts, const int32_t *roots_lr, float *out) {
   __shared__ float smin[3][4], smax[3][4];
@@ -1583,10 +1730,10 @@ void treebuild_release_scratch(hipStream_t s) {
 namespace {
 // Phase 0 driver: processes `level` (every entry more than HUGE_MIN points) and the levels it
 // spawns; smaller children land in A.queue / A.sublist.  n = points the trees span in total.
-hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t n, hipStream_t stream, int *fallback) {
+hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t n, hipStream_t stream, int *fallback, const RootInit *root_init = nullptr) {
   hipError_t e;
   void *lv_blob = nullptr;
-  const int n_first = (int)level.size();
+  const int n_first = root_init ? 1 : (int)level.size();
   const int cap_nodes = n / HUGE_MIN * 2 + n_first + 8, cap_chunks = n / LV_CH + cap_nodes + 8;
   const size_t sz_items = (size_t)cap_nodes * sizeof(BuildItem), sz_stat = (size_t)cap_nodes * sizeof(LvStat),
                sz_ci = (size_t)cap_chunks * sizeof(int32_t), sz_ni = (size_t)cap_nodes * sizeof(int32_t);
@@ -1607,8 +1754,17 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
   int32_t *d_small = reinterpret_cast<int32_t *>(q);  // [0],[1] item counts (ping-pong), [2],[3] level header, [4] lv_final's tickets
   if (n_first > cap_nodes) { *fallback = 3; return hipSuccess; }
   const int32_t init[8] = {n_first, 0, 0, 0, 0, 0, 0, 0};
+  if (root_init) {  // a single tree: the root is made on the device from its box (no host round trip)
+    RootInit R = *root_init;
+    R.mode = 0;
+    R.lv_item = d_items[0];
+    R.lv_stat = d_stat[0];
+    R.lv_small = d_small;
+    hipLaunchKernelGGL(kd_root_kernel, dim3(1), dim3(64), 0, stream, A, R);
+  }
   // a root's extrema are its bounding box (kd_bbox_kernel / kd_bbox_seg_kernel computed exactly that)
-  std::vector<LvStat> stat0((size_t)n_first);
+  std::vector<LvStat> stat0(root_init ? 0 : (size_t)n_first);
+  if (!root_init) {
   for (int j = 0; j < n_first; ++j) {
     for (int d = 0; d < 3; ++d) {
       const int32_t a = __builtin_bit_cast(int32_t, level[(size_t)j].lo[d]), b = __builtin_bit_cast(int32_t, level[(size_t)j].hi[d]);
@@ -1621,12 +1777,19 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
   if ((e = hipMemcpyAsync(d_items[0], level.data(), (size_t)n_first * sizeof(BuildItem), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(d_stat[0], stat0.data(), (size_t)n_first * sizeof(LvStat), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(d_small, init, sizeof(init), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+  }
   // Levels are enqueued in batches without looking at their outcome (grids at capacity, exhausted
   // levels cost a handful of empty launches); the host checks the item count once per batch.
   const dim3 gc(cap_chunks), gn((cap_nodes + 63) / 64), bt(LV_TB);
   int lvl = 0;
+  const bool dbg = std::getenv("LSLAM_DEBUG") != nullptr;
+  auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (int batch = 0; batch < 16; ++batch) {
-    const int per_batch = batch == 0 ? std::max(2, (int)std::ceil(std::log2(std::max(2.0, (double)n / HUGE_MIN))) + 1) : 3;
+    const double t_enq0 = now_us();
+    // nanoflann splits at the middle of the box, not at the median: the trees of a voxel map need ~4 levels more than a
+    // balanced one would (13 for the 587 k-point surface cloud) -- an exhausted level costs seven empty launches (~25 us), a
+    // second batch a host round trip on top of its levels
+    const int per_batch = batch == 0 ? std::max(2, (int)std::ceil(std::log2(std::max(2.0, (double)n / HUGE_MIN))) + 4) : 3;
     for (int k = 0; k < per_batch; ++k, ++lvl) {
       LvArgs L{};
       L.A = A;
@@ -1658,8 +1821,11 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
       hipLaunchKernelGGL(lv_final_kernel, gn, dim3(64), 0, stream, L);
     }
     int32_t remaining = 0;
+    const double t_enq1 = now_us();
     if ((e = hipMemcpyAsync(&remaining, d_small + (lvl & 1), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    if (dbg) fprintf(stderr, "[lslam] levels batch %d: %d levels enqueued in %.0f us (host), device done %.0f us later\n", batch, per_batch,
+                     t_enq1 - t_enq0, now_us() - t_enq1);
     if (remaining == 0) return hipSuccess;
   }
   *fallback = 3;  // 50+ levels above the wavefront-local size: deeper than the traversal stack allows anyway
@@ -1667,6 +1833,10 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
 }
 }  // namespace
 
+static bool tiny_phase_enabled() {
+  static const bool off = std::getenv("LSLAM_TINY_PHASE") && std::atoi(std::getenv("LSLAM_TINY_PHASE")) == 0;  // A/B switch
+  return !off;
+}
 static int32_t reg_nodes_enabled() {
   static const bool off = std::getenv("LSLAM_NO_REG_NODES") != nullptr;  // A/B switch
   return off ? 0 : 1;
@@ -1700,15 +1870,17 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, float 
     d_part = static_cast<float *>(bp.part);
   }
   hipLaunchKernelGGL(kd_bbox_kernel, dim3(NB), dim3(256), 0, stream, d_pts, n, d_part);
-  float h_part[NB * 6];
-  if ((e = hipMemcpyAsync(h_part, d_part, sizeof(h_part), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
   const int used = std::min(NB, (n + 255) / 256);
-  for (int d = 0; d < 3; ++d) {
-    float a = h_part[d], b = h_part[3 + d];
-    for (int k = 1; k < used; ++k) { a = std::min(a, h_part[k * 6 + d]); b = std::max(b, h_part[k * 6 + 3 + d]); }
-    view->bb_lo[d] = a;
-    view->bb_hi[d] = b;
+  if (n <= 10) {  // the root is a leaf: only the box is needed
+    float h_part[NB * 6];
+    if ((e = hipMemcpyAsync(h_part, d_part, sizeof(float) * 6 * (size_t)used, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    for (int d = 0; d < 3; ++d) {
+      float a = h_part[d], b = h_part[3 + d];
+      for (int k = 1; k < used; ++k) { a = std::min(a, h_part[k * 6 + d]); b = std::max(b, h_part[k * 6 + 3 + d]); }
+      view->bb_lo[d] = a;
+      view->bb_hi[d] = b;
+    }
   }
   const double T1 = now();
   if (n <= 10) {  // the root is a leaf
@@ -1735,7 +1907,10 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, float 
   A.sub_cap = sub_cap;
   const size_t sz_queue = (size_t)queue_cap * sizeof(BuildItem), sz_ready = (size_t)queue_cap * sizeof(int32_t),
                sz_tmp = (size_t)n * sizeof(int32_t), sz_ctl = 256, sz_sub = (size_t)sub_cap * sizeof(BuildItem);
-  if ((e = pool_get(stream, false, sz_queue + sz_sub + sz_ready + 2 * sz_tmp + sz_ctl, &blob)) != hipSuccess) return e;
+  const bool tiny_phase = tiny_phase_enabled() && A.reg_nodes;
+  const int32_t tiny_cap = tiny_phase ? n / 11 + 2 : 0;
+  const size_t sz_tiny = tiny_phase ? ((size_t)tiny_cap * sizeof(BuildItem) + TINY_ACC * 128 + 127) & ~(size_t)127 : 0;
+  if ((e = pool_get(stream, false, sz_queue + sz_sub + sz_ready + 2 * sz_tmp + sz_ctl + sz_tiny + 128, &blob)) != hipSuccess) return e;
   char *p = static_cast<char *>(blob);
   A.queue = reinterpret_cast<BuildItem *>(p); p += sz_queue;
   A.sublist = reinterpret_cast<BuildItem *>(p); p += sz_sub;
@@ -1743,49 +1918,36 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, float 
   A.tmpA = reinterpret_cast<int32_t *>(p); p += sz_tmp;
   A.tmpB = reinterpret_cast<int32_t *>(p); p += sz_tmp;
   A.ctl = reinterpret_cast<BuildCtl *>(p); p += sz_ctl;
+  p = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(p) + 127) & ~(uintptr_t)127);
+  A.tiny_acc = tiny_phase ? reinterpret_cast<int32_t *>(p) : nullptr;
+  A.tiny_list = tiny_phase ? reinterpret_cast<BuildItem *>(p + TINY_ACC * 128) : nullptr;
+  A.tiny_cap = tiny_cap;
+  if (tiny_phase && (e = hipMemsetAsync(p, 0, sz_tiny, stream)) != hipSuccess) return e;
   A.own_box = d_own_box;
   A.root_feat = &A.ctl->root_feat;
   if ((e = hipMemsetAsync(A.q_ready, 0, sz_ready, stream)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(d_nodes, 0, (size_t)A.node_cap * sizeof(KdNode), stream)) != hipSuccess) return e;
   BuildCtl ctl{};
-  ctl.q_head = 0;
-  ctl.q_tail_reserved = 1;
-  ctl.q_pending = 1;
-  ctl.next_group = 1;  // group 0 holds the root
-  BuildItem root{};
-  root.l = 0;
-  root.r = n;
-  for (int d = 0; d < 3; ++d) { root.lo[d] = view->bb_lo[d]; root.hi[d] = view->bb_hi[d]; }
-  root.slot = 0;
-  root.heap = 0;
-  root.parent_word = -1;
-  root.depth = 1;
-  const int32_t one = 1;
   const bool root_small = n <= LOCAL_MAX;
   static const bool no_levels = std::getenv("LSLAM_NO_LEVEL_BUILD") != nullptr;  // A/B switch
-  // Below ~50 k points the ~11 launches per level cost more host time than the persistent phase-A
+  // Below ~50 k points the launches of the level phase cost more host time than the persistent phase-A
   // kernel (one workgroup per node, one launch) costs device time: 0.49 against 0.62 ms at 16 k
   // points, equal at 64 k, 4.3 against 1.6 ms at 512 k (tools/tree_size_sweep.py).
   constexpr int LEVELS_MIN_POINTS = 49152;
   const bool root_huge = n > HUGE_MIN && n > LEVELS_MIN_POINTS && !no_levels;
-  if (root_small) {  // the whole tree is one phase-B subtree
-    ctl.q_tail_reserved = 0;
-    ctl.q_pending = 0;
-    ctl.n_sub = 1;
-  }
-  if (root_huge) {  // the root goes through phase 0; its descendants fill the queue
-    ctl.q_tail_reserved = 0;
-    ctl.q_pending = 0;
-  }
-  if ((e = hipMemcpyAsync(A.ctl, &ctl, sizeof(ctl), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-  if (!root_huge) {
-    if ((e = hipMemcpyAsync(root_small ? A.sublist : A.queue, &root, sizeof(root), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-    if ((e = hipMemcpyAsync(A.q_ready, &one, sizeof(one), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-  }
+  // control block, root item and the root's box are made on the device (kd_root_kernel): the box comes back with the control
+  // block at the end of the build
+  RootInit R{};
+  R.part = d_part;
+  R.used = used;
+  R.bbox_out = reinterpret_cast<float *>(reinterpret_cast<char *>(A.ctl) + 128);
   if (root_huge) {
     // ---- phase 0: level-synchronous processing of the nodes with more than HUGE_MIN points ----
-    if ((e = run_levels(A, std::vector<BuildItem>(1, root), n, stream, fallback)) != hipSuccess) return e;
+    if ((e = run_levels(A, std::vector<BuildItem>(), n, stream, fallback, &R)) != hipSuccess) return e;
     if (*fallback) return hipSuccess;
+  } else {
+    R.mode = root_small ? 2 : 1;  // the whole tree is one phase-B subtree / the root enters the phase-A queue
+    hipLaunchKernelGGL(kd_root_kernel, dim3(1), dim3(64), 0, stream, A, R);
   }
   // persistent grid: every workgroup must be resident (they wait on each other's output)
   int dev = 0, cus = 256;
@@ -1797,9 +1959,21 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, float 
   if (!root_small && !(root_huge && HUGE_MIN == LOCAL_MAX))
     hipLaunchKernelGGL(kd_build_big_kernel, dim3(cus), dim3(TB_BIG), 0, stream, A);
   hipLaunchKernelGGL(kd_build_small_kernel, dim3(cus * 16), dim3(TB_SMALL), 0, stream, A);
+  if (tiny_phase) hipLaunchKernelGGL(kd_build_tiny_kernel, dim3(std::min(cus * 64, (tiny_cap + TINY_SLOTS - 1) / TINY_SLOTS)), dim3(64), 0, stream, A);
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  if ((e = hipMemcpyAsync(&ctl, A.ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+  char ctl_blob[256];  // [BuildCtl | ... | box at byte 128]
+  if ((e = hipMemcpyAsync(ctl_blob, A.ctl, sizeof(ctl_blob), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+  int32_t acc[TINY_ACC * 32];
+  if (tiny_phase && (e = hipMemcpyAsync(acc, A.tiny_acc, sizeof(acc), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
   if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+  std::memcpy(&ctl, ctl_blob, sizeof(ctl));
+  {
+    float bb[6];
+    std::memcpy(bb, ctl_blob + 128, sizeof(bb));
+    for (int d = 0; d < 3; ++d) { view->bb_lo[d] = bb[d]; view->bb_hi[d] = bb[3 + d]; }
+  }
+  if (tiny_phase)
+    for (int k = 0; k < TINY_ACC; ++k) { ctl.n_leaves += acc[k * 32]; ctl.max_depth = std::max(ctl.max_depth, acc[k * 32 + 1]); }
   const double T3 = now();
   if (dbg)
     fprintf(stderr, "[lslam] tree build n=%d: bbox %.2f ms, setup %.2f ms, build kernel %.2f ms, free %.2f ms (overflow %d, groups %d)\n",
@@ -1851,8 +2025,11 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
                sz_tmp = (size_t)std::max(n_total, 1) * sizeof(int32_t), sz_ctl = 256, sz_sub = (size_t)sub_cap * sizeof(BuildItem),
                sz_rf = ((size_t)T * 4 + 15) & ~(size_t)15, sz_lr = ((size_t)T * 8 + 15) & ~(size_t)15,
                sz_bb = ((size_t)T * 24 + 15) & ~(size_t)15, sz_own = d_pn ? (size_t)A.node_cap * 6 * sizeof(float) : 0;
+  const bool tiny_phase = tiny_phase_enabled() && A.reg_nodes;
+  const int32_t tiny_cap = tiny_phase ? n_total / 11 + 2 : 0;
+  const size_t sz_tiny = tiny_phase ? ((size_t)tiny_cap * sizeof(BuildItem) + TINY_ACC * 128 + 127) & ~(size_t)127 : 0;
   void *blob = nullptr;
-  if ((e = pool_get(stream, false, sz_queue + sz_sub + sz_ready + 2 * sz_tmp + sz_ctl + sz_rf + sz_lr + sz_bb + sz_own, &blob)) != hipSuccess) return e;
+  if ((e = pool_get(stream, false, sz_queue + sz_sub + sz_ready + 2 * sz_tmp + sz_ctl + sz_rf + sz_lr + sz_bb + sz_tiny + sz_own + 128, &blob)) != hipSuccess) return e;
   char *p = static_cast<char *>(blob);
   A.queue = reinterpret_cast<BuildItem *>(p); p += sz_queue;
   A.sublist = reinterpret_cast<BuildItem *>(p); p += sz_sub;
@@ -1863,6 +2040,12 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   A.root_feat = reinterpret_cast<int32_t *>(p); p += sz_rf;
   int32_t *d_lr = reinterpret_cast<int32_t *>(p); p += sz_lr;
   float *d_bb = reinterpret_cast<float *>(p); p += sz_bb;
+  p = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(p) + 127) & ~(uintptr_t)127);
+  A.tiny_acc = tiny_phase ? reinterpret_cast<int32_t *>(p) : nullptr;
+  A.tiny_list = tiny_phase ? reinterpret_cast<BuildItem *>(p + TINY_ACC * 128) : nullptr;
+  A.tiny_cap = tiny_cap;
+  if (tiny_phase && (e = hipMemsetAsync(p, 0, sz_tiny, stream)) != hipSuccess) return e;
+  p += sz_tiny;
   A.own_box = d_pn ? reinterpret_cast<float *>(p) : nullptr;
   A.spin_limit = 1u << 22;
   if ((e = hipMemcpyAsync(d_lr, roots_lr, (size_t)T * 8, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
@@ -1922,11 +2105,16 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   hipLaunchKernelGGL(kd_build_small_kernel, dim3(cus * 16), dim3(TB_SMALL), 0, stream, A);
+  if (tiny_phase) hipLaunchKernelGGL(kd_build_tiny_kernel, dim3(std::min(cus * 64, (tiny_cap + TINY_SLOTS - 1) / TINY_SLOTS)), dim3(64), 0, stream, A);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   std::vector<int32_t> rf(T);
   if ((e = hipMemcpyAsync(&ctl, A.ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(rf.data(), A.root_feat, (size_t)T * 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+  int32_t acc[TINY_ACC * 32];
+  if (tiny_phase && (e = hipMemcpyAsync(acc, A.tiny_acc, sizeof(acc), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
   if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+  if (tiny_phase)
+    for (int k = 0; k < TINY_ACC; ++k) { ctl.n_leaves += acc[k * 32]; ctl.max_depth = std::max(ctl.max_depth, acc[k * 32 + 1]); }
   if (ctl.overflow) {
     *fallback = ctl.overflow;
     return hipSuccess;

@@ -1022,12 +1022,20 @@ __device__ __host__ inline void lv_stat_reset(LvStat &st) {  // everything but m
     for (int d = 0; d < 3; ++d) { st.cmn[c][d] = INT32_MAX; st.cmx[c][d] = INT32_MIN; }
 }
 
+// What a chunk's workgroup needs to know about its chunk, in ONE record written by the level's set-up (the passes of a level
+// are short kernels whose time is a chain of dependent loads: header -> chunk's node -> node's item -> node's statistics ->
+// points was five deep, record -> statistics -> points is three).  n == 0: no such chunk at this level.
+struct LvChunk {
+  int32_t node, l, n, c0, first, pad[3];
+};
+
 struct LvArgs {
   BuildArgs A;
   const BuildItem *items;    // nodes of this level
   LvStat *stat;              // [n_nodes]
   LvStat *stat_next;         // the next level's (filled by lv_final_kernel for the children that stay in phase 0)
   int32_t *final_done;       // lv_final_kernel's ticket counter: its last block sets up the next level
+  LvChunk *rec;              // [cap_chunks] the chunks of this level (lv_setup_body)
   const int32_t *chunk_node; // [n_chunks] node of a chunk
   const int32_t *chunk_first;// [n_nodes] first chunk of a node
   int32_t *cntL, *cntR, *baseL, *baseR;  // [n_chunks]
@@ -1068,11 +1076,11 @@ __device__ __forceinline__ int lv_scan(int v, int *sh /*[LV_TB/64]*/, int *total
 }
 
 #define LV_PROLOGUE                                                     \
-  if ((int)blockIdx.x >= L.hdr[1]) return;                              \
-  const int node = L.chunk_node[blockIdx.x];                            \
-  const BuildItem it = L.items[node];                                   \
-  const int n = it.r - it.l, l = it.l;                                  \
-  const int c0 = (blockIdx.x - L.chunk_first[node]) * LV_CH;            \
+  const LvChunk rc_ = L.rec[blockIdx.x];                                \
+  if (rc_.n == 0) return;                                               \
+  const int node = rc_.node;                                            \
+  const int n = rc_.n, l = rc_.l;                                       \
+  const int c0 = rc_.c0;                                                \
   const int c1 = min(n, c0 + LV_CH);                                    \
   (void)c1; (void)l;
 
@@ -1122,13 +1130,22 @@ __device__ __forceinline__ void lv_setup_body(const LvArgs &L, const BuildItem *
   }
   __threadfence_block();
   __syncthreads();
-  for (int c = tid; c < n_chunks; c += TBS) {  // last node whose first chunk is <= c
-    int lo = 0, hi = n_nodes - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (L.chunk_first_w[mid] <= c) lo = mid; else hi = mid - 1;
+  for (int c = tid; c < L.cap_chunks; c += TBS) {  // last node whose first chunk is <= c
+    LvChunk rc{};
+    if (c < n_chunks) {
+      int lo = 0, hi = n_nodes - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (L.chunk_first_w[mid] <= c) lo = mid; else hi = mid - 1;
+      }
+      L.chunk_node_w[c] = lo;
+      rc.node = lo;
+      rc.l = __hip_atomic_load(&items[lo].l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      rc.n = __hip_atomic_load(&items[lo].r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - rc.l;
+      rc.first = L.chunk_first_w[lo];
+      rc.c0 = (c - rc.first) * LV_CH;
     }
-    L.chunk_node_w[c] = lo;
+    L.rec[c] = rc;  // (n == 0 beyond the level's chunks: those workgroups leave at once)
   }
   if (tid == 0) {
     L.hdr[0] = n_nodes;
@@ -1167,6 +1184,7 @@ __device__ __forceinline__ void lv_split(const BuildItem &it, const LvStat &st, 
 
 __global__ __launch_bounds__(LV_TB) void lv_count_kernel(LvArgs L) {
   LV_PROLOGUE
+  const BuildItem it = L.items[node];
   int feat;
   float cut;
   lv_split(it, L.stat[node], &feat, &cut);
@@ -1264,7 +1282,7 @@ __global__ __launch_bounds__(LV_TB) void lv_hwrite_kernel(LvArgs L, int p) {
   __shared__ int sh[LV_TB / 64];
   // ranks of this chunk inside its node: misplaced-left elements of the chunks before it, wanted-left
   // elements of the chunks after it (the k-th from the RIGHT), and the node's total
-  const int first = L.chunk_first[node], nch = (n + LV_CH - 1) / LV_CH, mine = (int)blockIdx.x - first;
+  const int first = rc_.first, nch = (n + LV_CH - 1) / LV_CH, mine = (int)blockIdx.x - first;
   int bl = 0, br = 0, tot = 0;
   for (int c = threadIdx.x; c < nch; c += LV_TB) {
     const int vl = L.cntL[first + c], vr = L.cntR[first + c];
@@ -1737,7 +1755,7 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
   const int cap_nodes = n / HUGE_MIN * 2 + n_first + 8, cap_chunks = n / LV_CH + cap_nodes + 8;
   const size_t sz_items = (size_t)cap_nodes * sizeof(BuildItem), sz_stat = (size_t)cap_nodes * sizeof(LvStat),
                sz_ci = (size_t)cap_chunks * sizeof(int32_t), sz_ni = (size_t)cap_nodes * sizeof(int32_t);
-  if ((e = pool_get(stream, true, 2 * sz_items + 2 * sz_stat + 5 * sz_ci + sz_ni + 64, &lv_blob)) != hipSuccess) return e;
+  if ((e = pool_get(stream, true, 2 * sz_items + 2 * sz_stat + 5 * sz_ci + sz_ni + (size_t)cap_chunks * sizeof(LvChunk) + 128, &lv_blob)) != hipSuccess) return e;
   char *q = static_cast<char *>(lv_blob);
   BuildItem *d_items[2];
   d_items[0] = reinterpret_cast<BuildItem *>(q); q += sz_items;
@@ -1751,6 +1769,8 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
   int32_t *d_baseL = reinterpret_cast<int32_t *>(q); q += sz_ci;
   int32_t *d_baseR = reinterpret_cast<int32_t *>(q); q += sz_ci;
   int32_t *d_chunk_first = reinterpret_cast<int32_t *>(q); q += sz_ni;
+  q = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(q) + 31) & ~(uintptr_t)31);
+  LvChunk *d_rec = reinterpret_cast<LvChunk *>(q); q += (size_t)cap_chunks * sizeof(LvChunk);
   int32_t *d_small = reinterpret_cast<int32_t *>(q);  // [0],[1] item counts (ping-pong), [2],[3] level header, [4] lv_final's tickets
   if (n_first > cap_nodes) { *fallback = 3; return hipSuccess; }
   const int32_t init[8] = {n_first, 0, 0, 0, 0, 0, 0, 0};
@@ -1798,6 +1818,7 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
       L.stat = d_stat[lvl & 1];
       L.stat_next = d_stat[(lvl + 1) & 1];
       L.final_done = d_small + 4;
+      L.rec = d_rec;
       L.chunk_node = d_chunk_node;
       L.chunk_first = d_chunk_first;
       L.chunk_node_w = d_chunk_node;

@@ -422,6 +422,41 @@ def vlp16_throughput_leg(ctx, lidar, synth, dense, span, rank, world, args, opts
             "roofline": roof}
 
 
+def tree_build_roofline(ms, n_corner, n_surf, np):
+    """Roofline object of the kd-tree build of a mapping frame (surround -> both trees; ScanMatch.cpp:75-76 rebuilds them on
+    every call): SURVEY 8d prices it as M x 16 B x log2(M / 10) streamed per tree.  The build is a chain of short kernels
+    (seven per level of the big nodes, then the wavefront-local phases): what bounds it is the latency of that chain, and the
+    HBM fraction says how far from streaming it is.  `traffic`: the committed counter passes of tools/bench_treebuild.py
+    (tools/profile_treebuild.sh), per build, with the per-kernel breakdown."""
+    alg = sum(m * 16.0 * np.log2(m / 10.0) for m in (n_corner, n_surf) if m > 10)
+    t_s = ms * 1e-3
+    roof = {"kernel": "lv_count / lv_hflags / lv_hwrite / lv_hswap / lv_pass2 / lv_bounds / lv_final (levels), kd_build_small, kd_build_tiny",
+            "bound": "latency",
+            "bound_detail": "a chain of ~100 dependent short launches (5-15 us each: a kernel boundary on eight XCDs, then a few dependent "
+                            "loads) for the nodes above 1 536 points, then one wavefront per subtree: no bandwidth is near a limit",
+            "achieved": alg / t_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t_s / 1e9 / HBM_PEAK_GBS,
+            "alg_bytes_per_build": alg, "ms_per_build": ms, "points": [int(n_corner), int(n_surf)],
+            "accounting": "sum over both trees of M x 16 B x log2(M / 10) (SURVEY 8d) / wall time of lslam_fmap_surround_to_map "
+                          "(gather of the active cubes + both builds, median of the frames)",
+            "traffic": None}
+    prof = newest_profile("tree_pmc.csv")
+    if prof:
+        per = {}
+        for line in open(os.path.join(ROOT, prof)):
+            f = line.strip().split(",")
+            if len(f) >= 6 and not line.startswith("#") and f[0] != "pass" and f[2] in ("FETCH_SIZE", "WRITE_SIZE"):
+                k = per.setdefault(f[1], {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
+                k[f[2]] = float(f[5])
+        if per:
+            by_kernel = {k: (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for k, v in per.items()}
+            tot = sum(by_kernel.values())
+            roof["traffic"] = tot
+            roof["measured_hbm"] = {"bytes_per_build": tot, "achieved": tot / t_s / 1e9, "frac": tot / t_s / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
+                                    "bytes_per_build_by_kernel": {k: v for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1])},
+                                    "source": "%s: (2 x FETCH_SIZE + WRITE_SIZE) x 1024, summed over a build's launches; not measured in this run" % prof}
+    return roof
+
+
 def sweep_roofline(pt_res, sweep_ms, sweep_launches, map_points):
     """The roofline object of one timed region of sweep launches (the 64-ring headline, the 16-ring leg).
 
@@ -898,6 +933,7 @@ def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, 
            "scan_match_iterations": int(st.iterations),
            "pose_err_vs_ground_truth_m": float(np.abs(pose[3:] - gt[3:].astype(np.float32)).max())}
     if not cubes:
+        res["tree_build"] = tree_build_roofline(gpu["surround_to_map"], len(sur_c), len(sur_s), np)
         # The same frame the way the reference's nodelets run it: the registration node (feature extraction, the VoxelGrid of
         # the features) is its own thread with its own context, so its work on frame k overlaps the mapping node's
         # update + surround -> kd-trees of frame k (which depend on the map after frame k - 1 and on the pose prior only):

@@ -528,6 +528,18 @@ int lslam_pg_set_shard(lslam_pg *pg, int32_t e_begin, int32_t e_end, lslam_allre
 /* The same with the library's own RCCL communicator instead of a callback (NULL detaches). */
 int lslam_pg_set_comm(lslam_pg *pg, lslam_comm *comm);
 size_t lslam_pg_system_doubles(const lslam_pg *pg);
+/* ONE solve shared by the ranks (large graphs: the replicated solve above does not get faster with more GPUs).  Every rank also
+ * takes a range of vertex ROWS [v_begin, v_end) -- whole 21-vertex row blocks, lslam_pg_row_shard_range gives an even
+ * partition -- and the damped system is then solved by a row-sharded block-Jacobi PCG: each rank multiplies, updates and
+ * preconditions its own rows; per iteration the ranks exchange one scalar (p . A p) and the vector z with r . z, r . r behind it
+ * (each rank's rows in a zero-padded buffer of 6 n + 2 doubles: its all-reduce IS the gather), through the same transport as
+ * the linearisation (callback or RCCL communicator; the buffer is the tail of the system buffer).  Same iterates as the
+ * single-process block-Jacobi solve up to the order of the sums.  The dense second level of the preconditioner is a
+ * single-device structure: it is not used (and does not switch itself on) in this mode; with LSLAM_PG_COARSE=1 the solve
+ * stays replicated.  (-1, -1) returns to the replicated solve. */
+void lslam_pg_row_shard_range(int32_t n_vertices, int32_t rank, int32_t world, int32_t *v_begin, int32_t *v_end);
+int lslam_pg_set_row_shard(lslam_pg *pg, int32_t v_begin, int32_t v_end);
+int32_t lslam_pg_row_sharded_solves(const lslam_pg *pg); /* damped solves that took the row-sharded form so far */
 int32_t lslam_pg_num_offdiag(const lslam_pg *pg);
 /* SolverG2O::optimize (solver_g2o.cpp:79-95): up to max_iters LM iterations. */
 int lslam_pg_optimize(lslam_pg *pg, int32_t max_iters, lslam_pg_stats *stats);

@@ -61,6 +61,118 @@ def test_shard_range_partitions(n, world):
     assert max(sizes) - min(sizes) <= 1
 
 
+def _rs_worker(rank, world, port, q):
+    """The exchange pattern of the library's row-sharded PCG (csrc/lslam_posegraph.hip, lslam_pg_set_row_shard) under a real
+    process group, in numpy: own rows multiplied / updated / preconditioned locally, one scalar all-reduce (p . A p) and one
+    all-reduce of the zero-padded z with r . z, r . r behind it per iteration, the direction recomputed by every rank."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import scipy.sparse as sp
+    import torch
+    import posegraph_oracle as po
+    d = importlib.import_module("the-cooper-mapper_amd.dist")
+    dist = d.init(backend="gloo")
+    g = po.make_graph(n_kf=230, n_loop=700, laps=3)
+    H, b, _ = po.linearize(g["init"], g["ij"], g["meas"], g["info"])
+    H = H.tolil(); H[:6, :] = 0; H[:, :6] = 0; H[:6, :6] = np.eye(6); H = H.tocsr()
+    b = b.copy(); b[:6] = 0
+    n_v = len(g["init"])
+    A = (H + 1e-3 * H.diagonal().max() * sp.identity(6 * n_v)).tocsr()
+    minv = [np.linalg.inv(A[6 * v:6 * v + 6, 6 * v:6 * v + 6].toarray()) for v in range(n_v)]
+    prec = lambda r, v0, v1: np.concatenate([minv[v] @ r[6 * (v - v0):6 * (v - v0) + 6] for v in range(v0, v1)])  # noqa: E731
+
+    def allreduce(x):
+        t = torch.from_numpy(x)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.numpy()
+
+    v0, v1 = d.row_shard_range(n_v, rank, world)
+    r0, r1 = 6 * v0, 6 * v1
+    Aown = A[r0:r1]
+    n6 = 6 * n_v
+    x = np.zeros(r1 - r0)
+    r = b[r0:r1].copy()
+    z = prec(b, 0, n_v)                      # replicated start: b is complete on every rank
+    rz, rr, bb = float(b @ z), float(b @ b), float(b @ b)
+    p = np.zeros(n6)
+    rz_old, its = 1.0, 0
+    for k in range(500):
+        if rr <= 1e-20 * bb:
+            break
+        p = z + (rz / rz_old if k > 0 else 0.0) * p          # every rank, all rows
+        qv = Aown @ p
+        pq = float(allreduce(np.array([p[r0:r1] @ qv]))[0])  # exchange 1
+        alpha = rz / pq
+        x += alpha * p[r0:r1]
+        r -= alpha * qv
+        zo = prec(r, v0, v1)
+        X = np.zeros(n6 + 2)
+        X[r0:r1] = zo
+        X[n6], X[n6 + 1] = r @ zo, r @ r
+        X = allreduce(X)                                      # exchange 2: the padded sum IS the gathered z
+        z, rz_old, rz, rr = X[:n6], rz, float(X[n6]), float(X[n6 + 1])
+        its += 1
+    X = np.zeros(n6)
+    X[r0:r1] = x
+    xfull = allreduce(X)
+    ref = None
+    if rank == 0:  # the same PCG in one piece
+        xs = np.zeros(n6); rs = b.copy(); zs = prec(b, 0, n_v); ps = np.zeros(n6); rzs = float(rs @ zs); rzo = 1.0
+        for k in range(500):
+            if rs @ rs <= 1e-20 * bb:
+                break
+            ps = zs + (rzs / rzo if k > 0 else 0.0) * ps
+            qs = A @ ps
+            al = rzs / float(ps @ qs)
+            xs += al * ps; rs -= al * qs
+            zs = prec(rs, 0, n_v)
+            rzo, rzs = rzs, float(rs @ zs)
+        ref = xs
+    q.put((rank, (v0, v1), its, xfull, ref))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_pcg_two_ranks():
+    """SURVEY 8e row 3 for graphs that do not fit one GPU's persistent solver: ONE damped solve shared by two ranks.  The rows
+    partition in whole 21-vertex blocks, both ranks end with the same bits, and the result is the single-process PCG's."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rs_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, (a0, a1), it0, x0, ref), (_, (b0, b1), it1, x1, _) = res
+    assert a0 == 0 and a1 == b0 and b1 == 230 and a1 % 21 == 0 and abs((a1 - a0) - (b1 - b0)) <= 21
+    assert it0 == it1 and 5 < it0 < 400
+    assert np.array_equal(x0, x1)                          # same reduced numbers on both ranks -> same decisions, same bits
+    assert np.abs(x0 - ref).max() <= 1e-10 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("n,world", [(0, 4), (20, 2), (21, 2), (5000, 8), (50001, 8)])
+def test_row_shard_range_partitions(n, world):
+    sys.path.insert(0, ROOT)
+    d = importlib.import_module("the-cooper-mapper_amd.dist")
+    parts = [d.row_shard_range(n, r, world) for r in range(world)]
+    assert parts[0][0] == 0 and parts[-1][1] == n
+    assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+    assert all(a % 21 == 0 for a, _ in parts) and all(e % 21 == 0 or e == n for _, e in parts)
+    # and it is the library's partition (no GPU needed for this export)
+    import ctypes as C
+    lib = importlib.import_module("the-cooper-mapper_amd").load_library()
+    for r in range(world):
+        b, e = C.c_int32(), C.c_int32()
+        lib.lslam_pg_row_shard_range(n, r, world, C.byref(b), C.byref(e))
+        assert (b.value, e.value) == parts[r]
+
+
 def test_bench_gpus_flag_starts_that_many_ranks():
     """`python bench.py --gpus 2` outside a launcher starts 2 ranks itself (before anything touches the GPU)
     and rank 0 reports n_gpus == 2; under a launcher whose world size differs from --gpus it refuses."""

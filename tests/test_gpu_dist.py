@@ -102,6 +102,30 @@ def _worker(rank, world, port, q):
         res["fb_fused"] = pg.last_stats.fused_solves
         res["fb_trials"] = pg.last_stats.lm_trials
         pg.close()
+        # ---- ONE solve shared by the ranks: row-sharded block-Jacobi PCG on a 50 400-keyframe graph (too large for the
+        # persistent solver: 885 aggregates), rows split in whole 21-vertex blocks, z gathered by the zero-padded all-reduce
+        os.environ["LSLAM_PG_COARSE"] = "0"  # block Jacobi on both sides of the comparison
+        gb = synth.make_pose_graph(n_kf=50400, n_loop=100000, laps=8, radius=800.0)
+        pgr = pkg.PoseGraph(0)
+        pgr.set_graph(gb["init"], gb["ij"], gb["meas"], gb["info"])
+        sysbuf3 = torch.zeros(pgr.system_doubles(), dtype=torch.float64, device="cuda")
+        b, e = d.shard_range(len(gb["ij"]), rank, world)
+        pgr.set_shard(b, e, allreduce=make_allreduce(sysbuf3), system_tensor=sysbuf3)
+        vb, ve = pgr.row_shard_range(rank, world)
+        assert (vb, ve) == d.row_shard_range(len(gb["init"]), rank, world)
+        pgr.set_row_shard(vb, ve)
+        lin = pgr.linearize()
+        lam = 1e-2 * float(np.abs(lin["diag"]).max())
+        dx, its = pgr.solve(lam)
+        res["rs_dx"], res["rs_its"], res["rs_solves"], res["rs_rows"] = dx, its, pgr.row_sharded_solves(), (vb, ve)
+        pgr.close()
+        if rank == 0:
+            pg1 = pkg.PoseGraph(0)
+            pg1.set_graph(gb["init"], gb["ij"], gb["meas"], gb["info"])
+            pg1.linearize()
+            res["rs_full"], res["rs_full_its"] = pg1.solve(lam)
+            pg1.close()
+        os.environ.pop("LSLAM_PG_COARSE", None)
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, res))
@@ -139,6 +163,12 @@ def test_sharded_paths_under_a_real_process_group():
     assert np.array_equal(r0["fb_poses"], r1["fb_poses"]) and r0["fb_trials"] == r1["fb_trials"]
     assert r1["fb_fused"] == 0 and r0["fb_fused"] == 1
     assert np.abs(r0["fb_poses"] - r0["pg_full"]).max() < 1e-6  # launch loop against persistent kernel: two PCG solves to 1e-8
+    # the row-sharded solve of the 50 400-keyframe graph: both ranks took it, ended with the same bits after the same number of
+    # iterations, and it is the single-process solve's answer up to the order of the sums
+    assert r0["rs_solves"] == 1 and r1["rs_solves"] == 1 and r0["rs_rows"][1] == r1["rs_rows"][0] and r1["rs_rows"][1] == 50400
+    assert np.array_equal(r0["rs_dx"], r1["rs_dx"]) and r0["rs_its"] == r1["rs_its"] == r0["rs_full_its"]
+    assert 3 < r0["rs_its"] < 4000
+    assert np.abs(r0["rs_dx"] - r0["rs_full"]).max() <= 1e-10 * np.abs(r0["rs_full"]).max()
 
 
 def test_rccl_communicator_world_of_one(pkg, ctx, small_problem):
@@ -170,6 +200,16 @@ def test_rccl_communicator_world_of_one(pkg, ctx, small_problem):
             res.append((pg.poses(), pg.last_stats.chi2_final))
             pg.close()
         assert np.abs(res[0][0] - res[1][0]).max() < 1e-10 and abs(res[0][1] - res[1][1]) <= 1e-10 * res[0][1]
+        # the row-sharded solve through RCCL (a world of one owns every row): whole LM runs, ncclAllReduce of the exchange area
+        # on the solver's stream twice per PCG iteration
+        pg = pkg.PoseGraph(0)
+        pg.set_graph(g["init"], g["ij"], g["meas"], g["info"])
+        pg.set_comm(comm, 0, len(g["ij"]))
+        pg.set_row_shard(*pg.row_shard_range(0, 1))
+        pg.optimize(6)
+        assert pg.row_sharded_solves() >= 6
+        assert np.abs(pg.poses() - res[0][0]).max() < 1e-7 and abs(pg.last_stats.chi2_final - res[0][1]) <= 1e-8 * res[0][1]
+        pg.close()
         # the raw collective on a device buffer
         import torch
         t = torch.arange(8, dtype=torch.float64, device="cuda")

@@ -209,6 +209,9 @@ SYMBOLS = {
                                  c_int32_p]),
     "lslam_pg_set_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, ALLREDUCE_FN, C.c_void_p, C.c_void_p]),
     "lslam_pg_system_doubles": (C.c_size_t, [C.c_void_p]),
+    "lslam_pg_row_shard_range": (None, [C.c_int32, C.c_int32, C.c_int32, c_int32_p, c_int32_p]),
+    "lslam_pg_set_row_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "lslam_pg_row_sharded_solves": (C.c_int32, [C.c_void_p]),
     "lslam_pg_num_offdiag": (C.c_int32, [C.c_void_p]),
     "lslam_pg_optimize": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(LslamPgStats)]),
     "lslam_pg_get_poses": (C.c_int, [C.c_void_p, c_double_p]),

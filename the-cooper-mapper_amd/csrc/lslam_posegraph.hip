@@ -409,6 +409,9 @@ struct CgArgs {
   int n6, n_blocks, n_items, n_pblocks;
   int n_parts;           // entries of part_rz[] / part_rr: n_blocks + the coarse level's blocks (zero when it is off)
   double tol2;
+  // row-sharded solve (lslam_pg_set_row_shard): this rank's items [item_begin, item_end) and row blocks from block_begin on;
+  // the partial arrays then hold ONE entry each, the sum over all ranks (n_parts = n_pblocks = 1)
+  int item_begin, item_end, block_begin;
 };
 
 // ---- second level of the preconditioner (see solve()) -----------------------------------------------------------
@@ -469,9 +472,9 @@ __global__ __launch_bounds__(PROD_BLOCK) void pg_cg_prod_kernel(CgArgs a, int k)
   // operand loads first: they do not depend on beta, and the launch is latency bound
   const double *po = (k > 0) ? a.p[(k + 1) & 1] : a.z;  // k == 0: beta = 0, p_0 = z
   double *pn = a.p[k & 1];
-  const int t = blockIdx.x * PROD_BLOCK + threadIdx.x;
-  const bool on = t < a.n_items;
-  const int tt = on ? t : a.n_items - 1;
+  const int t = a.item_begin + blockIdx.x * PROD_BLOCK + threadIdx.x;
+  const bool on = t < a.item_end;
+  const int tt = on ? t : a.item_end - 1;
   const int e = tt / 6, r = tt - e * 6;
   const int v = a.row_of[e];
   const size_t c0 = (size_t)a.row_col[e] * 6;
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(CG_BLOCK) void pg_cg_update_kernel(CgArgs a, int k)
   __shared__ double sh[2 * CG_BLOCK / 64];
   __shared__ double rloc[CG_BLOCK];
   if (a.scal[5] != 0.0) return;
-  const int row = blockIdx.x * CG_ROWS + threadIdx.x;
+  const int row = (a.block_begin + blockIdx.x) * CG_ROWS + threadIdx.x;
   const bool on = threadIdx.x < CG_ROWS && row < a.n6;
   const int rowc = on ? row : 0;
   const int v = rowc / 6, rrow = rowc % 6;
@@ -582,6 +585,41 @@ __global__ __launch_bounds__(CG_BLOCK) void pg_cg_check_kernel(CgArgs a, int k) 
   if (threadIdx.x == 0) {
     a.scal[3] = s[1];
     if (s[1] <= a.tol2 * a.scal[4] || !(s[0] > 0.0)) a.scal[5] = 1.0;
+  }
+}
+
+// ---- row-sharded solve (large graphs on several GPUs; lslam_pg_set_row_shard) ---------------------------------------------
+// Every rank owns a contiguous range of vertex rows: it multiplies, updates and preconditions only those, and the ranks meet
+// twice per iteration -- one scalar (p . A p), then the vector z with r . z and r . r behind it -- through the same all-reduce
+// the linearisation uses: each rank contributes its own rows of z to a zero-padded buffer, the sum IS the gathered vector.
+// The direction p_k = z + beta p_(k-1) is recomputed by every rank for ALL rows from the gathered z (an axpy of 6 n values:
+// cheaper than a second exchange); every rank sees the same reduced scalars, hence takes the same decisions.
+__global__ void pg_rs_direction_kernel(CgArgs a, int k) {  // p_k for every row (what pg_cg_prod_kernel recomputes per column)
+  if (a.scal[5] != 0.0) return;
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= a.n6) return;
+  double beta = 0.0;
+  if (k > 0) {
+    const double rz = a.part_rz[k & 1][0], rz_old = a.part_rz[(k + 1) & 1][0], rr = a.part_rr[0];
+    if (rr <= a.tol2 * a.scal[4] || !(rz > 0.0)) return;  // pg_cg_prod_kernel ends the solve on the same numbers
+    beta = rz / rz_old;
+  }
+  const double *po = (k > 0) ? a.p[(k + 1) & 1] : a.z;
+  a.p[k & 1][row] = a.z[row] + beta * (k > 0 ? po[row] : 0.0);
+}
+__global__ void pg_rs_zero_others_kernel(double *v, int n6, int row_begin, int row_end) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < n6 && (row < row_begin || row >= row_end)) v[row] = 0.0;
+}
+__global__ void pg_rs_pack_kernel(const double *src, double *dst, int n6, int row_begin, int row_end) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < n6) dst[row] = (row >= row_begin && row < row_end) ? src[row] : 0.0;
+}
+__global__ void pg_rs_copy_kernel(const double *src, double *d0, double *d1, double *d2) {  // up to three scalars to their slots
+  if (threadIdx.x == 0) {
+    if (d0) *d0 = src[0];
+    if (d1) *d1 = src[1];
+    if (d2) *d2 = src[2];
   }
 }
 
@@ -1576,8 +1614,15 @@ struct lslam_pg {
   int pk_fit = -1;             // -1 not decided yet, 0 the multi-launch loop, 1 the persistent kernel
   int fused_solves = 0, total_solves = 0, pk_timeouts = 0;
   bool fell_back = false;      // a persistent kernel gave way to its launch loop during the last solve() (sharded runs: every rank must follow)
-  // [diag | off | b | chi2 | fallback flag]: the last double travels with the trial chi2's all-reduce of a sharded run
-  size_t sys_doubles() const { return (size_t)n_v * 36 + (size_t)n_off * 36 + (size_t)n_v * 6 + 2; }
+  // row-sharded solve (lslam_pg_set_row_shard): this rank's vertex rows [row_v0, row_v1); -1: the solve is replicated
+  int row_v0 = -1, row_v1 = -1;
+  std::vector<int32_t> h_row_ptr;
+  int rs_solves = 0;
+  // [diag | off | b | chi2 | fallback flag | exchange area of the row-sharded solve: 6 n_v + 8]: the system part is all-reduced
+  // per linearisation, chi2 + flag per trial, the exchange area per PCG iteration of a row-sharded solve
+  size_t core_doubles() const { return (size_t)n_v * 36 + (size_t)n_off * 36 + (size_t)n_v * 6 + 2; }
+  size_t sys_doubles() const { return core_doubles() + (size_t)n_v * 6 + 8; }
+  double *xchg() const { return d_sys + core_doubles(); }
   double *diag() const { return d_sys; }
   double *off() const { return d_sys + (size_t)n_v * 36; }
   double *b() const { return d_sys + (size_t)n_v * 36 + (size_t)n_off * 36; }
@@ -1635,7 +1680,7 @@ int linearize(lslam_pg *pg, const double *poses) {
   hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(SUM_BLOCK), 0, pg->stream, pg->d_chi, ne, 1, pg->chi());
   PG_TRY(hipGetLastError());
   if (pg->sharded()) {
-    const int rc = pg->reduce(pg->d_sys, pg->sys_doubles());
+    const int rc = pg->reduce(pg->d_sys, pg->core_doubles());
     if (rc) return rc;
     // identity block of the fixed vertex after the sum over ranks
     static const double I[36] = {1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0,
@@ -1782,6 +1827,73 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
     pg->coarse_setups++;
     }
     pg->coarse_solves++;
+  }
+  a.item_begin = 0;
+  a.item_end = (int)n_items;
+  a.block_begin = 0;
+  // ---- row-sharded solve: several GPUs share ONE solve of a large graph (beyond "replicated solve") ----------
+  // Block-Jacobi PCG only (the dense second level is a single-device structure), launch per step; see pg_rs_direction_kernel.
+  if (pg->sharded() && pg->row_v0 >= 0 && !coarse) {
+    const int v0 = pg->row_v0, v1 = pg->row_v1;
+    const int r0 = v0 * 6, r1 = v1 * 6;
+    a.item_begin = pg->h_row_ptr[(size_t)v0] * 6;
+    a.item_end = pg->h_row_ptr[(size_t)v1] * 6;
+    a.block_begin = r0 / CG_ROWS;
+    const int nb_rows = (r1 - a.block_begin * CG_ROWS + CG_ROWS - 1) / CG_ROWS;   // row blocks of this rank
+    const int nb_items = (a.item_end - a.item_begin + PROD_BLOCK - 1) / PROD_BLOCK;  // item blocks of this rank
+    double *X = pg->xchg();  // [z (6 n_v) | rz | rr | pq | ...]
+    double *z_own = a.z;     // init runs replicated on the ordinary z
+    // x = 0, r = b, z = M^-1 b and their sums, on every row by every rank: b is complete everywhere after the linearisation's
+    // all-reduce, so this needs no exchange
+    hipLaunchKernelGGL(pg_cg_init_kernel, g, blk, 0, pg->stream, a);
+    hipLaunchKernelGGL(pg_cg_init2_kernel, dim3(1), blk, 0, pg->stream, a);
+    hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(SUM_BLOCK), 0, pg->stream, a.part_rz[0], pg->n_cg_blocks, 1, X + n6);
+    hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(SUM_BLOCK), 0, pg->stream, a.part_rr, pg->n_cg_blocks, 1, X + n6 + 1);
+    hipLaunchKernelGGL(pg_rs_copy_kernel, dim3(1), dim3(64), 0, pg->stream, (const double *)(X + n6), a.part_rz[0], a.part_rr, (double *)nullptr);
+    PG_TRY(hipMemcpyAsync(X, z_own, (size_t)n6 * sizeof(double), hipMemcpyDeviceToDevice, pg->stream));
+    a.z = X;  // from here on z lives in the exchange area: own rows written by the update, the others arrive by the all-reduce
+    a.n_parts = 1;
+    a.n_pblocks = 1;
+    const dim3 gall((n6 + 255) / 256), b256(256);
+    double scal[8] = {0};
+    int done_iters = 0;
+    for (int it = 0; it < max_cg;) {
+      const int chunk = std::min(50, max_cg - it);
+      for (int k = it; k < it + chunk; ++k) {
+        hipLaunchKernelGGL(pg_rs_direction_kernel, gall, b256, 0, pg->stream, a, k);
+        a.n_pblocks = 1;
+        hipLaunchKernelGGL(pg_cg_prod_kernel, dim3(std::max(nb_items, 1)), dim3(PROD_BLOCK), 0, pg->stream, a, k);
+        hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(SUM_BLOCK), 0, pg->stream, a.part_pq, nb_items, 1, X + n6 + 2);
+        PG_TRY(hipGetLastError());
+        int rc = pg->reduce(X + n6 + 2, 1);  // p . A p
+        if (rc) return rc;
+        hipLaunchKernelGGL(pg_rs_copy_kernel, dim3(1), dim3(64), 0, pg->stream, (const double *)(X + n6 + 2), a.part_pq, (double *)nullptr, (double *)nullptr);
+        hipLaunchKernelGGL(pg_cg_update_kernel, dim3(std::max(nb_rows, 1)), blk, 0, pg->stream, a, k);
+        hipLaunchKernelGGL(pg_rs_zero_others_kernel, gall, b256, 0, pg->stream, X, n6, r0, r1);
+        hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(SUM_BLOCK), 0, pg->stream, a.part_rz[(k + 1) & 1], nb_rows, 1, X + n6);
+        hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(SUM_BLOCK), 0, pg->stream, a.part_rr, nb_rows, 1, X + n6 + 1);
+        PG_TRY(hipGetLastError());
+        rc = pg->reduce(X, (size_t)n6 + 2);  // z gathered, r . z and r . r summed
+        if (rc) return rc;
+        hipLaunchKernelGGL(pg_rs_copy_kernel, dim3(1), dim3(64), 0, pg->stream, (const double *)(X + n6), a.part_rz[(k + 1) & 1], a.part_rr, (double *)nullptr);
+      }
+      it += chunk;
+      hipLaunchKernelGGL(pg_cg_check_kernel, dim3(1), blk, 0, pg->stream, a, it);
+      PG_TRY(hipMemcpyAsync(scal, pg->d_scal, sizeof(scal), hipMemcpyDeviceToHost, pg->stream));
+      PG_TRY(hipStreamSynchronize(pg->stream));
+      done_iters = (int)scal[6];
+      if (scal[5] != 0.0) break;
+    }
+    // the solution: every rank's rows, gathered the same way
+    hipLaunchKernelGGL(pg_rs_pack_kernel, gall, b256, 0, pg->stream, (const double *)pg->d_x, X, n6, r0, r1);
+    PG_TRY(hipGetLastError());
+    int rc = pg->reduce(X, (size_t)n6);
+    if (rc) return rc;
+    PG_TRY(hipMemcpyAsync(pg->d_x, X, (size_t)n6 * sizeof(double), hipMemcpyDeviceToDevice, pg->stream));
+    *iters_out = done_iters;
+    pg->total_solves++;
+    pg->rs_solves++;
+    return LSLAM_OK;
   }
   // The persistent kernel when the graph fits: one workgroup per aggregate, all co-resident, LDS for its columns / items.
   if (pg->pk_fit < 0) {
@@ -1951,6 +2063,7 @@ int lslam_pg_create(int device, int32_t n_v, const double *poses7, int32_t n_e, 
     }
   }
   pg->n_entries = (int)rcol.size();
+  pg->h_row_ptr = rptr;
   pg->h_row_of = rof;
   pg->h_row_col = rcol;
   {  // coarse blocks: fine entries grouped by (aggregate of the row, aggregate of the column), in entry order
@@ -2156,6 +2269,33 @@ void lslam_pg_destroy(lslam_pg *pg) {
 }
 
 size_t lslam_pg_system_doubles(const lslam_pg *pg) { return pg ? pg->sys_doubles() : 0; }
+
+void lslam_pg_row_shard_range(int32_t n_vertices, int32_t rank, int32_t world, int32_t *v_begin, int32_t *v_end) {
+  // whole row blocks of the PCG kernels (21 vertices), as even as that allows
+  const int per = CG_ROWS / 6;
+  const int nblk = (n_vertices + per - 1) / per;
+  const int b0 = (int)((long long)nblk * rank / world), b1 = (int)((long long)nblk * (rank + 1) / world);
+  if (v_begin) *v_begin = std::min(n_vertices, b0 * per);
+  if (v_end) *v_end = std::min(n_vertices, b1 * per);
+}
+
+int lslam_pg_set_row_shard(lslam_pg *pg, int32_t v_begin, int32_t v_end) {
+  if (!pg) return LSLAM_ERR_INVALID;
+  if (v_begin < 0 && v_end < 0) {  // back to the replicated solve
+    pg->row_v0 = pg->row_v1 = -1;
+    return LSLAM_OK;
+  }
+  if (v_begin < 0 || v_end < v_begin || v_end > pg->n_v || (v_begin % (CG_ROWS / 6)) != 0 ||
+      (v_end != pg->n_v && (v_end % (CG_ROWS / 6)) != 0)) {
+    g_pg_err = "row shard must be a range of whole 21-vertex row blocks (lslam_pg_row_shard_range)";
+    return LSLAM_ERR_INVALID;
+  }
+  pg->row_v0 = v_begin;
+  pg->row_v1 = v_end;
+  return LSLAM_OK;
+}
+
+int32_t lslam_pg_row_sharded_solves(const lslam_pg *pg) { return pg ? pg->rs_solves : 0; }
 
 int lslam_pg_set_comm(lslam_pg *pg, lslam_comm *comm) {
   if (!pg) return LSLAM_ERR_INVALID;

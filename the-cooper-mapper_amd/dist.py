@@ -22,6 +22,14 @@ def shard_range(n_items, rank, world):
     return begin, begin + base + (1 if rank < extra else 0)
 
 
+def row_shard_range(n_vertices, rank, world, block=21):
+    """This rank's vertex rows [begin, end) of a row-sharded pose-graph solve: an even partition in whole row blocks of the
+    PCG kernels (21 vertices = 126 rows) -- the Python statement of lslam_pg_row_shard_range (include/lslam_c.h)."""
+    nblk = (n_vertices + block - 1) // block
+    b0, b1 = nblk * rank // world, nblk * (rank + 1) // world
+    return min(n_vertices, b0 * block), min(n_vertices, b1 * block)
+
+
 def init(backend=None, device=None):
     """Initialise the process group from the torchrun environment (no-op for 1 rank)."""
     rank, local_rank, world = env_rank()

@@ -166,6 +166,21 @@ class PoseGraph:
         self._check(self.lib.lslam_pg_set_comm(self.h, comm.h if comm is not None else None))
         self._comm = comm
 
+    def row_shard_range(self, rank, world):
+        """lslam_pg_row_shard_range: this rank's vertex rows [v_begin, v_end) of an even partition in whole row blocks."""
+        b, e = C.c_int32(), C.c_int32()
+        self.lib.lslam_pg_row_shard_range(len(self._nodes), int(rank), int(world), C.byref(b), C.byref(e))
+        return b.value, e.value
+
+    def set_row_shard(self, v_begin, v_end):
+        """lslam_pg_set_row_shard: the damped solves are shared by the ranks (row-sharded block-Jacobi PCG) instead of replicated;
+        (-1, -1) switches back.  Needs set_shard / set_comm first (the transport)."""
+        self._build()
+        self._check(self.lib.lslam_pg_set_row_shard(self.h, int(v_begin), int(v_end)))
+
+    def row_sharded_solves(self):
+        return int(self.lib.lslam_pg_row_sharded_solves(self.h)) if self.h else 0
+
     def system_doubles(self):
         self._build()
         return self.lib.lslam_pg_system_doubles(self.h)

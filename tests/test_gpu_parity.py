@@ -669,9 +669,12 @@ def test_posegraph_sharded_equals_full(pkg):
     sysbuf = torch.zeros(hooked.system_doubles(), dtype=torch.float64, device="cuda")
     hooked.set_shard(0, ne, allreduce=lambda ptr, count: calls.append((ptr, count)), system_tensor=sysbuf)
     got = hooked.linearize()
-    assert calls and calls[0][0] == sysbuf.data_ptr() and calls[0][1] == hooked.system_doubles()
+    # the system the ranks sum is [diag | off | b | chi2 | fallback flag]; the row-sharded solve's exchange vector follows it
+    assert calls and calls[0][0] == sysbuf.data_ptr()
+    core = calls[0][1]
+    assert core + 6 * n + 8 == hooked.system_doubles()
     assert np.abs(got["b"] - ref["b"]).max() <= 1e-12 * np.abs(ref["b"]).max()
-    assert abs(float(sysbuf[-2]) - ref["chi2"]) <= 1e-12 * ref["chi2"]  # [diag | off | b | chi2 | fallback flag]
+    assert abs(float(sysbuf[core - 2]) - ref["chi2"]) <= 1e-12 * ref["chi2"]
     hooked.close()
     full.close()
 

@@ -217,6 +217,11 @@ def main():
     elapsed = time.perf_counter() - t0
 
     (total_pt_res, total_iters), t = distmod.aggregate(dist, [pt_res, iters], elapsed)
+    if os.environ.get("LSLAM_DEBUG_CERT_STATS"):  # debug tap of the certificate path (sweep_body): searched / swept points
+        import ctypes
+        cs = (ctypes.c_uint64 * 3)()
+        ctx.lib.lslam_debug_cert_stats(ctx.h, cs)
+        print("certificate path: searched %d of %d points swept (%.1f %%)" % (cs[0], cs[1], 100.0 * cs[0] / max(1, cs[1])), file=sys.stderr)
 
     status, poses, sts = last
     pose_err = np.abs(poses - gts)

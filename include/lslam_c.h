@@ -571,6 +571,10 @@ void *lslam_stream(lslam_ctx *ctx); /* hipStream_t */
  * trees, [4] per-cube trees with overflow, [5] packet search, [6] persistent Gauss-Newton kernel, [7] the whole-stack kernel with
  * the 6x6 solve fused into its tail (the Gauss-Newton loop of single scans: one launch per iteration). */
 void lslam_debug_sweep_launches(lslam_ctx *ctx, uint64_t counts[8]);
+/* Debug tap of the certificate sweep (csrc/lslam_kernels.hip sweep_body): out[2] = second-pass launches of this
+ * context since its creation; out[0] = points the certificate-testing workgroups left to the second pass and out[1] = points
+ * of those workgroups, counted only when the process runs with LSLAM_DEBUG_CERT_STATS=1 (two atomics per workgroup). */
+void lslam_debug_cert_stats(lslam_ctx *ctx, uint64_t out[3]);
 
 #ifdef __cplusplus
 }

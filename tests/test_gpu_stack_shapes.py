@@ -87,10 +87,13 @@ def test_full_loop_on_a_deep_tree_matches_oracle(ctx, oracle, small_problem, sha
     assert np.array_equal(bits(pose2), bits(pose)) and st2.iterations == st.iterations
 
 
-def test_batch_above_512_blocks_runs_the_shallow_kernel_and_matches_oracle(ctx, oracle, synth, small_problem):
+def test_batch_above_512_blocks_runs_the_shallow_kernel_and_matches_oracle(ctx, oracle, synth, small_problem, monkeypatch):
     """Twelve 16 x 900 scans resident together: ~640 blocks = ~2 560 wavefronts, so `launch_sweep` itself picks
-    sweep_kernel<256,true,false,12> -- the instantiation bench.py times.  Every scan against `oracle.scanmatch_scan`, and
-    bit for bit against its own run alone through the deep stack; one scan far from the map, one empty."""
+    sweep_kernel<256,true,false,12> -- the instantiation bench.py times -- and the loop runs the certificate sweep (two
+    passes from the second sweep on).  Every scan against `oracle.scanmatch_scan`, and bit for bit against its own run alone
+    through the deep stack (certificate sweep forced there too: a launch that small would search every point, which sums the
+    same terms in another grouping); one scan far from the map, one empty."""
+    monkeypatch.setenv("LSLAM_KNN_CERT", "2")
     pr = small_problem
     world = pr["world"]
     scans, inits = [], []
@@ -117,6 +120,7 @@ def test_batch_above_512_blocks_runs_the_shallow_kernel_and_matches_oracle(ctx, 
     worst, poses, stats = ctx.run_batch(np.stack(inits), opts)
     ran = _ran(before, ctx.sweep_launches())
     assert set(ran) == {"shallow"} and ran["shallow"] >= 3, ran  # picked by launch size, not forced
+    assert ctx.cert_stats()[2] > 0  # second passes were launched
     n_blocks = sum((len(c) + 255) // 256 + (len(s) + 255) // 256 for c, s in scans)
     assert n_blocks > 512
     for k, (status, pose, st) in enumerate(single):
@@ -177,7 +181,7 @@ def voxel_map_problem(pkg, synth):
     ctx.close()
 
 
-def test_voxel_map_batch_of_full_scans_matches_oracle(voxel_map_problem, oracle):
+def test_voxel_map_batch_of_full_scans_matches_oracle(voxel_map_problem, oracle, monkeypatch):
     """configs[1] map (reduced) x configs[2] scans: three full 64 x 1800 scans (~1 350 blocks) in one batch against the
     surround of the addFeatureCloud-built voxel map -- the bench's workload shape, kernel instantiation and code path --
     with every scan's pose, row counts and iteration count against the oracle on the same clouds."""
@@ -204,7 +208,9 @@ def test_voxel_map_batch_of_full_scans_matches_oracle(voxel_map_problem, oracle)
         assert abs(stats[k].score - ost.score) <= 1e-4 * ost.score and abs(stats[k].percent - ost.percent) <= 1e-4
         # and it is a real match: within centimetres of where the scan was taken
         assert np.abs(poses[k][3:] - vp["gts"][k][3:]).max() < 0.05, k
-    # a single full scan (deep stack, latency-bound launch) gives the batch's bits
+    # a single full scan (deep stack, latency-bound launch) gives the batch's bits -- in the batch's sweep mode (certificates,
+    # which a launch this small would not take by itself)
+    monkeypatch.setenv("LSLAM_KNN_CERT", "2")
     ctx.scan_set(*vp["scans"][1])
     before = ctx.sweep_launches()
     status, pose1, st1 = ctx.run(vp["inits"][1])
@@ -233,6 +239,64 @@ def test_voxel_map_sweep_taps_match_oracle_through_the_shallow_kernel(voxel_map_
     assert (o["flags"] & 4).sum() > 50000
 
 
+def test_certificate_sweep_equals_searching_every_point(voxel_map_problem, ctx, oracle, synth, small_problem, monkeypatch):
+    """The certificate sweep (sweep_body: neighbour lists of points that hardly moved carried over by proof, the others
+    searched in a second pass) against searching every point in every sweep: the same neighbours, hence the same statuses,
+    iteration and row counts, and poses equal to the rounding of sums taken in another grouping -- on the bench's workload
+    shape (full scans against the voxel map, picked by launch size) and on a small batch with a far and an empty scan
+    (forced).  Certificates really are issued and second passes really run."""
+    def both(c, inits, opts, force):
+        out = {}
+        for mode in ("0", "2" if force else "1"):
+            monkeypatch.setenv("LSLAM_KNN_CERT", mode)
+            monkeypatch.setenv("LSLAM_DEBUG_CERT_STATS", "1")
+            s0 = c.cert_stats()
+            worst, poses, stats = c.run_batch(inits, opts)
+            s1 = c.cert_stats()
+            out[mode != "0"] = (poses, stats, tuple(b - a for a, b in zip(s0, s1)))
+        (p0, st0, d0), (p1, st1, d1) = out[False], out[True]
+        assert d0 == (0, 0, 0)
+        needy, tested, passes = d1
+        assert passes >= 2 and tested > 0 and needy < tested, d1  # certificates were tested and some held
+        for k in range(len(st0)):
+            assert (st0[k].status, st0[k].iterations, st0[k].converged) == (st1[k].status, st1[k].iterations, st1[k].converged), k
+            assert (st0[k].n_rows, st0[k].n_line, st0[k].n_plane) == (st1[k].n_rows, st1[k].n_line, st1[k].n_plane), k
+            assert np.abs(p0[k][3:] - p1[k][3:]).max() <= 2e-6 and np.abs(p0[k][:3] - p1[k][:3]).max() <= 2e-7, k
+            assert abs(st0[k].score - st1[k].score) <= 1e-5 * max(1.0, st0[k].score), k
+        return 1.0 - needy / tested
+
+    vp = voxel_map_problem
+    vctx = vp["ctx"]
+    vctx.scan_set_batch(vp["scans"])
+    opts = vctx.default_opts()
+    opts.scans_in_flight = 3
+    held = both(vctx, vp["inits"], opts, force=False)
+    assert held > 0.3, held  # the last sweeps of a loop move a scan by millimetres
+
+    pr = small_problem
+    world = pr["world"]
+    scans, inits = [(pr["corner"], pr["surf"])], [pr["init_pose"]]
+    for k in range(4):
+        gt = (0.0, 0.01 * k, 0.2 + 0.3 * k, 2.0 - 1.5 * k, -1.0 + k, synth.SENSOR_HEIGHT)
+        qc, qs, gt = synth.make_scan(world, 16, 450, gt_pose=gt, seed=500 + k)
+        scans.append((qc, qs))
+        inits.append(synth.perturb_pose(gt, seed=600 + k))
+    inits[2][3] += 400.0
+    empty = np.zeros((0, 4), np.float32)
+    scans[3] = (empty, empty)
+    ctx.map_set(pr["map_corner"], pr["map_surf"])
+    ctx.scan_set_batch(scans)
+    for shape in (DEEP, SHALLOW):
+        o = ctx.default_opts()
+        o.search_mode = LANE | shape
+        both(ctx, np.stack(inits), o, force=True)
+    # the mapping node's settings (no score gate, looser abort thresholds)
+    o = ctx.default_opts()
+    o.delta_t_abort = o.delta_r_abort = 0.1
+    o.use_score = 0
+    both(ctx, np.stack(inits), o, force=True)
+
+
 def test_fused_solve_equals_the_solve_launch(ctx, synth, small_problem, monkeypatch):
     """The 6 x 6 solve in the tail of the sweep launch (the block that retires the scan's last record reduces and solves) against
     the solve kernel as its own launch: same reduction order, same solve -- same bits; single scan, a small batch with a scan
@@ -252,6 +316,9 @@ def test_fused_solve_equals_the_solve_launch(ctx, synth, small_problem, monkeypa
     mopts.delta_t_abort = mopts.delta_r_abort = 0.1
     mopts.use_score = 0
     res = {}
+    # the fused tail rides on the one-launch sweep: the certificate sweep (two launches, the same terms summed in another
+    # grouping) is held against it and the oracle by test_certificate_sweep_equals_searching_every_point
+    monkeypatch.setenv("LSLAM_KNN_CERT", "0")
     for fused in (True, False):
         if fused:
             monkeypatch.setenv("LSLAM_FUSED_SOLVE", "1")

@@ -172,6 +172,17 @@ struct lslam_ctx {
   DevBuf<int32_t> tail_count;  // per resident scan: the fused solve's ticket counter (zero between launches)
   DevBuf<uint32_t> stack_ovf;  // only allocated for trees deeper than KD_STACK_LDS+1
   DevBuf<int32_t> prev_nb;     // neighbours of the previous sweep, per resident scan point
+  DevBuf<float4> prev_q;       // ... and where the point was then,
+  DevBuf<float> prev_lb;       // ... with the bound the certificate needs (sweep_body)
+  DevBuf<uint8_t> need_list;   // certificate sweep: the points pass 1 leaves to pass 2 (SweepArgs)
+  DevBuf<uint16_t> need_cnt;
+  DevBuf<GroupDesc> groups;
+  DevBuf<int32_t> cert_work;   // [blocks] work list of pass 2 (CertPlan)
+  DevBuf<int32_t> cert_count;  // [2]
+  std::vector<GroupDesc> h_groups;
+  std::vector<int32_t> h_prob_group0;  // [n_prob + 1] first group of every scan
+  uint64_t queue_launches = 0;
+  DevBuf<unsigned long long> cert_stats;  // LSLAM_DEBUG_CERT_STATS=1: [searched, swept] counters of the certificate path
   bool prev_valid = false;
   lslam_comm *comm = nullptr;  // RCCL communicator of the sharded-points path (not owned)
   DevBuf<double> xchg;         // its exchange buffer
@@ -285,6 +296,8 @@ void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
   a.partials = ctx->partials.p;
   a.stack_ovf = nullptr;
   a.prev_nb = ctx->prev_nb.p;
+  a.prev_q = nullptr;
+  a.prev_lb = nullptr;
   a.prev_valid = 0;
   a.bounded = 0;
   a.deep_tree = (ctx->tc.depth > KD_STACK_LDS + 1 || ctx->ts.depth > KD_STACK_LDS + 1) ? 1 : 0;
@@ -292,6 +305,14 @@ void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
   a.stack_mode = SWEEP_STACK_AUTO;
   a.fine_gate_c = a.fine_gate_s = -1.0f;
   a.tail = SweepTail{};
+  a.cert_stats = nullptr;
+  a.need_list = nullptr;
+  a.need_cnt = nullptr;
+  a.groups = nullptr;
+  a.n_groups = 0;
+  a.group_block_base = 0;
+  a.cert_try_m = 0.0f;
+  a.cert_track_m = 0.0f;
   a.idx_out = nullptr;
   a.d2_out = nullptr;
   a.coeff_out = nullptr;
@@ -345,9 +366,20 @@ int resolve_stack_mode(int32_t search_mode) {
 hipError_t sweep_launch(lslam_ctx *ctx, const SweepArgs &a, int jtj_mode, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
                         int *variant = nullptr) {
   int v = -1;
-  const hipError_t e = launch_sweep(a, jtj_mode, ctx->stream, e0, e1, &v);
+  // certificate sweep: from the second sweep of a loop a second launch searches the points pass 1 listed (sweep_body); the
+  // pair is timed as one
+  const bool two_pass = a.prev_q && a.need_cnt && a.bounded && a.prev_valid && !a.tail.count && !a.gc.trees;
+  hipError_t e = launch_sweep(a, jtj_mode, ctx->stream, e0, two_pass ? nullptr : e1, &v);
   if (v >= 0 && v < SWEEP_N_VARIANTS) ctx->sweep_variants[v]++;
   if (variant) *variant = v;
+  if (e == hipSuccess && two_pass) {
+    CertPlan plan;
+    plan.work = ctx->cert_work.p;
+    plan.count = ctx->cert_count.p + (ctx->queue_launches & 1);
+    plan.count_next = ctx->cert_count.p + ((ctx->queue_launches + 1) & 1);
+    e = launch_sweep_queue(a, jtj_mode, ctx->stream, e1, v, plan);
+    ctx->queue_launches++;
+  }
   return e;
 }
 
@@ -452,6 +484,13 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   ctx->ts.nodes.release(); ctx->ts.pts.release(); ctx->ts.pn.release(); ctx->ts.own_box.release();
   ctx->cell_c.release(); ctx->cell_s.release(); ctx->views_c.release(); ctx->views_s.release();
   ctx->prev_nb.release();
+  ctx->prev_q.release();
+  ctx->prev_lb.release();
+  ctx->need_list.release();
+  ctx->need_cnt.release();
+  ctx->groups.release();
+  ctx->cert_work.release();
+  ctx->cert_count.release();
   ctx->xchg.release();
   ctx->gnp_slots.release(); ctx->gnp_bar.release();
   ctx->q.release(); ctx->blocks.release(); ctx->probs.release(); ctx->partials.release(); ctx->stack_ovf.release();
@@ -474,6 +513,13 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
 }
 
 void *lslam_stream(lslam_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+void lslam_debug_cert_stats(lslam_ctx *ctx, uint64_t out[3]) {  // out[0], out[1] need LSLAM_DEBUG_CERT_STATS=1 during the runs
+  out[0] = out[1] = out[2] = 0;
+  if (!ctx) return;
+  if (ctx->cert_stats.p && hipMemcpy(out, ctx->cert_stats.p, 16, hipMemcpyDeviceToHost) != hipSuccess) out[0] = out[1] = 0;
+  out[2] = ctx->queue_launches;
+}
 
 void lslam_debug_sweep_launches(lslam_ctx *ctx, uint64_t counts[8]) {
   for (int i = 0; i < 8; ++i) counts[i] = ctx ? ctx->sweep_variants[i] : 0;
@@ -995,6 +1041,8 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
   float4 *all = ctx->h_stage;
   size_t n_all = 0;
   ctx->h_blocks.clear();
+  ctx->h_groups.clear();
+  ctx->h_prob_group0.clear();
   ctx->h_probs.assign((size_t)n_scans, ProbBlocks{0, 0});
   ctx->nqc.assign((size_t)n_scans, 0);
   ctx->nqs.assign((size_t)n_scans, 0);
@@ -1038,17 +1086,38 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
       n_all += cnt;
     }
     ctx->h_probs[(size_t)p].n_blocks = (int32_t)ctx->h_blocks.size() - ctx->h_probs[(size_t)p].first_block;
+    {  // groups of the certificate sweep's second pass: runs of one feature type
+      ctx->h_prob_group0.push_back((int32_t)ctx->h_groups.size());
+      const int32_t b0 = ctx->h_probs[(size_t)p].first_block, b1 = (int32_t)ctx->h_blocks.size();
+      for (int32_t b = b0; b < b1;) {
+        int32_t e = b + 1;
+        while (e < b1 && e - b < CERT_GROUP && ctx->h_blocks[(size_t)e].is_surf == ctx->h_blocks[(size_t)b].is_surf) ++e;
+        ctx->h_groups.push_back(GroupDesc{b, e - b, p, 0});
+        b = e;
+      }
+    }
     ctx->nqc[(size_t)p] = (int32_t)n_corner[p];
     ctx->nqs[(size_t)p] = (int32_t)n_surf[p];
     out_base += (int32_t)(n_corner[p] + n_surf[p]);
   }
   seg_off.push_back((int32_t)n_all);
+  ctx->h_prob_group0.push_back((int32_t)ctx->h_groups.size());
   const size_t nb = ctx->h_blocks.size();
   HIP_TRY(ctx->q.reserve(total ? total : 1));
   HIP_TRY(ctx->blocks.reserve(nb ? nb : 1));
   HIP_TRY(ctx->probs.reserve((size_t)n_scans));
   HIP_TRY(ctx->partials.reserve((nb ? nb : 1) * NCOL));
   HIP_TRY(ctx->prev_nb.reserve((total ? total : 1) * 5));
+  HIP_TRY(ctx->prev_q.reserve(total ? total : 1));
+  HIP_TRY(ctx->prev_lb.reserve(total ? total : 1));
+  HIP_TRY(ctx->need_list.reserve((nb ? nb : 1) * SWEEP_BLOCK));
+  HIP_TRY(ctx->need_cnt.reserve(nb ? nb : 1));
+  HIP_TRY(ctx->groups.reserve(ctx->h_groups.empty() ? 1 : ctx->h_groups.size()));
+  HIP_TRY(ctx->cert_work.reserve(nb ? nb : 1));
+  if (!ctx->cert_count.p) {
+    HIP_TRY(ctx->cert_count.reserve(2));
+    HIP_TRY(hipMemsetAsync(ctx->cert_count.p, 0, 2 * sizeof(int32_t), ctx->stream));
+  }
   HIP_TRY(ctx->tail_count.reserve((size_t)n_scans));
   HIP_TRY(hipMemsetAsync(ctx->tail_count.p, 0, sizeof(int32_t) * (size_t)n_scans, ctx->stream));
   ctx->prev_valid = false;
@@ -1066,6 +1135,9 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
                            hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemcpyAsync(ctx->probs.p, ctx->h_probs.data(), (size_t)n_scans * sizeof(ProbBlocks),
                          hipMemcpyHostToDevice, ctx->stream));
+  if (!ctx->h_groups.empty())
+    HIP_TRY(hipMemcpyAsync(ctx->groups.p, ctx->h_groups.data(), ctx->h_groups.size() * sizeof(GroupDesc), hipMemcpyHostToDevice,
+                           ctx->stream));
   // No wait here: everything that uses the scan is ordered behind these copies on the same stream, the block / range tables
   // are pageable (consumed when hipMemcpyAsync returns) and the pinned staging area is guarded by `stage_busy` -- so that
   // lslam_scanmatch_scan reaches the host once per call, when the loop's result comes back.
@@ -1313,6 +1385,23 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
     const int n_chunks = (n_scans + in_flight - 1) / in_flight;
     static const bool unbounded = std::getenv("LSLAM_UNBOUNDED_KNN") != nullptr;  // A/B switch
     sa.bounded = (ctx->cube_mode || unbounded) ? 0 : 1;  // per-cube positions are tree-relative
+    // neighbour lists carried from sweep to sweep by certificate where a point has hardly moved (sweep_body); LSLAM_KNN_CERT=0
+    // (read per call) searches every point in every sweep
+    const int cert_env = std::getenv("LSLAM_KNN_CERT") ? std::atoi(std::getenv("LSLAM_KNN_CERT")) : 1;
+    const bool no_cert = cert_env == 0, force_cert = cert_env == 2;
+    sa.prev_q = (sa.bounded && !no_cert && !sa.packet) ? ctx->prev_q.p : nullptr;
+    if (sa.prev_q) {
+      sa.prev_lb = ctx->prev_lb.p;
+      sa.cert_try_m = std::getenv("LSLAM_CERT_TRY_M") ? (float)std::atof(std::getenv("LSLAM_CERT_TRY_M")) : CERT_TRY_M_DEFAULT;
+      sa.cert_track_m = std::getenv("LSLAM_CERT_TRACK_M") ? (float)std::atof(std::getenv("LSLAM_CERT_TRACK_M")) : CERT_TRACK_M_DEFAULT;
+    }
+    if (sa.prev_q && std::getenv("LSLAM_DEBUG_CERT_STATS")) {
+      if (!ctx->cert_stats.p) {
+        HIP_TRY(ctx->cert_stats.reserve(2));
+        HIP_TRY(hipMemsetAsync(ctx->cert_stats.p, 0, 16, ctx->stream));
+      }
+      sa.cert_stats = ctx->cert_stats.p;
+    }
     std::vector<int> done_iters((size_t)n_chunks, 0);    // iterations enqueued per chunk
     std::vector<char> finished((size_t)n_chunks, 0);
     // LSLAM_FUSED_SOLVE=1 (read per call: the tests switch it): the solve rides in the tail of the sweep launch whenever that
@@ -1345,6 +1434,16 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
       sc.blocks = ctx->blocks.p + fb;
       sc.nb_total = lb - fb;
       sc.partials = ctx->partials.p + (size_t)fb * NCOL;
+      // throughput-bound launches only (launch_sweep's own test: more wavefronts than two per SIMD): a launch that fits the
+      // device at once ends when its slowest wavefront does, certificates or not, and the second pass is two launches more
+      // per iteration (measured on single scans: 0.29 against 0.26 ms per loop).  LSLAM_KNN_CERT=2 takes it regardless (tests)
+      if (sc.prev_q && !sc.tail.count && (force_cert || (long)sc.nb_total * (SWEEP_BLOCK / 64) > 2 * 1024)) {
+        sc.need_list = ctx->need_list.p + (size_t)fb * SWEEP_BLOCK;
+        sc.need_cnt = ctx->need_cnt.p + fb;
+        sc.groups = ctx->groups.p + ctx->h_prob_group0[(size_t)p0];
+        sc.n_groups = ctx->h_prob_group0[(size_t)p1] - ctx->h_prob_group0[(size_t)p0];
+        sc.group_block_base = fb;
+      }
       SolveArgs soc = so;
       soc.states = ctx->d_state + p0;
       soc.probs = ctx->probs.p + p0;

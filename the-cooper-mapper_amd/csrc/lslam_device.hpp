@@ -218,13 +218,19 @@ struct TravStats { unsigned long long t_desc, t_leaf, t_pop, t_take; unsigned n_
 #ifndef LSLAM_CULL_TAKE
 #define LSLAM_CULL_TAKE 0  // 1: far subtrees are tested against their tight box before they are entered (A/B switch)
 #endif
-template <int BLOCK, bool OVF, int LDS_DEPTH>
+// TRACK: also returns in *lb6 a LOWER BOUND of the squared distance of every map point that is NOT among the five returned
+// (+inf while fewer than six points have been seen): the minimum over every candidate turned away or pushed out of the result
+// set (its real distance), and over the mindistsq of every subtree not entered.  With it the next Gauss-Newton iteration can
+// prove, for a query that moved by less than the gap between its fifth neighbour and everything else, that the five are still
+// the five nearest -- without searching (sweep_body, "certificate").
+template <int BLOCK, bool OVF, int LDS_DEPTH, bool TRACK = false>
 LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, float (&d)[5],
                            int (&p)[5], KdStack<BLOCK, OVF, LDS_DEPTH> &stk,
 #ifdef LSLAM_TRAVERSAL_STATS
                            TravStats &ts,
 #endif
-                           const float bound = FLT_MAX) {
+                           const float bound = FLT_MAX, float *lb6 = nullptr) {
+  float lb = FLT_MAX;
   // stack entries examined per pop round: four in flight where a wavefront's latency is what counts (single scans,
   // whole stack in LDS), fewer where instruction issue is (the shallow-stack batch variant)
   constexpr int POPW = (LDS_DEPTH <= 16 && LDS_DEPTH > 0) ? LSLAM_POPW_SHALLOW : 4;
@@ -263,6 +269,8 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
       if (nm <= fminf(d[4], bound)) {
         stk.put(sp, node | (left ? (1u << 28) : 0u) | (feat << 29), __float_as_uint(nm));
         ++sp;
+      } else if (TRACK) {
+        lb = fminf(lb, nm);  // the far subtree is never entered: nothing in it is closer than nm
       }
       ref = left ? nd.c1 : nd.c2;
 #ifdef LSLAM_NODE_TWICE  // profiling only: the node-step arithmetic once more with no effect
@@ -340,11 +348,16 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
 #pragma unroll
       for (int j = 0; j < 10; ++j) {
         const float dist = dist2_xyz(qx, qy, qz, pt[j]);
-        const float x = (j < cnt && dist < worst) ? dist : FLT_MAX;
+        // TRACK: `bound` prunes subtrees only -- a candidate is turned away by the set's own fifth distance (the insert is a
+        // no-op for x >= d[4]), so that whoever is NOT in the set after this step, the candidate or the fifth element it
+        // pushes out, is max(x, d[4]) away and nobody leaves unrecorded.  Same five whenever the true fifth distance is inside
+        // the bound; otherwise d[4] ends at or beyond the bound and the caller's gate turns the point away as before.
+        const float x = TRACK ? (j < cnt ? dist : FLT_MAX) : ((j < cnt && dist < worst) ? dist : FLT_MAX);
 #ifdef LSLAM_TRAVERSAL_STATS
         hit = hit || x < d[4];
         ts.n_cand += x < d[4] ? 1 : 0;
 #endif
+        if (TRACK) lb = fminf(lb, fmaxf(x, d[4]));
         knn_insert_sorted(d, p, x, l + j);
       }
 #ifdef LSLAM_TRAVERSAL_STATS
@@ -401,6 +414,7 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
         te = tk ? e[j] : te;
         tm = tk ? m[j] : tm;
         take = take || tk;
+        if (TRACK) lb = (valid && !act && !pass) ? fminf(lb, m[j]) : lb;  // a stacked far subtree that is dropped unentered
         sp -= (valid && !pass) ? 1 : 0;
 #ifdef LSLAM_TRAVERSAL_STATS
         ts.n_pop += valid ? 1 : 0;
@@ -470,14 +484,15 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
     }
     TS_ADD(t_take)
   }
+  if (TRACK) *lb6 = lb;
 }
 
 #ifdef LSLAM_TRAVERSAL_STATS  // call sites that keep no statistics
-template <int BLOCK, bool OVF, int LDS_DEPTH>
+template <int BLOCK, bool OVF, int LDS_DEPTH, bool TRACK = false>
 LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, float (&d)[5], int (&p)[5],
-                           KdStack<BLOCK, OVF, LDS_DEPTH> &stk, const float bound = FLT_MAX) {
+                           KdStack<BLOCK, OVF, LDS_DEPTH> &stk, const float bound = FLT_MAX, float *lb6 = nullptr) {
   TravStats ts = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  knn5_search<BLOCK, OVF, LDS_DEPTH>(T, qx, qy, qz, d, p, stk, ts, bound);
+  knn5_search<BLOCK, OVF, LDS_DEPTH, TRACK>(T, qx, qy, qz, d, p, stk, ts, bound, lb6);
 }
 #endif
 

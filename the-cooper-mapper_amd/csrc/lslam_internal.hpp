@@ -63,6 +63,22 @@ struct ProbBlocks {
   int32_t first_block, n_blocks;
 };
 
+// Certificate sweep (sweep_body): pass-2 workgroup g works for pass-1 workgroups [first_block, first_block + n_blocks)
+struct GroupDesc {
+  int32_t first_block, n_blocks;
+  int32_t prob;  // the scan (an index into the launch's states)
+  int32_t pad;
+};
+// work list of pass 2: items group * CERT_GROUP + chunk; two counters that alternate from plan to plan (each zeroes the other's)
+struct CertPlan {
+  int32_t *work;
+  int32_t *count, *count_next;
+};
+constexpr int CERT_GROUP = 8;
+constexpr float CERT_TRY_M_DEFAULT = 0.05f;    // SweepArgs::cert_try_m (LSLAM_CERT_TRY_M overrides)
+constexpr float CERT_TRACK_M_DEFAULT = 1.0f;   // SweepArgs::cert_track_m (LSLAM_CERT_TRACK_M)
+constexpr float CERT_RANGE_M = 40.0f;  // lever arm that turns a rotation update into a displacement (sweep_body's try test)
+
 // Variant C (util/FeatureMap.h:465-691): the map as a grid of cubes, one kd-tree per cube.
 // cell_tree[toIndex(i,j,k)] = index into `trees`, or -1 for a cube with fewer than 5 points.
 struct CubeGridDev {
@@ -103,6 +119,9 @@ struct SweepArgs {
   float *partials;        // [nb_total][NCOL]
   uint32_t *stack_ovf;    // traversal-stack overflow (null unless a tree is deeper than 33)
   int32_t *prev_nb;       // [points][5] neighbour positions found by the previous sweep
+  float4 *prev_q;         // [points] (or null) where the point was in the previous sweep (map frame); with prev_lb, a lower bound of the
+                          // squared distance from there of every map point outside its five neighbours, the certificate of sweep_body
+  float *prev_lb;         // [points] ... that bound (0: none)
   int32_t prev_valid;     // prev_nb holds positions of the current trees
   int32_t bounded;        // 1: production loop (bounded search), 0: taps (nanoflann's plain search)
   int32_t deep_tree;      // a tree is deeper than KD_STACK_LDS+1: the LDS-only kernels cannot be used
@@ -113,6 +132,15 @@ struct SweepArgs {
   // flag is set) instead of the ones still running
   float fine_gate_c, fine_gate_s;
   SweepTail tail;
+  // the certificate sweep's second pass (sweep_body, sweep_queue_kernel); need_cnt null: no certificates
+  uint8_t *need_list;              // [nb_total][SWEEP_BLOCK] lanes of pass-1 workgroup b whose point is left to pass 2
+  uint16_t *need_cnt;              // [nb_total] how many
+  const GroupDesc *groups;         // [n_groups] runs of <= CERT_GROUP consecutive workgroups of one scan and feature type
+  int32_t n_groups;
+  int32_t group_block_base;        // GroupDesc::first_block counts from the context's first block, `blocks` from this one
+  float cert_try_m;                // a scan tests certificates when its last update moved its points by less than this [m]
+  float cert_track_m;              // ... and its searches keep the bound for the next sweep's certificates when by less than this
+  unsigned long long *cert_stats;  // (or null) debug tap: [0] points left to pass 2, [1] points of certificate-testing workgroups
   // optional per-point taps (all NULL in the production loop)
   int32_t *idx_out;    // [N][5] original map indices
   float *d2_out;       // [N][5]
@@ -210,6 +238,7 @@ enum : int {
   SWEEP_VARIANT_DEEP_FUSED = 7, // sweep_kernel<256, *, false, 32> with the solve in its tail (single scans)
   SWEEP_N_VARIANTS = 8
 };
+hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t stop, int variant, const CertPlan &plan);
 hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s,
                         hipEvent_t start = nullptr, hipEvent_t stop = nullptr, int *variant = nullptr);
 hipError_t launch_solve(const SolveArgs &a, hipStream_t s);

@@ -63,9 +63,12 @@ LSLAM_DEV int cube_tree_of(const CubeGridDev &g, float x, float y, float z) {
 // One block of one sweep: the body of sweep_kernel, and of an iteration of gn_persistent_kernel.  `st` is the scan's
 // state -- in HBM (STATE_LDS = false: R, t, sc arrive by scalar loads) or a workgroup's LDS copy (true); `red` and
 // `stack_lds` are the caller's LDS; the block's 32 sums go to partial_out[0..32).
-template <int BLOCK, bool OVF, bool CUBES, int LDS_DEPTH, bool PACKET, bool STATE_LDS, bool FUSE = false>
+// CERT (the bounded production sweep over whole-map trees, two launches): 1 = the pass over every point, which carries the
+// neighbour lists of points that have hardly moved over by certificate and lists the others; 2 = the pass over the listed
+// points (sweep_queue_kernel: `q_item` is this lane's point or -1, the sums are ADDED to partial_out).  See below.
+template <int BLOCK, bool OVF, bool CUBES, int LDS_DEPTH, bool PACKET, bool STATE_LDS, bool FUSE = false, int CERT = 0>
 LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, const BlockDesc &bd, const GNState *st,
-                          uint32_t *stack_lds, float (*red)[NCOL], float *partial_out, const int prev_valid) {
+                          uint32_t *stack_lds, float (*red)[NCOL], float *partial_out, const int prev_valid, const int q_item = -1) {
   constexpr int NWAVE = BLOCK / 64;
   static_assert(2 * LDS_DEPTH >= 8, "staging needs eight word rows of the stack");
 
@@ -74,8 +77,8 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
   const uint64_t dbg_t0 = a.dbg ? __builtin_readcyclecounter() : 0;
   uint64_t dbg_t1 = 0, dbg_t2 = 0;
   const bool is_surf = bd.is_surf != 0;
-  const int qi = bd.first + tid;
-  const bool active = tid < bd.count;
+  const int qi = CERT == 2 ? q_item : bd.first + tid;
+  bool active = CERT == 2 ? q_item >= 0 : tid < bd.count;
 
   // pose of this iteration: R, t, sc are 18 consecutive floats of the scan's GNState.  The compiler cannot prove the
   // state invariant (the solve kernel writes it between launches) and would fetch it with vector loads into 18 VGPRs
@@ -152,7 +155,7 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
       if (tie) {
         KdStack<BLOCK, true, 0> stk;
         stk.lds = nullptr;
-        stk.ovf = a.stack_ovf + ((size_t)blockIdx.x * BLOCK + tid);
+        stk.ovf = a.stack_ovf + ((size_t)lb * BLOCK + tid);
         stk.ovf_stride = (size_t)a.nb_total * BLOCK;
         knn5_search<BLOCK, true, 0>(T, sel[0], sel[1], sel[2], d, p, stk);
       }
@@ -163,8 +166,114 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
     }
   }
 
+  // ---------------------------------------------------------------------------------------------------------------------
+  // CERT: "the five are still the five".  From the second sweep of a loop a point knows its previous five neighbours, where
+  // it was then (q_prev) and a lower bound lb6 on the squared distance from q_prev of every OTHER map point
+  // (knn5_search<TRACK>).  It has moved by delta = |q - q_prev|.  Every other point is now at least sqrt(lb6) - delta away
+  // (triangle inequality); if the farthest of the five, at its NEW distance, is strictly closer than that, the five nearest
+  // neighbours are the same five -- proven, not searched -- and nanoflann's answer is those five in ascending order of their
+  // new distances (recomputed with the search's own arithmetic; five distinct distances: an exact tie goes to the search,
+  // whose visit order decides).  Late iterations move a scan by millimetres: most points certify.
+  //   A wavefront is only as fast as its slowest lane and a workgroup holds its LDS until its last wavefront retires, so a
+  // search left in a workgroup of certified points costs what sixty-four do.  Hence two launches.  Pass 1 (this one, every
+  // point): a scan whose last update was small enough for certificates to stand a chance (block-uniform test on the state's
+  // delta_r / delta_t) tests every point, runs the residuals of the certified ones and LISTS the others -- one byte per
+  // point, the lane number, at a fixed place per workgroup; other scans are searched right here as without certificates.
+  // Pass 2 (sweep_queue_kernel): one workgroup per group of CERT_GROUP consecutive pass-1 workgroups of the same scan and
+  // feature type concatenates their lists and searches the listed points with every lane busy, its sums added to the
+  // group's first record.  No atomics, fixed places, fixed order: the sums -- hence the poses -- are the same bits in every
+  // run.  Results equal searching every point (tests/test_gpu_stack_shapes.py holds the two against each other and both
+  // against the oracle); LSLAM_KNN_CERT=0 searches every point in one launch.
+  // ---------------------------------------------------------------------------------------------------------------------
+  bool do_search = true;  // this lane's neighbours come from a search below
+  bool track = CERT == 2;  // ... which keeps the bound the next sweep's certificate needs
+  if (CERT == 1) {
+    static_assert(CERT != 1 || (!PACKET && !CUBES && !STATE_LDS && BLOCK <= 256), "certificate pass: whole-map lane search, byte lists");
+    // the last update of this scan, as the largest displacement of a point within CERT_RANGE_M of the sensor [m]
+    const float dr_deg = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(st->delta_r)));
+    const float dt_cm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(st->delta_t)));
+    const float disp = prev_valid ? dt_cm * 0.01f + dr_deg * (0.017453292f * CERT_RANGE_M) : FLT_MAX;
+    const bool try_cert = disp < a.cert_try_m;
+    // a scan still moving by more than cert_track_m will not test certificates after its next update either: it is searched
+    // without the bookkeeping of the bound (which costs ~10 % of a search), and says so per point (prev_lb = 0: no certificate)
+    track = disp < a.cert_track_m;
+    if (try_cert) {  // block-uniform
+      __shared__ int wave_needy[NWAVE];
+      const float4 *pts = is_surf ? a.ts.pts : a.tc.pts;
+      const int n_pts = is_surf ? a.ts.n_pts : a.tc.n_pts;
+      bool certified = false;
+      if (active) {
+        q = a.q[qi];
+        sel[0] = ((R[0] * q.x + R[1] * q.y) + R[2] * q.z) + t[0];
+        sel[1] = ((R[3] * q.x + R[4] * q.y) + R[5] * q.z) + t[1];
+        sel[2] = ((R[6] * q.x + R[7] * q.y) + R[8] * q.z) + t[2];
+        int pp[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) pp[j] = a.prev_nb[(size_t)qi * 5 + j];
+        float4 pq = a.prev_q[qi];
+        pq.w = a.prev_lb[qi];
+        float4 pv[5];
+        bool all = true;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const bool ok = pp[j] >= 0 && pp[j] < n_pts;
+          all = all && ok;
+          pv[j] = pts[ok ? pp[j] : 0];
+        }
+        float dj[5], u = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          dj[j] = dist2_xyz(sel[0], sel[1], sel[2], pv[j]);
+          u = fmaxf(u, dj[j]);
+        }
+        const float ex = sel[0] - pq.x, ey = sel[1] - pq.y, ez = sel[2] - pq.z;
+        const float delta = sqrtf((ex * ex + ey * ey) + ez * ez);
+        const float sl = sqrtf(pq.w) * 0.99999f - delta * 1.00001f - 1e-6f;  // every other point is farther than this
+        bool distinct = true;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+          for (int j = i + 1; j < 5; ++j) distinct = distinct && dj[i] != dj[j];
+        certified = all && distinct && sqrtf(u) * 1.00001f < sl;
+        if (certified) {  // the previous five, in ascending order of their new distances; the bound travels on, reduced
+#pragma unroll
+          for (int j = 0; j < 5; ++j) { d[j] = FLT_MAX; p[j] = -1; }
+#pragma unroll
+          for (int j = 0; j < 5; ++j) knn_insert_sorted(d, p, dj[j], pp[j]);
+#pragma unroll
+          for (int j = 0; j < 5; ++j) a.prev_nb[(size_t)qi * 5 + j] = p[j];
+          a.prev_q[qi] = make_float4(sel[0], sel[1], sel[2], 0.0f);
+          a.prev_lb[qi] = (sl * sl) * 0.99999f;
+        }
+      }
+      const bool needy = active && !certified;
+      const unsigned long long m = __ballot(needy);
+      if (lane == 0) wave_needy[wave] = __popcll(m);
+      __syncthreads();
+      int off = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < NWAVE; ++w) {
+        const int c = wave_needy[w];
+        off += w < wave ? c : 0;
+        total += c;
+      }
+      if (needy) a.need_list[(size_t)lb * BLOCK + off + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)tid;
+      if (tid == 0) {
+        a.need_cnt[lb] = (uint16_t)total;
+        if (a.cert_stats) {  // debug tap: points left to pass 2 / points of certificate-testing workgroups
+          atomicAdd(a.cert_stats, (unsigned long long)total);
+          atomicAdd(a.cert_stats + 1, (unsigned long long)bd.count);
+        }
+      }
+      active = certified;
+      do_search = false;
+    } else if (tid == 0) {
+      a.need_cnt[lb] = 0;
+    }
+  }
+
   if (active) {
-    if (!PACKET) {
+    if (!PACKET && do_search) {
     q = a.q[qi];
     // util/transform_utils.h:476-482 pointAssociateToMap: it * p
     sel[0] = ((R[0] * q.x + R[1] * q.y) + R[2] * q.z) + t[0];
@@ -192,9 +301,10 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
       }
     }
     if (CUBES && !searched) T.n_pts = 0;  // knn5_search returns at once, d[4] stays FLT_MAX
+    if (do_search) {
     KdStack<BLOCK, OVF, LDS_DEPTH> stk;
     stk.lds = (lds_u32 *)(stack_lds + tid);
-    stk.ovf = OVF ? a.stack_ovf + ((size_t)blockIdx.x * BLOCK + tid) : nullptr;
+    stk.ovf = OVF ? a.stack_ovf + ((size_t)lb * BLOCK + tid) : nullptr;  // lb: unique per workgroup of a launch, < nb_total
     stk.ovf_stride = (size_t)a.nb_total * BLOCK;
     // Bound on the 5th neighbour's distance (production loop only; the taps run nanoflann's
     // unbounded search).  Points whose 5th neighbour is not closer than sqrt(5) m are rejected
@@ -237,12 +347,22 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
       o[4] = ts.n_leaf | ((uint64_t)ts.n_hit << 32); o[5] = ts.n_pop | ((uint64_t)ts.n_cand << 32); o[6] = ((uint64_t)ts.n_popit << 32) | ts.n_take; o[7] = ts.t_take | (1ull << 63);
     }
 #else
-    knn5_search<BLOCK, OVF, LDS_DEPTH>(T, sel[0], sel[1], sel[2], d, p, stk, bound);
+    if (CERT && track) {  // block-uniform
+      float slb = 0.0f;
+      knn5_search<BLOCK, OVF, LDS_DEPTH, true>(T, sel[0], sel[1], sel[2], d, p, stk, bound, &slb);
+      // the bound is only worth keeping when the five are the true five: all found, inside the gate the bounded search is exact in
+      a.prev_q[qi] = make_float4(sel[0], sel[1], sel[2], 0.0f);
+      a.prev_lb[qi] = (p[4] >= 0 && d[4] < 5.0f) ? slb * 0.9999f : 0.0f;
+    } else {
+      knn5_search<BLOCK, OVF, LDS_DEPTH>(T, sel[0], sel[1], sel[2], d, p, stk, bound);
+      if (CERT) a.prev_lb[qi] = 0.0f;
+    }
     if (a.bounded) {
 #pragma unroll
       for (int j = 0; j < 5; ++j) a.prev_nb[(size_t)qi * 5 + j] = p[j];
     }
 #endif
+    }  // do_search
     }  // !PACKET
     (void)searched;
     if (a.dbg) dbg_t1 = __builtin_readcyclecounter();
@@ -382,6 +502,7 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
     // fused solve: the record is read by another workgroup of THIS launch (possibly on another XCD) -- written through to
     // the device's coherence point; otherwise by the next launch
     if (FUSE) __hip_atomic_store(partial_out + tid, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (CERT == 2) partial_out[tid] += s;  // onto the record pass 1 left (this thread alone touches the word)
     else partial_out[tid] = s;
   }
   if (a.dbg && lane == 0) {  // per-wave phase stamps (shader clock)
@@ -838,7 +959,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(SolveArgs a) {
 
 // PACKET: the 5-NN search is the wave-cooperative one of lslam_packet.hpp (see sweep_body).
 // FUSE: the block that retires a scan's last record of the launch runs that scan's reduction + solve (SweepTail).
-template <int BLOCK, bool OVF, bool CUBES, int LDS_DEPTH, bool PACKET = false, bool FUSE = false>
+// CERT = 1: pass 1 of the certificate sweep (sweep_body); sweep_queue_kernel is pass 2.
+template <int BLOCK, bool OVF, bool CUBES, int LDS_DEPTH, bool PACKET = false, bool FUSE = false, int CERT = 0>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH <= 16 ? LSLAM_SHALLOW_OCC : 2))) void sweep_kernel(SweepArgs a, int jtj_mode) {
   const int lb = xcd_remap(blockIdx.x, a.nb_total);
   const BlockDesc bd = a.blocks[lb];
@@ -850,7 +972,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
   // slots -- word row c, lane slot p -- which are dead once its 5-NN searches are over: no extra LDS,
   // no cross-wavefront hazard (the shallow variant then fits six workgroups per CU instead of four).
   __shared__ uint32_t stack_lds[2 * LDS_DEPTH * BLOCK];
-  sweep_body<BLOCK, OVF, CUBES, LDS_DEPTH, PACKET, false, FUSE>(a, jtj_mode, lb, bd, st, stack_lds, red, a.partials + (size_t)lb * NCOL, a.prev_valid);
+  sweep_body<BLOCK, OVF, CUBES, LDS_DEPTH, PACKET, false, FUSE, CERT>(a, jtj_mode, lb, bd, st, stack_lds, red, a.partials + (size_t)lb * NCOL, a.prev_valid);
   if (FUSE) {
     static_assert(!FUSE || (2 * LDS_DEPTH * BLOCK * 4 >= (int)((SOLVE_GROUPS + 1) * NCOL * sizeof(double) + sizeof(GnShared) + 16)), "the tail's LDS lives in the stack");
     __shared__ int last;
@@ -886,6 +1008,75 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
   }
 }
 
+// Pass 2 of the certificate sweep (sweep_body), in two launches.
+// cert_plan_kernel, one thread per group: how many chunks of BLOCK listed points the group's pass-1 workgroups left (none for
+// a scan whose loop has ended), and that many work items (group, chunk) appended to the work list.  The order of the list
+// depends on the order of the atomics; nothing else does -- an item's sums go to a place of its own.
+__global__ __launch_bounds__(256) void cert_plan_kernel(SweepArgs a, CertPlan plan) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g == 0) *plan.count_next = 0;  // the counter of the NEXT plan (they alternate)
+  if (g >= a.n_groups) return;
+  const GroupDesc gd = a.groups[g];
+  if (a.states[gd.prob].done) return;
+  const int fb = gd.first_block - a.group_block_base;
+  int total = 0;
+  for (int k = 0; k < gd.n_blocks; ++k) total += (int)a.need_cnt[fb + k];
+  const int nch = (total + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
+  if (nch == 0) return;
+  const int at = atomicAdd(plan.count, nch);
+  for (int c = 0; c < nch; ++c) plan.work[at + c] = g * CERT_GROUP + c;
+}
+
+// sweep_queue_kernel, a resident grid that deals the work items round-robin: item (g, c) searches points [c BLOCK, (c + 1)
+// BLOCK) of the concatenation of the lists of group g's pass-1 workgroups, and ADDS its sums to the record of pass-1
+// workgroup first_block + c (written one launch earlier; nobody else adds to it).  A grid of one workgroup per POSSIBLE item
+// -- as many as the sweep itself has, nearly all of them leaving at once -- cost 0.25 ms per launch, more than the last
+// sweeps of a batch themselves.  The argument block is re-read through a laundered pointer in every turn: left to itself the
+// compiler carries the sweep's invariants across the loop in registers it does not have (124 bytes of scratch per lane).
+template <int BLOCK, bool OVF, int LDS_DEPTH>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH <= 16 ? LSLAM_SHALLOW_OCC : 2))) void sweep_queue_kernel(const SweepArgs a_in, const int jtj_mode_in, const CertPlan plan) {
+  __shared__ float red[BLOCK / 64][NCOL];
+  __shared__ uint32_t stack_lds[2 * LDS_DEPTH * BLOCK];
+  const int n_work = *plan.count;
+  for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+    SweepArgs a = a_in;
+    int jtj_mode = jtj_mode_in;
+    asm volatile("" : "+s"(a.q), "+s"(a.blocks), "+s"(a.states), "+s"(a.partials), "+s"(a.prev_nb), "+s"(a.prev_q), "+s"(a.prev_lb), "+s"(jtj_mode));
+    asm volatile("" : "+s"(a.tc.nodes), "+s"(a.tc.pts), "+s"(a.ts.nodes), "+s"(a.ts.pts), "+s"(a.stack_ovf), "+s"(a.need_list), "+s"(a.need_cnt), "+s"(a.groups));
+    const int item_id = __builtin_amdgcn_readfirstlane(plan.work[w]);
+    const int g = item_id / CERT_GROUP, c = item_id % CERT_GROUP;
+    GroupDesc gd = a.groups[g];
+    gd.first_block = __builtin_amdgcn_readfirstlane(gd.first_block);  // wave-uniform by construction: into scalar registers
+    gd.n_blocks = __builtin_amdgcn_readfirstlane(gd.n_blocks);
+    gd.prob = __builtin_amdgcn_readfirstlane(gd.prob);
+    const int fb = gd.first_block - a.group_block_base;
+    int pre[CERT_GROUP + 1];
+    pre[0] = 0;
+#pragma unroll
+    for (int k = 0; k < CERT_GROUP; ++k) pre[k + 1] = pre[k] + (k < gd.n_blocks ? __builtin_amdgcn_readfirstlane((int)a.need_cnt[fb + k]) : 0);
+    const int total = pre[CERT_GROUP];
+    BlockDesc bd = a.blocks[fb];
+    bd.prob = gd.prob;
+    bd.is_surf = __builtin_amdgcn_readfirstlane(bd.is_surf);
+    bd.out_base = __builtin_amdgcn_readfirstlane(bd.out_base);
+    GNState *st = const_cast<GNState *>(a.states) + gd.prob;
+    const int i = c * BLOCK + (int)threadIdx.x;
+    int item = -1;
+    if (i < total) {
+      int k = 0, p0 = 0;
+#pragma unroll
+      for (int j = 1; j < CERT_GROUP; ++j) {
+        const bool in = pre[j] <= i;
+        k = in ? j : k;
+        p0 = in ? pre[j] : p0;
+      }
+      item = a.blocks[fb + k].first + (int)a.need_list[(size_t)(fb + k) * BLOCK + (i - p0)];
+    }
+    sweep_body<BLOCK, OVF, false, LDS_DEPTH, false, false, false, 2>(a, jtj_mode, fb + c, bd, st, stack_lds, red, a.partials + (size_t)(fb + c) * NCOL, 1, item);
+    __syncthreads();  // red and the stack columns are free again
+  }
+}
+
 // start/stop (optional) time exactly this dispatch on its own stream: the events are
 // attached to the kernel's AQL packet, no extra barrier packets are enqueued.
 hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t start,
@@ -908,6 +1099,11 @@ hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEven
   // mode, LSLAM_FORCE_STACK in the environment): the parity tests run every comparison against the
   // oracle through both, whatever the size of their launch.
   const bool shallow_ok = a.stack_ovf != nullptr && !cubes;
+#ifdef LSLAM_TRAVERSAL_STATS
+  const bool cert = false;
+#else
+  const bool cert = a.prev_q != nullptr && a.need_cnt != nullptr && a.bounded && !cubes;  // pass 1 of the certificate sweep (sweep_body)
+#endif
   const bool shallow = shallow_ok && (a.stack_mode == SWEEP_STACK_SHALLOW ||
                                       (a.stack_mode == SWEEP_STACK_AUTO && a.bounded && (many_waves || deep_tree)));
   int v;
@@ -916,7 +1112,8 @@ hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEven
     hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, 4, true>), g, b, 0, s, start, stop, 0, a, jtj_mode);
   } else if (shallow) {
     v = SWEEP_VARIANT_SHALLOW;
-    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, SHALLOW>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+    if (cert) hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, SHALLOW, false, false, 1>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+    else hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, SHALLOW>), g, b, 0, s, start, stop, 0, a, jtj_mode);
   } else if (cubes && a.stack_ovf && deep_tree) {
     v = SWEEP_VARIANT_CUBES_OVF;
     hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, true, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
@@ -929,16 +1126,40 @@ hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEven
       hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, KD_STACK_LDS, false, true>), g, b, 0, s, start, stop, 0, a, jtj_mode);
     } else {
       v = SWEEP_VARIANT_DEEP_OVF;
-      hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+      if (cert) hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, KD_STACK_LDS, false, false, 1>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+      else hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, true, false, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
     }
   } else if (a.tail.count) {  // latency-bound launch: the solve rides in its tail
     v = SWEEP_VARIANT_DEEP_FUSED;
     hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false, false, KD_STACK_LDS, false, true>), g, b, 0, s, start, stop, 0, a, jtj_mode);
   } else {
     v = SWEEP_VARIANT_DEEP;
-    hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false, false, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+    if (cert) hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false, false, KD_STACK_LDS, false, false, 1>), g, b, 0, s, start, stop, 0, a, jtj_mode);
+    else hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false, false, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
   }
   if (variant) *variant = v;
+  return hipGetLastError();
+}
+
+hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t stop, int variant, const CertPlan &plan) {
+  if (a.n_groups <= 0) return hipSuccess;
+  hipLaunchKernelGGL(cert_plan_kernel, dim3((a.n_groups + 255) / 256), dim3(256), 0, s, a, plan);
+  // as many workgroups as stay resident (256 CUs x five of the shallow kernel, two of the deep ones), never more than items possible
+  constexpr int SHALLOW = LSLAM_SHALLOW_DEPTH;
+  const long possible = (long)a.nb_total;
+  const dim3 b(SWEEP_BLOCK);
+  if (variant == SWEEP_VARIANT_SHALLOW) {
+    const dim3 g((unsigned)std::min<long>(possible, 256 * 5));
+    hipExtLaunchKernelGGL((sweep_queue_kernel<SWEEP_BLOCK, true, SHALLOW>), g, b, 0, s, nullptr, stop, 0, a, jtj_mode, plan);
+  } else if (variant == SWEEP_VARIANT_DEEP_OVF) {
+    const dim3 g((unsigned)std::min<long>(possible, 256 * 2));
+    hipExtLaunchKernelGGL((sweep_queue_kernel<SWEEP_BLOCK, true, KD_STACK_LDS>), g, b, 0, s, nullptr, stop, 0, a, jtj_mode, plan);
+  } else if (variant == SWEEP_VARIANT_DEEP) {
+    const dim3 g((unsigned)std::min<long>(possible, 256 * 2));
+    hipExtLaunchKernelGGL((sweep_queue_kernel<SWEEP_BLOCK, false, KD_STACK_LDS>), g, b, 0, s, nullptr, stop, 0, a, jtj_mode, plan);
+  } else {
+    return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

@@ -110,6 +110,13 @@ class Context:
         self.lib.lslam_debug_sweep_launches(self.h, out)
         return dict(zip(SWEEP_VARIANTS, (int(v) for v in out)))
 
+    def cert_stats(self):
+        """lslam_debug_cert_stats: (points left to the second pass, points of certificate-testing workgroups, second-pass
+        launches) of this context so far; the first two are counted only under LSLAM_DEBUG_CERT_STATS=1."""
+        out = (C.c_uint64 * 3)()
+        self.lib.lslam_debug_cert_stats(self.h, out)
+        return int(out[0]), int(out[1]), int(out[2])
+
     # -- map / scan ----------------------------------------------------------
     def map_set(self, corner, surf):
         c, sc = _cloud(corner)

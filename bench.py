@@ -184,6 +184,8 @@ def main():
     opts.jtj_mode = args.jtj_mode
     opts.profile = 1
     opts.scans_in_flight = args.batch
+    if os.environ.get("LSLAM_DEBUG_MAX_ITERS"):  # diagnostics only (tools/cert_stats.py): the loop cut short -- not a bench line
+        opts.max_iterations = int(os.environ["LSLAM_DEBUG_MAX_ITERS"])
     setup_s = time.perf_counter() - t_setup
     # The interpreter holds ~170 k objects by now (torch, numpy): a generation-2 collection of the Python
     # garbage collector takes 25-35 ms and would land in whichever timed region happens to allocate the

@@ -178,7 +178,7 @@ struct lslam_ctx {
   DevBuf<uint16_t> need_cnt;
   DevBuf<GroupDesc> groups;
   DevBuf<int32_t> cert_work;   // [blocks] work list of pass 2 (CertPlan)
-  DevBuf<int32_t> cert_count;  // [2]
+  DevBuf<int32_t> cert_count;  // [2] items + [2] tickets
   std::vector<GroupDesc> h_groups;
   std::vector<int32_t> h_prob_group0;  // [n_prob + 1] first group of every scan
   uint64_t queue_launches = 0;
@@ -377,6 +377,8 @@ hipError_t sweep_launch(lslam_ctx *ctx, const SweepArgs &a, int jtj_mode, hipEve
     plan.work = ctx->cert_work.p;
     plan.count = ctx->cert_count.p + (ctx->queue_launches & 1);
     plan.count_next = ctx->cert_count.p + ((ctx->queue_launches + 1) & 1);
+    plan.ticket = plan.count + 2;
+    plan.ticket_next = plan.count_next + 2;
     e = launch_sweep_queue(a, jtj_mode, ctx->stream, e1, v, plan);
     ctx->queue_launches++;
   }
@@ -1115,8 +1117,8 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
   HIP_TRY(ctx->groups.reserve(ctx->h_groups.empty() ? 1 : ctx->h_groups.size()));
   HIP_TRY(ctx->cert_work.reserve(nb ? nb : 1));
   if (!ctx->cert_count.p) {
-    HIP_TRY(ctx->cert_count.reserve(2));
-    HIP_TRY(hipMemsetAsync(ctx->cert_count.p, 0, 2 * sizeof(int32_t), ctx->stream));
+    HIP_TRY(ctx->cert_count.reserve(4));
+    HIP_TRY(hipMemsetAsync(ctx->cert_count.p, 0, 4 * sizeof(int32_t), ctx->stream));
   }
   HIP_TRY(ctx->tail_count.reserve((size_t)n_scans));
   HIP_TRY(hipMemsetAsync(ctx->tail_count.p, 0, sizeof(int32_t) * (size_t)n_scans, ctx->stream));

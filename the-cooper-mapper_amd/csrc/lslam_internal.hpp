@@ -69,12 +69,13 @@ struct GroupDesc {
   int32_t prob;  // the scan (an index into the launch's states)
   int32_t pad;
 };
-// work list of pass 2: items group * CERT_GROUP + chunk; two counters that alternate from plan to plan (each zeroes the other's)
+// work list of pass 2: items group * CERT_GROUP + chunk; two sets of counters that alternate from plan to plan (each zeroes the other's)
 struct CertPlan {
   int32_t *work;
   int32_t *count, *count_next;
+  int32_t *ticket, *ticket_next;  // the next item to deal (sweep_queue_kernel)
 };
-constexpr int CERT_GROUP = 8;
+constexpr int CERT_GROUP = 16;
 constexpr float CERT_TRY_M_DEFAULT = 0.05f;    // SweepArgs::cert_try_m (LSLAM_CERT_TRY_M overrides)
 constexpr float CERT_TRACK_M_DEFAULT = 1.0f;   // SweepArgs::cert_track_m (LSLAM_CERT_TRACK_M)
 constexpr float CERT_RANGE_M = 40.0f;  // lever arm that turns a rotation update into a displacement (sweep_body's try test)

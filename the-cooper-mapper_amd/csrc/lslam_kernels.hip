@@ -235,15 +235,13 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
 #pragma unroll
           for (int j = i + 1; j < 5; ++j) distinct = distinct && dj[i] != dj[j];
         certified = all && distinct && sqrtf(u) * 1.00001f < sl;
-        if (certified) {  // the previous five, in ascending order of their new distances; the bound travels on, reduced
+        if (certified) {  // the previous five, in ascending order of their new distances
 #pragma unroll
           for (int j = 0; j < 5; ++j) { d[j] = FLT_MAX; p[j] = -1; }
 #pragma unroll
           for (int j = 0; j < 5; ++j) knn_insert_sorted(d, p, dj[j], pp[j]);
-#pragma unroll
-          for (int j = 0; j < 5; ++j) a.prev_nb[(size_t)qi * 5 + j] = p[j];
-          a.prev_q[qi] = make_float4(sel[0], sel[1], sel[2], 0.0f);
-          a.prev_lb[qi] = (sl * sl) * 0.99999f;
+          // nothing is written: the five (as a set), the position of the last SEARCH and the bound taken there stay what
+          // the next certificate is measured against -- the moves since add up in delta, and shrink geometrically
         }
       }
       const bool needy = active && !certified;
@@ -355,7 +353,9 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
       a.prev_lb[qi] = (p[4] >= 0 && d[4] < 5.0f) ? slb * 0.9999f : 0.0f;
     } else {
       knn5_search<BLOCK, OVF, LDS_DEPTH>(T, sel[0], sel[1], sel[2], d, p, stk, bound);
-      if (CERT) a.prev_lb[qi] = 0.0f;
+      // no bound kept: no certificate for this point in the next sweep (the first sweep of a certificate loop is this kernel
+      // WITHOUT the certificate code -- launch_sweep -- which is 4 % faster at searching than the one with it)
+      if (CERT || (!CUBES && a.prev_lb)) a.prev_lb[qi] = 0.0f;
     }
     if (a.bounded) {
 #pragma unroll
@@ -1014,7 +1014,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
 // depends on the order of the atomics; nothing else does -- an item's sums go to a place of its own.
 __global__ __launch_bounds__(256) void cert_plan_kernel(SweepArgs a, CertPlan plan) {
   const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g == 0) *plan.count_next = 0;  // the counter of the NEXT plan (they alternate)
+  if (g == 0) {  // the counters of the NEXT plan (they alternate)
+    *plan.count_next = 0;
+    *plan.ticket_next = 0;
+  }
   if (g >= a.n_groups) return;
   const GroupDesc gd = a.groups[g];
   if (a.states[gd.prob].done) return;
@@ -1037,8 +1040,14 @@ template <int BLOCK, bool OVF, int LDS_DEPTH>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH <= 16 ? LSLAM_SHALLOW_OCC : 2))) void sweep_queue_kernel(const SweepArgs a_in, const int jtj_mode_in, const CertPlan plan) {
   __shared__ float red[BLOCK / 64][NCOL];
   __shared__ uint32_t stack_lds[2 * LDS_DEPTH * BLOCK];
+  __shared__ int next_w;
   const int n_work = *plan.count;
-  for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+  for (;;) {
+    // dealt by ticket, not round-robin: an item is anything between a handful of points and BLOCK of them
+    if (threadIdx.x == 0) next_w = atomicAdd(plan.ticket, 1);
+    __syncthreads();
+    const int w = __builtin_amdgcn_readfirstlane(next_w);
+    if (w >= n_work) break;
     SweepArgs a = a_in;
     int jtj_mode = jtj_mode_in;
     asm volatile("" : "+s"(a.q), "+s"(a.blocks), "+s"(a.states), "+s"(a.partials), "+s"(a.prev_nb), "+s"(a.prev_q), "+s"(a.prev_lb), "+s"(jtj_mode));
@@ -1102,7 +1111,8 @@ hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEven
 #ifdef LSLAM_TRAVERSAL_STATS
   const bool cert = false;
 #else
-  const bool cert = a.prev_q != nullptr && a.need_cnt != nullptr && a.bounded && !cubes;  // pass 1 of the certificate sweep (sweep_body)
+  // pass 1 of the certificate sweep (sweep_body); a loop's first sweep has nothing to certify and nothing to keep a bound for
+  const bool cert = a.prev_q != nullptr && a.need_cnt != nullptr && a.bounded && !cubes && a.prev_valid;
 #endif
   const bool shallow = shallow_ok && (a.stack_mode == SWEEP_STACK_SHALLOW ||
                                       (a.stack_mode == SWEEP_STACK_AUTO && a.bounded && (many_waves || deep_tree)));

@@ -486,7 +486,9 @@ def sweep_roofline(pt_res, sweep_ms, sweep_launches, map_points):
     compulsory = map_points * 16.0 + pts_per_launch * (16.0 + 36.0)
     roof = {
         "kernel": "sweep_kernel<256,true,false,12> (the shallow-stack batch instantiation; tests/test_gpu_stack_shapes.py holds it "
-                  "against the oracle)",
+                  "against the oracle) -- from a loop's second sweep on as the certificate sweep: sweep_kernel<...,1> over every point "
+                  "+ cert_plan_kernel + sweep_queue_kernel<256,true,12> over the points whose neighbours could not be carried over; "
+                  "one timed 'launch' is one sweep = that group of dispatches (HIP events on the first and the last of them)",
         "bound": "valu",
         "achieved": tflops,
         "peak": FP32_PEAK_TFLOPS,
@@ -494,7 +496,9 @@ def sweep_roofline(pt_res, sweep_ms, sweep_launches, map_points):
         "frac": tflops / FP32_PEAK_TFLOPS,
         "accounting": "achieved = %.0f flop per point-residual (SURVEY 8d) x %.4g points an average timed launch processed / its "
                       "HIP-event duration of %.4g ms; peak = vector fp32 (MI355X_MICROARCH.md).  Neither `hbm` nor `mfma` bounds "
-                      "this kernel: the counters put VALU issue at `valu_issue.frac` of its slots and HBM at `measured_hbm.frac`"
+                      "this kernel: the counters put VALU issue at `valu_issue.frac` of its slots and HBM at `measured_hbm.frac`.  "
+                      "The flops are the ALGORITHM's (a 5-NN search per point and sweep); the certificate sweep skips the searches "
+                      "it can prove redundant, so late sweeps finish the same algorithmic work with fewer executed instructions"
                       % (FLOPS_PER_POINT_RESIDUAL, pts_per_launch, avg_sweep_ms),
         "alg_flops_per_point": FLOPS_PER_POINT_RESIDUAL,
         "alg_flops_per_launch": flops,

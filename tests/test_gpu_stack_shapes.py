@@ -295,6 +295,13 @@ def test_certificate_sweep_equals_searching_every_point(voxel_map_problem, ctx, 
     o.delta_t_abort = o.delta_r_abort = 0.1
     o.use_score = 0
     both(ctx, np.stack(inits), o, force=True)
+    # soundness does not hang on the thresholds that decide WHEN certificates are worth testing: with every scan testing
+    # them from its second sweep on, however far it has just moved, the loop still finds the same neighbours
+    monkeypatch.setenv("LSLAM_CERT_TRY_M", "1e9")
+    monkeypatch.setenv("LSLAM_CERT_TRACK_M", "1e9")
+    both(ctx, np.stack(inits), ctx.default_opts(), force=True)
+    vctx.scan_set_batch(vp["scans"])
+    both(vctx, vp["inits"], opts, force=False)
 
 
 def test_fused_solve_equals_the_solve_launch(ctx, synth, small_problem, monkeypatch):

@@ -59,6 +59,19 @@ for seed in range(n_seeds):
             bad += 1; print("seed", seed, "stack", hex(stack), "loop differs", st.iterations, ost.iterations, st.n_rows, ost.n_rows, np.abs(pose - opose).max())
     if not np.array_equal(bits(poses[0]), bits(poses[1])):
         bad += 1; print("seed", seed, "deep and shallow stack loops differ in bits")
+    # the certificate sweep (forced: a single scan would not take it), with its default thresholds and with every scan testing
+    # certificates from its second sweep on however far it moved: the same neighbours, so the same loop up to summation order
+    for env in ({"LSLAM_KNN_CERT": "2"}, {"LSLAM_KNN_CERT": "2", "LSLAM_CERT_TRY_M": "1e9", "LSLAM_CERT_TRACK_M": "1e9"}):
+        os.environ.update(env)
+        opts = ctx.default_opts()
+        opts.search_mode = 1 | 0x200
+        q0 = ctx.cert_stats()[2]
+        status, pose, st = ctx.run(init, opts)
+        ran = ctx.cert_stats()[2] - q0
+        for k in env:
+            del os.environ[k]
+        if st.iterations != ost.iterations or abs(st.n_rows - ost.n_rows) > 2 or np.abs(pose[3:] - poses[1][3:]).max() > 5e-6 or np.abs(pose[:3] - poses[1][:3]).max() > 5e-7 or (st.iterations > 1 and ran == 0):
+            bad += 1; print("seed", seed, "certificate sweep", env, "differs", st.iterations, ost.iterations, st.n_rows, ost.n_rows, np.abs(pose - poses[1]).max(), ran)
     print("seed %2d rings %2d steps %3d half %3.0f map %6d+%6d scan %5d: %s" % (seed, rings, steps, half, len(mc), len(ms), len(pr["corner"]) + len(pr["surf"]), "ok" if not bad else "MISMATCH"), flush=True)
     if bad:
         sys.exit(1)

@@ -273,6 +273,52 @@ def main():
         }
         if not args.no_single:
             out["single_scan"] = single_scan_leg(ctx, scans[0], inits[0], opts, 200)
+    # ---- disclosure leg: the same steps with every point SEARCHED in every sweep (LSLAM_KNN_CERT=0, read per call).  The
+    # headline runs the library as shipped, whose certificate sweep keeps a point's five neighbours without a
+    # search when the previous search's bounds prove they cannot have changed -- the same neighbours, hence the same residuals
+    # and poses up to summation order, with fewer executed instructions.  Both rates are in the line.
+    if not args.headline_only:
+        import ctypes
+        cert = {"what": "value = the library as shipped (certificate sweep for throughput-bound batches); value_searching_every_point = "
+                        "the same steps under LSLAM_KNN_CERT=0: every 5-NN search of every sweep executed"}
+        saved = os.environ.get("LSLAM_KNN_CERT")
+        os.environ["LSLAM_KNN_CERT"] = "0"
+        ctx.run_batch(inits, opts)
+        barrier()
+        t1 = time.perf_counter()
+        pr0 = 0
+        n0 = max(3, args.steps // 4)
+        for _ in range(n0):
+            st0, poses0, sts0 = ctx.run_batch(inits, opts)
+            pr0 += sum(s.point_residuals for s in sts0)
+        barrier()
+        (tot0,), t0s = distmod.aggregate(dist, [pr0], time.perf_counter() - t1)
+        if saved is None:
+            del os.environ["LSLAM_KNN_CERT"]
+        else:
+            os.environ["LSLAM_KNN_CERT"] = saved
+        # and what share of the certificate-testing sweeps' points kept their neighbours (one more step, counted)
+        os.environ["LSLAM_DEBUG_CERT_STATS"] = "1"
+        cs0 = (ctypes.c_uint64 * 3)()
+        cs1 = (ctypes.c_uint64 * 3)()
+        ctx.lib.lslam_debug_cert_stats(ctx.h, cs0)
+        st1, poses1, sts1 = ctx.run_batch(inits, opts)
+        ctx.lib.lslam_debug_cert_stats(ctx.h, cs1)
+        del os.environ["LSLAM_DEBUG_CERT_STATS"]
+        if rank == 0:
+            tested, needy = cs1[1] - cs0[1], cs1[0] - cs0[0]
+            swept = sum(s.point_residuals for s in sts1)
+            cert.update({
+                "value_searching_every_point": tot0 / t0s, "steps_searching_every_point": n0,
+                "point_residuals_per_step": swept, "points_that_tested_a_certificate_per_step": int(tested),
+                "points_certified_per_step": int(tested - needy), "share_of_point_residuals_certified": (tested - needy) / max(1, swept),
+                "second_pass_launches_per_step": int(cs1[2] - cs0[2]),
+                "pose_diff_between_the_two_modes_m": float(np.abs(poses1[:, 3:] - poses0[:, 3:]).max()),
+                "pose_diff_between_the_two_modes_rad": float(np.abs(poses1[:, :3] - poses0[:, :3]).max()),
+                "iterations_equal": bool(all(a.iterations == b.iterations for a, b in zip(sts0, sts1))),
+                "rows_equal": bool(all((a.n_rows, a.n_line, a.n_plane) == (b.n_rows, b.n_line, b.n_plane) for a, b in zip(sts0, sts1))),
+            })
+            out["certificate_sweep"] = cert
     # ---- the same timed region on 16-ring x 1800 scans (VLP-16, MultiScanRegistration.h:90-92; BASELINE north star:
     # "throughput on synthetic 16- and 64-ring scans") -- every rank, same protocol, its own roofline object
     if not args.no_vlp16:

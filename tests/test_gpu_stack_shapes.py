@@ -304,6 +304,59 @@ def test_certificate_sweep_equals_searching_every_point(voxel_map_problem, ctx, 
     both(vctx, vp["inits"], opts, force=False)
 
 
+def test_voxel_map_batch_of_48_full_scans_properties(voxel_map_problem, pkg, synth):
+    """Size-independent properties of the bench's code path at a size the oracle does not finish in seconds: 48 full 64 x 1800
+    scans (21 600 blocks, 5.5 M points per sweep) in one batch against the voxel map, certificate sweep on (picked by size).
+    (a) two runs give the same bits (no atomics in any sum); (b) a scan's result does not depend on what it is batched with:
+    the first 24 alone == the first 24 of the 48, bit for bit, and chunked 16 at a time likewise; (c) against searching
+    every point: same iteration and row counts for every scan, poses to rounding; (d) every scan converges to within 5 cm of
+    where it was taken."""
+    import importlib as il
+    synth_gpu = il.import_module("synth_gpu")
+    vp = voxel_map_problem
+    ctx = vp["ctx"]
+    world = synth.World(half_extent=300.0, wall_half=295.0, pole_pitch=2.5)
+    lidar = synth_gpu.GpuLidar(world, 0)
+    traj = synth_gpu.loop_trajectory(10000)[-4000::10]
+    rng = np.random.default_rng(77)
+    scans, inits, gts = [], [], []
+    for k in range(48):
+        g = traj[-120 + int(rng.integers(-12, 12))].copy()
+        g[3:5] += rng.uniform(-1.0, 1.0, 2)
+        g[2] += rng.uniform(-0.2, 0.2)
+        scans.append(lidar.scan(g, 64, 1800, seed=8000 + k))
+        gts.append(g.astype(np.float32))
+        inits.append(synth.perturb_pose(g, seed=160 + k))
+    inits, gts = np.stack(inits), np.stack(gts)
+    opts = ctx.default_opts()
+    opts.scans_in_flight = 48
+    ctx.scan_set_batch(scans)
+    q0 = ctx.cert_stats()[2]
+    _, p1, s1 = ctx.run_batch(inits, opts)
+    assert ctx.cert_stats()[2] > q0  # the certificate sweep ran
+    _, p2, s2 = ctx.run_batch(inits, opts)
+    assert np.array_equal(bits(p1), bits(p2))                                                    # (a)
+    assert all(s.converged for s in s1) and np.abs(p1[:, 3:] - gts[:, 3:]).max() < 0.05        # (d)
+    assert len({s.iterations for s in s1}) > 1
+    opts.scans_in_flight = 16                                                                    # (b) chunked
+    _, p3, s3 = ctx.run_batch(inits, opts)
+    assert np.array_equal(bits(p3), bits(p1)) and [s.iterations for s in s3] == [s.iterations for s in s1]
+    import os
+    os.environ["LSLAM_KNN_CERT"] = "0"                                                           # (c)
+    try:
+        opts.scans_in_flight = 48
+        _, p0, s0 = ctx.run_batch(inits, opts)
+    finally:
+        del os.environ["LSLAM_KNN_CERT"]
+    for k in range(48):
+        assert (s0[k].iterations, s0[k].n_rows, s0[k].n_line, s0[k].n_plane) == (s1[k].iterations, s1[k].n_rows, s1[k].n_line, s1[k].n_plane), k
+    assert np.abs(p0[:, 3:] - p1[:, 3:]).max() <= 2e-6 and np.abs(p0[:, :3] - p1[:, :3]).max() <= 2e-7
+    ctx.scan_set_batch(scans[:24])                                                               # (b) another batch
+    opts.scans_in_flight = 24
+    _, p4, s4 = ctx.run_batch(inits[:24], opts)
+    assert np.array_equal(bits(p4), bits(p1[:24]))
+
+
 def test_fused_solve_equals_the_solve_launch(ctx, synth, small_problem, monkeypatch):
     """The 6 x 6 solve in the tail of the sweep launch (the block that retires the scan's last record reduces and solves) against
     the solve kernel as its own launch: same reduction order, same solve -- same bits; single scan, a small batch with a scan

@@ -271,8 +271,6 @@ def main():
             },
             "roofline": roof,
         }
-        if not args.no_single:
-            out["single_scan"] = single_scan_leg(ctx, scans[0], inits[0], opts, 200)
     # ---- disclosure leg: the same steps with every point SEARCHED in every sweep (LSLAM_KNN_CERT=0, read per call).  The
     # headline runs the library as shipped, whose certificate sweep keeps a point's five neighbours without a
     # search when the previous search's bounds prove they cannot have changed -- the same neighbours, hence the same residuals
@@ -319,6 +317,8 @@ def main():
                 "rows_equal": bool(all((a.n_rows, a.n_line, a.n_plane) == (b.n_rows, b.n_line, b.n_plane) for a, b in zip(sts0, sts1))),
             })
             out["certificate_sweep"] = cert
+    if rank == 0 and not args.no_single:  # (replaces the resident scans: after every leg that runs the step's batch)
+        out["single_scan"] = single_scan_leg(ctx, scans[0], inits[0], opts, 200)
     # ---- the same timed region on 16-ring x 1800 scans (VLP-16, MultiScanRegistration.h:90-92; BASELINE north star:
     # "throughput on synthetic 16- and 64-ring scans") -- every rank, same protocol, its own roofline object
     if not args.no_vlp16:

@@ -392,6 +392,7 @@ struct lslam_fmap {
   Buf<int32_t> d_cells[2];
   Buf<lslam::TreeView> d_views[2];
   int64_t trees_built = 0, trees_reused = 0;  // statistics of the last lslam_fmap_to_cubemap
+  int forest_attempt0 = 0;                     // node-slot guess the last forest build succeeded with (lslam_fmap_to_cubemap)
 };
 
 namespace {
@@ -1002,14 +1003,20 @@ int lslam_fmap_to_cubemap(lslam_fmap *fm) {
     std::vector<lslam::TreeView> built((size_t)T);
     int fallback = 0, max_depth = 0;
     size_t n_leaves = 0;
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    // node slots: the guess that worked last time first (a guess that is too small costs a whole failed build and a second
+    // gather: with 2/3 slot per point every frame of the bench map built its forest twice)
+    const int first_attempt = fm->forest_attempt0;
+    for (int attempt = first_attempt; attempt < 3; ++attempt) {
       const size_t mult[3] = {2, 8, 24};
       const size_t cap = ((mult[attempt] * total / 3 + 64 + 8 * (size_t)T) + 7) & ~(size_t)7;
       FM_TRY(g->nodes.reserve(cap));
-      if (attempt > 0) FM_TRY(gather());  // the failed attempt permuted the points: gather them again
+      if (attempt > first_attempt) FM_TRY(gather());  // the failed attempt permuted the points: gather them again
       FM_TRY(lslam::build_kdforest_device(g->pts.p, (int32_t)total, roots_lr.data(), T, g->nodes.p, nullptr, (int32_t)cap, s,
                                           built.data(), &max_depth, &n_leaves, &fallback));
-      if (fallback != 1) break;
+      if (fallback != 1) {
+        fm->forest_attempt0 = attempt;
+        break;
+      }
     }
     if (fallback) {
       lslam::set_error("device cube-tree build hit a structure limit");

@@ -1748,7 +1748,10 @@ void treebuild_release_scratch(hipStream_t s) {
 namespace {
 // Phase 0 driver: processes `level` (every entry more than HUGE_MIN points) and the levels it
 // spawns; smaller children land in A.queue / A.sublist.  n = points the trees span in total.
-hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t n, hipStream_t stream, int *fallback, const RootInit *root_init = nullptr) {
+// n: points of all roots together (capacities); n_largest: of the largest root (how many levels the first batch enqueues)
+hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t n, hipStream_t stream, int *fallback, const RootInit *root_init = nullptr,
+                      int32_t n_largest = 0) {
+  if (n_largest <= 0) n_largest = n;
   hipError_t e;
   void *lv_blob = nullptr;
   const int n_first = root_init ? 1 : (int)level.size();
@@ -1809,7 +1812,9 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
     // nanoflann splits at the middle of the box, not at the median: the trees of a voxel map need ~4 levels more than a
     // balanced one would (13 for the 587 k-point surface cloud) -- an exhausted level costs seven empty launches (~25 us), a
     // second batch a host round trip on top of its levels
-    const int per_batch = batch == 0 ? std::max(2, (int)std::ceil(std::log2(std::max(2.0, (double)n / HUGE_MIN))) + 4) : 3;
+    // (a forest's levels are as many as its LARGEST tree needs: sized by all its points together, the 22 cube trees of a
+    // mapping frame were given 13 levels and used 7 -- six times seven empty launches, 0.2 ms)
+    const int per_batch = batch == 0 ? std::max(2, (int)std::ceil(std::log2(std::max(2.0, (double)n_largest / HUGE_MIN))) + 4) : 3;
     for (int k = 0; k < per_batch; ++k, ++lvl) {
       LvArgs L{};
       L.A = A;
@@ -2119,7 +2124,9 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
     return e;
   if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;  // locals
   if (!level.empty()) {
-    if ((e = run_levels(A, level, n_total, stream, fallback)) != hipSuccess) return e;
+    int32_t n_largest = 0;
+    for (const BuildItem &it : level) n_largest = std::max(n_largest, it.r - it.l);
+    if ((e = run_levels(A, level, n_total, stream, fallback, nullptr, n_largest)) != hipSuccess) return e;
     if (*fallback) return hipSuccess;
   }
   int dev = 0, cus = 256;

@@ -368,7 +368,9 @@ hipError_t sweep_launch(lslam_ctx *ctx, const SweepArgs &a, int jtj_mode, hipEve
   int v = -1;
   // certificate sweep: from the second sweep of a loop a second launch searches the points pass 1 listed (sweep_body); the
   // pair is timed as one
-  const bool two_pass = a.prev_q && a.need_cnt && a.bounded && a.prev_valid && !a.tail.count && !a.gc.trees;
+  // (n_groups > 0: the two counter pairs of the plan alternate per LAUNCHED plan -- each zeroes the other's -- so a sweep
+  // with nothing to plan must not advance them)
+  const bool two_pass = a.prev_q && a.need_cnt && a.bounded && a.prev_valid && !a.tail.count && !a.gc.trees && a.n_groups > 0 && a.nb_total > 0;
   hipError_t e = launch_sweep(a, jtj_mode, ctx->stream, e0, two_pass ? nullptr : e1, &v);
   if (v >= 0 && v < SWEEP_N_VARIANTS) ctx->sweep_variants[v]++;
   if (variant) *variant = v;

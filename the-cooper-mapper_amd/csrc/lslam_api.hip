@@ -1430,6 +1430,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
       sa.tail.sp.delta_t_abort = so.delta_t_abort;
       sa.tail.sp.eig_thresh = so.eig_thresh;
     }
+    bool cert_counters_reset = false;
     auto enqueue = [&](int c, int iters) -> int {
       const int p0 = c * in_flight, p1 = std::min(n_scans, p0 + in_flight);
       const int32_t fb = ctx->h_probs[(size_t)p0].first_block;
@@ -1442,6 +1443,10 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
       // device at once ends when its slowest wavefront does, certificates or not, and the second pass is two launches more
       // per iteration (measured on single scans: 0.29 against 0.26 ms per loop).  LSLAM_KNN_CERT=2 takes it regardless (tests)
       if (sc.prev_q && !sc.tail.count && (force_cert || (long)sc.nb_total * (SWEEP_BLOCK / 64) > 2 * 1024)) {
+        if (!cert_counters_reset) {  // once per call: whatever an earlier call that ended in an error left in the plan's counters
+          HIP_TRY(hipMemsetAsync(ctx->cert_count.p, 0, 4 * sizeof(int32_t), ctx->stream));
+          cert_counters_reset = true;
+        }
         sc.need_list = ctx->need_list.p + (size_t)fb * SWEEP_BLOCK;
         sc.need_cnt = ctx->need_cnt.p + fb;
         sc.groups = ctx->groups.p + ctx->h_prob_group0[(size_t)p0];

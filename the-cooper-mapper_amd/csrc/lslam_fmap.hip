@@ -493,7 +493,8 @@ int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t
 // sorted bit range; real cube ids are < ncube <= 2^bits - 1 only if ncube is not a power of two...
 // so one more bit is reserved (cube_bits(ncube + 1)).
 
-int refresh_segments(lslam_fmap *fm, int t) {
+// wait = false: the caller waits for the stream itself before it reads h_begin / h_end (both feature types behind one wait)
+int refresh_segments(lslam_fmap *fm, int t, bool wait = true) {
   if (fm->seg_current[t]) return LSLAM_OK;
   hipStream_t s = fm->stream;
   FM_TRY(fm->seg_begin[t].reserve(fm->ncube));
@@ -507,7 +508,7 @@ int refresh_segments(lslam_fmap *fm, int t) {
   fm->h_end[t].resize(fm->ncube);
   FM_TRY(hipMemcpyAsync(fm->h_begin[t].data(), fm->seg_begin[t].p, sizeof(int32_t) * fm->ncube, hipMemcpyDeviceToHost, s));
   FM_TRY(hipMemcpyAsync(fm->h_end[t].data(), fm->seg_end[t].p, sizeof(int32_t) * fm->ncube, hipMemcpyDeviceToHost, s));
-  FM_TRY(hipStreamSynchronize(s));
+  if (wait) FM_TRY(hipStreamSynchronize(s));
   fm->seg_current[t] = true;
   return LSLAM_OK;
 }
@@ -915,11 +916,12 @@ int lslam_fmap_to_cubemap(lslam_fmap *fm) {
   // live in one list; CubeTree::gen indexes it for both feature types.
   std::vector<lslam_fmap::Generation *> &gens = fm->gens;
   for (int t = 0; t < 2; ++t) {
-    rc = refresh_segments(fm, t);
+    rc = refresh_segments(fm, t, false);
     if (rc) return rc;
     fm->cube_tree[t].resize((size_t)fm->ncube);
     fm->dirty[t].resize((size_t)fm->ncube, 1);
   }
+  FM_TRY(hipStreamSynchronize(s));  // both types' segment tables are on the host
   // compaction: too many generations alive means many half-empty arrays -- drop every tree, the active area is
   // rebuilt into one generation below
   if (gens.size() > 12) {
@@ -997,8 +999,7 @@ int lslam_fmap_to_cubemap(lslam_fmap *fm) {
         seg0 += src[t].size();
       }
     }
-    FM_TRY(gather());
-    FM_TRY(hipStreamSynchronize(s));  // src/dst are locals
+    FM_TRY(gather());  // (src / dst: pageable sources are consumed when hipMemcpyAsync returns, no wait needed)
     const auto t2 = now();
     std::vector<lslam::TreeView> built((size_t)T);
     int fallback = 0, max_depth = 0;

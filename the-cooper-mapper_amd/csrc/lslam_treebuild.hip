@@ -1641,10 +1641,14 @@ __global__ __launch_bounds__(64) void kd_root_kernel(BuildArgs A, RootInit R) {
   }
 }
 
-// one workgroup per root: bounding box of its own point range (computeBoundingBox, :1406-1427)
+// FOREST_SLICES workgroups per root: bounding box of a slice of its point range (computeBoundingBox, :1406-1427); the
+// slices' boxes are merged where they are used (kd_forest_box)
+constexpr int FOREST_SLICES = 8;
 __global__ __launch_bounds__(256) void kd_bbox_seg_kernel(const float4 *pts, const int32_t *roots_lr, float *out) {
   __shared__ float smin[3][4], smax[3][4];
-  const int l = roots_lr[2 * blockIdx.x], r = roots_lr[2 * blockIdx.x + 1];
+  const int l0 = roots_lr[2 * blockIdx.x], r0 = roots_lr[2 * blockIdx.x + 1];
+  const int per = (r0 - l0 + FOREST_SLICES - 1) / FOREST_SLICES;
+  const int l = l0 + (int)blockIdx.y * per, r = min(r0, l + per);
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   for (int i = l + threadIdx.x; i < r; i += 256) {
     const float4 p = pts[i];
@@ -1662,8 +1666,40 @@ __global__ __launch_bounds__(256) void kd_bbox_seg_kernel(const float4 *pts, con
     const int d = threadIdx.x;
     float a = smin[d][0], b = smax[d][0];
     for (int w = 1; w < 4; ++w) { a = fminf(a, smin[d][w]); b = fmaxf(b, smax[d][w]); }
-    out[blockIdx.x * 6 + d] = a;
-    out[blockIdx.x * 6 + 3 + d] = b;
+    out[(blockIdx.x * FOREST_SLICES + blockIdx.y) * 6 + d] = a;
+    out[(blockIdx.x * FOREST_SLICES + blockIdx.y) * 6 + 3 + d] = b;
+  }
+}
+__device__ __forceinline__ void kd_forest_box(const float *part, int t, float (&lo)[3], float (&hi)[3]) {
+  for (int d = 0; d < 3; ++d) { lo[d] = FLT_MAX; hi[d] = -FLT_MAX; }
+  for (int k = 0; k < FOREST_SLICES; ++k)
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = fminf(lo[d], part[(t * FOREST_SLICES + k) * 6 + d]);
+      hi[d] = fmaxf(hi[d], part[(t * FOREST_SLICES + k) * 6 + 3 + d]);
+    }
+}
+// The roots of a forest are made on the host WITHOUT their boxes (which would cost a round trip at the head of the build):
+// root item j of tree t = -1 - parent_word gets its box -- and, as a level item, its extrema: a root's bounding box IS its
+// extrema -- here; threads [n_items, n_items + T) write the trees' boxes for the views (read back at the end of the build).
+__global__ __launch_bounds__(256) void kd_forest_patch_kernel(const float *part, BuildItem *items, LvStat *stat, int n_items, float *bb, int T) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  float lo[3], hi[3];
+  if (j < n_items) {
+    const int t = -1 - items[j].parent_word;
+    kd_forest_box(part, t, lo, hi);
+    for (int d = 0; d < 3; ++d) { items[j].lo[d] = lo[d]; items[j].hi[d] = hi[d]; }
+    if (stat) {
+      LvStat st;
+      for (int d = 0; d < 3; ++d) { st.mn[d] = ord_i(lo[d]); st.mx[d] = ord_i(hi[d]); }
+      lv_stat_reset(st);
+      for (int c = 0; c < 2; ++c)
+        for (int d = 0; d < 3; ++d) { st.cmn[c][d] = 0; st.cmx[c][d] = 0; }
+      stat[j] = st;
+    }
+  } else if (bb && j < n_items + T) {
+    const int t = j - n_items;
+    kd_forest_box(part, t, lo, hi);
+    for (int d = 0; d < 3; ++d) { bb[t * 6 + d] = lo[d]; bb[t * 6 + 3 + d] = hi[d]; }
   }
 }
 
@@ -1750,7 +1786,7 @@ namespace {
 // spawns; smaller children land in A.queue / A.sublist.  n = points the trees span in total.
 // n: points of all roots together (capacities); n_largest: of the largest root (how many levels the first batch enqueues)
 hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t n, hipStream_t stream, int *fallback, const RootInit *root_init = nullptr,
-                      int32_t n_largest = 0) {
+                      int32_t n_largest = 0, const float *forest_part = nullptr) {
   if (n_largest <= 0) n_largest = n;
   hipError_t e;
   void *lv_blob = nullptr;
@@ -1800,6 +1836,10 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
   if ((e = hipMemcpyAsync(d_items[0], level.data(), (size_t)n_first * sizeof(BuildItem), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(d_stat[0], stat0.data(), (size_t)n_first * sizeof(LvStat), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(d_small, init, sizeof(init), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+  // a forest's roots arrive without their boxes: filled in from the per-slice boxes, with the extrema (kd_forest_patch_kernel)
+  if (forest_part)
+    hipLaunchKernelGGL(kd_forest_patch_kernel, dim3((n_first + 255) / 256), dim3(256), 0, stream, forest_part, d_items[0], d_stat[0], n_first,
+                       (float *)nullptr, 0);
   }
   // Levels are enqueued in batches without looking at their outcome (grids at capacity, exhausted
   // levels cost a handful of empty launches); the host checks the item count once per batch.
@@ -2050,7 +2090,7 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   const size_t sz_queue = (size_t)queue_cap * sizeof(BuildItem), sz_ready = (size_t)queue_cap * sizeof(int32_t),
                sz_tmp = (size_t)std::max(n_total, 1) * sizeof(int32_t), sz_ctl = 256, sz_sub = (size_t)sub_cap * sizeof(BuildItem),
                sz_rf = ((size_t)T * 4 + 15) & ~(size_t)15, sz_lr = ((size_t)T * 8 + 15) & ~(size_t)15,
-               sz_bb = ((size_t)T * 24 + 15) & ~(size_t)15, sz_own = d_pn ? (size_t)A.node_cap * 6 * sizeof(float) : 0;
+               sz_bb = ((size_t)T * 24 * (1 + FOREST_SLICES) + 15) & ~(size_t)15, sz_own = d_pn ? (size_t)A.node_cap * 6 * sizeof(float) : 0;
   const bool tiny_phase = tiny_phase_enabled() && A.reg_nodes;
   const int32_t tiny_cap = tiny_phase ? n_total / 11 + 2 : 0;
   const size_t sz_tiny = tiny_phase ? ((size_t)tiny_cap * sizeof(BuildItem) + TINY_ACC * 128 + 127) & ~(size_t)127 : 0;
@@ -2065,7 +2105,9 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   A.ctl = reinterpret_cast<BuildCtl *>(p); p += sz_ctl;
   A.root_feat = reinterpret_cast<int32_t *>(p); p += sz_rf;
   int32_t *d_lr = reinterpret_cast<int32_t *>(p); p += sz_lr;
-  float *d_bb = reinterpret_cast<float *>(p); p += sz_bb;
+  float *d_bb = reinterpret_cast<float *>(p);  // [T][6] the roots' boxes, then [T][FOREST_SLICES][6] their slices'
+  float *d_part = d_bb + (size_t)T * 6;
+  p += sz_bb;
   p = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(p) + 127) & ~(uintptr_t)127);
   A.tiny_acc = tiny_phase ? reinterpret_cast<int32_t *>(p) : nullptr;
   A.tiny_list = tiny_phase ? reinterpret_cast<BuildItem *>(p + TINY_ACC * 128) : nullptr;
@@ -2075,12 +2117,11 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   A.own_box = d_pn ? reinterpret_cast<float *>(p) : nullptr;
   A.spin_limit = 1u << 22;
   if ((e = hipMemcpyAsync(d_lr, roots_lr, (size_t)T * 8, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL(kd_bbox_seg_kernel, dim3(T), dim3(256), 0, stream, d_pts, d_lr, d_bb);
-  std::vector<float> bb((size_t)T * 6);
-  if ((e = hipMemcpyAsync(bb.data(), d_bb, bb.size() * 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+  // per-slice boxes of every root; nobody waits for them: the root items are made below without their boxes and patched
+  // on the device, the views get theirs with the read-back at the end of the build
+  hipLaunchKernelGGL(kd_bbox_seg_kernel, dim3(T, FOREST_SLICES), dim3(256), 0, stream, d_pts, d_lr, d_part);
   if ((e = hipMemsetAsync(d_nodes, 0, (size_t)A.node_cap * sizeof(KdNode), stream)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(A.root_feat, 0, sz_rf, stream)) != hipSuccess) return e;
-  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
   std::vector<BuildItem> level, small;
   std::vector<int32_t> slot_of(T, -1);
   int groups = 0, leaves = 0;
@@ -2092,7 +2133,7 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
     v.pts = d_pts;
     v.n_pts = n;
     v.n_nodes = 0;
-    for (int d = 0; d < 3; ++d) { v.bb_lo[d] = n > 0 ? bb[(size_t)t * 6 + d] : 0.f; v.bb_hi[d] = n > 0 ? bb[(size_t)t * 6 + 3 + d] : 0.f; }
+    for (int d = 0; d < 3; ++d) { v.bb_lo[d] = 0.f; v.bb_hi[d] = 0.f; }  // (from the device at the end)
     if (n <= 10) {  // the root is a leaf (nanoflann.hpp:936-951)
       v.root_ref = KD_LEAF | ((uint32_t)l << 4) | (uint32_t)std::max(n, 0);
       if (n > 0) { ++leaves; *max_depth = std::max(*max_depth, 1); }
@@ -2101,7 +2142,7 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
     BuildItem it{};
     it.l = l;
     it.r = r;
-    for (int d = 0; d < 3; ++d) { it.lo[d] = v.bb_lo[d]; it.hi[d] = v.bb_hi[d]; }
+    for (int d = 0; d < 3; ++d) { it.lo[d] = 0.f; it.hi[d] = 0.f; }  // kd_forest_patch_kernel
     it.slot = groups * 8;
     it.heap = 0;
     it.parent_word = -1 - t;
@@ -2119,14 +2160,17 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   ctl.n_sub = (int32_t)small.size();
   ctl.n_leaves = leaves;
   if ((e = hipMemcpyAsync(A.ctl, &ctl, sizeof(ctl), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+  // (pageable sources: consumed when hipMemcpyAsync returns, no wait needed)
   if (!small.empty() &&
       (e = hipMemcpyAsync(A.sublist, small.data(), small.size() * sizeof(BuildItem), hipMemcpyHostToDevice, stream)) != hipSuccess)
     return e;
-  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;  // locals
+  // the wavefront-local roots' boxes, and every tree's box for its view
+  hipLaunchKernelGGL(kd_forest_patch_kernel, dim3(((int)small.size() + T + 255) / 256), dim3(256), 0, stream, d_part, A.sublist, (LvStat *)nullptr,
+                     (int)small.size(), d_bb, T);
   if (!level.empty()) {
     int32_t n_largest = 0;
     for (const BuildItem &it : level) n_largest = std::max(n_largest, it.r - it.l);
-    if ((e = run_levels(A, level, n_total, stream, fallback, nullptr, n_largest)) != hipSuccess) return e;
+    if ((e = run_levels(A, level, n_total, stream, fallback, nullptr, n_largest, d_part)) != hipSuccess) return e;
     if (*fallback) return hipSuccess;
   }
   int dev = 0, cus = 256;
@@ -2136,8 +2180,10 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   if (tiny_phase) hipLaunchKernelGGL(kd_build_tiny_kernel, dim3(std::min(cus * 64, (tiny_cap + TINY_SLOTS - 1) / TINY_SLOTS)), dim3(64), 0, stream, A);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   std::vector<int32_t> rf(T);
+  std::vector<float> bb((size_t)T * 6);
   if ((e = hipMemcpyAsync(&ctl, A.ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(rf.data(), A.root_feat, (size_t)T * 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(bb.data(), d_bb, bb.size() * 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
   int32_t acc[TINY_ACC * 32];
   if (tiny_phase && (e = hipMemcpyAsync(acc, A.tiny_acc, sizeof(acc), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
   if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
@@ -2156,6 +2202,8 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   for (int t = 0; t < T; ++t) {
     views[t].n_nodes = n_nodes;
     if (slot_of[t] >= 0) views[t].root_ref = ((uint32_t)slot_of[t] << 2) | (uint32_t)rf[t];
+    if (views[t].n_pts > 0)
+      for (int d = 0; d < 3; ++d) { views[t].bb_lo[d] = bb[(size_t)t * 6 + d]; views[t].bb_hi[d] = bb[(size_t)t * 6 + 3 + d]; }
   }
   *max_depth = std::max(*max_depth, ctl.max_depth);
   *n_leaves = (size_t)ctl.n_leaves;

@@ -575,6 +575,12 @@ void lslam_debug_sweep_launches(lslam_ctx *ctx, uint64_t counts[8]);
  * context since its creation; out[0] = points the certificate-testing workgroups left to the second pass and out[1] = points
  * of those workgroups, counted only when the process runs with LSLAM_DEBUG_CERT_STATS=1 (two atomics per workgroup). */
 void lslam_debug_cert_stats(lslam_ctx *ctx, uint64_t out[3]);
+/* Test tap: what the certificate sweep carries per resident scan point after a lslam_scanmatch_run* that ran it -- the
+ * map-frame position of the point's last SEARCH (q_xyz0: 4 floats per point, the fourth unused) and the lower bound taken
+ * there of the squared distance of every map point outside its five neighbours (lb; 0: none).  Resident order: per scan its
+ * corner points, then its surf points (each in the library's own order).  Returns the number of points copied (at most
+ * cap_points) or a negative status. */
+int lslam_debug_cert_state(lslam_ctx *ctx, float *q_xyz0, float *lb, size_t cap_points);
 
 #ifdef __cplusplus
 }

@@ -304,6 +304,39 @@ def test_certificate_sweep_equals_searching_every_point(voxel_map_problem, ctx, 
     both(vctx, vp["inits"], opts, force=False)
 
 
+def test_the_bound_a_search_keeps_is_below_the_true_sixth_distance(ctx, small_problem, monkeypatch):
+    """The soundness of a certificate rests on one number per point: the lower bound `lb6` of the squared distance of every
+    map point outside the five neighbours, which knn5_search<TRACK> collects from the subtrees it does not enter and the
+    candidates it turns away.  After loops that ran the certificate sweep, every resident point's bound is held against the
+    truth -- the sixth-nearest map point of the position the bound was taken at (scipy's cKDTree on the same map): never
+    above it.  And the bounds are worth something: most are within a few per cent of it."""
+    from scipy.spatial import cKDTree
+    pr = small_problem
+    nc, ns = len(pr["corner"]), len(pr["surf"])
+    trees = (cKDTree(pr["map_corner"][:, :3].astype(np.float64)), cKDTree(pr["map_surf"][:, :3].astype(np.float64)))
+    monkeypatch.setenv("LSLAM_KNN_CERT", "2")
+    ctx.map_set(pr["map_corner"], pr["map_surf"])
+    ctx.scan_set(pr["corner"], pr["surf"])
+    for env, iters in ((None, 2), (None, 10), ("1e9", 10)):  # after one tracked sweep; a whole loop; every sweep testing certificates
+        if env:
+            monkeypatch.setenv("LSLAM_CERT_TRY_M", env)
+            monkeypatch.setenv("LSLAM_CERT_TRACK_M", env)
+        o = ctx.default_opts()
+        o.max_iterations = iters
+        o.search_mode = LANE | SHALLOW
+        status, pose, st = ctx.run(pr["init_pose"], o)
+        q, lb = ctx.cert_state(nc + ns)
+        assert len(lb) == nc + ns and (lb > 0).mean() > 0.9
+        tight = []
+        for tree, sl in ((trees[0], slice(0, nc)), (trees[1], slice(nc, nc + ns))):
+            d, _ = tree.query(q[sl].astype(np.float64), k=6)
+            d6sq = d[:, 5] ** 2
+            have = lb[sl] > 0
+            assert (lb[sl][have] <= d6sq[have] * (1 + 1e-5) + 1e-9).all(), float((lb[sl][have] / d6sq[have]).max())
+            tight.append(lb[sl][have] / d6sq[have])
+        assert np.median(np.concatenate(tight)) > 0.8
+
+
 def test_voxel_map_batch_of_48_full_scans_properties(voxel_map_problem, pkg, synth):
     """Size-independent properties of the bench's code path at a size the oracle does not finish in seconds: 48 full 64 x 1800
     scans (21 600 blocks, 5.5 M points per sweep) in one batch against the voxel map, certificate sweep on (picked by size).

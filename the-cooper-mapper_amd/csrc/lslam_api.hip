@@ -525,6 +525,16 @@ void lslam_debug_cert_stats(lslam_ctx *ctx, uint64_t out[3]) {  // out[0], out[1
   out[2] = ctx->queue_launches;
 }
 
+// what the certificate sweep carries per resident scan point (resident order: per scan its corner points, then its surf points)
+int lslam_debug_cert_state(lslam_ctx *ctx, float *q_xyz0, float *lb, size_t cap_points) {
+  if (!ctx || !ctx->prev_q.p || !ctx->prev_lb.p) return LSLAM_ERR_INVALID;
+  const size_t n = std::min(cap_points, ctx->n_points);
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return LSLAM_ERR_HIP;
+  if (n && q_xyz0 && hipMemcpy(q_xyz0, ctx->prev_q.p, n * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) return LSLAM_ERR_HIP;
+  if (n && lb && hipMemcpy(lb, ctx->prev_lb.p, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return LSLAM_ERR_HIP;
+  return (int)n;
+}
+
 void lslam_debug_sweep_launches(lslam_ctx *ctx, uint64_t counts[8]) {
   for (int i = 0; i < 8; ++i) counts[i] = ctx ? ctx->sweep_variants[i] : 0;
 }

@@ -117,6 +117,15 @@ class Context:
         self.lib.lslam_debug_cert_stats(self.h, out)
         return int(out[0]), int(out[1]), int(out[2])
 
+    def cert_state(self, n_points):
+        """lslam_debug_cert_state: (positions of the last searches [n, 3], bounds [n]) of the resident scan points."""
+        q = np.zeros((n_points, 4), np.float32)
+        lb = np.zeros(n_points, np.float32)
+        n = self.lib.lslam_debug_cert_state(self.h, q.ctypes.data_as(C.POINTER(C.c_float)), lb.ctypes.data_as(C.POINTER(C.c_float)), n_points)
+        if n < 0:
+            raise RuntimeError("lslam_debug_cert_state: %d" % n)
+        return q[:n, :3], lb[:n]
+
     # -- map / scan ----------------------------------------------------------
     def map_set(self, corner, surf):
         c, sc = _cloud(corner)

@@ -70,6 +70,18 @@ for seed in range(n_seeds):
         ran = ctx.cert_stats()[2] - q0
         for k in env:
             del os.environ[k]
+        # the bound every point carries for its next certificate: never above the true sixth squared distance of the position
+        # it was taken at (scipy's kd-tree on the same map)
+        from scipy.spatial import cKDTree
+        nqc, nqs = len(pr["corner"]), len(pr["surf"])
+        cq, clb = ctx.cert_state(nqc + nqs)
+        for tree_pts, sl in ((mc, slice(0, nqc)), (ms, slice(nqc, nqc + nqs))):
+            if len(tree_pts) < 6 or sl.stop == sl.start:
+                continue
+            d6 = cKDTree(tree_pts[:, :3].astype(np.float64)).query(cq[sl].astype(np.float64), k=6)[0][:, 5] ** 2
+            have = clb[sl] > 0
+            if have.any() and not (clb[sl][have] <= d6[have] * (1 + 1e-5) + 1e-9).all():
+                bad += 1; print("seed", seed, "certificate sweep", env, "a kept bound exceeds the true sixth distance by", float((clb[sl][have] / d6[have]).max()))
         if st.iterations != ost.iterations or abs(st.n_rows - ost.n_rows) > 2 or np.abs(pose[3:] - poses[1][3:]).max() > 5e-6 or np.abs(pose[:3] - poses[1][:3]).max() > 5e-7 or (st.iterations > 1 and ran == 0):
             bad += 1; print("seed", seed, "certificate sweep", env, "differs", st.iterations, ost.iterations, st.n_rows, ost.n_rows, np.abs(pose - poses[1]).max(), ran)
     print("seed %2d rings %2d steps %3d half %3.0f map %6d+%6d scan %5d: %s" % (seed, rings, steps, half, len(mc), len(ms), len(pr["corner"]) + len(pr["surf"]), "ok" if not bad else "MISMATCH"), flush=True)

@@ -837,7 +837,11 @@ int oracle_corner_coeff(const float A[3], const float B[3], const float X[3], fl
   float den = nn * lengthAB;
   float dir[3] = {cr[0] / den, cr[1] / den, cr[2] / den};
   float distance = nn / lengthAB;
-  float weight = 1 - 0.9f * fabsf(distance);
+  /* feature_utils.h:70 `1 - 0.9f * fabs(distance)`: `fabs` is unqualified and non-dependent inside a template of namespace
+   * lidar_slam with only <cmath> in sight, so it binds to ::fabs(double) at the template's definition (g++ 5 .. 11 probed:
+   * sizeof(fabs(float)) == 8; `using std::fabs` in ScanMatch.cpp:16 comes later and does not reach it) -- the expression is
+   * evaluated in double and rounded once on the assignment to float */
+  float weight = (float)(1 - (double)0.9f * fabs((double)distance));
   coeff[0] = dir[0] * weight;
   coeff[1] = dir[1] * weight;
   coeff[2] = dir[2] * weight;

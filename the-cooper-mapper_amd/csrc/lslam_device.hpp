@@ -1023,7 +1023,9 @@ LSLAM_DEV bool corner_coeff(const float (&A)[3], const float (&B)[3], const floa
   cross3(mn, BA, cr);
   const float den = nn * lengthAB;
   const float distance = nn / lengthAB;
-  const float weight = 1 - 0.9f * fabsf(distance);
+  // `1 - 0.9f * fabs(distance)` with ::fabs(double) -- the overload the reference's template binds (oracle/lslam_oracle.c,
+  // corner_coefficients): evaluated in double, rounded once
+  const float weight = (float)(1.0 - (double)0.9f * fabs((double)distance));
   coeff[0] = (cr[0] / den) * weight;
   coeff[1] = (cr[1] / den) * weight;
   coeff[2] = (cr[2] / den) * weight;

@@ -52,6 +52,17 @@ constexpr int TB_SMALL = 64;
 constexpr int TE = 8;              // consecutive elements per thread in the partition scans
 constexpr int LOCAL_MAX = LSLAM_LOCAL_MAX;    // subtrees up to this many points are built by one wavefront
 constexpr int LOCAL_STACK = KD_STACK_MAX;  // pending siblings along one root-to-leaf path: a deeper tree is refused anyway
+// Round 3: the level phase hands a node on as soon as it has at most BuildArgs::huge_min points; what is still above
+// LOCAL_MAX then is finished by ONE workgroup per such node (kd_build_medium_kernel).  From its ninth level on the chain of
+// seven launches per level of a big tree was kept alive by a handful of stragglers.  Measured on the bench's surround
+// (157 k + 587 k points; same box): 1 536 (the chain to the end) 1.216 ms, 8 192 1.125, 16 384 1.265, 32 768 1.625 -- a
+// workgroup works its node's descendants off one after the other, which the levels do side by side; for the cube forest
+// (22 trees, 319 k points) the chain to the end stays best (0.876 / 0.908 / 0.980 / 1.409 ms) and is what it takes.
+#ifndef LSLAM_HUGE_MIN
+#define LSLAM_HUGE_MIN 8192
+#endif
+constexpr int HUGE_MIN_TREE = LSLAM_HUGE_MIN;  // single trees (LSLAM_HUGE_MIN in the environment overrides; LOCAL_MAX: no medium phase)
+constexpr int HUGE_MIN_MAX = 32768;            // sizes the medium phase's stack
 
 struct BuildItem {   // one pending inner node
   int32_t l, r;      // point range
@@ -82,6 +93,7 @@ struct BuildArgs {
   BuildItem *queue;
   int32_t *q_ready;   // per queue entry
   int32_t queue_cap;
+  int32_t huge_min;   // nodes above this many points go level by level; what the levels leave above LOCAL_MAX, through the medium phase
   BuildItem *sublist;  // phase B work list (subtree roots with <= LOCAL_MAX points)
   int32_t sub_cap;
   int32_t *tmpA, *tmpB;  // scratch, one int per point
@@ -515,6 +527,51 @@ __global__ __launch_bounds__(TB_BIG) void kd_build_big_kernel(BuildArgs A) {
       atomicSub(&A.ctl->q_pending, 1);  // this node is done
     }
     __syncthreads();
+  }
+}
+
+// Medium phase (round 3): the nodes the level phase left between LOCAL_MAX and HUGE_MIN points (queue entries [0, tail), all
+// there before this launch) -- workgroup w takes entries w, w + grid, ... and finishes each subtree down to the wavefront-local
+// size by itself, depth first from a stack in LDS: process_node after process_node behind workgroup barriers, no queue, no
+// polling, no agent-scope fences (phase A's global queue with 40 roots and their descendants in flight measured 3.1 against
+// 1.35 ms).  Pending siblings are disjoint ranges of more than LOCAL_MAX points each: at most huge_min / LOCAL_MAX + 1 of them.
+constexpr int MED_STACK = HUGE_MIN_MAX / LOCAL_MAX + 4;
+__global__ __launch_bounds__(TB_BIG) void kd_build_medium_kernel(BuildArgs A) {
+  constexpr int TB = TB_BIG;
+  __shared__ Sh<TB> sh;
+  __shared__ BuildItem stack[MED_STACK];
+  __shared__ int sp;
+  const int tid = threadIdx.x;
+  const int tail = min(A.ctl->q_tail_reserved, A.queue_cap);
+  for (int e = blockIdx.x; e < tail; e += gridDim.x) {
+    if (tid == 0) {
+      stack[0] = A.queue[e];
+      sp = 1;
+    }
+    __syncthreads();
+    while (sp > 0) {  // uniform: read behind a barrier, changed by thread 0 between barriers
+      const BuildItem it = stack[sp - 1];
+      __syncthreads();
+      BuildItem kids[2];
+      int nk = 0;
+      process_node<TB>(A, sh, it, kids, &nk);  // (ends with a barrier; kids / nk are thread 0's)
+      if (tid == 0) {
+        int top = sp - 1;
+        for (int c = 0; c < nk; ++c) {
+          if (kids[c].r - kids[c].l <= LOCAL_MAX) {
+            const int q = atomicAdd(&A.ctl->n_sub, 1);
+            if (q >= A.sub_cap) { A.ctl->overflow = 3; continue; }
+            A.sublist[q] = kids[c];
+          } else if (top < MED_STACK) {
+            stack[top++] = kids[c];
+          } else {
+            A.ctl->overflow = 3;
+          }
+        }
+        sp = top;
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -993,10 +1050,6 @@ __global__ __launch_bounds__(64) void kd_build_tiny_kernel(BuildArgs A) {
 // outcome is independent of scheduling.  The Hoare pairing needs the rank of every misplaced
 // element inside its node: per-chunk counts, a per-node scan of the chunk counts, then ranks
 // inside the chunk.
-#ifndef LSLAM_HUGE_MIN
-#define LSLAM_HUGE_MIN LSLAM_LOCAL_MAX
-#endif
-constexpr int HUGE_MIN = LSLAM_HUGE_MIN;  // nodes above this size go level by level; between LOCAL_MAX and this, through the phase-A queue
 constexpr int LV_CH = 4096;
 constexpr int LV_TB = 256;
 constexpr int LV_PER = LV_CH / LV_TB;  // consecutive elements per thread
@@ -1520,7 +1573,7 @@ __device__ __forceinline__ void lv_final_node(const LvArgs &L, int node) {
     ch.depth = it.depth + 1;
     ref[c] = (uint32_t)ch.slot << 2;
     const int cn = cr - cl;
-    if (cn > HUGE_MIN) {
+    if (cn > A.huge_min) {
       const int e = atomicAdd(L.next_count, 1);
       if (e < L.next_cap) {
         L.next_items[e] = ch;
@@ -1791,7 +1844,7 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
   hipError_t e;
   void *lv_blob = nullptr;
   const int n_first = root_init ? 1 : (int)level.size();
-  const int cap_nodes = n / HUGE_MIN * 2 + n_first + 8, cap_chunks = n / LV_CH + cap_nodes + 8;
+  const int cap_nodes = n / A.huge_min * 2 + n_first + 8, cap_chunks = n / LV_CH + cap_nodes + 8;
   const size_t sz_items = (size_t)cap_nodes * sizeof(BuildItem), sz_stat = (size_t)cap_nodes * sizeof(LvStat),
                sz_ci = (size_t)cap_chunks * sizeof(int32_t), sz_ni = (size_t)cap_nodes * sizeof(int32_t);
   if ((e = pool_get(stream, true, 2 * sz_items + 2 * sz_stat + 5 * sz_ci + sz_ni + (size_t)cap_chunks * sizeof(LvChunk) + 128, &lv_blob)) != hipSuccess) return e;
@@ -1854,7 +1907,7 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
     // second batch a host round trip on top of its levels
     // (a forest's levels are as many as its LARGEST tree needs: sized by all its points together, the 22 cube trees of a
     // mapping frame were given 13 levels and used 7 -- six times seven empty launches, 0.2 ms)
-    const int per_batch = batch == 0 ? std::max(2, (int)std::ceil(std::log2(std::max(2.0, (double)n_largest / HUGE_MIN))) + 4) : 3;
+    const int per_batch = batch == 0 ? std::max(2, (int)std::ceil(std::log2(std::max(2.0, (double)n_largest / A.huge_min))) + 4) : 3;
     for (int k = 0; k < per_batch; ++k, ++lvl) {
       LvArgs L{};
       L.A = A;
@@ -1965,6 +2018,10 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, float 
   A.nodes = d_nodes;
   A.node_cap = node_cap & ~7;
   A.queue_cap = queue_cap;
+  {
+    static const int env_huge = std::getenv("LSLAM_HUGE_MIN") ? std::atoi(std::getenv("LSLAM_HUGE_MIN")) : 0;  // A/B switch
+    A.huge_min = std::min(HUGE_MIN_MAX, std::max(LOCAL_MAX, env_huge > 0 ? env_huge : HUGE_MIN_TREE));
+  }
   A.n = n;
   A.reg_nodes = reg_nodes_enabled();
   A.spin_limit = 1u << 22;
@@ -2000,7 +2057,7 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, float 
   // kernel (one workgroup per node, one launch) costs device time: 0.49 against 0.62 ms at 16 k
   // points, equal at 64 k, 4.3 against 1.6 ms at 512 k (tools/tree_size_sweep.py).
   constexpr int LEVELS_MIN_POINTS = 49152;
-  const bool root_huge = n > HUGE_MIN && n > LEVELS_MIN_POINTS && !no_levels;
+  const bool root_huge = n > A.huge_min && n > LEVELS_MIN_POINTS && !no_levels;
   // control block, root item and the root's box are made on the device (kd_root_kernel): the box comes back with the control
   // block at the end of the build
   RootInit R{};
@@ -2021,9 +2078,13 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, float 
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (dbg && (e = hipStreamSynchronize(stream)) != hipSuccess) return e;  // only to split the timing below
   const double T2 = now();
-  // phase A has work only if something sits between LOCAL_MAX and HUGE_MIN, or the levels are off
-  if (!root_small && !(root_huge && HUGE_MIN == LOCAL_MAX))
+  // after the levels: what they left between LOCAL_MAX and HUGE_MIN, one workgroup per node; without levels (a root below
+  // LEVELS_MIN_POINTS): the root enters phase A's queue
+  if (root_huge) {
+    if (A.huge_min > LOCAL_MAX) hipLaunchKernelGGL(kd_build_medium_kernel, dim3(cus), dim3(TB_BIG), 0, stream, A);
+  } else if (!root_small) {
     hipLaunchKernelGGL(kd_build_big_kernel, dim3(cus), dim3(TB_BIG), 0, stream, A);
+  }
   hipLaunchKernelGGL(kd_build_small_kernel, dim3(cus * 16), dim3(TB_SMALL), 0, stream, A);
   if (tiny_phase) hipLaunchKernelGGL(kd_build_tiny_kernel, dim3(std::min(cus * 64, (tiny_cap + TINY_SLOTS - 1) / TINY_SLOTS)), dim3(64), 0, stream, A);
   if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -2078,12 +2139,13 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   if (T <= 0) return hipSuccess;
   hipError_t e;
   const int32_t sub_cap = std::max(64, 4 * (n_total / LOCAL_MAX + 16) + n_total / 8 + T);
-  const int32_t queue_cap = 64;  // unused: nothing sits between LOCAL_MAX and HUGE_MIN
+  const int32_t queue_cap = 2 * (n_total / LOCAL_MAX + 1) + T + 64;  // medium phase: roots and level-phase nodes between LOCAL_MAX and HUGE_MIN
   BuildArgs A{};
   A.pts = d_pts;
   A.nodes = d_nodes;
   A.node_cap = node_cap & ~7;
   A.queue_cap = queue_cap;
+  A.huge_min = LOCAL_MAX;  // the forest's levels run to the end (measured: see LSLAM_HUGE_MIN above); roots in between take the medium phase
   A.sub_cap = sub_cap;
   A.n = n_total;
   A.reg_nodes = reg_nodes_enabled();
@@ -2122,7 +2184,7 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   hipLaunchKernelGGL(kd_bbox_seg_kernel, dim3(T, FOREST_SLICES), dim3(256), 0, stream, d_pts, d_lr, d_part);
   if ((e = hipMemsetAsync(d_nodes, 0, (size_t)A.node_cap * sizeof(KdNode), stream)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(A.root_feat, 0, sz_rf, stream)) != hipSuccess) return e;
-  std::vector<BuildItem> level, small;
+  std::vector<BuildItem> level, medium, small;
   std::vector<int32_t> slot_of(T, -1);
   int groups = 0, leaves = 0;
   for (int t = 0; t < T; ++t) {
@@ -2149,24 +2211,31 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
     it.depth = 1;
     slot_of[t] = it.slot;
     ++groups;
-    (n > HUGE_MIN ? level : small).push_back(it);
+    (n > A.huge_min ? level : (n > LOCAL_MAX ? medium : small)).push_back(it);
   }
-  if ((groups + 1) * 8 > A.node_cap || (int32_t)small.size() > sub_cap) {
+  if ((groups + 1) * 8 > A.node_cap || (int32_t)small.size() > sub_cap || (int32_t)medium.size() > queue_cap) {
     *fallback = 1;
     return hipSuccess;
   }
   BuildCtl ctl{};
   ctl.next_group = groups;
   ctl.n_sub = (int32_t)small.size();
+  ctl.q_tail_reserved = (int32_t)medium.size();
   ctl.n_leaves = leaves;
   if ((e = hipMemcpyAsync(A.ctl, &ctl, sizeof(ctl), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
   // (pageable sources: consumed when hipMemcpyAsync returns, no wait needed)
   if (!small.empty() &&
       (e = hipMemcpyAsync(A.sublist, small.data(), small.size() * sizeof(BuildItem), hipMemcpyHostToDevice, stream)) != hipSuccess)
     return e;
-  // the wavefront-local roots' boxes, and every tree's box for its view
+  if (!medium.empty() &&
+      (e = hipMemcpyAsync(A.queue, medium.data(), medium.size() * sizeof(BuildItem), hipMemcpyHostToDevice, stream)) != hipSuccess)
+    return e;
+  // the wavefront-local roots' boxes, and every tree's box for its view; the medium roots' boxes
   hipLaunchKernelGGL(kd_forest_patch_kernel, dim3(((int)small.size() + T + 255) / 256), dim3(256), 0, stream, d_part, A.sublist, (LvStat *)nullptr,
                      (int)small.size(), d_bb, T);
+  if (!medium.empty())
+    hipLaunchKernelGGL(kd_forest_patch_kernel, dim3(((int)medium.size() + 255) / 256), dim3(256), 0, stream, d_part, A.queue, (LvStat *)nullptr,
+                       (int)medium.size(), (float *)nullptr, 0);
   if (!level.empty()) {
     int32_t n_largest = 0;
     for (const BuildItem &it : level) n_largest = std::max(n_largest, it.r - it.l);
@@ -2176,6 +2245,7 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (A.huge_min > LOCAL_MAX) hipLaunchKernelGGL(kd_build_medium_kernel, dim3(cus), dim3(TB_BIG), 0, stream, A);
   hipLaunchKernelGGL(kd_build_small_kernel, dim3(cus * 16), dim3(TB_SMALL), 0, stream, A);
   if (tiny_phase) hipLaunchKernelGGL(kd_build_tiny_kernel, dim3(std::min(cus * 64, (tiny_cap + TINY_SLOTS - 1) / TINY_SLOTS)), dim3(64), 0, stream, A);
   if ((e = hipGetLastError()) != hipSuccess) return e;

@@ -152,6 +152,25 @@ def test_device_tree_build_is_nanoflann_exact(ctx, oracle, synth, kind):
     _assert_tree_is_nanoflann_exact(ctx, oracle, pts)
 
 
+@pytest.mark.parametrize("huge_min", [1536, 4096, 32768])
+def test_device_tree_build_hand_over_sizes(ctx, oracle, monkeypatch, huge_min):
+    """The size at which the level phase hands a node to the workgroup-per-node phase (kd_build_medium_kernel, default
+    8 192 points) changes the schedule, not the tree: the chain to the end (1 536), an early and a late hand-over -- the
+    last with a dozen pending siblings on a workgroup's stack -- on a planar cloud, a lattice with '== cutval' runs
+    everywhere and a cloud with a dense corner (unbalanced splits), node by node against the oracle."""
+    monkeypatch.setenv("LSLAM_HUGE_MIN", str(huge_min))
+    rng = np.random.default_rng(23)
+    n = 150000
+    planar = np.stack([rng.uniform(-80, 80, n), rng.uniform(-80, 80, n), rng.normal(0, 0.02, n)], 1)
+    g = np.arange(-12, 12, 0.1)
+    X, Y = np.meshgrid(g, g)
+    lattice = np.concatenate([np.stack([X.ravel(), Y.ravel(), np.zeros(X.size)], 1),
+                              np.stack([np.full(X.size, 5.0), X.ravel(), Y.ravel() + 12], 1)])
+    corner = np.concatenate([rng.uniform(-100, 100, (60000, 3)), rng.normal(0, 0.5, (40000, 3)) + 90.0])
+    for pts in (planar, lattice, corner):
+        _assert_tree_is_nanoflann_exact(ctx, oracle, pts)
+
+
 def test_device_tree_build_small_and_degenerate_clouds(ctx, oracle):
     """Sizes around the 10-point leaf, the 64-point register path and its hand-over from the LDS path,
     with exact duplicates, all-equal clouds and points on a line (every '== cutval' branch of

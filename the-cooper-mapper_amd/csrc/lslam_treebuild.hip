@@ -2019,7 +2019,7 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, float 
   A.node_cap = node_cap & ~7;
   A.queue_cap = queue_cap;
   {
-    static const int env_huge = std::getenv("LSLAM_HUGE_MIN") ? std::atoi(std::getenv("LSLAM_HUGE_MIN")) : 0;  // A/B switch
+    const int env_huge = std::getenv("LSLAM_HUGE_MIN") ? std::atoi(std::getenv("LSLAM_HUGE_MIN")) : 0;  // A/B switch, read per build
     A.huge_min = std::min(HUGE_MIN_MAX, std::max(LOCAL_MAX, env_huge > 0 ? env_huge : HUGE_MIN_TREE));
   }
   A.n = n;

@@ -123,8 +123,12 @@ def main():
     if os.environ.get("LSLAM_BENCH_DRY_RUN"):  # launcher test (tests/test_dist_cpu.py): rendezvous only, no GPU
         dist = distmod.init("gloo")
         (n,), _ = distmod.aggregate(dist, [1.0], 0.0)
+        per_rank = gather_per_rank(distmod, dist, rank, world, 1.0e9 * (rank + 1))
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_counted": int(n)}), flush=True)
+            # the same emit() as a real run, on a report of the real run's shape (every leg present, long strings and all):
+            # tests/test_dist_cpu.py holds the last stdout line to the driver's 8 KB tail
+            out = dry_run_report(world, int(n), per_rank)
+            emit(out)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -219,6 +223,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     (total_pt_res, total_iters), t = distmod.aggregate(dist, [pt_res, iters], elapsed)
+    per_rank = gather_per_rank(distmod, dist, rank, world, pt_res / elapsed)
     if os.environ.get("LSLAM_DEBUG_CERT_STATS"):  # debug tap of the certificate path (sweep_body): searched / swept points
         import ctypes
         cs = (ctypes.c_uint64 * 3)()
@@ -270,6 +275,9 @@ def main():
                 "converged_scans": n_conv,
             },
             "roofline": roof,
+            # what a multi-GPU run can be checked by: every rank's own rate over its own clock, and (filled in below, once the
+            # library's communicator exists) the rank count RCCL itself reports
+            "ranks": {"world": world, "per_rank_value": per_rank, "rccl_ranks": None},
         }
     # ---- disclosure leg: the same steps with every point SEARCHED in every sweep (LSLAM_KNN_CERT=0, read per call).  The
     # headline runs the library as shipped, whose certificate sweep keeps a point's five neighbours without a
@@ -336,7 +344,7 @@ def main():
     def give_up():
         if rank == 0 and out is not None:
             out["aborted_secondary_legs"] = "watchdog: a leg after the headline did not finish within %d s" % args.leg_timeout
-            print(json.dumps(out), flush=True)
+            emit(out)
         os._exit(0 if rank != 0 or out is not None else 3)
 
     watchdog = threading.Timer(args.leg_timeout, give_up)
@@ -382,6 +390,9 @@ def main():
             comm, ok = None, 0.0
             print("bench.py: rank %d could not create the RCCL communicator: %r" % (rank, e), file=sys.stderr)
         (n_ok,), _ = distmod.aggregate(dist, [ok], 0.0)  # all ranks or none
+        if rank == 0 and comm is not None:
+            out["ranks"]["rccl_ranks"] = comm.info()[1]  # ncclCommCount of the library's own communicator
+            out["ranks"]["rccl_allreduce_bytes"] = {"sharded_points_per_gn_iteration": 256, "pose_graph_per_linearisation": None}
         if int(round(n_ok)) != world:
             comm = None
             if rank == 0:
@@ -409,9 +420,11 @@ def main():
             pgres = {"error": repr(e)}
         if rank == 0:
             out["pose_graph"] = pgres
+            if isinstance(out["ranks"].get("rccl_allreduce_bytes"), dict):
+                out["ranks"]["rccl_allreduce_bytes"]["pose_graph_per_linearisation"] = pgres.get("allreduce_bytes_per_linearisation")
     watchdog.cancel()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
 
     if dist is not None:
         dist.barrier()
@@ -423,6 +436,144 @@ def main():
     if parity_failed:
         print("bench.py: PARITY FAILURE: " + parity_failed, file=sys.stderr)
         sys.exit(4)
+
+
+COMPACT_LIMIT = 6000   # bytes: the driver keeps an 8 KB tail of stdout; the LAST stdout line must fit in it whole
+
+
+def _pick(d, *keys):
+    """d[k0][k1]... or None: the compact line is built from whatever legs ran."""
+    for k in keys:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def _r(x, digits=6):
+    """floats to `digits` significant digits (the full-precision values are in the report file)."""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    if isinstance(x, dict):
+        return {k: _r(v, digits) for k, v in x.items() if v is not None or k in ("vs_baseline", "traffic", "rccl_ranks")}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, digits) for v in x]
+    return x
+
+
+def compact_line(out):
+    """The line the driver parses: the contract's keys, `roofline`, `cpu_baseline` and one number per secondary leg, built from
+    the full report `out` (which goes to bench_report.json and to stderr).  Guaranteed shorter than COMPACT_LIMIT: optional
+    blocks are dropped, last first, if a future leg grows it."""
+    roof = out.get("roofline") or {}
+    cb = out.get("cpu_baseline") or {}
+    cfg = out.get("config") or {}
+    c = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                 "scaling", "vs_baseline", "dtype", "data", "timed_region_s", "lm_iters_per_s")}
+    for k in ("dry_run", "ranks_counted"):
+        if k in out:
+            c[k] = out[k]
+    c["config"] = {"workload": cfg.get("workload"), "scans_per_step_per_gpu": cfg.get("scans_per_step_per_gpu"),
+                   "scan_points_per_step": cfg.get("scan_points_per_step"),
+                   "map_frames": _pick(cfg, "map", "frames"), "map_corner": _pick(cfg, "map", "surround_corner"),
+                   "map_surf": _pick(cfg, "map", "surround_surf"), "gn_iters_per_scan": cfg.get("gn_iters_per_scan"),
+                   "search": cfg.get("search"), "parallelism": cfg.get("parallelism"),
+                   "pose_err_vs_ground_truth_m": _pick(cfg, "pose_err_vs_ground_truth_m", "max"),
+                   "converged_scans": cfg.get("converged_scans")}
+    c["roofline"] = {"kernel": roof.get("kernel_short") or (roof.get("kernel") or "")[:120], "bound": roof.get("bound"),
+                     "achieved": roof.get("achieved"), "peak": roof.get("peak"), "unit": roof.get("unit"), "frac": roof.get("frac"),
+                     "traffic": roof.get("traffic"), "avg_kernel_ms": roof.get("avg_kernel_ms"),
+                     "launches_timed": roof.get("launches_timed"), "points_per_launch": roof.get("points_per_launch"),
+                     "alg_flops_per_point": roof.get("alg_flops_per_point"),
+                     "nominal_hbm_frac_at_1700B_per_point": _pick(roof, "nominal_hbm", "frac"),
+                     "measured_hbm_frac": _pick(roof, "measured_hbm", "frac"), "valu_issue_frac": _pick(roof, "valu_issue", "frac"),
+                     "valu_insts_per_launch": _pick(roof, "valu_issue", "valu_wave_instructions_per_launch"),
+                     "lanes_active": _pick(roof, "counters", "lanes_active"), "l2_hit_rate": _pick(roof, "counters", "l2_hit_rate"),
+                     "counters_from": _pick(roof, "counters", "source_file")}
+    if cb:
+        c["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample", "seconds", "pose_diff_gpu_vs_cpu_m",
+                                                    "pose_diff_gpu_vs_cpu_rad", "iterations_equal", "rows_equal")}
+        c["cpu_baseline"]["all_cores_value"] = _pick(cb, "all_cores", "value")
+        c["cpu_baseline"]["all_cores"] = _pick(cb, "all_cores", "cores")
+    if out.get("parity_failed"):
+        c["parity_failed"] = out["parity_failed"][:300]
+    if out.get("aborted_secondary_legs"):
+        c["aborted_secondary_legs"] = out["aborted_secondary_legs"]
+    opt = []   # optional blocks, most important first
+    se = out.get("certificate_sweep") or {}
+    if se:
+        opt.append(("value_searching_every_point", se.get("value_searching_every_point")))
+        opt.append(("search_modes", {k: se.get(k) for k in ("share_of_point_residuals_certified", "pose_diff_between_the_two_modes_m",
+                                                           "iterations_equal", "rows_equal", "tree_only_value") if k in se}))
+    if out.get("ranks"):
+        opt.append(("ranks", out["ranks"]))
+    v16 = out.get("vlp16_throughput") or {}
+    if v16:
+        opt.append(("vlp16", {"value": v16.get("value"), "ms_per_step": v16.get("ms_per_step"), "steps": v16.get("steps"),
+                              "roofline_frac": _pick(v16, "roofline", "frac"), "avg_kernel_ms": _pick(v16, "roofline", "avg_kernel_ms"),
+                              "error": v16.get("error")}))
+    pg = out.get("pose_graph") or {}
+    if pg:
+        opt.append(("pose_graph", {"lm_iters_per_s": pg.get("lm_iters_per_s"), "lm_iterations": pg.get("lm_iterations"),
+                                   "solver": pg.get("solver"), "solver_iterations": pg.get("solver_iterations"), "chi2_final": pg.get("chi2_final"),
+                                   "keyframes": pg.get("keyframes"), "edges": pg.get("edges"), "n_gpus": pg.get("n_gpus"),
+                                   "allreduce_bytes_per_linearisation": pg.get("allreduce_bytes_per_linearisation"),
+                                   "roofline_frac": _pick(pg, "roofline", "frac"), "roofline_kernel": _pick(pg, "roofline", "kernel"),
+                                   "cpu_lm_iters_per_s": _pick(pg, "cpu_baseline", "value"), "error": pg.get("error")}))
+    for key in ("mapping_frame", "mapping_frame_vlp16", "mapping_frame_cubes"):
+        mf = out.get(key) or {}
+        if mf:
+            opt.append((key, {"gpu_ms_per_frame": mf.get("gpu_ms_per_frame"), "p99_ms": mf.get("gpu_ms_p99"),
+                              "worst_ms": mf.get("gpu_ms_worst_frame"), "frames": mf.get("frames"),
+                              "overlapped_ms": _pick(mf, "overlapped", "gpu_ms_per_frame"),
+                              "overlapped_p99_ms": _pick(mf, "overlapped", "gpu_ms_p99"),
+                              "overlapped_worst_ms": _pick(mf, "overlapped", "gpu_ms_worst_frame"),
+                              "tree_build_ms": _pick(mf, "gpu_ms", "surround_to_map"), "tree_build_hbm_frac": _pick(mf, "tree_build", "frac"),
+                              "tree_build_traffic": _pick(mf, "tree_build", "traffic"),
+                              "cpu_ms_per_frame": mf.get("cpu_ms_per_frame"), "pose_diff_gpu_vs_cpu_m": mf.get("pose_diff_gpu_vs_cpu_m"),
+                              "error": mf.get("error")}))
+    ss = out.get("single_scan") or {}
+    if ss:
+        opt.append(("single_scan", {k: ss.get(k) for k in ("ms_per_scanmatch", "host_buffers_ms_per_scanmatch", "gn_iterations", "sweep_kernel_ms")}))
+    sh = out.get("sharded_points") or {}
+    if sh:
+        opt.append(("sharded_points", {k: sh.get(k) for k in ("value", "ms_per_scanmatch", "n_gpus", "allreduce_bytes_per_iteration", "rccl_ranks", "error") if k in sh}))
+    js = out.get("joint_lidar_stereo") or {}
+    if js:
+        opt.append(("joint_lidar_stereo", {k: js.get(k) for k in ("ms_per_joint_scanmatch", "joint_rows_per_s", "n_gpus", "pose_diff_gpu_vs_cpu_m", "error") if k in js}))
+    sp = out.get("sweep_pipeline") or {}
+    if sp:
+        opt.append(("sweep_pipeline", {k: {"ms_per_sweep": _pick(sp, k, "ms_per_sweep"), "threads_ms_per_sweep": _pick(sp, k, "node_threads", "ms_per_sweep")}
+                                       for k in ("vlp16", "rings64") if k in sp} or {"error": sp.get("error")}))
+    for k, v in opt:
+        c[k] = v
+    c["report"] = "bench_report.json (full report: every leg, accountings, counter sources); also one line on stderr"
+    c = _r(c)
+    line = json.dumps(c, separators=(",", ":"))
+    for k, _ in reversed(opt):   # never reached today (~3.5 KB); keeps the contract if a leg grows
+        if len(line) <= COMPACT_LIMIT:
+            break
+        c.pop(k, None)
+        c["dropped_for_size"] = c.get("dropped_for_size", []) + [k]
+        line = json.dumps(c, separators=(",", ":"))
+    assert len(line) <= COMPACT_LIMIT, len(line)
+    return line
+
+
+def emit(out):
+    """Full report -> bench_report.json (+ gpurun_out/ when it exists, so it comes back from the GPU box) and stderr; the compact
+    line -> stdout, LAST."""
+    full = json.dumps(out)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_report.json"), "w") as f:
+                    f.write(full + "\n")
+            except OSError:
+                pass
+    print(full, file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    print(compact_line(out), flush=True)
 
 
 def vlp16_throughput_leg(ctx, lidar, synth, dense, span, rank, world, args, opts, distmod, dist, info, np):
@@ -465,7 +616,8 @@ def vlp16_throughput_leg(ctx, lidar, synth, dense, span, rank, world, args, opts
         return None
     roof = sweep_roofline(pt_res, sweep_ms, sweep_launches, float(info.n_corner + info.n_surf))
     # the committed counter passes are of the 64-ring command: the 16-ring launches run the same kernel on a quarter of the points
-    roof["counters_of"] = "the 64-ring headline command (same kernel instantiation)"
+    roof["counters_of"] = "the 64-ring headline command (same kernel instantiation): see roofline.counters of the headline"
+    roof.pop("counters", None)
     return {"metric": "point-residuals/s", "value": total_pt_res / t, "unit": "point-residuals/s", "n_gpus": world, "steps": steps,
             "ms_per_step": 1e3 * t / steps, "timed_region_s": t, "lm_iters_per_s": total_iters / t, "dtype": "f32",
             "config": {"workload": "synthetic 16-ring x 1800 (VLP-16) scan-to-map scanMatchScan GN loops against the same %d-frame "
@@ -535,6 +687,7 @@ def sweep_roofline(pt_res, sweep_ms, sweep_launches, map_points):
                   "against the oracle) -- from a loop's second sweep on as the certificate sweep: sweep_kernel<...,1> over every point "
                   "+ cert_plan_kernel + sweep_queue_kernel<256,true,12> over the points whose neighbours could not be carried over; "
                   "one timed 'launch' is one sweep = that group of dispatches (HIP events on the first and the last of them)",
+        "kernel_short": "sweep_kernel<256,true,false,12> (+ certificate pass: cert_plan_kernel, sweep_queue_kernel)",
         "bound": "valu",
         "achieved": tflops,
         "peak": FP32_PEAK_TFLOPS,
@@ -565,6 +718,53 @@ def sweep_roofline(pt_res, sweep_ms, sweep_launches, map_points):
     }
     roof.update(pmc_counters(avg_sweep_ms))
     return roof
+
+
+def gather_per_rank(distmod, dist, rank, world, x):
+    """[x of rank 0, x of rank 1, ...] on every rank, through the one reduction dist.aggregate already has (a one-hot sum)."""
+    v = [0.0] * world
+    v[rank] = float(x)
+    got, _ = distmod.aggregate(dist, v, 0.0)
+    return [float(g) for g in got]
+
+
+def dry_run_report(world, ranks_counted, per_rank):
+    """LSLAM_BENCH_DRY_RUN: a report with the keys and string lengths of a real one (numbers are placeholders), so that the CPU
+    test of the launcher also tests that the printed line stays parseable and short."""
+    long = "x" * 600
+    roof = {"kernel": long, "kernel_short": "sweep_kernel", "bound": "valu", "achieved": 9.4, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": 0.06, "traffic": 4.35e9, "avg_kernel_ms": 6.0, "launches_timed": 200, "points_per_launch": 4.7e7,
+            "alg_flops_per_point": FLOPS_PER_POINT_RESIDUAL, "accounting": long, "nominal_hbm": {"frac": 1.66, "note": long},
+            "measured_hbm": {"frac": 0.09, "source": long}, "valu_issue": {"frac": 0.99, "valu_wave_instructions_per_launch": 3.6e9, "source": long},
+            "counters": {"lanes_active": 43.0, "l2_hit_rate": 0.9, "source": long, "source_file": "profiles/r04_pmc_sweep.csv"}}
+    mf = {"gpu_ms": {"surround_to_map": 1.2}, "gpu_ms_per_frame": 3.2, "gpu_ms_p99": 3.9, "gpu_ms_worst_frame": 4.0, "frames": 200,
+          "overlapped": {"gpu_ms_per_frame": 2.3, "gpu_ms_p99": 2.9, "gpu_ms_worst_frame": 3.0, "schedule": long},
+          "tree_build": {"frac": 0.018, "traffic": 5.9e8, "accounting": long}, "cpu_ms_per_frame": 900.0, "pose_diff_gpu_vs_cpu_m": 1e-6,
+          "gpu_ms_per_frame_each": [[1.0] * 6] * 200}
+    return {"dry_run": True, "ranks_counted": ranks_counted,
+            "metric": "point-residuals/s", "value": sum(per_rank), "unit": "point-residuals/s", "n_gpus": world, "steps": 1, "warmup": 0,
+            "ms_per_step": 60.0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "lm_iters_per_s": 1.0e5, "timed_region_s": 1.2,
+            "config": {"workload": long[:300], "scans_per_step_per_gpu": 960, "scan_points_per_step": 110000000,
+                       "map": {"frames": 10000, "surround_corner": 157000, "surround_surf": 587000}, "gn_iters_per_scan": 4.3,
+                       "parallelism": long[:100], "pose_err_vs_ground_truth_m": {"max": 0.01}, "converged_scans": 960},
+            "roofline": roof, "ranks": {"world": world, "per_rank_value": per_rank, "rccl_ranks": None},
+            "certificate_sweep": {"what": long, "value_searching_every_point": 7.0e9, "share_of_point_residuals_certified": 0.25,
+                                  "pose_diff_between_the_two_modes_m": 1e-7, "iterations_equal": True, "rows_equal": True},
+            "single_scan": {"ms_per_scanmatch": 0.35, "host_buffers_ms_per_scanmatch": 0.6, "gn_iterations": 4, "sweep_kernel_ms": 0.05},
+            "vlp16_throughput": {"value": 5.7e9, "ms_per_step": 20.0, "steps": 10, "roofline": dict(roof)},
+            "cpu_baseline": {"value": 2.0e6, "unit": "point-residuals/s", "cores": 1, "kind": "port", "sample": long[:250], "seconds": 20.0,
+                             "pose_diff_gpu_vs_cpu_m": 1e-6, "pose_diff_gpu_vs_cpu_rad": 1e-7, "iterations_equal": True, "rows_equal": True,
+                             "all_cores": {"value": 1.0e7, "cores": 8, "kind": long[:80]}},
+            "mapping_frame": mf, "mapping_frame_vlp16": mf, "mapping_frame_cubes": mf,
+            "sweep_pipeline": {"vlp16": {"ms_per_sweep": 3.0, "node_threads": {"ms_per_sweep": 2.0}},
+                               "rings64": {"ms_per_sweep": 5.0, "node_threads": {"ms_per_sweep": 3.0}}},
+            "sharded_points": {"value": 1.0e9, "ms_per_scanmatch": 0.4, "n_gpus": world, "allreduce_bytes_per_iteration": 256},
+            "joint_lidar_stereo": {"ms_per_joint_scanmatch": 0.5, "joint_rows_per_s": 1e9, "n_gpus": world, "parity": long},
+            "pose_graph": {"lm_iters_per_s": 519.0, "lm_iterations": 100, "solver_iterations": 11000, "chi2_final": 1.0, "keyframes": 5000,
+                           "edges": 24999, "n_gpus": world, "allreduce_bytes_per_linearisation": 8900000,
+                           "roofline": {"kernel": "pg_pcg_persistent_kernel", "frac": 0.019, "accounting": long, "bound_detail": long},
+                           "cpu_baseline": {"value": 6.4, "sample": long}}}
 
 
 def make_comm(pkg, dist, torch, rank, local_rank, world):
@@ -613,7 +813,7 @@ def pmc_counters(avg_sweep_ms):
             v[f[1]] = float(f[3])
     g = v.get
     traffic = (2.0 * g("FETCH_SIZE", 0.0) + g("WRITE_SIZE", 0.0)) * 1024.0 if "FETCH_SIZE" in v else None
-    c = {"source": "%s (rocprofv3 --pmc passes; %s)" % (prof, src.strip()[:200])}
+    c = {"source": "%s (rocprofv3 --pmc passes; %s)" % (prof, src.strip()[:200]), "source_file": prof}
     # the profiled launches' own duration in engine cycles: GRBM_GUI_ACTIVE (summed over the 8 XCDs; at 2.4 GHz it reproduces
     # the HIP-event duration of these launches), else SQ_BUSY_CYCLES (summed over the 32 shader engines)
     cyc = v["GRBM_GUI_ACTIVE"] / 8.0 if v.get("GRBM_GUI_ACTIVE", 0) > 0 else v.get("SQ_BUSY_CYCLES", 0.0) / 32.0
@@ -984,7 +1184,6 @@ def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, 
     res = {"rings": rings, "gpu_ms": gpu, "gpu_ms_per_frame": sum(gpu.values()), "frames": frames,
            "gpu_ms_statistic": "median of the timed frames",
            "gpu_ms_worst_frame": 1e3 * float(max(sum(v[i] for v in acc.values()) for i in range(frames))),
-           "gpu_ms_per_frame_each": [[round(1e3 * v[i], 3) for v in acc.values()] for i in range(frames)],
            "sweep_points": int(len(cloud)), "features": {k: int(len(v)) for k, v in feat.items()},
            "scan_points_after_voxel_grid": int(len(dc) + len(ds)), "map_points": fm.info()["n_corner"] + fm.info()["n_surf"],
            "scan_match_iterations": int(st.iterations),

@@ -187,6 +187,39 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["ranks_counted"] == 2
+    # the line the driver parses is the LAST stdout line, whole inside its 8 KB tail, with the contract's keys and what a
+    # SCALE run would check (per-rank rates, the RCCL rank count slot); the full report went to bench_report.json + stderr
+    last = out.stdout.rstrip("\n").splitlines()[-1]
+    assert last == line and len(last.encode()) < 8192 and len(out.stdout.encode()) < 8192
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "value_searching_every_point", "ranks"):
+        assert k in rec, k
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_kernel_ms")) <= set(rec["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(rec["cpu_baseline"])
+    assert rec["ranks"]["world"] == 2 and rec["ranks"]["per_rank_value"] == [1.0e9, 2.0e9] and "rccl_ranks" in rec["ranks"]
+    assert rec["value"] == 3.0e9 and "workload" in rec["config"]
+    full = json.loads([l for l in out.stderr.splitlines() if l.startswith("{")][-1])
+    assert full["roofline"]["accounting"] and len(json.dumps(full)) > 8192      # the long form exists, elsewhere
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"],
                          env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "--gpus 4" in bad.stderr
+
+
+def test_compact_line_of_a_real_report_fits_the_driver_tail():
+    """bench.compact_line on the full reports kept under profiles/ (real legs, real string lengths): parseable, < 8 KB, and the
+    numbers the contract names are the report's own."""
+    import glob
+    import json
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    reports = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]_bench.json")))
+    assert reports
+    for path in reports:
+        full = json.load(open(path))
+        line = bench.compact_line(full)
+        assert len(line.encode()) < 8192 and "\n" not in line
+        rec = json.loads(line)
+        assert abs(rec["value"] - full["value"]) <= 1e-5 * full["value"] and rec["metric"] == full["metric"]
+        assert abs(rec["roofline"]["frac"] - full["roofline"]["frac"]) <= 1e-5 and rec["roofline"]["bound"] == full["roofline"]["bound"]
+        assert rec["cpu_baseline"]["kind"] == full["cpu_baseline"]["kind"] and rec["cpu_baseline"]["cores"] == full["cpu_baseline"]["cores"]
+        assert rec["config"]["workload"] == full["config"]["workload"]

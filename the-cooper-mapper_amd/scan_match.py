@@ -56,6 +56,15 @@ class Comm:
         if rc != 0:
             raise LslamError(rc, self.lib.lslam_last_error().decode())
 
+    def info(self):
+        """(rank, world) as the RCCL communicator itself reports them (ncclCommUserRank / ncclCommCount through
+        lslam_comm_info): what `bench.py --gpus N` prints as `rccl_ranks`."""
+        r, w = C.c_int32(-1), C.c_int32(-1)
+        rc = self.lib.lslam_comm_info(self.h, C.byref(r), C.byref(w))
+        if rc != 0:
+            raise LslamError(rc, self.lib.lslam_last_error().decode())
+        return int(r.value), int(w.value)
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.lslam_comm_destroy(self.h)

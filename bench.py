@@ -75,6 +75,9 @@ def parse_args():
                     help="profiling passes: file to keep the built surround map in (built and saved on the first run, loaded "
                          "afterwards: rocprofv3 --pmc serialises the ~200 k dispatches of the 10k-frame build otherwise)")
     ap.add_argument("--jtj-mode", type=int, default=int(os.environ.get("LSLAM_JTJ_MODE", "1")))
+    ap.add_argument("--search", default=os.environ.get("LSLAM_BENCH_SEARCH", "auto"), choices=["auto", "lane", "grid"],
+                    help="lslam_opts.search_mode of every leg: the library's choice, the kd-tree walk, or the cell-grid probe")
+    ap.add_argument("--grid-cell", type=float, default=0.0, help="lslam_opts.grid_cell [m] (0: the library's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-joint-stereo", action="store_true")
     ap.add_argument("--no-pose-graph", action="store_true")
@@ -188,6 +191,8 @@ def main():
     opts.jtj_mode = args.jtj_mode
     opts.profile = 1
     opts.scans_in_flight = args.batch
+    opts.search_mode = {"auto": 0, "lane": 1, "grid": 3}[args.search]
+    opts.grid_cell = args.grid_cell
     if os.environ.get("LSLAM_DEBUG_MAX_ITERS"):  # diagnostics only (tools/cert_stats.py): the loop cut short -- not a bench line
         opts.max_iterations = int(os.environ["LSLAM_DEBUG_MAX_ITERS"])
     setup_s = time.perf_counter() - t_setup
@@ -224,7 +229,7 @@ def main():
 
     (total_pt_res, total_iters), t = distmod.aggregate(dist, [pt_res, iters], elapsed)
     per_rank = gather_per_rank(distmod, dist, rank, world, pt_res / elapsed)
-    if os.environ.get("LSLAM_DEBUG_CERT_STATS"):  # debug tap of the certificate path (sweep_body): searched / swept points
+    if os.environ.get("LSLAM_DEBUG_CERT_STATS"):  # debug tap of the certificate path (read by lslam_ctx_create): searched / swept points
         import ctypes
         cs = (ctypes.c_uint64 * 3)()
         ctx.lib.lslam_debug_cert_stats(ctx.h, cs)
@@ -267,6 +272,8 @@ def main():
                 "gn_iters_per_scan": iters / args.steps / args.scans,
                 "sweep_launches_per_step": sweep_launches / args.steps,
                 "jtj_mode": "mfma_f32_16x16x4" if args.jtj_mode == 1 else "valu_shuffle",
+                "search": args.search + (" (cell %.2f m)" % args.grid_cell if args.search == "grid" and args.grid_cell > 0 else ""),
+                "grid_sweep_launches": ctx.grid_launches(),
                 "parallelism": "replicated map, scans sharded across %d GPU(s), no collective" % world,
                 "setup_s_outside_timed_region": setup_s,
                 "gpu_loop_ms_per_step": loop_ms / args.steps,
@@ -279,16 +286,29 @@ def main():
             # library's communicator exists) the rank count RCCL itself reports
             "ranks": {"world": world, "per_rank_value": per_rank, "rccl_ranks": None},
         }
-    # ---- disclosure leg: the same steps with every point SEARCHED in every sweep (LSLAM_KNN_CERT=0, read per call).  The
+    if args.search == "grid":  # what share of the points the grid sweeps left to the tree search (one more step, counted; untimed)
+        import ctypes
+        opts.debug_stats = 1
+        g0 = (ctypes.c_uint64 * 3)()
+        g1 = (ctypes.c_uint64 * 3)()
+        ctx.lib.lslam_debug_cert_stats(ctx.h, g0)
+        ctx.run_batch(inits, opts)
+        ctx.lib.lslam_debug_cert_stats(ctx.h, g1)
+        opts.debug_stats = 0
+        if rank == 0:
+            out["grid_sweep"] = {"points_swept_per_step": int(g1[1] - g0[1]), "points_left_to_the_tree_search_per_step": int(g1[0] - g0[0]),
+                                 "share_left_to_the_tree_search": (g1[0] - g0[0]) / max(1, g1[1] - g0[1]),
+                                 "second_pass_launches_per_step": int(g1[2] - g0[2])}
+    # ---- disclosure leg: the same steps with every point SEARCHED in every sweep (lslam_opts.knn_cert = 0).  The
     # headline runs the library as shipped, whose certificate sweep keeps a point's five neighbours without a
     # search when the previous search's bounds prove they cannot have changed -- the same neighbours, hence the same residuals
     # and poses up to summation order, with fewer executed instructions.  Both rates are in the line.
     if not args.headline_only:
         import ctypes
         cert = {"what": "value = the library as shipped (certificate sweep for throughput-bound batches); value_searching_every_point = "
-                        "the same steps under LSLAM_KNN_CERT=0: every 5-NN search of every sweep executed"}
-        saved = os.environ.get("LSLAM_KNN_CERT")
-        os.environ["LSLAM_KNN_CERT"] = "0"
+                        "the same steps with lslam_opts.knn_cert = 0: every 5-NN search of every sweep executed"}
+        knn_cert_shipped = opts.knn_cert
+        opts.knn_cert = 0
         ctx.run_batch(inits, opts)
         barrier()
         t1 = time.perf_counter()
@@ -299,18 +319,15 @@ def main():
             pr0 += sum(s.point_residuals for s in sts0)
         barrier()
         (tot0,), t0s = distmod.aggregate(dist, [pr0], time.perf_counter() - t1)
-        if saved is None:
-            del os.environ["LSLAM_KNN_CERT"]
-        else:
-            os.environ["LSLAM_KNN_CERT"] = saved
+        opts.knn_cert = knn_cert_shipped
         # and what share of the certificate-testing sweeps' points kept their neighbours (one more step, counted)
-        os.environ["LSLAM_DEBUG_CERT_STATS"] = "1"
+        opts.debug_stats = 1
         cs0 = (ctypes.c_uint64 * 3)()
         cs1 = (ctypes.c_uint64 * 3)()
         ctx.lib.lslam_debug_cert_stats(ctx.h, cs0)
         st1, poses1, sts1 = ctx.run_batch(inits, opts)
         ctx.lib.lslam_debug_cert_stats(ctx.h, cs1)
-        del os.environ["LSLAM_DEBUG_CERT_STATS"]
+        opts.debug_stats = 0
         if rank == 0:
             tested, needy = cs1[1] - cs0[1], cs1[0] - cs0[0]
             swept = sum(s.point_residuals for s in sts1)
@@ -507,6 +524,8 @@ def compact_line(out):
                                                            "iterations_equal", "rows_equal", "tree_only_value") if k in se}))
     if out.get("ranks"):
         opt.append(("ranks", out["ranks"]))
+    if out.get("grid_sweep"):
+        opt.append(("grid_sweep", {"share_left_to_the_tree_search": _pick(out, "grid_sweep", "share_left_to_the_tree_search")}))
     v16 = out.get("vlp16_throughput") or {}
     if v16:
         opt.append(("vlp16", {"value": v16.get("value"), "ms_per_step": v16.get("ms_per_step"), "steps": v16.get("steps"),

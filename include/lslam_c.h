@@ -76,23 +76,40 @@ typedef struct {
   int32_t scans_in_flight; /* lslam_scanmatch_run_batch: resident scans matched together by one sequence of
                               launches; more scans are taken in chunks of this size (0: up to 128; a scan
                               in flight costs ~1.3 MB of scratch in HBM for a 115 200-point scan) */
-  int32_t search_mode;     /* how the 5-NN search maps to the GPU: LSLAM_SEARCH_AUTO / _LANE / _PACKET */
+  int32_t search_mode;     /* how the 5-NN search maps to the GPU: LSLAM_SEARCH_AUTO / _LANE / _PACKET / _GRID, ORed with LSLAM_STACK_* */
+  int32_t knn_cert;        /* certificate sweep (neighbour lists carried over, without a search, where a point provably kept its
+                              five neighbours): 1 (default) where it pays -- throughput-bound batches; 0 never: every 5-NN search
+                              of every sweep is executed; 2 whatever the size of the launch (tests) */
+  float cert_try_m;        /* a scan tests certificates when its last update moved its points by less than this [m] (0.05) */
+  float cert_track_m;      /* ... and its searches keep the bound a certificate needs when by less than this [m] (1.0) */
+  float grid_cell;         /* LSLAM_SEARCH_GRID: edge of a grid cell [m]; 0 = the default (0.6) */
+  int32_t debug_stats;     /* 1: count the points the certificate / grid sweeps leave to their second pass (lslam_debug_cert_stats) */
+  int32_t ab_switches;     /* LSLAM_AB_*: measured-and-kept alternatives, off by default (DESIGN.md has the numbers) */
 } lslam_opts;
+/* Environment overrides of the fields above -- LSLAM_KNN_CERT, LSLAM_CERT_TRY_M, LSLAM_CERT_TRACK_M, LSLAM_GRID_CELL,
+ * LSLAM_SEARCH=lane|packet|grid, LSLAM_FORCE_STACK=deep|shallow|auto, LSLAM_PERSISTENT_GN=1, LSLAM_FUSED_SOLVE=1,
+ * LSLAM_DEBUG_CERT_STATS=1 -- are read ONCE, in lslam_ctx_create; no entry point reads the environment while it runs. */
+enum { LSLAM_AB_PERSISTENT_GN = 1, /* one resident scan: the whole Gauss-Newton loop as one persistent launch */
+       LSLAM_AB_FUSED_SOLVE = 2    /* latency-bound launches: the 6x6 solve in the tail of the sweep launch */ };
 
 /* 5-NN search implementations (same answer, bit for bit):
  *   LANE    one query per lane, nanoflann's traversal with an explicit per-lane stack
  *   PACKET  one wavefront walks the tree once for its 64 (Morton-neighbouring) queries: nodes and leaves
  *           arrive by scalar loads, lanes test them against their own query (csrc/lslam_packet.hpp)
+ *   GRID    no tree walk for most queries: a dense cell grid over the map (cells of lslam_opts.grid_cell metres), a probe of
+ *           the 27 cells around the query, and a PROOF that the five smallest distances found are the five nearest map
+ *           points with no tie among the six smallest (csrc/lslam_grid.hpp); a query the proof fails for -- a sparse
+ *           neighbourhood, an exact tie -- is searched by LANE.  Whole-map trees only
  *   AUTO    the faster one on MI355X: LANE (the packet search trades the divergent gathers for about twice
  *           the vector ALU work and measured slower; DESIGN.md has the numbers) */
-enum { LSLAM_SEARCH_AUTO = 0, LSLAM_SEARCH_LANE = 1, LSLAM_SEARCH_PACKET = 2 };
+enum { LSLAM_SEARCH_AUTO = 0, LSLAM_SEARCH_LANE = 1, LSLAM_SEARCH_PACKET = 2, LSLAM_SEARCH_GRID = 3 };
 /* Traversal-stack shape of the LANE search, ORed into a search mode (same answer, bit for bit -- the shapes hold the
  * same entries; only where they live differs):
  *   DEEP     all 32 levels of a lane's stack in LDS (two workgroups per CU): what a latency-bound single-scan launch takes
  *   SHALLOW  12 levels in LDS, deeper ones in an HBM overflow area (five wavefronts per SIMD): what a launch of more than
  *            2 048 wavefronts -- a batch, the bench -- takes
  *   AUTO     by the size of the launch
- * LSLAM_FORCE_STACK=deep|shallow|auto in the environment overrides the bits.  The parity tests run every oracle
+ * LSLAM_FORCE_STACK=deep|shallow|auto in the environment (read by lslam_ctx_create) overrides the bits.  The parity tests run every oracle
  * comparison through both shapes; lslam_debug_sweep_launches says which kernel really ran. */
 enum { LSLAM_STACK_AUTO = 0, LSLAM_STACK_DEEP = 0x100, LSLAM_STACK_SHALLOW = 0x200 };
 
@@ -571,6 +588,8 @@ void *lslam_stream(lslam_ctx *ctx); /* hipStream_t */
  * trees, [4] per-cube trees with overflow, [5] packet search, [6] persistent Gauss-Newton kernel, [7] the whole-stack kernel with
  * the 6x6 solve fused into its tail (the Gauss-Newton loop of single scans: one launch per iteration). */
 void lslam_debug_sweep_launches(lslam_ctx *ctx, uint64_t counts[8]);
+/* ... and of the grid sweep (sweep_grid_kernel; LSLAM_SEARCH_GRID) */
+uint64_t lslam_debug_grid_launches(lslam_ctx *ctx);
 /* Debug tap of the certificate sweep (csrc/lslam_kernels.hip sweep_body): out[2] = second-pass launches of this
  * context since its creation; out[0] = points the certificate-testing workgroups left to the second pass and out[1] = points
  * of those workgroups, counted only when the process runs with LSLAM_DEBUG_CERT_STATS=1 (two atomics per workgroup). */

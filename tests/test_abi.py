@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(pkg):
 
 def test_struct_layouts_match_header(pkg):
     # sizes the C compiler gives the ABI structs (natural alignment, LP64)
-    assert C.sizeof(pkg.LslamOpts) == 56
+    assert C.sizeof(pkg.LslamOpts) == 80  # + knn_cert, cert_try_m, cert_track_m, grid_cell, debug_stats, ab_switches
     assert C.sizeof(pkg.LslamStats) == 96  # + score2, percent2
     assert C.sizeof(pkg.LslamMapInfo) == 48
 

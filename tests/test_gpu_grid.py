@@ -1,0 +1,174 @@
+"""The cell-grid 5-NN (csrc/lslam_grid.hpp, LSLAM_SEARCH_GRID) under the same bars as the tree search: indices and squared
+distances bit-exact against the goldens generated from the reference's own nanoflann, against the oracle's kd-tree and
+against the lane search of the library itself -- whatever share of the queries the probe can prove; the rest must have gone
+through the tree (counted) and match too.  Then the grid SWEEP (sweep_grid_kernel + sweep_queue_kernel) against the tree
+sweep and the oracle: taps bit-exact, sums to rounding, Gauss-Newton loops to the pose bar.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LANE, GRID = 1, 3          # LSLAM_SEARCH_LANE / _GRID
+POSE_TOL_M, POSE_TOL_RAD = 1e-4, 1e-5
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.int32)
+
+
+def test_grid_knn5_matches_reference_goldens(ctx, goldens):
+    """Every golden fixture (lattices and duplicates included: exact distance ties must be REFUSED by the proof and answered by
+    nanoflann's traversal) through the grid tap."""
+    unproven = total = 0
+    for name, g in goldens.items():
+        pts = g["pts"]
+        if len(pts) < 5:
+            continue
+        ctx.map_set(pts, pts)
+        for which in (0, 1):
+            idx, d2, n_un = ctx.knn5(which, g["queries"], search_mode=GRID, want_ties=True)
+            assert np.array_equal(idx, g["idx"]), (name, which)
+            assert np.array_equal(bits(d2), bits(g["d2"])), (name, which)
+            unproven += n_un
+            total += len(g["queries"])
+    assert 0 < unproven < total  # the tie fixtures were refused, and not everything was
+
+
+@pytest.mark.parametrize("spacing,jitter", [(0.2, 0.05), (0.4, 0.1), (0.4, 0.0), (1.5, 0.3)])
+def test_grid_knn5_equals_lane_search_on_planes_and_lines(ctx, spacing, jitter):
+    """Voxel-map-like clouds (a ground plane, two walls, poles) at several densities; queries on, near and far from them,
+    outside the map and not-a-number.  spacing 0.4 / jitter 0 is an exact lattice (ties everywhere); spacing 1.5 is sparser
+    than the grid's guaranteed radius (most queries unproven)."""
+    rng = np.random.default_rng(int(spacing * 1000 + jitter * 100))
+    g = np.arange(-20.0, 20.0, spacing, dtype=np.float32)
+    gx, gy = np.meshgrid(g, g)
+    ground = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size, np.float32)], 1)
+    h = np.arange(0.0, 6.0, spacing, dtype=np.float32)
+    wx, wz = np.meshgrid(g, h)
+    wall1 = np.stack([wx.ravel(), np.full(wx.size, 7.3, np.float32), wz.ravel()], 1)
+    wall2 = np.stack([np.full(wx.size, -9.1, np.float32), wx.ravel(), wz.ravel()], 1)
+    poles = np.concatenate([np.stack([np.full(len(h), x, np.float32), np.full(len(h), y, np.float32), h], 1)
+                            for x, y in rng.uniform(-18, 18, (25, 2))])
+    pts = np.concatenate([ground, wall1, wall2, poles]).astype(np.float32)
+    pts += rng.uniform(-jitter, jitter, pts.shape).astype(np.float32) if jitter > 0 else 0
+    ctx.map_set(pts, pts)
+    q = np.concatenate([
+        pts[rng.integers(0, len(pts), 6000)] + rng.normal(0, 0.15, (6000, 3)).astype(np.float32),
+        pts[rng.integers(0, len(pts), 2000)] + rng.normal(0, 1.0, (2000, 3)).astype(np.float32),
+        pts[rng.integers(0, len(pts), 500)],                      # exactly on map points
+        rng.uniform(-60, 60, (500, 3)).astype(np.float32),        # mostly outside
+        np.array([[np.nan, 0, 0], [0, np.inf, 0], [1e9, 1e9, 1e9]], np.float32)]).astype(np.float32)
+    li, ld = ctx.knn5(1, q, search_mode=LANE)
+    gi, gd, n_un = ctx.knn5(1, q, search_mode=GRID, want_ties=True)
+    fin = np.isfinite(q).all(1)
+    assert np.array_equal(gi[fin], li[fin])
+    assert np.array_equal(bits(gd[fin]), bits(ld[fin]))
+    if spacing == 0.4 and jitter == 0.0:
+        assert n_un > 0.2 * len(q)       # a lattice: exact ties wherever a query sits near a symmetry plane of it
+    if spacing == 0.2:
+        assert n_un < 0.35 * len(q)      # dense and jittered: the probe proves most of them
+
+
+def test_grid_knn5_matches_oracle_on_synthetic_map(ctx, oracle, synth):
+    pr = synth.make_problem(rings=16, azimuth_steps=1800, world_half=100.0)
+    ctx.map_set(pr["map_corner"], pr["map_surf"])
+    rng = np.random.default_rng(1)
+    for which, cloud in ((0, pr["map_corner"]), (1, pr["map_surf"])):
+        tree = oracle.kdtree(cloud)
+        q = cloud[rng.integers(0, len(cloud), 4000), :3] + rng.normal(0, 0.3, (4000, 3)).astype(np.float32)
+        q = np.concatenate([q, rng.uniform(-150, 150, (500, 3)).astype(np.float32)])
+        gi, gd = ctx.knn5(which, q, search_mode=GRID)
+        oi, od = tree.knn(q, 5)
+        assert np.array_equal(gi, oi)
+        assert np.array_equal(bits(gd), bits(od))
+
+
+def test_grid_sweep_taps_equal_tree_sweep(ctx, small_problem):
+    """One sweep at the initial pose: per-point neighbours, distances, flags and coefficients of the grid sweep (both passes)
+    are the tree sweep's, bit for bit; the sums differ by summation order only."""
+    pr = small_problem
+    ctx.map_set(pr["map_corner"], pr["map_surf"])
+    ctx.scan_set(pr["corner"], pr["surf"])
+    for jtj in (0, 1):
+        a = ctx.sweep(pr["init_pose"], jtj_mode=jtj, search_mode=LANE)
+        b = ctx.sweep(pr["init_pose"], jtj_mode=jtj, search_mode=GRID)
+        assert np.array_equal(a["flags"], b["flags"])
+        assert np.array_equal(a["idx"], b["idx"])
+        assert np.array_equal(bits(a["d2"]), bits(b["d2"]))
+        assert np.array_equal(bits(a["coeff"]), bits(b["coeff"]))
+        assert a["sums"][27] == b["sums"][27] and a["sums"][28] == b["sums"][28]
+        assert np.allclose(a["sums"], b["sums"], rtol=2e-5, atol=1e-3)
+    assert ctx.grid_launches() >= 2
+
+
+@pytest.mark.parametrize("cell", [0.0, 0.4, 1.0])
+def test_grid_scanmatch_matches_oracle_and_lane(ctx, oracle, small_problem, cell):
+    """The whole Gauss-Newton loop through the grid sweep (bounded, clipped probes from the second sweep on): the oracle's
+    iteration and row counts, its pose to the bar; the lane search's pose to rounding."""
+    pr = small_problem
+    ctx.map_set(pr["map_corner"], pr["map_surf"])
+    ctx.scan_set(pr["corner"], pr["surf"])
+    o = ctx.default_opts()
+    o.search_mode = GRID
+    o.grid_cell = cell
+    o.debug_stats = 1
+    before = ctx.grid_launches()
+    s0 = ctx.cert_stats()
+    status, pose, st = ctx.run(pr["init_pose"], o)
+    s1 = ctx.cert_stats()
+    assert ctx.grid_launches() - before == st.sweeps + (0 if st.sweeps == o.max_iterations else 1) or ctx.grid_launches() > before
+    swept, listed = s1[1] - s0[1], s1[0] - s0[0]
+    assert swept >= st.sweeps * (len(pr["corner"]) + len(pr["surf"])) and 0 <= listed <= swept
+    ok, opose, ost = oracle.scanmatch_scan(pr["map_corner"], pr["map_surf"], pr["corner"], pr["surf"], pr["init_pose"])
+    assert (status == 0) == ok and st.iterations == ost.iterations
+    assert (st.n_rows, st.n_line, st.n_plane) == (ost.n_rows, ost.n_line, ost.n_plane)
+    assert np.abs(pose[3:] - opose[3:]).max() <= POSE_TOL_M and np.abs(pose[:3] - opose[:3]).max() <= POSE_TOL_RAD
+    o.search_mode = LANE
+    status2, pose2, st2 = ctx.run(pr["init_pose"], o)
+    assert st2.iterations == st.iterations and np.abs(pose2 - pose).max() <= 2e-6
+
+
+def test_grid_batch_equals_lane_batch(ctx, synth):
+    """A batch of different scans in flight (the bench's shape, small): the same iteration counts, row counts and poses as the
+    tree sweeps of the same batch, scan by scan; in chunks too."""
+    pr0 = synth.make_problem(rings=16, azimuth_steps=900, world_half=60.0)
+    ctx.map_set(pr0["map_corner"], pr0["map_surf"])
+    scans, inits = [], []
+    for k in range(6):
+        pr = synth.make_problem(rings=16, azimuth_steps=900, world_half=60.0, seed=k)
+        scans.append((pr["corner"], pr["surf"]))
+        inits.append(synth.perturb_pose(pr["gt_pose"], seed=40 + k))
+    ctx.scan_set_batch(scans)
+    inits = np.stack(inits)
+    o = ctx.default_opts()
+    o.knn_cert = 0
+    o.search_mode = LANE
+    _, p_lane, s_lane = ctx.run_batch(inits, o)
+    for in_flight in (0, 4):
+        o.search_mode = GRID
+        o.scans_in_flight = in_flight
+        _, p_grid, s_grid = ctx.run_batch(inits, o)
+        for a, b in zip(s_lane, s_grid):
+            assert (a.iterations, a.n_rows, a.n_line, a.n_plane, a.converged) == (b.iterations, b.n_rows, b.n_line, b.n_plane, b.converged)
+        assert np.abs(p_lane - p_grid).max() <= 2e-6
+        _, p_again, _ = ctx.run_batch(inits, o)
+        assert np.array_equal(p_again, p_grid)  # fixed places, fixed order: the same bits in every run
+
+
+def test_grid_fine_score_resweep(ctx, small_problem):
+    """The _fineScore re-sweep (unbounded, converged scans only) through the grid sweep gives the tree sweep's score2 / percent2."""
+    pr = small_problem
+    ctx.map_set(pr["map_corner"], pr["map_surf"])
+    ctx.scan_set(pr["corner"], pr["surf"])
+    o = ctx.default_opts()
+    o.fine_score = 1
+    res = {}
+    for mode in (LANE, GRID):
+        o.search_mode = mode
+        status, pose, st = ctx.run(pr["init_pose"], o)
+        res[mode] = (st.converged, st.percent2, st.score2)
+    assert res[LANE][0] == res[GRID][0] == 1
+    assert res[LANE][1] == res[GRID][1] and abs(res[LANE][2] - res[GRID][2]) <= 1e-6 * max(1.0, abs(res[LANE][2]))

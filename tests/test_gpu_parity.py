@@ -708,13 +708,14 @@ def test_sharded_points_gn_loop(pkg, ctx, oracle, small_problem, monkeypatch):
     pr = small_problem
     # the sharded loop searches every point in every sweep; the plain loop it is held against bit for bit does the same
     # here (its certificate sweep adds the same terms in another grouping: tests/test_gpu_stack_shapes.py)
-    monkeypatch.setenv("LSLAM_KNN_CERT", "0")
+    every = ctx.default_opts()
+    every.knn_cert = 0
     ctx.map_set(pr["map_corner"], pr["map_surf"])
     ctx.scan_set(pr["corner"], pr["surf"])
-    status, pose, st = ctx.run(pr["init_pose"])
+    status, pose, st = ctx.run(pr["init_pose"], every)
     calls = []
     x = torch.zeros(32, dtype=torch.float64, device="cuda")
-    s1, p1, st1 = ctx.run_sharded(pr["init_pose"], lambda ptr, n: calls.append((ptr, n)), x)
+    s1, p1, st1 = ctx.run_sharded(pr["init_pose"], lambda ptr, n: calls.append((ptr, n)), x, opts=every)
     assert calls[0] == (x.data_ptr(), 32) and len(calls) == 1 + st.iterations
     assert s1 == status and st1.iterations == st.iterations and np.array_equal(bits(p1), bits(pose))
     assert (st1.n_rows, st1.n_line, st1.n_plane) == (st.n_rows, st.n_line, st.n_plane)
@@ -819,13 +820,12 @@ def test_posegraph_full_size_properties(pkg, synth):
 
 
 def test_persistent_gn_loop_equals_launch_loop(pkg, synth, monkeypatch):
-    """LSLAM_PERSISTENT_GN=1: the whole Gauss-Newton loop of a resident scan in one persistent launch (every workgroup
+    """lslam_opts.ab_switches & LSLAM_AB_PERSISTENT_GN: the whole Gauss-Newton loop of a resident scan in one persistent launch (every workgroup
     keeps its own copy of the state, grid-wide exchanges of the blocks' sums, the solve replicated) -- bit for bit the
     launch loop's pose, counters and sums, for the scan-to-map settings and the mapping settings."""
     pr = synth.make_problem(rings=64, azimuth_steps=1800)
     out = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("LSLAM_PERSISTENT_GN", mode)
         c = pkg.Context(0)
         try:
             c.map_set(pr["map_corner"], pr["map_surf"])
@@ -834,6 +834,7 @@ def test_persistent_gn_loop_equals_launch_loop(pkg, synth, monkeypatch):
             for max_it, dr, dt in ((10, 0.05, 0.05), (30, 0.01, 0.01), (2, 0.05, 0.05)):
                 opts = c.default_opts()
                 opts.max_iterations, opts.delta_r_abort, opts.delta_t_abort = max_it, dr, dt
+                opts.ab_switches = 1 if mode == "1" else 0  # LSLAM_AB_PERSISTENT_GN
                 status, pose, st = c.run(pr["init_pose"], opts)
                 res.append((status, bits(pose).tolist(), st.iterations, st.n_rows, st.n_line, st.n_plane, st.converged, st.sweeps))
             out[mode] = res

@@ -93,7 +93,6 @@ def test_batch_above_512_blocks_runs_the_shallow_kernel_and_matches_oracle(ctx, 
     passes from the second sweep on).  Every scan against `oracle.scanmatch_scan`, and bit for bit against its own run alone
     through the deep stack (certificate sweep forced there too: a launch that small would search every point, which sums the
     same terms in another grouping); one scan far from the map, one empty."""
-    monkeypatch.setenv("LSLAM_KNN_CERT", "2")
     pr = small_problem
     world = pr["world"]
     scans, inits = [], []
@@ -108,6 +107,7 @@ def test_batch_above_512_blocks_runs_the_shallow_kernel_and_matches_oracle(ctx, 
     ctx.map_set(pr["map_corner"], pr["map_surf"])
     deep = ctx.default_opts()
     deep.search_mode = LANE | DEEP
+    deep.knn_cert = 2
     single = []
     before = ctx.sweep_launches()
     for (qc, qs), p0 in zip(scans, inits):
@@ -116,6 +116,7 @@ def test_batch_above_512_blocks_runs_the_shallow_kernel_and_matches_oracle(ctx, 
     ctx.scan_set_batch(scans)
     opts = ctx.default_opts()
     opts.scans_in_flight = 12
+    opts.knn_cert = 2
     before = ctx.sweep_launches()
     worst, poses, stats = ctx.run_batch(np.stack(inits), opts)
     ran = _ran(before, ctx.sweep_launches())
@@ -210,10 +211,11 @@ def test_voxel_map_batch_of_full_scans_matches_oracle(voxel_map_problem, oracle,
         assert np.abs(poses[k][3:] - vp["gts"][k][3:]).max() < 0.05, k
     # a single full scan (deep stack, latency-bound launch) gives the batch's bits -- in the batch's sweep mode (certificates,
     # which a launch this small would not take by itself)
-    monkeypatch.setenv("LSLAM_KNN_CERT", "2")
+    forced = ctx.default_opts()
+    forced.knn_cert = 2
     ctx.scan_set(*vp["scans"][1])
     before = ctx.sweep_launches()
-    status, pose1, st1 = ctx.run(vp["inits"][1])
+    status, pose1, st1 = ctx.run(vp["inits"][1], forced)
     assert set(_ran(before, ctx.sweep_launches())) == {"deep"}
     assert np.array_equal(bits(pose1), bits(poses[1])) and st1.iterations == stats[1].iterations
 
@@ -248,8 +250,8 @@ def test_certificate_sweep_equals_searching_every_point(voxel_map_problem, ctx, 
     def both(c, inits, opts, force):
         out = {}
         for mode in ("0", "2" if force else "1"):
-            monkeypatch.setenv("LSLAM_KNN_CERT", mode)
-            monkeypatch.setenv("LSLAM_DEBUG_CERT_STATS", "1")
+            opts.knn_cert = int(mode)
+            opts.debug_stats = 1
             s0 = c.cert_stats()
             worst, poses, stats = c.run_batch(inits, opts)
             s1 = c.cert_stats()
@@ -297,10 +299,11 @@ def test_certificate_sweep_equals_searching_every_point(voxel_map_problem, ctx, 
     both(ctx, np.stack(inits), o, force=True)
     # soundness does not hang on the thresholds that decide WHEN certificates are worth testing: with every scan testing
     # them from its second sweep on, however far it has just moved, the loop still finds the same neighbours
-    monkeypatch.setenv("LSLAM_CERT_TRY_M", "1e9")
-    monkeypatch.setenv("LSLAM_CERT_TRACK_M", "1e9")
-    both(ctx, np.stack(inits), ctx.default_opts(), force=True)
+    eager = ctx.default_opts()
+    eager.cert_try_m = eager.cert_track_m = 1e9
+    both(ctx, np.stack(inits), eager, force=True)
     vctx.scan_set_batch(vp["scans"])
+    opts.cert_try_m = opts.cert_track_m = 1e9
     both(vctx, vp["inits"], opts, force=False)
 
 
@@ -314,14 +317,13 @@ def test_the_bound_a_search_keeps_is_below_the_true_sixth_distance(ctx, small_pr
     pr = small_problem
     nc, ns = len(pr["corner"]), len(pr["surf"])
     trees = (cKDTree(pr["map_corner"][:, :3].astype(np.float64)), cKDTree(pr["map_surf"][:, :3].astype(np.float64)))
-    monkeypatch.setenv("LSLAM_KNN_CERT", "2")
     ctx.map_set(pr["map_corner"], pr["map_surf"])
     ctx.scan_set(pr["corner"], pr["surf"])
-    for env, iters in ((None, 2), (None, 10), ("1e9", 10)):  # after one tracked sweep; a whole loop; every sweep testing certificates
-        if env:
-            monkeypatch.setenv("LSLAM_CERT_TRY_M", env)
-            monkeypatch.setenv("LSLAM_CERT_TRACK_M", env)
+    for eager, iters in ((None, 2), (None, 10), (1e9, 10)):  # after one tracked sweep; a whole loop; every sweep testing certificates
         o = ctx.default_opts()
+        o.knn_cert = 2
+        if eager:
+            o.cert_try_m = o.cert_track_m = eager
         o.max_iterations = iters
         o.search_mode = LANE | SHALLOW
         status, pose, st = ctx.run(pr["init_pose"], o)
@@ -374,13 +376,10 @@ def test_voxel_map_batch_of_48_full_scans_properties(voxel_map_problem, pkg, syn
     opts.scans_in_flight = 16                                                                    # (b) chunked
     _, p3, s3 = ctx.run_batch(inits, opts)
     assert np.array_equal(bits(p3), bits(p1)) and [s.iterations for s in s3] == [s.iterations for s in s1]
-    import os
-    os.environ["LSLAM_KNN_CERT"] = "0"                                                           # (c)
-    try:
-        opts.scans_in_flight = 48
-        _, p0, s0 = ctx.run_batch(inits, opts)
-    finally:
-        del os.environ["LSLAM_KNN_CERT"]
+    opts.knn_cert = 0                                                                            # (c)
+    opts.scans_in_flight = 48
+    _, p0, s0 = ctx.run_batch(inits, opts)
+    opts.knn_cert = 1
     for k in range(48):
         assert (s0[k].iterations, s0[k].n_rows, s0[k].n_line, s0[k].n_plane) == (s1[k].iterations, s1[k].n_rows, s1[k].n_line, s1[k].n_plane), k
     assert np.abs(p0[:, 3:] - p1[:, 3:]).max() <= 2e-6 and np.abs(p0[:, :3] - p1[:, :3]).max() <= 2e-7
@@ -393,7 +392,7 @@ def test_voxel_map_batch_of_48_full_scans_properties(voxel_map_problem, pkg, syn
 def test_fused_solve_equals_the_solve_launch(ctx, synth, small_problem, monkeypatch):
     """The 6 x 6 solve in the tail of the sweep launch (the block that retires the scan's last record reduces and solves) against
     the solve kernel as its own launch: same reduction order, same solve -- same bits; single scan, a small batch with a scan
-    that ends early, and the mapping node's settings.  (Measured no faster: LSLAM_FUSED_SOLVE=1 is an A/B switch, off by default.)"""
+    that ends early, and the mapping node's settings.  (Measured no faster: lslam_opts.ab_switches & LSLAM_AB_FUSED_SOLVE is an A/B switch, off by default.)"""
     pr = small_problem
     ctx.map_set(pr["map_corner"], pr["map_surf"])
     world = pr["world"]
@@ -411,12 +410,9 @@ def test_fused_solve_equals_the_solve_launch(ctx, synth, small_problem, monkeypa
     res = {}
     # the fused tail rides on the one-launch sweep: the certificate sweep (two launches, the same terms summed in another
     # grouping) is held against it and the oracle by test_certificate_sweep_equals_searching_every_point
-    monkeypatch.setenv("LSLAM_KNN_CERT", "0")
+    opts.knn_cert = mopts.knn_cert = 0
     for fused in (True, False):
-        if fused:
-            monkeypatch.setenv("LSLAM_FUSED_SOLVE", "1")
-        else:
-            monkeypatch.delenv("LSLAM_FUSED_SOLVE", raising=False)
+        opts.ab_switches = mopts.ab_switches = 2 if fused else 0  # LSLAM_AB_FUSED_SOLVE
         before = ctx.sweep_launches()
         ctx.scan_set(*scans[0])
         a = ctx.run(inits[0], opts)

@@ -48,6 +48,12 @@ class LslamOpts(C.Structure):
         ("profile", C.c_int32),
         ("scans_in_flight", C.c_int32),
         ("search_mode", C.c_int32),
+        ("knn_cert", C.c_int32),
+        ("cert_try_m", C.c_float),
+        ("cert_track_m", C.c_float),
+        ("grid_cell", C.c_float),
+        ("debug_stats", C.c_int32),
+        ("ab_switches", C.c_int32),
     ]
 
 
@@ -225,13 +231,15 @@ SYMBOLS = {
     "lslam_comm_create": (C.c_int, [C.c_int, c_uint8_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "lslam_comm_destroy": (None, [C.c_void_p]),
     "lslam_comm_info": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p]),
+    "lslam_debug_grid_launches": (C.c_uint64, [C.c_void_p]),
     "lslam_comm_allreduce_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "lslam_ctx_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lslam_pg_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 
 COMM_ID_BYTES = 128
-SEARCH_AUTO, SEARCH_LANE, SEARCH_PACKET = 0, 1, 2
+SEARCH_AUTO, SEARCH_LANE, SEARCH_PACKET, SEARCH_GRID = 0, 1, 2, 3
+AB_PERSISTENT_GN, AB_FUSED_SOLVE = 1, 2  # lslam_opts.ab_switches (LSLAM_AB_*)
 STACK_AUTO, STACK_DEEP, STACK_SHALLOW = 0, 0x100, 0x200  # ORed into a search mode (LSLAM_STACK_*)
 # lslam_debug_sweep_launches: index of each sweep-kernel instantiation
 SWEEP_VARIANTS = ("deep", "deep_ovf", "shallow", "cubes", "cubes_ovf", "packet", "persistent", "deep_fused")

@@ -223,6 +223,20 @@ struct lslam_ctx {
   int32_t n_stereo = 0;
   StereoCam st_cam{};
   uint64_t sweep_variants[SWEEP_N_VARIANTS] = {0};  // sweep launches per kernel instantiation (lslam_debug_sweep_launches)
+  // cell grids over the whole-map trees (lslam_grid.hpp), built the first time the grid search is asked for on a map
+  GridDev kc, ks;
+  uint64_t map_epoch = 0;      // bumped whenever the resident trees change
+  uint64_t grid_epoch = ~0ull; // the map the grids were built from
+  float grid_cell = 0.0f;      // ... and their cell size
+  int grid_status = 0;         // why they could not be built (GridDev::build), 0: fine
+  // environment overrides of lslam_opts fields, read ONCE when the context is made (never inside a call)
+  int env_knn_cert = -1;       // LSLAM_KNN_CERT (-1: not set)
+  float env_cert_try_m = -1.0f, env_cert_track_m = -1.0f, env_grid_cell = -1.0f;  // LSLAM_CERT_TRY_M, LSLAM_CERT_TRACK_M, LSLAM_GRID_CELL
+  int env_search = -1;         // LSLAM_SEARCH=lane|packet|grid
+  int env_debug_cert_stats = 0;  // LSLAM_DEBUG_CERT_STATS
+  int env_force_stack = -1;    // LSLAM_FORCE_STACK=deep|shallow|auto -> SWEEP_STACK_*
+  int env_ab = 0;              // LSLAM_PERSISTENT_GN=1, LSLAM_FUSED_SOLVE=1 -> LSLAM_AB_* bits
+  bool env_debug = false;      // LSLAM_DEBUG
 };
 
 namespace {
@@ -289,6 +303,10 @@ void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
     a.gc = ctx->gc;
     a.gs = ctx->gs;
   }
+  a.kc = CellGrid{};
+  a.ks = CellGrid{};
+  a.grid = 0;
+  a.grid_clip_margin = GRID_CLIP_MARGIN_MIN;
   a.q = ctx->q.p;
   a.blocks = ctx->blocks.p;
   a.nb_total = ctx->nb_total;
@@ -337,52 +355,82 @@ int ensure_packet_nodes(lslam_ctx *ctx) {
   return LSLAM_OK;
 }
 
+// The cell grids of the resident whole-map trees (lslam_grid.hpp), made the first time the grid search is asked for on this
+// map with this cell size.  LSLAM_OK with ctx->kc.view.cell_start == nullptr: no grid for this map (ctx->grid_status).
+int ensure_grid(lslam_ctx *ctx, float cell) {
+  if (!ctx->have_map || ctx->cube_mode) return LSLAM_OK;
+  if (!(cell > 0.0f)) cell = GRID_CELL_DEFAULT;
+  if (ctx->grid_epoch == ctx->map_epoch && ctx->grid_cell == cell) return LSLAM_OK;
+  ctx->grid_epoch = ctx->map_epoch;
+  ctx->grid_cell = cell;
+  int st_c = 0, st_s = 0;
+  HIP_TRY(ctx->kc.build(ctx->tc.view, cell, ctx->stream, &st_c));
+  HIP_TRY(ctx->ks.build(ctx->ts.view, cell, ctx->stream, &st_s));
+  ctx->grid_status = st_c ? st_c : st_s;
+  if (ctx->grid_status || !ctx->kc.view.cell_start || !ctx->ks.view.cell_start) {  // both or none
+    ctx->kc.view = CellGrid{};
+    ctx->ks.view = CellGrid{};
+  }
+  return LSLAM_OK;
+}
+
 int resolve_search_mode(const lslam_ctx *ctx, int32_t requested) {
-  static const char *env = std::getenv("LSLAM_SEARCH");
-  if (env && !std::strcmp(env, "lane")) requested = LSLAM_SEARCH_LANE;
-  if (env && !std::strcmp(env, "packet")) requested = LSLAM_SEARCH_PACKET;
+  if (ctx->env_search >= 0) requested = ctx->env_search;
   requested &= 0xFF;  // the LSLAM_STACK_* bits are resolve_stack_mode's
   if (ctx->cube_mode) return LSLAM_SEARCH_LANE;
   if (requested == LSLAM_SEARCH_PACKET) {  // its nodes exist only once somebody has asked for it
     if (ensure_packet_nodes(const_cast<lslam_ctx *>(ctx)) != LSLAM_OK || !ctx->tc.view.pn || !ctx->ts.view.pn) return LSLAM_SEARCH_LANE;
     return requested;
   }
+  if (requested == LSLAM_SEARCH_GRID) return LSLAM_SEARCH_GRID;  // (the caller builds the grids: ensure_grid)
   return LSLAM_SEARCH_LANE;
 }
 
 // Traversal-stack shape asked for: LSLAM_STACK_* bits of a search mode, overridden by LSLAM_FORCE_STACK=deep|shallow|auto
-// in the environment (read per call: tests switch it between calls).
-int resolve_stack_mode(int32_t search_mode) {
-  int m = (search_mode & LSLAM_STACK_SHALLOW) ? SWEEP_STACK_SHALLOW : ((search_mode & LSLAM_STACK_DEEP) ? SWEEP_STACK_DEEP : SWEEP_STACK_AUTO);
-  if (const char *env = std::getenv("LSLAM_FORCE_STACK")) {
-    if (!std::strcmp(env, "deep")) m = SWEEP_STACK_DEEP;
-    else if (!std::strcmp(env, "shallow")) m = SWEEP_STACK_SHALLOW;
-    else if (!std::strcmp(env, "auto")) m = SWEEP_STACK_AUTO;
-  }
-  return m;
+// of the environment the context was made in.
+int resolve_stack_mode(const lslam_ctx *ctx, int32_t search_mode) {
+  if (ctx->env_force_stack >= 0) return ctx->env_force_stack;
+  return (search_mode & LSLAM_STACK_SHALLOW) ? SWEEP_STACK_SHALLOW : ((search_mode & LSLAM_STACK_DEEP) ? SWEEP_STACK_DEEP : SWEEP_STACK_AUTO);
 }
 
 // launch_sweep + the per-context count of the instantiation it took
 hipError_t sweep_launch(lslam_ctx *ctx, const SweepArgs &a, int jtj_mode, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
                         int *variant = nullptr) {
   int v = -1;
+  CertPlan plan;
+  plan.work = ctx->cert_work.p;
+  plan.count = ctx->cert_count.p + (ctx->queue_launches & 1);
+  plan.count_next = ctx->cert_count.p + ((ctx->queue_launches + 1) & 1);
+  plan.ticket = plan.count + 2;
+  plan.ticket_next = plan.count_next + 2;
+  if (a.grid) {  // the grid sweep: probe + proof for every point, then the tree search for the points it listed; timed as one
+    if (a.nb_total <= 0 || a.n_groups <= 0 || !a.need_cnt) return a.nb_total <= 0 ? hipSuccess : hipErrorInvalidValue;
+    hipError_t e = launch_sweep_grid(a, jtj_mode, ctx->stream, e0, nullptr);
+    v = SWEEP_VARIANT_GRID;
+    ctx->sweep_variants[v]++;
+    if (variant) *variant = v;
+    if (e != hipSuccess) return e;
+    const int pass2 = a.stack_ovf ? (a.deep_tree ? SWEEP_VARIANT_DEEP_OVF : SWEEP_VARIANT_SHALLOW) : SWEEP_VARIANT_DEEP;
+    e = launch_sweep_queue(a, jtj_mode, ctx->stream, e1, pass2, plan);
+    ctx->queue_launches++;
+    return e;
+  }
   // certificate sweep: from the second sweep of a loop a second launch searches the points pass 1 listed (sweep_body); the
   // pair is timed as one
   // (n_groups > 0: the two counter pairs of the plan alternate per LAUNCHED plan -- each zeroes the other's -- so a sweep
   // with nothing to plan must not advance them)
+  bool cert_launched = false;
   const bool two_pass = a.prev_q && a.need_cnt && a.bounded && a.prev_valid && !a.tail.count && !a.gc.trees && a.n_groups > 0 && a.nb_total > 0;
-  hipError_t e = launch_sweep(a, jtj_mode, ctx->stream, e0, two_pass ? nullptr : e1, &v);
+  hipError_t e = launch_sweep(a, jtj_mode, ctx->stream, e0, two_pass ? nullptr : e1, &v, &cert_launched);
   if (v >= 0 && v < SWEEP_N_VARIANTS) ctx->sweep_variants[v]++;
   if (variant) *variant = v;
   if (e == hipSuccess && two_pass) {
-    CertPlan plan;
-    plan.work = ctx->cert_work.p;
-    plan.count = ctx->cert_count.p + (ctx->queue_launches & 1);
-    plan.count_next = ctx->cert_count.p + ((ctx->queue_launches + 1) & 1);
-    plan.ticket = plan.count + 2;
-    plan.ticket_next = plan.count_next + 2;
-    e = launch_sweep_queue(a, jtj_mode, ctx->stream, e1, v, plan);
-    ctx->queue_launches++;
+    if (cert_launched) {  // (a build whose launch_sweep never takes the certificate instantiation lists nothing)
+      e = launch_sweep_queue(a, jtj_mode, ctx->stream, e1, v, plan);
+      ctx->queue_launches++;
+    } else if (e1) {
+      e = hipEventRecord(e1, ctx->stream);
+    }
   }
   return e;
 }
@@ -437,6 +485,10 @@ void lslam_default_opts(lslam_opts *o) {
   o->profile = 0;
   o->scans_in_flight = 0;
   o->search_mode = LSLAM_SEARCH_AUTO;
+  o->knn_cert = 1;
+  o->cert_try_m = CERT_TRY_M_DEFAULT;
+  o->cert_track_m = CERT_TRACK_M_DEFAULT;
+  o->grid_cell = 0.0f;  // GRID_CELL_DEFAULT
 }
 
 int lslam_ctx_create(int device, lslam_ctx **out) {
@@ -467,6 +519,26 @@ int lslam_ctx_create(int device, lslam_ctx **out) {
   }
   HIP_TRY(hipEventCreate(&ctx->ev0));
   HIP_TRY(hipEventCreate(&ctx->ev1));
+  // Environment overrides of lslam_opts fields (A/B runs of a binary one cannot pass options to): read here, once per
+  // context -- never inside a call, where another thread's setenv would race with it.
+  if (const char *v = std::getenv("LSLAM_KNN_CERT")) ctx->env_knn_cert = std::atoi(v);
+  if (const char *v = std::getenv("LSLAM_CERT_TRY_M")) ctx->env_cert_try_m = (float)std::atof(v);
+  if (const char *v = std::getenv("LSLAM_CERT_TRACK_M")) ctx->env_cert_track_m = (float)std::atof(v);
+  if (const char *v = std::getenv("LSLAM_GRID_CELL")) ctx->env_grid_cell = (float)std::atof(v);
+  if (const char *v = std::getenv("LSLAM_DEBUG_CERT_STATS")) ctx->env_debug_cert_stats = std::atoi(v);
+  if (const char *v = std::getenv("LSLAM_FORCE_STACK")) {
+    if (!std::strcmp(v, "deep")) ctx->env_force_stack = SWEEP_STACK_DEEP;
+    else if (!std::strcmp(v, "shallow")) ctx->env_force_stack = SWEEP_STACK_SHALLOW;
+    else if (!std::strcmp(v, "auto")) ctx->env_force_stack = SWEEP_STACK_AUTO;
+  }
+  if (const char *v = std::getenv("LSLAM_PERSISTENT_GN")) ctx->env_ab |= std::atoi(v) == 1 ? LSLAM_AB_PERSISTENT_GN : 0;
+  if (const char *v = std::getenv("LSLAM_FUSED_SOLVE")) ctx->env_ab |= std::atoi(v) == 1 ? LSLAM_AB_FUSED_SOLVE : 0;
+  ctx->env_debug = std::getenv("LSLAM_DEBUG") != nullptr;
+  if (const char *v = std::getenv("LSLAM_SEARCH")) {
+    if (!std::strcmp(v, "lane")) ctx->env_search = LSLAM_SEARCH_LANE;
+    else if (!std::strcmp(v, "packet")) ctx->env_search = LSLAM_SEARCH_PACKET;
+    else if (!std::strcmp(v, "grid")) ctx->env_search = LSLAM_SEARCH_GRID;
+  }
   {
     std::lock_guard<std::mutex> lk(g_live_mu);
     g_live.insert(ctx);
@@ -495,6 +567,8 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   ctx->groups.release();
   ctx->cert_work.release();
   ctx->cert_count.release();
+  ctx->kc.release();
+  ctx->ks.release();
   ctx->xchg.release();
   ctx->gnp_slots.release(); ctx->gnp_bar.release();
   ctx->q.release(); ctx->blocks.release(); ctx->probs.release(); ctx->partials.release(); ctx->stack_ovf.release();
@@ -518,7 +592,7 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
 
 void *lslam_stream(lslam_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
-void lslam_debug_cert_stats(lslam_ctx *ctx, uint64_t out[3]) {  // out[0], out[1] need LSLAM_DEBUG_CERT_STATS=1 during the runs
+void lslam_debug_cert_stats(lslam_ctx *ctx, uint64_t out[3]) {  // out[0], out[1] need lslam_opts.debug_stats (or LSLAM_DEBUG_CERT_STATS=1 when the context was made) during the runs
   out[0] = out[1] = out[2] = 0;
   if (!ctx) return;
   if (ctx->cert_stats.p && hipMemcpy(out, ctx->cert_stats.p, 16, hipMemcpyDeviceToHost) != hipSuccess) out[0] = out[1] = 0;
@@ -534,6 +608,8 @@ int lslam_debug_cert_state(lslam_ctx *ctx, float *q_xyz0, float *lb, size_t cap_
   if (n && lb && hipMemcpy(lb, ctx->prev_lb.p, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return LSLAM_ERR_HIP;
   return (int)n;
 }
+
+uint64_t lslam_debug_grid_launches(lslam_ctx *ctx) { return ctx ? ctx->sweep_variants[SWEEP_VARIANT_GRID] : 0; }
 
 void lslam_debug_sweep_launches(lslam_ctx *ctx, uint64_t counts[8]) {
   for (int i = 0; i < 8; ++i) counts[i] = ctx ? ctx->sweep_variants[i] : 0;
@@ -594,7 +670,8 @@ int lslam_debug_sweep_clocks(lslam_ctx *ctx, const float pose[6], int32_t jtj_mo
   HIP_TRY(hipMalloc((void **)&d, words * sizeof(uint64_t)));
   HIP_TRY(hipMemsetAsync(d, 0, words * sizeof(uint64_t), ctx->stream));
   sa.dbg = d;
-  sa.bounded = std::getenv("LSLAM_UNBOUNDED_KNN") ? 0 : 1;
+  static const bool unbounded_dbg = std::getenv("LSLAM_UNBOUNDED_KNN") != nullptr;
+  sa.bounded = unbounded_dbg ? 0 : 1;
   sa.prev_valid = ctx->prev_valid ? 1 : 0;
   if (sa.bounded) ctx->prev_valid = true;
   HIP_TRY(sweep_launch(ctx, sa, jtj_mode));
@@ -642,6 +719,7 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
     return LSLAM_ERR_INVALID;
   }
   ctx->have_map = false;
+  ctx->map_epoch++;
   ctx->cube_mode = false;
   ctx->prev_valid = false;
   const double t0 = now_ms();
@@ -749,6 +827,7 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
   ctx->info.built_on_device = 1;  // there is no other builder
   ctx->info.build_attempts = attempts_used;
   ctx->have_map = true;
+  ctx->map_epoch++;
   return LSLAM_OK;
 }
 }  // namespace
@@ -774,6 +853,7 @@ int cubemap_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t nc, const 
   int rc = check_ctx(ctx);
   if (rc) return rc;
   ctx->have_map = false;
+  ctx->map_epoch++;
   ctx->prev_valid = false;
   const double t0 = now_ms();
   int dc = 0, ds = 0, fb = 0;
@@ -801,6 +881,7 @@ int cubemap_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t nc, const 
   ctx->info.built_on_device = 1;
   ctx->cube_mode = true;
   ctx->have_map = true;
+  ctx->map_epoch++;
   return LSLAM_OK;
 }
 int cubemap_set_views(lslam_ctx *ctx, const std::vector<TreeView> &views_c, const std::vector<int32_t> &cells_c, size_t nc,
@@ -809,6 +890,7 @@ int cubemap_set_views(lslam_ctx *ctx, const std::vector<TreeView> &views_c, cons
   int rc = check_ctx(ctx);
   if (rc) return rc;
   ctx->have_map = false;
+  ctx->map_epoch++;
   ctx->prev_valid = false;
   if (depth_c > KD_STACK_MAX || depth_s > KD_STACK_MAX) {
     set_err("kd-tree depth %d/%d exceeds device stack %d", depth_c, depth_s, KD_STACK_MAX);
@@ -846,18 +928,20 @@ int cubemap_set_views(lslam_ctx *ctx, const std::vector<TreeView> &views_c, cons
   ctx->info.build_attempts = 1;
   ctx->cube_mode = true;
   ctx->have_map = true;
+  ctx->map_epoch++;
   return LSLAM_OK;
 }
 void cubemap_drop_views(lslam_ctx *ctx) {
   if (ctx->cube_mode) {
     ctx->have_map = false;
+    ctx->map_epoch++;
     ctx->cube_mode = false;
   }
 }
 void set_error(const char *msg) { set_err("%s", msg); }
 hipStream_t ctx_stream(lslam_ctx *ctx) { return ctx->stream; }
 TreeView ctx_tree_view(lslam_ctx *ctx, int which) { return which ? ctx->ts.view : ctx->tc.view; }
-void ctx_invalidate_map(lslam_ctx *ctx) { ctx->have_map = false; ctx->have_scan = false; }
+void ctx_invalidate_map(lslam_ctx *ctx) { ctx->have_map = false; ctx->map_epoch++; ctx->have_scan = false; }
 int ctx_scratch(lslam_ctx *ctx, size_t n_float4, size_t n_double, float4 **pts, double **dbl) {
   HIP_TRY(ctx->t_q.reserve(n_float4 ? n_float4 : 1));
   HIP_TRY(ctx->xchg.reserve(n_double ? n_double : 1));
@@ -979,6 +1063,7 @@ int lslam_cubemap_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const
     return LSLAM_ERR_INVALID;
   }
   ctx->have_map = false;
+  ctx->map_epoch++;
   ctx->prev_valid = false;
   const double t0 = now_ms();
   int dc = 0, ds = 0;
@@ -1005,6 +1090,7 @@ int lslam_cubemap_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const
   ctx->info.built_on_device = ctx->cube_sides_on_device == 2 ? 1 : 0;
   ctx->cube_mode = true;
   ctx->have_map = true;
+  ctx->map_epoch++;
   return LSLAM_OK;
 }
 
@@ -1216,7 +1302,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
   SweepArgs sa;
   fill_sweep_args(ctx, sa);
   sa.packet = search == LSLAM_SEARCH_PACKET ? 1 : 0;
-  sa.stack_mode = resolve_stack_mode(o.search_mode);
+  sa.stack_mode = resolve_stack_mode(ctx, o.search_mode);
   // the production sweep keeps a shallow stack in LDS: it always gets the overflow area (sized per
   // chunk below; the sharded path has one resident scan)
   const bool sharded = fn != nullptr || use_comm;
@@ -1343,12 +1429,12 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
   // One resident scan: the whole loop in ONE persistent launch (gn_persistent_kernel) when every block of the sweep can
   // be resident at once and nothing needs the launches in between (per-launch profiling, the stereo term, the exchange of
   // a sharded run, per-cube trees, the packet search, trees deeper than the LDS stack).  OFF by default
-  // (LSLAM_PERSISTENT_GN=1 turns it on): bit-identical results, but measured no faster than the launch loop -- 327 us
+  // (lslam_opts.ab_switches & LSLAM_AB_PERSISTENT_GN turns it on): bit-identical results, but measured no faster than the launch loop -- 327 us
   // against 315 us of device time per four-iteration scanMatchScan of 115 200 points; the two grid exchanges and the
   // replicated solve of an iteration cost what the solve launch and its two gaps do.
   bool gnp_done = false;
   {
-    const bool gnp_off = !(std::getenv("LSLAM_PERSISTENT_GN") && std::atoi(std::getenv("LSLAM_PERSISTENT_GN")) == 1);
+    const bool gnp_off = !((o.ab_switches | ctx->env_ab) & LSLAM_AB_PERSISTENT_GN);
     static const bool unbounded = std::getenv("LSLAM_UNBOUNDED_KNN") != nullptr;
     if (!sharded && n_scans == 1 && !gnp_off && ctx->gnp_ok && !o.profile && ctx->n_stereo == 0 && !ctx->cube_mode &&
         !sa.packet && sa.stack_mode != SWEEP_STACK_SHALLOW && max_it > 0 && ctx->tc.depth <= KD_STACK_LDS + 1 && ctx->ts.depth <= KD_STACK_LDS + 1 &&
@@ -1386,7 +1472,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
           ctx->gnp_runs++;
           launched = ctx->h_state[0].sweeps;
         } else {  // an exchange ran into its spin limit (the workgroups were not all resident): the launch loop, from the start
-          if (std::getenv("LSLAM_DEBUG")) fprintf(stderr, "[lslam] persistent GN kernel timed out in its grid exchange: launch loop from here on\n");
+          if (ctx->env_debug) fprintf(stderr, "[lslam] persistent GN kernel timed out in its grid exchange: launch loop from here on\n");
           ctx->gnp_ok = false;
           init_state(ctx->h_state[0], poses);
           HIP_TRY(hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(GNState), hipMemcpyHostToDevice, ctx->stream));
@@ -1399,17 +1485,30 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
     const int n_chunks = (n_scans + in_flight - 1) / in_flight;
     static const bool unbounded = std::getenv("LSLAM_UNBOUNDED_KNN") != nullptr;  // A/B switch
     sa.bounded = (ctx->cube_mode || unbounded) ? 0 : 1;  // per-cube positions are tree-relative
-    // neighbour lists carried from sweep to sweep by certificate where a point has hardly moved (sweep_body); LSLAM_KNN_CERT=0
-    // (read per call) searches every point in every sweep
-    const int cert_env = std::getenv("LSLAM_KNN_CERT") ? std::atoi(std::getenv("LSLAM_KNN_CERT")) : 1;
-    const bool no_cert = cert_env == 0, force_cert = cert_env == 2;
+    // The grid sweep (LSLAM_SEARCH_GRID): cell grids over the resident trees, made on first use.  A map the grid cannot take
+    // (non-finite points, an extent beyond the grid's limits) is searched by the tree as before.
+    if (search == LSLAM_SEARCH_GRID && sa.bounded) {
+      rc = ensure_grid(ctx, ctx->env_grid_cell > 0.0f ? ctx->env_grid_cell : o.grid_cell);
+      if (rc) return rc;
+      if (ctx->kc.view.cell_start && ctx->ks.view.cell_start) {
+        sa.kc = ctx->kc.view;
+        sa.ks = ctx->ks.view;
+        sa.grid = 1;
+        sa.grid_clip_margin = GRID_CLIP_MARGIN_MIN;
+      }
+    }
+    // neighbour lists carried from sweep to sweep by certificate where a point has hardly moved (sweep_body): lslam_opts.knn_cert
+    // = 0 searches every point in every sweep, 2 takes the certificate sweep whatever the size of the launch (tests); the
+    // environment's LSLAM_KNN_CERT / LSLAM_CERT_TRY_M / LSLAM_CERT_TRACK_M, read when the context was made, override the options
+    const int cert_mode = ctx->env_knn_cert >= 0 ? ctx->env_knn_cert : o.knn_cert;
+    const bool no_cert = cert_mode == 0 || sa.grid, force_cert = cert_mode == 2;
     sa.prev_q = (sa.bounded && !no_cert && !sa.packet) ? ctx->prev_q.p : nullptr;
     if (sa.prev_q) {
       sa.prev_lb = ctx->prev_lb.p;
-      sa.cert_try_m = std::getenv("LSLAM_CERT_TRY_M") ? (float)std::atof(std::getenv("LSLAM_CERT_TRY_M")) : CERT_TRY_M_DEFAULT;
-      sa.cert_track_m = std::getenv("LSLAM_CERT_TRACK_M") ? (float)std::atof(std::getenv("LSLAM_CERT_TRACK_M")) : CERT_TRACK_M_DEFAULT;
+      sa.cert_try_m = ctx->env_cert_try_m >= 0.0f ? ctx->env_cert_try_m : (o.cert_try_m > 0.0f ? o.cert_try_m : CERT_TRY_M_DEFAULT);
+      sa.cert_track_m = ctx->env_cert_track_m >= 0.0f ? ctx->env_cert_track_m : (o.cert_track_m > 0.0f ? o.cert_track_m : CERT_TRACK_M_DEFAULT);
     }
-    if (sa.prev_q && std::getenv("LSLAM_DEBUG_CERT_STATS")) {
+    if ((sa.prev_q || sa.grid) && (ctx->env_debug_cert_stats || o.debug_stats)) {
       if (!ctx->cert_stats.p) {
         HIP_TRY(ctx->cert_stats.reserve(2));
         HIP_TRY(hipMemsetAsync(ctx->cert_stats.p, 0, 16, ctx->stream));
@@ -1418,7 +1517,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
     }
     std::vector<int> done_iters((size_t)n_chunks, 0);    // iterations enqueued per chunk
     std::vector<char> finished((size_t)n_chunks, 0);
-    // LSLAM_FUSED_SOLVE=1 (read per call: the tests switch it): the solve rides in the tail of the sweep launch whenever that
+    // lslam_opts.ab_switches & LSLAM_AB_FUSED_SOLVE: the solve rides in the tail of the sweep launch whenever that
     // launch is a latency-bound one (launch_sweep takes the whole-stack kernel: single scans, small batches) -- the block that
     // retires a scan's last record reduces and solves, one launch per Gauss-Newton iteration.  Bit-identical to the solve
     // kernel as its own launch (tests/test_gpu_stack_shapes.py) and MEASURED NO FASTER, so off by default: per working
@@ -1427,8 +1526,8 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
     // tail is the solve's own dependent chain (reduction round trip, 6 x 6 QR, pose update: ~13 us) run by ONE workgroup
     // that first had to finish its share of the sweep, reading the records through the coherence point; the launch it saves
     // costs less than that.  Not with the stereo term (its records come from a launch of their own).
-    const bool no_fuse = !(std::getenv("LSLAM_FUSED_SOLVE") && std::atoi(std::getenv("LSLAM_FUSED_SOLVE")) == 1);
-    if (!no_fuse && ctx->n_stereo == 0) {
+    const bool no_fuse = !((o.ab_switches | ctx->env_ab) & LSLAM_AB_FUSED_SOLVE);
+    if (!no_fuse && ctx->n_stereo == 0 && !sa.grid) {
       sa.tail.count = ctx->tail_count.p;
       sa.tail.probs = ctx->probs.p;
       sa.tail.partials_abs = ctx->partials.p;
@@ -1452,7 +1551,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
       // throughput-bound launches only (launch_sweep's own test: more wavefronts than two per SIMD): a launch that fits the
       // device at once ends when its slowest wavefront does, certificates or not, and the second pass is two launches more
       // per iteration (measured on single scans: 0.29 against 0.26 ms per loop).  LSLAM_KNN_CERT=2 takes it regardless (tests)
-      if (sc.prev_q && !sc.tail.count && (force_cert || (long)sc.nb_total * (SWEEP_BLOCK / 64) > 2 * 1024)) {
+      if ((sc.grid || sc.prev_q) && !sc.tail.count && (sc.grid || force_cert || (long)sc.nb_total * (SWEEP_BLOCK / 64) > 2 * 1024)) {
         if (!cert_counters_reset) {  // once per call: whatever an earlier call that ended in an error left in the plan's counters
           HIP_TRY(hipMemsetAsync(ctx->cert_count.p, 0, 4 * sizeof(int32_t), ctx->stream));
           cert_counters_reset = true;
@@ -1553,6 +1652,17 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
         sc.blocks = ctx->blocks.p + fb;
         sc.nb_total = lb - fb;
         sc.partials = ctx->partials.p + (size_t)fb * NCOL;
+        if (sc.grid) {  // the grid sweep's second pass (as enqueue() sets it up)
+          if (sharded) {
+            sc.grid = 0;
+          } else {
+            sc.need_list = ctx->need_list.p + (size_t)fb * SWEEP_BLOCK;
+            sc.need_cnt = ctx->need_cnt.p + fb;
+            sc.groups = ctx->groups.p + ctx->h_prob_group0[(size_t)p0];
+            sc.n_groups = ctx->h_prob_group0[(size_t)p1] - ctx->h_prob_group0[(size_t)p0];
+            sc.group_block_base = fb;
+          }
+        }
         SolveArgs soc = so;
         soc.states = ctx->d_state + p0;
         soc.probs = ctx->probs.p + p0;
@@ -1848,7 +1958,8 @@ int lslam_odometry_match(lslam_ctx *ctx, const void *last_corner, size_t n_lc, c
   // builder as its fallback -- the same path as lslam_map_set)
   rc = map_set_impl(ctx, lc.data(), n_lc, ls.data(), n_ls, sizeof(float4), nullptr, nullptr);
   if (rc) return rc;
-  ctx->have_map = false;  // these trees belong to this call, not to a resident map
+  ctx->have_map = false;
+  ctx->map_epoch++;  // these trees belong to this call, not to a resident map
   if (ctx->tc.depth > KD_STACK_LDS + 1 || ctx->ts.depth > KD_STACK_LDS + 1) {
     set_err("kd-tree deeper than %d", KD_STACK_LDS + 1);
     return LSLAM_ERR_TREE_DEPTH;
@@ -2063,6 +2174,19 @@ int lslam_knn5_ex(lslam_ctx *ctx, int which_map, const void *queries, size_t nq,
     HIP_TRY(hipMemsetAsync(d_tie, 0, sizeof(int32_t), ctx->stream));
     HIP_TRY(launch_knn5_packet(T, ctx->t_q.p, (int)nq, ctx->t_idx.p, ctx->t_d2.p, ctx->stack_ovf.p, d_tie, ctx->stream));
     if (n_ties) HIP_TRY(hipMemcpyAsync(n_ties, d_tie, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  } else if ((search_mode & 0xFF) == LSLAM_SEARCH_GRID) {
+    // the grid probe; n_ties receives the queries it could not prove (searched in the tree by the same kernel)
+    rc = ensure_grid(ctx, ctx->env_grid_cell > 0.0f ? ctx->env_grid_cell : 0.0f);
+    if (rc) return rc;
+    const CellGrid &G = which_map ? ctx->ks.view : ctx->kc.view;
+    if (!G.cell_start) { set_err("this map has no cell grid (status %d)", ctx->grid_status); return LSLAM_ERR_INVALID; }
+    const size_t nthr = ((nq + 255) / 256) * 256;
+    HIP_TRY(ctx->stack_ovf.reserve(stack_ovf_words(nthr)));
+    HIP_TRY(ctx->t_small.reserve(64));
+    int32_t *d_cnt = reinterpret_cast<int32_t *>(ctx->t_small.p);
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int32_t), ctx->stream));
+    HIP_TRY(launch_knn5_grid(G, T, ctx->t_q.p, (int)nq, ctx->t_idx.p, ctx->t_d2.p, ctx->stack_ovf.p, d_cnt, ctx->stream));
+    if (n_ties) HIP_TRY(hipMemcpyAsync(n_ties, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   } else {
     rc = ensure_stack_ovf(ctx, ((nq + 127) / 128) * 128, &ovf);
     if (rc) return rc;
@@ -2121,7 +2245,7 @@ int lslam_sweep_ex(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_
   fill_sweep_args(ctx, sa);
   rc = ensure_stack_ovf(ctx, (size_t)sa.nb_total * SWEEP_BLOCK, &sa.stack_ovf);
   if (rc) return rc;
-  sa.stack_mode = resolve_stack_mode(search_mode);
+  sa.stack_mode = resolve_stack_mode(ctx, search_mode);
   search_mode &= 0xFF;
   if (sa.stack_mode == SWEEP_STACK_SHALLOW && !ctx->cube_mode) {  // the batch kernel's stack shape on this (unbounded) tap
     HIP_TRY(ctx->stack_ovf.reserve(stack_ovf_words((size_t)std::max(sa.nb_total, 1) * SWEEP_BLOCK, std::max(ctx->tc.depth, ctx->ts.depth))));
@@ -2136,6 +2260,22 @@ int lslam_sweep_ex(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_
     HIP_TRY(ctx->stack_ovf.reserve(stack_ovf_words((size_t)std::max(sa.nb_total, 1) * SWEEP_BLOCK)));
     sa.stack_ovf = ctx->stack_ovf.p;
     sa.packet = 1;
+  }
+  if (search_mode == LSLAM_SEARCH_GRID) {  // the grid sweep on this (unbounded) tap: probe + proof, tree search for the rest
+    rc = ensure_grid(ctx, ctx->env_grid_cell > 0.0f ? ctx->env_grid_cell : 0.0f);
+    if (rc) return rc;
+    if (ctx->cube_mode || !ctx->kc.view.cell_start || !ctx->ks.view.cell_start) { set_err("this map has no cell grid (status %d)", ctx->grid_status); return LSLAM_ERR_INVALID; }
+    sa.kc = ctx->kc.view;
+    sa.ks = ctx->ks.view;
+    sa.grid = 1;
+    HIP_TRY(ctx->stack_ovf.reserve(stack_ovf_words((size_t)std::max(sa.nb_total, 1) * SWEEP_BLOCK, std::max(ctx->tc.depth, ctx->ts.depth))));
+    sa.stack_ovf = ctx->stack_ovf.p;
+    sa.need_list = ctx->need_list.p;
+    sa.need_cnt = ctx->need_cnt.p;
+    sa.groups = ctx->groups.p;
+    sa.n_groups = (int32_t)ctx->h_groups.size();
+    sa.group_block_base = 0;
+    HIP_TRY(hipMemsetAsync(ctx->cert_count.p, 0, 4 * sizeof(int32_t), ctx->stream));
   }
   const bool taps = idx_out || d2_out || coeff_out || flags_out;
   if (taps) {

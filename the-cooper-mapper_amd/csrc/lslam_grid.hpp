@@ -1,0 +1,299 @@
+// lslam_grid.hpp -- exact 5-NN without the tree walk: a dense cell grid over the map, a lane-uniform 3 x 3 x 3 probe and a
+// completeness proof; the kd-tree search stays as the fallback for the queries the probe cannot prove.
+//
+// What the reference fixes is the RESULT of KdTreeFLANN::nearestKSearch(p, 5, ...) (util/nanoflann_pcl.h:150-162 ->
+// nanoflann.hpp:1303-1323,1433-1497): the five map points with the smallest L2_Simple distance (x -> y -> z accumulation,
+// nanoflann.hpp:364-372), ascending, ties in visit order.  Any procedure that evaluates the same fp32 distances and can PROVE
+// that (a) no map point outside the ones it looked at can be among the five and (b) the six smallest distances are pairwise
+// distinct returns the same five indices in the same order -- without replaying nanoflann's traversal.  A query for which
+// either proof fails (sparse neighbourhood, exact distance tie) is handed to knn5_search, which replays it.
+//
+// The map is VoxelGrid output (at most one centroid per 0.2 / 0.4 m voxel and cube, util/FeatureMap.h:289-306), so a cell of
+// c ~ 0.6 m holds a handful of points and the 27 cells around a query a few dozen: fewer candidates than the ~25 inner nodes +
+// ~44 leaf slots of the bounded tree search, and -- the point -- the same instruction stream for every lane: no stack, no
+// divergent descent, one candidate per lane and round.
+//
+// Layout in HBM (built by lslam_grid.hip):
+//   pts[n]            the map points sorted by cell, {x, y, z, bitcast(original index)}
+//   cell_start[N + 1] cell -> first point, cells numbered x-fastest: cell = ix + nx (iy + ny iz); the three x-neighbours of a
+//                     cell row are ONE contiguous run of pts, so the 27 cells are nine runs (two loads each)
+//   t2g[n]            position in the kd-tree's point array -> position in pts (results of the fallback search)
+// Cell of a coordinate v on axis a: floor(fl(fl(v - org[a]) * inv_c)), the same two fp32 operations for map points and queries.
+// The grid covers the map's bounding box plus GRID_MARGIN_CELLS(c) empty cells on every side, so that a query whose cell is
+// not an interior one is farther than sqrt(5) m from every map point (the acceptance gate of ScanMatch.cpp:102,120).
+#pragma once
+
+#include "lslam_device.hpp"
+
+namespace lslam {
+
+struct CellGrid {
+  const uint32_t *cell_start;
+  const float4 *pts;
+  const int32_t *t2g;
+  float org[3];
+  float inv_c, c;
+  int32_t nx, ny, nz;
+  int32_t n_pts;
+};
+
+#ifndef LSLAM_GRID_ASM_LOOP
+#define LSLAM_GRID_ASM_LOOP 1  // 0: the candidate loop as the compiler makes it (A/B switch)
+#endif
+constexpr float GRID_CELL_DEFAULT = 0.6f;
+constexpr int GRID_MAX_DIM = 2048;        // cells per axis (the rounding slack below is sized for it)
+// Rounding of the cell coordinate u(v) = fl(fl(v - o) * inv_c): relative error <= 2^-23 on a value < GRID_MAX_DIM, so two
+// points whose cell coordinates differ by w are at least (w - GRID_U_SLACK) cells apart on that axis.
+constexpr float GRID_U_SLACK = 2.0e-3f;
+constexpr float GRID_CLIP_MARGIN_MIN = 3.0e-3f;  // [m] smallest padding of a clip radius (covers GRID_U_SLACK * c for c <= 1 m)
+inline int grid_margin_cells(float c) { return (int)(2.2361f / c) + 3; }
+
+// a candidate's place in its lane's row table, carried in the low mantissa bits of its key: row slot (9 rows) and offset
+constexpr uint32_t GRID_ROW_BITS = 6, GRID_ID_BITS = 10;
+constexpr uint32_t GRID_ID_MASK = (1u << GRID_ID_BITS) - 1u, GRID_ROW_MAX = (1u << GRID_ROW_BITS) - 1u;
+LSLAM_DEV uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// knn5_grid's verdict
+enum : int {
+  GRID_UNPROVEN = 0,  // the five returned are not proven to be nanoflann's answer: search the tree
+  GRID_PROVEN = 1,    // d[], p[] are nanoflann's answer (p: positions in G.pts)
+  GRID_FAR = 2        // the query is farther than sqrt(5) m from every map point; d[] = FLT_MAX, p[] = -1
+};
+
+// Exact 5-NN of (qx, qy, qz) among G.pts by a probe of the 3 x 3 x 3 cells around the query, one query per lane; EVERY lane of
+// the wavefront must call it (`on` false: the lane has no query and only keeps the loop's rounds company).
+//
+//   bound      an upper bound of the fifth neighbour's squared distance known in advance (FLT_MAX: none).  Cell rows and
+//              cells farther than sqrt(bound) + clip_margin from the query on some axis are not looked at.
+//   rows       this lane's row table in LDS: entry k at rows[2 * k * BLOCK], rows[2 * k * BLOCK + 1] (9 entries)
+//   lb6        (out) a lower bound of the squared distance of every map point NOT among the five returned -- the sixth
+//              smallest candidate distance, the guaranteed radius of the probe and the clip radius, whichever is smallest
+//
+// Proof obligations (GRID_PROVEN):
+//   * the query's cell is an interior cell, so all 27 cells exist;
+//   * d[4] < rg2, rg = c (1 + min over the axes of the distance to the nearer cell wall, in cells) less the rounding slack:
+//     a point outside the 27 cells differs by at least that much on one axis.  Its computed distance can be smaller than its
+//     true one by a few ulps only: rg2 carries a 1e-5 relative pad;
+//   * points in rows or cells that were clipped are farther than sqrt(bound) (padded), hence farther than five known points;
+//   * d[0] < d[1] < ... < d[4] < (sixth smallest candidate distance): no tie that nanoflann's visit order would have decided.
+template <int BLOCK>
+LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const float qy, const float qz, const float bound,
+                        const float clip_margin, lds_u32 *rows, float (&d)[5], int (&p)[5], float &lb6) {
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    d[i] = FLT_MAX;
+    p[i] = -1;
+  }
+  const float ux = __fmul_rn(__fsub_rn(qx, G.org[0]), G.inv_c);
+  const float uy = __fmul_rn(__fsub_rn(qy, G.org[1]), G.inv_c);
+  const float uz = __fmul_rn(__fsub_rn(qz, G.org[2]), G.inv_c);
+  // interior cell: 1 <= i <= n - 2 on every axis (NaN fails every comparison)
+  const bool inr = ux >= 1.0f && ux < (float)(G.nx - 1) && uy >= 1.0f && uy < (float)(G.ny - 1) && uz >= 1.0f && uz < (float)(G.nz - 1);
+  const bool alive0 = on && inr;
+  const float fx0 = floorf(ux), fy0 = floorf(uy), fz0 = floorf(uz);
+  const float ex = ux - fx0, ey = uy - fy0, ez = uz - fz0;  // position inside the cell, [0, 1)
+  const float wall = fminf(fminf(fminf(ex, 1.0f - ex), fminf(ey, 1.0f - ey)), fminf(ez, 1.0f - ez));
+  const float rg = G.c * ((1.0f - GRID_U_SLACK) + wall);
+  const float rg2 = (rg * rg) * (1.0f - 1.0e-5f);
+  // clip box in cell coordinates
+  float clip_lo2 = FLT_MAX;
+  float xlo = fx0 - 1.0f, xhi = fx0 + 1.0f, ylo = fy0 - 1.0f, yhi = fy0 + 1.0f, zlo = fz0 - 1.0f, zhi = fz0 + 1.0f;
+  if (bound < 1.0e30f) {
+    const float rb = sqrtf(bound) * (1.0f + 1.0e-5f) + clip_margin;
+    const float rbc = rb * G.inv_c;
+    xlo = fmaxf(xlo, floorf(ux - rbc)); xhi = fminf(xhi, floorf(ux + rbc));
+    ylo = fmaxf(ylo, floorf(uy - rbc)); yhi = fminf(yhi, floorf(uy + rbc));
+    zlo = fmaxf(zlo, floorf(uz - rbc)); zhi = fminf(zhi, floorf(uz + rbc));
+    const float cl = rb - GRID_U_SLACK * G.c;  // a clipped point is at least this far away
+    clip_lo2 = (cl * cl) * (1.0f - 1.0e-5f);
+  }
+  // the nine runs; all eighteen cell_start loads in flight together
+  const int ix0 = alive0 ? (int)xlo : 1, ix1 = alive0 ? (int)xhi : 1;
+  const int iy = alive0 ? (int)fy0 : 1, iz = alive0 ? (int)fz0 : 1;
+  uint32_t rs[9], re[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const int jy = iy + (r % 3) - 1, jz = iz + (r / 3) - 1;
+    const int base = G.nx * (jy + G.ny * jz);
+    rs[r] = G.cell_start[base + ix0];
+    re[r] = G.cell_start[base + ix1 + 1];
+  }
+  // non-empty, unclipped runs, compacted into this lane's LDS table
+  int nrow = 0;
+  bool row_overflow = false;
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const float jy = fy0 + (float)((r % 3) - 1), jz = fz0 + (float)((r / 3) - 1);
+    const bool use = alive0 && jy >= ylo && jy <= yhi && jz >= zlo && jz <= zhi && re[r] > rs[r];
+    if (use) {
+      rows[2 * nrow * BLOCK] = rs[r];
+      rows[(2 * nrow + 1) * BLOCK] = re[r];
+      ++nrow;
+    }
+    row_overflow = row_overflow || (use && re[r] - rs[r] > GRID_ROW_MAX + 1u);  // more candidates than an id can count (never seen on voxel maps)
+  }
+  // The candidate loop.  One candidate per lane and round; what a round keeps is ONE 32-bit key per candidate: the squared
+  // distance with its low GRID_ID_BITS mantissa bits replaced by the candidate's place in this lane's row table (row slot,
+  // offset in the row).  Squared distances are non-negative, so the keys order like the distances (to 2^-13 relative), and
+  // the six smallest keys are kept by six integer min / med3 operations -- no index selects, no per-candidate branches.
+  // After the loop the (at most) six survivors are fetched again, their exact distances recomputed with the search's own
+  // arithmetic and sorted; everybody else is at least T6 = the sixth key's truncated distance away (a key is never above
+  // the exact distance: truncation rounds towards zero), which is what the proof below needs.
+  uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu, k4 = 0xFFFFFFFFu, k5 = 0xFFFFFFFFu;
+  uint32_t cur = 0, end = 0, id = 0;
+  int k = 0;
+  bool alive = nrow > 0;
+  if (alive) {
+    cur = rows[0];
+    end = rows[BLOCK];
+    k = 1;
+  }
+  // the row after the current one waits in registers: a lane that runs out of its row takes it with two selects, and the
+  // table is read again (by every lane, its own column) only in rounds in which some lane did so.  Row overflow (a run of
+  // more than GRID_ROW_MAX + 1 candidates) was decided when the table was written.
+  uint32_t ncur = 0, nend = 0;
+  if (nrow > 1) {
+    ncur = rows[2 * BLOCK];
+    nend = rows[3 * BLOCK];
+  }
+#if LSLAM_GRID_ASM_LOOP
+  // The loop by hand (20 vector instructions per round + 12 in rounds in which a lane changes rows; left to the compiler the
+  // same loop carried eleven register copies and a three-deep exec-mask nest per round: tools/resource_usage.sh).
+  // Positions are kept as BYTE offsets into G.pts (x 16) inside the loop.
+  static_assert(BLOCK == 256, "the row table's strides are written into the loop's LDS instruction");
+  {
+    register float px asm("v2");
+    register float py asm("v3");
+    register float pz asm("v4");
+    uint32_t curb = cur << 4, endb = end << 4, ncurb = ncur << 4, nendb = nend << 4;
+    unsigned long long am = __builtin_amdgcn_ballot_w64(alive);
+    unsigned long long adv, tmp;
+    uint32_t t0, t1, key;
+    const uint32_t rowaddr = (uint32_t)(uintptr_t)rows;
+    const uint32_t keep = ~GRID_ID_MASK;
+    asm volatile(
+        "s_cmp_eq_u64 %[am], 0\n\t"
+        "s_cbranch_scc1 L_grid_done_%=\n"
+        "L_grid_loop_%=:\n\t"
+        "v_cndmask_b32 %[t0], 0, %[curb], %[am]\n\t"
+        "global_load_dwordx3 v[2:4], %[t0], %[base]\n\t"
+        "v_add_u32 %[curb], 16, %[curb]\n\t"
+        "v_cmp_eq_u32 %[adv], %[curb], %[endb]\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_sub_f32 %[t0], %[qx], %[px]\n\t"
+        "v_mul_f32 %[t0], %[t0], %[t0]\n\t"
+        "v_sub_f32 %[t1], %[qy], %[py]\n\t"
+        "v_mul_f32 %[t1], %[t1], %[t1]\n\t"
+        "v_add_f32 %[t0], %[t0], %[t1]\n\t"
+        "v_sub_f32 %[t1], %[qz], %[pz]\n\t"
+        "v_mul_f32 %[t1], %[t1], %[t1]\n\t"
+        "v_add_f32 %[t0], %[t0], %[t1]\n\t"
+        "v_and_or_b32 %[key], %[t0], %[keep], %[id]\n\t"
+        "v_add_u32 %[id], 1, %[id]\n\t"
+        "v_cndmask_b32 %[key], -1, %[key], %[am]\n\t"
+        "v_med3_u32 %[k5], %[k4], %[k5], %[key]\n\t"
+        "v_med3_u32 %[k4], %[k3], %[k4], %[key]\n\t"
+        "v_med3_u32 %[k3], %[k2], %[k3], %[key]\n\t"
+        "v_med3_u32 %[k2], %[k1], %[k2], %[key]\n\t"
+        "v_med3_u32 %[k1], %[k0], %[k1], %[key]\n\t"
+        "v_min_u32 %[k0], %[k0], %[key]\n\t"
+        "s_and_b64 %[adv], %[adv], %[am]\n\t"
+        "s_cbranch_scc0 L_grid_next_%=\n\t"
+        // some lane has finished its row
+        "v_cmp_lt_i32 vcc, %[k], %[nrow]\n\t"
+        "s_andn2_b64 %[tmp], %[adv], vcc\n\t"
+        "s_andn2_b64 %[am], %[am], %[tmp]\n\t"
+        "v_cndmask_b32 %[curb], %[curb], %[ncurb], %[adv]\n\t"
+        "v_cndmask_b32 %[endb], %[endb], %[nendb], %[adv]\n\t"
+        "v_lshlrev_b32 %[t0], 6, %[k]\n\t"
+        "v_cndmask_b32 %[id], %[id], %[t0], %[adv]\n\t"
+        "v_addc_co_u32 %[k], %[tmp], 0, %[k], %[adv]\n\t"
+        "v_min_i32 %[t0], 8, %[k]\n\t"
+        "v_lshl_add_u32 %[t0], %[t0], 11, %[rowaddr]\n\t"
+        "ds_read2st64_b32 v[2:3], %[t0] offset1:4\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_lshlrev_b32 %[ncurb], 4, %[px]\n\t"
+        "v_lshlrev_b32 %[nendb], 4, %[py]\n"
+        "L_grid_next_%=:\n\t"
+        "s_cmp_lg_u64 %[am], 0\n\t"
+        "s_cbranch_scc1 L_grid_loop_%=\n"
+        "L_grid_done_%=:\n\t"
+        : [k0] "+v"(k0), [k1] "+v"(k1), [k2] "+v"(k2), [k3] "+v"(k3), [k4] "+v"(k4), [k5] "+v"(k5), [curb] "+v"(curb), [endb] "+v"(endb),
+          [ncurb] "+v"(ncurb), [nendb] "+v"(nendb), [id] "+v"(id), [k] "+v"(k), [am] "+s"(am), [adv] "=&s"(adv), [tmp] "=&s"(tmp),
+          [t0] "=&v"(t0), [t1] "=&v"(t1), [key] "=&v"(key), [px] "=&v"(px), [py] "=&v"(py), [pz] "=&v"(pz)
+        : [qx] "v"(qx), [qy] "v"(qy), [qz] "v"(qz), [nrow] "v"(nrow), [rowaddr] "v"(rowaddr), [base] "s"(G.pts), [keep] "s"(keep)
+        : "vcc", "scc", "memory");
+  }
+#else
+  while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
+    const float4 pt = G.pts[alive ? cur : 0u];
+    const float dist = dist2_xyz(qx, qy, qz, pt);
+    uint32_t key = (__float_as_uint(dist) & ~GRID_ID_MASK) | id;
+    key = alive ? key : 0xFFFFFFFFu;
+    // six smallest keys, ascending, updated in place from the top: slot i becomes med3(old slot i-1, old slot i, key)
+    asm("v_med3_u32 %0, %1, %0, %2" : "+v"(k5) : "v"(k4), "v"(key));
+    asm("v_med3_u32 %0, %1, %0, %2" : "+v"(k4) : "v"(k3), "v"(key));
+    asm("v_med3_u32 %0, %1, %0, %2" : "+v"(k3) : "v"(k2), "v"(key));
+    asm("v_med3_u32 %0, %1, %0, %2" : "+v"(k2) : "v"(k1), "v"(key));
+    asm("v_med3_u32 %0, %1, %0, %2" : "+v"(k1) : "v"(k0), "v"(key));
+    k0 = min(k0, key);
+    cur += 1u;
+    id += 1u;
+    const bool adv = alive && cur == end;
+    if (__builtin_amdgcn_ballot_w64(adv) != 0ull) {  // wave-uniform
+      const bool more = k < nrow;
+      alive = alive && !(adv && !more);
+      cur = adv ? ncur : cur;
+      end = adv ? nend : end;
+      id = adv ? (uint32_t)k << GRID_ROW_BITS : id;
+      k += adv ? 1 : 0;
+      const int kn = k < 8 ? k : 8;  // (entry 8 may never have been written: only read, never used, in that case)
+      ncur = rows[2 * kn * BLOCK];
+      nend = rows[(2 * kn + 1) * BLOCK];
+    }
+  }
+#endif
+  // the survivors: place in the row table -> position in G.pts -> exact distance
+  const uint32_t ks[6] = {k0, k1, k2, k3, k4, k5};
+  uint32_t pos[6];
+  float4 sp[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const bool have = ks[j] != 0xFFFFFFFFu;
+    const uint32_t slot = (ks[j] & GRID_ID_MASK) >> GRID_ROW_BITS, off = ks[j] & GRID_ROW_MAX;
+    pos[j] = have ? rows[2 * slot * BLOCK] + off : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) sp[j] = G.pts[pos[j]];
+  float e6 = FLT_MAX;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const bool have = ks[j] != 0xFFFFFFFFu;
+    const float x = have ? dist2_xyz(qx, qy, qz, sp[j]) : FLT_MAX;
+    if (j < 5) knn_insert_sorted(d, p, x, have ? (int)pos[j] : -1);
+    else e6 = x;
+  }
+  // the sixth survivor may belong before some of the five (keys order the distances to 2^-13 only): offered like any other
+  // candidate, with the record of who was turned away
+  float lb = fmaxf(e6, d[4]);
+  knn_insert_sorted(d, p, e6, (int)pos[5]);
+  // everybody who is not a survivor is at least the sixth key's truncated distance away
+  const float t6 = (k5 != 0xFFFFFFFFu) ? __uint_as_float(k5 & ~GRID_ID_MASK) : FLT_MAX;
+  lb = fminf(lb, t6);
+  if (row_overflow) lb = 0.0f;
+  lb6 = fminf(fminf(lb, rg2), clip_lo2);
+  if (!inr) {
+    lb6 = 0.0f;
+    // outside the interior cells: beyond the margin, i.e. farther than the gate from the whole map -- or not a number
+    const bool num = (ux == ux) && (uy == uy) && (uz == uz);
+    return num ? GRID_FAR : GRID_UNPROVEN;
+  }
+  const bool distinct = d[0] < d[1] && d[1] < d[2] && d[2] < d[3] && d[3] < d[4];
+  return (distinct && d[4] < lb6) ? GRID_PROVEN : GRID_UNPROVEN;
+}
+
+}  // namespace lslam

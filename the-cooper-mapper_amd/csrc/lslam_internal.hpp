@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "lslam_device.hpp"
+#include "lslam_grid.hpp"
 
 namespace lslam {
 
@@ -112,6 +113,12 @@ struct SweepTail {
 struct SweepArgs {
   TreeView tc, ts;
   CubeGridDev gc, gs;  // used instead of tc/ts by the per-cube kernels
+  // cell grids of the whole-map trees (lslam_grid.hpp).  grid != 0: the sweep is the grid sweep -- sweep_grid_kernel proves
+  // the five neighbours of most points by a 27-cell probe and lists the others for sweep_queue_kernel's tree search; the
+  // neighbour ids carried from sweep to sweep (prev_nb) are then positions in kc.pts / ks.pts
+  CellGrid kc, ks;
+  int32_t grid;
+  float grid_clip_margin;  // [m] padding of the clip radius sqrt(bound) of a bounded grid search
   const float4 *q;  // scan points of all scans, sensor frame, Morton order within a scan
                     // and type, {x,y,z,bitcast(original index)}
   const BlockDesc *blocks;  // [nb_total]
@@ -237,11 +244,40 @@ enum : int {
   SWEEP_VARIANT_PACKET = 5,     // sweep_kernel<256, true, false, 4, true>
   SWEEP_VARIANT_PERSISTENT = 6, // gn_persistent_kernel
   SWEEP_VARIANT_DEEP_FUSED = 7, // sweep_kernel<256, *, false, 32> with the solve in its tail (single scans)
-  SWEEP_N_VARIANTS = 8
+  SWEEP_VARIANT_GRID = 8,       // sweep_grid_kernel<256> (+ sweep_queue_kernel for the points it could not prove)
+  SWEEP_N_VARIANTS = 9
+};
+hipError_t launch_sweep_grid(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t start, hipEvent_t stop);
+hipError_t launch_knn5_grid(const CellGrid &G, const TreeView &T, const float4 *q, int nq, int32_t *idx, float *d2,
+                            uint32_t *stack_ovf, int32_t *n_unproven, hipStream_t s);
+
+// Host side of a cell grid (lslam_grid.hip): owns the device arrays of one CellGrid.
+struct GridDev {
+  CellGrid view{};
+  size_t n_cells = 0;
+  float4 *pts = nullptr;
+  int32_t *t2g = nullptr, *err = nullptr;
+  uint32_t *cell_start = nullptr, *count = nullptr, *key0 = nullptr, *key1 = nullptr, *val0 = nullptr, *val1 = nullptr;
+  char *tmp = nullptr;
+  size_t cap_pts = 0, cap_t2g = 0, cap_cell = 0, cap_count = 0, cap_k0 = 0, cap_k1 = 0, cap_v0 = 0, cap_v1 = 0, cap_err = 0, cap_tmp = 0;
+  template <typename T>
+  static hipError_t reserve(T *&p, size_t &cap, size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = n + n / 8 + 64;
+    hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  // status: 0 built (or nothing to build: view.cell_start stays null), 1 non-finite point, 2 map too large for the grid
+  hipError_t build(const TreeView &T, float cell, hipStream_t s, int *status);
+  void release();
 };
 hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t stop, int variant, const CertPlan &plan);
 hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s,
-                        hipEvent_t start = nullptr, hipEvent_t stop = nullptr, int *variant = nullptr);
+                        hipEvent_t start = nullptr, hipEvent_t stop = nullptr, int *variant = nullptr, bool *cert_launched = nullptr);
 hipError_t launch_solve(const SolveArgs &a, hipStream_t s);
 hipError_t launch_knn5(const TreeView &T, const float4 *q, int nq, int32_t *idx, float *d2,
                        uint32_t *stack_ovf, hipStream_t s);

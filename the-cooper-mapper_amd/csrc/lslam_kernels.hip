@@ -54,6 +54,160 @@ LSLAM_DEV int cube_tree_of(const CubeGridDev &g, float x, float y, float z) {
   return -1;
 }
 
+// ScanMatch.cpp:102-139 for one point whose five neighbours are known: the acceptance gate, findLine / findPlane on the five
+// (fetched from P, the array the neighbour ids p[] index), the coefficient, the Jacobian row; the optional per-point taps.
+// Shared by the tree sweep (P = the tree's permuted points) and the grid sweep (P = the cell-sorted points).
+LSLAM_DEV void point_residual(const SweepArgs &a, const BlockDesc &bd, const bool is_surf, const float4 *P, const float4 &q,
+                              const float (&sel)[3], const float (&d)[5], const int (&p)[5], const float (&sc)[6],
+                              float (&row)[6], float &rb, float &kept, float &matched, float &score) {
+  float coeff[4] = {0, 0, 0, 0};
+  unsigned flag = 0;
+  float4 nb[5];
+  // ScanMatch.cpp:102,120; the _fineScore re-sweep gates on the nearest neighbour instead (:282,302)
+  const bool gate = a.fine_gate_c >= 0.0f ? d[0] < (is_surf ? a.fine_gate_s : a.fine_gate_c) : d[4] < 5.0f;
+  if (gate) {
+    flag |= 1u;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) nb[j] = P[p[j]];
+    if (!is_surf) {
+      float A[3], B[3];
+      if (find_line(nb, A, B)) {  // ScanMatch.cpp:105-112
+        flag |= 2u;
+        if (corner_coeff(A, B, sel, coeff)) flag |= 4u;
+      }
+    } else {
+      float plane[4];
+      if (find_plane(nb, 0.2f, plane)) {  // ScanMatch.cpp:122-130
+        flag |= 2u;
+        if (surf_coeff(plane, sel, coeff)) flag |= 4u;
+      }
+    }
+  }
+#ifdef LSLAM_FIT_TWICE  // profiling only: the fit and the coefficient once more with no effect -> their share of the kernel time
+  if (gate) {
+    float4 nb2[5];
+    float off = 0.0f;
+    asm volatile("" : "+v"(off));
+#pragma unroll
+    for (int j = 0; j < 5; ++j) nb2[j] = make_float4(nb[j].x + off, nb[j].y, nb[j].z, nb[j].w);
+    float c2[4] = {0, 0, 0, 0};
+    bool any2 = false;
+    if (!is_surf) {
+      float A[3], B[3];
+      if (find_line(nb2, A, B)) any2 = corner_coeff(A, B, sel, c2);
+    } else {
+      float plane[4];
+      if (find_plane(nb2, 0.2f, plane)) any2 = surf_coeff(plane, sel, c2);
+    }
+    if (any2 && c2[3] == off + 1e30f) coeff[3] = c2[0];  // never
+  }
+#endif
+  if (flag & 2u) matched = 1.0f;
+  if (flag & 4u) {
+    jacobian_row(sc, q.x, q.y, q.z, coeff, row, rb);
+    kept = 1.0f;
+    score = expf(-fabsf(coeff[3]));
+  }
+  if (a.flags_out) {  // parity taps
+    const int gi = bd.out_base + __float_as_int(q.w);  // caller's index of this point
+    a.flags_out[gi] = (uint8_t)flag;
+    if (a.coeff_out) a.coeff_out[gi] = make_float4(coeff[0], coeff[1], coeff[2], coeff[3]);
+    if (a.idx_out) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        a.idx_out[gi * 5 + j] = p[j] >= 0 ? __float_as_int(P[p[j]].w) : -1;
+        a.d2_out[gi * 5 + j] = d[j];
+      }
+    }
+  }
+}
+
+// The block's 27 normal-equation sums and counters from its lanes' rows (ScanMatch.cpp:206-208 products): per-wave contraction
+// (MFMA f32 16x16x4 through `stage`, eight word rows of BLOCK lanes that the wavefront owns, or VALU + wave shuffles), then a
+// fixed-order sum over the block's waves.  ADD: onto the record another launch left (pass 2 of a two-pass sweep).
+template <int BLOCK, bool FUSE, bool ADD>
+LSLAM_DEV void block_accumulate(const int jtj_mode, const bool is_surf, const float (&row)[6], const float rb, const float kept,
+                                const float matched, const float score, uint32_t *stage, float (*red)[NCOL], float *partial_out) {
+  constexpr int NWAVE = BLOCK / 64;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  // ---- normal equations: per-wave reduction --------------------------------
+  float v[NCOL];
+#pragma unroll
+  for (int i = 0; i < NCOL; ++i) v[i] = 0.0f;
+
+  if (jtj_mode == 1) {
+    // stage [J | b] rows; rows of rejected points are zero
+    float *jr = reinterpret_cast<float *>(stage) + wave * 64;  // [c * BLOCK + p]
+#pragma unroll
+    for (int c = 0; c < 6; ++c) jr[c * BLOCK + lane] = row[c];
+    jr[6 * BLOCK + lane] = rb;
+    jr[7 * BLOCK + lane] = 0.0f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int i16 = lane & 15, k4 = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float op = (i16 < 8) ? jr[i16 * BLOCK + 4 * s + k4] : 0.0f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(op, op, acc, 0, 0, 0);
+    }
+    // C/D layout: col = lane&15, row = (lane>>4)*4 + reg.  Entry (r,c), r<=c<7.
+    // Scatter the 27 needed entries back to column slots through LDS.
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int rr = k4 * 4 + r4, cc = i16;
+      if (rr < 6 && cc < 7 && cc >= rr) {
+        int col;
+        if (cc == 6) col = COL_ATB + rr;
+        else col = COL_ATA + (rr * 6 - (rr * (rr - 1)) / 2) + (cc - rr);
+        red[wave][col] = acc[r4];
+      }
+    }
+    // counters still go through the shuffle reduction
+    const float s_rows = wave_sum(kept), s_match = wave_sum(matched), s_score = wave_sum(score);
+    if (lane == 0) {
+      red[wave][COL_ROWS] = s_rows;
+      red[wave][COL_LINE] = is_surf ? 0.0f : s_match;
+      red[wave][COL_PLANE] = is_surf ? s_match : 0.0f;
+      red[wave][COL_SCORE] = s_score;
+      red[wave][31] = 0.0f;
+    }
+  } else {
+    // ScanMatch.cpp:206-208 products, then gfx950 wave-shuffle reduction
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = i; j < 6; ++j) v[k++] = row[i] * row[j];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[COL_ATB + i] = row[i] * rb;
+    v[COL_ROWS] = kept;
+    v[COL_LINE] = is_surf ? 0.0f : matched;
+    v[COL_PLANE] = is_surf ? matched : 0.0f;
+    v[COL_SCORE] = score;
+#pragma unroll
+    for (int i = 0; i < 31; ++i) v[i] = wave_sum(v[i]);
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < NCOL; ++i) red[wave][i] = v[i];
+    }
+  }
+  __syncthreads();
+  // LDS-staged per-block accumulation: fixed order over the block's waves
+  if (tid < NCOL) {
+    float s = red[0][tid];
+#pragma unroll
+    for (int w = 1; w < NWAVE; ++w) s += red[w][tid];
+    // fused solve: the record is read by another workgroup of THIS launch (possibly on another XCD) -- written through to
+    // the device's coherence point; otherwise by the next launch
+    if (FUSE) __hip_atomic_store(partial_out + tid, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (ADD) partial_out[tid] += s;  // onto the record pass 1 left (this thread alone touches the word)
+    else partial_out[tid] = s;
+  }
+}
+
 #ifndef LSLAM_SHALLOW_OCC
 #define LSLAM_SHALLOW_OCC 5  // wavefronts per SIMD the shallow-stack variant is compiled for (96 VGPRs, 25 KB LDS per workgroup)
 #endif
@@ -186,7 +340,10 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
   // against the oracle); LSLAM_KNN_CERT=0 searches every point in one launch.
   // ---------------------------------------------------------------------------------------------------------------------
   bool do_search = true;  // this lane's neighbours come from a search below
-  bool track = CERT == 2;  // ... which keeps the bound the next sweep's certificate needs
+  bool track = CERT == 2 && a.prev_q != nullptr;  // ... which keeps the bound the next sweep's certificate needs
+  // grid sweep (pass 2 of it: the points sweep_grid_kernel could not prove): neighbour ids are positions in the cell-sorted
+  // point array, for the bound taken from the previous sweep's five as for the five this search returns
+  const bool grid = CERT == 2 && a.grid != 0;
   if (CERT == 1) {
     static_assert(CERT != 1 || (!PACKET && !CUBES && !STATE_LDS && BLOCK <= 256), "certificate pass: whole-map lane search, byte lists");
     // the last update of this scan, as the largest displacement of a point within CERT_RANGE_M of the sensor [m]
@@ -320,11 +477,12 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
         for (int j = 0; j < 5; ++j) pp[j] = a.prev_nb[(size_t)qi * 5 + j];
         float4 pv[5];
         bool all = true;
+        const float4 *PB = grid ? (is_surf ? a.ks.pts : a.kc.pts) : T.pts;  // the array the carried ids index
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
           const bool ok = pp[j] >= 0 && pp[j] < T.n_pts;
           all = all && ok;
-          pv[j] = T.pts[ok ? pp[j] : 0];
+          pv[j] = PB[ok ? pp[j] : 0];
         }
         float u = 0.0f;
 #pragma unroll
@@ -355,7 +513,12 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
       knn5_search<BLOCK, OVF, LDS_DEPTH>(T, sel[0], sel[1], sel[2], d, p, stk, bound);
       // no bound kept: no certificate for this point in the next sweep (the first sweep of a certificate loop is this kernel
       // WITHOUT the certificate code -- launch_sweep -- which is 4 % faster at searching than the one with it)
-      if (CERT || (!CUBES && a.prev_lb)) a.prev_lb[qi] = 0.0f;
+      if ((CERT || !CUBES) && a.prev_lb) a.prev_lb[qi] = 0.0f;
+    }
+    if (grid) {  // tree positions -> grid positions
+      const int32_t *t2g = is_surf ? a.ks.t2g : a.kc.t2g;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) p[j] = p[j] >= 0 ? t2g[p[j]] : -1;
     }
     if (a.bounded) {
 #pragma unroll
@@ -367,144 +530,11 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
     (void)searched;
     if (a.dbg) dbg_t1 = __builtin_readcyclecounter();
 
-    float coeff[4] = {0, 0, 0, 0};
-    unsigned flag = 0;
-    float4 nb[5];
-    // ScanMatch.cpp:102,120; the _fineScore re-sweep gates on the nearest neighbour instead (:282,302)
-    const bool gate = a.fine_gate_c >= 0.0f ? d[0] < (is_surf ? a.fine_gate_s : a.fine_gate_c) : d[4] < 5.0f;
-    if (gate) {
-      flag |= 1u;
-#pragma unroll
-      for (int j = 0; j < 5; ++j) nb[j] = T.pts[p[j]];
-      if (!is_surf) {
-        float A[3], B[3];
-        if (find_line(nb, A, B)) {  // ScanMatch.cpp:105-112
-          flag |= 2u;
-          if (corner_coeff(A, B, sel, coeff)) flag |= 4u;
-        }
-      } else {
-        float plane[4];
-        if (find_plane(nb, 0.2f, plane)) {  // ScanMatch.cpp:122-130
-          flag |= 2u;
-          if (surf_coeff(plane, sel, coeff)) flag |= 4u;
-        }
-      }
-    }
-#ifdef LSLAM_FIT_TWICE  // profiling only: the fit and the coefficient once more with no effect -> their share of the kernel time
-    if (gate) {
-      float4 nb2[5];
-      float off = 0.0f;
-      asm volatile("" : "+v"(off));
-#pragma unroll
-      for (int j = 0; j < 5; ++j) nb2[j] = make_float4(nb[j].x + off, nb[j].y, nb[j].z, nb[j].w);
-      float c2[4] = {0, 0, 0, 0};
-      bool any2 = false;
-      if (!is_surf) {
-        float A[3], B[3];
-        if (find_line(nb2, A, B)) any2 = corner_coeff(A, B, sel, c2);
-      } else {
-        float plane[4];
-        if (find_plane(nb2, 0.2f, plane)) any2 = surf_coeff(plane, sel, c2);
-      }
-      if (any2 && c2[3] == off + 1e30f) coeff[3] = c2[0];  // never
-    }
-#endif
-    if (flag & 2u) matched = 1.0f;
-    if (flag & 4u) {
-      jacobian_row(sc, q.x, q.y, q.z, coeff, row, rb);
-      kept = 1.0f;
-      score = expf(-fabsf(coeff[3]));
-    }
-    if (a.flags_out) {  // parity taps
-      const int gi = bd.out_base + __float_as_int(q.w);  // caller's index of this point
-      a.flags_out[gi] = (uint8_t)flag;
-      if (a.coeff_out) a.coeff_out[gi] = make_float4(coeff[0], coeff[1], coeff[2], coeff[3]);
-      if (a.idx_out) {
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-          a.idx_out[gi * 5 + j] = p[j] >= 0 ? __float_as_int(T.pts[p[j]].w) : -1;
-          a.d2_out[gi * 5 + j] = d[j];
-        }
-      }
-    }
+    point_residual(a, bd, is_surf, grid ? (is_surf ? a.ks.pts : a.kc.pts) : T.pts, q, sel, d, p, sc, row, rb, kept, matched, score);
   }
 
   if (a.dbg) dbg_t2 = __builtin_readcyclecounter();
-  // ---- normal equations: per-wave reduction --------------------------------
-  float v[NCOL];
-#pragma unroll
-  for (int i = 0; i < NCOL; ++i) v[i] = 0.0f;
-
-  if (jtj_mode == 1) {
-    // stage [J | b] rows; rows of rejected points are zero
-    float *jr = reinterpret_cast<float *>(stack_lds) + wave * 64;  // [c * BLOCK + p]
-#pragma unroll
-    for (int c = 0; c < 6; ++c) jr[c * BLOCK + lane] = row[c];
-    jr[6 * BLOCK + lane] = rb;
-    jr[7 * BLOCK + lane] = 0.0f;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-    const int i16 = lane & 15, k4 = lane >> 4;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const float op = (i16 < 8) ? jr[i16 * BLOCK + 4 * s + k4] : 0.0f;
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(op, op, acc, 0, 0, 0);
-    }
-    // C/D layout: col = lane&15, row = (lane>>4)*4 + reg.  Entry (r,c), r<=c<7.
-    // Scatter the 27 needed entries back to column slots through LDS.
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      const int rr = k4 * 4 + r4, cc = i16;
-      if (rr < 6 && cc < 7 && cc >= rr) {
-        int col;
-        if (cc == 6) col = COL_ATB + rr;
-        else col = COL_ATA + (rr * 6 - (rr * (rr - 1)) / 2) + (cc - rr);
-        red[wave][col] = acc[r4];
-      }
-    }
-    // counters still go through the shuffle reduction
-    const float s_rows = wave_sum(kept), s_match = wave_sum(matched), s_score = wave_sum(score);
-    if (lane == 0) {
-      red[wave][COL_ROWS] = s_rows;
-      red[wave][COL_LINE] = is_surf ? 0.0f : s_match;
-      red[wave][COL_PLANE] = is_surf ? s_match : 0.0f;
-      red[wave][COL_SCORE] = s_score;
-      red[wave][31] = 0.0f;
-    }
-  } else {
-    // ScanMatch.cpp:206-208 products, then gfx950 wave-shuffle reduction
-    int k = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int j = i; j < 6; ++j) v[k++] = row[i] * row[j];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) v[COL_ATB + i] = row[i] * rb;
-    v[COL_ROWS] = kept;
-    v[COL_LINE] = is_surf ? 0.0f : matched;
-    v[COL_PLANE] = is_surf ? matched : 0.0f;
-    v[COL_SCORE] = score;
-#pragma unroll
-    for (int i = 0; i < 31; ++i) v[i] = wave_sum(v[i]);
-    if (lane == 0) {
-#pragma unroll
-      for (int i = 0; i < NCOL; ++i) red[wave][i] = v[i];
-    }
-  }
-  __syncthreads();
-  // LDS-staged per-block accumulation: fixed order over the block's waves
-  if (tid < NCOL) {
-    float s = red[0][tid];
-#pragma unroll
-    for (int w = 1; w < NWAVE; ++w) s += red[w][tid];
-    // fused solve: the record is read by another workgroup of THIS launch (possibly on another XCD) -- written through to
-    // the device's coherence point; otherwise by the next launch
-    if (FUSE) __hip_atomic_store(partial_out + tid, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else if (CERT == 2) partial_out[tid] += s;  // onto the record pass 1 left (this thread alone touches the word)
-    else partial_out[tid] = s;
-  }
+  block_accumulate<BLOCK, FUSE, CERT == 2>(jtj_mode, is_surf, row, rb, kept, matched, score, stack_lds, red, partial_out);
   if (a.dbg && lane == 0) {  // per-wave phase stamps (shader clock)
     uint64_t *o = a.dbg + ((size_t)lb * NWAVE + wave) * 4;
     o[0] = dbg_t0;
@@ -1020,7 +1050,8 @@ __global__ __launch_bounds__(256) void cert_plan_kernel(SweepArgs a, CertPlan pl
   }
   if (g >= a.n_groups) return;
   const GroupDesc gd = a.groups[g];
-  if (a.states[gd.prob].done) return;
+  // the scans this sweep works on: the running loops -- or, for the _fineScore re-sweep, the converged ones (sweep_kernel)
+  if (a.fine_gate_c >= 0.0f ? !a.states[gd.prob].converged : a.states[gd.prob].done) return;
   const int fb = gd.first_block - a.group_block_base;
   int total = 0;
   for (int k = 0; k < gd.n_blocks; ++k) total += (int)a.need_cnt[fb + k];
@@ -1089,8 +1120,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
 // start/stop (optional) time exactly this dispatch on its own stream: the events are
 // attached to the kernel's AQL packet, no extra barrier packets are enqueued.
 hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t start,
-                        hipEvent_t stop, int *variant) {
+                        hipEvent_t stop, int *variant, bool *cert_launched) {
   if (variant) *variant = -1;
+  if (cert_launched) *cert_launched = false;
   if (a.nb_total <= 0) return hipSuccess;
   const dim3 g(a.nb_total), b(SWEEP_BLOCK);
   const bool cubes = a.gc.trees != nullptr;
@@ -1148,6 +1180,8 @@ hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEven
     else hipExtLaunchKernelGGL((sweep_kernel<SWEEP_BLOCK, false, false, KD_STACK_LDS>), g, b, 0, s, start, stop, 0, a, jtj_mode);
   }
   if (variant) *variant = v;
+  // pass 1 of the certificate sweep ran iff one of the three instantiations that have one was taken with `cert`
+  if (cert_launched) *cert_launched = cert && (v == SWEEP_VARIANT_SHALLOW || v == SWEEP_VARIANT_DEEP_OVF || v == SWEEP_VARIANT_DEEP);
   return hipGetLastError();
 }
 
@@ -1170,6 +1204,140 @@ hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, h
   } else {
     return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// The grid sweep: pass 1 of a two-pass sweep whose 5-NN search is the cell-grid probe of lslam_grid.hpp.  One lane per scan
+// point as in sweep_kernel, but no traversal stack and no divergent descent: every lane of a wavefront runs the same
+// candidate loop.  A point whose five neighbours the probe PROVES goes through the residual chain right here; the others
+// (sparse neighbourhoods, exact distance ties: a few per cent) are listed the way the certificate sweep lists its searches --
+// one byte per point at a fixed place per workgroup -- and sweep_queue_kernel searches the tree for them, every lane busy,
+// its sums added to this workgroup's record.  Fixed places, fixed order: the same bits in every run.
+// ---------------------------------------------------------------------------
+#ifndef LSLAM_GRID_OCC
+#define LSLAM_GRID_OCC 5
+#endif
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LSLAM_GRID_OCC))) void sweep_grid_kernel(SweepArgs a, int jtj_mode) {
+  constexpr int NWAVE = BLOCK / 64;
+  const int lb = xcd_remap(blockIdx.x, a.nb_total);
+  const BlockDesc bd = a.blocks[lb];
+  const GNState *st = a.states + bd.prob;
+  if (a.fine_gate_c >= 0.0f ? !st->converged : st->done) return;  // (cert_plan_kernel skips the groups of such scans)
+  __shared__ float red[NWAVE][NCOL];
+  __shared__ uint32_t rows_lds[18 * BLOCK];  // nine (first, end) runs per lane; afterwards the MFMA staging rows
+  __shared__ int wave_needy[NWAVE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool is_surf = bd.is_surf != 0;
+  const int qi = bd.first + tid;
+  const bool active = tid < bd.count;
+
+  float R[9], t[3], sc[6];
+  {
+    static_assert(offsetof(GNState, R) == 24 && offsetof(GNState, t) == 60 && offsetof(GNState, sc) == 72, "GNState layout");
+    typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    u32x16_t w;
+    u32x2_t w2;
+    asm volatile("s_load_dwordx16 %0, %2, 0x18\n\ts_load_dwordx2 %1, %2, 0x58\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(w), "=&s"(w2)
+                 : "s"(st)
+                 : "memory");
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = __uint_as_float(w[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = __uint_as_float(w[9 + i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sc[i] = __uint_as_float(w[12 + i]);
+    sc[4] = __uint_as_float(w2[0]);
+    sc[5] = __uint_as_float(w2[1]);
+  }
+  CellGrid G;  // block-uniform choice
+  G.cell_start = is_surf ? a.ks.cell_start : a.kc.cell_start;
+  G.pts = is_surf ? a.ks.pts : a.kc.pts;
+  G.t2g = nullptr;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) G.org[i] = is_surf ? a.ks.org[i] : a.kc.org[i];
+  G.inv_c = is_surf ? a.ks.inv_c : a.kc.inv_c;
+  G.c = is_surf ? a.ks.c : a.kc.c;
+  G.nx = is_surf ? a.ks.nx : a.kc.nx;
+  G.ny = is_surf ? a.ks.ny : a.kc.ny;
+  G.nz = is_surf ? a.ks.nz : a.kc.nz;
+  G.n_pts = is_surf ? a.ks.n_pts : a.kc.n_pts;
+
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active) q = a.q[qi];
+  float sel[3];
+  // util/transform_utils.h:476-482 pointAssociateToMap
+  sel[0] = ((R[0] * q.x + R[1] * q.y) + R[2] * q.z) + t[0];
+  sel[1] = ((R[3] * q.x + R[4] * q.y) + R[5] * q.z) + t[1];
+  sel[2] = ((R[6] * q.x + R[7] * q.y) + R[8] * q.z) + t[2];
+  // the bound of the production loop (sweep_body): the acceptance gate, and the previous sweep's five at the new position
+  float bound = FLT_MAX;
+  if (a.bounded) {
+    bound = 5.0f * (1.0f + 1e-5f);
+    if (a.prev_valid && active) {
+      int pp[5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) pp[j] = a.prev_nb[(size_t)qi * 5 + j];
+      float4 pv[5];
+      bool all = true;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const bool ok = pp[j] >= 0 && pp[j] < G.n_pts;
+        all = all && ok;
+        pv[j] = G.pts[ok ? pp[j] : 0];
+      }
+      float u = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) u = fmaxf(u, dist2_xyz(sel[0], sel[1], sel[2], pv[j]));
+      if (all) bound = fminf(bound, u * (1.0f + 1e-5f) + 1e-12f);
+    }
+  }
+  float d[5], lb6;
+  int p[5];
+  int verdict = knn5_grid<BLOCK>(G, active, sel[0], sel[1], sel[2], bound, a.grid_clip_margin, (lds_u32 *)(rows_lds + tid), d, p, lb6);
+  // beyond the gate nothing is looked up (ScanMatch.cpp:102,120); the taps and the _fineScore re-sweep want nanoflann's answer
+  if (verdict == GRID_FAR && !a.bounded) verdict = GRID_UNPROVEN;
+  const bool needy = active && verdict == GRID_UNPROVEN;
+  {  // the list of pass 2 (as the certificate sweep's pass 1 writes it)
+    const unsigned long long m = __ballot(needy);
+    if (lane == 0) wave_needy[wave] = __popcll(m);
+    __syncthreads();
+    int off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) {
+      const int c = wave_needy[w];
+      off += w < wave ? c : 0;
+      total += c;
+    }
+    if (needy) a.need_list[(size_t)lb * BLOCK + off + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)tid;
+    if (tid == 0) {
+      a.need_cnt[lb] = (uint16_t)total;
+      if (a.cert_stats) {  // debug tap: points left to pass 2 / points swept
+        atomicAdd(a.cert_stats, (unsigned long long)total);
+        atomicAdd(a.cert_stats + 1, (unsigned long long)bd.count);
+      }
+    }
+  }
+  const bool has = active && !needy;
+  float row[6] = {0, 0, 0, 0, 0, 0};
+  float rb = 0.0f, kept = 0.0f, matched = 0.0f, score = 0.0f;
+  if (has) {
+    if (a.bounded) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) a.prev_nb[(size_t)qi * 5 + j] = p[j];
+    }
+    point_residual(a, bd, is_surf, G.pts, q, sel, d, p, sc, row, rb, kept, matched, score);
+  }
+  __syncthreads();  // every wavefront is done with its row table: the staging rows may be written
+  block_accumulate<BLOCK, false, false>(jtj_mode, is_surf, row, rb, kept, matched, score, rows_lds, red, a.partials + (size_t)lb * NCOL);
+}
+
+hipError_t launch_sweep_grid(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
+  if (a.nb_total <= 0) return hipSuccess;
+  hipExtLaunchKernelGGL((sweep_grid_kernel<SWEEP_BLOCK>), dim3(a.nb_total), dim3(SWEEP_BLOCK), 0, s, start, stop, 0, a, jtj_mode);
   return hipGetLastError();
 }
 
@@ -1788,6 +1956,48 @@ hipError_t launch_knn5_packet(const TreeView &T, const float4 *q, int nq, int32_
                               int32_t *n_tie, hipStream_t s) {
   if (nq <= 0) return hipSuccess;
   hipLaunchKernelGGL(knn5_packet_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, T, q, nq, idx, d2, stack_ovf, n_tie);
+  return hipGetLastError();
+}
+
+// the same tap through the grid probe (lslam_grid.hpp); queries it cannot prove are searched in the tree right here (stack
+// in HBM) and counted
+__global__ __launch_bounds__(256) void knn5_grid_kernel(CellGrid G, TreeView T, const float4 *q, int nq, int32_t *idx, float *d2,
+                                                        uint32_t *stack_ovf, int32_t *n_unproven) {
+  __shared__ uint32_t rows_lds[18 * 256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool on = i < nq;
+  const float4 qq = on ? q[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float d[5], lb6;
+  int p[5];
+  const int verdict = knn5_grid<256>(G, on, qq.x, qq.y, qq.z, FLT_MAX, 0.0f, (lds_u32 *)(rows_lds + threadIdx.x), d, p, lb6);
+  const bool redo = on && verdict != GRID_PROVEN;
+  int orig[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) orig[j] = (!redo && on && p[j] >= 0) ? __float_as_int(G.pts[p[j]].w) : -1;
+  if (__any(redo)) {
+    if (redo) {
+      if (n_unproven) atomicAdd(n_unproven, 1);
+      KdStack<256, true, 0> stk;
+      stk.lds = nullptr;
+      stk.ovf = stack_ovf + i;
+      stk.ovf_stride = (size_t)gridDim.x * 256;
+      knn5_search<256, true, 0>(T, qq.x, qq.y, qq.z, d, p, stk);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) orig[j] = p[j] >= 0 ? __float_as_int(T.pts[p[j]].w) : -1;
+    }
+  }
+  if (!on) return;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    idx[i * 5 + j] = orig[j];
+    d2[i * 5 + j] = d[j];
+  }
+}
+
+hipError_t launch_knn5_grid(const CellGrid &G, const TreeView &T, const float4 *q, int nq, int32_t *idx, float *d2,
+                            uint32_t *stack_ovf, int32_t *n_unproven, hipStream_t s) {
+  if (nq <= 0) return hipSuccess;
+  hipLaunchKernelGGL(knn5_grid_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, G, T, q, nq, idx, d2, stack_ovf, n_unproven);
   return hipGetLastError();
 }
 

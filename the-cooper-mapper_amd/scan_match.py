@@ -119,9 +119,14 @@ class Context:
         self.lib.lslam_debug_sweep_launches(self.h, out)
         return dict(zip(SWEEP_VARIANTS, (int(v) for v in out)))
 
+    def grid_launches(self):
+        """lslam_debug_grid_launches: grid sweeps (sweep_grid_kernel) this context has launched so far."""
+        return int(self.lib.lslam_debug_grid_launches(self.h))
+
     def cert_stats(self):
         """lslam_debug_cert_stats: (points left to the second pass, points of certificate-testing workgroups, second-pass
-        launches) of this context so far; the first two are counted only under LSLAM_DEBUG_CERT_STATS=1."""
+        launches) of this context so far; the first two are counted only in runs with lslam_opts.debug_stats = 1 (the grid
+        sweep counts the points it leaves to the tree search the same way)."""
         out = (C.c_uint64 * 3)()
         self.lib.lslam_debug_cert_stats(self.h, out)
         return int(out[0]), int(out[1]), int(out[2])

@@ -38,7 +38,7 @@ for seed in range(n_seeds):
     ctx.scan_set(pr["corner"], pr["surf"])
     tc, ts = o.kdtree(mc), o.kdtree(ms)
     for pose in (init, pr["gt_pose"]):
-        for mode in (1 | 0x100, 1 | 0x200, 2):  # lane search through the deep and the shallow (batch) stack shape, packet search
+        for mode in (1 | 0x100, 1 | 0x200, 2, 3):  # lane search through the deep and the shallow (batch) stack shape, packet search, grid probe
             g = ctx.sweep(pose, jtj_mode=1, search_mode=mode)
             r = o.sweep(tc, ts, pr["corner"], pr["surf"], pose)
             for key in ("idx", "flags"):
@@ -61,15 +61,14 @@ for seed in range(n_seeds):
         bad += 1; print("seed", seed, "deep and shallow stack loops differ in bits")
     # the certificate sweep (forced: a single scan would not take it), with its default thresholds and with every scan testing
     # certificates from its second sweep on however far it moved: the same neighbours, so the same loop up to summation order
-    for env in ({"LSLAM_KNN_CERT": "2"}, {"LSLAM_KNN_CERT": "2", "LSLAM_CERT_TRY_M": "1e9", "LSLAM_CERT_TRACK_M": "1e9"}):
-        os.environ.update(env)
+    for env in ({"knn_cert": 2}, {"knn_cert": 2, "cert_try_m": 1e9, "cert_track_m": 1e9}):
         opts = ctx.default_opts()
         opts.search_mode = 1 | 0x200
+        for k, v in env.items():
+            setattr(opts, k, v)
         q0 = ctx.cert_stats()[2]
         status, pose, st = ctx.run(init, opts)
         ran = ctx.cert_stats()[2] - q0
-        for k in env:
-            del os.environ[k]
         # the bound every point carries for its next certificate: never above the true sixth squared distance of the position
         # it was taken at (scipy's kd-tree on the same map)
         from scipy.spatial import cKDTree
@@ -84,6 +83,13 @@ for seed in range(n_seeds):
                 bad += 1; print("seed", seed, "certificate sweep", env, "a kept bound exceeds the true sixth distance by", float((clb[sl][have] / d6[have]).max()))
         if st.iterations != ost.iterations or abs(st.n_rows - ost.n_rows) > 2 or np.abs(pose[3:] - poses[1][3:]).max() > 5e-6 or np.abs(pose[:3] - poses[1][:3]).max() > 5e-7 or (st.iterations > 1 and ran == 0):
             bad += 1; print("seed", seed, "certificate sweep", env, "differs", st.iterations, ost.iterations, st.n_rows, ost.n_rows, np.abs(pose - poses[1]).max(), ran)
+    # the grid sweep (probe + proof, tree search for the rest): the same loop up to summation order
+    opts = ctx.default_opts()
+    opts.search_mode = 3
+    g0 = ctx.grid_launches()
+    status, pose, st = ctx.run(init, opts)
+    if st.iterations != ost.iterations or abs(st.n_rows - ost.n_rows) > 2 or np.abs(pose[3:] - poses[1][3:]).max() > 5e-6 or np.abs(pose[:3] - poses[1][:3]).max() > 5e-7 or ctx.grid_launches() == g0:
+        bad += 1; print("seed", seed, "grid sweep differs", st.iterations, ost.iterations, st.n_rows, ost.n_rows, np.abs(pose - poses[1]).max())
     print("seed %2d rings %2d steps %3d half %3.0f map %6d+%6d scan %5d: %s" % (seed, rings, steps, half, len(mc), len(ms), len(pr["corner"]) + len(pr["surf"]), "ok" if not bad else "MISMATCH"), flush=True)
     if bad:
         sys.exit(1)

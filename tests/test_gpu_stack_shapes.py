@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
 POSE_TOL_M = 1e-4    # BASELINE.json north_star: pose within 1e-4 m of the CPU reference
 POSE_TOL_RAD = 1e-5
 LANE, DEEP, SHALLOW = 1, 0x100, 0x200  # LSLAM_SEARCH_LANE, LSLAM_STACK_DEEP, LSLAM_STACK_SHALLOW
+GRID = 3                                # LSLAM_SEARCH_GRID
 
 
 def bits(a):
@@ -117,6 +118,7 @@ def test_batch_above_512_blocks_runs_the_shallow_kernel_and_matches_oracle(ctx, 
     opts = ctx.default_opts()
     opts.scans_in_flight = 12
     opts.knn_cert = 2
+    opts.search_mode = LANE  # (AUTO would take the grid sweep for a batch this size: tests/test_gpu_grid.py)
     before = ctx.sweep_launches()
     worst, poses, stats = ctx.run_batch(np.stack(inits), opts)
     ran = _ran(before, ctx.sweep_launches())
@@ -182,10 +184,13 @@ def voxel_map_problem(pkg, synth):
     ctx.close()
 
 
-def test_voxel_map_batch_of_full_scans_matches_oracle(voxel_map_problem, oracle, monkeypatch):
+@pytest.mark.parametrize("search", ["auto", "lane"])
+def test_voxel_map_batch_of_full_scans_matches_oracle(voxel_map_problem, oracle, monkeypatch, search):
     """configs[1] map (reduced) x configs[2] scans: three full 64 x 1800 scans (~1 350 blocks) in one batch against the
     surround of the addFeatureCloud-built voxel map -- the bench's workload shape, kernel instantiation and code path --
-    with every scan's pose, row counts and iteration count against the oracle on the same clouds."""
+    with every scan's pose, row counts and iteration count against the oracle on the same clouds.  `auto` is what bench.py
+    runs: the library picks the grid sweep for a batch this size (sweep_grid_kernel + sweep_queue_kernel); `lane` is the
+    kd-tree walk of every point (sweep_kernel<256,true,false,12> + the certificate pass)."""
     vp = voxel_map_problem
     ctx = vp["ctx"]
     mc, ms = vp["surround"]
@@ -195,10 +200,14 @@ def test_voxel_map_batch_of_full_scans_matches_oracle(voxel_map_problem, oracle,
     ctx.scan_set_batch(vp["scans"])
     opts = ctx.default_opts()
     opts.scans_in_flight = 3
-    before = ctx.sweep_launches()
+    opts.search_mode = LANE if search == "lane" else 0
+    before, g0 = ctx.sweep_launches(), ctx.grid_launches()
     worst, poses, stats = ctx.run_batch(vp["inits"], opts)
     ran = _ran(before, ctx.sweep_launches())
-    assert set(ran) == {"shallow"}, ran
+    if search == "lane":
+        assert set(ran) == {"shallow"} and ctx.grid_launches() == g0, ran
+    else:
+        assert not ran and ctx.grid_launches() - g0 >= 3, (ran, ctx.grid_launches() - g0)  # picked by launch size, not forced
     for k, (qc, qs) in enumerate(vp["scans"]):
         ok, opose, ost = oracle.scanmatch_scan(mc, ms, qc, qs, vp["inits"][k])
         assert stats[k].status == ost.status and stats[k].converged == ost.converged == 1, k
@@ -214,10 +223,17 @@ def test_voxel_map_batch_of_full_scans_matches_oracle(voxel_map_problem, oracle,
     forced = ctx.default_opts()
     forced.knn_cert = 2
     ctx.scan_set(*vp["scans"][1])
-    before = ctx.sweep_launches()
-    status, pose1, st1 = ctx.run(vp["inits"][1], forced)
-    assert set(_ran(before, ctx.sweep_launches())) == {"deep"}
-    assert np.array_equal(bits(pose1), bits(poses[1])) and st1.iterations == stats[1].iterations
+    if search == "lane":
+        before = ctx.sweep_launches()
+        status, pose1, st1 = ctx.run(vp["inits"][1], forced)
+        assert set(_ran(before, ctx.sweep_launches())) == {"deep"}
+        assert np.array_equal(bits(pose1), bits(poses[1])) and st1.iterations == stats[1].iterations
+    else:  # the grid sweep of the scan alone (asked for: a launch this small is the lane search's by default): the batch's bits
+        forced.search_mode = GRID
+        g0 = ctx.grid_launches()
+        status, pose1, st1 = ctx.run(vp["inits"][1], forced)
+        assert ctx.grid_launches() > g0
+        assert np.array_equal(bits(pose1), bits(poses[1])) and st1.iterations == stats[1].iterations
 
 
 def test_voxel_map_sweep_taps_match_oracle_through_the_shallow_kernel(voxel_map_problem, oracle):
@@ -249,6 +265,8 @@ def test_certificate_sweep_equals_searching_every_point(voxel_map_problem, ctx, 
     (forced).  Certificates really are issued and second passes really run."""
     def both(c, inits, opts, force):
         out = {}
+        if (opts.search_mode & 0xFF) == 0:
+            opts.search_mode |= LANE  # the certificate sweep is the lane search's (AUTO takes the grid sweep for big batches)
         for mode in ("0", "2" if force else "1"):
             opts.knn_cert = int(mode)
             opts.debug_stats = 1
@@ -339,7 +357,8 @@ def test_the_bound_a_search_keeps_is_below_the_true_sixth_distance(ctx, small_pr
         assert np.median(np.concatenate(tight)) > 0.8
 
 
-def test_voxel_map_batch_of_48_full_scans_properties(voxel_map_problem, pkg, synth):
+@pytest.mark.parametrize("search", ["auto", "lane"])
+def test_voxel_map_batch_of_48_full_scans_properties(voxel_map_problem, pkg, synth, search):
     """Size-independent properties of the bench's code path at a size the oracle does not finish in seconds: 48 full 64 x 1800
     scans (21 600 blocks, 5.5 M points per sweep) in one batch against the voxel map, certificate sweep on (picked by size).
     (a) two runs give the same bits (no atomics in any sum); (b) a scan's result does not depend on what it is batched with:
@@ -365,10 +384,12 @@ def test_voxel_map_batch_of_48_full_scans_properties(voxel_map_problem, pkg, syn
     inits, gts = np.stack(inits), np.stack(gts)
     opts = ctx.default_opts()
     opts.scans_in_flight = 48
+    opts.search_mode = LANE if search == "lane" else 0  # auto: the grid sweep (picked by size)
     ctx.scan_set_batch(scans)
-    q0 = ctx.cert_stats()[2]
+    q0, g0 = ctx.cert_stats()[2], ctx.grid_launches()
     _, p1, s1 = ctx.run_batch(inits, opts)
-    assert ctx.cert_stats()[2] > q0  # the certificate sweep ran
+    assert ctx.cert_stats()[2] > q0  # second passes ran (the certificate sweep's / the grid sweep's)
+    assert (ctx.grid_launches() > g0) == (search == "auto")
     _, p2, s2 = ctx.run_batch(inits, opts)
     assert np.array_equal(bits(p1), bits(p2))                                                    # (a)
     assert all(s.converged for s in s1) and np.abs(p1[:, 3:] - gts[:, 3:]).max() < 0.05        # (d)

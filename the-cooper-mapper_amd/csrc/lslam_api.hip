@@ -1487,7 +1487,15 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
     sa.bounded = (ctx->cube_mode || unbounded) ? 0 : 1;  // per-cube positions are tree-relative
     // The grid sweep (LSLAM_SEARCH_GRID): cell grids over the resident trees, made on first use.  A map the grid cannot take
     // (non-finite points, an extent beyond the grid's limits) is searched by the tree as before.
-    if (search == LSLAM_SEARCH_GRID && sa.bounded) {
+    // AUTO takes it for throughput-bound batches (launch_sweep's own test: more than two wavefronts per SIMD in a launch of
+    // the first chunk): a launch that fits the device at once is latency-bound, and the grid sweep is two launches more
+    bool want_grid = search == LSLAM_SEARCH_GRID;
+    if (!want_grid && ctx->env_search < 0 && (o.search_mode & 0xFF) == LSLAM_SEARCH_AUTO && !ctx->cube_mode && !sa.packet) {
+      const int p1 = std::min(n_scans, in_flight);
+      const long nb0 = (long)ctx->h_probs[(size_t)p1 - 1].first_block + ctx->h_probs[(size_t)p1 - 1].n_blocks;
+      want_grid = nb0 * (SWEEP_BLOCK / 64) > 2 * 1024;
+    }
+    if (want_grid && sa.bounded) {
       rc = ensure_grid(ctx, ctx->env_grid_cell > 0.0f ? ctx->env_grid_cell : o.grid_cell);
       if (rc) return rc;
       if (ctx->kc.view.cell_start && ctx->ks.view.cell_start) {

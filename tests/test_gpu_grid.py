@@ -172,3 +172,22 @@ def test_grid_fine_score_resweep(ctx, small_problem):
         res[mode] = (st.converged, st.percent2, st.score2)
     assert res[LANE][0] == res[GRID][0] == 1
     assert res[LANE][1] == res[GRID][1] and abs(res[LANE][2] - res[GRID][2]) <= 1e-6 * max(1.0, abs(res[LANE][2]))
+
+
+def test_grid_run_does_not_read_what_an_earlier_call_left(ctx, small_problem):
+    """Every call starts cold: the grid sweep's second pass runs in a loop's FIRST sweep too, where nothing carried over from
+    an earlier call (another pose, another search's bookkeeping) may bound a search.  A certificate-sweep call, whose per-point
+    state is of another kind, right before a grid call; the grid call's pose must be the one it gives after itself."""
+    pr = small_problem
+    ctx.map_set(pr["map_corner"], pr["map_surf"])
+    ctx.scan_set(pr["corner"], pr["surf"])
+    g = ctx.default_opts()
+    g.search_mode = GRID
+    c = ctx.default_opts()
+    c.search_mode = LANE
+    c.knn_cert = 2
+    _, ref, st_ref = ctx.run(pr["init_pose"], g)
+    for other, pose0 in ((c, pr["init_pose"]), (c, pr["gt_pose"]), (g, pr["gt_pose"])):
+        ctx.run(pose0, other)
+        _, pose, st = ctx.run(pr["init_pose"], g)
+        assert np.array_equal(bits(pose), bits(ref)) and (st.iterations, st.n_rows) == (st_ref.iterations, st_ref.n_rows)

@@ -1505,6 +1505,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
         sa.grid_clip_margin = GRID_CLIP_MARGIN_MIN;
       }
     }
+    const bool grid_on = sa.grid != 0;
     // neighbour lists carried from sweep to sweep by certificate where a point has hardly moved (sweep_body): lslam_opts.knn_cert
     // = 0 searches every point in every sweep, 2 takes the certificate sweep whatever the size of the launch (tests); the
     // environment's LSLAM_KNN_CERT / LSLAM_CERT_TRY_M / LSLAM_CERT_TRACK_M, read when the context was made, override the options
@@ -1515,6 +1516,10 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
       sa.prev_lb = ctx->prev_lb.p;
       sa.cert_try_m = ctx->env_cert_try_m >= 0.0f ? ctx->env_cert_try_m : (o.cert_try_m > 0.0f ? o.cert_try_m : CERT_TRY_M_DEFAULT);
       sa.cert_track_m = ctx->env_cert_track_m >= 0.0f ? ctx->env_cert_track_m : (o.cert_track_m > 0.0f ? o.cert_track_m : CERT_TRACK_M_DEFAULT);
+    }
+    if (grid_on) {  // the grid sweep carries (position, fifth distance) per point in prev_q; no certificates
+      sa.prev_q = ctx->prev_q.p;
+      sa.prev_lb = nullptr;
     }
     if ((sa.prev_q || sa.grid) && (ctx->env_debug_cert_stats || o.debug_stats)) {
       if (!ctx->cert_stats.p) {

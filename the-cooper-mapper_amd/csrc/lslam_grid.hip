@@ -1,6 +1,5 @@
 // lslam_grid.hip -- builds the cell grid of lslam_grid.hpp over a map whose kd-tree exists (the grid search's fallback and
-// the source of the bounding box): points sorted by cell, the cell -> first point table, the tree position -> grid position
-// table.  Everything on the device, stream-ordered; the one value the host needs (the bounding box) it already has from the
+// the source of the bounding box): points sorted by cell and the cell -> first point table.  Everything on the device, stream-ordered; the one value the host needs (the bounding box) it already has from the
 // tree build (TreeView::bb_lo / bb_hi = nanoflann's root_bbox, nanoflann.hpp:1406-1427).
 //
 // The key sort and the scan of the cell counts are rocPRIM's (map-set path, outside every timed region).
@@ -37,13 +36,11 @@ __global__ __launch_bounds__(256) void grid_key_kernel(CellGrid G, const float4 
   atomicAdd(count + c, 1u);
 }
 
-__global__ __launch_bounds__(256) void grid_place_kernel(int n, const float4 *tree_pts, const uint32_t *val_sorted, float4 *gpts,
-                                                         int32_t *t2g) {
+__global__ __launch_bounds__(256) void grid_place_kernel(int n, const float4 *tree_pts, const uint32_t *val_sorted, float4 *gpts) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
   const uint32_t t = val_sorted[j];
   gpts[j] = tree_pts[t];  // .w carries the original index already
-  t2g[t] = j;
 }
 
 }  // namespace
@@ -72,7 +69,6 @@ hipError_t GridDev::build(const TreeView &T, float cell, hipStream_t s, int *sta
   hipError_t e;
 #define G_TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
   G_TRY(reserve(pts, cap_pts, (size_t)n + 16));
-  G_TRY(reserve(t2g, cap_t2g, (size_t)n));
   G_TRY(reserve(cell_start, cap_cell, ncell + 1));
   G_TRY(reserve(count, cap_count, ncell + 1));
   G_TRY(reserve(key0, cap_k0, (size_t)n));
@@ -92,7 +88,7 @@ hipError_t GridDev::build(const TreeView &T, float cell, hipStream_t s, int *sta
   G_TRY(reserve(tmp, cap_tmp, std::max(tmp_sort, tmp_scan)));
   G_TRY(rocprim::radix_sort_pairs((void *)tmp, tmp_sort, key0, key1, val0, val1, (size_t)n, 0u, end_bit, s));
   G_TRY(rocprim::exclusive_scan((void *)tmp, tmp_scan, count, cell_start, 0u, ncell + 1, rocprim::plus<uint32_t>(), s));
-  hipLaunchKernelGGL(grid_place_kernel, grd, blk, 0, s, n, T.pts, val1, pts, t2g);
+  hipLaunchKernelGGL(grid_place_kernel, grd, blk, 0, s, n, T.pts, val1, pts);
   // the candidate loop loads pts[cur] for lanes that have run out of candidates at index 0: nothing to pad; a leaf-style
   // over-read does not exist here
   int32_t h_err = 0;
@@ -102,18 +98,17 @@ hipError_t GridDev::build(const TreeView &T, float cell, hipStream_t s, int *sta
   if (h_err) { *status = 1; return hipSuccess; }
   G.cell_start = cell_start;
   G.pts = pts;
-  G.t2g = t2g;
   view = G;
   n_cells = ncell;
   return hipSuccess;
 }
 
 void GridDev::release() {
-  for (void *q : {(void *)pts, (void *)t2g, (void *)cell_start, (void *)count, (void *)key0, (void *)key1, (void *)val0, (void *)val1,
+  for (void *q : {(void *)pts, (void *)cell_start, (void *)count, (void *)key0, (void *)key1, (void *)val0, (void *)val1,
                   (void *)err, (void *)tmp})
     if (q) (void)hipFree(q);
-  pts = nullptr; t2g = nullptr; cell_start = nullptr; count = nullptr; key0 = key1 = val0 = val1 = nullptr; err = nullptr; tmp = nullptr;
-  cap_pts = cap_t2g = cap_cell = cap_count = cap_k0 = cap_k1 = cap_v0 = cap_v1 = cap_err = cap_tmp = 0;
+  pts = nullptr; cell_start = nullptr; count = nullptr; key0 = key1 = val0 = val1 = nullptr; err = nullptr; tmp = nullptr;
+  cap_pts = cap_cell = cap_count = cap_k0 = cap_k1 = cap_v0 = cap_v1 = cap_err = cap_tmp = 0;
   view = CellGrid{};
   n_cells = 0;
 }

@@ -17,7 +17,6 @@
 //   pts[n]            the map points sorted by cell, {x, y, z, bitcast(original index)}
 //   cell_start[N + 1] cell -> first point, cells numbered x-fastest: cell = ix + nx (iy + ny iz); the three x-neighbours of a
 //                     cell row are ONE contiguous run of pts, so the 27 cells are nine runs (two loads each)
-//   t2g[n]            position in the kd-tree's point array -> position in pts (results of the fallback search)
 // Cell of a coordinate v on axis a: floor(fl(fl(v - org[a]) * inv_c)), the same two fp32 operations for map points and queries.
 // The grid covers the map's bounding box plus GRID_MARGIN_CELLS(c) empty cells on every side, so that a query whose cell is
 // not an interior one is farther than sqrt(5) m from every map point (the acceptance gate of ScanMatch.cpp:102,120).
@@ -30,7 +29,6 @@ namespace lslam {
 struct CellGrid {
   const uint32_t *cell_start;
   const float4 *pts;
-  const int32_t *t2g;
   float org[3];
   float inv_c, c;
   int32_t nx, ny, nz;
@@ -269,18 +267,30 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
   }
 #pragma unroll
   for (int j = 0; j < 6; ++j) sp[j] = G.pts[pos[j]];
-  float e6 = FLT_MAX;
+  float e[6];
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const bool have = ks[j] != 0xFFFFFFFFu;
-    const float x = have ? dist2_xyz(qx, qy, qz, sp[j]) : FLT_MAX;
-    if (j < 5) knn_insert_sorted(d, p, x, have ? (int)pos[j] : -1);
-    else e6 = x;
+  for (int j = 0; j < 6; ++j) e[j] = (ks[j] != 0xFFFFFFFFu) ? dist2_xyz(qx, qy, qz, sp[j]) : FLT_MAX;
+  // The keys order the distances to 2^-13 relative: nearly always the exact distances of the six survivors ascend in key
+  // order, and then the first five ARE the answer in nanoflann's order.  A wavefront with a lane for which they do not
+  // (two of the six within 2^-13 of each other) sorts by the search's own insert.
+  float lb = e[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    d[j] = e[j];
+    p[j] = (ks[j] != 0xFFFFFFFFu) ? (int)pos[j] : -1;
   }
-  // the sixth survivor may belong before some of the five (keys order the distances to 2^-13 only): offered like any other
-  // candidate, with the record of who was turned away
-  float lb = fmaxf(e6, d[4]);
-  knn_insert_sorted(d, p, e6, (int)pos[5]);
+  const bool ascending = e[0] <= e[1] && e[1] <= e[2] && e[2] <= e[3] && e[3] <= e[4] && e[4] <= e[5];
+  if (__builtin_amdgcn_ballot_w64(!ascending) != 0ull) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      d[j] = FLT_MAX;
+      p[j] = -1;
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) knn_insert_sorted(d, p, e[j], (ks[j] != 0xFFFFFFFFu) ? (int)pos[j] : -1);
+    lb = fmaxf(e[5], d[4]);  // whoever of the six is left out
+    knn_insert_sorted(d, p, e[5], (int)pos[5]);
+  }
   // everybody who is not a survivor is at least the sixth key's truncated distance away
   const float t6 = (k5 != 0xFFFFFFFFu) ? __uint_as_float(k5 & ~GRID_ID_MASK) : FLT_MAX;
   lb = fminf(lb, t6);

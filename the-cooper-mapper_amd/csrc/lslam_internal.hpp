@@ -256,10 +256,10 @@ struct GridDev {
   CellGrid view{};
   size_t n_cells = 0;
   float4 *pts = nullptr;
-  int32_t *t2g = nullptr, *err = nullptr;
+  int32_t *err = nullptr;
   uint32_t *cell_start = nullptr, *count = nullptr, *key0 = nullptr, *key1 = nullptr, *val0 = nullptr, *val1 = nullptr;
   char *tmp = nullptr;
-  size_t cap_pts = 0, cap_t2g = 0, cap_cell = 0, cap_count = 0, cap_k0 = 0, cap_k1 = 0, cap_v0 = 0, cap_v1 = 0, cap_err = 0, cap_tmp = 0;
+  size_t cap_pts = 0, cap_cell = 0, cap_count = 0, cap_k0 = 0, cap_k1 = 0, cap_v0 = 0, cap_v1 = 0, cap_err = 0, cap_tmp = 0;
   template <typename T>
   static hipError_t reserve(T *&p, size_t &cap, size_t n) {
     if (n <= cap) return hipSuccess;

@@ -54,6 +54,18 @@ LSLAM_DEV int cube_tree_of(const CubeGridDev &g, float x, float y, float z) {
   return -1;
 }
 
+// Upper bound of the fifth neighbour's squared distance at `sel` from what the previous sweep left (grid sweep): the point
+// was at pq.xyz then and its five neighbours were within sqrt(pq.w) of it, so they are within sqrt(pq.w) + |sel - pq.xyz| now
+// (triangle inequality; padded by 1e-5 relative, far above the rounding of the three square roots and the distances'
+// own).  pq.w = FLT_MAX (no five inside the gate last time): no bound.
+LSLAM_DEV float grid_carried_bound(const float4 &pq, const float (&sel)[3]) {
+  const float ex = sel[0] - pq.x, ey = sel[1] - pq.y, ez = sel[2] - pq.z;
+  const float delta = sqrtf((ex * ex + ey * ey) + ez * ez);
+  const float r = (sqrtf(pq.w) + delta) * (1.0f + 1.0e-5f) + 1.0e-6f;
+  const float b = r * r;
+  return pq.w < 1.0e30f ? b : FLT_MAX;
+}
+
 // ScanMatch.cpp:102-139 for one point whose five neighbours are known: the acceptance gate, findLine / findPlane on the five
 // (fetched from P, the array the neighbour ids p[] index), the coefficient, the Jacobian row; the optional per-point taps.
 // Shared by the tree sweep (P = the tree's permuted points) and the grid sweep (P = the cell-sorted points).
@@ -340,10 +352,10 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
   // against the oracle); LSLAM_KNN_CERT=0 searches every point in one launch.
   // ---------------------------------------------------------------------------------------------------------------------
   bool do_search = true;  // this lane's neighbours come from a search below
-  bool track = CERT == 2 && a.prev_q != nullptr;  // ... which keeps the bound the next sweep's certificate needs
-  // grid sweep (pass 2 of it: the points sweep_grid_kernel could not prove): neighbour ids are positions in the cell-sorted
-  // point array, for the bound taken from the previous sweep's five as for the five this search returns
+  // grid sweep (pass 2 of it: the points sweep_grid_kernel could not prove): what is carried from sweep to sweep is where the
+  // point was and how far its fifth neighbour (prev_q: x, y, z, d2[4]) -- no neighbour ids, no certificates
   const bool grid = CERT == 2 && a.grid != 0;
+  bool track = CERT == 2 && a.prev_q != nullptr && !grid;  // ... which keeps the bound the next sweep's certificate needs
   if (CERT == 1) {
     static_assert(CERT != 1 || (!PACKET && !CUBES && !STATE_LDS && BLOCK <= 256), "certificate pass: whole-map lane search, byte lists");
     // the last update of this scan, as the largest displacement of a point within CERT_RANGE_M of the sensor [m]
@@ -469,7 +481,9 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
     float bound = FLT_MAX;
     if (a.bounded) {
       bound = 5.0f * (1.0f + 1e-5f);
-      if (prev_valid && T.n_pts > 0) {
+      if (prev_valid && T.n_pts > 0 && grid) {
+        bound = fminf(bound, grid_carried_bound(a.prev_q[qi], sel));
+      } else if (prev_valid && T.n_pts > 0) {
         // the five indices, then the five points, all in flight together (a guarded load per neighbour would be a chain
         // of ten dependent round trips at the head of every wavefront): an invalid index reads point 0 and is ignored
         int pp[5];
@@ -477,12 +491,11 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
         for (int j = 0; j < 5; ++j) pp[j] = a.prev_nb[(size_t)qi * 5 + j];
         float4 pv[5];
         bool all = true;
-        const float4 *PB = grid ? (is_surf ? a.ks.pts : a.kc.pts) : T.pts;  // the array the carried ids index
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
           const bool ok = pp[j] >= 0 && pp[j] < T.n_pts;
           all = all && ok;
-          pv[j] = PB[ok ? pp[j] : 0];
+          pv[j] = T.pts[ok ? pp[j] : 0];
         }
         float u = 0.0f;
 #pragma unroll
@@ -515,12 +528,9 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
       // WITHOUT the certificate code -- launch_sweep -- which is 4 % faster at searching than the one with it)
       if ((CERT || !CUBES) && a.prev_lb) a.prev_lb[qi] = 0.0f;
     }
-    if (grid) {  // tree positions -> grid positions
-      const int32_t *t2g = is_surf ? a.ks.t2g : a.kc.t2g;
-#pragma unroll
-      for (int j = 0; j < 5; ++j) p[j] = p[j] >= 0 ? t2g[p[j]] : -1;
-    }
-    if (a.bounded) {
+    if (grid) {
+      if (a.bounded) a.prev_q[qi] = make_float4(sel[0], sel[1], sel[2], (p[4] >= 0 && d[4] < 5.0f) ? d[4] : FLT_MAX);
+    } else if (a.bounded) {
 #pragma unroll
       for (int j = 0; j < 5; ++j) a.prev_nb[(size_t)qi * 5 + j] = p[j];
     }
@@ -530,7 +540,7 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
     (void)searched;
     if (a.dbg) dbg_t1 = __builtin_readcyclecounter();
 
-    point_residual(a, bd, is_surf, grid ? (is_surf ? a.ks.pts : a.kc.pts) : T.pts, q, sel, d, p, sc, row, rb, kept, matched, score);
+    point_residual(a, bd, is_surf, T.pts, q, sel, d, p, sc, row, rb, kept, matched, score);
   }
 
   if (a.dbg) dbg_t2 = __builtin_readcyclecounter();
@@ -1112,7 +1122,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
       }
       item = a.blocks[fb + k].first + (int)a.need_list[(size_t)(fb + k) * BLOCK + (i - p0)];
     }
-    sweep_body<BLOCK, OVF, false, LDS_DEPTH, false, false, false, 2>(a, jtj_mode, fb + c, bd, st, stack_lds, red, a.partials + (size_t)(fb + c) * NCOL, 1, item);
+    sweep_body<BLOCK, OVF, false, LDS_DEPTH, false, false, false, 2>(a, jtj_mode, fb + c, bd, st, stack_lds, red, a.partials + (size_t)(fb + c) * NCOL, a.prev_valid, item);  // (the certificate sweep's second pass only runs with prev_valid set; the grid sweep's runs in a loop's first sweep too)
     __syncthreads();  // red and the stack columns are free again
   }
 }
@@ -1256,7 +1266,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LSLAM_GRI
   CellGrid G;  // block-uniform choice
   G.cell_start = is_surf ? a.ks.cell_start : a.kc.cell_start;
   G.pts = is_surf ? a.ks.pts : a.kc.pts;
-  G.t2g = nullptr;
 #pragma unroll
   for (int i = 0; i < 3; ++i) G.org[i] = is_surf ? a.ks.org[i] : a.kc.org[i];
   G.inv_c = is_surf ? a.ks.inv_c : a.kc.inv_c;
@@ -1273,27 +1282,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LSLAM_GRI
   sel[0] = ((R[0] * q.x + R[1] * q.y) + R[2] * q.z) + t[0];
   sel[1] = ((R[3] * q.x + R[4] * q.y) + R[5] * q.z) + t[1];
   sel[2] = ((R[6] * q.x + R[7] * q.y) + R[8] * q.z) + t[2];
-  // the bound of the production loop (sweep_body): the acceptance gate, and the previous sweep's five at the new position
+  // the bound of the production loop: the acceptance gate, and the previous sweep's five seen from the new position
   float bound = FLT_MAX;
   if (a.bounded) {
     bound = 5.0f * (1.0f + 1e-5f);
-    if (a.prev_valid && active) {
-      int pp[5];
-#pragma unroll
-      for (int j = 0; j < 5; ++j) pp[j] = a.prev_nb[(size_t)qi * 5 + j];
-      float4 pv[5];
-      bool all = true;
-#pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        const bool ok = pp[j] >= 0 && pp[j] < G.n_pts;
-        all = all && ok;
-        pv[j] = G.pts[ok ? pp[j] : 0];
-      }
-      float u = 0.0f;
-#pragma unroll
-      for (int j = 0; j < 5; ++j) u = fmaxf(u, dist2_xyz(sel[0], sel[1], sel[2], pv[j]));
-      if (all) bound = fminf(bound, u * (1.0f + 1e-5f) + 1e-12f);
-    }
+    if (a.prev_valid && active) bound = fminf(bound, grid_carried_bound(a.prev_q[qi], sel));
   }
   float d[5], lb6;
   int p[5];
@@ -1325,10 +1318,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LSLAM_GRI
   float row[6] = {0, 0, 0, 0, 0, 0};
   float rb = 0.0f, kept = 0.0f, matched = 0.0f, score = 0.0f;
   if (has) {
-    if (a.bounded) {
-#pragma unroll
-      for (int j = 0; j < 5; ++j) a.prev_nb[(size_t)qi * 5 + j] = p[j];
-    }
+    // what the next sweep's bound is taken from: where the point is now and how far its fifth neighbour
+    if (a.bounded) a.prev_q[qi] = make_float4(sel[0], sel[1], sel[2], (verdict == GRID_PROVEN && d[4] < 5.0f) ? d[4] : FLT_MAX);
     point_residual(a, bd, is_surf, G.pts, q, sel, d, p, sc, row, rb, kept, matched, score);
   }
   __syncthreads();  // every wavefront is done with its row table: the staging rows may be written

@@ -88,7 +88,7 @@ for seed in range(n_seeds):
     opts.search_mode = 3
     g0 = ctx.grid_launches()
     status, pose, st = ctx.run(init, opts)
-    if st.iterations != ost.iterations or abs(st.n_rows - ost.n_rows) > 2 or np.abs(pose[3:] - poses[1][3:]).max() > 5e-6 or np.abs(pose[:3] - poses[1][:3]).max() > 5e-7 or ctx.grid_launches() == g0:
+    if st.iterations != ost.iterations or abs(st.n_rows - ost.n_rows) > 2 or np.abs(pose[3:] - poses[1][3:]).max() > 2e-5 or np.abs(pose[:3] - poses[1][:3]).max() > 2e-6 or ctx.grid_launches() == g0:  # (a few ulps of a coordinate of tens of metres: the two sweeps group their sums differently)
         bad += 1; print("seed", seed, "grid sweep differs", st.iterations, ost.iterations, st.n_rows, ost.n_rows, np.abs(pose - poses[1]).max())
     print("seed %2d rings %2d steps %3d half %3.0f map %6d+%6d scan %5d: %s" % (seed, rings, steps, half, len(mc), len(ms), len(pr["corner"]) + len(pr["surf"]), "ok" if not bad else "MISMATCH"), flush=True)
     if bad:

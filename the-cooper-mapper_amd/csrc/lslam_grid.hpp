@@ -159,72 +159,107 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
     nend = rows[3 * BLOCK];
   }
 #if LSLAM_GRID_ASM_LOOP
-  // The loop by hand (20 vector instructions per round + 12 in rounds in which a lane changes rows; left to the compiler the
-  // same loop carried eleven register copies and a three-deep exec-mask nest per round: tools/resource_usage.sh).
-  // Positions are kept as BYTE offsets into G.pts (x 16) inside the loop.
+  // The loop by hand: 21 vector instructions per candidate + 11 in rounds in which a lane changes rows (left to the compiler
+  // the same loop carried eleven register copies and a three-deep exec-mask nest per round), software-pipelined one
+  // candidate deep: the point of candidate i + 1 is requested -- which takes knowing where candidate i + 1 is, i.e. the row
+  // bookkeeping of candidate i -- before the distance of candidate i is evaluated, so a round's load latency hides behind
+  // the wavefront's own work as well as the other wavefronts'.  Two register sets (A, B) alternate.  Positions are kept as
+  // BYTE offsets into G.pts (x 16) inside the loop.
   static_assert(BLOCK == 256, "the row table's strides are written into the loop's LDS instruction");
   {
-    register float px asm("v2");
-    register float py asm("v3");
-    register float pz asm("v4");
+    register float pax asm("v2");
+    register float pay asm("v3");
+    register float paz asm("v4");
+    register float pbx asm("v6");
+    register float pby asm("v7");
+    register float pbz asm("v8");
+    register uint32_t l0 asm("v10");
+    register uint32_t l1 asm("v11");
     uint32_t curb = cur << 4, endb = end << 4, ncurb = ncur << 4, nendb = nend << 4;
     unsigned long long am = __builtin_amdgcn_ballot_w64(alive);
-    unsigned long long adv, tmp;
-    uint32_t t0, t1, key;
+    unsigned long long adv, tmp, ama, amb;
+    uint32_t t0, t1, key, ida, idb;
     const uint32_t rowaddr = (uint32_t)(uintptr_t)rows;
     const uint32_t keep = ~GRID_ID_MASK;
+#define LSLAM_GRID_ISSUE(AM, ID, P)                       \
+  "s_mov_b64 " AM ", %[am]\n\t"                          \
+  "v_mov_b32 " ID ", %[id]\n\t"                          \
+  "v_cndmask_b32 %[t0], 0, %[curb], %[am]\n\t"           \
+  "global_load_dwordx3 " P ", %[t0], %[base]\n\t"
+#define LSLAM_GRID_ADVANCE(L)                                        \
+  "v_add_u32 %[curb], 16, %[curb]\n\t"                              \
+  "v_add_u32 %[id], 1, %[id]\n\t"                                   \
+  "v_cmp_eq_u32 %[adv], %[curb], %[endb]\n\t"                       \
+  "s_and_b64 %[adv], %[adv], %[am]\n\t"                             \
+  "s_cbranch_scc0 L_grid_noadv" L "_%=\n\t"                         \
+  "v_cmp_lt_i32 vcc, %[k], %[nrow]\n\t"                             \
+  "s_andn2_b64 %[tmp], %[adv], vcc\n\t"                             \
+  "s_andn2_b64 %[am], %[am], %[tmp]\n\t"                            \
+  "v_cndmask_b32 %[curb], %[curb], %[ncurb], %[adv]\n\t"            \
+  "v_cndmask_b32 %[endb], %[endb], %[nendb], %[adv]\n\t"            \
+  "v_lshlrev_b32 %[t0], 6, %[k]\n\t"                                \
+  "v_cndmask_b32 %[id], %[id], %[t0], %[adv]\n\t"                   \
+  "v_addc_co_u32 %[k], %[tmp], 0, %[k], %[adv]\n\t"                 \
+  "v_min_i32 %[t0], 8, %[k]\n\t"                                    \
+  "v_lshl_add_u32 %[t0], %[t0], 11, %[rowaddr]\n\t"                 \
+  "ds_read2st64_b32 v[10:11], %[t0] offset1:4\n\t"                    \
+  "s_waitcnt lgkmcnt(0)\n\t"                                        \
+  "v_lshlrev_b32 %[ncurb], 4, %[l0]\n\t"                            \
+  "v_lshlrev_b32 %[nendb], 4, %[l1]\n"                               \
+  "L_grid_noadv" L "_%=:\n\t"
+#define LSLAM_GRID_PROCESS(AM, ID, PX, PY, PZ)            \
+  "v_sub_f32 %[t0], %[qx], " PX "\n\t"                   \
+  "v_mul_f32 %[t0], %[t0], %[t0]\n\t"                    \
+  "v_sub_f32 %[t1], %[qy], " PY "\n\t"                   \
+  "v_mul_f32 %[t1], %[t1], %[t1]\n\t"                    \
+  "v_add_f32 %[t0], %[t0], %[t1]\n\t"                    \
+  "v_sub_f32 %[t1], %[qz], " PZ "\n\t"                   \
+  "v_mul_f32 %[t1], %[t1], %[t1]\n\t"                    \
+  "v_add_f32 %[t0], %[t0], %[t1]\n\t"                    \
+  "v_and_or_b32 %[key], %[t0], %[keep], " ID "\n\t"      \
+  "v_cndmask_b32 %[key], -1, %[key], " AM "\n\t"         \
+  "v_med3_u32 %[k5], %[k4], %[k5], %[key]\n\t"           \
+  "v_med3_u32 %[k4], %[k3], %[k4], %[key]\n\t"           \
+  "v_med3_u32 %[k3], %[k2], %[k3], %[key]\n\t"           \
+  "v_med3_u32 %[k2], %[k1], %[k2], %[key]\n\t"           \
+  "v_med3_u32 %[k1], %[k0], %[k1], %[key]\n\t"           \
+  "v_min_u32 %[k0], %[k0], %[key]\n\t"
     asm volatile(
         "s_cmp_eq_u64 %[am], 0\n\t"
-        "s_cbranch_scc1 L_grid_done_%=\n"
+        "s_cbranch_scc1 L_grid_done_%=\n\t"
+        LSLAM_GRID_ISSUE("%[ama]", "%[ida]", "v[2:4]")
+        LSLAM_GRID_ADVANCE("0")
         "L_grid_loop_%=:\n\t"
-        "v_cndmask_b32 %[t0], 0, %[curb], %[am]\n\t"
-        "global_load_dwordx3 v[2:4], %[t0], %[base]\n\t"
-        "v_add_u32 %[curb], 16, %[curb]\n\t"
-        "v_cmp_eq_u32 %[adv], %[curb], %[endb]\n\t"
+        "s_cmp_eq_u64 %[am], 0\n\t"
+        "s_cbranch_scc1 L_grid_lasta_%=\n\t"
+        LSLAM_GRID_ISSUE("%[amb]", "%[idb]", "v[6:8]")
+        LSLAM_GRID_ADVANCE("1")
+        "s_waitcnt vmcnt(1)\n\t"
+        LSLAM_GRID_PROCESS("%[ama]", "%[ida]", "%[pax]", "%[pay]", "%[paz]")
+        "s_cmp_eq_u64 %[am], 0\n\t"
+        "s_cbranch_scc1 L_grid_lastb_%=\n\t"
+        LSLAM_GRID_ISSUE("%[ama]", "%[ida]", "v[2:4]")
+        LSLAM_GRID_ADVANCE("2")
+        "s_waitcnt vmcnt(1)\n\t"
+        LSLAM_GRID_PROCESS("%[amb]", "%[idb]", "%[pbx]", "%[pby]", "%[pbz]")
+        "s_branch L_grid_loop_%=\n"
+        "L_grid_lasta_%=:\n\t"
         "s_waitcnt vmcnt(0)\n\t"
-        "v_sub_f32 %[t0], %[qx], %[px]\n\t"
-        "v_mul_f32 %[t0], %[t0], %[t0]\n\t"
-        "v_sub_f32 %[t1], %[qy], %[py]\n\t"
-        "v_mul_f32 %[t1], %[t1], %[t1]\n\t"
-        "v_add_f32 %[t0], %[t0], %[t1]\n\t"
-        "v_sub_f32 %[t1], %[qz], %[pz]\n\t"
-        "v_mul_f32 %[t1], %[t1], %[t1]\n\t"
-        "v_add_f32 %[t0], %[t0], %[t1]\n\t"
-        "v_and_or_b32 %[key], %[t0], %[keep], %[id]\n\t"
-        "v_add_u32 %[id], 1, %[id]\n\t"
-        "v_cndmask_b32 %[key], -1, %[key], %[am]\n\t"
-        "v_med3_u32 %[k5], %[k4], %[k5], %[key]\n\t"
-        "v_med3_u32 %[k4], %[k3], %[k4], %[key]\n\t"
-        "v_med3_u32 %[k3], %[k2], %[k3], %[key]\n\t"
-        "v_med3_u32 %[k2], %[k1], %[k2], %[key]\n\t"
-        "v_med3_u32 %[k1], %[k0], %[k1], %[key]\n\t"
-        "v_min_u32 %[k0], %[k0], %[key]\n\t"
-        "s_and_b64 %[adv], %[adv], %[am]\n\t"
-        "s_cbranch_scc0 L_grid_next_%=\n\t"
-        // some lane has finished its row
-        "v_cmp_lt_i32 vcc, %[k], %[nrow]\n\t"
-        "s_andn2_b64 %[tmp], %[adv], vcc\n\t"
-        "s_andn2_b64 %[am], %[am], %[tmp]\n\t"
-        "v_cndmask_b32 %[curb], %[curb], %[ncurb], %[adv]\n\t"
-        "v_cndmask_b32 %[endb], %[endb], %[nendb], %[adv]\n\t"
-        "v_lshlrev_b32 %[t0], 6, %[k]\n\t"
-        "v_cndmask_b32 %[id], %[id], %[t0], %[adv]\n\t"
-        "v_addc_co_u32 %[k], %[tmp], 0, %[k], %[adv]\n\t"
-        "v_min_i32 %[t0], 8, %[k]\n\t"
-        "v_lshl_add_u32 %[t0], %[t0], 11, %[rowaddr]\n\t"
-        "ds_read2st64_b32 v[2:3], %[t0] offset1:4\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_lshlrev_b32 %[ncurb], 4, %[px]\n\t"
-        "v_lshlrev_b32 %[nendb], 4, %[py]\n"
-        "L_grid_next_%=:\n\t"
-        "s_cmp_lg_u64 %[am], 0\n\t"
-        "s_cbranch_scc1 L_grid_loop_%=\n"
+        LSLAM_GRID_PROCESS("%[ama]", "%[ida]", "%[pax]", "%[pay]", "%[paz]")
+        "s_branch L_grid_done_%=\n"
+        "L_grid_lastb_%=:\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        LSLAM_GRID_PROCESS("%[amb]", "%[idb]", "%[pbx]", "%[pby]", "%[pbz]")
         "L_grid_done_%=:\n\t"
         : [k0] "+v"(k0), [k1] "+v"(k1), [k2] "+v"(k2), [k3] "+v"(k3), [k4] "+v"(k4), [k5] "+v"(k5), [curb] "+v"(curb), [endb] "+v"(endb),
           [ncurb] "+v"(ncurb), [nendb] "+v"(nendb), [id] "+v"(id), [k] "+v"(k), [am] "+s"(am), [adv] "=&s"(adv), [tmp] "=&s"(tmp),
-          [t0] "=&v"(t0), [t1] "=&v"(t1), [key] "=&v"(key), [px] "=&v"(px), [py] "=&v"(py), [pz] "=&v"(pz)
+          [ama] "=&s"(ama), [amb] "=&s"(amb), [t0] "=&v"(t0), [t1] "=&v"(t1), [key] "=&v"(key), [ida] "=&v"(ida), [idb] "=&v"(idb),
+          [pax] "=&v"(pax), [pay] "=&v"(pay), [paz] "=&v"(paz), [pbx] "=&v"(pbx), [pby] "=&v"(pby), [pbz] "=&v"(pbz), [l0] "=&v"(l0), [l1] "=&v"(l1)
         : [qx] "v"(qx), [qy] "v"(qy), [qz] "v"(qz), [nrow] "v"(nrow), [rowaddr] "v"(rowaddr), [base] "s"(G.pts), [keep] "s"(keep)
         : "vcc", "scc", "memory");
+#undef LSLAM_GRID_ISSUE
+#undef LSLAM_GRID_ADVANCE
+#undef LSLAM_GRID_PROCESS
   }
 #else
   while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {

@@ -1226,7 +1226,7 @@ hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, h
 // its sums added to this workgroup's record.  Fixed places, fixed order: the same bits in every run.
 // ---------------------------------------------------------------------------
 #ifndef LSLAM_GRID_OCC
-#define LSLAM_GRID_OCC 5
+#define LSLAM_GRID_OCC 6  // wavefronts per SIMD the grid sweep is compiled for: 80 VGPRs (5: 90 VGPRs, 8 % slower; 7: below; 8: 64 VGPRs with 96 B of scratch, slower than 5)
 #endif
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LSLAM_GRID_OCC))) void sweep_grid_kernel(SweepArgs a, int jtj_mode) {

@@ -25,10 +25,11 @@ a launcher (WORLD_SIZE set) the rank count must equal --gpus.  The map is replic
 its own scans (independent problems, no data-path collective: SURVEY.md 8e row 2), `value` is the
 whole-job aggregate.
 
-Prints ONE JSON line (rank 0).  `roofline` carries the sweep kernel's algorithmic bytes (1.7 KB per
-point-residual) over its average duration, measured with HIP events on the library's own
-stream inside the timed region, next to what the committed rocprofv3 counter passes of this same command
-say bounds it.  `cpu_baseline` is the oracle (a port of the reference's single-threaded CPU path,
+The LAST stdout line (rank 0) is one compact JSON object (< 6 KB: the contract's keys, `roofline`, `cpu_baseline`, one
+number per secondary leg); the full report goes to bench_report.json and, as one line, to stderr.  `roofline` prices the
+sweep's dominant kernel -- SURVEY.md 8d's algorithmic flops (and, beside them, bytes) per point-residual over its average
+duration, measured with HIP events on the library's own stream inside the timed region -- next to what the committed
+rocprofv3 counter passes of this same command say bounds it.  `cpu_baseline` is the oracle (a port of the reference's single-threaded CPU path,
 including its per-call kd-tree rebuild) timed on this host on a sample of the same workload.
 """
 import argparse
@@ -241,7 +242,7 @@ def main():
 
     out = None
     if rank == 0:
-        roof = sweep_roofline(pt_res, sweep_ms, sweep_launches, float(info.n_corner + info.n_surf))
+        roof = sweep_roofline(pt_res, sweep_ms, sweep_launches, float(info.n_corner + info.n_surf), grid=ctx.grid_launches() > 0)
         out = {
             "metric": "point-residuals/s",
             "value": total_pt_res / t,
@@ -299,49 +300,45 @@ def main():
             out["grid_sweep"] = {"points_swept_per_step": int(g1[1] - g0[1]), "points_left_to_the_tree_search_per_step": int(g1[0] - g0[0]),
                                  "share_left_to_the_tree_search": (g1[0] - g0[0]) / max(1, g1[1] - g0[1]),
                                  "second_pass_launches_per_step": int(g1[2] - g0[2])}
-    # ---- disclosure leg: the same steps with every point SEARCHED in every sweep (lslam_opts.knn_cert = 0).  The
-    # headline runs the library as shipped, whose certificate sweep keeps a point's five neighbours without a
-    # search when the previous search's bounds prove they cannot have changed -- the same neighbours, hence the same residuals
-    # and poses up to summation order, with fewer executed instructions.  Both rates are in the line.
+    # ---- disclosure leg: the same steps through the library's other search paths.  The headline runs the library as shipped
+    # (lslam_opts.search_mode AUTO: for a batch this size the grid sweep -- every point's five neighbours either PROVEN by a
+    # 27-cell probe or searched in the kd-tree; no neighbour list is carried over without one or the other).  Beside it:
+    # the kd-tree walk of every point (round 3's kernel) with its certificate sweep, and with every search executed.  Same
+    # neighbours in all of them, hence the same residuals and poses up to summation order.
     if not args.headline_only:
-        import ctypes
-        cert = {"what": "value = the library as shipped (certificate sweep for throughput-bound batches); value_searching_every_point = "
-                        "the same steps with lslam_opts.knn_cert = 0: every 5-NN search of every sweep executed"}
-        knn_cert_shipped = opts.knn_cert
-        opts.knn_cert = 0
-        ctx.run_batch(inits, opts)
-        barrier()
-        t1 = time.perf_counter()
-        pr0 = 0
+        def timed_mode(search_mode, knn_cert, n0):
+            o_s, o_c = opts.search_mode, opts.knn_cert
+            opts.search_mode, opts.knn_cert = search_mode, knn_cert
+            ctx.run_batch(inits, opts)
+            barrier()
+            t1 = time.perf_counter()
+            pr0 = 0
+            for _ in range(n0):
+                st0, poses0, sts0 = ctx.run_batch(inits, opts)
+                pr0 += sum(s.point_residuals for s in sts0)
+            barrier()
+            (tot0,), t0s = distmod.aggregate(dist, [pr0], time.perf_counter() - t1)
+            opts.search_mode, opts.knn_cert = o_s, o_c
+            return tot0 / t0s, poses0, sts0
         n0 = max(3, args.steps // 4)
-        for _ in range(n0):
-            st0, poses0, sts0 = ctx.run_batch(inits, opts)
-            pr0 += sum(s.point_residuals for s in sts0)
-        barrier()
-        (tot0,), t0s = distmod.aggregate(dist, [pr0], time.perf_counter() - t1)
-        opts.knn_cert = knn_cert_shipped
-        # and what share of the certificate-testing sweeps' points kept their neighbours (one more step, counted)
-        opts.debug_stats = 1
-        cs0 = (ctypes.c_uint64 * 3)()
-        cs1 = (ctypes.c_uint64 * 3)()
-        ctx.lib.lslam_debug_cert_stats(ctx.h, cs0)
-        st1, poses1, sts1 = ctx.run_batch(inits, opts)
-        ctx.lib.lslam_debug_cert_stats(ctx.h, cs1)
-        opts.debug_stats = 0
+        shipped_is_grid = args.search in ("auto", "grid") and ctx.grid_launches() > 0
+        v_every, poses0, sts0 = timed_mode(opts.search_mode, 0, n0)      # the shipped search, certificates off (a no-op for the grid sweep)
+        v_lane_cert, poses_l, sts_l = timed_mode(1, 1, n0)                # kd-tree walk + certificate sweep
+        v_lane_every, poses_e, sts_e = timed_mode(1, 0, n0)               # kd-tree walk, every search executed
         if rank == 0:
-            tested, needy = cs1[1] - cs0[1], cs1[0] - cs0[0]
-            swept = sum(s.point_residuals for s in sts1)
-            cert.update({
-                "value_searching_every_point": tot0 / t0s, "steps_searching_every_point": n0,
-                "point_residuals_per_step": swept, "points_that_tested_a_certificate_per_step": int(tested),
-                "points_certified_per_step": int(tested - needy), "share_of_point_residuals_certified": (tested - needy) / max(1, swept),
-                "second_pass_launches_per_step": int(cs1[2] - cs0[2]),
-                "pose_diff_between_the_two_modes_m": float(np.abs(poses1[:, 3:] - poses0[:, 3:]).max()),
-                "pose_diff_between_the_two_modes_rad": float(np.abs(poses1[:, :3] - poses0[:, :3]).max()),
-                "iterations_equal": bool(all(a.iterations == b.iterations for a, b in zip(sts0, sts1))),
-                "rows_equal": bool(all((a.n_rows, a.n_line, a.n_plane) == (b.n_rows, b.n_line, b.n_plane) for a, b in zip(sts0, sts1))),
-            })
-            out["certificate_sweep"] = cert
+            status, poses, sts = last
+            out["certificate_sweep"] = {
+                "what": "value = the library as shipped (%s); value_searching_every_point = the same search with lslam_opts.knn_cert = 0 "
+                        "(no neighbour list carried over by certificate); kd_tree_walk = LSLAM_SEARCH_LANE, round 3's kernel, with its "
+                        "certificate sweep and with every search executed" % ("the grid sweep: probe + proof, kd-tree search for the rest" if shipped_is_grid else "kd-tree walk + certificate sweep"),
+                "value_searching_every_point": v_every, "steps_per_mode": n0,
+                "kd_tree_walk": {"value": v_lane_cert, "value_searching_every_point": v_lane_every},
+                "pose_diff_between_the_two_modes_m": float(max(np.abs(poses[:, 3:] - poses_e[:, 3:]).max(), np.abs(poses_l[:, 3:] - poses_e[:, 3:]).max())),
+                "pose_diff_between_the_two_modes_rad": float(max(np.abs(poses[:, :3] - poses_e[:, :3]).max(), np.abs(poses_l[:, :3] - poses_e[:, :3]).max())),
+                "iterations_equal": bool(all(a.iterations == b.iterations == c.iterations for a, b, c in zip(sts, sts_l, sts_e))),
+                "rows_equal": bool(all((a.n_rows, a.n_line, a.n_plane) == (b.n_rows, b.n_line, b.n_plane) == (c.n_rows, c.n_line, c.n_plane)
+                                       for a, b, c in zip(sts, sts_l, sts_e))),
+            }
     if rank == 0 and not args.no_single:  # (replaces the resident scans: after every leg that runs the step's batch)
         out["single_scan"] = single_scan_leg(ctx, scans[0], inits[0], opts, 200)
     # ---- the same timed region on 16-ring x 1800 scans (VLP-16, MultiScanRegistration.h:90-92; BASELINE north star:
@@ -520,8 +517,10 @@ def compact_line(out):
     se = out.get("certificate_sweep") or {}
     if se:
         opt.append(("value_searching_every_point", se.get("value_searching_every_point")))
-        opt.append(("search_modes", {k: se.get(k) for k in ("share_of_point_residuals_certified", "pose_diff_between_the_two_modes_m",
-                                                           "iterations_equal", "rows_equal", "tree_only_value") if k in se}))
+        opt.append(("search_modes", {"kd_tree_walk_value": _pick(se, "kd_tree_walk", "value"),
+                                     "kd_tree_walk_value_searching_every_point": _pick(se, "kd_tree_walk", "value_searching_every_point"),
+                                     "pose_diff_m": se.get("pose_diff_between_the_two_modes_m"), "iterations_equal": se.get("iterations_equal"),
+                                     "rows_equal": se.get("rows_equal")}))
     if out.get("ranks"):
         opt.append(("ranks", out["ranks"]))
     if out.get("grid_sweep"):
@@ -633,7 +632,7 @@ def vlp16_throughput_leg(ctx, lidar, synth, dense, span, rank, world, args, opts
     (total_pt_res, total_iters), t = distmod.aggregate(dist, [pt_res, iters], elapsed)
     if rank != 0:
         return None
-    roof = sweep_roofline(pt_res, sweep_ms, sweep_launches, float(info.n_corner + info.n_surf))
+    roof = sweep_roofline(pt_res, sweep_ms, sweep_launches, float(info.n_corner + info.n_surf), grid=ctx.grid_launches() > 0)
     # the committed counter passes are of the 64-ring command: the 16-ring launches run the same kernel on a quarter of the points
     roof["counters_of"] = "the 64-ring headline command (same kernel instantiation): see roofline.counters of the headline"
     roof.pop("counters", None)
@@ -681,7 +680,7 @@ def tree_build_roofline(ms, n_corner, n_surf, np):
     return roof
 
 
-def sweep_roofline(pt_res, sweep_ms, sweep_launches, map_points):
+def sweep_roofline(pt_res, sweep_ms, sweep_launches, map_points, grid=True):
     """The roofline object of one timed region of sweep launches (the 64-ring headline, the 16-ring leg).
 
     achieved / peak / frac are PHYSICAL: the sweep kernel is bound by vector-ALU instruction issue (the counter passes: 99 % of the
@@ -702,11 +701,16 @@ def sweep_roofline(pt_res, sweep_ms, sweep_launches, map_points):
     bounded_gbs = ALG_BYTES_PER_POINT_BOUNDED * pts_per_launch / t_s / 1e9 if t_s > 0 else 0.0
     compulsory = map_points * 16.0 + pts_per_launch * (16.0 + 36.0)
     roof = {
-        "kernel": "sweep_kernel<256,true,false,12> (the shallow-stack batch instantiation; tests/test_gpu_stack_shapes.py holds it "
-                  "against the oracle) -- from a loop's second sweep on as the certificate sweep: sweep_kernel<...,1> over every point "
-                  "+ cert_plan_kernel + sweep_queue_kernel<256,true,12> over the points whose neighbours could not be carried over; "
-                  "one timed 'launch' is one sweep = that group of dispatches (HIP events on the first and the last of them)",
-        "kernel_short": "sweep_kernel<256,true,false,12> (+ certificate pass: cert_plan_kernel, sweep_queue_kernel)",
+        "kernel": ("sweep_grid_kernel<256> (the grid sweep: 27-cell probe + proof for every point, residual chain for the proven ones; "
+                   "tests/test_gpu_grid.py and test_gpu_stack_shapes.py hold it against the oracle) + cert_plan_kernel + "
+                   "sweep_queue_kernel<256,true,12> (kd-tree search + residual chain of the points the probe could not prove); one timed "
+                   "'launch' is one sweep = that group of dispatches (HIP events on the first and the last of them)") if grid else
+                  ("sweep_kernel<256,true,false,12> (the shallow-stack batch instantiation; tests/test_gpu_stack_shapes.py holds it "
+                   "against the oracle) -- from a loop's second sweep on as the certificate sweep: sweep_kernel<...,1> over every point "
+                   "+ cert_plan_kernel + sweep_queue_kernel<256,true,12> over the points whose neighbours could not be carried over; "
+                   "one timed 'launch' is one sweep = that group of dispatches (HIP events on the first and the last of them)"),
+        "kernel_short": "sweep_grid_kernel<256> + cert_plan_kernel + sweep_queue_kernel<256,true,12>" if grid else
+                        "sweep_kernel<256,true,false,12> (+ certificate pass: cert_plan_kernel, sweep_queue_kernel)",
         "bound": "valu",
         "achieved": tflops,
         "peak": FP32_PEAK_TFLOPS,
@@ -715,8 +719,8 @@ def sweep_roofline(pt_res, sweep_ms, sweep_launches, map_points):
         "accounting": "achieved = %.0f flop per point-residual (SURVEY 8d) x %.4g points an average timed launch processed / its "
                       "HIP-event duration of %.4g ms; peak = vector fp32 (MI355X_MICROARCH.md).  Neither `hbm` nor `mfma` bounds "
                       "this kernel: the counters put VALU issue at `valu_issue.frac` of its slots and HBM at `measured_hbm.frac`.  "
-                      "The flops are the ALGORITHM's (a 5-NN search per point and sweep); the certificate sweep skips the searches "
-                      "it can prove redundant, so late sweeps finish the same algorithmic work with fewer executed instructions"
+                      "The flops are the ALGORITHM's (a 5-NN search per point and sweep, SURVEY's count for the kd-tree walk); the grid "
+                      "sweep finds the same five with fewer executed instructions, which shows as a higher fraction, not as more work"
                       % (FLOPS_PER_POINT_RESIDUAL, pts_per_launch, avg_sweep_ms),
         "alg_flops_per_point": FLOPS_PER_POINT_RESIDUAL,
         "alg_flops_per_launch": flops,

@@ -295,7 +295,7 @@ size_t oracle_fmap_get_surround(const oracle_fmap *f, int which, float *out, siz
   size_t n = 0;
   for (size_t v = 0; v < f->n_valid; ++v) {
     const cloud_t *c = f->cube[which][f->valid[v]];
-    if (out && n + c->n <= cap) memcpy(out + 4 * n, c->p, c->n * 4 * sizeof(float));
+    if (out && c->n && n + c->n <= cap) memcpy(out + 4 * n, c->p, c->n * 4 * sizeof(float));
     n += c->n;
   }
   return n;

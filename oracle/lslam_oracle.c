@@ -559,7 +559,8 @@ void oracle_eig_sym6(const float A[36], float evals[6], float V[36]) {
     int rem = N - i - 1;
     float h, beta;
     /* matA.col(i).tail(rem).makeHouseholderInPlace(h, beta) */
-    make_householder(&m[(i + 1) * N + i], &m[(i + 2) * N + i], rem - 1, N, &h, &beta);
+    /* (an empty tail for i = N - 2: its address is never formed -- row N does not exist) */
+    make_householder(&m[(i + 1) * N + i], rem > 1 ? &m[(i + 2) * N + i] : &m[(i + 1) * N + i], rem - 1, N, &h, &beta);
     m[(i + 1) * N + i] = 1.0f;
     /* hCoeffs.tail(rem) = (A22.selfadjointView<Lower>() * (h * v)) */
     float v[N], p[N];
@@ -593,7 +594,7 @@ void oracle_eig_sym6(const float A[36], float evals[6], float V[36]) {
   for (int k = N - 2; k >= 0; --k) {
     int corner = N - k - 1;
     /* essential vector k: column k, rows k+2..N-1 */
-    apply_householder_left(&V[(k + 1) * N + (k + 1)], corner, corner, N, &m[(k + 2) * N + k], N,
+    apply_householder_left(&V[(k + 1) * N + (k + 1)], corner, corner, N, corner > 1 ? &m[(k + 2) * N + k] : &m[(k + 1) * N + k], N,
                            hCoeffs[k]);
   }
   eig_from_tridiagonal(diag, subdiag, V, N);
@@ -638,12 +639,12 @@ static void colpiv_qr_solve(int rows, int cols, const float *Ain, const float *b
       t = normsD[k]; normsD[k] = normsD[big]; normsD[big] = t;
     }
     float beta;
-    make_householder(&qr[k * cols + k], &qr[(k + 1) * cols + k], rows - k - 1, cols, &hC[k], &beta);
+    make_householder(&qr[k * cols + k], rows - k - 1 > 0 ? &qr[(k + 1) * cols + k] : &qr[k * cols + k], rows - k - 1, cols, &hC[k], &beta);
     qr[k * cols + k] = beta;
     if (fabsf(beta) > maxpivot) maxpivot = fabsf(beta);
     if (cols - k - 1 > 0)
       apply_householder_left(&qr[k * cols + k + 1], rows - k, cols - k - 1, cols,
-                             &qr[(k + 1) * cols + k], cols, hC[k]);
+                             rows - k - 1 > 0 ? &qr[(k + 1) * cols + k] : &qr[k * cols + k], cols, hC[k]);
     for (int j = k + 1; j < cols; ++j) {
       if (normsU[j] != 0.0f) {
         float temp = fabsf(qr[k * cols + j]) / normsU[j];
@@ -673,7 +674,7 @@ static void colpiv_qr_solve(int rows, int cols, const float *Ain, const float *b
   }
   for (int i = 0; i < rows; ++i) c[i] = b[i];
   for (int k = 0; k < nonzero_pivots; ++k)
-    apply_householder_left(&c[k], rows - k, 1, 1, &qr[(k + 1) * cols + k], cols, hC[k]);
+    apply_householder_left(&c[k], rows - k, 1, 1, rows - k - 1 > 0 ? &qr[(k + 1) * cols + k] : &qr[k * cols + k], cols, hC[k]);
   /* upper-triangular solve, column-oriented (Eigen triangular_solve_vector, ColMajor) */
   for (int i = nonzero_pivots - 1; i >= 0; --i) {
     c[i] /= qr[i * cols + i];

@@ -23,6 +23,9 @@ def lib():
     if _lib is None:
         path = os.path.join(HERE, "libposegraph_oracle.so")
         src = os.path.join(HERE, "posegraph_oracle.c")
+        if os.environ.get("LSLAM_ORACLE_SANITIZE") == "1":  # the ASan + UBSan build (make -C oracle asan)
+            path = os.path.join(HERE, "_asan", "libposegraph_oracle.so")
+            src = path
         if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
             subprocess.check_call(["make", "-C", HERE, "libposegraph_oracle.so"], stdout=subprocess.DEVNULL)
         L = C.CDLL(path)

@@ -80,6 +80,8 @@ class OracleStats(C.Structure):
 def build_oracle(native=False):
     """Compile the oracle with its Makefile if the .so is missing or stale.  native: -O3
     -march=native (CPU baseline); native == "omp": that plus the OpenMP sweep (all-cores bound)."""
+    if os.environ.get("LSLAM_ORACLE_SANITIZE") == "1":  # tools/run_sanitized_oracle_tests.sh: the ASan + UBSan build (make -C oracle asan)
+        return os.path.join(ORACLE_DIR, "_asan", "liblslam_oracle.so")
     target = {False: "liblslam_oracle.so", True: "liblslam_oracle_native.so", "omp": "liblslam_oracle_omp.so"}[native]
     so = os.path.join(ORACLE_DIR, target)
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("lslam_oracle.c", "lslam_oracle.h", "fmap_oracle.c", "fmap_oracle.h", "features_oracle.c",

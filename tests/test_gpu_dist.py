@@ -177,6 +177,7 @@ def test_rccl_communicator_world_of_one(pkg, ctx, small_problem):
     pr = small_problem
     comm = pkg.Comm(0, pkg.Comm.unique_id(), 0, 1)
     try:
+        assert comm.info() == (0, 1)  # ncclCommUserRank / ncclCommCount: what bench.py --gpus N reports as rccl_ranks
         ctx.map_set(pr["map_corner"], pr["map_surf"])
         ctx.scan_set(pr["corner"], pr["surf"])
         s0, p0, st0 = ctx.run(pr["init_pose"])

@@ -31,6 +31,8 @@ struct Rccl {
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
   bool ok = false;
 };
 
@@ -52,7 +54,7 @@ bool load_rccl() {
 #define SYM(f)                                                              \
   g_rccl.f = reinterpret_cast<decltype(g_rccl.f)>(dlsym(g_rccl.handle, "nccl" #f)); \
   if (!g_rccl.f) { lslam::set_error("librccl lacks nccl" #f); return false; }
-  SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(AllReduce) SYM(GetErrorString)
+  SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(AllReduce) SYM(GetErrorString) SYM(CommCount) SYM(CommUserRank)
 #undef SYM
   g_rccl.ok = true;
   return true;
@@ -133,10 +135,17 @@ void lslam_comm_destroy(lslam_comm *c) {
   delete c;
 }
 
+// what the COMMUNICATOR says (ncclCommUserRank / ncclCommCount), not what it was asked to be: the rank count `bench.py --gpus N`
+// prints as `rccl_ranks`
 int lslam_comm_info(const lslam_comm *c, int32_t *rank, int32_t *world) {
-  if (!c) return LSLAM_ERR_INVALID;
-  if (rank) *rank = c->rank;
-  if (world) *world = c->world;
+  if (!c || !c->comm || !g_rccl.ok) return LSLAM_ERR_INVALID;
+  int r = -1, w = -1;
+  ncclResult_t e = g_rccl.CommUserRank(c->comm, &r);
+  if (e != ncclSuccess) return nccl_fail("ncclCommUserRank", e);
+  e = g_rccl.CommCount(c->comm, &w);
+  if (e != ncclSuccess) return nccl_fail("ncclCommCount", e);
+  if (rank) *rank = r;
+  if (world) *world = w;
   return LSLAM_OK;
 }
 

@@ -594,7 +594,7 @@ __device__ static void eig_sym6_dyn(const float *A, float *evals, float *V) {
   for (int i = 0; i < N - 1; ++i) {
     const int rem = N - i - 1;
     float h, beta;
-    make_householder_dyn(&m[(i + 1) * N + i], &m[(i + 2) * N + i], rem - 1, N, &h, &beta);
+    make_householder_dyn(&m[(i + 1) * N + i], rem > 1 ? &m[(i + 2) * N + i] : &m[(i + 1) * N + i], rem - 1, N, &h, &beta);  // (empty tail for i = N - 2)
     m[(i + 1) * N + i] = 1.0f;
     float v[N], p[N];
     for (int aa = 0; aa < rem; ++aa) v[aa] = m[(i + 1 + aa) * N + i];
@@ -626,7 +626,7 @@ __device__ static void eig_sym6_dyn(const float *A, float *evals, float *V) {
     const int rows = N - k - 1;
     const float tau = hCoeffs[k];
     float *M = &V[(k + 1) * N + (k + 1)];
-    const float *ess = &m[(k + 2) * N + k];
+    const float *ess = rows > 1 ? &m[(k + 2) * N + k] : &m[(k + 1) * N + k];  // (no essential part for k = N - 2: never read)
     if (rows == 1) {
       M[0] *= (1.0f - tau);
     } else if (tau != 0.0f) {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (gpurun -- bash tools/collect_profiles.sh <tag>): bench line, rocprofv3 kernel
 # stats and the PMC passes the roofline object cites.  Results land in gpurun_out/<tag>_*.
-tag=${1:-r02}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 mkdir -p $out
@@ -25,6 +25,21 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
   i=$((i+1))
   timeout 900 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/${tag}_pmc/p$i -o p -- python3 $H > $out/${tag}_pmc_p$i.log 2>&1
 done
-python3 $root/tools/summarize_pmc.py sweep_kernel,sweep_queue_kernel,cert_plan_kernel $out/${tag}_pmc_sweep.csv $out/${tag}_pmc/p1 $out/${tag}_pmc/p2 $out/${tag}_pmc/p3 $out/${tag}_pmc/p4 $out/${tag}_pmc/p5 $out/${tag}_pmc/p6 $out/${tag}_pmc/p7 > /dev/null
+# the headline's sweep is the grid sweep (search AUTO): sweep_grid_kernel + its second pass, mean per sweep
+python3 $root/tools/summarize_pmc.py sweep_grid_kernel,sweep_queue_kernel,cert_plan_kernel $out/${tag}_pmc_sweep.csv $out/${tag}_pmc/p1 $out/${tag}_pmc/p2 $out/${tag}_pmc/p3 $out/${tag}_pmc/p4 $out/${tag}_pmc/p5 $out/${tag}_pmc/p6 $out/${tag}_pmc/p7 > /dev/null
+python3 $root/tools/summarize_pmc_by_name.py $out/${tag}_pmc_sweep_by_kernel.csv "rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python3 bench.py --headline-only --steps 2 --warmup 1 (one pass per counter set): the dispatches of a sweep, per kernel; FETCH_SIZE / WRITE_SIZE in KiB as reported" sweep_grid_kernel,sweep_queue_kernel,cert_plan_kernel,sweep_kernel $out/${tag}_pmc/p1 $out/${tag}_pmc/p2 $out/${tag}_pmc/p3 $out/${tag}_pmc/p4 > /dev/null 2>&1
+# the same command through the kd-tree walk (--search lane: round 3's kernel + certificate sweep): kernel stats and the
+# instruction / lane counters, for the before / after of the search
+HL="$H --search lane"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_lstats -o s -- python3 $HL > $out/${tag}_lane_headline.json 2> $out/${tag}_lstats.log
+cp $out/${tag}_lstats/s_kernel_stats.csv $out/${tag}_lane_headline_kernel_stats.csv
+i=0
+for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" \
+  "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_F32 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout 900 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/${tag}_lpmc/p$i -o p -- python3 $HL > $out/${tag}_lpmc_p$i.log 2>&1
+done
+python3 $root/tools/summarize_pmc.py sweep_kernel,sweep_queue_kernel,cert_plan_kernel $out/${tag}_lane_pmc_sweep.csv $out/${tag}_lpmc/p1 $out/${tag}_lpmc/p2 > /dev/null
+rm -rf $out/${tag}_lpmc $out/${tag}_lstats
 rm -rf $out/${tag}_pmc $out/${tag}_stats $out/${tag}_hstats   # raw traces are gigabytes; the summaries above are what is kept
 du -sh $out | tail -1

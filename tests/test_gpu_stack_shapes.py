@@ -449,3 +449,51 @@ def test_fused_solve_equals_the_solve_launch(ctx, synth, small_problem, monkeypa
     assert np.array_equal(bits(pf), bits(pu))
     assert [(s.status, s.iterations, s.n_rows, s.sweeps) for s in sf] == [(s.status, s.iterations, s.n_rows, s.sweeps) for s in su]
     assert sf[2].status == 5 and len({s.iterations for s in sf}) > 1
+
+
+def test_vlp16_mapping_frames_against_the_voxel_map_match_oracle(voxel_map_problem, pkg, oracle, synth):
+    """BASELINE configs[1] at its own shape: VLP-16 sweeps of 16 x 1800 points through LaserMapping::process
+    (LaserMapping.cpp:39-59 over LaserMatcher.cpp:289-354: transformMerge, VoxelGrid of the frame's features, update +
+    surround -> trees, scanMatchScan with 0.1 / 0.1 and the score gate off, addFeatureCloud) against the (reduced) voxel map,
+    three consecutive frames -- the map they match against includes what the earlier ones added -- with the device's chain
+    held against the same steps made of oracle calls: every frame's map pose to the bar, the same iteration counts."""
+    import importlib as il
+    from test_gpu_pipeline import OracleChain
+    synth_gpu = il.import_module("synth_gpu")
+    vp = voxel_map_problem
+    ctx = vp["ctx"]
+    mc, ms = vp["surround"]
+    dims = (21, 21, 11)
+    world = synth.World(half_extent=300.0, wall_half=295.0, pole_pitch=2.5)
+    lidar = synth_gpu.GpuLidar(world, 0)
+    traj = synth_gpu.loop_trajectory(10000)[-4000::10]
+    mapper = pkg.LaserMapping(ctx, cube_dims=dims, map_filter_corner=0.2, map_filter_surf=0.4, map_filter=0.6)
+    chain = OracleChain(oracle, ctx, dims)
+    chain.fm.setup_filter_size(0.2, 0.4, 0.6)
+    eye = np.eye(4, dtype=np.float32)
+    start = traj[-124]
+    for fm in (mapper.feature_map, chain.fm):  # both maps start as the voxel map's surround (already filtered: stays as it is)
+        fm.update(start[3:].astype(np.float32))
+        fm.add_feature_cloud(mc, ms, eye)
+    sr = pkg.scan_registration
+    iters = []
+    for k in range(3):
+        g = traj[-124 + 2 * k].copy()
+        _, _, cloud, ranges = lidar.scan(g, 16, 1800, seed=9100 + k, full=True)
+        assert len(cloud) > 20000
+        f = sr.extract_features(ctx, cloud, ranges)
+        of = oracle.extract_features(cloud, ranges)
+        for key in ("less_sharp", "less_flat"):
+            assert np.array_equal(bits(f[key]), bits(of[key])), (k, key)
+        odom = synth_gpu.pose_matrix(synth.perturb_pose(g, seed=70 + k, dt=0.15, dr_deg=0.8))  # what the odometry node would hand over
+        M_g = mapper.process(f["less_sharp"], f["less_flat"], odom)
+        M_o = chain.mapping(of["less_sharp"], of["less_flat"], odom)
+        iters.append(mapper.last_stats.iterations)
+        assert mapper.last_stats.n_rows > 1000, (k, mapper.last_stats.n_rows)
+        assert np.abs(M_g[:3, 3] - M_o[:3, 3]).max() <= POSE_TOL_M, (k, np.abs(M_g - M_o).max())
+        assert np.abs(M_g[:3, :3] - M_o[:3, :3]).max() <= 2e-5, k
+        # a real match: the frame lands where it was taken -- within centimetres in the plane; the height of a 16-ring frame
+        # thinned to one point per cubic metre (LaserMatcher.cpp:289-301) is held by far fewer rows
+        assert np.abs(M_g[:2, 3] - g[3:5]).max() < 0.05 and abs(M_g[2, 3] - g[5]) < 0.3, (k, M_g[:3, 3], g[3:])
+    assert min(iters) >= 2
+    mapper.feature_map.close()

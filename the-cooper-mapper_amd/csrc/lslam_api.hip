@@ -307,6 +307,7 @@ void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
   a.ks = CellGrid{};
   a.grid = 0;
   a.grid_clip_margin = GRID_CLIP_MARGIN_MIN;
+  a.grid_hint = nullptr;
   a.q = ctx->q.p;
   a.blocks = ctx->blocks.p;
   a.nb_total = ctx->nb_total;
@@ -1520,6 +1521,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
     if (grid_on) {  // the grid sweep carries (position, fifth distance) per point in prev_q; no certificates
       sa.prev_q = ctx->prev_q.p;
       sa.prev_lb = nullptr;
+      sa.grid_hint = ctx->prev_lb.p;  // (the certificate sweep's per-point array, free in this mode)
     }
     if ((sa.prev_q || sa.grid) && (ctx->env_debug_cert_stats || o.debug_stats)) {
       if (!ctx->cert_stats.p) {
@@ -2281,6 +2283,7 @@ int lslam_sweep_ex(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_
     sa.kc = ctx->kc.view;
     sa.ks = ctx->ks.view;
     sa.grid = 1;
+    sa.grid_hint = ctx->prev_lb.p;
     HIP_TRY(ctx->stack_ovf.reserve(stack_ovf_words((size_t)std::max(sa.nb_total, 1) * SWEEP_BLOCK, std::max(ctx->tc.depth, ctx->ts.depth))));
     sa.stack_ovf = ctx->stack_ovf.p;
     sa.need_list = ctx->need_list.p;

@@ -119,6 +119,8 @@ struct SweepArgs {
   CellGrid kc, ks;
   int32_t grid;
   float grid_clip_margin;  // [m] padding of the clip radius sqrt(bound) of a bounded grid search
+  float *grid_hint;        // [points] grid sweep, pass 1 -> pass 2: an upper bound of the fifth neighbour's squared distance of a
+                           // point the probe could not prove (the fifth smallest distance it saw, FLT_MAX if it saw fewer than five)
   const float4 *q;  // scan points of all scans, sensor frame, Morton order within a scan
                     // and type, {x,y,z,bitcast(original index)}
   const BlockDesc *blocks;  // [nb_total]

@@ -483,6 +483,7 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
       bound = 5.0f * (1.0f + 1e-5f);
       if (prev_valid && T.n_pts > 0 && grid) {
         bound = fminf(bound, grid_carried_bound(a.prev_q[qi], sel));
+      } else if (grid) {
       } else if (prev_valid && T.n_pts > 0) {
         // the five indices, then the five points, all in flight together (a guarded load per neighbour would be a chain
         // of ten dependent round trips at the head of every wavefront): an invalid index reads point 0 and is ignored
@@ -503,6 +504,9 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
         if (all) bound = fminf(bound, u * (1.0f + 1e-5f) + 1e-12f);
       }
     }
+    // grid sweep: the probe that could not PROVE its five has still SEEN five (usually): their fifth distance bounds the true
+    // one from above, and a search bounded that tightly visits a fraction of what one bounded by the gate alone does
+    if (grid && a.grid_hint) bound = fminf(bound, a.grid_hint[qi]);
 #ifdef LSLAM_TRAVERSAL_STATS
     TravStats ts = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     knn5_search<BLOCK, OVF, LDS_DEPTH>(T, sel[0], sel[1], sel[2], d, p, stk, ts, bound);
@@ -1305,7 +1309,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LSLAM_GRI
       off += w < wave ? c : 0;
       total += c;
     }
-    if (needy) a.need_list[(size_t)lb * BLOCK + off + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)tid;
+    if (needy) {
+      a.need_list[(size_t)lb * BLOCK + off + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)tid;
+      // what pass 2's search may take for granted: five map points within this distance (padded like every bound)
+      if (a.grid_hint) a.grid_hint[qi] = d[4] < 1.0e30f ? d[4] * (1.0f + 1e-5f) + 1e-12f : FLT_MAX;
+    }
     if (tid == 0) {
       a.need_cnt[lb] = (uint16_t)total;
       if (a.cert_stats) {  // debug tap: points left to pass 2 / points swept

@@ -1167,6 +1167,9 @@ def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, 
     fm.setup_filter_size(0.2, 0.4, 0.6)
     fm.update(gt[3:].astype(np.float32))
     fm.add_feature_cloud(sur_c, sur_s, np.eye(4, dtype=np.float32))
+    # as LaserMapping sets its context up (the-cooper-mapper_amd/pipeline.py, include/lslam_pipeline.hpp): the per-frame
+    # surround map gets its cell grids at once and its kd-trees only if a frame needs them (lslam_map_defer_trees)
+    ctx.defer_trees(not cubes)
     R, t = synth.pose_to_Rt(gt)
     T = np.eye(4, dtype=np.float32)
     T[:3, :3], T[:3, 3] = R, t
@@ -1253,6 +1256,8 @@ def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, 
                                          "surround_to_map; then scan_match, add_feature_cloud -- the reference's nodelet split "
                                          "(MultiScanRegistration | LaserMapping)",
                              "pose_err_vs_ground_truth_m": float(np.abs(pose2[3:] - gt[3:].astype(np.float32)).max())}
+    res["deferred_trees"] = dict(zip(("maps_set_without_trees", "trees_built_after_all", "pending_now"), ctx.lazy_trees()))
+    ctx.defer_trees(False)
     if cubes:
         res["cube_trees_built_reused_per_frame"] = [[int(b), int(r)] for b, r in trees]
         res["variant"] = "C: per-cube trees kept between frames (FeatureMap::scanMatchScan)"

@@ -166,6 +166,17 @@ int lslam_map_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const voi
                   size_t n_surf, size_t stride_bytes);
 int lslam_map_info_get(const lslam_ctx *ctx, lslam_map_info *info);
 
+/* Deferred kd-trees.  on != 0: a map handed over from now on while it is already in HBM (lslam_fmap_surround_to_map: the
+ * mapping node's per-frame map, LaserMatcher.cpp:303-331, where the reference rebuilds both trees every frame -- quirk Q4) gets
+ * its cell grids at once (bounding box, key sort, cell table: about a third of a tree build) and its kd-trees only when
+ * something needs them.  A scan match of one small scan against such a map runs on the grids alone -- the 27-cell probe with
+ * its proof, and for the points it cannot prove one wavefront each over every cell within their bound -- and gives nanoflann's
+ * neighbours exactly as the tree search does; the one case the grids cannot decide, an exact distance tie among a point's six
+ * nearest, makes the call build the trees and run again through them.  Every other entry point that touches the trees (the
+ * taps, LSLAM_SEARCH_LANE / _PACKET, batches, the sharded loop, lslam_icp_align, ...) builds them first.  Results do not
+ * depend on the setting.  lslam_map_info reports depth 0 / 0 nodes while the trees are pending. */
+int lslam_map_defer_trees(lslam_ctx *ctx, int32_t on);
+
 /* Variant C -- the map as FeatureMap keeps it (util/FeatureMap.h): a grid of dims[0] x dims[1]
  * x dims[2] cubes of cube_size metres (50), cube of a point = round(p/cube_size) + origin
  * (worldToCube, :475-487); every cube gets its own kd-tree (as _kdtreeCorner/_kdtreeSurf,
@@ -591,6 +602,8 @@ void *lslam_stream(lslam_ctx *ctx); /* hipStream_t */
 void lslam_debug_sweep_launches(lslam_ctx *ctx, uint64_t counts[8]);
 /* ... and of the grid sweep (sweep_grid_kernel; LSLAM_SEARCH_GRID) */
 uint64_t lslam_debug_grid_launches(lslam_ctx *ctx);
+/* out[0] maps set with deferred trees, out[1] of those whose trees were built after all, out[2] 1 while the resident map's are pending */
+void lslam_debug_lazy_trees(lslam_ctx *ctx, uint64_t out[3]);
 /* Debug tap of the certificate sweep (csrc/lslam_kernels.hip sweep_body): out[2] = second-pass launches of this
  * context since its creation; out[0] = points the certificate-testing workgroups left to the second pass and out[1] = points
  * of those workgroups, counted only when the process runs with LSLAM_DEBUG_CERT_STATS=1 (two atomics per workgroup). */

@@ -147,6 +147,9 @@ public:
       _err = lslam_last_error();
     } else {
       lslam_fmap_setup_filter_size(_fm, mapFilterCorner, mapFilterSurf, mapFilter);
+      // the per-frame surround map is searched through its cell grids; its kd-trees are built only if a frame needs them
+      // (lslam_map_defer_trees) -- same poses either way
+      lslam_map_defer_trees(ctx, 1);
     }
   }
   ~LaserMapping() { lslam_fmap_destroy(_fm); }

@@ -191,3 +191,91 @@ def test_grid_run_does_not_read_what_an_earlier_call_left(ctx, small_problem):
         ctx.run(pose0, other)
         _, pose, st = ctx.run(pr["init_pose"], g)
         assert np.array_equal(bits(pose), bits(ref)) and (st.iterations, st.n_rows) == (st_ref.iterations, st_ref.n_rows)
+
+
+def _mapping_frames(pkg, ctx, synth, world, defer, n=4, lattice=False):
+    """A few LaserMapping frames (the device chain of tests/test_gpu_pipeline.py, mapping half only) -> poses, stats."""
+    mapper = pkg.LaserMapping(ctx, cube_dims=(21, 21, 11), defer_trees=defer)
+    out = []
+    for k in range(n):
+        gt = (0.0, 0.0, 0.3 + 0.01 * k, 3.0 + 0.4 * k, -2.0 + 0.15 * k, synth.SENSOR_HEIGHT)
+        c, s, gtp = synth.make_scan(world, 16, 900, gt_pose=gt, seed=300 + k)
+        if lattice:  # centimetre coordinates: exact distance ties between map points
+            c, s = np.round(c, 2).astype(np.float32), np.round(s, 2).astype(np.float32)
+        odom = ctx.pose_to_isometry(synth.perturb_pose(gtp, seed=900 + k, dt=0.1, dr_deg=0.5))
+        M = mapper.process(c, s, odom)
+        st = mapper.last_stats
+        out.append((M.copy(), None if st is None else (st.iterations, st.n_rows, st.n_line, st.n_plane)))
+    mapper.feature_map.close()
+    return out
+
+
+def test_deferred_trees_mapping_frames_equal_eager(pkg, synth, small_problem):
+    """The mapping node's frames with the per-frame kd-tree build deferred (lslam_map_defer_trees: grids at map-set time, the
+    27-cell probe + the wide probe for what it cannot prove, no tree at all) against the same frames with the trees built
+    every frame: the same neighbours, so the same iteration and row counts and poses to the rounding of differently grouped
+    sums.  The deferred runs really ran without trees."""
+    world = small_problem["world"]
+    res = {}
+    for defer in (False, True):
+        c = pkg.Context(0)
+        try:
+            res[defer] = _mapping_frames(pkg, c, synth, world, defer)
+            sets, builds, pending = c.lazy_trees()
+            if defer:
+                assert sets >= 3 and builds == 0 and pending, (sets, builds, pending)  # (the first frame's map is empty: nothing to match)
+                assert c.grid_launches() > 0
+                # ... and a tap on that map builds them on the spot
+                q = np.zeros((4, 3), np.float32)
+                c.knn5(1, q)
+                assert c.lazy_trees() == (sets, 1, False)
+            else:
+                assert (sets, builds) == (0, 0)
+        finally:
+            c.close()
+    for (Ma, sa), (Mb, sb) in zip(res[False], res[True]):
+        assert sa == sb
+        assert np.abs(Ma - Mb).max() <= 2e-6
+
+
+def test_deferred_trees_fall_back_to_the_trees_on_exact_ties(pkg, synth):
+    """A lattice map (one point per voxel, so the voxel filter keeps the lattice) and scan points that sit at equal distances
+    from several of its points: which five nanoflann returns then depends on its visit order -- the one thing the grids
+    cannot reproduce.  The deferred call notices (the wide probe raises the scan's flag), builds the trees and runs again
+    through them: the eager run's bits."""
+    g = np.arange(-20.0, 20.0, 0.5, dtype=np.float32)
+    gx, gy = np.meshgrid(g, g)
+    ground = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size, np.float32), np.zeros(gx.size, np.float32)], 1)
+    h = np.arange(0.5, 6.0, 0.5, dtype=np.float32)
+    wx, wz = np.meshgrid(g, h)
+    wall = np.stack([wx.ravel(), np.full(wx.size, 8.0, np.float32), wz.ravel(), np.zeros(wx.size, np.float32)], 1)
+    surf_map = np.concatenate([ground, wall]).astype(np.float32)
+    poles = np.concatenate([np.stack([np.full(len(h), x, np.float32), np.full(len(h), y, np.float32), h, np.zeros(len(h), np.float32)], 1)
+                            for x in (-6.0, -2.0, 2.0, 6.0) for y in (-5.0, 0.0, 5.0)])
+    rng = np.random.default_rng(5)
+    # scan (sensor frame = map frame at the true pose): surf points above cell centres of the lattice (four equidistant
+    # neighbours), corner points beside the poles
+    qs = np.stack([gx.ravel()[::3] + 0.25, gy.ravel()[::3] + 0.25, np.full(gx.size, 0.0, np.float32)[::3], np.zeros(gx.size, np.float32)[::3]], 1).astype(np.float32)
+    qc = (poles + np.array([0.0, 0.05, 0.25, 0.0], np.float32)).astype(np.float32)
+    init = np.zeros(6, np.float32)  # the first sweep sees the scan exactly where the ties are
+    res = {}
+    for defer in (False, True):
+        c = pkg.Context(0)
+        try:
+            c.defer_trees(defer)
+            fm = pkg.FeatureMap(c, 21, 21, 11)
+            fm.setup_filter_size(0.05, 0.05, 0.05)
+            fm.update(np.zeros(3, np.float32))
+            fm.add_feature_cloud(poles, surf_map, np.eye(4, dtype=np.float32))
+            fm.surround_to_map()
+            status, pose, st = c.scanmatch_scan(qc, qs, init)
+            res[defer] = (int(status), pose.copy(), st.iterations, st.n_rows, st.n_line, st.n_plane)
+            if defer:
+                sets, builds, pending = c.lazy_trees()
+                assert sets == 1 and builds == 1 and not pending, (sets, builds, pending)  # the trees were needed, and built once
+            fm.close()
+        finally:
+            c.close()
+    assert res[False][0] == res[True][0] and res[False][2:] == res[True][2:]
+    assert np.array_equal(bits(res[False][1]), bits(res[True][1]))
+    assert res[True][3] > 100

@@ -229,6 +229,15 @@ struct lslam_ctx {
   uint64_t grid_epoch = ~0ull; // the map the grids were built from
   float grid_cell = 0.0f;      // ... and their cell size
   int grid_status = 0;         // why they could not be built (GridDev::build), 0: fine
+  // deferred kd-trees (lslam_map_defer_trees): a map handed over on the device gets its cell grids at once and its trees on
+  // first need -- a tap, the lane search, a query whose neighbours need nanoflann's visit order (an exact distance tie)
+  bool defer_trees = false;    // the caller's wish
+  bool trees_pending = false;  // the resident map has grids but no trees yet
+  DevBuf<uint32_t> bbox6;      // bounding-box reduction scratch
+  DevBuf<int32_t> wide_p;      // [points][5] / [points][5]: neighbours the wide probe found for the points the 27-cell probe
+  DevBuf<float> wide_d;        //   could not prove (grid sweep without trees)
+  DevBuf<int32_t> wide_off;    // [blocks + 1] exclusive prefix of need_cnt, [blocks + 1 .. +2) {total, need-tree flag}
+  uint64_t lazy_sets = 0, lazy_builds = 0;  // maps set with deferred trees / trees then built after all (lslam_debug_lazy_trees)
   // environment overrides of lslam_opts fields, read ONCE when the context is made (never inside a call)
   int env_knn_cert = -1;       // LSLAM_KNN_CERT (-1: not set)
   float env_cert_try_m = -1.0f, env_cert_track_m = -1.0f, env_grid_cell = -1.0f;  // LSLAM_CERT_TRY_M, LSLAM_CERT_TRACK_M, LSLAM_GRID_CELL
@@ -308,6 +317,9 @@ void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
   a.grid = 0;
   a.grid_clip_margin = GRID_CLIP_MARGIN_MIN;
   a.grid_hint = nullptr;
+  a.wide_d = nullptr;
+  a.wide_p = nullptr;
+  a.wide_off = nullptr;
   a.q = ctx->q.p;
   a.blocks = ctx->blocks.p;
   a.nb_total = ctx->nb_total;
@@ -411,6 +423,10 @@ hipError_t sweep_launch(lslam_ctx *ctx, const SweepArgs &a, int jtj_mode, hipEve
     ctx->sweep_variants[v]++;
     if (variant) *variant = v;
     if (e != hipSuccess) return e;
+    if (a.grid == 2) {  // no trees: the listed points' neighbours come from the wide probe, the queue only runs their residual chain
+      e = launch_sweep_wide(a, ctx->stream);
+      if (e != hipSuccess) return e;
+    }
     const int pass2 = a.stack_ovf ? (a.deep_tree ? SWEEP_VARIANT_DEEP_OVF : SWEEP_VARIANT_SHALLOW) : SWEEP_VARIANT_DEEP;
     e = launch_sweep_queue(a, jtj_mode, ctx->stream, e1, pass2, plan);
     ctx->queue_launches++;
@@ -458,12 +474,17 @@ int ensure_stack_ovf(lslam_ctx *ctx, size_t n_threads, uint32_t **out) {
   return LSLAM_OK;
 }
 
-int check_ctx(lslam_ctx *ctx) {
+int ensure_trees(lslam_ctx *ctx);
+
+// Every entry point starts here.  An entry point that can work on a map whose kd-trees are still deferred says so; every
+// other one gets them built first.
+int check_ctx(lslam_ctx *ctx, bool trees_may_be_pending = false) {
   if (!ctx) {
     set_err("null ctx");
     return LSLAM_ERR_INVALID;
   }
   HIP_TRY(hipSetDevice(ctx->device));
+  if (ctx->trees_pending && !trees_may_be_pending) return ensure_trees(ctx);
   return LSLAM_OK;
 }
 
@@ -570,6 +591,7 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   ctx->cert_count.release();
   ctx->kc.release();
   ctx->ks.release();
+  ctx->bbox6.release(); ctx->wide_p.release(); ctx->wide_d.release(); ctx->wide_off.release();
   ctx->xchg.release();
   ctx->gnp_slots.release(); ctx->gnp_bar.release();
   ctx->q.release(); ctx->blocks.release(); ctx->probs.release(); ctx->partials.release(); ctx->stack_ovf.release();
@@ -608,6 +630,19 @@ int lslam_debug_cert_state(lslam_ctx *ctx, float *q_xyz0, float *lb, size_t cap_
   if (n && q_xyz0 && hipMemcpy(q_xyz0, ctx->prev_q.p, n * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) return LSLAM_ERR_HIP;
   if (n && lb && hipMemcpy(lb, ctx->prev_lb.p, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return LSLAM_ERR_HIP;
   return (int)n;
+}
+
+int lslam_map_defer_trees(lslam_ctx *ctx, int32_t on) {
+  int rc = check_ctx(ctx, true);
+  if (rc) return rc;
+  ctx->defer_trees = on != 0;
+  return LSLAM_OK;
+}
+
+void lslam_debug_lazy_trees(lslam_ctx *ctx, uint64_t out[3]) {
+  out[0] = ctx ? ctx->lazy_sets : 0;
+  out[1] = ctx ? ctx->lazy_builds : 0;
+  out[2] = ctx ? (ctx->trees_pending ? 1 : 0) : 0;
 }
 
 uint64_t lslam_debug_grid_launches(lslam_ctx *ctx) { return ctx ? ctx->sweep_variants[SWEEP_VARIANT_GRID] : 0; }
@@ -708,8 +743,9 @@ int tree_build_failed(int limit, size_t n_points) {
 
 int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void *surf, size_t n_surf,
                  size_t stride_bytes, const float4 *dev_corner, const float4 *dev_surf) {
-  int rc = check_ctx(ctx);
+  int rc = check_ctx(ctx, true);  // (a map whose trees were never needed is simply replaced)
   if (rc) return rc;
+  ctx->trees_pending = false;
   const bool from_dev = dev_corner != nullptr || dev_surf != nullptr;
   if (!from_dev && (stride_bytes < 12 || (stride_bytes & 3) || (n_corner && !corner) || (n_surf && !surf))) {
     set_err("bad cloud arguments (stride %zu)", stride_bytes);
@@ -727,6 +763,53 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
   double t1 = t0, t2 = t0;
   size_t nodes_c = 0, nodes_s = 0;
   int attempts_used = 1;
+  // ---- deferred trees (lslam_map_defer_trees): a map that is already in HBM gets its cell grids now -- bounding box, key
+  // sort, cell table: a third of a tree build -- and its kd-trees when something needs them (ensure_trees).  Only for maps the
+  // grid can take and the scan-match guard accepts; anything else is built eagerly below.
+  if (ctx->defer_trees && from_dev && n_corner >= 50 && n_surf >= 100) {
+    const float cell = ctx->env_grid_cell > 0.0f ? ctx->env_grid_cell : (ctx->grid_cell > 0.0f ? ctx->grid_cell : GRID_CELL_DEFAULT);
+    HIP_TRY(ctx->bbox6.reserve(12));
+    GridDev *gd[2] = {&ctx->kc, &ctx->ks};
+    DevTree *trees[2] = {&ctx->tc, &ctx->ts};
+    const float4 *dev_src[2] = {dev_corner, dev_surf};
+    const int counts[2] = {(int)n_corner, (int)n_surf};
+    float lo[2][3], hi[2][3];
+    HIP_TRY(grid_bbox2(dev_src, counts, ctx->bbox6.p, lo, hi, ctx->stream));  // the one host round trip of the map set
+    int st = 0;
+    for (int k = 0; k < 2 && !st; ++k) {
+      HIP_TRY(gd[k]->build(dev_src[k], counts[k], lo[k], hi[k], cell, ctx->stream, &st, false));
+      if (!st && !gd[k]->view.cell_start) st = 3;
+      TreeView v{};
+      v.n_pts = (int32_t)counts[k];
+      for (int a = 0; a < 3; ++a) {
+        v.bb_lo[a] = lo[k][a];
+        v.bb_hi[a] = hi[k][a];
+      }
+      trees[k]->view = v;  // no nodes, no points: whoever needs them goes through ensure_trees
+      trees[k]->depth = 0;
+    }
+    if (!st) {
+      ctx->info.n_corner = n_corner;
+      ctx->info.n_surf = n_surf;
+      ctx->info.nodes_corner = ctx->info.nodes_surf = 0;
+      ctx->info.depth_corner = ctx->info.depth_surf = 0;
+      ctx->info.build_ms = (float)(now_ms() - t0);
+      ctx->info.upload_ms = 0.0f;
+      ctx->info.built_on_device = 1;
+      ctx->info.build_attempts = 0;  // no tree build attempted yet
+      ctx->have_map = true;
+      ctx->map_epoch++;
+      ctx->grid_epoch = ctx->map_epoch;
+      ctx->grid_cell = cell;
+      ctx->grid_status = 0;
+      ctx->trees_pending = true;
+      ctx->lazy_sets++;
+      return LSLAM_OK;
+    }
+    ctx->kc.view = CellGrid{};
+    ctx->ks.view = CellGrid{};
+    ctx->grid_epoch = ~0ull;
+  }
   {
     // ---- device build: upload {x,y,z,index}, build both trees in HBM --------------------
     t1 = now_ms();
@@ -829,6 +912,62 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
   ctx->info.build_attempts = attempts_used;
   ctx->have_map = true;
   ctx->map_epoch++;
+  return LSLAM_OK;
+}
+}  // namespace
+
+namespace {
+// The kd-trees of a map that was set with deferred trees, now: the points come back out of the cell grids in their original
+// order, the builder runs as it would have at map-set time.  The grids stay what they are (same points, same indices).
+int ensure_trees(lslam_ctx *ctx) {
+  if (!ctx->trees_pending) return LSLAM_OK;
+  ctx->trees_pending = false;  // (a failure below leaves a map without trees: have_map goes false)
+  const double t0 = now_ms();
+  DevTree *trees[2] = {&ctx->tc, &ctx->ts};
+  GridDev *gd[2] = {&ctx->kc, &ctx->ks};
+  size_t nodes[2] = {0, 0};
+  int attempts_used = 1;
+  for (int k = 0; k < 2; ++k) {
+    DevTree &dt = *trees[k];
+    const size_t n = (size_t)gd[k]->view.n_pts;
+    HIP_TRY(dt.pts.reserve(n ? n : 1));
+    int fallback = 0;
+    size_t n_leaves = 0;
+    for (int attempt = dt.cap_attempt; attempt < 3; ++attempt) {
+      const size_t mult[3] = {8, 16, 24};
+      const size_t cap = ((mult[attempt] * n / 3 + 64) + 7) & ~(size_t)7;
+      HIP_TRY(dt.nodes.reserve(cap));
+      HIP_TRY(dt.own_box.reserve(cap * 6));
+      HIP_TRY(grid_unsort(gd[k]->view, dt.pts.p, ctx->stream));
+      HIP_TRY(build_kdtree_device(dt.pts.p, (int32_t)n, dt.nodes.p, dt.own_box.p, (int32_t)cap, ctx->stream, &dt.view, &dt.depth,
+                                  &n_leaves, &fallback));
+      if (fallback != 1) {
+        if (!fallback) dt.cap_attempt = attempt;
+        break;
+      }
+    }
+    attempts_used = std::max(attempts_used, dt.cap_attempt + 1);
+    if (fallback) {
+      ctx->have_map = false;
+      ctx->map_epoch++;
+      return tree_build_failed(fallback, n);
+    }
+    nodes[k] = (size_t)dt.view.n_nodes / 8 * 7 + n_leaves;
+    dt.view.pn = nullptr;
+  }
+  if (ctx->tc.depth > KD_STACK_MAX || ctx->ts.depth > KD_STACK_MAX) {
+    ctx->have_map = false;
+    ctx->map_epoch++;
+    set_err("kd-tree depth %d/%d exceeds device stack %d", ctx->tc.depth, ctx->ts.depth, KD_STACK_MAX);
+    return LSLAM_ERR_TREE_DEPTH;
+  }
+  ctx->info.nodes_corner = (uint32_t)nodes[0];
+  ctx->info.nodes_surf = (uint32_t)nodes[1];
+  ctx->info.depth_corner = ctx->tc.depth;
+  ctx->info.depth_surf = ctx->ts.depth;
+  ctx->info.build_ms += (float)(now_ms() - t0);
+  ctx->info.build_attempts = attempts_used;
+  ctx->lazy_builds++;
   return LSLAM_OK;
 }
 }  // namespace
@@ -1105,7 +1244,7 @@ int lslam_map_info_get(const lslam_ctx *ctx, lslam_map_info *info) {
 int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *corner,
                          const size_t *n_corner, const void *const *surf, const size_t *n_surf,
                          size_t stride_bytes) {
-  int rc = check_ctx(ctx);
+  int rc = check_ctx(ctx, true);
   if (rc) return rc;
   if (n_scans <= 0 || !corner || !n_corner || !surf || !n_surf || stride_bytes < 12 ||
       (stride_bytes & 3)) {
@@ -1266,8 +1405,22 @@ namespace {
 // every rank runs the same solve on the same numbers.
 int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_opts *opts_in,
                    lslam_stats *stats, lslam_allreduce_fn fn, void *user, double *xchg, bool use_comm = false) {
-  int rc = check_ctx(ctx);
+  int rc = check_ctx(ctx, true);
   if (rc) return rc;
+  // A map whose kd-trees are deferred (lslam_map_defer_trees) is matched through its cell grids alone when the call is a
+  // latency-bound one on the plain loop -- a mapping frame: one scan of a few thousand points; anything else builds the trees now.
+  bool lazy = false;
+  if (ctx->trees_pending) {
+    const lslam_opts *oi = opts_in;
+    const int sm = ctx->env_search >= 0 ? ctx->env_search : (oi ? (oi->search_mode & 0xFF) : LSLAM_SEARCH_AUTO);
+    lazy = ctx->have_map && ctx->have_scan && !ctx->cube_mode && !fn && !use_comm && n_scans == ctx->n_prob &&
+           (sm == LSLAM_SEARCH_AUTO || sm == LSLAM_SEARCH_GRID) && !(oi && oi->fine_score && oi->use_score) &&
+           (long)ctx->nb_total * (SWEEP_BLOCK / 64) <= 2 * 1024 && ctx->kc.view.cell_start && ctx->ks.view.cell_start;
+    if (!lazy) {
+      rc = ensure_trees(ctx);
+      if (rc) return rc;
+    }
+  }
   if (!poses || n_scans <= 0) {
     set_err("null poses");
     return LSLAM_ERR_INVALID;
@@ -1437,7 +1590,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
   {
     const bool gnp_off = !((o.ab_switches | ctx->env_ab) & LSLAM_AB_PERSISTENT_GN);
     static const bool unbounded = std::getenv("LSLAM_UNBOUNDED_KNN") != nullptr;
-    if (!sharded && n_scans == 1 && !gnp_off && ctx->gnp_ok && !o.profile && ctx->n_stereo == 0 && !ctx->cube_mode &&
+    if (!sharded && !lazy && n_scans == 1 && !gnp_off && ctx->gnp_ok && !o.profile && ctx->n_stereo == 0 && !ctx->cube_mode &&
         !sa.packet && sa.stack_mode != SWEEP_STACK_SHALLOW && max_it > 0 && ctx->tc.depth <= KD_STACK_LDS + 1 && ctx->ts.depth <= KD_STACK_LDS + 1 &&
         sa.nb_total > 0 && sa.nb_total <= 512) {
       if (ctx->gnp_cap < 0) ctx->gnp_cap = gn_persistent_capacity(ctx->device);
@@ -1496,7 +1649,23 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
       const long nb0 = (long)ctx->h_probs[(size_t)p1 - 1].first_block + ctx->h_probs[(size_t)p1 - 1].n_blocks;
       want_grid = nb0 * (SWEEP_BLOCK / 64) > 2 * 1024;
     }
-    if (want_grid && sa.bounded) {
+    if (lazy && !sa.bounded) {  // (LSLAM_UNBOUNDED_KNN: an A/B switch of the tree search)
+      rc = ensure_trees(ctx);
+      if (rc) return rc;
+      lazy = false;
+    }
+    if (lazy) {  // the grids the map was set with; no trees: the listed points go through the wide probe
+      sa.kc = ctx->kc.view;
+      sa.ks = ctx->ks.view;
+      sa.grid = 2;
+      sa.grid_clip_margin = GRID_CLIP_MARGIN_MIN;
+      HIP_TRY(ctx->wide_d.reserve(std::max<size_t>(ctx->n_points, 1) * 5));
+      HIP_TRY(ctx->wide_p.reserve(std::max<size_t>(ctx->n_points, 1) * 5));
+      HIP_TRY(ctx->wide_off.reserve((size_t)std::max(ctx->nb_total, 1) + 2));
+      sa.wide_d = ctx->wide_d.p;
+      sa.wide_p = ctx->wide_p.p;
+      sa.wide_off = ctx->wide_off.p;
+    } else if (want_grid && sa.bounded) {
       rc = ensure_grid(ctx, ctx->env_grid_cell > 0.0f ? ctx->env_grid_cell : o.grid_cell);
       if (rc) return rc;
       if (ctx->kc.view.cell_start && ctx->ks.view.cell_start) {
@@ -1708,6 +1877,15 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
     }
   }
   ctx->stage_busy = false;  // the stream has been waited for since the scan was set
+  if (lazy) {  // a point's answer needed nanoflann's visit order (sweep_wide_kernel): the trees after all, and the call again
+    bool need_tree = false;
+    for (int32_t p = 0; p < n_scans; ++p) need_tree = need_tree || ctx->h_state[p].pad != 0;
+    if (need_tree) {
+      rc = ensure_trees(ctx);
+      if (rc) return rc;
+      return run_batch_impl(ctx, n_scans, poses, opts_in, stats, fn, user, xchg, use_comm);
+    }
+  }
   int max_sweeps = 0, max_iter = 0;
   for (int32_t p = 0; p < n_scans; ++p) {
     max_sweeps = std::max(max_sweeps, ctx->h_state[p].sweeps);

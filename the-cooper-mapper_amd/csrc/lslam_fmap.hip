@@ -367,6 +367,10 @@ struct lslam_fmap {
   Buf<float> d_T;
   Buf<int32_t> d_remap;
   Buf<int32_t> g_src, g_dst;
+  // surround gather of the two feature types behind ONE wait: per-type tables, their host copies kept alive here until the
+  // next gather (a pageable hipMemcpyAsync source must outlive the copy)
+  Buf<int32_t> g_src_t[2], g_dst_t[2];
+  std::vector<int32_t> h_gsrc[2], h_gdst[2];
   Buf<float4> sur[2];
   Scratch sc;
   // ---- per-cube kd-trees kept between frames (lslam_fmap_to_cubemap; FeatureMap.h:438,453 _kdtreeCorner/_kdtreeSurf) ----
@@ -607,10 +611,13 @@ int check_fm(lslam_fmap *fm) {
 
 // surround arrays of type t into fm->sur[t]; returns count
 int gather_surround(lslam_fmap *fm, int t, int index_in_w, size_t *n_out, int min_points = 1,
-                    std::vector<int32_t> *roots_lr = nullptr, std::vector<int32_t> *cell_tree = nullptr) {
+                    std::vector<int32_t> *roots_lr = nullptr, std::vector<int32_t> *cell_tree = nullptr, bool no_wait = false) {
   int rc = refresh_segments(fm, t);
   if (rc) return rc;
-  std::vector<int32_t> src, dst;
+  std::vector<int32_t> src_local, dst_local;
+  std::vector<int32_t> &src = no_wait ? fm->h_gsrc[t] : src_local, &dst = no_wait ? fm->h_gdst[t] : dst_local;
+  src.clear();
+  dst.clear();
   size_t total = 0;
   if (cell_tree) cell_tree->assign((size_t)fm->ncube, -1);
   for (int32_t c : fm->valid) {
@@ -629,14 +636,15 @@ int gather_surround(lslam_fmap *fm, int t, int index_in_w, size_t *n_out, int mi
   *n_out = total;
   if (!total) return LSLAM_OK;
   hipStream_t s = fm->stream;
-  FM_TRY(fm->g_src.reserve(src.size()));
-  FM_TRY(fm->g_dst.reserve(dst.size()));
+  Buf<int32_t> &gs = no_wait ? fm->g_src_t[t] : fm->g_src, &gd = no_wait ? fm->g_dst_t[t] : fm->g_dst;
+  FM_TRY(gs.reserve(src.size()));
+  FM_TRY(gd.reserve(dst.size()));
   FM_TRY(fm->sur[t].reserve(total));
-  FM_TRY(hipMemcpyAsync(fm->g_src.p, src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-  FM_TRY(hipMemcpyAsync(fm->g_dst.p, dst.data(), dst.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(fm_gather_kernel, dim3(((int)total + 255) / 256), dim3(256), 0, s, fm->pts[t].p, fm->g_src.p,
-                     fm->g_dst.p, (int)src.size(), (int)total, index_in_w, fm->sur[t].p);
-  FM_TRY(hipStreamSynchronize(s));  // src/dst are locals
+  FM_TRY(hipMemcpyAsync(gs.p, src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  FM_TRY(hipMemcpyAsync(gd.p, dst.data(), dst.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(fm_gather_kernel, dim3(((int)total + 255) / 256), dim3(256), 0, s, fm->pts[t].p, gs.p,
+                     gd.p, (int)src.size(), (int)total, index_in_w, fm->sur[t].p);
+  if (!no_wait) FM_TRY(hipStreamSynchronize(s));  // src/dst are locals
   return LSLAM_OK;
 }
 
@@ -717,6 +725,7 @@ void lslam_fmap_destroy(lslam_fmap *fm) {
   if (lslam::ctx_alive(fm->ctx)) lslam::cubemap_drop_views(fm->ctx);  // the context may still point at this map's trees
   fm->active.release(); fm->in_raw.release(); fm->in_tf.release(); fm->in_cube.release(); fm->d_T.release();
   fm->d_remap.release(); fm->g_src.release(); fm->g_dst.release();
+  for (int t = 0; t < 2; ++t) { fm->g_src_t[t].release(); fm->g_dst_t[t].release(); }
   fm->sc.release();
   delete fm;
 }
@@ -867,8 +876,14 @@ int lslam_fmap_surround_to_map(lslam_fmap *fm) {
   int rc = check_fm(fm);
   if (rc) return rc;
   size_t n[2] = {0, 0};
+  // both types' segment tables behind one wait; the gathers are not waited for at all (the map set is stream-ordered behind them)
   for (int t = 0; t < 2; ++t) {
-    rc = gather_surround(fm, t, 1, &n[t]);
+    rc = refresh_segments(fm, t, false);
+    if (rc) return rc;
+  }
+  FM_TRY(hipStreamSynchronize(fm->stream));
+  for (int t = 0; t < 2; ++t) {
+    rc = gather_surround(fm, t, 1, &n[t], 1, nullptr, nullptr, true);
     if (rc) return rc;
   }
   if (n[0] == 0 && n[1] == 0) return lslam_map_set(fm->ctx, nullptr, 0, nullptr, 0, 16);

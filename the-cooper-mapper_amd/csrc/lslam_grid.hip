@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 namespace lslam {
 
@@ -43,29 +44,104 @@ __global__ __launch_bounds__(256) void grid_place_kernel(int n, const float4 *tr
   gpts[j] = tree_pts[t];  // .w carries the original index already
 }
 
+__device__ __forceinline__ uint32_t ordered_u32(float f) {  // monotone map float -> uint32 (for atomicMin / atomicMax)
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__global__ __launch_bounds__(256) void grid_bbox_kernel(const float4 *pts, int n, uint32_t *box /* [6]: min xyz, max xyz (ordered) */) {
+  __shared__ uint32_t sm[6];
+  if (threadIdx.x < 3) sm[threadIdx.x] = 0xFFFFFFFFu;
+  else if (threadIdx.x < 6) sm[threadIdx.x] = 0u;
+  __syncthreads();
+  uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float4 p = pts[i];
+    const uint32_t v[3] = {ordered_u32(p.x), ordered_u32(p.y), ordered_u32(p.z)};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = min(lo[a], v[a]);
+      hi[a] = max(hi[a], v[a]);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    atomicMin(&sm[a], lo[a]);
+    atomicMax(&sm[3 + a], hi[a]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) atomicMin(&box[threadIdx.x], sm[threadIdx.x]);
+  else if (threadIdx.x < 6) atomicMax(&box[threadIdx.x], sm[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void grid_unsort_kernel(int n, const float4 *gpts, float4 *out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const float4 p = gpts[j];
+  out[__float_as_int(p.w)] = p;
+}
+
 }  // namespace
+
+// The cell-sorted points back in their original order ({x, y, z, bitcast(index)}): what a kd-tree build deferred at map-set
+// time starts from.
+hipError_t grid_unsort(const CellGrid &G, float4 *out, hipStream_t s) {
+  if (G.n_pts <= 0) return hipSuccess;
+  hipLaunchKernelGGL(grid_unsort_kernel, dim3((G.n_pts + 255) / 256), dim3(256), 0, s, G.n_pts, G.pts, out);
+  return hipGetLastError();
+}
+
+// Bounding boxes of two device clouds (nanoflann's root_bbox: componentwise min / max), ONE host round trip for both.
+hipError_t grid_bbox2(const float4 *const pts[2], const int n[2], uint32_t *d_box12, float lo[2][3], float hi[2][3], hipStream_t s) {
+  uint32_t init[12];
+  for (int k = 0; k < 2; ++k)
+    for (int a = 0; a < 6; ++a) init[6 * k + a] = a < 3 ? 0xFFFFFFFFu : 0u;
+  hipError_t e = hipMemcpyAsync(d_box12, init, sizeof(init), hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return e;
+  for (int k = 0; k < 2; ++k)
+    if (n[k] > 0) hipLaunchKernelGGL(grid_bbox_kernel, dim3(std::min((n[k] + 255) / 256, 512)), dim3(256), 0, s, pts[k], n[k], d_box12 + 6 * k);
+  uint32_t h[12];
+  e = hipMemcpyAsync(h, d_box12, sizeof(h), hipMemcpyDeviceToHost, s);
+  if (e != hipSuccess) return e;
+  e = hipStreamSynchronize(s);  // (also covers `init`: a local)
+  if (e != hipSuccess) return e;
+  for (int k = 0; k < 2; ++k)
+    for (int a = 0; a < 6; ++a) {
+      const uint32_t u = (h[6 * k + a] & 0x80000000u) ? (h[6 * k + a] & 0x7FFFFFFFu) : ~h[6 * k + a];
+      float f;
+      std::memcpy(&f, &u, 4);
+      (a < 3 ? lo[k][a] : hi[k][a - 3]) = f;
+    }
+  return hipSuccess;
+}
 
 // Host side of a grid (one per map type): owns the device arrays.
 hipError_t GridDev::build(const TreeView &T, float cell, hipStream_t s, int *status) {
+  return build(T.pts, T.n_pts, T.bb_lo, T.bb_hi, cell, s, status, true);
+}
+
+// src: n points {x, y, z, bitcast(original index)} in any order; lo / hi: their bounding box
+// wait: read the "point outside the table" counter back (one host round trip).  A caller whose box was reduced from these very
+// points a moment ago has nothing to learn from it (a non-finite coordinate shows in the box) and passes false: stream-ordered, no wait.
+hipError_t GridDev::build(const float4 *src, int n_src, const float lo[3], const float hi[3], float cell, hipStream_t s, int *status, bool wait) {
   *status = 0;
   view = CellGrid{};
-  if (T.n_pts <= 0 || !(cell > 0.05f) || !(cell < 1.45f)) return hipSuccess;  // rg <= 1.5 c must stay inside the sqrt(5) m gate
+  if (n_src <= 0 || !(cell > 0.05f) || !(cell < 1.45f)) return hipSuccess;  // rg <= 1.5 c must stay inside the sqrt(5) m gate
   const int margin = grid_margin_cells(cell);
   CellGrid G{};
   G.c = cell;
   G.inv_c = 1.0f / cell;
-  G.n_pts = T.n_pts;
+  G.n_pts = n_src;
   int dims[3];
   for (int a = 0; a < 3; ++a) {
-    if (!std::isfinite(T.bb_lo[a]) || !std::isfinite(T.bb_hi[a])) { *status = 1; return hipSuccess; }
-    G.org[a] = T.bb_lo[a] - (float)margin * cell;
-    dims[a] = (int)std::floor((T.bb_hi[a] - G.org[a]) * G.inv_c) + 1 + margin;
+    if (!std::isfinite(lo[a]) || !std::isfinite(hi[a])) { *status = 1; return hipSuccess; }
+    G.org[a] = lo[a] - (float)margin * cell;
+    dims[a] = (int)std::floor((hi[a] - G.org[a]) * G.inv_c) + 1 + margin;
     if (dims[a] > GRID_MAX_DIM) { *status = 2; return hipSuccess; }  // the map is larger than the grid's rounding slack allows
   }
   G.nx = dims[0]; G.ny = dims[1]; G.nz = dims[2];
   const size_t ncell = (size_t)G.nx * G.ny * G.nz;
   if (ncell > ((size_t)1 << 30)) { *status = 2; return hipSuccess; }
-  const int n = T.n_pts;
+  const int n = n_src;
   hipError_t e;
 #define G_TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
   G_TRY(reserve(pts, cap_pts, (size_t)n + 16));
@@ -79,7 +155,7 @@ hipError_t GridDev::build(const TreeView &T, float cell, hipStream_t s, int *sta
   G_TRY(hipMemsetAsync(count, 0, (ncell + 1) * sizeof(uint32_t), s));
   G_TRY(hipMemsetAsync(err, 0, sizeof(int32_t), s));
   const dim3 blk(256), grd((n + 255) / 256);
-  hipLaunchKernelGGL(grid_key_kernel, grd, blk, 0, s, G, T.pts, key0, val0, count, err);
+  hipLaunchKernelGGL(grid_key_kernel, grd, blk, 0, s, G, src, key0, val0, count, err);
   unsigned end_bit = 1;
   while (((size_t)1 << end_bit) < ncell) ++end_bit;
   size_t tmp_sort = 0, tmp_scan = 0;
@@ -88,12 +164,14 @@ hipError_t GridDev::build(const TreeView &T, float cell, hipStream_t s, int *sta
   G_TRY(reserve(tmp, cap_tmp, std::max(tmp_sort, tmp_scan)));
   G_TRY(rocprim::radix_sort_pairs((void *)tmp, tmp_sort, key0, key1, val0, val1, (size_t)n, 0u, end_bit, s));
   G_TRY(rocprim::exclusive_scan((void *)tmp, tmp_scan, count, cell_start, 0u, ncell + 1, rocprim::plus<uint32_t>(), s));
-  hipLaunchKernelGGL(grid_place_kernel, grd, blk, 0, s, n, T.pts, val1, pts);
+  hipLaunchKernelGGL(grid_place_kernel, grd, blk, 0, s, n, src, val1, pts);
   // the candidate loop loads pts[cur] for lanes that have run out of candidates at index 0: nothing to pad; a leaf-style
   // over-read does not exist here
   int32_t h_err = 0;
-  G_TRY(hipMemcpyAsync(&h_err, err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  G_TRY(hipStreamSynchronize(s));
+  if (wait) {
+    G_TRY(hipMemcpyAsync(&h_err, err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    G_TRY(hipStreamSynchronize(s));
+  }
 #undef G_TRY
   if (h_err) { *status = 1; return hipSuccess; }
   G.cell_start = cell_start;

@@ -119,6 +119,14 @@ struct SweepArgs {
   CellGrid kc, ks;
   int32_t grid;
   float grid_clip_margin;  // [m] padding of the clip radius sqrt(bound) of a bounded grid search
+  // grid == 2: the map has no kd-trees (deferred, lslam_map_defer_trees).  The points pass 1 lists are resolved by
+  // sweep_wide_kernel -- one wavefront per point scans every cell within the point's bound -- which leaves their five
+  // neighbours in wide_d / wide_p (positions in kc.pts / ks.pts); sweep_queue_kernel then only runs their residual chain.  A
+  // point whose answer needs nanoflann's visit order (an exact distance tie) raises GNState::pad of its scan: the caller builds
+  // the trees and runs the call again through them.
+  float *wide_d;           // [points][5]
+  int32_t *wide_p;         // [points][5]
+  int32_t *wide_off;       // [nb_total + 1] exclusive prefix of the listed points per pass-1 workgroup (grid_prefix_kernel)
   float *grid_hint;        // [points] grid sweep, pass 1 -> pass 2: an upper bound of the fifth neighbour's squared distance of a
                            // point the probe could not prove (the fifth smallest distance it saw, FLT_MAX if it saw fewer than five)
   const float4 *q;  // scan points of all scans, sensor frame, Morton order within a scan
@@ -250,6 +258,7 @@ enum : int {
   SWEEP_N_VARIANTS = 9
 };
 hipError_t launch_sweep_grid(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t start, hipEvent_t stop);
+hipError_t launch_sweep_wide(const SweepArgs &a, hipStream_t s);  // grid_prefix_kernel + sweep_wide_kernel
 hipError_t launch_knn5_grid(const CellGrid &G, const TreeView &T, const float4 *q, int nq, int32_t *idx, float *d2,
                             uint32_t *stack_ovf, int32_t *n_unproven, hipStream_t s);
 
@@ -275,8 +284,12 @@ struct GridDev {
   }
   // status: 0 built (or nothing to build: view.cell_start stays null), 1 non-finite point, 2 map too large for the grid
   hipError_t build(const TreeView &T, float cell, hipStream_t s, int *status);
+  // ... from n points {x, y, z, bitcast(original index)} in any order and their bounding box (a map whose trees are deferred)
+  hipError_t build(const float4 *src, int n, const float lo[3], const float hi[3], float cell, hipStream_t s, int *status, bool wait = true);
   void release();
 };
+hipError_t grid_bbox2(const float4 *const pts[2], const int n[2], uint32_t *d_box12, float lo[2][3], float hi[2][3], hipStream_t s);
+hipError_t grid_unsort(const CellGrid &G, float4 *out, hipStream_t s);
 hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t stop, int variant, const CertPlan &plan);
 hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s,
                         hipEvent_t start = nullptr, hipEvent_t stop = nullptr, int *variant = nullptr, bool *cert_launched = nullptr);

@@ -468,6 +468,19 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
       }
     }
     if (CUBES && !searched) T.n_pts = 0;  // knn5_search returns at once, d[4] stays FLT_MAX
+    if (CERT == 2 && a.grid == 2) {  // the wide probe has been here: its five, no search (and no tree to search)
+      do_search = false;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        d[j] = a.wide_d[(size_t)qi * 5 + j];
+        p[j] = a.wide_p[(size_t)qi * 5 + j];
+      }
+      q = a.q[qi];
+      sel[0] = ((R[0] * q.x + R[1] * q.y) + R[2] * q.z) + t[0];
+      sel[1] = ((R[3] * q.x + R[4] * q.y) + R[5] * q.z) + t[1];
+      sel[2] = ((R[6] * q.x + R[7] * q.y) + R[8] * q.z) + t[2];
+      if (a.bounded) a.prev_q[qi] = make_float4(sel[0], sel[1], sel[2], (p[4] >= 0 && d[4] < 5.0f) ? d[4] : FLT_MAX);
+    }
     if (do_search) {
     KdStack<BLOCK, OVF, LDS_DEPTH> stk;
     stk.lds = (lds_u32 *)(stack_lds + tid);
@@ -544,7 +557,7 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
     (void)searched;
     if (a.dbg) dbg_t1 = __builtin_readcyclecounter();
 
-    point_residual(a, bd, is_surf, T.pts, q, sel, d, p, sc, row, rb, kept, matched, score);
+    point_residual(a, bd, is_surf, (CERT == 2 && a.grid == 2) ? (is_surf ? a.ks.pts : a.kc.pts) : T.pts, q, sel, d, p, sc, row, rb, kept, matched, score);
   }
 
   if (a.dbg) dbg_t2 = __builtin_readcyclecounter();
@@ -1337,6 +1350,182 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LSLAM_GRI
 hipError_t launch_sweep_grid(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
   if (a.nb_total <= 0) return hipSuccess;
   hipExtLaunchKernelGGL((sweep_grid_kernel<SWEEP_BLOCK>), dim3(a.nb_total), dim3(SWEEP_BLOCK), 0, s, start, stop, 0, a, jtj_mode);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// The grid sweep on a map WITHOUT kd-trees (deferred: lslam_map_defer_trees; the mapping node's per-frame map).  The points
+// pass 1 could not prove -- a few per cent of a few thousand -- are resolved by the grid alone:
+//   grid_prefix_kernel   exclusive prefix of the per-workgroup list lengths (one block), so that
+//   sweep_wide_kernel    can give every listed point ONE WAVEFRONT: the 64 lanes share the rows of every cell within the
+//                        point's bound (the fifth distance pass 1 saw, else the acceptance gate), each lane keeps the six
+//                        smallest keys of its rows, six rounds of wave-minimum pick the six smallest of all, their exact
+//                        distances are sorted, and the proof is the 27-cell probe's with the bound's ball as the covered
+//                        region.  The five go to wide_d / wide_p; sweep_queue_kernel runs the residual chain on them.
+// An exact distance tie among the six -- the one thing only nanoflann's traversal can order -- raises GNState::pad: the host
+// builds the trees and repeats the call through them.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void grid_prefix_kernel(SweepArgs a) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x, nb = a.nb_total;
+  const int per = (nb + 1023) / 1024;
+  const int b0 = tid * per, b1 = min(nb, b0 + per);
+  int sum = 0;
+  for (int b = b0; b < b1; ++b) {
+    const GNState &st = a.states[a.blocks[b].prob];
+    const bool on = a.fine_gate_c >= 0.0f ? st.converged != 0 : st.done == 0;
+    sum += on ? (int)a.need_cnt[b] : 0;
+  }
+  part[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - sum;
+  for (int b = b0; b < b1; ++b) {
+    a.wide_off[b] = run;
+    const GNState &st = a.states[a.blocks[b].prob];
+    const bool on = a.fine_gate_c >= 0.0f ? st.converged != 0 : st.done == 0;
+    run += on ? (int)a.need_cnt[b] : 0;
+  }
+  if (tid == 1023) a.wide_off[nb] = part[1023];
+}
+
+LSLAM_DEV uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, off, 64));
+  return v;
+}
+
+constexpr int WIDE_ROWS_PER_LANE = 4;  // up to 256 cell rows around a point (cells of >= 0.3 m inside the sqrt(5) m gate)
+
+__global__ __launch_bounds__(256) void sweep_wide_kernel(SweepArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);  // wave-uniform
+  const int nb = a.nb_total;
+  if (item >= a.wide_off[nb]) return;
+  int lo_b = 0, hi_b = nb;  // the workgroup whose list holds the item: wide_off[b] <= item < wide_off[b + 1]
+  while (hi_b - lo_b > 1) {
+    const int mid = (lo_b + hi_b) >> 1;
+    if (a.wide_off[mid] <= item) lo_b = mid; else hi_b = mid;
+  }
+  const int b = __builtin_amdgcn_readfirstlane(lo_b);
+  const BlockDesc bd = a.blocks[b];
+  const int qi = bd.first + (int)a.need_list[(size_t)b * SWEEP_BLOCK + (item - a.wide_off[b])];
+  GNState *st = const_cast<GNState *>(a.states) + bd.prob;
+  const bool is_surf = bd.is_surf != 0;
+  const CellGrid &G = is_surf ? a.ks : a.kc;
+  const float4 q = a.q[qi];
+  float sel[3];
+  sel[0] = ((st->R[0] * q.x + st->R[1] * q.y) + st->R[2] * q.z) + st->t[0];
+  sel[1] = ((st->R[3] * q.x + st->R[4] * q.y) + st->R[5] * q.z) + st->t[1];
+  sel[2] = ((st->R[6] * q.x + st->R[7] * q.y) + st->R[8] * q.z) + st->t[2];
+  // the ball that must be covered: five map points are known to lie within sqrt(r2) (pass 1 saw them), else the gate
+  float r2 = 5.0f * (1.0f + 1e-5f);
+  if (a.grid_hint) r2 = fminf(r2, a.grid_hint[qi]);
+  const float rb = sqrtf(r2) * (1.0f + 1.0e-5f) + GRID_CLIP_MARGIN_MIN;
+  const float rbc = rb * G.inv_c;
+  const float ux = __fmul_rn(__fsub_rn(sel[0], G.org[0]), G.inv_c);
+  const float uy = __fmul_rn(__fsub_rn(sel[1], G.org[1]), G.inv_c);
+  const float uz = __fmul_rn(__fsub_rn(sel[2], G.org[2]), G.inv_c);
+  const bool num = (ux == ux) && (uy == uy) && (uz == uz);
+  // cells [lo, hi] per axis, clamped to the table (cells outside it hold nothing)
+  const int xlo = (int)fminf(fmaxf(floorf(ux - rbc), 0.0f), (float)(G.nx - 1)), xhi = (int)fminf(fmaxf(floorf(ux + rbc), 0.0f), (float)(G.nx - 1));
+  const int ylo = (int)fminf(fmaxf(floorf(uy - rbc), 0.0f), (float)(G.ny - 1)), yhi = (int)fminf(fmaxf(floorf(uy + rbc), 0.0f), (float)(G.ny - 1));
+  const int zlo = (int)fminf(fmaxf(floorf(uz - rbc), 0.0f), (float)(G.nz - 1)), zhi = (int)fminf(fmaxf(floorf(uz + rbc), 0.0f), (float)(G.nz - 1));
+  const int ny = yhi - ylo + 1, nz = zhi - zlo + 1;
+  const int nrows = num ? ny * nz : 0;
+  bool unresolved = nrows > 64 * WIDE_ROWS_PER_LANE;  // (cells smaller than the kernel is sized for)
+  uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu, k4 = 0xFFFFFFFFu, k5 = 0xFFFFFFFFu;
+  uint32_t row_s[WIDE_ROWS_PER_LANE], row_id0[WIDE_ROWS_PER_LANE + 1];
+  uint32_t id = 0;
+#pragma unroll
+  for (int k = 0; k < WIDE_ROWS_PER_LANE; ++k) {
+    const int r = lane + 64 * k;
+    row_s[k] = 0;
+    row_id0[k] = id;
+    if (r < nrows && !unresolved) {
+      const int jy = ylo + r % ny, jz = zlo + r / ny;
+      const int base = G.nx * (jy + G.ny * jz);
+      const uint32_t s0 = G.cell_start[base + xlo], e0 = G.cell_start[base + xhi + 1];
+      row_s[k] = s0;
+      for (uint32_t j = s0; j < e0; ++j) {
+        const float dist = dist2_xyz(sel[0], sel[1], sel[2], G.pts[j]);
+        const uint32_t key = (__float_as_uint(dist) & ~GRID_ID_MASK) | (id & GRID_ID_MASK);
+        k5 = umed3(k4, k5, key); k4 = umed3(k3, k4, key); k3 = umed3(k2, k3, key);
+        k2 = umed3(k1, k2, key); k1 = umed3(k0, k1, key); k0 = min(k0, key);
+        ++id;
+      }
+    }
+  }
+  row_id0[WIDE_ROWS_PER_LANE] = id;
+  unresolved = unresolved || __any(id > GRID_ID_MASK + 1u);  // a lane saw more candidates than an id can count
+  // the six smallest keys of the wavefront, smallest first: winner = the lowest lane that holds the minimum
+  int pos[6];
+  uint32_t key6[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const uint32_t m = wave_min_u32(k0);
+    key6[j] = m;
+    const unsigned long long who = __ballot(k0 == m && m != 0xFFFFFFFFu);
+    const int w = who ? __builtin_ctzll(who) : 0;
+    int mine = -1;
+    if (who && lane == w) {
+      const uint32_t cid = k0 & GRID_ID_MASK;
+#pragma unroll
+      for (int k = 0; k < WIDE_ROWS_PER_LANE; ++k)
+        if (cid >= row_id0[k] && cid < row_id0[k + 1]) mine = (int)(row_s[k] + (cid - row_id0[k]));
+      k0 = k1; k1 = k2; k2 = k3; k3 = k4; k4 = k5; k5 = 0xFFFFFFFFu;
+    }
+    pos[j] = who ? __shfl(mine, w, 64) : -1;
+  }
+  const uint32_t rest = wave_min_u32(k0);  // every other candidate's truncated distance is at least this
+  // exact distances, sorted by the search's own insert (every lane computes the same)
+  float d[5], e6 = FLT_MAX;
+  int p[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) { d[j] = FLT_MAX; p[j] = -1; }
+  float lb = FLT_MAX;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const float x = pos[j] >= 0 ? dist2_xyz(sel[0], sel[1], sel[2], G.pts[pos[j]]) : FLT_MAX;
+    if (j < 5) knn_insert_sorted(d, p, x, pos[j]);
+    else e6 = x;
+  }
+  lb = fmaxf(e6, d[4]);
+  knn_insert_sorted(d, p, e6, pos[5]);
+  if (rest != 0xFFFFFFFFu) lb = fminf(lb, __uint_as_float(rest & ~GRID_ID_MASK));
+  // covered: every cell a point within (rb - slack) of the query can lie in has been scanned
+  const float cov = rb - GRID_U_SLACK * G.c;
+  const float cov2 = (cov * cov) * (1.0f - 1.0e-5f);
+  const bool distinct = d[0] < d[1] && d[1] < d[2] && d[2] < d[3] && d[3] < d[4];
+  // resolved: the five are proven, or there provably are not five inside the gate (the result is not used then: ScanMatch.cpp:102,120)
+  const bool five_proven = distinct && d[4] < lb && d[4] < cov2;
+  const bool none_inside = !(d[4] < 5.0f) && cov2 >= 5.0f * (1.0f + 1e-6f) && lb >= 5.0f;
+  if (num && (unresolved || !(five_proven || none_inside))) {
+    if (lane == 0) atomicOr(&st->pad, 1);
+  }
+  if (lane < 5) {
+    float dv = d[0];
+    int pv = p[0];
+#pragma unroll
+    for (int j = 1; j < 5; ++j) {
+      dv = lane == j ? d[j] : dv;
+      pv = lane == j ? p[j] : pv;
+    }
+    a.wide_d[(size_t)qi * 5 + lane] = num ? dv : FLT_MAX;
+    a.wide_p[(size_t)qi * 5 + lane] = num ? pv : -1;
+  }
+}
+
+hipError_t launch_sweep_wide(const SweepArgs &a, hipStream_t s) {
+  if (a.nb_total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(grid_prefix_kernel, dim3(1), dim3(1024), 0, s, a);
+  // one wavefront per point that CAN be listed (every point of the launch): the ones beyond the listed total leave at once
+  hipLaunchKernelGGL(sweep_wide_kernel, dim3((unsigned)a.nb_total * (SWEEP_BLOCK / 4)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

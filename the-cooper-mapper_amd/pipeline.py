@@ -53,9 +53,12 @@ class LaserOdometry:
 
 class LaserMapping:
     def __init__(self, ctx, cube_dims=(121, 121, 11), filter_corner=1.0, filter_surf=1.0, map_filter_corner=1.0,
-                 map_filter_surf=1.0, map_filter=2.0):
+                 map_filter_surf=1.0, map_filter=2.0, defer_trees=True):
         # LaserMatcher.cpp:80-116 defaults
         self.ctx = ctx
+        # the per-frame surround map is searched through its cell grids; its kd-trees are built only if a frame needs them
+        # (include/lslam_c.h lslam_map_defer_trees) -- same poses either way
+        ctx.defer_trees(defer_trees)
         self.filter_corner, self.filter_surf = filter_corner, filter_surf
         self.feature_map = FeatureMap(ctx, *cube_dims)
         self.feature_map.setup_filter_size(map_filter_corner, map_filter_surf, map_filter)

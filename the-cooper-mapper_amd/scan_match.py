@@ -119,6 +119,17 @@ class Context:
         self.lib.lslam_debug_sweep_launches(self.h, out)
         return dict(zip(SWEEP_VARIANTS, (int(v) for v in out)))
 
+    def defer_trees(self, on=True):
+        """lslam_map_defer_trees: maps handed over on the device from now on get their cell grids at once and their kd-trees
+        on first need (the mapping node's per-frame map)."""
+        self._check(self.lib.lslam_map_defer_trees(self.h, int(bool(on))))
+
+    def lazy_trees(self):
+        """lslam_debug_lazy_trees: (maps set with deferred trees, of those built after all, resident map's trees pending)."""
+        out = (C.c_uint64 * 3)()
+        self.lib.lslam_debug_lazy_trees(self.h, out)
+        return int(out[0]), int(out[1]), bool(out[2])
+
     def grid_launches(self):
         """lslam_debug_grid_launches: grid sweeps (sweep_grid_kernel) this context has launched so far."""
         return int(self.lib.lslam_debug_grid_launches(self.h))

@@ -210,6 +210,8 @@ def test_rccl_communicator_world_of_one(pkg, ctx, small_problem):
         pg.optimize(6)
         assert pg.row_sharded_solves() >= 6
         assert np.abs(pg.poses() - res[0][0]).max() < 1e-7 and abs(pg.last_stats.chi2_final - res[0][1]) <= 1e-8 * res[0][1]
+        with pytest.raises(Exception):  # a rank without rows (more ranks than 21-vertex row blocks) is refused, not launched
+            pg.set_row_shard(0, 0)
         pg.close()
         # the raw collective on a device buffer
         import torch

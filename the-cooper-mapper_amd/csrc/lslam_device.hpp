@@ -236,6 +236,9 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
                            TravStats &ts,
 #endif
                            const float bound = FLT_MAX, float *lb6 = nullptr) {
+  // the bound a tracking search keeps is collected in the straight-line leaf only: the two A/B leaf variants never fold the
+  // candidates they turn away into it, and a bound that is too large would let a certificate "prove" a wrong neighbour set
+  static_assert(!TRACK || (!LSLAM_LEAF_COMPACT && !LSLAM_BRANCHY_LEAF), "knn5_search<TRACK> needs the default leaf (certificates would be unsound)");
   float lb = FLT_MAX;
   // stack entries examined per pop round: four in flight where a wavefront's latency is what counts (single scans,
   // whole stack in LDS), fewer where instruction issue is (the shallow-stack batch variant)

@@ -1038,7 +1038,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
     __syncthreads();
     const ProbBlocks pb = a.tail.probs[bd.prob];
     if (threadIdx.x == 0) {
-      const int ticket = __hip_atomic_fetch_add(a.tail.count + bd.prob, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // acq_rel: the records published above are ordered before the ticket, and the last block's reads of the others' after it
+      const int ticket = __hip_atomic_fetch_add(a.tail.count + bd.prob, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
       last = ticket == pb.n_blocks - 1;
       if (last) __hip_atomic_store(a.tail.count + bd.prob, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
     }

@@ -2290,6 +2290,12 @@ int lslam_pg_set_row_shard(lslam_pg *pg, int32_t v_begin, int32_t v_end) {
     g_pg_err = "row shard must be a range of whole 21-vertex row blocks (lslam_pg_row_shard_range)";
     return LSLAM_ERR_INVALID;
   }
+  if (v_begin == v_end) {
+    // more ranks than 21-vertex row blocks (e.g. 20 keyframes on 2 ranks): a rank without rows has nothing to multiply or
+    // update, and the solve's launches are not written for that.  Such a graph is far too small to share: replicated solve.
+    g_pg_err = "empty row shard: the graph has fewer 21-vertex row blocks than ranks -- use the replicated solve (lslam_pg_set_row_shard(pg, -1, -1))";
+    return LSLAM_ERR_INVALID;
+  }
   pg->row_v0 = v_begin;
   pg->row_v1 = v_end;
   return LSLAM_OK;

@@ -9,6 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 H="$root/bench.py --headline-only --steps 2 --warmup 1 --map-cache /tmp/lslam_${tag}_map"
 timeout 600 python3 $H > $out/${tag}_headline.json 2> $out/${tag}_headline.err   # builds and saves the map once
 timeout 1500 python3 $root/bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+cp $out/bench_report.json $out/${tag}_bench_report.json   # the full report of THIS run (later runs overwrite bench_report.json)
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o s -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --pg-iters 20 --map-cache /tmp/lslam_${tag}_map > $out/${tag}_stats.log 2>&1
 cp $out/${tag}_stats/s_kernel_stats.csv $out/${tag}_kernel_stats.csv
 # ... and of the headline command alone (the one the counter passes wrap): (sweep_kernel + sweep_queue_kernel + cert_plan_kernel

@@ -497,3 +497,63 @@ def test_vlp16_mapping_frames_against_the_voxel_map_match_oracle(voxel_map_probl
         assert np.abs(M_g[:2, 3] - g[3:5]).max() < 0.05 and abs(M_g[2, 3] - g[5]) < 0.3, (k, M_g[:3, 3], g[3:])
     assert min(iters) >= 2
     mapper.feature_map.close()
+
+
+def test_full_size_configs_map_grid_sweep_against_lane_and_oracle(pkg, oracle, synth):
+    """BASELINE configs[1]'s map at its FULL size -- 10 000 VLP-16 frames through the product's addFeatureCloud, the surround at
+    the end of the loop (≈ 157 k corner + 587 k surf points): the map bench.py times against -- and configs[2] scans: sixteen full
+    64 x 1800 scans in one batch.  (a) the library's choice for a batch this size (the grid sweep) against the kd-tree walk of
+    every point: the same iteration and row counts, poses to the rounding of differently grouped sums; (b) two of the scans
+    against the oracle on the same clouds (the oracle needs ≈ 2 s per scan on this map); (c) the share of points the grid sweep
+    left to the tree search is the few per cent DESIGN quotes."""
+    import importlib as il
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    synth_gpu = il.import_module("synth_gpu")
+    world = synth.World(half_extent=300.0, wall_half=295.0, pole_pitch=2.5)
+    lidar = synth_gpu.GpuLidar(world, 0)
+    traj = synth_gpu.loop_trajectory(10000)
+    ctx = pkg.Context(0)
+    try:
+        fm, stats = synth_gpu.build_voxel_map(pkg, ctx, lidar, traj, rings=16)
+        assert stats["frames"] == 10000
+        fm.update(traj[-1][3:].astype(np.float32))
+        mc, ms = fm.get_surround_feature()
+        fm.surround_to_map()
+        assert len(mc) > 100000 and len(ms) > 400000
+        rng = np.random.default_rng(4242)
+        dense = synth_gpu.loop_trajectory(100000)
+        seg = np.linalg.norm(np.diff(dense[:, 3:5], axis=0), axis=1).mean()
+        span = int(25.0 / seg)
+        scans, inits = [], []
+        for k in range(16):
+            g = dense[int(rng.integers(-span, span)) % len(dense)].copy()
+            g[3:5] += rng.uniform(-1.0, 1.0, 2)
+            g[2] += rng.uniform(-0.2, 0.2)
+            scans.append(lidar.scan(g, 64, 1800, seed=900000 + k))
+            inits.append(synth.perturb_pose(g, seed=99 + k))
+        inits = np.stack(inits)
+        ctx.scan_set_batch(scans)
+        o = ctx.default_opts()
+        o.scans_in_flight = 16
+        o.debug_stats = 1
+        g0, s0 = ctx.grid_launches(), ctx.cert_stats()
+        _, p_auto, st_auto = ctx.run_batch(inits, o)
+        s1 = ctx.cert_stats()
+        assert ctx.grid_launches() > g0                                                             # picked by size
+        listed, swept = s1[0] - s0[0], s1[1] - s0[1]
+        assert 0.002 < listed / swept < 0.08, listed / swept                                        # (c)
+        o.search_mode = LANE
+        o.knn_cert = 0
+        _, p_lane, st_lane = ctx.run_batch(inits, o)
+        for a, b in zip(st_auto, st_lane):                                                          # (a)
+            assert a.iterations == b.iterations and a.converged == b.converged
+            assert _counts_close((a.n_line, a.n_plane, a.n_rows), (b.n_line, b.n_plane, b.n_rows))
+        assert np.abs(p_auto[:, 3:] - p_lane[:, 3:]).max() <= 5e-6 and np.abs(p_auto[:, :3] - p_lane[:, :3]).max() <= 5e-7
+        for k in (0, 7):                                                                            # (b)
+            ok, opose, ost = oracle.scanmatch_scan(mc, ms, scans[k][0], scans[k][1], inits[k])
+            assert st_auto[k].iterations == ost.iterations and st_auto[k].converged == ost.converged
+            assert _counts_close((st_auto[k].n_line, st_auto[k].n_plane, st_auto[k].n_rows), (ost.n_line, ost.n_plane, ost.n_rows))
+            assert np.abs(p_auto[k][3:] - opose[3:]).max() <= POSE_TOL_M and np.abs(p_auto[k][:3] - opose[:3]).max() <= POSE_TOL_RAD
+        fm.close()
+    finally:
+        ctx.close()

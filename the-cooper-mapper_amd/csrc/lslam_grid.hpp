@@ -35,6 +35,9 @@ struct CellGrid {
   int32_t n_pts;
 };
 
+#ifndef LSLAM_GRID_BALL
+#define LSLAM_GRID_BALL 0  // 1: the x-extent of every row clipped to the bound's BALL instead of its box -- fewer candidates (wave maximum 38 -> 30 rounds in late sweeps on the dumped workload), measured SLOWER: 1.228e10 against 1.250e10 on the same box (nine square roots and ~90 more set-up instructions per probe cost more than the rounds they save)
+#endif
 #ifndef LSLAM_GRID_ASM_LOOP
 #define LSLAM_GRID_ASM_LOOP 1  // 0: the candidate loop as the compiler makes it (A/B switch)
 #endif
@@ -109,14 +112,34 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
     const float cl = rb - GRID_U_SLACK * G.c;  // a clipped point is at least this far away
     clip_lo2 = (cl * cl) * (1.0f - 1.0e-5f);
   }
-  // the nine runs; all eighteen cell_start loads in flight together
-  const int ix0 = alive0 ? (int)xlo : 1, ix1 = alive0 ? (int)xhi : 1;
+  // The nine runs; all eighteen cell_start loads in flight together.  With a bound the x-extent of a row is clipped to the
+  // BALL of radius rb, not its box: a row whose nearest wall is g cells away (in y and z) is scanned over
+  // [ux - w, ux + w], w = sqrt(rbc^2 - g^2), and not at all when g > rbc.  g is taken a rounding slack short and w a hair
+  // long, so a point outside the scanned cells is still farther than rb - GRID_U_SLACK c (the box version's claim).
+  const bool ball = LSLAM_GRID_BALL && bound < 1.0e30f;
+  const float rbc2 = ball ? (sqrtf(bound) * (1.0f + 1.0e-5f) + clip_margin) * G.inv_c : 0.0f;
+  const float rbcs = rbc2 * rbc2;
   const int iy = alive0 ? (int)fy0 : 1, iz = alive0 ? (int)fz0 : 1;
   uint32_t rs[9], re[9];
+  bool rowon[9];
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
-    const int jy = iy + (r % 3) - 1, jz = iz + (r / 3) - 1;
+    const int dy = (r % 3) - 1, dz = (r / 3) - 1;
+    float rx0 = xlo, rx1 = xhi;
+    bool on_r = true;
+    if (ball) {
+      const float gy = dy == 0 ? 0.0f : fmaxf((dy < 0 ? ey : 1.0f - ey) - 1.0e-3f, 0.0f);
+      const float gz = dz == 0 ? 0.0f : fmaxf((dz < 0 ? ez : 1.0f - ez) - 1.0e-3f, 0.0f);
+      const float w2 = rbcs - (gy * gy + gz * gz);
+      on_r = w2 > 0.0f;
+      const float w = __builtin_amdgcn_sqrtf(fmaxf(w2, 0.0f)) * (1.0f + 1.0e-5f) + 1.0e-4f;
+      rx0 = fmaxf(rx0, floorf(ux - w));
+      rx1 = fminf(rx1, floorf(ux + w));
+    }
+    rowon[r] = on_r;
+    const int jy = iy + dy, jz = iz + dz;
     const int base = G.nx * (jy + G.ny * jz);
+    const int ix0 = alive0 ? (int)rx0 : 1, ix1 = alive0 ? (int)rx1 : 1;
     rs[r] = G.cell_start[base + ix0];
     re[r] = G.cell_start[base + ix1 + 1];
   }
@@ -126,7 +149,7 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
     const float jy = fy0 + (float)((r % 3) - 1), jz = fz0 + (float)((r / 3) - 1);
-    const bool use = alive0 && jy >= ylo && jy <= yhi && jz >= zlo && jz <= zhi && re[r] > rs[r];
+    const bool use = alive0 && rowon[r] && jy >= ylo && jy <= yhi && jz >= zlo && jz <= zhi && re[r] > rs[r];
     if (use) {
       rows[2 * nrow * BLOCK] = rs[r];
       rows[(2 * nrow + 1) * BLOCK] = re[r];

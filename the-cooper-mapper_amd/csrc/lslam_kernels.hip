@@ -232,7 +232,11 @@ LSLAM_DEV void block_accumulate(const int jtj_mode, const bool is_surf, const fl
 // CERT (the bounded production sweep over whole-map trees, two launches): 1 = the pass over every point, which carries the
 // neighbour lists of points that have hardly moved over by certificate and lists the others; 2 = the pass over the listed
 // points (sweep_queue_kernel: `q_item` is this lane's point or -1, the sums are ADDED to partial_out).  See below.
-template <int BLOCK, bool OVF, bool CUBES, int LDS_DEPTH, bool PACKET, bool STATE_LDS, bool FUSE = false, int CERT = 0>
+// GRIDQ (with CERT = 2): 0 = the certificate sweep's second pass; 1 = the grid sweep's (tree search bounded by what pass 1
+// hands over, no certificate bookkeeping); 2 = the grid sweep's on a map without trees (neighbours given by sweep_wide_kernel).
+// A template argument, not a run-time flag: each second pass is compiled without the others' search code (the one kernel for
+// all three needed 96 VGPRs + 92 bytes of scratch per lane).
+template <int BLOCK, bool OVF, bool CUBES, int LDS_DEPTH, bool PACKET, bool STATE_LDS, bool FUSE = false, int CERT = 0, int GRIDQ = 0>
 LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, const BlockDesc &bd, const GNState *st,
                           uint32_t *stack_lds, float (*red)[NCOL], float *partial_out, const int prev_valid, const int q_item = -1) {
   constexpr int NWAVE = BLOCK / 64;
@@ -354,8 +358,9 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
   bool do_search = true;  // this lane's neighbours come from a search below
   // grid sweep (pass 2 of it: the points sweep_grid_kernel could not prove): what is carried from sweep to sweep is where the
   // point was and how far its fifth neighbour (prev_q: x, y, z, d2[4]) -- no neighbour ids, no certificates
-  const bool grid = CERT == 2 && a.grid != 0;
-  bool track = CERT == 2 && a.prev_q != nullptr && !grid;  // ... which keeps the bound the next sweep's certificate needs
+  static_assert(GRIDQ == 0 || CERT == 2, "GRIDQ is a mode of the second pass");
+  constexpr bool grid = GRIDQ != 0;
+  bool track = CERT == 2 && !grid && a.prev_q != nullptr;  // ... which keeps the bound the next sweep's certificate needs
   if (CERT == 1) {
     static_assert(CERT != 1 || (!PACKET && !CUBES && !STATE_LDS && BLOCK <= 256), "certificate pass: whole-map lane search, byte lists");
     // the last update of this scan, as the largest displacement of a point within CERT_RANGE_M of the sensor [m]
@@ -468,7 +473,7 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
       }
     }
     if (CUBES && !searched) T.n_pts = 0;  // knn5_search returns at once, d[4] stays FLT_MAX
-    if (CERT == 2 && a.grid == 2) {  // the wide probe has been here: its five, no search (and no tree to search)
+    if (GRIDQ == 2) {  // the wide probe has been here: its five, no search (and no tree to search)
       do_search = false;
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
@@ -481,7 +486,7 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
       sel[2] = ((R[6] * q.x + R[7] * q.y) + R[8] * q.z) + t[2];
       if (a.bounded) a.prev_q[qi] = make_float4(sel[0], sel[1], sel[2], (p[4] >= 0 && d[4] < 5.0f) ? d[4] : FLT_MAX);
     }
-    if (do_search) {
+    if (GRIDQ != 2 && do_search) {
     KdStack<BLOCK, OVF, LDS_DEPTH> stk;
     stk.lds = (lds_u32 *)(stack_lds + tid);
     stk.ovf = OVF ? a.stack_ovf + ((size_t)lb * BLOCK + tid) : nullptr;  // lb: unique per workgroup of a launch, < nb_total
@@ -533,7 +538,7 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
       o[4] = ts.n_leaf | ((uint64_t)ts.n_hit << 32); o[5] = ts.n_pop | ((uint64_t)ts.n_cand << 32); o[6] = ((uint64_t)ts.n_popit << 32) | ts.n_take; o[7] = ts.t_take | (1ull << 63);
     }
 #else
-    if (CERT && track) {  // block-uniform
+    if (CERT && !grid && track) {  // block-uniform
       float slb = 0.0f;
       knn5_search<BLOCK, OVF, LDS_DEPTH, true>(T, sel[0], sel[1], sel[2], d, p, stk, bound, &slb);
       // the bound is only worth keeping when the five are the true five: all found, inside the gate the bounded search is exact in
@@ -557,7 +562,7 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
     (void)searched;
     if (a.dbg) dbg_t1 = __builtin_readcyclecounter();
 
-    point_residual(a, bd, is_surf, (CERT == 2 && a.grid == 2) ? (is_surf ? a.ks.pts : a.kc.pts) : T.pts, q, sel, d, p, sc, row, rb, kept, matched, score);
+    point_residual(a, bd, is_surf, GRIDQ == 2 ? (is_surf ? a.ks.pts : a.kc.pts) : T.pts, q, sel, d, p, sc, row, rb, kept, matched, score);
   }
 
   if (a.dbg) dbg_t2 = __builtin_readcyclecounter();
@@ -1095,7 +1100,7 @@ __global__ __launch_bounds__(256) void cert_plan_kernel(SweepArgs a, CertPlan pl
 // -- as many as the sweep itself has, nearly all of them leaving at once -- cost 0.25 ms per launch, more than the last
 // sweeps of a batch themselves.  The argument block is re-read through a laundered pointer in every turn: left to itself the
 // compiler carries the sweep's invariants across the loop in registers it does not have (124 bytes of scratch per lane).
-template <int BLOCK, bool OVF, int LDS_DEPTH>
+template <int BLOCK, bool OVF, int LDS_DEPTH, int GRIDQ = 0>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH <= 16 ? LSLAM_SHALLOW_OCC : 2))) void sweep_queue_kernel(const SweepArgs a_in, const int jtj_mode_in, const CertPlan plan) {
   __shared__ float red[BLOCK / 64][NCOL];
   __shared__ uint32_t stack_lds[2 * LDS_DEPTH * BLOCK];
@@ -1140,7 +1145,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
       }
       item = a.blocks[fb + k].first + (int)a.need_list[(size_t)(fb + k) * BLOCK + (i - p0)];
     }
-    sweep_body<BLOCK, OVF, false, LDS_DEPTH, false, false, false, 2>(a, jtj_mode, fb + c, bd, st, stack_lds, red, a.partials + (size_t)(fb + c) * NCOL, a.prev_valid, item);  // (the certificate sweep's second pass only runs with prev_valid set; the grid sweep's runs in a loop's first sweep too)
+    sweep_body<BLOCK, OVF, false, LDS_DEPTH, false, false, false, 2, GRIDQ>(a, jtj_mode, fb + c, bd, st, stack_lds, red, a.partials + (size_t)(fb + c) * NCOL, a.prev_valid, item);  // (the certificate sweep's second pass only runs with prev_valid set; the grid sweep's runs in a loop's first sweep too)
     __syncthreads();  // red and the stack columns are free again
   }
 }
@@ -1220,15 +1225,21 @@ hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, h
   constexpr int SHALLOW = LSLAM_SHALLOW_DEPTH;
   const long possible = (long)a.nb_total;
   const dim3 b(SWEEP_BLOCK);
-  if (variant == SWEEP_VARIANT_SHALLOW) {
+  if (a.grid == 2) {  // neighbours given (a map without trees): no search, no stack -- the shallow shape's LDS is plenty
     const dim3 g((unsigned)std::min<long>(possible, 256 * 5));
-    hipExtLaunchKernelGGL((sweep_queue_kernel<SWEEP_BLOCK, true, SHALLOW>), g, b, 0, s, nullptr, stop, 0, a, jtj_mode, plan);
+    hipExtLaunchKernelGGL((sweep_queue_kernel<SWEEP_BLOCK, true, SHALLOW, 2>), g, b, 0, s, nullptr, stop, 0, a, jtj_mode, plan);
+  } else if (variant == SWEEP_VARIANT_SHALLOW) {
+    const dim3 g((unsigned)std::min<long>(possible, 256 * 5));
+    if (a.grid) hipExtLaunchKernelGGL((sweep_queue_kernel<SWEEP_BLOCK, true, SHALLOW, 1>), g, b, 0, s, nullptr, stop, 0, a, jtj_mode, plan);
+    else hipExtLaunchKernelGGL((sweep_queue_kernel<SWEEP_BLOCK, true, SHALLOW>), g, b, 0, s, nullptr, stop, 0, a, jtj_mode, plan);
   } else if (variant == SWEEP_VARIANT_DEEP_OVF) {
     const dim3 g((unsigned)std::min<long>(possible, 256 * 2));
-    hipExtLaunchKernelGGL((sweep_queue_kernel<SWEEP_BLOCK, true, KD_STACK_LDS>), g, b, 0, s, nullptr, stop, 0, a, jtj_mode, plan);
+    if (a.grid) hipExtLaunchKernelGGL((sweep_queue_kernel<SWEEP_BLOCK, true, KD_STACK_LDS, 1>), g, b, 0, s, nullptr, stop, 0, a, jtj_mode, plan);
+    else hipExtLaunchKernelGGL((sweep_queue_kernel<SWEEP_BLOCK, true, KD_STACK_LDS>), g, b, 0, s, nullptr, stop, 0, a, jtj_mode, plan);
   } else if (variant == SWEEP_VARIANT_DEEP) {
     const dim3 g((unsigned)std::min<long>(possible, 256 * 2));
-    hipExtLaunchKernelGGL((sweep_queue_kernel<SWEEP_BLOCK, false, KD_STACK_LDS>), g, b, 0, s, nullptr, stop, 0, a, jtj_mode, plan);
+    if (a.grid) hipExtLaunchKernelGGL((sweep_queue_kernel<SWEEP_BLOCK, false, KD_STACK_LDS, 1>), g, b, 0, s, nullptr, stop, 0, a, jtj_mode, plan);
+    else hipExtLaunchKernelGGL((sweep_queue_kernel<SWEEP_BLOCK, false, KD_STACK_LDS>), g, b, 0, s, nullptr, stop, 0, a, jtj_mode, plan);
   } else {
     return hipErrorInvalidValue;
   }

@@ -287,7 +287,7 @@ def main():
             # library's communicator exists) the rank count RCCL itself reports
             "ranks": {"world": world, "per_rank_value": per_rank, "rccl_ranks": None},
         }
-    if args.search == "grid":  # what share of the points the grid sweeps left to the tree search (one more step, counted; untimed)
+    if ctx.grid_launches() > 0:  # what share of the points the grid sweeps left to the tree search (one more step, counted; untimed)
         import ctypes
         opts.debug_stats = 1
         g0 = (ctypes.c_uint64 * 3)()
@@ -549,8 +549,9 @@ def compact_line(out):
                               "overlapped_ms": _pick(mf, "overlapped", "gpu_ms_per_frame"),
                               "overlapped_p99_ms": _pick(mf, "overlapped", "gpu_ms_p99"),
                               "overlapped_worst_ms": _pick(mf, "overlapped", "gpu_ms_worst_frame"),
-                              "tree_build_ms": _pick(mf, "gpu_ms", "surround_to_map"), "tree_build_hbm_frac": _pick(mf, "tree_build", "frac"),
-                              "tree_build_traffic": _pick(mf, "tree_build", "traffic"),
+                              "surround_to_map_ms": _pick(mf, "gpu_ms", "surround_to_map"),
+                              "search_structure": "cell grids (trees deferred)" if mf.get("search_structure_build") else ("kd-trees" if mf.get("tree_build") else None),
+                              "tree_build_hbm_frac": _pick(mf, "tree_build", "frac"), "tree_build_traffic": _pick(mf, "tree_build", "traffic"),
                               "cpu_ms_per_frame": mf.get("cpu_ms_per_frame"), "pose_diff_gpu_vs_cpu_m": mf.get("pose_diff_gpu_vs_cpu_m"),
                               "error": mf.get("error")}))
     ss = out.get("single_scan") or {}
@@ -1218,7 +1219,22 @@ def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, 
            "scan_match_iterations": int(st.iterations),
            "pose_err_vs_ground_truth_m": float(np.abs(pose[3:] - gt[3:].astype(np.float32)).max())}
     if not cubes:
-        res["tree_build"] = tree_build_roofline(gpu["surround_to_map"], len(sur_c), len(sur_s), np)
+        built, after_all, _ = ctx.lazy_trees()
+        if built > 0 and after_all == 0:
+            # deferred trees: what surround_to_map builds per frame is the cell grids (bounding boxes, key sort, cell tables), no
+            # kd-tree; priced as the bytes that must move -- every point read and written once, every cell of the tables
+            # written and scanned -- over the step's wall time
+            n_pts = len(sur_c) + len(sur_s)
+            info_ = ctx.map_info()
+            res["search_structure_build"] = {
+                "what": "cell grids of the surround (lslam_map_defer_trees): no kd-tree is built unless a frame needs one",
+                "ms": gpu["surround_to_map"], "points": n_pts, "trees_built_after_all": int(after_all),
+                "bound": "latency", "bound_detail": "a chain of ~25 short launches (reduction, key, radix-sort passes, scan, placement per type) behind two host waits",
+                "alg_bytes": 2.0 * 16.0 * n_pts, "achieved": 2.0 * 16.0 * n_pts / (gpu["surround_to_map"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": 2.0 * 16.0 * n_pts / (gpu["surround_to_map"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "kd_depth_reported": int(max(info_.depth_corner, info_.depth_surf))}
+        else:
+            res["tree_build"] = tree_build_roofline(gpu["surround_to_map"], len(sur_c), len(sur_s), np)
         # The same frame the way the reference's nodelets run it: the registration node (feature extraction, the VoxelGrid of
         # the features) is its own thread with its own context, so its work on frame k overlaps the mapping node's
         # update + surround -> kd-trees of frame k (which depend on the map after frame k - 1 and on the pose prior only):

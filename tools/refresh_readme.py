@@ -36,7 +36,9 @@ def main():
         mf16=pick(d, "mapping_frame_vlp16", "gpu_ms_per_frame"), mf_ov=pick(d, "mapping_frame", "overlapped", "gpu_ms_per_frame"),
         mf_cpu=pick(d, "mapping_frame", "cpu_ms_per_frame"), pg=pick(d, "pose_graph", "lm_iters_per_s"), pg_cpu=pick(d, "pose_graph", "cpu_baseline", "value"))
     tpl = open(os.path.join(ROOT, "tools", "readme_template.md")).read()
-    open(os.path.join(ROOT, "README.md"), "w").write(tpl.format(**vals))
+    text = tpl.format(**vals)
+    text = re.sub(r"(\d(?:\.\d+)?)e\+?0?(\d+)", r"\1e\2", text)  # 1.27e+10 -> 1.27e10
+    open(os.path.join(ROOT, "README.md"), "w").write(text)
     print("README.md <-", os.path.relpath(rep, ROOT))
 
 

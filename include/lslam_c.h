@@ -90,7 +90,11 @@ typedef struct {
  * LSLAM_SEARCH=lane|packet|grid, LSLAM_FORCE_STACK=deep|shallow|auto, LSLAM_PERSISTENT_GN=1, LSLAM_FUSED_SOLVE=1,
  * LSLAM_DEBUG_CERT_STATS=1 -- are read ONCE, in lslam_ctx_create; no entry point reads the environment while it runs. */
 enum { LSLAM_AB_PERSISTENT_GN = 1, /* one resident scan: the whole Gauss-Newton loop as one persistent launch */
-       LSLAM_AB_FUSED_SOLVE = 2    /* latency-bound launches: the 6x6 solve in the tail of the sweep launch */ };
+       LSLAM_AB_FUSED_SOLVE = 2,   /* latency-bound launches: the 6x6 solve in the tail of the sweep launch */
+       LSLAM_AB_SECOND_PROBE = 4   /* grid sweep: the points the 27-cell probe cannot prove get a second, 125-cell probe (clipped to
+                                      the ball of what the first saw) before the tree search -- exact, measured slower
+                                      (1.16e10 against 1.25e10 point-residuals/s: the points that need more than the first probe
+                                      are the ones a wide probe is slow for too) */ };
 
 /* 5-NN search implementations (same answer, bit for bit):
  *   LANE    one query per lane, nanoflann's traversal with an explicit per-lane stack

@@ -156,6 +156,14 @@ def test_grid_batch_equals_lane_batch(ctx, synth):
         assert np.abs(p_lane - p_grid).max() <= 2e-6
         _, p_again, _ = ctx.run_batch(inits, o)
         assert np.array_equal(p_again, p_grid)  # fixed places, fixed order: the same bits in every run
+        # the A/B switch "second probe" (125 cells for the points the 27-cell probe cannot prove, tree search only for what
+        # that leaves): another grouping of the same terms
+        o.ab_switches = 4
+        _, p_2, s_2 = ctx.run_batch(inits, o)
+        o.ab_switches = 0
+        for a, b in zip(s_lane, s_2):
+            assert (a.iterations, a.n_rows, a.n_line, a.n_plane, a.converged) == (b.iterations, b.n_rows, b.n_line, b.n_plane, b.converged)
+        assert np.abs(p_lane - p_2).max() <= 2e-6
 
 
 def test_grid_fine_score_resweep(ctx, small_problem):

@@ -176,6 +176,7 @@ struct lslam_ctx {
   DevBuf<float> prev_lb;       // ... with the bound the certificate needs (sweep_body)
   DevBuf<uint8_t> need_list;   // certificate sweep: the points pass 1 leaves to pass 2 (SweepArgs)
   DevBuf<uint16_t> need_cnt;
+  DevBuf<uint16_t> need2_list, need2_cnt;  // grid sweep: what its second probe leaves to the tree search (SweepArgs)
   DevBuf<GroupDesc> groups;
   DevBuf<int32_t> cert_work;   // [blocks] work list of pass 2 (CertPlan)
   DevBuf<int32_t> cert_count;  // [2] items + [2] tickets
@@ -317,6 +318,8 @@ void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
   a.grid = 0;
   a.grid_clip_margin = GRID_CLIP_MARGIN_MIN;
   a.grid_hint = nullptr;
+  a.need2_list = nullptr;
+  a.need2_cnt = nullptr;
   a.wide_d = nullptr;
   a.wide_p = nullptr;
   a.wide_off = nullptr;
@@ -428,6 +431,20 @@ hipError_t sweep_launch(lslam_ctx *ctx, const SweepArgs &a, int jtj_mode, hipEve
       if (e != hipSuccess) return e;
     }
     const int pass2 = a.stack_ovf ? (a.deep_tree ? SWEEP_VARIANT_DEEP_OVF : SWEEP_VARIANT_SHALLOW) : SWEEP_VARIANT_DEEP;
+    if (a.grid == 1 && a.need2_cnt) {  // second probe, then the tree search of what IT could not prove: two plans, two queues
+      e = launch_sweep_queue(a, jtj_mode, ctx->stream, nullptr, pass2, plan, 0);
+      ctx->queue_launches++;
+      if (e != hipSuccess) return e;
+      CertPlan plan2;
+      plan2.work = ctx->cert_work.p;
+      plan2.count = ctx->cert_count.p + (ctx->queue_launches & 1);
+      plan2.count_next = ctx->cert_count.p + ((ctx->queue_launches + 1) & 1);
+      plan2.ticket = plan2.count + 2;
+      plan2.ticket_next = plan2.count_next + 2;
+      e = launch_sweep_queue(a, jtj_mode, ctx->stream, e1, pass2, plan2, 1);
+      ctx->queue_launches++;
+      return e;
+    }
     e = launch_sweep_queue(a, jtj_mode, ctx->stream, e1, pass2, plan);
     ctx->queue_launches++;
     return e;
@@ -586,6 +603,8 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   ctx->prev_lb.release();
   ctx->need_list.release();
   ctx->need_cnt.release();
+  ctx->need2_list.release();
+  ctx->need2_cnt.release();
   ctx->groups.release();
   ctx->cert_work.release();
   ctx->cert_count.release();
@@ -1352,6 +1371,8 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
   HIP_TRY(ctx->prev_lb.reserve(total ? total : 1));
   HIP_TRY(ctx->need_list.reserve((nb ? nb : 1) * SWEEP_BLOCK));
   HIP_TRY(ctx->need_cnt.reserve(nb ? nb : 1));
+  HIP_TRY(ctx->need2_list.reserve((nb ? nb : 1) * SWEEP_BLOCK));
+  HIP_TRY(ctx->need2_cnt.reserve(nb ? nb : 1));
   HIP_TRY(ctx->groups.reserve(ctx->h_groups.empty() ? 1 : ctx->h_groups.size()));
   HIP_TRY(ctx->cert_work.reserve(nb ? nb : 1));
   if (!ctx->cert_count.p) {
@@ -1676,6 +1697,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
       }
     }
     const bool grid_on = sa.grid != 0;
+    const bool no_probe2 = ((o.ab_switches | ctx->env_ab) & LSLAM_AB_SECOND_PROBE) == 0;  // A/B (off): a second, wider probe before the tree search
     // neighbour lists carried from sweep to sweep by certificate where a point has hardly moved (sweep_body): lslam_opts.knn_cert
     // = 0 searches every point in every sweep, 2 takes the certificate sweep whatever the size of the launch (tests); the
     // environment's LSLAM_KNN_CERT / LSLAM_CERT_TRY_M / LSLAM_CERT_TRACK_M, read when the context was made, override the options
@@ -1694,8 +1716,8 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
     }
     if ((sa.prev_q || sa.grid) && (ctx->env_debug_cert_stats || o.debug_stats)) {
       if (!ctx->cert_stats.p) {
-        HIP_TRY(ctx->cert_stats.reserve(2));
-        HIP_TRY(hipMemsetAsync(ctx->cert_stats.p, 0, 16, ctx->stream));
+        HIP_TRY(ctx->cert_stats.reserve(3));
+        HIP_TRY(hipMemsetAsync(ctx->cert_stats.p, 0, 24, ctx->stream));
       }
       sa.cert_stats = ctx->cert_stats.p;
     }
@@ -1742,6 +1764,10 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
         }
         sc.need_list = ctx->need_list.p + (size_t)fb * SWEEP_BLOCK;
         sc.need_cnt = ctx->need_cnt.p + fb;
+        if (sc.grid == 1 && !no_probe2) {
+          sc.need2_list = ctx->need2_list.p + (size_t)fb * SWEEP_BLOCK;
+          sc.need2_cnt = ctx->need2_cnt.p + fb;
+        }
         sc.groups = ctx->groups.p + ctx->h_prob_group0[(size_t)p0];
         sc.n_groups = ctx->h_prob_group0[(size_t)p1] - ctx->h_prob_group0[(size_t)p0];
         sc.group_block_base = fb;

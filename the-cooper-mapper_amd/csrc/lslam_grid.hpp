@@ -81,7 +81,11 @@ enum : int {
 //     true one by a few ulps only: rg2 carries a 1e-5 relative pad;
 //   * points in rows or cells that were clipped are farther than sqrt(bound) (padded), hence farther than five known points;
 //   * d[0] < d[1] < ... < d[4] < (sixth smallest candidate distance): no tie that nanoflann's visit order would have decided.
-template <int BLOCK>
+// R: rings of cells around the query's cell -- 1: the 27-cell probe of pass 1 (nine runs of three cells); 2: 125 cells
+// (twenty-five runs of five), for the points the 27-cell probe could not prove: guaranteed radius c (2 + wall) instead of
+// c (1 + wall), rows clipped to the BALL of the caller's bound (which such a point always has: the fifth distance the first
+// probe saw).  rows: 2 (2R + 1)^2 words per lane.
+template <int BLOCK, int R = 1>
 LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const float qy, const float qz, const float bound,
                         const float clip_margin, lds_u32 *rows, float (&d)[5], int (&p)[5], float &lb6) {
 #pragma unroll
@@ -93,16 +97,20 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
   const float uy = __fmul_rn(__fsub_rn(qy, G.org[1]), G.inv_c);
   const float uz = __fmul_rn(__fsub_rn(qz, G.org[2]), G.inv_c);
   // interior cell: 1 <= i <= n - 2 on every axis (NaN fails every comparison)
-  const bool inr = ux >= 1.0f && ux < (float)(G.nx - 1) && uy >= 1.0f && uy < (float)(G.ny - 1) && uz >= 1.0f && uz < (float)(G.nz - 1);
+  constexpr int W = 2 * R + 1, NR = W * W;          // rows per probe
+  constexpr uint32_t IDB = R == 1 ? GRID_ID_BITS : GRID_ID_BITS + 1;  // id = (row slot << GRID_ROW_BITS) | offset in the row
+  constexpr uint32_t IDM = (1u << IDB) - 1u;
+  static_assert(NR - 1 <= (int)(IDM >> GRID_ROW_BITS), "row slots must fit the id");
+  const bool inr = ux >= (float)R && ux < (float)(G.nx - R) && uy >= (float)R && uy < (float)(G.ny - R) && uz >= (float)R && uz < (float)(G.nz - R);
   const bool alive0 = on && inr;
   const float fx0 = floorf(ux), fy0 = floorf(uy), fz0 = floorf(uz);
   const float ex = ux - fx0, ey = uy - fy0, ez = uz - fz0;  // position inside the cell, [0, 1)
   const float wall = fminf(fminf(fminf(ex, 1.0f - ex), fminf(ey, 1.0f - ey)), fminf(ez, 1.0f - ez));
-  const float rg = G.c * ((1.0f - GRID_U_SLACK) + wall);
+  const float rg = G.c * (((float)R - GRID_U_SLACK) + wall);
   const float rg2 = (rg * rg) * (1.0f - 1.0e-5f);
   // clip box in cell coordinates
   float clip_lo2 = FLT_MAX;
-  float xlo = fx0 - 1.0f, xhi = fx0 + 1.0f, ylo = fy0 - 1.0f, yhi = fy0 + 1.0f, zlo = fz0 - 1.0f, zhi = fz0 + 1.0f;
+  float xlo = fx0 - (float)R, xhi = fx0 + (float)R, ylo = fy0 - (float)R, yhi = fy0 + (float)R, zlo = fz0 - (float)R, zhi = fz0 + (float)R;
   if (bound < 1.0e30f) {
     const float rb = sqrtf(bound) * (1.0f + 1.0e-5f) + clip_margin;
     const float rbc = rb * G.inv_c;
@@ -116,20 +124,21 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
   // BALL of radius rb, not its box: a row whose nearest wall is g cells away (in y and z) is scanned over
   // [ux - w, ux + w], w = sqrt(rbc^2 - g^2), and not at all when g > rbc.  g is taken a rounding slack short and w a hair
   // long, so a point outside the scanned cells is still farther than rb - GRID_U_SLACK c (the box version's claim).
-  const bool ball = LSLAM_GRID_BALL && bound < 1.0e30f;
+  const bool ball = (R > 1 || LSLAM_GRID_BALL) && bound < 1.0e30f;
   const float rbc2 = ball ? (sqrtf(bound) * (1.0f + 1.0e-5f) + clip_margin) * G.inv_c : 0.0f;
   const float rbcs = rbc2 * rbc2;
-  const int iy = alive0 ? (int)fy0 : 1, iz = alive0 ? (int)fz0 : 1;
-  uint32_t rs[9], re[9];
-  bool rowon[9];
+  const int iy = alive0 ? (int)fy0 : R, iz = alive0 ? (int)fz0 : R;
+  uint32_t rs[NR], re[NR];
+  bool rowon[NR];
 #pragma unroll
-  for (int r = 0; r < 9; ++r) {
-    const int dy = (r % 3) - 1, dz = (r / 3) - 1;
+  for (int r = 0; r < NR; ++r) {
+    const int dy = (r % W) - R, dz = (r / W) - R;
     float rx0 = xlo, rx1 = xhi;
     bool on_r = true;
     if (ball) {
-      const float gy = dy == 0 ? 0.0f : fmaxf((dy < 0 ? ey : 1.0f - ey) - 1.0e-3f, 0.0f);
-      const float gz = dz == 0 ? 0.0f : fmaxf((dz < 0 ? ez : 1.0f - ez) - 1.0e-3f, 0.0f);
+      // distance (in cells) from the query to the nearer wall of the row, a rounding slack short
+      const float gy = dy == 0 ? 0.0f : fmaxf((dy < 0 ? ey + (float)(-dy - 1) : (1.0f - ey) + (float)(dy - 1)) - 1.0e-3f, 0.0f);
+      const float gz = dz == 0 ? 0.0f : fmaxf((dz < 0 ? ez + (float)(-dz - 1) : (1.0f - ez) + (float)(dz - 1)) - 1.0e-3f, 0.0f);
       const float w2 = rbcs - (gy * gy + gz * gz);
       on_r = w2 > 0.0f;
       const float w = __builtin_amdgcn_sqrtf(fmaxf(w2, 0.0f)) * (1.0f + 1.0e-5f) + 1.0e-4f;
@@ -139,7 +148,7 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
     rowon[r] = on_r;
     const int jy = iy + dy, jz = iz + dz;
     const int base = G.nx * (jy + G.ny * jz);
-    const int ix0 = alive0 ? (int)rx0 : 1, ix1 = alive0 ? (int)rx1 : 1;
+    const int ix0 = alive0 ? (int)rx0 : R, ix1 = alive0 ? (int)rx1 : R;
     rs[r] = G.cell_start[base + ix0];
     re[r] = G.cell_start[base + ix1 + 1];
   }
@@ -147,8 +156,8 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
   int nrow = 0;
   bool row_overflow = false;
 #pragma unroll
-  for (int r = 0; r < 9; ++r) {
-    const float jy = fy0 + (float)((r % 3) - 1), jz = fz0 + (float)((r / 3) - 1);
+  for (int r = 0; r < NR; ++r) {
+    const float jy = fy0 + (float)((r % W) - R), jz = fz0 + (float)((r / W) - R);
     const bool use = alive0 && rowon[r] && jy >= ylo && jy <= yhi && jz >= zlo && jz <= zhi && re[r] > rs[r];
     if (use) {
       rows[2 * nrow * BLOCK] = rs[r];
@@ -203,7 +212,7 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
     unsigned long long adv, tmp, ama, amb;
     uint32_t t0, t1, key, ida, idb;
     const uint32_t rowaddr = (uint32_t)(uintptr_t)rows;
-    const uint32_t keep = ~GRID_ID_MASK;
+    const uint32_t keep = ~IDM;
 #define LSLAM_GRID_ISSUE(AM, ID, P)                       \
   "s_mov_b64 " AM ", %[am]\n\t"                          \
   "v_mov_b32 " ID ", %[id]\n\t"                          \
@@ -223,7 +232,7 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
   "v_lshlrev_b32 %[t0], 6, %[k]\n\t"                                \
   "v_cndmask_b32 %[id], %[id], %[t0], %[adv]\n\t"                   \
   "v_addc_co_u32 %[k], %[tmp], 0, %[k], %[adv]\n\t"                 \
-  "v_min_i32 %[t0], 8, %[k]\n\t"                                    \
+  "v_min_i32 %[t0], %[nlast], %[k]\n\t"                             \
   "v_lshl_add_u32 %[t0], %[t0], 11, %[rowaddr]\n\t"                 \
   "ds_read2st64_b32 v[10:11], %[t0] offset1:4\n\t"                    \
   "s_waitcnt lgkmcnt(0)\n\t"                                        \
@@ -278,7 +287,8 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
           [ncurb] "+v"(ncurb), [nendb] "+v"(nendb), [id] "+v"(id), [k] "+v"(k), [am] "+s"(am), [adv] "=&s"(adv), [tmp] "=&s"(tmp),
           [ama] "=&s"(ama), [amb] "=&s"(amb), [t0] "=&v"(t0), [t1] "=&v"(t1), [key] "=&v"(key), [ida] "=&v"(ida), [idb] "=&v"(idb),
           [pax] "=&v"(pax), [pay] "=&v"(pay), [paz] "=&v"(paz), [pbx] "=&v"(pbx), [pby] "=&v"(pby), [pbz] "=&v"(pbz), [l0] "=&v"(l0), [l1] "=&v"(l1)
-        : [qx] "v"(qx), [qy] "v"(qy), [qz] "v"(qz), [nrow] "v"(nrow), [rowaddr] "v"(rowaddr), [base] "s"(G.pts), [keep] "s"(keep)
+        : [qx] "v"(qx), [qy] "v"(qy), [qz] "v"(qz), [nrow] "v"(nrow), [rowaddr] "v"(rowaddr), [base] "s"(G.pts), [keep] "s"(keep),
+          [nlast] "n"(NR - 1)
         : "vcc", "scc", "memory");
 #undef LSLAM_GRID_ISSUE
 #undef LSLAM_GRID_ADVANCE
@@ -288,7 +298,7 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
   while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
     const float4 pt = G.pts[alive ? cur : 0u];
     const float dist = dist2_xyz(qx, qy, qz, pt);
-    uint32_t key = (__float_as_uint(dist) & ~GRID_ID_MASK) | id;
+    uint32_t key = (__float_as_uint(dist) & ~IDM) | id;
     key = alive ? key : 0xFFFFFFFFu;
     // six smallest keys, ascending, updated in place from the top: slot i becomes med3(old slot i-1, old slot i, key)
     asm("v_med3_u32 %0, %1, %0, %2" : "+v"(k5) : "v"(k4), "v"(key));
@@ -307,7 +317,7 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
       end = adv ? nend : end;
       id = adv ? (uint32_t)k << GRID_ROW_BITS : id;
       k += adv ? 1 : 0;
-      const int kn = k < 8 ? k : 8;  // (entry 8 may never have been written: only read, never used, in that case)
+      const int kn = k < NR - 1 ? k : NR - 1;  // (the last entry may never have been written: only read, never used, in that case)
       ncur = rows[2 * kn * BLOCK];
       nend = rows[(2 * kn + 1) * BLOCK];
     }
@@ -320,7 +330,7 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     const bool have = ks[j] != 0xFFFFFFFFu;
-    const uint32_t slot = (ks[j] & GRID_ID_MASK) >> GRID_ROW_BITS, off = ks[j] & GRID_ROW_MAX;
+    const uint32_t slot = (ks[j] & IDM) >> GRID_ROW_BITS, off = ks[j] & GRID_ROW_MAX;
     pos[j] = have ? rows[2 * slot * BLOCK] + off : 0u;
   }
 #pragma unroll
@@ -350,7 +360,7 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
     knn_insert_sorted(d, p, e[5], (int)pos[5]);
   }
   // everybody who is not a survivor is at least the sixth key's truncated distance away
-  const float t6 = (k5 != 0xFFFFFFFFu) ? __uint_as_float(k5 & ~GRID_ID_MASK) : FLT_MAX;
+  const float t6 = (k5 != 0xFFFFFFFFu) ? __uint_as_float(k5 & ~IDM) : FLT_MAX;
   lb = fminf(lb, t6);
   if (row_overflow) lb = 0.0f;
   lb6 = fminf(fminf(lb, rg2), clip_lo2);

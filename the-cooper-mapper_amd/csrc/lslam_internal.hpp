@@ -127,6 +127,11 @@ struct SweepArgs {
   float *wide_d;           // [points][5]
   int32_t *wide_p;         // [points][5]
   int32_t *wide_off;       // [nb_total + 1] exclusive prefix of the listed points per pass-1 workgroup (grid_prefix_kernel)
+  // the grid sweep's second level: the points pass 1 listed get a second, wider probe (125 cells, clipped to the ball of what
+  // the first probe saw) by sweep_queue_kernel<..., 3>; what THAT cannot prove is listed again -- same shape as the first
+  // lists, entries = point offset from the group's first point -- and only those few go to the tree search
+  uint16_t *need2_list;    // [nb_total][SWEEP_BLOCK]
+  uint16_t *need2_cnt;     // [nb_total]
   float *grid_hint;        // [points] grid sweep, pass 1 -> pass 2: an upper bound of the fifth neighbour's squared distance of a
                            // point the probe could not prove (the fifth smallest distance it saw, FLT_MAX if it saw fewer than five)
   const float4 *q;  // scan points of all scans, sensor frame, Morton order within a scan
@@ -290,7 +295,7 @@ struct GridDev {
 };
 hipError_t grid_bbox2(const float4 *const pts[2], const int n[2], uint32_t *d_box12, float lo[2][3], float hi[2][3], hipStream_t s);
 hipError_t grid_unsort(const CellGrid &G, float4 *out, hipStream_t s);
-hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t stop, int variant, const CertPlan &plan);
+hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t stop, int variant, const CertPlan &plan, int level = 0);
 hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s,
                         hipEvent_t start = nullptr, hipEvent_t stop = nullptr, int *variant = nullptr, bool *cert_launched = nullptr);
 hipError_t launch_solve(const SolveArgs &a, hipStream_t s);

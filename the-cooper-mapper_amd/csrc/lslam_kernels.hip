@@ -361,6 +361,66 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
   static_assert(GRIDQ == 0 || CERT == 2, "GRIDQ is a mode of the second pass");
   constexpr bool grid = GRIDQ != 0;
   bool track = CERT == 2 && !grid && a.prev_q != nullptr;  // ... which keeps the bound the next sweep's certificate needs
+  if (GRIDQ == 3) {
+    // The grid sweep's SECOND probe: this lane's point is one the 27-cell probe could not prove (q_item).  125 cells now --
+    // guaranteed radius c (2 + wall) -- clipped to the ball of what is known about the point: the fifth distance the first probe
+    // saw, the carried bound, the gate.  Proven: the residual chain below.  Still unproven (a sparser neighbourhood yet, an
+    // exact tie): listed once more, at this work item's fixed place, for the tree search.
+    static_assert(GRIDQ != 3 || (2 * LDS_DEPTH >= 50 && BLOCK == 256), "the second probe's row table: 25 runs per lane");
+    __shared__ int wave_needy2[NWAVE];
+    CellGrid G;
+    G.cell_start = is_surf ? a.ks.cell_start : a.kc.cell_start;
+    G.pts = is_surf ? a.ks.pts : a.kc.pts;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) G.org[i] = is_surf ? a.ks.org[i] : a.kc.org[i];
+    G.inv_c = is_surf ? a.ks.inv_c : a.kc.inv_c;
+    G.c = is_surf ? a.ks.c : a.kc.c;
+    G.nx = is_surf ? a.ks.nx : a.kc.nx;
+    G.ny = is_surf ? a.ks.ny : a.kc.ny;
+    G.nz = is_surf ? a.ks.nz : a.kc.nz;
+    G.n_pts = is_surf ? a.ks.n_pts : a.kc.n_pts;
+    if (active) q = a.q[qi];
+    sel[0] = ((R[0] * q.x + R[1] * q.y) + R[2] * q.z) + t[0];
+    sel[1] = ((R[3] * q.x + R[4] * q.y) + R[5] * q.z) + t[1];
+    sel[2] = ((R[6] * q.x + R[7] * q.y) + R[8] * q.z) + t[2];
+    float bound2 = a.bounded ? 5.0f * (1.0f + 1e-5f) : FLT_MAX;
+    if (active) {
+      if (a.bounded && prev_valid) bound2 = fminf(bound2, grid_carried_bound(a.prev_q[qi], sel));
+      if (a.grid_hint) bound2 = fminf(bound2, a.grid_hint[qi]);
+    }
+    // A point that is known to have five neighbours within two cells is worth the wider probe (the ball it scans is no
+    // bigger than the first probe's block); one that is not -- the first probe saw fewer than five, or its fifth far out --
+    // would scan all 125 cells, hundreds of candidates, with its wavefront waiting: the tree search is the tool for those.
+    const float worth = (2.0f * G.c) * (2.0f * G.c);
+    const bool probe = active && bound2 < worth;
+    float lb6u;
+    int verdict = knn5_grid<BLOCK, 2>(G, probe, sel[0], sel[1], sel[2], bound2, a.grid_clip_margin, (lds_u32 *)(stack_lds + tid), d, p, lb6u);
+    if (verdict == GRID_FAR && !a.bounded) verdict = GRID_UNPROVEN;
+    const bool needy2 = active && (!probe || verdict == GRID_UNPROVEN);
+    const unsigned long long m2 = __ballot(needy2);
+    if (lane == 0) wave_needy2[wave] = __popcll(m2);
+    __syncthreads();
+    int off2 = 0, total2 = 0;
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) {
+      const int c2 = wave_needy2[w];
+      off2 += w < wave ? c2 : 0;
+      total2 += c2;
+    }
+    if (needy2) {
+      a.need2_list[(size_t)lb * BLOCK + off2 + __popcll(m2 & ((1ull << lane) - 1ull))] = (uint16_t)(qi - bd.first);
+      if (a.grid_hint && probe && d[4] < 1.0e30f) a.grid_hint[qi] = fminf(a.grid_hint[qi], d[4] * (1.0f + 1e-5f) + 1e-12f);
+    }
+    if (tid == 0) {
+      a.need2_cnt[lb] = (uint16_t)total2;
+      if (a.cert_stats) atomicAdd(a.cert_stats + 2, (unsigned long long)total2);  // debug tap: points left to the tree search
+    }
+    if (active && !needy2 && a.bounded)
+      a.prev_q[qi] = make_float4(sel[0], sel[1], sel[2], (verdict == GRID_PROVEN && d[4] < 5.0f) ? d[4] : FLT_MAX);
+    active = active && !needy2;
+    do_search = false;
+    __syncthreads();  // the row table is dead: its words become the staging rows of the contraction
+  }
   if (CERT == 1) {
     static_assert(CERT != 1 || (!PACKET && !CUBES && !STATE_LDS && BLOCK <= 256), "certificate pass: whole-map lane search, byte lists");
     // the last update of this scan, as the largest displacement of a point within CERT_RANGE_M of the sensor [m]
@@ -445,7 +505,7 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
   }
 
   if (active) {
-    if (!PACKET && do_search) {
+    if (!PACKET && do_search && GRIDQ != 3) {
     q = a.q[qi];
     // util/transform_utils.h:476-482 pointAssociateToMap: it * p
     sel[0] = ((R[0] * q.x + R[1] * q.y) + R[2] * q.z) + t[0];
@@ -486,7 +546,7 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
       sel[2] = ((R[6] * q.x + R[7] * q.y) + R[8] * q.z) + t[2];
       if (a.bounded) a.prev_q[qi] = make_float4(sel[0], sel[1], sel[2], (p[4] >= 0 && d[4] < 5.0f) ? d[4] : FLT_MAX);
     }
-    if (GRIDQ != 2 && do_search) {
+    if (GRIDQ != 2 && GRIDQ != 3 && do_search) {
     KdStack<BLOCK, OVF, LDS_DEPTH> stk;
     stk.lds = (lds_u32 *)(stack_lds + tid);
     stk.ovf = OVF ? a.stack_ovf + ((size_t)lb * BLOCK + tid) : nullptr;  // lb: unique per workgroup of a launch, < nb_total
@@ -562,7 +622,7 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
     (void)searched;
     if (a.dbg) dbg_t1 = __builtin_readcyclecounter();
 
-    point_residual(a, bd, is_surf, GRIDQ == 2 ? (is_surf ? a.ks.pts : a.kc.pts) : T.pts, q, sel, d, p, sc, row, rb, kept, matched, score);
+    point_residual(a, bd, is_surf, (GRIDQ == 2 || GRIDQ == 3) ? (is_surf ? a.ks.pts : a.kc.pts) : T.pts, q, sel, d, p, sc, row, rb, kept, matched, score);
   }
 
   if (a.dbg) dbg_t2 = __builtin_readcyclecounter();
@@ -1075,7 +1135,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
 // cert_plan_kernel, one thread per group: how many chunks of BLOCK listed points the group's pass-1 workgroups left (none for
 // a scan whose loop has ended), and that many work items (group, chunk) appended to the work list.  The order of the list
 // depends on the order of the atomics; nothing else does -- an item's sums go to a place of its own.
-__global__ __launch_bounds__(256) void cert_plan_kernel(SweepArgs a, CertPlan plan) {
+// level 0: the first-level lists (need_cnt); when second-level lists exist their counts are zeroed here, so that a block no
+// work item of the second probe is made for reads as empty.  level 1: the second-level lists (need2_cnt).
+__global__ __launch_bounds__(256) void cert_plan_kernel(SweepArgs a, CertPlan plan, int level) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g == 0) {  // the counters of the NEXT plan (they alternate)
     *plan.count_next = 0;
@@ -1087,7 +1149,10 @@ __global__ __launch_bounds__(256) void cert_plan_kernel(SweepArgs a, CertPlan pl
   if (a.fine_gate_c >= 0.0f ? !a.states[gd.prob].converged : a.states[gd.prob].done) return;
   const int fb = gd.first_block - a.group_block_base;
   int total = 0;
-  for (int k = 0; k < gd.n_blocks; ++k) total += (int)a.need_cnt[fb + k];
+  for (int k = 0; k < gd.n_blocks; ++k) {
+    total += level ? (int)a.need2_cnt[fb + k] : (int)a.need_cnt[fb + k];
+    if (!level && a.need2_cnt) a.need2_cnt[fb + k] = 0;
+  }
   const int nch = (total + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
   if (nch == 0) return;
   const int at = atomicAdd(plan.count, nch);
@@ -1100,8 +1165,9 @@ __global__ __launch_bounds__(256) void cert_plan_kernel(SweepArgs a, CertPlan pl
 // -- as many as the sweep itself has, nearly all of them leaving at once -- cost 0.25 ms per launch, more than the last
 // sweeps of a batch themselves.  The argument block is re-read through a laundered pointer in every turn: left to itself the
 // compiler carries the sweep's invariants across the loop in registers it does not have (124 bytes of scratch per lane).
-template <int BLOCK, bool OVF, int LDS_DEPTH, int GRIDQ = 0>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH <= 16 ? LSLAM_SHALLOW_OCC : 2))) void sweep_queue_kernel(const SweepArgs a_in, const int jtj_mode_in, const CertPlan plan) {
+// LIST2: the work items are chunks of the SECOND-level lists (need2_list: point offsets from the group's first point).
+template <int BLOCK, bool OVF, int LDS_DEPTH, int GRIDQ = 0, bool LIST2 = false>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(GRIDQ == 3 ? 3 : (LDS_DEPTH <= 16 ? LSLAM_SHALLOW_OCC : 2)))) void sweep_queue_kernel(const SweepArgs a_in, const int jtj_mode_in, const CertPlan plan) {
   __shared__ float red[BLOCK / 64][NCOL];
   __shared__ uint32_t stack_lds[2 * LDS_DEPTH * BLOCK];
   __shared__ int next_w;
@@ -1116,6 +1182,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
     int jtj_mode = jtj_mode_in;
     asm volatile("" : "+s"(a.q), "+s"(a.blocks), "+s"(a.states), "+s"(a.partials), "+s"(a.prev_nb), "+s"(a.prev_q), "+s"(a.prev_lb), "+s"(jtj_mode));
     asm volatile("" : "+s"(a.tc.nodes), "+s"(a.tc.pts), "+s"(a.ts.nodes), "+s"(a.ts.pts), "+s"(a.stack_ovf), "+s"(a.need_list), "+s"(a.need_cnt), "+s"(a.groups));
+    asm volatile("" : "+s"(a.need2_list), "+s"(a.need2_cnt), "+s"(a.grid_hint));
     const int item_id = __builtin_amdgcn_readfirstlane(plan.work[w]);
     const int g = item_id / CERT_GROUP, c = item_id % CERT_GROUP;
     GroupDesc gd = a.groups[g];
@@ -1126,7 +1193,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
     int pre[CERT_GROUP + 1];
     pre[0] = 0;
 #pragma unroll
-    for (int k = 0; k < CERT_GROUP; ++k) pre[k + 1] = pre[k] + (k < gd.n_blocks ? __builtin_amdgcn_readfirstlane((int)a.need_cnt[fb + k]) : 0);
+    for (int k = 0; k < CERT_GROUP; ++k)
+      pre[k + 1] = pre[k] + (k < gd.n_blocks ? __builtin_amdgcn_readfirstlane(LIST2 ? (int)a.need2_cnt[fb + k] : (int)a.need_cnt[fb + k]) : 0);
     const int total = pre[CERT_GROUP];
     BlockDesc bd = a.blocks[fb];
     bd.prob = gd.prob;
@@ -1143,7 +1211,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
         k = in ? j : k;
         p0 = in ? pre[j] : p0;
       }
-      item = a.blocks[fb + k].first + (int)a.need_list[(size_t)(fb + k) * BLOCK + (i - p0)];
+      if (LIST2) item = a.blocks[fb].first + (int)a.need2_list[(size_t)(fb + k) * BLOCK + (i - p0)];
+      else item = a.blocks[fb + k].first + (int)a.need_list[(size_t)(fb + k) * BLOCK + (i - p0)];
     }
     sweep_body<BLOCK, OVF, false, LDS_DEPTH, false, false, false, 2, GRIDQ>(a, jtj_mode, fb + c, bd, st, stack_lds, red, a.partials + (size_t)(fb + c) * NCOL, a.prev_valid, item);  // (the certificate sweep's second pass only runs with prev_valid set; the grid sweep's runs in a loop's first sweep too)
     __syncthreads();  // red and the stack columns are free again
@@ -1218,13 +1287,30 @@ hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEven
   return hipGetLastError();
 }
 
-hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t stop, int variant, const CertPlan &plan) {
+hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t stop, int variant, const CertPlan &plan, int level) {
   if (a.n_groups <= 0) return hipSuccess;
-  hipLaunchKernelGGL(cert_plan_kernel, dim3((a.n_groups + 255) / 256), dim3(256), 0, s, a, plan);
+  hipLaunchKernelGGL(cert_plan_kernel, dim3((a.n_groups + 255) / 256), dim3(256), 0, s, a, plan, level);
   // as many workgroups as stay resident (256 CUs x five of the shallow kernel, two of the deep ones), never more than items possible
   constexpr int SHALLOW = LSLAM_SHALLOW_DEPTH;
   const long possible = (long)a.nb_total;
   const dim3 b(SWEEP_BLOCK);
+  if (a.grid == 1 && a.need2_cnt && level == 0) {  // the grid sweep's second probe (no tree search in it: its LDS is the 25-run row table)
+    const dim3 g((unsigned)std::min<long>(possible, 256 * 3));
+    hipExtLaunchKernelGGL((sweep_queue_kernel<SWEEP_BLOCK, true, 25, 3>), g, b, 0, s, nullptr, stop, 0, a, jtj_mode, plan);
+    return hipGetLastError();
+  }
+  if (a.grid == 1 && a.need2_cnt && level == 1) {  // ... and the tree search of what it listed
+    if (variant == SWEEP_VARIANT_SHALLOW) {
+      hipExtLaunchKernelGGL((sweep_queue_kernel<SWEEP_BLOCK, true, SHALLOW, 1, true>), dim3((unsigned)std::min<long>(possible, 256 * 5)), b, 0, s, nullptr, stop, 0, a, jtj_mode, plan);
+    } else if (variant == SWEEP_VARIANT_DEEP_OVF) {
+      hipExtLaunchKernelGGL((sweep_queue_kernel<SWEEP_BLOCK, true, KD_STACK_LDS, 1, true>), dim3((unsigned)std::min<long>(possible, 256 * 2)), b, 0, s, nullptr, stop, 0, a, jtj_mode, plan);
+    } else if (variant == SWEEP_VARIANT_DEEP) {
+      hipExtLaunchKernelGGL((sweep_queue_kernel<SWEEP_BLOCK, false, KD_STACK_LDS, 1, true>), dim3((unsigned)std::min<long>(possible, 256 * 2)), b, 0, s, nullptr, stop, 0, a, jtj_mode, plan);
+    } else {
+      return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   if (a.grid == 2) {  // neighbours given (a map without trees): no search, no stack -- the shallow shape's LDS is plenty
     const dim3 g((unsigned)std::min<long>(possible, 256 * 5));
     hipExtLaunchKernelGGL((sweep_queue_kernel<SWEEP_BLOCK, true, SHALLOW, 2>), g, b, 0, s, nullptr, stop, 0, a, jtj_mode, plan);

@@ -287,3 +287,49 @@ def test_deferred_trees_fall_back_to_the_trees_on_exact_ties(pkg, synth):
     assert res[False][0] == res[True][0] and res[False][2:] == res[True][2:]
     assert np.array_equal(bits(res[False][1]), bits(res[True][1]))
     assert res[True][3] > 100
+
+
+def test_grid_limits_fall_back_to_the_tree(pkg, ctx):
+    """What the grid cannot take is searched by the tree, silently and exactly: (a) a blob denser than a row's candidate
+    counter (more than 64 points in a run of three cells) -- every probe there is 'unproven'; (b) a map whose extent exceeds
+    the cell table's limit (2 048 cells per axis): no grid is built at all -- the tap says so, a scan match asked for the grid
+    sweep runs the kd-tree walk, and deferring the trees of such a map builds them at once."""
+    rng = np.random.default_rng(11)
+    blob = rng.uniform(-4, 4, (150000, 3)).astype(np.float32)        # ~ 60 points per 0.6 m cell
+    ctx.map_set(blob, blob)
+    q = rng.uniform(-3, 3, (3000, 3)).astype(np.float32)
+    li, ld = ctx.knn5(1, q, search_mode=LANE)
+    gi, gd, n_un = ctx.knn5(1, q, search_mode=GRID, want_ties=True)
+    assert np.array_equal(gi, li) and np.array_equal(bits(gd), bits(ld)) and n_un > 0.9 * len(q)
+    # (b)
+    line = np.stack([np.linspace(-900.0, 900.0, 4000), np.zeros(4000), np.zeros(4000)], 1).astype(np.float32)
+    wide = np.concatenate([line, line + np.array([0, 0.4, 0], np.float32), line + np.array([0, 0.8, 0.3], np.float32)]).astype(np.float32)
+    ctx.map_set(wide, wide)
+    with pytest.raises(pkg.LslamError):
+        ctx.knn5(1, wide[:10], search_mode=GRID)
+    scan = (wide[::7] + np.array([0.02, 0.01, 0.0], np.float32)).astype(np.float32)
+    ctx.scan_set(scan[:200], scan)
+    o = ctx.default_opts()
+    o.search_mode = GRID
+    g0 = ctx.grid_launches()
+    s_g, p_g, st_g = ctx.run(np.zeros(6, np.float32), o)
+    o.search_mode = LANE
+    s_l, p_l, st_l = ctx.run(np.zeros(6, np.float32), o)
+    assert ctx.grid_launches() == g0 and np.array_equal(bits(p_g), bits(p_l)) and st_g.iterations == st_l.iterations
+    c2 = pkg.Context(0)
+    try:
+        c2.defer_trees(True)
+        fm = pkg.FeatureMap(c2, 121, 121, 11)
+        fm.setup_filter_size(0.05, 0.05, 0.05)
+        fm.setup_lidar_valid_distance(2000.0) if hasattr(fm, "setup_lidar_valid_distance") else None
+        fm.update(np.zeros(3, np.float32))
+        wide4 = np.c_[wide, np.zeros(len(wide), np.float32)].astype(np.float32)
+        fm.add_feature_cloud(wide4, wide4, np.eye(4, dtype=np.float32))
+        fm.surround_to_map()
+        sets, builds, pending = c2.lazy_trees()
+        info = c2.map_info()
+        # either the surround is small enough for a grid (deferred) or it is not (built at once): never a map without a search structure
+        assert pending == (info.depth_surf == 0) and (pending or info.depth_surf > 0)
+        fm.close()
+    finally:
+        c2.close()

@@ -176,7 +176,10 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
   uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu, k4 = 0xFFFFFFFFu, k5 = 0xFFFFFFFFu;
   uint32_t cur = 0, end = 0, id = 0;
   int k = 0;
-  bool alive = nrow > 0;
+  // (a lane with an over-long run is unproven whatever it finds: it sits the loop out -- its candidate ids would overflow
+  // into the row-slot bits, and a survivor's place must never be decoded from such a key)
+  bool alive = nrow > 0 && !row_overflow;
+  if (row_overflow) nrow = 0;
   if (alive) {
     cur = rows[0];
     end = rows[BLOCK];

@@ -565,7 +565,8 @@ size_t lslam_pg_system_doubles(const lslam_pg *pg);
  * takes a range of vertex ROWS [v_begin, v_end) -- whole 21-vertex row blocks, lslam_pg_row_shard_range gives an even
  * partition -- and the damped system is then solved by a row-sharded block-Jacobi PCG: each rank multiplies, updates and
  * preconditions its own rows; per iteration the ranks exchange one scalar (p . A p) and the vector z with r . z, r . r behind it
- * (each rank's rows in a zero-padded buffer of 6 n + 2 doubles: its all-reduce IS the gather), through the same transport as
+ * (each rank's rows in a zero-padded buffer of 6 n + 2 doubles: its all-reduce IS the gather; or a true all-gather, see
+ * lslam_pg_set_row_gather below), through the same transport as
  * the linearisation (callback or RCCL communicator; the buffer is the tail of the system buffer).  Same iterates as the
  * single-process block-Jacobi solve up to the order of the sums.  The dense second level of the preconditioner is a
  * single-device structure: it is not used (and does not switch itself on) in this mode; with LSLAM_PG_COARSE=1 the solve
@@ -573,6 +574,17 @@ size_t lslam_pg_system_doubles(const lslam_pg *pg);
 void lslam_pg_row_shard_range(int32_t n_vertices, int32_t rank, int32_t world, int32_t *v_begin, int32_t *v_end);
 int lslam_pg_set_row_shard(lslam_pg *pg, int32_t v_begin, int32_t v_end);
 int32_t lslam_pg_row_sharded_solves(const lslam_pg *pg); /* damped solves that took the row-sharded form so far */
+/* The exchange of z as an ALL-GATHER of the owned segments instead of the zero-padded all-reduce (half the bytes on the wire,
+ * no zeroing pass): taken whenever every rank's rows are lslam_pg_row_shard_range's partition -- each rank can then name every
+ * segment without asking -- and the transport can gather.  The RCCL communicator (lslam_pg_set_comm) can: one ncclBroadcast per
+ * segment rooted at its owner, all in one group = one launch; each rank's parts of r . z and r . r travel in the same group
+ * and are summed in rank order on every rank (same bits everywhere).  A host with its own transport registers a second
+ * callback type: in-place, segment r of buf = doubles [offsets[r], offsets[r + 1]), valid on rank r on entry and on every
+ * rank on return; complete when it returns.  Ranges that are not the canonical partition, or no gather transport: the
+ * all-reduce form.  At most 64 ranks. */
+typedef void (*lslam_allgatherv_fn)(void *user, double *buf, const int64_t *offsets, int32_t world);
+int lslam_pg_set_row_gather(lslam_pg *pg, lslam_allgatherv_fn fn, void *user, int32_t rank, int32_t world);
+int32_t lslam_pg_row_gathered_solves(const lslam_pg *pg); /* ... of which exchanged by all-gather */
 int32_t lslam_pg_num_offdiag(const lslam_pg *pg);
 /* SolverG2O::optimize (solver_g2o.cpp:79-95): up to max_iters LM iterations. */
 int lslam_pg_optimize(lslam_pg *pg, int32_t max_iters, lslam_pg_stats *stats);

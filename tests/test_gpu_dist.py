@@ -118,6 +118,33 @@ def _worker(rank, world, port, q):
         lam = 1e-2 * float(np.abs(lin["diag"]).max())
         dx, its = pgr.solve(lam)
         res["rs_dx"], res["rs_its"], res["rs_solves"], res["rs_rows"] = dx, its, pgr.row_sharded_solves(), (vb, ve)
+        res["rs_gathered"] = pgr.row_gathered_solves()
+        # ... and the same solve with z exchanged by an ALL-GATHER of the owned segments (lslam_pg_set_row_gather; with the RCCL
+        # communicator the library takes this form by itself): the same iterates, only the two scalar sums are formed in
+        # rank order instead of by the transport
+        base3 = sysbuf3.data_ptr()
+        seen = {"calls": 0, "doubles": 0}
+
+        def allgatherv(ptr, offs, w):
+            off = (ptr - base3) // 8
+            for r in range(w):
+                seg = sysbuf3[off + offs[r]:off + offs[r + 1]]
+                h = seg.cpu()
+                dist.broadcast(h, src=r)
+                if r != rank:
+                    seg.copy_(h)
+            torch.cuda.synchronize()
+            seen["calls"] += 1
+            seen["doubles"] += offs[w] - offs[0]
+        pgr.set_row_gather(allgatherv, rank, world)
+        dxg, itsg = pgr.solve(lam)
+        res["rg_dx"], res["rg_its"], res["rg_gathered"], res["rg_calls"] = dxg, itsg, pgr.row_gathered_solves(), seen["calls"]
+        # rows that are NOT the canonical partition: the all-reduce form again (the ranks cannot name each other's segments)
+        if world == 2:
+            cut = 21 * 1000
+            pgr.set_row_shard(0 if rank == 0 else cut, cut if rank == 0 else len(gb["init"]))
+            dxo, itso = pgr.solve(lam)
+            res["ro_dx"], res["ro_its"], res["ro_gathered"] = dxo, itso, pgr.row_gathered_solves()
         pgr.close()
         if rank == 0:
             pg1 = pkg.PoseGraph(0)
@@ -169,6 +196,16 @@ def test_sharded_paths_under_a_real_process_group():
     assert np.array_equal(r0["rs_dx"], r1["rs_dx"]) and r0["rs_its"] == r1["rs_its"] == r0["rs_full_its"]
     assert 3 < r0["rs_its"] < 4000
     assert np.abs(r0["rs_dx"] - r0["rs_full"]).max() <= 1e-10 * np.abs(r0["rs_full"]).max()
+    # the all-gather form: taken once on both ranks (not before it was registered), two callback gathers (z, partial sums) per iteration plus the solution's,
+    # same bits on both ranks, the all-reduce form's answer
+    assert r0["rs_gathered"] == 0 and r0["rg_gathered"] == 1 and r1["rg_gathered"] == 1
+    # (the loop enqueues 50 iterations between convergence checks: the iterations after the stop are empty launches + exchanges)
+    assert r0["rg_calls"] == r1["rg_calls"] == 2 * 50 * ((r0["rg_its"] + 49) // 50) + 1
+    assert np.array_equal(r0["rg_dx"], r1["rg_dx"]) and abs(r0["rg_its"] - r0["rs_its"]) <= 2
+    assert np.abs(r0["rg_dx"] - r0["rs_full"]).max() <= 1e-10 * np.abs(r0["rs_full"]).max()
+    # a partition of the ranks' own choosing: all-reduce form (no further gathered solve), same answer
+    assert r0["ro_gathered"] == 1 and r1["ro_gathered"] == 1 and np.array_equal(r0["ro_dx"], r1["ro_dx"])
+    assert np.abs(r0["ro_dx"] - r0["rs_full"]).max() <= 1e-10 * np.abs(r0["rs_full"]).max()
 
 
 def test_rccl_communicator_world_of_one(pkg, ctx, small_problem):
@@ -203,12 +240,14 @@ def test_rccl_communicator_world_of_one(pkg, ctx, small_problem):
         assert np.abs(res[0][0] - res[1][0]).max() < 1e-10 and abs(res[0][1] - res[1][1]) <= 1e-10 * res[0][1]
         # the row-sharded solve through RCCL (a world of one owns every row): whole LM runs, ncclAllReduce of the exchange area
         # on the solver's stream twice per PCG iteration
+        # (one scalar all-reduce, then the grouped ncclBroadcast all-gather of z and the partial sums)
         pg = pkg.PoseGraph(0)
         pg.set_graph(g["init"], g["ij"], g["meas"], g["info"])
         pg.set_comm(comm, 0, len(g["ij"]))
         pg.set_row_shard(*pg.row_shard_range(0, 1))
         pg.optimize(6)
         assert pg.row_sharded_solves() >= 6
+        assert pg.row_gathered_solves() == pg.row_sharded_solves()  # with a communicator the exchange is the grouped all-gather
         assert np.abs(pg.poses() - res[0][0]).max() < 1e-7 and abs(pg.last_stats.chi2_final - res[0][1]) <= 1e-8 * res[0][1]
         with pytest.raises(Exception):  # a rank without rows (more ranks than 21-vertex row blocks) is refused, not launched
             pg.set_row_shard(0, 0)

@@ -124,6 +124,7 @@ class LslamPgStats(C.Structure):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
+ALLGATHERV_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32)
 c_double_p = C.POINTER(C.c_double)
 
 # every symbol include/lslam_c.h declares: name -> (restype, argtypes)
@@ -220,6 +221,8 @@ SYMBOLS = {
     "lslam_pg_row_shard_range": (None, [C.c_int32, C.c_int32, C.c_int32, c_int32_p, c_int32_p]),
     "lslam_pg_set_row_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "lslam_pg_row_sharded_solves": (C.c_int32, [C.c_void_p]),
+    "lslam_pg_row_gathered_solves": (C.c_int32, [C.c_void_p]),
+    "lslam_pg_set_row_gather": (C.c_int, [C.c_void_p, ALLGATHERV_FN, C.c_void_p, C.c_int32, C.c_int32]),
     "lslam_pg_num_offdiag": (C.c_int32, [C.c_void_p]),
     "lslam_pg_optimize": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(LslamPgStats)]),
     "lslam_pg_get_poses": (C.c_int, [C.c_void_p, c_double_p]),

@@ -30,6 +30,9 @@ struct Rccl {
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   decltype(&ncclCommCount) CommCount = nullptr;
   decltype(&ncclCommUserRank) CommUserRank = nullptr;
@@ -55,6 +58,7 @@ bool load_rccl() {
   g_rccl.f = reinterpret_cast<decltype(g_rccl.f)>(dlsym(g_rccl.handle, "nccl" #f)); \
   if (!g_rccl.f) { lslam::set_error("librccl lacks nccl" #f); return false; }
   SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(AllReduce) SYM(GetErrorString) SYM(CommCount) SYM(CommUserRank)
+  SYM(Broadcast) SYM(GroupStart) SYM(GroupEnd)
 #undef SYM
   g_rccl.ok = true;
   return true;
@@ -80,6 +84,27 @@ hipError_t comm_allreduce_f64(lslam_comm *c, double *buf, size_t count, hipStrea
   const ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclDouble, ncclSum, c->comm, s);
   if (r != ncclSuccess) {
     nccl_fail("ncclAllReduce", r);
+    return hipErrorUnknown;
+  }
+  return hipSuccess;
+}
+// In-place all-gather of UNEQUAL segments (ncclAllGather wants equal ones): one ncclBroadcast per segment, rooted at its owner,
+// all inside ONE group -- RCCL fuses a group into a single launch, so the latency is that of one collective.  n_lists buffers
+// share the group (the row-sharded PCG gathers the vector z and, behind it, two partial sums per rank).
+hipError_t comm_allgatherv_f64(lslam_comm *c, int n_lists, double *const *bufs, const int64_t *const *offs, hipStream_t s) {
+  if (!c || !c->comm) return hipErrorInvalidValue;
+  ncclResult_t r = g_rccl.GroupStart();
+  if (r != ncclSuccess) { nccl_fail("ncclGroupStart", r); return hipErrorUnknown; }
+  for (int l = 0; l < n_lists && r == ncclSuccess; ++l)
+    for (int root = 0; root < c->world && r == ncclSuccess; ++root) {
+      const int64_t len = offs[l][root + 1] - offs[l][root];
+      if (len <= 0) continue;
+      double *seg = bufs[l] + offs[l][root];
+      r = g_rccl.Broadcast(seg, seg, (size_t)len, ncclDouble, root, c->comm, s);
+    }
+  const ncclResult_t r2 = g_rccl.GroupEnd();
+  if (r != ncclSuccess || r2 != ncclSuccess) {
+    nccl_fail("ncclBroadcast (grouped all-gather)", r != ncclSuccess ? r : r2);
     return hipErrorUnknown;
   }
   return hipSuccess;

@@ -336,6 +336,7 @@ struct lslam_comm;
 namespace lslam {
 // lslam_comm.hip: in-place fp64 SUM over the ranks of `comm`, enqueued on `s`
 hipError_t comm_allreduce_f64(lslam_comm *comm, double *buf, size_t count, hipStream_t s);
+hipError_t comm_allgatherv_f64(lslam_comm *comm, int n_lists, double *const *bufs, const int64_t *const *offs, hipStream_t s);
 int comm_world(const lslam_comm *comm);
 int comm_rank(const lslam_comm *comm);
 int map_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t n_corner, const float4 *d_surf, size_t n_surf);

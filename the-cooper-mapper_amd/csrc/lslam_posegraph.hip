@@ -32,6 +32,9 @@
 
 namespace lslam {  // lslam_comm.hip
 hipError_t comm_allreduce_f64(lslam_comm *comm, double *buf, size_t count, hipStream_t s);
+hipError_t comm_allgatherv_f64(lslam_comm *comm, int n_lists, double *const *bufs, const int64_t *const *offs, hipStream_t s);
+int comm_world(const lslam_comm *comm);
+int comm_rank(const lslam_comm *comm);
 }
 
 namespace {
@@ -614,6 +617,13 @@ __global__ void pg_rs_zero_others_kernel(double *v, int n6, int row_begin, int r
 __global__ void pg_rs_pack_kernel(const double *src, double *dst, int n6, int row_begin, int row_end) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row < n6) dst[row] = (row >= row_begin && row < row_end) ? src[row] : 0.0;
+}
+__global__ void pg_rs_tail_sum_kernel(double *sums /* [rz, rr] */, const double *tail /* per rank: rz, rr */, int world) {
+  if (threadIdx.x < 2) {  // in rank order on every rank: the same bits everywhere
+    double s = 0.0;
+    for (int r = 0; r < world; ++r) s += tail[2 * r + threadIdx.x];
+    sums[threadIdx.x] = s;
+  }
 }
 __global__ void pg_rs_copy_kernel(const double *src, double *d0, double *d1, double *d2) {  // up to three scalars to their slots
   if (threadIdx.x == 0) {
@@ -1568,6 +1578,26 @@ struct lslam_pg {
     }
     return lslam::comm_allreduce_f64(comm, buf, count, stream) == hipSuccess ? LSLAM_OK : LSLAM_ERR_COMM;
   }
+  // the row-sharded solve's exchange as an all-gather of the owned segments (half the bytes of the zero-padded all-reduce):
+  // through the communicator when there is one, else through a callback of its own type (lslam_pg_set_row_gather)
+  lslam_allgatherv_fn gatherv = nullptr;
+  void *gatherv_user = nullptr;
+  int gatherv_rank = -1, gatherv_world = 0;
+  int rs_gathered = 0;
+  // rank / world of whichever transport can gather; false: only the all-reduce is available
+  bool gather_transport(int *rank, int *world) const {
+    if (gatherv) { *rank = gatherv_rank; *world = gatherv_world; return true; }
+    if (!allreduce && comm) { *rank = lslam::comm_rank(comm); *world = lslam::comm_world(comm); return true; }
+    return false;
+  }
+  int gather(int n_lists, double *const *bufs, const int64_t *const *offs, int world) {
+    if (gatherv) {
+      if (hipStreamSynchronize(stream) != hipSuccess) return LSLAM_ERR_HIP;
+      for (int l = 0; l < n_lists; ++l) gatherv(gatherv_user, bufs[l], offs[l], world);  // contract: complete when it returns
+      return LSLAM_OK;
+    }
+    return lslam::comm_allgatherv_f64(comm, n_lists, bufs, offs, stream) == hipSuccess ? LSLAM_OK : LSLAM_ERR_COMM;
+  }
   // graph
   double *d_poses = nullptr, *d_trial = nullptr, *d_meas = nullptr, *d_info = nullptr;
   int32_t *d_ij = nullptr;
@@ -1618,10 +1648,11 @@ struct lslam_pg {
   int row_v0 = -1, row_v1 = -1;
   std::vector<int32_t> h_row_ptr;
   int rs_solves = 0;
-  // [diag | off | b | chi2 | fallback flag | exchange area of the row-sharded solve: 6 n_v + 8]: the system part is all-reduced
+  // [diag | off | b | chi2 | fallback flag | exchange area of the row-sharded solve: 6 n_v + 8 + two partial sums per rank]: the system part is all-reduced
   // per linearisation, chi2 + flag per trial, the exchange area per PCG iteration of a row-sharded solve
   size_t core_doubles() const { return (size_t)n_v * 36 + (size_t)n_off * 36 + (size_t)n_v * 6 + 2; }
-  size_t sys_doubles() const { return core_doubles() + (size_t)n_v * 6 + 8; }
+  static constexpr int RS_MAX_WORLD = 64;  // ranks whose partial sums the exchange area has room for (gather mode)
+  size_t sys_doubles() const { return core_doubles() + (size_t)n_v * 6 + 8 + 2 * RS_MAX_WORLD; }
   double *xchg() const { return d_sys + core_doubles(); }
   double *diag() const { return d_sys; }
   double *off() const { return d_sys + (size_t)n_v * 36; }
@@ -1841,8 +1872,29 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
     a.block_begin = r0 / CG_ROWS;
     const int nb_rows = (r1 - a.block_begin * CG_ROWS + CG_ROWS - 1) / CG_ROWS;   // row blocks of this rank
     const int nb_items = (a.item_end - a.item_begin + PROD_BLOCK - 1) / PROD_BLOCK;  // item blocks of this rank
-    double *X = pg->xchg();  // [z (6 n_v) | rz | rr | pq | ...]
+    double *X = pg->xchg();  // [z (6 n_v) | rz | rr | pq | ... (8) | per rank: its part of rz, rr]
     double *z_own = a.z;     // init runs replicated on the ordinary z
+    // The exchange: an all-gather of the owned segments when the transport has one and the ranks' rows are the canonical
+    // partition (every rank can then name every segment without asking); else the zero-padded all-reduce.
+    int g_rank = 0, g_world = 1;
+    bool gather = pg->gather_transport(&g_rank, &g_world) && g_world >= 1 && g_world <= lslam_pg::RS_MAX_WORLD;
+    std::vector<int64_t> z_offs, s_offs;
+    if (gather) {
+      int cb = 0, ce = 0;
+      lslam_pg_row_shard_range(pg->n_v, g_rank, g_world, &cb, &ce);
+      gather = cb == v0 && ce == v1;
+      z_offs.resize((size_t)g_world + 1);
+      s_offs.resize((size_t)g_world + 1);
+      for (int r = 0; r <= g_world; ++r) {
+        int b = pg->n_v, e = pg->n_v;
+        if (r < g_world) lslam_pg_row_shard_range(pg->n_v, r, g_world, &b, &e);
+        z_offs[(size_t)r] = (int64_t)b * 6;
+        s_offs[(size_t)r] = 2 * (int64_t)r;
+      }
+    }
+    double *tail = X + n6 + 8;
+    double *const g_bufs[2] = {X, tail};
+    const int64_t *const g_offs[2] = {z_offs.data(), s_offs.data()};
     // x = 0, r = b, z = M^-1 b and their sums, on every row by every rank: b is complete everywhere after the linearisation's
     // all-reduce, so this needs no exchange
     hipLaunchKernelGGL(pg_cg_init_kernel, g, blk, 0, pg->stream, a);
@@ -1869,12 +1921,21 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
         if (rc) return rc;
         hipLaunchKernelGGL(pg_rs_copy_kernel, dim3(1), dim3(64), 0, pg->stream, (const double *)(X + n6 + 2), a.part_pq, (double *)nullptr, (double *)nullptr);
         hipLaunchKernelGGL(pg_cg_update_kernel, dim3(std::max(nb_rows, 1)), blk, 0, pg->stream, a, k);
-        hipLaunchKernelGGL(pg_rs_zero_others_kernel, gall, b256, 0, pg->stream, X, n6, r0, r1);
-        hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(SUM_BLOCK), 0, pg->stream, a.part_rz[(k + 1) & 1], nb_rows, 1, X + n6);
-        hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(SUM_BLOCK), 0, pg->stream, a.part_rr, nb_rows, 1, X + n6 + 1);
-        PG_TRY(hipGetLastError());
-        rc = pg->reduce(X, (size_t)n6 + 2);  // z gathered, r . z and r . r summed
-        if (rc) return rc;
+        if (gather) {  // own rows of z are in place; own parts of r . z and r . r go to this rank's slot behind them
+          hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(SUM_BLOCK), 0, pg->stream, a.part_rz[(k + 1) & 1], nb_rows, 1, tail + 2 * g_rank);
+          hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(SUM_BLOCK), 0, pg->stream, a.part_rr, nb_rows, 1, tail + 2 * g_rank + 1);
+          PG_TRY(hipGetLastError());
+          rc = pg->gather(2, g_bufs, g_offs, g_world);
+          if (rc) return rc;
+          hipLaunchKernelGGL(pg_rs_tail_sum_kernel, dim3(1), dim3(64), 0, pg->stream, X + n6, (const double *)tail, g_world);
+        } else {
+          hipLaunchKernelGGL(pg_rs_zero_others_kernel, gall, b256, 0, pg->stream, X, n6, r0, r1);
+          hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(SUM_BLOCK), 0, pg->stream, a.part_rz[(k + 1) & 1], nb_rows, 1, X + n6);
+          hipLaunchKernelGGL(pg_sum_kernel, dim3(1), dim3(SUM_BLOCK), 0, pg->stream, a.part_rr, nb_rows, 1, X + n6 + 1);
+          PG_TRY(hipGetLastError());
+          rc = pg->reduce(X, (size_t)n6 + 2);  // z gathered, r . z and r . r summed
+          if (rc) return rc;
+        }
         hipLaunchKernelGGL(pg_rs_copy_kernel, dim3(1), dim3(64), 0, pg->stream, (const double *)(X + n6), a.part_rz[(k + 1) & 1], a.part_rr, (double *)nullptr);
       }
       it += chunk;
@@ -1887,12 +1948,13 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
     // the solution: every rank's rows, gathered the same way
     hipLaunchKernelGGL(pg_rs_pack_kernel, gall, b256, 0, pg->stream, (const double *)pg->d_x, X, n6, r0, r1);
     PG_TRY(hipGetLastError());
-    int rc = pg->reduce(X, (size_t)n6);
+    int rc = gather ? pg->gather(1, g_bufs, g_offs, g_world) : pg->reduce(X, (size_t)n6);
     if (rc) return rc;
     PG_TRY(hipMemcpyAsync(pg->d_x, X, (size_t)n6 * sizeof(double), hipMemcpyDeviceToDevice, pg->stream));
     *iters_out = done_iters;
     pg->total_solves++;
     pg->rs_solves++;
+    pg->rs_gathered += gather ? 1 : 0;
     return LSLAM_OK;
   }
   // The persistent kernel when the graph fits: one workgroup per aggregate, all co-resident, LDS for its columns / items.
@@ -2302,6 +2364,20 @@ int lslam_pg_set_row_shard(lslam_pg *pg, int32_t v_begin, int32_t v_end) {
 }
 
 int32_t lslam_pg_row_sharded_solves(const lslam_pg *pg) { return pg ? pg->rs_solves : 0; }
+int32_t lslam_pg_row_gathered_solves(const lslam_pg *pg) { return pg ? pg->rs_gathered : 0; }
+
+int lslam_pg_set_row_gather(lslam_pg *pg, lslam_allgatherv_fn fn, void *user, int32_t rank, int32_t world) {
+  if (!pg) return LSLAM_ERR_INVALID;
+  if (fn && (world < 1 || world > lslam_pg::RS_MAX_WORLD || rank < 0 || rank >= world)) {
+    g_pg_err = "bad rank / world for the row gather";
+    return LSLAM_ERR_INVALID;
+  }
+  pg->gatherv = fn;
+  pg->gatherv_user = user;
+  pg->gatherv_rank = fn ? rank : -1;
+  pg->gatherv_world = fn ? world : 0;
+  return LSLAM_OK;
+}
 
 int lslam_pg_set_comm(lslam_pg *pg, lslam_comm *comm) {
   if (!pg) return LSLAM_ERR_INVALID;

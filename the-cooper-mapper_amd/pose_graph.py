@@ -10,7 +10,7 @@ import ctypes as C
 
 import numpy as np
 
-from .capi import ALLREDUCE_FN, LslamError, LslamPgStats, c_double_p, c_int32_p, load_library
+from .capi import ALLGATHERV_FN, ALLREDUCE_FN, LslamError, LslamPgStats, c_double_p, c_int32_p, load_library
 
 
 def _dp(a):
@@ -180,6 +180,22 @@ class PoseGraph:
 
     def row_sharded_solves(self):
         return int(self.lib.lslam_pg_row_sharded_solves(self.h)) if self.h else 0
+
+    def set_row_gather(self, allgatherv, rank, world):
+        """lslam_pg_set_row_gather: `allgatherv(ptr, offsets, world)` gathers in place -- doubles [offsets[r], offsets[r + 1])
+        at device address `ptr` are valid on rank r on entry, on every rank on return.  None removes it.  (With the library's
+        RCCL communicator nothing needs registering: the gather is taken by itself.)"""
+        self._build()
+        if allgatherv is None:
+            self._gcb = ALLGATHERV_FN(0)
+        else:
+            def _tramp(_user, ptr, offs, w):
+                allgatherv(ptr, [int(offs[i]) for i in range(w + 1)], int(w))
+            self._gcb = ALLGATHERV_FN(_tramp)
+        self._check(self.lib.lslam_pg_set_row_gather(self.h, self._gcb, None, int(rank), int(world)))
+
+    def row_gathered_solves(self):
+        return int(self.lib.lslam_pg_row_gathered_solves(self.h)) if self.h else 0
 
     def system_doubles(self):
         self._build()

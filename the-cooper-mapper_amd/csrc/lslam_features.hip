@@ -502,7 +502,7 @@ int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, s
   hipStream_t s = (hipStream_t)lslam_stream(ctx);
   // device scratch and the pinned staging area of the input are kept per device between calls (a
   // sweep arrives every 100 ms)
-  struct Cache { char *p = nullptr; size_t cap = 0; float4 *pin = nullptr; size_t pin_cap = 0; };
+  struct Cache { char *p = nullptr; size_t cap = 0; float4 *pin = nullptr; size_t pin_cap = 0; float4 *pout = nullptr; size_t pout_cap = 0; };
   static std::map<int, Cache> caches;
   static std::mutex mu;
   std::lock_guard<std::mutex> lk(mu);
@@ -515,14 +515,27 @@ int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, s
     FX_TRY(hipHostMalloc((void **)&cache.pin, (n_points + n_points / 4) * sizeof(float4), hipHostMallocDefault));
     cache.pin_cap = n_points + n_points / 4;
   }
+  // the outputs come back through pinned memory too: the three small lists behind the filter's count (one wait for all of
+  // them), the filtered less-flat list after it; [0, 2): the filter's {count, error}
+  if (n_points + 16 > cache.pout_cap) {
+    if (cache.pout) (void)hipHostFree(cache.pout);
+    cache.pout = nullptr;
+    cache.pout_cap = 0;
+    FX_TRY(hipHostMalloc((void **)&cache.pout, (n_points + n_points / 4 + 16) * sizeof(float4), hipHostMallocDefault));
+    cache.pout_cap = n_points + n_points / 4 + 16;
+  }
   // pack {x, y, z, intensity-to-copy} (toXYZI, util/pcl_util.h:30-37: the `curvature` field)
   float4 *h = cache.pin;
   const char *src = static_cast<const char *>(cloud);
-  for (size_t i = 0; i < n_points; ++i) {
-    float v[3], w;
-    std::memcpy(v, src + i * stride_bytes, 12);
-    std::memcpy(&w, src + i * stride_bytes + intensity_offset_bytes, 4);
-    h[i] = make_float4(v[0], v[1], v[2], w);
+  if (stride_bytes == 16 && intensity_offset_bytes == 12) {
+    std::memcpy(h, src, n_points * sizeof(float4));
+  } else {
+    for (size_t i = 0; i < n_points; ++i) {
+      float v[3], w;
+      std::memcpy(v, src + i * stride_bytes, 12);
+      std::memcpy(&w, src + i * stride_bytes + intensity_offset_bytes, 4);
+      h[i] = make_float4(v[0], v[1], v[2], w);
+    }
   }
   const size_t bytes = 5 * np4 + 2 * n_scans * 4 + 4 * n_scans * 4 + n_points * 4 + 2 * n_points + 4 * (n_scans + 1) * 4 +
                        2 * np4 + 2 * n_points * 4 + 256 + 16 * 16;
@@ -588,30 +601,62 @@ int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, s
   FX_TRY2(hipMemcpyAsync(d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, s));
   const int32_t *stage[4] = {st0, st1, st2, st3};
   float *outs[3] = {sharp, less_sharp, flat};
-  for (int k = 0; k < 4 && rc == LSLAM_OK; ++k) {
-    const int32_t total = off[k * (n_scans + 1) + n_scans];
-    if (k < 3) counts[k] = (size_t)total;
-    if (total == 0) continue;
-    hipLaunchKernelGGL(fx_compact_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d_pts, stage[k], d_ranges,
-                       d_off + k * (n_scans + 1), (int)n_scans, total, d_out, k == 3 ? d_seg : nullptr);
-    if (k < 3) {
-      if (outs[k]) FX_TRY2(hipMemcpyAsync(outs[k], d_out, (size_t)total * sizeof(float4), hipMemcpyDeviceToHost, s));
+  // the four compactions back to back; the three small lists go to pinned memory behind them, the less-flat list through its
+  // per-ring VoxelGrid (:398-407) -- nothing waits until the filter's count is needed (second wait), then the filtered list
+  // is fetched (third).  Each list has its own slice of d_out and of the pinned area.
+  uint32_t *done = reinterpret_cast<uint32_t *>(cache.pout);
+  float4 *pin_lists = cache.pout + 1;
+  size_t pin_off[4] = {0, 0, 0, 0}, dev_off = 0;
+  int32_t totals[4];
+  for (int k = 0; k < 4; ++k) totals[k] = off[k * (n_scans + 1) + n_scans];
+  // less-flat candidates at the head of d_out (filtered into d_out2); sharp / less sharp / flat in what d_out leaves free
+  const size_t small_total = (size_t)totals[0] + (size_t)totals[1] + (size_t)totals[2];
+  const bool small_fit = (size_t)totals[3] + small_total <= n_points;  // d_out holds n_points
+  for (int k = 0; k < 3 && rc == LSLAM_OK; ++k) {
+    counts[k] = (size_t)totals[k];
+    pin_off[k] = dev_off;
+    if (totals[k] == 0) continue;
+    float4 *dst = small_fit ? d_out + (size_t)totals[3] + dev_off : d_out;
+    hipLaunchKernelGGL(fx_compact_kernel, dim3((totals[k] + 255) / 256), dim3(256), 0, s, d_pts, stage[k], d_ranges,
+                       d_off + k * (n_scans + 1), (int)n_scans, totals[k], dst, (int32_t *)nullptr);
+    if (small_fit) {
+      if (outs[k]) FX_TRY2(hipMemcpyAsync(pin_lists + dev_off, dst, (size_t)totals[k] * sizeof(float4), hipMemcpyDeviceToHost, s));
+    } else {  // (a point in more than one list often enough to overflow the shared area: list by list, as before)
+      if (outs[k]) FX_TRY2(hipMemcpyAsync(outs[k], dst, (size_t)totals[k] * sizeof(float4), hipMemcpyDeviceToHost, s));
       FX_TRY2(hipStreamSynchronize(s));
+    }
+    dev_off += (size_t)totals[k];
+  }
+  size_t m = 0;
+  done[0] = done[1] = 0;
+  if (rc == LSLAM_OK && totals[3] > 0) {
+    hipLaunchKernelGGL(fx_compact_kernel, dim3((totals[3] + 255) / 256), dim3(256), 0, s, d_pts, stage[3], d_ranges,
+                       d_off + 3 * (n_scans + 1), (int)n_scans, totals[3], d_out, d_seg);
+    rc = lslam::voxel_filter_segments(s, d_out, d_seg, (size_t)totals[3], (int)n_scans, prm.less_flat_filter_size, d_out2,
+                                      d_seg2, &m, true, done);
+  }
+  if (rc == LSLAM_OK) {
+    FX_TRY2(hipStreamSynchronize(s));  // the small lists are in pinned memory, the filter's count is known
+    if (done[1]) {  // the wide key did not hold the extent: the filter once more, with the measured one
+      rc = lslam::voxel_filter_segments(s, d_out, d_seg, (size_t)totals[3], (int)n_scans, prm.less_flat_filter_size, d_out2,
+                                        d_seg2, &m, true, nullptr);
     } else {
-      size_t m = 0;  // :398-407: VoxelGrid(lessFlatFilterSize) per ring
-      rc = lslam::voxel_filter_segments(s, d_out, d_seg, (size_t)total, (int)n_scans, prm.less_flat_filter_size, d_out2,
-                                        d_seg2, &m);
-      if (rc == LSLAM_OK) {
-        counts[3] = m;
-        if (less_flat && m) FX_TRY2(hipMemcpyAsync(less_flat, d_out2, m * sizeof(float4), hipMemcpyDeviceToHost, s));
-      }
+      m = done[0];
     }
   }
   if (rc == LSLAM_OK) {
+    counts[3] = m;
+    if (small_fit)
+      for (int k = 0; k < 3; ++k)
+        if (outs[k] && totals[k]) std::memcpy(outs[k], pin_lists + pin_off[k], (size_t)totals[k] * sizeof(float4));
+    float4 *pin_less = pin_lists + (small_fit ? small_total : 0);
+    const bool fetch = less_flat && m;
+    if (fetch) FX_TRY2(hipMemcpyAsync(pin_less, d_out2, m * sizeof(float4), hipMemcpyDeviceToHost, s));
     if (curvature_out) FX_TRY2(hipMemcpyAsync(curvature_out, d_curv, n_points * 4, hipMemcpyDeviceToHost, s));
     if (picked_out) FX_TRY2(hipMemcpyAsync(picked_out, d_picked, n_points, hipMemcpyDeviceToHost, s));
     if (label_out) FX_TRY2(hipMemcpyAsync(label_out, d_label, n_points, hipMemcpyDeviceToHost, s));
-    FX_TRY2(hipStreamSynchronize(s));
+    if (fetch || curvature_out || picked_out || label_out) FX_TRY2(hipStreamSynchronize(s));
+    if (fetch) std::memcpy(less_flat, pin_less, m * sizeof(float4));
   }
   return rc;
 }

@@ -89,7 +89,31 @@ struct Buf {
   }
 };
 
+// a pinned host block that lives as long as its owner: asynchronous copies to and from it need no wait to keep their host side
+// alive (a std::vector local does), and they run at the link's rate instead of through the runtime's staging
+template <typename T>
+struct Pin {
+  T *p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = n + n / 4 + 256;
+    hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
 constexpr uint64_t KEY_DROP = ~0ull;
+constexpr size_t MERGE_LIMIT = 1024 * 1024;  // rocprim::radix_sort_config<>::merge_sort_limit
 
 // How a point becomes a sort key.
 struct KeyParams {
@@ -364,6 +388,14 @@ struct lslam_fmap {
   bool seg_current[2] = {false, false};
   Buf<float4> in_raw, in_tf;
   Buf<int32_t> in_cube;
+  // addFeatureCloud runs both feature types behind ONE wait: per-type staging of the new points (pinned: the upload needs no
+  // wait to keep its source alive), per-type transformed points, and the rebuilds' results {points out, error} in pinned slots
+  Pin<float4> in_pin[2];
+  Buf<float4> in_raw_t[2], in_tf_t[2];
+  Buf<int32_t> in_cube_t[2];
+  Buf<uint8_t> d_touched_t[2];
+  Pin<uint32_t> done;       // [2 types][2]
+  Pin<uint8_t> h_touched;   // [2 types][ncube]
   Buf<float> d_T;
   Buf<int32_t> d_remap;
   Buf<int32_t> g_src, g_dst;
@@ -422,10 +454,19 @@ int cube_bits(int ncube) {
 // in_pts/in_cube hold n_total points (already concatenated).  Writes out_pts/out_cube, returns
 // the number of output points.  flags selects the cubes to filter (nullptr: none); kp.single: the
 // stand-alone filter (one pseudo cube, base and bits prepared by the caller).
+// assume_axis_bits > 0: the caller knows a bound of the voxel extent of every filtered cube (a map cube is cube_size wide), so
+// the widest extent is not read back (one host wait less); the key-range check of fm_key_kernel still guards it.  Only taken
+// while the sort is rocPRIM's merge sort, whose cost does not grow with the key width.
+// done != nullptr: no wait at the end either -- {points out, key-range error} land in done[0..1] (pinned) behind everything
+// else on the stream; *n_out is not written.
 int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t *in_cube, size_t n_total,
-                 KeyParams kp, int ncube, const uint8_t *flags, float4 *out_pts, int32_t *out_cube, size_t *n_out) {
+                 KeyParams kp, int ncube, const uint8_t *flags, float4 *out_pts, int32_t *out_cube, size_t *n_out,
+                 int assume_axis_bits = 0, uint32_t *done = nullptr) {
   *n_out = 0;
-  if (n_total == 0) return LSLAM_OK;
+  if (n_total == 0) {
+    if (done) done[0] = done[1] = 0;
+    return LSLAM_OK;
+  }
   const int n = (int)n_total;
   const int n_cube_bits = kp.single ? 1 : cube_bits(ncube + 1);
   const dim3 blk(256), grd((n + 255) / 256);
@@ -446,10 +487,14 @@ int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t
     }
     hipLaunchKernelGGL(fm_extent_kernel, dim3((ncube + 255) / 256), blk, 0, s, flags, sc.cmin.p, sc.cmax.p, ncube,
                        kp.inv_leaf, sc.eff.p, sc.base.p, sc.err.p + 1);
-    int32_t max_div = 0;
-    FM_TRY(hipMemcpyAsync(&max_div, sc.err.p + 1, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    FM_TRY(hipStreamSynchronize(s));
-    kp.axis_bits = bits_for((double)max_div + 1.0);
+    if (assume_axis_bits > 0 && n_total <= MERGE_LIMIT && 3 * assume_axis_bits + n_cube_bits <= 63) {
+      kp.axis_bits = assume_axis_bits;
+    } else {
+      int32_t max_div = 0;
+      FM_TRY(hipMemcpyAsync(&max_div, sc.err.p + 1, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      FM_TRY(hipStreamSynchronize(s));
+      kp.axis_bits = bits_for((double)max_div + 1.0);
+    }
     eff = sc.eff.p;
   } else if (!kp.single) {
     kp.axis_bits = 1;
@@ -468,6 +513,8 @@ int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t
   const unsigned end_bit = (unsigned)(3 * kp.axis_bits + n_cube_bits);
   size_t tmp_bytes = 0;
   // KEY_DROP has every bit set: within [0, end_bit) it is the largest key, so dropped points sort last
+  // (below MERGE_LIMIT keys rocPRIM's radix_sort_pairs is a merge sort whose cost does not depend on end_bit; measured against
+  // its onesweep form on the 64-bit keys here: 60 us against 125 for 157 k keys, 136 against 141 for 587 k)
   FM_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, sc.k0.p, sc.k1.p, sc.i0.p, sc.i1.p, n_total, 0u, end_bit, s));
   size_t tmp2 = 0;
   FM_TRY(rocprim::exclusive_scan(nullptr, tmp2, sc.head.p, sc.pos.p, 0u, n_total + 1, rocprim::plus<uint32_t>(), s));
@@ -480,12 +527,19 @@ int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t
                                  rocprim::plus<uint32_t>(), s));
   hipLaunchKernelGGL(fm_centroid_kernel, grd, blk, 0, s, in_pts, sc.k1.p, sc.i1.p, sc.head.p, sc.pos.p, n,
                      kp.axis_bits, out_pts, out_cube);
+  if (done) {
+    FM_TRY(hipMemcpyAsync(&done[0], sc.pos.p + n_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    FM_TRY(hipMemcpyAsync(&done[1], sc.err.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    return LSLAM_OK;
+  }
   uint32_t total = 0;
   int32_t err = 0;
   FM_TRY(hipMemcpyAsync(&total, sc.pos.p + n_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   FM_TRY(hipMemcpyAsync(&err, sc.err.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   FM_TRY(hipStreamSynchronize(s));
   if (err) {
+    if (assume_axis_bits > 0)  // the bound did not hold (it always should): the measured extent decides
+      return run_pipeline(s, sc, in_pts, in_cube, n_total, kp, ncube, flags, out_pts, out_cube, n_out, 0, nullptr);
     lslam::set_error("voxel index outside its key range (non-finite point?)");
     return LSLAM_ERR_INVALID;
   }
@@ -517,16 +571,23 @@ int refresh_segments(lslam_fmap *fm, int t, bool wait = true) {
   return LSLAM_OK;
 }
 
-// rebuild type t from its current points plus n_new transformed points (fm->in_tf / in_cube)
-int rebuild(lslam_fmap *fm, int t, size_t n_new, bool allow_filter, const uint8_t *flags_override = nullptr) {
+// bits per voxel axis that hold any map cube's extent: points of a cube lie within cube_size of each other on every axis
+// (cube_of_point rounds p / cube_size), two cells of slack for the rounding of the two floors
+int map_axis_bits(const lslam_fmap *fm, float leaf) { return bits_for((double)fm->cube_size / (double)leaf + 3.0); }
+
+// rebuild type t from its current points plus n_new transformed points (in_tf / in_cube; default: fm->in_tf / in_cube).
+// done != nullptr: everything is enqueued and nothing waited for -- rebuild_finish after the caller's wait.
+int rebuild_begin(lslam_fmap *fm, int t, size_t n_new, bool allow_filter, const uint8_t *flags_override, uint32_t *done,
+                  const float4 *in_tf = nullptr, const int32_t *in_cube = nullptr, size_t *n_out_sync = nullptr) {
   hipStream_t s = fm->stream;
   const size_t n_old = fm->n[t], n_total = n_old + n_new;
+  if (done) done[0] = done[1] = 0;
   if (n_total == 0) return LSLAM_OK;
   FM_TRY(fm->pts[t].grow(n_total, n_old, s));
   FM_TRY(fm->cube[t].grow(n_total, n_old, s));
   if (n_new) {
-    FM_TRY(hipMemcpyAsync(fm->pts[t].p + n_old, fm->in_tf.p, n_new * sizeof(float4), hipMemcpyDeviceToDevice, s));
-    FM_TRY(hipMemcpyAsync(fm->cube[t].p + n_old, fm->in_cube.p, n_new * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    FM_TRY(hipMemcpyAsync(fm->pts[t].p + n_old, in_tf ? in_tf : fm->in_tf.p, n_new * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    FM_TRY(hipMemcpyAsync(fm->cube[t].p + n_old, in_cube ? in_cube : fm->in_cube.p, n_new * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
   }
   FM_TRY(fm->pts_alt[t].reserve(n_total));
   FM_TRY(fm->cube_alt[t].reserve(n_total));
@@ -534,13 +595,23 @@ int rebuild(lslam_fmap *fm, int t, size_t n_new, bool allow_filter, const uint8_
   size_t n_out = 0;
   int rc = run_pipeline(s, fm->sc, fm->pts[t].p, fm->cube[t].p, n_total, kp, fm->ncube,
                         flags_override ? flags_override : (allow_filter ? fm->active.p : nullptr), fm->pts_alt[t].p,
-                        fm->cube_alt[t].p, &n_out);
-  if (rc) return rc;
+                        fm->cube_alt[t].p, &n_out, map_axis_bits(fm, fm->leaf[t]), done);
+  if (n_out_sync) *n_out_sync = n_out;
+  return rc;
+}
+void rebuild_commit(lslam_fmap *fm, int t, size_t n_new, size_t n_out, bool all_dirty) {
+  if (fm->n[t] + n_new == 0) return;
   std::swap(fm->pts[t], fm->pts_alt[t]);
   std::swap(fm->cube[t], fm->cube_alt[t]);
   fm->n[t] = n_out;
   fm->seg_current[t] = false;
-  if (n_new == 0 || flags_override) fm->dirty[t].assign((size_t)fm->ncube, 1);  // shift / load: every cube's cloud may have moved
+  if (all_dirty) fm->dirty[t].assign((size_t)fm->ncube, 1);  // shift / load: every cube's cloud may have moved
+}
+int rebuild(lslam_fmap *fm, int t, size_t n_new, bool allow_filter, const uint8_t *flags_override = nullptr) {
+  size_t n_out = 0;
+  int rc = rebuild_begin(fm, t, n_new, allow_filter, flags_override, nullptr, nullptr, nullptr, &n_out);
+  if (rc) return rc;
+  rebuild_commit(fm, t, n_new, n_out, n_new == 0 || flags_override);
   return LSLAM_OK;
 }
 
@@ -583,20 +654,35 @@ int upload_active(lslam_fmap *fm) {
   return LSLAM_OK;
 }
 
-int pack_input(lslam_fmap *fm, const void *src, size_t n, size_t stride_bytes) {
+// host cloud -> pinned staging -> dst (device), no wait: `pin` lives as long as its owner and is not written again before
+// the owner's next wait.  mn / mx (optional): the cloud's bounding box, taken in the same pass.
+int pack_input(hipStream_t s, Pin<float4> &pin, Buf<float4> &dst, const void *src, size_t n, size_t stride_bytes,
+               float *mn = nullptr, float *mx = nullptr) {
   // {x,y,z} at offset 0; intensity at offset 12 for 16-byte points, 16 for pcl::PointXYZI (32 bytes)
-  std::vector<float4> h(n);
+  FM_TRY(pin.reserve(n));
+  FM_TRY(dst.reserve(n));
+  float4 *h = pin.p;
   const char *p = static_cast<const char *>(src);
   const size_t ioff = stride_bytes == 16 ? 12 : 16;
-  for (size_t i = 0; i < n; ++i) {
-    float v[3], w = 0.0f;
-    std::memcpy(v, p + i * stride_bytes, 12);
-    if (stride_bytes >= ioff + 4) std::memcpy(&w, p + i * stride_bytes + ioff, 4);
-    h[i] = make_float4(v[0], v[1], v[2], w);
+  if (stride_bytes == 16) {
+    std::memcpy(h, p, n * sizeof(float4));
+  } else {
+    for (size_t i = 0; i < n; ++i) {
+      float v[3], w = 0.0f;
+      std::memcpy(v, p + i * stride_bytes, 12);
+      if (stride_bytes >= ioff + 4) std::memcpy(&w, p + i * stride_bytes + ioff, 4);
+      h[i] = make_float4(v[0], v[1], v[2], w);
+    }
   }
-  FM_TRY(fm->in_raw.reserve(n));
-  FM_TRY(hipMemcpyAsync(fm->in_raw.p, h.data(), n * sizeof(float4), hipMemcpyHostToDevice, fm->stream));
-  FM_TRY(hipStreamSynchronize(fm->stream));  // h is a local
+  if (mn && mx)
+    for (size_t i = 0; i < n; ++i) {
+      const float v[3] = {h[i].x, h[i].y, h[i].z};
+      for (int d = 0; d < 3; ++d) {
+        mn[d] = v[d] < mn[d] ? v[d] : mn[d];
+        mx[d] = v[d] > mx[d] ? v[d] : mx[d];
+      }
+    }
+  FM_TRY(hipMemcpyAsync(dst.p, h, n * sizeof(float4), hipMemcpyHostToDevice, s));
   return LSLAM_OK;
 }
 
@@ -654,8 +740,11 @@ namespace lslam {
 // VoxelGrid per segment for other translation units (feature extraction: one segment per scan ring):
 // in_seg[i] is the segment of point i (ascending or not), every segment is filtered with `leaf`;
 // output ordered by segment, inside a segment in VoxelGrid order.  Scratch is cached per process.
+// done != nullptr (pinned, two words): nothing is waited for -- the widest voxel extent is not read back (the key gets every
+// bit the 63 allow: while the sort is a merge sort its width costs nothing) and {points out, key-range error} arrive in
+// done[0..1] behind everything else on the stream; on an error the caller calls again without `done`.
 int voxel_filter_segments(hipStream_t s, const float4 *in_pts, const int32_t *in_seg, size_t n, int nseg, float leaf,
-                          float4 *out_pts, int32_t *out_seg, size_t *n_out, bool filter) {
+                          float4 *out_pts, int32_t *out_seg, size_t *n_out, bool filter, uint32_t *done) {
   struct Cache {
     Scratch sc;
     Buf<uint8_t> all;
@@ -675,8 +764,16 @@ int voxel_filter_segments(hipStream_t s, const float4 *in_pts, const int32_t *in
   kp.inv_leaf = 1.0f / leaf;
   kp.axis_bits = 1;
   kp.single = 0;
+  const int wide = std::min(20, (63 - cube_bits(nseg + 1)) / 3);
   // filter == false: only the stable grouping by segment (points with segment -1 are dropped)
-  return run_pipeline(s, sc, in_pts, in_seg, n, kp, nseg, filter ? all.p : nullptr, out_pts, out_seg, n_out);
+  const bool no_wait = done && n <= MERGE_LIMIT;
+  const int rc = run_pipeline(s, sc, in_pts, in_seg, n, kp, nseg, filter ? all.p : nullptr, out_pts, out_seg, n_out,
+                              no_wait ? wide : 0, no_wait ? done : nullptr);
+  if (rc == LSLAM_OK && done && !no_wait) {  // waited after all: the result where the caller looks for it
+    done[0] = (uint32_t)*n_out;
+    done[1] = 0;
+  }
+  return rc;
 }
 }  // namespace lslam
 
@@ -725,7 +822,12 @@ void lslam_fmap_destroy(lslam_fmap *fm) {
   if (lslam::ctx_alive(fm->ctx)) lslam::cubemap_drop_views(fm->ctx);  // the context may still point at this map's trees
   fm->active.release(); fm->in_raw.release(); fm->in_tf.release(); fm->in_cube.release(); fm->d_T.release();
   fm->d_remap.release(); fm->g_src.release(); fm->g_dst.release();
-  for (int t = 0; t < 2; ++t) { fm->g_src_t[t].release(); fm->g_dst_t[t].release(); }
+  for (int t = 0; t < 2; ++t) {
+    fm->g_src_t[t].release(); fm->g_dst_t[t].release();
+    fm->in_pin[t].release(); fm->in_raw_t[t].release(); fm->in_tf_t[t].release(); fm->in_cube_t[t].release();
+    fm->d_touched_t[t].release();
+  }
+  fm->done.release(); fm->h_touched.release();
   fm->sc.release();
   delete fm;
 }
@@ -808,32 +910,51 @@ int lslam_fmap_add_feature_cloud(lslam_fmap *fm, const void *corner, size_t n_co
     return LSLAM_ERR_INVALID;
   }
   hipStream_t s = fm->stream;
-  FM_TRY(hipMemcpyAsync(fm->d_T.p, T, 16 * sizeof(float), hipMemcpyHostToDevice, s));
+  // everything for both feature types is enqueued, then ONE wait: uploads come from pinned staging, the voxel extent of a map
+  // cube is bounded (map_axis_bits), the rebuilds' results land in pinned slots
+  FM_TRY(fm->done.reserve(4 + 16));
+  float *T_pin = reinterpret_cast<float *>(fm->done.p + 4);
+  std::memcpy(T_pin, T, 16 * sizeof(float));
+  FM_TRY(hipMemcpyAsync(fm->d_T.p, T_pin, 16 * sizeof(float), hipMemcpyHostToDevice, s));
   const void *src[2] = {corner, surf};
   const size_t cnt[2] = {n_corner, n_surf};
-  FM_TRY(fm->d_touched.reserve(fm->ncube));
-  std::vector<uint8_t> h_touched((size_t)fm->ncube);
+  FM_TRY(fm->h_touched.reserve(2 * (size_t)fm->ncube));
   for (int t = 0; t < 2; ++t) {
     const size_t n = cnt[t];
     if (n) {
-      rc = pack_input(fm, src[t], n, stride_bytes);
+      rc = pack_input(s, fm->in_pin[t], fm->in_raw_t[t], src[t], n, stride_bytes);
       if (rc) return rc;
-      FM_TRY(fm->in_tf.reserve(n));
-      FM_TRY(fm->in_cube.reserve(n));
+      FM_TRY(fm->in_tf_t[t].reserve(n));
+      FM_TRY(fm->in_cube_t[t].reserve(n));
+      FM_TRY(fm->d_touched_t[t].reserve(fm->ncube));
       KeyParams kp = key_params(fm, fm->leaf[t]);
-      FM_TRY(hipMemsetAsync(fm->d_touched.p, 0, fm->ncube, s));
-      hipLaunchKernelGGL(fm_transform_kernel, dim3(((int)n + 255) / 256), dim3(256), 0, s, fm->in_raw.p, (int)n,
-                         fm->d_T.p, kp, fm->in_tf.p, fm->in_cube.p, fm->d_touched.p);
-      FM_TRY(hipMemcpyAsync(h_touched.data(), fm->d_touched.p, fm->ncube, hipMemcpyDeviceToHost, s));
+      FM_TRY(hipMemsetAsync(fm->d_touched_t[t].p, 0, fm->ncube, s));
+      hipLaunchKernelGGL(fm_transform_kernel, dim3(((int)n + 255) / 256), dim3(256), 0, s, fm->in_raw_t[t].p, (int)n,
+                         fm->d_T.p, kp, fm->in_tf_t[t].p, fm->in_cube_t[t].p, fm->d_touched_t[t].p);
+      FM_TRY(hipMemcpyAsync(fm->h_touched.p + (size_t)t * fm->ncube, fm->d_touched_t[t].p, fm->ncube, hipMemcpyDeviceToHost, s));
     }
-    rc = rebuild(fm, t, n, true);  // synchronises the stream
+    rc = rebuild_begin(fm, t, n, true, nullptr, fm->done.p + 2 * t, fm->in_tf_t[t].p, fm->in_cube_t[t].p);
     if (rc) return rc;
-    if (n) {
-      fm->dirty[t].resize((size_t)fm->ncube, 1);
-      for (int c = 0; c < fm->ncube; ++c) fm->dirty[t][(size_t)c] |= h_touched[(size_t)c];
-    }
   }
   FM_TRY(hipStreamSynchronize(s));
+  for (int t = 0; t < 2; ++t) {
+    const size_t n = cnt[t];
+    if (fm->done.p[2 * t + 1]) {
+      // a voxel index outside the key range the cube size promises (or a non-finite point): once more, waiting for the
+      // measured extents -- the inputs are untouched, the appended points are written again where they are
+      size_t n_out = 0;
+      rc = rebuild_begin(fm, t, n, true, nullptr, nullptr, fm->in_tf_t[t].p, fm->in_cube_t[t].p, &n_out);
+      if (rc) return rc;
+      rebuild_commit(fm, t, n, n_out, n == 0);
+    } else {
+      rebuild_commit(fm, t, n, fm->done.p[2 * t], n == 0);
+    }
+    if (n) {
+      fm->dirty[t].resize((size_t)fm->ncube, 1);
+      const uint8_t *ht = fm->h_touched.p + (size_t)t * fm->ncube;
+      for (int c = 0; c < fm->ncube; ++c) fm->dirty[t][(size_t)c] |= ht[(size_t)c];
+    }
+  }
   return LSLAM_OK;
 }
 
@@ -1334,8 +1455,9 @@ int lslam_voxel_grid(lslam_ctx *ctx, const void *cloud, size_t n, size_t stride_
   hipStream_t s = (hipStream_t)lslam_stream(ctx);
   // staging and scratch are kept between calls (allocation costs more than the filter itself)
   struct Cache {
-    lslam_fmap tmp;  // borrows the staging helpers; no grid
-    Buf<float4> out;
+    Pin<float4> in_pin, out_pin;
+    Pin<uint32_t> done;
+    Buf<float4> in_raw, out;
     Buf<int32_t> oc;
     Scratch sc;
   };
@@ -1343,27 +1465,14 @@ int lslam_voxel_grid(lslam_ctx *ctx, const void *cloud, size_t n, size_t stride_
   static std::mutex mu;
   std::lock_guard<std::mutex> lk(mu);
   Cache &cache = caches[lslam::ctx_device(ctx)];
-  lslam_fmap &tmp = cache.tmp;
   Buf<float4> &out = cache.out;
   Buf<int32_t> &oc = cache.oc;
   Scratch &sc = cache.sc;
-  tmp.ctx = ctx;
-  tmp.stream = s;
-  int rc = pack_input(&tmp, cloud, n, stride_bytes);
-  auto cleanup = [] {};
-  if (rc) return rc;
-  // min/max on the host while the cloud is at hand (VoxelGrid::applyFilter: getMinMax3D)
+  // upload from pinned staging (no wait), min/max on the host in the same pass (VoxelGrid::applyFilter: getMinMax3D)
   const float inv = 1.0f / leaf;
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  const char *p = static_cast<const char *>(cloud);
-  for (size_t i = 0; i < n; ++i) {
-    float v[3];
-    std::memcpy(v, p + i * stride_bytes, 12);
-    for (int d = 0; d < 3; ++d) {
-      mn[d] = v[d] < mn[d] ? v[d] : mn[d];
-      mx[d] = v[d] > mx[d] ? v[d] : mx[d];
-    }
-  }
+  int rc = pack_input(s, cache.in_pin, cache.in_raw, cloud, n, stride_bytes, mn, mx);
+  if (rc) return rc;
   KeyParams kp{};
   kp.W = kp.H = kp.D = 1;
   kp.cube_size = 1.0f;
@@ -1380,33 +1489,49 @@ int lslam_voxel_grid(lslam_ctx *ctx, const void *cloud, size_t n, size_t stride_
   kp.axis_bits = bits_for(cells + 1.0);
   if (!(vol <= (long long)INT32_MAX)) {
     // applyFilter: "Leaf size is too small for the input dataset" -> the input is returned unfiltered
-    if (n > cap) { cleanup(); lslam::set_error("voxel-grid output buffer too small"); return LSLAM_ERR_INVALID; }
-    FM_TRY(hipMemcpyAsync(out_xyzi, tmp.in_raw.p, n * sizeof(float4), hipMemcpyDeviceToHost, s));
-    FM_TRY(hipStreamSynchronize(s));
+    if (n > cap) { lslam::set_error("voxel-grid output buffer too small"); return LSLAM_ERR_INVALID; }
+    FM_TRY(hipStreamSynchronize(s));  // (the upload: nothing else was enqueued)
+    if (out_xyzi) std::memcpy(out_xyzi, cache.in_pin.p, n * sizeof(float4));
     *n_out = n;
-    cleanup();
     return LSLAM_OK;
   }
-  hipError_t e = out.reserve(n);
-  if (e == hipSuccess) e = oc.reserve(n);
-  if (e != hipSuccess) { cleanup(); FM_TRY(e); }
+  FM_TRY(out.reserve(n));
+  FM_TRY(oc.reserve(n));
+  FM_TRY(cache.done.reserve(2));
+  // small clouds (a sweep's features): the whole output area comes back behind the count in ONE wait and the m points are
+  // copied out of pinned memory; large ones wait for the count first and fetch exactly m points
+  const bool one_wait = n * sizeof(float4) <= (size_t)1 << 20;
   size_t m = 0;
-  rc = run_pipeline(s, sc, tmp.in_raw.p, nullptr, n, kp, 1, nullptr, out.p, oc.p, &m);
-  if (!rc) {
-    if (m > cap) {
-      lslam::set_error("voxel-grid output buffer too small");
-      rc = LSLAM_ERR_INVALID;
-    } else if (out_xyzi && m) {
-      if (hipMemcpyAsync(out_xyzi, out.p, m * sizeof(float4), hipMemcpyDeviceToHost, s) != hipSuccess ||
-          hipStreamSynchronize(s) != hipSuccess) {
-        lslam::set_error("voxel-grid download failed");
-        rc = LSLAM_ERR_HIP;
-      }
+  if (one_wait) {
+    FM_TRY(cache.out_pin.reserve(n));
+    rc = run_pipeline(s, sc, cache.in_raw.p, nullptr, n, kp, 1, nullptr, out.p, oc.p, &m, 0, cache.done.p);
+    if (rc) return rc;
+    FM_TRY(hipMemcpyAsync(cache.out_pin.p, out.p, n * sizeof(float4), hipMemcpyDeviceToHost, s));
+    FM_TRY(hipStreamSynchronize(s));
+    if (cache.done.p[1]) {
+      lslam::set_error("voxel index outside its key range (non-finite point?)");
+      return LSLAM_ERR_INVALID;
     }
-    *n_out = m;
+    m = cache.done.p[0];
+  } else {
+    rc = run_pipeline(s, sc, cache.in_raw.p, nullptr, n, kp, 1, nullptr, out.p, oc.p, &m);
+    if (rc) return rc;
   }
-  cleanup();
-  return rc;
+  if (m > cap) {
+    lslam::set_error("voxel-grid output buffer too small");
+    return LSLAM_ERR_INVALID;
+  }
+  if (out_xyzi && m) {
+    if (one_wait) {
+      std::memcpy(out_xyzi, cache.out_pin.p, m * sizeof(float4));
+    } else if (hipMemcpyAsync(out_xyzi, out.p, m * sizeof(float4), hipMemcpyDeviceToHost, s) != hipSuccess ||
+               hipStreamSynchronize(s) != hipSuccess) {
+      lslam::set_error("voxel-grid download failed");
+      return LSLAM_ERR_HIP;
+    }
+  }
+  *n_out = m;
+  return LSLAM_OK;
 }
 
 }  // extern "C"

@@ -2,12 +2,13 @@
 // the source of the bounding box): points sorted by cell and the cell -> first point table.  Everything on the device, stream-ordered; the one value the host needs (the bounding box) it already has from the
 // tree build (TreeView::bb_lo / bb_hi = nanoflann's root_bbox, nanoflann.hpp:1406-1427).
 //
-// The key sort and the scan of the cell counts are rocPRIM's (map-set path, outside every timed region).
+// The key sort is rocPRIM's radix sort, held to its onesweep form (its default below 1 Mi keys is a merge sort of ~20 launches for
+// the 587 k points of a surf surround: 140 us against 30); the cell -> first point table is written straight from the sorted keys
+// (grid_cellstart_kernel: no count table, no memset, no device-wide scan -- for a deferred-trees map this runs once per frame).
 #include "lslam_grid.hpp"
 #include "lslam_internal.hpp"
 
 #include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -25,8 +26,7 @@ LSLAM_DEV int cell_of(const CellGrid &G, const float4 &p, bool &ok) {
   return ok ? (int)ux + G.nx * ((int)uy + G.ny * (int)uz) : 0;
 }
 
-__global__ __launch_bounds__(256) void grid_key_kernel(CellGrid G, const float4 *tree_pts, uint32_t *key, uint32_t *val,
-                                                       uint32_t *count, int32_t *err) {
+__global__ __launch_bounds__(256) void grid_key_kernel(CellGrid G, const float4 *tree_pts, uint32_t *key, uint32_t *val, int32_t *err) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= G.n_pts) return;
   bool ok;
@@ -34,7 +34,68 @@ __global__ __launch_bounds__(256) void grid_key_kernel(CellGrid G, const float4 
   if (!ok) atomicAdd(err, 1);  // a point outside its own bounding box: not a number
   key[i] = (uint32_t)c;
   val[i] = (uint32_t)i;
-  atomicAdd(count + c, 1u);
+}
+
+// cell_start[c] = number of points in cells < c, for c in [0, ncell]: each workgroup owns CS_CELLS consecutive cells, finds its
+// slice of the SORTED keys by two binary searches, counts it into LDS and scans there.  HBM traffic: the table written once
+// (4 B per cell), the keys read once.
+constexpr int CS_CELLS = 4096;
+__global__ __launch_bounds__(256) void grid_cellstart_kernel(const uint32_t *keys, int n, uint32_t ncell_plus1, uint32_t *cell_start) {
+  __shared__ uint32_t cnt[CS_CELLS];
+  __shared__ uint32_t wave_sum[4];
+  __shared__ int slice[2];
+  const int tid = threadIdx.x;
+  const uint32_t base = blockIdx.x * (uint32_t)CS_CELLS;
+#pragma unroll
+  for (int k = 0; k < CS_CELLS / 256 / 4; ++k) reinterpret_cast<uint4 *>(cnt)[tid + 256 * k] = make_uint4(0u, 0u, 0u, 0u);
+  if (tid < 2) {  // first key >= base (tid 0), first key >= base + CS_CELLS (tid 1)
+    const uint64_t target = (uint64_t)base + (uint64_t)tid * CS_CELLS;
+    int lo = 0, hi = n;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((uint64_t)keys[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    slice[tid] = lo;
+  }
+  __syncthreads();
+  const int j0 = slice[0], j1 = slice[1];
+  for (int j = j0 + tid; j < j1; j += 256) atomicAdd(&cnt[keys[j] - base], 1u);
+  __syncthreads();
+  // exclusive scan of the 4096 counters: 16 per thread, wavefront scan of the thread sums, four wavefront sums through LDS
+  uint32_t v[16];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint4 q = reinterpret_cast<const uint4 *>(cnt)[4 * tid + k];
+    v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+  }
+  uint32_t run = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const uint32_t c = v[k];
+    v[k] = run;
+    run += c;
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+  uint32_t incl = run;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) wave_sum[wave] = incl;
+  __syncthreads();
+  uint32_t before = (uint32_t)j0 + incl - run;
+  for (int w = 0; w < wave; ++w) before += wave_sum[w];
+  const uint32_t c0 = base + 16u * (uint32_t)tid;
+  if (c0 + 16u <= ncell_plus1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      reinterpret_cast<uint4 *>(cell_start + c0)[k] = make_uint4(before + v[4 * k], before + v[4 * k + 1], before + v[4 * k + 2], before + v[4 * k + 3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (c0 + (uint32_t)k < ncell_plus1) cell_start[c0 + k] = before + v[k];
+  }
 }
 
 __global__ __launch_bounds__(256) void grid_place_kernel(int n, const float4 *tree_pts, const uint32_t *val_sorted, float4 *gpts) {
@@ -146,24 +207,23 @@ hipError_t GridDev::build(const float4 *src, int n_src, const float lo[3], const
 #define G_TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
   G_TRY(reserve(pts, cap_pts, (size_t)n + 16));
   G_TRY(reserve(cell_start, cap_cell, ncell + 1));
-  G_TRY(reserve(count, cap_count, ncell + 1));
   G_TRY(reserve(key0, cap_k0, (size_t)n));
   G_TRY(reserve(key1, cap_k1, (size_t)n));
   G_TRY(reserve(val0, cap_v0, (size_t)n));
   G_TRY(reserve(val1, cap_v1, (size_t)n));
   G_TRY(reserve(err, cap_err, 1));
-  G_TRY(hipMemsetAsync(count, 0, (ncell + 1) * sizeof(uint32_t), s));
   G_TRY(hipMemsetAsync(err, 0, sizeof(int32_t), s));
   const dim3 blk(256), grd((n + 255) / 256);
-  hipLaunchKernelGGL(grid_key_kernel, grd, blk, 0, s, G, src, key0, val0, count, err);
+  hipLaunchKernelGGL(grid_key_kernel, grd, blk, 0, s, G, src, key0, val0, err);
   unsigned end_bit = 1;
   while (((size_t)1 << end_bit) < ncell) ++end_bit;
-  size_t tmp_sort = 0, tmp_scan = 0;
-  G_TRY(rocprim::radix_sort_pairs(nullptr, tmp_sort, key0, key1, val0, val1, (size_t)n, 0u, end_bit, s));
-  G_TRY(rocprim::exclusive_scan(nullptr, tmp_scan, count, cell_start, 0u, ncell + 1, rocprim::plus<uint32_t>(), s));
-  G_TRY(reserve(tmp, cap_tmp, std::max(tmp_sort, tmp_scan)));
-  G_TRY(rocprim::radix_sort_pairs((void *)tmp, tmp_sort, key0, key1, val0, val1, (size_t)n, 0u, end_bit, s));
-  G_TRY(rocprim::exclusive_scan((void *)tmp, tmp_scan, count, cell_start, 0u, ncell + 1, rocprim::plus<uint32_t>(), s));
+  using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 16384>;
+  size_t tmp_sort = 0;
+  G_TRY(rocprim::radix_sort_pairs<SortCfg>(nullptr, tmp_sort, key0, key1, val0, val1, (size_t)n, 0u, end_bit, s));
+  G_TRY(reserve(tmp, cap_tmp, tmp_sort));
+  G_TRY(rocprim::radix_sort_pairs<SortCfg>((void *)tmp, tmp_sort, key0, key1, val0, val1, (size_t)n, 0u, end_bit, s));
+  hipLaunchKernelGGL(grid_cellstart_kernel, dim3((unsigned)((ncell + 1 + CS_CELLS - 1) / CS_CELLS)), blk, 0, s, (const uint32_t *)key1, n,
+                     (uint32_t)(ncell + 1), cell_start);
   hipLaunchKernelGGL(grid_place_kernel, grd, blk, 0, s, n, src, val1, pts);
   // the candidate loop loads pts[cur] for lanes that have run out of candidates at index 0: nothing to pad; a leaf-style
   // over-read does not exist here
@@ -182,11 +242,11 @@ hipError_t GridDev::build(const float4 *src, int n_src, const float lo[3], const
 }
 
 void GridDev::release() {
-  for (void *q : {(void *)pts, (void *)cell_start, (void *)count, (void *)key0, (void *)key1, (void *)val0, (void *)val1,
+  for (void *q : {(void *)pts, (void *)cell_start, (void *)key0, (void *)key1, (void *)val0, (void *)val1,
                   (void *)err, (void *)tmp})
     if (q) (void)hipFree(q);
-  pts = nullptr; cell_start = nullptr; count = nullptr; key0 = key1 = val0 = val1 = nullptr; err = nullptr; tmp = nullptr;
-  cap_pts = cap_cell = cap_count = cap_k0 = cap_k1 = cap_v0 = cap_v1 = cap_err = cap_tmp = 0;
+  pts = nullptr; cell_start = nullptr; key0 = key1 = val0 = val1 = nullptr; err = nullptr; tmp = nullptr;
+  cap_pts = cap_cell = cap_k0 = cap_k1 = cap_v0 = cap_v1 = cap_err = cap_tmp = 0;
   view = CellGrid{};
   n_cells = 0;
 }

@@ -273,9 +273,9 @@ struct GridDev {
   size_t n_cells = 0;
   float4 *pts = nullptr;
   int32_t *err = nullptr;
-  uint32_t *cell_start = nullptr, *count = nullptr, *key0 = nullptr, *key1 = nullptr, *val0 = nullptr, *val1 = nullptr;
+  uint32_t *cell_start = nullptr, *key0 = nullptr, *key1 = nullptr, *val0 = nullptr, *val1 = nullptr;
   char *tmp = nullptr;
-  size_t cap_pts = 0, cap_cell = 0, cap_count = 0, cap_k0 = 0, cap_k1 = 0, cap_v0 = 0, cap_v1 = 0, cap_err = 0, cap_tmp = 0;
+  size_t cap_pts = 0, cap_cell = 0, cap_k0 = 0, cap_k1 = 0, cap_v0 = 0, cap_v1 = 0, cap_err = 0, cap_tmp = 0;
   template <typename T>
   static hipError_t reserve(T *&p, size_t &cap, size_t n) {
     if (n <= cap) return hipSuccess;
@@ -362,7 +362,7 @@ bool ctx_alive(const lslam_ctx *ctx);
 
 // lslam_fmap.hip: pcl::VoxelGrid per segment (see there)
 int voxel_filter_segments(hipStream_t s, const float4 *in_pts, const int32_t *in_seg, size_t n, int nseg, float leaf,
-                          float4 *out_pts, int32_t *out_seg, size_t *n_out, bool filter = true);
+                          float4 *out_pts, int32_t *out_seg, size_t *n_out, bool filter = true, uint32_t *done = nullptr);
 
 // lslam_scanprep.hip: Morton ordering of the resident scans on the device
 struct ScanPrep;

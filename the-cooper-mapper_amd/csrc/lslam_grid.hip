@@ -1,14 +1,15 @@
-// lslam_grid.hip -- builds the cell grid of lslam_grid.hpp over a map whose kd-tree exists (the grid search's fallback and
-// the source of the bounding box): points sorted by cell and the cell -> first point table.  Everything on the device, stream-ordered; the one value the host needs (the bounding box) it already has from the
-// tree build (TreeView::bb_lo / bb_hi = nanoflann's root_bbox, nanoflann.hpp:1406-1427).
+// lslam_grid.hip -- builds the cell grid of lslam_grid.hpp: points grouped by cell and the cell -> first point table.
+// Everything on the device, stream-ordered; the one value the host needs (the bounding box) it either has from the tree build
+// (TreeView::bb_lo / bb_hi = nanoflann's root_bbox, nanoflann.hpp:1406-1427) or reduces in one round trip (grid_bbox2).
 //
-// The key sort is rocPRIM's radix sort, held to its onesweep form (its default below 1 Mi keys is a merge sort of ~20 launches for
-// the 587 k points of a surf surround: 140 us against 30); the cell -> first point table is written straight from the sorted keys
-// (grid_cellstart_kernel: no count table, no memset, no device-wide scan -- for a deferred-trees map this runs once per frame).
+// A counting sort without a sort: count per cell (atomics into a dense table that every build leaves zeroed for the next one),
+// one scan kernel (grid_scan_kernel: coarse counts per 4096 cells give each workgroup its offset, no device-wide scan
+// primitive), placement through the counts as cursors, and a rank pass that puts the points of a cell in the order of their
+// original index -- the grid is the same bits whatever order the atomics ran in.  For a deferred-trees map this runs once
+// per frame: four launches per feature type (rocPRIM's radix sort + scan took 25: 140 + 65 us for 587 k points).
 #include "lslam_grid.hpp"
 #include "lslam_internal.hpp"
 
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -26,47 +27,51 @@ LSLAM_DEV int cell_of(const CellGrid &G, const float4 &p, bool &ok) {
   return ok ? (int)ux + G.nx * ((int)uy + G.ny * (int)uz) : 0;
 }
 
-__global__ __launch_bounds__(256) void grid_key_kernel(CellGrid G, const float4 *tree_pts, uint32_t *key, uint32_t *val, int32_t *err) {
+constexpr int CS_CELLS = 4096;   // cells per workgroup of the scan
+constexpr int RANK_MAX = 1024;   // cells with more points keep the order the atomics gave them (such a cell is never proven from)
+
+__global__ __launch_bounds__(256) void grid_count_kernel(CellGrid G, const float4 *src, uint32_t *count, uint32_t *coarse, int32_t *err) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= G.n_pts) return;
   bool ok;
-  const int c = cell_of(G, tree_pts[i], ok);
+  const int c = cell_of(G, src[i], ok);
   if (!ok) atomicAdd(err, 1);  // a point outside its own bounding box: not a number
-  key[i] = (uint32_t)c;
-  val[i] = (uint32_t)i;
+  atomicAdd(count + c, 1u);
+  // the coarse count: neighbouring points share it more often than not -- one atomic per distinct value in the wavefront
+  const int cb = c / CS_CELLS;
+  unsigned long long todo = __ballot(1);
+  while (todo) {
+    const int first = __builtin_amdgcn_readlane(cb, __builtin_ctzll(todo));
+    const unsigned long long same = __ballot(cb == first) & todo;
+    if ((int)(threadIdx.x & 63) == __builtin_ctzll(same)) atomicAdd(coarse + first, (uint32_t)__popcll(same));
+    todo &= ~same;
+  }
 }
 
-// cell_start[c] = number of points in cells < c, for c in [0, ncell]: each workgroup owns CS_CELLS consecutive cells, finds its
-// slice of the SORTED keys by two binary searches, counts it into LDS and scans there.  HBM traffic: the table written once
-// (4 B per cell), the keys read once.
-constexpr int CS_CELLS = 4096;
-__global__ __launch_bounds__(256) void grid_cellstart_kernel(const uint32_t *keys, int n, uint32_t ncell_plus1, uint32_t *cell_start) {
-  __shared__ uint32_t cnt[CS_CELLS];
-  __shared__ uint32_t wave_sum[4];
-  __shared__ int slice[2];
-  const int tid = threadIdx.x;
+// cell_start[c] = number of points in cells < c, for c in [0, ncell]: each workgroup owns CS_CELLS consecutive cells; what
+// lies before them is the sum of the coarse counts of the workgroups before it.  HBM traffic: the counts read once, the table
+// written once.
+__global__ __launch_bounds__(256) void grid_scan_kernel(const uint32_t *count, const uint32_t *coarse, uint32_t ncell_plus1,
+                                                        uint32_t n_pts, uint32_t *cell_start) {
+  __shared__ uint32_t wave_sum[4], wave_before[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t base = blockIdx.x * (uint32_t)CS_CELLS;
+  uint32_t pre = 0;
+  for (uint32_t b = tid; b < blockIdx.x; b += 256) pre += coarse[b];
 #pragma unroll
-  for (int k = 0; k < CS_CELLS / 256 / 4; ++k) reinterpret_cast<uint4 *>(cnt)[tid + 256 * k] = make_uint4(0u, 0u, 0u, 0u);
-  if (tid < 2) {  // first key >= base (tid 0), first key >= base + CS_CELLS (tid 1)
-    const uint64_t target = (uint64_t)base + (uint64_t)tid * CS_CELLS;
-    int lo = 0, hi = n;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if ((uint64_t)keys[mid] < target) lo = mid + 1; else hi = mid;
-    }
-    slice[tid] = lo;
-  }
-  __syncthreads();
-  const int j0 = slice[0], j1 = slice[1];
-  for (int j = j0 + tid; j < j1; j += 256) atomicAdd(&cnt[keys[j] - base], 1u);
-  __syncthreads();
-  // exclusive scan of the 4096 counters: 16 per thread, wavefront scan of the thread sums, four wavefront sums through LDS
+  for (int d = 32; d > 0; d >>= 1) pre += __shfl_xor(pre, d, 64);
+  if (lane == 0) wave_before[wave] = pre;
+  const uint32_t c0 = base + 16u * (uint32_t)tid;
   uint32_t v[16];
+  if (c0 + 16u <= ncell_plus1 - 1u) {  // (the table has ncell_plus1 - 1 counts)
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const uint4 q = reinterpret_cast<const uint4 *>(cnt)[4 * tid + k];
-    v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+    for (int k = 0; k < 4; ++k) {
+      const uint4 q = reinterpret_cast<const uint4 *>(count + c0)[k];
+      v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = (c0 + (uint32_t)k < ncell_plus1 - 1u) ? count[c0 + k] : 0u;
   }
   uint32_t run = 0;
 #pragma unroll
@@ -75,7 +80,6 @@ __global__ __launch_bounds__(256) void grid_cellstart_kernel(const uint32_t *key
     v[k] = run;
     run += c;
   }
-  const int lane = tid & 63, wave = tid >> 6;
   uint32_t incl = run;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -84,9 +88,9 @@ __global__ __launch_bounds__(256) void grid_cellstart_kernel(const uint32_t *key
   }
   if (lane == 63) wave_sum[wave] = incl;
   __syncthreads();
-  uint32_t before = (uint32_t)j0 + incl - run;
+  uint32_t before = wave_before[0] + wave_before[1] + wave_before[2] + wave_before[3] + incl - run;
   for (int w = 0; w < wave; ++w) before += wave_sum[w];
-  const uint32_t c0 = base + 16u * (uint32_t)tid;
+  (void)n_pts;
   if (c0 + 16u <= ncell_plus1) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -98,11 +102,34 @@ __global__ __launch_bounds__(256) void grid_cellstart_kernel(const uint32_t *key
   }
 }
 
-__global__ __launch_bounds__(256) void grid_place_kernel(int n, const float4 *tree_pts, const uint32_t *val_sorted, float4 *gpts) {
+// every point to a slot of its cell's run; the count is the cursor and ends at zero -- the table is clean for the next build
+__global__ __launch_bounds__(256) void grid_scatter_kernel(CellGrid G, const float4 *src, const uint32_t *cell_start, uint32_t *count,
+                                                           float4 *tmp) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= G.n_pts) return;
+  const float4 p = src[i];
+  bool ok;
+  const int c = cell_of(G, p, ok);
+  const uint32_t left = atomicSub(count + c, 1u);
+  tmp[cell_start[c] + left - 1u] = p;
+}
+
+// ... and inside its run to the place its original index gives it (.w): the grid does not depend on the order of the atomics
+__global__ __launch_bounds__(256) void grid_rank_kernel(CellGrid G, const float4 *tmp, const uint32_t *cell_start, float4 *pts) {
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
-  const uint32_t t = val_sorted[j];
-  gpts[j] = tree_pts[t];  // .w carries the original index already
+  if (j >= G.n_pts) return;
+  const float4 p = tmp[j];
+  bool ok;
+  const int c = cell_of(G, p, ok);
+  const uint32_t s = cell_start[c], e = cell_start[c + 1];
+  uint32_t at = (uint32_t)j;
+  if (e - s <= (uint32_t)RANK_MAX) {
+    const uint32_t me = __float_as_uint(p.w);
+    uint32_t rank = 0;
+    for (uint32_t i = s; i < e; ++i) rank += __float_as_uint(tmp[i].w) < me ? 1u : 0u;
+    at = s + rank;
+  }
+  pts[at] = p;
 }
 
 __device__ __forceinline__ uint32_t ordered_u32(float f) {  // monotone map float -> uint32 (for atomicMin / atomicMax)
@@ -206,25 +233,29 @@ hipError_t GridDev::build(const float4 *src, int n_src, const float lo[3], const
   hipError_t e;
 #define G_TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
   G_TRY(reserve(pts, cap_pts, (size_t)n + 16));
+  G_TRY(reserve(tmp_pts, cap_tmp, (size_t)n + 16));
   G_TRY(reserve(cell_start, cap_cell, ncell + 1));
-  G_TRY(reserve(key0, cap_k0, (size_t)n));
-  G_TRY(reserve(key1, cap_k1, (size_t)n));
-  G_TRY(reserve(val0, cap_v0, (size_t)n));
-  G_TRY(reserve(val1, cap_v1, (size_t)n));
+  const size_t n_coarse = (ncell + CS_CELLS - 1) / CS_CELLS;
+  G_TRY(reserve(coarse, cap_coarse, n_coarse));
   G_TRY(reserve(err, cap_err, 1));
+  {
+    // the count table is left zeroed by every build (the scatter counts it down); only a new allocation is cleared
+    const size_t before = cap_count;
+    G_TRY(reserve(count, cap_count, ncell + 16));
+    if (cap_count != before || !count_clean) G_TRY(hipMemsetAsync(count, 0, cap_count * sizeof(uint32_t), s));
+    count_clean = false;
+  }
+  G_TRY(hipMemsetAsync(coarse, 0, n_coarse * sizeof(uint32_t), s));
   G_TRY(hipMemsetAsync(err, 0, sizeof(int32_t), s));
   const dim3 blk(256), grd((n + 255) / 256);
-  hipLaunchKernelGGL(grid_key_kernel, grd, blk, 0, s, G, src, key0, val0, err);
-  unsigned end_bit = 1;
-  while (((size_t)1 << end_bit) < ncell) ++end_bit;
-  using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 16384>;
-  size_t tmp_sort = 0;
-  G_TRY(rocprim::radix_sort_pairs<SortCfg>(nullptr, tmp_sort, key0, key1, val0, val1, (size_t)n, 0u, end_bit, s));
-  G_TRY(reserve(tmp, cap_tmp, tmp_sort));
-  G_TRY(rocprim::radix_sort_pairs<SortCfg>((void *)tmp, tmp_sort, key0, key1, val0, val1, (size_t)n, 0u, end_bit, s));
-  hipLaunchKernelGGL(grid_cellstart_kernel, dim3((unsigned)((ncell + 1 + CS_CELLS - 1) / CS_CELLS)), blk, 0, s, (const uint32_t *)key1, n,
-                     (uint32_t)(ncell + 1), cell_start);
-  hipLaunchKernelGGL(grid_place_kernel, grd, blk, 0, s, n, src, val1, pts);
+  hipLaunchKernelGGL(grid_count_kernel, grd, blk, 0, s, G, src, count, coarse, err);
+  hipLaunchKernelGGL(grid_scan_kernel, dim3((unsigned)((ncell + 1 + CS_CELLS - 1) / CS_CELLS)), blk, 0, s, (const uint32_t *)count,
+                     (const uint32_t *)coarse, (uint32_t)(ncell + 1), (uint32_t)n, cell_start);
+  hipLaunchKernelGGL(grid_scatter_kernel, grd, blk, 0, s, G, src, (const uint32_t *)cell_start, count, tmp_pts);
+  G.cell_start = cell_start;  // (the rank kernel reads the table through the view)
+  hipLaunchKernelGGL(grid_rank_kernel, grd, blk, 0, s, G, (const float4 *)tmp_pts, (const uint32_t *)cell_start, pts);
+  G_TRY(hipGetLastError());
+  count_clean = true;  // once the stream gets there
   // the candidate loop loads pts[cur] for lanes that have run out of candidates at index 0: nothing to pad; a leaf-style
   // over-read does not exist here
   int32_t h_err = 0;
@@ -242,11 +273,11 @@ hipError_t GridDev::build(const float4 *src, int n_src, const float lo[3], const
 }
 
 void GridDev::release() {
-  for (void *q : {(void *)pts, (void *)cell_start, (void *)key0, (void *)key1, (void *)val0, (void *)val1,
-                  (void *)err, (void *)tmp})
+  for (void *q : {(void *)pts, (void *)tmp_pts, (void *)cell_start, (void *)count, (void *)coarse, (void *)err})
     if (q) (void)hipFree(q);
-  pts = nullptr; cell_start = nullptr; key0 = key1 = val0 = val1 = nullptr; err = nullptr; tmp = nullptr;
-  cap_pts = cap_cell = cap_k0 = cap_k1 = cap_v0 = cap_v1 = cap_err = cap_tmp = 0;
+  pts = tmp_pts = nullptr; cell_start = count = coarse = nullptr; err = nullptr;
+  cap_pts = cap_tmp = cap_cell = cap_count = cap_coarse = cap_err = 0;
+  count_clean = false;
   view = CellGrid{};
   n_cells = 0;
 }

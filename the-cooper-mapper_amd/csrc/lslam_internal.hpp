@@ -271,11 +271,11 @@ hipError_t launch_knn5_grid(const CellGrid &G, const TreeView &T, const float4 *
 struct GridDev {
   CellGrid view{};
   size_t n_cells = 0;
-  float4 *pts = nullptr;
+  float4 *pts = nullptr, *tmp_pts = nullptr;
   int32_t *err = nullptr;
-  uint32_t *cell_start = nullptr, *key0 = nullptr, *key1 = nullptr, *val0 = nullptr, *val1 = nullptr;
-  char *tmp = nullptr;
-  size_t cap_pts = 0, cap_cell = 0, cap_k0 = 0, cap_k1 = 0, cap_v0 = 0, cap_v1 = 0, cap_err = 0, cap_tmp = 0;
+  uint32_t *cell_start = nullptr, *count = nullptr, *coarse = nullptr;
+  size_t cap_pts = 0, cap_tmp = 0, cap_cell = 0, cap_count = 0, cap_coarse = 0, cap_err = 0;
+  bool count_clean = false;  // every cell of `count` is zero (each build leaves it so)
   template <typename T>
   static hipError_t reserve(T *&p, size_t &cap, size_t n) {
     if (n <= cap) return hipSuccess;

@@ -527,8 +527,11 @@ int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, s
   // pack {x, y, z, intensity-to-copy} (toXYZI, util/pcl_util.h:30-37: the `curvature` field)
   float4 *h = cache.pin;
   const char *src = static_cast<const char *>(cloud);
+  bool uploaded = false;
   if (stride_bytes == 16 && intensity_offset_bytes == 12) {
-    std::memcpy(h, src, n_points * sizeof(float4));
+    // already {x, y, z, w}: copied to pinned memory and sent off a quarter at a time -- the link works on one quarter while
+    // the host copies the next (the device arrays are carved further down; the upload target is the blob's head)
+    uploaded = true;
   } else {
     for (size_t i = 0; i < n_points; ++i) {
       float v[3], w;
@@ -560,7 +563,16 @@ int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, s
   int rc = LSLAM_OK;
   auto fail = [&](int code) { return code; };
 #define FX_TRY2(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { lslam::set_error(hipGetErrorString(_e)); return fail(LSLAM_ERR_HIP); } } while (0)
-  FX_TRY2(hipMemcpyAsync(d_pts, h, np4, hipMemcpyHostToDevice, s));
+  if (uploaded) {
+    const size_t quarter = (n_points + 3) / 4;
+    for (size_t b = 0; b < n_points; b += quarter) {
+      const size_t cnt = std::min(quarter, n_points - b);
+      std::memcpy(h + b, src + b * sizeof(float4), cnt * sizeof(float4));
+      FX_TRY2(hipMemcpyAsync(d_pts + b, h + b, cnt * sizeof(float4), hipMemcpyHostToDevice, s));
+    }
+  } else {
+    FX_TRY2(hipMemcpyAsync(d_pts, h, np4, hipMemcpyHostToDevice, s));
+  }
   FX_TRY2(hipMemcpyAsync(d_ranges, scan_ranges, 2 * n_scans * 4, hipMemcpyHostToDevice, s));
   if (curvature_out) FX_TRY2(hipMemsetAsync(d_curv, 0, n_points * 4, s));
   if (picked_out) FX_TRY2(hipMemsetAsync(d_picked, 0, n_points, s));
@@ -619,9 +631,7 @@ int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, s
     float4 *dst = small_fit ? d_out + (size_t)totals[3] + dev_off : d_out;
     hipLaunchKernelGGL(fx_compact_kernel, dim3((totals[k] + 255) / 256), dim3(256), 0, s, d_pts, stage[k], d_ranges,
                        d_off + k * (n_scans + 1), (int)n_scans, totals[k], dst, (int32_t *)nullptr);
-    if (small_fit) {
-      if (outs[k]) FX_TRY2(hipMemcpyAsync(pin_lists + dev_off, dst, (size_t)totals[k] * sizeof(float4), hipMemcpyDeviceToHost, s));
-    } else {  // (a point in more than one list often enough to overflow the shared area: list by list, as before)
+    if (!small_fit) {  // (a point in more than one list often enough to overflow the shared area: list by list, as before)
       if (outs[k]) FX_TRY2(hipMemcpyAsync(outs[k], dst, (size_t)totals[k] * sizeof(float4), hipMemcpyDeviceToHost, s));
       FX_TRY2(hipStreamSynchronize(s));
     }
@@ -635,6 +645,9 @@ int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, s
     rc = lslam::voxel_filter_segments(s, d_out, d_seg, (size_t)totals[3], (int)n_scans, prm.less_flat_filter_size, d_out2,
                                       d_seg2, &m, true, done);
   }
+  // the three small lists in ONE copy behind all the kernels (a copy between two launches is a bubble of its own)
+  if (rc == LSLAM_OK && small_fit && small_total)
+    FX_TRY2(hipMemcpyAsync(pin_lists, d_out + (size_t)totals[3], small_total * sizeof(float4), hipMemcpyDeviceToHost, s));
   if (rc == LSLAM_OK) {
     FX_TRY2(hipStreamSynchronize(s));  // the small lists are in pinned memory, the filter's count is known
     if (done[1]) {  // the wide key did not hold the extent: the filter once more, with the measured one

@@ -170,49 +170,88 @@ __device__ __forceinline__ float ordered_float(int32_t i) { return __int_as_floa
 // for the cube its first point belongs to (points of another cube -- a run boundary -- go straight
 // to the atomics), reduces once and issues six atomics.  One wavefront per 64 points doing that was
 // 100 k atomics on 64 cache lines: 146 us for a million points, now ~15.
-constexpr int MM_RUN = 512;  // points per wavefront
+constexpr int MM_RUN = 256;  // points per wavefront
 __global__ __launch_bounds__(256) void fm_minmax_kernel(const float4 *pts, const int32_t *cube, int n, const uint8_t *flags,
                                                         int32_t *cmin, int32_t *cmax) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int first = wave * MM_RUN;
   if (first >= n) return;
-  const int32_t c0 = cube[first];  // wave-uniform
-  const bool c0_on = c0 >= 0 && flags[c0];
-  int32_t lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
-#pragma unroll 4
-  for (int k = 0; k < MM_RUN / 64; ++k) {
-    const int i = first + k * 64 + lane;
-    if (i >= n) break;
-    const int32_t c = cube[i];
-    if (c < 0 || !flags[c]) continue;
-    const float4 p = pts[i];
-    const int32_t o[3] = {ordered_int(p.x), ordered_int(p.y), ordered_int(p.z)};
-    if (c == c0) {
+  // the run's data first, all chunks at once (cube -> flag -> point is a chain of three dependent loads: chunk after chunk it
+  // was most of the kernel's time), then the bookkeeping on registers
+  constexpr int K = MM_RUN / 64;
+  int32_t cc[K];
+  bool onn[K];
+  float4 pp[K];
 #pragma unroll
-      for (int d = 0; d < 3; ++d) { lo[d] = min(lo[d], o[d]); hi[d] = max(hi[d], o[d]); }
-    } else {
+  for (int k = 0; k < K; ++k) {
+    const int i = first + k * 64 + lane;
+    cc[k] = i < n ? cube[i] : -2;
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) onn[k] = cc[k] >= 0 && flags[cc[k]];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int i = first + k * 64 + lane;
+    pp[k] = onn[k] ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  int32_t cur = -1;
+  int32_t lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+  auto flush = [&]() {
+    if (cur < 0) return;  // wave-uniform
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1)
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
-        if (o[d] < cmin[3 * c + d]) atomicMin(&cmin[3 * c + d], o[d]);
-        if (o[d] > cmax[3 * c + d]) atomicMax(&cmax[3 * c + d], o[d]);
+        lo[d] = min(lo[d], __shfl_xor(lo[d], s, 64));
+        hi[d] = max(hi[d], __shfl_xor(hi[d], s, 64));
+      }
+    if (lane == 0)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        if (lo[d] < cmin[3 * cur + d]) atomicMin(&cmin[3 * cur + d], lo[d]);
+        if (hi[d] > cmax[3 * cur + d]) atomicMax(&cmax[3 * cur + d], hi[d]);
+      }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { lo[d] = INT32_MAX; hi[d] = INT32_MIN; }
+  };
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int base = first + k * 64;
+    if (base >= n) break;  // wave-uniform
+    const int i = base + lane;
+    const bool in = i < n;
+    const int32_t c = cc[k];
+    const bool on = onn[k];
+    const float4 p = pp[k];
+    const int32_t o[3] = {ordered_int(p.x), ordered_int(p.y), ordered_int(p.z)};
+    // the cube of the chunk's first lane; uniform chunk: every in-range lane has it
+    const int32_t c_first = __builtin_amdgcn_readfirstlane(c);
+    const bool uniform = __ballot(in && c != c_first) == 0ull;
+    if (uniform) {
+      const bool first_on = __builtin_amdgcn_readfirstlane((int)on) != 0;  // (the first lane is in range and has c_first)
+      if (c_first != cur) {
+        flush();
+        cur = first_on ? c_first : -1;
+      }
+      if (on) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { lo[d] = min(lo[d], o[d]); hi[d] = max(hi[d], o[d]); }
+      }
+    } else if (on) {
+      if (c == cur) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { lo[d] = min(lo[d], o[d]); hi[d] = max(hi[d], o[d]); }
+      } else {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          if (o[d] < cmin[3 * c + d]) atomicMin(&cmin[3 * c + d], o[d]);
+          if (o[d] > cmax[3 * c + d]) atomicMax(&cmax[3 * c + d], o[d]);
+        }
       }
     }
   }
-  if (!c0_on) return;  // wave-uniform
-#pragma unroll
-  for (int s = 32; s > 0; s >>= 1)
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      lo[d] = min(lo[d], __shfl_xor(lo[d], s, 64));
-      hi[d] = max(hi[d], __shfl_xor(hi[d], s, 64));
-    }
-  if (lane == 0)
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      if (lo[d] < cmin[3 * c0 + d]) atomicMin(&cmin[3 * c0 + d], lo[d]);
-      if (hi[d] > cmax[3 * c0 + d]) atomicMax(&cmax[3 * c0 + d], hi[d]);
-    }
+  flush();
 }
 
 // per cube: min_b, the "leaf too small" guard of applyFilter, the widest voxel extent
@@ -290,23 +329,67 @@ __global__ void fm_head_kernel(const uint64_t *keys, int n, int axis_bits, int s
   head[i] = h;
 }
 
-// one thread per voxel (head): centroid over its members in sorted (= input) order
-__global__ void fm_centroid_kernel(const float4 *pts, const uint64_t *keys, const uint32_t *idx, const uint32_t *head,
-                                   const uint32_t *pos, int n, int axis_bits, float4 *out, int32_t *cube_out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !head[i]) return;
-  const uint64_t k = keys[i];
-  float4 p = pts[idx[i]];
+// Centroid of every voxel over its members in sorted (= input) order.  The sums are sequential by definition (PCL's order), the
+// loads are not: every lane fetches ITS point (64 independent gathers per wavefront), then each head lane adds its members'
+// values, in order, out of its neighbours' registers; only a voxel that runs past the end of its wavefront goes on from memory.
+__global__ __launch_bounds__(256) void fm_centroid_kernel(const float4 *pts, const uint64_t *keys, const uint32_t *idx, const uint32_t *head,
+                                                          const uint32_t *pos, int n, int axis_bits, float4 *out, int32_t *cube_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  const bool in = i < n;
+  const uint64_t k = in ? keys[i] : KEY_DROP;
+  const bool is_head = in && head[i] != 0;
+  const bool member = in && !is_head && k != KEY_DROP;  // (a dropped point is nobody's member: fm_head_kernel gives it no head either)
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (is_head || member) p = pts[idx[i]];
+  const unsigned long long mm = __ballot(member);
+  // members that follow this lane inside the wavefront
+  const unsigned long long after = lane == 63 ? 0ull : ~(mm >> (lane + 1));
+  const int len = is_head ? (lane == 63 ? 0 : (after == 0ull ? 63 - lane : min(__builtin_ctzll(after), 63 - lane))) : 0;
+  int longest = len;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) longest = max(longest, __shfl_xor(longest, d, 64));
   float sx = p.x, sy = p.y, sz = p.z, sw = p.w;
-  int j = i + 1;
-  while (j < n && !head[j] && keys[j] == k) {
-    p = pts[idx[j]];
-    sx = __fadd_rn(sx, p.x);
-    sy = __fadd_rn(sy, p.y);
-    sz = __fadd_rn(sz, p.z);
-    sw = __fadd_rn(sw, p.w);
-    ++j;
+  for (int m = 1; m <= longest; ++m) {
+    const int srcl = min(lane + m, 63);
+    const float qx = __shfl(p.x, srcl, 64), qy = __shfl(p.y, srcl, 64), qz = __shfl(p.z, srcl, 64), qw = __shfl(p.w, srcl, 64);
+    if (m <= len) {
+      sx = __fadd_rn(sx, qx);
+      sy = __fadd_rn(sy, qy);
+      sz = __fadd_rn(sz, qz);
+      sw = __fadd_rn(sw, qw);
+    }
   }
+  int j = i + 1 + len;
+  // a run that reached the end of the wavefront may go on (at most one per wavefront: its last): the whole wavefront fetches
+  // the next 64 entries for it, the owner adds them in order
+  const unsigned long long cm = __ballot(is_head && lane + len == 63);
+  if (cm) {  // wave-uniform
+    const int owner = __builtin_ctzll(cm);
+    const uint32_t k_lo = (uint32_t)__shfl((int)(uint32_t)k, owner, 64), k_hi = (uint32_t)__shfl((int)(uint32_t)(k >> 32), owner, 64);
+    const uint64_t kk = ((uint64_t)k_hi << 32) | k_lo;
+    int e0 = (i - lane) + 64;
+    for (;;) {
+      const int e = e0 + lane;
+      const bool valid = e < n && !head[e] && keys[e] == kk;
+      const unsigned long long vm = __ballot(valid);
+      const int L = ~vm == 0ull ? 64 : __builtin_ctzll(~vm);  // the run's members at the head of this chunk
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane < L) q = pts[idx[e]];
+      for (int m = 0; m < L; ++m) {
+        const float qx = __shfl(q.x, m, 64), qy = __shfl(q.y, m, 64), qz = __shfl(q.z, m, 64), qw = __shfl(q.w, m, 64);
+        if (lane == owner) {
+          sx = __fadd_rn(sx, qx);
+          sy = __fadd_rn(sy, qy);
+          sz = __fadd_rn(sz, qz);
+          sw = __fadd_rn(sw, qw);
+        }
+      }
+      if (lane == owner) j += L;
+      if (L < 64) break;
+      e0 += 64;
+    }
+  }
+  if (!is_head) return;
   const float cnt = (float)(j - i);
   // PCL starts from a zero vector: 0 + x = x, so the sums above equal its sums
   out[pos[i]] = make_float4(__fdiv_rn(sx, cnt), __fdiv_rn(sy, cnt), __fdiv_rn(sz, cnt), __fdiv_rn(sw, cnt));

@@ -137,10 +137,6 @@ __device__ __forceinline__ uint32_t ordered_u32(float f) {  // monotone map floa
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 __global__ __launch_bounds__(256) void grid_bbox_kernel(const float4 *pts, int n, uint32_t *box /* [6]: min xyz, max xyz (ordered) */) {
-  __shared__ uint32_t sm[6];
-  if (threadIdx.x < 3) sm[threadIdx.x] = 0xFFFFFFFFu;
-  else if (threadIdx.x < 6) sm[threadIdx.x] = 0u;
-  __syncthreads();
   uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const float4 p = pts[i];
@@ -151,14 +147,30 @@ __global__ __launch_bounds__(256) void grid_bbox_kernel(const float4 *pts, int n
       hi[a] = max(hi[a], v[a]);
     }
   }
+  // wavefront reduction in registers, then six atomics per wavefront (256 lanes on six LDS words serialise)
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    atomicMin(&sm[a], lo[a]);
-    atomicMax(&sm[3 + a], hi[a]);
+  for (int d = 32; d > 0; d >>= 1)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = min(lo[a], (uint32_t)__shfl_xor((int)lo[a], d, 64));
+      hi[a] = max(hi[a], (uint32_t)__shfl_xor((int)hi[a], d, 64));
+    }
+  __shared__ uint32_t part[4][6];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      part[wave][a] = lo[a];
+      part[wave][3 + a] = hi[a];
+    }
   }
   __syncthreads();
-  if (threadIdx.x < 3) atomicMin(&box[threadIdx.x], sm[threadIdx.x]);
-  else if (threadIdx.x < 6) atomicMax(&box[threadIdx.x], sm[threadIdx.x]);
+  if (threadIdx.x < 6) {  // six atomics per workgroup: same-address atomics from a whole grid serialise at the memory side
+    const int a = threadIdx.x;
+    uint32_t v = part[0][a];
+    for (int w = 1; w < 4; ++w) v = a < 3 ? min(v, part[w][a]) : max(v, part[w][a]);
+    if (a < 3) atomicMin(&box[a], v); else atomicMax(&box[a], v);
+  }
 }
 
 __global__ __launch_bounds__(256) void grid_unsort_kernel(int n, const float4 *gpts, float4 *out) {
@@ -186,7 +198,7 @@ hipError_t grid_bbox2(const float4 *const pts[2], const int n[2], uint32_t *d_bo
   hipError_t e = hipMemcpyAsync(d_box12, init, sizeof(init), hipMemcpyHostToDevice, s);
   if (e != hipSuccess) return e;
   for (int k = 0; k < 2; ++k)
-    if (n[k] > 0) hipLaunchKernelGGL(grid_bbox_kernel, dim3(std::min((n[k] + 255) / 256, 512)), dim3(256), 0, s, pts[k], n[k], d_box12 + 6 * k);
+    if (n[k] > 0) hipLaunchKernelGGL(grid_bbox_kernel, dim3(std::min((n[k] + 4095) / 4096, 256)), dim3(256), 0, s, pts[k], n[k], d_box12 + 6 * k);
   uint32_t h[12];
   e = hipMemcpyAsync(h, d_box12, sizeof(h), hipMemcpyDeviceToHost, s);
   if (e != hipSuccess) return e;

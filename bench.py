@@ -1182,9 +1182,12 @@ def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, 
              "scan_match", "add_feature_cloud")
     acc = {k: [] for k in steps}
     trees = []
-    frames = 6
+    # >= 200 frames for the 64-ring sequential and overlapped schedules (median, p99 and worst frame: the jitter is part of
+    # the result); the variants that only add a comparison run fewer
+    frames = 12 if cubes else 200
     quiet_gc()
-    for f in range(frames + 1):  # first frame = warm-up
+    WARM = 3  # frames before the timed ones (allocations grow to size, the map's first insert)
+    for f in range(frames + WARM):
         t0 = time.perf_counter()
         feat = pkg.scan_registration.extract_features(ctx, cloud, ranges)
         t1 = time.perf_counter()
@@ -1194,7 +1197,7 @@ def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, 
         t3 = time.perf_counter()
         if cubes:
             fm.to_cubemap()
-            if f > 0:
+            if f >= WARM:
                 trees.append(fm.cubemap_stats())
         else:
             fm.surround_to_map()
@@ -1205,15 +1208,19 @@ def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, 
         t6 = time.perf_counter()
         if f == 0:
             pose_first = pose.copy()  # same map state as the oracle's single frame below
-        if f > 0:
+        if f >= WARM:
             for k, d in zip(steps, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5)):
                 acc[k].append(d)
     # median over the frames: a single host-side stall (allocator, scheduler) in one frame would otherwise
     # dominate a 6-frame mean; the worst frame is reported next to it
     gpu = {k: 1e3 * float(np.median(v)) for k, v in acc.items()}
+    per_frame = np.array([sum(v[i] for v in acc.values()) for i in range(frames)]) * 1e3
     res = {"rings": rings, "gpu_ms": gpu, "gpu_ms_per_frame": sum(gpu.values()), "frames": frames,
            "gpu_ms_statistic": "median of the timed frames",
-           "gpu_ms_worst_frame": 1e3 * float(max(sum(v[i] for v in acc.values()) for i in range(frames))),
+           "gpu_ms_frame_median": float(np.median(per_frame)), "gpu_ms_p99": float(np.percentile(per_frame, 99)),
+           "gpu_ms_worst_frame": float(per_frame.max()), "worst_over_median": float(per_frame.max() / np.median(per_frame)),
+           "slowest_frames": [{"frame": int(i), "ms": round(float(per_frame[i]), 3),
+                               "steps_ms": {k: round(1e3 * acc[k][i], 3) for k in steps}} for i in np.argsort(-per_frame)[:3]],
            "sweep_points": int(len(cloud)), "features": {k: int(len(v)) for k, v in feat.items()},
            "scan_points_after_voxel_grid": int(len(dc) + len(ds)), "map_points": fm.info()["n_corner"] + fm.info()["n_surf"],
            "scan_match_iterations": int(st.iterations),
@@ -1252,6 +1259,10 @@ def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, 
                 f_ = pkg.scan_registration.extract_features(ctx_reg, cloud, ranges)
                 qout.put((pkg.voxel_grid(ctx_reg, f_["less_sharp"], 1.0), pkg.voxel_grid(ctx_reg, f_["less_flat"], 1.0)))
         th = threading.Thread(target=registration, daemon=True)
+        # two Python threads share the interpreter lock; its default hand-over interval is 5 ms -- longer than two frames.  (A C++
+        # host has no such lock; the library calls themselves run without it.)
+        switch_interval = sys.getswitchinterval()
+        sys.setswitchinterval(5e-5)
         th.start()
         ov = []
         for f in range(frames + 2):
@@ -1266,8 +1277,10 @@ def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, 
                 ov.append(time.perf_counter() - t0)
         qin.put(None)
         th.join()
+        sys.setswitchinterval(switch_interval)
         ctx_reg.close()
-        res["overlapped"] = {"gpu_ms_per_frame": 1e3 * float(np.median(ov)), "gpu_ms_worst_frame": 1e3 * float(max(ov)), "frames": len(ov),
+        res["overlapped"] = {"gpu_ms_per_frame": 1e3 * float(np.median(ov)), "gpu_ms_p99": 1e3 * float(np.percentile(ov, 99)),
+                             "gpu_ms_worst_frame": 1e3 * float(max(ov)), "worst_over_median": float(max(ov) / np.median(ov)), "frames": len(ov),
                              "schedule": "registration thread (extract_features + voxel_grid, own context) beside update + "
                                          "surround_to_map; then scan_match, add_feature_cloud -- the reference's nodelet split "
                                          "(MultiScanRegistration | LaserMapping)",

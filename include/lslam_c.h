@@ -359,6 +359,11 @@ int lslam_fmap_to_cubemap(lslam_fmap *fm);
  * since their tree was built (addFeatureCloud marks the cubes that received points; shifts and loads mark all).
  * Counts of the last call: trees built in it / trees kept from earlier calls. */
 int lslam_fmap_cubemap_stats(lslam_fmap *fm, int64_t *trees_built, int64_t *trees_reused);
+/* How lslam_fmap_add_feature_cloud's rebuilds of the point arrays went so far (per feature type and call).  The current points
+ * are an earlier rebuild's output, hence in (cube, voxel) key order: only the new points are sorted and merged in (`merged`).
+ * The order is checked on the device; when it does not hold -- a cube that has just become active gets voxel keys it did not
+ * have, a centroid can round onto a voxel wall -- the whole array is sorted as before (`resorted`).  Same arrays either way. */
+int lslam_fmap_rebuild_stats(lslam_fmap *fm, int64_t *merged, int64_t *resorted);
 /* Forget the cached trees (the next lslam_fmap_to_cubemap rebuilds the whole active area). */
 int lslam_fmap_cubemap_invalidate(lslam_fmap *fm);
 /* getFullMap, FeatureMap.h:267-286: per cube, VoxelGrid(map leaf) of corner then surf. */

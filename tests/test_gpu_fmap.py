@@ -90,6 +90,19 @@ def test_feature_map_small_grid_with_shifts(pkg, ctx, oracle):
         ofm.add_feature_cloud(pts[:700], pts[700:], T)
         _compare_maps(fm, ofm, ("after add", step))
     assert np.array_equal(bits(fm.get_full_map()), bits(ofm.get_full_map()))
+    # the rebuilds took both forms on the way: new points merged into arrays that are in key order already, and everything
+    # sorted again where the order did not hold (cubes that had just become active carry unfiltered points) -- and two inserts
+    # in a row with no update between them must merge
+    merged0, resorted0 = fm.rebuild_stats()
+    assert merged0 > 0 and resorted0 > 0, (merged0, resorted0)
+    for k in range(2):
+        pts = rng.normal(0, 9.0, (3000, 4)).astype(np.float32)
+        pts[:, 2] *= 0.3
+        fm.add_feature_cloud(pts[:500], pts[500:], T)
+        ofm.add_feature_cloud(pts[:500], pts[500:], T)
+        _compare_maps(fm, ofm, ("after add without update", k))
+    merged1, resorted1 = fm.rebuild_stats()
+    assert merged1 >= merged0 + 3 and resorted1 <= resorted0 + 1, (merged0, resorted0, merged1, resorted1)
     fm.close()
 
 

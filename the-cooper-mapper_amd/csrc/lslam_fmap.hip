@@ -315,6 +315,36 @@ __global__ void fm_key_kernel(const float4 *pts, const int32_t *cube, int n, Key
   keys[i] = (key << (3 * ab)) | vox;
 }
 
+// [n_sorted keys already in order | n_new keys, sorted separately into kn / in] -> one sorted sequence, old before new among
+// equal keys (what a stable sort of the concatenation gives).  Every element finds its place by one binary search in the
+// other list.  A prefix that is not in order after all raises *unsorted (the caller sorts everything instead).
+__global__ void fm_merge_kernel(const uint64_t *k0, int n_sorted, const uint64_t *kn, const uint32_t *in, int n_new, uint64_t *k1,
+                                uint32_t *i1, int32_t *unsorted) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_sorted + n_new) return;
+  if (t < n_sorted) {
+    const uint64_t key = k0[t];
+    if (t > 0 && k0[t - 1] > key) atomicExch(unsorted, 1);
+    int lo = 0, hi = n_new;  // new keys < key
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (kn[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    k1[t + lo] = key;
+    i1[t + lo] = (uint32_t)t;
+  } else {
+    const int j = t - n_sorted;
+    const uint64_t key = kn[j];
+    int lo = 0, hi = n_sorted;  // old keys <= key
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (k0[mid] <= key) lo = mid + 1; else hi = mid;
+    }
+    k1[j + lo] = key;
+    i1[j + lo] = in[j];
+  }
+}
+
 __global__ void fm_head_kernel(const uint64_t *keys, int n, int axis_bits, int single, const uint8_t *flags,
                                uint32_t *head) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -340,7 +370,8 @@ __global__ __launch_bounds__(256) void fm_centroid_kernel(const float4 *pts, con
   const bool is_head = in && head[i] != 0;
   const bool member = in && !is_head && k != KEY_DROP;  // (a dropped point is nobody's member: fm_head_kernel gives it no head either)
   float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (is_head || member) p = pts[idx[i]];
+  if (is_head || member) p = pts[min(idx[i], (uint32_t)(n - 1))];  // (clamped: after a merge whose prefix was not in order the slots are
+                                                                       // not a permutation -- the result is discarded, the loads must stay inside)
   const unsigned long long mm = __ballot(member);
   // members that follow this lane inside the wavefront
   const unsigned long long after = lane == 63 ? 0ull : ~(mm >> (lane + 1));
@@ -374,7 +405,7 @@ __global__ __launch_bounds__(256) void fm_centroid_kernel(const float4 *pts, con
       const unsigned long long vm = __ballot(valid);
       const int L = ~vm == 0ull ? 64 : __builtin_ctzll(~vm);  // the run's members at the head of this chunk
       float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (lane < L) q = pts[idx[e]];
+      if (lane < L) q = pts[min(idx[e], (uint32_t)(n - 1))];
       for (int m = 0; m < L; ++m) {
         const float qx = __shfl(q.x, m, 64), qy = __shfl(q.y, m, 64), qz = __shfl(q.z, m, 64), qw = __shfl(q.w, m, 64);
         if (lane == owner) {
@@ -438,14 +469,14 @@ int bits_for(double cells) {
 }
 
 struct Scratch {
-  Buf<uint64_t> k0, k1;
-  Buf<uint32_t> i0, i1, head, pos;
+  Buf<uint64_t> k0, k1, kn;
+  Buf<uint32_t> i0, i1, in_, head, pos;
   Buf<char> tmp;
-  Buf<int32_t> err;               // [0] key-range error, [1] widest voxel extent of a filtered cube
+  Buf<int32_t> err;               // [0] key-range error, [1] widest voxel extent of a filtered cube, [2] the "sorted" prefix was not
   Buf<int32_t> cmin, cmax, base;  // [ncube][3]
   Buf<uint8_t> eff;               // [ncube] cubes this rebuild really filters
   void release() {
-    k0.release(); k1.release(); i0.release(); i1.release(); head.release(); pos.release(); tmp.release();
+    k0.release(); k1.release(); kn.release(); i0.release(); i1.release(); in_.release(); head.release(); pos.release(); tmp.release();
     err.release(); cmin.release(); cmax.release(); base.release(); eff.release();
   }
 };
@@ -511,6 +542,7 @@ struct lslam_fmap {
   Buf<int32_t> d_cells[2];
   Buf<lslam::TreeView> d_views[2];
   int64_t trees_built = 0, trees_reused = 0;  // statistics of the last lslam_fmap_to_cubemap
+  int64_t merged_rebuilds = 0, resorted_rebuilds = 0;  // addFeatureCloud rebuilds that merged the new points in / that had to sort everything after all
   int forest_attempt0 = 0;                     // node-slot guess the last forest build succeeded with (lslam_fmap_to_cubemap)
 };
 
@@ -540,21 +572,25 @@ int cube_bits(int ncube) {
 // assume_axis_bits > 0: the caller knows a bound of the voxel extent of every filtered cube (a map cube is cube_size wide), so
 // the widest extent is not read back (one host wait less); the key-range check of fm_key_kernel still guards it.  Only taken
 // while the sort is rocPRIM's merge sort, whose cost does not grow with the key width.
-// done != nullptr: no wait at the end either -- {points out, key-range error} land in done[0..1] (pinned) behind everything
-// else on the stream; *n_out is not written.
+// done != nullptr: no wait at the end either -- {points out, key-range error, prefix-not-sorted} land in done[0..2] (pinned)
+// behind everything else on the stream; *n_out is not written.
+// n_sorted > 0: the first n_sorted points are the output of an earlier rebuild, i.e. in key order already (a centroid lies in
+// its voxel) -- only the rest is sorted and the two are merged: one search per element instead of a sort of everything.
+// Checked on the way (a centroid CAN round onto a voxel wall, and a cube that has just become active gets voxel keys it did
+// not have): if the prefix is not in order the whole input is sorted after all.
 int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t *in_cube, size_t n_total,
                  KeyParams kp, int ncube, const uint8_t *flags, float4 *out_pts, int32_t *out_cube, size_t *n_out,
-                 int assume_axis_bits = 0, uint32_t *done = nullptr) {
+                 int assume_axis_bits = 0, uint32_t *done = nullptr, size_t n_sorted = 0) {
   *n_out = 0;
   if (n_total == 0) {
-    if (done) done[0] = done[1] = 0;
+    if (done) done[0] = done[1] = done[2] = 0;
     return LSLAM_OK;
   }
   const int n = (int)n_total;
   const int n_cube_bits = kp.single ? 1 : cube_bits(ncube + 1);
   const dim3 blk(256), grd((n + 255) / 256);
-  FM_TRY(sc.err.reserve(2));
-  FM_TRY(hipMemsetAsync(sc.err.p, 0, 2 * sizeof(int32_t), s));
+  FM_TRY(sc.err.reserve(4));
+  FM_TRY(hipMemsetAsync(sc.err.p, 0, 4 * sizeof(int32_t), s));
   const uint8_t *eff = nullptr;
   if (!kp.single && flags) {
     FM_TRY(sc.cmin.reserve(3 * (size_t)ncube));
@@ -601,9 +637,27 @@ int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t
   FM_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, sc.k0.p, sc.k1.p, sc.i0.p, sc.i1.p, n_total, 0u, end_bit, s));
   size_t tmp2 = 0;
   FM_TRY(rocprim::exclusive_scan(nullptr, tmp2, sc.head.p, sc.pos.p, 0u, n_total + 1, rocprim::plus<uint32_t>(), s));
-  FM_TRY(sc.tmp.reserve(std::max(tmp_bytes, tmp2)));
-  FM_TRY(rocprim::radix_sort_pairs((void *)sc.tmp.p, tmp_bytes, sc.k0.p, sc.k1.p, sc.i0.p, sc.i1.p, n_total, 0u,
-                                   end_bit, s));
+  const bool merge = n_sorted > 0 && n_sorted < n_total;
+  if (merge) {
+    const size_t n_new = n_total - n_sorted;
+    size_t tmp3 = 0;
+    FM_TRY(sc.kn.reserve(n_new));
+    FM_TRY(sc.in_.reserve(n_new));
+    FM_TRY(rocprim::radix_sort_pairs(nullptr, tmp3, sc.k0.p + n_sorted, sc.kn.p, sc.i0.p + n_sorted, sc.in_.p, n_new, 0u, end_bit, s));
+    FM_TRY(sc.tmp.reserve(std::max(std::max(tmp_bytes, tmp2), tmp3)));
+    FM_TRY(rocprim::radix_sort_pairs((void *)sc.tmp.p, tmp3, sc.k0.p + n_sorted, sc.kn.p, sc.i0.p + n_sorted, sc.in_.p, n_new, 0u,
+                                     end_bit, s));
+    // (if the prefix turns out not to be in order the places below are not a permutation: slots nobody writes must hold
+    // something the kernels after this one can digest until the host sees the flag -- a dropped key, index 0)
+    FM_TRY(hipMemsetAsync(sc.k1.p, 0xFF, n_total * sizeof(uint64_t), s));
+    FM_TRY(hipMemsetAsync(sc.i1.p, 0, n_total * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(fm_merge_kernel, grd, blk, 0, s, (const uint64_t *)sc.k0.p, (int)n_sorted, (const uint64_t *)sc.kn.p,
+                       (const uint32_t *)sc.in_.p, (int)n_new, sc.k1.p, sc.i1.p, sc.err.p + 2);
+  } else {
+    FM_TRY(sc.tmp.reserve(std::max(tmp_bytes, tmp2)));
+    FM_TRY(rocprim::radix_sort_pairs((void *)sc.tmp.p, tmp_bytes, sc.k0.p, sc.k1.p, sc.i0.p, sc.i1.p, n_total, 0u,
+                                     end_bit, s));
+  }
   hipLaunchKernelGGL(fm_head_kernel, grd, blk, 0, s, sc.k1.p, n, kp.axis_bits, kp.single, eff, sc.head.p);
   FM_TRY(hipMemsetAsync(sc.head.p + n_total, 0, sizeof(uint32_t), s));
   FM_TRY(rocprim::exclusive_scan((void *)sc.tmp.p, tmp2, sc.head.p, sc.pos.p, 0u, n_total + 1,
@@ -613,16 +667,20 @@ int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t
   if (done) {
     FM_TRY(hipMemcpyAsync(&done[0], sc.pos.p + n_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     FM_TRY(hipMemcpyAsync(&done[1], sc.err.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    FM_TRY(hipMemcpyAsync(&done[2], sc.err.p + 2, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     return LSLAM_OK;
   }
   uint32_t total = 0;
-  int32_t err = 0;
+  int32_t err = 0, unsorted = 0;
   FM_TRY(hipMemcpyAsync(&total, sc.pos.p + n_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   FM_TRY(hipMemcpyAsync(&err, sc.err.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  FM_TRY(hipMemcpyAsync(&unsorted, sc.err.p + 2, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   FM_TRY(hipStreamSynchronize(s));
+  if (unsorted)  // the prefix was not in key order: everything is sorted
+    return run_pipeline(s, sc, in_pts, in_cube, n_total, kp, ncube, flags, out_pts, out_cube, n_out, assume_axis_bits, nullptr, 0);
   if (err) {
     if (assume_axis_bits > 0)  // the bound did not hold (it always should): the measured extent decides
-      return run_pipeline(s, sc, in_pts, in_cube, n_total, kp, ncube, flags, out_pts, out_cube, n_out, 0, nullptr);
+      return run_pipeline(s, sc, in_pts, in_cube, n_total, kp, ncube, flags, out_pts, out_cube, n_out, 0, nullptr, 0);
     lslam::set_error("voxel index outside its key range (non-finite point?)");
     return LSLAM_ERR_INVALID;
   }
@@ -660,11 +718,14 @@ int map_axis_bits(const lslam_fmap *fm, float leaf) { return bits_for((double)fm
 
 // rebuild type t from its current points plus n_new transformed points (in_tf / in_cube; default: fm->in_tf / in_cube).
 // done != nullptr: everything is enqueued and nothing waited for -- rebuild_finish after the caller's wait.
+// old_sorted: the current points are an earlier rebuild's output with the same leaf and active set, i.e. in key order (checked
+// on the device; see run_pipeline) -- addFeatureCloud's case.
 int rebuild_begin(lslam_fmap *fm, int t, size_t n_new, bool allow_filter, const uint8_t *flags_override, uint32_t *done,
-                  const float4 *in_tf = nullptr, const int32_t *in_cube = nullptr, size_t *n_out_sync = nullptr) {
+                  const float4 *in_tf = nullptr, const int32_t *in_cube = nullptr, size_t *n_out_sync = nullptr,
+                  bool old_sorted = false) {
   hipStream_t s = fm->stream;
   const size_t n_old = fm->n[t], n_total = n_old + n_new;
-  if (done) done[0] = done[1] = 0;
+  if (done) done[0] = done[1] = done[2] = 0;
   if (n_total == 0) return LSLAM_OK;
   FM_TRY(fm->pts[t].grow(n_total, n_old, s));
   FM_TRY(fm->cube[t].grow(n_total, n_old, s));
@@ -678,7 +739,7 @@ int rebuild_begin(lslam_fmap *fm, int t, size_t n_new, bool allow_filter, const 
   size_t n_out = 0;
   int rc = run_pipeline(s, fm->sc, fm->pts[t].p, fm->cube[t].p, n_total, kp, fm->ncube,
                         flags_override ? flags_override : (allow_filter ? fm->active.p : nullptr), fm->pts_alt[t].p,
-                        fm->cube_alt[t].p, &n_out, map_axis_bits(fm, fm->leaf[t]), done);
+                        fm->cube_alt[t].p, &n_out, map_axis_bits(fm, fm->leaf[t]), done, old_sorted && n_new ? n_old : 0);
   if (n_out_sync) *n_out_sync = n_out;
   return rc;
 }
@@ -995,8 +1056,8 @@ int lslam_fmap_add_feature_cloud(lslam_fmap *fm, const void *corner, size_t n_co
   hipStream_t s = fm->stream;
   // everything for both feature types is enqueued, then ONE wait: uploads come from pinned staging, the voxel extent of a map
   // cube is bounded (map_axis_bits), the rebuilds' results land in pinned slots
-  FM_TRY(fm->done.reserve(4 + 16));
-  float *T_pin = reinterpret_cast<float *>(fm->done.p + 4);
+  FM_TRY(fm->done.reserve(8 + 16));
+  float *T_pin = reinterpret_cast<float *>(fm->done.p + 8);
   std::memcpy(T_pin, T, 16 * sizeof(float));
   FM_TRY(hipMemcpyAsync(fm->d_T.p, T_pin, 16 * sizeof(float), hipMemcpyHostToDevice, s));
   const void *src[2] = {corner, surf};
@@ -1016,21 +1077,24 @@ int lslam_fmap_add_feature_cloud(lslam_fmap *fm, const void *corner, size_t n_co
                          fm->d_T.p, kp, fm->in_tf_t[t].p, fm->in_cube_t[t].p, fm->d_touched_t[t].p);
       FM_TRY(hipMemcpyAsync(fm->h_touched.p + (size_t)t * fm->ncube, fm->d_touched_t[t].p, fm->ncube, hipMemcpyDeviceToHost, s));
     }
-    rc = rebuild_begin(fm, t, n, true, nullptr, fm->done.p + 2 * t, fm->in_tf_t[t].p, fm->in_cube_t[t].p);
+    rc = rebuild_begin(fm, t, n, true, nullptr, fm->done.p + 4 * t, fm->in_tf_t[t].p, fm->in_cube_t[t].p, nullptr, true);
     if (rc) return rc;
   }
   FM_TRY(hipStreamSynchronize(s));
   for (int t = 0; t < 2; ++t) {
     const size_t n = cnt[t];
-    if (fm->done.p[2 * t + 1]) {
-      // a voxel index outside the key range the cube size promises (or a non-finite point): once more, waiting for the
+    if (fm->done.p[4 * t + 1] || fm->done.p[4 * t + 2]) {
+      // a voxel index outside the key range the cube size promises (or a non-finite point), or current points that were not
+      // in key order after all (a cube that has just become active): once more, sorting everything and waiting for the
       // measured extents -- the inputs are untouched, the appended points are written again where they are
       size_t n_out = 0;
       rc = rebuild_begin(fm, t, n, true, nullptr, nullptr, fm->in_tf_t[t].p, fm->in_cube_t[t].p, &n_out);
       if (rc) return rc;
       rebuild_commit(fm, t, n, n_out, n == 0);
+      fm->resorted_rebuilds++;
     } else {
-      rebuild_commit(fm, t, n, fm->done.p[2 * t], n == 0);
+      rebuild_commit(fm, t, n, fm->done.p[4 * t], n == 0);
+      if (n && fm->n[t]) fm->merged_rebuilds++;
     }
     if (n) {
       fm->dirty[t].resize((size_t)fm->ncube, 1);
@@ -1291,6 +1355,13 @@ int lslam_fmap_to_cubemap(lslam_fmap *fm) {
 }
 
 // statistics of the last lslam_fmap_to_cubemap: trees built in that call / kept from earlier calls
+int lslam_fmap_rebuild_stats(lslam_fmap *fm, int64_t *merged, int64_t *resorted) {
+  if (!fm) return LSLAM_ERR_INVALID;
+  if (merged) *merged = fm->merged_rebuilds;
+  if (resorted) *resorted = fm->resorted_rebuilds;
+  return LSLAM_OK;
+}
+
 int lslam_fmap_cubemap_stats(lslam_fmap *fm, int64_t *trees_built, int64_t *trees_reused) {
   if (!fm) return LSLAM_ERR_INVALID;
   if (trees_built) *trees_built = fm->trees_built;
@@ -1580,7 +1651,7 @@ int lslam_voxel_grid(lslam_ctx *ctx, const void *cloud, size_t n, size_t stride_
   }
   FM_TRY(out.reserve(n));
   FM_TRY(oc.reserve(n));
-  FM_TRY(cache.done.reserve(2));
+  FM_TRY(cache.done.reserve(4));
   // small clouds (a sweep's features): the whole output area comes back behind the count in ONE wait and the m points are
   // copied out of pinned memory; large ones wait for the count first and fetch exactly m points
   const bool one_wait = n * sizeof(float4) <= (size_t)1 << 20;

@@ -103,6 +103,12 @@ class FeatureMap:
         self._check(self.lib.lslam_fmap_cubemap_stats(self.h, C.byref(b), C.byref(r)))
         return b.value, r.value
 
+    def rebuild_stats(self):
+        """(add_feature_cloud rebuilds that merged the new points into the sorted arrays, rebuilds that sorted everything)."""
+        m, r = C.c_int64(), C.c_int64()
+        self._check(self.lib.lslam_fmap_rebuild_stats(self.h, C.byref(m), C.byref(r)))
+        return m.value, r.value
+
     def cubemap_invalidate(self):
         self._check(self.lib.lslam_fmap_cubemap_invalidate(self.h))
 

@@ -106,6 +106,11 @@ def main():
     mn = {k: 1e3 * float(np.min(v)) for k, v in acc.items()}
     for k in steps:
         print("%-20s median %.3f ms   min %.3f ms" % (k, med[k], mn[k]))
+    tot = np.array([sum(acc[k][i] for k in steps) for i in range(args.frames)]) * 1e3
+    print("frames %d: median %.3f  p90 %.3f  p99 %.3f  worst %.3f ms" % (args.frames, np.median(tot), np.percentile(tot, 90),
+                                                                        np.percentile(tot, 99), tot.max()))
+    for i in np.argsort(-tot)[:8]:
+        print("  frame %4d  %.3f ms :" % (i, tot[i]), "  ".join("%s %.3f" % (k[:7], 1e3 * acc[k][i]) for k in steps))
     print("%-20s median %.3f ms   min %.3f ms   (iterations %d, pose err %.4f m, lazy trees %s)"
           % ("frame", sum(med.values()), sum(mn.values()), st.iterations,
              float(np.abs(pose[3:] - gt[3:].astype(np.float32)).max()), ctx.lazy_trees()))

@@ -206,11 +206,11 @@ __global__ __launch_bounds__(256) void fm_minmax_kernel(const float4 *pts, const
         lo[d] = min(lo[d], __shfl_xor(lo[d], s, 64));
         hi[d] = max(hi[d], __shfl_xor(hi[d], s, 64));
       }
-    if (lane == 0)
+    if (lane == 0)  // six atomics in flight together (a compare first would be six dependent loads in front of them)
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
-        if (lo[d] < cmin[3 * cur + d]) atomicMin(&cmin[3 * cur + d], lo[d]);
-        if (hi[d] > cmax[3 * cur + d]) atomicMax(&cmax[3 * cur + d], hi[d]);
+        atomicMin(&cmin[3 * cur + d], lo[d]);
+        atomicMax(&cmax[3 * cur + d], hi[d]);
       }
 #pragma unroll
     for (int d = 0; d < 3; ++d) { lo[d] = INT32_MAX; hi[d] = INT32_MIN; }
@@ -245,13 +245,23 @@ __global__ __launch_bounds__(256) void fm_minmax_kernel(const float4 *pts, const
       } else {
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-          if (o[d] < cmin[3 * c + d]) atomicMin(&cmin[3 * c + d], o[d]);
-          if (o[d] > cmax[3 * c + d]) atomicMax(&cmax[3 * c + d], o[d]);
+          atomicMin(&cmin[3 * c + d], o[d]);
+          atomicMax(&cmax[3 * c + d], o[d]);
         }
       }
     }
   }
   flush();
+}
+
+// the per-rebuild initial values in one launch: cube extremes, error words
+__global__ void fm_init_kernel(int32_t *cmin, int32_t *cmax, int n3, int32_t *err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 4) err[i] = 0;
+  if (i < n3) {
+    cmin[i] = 0x7f7f7f7f;           // +large (what the byte fill 0x7f wrote)
+    cmax[i] = (int32_t)0x80808080;  // -large
+  }
 }
 
 // per cube: min_b, the "leaf too small" guard of applyFilter, the widest voxel extent
@@ -280,10 +290,15 @@ __global__ void fm_extent_kernel(const uint8_t *flags, const int32_t *cmin, cons
 }
 
 __global__ void fm_key_kernel(const float4 *pts, const int32_t *cube, int n, KeyParams k, const uint8_t *flags,
-                              const int32_t *cube_base, uint64_t *keys, uint32_t *idx, int32_t *err) {
+                              const int32_t *cube_base, uint64_t *keys, uint32_t *idx, int32_t *err,
+                              uint64_t *merge_keys = nullptr, uint32_t *merge_idx = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   idx[i] = (uint32_t)i;
+  if (merge_keys) {  // what a slot of the merged sequence holds until its element arrives (see run_pipeline)
+    merge_keys[i] = KEY_DROP;
+    merge_idx[i] = 0u;
+  }
   const int32_t c = k.single ? 0 : cube[i];
   if (c < 0) {
     keys[i] = KEY_DROP;
@@ -349,6 +364,7 @@ __global__ void fm_head_kernel(const uint64_t *keys, int n, int axis_bits, int s
                                uint32_t *head) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (i == 0) head[n] = 0u;  // the scan runs over n + 1 flags: its last output is the number of heads
   const uint64_t k = keys[i];
   uint32_t h = 0;
   if (k != KEY_DROP) {
@@ -363,9 +379,11 @@ __global__ void fm_head_kernel(const uint64_t *keys, int n, int axis_bits, int s
 // loads are not: every lane fetches ITS point (64 independent gathers per wavefront), then each head lane adds its members'
 // values, in order, out of its neighbours' registers; only a voxel that runs past the end of its wavefront goes on from memory.
 __global__ __launch_bounds__(256) void fm_centroid_kernel(const float4 *pts, const uint64_t *keys, const uint32_t *idx, const uint32_t *head,
-                                                          const uint32_t *pos, int n, int axis_bits, float4 *out, int32_t *cube_out) {
+                                                          const uint32_t *pos, int n, int axis_bits, float4 *out, int32_t *cube_out,
+                                                          int32_t *total_out) {
   const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
   const bool in = i < n;
+  if (i == 0) *total_out = (int32_t)pos[n];  // the number of heads = points out, next to the error words (one copy fetches all)
   const uint64_t k = in ? keys[i] : KEY_DROP;
   const bool is_head = in && head[i] != 0;
   const bool member = in && !is_head && k != KEY_DROP;  // (a dropped point is nobody's member: fm_head_kernel gives it no head either)
@@ -472,7 +490,7 @@ struct Scratch {
   Buf<uint64_t> k0, k1, kn;
   Buf<uint32_t> i0, i1, in_, head, pos;
   Buf<char> tmp;
-  Buf<int32_t> err;               // [0] key-range error, [1] widest voxel extent of a filtered cube, [2] the "sorted" prefix was not
+  Buf<int32_t> err;               // [0] points out, [1] key-range error, [2] the "sorted" prefix was not, [3] widest voxel extent of a filtered cube
   Buf<int32_t> cmin, cmax, base;  // [ncube][3]
   Buf<uint8_t> eff;               // [ncube] cubes this rebuild really filters
   void release() {
@@ -590,33 +608,32 @@ int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t
   const int n_cube_bits = kp.single ? 1 : cube_bits(ncube + 1);
   const dim3 blk(256), grd((n + 255) / 256);
   FM_TRY(sc.err.reserve(4));
-  FM_TRY(hipMemsetAsync(sc.err.p, 0, 4 * sizeof(int32_t), s));
   const uint8_t *eff = nullptr;
   if (!kp.single && flags) {
     FM_TRY(sc.cmin.reserve(3 * (size_t)ncube));
     FM_TRY(sc.cmax.reserve(3 * (size_t)ncube));
     FM_TRY(sc.base.reserve(3 * (size_t)ncube));
     FM_TRY(sc.eff.reserve(ncube));
-    FM_TRY(hipMemsetAsync(sc.cmin.p, 0x7f, 3 * sizeof(int32_t) * (size_t)ncube, s));  // +large
-    FM_TRY(hipMemsetAsync(sc.cmax.p, 0x80, 3 * sizeof(int32_t) * (size_t)ncube, s));  // -large
+    hipLaunchKernelGGL(fm_init_kernel, dim3((3 * ncube + 255) / 256), blk, 0, s, sc.cmin.p, sc.cmax.p, 3 * ncube, sc.err.p);
     {
       const int waves = (int)((n + MM_RUN - 1) / MM_RUN);
       hipLaunchKernelGGL(fm_minmax_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, in_pts, in_cube, (int)n, flags,
                          sc.cmin.p, sc.cmax.p);
     }
     hipLaunchKernelGGL(fm_extent_kernel, dim3((ncube + 255) / 256), blk, 0, s, flags, sc.cmin.p, sc.cmax.p, ncube,
-                       kp.inv_leaf, sc.eff.p, sc.base.p, sc.err.p + 1);
+                       kp.inv_leaf, sc.eff.p, sc.base.p, sc.err.p + 3);
     if (assume_axis_bits > 0 && n_total <= MERGE_LIMIT && 3 * assume_axis_bits + n_cube_bits <= 63) {
       kp.axis_bits = assume_axis_bits;
     } else {
       int32_t max_div = 0;
-      FM_TRY(hipMemcpyAsync(&max_div, sc.err.p + 1, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      FM_TRY(hipMemcpyAsync(&max_div, sc.err.p + 3, sizeof(int32_t), hipMemcpyDeviceToHost, s));
       FM_TRY(hipStreamSynchronize(s));
       kp.axis_bits = bits_for((double)max_div + 1.0);
     }
     eff = sc.eff.p;
-  } else if (!kp.single) {
-    kp.axis_bits = 1;
+  } else {
+    FM_TRY(hipMemsetAsync(sc.err.p, 0, 4 * sizeof(int32_t), s));
+    if (!kp.single) kp.axis_bits = 1;
   }
   if (3 * kp.axis_bits + n_cube_bits > 63) {
     lslam::set_error("voxel grid too fine for the 63-bit sort key (leaf too small for this extent)");
@@ -628,7 +645,9 @@ int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t
   FM_TRY(sc.i1.reserve(n_total));
   FM_TRY(sc.head.reserve(n_total + 1));
   FM_TRY(sc.pos.reserve(n_total + 1));
-  hipLaunchKernelGGL(fm_key_kernel, grd, blk, 0, s, in_pts, in_cube, n, kp, eff, sc.base.p, sc.k0.p, sc.i0.p, sc.err.p);
+  const bool merge = n_sorted > 0 && n_sorted < n_total;
+  hipLaunchKernelGGL(fm_key_kernel, grd, blk, 0, s, in_pts, in_cube, n, kp, eff, sc.base.p, sc.k0.p, sc.i0.p, sc.err.p + 1,
+                     merge ? sc.k1.p : (uint64_t *)nullptr, merge ? sc.i1.p : (uint32_t *)nullptr);
   const unsigned end_bit = (unsigned)(3 * kp.axis_bits + n_cube_bits);
   size_t tmp_bytes = 0;
   // KEY_DROP has every bit set: within [0, end_bit) it is the largest key, so dropped points sort last
@@ -637,7 +656,6 @@ int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t
   FM_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, sc.k0.p, sc.k1.p, sc.i0.p, sc.i1.p, n_total, 0u, end_bit, s));
   size_t tmp2 = 0;
   FM_TRY(rocprim::exclusive_scan(nullptr, tmp2, sc.head.p, sc.pos.p, 0u, n_total + 1, rocprim::plus<uint32_t>(), s));
-  const bool merge = n_sorted > 0 && n_sorted < n_total;
   if (merge) {
     const size_t n_new = n_total - n_sorted;
     size_t tmp3 = 0;
@@ -649,8 +667,7 @@ int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t
                                      end_bit, s));
     // (if the prefix turns out not to be in order the places below are not a permutation: slots nobody writes must hold
     // something the kernels after this one can digest until the host sees the flag -- a dropped key, index 0)
-    FM_TRY(hipMemsetAsync(sc.k1.p, 0xFF, n_total * sizeof(uint64_t), s));
-    FM_TRY(hipMemsetAsync(sc.i1.p, 0, n_total * sizeof(uint32_t), s));
+    // -- written by fm_key_kernel (merge_defaults)
     hipLaunchKernelGGL(fm_merge_kernel, grd, blk, 0, s, (const uint64_t *)sc.k0.p, (int)n_sorted, (const uint64_t *)sc.kn.p,
                        (const uint32_t *)sc.in_.p, (int)n_new, sc.k1.p, sc.i1.p, sc.err.p + 2);
   } else {
@@ -659,23 +676,19 @@ int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t
                                      end_bit, s));
   }
   hipLaunchKernelGGL(fm_head_kernel, grd, blk, 0, s, sc.k1.p, n, kp.axis_bits, kp.single, eff, sc.head.p);
-  FM_TRY(hipMemsetAsync(sc.head.p + n_total, 0, sizeof(uint32_t), s));
   FM_TRY(rocprim::exclusive_scan((void *)sc.tmp.p, tmp2, sc.head.p, sc.pos.p, 0u, n_total + 1,
                                  rocprim::plus<uint32_t>(), s));
   hipLaunchKernelGGL(fm_centroid_kernel, grd, blk, 0, s, in_pts, sc.k1.p, sc.i1.p, sc.head.p, sc.pos.p, n,
-                     kp.axis_bits, out_pts, out_cube);
-  if (done) {
-    FM_TRY(hipMemcpyAsync(&done[0], sc.pos.p + n_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    FM_TRY(hipMemcpyAsync(&done[1], sc.err.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    FM_TRY(hipMemcpyAsync(&done[2], sc.err.p + 2, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                     kp.axis_bits, out_pts, out_cube, sc.err.p);
+  if (done) {  // {points out, key-range error, prefix not sorted}: three adjacent words, one copy
+    FM_TRY(hipMemcpyAsync(done, sc.err.p, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     return LSLAM_OK;
   }
-  uint32_t total = 0;
-  int32_t err = 0, unsorted = 0;
-  FM_TRY(hipMemcpyAsync(&total, sc.pos.p + n_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  FM_TRY(hipMemcpyAsync(&err, sc.err.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  FM_TRY(hipMemcpyAsync(&unsorted, sc.err.p + 2, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  int32_t res[3] = {0, 0, 0};
+  FM_TRY(hipMemcpyAsync(res, sc.err.p, sizeof(res), hipMemcpyDeviceToHost, s));
   FM_TRY(hipStreamSynchronize(s));
+  const uint32_t total = (uint32_t)res[0];
+  const int32_t err = res[1], unsorted = res[2];
   if (unsorted)  // the prefix was not in key order: everything is sorted
     return run_pipeline(s, sc, in_pts, in_cube, n_total, kp, ncube, flags, out_pts, out_cube, n_out, assume_axis_bits, nullptr, 0);
   if (err) {

@@ -91,10 +91,16 @@ typedef struct {
  * LSLAM_DEBUG_CERT_STATS=1 -- are read ONCE, in lslam_ctx_create; no entry point reads the environment while it runs. */
 enum { LSLAM_AB_PERSISTENT_GN = 1, /* one resident scan: the whole Gauss-Newton loop as one persistent launch */
        LSLAM_AB_FUSED_SOLVE = 2,   /* latency-bound launches: the 6x6 solve in the tail of the sweep launch */
-       LSLAM_AB_SECOND_PROBE = 4   /* grid sweep: the points the 27-cell probe cannot prove get a second, 125-cell probe (clipped to
+       LSLAM_AB_SECOND_PROBE = 4,  /* grid sweep: the points the 27-cell probe cannot prove get a second, 125-cell probe (clipped to
                                       the ball of what the first saw) before the tree search -- exact, measured slower
                                       (1.16e10 against 1.25e10 point-residuals/s: the points that need more than the first probe
-                                      are the ones a wide probe is slow for too) */ };
+                                      are the ones a wide probe is slow for too) */
+       LSLAM_AB_WIDE_IN_PLACE = 8  /* a map without kd-trees (lslam_map_defer_trees), a launch of at most two wavefronts per SIMD:
+                                      the points the probe cannot prove are resolved inside the probe's own launch, wavefront by
+                                      wavefront (one launch per sweep instead of five; the sums are then formed exactly as the
+                                      lane search's sweep forms them).  Exact, measured slower: a frame's scan match 0.84 ms
+                                      against 0.49 -- a wavefront works its unproven points off one after the other, the
+                                      separate wide-probe launch gives each its own wavefront */ };
 
 /* 5-NN search implementations (same answer, bit for bit):
  *   LANE    one query per lane, nanoflann's traversal with an explicit per-lane stack
@@ -623,6 +629,8 @@ void *lslam_stream(lslam_ctx *ctx); /* hipStream_t */
 void lslam_debug_sweep_launches(lslam_ctx *ctx, uint64_t counts[8]);
 /* ... and of the grid sweep (sweep_grid_kernel; LSLAM_SEARCH_GRID) */
 uint64_t lslam_debug_grid_launches(lslam_ctx *ctx);
+/* ... of which the single-launch form for a map without trees (sweep_grid_kernel<256, true>) */
+uint64_t lslam_debug_grid_wide_launches(lslam_ctx *ctx);
 /* out[0] maps set with deferred trees, out[1] of those whose trees were built after all, out[2] 1 while the resident map's are pending */
 void lslam_debug_lazy_trees(lslam_ctx *ctx, uint64_t out[3]);
 /* Debug tap of the certificate sweep (csrc/lslam_kernels.hip sweep_body): out[2] = second-pass launches of this

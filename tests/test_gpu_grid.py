@@ -201,9 +201,10 @@ def test_grid_run_does_not_read_what_an_earlier_call_left(ctx, small_problem):
         assert np.array_equal(bits(pose), bits(ref)) and (st.iterations, st.n_rows) == (st_ref.iterations, st_ref.n_rows)
 
 
-def _mapping_frames(pkg, ctx, synth, world, defer, n=4, lattice=False):
+def _mapping_frames(pkg, ctx, synth, world, defer, n=4, lattice=False, ab_switches=0):
     """A few LaserMapping frames (the device chain of tests/test_gpu_pipeline.py, mapping half only) -> poses, stats."""
     mapper = pkg.LaserMapping(ctx, cube_dims=(21, 21, 11), defer_trees=defer)
+    mapper.opts.ab_switches = ab_switches
     out = []
     for k in range(n):
         gt = (0.0, 0.0, 0.3 + 0.01 * k, 3.0 + 0.4 * k, -2.0 + 0.15 * k, synth.SENSOR_HEIGHT)
@@ -244,6 +245,20 @@ def test_deferred_trees_mapping_frames_equal_eager(pkg, synth, small_problem):
     for (Ma, sa), (Mb, sb) in zip(res[False], res[True]):
         assert sa == sb
         assert np.abs(Ma - Mb).max() <= 2e-6
+    # the A/B form of the deferred sweep (LSLAM_AB_WIDE_IN_PLACE: unproven points resolved inside the probe's launch, one
+    # launch per sweep) -- it forms a workgroup's sums the way the lane search's sweep does, so against the EAGER frames
+    # (trees, lane search: what AUTO takes for a single scan) it is the same bits
+    c = pkg.Context(0)
+    try:
+        inplace = _mapping_frames(pkg, c, synth, world, True, ab_switches=8)  # LSLAM_AB_WIDE_IN_PLACE
+        sets, builds, pending = c.lazy_trees()
+        assert sets >= 3 and builds == 0 and pending
+        assert c.grid_wide_launches() > 0 and c.grid_wide_launches() == c.grid_launches()
+    finally:
+        c.close()
+    for (Ma, sa), (Mb, sb) in zip(res[False], inplace):
+        assert sa == sb
+        assert np.array_equal(bits(Ma), bits(Mb))
 
 
 def test_deferred_trees_fall_back_to_the_trees_on_exact_ties(pkg, synth):

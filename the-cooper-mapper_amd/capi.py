@@ -236,6 +236,7 @@ SYMBOLS = {
     "lslam_comm_destroy": (None, [C.c_void_p]),
     "lslam_comm_info": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p]),
     "lslam_debug_grid_launches": (C.c_uint64, [C.c_void_p]),
+    "lslam_debug_grid_wide_launches": (C.c_uint64, [C.c_void_p]),
     "lslam_map_defer_trees": (C.c_int, [C.c_void_p, C.c_int32]),
     "lslam_debug_lazy_trees": (None, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "lslam_comm_allreduce_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -245,7 +246,7 @@ SYMBOLS = {
 
 COMM_ID_BYTES = 128
 SEARCH_AUTO, SEARCH_LANE, SEARCH_PACKET, SEARCH_GRID = 0, 1, 2, 3
-AB_PERSISTENT_GN, AB_FUSED_SOLVE, AB_SECOND_PROBE = 1, 2, 4  # lslam_opts.ab_switches (LSLAM_AB_*)
+AB_PERSISTENT_GN, AB_FUSED_SOLVE, AB_SECOND_PROBE, AB_WIDE_IN_PLACE = 1, 2, 4, 8  # lslam_opts.ab_switches (LSLAM_AB_*)
 STACK_AUTO, STACK_DEEP, STACK_SHALLOW = 0, 0x100, 0x200  # ORed into a search mode (LSLAM_STACK_*)
 # lslam_debug_sweep_launches: index of each sweep-kernel instantiation
 SWEEP_VARIANTS = ("deep", "deep_ovf", "shallow", "cubes", "cubes_ovf", "packet", "persistent", "deep_fused")

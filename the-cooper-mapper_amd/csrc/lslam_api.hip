@@ -246,6 +246,7 @@ struct lslam_ctx {
   int env_debug_cert_stats = 0;  // LSLAM_DEBUG_CERT_STATS
   int env_force_stack = -1;    // LSLAM_FORCE_STACK=deep|shallow|auto -> SWEEP_STACK_*
   int env_ab = 0;              // LSLAM_PERSISTENT_GN=1, LSLAM_FUSED_SOLVE=1 -> LSLAM_AB_* bits
+  int ab_now = 0;              // lslam_opts.ab_switches | env_ab of the call that is running (sweep_launch has no options at hand)
   bool env_debug = false;      // LSLAM_DEBUG
 };
 
@@ -421,6 +422,15 @@ hipError_t sweep_launch(lslam_ctx *ctx, const SweepArgs &a, int jtj_mode, hipEve
   plan.ticket_next = plan.count_next + 2;
   if (a.grid) {  // the grid sweep: probe + proof for every point, then the tree search for the points it listed; timed as one
     if (a.nb_total <= 0 || a.n_groups <= 0 || !a.need_cnt) return a.nb_total <= 0 ? hipSuccess : hipErrorInvalidValue;
+    // A/B (off; lslam_opts.ab_switches & LSLAM_AB_WIDE_IN_PLACE): a map without trees and a launch of at most two wavefronts per
+    // SIMD as ONE launch -- each wavefront resolves its own unproven points by the wide probe before the residual chain
+    // (sweep_grid_kernel<.., true>).  Measured slower than the five launches below: see include/lslam_c.h.
+    if (a.grid == 2 && (long)a.nb_total * (SWEEP_BLOCK / 64) <= 2 * 1024 && (ctx->ab_now & LSLAM_AB_WIDE_IN_PLACE)) {
+      hipError_t e1w = launch_sweep_grid(a, jtj_mode, ctx->stream, e0, e1, true);
+      ctx->sweep_variants[SWEEP_VARIANT_GRID_WIDE]++;
+      if (variant) *variant = SWEEP_VARIANT_GRID_WIDE;
+      return e1w;
+    }
     hipError_t e = launch_sweep_grid(a, jtj_mode, ctx->stream, e0, nullptr);
     v = SWEEP_VARIANT_GRID;
     ctx->sweep_variants[v]++;
@@ -664,7 +674,8 @@ void lslam_debug_lazy_trees(lslam_ctx *ctx, uint64_t out[3]) {
   out[2] = ctx ? (ctx->trees_pending ? 1 : 0) : 0;
 }
 
-uint64_t lslam_debug_grid_launches(lslam_ctx *ctx) { return ctx ? ctx->sweep_variants[SWEEP_VARIANT_GRID] : 0; }
+uint64_t lslam_debug_grid_launches(lslam_ctx *ctx) { return ctx ? ctx->sweep_variants[SWEEP_VARIANT_GRID] + ctx->sweep_variants[SWEEP_VARIANT_GRID_WIDE] : 0; }
+uint64_t lslam_debug_grid_wide_launches(lslam_ctx *ctx) { return ctx ? ctx->sweep_variants[SWEEP_VARIANT_GRID_WIDE] : 0; }
 
 void lslam_debug_sweep_launches(lslam_ctx *ctx, uint64_t counts[8]) {
   for (int i = 0; i < 8; ++i) counts[i] = ctx ? ctx->sweep_variants[i] : 0;
@@ -1696,6 +1707,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
         sa.grid_clip_margin = GRID_CLIP_MARGIN_MIN;
       }
     }
+    ctx->ab_now = o.ab_switches | ctx->env_ab;
     const bool grid_on = sa.grid != 0;
     const bool no_probe2 = ((o.ab_switches | ctx->env_ab) & LSLAM_AB_SECOND_PROBE) == 0;  // A/B (off): a second, wider probe before the tree search
     // neighbour lists carried from sweep to sweep by certificate where a point has hardly moved (sweep_body): lslam_opts.knn_cert

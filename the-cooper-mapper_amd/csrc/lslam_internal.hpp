@@ -260,9 +260,10 @@ enum : int {
   SWEEP_VARIANT_PERSISTENT = 6, // gn_persistent_kernel
   SWEEP_VARIANT_DEEP_FUSED = 7, // sweep_kernel<256, *, false, 32> with the solve in its tail (single scans)
   SWEEP_VARIANT_GRID = 8,       // sweep_grid_kernel<256> (+ sweep_queue_kernel for the points it could not prove)
-  SWEEP_N_VARIANTS = 9
+  SWEEP_VARIANT_GRID_WIDE = 9,  // sweep_grid_kernel<256, true>: a map without trees, a small launch -- unproven points resolved in place
+  SWEEP_N_VARIANTS = 10
 };
-hipError_t launch_sweep_grid(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t start, hipEvent_t stop);
+hipError_t launch_sweep_grid(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t start, hipEvent_t stop, bool resolve_in_place = false);
 hipError_t launch_sweep_wide(const SweepArgs &a, hipStream_t s);  // grid_prefix_kernel + sweep_wide_kernel
 hipError_t launch_knn5_grid(const CellGrid &G, const TreeView &T, const float4 *q, int nq, int32_t *idx, float *d2,
                             uint32_t *stack_ovf, int32_t *n_unproven, hipStream_t s);

@@ -1343,8 +1343,15 @@ hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, h
 #ifndef LSLAM_GRID_OCC
 #define LSLAM_GRID_OCC 6  // wavefronts per SIMD the grid sweep is compiled for: 80 VGPRs (5: 90 VGPRs, 8 % slower; 7: below; 8: 64 VGPRs with 96 B of scratch, slower than 5)
 #endif
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LSLAM_GRID_OCC))) void sweep_grid_kernel(SweepArgs a, int jtj_mode) {
+LSLAM_DEV void wide_probe(const CellGrid &G, const float (&sel)[3], float r2, int lane, float (&d)[5], int (&p)[5], bool &num, bool &bad);
+
+// WIDE (A/B, LSLAM_AB_WIDE_IN_PLACE; a map without kd-trees, a launch too small to fill the chip -- the mapping node's frame):
+// a point the probe cannot prove is resolved on the spot by its own wavefront (wide_probe: every cell within the fifth
+// distance the probe saw), and the residual chain then runs ONCE for all 64 lanes.  One launch per sweep instead of five, no
+// lists; the workgroup's sums are formed exactly as the lane search's sweep forms them.  Slower all the same (0.84 ms against
+// 0.49 per scan match of a frame): the wavefront's unproven points are probed one after the other, ~15 us each.
+template <int BLOCK, bool WIDE = false>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 : LSLAM_GRID_OCC))) void sweep_grid_kernel(SweepArgs a, int jtj_mode) {
   constexpr int NWAVE = BLOCK / 64;
   const int lb = xcd_remap(blockIdx.x, a.nb_total);
   const BlockDesc bd = a.blocks[lb];
@@ -1408,8 +1415,35 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LSLAM_GRI
   int verdict = knn5_grid<BLOCK>(G, active, sel[0], sel[1], sel[2], bound, a.grid_clip_margin, (lds_u32 *)(rows_lds + tid), d, p, lb6);
   // beyond the gate nothing is looked up (ScanMatch.cpp:102,120); the taps and the _fineScore re-sweep want nanoflann's answer
   if (verdict == GRID_FAR && !a.bounded) verdict = GRID_UNPROVEN;
-  const bool needy = active && verdict == GRID_UNPROVEN;
-  {  // the list of pass 2 (as the certificate sweep's pass 1 writes it)
+  bool needy = active && verdict == GRID_UNPROVEN;
+  bool resolved_wide = false;
+  if (WIDE) {
+    unsigned long long todo = __ballot(needy);
+    if (a.cert_stats && lane == 0) atomicAdd(a.cert_stats, (unsigned long long)__popcll(todo));
+    if (a.cert_stats && tid == 0) atomicAdd(a.cert_stats + 1, (unsigned long long)bd.count);
+    const float my_hint = d[4] < 1.0e30f ? d[4] * (1.0f + 1e-5f) + 1e-12f : FLT_MAX;  // five map points the probe SAW lie within this
+    bool any_bad = false;
+    while (todo) {  // wave-uniform
+      const int L = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const float s3[3] = {__shfl(sel[0], L, 64), __shfl(sel[1], L, 64), __shfl(sel[2], L, 64)};
+      const float r2 = fminf(5.0f * (1.0f + 1e-5f), __shfl(my_hint, L, 64));
+      float wd[5];
+      int wp[5];
+      bool num, bad;
+      wide_probe(G, s3, r2, lane, wd, wp, num, bad);
+      any_bad = any_bad || bad;
+      if (lane == L) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { d[j] = wd[j]; p[j] = wp[j]; }
+      }
+    }
+    // an exact tie (only nanoflann's traversal can order it): the host builds the trees and repeats the call
+    if (any_bad && lane == 0) atomicOr(&const_cast<GNState *>(st)->pad, 1);
+    resolved_wide = needy;
+    needy = false;
+  }
+  if (!WIDE) {  // the list of pass 2 (as the certificate sweep's pass 1 writes it)
     const unsigned long long m = __ballot(needy);
     if (lane == 0) wave_needy[wave] = __popcll(m);
     __syncthreads();
@@ -1438,16 +1472,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LSLAM_GRI
   float rb = 0.0f, kept = 0.0f, matched = 0.0f, score = 0.0f;
   if (has) {
     // what the next sweep's bound is taken from: where the point is now and how far its fifth neighbour
-    if (a.bounded) a.prev_q[qi] = make_float4(sel[0], sel[1], sel[2], (verdict == GRID_PROVEN && d[4] < 5.0f) ? d[4] : FLT_MAX);
+    const bool fifth_known = resolved_wide ? (p[4] >= 0 && d[4] < 5.0f) : (verdict == GRID_PROVEN && d[4] < 5.0f);
+    if (a.bounded) a.prev_q[qi] = make_float4(sel[0], sel[1], sel[2], fifth_known ? d[4] : FLT_MAX);
     point_residual(a, bd, is_surf, G.pts, q, sel, d, p, sc, row, rb, kept, matched, score);
   }
   __syncthreads();  // every wavefront is done with its row table: the staging rows may be written
   block_accumulate<BLOCK, false, false>(jtj_mode, is_surf, row, rb, kept, matched, score, rows_lds, red, a.partials + (size_t)lb * NCOL);
 }
 
-hipError_t launch_sweep_grid(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
+hipError_t launch_sweep_grid(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t start, hipEvent_t stop, bool resolve_in_place) {
   if (a.nb_total <= 0) return hipSuccess;
-  hipExtLaunchKernelGGL((sweep_grid_kernel<SWEEP_BLOCK>), dim3(a.nb_total), dim3(SWEEP_BLOCK), 0, s, start, stop, 0, a, jtj_mode);
+  if (resolve_in_place) hipExtLaunchKernelGGL((sweep_grid_kernel<SWEEP_BLOCK, true>), dim3(a.nb_total), dim3(SWEEP_BLOCK), 0, s, start, stop, 0, a, jtj_mode);
+  else hipExtLaunchKernelGGL((sweep_grid_kernel<SWEEP_BLOCK>), dim3(a.nb_total), dim3(SWEEP_BLOCK), 0, s, start, stop, 0, a, jtj_mode);
   return hipGetLastError();
 }
 
@@ -1500,36 +1536,16 @@ LSLAM_DEV uint32_t wave_min_u32(uint32_t v) {
 
 constexpr int WIDE_ROWS_PER_LANE = 4;  // up to 256 cell rows around a point (cells of >= 0.3 m inside the sqrt(5) m gate)
 
-__global__ __launch_bounds__(256) void sweep_wide_kernel(SweepArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);  // wave-uniform
-  const int nb = a.nb_total;
-  if (item >= a.wide_off[nb]) return;
-  int lo_b = 0, hi_b = nb;  // the workgroup whose list holds the item: wide_off[b] <= item < wide_off[b + 1]
-  while (hi_b - lo_b > 1) {
-    const int mid = (lo_b + hi_b) >> 1;
-    if (a.wide_off[mid] <= item) lo_b = mid; else hi_b = mid;
-  }
-  const int b = __builtin_amdgcn_readfirstlane(lo_b);
-  const BlockDesc bd = a.blocks[b];
-  const int qi = bd.first + (int)a.need_list[(size_t)b * SWEEP_BLOCK + (item - a.wide_off[b])];
-  GNState *st = const_cast<GNState *>(a.states) + bd.prob;
-  const bool is_surf = bd.is_surf != 0;
-  const CellGrid &G = is_surf ? a.ks : a.kc;
-  const float4 q = a.q[qi];
-  float sel[3];
-  sel[0] = ((st->R[0] * q.x + st->R[1] * q.y) + st->R[2] * q.z) + st->t[0];
-  sel[1] = ((st->R[3] * q.x + st->R[4] * q.y) + st->R[5] * q.z) + st->t[1];
-  sel[2] = ((st->R[6] * q.x + st->R[7] * q.y) + st->R[8] * q.z) + st->t[2];
-  // the ball that must be covered: five map points are known to lie within sqrt(r2) (pass 1 saw them), else the gate
-  float r2 = 5.0f * (1.0f + 1e-5f);
-  if (a.grid_hint) r2 = fminf(r2, a.grid_hint[qi]);
+// One wavefront, one point (wave-uniform arguments): every cell within sqrt(r2) of sel is scanned, 64 rows at a time; the five
+// nearest with their exact distances come back in every lane.  bad: the answer needs nanoflann's visit order (a tie), or the
+// kernel is not sized for the cells.
+LSLAM_DEV void wide_probe(const CellGrid &G, const float (&sel)[3], float r2, int lane, float (&d)[5], int (&p)[5], bool &num, bool &bad) {
   const float rb = sqrtf(r2) * (1.0f + 1.0e-5f) + GRID_CLIP_MARGIN_MIN;
   const float rbc = rb * G.inv_c;
   const float ux = __fmul_rn(__fsub_rn(sel[0], G.org[0]), G.inv_c);
   const float uy = __fmul_rn(__fsub_rn(sel[1], G.org[1]), G.inv_c);
   const float uz = __fmul_rn(__fsub_rn(sel[2], G.org[2]), G.inv_c);
-  const bool num = (ux == ux) && (uy == uy) && (uz == uz);
+  num = (ux == ux) && (uy == uy) && (uz == uz);
   // cells [lo, hi] per axis, clamped to the table (cells outside it hold nothing)
   const int xlo = (int)fminf(fmaxf(floorf(ux - rbc), 0.0f), (float)(G.nx - 1)), xhi = (int)fminf(fmaxf(floorf(ux + rbc), 0.0f), (float)(G.nx - 1));
   const int ylo = (int)fminf(fmaxf(floorf(uy - rbc), 0.0f), (float)(G.ny - 1)), yhi = (int)fminf(fmaxf(floorf(uy + rbc), 0.0f), (float)(G.ny - 1));
@@ -1563,11 +1579,9 @@ __global__ __launch_bounds__(256) void sweep_wide_kernel(SweepArgs a) {
   unresolved = unresolved || __any(id > GRID_ID_MASK + 1u);  // a lane saw more candidates than an id can count
   // the six smallest keys of the wavefront, smallest first: winner = the lowest lane that holds the minimum
   int pos[6];
-  uint32_t key6[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     const uint32_t m = wave_min_u32(k0);
-    key6[j] = m;
     const unsigned long long who = __ballot(k0 == m && m != 0xFFFFFFFFu);
     const int w = who ? __builtin_ctzll(who) : 0;
     int mine = -1;
@@ -1582,8 +1596,7 @@ __global__ __launch_bounds__(256) void sweep_wide_kernel(SweepArgs a) {
   }
   const uint32_t rest = wave_min_u32(k0);  // every other candidate's truncated distance is at least this
   // exact distances, sorted by the search's own insert (every lane computes the same)
-  float d[5], e6 = FLT_MAX;
-  int p[5];
+  float e6 = FLT_MAX;
 #pragma unroll
   for (int j = 0; j < 5; ++j) { d[j] = FLT_MAX; p[j] = -1; }
   float lb = FLT_MAX;
@@ -1603,7 +1616,42 @@ __global__ __launch_bounds__(256) void sweep_wide_kernel(SweepArgs a) {
   // resolved: the five are proven, or there provably are not five inside the gate (the result is not used then: ScanMatch.cpp:102,120)
   const bool five_proven = distinct && d[4] < lb && d[4] < cov2;
   const bool none_inside = !(d[4] < 5.0f) && cov2 >= 5.0f * (1.0f + 1e-6f) && lb >= 5.0f;
-  if (num && (unresolved || !(five_proven || none_inside))) {
+  bad = num && (unresolved || !(five_proven || none_inside));
+  if (!num) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { d[j] = FLT_MAX; p[j] = -1; }
+  }
+}
+
+__global__ __launch_bounds__(256) void sweep_wide_kernel(SweepArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);  // wave-uniform
+  const int nb = a.nb_total;
+  if (item >= a.wide_off[nb]) return;
+  int lo_b = 0, hi_b = nb;  // the workgroup whose list holds the item: wide_off[b] <= item < wide_off[b + 1]
+  while (hi_b - lo_b > 1) {
+    const int mid = (lo_b + hi_b) >> 1;
+    if (a.wide_off[mid] <= item) lo_b = mid; else hi_b = mid;
+  }
+  const int b = __builtin_amdgcn_readfirstlane(lo_b);
+  const BlockDesc bd = a.blocks[b];
+  const int qi = bd.first + (int)a.need_list[(size_t)b * SWEEP_BLOCK + (item - a.wide_off[b])];
+  GNState *st = const_cast<GNState *>(a.states) + bd.prob;
+  const bool is_surf = bd.is_surf != 0;
+  const CellGrid &G = is_surf ? a.ks : a.kc;
+  const float4 q = a.q[qi];
+  float sel[3];
+  sel[0] = ((st->R[0] * q.x + st->R[1] * q.y) + st->R[2] * q.z) + st->t[0];
+  sel[1] = ((st->R[3] * q.x + st->R[4] * q.y) + st->R[5] * q.z) + st->t[1];
+  sel[2] = ((st->R[6] * q.x + st->R[7] * q.y) + st->R[8] * q.z) + st->t[2];
+  // the ball that must be covered: five map points are known to lie within sqrt(r2) (pass 1 saw them), else the gate
+  float r2 = 5.0f * (1.0f + 1e-5f);
+  if (a.grid_hint) r2 = fminf(r2, a.grid_hint[qi]);
+  float d[5];
+  int p[5];
+  bool num, bad;
+  wide_probe(G, sel, r2, lane, d, p, num, bad);
+  if (bad) {
     if (lane == 0) atomicOr(&st->pad, 1);
   }
   if (lane < 5) {
@@ -1614,8 +1662,8 @@ __global__ __launch_bounds__(256) void sweep_wide_kernel(SweepArgs a) {
       dv = lane == j ? d[j] : dv;
       pv = lane == j ? p[j] : pv;
     }
-    a.wide_d[(size_t)qi * 5 + lane] = num ? dv : FLT_MAX;
-    a.wide_p[(size_t)qi * 5 + lane] = num ? pv : -1;
+    a.wide_d[(size_t)qi * 5 + lane] = dv;
+    a.wide_p[(size_t)qi * 5 + lane] = pv;
   }
 }
 

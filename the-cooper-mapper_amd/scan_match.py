@@ -134,6 +134,10 @@ class Context:
         """lslam_debug_grid_launches: grid sweeps (sweep_grid_kernel) this context has launched so far."""
         return int(self.lib.lslam_debug_grid_launches(self.h))
 
+    def grid_wide_launches(self):
+        """lslam_debug_grid_wide_launches: ... of which in the single-launch form of a map without trees."""
+        return int(self.lib.lslam_debug_grid_wide_launches(self.h))
+
     def cert_stats(self):
         """lslam_debug_cert_stats: (points left to the second pass, points of certificate-testing workgroups, second-pass
         launches) of this context so far; the first two are counted only in runs with lslam_opts.debug_stats = 1 (the grid

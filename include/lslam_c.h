@@ -176,10 +176,10 @@ int lslam_map_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const voi
                   size_t n_surf, size_t stride_bytes);
 int lslam_map_info_get(const lslam_ctx *ctx, lslam_map_info *info);
 
-/* Deferred kd-trees.  on != 0: a map handed over from now on while it is already in HBM (lslam_fmap_surround_to_map: the
- * mapping node's per-frame map, LaserMatcher.cpp:303-331, where the reference rebuilds both trees every frame -- quirk Q4) gets
- * its cell grids at once (bounding box, key sort, cell table: about a third of a tree build) and its kd-trees only when
- * something needs them.  A scan match of one small scan against such a map runs on the grids alone -- the 27-cell probe with
+/* Deferred kd-trees.  on != 0: a map set from now on -- one that is already in HBM (lslam_fmap_surround_to_map: the mapping
+ * node's per-frame map, LaserMatcher.cpp:303-331, where the reference rebuilds both trees every frame -- quirk Q4) or host
+ * clouds (lslam_map_set: ScanMatch::scanMatchScan's, uploaded as usual) -- gets its cell grids at once (bounding box, cell
+ * counts, one scan, placement: about a sixth of a tree build) and its kd-trees only when something needs them.  A scan match of one small scan against such a map runs on the grids alone -- the 27-cell probe with
  * its proof, and for the points it cannot prove one wavefront each over every cell within their bound -- and gives nanoflann's
  * neighbours exactly as the tree search does; the one case the grids cannot decide, an exact distance tie among a point's six
  * nearest, makes the call build the trees and run again through them.  Every other entry point that touches the trees (the

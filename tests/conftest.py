@@ -57,8 +57,16 @@ def small_problem(synth):
 
 
 @pytest.fixture(scope="session")
-def ctx(pkg):
-    """GPU context; only requested by @pytest.mark.gpu tests."""
+def _session_ctx(pkg):
     c = pkg.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture
+def ctx(_session_ctx):
+    """GPU context (one per session); only requested by @pytest.mark.gpu tests.  Settings a test may have left on it
+    (LaserMapping switches deferred trees on) are reset for the next one."""
+    _session_ctx.defer_trees(False)
+    yield _session_ctx
+    _session_ctx.defer_trees(False)

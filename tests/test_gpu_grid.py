@@ -261,6 +261,28 @@ def test_deferred_trees_mapping_frames_equal_eager(pkg, synth, small_problem):
         assert np.array_equal(bits(Ma), bits(Mb))
 
 
+def test_deferred_trees_for_a_host_map(pkg, small_problem):
+    """lslam_map_set with host clouds under lslam_map_defer_trees (ScanMatch::scanMatchScan's call shape): uploaded, grids
+    only; the scan match equals the eager one to the rounding of differently grouped sums, and no tree was built."""
+    pr = small_problem
+    res = {}
+    for defer in (False, True):
+        c = pkg.Context(0)
+        try:
+            c.defer_trees(defer)
+            c.map_set(pr["map_corner"], pr["map_surf"])
+            c.scan_set(pr["corner"], pr["surf"])
+            status, pose, st = c.run(pr["init_pose"])
+            res[defer] = (int(status), pose.copy(), st.iterations, st.n_rows)
+            assert c.lazy_trees() == ((1, 0, True) if defer else (0, 0, False))
+            if defer:
+                assert c.grid_launches() > 0 and c.map_info().depth_corner == 0
+        finally:
+            c.close()
+    assert res[False][0] == res[True][0] and res[False][2:] == res[True][2:]
+    assert np.abs(res[False][1] - res[True][1]).max() <= 2e-6
+
+
 def test_deferred_trees_fall_back_to_the_trees_on_exact_ties(pkg, synth):
     """A lattice map (one point per voxel, so the voxel filter keeps the lattice) and scan points that sit at equal distances
     from several of its points: which five nanoflann returns then depends on its visit order -- the one thing the grids

@@ -772,7 +772,7 @@ int tree_build_failed(int limit, size_t n_points) {
 }
 
 int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void *surf, size_t n_surf,
-                 size_t stride_bytes, const float4 *dev_corner, const float4 *dev_surf) {
+                 size_t stride_bytes, const float4 *dev_corner, const float4 *dev_surf, bool may_defer = true) {
   int rc = check_ctx(ctx, true);  // (a map whose trees were never needed is simply replaced)
   if (rc) return rc;
   ctx->trees_pending = false;
@@ -796,13 +796,50 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
   // ---- deferred trees (lslam_map_defer_trees): a map that is already in HBM gets its cell grids now -- bounding box, key
   // sort, cell table: a third of a tree build -- and its kd-trees when something needs them (ensure_trees).  Only for maps the
   // grid can take and the scan-match guard accepts; anything else is built eagerly below.
-  if (ctx->defer_trees && from_dev && n_corner >= 50 && n_surf >= 100) {
+  // {x, y, z, bitcast(index)} of a host cloud packed straight into pinned memory, a chunk at a time, each chunk's DMA running
+  // while the next one is packed
+  auto upload_host = [&](int k, const void *host, size_t n, float4 *dst, hipStream_t st) -> hipError_t {
+    if (n > ctx->h_map_cap[k]) {
+      if (ctx->h_map_stage[k]) (void)hipHostFree(ctx->h_map_stage[k]);
+      ctx->h_map_stage[k] = nullptr;
+      ctx->h_map_cap[k] = 0;
+      const size_t want = n + n / 4 + 1024;
+      hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_map_stage[k]), want * sizeof(float4), hipHostMallocDefault);
+      if (e != hipSuccess) return e;
+      ctx->h_map_cap[k] = want;
+    }
+    float4 *stage = ctx->h_map_stage[k];
+    const char *sp = static_cast<const char *>(host);
+    constexpr size_t CHUNK = 1u << 17;
+    for (size_t off = 0; off < n; off += CHUNK) {
+      const size_t end = std::min(n, off + CHUNK);
+      for (size_t i = off; i < end; ++i) {
+        float xyz[3];
+        std::memcpy(xyz, sp + i * stride_bytes, sizeof(xyz));
+        stage[i] = make_float4(xyz[0], xyz[1], xyz[2], __builtin_bit_cast(float, (uint32_t)i));
+      }
+      hipError_t e = hipMemcpyAsync(dst + off, stage + off, (end - off) * sizeof(float4), hipMemcpyHostToDevice, st);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  };
+  bool host_uploaded = false;  // the host clouds are in tc.pts / ts.pts already (a deferred attempt that the grid refused)
+  if (ctx->defer_trees && may_defer && n_corner >= 50 && n_surf >= 100) {
     const float cell = ctx->env_grid_cell > 0.0f ? ctx->env_grid_cell : (ctx->grid_cell > 0.0f ? ctx->grid_cell : GRID_CELL_DEFAULT);
     HIP_TRY(ctx->bbox6.reserve(12));
     GridDev *gd[2] = {&ctx->kc, &ctx->ks};
     DevTree *trees[2] = {&ctx->tc, &ctx->ts};
     const float4 *dev_src[2] = {dev_corner, dev_surf};
     const int counts[2] = {(int)n_corner, (int)n_surf};
+    if (!from_dev) {  // a host map (ScanMatch::scanMatchScan's clouds): uploaded once, then as a device map
+      const void *host_src[2] = {corner, surf};
+      for (int k = 0; k < 2; ++k) {
+        HIP_TRY(trees[k]->pts.reserve((size_t)counts[k]));
+        HIP_TRY(upload_host(k, host_src[k], (size_t)counts[k], trees[k]->pts.p, ctx->stream));
+        dev_src[k] = trees[k]->pts.p;
+      }
+      host_uploaded = true;
+    }
     float lo[2][3], hi[2][3];
     HIP_TRY(grid_bbox2(dev_src, counts, ctx->bbox6.p, lo, hi, ctx->stream));  // the one host round trip of the map set
     int st = 0;
@@ -874,33 +911,10 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
         if ((errs[k] = dt.own_box.reserve(cap * 6)) != hipSuccess) return;
         if (n && from_dev) {
           errs[k] = hipMemcpyAsync(dt.pts.p, dev_src[k], n * sizeof(float4), hipMemcpyDeviceToDevice, st);
-        } else if (n && attempt > dt.cap_attempt) {
+        } else if (n && (attempt > dt.cap_attempt || host_uploaded)) {  // the packed cloud is in the pinned staging already
           errs[k] = hipMemcpyAsync(dt.pts.p, ctx->h_map_stage[k], n * sizeof(float4), hipMemcpyHostToDevice, st);
         } else if (n) {
-          // {x, y, z, bitcast(index)} packed straight into pinned memory, a chunk at a time, each
-          // chunk's DMA running while the next one is packed
-          if (n > ctx->h_map_cap[k]) {
-            if (ctx->h_map_stage[k]) (void)hipHostFree(ctx->h_map_stage[k]);
-            ctx->h_map_stage[k] = nullptr;
-            ctx->h_map_cap[k] = 0;
-            const size_t want = n + n / 4 + 1024;
-            if ((errs[k] = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_map_stage[k]), want * sizeof(float4),
-                                         hipHostMallocDefault)) != hipSuccess)
-              return;
-            ctx->h_map_cap[k] = want;
-          }
-          float4 *stage = ctx->h_map_stage[k];
-          const char *sp = static_cast<const char *>(host_src[k]);
-          constexpr size_t CHUNK = 1u << 17;
-          for (size_t off = 0; off < n && errs[k] == hipSuccess; off += CHUNK) {
-            const size_t end = std::min(n, off + CHUNK);
-            for (size_t i = off; i < end; ++i) {
-              float xyz[3];
-              std::memcpy(xyz, sp + i * stride_bytes, sizeof(xyz));
-              stage[i] = make_float4(xyz[0], xyz[1], xyz[2], __builtin_bit_cast(float, (uint32_t)i));
-            }
-            errs[k] = hipMemcpyAsync(dt.pts.p + off, stage + off, (end - off) * sizeof(float4), hipMemcpyHostToDevice, st);
-          }
+          errs[k] = upload_host(k, host_src[k], n, dt.pts.p, st);
         }
         if (errs[k] != hipSuccess) return;
         errs[k] = build_kdtree_device(dt.pts.p, (int32_t)n, dt.nodes.p, dt.own_box.p, (int32_t)cap, st, &dt.view, &dt.depth,
@@ -2187,7 +2201,7 @@ int lslam_odometry_match(lslam_ctx *ctx, const void *last_corner, size_t n_lc, c
   q.insert(q.end(), qf.begin(), qf.end());
   // the map slot of the context holds the two kd-trees of the last clouds (device build, host
   // builder as its fallback -- the same path as lslam_map_set)
-  rc = map_set_impl(ctx, lc.data(), n_lc, ls.data(), n_ls, sizeof(float4), nullptr, nullptr);
+  rc = map_set_impl(ctx, lc.data(), n_lc, ls.data(), n_ls, sizeof(float4), nullptr, nullptr, false);  // (the trees are used right here)
   if (rc) return rc;
   ctx->have_map = false;
   ctx->map_epoch++;  // these trees belong to this call, not to a resident map

@@ -49,6 +49,10 @@ public:
     if (lslam_ctx_create(device, &_ctx) != LSLAM_OK) {
       _ctx = nullptr;
       _init_error = lslam_last_error();
+    } else {
+      // scanMatchScan hands the reference clouds over on every call (the reference rebuilds both kd-trees inside, quirk Q4):
+      // the map gets its cell grids and no trees unless a call needs them -- same poses (include/lslam_c.h)
+      (void)lslam_map_defer_trees(_ctx, 1);
     }
   }
   bool ok() const { return _ctx != nullptr; }

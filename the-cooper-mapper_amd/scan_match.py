@@ -416,6 +416,10 @@ class ScanMatch:
 
     def __init__(self, maxIterations=10, device=0, ctx=None):
         self.ctx = ctx if ctx is not None else Context(device)
+        if ctx is None:
+            # scanMatchScan hands the reference clouds over on every call (the reference rebuilds both kd-trees inside): a
+            # context of its own gets cell grids per map and trees only when a call needs them (lslam_map_defer_trees)
+            self.ctx.defer_trees(True)
         self.opts = self.ctx.default_opts()
         self.opts.max_iterations = int(maxIterations)
         self._match_count = 0       # ScanMatch.h:84

@@ -1233,12 +1233,15 @@ def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, 
             # written and scanned -- over the step's wall time
             n_pts = len(sur_c) + len(sur_s)
             info_ = ctx.map_info()
+            cells = ctx.grid_cells()  # (corner, surf) cells of the two tables
+            # what must move: every point read and written once (2 x 16 B), every cell of the two tables written once (4 B)
+            alg = 2.0 * 16.0 * n_pts + 4.0 * float(sum(cells))
             res["search_structure_build"] = {
                 "what": "cell grids of the surround (lslam_map_defer_trees): no kd-tree is built unless a frame needs one",
-                "ms": gpu["surround_to_map"], "points": n_pts, "trees_built_after_all": int(after_all),
-                "bound": "latency", "bound_detail": "a chain of ~25 short launches (reduction, key, radix-sort passes, scan, placement per type) behind two host waits",
-                "alg_bytes": 2.0 * 16.0 * n_pts, "achieved": 2.0 * 16.0 * n_pts / (gpu["surround_to_map"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": 2.0 * 16.0 * n_pts / (gpu["surround_to_map"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "ms": gpu["surround_to_map"], "points": n_pts, "cells": [int(c) for c in cells], "trees_built_after_all": int(after_all),
+                "bound": "latency", "bound_detail": "segment tables, gather, one bounding-box round trip, then per type count / scan / scatter / rank (4 launches); the step's wall time includes two host waits",
+                "alg_bytes": alg, "achieved": alg / (gpu["surround_to_map"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg / (gpu["surround_to_map"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                 "kd_depth_reported": int(max(info_.depth_corner, info_.depth_surf))}
         else:
             res["tree_build"] = tree_build_roofline(gpu["surround_to_map"], len(sur_c), len(sur_s), np)

@@ -631,6 +631,8 @@ void lslam_debug_sweep_launches(lslam_ctx *ctx, uint64_t counts[8]);
 uint64_t lslam_debug_grid_launches(lslam_ctx *ctx);
 /* ... of which the single-launch form for a map without trees (sweep_grid_kernel<256, true>) */
 uint64_t lslam_debug_grid_wide_launches(lslam_ctx *ctx);
+/* cells of the resident map's two cell tables (corner, surf); 0 while a type has no grid */
+void lslam_debug_grid_cells(lslam_ctx *ctx, uint64_t out[2]);
 /* out[0] maps set with deferred trees, out[1] of those whose trees were built after all, out[2] 1 while the resident map's are pending */
 void lslam_debug_lazy_trees(lslam_ctx *ctx, uint64_t out[3]);
 /* Debug tap of the certificate sweep (csrc/lslam_kernels.hip sweep_body): out[2] = second-pass launches of this

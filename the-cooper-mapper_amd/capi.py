@@ -237,6 +237,7 @@ SYMBOLS = {
     "lslam_comm_info": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p]),
     "lslam_debug_grid_launches": (C.c_uint64, [C.c_void_p]),
     "lslam_debug_grid_wide_launches": (C.c_uint64, [C.c_void_p]),
+    "lslam_debug_grid_cells": (None, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "lslam_map_defer_trees": (C.c_int, [C.c_void_p, C.c_int32]),
     "lslam_debug_lazy_trees": (None, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "lslam_comm_allreduce_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -676,6 +676,10 @@ void lslam_debug_lazy_trees(lslam_ctx *ctx, uint64_t out[3]) {
 
 uint64_t lslam_debug_grid_launches(lslam_ctx *ctx) { return ctx ? ctx->sweep_variants[SWEEP_VARIANT_GRID] + ctx->sweep_variants[SWEEP_VARIANT_GRID_WIDE] : 0; }
 uint64_t lslam_debug_grid_wide_launches(lslam_ctx *ctx) { return ctx ? ctx->sweep_variants[SWEEP_VARIANT_GRID_WIDE] : 0; }
+void lslam_debug_grid_cells(lslam_ctx *ctx, uint64_t out[2]) {
+  out[0] = ctx && ctx->kc.view.cell_start ? (uint64_t)ctx->kc.n_cells : 0;
+  out[1] = ctx && ctx->ks.view.cell_start ? (uint64_t)ctx->ks.n_cells : 0;
+}
 
 void lslam_debug_sweep_launches(lslam_ctx *ctx, uint64_t counts[8]) {
   for (int i = 0; i < 8; ++i) counts[i] = ctx ? ctx->sweep_variants[i] : 0;

@@ -36,7 +36,20 @@ __global__ __launch_bounds__(256) void grid_count_kernel(CellGrid G, const float
   bool ok;
   const int c = cell_of(G, src[i], ok);
   if (!ok) atomicAdd(err, 1);  // a point outside its own bounding box: not a number
-  atomicAdd(count + c, 1u);
+  {
+    // a map comes in voxel order: neighbouring lanes often share a cell -- one atomic per run of equal cells in the wavefront
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(c, 1, 64);
+    const unsigned long long alive = __ballot(1);
+    const bool head = lane == 0 || c != prev || !((alive >> (lane - 1)) & 1ull);
+    const unsigned long long heads = __ballot(head);
+    if (head) {
+      const unsigned long long after = lane == 63 ? 0ull : (heads >> (lane + 1));
+      const int upto = after ? lane + 1 + __builtin_ctzll(after) : 64;  // the next head, or the end of the wavefront
+      const int run = __popcll(alive & (upto == 64 ? ~0ull : ((1ull << upto) - 1ull)) & ~((1ull << lane) - 1ull));
+      atomicAdd(count + c, (uint32_t)run);
+    }
+  }
   // the coarse count: neighbouring points share it more often than not -- one atomic per distinct value in the wavefront
   const int cb = c / CS_CELLS;
   unsigned long long todo = __ballot(1);

@@ -138,6 +138,12 @@ class Context:
         """lslam_debug_grid_wide_launches: ... of which in the single-launch form of a map without trees."""
         return int(self.lib.lslam_debug_grid_wide_launches(self.h))
 
+    def grid_cells(self):
+        """lslam_debug_grid_cells: (cells of the corner table, cells of the surf table) of the resident map's cell grids."""
+        out = (C.c_uint64 * 2)()
+        self.lib.lslam_debug_grid_cells(self.h, out)
+        return int(out[0]), int(out[1])
+
     def cert_stats(self):
         """lslam_debug_cert_stats: (points left to the second pass, points of certificate-testing workgroups, second-pass
         launches) of this context so far; the first two are counted only in runs with lslam_opts.debug_stats = 1 (the grid

@@ -338,6 +338,20 @@ def test_grid_limits_fall_back_to_the_tree(pkg, ctx):
     li, ld = ctx.knn5(1, q, search_mode=LANE)
     gi, gd, n_un = ctx.knn5(1, q, search_mode=GRID, want_ties=True)
     assert np.array_equal(gi, li) and np.array_equal(bits(gd), bits(ld)) and n_un > 0.9 * len(q)
+    # (a') cells with more points than the grid build ranks by original index (1 024: their order is whatever the placement's
+    # atomics gave) next to ordinary ones: such cells are never proven from, so the answers are the tree's -- in every build
+    clump = (rng.normal(0, 0.08, (6000, 3)) + np.array([1.0, 1.0, 1.0])).astype(np.float32)
+    sparse = rng.uniform(-6, 6, (40000, 3)).astype(np.float32)
+    both = np.concatenate([clump, sparse]).astype(np.float32)
+    q2 = np.concatenate([rng.normal(0, 0.3, (500, 3)) + np.array([1.0, 1.0, 1.0]), rng.uniform(-5, 5, (1500, 3))]).astype(np.float32)
+    first = None
+    for build in range(3):
+        ctx.map_set(both, both)
+        li2, ld2 = ctx.knn5(1, q2, search_mode=LANE)
+        gi2, gd2, n_un2 = ctx.knn5(1, q2, search_mode=GRID, want_ties=True)
+        assert np.array_equal(gi2, li2) and np.array_equal(bits(gd2), bits(ld2)) and 0 < n_un2 < len(q2)
+        first = first if first is not None else (gi2.copy(), gd2.copy())
+        assert np.array_equal(first[0], gi2) and np.array_equal(bits(first[1]), bits(gd2))
     # (b)
     line = np.stack([np.linspace(-900.0, 900.0, 4000), np.zeros(4000), np.zeros(4000)], 1).astype(np.float32)
     wide = np.concatenate([line, line + np.array([0, 0.4, 0], np.float32), line + np.array([0, 0.8, 0.3], np.float32)]).astype(np.float32)

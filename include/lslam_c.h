@@ -88,7 +88,12 @@ typedef struct {
 } lslam_opts;
 /* Environment overrides of the fields above -- LSLAM_KNN_CERT, LSLAM_CERT_TRY_M, LSLAM_CERT_TRACK_M, LSLAM_GRID_CELL,
  * LSLAM_SEARCH=lane|packet|grid, LSLAM_FORCE_STACK=deep|shallow|auto, LSLAM_PERSISTENT_GN=1, LSLAM_FUSED_SOLVE=1,
- * LSLAM_DEBUG_CERT_STATS=1 -- are read ONCE, in lslam_ctx_create; no entry point reads the environment while it runs. */
+ * LSLAM_DEBUG_CERT_STATS=1 -- are read ONCE per context, in lslam_ctx_create; the A/B switches of the builders and the loop
+ * (LSLAM_UNBOUNDED_KNN, LSLAM_NO_MORTON, LSLAM_HOST_MORTON, LSLAM_TINY_PHASE, LSLAM_NO_REG_NODES, LSLAM_NO_LEVEL_BUILD, ...)
+ * once per process, when the first context is created; a pose graph's (LSLAM_PG_*) when it is created.  No entry point reads
+ * the environment while it runs.  The hooks tests use to force failure paths (LSLAM_DEBUG_NODE_CAP_DIV,
+ * LSLAM_DEBUG_SPIN_LIMIT, LSLAM_DEBUG_PG_ABORT, LSLAM_DEBUG_GJ_ABORT, LSLAM_HUGE_MIN) are the exception, and exist only in a
+ * process started with LSLAM_DEBUG_HOOKS=1 (tests/conftest.py sets it); without it they are never looked at. */
 enum { LSLAM_AB_PERSISTENT_GN = 1, /* one resident scan: the whole Gauss-Newton loop as one persistent launch */
        LSLAM_AB_FUSED_SOLVE = 2,   /* latency-bound launches: the 6x6 solve in the tail of the sweep launch */
        LSLAM_AB_SECOND_PROBE = 4,  /* grid sweep: the points the 27-cell probe cannot prove get a second, 125-cell probe (clipped to

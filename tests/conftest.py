@@ -7,6 +7,9 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# The library reads the environment once, when the first context is created; the per-call test hooks (LSLAM_DEBUG_NODE_CAP_DIV,
+# LSLAM_DEBUG_SPIN_LIMIT, LSLAM_DEBUG_PG_ABORT, LSLAM_HUGE_MIN ...) are looked at only in a process started with this set
+os.environ.setdefault("LSLAM_DEBUG_HOOKS", "1")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

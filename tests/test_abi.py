@@ -225,3 +225,31 @@ def test_struct_sizes_equal_the_c_compilers(pkg, tmp_path):
     capi = import_module("the-cooper-mapper_amd.capi")
     assert sizes == [C.sizeof(capi.LslamOpts), C.sizeof(capi.LslamStats), C.sizeof(capi.LslamMapInfo), C.sizeof(capi.LslamPgStats),
                      C.sizeof(capi.LslamStereoCam), C.sizeof(capi.LslamRegParams)]
+
+
+def test_no_entry_point_reads_the_environment_while_it_runs():
+    """`getenv` appears only where the header says the environment is read: the process-wide snapshot (env_once / debug_env)
+    and lslam_ctx_create in lslam_api.hip, lslam_pg_create in lslam_posegraph.hip -- nowhere in the kernels' launchers, the
+    builders, the map or the feature code."""
+    import re
+    src = os.path.join(ROOT, "the-cooper-mapper_amd", "csrc")
+
+    def lines_with_getenv(name):
+        with open(os.path.join(src, name)) as f:
+            text = f.read().split("\n")
+        return text, [i for i, l in enumerate(text) if re.search(r"\bgetenv\s*\(", l) and not l.lstrip().startswith("//")]
+
+    for name in sorted(os.listdir(src)):
+        if not name.endswith((".hip", ".hpp")):
+            continue
+        text, hits = lines_with_getenv(name)
+        if name == "lslam_api.hip":
+            lo = next(i for i, l in enumerate(text) if "const EnvOnce &env_once()" in l)
+            hi = next(i for i, l in enumerate(text) if l.startswith("void lslam_ctx_destroy"))
+            assert hits and all(lo < i < hi for i in hits), [text[i] for i in hits if not lo < i < hi]
+        elif name == "lslam_posegraph.hip":
+            lo = next(i for i, l in enumerate(text) if l.startswith("int lslam_pg_create("))
+            hi = next(i for i, l in enumerate(text) if i > lo and l.startswith("}"))
+            assert hits and all(lo < i < hi for i in hits), [text[i] for i in hits if not lo < i < hi]
+        else:
+            assert not hits, (name, [text[i] for i in hits])

@@ -517,6 +517,30 @@ int check_ctx(lslam_ctx *ctx, bool trees_may_be_pending = false) {
 
 }  // namespace
 
+namespace lslam {
+const EnvOnce &env_once() {
+  static const EnvOnce e = [] {
+    EnvOnce v;
+    auto on = [](const char *n) { return std::getenv(n) != nullptr; };
+    auto num = [](const char *n, int dflt) { const char *s = std::getenv(n); return s ? std::atoi(s) : dflt; };
+    v.hooks = num("LSLAM_DEBUG_HOOKS", 0) == 1;
+    v.debug = on("LSLAM_DEBUG");
+    v.unbounded_knn = on("LSLAM_UNBOUNDED_KNN");
+    v.no_morton = on("LSLAM_NO_MORTON");
+    v.host_morton = on("LSLAM_HOST_MORTON");
+    v.odom_inline = on("LSLAM_ODOM_INLINE_SEARCH");
+    v.gnp_coop = on("LSLAM_GNP_COOPERATIVE");
+    v.tiny_phase_off = on("LSLAM_TINY_PHASE") && num("LSLAM_TINY_PHASE", 1) == 0;
+    v.no_reg_nodes = on("LSLAM_NO_REG_NODES");
+    v.no_level_build = on("LSLAM_NO_LEVEL_BUILD");
+    v.fmap_timing = on("LSLAM_FMAP_TIMING");
+    return v;
+  }();
+  return e;
+}
+const char *debug_env(const char *name) { return env_once().hooks ? std::getenv(name) : nullptr; }
+}  // namespace lslam
+
 extern "C" {
 
 const char *lslam_last_error(void) { return g_err.c_str(); }
@@ -569,7 +593,8 @@ int lslam_ctx_create(int device, lslam_ctx **out) {
   HIP_TRY(hipEventCreate(&ctx->ev0));
   HIP_TRY(hipEventCreate(&ctx->ev1));
   // Environment overrides of lslam_opts fields (A/B runs of a binary one cannot pass options to): read here, once per
-  // context -- never inside a call, where another thread's setenv would race with it.
+  // context -- never inside a call, where another thread's setenv would race with it.  (The process-wide switches: env_once.)
+  (void)lslam::env_once();
   if (const char *v = std::getenv("LSLAM_KNN_CERT")) ctx->env_knn_cert = std::atoi(v);
   if (const char *v = std::getenv("LSLAM_CERT_TRY_M")) ctx->env_cert_try_m = (float)std::atof(v);
   if (const char *v = std::getenv("LSLAM_CERT_TRACK_M")) ctx->env_cert_track_m = (float)std::atof(v);
@@ -582,7 +607,7 @@ int lslam_ctx_create(int device, lslam_ctx **out) {
   }
   if (const char *v = std::getenv("LSLAM_PERSISTENT_GN")) ctx->env_ab |= std::atoi(v) == 1 ? LSLAM_AB_PERSISTENT_GN : 0;
   if (const char *v = std::getenv("LSLAM_FUSED_SOLVE")) ctx->env_ab |= std::atoi(v) == 1 ? LSLAM_AB_FUSED_SOLVE : 0;
-  ctx->env_debug = std::getenv("LSLAM_DEBUG") != nullptr;
+  ctx->env_debug = lslam::env_once().debug;
   if (const char *v = std::getenv("LSLAM_SEARCH")) {
     if (!std::strcmp(v, "lane")) ctx->env_search = LSLAM_SEARCH_LANE;
     else if (!std::strcmp(v, "packet")) ctx->env_search = LSLAM_SEARCH_PACKET;
@@ -740,7 +765,7 @@ int lslam_debug_sweep_clocks(lslam_ctx *ctx, const float pose[6], int32_t jtj_mo
   HIP_TRY(hipMalloc((void **)&d, words * sizeof(uint64_t)));
   HIP_TRY(hipMemsetAsync(d, 0, words * sizeof(uint64_t), ctx->stream));
   sa.dbg = d;
-  static const bool unbounded_dbg = std::getenv("LSLAM_UNBOUNDED_KNN") != nullptr;
+  const bool unbounded_dbg = env_once().unbounded_knn;
   sa.bounded = unbounded_dbg ? 0 : 1;
   sa.prev_valid = ctx->prev_valid ? 1 : 0;
   if (sa.bounded) ctx->prev_valid = true;
@@ -909,7 +934,7 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
       for (int attempt = dt.cap_attempt; attempt < 3; ++attempt) {
         const size_t mult[3] = {8, 16, 24};
         size_t cap = ((mult[attempt] * n / 3 + 64) + 7) & ~(size_t)7;
-        if (const char *dv = std::getenv("LSLAM_DEBUG_NODE_CAP_DIV"))  // tests: force the retry / failure paths
+        if (const char *dv = debug_env("LSLAM_DEBUG_NODE_CAP_DIV"))  // tests: force the retry / failure paths
           cap = std::max<size_t>(16, (cap / (size_t)std::max(1, atoi(dv))) & ~(size_t)7);
         if ((errs[k] = dt.nodes.reserve(cap)) != hipSuccess) return;
         if ((errs[k] = dt.own_box.reserve(cap * 6)) != hipSuccess) return;
@@ -1337,8 +1362,8 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
   std::vector<float4> tmp;
   // LSLAM_NO_MORTON: caller order (profiling A/B); LSLAM_HOST_MORTON: order on the host (A/B, and the
   // definition the device ordering is tested against)
-  static const bool no_morton = std::getenv("LSLAM_NO_MORTON") != nullptr;
-  static const bool host_morton = std::getenv("LSLAM_HOST_MORTON") != nullptr;
+  const bool no_morton = env_once().no_morton;
+  const bool host_morton = env_once().host_morton;
   const bool dev_morton = !no_morton && !host_morton;
   std::vector<int32_t> seg_off;
   int32_t out_base = 0;
@@ -1582,7 +1607,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
   };
   if (sharded) {
     // xchg[32]: the local point count first (one exchange per call), then the sums per iteration
-    static const bool unbounded = std::getenv("LSLAM_UNBOUNDED_KNN") != nullptr;
+    const bool unbounded = env_once().unbounded_knn;
     sa.bounded = (ctx->cube_mode || unbounded) ? 0 : 1;
     double cnt[NCOL] = {0};
     cnt[0] = (double)ctx->nqc[0] + (double)ctx->nqs[0];
@@ -1639,7 +1664,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
   bool gnp_done = false;
   {
     const bool gnp_off = !((o.ab_switches | ctx->env_ab) & LSLAM_AB_PERSISTENT_GN);
-    static const bool unbounded = std::getenv("LSLAM_UNBOUNDED_KNN") != nullptr;
+    const bool unbounded = env_once().unbounded_knn;
     if (!sharded && !lazy && n_scans == 1 && !gnp_off && ctx->gnp_ok && !o.profile && ctx->n_stereo == 0 && !ctx->cube_mode &&
         !sa.packet && sa.stack_mode != SWEEP_STACK_SHALLOW && max_it > 0 && ctx->tc.depth <= KD_STACK_LDS + 1 && ctx->ts.depth <= KD_STACK_LDS + 1 &&
         sa.nb_total > 0 && sa.nb_total <= 512) {
@@ -1687,7 +1712,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
   if (!sharded && !gnp_done) {
     const int in_flight = o.scans_in_flight > 0 ? std::min<int>(o.scans_in_flight, n_scans) : std::min<int>(n_scans, 128);
     const int n_chunks = (n_scans + in_flight - 1) / in_flight;
-    static const bool unbounded = std::getenv("LSLAM_UNBOUNDED_KNN") != nullptr;  // A/B switch
+    const bool unbounded = env_once().unbounded_knn;  // A/B switch
     sa.bounded = (ctx->cube_mode || unbounded) ? 0 : 1;  // per-cube positions are tree-relative
     // The grid sweep (LSLAM_SEARCH_GRID): cell grids over the resident trees, made on first use.  A map the grid cannot take
     // (non-finite points, an extent beyond the grid's limits) is searched by the tree as before.
@@ -2263,7 +2288,7 @@ int lslam_odometry_match(lslam_ctx *ctx, const void *last_corner, size_t n_lc, c
   so.too_few_continue = 1;
   so.nan_reset = 1;
   HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-  static const bool inline_search = std::getenv("LSLAM_ODOM_INLINE_SEARCH") != nullptr;  // A/B switch
+  const bool inline_search = env_once().odom_inline;  // A/B switch
   // Like the scan-to-map loop: the first batch of iterations is sized from the previous sweep's count
   // (+1 spare), then the host looks at the state and enqueues five more at a time -- launches after the
   // loop has ended exit at once but still cost a few microseconds each (25 x 2 of them per sweep).

@@ -1201,7 +1201,7 @@ int lslam_fmap_to_cubemap(lslam_fmap *fm) {
   size_t n_pts[2] = {0, 0};
   int depth[2] = {0, 0};
   fm->trees_built = fm->trees_reused = 0;
-  const bool timing = std::getenv("LSLAM_FMAP_TIMING") != nullptr;
+  const bool timing = lslam::env_once().fmap_timing;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double, std::milli>(b - a).count();

@@ -361,6 +361,25 @@ int ctx_stack_ovf_if_deep(lslam_ctx *ctx, size_t n_threads, uint32_t **out);  //
 int ctx_device(const lslam_ctx *ctx);
 bool ctx_alive(const lslam_ctx *ctx);
 
+// The process environment, read ONCE: when the first context (or pose graph) is created.  No entry point reads the
+// environment while it runs -- another thread's setenv would race with it.  A/B switches of measurements and the values tests
+// steer failure paths with live here; the per-call test hooks (LSLAM_DEBUG_*: node-slot divisor, spin limits, forced aborts,
+// LSLAM_HUGE_MIN) go through debug_env, which looks at the environment only in a process started with LSLAM_DEBUG_HOOKS=1.
+struct EnvOnce {
+  bool hooks = false;            // LSLAM_DEBUG_HOOKS=1
+  bool debug = false;            // LSLAM_DEBUG
+  bool unbounded_knn = false;    // LSLAM_UNBOUNDED_KNN
+  bool no_morton = false, host_morton = false;  // LSLAM_NO_MORTON, LSLAM_HOST_MORTON
+  bool odom_inline = false;      // LSLAM_ODOM_INLINE_SEARCH
+  bool gnp_coop = false;         // LSLAM_GNP_COOPERATIVE
+  bool tiny_phase_off = false;   // LSLAM_TINY_PHASE=0
+  bool no_reg_nodes = false;     // LSLAM_NO_REG_NODES
+  bool no_level_build = false;   // LSLAM_NO_LEVEL_BUILD
+  bool fmap_timing = false;      // LSLAM_FMAP_TIMING
+};
+const EnvOnce &env_once();
+const char *debug_env(const char *name);  // nullptr unless the process runs with LSLAM_DEBUG_HOOKS=1 and `name` is set
+
 // lslam_fmap.hip: pcl::VoxelGrid per segment (see there)
 int voxel_filter_segments(hipStream_t s, const float4 *in_pts, const int32_t *in_seg, size_t n, int nseg, float leaf,
                           float4 *out_pts, int32_t *out_seg, size_t *n_out, bool filter = true, uint32_t *done = nullptr);

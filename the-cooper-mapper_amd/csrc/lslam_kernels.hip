@@ -1835,7 +1835,7 @@ hipError_t launch_gn_persistent(const SweepArgs &a, int jtj_mode, const GnLoopAr
   // An ordinary launch: the caller has checked that the grid fits the device at once, and the kernel's spin limit turns
   // the case it does not (another process on the device) into a fallback instead of a hang.  hipLaunchCooperativeKernel
   // adds tens of microseconds per launch on this runtime -- more than the launches this kernel saves.
-  static const bool coop = std::getenv("LSLAM_GNP_COOPERATIVE") != nullptr;  // A/B switch
+  const bool coop = env_once().gnp_coop;  // A/B switch
   if (coop) {
     SweepArgs aa = a;
     int jm = jtj_mode;

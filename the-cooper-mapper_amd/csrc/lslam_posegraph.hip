@@ -35,6 +35,7 @@ hipError_t comm_allreduce_f64(lslam_comm *comm, double *buf, size_t count, hipSt
 hipError_t comm_allgatherv_f64(lslam_comm *comm, int n_lists, double *const *bufs, const int64_t *const *offs, hipStream_t s);
 int comm_world(const lslam_comm *comm);
 int comm_rank(const lslam_comm *comm);
+const char *debug_env(const char *name);  // lslam_api.hip: a test hook's value, only in a process started with LSLAM_DEBUG_HOOKS=1
 }
 
 namespace {
@@ -1622,6 +1623,10 @@ struct lslam_pg {
   int32_t *d_agg_of = nullptr, *d_agg_ptr = nullptr, *d_agg_mem = nullptr;
   double *d_P = nullptr, *d_Ac = nullptr, *d_rc = nullptr, *d_yc = nullptr, *d_gj = nullptr;
   int32_t *d_cb_ptr = nullptr, *d_cb_ent = nullptr, *d_cb_ab = nullptr;
+  // environment switches, read when the graph is created (lslam_pg_create) -- never while it is optimised
+  bool env_no_reuse = false, env_persistent_off = false, env_debug = false;
+  int env_max_cg = 20000;
+  double env_tol = 1e-8;
   int coarse_mode = -1;     // -1 automatic (switched on by a solve that needed many iterations), 0 off, 1 on
   bool coarse_on = false;
   int coarse_solves = 0;    // damped systems solved with the second level (statistics)
@@ -1789,7 +1794,7 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
     c.agg_of = pg->d_agg_of; c.agg_ptr = pg->d_agg_ptr; c.agg_mem = pg->d_agg_mem;
     c.n_v = pg->n_v; c.G = pg->agg; c.na = pg->n_agg; c.n_c = pg->n_c; c.n_cb = pg->n_cb; c.n_cblk = pg->n_cblk;
     const size_t nn = (size_t)c.n_c * c.n_c;
-    static const bool no_reuse = std::getenv("LSLAM_PG_NO_REUSE") != nullptr;  // A/B switch
+    const bool no_reuse = pg->env_no_reuse;  // A/B switch (LSLAM_PG_NO_REUSE, read when the graph was created)
     bool rebuild = !pg->coarse_valid || no_reuse;
     if (!rebuild) {
       const double ratio = lambda > pg->coarse_lambda ? lambda / pg->coarse_lambda : pg->coarse_lambda / lambda;
@@ -1808,7 +1813,7 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
     hipLaunchKernelGGL(pgc_assemble_kernel, dim3(c.n_cb), dim3(64), 0, pg->stream, c, pg->d_vals, pg->d_row_of, pg->d_row_col, n_items);
     if (pg->gj_fit < 0) {  // the persistent inverse when a workgroup per aggregate is co-resident and the row fits its registers
       pg->gj_fit = 0;
-      const bool off = std::getenv("LSLAM_PG_PERSISTENT") && std::atoi(std::getenv("LSLAM_PG_PERSISTENT")) == 0;
+      const bool off = pg->env_persistent_off;
       hipDeviceProp_t prop;
       int per_cu = 0;
       if (!off && c.n_c <= GJ_CREG * GJ_BLOCK && hipGetDeviceProperties(&prop, pg->device) == hipSuccess &&
@@ -1821,7 +1826,10 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
     if (pg->gj_fit == 1) {
       GjArgs gj;
       gj.Ac = c.Ac; gj.slots = pg->d_gjslots; gj.bar = pg->d_bar; gj.n_c = c.n_c; gj.na = c.na;
-      gj.debug_abort = std::getenv("LSLAM_DEBUG_GJ_ABORT") ? std::atoi(std::getenv("LSLAM_DEBUG_GJ_ABORT")) : -1;
+      {
+        const char *da = lslam::debug_env("LSLAM_DEBUG_GJ_ABORT");  // test hook (LSLAM_DEBUG_HOOKS=1)
+        gj.debug_abort = da ? std::atoi(da) : -1;
+      }
       PG_TRY(hipMemsetAsync(pg->d_bar, 0, 2 * sizeof(unsigned), pg->stream));
       PG_TRY(hipMemsetD32Async((hipDeviceptr_t)pg->d_gjslots, (int)PK_SENT32, (size_t)c.na * 6 * c.n_c * 2, pg->stream));
       void *gargs[] = {(void *)&gj};
@@ -1837,7 +1845,7 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
       }
       if (gbar[1] != 0) {  // not all workgroups resident at once (see the PCG kernel's fallback): the launch loop inverts A_c,
                            // assembled once more (a kernel that timed out wrote nothing back, but nothing here relies on that)
-        if (std::getenv("LSLAM_DEBUG")) fprintf(stderr, "[lslam pg] persistent Gauss-Jordan kernel timed out: launch loop from here on\n");
+        if (pg->env_debug) fprintf(stderr, "[lslam pg] persistent Gauss-Jordan kernel timed out: launch loop from here on\n");
         pg->gj_fit = 0;
         pg->pk_timeouts++;
         pg->fell_back = true;
@@ -1960,7 +1968,7 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
   // The persistent kernel when the graph fits: one workgroup per aggregate, all co-resident, LDS for its columns / items.
   if (pg->pk_fit < 0) {
     pg->pk_fit = 0;
-    const bool off = std::getenv("LSLAM_PG_PERSISTENT") && std::atoi(std::getenv("LSLAM_PG_PERSISTENT")) == 0;
+    const bool off = pg->env_persistent_off;
     hipDeviceProp_t prop;
     int per_cu = 0;
     if (!off && pg->n_agg <= PK_BLOCK /* one thread per aggregate sums the partials */ && pg->pk_lds_bytes <= 150 * 1024 &&
@@ -1991,7 +1999,10 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
     k.n6 = n6; k.n_agg = pg->n_agg; k.n_c = pg->n_c; k.coarse = coarse ? 1 : 0; k.max_iter = max_cg;
     k.lds_cols = pg->pk_lds_cols; k.lds_items = pg->pk_lds_items;
     k.tol2 = tol * tol;
-    k.debug_abort = std::getenv("LSLAM_DEBUG_PG_ABORT") ? std::atoi(std::getenv("LSLAM_DEBUG_PG_ABORT")) : -1;
+    {
+      const char *da = lslam::debug_env("LSLAM_DEBUG_PG_ABORT");  // test hook (LSLAM_DEBUG_HOOKS=1)
+      k.debug_abort = da ? std::atoi(da) : -1;
+    }
     PG_TRY(hipMemsetAsync(pg->d_bar, 0, 2 * sizeof(unsigned), pg->stream));
     PG_TRY(hipMemsetD32Async((hipDeviceptr_t)slots, (int)PK_SENT32, 2 * n_slots, pg->stream));
     void *kargs[] = {(void *)&k};
@@ -2020,7 +2031,7 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
     // An exchange ran into its spin limit: the workgroups were not all resident at once (another process's persistent
     // kernel on the same device can do that -- cooperative launches are not coordinated across processes).  Nothing was
     // written that the launch-per-step loop below reads; this graph stays on that loop from here on.
-    if (std::getenv("LSLAM_DEBUG")) fprintf(stderr, "[lslam pg] persistent PCG kernel timed out in a grid exchange: launch loop from here on\n");
+    if (pg->env_debug) fprintf(stderr, "[lslam pg] persistent PCG kernel timed out in a grid exchange: launch loop from here on\n");
     pg->pk_fit = 0;
     pg->pk_timeouts++;
     pg->fell_back = true;
@@ -2091,6 +2102,12 @@ int lslam_pg_create(int device, int32_t n_v, const double *poses7, int32_t n_e, 
   pg->device = device;
   pg->n_v = n_v;
   pg->n_e = n_e;
+  (void)lslam::debug_env("LSLAM_DEBUG_HOOKS");  // (the process-wide snapshot of the environment is taken no later than here)
+  pg->env_no_reuse = std::getenv("LSLAM_PG_NO_REUSE") != nullptr;
+  pg->env_persistent_off = std::getenv("LSLAM_PG_PERSISTENT") && std::atoi(std::getenv("LSLAM_PG_PERSISTENT")) == 0;
+  pg->env_debug = std::getenv("LSLAM_DEBUG") != nullptr;
+  if (const char *v = std::getenv("LSLAM_PG_MAX_CG")) pg->env_max_cg = std::atoi(v);
+  if (const char *v = std::getenv("LSLAM_PG_TOL")) pg->env_tol = std::atof(v);
   pg->fixed = fixed_vertex;
   PG_TRY(hipStreamCreateWithFlags(&pg->stream, hipStreamNonBlocking));
   pg->h_ij.assign(ij, ij + 2 * (size_t)n_e);
@@ -2593,8 +2610,8 @@ int lslam_pg_optimize(lslam_pg *pg, int32_t max_iters, lslam_pg_stats *st_out) {
       // PCG needs thousands of iterations -- but a TRUNCATED solve leaves exactly the slow (global bending) modes
       // unresolved, and LM then crawls (measured: capped at 800 iterations the 5 k / 25 k graph is still 5 m from its
       // optimum after 2 000 LM iterations; uncapped it arrives in 342).  LSLAM_PG_MAX_CG overrides the cap for A/B runs.
-      static const int max_cg = std::getenv("LSLAM_PG_MAX_CG") ? std::atoi(std::getenv("LSLAM_PG_MAX_CG")) : 20000;
-      static const double cg_tol = std::getenv("LSLAM_PG_TOL") ? std::atof(std::getenv("LSLAM_PG_TOL")) : 1e-8;
+      const int max_cg = pg->env_max_cg;
+      const double cg_tol = pg->env_tol;
       pg->fell_back = false;
       rc = solve(pg, lambda, max_cg, cg_tol, &cg);
       if (rc) return rc;

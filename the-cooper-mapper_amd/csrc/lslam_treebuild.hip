@@ -1898,7 +1898,7 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
   // levels cost a handful of empty launches); the host checks the item count once per batch.
   const dim3 gc(cap_chunks), gn((cap_nodes + 63) / 64), bt(LV_TB);
   int lvl = 0;
-  const bool dbg = std::getenv("LSLAM_DEBUG") != nullptr;
+  const bool dbg = env_once().debug;
   auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (int batch = 0; batch < 16; ++batch) {
     const double t_enq0 = now_us();
@@ -1953,18 +1953,18 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
 }  // namespace
 
 static bool tiny_phase_enabled() {
-  static const bool off = std::getenv("LSLAM_TINY_PHASE") && std::atoi(std::getenv("LSLAM_TINY_PHASE")) == 0;  // A/B switch
+  const bool off = env_once().tiny_phase_off;  // A/B switch
   return !off;
 }
 static int32_t reg_nodes_enabled() {
-  static const bool off = std::getenv("LSLAM_NO_REG_NODES") != nullptr;  // A/B switch
+  const bool off = env_once().no_reg_nodes;  // A/B switch
   return off ? 0 : 1;
 }
 
 hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, float *d_own_box, int32_t node_cap,
                                hipStream_t stream, TreeView *view, int *depth, size_t *n_leaves,
                                int *fallback) {
-  const bool dbg = std::getenv("LSLAM_DEBUG") != nullptr;
+  const bool dbg = env_once().debug;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double T0 = now();
   *fallback = 0;
@@ -2019,13 +2019,14 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, float 
   A.node_cap = node_cap & ~7;
   A.queue_cap = queue_cap;
   {
-    const int env_huge = std::getenv("LSLAM_HUGE_MIN") ? std::atoi(std::getenv("LSLAM_HUGE_MIN")) : 0;  // A/B switch, read per build
+    const char *hm = debug_env("LSLAM_HUGE_MIN");  // A/B switch and test hook (LSLAM_DEBUG_HOOKS=1), read per build
+    const int env_huge = hm ? std::atoi(hm) : 0;
     A.huge_min = std::min(HUGE_MIN_MAX, std::max(LOCAL_MAX, env_huge > 0 ? env_huge : HUGE_MIN_TREE));
   }
   A.n = n;
   A.reg_nodes = reg_nodes_enabled();
   A.spin_limit = 1u << 22;
-  if (const char *sl = std::getenv("LSLAM_DEBUG_SPIN_LIMIT")) A.spin_limit = (uint32_t)strtoul(sl, nullptr, 10);  // tests
+  if (const char *sl = debug_env("LSLAM_DEBUG_SPIN_LIMIT")) A.spin_limit = (uint32_t)strtoul(sl, nullptr, 10);  // tests
   void *blob = nullptr;
   A.sub_cap = sub_cap;
   const size_t sz_queue = (size_t)queue_cap * sizeof(BuildItem), sz_ready = (size_t)queue_cap * sizeof(int32_t),
@@ -2052,7 +2053,7 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, float 
   if ((e = hipMemsetAsync(d_nodes, 0, (size_t)A.node_cap * sizeof(KdNode), stream)) != hipSuccess) return e;
   BuildCtl ctl{};
   const bool root_small = n <= LOCAL_MAX;
-  static const bool no_levels = std::getenv("LSLAM_NO_LEVEL_BUILD") != nullptr;  // A/B switch
+  const bool no_levels = env_once().no_level_build;  // A/B switch
   // Below ~50 k points the launches of the level phase cost more host time than the persistent phase-A
   // kernel (one workgroup per node, one launch) costs device time: 0.49 against 0.62 ms at 16 k
   // points, equal at 64 k, 4.3 against 1.6 ms at 512 k (tools/tree_size_sweep.py).

@@ -540,7 +540,8 @@ def compact_line(out):
                                    "keyframes": pg.get("keyframes"), "edges": pg.get("edges"), "n_gpus": pg.get("n_gpus"),
                                    "allreduce_bytes_per_linearisation": pg.get("allreduce_bytes_per_linearisation"),
                                    "roofline_frac": _pick(pg, "roofline", "frac"), "roofline_kernel": _pick(pg, "roofline", "kernel"),
-                                   "cpu_lm_iters_per_s": _pick(pg, "cpu_baseline", "value"), "error": pg.get("error")}))
+                                   "cpu_lm_iters_per_s": _pick(pg, "cpu_baseline", "value"),
+                                   "inexact_lm_tol_1e-3_iters_per_s": _pick(pg, "inexact_lm", "lm_iters_per_s"), "error": pg.get("error")}))
     for key in ("mapping_frame", "mapping_frame_vlp16", "mapping_frame_cubes"):
         mf = out.get(key) or {}
         if mf:
@@ -1091,6 +1092,26 @@ def pose_graph_leg(pkg, synth, distmod, dist, rank, world, local_rank, comm, np,
                 if v.get("SQ_WAVE_CYCLES", 0) > 0:
                     res["roofline"]["wait_frac"] = v.get("SQ_WAIT_ANY", 0.0) / v["SQ_WAVE_CYCLES"]
     pg.close()
+    if world == 1:
+        # Next to the default, never instead of it: the same run as an INEXACT Levenberg-Marquardt (lslam_pg_set_solve_tolerance:
+        # a damped solve stops at relative residual 1e-3 instead of 1e-8).  Another trajectory of iterates -- the reference's
+        # direct solver ("lm_var", solver_g2o.cpp:16) gives LM exact steps, and 1e-8 is indistinguishable from that -- the same
+        # optimum: compared here with the default run's.
+        pgi = pkg.PoseGraph(local_rank)
+        pgi.set_graph(g["init"], g["ij"], g["meas"], g["info"])
+        pgi.build()
+        pgi.set_solve_tolerance(1e-3)
+        t0 = time.perf_counter()
+        it_i = pgi.optimize(lm_iters)
+        dt_i = time.perf_counter() - t0
+        sti = pgi.last_stats
+        esti = pgi.poses()
+        pgi.close()
+        res["inexact_lm"] = {"solve_tolerance": 1e-3, "lm_iters_per_s": it_i / dt_i, "lm_iterations": it_i, "lm_trials": sti.lm_trials,
+                             "solver_iterations": sti.cg_iterations, "seconds": dt_i, "chi2_final": sti.chi2_final,
+                             "chi2_rel_diff_vs_default": abs(sti.chi2_final - st.chi2_final) / st.chi2_final,
+                             "max_position_diff_vs_default_m": float(np.abs(esti[:, :3] - est[:, :3]).max()),
+                             "note": "not the pose_graph value: the default solves every damped system to 1e-8, which is what the reference's direct solver gives LM"}
     if with_cpu and rank == 0:
         # a compiled direct solver beside it: oracle/posegraph_oracle.c -- the same LM with analytic Jacobians and an RCM-ordered
         # envelope block Cholesky, one core (what g2o + CSparse, the reference's solver, do; g2o itself is not available)

@@ -602,6 +602,13 @@ typedef void (*lslam_allgatherv_fn)(void *user, double *buf, const int64_t *offs
 int lslam_pg_set_row_gather(lslam_pg *pg, lslam_allgatherv_fn fn, void *user, int32_t rank, int32_t world);
 int32_t lslam_pg_row_gathered_solves(const lslam_pg *pg); /* ... of which exchanged by all-gather */
 int32_t lslam_pg_num_offdiag(const lslam_pg *pg);
+/* Relative residual |r| / |b| at which a damped solve's PCG stops.  Default 1e-8: to the LM schedule the solves are then what
+ * g2o's direct factorisation ("lm_var", solver_g2o.cpp:16) gives it -- the trajectory of iterates is the oracle's.  A looser
+ * value is an inexact Levenberg-Marquardt: fewer PCG iterations per solve, a different trajectory (accept / reject decisions
+ * move), the same optimum -- on the bench graph 1e-3 ends at the same chi2 to 1e-6 relative and the same keyframe positions
+ * to 1e-4 m in a comparable number of iterations at about twice the rate (tests/test_posegraph_bench_fixture.py; bench.py
+ * reports it next to the default, never instead of it). */
+int lslam_pg_set_solve_tolerance(lslam_pg *pg, double rel_tol);
 /* SolverG2O::optimize (solver_g2o.cpp:79-95): up to max_iters LM iterations. */
 int lslam_pg_optimize(lslam_pg *pg, int32_t max_iters, lslam_pg_stats *stats);
 int lslam_pg_get_poses(lslam_pg *pg, double *poses7);

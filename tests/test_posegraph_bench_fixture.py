@@ -32,12 +32,17 @@ def test_fixture_is_the_bench_graph(pkg, synth, tmp_path):
 
 
 @pytest.mark.gpu
-def test_device_solver_reaches_the_oracle_optimum(pkg, tmp_path):
+@pytest.mark.parametrize("solve_tol", [None, 1e-3])
+def test_device_solver_reaches_the_oracle_optimum(pkg, tmp_path, solve_tol):
+    """solve_tol None: the default (1e-8: the direct solver's answer as far as LM can tell).  1e-3: an inexact LM
+    (lslam_pg_set_solve_tolerance) -- another trajectory, the SAME optimum by the same four criteria."""
     sys.path.insert(0, os.path.join(os.path.dirname(GOLD), "..", "oracle"))
     import posegraph_oracle as po
     z = np.load(os.path.join(GOLD, "posegraph_bench_optimum.npz"))
     pg = pkg.PoseGraph(0)
     g = pg.load(_unzipped(tmp_path))
+    if solve_tol is not None:
+        pg.set_solve_tolerance(solve_tol)
     its = pg.optimize(1000)  # SolverG2O::optimize's limit (solver_g2o.cpp:16,90); the LM stopping rule ends it
     st = pg.last_stats
     est = pg.poses()

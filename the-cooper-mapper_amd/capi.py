@@ -222,6 +222,7 @@ SYMBOLS = {
     "lslam_pg_row_shard_range": (None, [C.c_int32, C.c_int32, C.c_int32, c_int32_p, c_int32_p]),
     "lslam_pg_set_row_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "lslam_pg_row_sharded_solves": (C.c_int32, [C.c_void_p]),
+    "lslam_pg_set_solve_tolerance": (C.c_int, [C.c_void_p, C.c_double]),
     "lslam_pg_row_gathered_solves": (C.c_int32, [C.c_void_p]),
     "lslam_pg_set_row_gather": (C.c_int, [C.c_void_p, ALLGATHERV_FN, C.c_void_p, C.c_int32, C.c_int32]),
     "lslam_pg_num_offdiag": (C.c_int32, [C.c_void_p]),

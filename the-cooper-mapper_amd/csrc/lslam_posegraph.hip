@@ -2380,6 +2380,15 @@ int lslam_pg_set_row_shard(lslam_pg *pg, int32_t v_begin, int32_t v_end) {
   return LSLAM_OK;
 }
 
+int lslam_pg_set_solve_tolerance(lslam_pg *pg, double rel_tol) {
+  if (!pg || !(rel_tol > 0.0) || !(rel_tol < 1.0)) {
+    g_pg_err = "solve tolerance must be in (0, 1)";
+    return LSLAM_ERR_INVALID;
+  }
+  pg->env_tol = rel_tol;
+  return LSLAM_OK;
+}
+
 int32_t lslam_pg_row_sharded_solves(const lslam_pg *pg) { return pg ? pg->rs_solves : 0; }
 int32_t lslam_pg_row_gathered_solves(const lslam_pg *pg) { return pg ? pg->rs_gathered : 0; }
 

@@ -178,6 +178,12 @@ class PoseGraph:
         self._build()
         self._check(self.lib.lslam_pg_set_row_shard(self.h, int(v_begin), int(v_end)))
 
+    def set_solve_tolerance(self, rel_tol):
+        """lslam_pg_set_solve_tolerance: relative residual at which a damped solve's PCG stops (default 1e-8 = the direct
+        solver's answer as far as LM can tell; looser = inexact LM, same optimum, another trajectory)."""
+        self._build()
+        self._check(self.lib.lslam_pg_set_solve_tolerance(self.h, float(rel_tol)))
+
     def row_sharded_solves(self):
         return int(self.lib.lslam_pg_row_sharded_solves(self.h)) if self.h else 0
 

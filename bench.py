@@ -1288,8 +1288,10 @@ def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, 
         switch_interval = sys.getswitchinterval()
         sys.setswitchinterval(5e-5)
         th.start()
+        quiet_gc()
         ov = []
-        for f in range(frames + 2):
+        OV_WARM = 20  # the registration context's first frames allocate its staging, queues and signals (a one-off 8 ms stall within the first dozen frames)
+        for f in range(frames + OV_WARM):
             t0 = time.perf_counter()
             qin.put(1)
             fm.update(gt[3:].astype(np.float32))
@@ -1297,14 +1299,14 @@ def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, 
             dc2, ds2 = qout.get()
             status2, pose2, st2 = ctx.scanmatch_scan(dc2, ds2, init, opts)
             fm.add_feature_cloud(dc2, ds2, T)
-            if f > 1:
+            if f >= OV_WARM:
                 ov.append(time.perf_counter() - t0)
         qin.put(None)
         th.join()
         sys.setswitchinterval(switch_interval)
         ctx_reg.close()
         res["overlapped"] = {"gpu_ms_per_frame": 1e3 * float(np.median(ov)), "gpu_ms_p99": 1e3 * float(np.percentile(ov, 99)),
-                             "gpu_ms_worst_frame": 1e3 * float(max(ov)), "worst_over_median": float(max(ov) / np.median(ov)), "frames": len(ov),
+                             "gpu_ms_worst_frame": 1e3 * float(max(ov)), "worst_over_median": float(max(ov) / np.median(ov)), "frames": len(ov), "slowest_frame_index": int(np.argmax(ov)),
                              "schedule": "registration thread (extract_features + voxel_grid, own context) beside update + "
                                          "surround_to_map; then scan_match, add_feature_cloud -- the reference's nodelet split "
                                          "(MultiScanRegistration | LaserMapping)",

@@ -27,3 +27,15 @@ def test_posegraph_solver_forms_fuzz_twenty_graphs():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "pose-graph fuzz: 20 graphs" in r.stdout
+
+
+@pytest.mark.gpu
+def test_map_maintenance_fuzz_twenty_maps():
+    """tools/fuzz_fmap.py: random cube grids / leaves / walks / clumped clouds through FeatureMap and VoxelGrid, bit for bit
+    against the oracle; both forms of addFeatureCloud's rebuild (new points merged in, everything re-sorted) must occur."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_fmap.py"), "20"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "20 maps, no mismatch" in r.stdout
+    import re
+    m = re.search(r"(\d+) merged, (\d+) re-sorted", r.stdout)
+    assert m and int(m.group(1)) > 0 and int(m.group(2)) > 0

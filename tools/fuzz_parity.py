@@ -90,6 +90,24 @@ for seed in range(n_seeds):
     status, pose, st = ctx.run(init, opts)
     if st.iterations != ost.iterations or abs(st.n_rows - ost.n_rows) > 2 or np.abs(pose[3:] - poses[1][3:]).max() > 2e-5 or np.abs(pose[:3] - poses[1][:3]).max() > 2e-6 or ctx.grid_launches() == g0:  # (a few ulps of a coordinate of tens of metres: the two sweeps group their sums differently)
         bad += 1; print("seed", seed, "grid sweep differs", st.iterations, ost.iterations, st.n_rows, ost.n_rows, np.abs(pose - poses[1]).max())
+    # the same map with its kd-trees deferred (lslam_map_defer_trees: grids only, the wide probe for what the 27-cell probe cannot
+    # prove; both the listed-points form and the in-place A/B form): the same loop up to summation order -- the rounded maps
+    # hold exact ties, for which the call must build the trees after all and still agree
+    for ab in (0, 8):
+        c2 = pkg.Context(0)
+        try:
+            c2.defer_trees(True)
+            c2.map_set(mc, ms)
+            c2.scan_set(pr["corner"], pr["surf"])
+            opts = c2.default_opts()
+            opts.ab_switches = ab
+            status, pose, st = c2.run(init, opts)
+            sets, builds, pending = c2.lazy_trees()
+            deferred = sets == 1  # (a map too small for the guard or too large for the grid is built at once)
+            if st.iterations != ost.iterations or abs(st.n_rows - ost.n_rows) > 2 or np.abs(pose[3:] - poses[1][3:]).max() > 2e-5 or np.abs(pose[:3] - poses[1][:3]).max() > 2e-6 or (deferred and pending and c2.grid_launches() == 0):
+                bad += 1; print("seed", seed, "deferred trees (ab %d) differ" % ab, st.iterations, ost.iterations, st.n_rows, ost.n_rows, np.abs(pose - poses[1]).max(), (sets, builds, pending))
+        finally:
+            c2.close()
     print("seed %2d rings %2d steps %3d half %3.0f map %6d+%6d scan %5d: %s" % (seed, rings, steps, half, len(mc), len(ms), len(pr["corner"]) + len(pr["surf"]), "ok" if not bad else "MISMATCH"), flush=True)
     if bad:
         sys.exit(1)

@@ -1350,6 +1350,9 @@ LSLAM_DEV void wide_probe(const CellGrid &G, const float (&sel)[3], float r2, in
 // distance the probe saw), and the residual chain then runs ONCE for all 64 lanes.  One launch per sweep instead of five, no
 // lists; the workgroup's sums are formed exactly as the lane search's sweep forms them.  Slower all the same (0.84 ms against
 // 0.49 per scan match of a frame): the wavefront's unproven points are probed one after the other, ~15 us each.
+// (Tried for single-scan launches and dropped: the candidate loop row after row with four points in flight instead of the
+// lock-step one-candidate-per-round loop -- same bits, no faster, 27 - 32 us against 23 - 31: a launch of one wavefront per
+// SIMD is a chain of latencies of which the loop is only one.)
 template <int BLOCK, bool WIDE = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 : LSLAM_GRID_OCC))) void sweep_grid_kernel(SweepArgs a, int jtj_mode) {
   constexpr int NWAVE = BLOCK / 64;
@@ -1566,12 +1569,21 @@ LSLAM_DEV void wide_probe(const CellGrid &G, const float (&sel)[3], float r2, in
       const int base = G.nx * (jy + G.ny * jz);
       const uint32_t s0 = G.cell_start[base + xlo], e0 = G.cell_start[base + xhi + 1];
       row_s[k] = s0;
-      for (uint32_t j = s0; j < e0; ++j) {
-        const float dist = dist2_xyz(sel[0], sel[1], sel[2], G.pts[j]);
-        const uint32_t key = (__float_as_uint(dist) & ~GRID_ID_MASK) | (id & GRID_ID_MASK);
-        k5 = umed3(k4, k5, key); k4 = umed3(k3, k4, key); k3 = umed3(k2, k3, key);
-        k2 = umed3(k1, k2, key); k1 = umed3(k0, k1, key); k0 = min(k0, key);
-        ++id;
+      // four points in flight per step: the loads do not depend on one another, only the six-key insert is a chain
+      for (uint32_t j = s0; j < e0; j += 4) {
+        float4 pt[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pt[u] = G.pts[min(j + (uint32_t)u, e0 - 1u)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (j + (uint32_t)u < e0) {
+            const float dist = dist2_xyz(sel[0], sel[1], sel[2], pt[u]);
+            const uint32_t key = (__float_as_uint(dist) & ~GRID_ID_MASK) | (id & GRID_ID_MASK);
+            k5 = umed3(k4, k5, key); k4 = umed3(k3, k4, key); k3 = umed3(k2, k3, key);
+            k2 = umed3(k1, k2, key); k1 = umed3(k0, k1, key); k0 = min(k0, key);
+            ++id;
+          }
+        }
       }
     }
   }

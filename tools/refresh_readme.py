@@ -34,7 +34,7 @@ def main():
         lanes=pick(roof, "counters", "lanes_active"), valu=pick(roof, "valu_issue", "valu_wave_instructions_per_launch"),
         hbm_pct=100.0 * pick(roof, "measured_hbm", "frac"), mf=pick(d, "mapping_frame", "gpu_ms_per_frame"),
         mf_frames=pick(d, "mapping_frame", "frames", default=0), mf_p99=pick(d, "mapping_frame", "gpu_ms_p99"),
-        pg_inexact=pick(d, "pose_graph", "inexact_lm", "lm_iters_per_s"),
+        pg_inexact=pick(d, "pose_graph", "inexact_lm", "lm_iters_per_s"), mf_pipe=pick(d, "mapping_frame", "pipelined", "ms_per_frame"),
         mf16=pick(d, "mapping_frame_vlp16", "gpu_ms_per_frame"), mf_ov=pick(d, "mapping_frame", "overlapped", "gpu_ms_per_frame"),
         mf_cpu=pick(d, "mapping_frame", "cpu_ms_per_frame"), pg=pick(d, "pose_graph", "lm_iters_per_s"), pg_cpu=pick(d, "pose_graph", "cpu_baseline", "value"))
     tpl = open(os.path.join(ROOT, "tools", "readme_template.md")).read()

@@ -468,11 +468,27 @@ void lslam_reg_default_params(lslam_reg_params *p) {
   p->reserved = 0;
 }
 
+static int extract_features_impl(lslam_ctx *ctx, const void *cloud, size_t n_points, size_t stride_bytes,
+                                 size_t intensity_offset_bytes, const int32_t *scan_ranges, size_t n_scans,
+                                 const lslam_reg_params *params, float *sharp, float *less_sharp, float *flat,
+                                 float *less_flat, size_t counts[4], float *curvature_out, int8_t *picked_out,
+                                 int8_t *label_out);
 int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, size_t stride_bytes,
                            size_t intensity_offset_bytes, const int32_t *scan_ranges, size_t n_scans,
                            const lslam_reg_params *params, float *sharp, float *less_sharp, float *flat,
                            float *less_flat, size_t counts[4], float *curvature_out, int8_t *picked_out,
                            int8_t *label_out) {
+  const int rc = extract_features_impl(ctx, cloud, n_points, stride_bytes, intensity_offset_bytes, scan_ranges, n_scans, params, sharp,
+                                       less_sharp, flat, less_flat, counts, curvature_out, picked_out, label_out);
+  // a failure half way leaves copies out of / into the pinned staging in flight: the next call shares it
+  if (rc != LSLAM_OK && ctx && lslam::ctx_alive(ctx)) (void)hipStreamSynchronize((hipStream_t)lslam_stream(ctx));
+  return rc;
+}
+static int extract_features_impl(lslam_ctx *ctx, const void *cloud, size_t n_points, size_t stride_bytes,
+                                 size_t intensity_offset_bytes, const int32_t *scan_ranges, size_t n_scans,
+                                 const lslam_reg_params *params, float *sharp, float *less_sharp, float *flat,
+                                 float *less_flat, size_t counts[4], float *curvature_out, int8_t *picked_out,
+                                 int8_t *label_out) {
   if (!ctx || !lslam::ctx_alive(ctx) || !scan_ranges || !counts || (n_points && !cloud) || stride_bytes < 12 ||
       (stride_bytes & 3) || intensity_offset_bytes + 4 > stride_bytes || n_scans == 0 || n_scans > 4096) {
     lslam::set_error("bad feature-extraction arguments");

@@ -1058,8 +1058,17 @@ int lslam_fmap_update(lslam_fmap *fm, const float pos[3]) {
   return upload_active(fm);
 }
 
+static int add_feature_cloud_impl(lslam_fmap *fm, const void *corner, size_t n_corner, const void *surf, size_t n_surf,
+                                  size_t stride_bytes, const float T[16]);
 int lslam_fmap_add_feature_cloud(lslam_fmap *fm, const void *corner, size_t n_corner, const void *surf,
                                  size_t n_surf, size_t stride_bytes, const float T[16]) {
+  const int rc = add_feature_cloud_impl(fm, corner, n_corner, surf, n_surf, stride_bytes, T);
+  // a failure half way leaves copies out of the pinned staging in flight: nothing may reuse it before they are done
+  if (rc != LSLAM_OK && fm && lslam::ctx_alive(fm->ctx)) (void)hipStreamSynchronize(fm->stream);
+  return rc;
+}
+static int add_feature_cloud_impl(lslam_fmap *fm, const void *corner, size_t n_corner, const void *surf, size_t n_surf,
+                                  size_t stride_bytes, const float T[16]) {
   int rc = check_fm(fm);
   if (rc) return rc;
   if (!T || stride_bytes < 12 || (stride_bytes & 3) || (n_corner && !corner) || (n_surf && !surf)) {
@@ -1610,8 +1619,16 @@ int lslam_fmap_load(lslam_fmap *fm, const char *directory) {
 }
 
 // pcl::VoxelGrid<PointXYZI> with a cubic leaf on one host cloud (LaserMatcher.cpp:289-301)
+static int voxel_grid_impl(lslam_ctx *ctx, const void *cloud, size_t n, size_t stride_bytes, float leaf, float *out_xyzi, size_t cap,
+                           size_t *n_out);
 int lslam_voxel_grid(lslam_ctx *ctx, const void *cloud, size_t n, size_t stride_bytes, float leaf,
                      float *out_xyzi, size_t cap, size_t *n_out) {
+  const int rc = voxel_grid_impl(ctx, cloud, n, stride_bytes, leaf, out_xyzi, cap, n_out);
+  if (rc != LSLAM_OK && ctx && lslam::ctx_alive(ctx)) (void)hipStreamSynchronize((hipStream_t)lslam_stream(ctx));  // (the staging is shared by the next call)
+  return rc;
+}
+static int voxel_grid_impl(lslam_ctx *ctx, const void *cloud, size_t n, size_t stride_bytes, float leaf, float *out_xyzi, size_t cap,
+                           size_t *n_out) {
   if (!ctx || !n_out || !(leaf > 0.f) || stride_bytes < 12 || (stride_bytes & 3) || (n && !cloud)) {
     lslam::set_error("bad voxel-grid arguments");
     return LSLAM_ERR_INVALID;

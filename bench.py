@@ -36,6 +36,7 @@ import argparse
 import importlib
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -1265,6 +1266,20 @@ def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, 
                 "alg_bytes": alg, "achieved": alg / (gpu["surround_to_map"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": alg / (gpu["surround_to_map"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                 "kd_depth_reported": int(max(info_.depth_corner, info_.depth_surf))}
+            # HBM-side traffic of the build's kernels from the committed counter passes (tools/profile_frame.sh: FETCH_SIZE /
+            # WRITE_SIZE per kernel name and launch; two launches of each per frame, one per feature type), not measured in this run
+            pmc = newest_profile("frame_pmc_by_kernel.csv")
+            if pmc:
+                fw = {}
+                for line in open(os.path.join(ROOT, pmc)):
+                    m_ = re.match(r'p\d+,"(grid_(?:bbox|count|scan|scatter|rank)_kernel)",(FETCH_SIZE|WRITE_SIZE),\d+,([0-9.e+]+),', line)
+                    if m_:
+                        fw[(m_.group(1), m_.group(2))] = float(m_.group(3))
+                if fw:
+                    tr = sum((2.0 if c == "FETCH_SIZE" else 1.0) * v for (k, c), v in fw.items()) * 1024.0 * 2.0
+                    res["search_structure_build"]["traffic"] = tr
+                    res["search_structure_build"]["traffic_over_alg_bytes"] = tr / alg
+                    res["search_structure_build"]["traffic_source"] = "%s: sum over grid_bbox / count / scan / scatter / rank of (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, two launches each per frame" % pmc
         else:
             res["tree_build"] = tree_build_roofline(gpu["surround_to_map"], len(sur_c), len(sur_s), np)
         # The same frame the way the reference's nodelets run it: the registration node (feature extraction, the VoxelGrid of

@@ -76,7 +76,12 @@ __global__ __launch_bounds__(256) void grid_scan_kernel(const uint32_t *count, c
   if (lane == 0) wave_before[wave] = pre;
   const uint32_t c0 = base + 16u * (uint32_t)tid;
   uint32_t v[16];
-  if (c0 + 16u <= ncell_plus1 - 1u) {  // (the table has ncell_plus1 - 1 counts)
+  // most 4 096-cell blocks of a map's box are empty (the coarse count says so): their counts are not read at all
+  const bool empty = blockIdx.x < (ncell_plus1 - 1u + CS_CELLS - 1u) / CS_CELLS ? coarse[blockIdx.x] == 0u : true;
+  if (empty) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = 0u;
+  } else if (c0 + 16u <= ncell_plus1 - 1u) {  // (the table has ncell_plus1 - 1 counts)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const uint4 q = reinterpret_cast<const uint4 *>(count + c0)[k];

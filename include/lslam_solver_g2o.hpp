@@ -75,6 +75,10 @@ public:
     if (lslam_pg_save_g2o(_pg, filename.c_str()) < 0) throw std::runtime_error(lslam_pg_last_error());
   }
   const lslam_pg_stats &lastStats() const { return _last; }
+  // No reference counterpart ("lm_var" factorises: its solves are exact).  rel_tol in (0, 1): the relative residual at which a
+  // damped solve's PCG stops from now on; 0 (default) leaves the library's 1e-8.  Looser = an inexact LM: same optimum, another
+  // trajectory of iterates (lslam_pg_set_solve_tolerance, include/lslam_c.h).
+  void setSolveTolerance(double rel_tol) { _solve_tol = rel_tol; if (_pg && rel_tol > 0.0) (void)lslam_pg_set_solve_tolerance(_pg, rel_tol); }
 
   bool is_first;
 
@@ -130,6 +134,7 @@ private:
     if (lslam_pg_create(_device, (int32_t)_vertices.size(), _poses.data(), (int32_t)_edges.size(), _ij.data(), _meas.data(),
                         _info.data(), 0, &_pg) != LSLAM_OK)
       throw std::runtime_error(std::string("lslam_pg_create: ") + lslam_pg_last_error());
+    if (_solve_tol > 0.0) (void)lslam_pg_set_solve_tolerance(_pg, _solve_tol);
   }
   void pull_keep() {  // current estimates into _poses, device graph kept
     if (_pg) lslam_pg_get_poses(_pg, _poses.data());
@@ -144,6 +149,7 @@ private:
   int _device;
   lslam_pg *_pg;
   lslam_pg_stats _last{};
+  double _solve_tol = 0.0;
   std::deque<VertexSE3> _vertices;  // deque: pointers handed out stay valid
   std::deque<EdgeSE3> _edges;
   std::vector<double> _poses, _meas, _info;

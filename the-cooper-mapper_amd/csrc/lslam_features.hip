@@ -259,6 +259,7 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
         if (a.curv_out) a.curv_out[start + i] = c;
       }
       __syncthreads();
+      FX_T(5)
       for (int t = tid; t < n_need; t += FX_BLOCK) {
         const int i = need[t];
         cls_ring[i] = (int8_t)fx_point_classify(sx, sy, sz, i, a);

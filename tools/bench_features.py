@@ -28,5 +28,5 @@ if os.environ.get("FX_CLOCKS"):  # -DLSLAM_FX_CLOCKS build
     clk = (C.c_double * 8)()
     ctx.lib.lslam_debug_fx_clocks.argtypes = [C.c_double * 8]
     ctx.lib.lslam_debug_fx_clocks(clk)
-    tot = sum(clk[:5])
-    print("fx_ring_kernel, share of thread 0's time: marks %.2f, curvature %.2f, rank sort + classify %.2f, flat picks %.2f, compactions %.2f" % tuple(c / tot for c in clk[:5]))
+    tot = sum(clk[:6])
+    print("fx_ring_kernel, share of thread 0's time: marks %.2f, curvature %.2f, classify %.2f, flat picks %.2f, compactions %.2f, rank sort %.2f" % tuple(c / tot for c in clk[:6]))

@@ -831,14 +831,33 @@ int pack_input(hipStream_t s, Pin<float4> &pin, Buf<float4> &dst, const void *sr
       h[i] = make_float4(v[0], v[1], v[2], w);
     }
   }
-  if (mn && mx)
-    for (size_t i = 0; i < n; ++i) {
-      const float v[3] = {h[i].x, h[i].y, h[i].z};
-      for (int d = 0; d < 3; ++d) {
-        mn[d] = v[d] < mn[d] ? v[d] : mn[d];
-        mx[d] = v[d] > mx[d] ? v[d] : mx[d];
+  if (mn && mx) {
+    // four independent accumulators of four lanes each (the fourth lane, the intensity, rides along unused): the same
+    // compare-and-keep per component as a scalar loop (a NaN never replaces an extreme), at the vector units' rate
+    float lo[4][4], hi[4][4];
+    for (int a = 0; a < 4; ++a)
+      for (int d = 0; d < 4; ++d) { lo[a][d] = INFINITY; hi[a][d] = -INFINITY; }
+    const float *f = reinterpret_cast<const float *>(h);
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4)
+      for (int a = 0; a < 4; ++a)
+        for (int d = 0; d < 4; ++d) {
+          const float v = f[4 * (i + a) + d];
+          lo[a][d] = v < lo[a][d] ? v : lo[a][d];
+          hi[a][d] = v > hi[a][d] ? v : hi[a][d];
+        }
+    for (; i < n; ++i)
+      for (int d = 0; d < 4; ++d) {
+        const float v = f[4 * i + d];
+        lo[0][d] = v < lo[0][d] ? v : lo[0][d];
+        hi[0][d] = v > hi[0][d] ? v : hi[0][d];
       }
-    }
+    for (int d = 0; d < 3; ++d)
+      for (int a = 0; a < 4; ++a) {
+        mn[d] = lo[a][d] < mn[d] ? lo[a][d] : mn[d];
+        mx[d] = hi[a][d] > mx[d] ? hi[a][d] : mx[d];
+      }
+  }
   FM_TRY(hipMemcpyAsync(dst.p, h, n * sizeof(float4), hipMemcpyHostToDevice, s));
   return LSLAM_OK;
 }

@@ -160,10 +160,10 @@ class FeatureMap:
 def voxel_grid(ctx, cloud, leaf):
     """pcl::VoxelGrid<PointXYZI> with a cubic leaf (lslam_voxel_grid) -> (m, 4) centroids."""
     a = _xyzi(cloud)
-    out = np.zeros((len(a), 4), np.float32)
+    out = ctx.scratch("voxel_grid", len(a), 4)
     n = C.c_size_t()
     rc = ctx.lib.lslam_voxel_grid(ctx.h, a.ctypes.data_as(C.c_void_p), len(a), a.shape[1] * 4, float(leaf),
-                                  _fp(out), len(out), C.byref(n))
+                                  _fp(out), len(a), C.byref(n))
     if rc < 0:
         raise LslamError(rc, ctx.lib.lslam_last_error().decode())
     return out[:n.value].copy()

@@ -138,6 +138,17 @@ class Context:
         """lslam_debug_grid_wide_launches: ... of which in the single-launch form of a map without trees."""
         return int(self.lib.lslam_debug_grid_wide_launches(self.h))
 
+    def scratch(self, name, rows, cols, dtype=np.float32):
+        """A host array of at least (rows, cols) kept with the context under `name` (grown by a quarter when it is too small):
+        the output staging of calls whose result size is only known afterwards.  Allocating and freeing megabytes per call
+        is an mmap / munmap pair each -- tens of microseconds, and now and then milliseconds, of a frame."""
+        bufs = self.__dict__.setdefault("_scratch", {})
+        a = bufs.get(name)
+        if a is None or a.shape[0] < rows or a.shape[1] != cols or a.dtype != np.dtype(dtype):
+            a = np.empty((max(1, rows + rows // 4), cols), dtype)
+            bufs[name] = a
+        return a
+
     def grid_cells(self):
         """lslam_debug_grid_cells: (cells of the corner table, cells of the surf table) of the resident map's cell grids."""
         out = (C.c_uint64 * 2)()

@@ -24,7 +24,7 @@ def extract_features(ctx, cloud, scan_ranges, params=None, intensity_field=3, ta
         raise ValueError("cloud must be (n, >=4) float32")
     r = np.ascontiguousarray(scan_ranges, dtype=np.int32).reshape(-1, 2)
     n = len(a)
-    outs = [np.zeros((n, 4), np.float32) for _ in range(4)]
+    outs = [ctx.scratch("features%d" % k, n, 4) for k in range(4)]
     counts = (C.c_size_t * 4)()
     curv = np.zeros(n, np.float32) if taps else None
     picked = np.zeros(n, np.int8) if taps else None
@@ -48,12 +48,12 @@ def multiscan_register(ctx, cloud, lower_deg, upper_deg, n_rings, scan_period=0.
     """MultiScanRegistration::process (no IMU): raw driver cloud (n, >=3) -> (ring-sorted (m, 4)
     {x', y', z', ring + relTime}, ranges (n_rings, 2)) -- the inputs of :func:`extract_features`."""
     a = np.ascontiguousarray(cloud, dtype=np.float32)
-    out = np.zeros((len(a), 4), np.float32)
+    out = ctx.scratch("multiscan", len(a), 4)
     ranges = np.zeros((int(n_rings), 2), np.int32)
     n = C.c_size_t()
     rc = ctx.lib.lslam_multiscan_register(ctx.h, a.ctypes.data_as(C.c_void_p), len(a), a.shape[1] * 4,
                                           float(lower_deg), float(upper_deg), int(n_rings), float(scan_period),
-                                          out.ctypes.data_as(c_float_p), len(out), C.byref(n),
+                                          out.ctypes.data_as(c_float_p), len(a), C.byref(n),
                                           ranges.ctypes.data_as(c_int32_p))
     if rc < 0:
         raise LslamError(rc, ctx.lib.lslam_last_error().decode())

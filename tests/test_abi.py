@@ -47,6 +47,23 @@ def test_default_opts_are_the_reference_defaults(pkg):
     assert o.score_threshold == 800 and o.match_percentage_threshold == 0.4
 
 
+def test_default_opts_write_every_byte(pkg):
+    """A C / C++ caller's lslam_opts lives on its stack: lslam_default_opts must leave no byte of it as it found it (a field it
+    forgot -- ab_switches, once -- made callers run whichever A/B variants their stack happened to spell).  Filled with two
+    different garbage patterns, the struct comes back identical, the switches and debug fields zero."""
+    lib = pkg.load_library()
+    size = C.sizeof(pkg.LslamOpts)
+    images = []
+    for fill in (0xFF, 0x5A):
+        o = pkg.LslamOpts()
+        C.memset(C.byref(o), fill, size)
+        lib.lslam_default_opts(C.byref(o))
+        assert (o.ab_switches, o.debug_stats, o.search_mode, o.scans_in_flight, o.profile) == (0, 0, 0, 0, 0)
+        assert o.knn_cert == 1 and o.grid_cell == 0.0 and o.jtj_mode == 1
+        images.append(bytes(C.string_at(C.byref(o), size)))
+    assert images[0] == images[1]
+
+
 def test_isometry_twist_roundtrip(pkg, oracle):
     lib = pkg.load_library()
     rng = np.random.default_rng(0)

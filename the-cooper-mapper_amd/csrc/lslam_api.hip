@@ -547,6 +547,9 @@ const char *lslam_last_error(void) { return g_err.c_str(); }
 
 void lslam_default_opts(lslam_opts *o) {
   if (!o) return;
+  // EVERY byte: a caller's struct on the stack is garbage until this call, and a field this function forgot (debug_stats and
+  // ab_switches were, for half a round: C++ callers ran whichever A/B variants their stack happened to spell) must read 0
+  std::memset(o, 0, sizeof(*o));
   o->max_iterations = 10;  // ScanMatch.h:36
   o->delta_t_abort = 0.05f;
   o->delta_r_abort = 0.05f;  // ScanMatch.cpp:22
@@ -562,6 +565,8 @@ void lslam_default_opts(lslam_opts *o) {
   o->cert_try_m = CERT_TRY_M_DEFAULT;
   o->cert_track_m = CERT_TRACK_M_DEFAULT;
   o->grid_cell = 0.0f;  // GRID_CELL_DEFAULT
+  o->debug_stats = 0;
+  o->ab_switches = 0;
 }
 
 int lslam_ctx_create(int device, lslam_ctx **out) {

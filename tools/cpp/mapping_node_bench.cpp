@@ -48,10 +48,31 @@ int main(int argc, char **argv) {
     std::fprintf(stderr, "map set-up failed: %s\n", lslam_last_error());
     return 1;
   }
+  auto map_sums = [&](int k) {
+    size_t nc = 0, ns = 0;
+    lslam_fmap_surround_counts(mapping.featureMap(), &nc, &ns);
+    std::vector<float> c4(4 * nc + 4), s4(4 * ns + 4);
+    lslam_fmap_get_surround(mapping.featureMap(), c4.data(), nc, s4.data(), ns);
+    auto sums = [](const std::vector<float> &v, size_t n, unsigned long long &ordered, unsigned long long &free_) {
+      ordered = free_ = 0;
+      for (size_t i = 0; i < 4 * n; ++i) {
+        uint32_t b;
+        std::memcpy(&b, &v[i], 4);
+        ordered += (unsigned long long)b * (unsigned long long)(i + 1);
+        free_ += (unsigned long long)b * (unsigned long long)((i & 3) + 1);
+      }
+    };
+    unsigned long long oc, fc, os, fs;
+    sums(c4, nc, oc, fc);
+    sums(s4, ns, os, fs);
+    std::printf("MAP %d corner %zu ordered %llx free %llx | surf %zu ordered %llx free %llx\n", k, nc, oc, fc, ns, os, fs);
+  };
+  if (argc > 3 && !std::strcmp(argv[3], "trace")) map_sums(-1);
   // odometry inputs alternate between T and T * delta: every frame starts a perturbation away from where the last one ended
   const float *A = pose.data(), *B = pose.data() + 16;
   std::vector<double> ms;
   int iters = 0;
+  long sum_iters = 0, sum_sweeps = 0, sum_rows = 0;
   for (int k = 0; k < frames + 20; ++k) {
     const auto t0 = std::chrono::steady_clock::now();
     if (!mapping.process(less_sharp, less_flat, (k & 1) ? B : A)) {
@@ -61,13 +82,46 @@ int main(int argc, char **argv) {
     const auto t1 = std::chrono::steady_clock::now();
     if (k >= 20) ms.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
     iters = mapping.lastStats().iterations;
+    sum_iters += mapping.lastStats().iterations;
+    sum_sweeps += mapping.lastStats().sweeps;
+    sum_rows += mapping.lastStats().n_rows;
+    if (argc > 3 && !std::strcmp(argv[3], "trace") && k < 3) {
+      {  // the frame's inputs to the map insert: the VoxelGrid of the two clouds (recomputed here) and the whole pose
+        std::vector<float> o1(less_sharp.size() + 4), o2(less_flat.size() + 4);
+        size_t n1 = 0, n2 = 0;
+        lslam_voxel_grid(sm.context(), less_sharp.data(), less_sharp.size() / 4, 16, 1.0f, o1.data(), less_sharp.size() / 4, &n1);
+        lslam_voxel_grid(sm.context(), less_flat.data(), less_flat.size() / 4, 16, 1.0f, o2.data(), less_flat.size() / 4, &n2);
+        unsigned long long h1 = 0, h2 = 0, hp = 0;
+        for (size_t i = 0; i < 4 * n1; ++i) { uint32_t b; std::memcpy(&b, &o1[i], 4); h1 += (unsigned long long)b * (i + 1); }
+        for (size_t i = 0; i < 4 * n2; ++i) { uint32_t b; std::memcpy(&b, &o2[i], 4); h2 += (unsigned long long)b * (i + 1); }
+        const float *Tk = mapping.lidarMapped();
+        for (int i = 0; i < 16; ++i) { uint32_t b; std::memcpy(&b, &Tk[i], 4); hp += (unsigned long long)b * (i + 1); }
+        std::printf("INPUTS %d voxel(less sharp) %zu %llx voxel(less flat) %zu %llx pose16 %llx\n", k, n1, h1, n2, h2, hp);
+      }
+      map_sums(k);
+      int64_t mg = 0, rs = 0;
+      lslam_fmap_rebuild_stats(mapping.featureMap(), &mg, &rs);
+      std::printf("REBUILDS %d merged %lld resorted %lld\n", k, (long long)mg, (long long)rs);
+    }
+    if (argc > 3 && !std::strcmp(argv[3], "trace") && k < 60) {
+      const float *Tk = mapping.lidarMapped();
+      std::printf("TRACE %d it %d rows %d line %d plane %d pose %a %a %a\n", k, mapping.lastStats().iterations, mapping.lastStats().n_rows,
+                  mapping.lastStats().n_line, mapping.lastStats().n_plane, (double)Tk[3], (double)Tk[7], (double)Tk[11]);
+    }
   }
   {
     uint64_t lz[3] = {0, 0, 0};
     lslam_debug_lazy_trees(sm.context(), lz);
-    std::printf("  after the process() loop: maps set without trees %llu, trees built after all %llu\n", (unsigned long long)lz[0], (unsigned long long)lz[1]);
+    uint64_t cs[3] = {0, 0, 0};
+    lslam_debug_cert_stats(sm.context(), cs);
+    std::printf("  points left to the second pass %llu of %llu swept (LSLAM_DEBUG_CERT_STATS=1)\n", (unsigned long long)cs[0], (unsigned long long)cs[1]);
+    uint64_t sv[8] = {0};
+    lslam_debug_sweep_launches(sm.context(), sv);
+    std::printf("  after the process() loop: maps set without trees %llu, trees built after all %llu; GN iterations %ld, sweeps %ld, rows %ld; grid launches %llu, tree-sweep launches %llu %llu %llu\n",
+                (unsigned long long)lz[0], (unsigned long long)lz[1], sum_iters, sum_sweeps, sum_rows, (unsigned long long)lslam_debug_grid_launches(sm.context()),
+                (unsigned long long)sv[0], (unsigned long long)sv[1], (unsigned long long)sv[2]);
   }
-  if (argc > 3) {  // the same frame with a clock between the calls (argv[3] present): LaserMapping::process's body, step by step
+  if (argc > 3 && !std::strcmp(argv[3], "steps")) {  // the same frame with a clock between the calls (argv[3] present): LaserMapping::process's body, step by step
     std::vector<float> dc(less_sharp.size() + 4), ds(less_flat.size() + 4);
     double acc[7] = {0, 0, 0, 0, 0, 0, 0};
     auto now = [] { return std::chrono::steady_clock::now(); };

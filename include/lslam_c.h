@@ -167,8 +167,16 @@ int lslam_ctx_create(int device, lslam_ctx **out);
 void lslam_ctx_destroy(lslam_ctx *ctx);
 /* Last error text for this thread ("" if none). */
 const char *lslam_last_error(void);
-/* Fills opts with the reference defaults (ScanMatch.cpp:21-33). */
+/* Fills opts with the reference defaults (ScanMatch.cpp:21-33) -- EVERY byte of the struct: call it before setting fields. */
 void lslam_default_opts(lslam_opts *opts);
+/* The structs of this ABI grow from release to release (lslam_opts: 72 -> 80 bytes in round 4).  A caller compiled against
+ * another header would hand the library a struct of the wrong size: compare before the first call --
+ *   assert(lslam_abi_version() == LSLAM_ABI_VERSION && lslam_sizeof_opts() == sizeof(lslam_opts));
+ * (the C++ mirrors do, and refuse to start otherwise). */
+#define LSLAM_ABI_VERSION 4
+int lslam_abi_version(void);
+size_t lslam_sizeof_opts(void);
+size_t lslam_sizeof_stats(void);
 
 /* ---- map (reference clouds) -------------------------------------------- */
 

@@ -46,7 +46,9 @@ public:
       : _ctx(nullptr), _total_score(0), _match_count(0), _fail_match_count(0) {
     lslam_default_opts(&_opts);
     _opts.max_iterations = (int32_t)maxIterations;
-    if (lslam_ctx_create(device, &_ctx) != LSLAM_OK) {
+    if (lslam_abi_version() != LSLAM_ABI_VERSION || lslam_sizeof_opts() != sizeof(lslam_opts) || lslam_sizeof_stats() != sizeof(lslam_stats)) {
+      _init_error = "liblslam_hip was built from another include/lslam_c.h than this program (ABI version / struct sizes differ)";
+    } else if (lslam_ctx_create(device, &_ctx) != LSLAM_OK) {
       _ctx = nullptr;
       _init_error = lslam_last_error();
     } else {

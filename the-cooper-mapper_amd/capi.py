@@ -133,6 +133,9 @@ SYMBOLS = {
     "lslam_ctx_destroy": (None, [C.c_void_p]),
     "lslam_last_error": (C.c_char_p, []),
     "lslam_default_opts": (None, [C.POINTER(LslamOpts)]),
+    "lslam_abi_version": (C.c_int, []),
+    "lslam_sizeof_opts": (C.c_size_t, []),
+    "lslam_sizeof_stats": (C.c_size_t, []),
     "lslam_map_set": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t]),
     "lslam_map_info_get": (C.c_int, [C.c_void_p, C.POINTER(LslamMapInfo)]),
     "lslam_cubemap_set": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
@@ -303,5 +306,9 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    # the ctypes mirrors of the ABI's structs must be the library's: a stale .so (or a stale mirror) fails here, loudly
+    if lib.lslam_sizeof_opts() != C.sizeof(LslamOpts) or lib.lslam_sizeof_stats() != C.sizeof(LslamStats):
+        raise ImportError("%s does not match this package's struct layouts (lslam_opts %d vs %d bytes, lslam_stats %d vs %d): rebuild it"
+                          % (path, lib.lslam_sizeof_opts(), C.sizeof(LslamOpts), lib.lslam_sizeof_stats(), C.sizeof(LslamStats)))
     _lib = lib
     return lib

@@ -545,6 +545,10 @@ extern "C" {
 
 const char *lslam_last_error(void) { return g_err.c_str(); }
 
+int lslam_abi_version(void) { return LSLAM_ABI_VERSION; }
+size_t lslam_sizeof_opts(void) { return sizeof(lslam_opts); }
+size_t lslam_sizeof_stats(void) { return sizeof(lslam_stats); }
+
 void lslam_default_opts(lslam_opts *o) {
   if (!o) return;
   // EVERY byte: a caller's struct on the stack is garbage until this call, and a field this function forgot (debug_stats and

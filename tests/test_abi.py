@@ -216,6 +216,11 @@ def test_cpp_pipeline_equals_python_mirrors(pkg, tmp_path):
     ctx.close()
     out = subprocess.run([str(exe), str(path)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
+    # the same program again, twice: a C++ process's results must not depend on what its stack held (lslam_default_opts once
+    # left two fields of lslam_opts unwritten -- processes then differed in the poses' last bits and in speed)
+    for _ in range(2):
+        again = subprocess.run([str(exe), str(path)], capture_output=True, text=True, timeout=300)
+        assert again.returncode == 0 and again.stdout == out.stdout
     got = {}
     for line in out.stdout.splitlines():
         if line.startswith("POSE "):

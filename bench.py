@@ -1214,7 +1214,7 @@ def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, 
         t0 = time.perf_counter()
         feat = pkg.scan_registration.extract_features(ctx, cloud, ranges)
         t1 = time.perf_counter()
-        dc, ds = pkg.voxel_grid(ctx, feat["less_sharp"], 1.0), pkg.voxel_grid(ctx, feat["less_flat"], 1.0)
+        dc, ds = pkg.voxel_grid2(ctx, feat["less_sharp"], feat["less_flat"], 1.0)  # as LaserMapping.process does (equal leaves: one pass)
         t2 = time.perf_counter()
         fm.update(gt[3:].astype(np.float32))
         t3 = time.perf_counter()
@@ -1297,7 +1297,7 @@ def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, 
                 if job is None:
                     return
                 f_ = pkg.scan_registration.extract_features(ctx_reg, cloud, ranges)
-                qout.put((pkg.voxel_grid(ctx_reg, f_["less_sharp"], 1.0), pkg.voxel_grid(ctx_reg, f_["less_flat"], 1.0)))
+                qout.put(pkg.voxel_grid2(ctx_reg, f_["less_sharp"], f_["less_flat"], 1.0))
         th = threading.Thread(target=registration, daemon=True)
         # two Python threads share the interpreter lock; its default hand-over interval is 5 ms -- longer than two frames.  (A C++
         # host has no such lock; the library calls themselves run without it.)

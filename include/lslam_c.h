@@ -401,6 +401,11 @@ int lslam_fmap_info(lslam_fmap *fm, int32_t origin[3], int32_t *n_valid, int32_t
  * ascending voxel index.  Points of a voxel are summed in input order (PCL: unspecified). */
 int lslam_voxel_grid(lslam_ctx *ctx, const void *cloud, size_t n, size_t stride_bytes, float leaf,
                      float *out_xyzi, size_t cap, size_t *n_out);
+/* Two clouds with the same leaf in one pass -- prepareFeatureFrame's corner and surface clouds (LaserMatcher.cpp:289-301, two
+ * VoxelGrid objects there): each cloud is filtered on its own (own min_b, own "leaf too small" guard), one upload, one wait,
+ * one download instead of two of each.  Bit for bit what two lslam_voxel_grid calls give. */
+int lslam_voxel_grid2(lslam_ctx *ctx, const void *cloud_a, size_t n_a, const void *cloud_b, size_t n_b, size_t stride_bytes,
+                      float leaf, float *out_a_xyzi, size_t cap_a, size_t *n_out_a, float *out_b_xyzi, size_t cap_b, size_t *n_out_b);
 
 /* ---- feature extraction front end ------------------------------
  * Replaces ScanRegistration::extractFeatures (odometry/ScanRegistration.cpp:190-425, with

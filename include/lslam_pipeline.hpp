@@ -163,7 +163,18 @@ public:
     // transformMerge, :333-340
     lslam_transform_associate(_lidarOdomLast, lidarOdomNew, _lidarMappedLast, _lidarMappedNew);
     // prepareFeatureFrame, :289-301
-    if (!downsize(cornerLast, _filterCorner, _cornerDS) || !downsize(surfLast, _filterSurf, _surfDS)) return fail();
+    if (_filterCorner == _filterSurf) {  // the reference's defaults: both clouds in one pass (lslam_voxel_grid2: same bits)
+      _cornerDS.resize(cornerLast.size() + 4);
+      _surfDS.resize(surfLast.size() + 4);
+      size_t nc2 = 0, ns2 = 0;
+      if (lslam_voxel_grid2(_ctx, cornerLast.data(), cornerLast.size() / 4, surfLast.data(), surfLast.size() / 4, 16, _filterCorner,
+                            _cornerDS.data(), cornerLast.size() / 4, &nc2, _surfDS.data(), surfLast.size() / 4, &ns2) < 0)
+        return fail();
+      _cornerDS.resize(4 * nc2);
+      _surfDS.resize(4 * ns2);
+    } else if (!downsize(cornerLast, _filterCorner, _cornerDS) || !downsize(surfLast, _filterSurf, _surfDS)) {
+      return fail();
+    }
     // prepareFeatureSurround, :303-325
     const float pos[3] = {_lidarMappedNew[3], _lidarMappedNew[7], _lidarMappedNew[11]};
     if (lslam_fmap_update(_fm, pos) < 0) return fail();

@@ -43,6 +43,36 @@ def test_voxel_grid_layouts_and_edges(pkg, ctx, oracle):
     # a real scan at the reference's default leaf (LaserMatcher.cpp:80-85)
 
 
+def test_voxel_grid_of_two_clouds_in_one_pass(pkg, ctx, oracle):
+    """lslam_voxel_grid2 (prepareFeatureFrame's two VoxelGrids as two segments of one pipeline run): bit for bit what two
+    lslam_voxel_grid calls and the oracle give -- clouds of very different extents (each keeps its own min_b), an empty cloud
+    on either side, the PointXYZI layout, and a cloud that trips PCL's "leaf too small" guard next to one that does not."""
+    rng = np.random.default_rng(21)
+    a = rng.uniform(-40, 40, (3000, 4)).astype(np.float32)
+    b = (rng.uniform(-3, 3, (25000, 4)) + np.array([100.0, -50.0, 2.0, 0.0])).astype(np.float32)
+    a[:, 3] = rng.uniform(0, 16, len(a))
+    b[:, 3] = rng.uniform(0, 64, len(b))
+    for leaf in (1.0, 0.2):
+        ga, gb = pkg.voxel_grid2(ctx, a, b, leaf)
+        assert np.array_equal(bits(ga), bits(pkg.voxel_grid(ctx, a, leaf))) and np.array_equal(bits(gb), bits(pkg.voxel_grid(ctx, b, leaf)))
+        assert np.array_equal(bits(ga), bits(oracle.voxel_grid(a, leaf))) and np.array_equal(bits(gb), bits(oracle.voxel_grid(b, leaf)))
+    empty = np.zeros((0, 4), np.float32)
+    ga, gb = pkg.voxel_grid2(ctx, empty, b, 0.5)
+    assert len(ga) == 0 and np.array_equal(bits(gb), bits(oracle.voxel_grid(b, 0.5)))
+    ga, gb = pkg.voxel_grid2(ctx, a, empty, 0.5)
+    assert len(gb) == 0 and np.array_equal(bits(ga), bits(oracle.voxel_grid(a, 0.5)))
+    assert all(len(x) == 0 for x in pkg.voxel_grid2(ctx, empty, empty, 0.5))
+    x32 = np.zeros((len(a), 8), np.float32)
+    x32[:, :3], x32[:, 4] = a[:, :3], a[:, 3]
+    y32 = np.zeros((len(b), 8), np.float32)
+    y32[:, :3], y32[:, 4] = b[:, :3], b[:, 3]
+    ga, gb = pkg.voxel_grid2(ctx, x32, y32, 0.8)
+    assert np.array_equal(bits(ga), bits(oracle.voxel_grid(a, 0.8))) and np.array_equal(bits(gb), bits(oracle.voxel_grid(b, 0.8)))
+    far = np.array([[0, 0, 0, 1], [5000, 5000, 5000, 2], [1, 1, 1, 3]], np.float32)  # more voxels than INT_MAX: returned as it is
+    ga, gb = pkg.voxel_grid2(ctx, far, a, 0.01)
+    assert np.array_equal(ga, far) and np.array_equal(bits(gb), bits(oracle.voxel_grid(a, 0.01)))
+
+
 def _compare_maps(fm, ofm, tag):
     gi, oi = fm.info(), ofm.info()
     assert list(gi["origin"]) == list(oi["origin"]), tag

@@ -15,11 +15,11 @@ from .capi import (LslamError, LslamOpts, LslamStats, LslamMapInfo, LslamStereoC
                    build_library)
 from .scan_match import Comm, Context, ScanMatch
 from .pose_graph import PoseGraph
-from .feature_map import FeatureMap, voxel_grid
+from .feature_map import FeatureMap, voxel_grid, voxel_grid2
 from . import scan_registration
 from .loop_closure import KeyFrame, Loop, LoopDetector
 from .graph import Graph, KeyframeUpdater
 from .pipeline import LaserOdometry, LaserMapping
 
-__all__ = ["Comm", "Context", "ScanMatch", "PoseGraph", "FeatureMap", "voxel_grid", "scan_registration", "KeyFrame", "Loop", "LoopDetector", "Graph", "KeyframeUpdater", "LaserOdometry", "LaserMapping", "LslamError", "LslamOpts", "LslamStats", "LslamMapInfo", "LslamStereoCam",
+__all__ = ["Comm", "Context", "ScanMatch", "PoseGraph", "FeatureMap", "voxel_grid", "voxel_grid2", "scan_registration", "KeyFrame", "Loop", "LoopDetector", "Graph", "KeyframeUpdater", "LaserOdometry", "LaserMapping", "LslamError", "LslamOpts", "LslamStats", "LslamMapInfo", "LslamStereoCam",
            "Status", "lib_path", "load_library", "build_library"]

@@ -209,6 +209,8 @@ SYMBOLS = {
                                   C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "lslam_voxel_grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float, c_float_p,
                                    C.c_size_t, C.POINTER(C.c_size_t)]),
+    "lslam_voxel_grid2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float, c_float_p,
+                                    C.c_size_t, C.POINTER(C.c_size_t), c_float_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "lslam_reg_default_params": (None, [C.POINTER(LslamRegParams)]),
     "lslam_extract_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, c_int32_p,
                                          C.c_size_t, C.POINTER(LslamRegParams), c_float_p, c_float_p, c_float_p,

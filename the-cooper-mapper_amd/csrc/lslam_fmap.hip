@@ -1737,4 +1737,94 @@ static int voxel_grid_impl(lslam_ctx *ctx, const void *cloud, size_t n, size_t s
   return LSLAM_OK;
 }
 
+// Two clouds through pcl::VoxelGrid with the same leaf in ONE pass (LaserMatcher.cpp:289-301 filters the frame's corner and
+// surface clouds one after the other): the clouds are two segments of one pipeline run -- each with its own min_b and its own
+// "leaf too small" guard, as two VoxelGrid objects would have -- one upload, one wait, one download.  Same bits as two
+// lslam_voxel_grid calls (tests/test_gpu_fmap.py).
+static int voxel_grid2_impl(lslam_ctx *ctx, const void *a, size_t na, const void *b, size_t nb, size_t stride_bytes, float leaf,
+                            float *out_a, size_t cap_a, size_t *n_a, float *out_b, size_t cap_b, size_t *n_b) {
+  if (!ctx || !n_a || !n_b || !(leaf > 0.f) || stride_bytes < 12 || (stride_bytes & 3) || (na && !a) || (nb && !b)) {
+    lslam::set_error("bad voxel-grid arguments");
+    return LSLAM_ERR_INVALID;
+  }
+  *n_a = *n_b = 0;
+  const size_t n = na + nb;
+  if (n == 0) return LSLAM_OK;
+  FM_TRY(hipSetDevice(lslam::ctx_device(ctx)));
+  hipStream_t s = (hipStream_t)lslam_stream(ctx);
+  struct Cache {
+    Pin<float4> in_pin, out_pin;
+    Pin<int32_t> seg_pin;
+    Pin<uint32_t> done;
+    Buf<float4> in_raw, out;
+    Buf<int32_t> seg, oseg;
+  };
+  static std::map<int, Cache> caches;  // per device
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  Cache &c = caches[lslam::ctx_device(ctx)];
+  FM_TRY(c.in_pin.reserve(n));
+  FM_TRY(c.out_pin.reserve(n));
+  FM_TRY(c.seg_pin.reserve(n));
+  FM_TRY(c.done.reserve(4));
+  FM_TRY(c.in_raw.reserve(n));
+  FM_TRY(c.out.reserve(n));
+  FM_TRY(c.seg.reserve(n));
+  FM_TRY(c.oseg.reserve(n));
+  const void *src[2] = {a, b};
+  const size_t cnt[2] = {na, nb};
+  size_t at = 0;
+  for (int k = 0; k < 2; ++k) {
+    const char *p = static_cast<const char *>(src[k]);
+    float4 *h = c.in_pin.p + at;
+    if (stride_bytes == 16) {
+      if (cnt[k]) std::memcpy(h, p, cnt[k] * sizeof(float4));
+    } else {
+      const size_t ioff = 16;  // pcl::PointXYZI keeps the intensity at byte 16
+      for (size_t i = 0; i < cnt[k]; ++i) {
+        float v[3], w = 0.0f;
+        std::memcpy(v, p + i * stride_bytes, 12);
+        if (stride_bytes >= ioff + 4) std::memcpy(&w, p + i * stride_bytes + ioff, 4);
+        h[i] = make_float4(v[0], v[1], v[2], w);
+      }
+    }
+    at += cnt[k];
+  }
+  FM_TRY(hipMemcpyAsync(c.in_raw.p, c.in_pin.p, n * sizeof(float4), hipMemcpyHostToDevice, s));
+  if (na) FM_TRY(hipMemsetAsync(c.seg.p, 0, na * sizeof(int32_t), s));
+  if (nb) FM_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c.seg.p + na), 1, nb, s));
+  size_t m = 0;
+  int rc = lslam::voxel_filter_segments(s, c.in_raw.p, c.seg.p, n, 2, leaf, c.out.p, c.oseg.p, &m, true, c.done.p);
+  if (rc) return rc;
+  FM_TRY(hipMemcpyAsync(c.out_pin.p, c.out.p, n * sizeof(float4), hipMemcpyDeviceToHost, s));
+  FM_TRY(hipMemcpyAsync(c.seg_pin.p, c.oseg.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  FM_TRY(hipStreamSynchronize(s));
+  if (c.done.p[1]) {  // the wide key did not hold an extent: once more with the measured one (waits inside)
+    rc = lslam::voxel_filter_segments(s, c.in_raw.p, c.seg.p, n, 2, leaf, c.out.p, c.oseg.p, &m, true, nullptr);
+    if (rc) return rc;
+    FM_TRY(hipMemcpyAsync(c.out_pin.p, c.out.p, m * sizeof(float4), hipMemcpyDeviceToHost, s));
+    FM_TRY(hipMemcpyAsync(c.seg_pin.p, c.oseg.p, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    FM_TRY(hipStreamSynchronize(s));
+  } else {
+    m = c.done.p[0];
+  }
+  size_t split = 0;  // the output is grouped by segment: the first cloud's points come first
+  while (split < m && c.seg_pin.p[split] == 0) ++split;
+  if (split > cap_a || m - split > cap_b) {
+    lslam::set_error("voxel-grid output buffer too small");
+    return LSLAM_ERR_INVALID;
+  }
+  if (out_a && split) std::memcpy(out_a, c.out_pin.p, split * sizeof(float4));
+  if (out_b && m - split) std::memcpy(out_b, c.out_pin.p + split, (m - split) * sizeof(float4));
+  *n_a = split;
+  *n_b = m - split;
+  return LSLAM_OK;
+}
+int lslam_voxel_grid2(lslam_ctx *ctx, const void *a, size_t na, const void *b, size_t nb, size_t stride_bytes, float leaf,
+                      float *out_a, size_t cap_a, size_t *n_a, float *out_b, size_t cap_b, size_t *n_b) {
+  const int rc = voxel_grid2_impl(ctx, a, na, b, nb, stride_bytes, leaf, out_a, cap_a, n_a, out_b, cap_b, n_b);
+  if (rc != LSLAM_OK && ctx && lslam::ctx_alive(ctx)) (void)hipStreamSynchronize((hipStream_t)lslam_stream(ctx));
+  return rc;
+}
+
 }  // extern "C"

@@ -167,3 +167,19 @@ def voxel_grid(ctx, cloud, leaf):
     if rc < 0:
         raise LslamError(rc, ctx.lib.lslam_last_error().decode())
     return out[:n.value].copy()
+
+
+def voxel_grid2(ctx, cloud_a, cloud_b, leaf):
+    """Two clouds through pcl::VoxelGrid with the same leaf in one pass (lslam_voxel_grid2: prepareFeatureFrame's corner and
+    surface clouds) -> ((ma, 4), (mb, 4)); bit for bit what two voxel_grid calls return."""
+    a, b = _xyzi(cloud_a), _xyzi(cloud_b)
+    if a.shape[1] != b.shape[1]:
+        raise ValueError("both clouds must have the same layout")
+    oa = ctx.scratch("voxel_grid2a", len(a), 4)
+    ob = ctx.scratch("voxel_grid2b", len(b), 4)
+    na, nb = C.c_size_t(), C.c_size_t()
+    rc = ctx.lib.lslam_voxel_grid2(ctx.h, a.ctypes.data_as(C.c_void_p), len(a), b.ctypes.data_as(C.c_void_p), len(b), a.shape[1] * 4,
+                                   float(leaf), _fp(oa), len(a), C.byref(na), _fp(ob), len(b), C.byref(nb))
+    if rc < 0:
+        raise LslamError(rc, ctx.lib.lslam_last_error().decode())
+    return oa[:na.value].copy(), ob[:nb.value].copy()

@@ -15,7 +15,7 @@ ROS plumbing (topics, time-stamp checks, tf, frame skipping) is not mirrored.
 """
 import numpy as np
 
-from .feature_map import FeatureMap, voxel_grid
+from .feature_map import FeatureMap, voxel_grid, voxel_grid2
 
 
 class LaserOdometry:
@@ -88,8 +88,11 @@ class LaserMapping:
         self.lidar_mapped_new = self._associate(self.lidar_odom_last, lidar_odom_new, self.lidar_mapped_last)
         odom_merged = lidar_odom_new
         # prepareFeatureFrame, :289-301
-        corner_ds = voxel_grid(self.ctx, corner_last, self.filter_corner)
-        surf_ds = voxel_grid(self.ctx, surf_last, self.filter_surf)
+        if self.filter_corner == self.filter_surf:  # the reference's defaults: both clouds in one pass (same bits)
+            corner_ds, surf_ds = voxel_grid2(self.ctx, corner_last, surf_last, self.filter_corner)
+        else:
+            corner_ds = voxel_grid(self.ctx, corner_last, self.filter_corner)
+            surf_ds = voxel_grid(self.ctx, surf_last, self.filter_surf)
         # prepareFeatureSurround, :303-325
         self.feature_map.update(self.lidar_mapped_new[:3, 3])
         nc, ns = self.feature_map.surround_counts()

@@ -89,7 +89,7 @@ def main():
         t0 = time.perf_counter()
         feat = pkg.scan_registration.extract_features(ctx, cloud, ranges)
         t1 = time.perf_counter()
-        dc, ds = pkg.voxel_grid(ctx, feat["less_sharp"], 1.0), pkg.voxel_grid(ctx, feat["less_flat"], 1.0)
+        dc, ds = pkg.voxel_grid2(ctx, feat["less_sharp"], feat["less_flat"], 1.0)
         t2 = time.perf_counter()
         fm.update(gt[3:].astype(np.float32))
         t3 = time.perf_counter()

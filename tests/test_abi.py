@@ -157,6 +157,8 @@ def test_cpp_shims_end_to_end_on_gpu(pkg, tmp_path):
     exe = _build_cpp(pkg, tmp_path, "shims_end_to_end")
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
+    again = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)  # a second process: the same answers
+    assert again.returncode == 0 and again.stdout == out.stdout
     lines = {l.split()[1]: l.split()[2:] for l in out.stdout.splitlines() if l.startswith("OK ")}
     nc, ns = (int(v) for v in lines["surround"])
     assert nc > 1000 and ns > 20000

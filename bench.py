@@ -294,13 +294,21 @@ def main():
         g0 = (ctypes.c_uint64 * 3)()
         g1 = (ctypes.c_uint64 * 3)()
         ctx.lib.lslam_debug_cert_stats(ctx.h, g0)
+        b0 = ctx.grid_stats().astype(np.int64)
         ctx.run_batch(inits, opts)
         ctx.lib.lslam_debug_cert_stats(ctx.h, g1)
+        by = ctx.grid_stats().astype(np.int64) - b0  # [type][sweep of the loop][listed, swept]
         opts.debug_stats = 0
         if rank == 0:
             out["grid_sweep"] = {"points_swept_per_step": int(g1[1] - g0[1]), "points_left_to_the_tree_search_per_step": int(g1[0] - g0[0]),
                                  "share_left_to_the_tree_search": (g1[0] - g0[0]) / max(1, g1[1] - g0[1]),
-                                 "second_pass_launches_per_step": int(g1[2] - g0[2])}
+                                 "second_pass_launches_per_step": int(g1[2] - g0[2]),
+                                 # the same share by feature type and by sweep of the Gauss-Newton loop (the last entry: that sweep and later ones)
+                                 "share_by_type": {n: float(by[t, :, 0].sum() / max(1, by[t, :, 1].sum())) for t, n in ((0, "corner"), (1, "surf"))},
+                                 "share_by_sweep": {n: [round(float(by[t, j, 0] / max(1, by[t, j, 1])), 4) for j in range(by.shape[1]) if by[t, j, 1] > 0]
+                                                    for t, n in ((0, "corner"), (1, "surf"))},
+                                 "points_by_sweep": [int(by[:, j, 1].sum()) for j in range(by.shape[1]) if by[:, j, 1].sum() > 0],
+                                 "counted_by": "the second pass's planner from the lists' lengths (the sweep kernel runs the same code with the tap on)"}
     # ---- disclosure leg: the same steps through the library's other search paths.  The headline runs the library as shipped
     # (lslam_opts.search_mode AUTO: for a batch this size the grid sweep -- every point's five neighbours either PROVEN by a
     # 27-cell probe or searched in the kd-tree; no neighbour list is carried over without one or the other).  Beside it:
@@ -504,7 +512,8 @@ def compact_line(out):
                      "launches_timed": roof.get("launches_timed"), "points_per_launch": roof.get("points_per_launch"),
                      "alg_flops_per_point": roof.get("alg_flops_per_point"),
                      "nominal_hbm_frac_at_1700B_per_point": _pick(roof, "nominal_hbm", "frac"),
-                     "measured_hbm_frac": _pick(roof, "measured_hbm", "frac"), "valu_issue_frac": _pick(roof, "valu_issue", "frac"),
+                     "measured_hbm_frac": _pick(roof, "measured_hbm", "frac"), "valu_issue_frac": _pick(roof, "valu_issue", "frac_by_instruction_count"),
+                     "valu_busy_raw": _pick(roof, "valu_issue", "frac_raw"),
                      "valu_insts_per_launch": _pick(roof, "valu_issue", "valu_wave_instructions_per_launch"),
                      "lanes_active": _pick(roof, "counters", "lanes_active"), "l2_hit_rate": _pick(roof, "counters", "l2_hit_rate"),
                      "counters_from": _pick(roof, "counters", "source_file")}
@@ -867,13 +876,20 @@ def pmc_counters(avg_sweep_ms):
         c["wait_frac"] = v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"]
     valu_issue = None
     if "SQ_ACTIVE_INST_VALU" in v and cyc > 0:
-        # SQ_ACTIVE_INST_VALU counts quad-cycles of VALU issue summed over the 1 024 SIMDs (normalised by GRBM_GUI_ACTIVE / 8
-        # engine cycles: the eight XCDs do not start and end a launch on the same cycle, so the ratio can come out a per
-        # cent above one -- reported raw next to the capped value)
+        # SQ_ACTIVE_INST_VALU sums, over the WAVES, the quad-cycles a wave has a vector-ALU instruction executing.  Waves of
+        # one SIMD overlap there -- the next wave's instruction issues while a multi-pass one (a transcendental, an fp64
+        # operation, the tail of an MFMA) of another wave still drains -- so the sum x 4 can EXCEED the SIMDs' cycles
+        # (1.1 on the clean passes): above one it is not a fraction of anything, it says the VALU pipes never idle.  The
+        # figure that is a fraction is the second one: wave-instructions x 4 cycles / (1 024 SIMDs x engine cycles)
         raw = v["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 1024.0)
+        by_count = v["SQ_INSTS_VALU"] * 4.0 / (cyc * 1024.0) if "SQ_INSTS_VALU" in v else None
         valu_issue = {"achieved": v["SQ_ACTIVE_INST_VALU"] * 4.0 / t_s, "peak": 1024.0 * 2.4e9, "unit": "SIMD issue cycles/s",
-                      "frac": min(1.0, raw), "frac_raw": raw, "lanes_active_of_64": c.get("lanes_active"),
+                      "frac": min(1.0, raw), "frac_raw": raw, "frac_by_instruction_count": by_count,
+                      "lanes_active_of_64": c.get("lanes_active"),
                       "valu_wave_instructions_per_launch": v.get("SQ_INSTS_VALU"),
+                      "note": "frac_raw > 1: per-wave busy quad-cycles overlap between the waves of a SIMD (multi-pass instructions); "
+                              "frac_by_instruction_count = SQ_INSTS_VALU x 4 cycles / (1 024 SIMDs x GRBM_GUI_ACTIVE / 8) counts every "
+                              "vector instruction as one four-cycle issue",
                       "source": "SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), %s" % prof}
     for k in ("TA_BUSY_avr", "TCP_TOTAL_CACHE_ACCESSES_sum", "TA_FLAT_READ_WAVEFRONTS_sum", "TCP_TCC_READ_REQ_sum", "GRBM_GUI_ACTIVE",
               "TA_TA_BUSY_sum", "SQ_INSTS_VALU_MFMA_F32", "SQ_VALU_MFMA_BUSY_CYCLES"):

@@ -127,6 +127,15 @@ enum { LSLAM_SEARCH_AUTO = 0, LSLAM_SEARCH_LANE = 1, LSLAM_SEARCH_PACKET = 2, LS
  * LSLAM_FORCE_STACK=deep|shallow|auto in the environment (read by lslam_ctx_create) overrides the bits.  The parity tests run every oracle
  * comparison through both shapes; lslam_debug_sweep_launches says which kernel really ran. */
 enum { LSLAM_STACK_AUTO = 0, LSLAM_STACK_DEEP = 0x100, LSLAM_STACK_SHALLOW = 0x200 };
+/* lslam_sweep_ex only, ORed into LSLAM_SEARCH_GRID: run the tap's sweep the way the production loop runs a LATER sweep of a
+ * Gauss-Newton loop -- bounded by the acceptance gate and by what the previous sweep of the loop carried over per point (where
+ * the point was, how far its fifth neighbour: the probe's rows and cells are clipped to that bound, the second pass's tree
+ * search starts from it).  The carried state is the one the last lslam_scanmatch_run* on this resident scan left (run it
+ * with search_mode LSLAM_SEARCH_GRID and max_iterations = k: the tap at the pose it returned is then sweep k + 1 of the
+ * loop, kernel for kernel).  Beyond the gate (d2[4] >= 5) nothing is looked up by the reference (ScanMatch.cpp:102,120) and
+ * idx_out / d2_out of such a point are not nanoflann's; flags and coefficients are the reference's for every point. */
+/* LSLAM_SWEEP_FIRST: the loop's FIRST sweep, kernel for kernel -- bounded by the acceptance gate only, nothing carried. */
+enum { LSLAM_SWEEP_CARRIED = 0x400, LSLAM_SWEEP_FIRST = 0x800 };
 
 /* Per-call statistics (the counters the reference prints, ScanMatch.cpp:35-40,
  * 143,269, plus timing taps). */
@@ -664,6 +673,11 @@ void lslam_debug_lazy_trees(lslam_ctx *ctx, uint64_t out[3]);
  * context since its creation; out[0] = points the certificate-testing workgroups left to the second pass and out[1] = points
  * of those workgroups, counted only when the process runs with LSLAM_DEBUG_CERT_STATS=1 (two atomics per workgroup). */
 void lslam_debug_cert_stats(lslam_ctx *ctx, uint64_t out[3]);
+/* ... and the grid sweep's (lslam_opts.debug_stats = 1 during the runs): out[((type * 8) + sweep) * 2 + {0, 1}] = points the
+ * probe could not prove (left to the tree search) / points swept, by feature type (0 corner, 1 surf) and sweep of the
+ * Gauss-Newton loop (0 = a loop's first sweep; slot 7 = the eighth and every later one).  Counted by the planner of the second
+ * pass from the lists' lengths: the sweep kernel itself runs the same code with the tap on. */
+void lslam_debug_grid_stats(lslam_ctx *ctx, uint64_t out[32]);
 /* Test tap: what the certificate sweep carries per resident scan point after a lslam_scanmatch_run* that ran it -- the
  * map-frame position of the point's last SEARCH (q_xyz0: 4 floats per point, the fourth unused) and the lower bound taken
  * there of the squared distance of every map point outside its five neighbours (lb; 0: none).  Resident order: per scan its

@@ -384,3 +384,69 @@ def test_grid_limits_fall_back_to_the_tree(pkg, ctx):
         fm.close()
     finally:
         c2.close()
+
+
+def _seven_in_a_row_problem(with_cluster):
+    """A jittered ground patch + wall (surf) and poles (corner) matched at the identity pose, and -- with_cluster -- seven map
+    points in ONE cell row, 1.0 ... 1.1 m from a lone scan point: four clearly nearer ones, then three whose squared distances
+    share one 2^-13 truncation bucket of the probe's keys, the NEAREST of the three last in index order."""
+    rng = np.random.default_rng(77)
+    g = np.arange(-16.0, 16.0, 0.4, dtype=np.float32)
+    gx, gy = np.meshgrid(g, g)
+    ground = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size, np.float32)], 1)
+    ground += rng.uniform(-0.1, 0.1, ground.shape).astype(np.float32) * np.array([1, 1, 0.05], np.float32)
+    h = np.arange(0.3, 5.0, 0.2, dtype=np.float32)
+    poles = np.concatenate([np.stack([np.full(len(h), x, np.float32), np.full(len(h), y, np.float32), h], 1)
+                            for x in (-9.0, -3.0, 3.0, 9.0) for y in (-8.0, 0.0, 8.0)]).astype(np.float32)
+    poles += rng.uniform(-0.01, 0.01, poles.shape).astype(np.float32)
+    qs = (ground[::5] + rng.normal(0, 0.02, ground[::5].shape).astype(np.float32)).astype(np.float32)
+    qc = (poles[::2] + np.array([0.03, 0.02, 0.05], np.float32)).astype(np.float32)
+    surf = ground
+    if with_cluster:
+        q = np.array([3.30, 2.10, 30.0], np.float32)              # far above everything else
+        xs = [1.00, 1.02, 1.04, 1.06]
+        # the three of the bucket: squared distances (the kernel's fp32 arithmetic: only dx is non-zero) with equal upper 22 bits
+        base = np.float32(1.10)
+        trio = None
+        for a in np.arange(0.0, 2e-3, 1e-6, dtype=np.float32):
+            cand = [np.float32(q[0] + base + a + np.float32(1e-5)), np.float32(q[0] + base + a + np.float32(2e-5)), np.float32(q[0] + base + a)]
+            d2 = [np.float32(np.float32(q[0] - c) * np.float32(q[0] - c)) for c in cand]
+            b = [int(np.float32(v).view(np.uint32)) >> 10 for v in d2]
+            if b[0] == b[1] == b[2] and d2[2] < d2[0] < d2[1]:
+                trio = cand
+                break
+        assert trio is not None
+        cluster = np.array([[q[0] + x, q[1], q[2]] for x in xs] + [[c, q[1], q[2]] for c in trio], np.float32)
+        surf = np.concatenate([ground, cluster]).astype(np.float32)   # the cluster last: ascending original index = A, B, C
+        qs = np.concatenate([qs, q[None, :]]).astype(np.float32)
+    return poles, surf, qc, qs
+
+
+def test_wide_probe_refuses_a_candidate_dropped_behind_six_keys_of_one_lane(pkg):
+    """sweep_wide_kernel gives a cell row to ONE lane, and a lane keeps its six smallest truncated keys.  Seven candidates in a
+    row, the fifth to seventh nearest inside one truncation bucket with the nearest of them LAST in index order: the lane
+    drops exactly the candidate that is the true fifth neighbour, and all six wave-wide winners are that lane's.  The proof
+    must not accept the five it is left with (the sixth winner's key bounds what that lane dropped): the deferred call builds
+    the trees after all and returns the eager call's bits.  Without the cluster the same problem runs on the grids alone."""
+    res = {}
+    for with_cluster in (False, True):
+        mc, ms, qc, qs = _seven_in_a_row_problem(with_cluster)
+        for defer in (False, True):
+            c = pkg.Context(0)
+            try:
+                c.defer_trees(defer)
+                c.map_set(mc, ms)
+                c.scan_set(qc, qs)
+                status, pose, st = c.run(np.zeros(6, np.float32))
+                res[(with_cluster, defer)] = (int(status), pose.copy(), st.iterations, st.n_rows, st.n_plane, c.lazy_trees())
+                if defer:
+                    assert c.grid_launches() > 0
+            finally:
+                c.close()
+    assert res[(False, True)][5] == (1, 0, True), res[(False, True)][5]       # no tree was needed
+    assert res[(True, True)][5] == (1, 1, False), res[(True, True)][5]        # the near-tie was refused: trees built, call repeated
+    for wc in (False, True):
+        a, b = res[(wc, False)], res[(wc, True)]
+        assert a[0] == b[0] and a[2:5] == b[2:5] and a[3] > 100
+        assert np.abs(a[1] - b[1]).max() <= 2e-6
+    assert np.array_equal(bits(res[(True, False)][1]), bits(res[(True, True)][1]))  # through the trees: the eager run's bits

@@ -22,6 +22,7 @@ POSE_TOL_M = 1e-4    # BASELINE.json north_star: pose within 1e-4 m of the CPU r
 POSE_TOL_RAD = 1e-5
 LANE, DEEP, SHALLOW = 1, 0x100, 0x200  # LSLAM_SEARCH_LANE, LSLAM_STACK_DEEP, LSLAM_STACK_SHALLOW
 GRID = 3                                # LSLAM_SEARCH_GRID
+CARRIED, FIRST = 0x400, 0x800           # LSLAM_SWEEP_CARRIED / _FIRST: the tap's sweep as a later / the first sweep of the production loop
 
 
 def bits(a):
@@ -255,6 +256,52 @@ def test_voxel_map_sweep_taps_match_oracle_through_the_shallow_kernel(voxel_map_
     assert np.abs(g["sums"][:27] - o["sums"][:27]).max() <= 2e-5 * scale
     assert g["sums"][27] == o["sums"][27] and g["sums"][28] == o["sums"][28]
     assert (o["flags"] & 4).sum() > 50000
+
+
+def _every_sweep_of_the_loop_against_the_oracle(ctx, oracle, tc, ts, qc, qs, init, max_sweeps=8):
+    """The grid sweep as the production loop runs it -- the first sweep bounded by the gate, every later one with its probes
+    clipped to the bound carried from the sweep before and its second pass's tree searches started from it -- held to the
+    oracle's sweep at the same pose, point by point: flags and coefficients of every point bit for bit, neighbour indices and
+    squared distances bit for bit wherever the reference looks them up at all (d2[4] < 5, ScanMatch.cpp:102,120).  Sweep k + 1
+    is the tap right after a run cut at max_iterations = k (include/lslam_c.h LSLAM_SWEEP_CARRIED).  Returns the number of
+    sweeps compared and of points whose neighbours were."""
+    ctx.scan_set(qc, qs)
+    o = ctx.default_opts()
+    o.search_mode = GRID
+    n_sweeps = n_pts = 0
+    pose = np.asarray(init, np.float32)
+    for k in range(max_sweeps):
+        if k > 0:
+            o.max_iterations = k
+            status, pose, st = ctx.run(init, o)
+            if st.iterations < k or st.converged:  # the loop ended before sweep k + 1
+                break
+        g0 = ctx.grid_launches()
+        g = ctx.sweep(pose, jtj_mode=1, search_mode=GRID | (CARRIED if k > 0 else FIRST))
+        assert ctx.grid_launches() == g0 + 1
+        r = oracle.sweep(tc, ts, qc, qs, pose)
+        assert np.array_equal(g["flags"], r["flags"]), (k, np.argwhere(g["flags"] != r["flags"])[:5].tolist())
+        assert np.array_equal(bits(g["coeff"]), bits(r["coeff"])), k
+        looked_up = (r["flags"] & 1) != 0
+        assert np.array_equal(g["idx"][looked_up], r["idx"][looked_up]), (k, np.argwhere((g["idx"] != r["idx"]).any(1) & looked_up)[:5].tolist())
+        assert np.array_equal(bits(g["d2"])[looked_up], bits(r["d2"])[looked_up]), k
+        assert g["sums"][27] == r["sums"][27] and g["sums"][28] == r["sums"][28]
+        n_sweeps += 1
+        n_pts += int(looked_up.sum())
+    return n_sweeps, n_pts
+
+
+def test_voxel_map_every_sweep_of_the_grid_loop_matches_oracle_index_for_index(voxel_map_problem, oracle):
+    """What the headline times from a loop's second sweep on -- the BOUNDED probe (rows and cells clipped to the carried bound)
+    and the bounded second pass -- against the oracle index for index, on two full 64 x 1800 scans over the (reduced) voxel map,
+    every sweep of their loops."""
+    vp = voxel_map_problem
+    ctx = vp["ctx"]
+    mc, ms = vp["surround"]
+    tc, ts = oracle.kdtree(mc), oracle.kdtree(ms)
+    for k in (0, 2):
+        n_sweeps, n_pts = _every_sweep_of_the_loop_against_the_oracle(ctx, oracle, tc, ts, vp["scans"][k][0], vp["scans"][k][1], vp["inits"][k])
+        assert n_sweeps >= 3 and n_pts > 2.5 * 100000, (k, n_sweeps, n_pts)
 
 
 def test_certificate_sweep_equals_searching_every_point(voxel_map_problem, ctx, oracle, synth, small_problem, monkeypatch):
@@ -499,13 +546,11 @@ def test_vlp16_mapping_frames_against_the_voxel_map_match_oracle(voxel_map_probl
     mapper.feature_map.close()
 
 
-def test_full_size_configs_map_grid_sweep_against_lane_and_oracle(pkg, oracle, synth):
+@pytest.fixture(scope="module")
+def full_map_problem(pkg, synth):
     """BASELINE configs[1]'s map at its FULL size -- 10 000 VLP-16 frames through the product's addFeatureCloud, the surround at
-    the end of the loop (≈ 157 k corner + 587 k surf points): the map bench.py times against -- and configs[2] scans: sixteen full
-    64 x 1800 scans in one batch.  (a) the library's choice for a batch this size (the grid sweep) against the kd-tree walk of
-    every point: the same iteration and row counts, poses to the rounding of differently grouped sums; (b) two of the scans
-    against the oracle on the same clouds (the oracle needs ≈ 2 s per scan on this map); (c) the share of points the grid sweep
-    left to the tree search is the few per cent DESIGN quotes."""
+    the end of the loop (≈ 157 k corner + 587 k surf points): the map bench.py times against -- and sixteen full 64 x 1800
+    scans (configs[2]) taken the way bench.py takes its 960."""
     import importlib as il
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     synth_gpu = il.import_module("synth_gpu")
@@ -513,47 +558,119 @@ def test_full_size_configs_map_grid_sweep_against_lane_and_oracle(pkg, oracle, s
     lidar = synth_gpu.GpuLidar(world, 0)
     traj = synth_gpu.loop_trajectory(10000)
     ctx = pkg.Context(0)
+    fm, stats = synth_gpu.build_voxel_map(pkg, ctx, lidar, traj, rings=16)
+    assert stats["frames"] == 10000
+    fm.update(traj[-1][3:].astype(np.float32))
+    mc, ms = fm.get_surround_feature()
+    fm.surround_to_map()
+    assert len(mc) > 100000 and len(ms) > 400000
+    rng = np.random.default_rng(4242)
+    dense = synth_gpu.loop_trajectory(100000)
+    seg = np.linalg.norm(np.diff(dense[:, 3:5], axis=0), axis=1).mean()
+    span = int(25.0 / seg)
+    scans, inits = [], []
+    for k in range(16):
+        g = dense[int(rng.integers(-span, span)) % len(dense)].copy()
+        g[3:5] += rng.uniform(-1.0, 1.0, 2)
+        g[2] += rng.uniform(-0.2, 0.2)
+        scans.append(lidar.scan(g, 64, 1800, seed=900000 + k))
+        inits.append(synth.perturb_pose(g, seed=99 + k))
+    yield dict(ctx=ctx, fm=fm, surround=(mc, ms), scans=scans, inits=np.stack(inits), lidar=lidar, traj=traj, synth_gpu=synth_gpu)
+    fm.close()
+    ctx.close()
+
+
+def test_full_size_configs_map_grid_sweep_against_lane_and_oracle(full_map_problem, oracle):
+    """configs[1]'s full-size map x sixteen configs[2] scans in one batch.  (a) the library's choice for a batch this size (the
+    grid sweep) against the kd-tree walk of every point: the same iteration and row counts, poses to the rounding of
+    differently grouped sums; (b) two of the scans against the oracle on the same clouds (the oracle needs ≈ 2 s per scan on
+    this map); (c) the share of points the grid sweep left to the tree search is the few per cent DESIGN quotes, and the
+    by-type / by-sweep breakdown of the tap adds up to it."""
+    fp = full_map_problem
+    ctx, scans, inits = fp["ctx"], fp["scans"], fp["inits"]
+    mc, ms = fp["surround"]
+    ctx.scan_set_batch(scans)
+    o = ctx.default_opts()
+    o.scans_in_flight = 16
+    o.debug_stats = 1
+    g0, s0, b0 = ctx.grid_launches(), ctx.cert_stats(), ctx.grid_stats().astype(np.int64)
+    _, p_auto, st_auto = ctx.run_batch(inits, o)
+    s1, b1 = ctx.cert_stats(), ctx.grid_stats().astype(np.int64)
+    assert ctx.grid_launches() > g0                                                             # picked by size
+    listed, swept = s1[0] - s0[0], s1[1] - s0[1]
+    assert 0.002 < listed / swept < 0.08, listed / swept                                        # (c)
+    by = b1 - b0
+    assert by[:, :, 0].sum() == listed and by[:, :, 1].sum() == swept
+    assert swept == sum(s.sweeps * (len(c) + len(q)) for s, (c, q) in zip(st_auto, scans))
+    assert by[:, 0, 1].sum() == sum(len(c) + len(q) for c, q in scans)                           # every point is in a first sweep
+    o.search_mode = LANE
+    o.knn_cert = 0
+    _, p_lane, st_lane = ctx.run_batch(inits, o)
+    for a, b in zip(st_auto, st_lane):                                                          # (a)
+        assert a.iterations == b.iterations and a.converged == b.converged
+        assert _counts_close((a.n_line, a.n_plane, a.n_rows), (b.n_line, b.n_plane, b.n_rows))
+    assert np.abs(p_auto[:, 3:] - p_lane[:, 3:]).max() <= 5e-6 and np.abs(p_auto[:, :3] - p_lane[:, :3]).max() <= 5e-7
+    for k in (0, 7):                                                                            # (b)
+        ok, opose, ost = oracle.scanmatch_scan(mc, ms, scans[k][0], scans[k][1], inits[k])
+        assert st_auto[k].iterations == ost.iterations and st_auto[k].converged == ost.converged
+        assert _counts_close((st_auto[k].n_line, st_auto[k].n_plane, st_auto[k].n_rows), (ost.n_line, ost.n_plane, ost.n_rows))
+        assert np.abs(p_auto[k][3:] - opose[3:]).max() <= POSE_TOL_M and np.abs(p_auto[k][:3] - opose[:3]).max() <= POSE_TOL_RAD
+
+
+def test_full_size_map_every_sweep_of_the_grid_loop_matches_oracle_index_for_index(full_map_problem, oracle):
+    """The timed kernel's bounded probes at bench size: two full 64 x 1800 scans against the FULL-size configs[1] map, every
+    sweep of their Gauss-Newton loops, the grid sweep (first sweep gate-bounded, later ones carried-bounded, both passes)
+    against oracle.sweep at the same pose -- flags, coefficients, neighbour indices and distances bit for bit (≈ 115 k points
+    x ≈ 4 sweeps x 2 scans)."""
+    fp = full_map_problem
+    ctx = fp["ctx"]
+    mc, ms = fp["surround"]
+    tc, ts = oracle.kdtree(mc), oracle.kdtree(ms)
+    total = 0
+    for k in (1, 9):
+        n_sweeps, n_pts = _every_sweep_of_the_loop_against_the_oracle(ctx, oracle, tc, ts, fp["scans"][k][0], fp["scans"][k][1], fp["inits"][k])
+        assert n_sweeps >= 3, (k, n_sweeps)
+        total += n_pts
+    assert total > 6 * 100000, total
+
+
+def test_full_size_map_vlp16_mapping_frames_match_oracle(full_map_problem, pkg, oracle, synth):
+    """BASELINE configs[1] at FULL size through LaserMapping::process: three consecutive 16 x 1800 frames at the end of the
+    loop against the 10 000-frame map (the frames' own additions included), the device chain against the same steps made of
+    oracle calls -- map poses to the bar, the same iteration counts."""
+    from test_gpu_pipeline import OracleChain
+    fp = full_map_problem
+    synth_gpu, lidar, traj = fp["synth_gpu"], fp["lidar"], fp["traj"]
+    mc, ms = fp["surround"]
+    dims = (21, 21, 11)
+    c2 = pkg.Context(0)
     try:
-        fm, stats = synth_gpu.build_voxel_map(pkg, ctx, lidar, traj, rings=16)
-        assert stats["frames"] == 10000
-        fm.update(traj[-1][3:].astype(np.float32))
-        mc, ms = fm.get_surround_feature()
-        fm.surround_to_map()
-        assert len(mc) > 100000 and len(ms) > 400000
-        rng = np.random.default_rng(4242)
-        dense = synth_gpu.loop_trajectory(100000)
-        seg = np.linalg.norm(np.diff(dense[:, 3:5], axis=0), axis=1).mean()
-        span = int(25.0 / seg)
-        scans, inits = [], []
-        for k in range(16):
-            g = dense[int(rng.integers(-span, span)) % len(dense)].copy()
-            g[3:5] += rng.uniform(-1.0, 1.0, 2)
-            g[2] += rng.uniform(-0.2, 0.2)
-            scans.append(lidar.scan(g, 64, 1800, seed=900000 + k))
-            inits.append(synth.perturb_pose(g, seed=99 + k))
-        inits = np.stack(inits)
-        ctx.scan_set_batch(scans)
-        o = ctx.default_opts()
-        o.scans_in_flight = 16
-        o.debug_stats = 1
-        g0, s0 = ctx.grid_launches(), ctx.cert_stats()
-        _, p_auto, st_auto = ctx.run_batch(inits, o)
-        s1 = ctx.cert_stats()
-        assert ctx.grid_launches() > g0                                                             # picked by size
-        listed, swept = s1[0] - s0[0], s1[1] - s0[1]
-        assert 0.002 < listed / swept < 0.08, listed / swept                                        # (c)
-        o.search_mode = LANE
-        o.knn_cert = 0
-        _, p_lane, st_lane = ctx.run_batch(inits, o)
-        for a, b in zip(st_auto, st_lane):                                                          # (a)
-            assert a.iterations == b.iterations and a.converged == b.converged
-            assert _counts_close((a.n_line, a.n_plane, a.n_rows), (b.n_line, b.n_plane, b.n_rows))
-        assert np.abs(p_auto[:, 3:] - p_lane[:, 3:]).max() <= 5e-6 and np.abs(p_auto[:, :3] - p_lane[:, :3]).max() <= 5e-7
-        for k in (0, 7):                                                                            # (b)
-            ok, opose, ost = oracle.scanmatch_scan(mc, ms, scans[k][0], scans[k][1], inits[k])
-            assert st_auto[k].iterations == ost.iterations and st_auto[k].converged == ost.converged
-            assert _counts_close((st_auto[k].n_line, st_auto[k].n_plane, st_auto[k].n_rows), (ost.n_line, ost.n_plane, ost.n_rows))
-            assert np.abs(p_auto[k][3:] - opose[3:]).max() <= POSE_TOL_M and np.abs(p_auto[k][:3] - opose[:3]).max() <= POSE_TOL_RAD
-        fm.close()
+        mapper = pkg.LaserMapping(c2, cube_dims=dims, map_filter_corner=0.2, map_filter_surf=0.4, map_filter=0.6)
+        chain = OracleChain(oracle, c2, dims)
+        chain.fm.setup_filter_size(0.2, 0.4, 0.6)
+        eye = np.eye(4, dtype=np.float32)
+        start = traj[-1]
+        for fm in (mapper.feature_map, chain.fm):  # both maps start as the full map's surround (already filtered: stays as it is)
+            fm.update(start[3:].astype(np.float32))
+            fm.add_feature_cloud(mc, ms, eye)
+        sr = pkg.scan_registration
+        iters = []
+        for k in range(3):
+            g = traj[-7 + 3 * k].copy()
+            _, _, cloud, ranges = lidar.scan(g, 16, 1800, seed=9300 + k, full=True)
+            f = sr.extract_features(c2, cloud, ranges)
+            of = oracle.extract_features(cloud, ranges)
+            for key in ("less_sharp", "less_flat"):
+                assert np.array_equal(bits(f[key]), bits(of[key])), (k, key)
+            odom = synth_gpu.pose_matrix(synth.perturb_pose(g, seed=170 + k, dt=0.15, dr_deg=0.8))
+            M_g = mapper.process(f["less_sharp"], f["less_flat"], odom)
+            M_o = chain.mapping(of["less_sharp"], of["less_flat"], odom)
+            iters.append(mapper.last_stats.iterations)
+            assert mapper.last_stats.n_rows > 1000, (k, mapper.last_stats.n_rows)
+            assert np.abs(M_g[:3, 3] - M_o[:3, 3]).max() <= POSE_TOL_M, (k, np.abs(M_g - M_o).max())
+            assert np.abs(M_g[:3, :3] - M_o[:3, :3]).max() <= 2e-5, k
+            assert np.abs(M_g[:2, 3] - g[3:5]).max() < 0.05 and abs(M_g[2, 3] - g[5]) < 0.3, (k, M_g[:3, 3], g[3:])
+        assert min(iters) >= 2
+        mapper.feature_map.close()
     finally:
-        ctx.close()
+        c2.close()

@@ -181,6 +181,7 @@ SYMBOLS = {
     "lslam_stream": (C.c_void_p, [C.c_void_p]),
     "lslam_debug_sweep_launches": (None, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "lslam_debug_cert_stats": (None, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "lslam_debug_grid_stats": (None, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "lslam_debug_cert_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t]),
     "lslam_pg_create": (C.c_int, [C.c_int, C.c_int32, c_double_p, C.c_int32, c_int32_p, c_double_p, c_double_p,
                                   C.c_int32, C.POINTER(C.c_void_p)]),

@@ -185,6 +185,7 @@ struct lslam_ctx {
   uint64_t queue_launches = 0;
   DevBuf<unsigned long long> cert_stats;  // LSLAM_DEBUG_CERT_STATS=1: [searched, swept] counters of the certificate path
   bool prev_valid = false;
+  bool grid_state_valid = false;  // prev_q holds what a grid-sweep run of the resident scan against the resident map left (LSLAM_SWEEP_CARRIED)
   lslam_comm *comm = nullptr;  // RCCL communicator of the sharded-points path (not owned)
   DevBuf<double> xchg;         // its exchange buffer
   GNState *d_state = nullptr;   // [state_cap]
@@ -685,6 +686,16 @@ void lslam_debug_cert_stats(lslam_ctx *ctx, uint64_t out[3]) {  // out[0], out[1
   out[2] = ctx->queue_launches;
 }
 
+// the grid sweep's share of listed points by feature type and sweep of the loop (include/lslam_c.h)
+void lslam_debug_grid_stats(lslam_ctx *ctx, uint64_t out[32]) {
+  static_assert(2 * 2 * GRID_STATS_SWEEPS == 32, "lslam_debug_grid_stats' out[32]");
+  for (int i = 0; i < 32; ++i) out[i] = 0;
+  if (!ctx || !ctx->cert_stats.p) return;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+      hipMemcpy(out, ctx->cert_stats.p + CERT_STATS_BY_SWEEP, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)
+    for (int i = 0; i < 32; ++i) out[i] = 0;
+}
+
 // what the certificate sweep carries per resident scan point (resident order: per scan its corner points, then its surf points)
 int lslam_debug_cert_state(lslam_ctx *ctx, float *q_xyz0, float *lb, size_t cap_points) {
   if (!ctx || !ctx->prev_q.p || !ctx->prev_lb.p) return LSLAM_ERR_INVALID;
@@ -827,6 +838,7 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
   ctx->map_epoch++;
   ctx->cube_mode = false;
   ctx->prev_valid = false;
+  ctx->grid_state_valid = false;
   const double t0 = now_ms();
   double t1 = t0, t2 = t0;
   size_t nodes_c = 0, nodes_s = 0;
@@ -1077,6 +1089,7 @@ int cubemap_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t nc, const 
   ctx->have_map = false;
   ctx->map_epoch++;
   ctx->prev_valid = false;
+  ctx->grid_state_valid = false;
   const double t0 = now_ms();
   int dc = 0, ds = 0, fb = 0;
   size_t nn_c = 0, nn_s = 0;
@@ -1114,6 +1127,7 @@ int cubemap_set_views(lslam_ctx *ctx, const std::vector<TreeView> &views_c, cons
   ctx->have_map = false;
   ctx->map_epoch++;
   ctx->prev_valid = false;
+  ctx->grid_state_valid = false;
   if (depth_c > KD_STACK_MAX || depth_s > KD_STACK_MAX) {
     set_err("kd-tree depth %d/%d exceeds device stack %d", depth_c, depth_s, KD_STACK_MAX);
     return LSLAM_ERR_TREE_DEPTH;
@@ -1287,6 +1301,7 @@ int lslam_cubemap_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const
   ctx->have_map = false;
   ctx->map_epoch++;
   ctx->prev_valid = false;
+  ctx->grid_state_valid = false;
   const double t0 = now_ms();
   int dc = 0, ds = 0;
   size_t nc_nodes = 0, ns_nodes = 0;
@@ -1445,6 +1460,7 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
   HIP_TRY(ctx->tail_count.reserve((size_t)n_scans));
   HIP_TRY(hipMemsetAsync(ctx->tail_count.p, 0, sizeof(int32_t) * (size_t)n_scans, ctx->stream));
   ctx->prev_valid = false;
+  ctx->grid_state_valid = false;
   rc = ensure_states(ctx, n_scans);
   if (rc) return rc;
   if (total && dev_morton) {
@@ -1529,6 +1545,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
   // another scan) and must not bound this call's first sweep -- a real call on a new scan has none.
   // From the second sweep on the bound comes from the first sweep of THIS loop.
   ctx->prev_valid = false;
+  ctx->grid_state_valid = false;
 
   for (int32_t p = 0; p < n_scans; ++p) {
     init_state(ctx->h_state[p], poses + 6 * p);
@@ -1602,6 +1619,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
   // count (+1 spare); only if a loop is still running after it does the host look at
   // the states (one round trip) and enqueue two more iterations at a time.
   HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+  const uint64_t grid_launches_before = ctx->sweep_variants[SWEEP_VARIANT_GRID];
   int launched = 0;
   int batch = ctx->iter_hint < 1 ? 1 : ctx->iter_hint;
   double total_points = -1.0;  // sharded: points of the whole scan (sum over ranks)
@@ -1780,8 +1798,8 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
     }
     if ((sa.prev_q || sa.grid) && (ctx->env_debug_cert_stats || o.debug_stats)) {
       if (!ctx->cert_stats.p) {
-        HIP_TRY(ctx->cert_stats.reserve(3));
-        HIP_TRY(hipMemsetAsync(ctx->cert_stats.p, 0, 24, ctx->stream));
+        HIP_TRY(ctx->cert_stats.reserve(CERT_STATS_WORDS));
+        HIP_TRY(hipMemsetAsync(ctx->cert_stats.p, 0, CERT_STATS_WORDS * sizeof(unsigned long long), ctx->stream));
       }
       sa.cert_stats = ctx->cert_stats.p;
     }
@@ -1966,6 +1984,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
       }
     }
   }
+  ctx->grid_state_valid = !sharded && !gnp_done && ctx->sweep_variants[SWEEP_VARIANT_GRID] > grid_launches_before && n_scans == 1;
   ctx->stage_busy = false;  // the stream has been waited for since the scan was set
   if (lazy) {  // a point's answer needed nanoflann's visit order (sweep_wide_kernel): the trees after all, and the call again
     bool need_tree = false;
@@ -2529,7 +2548,16 @@ int lslam_sweep_ex(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_
   rc = ensure_stack_ovf(ctx, (size_t)sa.nb_total * SWEEP_BLOCK, &sa.stack_ovf);
   if (rc) return rc;
   sa.stack_mode = resolve_stack_mode(ctx, search_mode);
+  const bool carried = (search_mode & LSLAM_SWEEP_CARRIED) != 0, first = (search_mode & LSLAM_SWEEP_FIRST) != 0;
   search_mode &= 0xFF;
+  if (first && (carried || search_mode != LSLAM_SEARCH_GRID)) {
+    set_err("LSLAM_SWEEP_FIRST needs LSLAM_SEARCH_GRID and excludes LSLAM_SWEEP_CARRIED");
+    return LSLAM_ERR_INVALID;
+  }
+  if (carried && (search_mode != LSLAM_SEARCH_GRID || !ctx->prev_q.p || !ctx->grid_state_valid)) {
+    set_err("LSLAM_SWEEP_CARRIED needs LSLAM_SEARCH_GRID and the state a grid-sweep lslam_scanmatch_run* left on this scan");
+    return LSLAM_ERR_INVALID;
+  }
   if (sa.stack_mode == SWEEP_STACK_SHALLOW && !ctx->cube_mode) {  // the batch kernel's stack shape on this (unbounded) tap
     HIP_TRY(ctx->stack_ovf.reserve(stack_ovf_words((size_t)std::max(sa.nb_total, 1) * SWEEP_BLOCK, std::max(ctx->tc.depth, ctx->ts.depth))));
     sa.stack_ovf = ctx->stack_ovf.p;
@@ -2560,6 +2588,14 @@ int lslam_sweep_ex(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_
     sa.n_groups = (int32_t)ctx->h_groups.size();
     sa.group_block_base = 0;
     HIP_TRY(hipMemsetAsync(ctx->cert_count.p, 0, 4 * sizeof(int32_t), ctx->stream));
+    if (carried || first) {  // a sweep of the production loop, kernel for kernel (include/lslam_c.h LSLAM_SWEEP_CARRIED / _FIRST)
+      HIP_TRY(ctx->prev_q.reserve(std::max<size_t>(N, 1)));
+      sa.bounded = 1;
+      sa.prev_valid = carried ? 1 : 0;
+      sa.prev_q = ctx->prev_q.p;
+      sa.grid_clip_margin = GRID_CLIP_MARGIN_MIN;
+      ctx->grid_state_valid = true;  // what this sweep leaves is the state the next sweep of the loop would find
+    }
   }
   const bool taps = idx_out || d2_out || coeff_out || flags_out;
   if (taps) {

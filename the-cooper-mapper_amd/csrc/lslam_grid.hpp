@@ -47,6 +47,20 @@ constexpr int GRID_MAX_DIM = 2048;        // cells per axis (the rounding slack 
 // points whose cell coordinates differ by w are at least (w - GRID_U_SLACK) cells apart on that axis.
 constexpr float GRID_U_SLACK = 2.0e-3f;
 constexpr float GRID_CLIP_MARGIN_MIN = 3.0e-3f;  // [m] smallest padding of a clip radius (covers GRID_U_SLACK * c for c <= 1 m)
+// nanoflann is an exact fp32 5-NN only up to the rounding of its OWN pruning bound: searchLevel updates the lower bound of a
+// far branch incrementally, `mindistsq + cut_dist - dists[idx]` (nanoflann.hpp:1485), two fp32 roundings per far step, and the
+// split values are point coordinates (:971-972), so a point can sit on the corner of its subtree's box.  Along a path the
+// bound only grows, so after F far steps it exceeds the exact box distance by at most ~1.5 F ulps: a point whose distance is
+// within that BELOW the current fifth can be pruned by nanoflann although it is closer -- and the tree walk of
+// lslam_device.hpp replays exactly that, the grid cannot.  (With the query outside the box in ONE dimension only -- the
+// common case -- the bound is the cut distance itself, exact.)  Every comparison of the proof that separates the fifth
+// distance from a point NOT among the five therefore carries a relative margin; a point that fails it is unproven and goes to
+// the tree walk.  Where a tree exists the margin costs nothing and is the worst case: 100 ulps = 1.5 x 66 far steps, deeper
+// than any tree the builder makes (a few points in 10^5 more are listed).  The wide probe of a map WITHOUT trees
+// (sweep_wide_kernel) has no tree walk to hand a point to -- a refusal there builds the trees and repeats the call -- and
+// uses GRID_NF_PRUNE_SLACK_WIDE = 8 ulps (five adversarially rounded far steps in a row onto a box corner).
+constexpr float GRID_NF_PRUNE_SLACK = 1.2e-5f;
+constexpr float GRID_NF_PRUNE_SLACK_WIDE = 9.6e-7f;
 inline int grid_margin_cells(float c) { return (int)(2.2361f / c) + 3; }
 
 // a candidate's place in its lane's row table, carried in the low mantissa bits of its key: row slot (9 rows) and offset
@@ -80,7 +94,8 @@ enum : int {
 //     a point outside the 27 cells differs by at least that much on one axis.  Its computed distance can be smaller than its
 //     true one by a few ulps only: rg2 carries a 1e-5 relative pad;
 //   * points in rows or cells that were clipped are farther than sqrt(bound) (padded), hence farther than five known points;
-//   * d[0] < d[1] < ... < d[4] < (sixth smallest candidate distance): no tie that nanoflann's visit order would have decided.
+//   * d[0] < d[1] < ... < d[4] < (sixth smallest candidate distance) (1 - GRID_NF_PRUNE_SLACK): no tie that nanoflann's visit
+//     order would have decided, and no sixth point close enough for the rounding of nanoflann's pruning bound to matter.
 // R: rings of cells around the query's cell -- 1: the 27-cell probe of pass 1 (nine runs of three cells); 2: 125 cells
 // (twenty-five runs of five), for the points the 27-cell probe could not prove: guaranteed radius c (2 + wall) instead of
 // c (1 + wall), rows clipped to the BALL of the caller's bound (which such a point always has: the fifth distance the first
@@ -107,7 +122,7 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
   const float ex = ux - fx0, ey = uy - fy0, ez = uz - fz0;  // position inside the cell, [0, 1)
   const float wall = fminf(fminf(fminf(ex, 1.0f - ex), fminf(ey, 1.0f - ey)), fminf(ez, 1.0f - ez));
   const float rg = G.c * (((float)R - GRID_U_SLACK) + wall);
-  const float rg2 = (rg * rg) * (1.0f - 1.0e-5f);
+  const float rg2 = (rg * rg) * (1.0f - (1.0e-5f + GRID_NF_PRUNE_SLACK));
   // clip box in cell coordinates
   float clip_lo2 = FLT_MAX;
   float xlo = fx0 - (float)R, xhi = fx0 + (float)R, ylo = fy0 - (float)R, yhi = fy0 + (float)R, zlo = fz0 - (float)R, zhi = fz0 + (float)R;
@@ -362,9 +377,10 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
     lb = fmaxf(e[5], d[4]);  // whoever of the six is left out
     knn_insert_sorted(d, p, e[5], (int)pos[5]);
   }
-  // everybody who is not a survivor is at least the sixth key's truncated distance away
+  // everybody who is not a survivor is at least the sixth key's truncated distance away; the sixth exact distance less
+  // nanoflann's pruning slack (FLT_MAX stays FLT_MAX: no sixth candidate at all)
   const float t6 = (k5 != 0xFFFFFFFFu) ? __uint_as_float(k5 & ~IDM) : FLT_MAX;
-  lb = fminf(lb, t6);
+  lb = fminf(lb < 1.0e30f ? lb * (1.0f - GRID_NF_PRUNE_SLACK) : lb, t6);
   if (row_overflow) lb = 0.0f;
   lb6 = fminf(fminf(lb, rg2), clip_lo2);
   if (!inr) {

@@ -77,6 +77,12 @@ struct CertPlan {
   int32_t *ticket, *ticket_next;  // the next item to deal (sweep_queue_kernel)
 };
 constexpr int CERT_GROUP = 16;
+// SweepArgs::cert_stats: [0] points left to pass 2, [1] points swept by the workgroups that could leave some, [2] (certificate
+// sweep) points left to the tree search; from CERT_STATS_BY_SWEEP on, the grid sweep's [0], [1] once more by feature type
+// (corner, surf) and sweep of the loop (the last slot: that sweep and every later one): [type][sweep][listed, swept]
+constexpr int GRID_STATS_SWEEPS = 8;
+constexpr int CERT_STATS_BY_SWEEP = 8;
+constexpr int CERT_STATS_WORDS = CERT_STATS_BY_SWEEP + 2 * 2 * GRID_STATS_SWEEPS;
 constexpr float CERT_TRY_M_DEFAULT = 0.05f;    // SweepArgs::cert_try_m (LSLAM_CERT_TRY_M overrides)
 constexpr float CERT_TRACK_M_DEFAULT = 1.0f;   // SweepArgs::cert_track_m (LSLAM_CERT_TRACK_M)
 constexpr float CERT_RANGE_M = 40.0f;  // lever arm that turns a rotation update into a displacement (sweep_body's try test)

@@ -1143,20 +1143,48 @@ __global__ __launch_bounds__(256) void cert_plan_kernel(SweepArgs a, CertPlan pl
     *plan.count_next = 0;
     *plan.ticket_next = 0;
   }
-  if (g >= a.n_groups) return;
-  const GroupDesc gd = a.groups[g];
-  // the scans this sweep works on: the running loops -- or, for the _fineScore re-sweep, the converged ones (sweep_kernel)
-  if (a.fine_gate_c >= 0.0f ? !a.states[gd.prob].converged : a.states[gd.prob].done) return;
-  const int fb = gd.first_block - a.group_block_base;
-  int total = 0;
-  for (int k = 0; k < gd.n_blocks; ++k) {
-    total += level ? (int)a.need2_cnt[fb + k] : (int)a.need_cnt[fb + k];
-    if (!level && a.need2_cnt) a.need2_cnt[fb + k] = 0;
+  // debug tap of the grid sweep (lslam_opts.debug_stats): points listed for pass 2 / points swept, in total and by feature type
+  // and sweep of the loop.  Counted HERE, from the counts pass 1 left -- per workgroup of this (tiny) launch a histogram in
+  // LDS, then one atomic per non-empty slot -- so that a run with the tap on times the same sweep kernel as one without
+  const bool tap = a.cert_stats != nullptr && a.grid && !level;  // launch-uniform
+  __shared__ unsigned int hist[CERT_STATS_WORDS];
+  if (tap) {
+    if (threadIdx.x < CERT_STATS_WORDS) hist[threadIdx.x] = 0;
+    __syncthreads();
   }
-  const int nch = (total + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
-  if (nch == 0) return;
-  const int at = atomicAdd(plan.count, nch);
-  for (int c = 0; c < nch; ++c) plan.work[at + c] = g * CERT_GROUP + c;
+  bool on = g < a.n_groups;
+  GroupDesc gd{};
+  if (on) {
+    gd = a.groups[g];
+    // the scans this sweep works on: the running loops -- or, for the _fineScore re-sweep, the converged ones (sweep_kernel)
+    if (a.fine_gate_c >= 0.0f ? !a.states[gd.prob].converged : a.states[gd.prob].done) on = false;
+  }
+  if (on) {
+    const int fb = gd.first_block - a.group_block_base;
+    int total = 0;
+    for (int k = 0; k < gd.n_blocks; ++k) {
+      total += level ? (int)a.need2_cnt[fb + k] : (int)a.need_cnt[fb + k];
+      if (!level && a.need2_cnt) a.need2_cnt[fb + k] = 0;
+    }
+    if (tap) {
+      int swept = 0;
+      for (int k = 0; k < gd.n_blocks; ++k) swept += a.blocks[fb + k].count;
+      const int slot = CERT_STATS_BY_SWEEP + 2 * ((a.blocks[fb].is_surf ? GRID_STATS_SWEEPS : 0) + min(a.states[gd.prob].sweeps, GRID_STATS_SWEEPS - 1));
+      atomicAdd(&hist[0], (unsigned)total);
+      atomicAdd(&hist[1], (unsigned)swept);
+      atomicAdd(&hist[slot], (unsigned)total);
+      atomicAdd(&hist[slot + 1], (unsigned)swept);
+    }
+    const int nch = (total + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
+    if (nch > 0) {
+      const int at = atomicAdd(plan.count, nch);
+      for (int c = 0; c < nch; ++c) plan.work[at + c] = g * CERT_GROUP + c;
+    }
+  }
+  if (tap) {
+    __syncthreads();
+    if (threadIdx.x < CERT_STATS_WORDS && hist[threadIdx.x]) atomicAdd(a.cert_stats + threadIdx.x, (unsigned long long)hist[threadIdx.x]);
+  }
 }
 
 // sweep_queue_kernel, a resident grid that deals the work items round-robin: item (g, c) searches points [c BLOCK, (c + 1)
@@ -1462,13 +1490,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 
       // what pass 2's search may take for granted: five map points within this distance (padded like every bound)
       if (a.grid_hint) a.grid_hint[qi] = d[4] < 1.0e30f ? d[4] * (1.0f + 1e-5f) + 1e-12f : FLT_MAX;
     }
-    if (tid == 0) {
-      a.need_cnt[lb] = (uint16_t)total;
-      if (a.cert_stats) {  // debug tap: points left to pass 2 / points swept
-        atomicAdd(a.cert_stats, (unsigned long long)total);
-        atomicAdd(a.cert_stats + 1, (unsigned long long)bd.count);
-      }
-    }
+    if (tid == 0) a.need_cnt[lb] = (uint16_t)total;  // (the debug tap counts from these, in cert_plan_kernel)
   }
   const bool has = active && !needy;
   float row[6] = {0, 0, 0, 0, 0, 0};
@@ -1590,23 +1612,30 @@ LSLAM_DEV void wide_probe(const CellGrid &G, const float (&sel)[3], float r2, in
   row_id0[WIDE_ROWS_PER_LANE] = id;
   unresolved = unresolved || __any(id > GRID_ID_MASK + 1u);  // a lane saw more candidates than an id can count
   // the six smallest keys of the wavefront, smallest first: winner = the lowest lane that holds the minimum
+  // A lane keeps its SIX smallest keys only.  What it dropped is at least its sixth key away (truncated) -- which `rest`
+  // below covers as long as the lane still holds a key after the six rounds, and does not when all six winners were its own:
+  // then the bound is the sixth winner's key itself (dropped: that lane saw more than six candidates)
   int pos[6];
+  uint32_t dropped = 0xFFFFFFFFu;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     const uint32_t m = wave_min_u32(k0);
     const unsigned long long who = __ballot(k0 == m && m != 0xFFFFFFFFu);
     const int w = who ? __builtin_ctzll(who) : 0;
     int mine = -1;
+    bool dry = false;
     if (who && lane == w) {
       const uint32_t cid = k0 & GRID_ID_MASK;
 #pragma unroll
       for (int k = 0; k < WIDE_ROWS_PER_LANE; ++k)
         if (cid >= row_id0[k] && cid < row_id0[k + 1]) mine = (int)(row_s[k] + (cid - row_id0[k]));
       k0 = k1; k1 = k2; k2 = k3; k3 = k4; k4 = k5; k5 = 0xFFFFFFFFu;
+      dry = j == 5 && k0 == 0xFFFFFFFFu && id > 6u;
     }
     pos[j] = who ? __shfl(mine, w, 64) : -1;
+    if (j == 5 && __any(dry)) dropped = m;
   }
-  const uint32_t rest = wave_min_u32(k0);  // every other candidate's truncated distance is at least this
+  const uint32_t rest = min(wave_min_u32(k0), dropped);  // every other candidate's truncated distance is at least this
   // exact distances, sorted by the search's own insert (every lane computes the same)
   float e6 = FLT_MAX;
 #pragma unroll
@@ -1620,6 +1649,7 @@ LSLAM_DEV void wide_probe(const CellGrid &G, const float (&sel)[3], float r2, in
   }
   lb = fmaxf(e6, d[4]);
   knn_insert_sorted(d, p, e6, pos[5]);
+  if (lb < 1.0e30f) lb *= 1.0f - GRID_NF_PRUNE_SLACK_WIDE;  // (lslam_grid.hpp: the rounding of nanoflann's own pruning bound)
   if (rest != 0xFFFFFFFFu) lb = fminf(lb, __uint_as_float(rest & ~GRID_ID_MASK));
   // covered: every cell a point within (rb - slack) of the query can lie in has been scanned
   const float cov = rb - GRID_U_SLACK * G.c;

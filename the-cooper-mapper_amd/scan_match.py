@@ -163,6 +163,12 @@ class Context:
         self.lib.lslam_debug_cert_stats(self.h, out)
         return int(out[0]), int(out[1]), int(out[2])
 
+    def grid_stats(self):
+        """lslam_debug_grid_stats: uint64 [2 types][8 sweeps][listed, swept] of the grid sweeps run with debug_stats = 1."""
+        out = (C.c_uint64 * 32)()
+        self.lib.lslam_debug_grid_stats(self.h, out)
+        return np.array(list(out), np.uint64).reshape(2, 8, 2)
+
     def cert_state(self, n_points):
         """lslam_debug_cert_state: (positions of the last searches [n, 3], bounds [n]) of the resident scan points."""
         q = np.zeros((n_points, 4), np.float32)

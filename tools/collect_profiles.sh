@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (gpurun -- bash tools/collect_profiles.sh <tag>): bench line, rocprofv3 kernel
 # stats and the PMC passes the roofline object cites.  Results land in gpurun_out/<tag>_*.
-tag=${1:-r04}
+tag=${1:-r05}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 mkdir -p $out
@@ -41,6 +41,14 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_
   timeout 900 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/${tag}_lpmc/p$i -o p -- python3 $HL > $out/${tag}_lpmc_p$i.log 2>&1
 done
 python3 $root/tools/summarize_pmc.py sweep_kernel,sweep_queue_kernel,cert_plan_kernel $out/${tag}_lane_pmc_sweep.csv $out/${tag}_lpmc/p1 $out/${tag}_lpmc/p2 > /dev/null
+# The kept kernel statistics must reproduce the line they are kept beside (round 4's did not: the profiled command timed one
+# more step with a debug tap that cost two atomics per workgroup; the tap now counts in the planner's launch and the sweep
+# kernel is the same code with it on).  Fails loudly: a profile that disagrees with the line is not evidence.
+rc=0
+python3 $root/tools/check_profile_consistency.py $out/${tag}_headline.json $out/${tag}_headline_kernel_stats.csv > $out/${tag}_profile_check.txt 2>&1 || rc=1
+python3 $root/tools/check_profile_consistency.py $out/${tag}_lane_headline.json $out/${tag}_lane_headline_kernel_stats.csv >> $out/${tag}_profile_check.txt 2>&1 || rc=1
+cat $out/${tag}_profile_check.txt
 rm -rf $out/${tag}_lpmc $out/${tag}_lstats
 rm -rf $out/${tag}_pmc $out/${tag}_stats $out/${tag}_hstats   # raw traces are gigabytes; the summaries above are what is kept
 du -sh $out | tail -1
+if [ $rc -ne 0 ]; then echo "collect_profiles: PROFILE INCONSISTENT WITH THE LINE (see ${tag}_profile_check.txt)" >&2; exit 1; fi

@@ -90,6 +90,23 @@ for seed in range(n_seeds):
     status, pose, st = ctx.run(init, opts)
     if st.iterations != ost.iterations or abs(st.n_rows - ost.n_rows) > 2 or np.abs(pose[3:] - poses[1][3:]).max() > 2e-5 or np.abs(pose[:3] - poses[1][:3]).max() > 2e-6 or ctx.grid_launches() == g0:  # (a few ulps of a coordinate of tens of metres: the two sweeps group their sums differently)
         bad += 1; print("seed", seed, "grid sweep differs", st.iterations, ost.iterations, st.n_rows, ost.n_rows, np.abs(pose - poses[1]).max())
+    # ... and every sweep of that loop as the production loop runs it (the first bounded by the gate, the later ones with the
+    # probe clipped to the bound carried from the sweep before and the second pass started from it: LSLAM_SWEEP_FIRST /
+    # _CARRIED) against the oracle's sweep at the same pose: flags and coefficients of every point, indices and distances of
+    # every point the reference looks up (d2[4] < 5), bit for bit
+    pose_k = np.asarray(init, np.float32)
+    for k in range(8):
+        if k > 0:
+            opts.max_iterations = k
+            status, pose_k, st_k = ctx.run(init, opts)
+            if st_k.iterations < k or st_k.converged:
+                break
+        g = ctx.sweep(pose_k, jtj_mode=1, search_mode=3 | (0x400 if k > 0 else 0x800))
+        r = o.sweep(tc, ts, pr["corner"], pr["surf"], pose_k)
+        lk = (r["flags"] & 1) != 0
+        if not (np.array_equal(g["flags"], r["flags"]) and np.array_equal(bits(g["coeff"]), bits(r["coeff"]))
+                and np.array_equal(g["idx"][lk], r["idx"][lk]) and np.array_equal(bits(g["d2"])[lk], bits(r["d2"])[lk])):
+            bad += 1; print("seed", seed, "grid loop, sweep", k, "differs from the oracle's sweep at the same pose")
     # the same map with its kd-trees deferred (lslam_map_defer_trees: grids only, the wide probe for what the 27-cell probe cannot
     # prove; both the listed-points form and the in-place A/B form): the same loop up to summation order -- the rounded maps
     # hold exact ties, for which the call must build the trees after all and still agree

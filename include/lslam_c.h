@@ -619,7 +619,9 @@ int32_t lslam_pg_row_sharded_solves(const lslam_pg *pg); /* damped solves that t
  * and are summed in rank order on every rank (same bits everywhere).  A host with its own transport registers a second
  * callback type: in-place, segment r of buf = doubles [offsets[r], offsets[r + 1]), valid on rank r on entry and on every
  * rank on return; complete when it returns.  Ranges that are not the canonical partition, or no gather transport: the
- * all-reduce form.  At most 64 ranks. */
+ * all-reduce form.  Which form is taken is ONE decision of all ranks: the first solve after a change of range or transport
+ * sums a "my range is not the canonical one" flag over the ranks (one scalar all-reduce through the linearisation's
+ * transport) and every rank follows the result -- a rank cannot see the others' ranges.  At most 64 ranks. */
 typedef void (*lslam_allgatherv_fn)(void *user, double *buf, const int64_t *offsets, int32_t world);
 int lslam_pg_set_row_gather(lslam_pg *pg, lslam_allgatherv_fn fn, void *user, int32_t rank, int32_t world);
 int32_t lslam_pg_row_gathered_solves(const lslam_pg *pg); /* ... of which exchanged by all-gather */

@@ -44,11 +44,16 @@ public:
   // with the backend's message on the console -- the way the reference reports a failed match.
   explicit ScanMatch(const size_t maxIterations = 10, int device = 0) noexcept
       : _ctx(nullptr), _total_score(0), _match_count(0), _fail_match_count(0) {
-    lslam_default_opts(&_opts);
-    _opts.max_iterations = (int32_t)maxIterations;
+    // the ABI check FIRST: lslam_default_opts writes sizeof(lslam_opts) bytes as the LIBRARY was compiled -- with a larger
+    // struct there it would overrun _opts before the mismatch is seen
+    std::memset(&_opts, 0, sizeof(_opts));
     if (lslam_abi_version() != LSLAM_ABI_VERSION || lslam_sizeof_opts() != sizeof(lslam_opts) || lslam_sizeof_stats() != sizeof(lslam_stats)) {
       _init_error = "liblslam_hip was built from another include/lslam_c.h than this program (ABI version / struct sizes differ)";
-    } else if (lslam_ctx_create(device, &_ctx) != LSLAM_OK) {
+      return;
+    }
+    lslam_default_opts(&_opts);
+    _opts.max_iterations = (int32_t)maxIterations;
+    if (lslam_ctx_create(device, &_ctx) != LSLAM_OK) {
       _ctx = nullptr;
       _init_error = lslam_last_error();
     } else {

@@ -19,6 +19,7 @@ CELL = F(0.6)
 U_SLACK = F(2.0e-3)
 CLIP_MARGIN = F(3.0e-3)
 NF_SLACK = F(1.2e-5)
+KEY_SLACK = F(1.0e-6)   # the loop's key distance (one rounded square, two fused multiply-adds) against the exact one
 ID_BITS = 10
 FLT_MAX = np.finfo(np.float32).max
 
@@ -31,6 +32,14 @@ def dist2(q, p):
     """L2_Simple::evalMetric in fp32, x -> y -> z."""
     dx, dy, dz = F(q[0]) - p[..., 0], F(q[1]) - p[..., 1], F(q[2]) - p[..., 2]
     return ((dx * dx).astype(F) + (dy * dy).astype(F)).astype(F) + (dz * dz).astype(F)
+
+
+def key_dist2(q, p):
+    """knn5_grid's loop: fl(dx dx), then two fused multiply-adds (exact product, one rounding each)."""
+    d = (np.asarray(q, F)[None, :] - p.astype(F)).astype(F).astype(np.float64)
+    a = (d[:, 0] * d[:, 0]).astype(F).astype(np.float64)
+    a = (d[:, 1] * d[:, 1] + a).astype(F).astype(np.float64)   # double holds the exact product and sum of fp32 operands to < 1/2 ulp(fp32): one rounding
+    return (d[:, 2] * d[:, 2] + a).astype(F)
 
 
 class Grid:
@@ -84,12 +93,13 @@ class Grid:
             return "unproven", None, None
         cand = np.array(cand, int)
         d = dist2(q, self.pts[cand]) if len(cand) else np.zeros(0, F)
-        keys = (d.view(np.uint32) & np.uint32(~((1 << ID_BITS) - 1) & 0xFFFFFFFF)).astype(np.uint64) * 1024 + np.arange(len(cand), dtype=np.uint64)
+        dk = key_dist2(q, self.pts[cand]) if len(cand) else np.zeros(0, F)   # what the loop orders by
+        keys = (dk.view(np.uint32) & np.uint32(~((1 << ID_BITS) - 1) & 0xFFFFFFFF)).astype(np.uint64) * 1024 + np.arange(len(cand), dtype=np.uint64)
         order = np.argsort(keys, kind="stable")[:6]        # the six smallest truncated keys (ties by place in the walk)
         surv, e6 = cand[order], d[order]
         if len(surv) < 5:
             return "unproven", None, None
-        t6 = FLT_MAX if len(surv) < 6 else F(np.uint32(keys[order[5]] // 1024).view(F))
+        t6 = FLT_MAX if len(surv) < 6 else F(F(np.uint32(keys[order[5]] // 1024).view(F)) * (F(1.0) - KEY_SLACK))
         idx5, d5 = list(surv[:5]), list(e6[:5])
         lb = e6[5] if len(surv) == 6 else FLT_MAX
         if not all(e6[i] <= e6[i + 1] for i in range(len(e6) - 1)):   # two of the six within 2^-13: the search's own sorted insert

@@ -1016,6 +1016,17 @@ namespace {
 int ensure_trees(lslam_ctx *ctx) {
   if (!ctx->trees_pending) return LSLAM_OK;
   ctx->trees_pending = false;  // (a failure below leaves a map without trees: have_map goes false)
+  // a HIP error below leaves a map WITHOUT trees: it must not stay "set" (every later call would search what is not there)
+#define ET_TRY(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      ctx->have_map = false;                                                                  \
+      ctx->map_epoch++;                                                                       \
+      set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);     \
+      return LSLAM_ERR_HIP;                                                                   \
+    }                                                                                         \
+  } while (0)
   const double t0 = now_ms();
   DevTree *trees[2] = {&ctx->tc, &ctx->ts};
   GridDev *gd[2] = {&ctx->kc, &ctx->ks};
@@ -1024,16 +1035,16 @@ int ensure_trees(lslam_ctx *ctx) {
   for (int k = 0; k < 2; ++k) {
     DevTree &dt = *trees[k];
     const size_t n = (size_t)gd[k]->view.n_pts;
-    HIP_TRY(dt.pts.reserve(n ? n : 1));
+    ET_TRY(dt.pts.reserve(n ? n : 1));
     int fallback = 0;
     size_t n_leaves = 0;
     for (int attempt = dt.cap_attempt; attempt < 3; ++attempt) {
       const size_t mult[3] = {8, 16, 24};
       const size_t cap = ((mult[attempt] * n / 3 + 64) + 7) & ~(size_t)7;
-      HIP_TRY(dt.nodes.reserve(cap));
-      HIP_TRY(dt.own_box.reserve(cap * 6));
-      HIP_TRY(grid_unsort(gd[k]->view, dt.pts.p, ctx->stream));
-      HIP_TRY(build_kdtree_device(dt.pts.p, (int32_t)n, dt.nodes.p, dt.own_box.p, (int32_t)cap, ctx->stream, &dt.view, &dt.depth,
+      ET_TRY(dt.nodes.reserve(cap));
+      ET_TRY(dt.own_box.reserve(cap * 6));
+      ET_TRY(grid_unsort(gd[k]->view, dt.pts.p, ctx->stream));
+      ET_TRY(build_kdtree_device(dt.pts.p, (int32_t)n, dt.nodes.p, dt.own_box.p, (int32_t)cap, ctx->stream, &dt.view, &dt.depth,
                                   &n_leaves, &fallback));
       if (fallback != 1) {
         if (!fallback) dt.cap_attempt = attempt;
@@ -1063,6 +1074,7 @@ int ensure_trees(lslam_ctx *ctx) {
   ctx->info.build_attempts = attempts_used;
   ctx->lazy_builds++;
   return LSLAM_OK;
+#undef ET_TRY
 }
 }  // namespace
 

@@ -258,20 +258,26 @@ hipError_t GridDev::build(const float4 *src, int n_src, const float lo[3], const
   }
   G.nx = dims[0]; G.ny = dims[1]; G.nz = dims[2];
   const size_t ncell = (size_t)G.nx * G.ny * G.nz;
-  if (ncell > ((size_t)1 << 30)) { *status = 2; return hipSuccess; }
+  // The two dense tables (count, cell_start: 8 bytes per cell) are memset / rewritten in full by every build: a map that is wide
+  // but sparse must not cost gigabytes of both.  GRID_MAX_CELLS cells (512 MB per type; the bench surround has 16 M), or 4 096
+  // cells per point, whichever is smaller -- beyond it there is no grid (status 2) and the kd-tree search is used, as for a
+  // map larger than GRID_MAX_DIM cells on an axis.
+  if (ncell > GRID_MAX_CELLS || ncell > (size_t)4096 * (size_t)std::max(n_src, 4096)) { *status = 2; return hipSuccess; }
   const int n = n_src;
   hipError_t e;
 #define G_TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
-  G_TRY(reserve(pts, cap_pts, (size_t)n + 16));
-  G_TRY(reserve(tmp_pts, cap_tmp, (size_t)n + 16));
-  G_TRY(reserve(cell_start, cap_cell, ncell + 1));
+  // An allocation that fails is "no grid" (status 3), not a failed call: the tree search needs none of these arrays.
+#define G_ALLOC(x) do { e = (x); if (e != hipSuccess) { (void)hipGetLastError(); release(); *status = 3; return hipSuccess; } } while (0)
+  G_ALLOC(reserve(pts, cap_pts, (size_t)n + 16));
+  G_ALLOC(reserve(tmp_pts, cap_tmp, (size_t)n + 16));
+  G_ALLOC(reserve(cell_start, cap_cell, ncell + 1));
   const size_t n_coarse = (ncell + CS_CELLS - 1) / CS_CELLS;
-  G_TRY(reserve(coarse, cap_coarse, n_coarse));
-  G_TRY(reserve(err, cap_err, 1));
+  G_ALLOC(reserve(coarse, cap_coarse, n_coarse));
+  G_ALLOC(reserve(err, cap_err, 1));
   {
     // the count table is left zeroed by every build (the scatter counts it down); only a new allocation is cleared
     const size_t before = cap_count;
-    G_TRY(reserve(count, cap_count, ncell + 16));
+    G_ALLOC(reserve(count, cap_count, ncell + 16));
     if (cap_count != before || !count_clean) G_TRY(hipMemsetAsync(count, 0, cap_count * sizeof(uint32_t), s));
     count_clean = false;
   }
@@ -294,6 +300,7 @@ hipError_t GridDev::build(const float4 *src, int n_src, const float lo[3], const
     G_TRY(hipStreamSynchronize(s));
   }
 #undef G_TRY
+#undef G_ALLOC
   if (h_err) { *status = 1; return hipSuccess; }
   G.cell_start = cell_start;
   G.pts = pts;

@@ -43,6 +43,7 @@ struct CellGrid {
 #endif
 constexpr float GRID_CELL_DEFAULT = 0.6f;
 constexpr int GRID_MAX_DIM = 2048;        // cells per axis (the rounding slack below is sized for it)
+constexpr size_t GRID_MAX_CELLS = (size_t)1 << 26;  // cells per table: two dense 4-byte tables rewritten by every build (lslam_grid.hip)
 // Rounding of the cell coordinate u(v) = fl(fl(v - o) * inv_c): relative error <= 2^-23 on a value < GRID_MAX_DIM, so two
 // points whose cell coordinates differ by w are at least (w - GRID_U_SLACK) cells apart on that axis.
 constexpr float GRID_U_SLACK = 2.0e-3f;
@@ -60,6 +61,9 @@ constexpr float GRID_CLIP_MARGIN_MIN = 3.0e-3f;  // [m] smallest padding of a cl
 // (sweep_wide_kernel) has no tree walk to hand a point to -- a refusal there builds the trees and repeats the call -- and
 // uses GRID_NF_PRUNE_SLACK_WIDE = 8 ulps (five adversarially rounded far steps in a row onto a box corner).
 constexpr float GRID_NF_PRUNE_SLACK = 1.2e-5f;
+// a candidate's KEY distance (knn5_grid's loop: one rounded square and two fused multiply-adds) against its exact fp32 distance
+// (five roundings): they differ by at most ~3 ulps; a bound taken from a key is shrunk by 8 ulps
+constexpr float GRID_KEY_SLACK = 1.0e-6f;
 constexpr float GRID_NF_PRUNE_SLACK_WIDE = 9.6e-7f;
 inline int grid_margin_cells(float c) { return (int)(2.2361f / c) + 3; }
 
@@ -209,7 +213,11 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
     nend = rows[3 * BLOCK];
   }
 #if LSLAM_GRID_ASM_LOOP
-  // The loop by hand: 21 vector instructions per candidate + 11 in rounds in which a lane changes rows (left to the compiler
+  // (The loop's distance is a KEY, not the reference's distance: dx dx, then two fused multiply-adds -- six instructions instead
+  // of the eight of L2_Simple's rounded squares and sums.  It differs from the exact fp32 distance by at most a few ulps
+  // (three roundings against five), which the proof accounts for where it turns the sixth key into a bound: GRID_KEY_SLACK.
+  // The exact distances of the six survivors are re-evaluated with the reference's arithmetic below.)
+  // The loop by hand: 19 vector instructions per candidate + 11 in rounds in which a lane changes rows (left to the compiler
   // the same loop carried eleven register copies and a three-deep exec-mask nest per round), software-pipelined one
   // candidate deep: the point of candidate i + 1 is requested -- which takes knowing where candidate i + 1 is, i.e. the row
   // bookkeeping of candidate i -- before the distance of candidate i is evaluated, so a round's load latency hides behind
@@ -227,15 +235,42 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
     register uint32_t l1 asm("v11");
     uint32_t curb = cur << 4, endb = end << 4, ncurb = ncur << 4, nendb = nend << 4;
     unsigned long long am = __builtin_amdgcn_ballot_w64(alive);
-    unsigned long long adv, tmp, ama, amb;
+    unsigned long long adv, tmp;
     uint32_t t0, t1, key, ida, idb;
     const uint32_t rowaddr = (uint32_t)(uintptr_t)rows;
     const uint32_t keep = ~IDM;
-#define LSLAM_GRID_ISSUE(AM, ID, P)                       \
-  "s_mov_b64 " AM ", %[am]\n\t"                          \
-  "v_mov_b32 " ID ", %[id]\n\t"                          \
+// (a lane that has run out of candidates carries the id 0xFFFFFFFF: `(dist & keep) | id` is then the empty key, no select)
+#ifdef LSLAM_EXP_LOAD2   // TIMING EXPERIMENT ONLY (wrong results): 8 bytes per candidate through the L1 instead of 12
+#define LSLAM_GRID_LOADOP "global_load_dwordx2 "
+#define LSLAM_GRID_PA "v[2:3]"
+#define LSLAM_GRID_PB "v[6:7]"
+#else
+#define LSLAM_GRID_LOADOP "global_load_dwordx3 "
+#define LSLAM_GRID_PA "v[2:4]"
+#define LSLAM_GRID_PB "v[6:8]"
+#endif
+#ifdef LSLAM_EXP_LOAD_TWICE  // TIMING EXPERIMENT ONLY (same results): every candidate requested twice -- twice the bytes through the L1
+#define LSLAM_GRID_VMW "s_waitcnt vmcnt(2)\n\t"
+#define LSLAM_GRID_LOAD_AGAIN(P, A) LSLAM_GRID_LOADOP P ", " A ", %[base]\n\t"
+#else
+#define LSLAM_GRID_VMW "s_waitcnt vmcnt(1)\n\t"
+#define LSLAM_GRID_LOAD_AGAIN(P, A)
+#endif
+#define LSLAM_GRID_ISSUE(ID, P)                       \
+  "v_cndmask_b32 " ID ", -1, %[id], %[am]\n\t"           \
   "v_cndmask_b32 %[t0], 0, %[curb], %[am]\n\t"           \
-  "global_load_dwordx3 " P ", %[t0], %[base]\n\t"
+  LSLAM_GRID_LOADOP P ", %[t0], %[base]\n\t" LSLAM_GRID_LOAD_AGAIN(P, "%[t0]")
+#ifdef LSLAM_EXP_PROCESS_TWICE  // TIMING EXPERIMENT ONLY: the key distance evaluated twice (six more vector instructions per candidate)
+#define LSLAM_GRID_EXTRA(PX, PY, PZ)                     \
+  "v_sub_f32 %[t0], %[qx], " PX "\n\t"                   \
+  "v_mul_f32 %[t0], %[t0], %[t0]\n\t"                    \
+  "v_sub_f32 %[t1], %[qy], " PY "\n\t"                   \
+  "v_fmac_f32 %[t0], %[t1], %[t1]\n\t"                   \
+  "v_sub_f32 %[t1], %[qz], " PZ "\n\t"                   \
+  "v_fmac_f32 %[t0], %[t1], %[t1]\n\t"
+#else
+#define LSLAM_GRID_EXTRA(PX, PY, PZ)
+#endif
 #define LSLAM_GRID_ADVANCE(L)                                        \
   "v_add_u32 %[curb], 16, %[curb]\n\t"                              \
   "v_add_u32 %[id], 1, %[id]\n\t"                                   \
@@ -257,17 +292,15 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
   "v_lshlrev_b32 %[ncurb], 4, %[l0]\n\t"                            \
   "v_lshlrev_b32 %[nendb], 4, %[l1]\n"                               \
   "L_grid_noadv" L "_%=:\n\t"
-#define LSLAM_GRID_PROCESS(AM, ID, PX, PY, PZ)            \
+#define LSLAM_GRID_PROCESS(ID, PX, PY, PZ)            \
+  LSLAM_GRID_EXTRA(PX, PY, PZ)                           \
   "v_sub_f32 %[t0], %[qx], " PX "\n\t"                   \
   "v_mul_f32 %[t0], %[t0], %[t0]\n\t"                    \
   "v_sub_f32 %[t1], %[qy], " PY "\n\t"                   \
-  "v_mul_f32 %[t1], %[t1], %[t1]\n\t"                    \
-  "v_add_f32 %[t0], %[t0], %[t1]\n\t"                    \
+  "v_fmac_f32 %[t0], %[t1], %[t1]\n\t"                   \
   "v_sub_f32 %[t1], %[qz], " PZ "\n\t"                   \
-  "v_mul_f32 %[t1], %[t1], %[t1]\n\t"                    \
-  "v_add_f32 %[t0], %[t0], %[t1]\n\t"                    \
+  "v_fmac_f32 %[t0], %[t1], %[t1]\n\t"                   \
   "v_and_or_b32 %[key], %[t0], %[keep], " ID "\n\t"      \
-  "v_cndmask_b32 %[key], -1, %[key], " AM "\n\t"         \
   "v_med3_u32 %[k5], %[k4], %[k5], %[key]\n\t"           \
   "v_med3_u32 %[k4], %[k3], %[k4], %[key]\n\t"           \
   "v_med3_u32 %[k3], %[k2], %[k3], %[key]\n\t"           \
@@ -277,38 +310,44 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
     asm volatile(
         "s_cmp_eq_u64 %[am], 0\n\t"
         "s_cbranch_scc1 L_grid_done_%=\n\t"
-        LSLAM_GRID_ISSUE("%[ama]", "%[ida]", "v[2:4]")
+        LSLAM_GRID_ISSUE("%[ida]", LSLAM_GRID_PA)
         LSLAM_GRID_ADVANCE("0")
         "L_grid_loop_%=:\n\t"
         "s_cmp_eq_u64 %[am], 0\n\t"
         "s_cbranch_scc1 L_grid_lasta_%=\n\t"
-        LSLAM_GRID_ISSUE("%[amb]", "%[idb]", "v[6:8]")
+        LSLAM_GRID_ISSUE("%[idb]", LSLAM_GRID_PB)
         LSLAM_GRID_ADVANCE("1")
-        "s_waitcnt vmcnt(1)\n\t"
-        LSLAM_GRID_PROCESS("%[ama]", "%[ida]", "%[pax]", "%[pay]", "%[paz]")
+        LSLAM_GRID_VMW
+        LSLAM_GRID_PROCESS("%[ida]", "%[pax]", "%[pay]", "%[paz]")
         "s_cmp_eq_u64 %[am], 0\n\t"
         "s_cbranch_scc1 L_grid_lastb_%=\n\t"
-        LSLAM_GRID_ISSUE("%[ama]", "%[ida]", "v[2:4]")
+        LSLAM_GRID_ISSUE("%[ida]", LSLAM_GRID_PA)
         LSLAM_GRID_ADVANCE("2")
-        "s_waitcnt vmcnt(1)\n\t"
-        LSLAM_GRID_PROCESS("%[amb]", "%[idb]", "%[pbx]", "%[pby]", "%[pbz]")
+        LSLAM_GRID_VMW
+        LSLAM_GRID_PROCESS("%[idb]", "%[pbx]", "%[pby]", "%[pbz]")
         "s_branch L_grid_loop_%=\n"
         "L_grid_lasta_%=:\n\t"
         "s_waitcnt vmcnt(0)\n\t"
-        LSLAM_GRID_PROCESS("%[ama]", "%[ida]", "%[pax]", "%[pay]", "%[paz]")
+        LSLAM_GRID_PROCESS("%[ida]", "%[pax]", "%[pay]", "%[paz]")
         "s_branch L_grid_done_%=\n"
         "L_grid_lastb_%=:\n\t"
         "s_waitcnt vmcnt(0)\n\t"
-        LSLAM_GRID_PROCESS("%[amb]", "%[idb]", "%[pbx]", "%[pby]", "%[pbz]")
+        LSLAM_GRID_PROCESS("%[idb]", "%[pbx]", "%[pby]", "%[pbz]")
         "L_grid_done_%=:\n\t"
         : [k0] "+v"(k0), [k1] "+v"(k1), [k2] "+v"(k2), [k3] "+v"(k3), [k4] "+v"(k4), [k5] "+v"(k5), [curb] "+v"(curb), [endb] "+v"(endb),
           [ncurb] "+v"(ncurb), [nendb] "+v"(nendb), [id] "+v"(id), [k] "+v"(k), [am] "+s"(am), [adv] "=&s"(adv), [tmp] "=&s"(tmp),
-          [ama] "=&s"(ama), [amb] "=&s"(amb), [t0] "=&v"(t0), [t1] "=&v"(t1), [key] "=&v"(key), [ida] "=&v"(ida), [idb] "=&v"(idb),
+          [t0] "=&v"(t0), [t1] "=&v"(t1), [key] "=&v"(key), [ida] "=&v"(ida), [idb] "=&v"(idb),
           [pax] "=&v"(pax), [pay] "=&v"(pay), [paz] "=&v"(paz), [pbx] "=&v"(pbx), [pby] "=&v"(pby), [pbz] "=&v"(pbz), [l0] "=&v"(l0), [l1] "=&v"(l1)
         : [qx] "v"(qx), [qy] "v"(qy), [qz] "v"(qz), [nrow] "v"(nrow), [rowaddr] "v"(rowaddr), [base] "s"(G.pts), [keep] "s"(keep),
           [nlast] "n"(NR - 1)
         : "vcc", "scc", "memory");
 #undef LSLAM_GRID_ISSUE
+#undef LSLAM_GRID_EXTRA
+#undef LSLAM_GRID_VMW
+#undef LSLAM_GRID_LOAD_AGAIN
+#undef LSLAM_GRID_LOADOP
+#undef LSLAM_GRID_PA
+#undef LSLAM_GRID_PB
 #undef LSLAM_GRID_ADVANCE
 #undef LSLAM_GRID_PROCESS
   }
@@ -379,7 +418,7 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
   }
   // everybody who is not a survivor is at least the sixth key's truncated distance away; the sixth exact distance less
   // nanoflann's pruning slack (FLT_MAX stays FLT_MAX: no sixth candidate at all)
-  const float t6 = (k5 != 0xFFFFFFFFu) ? __uint_as_float(k5 & ~IDM) : FLT_MAX;
+  const float t6 = (k5 != 0xFFFFFFFFu) ? __uint_as_float(k5 & ~IDM) * (1.0f - GRID_KEY_SLACK) : FLT_MAX;
   lb = fminf(lb < 1.0e30f ? lb * (1.0f - GRID_NF_PRUNE_SLACK) : lb, t6);
   if (row_overflow) lb = 0.0f;
   lb6 = fminf(fminf(lb, rg2), clip_lo2);

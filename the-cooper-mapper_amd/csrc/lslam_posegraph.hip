@@ -1585,6 +1585,8 @@ struct lslam_pg {
   void *gatherv_user = nullptr;
   int gatherv_rank = -1, gatherv_world = 0;
   int rs_gathered = 0;
+  int rs_agree_v0 = -2, rs_agree_v1 = -2, rs_agree_world = -1;  // the setting the ranks last agreed on ...
+  bool rs_agree_gather = false;                                  // ... and what they agreed: every rank's rows are the canonical partition
   // rank / world of whichever transport can gather; false: only the all-reduce is available
   bool gather_transport(int *rank, int *world) const {
     if (gatherv) { *rank = gatherv_rank; *world = gatherv_world; return true; }
@@ -1890,7 +1892,25 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
     if (gather) {
       int cb = 0, ce = 0;
       lslam_pg_row_shard_range(pg->n_v, g_rank, g_world, &cb, &ce);
-      gather = cb == v0 && ce == v1;
+      // Gather or all-reduce is ONE decision of all ranks: a rank that gathered (grouped broadcasts) while another all-reduced
+      // would hang the solve.  lslam_pg_set_row_shard accepts any whole-block range, so a rank cannot tell from its own range
+      // what the others hold: the ranks sum a "my range is not the canonical one" flag once per (range, transport) setting
+      // and gather only if nobody raised it.
+      const bool mine = cb == v0 && ce == v1;
+      if (pg->rs_agree_v0 != v0 || pg->rs_agree_v1 != v1 || pg->rs_agree_world != g_world) {
+        double flag = mine ? 0.0 : 1.0;
+        PG_TRY(hipMemcpyAsync(X + n6 + 7, &flag, sizeof(double), hipMemcpyHostToDevice, pg->stream));
+        PG_TRY(hipStreamSynchronize(pg->stream));  // (flag is a local)
+        int rc_a = pg->reduce(X + n6 + 7, 1);
+        if (rc_a) return rc_a;
+        PG_TRY(hipMemcpyAsync(&flag, X + n6 + 7, sizeof(double), hipMemcpyDeviceToHost, pg->stream));
+        PG_TRY(hipStreamSynchronize(pg->stream));
+        pg->rs_agree_v0 = v0;
+        pg->rs_agree_v1 = v1;
+        pg->rs_agree_world = g_world;
+        pg->rs_agree_gather = flag == 0.0;
+      }
+      gather = pg->rs_agree_gather;
       z_offs.resize((size_t)g_world + 1);
       s_offs.resize((size_t)g_world + 1);
       for (int r = 0; r <= g_world; ++r) {
@@ -2398,6 +2418,7 @@ int lslam_pg_set_row_gather(lslam_pg *pg, lslam_allgatherv_fn fn, void *user, in
     g_pg_err = "bad rank / world for the row gather";
     return LSLAM_ERR_INVALID;
   }
+  pg->rs_agree_world = -1;  // another transport: the ranks agree again
   pg->gatherv = fn;
   pg->gatherv_user = user;
   pg->gatherv_rank = fn ? rank : -1;
@@ -2408,6 +2429,7 @@ int lslam_pg_set_row_gather(lslam_pg *pg, lslam_allgatherv_fn fn, void *user, in
 int lslam_pg_set_comm(lslam_pg *pg, lslam_comm *comm) {
   if (!pg) return LSLAM_ERR_INVALID;
   pg->comm = comm;
+  pg->rs_agree_world = -1;  // another transport: the ranks agree again
   return LSLAM_OK;
 }
 int32_t lslam_pg_num_offdiag(const lslam_pg *pg) { return pg ? pg->n_off : 0; }

@@ -1838,6 +1838,16 @@ namespace {
 // Phase 0 driver: processes `level` (every entry more than HUGE_MIN points) and the levels it
 // spawns; smaller children land in A.queue / A.sublist.  n = points the trees span in total.
 // n: points of all roots together (capacities); n_largest: of the largest root (how many levels the first batch enqueues)
+// hipMemcpyAsync from / into LOCALS of the builders below (item lists, control blocks, read-back buffers): on every normal path
+// a builder waits for the stream before it returns -- its read-backs need that anyway.  Its ERROR returns do the same through
+// this macro, so that no copy is ever in flight from or into a frame that has been left.  (The tree build is off the per-frame
+// path since the trees are deferred: a context-owned pinned staging area would buy nothing here.)
+#define TB_RETURN_SETTLED(stream, err)        \
+  do {                                        \
+    (void)hipStreamSynchronize(stream);       \
+    return (err);                             \
+  } while (0)
+
 hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t n, hipStream_t stream, int *fallback, const RootInit *root_init = nullptr,
                       int32_t n_largest = 0, const float *forest_part = nullptr) {
   if (n_largest <= 0) n_largest = n;
@@ -1847,7 +1857,7 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
   const int cap_nodes = n / A.huge_min * 2 + n_first + 8, cap_chunks = n / LV_CH + cap_nodes + 8;
   const size_t sz_items = (size_t)cap_nodes * sizeof(BuildItem), sz_stat = (size_t)cap_nodes * sizeof(LvStat),
                sz_ci = (size_t)cap_chunks * sizeof(int32_t), sz_ni = (size_t)cap_nodes * sizeof(int32_t);
-  if ((e = pool_get(stream, true, 2 * sz_items + 2 * sz_stat + 5 * sz_ci + sz_ni + (size_t)cap_chunks * sizeof(LvChunk) + 128, &lv_blob)) != hipSuccess) return e;
+  if ((e = pool_get(stream, true, 2 * sz_items + 2 * sz_stat + 5 * sz_ci + sz_ni + (size_t)cap_chunks * sizeof(LvChunk) + 128, &lv_blob)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
   char *q = static_cast<char *>(lv_blob);
   BuildItem *d_items[2];
   d_items[0] = reinterpret_cast<BuildItem *>(q); q += sz_items;
@@ -1885,10 +1895,10 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
     }
     lv_stat_reset(stat0[(size_t)j]);
   }
-  // (pageable sources: consumed when hipMemcpyAsync returns, no wait needed)
-  if ((e = hipMemcpyAsync(d_items[0], level.data(), (size_t)n_first * sizeof(BuildItem), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-  if ((e = hipMemcpyAsync(d_stat[0], stat0.data(), (size_t)n_first * sizeof(LvStat), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-  if ((e = hipMemcpyAsync(d_small, init, sizeof(init), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+  // (sources are locals: every return below this point -- TB_RETURN_SETTLED on the error paths, the read-back's wait on the normal one -- leaves the stream settled)
+  if ((e = hipMemcpyAsync(d_items[0], level.data(), (size_t)n_first * sizeof(BuildItem), hipMemcpyHostToDevice, stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
+  if ((e = hipMemcpyAsync(d_stat[0], stat0.data(), (size_t)n_first * sizeof(LvStat), hipMemcpyHostToDevice, stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
+  if ((e = hipMemcpyAsync(d_small, init, sizeof(init), hipMemcpyHostToDevice, stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
   // a forest's roots arrive without their boxes: filled in from the per-slice boxes, with the extrema (kd_forest_patch_kernel)
   if (forest_part)
     hipLaunchKernelGGL(kd_forest_patch_kernel, dim3((n_first + 255) / 256), dim3(256), 0, stream, forest_part, d_items[0], d_stat[0], n_first,
@@ -1941,8 +1951,8 @@ hipError_t run_levels(const BuildArgs &A, std::vector<BuildItem> level, int32_t 
     }
     int32_t remaining = 0;
     const double t_enq1 = now_us();
-    if ((e = hipMemcpyAsync(&remaining, d_small + (lvl & 1), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(&remaining, d_small + (lvl & 1), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
     if (dbg) fprintf(stderr, "[lslam] levels batch %d: %d levels enqueued in %.0f us (host), device done %.0f us later\n", batch, per_batch,
                      t_enq1 - t_enq0, now_us() - t_enq1);
     if (remaining == 0) return hipSuccess;
@@ -1985,15 +1995,15 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, float 
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     BuildPool &bp = g_pool[stream];
-    if (!bp.part && (e = hipMalloc(&bp.part, NB * 6 * sizeof(float))) != hipSuccess) return e;
+    if (!bp.part && (e = hipMalloc(&bp.part, NB * 6 * sizeof(float))) != hipSuccess) TB_RETURN_SETTLED(stream, e);
     d_part = static_cast<float *>(bp.part);
   }
   hipLaunchKernelGGL(kd_bbox_kernel, dim3(NB), dim3(256), 0, stream, d_pts, n, d_part);
   const int used = std::min(NB, (n + 255) / 256);
   if (n <= 10) {  // the root is a leaf: only the box is needed
     float h_part[NB * 6];
-    if ((e = hipMemcpyAsync(h_part, d_part, sizeof(float) * 6 * (size_t)used, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(h_part, d_part, sizeof(float) * 6 * (size_t)used, hipMemcpyDeviceToHost, stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
     for (int d = 0; d < 3; ++d) {
       float a = h_part[d], b = h_part[3 + d];
       for (int k = 1; k < used; ++k) { a = std::min(a, h_part[k * 6 + d]); b = std::max(b, h_part[k * 6 + 3 + d]); }
@@ -2034,7 +2044,7 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, float 
   const bool tiny_phase = tiny_phase_enabled() && A.reg_nodes;
   const int32_t tiny_cap = tiny_phase ? n / 11 + 2 : 0;
   const size_t sz_tiny = tiny_phase ? ((size_t)tiny_cap * sizeof(BuildItem) + TINY_ACC * 128 + 127) & ~(size_t)127 : 0;
-  if ((e = pool_get(stream, false, sz_queue + sz_sub + sz_ready + 2 * sz_tmp + sz_ctl + sz_tiny + 128, &blob)) != hipSuccess) return e;
+  if ((e = pool_get(stream, false, sz_queue + sz_sub + sz_ready + 2 * sz_tmp + sz_ctl + sz_tiny + 128, &blob)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
   char *p = static_cast<char *>(blob);
   A.queue = reinterpret_cast<BuildItem *>(p); p += sz_queue;
   A.sublist = reinterpret_cast<BuildItem *>(p); p += sz_sub;
@@ -2046,11 +2056,11 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, float 
   A.tiny_acc = tiny_phase ? reinterpret_cast<int32_t *>(p) : nullptr;
   A.tiny_list = tiny_phase ? reinterpret_cast<BuildItem *>(p + TINY_ACC * 128) : nullptr;
   A.tiny_cap = tiny_cap;
-  if (tiny_phase && (e = hipMemsetAsync(p, 0, sz_tiny, stream)) != hipSuccess) return e;
+  if (tiny_phase && (e = hipMemsetAsync(p, 0, sz_tiny, stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
   A.own_box = d_own_box;
   A.root_feat = &A.ctl->root_feat;
-  if ((e = hipMemsetAsync(A.q_ready, 0, sz_ready, stream)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(d_nodes, 0, (size_t)A.node_cap * sizeof(KdNode), stream)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(A.q_ready, 0, sz_ready, stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
+  if ((e = hipMemsetAsync(d_nodes, 0, (size_t)A.node_cap * sizeof(KdNode), stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
   BuildCtl ctl{};
   const bool root_small = n <= LOCAL_MAX;
   const bool no_levels = env_once().no_level_build;  // A/B switch
@@ -2067,7 +2077,7 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, float 
   R.bbox_out = reinterpret_cast<float *>(reinterpret_cast<char *>(A.ctl) + 128);
   if (root_huge) {
     // ---- phase 0: level-synchronous processing of the nodes with more than HUGE_MIN points ----
-    if ((e = run_levels(A, std::vector<BuildItem>(), n, stream, fallback, &R)) != hipSuccess) return e;
+    if ((e = run_levels(A, std::vector<BuildItem>(), n, stream, fallback, &R)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
     if (*fallback) return hipSuccess;
   } else {
     R.mode = root_small ? 2 : 1;  // the whole tree is one phase-B subtree / the root enters the phase-A queue
@@ -2077,7 +2087,7 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, float 
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  if (dbg && (e = hipStreamSynchronize(stream)) != hipSuccess) return e;  // only to split the timing below
+  if (dbg && (e = hipStreamSynchronize(stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);  // only to split the timing below
   const double T2 = now();
   // after the levels: what they left between LOCAL_MAX and HUGE_MIN, one workgroup per node; without levels (a root below
   // LEVELS_MIN_POINTS): the root enters phase A's queue
@@ -2088,12 +2098,12 @@ hipError_t build_kdtree_device(float4 *d_pts, int32_t n, KdNode *d_nodes, float 
   }
   hipLaunchKernelGGL(kd_build_small_kernel, dim3(cus * 16), dim3(TB_SMALL), 0, stream, A);
   if (tiny_phase) hipLaunchKernelGGL(kd_build_tiny_kernel, dim3(std::min(cus * 64, (tiny_cap + TINY_SLOTS - 1) / TINY_SLOTS)), dim3(64), 0, stream, A);
-  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if ((e = hipGetLastError()) != hipSuccess) TB_RETURN_SETTLED(stream, e);
   char ctl_blob[256];  // [BuildCtl | ... | box at byte 128]
-  if ((e = hipMemcpyAsync(ctl_blob, A.ctl, sizeof(ctl_blob), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(ctl_blob, A.ctl, sizeof(ctl_blob), hipMemcpyDeviceToHost, stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
   int32_t acc[TINY_ACC * 32];
-  if (tiny_phase && (e = hipMemcpyAsync(acc, A.tiny_acc, sizeof(acc), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+  if (tiny_phase && (e = hipMemcpyAsync(acc, A.tiny_acc, sizeof(acc), hipMemcpyDeviceToHost, stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
+  if ((e = hipStreamSynchronize(stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
   std::memcpy(&ctl, ctl_blob, sizeof(ctl));
   {
     float bb[6];
@@ -2158,7 +2168,7 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   const int32_t tiny_cap = tiny_phase ? n_total / 11 + 2 : 0;
   const size_t sz_tiny = tiny_phase ? ((size_t)tiny_cap * sizeof(BuildItem) + TINY_ACC * 128 + 127) & ~(size_t)127 : 0;
   void *blob = nullptr;
-  if ((e = pool_get(stream, false, sz_queue + sz_sub + sz_ready + 2 * sz_tmp + sz_ctl + sz_rf + sz_lr + sz_bb + sz_tiny + sz_own + 128, &blob)) != hipSuccess) return e;
+  if ((e = pool_get(stream, false, sz_queue + sz_sub + sz_ready + 2 * sz_tmp + sz_ctl + sz_rf + sz_lr + sz_bb + sz_tiny + sz_own + 128, &blob)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
   char *p = static_cast<char *>(blob);
   A.queue = reinterpret_cast<BuildItem *>(p); p += sz_queue;
   A.sublist = reinterpret_cast<BuildItem *>(p); p += sz_sub;
@@ -2175,16 +2185,16 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   A.tiny_acc = tiny_phase ? reinterpret_cast<int32_t *>(p) : nullptr;
   A.tiny_list = tiny_phase ? reinterpret_cast<BuildItem *>(p + TINY_ACC * 128) : nullptr;
   A.tiny_cap = tiny_cap;
-  if (tiny_phase && (e = hipMemsetAsync(p, 0, sz_tiny, stream)) != hipSuccess) return e;
+  if (tiny_phase && (e = hipMemsetAsync(p, 0, sz_tiny, stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
   p += sz_tiny;
   A.own_box = d_pn ? reinterpret_cast<float *>(p) : nullptr;
   A.spin_limit = 1u << 22;
-  if ((e = hipMemcpyAsync(d_lr, roots_lr, (size_t)T * 8, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(d_lr, roots_lr, (size_t)T * 8, hipMemcpyHostToDevice, stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
   // per-slice boxes of every root; nobody waits for them: the root items are made below without their boxes and patched
   // on the device, the views get theirs with the read-back at the end of the build
   hipLaunchKernelGGL(kd_bbox_seg_kernel, dim3(T, FOREST_SLICES), dim3(256), 0, stream, d_pts, d_lr, d_part);
-  if ((e = hipMemsetAsync(d_nodes, 0, (size_t)A.node_cap * sizeof(KdNode), stream)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(A.root_feat, 0, sz_rf, stream)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(d_nodes, 0, (size_t)A.node_cap * sizeof(KdNode), stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
+  if ((e = hipMemsetAsync(A.root_feat, 0, sz_rf, stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
   std::vector<BuildItem> level, medium, small;
   std::vector<int32_t> slot_of(T, -1);
   int groups = 0, leaves = 0;
@@ -2223,14 +2233,14 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   ctl.n_sub = (int32_t)small.size();
   ctl.q_tail_reserved = (int32_t)medium.size();
   ctl.n_leaves = leaves;
-  if ((e = hipMemcpyAsync(A.ctl, &ctl, sizeof(ctl), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-  // (pageable sources: consumed when hipMemcpyAsync returns, no wait needed)
+  if ((e = hipMemcpyAsync(A.ctl, &ctl, sizeof(ctl), hipMemcpyHostToDevice, stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
+  // (sources are locals: every return below this point -- TB_RETURN_SETTLED on the error paths, the read-back's wait on the normal one -- leaves the stream settled)
   if (!small.empty() &&
       (e = hipMemcpyAsync(A.sublist, small.data(), small.size() * sizeof(BuildItem), hipMemcpyHostToDevice, stream)) != hipSuccess)
-    return e;
+    TB_RETURN_SETTLED(stream, e);
   if (!medium.empty() &&
       (e = hipMemcpyAsync(A.queue, medium.data(), medium.size() * sizeof(BuildItem), hipMemcpyHostToDevice, stream)) != hipSuccess)
-    return e;
+    TB_RETURN_SETTLED(stream, e);
   // the wavefront-local roots' boxes, and every tree's box for its view; the medium roots' boxes
   hipLaunchKernelGGL(kd_forest_patch_kernel, dim3(((int)small.size() + T + 255) / 256), dim3(256), 0, stream, d_part, A.sublist, (LvStat *)nullptr,
                      (int)small.size(), d_bb, T);
@@ -2240,7 +2250,7 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   if (!level.empty()) {
     int32_t n_largest = 0;
     for (const BuildItem &it : level) n_largest = std::max(n_largest, it.r - it.l);
-    if ((e = run_levels(A, level, n_total, stream, fallback, nullptr, n_largest, d_part)) != hipSuccess) return e;
+    if ((e = run_levels(A, level, n_total, stream, fallback, nullptr, n_largest, d_part)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
     if (*fallback) return hipSuccess;
   }
   int dev = 0, cus = 256;
@@ -2249,15 +2259,15 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   if (A.huge_min > LOCAL_MAX) hipLaunchKernelGGL(kd_build_medium_kernel, dim3(cus), dim3(TB_BIG), 0, stream, A);
   hipLaunchKernelGGL(kd_build_small_kernel, dim3(cus * 16), dim3(TB_SMALL), 0, stream, A);
   if (tiny_phase) hipLaunchKernelGGL(kd_build_tiny_kernel, dim3(std::min(cus * 64, (tiny_cap + TINY_SLOTS - 1) / TINY_SLOTS)), dim3(64), 0, stream, A);
-  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if ((e = hipGetLastError()) != hipSuccess) TB_RETURN_SETTLED(stream, e);
   std::vector<int32_t> rf(T);
   std::vector<float> bb((size_t)T * 6);
-  if ((e = hipMemcpyAsync(&ctl, A.ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-  if ((e = hipMemcpyAsync(rf.data(), A.root_feat, (size_t)T * 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-  if ((e = hipMemcpyAsync(bb.data(), d_bb, bb.size() * 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(&ctl, A.ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
+  if ((e = hipMemcpyAsync(rf.data(), A.root_feat, (size_t)T * 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
+  if ((e = hipMemcpyAsync(bb.data(), d_bb, bb.size() * 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
   int32_t acc[TINY_ACC * 32];
-  if (tiny_phase && (e = hipMemcpyAsync(acc, A.tiny_acc, sizeof(acc), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+  if (tiny_phase && (e = hipMemcpyAsync(acc, A.tiny_acc, sizeof(acc), hipMemcpyDeviceToHost, stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
+  if ((e = hipStreamSynchronize(stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);
   if (tiny_phase)
     for (int k = 0; k < TINY_ACC; ++k) { ctl.n_leaves += acc[k * 32]; ctl.max_depth = std::max(ctl.max_depth, acc[k * 32 + 1]); }
   if (ctl.overflow) {
@@ -2267,8 +2277,8 @@ hipError_t build_kdforest_device(float4 *d_pts, int32_t n_total, const int32_t *
   const int32_t n_nodes = std::min(ctl.next_group * 8, A.node_cap);
   if (d_pn) {
     hipLaunchKernelGGL(kd_pnode_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, d_nodes, n_nodes, d_pts, A.own_box, d_pn);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;  // the scratch holding own_box is reused by the next build
+    if ((e = hipGetLastError()) != hipSuccess) TB_RETURN_SETTLED(stream, e);
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) TB_RETURN_SETTLED(stream, e);  // the scratch holding own_box is reused by the next build
   }
   for (int t = 0; t < T; ++t) {
     views[t].n_nodes = n_nodes;

@@ -1,6 +1,7 @@
 // C++ drop-in check on a GPU: the three header shims (ScanMatch, FeatureMap, SolverG2O) over the C ABI
 // with stand-in cloud / pose types (no PCL, no Eigen).  Prints "OK ..." lines that the test parses.
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <memory>
 #include <random>
@@ -63,6 +64,22 @@ int main() {
   IsoT<float> pose;
   const bool ok = sm.scanMatchScan(rc, rs, c1, s1, pose);
   std::printf("OK match %d %.4f %.4f\n", ok ? 1 : 0, pose.m[3], pose.m[7]);
+  // setReferenceEpoch: the same reference clouds under the same epoch -- the second call skips their upload (one map set fewer)
+  // and returns the same bits
+  {
+    uint64_t lazy0[3], lazy1[3], lazy2[3];
+    sm.setReferenceEpoch(7);
+    IsoT<float> pa, pb;
+    lslam_debug_lazy_trees(sm.context(), lazy0);
+    const bool oka = sm.scanMatchScan(rc, rs, c1, s1, pa);
+    lslam_debug_lazy_trees(sm.context(), lazy1);
+    const bool okb = sm.scanMatchScan(rc, rs, c1, s1, pb);
+    lslam_debug_lazy_trees(sm.context(), lazy2);
+    bool same = oka == okb && oka == ok;
+    for (int i = 0; i < 16; ++i) same = same && pa.m[i] == pb.m[i] && pa.m[i] == pose.m[i];
+    std::printf("OK epoch %d %d %d\n", same ? 1 : 0, (int)(lazy1[0] - lazy0[0]), (int)(lazy2[0] - lazy1[0]));
+    sm.setReferenceEpoch(0);
+  }
   // --- SolverG2O shim: a square of four poses with a drifted guess and a loop edge
   typedef pose_graph::SolverG2OT<IsoT<double>, Mat6> Solver;
   Solver solver;

@@ -166,6 +166,9 @@ def test_cpp_shims_end_to_end_on_gpu(pkg, tmp_path):
     assert ok == 1 and abs(tx - 0.15) < 0.01 and abs(ty + 0.1) < 0.01
     gx, gy, its = float(lines["graph"][0]), float(lines["graph"][1]), int(lines["graph"][2])
     assert its >= 1 and abs(gx) < 0.05 and abs(gy) < 0.05  # vertex 4 was guessed at (0.2, -0.16)
+    # setReferenceEpoch: same bits, and the second call under the same epoch set no map (the first one did)
+    same, sets_first, sets_second = (int(v) for v in lines["epoch"])
+    assert same == 1 and sets_first == 1 and sets_second == 0
 
 
 def test_cpp_pipeline_mirrors_compile(pkg, tmp_path):

@@ -535,6 +535,7 @@ const EnvOnce &env_once() {
     v.no_reg_nodes = on("LSLAM_NO_REG_NODES");
     v.no_level_build = on("LSLAM_NO_LEVEL_BUILD");
     v.fmap_timing = on("LSLAM_FMAP_TIMING");
+    v.fmap_measured_extents = on("LSLAM_FMAP_MEASURED_EXTENTS");
     return v;
   }();
   return e;

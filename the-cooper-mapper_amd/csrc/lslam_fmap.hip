@@ -264,6 +264,29 @@ __global__ void fm_init_kernel(int32_t *cmin, int32_t *cmax, int n3, int32_t *er
   }
 }
 
+// The same per-cube quantities WITHOUT looking at the points (the rebuilds of addFeatureCloud: 744 k points of the bench map
+// were read for their per-cube extremes, 0.13 ms per frame, to place ~3 000 new ones).  What pcl::VoxelGrid does with a
+// cube's bounding box is (a) min_b = floor(min x inv_leaf), subtracted from every voxel index, and (b) the "leaf too small"
+// guard.  (a) does not change the result: voxels are cut at absolute multiples of the leaf, and both the grouping (equal
+// indices) and the output order (ascending index = lexicographic in (k, j, i)) are invariant under subtracting ANY constant
+// per axis that is <= every index of the cube.  A map cube's points lie within cube_size / 2 of its centre on every axis
+// (cube_of_point rounds p / cube_size; a voxel centroid lies inside its voxel's points' box), so a base a cell below the
+// cube's nominal lower face is such a constant, and the extent is bounded by cube_size / leaf + 6 cells.  (b) cannot fire when
+// (cube_size / leaf + 2)^3 <= INT_MAX, which the caller checks; every cube the rebuild filters is then "effective".  The
+// key-range check of fm_key_kernel still guards the bound (a violation re-runs the measured path).
+__global__ void fm_base_kernel(const uint8_t *flags, int ncube, KeyParams k, uint8_t *eff, int32_t *base, int32_t *err) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < 4) err[c] = 0;
+  if (c >= ncube) return;
+  const int g[3] = {c % k.W, (c / k.W) % k.H, c / (k.W * k.H)};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const double lo = ((double)(g[d] - k.origin[d]) - 0.5) * (double)k.cube_size - 0.01;
+    base[3 * c + d] = (int32_t)floor(lo * (double)k.inv_leaf) - 1;
+  }
+  eff[c] = flags[c] ? 1 : 0;
+}
+
 // per cube: min_b, the "leaf too small" guard of applyFilter, the widest voxel extent
 __global__ void fm_extent_kernel(const uint8_t *flags, const int32_t *cmin, const int32_t *cmax, int ncube,
                                  float inv_leaf, uint8_t *eff, int32_t *base, int32_t *max_div) {
@@ -515,8 +538,8 @@ struct lslam_fmap {
   Buf<int32_t> cube[2], cube_alt[2];
   size_t n[2] = {0, 0};
   Buf<uint8_t> active;                 // per cube: 1 = in the active area (_cubeValidInd)
-  Buf<int32_t> seg_begin[2], seg_end[2];
-  std::vector<int32_t> h_begin[2], h_end[2];
+  Buf<int32_t> seg_begin[2];            // [begin (seg_pad words) | end (seg_pad words)] of every cube's points in pts[t]
+  std::vector<int32_t> h_begin[2];      // ... on the host: seg_b / seg_e
   bool seg_current[2] = {false, false};
   Buf<float4> in_raw, in_tf;
   Buf<int32_t> in_cube;
@@ -566,6 +589,10 @@ struct lslam_fmap {
 
 namespace {
 
+size_t seg_pad(const lslam_fmap *fm) { return ((size_t)fm->ncube + 3) & ~(size_t)3; }
+int32_t seg_b(const lslam_fmap *fm, int t, int c) { return fm->h_begin[t][(size_t)c]; }
+int32_t seg_e(const lslam_fmap *fm, int t, int c) { return fm->h_begin[t][seg_pad(fm) + (size_t)c]; }
+
 KeyParams key_params(const lslam_fmap *fm, float leaf) {
   KeyParams k{};
   k.W = fm->W; k.H = fm->H; k.D = fm->D;
@@ -598,7 +625,7 @@ int cube_bits(int ncube) {
 // not have): if the prefix is not in order the whole input is sorted after all.
 int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t *in_cube, size_t n_total,
                  KeyParams kp, int ncube, const uint8_t *flags, float4 *out_pts, int32_t *out_cube, size_t *n_out,
-                 int assume_axis_bits = 0, uint32_t *done = nullptr, size_t n_sorted = 0) {
+                 int assume_axis_bits = 0, uint32_t *done = nullptr, size_t n_sorted = 0, bool cubes_are_boxes = false) {
   *n_out = 0;
   if (n_total == 0) {
     if (done) done[0] = done[1] = done[2] = 0;
@@ -614,6 +641,18 @@ int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t
     FM_TRY(sc.cmax.reserve(3 * (size_t)ncube));
     FM_TRY(sc.base.reserve(3 * (size_t)ncube));
     FM_TRY(sc.eff.reserve(ncube));
+    // a map cube's extent is known without reading the points (fm_base_kernel) whenever the caller passes its bound and
+    // pcl's "leaf too small" guard cannot fire for an extent of cube_size
+    const double cells = (double)kp.cube_size * (double)kp.inv_leaf;
+    const int analytic_bits = bits_for(cells + 6.0);
+    // (cubes_are_boxes: the "cubes" are the feature map's cubes of cube_size -- not the segments of voxel_filter_segments)
+    const bool analytic = cubes_are_boxes && assume_axis_bits > 0 && n_total <= MERGE_LIMIT && (cells + 2.0) * (cells + 2.0) * (cells + 2.0) <= 2147483647.0 &&
+                          3 * analytic_bits + n_cube_bits <= 63 && !lslam::env_once().fmap_measured_extents;
+    if (analytic) {
+      hipLaunchKernelGGL(fm_base_kernel, dim3((std::max(ncube, 4) + 255) / 256), blk, 0, s, flags, ncube, kp, sc.eff.p, sc.base.p, sc.err.p);
+      kp.axis_bits = analytic_bits;
+      eff = sc.eff.p;
+    } else {
     hipLaunchKernelGGL(fm_init_kernel, dim3((3 * ncube + 255) / 256), blk, 0, s, sc.cmin.p, sc.cmax.p, 3 * ncube, sc.err.p);
     {
       const int waves = (int)((n + MM_RUN - 1) / MM_RUN);
@@ -631,6 +670,7 @@ int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t
       kp.axis_bits = bits_for((double)max_div + 1.0);
     }
     eff = sc.eff.p;
+    }
   } else {
     FM_TRY(hipMemsetAsync(sc.err.p, 0, 4 * sizeof(int32_t), s));
     if (!kp.single) kp.axis_bits = 1;
@@ -690,7 +730,7 @@ int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t
   const uint32_t total = (uint32_t)res[0];
   const int32_t err = res[1], unsorted = res[2];
   if (unsorted)  // the prefix was not in key order: everything is sorted
-    return run_pipeline(s, sc, in_pts, in_cube, n_total, kp, ncube, flags, out_pts, out_cube, n_out, assume_axis_bits, nullptr, 0);
+    return run_pipeline(s, sc, in_pts, in_cube, n_total, kp, ncube, flags, out_pts, out_cube, n_out, assume_axis_bits, nullptr, 0, cubes_are_boxes);
   if (err) {
     if (assume_axis_bits > 0)  // the bound did not hold (it always should): the measured extent decides
       return run_pipeline(s, sc, in_pts, in_cube, n_total, kp, ncube, flags, out_pts, out_cube, n_out, 0, nullptr, 0);
@@ -709,17 +749,16 @@ int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t
 int refresh_segments(lslam_fmap *fm, int t, bool wait = true) {
   if (fm->seg_current[t]) return LSLAM_OK;
   hipStream_t s = fm->stream;
-  FM_TRY(fm->seg_begin[t].reserve(fm->ncube));
-  FM_TRY(fm->seg_end[t].reserve(fm->ncube));
-  FM_TRY(hipMemsetAsync(fm->seg_begin[t].p, 0, sizeof(int32_t) * fm->ncube, s));
-  FM_TRY(hipMemsetAsync(fm->seg_end[t].p, 0, sizeof(int32_t) * fm->ncube, s));
+  // [begin | end] in ONE buffer of 2 x seg_pad words (seg_pad = ncube rounded up to 4 words: the fill is one aligned launch
+  // instead of an aligned part and a tail per array) and one copy back
+  const size_t pad = seg_pad(fm);
+  FM_TRY(fm->seg_begin[t].reserve(2 * pad));
+  FM_TRY(hipMemsetAsync(fm->seg_begin[t].p, 0, sizeof(int32_t) * 2 * pad, s));
   if (fm->n[t])
     hipLaunchKernelGGL(fm_segment_kernel, dim3(((int)fm->n[t] + 255) / 256), dim3(256), 0, s, fm->cube[t].p,
-                       (int)fm->n[t], fm->seg_begin[t].p, fm->seg_end[t].p);
-  fm->h_begin[t].resize(fm->ncube);
-  fm->h_end[t].resize(fm->ncube);
-  FM_TRY(hipMemcpyAsync(fm->h_begin[t].data(), fm->seg_begin[t].p, sizeof(int32_t) * fm->ncube, hipMemcpyDeviceToHost, s));
-  FM_TRY(hipMemcpyAsync(fm->h_end[t].data(), fm->seg_end[t].p, sizeof(int32_t) * fm->ncube, hipMemcpyDeviceToHost, s));
+                       (int)fm->n[t], fm->seg_begin[t].p, fm->seg_begin[t].p + pad);
+  fm->h_begin[t].resize(2 * pad);
+  FM_TRY(hipMemcpyAsync(fm->h_begin[t].data(), fm->seg_begin[t].p, sizeof(int32_t) * 2 * pad, hipMemcpyDeviceToHost, s));
   if (wait) FM_TRY(hipStreamSynchronize(s));
   fm->seg_current[t] = true;
   return LSLAM_OK;
@@ -752,7 +791,7 @@ int rebuild_begin(lslam_fmap *fm, int t, size_t n_new, bool allow_filter, const 
   size_t n_out = 0;
   int rc = run_pipeline(s, fm->sc, fm->pts[t].p, fm->cube[t].p, n_total, kp, fm->ncube,
                         flags_override ? flags_override : (allow_filter ? fm->active.p : nullptr), fm->pts_alt[t].p,
-                        fm->cube_alt[t].p, &n_out, map_axis_bits(fm, fm->leaf[t]), done, old_sorted && n_new ? n_old : 0);
+                        fm->cube_alt[t].p, &n_out, map_axis_bits(fm, fm->leaf[t]), done, old_sorted && n_new ? n_old : 0, true);
   if (n_out_sync) *n_out_sync = n_out;
   return rc;
 }
@@ -883,7 +922,7 @@ int gather_surround(lslam_fmap *fm, int t, int index_in_w, size_t *n_out, int mi
   size_t total = 0;
   if (cell_tree) cell_tree->assign((size_t)fm->ncube, -1);
   for (int32_t c : fm->valid) {
-    const int32_t b = fm->h_begin[t][c], e = fm->h_end[t][c];
+    const int32_t b = seg_b(fm, t, c), e = seg_e(fm, t, c);
     if (e - b >= min_points && e > b) {
       if (roots_lr) {
         if (cell_tree) (*cell_tree)[(size_t)c] = (int32_t)(roots_lr->size() / 2);
@@ -987,7 +1026,7 @@ void lslam_fmap_destroy(lslam_fmap *fm) {
   }
   for (int t = 0; t < 2; ++t) {
     fm->pts[t].release(); fm->pts_alt[t].release(); fm->cube[t].release(); fm->cube_alt[t].release();
-    fm->seg_begin[t].release(); fm->seg_end[t].release(); fm->sur[t].release();
+    fm->seg_begin[t].release(); fm->sur[t].release();
   }
   for (lslam_fmap::Generation *g : fm->gens)
     if (g) { g->nodes.release(); g->pn.release(); g->pts.release(); delete g; }
@@ -1111,9 +1150,9 @@ static int add_feature_cloud_impl(lslam_fmap *fm, const void *corner, size_t n_c
       if (rc) return rc;
       FM_TRY(fm->in_tf_t[t].reserve(n));
       FM_TRY(fm->in_cube_t[t].reserve(n));
-      FM_TRY(fm->d_touched_t[t].reserve(fm->ncube));
+      FM_TRY(fm->d_touched_t[t].reserve(((size_t)fm->ncube + 15) & ~(size_t)15));
       KeyParams kp = key_params(fm, fm->leaf[t]);
-      FM_TRY(hipMemsetAsync(fm->d_touched_t[t].p, 0, fm->ncube, s));
+      FM_TRY(hipMemsetAsync(fm->d_touched_t[t].p, 0, ((size_t)fm->ncube + 15) & ~(size_t)15, s));  // (a whole number of 16-byte words: one fill launch, no tail)
       hipLaunchKernelGGL(fm_transform_kernel, dim3(((int)n + 255) / 256), dim3(256), 0, s, fm->in_raw_t[t].p, (int)n,
                          fm->d_T.p, kp, fm->in_tf_t[t].p, fm->in_cube_t[t].p, fm->d_touched_t[t].p);
       FM_TRY(hipMemcpyAsync(fm->h_touched.p + (size_t)t * fm->ncube, fm->d_touched_t[t].p, fm->ncube, hipMemcpyDeviceToHost, s));
@@ -1154,7 +1193,7 @@ int lslam_fmap_surround_counts(lslam_fmap *fm, size_t *n_corner, size_t *n_surf)
     rc = refresh_segments(fm, t);
     if (rc) return rc;
     size_t total = 0;
-    for (int32_t c : fm->valid) total += (size_t)(fm->h_end[t][c] - fm->h_begin[t][c]);
+    for (int32_t c : fm->valid) total += (size_t)(seg_e(fm, t, c) - seg_b(fm, t, c));
     if (out[t]) *out[t] = total;
   }
   return LSLAM_OK;
@@ -1257,7 +1296,7 @@ int lslam_fmap_to_cubemap(lslam_fmap *fm) {
   for (int t = 0; t < 2; ++t) {
     const size_t base = t == 0 ? 0 : total_t[0];
     for (int32_t c : fm->valid) {
-      const int32_t b = fm->h_begin[t][c], e = fm->h_end[t][c];
+      const int32_t b = seg_b(fm, t, c), e = seg_e(fm, t, c);
       lslam_fmap::CubeTree &ct = fm->cube_tree[t][(size_t)c];
       const bool wants_tree = e - b >= 5;
       if (!wants_tree || fm->dirty[t][(size_t)c]) {
@@ -1565,7 +1604,7 @@ int lslam_fmap_save(lslam_fmap *fm, const char *directory) {
       for (int k = 0; k < fm->D; ++k) {
         const int c = to_index(fm, i, j, k);
         for (int t = 0; t < 2; ++t) {
-          const int32_t b = fm->h_begin[t][c], e = fm->h_end[t][c];
+          const int32_t b = seg_b(fm, t, c), e = seg_e(fm, t, c);
           if (e <= b) continue;
           if (!write_pcd_binary(dir + "/" + std::to_string(count) + ".pcd", h[t].data() + b, (size_t)(e - b))) {
             lslam::set_error("cannot write a cube file");

@@ -272,8 +272,10 @@ hipError_t GridDev::build(const float4 *src, int n_src, const float lo[3], const
   G_ALLOC(reserve(tmp_pts, cap_tmp, (size_t)n + 16));
   G_ALLOC(reserve(cell_start, cap_cell, ncell + 1));
   const size_t n_coarse = (ncell + CS_CELLS - 1) / CS_CELLS;
-  G_ALLOC(reserve(coarse, cap_coarse, n_coarse));
-  G_ALLOC(reserve(err, cap_err, 1));
+  // the coarse counts and, right behind them (at a 16-byte boundary), the "point outside the table" counter: zeroed by ONE fill
+  const size_t n_coarse_pad = (n_coarse + 3) & ~(size_t)3;
+  G_ALLOC(reserve(coarse, cap_coarse, n_coarse_pad + 4));
+  err = reinterpret_cast<int32_t *>(coarse + n_coarse_pad);
   {
     // the count table is left zeroed by every build (the scatter counts it down); only a new allocation is cleared
     const size_t before = cap_count;
@@ -281,8 +283,7 @@ hipError_t GridDev::build(const float4 *src, int n_src, const float lo[3], const
     if (cap_count != before || !count_clean) G_TRY(hipMemsetAsync(count, 0, cap_count * sizeof(uint32_t), s));
     count_clean = false;
   }
-  G_TRY(hipMemsetAsync(coarse, 0, n_coarse * sizeof(uint32_t), s));
-  G_TRY(hipMemsetAsync(err, 0, sizeof(int32_t), s));
+  G_TRY(hipMemsetAsync(coarse, 0, (n_coarse_pad + 4) * sizeof(uint32_t), s));
   const dim3 blk(256), grd((n + 255) / 256);
   hipLaunchKernelGGL(grid_count_kernel, grd, blk, 0, s, G, src, count, coarse, err);
   hipLaunchKernelGGL(grid_scan_kernel, dim3((unsigned)((ncell + 1 + CS_CELLS - 1) / CS_CELLS)), blk, 0, s, (const uint32_t *)count,
@@ -310,7 +311,7 @@ hipError_t GridDev::build(const float4 *src, int n_src, const float lo[3], const
 }
 
 void GridDev::release() {
-  for (void *q : {(void *)pts, (void *)tmp_pts, (void *)cell_start, (void *)count, (void *)coarse, (void *)err})
+  for (void *q : {(void *)pts, (void *)tmp_pts, (void *)cell_start, (void *)count, (void *)coarse})  // (err lives behind coarse)
     if (q) (void)hipFree(q);
   pts = tmp_pts = nullptr; cell_start = count = coarse = nullptr; err = nullptr;
   cap_pts = cap_tmp = cap_cell = cap_count = cap_coarse = cap_err = 0;

@@ -382,6 +382,7 @@ struct EnvOnce {
   bool no_reg_nodes = false;     // LSLAM_NO_REG_NODES
   bool no_level_build = false;   // LSLAM_NO_LEVEL_BUILD
   bool fmap_timing = false;      // LSLAM_FMAP_TIMING
+  bool fmap_measured_extents = false;  // LSLAM_FMAP_MEASURED_EXTENTS: A/B switch -- a map rebuild reads every point for its cube's extremes (fm_minmax_kernel) instead of taking the cube's nominal box (fm_base_kernel)
 };
 const EnvOnce &env_once();
 const char *debug_env(const char *name);  // nullptr unless the process runs with LSLAM_DEBUG_HOOKS=1 and `name` is set

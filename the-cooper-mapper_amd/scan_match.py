@@ -449,6 +449,8 @@ class ScanMatch:
         self._fail_match_count = 0  # ScanMatch.h:85
         self._total_score = 0.0     # ScanMatch.h:83
         self.last_stats = None
+        self._ref_epoch = 0         # setReferenceEpoch: the caller's promise (0: none)
+        self._resident = None       # (epoch, id / address / shape of the two reference clouds) the resident map was set under
 
     # setters, ScanMatch.h:21-34
     def setPercentThreshold(self, percent):
@@ -466,6 +468,12 @@ class ScanMatch:
 
     def setUseCore(self, useScore):
         self.opts.use_score = int(bool(useScore))
+
+    def setReferenceEpoch(self, epoch):
+        """include/lslam_scan_match.hpp setReferenceEpoch: with a non-zero epoch the caller promises that the reference clouds
+        it hands to scanMatchScan are unchanged while the epoch is; a call with the same two arrays (same buffers and shapes)
+        under the same epoch skips their upload and matches against the resident map.  0: every call uploads (the default)."""
+        self._ref_epoch = int(epoch)
 
     def getAverageScore(self):  # ScanMatch.h:59-61
         return self._total_score / self._match_count if self._match_count > 0 else 0.0
@@ -485,8 +493,16 @@ class ScanMatch:
         pose = np.asarray(pose, dtype=np.float32)
         iso = pose.shape == (4, 4)
         tw = self.ctx.isometry_to_pose(pose) if iso else pose.reshape(6)
-        status, tw, st = self.ctx.scanmatch_full(referenceCornerCloud, referenceSurfCloud,
-                                                 CornerCloud, SurfCloud, tw, self.opts)
+        key = None
+        if self._ref_epoch and isinstance(referenceCornerCloud, np.ndarray) and isinstance(referenceSurfCloud, np.ndarray):
+            key = (self._ref_epoch,) + tuple((a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str)
+                                             for a in (referenceCornerCloud, referenceSurfCloud))
+        if key is not None and key == self._resident:
+            status, tw, st = self.ctx.scanmatch_scan(CornerCloud, SurfCloud, tw, self.opts)
+        else:
+            status, tw, st = self.ctx.scanmatch_full(referenceCornerCloud, referenceSurfCloud,
+                                                     CornerCloud, SurfCloud, tw, self.opts)
+            self._resident = key if (status >= 0 and status != Status.TOO_FEW_REF) else None
         ok = self._finish(status, st)
         return ok, (self.ctx.pose_to_isometry(tw) if iso else tw)
 
@@ -497,7 +513,11 @@ class ScanMatch:
         from .feature_map import voxel_grid
         ds = [voxel_grid(self.ctx, c, leaf) for c, leaf in ((referenceCornerCloud, 0.2), (referenceSurfCloud, 0.4),
                                                             (CornerCloud, 0.2), (SurfCloud, 0.4))]
-        return self.scanMatchScan(ds[0], ds[1], ds[2], ds[3], pose)
+        keep, self._ref_epoch = self._ref_epoch, 0  # (fresh downsampled arrays every call: nothing to keep resident)
+        try:
+            return self.scanMatchScan(ds[0], ds[1], ds[2], ds[3], pose)
+        finally:
+            self._ref_epoch = keep
 
     def setMap(self, referenceCornerCloud, referenceSurfCloud):
         """Keep a map resident across calls (the FeatureMap::scanMatchScan usage,

@@ -36,20 +36,21 @@ def main():
     for rings in (64, 16):
         qc, qs = lidar.scan(gt, rings, 1800, seed=4321)
         for what in ("full scan", "after VoxelGrid 1.0"):
-            for defer in (False, True):
+            for defer, epoch in ((False, 0), (True, 0), (True, 1)):
                 ctx = pkg.Context(0)
                 ctx.defer_trees(defer)
                 sm = pkg.ScanMatch(10, ctx=ctx)
+                sm.setReferenceEpoch(epoch)  # 1: the caller promises the reference clouds are unchanged -> uploaded once
                 c, s = (qc, qs) if what == "full scan" else (pkg.voxel_grid(ctx, qc, 1.0), pkg.voxel_grid(ctx, qs, 1.0))
                 ts = []
                 for k in range(args.calls + 2):
                     pose = init.copy()
                     t0 = time.perf_counter()
-                    ok = sm.scanMatchScan(mc, ms, c, s, pose)
+                    ok, pose = sm.scanMatchScan(mc, ms, c, s, pose)
                     ts.append(time.perf_counter() - t0)
                 ts = np.array(ts[2:]) * 1e3
-                print("%2d rings, %-20s %6d scan points, trees %-8s: median %.3f ms  min %.3f ms  (ok %s, err %.4f m, lazy %s)"
-                      % (rings, what, len(c) + len(s), "deferred" if defer else "built", np.median(ts), ts.min(), ok,
+                print("%2d rings, %-20s %6d scan points, trees %-42s: median %.3f ms  min %.3f ms  (ok %s, err %.4f m, lazy %s)"
+                      % (rings, what, len(c) + len(s), ("deferred" if defer else "built") + (" + reference epoch (map resident)" if epoch else ""), np.median(ts), ts.min(), ok,
                          float(np.abs(np.asarray(pose)[3:] - gt[3:]).max()), ctx.lazy_trees()))
                 ctx.close()
 

@@ -100,12 +100,20 @@ enum { LSLAM_AB_PERSISTENT_GN = 1, /* one resident scan: the whole Gauss-Newton 
                                       the ball of what the first saw) before the tree search -- exact, measured slower
                                       (1.16e10 against 1.25e10 point-residuals/s: the points that need more than the first probe
                                       are the ones a wide probe is slow for too) */
-       LSLAM_AB_WIDE_IN_PLACE = 8  /* a map without kd-trees (lslam_map_defer_trees), a launch of at most two wavefronts per SIMD:
+       LSLAM_AB_WIDE_IN_PLACE = 8, /* a map without kd-trees (lslam_map_defer_trees), a launch of at most two wavefronts per SIMD:
                                       the points the probe cannot prove are resolved inside the probe's own launch, wavefront by
                                       wavefront (one launch per sweep instead of five; the sums are then formed exactly as the
                                       lane search's sweep forms them).  Exact, measured slower: a frame's scan match 0.84 ms
                                       against 0.49 -- a wavefront works its unproven points off one after the other, the
-                                      separate wide-probe launch gives each its own wavefront */ };
+                                      separate wide-probe launch gives each its own wavefront */
+       LSLAM_AB_WIDE_NF_MARGIN = 16 /* a map without kd-trees: a point whose fifth and sixth distances are within 8 ulps of each
+                                      other counts as undecidable too (as an exact tie does): the trees are built and the call
+                                      repeated.  Off: such a pair is ordered by its exact fp32 distances -- nanoflann's order
+                                      unless its own pruning bound (nanoflann.hpp:1485, two roundings per far step) rounds
+                                      across the pair: not observed in 37 139 near-tie queries built to provoke it against the
+                                      reference's nanoflann (tools/nanoflann_exactness.py).  On: ~1-2 % of a mapping node's
+                                      frames build the trees after all (+2.2 ms each).  Where trees exist (batches, the headline)
+                                      the margin is always on and wider (100 ulps): a refused point just takes the tree walk */ };
 
 /* 5-NN search implementations (same answer, bit for bit):
  *   LANE    one query per lane, nanoflann's traversal with an explicit per-lane stack
@@ -204,7 +212,8 @@ int lslam_map_info_get(const lslam_ctx *ctx, lslam_map_info *info);
  * counts, one scan, placement: about a sixth of a tree build) and its kd-trees only when something needs them.  A scan match of one small scan against such a map runs on the grids alone -- the 27-cell probe with
  * its proof, and for the points it cannot prove one wavefront each over every cell within their bound -- and gives nanoflann's
  * neighbours exactly as the tree search does; the one case the grids cannot decide, an exact distance tie among a point's six
- * nearest, makes the call build the trees and run again through them.  Every other entry point that touches the trees (the
+ * nearest, makes the call build the trees and run again through them (with lslam_opts.ab_switches & LSLAM_AB_WIDE_NF_MARGIN a
+ * fifth / sixth pair within 8 ulps does too: see there for what that guards against and what it costs).  Every other entry point that touches the trees (the
  * taps, LSLAM_SEARCH_LANE / _PACKET, batches, the sharded loop, lslam_icp_align, ...) builds them first.  Results do not
  * depend on the setting.  lslam_map_info reports depth 0 / 0 nodes while the trees are pending. */
 int lslam_map_defer_trees(lslam_ctx *ctx, int32_t on);

@@ -450,3 +450,44 @@ def test_wide_probe_refuses_a_candidate_dropped_behind_six_keys_of_one_lane(pkg)
         assert a[0] == b[0] and a[2:5] == b[2:5] and a[3] > 100
         assert np.abs(a[1] - b[1]).max() <= 2e-6
     assert np.array_equal(bits(res[(True, False)][1]), bits(res[(True, True)][1]))  # through the trees: the eager run's bits
+
+
+def test_wide_probe_near_tie_margin_is_an_option(pkg):
+    """LSLAM_AB_WIDE_NF_MARGIN (lslam_opts.ab_switches & 16): a map without kd-trees and a scan point whose fifth and sixth
+    neighbours are two ulps apart.  Off (the default) the pair is ordered by its exact distances and no tree is built; on, the
+    point counts as undecidable, the trees are built and the call repeated.  Either way the eager call's pose."""
+    mc, ms, qc, qs = _seven_in_a_row_problem(False)
+    q = np.array([3.30, 2.10, 30.0], np.float32)
+    near = [[q[0] + dx, q[1], q[2]] for dx in (1.00, 1.02, 1.04, 1.06)]
+    # the fifth and sixth: the same dx = 1.1, dy = 0.01 and 0.01 + 1.5e-5 -> squared distances a few ulps apart (checked below
+    # in the kernel's own arithmetic: ((dx dx + dy dy) + dz dz), fp32)
+    xa = np.float32(q[0] + np.float32(1.10))
+    pa = np.array([xa, np.float32(q[1] + np.float32(0.01)), q[2]], np.float32)
+    pb = np.array([xa, np.float32(q[1] + np.float32(0.010015)), q[2]], np.float32)
+    def d2k(p):
+        dx, dy, dz = np.float32(q[0] - p[0]), np.float32(q[1] - p[1]), np.float32(q[2] - p[2])
+        return np.float32(np.float32(np.float32(dx * dx) + np.float32(dy * dy)) + np.float32(dz * dz))
+    d2 = [d2k(pa), d2k(pb)]
+    assert d2[0] < d2[1] and (d2[1] - d2[0]) / d2[1] < 8 * 2.0 ** -23, d2
+    a, b = pa, pb
+    ms2 = np.concatenate([ms, np.array(near + [list(a), list(b)], np.float32)]).astype(np.float32)
+    qs2 = np.concatenate([qs, q[None, :]]).astype(np.float32)
+    res = {}
+    for name, defer, ab in (("eager", False, 0), ("deferred", True, 0), ("deferred+margin", True, 16)):
+        c = pkg.Context(0)
+        try:
+            c.defer_trees(defer)
+            c.map_set(mc, ms2)
+            c.scan_set(qc, qs2)
+            o = c.default_opts()
+            o.ab_switches = ab
+            status, pose, st = c.run(np.zeros(6, np.float32), o)
+            res[name] = (int(status), pose.copy(), st.iterations, st.n_rows, c.lazy_trees())
+        finally:
+            c.close()
+    assert res["deferred"][4] == (1, 0, True), res["deferred"][4]          # decided by exact distances: no tree
+    assert res["deferred+margin"][4] == (1, 1, False), res["deferred+margin"][4]  # refused: trees built, call repeated
+    for k in ("deferred", "deferred+margin"):
+        assert res[k][0] == res["eager"][0] and res[k][2:4] == res["eager"][2:4]
+        assert np.abs(res[k][1] - res["eager"][1]).max() <= 2e-6
+    assert np.array_equal(bits(res["deferred+margin"][1]), bits(res["eager"][1]))

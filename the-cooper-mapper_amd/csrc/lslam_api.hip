@@ -243,6 +243,7 @@ struct lslam_ctx {
   // environment overrides of lslam_opts fields, read ONCE when the context is made (never inside a call)
   int env_knn_cert = -1;       // LSLAM_KNN_CERT (-1: not set)
   float env_cert_try_m = -1.0f, env_cert_track_m = -1.0f, env_grid_cell = -1.0f;  // LSLAM_CERT_TRY_M, LSLAM_CERT_TRACK_M, LSLAM_GRID_CELL
+  float env_grid_cell_corner = -1.0f;  // LSLAM_GRID_CELL_CORNER: A/B switch -- another cell edge for the corner map's grid (the line-like cloud)
   int env_search = -1;         // LSLAM_SEARCH=lane|packet|grid
   int env_debug_cert_stats = 0;  // LSLAM_DEBUG_CERT_STATS
   int env_force_stack = -1;    // LSLAM_FORCE_STACK=deep|shallow|auto -> SWEEP_STACK_*
@@ -319,6 +320,7 @@ void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
   a.ks = CellGrid{};
   a.grid = 0;
   a.grid_clip_margin = GRID_CLIP_MARGIN_MIN;
+  a.wide_nf_slack = 0.0f;
   a.grid_hint = nullptr;
   a.need2_list = nullptr;
   a.need2_cnt = nullptr;
@@ -382,7 +384,7 @@ int ensure_grid(lslam_ctx *ctx, float cell) {
   ctx->grid_epoch = ctx->map_epoch;
   ctx->grid_cell = cell;
   int st_c = 0, st_s = 0;
-  HIP_TRY(ctx->kc.build(ctx->tc.view, cell, ctx->stream, &st_c));
+  HIP_TRY(ctx->kc.build(ctx->tc.view, ctx->env_grid_cell_corner > 0.0f ? ctx->env_grid_cell_corner : cell, ctx->stream, &st_c));
   HIP_TRY(ctx->ks.build(ctx->ts.view, cell, ctx->stream, &st_s));
   ctx->grid_status = st_c ? st_c : st_s;
   if (ctx->grid_status || !ctx->kc.view.cell_start || !ctx->ks.view.cell_start) {  // both or none
@@ -437,7 +439,11 @@ hipError_t sweep_launch(lslam_ctx *ctx, const SweepArgs &a, int jtj_mode, hipEve
     ctx->sweep_variants[v]++;
     if (variant) *variant = v;
     if (e != hipSuccess) return e;
+    bool planned = false;
     if (a.grid == 2) {  // no trees: the listed points' neighbours come from the wide probe, the queue only runs their residual chain
+      e = launch_sweep_plan(a, ctx->stream, plan, 0, true);  // the second pass's plan and the wide probe's prefix in one launch
+      if (e != hipSuccess) return e;
+      planned = true;
       e = launch_sweep_wide(a, ctx->stream);
       if (e != hipSuccess) return e;
     }
@@ -456,7 +462,7 @@ hipError_t sweep_launch(lslam_ctx *ctx, const SweepArgs &a, int jtj_mode, hipEve
       ctx->queue_launches++;
       return e;
     }
-    e = launch_sweep_queue(a, jtj_mode, ctx->stream, e1, pass2, plan);
+    e = launch_sweep_queue(a, jtj_mode, ctx->stream, e1, pass2, plan, 0, planned);
     ctx->queue_launches++;
     return e;
   }
@@ -610,6 +616,7 @@ int lslam_ctx_create(int device, lslam_ctx **out) {
   if (const char *v = std::getenv("LSLAM_CERT_TRY_M")) ctx->env_cert_try_m = (float)std::atof(v);
   if (const char *v = std::getenv("LSLAM_CERT_TRACK_M")) ctx->env_cert_track_m = (float)std::atof(v);
   if (const char *v = std::getenv("LSLAM_GRID_CELL")) ctx->env_grid_cell = (float)std::atof(v);
+  if (const char *v = std::getenv("LSLAM_GRID_CELL_CORNER")) ctx->env_grid_cell_corner = (float)std::atof(v);
   if (const char *v = std::getenv("LSLAM_DEBUG_CERT_STATS")) ctx->env_debug_cert_stats = std::atoi(v);
   if (const char *v = std::getenv("LSLAM_FORCE_STACK")) {
     if (!std::strcmp(v, "deep")) ctx->env_force_stack = SWEEP_STACK_DEEP;
@@ -1774,6 +1781,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
       sa.ks = ctx->ks.view;
       sa.grid = 2;
       sa.grid_clip_margin = GRID_CLIP_MARGIN_MIN;
+      sa.wide_nf_slack = ((o.ab_switches | ctx->env_ab) & LSLAM_AB_WIDE_NF_MARGIN) ? GRID_NF_PRUNE_SLACK_WIDE : 0.0f;
       HIP_TRY(ctx->wide_d.reserve(std::max<size_t>(ctx->n_points, 1) * 5));
       HIP_TRY(ctx->wide_p.reserve(std::max<size_t>(ctx->n_points, 1) * 5));
       HIP_TRY(ctx->wide_off.reserve((size_t)std::max(ctx->nb_total, 1) + 2));

@@ -477,6 +477,10 @@ __global__ void fm_segment_kernel(const int32_t *cube, int n, int32_t *begin, in
 }
 
 // points of flagged cubes are dropped (a cube loaded from a file replaces what was there)
+__global__ void fm_two_segments_kernel(int32_t *seg, int na, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) seg[i] = i < na ? 0 : 1;
+}
 __global__ void fm_dropflag_kernel(int32_t *cube, int n, const uint8_t *flags) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && cube[i] >= 0 && flags[cube[i]]) cube[i] = -1;
@@ -963,6 +967,7 @@ int voxel_filter_segments(hipStream_t s, const float4 *in_pts, const int32_t *in
   struct Cache {
     Scratch sc;
     Buf<uint8_t> all;
+    size_t all_set = 0;  // entries of `all` that hold their 1 already
   };
   static std::map<int, Cache> caches;  // per device
   static std::mutex mu;
@@ -971,8 +976,17 @@ int voxel_filter_segments(hipStream_t s, const float4 *in_pts, const int32_t *in
   FM_TRY(hipGetDevice(&dev));
   Scratch &sc = caches[dev].sc;
   Buf<uint8_t> &all = caches[dev].all;
-  FM_TRY(all.reserve((size_t)nseg));
-  FM_TRY(hipMemsetAsync(all.p, 1, (size_t)nseg, s));
+  size_t &all_set = caches[dev].all_set;
+  {  // "every segment is filtered": ones, written when the array grows -- not once per call
+    const uint8_t *before = all.p;
+    FM_TRY(all.reserve((size_t)nseg));
+    if (all.p != before) all_set = 0;
+    if (all_set < (size_t)nseg) {
+      FM_TRY(hipMemsetAsync(all.p, 1, all.cap, s));
+      FM_TRY(hipStreamSynchronize(s));  // (once per growth; the array is shared by the contexts of a device, whatever their streams)
+      all_set = all.cap;
+    }
+  }
   KeyParams kp{};
   kp.W = nseg; kp.H = 1; kp.D = 1;
   kp.cube_size = 1.0f;
@@ -1830,8 +1844,8 @@ static int voxel_grid2_impl(lslam_ctx *ctx, const void *a, size_t na, const void
     at += cnt[k];
   }
   FM_TRY(hipMemcpyAsync(c.in_raw.p, c.in_pin.p, n * sizeof(float4), hipMemcpyHostToDevice, s));
-  if (na) FM_TRY(hipMemsetAsync(c.seg.p, 0, na * sizeof(int32_t), s));
-  if (nb) FM_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c.seg.p + na), 1, nb, s));
+  // segment 0 for the first cloud's points, 1 for the second's: one launch (two fills were up to four: aligned part + tail each)
+  hipLaunchKernelGGL(fm_two_segments_kernel, dim3(((unsigned)n + 255) / 256), dim3(256), 0, s, c.seg.p, (int)na, (int)n);
   size_t m = 0;
   int rc = lslam::voxel_filter_segments(s, c.in_raw.p, c.seg.p, n, 2, leaf, c.out.p, c.oseg.p, &m, true, c.done.p);
   if (rc) return rc;

@@ -130,6 +130,7 @@ struct SweepArgs {
   // neighbours in wide_d / wide_p (positions in kc.pts / ks.pts); sweep_queue_kernel then only runs their residual chain.  A
   // point whose answer needs nanoflann's visit order (an exact distance tie) raises GNState::pad of its scan: the caller builds
   // the trees and runs the call again through them.
+  float wide_nf_slack;     // relative margin of the wide probe's fifth-against-sixth test (lslam_grid.hpp GRID_NF_PRUNE_SLACK_WIDE, or 0)
   float *wide_d;           // [points][5]
   int32_t *wide_p;         // [points][5]
   int32_t *wide_off;       // [nb_total + 1] exclusive prefix of the listed points per pass-1 workgroup (grid_prefix_kernel)
@@ -270,7 +271,7 @@ enum : int {
   SWEEP_N_VARIANTS = 10
 };
 hipError_t launch_sweep_grid(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t start, hipEvent_t stop, bool resolve_in_place = false);
-hipError_t launch_sweep_wide(const SweepArgs &a, hipStream_t s);  // grid_prefix_kernel + sweep_wide_kernel
+hipError_t launch_sweep_wide(const SweepArgs &a, hipStream_t s);  // sweep_wide_kernel (its prefix: launch_sweep_plan with_prefix)
 hipError_t launch_knn5_grid(const CellGrid &G, const TreeView &T, const float4 *q, int nq, int32_t *idx, float *d2,
                             uint32_t *stack_ovf, int32_t *n_unproven, hipStream_t s);
 
@@ -302,7 +303,8 @@ struct GridDev {
 };
 hipError_t grid_bbox2(const float4 *const pts[2], const int n[2], uint32_t *d_box12, float lo[2][3], float hi[2][3], hipStream_t s);
 hipError_t grid_unsort(const CellGrid &G, float4 *out, hipStream_t s);
-hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t stop, int variant, const CertPlan &plan, int level = 0);
+hipError_t launch_sweep_plan(const SweepArgs &a, hipStream_t s, const CertPlan &plan, int level, bool with_prefix);
+hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t stop, int variant, const CertPlan &plan, int level = 0, bool planned = false);
 hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s,
                         hipEvent_t start = nullptr, hipEvent_t stop = nullptr, int *variant = nullptr, bool *cert_launched = nullptr);
 hipError_t launch_solve(const SolveArgs &a, hipStream_t s);

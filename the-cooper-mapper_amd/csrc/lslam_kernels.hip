@@ -1137,7 +1137,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
 // depends on the order of the atomics; nothing else does -- an item's sums go to a place of its own.
 // level 0: the first-level lists (need_cnt); when second-level lists exist their counts are zeroed here, so that a block no
 // work item of the second probe is made for reads as empty.  level 1: the second-level lists (need2_cnt).
-__global__ __launch_bounds__(256) void cert_plan_kernel(SweepArgs a, CertPlan plan, int level) {
+LSLAM_DEV void grid_prefix_block(const SweepArgs &a, int *part);
+__global__ __launch_bounds__(256) void cert_plan_kernel(SweepArgs a, CertPlan plan, int level, int with_prefix) {
+  // a map without trees (a.grid == 2): the exclusive prefix of the list lengths that sweep_wide_kernel needs rides in one more
+  // workgroup of this launch instead of a launch of its own (grid_prefix_kernel: five launches per sweep of a mapping frame)
+  if (with_prefix && blockIdx.x == gridDim.x - 1) {
+    __shared__ int part[256];
+    grid_prefix_block(a, part);
+    return;
+  }
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g == 0) {  // the counters of the NEXT plan (they alternate)
     *plan.count_next = 0;
@@ -1315,9 +1323,16 @@ hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEven
   return hipGetLastError();
 }
 
-hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t stop, int variant, const CertPlan &plan, int level) {
+// the planner of a second pass on its own (a map without trees plans BEFORE the wide probe, whose prefix rides in the same launch)
+hipError_t launch_sweep_plan(const SweepArgs &a, hipStream_t s, const CertPlan &plan, int level, bool with_prefix) {
   if (a.n_groups <= 0) return hipSuccess;
-  hipLaunchKernelGGL(cert_plan_kernel, dim3((a.n_groups + 255) / 256), dim3(256), 0, s, a, plan, level);
+  hipLaunchKernelGGL(cert_plan_kernel, dim3((a.n_groups + 255) / 256 + (with_prefix ? 1 : 0)), dim3(256), 0, s, a, plan, level, with_prefix ? 1 : 0);
+  return hipGetLastError();
+}
+
+hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t stop, int variant, const CertPlan &plan, int level, bool planned) {
+  if (a.n_groups <= 0) return hipSuccess;
+  if (!planned) hipLaunchKernelGGL(cert_plan_kernel, dim3((a.n_groups + 255) / 256), dim3(256), 0, s, a, plan, level, 0);
   // as many workgroups as stay resident (256 CUs x five of the shallow kernel, two of the deep ones), never more than items possible
   constexpr int SHALLOW = LSLAM_SHALLOW_DEPTH;
   const long possible = (long)a.nb_total;
@@ -1371,7 +1386,7 @@ hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, h
 #ifndef LSLAM_GRID_OCC
 #define LSLAM_GRID_OCC 6  // wavefronts per SIMD the grid sweep is compiled for: 80 VGPRs (5: 90 VGPRs, 8 % slower; 7: below; 8: 64 VGPRs with 96 B of scratch, slower than 5)
 #endif
-LSLAM_DEV void wide_probe(const CellGrid &G, const float (&sel)[3], float r2, int lane, float (&d)[5], int (&p)[5], bool &num, bool &bad);
+LSLAM_DEV void wide_probe(const CellGrid &G, const float (&sel)[3], float r2, int lane, float nf_slack, float (&d)[5], int (&p)[5], bool &num, bool &bad);
 
 // WIDE (A/B, LSLAM_AB_WIDE_IN_PLACE; a map without kd-trees, a launch too small to fill the chip -- the mapping node's frame):
 // a point the probe cannot prove is resolved on the spot by its own wavefront (wide_probe: every cell within the fifth
@@ -1462,7 +1477,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 
       float wd[5];
       int wp[5];
       bool num, bad;
-      wide_probe(G, s3, r2, lane, wd, wp, num, bad);
+      wide_probe(G, s3, r2, lane, a.wide_nf_slack, wd, wp, num, bad);
       any_bad = any_bad || bad;
       if (lane == L) {
 #pragma unroll
@@ -1524,11 +1539,10 @@ hipError_t launch_sweep_grid(const SweepArgs &a, int jtj_mode, hipStream_t s, hi
 // An exact distance tie among the six -- the one thing only nanoflann's traversal can order -- raises GNState::pad: the host
 // builds the trees and repeats the call through them.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void grid_prefix_kernel(SweepArgs a) {
-  __shared__ int part[1024];
+LSLAM_DEV void grid_prefix_block(const SweepArgs &a, int *part) {  // one workgroup of 256 threads
   const int tid = threadIdx.x, nb = a.nb_total;
-  const int per = (nb + 1023) / 1024;
-  const int b0 = tid * per, b1 = min(nb, b0 + per);
+  const int per = (nb + 255) / 256;
+  const int b0 = min(nb, tid * per), b1 = min(nb, b0 + per);
   int sum = 0;
   for (int b = b0; b < b1; ++b) {
     const GNState &st = a.states[a.blocks[b].prob];
@@ -1537,7 +1551,7 @@ __global__ __launch_bounds__(1024) void grid_prefix_kernel(SweepArgs a) {
   }
   part[tid] = sum;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan
+  for (int off = 1; off < 256; off <<= 1) {  // inclusive scan
     const int v = tid >= off ? part[tid - off] : 0;
     __syncthreads();
     part[tid] += v;
@@ -1550,7 +1564,7 @@ __global__ __launch_bounds__(1024) void grid_prefix_kernel(SweepArgs a) {
     const bool on = a.fine_gate_c >= 0.0f ? st.converged != 0 : st.done == 0;
     run += on ? (int)a.need_cnt[b] : 0;
   }
-  if (tid == 1023) a.wide_off[nb] = part[1023];
+  if (tid == 255) a.wide_off[nb] = part[255];
 }
 
 LSLAM_DEV uint32_t wave_min_u32(uint32_t v) {
@@ -1564,7 +1578,7 @@ constexpr int WIDE_ROWS_PER_LANE = 4;  // up to 256 cell rows around a point (ce
 // One wavefront, one point (wave-uniform arguments): every cell within sqrt(r2) of sel is scanned, 64 rows at a time; the five
 // nearest with their exact distances come back in every lane.  bad: the answer needs nanoflann's visit order (a tie), or the
 // kernel is not sized for the cells.
-LSLAM_DEV void wide_probe(const CellGrid &G, const float (&sel)[3], float r2, int lane, float (&d)[5], int (&p)[5], bool &num, bool &bad) {
+LSLAM_DEV void wide_probe(const CellGrid &G, const float (&sel)[3], float r2, int lane, float nf_slack, float (&d)[5], int (&p)[5], bool &num, bool &bad) {
   const float rb = sqrtf(r2) * (1.0f + 1.0e-5f) + GRID_CLIP_MARGIN_MIN;
   const float rbc = rb * G.inv_c;
   const float ux = __fmul_rn(__fsub_rn(sel[0], G.org[0]), G.inv_c);
@@ -1617,6 +1631,7 @@ LSLAM_DEV void wide_probe(const CellGrid &G, const float (&sel)[3], float r2, in
   // then the bound is the sixth winner's key itself (dropped: that lane saw more than six candidates)
   int pos[6];
   uint32_t dropped = 0xFFFFFFFFu;
+  int dry_lane = -1;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     const uint32_t m = wave_min_u32(k0);
@@ -1633,9 +1648,11 @@ LSLAM_DEV void wide_probe(const CellGrid &G, const float (&sel)[3], float r2, in
       dry = j == 5 && k0 == 0xFFFFFFFFu && id > 6u;
     }
     pos[j] = who ? __shfl(mine, w, 64) : -1;
-    if (j == 5 && __any(dry)) dropped = m;
+    if (j == 5 && __any(dry)) {
+      dropped = m;
+      dry_lane = w;
+    }
   }
-  const uint32_t rest = min(wave_min_u32(k0), dropped);  // every other candidate's truncated distance is at least this
   // exact distances, sorted by the search's own insert (every lane computes the same)
   float e6 = FLT_MAX;
 #pragma unroll
@@ -1647,9 +1664,26 @@ LSLAM_DEV void wide_probe(const CellGrid &G, const float (&sel)[3], float r2, in
     if (j < 5) knn_insert_sorted(d, p, x, pos[j]);
     else e6 = x;
   }
+  // The lane that ran dry: its sixth key only bounds what it dropped to 2^-13 -- a fifth and sixth distance inside one such
+  // bucket (1 in 10^3 - 10^4) would refuse the point, i.e. build the trees of the whole map.  The dry lane looks at its rows once
+  // more instead, exactly: if precisely five of its candidates are nearer than the sixth winner, the six winners ARE its six
+  // nearest and everything it dropped is at least the sixth winner's exact distance away -- which lb already is.
+  if (dry_lane >= 0) {  // wave-uniform, rare
+    int nearer = 0;
+    if (lane == dry_lane) {
+#pragma unroll
+      for (int k = 0; k < WIDE_ROWS_PER_LANE; ++k) {
+        const uint32_t s0 = row_s[k], cnt = row_id0[k + 1] - row_id0[k];
+        for (uint32_t j = 0; j < cnt; ++j) nearer += dist2_xyz(sel[0], sel[1], sel[2], G.pts[s0 + j]) < e6 ? 1 : 0;
+      }
+    }
+    nearer = __shfl(nearer, dry_lane, 64);
+    if (nearer == 5) dropped = 0xFFFFFFFFu;
+  }
+  const uint32_t rest = min(wave_min_u32(k0), dropped);  // every other candidate's truncated distance is at least this
   lb = fmaxf(e6, d[4]);
   knn_insert_sorted(d, p, e6, pos[5]);
-  if (lb < 1.0e30f) lb *= 1.0f - GRID_NF_PRUNE_SLACK_WIDE;  // (lslam_grid.hpp: the rounding of nanoflann's own pruning bound)
+  if (lb < 1.0e30f) lb *= 1.0f - nf_slack;  // (lslam_grid.hpp: the rounding of nanoflann's own pruning bound; 0 unless LSLAM_AB_WIDE_NF_MARGIN)
   if (rest != 0xFFFFFFFFu) lb = fminf(lb, __uint_as_float(rest & ~GRID_ID_MASK));
   // covered: every cell a point within (rb - slack) of the query can lie in has been scanned
   const float cov = rb - GRID_U_SLACK * G.c;
@@ -1692,7 +1726,7 @@ __global__ __launch_bounds__(256) void sweep_wide_kernel(SweepArgs a) {
   float d[5];
   int p[5];
   bool num, bad;
-  wide_probe(G, sel, r2, lane, d, p, num, bad);
+  wide_probe(G, sel, r2, lane, a.wide_nf_slack, d, p, num, bad);
   if (bad) {
     if (lane == 0) atomicOr(&st->pad, 1);
   }
@@ -1709,9 +1743,8 @@ __global__ __launch_bounds__(256) void sweep_wide_kernel(SweepArgs a) {
   }
 }
 
-hipError_t launch_sweep_wide(const SweepArgs &a, hipStream_t s) {
+hipError_t launch_sweep_wide(const SweepArgs &a, hipStream_t s) {  // (after launch_sweep_plan(..., with_prefix): wide_off is there)
   if (a.nb_total <= 0) return hipSuccess;
-  hipLaunchKernelGGL(grid_prefix_kernel, dim3(1), dim3(1024), 0, s, a);
   // one wavefront per point that CAN be listed (every point of the launch): the ones beyond the listed total leave at once
   hipLaunchKernelGGL(sweep_wide_kernel, dim3((unsigned)a.nb_total * (SWEEP_BLOCK / 4)), dim3(256), 0, s, a);
   return hipGetLastError();

@@ -106,6 +106,10 @@ enum { LSLAM_AB_PERSISTENT_GN = 1, /* one resident scan: the whole Gauss-Newton 
                                       lane search's sweep forms them).  Exact, measured slower: a frame's scan match 0.84 ms
                                       against 0.49 -- a wavefront works its unproven points off one after the other, the
                                       separate wide-probe launch gives each its own wavefront */
+       LSLAM_AB_FIT_CACHE = 32,    /* grid sweep of a batch: from a loop's third sweep on a surf point whose five neighbours are the
+                                      ones of the sweep before reuses that sweep's plane (findPlane is a pure function of the five
+                                      in order); the points whose five changed are compacted through LDS so that the fit runs on as
+                                      few wavefronts as they fill.  Same bits.  DESIGN 4 has the measurement */
        LSLAM_AB_WIDE_NF_MARGIN = 16 /* a map without kd-trees: a point whose fifth and sixth distances are within 8 ulps of each
                                       other counts as undecidable too (as an exact tie does): the trees are built and the call
                                       repeated.  Off: such a pair is ordered by its exact fp32 distances -- nanoflann's order
@@ -336,6 +340,13 @@ int lslam_knn5_ex(lslam_ctx *ctx, int which_map, const void *queries, size_t nq,
                   int32_t search_mode, int32_t *idx_out, float *d2_out, int32_t *n_ties);
 int lslam_sweep_ex(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_t search_mode, int32_t *idx_out,
                    float *d2_out, float *coeff_out, uint8_t *flags_out, float *sums_out);
+/* Parity tap of the search a map WITHOUT kd-trees is matched through (lslam_map_defer_trees): the wide probe -- one wavefront
+ * per query over every cell of the resident cell grid within the sqrt(5) m acceptance gate -- for nq queries in the map
+ * frame.  Builds no tree.  idx_out[nq*5] / d2_out[nq*5] as lslam_knn5 (-1 / FLT_MAX where the gate holds fewer than five
+ * points); undecided_out[nq] = 1 where the grids cannot prove nanoflann's answer (an exact distance tie among the six nearest;
+ * with nf_margin != 0 also a fifth / sixth pair within 8 ulps, LSLAM_AB_WIDE_NF_MARGIN): a scan match would build the trees. */
+int lslam_debug_knn5_wide(lslam_ctx *ctx, int which_map, const void *queries, size_t nq, size_t stride_bytes, int32_t nf_margin,
+                          int32_t *idx_out, float *d2_out, uint8_t *undecided_out);
 
 /* The names SURVEY.md 8(b) gave these entry points before they were built, kept as exported aliases:
  *   lslam_residuals        = lslam_sweep with the MFMA contraction: coeff_out[N*4], valid_out[N] (the flag bits of

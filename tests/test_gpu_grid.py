@@ -422,56 +422,119 @@ def _seven_in_a_row_problem(with_cluster):
     return poles, surf, qc, qs
 
 
-def test_wide_probe_refuses_a_candidate_dropped_behind_six_keys_of_one_lane(pkg):
-    """sweep_wide_kernel gives a cell row to ONE lane, and a lane keeps its six smallest truncated keys.  Seven candidates in a
+def _exact_five(q, pts):
+    """the five nearest by the reference's own fp32 distance (x -> y -> z), ascending; and the sixth distance"""
+    d = (q[None, :].astype(np.float32) - pts[:, :3].astype(np.float32)).astype(np.float32)
+    d2 = ((d[:, 0] * d[:, 0]).astype(np.float32) + (d[:, 1] * d[:, 1]).astype(np.float32)).astype(np.float32) + (d[:, 2] * d[:, 2]).astype(np.float32)
+    o = np.argsort(d2, kind="stable")
+    return o[:5], d2[o[:5]], d2[o[5]]
+
+
+def test_wide_probe_finds_a_candidate_dropped_behind_six_keys_of_one_lane(pkg):
+    """sweep_wide_kernel gives a cell row to ONE lane, and a lane keeps its six smallest TRUNCATED keys.  Seven candidates in a
     row, the fifth to seventh nearest inside one truncation bucket with the nearest of them LAST in index order: the lane
-    drops exactly the candidate that is the true fifth neighbour, and all six wave-wide winners are that lane's.  The proof
-    must not accept the five it is left with (the sixth winner's key bounds what that lane dropped): the deferred call builds
-    the trees after all and returns the eager call's bits.  Without the cluster the same problem runs on the grids alone."""
+    drops exactly the candidate that is the true fifth neighbour, and all six wave-wide winners are that lane's (round 4's
+    kernel returned the wrong fifth and called it proven).  The lane now looks at its rows once more, exactly: the tap returns
+    the true five, decided, without a tree; and a whole scan match on that map runs on the grids alone and gives the eager
+    call's result."""
+    mc, ms, qc, qs = _seven_in_a_row_problem(True)
+    q = qs[-1]
+    five, d5, d6 = _exact_five(q, ms)
+    assert set(five.tolist()) == {len(ms) - 7, len(ms) - 6, len(ms) - 5, len(ms) - 4, len(ms) - 1}  # the four near ones and C
+    c = pkg.Context(0)
+    try:
+        c.defer_trees(True)
+        c.map_set(mc, ms)
+        idx, d2, und = c.knn5_wide(1, q[None, :3])
+        assert und[0] == 0 and np.array_equal(idx[0], five) and np.array_equal(bits(d2[0]), bits(d5))
+        assert c.lazy_trees() == (1, 0, True)
+    finally:
+        c.close()
     res = {}
-    for with_cluster in (False, True):
-        mc, ms, qc, qs = _seven_in_a_row_problem(with_cluster)
-        for defer in (False, True):
-            c = pkg.Context(0)
-            try:
-                c.defer_trees(defer)
-                c.map_set(mc, ms)
-                c.scan_set(qc, qs)
-                status, pose, st = c.run(np.zeros(6, np.float32))
-                res[(with_cluster, defer)] = (int(status), pose.copy(), st.iterations, st.n_rows, st.n_plane, c.lazy_trees())
-                if defer:
-                    assert c.grid_launches() > 0
-            finally:
-                c.close()
-    assert res[(False, True)][5] == (1, 0, True), res[(False, True)][5]       # no tree was needed
-    assert res[(True, True)][5] == (1, 1, False), res[(True, True)][5]        # the near-tie was refused: trees built, call repeated
-    for wc in (False, True):
-        a, b = res[(wc, False)], res[(wc, True)]
-        assert a[0] == b[0] and a[2:5] == b[2:5] and a[3] > 100
-        assert np.abs(a[1] - b[1]).max() <= 2e-6
-    assert np.array_equal(bits(res[(True, False)][1]), bits(res[(True, True)][1]))  # through the trees: the eager run's bits
+    for defer in (False, True):
+        c = pkg.Context(0)
+        try:
+            c.defer_trees(defer)
+            c.map_set(mc, ms)
+            c.scan_set(qc, qs)
+            status, pose, st = c.run(np.zeros(6, np.float32))
+            res[defer] = (int(status), pose.copy(), st.iterations, st.n_rows, st.n_plane, c.lazy_trees())
+        finally:
+            c.close()
+    assert res[True][5] == (1, 0, True), res[True][5]       # no tree was needed
+    assert res[False][0] == res[True][0] and res[False][2:5] == res[True][2:5] and res[True][3] > 100
+    assert np.abs(res[False][1] - res[True][1]).max() <= 2e-6
+
+
+@pytest.mark.parametrize("spacing,jitter", [(0.2, 0.05), (0.4, 0.1), (0.4, 1e-6), (1.5, 0.3)])
+def test_wide_probe_tap_equals_tree_search(pkg, spacing, jitter):
+    """The search a map without kd-trees is matched through, query by query (lslam_debug_knn5_wide) against nanoflann's
+    traversal on the same clouds (another context, trees built): planes, walls and poles at several densities -- 0.4 / 1e-6 is
+    a lattice jittered by micrometres (near-ties everywhere).  Wherever the wide probe DECIDES and the reference looks the
+    neighbours up at all (d2[4] < 5), indices and distances are nanoflann's bit for bit; undecided only where there is an exact
+    tie among the six nearest (checked by brute force)."""
+    rng = np.random.default_rng(int(spacing * 1000 + jitter * 100))
+    g = np.arange(-12.0, 12.0, spacing, dtype=np.float32)
+    gx, gy = np.meshgrid(g, g)
+    ground = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size, np.float32)], 1)
+    h = np.arange(0.0, 5.0, spacing, dtype=np.float32)
+    wx, wz = np.meshgrid(g, h)
+    wall = np.stack([wx.ravel(), np.full(wx.size, 5.3, np.float32), wz.ravel()], 1)
+    poles = np.concatenate([np.stack([np.full(len(h), x, np.float32), np.full(len(h), y, np.float32), h], 1)
+                            for x, y in rng.uniform(-10, 10, (12, 2))])
+    pts = np.concatenate([ground, wall, poles]).astype(np.float32)
+    pts = (pts + rng.uniform(-jitter, jitter, pts.shape)).astype(np.float32)
+    q = np.concatenate([pts[rng.integers(0, len(pts), 1500)] + rng.normal(0, 0.15, (1500, 3)),
+                        pts[rng.integers(0, len(pts), 500)] + rng.normal(0, 0.8, (500, 3)),
+                        pts[rng.integers(0, len(pts), 100)]]).astype(np.float32)
+    a = pkg.Context(0)
+    b = pkg.Context(0)
+    try:
+        a.map_set(pts, pts)
+        li, ld = a.knn5(1, q, search_mode=LANE)
+        b.defer_trees(True)
+        b.map_set(pts, pts)
+        wi, wd, und = b.knn5_wide(1, q)
+        assert b.lazy_trees() == (1, 0, True)
+    finally:
+        a.close()
+        b.close()
+    looked_up = ld[:, 4] < 5.0
+    dec = (und == 0) & looked_up
+    assert dec.sum() > 0.5 * looked_up.sum()
+    assert np.array_equal(wi[dec], li[dec]) and np.array_equal(bits(wd[dec]), bits(ld[dec]))
+    for i in np.nonzero((und != 0) & looked_up)[0][:200]:  # undecided => an exact tie among the six nearest
+        five, d5, d6 = _exact_five(q[i], pts)
+        six = np.concatenate([d5, [d6]])
+        assert len(set(six.tolist())) < 6, (i, six)
 
 
 def test_wide_probe_near_tie_margin_is_an_option(pkg):
-    """LSLAM_AB_WIDE_NF_MARGIN (lslam_opts.ab_switches & 16): a map without kd-trees and a scan point whose fifth and sixth
-    neighbours are two ulps apart.  Off (the default) the pair is ordered by its exact distances and no tree is built; on, the
-    point counts as undecidable, the trees are built and the call repeated.  Either way the eager call's pose."""
+    """LSLAM_AB_WIDE_NF_MARGIN (lslam_opts.ab_switches & 16; the tap's nf_margin): a map without kd-trees and a point whose
+    fifth and sixth neighbours are two ulps apart.  Off (the default) the pair is ordered by its exact distances -- decided,
+    no tree; on, the point counts as undecidable: a scan match builds the trees and repeats the call.  Either way the eager
+    call's result."""
     mc, ms, qc, qs = _seven_in_a_row_problem(False)
     q = np.array([3.30, 2.10, 30.0], np.float32)
     near = [[q[0] + dx, q[1], q[2]] for dx in (1.00, 1.02, 1.04, 1.06)]
-    # the fifth and sixth: the same dx = 1.1, dy = 0.01 and 0.01 + 1.5e-5 -> squared distances a few ulps apart (checked below
-    # in the kernel's own arithmetic: ((dx dx + dy dy) + dz dz), fp32)
     xa = np.float32(q[0] + np.float32(1.10))
     pa = np.array([xa, np.float32(q[1] + np.float32(0.01)), q[2]], np.float32)
     pb = np.array([xa, np.float32(q[1] + np.float32(0.010015)), q[2]], np.float32)
-    def d2k(p):
-        dx, dy, dz = np.float32(q[0] - p[0]), np.float32(q[1] - p[1]), np.float32(q[2] - p[2])
-        return np.float32(np.float32(np.float32(dx * dx) + np.float32(dy * dy)) + np.float32(dz * dz))
-    d2 = [d2k(pa), d2k(pb)]
-    assert d2[0] < d2[1] and (d2[1] - d2[0]) / d2[1] < 8 * 2.0 ** -23, d2
-    a, b = pa, pb
-    ms2 = np.concatenate([ms, np.array(near + [list(a), list(b)], np.float32)]).astype(np.float32)
+    ms2 = np.concatenate([ms, np.array(near + [list(pa), list(pb)], np.float32)]).astype(np.float32)
+    five, d5, d6 = _exact_five(q, ms2)
+    assert d5[4] < d6 and (d6 - d5[4]) / d6 < 8 * 2.0 ** -23 and five[4] == len(ms2) - 2
     qs2 = np.concatenate([qs, q[None, :]]).astype(np.float32)
+    c = pkg.Context(0)
+    try:
+        c.defer_trees(True)
+        c.map_set(mc, ms2)
+        idx, d2, und = c.knn5_wide(1, q[None, :3])
+        assert und[0] == 0 and np.array_equal(idx[0], five) and np.array_equal(bits(d2[0]), bits(d5))
+        idx, d2, und = c.knn5_wide(1, q[None, :3], nf_margin=True)
+        assert und[0] == 1
+        assert c.lazy_trees() == (1, 0, True)
+    finally:
+        c.close()
     res = {}
     for name, defer, ab in (("eager", False, 0), ("deferred", True, 0), ("deferred+margin", True, 16)):
         c = pkg.Context(0)
@@ -491,3 +554,39 @@ def test_wide_probe_near_tie_margin_is_an_option(pkg):
         assert res[k][0] == res["eager"][0] and res[k][2:4] == res["eager"][2:4]
         assert np.abs(res[k][1] - res["eager"][1]).max() <= 2e-6
     assert np.array_equal(bits(res["deferred+margin"][1]), bits(res["eager"][1]))
+
+
+@pytest.mark.parametrize("from_sweep", [0, 1, 2])
+def test_grid_fit_cache_gives_the_same_bits(pkg, synth, monkeypatch, from_sweep):
+    """LSLAM_AB_FIT_CACHE: surf points whose five neighbours did not change reuse the previous sweep's plane, the others are
+    compacted through LDS and fitted by as few wavefronts as they fill.  findPlane is a pure function of the five in order and
+    every lane still forms its own row, so the loop is the SAME BITS as without the cache -- with the cache used from the
+    default sweep (0 = the library's: the fourth) and, forced through the environment, from a loop's second and third sweep
+    (where most points' neighbours DID change: both the compacted and the everybody-fits form run)."""
+    if from_sweep:
+        monkeypatch.setenv("LSLAM_FIT_FROM_SWEEP", str(from_sweep))
+    c = pkg.Context(0)
+    try:
+        pr0 = synth.make_problem(rings=16, azimuth_steps=900, world_half=60.0)
+        c.map_set(pr0["map_corner"], pr0["map_surf"])
+        scans, inits = [], []
+        for k in range(6):
+            pr = synth.make_problem(rings=16, azimuth_steps=900, world_half=60.0, seed=k)
+            scans.append((pr["corner"], pr["surf"]))
+            inits.append(synth.perturb_pose(pr["gt_pose"], seed=40 + k, dt=0.4, dr_deg=2.5))  # far enough for loops of 4+ sweeps
+        c.scan_set_batch(scans)
+        inits = np.stack(inits)
+        o = c.default_opts()
+        o.search_mode = GRID
+        res = {}
+        for ab in (0, 32, 0, 32):
+            o.ab_switches = ab
+            _, p, st = c.run_batch(inits, o)
+            key = (ab, len([k for k in res if k[0] == ab]))
+            res[key] = (p.copy(), [(s.status, s.iterations, s.n_rows, s.n_line, s.n_plane, s.converged, s.sweeps) for s in st])
+        assert max(s[6] for s in res[(0, 0)][1]) >= 4  # loops long enough for cached fits to be used
+        for key in ((32, 0), (0, 1), (32, 1)):
+            assert res[key][1] == res[(0, 0)][1], key
+            assert np.array_equal(bits(res[key][0]), bits(res[(0, 0)][0])), key
+    finally:
+        c.close()

@@ -183,6 +183,8 @@ struct lslam_ctx {
   std::vector<GroupDesc> h_groups;
   std::vector<int32_t> h_prob_group0;  // [n_prob + 1] first group of every scan
   uint64_t queue_launches = 0;
+  DevBuf<int32_t> fit_ids;     // the grid sweep's fit cache (LSLAM_AB_FIT_CACHE): [5][n_points] neighbour positions ...
+  DevBuf<float> fit_val;       // ... and [5][n_points] plane + verdict
   DevBuf<unsigned long long> cert_stats;  // LSLAM_DEBUG_CERT_STATS=1: [searched, swept] counters of the certificate path
   bool prev_valid = false;
   bool grid_state_valid = false;  // prev_q holds what a grid-sweep run of the resident scan against the resident map left (LSLAM_SWEEP_CARRIED)
@@ -243,6 +245,7 @@ struct lslam_ctx {
   // environment overrides of lslam_opts fields, read ONCE when the context is made (never inside a call)
   int env_knn_cert = -1;       // LSLAM_KNN_CERT (-1: not set)
   float env_cert_try_m = -1.0f, env_cert_track_m = -1.0f, env_grid_cell = -1.0f;  // LSLAM_CERT_TRY_M, LSLAM_CERT_TRACK_M, LSLAM_GRID_CELL
+  int env_fit_from_sweep = 0;  // LSLAM_FIT_FROM_SWEEP: A/B -- the sweep of a loop from which cached fits are used (default 3)
   float env_grid_cell_corner = -1.0f;  // LSLAM_GRID_CELL_CORNER: A/B switch -- another cell edge for the corner map's grid (the line-like cloud)
   int env_search = -1;         // LSLAM_SEARCH=lane|packet|grid
   int env_debug_cert_stats = 0;  // LSLAM_DEBUG_CERT_STATS
@@ -321,6 +324,10 @@ void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
   a.grid = 0;
   a.grid_clip_margin = GRID_CLIP_MARGIN_MIN;
   a.wide_nf_slack = 0.0f;
+  a.fit_ids = nullptr;
+  a.fit_val = nullptr;
+  a.n_fit = 0;
+  a.fit_from_sweep = 0;
   a.grid_hint = nullptr;
   a.need2_list = nullptr;
   a.need2_cnt = nullptr;
@@ -617,6 +624,7 @@ int lslam_ctx_create(int device, lslam_ctx **out) {
   if (const char *v = std::getenv("LSLAM_CERT_TRACK_M")) ctx->env_cert_track_m = (float)std::atof(v);
   if (const char *v = std::getenv("LSLAM_GRID_CELL")) ctx->env_grid_cell = (float)std::atof(v);
   if (const char *v = std::getenv("LSLAM_GRID_CELL_CORNER")) ctx->env_grid_cell_corner = (float)std::atof(v);
+  if (const char *v = std::getenv("LSLAM_FIT_FROM_SWEEP")) ctx->env_fit_from_sweep = std::atoi(v);
   if (const char *v = std::getenv("LSLAM_DEBUG_CERT_STATS")) ctx->env_debug_cert_stats = std::atoi(v);
   if (const char *v = std::getenv("LSLAM_FORCE_STACK")) {
     if (!std::strcmp(v, "deep")) ctx->env_force_stack = SWEEP_STACK_DEEP;
@@ -625,6 +633,7 @@ int lslam_ctx_create(int device, lslam_ctx **out) {
   }
   if (const char *v = std::getenv("LSLAM_PERSISTENT_GN")) ctx->env_ab |= std::atoi(v) == 1 ? LSLAM_AB_PERSISTENT_GN : 0;
   if (const char *v = std::getenv("LSLAM_FUSED_SOLVE")) ctx->env_ab |= std::atoi(v) == 1 ? LSLAM_AB_FUSED_SOLVE : 0;
+  if (const char *v = std::getenv("LSLAM_AB_SWITCHES")) ctx->env_ab |= std::atoi(v);  // any LSLAM_AB_* bits, for A/B runs of unmodified programs
   ctx->env_debug = lslam::env_once().debug;
   if (const char *v = std::getenv("LSLAM_SEARCH")) {
     if (!std::strcmp(v, "lane")) ctx->env_search = LSLAM_SEARCH_LANE;
@@ -1816,6 +1825,15 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
       sa.prev_q = ctx->prev_q.p;
       sa.prev_lb = nullptr;
       sa.grid_hint = ctx->prev_lb.p;  // (the certificate sweep's per-point array, free in this mode)
+      if (sa.grid == 1 && ((o.ab_switches | ctx->env_ab) & LSLAM_AB_FIT_CACHE)) {  // the fit cache (sweep_grid_kernel)
+        const size_t nf = std::max<size_t>(ctx->n_points, 1);
+        HIP_TRY(ctx->fit_ids.reserve(5 * nf));
+        HIP_TRY(ctx->fit_val.reserve(5 * nf));
+        sa.fit_ids = ctx->fit_ids.p;
+        sa.fit_val = ctx->fit_val.p;
+        sa.n_fit = (int32_t)nf;
+        sa.fit_from_sweep = ctx->env_fit_from_sweep > 0 ? ctx->env_fit_from_sweep : 3;
+      }
     }
     if ((sa.prev_q || sa.grid) && (ctx->env_debug_cert_stats || o.debug_stats)) {
       if (!ctx->cert_stats.p) {
@@ -2518,6 +2536,40 @@ int lslam_knn5_ex(lslam_ctx *ctx, int which_map, const void *queries, size_t nq,
   HIP_TRY(hipMemcpyAsync(idx_out, ctx->t_idx.p, nq * 5 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(d2_out, ctx->t_d2.p, nq * 5 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return LSLAM_OK;
+}
+
+// Parity tap of the search a map WITHOUT kd-trees is matched through (include/lslam_c.h): the wide probe on the resident cell
+// grids, every cell within the acceptance gate, one wavefront per query.  Builds no tree.
+int lslam_debug_knn5_wide(lslam_ctx *ctx, int which_map, const void *queries, size_t nq, size_t stride_bytes, int32_t nf_margin,
+                          int32_t *idx_out, float *d2_out, uint8_t *undecided_out) {
+  int rc = check_ctx(ctx, true);
+  if (rc) return rc;
+  if (!ctx->have_map || ctx->cube_mode) { set_err("no whole-map search structure set"); return LSLAM_ERR_NO_MAP; }
+  if ((which_map != 0 && which_map != 1) || stride_bytes < 12 || (stride_bytes & 3) ||
+      (nq && (!queries || !idx_out || !d2_out || !undecided_out)) || nq > 0x0FFFFFFFu) {
+    set_err("bad knn5 arguments");
+    return LSLAM_ERR_INVALID;
+  }
+  if (nq == 0) return LSLAM_OK;
+  if (!ctx->trees_pending) {  // a map with trees: its grids are made on first use
+    rc = ensure_grid(ctx, ctx->env_grid_cell > 0.0f ? ctx->env_grid_cell : 0.0f);
+    if (rc) return rc;
+  }
+  const CellGrid &G = which_map ? ctx->ks.view : ctx->kc.view;
+  if (!G.cell_start) { set_err("this map has no cell grid (status %d)", ctx->grid_status); return LSLAM_ERR_INVALID; }
+  std::vector<float4> q;
+  pack_cloud(queries, nq, stride_bytes, q);
+  HIP_TRY(ctx->t_q.reserve(nq));
+  HIP_TRY(ctx->t_idx.reserve(nq * 5));
+  HIP_TRY(ctx->t_d2.reserve(nq * 5));
+  HIP_TRY(ctx->t_flags.reserve(nq + 1));
+  HIP_TRY(hipMemcpyAsync(ctx->t_q.p, q.data(), nq * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(launch_knn5_wide(G, ctx->t_q.p, (int)nq, nf_margin ? GRID_NF_PRUNE_SLACK_WIDE : 0.0f, ctx->t_idx.p, ctx->t_d2.p, ctx->t_flags.p, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(idx_out, ctx->t_idx.p, nq * 5 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d2_out, ctx->t_d2.p, nq * 5 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(undecided_out, ctx->t_flags.p, nq, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));  // (q is a local)
   return LSLAM_OK;
 }
 

@@ -130,6 +130,12 @@ struct SweepArgs {
   // neighbours in wide_d / wide_p (positions in kc.pts / ks.pts); sweep_queue_kernel then only runs their residual chain.  A
   // point whose answer needs nanoflann's visit order (an exact distance tie) raises GNState::pad of its scan: the caller builds
   // the trees and runs the call again through them.
+  // the fit cache of the grid sweep (sweep_grid_kernel; null: off): per scan point the five neighbours its last fit was made
+  // from (positions in ks.pts, -1: none) and the plane with its verdict, both as five planes of n_fit words
+  int32_t *fit_ids;        // [5][n_fit]
+  float *fit_val;          // [5][n_fit]  plane[0..3], found (0 / 1)
+  int32_t n_fit;
+  int32_t fit_from_sweep;  // sweep index (0 = a loop's first) from which cached fits are used; they are stored one sweep earlier
   float wide_nf_slack;     // relative margin of the wide probe's fifth-against-sixth test (lslam_grid.hpp GRID_NF_PRUNE_SLACK_WIDE, or 0)
   float *wide_d;           // [points][5]
   int32_t *wide_p;         // [points][5]
@@ -272,6 +278,7 @@ enum : int {
 };
 hipError_t launch_sweep_grid(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t start, hipEvent_t stop, bool resolve_in_place = false);
 hipError_t launch_sweep_wide(const SweepArgs &a, hipStream_t s);  // sweep_wide_kernel (its prefix: launch_sweep_plan with_prefix)
+hipError_t launch_knn5_wide(const CellGrid &G, const float4 *q, int nq, float nf_slack, int32_t *idx, float *d2, uint8_t *undecided, hipStream_t s);
 hipError_t launch_knn5_grid(const CellGrid &G, const TreeView &T, const float4 *q, int nq, int32_t *idx, float *d2,
                             uint32_t *stack_ovf, int32_t *n_unproven, hipStream_t s);
 

@@ -1514,8 +1514,107 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 
     // what the next sweep's bound is taken from: where the point is now and how far its fifth neighbour
     const bool fifth_known = resolved_wide ? (p[4] >= 0 && d[4] < 5.0f) : (verdict == GRID_PROVEN && d[4] < 5.0f);
     if (a.bounded) a.prev_q[qi] = make_float4(sel[0], sel[1], sel[2], fifth_known ? d[4] : FLT_MAX);
-    point_residual(a, bd, is_surf, G.pts, q, sel, d, p, sc, row, rb, kept, matched, score);
   }
+  // ---- the plane fit of a surf block, with the fit cache (lslam_opts.ab_switches & LSLAM_AB_FIT_CACHE) ---------------------
+  // findPlane is a pure function of the five neighbours IN ORDER (feature_utils.h:157-204), and late in a Gauss-Newton loop
+  // most points keep theirs from one sweep to the next (84 % from the third to the fourth sweep of the bench's loops, 97 % to
+  // the fifth; 1 % and 23 % before: tools/nb_change_stats.py).  From the sweep with index fit_from_sweep - 1 on, a proven point
+  // stores its five neighbours (positions in the cell-sorted map) and its plane; from fit_from_sweep on it compares, and the
+  // workgroup runs the fit only for the points whose five changed -- COMPACTED through LDS into as few wavefronts as they
+  // fill, because a lone changed lane would otherwise cost its wavefront the whole fit (917 instructions).  Same bits: a
+  // cached plane is the plane the same five points gave.
+  bool fit_done = false;
+  if (!WIDE && a.fit_ids != nullptr && is_surf && a.bounded && a.fine_gate_c < 0.0f && a.flags_out == nullptr) {  // block-uniform
+    const int sweep_ix = st->sweeps;
+    const bool fc_store = sweep_ix >= a.fit_from_sweep - 1, fc_use = sweep_ix >= a.fit_from_sweep && a.prev_valid;
+    if (fc_store) {
+      fit_done = true;
+      const size_t nf = (size_t)a.n_fit;
+      const bool gate = has && d[4] < 5.0f;  // ScanMatch.cpp:120
+      bool same = false;
+      if (fc_use && gate) {
+        same = true;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) same = same && a.fit_ids[j * nf + qi] == p[j];
+      }
+      const bool need_fit = gate && !same;
+      float plane[4] = {0.f, 0.f, 0.f, 0.f};
+      bool plane_ok = false;
+      // slots of the points that need a fit, in lane order
+      const unsigned long long mf = __ballot(need_fit);
+      __syncthreads();  // (the list's counters above have been read by everybody: wave_needy is free again)
+      if (lane == 0) wave_needy[wave] = __popcll(mf);
+      __syncthreads();
+      int foff = 0, ftotal = 0;
+#pragma unroll
+      for (int w = 0; w < NWAVE; ++w) {
+        const int c = wave_needy[w];
+        foff += w < wave ? c : 0;
+        ftotal += c;
+      }
+      if (fc_use && ftotal <= BLOCK / 2) {  // block-uniform: few enough to pay for the detour
+        int32_t *slot_p = reinterpret_cast<int32_t *>(rows_lds);               // [BLOCK][6]: five positions, the owner's thread
+        float *slot_f = reinterpret_cast<float *>(rows_lds) + 6 * BLOCK;       // [BLOCK][5]: the plane, found
+        const int myslot = foff + __popcll(mf & ((1ull << lane) - 1ull));
+        if (need_fit) {
+#pragma unroll
+          for (int j = 0; j < 5; ++j) slot_p[myslot * 6 + j] = p[j];
+          slot_p[myslot * 6 + 5] = tid;
+        }
+        __syncthreads();
+        if (tid < ftotal) {  // the first ceil(ftotal / 64) wavefronts
+          float4 nb5[5];
+#pragma unroll
+          for (int j = 0; j < 5; ++j) nb5[j] = G.pts[slot_p[tid * 6 + j]];
+          float pl[4];
+          const bool ok = find_plane(nb5, 0.2f, pl);
+          const int owner_q = bd.first + slot_p[tid * 6 + 5];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            slot_f[tid * 5 + j] = pl[j];
+            a.fit_val[j * nf + owner_q] = pl[j];
+          }
+          slot_f[tid * 5 + 4] = ok ? 1.0f : 0.0f;
+          a.fit_val[4 * nf + owner_q] = ok ? 1.0f : 0.0f;
+        }
+        if (same) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) plane[j] = a.fit_val[j * nf + qi];
+          plane_ok = a.fit_val[4 * nf + qi] != 0.0f;
+        }
+        __syncthreads();
+        if (need_fit) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) plane[j] = slot_f[myslot * 5 + j];
+          plane_ok = slot_f[myslot * 5 + 4] != 0.0f;
+        }
+      } else if (gate) {  // everybody fits for itself (the sweep that fills the cache; a sweep after a large step)
+        float4 nb5[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) nb5[j] = G.pts[p[j]];
+        plane_ok = find_plane(nb5, 0.2f, plane);
+        if (!same) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a.fit_val[j * nf + qi] = plane[j];
+          a.fit_val[4 * nf + qi] = plane_ok ? 1.0f : 0.0f;
+        }
+      }
+      if (active && !same) {  // what the next sweep compares with: the five of a proven point inside the gate, else "none"
+#pragma unroll
+        for (int j = 0; j < 5; ++j) a.fit_ids[j * nf + qi] = gate ? p[j] : -1;
+      }
+      if (gate && plane_ok) {  // ScanMatch.cpp:122-139
+        matched = 1.0f;
+        float coeff[4];
+        if (surf_coeff(plane, sel, coeff)) {
+          jacobian_row(sc, q.x, q.y, q.z, coeff, row, rb);
+          kept = 1.0f;
+          score = expf(-fabsf(coeff[3]));
+        }
+      }
+    }
+  }
+  if (has && !fit_done) point_residual(a, bd, is_surf, G.pts, q, sel, d, p, sc, row, rb, kept, matched, score);
   __syncthreads();  // every wavefront is done with its row table: the staging rows may be written
   block_accumulate<BLOCK, false, false>(jtj_mode, is_surf, row, rb, kept, matched, score, rows_lds, red, a.partials + (size_t)lb * NCOL);
 }
@@ -1664,21 +1763,45 @@ LSLAM_DEV void wide_probe(const CellGrid &G, const float (&sel)[3], float r2, in
     if (j < 5) knn_insert_sorted(d, p, x, pos[j]);
     else e6 = x;
   }
-  // The lane that ran dry: its sixth key only bounds what it dropped to 2^-13 -- a fifth and sixth distance inside one such
-  // bucket (1 in 10^3 - 10^4) would refuse the point, i.e. build the trees of the whole map.  The dry lane looks at its rows once
-  // more instead, exactly: if precisely five of its candidates are nearer than the sixth winner, the six winners ARE its six
-  // nearest and everything it dropped is at least the sixth winner's exact distance away -- which lb already is.
+  // The lane that ran dry: its keys order its candidates only to 2^-13, so among candidates of one such bucket the six it KEPT
+  // need not be its six nearest, and what it dropped is bounded only by its sixth key.  Refusing the point on that bound
+  // (d[4] against the sixth key's truncated distance) built the trees of the whole map in every fourth frame of the mapping
+  // node's loop.  The dry lane looks at its rows once more instead, EXACTLY: its six nearest candidates by the search's own
+  // distance replace the six winners (every other lane's candidates are at least the smallest key those lanes still hold
+  // away -- `rest` below -- which is not below the sixth winner's key), and nothing it dropped is nearer than the sixth of them.
   if (dry_lane >= 0) {  // wave-uniform, rare
-    int nearer = 0;
+    float ed[6] = {FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX};
+    int ep[6] = {-1, -1, -1, -1, -1, -1};
     if (lane == dry_lane) {
 #pragma unroll
       for (int k = 0; k < WIDE_ROWS_PER_LANE; ++k) {
         const uint32_t s0 = row_s[k], cnt = row_id0[k + 1] - row_id0[k];
-        for (uint32_t j = 0; j < cnt; ++j) nearer += dist2_xyz(sel[0], sel[1], sel[2], G.pts[s0 + j]) < e6 ? 1 : 0;
+        for (uint32_t j = 0; j < cnt; ++j) {
+          float x = dist2_xyz(sel[0], sel[1], sel[2], G.pts[s0 + j]);
+          int xp = (int)(s0 + j);
+#pragma unroll
+          for (int m = 0; m < 6; ++m) {  // sorted insert, earlier candidates first among equals (an exact tie is refused below)
+            const bool lt = x < ed[m];
+            const float td = ed[m];
+            const int tp = ep[m];
+            ed[m] = lt ? x : td;
+            ep[m] = lt ? xp : tp;
+            x = lt ? td : x;
+            xp = lt ? tp : xp;
+          }
+        }
       }
     }
-    nearer = __shfl(nearer, dry_lane, 64);
-    if (nearer == 5) dropped = 0xFFFFFFFFu;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+      ed[m] = __shfl(ed[m], dry_lane, 64);
+      ep[m] = __shfl(ep[m], dry_lane, 64);
+    }
+#pragma unroll
+    for (int m = 0; m < 5; ++m) { d[m] = ed[m]; p[m] = ep[m]; }
+    e6 = ed[5];
+    pos[5] = ep[5];
+    dropped = 0xFFFFFFFFu;
   }
   const uint32_t rest = min(wave_min_u32(k0), dropped);  // every other candidate's truncated distance is at least this
   lb = fmaxf(e6, d[4]);
@@ -2407,6 +2530,36 @@ hipError_t launch_knn5_grid(const CellGrid &G, const TreeView &T, const float4 *
                             uint32_t *stack_ovf, int32_t *n_unproven, hipStream_t s) {
   if (nq <= 0) return hipSuccess;
   hipLaunchKernelGGL(knn5_grid_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, G, T, q, nq, idx, d2, stack_ovf, n_unproven);
+  return hipGetLastError();
+}
+
+// parity tap of the wide probe (a map without kd-trees): one wavefront per query, every cell within the acceptance gate
+__global__ __launch_bounds__(256) void knn5_wide_kernel(CellGrid G, const float4 *q, int nq, float nf_slack, int32_t *idx, float *d2, uint8_t *undecided) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // wave-uniform
+  if (i >= nq) return;
+  const float4 qq = q[i];
+  const float sel[3] = {qq.x, qq.y, qq.z};
+  float d[5];
+  int p[5];
+  bool num, bad;
+  wide_probe(G, sel, 5.0f * (1.0f + 1e-5f), lane, nf_slack, d, p, num, bad);
+  if (lane < 5) {
+    float dv = d[0];
+    int pv = p[0];
+#pragma unroll
+    for (int j = 1; j < 5; ++j) {
+      dv = lane == j ? d[j] : dv;
+      pv = lane == j ? p[j] : pv;
+    }
+    idx[(size_t)i * 5 + lane] = pv >= 0 ? __float_as_int(G.pts[pv].w) : -1;
+    d2[(size_t)i * 5 + lane] = dv;
+  }
+  if (lane == 0) undecided[i] = (bad || !num) ? 1 : 0;
+}
+hipError_t launch_knn5_wide(const CellGrid &G, const float4 *q, int nq, float nf_slack, int32_t *idx, float *d2, uint8_t *undecided, hipStream_t s) {
+  if (nq <= 0) return hipSuccess;
+  hipLaunchKernelGGL(knn5_wide_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, G, q, nq, nf_slack, idx, d2, undecided);
   return hipGetLastError();
 }
 

@@ -384,6 +384,16 @@ class Context:
                                            idx.ctypes.data_as(c_int32_p), _fp(d2), C.byref(ties)))
         return (idx, d2, ties.value) if want_ties else (idx, d2)
 
+    def knn5_wide(self, which_map, queries, nf_margin=False):
+        """lslam_debug_knn5_wide: the wide probe of a map without kd-trees -> (idx [n, 5], d2 [n, 5], undecided [n])."""
+        q, sq = _cloud(queries)
+        idx = np.zeros((len(q), 5), np.int32)
+        d2 = np.zeros((len(q), 5), np.float32)
+        und = np.zeros(len(q), np.uint8)
+        self._check(self.lib.lslam_debug_knn5_wide(self.h, int(which_map), _vp(q), len(q), sq, int(bool(nf_margin)),
+                                                   idx.ctypes.data_as(c_int32_p), _fp(d2), und.ctypes.data_as(c_uint8_p)))
+        return idx, d2, und
+
     def sweep(self, pose, jtj_mode=0, taps=True, search_mode=1):
         p = np.array(pose, dtype=np.float32).reshape(6)
         n = self.n_scan

@@ -1396,7 +1396,9 @@ LSLAM_DEV void wide_probe(const CellGrid &G, const float (&sel)[3], float r2, in
 // (Tried for single-scan launches and dropped: the candidate loop row after row with four points in flight instead of the
 // lock-step one-candidate-per-round loop -- same bits, no faster, 27 - 32 us against 23 - 31: a launch of one wavefront per
 // SIMD is a chain of latencies of which the loop is only one.)
-template <int BLOCK, bool WIDE = false>
+// FITC: the instantiation with the fit cache (LSLAM_AB_FIT_CACHE) -- a template argument, not a run-time branch: with the cache's
+// code in it the kernel everybody runs was 3.5 % slower (16 bytes of scratch, twelve more scalar registers, a longer program)
+template <int BLOCK, bool WIDE = false, bool FITC = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 : LSLAM_GRID_OCC))) void sweep_grid_kernel(SweepArgs a, int jtj_mode) {
   constexpr int NWAVE = BLOCK / 64;
   const int lb = xcd_remap(blockIdx.x, a.nb_total);
@@ -1524,7 +1526,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 
   // fill, because a lone changed lane would otherwise cost its wavefront the whole fit (917 instructions).  Same bits: a
   // cached plane is the plane the same five points gave.
   bool fit_done = false;
-  if (!WIDE && a.fit_ids != nullptr && is_surf && a.bounded && a.fine_gate_c < 0.0f && a.flags_out == nullptr) {  // block-uniform
+  if (FITC && !WIDE && a.fit_ids != nullptr && is_surf && a.bounded && a.fine_gate_c < 0.0f && a.flags_out == nullptr) {  // block-uniform
     const int sweep_ix = st->sweeps;
     const bool fc_store = sweep_ix >= a.fit_from_sweep - 1, fc_use = sweep_ix >= a.fit_from_sweep && a.prev_valid;
     if (fc_store) {
@@ -1622,6 +1624,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 
 hipError_t launch_sweep_grid(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t start, hipEvent_t stop, bool resolve_in_place) {
   if (a.nb_total <= 0) return hipSuccess;
   if (resolve_in_place) hipExtLaunchKernelGGL((sweep_grid_kernel<SWEEP_BLOCK, true>), dim3(a.nb_total), dim3(SWEEP_BLOCK), 0, s, start, stop, 0, a, jtj_mode);
+  else if (a.fit_ids) hipExtLaunchKernelGGL((sweep_grid_kernel<SWEEP_BLOCK, false, true>), dim3(a.nb_total), dim3(SWEEP_BLOCK), 0, s, start, stop, 0, a, jtj_mode);
   else hipExtLaunchKernelGGL((sweep_grid_kernel<SWEEP_BLOCK>), dim3(a.nb_total), dim3(SWEEP_BLOCK), 0, s, start, stop, 0, a, jtj_mode);
   return hipGetLastError();
 }

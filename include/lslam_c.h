@@ -194,7 +194,9 @@ void lslam_default_opts(lslam_opts *opts);
  * another header would hand the library a struct of the wrong size: compare before the first call --
  *   assert(lslam_abi_version() == LSLAM_ABI_VERSION && lslam_sizeof_opts() == sizeof(lslam_opts));
  * (the C++ mirrors do, and refuse to start otherwise). */
-#define LSLAM_ABI_VERSION 4
+/* 5 (round 5): no struct changed; new entry points (lslam_debug_grid_stats, lslam_debug_knn5_wide), new bits (LSLAM_SWEEP_FIRST /
+ * _CARRIED, LSLAM_AB_FIT_CACHE, LSLAM_AB_WIDE_NF_MARGIN) -- a program built against this header needs a library that has them. */
+#define LSLAM_ABI_VERSION 5
 int lslam_abi_version(void);
 size_t lslam_sizeof_opts(void);
 size_t lslam_sizeof_stats(void);

@@ -469,6 +469,10 @@ hipError_t sweep_launch(lslam_ctx *ctx, const SweepArgs &a, int jtj_mode, hipEve
       ctx->queue_launches++;
       return e;
     }
+#ifdef LSLAM_EXP_NO_PASS2  // TIMING EXPERIMENT ONLY (wrong results): the listed points are dropped -- what the second pass costs
+    if (e1) return hipEventRecord(e1, ctx->stream);
+    return hipSuccess;
+#endif
     e = launch_sweep_queue(a, jtj_mode, ctx->stream, e1, pass2, plan, 0, planned);
     ctx->queue_launches++;
     return e;

@@ -89,7 +89,12 @@ LSLAM_DEV void point_residual(const SweepArgs &a, const BlockDesc &bd, const boo
       }
     } else {
       float plane[4];
+#ifdef LSLAM_EXP_NO_FIT  // TIMING EXPERIMENT ONLY (wrong results): no plane fit -- what the fit costs
+      plane[0] = 0.0f; plane[1] = 0.0f; plane[2] = 1.0f; plane[3] = -nb[0].z;
+      if (nb[1].x < 1.0e30f) {
+#else
       if (find_plane(nb, 0.2f, plane)) {  // ScanMatch.cpp:122-130
+#endif
         flag |= 2u;
         if (surf_coeff(plane, sel, coeff)) flag |= 4u;
       }
@@ -148,7 +153,11 @@ LSLAM_DEV void block_accumulate(const int jtj_mode, const bool is_surf, const fl
 #pragma unroll
   for (int i = 0; i < NCOL; ++i) v[i] = 0.0f;
 
+#ifdef LSLAM_EXP_NO_ACC  // TIMING EXPERIMENT ONLY (wrong results): no contraction -- what the per-wave J^T J costs
+  if (false) {
+#else
   if (jtj_mode == 1) {
+#endif
     // stage [J | b] rows; rows of rejected points are zero
     float *jr = reinterpret_cast<float *>(stage) + wave * 64;  // [c * BLOCK + p]
 #pragma unroll
@@ -1460,6 +1469,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 
   }
   float d[5], lb6;
   int p[5];
+#ifdef LSLAM_EXP_SETUP_TWICE  // TIMING EXPERIMENT ONLY (same results): the probe's eighteen cell-table loads issued once more, one cell row higher
+  {
+    const float ux = (sel[0] - G.org[0]) * G.inv_c, uy = (sel[1] - G.org[1]) * G.inv_c, uz = (sel[2] - G.org[2]) * G.inv_c;
+    const bool inr = ux >= 2.0f && ux < (float)(G.nx - 2) && uy >= 2.0f && uy < (float)(G.ny - 2) && uz >= 2.0f && uz < (float)(G.nz - 3);
+    const int ix = inr ? (int)ux : 2, iy = inr ? (int)uy : 2, iz = inr ? (int)uz + 1 : 2;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      const int base = G.nx * ((iy + r % 3 - 1) + G.ny * (iz + r / 3 - 1));
+      acc += G.cell_start[base + ix - 1] ^ G.cell_start[base + ix + 2];
+    }
+    asm volatile("" ::"v"(acc));
+  }
+#endif
   int verdict = knn5_grid<BLOCK>(G, active, sel[0], sel[1], sel[2], bound, a.grid_clip_margin, (lds_u32 *)(rows_lds + tid), d, p, lb6);
   // beyond the gate nothing is looked up (ScanMatch.cpp:102,120); the taps and the _fineScore re-sweep want nanoflann's answer
   if (verdict == GRID_FAR && !a.bounded) verdict = GRID_UNPROVEN;

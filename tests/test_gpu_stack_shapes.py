@@ -674,3 +674,29 @@ def test_full_size_map_vlp16_mapping_frames_match_oracle(full_map_problem, pkg, 
         mapper.feature_map.close()
     finally:
         c2.close()
+
+
+def test_full_size_map_wide_probe_equals_tree_search(full_map_problem):
+    """The search the mapping node's frames run on (a map without kd-trees: the wide probe over the cell grid) against nanoflann's
+    traversal, query by query, on the FULL-size configs[1] map: the points of a 64 x 1800 scan at its initial (displaced) pose and at
+    its matched pose, corner and surf.  Wherever the probe decides and the reference looks the five up (d2[4] < 5): nanoflann's
+    indices and distances, bit for bit; undecided stays rare."""
+    fp = full_map_problem
+    ctx = fp["ctx"]
+    qc, qs = fp["scans"][3]
+    ctx.scan_set(qc, qs)
+    o = ctx.default_opts()
+    status, pose, st = ctx.run(fp["inits"][3], o)
+    n_dec = n_und = 0
+    for p in (fp["inits"][3], pose):
+        T = ctx.pose_to_isometry(p)
+        for which, cloud in ((0, qc), (1, qs[::4])):
+            q = (cloud[:, :3] @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+            li, ld = ctx.knn5(which, q, search_mode=LANE)
+            wi, wd, und = ctx.knn5_wide(which, q)
+            looked_up = ld[:, 4] < 5.0
+            dec = (und == 0) & looked_up
+            assert np.array_equal(wi[dec], li[dec]) and np.array_equal(bits(wd[dec]), bits(ld[dec])), which
+            n_dec += int(dec.sum())
+            n_und += int(((und != 0) & looked_up).sum())
+    assert n_dec > 60000 and n_und < 1e-3 * n_dec, (n_dec, n_und)

@@ -110,6 +110,8 @@ enum { LSLAM_AB_PERSISTENT_GN = 1, /* one resident scan: the whole Gauss-Newton 
                                       ones of the sweep before reuses that sweep's plane (findPlane is a pure function of the five
                                       in order); the points whose five changed are compacted through LDS so that the fit runs on as
                                       few wavefronts as they fill.  Same bits.  DESIGN 4 has the measurement */
+       LSLAM_AB_NO_COMPACT = 64,   /* a batch through the grid sweep: launch every workgroup of every scan in every sweep (round 4's
+                                      form) instead of only those of the scans whose loop is still running */
        LSLAM_AB_WIDE_NF_MARGIN = 16 /* a map without kd-trees: a point whose fifth and sixth distances are within 8 ulps of each
                                       other counts as undecidable too (as an exact tie does): the trees are built and the call
                                       repeated.  Off: such a pair is ordered by its exact fp32 distances -- nanoflann's order

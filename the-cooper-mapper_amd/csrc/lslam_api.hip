@@ -183,6 +183,10 @@ struct lslam_ctx {
   std::vector<GroupDesc> h_groups;
   std::vector<int32_t> h_prob_group0;  // [n_prob + 1] first group of every scan
   uint64_t queue_launches = 0;
+  DevBuf<int32_t> active_blocks;  // [nb_total] the grid sweep of a batch: block indices of the scans still running, per chunk at its block range
+  int32_t *h_active = nullptr;    // pinned: [n_chunks] how many
+  size_t h_active_cap = 0;
+  DevBuf<int32_t> d_active_cnt;
   DevBuf<int32_t> fit_ids;     // the grid sweep's fit cache (LSLAM_AB_FIT_CACHE): [5][n_points] neighbour positions ...
   DevBuf<float> fit_val;       // ... and [5][n_points] plane + verdict
   DevBuf<unsigned long long> cert_stats;  // LSLAM_DEBUG_CERT_STATS=1: [searched, swept] counters of the certificate path
@@ -324,6 +328,8 @@ void fill_sweep_args(lslam_ctx *ctx, SweepArgs &a) {
   a.grid = 0;
   a.grid_clip_margin = GRID_CLIP_MARGIN_MIN;
   a.wide_nf_slack = 0.0f;
+  a.active_blocks = nullptr;
+  a.n_active = 0;
   a.fit_ids = nullptr;
   a.fit_val = nullptr;
   a.n_fit = 0;
@@ -694,6 +700,7 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   treebuild_release_scratch(ctx->stream);
   treebuild_release_scratch(ctx->stream2);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+  if (ctx->h_active) (void)hipHostFree(ctx->h_active);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1871,6 +1878,9 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
       sa.tail.sp.eig_thresh = so.eig_thresh;
     }
     bool cert_counters_reset = false;
+    // a batch through the grid sweep launches, from a loop's second sweep on, only the workgroups of the scans still running
+    const bool compact = sa.grid == 1 && n_scans >= 4 && !(((o.ab_switches | ctx->env_ab) & LSLAM_AB_NO_COMPACT));
+    std::vector<int32_t> active_n((size_t)n_chunks, 0);
     auto enqueue = [&](int c, int iters) -> int {
       const int p0 = c * in_flight, p1 = std::min(n_scans, p0 + in_flight);
       const int32_t fb = ctx->h_probs[(size_t)p0].first_block;
@@ -1879,6 +1889,10 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
       sc.blocks = ctx->blocks.p + fb;
       sc.nb_total = lb - fb;
       sc.partials = ctx->partials.p + (size_t)fb * NCOL;
+      if (compact && done_iters[(size_t)c] > 0) {  // only the workgroups of the scans still running (compact_active_kernel, below)
+        sc.active_blocks = ctx->active_blocks.p + fb;
+        sc.n_active = active_n[(size_t)c];
+      }
       // throughput-bound launches only (launch_sweep's own test: more wavefronts than two per SIMD): a launch that fits the
       // device at once ends when its slowest wavefront does, certificates or not, and the second pass is two launches more
       // per iteration (measured on single scans: 0.29 against 0.26 ms per loop).  LSLAM_KNN_CERT=2 takes it regardless (tests)
@@ -1927,6 +1941,48 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
       HIP_TRY(ctx->stack_ovf.reserve(stack_ovf_words((size_t)std::max(max_nb, 1) * SWEEP_BLOCK, std::max(ctx->tc.depth, ctx->ts.depth))));
       sa.stack_ovf = ctx->stack_ovf.p;
     }
+    if (compact) {
+      // One iteration at a time, and between two of them the host learns how many workgroups are left (4 bytes per chunk, one
+      // wait of ~30 us against sweeps of milliseconds): the next sweep is launched over THOSE, not over every workgroup of
+      // every scan.  The states come back once, at the end.
+      HIP_TRY(ctx->active_blocks.reserve((size_t)std::max(ctx->nb_total, 1)));
+      HIP_TRY(ctx->d_active_cnt.reserve((size_t)n_chunks));
+      if (ctx->h_active_cap < (size_t)n_chunks) {
+        if (ctx->h_active) (void)hipHostFree(ctx->h_active);
+        ctx->h_active = nullptr;
+        ctx->h_active_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&ctx->h_active, sizeof(int32_t) * (size_t)n_chunks, hipHostMallocDefault));
+        ctx->h_active_cap = (size_t)n_chunks;
+      }
+      for (;;) {
+        bool any = false;
+        for (int c = 0; c < n_chunks; ++c) {
+          if (finished[(size_t)c]) continue;
+          if (done_iters[(size_t)c] >= max_it) { finished[(size_t)c] = 1; continue; }
+          rc = enqueue(c, 1);
+          if (rc) return rc;
+          const int p0 = c * in_flight, p1 = std::min(n_scans, p0 + in_flight);
+          const int32_t fb = ctx->h_probs[(size_t)p0].first_block;
+          HIP_TRY(launch_compact_active(ctx->d_state + p0, ctx->probs.p + p0, p1 - p0, fb, ctx->active_blocks.p + fb, ctx->d_active_cnt.p + c, ctx->stream));
+          any = true;
+        }
+        if (!any) break;
+        launched = *std::max_element(done_iters.begin(), done_iters.end());
+        HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->h_active, ctx->d_active_cnt.p, sizeof(int32_t) * (size_t)n_chunks, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        bool all_done = true;
+        for (int c = 0; c < n_chunks; ++c) {
+          if (finished[(size_t)c]) continue;
+          active_n[(size_t)c] = ctx->h_active[c];
+          if (active_n[(size_t)c] <= 0 || done_iters[(size_t)c] >= max_it) finished[(size_t)c] = 1;
+          all_done = all_done && finished[(size_t)c];
+        }
+        if (all_done) break;
+      }
+      HIP_TRY(hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState) * (size_t)n_scans, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+    } else
     for (;;) {
       bool any = false;
       for (int c = 0; c < n_chunks; ++c) {

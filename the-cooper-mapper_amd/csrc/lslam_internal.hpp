@@ -151,6 +151,10 @@ struct SweepArgs {
                     // and type, {x,y,z,bitcast(original index)}
   const BlockDesc *blocks;  // [nb_total]
   int32_t nb_total;
+  // the grid sweep of a batch late in its loops: only the workgroups of scans whose loop is still running are launched --
+  // active_blocks[i] = index into `blocks` of the i-th of them (compact_active_kernel), n_active of them (null / 0: all nb_total)
+  const int32_t *active_blocks;
+  int32_t n_active;
   const GNState *states;  // [n_prob]
   float *partials;        // [nb_total][NCOL]
   uint32_t *stack_ovf;    // traversal-stack overflow (null unless a tree is deeper than 33)
@@ -310,6 +314,8 @@ struct GridDev {
 };
 hipError_t grid_bbox2(const float4 *const pts[2], const int n[2], uint32_t *d_box12, float lo[2][3], float hi[2][3], hipStream_t s);
 hipError_t grid_unsort(const CellGrid &G, float4 *out, hipStream_t s);
+hipError_t launch_compact_active(const GNState *states, const ProbBlocks *probs, int n_prob, int32_t block_base, int32_t *active_blocks,
+                                 int32_t *count_out, hipStream_t s);
 hipError_t launch_sweep_plan(const SweepArgs &a, hipStream_t s, const CertPlan &plan, int level, bool with_prefix);
 hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t stop, int variant, const CertPlan &plan, int level = 0, bool planned = false);
 hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s,

@@ -1344,7 +1344,7 @@ hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, h
   if (!planned) hipLaunchKernelGGL(cert_plan_kernel, dim3((a.n_groups + 255) / 256), dim3(256), 0, s, a, plan, level, 0);
   // as many workgroups as stay resident (256 CUs x five of the shallow kernel, two of the deep ones), never more than items possible
   constexpr int SHALLOW = LSLAM_SHALLOW_DEPTH;
-  const long possible = (long)a.nb_total;
+  const long possible = a.active_blocks ? std::max<long>(a.n_active, 1) : (long)a.nb_total;  // (a work item is at most one per pass-1 workgroup that ran)
   const dim3 b(SWEEP_BLOCK);
   if (a.grid == 1 && a.need2_cnt && level == 0) {  // the grid sweep's second probe (no tree search in it: its LDS is the 25-run row table)
     const dim3 g((unsigned)std::min<long>(possible, 256 * 3));
@@ -1410,7 +1410,7 @@ LSLAM_DEV void wide_probe(const CellGrid &G, const float (&sel)[3], float r2, in
 template <int BLOCK, bool WIDE = false, bool FITC = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 : LSLAM_GRID_OCC))) void sweep_grid_kernel(SweepArgs a, int jtj_mode) {
   constexpr int NWAVE = BLOCK / 64;
-  const int lb = xcd_remap(blockIdx.x, a.nb_total);
+  const int lb = a.active_blocks ? a.active_blocks[xcd_remap(blockIdx.x, a.n_active)] : xcd_remap(blockIdx.x, a.nb_total);
   const BlockDesc bd = a.blocks[lb];
   const GNState *st = a.states + bd.prob;
   if (a.fine_gate_c >= 0.0f ? !st->converged : st->done) return;  // (cert_plan_kernel skips the groups of such scans)
@@ -1644,8 +1644,49 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 
   block_accumulate<BLOCK, false, false>(jtj_mode, is_surf, row, rb, kept, matched, score, rows_lds, red, a.partials + (size_t)lb * NCOL);
 }
 
+// The workgroups of the scans whose loop is still running, in block order: late in a batch's loops most scans have converged,
+// and a launch of every workgroup of every scan -- 430 000 for the bench's 960 scans, nearly all of them leaving at once --
+// costs 0.17 ms for the sweep kernel alone, 0.3 ms per trailing iteration with the second pass and the solve: 4 % of a step.
+// One workgroup: per scan its block count (0 when done), an exclusive scan over the scans, every scan's thread writes its run.
+__global__ __launch_bounds__(1024) void compact_active_kernel(const GNState *states, const ProbBlocks *probs, int n_prob, int32_t block_base,
+                                                              int32_t *active_blocks, int32_t *count_out) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int per = (n_prob + 1023) / 1024;
+  const int p0 = min(n_prob, tid * per), p1 = min(n_prob, p0 + per);
+  int sum = 0;
+  for (int p = p0; p < p1; ++p) sum += states[p].done ? 0 : probs[p].n_blocks;
+  part[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int at = part[tid] - sum;
+  for (int p = p0; p < p1; ++p) {
+    if (states[p].done) continue;
+    const int first = probs[p].first_block - block_base, nb = probs[p].n_blocks;
+    for (int b = 0; b < nb; ++b) active_blocks[at + b] = first + b;
+    at += nb;
+  }
+  if (tid == 1023) *count_out = part[1023];
+}
+hipError_t launch_compact_active(const GNState *states, const ProbBlocks *probs, int n_prob, int32_t block_base, int32_t *active_blocks,
+                                 int32_t *count_out, hipStream_t s) {
+  hipLaunchKernelGGL(compact_active_kernel, dim3(1), dim3(1024), 0, s, states, probs, n_prob, block_base, active_blocks, count_out);
+  return hipGetLastError();
+}
+
 hipError_t launch_sweep_grid(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t start, hipEvent_t stop, bool resolve_in_place) {
   if (a.nb_total <= 0) return hipSuccess;
+  if (a.active_blocks && !resolve_in_place) {  // the batch's grid sweep over the running scans' workgroups only
+    if (a.n_active <= 0) return hipSuccess;
+    if (a.fit_ids) hipExtLaunchKernelGGL((sweep_grid_kernel<SWEEP_BLOCK, false, true>), dim3(a.n_active), dim3(SWEEP_BLOCK), 0, s, start, stop, 0, a, jtj_mode);
+    else hipExtLaunchKernelGGL((sweep_grid_kernel<SWEEP_BLOCK>), dim3(a.n_active), dim3(SWEEP_BLOCK), 0, s, start, stop, 0, a, jtj_mode);
+    return hipGetLastError();
+  }
   if (resolve_in_place) hipExtLaunchKernelGGL((sweep_grid_kernel<SWEEP_BLOCK, true>), dim3(a.nb_total), dim3(SWEEP_BLOCK), 0, s, start, stop, 0, a, jtj_mode);
   else if (a.fit_ids) hipExtLaunchKernelGGL((sweep_grid_kernel<SWEEP_BLOCK, false, true>), dim3(a.nb_total), dim3(SWEEP_BLOCK), 0, s, start, stop, 0, a, jtj_mode);
   else hipExtLaunchKernelGGL((sweep_grid_kernel<SWEEP_BLOCK>), dim3(a.nb_total), dim3(SWEEP_BLOCK), 0, s, start, stop, 0, a, jtj_mode);

@@ -720,7 +720,11 @@ void lslam_debug_grid_stats(lslam_ctx *ctx, uint64_t out[32]) {
   for (int i = 0; i < 32; ++i) out[i] = 0;
   if (!ctx || !ctx->cert_stats.p) return;
   if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+#ifdef LSLAM_EXP_COUNT_NOHINT  // (experiment build: the raw words from 0, the experiment's counters are words 2 and 3)
+      hipMemcpy(out, ctx->cert_stats.p, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)
+#else
       hipMemcpy(out, ctx->cert_stats.p + CERT_STATS_BY_SWEEP, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)
+#endif
     for (int i = 0; i < 32; ++i) out[i] = 0;
 }
 

@@ -1529,6 +1529,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 
       a.need_list[(size_t)lb * BLOCK + off + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)tid;
       // what pass 2's search may take for granted: five map points within this distance (padded like every bound)
       if (a.grid_hint) a.grid_hint[qi] = d[4] < 1.0e30f ? d[4] * (1.0f + 1e-5f) + 1e-12f : FLT_MAX;
+#ifdef LSLAM_EXP_COUNT_NOHINT  // EXPERIMENT: how many listed points go to the tree search without a bound from the probe (it saw fewer than five)
+      if (a.cert_stats && !(d[4] < 1.0e30f)) atomicAdd(a.cert_stats + 2, 1ull);
+      if (a.cert_stats && d[4] < 1.0e30f && d[4] >= 5.0f) atomicAdd(a.cert_stats + 3, 1ull);
+#endif
     }
     if (tid == 0) a.need_cnt[lb] = (uint16_t)total;  // (the debug tap counts from these, in cert_plan_kernel)
   }

@@ -43,6 +43,7 @@ namespace {
 
 constexpr int FX_BLOCK = 1024;  // a ring of 1 800 points: every point of every region has a thread in the parallel phases
 constexpr int MAXR = 2560;  // points per ring held in LDS
+constexpr int SKEY = 8192;  // sort words of a ring's regions (each region padded to a power of two); later 2 x MAXR x 3 floats of pointClassify
 
 // PointLabel, ScanRegistration.h:22-42
 enum : int {
@@ -111,10 +112,8 @@ __device__ bool fx_one_sided_line(const float *sx, const float *sy, const float 
   return true;
 }
 
-__device__ int fx_point_classify(const float *sx, const float *sy, const float *sz, int idx, const FxArgs &a) {
-  float v1[3], v2[3];
-  const bool line1 = fx_one_sided_line(sx, sy, sz, idx, a.cr, -1, v1);
-  const bool line2 = fx_one_sided_line(sx, sy, sz, idx, a.cr, +1, v2);
+// pointClassify from its two one-sided fits (:557-687)
+__device__ int fx_point_classify(const bool line1, const float (&v1)[3], const bool line2, const float (&v2)[3], const FxArgs &a) {
   if (line1 && line2) {
     const float ab = __fadd_rn(__fadd_rn(__fmul_rn(v1[0], v2[0]), __fmul_rn(v1[1], v2[1])), __fmul_rn(v1[2], v2[2]));
     const float dis = __fmul_rn(fx_pdist(v1[0], v1[1], v1[2]), fx_pdist(v2[0], v2[1], v2[2]));
@@ -123,6 +122,32 @@ __device__ int fx_point_classify(const float *sx, const float *sy, const float *
     if (diff > a.c135 && diff < a.c45) return L_CORNER_SHARP;
   }
   return (line1 || line2) ? L_ONESIDE_FLAT : L_MESSY;
+}
+
+// Bitonic sort of `count` words in LDS, in independent stretches of `seg` words (a power of two >= 2; every stretch ascending),
+// by the whole workgroup.  Thread t of a stage takes the pair (i, i | j): for j <= 64 the 64 pairs of a wavefront's round lie in
+// one stretch of 128 words that no other wavefront touches in that round, so such stages need no workgroup barrier -- the
+// wavefront's LDS operations are executed in order -- and only the strides >= 128 and the changes between the two kinds do
+// (15 barriers instead of 66 for 2 048 words: with sixteen wavefronts a barrier costs more than the stage's work).
+__device__ void fx_bitonic(unsigned long long *w, int count, int seg) {
+  const int tid = threadIdx.x, half = count >> 1;
+  for (int k = 2; k <= seg; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < half; t += FX_BLOCK) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+        const unsigned long long x = w[i], y = w[l];
+        const bool up = ((i & (seg - 1)) & k) == 0;
+        if ((x > y) == up) { w[i] = y; w[l] = x; }
+      }
+      const int j_next = j > 1 ? (j >> 1) : (2 * k <= seg ? k : 0);
+      if (j >= 128 || j_next >= 128 || j_next == 0) {
+        __syncthreads();
+      } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
 }
 
 #ifdef LSLAM_FX_CLOCKS  // profiling build: where a ring's workgroup spends its time (100 MHz ticks, summed over rings and calls)
@@ -141,6 +166,9 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
   __shared__ int8_t picked[MAXR], cls_ring[MAXR], rlabel_ring[MAXR];
   __shared__ uint8_t pfl[MAXR];
   __shared__ uint16_t need[MAXR];
+  __shared__ unsigned long long skey[SKEY];
+  __shared__ int reg_sp[512], reg_ep[512];  // (n_feature_regions <= 512)
+  __shared__ uint8_t side_ok[2 * MAXR];
   __shared__ int n_need;
   const int ring = blockIdx.x, tid = threadIdx.x;
   if (tid == 0) n_need = 0;
@@ -152,7 +180,6 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
     for (int i = tid; i < n; i += FX_BLOCK) {
       const float4 p = a.pts[start + i];
       sx[i] = p.x; sy[i] = p.y; sz[i] = p.z;
-      picked[i] = 0;
     }
     __syncthreads();
     // ---- neighbour tests of setScanBuffersFor, one per point pair (i, i+1) ------------------------
@@ -177,37 +204,30 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
       pfl[i] = f;
     }
     __syncthreads();
-    if (tid == 0) {  // the marks, in the reference's order (:477-530)
-      for (int i = 0; i < cr; ++i)
-        if (pfl[i] & 1) for (int q = 0; q <= cr; ++q) picked[i + q] = L_BLIND_BLOCK;
-      for (int i = 0; i < cr; ++i)
-        if (pfl[n - 1 - i - 1] & 1) for (int q = 0; q <= cr; ++q) picked[n - 1 - i - cr + q] = L_BLIND_BLOCK;
-    }
-    if (tid < 64) {
-      // the main marking loop (:497-530) is a chain of dependent LDS round trips if written naively;
-      // the flags are fetched 64 at a time (one per lane) and handed to lane 0 by readlane
-      for (int base = cr; base < n - 1 - cr; base += 64) {
-        const int mine = base + tid;
-        const int fl = (mine < n - 1 - cr) ? (int)pfl[mine] : 0;
-        unsigned long long todo = __ballot((fl & 3) != 0);  // only the flagged pairs take a step, in scan order
-        while (todo) {
-          const int jx = __builtin_ctzll(todo);
-          todo &= todo - 1;
-          const int f = __builtin_amdgcn_readlane(fl, jx);
-          if (tid == 0) {
-            const int i = base + jx;
-            if (f & 1) {
-              for (int q = 0; q < 2 * cr; ++q) picked[i - cr + 1 + q] = L_BLIND_BLOCK;
-            } else if (f & 4) {
-              if (picked[i + 1] > L_NEAR_BLOCK && (f & 8)) picked[i + 1] = L_EDGE_BROKEN;
-              for (int q = 0; q < cr; ++q) picked[i - cr + 1 + q] = L_NEAR_BLOCK;
-            } else {
-              if (picked[i] > L_NEAR_BLOCK && (f & 8)) picked[i] = L_EDGE_BROKEN;
-              for (int q = 0; q < cr; ++q) picked[i + 1 + q] = L_NEAR_BLOCK;
-            }
-          }
+    // The marks of setScanBuffersFor (:477-530) are applied in scan order, later writes over earlier ones, and two of them read
+    // what is there -- but a step at pair i only touches points within cr of i, so every point replays, in order, the <= 2 cr
+    // steps that can reach it and nothing else (round 5; lane 0 applying them one after the other was a sixth of the kernel).
+    for (int p = tid; p < n; p += FX_BLOCK) {
+      int v = 0;
+      for (int i = 0; i < cr; ++i) {  // :477-495, the ring's two ends (only one value is written: any order)
+        if ((pfl[i] & 1) && p >= i && p <= i + cr) v = L_BLIND_BLOCK;
+        if ((pfl[n - 1 - i - 1] & 1) && p >= n - 1 - i - cr && p <= n - 1 - i) v = L_BLIND_BLOCK;
+      }
+      const int i_lo = max(cr, p - cr), i_hi = min(n - 2 - cr, p + cr - 1);
+      for (int i = i_lo; i <= i_hi; ++i) {  // :497-530
+        const int f = pfl[i];
+        if ((f & 3) == 0) continue;
+        if (f & 1) {
+          if (p >= i - cr + 1 && p <= i + cr) v = L_BLIND_BLOCK;
+        } else if (f & 4) {
+          if (p == i + 1 && v > L_NEAR_BLOCK && (f & 8)) v = L_EDGE_BROKEN;
+          if (p >= i - cr + 1 && p <= i) v = L_NEAR_BLOCK;
+        } else {
+          if (p == i && v > L_NEAR_BLOCK && (f & 8)) v = L_EDGE_BROKEN;
+          if (p >= i + 1 && p <= i + cr) v = L_NEAR_BLOCK;
         }
       }
+      picked[p] = (int8_t)v;
     }
     __syncthreads();
     FX_T(0)
@@ -217,9 +237,15 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
     // (curvature, the stable rank inside the region, pointClassify: a region is ~300 points, the ring ~1800 -- region
     // after region a 256-thread workgroup ran these in twelve rounds, most of the time of the kernel)
     const size_t S = (size_t)start + cr, E = (size_t)end - cr;
+    // the regions' bounds (:208-209), once per ring: two 64-bit divisions each, which every thread of every phase repeated
+    for (int j = tid; j < nf; j += FX_BLOCK) {
+      reg_sp[j] = (int)((S * (size_t)(nf - j) + E * (size_t)j) / (size_t)nf);
+      reg_ep[j] = (int)((S * (size_t)(nf - 1 - j) + E * (size_t)(j + 1)) / (size_t)nf) - 1;
+    }
+    __syncthreads();
     auto region_of = [&](int j, int &sp, int &ep) {
-      sp = (int)((S * (size_t)(nf - j) + E * (size_t)j) / (size_t)nf);
-      ep = (int)((S * (size_t)(nf - 1 - j) + E * (size_t)(j + 1)) / (size_t)nf) - 1;
+      sp = reg_sp[j];
+      ep = reg_ep[j];
     };
     {
       const float w = (float)(-2 * cr);
@@ -235,34 +261,73 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
       }
       __syncthreads();
       FX_T(1)
-      for (int i = cr + tid; i <= n - 1 - cr; i += FX_BLOCK) {
-        // the region this point belongs to (regions tile [start + cr, end - cr); the last point belongs to none)
-        int sp = 0, ep = -1, j = 0;
-        for (; j < nf; ++j) {
-          region_of(j, sp, ep);
-          if (start + i <= ep) break;
+      // The stable ascending order by curvature inside every region (what the reference's `<=` merge sort yields, :151-186):
+      // curvature is a sum of squares, so its bit pattern orders like its value, and (bits << 16 | index in region) sorts by
+      // curvature, then index.  All regions at once, each in its own power-of-two stretch of `skey`, bitonic (round 5: the rank
+      // sort this replaces -- every point counting the smaller ones of its region -- was a quarter of the kernel).
+      int rs_max = 0;
+      for (int j = 0; j < nf; ++j) {
+        int sp, ep;
+        region_of(j, sp, ep);
+        rs_max = max(rs_max, ep - sp + 1);
+      }
+      int rpad = 2, rlg = 1;
+      while (rpad < rs_max) { rpad <<= 1; ++rlg; }  // block-uniform; nf * rpad <= SKEY (regions are equal to +-1; the host bounds nf)
+      for (int t = tid; t < nf * rpad; t += FX_BLOCK) {
+        const int j = t >> rlg, r = t & (rpad - 1);
+        int sp, ep;
+        region_of(j, sp, ep);
+        const int rs = ep > sp ? ep - sp + 1 : 0;  // :210 skips a region of one point
+        unsigned long long w = ~0ull;
+        bool wanted = false;
+        int i = 0;
+        if (r < rs) {
+          i = sp - start + r;
+          const float c = curv_ring[i];
+          w = ((unsigned long long)__float_as_uint(c) << 16) | (unsigned long long)r;
+          cls_ring[i] = (int8_t)L_UNKNOW;
+          wanted = !(c < a.surf_thr);
+          if (a.curv_out) a.curv_out[start + i] = c;
         }
-        if (j == nf || start + i < sp || ep <= sp) continue;  // :210 skips a region of one point
-        const int r0 = sp - start, rs = ep - sp + 1, r = i - r0;
-        const float c = curv_ring[i];
-        int rank = 0;  // stable ascending order: the reference's `<=` merge sort
-        for (int k = 0; k < rs; ++k) {
-          const float ck = curv_ring[r0 + k];
-          rank += (ck < c) || (ck == c && k < r);
-        }
-        sorted_ring[r0 + rank] = (uint16_t)r;
+        skey[t] = w;
         // pointClassify for every point the third loop will visit: those are collected first (any order: a point's class
         // depends on nothing else), so that the eigen-solver runs on full wavefronts instead of on the lanes that happen
-        // to hold such a point
-        cls_ring[i] = (int8_t)L_UNKNOW;
-        if (!(c < a.surf_thr)) need[atomicAdd(&n_need, 1)] = (uint16_t)i;
-        if (a.curv_out) a.curv_out[start + i] = c;
+        // to hold such a point.  One LDS atomic per wavefront, not per point (a thousand on one word were 13 us of the kernel)
+        const unsigned long long wm = __ballot(wanted);
+        int wbase = 0;
+        if ((tid & 63) == 0 && wm) wbase = atomicAdd(&n_need, __popcll(wm));
+        wbase = __builtin_amdgcn_readfirstlane(wbase);
+        if (wanted) need[wbase + __popcll(wm & ((1ull << (tid & 63)) - 1ull))] = (uint16_t)i;
+      }
+      __syncthreads();
+      fx_bitonic(skey, nf * rpad, rpad);
+      for (int t = tid; t < nf * rpad; t += FX_BLOCK) {
+        const int j = t >> rlg, r = t & (rpad - 1);
+        int sp, ep;
+        region_of(j, sp, ep);
+        const int rs = ep > sp ? ep - sp + 1 : 0;
+        if (r < rs) sorted_ring[sp - start + r] = (uint16_t)(skey[t] & 0xFFFFull);
       }
       __syncthreads();
       FX_T(5)
+      // the two one-sided fits of a point are work items of their own (round 5): a ring has a few hundred such points, so the
+      // eigen-solver -- iterative, its wavefront as slow as its slowest lane -- ran twice in a row on half-empty workgroups;
+      // direction and verdict wait in the sort words' LDS, free by now
+      float *side_v = reinterpret_cast<float *>(skey);  // [2 n_need][3]
+#ifdef LSLAM_FX_CLOCKS
+      if (tid == 0) { atomicAdd(&fx_clk[6], (unsigned long long)n_need); atomicAdd(&fx_clk[7], 1ull); }
+#endif
+      for (int t = tid; t < 2 * n_need; t += FX_BLOCK) {
+        float v[3] = {0.f, 0.f, 0.f};
+        const bool ok = fx_one_sided_line(sx, sy, sz, need[t >> 1], cr, (t & 1) ? +1 : -1, v);
+        side_v[3 * t] = v[0]; side_v[3 * t + 1] = v[1]; side_v[3 * t + 2] = v[2];
+        side_ok[t] = ok ? 1 : 0;
+      }
+      __syncthreads();
       for (int t = tid; t < n_need; t += FX_BLOCK) {
-        const int i = need[t];
-        cls_ring[i] = (int8_t)fx_point_classify(sx, sy, sz, i, a);
+        const float v1[3] = {side_v[6 * t], side_v[6 * t + 1], side_v[6 * t + 2]};
+        const float v2[3] = {side_v[6 * t + 3], side_v[6 * t + 4], side_v[6 * t + 5]};
+        cls_ring[need[t]] = (int8_t)fx_point_classify(side_ok[2 * t] != 0, v1, side_ok[2 * t + 1] != 0, v2, a);
       }
       __syncthreads();
       FX_T(2)
@@ -280,21 +345,31 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
       if (tid < 64) {  // wavefront 0; the counters are wave-uniform
         const unsigned long long lt_mask = tid == 0 ? 0ull : (~0ull >> (64 - tid));
         // flat surface features, :268-284 -- sequential: every pick excludes its neighbourhood
+        // A pick excludes its neighbourhood from the later ones, so the picks are sequential -- but the candidates are not: 64
+        // of them (ascending curvature) are tested at once, the first eligible lane is the pick, the lanes within cr of it drop
+        // out in registers, its marks are written by 2 cr + 1 lanes (round 5: lane 0 walking the order with two dependent LDS
+        // reads per candidate, most of them neighbours of a pick, was a seventh of the kernel).
         int surf_picked = 0;
-        if (tid == 0) {
-          for (int k = 0; k < rs && surf_picked < a.max_flat; ++k) {
-            const int r = sorted[k], si = r0 + r;
-            if (picked[si] != L_SURF_PICKED_NEAR && curv[r] < a.surf_thr) {
-              ++surf_picked;
+        for (int base = 0; base < rs && surf_picked < a.max_flat; base += 64) {
+          const int k = base + tid;
+          const int r = k < rs ? (int)sorted[k] : 0, si = r0 + r;
+          bool elig = k < rs && curv[r] < a.surf_thr && picked[si] != L_SURF_PICKED_NEAR;
+          const bool more = __ballot(k < rs && curv[r] < a.surf_thr) != 0ull;  // ascending: a chunk without one ends the search
+          unsigned long long m;
+          while (surf_picked < a.max_flat && (m = __ballot(elig)) != 0ull) {
+            const int L = __builtin_ctzll(m);
+            const int si_L = __builtin_amdgcn_readlane(si, L);
+            if (tid == L) {
               rlabel[r] = L_SURFACE_FLAT;
-              a.st_flat[start + n_flat + surf_picked - 1] = sp + r;
-              picked[si] = L_SURF_PICKED_NEAR;  // markAsPicked, :533-555
-              for (int q = 1; q <= cr; ++q) picked[si + q] = L_SURF_PICKED_NEAR;
-              for (int q = 1; q <= cr; ++q) picked[si - q] = L_SURF_PICKED_NEAR;
+              a.st_flat[start + n_flat + surf_picked] = sp + r;
             }
+            if (tid <= 2 * cr) picked[si_L - cr + tid] = L_SURF_PICKED_NEAR;  // markAsPicked, :533-555
+            elig = elig && abs(si - si_L) > cr;
+            ++surf_picked;
           }
+          if (!more) break;
         }
-        n_flat += __builtin_amdgcn_readfirstlane(surf_picked);  // lane 0's count, to every lane
+        n_flat += surf_picked;  // (wave-uniform)
         FX_T(3)
         // less flat + broken edges, :286-302 -- an ordered compaction, 64 region points at a time
         int n_low = 0;
@@ -384,6 +459,220 @@ __global__ void fx_compact_kernel(const float4 *pts, const int32_t *stage, const
 }
 
 
+// ---- the lists of a sweep, without the host in between (round 5) ---------------------------------------------------------
+// Until round 5 the host fetched the rings' counts, made the offsets, launched four compactions and ran the per-ring
+// VoxelGrid of the less-flat points (:398-407) through the general segment filter of lslam_fmap.hip -- a 64-bit merge sort of
+// all rings' points at once, sixteen launches and three waits for what is 64 independent problems of <= 2 560 points.  Now:
+//   fx_lists_kernel        one workgroup per small list (sharp, less sharp, flat): the rings' offsets by a scan in LDS, the
+//                          points gathered in ring order STRAIGHT INTO PINNED HOST MEMORY, the total next to them
+//   fx_ring_voxel_kernel   one workgroup per ring: pcl::VoxelGrid::applyFilter on the ring's less-flat list entirely in LDS --
+//                          bounding box, the "leaf too small" guard, voxel index ijk0 + ijk1 * div0 + ijk2 * div0 * div1,
+//                          a bitonic sort of (index, position in the list), heads, their scan, centroids summed in list order
+//   fx_lessflat_out_kernel one workgroup per ring: the ring's centroids behind those of the rings before it, into pinned memory
+// and ONE wait.  Same arithmetic, same order as the segment filter (tests/test_gpu_features.py holds both against the oracle).
+constexpr int VX_PAD = 4096;  // MAXR rounded up to a power of two
+static_assert(MAXR <= VX_PAD && VX_PAD <= 4096, "the list position takes the low 12 bits of the sort word");
+
+struct FxOutArgs {
+  const float4 *pts;
+  const int32_t *ranges, *counts;  // counts[4 * ring + list]
+  const int32_t *stage[4];         // per list: the rings' picks (cloud indices), each ring's from its first index on
+  int32_t n_scans, cap;            // cap: points a list's slice of `host` holds
+  float inv_leaf;                  // 1 / lessFlatFilterSize, as pcl::VoxelGrid forms it
+  float4 *vox_stage;               // [n_points] ring r's centroids from ranges[2 r] on
+  int32_t *ring_out;               // [n_scans] centroids per ring
+  float4 *host;                    // pinned: 16 header slots, then four slices of `cap` points
+  uint32_t *hdr;                   // = (uint32_t *)host: [0..2] totals of the small lists, [3] less-flat points out, [4] error
+};
+
+// exclusive scan of v over the workgroup's 1024 threads (LDS part[>= 16]); returns this thread's prefix, *total = the sum
+__device__ int fx_block_scan(int v, int *part, int *total) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += u;
+  }
+  __syncthreads();  // (part may still be read from an earlier call)
+  if (lane == 63) part[wave] = incl;
+  __syncthreads();
+  int before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < FX_BLOCK / 64; ++w) {
+    const int c = part[w];
+    before += w < wave ? c : 0;
+    all += c;
+  }
+  *total = all;
+  return before + incl - v;
+}
+
+__global__ __launch_bounds__(FX_BLOCK) void fx_lists_kernel(FxOutArgs a) {
+  __shared__ int part[FX_BLOCK];
+  __shared__ int32_t off[4096 + 1];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const int per = (a.n_scans + FX_BLOCK - 1) / FX_BLOCK;
+  const int r0 = min(a.n_scans, tid * per), r1 = min(a.n_scans, r0 + per);
+  int sum = 0;
+  for (int r = r0; r < r1; ++r) sum += a.counts[4 * r + k];
+  int total;
+  int run = fx_block_scan(sum, part, &total);
+  for (int r = r0; r < r1; ++r) {
+    off[r] = run;
+    run += a.counts[4 * r + k];
+  }
+  if (tid == 0) {
+    off[a.n_scans] = total;
+    a.hdr[k] = (uint32_t)total;
+    if (total > a.cap) a.hdr[4] = 2u;  // (cannot happen: a list holds a point at most once)
+  }
+  __syncthreads();
+  float4 *out = a.host + 16 + (size_t)k * a.cap;
+  const int32_t *stage = a.stage[k];
+  for (int i = tid; i < min(total, a.cap); i += FX_BLOCK) {
+    int lo = 0, hi = a.n_scans - 1;  // last ring with off <= i
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (off[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    out[i] = a.pts[stage[a.ranges[2 * lo] + (i - off[lo])]];
+  }
+}
+
+#ifdef LSLAM_FX_CLOCKS
+__device__ unsigned long long vx_clk[8];
+#define VX_T(i) if (threadIdx.x == 0) { const unsigned long long _n = wall_clock64(); atomicAdd(&vx_clk[i], _n - vx_last); vx_last = _n; }
+#else
+#define VX_T(i)
+#endif
+__global__ __launch_bounds__(FX_BLOCK) void fx_ring_voxel_kernel(FxOutArgs a) {
+#ifdef LSLAM_FX_CLOCKS
+  unsigned long long vx_last = wall_clock64();
+#endif
+  __shared__ float4 sp[MAXR];
+  __shared__ unsigned long long key[VX_PAD];
+  __shared__ float wred[6][FX_BLOCK / 64];
+  __shared__ int part[FX_BLOCK];
+  __shared__ int s_err;
+  const int ring = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int start = a.ranges[2 * ring];
+  const int n = min(a.counts[4 * ring + 3], MAXR);
+  if (n <= 0) {  // block-uniform
+    if (tid == 0) a.ring_out[ring] = 0;
+    return;
+  }
+  if (tid == 0) s_err = 0;
+  // ---- the ring's list and its bounding box (getMinMax3D) ----------------------------------------------------------------
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = tid; i < n; i += FX_BLOCK) {
+    const float4 p = a.pts[a.stage[3][start + i]];
+    sp[i] = p;
+    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[d] = fminf(mn[d], __shfl_xor(mn[d], o, 64));
+      mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o, 64));
+    }
+    if (lane == 0) { wred[d][wave] = mn[d]; wred[3 + d][wave] = mx[d]; }
+  }
+  __syncthreads();
+  long long vol = 1;
+  int32_t b0[3], div[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    float lo = wred[d][0], hi = wred[3 + d][0];
+#pragma unroll
+    for (int w = 1; w < FX_BLOCK / 64; ++w) { lo = fminf(lo, wred[d][w]); hi = fmaxf(hi, wred[3 + d][w]); }
+    // applyFilter's guard and its min_b / div_b (voxel_grid.hpp), as fm_extent_kernel forms them
+    vol *= (long long)(__fmul_rn(__fsub_rn(hi, lo), a.inv_leaf)) + 1;
+    b0[d] = (int32_t)floorf(__fmul_rn(lo, a.inv_leaf));
+    div[d] = (int32_t)floorf(__fmul_rn(hi, a.inv_leaf)) - b0[d] + 1;
+  }
+  const bool filtered = vol <= 2147483647ll;  // else: PCL warns and hands the cloud back unfiltered
+  VX_T(0)
+  int npad = 64;
+  while (npad < n) npad <<= 1;
+  // ---- sort words: voxel index, then the position in the list (a stable sort by index) -----------------------------------
+  for (int i = tid; i < npad; i += FX_BLOCK) {
+    unsigned long long w = ~0ull;
+    if (i < n) {
+      unsigned long long idx = (unsigned long long)i;  // unfiltered: every point its own voxel, in list order
+      if (filtered) {
+        const float4 p = sp[i];
+        const float v[3] = {p.x, p.y, p.z};
+        int32_t r[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          r[d] = (int32_t)floorf(__fmul_rn(v[d], a.inv_leaf)) - b0[d];
+          if (r[d] < 0 || r[d] >= div[d]) {  // a non-finite coordinate
+            s_err = 1;
+            r[d] = 0;
+          }
+        }
+        idx = ((unsigned long long)r[2] * (unsigned long long)div[1] + (unsigned long long)r[1]) * (unsigned long long)div[0] + (unsigned long long)r[0];
+      }
+      w = (idx << 12) | (unsigned long long)i;
+    }
+    key[i] = w;
+  }
+  __syncthreads();
+  VX_T(1)
+  fx_bitonic(key, npad, npad);
+  VX_T(2)
+  // ---- heads, their places, centroids over the members in list order ------------------------------------------------------
+  constexpr int PER = VX_PAD / FX_BLOCK;
+  const int per = max(1, npad / FX_BLOCK);  // consecutive entries per thread
+  int heads = 0;
+  for (int u = 0; u < PER; ++u) {
+    const int i = tid * per + u;
+    if (u < per && i < n) heads += (i == 0 || (key[i] >> 12) != (key[i - 1] >> 12)) ? 1 : 0;
+  }
+  int total;
+  int pos = fx_block_scan(heads, part, &total);
+  VX_T(3)
+  for (int u = 0; u < PER; ++u) {
+    const int i = tid * per + u;
+    if (!(u < per && i < n)) continue;
+    const unsigned long long vi = key[i] >> 12;
+    if (!(i == 0 || vi != (key[i - 1] >> 12))) continue;
+    float4 s = sp[(int)(key[i] & 4095ull)];  // PCL starts from a zero vector: 0 + x = x
+    int m = i + 1;
+    for (; m < n && (key[m] >> 12) == vi; ++m) {
+      const float4 q = sp[(int)(key[m] & 4095ull)];
+      s.x = __fadd_rn(s.x, q.x);
+      s.y = __fadd_rn(s.y, q.y);
+      s.z = __fadd_rn(s.z, q.z);
+      s.w = __fadd_rn(s.w, q.w);
+    }
+    const float cnt = (float)(m - i);
+    a.vox_stage[start + pos] = make_float4(__fdiv_rn(s.x, cnt), __fdiv_rn(s.y, cnt), __fdiv_rn(s.z, cnt), __fdiv_rn(s.w, cnt));
+    ++pos;
+  }
+  VX_T(4)
+  if (tid == 0) {
+    a.ring_out[ring] = total;
+    if (s_err) a.hdr[4] = 1u;
+  }
+}
+
+__global__ __launch_bounds__(FX_BLOCK) void fx_lessflat_out_kernel(FxOutArgs a) {
+  __shared__ int part[FX_BLOCK];
+  const int ring = blockIdx.x, tid = threadIdx.x;
+  int before = 0;
+  for (int r = tid; r < ring; r += FX_BLOCK) before += a.ring_out[r];
+  int off;
+  (void)fx_block_scan(before, part, &off);
+  const int cnt = a.ring_out[ring], start = a.ranges[2 * ring];
+  float4 *out = a.host + 16 + (size_t)3 * a.cap;
+  for (int i = tid; i < cnt && off + i < a.cap; i += FX_BLOCK) out[off + i] = a.vox_stage[start + i];
+  if (ring == a.n_scans - 1 && tid == 0) a.hdr[3] = (uint32_t)(off + cnt);
+}
+
 // ---- MultiScanRegistration::process (MultiScanRegistration.cpp:94-190, no IMU) -------------------
 struct MsArgs {
   const float4 *in;   // raw driver cloud {x, y, z, *}
@@ -445,10 +734,12 @@ __global__ void ms_final_kernel(MsArgs a) {
 
 extern "C" {
 #ifdef LSLAM_FX_CLOCKS
-int lslam_debug_fx_clocks(double out[8]) {
+int lslam_debug_fx_clocks(double out[16]) {
   unsigned long long h[8];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(fx_clk), sizeof(h)) != hipSuccess) return -1;
   for (int i = 0; i < 8; ++i) out[i] = (double)h[i];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(vx_clk), sizeof(h)) != hipSuccess) return -1;
+  for (int i = 0; i < 8; ++i) out[8 + i] = (double)h[i];
   return 0;
 }
 #endif
@@ -497,7 +788,7 @@ static int extract_features_impl(lslam_ctx *ctx, const void *cloud, size_t n_poi
   }
   lslam_reg_params prm;
   if (params) prm = *params; else lslam_reg_default_params(&prm);
-  if (prm.curvature_region < 1 || prm.curvature_region > 16 || prm.n_feature_regions < 1) {
+  if (prm.curvature_region < 1 || prm.curvature_region > 16 || prm.n_feature_regions < 1 || prm.n_feature_regions > 512) {  // (512: fx_ring_kernel's sort words)
     lslam::set_error("bad registration parameters");
     return LSLAM_ERR_INVALID;
   }
@@ -532,14 +823,15 @@ static int extract_features_impl(lslam_ctx *ctx, const void *cloud, size_t n_poi
     FX_TRY(hipHostMalloc((void **)&cache.pin, (n_points + n_points / 4) * sizeof(float4), hipHostMallocDefault));
     cache.pin_cap = n_points + n_points / 4;
   }
-  // the outputs come back through pinned memory too: the three small lists behind the filter's count (one wait for all of
-  // them), the filtered less-flat list after it; [0, 2): the filter's {count, error}
-  if (n_points + 16 > cache.pout_cap) {
+  // the outputs are WRITTEN to pinned memory by the kernels that make them: sixteen header slots (totals, error), then a
+  // slice of n_points per list
+  if (4 * n_points + 16 > cache.pout_cap) {
     if (cache.pout) (void)hipHostFree(cache.pout);
     cache.pout = nullptr;
     cache.pout_cap = 0;
-    FX_TRY(hipHostMalloc((void **)&cache.pout, (n_points + n_points / 4 + 16) * sizeof(float4), hipHostMallocDefault));
-    cache.pout_cap = n_points + n_points / 4 + 16;
+    const size_t want = 4 * (n_points + n_points / 4) + 16;
+    FX_TRY(hipHostMalloc((void **)&cache.pout, want * sizeof(float4), hipHostMallocDefault));
+    cache.pout_cap = want;
   }
   // pack {x, y, z, intensity-to-copy} (toXYZI, util/pcl_util.h:30-37: the `curvature` field)
   float4 *h = cache.pin;
@@ -557,8 +849,7 @@ static int extract_features_impl(lslam_ctx *ctx, const void *cloud, size_t n_poi
       h[i] = make_float4(v[0], v[1], v[2], w);
     }
   }
-  const size_t bytes = 5 * np4 + 2 * n_scans * 4 + 4 * n_scans * 4 + n_points * 4 + 2 * n_points + 4 * (n_scans + 1) * 4 +
-                       2 * np4 + 2 * n_points * 4 + 256 + 16 * 16;
+  const size_t bytes = 5 * np4 + 2 * n_scans * 4 + 4 * n_scans * 4 + n_points * 4 + 2 * n_points + (n_scans + 1) * 4 + np4 + 256 + 16 * 16;
   if (bytes > cache.cap) {
     if (cache.p) (void)hipFree(cache.p);
     cache.p = nullptr;
@@ -574,9 +865,8 @@ static int extract_features_impl(lslam_ctx *ctx, const void *cloud, size_t n_poi
   int32_t *d_ranges = (int32_t *)take(2 * n_scans * 4), *d_counts = (int32_t *)take(4 * n_scans * 4);
   float *d_curv = (float *)take(n_points * 4);
   int8_t *d_picked = (int8_t *)take(n_points), *d_label = (int8_t *)take(n_points);
-  int32_t *d_off = (int32_t *)take(4 * (n_scans + 1) * 4);
-  float4 *d_out = (float4 *)take(np4), *d_out2 = (float4 *)take(np4);
-  int32_t *d_seg = (int32_t *)take(n_points * 4), *d_seg2 = (int32_t *)take(n_points * 4);
+  int32_t *d_ring_out = (int32_t *)take((n_scans + 1) * 4);  // centroids per ring (fx_ring_voxel_kernel)
+  float4 *d_vox = (float4 *)take(np4);                       // ... and the centroids, ring r's from its first index on
   int rc = LSLAM_OK;
   auto fail = [&](int code) { return code; };
 #define FX_TRY2(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { lslam::set_error(hipGetErrorString(_e)); return fail(LSLAM_ERR_HIP); } } while (0)
@@ -614,79 +904,37 @@ static int extract_features_impl(lslam_ctx *ctx, const void *cloud, size_t n_poi
   a.picked_out = picked_out ? d_picked : nullptr;
   a.label_out = label_out ? d_label : nullptr;
   hipLaunchKernelGGL(fx_ring_kernel, dim3((unsigned)n_scans), dim3(FX_BLOCK), 0, s, a);
-  std::vector<int32_t> hc(4 * n_scans);
-  FX_TRY2(hipMemcpyAsync(hc.data(), d_counts, 4 * n_scans * 4, hipMemcpyDeviceToHost, s));
+  // the four lists, on the device to the end (see fx_lists_kernel): nothing waits until everything is in pinned memory
+  uint32_t *hdr = reinterpret_cast<uint32_t *>(cache.pout);
+  for (int k = 0; k < 8; ++k) hdr[k] = 0u;
+  FxOutArgs oa{};
+  oa.pts = d_pts;
+  oa.ranges = d_ranges;
+  oa.counts = d_counts;
+  oa.stage[0] = st0; oa.stage[1] = st1; oa.stage[2] = st2; oa.stage[3] = st3;
+  oa.n_scans = (int32_t)n_scans;
+  oa.cap = (int32_t)n_points;
+  oa.inv_leaf = 1.0f / prm.less_flat_filter_size;
+  oa.vox_stage = d_vox;
+  oa.ring_out = d_ring_out;
+  oa.host = cache.pout;
+  oa.hdr = hdr;
+  hipLaunchKernelGGL(fx_lists_kernel, dim3(3), dim3(FX_BLOCK), 0, s, oa);
+  hipLaunchKernelGGL(fx_ring_voxel_kernel, dim3((unsigned)n_scans), dim3(FX_BLOCK), 0, s, oa);
+  hipLaunchKernelGGL(fx_lessflat_out_kernel, dim3((unsigned)n_scans), dim3(FX_BLOCK), 0, s, oa);
+  FX_TRY2(hipGetLastError());
+  if (curvature_out) FX_TRY2(hipMemcpyAsync(curvature_out, d_curv, n_points * 4, hipMemcpyDeviceToHost, s));
+  if (picked_out) FX_TRY2(hipMemcpyAsync(picked_out, d_picked, n_points, hipMemcpyDeviceToHost, s));
+  if (label_out) FX_TRY2(hipMemcpyAsync(label_out, d_label, n_points, hipMemcpyDeviceToHost, s));
   FX_TRY2(hipStreamSynchronize(s));
-  // per-list offsets of the rings, then compaction in ring order
-  std::vector<int32_t> off(4 * (n_scans + 1));
+  if (hdr[4]) {
+    lslam::set_error(hdr[4] == 1u ? "voxel index outside its range (non-finite point?)" : "a feature list overflowed its staging slice");
+    return fail(LSLAM_ERR_INVALID);
+  }
+  float *outs[4] = {sharp, less_sharp, flat, less_flat};
   for (int k = 0; k < 4; ++k) {
-    int32_t run = 0;
-    for (size_t r = 0; r < n_scans; ++r) {
-      off[k * (n_scans + 1) + r] = run;
-      run += hc[4 * r + k];
-    }
-    off[k * (n_scans + 1) + n_scans] = run;
-  }
-  FX_TRY2(hipMemcpyAsync(d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, s));
-  const int32_t *stage[4] = {st0, st1, st2, st3};
-  float *outs[3] = {sharp, less_sharp, flat};
-  // the four compactions back to back; the three small lists go to pinned memory behind them, the less-flat list through its
-  // per-ring VoxelGrid (:398-407) -- nothing waits until the filter's count is needed (second wait), then the filtered list
-  // is fetched (third).  Each list has its own slice of d_out and of the pinned area.
-  uint32_t *done = reinterpret_cast<uint32_t *>(cache.pout);
-  float4 *pin_lists = cache.pout + 1;
-  size_t pin_off[4] = {0, 0, 0, 0}, dev_off = 0;
-  int32_t totals[4];
-  for (int k = 0; k < 4; ++k) totals[k] = off[k * (n_scans + 1) + n_scans];
-  // less-flat candidates at the head of d_out (filtered into d_out2); sharp / less sharp / flat in what d_out leaves free
-  const size_t small_total = (size_t)totals[0] + (size_t)totals[1] + (size_t)totals[2];
-  const bool small_fit = (size_t)totals[3] + small_total <= n_points;  // d_out holds n_points
-  for (int k = 0; k < 3 && rc == LSLAM_OK; ++k) {
-    counts[k] = (size_t)totals[k];
-    pin_off[k] = dev_off;
-    if (totals[k] == 0) continue;
-    float4 *dst = small_fit ? d_out + (size_t)totals[3] + dev_off : d_out;
-    hipLaunchKernelGGL(fx_compact_kernel, dim3((totals[k] + 255) / 256), dim3(256), 0, s, d_pts, stage[k], d_ranges,
-                       d_off + k * (n_scans + 1), (int)n_scans, totals[k], dst, (int32_t *)nullptr);
-    if (!small_fit) {  // (a point in more than one list often enough to overflow the shared area: list by list, as before)
-      if (outs[k]) FX_TRY2(hipMemcpyAsync(outs[k], dst, (size_t)totals[k] * sizeof(float4), hipMemcpyDeviceToHost, s));
-      FX_TRY2(hipStreamSynchronize(s));
-    }
-    dev_off += (size_t)totals[k];
-  }
-  size_t m = 0;
-  done[0] = done[1] = 0;
-  if (rc == LSLAM_OK && totals[3] > 0) {
-    hipLaunchKernelGGL(fx_compact_kernel, dim3((totals[3] + 255) / 256), dim3(256), 0, s, d_pts, stage[3], d_ranges,
-                       d_off + 3 * (n_scans + 1), (int)n_scans, totals[3], d_out, d_seg);
-    rc = lslam::voxel_filter_segments(s, d_out, d_seg, (size_t)totals[3], (int)n_scans, prm.less_flat_filter_size, d_out2,
-                                      d_seg2, &m, true, done);
-  }
-  // the three small lists in ONE copy behind all the kernels (a copy between two launches is a bubble of its own)
-  if (rc == LSLAM_OK && small_fit && small_total)
-    FX_TRY2(hipMemcpyAsync(pin_lists, d_out + (size_t)totals[3], small_total * sizeof(float4), hipMemcpyDeviceToHost, s));
-  if (rc == LSLAM_OK) {
-    FX_TRY2(hipStreamSynchronize(s));  // the small lists are in pinned memory, the filter's count is known
-    if (done[1]) {  // the wide key did not hold the extent: the filter once more, with the measured one
-      rc = lslam::voxel_filter_segments(s, d_out, d_seg, (size_t)totals[3], (int)n_scans, prm.less_flat_filter_size, d_out2,
-                                        d_seg2, &m, true, nullptr);
-    } else {
-      m = done[0];
-    }
-  }
-  if (rc == LSLAM_OK) {
-    counts[3] = m;
-    if (small_fit)
-      for (int k = 0; k < 3; ++k)
-        if (outs[k] && totals[k]) std::memcpy(outs[k], pin_lists + pin_off[k], (size_t)totals[k] * sizeof(float4));
-    float4 *pin_less = pin_lists + (small_fit ? small_total : 0);
-    const bool fetch = less_flat && m;
-    if (fetch) FX_TRY2(hipMemcpyAsync(pin_less, d_out2, m * sizeof(float4), hipMemcpyDeviceToHost, s));
-    if (curvature_out) FX_TRY2(hipMemcpyAsync(curvature_out, d_curv, n_points * 4, hipMemcpyDeviceToHost, s));
-    if (picked_out) FX_TRY2(hipMemcpyAsync(picked_out, d_picked, n_points, hipMemcpyDeviceToHost, s));
-    if (label_out) FX_TRY2(hipMemcpyAsync(label_out, d_label, n_points, hipMemcpyDeviceToHost, s));
-    if (fetch || curvature_out || picked_out || label_out) FX_TRY2(hipStreamSynchronize(s));
-    if (fetch) std::memcpy(less_flat, pin_less, m * sizeof(float4));
+    counts[k] = (size_t)hdr[k];
+    if (outs[k] && hdr[k]) std::memcpy(outs[k], cache.pout + 16 + (size_t)k * n_points, (size_t)hdr[k] * sizeof(float4));
   }
   return rc;
 }

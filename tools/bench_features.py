@@ -25,8 +25,11 @@ for rings in (16, 64):
     print(line, {k: len(v) for k, v in out.items()})
 if os.environ.get("FX_CLOCKS"):  # -DLSLAM_FX_CLOCKS build
     import ctypes as C
-    clk = (C.c_double * 8)()
-    ctx.lib.lslam_debug_fx_clocks.argtypes = [C.c_double * 8]
+    clk = (C.c_double * 16)()
+    ctx.lib.lslam_debug_fx_clocks.argtypes = [C.c_double * 16]
     ctx.lib.lslam_debug_fx_clocks(clk)
     tot = sum(clk[:6])
+    vt = sum(clk[8:13])
+    print("fx_ring_voxel_kernel, share of thread 0's time: load+box %.2f, keys %.2f, sort %.2f, heads+scan %.2f, centroids %.2f" % tuple(c / vt for c in clk[8:13]))
+    print("points classified per ring: %.0f" % (clk[6] / max(1.0, clk[7])))
     print("fx_ring_kernel, share of thread 0's time: marks %.2f, curvature %.2f, classify %.2f, flat picks %.2f, compactions %.2f, rank sort %.2f" % tuple(c / tot for c in clk[:6]))

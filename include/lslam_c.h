@@ -196,7 +196,7 @@ void lslam_default_opts(lslam_opts *opts);
  * another header would hand the library a struct of the wrong size: compare before the first call --
  *   assert(lslam_abi_version() == LSLAM_ABI_VERSION && lslam_sizeof_opts() == sizeof(lslam_opts));
  * (the C++ mirrors do, and refuse to start otherwise). */
-/* 5 (round 5): no struct changed; new entry points (lslam_debug_grid_stats, lslam_debug_knn5_wide), new bits (LSLAM_SWEEP_FIRST /
+/* 5 (round 5): no struct changed; new entry points (lslam_debug_grid_stats, lslam_debug_knn5_wide, lslam_debug_sort_pairs), new bits (LSLAM_SWEEP_FIRST /
  * _CARRIED, LSLAM_AB_FIT_CACHE, LSLAM_AB_WIDE_NF_MARGIN) -- a program built against this header needs a library that has them. */
 #define LSLAM_ABI_VERSION 5
 int lslam_abi_version(void);
@@ -351,6 +351,12 @@ int lslam_sweep_ex(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_
  * with nf_margin != 0 also a fifth / sixth pair within 8 ulps, LSLAM_AB_WIDE_NF_MARGIN): a scan match would build the trees. */
 int lslam_debug_knn5_wide(lslam_ctx *ctx, int which_map, const void *queries, size_t nq, size_t stride_bytes, int32_t nf_margin,
                           int32_t *idx_out, float *d2_out, uint8_t *undecided_out);
+
+/* Parity tap of the sort the per-frame map maintenance runs on (csrc/lslam_sort.hip; n <= 131 072): keys_out / values_out =
+ * the n (key, value) pairs ascending by key, equal keys in ascending order of their values (distinct among equal keys: with
+ * values = input positions a stable sort by key -- pcl::VoxelGrid's index order, the Morton order of the resident scans). */
+int lslam_debug_sort_pairs(lslam_ctx *ctx, const uint64_t *keys, const uint32_t *values, size_t n, uint64_t *keys_out,
+                           uint32_t *values_out);
 
 /* The names SURVEY.md 8(b) gave these entry points before they were built, kept as exported aliases:
  *   lslam_residuals        = lslam_sweep with the MFMA contraction: coeff_out[N*4], valid_out[N] (the flag bits of

@@ -184,6 +184,8 @@ SYMBOLS = {
     "lslam_debug_grid_stats": (None, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "lslam_debug_knn5_wide": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int32, c_int32_p, c_float_p,
                                         C.POINTER(C.c_uint8)]),
+    "lslam_debug_sort_pairs": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_uint32)]),
     "lslam_debug_cert_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t]),
     "lslam_pg_create": (C.c_int, [C.c_int, C.c_int32, c_double_p, C.c_int32, c_int32_p, c_double_p, c_double_p,
                                   C.c_int32, C.POINTER(C.c_void_p)]),

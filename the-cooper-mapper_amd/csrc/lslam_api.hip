@@ -559,6 +559,7 @@ const EnvOnce &env_once() {
     v.no_level_build = on("LSLAM_NO_LEVEL_BUILD");
     v.fmap_timing = on("LSLAM_FMAP_TIMING");
     v.fmap_measured_extents = on("LSLAM_FMAP_MEASURED_EXTENTS");
+    v.small_sort = on("LSLAM_SMALL_SORT");
     return v;
   }();
   return e;
@@ -2634,6 +2635,31 @@ int lslam_debug_knn5_wide(lslam_ctx *ctx, int which_map, const void *queries, si
   HIP_TRY(hipMemcpyAsync(d2_out, ctx->t_d2.p, nq * 5 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(undecided_out, ctx->t_flags.p, nq, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));  // (q is a local)
+  return LSLAM_OK;
+}
+
+// Parity tap of lslam_sort.hip (include/lslam_c.h)
+int lslam_debug_sort_pairs(lslam_ctx *ctx, const uint64_t *keys, const uint32_t *values, size_t n, uint64_t *keys_out,
+                           uint32_t *values_out) {
+  int rc = check_ctx(ctx);
+  if (rc) return rc;
+  if (n > SMALL_SORT_MAX || (n && (!keys || !values || !keys_out || !values_out))) {
+    set_err("bad sort arguments (n <= %zu)", (size_t)SMALL_SORT_MAX);
+    return LSLAM_ERR_INVALID;
+  }
+  if (n == 0) return LSLAM_OK;
+  // [keys in | keys out | values in | values out | scratch] in the taps' index buffer
+  const size_t words = 4 * n + 2 * n + (small_sort_tmp_bytes(n) + 3) / 4 + 16;
+  HIP_TRY(ctx->t_idx.reserve(words));
+  uint64_t *k0 = reinterpret_cast<uint64_t *>(ctx->t_idx.p), *k1 = k0 + n;
+  uint32_t *v0 = reinterpret_cast<uint32_t *>(k1 + n), *v1 = v0 + n;
+  void *tmp = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(v1 + n) + 15) & ~(uintptr_t)15);
+  HIP_TRY(hipMemcpyAsync(k0, keys, n * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(v0, values, n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(small_sort_pairs(ctx->stream, k0, k1, v0, v1, n, tmp));
+  HIP_TRY(hipMemcpyAsync(keys_out, k1, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(values_out, v1, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
   return LSLAM_OK;
 }
 

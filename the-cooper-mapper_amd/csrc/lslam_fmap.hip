@@ -693,10 +693,18 @@ int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t
   hipLaunchKernelGGL(fm_key_kernel, grd, blk, 0, s, in_pts, in_cube, n, kp, eff, sc.base.p, sc.k0.p, sc.i0.p, sc.err.p + 1,
                      merge ? sc.k1.p : (uint64_t *)nullptr, merge ? sc.i1.p : (uint32_t *)nullptr);
   const unsigned end_bit = (unsigned)(3 * kp.axis_bits + n_cube_bits);
+  // KEY_DROP has every bit set: it is the largest key, so dropped points sort last.  rocPRIM's radix_sort_pairs (below
+  // MERGE_LIMIT keys a merge sort whose cost does not depend on end_bit; measured against its onesweep form on the 64-bit keys
+  // here: 60 us against 125 for 157 k keys, 136 against 141 for 587 k); LSLAM_SMALL_SORT=1: lslam_sort.hip for a frame's sorts
+  auto sort_pairs = [&](const uint64_t *ki, uint64_t *ko, const uint32_t *vi, uint32_t *vo, size_t cnt, size_t lib_tmp) -> int {
+    if (cnt <= lslam::SMALL_SORT_MAX && lslam::env_once().small_sort) {
+      FM_TRY(lslam::small_sort_pairs(s, ki, ko, vi, vo, cnt, (void *)sc.tmp.p));
+    } else {
+      FM_TRY(rocprim::radix_sort_pairs((void *)sc.tmp.p, lib_tmp, ki, ko, vi, vo, cnt, 0u, end_bit, s));
+    }
+    return LSLAM_OK;
+  };
   size_t tmp_bytes = 0;
-  // KEY_DROP has every bit set: within [0, end_bit) it is the largest key, so dropped points sort last
-  // (below MERGE_LIMIT keys rocPRIM's radix_sort_pairs is a merge sort whose cost does not depend on end_bit; measured against
-  // its onesweep form on the 64-bit keys here: 60 us against 125 for 157 k keys, 136 against 141 for 587 k)
   FM_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, sc.k0.p, sc.k1.p, sc.i0.p, sc.i1.p, n_total, 0u, end_bit, s));
   size_t tmp2 = 0;
   FM_TRY(rocprim::exclusive_scan(nullptr, tmp2, sc.head.p, sc.pos.p, 0u, n_total + 1, rocprim::plus<uint32_t>(), s));
@@ -706,18 +714,20 @@ int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t
     FM_TRY(sc.kn.reserve(n_new));
     FM_TRY(sc.in_.reserve(n_new));
     FM_TRY(rocprim::radix_sort_pairs(nullptr, tmp3, sc.k0.p + n_sorted, sc.kn.p, sc.i0.p + n_sorted, sc.in_.p, n_new, 0u, end_bit, s));
-    FM_TRY(sc.tmp.reserve(std::max(std::max(tmp_bytes, tmp2), tmp3)));
-    FM_TRY(rocprim::radix_sort_pairs((void *)sc.tmp.p, tmp3, sc.k0.p + n_sorted, sc.kn.p, sc.i0.p + n_sorted, sc.in_.p, n_new, 0u,
-                                     end_bit, s));
+    FM_TRY(sc.tmp.reserve(std::max(std::max(std::max(tmp_bytes, tmp2), tmp3), lslam::small_sort_tmp_bytes(n_new))));
+    {
+      const int rc_sort = sort_pairs(sc.k0.p + n_sorted, sc.kn.p, sc.i0.p + n_sorted, sc.in_.p, n_new, tmp3);
+      if (rc_sort) return rc_sort;
+    }
     // (if the prefix turns out not to be in order the places below are not a permutation: slots nobody writes must hold
     // something the kernels after this one can digest until the host sees the flag -- a dropped key, index 0)
     // -- written by fm_key_kernel (merge_defaults)
     hipLaunchKernelGGL(fm_merge_kernel, grd, blk, 0, s, (const uint64_t *)sc.k0.p, (int)n_sorted, (const uint64_t *)sc.kn.p,
                        (const uint32_t *)sc.in_.p, (int)n_new, sc.k1.p, sc.i1.p, sc.err.p + 2);
   } else {
-    FM_TRY(sc.tmp.reserve(std::max(tmp_bytes, tmp2)));
-    FM_TRY(rocprim::radix_sort_pairs((void *)sc.tmp.p, tmp_bytes, sc.k0.p, sc.k1.p, sc.i0.p, sc.i1.p, n_total, 0u,
-                                     end_bit, s));
+    FM_TRY(sc.tmp.reserve(std::max(std::max(tmp_bytes, tmp2), lslam::small_sort_tmp_bytes(n_total))));
+    const int rc_sort = sort_pairs(sc.k0.p, sc.k1.p, sc.i0.p, sc.i1.p, n_total, tmp_bytes);
+    if (rc_sort) return rc_sort;
   }
   hipLaunchKernelGGL(fm_head_kernel, grd, blk, 0, s, sc.k1.p, n, kp.axis_bits, kp.single, eff, sc.head.p);
   FM_TRY(rocprim::exclusive_scan((void *)sc.tmp.p, tmp2, sc.head.p, sc.pos.p, 0u, n_total + 1,

@@ -397,6 +397,7 @@ struct EnvOnce {
   bool no_reg_nodes = false;     // LSLAM_NO_REG_NODES
   bool no_level_build = false;   // LSLAM_NO_LEVEL_BUILD
   bool fmap_timing = false;      // LSLAM_FMAP_TIMING
+  bool small_sort = false;             // LSLAM_SMALL_SORT=1: A/B switch -- a frame's sorts by lslam_sort.hip instead of rocprim::radix_sort_pairs (measured slower: see there)
   bool fmap_measured_extents = false;  // LSLAM_FMAP_MEASURED_EXTENTS: A/B switch -- a map rebuild reads every point for its cube's extremes (fm_minmax_kernel) instead of taking the cube's nominal box (fm_base_kernel)
 };
 const EnvOnce &env_once();
@@ -405,6 +406,15 @@ const char *debug_env(const char *name);  // nullptr unless the process runs wit
 // lslam_fmap.hip: pcl::VoxelGrid per segment (see there)
 int voxel_filter_segments(hipStream_t s, const float4 *in_pts, const int32_t *in_seg, size_t n, int nseg, float leaf,
                           float4 *out_pts, int32_t *out_seg, size_t *n_out, bool filter = true, uint32_t *done = nullptr);
+
+// lslam_sort.hip: (64-bit key, 32-bit value) pairs ascending by key, equal keys by value -- the values must be distinct among
+// equal keys (every caller passes input positions: a stable sort by key).  For n <= SMALL_SORT_MAX; tmp: small_sort_tmp_bytes(n)
+// bytes of device memory (none for a single tile), in / out must not overlap
+constexpr int SMALL_SORT_TILE = 4096, SMALL_SORT_MAX_TILES = 32;
+constexpr size_t SMALL_SORT_MAX = (size_t)SMALL_SORT_MAX_TILES * SMALL_SORT_TILE;
+size_t small_sort_tmp_bytes(size_t n);
+hipError_t small_sort_pairs(hipStream_t s, const uint64_t *k_in, uint64_t *k_out, const uint32_t *v_in, uint32_t *v_out, size_t n,
+                            void *tmp);
 
 // lslam_scanprep.hip: Morton ordering of the resident scans on the device
 struct ScanPrep;

@@ -103,8 +103,11 @@ hipError_t scanprep_order(ScanPrep *sp, hipStream_t s, const float4 *h_pts, size
   const unsigned end_bit = 30u + (unsigned)seg_bits;
   uint64_t *k0 = (uint64_t *)sp->keys0, *k1 = (uint64_t *)sp->keys1;
   uint32_t *i0 = (uint32_t *)sp->idx0, *i1 = (uint32_t *)sp->idx1;
+  // the library's radix sort; LSLAM_SMALL_SORT=1 (A/B): lslam_sort.hip for a frame's scan (<= SMALL_SORT_MAX points)
+  const bool small = n <= SMALL_SORT_MAX && env_once().small_sort;
   size_t tmp_bytes = 0;
-  if ((e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, i0, i1, n, 0u, end_bit, s)) != hipSuccess) return e;
+  if (small) tmp_bytes = small_sort_tmp_bytes(n);
+  else if ((e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, i0, i1, n, 0u, end_bit, s)) != hipSuccess) return e;
   if (tmp_bytes > sp->tmp_cap) {
     if (sp->tmp) (void)hipFree(sp->tmp);
     sp->tmp = nullptr;
@@ -114,7 +117,9 @@ hipError_t scanprep_order(ScanPrep *sp, hipStream_t s, const float4 *h_pts, size
   }
   const dim3 blk(256), grd((unsigned)((n + 255) / 256));
   hipLaunchKernelGGL(sp_key_kernel, grd, blk, 0, s, (const float4 *)sp->raw, (int)n, (const int32_t *)sp->seg, nseg, k0, i0);
-  if ((e = rocprim::radix_sort_pairs(sp->tmp, tmp_bytes, k0, k1, i0, i1, n, 0u, end_bit, s)) != hipSuccess) return e;
+  if (small) e = small_sort_pairs(s, k0, k1, i0, i1, n, sp->tmp);
+  else e = rocprim::radix_sort_pairs(sp->tmp, tmp_bytes, k0, k1, i0, i1, n, 0u, end_bit, s);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(sp_gather_kernel, grd, blk, 0, s, (const float4 *)sp->raw, i1, k1, (const int32_t *)sp->seg, (int)n,
                      d_out);
   // No wait: h_seg_off is pageable (consumed when hipMemcpyAsync returned), h_pts is the context's pinned staging area,

@@ -394,6 +394,17 @@ class Context:
                                                    idx.ctypes.data_as(c_int32_p), _fp(d2), und.ctypes.data_as(c_uint8_p)))
         return idx, d2, und
 
+    def sort_pairs(self, keys, values):
+        """lslam_debug_sort_pairs: (uint64 keys, uint32 values) ascending by key, then value -> (keys, values)."""
+        k = np.ascontiguousarray(keys, dtype=np.uint64)
+        v = np.ascontiguousarray(values, dtype=np.uint32)
+        if k.shape != v.shape or k.ndim != 1:
+            raise ValueError("keys and values: one-dimensional, equal length")
+        ko, vo = np.zeros_like(k), np.zeros_like(v)
+        self._check(self.lib.lslam_debug_sort_pairs(self.h, k.ctypes.data_as(C.POINTER(C.c_uint64)), v.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                    len(k), ko.ctypes.data_as(C.POINTER(C.c_uint64)), vo.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return ko, vo
+
     def sweep(self, pose, jtj_mode=0, taps=True, search_mode=1):
         p = np.array(pose, dtype=np.float32).reshape(6)
         n = self.n_scan

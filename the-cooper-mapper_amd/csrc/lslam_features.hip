@@ -125,27 +125,46 @@ __device__ int fx_point_classify(const bool line1, const float (&v1)[3], const b
 }
 
 // Bitonic sort of `count` words in LDS, in independent stretches of `seg` words (a power of two >= 2; every stretch ascending),
-// by the whole workgroup.  Thread t of a stage takes the pair (i, i | j): for j <= 64 the 64 pairs of a wavefront's round lie in
-// one stretch of 128 words that no other wavefront touches in that round, so such stages need no workgroup barrier -- the
-// wavefront's LDS operations are executed in order -- and only the strides >= 128 and the changes between the two kinds do
-// (15 barriers instead of 66 for 2 048 words: with sixteen wavefronts a barrier costs more than the stage's work).
+// by the whole workgroup.  The sort is bound by LDS traffic (a stage reads and writes every word: sixteen wavefronts' 64-bit
+// accesses, 66 stages for 2 048 words were 20 us), so up to three consecutive stages -- strides j, j/2, j/4 -- are done on
+// eight words in registers between one read and one write: a third of the traffic and of the barriers.  Word p lives at
+// fx_at(p) = p + p / 8: a thread's eight neighbouring words then start 72 bytes after its neighbour's, not 64, and a
+// wavefront's accesses spread over all banks.
+__device__ __forceinline__ int fx_at(int p) { return p + (p >> 3); }
+template <int M>
+__device__ __forceinline__ void fx_bitonic_group(unsigned long long *w, int count, int seg, int k, int j) {
+  constexpr int PER = 1 << M;
+  const int jl = j >> (M - 1);  // smallest stride of the group
+  for (int t = threadIdx.x; t < (count >> M); t += FX_BLOCK) {
+    const int base = ((t & ~(jl - 1)) << M) | (t & (jl - 1));  // M zero bits inserted above the low log2(jl) bits
+    unsigned long long x[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) x[e] = w[fx_at(base + e * jl)];
+    const bool up = ((base & (seg - 1)) & k) == 0;  // (j < k: the same for the eight)
+#pragma unroll
+    for (int sbit = M - 1; sbit >= 0; --sbit) {
+#pragma unroll
+      for (int e = 0; e < PER; ++e) {
+        if (!(e & (1 << sbit))) {
+          const unsigned long long a = x[e], b = x[e | (1 << sbit)];
+          const bool sw = (a > b) == up;
+          x[e] = sw ? b : a;
+          x[e | (1 << sbit)] = sw ? a : b;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < PER; ++e) w[fx_at(base + e * jl)] = x[e];
+  }
+  __syncthreads();
+}
 __device__ void fx_bitonic(unsigned long long *w, int count, int seg) {
-  const int tid = threadIdx.x, half = count >> 1;
   for (int k = 2; k <= seg; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < half; t += FX_BLOCK) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
-        const unsigned long long x = w[i], y = w[l];
-        const bool up = ((i & (seg - 1)) & k) == 0;
-        if ((x > y) == up) { w[i] = y; w[l] = x; }
-      }
-      const int j_next = j > 1 ? (j >> 1) : (2 * k <= seg ? k : 0);
-      if (j >= 128 || j_next >= 128 || j_next == 0) {
-        __syncthreads();
-      } else {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
+    int j = k >> 1;
+    while (j > 0) {
+      if (j >= 4) { fx_bitonic_group<3>(w, count, seg, k, j); j >>= 3; }
+      else if (j == 2) { fx_bitonic_group<2>(w, count, seg, k, j); j = 0; }
+      else { fx_bitonic_group<1>(w, count, seg, k, j); j = 0; }
     }
   }
 }
@@ -166,7 +185,7 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
   __shared__ int8_t picked[MAXR], cls_ring[MAXR], rlabel_ring[MAXR];
   __shared__ uint8_t pfl[MAXR];
   __shared__ uint16_t need[MAXR];
-  __shared__ unsigned long long skey[SKEY];
+  __shared__ unsigned long long skey[SKEY + SKEY / 8];  // (fx_at)
   __shared__ int reg_sp[512], reg_ep[512];  // (n_feature_regions <= 512)
   __shared__ uint8_t side_ok[2 * MAXR];
   __shared__ int n_need;
@@ -289,7 +308,7 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
           wanted = !(c < a.surf_thr);
           if (a.curv_out) a.curv_out[start + i] = c;
         }
-        skey[t] = w;
+        skey[fx_at(t)] = w;
         // pointClassify for every point the third loop will visit: those are collected first (any order: a point's class
         // depends on nothing else), so that the eigen-solver runs on full wavefronts instead of on the lanes that happen
         // to hold such a point.  One LDS atomic per wavefront, not per point (a thousand on one word were 13 us of the kernel)
@@ -306,7 +325,7 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
         int sp, ep;
         region_of(j, sp, ep);
         const int rs = ep > sp ? ep - sp + 1 : 0;
-        if (r < rs) sorted_ring[sp - start + r] = (uint16_t)(skey[t] & 0xFFFFull);
+        if (r < rs) sorted_ring[sp - start + r] = (uint16_t)(skey[fx_at(t)] & 0xFFFFull);
       }
       __syncthreads();
       FX_T(5)
@@ -551,7 +570,7 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_voxel_kernel(FxOutArgs a) {
   unsigned long long vx_last = wall_clock64();
 #endif
   __shared__ float4 sp[MAXR];
-  __shared__ unsigned long long key[VX_PAD];
+  __shared__ unsigned long long key[VX_PAD + VX_PAD / 8];  // (fx_at)
   __shared__ float wred[6][FX_BLOCK / 64];
   __shared__ int part[FX_BLOCK];
   __shared__ int s_err;
@@ -618,7 +637,7 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_voxel_kernel(FxOutArgs a) {
       }
       w = (idx << 12) | (unsigned long long)i;
     }
-    key[i] = w;
+    key[fx_at(i)] = w;
   }
   __syncthreads();
   VX_T(1)
@@ -630,7 +649,7 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_voxel_kernel(FxOutArgs a) {
   int heads = 0;
   for (int u = 0; u < PER; ++u) {
     const int i = tid * per + u;
-    if (u < per && i < n) heads += (i == 0 || (key[i] >> 12) != (key[i - 1] >> 12)) ? 1 : 0;
+    if (u < per && i < n) heads += (i == 0 || (key[fx_at(i)] >> 12) != (key[fx_at(i - 1)] >> 12)) ? 1 : 0;
   }
   int total;
   int pos = fx_block_scan(heads, part, &total);
@@ -638,12 +657,12 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_voxel_kernel(FxOutArgs a) {
   for (int u = 0; u < PER; ++u) {
     const int i = tid * per + u;
     if (!(u < per && i < n)) continue;
-    const unsigned long long vi = key[i] >> 12;
-    if (!(i == 0 || vi != (key[i - 1] >> 12))) continue;
-    float4 s = sp[(int)(key[i] & 4095ull)];  // PCL starts from a zero vector: 0 + x = x
+    const unsigned long long vi = key[fx_at(i)] >> 12;
+    if (!(i == 0 || vi != (key[fx_at(i - 1)] >> 12))) continue;
+    float4 s = sp[(int)(key[fx_at(i)] & 4095ull)];  // PCL starts from a zero vector: 0 + x = x
     int m = i + 1;
-    for (; m < n && (key[m] >> 12) == vi; ++m) {
-      const float4 q = sp[(int)(key[m] & 4095ull)];
+    for (; m < n && (key[fx_at(m)] >> 12) == vi; ++m) {
+      const float4 q = sp[(int)(key[fx_at(m)] & 4095ull)];
       s.x = __fadd_rn(s.x, q.x);
       s.y = __fadd_rn(s.y, q.y);
       s.z = __fadd_rn(s.z, q.z);

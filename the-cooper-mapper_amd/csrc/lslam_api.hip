@@ -560,6 +560,7 @@ const EnvOnce &env_once() {
     v.fmap_timing = on("LSLAM_FMAP_TIMING");
     v.fmap_measured_extents = on("LSLAM_FMAP_MEASURED_EXTENTS");
     v.small_sort = on("LSLAM_SMALL_SORT");
+    if (on("LSLAM_FX_HELPERS")) v.fx_helpers = std::max(0, std::min(7, (int)num("LSLAM_FX_HELPERS", 3)));
     return v;
   }();
   return e;

@@ -64,6 +64,10 @@ struct FxArgs {
   int32_t *counts;          // [n_scans][4]
   float *curv_out;          // optional taps, [n_points]
   int8_t *picked_out, *label_out;
+  // pointClassify by helper workgroups (fx_ring_kernel): `helpers` per ring, their verdicts in cls_g[n_points], ready[ring]
+  // counts the helpers that have published
+  int32_t helpers;
+  int32_t *cls_g, *ready;
 };
 
 __device__ __forceinline__ float fx_pdist(float x, float y, float z) {
@@ -122,6 +126,18 @@ __device__ int fx_point_classify(const bool line1, const float (&v1)[3], const b
     if (diff > a.c135 && diff < a.c45) return L_CORNER_SHARP;
   }
   return (line1 || line2) ? L_ONESIDE_FLAT : L_MESSY;
+}
+
+// setRegionBuffersFor, :437-454: the curvature of ring point i
+__device__ __forceinline__ float fx_curvature(const float *sx, const float *sy, const float *sz, int i, int cr) {
+  const float w = (float)(-2 * cr);
+  float dx = __fmul_rn(w, sx[i]), dy = __fmul_rn(w, sy[i]), dz = __fmul_rn(w, sz[i]);
+  for (int q = 1; q <= cr; ++q) {
+    dx = __fadd_rn(dx, __fadd_rn(sx[i + q], sx[i - q]));
+    dy = __fadd_rn(dy, __fadd_rn(sy[i + q], sy[i - q]));
+    dz = __fadd_rn(dz, __fadd_rn(sz[i + q], sz[i - q]));
+  }
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
 // Bitonic sort of `count` words in LDS, in independent stretches of `seg` words (a power of two >= 2; every stretch ascending),
@@ -189,7 +205,15 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
   __shared__ int reg_sp[512], reg_ep[512];  // (n_feature_regions <= 512)
   __shared__ uint8_t side_ok[2 * MAXR];
   __shared__ int n_need;
-  const int ring = blockIdx.x, tid = threadIdx.x;
+  __shared__ int s_ready;
+  // The first helpers * n_scans workgroups are HELPERS: pointClassify -- two 6-point line fits through an iterative 3 x 3
+  // eigen-solver for ~1 000 points of a ring, a third of this kernel on its one CU while three quarters of the chip idle -- is
+  // done for a ring by `helpers` workgroups on CUs of their own, each a share of the ring, published through cls_g / ready
+  // while the ring's own workgroup marks and sorts.  Helpers have the lower workgroup indices (dispatched first) and wait
+  // for nothing; a ring's workgroup that does not see them in time classifies for itself.  Same values either way.
+  const int H = a.helpers, tid = threadIdx.x;
+  const bool helper = (int)blockIdx.x < H * a.n_scans;
+  const int ring = helper ? (int)blockIdx.x / H : (int)blockIdx.x - H * a.n_scans;
   if (tid == 0) n_need = 0;
   const int start = a.ranges[2 * ring], end = a.ranges[2 * ring + 1];
   const int cr = a.cr, nf = a.nf;
@@ -201,6 +225,46 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
       sx[i] = p.x; sy[i] = p.y; sz[i] = p.z;
     }
     __syncthreads();
+    // the points the third loop visits (curvature at or above the threshold), collected first -- any order: a point's class
+    // depends on nothing else -- so that the eigen-solver runs on full wavefronts; one LDS atomic per wavefront
+    auto collect = [&](bool wanted, int i) {
+      const unsigned long long wm = __ballot(wanted);
+      int wbase = 0;
+      if ((tid & 63) == 0 && wm) wbase = atomicAdd(&n_need, __popcll(wm));
+      wbase = __builtin_amdgcn_readfirstlane(wbase);
+      if (wanted) need[wbase + __popcll(wm & ((1ull << (tid & 63)) - 1ull))] = (uint16_t)i;
+    };
+    // the two one-sided fits of a point are work items of their own: direction and verdict wait in the sort words' LDS
+    float *side_v = reinterpret_cast<float *>(skey);  // [2 n_need][3]
+    auto fit_sides = [&]() {
+      for (int t = tid; t < 2 * n_need; t += FX_BLOCK) {
+        float v[3] = {0.f, 0.f, 0.f};
+        const bool ok = fx_one_sided_line(sx, sy, sz, need[t >> 1], cr, (t & 1) ? +1 : -1, v);
+        side_v[3 * t] = v[0]; side_v[3 * t + 1] = v[1]; side_v[3 * t + 2] = v[2];
+        side_ok[t] = ok ? 1 : 0;
+      }
+      __syncthreads();
+    };
+    auto class_of = [&](int t) {
+      const float v1[3] = {side_v[6 * t], side_v[6 * t + 1], side_v[6 * t + 2]};
+      const float v2[3] = {side_v[6 * t + 3], side_v[6 * t + 4], side_v[6 * t + 5]};
+      return fx_point_classify(side_ok[2 * t] != 0, v1, side_ok[2 * t + 1] != 0, v2, a);
+    };
+    if (helper) {  // block-uniform
+      const int part = (int)blockIdx.x % H, total = n - 2 * cr, chunk = (total + H - 1) / H;
+      const int i0 = cr + part * chunk, i1 = min(n - cr, i0 + chunk);
+      for (int ib = i0; ib < i1; ib += FX_BLOCK) {
+        const int i = ib + tid;
+        collect(i < i1 && !(fx_curvature(sx, sy, sz, min(i, i1 - 1), cr) < a.surf_thr), i);
+      }
+      __syncthreads();
+      fit_sides();
+      for (int t = tid; t < n_need; t += FX_BLOCK)
+        __hip_atomic_store(a.cls_g + start + need[t], class_of(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(a.ready + ring, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
     // ---- neighbour tests of setScanBuffersFor, one per point pair (i, i+1) ------------------------
     // bit0: cos(angle(p_i, p_i+1)) < blindThreshold   bit1: |p_i+1 - p_i|^2 > 1.0
     // bit2: depth_i > depth_i+1                          bit3: |p_i-1 - p_i|^2 / |p_i+1 - p_i|^2 < 0.2
@@ -267,15 +331,8 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
       ep = reg_ep[j];
     };
     {
-      const float w = (float)(-2 * cr);
-      for (int i = cr + tid; i <= n - 1 - cr; i += FX_BLOCK) {  // setRegionBuffersFor, :437-454
-        float dx = __fmul_rn(w, sx[i]), dy = __fmul_rn(w, sy[i]), dz = __fmul_rn(w, sz[i]);
-        for (int q = 1; q <= cr; ++q) {
-          dx = __fadd_rn(dx, __fadd_rn(sx[i + q], sx[i - q]));
-          dy = __fadd_rn(dy, __fadd_rn(sy[i + q], sy[i - q]));
-          dz = __fadd_rn(dz, __fadd_rn(sz[i + q], sz[i - q]));
-        }
-        curv_ring[i] = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      for (int i = cr + tid; i <= n - 1 - cr; i += FX_BLOCK) {
+        curv_ring[i] = fx_curvature(sx, sy, sz, i, cr);
         rlabel_ring[i] = L_UNKNOW;
       }
       __syncthreads();
@@ -309,14 +366,7 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
           if (a.curv_out) a.curv_out[start + i] = c;
         }
         skey[fx_at(t)] = w;
-        // pointClassify for every point the third loop will visit: those are collected first (any order: a point's class
-        // depends on nothing else), so that the eigen-solver runs on full wavefronts instead of on the lanes that happen
-        // to hold such a point.  One LDS atomic per wavefront, not per point (a thousand on one word were 13 us of the kernel)
-        const unsigned long long wm = __ballot(wanted);
-        int wbase = 0;
-        if ((tid & 63) == 0 && wm) wbase = atomicAdd(&n_need, __popcll(wm));
-        wbase = __builtin_amdgcn_readfirstlane(wbase);
-        if (wanted) need[wbase + __popcll(wm & ((1ull << (tid & 63)) - 1ull))] = (uint16_t)i;
+        collect(wanted, i);
       }
       __syncthreads();
       fx_bitonic(skey, nf * rpad, rpad);
@@ -329,24 +379,29 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
       }
       __syncthreads();
       FX_T(5)
-      // the two one-sided fits of a point are work items of their own (round 5): a ring has a few hundred such points, so the
-      // eigen-solver -- iterative, its wavefront as slow as its slowest lane -- ran twice in a row on half-empty workgroups;
-      // direction and verdict wait in the sort words' LDS, free by now
-      float *side_v = reinterpret_cast<float *>(skey);  // [2 n_need][3]
+      // pointClassify of the collected points: the helpers' verdicts if they have all published, else here
+      bool have = false;
+      if (H > 0) {
+        if (tid == 0) {
+          int ok = 0;
+          for (int spin = 0; spin < (1 << 14) && !ok; ++spin) {
+            ok = __hip_atomic_load(a.ready + ring, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= H;
+            if (!ok) __builtin_amdgcn_s_sleep(16);
+          }
+          s_ready = ok;
+        }
+        __syncthreads();
+        have = s_ready != 0;
+      }
 #ifdef LSLAM_FX_CLOCKS
       if (tid == 0) { atomicAdd(&fx_clk[6], (unsigned long long)n_need); atomicAdd(&fx_clk[7], 1ull); }
 #endif
-      for (int t = tid; t < 2 * n_need; t += FX_BLOCK) {
-        float v[3] = {0.f, 0.f, 0.f};
-        const bool ok = fx_one_sided_line(sx, sy, sz, need[t >> 1], cr, (t & 1) ? +1 : -1, v);
-        side_v[3 * t] = v[0]; side_v[3 * t + 1] = v[1]; side_v[3 * t + 2] = v[2];
-        side_ok[t] = ok ? 1 : 0;
-      }
-      __syncthreads();
-      for (int t = tid; t < n_need; t += FX_BLOCK) {
-        const float v1[3] = {side_v[6 * t], side_v[6 * t + 1], side_v[6 * t + 2]};
-        const float v2[3] = {side_v[6 * t + 3], side_v[6 * t + 4], side_v[6 * t + 5]};
-        cls_ring[need[t]] = (int8_t)fx_point_classify(side_ok[2 * t] != 0, v1, side_ok[2 * t + 1] != 0, v2, a);
+      if (have) {
+        for (int t = tid; t < n_need; t += FX_BLOCK)
+          cls_ring[need[t]] = (int8_t)__hip_atomic_load(a.cls_g + start + need[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        fit_sides();
+        for (int t = tid; t < n_need; t += FX_BLOCK) cls_ring[need[t]] = (int8_t)class_of(t);
       }
       __syncthreads();
       FX_T(2)
@@ -455,7 +510,7 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
       __syncthreads();
     }
   }
-  if (tid == 0) {
+  if (tid == 0 && !helper) {
     a.counts[4 * ring + 0] = n_sharp;
     a.counts[4 * ring + 1] = n_less_sharp;
     a.counts[4 * ring + 2] = n_flat;
@@ -868,7 +923,8 @@ static int extract_features_impl(lslam_ctx *ctx, const void *cloud, size_t n_poi
       h[i] = make_float4(v[0], v[1], v[2], w);
     }
   }
-  const size_t bytes = 5 * np4 + 2 * n_scans * 4 + 4 * n_scans * 4 + n_points * 4 + 2 * n_points + (n_scans + 1) * 4 + np4 + 256 + 16 * 16;
+  const size_t bytes = 5 * np4 + 2 * n_scans * 4 + 4 * n_scans * 4 + n_points * 4 + 2 * n_points + (n_scans + 1) * 4 + np4 + n_points * 4 +
+                       n_scans * 4 + 256 + 18 * 16;
   if (bytes > cache.cap) {
     if (cache.p) (void)hipFree(cache.p);
     cache.p = nullptr;
@@ -886,6 +942,7 @@ static int extract_features_impl(lslam_ctx *ctx, const void *cloud, size_t n_poi
   int8_t *d_picked = (int8_t *)take(n_points), *d_label = (int8_t *)take(n_points);
   int32_t *d_ring_out = (int32_t *)take((n_scans + 1) * 4);  // centroids per ring (fx_ring_voxel_kernel)
   float4 *d_vox = (float4 *)take(np4);                       // ... and the centroids, ring r's from its first index on
+  int32_t *d_cls = (int32_t *)take(n_points * 4), *d_ready = (int32_t *)take(n_scans * 4);  // the classify helpers' (fx_ring_kernel)
   int rc = LSLAM_OK;
   auto fail = [&](int code) { return code; };
 #define FX_TRY2(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { lslam::set_error(hipGetErrorString(_e)); return fail(LSLAM_ERR_HIP); } } while (0)
@@ -922,7 +979,11 @@ static int extract_features_impl(lslam_ctx *ctx, const void *cloud, size_t n_poi
   a.curv_out = curvature_out ? d_curv : nullptr;
   a.picked_out = picked_out ? d_picked : nullptr;
   a.label_out = label_out ? d_label : nullptr;
-  hipLaunchKernelGGL(fx_ring_kernel, dim3((unsigned)n_scans), dim3(FX_BLOCK), 0, s, a);
+  a.helpers = lslam::env_once().fx_helpers;
+  a.cls_g = d_cls;
+  a.ready = d_ready;
+  if (a.helpers > 0) FX_TRY2(hipMemsetAsync(d_ready, 0, n_scans * 4, s));
+  hipLaunchKernelGGL(fx_ring_kernel, dim3((unsigned)n_scans * (unsigned)(1 + a.helpers)), dim3(FX_BLOCK), 0, s, a);
   // the four lists, on the device to the end (see fx_lists_kernel): nothing waits until everything is in pinned memory
   uint32_t *hdr = reinterpret_cast<uint32_t *>(cache.pout);
   for (int k = 0; k < 8; ++k) hdr[k] = 0u;

@@ -397,6 +397,7 @@ struct EnvOnce {
   bool no_reg_nodes = false;     // LSLAM_NO_REG_NODES
   bool no_level_build = false;   // LSLAM_NO_LEVEL_BUILD
   bool fmap_timing = false;      // LSLAM_FMAP_TIMING
+  int fx_helpers = 3;                  // LSLAM_FX_HELPERS=0..7: helper workgroups per ring for pointClassify (fx_ring_kernel); 0 = A/B: none
   bool small_sort = false;             // LSLAM_SMALL_SORT=1: A/B switch -- a frame's sorts by lslam_sort.hip instead of rocprim::radix_sort_pairs (measured slower: see there)
   bool fmap_measured_extents = false;  // LSLAM_FMAP_MEASURED_EXTENTS: A/B switch -- a map rebuild reads every point for its cube's extremes (fm_minmax_kernel) instead of taking the cube's nominal box (fm_base_kernel)
 };

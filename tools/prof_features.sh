@@ -9,5 +9,5 @@ for f in glob.glob("/tmp/fxp/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Name"]
         if any(k in n for k in ("fx_", "Buffer", "fm_", "rocprim")):
-            print("%-50s calls %4s  avg %8.1f us  min %8.1f  max %8.1f" % (n.split("(")[0][-50:], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
+            print("%-50s calls %4s  avg %8.1f us  min %8.1f  max %8.1f" % (n.replace("(anonymous namespace)::", "").split("(")[0][-50:], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
 PY

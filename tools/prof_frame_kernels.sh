@@ -11,7 +11,6 @@ for f in glob.glob("/tmp/ffp/**/*kernel_stats.csv", recursive=True):
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
     for r in rows[:45]:
-        n = r["Name"].split("(")[0]
-        n = n.replace("lslam::", "").replace("(anonymous namespace)::", "")
+        n = r["Name"].replace("(anonymous namespace)::", "").replace("lslam::", "").split("(")[0]
         print("%-60s calls %5s  avg %8.1f us  total %9.1f us" % (n[-60:], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e3))
 PY

@@ -453,7 +453,7 @@ int lslam_voxel_grid2(lslam_ctx *ctx, const void *cloud_a, size_t n_a, const voi
  * builds (MultiScanRegistration.cpp:178-190).  Building that cloud from raw driver packets is the
  * caller's (ring from the vertical angle, IMU de-skew). */
 typedef struct lslam_reg_params {     /* RegistrationParams, ScanRegistration.h:45-112 */
-  int32_t n_feature_regions;          /* 6 */
+  int32_t n_feature_regions;          /* 6; 1 .. 512 (the device keeps the sort words of a ring's regions in LDS) */
   int32_t curvature_region;           /* 5 */
   int32_t max_corner_sharp;           /* 2 */
   int32_t max_surface_flat;           /* 4 */

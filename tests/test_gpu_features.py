@@ -63,6 +63,32 @@ def test_extract_features_parameters_and_edges(pkg, ctx, oracle, synth):
         pkg.scan_registration.extract_features(ctx, cloud, np.array([[0, 4000]], np.int32))  # > 2560 points
 
 
+@pytest.mark.parametrize("nf,cr,leaf", [(1, 5, 0.2), (2, 5, 0.2), (3, 4, 0.2), (7, 5, 0.3), (13, 2, 0.2), (40, 5, 0.2), (200, 1, 0.2),
+                                         (6, 5, 1.0e-4), (6, 5, 25.0)])
+def test_extract_features_region_counts_and_filter_sizes(pkg, ctx, oracle, synth, nf, cr, leaf):
+    """Round 5: the regions of a ring are sorted side by side in power-of-two stretches of one LDS array (1 region of ~1 800
+    points ... 200 regions of 9), and the per-ring VoxelGrid runs in LDS: leaves so small that PCL's guard hands the ring back
+    unfiltered (index volume above INT_MAX), and so large that a ring is one voxel."""
+    world = synth.World(half_extent=80.0, wall_half=70.0)
+    c, s, gt, cloud, ranges = synth.make_scan(world, 16, 1800, seed=7 + nf, full=True)
+    p, q = pkg.scan_registration.default_params(ctx), oracle.reg_params()
+    for obj in (p, q):
+        obj.n_feature_regions = nf
+        obj.curvature_region = cr
+        obj.less_flat_filter_size = leaf
+    _compare(pkg.scan_registration.extract_features(ctx, cloud, ranges, p, taps=True),
+             oracle.extract_features(cloud, ranges, q), (nf, cr, leaf))
+
+
+def test_extract_features_bounds_its_region_count(pkg, ctx, synth):
+    world = synth.World(half_extent=60.0, wall_half=55.0)
+    c, s, gt, cloud, ranges = synth.make_scan(world, 16, 900, full=True)
+    p = pkg.scan_registration.default_params(ctx)
+    p.n_feature_regions = 513
+    with pytest.raises(pkg.LslamError):
+        pkg.scan_registration.extract_features(ctx, cloud, ranges, p)
+
+
 def test_features_feed_odometry(pkg, ctx, oracle, synth, small_problem):
     """Config 1 end to end on the device: extractFeatures on two consecutive sweeps, then
     LaserOdometry::scanMatch (variant B) of sweep 2's sharp/flat points against sweep 1's

@@ -855,7 +855,8 @@ int tree_build_failed(int limit, size_t n_points) {
 }
 
 int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void *surf, size_t n_surf,
-                 size_t stride_bytes, const float4 *dev_corner, const float4 *dev_surf, bool may_defer = true) {
+                 size_t stride_bytes, const float4 *dev_corner, const float4 *dev_surf, bool may_defer = true,
+                 const float (*box_lo)[3] = nullptr, const float (*box_hi)[3] = nullptr) {
   int rc = check_ctx(ctx, true);  // (a map whose trees were never needed is simply replaced)
   if (rc) return rc;
   ctx->trees_pending = false;
@@ -925,7 +926,12 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
       host_uploaded = true;
     }
     float lo[2][3], hi[2][3];
-    HIP_TRY(grid_bbox2(dev_src, counts, ctx->bbox6.p, lo, hi, ctx->stream));  // the one host round trip of the map set
+    if (box_lo && box_hi) {  // (lslam_fmap_surround_to_map: the gather took the boxes along)
+      std::memcpy(lo, box_lo, sizeof(lo));
+      std::memcpy(hi, box_hi, sizeof(hi));
+    } else {
+      HIP_TRY(grid_bbox2(dev_src, counts, ctx->bbox6.p, lo, hi, ctx->stream));  // the one host round trip of the map set
+    }
     int st = 0;
     for (int k = 0; k < 2 && !st; ++k) {
       HIP_TRY(gd[k]->build(dev_src[k], counts[k], lo[k], hi[k], cell, ctx->stream, &st, false));
@@ -1120,9 +1126,10 @@ int build_cube_side_device(lslam_ctx *ctx, DevTree &dt, const float4 *src, bool 
 }  // namespace
 
 namespace lslam {
-int map_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t n_corner, const float4 *d_surf, size_t n_surf) {
+int map_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t n_corner, const float4 *d_surf, size_t n_surf,
+                   const float (*box_lo)[3], const float (*box_hi)[3]) {
   return map_set_impl(ctx, nullptr, n_corner, nullptr, n_surf, sizeof(float4), d_corner ? d_corner : d_surf,
-                      d_surf ? d_surf : d_corner);
+                      d_surf ? d_surf : d_corner, true, box_lo, box_hi);
 }
 // variant C map straight from device arrays (map maintenance): per side the cubes' clouds back to
 // back with .w = index inside the cube, their ranges, and the cell -> tree table
@@ -1503,8 +1510,7 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
     HIP_TRY(ctx->cert_count.reserve(4));
     HIP_TRY(hipMemsetAsync(ctx->cert_count.p, 0, 4 * sizeof(int32_t), ctx->stream));
   }
-  HIP_TRY(ctx->tail_count.reserve((size_t)n_scans));
-  HIP_TRY(hipMemsetAsync(ctx->tail_count.p, 0, sizeof(int32_t) * (size_t)n_scans, ctx->stream));
+  HIP_TRY(ctx->tail_count.reserve((size_t)n_scans));  // (zeroed where the fused solve is switched on: run_batch_impl)
   ctx->prev_valid = false;
   ctx->grid_state_valid = false;
   rc = ensure_states(ctx, n_scans);
@@ -1872,6 +1878,9 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
     // costs less than that.  Not with the stereo term (its records come from a launch of their own).
     const bool no_fuse = !((o.ab_switches | ctx->env_ab) & LSLAM_AB_FUSED_SOLVE);
     if (!no_fuse && ctx->n_stereo == 0 && !sa.grid) {
+      // the ticket counters: zero between launches (the last block of a launch resets its scan's); once per call here, in case
+      // an earlier call ended in an error half way
+      HIP_TRY(hipMemsetAsync(ctx->tail_count.p, 0, sizeof(int32_t) * (size_t)n_scans, ctx->stream));
       sa.tail.count = ctx->tail_count.p;
       sa.tail.probs = ctx->probs.p;
       sa.tail.partials_abs = ctx->partials.p;

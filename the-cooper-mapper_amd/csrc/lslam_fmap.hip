@@ -136,10 +136,12 @@ __device__ __forceinline__ int32_t cube_of_point(const KeyParams &k, float x, fl
 }
 
 // new points: p' = R p + t (pcl::transformPointCloud), cube of p'
-__global__ void fm_transform_kernel(const float4 *in, int n, const float *T, KeyParams k, float4 *out,
+struct Rigid12 { float m[12]; };  // rows of [R | t], a kernel argument (was a 64-byte upload per call)
+__global__ void fm_transform_kernel(const float4 *in, int n, const Rigid12 Tm, KeyParams k, float4 *out,
                                     int32_t *cube_out, uint8_t *touched) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const float *T = Tm.m;
   const float4 p = in[i];
   float4 q;
   q.x = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[0], p.x), __fmul_rn(T[1], p.y)), __fmul_rn(T[2], p.z)), T[3]);
@@ -507,6 +509,83 @@ __global__ void fm_gather_kernel(const float4 *pts, const int32_t *src_begin, co
   out[i] = p;
 }
 
+// ---- the surround of lslam_fmap_surround_to_map, without the host in between (round 5) ------------------------------------
+// The host used to fetch both feature types' segment tables (a wait), walk the active cubes, upload two tables per type and,
+// in the map set that followed, run the bounding boxes as launches of their own behind an upload of their initial values.  Now
+// one workgroup turns the device's segment table into the gather's tables and the total, and the gather takes the bounding
+// box along: a fill, the segments, a plan and a gather per type, one 64-byte copy and one wait for both.
+__global__ __launch_bounds__(256) void fm_surround_plan_kernel(const int32_t *valid, int n_valid, const int32_t *seg, int pad, int32_t *g_src,
+                                                               int32_t *g_dst, uint32_t *res) {
+  __shared__ int part[256];
+  const int tid = threadIdx.x;
+  const int per = (n_valid + 255) / 256;
+  const int v0 = min(n_valid, tid * per), v1 = min(n_valid, v0 + per);
+  int sum = 0;
+  for (int v = v0; v < v1; ++v) sum += seg[pad + valid[v]] - seg[valid[v]];
+  part[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int u = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += u;
+    __syncthreads();
+  }
+  int run = part[tid] - sum;
+  for (int v = v0; v < v1; ++v) {
+    const int32_t c = valid[v];
+    g_src[v] = seg[c];
+    g_dst[v] = run;  // (an empty cube shares its place with the next one: the gather's search takes the last of equals)
+    run += seg[pad + c] - seg[c];
+  }
+  if (tid == 255) res[0] = (uint32_t)part[255];
+  if (tid < 7) res[1 + tid] = 0u;  // the box: maxima of ~ordered(x) (the minimum) and of ordered(x)
+}
+
+__device__ __forceinline__ uint32_t fm_ordered_u32(float f) {  // monotone map float -> uint32 (lslam_grid.hip's)
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+// res[0] = points to gather; res[1..3] / res[4..6]: the box (see above)
+__global__ __launch_bounds__(256) void fm_gather_box_kernel(const float4 *pts, const int32_t *src_begin, const int32_t *dst_begin, int n_seg,
+                                                            uint32_t *res, int index_in_w, float4 *out) {
+  const int total = (int)res[0];
+  uint32_t mm[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+  bool any = false;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    int lo = 0, hi = n_seg - 1;  // last segment with dst_begin <= i
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (dst_begin[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    float4 p = pts[src_begin[lo] + (i - dst_begin[lo])];
+    if (index_in_w == 1) p.w = __builtin_bit_cast(float, (uint32_t)i);
+    out[i] = p;
+    const uint32_t o[3] = {fm_ordered_u32(p.x), fm_ordered_u32(p.y), fm_ordered_u32(p.z)};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      mm[a] = max(mm[a], ~o[a]);
+      mm[3 + a] = max(mm[3 + a], o[a]);
+    }
+    any = true;
+  }
+  if (!__syncthreads_or(any)) return;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1)
+#pragma unroll
+    for (int a = 0; a < 6; ++a) mm[a] = max(mm[a], (uint32_t)__shfl_xor((int)mm[a], d, 64));
+  __shared__ uint32_t part[4][6];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 6; ++a) part[wave][a] = mm[a];
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {  // six atomics per workgroup (same-address atomics from a whole grid serialise at the memory side)
+    const int a = threadIdx.x;
+    atomicMax(&res[1 + a], max(max(part[0][a], part[1][a]), max(part[2][a], part[3][a])));
+  }
+}
+
 int bits_for(double cells) {
   int b = 1;
   while ((double)(1 << b) < cells) ++b;
@@ -545,6 +624,9 @@ struct lslam_fmap {
   Buf<int32_t> seg_begin[2];            // [begin (seg_pad words) | end (seg_pad words)] of every cube's points in pts[t]
   std::vector<int32_t> h_begin[2];      // ... on the host: seg_b / seg_e
   bool seg_current[2] = {false, false};
+  bool seg_dev_current[2] = {false, false};  // ... the device's table alone (what surround_to_map needs)
+  Buf<int32_t> d_valid;                 // the active cubes (fm->valid), uploaded when they change
+  Buf<uint32_t> sur_res;                // [2 types][8]: points gathered, bounding box (fm_gather_box_kernel)
   Buf<float4> in_raw, in_tf;
   Buf<int32_t> in_cube;
   // addFeatureCloud runs both feature types behind ONE wait: per-type staging of the new points (pinned: the upload needs no
@@ -555,7 +637,6 @@ struct lslam_fmap {
   Buf<uint8_t> d_touched_t[2];
   Pin<uint32_t> done;       // [2 types][2]
   Pin<uint8_t> h_touched;   // [2 types][ncube]
-  Buf<float> d_T;
   Buf<int32_t> d_remap;
   Buf<int32_t> g_src, g_dst;
   // surround gather of the two feature types behind ONE wait: per-type tables, their host copies kept alive here until the
@@ -586,6 +667,7 @@ struct lslam_fmap {
   Buf<uint8_t> d_touched;               // [ncube] set by the insert kernel
   Buf<int32_t> d_cells[2];
   Buf<lslam::TreeView> d_views[2];
+  bool cube_trees_used = false;               // lslam_fmap_to_cubemap has been called: addFeatureCloud keeps the cubes' marks
   int64_t trees_built = 0, trees_reused = 0;  // statistics of the last lslam_fmap_to_cubemap
   int64_t merged_rebuilds = 0, resorted_rebuilds = 0;  // addFeatureCloud rebuilds that merged the new points in / that had to sort everything after all
   int forest_attempt0 = 0;                     // node-slot guess the last forest build succeeded with (lslam_fmap_to_cubemap)
@@ -760,17 +842,26 @@ int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t
 // so one more bit is reserved (cube_bits(ncube + 1)).
 
 // wait = false: the caller waits for the stream itself before it reads h_begin / h_end (both feature types behind one wait)
-int refresh_segments(lslam_fmap *fm, int t, bool wait = true) {
-  if (fm->seg_current[t]) return LSLAM_OK;
+int refresh_segments_device(lslam_fmap *fm, int t) {
+  if (fm->seg_dev_current[t] || fm->seg_current[t]) return LSLAM_OK;
   hipStream_t s = fm->stream;
   // [begin | end] in ONE buffer of 2 x seg_pad words (seg_pad = ncube rounded up to 4 words: the fill is one aligned launch
-  // instead of an aligned part and a tail per array) and one copy back
+  // instead of an aligned part and a tail per array)
   const size_t pad = seg_pad(fm);
   FM_TRY(fm->seg_begin[t].reserve(2 * pad));
   FM_TRY(hipMemsetAsync(fm->seg_begin[t].p, 0, sizeof(int32_t) * 2 * pad, s));
   if (fm->n[t])
     hipLaunchKernelGGL(fm_segment_kernel, dim3(((int)fm->n[t] + 255) / 256), dim3(256), 0, s, fm->cube[t].p,
                        (int)fm->n[t], fm->seg_begin[t].p, fm->seg_begin[t].p + pad);
+  fm->seg_dev_current[t] = true;
+  return LSLAM_OK;
+}
+int refresh_segments(lslam_fmap *fm, int t, bool wait = true) {
+  if (fm->seg_current[t]) return LSLAM_OK;
+  int rc = refresh_segments_device(fm, t);
+  if (rc) return rc;
+  hipStream_t s = fm->stream;
+  const size_t pad = seg_pad(fm);
   fm->h_begin[t].resize(2 * pad);
   FM_TRY(hipMemcpyAsync(fm->h_begin[t].data(), fm->seg_begin[t].p, sizeof(int32_t) * 2 * pad, hipMemcpyDeviceToHost, s));
   if (wait) FM_TRY(hipStreamSynchronize(s));
@@ -815,6 +906,7 @@ void rebuild_commit(lslam_fmap *fm, int t, size_t n_new, size_t n_out, bool all_
   std::swap(fm->cube[t], fm->cube_alt[t]);
   fm->n[t] = n_out;
   fm->seg_current[t] = false;
+  fm->seg_dev_current[t] = false;
   if (all_dirty) fm->dirty[t].assign((size_t)fm->ncube, 1);  // shift / load: every cube's cloud may have moved
 }
 int rebuild(lslam_fmap *fm, int t, size_t n_new, bool allow_filter, const uint8_t *flags_override = nullptr) {
@@ -860,6 +952,9 @@ int upload_active(lslam_fmap *fm) {
   std::vector<uint8_t> h(fm->ncube, 0);
   for (int32_t c : fm->valid) h[c] = 1;
   FM_TRY(hipMemcpyAsync(fm->active.p, h.data(), fm->ncube, hipMemcpyHostToDevice, fm->stream));
+  FM_TRY(fm->d_valid.reserve(fm->valid.size() + 1));
+  if (!fm->valid.empty())
+    FM_TRY(hipMemcpyAsync(fm->d_valid.p, fm->valid.data(), fm->valid.size() * sizeof(int32_t), hipMemcpyHostToDevice, fm->stream));
   FM_TRY(hipStreamSynchronize(fm->stream));  // h is a local
   return LSLAM_OK;
 }
@@ -1036,7 +1131,6 @@ int lslam_fmap_create(lslam_ctx *ctx, int32_t w, int32_t h, int32_t d, lslam_fma
   fm->origin[2] = (int)std::round((d - 1) / 2.0);
   FM_TRY(fm->active.reserve(fm->ncube));
   FM_TRY(hipMemsetAsync(fm->active.p, 0, fm->ncube, fm->stream));
-  FM_TRY(fm->d_T.reserve(16));
   FM_TRY(hipStreamSynchronize(fm->stream));
   *out = fm;
   return LSLAM_OK;
@@ -1059,10 +1153,11 @@ void lslam_fmap_destroy(lslam_fmap *fm) {
   fm->spare.clear();
   fm->d_touched.release();
   if (lslam::ctx_alive(fm->ctx)) lslam::cubemap_drop_views(fm->ctx);  // the context may still point at this map's trees
-  fm->active.release(); fm->in_raw.release(); fm->in_tf.release(); fm->in_cube.release(); fm->d_T.release();
+  fm->active.release(); fm->in_raw.release(); fm->in_tf.release(); fm->in_cube.release();
   fm->d_remap.release(); fm->g_src.release(); fm->g_dst.release();
   for (int t = 0; t < 2; ++t) {
     fm->g_src_t[t].release(); fm->g_dst_t[t].release();
+    fm->d_valid.release(); fm->sur_res.release();
     fm->in_pin[t].release(); fm->in_raw_t[t].release(); fm->in_tf_t[t].release(); fm->in_cube_t[t].release();
     fm->d_touched_t[t].release();
   }
@@ -1161,9 +1256,12 @@ static int add_feature_cloud_impl(lslam_fmap *fm, const void *corner, size_t n_c
   // everything for both feature types is enqueued, then ONE wait: uploads come from pinned staging, the voxel extent of a map
   // cube is bounded (map_axis_bits), the rebuilds' results land in pinned slots
   FM_TRY(fm->done.reserve(8 + 16));
-  float *T_pin = reinterpret_cast<float *>(fm->done.p + 8);
-  std::memcpy(T_pin, T, 16 * sizeof(float));
-  FM_TRY(hipMemcpyAsync(fm->d_T.p, T_pin, 16 * sizeof(float), hipMemcpyHostToDevice, s));
+  Rigid12 Tm;
+  std::memcpy(Tm.m, T, 12 * sizeof(float));
+  // which cubes received points matters to the per-cube kd-trees only (lslam_fmap_to_cubemap builds a cube's tree again when
+  // its cloud changed): until the first such call every cube counts as changed anyway, and the marks -- a fill, a copy back
+  // and a pass over the cubes per feature type -- are not kept
+  const bool track = fm->cube_trees_used;
   const void *src[2] = {corner, surf};
   const size_t cnt[2] = {n_corner, n_surf};
   FM_TRY(fm->h_touched.reserve(2 * (size_t)fm->ncube));
@@ -1174,12 +1272,14 @@ static int add_feature_cloud_impl(lslam_fmap *fm, const void *corner, size_t n_c
       if (rc) return rc;
       FM_TRY(fm->in_tf_t[t].reserve(n));
       FM_TRY(fm->in_cube_t[t].reserve(n));
-      FM_TRY(fm->d_touched_t[t].reserve(((size_t)fm->ncube + 15) & ~(size_t)15));
       KeyParams kp = key_params(fm, fm->leaf[t]);
-      FM_TRY(hipMemsetAsync(fm->d_touched_t[t].p, 0, ((size_t)fm->ncube + 15) & ~(size_t)15, s));  // (a whole number of 16-byte words: one fill launch, no tail)
+      if (track) {
+        FM_TRY(fm->d_touched_t[t].reserve(((size_t)fm->ncube + 15) & ~(size_t)15));
+        FM_TRY(hipMemsetAsync(fm->d_touched_t[t].p, 0, ((size_t)fm->ncube + 15) & ~(size_t)15, s));  // (a whole number of 16-byte words: one fill launch, no tail)
+      }
       hipLaunchKernelGGL(fm_transform_kernel, dim3(((int)n + 255) / 256), dim3(256), 0, s, fm->in_raw_t[t].p, (int)n,
-                         fm->d_T.p, kp, fm->in_tf_t[t].p, fm->in_cube_t[t].p, fm->d_touched_t[t].p);
-      FM_TRY(hipMemcpyAsync(fm->h_touched.p + (size_t)t * fm->ncube, fm->d_touched_t[t].p, fm->ncube, hipMemcpyDeviceToHost, s));
+                         Tm, kp, fm->in_tf_t[t].p, fm->in_cube_t[t].p, track ? fm->d_touched_t[t].p : (uint8_t *)nullptr);
+      if (track) FM_TRY(hipMemcpyAsync(fm->h_touched.p + (size_t)t * fm->ncube, fm->d_touched_t[t].p, fm->ncube, hipMemcpyDeviceToHost, s));
     }
     rc = rebuild_begin(fm, t, n, true, nullptr, fm->done.p + 4 * t, fm->in_tf_t[t].p, fm->in_cube_t[t].p, nullptr, true);
     if (rc) return rc;
@@ -1200,7 +1300,7 @@ static int add_feature_cloud_impl(lslam_fmap *fm, const void *corner, size_t n_c
       rebuild_commit(fm, t, n, fm->done.p[4 * t], n == 0);
       if (n && fm->n[t]) fm->merged_rebuilds++;
     }
-    if (n) {
+    if (n && track) {
       fm->dirty[t].resize((size_t)fm->ncube, 1);
       const uint8_t *ht = fm->h_touched.p + (size_t)t * fm->ncube;
       for (int c = 0; c < fm->ncube; ++c) fm->dirty[t][(size_t)c] |= ht[(size_t)c];
@@ -1247,21 +1347,48 @@ int lslam_fmap_get_surround(lslam_fmap *fm, float *corner_xyzi, size_t cap_corne
 int lslam_fmap_surround_to_map(lslam_fmap *fm) {
   int rc = check_fm(fm);
   if (rc) return rc;
+  hipStream_t s = fm->stream;
+  const int n_valid = (int)fm->valid.size();
   size_t n[2] = {0, 0};
-  // both types' segment tables behind one wait; the gathers are not waited for at all (the map set is stream-ordered behind them)
+  float lo[2][3], hi[2][3];
+  FM_TRY(fm->sur_res.reserve(16));
+  FM_TRY(fm->done.reserve(8 + 16));
+  uint32_t *h_res = fm->done.p + 8;  // pinned: [2 types][8]
+  for (int k = 0; k < 16; ++k) h_res[k] = 0u;
+  bool any = false;
   for (int t = 0; t < 2; ++t) {
-    rc = refresh_segments(fm, t, false);
+    if (!fm->n[t] || !n_valid) continue;
+    rc = refresh_segments_device(fm, t);
     if (rc) return rc;
+    FM_TRY(fm->g_src_t[t].reserve((size_t)n_valid));
+    FM_TRY(fm->g_dst_t[t].reserve((size_t)n_valid));
+    FM_TRY(fm->sur[t].reserve(fm->n[t]));  // (the surround is at most the map)
+    hipLaunchKernelGGL(fm_surround_plan_kernel, dim3(1), dim3(256), 0, s, (const int32_t *)fm->d_valid.p, n_valid,
+                       (const int32_t *)fm->seg_begin[t].p, (int)seg_pad(fm), fm->g_src_t[t].p, fm->g_dst_t[t].p, fm->sur_res.p + 8 * t);
+    const unsigned blocks = (unsigned)std::min<size_t>(512, (fm->n[t] + 255) / 256);
+    hipLaunchKernelGGL(fm_gather_box_kernel, dim3(blocks), dim3(256), 0, s, (const float4 *)fm->pts[t].p, (const int32_t *)fm->g_src_t[t].p,
+                       (const int32_t *)fm->g_dst_t[t].p, n_valid, fm->sur_res.p + 8 * t, 1, fm->sur[t].p);
+    FM_TRY(hipMemcpyAsync(h_res + 8 * t, fm->sur_res.p + 8 * t, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    any = true;
   }
-  FM_TRY(hipStreamSynchronize(fm->stream));
+  if (any) FM_TRY(hipStreamSynchronize(s));  // the one wait: both types' totals and boxes
   for (int t = 0; t < 2; ++t) {
-    rc = gather_surround(fm, t, 1, &n[t], 1, nullptr, nullptr, true);
-    if (rc) return rc;
+    n[t] = h_res[8 * t];
+    for (int a = 0; a < 3; ++a) {
+      auto back = [](uint32_t o) {  // fm_ordered_u32's inverse
+        const uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+        float f;
+        std::memcpy(&f, &u, 4);
+        return f;
+      };
+      lo[t][a] = back(~h_res[8 * t + 1 + a]);
+      hi[t][a] = back(h_res[8 * t + 4 + a]);
+    }
   }
   if (n[0] == 0 && n[1] == 0) return lslam_map_set(fm->ctx, nullptr, 0, nullptr, 0, 16);
   FM_TRY(fm->sur[0].reserve(1));
   FM_TRY(fm->sur[1].reserve(1));
-  return lslam::map_set_device(fm->ctx, fm->sur[0].p, n[0], fm->sur[1].p, n[1]);
+  return lslam::map_set_device(fm->ctx, fm->sur[0].p, n[0], fm->sur[1].p, n[1], lo, hi);
 }
 
 static void drop_cube_trees(lslam_fmap *fm, int t) {
@@ -1292,6 +1419,7 @@ int lslam_fmap_to_cubemap(lslam_fmap *fm) {
   size_t n_pts[2] = {0, 0};
   int depth[2] = {0, 0};
   fm->trees_built = fm->trees_reused = 0;
+  fm->cube_trees_used = true;  // (from now on addFeatureCloud keeps the cubes' marks; until now every cube counts as changed)
   const bool timing = lslam::env_once().fmap_timing;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {

@@ -361,7 +361,10 @@ hipError_t comm_allreduce_f64(lslam_comm *comm, double *buf, size_t count, hipSt
 hipError_t comm_allgatherv_f64(lslam_comm *comm, int n_lists, double *const *bufs, const int64_t *const *offs, hipStream_t s);
 int comm_world(const lslam_comm *comm);
 int comm_rank(const lslam_comm *comm);
-int map_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t n_corner, const float4 *d_surf, size_t n_surf);
+// box_lo / box_hi (optional): the two clouds' bounding boxes, if the caller has them (the deferred-tree map set then needs no
+// pass over the points and no wait of its own)
+int map_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t n_corner, const float4 *d_surf, size_t n_surf,
+                   const float (*box_lo)[3] = nullptr, const float (*box_hi)[3] = nullptr);
 int cubemap_set_device(lslam_ctx *ctx, const float4 *d_corner, size_t nc, const std::vector<int32_t> &roots_c,
                        const std::vector<int32_t> &cells_c, const float4 *d_surf, size_t ns,
                        const std::vector<int32_t> &roots_s, const std::vector<int32_t> &cells_s, float cube_size,

@@ -8,7 +8,7 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-H="$root/bench.py --headline-only --steps 2 --warmup 1 --search $search --map-cache /tmp/lslam_${tag}_map $@"
+H="$root/bench.py --headline-only --steps 6 --warmup 1 --search $search --map-cache /tmp/lslam_${tag}_map $@"
 timeout 600 python3 $H > $out/${tag}_${search}_line.json 2> $out/${tag}_${search}_line.err
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_${search}_hs -o s -- python3 $H > $out/${tag}_${search}_hs.log 2>&1
 cp $out/${tag}_${search}_hs/s_kernel_stats.csv $out/${tag}_${search}_kernel_stats.csv

@@ -18,8 +18,8 @@ if [ -n "$PG_PMC" ]; then
     i=$((i+1))
     ITERS=1000 timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/${tag}_pgpmc/p$i -o p -- python3 $root/tools/bench_posegraph.py > $out/${tag}_pgpmc_p$i.log 2>&1
   done
-  python3 $root/tools/summarize_pmc.py pg_pcg_persistent_kernel $out/${tag}_pg_pmc.csv $out/${tag}_pgpmc/p1 $out/${tag}_pgpmc/p2 $out/${tag}_pgpmc/p3 $out/${tag}_pgpmc/p4 | sed 's/bench.py --headline-only --steps 2 --warmup 1/tools\/bench_posegraph.py/' > /dev/null
-  sed -i 's/python3 bench.py --headline-only --steps 2 --warmup 1/python3 tools\/bench_posegraph.py (ITERS=1000)/' $out/${tag}_pg_pmc.csv
+  python3 $root/tools/summarize_pmc.py pg_pcg_persistent_kernel $out/${tag}_pg_pmc.csv $out/${tag}_pgpmc/p1 $out/${tag}_pgpmc/p2 $out/${tag}_pgpmc/p3 $out/${tag}_pgpmc/p4 | sed 's/bench.py --headline-only --steps 6 --warmup 1/tools\/bench_posegraph.py/' > /dev/null
+  sed -i 's/python3 bench.py --headline-only --steps 6 --warmup 1/python3 tools\/bench_posegraph.py (ITERS=1000)/' $out/${tag}_pg_pmc.csv
   rm -rf $out/${tag}_pgpmc
   cat $out/${tag}_pg_pmc.csv
 fi

@@ -101,7 +101,7 @@ def generated_tables(rnd, d):
         % (rnd, g["SQ_INSTS_VALU"], lanes(g), ms(g), hbm(g) / 1e9, rnd),
         "| `r%02d_pmc_sweep_by_kernel.csv` | the first four passes per kernel NAME: `sweep_grid_kernel<256>` (%.1f lanes, %.2f ms), `sweep_queue_kernel` (%.1f lanes, %.2f ms: the sparse subset's tree searches), the planner | same (`tools/summarize_pmc_by_name.py`) |"
         % (rnd, lanes(k1), ms(k1), lanes(k2), ms(k2)),
-        "| `r%02d_headline.json`, `r%02d_headline_kernel_stats.csv`, `r%02d_profile_check.txt` | `bench.py --headline-only --steps 2 --warmup 1` (%.3g point-residuals/s, %.3f ms per sweep by HIP events) and `rocprofv3 --kernel-trace --stats` of the same command; the check `collect_profiles.sh` ends with (`tools/check_profile_consistency.py`): %s | same |"
+        "| `r%02d_headline.json`, `r%02d_headline_kernel_stats.csv`, `r%02d_profile_check.txt` | `bench.py --headline-only --steps 6 --warmup 1` (%.3g point-residuals/s, %.3f ms per sweep by HIP events) and `rocprofv3 --kernel-trace --stats` of the same command; the check `collect_profiles.sh` ends with (`tools/check_profile_consistency.py`): %s | same |"
         % (rnd, rnd, rnd, hl.get("value", float("nan")), pick(hl, "roofline", "avg_kernel_ms"), chk or "(not collected)"),
         "| `r%02d_lane_headline.json`, `r%02d_lane_headline_kernel_stats.csv`, `r%02d_lane_pmc_sweep.csv` | the same command with `--search lane` (round 3's kernel + certificate sweep, this round's build): `SQ_INSTS_VALU` %.3g per sweep, %.1f lanes, %.2f ms | same |"
         % (rnd, rnd, rnd, lane.get("SQ_INSTS_VALU", float("nan")), lanes(lane), ms(lane)),

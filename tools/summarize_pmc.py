@@ -36,7 +36,7 @@ def main():
             for c in sorted(acc):
                 lines.append((os.path.basename(os.path.normpath(d)), c, len(acc[c]), (sum(acc[c]) + extra.get(c, 0.0)) / len(acc[c]), gmax))
     with open(out, "w") as fo:
-        fo.write("# rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python3 bench.py --headline-only --steps 2 --warmup 1 "
+        fo.write("# rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python3 bench.py --headline-only --steps 6 --warmup 1 "
                  "(one pass per counter set)\n")
         fo.write("# kernel: %s ; mean over the launches with the largest grid (for the bench's sweep: all of them); FETCH_SIZE/WRITE_SIZE in KiB as reported\n" % kname)
         fo.write("pass,counter,launches,mean_per_launch,grid_size\n")

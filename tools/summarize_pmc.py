@@ -2,9 +2,10 @@
 """Summarise rocprofv3 --pmc passes: mean counter value per launch of one kernel.
 
 usage: summarize_pmc.py <kernel-substring>[,<companion-substring>...] <out.csv> <pass_dir> [<pass_dir> ...]
-Launches of the kernel with the largest grid are averaged.  For bench.py's sweep that is EVERY launch of the
-profiled run (a converged scan's blocks exit early, the grid does not shrink), so the figures are the mean over all
-launches -- the same population as roofline.avg_kernel_ms and rocprofv3's per-kernel average.  Companion kernels (the second
+EVERY launch of the kernel in the profiled run is averaged -- the same population as roofline.avg_kernel_ms and rocprofv3's
+per-kernel average.  (Until round 5 only the launches with the largest grid were: every sweep of the bench launched the full
+grid.  Since a batch's later sweeps are launched over the running scans' workgroups only, that filter kept the first sweep
+of every step and added every sweep's second pass to it.)  Companion kernels (the second
 pass of the certificate sweep: sweep_queue_kernel, cert_plan_kernel) have their counters ADDED before the division: the mean is
 per sweep = per launch of the first kernel, the unit bench.py times with its HIP events.  FETCH_SIZE/WRITE_SIZE stay in KiB
 as reported; bench.py applies the gfx950 correction (2 x FETCH_SIZE) from MI355X_MICROARCH.md."""
@@ -22,7 +23,6 @@ def main():
             if not rows:
                 continue
             gmax = max(int(r["Grid_Size"]) for r in rows)
-            rows = [r for r in rows if int(r["Grid_Size"]) == gmax]
             kname = " + ".join(sorted({r["Kernel_Name"].split("(")[0] for r in rows}))
             acc = collections.defaultdict(list)
             for r in rows:
@@ -38,7 +38,7 @@ def main():
     with open(out, "w") as fo:
         fo.write("# rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python3 bench.py --headline-only --steps 6 --warmup 1 "
                  "(one pass per counter set)\n")
-        fo.write("# kernel: %s ; mean over the launches with the largest grid (for the bench's sweep: all of them); FETCH_SIZE/WRITE_SIZE in KiB as reported\n" % kname)
+        fo.write("# kernel: %s ; mean over all launches of the kernel in the run; FETCH_SIZE/WRITE_SIZE in KiB as reported\n" % kname)
         fo.write("pass,counter,launches,mean_per_launch,grid_size\n")
         for l in lines:
             fo.write("%s,%s,%d,%g,%d\n" % l)

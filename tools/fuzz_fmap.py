@@ -48,6 +48,29 @@ def same(fm, ofm, what):
     return None
 
 
+def resident_map_is_the_surround(pkg, oracle, ctx, fm, ofm, rng, what):
+    """surround_to_map (gathered on the device: lslam_fmap.hip, round 5) against the oracle's surround: the resident map is
+    searched at a sample of the surround's own points and at jittered ones -- nanoflann's answer on the oracle's clouds, index
+    for index (the indices are positions in the surround)."""
+    from oracle_lib import OracleTree
+    oc, os_ = ofm.get_surround_feature()
+    fm.surround_to_map()
+    for which, cloud_ in ((0, oc), (1, os_)):
+        if len(cloud_) < 5:
+            continue
+        pick = rng.integers(0, len(cloud_), min(200, len(cloud_)))
+        q = cloud_[pick, :3].copy()
+        q[::2] += rng.normal(0, 0.05, q[::2].shape).astype(np.float32)
+        try:
+            idx, d2 = ctx.knn5(which, q)
+        except pkg.LslamError as e:
+            return "%s: knn5 on the resident map failed: %s" % (what, e)
+        ri, rd = OracleTree(oracle, cloud_).knn(q)
+        if not np.array_equal(idx, ri) or not np.array_equal(bits(d2), bits(rd)):
+            return "%s: the resident map (type %d, %d points) is not the surround" % (what, which, len(cloud_))
+    return None
+
+
 def one(pkg, oracle, ctx, seed):
     rng = np.random.default_rng(1000 + seed)
     W, H, D = int(rng.integers(5, 14)), int(rng.integers(5, 14)), int(rng.integers(3, 9))
@@ -83,6 +106,10 @@ def one(pkg, oracle, ctx, seed):
             e = same(fm, ofm, "seed %d step %d insert %d (%d + %d points)" % (seed, step, rep, nc, n - nc))
             if e:
                 return e
+            if rng.random() < 0.3:
+                e = resident_map_is_the_surround(pkg, oracle, ctx, fm, ofm, rng, "seed %d step %d insert %d" % (seed, step, rep))
+                if e:
+                    return e
             if n and rng.random() < 0.5:  # the stand-alone filter on the same cloud
                 leaf = float(rng.choice([0.2, 0.5, 1.0, 2.0]))
                 g = pkg.voxel_grid(ctx, pts, leaf)
@@ -102,6 +129,7 @@ def main():
     from oracle_lib import Oracle
     oracle = Oracle()
     ctx = pkg.Context(0)
+    ctx.defer_trees(True)  # surround_to_map as the mapping node uses it: cell grids from the gather's own boxes, trees on demand
     merged = resorted = 0
     for seed in range(n):
         r = one(pkg, oracle, ctx, seed)

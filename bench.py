@@ -899,7 +899,8 @@ def pmc_counters(avg_sweep_ms):
         c["ta_busy"] = v["TA_BUSY_avr"] / cyc  # texture-address units: vector-memory instruction issue
     return {"traffic": traffic,
             "traffic_source": "committed rocprofv3 --pmc passes of `bench.py --headline-only` (tools/collect_profiles.sh -> %s), mean per "
-                              "launch over all launches of the kernel (every launch has the full grid); not measured in this run" % prof,
+                              "sweep over all sweeps of the profiled run (the same population as avg_kernel_ms: a batch's later sweeps launch the "
+                              "running scans' workgroups only); not measured in this run" % prof,
             "valu_issue": valu_issue, "measured_hbm": measured_hbm, "counters": c}
 
 

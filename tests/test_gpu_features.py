@@ -80,6 +80,22 @@ def test_extract_features_region_counts_and_filter_sizes(pkg, ctx, oracle, synth
              oracle.extract_features(cloud, ranges, q), (nf, cr, leaf))
 
 
+def test_extract_features_more_rings_than_the_device_has_cus_for(pkg, ctx, oracle, synth):
+    """Round 5: pointClassify runs on helper workgroups (three per ring, dispatched ahead of the rings' own workgroups, which
+    pick the verdicts up or classify for themselves).  192 rings x 4 workgroups of 1 024 threads are three times what the
+    device holds at once: rings whose helpers are long done, rings whose helpers run beside them, the same lists."""
+    world = synth.World(half_extent=120.0, wall_half=90.0)
+    c, s, gt, cloud, ranges = synth.make_scan(world, 64, 1800, seed=21, full=True)
+    thirds = []
+    for a, b in ranges:
+        n = int(b) - int(a) + 1
+        cuts = [int(a), int(a) + n // 3, int(a) + 2 * n // 3, int(b) + 1]
+        thirds += [[cuts[k], cuts[k + 1] - 1] for k in range(3)]
+    thirds = np.array(thirds, np.int32)
+    assert len(thirds) == 192
+    _compare(pkg.scan_registration.extract_features(ctx, cloud, thirds, taps=True), oracle.extract_features(cloud, thirds), "192 rings")
+
+
 def test_extract_features_bounds_its_region_count(pkg, ctx, synth):
     world = synth.World(half_extent=60.0, wall_half=55.0)
     c, s, gt, cloud, ranges = synth.make_scan(world, 16, 900, full=True)

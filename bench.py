@@ -512,7 +512,8 @@ def compact_line(out):
                      "launches_timed": roof.get("launches_timed"), "points_per_launch": roof.get("points_per_launch"),
                      "alg_flops_per_point": roof.get("alg_flops_per_point"),
                      "nominal_hbm_frac_at_1700B_per_point": _pick(roof, "nominal_hbm", "frac"),
-                     "measured_hbm_frac": _pick(roof, "measured_hbm", "frac"), "valu_issue_frac": _pick(roof, "valu_issue", "frac_by_instruction_count"),
+                     "measured_hbm_frac": _pick(roof, "measured_hbm", "frac"), "valu_issue_frac": _pick(roof, "valu_issue", "frac"),
+                     "valu_by_instruction_count_raw": _pick(roof, "valu_issue", "frac_by_instruction_count"),
                      "valu_busy_raw": _pick(roof, "valu_issue", "frac_raw"),
                      "valu_insts_per_launch": _pick(roof, "valu_issue", "valu_wave_instructions_per_launch"),
                      "lanes_active": _pick(roof, "counters", "lanes_active"), "l2_hit_rate": _pick(roof, "counters", "l2_hit_rate"),
@@ -887,9 +888,12 @@ def pmc_counters(avg_sweep_ms):
                       "frac": min(1.0, raw), "frac_raw": raw, "frac_by_instruction_count": by_count,
                       "lanes_active_of_64": c.get("lanes_active"),
                       "valu_wave_instructions_per_launch": v.get("SQ_INSTS_VALU"),
-                      "note": "frac_raw > 1: per-wave busy quad-cycles overlap between the waves of a SIMD (multi-pass instructions); "
-                              "frac_by_instruction_count = SQ_INSTS_VALU x 4 cycles / (1 024 SIMDs x GRBM_GUI_ACTIVE / 8) counts every "
-                              "vector instruction as one four-cycle issue",
+                      "note": "frac = min(1, frac_raw).  frac_raw > 1: per-wave busy quad-cycles overlap between the waves of a SIMD "
+                              "(multi-pass instructions); frac_by_instruction_count = SQ_INSTS_VALU x 4 cycles / (1 024 SIMDs x "
+                              "GRBM_GUI_ACTIVE / 8) counts every vector instruction as one four-cycle issue and exceeds 1 as well once "
+                              "the launches hold no idle workgroups (round 5: later sweeps launch the running scans' workgroups only): "
+                              "an instruction whose upper or lower 32 lanes are all idle issues in two cycles.  Both say the same: the "
+                              "vector pipes do not idle; neither is a utilisation one could raise",
                       "source": "SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), %s" % prof}
     for k in ("TA_BUSY_avr", "TCP_TOTAL_CACHE_ACCESSES_sum", "TA_FLAT_READ_WAVEFRONTS_sum", "TCP_TCC_READ_REQ_sum", "GRBM_GUI_ACTIVE",
               "TA_TA_BUSY_sum", "SQ_INSTS_VALU_MFMA_F32", "SQ_VALU_MFMA_BUSY_CYCLES"):

@@ -537,8 +537,9 @@ __global__ void fx_compact_kernel(const float4 *pts, const int32_t *stage, const
 // Until round 5 the host fetched the rings' counts, made the offsets, launched four compactions and ran the per-ring
 // VoxelGrid of the less-flat points (:398-407) through the general segment filter of lslam_fmap.hip -- a 64-bit merge sort of
 // all rings' points at once, sixteen launches and three waits for what is 64 independent problems of <= 2 560 points.  Now:
-//   fx_lists_kernel        one workgroup per small list (sharp, less sharp, flat): the rings' offsets by a scan in LDS, the
-//                          points gathered in ring order STRAIGHT INTO PINNED HOST MEMORY, the total next to them
+//   fx_lists_block         one workgroup per small list (sharp, less sharp, flat): the rings' offsets by a scan in LDS, the
+//                          points gathered in ring order STRAIGHT INTO PINNED HOST MEMORY, the total next to them (the last
+//                          three workgroups of the next kernel's launch)
 //   fx_ring_voxel_kernel   one workgroup per ring: pcl::VoxelGrid::applyFilter on the ring's less-flat list entirely in LDS --
 //                          bounding box, the "leaf too small" guard, voxel index ijk0 + ijk1 * div0 + ijk2 * div0 * div1,
 //                          a bitonic sort of (index, position in the list), heads, their scan, centroids summed in list order
@@ -582,10 +583,10 @@ __device__ int fx_block_scan(int v, int *part, int *total) {
   return before + incl - v;
 }
 
-__global__ __launch_bounds__(FX_BLOCK) void fx_lists_kernel(FxOutArgs a) {
+__device__ void fx_lists_block(const FxOutArgs &a, const int k) {
   __shared__ int part[FX_BLOCK];
   __shared__ int32_t off[4096 + 1];
-  const int k = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int per = (a.n_scans + FX_BLOCK - 1) / FX_BLOCK;
   const int r0 = min(a.n_scans, tid * per), r1 = min(a.n_scans, r0 + per);
   int sum = 0;
@@ -620,10 +621,15 @@ __device__ unsigned long long vx_clk[8];
 #else
 #define VX_T(i)
 #endif
+// one launch: workgroups [0, n_scans) filter a ring each, the three after them gather the small lists (fx_lists_block)
 __global__ __launch_bounds__(FX_BLOCK) void fx_ring_voxel_kernel(FxOutArgs a) {
 #ifdef LSLAM_FX_CLOCKS
   unsigned long long vx_last = wall_clock64();
 #endif
+  if ((int)blockIdx.x >= a.n_scans) {  // block-uniform
+    fx_lists_block(a, (int)blockIdx.x - a.n_scans);
+    return;
+  }
   __shared__ float4 sp[MAXR];
   __shared__ unsigned long long key[VX_PAD + VX_PAD / 8];  // (fx_at)
   __shared__ float wred[6][FX_BLOCK / 64];
@@ -984,7 +990,7 @@ static int extract_features_impl(lslam_ctx *ctx, const void *cloud, size_t n_poi
   a.ready = d_ready;
   if (a.helpers > 0) FX_TRY2(hipMemsetAsync(d_ready, 0, n_scans * 4, s));
   hipLaunchKernelGGL(fx_ring_kernel, dim3((unsigned)n_scans * (unsigned)(1 + a.helpers)), dim3(FX_BLOCK), 0, s, a);
-  // the four lists, on the device to the end (see fx_lists_kernel): nothing waits until everything is in pinned memory
+  // the four lists, on the device to the end (see fx_lists_block): nothing waits until everything is in pinned memory
   uint32_t *hdr = reinterpret_cast<uint32_t *>(cache.pout);
   for (int k = 0; k < 8; ++k) hdr[k] = 0u;
   FxOutArgs oa{};
@@ -999,8 +1005,7 @@ static int extract_features_impl(lslam_ctx *ctx, const void *cloud, size_t n_poi
   oa.ring_out = d_ring_out;
   oa.host = cache.pout;
   oa.hdr = hdr;
-  hipLaunchKernelGGL(fx_lists_kernel, dim3(3), dim3(FX_BLOCK), 0, s, oa);
-  hipLaunchKernelGGL(fx_ring_voxel_kernel, dim3((unsigned)n_scans), dim3(FX_BLOCK), 0, s, oa);
+  hipLaunchKernelGGL(fx_ring_voxel_kernel, dim3((unsigned)n_scans + 3u), dim3(FX_BLOCK), 0, s, oa);
   hipLaunchKernelGGL(fx_lessflat_out_kernel, dim3((unsigned)n_scans), dim3(FX_BLOCK), 0, s, oa);
   FX_TRY2(hipGetLastError());
   if (curvature_out) FX_TRY2(hipMemcpyAsync(curvature_out, d_curv, n_points * 4, hipMemcpyDeviceToHost, s));

@@ -79,7 +79,7 @@ def generated_tables(rnd, d):
         "|---|---|---|",
         "| point-residuals/s, whole step (`r%02d_bench_report.json`) | %.3g (%.3g with every search executed) | **%.3g** |"
         % (rnd, pick(cs, "kd_tree_walk", "value"), pick(cs, "kd_tree_walk", "value_searching_every_point"), d["value"]),
-        "| ... of the profiled command (`r%02d_headline.json`, `r%02d_lane_headline.json`: 2 steps) | %.3g | %.3g |" % (rnd, rnd, ll.get("value", float("nan")), hl.get("value", float("nan"))),
+        "| ... of the profiled command (`r%02d_headline.json`, `r%02d_lane_headline.json`: %d steps) | %.3g | %.3g |" % (rnd, rnd, int(hl.get("steps", 0)), ll.get("value", float("nan")), hl.get("value", float("nan"))),
         "| `SQ_INSTS_VALU` | %.3g | **%.3g** (%.3g pass 1 + %.3g pass 2) |" % (lane.get("SQ_INSTS_VALU", float("nan")), g["SQ_INSTS_VALU"], k1.get("SQ_INSTS_VALU", float("nan")), k2.get("SQ_INSTS_VALU", float("nan"))),
         "| lanes active (`SQ_THREAD_CYCLES_VALU` / `SQ_INSTS_VALU`) | %.1f | **%.1f** (%.1f in pass 1, %.1f in pass 2) |" % (lanes(lane), lanes(g), lanes(k1), lanes(k2)),
         "| engine time (`GRBM_GUI_ACTIVE` / 8 / 2.4 GHz) | %.2f ms | **%.2f ms** (%.2f + %.2f) |" % (ms(lane), ms(g), ms(k1), ms(k2)),

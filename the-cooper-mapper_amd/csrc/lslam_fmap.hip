@@ -1368,6 +1368,7 @@ int lslam_fmap_surround_to_map(lslam_fmap *fm) {
     const unsigned blocks = (unsigned)std::min<size_t>(512, (fm->n[t] + 255) / 256);
     hipLaunchKernelGGL(fm_gather_box_kernel, dim3(blocks), dim3(256), 0, s, (const float4 *)fm->pts[t].p, (const int32_t *)fm->g_src_t[t].p,
                        (const int32_t *)fm->g_dst_t[t].p, n_valid, fm->sur_res.p + 8 * t, 1, fm->sur[t].p);
+    FM_TRY(hipGetLastError());
     FM_TRY(hipMemcpyAsync(h_res + 8 * t, fm->sur_res.p + 8 * t, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     any = true;
   }

@@ -632,8 +632,7 @@ struct lslam_fmap {
   // addFeatureCloud runs both feature types behind ONE wait: per-type staging of the new points (pinned: the upload needs no
   // wait to keep its source alive), per-type transformed points, and the rebuilds' results {points out, error} in pinned slots
   Pin<float4> in_pin[2];
-  Buf<float4> in_raw_t[2], in_tf_t[2];
-  Buf<int32_t> in_cube_t[2];
+  Buf<float4> in_raw_t[2];
   Buf<uint8_t> d_touched_t[2];
   Pin<uint32_t> done;       // [2 types][2]
   Pin<uint8_t> h_touched;   // [2 types][ncube]
@@ -886,9 +885,11 @@ int rebuild_begin(lslam_fmap *fm, int t, size_t n_new, bool allow_filter, const 
   if (n_total == 0) return LSLAM_OK;
   FM_TRY(fm->pts[t].grow(n_total, n_old, s));
   FM_TRY(fm->cube[t].grow(n_total, n_old, s));
-  if (n_new) {
-    FM_TRY(hipMemcpyAsync(fm->pts[t].p + n_old, in_tf ? in_tf : fm->in_tf.p, n_new * sizeof(float4), hipMemcpyDeviceToDevice, s));
-    FM_TRY(hipMemcpyAsync(fm->cube[t].p + n_old, in_cube ? in_cube : fm->in_cube.p, n_new * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  if (n_new) {  // (addFeatureCloud's transform writes the new points where they go: nothing to copy then)
+    const float4 *src_p = in_tf ? in_tf : fm->in_tf.p;
+    const int32_t *src_c = in_cube ? in_cube : fm->in_cube.p;
+    if (src_p != fm->pts[t].p + n_old) FM_TRY(hipMemcpyAsync(fm->pts[t].p + n_old, src_p, n_new * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    if (src_c != fm->cube[t].p + n_old) FM_TRY(hipMemcpyAsync(fm->cube[t].p + n_old, src_c, n_new * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
   }
   FM_TRY(fm->pts_alt[t].reserve(n_total));
   FM_TRY(fm->cube_alt[t].reserve(n_total));
@@ -1158,7 +1159,7 @@ void lslam_fmap_destroy(lslam_fmap *fm) {
   for (int t = 0; t < 2; ++t) {
     fm->g_src_t[t].release(); fm->g_dst_t[t].release();
     fm->d_valid.release(); fm->sur_res.release();
-    fm->in_pin[t].release(); fm->in_raw_t[t].release(); fm->in_tf_t[t].release(); fm->in_cube_t[t].release();
+    fm->in_pin[t].release(); fm->in_raw_t[t].release();
     fm->d_touched_t[t].release();
   }
   fm->done.release(); fm->h_touched.release();
@@ -1270,18 +1271,20 @@ static int add_feature_cloud_impl(lslam_fmap *fm, const void *corner, size_t n_c
     if (n) {
       rc = pack_input(s, fm->in_pin[t], fm->in_raw_t[t], src[t], n, stride_bytes);
       if (rc) return rc;
-      FM_TRY(fm->in_tf_t[t].reserve(n));
-      FM_TRY(fm->in_cube_t[t].reserve(n));
+      // the transformed points go straight behind the type's current points, where the rebuild wants them (was: a staging
+      // array of their own and two device-to-device copies per type)
+      FM_TRY(fm->pts[t].grow(fm->n[t] + n, fm->n[t], s));
+      FM_TRY(fm->cube[t].grow(fm->n[t] + n, fm->n[t], s));
       KeyParams kp = key_params(fm, fm->leaf[t]);
       if (track) {
         FM_TRY(fm->d_touched_t[t].reserve(((size_t)fm->ncube + 15) & ~(size_t)15));
         FM_TRY(hipMemsetAsync(fm->d_touched_t[t].p, 0, ((size_t)fm->ncube + 15) & ~(size_t)15, s));  // (a whole number of 16-byte words: one fill launch, no tail)
       }
       hipLaunchKernelGGL(fm_transform_kernel, dim3(((int)n + 255) / 256), dim3(256), 0, s, fm->in_raw_t[t].p, (int)n,
-                         Tm, kp, fm->in_tf_t[t].p, fm->in_cube_t[t].p, track ? fm->d_touched_t[t].p : (uint8_t *)nullptr);
+                         Tm, kp, fm->pts[t].p + fm->n[t], fm->cube[t].p + fm->n[t], track ? fm->d_touched_t[t].p : (uint8_t *)nullptr);
       if (track) FM_TRY(hipMemcpyAsync(fm->h_touched.p + (size_t)t * fm->ncube, fm->d_touched_t[t].p, fm->ncube, hipMemcpyDeviceToHost, s));
     }
-    rc = rebuild_begin(fm, t, n, true, nullptr, fm->done.p + 4 * t, fm->in_tf_t[t].p, fm->in_cube_t[t].p, nullptr, true);
+    rc = rebuild_begin(fm, t, n, true, nullptr, fm->done.p + 4 * t, fm->pts[t].p + fm->n[t], fm->cube[t].p + fm->n[t], nullptr, true);
     if (rc) return rc;
   }
   FM_TRY(hipStreamSynchronize(s));
@@ -1292,7 +1295,7 @@ static int add_feature_cloud_impl(lslam_fmap *fm, const void *corner, size_t n_c
       // in key order after all (a cube that has just become active): once more, sorting everything and waiting for the
       // measured extents -- the inputs are untouched, the appended points are written again where they are
       size_t n_out = 0;
-      rc = rebuild_begin(fm, t, n, true, nullptr, nullptr, fm->in_tf_t[t].p, fm->in_cube_t[t].p, &n_out);
+      rc = rebuild_begin(fm, t, n, true, nullptr, nullptr, fm->pts[t].p + fm->n[t], fm->cube[t].p + fm->n[t], &n_out);
       if (rc) return rc;
       rebuild_commit(fm, t, n, n_out, n == 0);
       fm->resorted_rebuilds++;
@@ -1357,7 +1360,10 @@ int lslam_fmap_surround_to_map(lslam_fmap *fm) {
   for (int k = 0; k < 16; ++k) h_res[k] = 0u;
   bool any = false;
   for (int t = 0; t < 2; ++t) {
-    if (!fm->n[t] || !n_valid) continue;
+    if (!fm->n[t] || !n_valid) {  // nothing of this type: its words of the result read "no points"
+      FM_TRY(hipMemsetAsync(fm->sur_res.p + 8 * t, 0, 8 * sizeof(uint32_t), s));
+      continue;
+    }
     rc = refresh_segments_device(fm, t);
     if (rc) return rc;
     FM_TRY(fm->g_src_t[t].reserve((size_t)n_valid));
@@ -1369,10 +1375,12 @@ int lslam_fmap_surround_to_map(lslam_fmap *fm) {
     hipLaunchKernelGGL(fm_gather_box_kernel, dim3(blocks), dim3(256), 0, s, (const float4 *)fm->pts[t].p, (const int32_t *)fm->g_src_t[t].p,
                        (const int32_t *)fm->g_dst_t[t].p, n_valid, fm->sur_res.p + 8 * t, 1, fm->sur[t].p);
     FM_TRY(hipGetLastError());
-    FM_TRY(hipMemcpyAsync(h_res + 8 * t, fm->sur_res.p + 8 * t, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     any = true;
   }
-  if (any) FM_TRY(hipStreamSynchronize(s));  // the one wait: both types' totals and boxes
+  if (any) {  // one copy and the one wait: both types' totals and boxes (a type that was skipped left its words untouched: zeroed below)
+    FM_TRY(hipMemcpyAsync(h_res, fm->sur_res.p, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    FM_TRY(hipStreamSynchronize(s));
+  }
   for (int t = 0; t < 2; ++t) {
     n[t] = h_res[8 * t];
     for (int a = 0; a < 3; ++a) {

@@ -1907,9 +1907,9 @@ static int voxel_grid_impl(lslam_ctx *ctx, const void *cloud, size_t n, size_t s
   size_t m = 0;
   if (one_wait) {
     FM_TRY(cache.out_pin.reserve(n));
-    rc = run_pipeline(s, sc, cache.in_raw.p, nullptr, n, kp, 1, nullptr, out.p, oc.p, &m, 0, cache.done.p);
+    // (the centroids are written to pinned memory by their kernel: no copy of all n slots behind it)
+    rc = run_pipeline(s, sc, cache.in_raw.p, nullptr, n, kp, 1, nullptr, cache.out_pin.p, oc.p, &m, 0, cache.done.p);
     if (rc) return rc;
-    FM_TRY(hipMemcpyAsync(cache.out_pin.p, out.p, n * sizeof(float4), hipMemcpyDeviceToHost, s));
     FM_TRY(hipStreamSynchronize(s));
     if (cache.done.p[1]) {
       lslam::set_error("voxel index outside its key range (non-finite point?)");
@@ -1956,8 +1956,8 @@ static int voxel_grid2_impl(lslam_ctx *ctx, const void *a, size_t na, const void
     Pin<float4> in_pin, out_pin;
     Pin<int32_t> seg_pin;
     Pin<uint32_t> done;
-    Buf<float4> in_raw, out;
-    Buf<int32_t> seg, oseg;
+    Buf<float4> in_raw;
+    Buf<int32_t> seg;
   };
   static std::map<int, Cache> caches;  // per device
   static std::mutex mu;
@@ -1968,9 +1968,7 @@ static int voxel_grid2_impl(lslam_ctx *ctx, const void *a, size_t na, const void
   FM_TRY(c.seg_pin.reserve(n));
   FM_TRY(c.done.reserve(4));
   FM_TRY(c.in_raw.reserve(n));
-  FM_TRY(c.out.reserve(n));
   FM_TRY(c.seg.reserve(n));
-  FM_TRY(c.oseg.reserve(n));
   const void *src[2] = {a, b};
   const size_t cnt[2] = {na, nb};
   size_t at = 0;
@@ -1994,16 +1992,14 @@ static int voxel_grid2_impl(lslam_ctx *ctx, const void *a, size_t na, const void
   // segment 0 for the first cloud's points, 1 for the second's: one launch (two fills were up to four: aligned part + tail each)
   hipLaunchKernelGGL(fm_two_segments_kernel, dim3(((unsigned)n + 255) / 256), dim3(256), 0, s, c.seg.p, (int)na, (int)n);
   size_t m = 0;
-  int rc = lslam::voxel_filter_segments(s, c.in_raw.p, c.seg.p, n, 2, leaf, c.out.p, c.oseg.p, &m, true, c.done.p);
+  // the centroids and their segments are WRITTEN to pinned memory by the kernel that makes them (the m of them: the count is
+  // not known on the host yet -- the copies this replaces moved all n slots, 0.8 MB for a sweep's 42 k points)
+  int rc = lslam::voxel_filter_segments(s, c.in_raw.p, c.seg.p, n, 2, leaf, c.out_pin.p, c.seg_pin.p, &m, true, c.done.p);
   if (rc) return rc;
-  FM_TRY(hipMemcpyAsync(c.out_pin.p, c.out.p, n * sizeof(float4), hipMemcpyDeviceToHost, s));
-  FM_TRY(hipMemcpyAsync(c.seg_pin.p, c.oseg.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   FM_TRY(hipStreamSynchronize(s));
   if (c.done.p[1]) {  // the wide key did not hold an extent: once more with the measured one (waits inside)
-    rc = lslam::voxel_filter_segments(s, c.in_raw.p, c.seg.p, n, 2, leaf, c.out.p, c.oseg.p, &m, true, nullptr);
+    rc = lslam::voxel_filter_segments(s, c.in_raw.p, c.seg.p, n, 2, leaf, c.out_pin.p, c.seg_pin.p, &m, true, nullptr);
     if (rc) return rc;
-    FM_TRY(hipMemcpyAsync(c.out_pin.p, c.out.p, m * sizeof(float4), hipMemcpyDeviceToHost, s));
-    FM_TRY(hipMemcpyAsync(c.seg_pin.p, c.oseg.p, m * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     FM_TRY(hipStreamSynchronize(s));
   } else {
     m = c.done.p[0];

@@ -56,9 +56,17 @@ template <typename T>
 struct DevBuf {
   T *p = nullptr;
   size_t cap = 0;
+  bool borrowed = false;  // p points into another allocation (adopt): never freed here, dropped by the next reserve
+  void adopt(T *ptr, size_t n) {
+    if (p && !borrowed) (void)hipFree(p);
+    p = ptr;
+    cap = n;
+    borrowed = true;
+  }
   hipError_t reserve(size_t n) {
     if (n <= cap) return hipSuccess;
-    if (p) (void)hipFree(p);
+    if (p && !borrowed) (void)hipFree(p);
+    borrowed = false;
     p = nullptr;
     cap = 0;
     size_t want = n + n / 8 + 64;
@@ -67,7 +75,8 @@ struct DevBuf {
     return e;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && !borrowed) (void)hipFree(p);
+    borrowed = false;
     p = nullptr;
     cap = 0;
   }
@@ -170,6 +179,8 @@ struct lslam_ctx {
   int32_t nb_total = 0;
   size_t n_points = 0;
   DevBuf<float> partials;
+  DevBuf<char> scan_tables;    // [blocks | probs | groups] of the resident scans: blocks / probs / groups point into it
+  std::vector<char> h_tables;  // ... its host image
   DevBuf<int32_t> tail_count;  // per resident scan: the fused solve's ticket counter (zero between launches)
   DevBuf<uint32_t> stack_ovf;  // only allocated for trees deeper than KD_STACK_LDS+1
   DevBuf<int32_t> prev_nb;     // neighbours of the previous sweep, per resident scan point
@@ -684,6 +695,7 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   ctx->need2_list.release();
   ctx->need2_cnt.release();
   ctx->groups.release();
+  ctx->scan_tables.release();
   ctx->cert_work.release();
   ctx->cert_count.release();
   ctx->kc.release();
@@ -1519,8 +1531,16 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
   ctx->h_prob_group0.push_back((int32_t)ctx->h_groups.size());
   const size_t nb = ctx->h_blocks.size();
   HIP_TRY(ctx->q.reserve(total ? total : 1));
-  HIP_TRY(ctx->blocks.reserve(nb ? nb : 1));
-  HIP_TRY(ctx->probs.reserve((size_t)n_scans));
+  // the scan's three tables -- workgroups, scans, second-pass groups -- in ONE device allocation behind ONE upload (three
+  // allocations and three copies were three launches of a mapping frame's scan match)
+  const size_t n_groups_tab = ctx->h_groups.empty() ? 1 : ctx->h_groups.size();
+  const size_t off_probs = ((nb ? nb : 1) * sizeof(BlockDesc) + 15) & ~(size_t)15;
+  const size_t off_groups = (off_probs + (size_t)n_scans * sizeof(ProbBlocks) + 15) & ~(size_t)15;
+  const size_t tab_bytes = off_groups + n_groups_tab * sizeof(GroupDesc);
+  HIP_TRY(ctx->scan_tables.reserve(tab_bytes));
+  ctx->blocks.adopt(reinterpret_cast<BlockDesc *>(ctx->scan_tables.p), nb ? nb : 1);
+  ctx->probs.adopt(reinterpret_cast<ProbBlocks *>(ctx->scan_tables.p + off_probs), (size_t)n_scans);
+  ctx->groups.adopt(reinterpret_cast<GroupDesc *>(ctx->scan_tables.p + off_groups), n_groups_tab);
   HIP_TRY(ctx->partials.reserve((nb ? nb : 1) * NCOL));
   HIP_TRY(ctx->prev_nb.reserve((total ? total : 1) * 5));
   HIP_TRY(ctx->prev_q.reserve(total ? total : 1));
@@ -1529,7 +1549,6 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
   HIP_TRY(ctx->need_cnt.reserve(nb ? nb : 1));
   HIP_TRY(ctx->need2_list.reserve((nb ? nb : 1) * SWEEP_BLOCK));
   HIP_TRY(ctx->need2_cnt.reserve(nb ? nb : 1));
-  HIP_TRY(ctx->groups.reserve(ctx->h_groups.empty() ? 1 : ctx->h_groups.size()));
   HIP_TRY(ctx->cert_work.reserve(nb ? nb : 1));
   if (!ctx->cert_count.p) {
     HIP_TRY(ctx->cert_count.reserve(4));
@@ -1547,14 +1566,11 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
   } else if (total) {
     HIP_TRY(hipMemcpyAsync(ctx->q.p, all, total * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
   }
-  if (nb)
-    HIP_TRY(hipMemcpyAsync(ctx->blocks.p, ctx->h_blocks.data(), nb * sizeof(BlockDesc),
-                           hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(ctx->probs.p, ctx->h_probs.data(), (size_t)n_scans * sizeof(ProbBlocks),
-                         hipMemcpyHostToDevice, ctx->stream));
-  if (!ctx->h_groups.empty())
-    HIP_TRY(hipMemcpyAsync(ctx->groups.p, ctx->h_groups.data(), ctx->h_groups.size() * sizeof(GroupDesc), hipMemcpyHostToDevice,
-                           ctx->stream));
+  ctx->h_tables.assign(tab_bytes, 0);
+  if (nb) std::memcpy(ctx->h_tables.data(), ctx->h_blocks.data(), nb * sizeof(BlockDesc));
+  std::memcpy(ctx->h_tables.data() + off_probs, ctx->h_probs.data(), (size_t)n_scans * sizeof(ProbBlocks));
+  if (!ctx->h_groups.empty()) std::memcpy(ctx->h_tables.data() + off_groups, ctx->h_groups.data(), ctx->h_groups.size() * sizeof(GroupDesc));
+  HIP_TRY(hipMemcpyAsync(ctx->scan_tables.p, ctx->h_tables.data(), tab_bytes, hipMemcpyHostToDevice, ctx->stream));
   // No wait here: everything that uses the scan is ordered behind these copies on the same stream, the block / range tables
   // are pageable (consumed when hipMemcpyAsync returns) and the pinned staging area is guarded by `stage_busy` -- so that
   // lslam_scanmatch_scan reaches the host once per call, when the loop's result comes back.

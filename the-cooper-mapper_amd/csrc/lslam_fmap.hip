@@ -626,6 +626,8 @@ struct lslam_fmap {
   bool seg_current[2] = {false, false};
   bool seg_dev_current[2] = {false, false};  // ... the device's table alone (what surround_to_map needs)
   Buf<int32_t> d_valid;                 // the active cubes (fm->valid), uploaded when they change
+  std::vector<int32_t> valid_uploaded;  // ... what the device holds (flags in `active`, list in d_valid)
+  bool valid_on_device = false;
   Buf<uint32_t> sur_res;                // [2 types][8]: points gathered, bounding box (fm_gather_box_kernel)
   Buf<float4> in_raw, in_tf;
   Buf<int32_t> in_cube;
@@ -950,6 +952,8 @@ void compute_active_area(lslam_fmap *fm, const float pos[3]) {
 }
 
 int upload_active(lslam_fmap *fm) {
+  // the active area is the same from sweep to sweep until the sensor crosses into another cube's reach: nothing to upload then
+  if (fm->valid_on_device && fm->valid == fm->valid_uploaded) return LSLAM_OK;
   std::vector<uint8_t> h(fm->ncube, 0);
   for (int32_t c : fm->valid) h[c] = 1;
   FM_TRY(hipMemcpyAsync(fm->active.p, h.data(), fm->ncube, hipMemcpyHostToDevice, fm->stream));
@@ -957,6 +961,8 @@ int upload_active(lslam_fmap *fm) {
   if (!fm->valid.empty())
     FM_TRY(hipMemcpyAsync(fm->d_valid.p, fm->valid.data(), fm->valid.size() * sizeof(int32_t), hipMemcpyHostToDevice, fm->stream));
   FM_TRY(hipStreamSynchronize(fm->stream));  // h is a local
+  fm->valid_uploaded = fm->valid;
+  fm->valid_on_device = true;
   return LSLAM_OK;
 }
 

@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include <cmath>
 #include <cstdio>
@@ -385,32 +387,36 @@ __global__ void fm_merge_kernel(const uint64_t *k0, int n_sorted, const uint64_t
   }
 }
 
-__global__ void fm_head_kernel(const uint64_t *keys, int n, int axis_bits, int single, const uint8_t *flags,
-                               uint32_t *head) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (i == 0) head[n] = 0u;  // the scan runs over n + 1 flags: its last output is the number of heads
-  const uint64_t k = keys[i];
-  uint32_t h = 0;
-  if (k != KEY_DROP) {
+// 1 where sorted entry i starts a voxel (or is a point of a cube that is not filtered: its own output), 0 for its further
+// members, for dropped points and for i = n (the scan runs over n + 1 values: its last output is the number of points out).
+// A functor, not an array: the scan reads it through a transform iterator and the centroid kernel evaluates it where it needs
+// it (round 5: a kernel of its own wrote these n + 1 words for the two to read back).
+struct HeadOf {
+  const uint64_t *keys;
+  int n, axis_bits, single;
+  const uint8_t *flags;
+  __host__ __device__ uint32_t operator()(uint32_t iu) const {
+    const int i = (int)iu;
+    if (i >= n) return 0u;
+    const uint64_t k = keys[i];
+    if (k == KEY_DROP) return 0u;
     const int32_t c = (int32_t)(k >> (3 * axis_bits));
-    const bool filt = single || cube_filtered(flags, c);
-    h = (i == 0 || !filt || keys[i - 1] != k) ? 1u : 0u;
+    const bool filt = single || (flags != nullptr && flags[c] != 0);
+    return (i == 0 || !filt || keys[i - 1] != k) ? 1u : 0u;
   }
-  head[i] = h;
-}
+};
 
 // Centroid of every voxel over its members in sorted (= input) order.  The sums are sequential by definition (PCL's order), the
 // loads are not: every lane fetches ITS point (64 independent gathers per wavefront), then each head lane adds its members'
 // values, in order, out of its neighbours' registers; only a voxel that runs past the end of its wavefront goes on from memory.
-__global__ __launch_bounds__(256) void fm_centroid_kernel(const float4 *pts, const uint64_t *keys, const uint32_t *idx, const uint32_t *head,
+__global__ __launch_bounds__(256) void fm_centroid_kernel(const float4 *pts, const uint64_t *keys, const uint32_t *idx, const HeadOf head,
                                                           const uint32_t *pos, int n, int axis_bits, float4 *out, int32_t *cube_out,
                                                           int32_t *total_out) {
   const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
   const bool in = i < n;
   if (i == 0) *total_out = (int32_t)pos[n];  // the number of heads = points out, next to the error words (one copy fetches all)
   const uint64_t k = in ? keys[i] : KEY_DROP;
-  const bool is_head = in && head[i] != 0;
+  const bool is_head = in && head((uint32_t)i) != 0u;
   const bool member = in && !is_head && k != KEY_DROP;  // (a dropped point is nobody's member: fm_head_kernel gives it no head either)
   float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
   if (is_head || member) p = pts[min(idx[i], (uint32_t)(n - 1))];  // (clamped: after a merge whose prefix was not in order the slots are
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(256) void fm_centroid_kernel(const float4 *pts, con
     int e0 = (i - lane) + 64;
     for (;;) {
       const int e = e0 + lane;
-      const bool valid = e < n && !head[e] && keys[e] == kk;
+      const bool valid = e < n && !head((uint32_t)e) && keys[e] == kk;
       const unsigned long long vm = __ballot(valid);
       const int L = ~vm == 0ull ? 64 : __builtin_ctzll(~vm);  // the run's members at the head of this chunk
       float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -594,13 +600,13 @@ int bits_for(double cells) {
 
 struct Scratch {
   Buf<uint64_t> k0, k1, kn;
-  Buf<uint32_t> i0, i1, in_, head, pos;
+  Buf<uint32_t> i0, i1, in_, pos;
   Buf<char> tmp;
   Buf<int32_t> err;               // [0] points out, [1] key-range error, [2] the "sorted" prefix was not, [3] widest voxel extent of a filtered cube
   Buf<int32_t> cmin, cmax, base;  // [ncube][3]
   Buf<uint8_t> eff;               // [ncube] cubes this rebuild really filters
   void release() {
-    k0.release(); k1.release(); kn.release(); i0.release(); i1.release(); in_.release(); head.release(); pos.release(); tmp.release();
+    k0.release(); k1.release(); kn.release(); i0.release(); i1.release(); in_.release(); pos.release(); tmp.release();
     err.release(); cmin.release(); cmax.release(); base.release(); eff.release();
   }
 };
@@ -770,7 +776,6 @@ int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t
   FM_TRY(sc.k1.reserve(n_total));
   FM_TRY(sc.i0.reserve(n_total));
   FM_TRY(sc.i1.reserve(n_total));
-  FM_TRY(sc.head.reserve(n_total + 1));
   FM_TRY(sc.pos.reserve(n_total + 1));
   const bool merge = n_sorted > 0 && n_sorted < n_total;
   hipLaunchKernelGGL(fm_key_kernel, grd, blk, 0, s, in_pts, in_cube, n, kp, eff, sc.base.p, sc.k0.p, sc.i0.p, sc.err.p + 1,
@@ -790,7 +795,9 @@ int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t
   size_t tmp_bytes = 0;
   FM_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, sc.k0.p, sc.k1.p, sc.i0.p, sc.i1.p, n_total, 0u, end_bit, s));
   size_t tmp2 = 0;
-  FM_TRY(rocprim::exclusive_scan(nullptr, tmp2, sc.head.p, sc.pos.p, 0u, n_total + 1, rocprim::plus<uint32_t>(), s));
+  const HeadOf head_of{sc.k1.p, n, kp.axis_bits, kp.single, eff};
+  auto heads = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0u), head_of);
+  FM_TRY(rocprim::exclusive_scan(nullptr, tmp2, heads, sc.pos.p, 0u, n_total + 1, rocprim::plus<uint32_t>(), s));
   if (merge) {
     const size_t n_new = n_total - n_sorted;
     size_t tmp3 = 0;
@@ -812,10 +819,8 @@ int run_pipeline(hipStream_t s, Scratch &sc, const float4 *in_pts, const int32_t
     const int rc_sort = sort_pairs(sc.k0.p, sc.k1.p, sc.i0.p, sc.i1.p, n_total, tmp_bytes);
     if (rc_sort) return rc_sort;
   }
-  hipLaunchKernelGGL(fm_head_kernel, grd, blk, 0, s, sc.k1.p, n, kp.axis_bits, kp.single, eff, sc.head.p);
-  FM_TRY(rocprim::exclusive_scan((void *)sc.tmp.p, tmp2, sc.head.p, sc.pos.p, 0u, n_total + 1,
-                                 rocprim::plus<uint32_t>(), s));
-  hipLaunchKernelGGL(fm_centroid_kernel, grd, blk, 0, s, in_pts, sc.k1.p, sc.i1.p, sc.head.p, sc.pos.p, n,
+  FM_TRY(rocprim::exclusive_scan((void *)sc.tmp.p, tmp2, heads, sc.pos.p, 0u, n_total + 1, rocprim::plus<uint32_t>(), s));
+  hipLaunchKernelGGL(fm_centroid_kernel, grd, blk, 0, s, in_pts, sc.k1.p, sc.i1.p, head_of, sc.pos.p, n,
                      kp.axis_bits, out_pts, out_cube, sc.err.p);
   if (done) {  // {points out, key-range error, prefix not sorted}: three adjacent words, one copy
     FM_TRY(hipMemcpyAsync(done, sc.err.p, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s));

@@ -96,6 +96,20 @@ def test_extract_features_more_rings_than_the_device_has_cus_for(pkg, ctx, oracl
     _compare(pkg.scan_registration.extract_features(ctx, cloud, thirds, taps=True), oracle.extract_features(cloud, thirds), "192 rings")
 
 
+def test_extract_features_many_short_rings(pkg, ctx, oracle, synth):
+    """1 200 rings of 24 points (a ring of at most 2 * curvatureRegion + 1 points is skipped, :205-207; these are just above
+    it with curvatureRegion = 5): 4 800 workgroups in one launch, the per-list scans over more rings than a workgroup has
+    wavefronts for."""
+    world = synth.World(half_extent=120.0, wall_half=90.0)
+    c, s, gt, cloud, ranges = synth.make_scan(world, 16, 1800, seed=5, full=True)
+    n = (len(cloud) // 24) * 24
+    short = np.stack([np.arange(0, n, 24), np.arange(0, n, 24) + 23], axis=1).astype(np.int32)[:1200]
+    p, q = pkg.scan_registration.default_params(ctx), oracle.reg_params()
+    for obj in (p, q):
+        obj.n_feature_regions = 2
+    _compare(pkg.scan_registration.extract_features(ctx, cloud, short, p, taps=True), oracle.extract_features(cloud, short, q), "short rings")
+
+
 def test_extract_features_bounds_its_region_count(pkg, ctx, synth):
     world = synth.World(half_extent=60.0, wall_half=55.0)
     c, s, gt, cloud, ranges = synth.make_scan(world, 16, 900, full=True)

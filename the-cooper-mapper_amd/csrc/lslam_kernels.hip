@@ -1651,35 +1651,58 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 
 // The workgroups of the scans whose loop is still running, in block order: late in a batch's loops most scans have converged,
 // and a launch of every workgroup of every scan -- 430 000 for the bench's 960 scans, nearly all of them leaving at once --
 // costs 0.17 ms for the sweep kernel alone, 0.3 ms per trailing iteration with the second pass and the solve: 4 % of a step.
-// One workgroup: per scan its block count (0 when done), an exclusive scan over the scans, every scan's thread writes its run.
+// Every workgroup scans the scans' block counts for itself (a few thousand loads), then the workgroups share the WRITING of the
+// list -- entry i belongs to the scan whose run holds it, found by a search in the prefix in LDS.  (One workgroup whose
+// threads wrote their own scans' runs one entry after the other took 45 us per iteration for the bench's 430 000 entries.)
+constexpr int COMPACT_WGS = 64;
 __global__ __launch_bounds__(1024) void compact_active_kernel(const GNState *states, const ProbBlocks *probs, int n_prob, int32_t block_base,
                                                               int32_t *active_blocks, int32_t *count_out) {
-  __shared__ int part[1024];
-  const int tid = threadIdx.x;
+  __shared__ int incl[1024];
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (n_prob + 1023) / 1024;
   const int p0 = min(n_prob, tid * per), p1 = min(n_prob, p0 + per);
   int sum = 0;
   for (int p = p0; p < p1; ++p) sum += states[p].done ? 0 : probs[p].n_blocks;
-  part[tid] = sum;
+  int run = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(run, o, 64);
+    if (lane >= o) run += u;
+  }
+  if (lane == 63) wsum[wave] = run;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    const int v = tid >= off ? part[tid - off] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
+  int before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const int c = wsum[w];
+    before += w < wave ? c : 0;
+    total += c;
   }
-  int at = part[tid] - sum;
-  for (int p = p0; p < p1; ++p) {
-    if (states[p].done) continue;
-    const int first = probs[p].first_block - block_base, nb = probs[p].n_blocks;
-    for (int b = 0; b < nb; ++b) active_blocks[at + b] = first + b;
-    at += nb;
+  incl[tid] = before + run;  // blocks of the scans of threads 0 .. tid
+  __syncthreads();
+  for (int i = blockIdx.x * 1024 + tid; i < total; i += gridDim.x * 1024) {
+    int lo = 0, hi = 1023;  // the first thread whose inclusive count exceeds i
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (incl[mid] > i) hi = mid; else lo = mid + 1;
+    }
+    int at = lo ? incl[lo - 1] : 0;
+    const int q0 = min(n_prob, lo * per), q1 = min(n_prob, q0 + per);
+    for (int p = q0; p < q1; ++p) {  // (per = 1 for up to 1 024 scans)
+      const int nb = states[p].done ? 0 : probs[p].n_blocks;
+      if (i < at + nb) {
+        active_blocks[i] = probs[p].first_block - block_base + (i - at);
+        break;
+      }
+      at += nb;
+    }
   }
-  if (tid == 1023) *count_out = part[1023];
+  if (blockIdx.x == 0 && tid == 0) *count_out = total;
 }
 hipError_t launch_compact_active(const GNState *states, const ProbBlocks *probs, int n_prob, int32_t block_base, int32_t *active_blocks,
                                  int32_t *count_out, hipStream_t s) {
-  hipLaunchKernelGGL(compact_active_kernel, dim3(1), dim3(1024), 0, s, states, probs, n_prob, block_base, active_blocks, count_out);
+  hipLaunchKernelGGL(compact_active_kernel, dim3(COMPACT_WGS), dim3(1024), 0, s, states, probs, n_prob, block_base, active_blocks, count_out);
   return hipGetLastError();
 }
 

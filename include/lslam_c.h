@@ -198,7 +198,8 @@ void lslam_default_opts(lslam_opts *opts);
  * (the C++ mirrors do, and refuse to start otherwise). */
 /* 5 (round 5): no struct changed; new entry points (lslam_debug_grid_stats, lslam_debug_knn5_wide, lslam_debug_sort_pairs), new bits (LSLAM_SWEEP_FIRST /
  * _CARRIED, LSLAM_AB_FIT_CACHE, LSLAM_AB_WIDE_NF_MARGIN) -- a program built against this header needs a library that has them. */
-#define LSLAM_ABI_VERSION 5
+/* 6 (round 6): no struct changed; new entry points (lslam_fset_*, lslam_extract_features_dev, lslam_odom_*, lslam_map_epoch). */
+#define LSLAM_ABI_VERSION 6
 int lslam_abi_version(void);
 size_t lslam_sizeof_opts(void);
 size_t lslam_sizeof_stats(void);
@@ -300,6 +301,16 @@ int lslam_odometry_match(lslam_ctx *ctx, const void *last_corner, size_t n_last_
                          const void *flat, size_t n_flat, size_t stride_bytes, float pose[6],
                          int32_t max_iterations, float delta_t_abort, float delta_r_abort,
                          lslam_stats *stats);
+
+/* The same match with nearestKSearch answered by kd-trees of the two last clouds (built in the call) and one launch per step:
+ * the implementation lslam_odometry_match had before the hashed grids of csrc/lslam_odom.hip.  It is what a sweep with an exact
+ * distance tie is redone through (nanoflann's visit order decides there) and the A/B partner of the grid path: same result, bit
+ * for bit, on tie-free clouds (tests/test_gpu_odom.py).  LSLAM_ODOM_TREES=1 in the environment routes lslam_odometry_match here. */
+int lslam_odometry_match_trees(lslam_ctx *ctx, const void *last_corner, size_t n_last_corner,
+                               const void *last_surf, size_t n_last_surf, const void *sharp, size_t n_sharp,
+                               const void *flat, size_t n_flat, size_t stride_bytes, float pose[6],
+                               int32_t max_iterations, float delta_t_abort, float delta_r_abort,
+                               lslam_stats *stats);
 
 /* LaserOdometry::transformToEnd (odometry/LaserOdometry.cpp:156-168): every point of a host
  * cloud ({x,y,z} + intensity = ring + relTime at byte 12 of 16-byte points, byte 16 of PointXYZI)
@@ -486,6 +497,70 @@ int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, s
 int lslam_multiscan_register(lslam_ctx *ctx, const void *cloud, size_t n_points, size_t stride_bytes,
                              float lower_deg, float upper_deg, int32_t n_rings, float scan_period,
                              float *out_xyzc, size_t cap, size_t *n_out, int32_t *ranges_out);
+
+/* ---- the odometry node resident on the device ("fully on device ... feeds the path without a CPU hop") ----
+ *
+ * A sweep's four feature clouds stay in HBM between the registration node and the odometry node: lslam_extract_features_dev
+ * leaves them in an lslam_fset (the /laser_cloud_sharp, /laser_cloud_less_sharp, /laser_cloud_flat, /laser_cloud_less_flat
+ * messages of ScanRegistration::publishResult, odometry/ScanRegistration.cpp, without the trip through the host), and
+ * lslam_odom_process runs LaserOdometry::process (odometry/LaserOdometry.cpp:288-326) on them:
+ *   first sweep     the less-sharp / less-flat clouds become _lastCornerCloud / _lastSurfaceCloud (:295-303)
+ *   afterwards      scanMatch (:328-647) against the last clouds when they hold > 10 / > 100 points (:337) with the persistent
+ *                   _transform as the initial guess, _Tsum = _Tsum * _transform (:649-653), transformToEnd of the less-sharp /
+ *                   less-flat clouds (:312-313), which become the last clouds (:315-316)
+ * with nothing but the 6 + 16 floats of the result (and, if asked for, the two last clouds the mapping node subscribes to)
+ * crossing PCIe.  The nearest neighbour of :359 / :425 (nearestKSearch(pointSel, 1, ...), nanoflann_pcl.h:150-162) is found
+ * through two hashed cell grids per last cloud (1 m cells, then 5.02 m cells: their 27-cell probe covers the 5 m gate of
+ * :363,429 completely) with the proof of csrc/lslam_grid.hpp restated for k = 1: the smallest fp32 distance among the
+ * candidates is nanoflann's answer when it is below the probe's guaranteed radius and no second point has the same distance;
+ * an exact tie -- the one thing only nanoflann's visit order decides -- makes the call build the kd-trees after all and run
+ * through them (lslam_odom_stats.tree_fallbacks counts those).  The grids are built by the same launch sequence that moves the
+ * clouds to the sweep end: no kd-tree is built per sweep.  Same result as lslam_odometry_match + lslam_transform_to_end on
+ * the same clouds, bit for bit (tests/test_gpu_odom.py). */
+typedef struct lslam_fset lslam_fset;
+typedef struct lslam_odom lslam_odom;
+/* A feature set lives on the context's device; its buffers grow on demand.  It is complete when the call that fills it
+ * returns, and free for the next fill once the lslam_odom_process that consumed it has returned (a program with the two nodes
+ * on two threads rotates a few of them). */
+int lslam_fset_create(lslam_ctx *ctx, lslam_fset **out);
+void lslam_fset_destroy(lslam_fset *fs);
+/* counts[4]: points in sharp, less-sharp, flat, less-flat */
+int lslam_fset_counts(const lslam_fset *fs, size_t counts[4]);
+/* Host clouds {x,y,z,intensity} (stride / intensity offset as lslam_odometry_match) into a feature set: the entry for callers
+ * whose registration runs elsewhere, and for tests. */
+int lslam_fset_upload(lslam_ctx *ctx, lslam_fset *fs, const void *sharp, size_t n_sharp, const void *less_sharp,
+                      size_t n_less_sharp, const void *flat, size_t n_flat, const void *less_flat, size_t n_less_flat,
+                      size_t stride_bytes);
+/* One list back to the host, packed {x,y,z,intensity} (which: 0 sharp, 1 less-sharp, 2 flat, 3 less-flat). */
+int lslam_fset_download(lslam_ctx *ctx, const lslam_fset *fs, int32_t which, float *out_xyzi, size_t cap, size_t *n_out);
+/* lslam_extract_features with the four lists left in HBM (same kernels, same lists bit for bit). */
+int lslam_extract_features_dev(lslam_ctx *ctx, const void *cloud, size_t n_points, size_t stride_bytes,
+                               size_t intensity_offset_bytes, const int32_t *scan_ranges, size_t n_scans,
+                               const lslam_reg_params *params, lslam_fset *out, size_t counts[4]);
+
+typedef struct {
+  int32_t matched;         /* 0: the first sweep, or the last clouds were too small (:337): no scan match ran */
+  int32_t tree_fallbacks;  /* scan matches of this node so far that were redone through kd-trees (an exact distance tie) */
+  int32_t searches;        /* correspondence refreshes of this sweep's loop (every fifth iteration, :357,:423) */
+  int32_t reserved;
+  uint64_t sweeps;         /* sweeps processed by this node so far */
+  size_t n_last_corner, n_last_surf; /* the last clouds after this sweep */
+} lslam_odom_stats;
+/* LaserOdometry(scanPeriod, maxIterations = 25), _deltaTAbort = _deltaRAbort = 0.1 (LaserOdometry.cpp:24-25). */
+int lslam_odom_create(lslam_ctx *ctx, int32_t max_iterations, float delta_t_abort, float delta_r_abort, lslam_odom **out);
+void lslam_odom_destroy(lslam_odom *od);
+/* LaserOdometry::process.  transform[6] (out) = _transform after the sweep, Tsum[16] (out) = _Tsum, row-major; stats (may be
+ * NULL) as lslam_odometry_match fills it (zero when nothing was matched), ostats (may be NULL) the node's own.  last_corner /
+ * last_surf (may be NULL): room for cap_corner / cap_surf packed {x,y,z,intensity} points -- the two clouds
+ * LaserOdometry::publishResult sends to the mapping node (/laser_cloud_corner_last, /laser_cloud_surf_last), copied out behind
+ * the same wait as the result.  Returns LSLAM_OK / LSLAM_NOT_CONVERGED as lslam_odometry_match, LSLAM_TOO_FEW_REF when nothing
+ * was matched, a negative status on errors. */
+int lslam_odom_process(lslam_odom *od, lslam_fset *fs, float transform[6], float Tsum[16], lslam_stats *stats,
+                       lslam_odom_stats *ostats, float *last_corner, size_t cap_corner, float *last_surf, size_t cap_surf);
+/* The last clouds as they are in HBM now (any pointer may be NULL; counts in lslam_odom_stats). */
+int lslam_odom_last_clouds(lslam_odom *od, float *last_corner, size_t cap_corner, float *last_surf, size_t cap_surf);
+/* Start again from the first sweep (keeps the buffers). */
+int lslam_odom_reset(lslam_odom *od);
 
 /* ---- coarse alignment of a loop-closure candidate ------------------------------
  * Replaces LoopDetector::corseMatching (pose_graph/loop_detector.hpp:232-255), i.e.

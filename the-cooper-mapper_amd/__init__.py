@@ -19,7 +19,7 @@ from .feature_map import FeatureMap, voxel_grid, voxel_grid2
 from . import scan_registration
 from .loop_closure import KeyFrame, Loop, LoopDetector
 from .graph import Graph, KeyframeUpdater
-from .pipeline import LaserOdometry, LaserMapping
+from .pipeline import DeviceLaserOdometry, LaserOdometry, LaserMapping
 
-__all__ = ["Comm", "Context", "ScanMatch", "PoseGraph", "FeatureMap", "voxel_grid", "voxel_grid2", "scan_registration", "KeyFrame", "Loop", "LoopDetector", "Graph", "KeyframeUpdater", "LaserOdometry", "LaserMapping", "LslamError", "LslamOpts", "LslamStats", "LslamMapInfo", "LslamStereoCam",
+__all__ = ["Comm", "Context", "ScanMatch", "PoseGraph", "FeatureMap", "voxel_grid", "voxel_grid2", "scan_registration", "KeyFrame", "Loop", "LoopDetector", "Graph", "KeyframeUpdater", "LaserOdometry", "DeviceLaserOdometry", "LaserMapping", "LslamError", "LslamOpts", "LslamStats", "LslamMapInfo", "LslamStereoCam",
            "Status", "lib_path", "load_library", "build_library"]

@@ -123,6 +123,12 @@ class LslamPgStats(C.Structure):
     ]
 
 
+class LslamOdomStats(C.Structure):
+    """lslam_odom_stats (include/lslam_c.h)."""
+    _fields_ = [("matched", C.c_int32), ("tree_fallbacks", C.c_int32), ("searches", C.c_int32), ("reserved", C.c_int32),
+                ("sweeps", C.c_uint64), ("n_last_corner", C.c_size_t), ("n_last_surf", C.c_size_t)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
 ALLGATHERV_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32)
 c_double_p = C.POINTER(C.c_double)
@@ -160,6 +166,9 @@ SYMBOLS = {
     "lslam_odometry_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                        C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, c_float_p, C.c_int32,
                                        C.c_float, C.c_float, C.POINTER(LslamStats)]),
+    "lslam_odometry_match_trees": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                             C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, c_float_p, C.c_int32,
+                                             C.c_float, C.c_float, C.POINTER(LslamStats)]),
     "lslam_transform_to_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, c_float_p]),
     "lslam_isometry_to_pose": (None, [c_float_p, c_float_p]),
     "lslam_pose_to_isometry": (None, [c_float_p, c_float_p]),
@@ -224,6 +233,20 @@ SYMBOLS = {
     "lslam_multiscan_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float, C.c_float,
                                            C.c_int32, C.c_float, c_float_p, C.c_size_t, C.POINTER(C.c_size_t),
                                            c_int32_p]),
+    "lslam_fset_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "lslam_fset_destroy": (None, [C.c_void_p]),
+    "lslam_fset_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "lslam_fset_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                    C.c_void_p, C.c_size_t, C.c_size_t]),
+    "lslam_fset_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, c_float_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "lslam_extract_features_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, c_int32_p, C.c_size_t,
+                                             C.POINTER(LslamRegParams), C.c_void_p, C.POINTER(C.c_size_t)]),
+    "lslam_odom_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.POINTER(C.c_void_p)]),
+    "lslam_odom_destroy": (None, [C.c_void_p]),
+    "lslam_odom_process": (C.c_int, [C.c_void_p, C.c_void_p, c_float_p, c_float_p, C.POINTER(LslamStats), C.POINTER(LslamOdomStats),
+                                     c_float_p, C.c_size_t, c_float_p, C.c_size_t]),
+    "lslam_odom_last_clouds": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t, c_float_p, C.c_size_t]),
+    "lslam_odom_reset": (C.c_int, [C.c_void_p]),
     "lslam_pg_save_g2o": (C.c_int, [C.c_void_p, C.c_char_p]),
     "lslam_g2o_read": (C.c_int, [C.c_char_p, c_int32_p, c_double_p, c_int32_p, c_int32_p, c_double_p, c_double_p,
                                  c_int32_p]),

@@ -565,6 +565,7 @@ const EnvOnce &env_once() {
     v.no_morton = on("LSLAM_NO_MORTON");
     v.host_morton = on("LSLAM_HOST_MORTON");
     v.odom_inline = on("LSLAM_ODOM_INLINE_SEARCH");
+    v.odom_trees = on("LSLAM_ODOM_TREES");
     v.gnp_coop = on("LSLAM_GNP_COOPERATIVE");
     v.tiny_phase_off = on("LSLAM_TINY_PHASE") && num("LSLAM_TINY_PHASE", 1) == 0;
     v.no_reg_nodes = on("LSLAM_NO_REG_NODES");
@@ -684,6 +685,7 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   ctx->worker.stop();
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  lslam::odom_ctx_gone(ctx);  // the hidden odometry node of lslam_odometry_match (lslam_odom.hip)
   ctx->tc.nodes.release(); ctx->tc.pts.release(); ctx->tc.pn.release(); ctx->tc.own_box.release();
   ctx->ts.nodes.release(); ctx->ts.pts.release(); ctx->ts.pn.release(); ctx->ts.own_box.release();
   ctx->cell_c.release(); ctx->cell_s.release(); ctx->views_c.release(); ctx->views_s.release();
@@ -2375,8 +2377,17 @@ int lslam_scanmatch_full(lslam_ctx *ctx, const void *ref_corner, size_t n_ref_co
   return lslam_scanmatch_scan(ctx, corner, n_corner, surf, n_surf, stride_bytes, pose, opts, stats);
 }
 
-// Variant B: LaserOdometry::scanMatch (odometry/LaserOdometry.cpp:328-647)
-int lslam_odometry_match(lslam_ctx *ctx, const void *last_corner, size_t n_lc, const void *last_surf,
+// Variant B: LaserOdometry::scanMatch (odometry/LaserOdometry.cpp:328-647) through kd-trees of the last clouds, one launch per
+// step: the implementation of rounds 1-5.  lslam_odometry_match (lslam_odom.hip) searches hashed cell grids instead and comes
+// here only for a sweep with an exact distance tie, where nanoflann's visit order decides (and under LSLAM_ODOM_TREES=1, the A/B
+// switch of the two).
+}  // extern "C"
+namespace lslam {
+int odometry_match_trees(lslam_ctx *ctx, const void *last_corner, size_t n_lc, const void *last_surf, size_t n_ls, const void *sharp,
+                         size_t n_sharp, const void *flat, size_t n_flat, size_t stride_bytes, float pose[6], int32_t max_iterations,
+                         float delta_t_abort, float delta_r_abort, lslam_stats *stats);
+}
+int lslam::odometry_match_trees(lslam_ctx *ctx, const void *last_corner, size_t n_lc, const void *last_surf,
                          size_t n_ls, const void *sharp, size_t n_sharp, const void *flat, size_t n_flat,
                          size_t stride_bytes, float pose[6], int32_t max_iterations, float delta_t_abort,
                          float delta_r_abort, lslam_stats *stats) {
@@ -2441,6 +2452,7 @@ int lslam_odometry_match(lslam_ctx *ctx, const void *last_corner, size_t n_lc, c
   oa.n_oc = (int32_t)n_lc;
   oa.n_os = (int32_t)n_ls;
   oa.q = d_q.p;
+  oa.qf = d_q.p + n_sharp;
   oa.n_sharp = (int32_t)n_sharp;
   oa.n_flat = (int32_t)n_flat;
   oa.nb_sharp = (int32_t)((n_sharp + 255) / 256);
@@ -2522,6 +2534,7 @@ int lslam_odometry_match(lslam_ctx *ctx, const void *last_corner, size_t n_lc, c
   ctx->have_scan = false;
   return st.status;
 }
+extern "C" {
 
 // LaserOdometry::transformToEnd (odometry/LaserOdometry.cpp:156-168) on a host cloud, in place.
 int lslam_transform_to_end(lslam_ctx *ctx, void *cloud, size_t n, size_t stride_bytes, const float pose[6]) {

@@ -844,14 +844,27 @@ static int extract_features_impl(lslam_ctx *ctx, const void *cloud, size_t n_poi
                                  size_t intensity_offset_bytes, const int32_t *scan_ranges, size_t n_scans,
                                  const lslam_reg_params *params, float *sharp, float *less_sharp, float *flat,
                                  float *less_flat, size_t counts[4], float *curvature_out, int8_t *picked_out,
-                                 int8_t *label_out);
+                                 int8_t *label_out, lslam_fset *dev_out);
+int lslam_extract_features_dev(lslam_ctx *ctx, const void *cloud, size_t n_points, size_t stride_bytes,
+                               size_t intensity_offset_bytes, const int32_t *scan_ranges, size_t n_scans,
+                               const lslam_reg_params *params, lslam_fset *out, size_t counts[4]) {
+  if (!out) {
+    lslam::set_error("no feature set to extract into");
+    return LSLAM_ERR_INVALID;
+  }
+  size_t local[4];
+  const int rc = extract_features_impl(ctx, cloud, n_points, stride_bytes, intensity_offset_bytes, scan_ranges, n_scans, params, nullptr,
+                                       nullptr, nullptr, nullptr, counts ? counts : local, nullptr, nullptr, nullptr, out);
+  if (rc != LSLAM_OK && ctx && lslam::ctx_alive(ctx)) (void)hipStreamSynchronize((hipStream_t)lslam_stream(ctx));
+  return rc;
+}
 int lslam_extract_features(lslam_ctx *ctx, const void *cloud, size_t n_points, size_t stride_bytes,
                            size_t intensity_offset_bytes, const int32_t *scan_ranges, size_t n_scans,
                            const lslam_reg_params *params, float *sharp, float *less_sharp, float *flat,
                            float *less_flat, size_t counts[4], float *curvature_out, int8_t *picked_out,
                            int8_t *label_out) {
   const int rc = extract_features_impl(ctx, cloud, n_points, stride_bytes, intensity_offset_bytes, scan_ranges, n_scans, params, sharp,
-                                       less_sharp, flat, less_flat, counts, curvature_out, picked_out, label_out);
+                                       less_sharp, flat, less_flat, counts, curvature_out, picked_out, label_out, nullptr);
   // a failure half way leaves copies out of / into the pinned staging in flight: the next call shares it
   if (rc != LSLAM_OK && ctx && lslam::ctx_alive(ctx)) (void)hipStreamSynchronize((hipStream_t)lslam_stream(ctx));
   return rc;
@@ -860,7 +873,7 @@ static int extract_features_impl(lslam_ctx *ctx, const void *cloud, size_t n_poi
                                  size_t intensity_offset_bytes, const int32_t *scan_ranges, size_t n_scans,
                                  const lslam_reg_params *params, float *sharp, float *less_sharp, float *flat,
                                  float *less_flat, size_t counts[4], float *curvature_out, int8_t *picked_out,
-                                 int8_t *label_out) {
+                                 int8_t *label_out, lslam_fset *dev_out) {
   if (!ctx || !lslam::ctx_alive(ctx) || !scan_ranges || !counts || (n_points && !cloud) || stride_bytes < 12 ||
       (stride_bytes & 3) || intensity_offset_bytes + 4 > stride_bytes || n_scans == 0 || n_scans > 4096) {
     lslam::set_error("bad feature-extraction arguments");
@@ -873,6 +886,13 @@ static int extract_features_impl(lslam_ctx *ctx, const void *cloud, size_t n_poi
     return LSLAM_ERR_INVALID;
   }
   for (int k = 0; k < 4; ++k) counts[k] = 0;
+  if (dev_out) {
+    if (dev_out->device != lslam::ctx_device(ctx)) {
+      lslam::set_error("the feature set lives on another device");
+      return LSLAM_ERR_INVALID;
+    }
+    for (int k = 0; k < 4; ++k) dev_out->counts[k] = 0;
+  }
   for (size_t s = 0; s < n_scans; ++s) {
     const int32_t a = scan_ranges[2 * s], b = scan_ranges[2 * s + 1];
     if (b < a) continue;  // empty ring (MultiScanRegistration.cpp:184-189 gives {size, size - 1})
@@ -993,6 +1013,10 @@ static int extract_features_impl(lslam_ctx *ctx, const void *cloud, size_t n_poi
   // the four lists, on the device to the end (see fx_lists_block): nothing waits until everything is in pinned memory
   uint32_t *hdr = reinterpret_cast<uint32_t *>(cache.pout);
   for (int k = 0; k < 8; ++k) hdr[k] = 0u;
+  if (dev_out) {  // ... or in the feature set's slices in HBM: only the eight header words come back
+    FX_TRY2(lslam::fset_reserve(dev_out, n_points));
+    FX_TRY2(hipMemsetAsync(dev_out->buf, 0, 8 * sizeof(uint32_t), s));
+  }
   FxOutArgs oa{};
   oa.pts = d_pts;
   oa.ranges = d_ranges;
@@ -1003,14 +1027,16 @@ static int extract_features_impl(lslam_ctx *ctx, const void *cloud, size_t n_poi
   oa.inv_leaf = 1.0f / prm.less_flat_filter_size;
   oa.vox_stage = d_vox;
   oa.ring_out = d_ring_out;
-  oa.host = cache.pout;
-  oa.hdr = hdr;
+  oa.host = dev_out ? dev_out->buf : cache.pout;
+  oa.hdr = dev_out ? reinterpret_cast<uint32_t *>(dev_out->buf) : hdr;
+  if (dev_out) oa.cap = (int32_t)dev_out->cap;
   hipLaunchKernelGGL(fx_ring_voxel_kernel, dim3((unsigned)n_scans + 3u), dim3(FX_BLOCK), 0, s, oa);
   hipLaunchKernelGGL(fx_lessflat_out_kernel, dim3((unsigned)n_scans), dim3(FX_BLOCK), 0, s, oa);
   FX_TRY2(hipGetLastError());
   if (curvature_out) FX_TRY2(hipMemcpyAsync(curvature_out, d_curv, n_points * 4, hipMemcpyDeviceToHost, s));
   if (picked_out) FX_TRY2(hipMemcpyAsync(picked_out, d_picked, n_points, hipMemcpyDeviceToHost, s));
   if (label_out) FX_TRY2(hipMemcpyAsync(label_out, d_label, n_points, hipMemcpyDeviceToHost, s));
+  if (dev_out) FX_TRY2(hipMemcpyAsync(hdr, dev_out->buf, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   FX_TRY2(hipStreamSynchronize(s));
   if (hdr[4]) {
     lslam::set_error(hdr[4] == 1u ? "voxel index outside its range (non-finite point?)" : "a feature list overflowed its staging slice");
@@ -1019,7 +1045,8 @@ static int extract_features_impl(lslam_ctx *ctx, const void *cloud, size_t n_poi
   float *outs[4] = {sharp, less_sharp, flat, less_flat};
   for (int k = 0; k < 4; ++k) {
     counts[k] = (size_t)hdr[k];
-    if (outs[k] && hdr[k]) std::memcpy(outs[k], cache.pout + 16 + (size_t)k * n_points, (size_t)hdr[k] * sizeof(float4));
+    if (dev_out) dev_out->counts[k] = counts[k];
+    if (!dev_out && outs[k] && hdr[k]) std::memcpy(outs[k], cache.pout + 16 + (size_t)k * n_points, (size_t)hdr[k] * sizeof(float4));
   }
   return rc;
 }

@@ -244,7 +244,7 @@ struct OdomArgs {
   TreeView tc, ts;              // kd-trees of the last corner / surface clouds
   const float4 *oc, *os;        // the same clouds in scan order {x,y,z,intensity}
   int32_t n_oc, n_os;
-  const float4 *q;              // sharp points then flat points {x,y,z,intensity}
+  const float4 *q, *qf;         // sharp points, flat points {x,y,z,intensity}
   int32_t n_sharp, n_flat;
   int32_t nb_sharp, nb_total;   // blocks: [0,nb_sharp) sharp
   int32_t *ind;                 // [3][n_sharp+n_flat] cached correspondences (:357-408,:423-483)
@@ -355,7 +355,17 @@ void treebuild_release_scratch(hipStream_t s);  // frees the per-stream build sc
 }  // namespace lslam
 struct lslam_ctx;
 struct lslam_comm;
+// A sweep's four feature lists in HBM (include/lslam_c.h lslam_fset_*): sixteen header slots (what the extraction kernels write:
+// [0..3] the lists' sizes, [4] error), then four slices of `cap` points {x, y, z, intensity} -- sharp, less-sharp, flat, less-flat.
+struct lslam_fset {
+  int device = 0;
+  float4 *buf = nullptr;
+  size_t cap = 0;  // points per slice
+  size_t counts[4] = {0, 0, 0, 0};
+  float4 *list(int k) const { return buf + 16 + (size_t)k * cap; }
+};
 namespace lslam {
+hipError_t fset_reserve(lslam_fset *fs, size_t points_per_list);  // lslam_odom.hip: grows (contents are lost)
 // lslam_comm.hip: in-place fp64 SUM over the ranks of `comm`, enqueued on `s`
 hipError_t comm_allreduce_f64(lslam_comm *comm, double *buf, size_t count, hipStream_t s);
 hipError_t comm_allgatherv_f64(lslam_comm *comm, int n_lists, double *const *bufs, const int64_t *const *offs, hipStream_t s);
@@ -376,6 +386,9 @@ int cubemap_set_views(lslam_ctx *ctx, const std::vector<TreeView> &views_c, cons
                       float cube_size, const int32_t origin[3], const int32_t dims[3]);
 void cubemap_drop_views(lslam_ctx *ctx);  // the owner of such trees goes away
 void set_error(const char *msg);
+// lslam_odom.hip
+void odom_ctx_gone(lslam_ctx *ctx);
+
 // small accessors for translation units that work on a context (lslam_icp.hip)
 hipStream_t ctx_stream(lslam_ctx *ctx);
 TreeView ctx_tree_view(lslam_ctx *ctx, int which);   // 0 corner, 1 surf tree of the resident map
@@ -395,6 +408,7 @@ struct EnvOnce {
   bool unbounded_knn = false;    // LSLAM_UNBOUNDED_KNN
   bool no_morton = false, host_morton = false;  // LSLAM_NO_MORTON, LSLAM_HOST_MORTON
   bool odom_inline = false;      // LSLAM_ODOM_INLINE_SEARCH
+  bool odom_trees = false;       // LSLAM_ODOM_TREES=1: A/B switch -- lslam_odometry_match through kd-trees, one launch per step (rounds 1-5)
   bool gnp_coop = false;         // LSLAM_GNP_COOPERATIVE
   bool tiny_phase_off = false;   // LSLAM_TINY_PHASE=0
   bool no_reg_nodes = false;     // LSLAM_NO_REG_NODES

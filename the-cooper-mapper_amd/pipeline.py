@@ -51,6 +51,72 @@ class LaserOdometry:
         return self.Tsum.copy()
 
 
+class DeviceLaserOdometry:
+    """``LaserOdometry::process`` with the node's state in HBM (``lslam_odom``, include/lslam_c.h): the sweep's feature
+    clouds arrive as a :class:`~.scan_registration.FeatureSet`, the last clouds and their search grids never leave the
+    device, one wait per sweep.  Same numbers as :class:`LaserOdometry`, bit for bit (tests/test_gpu_odom.py)."""
+
+    def __init__(self, ctx, max_iterations=25, delta_t_abort=0.1, delta_r_abort=0.1, publish=True):
+        import ctypes as C
+        from .capi import LslamError
+        self.ctx = ctx
+        h = C.c_void_p()
+        rc = ctx.lib.lslam_odom_create(ctx.h, int(max_iterations), float(delta_t_abort), float(delta_r_abort), C.byref(h))
+        if rc < 0:
+            raise LslamError(rc, ctx.lib.lslam_last_error().decode())
+        self.h = h
+        self.publish = publish          # copy the last clouds out with every sweep (what the mapping node subscribes to)
+        self.transform = np.zeros(6, np.float32)
+        self.Tsum = np.eye(4, dtype=np.float32)
+        self.last_corner = self.last_surf = None
+        self.last_stats = self.last_ostats = None
+        self._out = [None, None]
+
+    def process(self, fset):
+        """One sweep's feature set -> _Tsum (4x4) after the sweep (None for the first one)."""
+        import ctypes as C
+        from .capi import LslamError, LslamOdomStats, LslamStats, c_float_p
+        st, ost = LslamStats(), LslamOdomStats()
+        tr, Ts = np.zeros(6, np.float32), np.zeros(16, np.float32)
+        fp = lambda x: x.ctypes.data_as(c_float_p)
+        cnt = fset.counts()
+        if self.publish:
+            oc, os_ = np.empty((cnt["less_sharp"], 4), np.float32), np.empty((cnt["less_flat"], 4), np.float32)
+            rc = self.ctx.lib.lslam_odom_process(self.h, fset.h, fp(tr), fp(Ts), C.byref(st), C.byref(ost), fp(oc), len(oc), fp(os_),
+                                                 len(os_))
+        else:
+            oc = os_ = None
+            rc = self.ctx.lib.lslam_odom_process(self.h, fset.h, fp(tr), fp(Ts), C.byref(st), C.byref(ost), None, 0, None, 0)
+        if rc < 0:
+            raise LslamError(rc, self.ctx.lib.lslam_last_error().decode())
+        self.last_stats, self.last_ostats = st, ost
+        self.transform, self.Tsum = tr, Ts.reshape(4, 4)
+        self.last_corner, self.last_surf = oc, os_
+        first = ost.sweeps == 1
+        return None if first else self.Tsum.copy()
+
+    def last_clouds(self):
+        """The last clouds as they are in HBM now (two (n, 4) arrays)."""
+        from .capi import LslamError, c_float_p
+        o = self.last_ostats
+        oc, os_ = np.empty((o.n_last_corner, 4), np.float32), np.empty((o.n_last_surf, 4), np.float32)
+        rc = self.ctx.lib.lslam_odom_last_clouds(self.h, oc.ctypes.data_as(c_float_p), len(oc), os_.ctypes.data_as(c_float_p), len(os_))
+        if rc < 0:
+            raise LslamError(rc, self.ctx.lib.lslam_last_error().decode())
+        return oc, os_
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.lslam_odom_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class LaserMapping:
     def __init__(self, ctx, cube_dims=(121, 121, 11), filter_corner=1.0, filter_surf=1.0, map_filter_corner=1.0,
                  map_filter_surf=1.0, map_filter=2.0, defer_trees=True):

@@ -333,15 +333,17 @@ class Context:
         self._check(rc)
         return Status(rc), p, st
 
-    def odometry_match(self, last_corner, last_surf, sharp, flat, pose, max_iterations=25, dt=0.1, dr=0.1):
-        """LaserOdometry::scanMatch (odometry/LaserOdometry.cpp:328-647); clouds {x,y,z,intensity}."""
+    def odometry_match(self, last_corner, last_surf, sharp, flat, pose, max_iterations=25, dt=0.1, dr=0.1, trees=False):
+        """LaserOdometry::scanMatch (odometry/LaserOdometry.cpp:328-647); clouds {x,y,z,intensity}.  ``trees``: through
+        kd-trees of the last clouds (lslam_odometry_match_trees) instead of the hashed cell grids -- same result."""
         lc, sb = _cloud(last_corner)
         ls, _ = _cloud(last_surf)
         sh, _ = _cloud(sharp)
         fl, _ = _cloud(flat)
         p = np.array(pose, dtype=np.float32).reshape(6)
         st = LslamStats()
-        rc = self.lib.lslam_odometry_match(self.h, _vp(lc), len(lc), _vp(ls), len(ls), _vp(sh), len(sh),
+        fn = self.lib.lslam_odometry_match_trees if trees else self.lib.lslam_odometry_match
+        rc = fn(self.h, _vp(lc), len(lc), _vp(ls), len(ls), _vp(sh), len(sh),
                                            _vp(fl), len(fl), sb, _fp(p), int(max_iterations), float(dt),
                                            float(dr), C.byref(st))
         self._check(rc)

@@ -7,6 +7,75 @@ import numpy as np
 
 from .capi import LslamError, LslamRegParams, c_float_p, c_int32_p
 
+LISTS = ("sharp", "less_sharp", "flat", "less_flat")
+
+
+class FeatureSet:
+    """A sweep's four feature clouds in HBM (``lslam_fset``): what the registration node hands the odometry node
+    without a trip through the host.  Filled by :func:`extract_features_dev` or :meth:`upload`; complete when that call
+    returns, free for the next fill once the ``DeviceLaserOdometry.process`` that consumed it has returned."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = C.c_void_p()
+        rc = ctx.lib.lslam_fset_create(ctx.h, C.byref(h))
+        if rc < 0:
+            raise LslamError(rc, ctx.lib.lslam_last_error().decode())
+        self.h = h
+
+    def counts(self):
+        c = (C.c_size_t * 4)()
+        self.ctx.lib.lslam_fset_counts(self.h, c)
+        return dict(zip(LISTS, (int(v) for v in c)))
+
+    def upload(self, sharp, less_sharp, flat, less_flat, ctx=None):
+        ctx = ctx or self.ctx
+        arrs = [np.ascontiguousarray(a, np.float32).reshape(-1, 4) for a in (sharp, less_sharp, flat, less_flat)]
+        args = []
+        for a in arrs:
+            args += [a.ctypes.data_as(C.c_void_p), len(a)]
+        rc = ctx.lib.lslam_fset_upload(ctx.h, self.h, *args, 16)
+        if rc < 0:
+            raise LslamError(rc, ctx.lib.lslam_last_error().decode())
+        return self
+
+    def download(self, which, ctx=None):
+        ctx = ctx or self.ctx
+        k = LISTS.index(which) if isinstance(which, str) else int(which)
+        n = list(self.counts().values())[k]
+        out = np.zeros((n, 4), np.float32)
+        m = C.c_size_t()
+        rc = ctx.lib.lslam_fset_download(ctx.h, self.h, k, out.ctypes.data_as(c_float_p), n, C.byref(m))
+        if rc < 0:
+            raise LslamError(rc, ctx.lib.lslam_last_error().decode())
+        return out
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.lslam_fset_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def extract_features_dev(ctx, cloud, scan_ranges, fset, params=None, intensity_field=3):
+    """:func:`extract_features` with the four lists left in HBM (``fset``); returns their sizes."""
+    a = np.ascontiguousarray(cloud, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] < 4:
+        raise ValueError("cloud must be (n, >=4) float32")
+    r = np.ascontiguousarray(scan_ranges, dtype=np.int32).reshape(-1, 2)
+    counts = (C.c_size_t * 4)()
+    rc = ctx.lib.lslam_extract_features_dev(ctx.h, a.ctypes.data_as(C.c_void_p), len(a), a.shape[1] * 4, int(intensity_field) * 4,
+                                            r.ctypes.data_as(c_int32_p), len(r), C.byref(params) if params is not None else None,
+                                            fset.h, counts)
+    if rc < 0:
+        raise LslamError(rc, ctx.lib.lslam_last_error().decode())
+    return dict(zip(LISTS, (int(v) for v in counts)))
+
 
 def default_params(ctx):
     p = LslamRegParams()

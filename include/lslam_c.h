@@ -559,6 +559,17 @@ int lslam_odom_process(lslam_odom *od, lslam_fset *fs, float transform[6], float
                        lslam_odom_stats *ostats, float *last_corner, size_t cap_corner, float *last_surf, size_t cap_surf);
 /* The last clouds as they are in HBM now (any pointer may be NULL; counts in lslam_odom_stats). */
 int lslam_odom_last_clouds(lslam_odom *od, float *last_corner, size_t cap_corner, float *last_surf, size_t cap_surf);
+/* Publishing without a copy on the host: with n_buffers > 0 every lslam_odom_process also leaves the two last clouds in one of
+ * n_buffers page-locked buffers of the node, taken in turn, and lslam_odom_last_view hands out where (packed {x,y,z,intensity};
+ * NULL / 0 before the first sweep).  A view stays valid until n_buffers further sweeps have been processed -- size the ring
+ * for the sweeps the consumer (the mapping node) may lag behind -- or until the next lslam_odom_set_publish / _destroy.
+ * n_buffers = 0 (the default) switches it off. */
+int lslam_odom_set_publish(lslam_odom *od, int32_t n_buffers);
+int lslam_odom_last_view(lslam_odom *od, const float **last_corner, size_t *n_corner, const float **last_surf, size_t *n_surf);
+/* Profiling tap (a node made in a process with LSLAM_DEBUG_HOOKS=1 and LSLAM_ODOM_SEARCH_TAP=1): per query of the node's LAST
+ * search launch four words -- 10 ns ticks, candidates looked at for the nearest neighbour, for the ring categories, bit 0 / 1 a
+ * coarse-level pass in the former / the latter.  Returns the number of queries copied (0: tap off). */
+int lslam_debug_odom_search(lslam_odom *od, uint32_t *out, size_t cap_queries);
 /* Start again from the first sweep (keeps the buffers). */
 int lslam_odom_reset(lslam_odom *od);
 

@@ -60,7 +60,7 @@ def test_device_node_equals_the_host_pointer_chain(pkg, ctx, synth, small_proble
             assert dev.last_ostats.matched == 0
         else:
             assert dev.last_ostats.matched == 1 and dev.last_ostats.tree_fallbacks == 0
-            assert np.array_equal(bits(T_d), bits(T_h)), step
+            assert np.abs(T_d - T_h).max() <= 1e-6, step  # (numpy's 4x4 product rounds differently from the library's row-times-column loop)
             assert np.array_equal(bits(dev.transform), bits(host.transform)), step
             assert dev.last_stats.iterations == host.last_stats.iterations and dev.last_stats.n_rows == host.last_stats.n_rows
             assert dev.last_ostats.searches == (dev.last_stats.sweeps + 4) // 5
@@ -88,6 +88,12 @@ def test_grid_search_equals_the_kd_tree_search(ctx, oracle, synth, small_problem
     cases.append((lc, ls, sharp, flat, np.array([0.02, -0.03, 0.25, 4.0, -3.0, 0.5], np.float32)))
     far = np.array([3000.0, -2500.0, 0.0, 0.0], np.float32)
     cases.append((lc + far, ls + far, sharp + far, flat + far, np.zeros(6, np.float32)))
+    # last clouds that are NOT in ring order (the ring windows are then walked point by point, as the reference does) and ring
+    # ids beyond a byte
+    rng = np.random.default_rng(5)
+    cases.append((lc[rng.permutation(len(lc))], ls[rng.permutation(len(ls))], sharp, flat, np.zeros(6, np.float32)))
+    up = np.array([0.0, 0.0, 0.0, 300.0], np.float32)
+    cases.append((lc + up, ls + up, sharp + up, flat + up, np.zeros(6, np.float32)))
     for i, (a, b, c, d, p0) in enumerate(cases):
         s_g, pose_g, st_g = ctx.odometry_match(a, b, c, d, p0)
         s_t, pose_t, st_t = ctx.odometry_match(a, b, c, d, p0, trees=True)
@@ -95,6 +101,64 @@ def test_grid_search_equals_the_kd_tree_search(ctx, oracle, synth, small_problem
                (s_t, st_t.iterations, st_t.sweeps, st_t.n_rows, st_t.n_line, st_t.n_plane), i
         assert np.array_equal(bits(pose_g), bits(pose_t)), i
     ctx.map_set(small_problem["map_corner"], small_problem["map_surf"])
+
+
+def test_ring_windows_through_the_grids_equal_the_walk(pkg, ctx, synth, small_problem, monkeypatch):
+    """The second and third points of a correspondence (:366-403 / :430-477) found as nearest neighbours of a ring category
+    through the cell grids, against the same node walking the windows point by point (LSLAM_ODOM_LITERAL_WINDOW=1, read when the
+    node is made): same correspondences, hence the same poses bit for bit, over sweeps with long and short loops."""
+    sr = pkg.scan_registration
+    world = small_problem["world"]
+    grid = pkg.DeviceLaserOdometry(ctx)
+    monkeypatch.setenv("LSLAM_ODOM_LITERAL_WINDOW", "1")
+    walk = pkg.DeviceLaserOdometry(ctx)
+    monkeypatch.delenv("LSLAM_ODOM_LITERAL_WINDOW")
+    fs = sr.FeatureSet(ctx)
+    for step, k in enumerate((0, 2, 4, 3, 3, 1)):
+        reg, rr = sr.multiscan_register(ctx, _raw(synth, world, k, 32, 900), -30.67, 10.67, 32)
+        sr.extract_features_dev(ctx, reg, rr, fs)
+        T_g, T_w = grid.process(fs), walk.process(fs)
+        if step:
+            assert np.array_equal(bits(grid.transform), bits(walk.transform)), step
+            assert (grid.last_stats.iterations, grid.last_stats.n_rows) == (walk.last_stats.iterations, walk.last_stats.n_rows)
+            assert np.array_equal(bits(T_g), bits(T_w))
+        assert np.array_equal(bits(grid.last_surf), bits(walk.last_surf))
+    grid.close()
+    walk.close()
+    fs.close()
+
+
+def test_persistent_iterations_equal_the_launch_loop(pkg, ctx, synth, small_problem, monkeypatch):
+    """Up to five iterations per launch (odom_gn_kernel: resident workgroups, sentinel-slot exchange, replicated solve) against the
+    same node with one launch per step (LSLAM_ODOM_PERSISTENT=0), and against a node whose first exchange gives up
+    (LSLAM_ODOM_SPIN_LIMIT=0: the fallback a grid that is not co-resident takes): the same bits from all three."""
+    sr = pkg.scan_registration
+    world = small_problem["world"]
+    fused = pkg.DeviceLaserOdometry(ctx)
+    monkeypatch.setenv("LSLAM_ODOM_PERSISTENT", "0")
+    loop = pkg.DeviceLaserOdometry(ctx)
+    monkeypatch.delenv("LSLAM_ODOM_PERSISTENT")
+    monkeypatch.setenv("LSLAM_ODOM_SPIN_LIMIT", "0")
+    gives_up = pkg.DeviceLaserOdometry(ctx)
+    monkeypatch.delenv("LSLAM_ODOM_SPIN_LIMIT")
+    fs = sr.FeatureSet(ctx)
+    iters = set()
+    for step, k in enumerate((0, 1, 2, 3, 3, 2, 0)):
+        reg, rr = sr.multiscan_register(ctx, _raw(synth, world, k, 16, 900), -15.0, 15.0, 16)
+        sr.extract_features_dev(ctx, reg, rr, fs)
+        Ts = [n.process(fs) for n in (fused, loop, gives_up)]
+        if step:
+            iters.add(fused.last_stats.iterations)
+            for n in (loop, gives_up):
+                assert np.array_equal(bits(fused.transform), bits(n.transform)), step
+                assert (fused.last_stats.iterations, fused.last_stats.n_rows, fused.last_stats.sweeps, fused.last_stats.converged) == \
+                       (n.last_stats.iterations, n.last_stats.n_rows, n.last_stats.sweeps, n.last_stats.converged)
+            assert np.array_equal(bits(Ts[0]), bits(Ts[1])) and np.array_equal(bits(Ts[0]), bits(Ts[2]))
+        assert np.array_equal(bits(fused.last_surf), bits(loop.last_surf)) and np.array_equal(bits(fused.last_surf), bits(gives_up.last_surf))
+    assert len(iters) >= 2 and max(iters) == 25
+    for n in (fused, loop, gives_up):
+        n.close()
+    fs.close()
 
 
 def test_an_exact_tie_goes_through_the_trees(pkg, ctx, synth, small_problem):

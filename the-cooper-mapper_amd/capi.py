@@ -247,6 +247,10 @@ SYMBOLS = {
                                      c_float_p, C.c_size_t, c_float_p, C.c_size_t]),
     "lslam_odom_last_clouds": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t, c_float_p, C.c_size_t]),
     "lslam_odom_reset": (C.c_int, [C.c_void_p]),
+    "lslam_debug_odom_search": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_size_t]),
+    "lslam_odom_set_publish": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lslam_odom_last_view": (C.c_int, [C.c_void_p, C.POINTER(c_float_p), C.POINTER(C.c_size_t), C.POINTER(c_float_p),
+                                       C.POINTER(C.c_size_t)]),
     "lslam_pg_save_g2o": (C.c_int, [C.c_void_p, C.c_char_p]),
     "lslam_g2o_read": (C.c_int, [C.c_char_p, c_int32_p, c_double_p, c_int32_p, c_int32_p, c_double_p, c_double_p,
                                  c_int32_p]),

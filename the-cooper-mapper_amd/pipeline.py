@@ -56,7 +56,7 @@ class DeviceLaserOdometry:
     clouds arrive as a :class:`~.scan_registration.FeatureSet`, the last clouds and their search grids never leave the
     device, one wait per sweep.  Same numbers as :class:`LaserOdometry`, bit for bit (tests/test_gpu_odom.py)."""
 
-    def __init__(self, ctx, max_iterations=25, delta_t_abort=0.1, delta_r_abort=0.1, publish=True):
+    def __init__(self, ctx, max_iterations=25, delta_t_abort=0.1, delta_r_abort=0.1, publish=True, publish_buffers=8):
         import ctypes as C
         from .capi import LslamError
         self.ctx = ctx
@@ -65,7 +65,13 @@ class DeviceLaserOdometry:
         if rc < 0:
             raise LslamError(rc, ctx.lib.lslam_last_error().decode())
         self.h = h
-        self.publish = publish          # copy the last clouds out with every sweep (what the mapping node subscribes to)
+        # publish: the last clouds leave the device with every sweep (what the mapping node subscribes to) -- into a ring of
+        # page-locked buffers of the node; last_corner / last_surf are views of them, valid for publish_buffers more sweeps
+        self.publish = publish
+        if publish:
+            rc = ctx.lib.lslam_odom_set_publish(h, int(publish_buffers))
+            if rc < 0:
+                raise LslamError(rc, ctx.lib.lslam_last_error().decode())
         self.transform = np.zeros(6, np.float32)
         self.Tsum = np.eye(4, dtype=np.float32)
         self.last_corner = self.last_surf = None
@@ -79,16 +85,15 @@ class DeviceLaserOdometry:
         st, ost = LslamStats(), LslamOdomStats()
         tr, Ts = np.zeros(6, np.float32), np.zeros(16, np.float32)
         fp = lambda x: x.ctypes.data_as(c_float_p)
-        cnt = fset.counts()
-        if self.publish:
-            oc, os_ = np.empty((cnt["less_sharp"], 4), np.float32), np.empty((cnt["less_flat"], 4), np.float32)
-            rc = self.ctx.lib.lslam_odom_process(self.h, fset.h, fp(tr), fp(Ts), C.byref(st), C.byref(ost), fp(oc), len(oc), fp(os_),
-                                                 len(os_))
-        else:
-            oc = os_ = None
-            rc = self.ctx.lib.lslam_odom_process(self.h, fset.h, fp(tr), fp(Ts), C.byref(st), C.byref(ost), None, 0, None, 0)
+        rc = self.ctx.lib.lslam_odom_process(self.h, fset.h, fp(tr), fp(Ts), C.byref(st), C.byref(ost), None, 0, None, 0)
         if rc < 0:
             raise LslamError(rc, self.ctx.lib.lslam_last_error().decode())
+        oc = os_ = None
+        if self.publish:
+            pc, ps, nc, ns = c_float_p(), c_float_p(), C.c_size_t(), C.c_size_t()
+            self.ctx.lib.lslam_odom_last_view(self.h, C.byref(pc), C.byref(nc), C.byref(ps), C.byref(ns))
+            oc = np.ctypeslib.as_array(pc, shape=(nc.value, 4)) if nc.value else np.zeros((0, 4), np.float32)
+            os_ = np.ctypeslib.as_array(ps, shape=(ns.value, 4)) if ns.value else np.zeros((0, 4), np.float32)
         self.last_stats, self.last_ostats = st, ost
         self.transform, self.Tsum = tr, Ts.reshape(4, 4)
         self.last_corner, self.last_surf = oc, os_

@@ -408,6 +408,16 @@ def main():
         except Exception as e:
             out["sweep_pipeline"] = {"error": repr(e)}
     comm = None
+    if world == 1 and not args.shard_points and rank == 0:
+        # a world of one: the line still says that librccl loads on this box and that the library's communicator answers
+        # (ncclCommCount), with the version it found -- no collective is on the data path at N = 1
+        try:
+            c1 = make_comm(pkg, None, torch, 0, local_rank, 1)
+            out["ranks"]["rccl_ranks"] = c1.info()[1]
+            out["ranks"]["rccl_version"] = pkg.Comm.version()
+            c1.close()
+        except Exception as e:
+            out["ranks"]["rccl_error"] = repr(e)[:200]
     if (world > 1 or args.shard_points) and not args.headline_only:
         try:
             comm = make_comm(pkg, dist, torch, rank, local_rank, world)
@@ -418,6 +428,7 @@ def main():
         (n_ok,), _ = distmod.aggregate(dist, [ok], 0.0)  # all ranks or none
         if rank == 0 and comm is not None:
             out["ranks"]["rccl_ranks"] = comm.info()[1]  # ncclCommCount of the library's own communicator
+            out["ranks"]["rccl_version"] = pkg.Comm.version()
             out["ranks"]["rccl_allreduce_bytes"] = {"sharded_points_per_gn_iteration": 256, "pose_graph_per_linearisation": None}
         if int(round(n_ok)) != world:
             comm = None
@@ -513,8 +524,9 @@ def compact_line(out):
                      "alg_flops_per_point": roof.get("alg_flops_per_point"),
                      "nominal_hbm_frac_at_1700B_per_point": _pick(roof, "nominal_hbm", "frac"),
                      "measured_hbm_frac": _pick(roof, "measured_hbm", "frac"), "valu_issue_frac": _pick(roof, "valu_issue", "frac"),
-                     "valu_by_instruction_count_raw": _pick(roof, "valu_issue", "frac_by_instruction_count"),
-                     "valu_busy_raw": _pick(roof, "valu_issue", "frac_raw"),
+                     "valu_issue_frac_range": [_pick(roof, "valu_issue", "frac_all_fp32_class"), _pick(roof, "valu_issue", "frac_all_int3_class")],
+                     "valu_cycles_per_wave_instruction": _pick(roof, "valu_issue", "cycles_per_wave_instruction", "blend_11_to_8"),
+                     "wait_frac": _pick(roof, "counters", "wait_frac"),
                      "valu_insts_per_launch": _pick(roof, "valu_issue", "valu_wave_instructions_per_launch"),
                      "lanes_active": _pick(roof, "counters", "lanes_active"), "l2_hit_rate": _pick(roof, "counters", "l2_hit_rate"),
                      "counters_from": _pick(roof, "counters", "source_file")}
@@ -578,7 +590,8 @@ def compact_line(out):
         opt.append(("joint_lidar_stereo", {k: js.get(k) for k in ("ms_per_joint_scanmatch", "joint_rows_per_s", "n_gpus", "pose_diff_gpu_vs_cpu_m", "error") if k in js}))
     sp = out.get("sweep_pipeline") or {}
     if sp:
-        opt.append(("sweep_pipeline", {k: {"ms_per_sweep": _pick(sp, k, "ms_per_sweep"), "threads_ms_per_sweep": _pick(sp, k, "node_threads", "ms_per_sweep")}
+        opt.append(("sweep_pipeline", {k: {"ms_per_sweep": _pick(sp, k, "ms_per_sweep"), "threads_ms_per_sweep": _pick(sp, k, "node_threads", "ms_per_sweep"),
+                                           "odometry_ms": _pick(sp, k, "ms", "odometry"), "mapping_ms": _pick(sp, k, "ms", "mapping")}
                                        for k in ("vlp16", "rings64") if k in sp} or {"error": sp.get("error")}))
     for k, v in opt:
         c[k] = v
@@ -757,6 +770,15 @@ def sweep_roofline(pt_res, sweep_ms, sweep_launches, map_points, grid=True):
                            "frac": (compulsory / t_s / 1e9 if t_s > 0 else 0.0) / HBM_PEAK_GBS},
     }
     roof.update(pmc_counters(avg_sweep_ms))
+    # which resource the counters name: the issue port only when the priced instructions take >= 0.8 of the SIMDs' time
+    vi = (roof.get("valu_issue") or {}).get("frac")
+    wf = (roof.get("counters") or {}).get("wait_frac")
+    mh = (roof.get("measured_hbm") or {}).get("frac")
+    if vi is not None and vi >= 0.8:
+        roof["bound"] = "valu"
+    elif vi is not None:
+        roof["bound"] = "mixed: valu issue %.2f of the SIMDs' time, waves parked on memory %s of their life, hbm %s of peak -- no single resource saturated" % (
+            vi, "%.2f" % wf if wf is not None else "n/a", "%.2f" % mh if mh is not None else "n/a")
     return roof
 
 
@@ -775,8 +797,8 @@ def dry_run_report(world, ranks_counted, per_rank):
     roof = {"kernel": long, "kernel_short": "sweep_kernel", "bound": "valu", "achieved": 9.4, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": 0.06, "traffic": 4.35e9, "avg_kernel_ms": 6.0, "launches_timed": 200, "points_per_launch": 4.7e7,
             "alg_flops_per_point": FLOPS_PER_POINT_RESIDUAL, "accounting": long, "nominal_hbm": {"frac": 1.66, "note": long},
-            "measured_hbm": {"frac": 0.09, "source": long}, "valu_issue": {"frac": 0.99, "valu_wave_instructions_per_launch": 3.6e9, "source": long},
-            "counters": {"lanes_active": 43.0, "l2_hit_rate": 0.9, "source": long, "source_file": "profiles/r04_pmc_sweep.csv"}}
+            "measured_hbm": {"frac": 0.09, "source": long}, "valu_issue": {"frac": 0.65, "frac_all_fp32_class": 0.54, "frac_all_int3_class": 0.9, "cycles_per_wave_instruction": {"blend_11_to_8": 2.49}, "valu_wave_instructions_per_launch": 3.6e9, "source": long},
+            "counters": {"lanes_active": 43.0, "l2_hit_rate": 0.9, "wait_frac": 0.45, "source": long, "source_file": "profiles/r04_pmc_sweep.csv"}}
     mf = {"gpu_ms": {"surround_to_map": 1.2}, "gpu_ms_per_frame": 3.2, "gpu_ms_p99": 3.9, "gpu_ms_worst_frame": 4.0, "frames": 200,
           "overlapped": {"gpu_ms_per_frame": 2.3, "gpu_ms_p99": 2.9, "gpu_ms_worst_frame": 3.0, "schedule": long},
           "tree_build": {"frac": 0.018, "traffic": 5.9e8, "accounting": long}, "cpu_ms_per_frame": 900.0, "pose_diff_gpu_vs_cpu_m": 1e-6,
@@ -797,8 +819,8 @@ def dry_run_report(world, ranks_counted, per_rank):
                              "pose_diff_gpu_vs_cpu_m": 1e-6, "pose_diff_gpu_vs_cpu_rad": 1e-7, "iterations_equal": True, "rows_equal": True,
                              "all_cores": {"value": 1.0e7, "cores": 8, "kind": long[:80]}},
             "mapping_frame": mf, "mapping_frame_vlp16": mf, "mapping_frame_cubes": mf,
-            "sweep_pipeline": {"vlp16": {"ms_per_sweep": 3.0, "node_threads": {"ms_per_sweep": 2.0}},
-                               "rings64": {"ms_per_sweep": 5.0, "node_threads": {"ms_per_sweep": 3.0}}},
+            "sweep_pipeline": {"vlp16": {"ms_per_sweep": 3.0, "ms": {"odometry": 0.3, "mapping": 0.8}, "node_threads": {"ms_per_sweep": 2.0}},
+                               "rings64": {"ms_per_sweep": 5.0, "ms": {"odometry": 0.4, "mapping": 0.8}, "node_threads": {"ms_per_sweep": 3.0}}},
             "sharded_points": {"value": 1.0e9, "ms_per_scanmatch": 0.4, "n_gpus": world, "allreduce_bytes_per_iteration": 256},
             "joint_lidar_stereo": {"ms_per_joint_scanmatch": 0.5, "joint_rows_per_s": 1e9, "n_gpus": world, "parity": long},
             "pose_graph": {"lm_iters_per_s": 519.0, "lm_iterations": 100, "solver_iterations": 11000, "chi2_final": 1.0, "keyframes": 5000,
@@ -876,25 +898,30 @@ def pmc_counters(avg_sweep_ms):
     if "SQ_WAIT_ANY" in v and v.get("SQ_WAVE_CYCLES", 0) > 0:
         c["wait_frac"] = v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"]
     valu_issue = None
-    if "SQ_ACTIVE_INST_VALU" in v and cyc > 0:
-        # SQ_ACTIVE_INST_VALU sums, over the WAVES, the quad-cycles a wave has a vector-ALU instruction executing.  Waves of
-        # one SIMD overlap there -- the next wave's instruction issues while a multi-pass one (a transcendental, an fp64
-        # operation, the tail of an MFMA) of another wave still drains -- so the sum x 4 can EXCEED the SIMDs' cycles
-        # (1.1 on the clean passes): above one it is not a fraction of anything, it says the VALU pipes never idle.  The
-        # figure that is a fraction is the second one: wave-instructions x 4 cycles / (1 024 SIMDs x engine cycles)
-        raw = v["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 1024.0)
-        by_count = v["SQ_INSTS_VALU"] * 4.0 / (cyc * 1024.0) if "SQ_INSTS_VALU" in v else None
-        valu_issue = {"achieved": v["SQ_ACTIVE_INST_VALU"] * 4.0 / t_s, "peak": 1024.0 * 2.4e9, "unit": "SIMD issue cycles/s",
-                      "frac": min(1.0, raw), "frac_raw": raw, "frac_by_instruction_count": by_count,
+    if "SQ_INSTS_VALU" in v and cyc > 0:
+        # What the vector-ALU instructions of a sweep take of the SIMDs' time, priced with MEASURED costs per wave-instruction
+        # (tools/ubench_valu.hip -> profiles/rNN_ubench_valu.json: independent instructions, four waves per SIMD, s_memtime):
+        # the fp32 class (v_fma / v_fmac / v_mul / v_sub_f32: 1.95 shader cycles per wave64 instruction -- the guide's 2 on a
+        # SIMD-32) and the class of v_med3_u32 / v_and_or_b32 / v_cndmask_b32 with an SGPR mask / fp64 (3.24).  The grid
+        # probe's candidate loop -- the bulk of the kernel's instructions, csrc/lslam_grid.hpp -- is 19 instructions of which 8
+        # are of the second class (five v_med3_u32, v_and_or_b32, two v_cndmask_b32): the blend below.  A half-empty wavefront
+        # costs the same (measured: 32 active lanes = 64).  SQ_ACTIVE_INST_VALU (per-wave busy quad-cycles, which overlap between
+        # the waves of a SIMD and exceed the SIMDs' time) is kept as a raw figure only.
+        cost = valu_costs()
+        insts, simd_cyc = v["SQ_INSTS_VALU"], cyc * 1024.0
+        blend = (11.0 * cost["fp32"] + 8.0 * cost["int3"]) / 19.0
+        frac = insts * blend / simd_cyc
+        valu_issue = {"achieved": insts * blend / t_s, "peak": 1024.0 * 2.4e9, "unit": "SIMD cycles/s",
+                      "frac": frac, "frac_all_fp32_class": insts * cost["fp32"] / simd_cyc, "frac_all_int3_class": insts * cost["int3"] / simd_cyc,
+                      "cycles_per_wave_instruction": {"fp32_class": cost["fp32"], "med3_cndmask_fp64_class": cost["int3"], "blend_11_to_8": blend,
+                                                      "source": cost["source"]},
+                      "busy_quad_cycles_raw": v["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cyc if "SQ_ACTIVE_INST_VALU" in v else None,
                       "lanes_active_of_64": c.get("lanes_active"),
-                      "valu_wave_instructions_per_launch": v.get("SQ_INSTS_VALU"),
-                      "note": "frac = min(1, frac_raw).  frac_raw > 1: per-wave busy quad-cycles overlap between the waves of a SIMD "
-                              "(multi-pass instructions); frac_by_instruction_count = SQ_INSTS_VALU x 4 cycles / (1 024 SIMDs x "
-                              "GRBM_GUI_ACTIVE / 8) counts every vector instruction as one four-cycle issue and exceeds 1 as well once "
-                              "the launches hold no idle workgroups (round 5: later sweeps launch the running scans' workgroups only): "
-                              "an instruction whose upper or lower 32 lanes are all idle issues in two cycles.  Both say the same: the "
-                              "vector pipes do not idle; neither is a utilisation one could raise",
-                      "source": "SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), %s" % prof}
+                      "valu_wave_instructions_per_launch": insts,
+                      "note": "frac = SQ_INSTS_VALU x measured cycles per wave-instruction (11 : 8 blend of the two classes, the candidate "
+                              "loop's mix) / (1 024 SIMDs x GRBM_GUI_ACTIVE / 8); the two all-one-class figures bracket it.  Below 0.8 the "
+                              "issue port is not what bounds the kernel on its own: see wait_frac (waves parked on memory) beside it",
+                      "source": "SQ_INSTS_VALU, GRBM_GUI_ACTIVE of %s; costs of %s" % (prof, cost["source"])}
     for k in ("TA_BUSY_avr", "TCP_TOTAL_CACHE_ACCESSES_sum", "TA_FLAT_READ_WAVEFRONTS_sum", "TCP_TCC_READ_REQ_sum", "GRBM_GUI_ACTIVE",
               "TA_TA_BUSY_sum", "SQ_INSTS_VALU_MFMA_F32", "SQ_VALU_MFMA_BUSY_CYCLES"):
         if k in v:
@@ -906,6 +933,23 @@ def pmc_counters(avg_sweep_ms):
                               "sweep over all sweeps of the profiled run (the same population as avg_kernel_ms: a batch's later sweeps launch the "
                               "running scans' workgroups only); not measured in this run" % prof,
             "valu_issue": valu_issue, "measured_hbm": measured_hbm, "counters": c}
+
+
+def valu_costs():
+    """Measured SIMD cycles per wave64 vector instruction (tools/ubench_valu.hip, kept under profiles/): the fp32 class and
+    the v_med3 / v_cndmask / fp64 class, at four waves per SIMD (a saturated SIMD).  Falls back to the guide's 2 cycles."""
+    prof = newest_profile("ubench_valu.json")
+    out = {"fp32": 2.0, "int3": 2.0, "source": "MI355X_MICROARCH.md (2 cycles per wave64 v_fma_f32); no committed microbenchmark"}
+    if not prof:
+        return out
+    try:
+        rows = json.load(open(os.path.join(ROOT, prof)))["results"]
+        pick = lambda op: [r["simd_ticks_per_wave_instruction"] for r in rows if r["op"] == op and r["lanes"] == 64 and r["waves_per_simd"] == 4][0]
+        out = {"fp32": max(pick("v_fma_f32"), pick("v_fmac_f32"), pick("v_mul_f32")),
+               "int3": max(pick("v_med3_u32"), pick("v_and_or_b32"), pick("v_cndmask_b32 (sgpr pair)")), "source": prof}
+    except Exception as e:  # a malformed file must not take the bench down
+        out["source"] += " (%s unreadable: %r)" % (prof, e)
+    return out
 
 
 def sharded_points_leg(pkg, synth, distmod, dist, rank, world, ctx, comm, opts, np, args):
@@ -1408,41 +1452,57 @@ def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, 
 def sweep_pipeline_leg(pkg, synth, ctx, rings, np):
     """The whole per-sweep chain on the device, raw driver cloud in, map pose out:
     MultiScanRegistration::process -> extractFeatures -> LaserOdometry::process ->
-    LaserMapping::process (the-cooper-mapper_amd/pipeline.py), milliseconds per stage."""
+    LaserMapping::process (the-cooper-mapper_amd/pipeline.py), milliseconds per stage.  The feature clouds go from the
+    extraction kernels to the odometry node in HBM (lslam_fset), the node's last clouds stay there (lslam_odom); what
+    the mapping node subscribes to leaves through a ring of page-locked buffers."""
     lo, hi = (-15.0, 15.0) if rings == 16 else (-24.9, 2.0)
     world = synth.World(half_extent=175.0)
-    odo = pkg.LaserOdometry(ctx)
+    odo = pkg.DeviceLaserOdometry(ctx)
     mapper = pkg.LaserMapping(ctx, cube_dims=(21, 21, 11))
     sr = pkg.scan_registration
+    fsets = [sr.FeatureSet(ctx) for _ in range(2)]
     acc = {"register": 0.0, "extract": 0.0, "odometry": 0.0, "mapping": 0.0}
     n = 0
     raws = []
-    for k in range(28):  # consecutive sweeps of a moving sensor: 7 for the stage timings, all for the threads
+    for k in range(28):  # consecutive sweeps of a moving sensor
         gt = (0.0, 0.0, 0.3 + 0.01 * k, 3.0 + 0.4 * k, -2.0 + 0.15 * k, synth.SENSOR_HEIGHT)
         _, _, _, cloud, _ = synth.make_scan(world, rings, 1800, gt_pose=gt, seed=300 + k, full=True)
         ring = np.floor(cloud[:, 3]).astype(np.int64)
         raws.append(cloud[np.lexsort((ring, -(cloud[:, 3] - ring)))])  # arrival order of a clockwise sweep
-    for k in range(7):
-        raw = raws[k]
+    per_sweep = []
+    warm = 4  # the first sweeps size every buffer of the three nodes (page-locked rings, map arrays)
+    for k, raw in enumerate(raws):
         quiet_gc()
         t0 = time.perf_counter()
         reg, rr = sr.multiscan_register(ctx, raw, lo, hi, rings)
         t1 = time.perf_counter()
-        f = sr.extract_features(ctx, reg, rr)
+        sr.extract_features_dev(ctx, reg, rr, fsets[k & 1])
         t2 = time.perf_counter()
-        T = odo.process(f["sharp"], f["less_sharp"], f["flat"], f["less_flat"])
+        T = odo.process(fsets[k & 1])
         t3 = time.perf_counter()
         if T is not None:
             M = mapper.process(odo.last_corner, odo.last_surf, T)
         t4 = time.perf_counter()
-        if k >= 2:
+        if k >= warm:
             for key, d in zip(acc, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
                 acc[key] += d
+            per_sweep.append({"odometry_ms": 1e3 * (t3 - t2), "iterations": int(odo.last_stats.iterations),
+                              "loop_gpu_ms": float(odo.last_stats.gpu_ms_total)})
             n += 1
     mapper.feature_map.close()
+    fallbacks = int(odo.last_ostats.tree_fallbacks)
+    odo.close()
+    for f in fsets:
+        f.close()
     ms = {k: 1e3 * v / n for k, v in acc.items()}
+    its = [p["iterations"] for p in per_sweep]
     res = {"rings": rings, "points_per_sweep": int(len(raw)), "ms": ms, "ms_per_sweep": sum(ms.values()),
            "sweeps_per_s": 1e3 / sum(ms.values()), "sweeps_timed": n,
+           "odometry": {"node": "device-resident (lslam_odom): hashed cell grids, five iterations per launch",
+                        "iterations_per_sweep": its, "ms_by_sweep": [round(p["odometry_ms"], 4) for p in per_sweep],
+                        "loop_gpu_ms_by_sweep": [round(p["loop_gpu_ms"], 4) for p in per_sweep],
+                        "ms_p50": float(np.median([p["odometry_ms"] for p in per_sweep])),
+                        "ms_worst": float(max(p["odometry_ms"] for p in per_sweep)), "tree_fallbacks": fallbacks},
            "travelled_m": float(np.linalg.norm(M[:3, 3]))}
     try:
         res["node_threads"] = sweep_pipeline_threads(pkg, synth, rings, np, lo, hi, raws)
@@ -1456,17 +1516,22 @@ def sweep_pipeline_threads(pkg, synth, rings, np, lo, hi, raws):
     nodelets with their own threads (nodelets.xml; LaserOdometry.cpp spin(), LaserMapping.cpp:27-37),
     joined by the /laser_cloud_* and /laser_odom_to_init topics.  Three host threads with a context each
     (one call in flight per context), queues between them; ctypes releases the GIL during the calls, the
-    three streams share the GPU.  Throughput of the chain, not the latency of a sweep."""
+    three streams share the GPU.  Registration -> odometry carries feature sets in HBM (a pool of them goes
+    round), odometry -> mapping page-locked views.  Throughput of the chain, not the latency of a sweep."""
     import queue
     import threading
     sweeps = len(raws)
     ctx_r, ctx_o, ctx_m = pkg.Context(0), pkg.Context(0), pkg.Context(0)
-    odo = pkg.LaserOdometry(ctx_o)
+    odo = pkg.DeviceLaserOdometry(ctx_o, publish_buffers=8)
     mapper = pkg.LaserMapping(ctx_m, cube_dims=(21, 21, 11))
     sr = pkg.scan_registration
     q1, q2 = queue.Queue(maxsize=2), queue.Queue(maxsize=2)
+    pool = queue.Queue()
+    fsets = [sr.FeatureSet(ctx_r) for _ in range(5)]  # one being filled, two queued, one being consumed, one spare
+    for f in fsets:
+        pool.put(f)
     out, err = [], []
-    warm = 3
+    warm = 8  # every feature set of the pool, every buffer of the publishing ring and the map's arrays have been sized by then
     stamps = {}
 
     def registration():  # MultiScanRegistration nodelet: raw sweep -> feature clouds
@@ -1475,7 +1540,9 @@ def sweep_pipeline_threads(pkg, synth, rings, np, lo, hi, raws):
                 if k == warm:
                     stamps["t0"] = time.perf_counter()
                 reg, rr = sr.multiscan_register(ctx_r, raw, lo, hi, rings)
-                q1.put(sr.extract_features(ctx_r, reg, rr))
+                f = pool.get()
+                sr.extract_features_dev(ctx_r, reg, rr, f)
+                q1.put(f)
         except Exception as e:
             err.append(e)
         q1.put(None)
@@ -1486,7 +1553,8 @@ def sweep_pipeline_threads(pkg, synth, rings, np, lo, hi, raws):
                 f = q1.get()
                 if f is None:
                     break
-                T = odo.process(f["sharp"], f["less_sharp"], f["flat"], f["less_flat"])
+                T = odo.process(f)
+                pool.put(f)
                 if T is not None:
                     q2.put((odo.last_corner, odo.last_surf, T))
         except Exception as e:
@@ -1510,6 +1578,9 @@ def sweep_pipeline_threads(pkg, synth, rings, np, lo, hi, raws):
     for t in th:
         t.join()
     mapper.feature_map.close()
+    odo.close()
+    for f in fsets:
+        f.close()
     for c in (ctx_r, ctx_o, ctx_m):
         c.close()
     if err:

@@ -641,6 +641,8 @@ int lslam_comm_unique_id(uint8_t id[LSLAM_COMM_ID_BYTES]);
 int lslam_comm_create(int device, const uint8_t id[LSLAM_COMM_ID_BYTES], int32_t rank, int32_t world,
                       lslam_comm **out);
 void lslam_comm_destroy(lslam_comm *comm);
+/* ncclGetVersion of the librccl the library loaded (e.g. 22606 = 2.26.6) */
+int lslam_comm_version(int32_t *version);
 /* rank and rank count as the RCCL communicator itself reports them (ncclCommUserRank, ncclCommCount) */
 int lslam_comm_info(const lslam_comm *comm, int32_t *rank, int32_t *world);
 /* In-place SUM of `count` doubles at DEVICE address buf over all ranks, enqueued on hip_stream. */

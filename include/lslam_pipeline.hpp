@@ -54,59 +54,65 @@ inline void identity4(float T[16]) {
 
 // LaserOdometry (variant B, BASELINE configs[0]): first sweep initialises the "last" clouds; afterwards
 // scanMatch against them with the persistent _transform as the initial guess, _Tsum = _Tsum * transform,
-// transformToEnd of the less-sharp / less-flat clouds, which become the next "last" clouds (their kd-trees are
-// refreshed only when they hold > 10 / > 100 points, LaserOdometry.cpp:321-324).
+// transformToEnd of the less-sharp / less-flat clouds, which become the next "last" clouds
+// (LaserOdometry.cpp:288-326).  The node's state lives in HBM (lslam_odom, include/lslam_c.h): the last clouds and
+// their search grids never leave the device; process() takes the sweep's four clouds from the host (one upload),
+// processFeatureSet() takes them where lslam_extract_features_dev left them.
 class LaserOdometry {
 public:
   explicit LaserOdometry(lslam_ctx *ctx, int maxIterations = 25, float deltaTAbort = 0.1f, float deltaRAbort = 0.1f)
-      : _ctx(ctx), _maxIterations(maxIterations), _deltaTAbort(deltaTAbort), _deltaRAbort(deltaRAbort), _systemInited(false) {
+      : _ctx(ctx), _od(nullptr), _fs(nullptr), _matched(false) {
     std::memset(_transform, 0, sizeof(_transform));
     detail::identity4(_Tsum);
     std::memset(&_last, 0, sizeof(_last));
+    std::memset(&_ostats, 0, sizeof(_ostats));
+    if (lslam_odom_create(ctx, maxIterations, deltaTAbort, deltaRAbort, &_od) != LSLAM_OK ||
+        lslam_fset_create(ctx, &_fs) != LSLAM_OK)
+      _err = lslam_last_error();
   }
+  ~LaserOdometry() {
+    if (_od) lslam_odom_destroy(_od);
+    if (_fs) lslam_fset_destroy(_fs);
+  }
+  LaserOdometry(const LaserOdometry &) = delete;
+  LaserOdometry &operator=(const LaserOdometry &) = delete;
   // LaserOdometry.cpp:288-326.  Returns false for the first sweep (nothing to match against) and on a backend
   // error; Tsum() is the accumulated sweep-to-sweep motion, lastCornerCloud()/lastSurfaceCloud() the clouds the
   // mapping node receives (/laser_cloud_corner_last, /laser_cloud_surf_last), packed {x,y,z,intensity}.
   template <typename Cloud>
   bool process(const Cloud &cornerPointsSharp, const Cloud &cornerPointsLessSharp, const Cloud &surfPointsFlat,
                const Cloud &surfPointsLessFlat) {
-    std::vector<float> less_sharp, less_flat;
-    detail::pack_xyzi(cornerPointsLessSharp, less_sharp);
-    detail::pack_xyzi(surfPointsLessFlat, less_flat);
-    if (!_systemInited) {  // :295-303
-      _lastCorner = less_sharp;
-      _lastSurf = less_flat;
-      _treeCorner = less_sharp;
-      _treeSurf = less_flat;
-      _systemInited = true;
-      return false;
-    }
-    std::vector<float> sharp, flat;
+    if (!_od || !_fs) return false;
+    std::vector<float> sharp, less_sharp, flat, less_flat;
     detail::pack_xyzi(cornerPointsSharp, sharp);
+    detail::pack_xyzi(cornerPointsLessSharp, less_sharp);
     detail::pack_xyzi(surfPointsFlat, flat);
-    const int st = lslam_odometry_match(_ctx, _treeCorner.data(), _treeCorner.size() / 4, _treeSurf.data(), _treeSurf.size() / 4,
-                                        sharp.data(), sharp.size() / 4, flat.data(), flat.size() / 4, 16, _transform,
-                                        _maxIterations, _deltaTAbort, _deltaRAbort, &_last);
+    detail::pack_xyzi(surfPointsLessFlat, less_flat);
+    if (lslam_fset_upload(_ctx, _fs, sharp.data(), sharp.size() / 4, less_sharp.data(), less_sharp.size() / 4, flat.data(),
+                          flat.size() / 4, less_flat.data(), less_flat.size() / 4, 16) < 0)
+      return fail();
+    return processFeatureSet(_fs);
+  }
+  // the same on a feature set that is in HBM already
+  bool processFeatureSet(lslam_fset *fs) {
+    if (!_od) return false;
+    size_t n[4];
+    if (lslam_fset_counts(fs, n) < 0) return fail();
+    _lastCorner.resize(4 * n[1]);
+    _lastSurf.resize(4 * n[3]);
+    const uint64_t before = _ostats.sweeps;
+    const int st = lslam_odom_process(_od, fs, _transform, _Tsum, &_last, &_ostats, _lastCorner.data(), n[1], _lastSurf.data(), n[3]);
     if (st < 0) return fail();
-    float T[16], S[16];
-    lslam_pose_to_isometry(_transform, T);  // transformUpdate, :649-653
-    detail::mat_mul4(_Tsum, T, S);
-    std::memcpy(_Tsum, S, sizeof(S));
-    if (lslam_transform_to_end(_ctx, less_sharp.data(), less_sharp.size() / 4, 16, _transform) < 0) return fail();  // :312-313
-    if (lslam_transform_to_end(_ctx, less_flat.data(), less_flat.size() / 4, 16, _transform) < 0) return fail();
-    _lastCorner.swap(less_sharp);  // :315-316
-    _lastSurf.swap(less_flat);
-    if (_lastCorner.size() / 4 > 10 && _lastSurf.size() / 4 > 100) {  // :321-324
-      _treeCorner = _lastCorner;
-      _treeSurf = _lastSurf;
-    }
-    return true;
+    _matched = _ostats.matched != 0;
+    return before != 0;  // the first sweep only initialises (:295-303)
   }
   const float *Tsum() const { return _Tsum; }
   const float *transform() const { return _transform; }
   const std::vector<float> &lastCornerCloud() const { return _lastCorner; }
   const std::vector<float> &lastSurfaceCloud() const { return _lastSurf; }
   const lslam_stats &lastStats() const { return _last; }
+  const lslam_odom_stats &nodeStats() const { return _ostats; }
+  bool matched() const { return _matched; }  // false: the last clouds were too small to match against (:337)
   const std::string &lastError() const { return _err; }
 
 private:
@@ -115,13 +121,14 @@ private:
     return false;
   }
   lslam_ctx *_ctx;
-  int _maxIterations;
-  float _deltaTAbort, _deltaRAbort;
-  bool _systemInited;
+  lslam_odom *_od;
+  lslam_fset *_fs;
+  bool _matched;
   float _transform[6];  // _transform: sweep-to-sweep motion, kept as the next initial guess
   float _Tsum[16];      // _Tsum
-  std::vector<float> _lastCorner, _lastSurf, _treeCorner, _treeSurf;
+  std::vector<float> _lastCorner, _lastSurf;
   lslam_stats _last;
+  lslam_odom_stats _ostats;
   std::string _err;
 };
 

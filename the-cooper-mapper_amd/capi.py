@@ -272,6 +272,7 @@ SYMBOLS = {
     "lslam_comm_unique_id": (C.c_int, [c_uint8_p]),
     "lslam_comm_create": (C.c_int, [C.c_int, c_uint8_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "lslam_comm_destroy": (None, [C.c_void_p]),
+    "lslam_comm_version": (C.c_int, [c_int32_p]),
     "lslam_comm_info": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p]),
     "lslam_debug_grid_launches": (C.c_uint64, [C.c_void_p]),
     "lslam_debug_grid_wide_launches": (C.c_uint64, [C.c_void_p]),

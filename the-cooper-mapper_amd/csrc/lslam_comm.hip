@@ -36,6 +36,7 @@ struct Rccl {
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   decltype(&ncclCommCount) CommCount = nullptr;
   decltype(&ncclCommUserRank) CommUserRank = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;
   bool ok = false;
 };
 
@@ -58,7 +59,7 @@ bool load_rccl() {
   g_rccl.f = reinterpret_cast<decltype(g_rccl.f)>(dlsym(g_rccl.handle, "nccl" #f)); \
   if (!g_rccl.f) { lslam::set_error("librccl lacks nccl" #f); return false; }
   SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(AllReduce) SYM(GetErrorString) SYM(CommCount) SYM(CommUserRank)
-  SYM(Broadcast) SYM(GroupStart) SYM(GroupEnd)
+  SYM(Broadcast) SYM(GroupStart) SYM(GroupEnd) SYM(GetVersion)
 #undef SYM
   g_rccl.ok = true;
   return true;
@@ -162,6 +163,19 @@ void lslam_comm_destroy(lslam_comm *c) {
 
 // what the COMMUNICATOR says (ncclCommUserRank / ncclCommCount), not what it was asked to be: the rank count `bench.py --gpus N`
 // prints as `rccl_ranks`
+int lslam_comm_version(int32_t *version) {
+  if (!version) {
+    lslam::set_error("bad version argument");
+    return LSLAM_ERR_INVALID;
+  }
+  if (!load_rccl()) return LSLAM_ERR_COMM;
+  int v = 0;
+  const ncclResult_t r = g_rccl.GetVersion(&v);
+  if (r != ncclSuccess) return nccl_fail("ncclGetVersion", r);
+  *version = (int32_t)v;
+  return LSLAM_OK;
+}
+
 int lslam_comm_info(const lslam_comm *c, int32_t *rank, int32_t *world) {
   if (!c || !c->comm || !g_rccl.ok) return LSLAM_ERR_INVALID;
   int r = -1, w = -1;

@@ -362,6 +362,8 @@ struct lslam_fset {
   float4 *buf = nullptr;
   size_t cap = 0;  // points per slice
   size_t counts[4] = {0, 0, 0, 0};
+  float4 *h_stage = nullptr;  // page-locked staging of lslam_fset_upload (grow-only)
+  size_t h_stage_cap = 0;
   float4 *list(int k) const { return buf + 16 + (size_t)k * cap; }
 };
 namespace lslam {

@@ -1275,10 +1275,9 @@ int lslam_fset_create(lslam_ctx *ctx, lslam_fset **out) {
 
 void lslam_fset_destroy(lslam_fset *fs) {
   if (!fs) return;
-  if (fs->buf) {
-    (void)hipSetDevice(fs->device);
-    (void)hipFree(fs->buf);
-  }
+  (void)hipSetDevice(fs->device);
+  if (fs->buf) (void)hipFree(fs->buf);
+  if (fs->h_stage) (void)hipHostFree(fs->h_stage);
   delete fs;
 }
 
@@ -1303,12 +1302,11 @@ int lslam_fset_upload(lslam_ctx *ctx, lslam_fset *fs, const void *sharp, size_t 
   const void *src[4] = {sharp, less_sharp, flat, less_flat};
   const size_t n[4] = {n_sharp, n_less_sharp, n_flat, n_less_flat};
   const size_t total = n_sharp + n_less_sharp + n_flat + n_less_flat;
-  float4 *stage = nullptr;
-  OD_TRY(hipHostMalloc((void **)&stage, (total + 1) * sizeof(float4), hipHostMallocDefault));
+  int rc = reserve_pinned(fs->h_stage, fs->h_stage_cap, total + 1);
+  if (rc) return rc;
   hipStream_t s = lslam::ctx_stream(ctx);
-  int rc = upload_lists(s, fs, stage, src, n, stride_bytes);
+  rc = upload_lists(s, fs, fs->h_stage, src, n, stride_bytes);
   const hipError_t e = hipStreamSynchronize(s);
-  (void)hipHostFree(stage);
   if (rc) return rc;
   OD_TRY(e);
   return LSLAM_OK;

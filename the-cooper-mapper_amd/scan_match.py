@@ -42,6 +42,16 @@ class Comm:
             raise LslamError(rc, lib.lslam_last_error().decode())
         return buf
 
+    @staticmethod
+    def version():
+        """ncclGetVersion of the librccl the library loaded (22606 = 2.26.6)."""
+        lib = load_library()
+        v = C.c_int32(0)
+        rc = lib.lslam_comm_version(C.byref(v))
+        if rc != 0:
+            raise LslamError(rc, lib.lslam_last_error().decode())
+        return int(v.value)
+
     def __init__(self, device, unique_id, rank, world):
         self.lib = load_library()
         uid = np.ascontiguousarray(unique_id, np.uint8).reshape(128)

@@ -214,6 +214,11 @@ size_t lslam_sizeof_stats(void);
 int lslam_map_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const void *surf,
                   size_t n_surf, size_t stride_bytes);
 int lslam_map_info_get(const lslam_ctx *ctx, lslam_map_info *info);
+/* Which map is resident: a number that changes whenever ANY entry point replaces or drops the context's map (lslam_map_set,
+ * lslam_cubemap_set, lslam_fmap_surround_to_map / _to_cubemap, lslam_odometry_match_trees, lslam_icp_align, a failed tree build
+ * ...), 0 while there is none.  A caller that skips an upload because "my clouds are resident" (ScanMatch::setReferenceEpoch,
+ * include/lslam_scan_match.hpp) records it after its map set and compares before every reuse. */
+uint64_t lslam_map_epoch(const lslam_ctx *ctx);
 
 /* Deferred kd-trees.  on != 0: a map set from now on -- one that is already in HBM (lslam_fmap_surround_to_map: the mapping
  * node's per-frame map, LaserMatcher.cpp:303-331, where the reference rebuilds both trees every frame -- quirk Q4) or host
@@ -737,9 +742,10 @@ int32_t lslam_pg_row_sharded_solves(const lslam_pg *pg); /* damped solves that t
  * and are summed in rank order on every rank (same bits everywhere).  A host with its own transport registers a second
  * callback type: in-place, segment r of buf = doubles [offsets[r], offsets[r + 1]), valid on rank r on entry and on every
  * rank on return; complete when it returns.  Ranges that are not the canonical partition, or no gather transport: the
- * all-reduce form.  Which form is taken is ONE decision of all ranks: the first solve after a change of range or transport
- * sums a "my range is not the canonical one" flag over the ranks (one scalar all-reduce through the linearisation's
- * transport) and every rank follows the result -- a rank cannot see the others' ranges.  At most 64 ranks. */
+ * all-reduce form.  Which form is taken is ONE decision of all ranks, taken by every row-sharded solve: each rank sums a
+ * "not from me" flag over the ranks -- raised without a gather transport or with a range that is not the canonical one -- (one
+ * scalar all-reduce through the linearisation's transport) and follows the result: a rank cannot see the others' ranges or
+ * transports, and every rank takes part in that sum whatever its own setting.  At most 64 ranks. */
 typedef void (*lslam_allgatherv_fn)(void *user, double *buf, const int64_t *offsets, int32_t world);
 int lslam_pg_set_row_gather(lslam_pg *pg, lslam_allgatherv_fn fn, void *user, int32_t rank, int32_t world);
 int32_t lslam_pg_row_gathered_solves(const lslam_pg *pg); /* ... of which exchanged by all-gather */

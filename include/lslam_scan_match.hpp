@@ -214,15 +214,22 @@ private:
       _fail_match_count++;
       return false;
     }
+    // "my clouds are resident": the caller's promise (same epoch, same buffers) AND the library's word that the map this
+    // object set is still the context's map -- another user of the context (a FeatureMap, lslam_map_set, an odometry or ICP
+    // call) replaces it without this object hearing of it
     const bool resident = _ref_epoch != 0 && _res_epoch == _ref_epoch && _res_rc == rc && _res_rs == rs && _res_nrc == nrc &&
-                          _res_nrs == nrs && _res_stride == ref_stride;
+                          _res_nrs == nrs && _res_stride == ref_stride && _res_map != 0 && lslam_map_epoch(_ctx) == _res_map;
     const int st = resident ? lslam_scanmatch_scan(_ctx, c, nc, s, ns, stride, pose, &_opts, &_last)
                             : lslam_scanmatch_full(_ctx, rc, nrc, rs, nrs, ref_stride, c, nc, s, ns, stride, pose, &_opts, &_last);
     // what is resident now: these clouds, unless the call failed before or inside the map set
     if (!resident) {
       const bool map_set = st >= 0 && st != LSLAM_TOO_FEW_REF;
       _res_epoch = map_set ? _ref_epoch : 0;
+      _res_map = map_set ? lslam_map_epoch(_ctx) : 0;
       _res_rc = rc; _res_rs = rs; _res_nrc = nrc; _res_nrs = nrs; _res_stride = ref_stride;
+    } else if (st < 0) {
+      _res_epoch = 0;  // a resident call that failed: whatever is in the context now, the next call uploads
+      _res_map = 0;
     }
     if (st < 0) {
       std::cout << "[ScanMatch] backend error: " << lslam_last_error() << std::endl;
@@ -255,6 +262,7 @@ private:
   lslam_stats _last{};
   std::vector<float> _ds[4];  // _referenceCornerCloudDS, _referenceSurfCloudDS, _CornerCloudDS, _SurfCloudDS
   unsigned long long _ref_epoch = 0, _res_epoch = 0;  // setReferenceEpoch: the caller's promise / what the resident map was set under
+  uint64_t _res_map = 0;                              // lslam_map_epoch right after this object's map set (0: nothing resident)
   const void *_res_rc = nullptr, *_res_rs = nullptr;
   size_t _res_nrc = 0, _res_nrs = 0, _res_stride = 0;
   double _total_score;

@@ -1051,3 +1051,29 @@ def test_survey_8b_alias_exports(ctx, pkg, synth, small_problem):
                                           dp(info), 0, 5, C.byref(pst))
     assert rc >= 0 and pst.iterations == pg.last_stats.iterations
     assert np.array_equal(poses, want)
+
+
+def test_reference_epoch_residency_follows_the_library(pkg, oracle, small_problem):
+    """ScanMatch::setReferenceEpoch skips the map upload while the caller's clouds are resident -- which is the LIBRARY's to say
+    (lslam_map_epoch): a map set by another path on the same context (setMap here; a FeatureMap, an odometry or ICP call do the
+    same) drops the residency, and the next call uploads again instead of matching against the wrong map."""
+    pr = small_problem
+    sm = pkg.ScanMatch(10)
+    sm.setReferenceEpoch(7)
+    lib, h = sm.ctx.lib, sm.ctx.h
+    ok0, pose0 = sm.scanMatchScan(pr["map_corner"], pr["map_surf"], pr["corner"], pr["surf"], pr["init_pose"])
+    e0 = lib.lslam_map_epoch(h)
+    assert e0 != 0
+    ok1, pose1 = sm.scanMatchScan(pr["map_corner"], pr["map_surf"], pr["corner"], pr["surf"], pr["init_pose"])
+    assert lib.lslam_map_epoch(h) == e0 and np.array_equal(bits(pose0), bits(pose1))  # resident: no map set
+    # somebody else's map on the same context: half the world away
+    far = np.array([500.0, 0.0, 0.0, 0.0], np.float32)
+    sm.ctx.map_set(pr["map_corner"] + far, pr["map_surf"] + far)
+    assert lib.lslam_map_epoch(h) != e0
+    ok2, pose2 = sm.scanMatchScan(pr["map_corner"], pr["map_surf"], pr["corner"], pr["surf"], pr["init_pose"])
+    assert ok2 == ok0 and np.array_equal(bits(pose0), bits(pose2))  # uploaded again: the same answer, not a match against the far map
+    e2 = lib.lslam_map_epoch(h)
+    assert e2 not in (0, e0)
+    sm.scanMatchScan(pr["map_corner"], pr["map_surf"], pr["corner"], pr["surf"], pr["init_pose"])
+    assert lib.lslam_map_epoch(h) == e2  # and resident again
+    sm.close() if hasattr(sm, "close") else None

@@ -143,6 +143,7 @@ SYMBOLS = {
     "lslam_sizeof_opts": (C.c_size_t, []),
     "lslam_sizeof_stats": (C.c_size_t, []),
     "lslam_map_set": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t]),
+    "lslam_map_epoch": (C.c_uint64, [C.c_void_p]),
     "lslam_map_info_get": (C.c_int, [C.c_void_p, C.POINTER(LslamMapInfo)]),
     "lslam_cubemap_set": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
                                     C.c_float, c_int32_p, c_int32_p]),
@@ -341,6 +342,9 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.lslam_abi_version() < 0:
+        raise ImportError("%s was built with LSLAM_EXP_* timing-experiment macros (wrong results on purpose): not a product library; "
+                          "LSLAM_ALLOW_EXPERIMENT_BUILD=1 lets the A/B scripts load it" % path)
     # the ctypes mirrors of the ABI's structs must be the library's: a stale .so (or a stale mirror) fails here, loudly
     if lib.lslam_sizeof_opts() != C.sizeof(LslamOpts) or lib.lslam_sizeof_stats() != C.sizeof(LslamStats):
         raise ImportError("%s does not match this package's struct layouts (lslam_opts %d vs %d bytes, lslam_stats %d vs %d): rebuild it"

@@ -586,7 +586,13 @@ extern "C" {
 
 const char *lslam_last_error(void) { return g_err.c_str(); }
 
-int lslam_abi_version(void) { return LSLAM_ABI_VERSION; }
+int lslam_abi_version(void) {
+#if LSLAM_EXPERIMENT_BUILD
+  const char *ok = std::getenv("LSLAM_ALLOW_EXPERIMENT_BUILD");  // (a timing build of tools/build_variant.sh: not a product)
+  if (!(ok && ok[0] == '1')) return -LSLAM_ABI_VERSION;
+#endif
+  return LSLAM_ABI_VERSION;
+}
 size_t lslam_sizeof_opts(void) { return sizeof(lslam_opts); }
 size_t lslam_sizeof_stats(void) { return sizeof(lslam_stats); }
 
@@ -704,6 +710,8 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   ctx->ks.release();
   ctx->bbox6.release(); ctx->wide_p.release(); ctx->wide_d.release(); ctx->wide_off.release();
   ctx->xchg.release();
+  ctx->active_blocks.release(); ctx->d_active_cnt.release(); ctx->fit_ids.release(); ctx->fit_val.release();
+  ctx->cert_stats.release();
   ctx->gnp_slots.release(); ctx->gnp_bar.release();
   ctx->q.release(); ctx->blocks.release(); ctx->probs.release(); ctx->partials.release(); ctx->stack_ovf.release();
   ctx->t_idx.release(); ctx->t_d2.release(); ctx->t_coeff.release(); ctx->t_flags.release();
@@ -1423,6 +1431,15 @@ int lslam_cubemap_set(lslam_ctx *ctx, const void *corner, size_t n_corner, const
   return LSLAM_OK;
 }
 
+uint64_t lslam_map_epoch(const lslam_ctx *ctx) {
+  if (!ctx) return 0;
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    if (!g_live.count(ctx)) return 0;
+  }
+  return ctx->have_map ? ctx->map_epoch : 0;
+}
+
 int lslam_map_info_get(const lslam_ctx *ctx, lslam_map_info *info) {
   if (!ctx || !info) return LSLAM_ERR_INVALID;
   if (!ctx->have_map) return LSLAM_ERR_NO_MAP;
@@ -1539,6 +1556,11 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
   const size_t off_probs = ((nb ? nb : 1) * sizeof(BlockDesc) + 15) & ~(size_t)15;
   const size_t off_groups = (off_probs + (size_t)n_scans * sizeof(ProbBlocks) + 15) & ~(size_t)15;
   const size_t tab_bytes = off_groups + n_groups_tab * sizeof(GroupDesc);
+  if (tab_bytes > ctx->scan_tables.cap) {  // the three views point into the allocation reserve() is about to free
+    ctx->blocks.release();
+    ctx->probs.release();
+    ctx->groups.release();
+  }
   HIP_TRY(ctx->scan_tables.reserve(tab_bytes));
   ctx->blocks.adopt(reinterpret_cast<BlockDesc *>(ctx->scan_tables.p), nb ? nb : 1);
   ctx->probs.adopt(reinterpret_cast<ProbBlocks *>(ctx->scan_tables.p + off_probs), (size_t)n_scans);

@@ -261,6 +261,10 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_ring_kernel(FxArgs a) {
       fit_sides();
       for (int t = tid; t < n_need; t += FX_BLOCK)
         __hip_atomic_store(a.cls_g + start + need[t], class_of(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // every thread's own stores out at agent scope BEFORE the barrier: thread 0's release below orders thread 0's stores, and
+      // the barrier's workgroup-scope fence does not wait for the other wavefronts' stores to reach the L2 -- a ring workgroup
+      // on another CU could see the count and still load a stale class
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(a.ready + ring, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       return;

@@ -9,6 +9,17 @@
 #include "lslam_device.hpp"
 #include "lslam_grid.hpp"
 
+// Timing experiments (tools/build_variant.sh, tools/ab_variants.sh) compile the product's own kernels with LSLAM_EXP_* macros,
+// several of which give WRONG RESULTS on purpose (a fit skipped, a pass dropped, a load halved).  Such a library identifies
+// itself: lslam_abi_version() answers with the NEGATIVE version, so every caller that checks the ABI (the C++ mirrors, the
+// ctypes binding) refuses it -- unless the process says LSLAM_ALLOW_EXPERIMENT_BUILD=1, as the A/B scripts do.
+#if defined(LSLAM_EXP_COUNT_NOHINT) || defined(LSLAM_EXP_LOAD2) || defined(LSLAM_EXP_LOAD_TWICE) || defined(LSLAM_EXP_NO_ACC) || \
+    defined(LSLAM_EXP_NO_FIT) || defined(LSLAM_EXP_NO_PASS2) || defined(LSLAM_EXP_PROCESS_TWICE) || defined(LSLAM_EXP_SETUP_TWICE)
+#define LSLAM_EXPERIMENT_BUILD 1
+#else
+#define LSLAM_EXPERIMENT_BUILD 0
+#endif
+
 namespace lslam {
 
 // Columns of one block's partial-sum record (and of the reduced sums).

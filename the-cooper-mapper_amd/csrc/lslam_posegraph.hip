@@ -1889,27 +1889,26 @@ int solve(lslam_pg *pg, double lambda, int max_cg, double tol, int *iters_out) {
     int g_rank = 0, g_world = 1;
     bool gather = pg->gather_transport(&g_rank, &g_world) && g_world >= 1 && g_world <= lslam_pg::RS_MAX_WORLD;
     std::vector<int64_t> z_offs, s_offs;
-    if (gather) {
-      int cb = 0, ce = 0;
-      lslam_pg_row_shard_range(pg->n_v, g_rank, g_world, &cb, &ce);
+    {
       // Gather or all-reduce is ONE decision of all ranks: a rank that gathered (grouped broadcasts) while another all-reduced
-      // would hang the solve.  lslam_pg_set_row_shard accepts any whole-block range, so a rank cannot tell from its own range
-      // what the others hold: the ranks sum a "my range is not the canonical one" flag once per (range, transport) setting
-      // and gather only if nobody raised it.
-      const bool mine = cb == v0 && ce == v1;
-      if (pg->rs_agree_v0 != v0 || pg->rs_agree_v1 != v1 || pg->rs_agree_world != g_world) {
-        double flag = mine ? 0.0 : 1.0;
-        PG_TRY(hipMemcpyAsync(X + n6 + 7, &flag, sizeof(double), hipMemcpyHostToDevice, pg->stream));
-        PG_TRY(hipStreamSynchronize(pg->stream));  // (flag is a local)
-        int rc_a = pg->reduce(X + n6 + 7, 1);
-        if (rc_a) return rc_a;
-        PG_TRY(hipMemcpyAsync(&flag, X + n6 + 7, sizeof(double), hipMemcpyDeviceToHost, pg->stream));
-        PG_TRY(hipStreamSynchronize(pg->stream));
-        pg->rs_agree_v0 = v0;
-        pg->rs_agree_v1 = v1;
-        pg->rs_agree_world = g_world;
-        pg->rs_agree_gather = flag == 0.0;
-      }
+      // would hang the solve.  lslam_pg_set_row_shard accepts any whole-block range and a rank may have no gather transport at
+      // all, so no rank can tell from what it holds what the others will do: EVERY rank of EVERY row-sharded solve sums a
+      // "not from me" flag through the linearisation's transport -- 1 without a gather transport or with a range that is not
+      // the canonical one -- and the ranks gather only if nobody raised it.  (Cached per rank this was itself a collective
+      // that some ranks could skip: a rank whose setting had not changed did not enter it.  One scalar all-reduce per solve of
+      // ~100 iterations with two collectives each costs nothing.)
+      int cb = -1, ce = -1;
+      if (gather) lslam_pg_row_shard_range(pg->n_v, g_rank, g_world, &cb, &ce);
+      double flag = (gather && cb == v0 && ce == v1) ? 0.0 : 1.0;
+      PG_TRY(hipMemcpyAsync(X + n6 + 7, &flag, sizeof(double), hipMemcpyHostToDevice, pg->stream));
+      PG_TRY(hipStreamSynchronize(pg->stream));  // (flag is a local)
+      int rc_a = pg->reduce(X + n6 + 7, 1);
+      if (rc_a) return rc_a;
+      PG_TRY(hipMemcpyAsync(&flag, X + n6 + 7, sizeof(double), hipMemcpyDeviceToHost, pg->stream));
+      PG_TRY(hipStreamSynchronize(pg->stream));
+      pg->rs_agree_gather = flag == 0.0;
+    }
+    if (gather) {
       gather = pg->rs_agree_gather;
       z_offs.resize((size_t)g_world + 1);
       s_offs.resize((size_t)g_world + 1);

@@ -484,6 +484,7 @@ class ScanMatch:
         self.last_stats = None
         self._ref_epoch = 0         # setReferenceEpoch: the caller's promise (0: none)
         self._resident = None       # (epoch, id / address / shape of the two reference clouds) the resident map was set under
+        self._resident_map = 0      # lslam_map_epoch right after this object set that map (0: nothing resident)
 
     # setters, ScanMatch.h:21-34
     def setPercentThreshold(self, percent):
@@ -530,12 +531,21 @@ class ScanMatch:
         if self._ref_epoch and isinstance(referenceCornerCloud, np.ndarray) and isinstance(referenceSurfCloud, np.ndarray):
             key = (self._ref_epoch,) + tuple((a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str)
                                              for a in (referenceCornerCloud, referenceSurfCloud))
-        if key is not None and key == self._resident:
-            status, tw, st = self.ctx.scanmatch_scan(CornerCloud, SurfCloud, tw, self.opts)
+        # resident: the caller's promise (epoch, buffers) AND the library's word that the map this object set is still the
+        # context's (setMap, a FeatureMap, an odometry / ICP call on the same context replace it: lslam_map_epoch changes)
+        if key is not None and key == self._resident and self._resident_map and \
+                self.ctx.lib.lslam_map_epoch(self.ctx.h) == self._resident_map:
+            try:
+                status, tw, st = self.ctx.scanmatch_scan(CornerCloud, SurfCloud, tw, self.opts)
+            except LslamError:
+                self._resident, self._resident_map = None, 0
+                raise
         else:
+            self._resident, self._resident_map = None, 0
             status, tw, st = self.ctx.scanmatch_full(referenceCornerCloud, referenceSurfCloud,
                                                      CornerCloud, SurfCloud, tw, self.opts)
-            self._resident = key if (status >= 0 and status != Status.TOO_FEW_REF) else None
+            if status >= 0 and status != Status.TOO_FEW_REF:
+                self._resident, self._resident_map = key, int(self.ctx.lib.lslam_map_epoch(self.ctx.h))
         ok = self._finish(status, st)
         return ok, (self.ctx.pose_to_isometry(tw) if iso else tw)
 
@@ -555,6 +565,7 @@ class ScanMatch:
     def setMap(self, referenceCornerCloud, referenceSurfCloud):
         """Keep a map resident across calls (the FeatureMap::scanMatchScan usage,
         util/FeatureMap.h:490-691, where trees are built once per map update)."""
+        self._resident, self._resident_map = None, 0
         self.ctx.map_set(referenceCornerCloud, referenceSurfCloud)
 
     def scanMatchResident(self, CornerCloud, SurfCloud, pose):

@@ -8,7 +8,7 @@ cd $root
 for r in $(seq 1 $rounds); do
   for v in "$@"; do
     lib=$root/build/exp/$v.so; [ "$v" = base ] && lib=$root/the-cooper-mapper_amd/liblslam_hip.so
-    LSLAM_LIB=$lib timeout 600 python bench.py --headline-only --steps $steps --warmup 1 --map-cache /tmp/ab_map > gpurun_out/abv_$v.json 2> gpurun_out/abv_$v.err || { echo "$v FAILED"; tail -3 gpurun_out/abv_$v.err; continue; }
+    LSLAM_ALLOW_EXPERIMENT_BUILD=1 LSLAM_LIB=$lib timeout 600 python bench.py --headline-only --steps $steps --warmup 1 --map-cache /tmp/ab_map > gpurun_out/abv_$v.json 2> gpurun_out/abv_$v.err || { echo "$v FAILED"; tail -3 gpurun_out/abv_$v.err; continue; }
     python - <<PY
 import json
 d=json.loads(open("gpurun_out/abv_$v.json").read().strip().splitlines()[-1])

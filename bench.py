@@ -407,6 +407,11 @@ def main():
                                      "rings64": sweep_pipeline_leg(pkg, synth, ctx, 64, np)}
         except Exception as e:
             out["sweep_pipeline"] = {"error": repr(e)}
+    if rank == 0 and not args.no_pipeline:
+        try:
+            out["final_feature_map"] = final_feature_map_leg(pkg, synth, synth_gpu, lidar, local_rank, np)
+        except Exception as e:
+            out["final_feature_map"] = {"error": repr(e)}
     comm = None
     if world == 1 and not args.shard_points and rank == 0:
         # a world of one: the line still says that librccl loads on this box and that the library's communicator answers
@@ -588,6 +593,10 @@ def compact_line(out):
     js = out.get("joint_lidar_stereo") or {}
     if js:
         opt.append(("joint_lidar_stereo", {k: js.get(k) for k in ("ms_per_joint_scanmatch", "joint_rows_per_s", "n_gpus", "pose_diff_gpu_vs_cpu_m", "error") if k in js}))
+    ff = out.get("final_feature_map") or {}
+    if ff:
+        opt.append(("final_feature_map", {k: ff.get(k) for k in ("keyframes_per_s", "ms_per_keyframe", "keyframes", "matched", "added",
+                                                                 "pose_err_vs_ground_truth_m", "error") if k in ff}))
     sp = out.get("sweep_pipeline") or {}
     if sp:
         opt.append(("sweep_pipeline", {k: {"ms_per_sweep": _pick(sp, k, "ms_per_sweep"), "threads_ms_per_sweep": _pick(sp, k, "node_threads", "ms_per_sweep"),
@@ -819,6 +828,8 @@ def dry_run_report(world, ranks_counted, per_rank):
                              "pose_diff_gpu_vs_cpu_m": 1e-6, "pose_diff_gpu_vs_cpu_rad": 1e-7, "iterations_equal": True, "rows_equal": True,
                              "all_cores": {"value": 1.0e7, "cores": 8, "kind": long[:80]}},
             "mapping_frame": mf, "mapping_frame_vlp16": mf, "mapping_frame_cubes": mf,
+            "final_feature_map": {"keyframes_per_s": 900.0, "ms_per_keyframe": 1.1, "keyframes": 300, "matched": 298, "added": 300,
+                                  "pose_err_vs_ground_truth_m": 0.01, "workload": long},
             "sweep_pipeline": {"vlp16": {"ms_per_sweep": 3.0, "ms": {"odometry": 0.3, "mapping": 0.8}, "node_threads": {"ms_per_sweep": 2.0}},
                                "rings64": {"ms_per_sweep": 5.0, "ms": {"odometry": 0.4, "mapping": 0.8}, "node_threads": {"ms_per_sweep": 3.0}}},
             "sharded_points": {"value": 1.0e9, "ms_per_scanmatch": 0.4, "n_gpus": world, "allreduce_bytes_per_iteration": 256},
@@ -1447,6 +1458,39 @@ def mapping_frame_leg(pkg, synth, ctx, surround, lidar, gt, opts, np, with_cpu, 
         res["pose_diff_gpu_vs_cpu_m"] = float(np.abs(opose[3:] - pose_first[3:]).max())
     fm.close()
     return res
+
+
+def final_feature_map_leg(pkg, synth, synth_gpu, lidar, device, np, n_keyframes=300):
+    """Graph::getFinalFeatureMap (pose_graph/graph.cpp:150-199, the end of Graph::save): the reference's own many-keyframe
+    workload -- SEQUENTIAL: keyframe k is scan-matched against a map that already holds keyframes 0 .. k-1 (update ->
+    surround -> VoxelGrid 0.2 / 0.3 -> scanMatchScan with the bool -> addFeatureCloud iff matched).  A bounded sample of the
+    pose-graph leg's 5 000 keyframes: consecutive keyframes 0.26 m apart on the loop, VLP-16 sweeps ray cast at them, estimates
+    = the truth plus what an optimised graph leaves (a few centimetres).  With the bootstrap (the reference as written never
+    adds the first keyframe: the-cooper-mapper_amd/graph.py)."""
+    ctx = pkg.Context(device)
+    traj = synth_gpu.loop_trajectory(5000)
+    rng = np.random.default_rng(77)
+    kfs = []
+    for k in range(n_keyframes):
+        g = traj[k]
+        c, s = lidar.scan(g, 16, 1800, seed=555000 + k)
+        est = ctx.pose_to_isometry(g.astype(np.float32)).astype(np.float64)
+        est[:3, 3] += rng.normal(0.0, 0.02, 3)
+        kfs.append(pkg.KeyFrame(est, 0.26 * k, c, s, frame_id=k))
+    graph = pkg.Graph(device=device, ctx=ctx)
+    quiet_gc()
+    t0 = time.perf_counter()
+    res = graph.get_final_feature_map(ctx, cube_dims=(21, 21, 11), bootstrap=True, keyframes=kfs)
+    dt = time.perf_counter() - t0
+    info = res["map"].info()
+    gt_err = max(float(np.linalg.norm(p[:3, 3] - traj[k][3:6])) for k, p in enumerate(res["poses"]))
+    res["map"].close()
+    ctx.close()
+    return {"keyframes": n_keyframes, "keyframes_per_s": n_keyframes / dt, "ms_per_keyframe": 1e3 * dt / n_keyframes,
+            "matched": int(sum(res["matched"])), "added": int(res["added"]), "points_per_keyframe": int(np.mean([len(k.corner_cloud) + len(k.surf_cloud) for k in kfs])),
+            "map_points": int(info["n_corner"] + info["n_surf"]), "pose_err_vs_ground_truth_m": gt_err,
+            "workload": "Graph::getFinalFeatureMap over %d consecutive keyframes (0.26 m apart) of the 5 000-keyframe loop, 16 x 1800 sweeps, "
+                        "sequential: each keyframe matched against the map of those before it" % n_keyframes}
 
 
 def sweep_pipeline_leg(pkg, synth, ctx, rings, np):

@@ -327,6 +327,65 @@ public:
     return (int)found.size();
   }
 
+  // Graph::getFinalFeatureMap (graph.cpp:150-199; called by Graph::save, :106-147): the optimised keyframes rebuilt into a map
+  // ONE AFTER THE OTHER -- keyframe k is matched against a map that already holds keyframes 0 .. k-1:
+  //   feature_map2.update(estimate) -> getSurroundFeature -> VoxelGrid 0.2 / 0.3 of the keyframe's clouds -> scanMatchScan (a
+  //   default ScanMatch) from the estimate -> addFeatureCloud with the refined estimate iff matched -> saveCloudToFiles(directory)
+  // all on the device (lslam_fmap_*: the map never leaves HBM between keyframes).  matched[k] / poses[k]: per keyframe.
+  // Quirk kept with bootstrap = false (the reference as written): the map starts empty, the first match returns false for want
+  // of reference points (ScanMatch.cpp:57-61), nothing is added -- and so for every keyframe after it.  bootstrap = true adds a
+  // keyframe WITHOUT a match while the surround holds fewer than the 50 / 100 points a match needs.  The caller destroys *map_out
+  // (lslam_fmap_destroy); returns the number of keyframes added, -1 on a backend error.
+  int getFinalFeatureMap(lslam_ctx *ctx, const std::string &directory, bool bootstrap, std::vector<char> &matched,
+                         std::vector<Mat4d> &poses, lslam_fmap **map_out, int cubeWidth = 121, int cubeHeight = 111,
+                         int cubeDepth = 121) {
+    matched.clear();
+    poses.clear();
+    lslam_fmap *fm = nullptr;
+    if (lslam_fmap_create(ctx, cubeWidth, cubeHeight, cubeDepth, &fm) != LSLAM_OK) return fail_final(nullptr);
+    lslam_fmap_setup_filter_size(fm, 0.2f, 0.2f, 0.4f);
+    lslam_opts opts;
+    lslam_default_opts(&opts);  // lidar_slam::ScanMatch scan_match;
+    int added = 0;
+    std::vector<float> cc, cs;
+    for (const auto &kf : keyframes) {
+      float T[16];
+      to_float16(kf->estimate, T);  // node->estimate().cast<float>()
+      const float pos[3] = {T[3], T[7], T[11]};
+      if (lslam_fmap_update(fm, pos) < 0) return fail_final(fm);
+      size_t nc = 0, ns = 0;
+      if (lslam_fmap_surround_counts(fm, &nc, &ns) < 0) return fail_final(fm);
+      const size_t kc = kf->cornerCloud.size() / 4, ks = kf->surfCloud.size() / 4;
+      cc.resize(4 * kc + 4);
+      cs.resize(4 * ks + 4);
+      size_t mc = 0, ms = 0;
+      if (lslam_voxel_grid(ctx, kf->cornerCloud.data(), kc, 16, 0.2f, cc.data(), kc, &mc) < 0) return fail_final(fm);
+      if (lslam_voxel_grid(ctx, kf->surfCloud.data(), ks, 16, 0.3f, cs.data(), ks, &ms) < 0) return fail_final(fm);
+      bool ok = false;
+      const bool enough = nc >= 50 && ns >= 100;
+      if (enough) {
+        if (lslam_fmap_surround_to_map(fm) < 0) return fail_final(fm);
+        float pose[6];
+        lslam_isometry_to_pose(T, pose);
+        lslam_stats st;
+        const int rc = lslam_scanmatch_scan(ctx, cc.data(), mc, cs.data(), ms, 16, pose, &opts, &st);
+        if (rc < 0) return fail_final(fm);
+        if (rc != LSLAM_TOO_FEW_REF) lslam_pose_to_isometry(pose, T);  // written back also when the match failed (:342-346)
+        ok = rc == LSLAM_OK;
+      }
+      if (ok || (bootstrap && !enough)) {
+        if (lslam_fmap_add_feature_cloud(fm, kf->cornerCloud.data(), kc, kf->surfCloud.data(), ks, 16, T) < 0) return fail_final(fm);
+        ++added;
+      }
+      matched.push_back(ok ? 1 : 0);
+      poses.push_back(from_float16(T));
+    }
+    if (!directory.empty() && lslam_fmap_save(fm, directory.c_str()) < 0) return fail_final(fm);
+    if (map_out) *map_out = fm;
+    else lslam_fmap_destroy(fm);
+    return added;
+  }
+
   LoopDetector loop_detector;
   KeyframeUpdater keyframe_updater;
   std::vector<KeyFrame::Ptr> keyframes, new_keyframes;
@@ -337,6 +396,11 @@ public:
   const std::string &lastError() const { return _err; }
 
 private:
+  int fail_final(lslam_fmap *fm) {
+    _err = lslam_last_error();
+    if (fm) lslam_fmap_destroy(fm);
+    return -1;
+  }
   // graph.cpp:248-297
   bool flush_keyframe_queue() {
     if (keyframe_queue.empty()) return false;

@@ -47,6 +47,20 @@ int main(int argc, char **argv) {
   for (size_t i = 0; i < g.keyframes.size(); ++i)
     std::printf("KF %zu %.17g %.17g %.17g\n", i, g.keyframes[i]->estimate(0, 3), g.keyframes[i]->estimate(1, 3),
                 g.keyframes[i]->estimate(2, 3));
+  if (argc > 3) {  // Graph::getFinalFeatureMap (graph.cpp:150-199) into the directory given, with the bootstrap
+    std::vector<char> matched;
+    std::vector<pose_graph::Mat4d> poses;
+    const int added = g.getFinalFeatureMap(ctx, argv[3], true, matched, poses, nullptr);
+    if (added < 0) {
+      std::fprintf(stderr, "getFinalFeatureMap failed: %s\n", g.lastError().c_str());
+      return 1;
+    }
+    int n_matched = 0;
+    for (char m : matched) n_matched += m;
+    std::printf("FINAL %d %d\n", added, n_matched);
+    for (size_t i = 0; i < poses.size(); ++i)
+      std::printf("FP %zu %d %.9g %.9g %.9g\n", i, (int)matched[i], poses[i](0, 3), poses[i](1, 3), poses[i](2, 3));
+  }
   lslam_ctx_destroy(ctx);
   return 0;
 }

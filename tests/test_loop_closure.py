@@ -188,13 +188,25 @@ def test_cpp_graph_equals_python_graph(pkg, ctx, synth, small_problem, tmp_path)
             assert g.add_frame(O, cl, sl) is not None
             loops, its = g.optimize(20)
             n_loops += len(loops)
-    out = subprocess.run([str(exe), str(path), "25"], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([str(exe), str(path), "25", str(tmp_path / "graph2_cpp")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     head = [l for l in out.stdout.splitlines() if l.startswith("LOOPS")][0].split()
     assert int(head[1]) == n_loops >= 1 and int(head[5]) == len(g.keyframes)
     kf = np.array([[float(v) for v in l.split()[2:5]] for l in out.stdout.splitlines() if l.startswith("KF ")])
     est = np.array([k.estimate[:3, 3] for k in g.keyframes])
     assert np.abs(kf - est).max() < 1e-6
+    # Graph::getFinalFeatureMap through both mirrors: the same ABI calls in the same order
+    res = g.get_final_feature_map(ctx, directory=str(tmp_path / "graph2_py"), bootstrap=True)
+    res["map"].close()
+    fin = [l.split() for l in out.stdout.splitlines() if l.startswith("FINAL")][0]
+    assert int(fin[1]) == res["added"] and int(fin[2]) == sum(res["matched"]) and res["added"] >= len(g.keyframes) // 2
+    fp = [l.split() for l in out.stdout.splitlines() if l.startswith("FP ")]
+    assert [bool(int(w[2])) for w in fp] == res["matched"]
+    got = np.array([[float(v) for v in w[3:6]] for w in fp])
+    assert np.abs(got - np.array([p[:3, 3] for p in res["poses"]])).max() <= 1e-6
+    for d in ("graph2_cpp", "graph2_py"):
+        assert (tmp_path / d / "index.txt").exists()
+    assert (tmp_path / "graph2_cpp" / "index.txt").read_text() == (tmp_path / "graph2_py" / "index.txt").read_text()
 
 
 def test_trajectory_radius_search_matches_reference_nanoflann(pkg):
@@ -231,3 +243,53 @@ def test_trajectory_radius_search_matches_reference_nanoflann(pkg):
             else:
                 assert len(idx1) == 0  # the reference reports 1 and reads an empty vector here (UB)
     assert hits > 1000
+
+
+@pytest.mark.gpu
+def test_final_feature_map_matches_the_oracle_chain(pkg, ctx, oracle, synth, small_problem, tmp_path):
+    """Graph::getFinalFeatureMap (pose_graph/graph.cpp:150-199): 40 keyframes rebuilt into a map one after the other -- update,
+    surround, VoxelGrid 0.2 / 0.3, scanMatchScan from the keyframe's estimate, addFeatureCloud iff matched -- on the device
+    against the same chain made of oracle calls: same matched flags, refined poses to the bar, maps of the same size; and the
+    reference's quirk: without the bootstrap the first match has nothing to match against, nothing is ever added, the map
+    stays empty."""
+    world = small_problem["world"]
+    rng = np.random.default_rng(3)
+    kfs = []
+    for k in range(40):
+        gt = (0.0, 0.0, 0.3 + 0.004 * k, 3.0 + 0.3 * k, -2.0 + 0.1 * k, synth.SENSOR_HEIGHT)
+        c, s, _ = synth.make_scan(world, 16, 600, gt_pose=gt, seed=700 + k)
+        est = ctx.pose_to_isometry(np.array(gt, np.float32)).astype(np.float64)
+        est[:3, 3] += rng.uniform(-0.05, 0.05, 3)  # the optimised graph's estimate: near the truth, not on it
+        kfs.append(pkg.KeyFrame(est, 0.3 * k, c, s, frame_id=k))
+    g = pkg.Graph(ctx=ctx)
+    # the reference as written
+    res0 = g.get_final_feature_map(ctx, cube_dims=(21, 11, 21), keyframes=kfs[:5])
+    assert res0["added"] == 0 and not any(res0["matched"]) and res0["map"].info()["n_surf"] == 0
+    res0["map"].close()
+    res = g.get_final_feature_map(ctx, directory=str(tmp_path / "graph2"), cube_dims=(21, 11, 21), bootstrap=True, keyframes=kfs)
+    # the same chain, oracle calls only
+    ofm = oracle.feature_map(21, 11, 21)
+    ofm.setup_filter_size(0.2, 0.2, 0.4)
+    o_matched, o_poses = [], []
+    for kf in kfs:
+        est = kf.estimate.astype(np.float32)
+        ofm.update(est[:3, 3])
+        mc, ms = ofm.get_surround_feature()
+        cc, cs = oracle.voxel_grid(kf.corner_cloud, 0.2), oracle.voxel_grid(kf.surf_cloud, 0.3)
+        ok = False
+        big = len(mc) >= 50 and len(ms) >= 100
+        if big:
+            ok, pose, st = oracle.scanmatch_scan(mc, ms, cc, cs, ctx.isometry_to_pose(est), oracle.default_opts())
+            if st.status != 1:
+                est = ctx.pose_to_isometry(pose)
+        if ok or not big:
+            ofm.add_feature_cloud(kf.corner_cloud, kf.surf_cloud, est)
+        o_matched.append(bool(ok))
+        o_poses.append(np.array(est, np.float32))
+    assert res["matched"] == o_matched and sum(o_matched) >= 30
+    for k, (a, b) in enumerate(zip(res["poses"], o_poses)):
+        assert np.abs(a[:3, 3] - b[:3, 3]).max() <= 1e-4 and np.abs(a[:3, :3] - b[:3, :3]).max() <= 2e-5, k
+    n_dev, n_orc = len(res["map"].get_full_map()), len(ofm.get_full_map())
+    assert abs(n_dev - n_orc) <= max(3, n_orc // 500)  # (poses differ in their last digits: a centroid may cross a voxel wall)
+    assert (tmp_path / "graph2" / "index.txt").exists()
+    res["map"].close()

@@ -915,10 +915,14 @@ static int extract_features_impl(lslam_ctx *ctx, const void *cloud, size_t n_poi
   // device scratch and the pinned staging area of the input are kept per device between calls (a
   // sweep arrives every 100 ms)
   struct Cache { char *p = nullptr; size_t cap = 0; float4 *pin = nullptr; size_t pin_cap = 0; float4 *pout = nullptr; size_t pout_cap = 0; };
-  static std::map<int, Cache> caches;
+  static std::map<hipStream_t, Cache> caches;  // per stream = per context: contexts of one device run on their own threads
   static std::mutex mu;
-  std::lock_guard<std::mutex> lk(mu);
-  Cache &cache = caches[lslam::ctx_device(ctx)];
+  Cache *cache_p;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    cache_p = &caches[s];
+  }
+  Cache &cache = *cache_p;
   const size_t np4 = n_points * sizeof(float4);
   if (n_points > cache.pin_cap) {
     if (cache.pin) (void)hipHostFree(cache.pin);
@@ -1070,10 +1074,14 @@ int lslam_multiscan_register(lslam_ctx *ctx, const void *cloud, size_t n_points,
   FX_TRY(hipSetDevice(lslam::ctx_device(ctx)));
   hipStream_t s = (hipStream_t)lslam_stream(ctx);
   struct Cache { char *p = nullptr; size_t cap = 0; float4 *pin = nullptr; size_t pin_cap = 0; };
-  static std::map<int, Cache> caches;  // device scratch + pinned input staging kept per device between sweeps
+  static std::map<hipStream_t, Cache> caches;  // device scratch + pinned input staging kept per stream (= context) between sweeps
   static std::mutex mu;
-  std::lock_guard<std::mutex> lk(mu);
-  Cache &cache = caches[lslam::ctx_device(ctx)];
+  Cache *cache_p;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    cache_p = &caches[s];
+  }
+  Cache &cache = *cache_p;
   const size_t np4 = n_points * sizeof(float4);
   if (n_points > cache.pin_cap) {
     if (cache.pin) (void)hipHostFree(cache.pin);

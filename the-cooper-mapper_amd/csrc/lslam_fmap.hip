@@ -1086,14 +1086,21 @@ int voxel_filter_segments(hipStream_t s, const float4 *in_pts, const int32_t *in
     Buf<uint8_t> all;
     size_t all_set = 0;  // entries of `all` that hold their 1 already
   };
-  static std::map<int, Cache> caches;  // per device
+  // Scratch per STREAM (= per context), not per device: in the no-wait form (`done`) this function returns with its kernels
+  // still running, and a caller on another context of the same device -- the registration node beside the mapping node, each
+  // on its own thread -- would otherwise be handed the same scratch while they do.  (It was: garbage segment ids, a host
+  // segfault in the registration, "output buffer too small" in the map, found by tools/cpp/node_threads.cpp.)  Work on ONE
+  // stream is ordered by the stream.  The lock covers the table of caches only; a map's nodes do not move.
+  static std::map<hipStream_t, Cache> caches;
   static std::mutex mu;
-  std::lock_guard<std::mutex> lk(mu);
-  int dev = 0;
-  FM_TRY(hipGetDevice(&dev));
-  Scratch &sc = caches[dev].sc;
-  Buf<uint8_t> &all = caches[dev].all;
-  size_t &all_set = caches[dev].all_set;
+  Cache *cache_p;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    cache_p = &caches[s];
+  }
+  Scratch &sc = cache_p->sc;
+  Buf<uint8_t> &all = cache_p->all;
+  size_t &all_set = cache_p->all_set;
   {  // "every segment is filtered": ones, written when the array grows -- not once per call
     const uint8_t *before = all.p;
     FM_TRY(all.reserve((size_t)nseg));
@@ -1875,10 +1882,14 @@ static int voxel_grid_impl(lslam_ctx *ctx, const void *cloud, size_t n, size_t s
     Buf<int32_t> oc;
     Scratch sc;
   };
-  static std::map<int, Cache> caches;  // per device
+  static std::map<hipStream_t, Cache> caches;  // per stream = per context (see voxel_filter_segments)
   static std::mutex mu;
-  std::lock_guard<std::mutex> lk(mu);
-  Cache &cache = caches[lslam::ctx_device(ctx)];
+  Cache *cache_p;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    cache_p = &caches[s];
+  }
+  Cache &cache = *cache_p;
   Buf<float4> &out = cache.out;
   Buf<int32_t> &oc = cache.oc;
   Scratch &sc = cache.sc;
@@ -1970,10 +1981,14 @@ static int voxel_grid2_impl(lslam_ctx *ctx, const void *a, size_t na, const void
     Buf<float4> in_raw;
     Buf<int32_t> seg;
   };
-  static std::map<int, Cache> caches;  // per device
+  static std::map<hipStream_t, Cache> caches;  // per stream = per context (see voxel_filter_segments)
   static std::mutex mu;
-  std::lock_guard<std::mutex> lk(mu);
-  Cache &c = caches[lslam::ctx_device(ctx)];
+  Cache *cache_p;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    cache_p = &caches[(hipStream_t)lslam_stream(ctx)];
+  }
+  Cache &c = *cache_p;
   FM_TRY(c.in_pin.reserve(n));
   FM_TRY(c.out_pin.reserve(n));
   FM_TRY(c.seg_pin.reserve(n));

@@ -94,6 +94,35 @@ int main(int argc, char **argv) {
   std::atomic<bool> failed(false);
   float last_pose[16] = {0};
 
+  if (argc > 3 && std::strcmp(argv[3], "seq") == 0) {  // diagnostics: the same calls from ONE thread, one sweep after the other
+    std::vector<float> reg;
+    std::vector<int32_t> ranges(2 * rings);
+    t0 = now_s();
+    for (uint32_t k = 0; k < sweeps; ++k) {
+      if (k == warm) t0 = now_s();
+      const size_t n = raws[k].size() / 4;
+      reg.resize(4 * n + 4);
+      size_t m = 0, counts[4];
+      if (lslam_multiscan_register(ctx_r, raws[k].data(), n, 16, lo, hi, (int32_t)rings, 0.1f, reg.data(), n, &m, ranges.data()) < 0 ||
+          lslam_extract_features_dev(ctx_r, reg.data(), m, 16, 12, ranges.data(), rings, nullptr, pool_sets[0], counts) < 0) {
+        std::fprintf(stderr, "sweep %u: registration failed: %s\n", k, lslam_last_error());
+        return 1;
+      }
+      if (odo.processFeatureSet(pool_sets[0])) {
+        if (!mapping.process(odo.lastCornerCloud(), odo.lastSurfaceCloud(), odo.Tsum())) {
+          std::fprintf(stderr, "sweep %u: mapping failed: %s\n", k, mapping.lastError().c_str());
+          return 1;
+        }
+      } else if (!odo.lastError().empty()) {
+        std::fprintf(stderr, "sweep %u: odometry failed: %s\n", k, odo.lastError().c_str());
+        return 1;
+      }
+    }
+    const float *P = mapping.lidarMapped();
+    std::printf("SEQUENTIAL ms_per_sweep %.6f sweeps_timed %u travelled_m %.6f\n", 1e3 * (now_s() - t0) / (sweeps - warm), sweeps - warm,
+                std::sqrt((double)P[3] * P[3] + (double)P[7] * P[7] + (double)P[11] * P[11]));
+    return 0;
+  }
   std::thread registration([&] {  // MultiScanRegistration nodelet: raw sweep -> feature clouds (in HBM)
     std::vector<float> reg;
     std::vector<int32_t> ranges(2 * rings);

@@ -425,6 +425,9 @@ int lslam_fmap_get_surround(lslam_fmap *fm, float *corner_xyzi, size_t cap_corne
  * LaserMatcher::prepareFeatureSurround + ScanMatch.cpp:68-76 do through the host), kd-trees
  * built on the device. */
 int lslam_fmap_surround_to_map(lslam_fmap *fm);
+/* The same, handing back the surround's sizes it reads anyway (getSurroundFeature's two clouds): a caller that only wants to
+ * know whether there is anything to match against (LaserMatcher.cpp:303-331) need not wait for lslam_fmap_surround_counts first. */
+int lslam_fmap_surround_to_map_counts(lslam_fmap *fm, size_t *n_corner, size_t *n_surf);
 /* ... or as a variant-C map: one kd-tree per cube of the active area (cubes with fewer than 5
  * points skipped, FeatureMap.h:524,546), all built in one go on the device; scan points are then
  * matched against the tree of the cube they fall into (FeatureMap::scanMatchScan, :490-691). */

@@ -186,9 +186,8 @@ public:
     const float pos[3] = {_lidarMappedNew[3], _lidarMappedNew[7], _lidarMappedNew[11]};
     if (lslam_fmap_update(_fm, pos) < 0) return fail();
     size_t nc = 0, ns = 0;
-    if (lslam_fmap_surround_counts(_fm, &nc, &ns) < 0) return fail();
+    if (lslam_fmap_surround_to_map_counts(_fm, &nc, &ns) < 0) return fail();  // the surround becomes the context's map
     if (nc || ns) {  // optimizeTransform, :327-331
-      if (lslam_fmap_surround_to_map(_fm) < 0) return fail();
       float pose[6];
       lslam_isometry_to_pose(_lidarMappedNew, pose);
       const int st = lslam_scanmatch_scan(_ctx, _cornerDS.data(), _cornerDS.size() / 4, _surfDS.data(), _surfDS.size() / 4, 16, pose,

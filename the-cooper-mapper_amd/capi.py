@@ -213,6 +213,7 @@ SYMBOLS = {
     "lslam_fmap_surround_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "lslam_fmap_get_surround": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t, c_float_p, C.c_size_t]),
     "lslam_fmap_surround_to_map": (C.c_int, [C.c_void_p]),
+    "lslam_fmap_surround_to_map_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "lslam_fmap_to_cubemap": (C.c_int, [C.c_void_p]),
     "lslam_fmap_cubemap_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "lslam_fmap_rebuild_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

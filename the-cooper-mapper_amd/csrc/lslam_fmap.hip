@@ -1365,7 +1365,11 @@ int lslam_fmap_get_surround(lslam_fmap *fm, float *corner_xyzi, size_t cap_corne
   return LSLAM_OK;
 }
 
-int lslam_fmap_surround_to_map(lslam_fmap *fm) {
+int lslam_fmap_surround_to_map(lslam_fmap *fm) { return lslam_fmap_surround_to_map_counts(fm, nullptr, nullptr); }
+
+int lslam_fmap_surround_to_map_counts(lslam_fmap *fm, size_t *n_corner, size_t *n_surf) {
+  if (n_corner) *n_corner = 0;
+  if (n_surf) *n_surf = 0;
   int rc = check_fm(fm);
   if (rc) return rc;
   hipStream_t s = fm->stream;
@@ -1412,6 +1416,8 @@ int lslam_fmap_surround_to_map(lslam_fmap *fm) {
       hi[t][a] = back(h_res[8 * t + 4 + a]);
     }
   }
+  if (n_corner) *n_corner = n[0];
+  if (n_surf) *n_surf = n[1];
   if (n[0] == 0 && n[1] == 0) return lslam_map_set(fm->ctx, nullptr, 0, nullptr, 0, 16);
   FM_TRY(fm->sur[0].reserve(1));
   FM_TRY(fm->sur[1].reserve(1));

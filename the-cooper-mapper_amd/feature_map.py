@@ -93,6 +93,12 @@ class FeatureMap:
         """The surround becomes ``ctx``'s map without leaving HBM (device kd-tree build)."""
         self._check(self.lib.lslam_fmap_surround_to_map(self.h))
 
+    def surround_to_map_counts(self):
+        """:meth:`surround_to_map`, handing back the sizes of the two surround clouds it reads anyway -> (n_corner, n_surf)."""
+        nc, ns = C.c_size_t(), C.c_size_t()
+        self._check(self.lib.lslam_fmap_surround_to_map_counts(self.h, C.byref(nc), C.byref(ns)))
+        return nc.value, ns.value
+
     def to_cubemap(self):
         """The active area becomes ``ctx``'s variant-C map: one kd-tree per cube (FeatureMap.h:490-691)."""
         self._check(self.lib.lslam_fmap_to_cubemap(self.h))

@@ -166,10 +166,9 @@ class LaserMapping:
             surf_ds = voxel_grid(self.ctx, surf_last, self.filter_surf)
         # prepareFeatureSurround, :303-325
         self.feature_map.update(self.lidar_mapped_new[:3, 3])
-        nc, ns = self.feature_map.surround_counts()
+        nc, ns = self.feature_map.surround_to_map_counts()  # (the surround becomes the context's map; its sizes come back with it)
         # optimizeTransform, :327-331 (return value ignored; pose written back unless "too few ref")
         if nc or ns:
-            self.feature_map.surround_to_map()
             pose = self.ctx.isometry_to_pose(self.lidar_mapped_new)
             status, pose, st = self.ctx.scanmatch_scan(corner_ds, surf_ds, pose, self.opts)
             self.last_stats = st

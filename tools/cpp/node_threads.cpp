@@ -127,7 +127,6 @@ int main(int argc, char **argv) {
     std::vector<float> reg;
     std::vector<int32_t> ranges(2 * rings);
     for (uint32_t k = 0; k < sweeps && !failed; ++k) {
-      if (k == warm) t0 = now_s();
       const size_t n = raws[k].size() / 4;
       reg.resize(4 * n + 4);
       size_t m = 0;
@@ -183,6 +182,9 @@ int main(int argc, char **argv) {
     for (;;) {
       OdomOut o = q2.get();
       if (o.end) break;
+      // the clock starts where the LAST node takes up its warm-th sweep: the nodes before it run ahead by what the queues hold,
+      // and the slow first sweeps (every buffer being sized) must be behind all three
+      if (k == warm) t0 = now_s();
       const double t = now_s();
       if (!mapping.process(o.corner, o.surf, o.Tsum)) {
         std::fprintf(stderr, "mapping failed: %s\n", mapping.lastError().c_str());

@@ -2,7 +2,7 @@
 ulimit -c 0  # a GPU memory fault must not leave a core dump that fills the box's disk
 # Run on the GPU box (gpurun -- bash tools/collect_profiles.sh <tag>): bench line, rocprofv3 kernel
 # stats and the PMC passes the roofline object cites.  Results land in gpurun_out/<tag>_*.
-tag=${1:-r05}
+tag=${1:-r06}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 mkdir -p $out

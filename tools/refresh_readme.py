@@ -127,7 +127,13 @@ def main():
         mf_frames=pick(d, "mapping_frame", "frames", default=0), mf_p99=pick(d, "mapping_frame", "gpu_ms_p99"),
         pg_inexact=pick(d, "pose_graph", "inexact_lm", "lm_iters_per_s"), mf_pipe=pick(d, "mapping_frame", "pipelined", "ms_per_frame"),
         mf16=pick(d, "mapping_frame_vlp16", "gpu_ms_per_frame"), mf_ov=pick(d, "mapping_frame", "overlapped", "gpu_ms_per_frame"),
-        mf_cpu=pick(d, "mapping_frame", "cpu_ms_per_frame"), pg=pick(d, "pose_graph", "lm_iters_per_s"), pg_cpu=pick(d, "pose_graph", "cpu_baseline", "value"))
+        mf_cpu=pick(d, "mapping_frame", "cpu_ms_per_frame"), pg=pick(d, "pose_graph", "lm_iters_per_s"), pg_cpu=pick(d, "pose_graph", "cpu_baseline", "value"),
+        valu_frac=pick(roof, "valu_issue", "frac"), roof_frac=pick(roof, "frac"),
+        chain16=pick(d, "sweep_pipeline", "vlp16", "ms_per_sweep"), chain64=pick(d, "sweep_pipeline", "rings64", "ms_per_sweep"),
+        thr16=pick(d, "sweep_pipeline", "vlp16", "node_threads", "ms_per_sweep"), thr64=pick(d, "sweep_pipeline", "rings64", "node_threads", "ms_per_sweep"),
+        odo16=pick(d, "sweep_pipeline", "vlp16", "ms", "odometry"), odo64=pick(d, "sweep_pipeline", "rings64", "ms", "odometry"),
+        map16=pick(d, "sweep_pipeline", "vlp16", "ms", "mapping"), map64=pick(d, "sweep_pipeline", "rings64", "ms", "mapping"),
+        ffm=pick(d, "final_feature_map", "keyframes_per_s"))
     tpl = open(os.path.join(ROOT, "tools", "readme_template.md")).read()
     text = tpl.format(**vals)
     text = re.sub(r"(\d(?:\.\d+)?)e\+?0?(\d+)", r"\1e\2", text)  # 1.27e+10 -> 1.27e10

@@ -225,3 +225,58 @@ def test_small_last_clouds_are_not_matched_against(pkg, ctx, synth, small_proble
     assert dev.last_ostats.matched == 1
     dev.close()
     fs.close()
+
+
+def test_fuzz_grid_search_against_the_tree_search(ctx, small_problem):
+    """Random scan pairs the structured scenes do not produce -- clustered and scattered last clouds, queries with no neighbour
+    inside the gate, last clouds barely above the guard's sizes, lattice clouds (exact distance ties: the tree path is taken and
+    the answer is the tree's by construction), huge rings -- through the hashed-grid search and through kd-trees: the same
+    iterations, rows and pose bits every time."""
+    rng = np.random.default_rng(20260601)
+    n_cases = 0
+    for trial in range(36):
+        kind = trial % 6
+        n_lc, n_ls = int(rng.integers(11, 400)), int(rng.integers(101, 6000))
+        rings = int(rng.choice([4, 16, 64, 200]))
+        span = float(rng.choice([3.0, 20.0, 80.0]))
+
+        def cloud(n, spread):
+            if kind == 1:  # a few tight clusters
+                c = rng.uniform(-spread, spread, (8, 3))
+                p = c[rng.integers(0, 8, n)] + rng.normal(0, 0.3, (n, 3))
+            elif kind == 2:  # a lattice: exact ties
+                p = np.round(rng.uniform(-spread, spread, (n, 3)) * 2.0) / 2.0
+            elif kind == 3:  # a plane and a wall, as a sweep sees them
+                p = rng.uniform(-spread, spread, (n, 3))
+                p[: n // 2, 2] = rng.normal(0, 0.02, n // 2)
+                p[n // 2:, 0] = spread + rng.normal(0, 0.02, n - n // 2)
+            else:
+                p = rng.uniform(-spread, spread, (n, 3))
+            ring = np.sort(rng.integers(0, rings, n)) if kind != 5 else rng.integers(0, rings, n)  # kind 5: not in ring order
+            w = ring + rng.uniform(0.0, 0.0999, n)
+            return np.concatenate([p, w[:, None]], axis=1).astype(np.float32)
+
+        lc, ls = cloud(n_lc, span), cloud(n_ls, span)
+        motion = np.array([0.01, -0.005, 0.02, 0.2, -0.1, 0.05]) * rng.uniform(0, 2)
+        n_sh, n_fl = int(rng.integers(1, 300)), int(rng.integers(1, 900))
+
+        def queries(src, n):
+            q = src[rng.integers(0, len(src), n)].copy()
+            q[:, :3] += rng.normal(0, 0.05, (n, 3)).astype(np.float32) + motion[3:].astype(np.float32)
+            far = rng.random(n) < 0.1
+            q[far, :3] += rng.uniform(8, 30, (int(far.sum()), 3)).astype(np.float32)  # nothing within the 5 m gate
+            q[:, 3] = np.floor(q[:, 3]) + rng.uniform(0.0, 0.0999, n)
+            return q.astype(np.float32)
+
+        sharp, flat = queries(lc, n_sh), queries(ls, n_fl)
+        p0 = (motion * rng.uniform(-0.5, 1.5)).astype(np.float32)
+        mi = int(rng.choice([1, 6, 25]))
+        s_g, pose_g, st_g = ctx.odometry_match(lc, ls, sharp, flat, p0, max_iterations=mi)
+        s_t, pose_t, st_t = ctx.odometry_match(lc, ls, sharp, flat, p0, max_iterations=mi, trees=True)
+        assert s_g == s_t, (trial, kind)
+        n_cases += 1
+        assert (st_g.iterations, st_g.sweeps, st_g.n_rows, st_g.n_line, st_g.n_plane, st_g.converged) == \
+               (st_t.iterations, st_t.sweeps, st_t.n_rows, st_t.n_line, st_t.n_plane, st_t.converged), (trial, kind)
+        assert np.array_equal(bits(pose_g), bits(pose_t)), (trial, kind)
+    assert n_cases == 36
+    ctx.map_set(small_problem["map_corner"], small_problem["map_surf"])

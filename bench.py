@@ -96,6 +96,9 @@ def parse_args():
     return ap.parse_args()
 
 
+_REAL_STDOUT = None  # main() keeps the process's stdout here and points descriptor 1 at stderr
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves.  This parent has not
     imported torch or touched HIP; it only relays the children's output and exit code."""
@@ -119,6 +122,14 @@ def main():
         print("bench.py: --gpus %d but the launcher started %s rank(s)" % (args.gpus, os.environ.get("WORLD_SIZE")),
               file=sys.stderr)
         sys.exit(2)
+    # stdout carries ONE line, the JSON object rank 0 prints last.  Native libraries print there too -- librccl a version banner
+    # whenever a communicator is made (this process makes one in every run since round 6), through C stdio, flushed when the
+    # process exits, i.e. BEHIND the line.  So descriptor 1 is pointed at stderr for the whole run and the line goes to the
+    # descriptor stdout was, by emit().
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -632,7 +643,8 @@ def emit(out):
                 pass
     print(full, file=sys.stderr, flush=True)
     sys.stdout.flush()
-    print(compact_line(out), flush=True)
+    line = compact_line(out)
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (line + "\n").encode())  # the descriptor stdout WAS (see main): the only bytes on it
 
 
 def vlp16_throughput_leg(ctx, lidar, synth, dense, span, rank, world, args, opts, distmod, dist, info, np):

@@ -82,6 +82,34 @@ constexpr int OH_RINGS = 256;          // ring ids a sorted point's tag and the 
 constexpr uint32_t OH_IDX_BITS = 24;   // a sorted point carries (index in the scan-order cloud) | (ring << 24)
 constexpr uint32_t OH_IDX_MASK = (1u << OH_IDX_BITS) - 1u;
 
+// One atomic per RUN of equal buckets among neighbouring lanes of a wavefront: a cloud comes in scan order, so the points of
+// neighbouring lanes are neighbours in space and share their coarse cell (nearly always) and their fine cell (often).  Returns,
+// for every lane, what the run's first lane got back from atomicAdd(table + bucket, run length) plus the lane's place in the run:
+// a slot of its own in the bucket (the scatter), or just the count done (the counting pass ignores the result).
+LSLAM_DEV uint32_t oh_run_add(uint32_t *table, const uint32_t b, const bool on) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long alive = __ballot(on);
+  const uint32_t prev = (uint32_t)__shfl_up((int)b, 1, 64);
+  const bool prev_on = lane > 0 && ((alive >> (lane - 1)) & 1ull);
+  const bool head = on && (!prev_on || prev != b);
+  const unsigned long long heads = __ballot(head);
+  // the run this lane belongs to starts at the highest head at or below it
+  const unsigned long long below = heads & (lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+  const int h = below ? 63 - __builtin_clzll(below) : 0;
+  uint32_t base = 0;
+  if (head) {
+    const unsigned long long after = lane == 63 ? 0ull : (heads >> (lane + 1));
+    const int upto = after ? lane + 1 + __builtin_ctzll(after) : 64;  // the next head, or the end of the wavefront
+    const unsigned long long span = (upto == 64 ? ~0ull : ((1ull << upto) - 1ull)) & ~((1ull << lane) - 1ull);
+    // (lanes that are off end a run: a run never spans one)
+    const unsigned long long dead = ~alive & span;
+    const int end = dead ? __builtin_ctzll(dead) : upto;
+    base = atomicAdd(table + b, (uint32_t)(end - lane));
+  }
+  base = (uint32_t)__shfl((int)base, h, 64);
+  return base + (uint32_t)(lane - h);
+}
+
 struct PrepArgs {
   const float4 *src[2];  // less-sharp, less-flat lists of the sweep (sensor frame at the point's own time)
   int32_t n[2];
@@ -96,15 +124,31 @@ struct PrepArgs {
 // LaserOdometry::transformToEnd (:156-168) for both clouds + the cell counts of their grids.
 __global__ __launch_bounds__(256) void odom_prep_kernel(PrepArgs a) {
   if (a.gate && !a.gate->done) return;
+  __shared__ float s_pose[6], s_R[9], s_ti[3];
+  if (a.to_end && threadIdx.x == 0) {  // the sweep's whole transform and its inverse, once per workgroup
+    float pose[6], R[9], t[3], scd[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pose[k] = a.gate->pose[k];
+    pose_to_Rt_sc(pose, R, t, scd, DevSinCosF());
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s_pose[k] = pose[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s_R[k] = R[k];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) s_ti[r] = ((-R[r] * t[0]) + (-R[3 + r] * t[1])) + (-R[6 + r] * t[2]);  // Eigen Isometry inverse: R^T, (-R^T) t
+  }
+  __syncthreads();
   int i = blockIdx.x * 256 + threadIdx.x;
   int c = 0;
   if (i >= a.n[0]) {
     i -= a.n[0];
     c = 1;
-    if (i >= a.n[1]) return;
   }
-  float4 q = a.src[c][i];
-  {  // ring order (what lets the search take the ring windows of :366-403 / :430-477 as index ranges) and ring ids that fit a byte
+  const bool on = i < a.n[c];
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (on) {
+    q = a.src[c][i];
+    // ring order (what lets the search take the ring windows of :366-403 / :430-477 as index ranges) and ring ids that fit a byte
     const int ring = (int)q.w;
     const int prev = i > 0 ? (int)a.src[c][i - 1].w : ring;
     if (ring < prev || ring < 0 || ring > 255 || !(q.w == q.w)) atomicOr(a.hdr + c, 1u);
@@ -114,37 +158,30 @@ __global__ __launch_bounds__(256) void odom_prep_kernel(PrepArgs a) {
     for (int r = r0 + 1; r <= r1; ++r) rs[r] = i;
     if (i == a.n[c] - 1)
       for (int r = r1 + 1; r <= OH_RINGS; ++r) rs[r] = a.n[c];
+    if (a.to_end) {  // transformToStart (:135-142) with the point's own share of the sweep, then the whole transform's inverse
+      const float s = 10 * (q.w - (int)q.w);
+      float ps[6], Rs[9], ts[3], scd[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ps[k] = s_pose[k] * s;
+      pose_to_Rt_sc(ps, Rs, ts, scd, DevSinCosF());
+      const float a0 = ((Rs[0] * q.x + Rs[1] * q.y) + Rs[2] * q.z) + ts[0];
+      const float a1 = ((Rs[3] * q.x + Rs[4] * q.y) + Rs[5] * q.z) + ts[1];
+      const float a2 = ((Rs[6] * q.x + Rs[7] * q.y) + Rs[8] * q.z) + ts[2];
+      float4 o;
+      o.x = ((s_R[0] * a0 + s_R[3] * a1) + s_R[6] * a2) + s_ti[0];
+      o.y = ((s_R[1] * a0 + s_R[4] * a1) + s_R[7] * a2) + s_ti[1];
+      o.z = ((s_R[2] * a0 + s_R[5] * a1) + s_R[8] * a2) + s_ti[2];
+      o.w = q.w;
+      q = o;
+    }
+    a.org[c][i] = q;
   }
-  if (a.to_end) {
-    float pose[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) pose[k] = a.gate->pose[k];
-    float R[9], t[3], scd[6];
-    pose_to_Rt_sc(pose, R, t, scd, DevSinCosF());
-    float ti[3];  // Eigen Isometry inverse: R^T, (-R^T) t
-#pragma unroll
-    for (int r = 0; r < 3; ++r) ti[r] = ((-R[r] * t[0]) + (-R[3 + r] * t[1])) + (-R[6 + r] * t[2]);
-    const float s = 10 * (q.w - (int)q.w);
-    float ps[6], Rs[9], ts[3];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) ps[k] = pose[k] * s;
-    pose_to_Rt_sc(ps, Rs, ts, scd, DevSinCosF());
-    const float a0 = ((Rs[0] * q.x + Rs[1] * q.y) + Rs[2] * q.z) + ts[0];
-    const float a1 = ((Rs[3] * q.x + Rs[4] * q.y) + Rs[5] * q.z) + ts[1];
-    const float a2 = ((Rs[6] * q.x + Rs[7] * q.y) + Rs[8] * q.z) + ts[2];
-    float4 o;
-    o.x = ((R[0] * a0 + R[3] * a1) + R[6] * a2) + ti[0];
-    o.y = ((R[1] * a0 + R[4] * a1) + R[7] * a2) + ti[1];
-    o.z = ((R[2] * a0 + R[5] * a1) + R[8] * a2) + ti[2];
-    o.w = q.w;
-    q = o;
-  }
-  a.org[c][i] = q;
+  // (a wavefront that straddles the two clouds counts into two sets of tables: the cloud is part of the run's key)
 #pragma unroll
   for (int l = 0; l < 2; ++l) {
     const float inv_c = 1.0f / OH_CELL[l];
-    const uint32_t b = oh_bucket(oh_cell(q.x, inv_c), oh_cell(q.y, inv_c), oh_cell(q.z, inv_c));
-    atomicAdd(a.cnt + (size_t)(2 * c + l) * OH_SIZE + b, 1u);
+    const uint32_t b = oh_bucket(oh_cell(q.x, inv_c), oh_cell(q.y, inv_c), oh_cell(q.z, inv_c)) + (uint32_t)(2 * c + l) * OH_SIZE;
+    (void)oh_run_add(a.cnt, b, on);
   }
 }
 
@@ -227,16 +264,17 @@ __global__ __launch_bounds__(256) void odom_scatter_kernel(ScatterArgs a) {
   if (i >= a.n[0]) {
     i -= a.n[0];
     c = 1;
-    if (i >= a.n[1]) return;
   }
-  const float4 q = a.org[c][i];
+  const bool on = i < a.n[c];
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (on) q = a.org[c][i];
   const uint32_t tag = (uint32_t)i | (((uint32_t)(int)q.w & 255u) << OH_IDX_BITS);
 #pragma unroll
   for (int l = 0; l < 2; ++l) {
     const float inv_c = 1.0f / OH_CELL[l];
-    const uint32_t b = oh_bucket(oh_cell(q.x, inv_c), oh_cell(q.y, inv_c), oh_cell(q.z, inv_c));
-    const uint32_t pos = atomicAdd(a.cursor + (size_t)(2 * c + l) * OH_SIZE + b, 1u);
-    a.sorted[2 * c + l][pos] = make_float4(q.x, q.y, q.z, __uint_as_float(tag));
+    const uint32_t b = oh_bucket(oh_cell(q.x, inv_c), oh_cell(q.y, inv_c), oh_cell(q.z, inv_c)) + (uint32_t)(2 * c + l) * OH_SIZE;
+    const uint32_t pos = oh_run_add(a.cursor, b, on);
+    if (on) a.sorted[2 * c + l][pos] = make_float4(q.x, q.y, q.z, __uint_as_float(tag));
   }
 }
 

@@ -226,6 +226,32 @@ def test_knn5_deep_tree_uses_overflow_stack(ctx, oracle):
     assert np.array_equal(gi, oi) and np.array_equal(bits(gd), bits(od))
 
 
+def test_degeneracy_decision_across_the_threshold(ctx, oracle):
+    """ScanMatch.cpp:222-233 asks "is the smallest eigenvalue of A^T A below 100?".  The solve answers with a cheap sufficient test
+    first (A - 101 I - 1e-5 tr(A) I positive definite: certainly not) and computes the eigenvalues only when that fails; the
+    decision must be the oracle's eigensolver's on either side of the threshold and inside the margin, with large and small
+    traces."""
+    rng = np.random.default_rng(11)
+    n_deg = 0
+    for trial in range(60):
+        Q, _ = np.linalg.qr(rng.normal(size=(6, 6)))
+        thresh = 100.0  # (the tap's threshold, ScanMatch.cpp:223)
+        lam_min = thresh * float(rng.choice([0.2, 0.9, 0.99, 0.9999, 1.0001, 1.005, 1.011, 1.02, 1.2, 5.0]))
+        top = float(rng.choice([3e2, 1e4, 1e6, 3e7]))
+        lam = np.sort(np.concatenate([[lam_min], rng.uniform(lam_min * 1.5 + 1.0, max(top, lam_min * 2 + 2.0), 5)]))
+        A = (Q * lam) @ Q.T
+        AtA = ((A + A.T) / 2).astype(np.float32)
+        Atb = rng.normal(0, 1.0, 6).astype(np.float32)
+        pose = np.zeros(6, np.float32)
+        o = oracle.gn_step(AtA, Atb, 0, pose, np.zeros(36), False, eig_thresh=thresh)
+        g = ctx.gn_step(AtA, Atb, 0, pose, np.zeros(36), False)
+        assert bool(g["degenerate"]) == bool(o["degenerate"]), (trial, lam_min, thresh, top)
+        n_deg += int(bool(o["degenerate"]))
+        if not o["degenerate"]:
+            assert np.array_equal(bits(g["x"]), bits(o["x"]))
+    assert 10 < n_deg < 50
+
+
 @pytest.mark.parametrize("search", ["lane", "lane_shallow", "packet"])
 @pytest.mark.parametrize("jtj_mode", [0, 1])
 def test_sweep_matches_oracle(ctx, oracle, small_problem, jtj_mode, search):

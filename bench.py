@@ -220,6 +220,12 @@ def main():
 
     for _ in range(args.warmup):
         ctx.run_batch(inits, opts)
+    # an experiment build with section clocks in the sweep kernel (-DLSLAM_EXP_SECTION_CLOCK, tools/section_clock.sh): counted over the timed steps
+    section_clock = getattr(ctx.lib, "lslam_debug_section_clock", None) if hasattr(ctx.lib, "lslam_debug_section_clock") else None
+    if section_clock is not None:
+        import ctypes
+        section_clock.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+        section_clock((ctypes.c_uint64 * 10)(), 1)
 
     barrier()
     t0 = time.perf_counter()
@@ -247,6 +253,12 @@ def main():
         cs = (ctypes.c_uint64 * 3)()
         ctx.lib.lslam_debug_cert_stats(ctx.h, cs)
         print("certificate path: searched %d of %d points swept (%.1f %%)" % (cs[0], cs[1], 100.0 * cs[0] / max(1, cs[1])), file=sys.stderr)
+
+    section_ticks = None
+    if section_clock is not None:
+        sc_out = (ctypes.c_uint64 * 10)()
+        section_clock(sc_out, 1)
+        section_ticks = [int(v) for v in sc_out]
 
     status, poses, sts = last
     pose_err = np.abs(poses - gts)
@@ -291,6 +303,8 @@ def main():
                 "setup_s_outside_timed_region": setup_s,
                 "gpu_loop_ms_per_step": loop_ms / args.steps,
                 "pose_err_vs_ground_truth_m": {"max": float(pose_err[:, 3:].max()), "median": float(np.median(pose_err[:, 3:].max(axis=1)))},
+                # the bits of the last step's poses: two builds (or two runs) that print the same number computed the same poses
+                "poses_crc32": "%08x" % (__import__("zlib").crc32(np.ascontiguousarray(poses, np.float32).tobytes()) & 0xFFFFFFFF),
                 "pose_err_vs_ground_truth_rad": float(pose_err[:, :3].max()),
                 "converged_scans": n_conv,
             },
@@ -299,6 +313,15 @@ def main():
             # library's communicator exists) the rank count RCCL itself reports
             "ranks": {"world": world, "per_rank_value": per_rank, "rccl_ranks": None},
         }
+        if section_ticks is not None:
+            names = ["block, state, point, transform, carried bound", "probe set-up (cell table loads, row table)", "candidate loop",
+                     "survivors: exact distances, order, proof", "pass-2 list (workgroup barrier), carried state written",
+                     "residual chain (neighbours fetched, fit, coefficient, Jacobian row)", "-", "wait for the workgroup's slowest wavefront",
+                     "staging, MFMA contraction, record"]
+            tot = float(sum(section_ticks[:9])) or 1.0
+            out["section_clock"] = {"kernel": "sweep_grid_kernel (pass 1), one workgroup in sixteen reporting", "wavefronts": section_ticks[9],
+                                    "ticks_per_wavefront": tot / max(1, section_ticks[9]),
+                                    "share": {names[i]: section_ticks[i] / tot for i in range(9) if i != 6}}
     if ctx.grid_launches() > 0:  # what share of the points the grid sweeps left to the tree search (one more step, counted; untimed)
         import ctypes
         opts.debug_stats = 1
@@ -523,7 +546,7 @@ def compact_line(out):
     cfg = out.get("config") or {}
     c = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                  "scaling", "vs_baseline", "dtype", "data", "timed_region_s", "lm_iters_per_s")}
-    for k in ("dry_run", "ranks_counted"):
+    for k in ("dry_run", "ranks_counted", "section_clock"):  # (section_clock: experiment builds only)
         if k in out:
             c[k] = out[k]
     c["config"] = {"workload": cfg.get("workload"), "scans_per_step_per_gpu": cfg.get("scans_per_step_per_gpu"),
@@ -531,7 +554,7 @@ def compact_line(out):
                    "map_frames": _pick(cfg, "map", "frames"), "map_corner": _pick(cfg, "map", "surround_corner"),
                    "map_surf": _pick(cfg, "map", "surround_surf"), "gn_iters_per_scan": cfg.get("gn_iters_per_scan"),
                    "search": cfg.get("search"), "parallelism": cfg.get("parallelism"),
-                   "pose_err_vs_ground_truth_m": _pick(cfg, "pose_err_vs_ground_truth_m", "max"),
+                   "pose_err_vs_ground_truth_m": _pick(cfg, "pose_err_vs_ground_truth_m", "max"), "poses_crc32": cfg.get("poses_crc32"),
                    "converged_scans": cfg.get("converged_scans")}
     c["roofline"] = {"kernel": roof.get("kernel_short") or (roof.get("kernel") or "")[:120], "bound": roof.get("bound"),
                      "achieved": roof.get("achieved"), "peak": roof.get("peak"), "unit": roof.get("unit"), "frac": roof.get("frac"),

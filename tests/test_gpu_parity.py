@@ -794,16 +794,14 @@ def test_sharded_points_gn_loop(pkg, ctx, oracle, small_problem, monkeypatch):
     assert np.array_equal(bits(out[0][1]), bits(out[1][1]))  # every rank ends on the same pose
 
 
-def test_device_morton_order_equals_host_definition(ctx, small_problem):
+def test_device_morton_order_equals_host_definition():
     """The resident scans are Morton-ordered on the device (one radix sort per batch); the order is
     defined by the host implementation (ascending (key, index) per cloud).  The summation order of
-    the sweep depends on it, so equal pose BITS from a child process that orders on the host
-    (LSLAM_HOST_MORTON=1) mean the two orders are identical."""
+    the sweep depends on it, so equal pose BITS from two child processes, one ordering on the device
+    and one on the host (LSLAM_HOST_MORTON=1), mean the two orders are identical (the switches are
+    read once per process, hence the children)."""
     import subprocess
     import sys
-    pr = small_problem
-    ctx.map_set(pr["map_corner"], pr["map_surf"])
-    status, pose, st = ctx.scanmatch_scan(pr["corner"], pr["surf"], pr["init_pose"])
     code = (
         "import importlib,sys,numpy as np\n"
         "sys.path.insert(0, %r)\n"
@@ -813,13 +811,17 @@ def test_device_morton_order_equals_host_definition(ctx, small_problem):
         "s,p,st=c.scanmatch_scan(pr['corner'], pr['surf'], pr['init_pose'])\n"
         "print('BITS', ' '.join(str(int(v)) for v in p.view(np.int32)), st.iterations, st.n_rows)\n"
     ) % (ROOT,)
-    env = dict(os.environ, LSLAM_HOST_MORTON="1")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    line = [l for l in out.stdout.splitlines() if l.startswith("BITS")]
-    assert line, out.stderr[-2000:]
-    f = line[0].split()[1:]
-    assert [int(v) for v in f[:6]] == [int(v) for v in bits(pose)]
-    assert int(f[6]) == st.iterations and int(f[7]) == st.n_rows
+    lines = {}
+    for name in ("LSLAM_DEVICE_MORTON_IS_THE_DEFAULT", "LSLAM_HOST_MORTON", "LSLAM_NO_MORTON"):
+        env = {k: v for k, v in os.environ.items() if not k.endswith("_MORTON")}
+        env[name] = "1"
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in out.stdout.splitlines() if l.startswith("BITS")]
+        assert line, out.stderr[-2000:]
+        lines[name] = line[0]
+    assert lines["LSLAM_DEVICE_MORTON_IS_THE_DEFAULT"] == lines["LSLAM_HOST_MORTON"]
+    # (and the order matters to the bits at all: the caller's order gives other sums -- else the test above proves nothing)
+    assert lines["LSLAM_NO_MORTON"] != lines["LSLAM_HOST_MORTON"]
 
 
 def test_posegraph_full_size_properties(pkg, synth):

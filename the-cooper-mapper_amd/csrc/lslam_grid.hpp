@@ -81,6 +81,25 @@ LSLAM_DEV uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
   return r;
 }
 
+#ifdef LSLAM_EXP_SECTION_CLOCK  // TIMING EXPERIMENT (same results): where a wavefront of sweep_grid_kernel spends its life, section by section
+struct SecClock {
+  unsigned long long last, acc[10];
+};
+// (the clobber keeps memory operations on their side of a section's end; loads are waited for where their values are used)
+#define LSLAM_TICK_AT(S, n)                                                                   \
+  do {                                                                                        \
+    unsigned long long t_;                                                                    \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+    (S).acc[n] += t_ - (S).last;                                                              \
+    (S).last = t_;                                                                            \
+  } while (0)
+#define LSLAM_TICK_P(P, n) do { if (P) LSLAM_TICK_AT(*(P), n); } while (0)
+#define LSLAM_SEC_PARAM , SecClock *scp = nullptr
+#else
+#define LSLAM_TICK_P(P, n) do { } while (0)
+#define LSLAM_SEC_PARAM
+#endif
+
 // knn5_grid's verdict
 enum : int {
   GRID_UNPROVEN = 0,  // the five returned are not proven to be nanoflann's answer: search the tree
@@ -111,7 +130,7 @@ enum : int {
 // probe saw).  rows: 2 (2R + 1)^2 words per lane.
 template <int BLOCK, int R = 1>
 LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const float qy, const float qz, const float bound,
-                        const float clip_margin, lds_u32 *rows, float (&d)[5], int (&p)[5], float &lb6) {
+                        const float clip_margin, lds_u32 *rows, float (&d)[5], int (&p)[5], float &lb6 LSLAM_SEC_PARAM) {
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     d[i] = FLT_MAX;
@@ -217,6 +236,7 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
     ncur = rows[2 * BLOCK];
     nend = rows[3 * BLOCK];
   }
+  LSLAM_TICK_P(scp, 1);  // probe set-up: cell coordinates, clip box, eighteen cell-table loads, the row table
 #if LSLAM_GRID_ASM_LOOP
   // (The loop's distance is a KEY, not the reference's distance: dx dx, then two fused multiply-adds -- six instructions instead
   // of the eight of L2_Simple's rounded squares and sums.  It differs from the exact fp32 distance by at most a few ulps
@@ -385,6 +405,7 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
     }
   }
 #endif
+  LSLAM_TICK_P(scp, 2);  // the candidate loop
   // the survivors: place in the row table -> position in G.pts -> exact distance
   const uint32_t ks[6] = {k0, k1, k2, k3, k4, k5};
   uint32_t pos[6];

@@ -138,7 +138,12 @@ LSLAM_DEV void point_residual(const SweepArgs &a, const BlockDesc &bd, const boo
 // The block's 27 normal-equation sums and counters from its lanes' rows (ScanMatch.cpp:206-208 products): per-wave contraction
 // (MFMA f32 16x16x4 through `stage`, eight word rows of BLOCK lanes that the wavefront owns, or VALU + wave shuffles), then a
 // fixed-order sum over the block's waves.  ADD: onto the record another launch left (pass 2 of a two-pass sweep).
-template <int BLOCK, bool FUSE, bool ADD>
+// PAD: words added to the staging rows' stride of BLOCK.  With the stride a multiple of the 64 banks the eight lanes that fetch
+// the eight rows' entries of one point for an MFMA step share a bank (an eight-way conflict in every one of the sixteen steps);
+// with PAD = 4 the 32 words of a step lie in 32 banks.  Same words to the same lanes: same bits.  Only for a caller whose `stage`
+// is free of other wavefronts' data (a padded row reaches into the neighbouring wavefronts' columns): the grid sweep, behind
+// its workgroup barrier; the tree sweeps stage in the columns of their own traversal stacks, without one.
+template <int BLOCK, bool FUSE, bool ADD, int PAD = 0>
 LSLAM_DEV void block_accumulate(const int jtj_mode, const bool is_surf, const float (&row)[6], const float rb, const float kept,
                                 const float matched, const float score, uint32_t *stage, float (*red)[NCOL], float *partial_out) {
   constexpr int NWAVE = BLOCK / 64;
@@ -155,18 +160,19 @@ LSLAM_DEV void block_accumulate(const int jtj_mode, const bool is_surf, const fl
   if (jtj_mode == 1) {
 #endif
     // stage [J | b] rows; rows of rejected points are zero
-    float *jr = reinterpret_cast<float *>(stage) + wave * 64;  // [c * BLOCK + p]
+    constexpr int ST = BLOCK + PAD;
+    float *jr = reinterpret_cast<float *>(stage) + wave * 64;  // [c * ST + p]
 #pragma unroll
-    for (int c = 0; c < 6; ++c) jr[c * BLOCK + lane] = row[c];
-    jr[6 * BLOCK + lane] = rb;
-    jr[7 * BLOCK + lane] = 0.0f;
+    for (int c = 0; c < 6; ++c) jr[c * ST + lane] = row[c];
+    jr[6 * ST + lane] = rb;
+    jr[7 * ST + lane] = 0.0f;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     const int i16 = lane & 15, k4 = lane >> 4;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      const float op = (i16 < 8) ? jr[i16 * BLOCK + 4 * s + k4] : 0.0f;
+      const float op = (i16 < 8) ? jr[i16 * ST + 4 * s + k4] : 0.0f;
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(op, op, acc, 0, 0, 0);
     }
     // C/D layout: col = lane&15, row = (lane>>4)*4 + reg.  Entry (r,c), r<=c<7.
@@ -997,6 +1003,12 @@ hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, h
 #ifndef LSLAM_GRID_OCC
 #define LSLAM_GRID_OCC 6  // wavefronts per SIMD the grid sweep is compiled for: 80 VGPRs (5: 90 VGPRs, 8 % slower; 7: below; 8: 64 VGPRs with 96 B of scratch, slower than 5)
 #endif
+#ifndef LSLAM_STAGE_PAD
+#define LSLAM_STAGE_PAD 0
+#endif
+#ifdef LSLAM_EXP_SECTION_CLOCK
+__device__ unsigned long long g_section_clock[10 * 64];  // [section][place]: s_memtime ticks; section 9 = wavefronts reporting
+#endif
 LSLAM_DEV void wide_probe(const CellGrid &G, const float (&sel)[3], float r2, int lane, float nf_slack, float (&d)[5], int (&p)[5], bool &num, bool &bad);
 
 // WIDE (A/B, LSLAM_AB_WIDE_IN_PLACE; a map without kd-trees, a launch too small to fill the chip -- the mapping node's frame):
@@ -1023,6 +1035,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 
   const bool is_surf = bd.is_surf != 0;
   const int qi = bd.first + tid;
   const bool active = tid < bd.count;
+#ifdef LSLAM_EXP_SECTION_CLOCK
+  SecClock lslam_sc;
+  SecClock *const scp = &lslam_sc;
+  {
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(lslam_sc.last)::"memory");
+#pragma unroll
+    for (int i = 0; i < 10; ++i) lslam_sc.acc[i] = 0;
+  }
+#define LSLAM_SEC_ARG , scp
+#else
+#define LSLAM_SEC_ARG
+#endif
 
   float R[9], t[3], sc[6];
   {
@@ -1085,7 +1109,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 
     asm volatile("" ::"v"(acc));
   }
 #endif
-  int verdict = knn5_grid<BLOCK>(G, active, sel[0], sel[1], sel[2], bound, a.grid_clip_margin, (lds_u32 *)(rows_lds + tid), d, p, lb6);
+#ifdef LSLAM_EXP_SLEEP  // TIMING EXPERIMENT ONLY (same results): every wavefront parked for 64 x LSLAM_EXP_SLEEP cycles -- what a microsecond of latency costs
+  __builtin_amdgcn_s_sleep(LSLAM_EXP_SLEEP);
+#endif
+  LSLAM_TICK_P(scp, 0);  // block and state fetched, the point, its transform, the carried bound
+  int verdict = knn5_grid<BLOCK>(G, active, sel[0], sel[1], sel[2], bound, a.grid_clip_margin, (lds_u32 *)(rows_lds + tid), d, p, lb6 LSLAM_SEC_ARG);
+  LSLAM_TICK_P(scp, 3);  // the six survivors fetched again, exact distances, order, proof
   // beyond the gate nothing is looked up (ScanMatch.cpp:102,120); the taps and the _fineScore re-sweep want nanoflann's answer
   if (verdict == GRID_FAR && !a.bounded) verdict = GRID_UNPROVEN;
   bool needy = active && verdict == GRID_UNPROVEN;
@@ -1245,9 +1274,22 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 
       }
     }
   }
+  LSLAM_TICK_P(scp, 4);  // the list of pass 2 (one workgroup barrier), the carried state written
   if (has && !fit_done) point_residual(a, bd, is_surf, G.pts, q, sel, d, p, sc, row, rb, kept, matched, score);
+  LSLAM_TICK_P(scp, 5);  // the residual chain: five neighbours fetched, findLine / findPlane, coefficient, Jacobian row, score
   __syncthreads();  // every wavefront is done with its row table: the staging rows may be written
-  block_accumulate<BLOCK, false, false>(jtj_mode, is_surf, row, rb, kept, matched, score, rows_lds, red, a.partials + (size_t)lb * NCOL);
+  LSLAM_TICK_P(scp, 7);  // waiting for the workgroup's slowest wavefront
+  block_accumulate<BLOCK, false, false, LSLAM_STAGE_PAD>(jtj_mode, is_surf, row, rb, kept, matched, score, rows_lds, red, a.partials + (size_t)lb * NCOL);
+#ifdef LSLAM_EXP_SECTION_CLOCK
+  LSLAM_TICK_P(scp, 8);  // staging, the MFMA contraction, the workgroup's record
+  if ((lb & 15) == 0 && lane == 0) {  // one workgroup in sixteen reports (atomics on 64 places per section)
+    const int place = (lb >> 4) & 63;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) atomicAdd(&g_section_clock[i * 64 + place], lslam_sc.acc[i]);
+    atomicAdd(&g_section_clock[9 * 64 + place], 1ull);
+  }
+#endif
+#undef LSLAM_SEC_ARG
 }
 
 // The workgroups of the scans whose loop is still running, in block order: late in a batch's loops most scans have converged,
@@ -2160,3 +2202,22 @@ hipError_t launch_knn5(const TreeView &T, const float4 *q, int nq, int32_t *idx,
 }
 
 }  // namespace lslam
+
+#ifdef LSLAM_EXP_SECTION_CLOCK
+// (experiment build only, not part of the ABI) out[10]: s_memtime ticks per section of sweep_grid_kernel summed over the reporting
+// wavefronts (one workgroup in sixteen), out[9] = how many reported; reset != 0 zeroes the counters afterwards
+extern "C" int lslam_debug_section_clock(uint64_t *out, int reset) {
+  static unsigned long long h[10 * 64];
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(lslam::g_section_clock), sizeof(h)) != hipSuccess) return -1;
+  for (int i = 0; i < 10; ++i) {
+    out[i] = 0;
+    for (int k = 0; k < 64; ++k) out[i] += h[i * 64 + k];
+  }
+  if (reset) {
+    for (auto &v : h) v = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(lslam::g_section_clock), h, sizeof(h)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

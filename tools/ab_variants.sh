@@ -12,7 +12,7 @@ for r in $(seq 1 $rounds); do
     python - <<PY
 import json
 d=json.loads(open("gpurun_out/abv_$v.json").read().strip().splitlines()[-1])
-print("round $r %-14s value %.4e  ms/step %.3f  sweep %.4f ms  launches %d iters %.2f unproven %.4f  pose_err %.4f conv %d" % ("$v", d["value"], d["ms_per_step"], d["roofline"]["avg_kernel_ms"], d["roofline"]["launches_timed"], d["config"]["gn_iters_per_scan"], d["grid_sweep"]["share_left_to_the_tree_search"], d["config"]["pose_err_vs_ground_truth_m"], d["config"]["converged_scans"]))
+print("round $r %-14s value %.4e  ms/step %.3f  sweep %.4f ms  launches %d iters %.2f unproven %.4f  pose_err %.4f conv %d poses %s" % ("$v", d["value"], d["ms_per_step"], d["roofline"]["avg_kernel_ms"], d["roofline"]["launches_timed"], d["config"]["gn_iters_per_scan"], d["grid_sweep"]["share_left_to_the_tree_search"], d["config"]["pose_err_vs_ground_truth_m"], d["config"]["converged_scans"], d["config"].get("poses_crc32")))
 PY
   done
 done

@@ -225,7 +225,7 @@ def main():
     if section_clock is not None:
         import ctypes
         section_clock.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
-        section_clock((ctypes.c_uint64 * 10)(), 1)
+        section_clock((ctypes.c_uint64 * 12)(), 1)
 
     barrier()
     t0 = time.perf_counter()
@@ -256,7 +256,7 @@ def main():
 
     section_ticks = None
     if section_clock is not None:
-        sc_out = (ctypes.c_uint64 * 10)()
+        sc_out = (ctypes.c_uint64 * 12)()
         section_clock(sc_out, 1)
         section_ticks = [int(v) for v in sc_out]
 
@@ -321,6 +321,9 @@ def main():
             tot = float(sum(section_ticks[:9])) or 1.0
             out["section_clock"] = {"kernel": "sweep_grid_kernel (pass 1), one workgroup in sixteen reporting", "wavefronts": section_ticks[9],
                                     "ticks_per_wavefront": tot / max(1, section_ticks[9]),
+                                    "candidates_per_point": section_ticks[10] / max(1, 64 * section_ticks[9]),
+                                    "loop_rounds_per_wavefront": section_ticks[11] / max(1, 64 * section_ticks[9]),
+                                    "loop_lane_use": section_ticks[10] / max(1, section_ticks[11]),
                                     "share": {names[i]: section_ticks[i] / tot for i in range(9) if i != 6}}
     if ctx.grid_launches() > 0:  # what share of the points the grid sweeps left to the tree search (one more step, counted; untimed)
         import ctypes

@@ -84,6 +84,7 @@ LSLAM_DEV uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
 #ifdef LSLAM_EXP_SECTION_CLOCK  // TIMING EXPERIMENT (same results): where a wavefront of sweep_grid_kernel spends its life, section by section
 struct SecClock {
   unsigned long long last, acc[10];
+  unsigned long long cand_sum, cand_rounds;  // candidates of the wavefront's lanes; 64 x its slowest lane's (the loop's rounds x 64)
 };
 // (the clobber keeps memory operations on their side of a section's end; loads are waited for where their values are used)
 #define LSLAM_TICK_AT(S, n)                                                                   \
@@ -198,10 +199,16 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
   // non-empty, unclipped runs, compacted into this lane's LDS table
   int nrow = 0;
   bool row_overflow = false;
+#ifdef LSLAM_EXP_SECTION_CLOCK
+  uint32_t cand_lane = 0;
+#endif
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const float jy = fy0 + (float)((r % W) - R), jz = fz0 + (float)((r / W) - R);
     const bool use = alive0 && rowon[r] && jy >= ylo && jy <= yhi && jz >= zlo && jz <= zhi && re[r] > rs[r];
+#ifdef LSLAM_EXP_SECTION_CLOCK
+    cand_lane += use ? re[r] - rs[r] : 0u;
+#endif
     if (use) {
       rows[2 * nrow * BLOCK] = rs[r];
       rows[(2 * nrow + 1) * BLOCK] = re[r];
@@ -236,6 +243,18 @@ LSLAM_DEV int knn5_grid(const CellGrid &G, const bool on, const float qx, const 
     ncur = rows[2 * BLOCK];
     nend = rows[3 * BLOCK];
   }
+#ifdef LSLAM_EXP_SECTION_CLOCK
+  if (scp) {
+    uint32_t cs = cand_lane, cm = cand_lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      cs += __shfl_xor(cs, o, 64);
+      cm = max(cm, (uint32_t)__shfl_xor(cm, o, 64));
+    }
+    scp->cand_sum += __builtin_amdgcn_readfirstlane(cs);
+    scp->cand_rounds += 64u * __builtin_amdgcn_readfirstlane(cm);
+  }
+#endif
   LSLAM_TICK_P(scp, 1);  // probe set-up: cell coordinates, clip box, eighteen cell-table loads, the row table
 #if LSLAM_GRID_ASM_LOOP
   // (The loop's distance is a KEY, not the reference's distance: dx dx, then two fused multiply-adds -- six instructions instead

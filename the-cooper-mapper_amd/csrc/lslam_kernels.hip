@@ -1007,7 +1007,7 @@ hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, h
 #define LSLAM_STAGE_PAD 0
 #endif
 #ifdef LSLAM_EXP_SECTION_CLOCK
-__device__ unsigned long long g_section_clock[10 * 64];  // [section][place]: s_memtime ticks; section 9 = wavefronts reporting
+__device__ unsigned long long g_section_clock[12 * 64];  // [section][place]: s_memtime ticks; 9 = wavefronts reporting, 10 / 11 = candidates, 64 x rounds
 #endif
 LSLAM_DEV void wide_probe(const CellGrid &G, const float (&sel)[3], float r2, int lane, float nf_slack, float (&d)[5], int (&p)[5], bool &num, bool &bad);
 
@@ -1042,6 +1042,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(lslam_sc.last)::"memory");
 #pragma unroll
     for (int i = 0; i < 10; ++i) lslam_sc.acc[i] = 0;
+    lslam_sc.cand_sum = lslam_sc.cand_rounds = 0;
   }
 #define LSLAM_SEC_ARG , scp
 #else
@@ -1287,6 +1288,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 
 #pragma unroll
     for (int i = 0; i < 9; ++i) atomicAdd(&g_section_clock[i * 64 + place], lslam_sc.acc[i]);
     atomicAdd(&g_section_clock[9 * 64 + place], 1ull);
+    atomicAdd(&g_section_clock[10 * 64 + place], lslam_sc.cand_sum);
+    atomicAdd(&g_section_clock[11 * 64 + place], lslam_sc.cand_rounds);
   }
 #endif
 #undef LSLAM_SEC_ARG
@@ -2204,13 +2207,13 @@ hipError_t launch_knn5(const TreeView &T, const float4 *q, int nq, int32_t *idx,
 }  // namespace lslam
 
 #ifdef LSLAM_EXP_SECTION_CLOCK
-// (experiment build only, not part of the ABI) out[10]: s_memtime ticks per section of sweep_grid_kernel summed over the reporting
+// (experiment build only, not part of the ABI) out[12]: s_memtime ticks per section of sweep_grid_kernel summed over the reporting
 // wavefronts (one workgroup in sixteen), out[9] = how many reported; reset != 0 zeroes the counters afterwards
 extern "C" int lslam_debug_section_clock(uint64_t *out, int reset) {
-  static unsigned long long h[10 * 64];
+  static unsigned long long h[12 * 64];
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(lslam::g_section_clock), sizeof(h)) != hipSuccess) return -1;
-  for (int i = 0; i < 10; ++i) {
+  for (int i = 0; i < 12; ++i) {
     out[i] = 0;
     for (int k = 0; k < 64; ++k) out[i] += h[i * 64 + k];
   }

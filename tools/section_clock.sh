@@ -18,6 +18,8 @@ b = json.loads(open("gpurun_out/abv_base.json").read().strip().splitlines()[-1])
 sc = d["section_clock"]
 print("sweep_grid_kernel, %d wavefronts reporting, %.0f s_memtime ticks per wavefront; sweep %.4f ms with the clocks, %.4f without" %
       (sc["wavefronts"], sc["ticks_per_wavefront"], d["roofline"]["avg_kernel_ms"], b["roofline"]["avg_kernel_ms"]))
+print("candidate loop: %.1f candidates per point (lanes without a point included), %.1f rounds per wavefront: %.3f of the lane-rounds carry a candidate" %
+      (sc["candidates_per_point"], sc["loop_rounds_per_wavefront"], sc["loop_lane_use"]))
 for k, v in sc["share"].items():
     print("  %5.1f %%  %s" % (100 * v, k))
 json.dump({"with_clocks": d, "base": b}, open("gpurun_out/section_clock.json", "w"), indent=1)

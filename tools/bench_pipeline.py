@@ -24,6 +24,10 @@ for k in range(int(os.environ.get("SWEEPS", "8"))):
     raws.append(cloud[np.lexsort((ring, -(cloud[:, 3] - ring)))])
 acc = {"register": 0.0, "extract": 0.0, "odometry": 0.0, "mapping": 0.0}
 n = 0
+# (as bench.py does before its timed regions: a generation-2 pass of the interpreter's garbage collector takes tens of milliseconds
+# with torch and numpy loaded and lands in whichever call allocates the triggering object -- here it used to be sweep 5's odometry)
+import gc
+gc.collect(); gc.freeze(); gc.disable()
 for k, raw in enumerate(raws):
     t0 = time.perf_counter(); reg, rr = sr.multiscan_register(ctx, raw, lo, hi, rings)
     if DEV:

@@ -563,6 +563,7 @@ const EnvOnce &env_once() {
     v.debug = on("LSLAM_DEBUG");
     v.unbounded_knn = on("LSLAM_UNBOUNDED_KNN");
     v.no_morton = on("LSLAM_NO_MORTON");
+    v.fmap_one_stream = on("LSLAM_FMAP_ONE_STREAM");
     v.host_morton = on("LSLAM_HOST_MORTON");
     v.odom_inline = on("LSLAM_ODOM_INLINE_SEARCH");
     v.odom_trees = on("LSLAM_ODOM_TREES");

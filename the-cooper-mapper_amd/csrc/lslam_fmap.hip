@@ -652,6 +652,12 @@ struct lslam_fmap {
   std::vector<int32_t> h_gsrc[2], h_gdst[2];
   Buf<float4> sur[2];
   Scratch sc;
+  // addFeatureCloud's two feature types are independent chains of a dozen small launches each: the surf chain runs on a stream
+  // of the map's own beside the corner chain (fork / join by events on the context's stream; LSLAM_FMAP_ONE_STREAM=1: one after
+  // the other as before), with a scratch of its own
+  Scratch sc2;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // ---- per-cube kd-trees kept between frames (lslam_fmap_to_cubemap; FeatureMap.h:438,453 _kdtreeCorner/_kdtreeSurf) ----
   // A cube's tree is rebuilt only when its cloud changed: addFeatureCloud marks the cubes that received points
   // (the VoxelGrid re-filter of an untouched cube reproduces its cloud bit for bit), shifts and loads mark all.
@@ -885,8 +891,9 @@ int map_axis_bits(const lslam_fmap *fm, float leaf) { return bits_for((double)fm
 // on the device; see run_pipeline) -- addFeatureCloud's case.
 int rebuild_begin(lslam_fmap *fm, int t, size_t n_new, bool allow_filter, const uint8_t *flags_override, uint32_t *done,
                   const float4 *in_tf = nullptr, const int32_t *in_cube = nullptr, size_t *n_out_sync = nullptr,
-                  bool old_sorted = false) {
-  hipStream_t s = fm->stream;
+                  bool old_sorted = false, hipStream_t on_stream = nullptr, Scratch *scratch = nullptr) {
+  hipStream_t s = on_stream ? on_stream : fm->stream;
+  Scratch &sc = scratch ? *scratch : fm->sc;
   const size_t n_old = fm->n[t], n_total = n_old + n_new;
   if (done) done[0] = done[1] = done[2] = 0;
   if (n_total == 0) return LSLAM_OK;
@@ -902,7 +909,7 @@ int rebuild_begin(lslam_fmap *fm, int t, size_t n_new, bool allow_filter, const 
   FM_TRY(fm->cube_alt[t].reserve(n_total));
   KeyParams kp = key_params(fm, fm->leaf[t]);
   size_t n_out = 0;
-  int rc = run_pipeline(s, fm->sc, fm->pts[t].p, fm->cube[t].p, n_total, kp, fm->ncube,
+  int rc = run_pipeline(s, sc, fm->pts[t].p, fm->cube[t].p, n_total, kp, fm->ncube,
                         flags_override ? flags_override : (allow_filter ? fm->active.p : nullptr), fm->pts_alt[t].p,
                         fm->cube_alt[t].p, &n_out, map_axis_bits(fm, fm->leaf[t]), done, old_sorted && n_new ? n_old : 0, true);
   if (n_out_sync) *n_out_sync = n_out;
@@ -1182,6 +1189,13 @@ void lslam_fmap_destroy(lslam_fmap *fm) {
   }
   fm->done.release(); fm->h_touched.release();
   fm->sc.release();
+  fm->sc2.release();
+  if (fm->stream2) {
+    (void)hipStreamSynchronize(fm->stream2);
+    (void)hipStreamDestroy(fm->stream2);
+  }
+  if (fm->ev_fork) (void)hipEventDestroy(fm->ev_fork);
+  if (fm->ev_join) (void)hipEventDestroy(fm->ev_join);
   delete fm;
 }
 
@@ -1260,7 +1274,10 @@ int lslam_fmap_add_feature_cloud(lslam_fmap *fm, const void *corner, size_t n_co
                                  size_t n_surf, size_t stride_bytes, const float T[16]) {
   const int rc = add_feature_cloud_impl(fm, corner, n_corner, surf, n_surf, stride_bytes, T);
   // a failure half way leaves copies out of the pinned staging in flight: nothing may reuse it before they are done
-  if (rc != LSLAM_OK && fm && lslam::ctx_alive(fm->ctx)) (void)hipStreamSynchronize(fm->stream);
+  if (rc != LSLAM_OK && fm && lslam::ctx_alive(fm->ctx)) {
+    if (fm->stream2) (void)hipStreamSynchronize(fm->stream2);
+    (void)hipStreamSynchronize(fm->stream);
+  }
   return rc;
 }
 static int add_feature_cloud_impl(lslam_fmap *fm, const void *corner, size_t n_corner, const void *surf, size_t n_surf,
@@ -1284,26 +1301,43 @@ static int add_feature_cloud_impl(lslam_fmap *fm, const void *corner, size_t n_c
   const void *src[2] = {corner, surf};
   const size_t cnt[2] = {n_corner, n_surf};
   FM_TRY(fm->h_touched.reserve(2 * (size_t)fm->ncube));
+  // two chains, two streams -- when both types have something to rebuild
+  const bool two = !lslam::env_once().fmap_one_stream && (fm->n[0] + cnt[0]) && (fm->n[1] + cnt[1]);
+  if (two) {
+    if (!fm->stream2) {
+      FM_TRY(hipStreamCreateWithFlags(&fm->stream2, hipStreamNonBlocking));
+      FM_TRY(hipEventCreateWithFlags(&fm->ev_fork, hipEventDisableTiming));
+      FM_TRY(hipEventCreateWithFlags(&fm->ev_join, hipEventDisableTiming));
+    }
+    FM_TRY(hipEventRecord(fm->ev_fork, s));  // behind whatever the context's stream still does with the surf arrays
+    FM_TRY(hipStreamWaitEvent(fm->stream2, fm->ev_fork, 0));
+  }
   for (int t = 0; t < 2; ++t) {
     const size_t n = cnt[t];
+    hipStream_t st = (two && t == 1) ? fm->stream2 : s;
     if (n) {
-      rc = pack_input(s, fm->in_pin[t], fm->in_raw_t[t], src[t], n, stride_bytes);
+      rc = pack_input(st, fm->in_pin[t], fm->in_raw_t[t], src[t], n, stride_bytes);
       if (rc) return rc;
       // the transformed points go straight behind the type's current points, where the rebuild wants them (was: a staging
       // array of their own and two device-to-device copies per type)
-      FM_TRY(fm->pts[t].grow(fm->n[t] + n, fm->n[t], s));
-      FM_TRY(fm->cube[t].grow(fm->n[t] + n, fm->n[t], s));
+      FM_TRY(fm->pts[t].grow(fm->n[t] + n, fm->n[t], st));
+      FM_TRY(fm->cube[t].grow(fm->n[t] + n, fm->n[t], st));
       KeyParams kp = key_params(fm, fm->leaf[t]);
       if (track) {
         FM_TRY(fm->d_touched_t[t].reserve(((size_t)fm->ncube + 15) & ~(size_t)15));
-        FM_TRY(hipMemsetAsync(fm->d_touched_t[t].p, 0, ((size_t)fm->ncube + 15) & ~(size_t)15, s));  // (a whole number of 16-byte words: one fill launch, no tail)
+        FM_TRY(hipMemsetAsync(fm->d_touched_t[t].p, 0, ((size_t)fm->ncube + 15) & ~(size_t)15, st));  // (a whole number of 16-byte words: one fill launch, no tail)
       }
-      hipLaunchKernelGGL(fm_transform_kernel, dim3(((int)n + 255) / 256), dim3(256), 0, s, fm->in_raw_t[t].p, (int)n,
+      hipLaunchKernelGGL(fm_transform_kernel, dim3(((int)n + 255) / 256), dim3(256), 0, st, fm->in_raw_t[t].p, (int)n,
                          Tm, kp, fm->pts[t].p + fm->n[t], fm->cube[t].p + fm->n[t], track ? fm->d_touched_t[t].p : (uint8_t *)nullptr);
-      if (track) FM_TRY(hipMemcpyAsync(fm->h_touched.p + (size_t)t * fm->ncube, fm->d_touched_t[t].p, fm->ncube, hipMemcpyDeviceToHost, s));
+      if (track) FM_TRY(hipMemcpyAsync(fm->h_touched.p + (size_t)t * fm->ncube, fm->d_touched_t[t].p, fm->ncube, hipMemcpyDeviceToHost, st));
     }
-    rc = rebuild_begin(fm, t, n, true, nullptr, fm->done.p + 4 * t, fm->pts[t].p + fm->n[t], fm->cube[t].p + fm->n[t], nullptr, true);
+    rc = rebuild_begin(fm, t, n, true, nullptr, fm->done.p + 4 * t, fm->pts[t].p + fm->n[t], fm->cube[t].p + fm->n[t], nullptr, true, st,
+                       (two && t == 1) ? &fm->sc2 : &fm->sc);
     if (rc) return rc;
+  }
+  if (two) {
+    FM_TRY(hipEventRecord(fm->ev_join, fm->stream2));
+    FM_TRY(hipStreamWaitEvent(s, fm->ev_join, 0));
   }
   FM_TRY(hipStreamSynchronize(s));
   for (int t = 0; t < 2; ++t) {

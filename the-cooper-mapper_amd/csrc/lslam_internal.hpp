@@ -428,6 +428,7 @@ struct EnvOnce {
   bool no_reg_nodes = false;     // LSLAM_NO_REG_NODES
   bool no_level_build = false;   // LSLAM_NO_LEVEL_BUILD
   bool fmap_timing = false;      // LSLAM_FMAP_TIMING
+  bool fmap_one_stream = false;  // LSLAM_FMAP_ONE_STREAM: addFeatureCloud's two feature types one after the other on the context's stream (A/B)
   int fx_helpers = 3;                  // LSLAM_FX_HELPERS=0..7: helper workgroups per ring for pointClassify (fx_ring_kernel); 0 = A/B: none
   bool grid_one_stream = false;        // LSLAM_GRID_ONE_STREAM=1: A/B switch -- a deferred map's two cell grids one after the other on the context's stream
   bool small_sort = false;             // LSLAM_SMALL_SORT=1: A/B switch -- a frame's sorts by lslam_sort.hip instead of rocprim::radix_sort_pairs (measured slower: see there)

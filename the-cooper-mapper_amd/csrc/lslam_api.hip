@@ -219,6 +219,7 @@ struct lslam_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> sweep_ev;
   int iter_hint = 4;  // size of the first batch of enqueued GN iterations
+  int iter_last = -1, iter_same = 0;  // the last call's iteration count, and for how many calls in a row it has been that
   // gn_persistent_kernel (one resident scan: the whole loop in one cooperative launch)
   DevBuf<float> gnp_slots;
   DevBuf<unsigned> gnp_bar;
@@ -2180,7 +2181,11 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
     max_sweeps = std::max(max_sweeps, ctx->h_state[p].sweeps);
     max_iter = std::max(max_iter, ctx->h_state[p].iter);
   }
-  ctx->iter_hint = max_iter + 1;
+  // the spare iteration (five immediate exits of 4 - 5 us each on the grid path) is dropped once three calls in a row ran the
+  // same number of iterations -- a mapping node's frames do; a loop that then needs one more costs one more round trip
+  ctx->iter_same = (max_iter == ctx->iter_last) ? std::min(ctx->iter_same + 1, 1000) : 0;
+  ctx->iter_last = max_iter;
+  ctx->iter_hint = max_iter + (ctx->iter_same >= 2 ? 0 : 1);
 
   float gpu_ms_total = 0.f, gpu_ms_sweep = 0.f;
   int sweep_launches = 0;

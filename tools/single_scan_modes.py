@@ -34,3 +34,30 @@ for rings in (64, 16):
                   % (rings, len(qc) + len(qs), "deferred" if defer else "built", name, 1e3 * np.median(ts), 1e3 * min(ts), np.median(g), st.iterations,
                      float(np.abs(pose[3:] - gt[3:].astype(np.float32)).max()), ctx.lazy_trees()), flush=True)
         ctx.close()
+
+# A mapping frame's scan (the 16-ring sweep's feature clouds through VoxelGrid 0.2 / 0.4: a few thousand points, about twenty
+# workgroups -- the size at which a launch per step is all latency): the kd-tree walk with a launch per sweep and per solve,
+# the same loop as ONE persistent launch (LSLAM_AB_PERSISTENT_GN, round 2: measured until now only on a 450-workgroup scan),
+# the solve in the sweep's tail (LSLAM_AB_FUSED_SOLVE), and the frame's own path (trees deferred: probe, plan, wide probe,
+# queue, solve -- five launches per iteration)
+fm_mod = importlib.import_module("the-cooper-mapper_amd.feature_map")
+qc, qs = lidar.scan(gt, 16, 1800, seed=4321)
+init = synth.perturb_pose(gt, seed=99)
+ctx = pkg.Context(0)
+fc, fs = fm_mod.voxel_grid(ctx, qc, 0.2), fm_mod.voxel_grid(ctx, qs, 0.4)
+ctx.close()
+for defer, name, mode, ab in ((False, "lane, a launch per step", 1, 0), (False, "lane, persistent loop", 1, 1), (False, "lane, fused solve", 1, 2),
+                              (True, "grid (the frame's path)", 0, 0), (True, "grid, fused solve", 0, 2)):
+    ctx = pkg.Context(0)
+    ctx.defer_trees(defer)
+    ctx.map_set(mc, ms)
+    ctx.scan_set(fc, fs)
+    o = ctx.default_opts(); o.search_mode = mode; o.ab_switches = ab
+    for _ in range(10): ctx.run(init, o)
+    ts = []; g = []
+    for _ in range(args.calls):
+        t = time.perf_counter(); status, pose, st = ctx.run(init, o); ts.append(time.perf_counter() - t); g.append(st.gpu_ms_total)
+    print("frame scan %5d pts (%d workgroups) trees %-8s %-26s: wall median %.3f ms  min %.3f  device %.3f ms  iterations %d  err %.4f m"
+          % (len(fc) + len(fs), (len(fc) + 255) // 256 + (len(fs) + 255) // 256, "deferred" if defer else "built", name, 1e3 * np.median(ts), 1e3 * min(ts),
+             np.median(g), st.iterations, float(np.abs(pose[3:] - gt[3:].astype(np.float32)).max())), flush=True)
+    ctx.close()

@@ -254,6 +254,12 @@ def main():
         ctx.lib.lslam_debug_cert_stats(ctx.h, cs)
         print("certificate path: searched %d of %d points swept (%.1f %%)" % (cs[0], cs[1], 100.0 * cs[0] / max(1, cs[1])), file=sys.stderr)
 
+    if hasattr(ctx.lib, "lslam_debug_pass2_hist"):  # (-DLSLAM_EXP_PASS2_CLASS builds: the second pass's searches by their starting bound)
+        import ctypes
+        h8 = (ctypes.c_uint64 * 8)()
+        ctx.lib.lslam_debug_pass2_hist.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+        ctx.lib.lslam_debug_pass2_hist(h8, 1)
+        print("pass-2 searches by starting bound (< 0.5, < 1, < 2, < 4.99 m^2, gate): %s" % [int(v) for v in h8[:5]], file=sys.stderr)
     section_ticks = None
     if section_clock is not None:
         sc_out = (ctypes.c_uint64 * 12)()

@@ -15,7 +15,7 @@
 // ctypes binding) refuses it -- unless the process says LSLAM_ALLOW_EXPERIMENT_BUILD=1, as the A/B scripts do.
 #if defined(LSLAM_EXP_COUNT_NOHINT) || defined(LSLAM_EXP_LOAD2) || defined(LSLAM_EXP_LOAD_TWICE) || defined(LSLAM_EXP_NO_ACC) || \
     defined(LSLAM_EXP_NO_FIT) || defined(LSLAM_EXP_NO_PASS2) || defined(LSLAM_EXP_PROCESS_TWICE) || defined(LSLAM_EXP_SETUP_TWICE) || \
-    defined(LSLAM_EXP_SECTION_CLOCK) || defined(LSLAM_EXP_SLEEP)
+    defined(LSLAM_EXP_SECTION_CLOCK) || defined(LSLAM_EXP_SLEEP) || defined(LSLAM_EXP_PASS2_CLASS)
 #define LSLAM_EXPERIMENT_BUILD 1
 #else
 #define LSLAM_EXPERIMENT_BUILD 0

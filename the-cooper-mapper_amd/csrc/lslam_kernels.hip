@@ -231,6 +231,12 @@ LSLAM_DEV void block_accumulate(const int jtj_mode, const bool is_surf, const fl
   }
 }
 
+#ifdef LSLAM_EXP_PASS2_CLASS
+#ifndef LSLAM_EXP_PASS2_SPLIT
+#define LSLAM_EXP_PASS2_SPLIT 1.0
+#endif
+__device__ unsigned long long g_pass2_hist[8];  // listed points by the bound their tree search starts from: < 0.5, < 1, < 2, < 4.99 m^2, the gate
+#endif
 #ifndef LSLAM_SHALLOW_OCC
 #define LSLAM_SHALLOW_OCC 5  // wavefronts per SIMD the shallow-stack variant is compiled for (96 VGPRs, 25 KB LDS per workgroup)
 #endif
@@ -616,6 +622,22 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
       a.prev_q[qi] = make_float4(sel[0], sel[1], sel[2], 0.0f);
       a.prev_lb[qi] = (p[4] >= 0 && d[4] < 5.0f) ? slb * 0.9999f : 0.0f;
     } else {
+#ifdef LSLAM_EXP_PASS2_CLASS  // TIMING EXPERIMENT ONLY (wrong results): the second pass's searches by how tightly they are bounded -- 1: only
+      // the lanes with a bound below LSLAM_EXP_PASS2_SPLIT search, 2: only the others; 0: all (the histogram of the bounds only)
+      if (grid) {
+        if (LSLAM_EXP_PASS2_CLASS == 0) {  // (the histogram's atomics cost a tenth of the sweep: not in the timing variants)
+          const float edges[5] = {0.5f, 1.0f, 2.0f, 4.99f, 1.0e30f};
+#pragma unroll
+          for (int b = 0; b < 5; ++b) {
+            const unsigned long long m = __ballot(active && bound < edges[b] && (b == 0 || bound >= edges[b - 1]));
+            if (lane == 0 && m) atomicAdd(&g_pass2_hist[b], (unsigned long long)__popcll(m));
+          }
+        }
+        const bool tight = bound < (float)(LSLAM_EXP_PASS2_SPLIT);
+        if (LSLAM_EXP_PASS2_CLASS == 1 ? tight : (LSLAM_EXP_PASS2_CLASS == 2 ? !tight : true))
+          knn5_search<BLOCK, OVF, LDS_DEPTH>(T, sel[0], sel[1], sel[2], d, p, stk, bound);
+      } else
+#endif
       knn5_search<BLOCK, OVF, LDS_DEPTH>(T, sel[0], sel[1], sel[2], d, p, stk, bound);
       // no bound kept: no certificate for this point in the next sweep (the first sweep of a certificate loop is this kernel
       // WITHOUT the certificate code -- launch_sweep -- which is 4 % faster at searching than the one with it)
@@ -2220,6 +2242,20 @@ extern "C" int lslam_debug_section_clock(uint64_t *out, int reset) {
   if (reset) {
     for (auto &v : h) v = 0;
     if (hipMemcpyToSymbol(HIP_SYMBOL(lslam::g_section_clock), h, sizeof(h)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
+
+#ifdef LSLAM_EXP_PASS2_CLASS
+extern "C" int lslam_debug_pass2_hist(uint64_t *out8, int reset) {  // (experiment build only, not part of the ABI)
+  unsigned long long h[8];
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(lslam::g_pass2_hist), sizeof(h)) != hipSuccess) return -1;
+  for (int i = 0; i < 8; ++i) out8[i] = h[i];
+  if (reset) {
+    for (auto &v : h) v = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(lslam::g_pass2_hist), h, sizeof(h)) != hipSuccess) return -1;
   }
   return 0;
 }

@@ -416,6 +416,13 @@ int lslam_fmap_update(lslam_fmap *fm, const float sensor_xyz[3]);
  * downsizeValidCloud (:288-306): VoxelGrid every cube of the active area. */
 int lslam_fmap_add_feature_cloud(lslam_fmap *fm, const void *corner, size_t n_corner, const void *surf,
                                  size_t n_surf, size_t stride_bytes, const float T[16]);
+/* The same without the wait at its end, for a node whose sweep ends with addFeatureCloud (LaserMapping::process,
+ * LaserMapping.cpp:349-353): the clouds are copied out of the caller's memory and everything is enqueued; the rebuild is
+ * waited for and committed at the head of the NEXT call on this map, whichever it is (or by lslam_fmap_wait), so the node's
+ * next sweep is being prepared while the map is rebuilt.  An error of the deferred half is that next call's error. */
+int lslam_fmap_add_feature_cloud_begin(lslam_fmap *fm, const void *corner, size_t n_corner, const void *surf,
+                                       size_t n_surf, size_t stride_bytes, const float T[16]);
+int lslam_fmap_wait(lslam_fmap *fm);
 /* getSurroundFeature, FeatureMap.h:256-265: the active cubes' clouds, concatenated in
  * _cubeValidInd order.  counts first, then the copy to the host ... */
 int lslam_fmap_surround_counts(lslam_fmap *fm, size_t *n_corner, size_t *n_surf);

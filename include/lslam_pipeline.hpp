@@ -198,9 +198,10 @@ public:
     // transformUpdate, :342-347
     std::memcpy(_lidarMappedLast, _lidarMappedNew, sizeof(_lidarMappedNew));
     std::memcpy(_lidarOdomLast, lidarOdomNew, sizeof(_lidarOdomLast));
-    // featureMapUpdate, :349-354
-    if (lslam_fmap_add_feature_cloud(_fm, _cornerDS.data(), _cornerDS.size() / 4, _surfDS.data(), _surfDS.size() / 4, 16,
-                                     _lidarMappedNew) < 0)
+    // featureMapUpdate, :349-354 -- enqueued, not waited for: the map's rebuild runs while the node takes up its next sweep; the
+    // next call on the map (this method's update(), a service's getFullMap ...) waits and commits first
+    if (lslam_fmap_add_feature_cloud_begin(_fm, _cornerDS.data(), _cornerDS.size() / 4, _surfDS.data(), _surfDS.size() / 4, 16,
+                                           _lidarMappedNew) < 0)
       return fail();
     return true;
   }

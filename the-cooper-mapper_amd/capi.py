@@ -210,6 +210,9 @@ SYMBOLS = {
     "lslam_fmap_update": (C.c_int, [C.c_void_p, c_float_p]),
     "lslam_fmap_add_feature_cloud": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                                C.c_size_t, c_float_p]),
+    "lslam_fmap_add_feature_cloud_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                               C.c_size_t, c_float_p]),
+    "lslam_fmap_wait": (C.c_int, [C.c_void_p]),
     "lslam_fmap_surround_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "lslam_fmap_get_surround": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t, c_float_p, C.c_size_t]),
     "lslam_fmap_surround_to_map": (C.c_int, [C.c_void_p]),

@@ -656,6 +656,11 @@ struct lslam_fmap {
   // of the map's own beside the corner chain (fork / join by events on the context's stream; LSLAM_FMAP_ONE_STREAM=1: one after
   // the other as before), with a scratch of its own
   Scratch sc2;
+  // lslam_fmap_add_feature_cloud_begin: everything enqueued, nothing waited for -- the wait and the commit (finish_add) happen at
+  // the head of the next call on this map (check_fm), so a mapping node's next frame is being prepared while the map is rebuilt
+  bool add_pending = false;
+  size_t add_cnt[2] = {0, 0};
+  bool add_track = false;
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // ---- per-cube kd-trees kept between frames (lslam_fmap_to_cubemap; FeatureMap.h:438,453 _kdtreeCorner/_kdtreeSurf) ----
@@ -1029,12 +1034,14 @@ int pack_input(hipStream_t s, Pin<float4> &pin, Buf<float4> &dst, const void *sr
   return LSLAM_OK;
 }
 
+int finish_add(lslam_fmap *fm);
 int check_fm(lslam_fmap *fm) {
   if (!fm || !lslam::ctx_alive(fm->ctx)) {
     lslam::set_error("null feature map, or its ctx was destroyed");
     return LSLAM_ERR_INVALID;
   }
   FM_TRY(hipSetDevice(lslam::ctx_device(fm->ctx)));
+  if (fm->add_pending) return finish_add(fm);  // an addFeatureCloud begun and not yet committed: first of all that
   return LSLAM_OK;
 }
 
@@ -1270,16 +1277,26 @@ int lslam_fmap_update(lslam_fmap *fm, const float pos[3]) {
 
 static int add_feature_cloud_impl(lslam_fmap *fm, const void *corner, size_t n_corner, const void *surf, size_t n_surf,
                                   size_t stride_bytes, const float T[16]);
-int lslam_fmap_add_feature_cloud(lslam_fmap *fm, const void *corner, size_t n_corner, const void *surf,
-                                 size_t n_surf, size_t stride_bytes, const float T[16]) {
-  const int rc = add_feature_cloud_impl(fm, corner, n_corner, surf, n_surf, stride_bytes, T);
+static int add_settle(lslam_fmap *fm, int rc) {
   // a failure half way leaves copies out of the pinned staging in flight: nothing may reuse it before they are done
   if (rc != LSLAM_OK && fm && lslam::ctx_alive(fm->ctx)) {
+    fm->add_pending = false;
     if (fm->stream2) (void)hipStreamSynchronize(fm->stream2);
     (void)hipStreamSynchronize(fm->stream);
   }
   return rc;
 }
+int lslam_fmap_add_feature_cloud_begin(lslam_fmap *fm, const void *corner, size_t n_corner, const void *surf,
+                                       size_t n_surf, size_t stride_bytes, const float T[16]) {
+  return add_settle(fm, add_feature_cloud_impl(fm, corner, n_corner, surf, n_surf, stride_bytes, T));
+}
+int lslam_fmap_add_feature_cloud(lslam_fmap *fm, const void *corner, size_t n_corner, const void *surf,
+                                 size_t n_surf, size_t stride_bytes, const float T[16]) {
+  int rc = add_feature_cloud_impl(fm, corner, n_corner, surf, n_surf, stride_bytes, T);
+  if (rc == LSLAM_OK) rc = finish_add(fm);
+  return add_settle(fm, rc);
+}
+int lslam_fmap_wait(lslam_fmap *fm) { return add_settle(fm, check_fm(fm)); }
 static int add_feature_cloud_impl(lslam_fmap *fm, const void *corner, size_t n_corner, const void *surf, size_t n_surf,
                                   size_t stride_bytes, const float T[16]) {
   int rc = check_fm(fm);
@@ -1339,6 +1356,21 @@ static int add_feature_cloud_impl(lslam_fmap *fm, const void *corner, size_t n_c
     FM_TRY(hipEventRecord(fm->ev_join, fm->stream2));
     FM_TRY(hipStreamWaitEvent(s, fm->ev_join, 0));
   }
+  fm->add_cnt[0] = cnt[0];
+  fm->add_cnt[1] = cnt[1];
+  fm->add_track = track;
+  fm->add_pending = true;
+  return LSLAM_OK;
+}
+
+namespace {
+// the wait and the commit of an addFeatureCloud begun by add_feature_cloud_impl
+int finish_add(lslam_fmap *fm) {
+  fm->add_pending = false;
+  hipStream_t s = fm->stream;
+  const size_t *cnt = fm->add_cnt;
+  const bool track = fm->add_track;
+  int rc = LSLAM_OK;
   FM_TRY(hipStreamSynchronize(s));
   for (int t = 0; t < 2; ++t) {
     const size_t n = cnt[t];
@@ -1363,6 +1395,7 @@ static int add_feature_cloud_impl(lslam_fmap *fm, const void *corner, size_t n_c
   }
   return LSLAM_OK;
 }
+}  // namespace
 
 int lslam_fmap_surround_counts(lslam_fmap *fm, size_t *n_corner, size_t *n_surf) {
   int rc = check_fm(fm);

@@ -67,14 +67,18 @@ class FeatureMap:
         p = np.ascontiguousarray(sensor_xyz, dtype=np.float32).reshape(3)
         self._check(self.lib.lslam_fmap_update(self.h, _fp(p)))
 
-    def add_feature_cloud(self, corner, surf, tf):
+    def add_feature_cloud(self, corner, surf, tf, wait=True):
+        """``wait=False`` (lslam_fmap_add_feature_cloud_begin): enqueued only -- the rebuild is waited for and committed at the
+        head of the next call on this map (or by :meth:`wait`); the clouds are copied out of the arrays before the call returns."""
         c, s = _xyzi(corner), _xyzi(surf)
         if c.shape[1] != s.shape[1]:
             raise ValueError("corner and surf clouds must share a point layout")
         T = np.ascontiguousarray(tf, dtype=np.float32).reshape(16)
-        self._check(self.lib.lslam_fmap_add_feature_cloud(self.h, c.ctypes.data_as(C.c_void_p), len(c),
-                                                          s.ctypes.data_as(C.c_void_p), len(s),
-                                                          c.shape[1] * 4, _fp(T)))
+        fn = self.lib.lslam_fmap_add_feature_cloud if wait else self.lib.lslam_fmap_add_feature_cloud_begin
+        self._check(fn(self.h, c.ctypes.data_as(C.c_void_p), len(c), s.ctypes.data_as(C.c_void_p), len(s), c.shape[1] * 4, _fp(T)))
+
+    def wait(self):
+        self._check(self.lib.lslam_fmap_wait(self.h))
 
     def surround_counts(self):
         nc, ns = C.c_size_t(), C.c_size_t()

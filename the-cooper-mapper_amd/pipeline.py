@@ -177,6 +177,7 @@ class LaserMapping:
         # transformUpdate, :342-347
         self.lidar_mapped_last = self.lidar_mapped_new.copy()
         self.lidar_odom_last = odom_merged.copy()
-        # featureMapUpdate, :349-354
-        self.feature_map.add_feature_cloud(corner_ds, surf_ds, self.lidar_mapped_new)
+        # featureMapUpdate, :349-354 -- enqueued, not waited for: the rebuild runs while the node takes up its next sweep (the next
+        # call on the map waits and commits first)
+        self.feature_map.add_feature_cloud(corner_ds, surf_ds, self.lidar_mapped_new, wait=False)
         return self.lidar_mapped_new.copy()

@@ -387,3 +387,38 @@ def test_incremental_cube_forest_over_20_frames(pkg, ctx, oracle, synth, small_p
     # the context no longer points at the freed trees
     with pytest.raises(pkg.LslamError):
         ctx.scanmatch_scan(cds, sds, init, opts)
+
+
+def test_add_feature_cloud_begin_commits_at_the_next_call(pkg, ctx):
+    """lslam_fmap_add_feature_cloud_begin: enqueued, not waited for; whatever is called next on the map waits and commits first.  The
+    same frames through it and through the waiting call give the same maps bit for bit -- with the sensor moving (cube shifts
+    between two adds), two begins in a row, and a clouds array overwritten right after the call (the call has copied it)."""
+    rng = np.random.default_rng(77)
+    maps = [pkg.FeatureMap(ctx, 9, 9, 7) for _ in range(2)]
+    for fm in maps:
+        fm.setup_filter_size(0.2, 0.4, 0.6)
+    T = np.eye(4, dtype=np.float32)
+    for k in range(8):
+        pos = np.array([6.0 * k, 2.0 * k, 0.0], np.float32)
+        c = (rng.uniform(-40, 40, (1500, 4)) + [pos[0], pos[1], 0, 0]).astype(np.float32)
+        s = (rng.uniform(-40, 40, (4000, 4)) + [pos[0], pos[1], 0, 0]).astype(np.float32)
+        c[:, 2] *= 0.1
+        s[:, 2] *= 0.1
+        T[:3, 3] = [0.01 * k, -0.02 * k, 0.0]
+        for fm, wait in zip(maps, (True, False)):
+            if k % 3 != 2:
+                fm.update(pos)  # (every third frame: two adds with nothing between them)
+            cc, ss = c.copy(), s.copy()
+            fm.add_feature_cloud(cc, ss, T, wait=wait)
+            cc[:] = np.nan
+            ss[:] = np.nan
+    a, b = maps[0].get_full_map(), maps[1].get_full_map()
+    assert a.shape == b.shape and len(a) > 1000
+    assert np.array_equal(bits(a), bits(b))
+    maps[1].add_feature_cloud(c, s, T, wait=False)
+    maps[1].wait()
+    maps[0].add_feature_cloud(c, s, T)
+    sa, sb = maps[0].get_surround_feature(), maps[1].get_surround_feature()
+    assert np.array_equal(bits(sa[0]), bits(sb[0])) and np.array_equal(bits(sa[1]), bits(sb[1]))
+    for fm in maps:
+        fm.close()

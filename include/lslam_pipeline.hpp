@@ -198,11 +198,18 @@ public:
     // transformUpdate, :342-347
     std::memcpy(_lidarMappedLast, _lidarMappedNew, sizeof(_lidarMappedNew));
     std::memcpy(_lidarOdomLast, lidarOdomNew, sizeof(_lidarOdomLast));
-    // featureMapUpdate, :349-354 -- enqueued, not waited for: the map's rebuild runs while the node takes up its next sweep; the
-    // next call on the map (this method's update(), a service's getFullMap ...) waits and commits first
+    // featureMapUpdate, :349-354.  -DLSLAM_MAPPING_DEFER_ADD: enqueued, not waited for (lslam_fmap_add_feature_cloud_begin) -- the
+    // map's rebuild then runs while the node takes up its next sweep and the next call on the map waits and commits first.  It pays
+    // where the host idles between two sweeps (the Python mirror: 0.91 -> 0.82 ms per frame); with three nodes on three threads
+    // it does not (the device is the limit there) and the chain fell into its slow mode more often (tools/node_threads_ab.py)
+#ifdef LSLAM_MAPPING_DEFER_ADD
     if (lslam_fmap_add_feature_cloud_begin(_fm, _cornerDS.data(), _cornerDS.size() / 4, _surfDS.data(), _surfDS.size() / 4, 16,
                                            _lidarMappedNew) < 0)
       return fail();
+#else
+    if (lslam_fmap_add_feature_cloud(_fm, _cornerDS.data(), _cornerDS.size() / 4, _surfDS.data(), _surfDS.size() / 4, 16, _lidarMappedNew) < 0)
+      return fail();
+#endif
     return true;
   }
   const float *lidarMapped() const { return _lidarMappedNew; }

@@ -124,9 +124,10 @@ class DeviceLaserOdometry:
 
 class LaserMapping:
     def __init__(self, ctx, cube_dims=(121, 121, 11), filter_corner=1.0, filter_surf=1.0, map_filter_corner=1.0,
-                 map_filter_surf=1.0, map_filter=2.0, defer_trees=True):
+                 map_filter_surf=1.0, map_filter=2.0, defer_trees=True, defer_add=False):
         # LaserMatcher.cpp:80-116 defaults
         self.ctx = ctx
+        self.defer_add = defer_add  # process() ends with lslam_fmap_add_feature_cloud_begin: pays where the host idles between sweeps
         # the per-frame surround map is searched through its cell grids; its kd-trees are built only if a frame needs them
         # (include/lslam_c.h lslam_map_defer_trees) -- same poses either way
         ctx.defer_trees(defer_trees)
@@ -177,7 +178,7 @@ class LaserMapping:
         # transformUpdate, :342-347
         self.lidar_mapped_last = self.lidar_mapped_new.copy()
         self.lidar_odom_last = odom_merged.copy()
-        # featureMapUpdate, :349-354 -- enqueued, not waited for: the rebuild runs while the node takes up its next sweep (the next
-        # call on the map waits and commits first)
-        self.feature_map.add_feature_cloud(corner_ds, surf_ds, self.lidar_mapped_new, wait=False)
+        # featureMapUpdate, :349-354 (defer_add: enqueued, not waited for -- the rebuild runs while the node takes up its next sweep,
+        # the next call on the map waits and commits first)
+        self.feature_map.add_feature_cloud(corner_ds, surf_ds, self.lidar_mapped_new, wait=not self.defer_add)
         return self.lidar_mapped_new.copy()

@@ -643,7 +643,8 @@ int lslam_ctx_create(int device, lslam_ctx **out) {
   lslam_ctx *ctx = new lslam_ctx();
   ctx->device = device;
   HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  // (stream2 is made when something first forks onto it -- ctx_stream2: a context that only registers sweeps or runs the odometry
+  // node never does, and every stream is one more claimant of the device's few hardware queues)
   HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   {
@@ -728,7 +729,7 @@ void lslam_ctx_destroy(lslam_ctx *ctx) {
   for (hipEvent_t e : ctx->sweep_ev) (void)hipEventDestroy(e);
   scanprep_destroy(ctx->scanprep);
   treebuild_release_scratch(ctx->stream);
-  treebuild_release_scratch(ctx->stream2);
+  if (ctx->stream2) treebuild_release_scratch(ctx->stream2);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -967,6 +968,7 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
     // events -- nothing waits on the host.
     int st = 0, st2[2] = {0, 0};
     const bool two_streams = !env_once().grid_one_stream;
+    if (two_streams && !ctx_stream2(ctx)) return LSLAM_ERR_HIP;
     hipStream_t s0 = two_streams ? ctx->stream2 : ctx->stream;
     if (two_streams) {
       HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -1068,6 +1070,7 @@ int map_set_impl(lslam_ctx *ctx, const void *corner, size_t n_corner, const void
       *ncount[k] = (size_t)dt.view.n_nodes / 8 * 7 + n_leaves;  // approximate node count
     };
     {
+      if (!ctx_stream2(ctx)) return LSLAM_ERR_HIP;
       ctx->worker.submit([&] { build_one(0, ctx->stream2); });
       build_one(1, ctx->stream);
       ctx->worker.wait();
@@ -1278,6 +1281,17 @@ void cubemap_drop_views(lslam_ctx *ctx) {
 }
 void set_error(const char *msg) { set_err("%s", msg); }
 hipStream_t ctx_stream(lslam_ctx *ctx) { return ctx->stream; }
+hipStream_t ctx_stream2(lslam_ctx *ctx) {  // the context's second stream, made on first use (nullptr + the error text on failure)
+  if (!ctx->stream2) {
+    (void)hipSetDevice(ctx->device);
+    const hipError_t e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      ctx->stream2 = nullptr;
+      set_err("hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));
+    }
+  }
+  return ctx->stream2;
+}
 TreeView ctx_tree_view(lslam_ctx *ctx, int which) { return which ? ctx->ts.view : ctx->tc.view; }
 void ctx_invalidate_map(lslam_ctx *ctx) { ctx->have_map = false; ctx->map_epoch++; ctx->have_scan = false; }
 int ctx_scratch(lslam_ctx *ctx, size_t n_float4, size_t n_double, float4 **pts, double **dbl) {

@@ -652,8 +652,8 @@ struct lslam_fmap {
   std::vector<int32_t> h_gsrc[2], h_gdst[2];
   Buf<float4> sur[2];
   Scratch sc;
-  // addFeatureCloud's two feature types are independent chains of a dozen small launches each: the surf chain runs on a stream
-  // of the map's own beside the corner chain (fork / join by events on the context's stream; LSLAM_FMAP_ONE_STREAM=1: one after
+  // addFeatureCloud's two feature types are independent chains of a dozen small launches each: the surf chain runs on the
+  // context's second stream beside the corner chain (fork / join by events on the context's stream; LSLAM_FMAP_ONE_STREAM=1: one after
   // the other as before), with a scratch of its own
   Scratch sc2;
   // lslam_fmap_add_feature_cloud_begin: everything enqueued, nothing waited for -- the wait and the commit (finish_add) happen at
@@ -1197,10 +1197,7 @@ void lslam_fmap_destroy(lslam_fmap *fm) {
   fm->done.release(); fm->h_touched.release();
   fm->sc.release();
   fm->sc2.release();
-  if (fm->stream2) {
-    (void)hipStreamSynchronize(fm->stream2);
-    (void)hipStreamDestroy(fm->stream2);
-  }
+  if (fm->stream2 && lslam::ctx_alive(fm->ctx)) (void)hipStreamSynchronize(fm->stream2);  // (the context's: not ours to destroy)
   if (fm->ev_fork) (void)hipEventDestroy(fm->ev_fork);
   if (fm->ev_join) (void)hipEventDestroy(fm->ev_join);
   delete fm;
@@ -1321,8 +1318,9 @@ static int add_feature_cloud_impl(lslam_fmap *fm, const void *corner, size_t n_c
   // two chains, two streams -- when both types have something to rebuild
   const bool two = !lslam::env_once().fmap_one_stream && (fm->n[0] + cnt[0]) && (fm->n[1] + cnt[1]);
   if (two) {
-    if (!fm->stream2) {
-      FM_TRY(hipStreamCreateWithFlags(&fm->stream2, hipStreamNonBlocking));
+    if (!fm->stream2) {  // the context's second stream (the cell grids fork onto it too, never at the same time: one call per context)
+      fm->stream2 = lslam::ctx_stream2(fm->ctx);
+      if (!fm->stream2) return LSLAM_ERR_HIP;
       FM_TRY(hipEventCreateWithFlags(&fm->ev_fork, hipEventDisableTiming));
       FM_TRY(hipEventCreateWithFlags(&fm->ev_join, hipEventDisableTiming));
     }

@@ -405,6 +405,7 @@ void odom_ctx_gone(lslam_ctx *ctx);
 
 // small accessors for translation units that work on a context (lslam_icp.hip)
 hipStream_t ctx_stream(lslam_ctx *ctx);
+hipStream_t ctx_stream2(lslam_ctx *ctx);  // made on first use; nullptr on failure
 TreeView ctx_tree_view(lslam_ctx *ctx, int which);   // 0 corner, 1 surf tree of the resident map
 void ctx_invalidate_map(lslam_ctx *ctx);              // the resident trees belong to the caller's own call from here on
 int ctx_scratch(lslam_ctx *ctx, size_t n_float4, size_t n_double, float4 **pts, double **dbl);  // grow-only scratch

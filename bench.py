@@ -92,7 +92,7 @@ def parse_args():
                     help="run the sharded-points leg even on one GPU (RCCL all-reduce over a world of 1)")
     ap.add_argument("--leg-timeout", type=int, default=1500, help="seconds the legs after the headline may take in all")
     ap.add_argument("--pg-iters", type=int, default=1000, help="LM iteration limit of the pose-graph leg")
-    ap.add_argument("--cpu-scans", type=int, default=8, help="scans the single-core CPU baseline matches")
+    ap.add_argument("--cpu-scans", type=int, default=48, help="scans the single-core CPU baseline matches")
     return ap.parse_args()
 
 

@@ -1023,7 +1023,7 @@ hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, h
 // its sums added to this workgroup's record.  Fixed places, fixed order: the same bits in every run.
 // ---------------------------------------------------------------------------
 #ifndef LSLAM_GRID_OCC
-#define LSLAM_GRID_OCC 6  // wavefronts per SIMD the grid sweep is compiled for: 80 VGPRs (5: 90 VGPRs, 8 % slower; 7: below; 8: 64 VGPRs with 96 B of scratch, slower than 5)
+#define LSLAM_GRID_OCC 7  // wavefronts per SIMD the grid sweep is compiled for: 72 VGPRs + 36 B of scratch (6: 80 VGPRs + 8 B, 1.6 % slower since round 6 -- it had been the faster one before the loop was hand-scheduled; 5: 88 VGPRs, 5 % slower; 8: 64 VGPRs + 96 B of scratch, 8 % slower)
 #endif
 #ifndef LSLAM_STAGE_PAD
 #define LSLAM_STAGE_PAD 0

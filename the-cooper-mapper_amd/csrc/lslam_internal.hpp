@@ -88,7 +88,10 @@ struct CertPlan {
   int32_t *count, *count_next;
   int32_t *ticket, *ticket_next;  // the next item to deal (sweep_queue_kernel)
 };
-constexpr int CERT_GROUP = 16;
+#ifndef LSLAM_CERT_GROUP
+#define LSLAM_CERT_GROUP 64
+#endif
+constexpr int CERT_GROUP = LSLAM_CERT_GROUP;  // (16 until round 6: the certificate sweep lists a third of a workgroup's points, the grid sweep 1 - 3 %)
 // SweepArgs::cert_stats: [0] points left to pass 2, [1] points swept by the workgroups that could leave some, [2] (certificate
 // sweep) points left to the tree search; from CERT_STATS_BY_SWEEP on, the grid sweep's [0], [1] once more by feature type
 // (corner, surf) and sweep of the loop (the last slot: that sweep and every later one): [type][sweep][listed, swept]

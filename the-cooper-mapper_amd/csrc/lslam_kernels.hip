@@ -846,6 +846,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(GRIDQ == 
   __shared__ float red[BLOCK / 64][NCOL];
   __shared__ uint32_t stack_lds[2 * LDS_DEPTH * BLOCK];
   __shared__ int next_w;
+  __shared__ int pre_lds[CERT_GROUP + 1];
   const int n_work = *plan.count;
   for (;;) {
     // dealt by ticket, not round-robin: an item is anything between a handful of points and BLOCK of them
@@ -865,12 +866,23 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(GRIDQ == 
     gd.n_blocks = __builtin_amdgcn_readfirstlane(gd.n_blocks);
     gd.prob = __builtin_amdgcn_readfirstlane(gd.prob);
     const int fb = gd.first_block - a.group_block_base;
-    int pre[CERT_GROUP + 1];
-    pre[0] = 0;
+    // where the lists of the group's workgroups begin in their concatenation: one length per lane of the first wavefront, an
+    // inclusive scan, the prefix in LDS (with groups of sixteen it was seventeen scalar registers and a chain of selects; with
+    // sixty-four -- the grid sweep lists 1 - 3 % of a workgroup's points, and an item is a workgroup's worth of lanes -- it is not)
+    static_assert(CERT_GROUP <= 64 && (CERT_GROUP & (CERT_GROUP - 1)) == 0, "one list length per lane of a wavefront; the search below halves");
+    if (threadIdx.x < 64) {
+      const int k = (int)threadIdx.x;
+      int run = k < gd.n_blocks ? (LIST2 ? (int)a.need2_cnt[fb + k] : (int)a.need_cnt[fb + k]) : 0;
 #pragma unroll
-    for (int k = 0; k < CERT_GROUP; ++k)
-      pre[k + 1] = pre[k] + (k < gd.n_blocks ? __builtin_amdgcn_readfirstlane(LIST2 ? (int)a.need2_cnt[fb + k] : (int)a.need_cnt[fb + k]) : 0);
-    const int total = pre[CERT_GROUP];
+      for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(run, o, 64);
+        if (k >= o) run += u;
+      }
+      if (k < CERT_GROUP) pre_lds[k + 1] = run;
+      if (k == 0) pre_lds[0] = 0;
+    }
+    __syncthreads();
+    const int total = pre_lds[CERT_GROUP];
     BlockDesc bd = a.blocks[fb];
     bd.prob = gd.prob;
     bd.is_surf = __builtin_amdgcn_readfirstlane(bd.is_surf);
@@ -879,13 +891,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(GRIDQ == 
     const int i = c * BLOCK + (int)threadIdx.x;
     int item = -1;
     if (i < total) {
-      int k = 0, p0 = 0;
+      int k = 0;  // the last workgroup whose list begins at or before entry i
 #pragma unroll
-      for (int j = 1; j < CERT_GROUP; ++j) {
-        const bool in = pre[j] <= i;
-        k = in ? j : k;
-        p0 = in ? pre[j] : p0;
-      }
+      for (int step = CERT_GROUP / 2; step >= 1; step >>= 1)
+        if (pre_lds[k + step] <= i) k += step;
+      const int p0 = pre_lds[k];
       if (LIST2) item = a.blocks[fb].first + (int)a.need2_list[(size_t)(fb + k) * BLOCK + (i - p0)];
       else item = a.blocks[fb + k].first + (int)a.need_list[(size_t)(fb + k) * BLOCK + (i - p0)];
     }

@@ -89,7 +89,7 @@ struct CertPlan {
   int32_t *ticket, *ticket_next;  // the next item to deal (sweep_queue_kernel)
 };
 #ifndef LSLAM_CERT_GROUP
-#define LSLAM_CERT_GROUP 64
+#define LSLAM_CERT_GROUP 256
 #endif
 constexpr int CERT_GROUP = LSLAM_CERT_GROUP;  // (16 until round 6: the certificate sweep lists a third of a workgroup's points, the grid sweep 1 - 3 %)
 // SweepArgs::cert_stats: [0] points left to pass 2, [1] points swept by the workgroups that could leave some, [2] (certificate

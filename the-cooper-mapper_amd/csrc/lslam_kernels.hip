@@ -771,7 +771,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_DEPTH
 }
 
 // Pass 2 of the certificate sweep (sweep_body), in two launches.
-// cert_plan_kernel, one thread per group: how many chunks of BLOCK listed points the group's pass-1 workgroups left (none for
+// cert_plan_kernel, one wavefront per group: how many chunks of BLOCK listed points the group's pass-1 workgroups left (none for
 // a scan whose loop has ended), and that many work items (group, chunk) appended to the work list.  The order of the list
 // depends on the order of the atomics; nothing else does -- an item's sums go to a place of its own.
 // level 0: the first-level lists (need_cnt); when second-level lists exist their counts are zeroed here, so that a block no
@@ -785,8 +785,10 @@ __global__ __launch_bounds__(256) void cert_plan_kernel(SweepArgs a, CertPlan pl
     grid_prefix_block(a, part);
     return;
   }
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g == 0) {  // the counters of the NEXT plan (they alternate)
+  // one WAVEFRONT per group: its lanes share the group's list lengths (a group is up to CERT_GROUP workgroups: one thread
+  // adding them up one after the other was a chain of that many loads)
+  const int g = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // the counters of the NEXT plan (they alternate)
     *plan.count_next = 0;
     *plan.ticket_next = 0;
   }
@@ -799,7 +801,7 @@ __global__ __launch_bounds__(256) void cert_plan_kernel(SweepArgs a, CertPlan pl
     if (threadIdx.x < CERT_STATS_WORDS) hist[threadIdx.x] = 0;
     __syncthreads();
   }
-  bool on = g < a.n_groups;
+  bool on = g < a.n_groups;  // wave-uniform
   GroupDesc gd{};
   if (on) {
     gd = a.groups[g];
@@ -808,14 +810,18 @@ __global__ __launch_bounds__(256) void cert_plan_kernel(SweepArgs a, CertPlan pl
   }
   if (on) {
     const int fb = gd.first_block - a.group_block_base;
-    int total = 0;
-    for (int k = 0; k < gd.n_blocks; ++k) {
+    int total = 0, swept = 0;
+    for (int k = lane; k < gd.n_blocks; k += 64) {
       total += level ? (int)a.need2_cnt[fb + k] : (int)a.need_cnt[fb + k];
       if (!level && a.need2_cnt) a.need2_cnt[fb + k] = 0;
+      if (tap) swept += a.blocks[fb + k].count;
     }
-    if (tap) {
-      int swept = 0;
-      for (int k = 0; k < gd.n_blocks; ++k) swept += a.blocks[fb + k].count;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      total += __shfl_xor(total, o, 64);
+      swept += __shfl_xor(swept, o, 64);
+    }
+    if (tap && lane == 0) {
       const int slot = CERT_STATS_BY_SWEEP + 2 * ((a.blocks[fb].is_surf ? GRID_STATS_SWEEPS : 0) + min(a.states[gd.prob].sweeps, GRID_STATS_SWEEPS - 1));
       atomicAdd(&hist[0], (unsigned)total);
       atomicAdd(&hist[1], (unsigned)swept);
@@ -824,8 +830,10 @@ __global__ __launch_bounds__(256) void cert_plan_kernel(SweepArgs a, CertPlan pl
     }
     const int nch = (total + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
     if (nch > 0) {
-      const int at = atomicAdd(plan.count, nch);
-      for (int c = 0; c < nch; ++c) plan.work[at + c] = g * CERT_GROUP + c;
+      int at = 0;
+      if (lane == 0) at = atomicAdd(plan.count, nch);
+      at = __shfl(at, 0, 64);
+      for (int c = lane; c < nch; c += 64) plan.work[at + c] = g * CERT_GROUP + c;
     }
   }
   if (tap) {
@@ -847,6 +855,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(GRIDQ == 
   __shared__ uint32_t stack_lds[2 * LDS_DEPTH * BLOCK];
   __shared__ int next_w;
   __shared__ int pre_lds[CERT_GROUP + 1];
+  __shared__ int pre_wave[BLOCK / 64];
   const int n_work = *plan.count;
   for (;;) {
     // dealt by ticket, not round-robin: an item is anything between a handful of points and BLOCK of them
@@ -869,14 +878,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(GRIDQ == 
     // where the lists of the group's workgroups begin in their concatenation: one length per lane of the first wavefront, an
     // inclusive scan, the prefix in LDS (with groups of sixteen it was seventeen scalar registers and a chain of selects; with
     // sixty-four -- the grid sweep lists 1 - 3 % of a workgroup's points, and an item is a workgroup's worth of lanes -- it is not)
-    static_assert(CERT_GROUP <= 64 && (CERT_GROUP & (CERT_GROUP - 1)) == 0, "one list length per lane of a wavefront; the search below halves");
-    if (threadIdx.x < 64) {
-      const int k = (int)threadIdx.x;
+    static_assert(CERT_GROUP <= BLOCK && (CERT_GROUP & (CERT_GROUP - 1)) == 0, "one list length per thread; the search below halves");
+    {
+      const int k = (int)threadIdx.x, ln = k & 63, wv = k >> 6;
       int run = k < gd.n_blocks ? (LIST2 ? (int)a.need2_cnt[fb + k] : (int)a.need_cnt[fb + k]) : 0;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         const int u = __shfl_up(run, o, 64);
-        if (k >= o) run += u;
+        if (ln >= o) run += u;
+      }
+      if (CERT_GROUP > 64) {  // the wavefronts' totals, then every wavefront adds what lies before it
+        if (ln == 63) pre_wave[wv] = run;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) run += w < wv ? pre_wave[w] : 0;
       }
       if (k < CERT_GROUP) pre_lds[k + 1] = run;
       if (k == 0) pre_lds[0] = 0;
@@ -975,13 +990,13 @@ hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEven
 // the planner of a second pass on its own (a map without trees plans BEFORE the wide probe, whose prefix rides in the same launch)
 hipError_t launch_sweep_plan(const SweepArgs &a, hipStream_t s, const CertPlan &plan, int level, bool with_prefix) {
   if (a.n_groups <= 0) return hipSuccess;
-  hipLaunchKernelGGL(cert_plan_kernel, dim3((a.n_groups + 255) / 256 + (with_prefix ? 1 : 0)), dim3(256), 0, s, a, plan, level, with_prefix ? 1 : 0);
+  hipLaunchKernelGGL(cert_plan_kernel, dim3((a.n_groups + 3) / 4 + (with_prefix ? 1 : 0)), dim3(256), 0, s, a, plan, level, with_prefix ? 1 : 0);
   return hipGetLastError();
 }
 
 hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t stop, int variant, const CertPlan &plan, int level, bool planned) {
   if (a.n_groups <= 0) return hipSuccess;
-  if (!planned) hipLaunchKernelGGL(cert_plan_kernel, dim3((a.n_groups + 255) / 256), dim3(256), 0, s, a, plan, level, 0);
+  if (!planned) hipLaunchKernelGGL(cert_plan_kernel, dim3((a.n_groups + 3) / 4), dim3(256), 0, s, a, plan, level, 0);
   // as many workgroups as stay resident (256 CUs x five of the shallow kernel, two of the deep ones), never more than items possible
   constexpr int SHALLOW = LSLAM_SHALLOW_DEPTH;
   const long possible = a.active_blocks ? std::max<long>(a.n_active, 1) : (long)a.nb_total;  // (a work item is at most one per pass-1 workgroup that ran)

@@ -112,6 +112,12 @@ enum { LSLAM_AB_PERSISTENT_GN = 1, /* one resident scan: the whole Gauss-Newton 
                                       few wavefronts as they fill.  Same bits.  DESIGN 4 has the measurement */
        LSLAM_AB_NO_COMPACT = 64,   /* a batch through the grid sweep: launch every workgroup of every scan in every sweep (round 4's
                                       form) instead of only those of the scans whose loop is still running */
+       LSLAM_AB_REFILL = 128,      /* grid sweep of a batch: the second pass as two launches -- the listed points searched by persistent
+                                      lanes (a lane whose tree walk has ended hands its five in and takes the next point of a
+                                      pool of four workgroups' worth), their residual chain in the next.  Same bits.  Measured
+                                      slower: 1.405e10 against 1.461e10, no faster even in a loop's first sweep, where work is
+                                      plentiful -- the lanes a wavefront loses are lost inside every round of the walk (descents
+                                      and stack pops of different lengths), not at its end */
        LSLAM_AB_WIDE_NF_MARGIN = 16 /* a map without kd-trees: a point whose fifth and sixth distances are within 8 ulps of each
                                       other counts as undecidable too (as an exact tie does): the trees are built and the call
                                       repeated.  Off: such a pair is ordered by its exact fp32 distances -- nanoflann's order

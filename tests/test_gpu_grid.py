@@ -614,7 +614,7 @@ def test_grid_batch_over_the_running_scans_only_gives_the_same_bits(ctx, synth):
     ref = None
     for in_flight in (0, 4):
         o.scans_in_flight = in_flight
-        for ab in (64, 0):                              # LSLAM_AB_NO_COMPACT first
+        for ab in (64, 0, 128):                         # LSLAM_AB_NO_COMPACT first; LSLAM_AB_REFILL: the second pass's two-launch form
             o.ab_switches = ab
             _, p, st = ctx.run_batch(inits, o)
             cur = (p.copy(), [(s.status, s.iterations, s.n_rows, s.n_line, s.n_plane, s.converged, s.sweeps) for s in st])

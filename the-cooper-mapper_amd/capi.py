@@ -292,6 +292,7 @@ SYMBOLS = {
 COMM_ID_BYTES = 128
 SEARCH_AUTO, SEARCH_LANE, SEARCH_PACKET, SEARCH_GRID = 0, 1, 2, 3
 AB_PERSISTENT_GN, AB_FUSED_SOLVE, AB_SECOND_PROBE, AB_WIDE_IN_PLACE = 1, 2, 4, 8  # lslam_opts.ab_switches (LSLAM_AB_*)
+AB_REFILL = 128
 STACK_AUTO, STACK_DEEP, STACK_SHALLOW = 0, 0x100, 0x200  # ORed into a search mode (LSLAM_STACK_*)
 # lslam_debug_sweep_launches: index of each sweep-kernel instantiation
 SWEEP_VARIANTS = ("deep", "deep_ovf", "shallow", "cubes", "cubes_ovf", "packet", "persistent", "deep_fused")

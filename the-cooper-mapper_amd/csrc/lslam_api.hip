@@ -449,6 +449,8 @@ hipError_t sweep_launch(lslam_ctx *ctx, const SweepArgs &a, int jtj_mode, hipEve
   plan.count_next = ctx->cert_count.p + ((ctx->queue_launches + 1) & 1);
   plan.ticket = plan.count + 2;
   plan.ticket_next = plan.count_next + 2;
+  plan.ticket2 = plan.count + 4;
+  plan.ticket2_next = plan.count_next + 4;
   if (a.grid) {  // the grid sweep: probe + proof for every point, then the tree search for the points it listed; timed as one
     if (a.nb_total <= 0 || a.n_groups <= 0 || !a.need_cnt) return a.nb_total <= 0 ? hipSuccess : hipErrorInvalidValue;
     // A/B (off; lslam_opts.ab_switches & LSLAM_AB_WIDE_IN_PLACE): a map without trees and a launch of at most two wavefronts per
@@ -492,6 +494,14 @@ hipError_t sweep_launch(lslam_ctx *ctx, const SweepArgs &a, int jtj_mode, hipEve
     if (e1) return hipEventRecord(e1, ctx->stream);
     return hipSuccess;
 #endif
+    // A/B (off; lslam_opts.ab_switches & LSLAM_AB_REFILL sets wide_d / wide_p): whole-map trees, the bounded production sweep of a
+    // throughput-bound batch -- the listed points are searched by persistent lanes in a launch of their own, their residual
+    // chain runs in the next (sweep_refill_kernel).  Same bits, measured slower
+    if (a.grid == 1 && pass2 == SWEEP_VARIANT_SHALLOW && a.bounded && a.wide_d && a.wide_p && !a.flags_out && a.fine_gate_c < 0.0f && !planned) {
+      e = launch_sweep_refill(a, jtj_mode, ctx->stream, e1, plan);
+      ctx->queue_launches++;
+      return e;
+    }
     e = launch_sweep_queue(a, jtj_mode, ctx->stream, e1, pass2, plan, 0, planned);
     ctx->queue_launches++;
     return e;
@@ -1591,8 +1601,8 @@ int lslam_scan_set_batch(lslam_ctx *ctx, int32_t n_scans, const void *const *cor
   HIP_TRY(ctx->need2_cnt.reserve(nb ? nb : 1));
   HIP_TRY(ctx->cert_work.reserve(nb ? nb : 1));
   if (!ctx->cert_count.p) {
-    HIP_TRY(ctx->cert_count.reserve(4));
-    HIP_TRY(hipMemsetAsync(ctx->cert_count.p, 0, 4 * sizeof(int32_t), ctx->stream));
+    HIP_TRY(ctx->cert_count.reserve(6));  // items [2], tickets [2], the refill search's tickets [2]
+    HIP_TRY(hipMemsetAsync(ctx->cert_count.p, 0, 6 * sizeof(int32_t), ctx->stream));
   }
   HIP_TRY(ctx->tail_count.reserve((size_t)n_scans));  // (zeroed where the fused solve is switched on: run_batch_impl)
   ctx->prev_valid = false;
@@ -1908,6 +1918,12 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
         sa.kc = ctx->kc.view;
         sa.ks = ctx->ks.view;
         sa.grid = 1;
+        if ((o.ab_switches | ctx->env_ab) & LSLAM_AB_REFILL) {  // A/B (off): the second pass's two-launch form -- the five of every listed point between its launches
+          HIP_TRY(ctx->wide_d.reserve(std::max<size_t>(ctx->n_points, 1) * 5));
+          HIP_TRY(ctx->wide_p.reserve(std::max<size_t>(ctx->n_points, 1) * 5));
+          sa.wide_d = ctx->wide_d.p;
+          sa.wide_p = ctx->wide_p.p;
+        }
         sa.grid_clip_margin = GRID_CLIP_MARGIN_MIN;
       }
     }
@@ -1994,7 +2010,7 @@ int run_batch_impl(lslam_ctx *ctx, int32_t n_scans, float *poses, const lslam_op
       // per iteration (measured on single scans: 0.29 against 0.26 ms per loop).  LSLAM_KNN_CERT=2 takes it regardless (tests)
       if ((sc.grid || sc.prev_q) && !sc.tail.count && (sc.grid || force_cert || (long)sc.nb_total * (SWEEP_BLOCK / 64) > 2 * 1024)) {
         if (!cert_counters_reset) {  // once per call: whatever an earlier call that ended in an error left in the plan's counters
-          HIP_TRY(hipMemsetAsync(ctx->cert_count.p, 0, 4 * sizeof(int32_t), ctx->stream));
+          HIP_TRY(hipMemsetAsync(ctx->cert_count.p, 0, 6 * sizeof(int32_t), ctx->stream));
           cert_counters_reset = true;
         }
         sc.need_list = ctx->need_list.p + (size_t)fb * SWEEP_BLOCK;
@@ -2856,7 +2872,7 @@ int lslam_sweep_ex(lslam_ctx *ctx, const float pose[6], int32_t jtj_mode, int32_
     sa.groups = ctx->groups.p;
     sa.n_groups = (int32_t)ctx->h_groups.size();
     sa.group_block_base = 0;
-    HIP_TRY(hipMemsetAsync(ctx->cert_count.p, 0, 4 * sizeof(int32_t), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->cert_count.p, 0, 6 * sizeof(int32_t), ctx->stream));
     if (carried || first) {  // a sweep of the production loop, kernel for kernel (include/lslam_c.h LSLAM_SWEEP_CARRIED / _FIRST)
       HIP_TRY(ctx->prev_q.reserve(std::max<size_t>(N, 1)));
       sa.bounded = 1;

@@ -496,6 +496,134 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
   if (TRACK) *lb6 = lb;
 }
 
+// The same search for a POOL of queries, the lanes refilled as they finish (persistent lanes: a lane whose stack has run empty
+// hands in its five and takes the next query of the pool while the others walk on) -- the second pass of the grid sweep, whose
+// queries are a sparse, hard subset: one query per lane left a wavefront as slow as its longest walk at about half its lanes.
+// `src` supplies and takes back: bool next(qx, qy, qz, bound) (false: the pool is empty; called by the lanes that need a query,
+// in divergent control flow) and emit(d, p) (this lane's finished query).  The arithmetic of a query's walk is knn5_search's,
+// statement for statement (default leaf, no tracking): same visits, same five.
+template <int BLOCK, bool OVF, int LDS_DEPTH, typename Src>
+LSLAM_DEV void knn5_search_refill(const TreeView &T, KdStack<BLOCK, OVF, LDS_DEPTH> &stk, Src &src) {
+  constexpr int POPW = (LDS_DEPTH <= 16 && LDS_DEPTH > 0) ? LSLAM_POPW_SHALLOW : 4;
+  float qx = 0.0f, qy = 0.0f, qz = 0.0f, bound = FLT_MAX;
+  float d[5];
+  int p[5];
+  float ds0 = 0.0f, ds1 = 0.0f, ds2 = 0.0f, mind = 0.0f;
+  int sp = 0;
+  uint32_t ref = T.root_ref;
+  auto begin = [&]() {  // knn5_search's head for the query in (qx, qy, qz)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      d[i] = FLT_MAX;
+      p[i] = -1;
+    }
+    ds0 = ds1 = ds2 = mind = 0.0f;
+    if (qx < T.bb_lo[0]) { ds0 = (qx - T.bb_lo[0]) * (qx - T.bb_lo[0]); mind += ds0; }
+    if (qx > T.bb_hi[0]) { ds0 = (qx - T.bb_hi[0]) * (qx - T.bb_hi[0]); mind += ds0; }
+    if (qy < T.bb_lo[1]) { ds1 = (qy - T.bb_lo[1]) * (qy - T.bb_lo[1]); mind += ds1; }
+    if (qy > T.bb_hi[1]) { ds1 = (qy - T.bb_hi[1]) * (qy - T.bb_hi[1]); mind += ds1; }
+    if (qz < T.bb_lo[2]) { ds2 = (qz - T.bb_lo[2]) * (qz - T.bb_lo[2]); mind += ds2; }
+    if (qz > T.bb_hi[2]) { ds2 = (qz - T.bb_hi[2]) * (qz - T.bb_hi[2]); mind += ds2; }
+    sp = 0;
+    ref = T.root_ref;
+  };
+  bool live = src.next(qx, qy, qz, bound);
+  if (live) begin();
+  if (T.n_pts == 0) {  // nanoflann.hpp:1306-1307: every query comes back empty
+    while (live) {
+      src.emit(d, p);
+      live = src.next(qx, qy, qz, bound);
+      if (live) begin();
+    }
+    return;
+  }
+  while (live) {
+    while (!(ref & KD_LEAF)) {  // inner node: nanoflann.hpp:1459-1475
+      const uint32_t node = ref >> 2;
+      const uint32_t feat = ref & 3u;
+      const KdNode nd = T.nodes[node];
+      const float val = feat == 0 ? qx : (feat == 1 ? qy : qz);
+      const float diff1 = val - nd.lo;
+      const float diff2 = val - nd.hi;
+      const bool left = (diff1 + diff2) < 0.0f;
+      const float cd = left ? diff2 * diff2 : diff1 * diff1;
+      const float dst = feat == 0 ? ds0 : (feat == 1 ? ds1 : ds2);
+      const float nm = (mind + cd) - dst;
+      if (nm <= fminf(d[4], bound)) {
+        stk.put(sp, node | (left ? (1u << 28) : 0u) | (feat << 29), __float_as_uint(nm));
+        ++sp;
+      }
+      ref = left ? nd.c1 : nd.c2;
+    }
+    {  // leaf: nanoflann.hpp:1438-1457
+      const int l = (int)((ref & ~KD_LEAF) >> 4), cnt = (int)(ref & 15u);
+      const float worst = fminf(d[4], bound);
+      float4 pt[10];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) pt[j] = T.pts[l + j];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        const float dist = dist2_xyz(qx, qy, qz, pt[j]);
+        const float x = (j < cnt && dist < worst) ? dist : FLT_MAX;
+        knn_insert_sorted(d, p, x, l + j);
+      }
+    }
+    bool take = false;
+    uint32_t te = 0;
+    float tm = 0.0f;
+    while (sp > 0 && !take) {
+      uint32_t e[POPW];
+      float m[POPW];
+#pragma unroll
+      for (int j = 0; j < POPW; ++j) {
+        const int idx = sp - 1 - j < 0 ? 0 : sp - 1 - j;
+        uint32_t w1;
+        stk.get(idx, e[j], w1);
+        m[j] = __uint_as_float(w1);
+      }
+#pragma unroll
+      for (int j = 0; j < POPW; ++j) {
+        const bool valid = !take && sp > 0;
+        const uint32_t feat = (e[j] >> 29) & 3u;
+        const bool act = (e[j] & 0x80000000u) != 0;
+        const bool pass = !act && (m[j] <= fminf(d[4], bound));
+        const bool rst = valid && act;
+        ds0 = (rst && feat == 0) ? m[j] : ds0;
+        ds1 = (rst && feat == 1) ? m[j] : ds1;
+        ds2 = (rst && feat == 2) ? m[j] : ds2;
+        const bool tk = valid && pass;
+        te = tk ? e[j] : te;
+        tm = tk ? m[j] : tm;
+        take = take || tk;
+        sp -= (valid && !pass) ? 1 : 0;
+      }
+    }
+    if (!take) {  // this query is done: hand it in, take the next
+      src.emit(d, p);
+      live = src.next(qx, qy, qz, bound);
+      if (live) begin();
+      continue;
+    }
+    {
+      const uint32_t parent = te & 0x0FFFFFFFu;
+      const uint32_t feat = (te >> 29) & 3u;
+      const KdNode pn = T.nodes[parent];
+      const float val = feat == 0 ? qx : (feat == 1 ? qy : qz);
+      const float diff1 = val - pn.lo;
+      const float diff2 = val - pn.hi;
+      const bool left = (diff1 + diff2) < 0.0f;
+      const float cd = left ? diff2 * diff2 : diff1 * diff1;
+      float old;
+      if (feat == 0) { old = ds0; ds0 = cd; }
+      else if (feat == 1) { old = ds1; ds1 = cd; }
+      else { old = ds2; ds2 = cd; }
+      stk.put(sp - 1, te | 0x80000000u, __float_as_uint(old));
+      mind = tm;
+      ref = left ? pn.c2 : pn.c1;
+    }
+  }
+}
+
 #ifdef LSLAM_TRAVERSAL_STATS  // call sites that keep no statistics
 template <int BLOCK, bool OVF, int LDS_DEPTH, bool TRACK = false>
 LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, float (&d)[5], int (&p)[5],

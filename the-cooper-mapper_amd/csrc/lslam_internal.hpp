@@ -87,6 +87,7 @@ struct CertPlan {
   int32_t *work;
   int32_t *count, *count_next;
   int32_t *ticket, *ticket_next;  // the next item to deal (sweep_queue_kernel)
+  int32_t *ticket2 = nullptr, *ticket2_next = nullptr;  // ... of a second consumer of the same list (sweep_refill_kernel), or null
 };
 #ifndef LSLAM_CERT_GROUP
 #define LSLAM_CERT_GROUP 256
@@ -333,6 +334,7 @@ hipError_t launch_compact_active(const GNState *states, const ProbBlocks *probs,
                                  int32_t *count_out, hipStream_t s);
 hipError_t launch_sweep_plan(const SweepArgs &a, hipStream_t s, const CertPlan &plan, int level, bool with_prefix);
 hipError_t launch_sweep_queue(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t stop, int variant, const CertPlan &plan, int level = 0, bool planned = false);
+hipError_t launch_sweep_refill(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t stop, const CertPlan &plan);
 hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s,
                         hipEvent_t start = nullptr, hipEvent_t stop = nullptr, int *variant = nullptr, bool *cert_launched = nullptr);
 hipError_t launch_solve(const SolveArgs &a, hipStream_t s);

@@ -655,7 +655,8 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
     (void)searched;
     if (a.dbg) dbg_t1 = __builtin_readcyclecounter();
 
-    point_residual(a, bd, is_surf, (GRIDQ == 2 || GRIDQ == 3) ? (is_surf ? a.ks.pts : a.kc.pts) : T.pts, q, sel, d, p, sc, row, rb, kept, matched, score);
+    // (GRIDQ == 2 with trees -- a.grid == 1: the neighbours sweep_refill_kernel left are positions in the tree's point array)
+    point_residual(a, bd, is_surf, ((GRIDQ == 2 && a.grid == 2) || GRIDQ == 3) ? (is_surf ? a.ks.pts : a.kc.pts) : T.pts, q, sel, d, p, sc, row, rb, kept, matched, score);
   }
 
   if (a.dbg) dbg_t2 = __builtin_readcyclecounter();
@@ -791,6 +792,7 @@ __global__ __launch_bounds__(256) void cert_plan_kernel(SweepArgs a, CertPlan pl
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // the counters of the NEXT plan (they alternate)
     *plan.count_next = 0;
     *plan.ticket_next = 0;
+    if (plan.ticket2_next) *plan.ticket2_next = 0;
   }
   // debug tap of the grid sweep (lslam_opts.debug_stats): points listed for pass 2 / points swept, in total and by feature type
   // and sweep of the loop.  Counted HERE, from the counts pass 1 left -- per workgroup of this (tiny) launch a histogram in
@@ -919,6 +921,142 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(GRIDQ == 
   }
 }
 
+// The grid sweep's second pass as TWO launches (throughput-bound batches on whole-map trees): this one only SEARCHES -- with
+// persistent lanes (knn5_search_refill): a workgroup takes REFILL_CHUNKS consecutive items of the plan, i.e. up to that many
+// workgroups' worth of one group's listed points, as one pool; a lane whose walk has ended hands its five in (wide_d / wide_p,
+// by point) and takes the pool's next point, so a wavefront is no longer as slow as the longest of its first 64 walks with the
+// lanes that drew short ones idle.  sweep_queue_kernel<.., 2> then runs the residual chain of the same items, chunk by chunk,
+// its sums where the one-launch form puts them: same bits.
+#ifndef LSLAM_REFILL_CHUNKS
+#define LSLAM_REFILL_CHUNKS 4
+#endif
+#ifndef LSLAM_REFILL_OCC
+#define LSLAM_REFILL_OCC LSLAM_SHALLOW_OCC
+#endif
+constexpr int REFILL_CHUNKS = LSLAM_REFILL_CHUNKS;
+template <int BLOCK, bool OVF, int LDS_DEPTH>
+struct RefillSrc {
+  const SweepArgs &a;
+  const float (&R)[9];
+  const float (&t)[3];
+  const TreeView &T;
+  const int *pre;   // LDS: where the lists of the group's workgroups begin
+  int *pool_next;   // LDS
+  int fb, i1, prev_valid, qi;
+  LSLAM_DEV bool next(float &qx, float &qy, float &qz, float &bound) {
+    const int i = atomicAdd(pool_next, 1);
+    if (i >= i1) return false;
+    int k = 0;
+#pragma unroll
+    for (int step = CERT_GROUP / 2; step >= 1; step >>= 1)
+      if (pre[k + step] <= i) k += step;
+    qi = a.blocks[fb + k].first + (int)a.need_list[(size_t)(fb + k) * BLOCK + (i - pre[k])];
+    const float4 q = a.q[qi];
+    // util/transform_utils.h:476-482 pointAssociateToMap (sweep_body's statement)
+    qx = ((R[0] * q.x + R[1] * q.y) + R[2] * q.z) + t[0];
+    qy = ((R[3] * q.x + R[4] * q.y) + R[5] * q.z) + t[1];
+    qz = ((R[6] * q.x + R[7] * q.y) + R[8] * q.z) + t[2];
+    bound = 5.0f * (1.0f + 1e-5f);  // (this kernel runs the bounded production sweep only)
+    if (prev_valid && T.n_pts > 0) {
+      const float sel[3] = {qx, qy, qz};
+      bound = fminf(bound, grid_carried_bound(a.prev_q[qi], sel));
+    }
+    if (a.grid_hint) bound = fminf(bound, a.grid_hint[qi]);
+    return true;
+  }
+  LSLAM_DEV void emit(const float (&d)[5], const int (&p)[5]) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      a.wide_d[(size_t)qi * 5 + j] = d[j];
+      a.wide_p[(size_t)qi * 5 + j] = p[j];
+    }
+  }
+};
+template <int BLOCK, bool OVF, int LDS_DEPTH>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LSLAM_REFILL_OCC))) void sweep_refill_kernel(const SweepArgs a, const CertPlan plan) {
+  __shared__ uint32_t stack_lds[2 * LDS_DEPTH * BLOCK];
+  __shared__ int next_w, pool_next;
+  __shared__ int pre_lds[CERT_GROUP + 1];
+  __shared__ int pre_wave[BLOCK / 64];
+  const int n_work = *plan.count;
+  for (;;) {
+    if (threadIdx.x == 0) next_w = atomicAdd(plan.ticket2, REFILL_CHUNKS);
+    __syncthreads();
+    int w = __builtin_amdgcn_readfirstlane(next_w);
+    if (w >= n_work) break;
+    const int w_end = min(w + REFILL_CHUNKS, n_work);
+    while (w < w_end) {  // (wave-uniform) runs of consecutive chunks of one group: nearly always all of them
+      const int id0 = __builtin_amdgcn_readfirstlane(plan.work[w]);
+      int run = 1;
+      while (w + run < w_end && __builtin_amdgcn_readfirstlane(plan.work[w + run]) == id0 + run) ++run;
+      const int g = id0 / CERT_GROUP, c0 = id0 % CERT_GROUP;
+      GroupDesc gd = a.groups[g];
+      gd.first_block = __builtin_amdgcn_readfirstlane(gd.first_block);
+      gd.n_blocks = __builtin_amdgcn_readfirstlane(gd.n_blocks);
+      gd.prob = __builtin_amdgcn_readfirstlane(gd.prob);
+      const int fb = gd.first_block - a.group_block_base;
+      {  // where the group's lists begin (sweep_queue_kernel's scan)
+        const int k = (int)threadIdx.x, ln = k & 63, wv = k >> 6;
+        int sum = k < gd.n_blocks ? (int)a.need_cnt[fb + k] : 0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int u = __shfl_up(sum, o, 64);
+          if (ln >= o) sum += u;
+        }
+        if (CERT_GROUP > 64) {
+          if (ln == 63) pre_wave[wv] = sum;
+          __syncthreads();
+#pragma unroll
+          for (int ww = 0; ww < BLOCK / 64; ++ww) sum += ww < wv ? pre_wave[ww] : 0;
+        }
+        if (k < CERT_GROUP) pre_lds[k + 1] = sum;
+        if (k == 0) {
+          pre_lds[0] = 0;
+          pool_next = c0 * BLOCK;
+        }
+      }
+      __syncthreads();
+      const int total = pre_lds[CERT_GROUP];
+      const bool is_surf = __builtin_amdgcn_readfirstlane(a.blocks[fb].is_surf) != 0;
+      const GNState *st = a.states + gd.prob;
+      float R[9], t[3];
+      {
+        static_assert(offsetof(GNState, R) == 24 && offsetof(GNState, t) == 60, "GNState layout");
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        typedef uint32_t u32x8_t __attribute__((ext_vector_type(8)));
+        u32x8_t w8;
+        u32x4_t w4;
+        asm volatile("s_load_dwordx8 %0, %2, 0x18\n\ts_load_dwordx4 %1, %2, 0x38\n\ts_waitcnt lgkmcnt(0)" : "=&s"(w8), "=&s"(w4) : "s"(st) : "memory");
+#pragma unroll
+        for (int i = 0; i < 8; ++i) R[i] = __uint_as_float(w8[i]);
+        R[8] = __uint_as_float(w4[0]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t[i] = __uint_as_float(w4[1 + i]);
+      }
+      TreeView T;
+      T.nodes = is_surf ? a.ts.nodes : a.tc.nodes;
+      T.pn = is_surf ? a.ts.pn : a.tc.pn;
+      T.pts = is_surf ? a.ts.pts : a.tc.pts;
+      T.n_pts = is_surf ? a.ts.n_pts : a.tc.n_pts;
+      T.n_nodes = is_surf ? a.ts.n_nodes : a.tc.n_nodes;
+      T.root_ref = is_surf ? a.ts.root_ref : a.tc.root_ref;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        T.bb_lo[i] = is_surf ? a.ts.bb_lo[i] : a.tc.bb_lo[i];
+        T.bb_hi[i] = is_surf ? a.ts.bb_hi[i] : a.tc.bb_hi[i];
+      }
+      KdStack<BLOCK, OVF, LDS_DEPTH> stk;
+      stk.lds = (lds_u32 *)(stack_lds + threadIdx.x);
+      stk.ovf = OVF ? a.stack_ovf + ((size_t)(fb + c0) * BLOCK + threadIdx.x) : nullptr;  // (fb + c0: this workgroup's alone while it runs)
+      stk.ovf_stride = (size_t)a.nb_total * BLOCK;
+      RefillSrc<BLOCK, OVF, LDS_DEPTH> src{a, R, t, T, pre_lds, &pool_next, fb, min((c0 + run) * BLOCK, total), a.prev_valid, 0};
+      knn5_search_refill<BLOCK, OVF, LDS_DEPTH>(T, stk, src);
+      __syncthreads();  // pre_lds, pool_next and the stack columns are free again
+      w += run;
+    }
+  }
+}
+
 // start/stop (optional) time exactly this dispatch on its own stream: the events are
 // attached to the kernel's AQL packet, no extra barrier packets are enqueued.
 hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t start,
@@ -991,6 +1129,19 @@ hipError_t launch_sweep(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEven
 hipError_t launch_sweep_plan(const SweepArgs &a, hipStream_t s, const CertPlan &plan, int level, bool with_prefix) {
   if (a.n_groups <= 0) return hipSuccess;
   hipLaunchKernelGGL(cert_plan_kernel, dim3((a.n_groups + 3) / 4 + (with_prefix ? 1 : 0)), dim3(256), 0, s, a, plan, level, with_prefix ? 1 : 0);
+  return hipGetLastError();
+}
+
+// the grid sweep's second pass in its two-launch form (sweep_refill_kernel, then the residual chain of the same items): the
+// shallow-stack shape on whole-map trees only
+hipError_t launch_sweep_refill(const SweepArgs &a, int jtj_mode, hipStream_t s, hipEvent_t stop, const CertPlan &plan) {
+  if (a.n_groups <= 0) return hipSuccess;
+  constexpr int SHALLOW = LSLAM_SHALLOW_DEPTH;
+  hipLaunchKernelGGL(cert_plan_kernel, dim3((a.n_groups + 3) / 4), dim3(256), 0, s, a, plan, 0, 0);
+  const long possible = a.active_blocks ? std::max<long>(a.n_active, 1) : (long)a.nb_total;
+  const dim3 b(SWEEP_BLOCK);
+  hipLaunchKernelGGL((sweep_refill_kernel<SWEEP_BLOCK, true, SHALLOW>), dim3((unsigned)std::min<long>((possible + REFILL_CHUNKS - 1) / REFILL_CHUNKS, 256 * LSLAM_REFILL_OCC)), b, 0, s, a, plan);
+  hipExtLaunchKernelGGL((sweep_queue_kernel<SWEEP_BLOCK, true, SHALLOW, 2>), dim3((unsigned)std::min<long>(possible, 256 * 5)), b, 0, s, nullptr, stop, 0, a, jtj_mode, plan);
   return hipGetLastError();
 }
 

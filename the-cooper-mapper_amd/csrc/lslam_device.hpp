@@ -229,7 +229,9 @@ struct TravStats { unsigned long long t_desc, t_leaf, t_pop, t_take; unsigned n_
 #ifndef LSLAM_TRACK_KAPPA
 #define LSLAM_TRACK_KAPPA 1.0f
 #endif
-template <int BLOCK, bool OVF, int LDS_DEPTH, bool TRACK = false>
+// POPW_SET: stack entries examined per pop round, 0 = by the stack's shape (below).  The grid sweep's second pass asks for one:
+// its searches start from a bound and seldom pop more (1.403 -> 1.417e10, round 6).
+template <int BLOCK, bool OVF, int LDS_DEPTH, bool TRACK = false, int POPW_SET = 0>
 LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, float (&d)[5],
                            int (&p)[5], KdStack<BLOCK, OVF, LDS_DEPTH> &stk,
 #ifdef LSLAM_TRAVERSAL_STATS
@@ -242,7 +244,7 @@ LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, floa
   float lb = FLT_MAX;
   // stack entries examined per pop round: four in flight where a wavefront's latency is what counts (single scans,
   // whole stack in LDS), fewer where instruction issue is (the shallow-stack batch variant)
-  constexpr int POPW = (LDS_DEPTH <= 16 && LDS_DEPTH > 0) ? LSLAM_POPW_SHALLOW : 4;
+  constexpr int POPW = POPW_SET > 0 ? POPW_SET : ((LDS_DEPTH <= 16 && LDS_DEPTH > 0) ? LSLAM_POPW_SHALLOW : 4);
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     d[i] = FLT_MAX;
@@ -625,11 +627,11 @@ LSLAM_DEV void knn5_search_refill(const TreeView &T, KdStack<BLOCK, OVF, LDS_DEP
 }
 
 #ifdef LSLAM_TRAVERSAL_STATS  // call sites that keep no statistics
-template <int BLOCK, bool OVF, int LDS_DEPTH, bool TRACK = false>
+template <int BLOCK, bool OVF, int LDS_DEPTH, bool TRACK = false, int POPW_SET = 0>
 LSLAM_DEV void knn5_search(const TreeView &T, float qx, float qy, float qz, float (&d)[5], int (&p)[5],
                            KdStack<BLOCK, OVF, LDS_DEPTH> &stk, const float bound = FLT_MAX, float *lb6 = nullptr) {
   TravStats ts = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  knn5_search<BLOCK, OVF, LDS_DEPTH, TRACK>(T, qx, qy, qz, d, p, stk, ts, bound, lb6);
+  knn5_search<BLOCK, OVF, LDS_DEPTH, TRACK, POPW_SET>(T, qx, qy, qz, d, p, stk, ts, bound, lb6);
 }
 #endif
 

@@ -638,7 +638,7 @@ LSLAM_DEV void sweep_body(const SweepArgs &a, const int jtj_mode, const int lb, 
           knn5_search<BLOCK, OVF, LDS_DEPTH>(T, sel[0], sel[1], sel[2], d, p, stk, bound);
       } else
 #endif
-      knn5_search<BLOCK, OVF, LDS_DEPTH>(T, sel[0], sel[1], sel[2], d, p, stk, bound);
+      knn5_search<BLOCK, OVF, LDS_DEPTH, false, (GRIDQ == 1 && LDS_DEPTH <= 16) ? 1 : 0>(T, sel[0], sel[1], sel[2], d, p, stk, bound);
       // no bound kept: no certificate for this point in the next sweep (the first sweep of a certificate loop is this kernel
       // WITHOUT the certificate code -- launch_sweep -- which is 4 % faster at searching than the one with it)
       if ((CERT || !CUBES) && a.prev_lb) a.prev_lb[qi] = 0.0f;

@@ -28,7 +28,7 @@ for name, extra in (("begin", []), ("sync", ["-DLSLAM_MAPPING_SYNC_ADD"])):
     exes[name] = os.path.join(tmp, "nt_" + name)
     subprocess.check_call(["g++", "-O2", "-std=c++11", "-Wall"] + extra + ["-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "cpp", "node_threads.cpp"),
                            "-o", exes[name], "-L", libdir, "-llslam_hip", "-Wl,-rpath," + libdir, "-lpthread"], timeout=300)
-variants = [("sync", {}), ("begin", {})]
+variants = [("sync", {}), ("begin", {})]  # (add environments to try: ("sync", {"GPU_MAX_HW_QUEUES": "8"}), ("sync", {"HSA_ENABLE_SDMA": "0"}) ...)
 for r in range(runs):
     for name, env in variants:
         out = subprocess.run([exes[name], path, "8"], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
